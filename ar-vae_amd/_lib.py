@@ -1,0 +1,84 @@
+"""ctypes binding of libarvae_hip.so (see include/arvae_hip.h).
+
+There is NO fallback: if the library is missing or a call is made without a GPU
+the caller gets a RuntimeError.  Build with ``python __graft_entry__.py`` or
+``python ar-vae_amd/build.py``.
+"""
+import ctypes
+import os
+import threading
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, 'libarvae_hip.so')
+ABI_VERSION = 1
+
+c_i32, c_i64, c_f32, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+
+class LinkDesc(ctypes.Structure):
+    """arvae_link_t"""
+    _fields_ = [(n, c_i32) for n in ('n', 'hh', 'hw', 'chi', 'lh', 'lw', 'clo', 'kh', 'kw', 'stride', 'pad',
+                                      'hi_perm_c', 'hi_perm_hw', 'lo_perm_c', 'lo_perm_hw')]
+
+
+class OperandDesc(ctypes.Structure):
+    """arvae_operand_t"""
+    _fields_ = [('v', c_vp), ('y', c_vp), ('mask', c_vp), ('act', c_i32)]
+
+
+_P = ctypes.POINTER
+# name -> (restype, argtypes); must list every symbol declared in include/arvae_hip.h
+SIGNATURES = {
+    'arvae_abi_version': (c_i32, []),
+    'arvae_last_error_string': (ctypes.c_char_p, []),
+    'arvae_device_count': (c_i32, []),
+    'arvae_link_down': (c_i32, [_P(LinkDesc), _P(OperandDesc), c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
+    'arvae_link_up': (c_i32, [_P(LinkDesc), _P(OperandDesc), c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
+    'arvae_link_wgrad': (c_i32, [_P(LinkDesc), _P(OperandDesc), _P(OperandDesc), c_vp, c_vp]),
+    'arvae_channel_sum': (c_i32, [_P(OperandDesc), c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    'arvae_latent_fwd': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    'arvae_latent_bwd': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    'arvae_kld_fwd': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_f32, c_vp, c_vp, c_vp]),
+    'arvae_kld_bwd': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'arvae_reg_loss_ws_floats': (c_i64, [c_i64, c_i32]),
+    'arvae_reg_loss': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, _P(c_i32), c_i32, c_f32, c_f32,
+                               c_vp, c_vp, c_vp, c_vp]),
+    'arvae_recon_ws_floats': (c_i64, [c_i64]),
+    'arvae_image_recon': (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    'arvae_token_recon': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    'arvae_scale_by_scalar': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp]),
+    'arvae_adam_step': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def load():
+    """dlopen the library and bind every symbol; raises RuntimeError when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} is missing: the AR-VAE HIP kernels are not built and there is no CPU '
+                f'fallback. Run `python __graft_entry__.py` (or `python ar-vae_amd/build.py`) first.')
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the .so does not export it
+            fn.restype = res
+            fn.argtypes = args
+        got = lib.arvae_abi_version()
+        if got != ABI_VERSION:
+            raise RuntimeError(f'libarvae_hip.so ABI {got} != expected {ABI_VERSION}: rebuild it')
+        _lib = lib
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().arvae_last_error_string().decode(errors='replace')
+        raise RuntimeError(f'libarvae_hip {what} failed ({rc}): {msg}')

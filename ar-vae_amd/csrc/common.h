@@ -1,0 +1,97 @@
+// Shared helpers for the gfx950 kernels of libarvae_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/arvae_hip.h"
+
+namespace arvae {
+
+// ---- error reporting -------------------------------------------------------------------------
+extern thread_local char g_last_error[512];
+
+int fail(int code, const char *fmt, ...);
+int check_launch(const char *what);
+
+#define ARVAE_REQUIRE(cond, ...)                                   \
+    do {                                                           \
+        if (!(cond)) return ::arvae::fail(ARVAE_E_INVALID, __VA_ARGS__); \
+    } while (0)
+
+static inline hipStream_t as_stream(arvae_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- division by a runtime constant (n < 2^31) -----------------------------------------------
+struct FastDiv {
+    uint32_t d, mul, sh;
+    FastDiv() : d(1), mul(0), sh(0) {}
+    explicit FastDiv(uint32_t div) : d(div), mul(0), sh(0) {
+        if (div > 1) {
+            uint32_t shift = 0;
+            while ((1ull << shift) < div) ++shift;
+            mul = (uint32_t)(((1ull << (31 + shift)) + div - 1) / div);
+            sh = shift - 1;
+        }
+    }
+    __device__ __forceinline__ uint32_t div(uint32_t n) const { return d == 1 ? n : (__umulhi(n, mul) >> sh); }
+    __device__ __forceinline__ void divmod(uint32_t n, uint32_t &q, uint32_t &r) const {
+        q = div(n);
+        r = n - q * d;
+    }
+};
+
+// ---- activations ------------------------------------------------------------------------------
+constexpr float kSeluAlpha = 1.6732632423543772f;
+constexpr float kSeluScale = 1.0507009873554805f;
+
+__device__ __forceinline__ float act_fwd(float x, int act) {
+    if (act == ARVAE_ACT_RELU) return fmaxf(x, 0.f);
+    if (act == ARVAE_ACT_SELU) return x > 0.f ? kSeluScale * x : (kSeluScale * kSeluAlpha) * (expf(x) - 1.f);
+    return x;
+}
+// derivative evaluated from the activation OUTPUT y
+__device__ __forceinline__ float act_bwd_from_out(float y, int act) {
+    if (act == ARVAE_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+    if (act == ARVAE_ACT_SELU) return y > 0.f ? kSeluScale : y + kSeluScale * kSeluAlpha;
+    return 1.f;
+}
+
+// device view of arvae_operand_t
+struct Operand {
+    const float *v;
+    const float *y;
+    const uint8_t *mask;
+    int act;
+    __device__ __forceinline__ float at(int64_t i) const {
+        float r = v[i];
+        if (y != nullptr) {
+            float yy = y[i];
+            if (mask != nullptr) {
+                r *= 2.f * (float)mask[i];
+                yy *= 0.5f;
+            }
+            r *= act_bwd_from_out(yy, act);
+        }
+        return r;
+    }
+};
+static inline Operand make_operand(const arvae_operand_t *o) { return Operand{o->v, o->y, o->mask, o->act}; }
+
+// ---- reductions -------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// sum over a 256-thread block; result valid in every thread. `red` = 4 floats of LDS.
+__device__ __forceinline__ float block_sum_256(float v, float *red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+}  // namespace arvae

@@ -1,0 +1,546 @@
+// Strided-link kernels (conv / conv-transpose / linear; forward, data-gradient, weight-gradient)
+// as gather-GEMMs on the gfx950 fp32 matrix core (v_mfma_f32_32x32x2_f32: exact fp32, same
+// k-ordered fmaf chain as a scalar loop, 64 FLOP/clk/SIMD).
+//
+// One kernel template, three index policies:
+//   Down  : lo[m=(n,ly,lx)][clo]  = sum_k hi(gather)[m][k=(ky,kx,chi)] * wt[k][clo]
+//   Up    : hi[m=(n,yy,xx) of one stride-parity class][chi] = sum_k lo(gather)[m][k=(ty,tx,clo)] * wt[k][chi]
+//   Wgrad : dwt[clo][n'=(ky,kx,chi)] += sum_{k=pixel} lo[k][clo] * hi(gather)[k][n']     (split over pixels)
+// Work decomposition: a workgroup of WM x WN wavefronts (64 lanes each) owns a (32*WM) x (32*WN)
+// output tile; every wave accumulates ONE 32x32 tile in 16 accumulator registers.  Operands are
+// gathered global -> registers (prefetched one K-tile ahead so the loads fly under the MFMAs) ->
+// LDS in k-major order [BK][BM+1], from where each lane reads the single A and B value the
+// 32x32x2 MFMA wants (lane = (row|col) + 32 * k-parity) with conflict-free ds_read_b32.
+#include "common.h"
+
+namespace arvae {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+
+struct Geom {
+    int n, hh, hw, chi, lh, lw, clo, kh, kw, stride, pad;
+    int hi_pc, lo_pc;
+    FastDiv d_chi, d_clo, d_kw, d_lw, d_lhlw, d_hi_phw, d_lo_phw;
+    // Up only: taps per axis and class grid
+    int tkh, tkw, yh, xw;
+    FastDiv d_tkw, d_xw, d_yhxw;
+
+    __device__ __forceinline__ int perm_hi(int f) const {
+        if (hi_pc == 0) return f;
+        uint32_t q, r;
+        d_hi_phw.divmod((uint32_t)f, q, r);
+        return (int)(r * hi_pc + q);
+    }
+    __device__ __forceinline__ int perm_lo(int f) const {
+        if (lo_pc == 0) return f;
+        uint32_t q, r;
+        d_lo_phw.divmod((uint32_t)f, q, r);
+        return (int)(r * lo_pc + q);
+    }
+};
+
+struct Epilogue {
+    const float *bias;
+    const uint8_t *mask;
+    float *out;
+    int act;
+};
+
+// gather context of a tensor position (n, y0, x0) and of a (ky, kx, channel) tap
+struct PosCtx {
+    int base, y0, x0;
+    bool ok;
+};
+struct TapCtx {
+    int ky, kx, coff;
+    bool ok;
+};
+struct OffCtx {
+    int off;
+    bool ok;
+};
+
+// ------------------------------------------------------------------------------------------------
+struct DownPolicy {
+    static constexpr bool A_CONTIG_K = true, B_CONTIG_K = true, ATOMIC_OUT = false;
+    Geom g;
+    Operand hi;
+    const float *wt;
+    Epilogue ep;
+    int M, N, K;
+
+    __device__ __forceinline__ void slice(int, int &m, int &n, int &kbeg, int &kend) const {
+        m = M; n = N; kbeg = 0; kend = K;
+    }
+    typedef PosCtx RowA; typedef TapCtx KA; typedef OffCtx RowB; typedef OffCtx KB;
+    __device__ __forceinline__ RowA rowA(int m, int) const {
+        uint32_t img, rem, ly, lx;
+        g.d_lhlw.divmod((uint32_t)m, img, rem);
+        g.d_lw.divmod(rem, ly, lx);
+        return RowA{(int)img * g.hh * g.hw * g.chi, (int)ly * g.stride - g.pad, (int)lx * g.stride - g.pad, m < M};
+    }
+    __device__ __forceinline__ KA kA(int k, int) const {
+        uint32_t tap, c, ky, kx;
+        g.d_chi.divmod((uint32_t)k, tap, c);
+        g.d_kw.divmod(tap, ky, kx);
+        return KA{(int)ky, (int)kx, g.perm_hi((int)c), k < K};
+    }
+    __device__ __forceinline__ float fetchA(const RowA &r, const KA &k) const {
+        const int iy = r.y0 + k.ky, ix = r.x0 + k.kx;
+        const bool ok = r.ok && k.ok && (unsigned)iy < (unsigned)g.hh && (unsigned)ix < (unsigned)g.hw;
+        return ok ? hi.at(r.base + (iy * g.hw + ix) * g.chi + k.coff) : 0.f;
+    }
+    __device__ __forceinline__ RowB rowB(int col, int) const { return RowB{col * g.chi * g.kh * g.kw, col < N}; }
+    __device__ __forceinline__ KB kB(int k, int) const {
+        uint32_t tap, c;
+        g.d_chi.divmod((uint32_t)k, tap, c);
+        return KB{(int)c * g.kh * g.kw + (int)tap, k < K};
+    }
+    __device__ __forceinline__ float fetchB(const RowB &r, const KB &k) const {
+        return (r.ok && k.ok) ? wt[r.off + k.off] : 0.f;
+    }
+    __device__ __forceinline__ int out_row(int m, int) const { return m * g.clo; }
+    struct ColC { int off; float bias; };
+    __device__ __forceinline__ ColC colC(int col, int) const {
+        return ColC{g.perm_lo(col), ep.bias != nullptr ? ep.bias[col] : 0.f};
+    }
+    __device__ __forceinline__ void store(int rowoff, const ColC &c, float acc) const {
+        const int idx = rowoff + c.off;
+        float v = act_fwd(acc + c.bias, ep.act);
+        if (ep.mask != nullptr) v *= 2.f * (float)ep.mask[idx];
+        ep.out[idx] = v;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+struct UpPolicy {
+    static constexpr bool A_CONTIG_K = true, B_CONTIG_K = true, ATOMIC_OUT = false;
+    Geom g;
+    Operand lo;
+    const float *wt;
+    Epilogue ep;
+    int M, N, K;   // per stride-parity class
+
+    __device__ __forceinline__ void slice(int, int &m, int &n, int &kbeg, int &kend) const {
+        m = M; n = N; kbeg = 0; kend = K;
+    }
+    typedef PosCtx RowA; typedef TapCtx KA; typedef OffCtx RowB; typedef OffCtx KB;
+    // z = cy * stride + cx ; ky0 = (cy+pad) % stride ; oy = (cy+pad) / stride
+    __device__ __forceinline__ RowA rowA(int m, int z) const {
+        const int cy = z / g.stride, cx = z - cy * g.stride;
+        uint32_t img, rem, yy, xx;
+        g.d_yhxw.divmod((uint32_t)m, img, rem);
+        g.d_xw.divmod(rem, yy, xx);
+        return RowA{(int)img * g.lh * g.lw * g.clo, (int)yy + (cy + g.pad) / g.stride, (int)xx + (cx + g.pad) / g.stride,
+                    m < M};
+    }
+    __device__ __forceinline__ KA kA(int k, int) const {
+        uint32_t tap, c, ty, tx;
+        g.d_clo.divmod((uint32_t)k, tap, c);
+        g.d_tkw.divmod(tap, ty, tx);
+        return KA{(int)ty, (int)tx, g.perm_lo((int)c), k < K};
+    }
+    __device__ __forceinline__ float fetchA(const RowA &r, const KA &k) const {
+        const int ly = r.y0 - k.ky, lx = r.x0 - k.kx;
+        const bool ok = r.ok && k.ok && (unsigned)ly < (unsigned)g.lh && (unsigned)lx < (unsigned)g.lw;
+        return ok ? lo.at(r.base + (ly * g.lw + lx) * g.clo + k.coff) : 0.f;
+    }
+    __device__ __forceinline__ RowB rowB(int col, int) const { return RowB{col * g.kh * g.kw, col < N}; }
+    __device__ __forceinline__ KB kB(int k, int z) const {
+        const int cy = z / g.stride, cx = z - cy * g.stride;
+        uint32_t tap, c, ty, tx;
+        g.d_clo.divmod((uint32_t)k, tap, c);
+        g.d_tkw.divmod(tap, ty, tx);
+        const int ky = (cy + g.pad) % g.stride + g.stride * (int)ty;
+        const int kx = (cx + g.pad) % g.stride + g.stride * (int)tx;
+        return KB{(int)c * g.chi * g.kh * g.kw + ky * g.kw + kx, k < K};
+    }
+    __device__ __forceinline__ float fetchB(const RowB &r, const KB &k) const {
+        return (r.ok && k.ok) ? wt[r.off + k.off] : 0.f;
+    }
+    __device__ __forceinline__ int out_row(int m, int z) const {
+        const int cy = z / g.stride, cx = z - cy * g.stride;
+        uint32_t img, rem, yy, xx;
+        g.d_yhxw.divmod((uint32_t)m, img, rem);
+        g.d_xw.divmod(rem, yy, xx);
+        return (((int)img * g.hh + (int)yy * g.stride + cy) * g.hw + (int)xx * g.stride + cx) * g.chi;
+    }
+    struct ColC { int off; float bias; };
+    __device__ __forceinline__ ColC colC(int col, int) const {
+        return ColC{g.perm_hi(col), ep.bias != nullptr ? ep.bias[col] : 0.f};
+    }
+    __device__ __forceinline__ void store(int rowoff, const ColC &c, float acc) const {
+        const int idx = rowoff + c.off;
+        float v = act_fwd(acc + c.bias, ep.act);
+        if (ep.mask != nullptr) v *= 2.f * (float)ep.mask[idx];
+        ep.out[idx] = v;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+struct WgradPolicy {
+    static constexpr bool A_CONTIG_K = false, B_CONTIG_K = false, ATOMIC_OUT = true;
+    Geom g;
+    Operand lo, hi;
+    float *dwt;
+    int M, N, P, chunk;   // M = clo, N = kh*kw*chi, P = n*lh*lw pixels, chunk = pixels per z-slice
+
+    __device__ __forceinline__ void slice(int z, int &m, int &n, int &kbeg, int &kend) const {
+        m = M; n = N; kbeg = z * chunk; kend = min(P, kbeg + chunk);
+    }
+    typedef OffCtx RowA; typedef OffCtx KA; typedef TapCtx RowB; typedef PosCtx KB;
+    __device__ __forceinline__ RowA rowA(int m, int) const { return RowA{g.perm_lo(m), m < M}; }
+    __device__ __forceinline__ KA kA(int pix, int) const { return KA{pix * g.clo, pix < P}; }   // kend checked by caller
+    __device__ __forceinline__ float fetchA(const RowA &r, const KA &k) const {
+        return (r.ok && k.ok) ? lo.at(k.off + r.off) : 0.f;
+    }
+    __device__ __forceinline__ RowB rowB(int col, int) const {
+        uint32_t tap, c, ky, kx;
+        g.d_chi.divmod((uint32_t)col, tap, c);
+        g.d_kw.divmod(tap, ky, kx);
+        return RowB{(int)ky, (int)kx, g.perm_hi((int)c), col < N};
+    }
+    __device__ __forceinline__ KB kB(int pix, int) const {
+        uint32_t img, rem, ly, lx;
+        g.d_lhlw.divmod((uint32_t)pix, img, rem);
+        g.d_lw.divmod(rem, ly, lx);
+        return KB{(int)img * g.hh * g.hw * g.chi, (int)ly * g.stride - g.pad, (int)lx * g.stride - g.pad, pix < P};
+    }
+    __device__ __forceinline__ float fetchB(const RowB &r, const KB &k) const {
+        const int iy = k.y0 + r.ky, ix = k.x0 + r.kx;
+        const bool ok = r.ok && k.ok && (unsigned)iy < (unsigned)g.hh && (unsigned)ix < (unsigned)g.hw;
+        return ok ? hi.at(k.base + (iy * g.hw + ix) * g.chi + r.coff) : 0.f;
+    }
+    __device__ __forceinline__ int out_row(int m, int) const { return m * g.chi * g.kh * g.kw; }
+    struct ColC { int off; };
+    __device__ __forceinline__ ColC colC(int col, int) const {
+        uint32_t tap, c;
+        g.d_chi.divmod((uint32_t)col, tap, c);
+        return ColC{(int)c * g.kh * g.kw + (int)tap};
+    }
+    __device__ __forceinline__ void store(int rowoff, const ColC &c, float acc) const {
+        atomicAdd(dwt + rowoff + c.off, acc);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+template <int WM, int WN, class P>
+__global__ __launch_bounds__(64 * WM * WN) void link_gemm_kernel(const P p) {
+    constexpr int BM = 32 * WM, BN = 32 * WN, NT = 64 * WM * WN;
+    constexpr int EA = BM * BK / NT, EB = BN * BK / NT;
+    static_assert(NT % BK == 0 && NT % BM == 0 && NT % BN == 0, "tile/thread mapping");
+    __shared__ float As[BK][BM + 1];
+    __shared__ float Bs[BK][BN + 1];
+    __shared__ int rowOff[BM];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int z = blockIdx.z;
+    int M, N, kbeg, kend;
+    p.slice(z, M, N, kbeg, kend);
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    if (m0 >= M || kbeg >= kend) return;
+
+    if (t < BM) rowOff[t] = (m0 + t < M) ? p.out_row(m0 + t, z) : 0;
+
+    // per-thread gather contexts that do not change over the K loop
+    typename P::RowA rowsA[P::A_CONTIG_K ? EA : 1];
+    typename P::RowB rowsB[P::B_CONTIG_K ? EB : 1];
+    if constexpr (P::A_CONTIG_K) {
+#pragma unroll
+        for (int j = 0; j < EA; ++j) rowsA[j] = p.rowA(m0 + t / BK + j * (NT / BK), z);
+    } else {
+        rowsA[0] = p.rowA(m0 + t % BM, z);
+    }
+    if constexpr (P::B_CONTIG_K) {
+#pragma unroll
+        for (int j = 0; j < EB; ++j) rowsB[j] = p.rowB(n0 + t / BK + j * (NT / BK), z);
+    } else {
+        rowsB[0] = p.rowB(n0 + t % BN, z);
+    }
+
+    float ra[EA], rb[EB];
+    auto gather = [&](int kt) {
+        if constexpr (P::A_CONTIG_K) {
+            const int k = kt + t % BK;
+            const auto ka = p.kA(k < kend ? k : 0x3fffffff, z);
+#pragma unroll
+            for (int j = 0; j < EA; ++j) ra[j] = p.fetchA(rowsA[j], ka);
+        } else {
+#pragma unroll
+            for (int j = 0; j < EA; ++j) {
+                const int k = kt + t / BM + j * (NT / BM);
+                ra[j] = p.fetchA(rowsA[0], p.kA(k < kend ? k : 0x3fffffff, z));
+            }
+        }
+        if constexpr (P::B_CONTIG_K) {
+            const int k = kt + t % BK;
+            const auto kb = p.kB(k < kend ? k : 0x3fffffff, z);
+#pragma unroll
+            for (int j = 0; j < EB; ++j) rb[j] = p.fetchB(rowsB[j], kb);
+        } else {
+#pragma unroll
+            for (int j = 0; j < EB; ++j) {
+                const int k = kt + t / BN + j * (NT / BN);
+                rb[j] = p.fetchB(rowsB[0], p.kB(k < kend ? k : 0x3fffffff, z));
+            }
+        }
+    };
+    auto stage = [&]() {
+        if constexpr (P::A_CONTIG_K) {
+#pragma unroll
+            for (int j = 0; j < EA; ++j) As[t % BK][t / BK + j * (NT / BK)] = ra[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < EA; ++j) As[t / BM + j * (NT / BM)][t % BM] = ra[j];
+        }
+        if constexpr (P::B_CONTIG_K) {
+#pragma unroll
+            for (int j = 0; j < EB; ++j) Bs[t % BK][t / BK + j * (NT / BK)] = rb[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < EB; ++j) Bs[t / BN + j * (NT / BN)][t % BN] = rb[j];
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    const int kh2 = lane >> 5, rc = lane & 31;
+    gather(kbeg);
+    for (int kt = kbeg; kt < kend; kt += BK) {
+        __syncthreads();
+        stage();
+        __syncthreads();
+        if (kt + BK < kend) gather(kt + BK);
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            const float a = As[2 * s + kh2][wm * 32 + rc];
+            const float b = Bs[2 * s + kh2][wn * 32 + rc];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+    }
+
+    const int col = n0 + wn * 32 + rc;
+    if (col < N) {
+        const auto cc = p.colC(col, z);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = (i & 3) + 8 * (i >> 2) + 4 * kh2;
+            if (m0 + wm * 32 + r < M) p.store(rowOff[wm * 32 + r], cc, acc[i]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Up with a single hi channel (the decoder's last ConvTranspose2d -> logits): N = 1 would waste
+// 31/32 of an MFMA tile, so this is a vector-ALU dot product: one lane per output pixel, the
+// (ky,kx,clo) weights staged in LDS, lo pixels read as float4 channel chunks.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void up_single_channel_kernel(Geom g, const float *__restrict__ lo,
+                                                                 const float *__restrict__ wt, Epilogue ep,
+                                                                 int total) {
+    extern __shared__ __attribute__((aligned(16))) float w_lds[];   // [kh*kw][clo]
+    const int taps = g.kh * g.kw;
+    for (int i = threadIdx.x; i < taps * g.clo; i += blockDim.x) {
+        const int tap = i / g.clo, c = i - tap * g.clo;
+        w_lds[i] = wt[c * taps + tap];   // wt[clo][chi=1][ky][kx]
+    }
+    __syncthreads();
+    const float bias = ep.bias != nullptr ? ep.bias[0] : 0.f;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int hx = idx % g.hw;
+        const int tmp = idx / g.hw;
+        const int hy = tmp % g.hh;
+        const int img = tmp / g.hh;
+        float acc = 0.f;
+        for (int ky = (hy + g.pad) % g.stride; ky < g.kh; ky += g.stride) {
+            const int ly = (hy + g.pad - ky) / g.stride;
+            if (hy + g.pad - ky < 0 || ly >= g.lh) continue;
+            for (int kx = (hx + g.pad) % g.stride; kx < g.kw; kx += g.stride) {
+                const int lx = (hx + g.pad - kx) / g.stride;
+                if (hx + g.pad - kx < 0 || lx >= g.lw) continue;
+                const float4 *src = reinterpret_cast<const float4 *>(lo + ((img * g.lh + ly) * g.lw + lx) * g.clo);
+                const float4 *w4 = reinterpret_cast<const float4 *>(w_lds + (ky * g.kw + kx) * g.clo);
+                for (int c = 0; c < g.clo / 4; ++c) {
+                    const float4 a = src[c], b = w4[c];
+                    acc = fmaf(a.x, b.x, acc);
+                    acc = fmaf(a.y, b.y, acc);
+                    acc = fmaf(a.z, b.z, acc);
+                    acc = fmaf(a.w, b.w, acc);
+                }
+            }
+        }
+        float v = act_fwd(acc + bias, ep.act);
+        if (ep.mask != nullptr) v *= 2.f * (float)ep.mask[idx];
+        ep.out[idx] = v;
+    }
+}
+
+// out[perm(c)] += sum_rows g[row, c]     (bias gradients)
+__global__ __launch_bounds__(256) void channel_sum_kernel(Operand g, int64_t rows, int channels, int perm_c,
+                                                           FastDiv d_perm_hw, int64_t rows_per_block, float *out) {
+    __shared__ float red[256];
+    const int t = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(rows, r0 + rows_per_block);
+    for (int cbase = 0; cbase < channels; cbase += 256) {
+        // threads tile [rows x min(channels,256)] with the channel index fastest (coalesced)
+        const int cw = min(channels - cbase, 256);
+        const int rstep = 256 / cw > 0 ? 256 / cw : 1;
+        const int c = t % cw, rsub = t / cw;
+        float s = 0.f;
+        if (rsub < rstep)
+            for (int64_t r = r0 + rsub; r < r1; r += rstep) s += g.at(r * channels + cbase + c);
+        red[t] = s;
+        __syncthreads();
+        if (t < cw) {
+            float tot = 0.f;
+            for (int j = 0; j < rstep; ++j) tot += red[j * cw + t];
+            int f = cbase + t;   // memory channel -> flattened NCHW feature
+            if (perm_c > 0) {
+                const uint32_t p = (uint32_t)f / (uint32_t)perm_c, cc = (uint32_t)f % (uint32_t)perm_c;
+                f = (int)(cc * d_perm_hw.d + p);
+            }
+            atomicAdd(out + f, tot);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+static int make_geom(const arvae_link_t *l, Geom &g) {
+    ARVAE_REQUIRE(l != nullptr, "link: null descriptor");
+    ARVAE_REQUIRE(l->n > 0 && l->hh > 0 && l->hw > 0 && l->chi > 0 && l->lh > 0 && l->lw > 0 && l->clo > 0,
+                  "link: non-positive extent");
+    ARVAE_REQUIRE(l->kh > 0 && l->kw > 0 && l->stride > 0 && l->pad >= 0, "link: bad kernel/stride/pad");
+    ARVAE_REQUIRE((l->hh + 2 * l->pad - l->kh) / l->stride + 1 == l->lh &&
+                      (l->hw + 2 * l->pad - l->kw) / l->stride + 1 == l->lw,
+                  "link: lo extent %dx%d does not match hi %dx%d k%dx%d s%d p%d", l->lh, l->lw, l->hh, l->hw, l->kh,
+                  l->kw, l->stride, l->pad);
+    ARVAE_REQUIRE((int64_t)l->n * l->hh * l->hw * l->chi < (1ll << 31) &&
+                      (int64_t)l->n * l->lh * l->lw * l->clo < (1ll << 31),
+                  "link: tensor exceeds 2^31 elements");
+    ARVAE_REQUIRE(l->hi_perm_c == 0 || l->hi_perm_c * l->hi_perm_hw == l->chi, "link: hi perm does not cover chi");
+    ARVAE_REQUIRE(l->lo_perm_c == 0 || l->lo_perm_c * l->lo_perm_hw == l->clo, "link: lo perm does not cover clo");
+    g.n = l->n; g.hh = l->hh; g.hw = l->hw; g.chi = l->chi; g.lh = l->lh; g.lw = l->lw; g.clo = l->clo;
+    g.kh = l->kh; g.kw = l->kw; g.stride = l->stride; g.pad = l->pad;
+    g.hi_pc = l->hi_perm_c; g.lo_pc = l->lo_perm_c;
+    g.d_chi = FastDiv(l->chi); g.d_clo = FastDiv(l->clo); g.d_kw = FastDiv(l->kw); g.d_lw = FastDiv(l->lw);
+    g.d_lhlw = FastDiv(l->lh * l->lw);
+    g.d_hi_phw = FastDiv(l->hi_perm_c ? l->hi_perm_hw : 1);
+    g.d_lo_phw = FastDiv(l->lo_perm_c ? l->lo_perm_hw : 1);
+    g.tkh = g.tkw = g.yh = g.xw = 1;
+    g.d_tkw = g.d_xw = g.d_yhxw = FastDiv(1);
+    return ARVAE_OK;
+}
+
+template <class P>
+static int launch_gemm(const P &p, int M, int N, int zdim, bool wide_m, hipStream_t s, const char *what) {
+    // wide_m: many rows, N small  -> 4x1 waves (128x32) when N<=32, else 2x2 (64x64)
+    // !wide_m (wgrad): few rows   -> 1x4 waves (32x128) when M<=32, else 2x2
+    if (wide_m && N <= 32) {
+        dim3 grid((M + 127) / 128, (N + 31) / 32, zdim);
+        hipLaunchKernelGGL((link_gemm_kernel<4, 1, P>), grid, dim3(256), 0, s, p);
+    } else if (!wide_m && M <= 32) {
+        dim3 grid((M + 31) / 32, (N + 127) / 128, zdim);
+        hipLaunchKernelGGL((link_gemm_kernel<1, 4, P>), grid, dim3(256), 0, s, p);
+    } else {
+        dim3 grid((M + 63) / 64, (N + 63) / 64, zdim);
+        hipLaunchKernelGGL((link_gemm_kernel<2, 2, P>), grid, dim3(256), 0, s, p);
+    }
+    return check_launch(what);
+}
+
+}  // namespace arvae
+
+using namespace arvae;
+
+extern "C" int arvae_link_down(const arvae_link_t *link, const arvae_operand_t *hi, const float *wt,
+                               const float *bias, int32_t out_act, const uint8_t *out_mask, float *lo,
+                               arvae_stream_t stream) {
+    DownPolicy p;
+    if (int rc = make_geom(link, p.g)) return rc;
+    ARVAE_REQUIRE(hi && hi->v && wt && lo, "link_down: null pointer");
+    p.hi = make_operand(hi);
+    p.wt = wt;
+    p.ep = Epilogue{bias, out_mask, lo, out_act};
+    p.M = link->n * link->lh * link->lw;
+    p.N = link->clo;
+    p.K = link->kh * link->kw * link->chi;
+    return launch_gemm(p, p.M, p.N, 1, true, as_stream(stream), "link_down");
+}
+
+extern "C" int arvae_link_up(const arvae_link_t *link, const arvae_operand_t *lo, const float *wt,
+                             const float *bias, int32_t out_act, const uint8_t *out_mask, float *hi,
+                             arvae_stream_t stream) {
+    UpPolicy p;
+    if (int rc = make_geom(link, p.g)) return rc;
+    ARVAE_REQUIRE(lo && lo->v && wt && hi, "link_up: null pointer");
+    const int s = link->stride;
+    ARVAE_REQUIRE(link->kh % s == 0 && link->kw % s == 0, "link_up: kernel %dx%d not a multiple of stride %d",
+                  link->kh, link->kw, s);
+    ARVAE_REQUIRE(link->hh % s == 0 && link->hw % s == 0, "link_up: hi extent not a multiple of the stride");
+    hipStream_t st = as_stream(stream);
+    if (link->chi == 1 && lo->y == nullptr && link->clo % 4 == 0 && link->lo_perm_c == 0) {
+        const int total = link->n * link->hh * link->hw;
+        Epilogue ep{bias, out_mask, hi, out_act};
+        const int blocks = min((total + 255) / 256, 256 * 8);
+        const size_t lds = sizeof(float) * link->kh * link->kw * link->clo;
+        hipLaunchKernelGGL(up_single_channel_kernel, dim3(blocks), dim3(256), lds, st, p.g, lo->v, wt, ep, total);
+        return check_launch("link_up(single channel)");
+    }
+    p.lo = make_operand(lo);
+    p.wt = wt;
+    p.ep = Epilogue{bias, out_mask, hi, out_act};
+    p.g.tkh = link->kh / s;
+    p.g.tkw = link->kw / s;
+    p.g.yh = link->hh / s;
+    p.g.xw = link->hw / s;
+    p.g.d_tkw = FastDiv(p.g.tkw);
+    p.g.d_xw = FastDiv(p.g.xw);
+    p.g.d_yhxw = FastDiv(p.g.yh * p.g.xw);
+    p.M = link->n * p.g.yh * p.g.xw;
+    p.N = link->chi;
+    p.K = p.g.tkh * p.g.tkw * link->clo;
+    return launch_gemm(p, p.M, p.N, s * s, true, st, "link_up");
+}
+
+extern "C" int arvae_link_wgrad(const arvae_link_t *link, const arvae_operand_t *lo, const arvae_operand_t *hi,
+                                float *dwt, arvae_stream_t stream) {
+    WgradPolicy p;
+    if (int rc = make_geom(link, p.g)) return rc;
+    ARVAE_REQUIRE(lo && lo->v && hi && hi->v && dwt, "link_wgrad: null pointer");
+    p.lo = make_operand(lo);
+    p.hi = make_operand(hi);
+    p.dwt = dwt;
+    p.M = link->clo;
+    p.N = link->kh * link->kw * link->chi;
+    p.P = link->n * link->lh * link->lw;
+    const int bm = p.M <= 32 ? 32 : 64, bn = p.M <= 32 ? 128 : 64;
+    const int tiles = ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
+    int zsplit = (1024 + tiles - 1) / tiles;
+    const int max_split = (p.P + BK - 1) / BK;
+    if (zsplit > max_split) zsplit = max_split;
+    if (zsplit < 1) zsplit = 1;
+    p.chunk = (((p.P + zsplit - 1) / zsplit) + BK - 1) / BK * BK;
+    zsplit = (p.P + p.chunk - 1) / p.chunk;
+    return launch_gemm(p, p.M, p.N, zsplit, false, as_stream(stream), "link_wgrad");
+}
+
+extern "C" int arvae_channel_sum(const arvae_operand_t *g, int64_t rows, int32_t channels, int32_t perm_c,
+                                 int32_t perm_hw, float *out, arvae_stream_t stream) {
+    ARVAE_REQUIRE(g && g->v && out, "channel_sum: null pointer");
+    ARVAE_REQUIRE(rows > 0 && channels > 0, "channel_sum: empty tensor");
+    ARVAE_REQUIRE(perm_c == 0 || perm_c * perm_hw == channels, "channel_sum: perm does not cover channels");
+    int64_t blocks = (rows + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    const int64_t rpb = (rows + blocks - 1) / blocks;
+    blocks = (rows + rpb - 1) / rpb;
+    hipLaunchKernelGGL(channel_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), make_operand(g), rows,
+                       channels, perm_c, FastDiv(perm_c ? perm_hw : 1), rpb, out);
+    return check_launch("channel_sum");
+}

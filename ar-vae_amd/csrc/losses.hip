@@ -1,0 +1,422 @@
+// Loss-side kernels of the AR-VAE step: latent head, beta-KL, all-pairs attribute regularisation,
+// reconstruction terms, Adam.  All are HBM/latency-bound reductions: coalesced float4 loads,
+// wavefront (64-lane) shuffle reductions, per-workgroup partials in a caller-provided workspace and a
+// fixed-order finishing pass (bitwise reproducible: no float atomics on the loss values).
+#include "common.h"
+
+namespace arvae {
+
+// =================================================================================================
+// latent head: sigma = exp(log_std), z = mu + eps*sigma            (reference mnist_vae.py:65,79)
+// =================================================================================================
+__global__ __launch_bounds__(256) void latent_fwd_kernel(const float *__restrict__ mu, const float *__restrict__ ls,
+                                                          const float *__restrict__ eps, int64_t count,
+                                                          float *__restrict__ sigma, float *__restrict__ z) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+        const float s = expf(ls[i]);
+        sigma[i] = s;
+        z[i] = fmaf(eps[i], s, mu[i]);
+    }
+}
+
+__global__ __launch_bounds__(256) void latent_bwd_kernel(const float *__restrict__ gz, const float *__restrict__ gs,
+                                                          const float *__restrict__ eps,
+                                                          const float *__restrict__ sigma, int64_t count,
+                                                          float *__restrict__ dmu, float *__restrict__ dls) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+        const float g = gz != nullptr ? gz[i] : 0.f;
+        dmu[i] = g;
+        dls[i] = (g * eps[i] + (gs != nullptr ? gs[i] : 0.f)) * sigma[i];
+    }
+}
+
+// =================================================================================================
+// beta-KL: one workgroup (B*Z is a few thousand elements), fixed summation order
+// =================================================================================================
+__device__ __forceinline__ float kl_elem(float mu, float s, float m0, float s0) {
+    const float r = s / s0, d = (mu - m0) / s0;
+    const float var = r * r;
+    return 0.5f * (var + d * d - 1.f - logf(var));       // torch _kl_normal_normal
+}
+
+__global__ __launch_bounds__(256) void kld_fwd_kernel(const float *__restrict__ mu, const float *__restrict__ sg,
+                                                       const float *__restrict__ pm, const float *__restrict__ ps,
+                                                       int64_t count, float inv_batch, float beta,
+                                                       const float *__restrict__ cap, float *__restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < count; i += 256)
+        s += kl_elem(mu[i], sg[i], pm ? pm[i] : 0.f, ps ? ps[i] : 1.f);
+    const float tot = block_sum_256(s, red);
+    if (threadIdx.x == 0) {
+        const float kl = tot * inv_batch;
+        out[0] = beta * fabsf(kl - (cap ? cap[0] : 0.f));
+        out[1] = kl;
+    }
+}
+
+__global__ __launch_bounds__(256) void kld_bwd_kernel(const float *__restrict__ g, const float *__restrict__ mu,
+                                                       const float *__restrict__ sg, const float *__restrict__ pm,
+                                                       const float *__restrict__ ps, int64_t count, float inv_batch,
+                                                       float beta, const float *__restrict__ kl_out,
+                                                       const float *__restrict__ cap, float *__restrict__ dmu,
+                                                       float *__restrict__ dsg) {
+    const float diff = kl_out[1] - (cap ? cap[0] : 0.f);
+    const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+    const float k = g[0] * beta * sgn * inv_batch;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+        const float m0 = pm ? pm[i] : 0.f, s0 = ps ? ps[i] : 1.f;
+        const float s = sg[i];
+        dmu[i] = k * (mu[i] - m0) / (s0 * s0);
+        dsg[i] = k * (s / (s0 * s0) - 1.f / s);
+    }
+}
+
+// =================================================================================================
+// all-pairs attribute regularisation                       (reference utils/trainer.py:369-403)
+// grid = (row blocks, R).  The column vectors z_cols[:,d] / lab_cols[:,d] are staged in LDS in chunks
+// (zero N x N traffic to HBM); each wavefront owns ROWS_PER_WAVE rows, its 64 lanes stride over the
+// staged columns and the two sums (|t-s| and (1-t^2) sgn(t-s)) are reduced with wave shuffles.
+// =================================================================================================
+constexpr int REG_ROWS_PER_WAVE = 2;
+constexpr int REG_ROWS_PER_BLOCK = 4 * REG_ROWS_PER_WAVE;
+constexpr int REG_CHUNK = 2048;   // columns staged per pass: 2 * 8 KB of LDS
+
+struct RegDims { int d[16]; };
+
+__global__ __launch_bounds__(256) void reg_loss_kernel(const float *__restrict__ zr, const float *__restrict__ lr,
+                                                        int64_t n_rows, const float *__restrict__ zc,
+                                                        const float *__restrict__ lc, int64_t n_cols, int64_t ldz,
+                                                        int64_t ldl, RegDims dims, float delta,
+                                                        float *__restrict__ row_loss, float *__restrict__ row_grad) {
+    __shared__ float xs[REG_CHUNK];
+    __shared__ float as[REG_CHUNK];
+    const int d = dims.d[blockIdx.y];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row0 = (int64_t)blockIdx.x * REG_ROWS_PER_BLOCK + wave * REG_ROWS_PER_WAVE;
+    float xi[REG_ROWS_PER_WAVE], ai[REG_ROWS_PER_WAVE], sl[REG_ROWS_PER_WAVE], sg[REG_ROWS_PER_WAVE];
+#pragma unroll
+    for (int r = 0; r < REG_ROWS_PER_WAVE; ++r) {
+        const int64_t row = row0 + r;
+        xi[r] = row < n_rows ? zr[row * ldz + d] : 0.f;
+        ai[r] = row < n_rows ? lr[row * ldl + d] : 0.f;
+        sl[r] = sg[r] = 0.f;
+    }
+    for (int64_t c0 = 0; c0 < n_cols; c0 += REG_CHUNK) {
+        const int cn = (int)min((int64_t)REG_CHUNK, n_cols - c0);
+        __syncthreads();
+        for (int j = threadIdx.x; j < cn; j += 256) {
+            xs[j] = zc[(c0 + j) * ldz + d];
+            as[j] = lc[(c0 + j) * ldl + d];
+        }
+        __syncthreads();
+        for (int j = lane; j < cn; j += 64) {
+            const float xj = xs[j], aj = as[j];
+#pragma unroll
+            for (int r = 0; r < REG_ROWS_PER_WAVE; ++r) {
+                const float t = tanhf(delta * (xi[r] - xj));
+                const float da = ai[r] - aj;
+                const float s = da > 0.f ? 1.f : (da < 0.f ? -1.f : 0.f);
+                const float e = t - s;
+                sl[r] += fabsf(e);
+                sg[r] += (1.f - t * t) * (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f));
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < REG_ROWS_PER_WAVE; ++r) {
+        const float l = wave_sum(sl[r]), g = wave_sum(sg[r]);
+        const int64_t row = row0 + r;
+        if (lane == 0 && row < n_rows) {
+            row_loss[(int64_t)blockIdx.y * n_rows + row] = l;
+            row_grad[(int64_t)blockIdx.y * n_rows + row] = g;
+        }
+    }
+}
+
+// fixed-order finish: loss scalar + dense dz rows
+__global__ __launch_bounds__(256) void reg_finish_kernel(const float *__restrict__ row_loss,
+                                                          const float *__restrict__ row_grad, int64_t n_rows, int r,
+                                                          RegDims dims, int64_t ldz, float loss_scale,
+                                                          float grad_scale, float *__restrict__ loss_out,
+                                                          float *__restrict__ dz) {
+    __shared__ float red[4];
+    if (dz != nullptr) {
+        for (int64_t i = threadIdx.x; i < n_rows * ldz; i += 256) dz[i] = 0.f;
+        __syncthreads();
+        for (int64_t i = threadIdx.x; i < n_rows * r; i += 256) {
+            const int k = (int)(i / n_rows);
+            const int64_t row = i - (int64_t)k * n_rows;
+            dz[row * ldz + dims.d[k]] = grad_scale * row_grad[i];
+        }
+    }
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n_rows * r; i += 256) s += row_loss[i];
+    const float tot = block_sum_256(s, red);
+    if (threadIdx.x == 0) loss_out[0] = tot * loss_scale;
+}
+
+// =================================================================================================
+// image reconstruction term + pixel accuracy (+ d/dlogits)     (image_vae_trainer.py:623-655)
+// =================================================================================================
+constexpr int RECON_MAX_BLOCKS = 1024;
+
+template <int DIST>
+__device__ __forceinline__ void recon_elem(float l, float x, float inv_b, float &loss, float &corr, float &dl) {
+    const float e = expf(-fabsf(l));
+    const float sig = l >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+    if (DIST == ARVAE_RECON_BERNOULLI) {
+        loss += fmaxf(l, 0.f) - l * x + log1pf(e);
+        dl = (sig - x) * inv_b;
+    } else {
+        const float df = sig - x;
+        loss += df * df;
+        dl = 2.f * df * sig * (1.f - sig) * inv_b;
+    }
+    corr += ((l >= 0.f) == (x >= 0.5f)) ? 1.f : 0.f;
+}
+
+template <int DIST>
+__global__ __launch_bounds__(256) void image_recon_kernel(const float *__restrict__ logits,
+                                                           const float *__restrict__ x, int64_t count, float inv_b,
+                                                           float *__restrict__ partial, float *__restrict__ dlogits) {
+    __shared__ float red[4];
+    float loss = 0.f, corr = 0.f;
+    const int64_t n4 = count >> 2;
+    const float4 *l4 = reinterpret_cast<const float4 *>(logits);
+    const float4 *x4 = reinterpret_cast<const float4 *>(x);
+    float4 *d4 = reinterpret_cast<float4 *>(dlogits);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 l = l4[i], xx = x4[i];
+        float4 d;
+        recon_elem<DIST>(l.x, xx.x, inv_b, loss, corr, d.x);
+        recon_elem<DIST>(l.y, xx.y, inv_b, loss, corr, d.y);
+        recon_elem<DIST>(l.z, xx.z, inv_b, loss, corr, d.z);
+        recon_elem<DIST>(l.w, xx.w, inv_b, loss, corr, d.w);
+        if (dlogits != nullptr) d4[i] = d;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (count & 3)) {       // tail
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        float d;
+        recon_elem<DIST>(logits[i], x[i], inv_b, loss, corr, d);
+        if (dlogits != nullptr) dlogits[i] = d;
+    }
+    const float tl = block_sum_256(loss, red);
+    const float tc = block_sum_256(corr, red);
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = tl;
+        partial[2 * blockIdx.x + 1] = tc;
+    }
+}
+
+__global__ __launch_bounds__(256) void pair_finish_kernel(const float *__restrict__ partial, int nblocks, float s0,
+                                                           float s1, float *__restrict__ out) {
+    __shared__ float red[4];
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < nblocks; i += 256) {
+        a += partial[2 * i];
+        b += partial[2 * i + 1];
+    }
+    const float ta = block_sum_256(a, red);
+    const float tb = block_sum_256(b, red);
+    if (threadIdx.x == 0) {
+        out[0] = ta * s0;
+        out[1] = tb * s1;
+    }
+}
+
+// =================================================================================================
+// token reconstruction: mean cross entropy + top-1 accuracy over [rows, V]   (utils/trainer.py:247-282)
+// one lane per row (V ~ 35 floats)
+// =================================================================================================
+__global__ __launch_bounds__(256) void token_recon_kernel(const float *__restrict__ w, const int64_t *__restrict__ tgt,
+                                                           int64_t rows, int vocab, float inv_rows,
+                                                           float *__restrict__ partial, float *__restrict__ dw) {
+    __shared__ float red[4];
+    float loss = 0.f, corr = 0.f;
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (int64_t)gridDim.x * 256) {
+        const float *row = w + r * vocab;
+        float mx = row[0];
+        int arg = 0;
+        for (int j = 1; j < vocab; ++j) {
+            const float v = row[j];
+            if (v > mx) { mx = v; arg = j; }
+        }
+        float se = 0.f;
+        for (int j = 0; j < vocab; ++j) se += expf(row[j] - mx);
+        const int t = (int)tgt[r];
+        const float lse = mx + logf(se);
+        loss += lse - row[t];
+        corr += (arg == t) ? 1.f : 0.f;
+        if (dw != nullptr) {
+            const float inv = 1.f / se;
+            for (int j = 0; j < vocab; ++j)
+                dw[r * vocab + j] = (expf(row[j] - mx) * inv - (j == t ? 1.f : 0.f)) * inv_rows;
+        }
+    }
+    const float tl = block_sum_256(loss, red);
+    const float tc = block_sum_256(corr, red);
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = tl;
+        partial[2 * blockIdx.x + 1] = tc;
+    }
+}
+
+__global__ __launch_bounds__(256) void scale_by_scalar_kernel(const float *__restrict__ g, const float *__restrict__ x,
+                                                               int64_t count, float *__restrict__ y) {
+    const float s = g[0];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) y[i] = s * x[i];
+}
+
+// =================================================================================================
+// Adam over the flat arena                                         (utils/trainer.py:31-34,170-174)
+// =================================================================================================
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g,
+                                                    float *__restrict__ m, float *__restrict__ v, int64_t count,
+                                                    float step_size, float inv_bc2_sqrt, float beta1, float beta2,
+                                                    float eps, float gscale) {
+    const int64_t n4 = count >> 2;
+    float4 *p4 = reinterpret_cast<float4 *>(p);
+    const float4 *g4 = reinterpret_cast<const float4 *>(g);
+    float4 *m4 = reinterpret_cast<float4 *>(m);
+    float4 *v4 = reinterpret_cast<float4 *>(v);
+    auto upd = [&](float &pp, float gg, float &mm, float &vv) {
+        gg *= gscale;
+        mm = beta1 * mm + (1.f - beta1) * gg;
+        vv = beta2 * vv + (1.f - beta2) * gg * gg;
+        pp -= step_size * (mm / (sqrtf(vv) * inv_bc2_sqrt + eps));
+    };
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 pp = p4[i], mm = m4[i], vv = v4[i];
+        const float4 gg = g4[i];
+        upd(pp.x, gg.x, mm.x, vv.x);
+        upd(pp.y, gg.y, mm.y, vv.y);
+        upd(pp.z, gg.z, mm.z, vv.z);
+        upd(pp.w, gg.w, mm.w, vv.w);
+        p4[i] = pp; m4[i] = mm; v4[i] = vv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (count & 3)) {
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        upd(p[i], g[i], m[i], v[i]);
+    }
+}
+
+static inline int grid_for(int64_t count, int per_thread = 1, int max_blocks = 2048) {
+    int64_t b = (count + 256ll * per_thread - 1) / (256ll * per_thread);
+    if (b < 1) b = 1;
+    if (b > max_blocks) b = max_blocks;
+    return (int)b;
+}
+
+}  // namespace arvae
+
+using namespace arvae;
+
+extern "C" int arvae_latent_fwd(const float *mu, const float *log_std, const float *eps, int64_t count, float *sigma,
+                                float *z, arvae_stream_t stream) {
+    ARVAE_REQUIRE(mu && log_std && eps && sigma && z && count > 0, "latent_fwd: bad argument");
+    hipLaunchKernelGGL(latent_fwd_kernel, dim3(grid_for(count)), dim3(256), 0, as_stream(stream), mu, log_std, eps,
+                       count, sigma, z);
+    return check_launch("latent_fwd");
+}
+
+extern "C" int arvae_latent_bwd(const float *g_z, const float *g_sigma, const float *eps, const float *sigma,
+                                int64_t count, float *d_mu, float *d_log_std, arvae_stream_t stream) {
+    ARVAE_REQUIRE(eps && sigma && d_mu && d_log_std && count > 0, "latent_bwd: bad argument");
+    hipLaunchKernelGGL(latent_bwd_kernel, dim3(grid_for(count)), dim3(256), 0, as_stream(stream), g_z, g_sigma, eps,
+                       sigma, count, d_mu, d_log_std);
+    return check_launch("latent_bwd");
+}
+
+extern "C" int arvae_kld_fwd(const float *mu, const float *sigma, const float *prior_mu, const float *prior_sigma,
+                             int64_t batch, int64_t zdim, float beta, const float *capacity, float *out,
+                             arvae_stream_t stream) {
+    ARVAE_REQUIRE(mu && sigma && out && batch > 0 && zdim > 0, "kld_fwd: bad argument");
+    hipLaunchKernelGGL(kld_fwd_kernel, dim3(1), dim3(256), 0, as_stream(stream), mu, sigma, prior_mu, prior_sigma,
+                       batch * zdim, 1.f / (float)batch, beta, capacity, out);
+    return check_launch("kld_fwd");
+}
+
+extern "C" int arvae_kld_bwd(const float *g, const float *mu, const float *sigma, const float *prior_mu,
+                             const float *prior_sigma, int64_t batch, int64_t zdim, float beta, const float *kl_out,
+                             const float *capacity, float *d_mu, float *d_sigma, arvae_stream_t stream) {
+    ARVAE_REQUIRE(g && mu && sigma && kl_out && d_mu && d_sigma && batch > 0 && zdim > 0, "kld_bwd: bad argument");
+    hipLaunchKernelGGL(kld_bwd_kernel, dim3(grid_for(batch * zdim)), dim3(256), 0, as_stream(stream), g, mu, sigma,
+                       prior_mu, prior_sigma, batch * zdim, 1.f / (float)batch, beta, kl_out, capacity, d_mu, d_sigma);
+    return check_launch("kld_bwd");
+}
+
+extern "C" int64_t arvae_reg_loss_ws_floats(int64_t n_rows, int32_t r) { return 2 * n_rows * (int64_t)r; }
+
+extern "C" int arvae_reg_loss(const float *z_rows, const float *lab_rows, int64_t n_rows, const float *z_cols,
+                              const float *lab_cols, int64_t n_cols, int64_t ldz, int64_t ldl, const int32_t *dims,
+                              int32_t r, float gamma, float delta, float *ws, float *loss_out, float *dz,
+                              arvae_stream_t stream) {
+    ARVAE_REQUIRE(z_rows && lab_rows && z_cols && lab_cols && dims && ws && loss_out, "reg_loss: null pointer");
+    ARVAE_REQUIRE(n_rows > 0 && n_cols > 0 && r > 0 && r <= 16, "reg_loss: need 1..16 dims and a non-empty batch");
+    RegDims rd;
+    for (int i = 0; i < 16; ++i) rd.d[i] = i < r ? dims[i] : 0;
+    for (int i = 0; i < r; ++i)
+        ARVAE_REQUIRE(dims[i] >= 0 && dims[i] < ldz && dims[i] < ldl, "reg_loss: dim %d outside z/labels", dims[i]);
+    float *row_loss = ws, *row_grad = ws + n_rows * r;
+    const unsigned bx = (unsigned)((n_rows + REG_ROWS_PER_BLOCK - 1) / REG_ROWS_PER_BLOCK);
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(reg_loss_kernel, dim3(bx, r), dim3(256), 0, s, z_rows, lab_rows, n_rows, z_cols, lab_cols,
+                       n_cols, ldz, ldl, rd, delta, row_loss, row_grad);
+    if (int rc = check_launch("reg_loss")) return rc;
+    const double nn = (double)n_cols * (double)n_cols;
+    hipLaunchKernelGGL(reg_finish_kernel, dim3(1), dim3(256), 0, s, row_loss, row_grad, n_rows, r, rd, ldz,
+                       (float)(gamma / nn), (float)(2.0 * gamma * delta / nn), loss_out, dz);
+    return check_launch("reg_loss(finish)");
+}
+
+extern "C" int64_t arvae_recon_ws_floats(int64_t) { return 2 * RECON_MAX_BLOCKS; }
+
+extern "C" int arvae_image_recon(const float *logits, const float *x, int64_t count, int64_t batch, int32_t dist,
+                                 float *ws, float *out, float *dlogits, arvae_stream_t stream) {
+    ARVAE_REQUIRE(logits && x && ws && out && count > 0 && batch > 0, "image_recon: bad argument");
+    ARVAE_REQUIRE(dist == ARVAE_RECON_BERNOULLI || dist == ARVAE_RECON_GAUSSIAN, "image_recon: invalid dist");
+    const int nb = grid_for(count, 8, RECON_MAX_BLOCKS);
+    hipStream_t s = as_stream(stream);
+    const float inv_b = 1.f / (float)batch;
+    if (dist == ARVAE_RECON_BERNOULLI)
+        hipLaunchKernelGGL(image_recon_kernel<ARVAE_RECON_BERNOULLI>, dim3(nb), dim3(256), 0, s, logits, x, count,
+                           inv_b, ws, dlogits);
+    else
+        hipLaunchKernelGGL(image_recon_kernel<ARVAE_RECON_GAUSSIAN>, dim3(nb), dim3(256), 0, s, logits, x, count,
+                           inv_b, ws, dlogits);
+    if (int rc = check_launch("image_recon")) return rc;
+    hipLaunchKernelGGL(pair_finish_kernel, dim3(1), dim3(256), 0, s, ws, nb, inv_b, 1.f / (float)count, out);
+    return check_launch("image_recon(finish)");
+}
+
+extern "C" int arvae_token_recon(const float *weights, const int64_t *targets, int64_t rows, int32_t vocab, float *ws,
+                                 float *out, float *dweights, arvae_stream_t stream) {
+    ARVAE_REQUIRE(weights && targets && ws && out && rows > 0 && vocab > 0, "token_recon: bad argument");
+    const int nb = grid_for(rows, 1, RECON_MAX_BLOCKS);
+    hipStream_t s = as_stream(stream);
+    const float inv = 1.f / (float)rows;
+    hipLaunchKernelGGL(token_recon_kernel, dim3(nb), dim3(256), 0, s, weights, targets, rows, vocab, inv, ws, dweights);
+    if (int rc = check_launch("token_recon")) return rc;
+    hipLaunchKernelGGL(pair_finish_kernel, dim3(1), dim3(256), 0, s, ws, nb, inv, inv, out);
+    return check_launch("token_recon(finish)");
+}
+
+extern "C" int arvae_scale_by_scalar(const float *g, const float *x, int64_t count, float *y, arvae_stream_t stream) {
+    ARVAE_REQUIRE(g && x && y && count > 0, "scale_by_scalar: bad argument");
+    hipLaunchKernelGGL(scale_by_scalar_kernel, dim3(grid_for(count, 4)), dim3(256), 0, as_stream(stream), g, x, count,
+                       y);
+    return check_launch("scale_by_scalar");
+}
+
+extern "C" int arvae_adam_step(float *p, const float *g, float *m, float *v, int64_t count, int64_t step, float lr,
+                               float beta1, float beta2, float eps, float grad_scale, arvae_stream_t stream) {
+    ARVAE_REQUIRE(p && g && m && v && count > 0 && step >= 1, "adam_step: bad argument");
+    ARVAE_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
+                  "adam_step: arenas must be 16-byte aligned");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(count, 4)), dim3(256), 0, as_stream(stream), p, g, m, v, count,
+                       (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, grad_scale);
+    return check_launch("adam_step");
+}

@@ -1,0 +1,125 @@
+"""ImageVAETrainer: the AR-VAE loss step for the conv VAEs on the HIP kernels.
+
+Loss recipe and API of the reference's imagevae/image_vae_trainer.py:65-217,
+623-655:   loss = recon + beta*|KL - c| + sum_{d in reg_dim} gamma * reg(z[:,d], labels[:,d])
+with the R-dimension Python loop replaced by one all-pairs kernel launch and the
+two passes over the logits (BCE, accuracy) by one fused reduction.
+"""
+from typing import Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+from .trainer import Trainer
+
+MNIST_REG_TYPES = {'digit_identity': 0, 'area': 1, 'length': 2, 'thickness': 3, 'slant': 4, 'width': 5,
+                   'height': 6}
+DSPRITES_REG_TYPE = {'color': 0, 'shape': 1, 'scale': 2, 'orientation': 3, 'posx': 4, 'posy': 5}
+DATASET_REG_TYPE_DICT = {'mnist': MNIST_REG_TYPES, 'dsprites': DSPRITES_REG_TYPE}
+
+
+def get_reg_dim(attr_dict):
+    return tuple(v for k, v in attr_dict.items() if k not in ('digit_identity', 'color'))
+
+
+class ImageVAETrainer(Trainer):
+    def __init__(self, dataset, model, lr=1e-4, reg_type: Tuple[str] = None, reg_dim: Tuple[int] = 0,
+                 dec_dist='bernoulli', beta=4.0, gamma=10.0, capacity=0.0, rand=0, delta=1.0):
+        super().__init__(dataset, model, lr)
+        kind = dataset.__class__.__name__
+        if kind == 'MorphoMnistDataset':
+            self.dataset_type = 'mnist'
+        elif kind == 'DspritesDataset':
+            self.dataset_type = 'dsprites'
+        else:
+            raise ValueError(f'Dataset type not recognized: {kind}')
+        self.attr_dict = DATASET_REG_TYPE_DICT[self.dataset_type]
+        self.reverse_attr_dict = {v: k for k, v in self.attr_dict.items()}
+        self.metrics = {}
+        self.beta = beta
+        self.capacity = torch.tensor([capacity], dtype=torch.float32)
+        self.gamma = 0.0
+        self.delta = 0.0
+        self.cur_epoch_num = 0
+        self.warm_up_epochs = 10
+        self.reg_type = reg_type if reg_type is not None else ()
+        self.reg_dim = ()
+        self.use_reg_loss = False
+        self.rand_seed = rand
+        torch.manual_seed(self.rand_seed)
+        np.random.seed(self.rand_seed)
+        self.trainer_config = f'_r_{self.rand_seed}_b_{self.beta}_'
+        if capacity != 0.0:
+            self.trainer_config += f'c_{capacity}_'
+        self.dec_dist = dec_dist
+        if len(self.reg_type) != 0:
+            self.use_reg_loss = True
+            self.reg_dim = reg_dim
+            self.gamma = gamma
+            self.delta = delta
+            self.trainer_config += f'g_{self.gamma}_d_{self.delta}_' + '_'.join(self.reg_type) + '_'
+        self.model.update_trainer_config(self.trainer_config)
+        self.last_terms = {}
+
+    def cuda(self):
+        super().cuda()
+        self.capacity = self.capacity.cuda()
+
+    def process_batch_data(self, batch):
+        if self.dataset_type == 'mnist':
+            inputs, _, labels = batch
+        else:
+            inputs, labels = batch
+        dev = next(self.model.parameters()).device
+        return (inputs.to(dev, torch.float32, non_blocking=True).contiguous(),
+                labels.to(dev, torch.float32, non_blocking=True).contiguous())
+
+    def loss_and_acc_for_batch(self, batch, epoch_num=None, batch_num=None, train=True):
+        first_of_epoch = self.cur_epoch_num != epoch_num
+        if first_of_epoch:
+            self.cur_epoch_num = epoch_num
+        inputs, labels = batch
+        if self.capacity.device != inputs.device:
+            self.capacity = self.capacity.to(inputs.device)
+
+        outputs, z_dist, prior_dist, z_tilde, _ = self.model(inputs)
+        recons_loss, accuracy = ops.image_recon(outputs, inputs, self.dec_dist)
+        dist_loss = self.compute_kld_loss(z_dist, prior_dist, beta=self.beta, c=self.capacity)
+        loss = recons_loss + dist_loss
+        reg_loss = None
+        if self.use_reg_loss:
+            if type(self.reg_dim) != tuple:
+                raise TypeError('Regularization dimension must be a tuple of integers')
+            if self.data_parallel is not None:
+                reg_loss = self.data_parallel.reg_loss(z_tilde, labels, self.reg_dim, self.gamma, self.delta)
+            else:
+                reg_loss = ops.reg_loss(z_tilde, labels, self.reg_dim, self.gamma, self.delta)
+            loss = loss + reg_loss
+        self.last_terms = {'recons': recons_loss.detach(), 'dist': dist_loss.detach(),
+                           'reg': None if reg_loss is None else reg_loss.detach()}
+        if first_of_epoch and self.writer is not None:
+            self.writer.add_scalar('loss_split/recons_loss', recons_loss.item(), epoch_num)
+            self.writer.add_scalar('loss_split/dist_loss', (dist_loss / self.beta).item(), epoch_num)
+            if reg_loss is not None:
+                self.writer.add_scalar('loss_split/reg_loss', (reg_loss / self.gamma).item(), epoch_num)
+        if not train and batch_num == 0 and self.writer is not None:
+            from .logging_utils import image_grid
+            n = min(inputs.size(0), 16)
+            self.writer.add_image('reconstruction',
+                                  image_grid(torch.cat([inputs[:n], torch.sigmoid(outputs[:n].detach())]).cpu(), n),
+                                  epoch_num)
+        return loss, accuracy
+
+    # -- static helpers (image_vae_trainer.py:623-655) ---------------------------------------------------
+    @staticmethod
+    def reconstruction_loss(x, x_recons, dist):
+        if dist not in ('bernoulli', 'gaussian'):
+            raise AttributeError('invalid dist')
+        return ops.image_recon(x_recons, x, dist)[0]
+
+    @staticmethod
+    def mean_accuracy(weights, targets):
+        """weights are probabilities (sigmoid already applied by the caller, as in the reference)."""
+        logits = torch.logit(weights.detach().clamp(0.0, 1.0))     # p >= .5  <=>  logit >= 0
+        return ops.image_recon(logits.nan_to_num(posinf=1e30, neginf=-1e30), targets, 'bernoulli')[1]

@@ -1,0 +1,385 @@
+"""torch.autograd wrappers over the libarvae_hip.so C-ABI (PyTorch = bookkeeping only).
+
+Every op takes fp32 contiguous HIP tensors and launches hand-written gfx950
+kernels on the current stream.  There is no CPU path: CPU tensors raise.
+
+Activation tensors are channels-last ([N, H, W, C]; [B, F] for dense layers).
+"""
+import ctypes
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+from ._lib import LinkDesc, OperandDesc
+
+ACT_NONE, ACT_RELU, ACT_SELU = 0, 1, 2
+RECON_DIST = {'bernoulli': 0, 'gaussian': 1}
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError('arvae_amd ops run on the GPU only (HIP kernels, no CPU fallback); '
+                               'got a CPU tensor -- call .cuda() on the model/inputs')
+        if t.dtype not in (torch.float32, torch.uint8, torch.int64):
+            raise TypeError(f'unsupported dtype {t.dtype}')
+        if not t.is_contiguous():
+            raise ValueError('arvae_amd ops need contiguous tensors')
+
+
+def _operand(v, y=None, mask=None, act=ACT_NONE):
+    return OperandDesc(_ptr(v), _ptr(y), _ptr(mask), act)
+
+
+@dataclass(frozen=True)
+class Link:
+    """Static geometry of a strided link (see include/arvae_hip.h): hi [.,hh,hw,chi] <-> lo [.,lh,lw,clo]."""
+    hh: int
+    hw: int
+    chi: int
+    lh: int
+    lw: int
+    clo: int
+    kh: int = 1
+    kw: int = 1
+    stride: int = 1
+    pad: int = 0
+    hi_perm: Tuple[int, int] = (0, 0)
+    lo_perm: Tuple[int, int] = (0, 0)
+
+    def desc(self, n):
+        return LinkDesc(n, self.hh, self.hw, self.chi, self.lh, self.lw, self.clo, self.kh, self.kw, self.stride,
+                        self.pad, self.hi_perm[0], self.hi_perm[1], self.lo_perm[0], self.lo_perm[1])
+
+    @staticmethod
+    def dense(in_features, out_features, in_perm=(0, 0), out_perm=(0, 0)):
+        return Link(1, 1, in_features, 1, 1, out_features, hi_perm=in_perm, lo_perm=out_perm)
+
+    def hi_shape(self, n):
+        return (n, self.chi) if self.hh == self.hw == self.lh == self.lw == 1 else (n, self.hh, self.hw, self.chi)
+
+    def lo_shape(self, n):
+        return (n, self.clo) if self.hh == self.hw == self.lh == self.lw == 1 else (n, self.lh, self.lw, self.clo)
+
+
+# ------------------------------------------------------------------------------------------------
+# raw launches (no autograd)
+# ------------------------------------------------------------------------------------------------
+def link_down(link: Link, n, hi_op, wt, bias, act, out_mask, out=None):
+    lib = _lib.load()
+    lo = out if out is not None else torch.empty(link.lo_shape(n), device=wt.device, dtype=torch.float32)
+    d = link.desc(n)
+    _lib.check(lib.arvae_link_down(ctypes.byref(d), ctypes.byref(hi_op), _ptr(wt), _ptr(bias), act, _ptr(out_mask),
+                                   _ptr(lo), _stream()), 'link_down')
+    return lo
+
+
+def link_up(link: Link, n, lo_op, wt, bias, act, out_mask, out=None):
+    lib = _lib.load()
+    hi = out if out is not None else torch.empty(link.hi_shape(n), device=wt.device, dtype=torch.float32)
+    d = link.desc(n)
+    _lib.check(lib.arvae_link_up(ctypes.byref(d), ctypes.byref(lo_op), _ptr(wt), _ptr(bias), act, _ptr(out_mask),
+                                 _ptr(hi), _stream()), 'link_up')
+    return hi
+
+
+def link_wgrad(link: Link, n, lo_op, hi_op, dwt):
+    lib = _lib.load()
+    d = link.desc(n)
+    _lib.check(lib.arvae_link_wgrad(ctypes.byref(d), ctypes.byref(lo_op), ctypes.byref(hi_op), _ptr(dwt), _stream()),
+               'link_wgrad')
+    return dwt
+
+
+def channel_sum(op, rows, channels, perm, out):
+    lib = _lib.load()
+    _lib.check(lib.arvae_channel_sum(ctypes.byref(op), rows, channels, perm[0], perm[1], _ptr(out), _stream()),
+               'channel_sum')
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# layers
+# ------------------------------------------------------------------------------------------------
+class _LinkDownFn(Function):
+    """nn.Conv2d / nn.Linear forward (+bias, activation, dropout keep-mask) and its backward."""
+
+    @staticmethod
+    def forward(ctx, hi, wt, bias, link, act, mask):
+        _dev(hi, wt, bias, mask)
+        n = hi.shape[0]
+        lo = link_down(link, n, _operand(hi), wt, bias, act, mask)
+        ctx.link, ctx.act, ctx.n = link, act, n
+        ctx.save_for_backward(hi, wt, lo, mask)
+        ctx.has_bias = bias is not None
+        return lo
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_lo):
+        hi, wt, lo, mask = ctx.saved_tensors
+        link, n = ctx.link, ctx.n
+        g_lo = g_lo.contiguous()
+        gop = _operand(g_lo, lo, mask, ctx.act)
+        d_hi = d_wt = d_bias = None
+        if ctx.needs_input_grad[0]:
+            d_hi = link_up(link, n, gop, wt, None, ACT_NONE, None)
+        if ctx.needs_input_grad[1]:
+            d_wt = link_wgrad(link, n, gop, _operand(hi), torch.zeros_like(wt))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            d_bias = channel_sum(gop, n * link.lh * link.lw, link.clo, link.lo_perm,
+                                 torch.zeros(link.clo, device=wt.device, dtype=torch.float32))
+        return d_hi, d_wt, d_bias, None, None, None
+
+
+class _LinkUpFn(Function):
+    """nn.ConvTranspose2d forward (+bias, activation, dropout keep-mask) and its backward."""
+
+    @staticmethod
+    def forward(ctx, lo, wt, bias, link, act, mask):
+        _dev(lo, wt, bias, mask)
+        n = lo.shape[0]
+        hi = link_up(link, n, _operand(lo), wt, bias, act, mask)
+        ctx.link, ctx.act, ctx.n = link, act, n
+        ctx.save_for_backward(lo, wt, hi, mask)
+        ctx.has_bias = bias is not None
+        return hi
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_hi):
+        lo, wt, hi, mask = ctx.saved_tensors
+        link, n = ctx.link, ctx.n
+        g_hi = g_hi.contiguous()
+        gop = _operand(g_hi, hi, mask, ctx.act)
+        d_lo = d_wt = d_bias = None
+        if ctx.needs_input_grad[0]:
+            d_lo = link_down(link, n, gop, wt, None, ACT_NONE, None)
+        if ctx.needs_input_grad[1]:
+            d_wt = link_wgrad(link, n, _operand(lo), gop, torch.zeros_like(wt))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            d_bias = channel_sum(gop, n * link.hh * link.hw, link.chi, link.hi_perm,
+                                 torch.zeros(link.chi, device=wt.device, dtype=torch.float32))
+        return d_lo, d_wt, d_bias, None, None, None
+
+
+def conv_down(hi, wt, bias, link, act=ACT_NONE, mask=None):
+    return _LinkDownFn.apply(hi, wt, bias, link, act, mask)
+
+
+def conv_up(lo, wt, bias, link, act=ACT_NONE, mask=None):
+    return _LinkUpFn.apply(lo, wt, bias, link, act, mask)
+
+
+def dense(x, wt, bias, link, act=ACT_NONE):
+    return _LinkDownFn.apply(x, wt, bias, link, act, None)
+
+
+# ------------------------------------------------------------------------------------------------
+# latent head / KL
+# ------------------------------------------------------------------------------------------------
+class _LatentFn(Function):
+    @staticmethod
+    def forward(ctx, mu, log_std, eps):
+        _dev(mu, log_std, eps)
+        lib = _lib.load()
+        sigma, z = torch.empty_like(mu), torch.empty_like(mu)
+        _lib.check(lib.arvae_latent_fwd(_ptr(mu), _ptr(log_std), _ptr(eps), mu.numel(), _ptr(sigma), _ptr(z),
+                                        _stream()), 'latent_fwd')
+        ctx.save_for_backward(eps, sigma)
+        return sigma, z
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_sigma, g_z):
+        eps, sigma = ctx.saved_tensors
+        lib = _lib.load()
+        g_sigma = None if g_sigma is None else g_sigma.contiguous()
+        g_z = None if g_z is None else g_z.contiguous()
+        d_mu, d_ls = torch.empty_like(sigma), torch.empty_like(sigma)
+        _lib.check(lib.arvae_latent_bwd(_ptr(g_z), _ptr(g_sigma), _ptr(eps), _ptr(sigma), sigma.numel(), _ptr(d_mu),
+                                        _ptr(d_ls), _stream()), 'latent_bwd')
+        return d_mu, d_ls, None
+
+
+def latent_head(mu, log_std, eps):
+    """-> (sigma, z) with sigma = exp(log_std), z = mu + eps * sigma."""
+    return _LatentFn.apply(mu.contiguous(), log_std.contiguous(), eps.contiguous())
+
+
+class _KLDFn(Function):
+    @staticmethod
+    def forward(ctx, mu, sigma, prior_mu, prior_sigma, beta, capacity):
+        _dev(mu, sigma, prior_mu, prior_sigma, capacity)
+        lib = _lib.load()
+        b, zd = mu.shape
+        out = torch.empty(2, device=mu.device, dtype=torch.float32)
+        _lib.check(lib.arvae_kld_fwd(_ptr(mu), _ptr(sigma), _ptr(prior_mu), _ptr(prior_sigma), b, zd, beta,
+                                     _ptr(capacity), _ptr(out), _stream()), 'kld_fwd')
+        ctx.beta = beta
+        ctx.save_for_backward(mu, sigma, prior_mu, prior_sigma, out, capacity)
+        return out[0:1] if capacity is not None else out[0]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        mu, sigma, prior_mu, prior_sigma, out, capacity = ctx.saved_tensors
+        lib = _lib.load()
+        b, zd = mu.shape
+        g = g.reshape(1).contiguous()
+        d_mu, d_sigma = torch.empty_like(mu), torch.empty_like(mu)
+        _lib.check(lib.arvae_kld_bwd(_ptr(g), _ptr(mu), _ptr(sigma), _ptr(prior_mu), _ptr(prior_sigma), b, zd,
+                                     ctx.beta, _ptr(out), _ptr(capacity), _ptr(d_mu), _ptr(d_sigma), _stream()),
+                   'kld_bwd')
+        return d_mu, d_sigma, None, None, None, None
+
+
+def kld_loss(mu, sigma, beta, capacity=None, prior_mu=None, prior_sigma=None):
+    """beta * |mean_b sum_z KL(N(mu,sigma) || prior) - c|; prior None = N(0,1).
+    capacity: 1-element tensor (result has shape (1,), like the reference) or None."""
+    if capacity is not None:
+        capacity = capacity.reshape(1).to(torch.float32).contiguous()
+    return _KLDFn.apply(mu.contiguous(), sigma.contiguous(), prior_mu, prior_sigma, float(beta), capacity)
+
+
+# ------------------------------------------------------------------------------------------------
+# attribute regularisation
+# ------------------------------------------------------------------------------------------------
+class _RegLossFn(Function):
+    @staticmethod
+    def forward(ctx, z, labels, dims, gamma, delta, z_cols, lab_cols):
+        _dev(z, labels, z_cols, lab_cols)
+        lib = _lib.load()
+        n_rows, ldz = z.shape
+        ldl = labels.shape[1]
+        zc = z if z_cols is None else z_cols
+        lc = labels if lab_cols is None else lab_cols
+        if zc.shape[1] != ldz or lc.shape[1] != ldl or zc.shape[0] != lc.shape[0]:
+            raise ValueError('column tensors must have the row tensors\' widths')
+        r = len(dims)
+        ws = torch.empty(lib.arvae_reg_loss_ws_floats(n_rows, r), device=z.device, dtype=torch.float32)
+        loss = torch.empty((), device=z.device, dtype=torch.float32)
+        dz = torch.empty_like(z)
+        cdims = (ctypes.c_int32 * r)(*dims)
+        _lib.check(lib.arvae_reg_loss(_ptr(z), _ptr(labels), n_rows, _ptr(zc), _ptr(lc), zc.shape[0], ldz, ldl, cdims,
+                                      r, gamma, delta, _ptr(ws), _ptr(loss), _ptr(dz), _stream()), 'reg_loss')
+        ctx.save_for_backward(dz)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (dz,) = ctx.saved_tensors
+        return scale_by_scalar(g, dz), None, None, None, None, None, None
+
+
+def reg_loss(z, labels, dims, gamma, delta, z_cols=None, lab_cols=None):
+    """sum over dims of gamma * mean_ij |tanh(delta (z_i - z_j)) - sign(a_i - a_j)|, all dims in one launch.
+    z[:, d] pairs with labels[:, d].  z_cols/lab_cols: the all-gathered global batch under data parallelism
+    (rows = this rank's samples); the mean is then over len(cols)^2 pairs."""
+    dims = tuple(int(d) for d in dims)
+    if len(dims) == 0:
+        raise ValueError('reg_loss needs at least one dimension')
+    return _RegLossFn.apply(z.contiguous(), labels.contiguous().to(torch.float32), dims, float(gamma), float(delta),
+                            None if z_cols is None else z_cols.contiguous(),
+                            None if lab_cols is None else lab_cols.contiguous().to(torch.float32))
+
+
+def scale_by_scalar(g, x):
+    lib = _lib.load()
+    g = g.reshape(1).contiguous()
+    y = torch.empty_like(x)
+    _lib.check(lib.arvae_scale_by_scalar(_ptr(g), _ptr(x), x.numel(), _ptr(y), _stream()), 'scale_by_scalar')
+    return y
+
+
+# ------------------------------------------------------------------------------------------------
+# reconstruction terms
+# ------------------------------------------------------------------------------------------------
+class _ImageReconFn(Function):
+    @staticmethod
+    def forward(ctx, logits, x, dist):
+        _dev(logits, x)
+        lib = _lib.load()
+        count, batch = logits.numel(), logits.shape[0]
+        ws = torch.empty(lib.arvae_recon_ws_floats(count), device=x.device, dtype=torch.float32)
+        out = torch.empty(2, device=x.device, dtype=torch.float32)
+        need = ctx.needs_input_grad[0]
+        dl = torch.empty_like(logits) if need else None
+        _lib.check(lib.arvae_image_recon(_ptr(logits), _ptr(x), count, batch, dist, _ptr(ws), _ptr(out), _ptr(dl),
+                                         _stream()), 'image_recon')
+        if need:
+            ctx.save_for_backward(dl)
+        loss, acc = out[0], out[1]
+        ctx.mark_non_differentiable(acc)
+        return loss, acc
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g, _g_acc):
+        (dl,) = ctx.saved_tensors
+        return scale_by_scalar(g, dl), None, None
+
+
+def image_recon(logits, x, dist='bernoulli'):
+    """-> (sum_all(term)/batch, pixel accuracy)."""
+    if dist not in RECON_DIST:
+        raise AttributeError('invalid dist')
+    return _ImageReconFn.apply(logits.contiguous(), x.contiguous(), RECON_DIST[dist])
+
+
+class _TokenReconFn(Function):
+    @staticmethod
+    def forward(ctx, weights, targets):
+        _dev(weights, targets)
+        lib = _lib.load()
+        vocab = weights.shape[-1]
+        rows = weights.numel() // vocab
+        ws = torch.empty(lib.arvae_recon_ws_floats(rows), device=weights.device, dtype=torch.float32)
+        out = torch.empty(2, device=weights.device, dtype=torch.float32)
+        need = ctx.needs_input_grad[0]
+        dw = torch.empty_like(weights) if need else None
+        _lib.check(lib.arvae_token_recon(_ptr(weights), _ptr(targets), rows, vocab, _ptr(ws), _ptr(out), _ptr(dw),
+                                         _stream()), 'token_recon')
+        if need:
+            ctx.save_for_backward(dw)
+        loss, acc = out[0], out[1]
+        ctx.mark_non_differentiable(acc)
+        return loss, acc
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g, _g_acc):
+        (dw,) = ctx.saved_tensors
+        return scale_by_scalar(g, dw), None
+
+
+def token_recon(weights, targets):
+    """-> (mean cross entropy over rows, top-1 accuracy) for weights [..., V], int64 targets [...]."""
+    if targets.dtype != torch.int64:
+        raise TypeError('targets must be int64')
+    return _TokenReconFn.apply(weights.contiguous(), targets.contiguous())
+
+
+# ------------------------------------------------------------------------------------------------
+# Adam
+# ------------------------------------------------------------------------------------------------
+def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    _dev(p, g, m, v)
+    lib = _lib.load()
+    _lib.check(lib.arvae_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), int(step), lr, beta1, beta2, eps,
+                                   grad_scale, _stream()), 'adam_step')

@@ -1,0 +1,95 @@
+"""Adam over one flat fp32 arena (one HIP kernel per step; one RCCL all-reduce per step).
+
+Replaces torch.optim.Adam as constructed by the reference's Trainer
+(utils/trainer.py:31-34): lr given, betas (0.9, 0.999), eps 1e-8, no weight
+decay, no amsgrad.  Parameters stay ordinary nn.Parameters (same state_dict);
+their storage is re-pointed into a contiguous arena, and `.grad` of each is a
+view into a matching gradient arena, so
+  zero_grad()  = one memset,
+  all-reduce   = one collective on `grad_arena`,
+  step()       = one multi-tensor kernel (arvae_adam_step).
+"""
+import torch
+
+from . import ops
+
+
+class FlatAdam:
+    def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8):
+        self.params = [p for p in params]
+        if not self.params:
+            raise ValueError('optimizer got an empty parameter list')
+        self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        self.step_count = 0
+        self.grad_scale = 1.0          # set to 1/world_size when gradients are SUM all-reduced
+        self.param_arena = self.grad_arena = self.exp_avg = self.exp_avg_sq = None
+        self._offsets = []
+
+    # -- arena management -----------------------------------------------------------------------
+    def _arena_valid(self):
+        if self.param_arena is None:
+            return False
+        base = self.param_arena.data_ptr()
+        for p, off in zip(self.params, self._offsets):
+            if p.data_ptr() != base + 4 * off or p.device != self.param_arena.device:
+                return False
+        return True
+
+    def _build_arena(self):
+        dev = self.params[0].device
+        offsets, total = [], 0
+        for p in self.params:
+            offsets.append(total)
+            total += (p.numel() + 3) // 4 * 4                 # keep every tensor 16-byte aligned
+        arena = torch.zeros(total, device=dev, dtype=torch.float32)
+        grads = torch.zeros(total, device=dev, dtype=torch.float32)
+        old_m, old_v, old_off = self.exp_avg, self.exp_avg_sq, self._offsets
+        self.exp_avg = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.exp_avg_sq = torch.zeros(total, device=dev, dtype=torch.float32)
+        with torch.no_grad():
+            for i, (p, off) in enumerate(zip(self.params, offsets)):
+                n = p.numel()
+                arena[off:off + n].copy_(p.detach().reshape(-1))
+                p.data = arena[off:off + n].view(p.shape)
+                p.grad = grads[off:off + n].view(p.shape)
+                if old_m is not None:                      # moved device mid-training: carry the moments
+                    self.exp_avg[off:off + n].copy_(old_m[old_off[i]:old_off[i] + n])
+                    self.exp_avg_sq[off:off + n].copy_(old_v[old_off[i]:old_off[i] + n])
+        self.param_arena, self.grad_arena, self._offsets = arena, grads, offsets
+
+    def ensure_arena(self):
+        if not self._arena_valid():
+            self._build_arena()
+        return self.param_arena
+
+    # -- torch.optim.Optimizer surface used by the trainer --------------------------------------
+    def zero_grad(self, set_to_none=False):
+        self.ensure_arena()
+        self.grad_arena.zero_()
+        for p, off in zip(self.params, self._offsets):     # re-attach views dropped by zero_grad(None) users
+            if p.grad is None or p.grad.data_ptr() != self.grad_arena.data_ptr() + 4 * off:
+                p.grad = self.grad_arena[off:off + p.numel()].view(p.shape)
+
+    @torch.no_grad()
+    def step(self):
+        self.ensure_arena()
+        for p, off in zip(self.params, self._offsets):
+            if p.grad is not None and p.grad.data_ptr() != self.grad_arena.data_ptr() + 4 * off:
+                self.grad_arena[off:off + p.numel()].copy_(p.grad.reshape(-1))
+                p.grad = self.grad_arena[off:off + p.numel()].view(p.shape)
+        self.step_count += 1
+        ops.adam_step(self.param_arena, self.grad_arena, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
+                      self.betas[0], self.betas[1], self.eps, self.grad_scale)
+
+    def state_dict(self):
+        return {'step': self.step_count, 'lr': self.lr, 'betas': self.betas, 'eps': self.eps,
+                'exp_avg': None if self.exp_avg is None else self.exp_avg.clone(),
+                'exp_avg_sq': None if self.exp_avg_sq is None else self.exp_avg_sq.clone()}
+
+    def load_state_dict(self, state):
+        self.step_count, self.lr = int(state['step']), float(state['lr'])
+        self.betas, self.eps = tuple(state['betas']), float(state['eps'])
+        if state.get('exp_avg') is not None:
+            self.ensure_arena()
+            self.exp_avg.copy_(state['exp_avg'])
+            self.exp_avg_sq.copy_(state['exp_avg_sq'])

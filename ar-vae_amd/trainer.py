@@ -1,0 +1,164 @@
+"""Trainer base: epoch loop, Adam, and the static loss helpers, on the HIP kernels.
+
+Public surface of the reference's utils/trainer.py:16-413 (constructor,
+train_model, loss_and_acc_on_epoch, cuda/zero_grad/step, load_model, the abstract
+hooks and the static loss helpers with their names and argument meaning).
+Differences a caller can observe:
+  * the optimizer is arvae_amd.optim.FlatAdam (same update rule, one kernel);
+  * epoch means are accumulated on the device (no per-step D2H sync);
+  * logging tolerates writer=None (the reference crashes in epoch 2 with --no_log).
+"""
+import datetime
+import os
+import time
+from abc import ABC, abstractmethod
+
+import torch
+
+from . import ops
+from .optim import FlatAdam
+
+
+def _is_standard_prior(prior_dist):
+    return prior_dist is None or getattr(prior_dist, '_arvae_standard', False)
+
+
+class Trainer(ABC):
+    def __init__(self, dataset, model, lr=1e-4):
+        self.dataset = dataset
+        self.model = model
+        self.optimizer = FlatAdam((p for p in self.model.parameters() if p.requires_grad), lr=lr)
+        self.global_iter = 0
+        self.trainer_config = ''
+        self.writer = None
+        self.data_parallel = None          # arvae_amd.parallel.DataParallel when world_size > 1
+
+    # -- epoch loop (reference utils/trainer.py:39-154) ------------------------------------------------
+    def train_model(self, batch_size, num_epochs, log=False):
+        if log:
+            from .logging_utils import make_writer
+            stamp = datetime.datetime.fromtimestamp(time.time()).strftime('%Y-%m-%d_%H:%M:%S')
+            self.writer = make_writer(os.path.join('runs', repr(self.model) + stamp))
+        train_loader, val_loader, _ = self.dataset.data_loaders(batch_size=batch_size, split=(0.70, 0.20))
+        print('Num Train Batches: ', len(train_loader))
+        print('Num Valid Batches: ', len(val_loader))
+        for epoch in range(num_epochs):
+            self.update_scheduler(epoch)
+            self.model.train()
+            loss_tr, acc_tr = self.loss_and_acc_on_epoch(train_loader, epoch_num=epoch, train=True)
+            self.model.eval()
+            with torch.no_grad():
+                loss_va, acc_va = self.loss_and_acc_on_epoch(val_loader, epoch_num=epoch, train=False)
+            self.eval_model(data_loader=val_loader, epoch_num=epoch)
+            if log and self.writer is not None:
+                self.writer.add_scalar('loss/train', loss_tr, epoch)
+                self.writer.add_scalar('loss/valid', loss_va, epoch)
+                self.writer.add_scalar('acc/train', acc_tr, epoch)
+                self.writer.add_scalar('acc/valid', acc_va, epoch)
+            self.print_epoch_stats(epoch, num_epochs, loss_tr, acc_tr, loss_va, acc_va)
+            self.model.save()
+
+    def loss_and_acc_on_epoch(self, data_loader, epoch_num=None, train=True):
+        loss_sum = acc_sum = None
+        count = 0
+        for batch_num, batch in enumerate(data_loader):
+            batch_data = self.process_batch_data(batch)
+            self.zero_grad()
+            loss, accuracy = self.loss_and_acc_for_batch(batch_data, epoch_num, batch_num, train=train)
+            if train:
+                loss.backward()
+                self.step()
+            l = loss.detach().mean()
+            loss_sum = l if loss_sum is None else loss_sum + l
+            if accuracy is not None:
+                a = accuracy.detach()
+                acc_sum = a if acc_sum is None else acc_sum + a
+            count += 1
+        n = max(count, 1)
+        mean_loss = float(loss_sum) / n if loss_sum is not None else 0.0       # single sync per epoch
+        mean_acc = float(acc_sum) / n if acc_sum is not None else 0.0
+        return mean_loss, mean_acc
+
+    def cuda(self):
+        self.model.cuda()
+
+    def zero_grad(self):
+        self.optimizer.zero_grad()
+
+    def step(self):
+        if self.data_parallel is not None:
+            self.data_parallel.reduce_gradients(self.optimizer)
+        self.optimizer.step()
+        self.global_iter += 1
+
+    def eval_model(self, data_loader, epoch_num):
+        pass
+
+    def load_model(self):
+        on_gpu = torch.cuda.is_available()
+        self.model.load(cpu=not on_gpu)
+        if on_gpu:
+            self.model.cuda()
+
+    @abstractmethod
+    def loss_and_acc_for_batch(self, batch, epoch_num=None, batch_num=None, train=True):
+        """-> (loss tensor with grad_fn, accuracy tensor or None)"""
+
+    @abstractmethod
+    def process_batch_data(self, batch):
+        """-> device tensors for loss_and_acc_for_batch"""
+
+    def update_scheduler(self, epoch_num):
+        pass
+
+    @staticmethod
+    def print_epoch_stats(epoch_index, num_epochs, mean_loss_train, mean_accuracy_train, mean_loss_val,
+                          mean_accuracy_val):
+        print(f'Train Epoch: {epoch_index + 1}/{num_epochs}')
+        print(f'\tTrain Loss: {mean_loss_train}\tTrain Accuracy: {mean_accuracy_train * 100} %')
+        print(f'\tValid Loss: {mean_loss_val}\tValid Accuracy: {mean_accuracy_val * 100} %')
+
+    # -- static loss helpers (same names / argument meaning as utils/trainer.py:247-413) ---------------
+    @staticmethod
+    def mean_crossentropy_loss(weights, targets):
+        """weights (B, T, V), targets (B, T) int64 -> mean cross entropy (utils/trainer.py:247-264)."""
+        if weights.size(0) != targets.size(0) or weights.size(1) != targets.size(1):
+            raise AssertionError('weights / targets shape mismatch')
+        return ops.token_recon(weights, targets)[0]
+
+    @staticmethod
+    def mean_accuracy(weights, targets):
+        """top-1 accuracy over B*T rows (utils/trainer.py:266-282)."""
+        return ops.token_recon(weights.detach(), targets)[1]
+
+    @staticmethod
+    def compute_kld_loss(z_dist, prior_dist, beta, c=0.0):
+        """beta * |KL(z_dist || prior).sum(1).mean() - c|   (utils/trainer.py:354-367)."""
+        if torch.is_tensor(c):
+            cap = c
+        else:
+            cap = None if c == 0.0 else torch.tensor([float(c)], device=z_dist.loc.device)
+        if _is_standard_prior(prior_dist):
+            out = ops.kld_loss(z_dist.loc, z_dist.scale, beta, cap)
+        else:
+            out = ops.kld_loss(z_dist.loc, z_dist.scale, beta, cap, prior_dist.loc.contiguous(),
+                               prior_dist.scale.contiguous())
+        return out if (torch.is_tensor(c) or cap is None) else out[0]
+
+    @staticmethod
+    def compute_reg_loss(z, labels, reg_dim, gamma, factor=1.0):
+        """gamma * reg_loss_sign(z[:, reg_dim], labels)   (utils/trainer.py:369-376)."""
+        return gamma * Trainer.reg_loss_sign(z[:, reg_dim], labels, factor=factor)
+
+    @staticmethod
+    def reg_loss_sign(latent_code, attribute, factor=1.0):
+        """mean_ij |tanh(factor (x_i - x_j)) - sign(a_i - a_j)|   (utils/trainer.py:378-403)."""
+        x = latent_code.reshape(-1, 1)
+        a = attribute.reshape(-1, 1).to(torch.float32)
+        return ops.reg_loss(x, a, (0,), 1.0, factor)
+
+    @staticmethod
+    def get_save_dir(model, sub_dir_name='results'):
+        path = os.path.join(os.path.dirname(model.filepath), sub_dir_name)
+        os.makedirs(path, exist_ok=True)
+        return path

@@ -1,0 +1,179 @@
+/* arvae_hip.h -- C-ABI of libarvae_hip.so, the MI355X (gfx950) AR-VAE training-path library.
+ *
+ * The reference (ashispati/ar-vae) has no FFI / plugin interface: its hot path is stock PyTorch ops
+ * called from Python classes.  This header is therefore the boundary a
+ * maintainer binds INSTEAD of those torch calls; every entry point cites the reference call site it
+ * replaces (paths relative to the reference repo).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller unless the
+ *    parameter is documented as "host".  The library allocates nothing and keeps no mutable global
+ *    state, so the forward (main thread) and backward (autograd thread) may call concurrently.
+ *  - `stream` is a hipStream_t passed as void*; calls only enqueue work and never synchronise.
+ *  - return value: 0 = ok, <0 = error (ARVAE_E_*); arvae_last_error_string() gives the thread-local text.
+ *  - tensors are fp32, contiguous, CHANNELS-LAST: activations [N, H, W, C]; a 1-channel image
+ *    [N,1,H,W] is bit-identical in both layouts.  Weights keep the reference's state_dict layouts.
+ *  - "accumulates" means the kernel ADDS into the buffer (caller zeroes it: Trainer.zero_grad()).
+ */
+#ifndef ARVAE_HIP_H
+#define ARVAE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ARVAE_ABI_VERSION 1
+
+#define ARVAE_OK 0
+#define ARVAE_E_INVALID (-1)  /* bad argument (null pointer, size out of range, unsupported shape) */
+#define ARVAE_E_LAUNCH (-2)   /* hipLaunch / runtime error; text in arvae_last_error_string()        */
+#define ARVAE_E_NODEVICE (-3) /* no HIP device visible to this process                              */
+
+/* activation fused into a producing kernel / differentiated in a consuming one */
+#define ARVAE_ACT_NONE 0
+#define ARVAE_ACT_RELU 1 /* nn.ReLU  (imagevae/dsprites_vae.py:13-46)                              */
+#define ARVAE_ACT_SELU 2 /* nn.SELU  (imagevae/mnist_vae.py:17-45, measurevae/encoder.py:39-51)    */
+
+#define ARVAE_RECON_BERNOULLI 0
+#define ARVAE_RECON_GAUSSIAN 1
+
+typedef void *arvae_stream_t;
+
+int arvae_abi_version(void);
+const char *arvae_last_error_string(void);
+/* number of HIP devices visible (0 on a CPU-only host; never initialises a context) */
+int arvae_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Strided "link" between a HI-resolution tensor hi[N,HH,HW,CHI] and a LO-resolution tensor
+ * lo[N,LH,LW,CLO] through a weight wt[CLO][CHI][KH][KW]:
+ *     lo(n,ly,lx,clo) <-> hi(n, ly*stride - pad + ky, lx*stride - pad + kx, chi)
+ * One link serves six roles of the reference's layers:
+ *   nn.Conv2d            (weight [Cout,Cin,KH,KW]: CLO=Cout, CHI=Cin)   forward = DOWN, dgrad = UP
+ *   nn.ConvTranspose2d   (weight [Cin,Cout,KH,KW]: CLO=Cin,  CHI=Cout)  forward = UP,   dgrad = DOWN
+ *   nn.Linear            (weight [out,in]: KH=KW=HH=HW=LH=LW=1, CLO=out, CHI=in) forward = DOWN
+ * and the weight gradient of all three = WGRAD.
+ * Replaces: imagevae/dsprites_vae.py:12-46, imagevae/mnist_vae.py:16-47 (layers) as executed by
+ * imagevae/mnist_vae.py:59-72 (encode/decode) and their autograd backward (utils/trainer.py:140).
+ *
+ * hi_perm_c/hi_perm_hw (and lo_*): when >0 the channel index of that tensor is a FLATTENED NCHW
+ * feature index f = c*hw + p of a [C=perm_c, HW=perm_hw] map that is stored channels-last, i.e. it
+ * lives at memory channel p*perm_c + c.  This is how `hidden.view(B,-1)` (mnist_vae.py:61) and
+ * `.view(B,-1,inter,inter)` (mnist_vae.py:70) are honoured without a transpose pass.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t n;
+    int32_t hh, hw, chi;
+    int32_t lh, lw, clo;
+    int32_t kh, kw, stride, pad;
+    int32_t hi_perm_c, hi_perm_hw;
+    int32_t lo_perm_c, lo_perm_hw;
+} arvae_link_t;
+
+/* An operand read by a kernel.  Plain tensor: y = mask = NULL.  Gradient operand: the value used is
+ *   v * act'(y) * (mask ? 2*mask : 1)
+ * where y is the SAVED OUTPUT of the layer that produced the tensor v is the gradient of (act' is
+ * evaluated from the output: ReLU y>0; SELU y>0 ? scale : y + scale*alpha; with dropout the saved
+ * output is act(.)*2*mask so act' is taken at y/2) and mask the uint8 keep-mask of nn.Dropout(0.5). */
+typedef struct {
+    const float *v;
+    const float *y;
+    const uint8_t *mask;
+    int32_t act;
+} arvae_operand_t;
+
+/* lo = epilogue( sum_{ky,kx,chi} hi * wt + bias[clo] );  epilogue = act, then *2*out_mask if given.
+ * bias may be NULL. */
+int arvae_link_down(const arvae_link_t *link, const arvae_operand_t *hi, const float *wt,
+                    const float *bias, int32_t out_act, const uint8_t *out_mask, float *lo,
+                    arvae_stream_t stream);
+
+/* hi = epilogue( sum_{ky,kx,clo} lo * wt + bias[chi] ), the adjoint map of arvae_link_down. */
+int arvae_link_up(const arvae_link_t *link, const arvae_operand_t *lo, const float *wt,
+                  const float *bias, int32_t out_act, const uint8_t *out_mask, float *hi,
+                  arvae_stream_t stream);
+
+/* dwt[clo][chi][ky][kx] += sum_{n,ly,lx} lo * hi   (accumulates; fp32 atomics across the batch split) */
+int arvae_link_wgrad(const arvae_link_t *link, const arvae_operand_t *lo, const arvae_operand_t *hi,
+                     float *dwt, arvae_stream_t stream);
+
+/* out[c] += sum_rows operand[row, c]  for a [rows, channels] channels-last view (bias gradients).
+ * perm_c/perm_hw as in arvae_link_t (out is indexed by the flattened NCHW feature). */
+int arvae_channel_sum(const arvae_operand_t *g, int64_t rows, int32_t channels, int32_t perm_c,
+                      int32_t perm_hw, float *out, arvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Latent head.  Replaces z_dist = Normal(mu, exp(log_std)); z = z_dist.rsample()
+ * (imagevae/mnist_vae.py:65,74-87; measurevae/encoder.py:123, measure_vae.py:115-123) with the noise
+ * eps as an explicit input:  sigma = exp(log_std),  z = mu + eps * sigma.
+ * ------------------------------------------------------------------------------------------------ */
+int arvae_latent_fwd(const float *mu, const float *log_std, const float *eps, int64_t count,
+                     float *sigma, float *z, arvae_stream_t stream);
+/* d_mu += ... is NOT accumulated: d_mu = g_z, d_log_std = (g_z*eps + g_sigma)*sigma (g_sigma may be NULL) */
+int arvae_latent_bwd(const float *g_z, const float *g_sigma, const float *eps, const float *sigma,
+                     int64_t count, float *d_mu, float *d_log_std, arvae_stream_t stream);
+
+/* beta-KL term.  Replaces Trainer.compute_kld_loss (utils/trainer.py:354-367):
+ *   kl = mean_b sum_z 0.5*((s/s0)^2 + ((mu-m0)/s0)^2 - 1 - log((s/s0)^2));  out[0] = beta*|kl - c|,
+ *   out[1] = kl.  prior_mu/prior_sigma NULL = standard normal.  `capacity` is a 1-element device
+ *   tensor (the reference keeps c as a tensor: image_vae_trainer.py:94) or NULL for c = 0.
+ * bwd: d_mu, d_sigma = g[0] * d out[0] / d(mu, sigma)  (g is a 1-element device tensor). */
+int arvae_kld_fwd(const float *mu, const float *sigma, const float *prior_mu, const float *prior_sigma,
+                  int64_t batch, int64_t zdim, float beta, const float *capacity, float *out,
+                  arvae_stream_t stream);
+int arvae_kld_bwd(const float *g, const float *mu, const float *sigma, const float *prior_mu,
+                  const float *prior_sigma, int64_t batch, int64_t zdim, float beta, const float *kl_out,
+                  const float *capacity, float *d_mu, float *d_sigma, arvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Attribute-regularisation loss over all pairs.  Replaces the per-dimension Python loop
+ * (imagevae/image_vae_trainer.py:171-180, measurevae/measure_vae_trainer.py:135-139) over
+ * Trainer.compute_reg_loss / reg_loss_sign (utils/trainer.py:369-403), all R dims in one launch:
+ *   loss = sum_r gamma/NC^2 * sum_{i in rows, j in cols} | tanh(delta*(z_i - z_j)) - sign(a_i - a_j) |
+ *   dz[i, dims[r]] = 2*gamma*delta/NC^2 * sum_j (1 - t_ij^2) * sgn(t_ij - s_ij)      (other columns 0)
+ * Rows are this rank's samples, cols the (all-gathered) global batch; single GPU: cols == rows.
+ * dims: HOST array of R latent/label column indices (z[:,d] pairs with labels[:,d]).
+ * ws: device scratch of arvae_reg_loss_ws_floats(n_rows, R) floats.  loss_out: 1 float.
+ * dz: [n_rows, ldz] fully written (gradient for unit upstream gradient), may be NULL.
+ * ------------------------------------------------------------------------------------------------ */
+int64_t arvae_reg_loss_ws_floats(int64_t n_rows, int32_t r);
+int arvae_reg_loss(const float *z_rows, const float *lab_rows, int64_t n_rows, const float *z_cols,
+                   const float *lab_cols, int64_t n_cols, int64_t ldz, int64_t ldl, const int32_t *dims,
+                   int32_t r, float gamma, float delta, float *ws, float *loss_out, float *dz,
+                   arvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Reconstruction terms.
+ * Image: replaces ImageVAETrainer.reconstruction_loss + mean_accuracy
+ * (imagevae/image_vae_trainer.py:623-655).  out[0] = sum_all(term)/batch, out[1] = pixel accuracy.
+ * dlogits (optional) = d out[0] / d logits.  ws: arvae_recon_ws_floats(count) floats.
+ * ------------------------------------------------------------------------------------------------ */
+int64_t arvae_recon_ws_floats(int64_t count);
+int arvae_image_recon(const float *logits, const float *x, int64_t count, int64_t batch, int32_t dist,
+                      float *ws, float *out, float *dlogits, arvae_stream_t stream);
+
+/* Measure: replaces Trainer.mean_crossentropy_loss + Trainer.mean_accuracy
+ * (utils/trainer.py:247-282) on [rows, V] ReLU-ed logits and int64 targets.
+ * out[0] = mean CE, out[1] = top-1 accuracy (lowest index on ties).  dweights optional. */
+int arvae_token_recon(const float *weights, const int64_t *targets, int64_t rows, int32_t vocab,
+                      float *ws, float *out, float *dweights, arvae_stream_t stream);
+
+/* y[i] = g[0] * x[i]   (chain rule through a scalar loss term) */
+int arvae_scale_by_scalar(const float *g, const float *x, int64_t count, float *y, arvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Adam over one flat fp32 arena.  Replaces torch.optim.Adam(...).step() (utils/trainer.py:31-34,
+ * 170-174) with defaults beta1=.9 beta2=.999 eps=1e-8, no weight decay, no amsgrad:
+ *   m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;  p -= (lr/(1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ * `step` is the 1-based step number t.  grad_scale multiplies g first (1/world_size after a SUM
+ * all-reduce; 1 otherwise).
+ * ------------------------------------------------------------------------------------------------ */
+int arvae_adam_step(float *p, const float *g, float *m, float *v, int64_t count, int64_t step, float lr,
+                    float beta1, float beta2, float eps, float grad_scale, arvae_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARVAE_HIP_H */

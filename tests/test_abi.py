@@ -1,0 +1,92 @@
+"""C-ABI surface checks that run without a GPU: the library builds/loads, exports every symbol the header
+declares, and the product refuses to compute on the CPU (no fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from arvae_amd import _lib, build
+    build.build_library(verbose=False)
+    return _lib.load()
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, 'include', 'arvae_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(arvae_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from arvae_amd import _lib
+    names = header_functions()
+    assert len(names) >= 18
+    for name in names:
+        assert hasattr(lib, name), f'{name} declared in arvae_hip.h but not exported'
+        assert name in _lib.SIGNATURES, f'{name} has no ctypes signature'
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_abi_version_and_error_string(lib):
+    from arvae_amd import _lib
+    assert lib.arvae_abi_version() == _lib.ABI_VERSION
+    assert isinstance(lib.arvae_last_error_string(), bytes)
+
+
+def test_argument_validation_without_gpu(lib):
+    """bad arguments are rejected before any launch (pure host code)."""
+    from arvae_amd._lib import LinkDesc, OperandDesc
+    rc = lib.arvae_link_down(None, None, None, None, 0, None, None, None)
+    assert rc == -1 and b'null' in lib.arvae_last_error_string()
+    d = LinkDesc(1, 8, 8, 4, 5, 5, 4, 4, 4, 2, 1, 0, 0, 0, 0)       # lo extent should be 4x4
+    op = OperandDesc(ctypes.c_void_p(16), None, None, 0)
+    rc = lib.arvae_link_down(ctypes.byref(d), ctypes.byref(op), ctypes.c_void_p(16), None, 0, None,
+                             ctypes.c_void_p(16), None)
+    assert rc == -1 and b'does not match' in lib.arvae_last_error_string()
+    assert lib.arvae_reg_loss_ws_floats(512, 5) == 2 * 512 * 5
+    assert lib.arvae_adam_step(None, None, None, None, 0, 0, 1e-4, 0.9, 0.999, 1e-8, 1.0, None) == -1
+
+
+def test_cpu_tensors_are_refused():
+    from arvae_amd import ops
+    z = torch.randn(8, 4)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        ops.reg_loss(z, torch.randn(8, 4), (1,), 1.0, 1.0)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        ops.latent_head(z, z, z)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from arvae_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(RuntimeError, match='no CPU'):
+        _lib.load()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'ar-vae_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f'{f} imports the oracle'
+
+
+def test_state_dict_keys_match_reference_layout():
+    """same keys, order and shapes as the reference modules (recorded in oracle.image_vae.*_SHAPES)."""
+    from arvae_amd.image_vae import DspritesVAE, MnistVAE
+    from oracle import image_vae as o
+    for cls, shapes, nparam in ((DspritesVAE, o.DSPRITES_SHAPES, 502005), (MnistVAE, o.MNIST_SHAPES, 1644145)):
+        m = cls()
+        sd = m.state_dict()
+        assert list(sd.keys()) == list(shapes.keys())
+        assert all(tuple(sd[k].shape) == tuple(v) for k, v in shapes.items())
+        assert sum(p.numel() for p in m.parameters()) == nparam
+        assert [k for k, _ in m.named_parameters()] == list(shapes.keys())

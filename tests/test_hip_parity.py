@@ -1,0 +1,425 @@
+"""Parity of the HIP path (through the C-ABI) against the CPU oracle and the reference goldens.
+Needs a real MI355X: run with `pytest -m gpu`."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from arvae_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+from oracle import image_vae as o_vae          # noqa: E402
+from oracle import losses as o_losses          # noqa: E402
+from oracle import step as o_step              # noqa: E402
+
+
+@pytest.fixture(scope='module')
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail('gpu-marked test needs a GPU (the HIP path has no CPU fallback)')
+    return torch.device('cuda:0')
+
+
+def G(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def close(a, b, rtol=1e-4, atol=0.0):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else a
+    b = b.detach().cpu().numpy() if torch.is_tensor(b) else b
+    np.testing.assert_allclose(np.asarray(a, np.float64), np.asarray(b, np.float64), rtol=rtol, atol=atol)
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+# ---------------------------------------------------------------- reg loss (G1)
+@pytest.mark.parametrize('n', [7, 64, 512])
+def test_reg_loss_golden(golden_dir, dev, n):
+    from arvae_amd import ops
+    g = G(golden_dir, 'reg_loss.npz')
+    x = g[f'n{n}/x']
+    for tag in ('cont', 'ties'):
+        a = g[f'n{n}/a_{tag}']
+        for delta in (1.0, 10.0):
+            for gamma in (1.0, 10.0):
+                key = f'n{n}_{tag}_d{delta:g}_g{gamma:g}'
+                z = torch.from_numpy(np.stack([x * 0, x], 1)).to(dev).requires_grad_(True)
+                lab = torch.from_numpy(np.stack([a * 0, a], 1)).to(dev)
+                loss = ops.reg_loss(z, lab, (1,), gamma, delta)
+                loss.backward()
+                close(loss, g[f'{key}/loss'], rtol=1e-5)
+                close(z.grad[:, 1], g[f'{key}/grad'], rtol=1e-4, atol=3e-7 * gamma * delta)
+                assert float(z.grad[:, 0].abs().max()) == 0.0
+
+
+def test_reg_loss_multi_dim_and_row_block(dev):
+    """all dims in one launch == sum of closed forms; row-block (data-parallel) form == global."""
+    from arvae_amd import ops
+    rs = np.random.RandomState(3)
+    n, zd = 200, 10
+    z = rs.standard_normal((n, zd)).astype(np.float32)
+    lab = rs.randint(0, 4, (n, 6)).astype(np.float32)
+    dims = (1, 2, 3, 4, 5)
+    want_l, want_g = 0.0, np.zeros((n, zd))
+    for d in dims:
+        l, gr = o_losses.reg_loss_closed_form(z[:, d], lab[:, d], 10.0, 1.0)
+        want_l += l
+        want_g[:, d] = gr
+    zt = torch.from_numpy(z).to(dev).requires_grad_(True)
+    lt = torch.from_numpy(lab).to(dev)
+    loss = ops.reg_loss(zt, lt, dims, 10.0, 1.0)
+    (3.0 * loss).backward()
+    close(loss, want_l, rtol=1e-5)
+    close(zt.grad, 3.0 * want_g, rtol=1e-4, atol=1e-6)
+    # two shards, gathered columns
+    parts, grads = [], []
+    for sl in (slice(0, 120), slice(120, 200)):
+        zs = torch.from_numpy(z[sl]).to(dev).requires_grad_(True)
+        ls = torch.from_numpy(lab[sl]).to(dev)
+        part = ops.reg_loss(zs, ls, dims, 10.0, 1.0, z_cols=zt.detach(), lab_cols=lt)
+        part.backward()
+        parts.append(float(part))
+        grads.append(zs.grad.cpu().numpy())
+    close(sum(parts), want_l, rtol=1e-5)
+    close(np.concatenate(grads), want_g, rtol=1e-4, atol=1e-6)
+
+
+def test_reg_loss_large_batch(dev):
+    """global batch 4096 (8 x 512): more columns than one LDS chunk."""
+    from arvae_amd import ops
+    rs = np.random.RandomState(4)
+    n = 4096
+    z = rs.standard_normal((n, 10)).astype(np.float32)
+    lab = rs.randint(0, 32, (n, 6)).astype(np.float32)
+    want_l, want_g = o_losses.reg_loss_closed_form(z[:, 4], lab[:, 4], 10.0, 1.0)
+    zt = torch.from_numpy(z).to(dev).requires_grad_(True)
+    loss = ops.reg_loss(zt, torch.from_numpy(lab).to(dev), (4,), 10.0, 1.0)
+    loss.backward()
+    close(loss, want_l, rtol=2e-5)
+    close(zt.grad[:, 4], want_g, rtol=1e-3, atol=1e-7)
+
+
+# ---------------------------------------------------------------- latent head / KL (G2)
+@pytest.mark.parametrize('b,z', [(8, 10), (64, 10), (32, 32)])
+def test_latent_head_golden(golden_dir, dev, b, z):
+    from arvae_amd import ops
+    g = G(golden_dir, 'latent_head.npz')
+    mu, ls, eps = (g[f'b{b}_z{z}/{k}'] for k in ('mu', 'log_std', 'eps'))
+    w = torch.from_numpy(syn.normal_noise((b, z), seed=99)).to(dev)
+    for c in (0.0, 25.0):
+        for beta in (4.0, 0.001):
+            key = f'b{b}_z{z}_c{c:g}_beta{beta:g}'
+            mt = torch.from_numpy(mu).to(dev).requires_grad_(True)
+            lt = torch.from_numpy(ls).to(dev).requires_grad_(True)
+            sigma, zt = ops.latent_head(mt, lt, torch.from_numpy(eps).to(dev))
+            kld = ops.kld_loss(mt, sigma, beta, torch.tensor([c], device=dev))
+            (kld.sum() + (zt * w).sum()).backward()
+            close(zt, g[f'b{b}_z{z}/z'], rtol=0, atol=1e-5)
+            close(sigma, g[f'b{b}_z{z}/sigma'], rtol=1e-5)
+            close(kld, g[f'{key}/kld'], rtol=1e-5)
+            close(mt.grad, g[f'{key}/dmu'], rtol=1e-4, atol=1e-6)
+            close(lt.grad, g[f'{key}/dls'], rtol=1e-4, atol=1e-6)
+
+
+# ---------------------------------------------------------------- reconstruction terms (G3)
+@pytest.mark.parametrize('b,hw', [(4, 64), (16, 28)])
+def test_image_recon_golden(golden_dir, dev, b, hw):
+    from arvae_amd import ops
+    g = G(golden_dir, 'recon.npz')
+    rs = np.random.RandomState(b * hw)
+    logits = (3.0 * rs.standard_normal((b, 1, hw, hw))).astype(np.float32)
+    logits.ravel()[::97] = 0.0
+    x = (rs.random_sample((b, 1, hw, hw)) < 0.2).astype(np.float32)
+    if hw == 28:
+        x = (x * rs.random_sample(x.shape)).astype(np.float32)
+    for dist in ('bernoulli', 'gaussian'):
+        lt = torch.from_numpy(logits).to(dev).requires_grad_(True)
+        loss, acc = ops.image_recon(lt, torch.from_numpy(x).to(dev), dist)
+        loss.backward()
+        close(loss, g[f'b{b}_{hw}_{dist}/loss'], rtol=1e-5)
+        close(lt.grad.cpu().numpy().ravel()[::131], g[f'b{b}_{hw}_{dist}/dlogits_samp'], rtol=1e-4, atol=1e-7)
+        close(lt.grad.double().abs().sum(), g[f'b{b}_{hw}_{dist}/dlogits_abs_sum'], rtol=1e-5)
+        close(acc, g[f'b{b}_{hw}/acc'], rtol=1e-6)
+
+
+@pytest.mark.parametrize('b', [5, 32])
+def test_token_recon_golden(golden_dir, dev, b):
+    from arvae_amd import ops
+    g = G(golden_dir, 'recon.npz')
+    w = torch.from_numpy(g[f'ce_b{b}/w']).to(dev).requires_grad_(True)
+    tgt = torch.from_numpy(g[f'ce_b{b}/tgt']).to(dev)
+    ce, acc = ops.token_recon(w, tgt)
+    ce.backward()
+    close(ce, g[f'ce_b{b}/loss'], rtol=1e-5)
+    close(acc, g[f'ce_b{b}/acc'], rtol=1e-6)
+    close(w.grad.cpu().numpy().ravel()[::37], g[f'ce_b{b}/dw_samp'], rtol=1e-4, atol=1e-8)
+
+
+# ---------------------------------------------------------------- links vs torch fp32 on CPU
+CONV_CASES = [  # (n, hi, chi, clo, k, s, p, act)
+    (3, 64, 1, 32, 4, 2, 1, 'relu'), (5, 32, 32, 32, 4, 2, 1, 'relu'), (9, 8, 32, 32, 4, 2, 1, 'relu'),
+    (2, 28, 1, 64, 4, 1, 0, 'selu'), (2, 25, 64, 64, 4, 1, 0, 'selu'), (3, 22, 64, 8, 4, 1, 0, 'selu'),
+]
+
+
+def _act(name):
+    return {'relu': F.relu, 'selu': F.selu, 'none': lambda t: t}[name]
+
+
+def _act_id(name):
+    return {'none': 0, 'relu': 1, 'selu': 2}[name]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=[str(c) for c in CONV_CASES])
+@pytest.mark.parametrize('use_mask', [False, True])
+def test_conv_down_vs_torch(dev, case, use_mask):
+    """nn.Conv2d forward + all three gradients."""
+    from arvae_amd import ops
+    n, hi, chi, clo, k, s, p, act = case
+    lo = (hi + 2 * p - k) // s + 1
+    rs = np.random.RandomState(hi * chi + clo)
+    x = rs.standard_normal((n, chi, hi, hi)).astype(np.float32)
+    w = (rs.standard_normal((clo, chi, k, k)) * 0.2).astype(np.float32)
+    b = rs.standard_normal(clo).astype(np.float32)
+    gy = rs.standard_normal((n, clo, lo, lo)).astype(np.float32)
+    mask = (rs.random_sample((n, clo, lo, lo)) >= 0.5).astype(np.uint8) if use_mask else None
+    xt, wt, bt = (torch.from_numpy(a).requires_grad_(True) for a in (x, w, b))
+    y = _act(act)(F.conv2d(xt, wt, bt, stride=s, padding=p))
+    if use_mask:
+        y = y * torch.from_numpy(mask).float() * 2.0
+    y.backward(torch.from_numpy(gy))
+    link = ops.Link(hi, hi, chi, lo, lo, clo, k, k, s, p)
+    xd = nhwc(torch.from_numpy(x)).to(dev).requires_grad_(True)
+    wd, bd = (torch.from_numpy(a).to(dev).requires_grad_(True) for a in (w, b))
+    md = None if mask is None else nhwc(torch.from_numpy(mask)).to(dev)
+    yd = ops.conv_down(xd, wd, bd, link, _act_id(act), md)
+    yd.backward(nhwc(torch.from_numpy(gy)).to(dev))
+    tol = dict(rtol=2e-4, atol=2e-4)
+    close(nchw(yd), y, **tol)
+    close(nchw(xd.grad), xt.grad, **tol)
+    close(wd.grad, wt.grad, rtol=2e-4, atol=2e-4 * float(wt.grad.abs().max()))
+    close(bd.grad, bt.grad, rtol=2e-4, atol=2e-4 * float(bt.grad.abs().max()))
+
+
+DECONV_CASES = [  # (n, lo, clo(in), chi(out), k, s, p, act)
+    (4, 4, 32, 32, 4, 2, 1, 'relu'), (3, 16, 32, 32, 4, 2, 1, 'relu'), (2, 32, 32, 1, 4, 2, 1, 'none'),
+    (2, 19, 8, 64, 4, 1, 0, 'selu'), (2, 22, 64, 64, 4, 1, 0, 'selu'), (3, 25, 64, 1, 4, 1, 0, 'none'),
+]
+
+
+@pytest.mark.parametrize('case', DECONV_CASES, ids=[str(c) for c in DECONV_CASES])
+@pytest.mark.parametrize('use_mask', [False, True])
+def test_conv_up_vs_torch(dev, case, use_mask):
+    """nn.ConvTranspose2d forward + all three gradients."""
+    from arvae_amd import ops
+    n, lo, clo, chi, k, s, p, act = case
+    hi = (lo - 1) * s - 2 * p + k
+    rs = np.random.RandomState(lo * clo + chi)
+    x = rs.standard_normal((n, clo, lo, lo)).astype(np.float32)
+    w = (rs.standard_normal((clo, chi, k, k)) * 0.2).astype(np.float32)
+    b = rs.standard_normal(chi).astype(np.float32)
+    gy = rs.standard_normal((n, chi, hi, hi)).astype(np.float32)
+    mask = (rs.random_sample((n, chi, hi, hi)) >= 0.5).astype(np.uint8) if use_mask else None
+    xt, wt, bt = (torch.from_numpy(a).requires_grad_(True) for a in (x, w, b))
+    y = _act(act)(F.conv_transpose2d(xt, wt, bt, stride=s, padding=p))
+    if use_mask:
+        y = y * torch.from_numpy(mask).float() * 2.0
+    y.backward(torch.from_numpy(gy))
+    link = ops.Link(hi, hi, chi, lo, lo, clo, k, k, s, p)
+    xd = nhwc(torch.from_numpy(x)).to(dev).requires_grad_(True)
+    wd, bd = (torch.from_numpy(a).to(dev).requires_grad_(True) for a in (w, b))
+    md = None if mask is None else nhwc(torch.from_numpy(mask)).to(dev)
+    yd = ops.conv_up(xd, wd, bd, link, _act_id(act), md)
+    yd.backward(nhwc(torch.from_numpy(gy)).to(dev))
+    tol = dict(rtol=2e-4, atol=2e-4)
+    close(nchw(yd), y, **tol)
+    close(nchw(xd.grad), xt.grad, **tol)
+    close(wd.grad, wt.grad, rtol=2e-4, atol=2e-4 * float(wt.grad.abs().max()))
+    close(bd.grad, bt.grad, rtol=2e-4, atol=2e-4 * float(bt.grad.abs().max()))
+
+
+DENSE_CASES = [(8, 512, 256, (32, 16), (0, 0)), (64, 256, 512, (0, 0), (32, 16)), (5, 2888, 256, (8, 361), (0, 0)),
+               (7, 256, 2888, (0, 0), (8, 361)), (33, 10, 256, (0, 0), (0, 0)), (512, 256, 10, (0, 0), (0, 0))]
+
+
+@pytest.mark.parametrize('case', DENSE_CASES, ids=[str(c) for c in DENSE_CASES])
+def test_dense_vs_torch(dev, case):
+    """nn.Linear with the NCHW-flatten channel permutation on either side."""
+    from arvae_amd import ops
+    n, fin, fout, in_perm, out_perm = case
+    rs = np.random.RandomState(fin + fout)
+    x = rs.standard_normal((n, fin)).astype(np.float32)          # feature order = NCHW flatten
+    w = (rs.standard_normal((fout, fin)) * 0.1).astype(np.float32)
+    b = rs.standard_normal(fout).astype(np.float32)
+    gy = rs.standard_normal((n, fout)).astype(np.float32)
+    xt, wt, bt = (torch.from_numpy(a).requires_grad_(True) for a in (x, w, b))
+    y = F.relu(F.linear(xt, wt, bt))
+    y.backward(torch.from_numpy(gy))
+
+    def to_mem(t, perm):          # NCHW-flatten feature order -> channels-last memory order
+        if perm == (0, 0):
+            return t.contiguous()
+        c, hw = perm
+        return t.reshape(t.shape[0], c, hw).permute(0, 2, 1).reshape(t.shape[0], -1).contiguous()
+
+    def from_mem(t, perm):
+        if perm == (0, 0):
+            return t
+        c, hw = perm
+        return t.reshape(t.shape[0], hw, c).permute(0, 2, 1).reshape(t.shape[0], -1)
+
+    link = ops.Link.dense(fin, fout, in_perm=in_perm, out_perm=out_perm)
+    xd = to_mem(torch.from_numpy(x), in_perm).to(dev).requires_grad_(True)
+    wd, bd = (torch.from_numpy(a).to(dev).requires_grad_(True) for a in (w, b))
+    yd = ops.dense(xd, wd, bd, link, 1)
+    yd.backward(to_mem(torch.from_numpy(gy), out_perm).to(dev))
+    close(from_mem(yd.detach().cpu(), out_perm), y, rtol=2e-4, atol=2e-4)
+    close(from_mem(xd.grad.cpu(), in_perm), xt.grad, rtol=2e-4, atol=2e-4)
+    close(wd.grad, wt.grad, rtol=2e-4, atol=2e-4 * float(wt.grad.abs().max()))
+    close(bd.grad, bt.grad, rtol=2e-4, atol=2e-4 * float(bt.grad.abs().max()))
+
+
+# ---------------------------------------------------------------- Adam
+def test_adam_vs_oracle(dev):
+    from arvae_amd import ops
+    rs = np.random.RandomState(8)
+    n = 10007
+    p = rs.standard_normal(n).astype(np.float32)
+    m = np.zeros(n, np.float32)
+    v = np.zeros(n, np.float32)
+    pad = (n + 3) // 4 * 4
+    pd, md, vd, gd = (torch.zeros(pad, device=dev) for _ in range(4))
+    pd[:n] = torch.from_numpy(p).to(dev)
+    for step in range(1, 4):
+        g = (rs.standard_normal(n) * 10 ** rs.uniform(-3, 1)).astype(np.float32)
+        p, m, v = o_losses.adam_step(p, g, m, v, step, lr=1e-3)
+        gd[:n] = torch.from_numpy(g).to(dev)
+        ops.adam_step(pd, gd, md, vd, step, 1e-3)
+        close(pd[:n], p, rtol=1e-5, atol=1e-7)
+        close(md[:n], m, rtol=1e-5, atol=1e-9)
+        close(vd[:n], v, rtol=1e-5, atol=1e-12)
+
+
+# ---------------------------------------------------------------- full steps (G4 / G5)
+class DspritesDataset:
+    pass
+
+
+class MorphoMnistDataset:
+    pass
+
+
+IMAGE_CASES = [
+    ('dsprites_step_b8.npz', 'dsprites', 8, 1, 1234, 11, 4.0, 0.0, 'bernoulli', None, 1.6),
+    ('dsprites_step_b64.npz', 'dsprites', 64, 1, 1234, 12, 4.0, 0.0, 'bernoulli', None, 1.6),
+    ('dsprites_step_b8_cap_gauss.npz', 'dsprites', 8, 2, 77, 13, 1.0, 25.0, 'gaussian', None, 1.6),
+    ('mnist_step_eval.npz', 'mnist', 8, 3, 4321, 14, 1.0, 0.0, 'bernoulli', None, 0.7),
+    ('mnist_step_train.npz', 'mnist', 8, 3, 4321, 15, 1.0, 0.0, 'bernoulli', 21, 0.7),
+]
+
+
+def run_hip_image_step(dev, kind, state, x, lab, eps, beta, cap, dist, masks, train=True, steps=1):
+    from arvae_amd.image_vae import DspritesVAE, MnistVAE
+    from arvae_amd.image_vae_trainer import ImageVAETrainer
+    model = DspritesVAE() if kind == 'dsprites' else MnistVAE()
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    dims = (1, 2, 3, 4, 5) if kind == 'dsprites' else (1, 2, 3, 4, 5, 6)
+    ds = DspritesDataset() if kind == 'dsprites' else MorphoMnistDataset()
+    trainer = ImageVAETrainer(ds, model, lr=1e-4, reg_type=('all',), reg_dim=dims, dec_dist=dist, beta=beta,
+                              gamma=10.0, capacity=cap, rand=0, delta=1.0)
+    trainer.cuda()
+    model.train() if train else model.eval()
+    xt, lt = torch.from_numpy(x).to(dev), torch.from_numpy(lab).to(dev)
+    out = None
+    for _ in range(steps):
+        model.push_noise(torch.from_numpy(eps))
+        if masks is not None:
+            model.push_dropout_masks([nhwc(torch.from_numpy(m)) for m in masks])
+        trainer.zero_grad()
+        loss, acc = trainer.loss_and_acc_for_batch((xt, lt), 0, 0, train)
+        loss.backward()
+        grads = {k: p.grad.detach().cpu().numpy().copy() for k, p in model.named_parameters()}
+        trainer.step()
+        out = dict(loss=float(loss), acc=float(acc), grads=grads,
+                   terms={k: (None if v is None else float(v)) for k, v in trainer.last_terms.items()})
+    out['params'] = {k: p.detach().cpu().numpy().copy() for k, p in model.named_parameters()}
+    out['model'], out['trainer'] = model, trainer
+    return out
+
+
+@pytest.mark.parametrize('case', IMAGE_CASES, ids=[c[0][:-4] for c in IMAGE_CASES])
+def test_image_step_vs_golden_and_oracle(golden_dir, dev, case):
+    fname, kind, b, wseed, xseed, eseed, beta, cap, dist, mseed, gain = case
+    g = G(golden_dir, fname)
+    state = syn.synth_state(o_vae.SHAPES[kind], wseed, gain)
+    x, lab = (syn.dsprites_batch if kind == 'dsprites' else syn.mnist_batch)(b, seed=xseed)
+    eps = syn.normal_noise((b, o_vae.Z_DIM[kind]), seed=eseed)
+    dims = (1, 2, 3, 4, 5) if kind == 'dsprites' else (1, 2, 3, 4, 5, 6)
+    masks = None if mseed is None else syn.dropout_masks([(b,) + s for s in o_vae.MNIST_MASK_SHAPES], mseed)
+    train = not fname.endswith('eval.npz')
+    got = run_hip_image_step(dev, kind, state, x, lab, eps, beta, cap, dist, masks, train=train)
+    ref = o_step.image_step(kind, state, x, lab, eps, dims, beta, 10.0, 1.0, capacity=cap, dec_dist=dist, masks=masks)
+    # loss terms: north_star tolerance rtol 1e-4 (fp32), against the reference golden AND the oracle
+    for src in (g, ref['terms']):
+        close(got['terms']['recons'], float(src['recons']), rtol=1e-4)
+        close(got['terms']['dist'], float(src['dist']), rtol=1e-4)
+        close(got['terms']['reg'], float(src['reg']), rtol=1e-4)
+        close(got['loss'], float(src['loss']), rtol=1e-4)
+        close(got['acc'], float(src['acc']), rtol=1e-4)
+    # gradients: per-tensor norm rtol 1e-3, sampled entries, Adam deltas
+    for name in state:
+        gr = got['grads'][name].astype(np.float64).ravel()
+        gn = float(g[f'gnorm/{name}'])
+        close(np.sqrt((gr * gr).sum()), gn, rtol=1e-3)
+        idx = syn.sample_indices(name, gr.size)
+        close(gr[idx], g[f'gsamp/{name}'], rtol=1e-3, atol=1e-3 * gn / np.sqrt(gr.size) + 1e-7)
+        close(gr, ref['grads'][name].ravel(), rtol=1e-3, atol=1e-3 * gn / np.sqrt(gr.size) + 1e-7)
+        d = (got['params'][name].astype(np.float64) - state[name].astype(np.float64)).ravel()
+        close(np.sqrt((d * d).sum()), g[f'dnorm/{name}'], rtol=2e-3)
+
+
+def test_image_forward_latents_vs_golden(golden_dir, dev):
+    """z, mu, sigma atol 1e-4 and logits against the goldens (dSprites B=64)."""
+    from arvae_amd.image_vae import DspritesVAE
+    g = G(golden_dir, 'dsprites_step_b64.npz')
+    state = syn.synth_state(o_vae.DSPRITES_SHAPES, 1, 1.6)
+    x, _ = syn.dsprites_batch(64, seed=1234)
+    model = DspritesVAE()
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    model.cuda().train()
+    model.push_noise(torch.from_numpy(syn.normal_noise((64, 10), seed=12)))
+    with torch.no_grad():
+        logits, z_dist, prior, z, z_prior = model(torch.from_numpy(x).to(dev))
+    assert logits.shape == (64, 1, 64, 64) and z.shape == (64, 10) and z_prior.shape == (64, 10)
+    close(z, g['z'], rtol=0, atol=1e-4)
+    close(z_dist.loc, g['mu'], rtol=0, atol=1e-4)
+    close(z_dist.scale, g['sigma'], rtol=1e-4, atol=1e-5)
+    lg = logits.cpu().numpy().ravel()
+    close(lg.astype(np.float64).sum(), g['logits_sum'], rtol=1e-4, atol=1e-2)
+    close(lg[syn.sample_indices('logits', lg.size, 64)], g['logits_samp'], rtol=1e-4, atol=1e-4)
+    assert float(prior.loc.abs().max()) == 0.0 and float(prior.scale.min()) == 1.0
+
+
+def test_three_steps_track_oracle(dev):
+    """Adam state carried over several steps stays on the oracle's trajectory."""
+    state = syn.synth_state(o_vae.DSPRITES_SHAPES, 5, 1.6)
+    x, lab = syn.dsprites_batch(16, seed=3)
+    eps = syn.normal_noise((16, 10), seed=4)
+    got = run_hip_image_step(dev, 'dsprites', state, x, lab, eps, 4.0, 0.0, 'bernoulli', None, steps=3)
+    cur, adam = state, None
+    for step_no in (1, 2, 3):
+        ref = o_step.image_step('dsprites', cur, x, lab, eps, (1, 2, 3, 4, 5), 4.0, 10.0, 1.0, adam_state=adam,
+                                step_no=step_no)
+        cur, adam = ref['params'], ref['adam']
+    close(got['loss'], ref['terms']['loss'], rtol=1e-4)
+    for name in state:
+        close(got['params'][name], cur[name], rtol=0, atol=5e-6)
