@@ -12,7 +12,7 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libarvae_hip.so')
 ABI_VERSION = 1
 
-c_i32, c_i64, c_f32, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+c_i32, c_i64, c_f32, c_f64, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
 
 
 class LinkDesc(ctypes.Structure):
@@ -34,8 +34,10 @@ SIGNATURES = {
     'arvae_device_count': (c_i32, []),
     'arvae_link_down': (c_i32, [_P(LinkDesc), _P(OperandDesc), c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     'arvae_link_up': (c_i32, [_P(LinkDesc), _P(OperandDesc), c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
-    'arvae_link_wgrad': (c_i32, [_P(LinkDesc), _P(OperandDesc), _P(OperandDesc), c_vp, c_vp]),
-    'arvae_channel_sum': (c_i32, [_P(OperandDesc), c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    'arvae_link_wgrad_ws_floats': (c_i64, [_P(LinkDesc)]),
+    'arvae_link_wgrad': (c_i32, [_P(LinkDesc), _P(OperandDesc), _P(OperandDesc), c_vp, c_vp, c_vp]),
+    'arvae_channel_sum_ws_floats': (c_i64, [c_i64, c_i32]),
+    'arvae_channel_sum': (c_i32, [_P(OperandDesc), c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     'arvae_latent_fwd': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     'arvae_latent_bwd': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     'arvae_kld_fwd': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_f32, c_vp, c_vp, c_vp]),
@@ -47,7 +49,7 @@ SIGNATURES = {
     'arvae_image_recon': (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
     'arvae_token_recon': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
     'arvae_scale_by_scalar': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp]),
-    'arvae_adam_step': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_vp]),
+    'arvae_adam_step': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_f64, c_f64, c_f64, c_f64, c_f32, c_vp]),
 }
 
 _lock = threading.Lock()
@@ -66,6 +68,11 @@ def load():
             raise RuntimeError(
                 f'{LIB_PATH} is missing: the AR-VAE HIP kernels are not built and there is no CPU '
                 f'fallback. Run `python __graft_entry__.py` (or `python ar-vae_amd/build.py`) first.')
+        # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so, soname libamdhip64.so.7).
+        # It must be the ONE runtime in the process: import torch first so that our NEEDED
+        # libamdhip64.so.7 resolves to the copy torch already loaded.  Loading this library first would
+        # pull in /opt/rocm's runtime as a second instance, which then sees no device.
+        import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)          # AttributeError if the .so does not export it

@@ -5,7 +5,8 @@
 // One kernel template, three index policies:
 //   Down  : lo[m=(n,ly,lx)][clo]  = sum_k hi(gather)[m][k=(ky,kx,chi)] * wt[k][clo]
 //   Up    : hi[m=(n,yy,xx) of one stride-parity class][chi] = sum_k lo(gather)[m][k=(ty,tx,clo)] * wt[k][chi]
-//   Wgrad : dwt[clo][n'=(ky,kx,chi)] += sum_{k=pixel} lo[k][clo] * hi(gather)[k][n']     (split over pixels)
+//   Wgrad : dwt[clo][n'=(ky,kx,chi)] += sum_{k=pixel} lo[k][clo] * hi(gather)[k][n']     (pixels split over
+//           workgroups; partial tiles go to a slab and are summed in a fixed order -- no float atomics)
 // Work decomposition: a workgroup of WM x WN wavefronts (64 lanes each) owns a (32*WM) x (32*WN)
 // output tile; every wave accumulates ONE 32x32 tile in 16 accumulator registers.  Operands are
 // gathered global -> registers (prefetched one K-tile ahead so the loads fly under the MFMAs) ->
@@ -64,7 +65,7 @@ struct OffCtx {
 
 // ------------------------------------------------------------------------------------------------
 struct DownPolicy {
-    static constexpr bool A_CONTIG_K = true, B_CONTIG_K = true, ATOMIC_OUT = false;
+    static constexpr bool A_CONTIG_K = true, B_CONTIG_K = true;
     Geom g;
     Operand hi;
     const float *wt;
@@ -116,7 +117,7 @@ struct DownPolicy {
 
 // ------------------------------------------------------------------------------------------------
 struct UpPolicy {
-    static constexpr bool A_CONTIG_K = true, B_CONTIG_K = true, ATOMIC_OUT = false;
+    static constexpr bool A_CONTIG_K = true, B_CONTIG_K = true;
     Geom g;
     Operand lo;
     const float *wt;
@@ -181,11 +182,12 @@ struct UpPolicy {
 
 // ------------------------------------------------------------------------------------------------
 struct WgradPolicy {
-    static constexpr bool A_CONTIG_K = false, B_CONTIG_K = false, ATOMIC_OUT = true;
+    static constexpr bool A_CONTIG_K = false, B_CONTIG_K = false;
     Geom g;
     Operand lo, hi;
-    float *dwt;
-    int M, N, P, chunk;   // M = clo, N = kh*kw*chi, P = n*lh*lw pixels, chunk = pixels per z-slice
+    float *dwt;     // zsplit == 1: accumulate here directly
+    float *slab;    // zsplit  > 1: partial tiles [z][M][N], summed by wgrad_reduce_kernel in a fixed order
+    int M, N, P, chunk, zsplit;   // M = clo, N = kh*kw*chi, P = n*lh*lw pixels, chunk = pixels per z-slice
 
     __device__ __forceinline__ void slice(int z, int &m, int &n, int &kbeg, int &kend) const {
         m = M; n = N; kbeg = z * chunk; kend = min(P, kbeg + chunk);
@@ -213,17 +215,44 @@ struct WgradPolicy {
         const bool ok = r.ok && k.ok && (unsigned)iy < (unsigned)g.hh && (unsigned)ix < (unsigned)g.hw;
         return ok ? hi.at(k.base + (iy * g.hw + ix) * g.chi + r.coff) : 0.f;
     }
-    __device__ __forceinline__ int out_row(int m, int) const { return m * g.chi * g.kh * g.kw; }
+    __device__ __forceinline__ int out_row(int m, int z) const {
+        return zsplit > 1 ? (z * M + m) * N : m * g.chi * g.kh * g.kw;
+    }
     struct ColC { int off; };
     __device__ __forceinline__ ColC colC(int col, int) const {
+        if (zsplit > 1) return ColC{col};
         uint32_t tap, c;
         g.d_chi.divmod((uint32_t)col, tap, c);
         return ColC{(int)c * g.kh * g.kw + (int)tap};
     }
     __device__ __forceinline__ void store(int rowoff, const ColC &c, float acc) const {
-        atomicAdd(dwt + rowoff + c.off, acc);
+        if (zsplit > 1)
+            slab[rowoff + c.off] = acc;
+        else
+            dwt[rowoff + c.off] += acc;      // one owner per element: no atomics
     }
 };
+
+// dwt[clo][chi][ky][kx] += sum_z slab[z][clo][(ky,kx,chi)]   -- fixed summation order (bitwise reproducible)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ slab, int zsplit, int mn, int n,
+                                                            int khkw, FastDiv d_n, FastDiv d_chi,
+                                                            float *__restrict__ dwt) {
+    __shared__ float red[4][64];
+    const int il = threadIdx.x & 63, zg = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + il;
+    float s = 0.f;
+    if (i < mn)
+        for (int z = zg; z < zsplit; z += 4) s += slab[(int64_t)z * mn + i];
+    red[zg][il] = s;
+    __syncthreads();
+    if (zg == 0 && i < mn) {
+        const float tot = (red[0][il] + red[1][il]) + (red[2][il] + red[3][il]);
+        uint32_t m, col, tap, c;
+        d_n.divmod((uint32_t)i, m, col);
+        d_chi.divmod(col, tap, c);
+        dwt[(int)m * n + (int)c * khkw + (int)tap] += tot;
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 template <int WM, int WN, class P>
@@ -380,32 +409,46 @@ __global__ __launch_bounds__(256) void up_single_channel_kernel(Geom g, const fl
     }
 }
 
-// out[perm(c)] += sum_rows g[row, c]     (bias gradients)
-__global__ __launch_bounds__(256) void channel_sum_kernel(Operand g, int64_t rows, int channels, int perm_c,
-                                                           FastDiv d_perm_hw, int64_t rows_per_block, float *out) {
+// bias gradients: out[feature(c)] += sum_rows g[row, c], two fixed-order stages (no float atomics)
+//   stage 1: each workgroup reduces a row range into partial[block][c]   (channel index fastest: coalesced)
+//   stage 2: one workgroup column-sums the partials the same way and applies the NCHW-flatten permutation
+template <bool FINISH>
+__global__ __launch_bounds__(256) void channel_sum_kernel(Operand g, int64_t rows, int channels,
+                                                           int64_t rows_per_block, int perm_c, int perm_hw,
+                                                           float *__restrict__ dst) {
     __shared__ float red[256];
     const int t = threadIdx.x;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = min(rows, r0 + rows_per_block);
     for (int cbase = 0; cbase < channels; cbase += 256) {
-        // threads tile [rows x min(channels,256)] with the channel index fastest (coalesced)
         const int cw = min(channels - cbase, 256);
         const int rstep = 256 / cw > 0 ? 256 / cw : 1;
         const int c = t % cw, rsub = t / cw;
-        float s = 0.f;
-        if (rsub < rstep)
-            for (int64_t r = r0 + rsub; r < r1; r += rstep) s += g.at(r * channels + cbase + c);
-        red[t] = s;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (rsub < rstep) {
+            int64_t r = r0 + rsub;
+            const int64_t step = rstep;
+            for (; r + 3 * step < r1; r += 4 * step) {       // 4 independent loads in flight per lane
+                s0 += g.at(r * channels + cbase + c);
+                s1 += g.at((r + step) * channels + cbase + c);
+                s2 += g.at((r + 2 * step) * channels + cbase + c);
+                s3 += g.at((r + 3 * step) * channels + cbase + c);
+            }
+            for (; r < r1; r += step) s0 += g.at(r * channels + cbase + c);
+        }
+        red[t] = (s0 + s1) + (s2 + s3);
         __syncthreads();
         if (t < cw) {
             float tot = 0.f;
             for (int j = 0; j < rstep; ++j) tot += red[j * cw + t];
-            int f = cbase + t;   // memory channel -> flattened NCHW feature
-            if (perm_c > 0) {
-                const uint32_t p = (uint32_t)f / (uint32_t)perm_c, cc = (uint32_t)f % (uint32_t)perm_c;
-                f = (int)(cc * d_perm_hw.d + p);
+            const int cm = cbase + t;
+            if (FINISH) {
+                int f = cm;                      // memory channel -> flattened NCHW feature
+                if (perm_c > 0) f = (cm % perm_c) * perm_hw + cm / perm_c;
+                dst[f] += tot;
+            } else {
+                dst[(int64_t)blockIdx.x * channels + cm] = tot;
             }
-            atomicAdd(out + f, tot);
         }
         __syncthreads();
     }
@@ -509,38 +552,78 @@ extern "C" int arvae_link_up(const arvae_link_t *link, const arvae_operand_t *lo
     return launch_gemm(p, p.M, p.N, s * s, true, st, "link_up");
 }
 
+static void wgrad_split(const arvae_link_t *link, int &m, int &n, int &pix, int &zsplit, int &chunk) {
+    m = link->clo;
+    n = link->kh * link->kw * link->chi;
+    pix = link->n * link->lh * link->lw;
+    const int bm = m <= 32 ? 32 : 64, bn = m <= 32 ? 128 : 64;
+    const int tiles = ((m + bm - 1) / bm) * ((n + bn - 1) / bn);
+    zsplit = (1024 + tiles - 1) / tiles;          // ~4 workgroups per CU
+    const int max_split = (pix + BK - 1) / BK;
+    if (zsplit > max_split) zsplit = max_split;
+    if (zsplit < 1) zsplit = 1;
+    chunk = (((pix + zsplit - 1) / zsplit) + BK - 1) / BK * BK;
+    zsplit = (pix + chunk - 1) / chunk;
+}
+
+extern "C" int64_t arvae_link_wgrad_ws_floats(const arvae_link_t *link) {
+    if (link == nullptr || link->n <= 0) return 0;
+    int m, n, pix, zsplit, chunk;
+    wgrad_split(link, m, n, pix, zsplit, chunk);
+    return zsplit > 1 ? (int64_t)zsplit * m * n : 0;
+}
+
 extern "C" int arvae_link_wgrad(const arvae_link_t *link, const arvae_operand_t *lo, const arvae_operand_t *hi,
-                                float *dwt, arvae_stream_t stream) {
+                                float *dwt, float *ws, arvae_stream_t stream) {
     WgradPolicy p;
     if (int rc = make_geom(link, p.g)) return rc;
     ARVAE_REQUIRE(lo && lo->v && hi && hi->v && dwt, "link_wgrad: null pointer");
     p.lo = make_operand(lo);
     p.hi = make_operand(hi);
     p.dwt = dwt;
-    p.M = link->clo;
-    p.N = link->kh * link->kw * link->chi;
-    p.P = link->n * link->lh * link->lw;
-    const int bm = p.M <= 32 ? 32 : 64, bn = p.M <= 32 ? 128 : 64;
-    const int tiles = ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
-    int zsplit = (1024 + tiles - 1) / tiles;
-    const int max_split = (p.P + BK - 1) / BK;
-    if (zsplit > max_split) zsplit = max_split;
-    if (zsplit < 1) zsplit = 1;
-    p.chunk = (((p.P + zsplit - 1) / zsplit) + BK - 1) / BK * BK;
-    zsplit = (p.P + p.chunk - 1) / p.chunk;
-    return launch_gemm(p, p.M, p.N, zsplit, false, as_stream(stream), "link_wgrad");
+    p.slab = ws;
+    wgrad_split(link, p.M, p.N, p.P, p.zsplit, p.chunk);
+    ARVAE_REQUIRE(p.zsplit == 1 || ws != nullptr, "link_wgrad: workspace of arvae_link_wgrad_ws_floats() floats needed");
+    ARVAE_REQUIRE((int64_t)p.zsplit * p.M * p.N < (1ll << 31), "link_wgrad: slab too large");
+    hipStream_t st = as_stream(stream);
+    if (int rc = launch_gemm(p, p.M, p.N, p.zsplit, false, st, "link_wgrad")) return rc;
+    if (p.zsplit > 1) {
+        const int mn = p.M * p.N;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((mn + 63) / 64), dim3(256), 0, st, ws, p.zsplit, mn, p.N,
+                           link->kh * link->kw, FastDiv(p.N), FastDiv(link->chi), dwt);
+        return check_launch("link_wgrad(reduce)");
+    }
+    return ARVAE_OK;
+}
+
+static void channel_sum_split(int64_t rows, int64_t &blocks, int64_t &rpb) {
+    blocks = (rows + 127) / 128;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    rpb = (rows + blocks - 1) / blocks;
+    blocks = (rows + rpb - 1) / rpb;
+}
+
+extern "C" int64_t arvae_channel_sum_ws_floats(int64_t rows, int32_t channels) {
+    if (rows <= 0 || channels <= 0) return 0;
+    int64_t blocks, rpb;
+    channel_sum_split(rows, blocks, rpb);
+    return blocks * channels;
 }
 
 extern "C" int arvae_channel_sum(const arvae_operand_t *g, int64_t rows, int32_t channels, int32_t perm_c,
-                                 int32_t perm_hw, float *out, arvae_stream_t stream) {
-    ARVAE_REQUIRE(g && g->v && out, "channel_sum: null pointer");
+                                 int32_t perm_hw, float *out, float *ws, arvae_stream_t stream) {
+    ARVAE_REQUIRE(g && g->v && out && ws, "channel_sum: null pointer");
     ARVAE_REQUIRE(rows > 0 && channels > 0, "channel_sum: empty tensor");
     ARVAE_REQUIRE(perm_c == 0 || perm_c * perm_hw == channels, "channel_sum: perm does not cover channels");
-    int64_t blocks = (rows + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
-    const int64_t rpb = (rows + blocks - 1) / blocks;
-    blocks = (rows + rpb - 1) / rpb;
-    hipLaunchKernelGGL(channel_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), make_operand(g), rows,
-                       channels, perm_c, FastDiv(perm_c ? perm_hw : 1), rpb, out);
-    return check_launch("channel_sum");
+    int64_t blocks, rpb;
+    channel_sum_split(rows, blocks, rpb);
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(channel_sum_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, make_operand(g), rows,
+                       channels, rpb, 0, 0, ws);
+    if (int rc = check_launch("channel_sum")) return rc;
+    Operand part{ws, nullptr, nullptr, ARVAE_ACT_NONE};
+    hipLaunchKernelGGL(channel_sum_kernel<true>, dim3(1), dim3(256), 0, st, part, blocks, channels, blocks, perm_c,
+                       perm_hw, out);
+    return check_launch("channel_sum(finish)");
 }

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void scale_by_scalar_kernel(const float *__res
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g,
                                                     float *__restrict__ m, float *__restrict__ v, int64_t count,
                                                     float step_size, float inv_bc2_sqrt, float beta1, float beta2,
-                                                    float eps, float gscale) {
+                                                    float omb1, float omb2, float eps, float gscale) {
     const int64_t n4 = count >> 2;
     float4 *p4 = reinterpret_cast<float4 *>(p);
     const float4 *g4 = reinterpret_cast<const float4 *>(g);
@@ -282,8 +282,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
     float4 *v4 = reinterpret_cast<float4 *>(v);
     auto upd = [&](float &pp, float gg, float &mm, float &vv) {
         gg *= gscale;
-        mm = beta1 * mm + (1.f - beta1) * gg;
-        vv = beta2 * vv + (1.f - beta2) * gg * gg;
+        mm = beta1 * mm + omb1 * gg;
+        vv = beta2 * vv + omb2 * gg * gg;
         pp -= step_size * (mm / (sqrtf(vv) * inv_bc2_sqrt + eps));
     };
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
@@ -409,14 +409,15 @@ extern "C" int arvae_scale_by_scalar(const float *g, const float *x, int64_t cou
     return check_launch("scale_by_scalar");
 }
 
-extern "C" int arvae_adam_step(float *p, const float *g, float *m, float *v, int64_t count, int64_t step, float lr,
-                               float beta1, float beta2, float eps, float grad_scale, arvae_stream_t stream) {
+extern "C" int arvae_adam_step(float *p, const float *g, float *m, float *v, int64_t count, int64_t step, double lr,
+                               double beta1, double beta2, double eps, float grad_scale, arvae_stream_t stream) {
     ARVAE_REQUIRE(p && g && m && v && count > 0 && step >= 1, "adam_step: bad argument");
     ARVAE_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
                   "adam_step: arenas must be 16-byte aligned");
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(count, 4)), dim3(256), 0, as_stream(stream), p, g, m, v, count,
-                       (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, grad_scale);
+                       (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), (float)beta1, (float)beta2, (float)(1.0 - beta1),
+                       (float)(1.0 - beta2), (float)eps, grad_scale);
     return check_launch("adam_step");
 }

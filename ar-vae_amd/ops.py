@@ -77,14 +77,65 @@ class Link:
 
 
 # ------------------------------------------------------------------------------------------------
+# per-kernel timing hook (bench.py): HIP events on the launch stream around every library call
+# ------------------------------------------------------------------------------------------------
+_PROFILE = None
+
+
+def profile_begin():
+    global _PROFILE
+    _PROFILE = []
+
+
+def profile_end():
+    """-> {kernel family: dict(calls, ms, flop, bytes)} aggregated over the recorded launches."""
+    global _PROFILE
+    rec, _PROFILE = _PROFILE, None
+    torch.cuda.synchronize()
+    out = {}
+    for name, flop, nbytes, e0, e1 in rec or []:
+        d = out.setdefault(name, dict(calls=0, ms=0.0, flop=0.0, bytes=0.0))
+        d['calls'] += 1
+        d['ms'] += e0.elapsed_time(e1)
+        d['flop'] += flop
+        d['bytes'] += nbytes
+    return out
+
+
+class _timed:
+    def __init__(self, name, flop=0.0, nbytes=0.0):
+        self.args = (name, flop, nbytes)
+
+    def __enter__(self):
+        if _PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if _PROFILE is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            _PROFILE.append(self.args + (self.e0, e1))
+
+
+def _link_cost(link, n, op):
+    """(algorithmic FLOP, layer-boundary bytes) of one link launch."""
+    macs = n * link.lh * link.lw * link.clo * link.chi * link.kh * link.kw
+    hi_b, lo_b = 4 * n * link.hh * link.hw * link.chi, 4 * n * link.lh * link.lw * link.clo
+    wt_b = 4 * link.clo * link.chi * link.kh * link.kw
+    return 2.0 * macs, float(hi_b + lo_b + wt_b)
+
+
+# ------------------------------------------------------------------------------------------------
 # raw launches (no autograd)
 # ------------------------------------------------------------------------------------------------
 def link_down(link: Link, n, hi_op, wt, bias, act, out_mask, out=None):
     lib = _lib.load()
     lo = out if out is not None else torch.empty(link.lo_shape(n), device=wt.device, dtype=torch.float32)
     d = link.desc(n)
-    _lib.check(lib.arvae_link_down(ctypes.byref(d), ctypes.byref(hi_op), _ptr(wt), _ptr(bias), act, _ptr(out_mask),
-                                   _ptr(lo), _stream()), 'link_down')
+    with _timed('link_gemm<down>', *_link_cost(link, n, hi_op)):
+        _lib.check(lib.arvae_link_down(ctypes.byref(d), ctypes.byref(hi_op), _ptr(wt), _ptr(bias), act,
+                                       _ptr(out_mask), _ptr(lo), _stream()), 'link_down')
     return lo
 
 
@@ -92,24 +143,44 @@ def link_up(link: Link, n, lo_op, wt, bias, act, out_mask, out=None):
     lib = _lib.load()
     hi = out if out is not None else torch.empty(link.hi_shape(n), device=wt.device, dtype=torch.float32)
     d = link.desc(n)
-    _lib.check(lib.arvae_link_up(ctypes.byref(d), ctypes.byref(lo_op), _ptr(wt), _ptr(bias), act, _ptr(out_mask),
-                                 _ptr(hi), _stream()), 'link_up')
+    name = 'up_single_channel' if (link.chi == 1 and not lo_op.y) else 'link_gemm<up>'
+    with _timed(name, *_link_cost(link, n, lo_op)):
+        _lib.check(lib.arvae_link_up(ctypes.byref(d), ctypes.byref(lo_op), _ptr(wt), _ptr(bias), act,
+                                     _ptr(out_mask), _ptr(hi), _stream()), 'link_up')
     return hi
 
 
 def link_wgrad(link: Link, n, lo_op, hi_op, dwt):
+    """dwt += weight gradient (accumulates)."""
     lib = _lib.load()
     d = link.desc(n)
-    _lib.check(lib.arvae_link_wgrad(ctypes.byref(d), ctypes.byref(lo_op), ctypes.byref(hi_op), _ptr(dwt), _stream()),
-               'link_wgrad')
+    nws = lib.arvae_link_wgrad_ws_floats(ctypes.byref(d))
+    ws = torch.empty(nws, device=dwt.device, dtype=torch.float32) if nws else None
+    with _timed('link_gemm<wgrad>', *_link_cost(link, n, lo_op)):
+        _lib.check(lib.arvae_link_wgrad(ctypes.byref(d), ctypes.byref(lo_op), ctypes.byref(hi_op), _ptr(dwt),
+                                        _ptr(ws), _stream()), 'link_wgrad')
     return dwt
 
 
 def channel_sum(op, rows, channels, perm, out):
+    """out += per-channel sums (accumulates)."""
     lib = _lib.load()
-    _lib.check(lib.arvae_channel_sum(ctypes.byref(op), rows, channels, perm[0], perm[1], _ptr(out), _stream()),
-               'channel_sum')
+    ws = torch.empty(lib.arvae_channel_sum_ws_floats(rows, channels), device=out.device, dtype=torch.float32)
+    with _timed('channel_sum', float(rows * channels), 4.0 * rows * channels * (2 if op.y else 1)):
+        _lib.check(lib.arvae_channel_sum(ctypes.byref(op), rows, channels, perm[0], perm[1], _ptr(out), _ptr(ws),
+                                         _stream()), 'channel_sum')
     return out
+
+
+def _grad_target(param):
+    """Where a parameter gradient is accumulated.  When the parameter already owns a `.grad` buffer (the
+    trainer's flat gradient arena after zero_grad()), the kernels add straight into it and autograd gets
+    None back -- no zero-fill and no AccumulateGrad add per tensor.  Otherwise a fresh zeroed tensor is
+    returned through autograd as usual."""
+    g = param.grad
+    if g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.device == param.device:
+        return g, True
+    return torch.zeros_like(param), False
 
 
 # ------------------------------------------------------------------------------------------------
@@ -125,7 +196,7 @@ class _LinkDownFn(Function):
         lo = link_down(link, n, _operand(hi), wt, bias, act, mask)
         ctx.link, ctx.act, ctx.n = link, act, n
         ctx.save_for_backward(hi, wt, lo, mask)
-        ctx.has_bias = bias is not None
+        ctx.wt_ref, ctx.bias_ref = wt, bias
         return lo
 
     @staticmethod
@@ -139,10 +210,13 @@ class _LinkDownFn(Function):
         if ctx.needs_input_grad[0]:
             d_hi = link_up(link, n, gop, wt, None, ACT_NONE, None)
         if ctx.needs_input_grad[1]:
-            d_wt = link_wgrad(link, n, gop, _operand(hi), torch.zeros_like(wt))
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            d_bias = channel_sum(gop, n * link.lh * link.lw, link.clo, link.lo_perm,
-                                 torch.zeros(link.clo, device=wt.device, dtype=torch.float32))
+            buf, direct = _grad_target(ctx.wt_ref)
+            link_wgrad(link, n, gop, _operand(hi), buf)
+            d_wt = None if direct else buf
+        if ctx.bias_ref is not None and ctx.needs_input_grad[2]:
+            buf, direct = _grad_target(ctx.bias_ref)
+            channel_sum(gop, n * link.lh * link.lw, link.clo, link.lo_perm, buf)
+            d_bias = None if direct else buf
         return d_hi, d_wt, d_bias, None, None, None
 
 
@@ -156,7 +230,7 @@ class _LinkUpFn(Function):
         hi = link_up(link, n, _operand(lo), wt, bias, act, mask)
         ctx.link, ctx.act, ctx.n = link, act, n
         ctx.save_for_backward(lo, wt, hi, mask)
-        ctx.has_bias = bias is not None
+        ctx.wt_ref, ctx.bias_ref = wt, bias
         return hi
 
     @staticmethod
@@ -170,10 +244,13 @@ class _LinkUpFn(Function):
         if ctx.needs_input_grad[0]:
             d_lo = link_down(link, n, gop, wt, None, ACT_NONE, None)
         if ctx.needs_input_grad[1]:
-            d_wt = link_wgrad(link, n, _operand(lo), gop, torch.zeros_like(wt))
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            d_bias = channel_sum(gop, n * link.hh * link.hw, link.chi, link.hi_perm,
-                                 torch.zeros(link.chi, device=wt.device, dtype=torch.float32))
+            buf, direct = _grad_target(ctx.wt_ref)
+            link_wgrad(link, n, _operand(lo), gop, buf)
+            d_wt = None if direct else buf
+        if ctx.bias_ref is not None and ctx.needs_input_grad[2]:
+            buf, direct = _grad_target(ctx.bias_ref)
+            channel_sum(gop, n * link.hh * link.hw, link.chi, link.hi_perm, buf)
+            d_bias = None if direct else buf
         return d_lo, d_wt, d_bias, None, None, None
 
 
@@ -275,8 +352,10 @@ class _RegLossFn(Function):
         loss = torch.empty((), device=z.device, dtype=torch.float32)
         dz = torch.empty_like(z)
         cdims = (ctypes.c_int32 * r)(*dims)
-        _lib.check(lib.arvae_reg_loss(_ptr(z), _ptr(labels), n_rows, _ptr(zc), _ptr(lc), zc.shape[0], ldz, ldl, cdims,
-                                      r, gamma, delta, _ptr(ws), _ptr(loss), _ptr(dz), _stream()), 'reg_loss')
+        with _timed('reg_loss', 0.0, 8.0 * (n_rows + zc.shape[0]) * r):
+            _lib.check(lib.arvae_reg_loss(_ptr(z), _ptr(labels), n_rows, _ptr(zc), _ptr(lc), zc.shape[0], ldz, ldl,
+                                          cdims, r, gamma, delta, _ptr(ws), _ptr(loss), _ptr(dz), _stream()),
+                       'reg_loss')
         ctx.save_for_backward(dz)
         return loss
 
@@ -320,8 +399,9 @@ class _ImageReconFn(Function):
         out = torch.empty(2, device=x.device, dtype=torch.float32)
         need = ctx.needs_input_grad[0]
         dl = torch.empty_like(logits) if need else None
-        _lib.check(lib.arvae_image_recon(_ptr(logits), _ptr(x), count, batch, dist, _ptr(ws), _ptr(out), _ptr(dl),
-                                         _stream()), 'image_recon')
+        with _timed('image_recon', 0.0, 4.0 * count * (3 if need else 2)):
+            _lib.check(lib.arvae_image_recon(_ptr(logits), _ptr(x), count, batch, dist, _ptr(ws), _ptr(out),
+                                             _ptr(dl), _stream()), 'image_recon')
         if need:
             ctx.save_for_backward(dl)
         loss, acc = out[0], out[1]
@@ -381,5 +461,6 @@ def token_recon(weights, targets):
 def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
     _dev(p, g, m, v)
     lib = _lib.load()
-    _lib.check(lib.arvae_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), int(step), lr, beta1, beta2, eps,
-                                   grad_scale, _stream()), 'adam_step')
+    with _timed('adam', 0.0, 28.0 * p.numel()):
+        _lib.check(lib.arvae_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), int(step), lr, beta1, beta2,
+                                       eps, grad_scale, _stream()), 'adam_step')

@@ -1,0 +1,71 @@
+"""Data-parallel AR-VAE step: one process per GPU, RCCL (torch.distributed 'nccl') over xGMI.
+
+The reference is single-process; this layer is new.  The minibatch is sharded
+by rows; the model is replicated.  Per step there are exactly two collectives:
+
+  1. all-gather of the regularised latent/label columns (2 * B_local * R floats per rank, ~20 KB): the
+     attribute-regularisation loss averages over ALL N_global^2 pairs (utils/trainer.py:390-401), so
+     each rank evaluates its row block against the gathered global columns.  The pair term is symmetric,
+     hence the row-block gradient is already the full d(global loss)/d z_i: no gradient exchange.
+  2. one SUM all-reduce of the flat gradient arena (2.0 MB for the dSprites model), after which Adam
+     scales by 1/world_size.
+
+Loss convention: rank r differentiates  L_r = recon_r + beta*|KL_r - c| + W * reg_rowblock_r ;
+mean_r(L_r) equals the single-process loss on the concatenated batch (exact for c = 0, the default),
+and mean_r(grad L_r) equals its gradient.
+"""
+import torch
+import torch.distributed as dist
+
+
+class DataParallel:
+    def __init__(self, process_group=None, reg_fn=None):
+        if not dist.is_initialized():
+            raise RuntimeError('torch.distributed is not initialised')
+        self.group = process_group
+        self.world_size = dist.get_world_size(process_group)
+        self.rank = dist.get_rank(process_group)
+        if reg_fn is None:
+            from . import ops
+            reg_fn = ops.reg_loss
+        self._reg_fn = reg_fn
+
+    def attach(self, trainer):
+        trainer.data_parallel = self
+        return trainer
+
+    def broadcast_parameters(self, model, src=0):
+        """Make every replica start from rank `src`'s weights."""
+        for p in model.parameters():
+            dist.broadcast(p.data, src=src, group=self.group)
+
+    def gather_columns(self, local):
+        """(B_local, R) -> (W * B_local, R), rank-major row order."""
+        local = local.contiguous()
+        out = torch.empty((self.world_size * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype,
+                          device=local.device)
+        dist.all_gather_into_tensor(out, local, group=self.group)
+        return out
+
+    def reg_loss(self, z, labels, dims, gamma, delta):
+        """W * (row-block regularisation loss of this rank's samples against the global batch)."""
+        idx = torch.as_tensor(list(dims), device=z.device, dtype=torch.long)
+        z_loc = z.index_select(1, idx)                       # differentiable compaction (B_local, R)
+        lab_loc = labels.index_select(1, idx).to(torch.float32)
+        packed = self.gather_columns(torch.cat([z_loc.detach(), lab_loc], dim=1))
+        r = len(dims)
+        z_all, lab_all = packed[:, :r].contiguous(), packed[:, r:].contiguous()
+        part = self._reg_fn(z_loc, lab_loc, tuple(range(r)), gamma, delta, z_cols=z_all, lab_cols=lab_all)
+        return part * float(self.world_size)
+
+    def reduce_gradients(self, optimizer):
+        """SUM all-reduce of the flat gradient arena; Adam then applies 1/W."""
+        optimizer.ensure_arena()
+        dist.all_reduce(optimizer.grad_arena, op=dist.ReduceOp.SUM, group=self.group)
+        optimizer.grad_scale = 1.0 / self.world_size
+
+    def mean_scalar(self, value):
+        """average a scalar tensor over ranks (reporting only)."""
+        v = value.detach().clone().reshape(1)
+        dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
+        return v / self.world_size

@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Throughput of the AR-VAE training step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[1]): dSprites AR-VAE, per-GPU batch 512, fp32,
+beta=4, gamma=10, delta=1, reg_dim=(1..5).  One step = zero_grad -> loss_and_acc_for_batch -> backward ->
+Adam, on synthetic dSprites-shaped inputs that are resident in HBM before the timed region; the
+reparameterisation noise is drawn on the device each step.  Prints ONE JSON line (rank 0).
+
+Extra objects in the line:
+  roofline      the dominant kernel family of the step, timed live with HIP events on the launch stream
+                in a separate instrumented pass (algorithmic FLOP / average launch duration vs the fp32
+                MFMA peak, or bytes vs HBM peak for a memory-bound family)
+  cpu_baseline  the CPU oracle (oracle/step.py, a port: the reference's Python cannot travel) timed on
+                this box's host cores on a bounded sample of the same workload (rank 0, N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+# roofline constants: /opt/skills/guides/MI355X_MICROARCH.md (chip-level parameters)
+PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+# algorithmic work per image per step, SURVEY.md section 8(d) (dSprites)
+FLOP_PER_IMAGE = 73_708_544
+BYTES_PER_IMAGE = 1_862_936
+PARAM_BYTES_PER_STEP = 20_080_200
+
+REG_DIMS = (1, 2, 3, 4, 5)
+BETA, GAMMA, DELTA = 4.0, 10.0, 1.0
+
+
+class DspritesDataset:          # ImageVAETrainer sniffs the dataset's class name (reference image_vae_trainer.py:81-86)
+    pass
+
+
+def dsprites_shapes():
+    from arvae_amd.image_vae import DspritesVAE
+    return {k: tuple(v.shape) for k, v in DspritesVAE().state_dict().items()}
+
+
+def build_trainer(device, world):
+    from arvae_amd import synthetic as syn
+    from arvae_amd.image_vae import DspritesVAE
+    from arvae_amd.image_vae_trainer import ImageVAETrainer
+    model = DspritesVAE()
+    state = syn.synth_state({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=1)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    trainer = ImageVAETrainer(DspritesDataset(), model, lr=1e-4, reg_type=('all',), reg_dim=REG_DIMS, beta=BETA,
+                              gamma=GAMMA, capacity=0.0, rand=0, delta=DELTA)
+    model.to(device)
+    trainer.capacity = trainer.capacity.to(device)
+    if world > 1:
+        from arvae_amd.parallel import DataParallel
+        DataParallel().attach(trainer)
+    model.train()
+    return trainer, state
+
+
+def cpu_baseline(batch, state, budget_s=20.0):
+    """CPU oracle on the same workload, bounded to ~budget_s of CPU work."""
+    from arvae_amd import synthetic as syn
+    from oracle import step as o_step
+    x, lab = syn.dsprites_batch(batch, seed=1234)
+    eps = syn.normal_noise((batch, 10), seed=1)
+    cores = torch.get_num_threads()
+    cur, adam = state, None
+    times = []
+    t_start = time.perf_counter()
+    n = 0
+    while True:
+        t0 = time.perf_counter()
+        res = o_step.image_step('dsprites', cur, x, lab, eps, REG_DIMS, BETA, GAMMA, DELTA, adam_state=adam,
+                                step_no=n + 1)
+        cur, adam = res['params'], res['adam']
+        times.append(time.perf_counter() - t0)
+        n += 1
+        if n >= 3 and (time.perf_counter() - t_start > budget_s or n >= 40):
+            break
+    steady = sorted(times[1:])
+    med = steady[len(steady) // 2]
+    return {'value': batch / med, 'unit': 'images/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{n} full training steps (first discarded) of the dSprites AR-VAE at batch {batch}, fp32, '
+                      f'PyTorch-CPU oracle, {cores} threads, median step {med * 1e3:.1f} ms'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--batch', type=int, default=512, help='per-GPU batch')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--breakdown', action='store_true', help='print the per-kernel-family table to stderr')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} '
+                         f'(WORLD_SIZE={world})')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the AR-VAE hot path has no CPU fallback')
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+
+    from arvae_amd import ops
+    from arvae_amd import synthetic as syn
+
+    trainer, state = build_trainer(device, world)
+    if world > 1:
+        trainer.data_parallel.broadcast_parameters(trainer.model)
+    b = args.batch
+    x_np, lab_np = syn.dsprites_batch(b, seed=1234 + rank)
+    x = torch.from_numpy(x_np).to(device)
+    lab = torch.from_numpy(lab_np).to(device)
+
+    def step(i):
+        trainer.zero_grad()
+        loss, _ = trainer.loss_and_acc_for_batch((x, lab), 0, i, True)
+        loss.backward()
+        trainer.step()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax)
+    final_loss = float(loss)
+    if not np.isfinite(final_loss):
+        raise SystemExit(f'non-finite loss {final_loss}')
+
+    # ---- instrumented pass: per-kernel-family device time (HIP events on the launch stream) -----------
+    ops.profile_begin()
+    prof_steps = 5
+    for i in range(prof_steps):
+        step(i)
+    prof = ops.profile_end()
+    fence()
+
+    if rank != 0:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+        return
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * b * args.steps / elapsed
+    dom_name, dom = max(prof.items(), key=lambda kv: kv[1]['ms'])
+    avg_ms = dom['ms'] / dom['calls']
+    if dom['flop'] > 0 and dom['flop'] / max(dom['bytes'], 1.0) > PEAK_F32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9):
+        achieved = dom['flop'] / dom['calls'] / (avg_ms * 1e-3) / 1e12
+        roof = {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None}
+    else:
+        achieved = dom['bytes'] / dom['calls'] / (avg_ms * 1e-3) / 1e9
+        roof = {'bound': 'hbm', 'achieved': achieved, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                'frac': achieved / PEAK_HBM_GBS, 'traffic': None}
+    roof.update({'kernel': dom_name, 'launches_per_step': dom['calls'] / prof_steps, 'avg_launch_us': avg_ms * 1e3,
+                 'share_of_device_time': dom['ms'] / sum(v['ms'] for v in prof.values())})
+    per_gpu = value / world
+    line = {
+        'metric': 'training images/sec (dSprites beta-VAE+AR, per-GPU batch 512)', 'value': value,
+        'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'dSprites AR-VAE full training step (fwd + bwd + Adam), 1x64x64 inputs, z=10, '
+                               'reg_dim=(1,2,3,4,5), beta=4 gamma=10 delta=1',
+                   'per_gpu_batch': b, 'global_batch': b * world, 'parallelism': f'dp{world}',
+                   'images_per_sec_per_gpu': per_gpu, 'final_loss': final_loss},
+        'roofline': roof,
+        'step_roofline': {
+            'flop_frac_fp32': per_gpu * FLOP_PER_IMAGE / (PEAK_F32_MFMA_TFLOPS * 1e12),
+            'hbm_frac': per_gpu * (BYTES_PER_IMAGE + PARAM_BYTES_PER_STEP / b) / (PEAK_HBM_GBS * 1e9),
+            'binding': 'fp32 matrix/vector FLOP roof (2.13 M img/s) before HBM (4.2 M img/s)'},
+    }
+    if args.breakdown:
+        tot = sum(v['ms'] for v in prof.values())
+        for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms']):
+            print(f"  {k:24s} {v['calls'] / prof_steps:6.1f} calls/step {v['ms'] / prof_steps * 1e3:9.1f} us/step "
+                  f"{100 * v['ms'] / tot:5.1f}%  {v['flop'] / max(v['ms'], 1e-9) / 1e9:8.2f} TFLOP/s "
+                  f"{v['bytes'] / max(v['ms'], 1e-9) / 1e6:8.1f} GB/s", file=sys.stderr)
+        print(f'  device-time sum {tot / prof_steps * 1e3:.1f} us/step vs wall {ms_per_step * 1e3:.1f} us/step',
+              file=sys.stderr)
+    if world == 1 and not args.no_cpu_baseline:
+        line['cpu_baseline'] = cpu_baseline(b, state)
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

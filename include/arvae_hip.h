@@ -95,14 +95,19 @@ int arvae_link_up(const arvae_link_t *link, const arvae_operand_t *lo, const flo
                   const float *bias, int32_t out_act, const uint8_t *out_mask, float *hi,
                   arvae_stream_t stream);
 
-/* dwt[clo][chi][ky][kx] += sum_{n,ly,lx} lo * hi   (accumulates; fp32 atomics across the batch split) */
+/* dwt[clo][chi][ky][kx] += sum_{n,ly,lx} lo * hi   (accumulates).  The batch is split over workgroups;
+ * partial tiles go to `ws` (arvae_link_wgrad_ws_floats(link) floats, may be 0 -> ws unused) and are summed
+ * in a fixed order: bitwise reproducible, no float atomics. */
+int64_t arvae_link_wgrad_ws_floats(const arvae_link_t *link);
 int arvae_link_wgrad(const arvae_link_t *link, const arvae_operand_t *lo, const arvae_operand_t *hi,
-                     float *dwt, arvae_stream_t stream);
+                     float *dwt, float *ws, arvae_stream_t stream);
 
 /* out[c] += sum_rows operand[row, c]  for a [rows, channels] channels-last view (bias gradients).
- * perm_c/perm_hw as in arvae_link_t (out is indexed by the flattened NCHW feature). */
+ * perm_c/perm_hw as in arvae_link_t (out is indexed by the flattened NCHW feature).
+ * ws: arvae_channel_sum_ws_floats(rows, channels) floats. */
+int64_t arvae_channel_sum_ws_floats(int64_t rows, int32_t channels);
 int arvae_channel_sum(const arvae_operand_t *g, int64_t rows, int32_t channels, int32_t perm_c,
-                      int32_t perm_hw, float *out, arvae_stream_t stream);
+                      int32_t perm_hw, float *out, float *ws, arvae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Latent head.  Replaces z_dist = Normal(mu, exp(log_std)); z = z_dist.rsample()
@@ -167,11 +172,12 @@ int arvae_scale_by_scalar(const float *g, const float *x, int64_t count, float *
  * Adam over one flat fp32 arena.  Replaces torch.optim.Adam(...).step() (utils/trainer.py:31-34,
  * 170-174) with defaults beta1=.9 beta2=.999 eps=1e-8, no weight decay, no amsgrad:
  *   m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;  p -= (lr/(1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ * Hyper-parameters are doubles (as torch holds them: 1-beta2 is formed in double, then rounded).
  * `step` is the 1-based step number t.  grad_scale multiplies g first (1/world_size after a SUM
  * all-reduce; 1 otherwise).
  * ------------------------------------------------------------------------------------------------ */
-int arvae_adam_step(float *p, const float *g, float *m, float *v, int64_t count, int64_t step, float lr,
-                    float beta1, float beta2, float eps, float grad_scale, arvae_stream_t stream);
+int arvae_adam_step(float *p, const float *g, float *m, float *v, int64_t count, int64_t step, double lr,
+                    double beta1, double beta2, double eps, float grad_scale, arvae_stream_t stream);
 
 #ifdef __cplusplus
 }

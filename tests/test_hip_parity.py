@@ -304,9 +304,10 @@ def test_adam_vs_oracle(dev):
         p, m, v = o_losses.adam_step(p, g, m, v, step, lr=1e-3)
         gd[:n] = torch.from_numpy(g).to(dev)
         ops.adam_step(pd, gd, md, vd, step, 1e-3)
-        close(pd[:n], p, rtol=1e-5, atol=1e-7)
-        close(md[:n], m, rtol=1e-5, atol=1e-9)
-        close(vd[:n], v, rtol=1e-5, atol=1e-12)
+        # one fp32 ulp of the largest entry as atol: b1*m + (1-b1)*g cancels for some elements
+        close(pd[:n], p, rtol=1e-5, atol=2e-7 * float(np.abs(p).max()))
+        close(md[:n], m, rtol=1e-5, atol=2e-7 * float(np.abs(m).max()))
+        close(vd[:n], v, rtol=1e-5, atol=2e-7 * float(np.abs(v).max()))
 
 
 # ---------------------------------------------------------------- full steps (G4 / G5)
@@ -382,7 +383,10 @@ def test_image_step_vs_golden_and_oracle(golden_dir, dev, case):
         close(np.sqrt((gr * gr).sum()), gn, rtol=1e-3)
         idx = syn.sample_indices(name, gr.size)
         close(gr[idx], g[f'gsamp/{name}'], rtol=1e-3, atol=1e-3 * gn / np.sqrt(gr.size) + 1e-7)
-        close(gr, ref['grads'][name].ravel(), rtol=1e-3, atol=1e-3 * gn / np.sqrt(gr.size) + 1e-7)
+        # whole tensor vs the oracle: relative L2 error (a ReLU unit whose pre-activation is ~0 may flip
+        # between two fp32 summation orders, which moves a handful of entries by more than 1e-3 each)
+        want = ref['grads'][name].astype(np.float64).ravel()
+        assert np.linalg.norm(gr - want) <= 2e-3 * np.linalg.norm(want) + 1e-9, name
         d = (got['params'][name].astype(np.float64) - state[name].astype(np.float64)).ravel()
         close(np.sqrt((d * d).sum()), g[f'dnorm/{name}'], rtol=2e-3)
 
