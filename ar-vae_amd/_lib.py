@@ -35,7 +35,7 @@ SIGNATURES = {
     'arvae_link_down': (c_i32, [_P(LinkDesc), _P(OperandDesc), c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     'arvae_link_up': (c_i32, [_P(LinkDesc), _P(OperandDesc), c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     'arvae_link_wgrad_ws_floats': (c_i64, [_P(LinkDesc)]),
-    'arvae_link_wgrad': (c_i32, [_P(LinkDesc), _P(OperandDesc), _P(OperandDesc), c_vp, c_vp, c_vp]),
+    'arvae_link_wgrad': (c_i32, [_P(LinkDesc), _P(OperandDesc), _P(OperandDesc), c_vp, c_vp, c_i32, c_vp, c_vp]),
     'arvae_channel_sum_ws_floats': (c_i64, [c_i64, c_i32]),
     'arvae_channel_sum': (c_i32, [_P(OperandDesc), c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     'arvae_latent_fwd': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),

@@ -1,0 +1,242 @@
+// nn.Linear forward / data-gradient / weight-gradient for batch-sized GEMMs (M = batch 64..4096,
+// features 10..2888) on the fp32 MFMA.  These are latency-bound, cache-resident problems: a
+// workgroup owns ONE 32x32 output tile, its 4 wavefronts split the reduction axis and sum through
+// LDS, and operands go straight from L2 to registers (no LDS staging): a lane reads 4 consecutive
+// reduction elements (16 B) when that axis is contiguous in memory, or 4 row-strided dwords that are
+// coalesced across the wave when the OTHER axis is contiguous.  The reduction order is permuted
+// (chunk of 8 = [half 0: 4][half 1: 4]) to fit the 32x32x2 MFMA's k = 2s + half lane layout.
+//
+// Channel permutations (hi_perm / lo_perm of arvae_link_t: the NCHW flatten between conv and dense
+// stacks over channels-last activations) are index remaps on the feature axis.
+#include "common.h"
+
+namespace arvae {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct Perm {           // feature f = c*hw + p  <->  memory column p*c_count + c ; c_count == 0: identity
+    int c_count, hw;
+    __device__ __forceinline__ int to_mem(int f) const { return c_count == 0 ? f : (f % hw) * c_count + f / hw; }
+    __device__ __forceinline__ int to_feat(int m) const { return c_count == 0 ? m : (m % c_count) * hw + m / c_count; }
+};
+
+struct DenseArgs {
+    Operand a;          // forward: X plain; dgrad / wgrad: G (gradient operand)
+    const float *x;     // wgrad: layer input X
+    const float *w;     // [n_out][n_in]
+    const float *bias;
+    float *out;         // forward: Y ; dgrad: dX ; wgrad: dW (accumulated)
+    float *dbias;       // wgrad: accumulated, may be null
+    int batch, n_in, n_out, act;
+    Perm in_perm, out_perm;
+};
+
+__device__ __forceinline__ void mfma4(f32x16 &acc, const float (&a)[4], const float (&b)[4]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
+}
+
+// sum the 4 waves' 32x32 partial tiles; wave w returns registers [4w, 4w+4) of the total in v[0..3]
+__device__ __forceinline__ void reduce_waves(float *red, const f32x16 &acc, int wave, int lane, float (&v)[4]) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4 *>(red + ((wave * 4 + q) * 64 + lane) * 4) =
+            make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    __syncthreads();
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int ws = 0; ws < 4; ++ws) {
+        const float4 p = *reinterpret_cast<const float4 *>(red + ((ws * 4 + wave) * 64 + lane) * 4);
+        s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+    }
+    v[0] = s.x; v[1] = s.y; v[2] = s.z; v[3] = s.w;
+}
+
+// ---- forward: Y[m][out_perm(n)] = act( sum_k X[m][km] * W[n][feat(km)] + b[n] ),  km = memory column ----------
+__global__ __launch_bounds__(256) void dense_fwd_kernel(DenseArgs p) {
+    __shared__ __attribute__((aligned(16))) float red[4 * 4 * 64 * 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, rc = lane & 31;
+    const int m = blockIdx.x * 32 + rc, n = blockIdx.y * 32 + rc;
+    const bool mok = m < p.batch, nok = n < p.n_out;
+    const bool vec = (p.n_in & 3) == 0;
+    const float *xrow = p.a.v + (int64_t)(mok ? m : 0) * p.n_in;
+    const float *wrow = p.w + (int64_t)(nok ? n : 0) * p.n_in;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int chunks = (p.n_in + 7) / 8;
+    for (int q = wave; q < chunks; q += 4) {
+        const int k0 = q * 8 + half * 4;
+        float a[4], b[4];
+        if (vec && k0 + 3 < p.n_in) {
+            const float4 av = *reinterpret_cast<const float4 *>(xrow + k0);
+            a[0] = av.x; a[1] = av.y; a[2] = av.z; a[3] = av.w;
+            if (p.in_perm.c_count == 0) {
+                const float4 bv = *reinterpret_cast<const float4 *>(wrow + k0);
+                b[0] = bv.x; b[1] = bv.y; b[2] = bv.z; b[3] = bv.w;
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) b[t] = wrow[p.in_perm.to_feat(k0 + t)];
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bool ok = k0 + t < p.n_in;
+                a[t] = ok ? xrow[k0 + t] : 0.f;
+                b[t] = ok ? wrow[p.in_perm.to_feat(k0 + t)] : 0.f;
+            }
+        }
+        if (!mok) a[0] = a[1] = a[2] = a[3] = 0.f;
+        if (!nok) b[0] = b[1] = b[2] = b[3] = 0.f;
+        mfma4(acc, a, b);
+    }
+    float v[4];
+    reduce_waves(red, acc, wave, lane, v);
+    if (nok) {
+        const float bias = p.bias != nullptr ? p.bias[n] : 0.f;
+        const int col = p.out_perm.to_mem(n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int reg = 4 * wave + e;
+            const int row = blockIdx.x * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+            if (row < p.batch) p.out[(int64_t)row * p.n_out + col] = act_fwd(v[e] + bias, p.act);
+        }
+    }
+}
+
+// ---- dgrad: dX[m][in_mem] = sum_{nm} G[m][nm] * W[feat_out(nm)][feat_in(in_mem)]  ---------------------------
+__global__ __launch_bounds__(256) void dense_dgrad_kernel(DenseArgs p) {
+    __shared__ __attribute__((aligned(16))) float red[4 * 4 * 64 * 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, rc = lane & 31;
+    const int m = blockIdx.x * 32 + rc, km = blockIdx.y * 32 + rc;      // km = memory column of dX
+    const bool mok = m < p.batch, kok = km < p.n_in;
+    const int kf = kok ? p.in_perm.to_feat(km) : 0;
+    const bool vec = (p.n_out & 3) == 0;
+    const int64_t grow = (int64_t)(mok ? m : 0) * p.n_out;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int chunks = (p.n_out + 7) / 8;
+    for (int q = wave; q < chunks; q += 4) {
+        const int n0 = q * 8 + half * 4;
+        float a[4], b[4];
+        if (vec && p.a.mask == nullptr && n0 + 3 < p.n_out) {
+            float4 av = *reinterpret_cast<const float4 *>(p.a.v + grow + n0);
+            if (p.a.y != nullptr) {
+                const float4 yv = *reinterpret_cast<const float4 *>(p.a.y + grow + n0);
+                av.x *= act_bwd_from_out(yv.x, p.a.act); av.y *= act_bwd_from_out(yv.y, p.a.act);
+                av.z *= act_bwd_from_out(yv.z, p.a.act); av.w *= act_bwd_from_out(yv.w, p.a.act);
+            }
+            a[0] = av.x; a[1] = av.y; a[2] = av.z; a[3] = av.w;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) b[t] = p.w[(int64_t)p.out_perm.to_feat(n0 + t) * p.n_in + kf];
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bool ok = n0 + t < p.n_out;
+                a[t] = ok ? p.a.at(grow + n0 + t) : 0.f;
+                b[t] = ok ? p.w[(int64_t)p.out_perm.to_feat(n0 + t) * p.n_in + kf] : 0.f;
+            }
+        }
+        if (!mok) a[0] = a[1] = a[2] = a[3] = 0.f;
+        if (!kok) b[0] = b[1] = b[2] = b[3] = 0.f;
+        mfma4(acc, a, b);
+    }
+    float v[4];
+    reduce_waves(red, acc, wave, lane, v);
+    if (kok) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int reg = 4 * wave + e;
+            const int row = blockIdx.x * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+            if (row < p.batch) p.out[(int64_t)row * p.n_in + km] = v[e];
+        }
+    }
+}
+
+// ---- wgrad: dW[n][feat_in(km)] += sum_m G[m][mem_out(n)] * X[m][km] ;  db[n] += sum_m G[m][mem_out(n)] ------
+__global__ __launch_bounds__(256) void dense_wgrad_kernel(DenseArgs p) {
+    __shared__ __attribute__((aligned(16))) float red[4 * 4 * 64 * 4];
+    __shared__ float bred[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, rc = lane & 31;
+    const int n = blockIdx.x * 32 + rc, km = blockIdx.y * 32 + rc;
+    const bool nok = n < p.n_out, kok = km < p.n_in;
+    const int ncol = nok ? p.out_perm.to_mem(n) : 0;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float bsum = 0.f;
+    const int chunks = (p.batch + 7) / 8;
+    for (int q = wave; q < chunks; q += 4) {
+        const int m0 = q * 8 + half * 4;
+        float a[4], b[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bool ok = m0 + t < p.batch;
+            a[t] = (ok && nok) ? p.a.at((int64_t)(m0 + t) * p.n_out + ncol) : 0.f;
+            b[t] = (ok && kok) ? p.x[(int64_t)(m0 + t) * p.n_in + km] : 0.f;
+            bsum += a[t];
+        }
+        mfma4(acc, a, b);
+    }
+    float v[4];
+    reduce_waves(red, acc, wave, lane, v);
+    if (kok) {
+        const int kf = p.in_perm.to_feat(km);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int reg = 4 * wave + e;
+            const int row = blockIdx.x * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;      // n
+            if (row < p.n_out) p.out[(int64_t)row * p.n_in + kf] += v[e];
+        }
+    }
+    if (p.dbias != nullptr && blockIdx.y == 0) {
+        bred[wave][lane] = bsum;
+        __syncthreads();
+        if (wave == 0 && half == 0 && nok) {
+            float tot = 0.f;
+#pragma unroll
+            for (int ws = 0; ws < 4; ++ws) tot += bred[ws][rc] + bred[ws][rc + 32];
+            p.dbias[n] += tot;
+        }
+    }
+}
+
+bool dense_fits(const arvae_link_t *l) {
+    return l->hh == 1 && l->hw == 1 && l->lh == 1 && l->lw == 1 && l->kh == 1 && l->kw == 1;
+}
+
+static DenseArgs dense_args(const arvae_link_t *l) {
+    DenseArgs p{};
+    p.batch = l->n;
+    p.n_in = l->chi;
+    p.n_out = l->clo;
+    p.in_perm = Perm{l->hi_perm_c, l->hi_perm_hw};
+    p.out_perm = Perm{l->lo_perm_c, l->lo_perm_hw};
+    return p;
+}
+
+int dense_fwd(const arvae_link_t *l, const float *x, const float *w, const float *bias, int act, float *y, hipStream_t s) {
+    DenseArgs p = dense_args(l);
+    p.a = Operand{x, nullptr, nullptr, ARVAE_ACT_NONE};
+    p.w = w; p.bias = bias; p.act = act; p.out = y;
+    hipLaunchKernelGGL(dense_fwd_kernel, dim3((p.batch + 31) / 32, (p.n_out + 31) / 32), dim3(256), 0, s, p);
+    return check_launch("dense_fwd");
+}
+
+int dense_dgrad(const arvae_link_t *l, const Operand &g, const float *w, float *dx, hipStream_t s) {
+    DenseArgs p = dense_args(l);
+    p.a = g; p.w = w; p.out = dx;
+    hipLaunchKernelGGL(dense_dgrad_kernel, dim3((p.batch + 31) / 32, (p.n_in + 31) / 32), dim3(256), 0, s, p);
+    return check_launch("dense_dgrad");
+}
+
+int dense_wgrad(const arvae_link_t *l, const Operand &g, const float *x, float *dw, float *dbias, hipStream_t s) {
+    DenseArgs p = dense_args(l);
+    p.a = g; p.x = x; p.out = dw; p.dbias = dbias;
+    hipLaunchKernelGGL(dense_wgrad_kernel, dim3((p.n_out + 31) / 32, (p.n_in + 31) / 32), dim3(256), 0, s, p);
+    return check_launch("dense_wgrad");
+}
+
+}  // namespace arvae

@@ -20,6 +20,22 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 32;
 
+// batch-sized nn.Linear kernels (dense.hip)
+bool dense_fits(const arvae_link_t *l);
+int dense_fwd(const arvae_link_t *l, const float *x, const float *w, const float *bias, int act, float *y, hipStream_t s);
+int dense_dgrad(const arvae_link_t *l, const Operand &g, const float *w, float *dx, hipStream_t s);
+int dense_wgrad(const arvae_link_t *l, const Operand &g, const float *x, float *dw, float *dbias, hipStream_t s);
+
+// specialised 32-channel k4/s2/p1 kernels (conv32.hip)
+bool conv32_fits(const arvae_link_t *l);
+int conv32_down(const arvae_link_t *l, const Operand &hi, const float *wt, const float *bias, int relu,
+                const float *gate, float *out, hipStream_t s);
+int conv32_up(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, int relu,
+              const float *gate, float *out, hipStream_t s);
+int64_t conv32_wgrad_ws_floats(const arvae_link_t *l);
+int conv32_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *dwt, float *dbias, int bias_mode,
+                 float *slab, hipStream_t s);
+
 struct Geom {
     int n, hh, hw, chi, lh, lw, clo, kh, kw, stride, pad;
     int hi_pc, lo_pc;
@@ -508,6 +524,11 @@ extern "C" int arvae_link_down(const arvae_link_t *link, const arvae_operand_t *
     DownPolicy p;
     if (int rc = make_geom(link, p.g)) return rc;
     ARVAE_REQUIRE(hi && hi->v && wt && lo, "link_down: null pointer");
+    if (dense_fits(link) && out_mask == nullptr && hi->y == nullptr)
+        return dense_fwd(link, hi->v, wt, bias, out_act, lo, as_stream(stream));
+    if (conv32_fits(link) && out_mask == nullptr && hi->mask == nullptr && out_act != ARVAE_ACT_SELU &&
+        hi->act != ARVAE_ACT_SELU)
+        return conv32_down(link, make_operand(hi), wt, bias, out_act == ARVAE_ACT_RELU, nullptr, lo, as_stream(stream));
     p.hi = make_operand(hi);
     p.wt = wt;
     p.ep = Epilogue{bias, out_mask, lo, out_act};
@@ -528,6 +549,11 @@ extern "C" int arvae_link_up(const arvae_link_t *link, const arvae_operand_t *lo
                   link->kh, link->kw, s);
     ARVAE_REQUIRE(link->hh % s == 0 && link->hw % s == 0, "link_up: hi extent not a multiple of the stride");
     hipStream_t st = as_stream(stream);
+    if (dense_fits(link) && out_mask == nullptr && bias == nullptr && out_act == ARVAE_ACT_NONE)
+        return dense_dgrad(link, make_operand(lo), wt, hi, st);
+    if (conv32_fits(link) && out_mask == nullptr && lo->mask == nullptr && out_act != ARVAE_ACT_SELU &&
+        lo->act != ARVAE_ACT_SELU)
+        return conv32_up(link, make_operand(lo), wt, bias, out_act == ARVAE_ACT_RELU, nullptr, hi, st);
     if (link->chi == 1 && lo->y == nullptr && link->clo % 4 == 0 && link->lo_perm_c == 0) {
         const int total = link->n * link->hh * link->hw;
         Epilogue ep{bias, out_mask, hi, out_act};
@@ -566,38 +592,67 @@ static void wgrad_split(const arvae_link_t *link, int &m, int &n, int &pix, int 
     zsplit = (pix + chunk - 1) / chunk;
 }
 
+static void channel_sum_split(int64_t rows, int64_t &blocks, int64_t &rpb);
+static int channel_sum_launch(const Operand &g, int64_t rows, int channels, int perm_c, int perm_hw, float *out,
+                              float *ws, hipStream_t st);
+
+static bool wgrad_fast(const arvae_link_t *l, const arvae_operand_t *lo, const arvae_operand_t *hi) {
+    return conv32_fits(l) && (lo == nullptr || (lo->mask == nullptr && lo->act != ARVAE_ACT_SELU)) &&
+           (hi == nullptr || (hi->mask == nullptr && hi->act != ARVAE_ACT_SELU));
+}
+
 extern "C" int64_t arvae_link_wgrad_ws_floats(const arvae_link_t *link) {
     if (link == nullptr || link->n <= 0) return 0;
     int m, n, pix, zsplit, chunk;
     wgrad_split(link, m, n, pix, zsplit, chunk);
-    return zsplit > 1 ? (int64_t)zsplit * m * n : 0;
+    int64_t need = zsplit > 1 ? (int64_t)zsplit * m * n : 0;
+    // bias sums share the workspace (stream ordered): the larger of the lo- and hi-side partial buffers
+    int64_t blocks, rpb;
+    channel_sum_split((int64_t)link->n * link->lh * link->lw, blocks, rpb);
+    if (blocks * link->clo > need) need = blocks * link->clo;
+    channel_sum_split((int64_t)link->n * link->hh * link->hw, blocks, rpb);
+    if (blocks * link->chi > need) need = blocks * link->chi;
+    if (conv32_fits(link) && conv32_wgrad_ws_floats(link) > need) need = conv32_wgrad_ws_floats(link);
+    return need;
 }
 
 extern "C" int arvae_link_wgrad(const arvae_link_t *link, const arvae_operand_t *lo, const arvae_operand_t *hi,
-                                float *dwt, float *ws, arvae_stream_t stream) {
+                                float *dwt, float *dbias, int32_t bias_side, float *ws, arvae_stream_t stream) {
     WgradPolicy p;
     if (int rc = make_geom(link, p.g)) return rc;
     ARVAE_REQUIRE(lo && lo->v && hi && hi->v && dwt, "link_wgrad: null pointer");
+    ARVAE_REQUIRE(bias_side >= 0 && bias_side <= 2 && (bias_side == 0 || dbias != nullptr), "link_wgrad: bad bias request");
+    ARVAE_REQUIRE(ws != nullptr || arvae_link_wgrad_ws_floats(link) == 0,
+                  "link_wgrad: workspace of arvae_link_wgrad_ws_floats() floats needed");
+    hipStream_t st = as_stream(stream);
+    if (dense_fits(link) && hi->y == nullptr && bias_side != 2)
+        return dense_wgrad(link, make_operand(lo), hi->v, dwt, bias_side == 1 ? dbias : nullptr, st);
+    if (wgrad_fast(link, lo, hi))
+        return conv32_wgrad(link, make_operand(lo), make_operand(hi), dwt, dbias, bias_side, ws, st);
     p.lo = make_operand(lo);
     p.hi = make_operand(hi);
     p.dwt = dwt;
     p.slab = ws;
     wgrad_split(link, p.M, p.N, p.P, p.zsplit, p.chunk);
-    ARVAE_REQUIRE(p.zsplit == 1 || ws != nullptr, "link_wgrad: workspace of arvae_link_wgrad_ws_floats() floats needed");
     ARVAE_REQUIRE((int64_t)p.zsplit * p.M * p.N < (1ll << 31), "link_wgrad: slab too large");
-    hipStream_t st = as_stream(stream);
     if (int rc = launch_gemm(p, p.M, p.N, p.zsplit, false, st, "link_wgrad")) return rc;
     if (p.zsplit > 1) {
         const int mn = p.M * p.N;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((mn + 63) / 64), dim3(256), 0, st, ws, p.zsplit, mn, p.N,
                            link->kh * link->kw, FastDiv(p.N), FastDiv(link->chi), dwt);
-        return check_launch("link_wgrad(reduce)");
+        if (int rc = check_launch("link_wgrad(reduce)")) return rc;
     }
+    if (bias_side == 1)
+        return channel_sum_launch(p.lo, (int64_t)link->n * link->lh * link->lw, link->clo, link->lo_perm_c,
+                                  link->lo_perm_hw, dbias, ws, st);
+    if (bias_side == 2)
+        return channel_sum_launch(p.hi, (int64_t)link->n * link->hh * link->hw, link->chi, link->hi_perm_c,
+                                  link->hi_perm_hw, dbias, ws, st);
     return ARVAE_OK;
 }
 
 static void channel_sum_split(int64_t rows, int64_t &blocks, int64_t &rpb) {
-    blocks = (rows + 127) / 128;
+    blocks = (rows + 15) / 16;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     rpb = (rows + blocks - 1) / blocks;
@@ -611,19 +666,23 @@ extern "C" int64_t arvae_channel_sum_ws_floats(int64_t rows, int32_t channels) {
     return blocks * channels;
 }
 
-extern "C" int arvae_channel_sum(const arvae_operand_t *g, int64_t rows, int32_t channels, int32_t perm_c,
-                                 int32_t perm_hw, float *out, float *ws, arvae_stream_t stream) {
-    ARVAE_REQUIRE(g && g->v && out && ws, "channel_sum: null pointer");
-    ARVAE_REQUIRE(rows > 0 && channels > 0, "channel_sum: empty tensor");
-    ARVAE_REQUIRE(perm_c == 0 || perm_c * perm_hw == channels, "channel_sum: perm does not cover channels");
+static int channel_sum_launch(const Operand &g, int64_t rows, int channels, int perm_c, int perm_hw, float *out,
+                              float *ws, hipStream_t st) {
     int64_t blocks, rpb;
     channel_sum_split(rows, blocks, rpb);
-    hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(channel_sum_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, make_operand(g), rows,
-                       channels, rpb, 0, 0, ws);
+    hipLaunchKernelGGL(channel_sum_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, g, rows, channels, rpb, 0, 0,
+                       ws);
     if (int rc = check_launch("channel_sum")) return rc;
     Operand part{ws, nullptr, nullptr, ARVAE_ACT_NONE};
     hipLaunchKernelGGL(channel_sum_kernel<true>, dim3(1), dim3(256), 0, st, part, blocks, channels, blocks, perm_c,
                        perm_hw, out);
     return check_launch("channel_sum(finish)");
+}
+
+extern "C" int arvae_channel_sum(const arvae_operand_t *g, int64_t rows, int32_t channels, int32_t perm_c,
+                                 int32_t perm_hw, float *out, float *ws, arvae_stream_t stream) {
+    ARVAE_REQUIRE(g && g->v && out && ws, "channel_sum: null pointer");
+    ARVAE_REQUIRE(rows > 0 && channels > 0, "channel_sum: empty tensor");
+    ARVAE_REQUIRE(perm_c == 0 || perm_c * perm_hw == channels, "channel_sum: perm does not cover channels");
+    return channel_sum_launch(make_operand(g), rows, channels, perm_c, perm_hw, out, ws, as_stream(stream));
 }

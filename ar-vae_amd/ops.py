@@ -150,15 +150,16 @@ def link_up(link: Link, n, lo_op, wt, bias, act, out_mask, out=None):
     return hi
 
 
-def link_wgrad(link: Link, n, lo_op, hi_op, dwt):
-    """dwt += weight gradient (accumulates)."""
+def link_wgrad(link: Link, n, lo_op, hi_op, dwt, dbias=None, bias_side=0):
+    """dwt += weight gradient; dbias += bias gradient (bias_side 1: sums of lo, 2: sums of hi). Accumulates."""
     lib = _lib.load()
     d = link.desc(n)
     nws = lib.arvae_link_wgrad_ws_floats(ctypes.byref(d))
     ws = torch.empty(nws, device=dwt.device, dtype=torch.float32) if nws else None
-    with _timed('link_gemm<wgrad>', *_link_cost(link, n, lo_op)):
+    with _timed('link_wgrad', *_link_cost(link, n, lo_op)):
         _lib.check(lib.arvae_link_wgrad(ctypes.byref(d), ctypes.byref(lo_op), ctypes.byref(hi_op), _ptr(dwt),
-                                        _ptr(ws), _stream()), 'link_wgrad')
+                                        _ptr(dbias), bias_side if dbias is not None else 0, _ptr(ws), _stream()),
+                   'link_wgrad')
     return dwt
 
 
@@ -209,14 +210,17 @@ class _LinkDownFn(Function):
         d_hi = d_wt = d_bias = None
         if ctx.needs_input_grad[0]:
             d_hi = link_up(link, n, gop, wt, None, ACT_NONE, None)
+        want_bias = ctx.bias_ref is not None and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             buf, direct = _grad_target(ctx.wt_ref)
-            link_wgrad(link, n, gop, _operand(hi), buf)
+            bbuf, bdirect = _grad_target(ctx.bias_ref) if want_bias else (None, True)
+            link_wgrad(link, n, gop, _operand(hi), buf, bbuf, 1)
             d_wt = None if direct else buf
-        if ctx.bias_ref is not None and ctx.needs_input_grad[2]:
-            buf, direct = _grad_target(ctx.bias_ref)
-            channel_sum(gop, n * link.lh * link.lw, link.clo, link.lo_perm, buf)
-            d_bias = None if direct else buf
+            d_bias = None if bdirect else bbuf
+        elif want_bias:
+            bbuf, bdirect = _grad_target(ctx.bias_ref)
+            channel_sum(gop, n * link.lh * link.lw, link.clo, link.lo_perm, bbuf)
+            d_bias = None if bdirect else bbuf
         return d_hi, d_wt, d_bias, None, None, None
 
 
@@ -243,14 +247,17 @@ class _LinkUpFn(Function):
         d_lo = d_wt = d_bias = None
         if ctx.needs_input_grad[0]:
             d_lo = link_down(link, n, gop, wt, None, ACT_NONE, None)
+        want_bias = ctx.bias_ref is not None and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             buf, direct = _grad_target(ctx.wt_ref)
-            link_wgrad(link, n, _operand(lo), gop, buf)
+            bbuf, bdirect = _grad_target(ctx.bias_ref) if want_bias else (None, True)
+            link_wgrad(link, n, _operand(lo), gop, buf, bbuf, 2)
             d_wt = None if direct else buf
-        if ctx.bias_ref is not None and ctx.needs_input_grad[2]:
-            buf, direct = _grad_target(ctx.bias_ref)
-            channel_sum(gop, n * link.hh * link.hw, link.chi, link.hi_perm, buf)
-            d_bias = None if direct else buf
+            d_bias = None if bdirect else bbuf
+        elif want_bias:
+            bbuf, bdirect = _grad_target(ctx.bias_ref)
+            channel_sum(gop, n * link.hh * link.hw, link.chi, link.hi_perm, bbuf)
+            d_bias = None if bdirect else bbuf
         return d_lo, d_wt, d_bias, None, None, None
 
 

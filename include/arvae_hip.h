@@ -97,10 +97,12 @@ int arvae_link_up(const arvae_link_t *link, const arvae_operand_t *lo, const flo
 
 /* dwt[clo][chi][ky][kx] += sum_{n,ly,lx} lo * hi   (accumulates).  The batch is split over workgroups;
  * partial tiles go to `ws` (arvae_link_wgrad_ws_floats(link) floats, may be 0 -> ws unused) and are summed
- * in a fixed order: bitwise reproducible, no float atomics. */
+ * in a fixed order: bitwise reproducible, no float atomics.
+ * The bias gradient rides along: bias_side 1: dbias[clo] += sum_pixels lo (nn.Conv2d / nn.Linear, whose
+ * output is the lo tensor); 2: dbias[chi] += sum_pixels hi (nn.ConvTranspose2d); 0: none (dbias unused). */
 int64_t arvae_link_wgrad_ws_floats(const arvae_link_t *link);
 int arvae_link_wgrad(const arvae_link_t *link, const arvae_operand_t *lo, const arvae_operand_t *hi,
-                     float *dwt, float *ws, arvae_stream_t stream);
+                     float *dwt, float *dbias, int32_t bias_side, float *ws, arvae_stream_t stream);
 
 /* out[c] += sum_rows operand[row, c]  for a [rows, channels] channels-last view (bias gradients).
  * perm_c/perm_hw as in arvae_link_t (out is indexed by the flattened NCHW feature).
