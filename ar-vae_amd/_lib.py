@@ -26,6 +26,22 @@ class OperandDesc(ctypes.Structure):
     _fields_ = [('v', c_vp), ('y', c_vp), ('mask', c_vp), ('act', c_i32)]
 
 
+class LayerDesc(ctypes.Structure):
+    """arvae_layer_t"""
+    _fields_ = [('link', LinkDesc), ('is_up', c_i32), ('act', c_i32), ('dropout', c_i32), ('reserved', c_i32),
+                ('w_off', c_i64), ('b_off', c_i64)]
+
+
+MAX_LAYERS = 8
+
+
+class ImageVaeDesc(ctypes.Structure):
+    """arvae_image_vae_t"""
+    _fields_ = [('n_enc', c_i32), ('n_dec', c_i32), ('enc', LayerDesc * MAX_LAYERS), ('dec', LayerDesc * MAX_LAYERS),
+                ('head_mu', LayerDesc), ('head_log_std', LayerDesc), ('zdim', c_i32), ('recon_dist', c_i32),
+                ('n_reg', c_i32), ('reg_dims', c_i32 * 16), ('beta', c_f32), ('gamma', c_f32), ('delta', c_f32)]
+
+
 _P = ctypes.POINTER
 # name -> (restype, argtypes); must list every symbol declared in include/arvae_hip.h
 SIGNATURES = {
@@ -49,6 +65,11 @@ SIGNATURES = {
     'arvae_image_recon': (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
     'arvae_token_recon': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
     'arvae_scale_by_scalar': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp]),
+    'arvae_image_vae_ws_floats': (c_i64, [_P(ImageVaeDesc), c_i32, c_i64]),
+    'arvae_image_vae_forward': (c_i32, [_P(ImageVaeDesc), c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, _P(c_vp), c_vp, c_vp,
+                                        c_vp, c_i64, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'arvae_image_vae_backward': (c_i32, [_P(ImageVaeDesc), c_i32, c_vp, c_vp, c_vp, c_vp, _P(c_vp), c_vp, c_vp, c_vp,
+                                         c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_vp, c_vp]),
     'arvae_adam_step': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_f64, c_f64, c_f64, c_f64, c_f32, c_vp]),
 }
 

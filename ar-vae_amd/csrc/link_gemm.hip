@@ -26,6 +26,15 @@ int dense_fwd(const arvae_link_t *l, const float *x, const float *w, const float
 int dense_dgrad(const arvae_link_t *l, const Operand &g, const float *w, float *dx, hipStream_t s);
 int dense_wgrad(const arvae_link_t *l, const Operand &g, const float *x, float *dw, float *dbias, hipStream_t s);
 
+// 1-channel 64x64 image links (conv_c1.hip)
+bool conv_c1_fits(const arvae_link_t *l);
+int conv_c1_down(const arvae_link_t *l, const Operand &img, const float *wt, const float *bias, int relu,
+                 const float *gate, float *out, hipStream_t s);
+int conv_c1_up(const arvae_link_t *l, const float *lo, const float *wt, const float *bias, float *out, hipStream_t s);
+int64_t conv_c1_wgrad_ws_floats(const arvae_link_t *l);
+int conv_c1_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &img, float *dwt, float *dbias, int bias_mode,
+                  float *slab, hipStream_t s);
+
 // specialised 32-channel k4/s2/p1 kernels (conv32.hip)
 bool conv32_fits(const arvae_link_t *l);
 int conv32_down(const arvae_link_t *l, const Operand &hi, const float *wt, const float *bias, int relu,
@@ -529,6 +538,9 @@ extern "C" int arvae_link_down(const arvae_link_t *link, const arvae_operand_t *
     if (conv32_fits(link) && out_mask == nullptr && hi->mask == nullptr && out_act != ARVAE_ACT_SELU &&
         hi->act != ARVAE_ACT_SELU)
         return conv32_down(link, make_operand(hi), wt, bias, out_act == ARVAE_ACT_RELU, nullptr, lo, as_stream(stream));
+    if (conv_c1_fits(link) && out_mask == nullptr && hi->mask == nullptr && out_act != ARVAE_ACT_SELU &&
+        hi->act != ARVAE_ACT_SELU)
+        return conv_c1_down(link, make_operand(hi), wt, bias, out_act == ARVAE_ACT_RELU, nullptr, lo, as_stream(stream));
     p.hi = make_operand(hi);
     p.wt = wt;
     p.ep = Epilogue{bias, out_mask, lo, out_act};
@@ -554,6 +566,8 @@ extern "C" int arvae_link_up(const arvae_link_t *link, const arvae_operand_t *lo
     if (conv32_fits(link) && out_mask == nullptr && lo->mask == nullptr && out_act != ARVAE_ACT_SELU &&
         lo->act != ARVAE_ACT_SELU)
         return conv32_up(link, make_operand(lo), wt, bias, out_act == ARVAE_ACT_RELU, nullptr, hi, st);
+    if (conv_c1_fits(link) && lo->y == nullptr && out_mask == nullptr && out_act == ARVAE_ACT_NONE)
+        return conv_c1_up(link, lo->v, wt, bias, hi, st);
     if (link->chi == 1 && lo->y == nullptr && link->clo % 4 == 0 && link->lo_perm_c == 0) {
         const int total = link->n * link->hh * link->hw;
         Epilogue ep{bias, out_mask, hi, out_act};
@@ -613,6 +627,7 @@ extern "C" int64_t arvae_link_wgrad_ws_floats(const arvae_link_t *link) {
     channel_sum_split((int64_t)link->n * link->hh * link->hw, blocks, rpb);
     if (blocks * link->chi > need) need = blocks * link->chi;
     if (conv32_fits(link) && conv32_wgrad_ws_floats(link) > need) need = conv32_wgrad_ws_floats(link);
+    if (conv_c1_fits(link) && conv_c1_wgrad_ws_floats(link) > need) need = conv_c1_wgrad_ws_floats(link);
     return need;
 }
 
@@ -627,6 +642,9 @@ extern "C" int arvae_link_wgrad(const arvae_link_t *link, const arvae_operand_t 
     hipStream_t st = as_stream(stream);
     if (dense_fits(link) && hi->y == nullptr && bias_side != 2)
         return dense_wgrad(link, make_operand(lo), hi->v, dwt, bias_side == 1 ? dbias : nullptr, st);
+    if (conv_c1_fits(link) && lo->mask == nullptr && hi->mask == nullptr && lo->act != ARVAE_ACT_SELU &&
+        hi->act != ARVAE_ACT_SELU)
+        return conv_c1_wgrad(link, make_operand(lo), make_operand(hi), dwt, dbias, bias_side, ws, st);
     if (wgrad_fast(link, lo, hi))
         return conv32_wgrad(link, make_operand(lo), make_operand(hi), dwt, dbias, bias_side, ws, st);
     p.lo = make_operand(lo);

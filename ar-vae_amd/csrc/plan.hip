@@ -1,0 +1,273 @@
+// Whole-model forward / backward executors for the conv AR-VAEs (see include/arvae_hip.h): one host call
+// enqueues every kernel of a pass on the caller's stream.  Host-side sequencing only -- the math lives in
+// the link / dense / loss kernels, reached through the same C-ABI entry points a per-layer caller uses.
+#include "common.h"
+
+namespace arvae {
+
+// ---- small glue kernels ---------------------------------------------------------------------------
+// scalars = [loss, recon, dist, reg_scaled, acc, kl]
+__global__ void vae_scalars_kernel(const float *__restrict__ rec, const float *__restrict__ kld,
+                                   const float *__restrict__ reg, float reg_scale, float *__restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const float r = reg != nullptr ? reg_scale * reg[0] : 0.f;
+        out[ARVAE_VAE_RECON] = rec[0];
+        out[ARVAE_VAE_ACC] = rec[1];
+        out[ARVAE_VAE_DIST] = kld[0];
+        out[ARVAE_VAE_KL] = kld[1];
+        out[ARVAE_VAE_REG] = r;
+        out[ARVAE_VAE_LOSS] = rec[0] + kld[0] + r;
+        out[6] = out[7] = 0.f;
+    }
+}
+
+// gradient of the loss w.r.t. (mu, log_std) from: the decoder path g_z (already times g), the
+// regularisation gradient dz_reg (unit upstream, scaled by g*reg_scale here), an optional external
+// z gradient, and the beta-KL term; sigma = exp(log_std), z = mu + eps*sigma.
+__global__ __launch_bounds__(256) void latent_bwd_full_kernel(const float *__restrict__ g_z, const float *__restrict__ dz_reg,
+                                                               const float *__restrict__ dz_extra, const float *__restrict__ mu,
+                                                               const float *__restrict__ sigma, const float *__restrict__ eps,
+                                                               const float *__restrict__ g_loss, const float *__restrict__ kl,
+                                                               const float *__restrict__ cap, float beta, float inv_batch,
+                                                               float reg_scale, int64_t count, float *__restrict__ d_mu,
+                                                               float *__restrict__ d_ls) {
+    const float g = g_loss[0];
+    const float diff = kl[0] - (cap != nullptr ? cap[0] : 0.f);
+    const float k = g * beta * (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f)) * inv_batch;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+        float gz = g_z[i];
+        if (dz_reg != nullptr) gz += g * reg_scale * dz_reg[i];
+        if (dz_extra != nullptr) gz += dz_extra[i];
+        const float s = sigma[i];
+        d_mu[i] = gz + k * mu[i];
+        d_ls[i] = (gz * eps[i] + k * (s - 1.f / s)) * s;
+    }
+}
+
+__global__ __launch_bounds__(256) void add_inplace_kernel(float *__restrict__ a, const float *__restrict__ b, int64_t count) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) a[i] += b[i];
+}
+
+// ---- workspace layout ------------------------------------------------------------------------------
+static inline int64_t up4(int64_t v) { return (v + 3) / 4 * 4; }
+
+static inline int64_t out_elems(const arvae_layer_t &l, int64_t n) {
+    return l.is_up ? n * l.link.hh * l.link.hw * l.link.chi : n * l.link.lh * l.link.lw * l.link.clo;
+}
+static inline int64_t in_elems(const arvae_layer_t &l, int64_t n) {
+    return l.is_up ? n * l.link.lh * l.link.lw * l.link.clo : n * l.link.hh * l.link.hw * l.link.chi;
+}
+
+struct Layout {
+    int64_t enc_out[ARVAE_MAX_LAYERS], dec_out[ARVAE_MAX_LAYERS];   // dec_out[last] unused (logits are external)
+    int64_t log_std, dlogits, dz_reg, d_mu, d_ls, g_a, g_b, slab, rec_ws, reg_ws, rec_out, kld_out, reg_out, total;
+    int64_t slab_floats;
+};
+
+static int make_layout(const arvae_image_vae_t *m, int64_t n, int64_t n_cols, Layout &L) {
+    ARVAE_REQUIRE(m != nullptr && n > 0, "image_vae: null model or empty batch");
+    ARVAE_REQUIRE(m->n_enc >= 1 && m->n_enc <= ARVAE_MAX_LAYERS && m->n_dec >= 1 && m->n_dec <= ARVAE_MAX_LAYERS,
+                  "image_vae: layer counts out of range");
+    ARVAE_REQUIRE(m->zdim > 0 && m->n_reg >= 0 && m->n_reg <= 16, "image_vae: bad zdim / n_reg");
+    int64_t off = 0, gmax = 0, slab = 0;
+    auto take = [&](int64_t count) { const int64_t o = off; off += up4(count); return o; };
+    auto visit = [&](const arvae_layer_t &l) {
+        arvae_link_t lk = l.link;
+        lk.n = (int32_t)n;
+        const int64_t s = arvae_link_wgrad_ws_floats(&lk);
+        if (s > slab) slab = s;
+        if (out_elems(l, n) > gmax) gmax = out_elems(l, n);
+        if (in_elems(l, n) > gmax) gmax = in_elems(l, n);
+    };
+    for (int i = 0; i < m->n_enc; ++i) { L.enc_out[i] = take(out_elems(m->enc[i], n)); visit(m->enc[i]); }
+    for (int i = 0; i < m->n_dec; ++i) {
+        L.dec_out[i] = (i + 1 < m->n_dec) ? take(out_elems(m->dec[i], n)) : -1;
+        visit(m->dec[i]);
+    }
+    visit(m->head_mu);
+    visit(m->head_log_std);
+    const int64_t bz = n * m->zdim;
+    L.log_std = take(bz);
+    L.dlogits = take(out_elems(m->dec[m->n_dec - 1], n));
+    L.dz_reg = take(bz);
+    L.d_mu = take(bz);
+    L.d_ls = take(bz);
+    L.g_a = take(gmax);
+    L.g_b = take(gmax);
+    L.slab_floats = slab;
+    L.slab = take(slab);
+    L.rec_ws = take(arvae_recon_ws_floats(out_elems(m->dec[m->n_dec - 1], n)));
+    L.reg_ws = take(arvae_reg_loss_ws_floats(n, m->n_reg > 0 ? m->n_reg : 1));
+    L.rec_out = take(4);
+    L.kld_out = take(4);
+    L.reg_out = take(4);
+    L.total = off;
+    (void)n_cols;
+    return ARVAE_OK;
+}
+
+static arvae_operand_t plain(const float *v) { return arvae_operand_t{v, nullptr, nullptr, ARVAE_ACT_NONE}; }
+
+static int layer_forward(const arvae_layer_t &l, int32_t n, const float *params, const float *in, const uint8_t *mask,
+                         float *out, arvae_stream_t st) {
+    arvae_link_t lk = l.link;
+    lk.n = n;
+    const arvae_operand_t op = plain(in);
+    const float *w = params + l.w_off, *b = l.b_off >= 0 ? params + l.b_off : nullptr;
+    return l.is_up ? arvae_link_up(&lk, &op, w, b, l.act, mask, out, st) : arvae_link_down(&lk, &op, w, b, l.act, mask, out, st);
+}
+
+// g_out: gradient w.r.t. the layer's OUTPUT (after activation / dropout); d_in may be null (first layer)
+static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params, float *grads, const float *in,
+                          const float *out, const uint8_t *mask, const float *g_out, float *d_in, float *slab,
+                          arvae_stream_t st) {
+    arvae_link_t lk = l.link;
+    lk.n = n;
+    const arvae_operand_t gop{g_out, out, mask, l.act};
+    const arvae_operand_t xin = plain(in);
+    const float *w = params + l.w_off;
+    float *dw = grads + l.w_off, *db = l.b_off >= 0 ? grads + l.b_off : nullptr;
+    if (l.is_up) {
+        if (d_in != nullptr)
+            if (int rc = arvae_link_down(&lk, &gop, w, nullptr, ARVAE_ACT_NONE, nullptr, d_in, st)) return rc;
+        return arvae_link_wgrad(&lk, &xin, &gop, dw, db, db ? 2 : 0, slab, st);
+    }
+    if (d_in != nullptr)
+        if (int rc = arvae_link_up(&lk, &gop, w, nullptr, ARVAE_ACT_NONE, nullptr, d_in, st)) return rc;
+    return arvae_link_wgrad(&lk, &gop, &xin, dw, db, db ? 1 : 0, slab, st);
+}
+
+static int count_masks(const arvae_image_vae_t *m) {
+    int c = 0;
+    for (int i = 0; i < m->n_enc; ++i) c += m->enc[i].dropout != 0;
+    for (int i = 0; i < m->n_dec; ++i) c += m->dec[i].dropout != 0;
+    return c;
+}
+
+}  // namespace arvae
+
+using namespace arvae;
+
+extern "C" int64_t arvae_image_vae_ws_floats(const arvae_image_vae_t *model, int32_t batch, int64_t n_cols) {
+    Layout L;
+    if (make_layout(model, batch, n_cols, L)) return -1;
+    return L.total;
+}
+
+extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch, const float *params, const float *x,
+                                       const float *labels, int64_t ld_labels, const float *eps,
+                                       const uint8_t *const *masks, const float *capacity, const float *z_cols,
+                                       const float *lab_cols, int64_t n_cols, float reg_scale, float *ws,
+                                       float *scalars, float *mu, float *sigma, float *z, float *logits,
+                                       arvae_stream_t stream) {
+    Layout L;
+    if (int rc = make_layout(m, batch, n_cols, L)) return rc;
+    ARVAE_REQUIRE(params && x && eps && ws && scalars && mu && sigma && z && logits, "image_vae_forward: null pointer");
+    ARVAE_REQUIRE(m->n_reg == 0 || n_cols < 0 || labels != nullptr, "image_vae_forward: labels needed for the reg loss");
+    hipStream_t st = as_stream(stream);
+    int mi = 0;
+    // encoder
+    const float *h = x;
+    for (int i = 0; i < m->n_enc; ++i) {
+        const uint8_t *mask = (masks != nullptr && m->enc[i].dropout) ? masks[mi] : nullptr;
+        mi += m->enc[i].dropout != 0;
+        if (int rc = layer_forward(m->enc[i], batch, params, h, mask, ws + L.enc_out[i], stream)) return rc;
+        h = ws + L.enc_out[i];
+    }
+    if (int rc = layer_forward(m->head_mu, batch, params, h, nullptr, mu, stream)) return rc;
+    if (int rc = layer_forward(m->head_log_std, batch, params, h, nullptr, ws + L.log_std, stream)) return rc;
+    const int64_t bz = (int64_t)batch * m->zdim;
+    if (int rc = arvae_latent_fwd(mu, ws + L.log_std, eps, bz, sigma, z, stream)) return rc;
+    // decoder
+    h = z;
+    for (int i = 0; i < m->n_dec; ++i) {
+        const uint8_t *mask = (masks != nullptr && m->dec[i].dropout) ? masks[mi] : nullptr;
+        mi += m->dec[i].dropout != 0;
+        float *out = (i + 1 < m->n_dec) ? ws + L.dec_out[i] : logits;
+        if (int rc = layer_forward(m->dec[i], batch, params, h, mask, out, stream)) return rc;
+        h = out;
+    }
+    // loss terms
+    const int64_t pix = out_elems(m->dec[m->n_dec - 1], batch);
+    if (int rc = arvae_image_recon(logits, x, pix, batch, m->recon_dist, ws + L.rec_ws, ws + L.rec_out, ws + L.dlogits,
+                                   stream))
+        return rc;
+    if (int rc = arvae_kld_fwd(mu, sigma, nullptr, nullptr, batch, m->zdim, m->beta, capacity, ws + L.kld_out, stream))
+        return rc;
+    const bool reg_here = m->n_reg > 0 && n_cols >= 0;
+    if (reg_here) {
+        const float *zc = z_cols != nullptr ? z_cols : z;
+        const float *lc = lab_cols != nullptr ? lab_cols : labels;
+        const int64_t nc = z_cols != nullptr ? n_cols : batch;
+        if (int rc = arvae_reg_loss(z, labels, batch, zc, lc, nc, m->zdim, ld_labels, m->reg_dims, m->n_reg, m->gamma,
+                                    m->delta, ws + L.reg_ws, ws + L.reg_out, ws + L.dz_reg, stream))
+            return rc;
+    }
+    hipLaunchKernelGGL(vae_scalars_kernel, dim3(1), dim3(64), 0, st, ws + L.rec_out, ws + L.kld_out,
+                       reg_here ? ws + L.reg_out : nullptr, reg_scale, scalars);
+    return check_launch("image_vae_forward(scalars)");
+}
+
+extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batch, const float *params, float *grads,
+                                        const float *x, const float *eps, const uint8_t *const *masks,
+                                        const float *capacity, const float *mu, const float *sigma, const float *z,
+                                        const float *logits, const float *g_loss, const float *dz_extra,
+                                        int32_t reg_fused, float reg_scale, float *ws, arvae_stream_t stream) {
+    Layout L;
+    if (int rc = make_layout(m, batch, 0, L)) return rc;
+    ARVAE_REQUIRE(params && grads && x && eps && mu && sigma && z && logits && g_loss && ws,
+                  "image_vae_backward: null pointer");
+    hipStream_t st = as_stream(stream);
+    // keep-mask index of every dropout layer, in forward order
+    int enc_mask[ARVAE_MAX_LAYERS], dec_mask[ARVAE_MAX_LAYERS], mi = 0;
+    for (int i = 0; i < m->n_enc; ++i) enc_mask[i] = m->enc[i].dropout ? mi++ : -1;
+    for (int i = 0; i < m->n_dec; ++i) dec_mask[i] = m->dec[i].dropout ? mi++ : -1;
+    auto mask_of = [&](int idx) -> const uint8_t * { return (masks != nullptr && idx >= 0) ? masks[idx] : nullptr; };
+
+    float *cur = ws + L.g_a, *other = ws + L.g_b, *slab = L.slab_floats ? ws + L.slab : nullptr;
+    const int64_t pix = out_elems(m->dec[m->n_dec - 1], batch);
+    const int64_t bz = (int64_t)batch * m->zdim;
+    if (int rc = arvae_scale_by_scalar(g_loss, ws + L.dlogits, pix, cur, stream)) return rc;
+    // decoder, last layer first
+    for (int i = m->n_dec - 1; i >= 0; --i) {
+        const float *in = i > 0 ? ws + L.dec_out[i - 1] : z;
+        const float *out = (i + 1 < m->n_dec) ? ws + L.dec_out[i] : logits;
+        if (int rc = layer_backward(m->dec[i], batch, params, grads, in, out, mask_of(dec_mask[i]), cur, other, slab,
+                                    stream))
+            return rc;
+        float *t = cur; cur = other; other = t;
+    }
+    // latent head (cur = gradient w.r.t. z from the decoder)
+    {
+        int64_t blocks = (bz + 255) / 256;
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(latent_bwd_full_kernel, dim3((unsigned)blocks), dim3(256), 0, st, cur,
+                           (reg_fused && m->n_reg > 0) ? ws + L.dz_reg : nullptr, dz_extra, mu, sigma, eps, g_loss,
+                           ws + L.kld_out + 1, capacity, m->beta, 1.f / (float)batch, reg_scale, bz, ws + L.d_mu,
+                           ws + L.d_ls);
+        if (int rc = check_launch("image_vae_backward(latent)")) return rc;
+    }
+    // heads: d_hidden = W_mu^T d_mu + W_ls^T d_ls
+    const float *hidden = ws + L.enc_out[m->n_enc - 1];
+    if (int rc = layer_backward(m->head_mu, batch, params, grads, hidden, nullptr, nullptr, ws + L.d_mu, cur, slab, stream))
+        return rc;
+    if (int rc = layer_backward(m->head_log_std, batch, params, grads, hidden, nullptr, nullptr, ws + L.d_ls, other, slab,
+                                stream))
+        return rc;
+    {
+        const int64_t hn = in_elems(m->head_mu, batch);
+        int64_t blocks = (hn + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)blocks), dim3(256), 0, st, cur, other, hn);
+        if (int rc = check_launch("image_vae_backward(add)")) return rc;
+    }
+    // encoder, last layer first; the image itself needs no gradient
+    for (int i = m->n_enc - 1; i >= 0; --i) {
+        const float *in = i > 0 ? ws + L.enc_out[i - 1] : x;
+        if (int rc = layer_backward(m->enc[i], batch, params, grads, in, ws + L.enc_out[i], mask_of(enc_mask[i]), cur,
+                                    i > 0 ? other : nullptr, slab, stream))
+            return rc;
+        float *t = cur; cur = other; other = t;
+    }
+    return ARVAE_OK;
+}

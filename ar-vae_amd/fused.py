@@ -1,0 +1,158 @@
+"""Whole-model training step for the conv AR-VAEs: forward (+ all loss terms) and backward are ONE C call each
+(arvae_image_vae_forward / arvae_image_vae_backward), so the host does no per-layer work.
+
+Used by ImageVAETrainer.loss_and_acc_for_batch when the model's parameters live in the trainer's flat
+Adam arena.  Autograd sees a single node: its backward accumulates every parameter gradient directly into the
+gradient arena and returns nothing for the parameters.
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib, ops
+from ._lib import ImageVaeDesc, LayerDesc
+
+LOSS, RECON, DIST, REG, ACC, KL, NSCALARS = 0, 1, 2, 3, 4, 5, 8
+
+
+def _layer_desc(link, is_up, act, dropout, w_off, b_off):
+    return LayerDesc(link.desc(0), int(is_up), int(act), int(dropout), 0, int(w_off), int(b_off))
+
+
+class FusedImageVAE:
+    """Descriptor + workspace cache binding a MnistVAE/DspritesVAE to a FlatAdam arena."""
+
+    def __init__(self, model, optimizer, reg_dims, beta, gamma, delta, dec_dist):
+        self.model, self.optimizer = model, optimizer
+        self.reg_dims = tuple(int(d) for d in reg_dims)
+        self.beta, self.gamma, self.delta = float(beta), float(gamma), float(delta)
+        self.dist = ops.RECON_DIST[dec_dist]
+        self._desc = None
+        self._arena_ptr = None
+        self._ws = {}
+
+    def _offset(self, param):
+        opt = self.optimizer
+        for p, off in zip(opt.params, opt._offsets):
+            if p is param:
+                return off
+        raise KeyError('parameter is not managed by the optimizer arena')
+
+    def descriptor(self):
+        arena = self.optimizer.ensure_arena()
+        if self._desc is not None and self._arena_ptr == arena.data_ptr():
+            return self._desc
+        m = self.model
+        d = ImageVaeDesc()
+        n_enc_conv = len(m.enc_conv_plan)
+        layers = []
+        for k, (idx, link) in enumerate(m.enc_conv_plan):
+            lay = m.enc_conv[idx]
+            layers.append(_layer_desc(link, 0, m.hidden_act, m.dropout_p > 0, self._offset(lay.weight),
+                                      self._offset(lay.bias)))
+        for idx, link in m.enc_lin_plan:
+            lay = m.enc_lin[idx]
+            layers.append(_layer_desc(link, 0, m.hidden_act, 0, self._offset(lay.weight), self._offset(lay.bias)))
+        d.n_enc = len(layers)
+        for i, l in enumerate(layers):
+            d.enc[i] = l
+        layers = []
+        for idx, link in m.dec_lin_plan:
+            lay = m.dec_lin[idx]
+            layers.append(_layer_desc(link, 0, m.hidden_act, 0, self._offset(lay.weight), self._offset(lay.bias)))
+        last = len(m.dec_conv_plan) - 1
+        for k, (idx, link) in enumerate(m.dec_conv_plan):
+            lay = m.dec_conv[idx]
+            hidden = k < last
+            layers.append(_layer_desc(link, 1, m.hidden_act if hidden else ops.ACT_NONE,
+                                      hidden and m.dropout_p > 0, self._offset(lay.weight), self._offset(lay.bias)))
+        d.n_dec = len(layers)
+        for i, l in enumerate(layers):
+            d.dec[i] = l
+        d.head_mu = _layer_desc(m.head_link, 0, ops.ACT_NONE, 0, self._offset(m.enc_mean.weight),
+                                self._offset(m.enc_mean.bias))
+        d.head_log_std = _layer_desc(m.head_link, 0, ops.ACT_NONE, 0, self._offset(m.enc_log_std.weight),
+                                     self._offset(m.enc_log_std.bias))
+        d.zdim, d.recon_dist = m.z_dim, self.dist
+        d.n_reg = len(self.reg_dims)
+        for i, r in enumerate(self.reg_dims):
+            d.reg_dims[i] = r
+        d.beta, d.gamma, d.delta = self.beta, self.gamma, self.delta
+        assert n_enc_conv <= d.n_enc
+        self._desc, self._arena_ptr = d, arena.data_ptr()
+        return d
+
+    def workspace(self, batch, device):
+        key = (batch, str(device))
+        ws = self._ws.get(key)
+        if ws is None:
+            n = _lib.load().arvae_image_vae_ws_floats(ctypes.byref(self.descriptor()), batch, 0)
+            if n < 0:
+                _lib.check(-1, 'image_vae_ws_floats')
+            ws = torch.empty(n, device=device, dtype=torch.float32)
+            self._ws = {key: ws}                      # keep one (batch-sized) workspace alive
+        return ws
+
+    def run(self, x, labels, eps, masks, capacity, external_reg=False, reg_scale=1.0):
+        """-> (scalars[8], acc, z, mu, sigma, logits); scalars[LOSS] carries the grad_fn."""
+        anchor = self.optimizer.params[0]
+        return _FusedStepFn.apply(anchor, self, x, labels, eps, masks, capacity, bool(external_reg), float(reg_scale))
+
+
+def _mask_array(masks):
+    if not masks or all(m is None for m in masks):
+        return None, None
+    arr = (ctypes.c_void_p * len(masks))(*[m.data_ptr() for m in masks])
+    return arr, masks
+
+
+class _FusedStepFn(Function):
+    @staticmethod
+    def forward(ctx, anchor, fused, x, labels, eps, masks, capacity, external_reg, reg_scale):
+        ops._dev(x, labels, eps, capacity)
+        lib = _lib.load()
+        desc = fused.descriptor()
+        opt = fused.optimizer
+        b = x.shape[0]
+        dev = x.device
+        ws = fused.workspace(b, dev)
+        zd = fused.model.z_dim
+        scalars = torch.empty(NSCALARS, device=dev, dtype=torch.float32)
+        mu = torch.empty(b, zd, device=dev, dtype=torch.float32)
+        sigma, z = torch.empty_like(mu), torch.empty_like(mu)
+        logits = torch.empty_like(x)
+        marr, keep = _mask_array(masks)
+        with ops._timed('image_vae_forward'):
+            _lib.check(lib.arvae_image_vae_forward(
+                ctypes.byref(desc), b, ops._ptr(opt.param_arena), ops._ptr(x), ops._ptr(labels),
+                labels.shape[1] if labels is not None else 0, ops._ptr(eps), marr, ops._ptr(capacity), None, None,
+                -1 if external_reg else 0, reg_scale, ops._ptr(ws), ops._ptr(scalars), ops._ptr(mu), ops._ptr(sigma),
+                ops._ptr(z), ops._ptr(logits), ops._stream()), 'image_vae_forward')
+        ctx.fused, ctx.masks, ctx.marr = fused, keep, marr
+        ctx.external_reg, ctx.reg_scale = external_reg, reg_scale
+        ctx.save_for_backward(x, eps, capacity, mu, sigma, z, logits)
+        acc = scalars[ACC]
+        ctx.mark_non_differentiable(acc, mu, sigma, logits)
+        if not external_reg:
+            ctx.mark_non_differentiable(z)
+        return scalars, acc, z, mu, sigma, logits
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_scalars, _g_acc, g_z, _g_mu, _g_sigma, _g_logits):
+        x, eps, capacity, mu, sigma, z, logits = ctx.saved_tensors
+        fused = ctx.fused
+        lib = _lib.load()
+        opt = fused.optimizer
+        g_loss = g_scalars[LOSS:LOSS + 1].contiguous()
+        dz_extra = g_z.contiguous() if (ctx.external_reg and g_z is not None) else None
+        ws = fused.workspace(x.shape[0], x.device)
+        with ops._timed('image_vae_backward'):
+            _lib.check(lib.arvae_image_vae_backward(
+                ctypes.byref(fused.descriptor()), x.shape[0], ops._ptr(opt.param_arena), ops._ptr(opt.grad_arena),
+                ops._ptr(x), ops._ptr(eps), ctx.marr, ops._ptr(capacity), ops._ptr(mu), ops._ptr(sigma), ops._ptr(z),
+                ops._ptr(logits), ops._ptr(g_loss), ops._ptr(dz_extra), 0 if ctx.external_reg else 1, ctx.reg_scale,
+                ops._ptr(ws), ops._stream()), 'image_vae_backward')
+        return (None,) * 9

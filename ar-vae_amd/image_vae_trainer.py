@@ -61,6 +61,8 @@ class ImageVAETrainer(Trainer):
             self.trainer_config += f'g_{self.gamma}_d_{self.delta}_' + '_'.join(self.reg_type) + '_'
         self.model.update_trainer_config(self.trainer_config)
         self.last_terms = {}
+        self.use_fused = True          # whole-model C calls (arvae_amd.fused); False = one autograd node per layer
+        self._fused = None
 
     def cuda(self):
         super().cuda()
@@ -82,6 +84,8 @@ class ImageVAETrainer(Trainer):
         inputs, labels = batch
         if self.capacity.device != inputs.device:
             self.capacity = self.capacity.to(inputs.device)
+        if self.use_fused and inputs.is_cuda:
+            return self._fused_loss_and_acc(inputs, labels, first_of_epoch, epoch_num, batch_num, train)
 
         outputs, z_dist, prior_dist, z_tilde, _ = self.model(inputs)
         recons_loss, accuracy = ops.image_recon(outputs, inputs, self.dec_dist)
@@ -109,6 +113,42 @@ class ImageVAETrainer(Trainer):
             self.writer.add_image('reconstruction',
                                   image_grid(torch.cat([inputs[:n], torch.sigmoid(outputs[:n].detach())]).cpu(), n),
                                   epoch_num)
+        return loss, accuracy
+
+    def _fused_loss_and_acc(self, inputs, labels, first_of_epoch, epoch_num, batch_num, train):
+        """Same loss as above through arvae_image_vae_forward / _backward (one C call per pass)."""
+        from .fused import DIST, LOSS, RECON, REG, FusedImageVAE
+        if type(self.reg_dim) != tuple and self.use_reg_loss:
+            raise TypeError('Regularization dimension must be a tuple of integers')
+        model = self.model
+        if self._fused is None:
+            self._fused = FusedImageVAE(model, self.optimizer, self.reg_dim if self.use_reg_loss else (), self.beta,
+                                        self.gamma, self.delta, self.dec_dist)
+        n = inputs.size(0)
+        x = inputs.contiguous().view(n, model.image_hw, model.image_hw, 1)
+        masks = model._next_masks(n, inputs.device)
+        eps = model._noise(torch.empty(n, model.z_dim, device=inputs.device))
+        dp = self.data_parallel if self.use_reg_loss else None
+        scalars, accuracy, z, mu, sigma, logits = self._fused.run(x, labels, eps, masks, self.capacity,
+                                                                  external_reg=dp is not None)
+        loss = scalars[LOSS:LOSS + 1]
+        reg_loss = scalars[REG].detach() if self.use_reg_loss else None
+        if dp is not None:
+            reg_loss = dp.reg_loss(z, labels, self.reg_dim, self.gamma, self.delta)
+            loss = loss + reg_loss
+            reg_loss = reg_loss.detach()
+        self.last_terms = {'recons': scalars[RECON].detach(), 'dist': scalars[DIST].detach(), 'reg': reg_loss}
+        self.last_outputs = {'logits': logits.view(inputs.size()), 'z': z, 'mu': mu, 'sigma': sigma}
+        if first_of_epoch and self.writer is not None:
+            self.writer.add_scalar('loss_split/recons_loss', scalars[RECON].item(), epoch_num)
+            self.writer.add_scalar('loss_split/dist_loss', scalars[DIST].item() / self.beta, epoch_num)
+            if reg_loss is not None:
+                self.writer.add_scalar('loss_split/reg_loss', reg_loss.item() / self.gamma, epoch_num)
+        if not train and batch_num == 0 and self.writer is not None:
+            from .logging_utils import image_grid
+            k = min(n, 16)
+            recon = torch.sigmoid(logits.view(inputs.size())[:k].detach())
+            self.writer.add_image('reconstruction', image_grid(torch.cat([inputs[:k], recon]).cpu(), k), epoch_num)
         return loss, accuracy
 
     # -- static helpers (image_vae_trainer.py:623-655) ---------------------------------------------------

@@ -181,6 +181,75 @@ int arvae_scale_by_scalar(const float *g, const float *x, int64_t count, float *
 int arvae_adam_step(float *p, const float *g, float *m, float *v, int64_t count, int64_t step, double lr,
                     double beta1, double beta2, double eps, float grad_scale, arvae_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Whole-model step for the conv VAEs: ONE call enqueues every kernel of the forward pass (+ loss terms)
+ * or of the backward pass, so the host does no per-layer work.  Replaces, as a unit,
+ *   ImageVAETrainer.loss_and_acc_for_batch (imagevae/image_vae_trainer.py:137-217)
+ *     = MnistVAE.forward (imagevae/mnist_vae.py:89-105) + reconstruction_loss + compute_kld_loss
+ *       + the compute_reg_loss loop + mean_accuracy,
+ *   and loss.backward() (utils/trainer.py:140) for that graph.
+ * The model is described layer by layer; weights/biases are float offsets into ONE parameter arena and
+ * gradients accumulate at the same offsets of a gradient arena (the trainer's flat Adam arenas).
+ * ------------------------------------------------------------------------------------------------ */
+#define ARVAE_MAX_LAYERS 8
+
+typedef struct {
+    arvae_link_t link;    /* geometry; link.n is ignored (the batch is a call argument)               */
+    int32_t is_up;        /* 0: forward is DOWN (nn.Conv2d / nn.Linear), 1: UP (nn.ConvTranspose2d)   */
+    int32_t act;          /* ARVAE_ACT_* applied after the bias                                        */
+    int32_t dropout;      /* 1: nn.Dropout(0.5) follows (a keep-mask is consumed in train mode)        */
+    int32_t reserved;
+    int64_t w_off, b_off; /* float offsets of weight and bias in the parameter / gradient arenas       */
+} arvae_layer_t;
+
+typedef struct {
+    int32_t n_enc, n_dec;                 /* encoder layers up to the hidden vector; decoder layers z -> logits */
+    arvae_layer_t enc[ARVAE_MAX_LAYERS];
+    arvae_layer_t dec[ARVAE_MAX_LAYERS];
+    arvae_layer_t head_mu, head_log_std;  /* dense heads on the encoder's hidden vector               */
+    int32_t zdim;
+    int32_t recon_dist;                   /* ARVAE_RECON_*                                             */
+    int32_t n_reg;                        /* regularised dims (0: no attribute regularisation)         */
+    int32_t reg_dims[16];
+    float beta, gamma, delta;
+} arvae_image_vae_t;
+
+/* scalars written by the forward pass (device array of ARVAE_VAE_NSCALARS floats) */
+#define ARVAE_VAE_LOSS 0   /* recon + dist + reg_scale*reg                                              */
+#define ARVAE_VAE_RECON 1
+#define ARVAE_VAE_DIST 2   /* beta * |kl - c|                                                            */
+#define ARVAE_VAE_REG 3    /* reg_scale * (sum over dims of the row-block regularisation loss)          */
+#define ARVAE_VAE_ACC 4
+#define ARVAE_VAE_KL 5
+#define ARVAE_VAE_NSCALARS 8
+
+int64_t arvae_image_vae_ws_floats(const arvae_image_vae_t *model, int32_t batch, int64_t n_cols);
+
+/* Forward + loss terms.  x [batch, H, W, 1]; labels [batch, ld_labels]; eps [batch, zdim];
+ * masks: HOST array with one device uint8 keep-mask per dropout layer (encoder first), or NULL (eval).
+ * z_cols/lab_cols [n_cols, ...]: all-gathered columns for the data-parallel row-block regularisation
+ * (NULL: this batch is the whole batch); they index dims 0..n_reg-1 compactly when given.
+ * reg_scale multiplies the regularisation term (world size under data parallelism, else 1).
+ * Outputs: scalars[ARVAE_VAE_NSCALARS], mu/sigma/z [batch, zdim], logits [batch, H, W, 1].
+ * Everything the backward pass needs stays in ws. */
+int arvae_image_vae_forward(const arvae_image_vae_t *model, int32_t batch, const float *params, const float *x,
+                            const float *labels, int64_t ld_labels, const float *eps,
+                            const uint8_t *const *masks, const float *capacity, const float *z_cols,
+                            const float *lab_cols, int64_t n_cols, float reg_scale, float *ws, float *scalars,
+                            float *mu, float *sigma, float *z, float *logits, arvae_stream_t stream);
+
+/* Backward of scalars[ARVAE_VAE_LOSS] times g_loss[0] (device scalar): parameter gradients ACCUMULATE into
+ * grads at the layers' offsets.  Must follow arvae_image_vae_forward on the same ws, with the same
+ * x / eps / masks / capacity and that call's mu / sigma / z / logits outputs.
+ * reg_fused: 1 when the forward evaluated the regularisation term itself (n_cols >= 0);
+ * dz_extra: optional extra gradient w.r.t. z [batch, zdim], ALREADY multiplied by the upstream gradient
+ * (the data-parallel caller evaluates the row-block regularisation outside and feeds its gradient here). */
+int arvae_image_vae_backward(const arvae_image_vae_t *model, int32_t batch, const float *params, float *grads,
+                             const float *x, const float *eps, const uint8_t *const *masks,
+                             const float *capacity, const float *mu, const float *sigma, const float *z,
+                             const float *logits, const float *g_loss, const float *dz_extra,
+                             int32_t reg_fused, float reg_scale, float *ws, arvae_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

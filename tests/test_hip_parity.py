@@ -328,7 +328,7 @@ IMAGE_CASES = [
 ]
 
 
-def run_hip_image_step(dev, kind, state, x, lab, eps, beta, cap, dist, masks, train=True, steps=1):
+def run_hip_image_step(dev, kind, state, x, lab, eps, beta, cap, dist, masks, train=True, steps=1, fused=True):
     from arvae_amd.image_vae import DspritesVAE, MnistVAE
     from arvae_amd.image_vae_trainer import ImageVAETrainer
     model = DspritesVAE() if kind == 'dsprites' else MnistVAE()
@@ -338,6 +338,7 @@ def run_hip_image_step(dev, kind, state, x, lab, eps, beta, cap, dist, masks, tr
     trainer = ImageVAETrainer(ds, model, lr=1e-4, reg_type=('all',), reg_dim=dims, dec_dist=dist, beta=beta,
                               gamma=10.0, capacity=cap, rand=0, delta=1.0)
     trainer.cuda()
+    trainer.use_fused = fused
     model.train() if train else model.eval()
     xt, lt = torch.from_numpy(x).to(dev), torch.from_numpy(lab).to(dev)
     out = None
@@ -357,8 +358,9 @@ def run_hip_image_step(dev, kind, state, x, lab, eps, beta, cap, dist, masks, tr
     return out
 
 
+@pytest.mark.parametrize('fused', [True, False], ids=['fused', 'per_layer'])
 @pytest.mark.parametrize('case', IMAGE_CASES, ids=[c[0][:-4] for c in IMAGE_CASES])
-def test_image_step_vs_golden_and_oracle(golden_dir, dev, case):
+def test_image_step_vs_golden_and_oracle(golden_dir, dev, case, fused):
     fname, kind, b, wseed, xseed, eseed, beta, cap, dist, mseed, gain = case
     g = G(golden_dir, fname)
     state = syn.synth_state(o_vae.SHAPES[kind], wseed, gain)
@@ -367,7 +369,7 @@ def test_image_step_vs_golden_and_oracle(golden_dir, dev, case):
     dims = (1, 2, 3, 4, 5) if kind == 'dsprites' else (1, 2, 3, 4, 5, 6)
     masks = None if mseed is None else syn.dropout_masks([(b,) + s for s in o_vae.MNIST_MASK_SHAPES], mseed)
     train = not fname.endswith('eval.npz')
-    got = run_hip_image_step(dev, kind, state, x, lab, eps, beta, cap, dist, masks, train=train)
+    got = run_hip_image_step(dev, kind, state, x, lab, eps, beta, cap, dist, masks, train=train, fused=fused)
     ref = o_step.image_step(kind, state, x, lab, eps, dims, beta, 10.0, 1.0, capacity=cap, dec_dist=dist, masks=masks)
     # loss terms: north_star tolerance rtol 1e-4 (fp32), against the reference golden AND the oracle
     for src in (g, ref['terms']):
@@ -413,12 +415,13 @@ def test_image_forward_latents_vs_golden(golden_dir, dev):
     assert float(prior.loc.abs().max()) == 0.0 and float(prior.scale.min()) == 1.0
 
 
-def test_three_steps_track_oracle(dev):
+@pytest.mark.parametrize('fused', [True, False], ids=['fused', 'per_layer'])
+def test_three_steps_track_oracle(dev, fused):
     """Adam state carried over several steps stays on the oracle's trajectory."""
     state = syn.synth_state(o_vae.DSPRITES_SHAPES, 5, 1.6)
     x, lab = syn.dsprites_batch(16, seed=3)
     eps = syn.normal_noise((16, 10), seed=4)
-    got = run_hip_image_step(dev, 'dsprites', state, x, lab, eps, 4.0, 0.0, 'bernoulli', None, steps=3)
+    got = run_hip_image_step(dev, 'dsprites', state, x, lab, eps, 4.0, 0.0, 'bernoulli', None, steps=3, fused=fused)
     cur, adam = state, None
     for step_no in (1, 2, 3):
         ref = o_step.image_step('dsprites', cur, x, lab, eps, (1, 2, 3, 4, 5), 4.0, 10.0, 1.0, adam_state=adam,
