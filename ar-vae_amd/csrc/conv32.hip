@@ -65,27 +65,58 @@ __device__ __forceinline__ float4 operand_load4(const Operand &op, int64_t idx) 
 }
 
 // ------------------------------------------------------------------------------------------------
-// hi patch for a tile of lo pixels: rows [2*r0-1, 2*r0-1+PR), cols [-1, PC-1) of TI images, 32 channels
+// Register-staged patch loader.  issue() starts every 16-byte global load of a tile's patch (all of them
+// in flight at once; called for tile t+1 before the MFMAs of tile t so HBM/L2 latency hides under them),
+// commit() writes the registers to LDS once the previous tile's readers have passed the barrier.
+//   STRIDE 2: hi patch of a lo tile: rows [2*r0-1, 2*r0-1+PR), cols [-1, PC-1), PR = 2*TR+2, PC = 2*TC+2
+//   STRIDE 1: lo patch with a 1-pixel halo: rows [r0-1, r0-1+PR), cols [-1, PC-1), PR = TR+2, PC = TC+2
 // ------------------------------------------------------------------------------------------------
-template <int LO, bool BIAS_SUM>
-__device__ __forceinline__ void load_hi_patch(float *patch, const Operand &hi, int img0, int r0, int n_img,
-                                               float4 &bsum) {
+template <int LO, int STRIDE>
+struct PatchLoader {
     using T = Tile<LO>;
-    constexpr int HI = 2 * LO, PR = 2 * T::TR + 2, PC = 2 * T::TC + 2;
-    constexpr int SLOTS = T::TI * PR * PC * 8;
-    for (int idx = threadIdx.x; idx < SLOTS; idx += 256) {
-        const int q = idx & 7, pix = idx >> 3;
-        const int pc = pix % PC, pr = (pix / PC) % PR, im = pix / (PC * PR);
-        const int gy = 2 * r0 - 1 + pr, gx = pc - 1, n = img0 + im;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n < n_img && (unsigned)gy < (unsigned)HI && (unsigned)gx < (unsigned)HI) {
-            v = operand_load4(hi, ((int64_t)(n * HI + gy) * HI + gx) * C32 + q * 4);
-            if (BIAS_SUM && pr >= 1 && pr <= 2 * T::TR && pc >= 1 && pc <= 2 * T::TC) {   // pixels this tile owns
-                bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w;
+    static constexpr int SZ = STRIDE * LO;                                  // spatial size of the source tensor
+    static constexpr int PR = STRIDE * T::TR + 2, PC = STRIDE * T::TC + 2;
+    static constexpr int SLOTS = T::TI * PR * PC * 8;
+    static constexpr int ITERS = (SLOTS + 255) / 256;
+    float4 r[ITERS];
+
+    __device__ __forceinline__ void issue(const Operand &src, int img0, int r0, int n_img) {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int idx = threadIdx.x + it * 256;
+            const int q = idx & 7, pix = idx >> 3;
+            const int pc = pix % PC, pr = (pix / PC) % PR, im = pix / (PC * PR);
+            const int gy = STRIDE * r0 - 1 + pr, gx = pc - 1, n = img0 + im;
+            r[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < SLOTS && n < n_img && (unsigned)gy < (unsigned)SZ && (unsigned)gx < (unsigned)SZ)
+                r[it] = operand_load4(src, ((int64_t)(n * SZ + gy) * SZ + gx) * C32 + q * 4);
+        }
+    }
+    // BIAS_SUM: also accumulate the pixels this tile owns (not the halo) per channel chunk q = threadIdx.x & 7
+    template <bool BIAS_SUM>
+    __device__ __forceinline__ void commit(float *patch, float4 &bsum) const {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int idx = threadIdx.x + it * 256;
+            if (idx < SLOTS) {
+                const int q = idx & 7, pix = idx >> 3;
+                *reinterpret_cast<float4 *>(patch + pix * PS + q * 4) = r[it];
+                if (BIAS_SUM) {
+                    const int pc = pix % PC, pr = (pix / PC) % PR;
+                    if (pr >= 1 && pr <= PR - 2 && pc >= 1 && pc <= PC - 2) {
+                        bsum.x += r[it].x; bsum.y += r[it].y; bsum.z += r[it].z; bsum.w += r[it].w;
+                    }
+                }
             }
         }
-        *reinterpret_cast<float4 *>(patch + pix * PS + q * 4) = v;
     }
+};
+
+template <int LO> __device__ __forceinline__ void tile_origin(int tile, int &img0, int &r0) {
+    using T = Tile<LO>;
+    constexpr int TILES_PER_IMG = LO / T::TR;
+    img0 = (T::TI == 1) ? tile / TILES_PER_IMG : tile * T::TI;
+    r0 = (T::TI == 1) ? (tile % TILES_PER_IMG) * T::TR : 0;
 }
 
 // ================================================================================================
@@ -119,15 +150,24 @@ __global__ __launch_bounds__(256, 2) void down32_kernel(Operand hi, const float 
         aoff[mt] = ((img * PR + 2 * r + wave) * PC + 2 * c) * PS + half * 4;
     }
     const float bias = ep.bias != nullptr ? ep.bias[rc] : 0.f;
-    constexpr int TILES_PER_IMG = LO / T::TR;                   // row blocks per image (TI == 1) or 1
     float4 dummy;
+    PatchLoader<LO, 2> pl;
+    int img0, r0;
+    if (blockIdx.x < n_tiles) {
+        tile_origin<LO>(blockIdx.x, img0, r0);
+        pl.issue(hi, img0, r0, n_img);
+    }
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int img0 = (T::TI == 1) ? tile / TILES_PER_IMG : tile * T::TI;
-        const int r0 = (T::TI == 1) ? (tile % TILES_PER_IMG) * T::TR : 0;
+        tile_origin<LO>(tile, img0, r0);
         __syncthreads();                                         // previous tile's reduce reads are done
-        load_hi_patch<LO, false>(lds, hi, img0, r0, n_img, dummy);
+        pl.template commit<false>(lds, dummy);
         __syncthreads();
+        if (tile + gridDim.x < n_tiles) {                        // next tile's loads fly under this tile's MFMAs
+            int ni, nr;
+            tile_origin<LO>(tile + gridDim.x, ni, nr);
+            pl.issue(hi, ni, nr, n_img);
+        }
 
         f32x16 acc[2];
 #pragma unroll
@@ -222,23 +262,24 @@ __global__ __launch_bounds__(256, 2) void up32_kernel(Operand lo, const float *_
         aoff[mt] = ((img * PR + r + 1 + py) * PC + c + 1 + px) * PS + half * 4;
     }
     const float bias = ep.bias != nullptr ? ep.bias[rc] : 0.f;
-    constexpr int TILES_PER_IMG = LO / T::TR;
-    constexpr int SLOTS = T::TI * PR * PC * 8;
+    float4 dummy;
+    PatchLoader<LO, 1> pl;
+    int img0, r0;
+    if (blockIdx.x < n_tiles) {
+        tile_origin<LO>(blockIdx.x, img0, r0);
+        pl.issue(lo, img0, r0, n_img);
+    }
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int img0 = (T::TI == 1) ? tile / TILES_PER_IMG : tile * T::TI;
-        const int r0 = (T::TI == 1) ? (tile % TILES_PER_IMG) * T::TR : 0;
+        tile_origin<LO>(tile, img0, r0);
         __syncthreads();
-        for (int idx = threadIdx.x; idx < SLOTS; idx += 256) {
-            const int q = idx & 7, pix = idx >> 3;
-            const int pc = pix % PC, pr = (pix / PC) % PR, im = pix / (PC * PR);
-            const int gy = r0 - 1 + pr, gx = pc - 1, n = img0 + im;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n < n_img && (unsigned)gy < (unsigned)LO && (unsigned)gx < (unsigned)LO)
-                v = operand_load4(lo, ((int64_t)(n * LO + gy) * LO + gx) * C32 + q * 4);
-            *reinterpret_cast<float4 *>(lds + pix * PS + q * 4) = v;
+        pl.template commit<false>(lds, dummy);
+        __syncthreads();
+        if (tile + gridDim.x < n_tiles) {
+            int ni, nr;
+            tile_origin<LO>(tile + gridDim.x, ni, nr);
+            pl.issue(lo, ni, nr, n_img);
         }
-        __syncthreads();
 
         f32x16 acc[2];
 #pragma unroll
@@ -298,7 +339,6 @@ __global__ __launch_bounds__(256, 2) void wgrad32_kernel(Operand lo, Operand hi,
     float *lo_t = lds + PATCH;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int half = lane >> 5, rc = lane & 31;
-    constexpr int TILES_PER_IMG = LO / T::TR;
 
     f32x16 acc[4];
 #pragma unroll
@@ -308,27 +348,48 @@ __global__ __launch_bounds__(256, 2) void wgrad32_kernel(Operand lo, Operand hi,
     float lo_sum = 0.f;
     float4 hi_sum = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int img0 = (T::TI == 1) ? tile / TILES_PER_IMG : tile * T::TI;
-        const int r0 = (T::TI == 1) ? (tile % TILES_PER_IMG) * T::TR : 0;
-        __syncthreads();
-        load_hi_patch<LO, BIAS == 2>(lds, hi, img0, r0, n_img, hi_sum);
-        for (int idx = threadIdx.x; idx < 64 * 8; idx += 256) {
+    // register-staged loads: hi patch + the 64-pixel lo tile (2 float4 per thread)
+    PatchLoader<LO, 2> pl;
+    float4 lr[2];
+    auto issue_lo = [&](int i0, int rr0) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = threadIdx.x + it * 256;
             const int q = idx & 7, p = idx >> 3;
             int img, r, c;
             tile_pixel<LO>(p, img, r, c);
-            const int n = img0 + img;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n < n_img) v = operand_load4(lo, ((int64_t)(n * LO + r0 + r) * LO + c) * C32 + q * 4);
-            *reinterpret_cast<float4 *>(lo_t + p * PS + q * 4) = v;
+            const int n = i0 + img;
+            lr[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n < n_img) lr[it] = operand_load4(lo, ((int64_t)(n * LO + rr0 + r) * LO + c) * C32 + q * 4);
+        }
+    };
+    int img0, r0;
+    if (blockIdx.x < n_tiles) {
+        tile_origin<LO>(blockIdx.x, img0, r0);
+        pl.issue(hi, img0, r0, n_img);
+        issue_lo(img0, r0);
+    }
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        tile_origin<LO>(tile, img0, r0);
+        __syncthreads();
+        pl.template commit<BIAS == 2>(lds, hi_sum);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = threadIdx.x + it * 256;
+            *reinterpret_cast<float4 *>(lo_t + (idx >> 3) * PS + (idx & 7) * 4) = lr[it];
         }
         __syncthreads();
+        if (tile + gridDim.x < n_tiles) {
+            int ni, nr;
+            tile_origin<LO>(tile + gridDim.x, ni, nr);
+            pl.issue(hi, ni, nr, n_img);
+            issue_lo(ni, nr);
+        }
 
 #pragma unroll
         for (int s = 0; s < 32; ++s) {
             // k-pair s covers lo pixels 2s and 2s+1 (adjacent columns of one row); this lane takes 2s+half
-            constexpr int dummy = 0;
-            (void)dummy;
             int img, r, c;
             tile_pixel<LO>(2 * s, img, r, c);            // compile-time after unrolling
             const float a = lo_t[(2 * s + half) * PS + rc];
@@ -369,18 +430,21 @@ __global__ __launch_bounds__(256, 2) void wgrad32_kernel(Operand lo, Operand hi,
 }
 
 // dwt[clo][chi][ky][kx] += sum_wg slab[wg][ky][kx][clo][chi];  dbias[c] += sum_wg slab[wg][16384 + c]
+// 16 outputs x 16 slab groups per workgroup: ~1000 workgroups keep enough loads in flight to stream the slab
 __global__ __launch_bounds__(256) void wgrad32_reduce_kernel(const float *__restrict__ slab, int n_wg,
                                                               float *__restrict__ dwt, float *__restrict__ dbias) {
-    __shared__ float red[4][64];
-    const int il = threadIdx.x & 63, zg = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + il;                    // 0 .. 16384+32
+    __shared__ float red[16][17];
+    const int il = threadIdx.x & 15, zg = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + il;                    // 0 .. 16384+32
     float s = 0.f;
     if (i < WG32_SLAB)
-        for (int z = zg; z < n_wg; z += 4) s += slab[(int64_t)z * WG32_SLAB + i];
+        for (int z = zg; z < n_wg; z += 16) s += slab[(int64_t)z * WG32_SLAB + i];
     red[zg][il] = s;
     __syncthreads();
     if (zg == 0 && i < WG32_SLAB) {
-        const float tot = (red[0][il] + red[1][il]) + (red[2][il] + red[3][il]);
+        float tot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) tot += red[j][il];
         if (i < 16 * C32 * C32) {
             const int chi = i & 31, clo = (i >> 5) & 31, tap = i >> 10;
             dwt[(clo * C32 + chi) * 16 + tap] += tot;
@@ -503,7 +567,7 @@ int conv32_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, fl
         default: rc = launch_wgrad<4>(l, lo, hi, slab, bias_mode, grid, s); break;
     }
     if (rc) return rc;
-    hipLaunchKernelGGL(wgrad32_reduce_kernel, dim3((WG32_SLAB + 63) / 64), dim3(256), 0, s, slab, grid, dwt,
+    hipLaunchKernelGGL(wgrad32_reduce_kernel, dim3((WG32_SLAB + 15) / 16), dim3(256), 0, s, slab, grid, dwt,
                        bias_mode ? dbias : nullptr);
     return check_launch("wgrad32(reduce)");
 }

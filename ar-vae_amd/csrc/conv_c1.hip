@@ -209,16 +209,18 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(Operand lo, Operand img, 
 __global__ __launch_bounds__(256) void wgrad_c1_reduce_kernel(const float *__restrict__ slab, int n_wg,
                                                                float *__restrict__ dwt, float *__restrict__ dbias,
                                                                int bias_mode) {
-    __shared__ float red[4][64];
-    const int il = threadIdx.x & 63, zg = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + il;
+    __shared__ float red[16][17];
+    const int il = threadIdx.x & 15, zg = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + il;
     float s = 0.f;
     if (i < WG1_SLAB)
-        for (int z = zg; z < n_wg; z += 4) s += slab[(int64_t)z * WG1_SLAB + i];
+        for (int z = zg; z < n_wg; z += 16) s += slab[(int64_t)z * WG1_SLAB + i];
     red[zg][il] = s;
     __syncthreads();
     if (zg == 0 && i < WG1_SLAB) {
-        const float tot = (red[0][il] + red[1][il]) + (red[2][il] + red[3][il]);
+        float tot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) tot += red[j][il];
         if (i < CC * 16)
             dwt[i] += tot;                                   // wt[clo][0][ky][kx] is exactly [clo][tap]
         else if (i < CC * 16 + CC) {
@@ -251,7 +253,7 @@ int conv_c1_up(const arvae_link_t *l, const float *lo, const float *wt, const fl
 
 static int wgrad_c1_groups(const arvae_link_t *l) {
     const int tiles = l->n * (LO1 / TR1);
-    return tiles < 512 ? tiles : 512;
+    return tiles < 1024 ? tiles : 1024;
 }
 
 int64_t conv_c1_wgrad_ws_floats(const arvae_link_t *l) { return (int64_t)wgrad_c1_groups(l) * WG1_SLAB; }
@@ -261,7 +263,7 @@ int conv_c1_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &img, 
     const int tiles = l->n * (LO1 / TR1), grid = wgrad_c1_groups(l);
     hipLaunchKernelGGL(wgrad_c1_kernel, dim3(grid), dim3(256), 0, s, lo, img, slab, tiles);
     if (int rc = check_launch("wgrad_c1")) return rc;
-    hipLaunchKernelGGL(wgrad_c1_reduce_kernel, dim3((WG1_SLAB + 63) / 64), dim3(256), 0, s, slab, grid, dwt, dbias,
+    hipLaunchKernelGGL(wgrad_c1_reduce_kernel, dim3((WG1_SLAB + 15) / 16), dim3(256), 0, s, slab, grid, dwt, dbias,
                        bias_mode);
     return check_launch("wgrad_c1(reduce)");
 }

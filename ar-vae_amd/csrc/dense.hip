@@ -1,7 +1,8 @@
 // nn.Linear forward / data-gradient / weight-gradient for batch-sized GEMMs (M = batch 64..4096,
 // features 10..2888) on the fp32 MFMA.  These are latency-bound, cache-resident problems: a
-// workgroup owns ONE 32x32 output tile, its 4 wavefronts split the reduction axis and sum through
-// LDS, and operands go straight from L2 to registers (no LDS staging): a lane reads 4 consecutive
+// workgroup owns ONE 32x32 output tile, its 16 wavefronts split the reduction axis (so a wave needs only
+// one or two rounds of loads: the kernels are latency-, not throughput-bound) and sum through LDS, and
+// operands go straight from L2 to registers (no LDS staging): a lane reads 4 consecutive
 // reduction elements (16 B) when that axis is contiguous in memory, or 4 row-strided dwords that are
 // coalesced across the wave when the OTHER axis is contiguous.  The reduction order is permuted
 // (chunk of 8 = [half 0: 4][half 1: 4]) to fit the 32x32x2 MFMA's k = 2s + half lane layout.
@@ -27,6 +28,7 @@ struct DenseArgs {
     const float *bias;
     float *out;         // forward: Y ; dgrad: dX ; wgrad: dW (accumulated)
     float *dbias;       // wgrad: accumulated, may be null
+    const float *gate;  // dgrad: optional saved activation of the dX location: dX *= (gate > 0)
     int batch, n_in, n_out, act;
     Perm in_perm, out_perm;
 };
@@ -36,26 +38,24 @@ __device__ __forceinline__ void mfma4(f32x16 &acc, const float (&a)[4], const fl
     for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[t], acc, 0, 0, 0);
 }
 
-// sum the 4 waves' 32x32 partial tiles; wave w returns registers [4w, 4w+4) of the total in v[0..3]
-__device__ __forceinline__ void reduce_waves(float *red, const f32x16 &acc, int wave, int lane, float (&v)[4]) {
+constexpr int NW = 16;                       // wavefronts per workgroup = reduction split
+constexpr int DENSE_THREADS = 64 * NW;
+
+// sum the NW waves' 32x32 partial tiles through LDS; wave w returns accumulator register w of the total
+__device__ __forceinline__ float reduce_waves(float *red, const f32x16 &acc, int wave, int lane) {
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<float4 *>(red + ((wave * 4 + q) * 64 + lane) * 4) =
-            make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
     __syncthreads();
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    float s = 0.f;
 #pragma unroll
-    for (int ws = 0; ws < 4; ++ws) {
-        const float4 p = *reinterpret_cast<const float4 *>(red + ((ws * 4 + wave) * 64 + lane) * 4);
-        s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
-    }
-    v[0] = s.x; v[1] = s.y; v[2] = s.z; v[3] = s.w;
+    for (int ws = 0; ws < NW; ++ws) s += red[(ws * 16 + wave) * 64 + lane];
+    return s;
 }
 
 // ---- forward: Y[m][out_perm(n)] = act( sum_k X[m][km] * W[n][feat(km)] + b[n] ),  km = memory column ----------
-__global__ __launch_bounds__(256) void dense_fwd_kernel(DenseArgs p) {
-    __shared__ __attribute__((aligned(16))) float red[4 * 4 * 64 * 4];
+__global__ __launch_bounds__(DENSE_THREADS) void dense_fwd_kernel(DenseArgs p) {
+    __shared__ float red[NW * 16 * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, rc = lane & 31;
     const int m = blockIdx.x * 32 + rc, n = blockIdx.y * 32 + rc;
     const bool mok = m < p.batch, nok = n < p.n_out;
@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(DenseArgs p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     const int chunks = (p.n_in + 7) / 8;
-    for (int q = wave; q < chunks; q += 4) {
+
+    for (int q = wave; q < chunks; q += NW) {
         const int k0 = q * 8 + half * 4;
         float a[4], b[4];
         if (vec && k0 + 3 < p.n_in) {
@@ -91,23 +92,18 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(DenseArgs p) {
         if (!nok) b[0] = b[1] = b[2] = b[3] = 0.f;
         mfma4(acc, a, b);
     }
-    float v[4];
-    reduce_waves(red, acc, wave, lane, v);
+    const float v = reduce_waves(red, acc, wave, lane);
     if (nok) {
         const float bias = p.bias != nullptr ? p.bias[n] : 0.f;
         const int col = p.out_perm.to_mem(n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int reg = 4 * wave + e;
-            const int row = blockIdx.x * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-            if (row < p.batch) p.out[(int64_t)row * p.n_out + col] = act_fwd(v[e] + bias, p.act);
-        }
+        const int row = blockIdx.x * 32 + (wave & 3) + 8 * (wave >> 2) + 4 * half;      // accumulator register = wave
+        if (row < p.batch) p.out[(int64_t)row * p.n_out + col] = act_fwd(v + bias, p.act);
     }
 }
 
 // ---- dgrad: dX[m][in_mem] = sum_{nm} G[m][nm] * W[feat_out(nm)][feat_in(in_mem)]  ---------------------------
-__global__ __launch_bounds__(256) void dense_dgrad_kernel(DenseArgs p) {
-    __shared__ __attribute__((aligned(16))) float red[4 * 4 * 64 * 4];
+__global__ __launch_bounds__(DENSE_THREADS) void dense_dgrad_kernel(DenseArgs p) {
+    __shared__ float red[NW * 16 * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, rc = lane & 31;
     const int m = blockIdx.x * 32 + rc, km = blockIdx.y * 32 + rc;      // km = memory column of dX
     const bool mok = m < p.batch, kok = km < p.n_in;
@@ -118,7 +114,8 @@ __global__ __launch_bounds__(256) void dense_dgrad_kernel(DenseArgs p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     const int chunks = (p.n_out + 7) / 8;
-    for (int q = wave; q < chunks; q += 4) {
+
+    for (int q = wave; q < chunks; q += NW) {
         const int n0 = q * 8 + half * 4;
         float a[4], b[4];
         if (vec && p.a.mask == nullptr && n0 + 3 < p.n_out) {
@@ -143,22 +140,19 @@ __global__ __launch_bounds__(256) void dense_dgrad_kernel(DenseArgs p) {
         if (!kok) b[0] = b[1] = b[2] = b[3] = 0.f;
         mfma4(acc, a, b);
     }
-    float v[4];
-    reduce_waves(red, acc, wave, lane, v);
+    const float v = reduce_waves(red, acc, wave, lane);
     if (kok) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int reg = 4 * wave + e;
-            const int row = blockIdx.x * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-            if (row < p.batch) p.out[(int64_t)row * p.n_in + km] = v[e];
+        const int row = blockIdx.x * 32 + (wave & 3) + 8 * (wave >> 2) + 4 * half;
+        if (row < p.batch) {
+            const int64_t idx = (int64_t)row * p.n_in + km;
+            p.out[idx] = (p.gate == nullptr || p.gate[idx] > 0.f) ? v : 0.f;
         }
     }
 }
 
 // ---- wgrad: dW[n][feat_in(km)] += sum_m G[m][mem_out(n)] * X[m][km] ;  db[n] += sum_m G[m][mem_out(n)] ------
-__global__ __launch_bounds__(256) void dense_wgrad_kernel(DenseArgs p) {
-    __shared__ __attribute__((aligned(16))) float red[4 * 4 * 64 * 4];
-    __shared__ float bred[4][64];
+__global__ __launch_bounds__(DENSE_THREADS) void dense_wgrad_kernel(DenseArgs p) {
+    __shared__ float red[NW * 16 * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, rc = lane & 31;
     const int n = blockIdx.x * 32 + rc, km = blockIdx.y * 32 + rc;
     const bool nok = n < p.n_out, kok = km < p.n_in;
@@ -168,7 +162,8 @@ __global__ __launch_bounds__(256) void dense_wgrad_kernel(DenseArgs p) {
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     float bsum = 0.f;
     const int chunks = (p.batch + 7) / 8;
-    for (int q = wave; q < chunks; q += 4) {
+
+    for (int q = wave; q < chunks; q += NW) {
         const int m0 = q * 8 + half * 4;
         float a[4], b[4];
 #pragma unroll
@@ -180,24 +175,20 @@ __global__ __launch_bounds__(256) void dense_wgrad_kernel(DenseArgs p) {
         }
         mfma4(acc, a, b);
     }
-    float v[4];
-    reduce_waves(red, acc, wave, lane, v);
+    const float v = reduce_waves(red, acc, wave, lane);
     if (kok) {
         const int kf = p.in_perm.to_feat(km);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int reg = 4 * wave + e;
-            const int row = blockIdx.x * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;      // n
-            if (row < p.n_out) p.out[(int64_t)row * p.n_in + kf] += v[e];
-        }
+        const int row = blockIdx.x * 32 + (wave & 3) + 8 * (wave >> 2) + 4 * half;      // n
+        if (row < p.n_out) p.out[(int64_t)row * p.n_in + kf] += v;
     }
     if (p.dbias != nullptr && blockIdx.y == 0) {
-        bred[wave][lane] = bsum;
+        __syncthreads();
+        red[wave * 64 + lane] = bsum;
         __syncthreads();
         if (wave == 0 && half == 0 && nok) {
             float tot = 0.f;
 #pragma unroll
-            for (int ws = 0; ws < 4; ++ws) tot += bred[ws][rc] + bred[ws][rc + 32];
+            for (int ws = 0; ws < NW; ++ws) tot += red[ws * 64 + rc] + red[ws * 64 + rc + 32];
             p.dbias[n] += tot;
         }
     }
@@ -221,21 +212,21 @@ int dense_fwd(const arvae_link_t *l, const float *x, const float *w, const float
     DenseArgs p = dense_args(l);
     p.a = Operand{x, nullptr, nullptr, ARVAE_ACT_NONE};
     p.w = w; p.bias = bias; p.act = act; p.out = y;
-    hipLaunchKernelGGL(dense_fwd_kernel, dim3((p.batch + 31) / 32, (p.n_out + 31) / 32), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(dense_fwd_kernel, dim3((p.batch + 31) / 32, (p.n_out + 31) / 32), dim3(DENSE_THREADS), 0, s, p);
     return check_launch("dense_fwd");
 }
 
-int dense_dgrad(const arvae_link_t *l, const Operand &g, const float *w, float *dx, hipStream_t s) {
+int dense_dgrad(const arvae_link_t *l, const Operand &g, const float *w, const float *gate, float *dx, hipStream_t s) {
     DenseArgs p = dense_args(l);
-    p.a = g; p.w = w; p.out = dx;
-    hipLaunchKernelGGL(dense_dgrad_kernel, dim3((p.batch + 31) / 32, (p.n_in + 31) / 32), dim3(256), 0, s, p);
+    p.a = g; p.w = w; p.out = dx; p.gate = gate;
+    hipLaunchKernelGGL(dense_dgrad_kernel, dim3((p.batch + 31) / 32, (p.n_in + 31) / 32), dim3(DENSE_THREADS), 0, s, p);
     return check_launch("dense_dgrad");
 }
 
 int dense_wgrad(const arvae_link_t *l, const Operand &g, const float *x, float *dw, float *dbias, hipStream_t s) {
     DenseArgs p = dense_args(l);
     p.a = g; p.x = x; p.out = dw; p.dbias = dbias;
-    hipLaunchKernelGGL(dense_wgrad_kernel, dim3((p.n_out + 31) / 32, (p.n_in + 31) / 32), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(dense_wgrad_kernel, dim3((p.n_out + 31) / 32, (p.n_in + 31) / 32), dim3(DENSE_THREADS), 0, s, p);
     return check_launch("dense_wgrad");
 }
 

@@ -23,7 +23,7 @@ constexpr int BK = 32;
 // batch-sized nn.Linear kernels (dense.hip)
 bool dense_fits(const arvae_link_t *l);
 int dense_fwd(const arvae_link_t *l, const float *x, const float *w, const float *bias, int act, float *y, hipStream_t s);
-int dense_dgrad(const arvae_link_t *l, const Operand &g, const float *w, float *dx, hipStream_t s);
+int dense_dgrad(const arvae_link_t *l, const Operand &g, const float *w, const float *gate, float *dx, hipStream_t s);
 int dense_wgrad(const arvae_link_t *l, const Operand &g, const float *x, float *dw, float *dbias, hipStream_t s);
 
 // 1-channel 64x64 image links (conv_c1.hip)
@@ -562,7 +562,7 @@ extern "C" int arvae_link_up(const arvae_link_t *link, const arvae_operand_t *lo
     ARVAE_REQUIRE(link->hh % s == 0 && link->hw % s == 0, "link_up: hi extent not a multiple of the stride");
     hipStream_t st = as_stream(stream);
     if (dense_fits(link) && out_mask == nullptr && bias == nullptr && out_act == ARVAE_ACT_NONE)
-        return dense_dgrad(link, make_operand(lo), wt, hi, st);
+        return dense_dgrad(link, make_operand(lo), wt, nullptr, hi, st);
     if (conv32_fits(link) && out_mask == nullptr && lo->mask == nullptr && out_act != ARVAE_ACT_SELU &&
         lo->act != ARVAE_ACT_SELU)
         return conv32_up(link, make_operand(lo), wt, bias, out_act == ARVAE_ACT_RELU, nullptr, hi, st);

@@ -5,6 +5,18 @@
 
 namespace arvae {
 
+// fast kernels with a gated epilogue (conv32.hip / conv_c1.hip / dense.hip)
+bool conv32_fits(const arvae_link_t *l);
+bool conv_c1_fits(const arvae_link_t *l);
+bool dense_fits(const arvae_link_t *l);
+int conv32_down(const arvae_link_t *l, const Operand &hi, const float *wt, const float *bias, int relu,
+                const float *gate, float *out, hipStream_t s);
+int conv32_up(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, int relu,
+              const float *gate, float *out, hipStream_t s);
+int conv_c1_down(const arvae_link_t *l, const Operand &img, const float *wt, const float *bias, int relu,
+                 const float *gate, float *out, hipStream_t s);
+int dense_dgrad(const arvae_link_t *l, const Operand &g, const float *w, const float *gate, float *dx, hipStream_t s);
+
 // ---- small glue kernels ---------------------------------------------------------------------------
 // scalars = [loss, recon, dist, reg_scaled, acc, kl]
 __global__ void vae_scalars_kernel(const float *__restrict__ rec, const float *__restrict__ kld,
@@ -44,8 +56,13 @@ __global__ __launch_bounds__(256) void latent_bwd_full_kernel(const float *__res
     }
 }
 
-__global__ __launch_bounds__(256) void add_inplace_kernel(float *__restrict__ a, const float *__restrict__ b, int64_t count) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) a[i] += b[i];
+// a += b, optionally gated by the saved ReLU output the gradient belongs to
+__global__ __launch_bounds__(256) void add_inplace_kernel(float *__restrict__ a, const float *__restrict__ b,
+                                                           const float *__restrict__ gate, int64_t count) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+        const float v = a[i] + b[i];
+        a[i] = (gate == nullptr || gate[i] > 0.f) ? v : 0.f;
+    }
 }
 
 // ---- workspace layout ------------------------------------------------------------------------------
@@ -117,23 +134,50 @@ static int layer_forward(const arvae_layer_t &l, int32_t n, const float *params,
     return l.is_up ? arvae_link_up(&lk, &op, w, b, l.act, mask, out, st) : arvae_link_down(&lk, &op, w, b, l.act, mask, out, st);
 }
 
-// g_out: gradient w.r.t. the layer's OUTPUT (after activation / dropout); d_in may be null (first layer)
+// One layer of the backward pass.
+//   g      : gradient arriving at this layer: w.r.t. its pre-activation (g_is_pre) or w.r.t. its output
+//   gate   : when non-null, the saved ReLU output of the PRODUCER of `in`; the data gradient is then
+//            written as d_in * (gate > 0), i.e. already w.r.t. the producer's pre-activation, so that the
+//            producer's dgrad and wgrad read ONE plain tensor instead of re-deriving ReLU' twice.
+//   *gated : set when the gate was applied (a fast kernel with a gated epilogue was available)
 static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params, float *grads, const float *in,
-                          const float *out, const uint8_t *mask, const float *g_out, float *d_in, float *slab,
-                          arvae_stream_t st) {
+                          const float *out, const uint8_t *mask, const float *g, bool g_is_pre, const float *gate,
+                          float *d_in, bool *gated, float *slab, arvae_stream_t st) {
     arvae_link_t lk = l.link;
     lk.n = n;
-    const arvae_operand_t gop{g_out, out, mask, l.act};
+    const arvae_operand_t gop = g_is_pre ? plain(g) : arvae_operand_t{g, out, mask, l.act};
     const arvae_operand_t xin = plain(in);
     const float *w = params + l.w_off;
     float *dw = grads + l.w_off, *db = l.b_off >= 0 ? grads + l.b_off : nullptr;
-    if (l.is_up) {
-        if (d_in != nullptr)
-            if (int rc = arvae_link_down(&lk, &gop, w, nullptr, ARVAE_ACT_NONE, nullptr, d_in, st)) return rc;
-        return arvae_link_wgrad(&lk, &xin, &gop, dw, db, db ? 2 : 0, slab, st);
+    hipStream_t hs = as_stream(st);
+    if (gated != nullptr) *gated = false;
+    const bool simple = gop.mask == nullptr && gop.act != ARVAE_ACT_SELU;
+    if (d_in != nullptr) {
+        int rc;
+        if (l.is_up) {                                   // forward UP  -> data gradient is a DOWN map
+            if (gate != nullptr && simple && conv32_fits(&lk)) {
+                rc = conv32_down(&lk, make_operand(&gop), w, nullptr, 0, gate, d_in, hs);
+                *gated = true;
+            } else if (gate != nullptr && simple && conv_c1_fits(&lk)) {
+                rc = conv_c1_down(&lk, make_operand(&gop), w, nullptr, 0, gate, d_in, hs);
+                *gated = true;
+            } else {
+                rc = arvae_link_down(&lk, &gop, w, nullptr, ARVAE_ACT_NONE, nullptr, d_in, st);
+            }
+        } else {                                         // forward DOWN -> data gradient is an UP map
+            if (gate != nullptr && simple && conv32_fits(&lk)) {
+                rc = conv32_up(&lk, make_operand(&gop), w, nullptr, 0, gate, d_in, hs);
+                *gated = true;
+            } else if (gate != nullptr && dense_fits(&lk)) {
+                rc = dense_dgrad(&lk, make_operand(&gop), w, gate, d_in, hs);
+                *gated = true;
+            } else {
+                rc = arvae_link_up(&lk, &gop, w, nullptr, ARVAE_ACT_NONE, nullptr, d_in, st);
+            }
+        }
+        if (rc) return rc;
     }
-    if (d_in != nullptr)
-        if (int rc = arvae_link_up(&lk, &gop, w, nullptr, ARVAE_ACT_NONE, nullptr, d_in, st)) return rc;
+    if (l.is_up) return arvae_link_wgrad(&lk, &xin, &gop, dw, db, db ? 2 : 0, slab, st);
     return arvae_link_wgrad(&lk, &gop, &xin, dw, db, db ? 1 : 0, slab, st);
 }
 
@@ -228,13 +272,22 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
     const int64_t pix = out_elems(m->dec[m->n_dec - 1], batch);
     const int64_t bz = (int64_t)batch * m->zdim;
     if (int rc = arvae_scale_by_scalar(g_loss, ws + L.dlogits, pix, cur, stream)) return rc;
+    // A layer's ReLU can be folded into the data-gradient epilogue of its consumer when no dropout mask sits
+    // between them; the gradient handed down is then w.r.t. the pre-activation.
+    auto relu_gate = [&](const arvae_layer_t &producer, int mask_idx, const float *saved) -> const float * {
+        return (producer.act == ARVAE_ACT_RELU && mask_of(mask_idx) == nullptr) ? saved : nullptr;
+    };
+    bool pre = true;                                     // the last decoder layer has no activation
     // decoder, last layer first
     for (int i = m->n_dec - 1; i >= 0; --i) {
         const float *in = i > 0 ? ws + L.dec_out[i - 1] : z;
         const float *out = (i + 1 < m->n_dec) ? ws + L.dec_out[i] : logits;
-        if (int rc = layer_backward(m->dec[i], batch, params, grads, in, out, mask_of(dec_mask[i]), cur, other, slab,
-                                    stream))
+        const float *gate = i > 0 ? relu_gate(m->dec[i - 1], dec_mask[i - 1], in) : nullptr;
+        bool gated = false;
+        if (int rc = layer_backward(m->dec[i], batch, params, grads, in, out, mask_of(dec_mask[i]), cur, pre, gate, other,
+                                    &gated, slab, stream))
             return rc;
+        pre = gated;
         float *t = cur; cur = other; other = t;
     }
     // latent head (cur = gradient w.r.t. z from the decoder)
@@ -247,26 +300,32 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
                            ws + L.d_ls);
         if (int rc = check_launch("image_vae_backward(latent)")) return rc;
     }
-    // heads: d_hidden = W_mu^T d_mu + W_ls^T d_ls
+    // heads: d_hidden = W_mu^T d_mu + W_ls^T d_ls   (gated by the last encoder layer's ReLU when possible)
     const float *hidden = ws + L.enc_out[m->n_enc - 1];
-    if (int rc = layer_backward(m->head_mu, batch, params, grads, hidden, nullptr, nullptr, ws + L.d_mu, cur, slab, stream))
+    if (int rc = layer_backward(m->head_mu, batch, params, grads, hidden, nullptr, nullptr, ws + L.d_mu, true, nullptr,
+                                cur, nullptr, slab, stream))
         return rc;
-    if (int rc = layer_backward(m->head_log_std, batch, params, grads, hidden, nullptr, nullptr, ws + L.d_ls, other, slab,
-                                stream))
+    if (int rc = layer_backward(m->head_log_std, batch, params, grads, hidden, nullptr, nullptr, ws + L.d_ls, true,
+                                nullptr, other, nullptr, slab, stream))
         return rc;
     {
+        const float *gate = relu_gate(m->enc[m->n_enc - 1], enc_mask[m->n_enc - 1], hidden);
         const int64_t hn = in_elems(m->head_mu, batch);
         int64_t blocks = (hn + 255) / 256;
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)blocks), dim3(256), 0, st, cur, other, hn);
+        hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)blocks), dim3(256), 0, st, cur, other, gate, hn);
         if (int rc = check_launch("image_vae_backward(add)")) return rc;
+        pre = gate != nullptr;
     }
     // encoder, last layer first; the image itself needs no gradient
     for (int i = m->n_enc - 1; i >= 0; --i) {
         const float *in = i > 0 ? ws + L.enc_out[i - 1] : x;
-        if (int rc = layer_backward(m->enc[i], batch, params, grads, in, ws + L.enc_out[i], mask_of(enc_mask[i]), cur,
-                                    i > 0 ? other : nullptr, slab, stream))
+        const float *gate = i > 0 ? relu_gate(m->enc[i - 1], enc_mask[i - 1], in) : nullptr;
+        bool gated = false;
+        if (int rc = layer_backward(m->enc[i], batch, params, grads, in, ws + L.enc_out[i], mask_of(enc_mask[i]), cur, pre,
+                                    gate, i > 0 ? other : nullptr, &gated, slab, stream))
             return rc;
+        pre = gated;
         float *t = cur; cur = other; other = t;
     }
     return ARVAE_OK;
