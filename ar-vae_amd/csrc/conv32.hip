@@ -199,8 +199,24 @@ __global__ __launch_bounds__(256, 2) void down32_kernel(Operand hi, const float 
                 *reinterpret_cast<float4 *>(lds + (((wave * 2 + mt) * 4 + q) * 64 + lane) * 4) =
                     make_float4(acc[mt][4 * q], acc[mt][4 * q + 1], acc[mt][4 * q + 2], acc[mt][4 * q + 3]);
         __syncthreads();
-        // wave w finishes registers [8*(w&1), +8) of MFMA tile (w>>1)
+        // wave w finishes registers [8*(w&1), +8) of MFMA tile (w>>1); gate loads first, then the stores
         const int mt = wave >> 1, q0 = (wave & 1) * 2;
+        int oidx[8];
+        float gv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int reg = 4 * q0 + j;
+            const int row = (reg & 3) + 8 * (reg >> 2) + 4 * half;      // pixel inside the MFMA tile
+            int img, r, c;
+            tile_pixel<LO>(mt * 32 + row, img, r, c);
+            const int n = img0 + img;
+            oidx[j] = n < n_img ? ((n * LO + r0 + r) * LO + c) * C32 + rc : -1;
+            gv[j] = 1.f;
+        }
+        if (ep.gate != nullptr) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gv[j] = ep.gate[oidx[j] < 0 ? 0 : oidx[j]];
+        }
 #pragma unroll
         for (int q = q0; q < q0 + 2; ++q) {
             float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -212,14 +228,11 @@ __global__ __launch_bounds__(256, 2) void down32_kernel(Operand hi, const float 
             const float sv[4] = {s.x, s.y, s.z, s.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int reg = 4 * q + e;
-                const int row = (reg & 3) + 8 * (reg >> 2) + 4 * half;      // pixel inside the MFMA tile
-                int img, r, c;
-                tile_pixel<LO>(mt * 32 + row, img, r, c);
-                const int n = img0 + img;
-                if (n < n_img) {
-                    const int idx = ((n * LO + r0 + r) * LO + c) * C32 + rc;
-                    ep.out[idx] = ep_apply(ep, sv[e], bias, idx);
+                const int j = 4 * (q - q0) + e;
+                if (oidx[j] >= 0) {
+                    float v = sv[e] + bias;
+                    if (ep.relu) v = fmaxf(v, 0.f);
+                    ep.out[oidx[j]] = gv[j] > 0.f ? v : 0.f;
                 }
             }
         }
@@ -305,6 +318,9 @@ __global__ __launch_bounds__(256, 2) void up32_kernel(Operand lo, const float *_
                     acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, w[ty][tx][ch][3], acc[1], 0, 0, 0);
                 }
 
+        // epilogue in two passes: all gate loads first (they must not queue behind the stores)
+        int oidx[2][16];
+        float gv[2][16];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -313,9 +329,23 @@ __global__ __launch_bounds__(256, 2) void up32_kernel(Operand lo, const float *_
                 int img, r, c;
                 tile_pixel<LO>(mt * 32 + row, img, r, c);
                 const int n = img0 + img;
-                if (n < n_img) {
-                    const int idx = ((n * HI + 2 * (r0 + r) + py) * HI + 2 * c + px) * C32 + rc;
-                    ep.out[idx] = ep_apply(ep, acc[mt][reg], bias, idx);
+                oidx[mt][reg] = n < n_img ? ((n * HI + 2 * (r0 + r) + py) * HI + 2 * c + px) * C32 + rc : -1;
+                gv[mt][reg] = 1.f;
+            }
+        if (ep.gate != nullptr) {                       // one uniform branch, then 32 independent loads in flight
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) gv[mt][reg] = ep.gate[oidx[mt][reg] < 0 ? 0 : oidx[mt][reg]];
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                if (oidx[mt][reg] >= 0) {
+                    float v = acc[mt][reg] + bias;
+                    if (ep.relu) v = fmaxf(v, 0.f);
+                    ep.out[oidx[mt][reg]] = gv[mt][reg] > 0.f ? v : 0.f;
                 }
             }
     }

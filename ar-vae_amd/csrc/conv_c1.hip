@@ -67,14 +67,23 @@ __global__ __launch_bounds__(256) void down_c1_kernel(Operand img, const float *
                 const float a = patch[(2 * r + (s >> 1)) * IPC + 2 * rc + 2 * (s & 1) + half];
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w8[s], acc, 0, 0, 0);
             }
+            float gv[16];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) gv[reg] = 1.f;
+            if (ep.gate != nullptr) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int ox = (reg & 3) + 8 * (reg >> 2) + 4 * half;
+                    gv[reg] = ep.gate[(((n * LO1) + r0 + r) * LO1 + ox) * CC + rc];
+                }
+            }
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int ox = (reg & 3) + 8 * (reg >> 2) + 4 * half;
                 const int idx = (((n * LO1) + r0 + r) * LO1 + ox) * CC + rc;
                 float v = acc[reg] + bias;
                 if (ep.relu) v = fmaxf(v, 0.f);
-                if (ep.gate != nullptr) v = ep.gate[idx] > 0.f ? v : 0.f;
-                ep.out[idx] = v;
+                ep.out[idx] = gv[reg] > 0.f ? v : 0.f;
             }
         }
     }
@@ -105,14 +114,16 @@ __global__ __launch_bounds__(256) void up_c1_kernel(const float *__restrict__ lo
         }
         __syncthreads();
         float acc[2][2] = {{bias, bias}, {bias, bias}};
+        // channel chunk outermost and NOT unrolled: only its 4 x 16 weights are live in scalar registers
+        // (all 512 at once spill through v_readlane)
+#pragma unroll 1
+        for (int q = 0; q < 8; ++q) {
+            const float *wq = wt + q * 64;                                  // wt[(q*4 + e)*16 + tap]
 #pragma unroll
-        for (int dy = -1; dy <= 1; ++dy)
+            for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-                const float *src = patch + ((yy + 1 + dy) * PC + xx + 1 + dx) * PS1;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const float4 a = *reinterpret_cast<const float4 *>(src + q * 4);
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const float4 a = *reinterpret_cast<const float4 *>(patch + ((yy + 1 + dy) * PC + xx + 1 + dx) * PS1 + q * 4);
                     const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
                     for (int py = 0; py < 2; ++py) {
@@ -124,12 +135,11 @@ __global__ __launch_bounds__(256) void up_c1_kernel(const float *__restrict__ lo
                             if (tx < 0 || tx > 1) continue;
                             const int tap = (1 - py + 2 * ty) * 4 + (1 - px + 2 * tx);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                acc[py][px] = fmaf(av[e], wt[(q * 4 + e) * 16 + tap], acc[py][px]);   // scalar load
+                            for (int e = 0; e < 4; ++e) acc[py][px] = fmaf(av[e], wq[e * 16 + tap], acc[py][px]);
                         }
                     }
                 }
-            }
+        }
         const int64_t o = (((int64_t)n * HI1) + 2 * (r0 + yy)) * HI1 + 2 * xx;
         *reinterpret_cast<float2 *>(out + o) = make_float2(acc[0][0], acc[0][1]);
         *reinterpret_cast<float2 *>(out + o + HI1) = make_float2(acc[1][0], acc[1][1]);
@@ -149,23 +159,53 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(Operand lo, Operand img, 
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     float lo_sum = 0.f, img_sum = 0.f;
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // register-staged loads (issued for tile t+1 before the MFMAs of tile t)
+    constexpr int IMG_ITERS = (IPR * 66 + 255) / 256;
+    float4 lr[8];
+    float ir[IMG_ITERS];
+    auto issue = [&](int tile) {
         const int n = tile / (LO1 / TR1), r0 = (tile % (LO1 / TR1)) * TR1;
-        __syncthreads();
-        img_sum += load_img_patch(patch, img, n, r0);
-        for (int idx = threadIdx.x; idx < 256 * 8; idx += 256) {
-            const int q = idx & 7, p = idx >> 3;        // p = r * 32 + c
-            float4 v;
-            const int64_t g = (((int64_t)n * LO1 + r0) * LO1 + p) * CC + q * 4;
-            v = *reinterpret_cast<const float4 *>(lo.v + g);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = threadIdx.x + it * 256;
+            const int64_t g = (((int64_t)n * LO1 + r0) * LO1 + (idx >> 3)) * CC + (idx & 7) * 4;
+            float4 v = *reinterpret_cast<const float4 *>(lo.v + g);
             if (lo.y != nullptr) {
                 const float4 y = *reinterpret_cast<const float4 *>(lo.y + g);
                 v.x *= act_bwd_from_out(y.x, lo.act); v.y *= act_bwd_from_out(y.y, lo.act);
                 v.z *= act_bwd_from_out(y.z, lo.act); v.w *= act_bwd_from_out(y.w, lo.act);
             }
-            *reinterpret_cast<float4 *>(lo_t + p * PS1 + q * 4) = v;
+            lr[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < IMG_ITERS; ++it) {
+            const int idx = threadIdx.x + it * 256;
+            const int pr = idx / 66, pc = idx - pr * 66;
+            const int gy = 2 * r0 - 1 + pr, gx = pc - 1;
+            ir[it] = 0.f;
+            if (idx < IPR * 66 && (unsigned)gy < (unsigned)HI1 && (unsigned)gx < (unsigned)HI1)
+                ir[it] = img.at(((int64_t)n * HI1 + gy) * HI1 + gx);
+        }
+    };
+    if (blockIdx.x < n_tiles) issue(blockIdx.x);
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int idx = threadIdx.x + it * 256;
+            *reinterpret_cast<float4 *>(lo_t + (idx >> 3) * PS1 + (idx & 7) * 4) = lr[it];
+        }
+#pragma unroll
+        for (int it = 0; it < IMG_ITERS; ++it) {
+            const int idx = threadIdx.x + it * 256;
+            if (idx < IPR * 66) {
+                const int pr = idx / 66, pc = idx - pr * 66;
+                patch[pr * IPC + pc] = ir[it];
+                if (pr >= 1 && pr <= 2 * TR1 && pc >= 1 && pc <= HI1) img_sum += ir[it];
+            }
         }
         __syncthreads();
+        if (tile + gridDim.x < n_tiles) issue(tile + gridDim.x);
 #pragma unroll
         for (int s = 0; s < 32; ++s) {                  // wave's 64 positions: rows 2w, 2w+1; pair (2s, 2s+1)
             const int r = 2 * wave + (s >> 4), c = (2 * s) & 31;
@@ -253,7 +293,7 @@ int conv_c1_up(const arvae_link_t *l, const float *lo, const float *wt, const fl
 
 static int wgrad_c1_groups(const arvae_link_t *l) {
     const int tiles = l->n * (LO1 / TR1);
-    return tiles < 1024 ? tiles : 1024;
+    return tiles < 512 ? tiles : 512;
 }
 
 int64_t conv_c1_wgrad_ws_floats(const arvae_link_t *l) { return (int64_t)wgrad_c1_groups(l) * WG1_SLAB; }
