@@ -19,7 +19,12 @@ int check_launch(const char *what);
         if (!(cond)) return ::arvae::fail(ARVAE_E_INVALID, __VA_ARGS__); \
     } while (0)
 
-static inline hipStream_t as_stream(arvae_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+// stream of the ABI call in progress on this thread (lets check_launch() timestamp kernels when profiling)
+extern thread_local hipStream_t g_cur_stream;
+static inline hipStream_t as_stream(arvae_stream_t s) {
+    g_cur_stream = reinterpret_cast<hipStream_t>(s);
+    return g_cur_stream;
+}
 
 // ---- division by a runtime constant (n < 2^31) -----------------------------------------------
 struct FastDiv {

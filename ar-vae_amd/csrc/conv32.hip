@@ -516,7 +516,7 @@ template <int LO> static int launch_down(const arvae_link_t *l, const Operand &h
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void *)down32_kernel<LO>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
     hipLaunchKernelGGL(down32_kernel<LO>, dim3(grid), dim3(256), LDS, s, hi, wt, ep, l->n, tiles);
-    return check_launch("down32");
+    return check_launch(LO == 16 ? "down32_kernel<16>" : LO == 8 ? "down32_kernel<8>" : "down32_kernel<4>");
 }
 
 int conv32_down(const arvae_link_t *l, const Operand &hi, const float *wt, const float *bias, int relu, const float *gate,
@@ -535,7 +535,7 @@ template <int LO> static int launch_up(const arvae_link_t *l, const Operand &lo,
     const int tiles = tiles_for<LO>(l->n);
     const int grid = tiles < 2 * cu_count() ? tiles : 2 * cu_count();
     hipLaunchKernelGGL(up32_kernel<LO>, dim3(grid), dim3(256), LDS, s, lo, wt, ep, l->n, tiles);
-    return check_launch("up32");
+    return check_launch(LO == 16 ? "up32_kernel<16>" : LO == 8 ? "up32_kernel<8>" : "up32_kernel<4>");
 }
 
 int conv32_up(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, int relu, const float *gate,
@@ -583,7 +583,7 @@ template <int LO> static int launch_wgrad(const arvae_link_t *l, const Operand &
         hipLaunchKernelGGL((wgrad32_kernel<LO, 2>), dim3(grid), dim3(256), LDS, s, lo, hi, slab, l->n, tiles);
     else
         hipLaunchKernelGGL((wgrad32_kernel<LO, 0>), dim3(grid), dim3(256), LDS, s, lo, hi, slab, l->n, tiles);
-    return check_launch("wgrad32");
+    return check_launch(LO == 16 ? "wgrad32_kernel<16>" : LO == 8 ? "wgrad32_kernel<8>" : "wgrad32_kernel<4>");
 }
 
 // bias_mode: 0 none, 1 dbias[clo] += sum lo, 2 dbias[chi] += sum hi
@@ -599,7 +599,7 @@ int conv32_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, fl
     if (rc) return rc;
     hipLaunchKernelGGL(wgrad32_reduce_kernel, dim3((WG32_SLAB + 15) / 16), dim3(256), 0, s, slab, grid, dwt,
                        bias_mode ? dbias : nullptr);
-    return check_launch("wgrad32(reduce)");
+    return check_launch("wgrad32_reduce_kernel");
 }
 
 }  // namespace arvae

@@ -281,14 +281,14 @@ int conv_c1_down(const arvae_link_t *l, const Operand &img, const float *wt, con
     const int tiles = l->n * (LO1 / TR1);
     Ep1 ep{bias, gate, out, relu};
     hipLaunchKernelGGL(down_c1_kernel, dim3(tiles < 2048 ? tiles : 2048), dim3(256), 0, s, img, wt, ep, tiles);
-    return check_launch("down_c1");
+    return check_launch("down_c1_kernel");
 }
 
 int conv_c1_up(const arvae_link_t *l, const float *lo, const float *wt, const float *bias, float *out, hipStream_t s) {
     const int tiles = l->n * (LO1 / TR1);
     constexpr int LDS = (TR1 + 2) * (LO1 + 2) * PS1 * 4;
     hipLaunchKernelGGL(up_c1_kernel, dim3(tiles < 768 ? tiles : 768), dim3(256), LDS, s, lo, wt, bias, out, tiles);
-    return check_launch("up_c1");
+    return check_launch("up_c1_kernel");
 }
 
 static int wgrad_c1_groups(const arvae_link_t *l) {
@@ -302,10 +302,10 @@ int conv_c1_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &img, 
                   float *slab, hipStream_t s) {
     const int tiles = l->n * (LO1 / TR1), grid = wgrad_c1_groups(l);
     hipLaunchKernelGGL(wgrad_c1_kernel, dim3(grid), dim3(256), 0, s, lo, img, slab, tiles);
-    if (int rc = check_launch("wgrad_c1")) return rc;
+    if (int rc = check_launch("wgrad_c1_kernel")) return rc;
     hipLaunchKernelGGL(wgrad_c1_reduce_kernel, dim3((WG1_SLAB + 15) / 16), dim3(256), 0, s, slab, grid, dwt, dbias,
                        bias_mode);
-    return check_launch("wgrad_c1(reduce)");
+    return check_launch("wgrad_c1_reduce_kernel");
 }
 
 }  // namespace arvae

@@ -213,21 +213,21 @@ int dense_fwd(const arvae_link_t *l, const float *x, const float *w, const float
     p.a = Operand{x, nullptr, nullptr, ARVAE_ACT_NONE};
     p.w = w; p.bias = bias; p.act = act; p.out = y;
     hipLaunchKernelGGL(dense_fwd_kernel, dim3((p.batch + 31) / 32, (p.n_out + 31) / 32), dim3(DENSE_THREADS), 0, s, p);
-    return check_launch("dense_fwd");
+    return check_launch("dense_fwd_kernel");
 }
 
 int dense_dgrad(const arvae_link_t *l, const Operand &g, const float *w, const float *gate, float *dx, hipStream_t s) {
     DenseArgs p = dense_args(l);
     p.a = g; p.w = w; p.out = dx; p.gate = gate;
     hipLaunchKernelGGL(dense_dgrad_kernel, dim3((p.batch + 31) / 32, (p.n_in + 31) / 32), dim3(DENSE_THREADS), 0, s, p);
-    return check_launch("dense_dgrad");
+    return check_launch("dense_dgrad_kernel");
 }
 
 int dense_wgrad(const arvae_link_t *l, const Operand &g, const float *x, float *dw, float *dbias, hipStream_t s) {
     DenseArgs p = dense_args(l);
     p.a = g; p.x = x; p.out = dw; p.dbias = dbias;
     hipLaunchKernelGGL(dense_wgrad_kernel, dim3((p.n_out + 31) / 32, (p.n_in + 31) / 32), dim3(DENSE_THREADS), 0, s, p);
-    return check_launch("dense_wgrad");
+    return check_launch("dense_wgrad_kernel");
 }
 
 }  // namespace arvae

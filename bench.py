@@ -9,9 +9,9 @@ Adam, on synthetic dSprites-shaped inputs that are resident in HBM before the ti
 reparameterisation noise is drawn on the device each step.  Prints ONE JSON line (rank 0).
 
 Extra objects in the line:
-  roofline      the dominant kernel family of the step, timed live with HIP events on the launch stream
-                in a separate instrumented pass (algorithmic FLOP / average launch duration vs the fp32
-                MFMA peak, or bytes vs HBM peak for a memory-bound family)
+  roofline      the dominant kernel of the step, timed live with HIP events on the launch stream in a
+                separate instrumented pass (algorithmic FLOP / average launch duration vs the fp32 MFMA
+                peak, or layer-boundary bytes vs the HBM peak for a memory-bound kernel)
   cpu_baseline  the CPU oracle (oracle/step.py, a port: the reference's Python cannot travel) timed on
                 this box's host cores on a bounded sample of the same workload (rank 0, N = 1 only)
 """
@@ -35,6 +35,19 @@ PEAK_HBM_GBS = 8000.0
 FLOP_PER_IMAGE = 73_708_544
 BYTES_PER_IMAGE = 1_862_936
 PARAM_BYTES_PER_STEP = 20_080_200
+
+# algorithmic work of the step's link kernels, per image and launch: MACs (SURVEY.md section 8(d) per-layer
+# table) and layer-boundary bytes (operand tensors read once + result written once, fp32)
+KERNEL_WORK = {
+    'down32_kernel<16>': (4_194_304, 4 * (32768 + 8192)), 'up32_kernel<16>': (4_194_304, 4 * (8192 + 32768)),
+    'wgrad32_kernel<16>': (4_194_304, 4 * (8192 + 32768)),
+    'down32_kernel<8>': (1_048_576, 4 * (8192 + 2048)), 'up32_kernel<8>': (1_048_576, 4 * (2048 + 8192)),
+    'wgrad32_kernel<8>': (1_048_576, 4 * (2048 + 8192)),
+    'down32_kernel<4>': (262_144, 4 * (2048 + 512)), 'up32_kernel<4>': (262_144, 4 * (512 + 2048)),
+    'wgrad32_kernel<4>': (262_144, 4 * (512 + 2048)),
+    'down_c1_kernel': (524_288, 4 * (4096 + 32768)), 'up_c1_kernel': (524_288, 4 * (32768 + 4096)),
+    'wgrad_c1_kernel': (524_288, 4 * (32768 + 4096)),
+}
 
 REG_DIMS = (1, 2, 3, 4, 5)
 BETA, GAMMA, DELTA = 4.0, 10.0, 1.0
@@ -119,7 +132,6 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=device)
 
-    from arvae_amd import ops
     from arvae_amd import synthetic as syn
 
     trainer, state = build_trainer(device, world)
@@ -161,12 +173,23 @@ def main():
     if not np.isfinite(final_loss):
         raise SystemExit(f'non-finite loss {final_loss}')
 
-    # ---- instrumented pass: per-kernel-family device time (HIP events on the launch stream) -----------
-    ops.profile_begin()
-    prof_steps = 5
+    # ---- instrumented pass: per-kernel device time from HIP events recorded by the library on the launch
+    # stream after every kernel (arvae_profile_begin/_end); a separate pass so the timed region is untouched
+    import ctypes
+    from arvae_amd import _lib
+    lib = _lib.load()
+    prof_steps = 10
+    lib.arvae_profile_begin(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     for i in range(prof_steps):
         step(i)
-    prof = ops.profile_end()
+    buf = ctypes.create_string_buffer(1 << 16)
+    lib.arvae_profile_end(buf, len(buf))
+    prof = {}
+    for line in buf.value.decode().splitlines():
+        name, calls, ms = line.split('\t')
+        macs, nbytes = KERNEL_WORK.get(name, (0, 0))
+        prof[name] = dict(calls=int(calls), ms=float(ms), flop=2.0 * macs * b * int(calls),
+                          bytes=float(nbytes) * b * int(calls))
     fence()
 
     if rank != 0:
@@ -175,7 +198,7 @@ def main():
         return
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * b * args.steps / elapsed
-    dom_name, dom = max(prof.items(), key=lambda kv: kv[1]['ms'])
+    dom_name, dom = max(((k, v) for k, v in prof.items() if v['flop'] > 0), key=lambda kv: kv[1]['ms'])
     avg_ms = dom['ms'] / dom['calls']
     if dom['flop'] > 0 and dom['flop'] / max(dom['bytes'], 1.0) > PEAK_F32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9):
         achieved = dom['flop'] / dom['calls'] / (avg_ms * 1e-3) / 1e12
@@ -185,6 +208,16 @@ def main():
         achieved = dom['bytes'] / dom['calls'] / (avg_ms * 1e-3) / 1e9
         roof = {'bound': 'hbm', 'achieved': achieved, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                 'frac': achieved / PEAK_HBM_GBS, 'traffic': None}
+    # HBM traffic of that kernel from the PMC counters: collected in separate rocprofv3 --pmc passes of this
+    # same command (FETCH_SIZE / WRITE_SIZE cannot share a pass) and committed under profiles/
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r1_pmc_traffic.json')) as f:
+            roof['traffic'] = json.load(f)['kernels'][dom_name]['hbm_bytes_per_launch']
+        roof['traffic_source'] = 'profiles/r1_pmc_traffic.json (rocprofv3 --pmc, 2*FETCH_SIZE + WRITE_SIZE, B=512)'
+    except (OSError, KeyError, ValueError):
+        roof['traffic'] = None
+    if b != 512:
+        roof['traffic'] = None
     roof.update({'kernel': dom_name, 'launches_per_step': dom['calls'] / prof_steps, 'avg_launch_us': avg_ms * 1e3,
                  'share_of_device_time': dom['ms'] / sum(v['ms'] for v in prof.values())})
     per_gpu = value / world

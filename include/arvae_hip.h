@@ -46,6 +46,14 @@ const char *arvae_last_error_string(void);
 /* number of HIP devices visible (0 on a CPU-only host; never initialises a context) */
 int arvae_device_count(void);
 
+/* Opt-in kernel timeline for benchmarking (off by default, no cost when off): after arvae_profile_begin
+ * every kernel the library launches on `stream` is followed by a HIP event on that stream; a kernel's
+ * duration is the time since the previous event.  arvae_profile_end stops recording, synchronises on
+ * the last event and writes one text line per kernel label: "<label>\t<launches>\t<total ms>\n";
+ * it returns the buffer size needed.  Labels name the __global__ function (e.g. "up32<16>"). */
+int arvae_profile_begin(arvae_stream_t stream);
+int64_t arvae_profile_end(char *out, int64_t cap);
+
 /* ------------------------------------------------------------------------------------------------
  * Strided "link" between a HI-resolution tensor hi[N,HH,HW,CHI] and a LO-resolution tensor
  * lo[N,LH,LW,CLO] through a weight wt[CLO][CHI][KH][KW]:
