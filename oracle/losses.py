@@ -137,3 +137,19 @@ def adam_step(p, g, m, v, step, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8):
     denom = np.sqrt(v) / np.float32(np.sqrt(bc2)) + np.float32(eps)
     p = (p - np.float32(lr / bc1) * (m / denom)).astype(np.float32)
     return p, m, v
+
+
+def reg_loss_row_block(z_rows, lab_rows, dims, gamma, delta, z_cols=None, lab_cols=None):
+    """Differentiable row-block form used under data parallelism: rows = this rank's
+    samples, cols = the gathered global batch (constants).  VALUE = this rank's share of the global loss
+    (mean over len(cols)^2 pairs); GRADIENT w.r.t. z_rows = the FULL d(global loss)/d z_i, i.e. twice the
+    row-role gradient (the pair term is symmetric under i <-> j)."""
+    zc = z_rows.detach() if z_cols is None else z_cols.detach()
+    lc = lab_rows if lab_cols is None else lab_cols
+    n = zc.shape[0]
+    total = z_rows.new_zeros(())
+    for d in dims:
+        dx = z_rows[:, d][:, None] - zc[:, d][None, :]
+        da = lab_rows[:, d][:, None] - lc[:, d][None, :]
+        total = total + gamma * (torch.tanh(delta * dx) - torch.sign(da)).abs().sum() / (n * n)
+    return 2.0 * total - total.detach()

@@ -1,0 +1,94 @@
+"""Data-parallel logic on CPU: two gloo ranks, each holding half of a batch, must reproduce the single-process
+loss and gradient.  The DP layer (ar-vae_amd/parallel.py) is compute-agnostic; here the CPU oracle supplies the
+math (tests may do that -- the product path never does), so this covers the N>1 collectives and scaling rules:
+row-major all-gather of the regularised columns, W x row-block reg loss, SUM all-reduce + 1/W in Adam."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DIMS = (1, 2, 3, 4, 5)
+BETA, GAMMA, DELTA = 4.0, 10.0, 1.0
+
+
+class ArenaStub:
+    """The two FlatAdam members DataParallel.reduce_gradients touches."""
+
+    def __init__(self, n):
+        self.grad_arena = torch.zeros(n)
+        self.grad_scale = 1.0
+
+    def ensure_arena(self):
+        return self.grad_arena
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, b_total, out_path):
+    import sys
+    sys.path.insert(0, ROOT)
+    from arvae_amd import synthetic as syn
+    from arvae_amd.parallel import DataParallel
+    from oracle import image_vae as o_vae
+    from oracle import losses as o_losses
+    torch.set_num_threads(1)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        state = syn.synth_state(o_vae.DSPRITES_SHAPES, 1, 1.6)
+        x, lab = syn.dsprites_batch(b_total, seed=1234)
+        eps = syn.normal_noise((b_total, 10), seed=12)
+        bl = b_total // world
+        sl = slice(rank * bl, (rank + 1) * bl)
+        p = {k: torch.from_numpy(v).clone().requires_grad_(True) for k, v in state.items()}
+        xt, lt, et = torch.from_numpy(x[sl]), torch.from_numpy(lab[sl]), torch.from_numpy(eps[sl])
+        dp = DataParallel(reg_fn=o_losses.reg_loss_row_block)
+        logits, mu, sigma, z = o_vae.forward('dsprites', p, xt, et)
+        recon = o_losses.bce_with_logits_per_batch(logits, xt)
+        kld = o_losses.kld_loss(mu, sigma, BETA, 0.0)
+        reg = dp.reg_loss(z, lt, DIMS, GAMMA, DELTA)           # = W * row-block share
+        loss = recon + kld + reg
+        loss.backward()
+        flat = torch.cat([p[k].grad.reshape(-1) for k in state])
+        opt = ArenaStub(flat.numel())
+        opt.grad_arena.copy_(flat)
+        dp.reduce_gradients(opt)
+        mean_loss = float(dp.mean_scalar(loss))
+        gathered = dp.gather_columns(torch.full((bl, 2), float(rank)))
+        if rank == 0:
+            np.savez(out_path, grad=(opt.grad_arena * opt.grad_scale).numpy(), loss=mean_loss,
+                     gathered=gathered.numpy(), scale=opt.grad_scale)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2])
+def test_two_rank_step_equals_single_process(tmp_path, world):
+    from arvae_amd import synthetic as syn
+    from oracle import image_vae as o_vae
+    from oracle import step as o_step
+    b_total = 16
+    out = str(tmp_path / 'dp.npz')
+    mp.spawn(_worker, args=(world, _free_port(), b_total, out), nprocs=world, join=True)
+    got = np.load(out)
+    state = syn.synth_state(o_vae.DSPRITES_SHAPES, 1, 1.6)
+    x, lab = syn.dsprites_batch(b_total, seed=1234)
+    eps = syn.normal_noise((b_total, 10), seed=12)
+    ref = o_step.image_step('dsprites', state, x, lab, eps, DIMS, BETA, GAMMA, DELTA)
+    want = np.concatenate([ref['grads'][k].ravel() for k in state])
+    assert got['scale'] == pytest.approx(1.0 / world)
+    np.testing.assert_allclose(got['loss'], ref['terms']['loss'], rtol=1e-5)
+    assert np.linalg.norm(got['grad'] - want) <= 1e-4 * np.linalg.norm(want)
+    # all_gather_into_tensor is rank-major: rows of rank 0 first
+    bl = b_total // world
+    assert (got['gathered'][:bl] == 0).all() and (got['gathered'][bl:] == 1).all()
