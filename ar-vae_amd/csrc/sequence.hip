@@ -1,0 +1,276 @@
+// Kernels of the MeasureVAE path that are not GEMMs: GRU gate math (forward / backward), embedding gather
+// and its gradient, top-1 feedback, column concat / split, dropout masks, and the measure attribute labels.
+// The GEMMs of the GRUs (W_ih x, W_hh h) run on the dense MFMA kernels (dense.hip).
+//
+// GRU cell (PyTorch gate order r, z, n stacked in rows; reference measurevae/encoder.py:27-34,
+// measurevae/decoder.py:338-368 via nn.GRU):
+//     r = sigmoid(gi_r + gh_r);  z = sigmoid(gi_z + gh_z);  n = tanh(gi_n + r * gh_n);  h' = (1-z)*n + z*h
+#include "common.h"
+
+namespace arvae {
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// gi, gh: [B, 3H] (bias already added); h_prev: [B, H] or null (zeros).  saved: [4][B][H] = r, z, n, gh_n
+__global__ __launch_bounds__(256) void gru_gates_fwd_kernel(const float *__restrict__ gi, const float *__restrict__ gh,
+                                                             const float *__restrict__ h_prev, int batch, int hid,
+                                                             float *__restrict__ h_new, float *__restrict__ saved) {
+    const int64_t total = (int64_t)batch * hid;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int b = (int)(i / hid), j = (int)(i - (int64_t)b * hid);
+        const float *gib = gi + (int64_t)b * 3 * hid, *ghb = gh + (int64_t)b * 3 * hid;
+        const float r = sigmoidf_(gib[j] + ghb[j]);
+        const float z = sigmoidf_(gib[hid + j] + ghb[hid + j]);
+        const float ghn = ghb[2 * hid + j];
+        const float n = tanhf(gib[2 * hid + j] + r * ghn);
+        const float hp = h_prev != nullptr ? h_prev[i] : 0.f;
+        h_new[i] = (1.f - z) * n + z * hp;
+        if (saved != nullptr) {
+            saved[i] = r;
+            saved[total + i] = z;
+            saved[2 * total + i] = n;
+            saved[3 * total + i] = ghn;
+        }
+    }
+}
+
+// dh: gradient w.r.t. h'.  Outputs dgi, dgh [B,3H] and dh_prev [B,H] (= dh * z, the direct path only).
+__global__ __launch_bounds__(256) void gru_gates_bwd_kernel(const float *__restrict__ dh, const float *__restrict__ saved,
+                                                             const float *__restrict__ h_prev, int batch, int hid,
+                                                             float *__restrict__ dgi, float *__restrict__ dgh,
+                                                             float *__restrict__ dh_prev) {
+    const int64_t total = (int64_t)batch * hid;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int b = (int)(i / hid), j = (int)(i - (int64_t)b * hid);
+        const float r = saved[i], z = saved[total + i], n = saved[2 * total + i], ghn = saved[3 * total + i];
+        const float hp = h_prev != nullptr ? h_prev[i] : 0.f;
+        const float g = dh[i];
+        const float dpn = g * (1.f - z) * (1.f - n * n);
+        const float dpz = g * (hp - n) * z * (1.f - z);
+        const float dpr = dpn * ghn * r * (1.f - r);
+        float *dgib = dgi + (int64_t)b * 3 * hid, *dghb = dgh + (int64_t)b * 3 * hid;
+        dgib[j] = dpr; dghb[j] = dpr;
+        dgib[hid + j] = dpz; dghb[hid + j] = dpz;
+        dgib[2 * hid + j] = dpn; dghb[2 * hid + j] = dpn * r;
+        dh_prev[i] = g * z;
+    }
+}
+
+// out[(t*B + b) or (b*T + t)][:] = table[idx[b*T + t]][:]
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t *__restrict__ idx, const float *__restrict__ table,
+                                                         int batch, int steps, int dim, int vocab, int time_major,
+                                                         float *__restrict__ out) {
+    const int64_t total = (int64_t)batch * steps * dim;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int d = (int)(i % dim);
+        const int64_t row = i / dim;                         // output row
+        const int b = time_major ? (int)(row % batch) : (int)(row / steps);
+        const int t = time_major ? (int)(row / batch) : (int)(row % steps);
+        int64_t v = idx[(int64_t)b * steps + t];
+        v = v < 0 ? 0 : (v >= vocab ? vocab - 1 : v);
+        out[i] = table[v * dim + d];
+    }
+}
+
+// dtable[v][d] += sum over positions with idx == v of g[row][d]; one workgroup per vocabulary row: fixed order
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t *__restrict__ idx, const float *__restrict__ g,
+                                                         int batch, int steps, int dim, int time_major,
+                                                         float *__restrict__ dtable) {
+    __shared__ float red[256];
+    const int v = blockIdx.x;
+    const int d = threadIdx.x % dim, lane_row = threadIdx.x / dim, rows_par = 256 / dim;
+    float s = 0.f;
+    if (lane_row < rows_par) {
+        const int64_t n = (int64_t)batch * steps;
+        for (int64_t pos = lane_row; pos < n; pos += rows_par) {           // pos = b*steps + t
+            if (idx[pos] == v) {
+                const int b = (int)(pos / steps), t = (int)(pos % steps);
+                const int64_t row = time_major ? (int64_t)t * batch + b : pos;
+                s += g[row * dim + d];
+            }
+        }
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < dim) {
+        float tot = 0.f;
+        for (int j = 0; j < rows_par; ++j) tot += red[j * dim + threadIdx.x];
+        dtable[(int64_t)v * dim + threadIdx.x] += tot;
+    }
+}
+
+// idx[b] = argmax_j w[b][j], lowest index on ties (reference decoder.py:506-507 topk(1))
+__global__ __launch_bounds__(256) void row_argmax_kernel(const float *__restrict__ w, int rows, int cols,
+                                                          int64_t *__restrict__ idx) {
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < rows; r += gridDim.x * 256) {
+        const float *row = w + (int64_t)r * cols;
+        float mx = row[0];
+        int arg = 0;
+        for (int j = 1; j < cols; ++j)
+            if (row[j] > mx) { mx = row[j]; arg = j; }
+        idx[r] = arg;
+    }
+}
+
+// out[r] = [a[r] | b[r]]  and the adjoint split
+__global__ __launch_bounds__(256) void concat_cols_kernel(const float *__restrict__ a, const float *__restrict__ b, int64_t rows,
+                                                           int ca, int cb, float *__restrict__ out) {
+    const int c = ca + cb;
+    const int64_t total = rows * c;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / c;
+        const int j = (int)(i - r * c);
+        out[i] = j < ca ? a[r * ca + j] : b[r * cb + (j - ca)];
+    }
+}
+__global__ __launch_bounds__(256) void split_cols_kernel(const float *__restrict__ g, int64_t rows, int ca, int cb,
+                                                          float *__restrict__ da, float *__restrict__ db, int accumulate_b) {
+    const int c = ca + cb;
+    const int64_t total = rows * c;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / c;
+        const int j = (int)(i - r * c);
+        if (j < ca) {
+            if (da != nullptr) da[r * ca + j] = g[i];
+        } else if (db != nullptr) {
+            if (accumulate_b) db[r * cb + (j - ca)] += g[i];
+            else db[r * cb + (j - ca)] = g[i];
+        }
+    }
+}
+
+// y = alpha * x * (mask ? mask : 1) + (accumulate ? y : 0)
+__global__ __launch_bounds__(256) void scale_mask_kernel(const float *__restrict__ x, const uint8_t *__restrict__ mask,
+                                                          float alpha, int64_t count, int accumulate, float *__restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+        const float v = alpha * x[i] * (mask != nullptr ? (float)mask[i] : 1.f);
+        y[i] = accumulate ? y[i] + v : v;
+    }
+}
+
+// broadcast rows: y[r][:] = v[:]  (learned start vectors x_0 / b_0) and its adjoint column sum
+__global__ __launch_bounds__(256) void broadcast_rows_kernel(const float *__restrict__ v, int64_t rows, int cols, float *__restrict__ y) {
+    const int64_t total = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) y[i] = v[i % cols];
+}
+
+// measure attributes (reference bar_dataset.py:338-500 via measure_vae_trainer.py:167-186): one lane per measure
+//   out[b] = [rhythmic complexity, pitch range / 26, note density, contour / 26]
+__global__ __launch_bounds__(256) void measure_attributes_kernel(const int64_t *__restrict__ score, int batch, int steps,
+                                                                  const int32_t *__restrict__ midi, const uint8_t *__restrict__ is_note,
+                                                                  const uint8_t *__restrict__ is_dens, int vocab,
+                                                                  const float *__restrict__ rhy_w, float rhy_norm,
+                                                                  float *__restrict__ out) {
+    for (int b = blockIdx.x * 256 + threadIdx.x; b < batch; b += gridDim.x * 256) {
+        float rhy = 0.f;
+        int dens = 0, count = 0, first = 0, last = 0, lo = 0, hi = 0;
+        for (int t = 0; t < steps; ++t) {
+            int64_t v = score[(int64_t)b * steps + t];
+            v = v < 0 ? 0 : (v >= vocab ? vocab - 1 : v);
+            dens += is_dens[v];
+            if (is_note[v]) {
+                rhy += rhy_w[t];
+                const int m = midi[v];
+                if (count == 0) { first = lo = hi = m; }
+                last = m;
+                lo = m < lo ? m : lo;
+                hi = m > hi ? m : hi;
+                ++count;
+            }
+        }
+        float *o = out + (int64_t)b * 4;
+        o[0] = rhy / rhy_norm;
+        o[1] = count >= 2 ? (float)(hi - lo) / 26.f : 0.f;
+        o[2] = (float)dens / (float)steps;
+        o[3] = count >= 2 ? (float)(last - first) / 26.f : 0.f;
+    }
+}
+
+static inline int blocks_for(int64_t n, int cap = 2048) {
+    int64_t b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace arvae
+
+using namespace arvae;
+
+extern "C" int arvae_gru_gates_fwd(const float *gi, const float *gh, const float *h_prev, int32_t batch, int32_t hidden,
+                                   float *h_new, float *saved, arvae_stream_t stream) {
+    ARVAE_REQUIRE(gi && gh && h_new && batch > 0 && hidden > 0, "gru_gates_fwd: bad argument");
+    hipLaunchKernelGGL(gru_gates_fwd_kernel, dim3(blocks_for((int64_t)batch * hidden)), dim3(256), 0, as_stream(stream), gi,
+                       gh, h_prev, batch, hidden, h_new, saved);
+    return check_launch("gru_gates_fwd_kernel");
+}
+
+extern "C" int arvae_gru_gates_bwd(const float *dh, const float *saved, const float *h_prev, int32_t batch, int32_t hidden,
+                                   float *dgi, float *dgh, float *dh_prev, arvae_stream_t stream) {
+    ARVAE_REQUIRE(dh && saved && dgi && dgh && dh_prev && batch > 0 && hidden > 0, "gru_gates_bwd: bad argument");
+    hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3(blocks_for((int64_t)batch * hidden)), dim3(256), 0, as_stream(stream), dh,
+                       saved, h_prev, batch, hidden, dgi, dgh, dh_prev);
+    return check_launch("gru_gates_bwd_kernel");
+}
+
+extern "C" int arvae_embed_fwd(const int64_t *idx, const float *table, int32_t batch, int32_t steps, int32_t dim,
+                               int32_t vocab, int32_t time_major, float *out, arvae_stream_t stream) {
+    ARVAE_REQUIRE(idx && table && out && batch > 0 && steps > 0 && dim > 0 && vocab > 0, "embed_fwd: bad argument");
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(blocks_for((int64_t)batch * steps * dim)), dim3(256), 0, as_stream(stream), idx,
+                       table, batch, steps, dim, vocab, time_major, out);
+    return check_launch("embed_fwd_kernel");
+}
+
+extern "C" int arvae_embed_bwd(const int64_t *idx, const float *g, int32_t batch, int32_t steps, int32_t dim,
+                               int32_t vocab, int32_t time_major, float *dtable, arvae_stream_t stream) {
+    ARVAE_REQUIRE(idx && g && dtable && batch > 0 && steps > 0 && dim > 0 && dim <= 256 && vocab > 0,
+                  "embed_bwd: bad argument (dim must be <= 256)");
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(vocab), dim3(256), 0, as_stream(stream), idx, g, batch, steps, dim, time_major,
+                       dtable);
+    return check_launch("embed_bwd_kernel");
+}
+
+extern "C" int arvae_row_argmax(const float *w, int32_t rows, int32_t cols, int64_t *idx, arvae_stream_t stream) {
+    ARVAE_REQUIRE(w && idx && rows > 0 && cols > 0, "row_argmax: bad argument");
+    hipLaunchKernelGGL(row_argmax_kernel, dim3(blocks_for(rows)), dim3(256), 0, as_stream(stream), w, rows, cols, idx);
+    return check_launch("row_argmax_kernel");
+}
+
+extern "C" int arvae_concat_cols(const float *a, const float *b, int64_t rows, int32_t ca, int32_t cb, float *out,
+                                 arvae_stream_t stream) {
+    ARVAE_REQUIRE(a && b && out && rows > 0 && ca > 0 && cb > 0, "concat_cols: bad argument");
+    hipLaunchKernelGGL(concat_cols_kernel, dim3(blocks_for(rows * (ca + cb))), dim3(256), 0, as_stream(stream), a, b, rows, ca,
+                       cb, out);
+    return check_launch("concat_cols_kernel");
+}
+
+extern "C" int arvae_split_cols(const float *g, int64_t rows, int32_t ca, int32_t cb, float *da, float *db,
+                                int32_t accumulate_b, arvae_stream_t stream) {
+    ARVAE_REQUIRE(g && rows > 0 && ca > 0 && cb > 0, "split_cols: bad argument");
+    hipLaunchKernelGGL(split_cols_kernel, dim3(blocks_for(rows * (ca + cb))), dim3(256), 0, as_stream(stream), g, rows, ca, cb,
+                       da, db, accumulate_b);
+    return check_launch("split_cols_kernel");
+}
+
+extern "C" int arvae_scale_mask(const float *x, const uint8_t *mask, float alpha, int64_t count, int32_t accumulate,
+                                float *y, arvae_stream_t stream) {
+    ARVAE_REQUIRE(x && y && count > 0, "scale_mask: bad argument");
+    hipLaunchKernelGGL(scale_mask_kernel, dim3(blocks_for(count)), dim3(256), 0, as_stream(stream), x, mask, alpha, count,
+                       accumulate, y);
+    return check_launch("scale_mask_kernel");
+}
+
+extern "C" int arvae_broadcast_rows(const float *v, int64_t rows, int32_t cols, float *y, arvae_stream_t stream) {
+    ARVAE_REQUIRE(v && y && rows > 0 && cols > 0, "broadcast_rows: bad argument");
+    hipLaunchKernelGGL(broadcast_rows_kernel, dim3(blocks_for(rows * cols)), dim3(256), 0, as_stream(stream), v, rows, cols, y);
+    return check_launch("broadcast_rows_kernel");
+}
+
+extern "C" int arvae_measure_attributes(const int64_t *score, int32_t batch, int32_t steps, const int32_t *midi_lut,
+                                             const uint8_t *is_note, const uint8_t *is_density_note, int32_t vocab,
+                                             const float *rhythm_weights, float rhythm_norm, float *out,
+                                             arvae_stream_t stream) {
+    ARVAE_REQUIRE(score && midi_lut && is_note && is_density_note && rhythm_weights && out && batch > 0 && steps > 0 &&
+                      vocab > 0 && rhythm_norm > 0.f, "measure_attributes: bad argument");
+    hipLaunchKernelGGL(measure_attributes_kernel, dim3(blocks_for(batch)), dim3(256), 0, as_stream(stream), score, batch, steps,
+                       midi_lut, is_note, is_density_note, vocab, rhythm_weights, rhythm_norm, out);
+    return check_launch("measure_attributes_kernel");
+}

@@ -1,0 +1,300 @@
+"""MeasureVAE (GRU encoder + hierarchical GRU decoder over 24-tick measures) on the HIP kernels.
+
+Same class names, constructor arguments, forward contract and state_dict keys as the reference
+(measurevae/encoder.py:8-124, measurevae/decoder.py:7-51,309-525, measurevae/measure_vae.py:11-131):
+    MeasureVAE.forward(score, metadata, train) -> (weights (B,24,V), samples (B,1,24), z_dist, prior_dist, z_tilde, z_prior)
+The GEMMs of the GRUs run on the dense MFMA kernels, the gate math / embedding / argmax feedback on the
+sequence kernels (csrc/sequence.hip); autograd chains them (round 1: one autograd node per kernel).
+"""
+from collections import deque
+
+import torch
+from torch import distributions, nn
+
+from . import ops
+from .model import LayerStack, Model, ParamLayer
+from .ops import ACT_NONE, ACT_RELU, ACT_SELU, Link
+
+
+class GRUParams(nn.Module):
+    """Parameters of an nn.GRU under torch's names (weight_ih_l0, weight_hh_l0_reverse, ...)."""
+
+    def __init__(self, input_size, hidden_size, num_layers, bidirectional):
+        super().__init__()
+        self.input_size, self.hidden_size, self.num_layers = input_size, hidden_size, num_layers
+        self.num_directions = 2 if bidirectional else 1
+        bound = 1.0 / (hidden_size ** 0.5)
+        for layer in range(num_layers):
+            in_l = input_size if layer == 0 else hidden_size * self.num_directions
+            for suf in ([''] + (['_reverse'] if bidirectional else [])):
+                for name, shape in ((f'weight_ih_l{layer}{suf}', (3 * hidden_size, in_l)),
+                                    (f'weight_hh_l{layer}{suf}', (3 * hidden_size, hidden_size)),
+                                    (f'bias_ih_l{layer}{suf}', (3 * hidden_size,)),
+                                    (f'bias_hh_l{layer}{suf}', (3 * hidden_size,))):
+                    p = nn.Parameter(torch.empty(*shape))
+                    nn.init.uniform_(p, -bound, bound)
+                    self.register_parameter(name, p)
+
+    def cell(self, layer, suffix=''):
+        g = lambda n: getattr(self, f'{n}_l{layer}{suffix}')
+        return g('weight_ih'), g('weight_hh'), g('bias_ih'), g('bias_hh')
+
+
+class Embedding(nn.Module):
+    def __init__(self, num, dim):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(num, dim))
+
+
+def _dense_layer(fin, fout):
+    return LayerStack([(0, ParamLayer((fout, fin), fout, fin))])
+
+
+def _lin(x, layer, act):
+    w = layer.weight
+    return ops.dense(x, w, layer.bias, Link.dense(w.shape[1], w.shape[0]), act)
+
+
+def _gru_step(x_proj, h, w_hh, b_hh):
+    """one GRU time step given the input projection gi = W_ih x + b_ih."""
+    gh = ops.dense(h, w_hh, b_hh, Link.dense(w_hh.shape[1], w_hh.shape[0]), ACT_NONE)
+    return ops.gru_gates(x_proj, gh, h)
+
+
+class Encoder(Model):
+    def __init__(self, note_embedding_dim, rnn_hidden_size, num_layers, num_notes, dropout, bidirectional, z_dim,
+                 rnn_class=nn.GRU):
+        super().__init__()
+        if not bidirectional or num_layers != 2:
+            raise NotImplementedError('the HIP encoder implements the reference configuration: 2-layer bidirectional GRU')
+        self.bidirectional, self.num_directions = bidirectional, 2
+        self.note_embedding_dim, self.num_layers = note_embedding_dim, num_layers
+        self.rnn_hidden_size, self.z_dim, self.dropout, self.rnn_class = rnn_hidden_size, z_dim, dropout, rnn_class
+        self.num_notes = num_notes
+        self.lstm = GRUParams(note_embedding_dim, rnn_hidden_size, num_layers, bidirectional)
+        self.note_embedding_layer = Embedding(num_notes, note_embedding_dim)
+        feat = rnn_hidden_size * 2 * num_layers
+        self.linear_mean = LayerStack([(0, ParamLayer((rnn_hidden_size * 2, feat), rnn_hidden_size * 2, feat)),
+                                       (2, ParamLayer((z_dim, rnn_hidden_size * 2), z_dim, rnn_hidden_size * 2))])
+        self.linear_log_std = LayerStack([(0, ParamLayer((rnn_hidden_size * 2, feat), rnn_hidden_size * 2, feat)),
+                                          (2, ParamLayer((z_dim, rnn_hidden_size * 2), z_dim, rnn_hidden_size * 2))])
+        self.xavier_initialization()
+        self._mask_queue = deque()
+        self._eps_queue = deque()
+
+    def __repr__(self):
+        return (f'Encoder({self.note_embedding_dim},{self.rnn_class},{self.num_layers},{self.rnn_hidden_size},'
+                f'{self.dropout},{self.bidirectional},{self.z_dim},)')
+
+    def push_dropout_mask(self, mask):
+        """explicit keep-mask (24, B, 2H) uint8 for the layer-0 outputs (parity runs)."""
+        self._mask_queue.append(mask)
+
+    def embed_forward(self, score_tensor):
+        return ops.embed(score_tensor, self.note_embedding_layer.weight)
+
+    def _layer(self, seq, layer):
+        """seq: list of T tensors (B, in) -> (list of T (B, 2H), [final fwd, final rev])."""
+        steps, b = len(seq), seq[0].shape[0]
+        x_all = torch.cat(seq, 0)                                    # (T*B, in), time-major rows
+        outs, finals = [], []
+        for suffix in ('', '_reverse'):
+            w_ih, w_hh, b_ih, b_hh = self.lstm.cell(layer, suffix)
+            gi_all = ops.dense(x_all, w_ih, b_ih, Link.dense(w_ih.shape[1], w_ih.shape[0]), ACT_NONE)
+            gi = torch.unbind(gi_all.view(steps, b, -1), 0)
+            h = torch.zeros(b, self.rnn_hidden_size, device=x_all.device)
+            hs = [None] * steps
+            for t in (range(steps) if suffix == '' else range(steps - 1, -1, -1)):
+                h = _gru_step(gi[t], h, w_hh, b_hh)
+                hs[t] = h
+            outs.append(hs)
+            finals.append(h)
+        return [ops.concat_cols(f, r) for f, r in zip(*outs)], finals
+
+    def push_noise(self, eps):
+        """use `eps` (B, z_dim) for the next reparameterised sample instead of drawing it."""
+        self._eps_queue.append(eps)
+
+    def forward(self, score_tensor):
+        """score (B, 24) int64 -> Normal(mu, exp(log_std)); the reparameterised sample computed by the same
+        fused kernel travels with the distribution object (z_dist._arvae_sample)."""
+        mu, log_std = self.encode_params(score_tensor)
+        eps = self._eps_queue.popleft().to(mu.device, torch.float32).contiguous() if self._eps_queue else torch.randn_like(mu)
+        sigma, z = ops.latent_head(mu, log_std, eps)
+        z_dist = distributions.Normal(loc=mu, scale=sigma, validate_args=False)
+        z_dist._arvae_sample = z
+        return z_dist
+
+    def encode_params(self, score_tensor):
+        """-> (mu, log_std)"""
+        b, steps = score_tensor.shape
+        emb = ops.embed(score_tensor, self.note_embedding_layer.weight, time_major=True)      # (T, B, E)
+        seq = list(torch.unbind(emb, 0))
+        seq, finals0 = self._layer(seq, 0)
+        if self.training and self.dropout > 0:
+            mask = self._mask_queue.popleft().to(emb.device) if self._mask_queue else \
+                (torch.rand(steps, b, 2 * self.rnn_hidden_size, device=emb.device) >= self.dropout).to(torch.uint8)
+            seq = [ops.dropout_mask(s, m, self.dropout) for s, m in zip(seq, torch.unbind(mask.contiguous(), 0))]
+        _, finals1 = self._layer(seq, 1)
+        hidden = ops.concat_cols(ops.concat_cols(finals0[0], finals0[1]), ops.concat_cols(finals1[0], finals1[1]))
+        mu = _lin(_lin(hidden, self.linear_mean[0], ACT_SELU), self.linear_mean[2], ACT_NONE)
+        log_std = _lin(_lin(hidden, self.linear_log_std[0], ACT_SELU), self.linear_log_std[2], ACT_NONE)
+        return mu, log_std
+
+
+class Decoder(nn.Module):
+    def __init__(self, note_embedding_dim, num_notes, z_dim):
+        super().__init__()
+        self.name = 'DecoderABC'
+        self.num_notes, self.note_embedding_dim, self.z_dim = num_notes, note_embedding_dim, z_dim
+
+    def xavier_initialization(self):
+        for name, param in self.named_parameters():
+            if 'weight' in name:
+                nn.init.xavier_normal_(param)
+
+
+class HierarchicalDecoder(Decoder):
+    def __init__(self, note_embedding_dim, num_notes, z_dim, num_layers, rnn_hidden_size, dropout, rnn_class=nn.GRU):
+        super().__init__(note_embedding_dim, num_notes, z_dim)
+        if num_layers != 2:
+            raise NotImplementedError('the HIP decoder implements the reference configuration: 2-layer GRUs')
+        self.name = 'HierarchicalDecoder'
+        self.rnn_class, self.num_layers, self.rnn_hidden_size, self.dropout = rnn_class, num_layers, rnn_hidden_size, dropout
+        h = rnn_hidden_size
+        self.b_0 = nn.Parameter(torch.zeros(1))
+        self.x_0 = nn.Parameter(torch.zeros(note_embedding_dim))
+        self.note_embedding_layer = Embedding(num_notes, note_embedding_dim)
+        self.z_to_beat_rnn_input = _dense_layer(z_dim, h * num_layers)
+        self.beat_rnn_input_dim = 1
+        self.rnn_beat = GRUParams(1, h, num_layers, False)
+        self.beat_emb_to_tick_rnn_hidden = _dense_layer(h, h * num_layers)
+        self.beat_emb_to_tick_rnn_input = _dense_layer(h, h)
+        self.rnn_tick = GRUParams(note_embedding_dim + h, h, num_layers, False)
+        self.tick_emb_to_note_emb = _dense_layer(h, num_notes)
+        self.use_teacher_forcing = True
+        self.teacher_forcing_prob = 0.5
+        self.sampling = 'argmax'
+        self.xavier_initialization()
+        self._mask_queue = deque()
+
+    def __repr__(self):
+        return f'{self.name}{self.note_embedding_dim},{self.rnn_class},{self.num_layers},{self.rnn_hidden_size},{self.dropout},)'
+
+    def push_dropout_masks(self, beat_mask, tick_mask):
+        """explicit keep-masks (4, B, H) and (24, B, H) uint8 for the layer-0 hidden states."""
+        self._mask_queue.append((beat_mask, tick_mask))
+
+    def hidden_init(self, inp, rnn_type):
+        """(B, feats) -> [layer-0 hidden, layer-1 hidden]  (view(B, 2, H).transpose(0, 1), decoder.py:388-406)."""
+        if rnn_type == 'beat':
+            flat = _lin(inp, self.z_to_beat_rnn_input[0], ACT_SELU)
+        elif rnn_type == 'tick':
+            flat = _lin(inp, self.beat_emb_to_tick_rnn_hidden[0], ACT_SELU)
+        else:
+            raise ValueError
+        return list(ops.split_cols(flat, self.rnn_hidden_size))
+
+    def _two_layer_step(self, rnn, gi0, h, mask):
+        w_hh0, b_hh0 = rnn.cell(0)[1], rnn.cell(0)[3]
+        h0 = _gru_step(gi0, h[0], w_hh0, b_hh0)
+        mid = ops.dropout_mask(h0, mask, self.dropout) if mask is not None else h0
+        w_ih1, w_hh1, b_ih1, b_hh1 = rnn.cell(1)
+        gi1 = ops.dense(mid, w_ih1, b_ih1, Link.dense(w_ih1.shape[1], w_ih1.shape[0]), ACT_NONE)
+        h1 = _gru_step(gi1, h[1], w_hh1, b_hh1)
+        return [h0, h1]
+
+    def forward(self, z, score_tensor, train):
+        if z.size(1) != self.z_dim or z.size(0) != score_tensor.size(0):
+            raise AssertionError('latent / score shape mismatch')
+        if self.use_teacher_forcing and train:
+            teacher_forced = torch.rand(1).item() < self.teacher_forcing_prob       # host coin (decoder.py:427-428)
+        else:
+            teacher_forced = False
+        if train and self.sampling != 'argmax':
+            raise NotImplementedError('only argmax sampling is implemented')
+        b = z.size(0)
+        masks = (None, None)
+        if self.training and self.dropout > 0:
+            if self._mask_queue:
+                masks = tuple(m.to(z.device) for m in self._mask_queue.popleft())
+            else:
+                h = self.rnn_hidden_size
+                masks = ((torch.rand(4, b, h, device=z.device) >= self.dropout).to(torch.uint8),
+                         (torch.rand(24, b, h, device=z.device) >= self.dropout).to(torch.uint8))
+        beat_out = self.forward_beat_rnn(z, 4, masks[0])
+        return self.forward_tick_rnn(score_tensor, beat_out, 6, teacher_forced, 'argmax', masks[1])
+
+    def forward_beat_rnn(self, z, seq_len, mask=None):
+        b = z.size(0)
+        h = self.hidden_init(z, 'beat')
+        w_ih0, _, b_ih0, _ = self.rnn_beat.cell(0)
+        x0 = ops.broadcast_rows(self.b_0, b)                               # constant input b_0 for every beat
+        gi0 = ops.dense(x0, w_ih0, b_ih0, Link.dense(1, w_ih0.shape[0]), ACT_NONE)
+        out = []
+        for i in range(seq_len):
+            h = self._two_layer_step(self.rnn_beat, gi0, h, None if mask is None else mask[i].contiguous())
+            out.append(h[1])
+        return out
+
+    def forward_tick_rnn(self, score_tensor, beat_rnn_out, tick_seq_len, teacher_forced, sampling, mask=None):
+        b = score_tensor.size(0)
+        w_ih0, _, b_ih0, _ = self.rnn_tick.cell(0)
+        prev = ops.broadcast_rows(self.x_0, b)                             # learned start embedding
+        weights, samples = [], []
+        for i, bo in enumerate(beat_rnn_out):
+            h = self.hidden_init(bo, 'tick')                               # hidden is reset per beat
+            beat_emb = _lin(bo, self.beat_emb_to_tick_rnn_input[0], ACT_SELU)
+            for j in range(tick_seq_len):
+                t = i * tick_seq_len + j
+                inp = ops.concat_cols(prev, beat_emb)
+                gi0 = ops.dense(inp, w_ih0, b_ih0, Link.dense(w_ih0.shape[1], w_ih0.shape[0]), ACT_NONE)
+                h = self._two_layer_step(self.rnn_tick, gi0, h, None if mask is None else mask[t].contiguous())
+                probs = _lin(h[1], self.tick_emb_to_note_emb[0], ACT_RELU)
+                if self.use_teacher_forcing and teacher_forced:
+                    idx = score_tensor[:, t].contiguous()
+                else:
+                    idx = ops.row_argmax(probs.detach())
+                prev = ops.embed(idx.view(b, 1), self.note_embedding_layer.weight).view(b, -1)   # carries across beats
+                weights.append(probs)
+                samples.append(idx)
+        return torch.stack(weights, 1), torch.stack(samples, 1)[:, None, :]
+
+
+class MeasureVAE(Model):
+    def __init__(self, dataset, note_embedding_dim=10, metadata_embedding_dim=2, num_encoder_layers=2,
+                 encoder_hidden_size=512, encoder_dropout_prob=0.5, latent_space_dim=256, num_decoder_layers=2,
+                 decoder_hidden_size=512, decoder_dropout_prob=0.5, has_metadata=True, dataset_type='folk'):
+        super().__init__()
+        self.dataset_type = dataset_type
+        self.num_beats_per_measure, self.num_ticks_per_measure = 4, 24
+        self.num_ticks_per_beat = 6
+        self.dataset = repr(dataset)
+        self.note_embedding_dim, self.metadata_embedding_dim = note_embedding_dim, metadata_embedding_dim
+        self.num_encoder_layers, self.encoder_hidden_size = num_encoder_layers, encoder_hidden_size
+        self.encoder_dropout_prob, self.latent_space_dim = encoder_dropout_prob, latent_space_dim
+        self.num_decoder_layers, self.decoder_hidden_size = num_decoder_layers, decoder_hidden_size
+        self.decoder_dropout_prob, self.has_metadata = decoder_dropout_prob, has_metadata
+        self.num_notes = len(dataset.note2index_dicts)
+        self.encoder = Encoder(note_embedding_dim, encoder_hidden_size, num_encoder_layers, self.num_notes,
+                               encoder_dropout_prob, True, latent_space_dim, nn.GRU)
+        self.decoder = HierarchicalDecoder(note_embedding_dim, self.num_notes, latent_space_dim, num_decoder_layers,
+                                           decoder_hidden_size, decoder_dropout_prob, nn.GRU)
+        self.update_filepath()
+
+    def __repr__(self):
+        return self.dataset_type + '_MeasureVAE' + self.trainer_config
+
+    def push_noise(self, eps):
+        self.encoder.push_noise(eps)
+
+    def forward(self, measure_score_tensor, measure_metadata_tensor=None, train=True):
+        if measure_score_tensor.size(1) != self.num_ticks_per_measure:
+            raise AssertionError('a measure has 24 ticks')
+        z_dist = self.encoder(measure_score_tensor)
+        mu, sigma, z_tilde = z_dist.loc, z_dist.scale, z_dist._arvae_sample
+        prior_dist = distributions.Normal(loc=torch.zeros_like(mu), scale=torch.ones_like(sigma), validate_args=False)
+        prior_dist._arvae_standard = True
+        z_prior = torch.randn_like(mu)                       # the reference's second, unused draw (measure_vae.py:123)
+        weights, samples = self.decoder(z=z_tilde, score_tensor=measure_score_tensor, train=train)
+        return weights, samples, z_dist, prior_dist, z_tilde, z_prior

@@ -471,3 +471,214 @@ def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale
     with _timed('adam', 0.0, 28.0 * p.numel()):
         _lib.check(lib.arvae_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), int(step), lr, beta1, beta2,
                                        eps, grad_scale, _stream()), 'adam_step')
+
+
+# ------------------------------------------------------------------------------------------------
+# MeasureVAE building blocks (GRU gate math, embedding, concat/split, masks, argmax, attribute labels)
+# ------------------------------------------------------------------------------------------------
+class _GruGatesFn(Function):
+    """h' = GRU cell gates given gi = W_ih x + b_ih and gh = W_hh h + b_hh ([B, 3H], gate order r|z|n)."""
+
+    @staticmethod
+    def forward(ctx, gi, gh, h_prev):
+        _dev(gi, gh, h_prev)
+        lib = _lib.load()
+        b, h3 = gi.shape
+        hid = h3 // 3
+        h_new = torch.empty(b, hid, device=gi.device, dtype=torch.float32)
+        saved = torch.empty(4, b, hid, device=gi.device, dtype=torch.float32)
+        _lib.check(lib.arvae_gru_gates_fwd(_ptr(gi), _ptr(gh), _ptr(h_prev), b, hid, _ptr(h_new), _ptr(saved),
+                                           _stream()), 'gru_gates_fwd')
+        ctx.save_for_backward(saved, h_prev)
+        ctx.dims = (b, hid)
+        return h_new
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dh):
+        saved, h_prev = ctx.saved_tensors
+        lib = _lib.load()
+        b, hid = ctx.dims
+        dh = dh.contiguous()
+        dgi = torch.empty(b, 3 * hid, device=dh.device, dtype=torch.float32)
+        dgh = torch.empty_like(dgi)
+        dhp = torch.empty(b, hid, device=dh.device, dtype=torch.float32)
+        _lib.check(lib.arvae_gru_gates_bwd(_ptr(dh), _ptr(saved), _ptr(h_prev), b, hid, _ptr(dgi), _ptr(dgh), _ptr(dhp),
+                                           _stream()), 'gru_gates_bwd')
+        return dgi, dgh, (dhp if h_prev is not None else None)
+
+
+def gru_gates(gi, gh, h_prev=None):
+    return _GruGatesFn.apply(gi.contiguous(), gh.contiguous(), None if h_prev is None else h_prev.contiguous())
+
+
+class _EmbedFn(Function):
+    @staticmethod
+    def forward(ctx, idx, table, time_major):
+        _dev(idx, table)
+        lib = _lib.load()
+        b, steps = idx.shape
+        v, dim = table.shape
+        rows = (steps, b) if time_major else (b, steps)
+        out = torch.empty(rows + (dim,), device=table.device, dtype=torch.float32)
+        _lib.check(lib.arvae_embed_fwd(_ptr(idx), _ptr(table), b, steps, dim, v, int(time_major), _ptr(out), _stream()),
+                   'embed_fwd')
+        ctx.save_for_backward(idx)
+        ctx.table_ref, ctx.time_major = table, time_major
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        lib = _lib.load()
+        table = ctx.table_ref
+        b, steps = idx.shape
+        v, dim = table.shape
+        buf, direct = _grad_target(table)
+        _lib.check(lib.arvae_embed_bwd(_ptr(idx), _ptr(g.contiguous()), b, steps, dim, v, int(ctx.time_major), _ptr(buf),
+                                       _stream()), 'embed_bwd')
+        return None, (None if direct else buf), None
+
+
+def embed(idx, table, time_major=False):
+    """nn.Embedding lookup of int64 idx [B, T] -> [B, T, D] (or [T, B, D] when time_major)."""
+    if idx.dtype != torch.int64:
+        raise TypeError('embedding indices must be int64')
+    return _EmbedFn.apply(idx.contiguous(), table, bool(time_major))
+
+
+def row_argmax(w):
+    """top-1 index per row of a [rows, cols] tensor, lowest index on ties; int64 [rows]."""
+    _dev(w)
+    lib = _lib.load()
+    w = w.contiguous()
+    idx = torch.empty(w.shape[0], device=w.device, dtype=torch.int64)
+    _lib.check(lib.arvae_row_argmax(_ptr(w), w.shape[0], w.shape[1], _ptr(idx), _stream()), 'row_argmax')
+    return idx
+
+
+class _ConcatFn(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        _dev(a, b)
+        lib = _lib.load()
+        rows, ca, cb = a.shape[0], a.shape[1], b.shape[1]
+        out = torch.empty(rows, ca + cb, device=a.device, dtype=torch.float32)
+        _lib.check(lib.arvae_concat_cols(_ptr(a), _ptr(b), rows, ca, cb, _ptr(out), _stream()), 'concat_cols')
+        ctx.dims = (rows, ca, cb)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        lib = _lib.load()
+        rows, ca, cb = ctx.dims
+        g = g.contiguous()
+        da = torch.empty(rows, ca, device=g.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        db = torch.empty(rows, cb, device=g.device, dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        _lib.check(lib.arvae_split_cols(_ptr(g), rows, ca, cb, _ptr(da), _ptr(db), 0, _stream()), 'split_cols')
+        return da, db
+
+
+def concat_cols(a, b):
+    """torch.cat((a, b), dim=1) for 2-D tensors."""
+    return _ConcatFn.apply(a.contiguous(), b.contiguous())
+
+
+class _SplitFn(Function):
+    @staticmethod
+    def forward(ctx, x, ca):
+        _dev(x)
+        lib = _lib.load()
+        rows, c = x.shape
+        cb = c - ca
+        a = torch.empty(rows, ca, device=x.device, dtype=torch.float32)
+        b = torch.empty(rows, cb, device=x.device, dtype=torch.float32)
+        _lib.check(lib.arvae_split_cols(_ptr(x), rows, ca, cb, _ptr(a), _ptr(b), 0, _stream()), 'split_cols')
+        ctx.dims = (rows, ca, cb)
+        return a, b
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, ga, gb):
+        lib = _lib.load()
+        rows, ca, cb = ctx.dims
+        dev = (ga if ga is not None else gb).device
+        ga = torch.zeros(rows, ca, device=dev) if ga is None else ga.contiguous()
+        gb = torch.zeros(rows, cb, device=dev) if gb is None else gb.contiguous()
+        out = torch.empty(rows, ca + cb, device=dev, dtype=torch.float32)
+        _lib.check(lib.arvae_concat_cols(_ptr(ga), _ptr(gb), rows, ca, cb, _ptr(out), _stream()), 'concat_cols')
+        return out, None
+
+
+def split_cols(x, ca):
+    """(x[:, :ca], x[:, ca:]) as contiguous tensors."""
+    return _SplitFn.apply(x.contiguous(), int(ca))
+
+
+class _ScaleMaskFn(Function):
+    @staticmethod
+    def forward(ctx, x, mask, alpha):
+        _dev(x, mask)
+        lib = _lib.load()
+        y = torch.empty_like(x)
+        _lib.check(lib.arvae_scale_mask(_ptr(x), _ptr(mask), alpha, x.numel(), 0, _ptr(y), _stream()), 'scale_mask')
+        ctx.save_for_backward(mask)
+        ctx.alpha = alpha
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        lib = _lib.load()
+        g = g.contiguous()
+        dx = torch.empty_like(g)
+        _lib.check(lib.arvae_scale_mask(_ptr(g), _ptr(mask), ctx.alpha, g.numel(), 0, _ptr(dx), _stream()), 'scale_mask')
+        return dx, None, None
+
+
+def dropout_mask(x, mask, p=0.5):
+    """y = x * mask / (1 - p) for an explicit uint8 keep-mask (None: identity)."""
+    if mask is None:
+        return x
+    return _ScaleMaskFn.apply(x.contiguous(), mask.contiguous(), 1.0 / (1.0 - p))
+
+
+class _BroadcastFn(Function):
+    @staticmethod
+    def forward(ctx, v, rows):
+        _dev(v)
+        lib = _lib.load()
+        cols = v.numel()
+        y = torch.empty(rows, cols, device=v.device, dtype=torch.float32)
+        _lib.check(lib.arvae_broadcast_rows(_ptr(v), rows, cols, _ptr(y), _stream()), 'broadcast_rows')
+        ctx.v_ref, ctx.dims = v, (rows, cols)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        rows, cols = ctx.dims
+        buf, direct = _grad_target(ctx.v_ref)
+        channel_sum(_operand(g.contiguous()), rows, cols, (0, 0), buf.view(-1))
+        return (None if direct else buf), None
+
+
+def broadcast_rows(v, rows):
+    """v[None, :].expand(rows, -1) materialised (the learned start vectors)."""
+    return _BroadcastFn.apply(v, int(rows))
+
+
+def measure_attributes(score, tables, rhythm_weights, rhythm_norm):
+    """(B, 24) int64 measures -> (B, 4) [rhythmic complexity, pitch range, note density, contour]."""
+    _dev(score)
+    lib = _lib.load()
+    midi, is_note, is_dens = tables
+    b, steps = score.shape
+    out = torch.empty(b, 4, device=score.device, dtype=torch.float32)
+    _lib.check(lib.arvae_measure_attributes(_ptr(score.contiguous()), b, steps, _ptr(midi), _ptr(is_note), _ptr(is_dens),
+                                            midi.numel(), _ptr(rhythm_weights), float(rhythm_norm), _ptr(out), _stream()),
+               'measure_attributes')
+    return out

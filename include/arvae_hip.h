@@ -190,6 +190,51 @@ int arvae_adam_step(float *p, const float *g, float *m, float *v, int64_t count,
                     double beta1, double beta2, double eps, float grad_scale, arvae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * MeasureVAE building blocks (GRU encoder / hierarchical GRU decoder over 24-tick measures).
+ * The GEMMs of nn.GRU (W_ih x and W_hh h, measurevae/encoder.py:27-34,115; decoder.py:338-368,504) run on
+ * arvae_link_down with a dense link; these are the non-GEMM pieces.
+ * ------------------------------------------------------------------------------------------------ */
+/* GRU gate math of one time step.  gi = W_ih x + b_ih, gh = W_hh h + b_hh as [batch, 3*hidden] (gates r|z|n);
+ * h_prev [batch, hidden] or NULL (zeros).  saved (optional, for the backward): 4*batch*hidden floats (r, z, n, gh_n). */
+int arvae_gru_gates_fwd(const float *gi, const float *gh, const float *h_prev, int32_t batch, int32_t hidden,
+                        float *h_new, float *saved, arvae_stream_t stream);
+/* dh = d/d h_new.  Writes dgi, dgh [batch, 3*hidden] and dh_prev = dh * z (the direct path; the caller adds W_hh^T dgh). */
+int arvae_gru_gates_bwd(const float *dh, const float *saved, const float *h_prev, int32_t batch, int32_t hidden,
+                        float *dgi, float *dgh, float *dh_prev, arvae_stream_t stream);
+
+/* nn.Embedding (measurevae/encoder.py:36-37,111; decoder.py:18,516): out row (b,t) = table[idx[b][t]];
+ * time_major: rows ordered (t, b) instead of (b, t).  embed_bwd ACCUMULATES dtable (fixed summation order). */
+int arvae_embed_fwd(const int64_t *idx, const float *table, int32_t batch, int32_t steps, int32_t dim, int32_t vocab,
+                    int32_t time_major, float *out, arvae_stream_t stream);
+int arvae_embed_bwd(const int64_t *idx, const float *g, int32_t batch, int32_t steps, int32_t dim, int32_t vocab,
+                    int32_t time_major, float *dtable, arvae_stream_t stream);
+
+/* top-1 index per row, lowest index on ties (the decoder's argmax feedback, measurevae/decoder.py:506-507) */
+int arvae_row_argmax(const float *w, int32_t rows, int32_t cols, int64_t *idx, arvae_stream_t stream);
+
+/* out[r] = [a[r] | b[r]] (torch.cat along dim 1/2, decoder.py:503) and its adjoint (db optionally accumulated) */
+int arvae_concat_cols(const float *a, const float *b, int64_t rows, int32_t ca, int32_t cb, float *out,
+                      arvae_stream_t stream);
+int arvae_split_cols(const float *g, int64_t rows, int32_t ca, int32_t cb, float *da, float *db, int32_t accumulate_b,
+                     arvae_stream_t stream);
+
+/* y = alpha * x * mask (mask NULL = 1), optionally added to y: inter-layer GRU dropout and gradient sums */
+int arvae_scale_mask(const float *x, const uint8_t *mask, float alpha, int64_t count, int32_t accumulate, float *y,
+                     arvae_stream_t stream);
+/* y[r][:] = v[:]  (the learned start vectors x_0 / b_0 expanded over the batch, decoder.py:459-463,485-489) */
+int arvae_broadcast_rows(const float *v, int64_t rows, int32_t cols, float *y, arvae_stream_t stream);
+
+/* Attribute labels of a batch of measures.  Replaces MeasureVAETrainer.compute_attribute_labels
+ * (measurevae/measure_vae_trainer.py:167-186 -> data/dataloaders/bar_dataset.py:338-500):
+ *   out[b] = [rhythmic complexity, pitch range/26, note density, contour/26]
+ * midi_lut / is_note / is_density_note: per-vocabulary tables (is_density_note also counts the `None` symbol,
+ * bar_dataset.py:348-356); rhythm_weights[steps] = RHY_COMPLEXITY_COEFFS (bar_dataset_helpers.py:21-30),
+ * rhythm_norm their sum. */
+int arvae_measure_attributes(const int64_t *score, int32_t batch, int32_t steps, const int32_t *midi_lut,
+                             const uint8_t *is_note, const uint8_t *is_density_note, int32_t vocab,
+                             const float *rhythm_weights, float rhythm_norm, float *out, arvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Whole-model step for the conv VAEs: ONE call enqueues every kernel of the forward pass (+ loss terms)
  * or of the backward pass, so the host does no per-layer work.  Replaces, as a unit,
  *   ImageVAETrainer.loss_and_acc_for_batch (imagevae/image_vae_trainer.py:137-217)

@@ -430,3 +430,163 @@ def test_three_steps_track_oracle(dev, fused):
     close(got['loss'], ref['terms']['loss'], rtol=1e-4)
     for name in state:
         close(got['params'][name], cur[name], rtol=0, atol=5e-6)
+
+
+# ---------------------------------------------------------------- MeasureVAE (G6 / G7)
+class _FolkDataset:
+    """the attributes MeasureVAE / MeasureVAETrainer read from the reference's FolkNBarDataset"""
+    class_name = '4by4_FolkNBarDataset_1_'
+    n_bars = 1
+
+    def __init__(self):
+        self.index2note_dicts, self.note2index_dicts = syn.measure_vocabulary()
+
+    def __repr__(self):
+        return self.class_name
+
+
+def test_measure_attributes_golden(golden_dir, dev):
+    from arvae_amd.measure_vae_trainer import MeasureVAETrainer, build_measure_tables
+    from oracle import attributes as o_attr
+    g = G(golden_dir, 'attributes.npz')
+    tables = build_measure_tables(_FolkDataset(), dev)
+    lut = syn.measure_tables()
+    for got, want in zip(tables, lut):
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+    from arvae_amd import ops
+    w = torch.tensor([0.20, 1, 2, 0.5, 2, 1, 0.67, 1, 2, 0.5, 2, 1, 0.25, 1, 2, 0.5, 2, 1, 0.67, 1, 2, 0.5, 2, 1],
+                     dtype=torch.float64).float()
+    out = ops.measure_attributes(torch.from_numpy(g['score']).to(dev), tables, w.to(dev), float(w.sum()))
+    close(out, g['attr'], rtol=1e-6, atol=1e-7)
+    big = syn.measure_batch(4096, seed=77)
+    out = ops.measure_attributes(torch.from_numpy(big).to(dev), tables, w.to(dev), float(w.sum()))
+    close(out, o_attr.attribute_labels(big, *lut), rtol=1e-6, atol=1e-7)
+
+
+def test_gru_cell_vs_torch(dev):
+    """dense + gate kernels reproduce torch.nn.GRUCell forward and gradients."""
+    from arvae_amd import ops
+    rs = np.random.RandomState(5)
+    b, fin, hid = 37, 138, 128
+    cell = torch.nn.GRUCell(fin, hid)
+    x = torch.from_numpy(rs.standard_normal((b, fin)).astype(np.float32)).requires_grad_(True)
+    h = torch.from_numpy(rs.standard_normal((b, hid)).astype(np.float32)).requires_grad_(True)
+    gy = torch.from_numpy(rs.standard_normal((b, hid)).astype(np.float32))
+    y = cell(x, h)
+    y.backward(gy)
+    prm = {k: v.detach().clone().to(dev).requires_grad_(True) for k, v in cell.named_parameters()}
+    xd, hd = x.detach().to(dev).requires_grad_(True), h.detach().to(dev).requires_grad_(True)
+    gi = ops.dense(xd, prm['weight_ih'], prm['bias_ih'], ops.Link.dense(fin, 3 * hid), 0)
+    gh = ops.dense(hd, prm['weight_hh'], prm['bias_hh'], ops.Link.dense(hid, 3 * hid), 0)
+    yd = ops.gru_gates(gi, gh, hd)
+    yd.backward(gy.to(dev))
+    close(yd, y, rtol=1e-5, atol=1e-6)
+    close(xd.grad, x.grad, rtol=1e-4, atol=1e-6)
+    close(hd.grad, h.grad, rtol=1e-4, atol=1e-6)
+    for k, v in cell.named_parameters():
+        close(prm[k].grad, v.grad, rtol=1e-4, atol=1e-5)
+
+
+def test_embedding_concat_argmax(dev):
+    from arvae_amd import ops
+    rs = np.random.RandomState(6)
+    table = torch.from_numpy(rs.standard_normal((35, 10)).astype(np.float32))
+    idx = torch.from_numpy(rs.randint(0, 35, (9, 24)).astype(np.int64))
+    gy = torch.from_numpy(rs.standard_normal((24, 9, 10)).astype(np.float32))
+    tt = table.clone().requires_grad_(True)
+    ref = tt[idx].permute(1, 0, 2)
+    ref.backward(gy)
+    td = table.to(dev).requires_grad_(True)
+    out = ops.embed(idx.to(dev), td, time_major=True)
+    out.backward(gy.to(dev))
+    close(out, ref, rtol=0, atol=0)
+    close(td.grad, tt.grad, rtol=1e-6, atol=1e-6)
+    a = torch.from_numpy(rs.standard_normal((7, 10)).astype(np.float32)).to(dev).requires_grad_(True)
+    b = torch.from_numpy(rs.standard_normal((7, 128)).astype(np.float32)).to(dev).requires_grad_(True)
+    c = ops.concat_cols(a, b)
+    lo, hi = ops.split_cols(c, 100)
+    (lo.sum() * 2 + hi.sum() * 3).backward()
+    close(c, torch.cat((a, b), 1).detach(), rtol=0, atol=0)
+    assert float(a.grad.min()) == 2.0 and float(b.grad[:, :90].max()) == 2.0 and float(b.grad[:, 90:].min()) == 3.0
+    w = torch.tensor([[0., 0., 0.], [1., 5., 5.], [2., 1., 0.]], device=dev)
+    assert ops.row_argmax(w).tolist() == [0, 1, 0]              # lowest index on ties
+
+
+MEASURE_CASES = [('measure_step_tf.npz', 5, 31, True, True), ('measure_step_free.npz', 5, 32, False, True),
+                 ('measure_step_eval.npz', 6, 33, False, False)]
+
+
+@pytest.mark.parametrize('case', MEASURE_CASES, ids=[c[0][:-4] for c in MEASURE_CASES])
+def test_measure_step_vs_golden_and_oracle(golden_dir, dev, case):
+    from arvae_amd.measure_vae import MeasureVAE
+    from arvae_amd.measure_vae_trainer import MeasureVAETrainer
+    from oracle import attributes as o_attr
+    from oracle import measure_vae as o_mvae
+    fname, sseed, eseed, teacher, train = case
+    g = G(golden_dir, fname)
+    state = syn.synth_state(o_mvae.shapes(), 4)
+    state['decoder.tick_emb_to_note_emb.0.bias'] = state['decoder.tick_emb_to_note_emb.0.bias'] + np.float32(0.5)
+    state['decoder.tick_emb_to_note_emb.0.weight'] = state['decoder.tick_emb_to_note_emb.0.weight'] * np.float32(3.0)
+    score = syn.measure_batch(16, seed=sseed)
+    eps = syn.normal_noise((16, 32), seed=eseed)
+    ds = _FolkDataset()
+    model = MeasureVAE(ds, 10, 2, 2, 128, 0.0, 32, 2, 128, 0.0, False, 'folk')
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    trainer = MeasureVAETrainer(ds, model, lr=1e-4, reg_type=('all',), reg_dim=(0, 1, 2, 3), beta=0.001, gamma=1.0,
+                                capacity=0.0, rand=0, delta=10.0)
+    trainer.cuda()
+    model.train() if train else model.eval()
+    model.decoder.teacher_forcing_prob = 1.0 if teacher else 0.0
+    model.push_noise(torch.from_numpy(eps))
+    st = torch.from_numpy(score).to(dev)
+    trainer.zero_grad()
+    loss, acc = trainer.loss_and_acc_for_batch((st, st), 0, 0, train)
+    loss.backward()
+    grads = {k: p.grad.detach().cpu().numpy().copy() for k, p in model.named_parameters()}
+    trainer.step()
+    attr = o_attr.attribute_labels(score, *syn.measure_tables())
+    ref = o_step.measure_step(state, score, eps, attr, (0, 1, 2, 3), 0.001, 1.0, 10.0, teacher)
+    for src in (g, ref['terms']):
+        close(trainer.last_terms['recons'], float(src['recons']), rtol=1e-4)
+        close(trainer.last_terms['dist'], float(src['dist']), rtol=1e-4)
+        close(trainer.last_terms['reg'], float(src['reg']), rtol=1e-4)
+        close(loss, float(src['loss']), rtol=1e-4)
+        close(acc, float(src['acc']), rtol=1e-4)
+    with torch.no_grad():
+        model.push_noise(torch.from_numpy(eps))
+        model.decoder.teacher_forcing_prob = 1.0 if teacher else 0.0
+    for name in state:
+        gr = grads[name].astype(np.float64).ravel()
+        gn = float(g[f'gnorm/{name}'])
+        close(np.sqrt((gr * gr).sum()), gn, rtol=2e-3)
+        want = ref['grads'][name].astype(np.float64).ravel()
+        assert np.linalg.norm(gr - want) <= 3e-3 * np.linalg.norm(want) + 1e-9, name
+        d = (model.state_dict()[name].cpu().numpy().astype(np.float64) - state[name].astype(np.float64)).ravel()
+        close(np.sqrt((d * d).sum()), g[f'dnorm/{name}'], rtol=3e-3)
+
+
+def test_measure_forward_outputs_vs_golden(golden_dir, dev):
+    """weights, samples, z, mu, sigma of the free-running decoder against the golden."""
+    from arvae_amd.measure_vae import MeasureVAE
+    from oracle import measure_vae as o_mvae
+    g = G(golden_dir, 'measure_step_free.npz')
+    state = syn.synth_state(o_mvae.shapes(), 4)
+    state['decoder.tick_emb_to_note_emb.0.bias'] = state['decoder.tick_emb_to_note_emb.0.bias'] + np.float32(0.5)
+    state['decoder.tick_emb_to_note_emb.0.weight'] = state['decoder.tick_emb_to_note_emb.0.weight'] * np.float32(3.0)
+    ds = _FolkDataset()
+    model = MeasureVAE(ds, 10, 2, 2, 128, 0.0, 32, 2, 128, 0.0, False, 'folk')
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    model.cuda().train()
+    model.decoder.teacher_forcing_prob = 0.0
+    model.push_noise(torch.from_numpy(syn.normal_noise((16, 32), seed=32)))
+    score = torch.from_numpy(syn.measure_batch(16, seed=5)).to(dev)
+    with torch.no_grad():
+        weights, samples, z_dist, prior, z, z_prior = model(score, score, train=True)
+    assert weights.shape == (16, 24, 35) and samples.shape == (16, 1, 24) and samples.dtype == torch.int64
+    np.testing.assert_array_equal(samples.cpu().numpy(), g['samples'])
+    close(z, g['z'], rtol=0, atol=1e-4)
+    close(z_dist.loc, g['mu'], rtol=0, atol=1e-4)
+    close(z_dist.scale, g['sigma'], rtol=1e-4, atol=1e-5)
+    w = weights.cpu().numpy()
+    close(w[0], g['weights_row0'], rtol=1e-4, atol=1e-5)
+    close(w.ravel()[syn.sample_indices('weights', w.size, 128)], g['weights_samp'], rtol=1e-4, atol=1e-5)
