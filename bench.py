@@ -62,6 +62,57 @@ def dsprites_shapes():
     return {k: tuple(v.shape) for k, v in DspritesVAE().state_dict().items()}
 
 
+class MorphoMnistDataset:
+    pass
+
+
+class FolkDataset:              # what MeasureVAE / MeasureVAETrainer read from the reference's FolkNBarDataset
+    class_name = '4by4_FolkNBarDataset_1_'
+    n_bars = 1
+
+    def __init__(self):
+        from arvae_amd import synthetic as syn
+        self.index2note_dicts, self.note2index_dicts = syn.measure_vocabulary()
+
+    def __repr__(self):
+        return self.class_name
+
+
+def build_side_workload(kind, device, batch):
+    """(step function, unit) for the secondary workloads (not the headline metric): BASELINE.json configs[2], [4]."""
+    from arvae_amd import synthetic as syn
+    if kind == 'mnist':
+        from arvae_amd.image_vae import MnistVAE
+        from arvae_amd.image_vae_trainer import ImageVAETrainer
+        model = MnistVAE()
+        state = syn.synth_state({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=3, gain=0.7)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+        trainer = ImageVAETrainer(MorphoMnistDataset(), model, lr=1e-4, reg_type=('all',), reg_dim=(1, 2, 3, 4, 5, 6),
+                                  beta=1.0, gamma=10.0, capacity=0.0, rand=0, delta=1.0)
+        trainer.cuda()
+        x, lab = syn.mnist_batch(batch, seed=4321)
+        data = (torch.from_numpy(x).to(device), torch.from_numpy(lab).to(device))
+    else:
+        from arvae_amd.measure_vae import MeasureVAE
+        from arvae_amd.measure_vae_trainer import MeasureVAETrainer
+        ds = FolkDataset()
+        model = MeasureVAE(ds, 10, 2, 2, 128, 0.5, 32, 2, 128, 0.5, False, 'folk')
+        trainer = MeasureVAETrainer(ds, model, lr=1e-4, reg_type=('all',), reg_dim=(0, 1, 2, 3), beta=0.001, gamma=1.0,
+                                    capacity=0.0, rand=0, delta=10.0)
+        trainer.cuda()
+        score = torch.from_numpy(syn.measure_batch(batch, seed=5)).to(device)
+        data = (score, score)
+    model.train()
+
+    def step(i):
+        trainer.zero_grad()
+        loss, _ = trainer.loss_and_acc_for_batch(data, 0, i, True)
+        loss.backward()
+        trainer.step()
+        return loss
+    return step, ('images/s' if kind == 'mnist' else 'measures/s')
+
+
 def build_trainer(device, world):
     from arvae_amd import synthetic as syn
     from arvae_amd.image_vae import DspritesVAE
@@ -115,6 +166,10 @@ def main():
     ap.add_argument('--batch', type=int, default=512, help='per-GPU batch')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--breakdown', action='store_true', help='print the per-kernel-family table to stderr')
+    ap.add_argument('--force-dp', action='store_true',
+                    help='run the data-parallel code path (RCCL all-gather + all-reduce) even with one rank')
+    ap.add_argument('--workload', default='dsprites', choices=['dsprites', 'mnist', 'measure'],
+                    help='dsprites = the headline metric (default); mnist / measure = secondary single-GPU timings')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -127,15 +182,37 @@ def main():
         raise SystemExit('bench.py needs a GPU: the AR-VAE hot path has no CPU fallback')
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
-    if world > 1:
+    use_dp = world > 1 or args.force_dp
+    if use_dp:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=device)
 
     from arvae_amd import synthetic as syn
 
-    trainer, state = build_trainer(device, world)
-    if world > 1:
+    if args.workload != 'dsprites':
+        bsz = args.batch if args.batch != 512 else (1024 if args.workload == 'mnist' else 256)
+        side_step, unit = build_side_workload(args.workload, device, bsz)
+        for i in range(args.warmup):
+            side_step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            loss = side_step(i)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(json.dumps({'metric': f'training {unit} ({args.workload} AR-VAE, batch {bsz}) -- secondary workload',
+                          'value': bsz * args.steps / dt, 'unit': unit, 'n_gpus': 1, 'steps': args.steps,
+                          'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
+                          'dtype': 'f32', 'data': 'synthetic', 'final_loss': float(loss.detach()),
+                          'config': {'workload': args.workload, 'batch': bsz}}))
+        return
+
+    trainer, state = build_trainer(device, 2 if use_dp else 1)
+    if use_dp:
         trainer.data_parallel.broadcast_parameters(trainer.model)
     b = args.batch
     x_np, lab_np = syn.dsprites_batch(b, seed=1234 + rank)
@@ -151,7 +228,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dp:
             import torch.distributed as dist
             dist.barrier()
             torch.cuda.synchronize()
@@ -164,12 +241,12 @@ def main():
         loss = step(i)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dp:
         import torch.distributed as dist
         tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax)
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
     if not np.isfinite(final_loss):
         raise SystemExit(f'non-finite loss {final_loss}')
 
@@ -193,7 +270,6 @@ def main():
     fence()
 
     if rank != 0:
-        import torch.distributed as dist
         dist.destroy_process_group()
         return
     ms_per_step = 1e3 * elapsed / args.steps
@@ -227,7 +303,7 @@ def main():
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'dSprites AR-VAE full training step (fwd + bwd + Adam), 1x64x64 inputs, z=10, '
                                'reg_dim=(1,2,3,4,5), beta=4 gamma=10 delta=1',
-                   'per_gpu_batch': b, 'global_batch': b * world, 'parallelism': f'dp{world}',
+                   'per_gpu_batch': b, 'global_batch': b * world, 'parallelism': f'dp{world}' + (' (forced DP path)' if args.force_dp and world == 1 else ''),
                    'images_per_sec_per_gpu': per_gpu, 'final_loss': final_loss},
         'roofline': roof,
         'step_roofline': {
@@ -246,8 +322,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         line['cpu_baseline'] = cpu_baseline(b, state)
     print(json.dumps(line), flush=True)
-    if world > 1:
-        import torch.distributed as dist
+    if use_dp:
         dist.destroy_process_group()
 
 

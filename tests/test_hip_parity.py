@@ -590,3 +590,23 @@ def test_measure_forward_outputs_vs_golden(golden_dir, dev):
     w = weights.cpu().numpy()
     close(w[0], g['weights_row0'], rtol=1e-4, atol=1e-5)
     close(w.ravel()[syn.sample_indices('weights', w.size, 128)], g['weights_samp'], rtol=1e-4, atol=1e-5)
+
+
+# ---------------------------------------------------------------- data-parallel path on one GPU
+def test_data_parallel_path_single_rank_rccl(dev):
+    """world_size 1 over RCCL: the all-gather / all-reduce code path runs on the GPU and must give the same
+    loss and gradients as the plain single-process step."""
+    import subprocess
+    import sys
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for extra in ([], ['--force-dp']):
+        r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '3', '--warmup', '1', '--batch', '64',
+                            '--no-cpu-baseline'] + extra, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+        assert lines, (r.stdout[-1000:], r.stderr[-2000:])
+        outs.append(json.loads(lines[-1]))
+    a, b = (o['config']['final_loss'] for o in outs)
+    assert abs(a - b) <= 2e-3 * abs(a), (a, b)     # eps differs per run only through the shared torch seed -> identical draws
