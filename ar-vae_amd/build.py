@@ -9,6 +9,7 @@ CSRC = os.path.join(PKG_DIR, 'csrc')
 LIB_PATH = os.path.join(PKG_DIR, 'libarvae_hip.so')
 ARCH = 'gfx950'
 FLAGS = [f'--offload-arch={ARCH}', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
+FLAGS += os.environ.get('ARVAE_HIPCC_FLAGS', '').split()      # ablation / diagnostic builds only
 
 
 def sources():
