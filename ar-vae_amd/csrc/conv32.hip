@@ -3,94 +3,151 @@
 // carry 85 % of the training step's FLOPs.  Same math and C-ABI as the
 // generic gather-GEMM (link_gemm.hip); arvae_link_down/up/wgrad dispatch here when the geometry fits.
 //
-// Common structure (one workgroup = 4 wavefronts of 64 lanes, persistent over tiles):
-//   * the activation patch a tile needs (with its halo, zero-filled outside the image) is staged
-//     global -> LDS once with coalesced 16-byte loads; pixel stride in LDS is 36 floats (144 B), which
-//     keeps ds_read_b128 of stride-1 / stride-2 pixel walks at <= 2-way bank conflicts;
-//   * the 32x32 weight slices a wave needs live in 64 VGPRs for the whole kernel, in the K-order
-//     the MFMA wants: v_mfma_f32_32x32x2_f32 lane (row|col = lane&31, half = lane>>5) supplies
-//     k = 2*s + half, and we choose K = (tap, 8-channel chunk, half, t) so that ONE ds_read_b128 of
-//     4 consecutive channels feeds 4 MFMAs;
-//   * Down : wave w owns kernel row ky = w (K split 4 ways), partial 32x32 tiles are summed through LDS;
-//     Up   : wave w owns one of the 4 stride-parity classes of output pixels (no reduction needed);
-//     Wgrad: wave w owns kernel row ky = w, 4 accumulator tiles (kx) per wave, pixels are the K axis;
-//            per-workgroup partial sums go to a slab that wgrad32_reduce_kernel adds up in a fixed order.
+// Design rule (measured, profiles/r1_down32_phase_stamps.txt): on gfx950 the fp32 MFMA
+// (v_mfma_f32_32x32x2_f32, 64 cycles each, runs at the fp32 vector rate) does NOT co-execute with VALU work of
+// another wave on the same SIMD, so SIMD time = MFMA cycles + VALU cycles.  The kernels therefore maximise MFMAs
+// per non-MFMA instruction:
+//   * one 256-thread workgroup per CU (one wave per SIMD), persistent over tiles of 128 lo pixels (full-width
+//     row blocks / whole images, so a tile is one contiguous span of the lo tensor);
+//   * 256 MFMAs per wave and tile; every operand read from LDS is one ds_read_b128 that feeds 4 MFMAs
+//     (K order = (tap, 8-channel chunk, lane half, t) matches the 32x32x2 lane layout k = 2s + half);
+//   * weights live in VGPRs for the whole kernel (Down: all 256 values of the wave's output column, so a
+//     wave owns its 32 output pixels over the full K = 512 and no cross-wave reduction exists;
+//     Up: the 64 values of the wave's stride-parity class; Wgrad: none, pixels are the K axis);
+//   * global traffic uses raw buffer loads / stores: the hardware bounds check zero-fills everything outside
+//     the tensor (images past the end of the batch, rows before its start), per-thread offsets are computed
+//     once per kernel, per tile a slot costs an add, a compare and a select;
+//   * a tile's patch (+halo) is prefetched into registers while the previous tile's MFMAs run and is
+//     committed to LDS (pixel stride 36 floats: <= 2-way bank conflicts for stride-1/2 pixel walks) between
+//     two barriers.
 #include "common.h"
+
+#include <type_traits>
 
 namespace arvae {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef int i32x4v __attribute__((ext_vector_type(4)));
 
 constexpr int C32 = 32;
-constexpr int PS = 36;   // LDS pixel stride in floats
+constexpr int PS = 36;                  // LDS pixel stride in floats
+constexpr int PIXB = C32 * 4;           // bytes of one 32-channel pixel
+constexpr unsigned OOB = 0x7fffffffu;   // byte offset beyond any tensor here: loads return 0, stores are dropped
 
-// tile geometry per lo-resolution size LO (hi = 2*LO): 64 lo pixels = two 32-row MFMA tiles
+// tile geometry per lo-resolution size LO (hi = 2*LO): 128 lo pixels = four 32-row MFMA tiles, TC == LO
 template <int LO> struct Tile;
-template <> struct Tile<16> { static constexpr int TI = 1, TR = 4, TC = 16; };   // 4 rows x 16 cols of one image
-template <> struct Tile<8>  { static constexpr int TI = 1, TR = 8, TC = 8;  };   // one whole 8x8 image
-template <> struct Tile<4>  { static constexpr int TI = 4, TR = 4, TC = 4;  };   // four whole 4x4 images
+template <> struct Tile<16> { static constexpr int TI = 1, TR = 8, TC = 16; };   // 8 rows x 16 cols of one image
+template <> struct Tile<8>  { static constexpr int TI = 2, TR = 8, TC = 8;  };   // two whole 8x8 images
+template <> struct Tile<4>  { static constexpr int TI = 8, TR = 4, TC = 4;  };   // eight whole 4x4 images
 
-// lo pixel p (0..63) of a tile -> (image, row, col) inside the tile
-template <int LO> __device__ __forceinline__ void tile_pixel(int p, int &img, int &r, int &c) {
+// lo pixel p (0..127) of a tile -> (image, row, col) inside the tile; in memory pixel p sits p*PIXB after the tile start
+template <int LO> __device__ __forceinline__ constexpr void tile_pixel(int p, int &img, int &r, int &c) {
     using T = Tile<LO>;
     c = p % T::TC;
     r = (p / T::TC) % T::TR;
     img = p / (T::TC * T::TR);
+}
+template <int LO> __device__ __forceinline__ void tile_origin(int tile, int &img0, int &r0) {
+    using T = Tile<LO>;
+    constexpr int TILES_PER_IMG = LO / T::TR;
+    img0 = (T::TI == 1) ? tile / TILES_PER_IMG : tile * T::TI;
+    r0 = (T::TI == 1) ? (tile % TILES_PER_IMG) * T::TR : 0;
+}
+// byte offset of hi pixel (2r, 2c) of lo pixel p inside a [*, 2LO, 2LO, 32] tensor, relative to hi (img0, 2*r0, 0)
+template <int LO> __device__ __forceinline__ constexpr int hi_rel(int p) {
+    int img = 0, r = 0, c = 0;
+    tile_pixel<LO>(p, img, r, c);
+    return ((img * 2 * LO + 2 * r) * 2 * LO + 2 * c) * PIXB;
+}
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [0, N); keeps every register-array index static
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
 }
 
 struct Ep32 {
     const float *bias;   // per output channel or null
     const float *gate;   // null, or saved activation of the OUTPUT location: result *= (gate > 0)
     float *out;
-    int relu;            // apply ReLU after bias
 };
 
-__device__ __forceinline__ float ep_apply(const Ep32 &ep, float acc, float bias, int idx) {
-    float v = acc + bias;
-    if (ep.relu) v = fmaxf(v, 0.f);
-    if (ep.gate != nullptr) v = ep.gate[idx] > 0.f ? v : 0.f;
-    return v;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, int64_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
 }
-
-__device__ __forceinline__ float4 operand_load4(const Operand &op, int64_t idx) {
-    float4 v = *reinterpret_cast<const float4 *>(op.v + idx);
-    if (op.y != nullptr) {
-        const float4 y = *reinterpret_cast<const float4 *>(op.y + idx);
-        v.x *= act_bwd_from_out(y.x, op.act);
-        v.y *= act_bwd_from_out(y.y, op.act);
-        v.z *= act_bwd_from_out(y.z, op.act);
-        v.w *= act_bwd_from_out(y.w, op.act);
-    }
-    return v;
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    const f32x4v v = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void buf_store4(float4 v, __amdgpu_buffer_rsrc_t r, unsigned off) {
+    f32x4v q;
+    q.x = v.x; q.y = v.y; q.z = v.z; q.w = v.w;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4v, q), r, (int)off, 0, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
-// Register-staged patch loader.  issue() starts every 16-byte global load of a tile's patch (all of them
-// in flight at once; called for tile t+1 before the MFMAs of tile t so HBM/L2 latency hides under them),
-// commit() writes the registers to LDS once the previous tile's readers have passed the barrier.
+// Register-staged patch loader for a [n_img, SZ, SZ, 32] fp32 tensor.
 //   STRIDE 2: hi patch of a lo tile: rows [2*r0-1, 2*r0-1+PR), cols [-1, PC-1), PR = 2*TR+2, PC = 2*TC+2
 //   STRIDE 1: lo patch with a 1-pixel halo: rows [r0-1, r0-1+PR), cols [-1, PC-1), PR = TR+2, PC = TC+2
+// Plain operands only (no fused act'(y) factor: the callers route such gradients to the generic kernel).
+// Per thread and slot: the byte offset relative to the tile's first patch row (OOB for the column halo and
+// padding slots) and the patch row (the row halo at image borders is a compare + select per tile).
+// Slots are issued one at a time so that the callers can spread them between the MFMAs of the previous tile.
 // ------------------------------------------------------------------------------------------------
 template <int LO, int STRIDE>
 struct PatchLoader {
     using T = Tile<LO>;
-    static constexpr int SZ = STRIDE * LO;                                  // spatial size of the source tensor
+    static constexpr int SZ = STRIDE * LO;
     static constexpr int PR = STRIDE * T::TR + 2, PC = STRIDE * T::TC + 2;
     static constexpr int SLOTS = T::TI * PR * PC * 8;
     static constexpr int ITERS = (SLOTS + 255) / 256;
+    static constexpr int PATCH_FLOATS = T::TI * PR * PC * PS;
     float4 r[ITERS];
+    unsigned rel[ITERS];
+    int prow[ITERS];
+    __amdgpu_buffer_rsrc_t rs_v;
+    bool valid;
+    int gy0, base;
 
-    __device__ __forceinline__ void issue(const Operand &src, int img0, int r0, int n_img) {
+    __device__ __forceinline__ void init(const float *src, int n_img) {
+        rs_v = make_rsrc(src, (int64_t)n_img * SZ * SZ * PIXB);
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             const int idx = threadIdx.x + it * 256;
             const int q = idx & 7, pix = idx >> 3;
             const int pc = pix % PC, pr = (pix / PC) % PR, im = pix / (PC * PR);
-            const int gy = STRIDE * r0 - 1 + pr, gx = pc - 1, n = img0 + im;
-            r[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < SLOTS && n < n_img && (unsigned)gy < (unsigned)SZ && (unsigned)gx < (unsigned)SZ)
-                r[it] = operand_load4(src, ((int64_t)(n * SZ + gy) * SZ + gx) * C32 + q * 4);
+            const int gx = pc - 1;
+            const bool ok = idx < SLOTS && (unsigned)gx < (unsigned)SZ;
+            // image im's rows follow image 0's SZ rows later; patch row pr is tensor row gy0 + pr of its image
+            rel[it] = ok ? (unsigned)(((im * SZ + pr) * SZ + gx) * PIXB + q * 16) : OOB;
+            prow[it] = pr;
         }
+    }
+    // next tile to fetch: first image img0, first lo row r0; !ok -> every slot reads zeros without touching memory
+    __device__ __forceinline__ void set_tile(int img0, int r0, bool ok) {
+        gy0 = STRIDE * r0 - 1;
+        base = ((img0 * SZ + gy0) * SZ) * PIXB;                  // negative for the very first patch row of the tensor
+        valid = ok;
+    }
+    __device__ __forceinline__ void issue_slot(int it) {
+        const bool row_ok = valid && (unsigned)(gy0 + prow[it]) < (unsigned)SZ;
+        // OOB + base stays out of range (tensors are < 2^31 - 2^20 bytes, |negative base| < 2^20)
+        const unsigned off = row_ok ? rel[it] + (unsigned)base : OOB;
+        r[it] = buf_load4(rs_v, off);
+    }
+    // the slots that belong to step `step` of `steps` evenly spaced issue points (compile-time after unrolling)
+    template <int STEPS, int STEP> __device__ __forceinline__ void issue_step() {
+        static_for<0, ITERS>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int it = decltype(ic)::value;
+            if constexpr (it * STEPS / ITERS == STEP) issue_slot(it);
+        });
+    }
+    __device__ __forceinline__ void issue_all() {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) issue_slot(it);
     }
     // BIAS_SUM: also accumulate the pixels this tile owns (not the halo) per channel chunk q = threadIdx.x & 7
     template <bool BIAS_SUM>
@@ -112,263 +169,348 @@ struct PatchLoader {
     }
 };
 
-template <int LO> __device__ __forceinline__ void tile_origin(int tile, int &img0, int &r0) {
-    using T = Tile<LO>;
-    constexpr int TILES_PER_IMG = LO / T::TR;
-    img0 = (T::TI == 1) ? tile / TILES_PER_IMG : tile * T::TI;
-    r0 = (T::TI == 1) ? (tile % TILES_PER_IMG) * T::TR : 0;
+#ifdef ARVAE_STAMPS
+// diagnostic build only (tools/stamp_conv32.py): per-workgroup phase timeline, 64 slots, s_memtime + wall clock
+__device__ unsigned long long g_stamps[512 * 64 * 2];
+#define STAMP(slot)                                                                      \
+    do {                                                                                 \
+        if (LO == 16 && threadIdx.x == 0 && blockIdx.x < 512 && (slot) < 64) {           \
+            g_stamps[(blockIdx.x * 64 + (slot)) * 2] = __builtin_readcyclecounter();     \
+            g_stamps[(blockIdx.x * 64 + (slot)) * 2 + 1] = wall_clock64();               \
+        }                                                                                \
+    } while (0)
+#define STAMP_WAIT() __builtin_amdgcn_s_waitcnt(0)
+#else
+#define STAMP(slot)
+#define STAMP_WAIT()
+#endif
+
+// The weight value is the MFMA's A operand (row = output channel = lane & 31) and the pixel value its B operand
+// (column = pixel = lane & 31), so a lane ends up with 4 x 4 consecutive output channels of ONE pixel:
+// accumulator register reg holds channel CH0(reg) + 4 * (lane >> 5) + (reg & 3), and the epilogue is four
+// 16-byte stores per 32x32 tile (dword stores run at a quarter of that rate).
+#define MFMA4(ACC, A, W)                                                                \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32((W)[0], (A).x, ACC, 0, 0, 0);            \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32((W)[1], (A).y, ACC, 0, 0, 0);            \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32((W)[2], (A).z, ACC, 0, 0, 0);            \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x2f32((W)[3], (A).w, ACC, 0, 0, 0);
+
+// bias -> ReLU -> gate on the four channel groups of one pixel, then 4 x 16-byte stores at byte offset off + g*32
+template <bool RELU, bool GATE>
+__device__ __forceinline__ void store_pixel(const f32x16 &acc, const float4 (&b4)[4], __amdgpu_buffer_rsrc_t rs_out,
+                                            __amdgpu_buffer_rsrc_t rs_gate, unsigned off) {
+    float4 gv[4];
+    if (GATE) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gv[g] = buf_load4(rs_gate, off + g * 32);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float4 v = make_float4(acc[4 * g] + b4[g].x, acc[4 * g + 1] + b4[g].y, acc[4 * g + 2] + b4[g].z,
+                               acc[4 * g + 3] + b4[g].w);
+        if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (GATE) {
+            v.x = gv[g].x > 0.f ? v.x : 0.f; v.y = gv[g].y > 0.f ? v.y : 0.f;
+            v.z = gv[g].z > 0.f ? v.z : 0.f; v.w = gv[g].w > 0.f ? v.w : 0.f;
+        }
+        buf_store4(v, rs_out, off + g * 32);
+    }
 }
+
+// one channel group g (4 channels) of one pixel: bias -> ReLU -> gate -> one 16-byte store
+template <bool RELU, bool GATE>
+__device__ __forceinline__ void store_group(const f32x16 &acc, int g, const float4 &b, const float4 &gv,
+                                            __amdgpu_buffer_rsrc_t rs_out, unsigned off) {
+    float4 v = make_float4(acc[4 * g] + b.x, acc[4 * g + 1] + b.y, acc[4 * g + 2] + b.z, acc[4 * g + 3] + b.w);
+    if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (GATE) {
+        v.x = gv.x > 0.f ? v.x : 0.f; v.y = gv.y > 0.f ? v.y : 0.f;
+        v.z = gv.z > 0.f ? v.z : 0.f; v.w = gv.w > 0.f ? v.w : 0.f;
+    }
+    buf_store4(v, rs_out, off + g * 32);
+}
+
+__device__ __forceinline__ void load_bias4(const float *bias, int half, float4 (&b4)[4]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        b4[g] = bias != nullptr ? *reinterpret_cast<const float4 *>(bias + 8 * g + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// the 64 KB weight tensor wt[32][32][4][4] as 4096 coalesced 16-byte loads of the workgroup (16 per thread)
+__device__ __forceinline__ void load_weights(const float *wt, float4 (&v)[16]) {
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(wt, 16 * C32 * C32 * 4);
+#pragma unroll
+    for (int it = 0; it < 16; ++it) v[it] = buf_load4(rs_w, (threadIdx.x + it * 256) * 16);
+}
+constexpr int WROW_DOWN = 16 * C32 + 4;          // LDS floats per clo row (bank-conflict-free 16-byte reads)
+constexpr int WROW_UP = 17;                      // LDS floats per (clo, chi) row (conflict-free dword reads)
+constexpr int WSTAGE_DOWN = C32 * WROW_DOWN;     // floats of LDS needed while staging
+constexpr int WSTAGE_UP = C32 * C32 * WROW_UP;
 
 // ================================================================================================
 // Down: lo[n,ly,lx,clo] = ep( sum_{ky,kx,chi} hi[n,2ly-1+ky,2lx-1+kx,chi] * wt[clo][chi][ky][kx] )
+// wave w owns lo pixels [32w, 32w+32) of the tile over the full K = 512.
 // ================================================================================================
-template <int LO>
-__global__ __launch_bounds__(256, 2) void down32_kernel(Operand hi, const float *__restrict__ wt, Ep32 ep, int n_img,
+template <int LO, bool RELU, bool GATE>
+__global__ __launch_bounds__(256, 1) void down32_kernel(const float *__restrict__ hi, const float *__restrict__ wt, Ep32 ep, int n_img,
                                                          int n_tiles) {
-    using T = Tile<LO>;
-    constexpr int PR = 2 * T::TR + 2, PC = 2 * T::TC + 2;
-    // LDS: max(patch, 8192) floats -- the patch, then reused as the reduce buffer [wave][mtile][reg/4][lane][4]
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+    using PL = PatchLoader<LO, 2>;
+    constexpr int PC = PL::PC, PR = PL::PR;
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // max(PL::PATCH_FLOATS, WSTAGE_DOWN)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int half = lane >> 5, rc = lane & 31;
+    STAMP(0);
 
-    // weights of kernel row ky = wave: w[kx][chunk][t] = wt[clo=rc][chi = chunk*8 + half*4 + t][ky][kx]
-    float w[4][4][4];
+    PL pl;                                                       // first tile's loads fly while the weights are staged
+    pl.init(hi, n_img);
+    int img0, r0;
+    tile_origin<LO>(blockIdx.x, img0, r0);
+    pl.set_tile(img0, r0, blockIdx.x < n_tiles);
+    pl.issue_all();
+
+    // w[tap][chunk][t] = wt[clo = rc][chi = chunk*8 + half*4 + t][ky][kx], tap = ky*4 + kx; staged through LDS
+    float w[16][4][4];
+    {
+        float4 v[16];
+        load_weights(wt, v);
 #pragma unroll
-    for (int kx = 0; kx < 4; ++kx)
+        for (int it = 0; it < 16; ++it) {
+            const int idx4 = threadIdx.x + it * 256;             // (clo, chi, tap/4) = (idx4 >> 7, (idx4 >> 2) & 31, idx4 & 3)
+            *reinterpret_cast<float4 *>(lds + (idx4 >> 7) * WROW_DOWN + (idx4 & 127) * 4) = v[it];
+        }
+        __syncthreads();
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) w[kx][ch][t] = wt[((rc * C32) + ch * 8 + half * 4 + t) * 16 + wave * 4 + kx];
-
-    // lane's two output pixels (one per MFMA tile) -> patch offsets
-    int aoff[2];
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        int img, r, c;
-        tile_pixel<LO>(mt * 32 + rc, img, r, c);
-        aoff[mt] = ((img * PR + 2 * r + wave) * PC + 2 * c) * PS + half * 4;
+                for (int k = 0; k < 4; ++k) {
+                    const float4 q = *reinterpret_cast<const float4 *>(lds + rc * WROW_DOWN + (ch * 8 + half * 4 + t) * 16 + k * 4);
+                    w[4 * k][ch][t] = q.x; w[4 * k + 1][ch][t] = q.y; w[4 * k + 2][ch][t] = q.z; w[4 * k + 3][ch][t] = q.w;
+                }
     }
-    const float bias = ep.bias != nullptr ? ep.bias[rc] : 0.f;
+
+    int img, r, c;
+    tile_pixel<LO>(wave * 32 + rc, img, r, c);
+    const int aoff = ((img * PR + 2 * r) * PC + 2 * c) * PS + half * 4;      // + (ky*PC + kx)*PS + chunk*8
+    float4 b4[4];
+    load_bias4(ep.bias, half, b4);
+    const int64_t out_bytes = (int64_t)n_img * LO * LO * PIXB;
+    const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(ep.out, out_bytes);
+    const __amdgpu_buffer_rsrc_t rs_gate = make_rsrc(GATE ? ep.gate : ep.out, out_bytes);
+    const unsigned out_lane = (unsigned)((wave * 32 + rc) * PIXB + half * 16);      // + tile start + g*32
+
+    STAMP(1);
     float4 dummy;
-    PatchLoader<LO, 2> pl;
-    int img0, r0;
-    if (blockIdx.x < n_tiles) {
-        tile_origin<LO>(blockIdx.x, img0, r0);
-        pl.issue(hi, img0, r0, n_img);
-    }
+    STAMP(2);
+    int sidx = 3;
+    (void)sidx;
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         tile_origin<LO>(tile, img0, r0);
-        __syncthreads();                                         // previous tile's reduce reads are done
+        STAMP(sidx);
+        __syncthreads();                                         // previous tile's (or the weights') LDS reads are done
+        STAMP(sidx + 1);
         pl.template commit<false>(lds, dummy);
         __syncthreads();
-        if (tile + gridDim.x < n_tiles) {                        // next tile's loads fly under this tile's MFMAs
+        STAMP(sidx + 2);
+        {                                                        // next tile's loads are spread between this tile's MFMAs
             int ni, nr;
             tile_origin<LO>(tile + gridDim.x, ni, nr);
-            pl.issue(hi, ni, nr, n_img);
+            pl.set_tile(ni, nr, tile + gridDim.x < n_tiles);
         }
+        STAMP(sidx + 3);
 
-        f32x16 acc[2];
+        f32x16 acc, acc1;                                        // two dependency chains: even / odd taps
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int i = 0; i < 16; ++i) acc[i] = acc1[i] = 0.f;
+        float4 a[2][4];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+        for (int ch = 0; ch < 4; ++ch) a[0][ch] = *reinterpret_cast<const float4 *>(lds + aoff + ch * 8);
+        static_for<0, 16>([&](auto tc) __attribute__((always_inline)) {
+            constexpr int tap = decltype(tc)::value;
+            if constexpr (tap + 1 < 16) {                        // next tap's operands are in flight during these 16 MFMAs
+                constexpr int ky = (tap + 1) >> 2, kx = (tap + 1) & 3;
 #pragma unroll
-        for (int kx = 0; kx < 4; ++kx)
+                for (int ch = 0; ch < 4; ++ch)
+                    a[(tap + 1) & 1][ch] = *reinterpret_cast<const float4 *>(lds + aoff + (ky * PC + kx) * PS + ch * 8);
+            }
+            pl.template issue_step<16, tap>();
+            __builtin_amdgcn_sched_barrier(0);                   // keep the prefetch ahead of the 16 MFMAs that hide it
 #pragma unroll
             for (int ch = 0; ch < 4; ++ch) {
-                const float4 a0 = *reinterpret_cast<const float4 *>(lds + aoff[0] + kx * PS + ch * 8);
-                const float4 a1 = *reinterpret_cast<const float4 *>(lds + aoff[1] + kx * PS + ch * 8);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, w[kx][ch][0], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, w[kx][ch][0], acc[1], 0, 0, 0);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, w[kx][ch][1], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, w[kx][ch][1], acc[1], 0, 0, 0);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, w[kx][ch][2], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, w[kx][ch][2], acc[1], 0, 0, 0);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, w[kx][ch][3], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, w[kx][ch][3], acc[1], 0, 0, 0);
+                if constexpr (tap & 1) { MFMA4(acc1, a[tap & 1][ch], w[tap][ch]) } else { MFMA4(acc, a[tap & 1][ch], w[tap][ch]) }
             }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] += acc1[i];
+        STAMP(sidx + 4);
 
-        // sum the four ky-partials through LDS (patch memory is reused)
-        __syncthreads();
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<float4 *>(lds + (((wave * 2 + mt) * 4 + q) * 64 + lane) * 4) =
-                    make_float4(acc[mt][4 * q], acc[mt][4 * q + 1], acc[mt][4 * q + 2], acc[mt][4 * q + 3]);
-        __syncthreads();
-        // wave w finishes registers [8*(w&1), +8) of MFMA tile (w>>1); gate loads first, then the stores
-        const int mt = wave >> 1, q0 = (wave & 1) * 2;
-        int oidx[8];
-        float gv[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int reg = 4 * q0 + j;
-            const int row = (reg & 3) + 8 * (reg >> 2) + 4 * half;      // pixel inside the MFMA tile
-            int img, r, c;
-            tile_pixel<LO>(mt * 32 + row, img, r, c);
-            const int n = img0 + img;
-            oidx[j] = n < n_img ? ((n * LO + r0 + r) * LO + c) * C32 + rc : -1;
-            gv[j] = 1.f;
-        }
-        if (ep.gate != nullptr) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) gv[j] = ep.gate[oidx[j] < 0 ? 0 : oidx[j]];
-        }
-#pragma unroll
-        for (int q = q0; q < q0 + 2; ++q) {
-            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int ws = 0; ws < 4; ++ws) {
-                const float4 v = *reinterpret_cast<const float4 *>(lds + (((ws * 2 + mt) * 4 + q) * 64 + lane) * 4);
-                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-            }
-            const float sv[4] = {s.x, s.y, s.z, s.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int j = 4 * (q - q0) + e;
-                if (oidx[j] >= 0) {
-                    float v = sv[e] + bias;
-                    if (ep.relu) v = fmaxf(v, 0.f);
-                    ep.out[oidx[j]] = gv[j] > 0.f ? v : 0.f;
-                }
-            }
-        }
+        store_pixel<RELU, GATE>(acc, b4, rs_out, rs_gate, out_lane + (unsigned)(((img0 * LO + r0) * LO) * PIXB));
+        STAMP(sidx + 5);
+        sidx += 6;
     }
+    STAMP_WAIT();
+    STAMP(63);
 }
 
 // ================================================================================================
 // Up: hi[n,hy,hx,chi] = ep( sum over the 2x2 taps valid for (hy,hx)'s parity and clo of lo * wt )
-// wave w = parity class (py, px) = (w>>1, w&1); a tile is 64 lo positions -> 256 hi pixels
+// wave w = parity class (py, px) = (w>>1, w&1) of the 4 x 128 hi pixels of a tile (four 32-pixel MFMA tiles)
 // ================================================================================================
-template <int LO>
-__global__ __launch_bounds__(256, 2) void up32_kernel(Operand lo, const float *__restrict__ wt, Ep32 ep, int n_img,
+// Epilogue: a CU moves store data at only ~16 bytes per clock and a wave is held while its 1 KB store instruction
+// drains (64 clocks alone, 256 when all four waves store together), so the 64 KB a tile produces would idle the
+// matrix pipes for ~4K clocks.  The stores of tile t are therefore issued between the MFMAs of tile t+1, one
+// 16-byte store per wave and 16-MFMA step, each wave in its own quarter of the step: the drain then hides
+// behind the wave's previous MFMA.  Gate values are fetched one tile ahead into registers.
+template <int LO, bool RELU, bool GATE>
+__global__ __launch_bounds__(256, 1) void up32_kernel(const float *__restrict__ lo, const float *__restrict__ wt, Ep32 ep, int n_img,
                                                        int n_tiles) {
-    using T = Tile<LO>;
-    constexpr int HI = 2 * LO, PR = T::TR + 2, PC = T::TC + 2;
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // TI*PR*PC*PS floats
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    using PL = PatchLoader<LO, 1>;
+    constexpr int HI = 2 * LO, PC = PL::PC, PR = PL::PR;
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // max(PL::PATCH_FLOATS, WSTAGE_UP)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, rc = lane & 31;
     const int py = wave >> 1, px = wave & 1;
     const int ky0 = 1 - py, kx0 = 1 - px;
+    STAMP(0);
 
-    // w[ty][tx][chunk][t] = wt[clo = chunk*8 + half*4 + t][chi = rc][ky0 + 2ty][kx0 + 2tx]
-    float w[2][2][4][4];
-#pragma unroll
-    for (int ty = 0; ty < 2; ++ty)
-#pragma unroll
-        for (int tx = 0; tx < 2; ++tx)
-#pragma unroll
-            for (int ch = 0; ch < 4; ++ch)
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    w[ty][tx][ch][t] = wt[((ch * 8 + half * 4 + t) * C32 + rc) * 16 + (ky0 + 2 * ty) * 4 + kx0 + 2 * tx];
-
-    int aoff[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        int img, r, c;
-        tile_pixel<LO>(mt * 32 + rc, img, r, c);
-        // patch origin is lo (r0-1, -1); tap (ty,tx) reads lo (r + py - ty, c + px - tx)
-        aoff[mt] = ((img * PR + r + 1 + py) * PC + c + 1 + px) * PS + half * 4;
-    }
-    const float bias = ep.bias != nullptr ? ep.bias[rc] : 0.f;
-    float4 dummy;
-    PatchLoader<LO, 1> pl;
+    PL pl;                                                       // first tile's loads fly while the weights are staged
+    pl.init(lo, n_img);
     int img0, r0;
-    if (blockIdx.x < n_tiles) {
-        tile_origin<LO>(blockIdx.x, img0, r0);
-        pl.issue(lo, img0, r0, n_img);
-    }
+    tile_origin<LO>(blockIdx.x, img0, r0);
+    pl.set_tile(img0, r0, blockIdx.x < n_tiles);
+    pl.issue_all();
 
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        tile_origin<LO>(tile, img0, r0);
-        __syncthreads();
-        pl.template commit<false>(lds, dummy);
-        __syncthreads();
-        if (tile + gridDim.x < n_tiles) {
-            int ni, nr;
-            tile_origin<LO>(tile + gridDim.x, ni, nr);
-            pl.issue(lo, ni, nr, n_img);
+    // w[ty][tx][chunk][t] = wt[clo = chunk*8 + half*4 + t][chi = rc][ky0 + 2ty][kx0 + 2tx]; staged through LDS
+    float w[2][2][4][4];
+    {
+        float4 v[16];
+        load_weights(wt, v);
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int idx4 = threadIdx.x + it * 256;             // row (clo*32 + chi) = idx4 >> 2, taps 4*(idx4 & 3)..+3
+            float *d = lds + (idx4 >> 2) * WROW_UP + (idx4 & 3) * 4;
+            d[0] = v[it].x; d[1] = v[it].y; d[2] = v[it].z; d[3] = v[it].w;
         }
-
-        f32x16 acc[2];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+        __syncthreads();
 #pragma unroll
         for (int ty = 0; ty < 2; ++ty)
 #pragma unroll
             for (int tx = 0; tx < 2; ++tx)
 #pragma unroll
-                for (int ch = 0; ch < 4; ++ch) {
-                    const int toff = -(ty * PC + tx) * PS + ch * 8;
-                    const float4 a0 = *reinterpret_cast<const float4 *>(lds + aoff[0] + toff);
-                    const float4 a1 = *reinterpret_cast<const float4 *>(lds + aoff[1] + toff);
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, w[ty][tx][ch][0], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, w[ty][tx][ch][0], acc[1], 0, 0, 0);
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, w[ty][tx][ch][1], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, w[ty][tx][ch][1], acc[1], 0, 0, 0);
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, w[ty][tx][ch][2], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, w[ty][tx][ch][2], acc[1], 0, 0, 0);
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, w[ty][tx][ch][3], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, w[ty][tx][ch][3], acc[1], 0, 0, 0);
-                }
-
-        // epilogue in two passes: all gate loads first (they must not queue behind the stores)
-        int oidx[2][16];
-        float gv[2][16];
+                for (int ch = 0; ch < 4; ++ch)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int row = (reg & 3) + 8 * (reg >> 2) + 4 * half;
-                int img, r, c;
-                tile_pixel<LO>(mt * 32 + row, img, r, c);
-                const int n = img0 + img;
-                oidx[mt][reg] = n < n_img ? ((n * HI + 2 * (r0 + r) + py) * HI + 2 * c + px) * C32 + rc : -1;
-                gv[mt][reg] = 1.f;
-            }
-        if (ep.gate != nullptr) {                       // one uniform branch, then 32 independent loads in flight
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) gv[mt][reg] = ep.gate[oidx[mt][reg] < 0 ? 0 : oidx[mt][reg]];
-        }
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                if (oidx[mt][reg] >= 0) {
-                    float v = acc[mt][reg] + bias;
-                    if (ep.relu) v = fmaxf(v, 0.f);
-                    ep.out[oidx[mt][reg]] = gv[mt][reg] > 0.f ? v : 0.f;
-                }
-            }
+                    for (int t = 0; t < 4; ++t)
+                        w[ty][tx][ch][t] = lds[((ch * 8 + half * 4 + t) * C32 + rc) * WROW_UP + (ky0 + 2 * ty) * 4 + kx0 + 2 * tx];
     }
+
+    // patch origin is lo (r0-1, -1); tap (ty,tx) of class (py,px) reads lo (r + py - ty, c + px - tx)
+    int aoff[4];
+    unsigned orel[4];                                            // output byte offset of this lane's pixel in M-tile mt
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        int img, r, c;
+        tile_pixel<LO>(mt * 32 + rc, img, r, c);
+        aoff[mt] = ((img * PR + r + 1 + py) * PC + c + 1 + px) * PS + half * 4;
+        orel[mt] = (unsigned)(((img * HI + 2 * r + py) * HI + 2 * c + px) * PIXB + half * 16);
+    }
+    float4 b4[4];
+    load_bias4(ep.bias, half, b4);
+    const int64_t out_bytes = (int64_t)n_img * HI * HI * PIXB;
+    const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(ep.out, out_bytes);
+    const __amdgpu_buffer_rsrc_t rs_gate = make_rsrc(GATE ? ep.gate : ep.out, out_bytes);
+
+    STAMP(1);
+    float4 dummy;
+    f32x16 prev[4];                                              // previous tile's accumulators, stored during this tile
+    float4 gq[16];                                               // its gate values (loaded while it was computed)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) prev[mt][i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) gq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned prev_base = OOB;                                    // out of range: the first tile's "previous" stores are dropped
+    STAMP(2);
+    int sidx = 3;
+    (void)sidx;
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        tile_origin<LO>(tile, img0, r0);
+        STAMP(sidx);
+        __syncthreads();
+        STAMP(sidx + 1);
+        pl.template commit<false>(lds, dummy);
+        __syncthreads();
+        STAMP(sidx + 2);
+        {
+            int ni, nr;
+            tile_origin<LO>(tile + gridDim.x, ni, nr);
+            pl.set_tile(ni, nr, tile + gridDim.x < n_tiles);
+        }
+        STAMP(sidx + 3);
+
+        const unsigned obase = (unsigned)(((img0 * HI + 2 * r0) * HI) * PIXB);
+        f32x16 acc[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+        static_for<0, 16>([&](auto sc) __attribute__((always_inline)) {
+            constexpr int step = decltype(sc)::value, ty = step >> 3, tx = (step >> 2) & 1, ch = step & 3;
+            constexpr int toff = -(ty * PC + tx) * PS + ch * 8;
+            float4 a[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const float4 *>(lds + aoff[mt] + toff);
+            pl.template issue_step<16, step>();
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, 4>([&](auto mc) __attribute__((always_inline)) {
+                constexpr int mt = decltype(mc)::value;
+                if (wave == mt) {                                // this wave's quarter of the step
+                    store_group<RELU, GATE>(prev[step >> 2], step & 3, b4[step & 3], gq[step], rs_out, prev_base + orel[step >> 2]);
+                    if (GATE) gq[step] = buf_load4(rs_gate, obase + orel[step >> 2] + (step & 3) * 32);
+                }
+                MFMA4(acc[mt], a[mt], w[ty][tx][ch])
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        STAMP(sidx + 4);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) prev[mt] = acc[mt];
+        prev_base = obase;
+        STAMP(sidx + 5);
+        sidx += 6;
+    }
+    // the last tile's epilogue has nothing to hide behind
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            store_group<RELU, GATE>(prev[mt], g, b4[g], gq[mt * 4 + g], rs_out, prev_base + orel[mt]);
+    STAMP_WAIT();
+    STAMP(63);
 }
 
 // ================================================================================================
 // Wgrad: dwt[clo][chi][ky][kx] += sum_{n,ly,lx} lo[n,ly,lx,clo] * hi[n,2ly-1+ky,2lx-1+kx,chi]
-// wave w = ky; acc[kx] = 32(clo) x 32(chi); pixels are the MFMA K axis (2 per instruction).
+// wave w = ky; acc[kx] = 32(chi) x 32(clo); pixels are the MFMA K axis (2 per instruction, 64 steps per tile).
 // slab layout per workgroup: [ky][kx][clo][chi] (16384 floats) + 32 bias sums.
 // BIAS: 0 none, 1 = sum of the lo operand per clo, 2 = sum of the hi operand per chi (interior pixels)
 // ================================================================================================
 constexpr int WG32_SLAB = 16 * C32 * C32 + C32;
 
 template <int LO, int BIAS>
-__global__ __launch_bounds__(256, 2) void wgrad32_kernel(Operand lo, Operand hi, float *__restrict__ slab, int n_img,
+__global__ __launch_bounds__(256, 1) void wgrad32_kernel(const float *__restrict__ lo, const float *__restrict__ hi, float *__restrict__ slab, int n_img,
                                                           int n_tiles) {
-    using T = Tile<LO>;
-    constexpr int PR = 2 * T::TR + 2, PC = 2 * T::TC + 2;
-    constexpr int PATCH = T::TI * PR * PC * PS;
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // hi patch | lo tile [64][PS]
-    float *lo_t = lds + PATCH;
+    using PL = PatchLoader<LO, 2>;
+    constexpr int PC = PL::PC, PR = PL::PR;
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // hi patch | lo tile [128][PS]
+    float *lo_t = lds + PL::PATCH_FLOATS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int half = lane >> 5, rc = lane & 31;
+    STAMP(0);
 
     f32x16 acc[4];
 #pragma unroll
@@ -378,68 +520,78 @@ __global__ __launch_bounds__(256, 2) void wgrad32_kernel(Operand lo, Operand hi,
     float lo_sum = 0.f;
     float4 hi_sum = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    // register-staged loads: hi patch + the 64-pixel lo tile (2 float4 per thread)
-    PatchLoader<LO, 2> pl;
-    float4 lr[2];
-    auto issue_lo = [&](int i0, int rr0) {
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int idx = threadIdx.x + it * 256;
-            const int q = idx & 7, p = idx >> 3;
-            int img, r, c;
-            tile_pixel<LO>(p, img, r, c);
-            const int n = i0 + img;
-            lr[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n < n_img) lr[it] = operand_load4(lo, ((int64_t)(n * LO + rr0 + r) * LO + c) * C32 + q * 4);
-        }
+    PL pl;
+    pl.init(hi, n_img);
+    // lo tile: 128 contiguous pixels x 8 float4 = 4 slots per thread
+    const int64_t lo_bytes = (int64_t)n_img * LO * LO * PIXB;
+    const __amdgpu_buffer_rsrc_t rs_lo = make_rsrc(lo, lo_bytes);
+    float4 lr[4];
+    unsigned lo_base = 0;
+    auto issue_lo = [&](int it) {
+        lr[it] = buf_load4(rs_lo, lo_base + it * 4096);
+    };
+    auto set_lo = [&](int i0, int rr0, bool ok) {
+        lo_base = ok ? (unsigned)(((i0 * LO + rr0) * LO) * PIXB) + threadIdx.x * 16 : OOB;
     };
     int img0, r0;
-    if (blockIdx.x < n_tiles) {
-        tile_origin<LO>(blockIdx.x, img0, r0);
-        pl.issue(hi, img0, r0, n_img);
-        issue_lo(img0, r0);
-    }
+    tile_origin<LO>(blockIdx.x, img0, r0);
+    pl.set_tile(img0, r0, blockIdx.x < n_tiles);
+    set_lo(img0, r0, blockIdx.x < n_tiles);
+    pl.issue_all();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) issue_lo(it);
+    STAMP(1);
+    STAMP(2);
+    int sidx = 3;
+    (void)sidx;
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        tile_origin<LO>(tile, img0, r0);
+        STAMP(sidx);
         __syncthreads();
+        STAMP(sidx + 1);
         pl.template commit<BIAS == 2>(lds, hi_sum);
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
+        for (int it = 0; it < 4; ++it) {
             const int idx = threadIdx.x + it * 256;
             *reinterpret_cast<float4 *>(lo_t + (idx >> 3) * PS + (idx & 7) * 4) = lr[it];
         }
         __syncthreads();
-        if (tile + gridDim.x < n_tiles) {
+        STAMP(sidx + 2);
+        {
             int ni, nr;
             tile_origin<LO>(tile + gridDim.x, ni, nr);
-            pl.issue(hi, ni, nr, n_img);
-            issue_lo(ni, nr);
+            pl.set_tile(ni, nr, tile + gridDim.x < n_tiles);
+            set_lo(ni, nr, tile + gridDim.x < n_tiles);
         }
+        STAMP(sidx + 3);
 
-#pragma unroll
-        for (int s = 0; s < 32; ++s) {
+        static_for<0, 64>([&](auto sc) __attribute__((always_inline)) {
             // k-pair s covers lo pixels 2s and 2s+1 (adjacent columns of one row); this lane takes 2s+half
-            int img, r, c;
-            tile_pixel<LO>(2 * s, img, r, c);            // compile-time after unrolling
-            const float a = lo_t[(2 * s + half) * PS + rc];
-            if (BIAS == 1) lo_sum += a;
+            constexpr int s = decltype(sc)::value;
+            int img = 0, r = 0, c = 0;
+            tile_pixel<LO>(2 * s, img, r, c);
+            const float lv = lo_t[(2 * s + half) * PS + rc];
+            if (BIAS == 1) lo_sum += lv;
             const int boff = ((img * PR + 2 * r + wave) * PC + 2 * (c + half)) * PS + rc;
+            pl.template issue_step<64, s>();
+            if constexpr ((s & 15) == 8) issue_lo(s >> 4);
 #pragma unroll
-            for (int kx = 0; kx < 4; ++kx)
-                acc[kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, lds[boff + kx * PS], acc[kx], 0, 0, 0);
-        }
+            for (int kx = 0; kx < 4; ++kx)               // A row = chi, B column = clo
+                acc[kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[boff + kx * PS], lv, acc[kx], 0, 0, 0);
+        });
+        STAMP(sidx + 4);
+        STAMP(sidx + 5);
+        sidx += 6;
     }
 
-    // partial results -> slab[blockIdx][ky][kx][clo][chi]
+    // partial results -> slab[blockIdx][ky][kx][clo = rc][chi = 8g + 4*half + j]: 16-byte stores
     float *out = slab + (int64_t)blockIdx.x * WG32_SLAB;
 #pragma unroll
     for (int kx = 0; kx < 4; ++kx)
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int row = (reg & 3) + 8 * (reg >> 2) + 4 * half;      // clo
-            out[((wave * 4 + kx) * C32 + row) * C32 + rc] = acc[kx][reg];
-        }
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4 *>(out + ((wave * 4 + kx) * C32 + rc) * C32 + 8 * g + 4 * half) =
+                make_float4(acc[kx][4 * g], acc[kx][4 * g + 1], acc[kx][4 * g + 2], acc[kx][4 * g + 3]);
     if (BIAS == 1) {
         if (wave == 0) {
             const float tot = lo_sum + __shfl_xor(lo_sum, 32, 64);
@@ -447,7 +599,7 @@ __global__ __launch_bounds__(256, 2) void wgrad32_kernel(Operand lo, Operand hi,
         }
     } else if (BIAS == 2) {
         __syncthreads();
-        // every thread summed channel chunk q = threadIdx.x & 7 (SLOTS stride 256 keeps q fixed)
+        // every thread summed channel chunk q = threadIdx.x & 7 (slot stride 256 keeps q fixed)
         *reinterpret_cast<float4 *>(lds + threadIdx.x * 4) = hi_sum;
         __syncthreads();
         if (threadIdx.x < C32) {
@@ -457,6 +609,8 @@ __global__ __launch_bounds__(256, 2) void wgrad32_kernel(Operand lo, Operand hi,
             out[16 * C32 * C32 + threadIdx.x] = tot;
         }
     }
+    STAMP_WAIT();
+    STAMP(63);
 }
 
 // dwt[clo][chi][ky][kx] += sum_wg slab[wg][ky][kx][clo][chi];  dbias[c] += sum_wg slab[wg][16384 + c]
@@ -499,52 +653,75 @@ static int cu_count() {
     return n;
 }
 
-template <int LO> static constexpr int tiles_for(int n) { return Tile<LO>::TI == 1 ? n * (LO / Tile<LO>::TR) : (n + Tile<LO>::TI - 1) / Tile<LO>::TI; }
+template <int LO> static constexpr int tiles_for(int n) {
+    return Tile<LO>::TI == 1 ? n * (LO / Tile<LO>::TR) : (n + Tile<LO>::TI - 1) / Tile<LO>::TI;
+}
+static int grid_for_tiles(int tiles) { return tiles < cu_count() ? tiles : cu_count(); }
 
 bool conv32_fits(const arvae_link_t *l) {
     return l->chi == 32 && l->clo == 32 && l->kh == 4 && l->kw == 4 && l->stride == 2 && l->pad == 1 &&
            l->hh == l->hw && l->lh == l->lw && (l->lh == 16 || l->lh == 8 || l->lh == 4) && l->hi_perm_c == 0 &&
-           l->lo_perm_c == 0;
+           l->lo_perm_c == 0 && (int64_t)l->n * l->hh * l->hw * PIXB < (1ll << 31) - (1ll << 20);
 }
 
-template <int LO> static int launch_down(const arvae_link_t *l, const Operand &hi, const float *wt, const Ep32 &ep, hipStream_t s) {
-    using T = Tile<LO>;
-    constexpr int PATCH = T::TI * (2 * T::TR + 2) * (2 * T::TC + 2) * PS;
-    constexpr int LDS = (PATCH > 8192 ? PATCH : 8192) * 4;
-    const int tiles = tiles_for<LO>(l->n);
-    const int grid = tiles < 2 * cu_count() ? tiles : 2 * cu_count();
+template <class K> static void allow_lds(K kernel, int bytes) {
+    (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+template <int A, int B> struct MaxOf { static constexpr int value = A > B ? A : B; };
+
+template <int LO, bool RELU, bool GATE>
+static void launch_down_v(int grid, const Operand &hi, const float *wt, const Ep32 &ep, int n, int tiles, hipStream_t s) {
+    constexpr int LDS = MaxOf<PatchLoader<LO, 2>::PATCH_FLOATS, WSTAGE_DOWN>::value * 4;
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)down32_kernel<LO>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
-    hipLaunchKernelGGL(down32_kernel<LO>, dim3(grid), dim3(256), LDS, s, hi, wt, ep, l->n, tiles);
+    if (!attr) { allow_lds(down32_kernel<LO, RELU, GATE>, LDS); attr = true; }
+    hipLaunchKernelGGL((down32_kernel<LO, RELU, GATE>), dim3(grid), dim3(256), LDS, s, hi.v, wt, ep, n, tiles);
+}
+template <int LO, bool RELU, bool GATE>
+static void launch_up_v(int grid, const Operand &lo, const float *wt, const Ep32 &ep, int n, int tiles, hipStream_t s) {
+    constexpr int LDS = MaxOf<PatchLoader<LO, 1>::PATCH_FLOATS, WSTAGE_UP>::value * 4;
+    static bool attr = false;
+    if (!attr) { allow_lds(up32_kernel<LO, RELU, GATE>, LDS); attr = true; }
+    hipLaunchKernelGGL((up32_kernel<LO, RELU, GATE>), dim3(grid), dim3(256), LDS, s, lo.v, wt, ep, n, tiles);
+}
+
+template <int LO> static int launch_down(const arvae_link_t *l, const Operand &hi, const float *wt, const Ep32 &ep, int relu, hipStream_t s) {
+    const int tiles = tiles_for<LO>(l->n), grid = grid_for_tiles(tiles);
+    const bool gate = ep.gate != nullptr;
+    if (relu && gate) launch_down_v<LO, true, true>(grid, hi, wt, ep, l->n, tiles, s);
+    else if (relu) launch_down_v<LO, true, false>(grid, hi, wt, ep, l->n, tiles, s);
+    else if (gate) launch_down_v<LO, false, true>(grid, hi, wt, ep, l->n, tiles, s);
+    else launch_down_v<LO, false, false>(grid, hi, wt, ep, l->n, tiles, s);
     return check_launch(LO == 16 ? "down32_kernel<16>" : LO == 8 ? "down32_kernel<8>" : "down32_kernel<4>");
 }
 
 int conv32_down(const arvae_link_t *l, const Operand &hi, const float *wt, const float *bias, int relu, const float *gate,
                 float *out, hipStream_t s) {
-    Ep32 ep{bias, gate, out, relu};
+    Ep32 ep{bias, gate, out};
     switch (l->lh) {
-        case 16: return launch_down<16>(l, hi, wt, ep, s);
-        case 8: return launch_down<8>(l, hi, wt, ep, s);
-        default: return launch_down<4>(l, hi, wt, ep, s);
+        case 16: return launch_down<16>(l, hi, wt, ep, relu, s);
+        case 8: return launch_down<8>(l, hi, wt, ep, relu, s);
+        default: return launch_down<4>(l, hi, wt, ep, relu, s);
     }
 }
 
-template <int LO> static int launch_up(const arvae_link_t *l, const Operand &lo, const float *wt, const Ep32 &ep, hipStream_t s) {
-    using T = Tile<LO>;
-    constexpr int LDS = T::TI * (T::TR + 2) * (T::TC + 2) * PS * 4;
-    const int tiles = tiles_for<LO>(l->n);
-    const int grid = tiles < 2 * cu_count() ? tiles : 2 * cu_count();
-    hipLaunchKernelGGL(up32_kernel<LO>, dim3(grid), dim3(256), LDS, s, lo, wt, ep, l->n, tiles);
+template <int LO> static int launch_up(const arvae_link_t *l, const Operand &lo, const float *wt, const Ep32 &ep, int relu, hipStream_t s) {
+    const int tiles = tiles_for<LO>(l->n), grid = grid_for_tiles(tiles);
+    const bool gate = ep.gate != nullptr;
+    if (relu && gate) launch_up_v<LO, true, true>(grid, lo, wt, ep, l->n, tiles, s);
+    else if (relu) launch_up_v<LO, true, false>(grid, lo, wt, ep, l->n, tiles, s);
+    else if (gate) launch_up_v<LO, false, true>(grid, lo, wt, ep, l->n, tiles, s);
+    else launch_up_v<LO, false, false>(grid, lo, wt, ep, l->n, tiles, s);
     return check_launch(LO == 16 ? "up32_kernel<16>" : LO == 8 ? "up32_kernel<8>" : "up32_kernel<4>");
 }
 
 int conv32_up(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, int relu, const float *gate,
               float *out, hipStream_t s) {
-    Ep32 ep{bias, gate, out, relu};
+    Ep32 ep{bias, gate, out};
     switch (l->lh) {
-        case 16: return launch_up<16>(l, lo, wt, ep, s);
-        case 8: return launch_up<8>(l, lo, wt, ep, s);
-        default: return launch_up<4>(l, lo, wt, ep, s);
+        case 16: return launch_up<16>(l, lo, wt, ep, relu, s);
+        case 8: return launch_up<8>(l, lo, wt, ep, relu, s);
+        default: return launch_up<4>(l, lo, wt, ep, relu, s);
     }
 }
 
@@ -555,34 +732,28 @@ int conv32_wgrad_groups(const arvae_link_t *l) {
         case 8: tiles = tiles_for<8>(l->n); break;
         default: tiles = tiles_for<4>(l->n); break;
     }
-    // one workgroup per CU for the big maps (>= 4 tiles each amortise the 64 KB partial it writes);
-    // small maps keep every CU busy with one tile per workgroup
-    int g = tiles;
-    if (g > cu_count()) g = cu_count();
-    if (g < 1) g = 1;
-    return g;
+    return grid_for_tiles(tiles);          // one persistent workgroup per CU: one 64 KB partial each
 }
 
 int64_t conv32_wgrad_ws_floats(const arvae_link_t *l) { return (int64_t)conv32_wgrad_groups(l) * WG32_SLAB; }
 
 template <int LO> static int launch_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *slab, int bias_mode,
                                           int grid, hipStream_t s) {
-    using T = Tile<LO>;
-    constexpr int LDS = (T::TI * (2 * T::TR + 2) * (2 * T::TC + 2) * PS + 64 * PS) * 4;
+    constexpr int LDS = (PatchLoader<LO, 2>::PATCH_FLOATS + 128 * PS) * 4;
     const int tiles = tiles_for<LO>(l->n);
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void *)wgrad32_kernel<LO, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        (void)hipFuncSetAttribute((const void *)wgrad32_kernel<LO, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        (void)hipFuncSetAttribute((const void *)wgrad32_kernel<LO, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        allow_lds(wgrad32_kernel<LO, 0>, LDS);
+        allow_lds(wgrad32_kernel<LO, 1>, LDS);
+        allow_lds(wgrad32_kernel<LO, 2>, LDS);
         attr = true;
     }
     if (bias_mode == 1)
-        hipLaunchKernelGGL((wgrad32_kernel<LO, 1>), dim3(grid), dim3(256), LDS, s, lo, hi, slab, l->n, tiles);
+        hipLaunchKernelGGL((wgrad32_kernel<LO, 1>), dim3(grid), dim3(256), LDS, s, lo.v, hi.v, slab, l->n, tiles);
     else if (bias_mode == 2)
-        hipLaunchKernelGGL((wgrad32_kernel<LO, 2>), dim3(grid), dim3(256), LDS, s, lo, hi, slab, l->n, tiles);
+        hipLaunchKernelGGL((wgrad32_kernel<LO, 2>), dim3(grid), dim3(256), LDS, s, lo.v, hi.v, slab, l->n, tiles);
     else
-        hipLaunchKernelGGL((wgrad32_kernel<LO, 0>), dim3(grid), dim3(256), LDS, s, lo, hi, slab, l->n, tiles);
+        hipLaunchKernelGGL((wgrad32_kernel<LO, 0>), dim3(grid), dim3(256), LDS, s, lo.v, hi.v, slab, l->n, tiles);
     return check_launch(LO == 16 ? "wgrad32_kernel<16>" : LO == 8 ? "wgrad32_kernel<8>" : "wgrad32_kernel<4>");
 }
 
@@ -603,3 +774,9 @@ int conv32_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, fl
 }
 
 }  // namespace arvae
+
+#ifdef ARVAE_STAMPS
+extern "C" int arvae_debug_stamps(unsigned long long *out, int count) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(arvae::g_stamps), sizeof(unsigned long long) * count);
+}
+#endif

@@ -535,8 +535,7 @@ extern "C" int arvae_link_down(const arvae_link_t *link, const arvae_operand_t *
     ARVAE_REQUIRE(hi && hi->v && wt && lo, "link_down: null pointer");
     if (dense_fits(link) && out_mask == nullptr && hi->y == nullptr)
         return dense_fwd(link, hi->v, wt, bias, out_act, lo, as_stream(stream));
-    if (conv32_fits(link) && out_mask == nullptr && hi->mask == nullptr && out_act != ARVAE_ACT_SELU &&
-        hi->act != ARVAE_ACT_SELU)
+    if (conv32_fits(link) && out_mask == nullptr && hi->y == nullptr && out_act != ARVAE_ACT_SELU)
         return conv32_down(link, make_operand(hi), wt, bias, out_act == ARVAE_ACT_RELU, nullptr, lo, as_stream(stream));
     if (conv_c1_fits(link) && out_mask == nullptr && hi->mask == nullptr && out_act != ARVAE_ACT_SELU &&
         hi->act != ARVAE_ACT_SELU)
@@ -563,8 +562,7 @@ extern "C" int arvae_link_up(const arvae_link_t *link, const arvae_operand_t *lo
     hipStream_t st = as_stream(stream);
     if (dense_fits(link) && out_mask == nullptr && bias == nullptr && out_act == ARVAE_ACT_NONE)
         return dense_dgrad(link, make_operand(lo), wt, nullptr, hi, st);
-    if (conv32_fits(link) && out_mask == nullptr && lo->mask == nullptr && out_act != ARVAE_ACT_SELU &&
-        lo->act != ARVAE_ACT_SELU)
+    if (conv32_fits(link) && out_mask == nullptr && lo->y == nullptr && out_act != ARVAE_ACT_SELU)
         return conv32_up(link, make_operand(lo), wt, bias, out_act == ARVAE_ACT_RELU, nullptr, hi, st);
     if (conv_c1_fits(link) && lo->y == nullptr && out_mask == nullptr && out_act == ARVAE_ACT_NONE)
         return conv_c1_up(link, lo->v, wt, bias, hi, st);
@@ -611,8 +609,8 @@ static int channel_sum_launch(const Operand &g, int64_t rows, int channels, int 
                               float *ws, hipStream_t st);
 
 static bool wgrad_fast(const arvae_link_t *l, const arvae_operand_t *lo, const arvae_operand_t *hi) {
-    return conv32_fits(l) && (lo == nullptr || (lo->mask == nullptr && lo->act != ARVAE_ACT_SELU)) &&
-           (hi == nullptr || (hi->mask == nullptr && hi->act != ARVAE_ACT_SELU));
+    // the 32-channel kernels take plain operands only (a gradient that still needs act'(y) goes the generic way)
+    return conv32_fits(l) && (lo == nullptr || lo->y == nullptr) && (hi == nullptr || hi->y == nullptr);
 }
 
 extern "C" int64_t arvae_link_wgrad_ws_floats(const arvae_link_t *link) {

@@ -155,7 +155,7 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
     if (d_in != nullptr) {
         int rc;
         if (l.is_up) {                                   // forward UP  -> data gradient is a DOWN map
-            if (gate != nullptr && simple && conv32_fits(&lk)) {
+            if (gate != nullptr && gop.y == nullptr && conv32_fits(&lk)) {
                 rc = conv32_down(&lk, make_operand(&gop), w, nullptr, 0, gate, d_in, hs);
                 *gated = true;
             } else if (gate != nullptr && simple && conv_c1_fits(&lk)) {
@@ -165,7 +165,7 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
                 rc = arvae_link_down(&lk, &gop, w, nullptr, ARVAE_ACT_NONE, nullptr, d_in, st);
             }
         } else {                                         // forward DOWN -> data gradient is an UP map
-            if (gate != nullptr && simple && conv32_fits(&lk)) {
+            if (gate != nullptr && gop.y == nullptr && conv32_fits(&lk)) {
                 rc = conv32_up(&lk, make_operand(&gop), w, nullptr, 0, gate, d_in, hs);
                 *gated = true;
             } else if (gate != nullptr && dense_fits(&lk)) {

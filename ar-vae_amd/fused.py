@@ -96,7 +96,7 @@ class FusedImageVAE:
         return ws
 
     def run(self, x, labels, eps, masks, capacity, external_reg=False, reg_scale=1.0):
-        """-> (scalars[8], acc, z, mu, sigma, logits); scalars[LOSS] carries the grad_fn."""
+        """-> (loss[1] with grad_fn, scalars[8], acc, z, mu, sigma, logits); loss is scalars[LOSS:LOSS+1]."""
         anchor = self.optimizer.params[0]
         return _FusedStepFn.apply(anchor, self, x, labels, eps, masks, capacity, bool(external_reg), float(reg_scale))
 
@@ -133,20 +133,26 @@ class _FusedStepFn(Function):
         ctx.fused, ctx.masks, ctx.marr = fused, keep, marr
         ctx.external_reg, ctx.reg_scale = external_reg, reg_scale
         ctx.save_for_backward(x, eps, capacity, mu, sigma, z, logits)
-        acc = scalars[ACC]
-        ctx.mark_non_differentiable(acc, mu, sigma, logits)
+        # the loss is handed out as its own output (a 1-element view of the scalars) so that backward receives
+        # its gradient directly: no slice-backward zeros + copy, and no zero-filled gradients for the outputs
+        # nobody differentiates (the logits alone would be an 8 MB fill per step)
+        ctx.set_materialize_grads(False)
+        loss, acc = scalars[LOSS:LOSS + 1], scalars[ACC]
+        ctx.mark_non_differentiable(scalars, acc, mu, sigma, logits)
         if not external_reg:
             ctx.mark_non_differentiable(z)
-        return scalars, acc, z, mu, sigma, logits
+        return loss, scalars, acc, z, mu, sigma, logits
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, g_scalars, _g_acc, g_z, _g_mu, _g_sigma, _g_logits):
+    def backward(ctx, g_loss, _g_scalars, _g_acc, g_z, _g_mu, _g_sigma, _g_logits):
         x, eps, capacity, mu, sigma, z, logits = ctx.saved_tensors
         fused = ctx.fused
         lib = _lib.load()
         opt = fused.optimizer
-        g_loss = g_scalars[LOSS:LOSS + 1].contiguous()
+        if g_loss is None:                                       # only z was differentiated (external regulariser)
+            g_loss = torch.zeros(1, device=x.device, dtype=torch.float32)
+        g_loss = g_loss.reshape(1).contiguous()
         dz_extra = g_z.contiguous() if (ctx.external_reg and g_z is not None) else None
         ws = fused.workspace(x.shape[0], x.device)
         with ops._timed('image_vae_backward'):

@@ -117,7 +117,7 @@ class ImageVAETrainer(Trainer):
 
     def _fused_loss_and_acc(self, inputs, labels, first_of_epoch, epoch_num, batch_num, train):
         """Same loss as above through arvae_image_vae_forward / _backward (one C call per pass)."""
-        from .fused import DIST, LOSS, RECON, REG, FusedImageVAE
+        from .fused import DIST, RECON, REG, FusedImageVAE
         if type(self.reg_dim) != tuple and self.use_reg_loss:
             raise TypeError('Regularization dimension must be a tuple of integers')
         model = self.model
@@ -129,9 +129,8 @@ class ImageVAETrainer(Trainer):
         masks = model._next_masks(n, inputs.device)
         eps = model._noise(torch.empty(n, model.z_dim, device=inputs.device))
         dp = self.data_parallel if self.use_reg_loss else None
-        scalars, accuracy, z, mu, sigma, logits = self._fused.run(x, labels, eps, masks, self.capacity,
-                                                                  external_reg=dp is not None)
-        loss = scalars[LOSS:LOSS + 1]
+        loss, scalars, accuracy, z, mu, sigma, logits = self._fused.run(x, labels, eps, masks, self.capacity,
+                                                                        external_reg=dp is not None)
         reg_loss = scalars[REG].detach() if self.use_reg_loss else None
         if dp is not None:
             reg_loss = dp.reg_loss(z, labels, self.reg_dim, self.gamma, self.delta)
