@@ -1,0 +1,39 @@
+// Argument blocks of the Linear-layer kernels (dense.hip), shared with the whole-model executor (plan.hip).
+#pragma once
+#include "common.h"
+
+namespace arvae {
+
+struct Perm {           // feature f = c*hw + p  <->  memory column p*c_count + c ; c_count == 0: identity
+    int c_count, hw;
+    __device__ __forceinline__ int to_mem(int f) const { return c_count == 0 ? f : (f % hw) * c_count + f / hw; }
+    __device__ __forceinline__ int to_feat(int m) const { return c_count == 0 ? m : (m % c_count) * hw + m / c_count; }
+};
+
+struct DenseArgs {
+    Operand a;          // forward: X plain; dgrad / wgrad: G (gradient operand)
+    const float *x;     // wgrad: layer input X
+    const float *w;     // [n_out][n_in]
+    const float *bias;
+    float *out;         // forward: Y ; dgrad: dX ; wgrad: dW (accumulated)
+    float *dbias;       // wgrad: accumulated, may be null
+    const float *gate;  // dgrad: optional saved activation of the dX location: dX *= (gate > 0)
+    int batch, n_in, n_out, act;
+    Perm in_perm, out_perm;
+};
+
+constexpr int DENSE_BATCH_MAX = 8;
+struct DenseWgradBatch {
+    int count;
+    int tile_end[DENSE_BATCH_MAX];      // running number of 32x32 tiles after job j
+    DenseArgs job[DENSE_BATCH_MAX];
+};
+
+bool dense_fits(const arvae_link_t *l);
+int dense_fwd(const arvae_link_t *l, const float *x, const float *w, const float *bias, int act, float *y, hipStream_t s);
+int dense_dgrad(const arvae_link_t *l, const Operand &g, const float *w, const float *gate, float *dx, hipStream_t s);
+int dense_wgrad(const arvae_link_t *l, const Operand &g, const float *x, float *dw, float *dbias, hipStream_t s);
+bool dense_wgrad_defer(DenseWgradBatch *b, const arvae_link_t *l, const Operand &g, const float *x, float *dw, float *dbias);
+int dense_wgrad_flush(DenseWgradBatch *b, hipStream_t s);
+
+}  // namespace arvae

@@ -10,28 +10,11 @@
 // Channel permutations (hi_perm / lo_perm of arvae_link_t: the NCHW flatten between conv and dense
 // stacks over channels-last activations) are index remaps on the feature axis.
 #include "common.h"
+#include "dense.h"
 
 namespace arvae {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct Perm {           // feature f = c*hw + p  <->  memory column p*c_count + c ; c_count == 0: identity
-    int c_count, hw;
-    __device__ __forceinline__ int to_mem(int f) const { return c_count == 0 ? f : (f % hw) * c_count + f / hw; }
-    __device__ __forceinline__ int to_feat(int m) const { return c_count == 0 ? m : (m % c_count) * hw + m / c_count; }
-};
-
-struct DenseArgs {
-    Operand a;          // forward: X plain; dgrad / wgrad: G (gradient operand)
-    const float *x;     // wgrad: layer input X
-    const float *w;     // [n_out][n_in]
-    const float *bias;
-    float *out;         // forward: Y ; dgrad: dX ; wgrad: dW (accumulated)
-    float *dbias;       // wgrad: accumulated, may be null
-    const float *gate;  // dgrad: optional saved activation of the dX location: dX *= (gate > 0)
-    int batch, n_in, n_out, act;
-    Perm in_perm, out_perm;
-};
 
 __device__ __forceinline__ void mfma4(f32x16 &acc, const float (&a)[4], const float (&b)[4]) {
 #pragma unroll
@@ -151,10 +134,9 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_dgrad_kernel(DenseArgs p)
 }
 
 // ---- wgrad: dW[n][feat_in(km)] += sum_m G[m][mem_out(n)] * X[m][km] ;  db[n] += sum_m G[m][mem_out(n)] ------
-__global__ __launch_bounds__(DENSE_THREADS) void dense_wgrad_kernel(DenseArgs p) {
-    __shared__ float red[NW * 16 * 64];
+__device__ __forceinline__ void dense_wgrad_tile(const DenseArgs &p, int bx, int by, float *red) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, rc = lane & 31;
-    const int n = blockIdx.x * 32 + rc, km = blockIdx.y * 32 + rc;
+    const int n = bx * 32 + rc, km = by * 32 + rc;
     const bool nok = n < p.n_out, kok = km < p.n_in;
     const int ncol = nok ? p.out_perm.to_mem(n) : 0;
     f32x16 acc;
@@ -178,10 +160,10 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_wgrad_kernel(DenseArgs p)
     const float v = reduce_waves(red, acc, wave, lane);
     if (kok) {
         const int kf = p.in_perm.to_feat(km);
-        const int row = blockIdx.x * 32 + (wave & 3) + 8 * (wave >> 2) + 4 * half;      // n
+        const int row = bx * 32 + (wave & 3) + 8 * (wave >> 2) + 4 * half;      // n
         if (row < p.n_out) p.out[(int64_t)row * p.n_in + kf] += v;
     }
-    if (p.dbias != nullptr && blockIdx.y == 0) {
+    if (p.dbias != nullptr && by == 0) {
         __syncthreads();
         red[wave * 64 + lane] = bsum;
         __syncthreads();
@@ -192,6 +174,24 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_wgrad_kernel(DenseArgs p)
             p.dbias[n] += tot;
         }
     }
+}
+
+__global__ __launch_bounds__(DENSE_THREADS) void dense_wgrad_kernel(DenseArgs p) {
+    __shared__ float red[NW * 16 * 64];
+    dense_wgrad_tile(p, blockIdx.x, blockIdx.y, red);
+}
+
+// Weight gradients of several Linear layers in ONE launch: they are independent once every layer's output gradient
+// exists, and each alone is a launch-latency-bound 8..128-tile problem.  Workgroup -> (job, tile) through the
+// running tile count.
+__global__ __launch_bounds__(DENSE_THREADS) void dense_wgrad_batch_kernel(DenseWgradBatch b) {
+    __shared__ float red[NW * 16 * 64];
+    int j = 0;
+    while (j + 1 < b.count && (int)blockIdx.x >= b.tile_end[j]) ++j;
+    const int tile = blockIdx.x - (j > 0 ? b.tile_end[j - 1] : 0);
+    const DenseArgs &p = b.job[j];
+    const int tx = (p.n_out + 31) / 32;
+    dense_wgrad_tile(p, tile % tx, tile / tx, red);
 }
 
 bool dense_fits(const arvae_link_t *l) {
@@ -228,6 +228,24 @@ int dense_wgrad(const arvae_link_t *l, const Operand &g, const float *x, float *
     p.a = g; p.x = x; p.out = dw; p.dbias = dbias;
     hipLaunchKernelGGL(dense_wgrad_kernel, dim3((p.n_out + 31) / 32, (p.n_in + 31) / 32), dim3(DENSE_THREADS), 0, s, p);
     return check_launch("dense_wgrad_kernel");
+}
+
+// deferred weight gradients (plan.hip): add a job / launch all of them
+bool dense_wgrad_defer(DenseWgradBatch *b, const arvae_link_t *l, const Operand &g, const float *x, float *dw, float *dbias) {
+    if (b->count >= DENSE_BATCH_MAX) return false;
+    DenseArgs p = dense_args(l);
+    p.a = g; p.x = x; p.out = dw; p.dbias = dbias;
+    const int tiles = ((p.n_out + 31) / 32) * ((p.n_in + 31) / 32);
+    b->tile_end[b->count] = (b->count > 0 ? b->tile_end[b->count - 1] : 0) + tiles;
+    b->job[b->count++] = p;
+    return true;
+}
+
+int dense_wgrad_flush(DenseWgradBatch *b, hipStream_t s) {
+    if (b->count == 0) return ARVAE_OK;
+    hipLaunchKernelGGL(dense_wgrad_batch_kernel, dim3(b->tile_end[b->count - 1]), dim3(DENSE_THREADS), 0, s, *b);
+    b->count = 0;
+    return check_launch("dense_wgrad_batch_kernel");
 }
 
 }  // namespace arvae

@@ -563,7 +563,16 @@ extern "C" int arvae_link_up(const arvae_link_t *link, const arvae_operand_t *lo
     if (dense_fits(link) && out_mask == nullptr && bias == nullptr && out_act == ARVAE_ACT_NONE)
         return dense_dgrad(link, make_operand(lo), wt, nullptr, hi, st);
     if (conv32_fits(link) && out_mask == nullptr && lo->y == nullptr && out_act != ARVAE_ACT_SELU)
+    {
+#ifdef ARVAE_STAMPS
+        static const float *stamp_gate = nullptr;                // diagnostic build: time the gated variant too
+        if (getenv("ARVAE_STAMP_GATE") != nullptr) {
+            if (stamp_gate == nullptr) (void)hipMalloc((void **)&stamp_gate, (size_t)link->n * link->hh * link->hw * link->chi * 4);
+            return conv32_up(link, make_operand(lo), wt, nullptr, 0, stamp_gate, hi, st);
+        }
+#endif
         return conv32_up(link, make_operand(lo), wt, bias, out_act == ARVAE_ACT_RELU, nullptr, hi, st);
+    }
     if (conv_c1_fits(link) && lo->y == nullptr && out_mask == nullptr && out_act == ARVAE_ACT_NONE)
         return conv_c1_up(link, lo->v, wt, bias, hi, st);
     if (link->chi == 1 && lo->y == nullptr && link->clo % 4 == 0 && link->lo_perm_c == 0) {

@@ -308,6 +308,116 @@ static inline int grid_for(int64_t count, int per_thread = 1, int max_blocks = 2
     return (int)b;
 }
 
+
+// =================================================================================================
+// One-workgroup tail of the conv-VAE forward pass (plan.hip): reduces the reconstruction partials, computes the
+// KL term against N(0, I) from (mu, sigma), reduces the regulariser's per-row partials and scatters its gradient,
+// and writes the step's scalars.  Replaces four launch-latency-bound kernels; all sums in a fixed order.
+// =================================================================================================
+__device__ __forceinline__ float block_sum_1024(float v, float *red) {       // red: 16 floats of LDS
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w];
+    return t;
+}
+
+struct VaeFinishArgs {
+    const float *rec_partial; int nb; float inv_batch, inv_count;              // reconstruction
+    const float *mu, *sigma; int64_t bz; float beta; const float *cap;         // KL
+    const float *row_loss, *row_grad; int64_t n_rows; int r; RegDims dims;     // regulariser (row_loss null: none)
+    int64_t ldz; float loss_scale, grad_scale, reg_scale; float *dz;
+    float *rec_out, *kld_out, *reg_out, *scalars;
+};
+
+__global__ __launch_bounds__(1024) void vae_finish_kernel(VaeFinishArgs p) {
+    __shared__ float red[16];
+    // every load first (one round of memory latency), then the four reductions
+    float a = 0.f, b = 0.f, s = 0.f, t = 0.f;
+    for (int i = threadIdx.x; i < p.nb; i += 1024) {
+        a += p.rec_partial[2 * i];
+        b += p.rec_partial[2 * i + 1];
+    }
+    for (int64_t i = threadIdx.x; i < p.bz; i += 1024) s += kl_elem(p.mu[i], p.sigma[i], 0.f, 1.f);
+    if (p.row_loss != nullptr) {
+        for (int64_t i = threadIdx.x; i < p.n_rows * p.r; i += 1024) t += p.row_loss[i];
+        if (p.dz != nullptr) {                                   // dz[row][c] = grad_scale * row_grad[k][row] for c = dims[k], else 0
+            for (int64_t i = threadIdx.x; i < p.n_rows * p.ldz; i += 1024) {
+                const int64_t row = i / p.ldz;
+                const int c = (int)(i - row * p.ldz);
+                float g = 0.f;
+                for (int k = 0; k < p.r; ++k)
+                    if (p.dims.d[k] == c) g = p.grad_scale * p.row_grad[(int64_t)k * p.n_rows + row];
+                p.dz[i] = g;
+            }
+        }
+    }
+    const float rec = block_sum_1024(a, red) * p.inv_batch;
+    const float acc = block_sum_1024(b, red) * p.inv_count;
+    const float kl = block_sum_1024(s, red) * p.inv_batch;
+    const float reg = block_sum_1024(t, red) * p.loss_scale;
+    const float dist = p.beta * fabsf(kl - (p.cap ? p.cap[0] : 0.f));
+    if (threadIdx.x == 0) {
+        p.rec_out[0] = rec; p.rec_out[1] = acc;
+        p.kld_out[0] = dist; p.kld_out[1] = kl;
+        if (p.row_loss != nullptr) p.reg_out[0] = reg;
+        const float rs = p.row_loss != nullptr ? p.reg_scale * reg : 0.f;
+        float *o = p.scalars;
+        o[ARVAE_VAE_RECON] = rec; o[ARVAE_VAE_ACC] = acc; o[ARVAE_VAE_DIST] = dist; o[ARVAE_VAE_KL] = kl;
+        o[ARVAE_VAE_REG] = rs; o[ARVAE_VAE_LOSS] = rec + dist + rs;
+        o[6] = o[7] = 0.f;
+    }
+}
+
+// per-block partial sums of the reconstruction term (+ d/dlogits); returns the block count through *nb
+int recon_partials(const float *logits, const float *x, int64_t count, int64_t batch, int32_t dist, float *ws,
+                   float *dlogits, hipStream_t s, int *nb_out) {
+    const int nb = grid_for(count, 8, RECON_MAX_BLOCKS);
+    const float inv_b = 1.f / (float)batch;
+    if (dist == ARVAE_RECON_BERNOULLI)
+        hipLaunchKernelGGL(image_recon_kernel<ARVAE_RECON_BERNOULLI>, dim3(nb), dim3(256), 0, s, logits, x, count,
+                           inv_b, ws, dlogits);
+    else
+        hipLaunchKernelGGL(image_recon_kernel<ARVAE_RECON_GAUSSIAN>, dim3(nb), dim3(256), 0, s, logits, x, count,
+                           inv_b, ws, dlogits);
+    *nb_out = nb;
+    return check_launch("image_recon");
+}
+
+// per-row partial sums of the all-pairs regulariser into ws = [row_loss | row_grad]
+int reg_partials(const float *z_rows, const float *lab_rows, int64_t n_rows, const float *z_cols, const float *lab_cols,
+                 int64_t n_cols, int64_t ldz, int64_t ldl, const RegDims &rd, int32_t r, float delta, float *ws,
+                 hipStream_t s) {
+    const unsigned bx = (unsigned)((n_rows + REG_ROWS_PER_BLOCK - 1) / REG_ROWS_PER_BLOCK);
+    hipLaunchKernelGGL(reg_loss_kernel, dim3(bx, r), dim3(256), 0, s, z_rows, lab_rows, n_rows, z_cols, lab_cols,
+                       n_cols, ldz, ldl, rd, delta, ws, ws + n_rows * r);
+    return check_launch("reg_loss");
+}
+
+int vae_finish(const float *rec_partial, int nb, int64_t batch, int64_t pix, const float *mu, const float *sigma,
+               int64_t zdim, float beta, const float *cap, const float *reg_ws, int64_t n_cols, int64_t ldz,
+               const int32_t *dims, int32_t r, float gamma, float delta, float reg_scale, float *dz, float *rec_out,
+               float *kld_out, float *reg_out, float *scalars, hipStream_t s) {
+    VaeFinishArgs p{};
+    p.rec_partial = rec_partial; p.nb = nb; p.inv_batch = 1.f / (float)batch; p.inv_count = 1.f / (float)pix;
+    p.mu = mu; p.sigma = sigma; p.bz = batch * zdim; p.beta = beta; p.cap = cap;
+    if (reg_ws != nullptr) {
+        p.row_loss = reg_ws; p.row_grad = reg_ws + batch * r; p.n_rows = batch; p.r = r;
+        for (int i = 0; i < 16; ++i) p.dims.d[i] = i < r ? dims[i] : 0;
+        const double nn = (double)n_cols * (double)n_cols;
+        p.ldz = ldz; p.loss_scale = (float)(gamma / nn); p.grad_scale = (float)(2.0 * gamma * delta / nn);
+        p.dz = dz;
+    }
+    p.reg_scale = reg_scale;
+    p.rec_out = rec_out; p.kld_out = kld_out; p.reg_out = reg_out; p.scalars = scalars;
+    hipLaunchKernelGGL(vae_finish_kernel, dim3(1), dim3(1024), 0, s, p);
+    return check_launch("image_vae_forward(finish)");
+}
+
 }  // namespace arvae
 
 using namespace arvae;
@@ -359,11 +469,8 @@ extern "C" int arvae_reg_loss(const float *z_rows, const float *lab_rows, int64_
     for (int i = 0; i < r; ++i)
         ARVAE_REQUIRE(dims[i] >= 0 && dims[i] < ldz && dims[i] < ldl, "reg_loss: dim %d outside z/labels", dims[i]);
     float *row_loss = ws, *row_grad = ws + n_rows * r;
-    const unsigned bx = (unsigned)((n_rows + REG_ROWS_PER_BLOCK - 1) / REG_ROWS_PER_BLOCK);
     hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL(reg_loss_kernel, dim3(bx, r), dim3(256), 0, s, z_rows, lab_rows, n_rows, z_cols, lab_cols,
-                       n_cols, ldz, ldl, rd, delta, row_loss, row_grad);
-    if (int rc = check_launch("reg_loss")) return rc;
+    if (int rc = reg_partials(z_rows, lab_rows, n_rows, z_cols, lab_cols, n_cols, ldz, ldl, rd, r, delta, ws, s)) return rc;
     const double nn = (double)n_cols * (double)n_cols;
     hipLaunchKernelGGL(reg_finish_kernel, dim3(1), dim3(256), 0, s, row_loss, row_grad, n_rows, r, rd, ldz,
                        (float)(gamma / nn), (float)(2.0 * gamma * delta / nn), loss_out, dz);
@@ -376,16 +483,10 @@ extern "C" int arvae_image_recon(const float *logits, const float *x, int64_t co
                                  float *ws, float *out, float *dlogits, arvae_stream_t stream) {
     ARVAE_REQUIRE(logits && x && ws && out && count > 0 && batch > 0, "image_recon: bad argument");
     ARVAE_REQUIRE(dist == ARVAE_RECON_BERNOULLI || dist == ARVAE_RECON_GAUSSIAN, "image_recon: invalid dist");
-    const int nb = grid_for(count, 8, RECON_MAX_BLOCKS);
     hipStream_t s = as_stream(stream);
     const float inv_b = 1.f / (float)batch;
-    if (dist == ARVAE_RECON_BERNOULLI)
-        hipLaunchKernelGGL(image_recon_kernel<ARVAE_RECON_BERNOULLI>, dim3(nb), dim3(256), 0, s, logits, x, count,
-                           inv_b, ws, dlogits);
-    else
-        hipLaunchKernelGGL(image_recon_kernel<ARVAE_RECON_GAUSSIAN>, dim3(nb), dim3(256), 0, s, logits, x, count,
-                           inv_b, ws, dlogits);
-    if (int rc = check_launch("image_recon")) return rc;
+    int nb = 0;
+    if (int rc = recon_partials(logits, x, count, batch, dist, ws, dlogits, s, &nb)) return rc;
     hipLaunchKernelGGL(pair_finish_kernel, dim3(1), dim3(256), 0, s, ws, nb, inv_b, 1.f / (float)count, out);
     return check_launch("image_recon(finish)");
 }

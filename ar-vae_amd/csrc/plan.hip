@@ -2,37 +2,33 @@
 // enqueues every kernel of a pass on the caller's stream.  Host-side sequencing only -- the math lives in
 // the link / dense / loss kernels, reached through the same C-ABI entry points a per-layer caller uses.
 #include "common.h"
+#include "dense.h"
 
 namespace arvae {
 
 // fast kernels with a gated epilogue (conv32.hip / conv_c1.hip / dense.hip)
 bool conv32_fits(const arvae_link_t *l);
 bool conv_c1_fits(const arvae_link_t *l);
-bool dense_fits(const arvae_link_t *l);
 int conv32_down(const arvae_link_t *l, const Operand &hi, const float *wt, const float *bias, int relu,
                 const float *gate, float *out, hipStream_t s);
 int conv32_up(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, int relu,
               const float *gate, float *out, hipStream_t s);
 int conv_c1_down(const arvae_link_t *l, const Operand &img, const float *wt, const float *bias, int relu,
                  const float *gate, float *out, hipStream_t s);
-int dense_dgrad(const arvae_link_t *l, const Operand &g, const float *w, const float *gate, float *dx, hipStream_t s);
+
+// loss-term pieces (losses.hip)
+int recon_partials(const float *logits, const float *x, int64_t count, int64_t batch, int32_t dist, float *ws,
+                   float *dlogits, hipStream_t s, int *nb_out);
+struct RegDims { int d[16]; };
+int reg_partials(const float *z_rows, const float *lab_rows, int64_t n_rows, const float *z_cols, const float *lab_cols,
+                 int64_t n_cols, int64_t ldz, int64_t ldl, const RegDims &rd, int32_t r, float delta, float *ws,
+                 hipStream_t s);
+int vae_finish(const float *rec_partial, int nb, int64_t batch, int64_t pix, const float *mu, const float *sigma,
+               int64_t zdim, float beta, const float *cap, const float *reg_ws, int64_t n_cols, int64_t ldz,
+               const int32_t *dims, int32_t r, float gamma, float delta, float reg_scale, float *dz, float *rec_out,
+               float *kld_out, float *reg_out, float *scalars, hipStream_t s);
 
 // ---- small glue kernels ---------------------------------------------------------------------------
-// scalars = [loss, recon, dist, reg_scaled, acc, kl]
-__global__ void vae_scalars_kernel(const float *__restrict__ rec, const float *__restrict__ kld,
-                                   const float *__restrict__ reg, float reg_scale, float *__restrict__ out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        const float r = reg != nullptr ? reg_scale * reg[0] : 0.f;
-        out[ARVAE_VAE_RECON] = rec[0];
-        out[ARVAE_VAE_ACC] = rec[1];
-        out[ARVAE_VAE_DIST] = kld[0];
-        out[ARVAE_VAE_KL] = kld[1];
-        out[ARVAE_VAE_REG] = r;
-        out[ARVAE_VAE_LOSS] = rec[0] + kld[0] + r;
-        out[6] = out[7] = 0.f;
-    }
-}
-
 // gradient of the loss w.r.t. (mu, log_std) from: the decoder path g_z (already times g), the
 // regularisation gradient dz_reg (unit upstream, scaled by g*reg_scale here), an optional external
 // z gradient, and the beta-KL term; sigma = exp(log_std), z = mu + eps*sigma.
@@ -77,6 +73,9 @@ static inline int64_t in_elems(const arvae_layer_t &l, int64_t n) {
 
 struct Layout {
     int64_t enc_out[ARVAE_MAX_LAYERS], dec_out[ARVAE_MAX_LAYERS];   // dec_out[last] unused (logits are external)
+    // Linear layers: the gradient w.r.t. the layer's output stays alive until the end of the backward pass, where
+    // all their weight gradients run as one launch (-1: not a Linear layer, gradient lives in the ping-pong pair)
+    int64_t enc_keep[ARVAE_MAX_LAYERS], dec_keep[ARVAE_MAX_LAYERS];
     int64_t log_std, dlogits, dz_reg, d_mu, d_ls, g_a, g_b, slab, rec_ws, reg_ws, rec_out, kld_out, reg_out, total;
     int64_t slab_floats;
 };
@@ -103,6 +102,8 @@ static int make_layout(const arvae_image_vae_t *m, int64_t n, int64_t n_cols, La
     }
     visit(m->head_mu);
     visit(m->head_log_std);
+    for (int i = 0; i < m->n_enc; ++i) L.enc_keep[i] = dense_fits(&m->enc[i].link) ? take(out_elems(m->enc[i], n)) : -1;
+    for (int i = 0; i < m->n_dec; ++i) L.dec_keep[i] = dense_fits(&m->dec[i].link) ? take(out_elems(m->dec[i], n)) : -1;
     const int64_t bz = n * m->zdim;
     L.log_std = take(bz);
     L.dlogits = take(out_elems(m->dec[m->n_dec - 1], n));
@@ -142,7 +143,7 @@ static int layer_forward(const arvae_layer_t &l, int32_t n, const float *params,
 //   *gated : set when the gate was applied (a fast kernel with a gated epilogue was available)
 static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params, float *grads, const float *in,
                           const float *out, const uint8_t *mask, const float *g, bool g_is_pre, const float *gate,
-                          float *d_in, bool *gated, float *slab, arvae_stream_t st) {
+                          float *d_in, bool *gated, float *slab, DenseWgradBatch *defer, arvae_stream_t st) {
     arvae_link_t lk = l.link;
     lk.n = n;
     const arvae_operand_t gop = g_is_pre ? plain(g) : arvae_operand_t{g, out, mask, l.act};
@@ -178,6 +179,7 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
         if (rc) return rc;
     }
     if (l.is_up) return arvae_link_wgrad(&lk, &xin, &gop, dw, db, db ? 2 : 0, slab, st);
+    if (defer != nullptr && dense_fits(&lk) && dense_wgrad_defer(defer, &lk, make_operand(&gop), in, dw, db)) return ARVAE_OK;
     return arvae_link_wgrad(&lk, &gop, &xin, dw, db, db ? 1 : 0, slab, st);
 }
 
@@ -231,25 +233,27 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
         if (int rc = layer_forward(m->dec[i], batch, params, h, mask, out, stream)) return rc;
         h = out;
     }
-    // loss terms
+    // loss terms: per-block partials of the reconstruction term and the regulariser, then one finishing workgroup
     const int64_t pix = out_elems(m->dec[m->n_dec - 1], batch);
-    if (int rc = arvae_image_recon(logits, x, pix, batch, m->recon_dist, ws + L.rec_ws, ws + L.rec_out, ws + L.dlogits,
-                                   stream))
-        return rc;
-    if (int rc = arvae_kld_fwd(mu, sigma, nullptr, nullptr, batch, m->zdim, m->beta, capacity, ws + L.kld_out, stream))
-        return rc;
+    int nb = 0;
+    if (int rc = recon_partials(logits, x, pix, batch, m->recon_dist, ws + L.rec_ws, ws + L.dlogits, st, &nb)) return rc;
     const bool reg_here = m->n_reg > 0 && n_cols >= 0;
+    int64_t nc = batch;
     if (reg_here) {
         const float *zc = z_cols != nullptr ? z_cols : z;
         const float *lc = lab_cols != nullptr ? lab_cols : labels;
-        const int64_t nc = z_cols != nullptr ? n_cols : batch;
-        if (int rc = arvae_reg_loss(z, labels, batch, zc, lc, nc, m->zdim, ld_labels, m->reg_dims, m->n_reg, m->gamma,
-                                    m->delta, ws + L.reg_ws, ws + L.reg_out, ws + L.dz_reg, stream))
+        nc = z_cols != nullptr ? n_cols : batch;
+        RegDims rd;
+        for (int i = 0; i < 16; ++i) rd.d[i] = i < m->n_reg ? m->reg_dims[i] : 0;
+        for (int i = 0; i < m->n_reg; ++i)
+            ARVAE_REQUIRE(m->reg_dims[i] >= 0 && m->reg_dims[i] < m->zdim && m->reg_dims[i] < ld_labels,
+                          "image_vae_forward: reg dim %d outside z/labels", m->reg_dims[i]);
+        if (int rc = reg_partials(z, labels, batch, zc, lc, nc, m->zdim, ld_labels, rd, m->n_reg, m->delta, ws + L.reg_ws, st))
             return rc;
     }
-    hipLaunchKernelGGL(vae_scalars_kernel, dim3(1), dim3(64), 0, st, ws + L.rec_out, ws + L.kld_out,
-                       reg_here ? ws + L.reg_out : nullptr, reg_scale, scalars);
-    return check_launch("image_vae_forward(scalars)");
+    return vae_finish(ws + L.rec_ws, nb, batch, pix, mu, sigma, m->zdim, m->beta, capacity,
+                      reg_here ? ws + L.reg_ws : nullptr, nc, m->zdim, m->reg_dims, m->n_reg, m->gamma, m->delta, reg_scale,
+                      ws + L.dz_reg, ws + L.rec_out, ws + L.kld_out, ws + L.reg_out, scalars, st);
 }
 
 extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batch, const float *params, float *grads,
@@ -268,9 +272,18 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
     for (int i = 0; i < m->n_dec; ++i) dec_mask[i] = m->dec[i].dropout ? mi++ : -1;
     auto mask_of = [&](int idx) -> const uint8_t * { return (masks != nullptr && idx >= 0) ? masks[idx] : nullptr; };
 
-    float *cur = ws + L.g_a, *other = ws + L.g_b, *slab = L.slab_floats ? ws + L.slab : nullptr;
+    float *const pp_a = ws + L.g_a, *const pp_b = ws + L.g_b, *slab = L.slab_floats ? ws + L.slab : nullptr;
+    DenseWgradBatch defer;
+    defer.count = 0;
+    // where the gradient for `keep` (a Linear layer's output, or -1) is written: its own buffer, or the ping-pong
+    // buffer that does not hold the gradient being consumed
+    auto grad_dst = [&](int64_t keep, const float *busy) -> float * {
+        if (keep >= 0) return ws + keep;
+        return busy == pp_a ? pp_b : pp_a;
+    };
     const int64_t pix = out_elems(m->dec[m->n_dec - 1], batch);
     const int64_t bz = (int64_t)batch * m->zdim;
+    float *cur = grad_dst(L.dec_keep[m->n_dec - 1], nullptr);
     if (int rc = arvae_scale_by_scalar(g_loss, ws + L.dlogits, pix, cur, stream)) return rc;
     // A layer's ReLU can be folded into the data-gradient epilogue of its consumer when no dropout mask sits
     // between them; the gradient handed down is then w.r.t. the pre-activation.
@@ -283,12 +296,13 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
         const float *in = i > 0 ? ws + L.dec_out[i - 1] : z;
         const float *out = (i + 1 < m->n_dec) ? ws + L.dec_out[i] : logits;
         const float *gate = i > 0 ? relu_gate(m->dec[i - 1], dec_mask[i - 1], in) : nullptr;
+        float *dst = grad_dst(i > 0 ? L.dec_keep[i - 1] : -1, cur);
         bool gated = false;
-        if (int rc = layer_backward(m->dec[i], batch, params, grads, in, out, mask_of(dec_mask[i]), cur, pre, gate, other,
-                                    &gated, slab, stream))
+        if (int rc = layer_backward(m->dec[i], batch, params, grads, in, out, mask_of(dec_mask[i]), cur, pre, gate, dst,
+                                    &gated, slab, &defer, stream))
             return rc;
         pre = gated;
-        float *t = cur; cur = other; other = t;
+        cur = dst;
     }
     // latent head (cur = gradient w.r.t. z from the decoder)
     {
@@ -302,11 +316,13 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
     }
     // heads: d_hidden = W_mu^T d_mu + W_ls^T d_ls   (gated by the last encoder layer's ReLU when possible)
     const float *hidden = ws + L.enc_out[m->n_enc - 1];
+    cur = grad_dst(L.enc_keep[m->n_enc - 1], nullptr);
+    float *other = grad_dst(-1, cur);
     if (int rc = layer_backward(m->head_mu, batch, params, grads, hidden, nullptr, nullptr, ws + L.d_mu, true, nullptr,
-                                cur, nullptr, slab, stream))
+                                cur, nullptr, slab, &defer, stream))
         return rc;
     if (int rc = layer_backward(m->head_log_std, batch, params, grads, hidden, nullptr, nullptr, ws + L.d_ls, true,
-                                nullptr, other, nullptr, slab, stream))
+                                nullptr, other, nullptr, slab, &defer, stream))
         return rc;
     {
         const float *gate = relu_gate(m->enc[m->n_enc - 1], enc_mask[m->n_enc - 1], hidden);
@@ -321,12 +337,14 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
     for (int i = m->n_enc - 1; i >= 0; --i) {
         const float *in = i > 0 ? ws + L.enc_out[i - 1] : x;
         const float *gate = i > 0 ? relu_gate(m->enc[i - 1], enc_mask[i - 1], in) : nullptr;
+        float *dst = i > 0 ? grad_dst(L.enc_keep[i - 1], cur) : nullptr;
         bool gated = false;
         if (int rc = layer_backward(m->enc[i], batch, params, grads, in, ws + L.enc_out[i], mask_of(enc_mask[i]), cur, pre,
-                                    gate, i > 0 ? other : nullptr, &gated, slab, stream))
+                                    gate, dst, &gated, slab, &defer, stream))
             return rc;
         pre = gated;
-        float *t = cur; cur = other; other = t;
+        cur = dst;
     }
+    if (int rc = dense_wgrad_flush(&defer, st)) return rc;
     return ARVAE_OK;
 }

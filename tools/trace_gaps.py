@@ -22,3 +22,8 @@ for r in seg:
     per[k][1] += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
 for k, (c, t) in sorted(per.items(), key=lambda kv: -kv[1][1]):
     print(f'  {k:70s} {c / steps:5.1f}/step {t / steps / 1e3:8.1f} us/step  {t / c / 1e3:7.1f} us each')
+if len(sys.argv) > 2:
+    print('--- last step, in order')
+    one = rows[adam[-2] + 1:adam[-1] + 1]
+    for r in one:
+        print(f"  {(int(r['Start_Timestamp']) - int(one[0]['Start_Timestamp'])) / 1e3:8.1f} us  {(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:6.1f} us  {r['Kernel_Name'][:90]}  grid {r.get('Grid_Size_X', '?')} wg {r.get('Workgroup_Size_X', '?')}")
