@@ -134,35 +134,56 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_dgrad_kernel(DenseArgs p)
 }
 
 // ---- wgrad: dW[n][feat_in(km)] += sum_m G[m][mem_out(n)] * X[m][km] ;  db[n] += sum_m G[m][mem_out(n)] ------
+// KU chunks are fetched per wave before the first MFMA, with unconditional loads (clamped row, zeroed by a select):
+// the tile lives on memory latency and every separately awaited load costs a full round trip.
+constexpr int KU = 4;
+
+template <bool PLAIN>
+__device__ __forceinline__ void dense_wgrad_loop(const DenseArgs &p, int ncol, int kcol, bool nok, bool kok, int wave, int half,
+                                                 f32x16 &acc, float &bsum) {
+    const int chunks = (p.batch + 7) / 8;
+    for (int q0 = wave; q0 < chunks; q0 += KU * NW) {
+        float a[KU][4], b[KU][4];
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const int m0 = (q0 + u * NW) * 8 + half * 4;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bool ok = m0 + t < p.batch;
+                const int mc = ok ? m0 + t : 0;
+                const int64_t gi = (int64_t)mc * p.n_out + ncol;
+                const float av = PLAIN ? p.a.v[gi] : p.a.at(gi), bv = p.x[(int64_t)mc * p.n_in + kcol];
+                a[u][t] = (ok && nok) ? av : 0.f;
+                b[u][t] = (ok && kok) ? bv : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bsum += a[u][t];
+            mfma4(acc, a[u], b[u]);
+        }
+    }
+}
+
 __device__ __forceinline__ void dense_wgrad_tile(const DenseArgs &p, int bx, int by, float *red) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, rc = lane & 31;
     const int n = bx * 32 + rc, km = by * 32 + rc;
     const bool nok = n < p.n_out, kok = km < p.n_in;
-    const int ncol = nok ? p.out_perm.to_mem(n) : 0;
+    const int ncol = nok ? p.out_perm.to_mem(n) : 0, kcol = kok ? km : 0;
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     float bsum = 0.f;
-    const int chunks = (p.batch + 7) / 8;
-
-    for (int q = wave; q < chunks; q += NW) {
-        const int m0 = q * 8 + half * 4;
-        float a[4], b[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const bool ok = m0 + t < p.batch;
-            a[t] = (ok && nok) ? p.a.at((int64_t)(m0 + t) * p.n_out + ncol) : 0.f;
-            b[t] = (ok && kok) ? p.x[(int64_t)(m0 + t) * p.n_in + km] : 0.f;
-            bsum += a[t];
-        }
-        mfma4(acc, a, b);
-    }
+    // this lane's dW element: read early, added to after the reduction
+    const int out_row = bx * 32 + (wave & 3) + 8 * (wave >> 2) + 4 * half;      // n
+    const bool out_ok = kok && out_row < p.n_out;
+    float *outp = p.out + (out_ok ? (int64_t)out_row * p.n_in + p.in_perm.to_feat(km) : 0);
+    const float old = *outp;
+    if (p.a.y == nullptr) dense_wgrad_loop<true>(p, ncol, kcol, nok, kok, wave, half, acc, bsum);
+    else dense_wgrad_loop<false>(p, ncol, kcol, nok, kok, wave, half, acc, bsum);
     const float v = reduce_waves(red, acc, wave, lane);
-    if (kok) {
-        const int kf = p.in_perm.to_feat(km);
-        const int row = bx * 32 + (wave & 3) + 8 * (wave >> 2) + 4 * half;      // n
-        if (row < p.n_out) p.out[(int64_t)row * p.n_in + kf] += v;
-    }
+    if (out_ok) *outp = old + v;
     if (p.dbias != nullptr && by == 0) {
         __syncthreads();
         red[wave * 64 + lane] = bsum;
@@ -184,7 +205,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_wgrad_kernel(DenseArgs p)
 // Weight gradients of several Linear layers in ONE launch: they are independent once every layer's output gradient
 // exists, and each alone is a launch-latency-bound 8..128-tile problem.  Workgroup -> (job, tile) through the
 // running tile count.
-__global__ __launch_bounds__(DENSE_THREADS) void dense_wgrad_batch_kernel(DenseWgradBatch b) {
+__global__ __launch_bounds__(DENSE_THREADS, 2) void dense_wgrad_batch_kernel(DenseWgradBatch b) {
     __shared__ float red[NW * 16 * 64];
     int j = 0;
     while (j + 1 < b.count && (int)blockIdx.x >= b.tile_end[j]) ++j;

@@ -1,0 +1,179 @@
+// Encoder heads of the conv VAEs fused with the reparameterisation (reference mnist_vae.py:59-66,79 /
+// dsprites_vae.py): mu = W_mu h + b_mu, log_std = W_ls h + b_ls, sigma = exp(log_std), z = mu + eps * sigma in one
+// launch, and in the backward pass d(mu, log_std) from the decoder / KL / regulariser gradients together with
+// d_hidden = W_mu^T d_mu + W_ls^T d_ls (gated by the hidden layer's ReLU).  The heads are [zdim <= 16] x [h] GEMVs
+// per sample: a few MFLOP per batch, so the cost is the number of launches; plain FMA loops, 8 batch rows per
+// 256-thread workgroup.
+#include "common.h"
+
+namespace arvae {
+
+constexpr int HEAD_ROWS = 8;
+constexpr int HEAD_ZMAX = 16;
+constexpr int HEAD_HMAX = 512;           // hidden width the fused kernels stage in LDS
+
+struct HeadsFwdArgs {
+    const float *hidden, *w_mu, *b_mu, *w_ls, *b_ls, *eps;
+    float *mu, *log_std, *sigma, *z;
+    int batch, h, zdim;
+};
+
+// LDS: HEAD_ROWS hidden rows | 2*zdim weight rows (stride h + 4: conflict-free float4 reads across rows) | outputs.
+// Every global load is issued up front (one round of memory latency); the dot products then run from LDS.
+__global__ __launch_bounds__(256) void heads_latent_fwd_kernel(HeadsFwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int ws = p.h + 4;
+    float *hs = lds, *wl = lds + HEAD_ROWS * p.h, *outs = wl + 2 * HEAD_ZMAX * ws;
+    const int row0 = blockIdx.x * HEAD_ROWS;
+    const int h4 = p.h >> 2;
+    for (int i = threadIdx.x; i < HEAD_ROWS * h4; i += 256) {
+        const int r = i / h4, row = row0 + r;
+        const int rr = row < p.batch ? row : p.batch - 1;         // clamped: unconditional load
+        const float4 v = reinterpret_cast<const float4 *>(p.hidden + (int64_t)rr * p.h)[i - r * h4];
+        reinterpret_cast<float4 *>(hs)[i] = v;
+    }
+    for (int i = threadIdx.x; i < 2 * p.zdim * h4; i += 256) {
+        const int j = i / h4, k = i - j * h4;
+        const float *src = j < p.zdim ? p.w_mu + (int64_t)j * p.h : p.w_ls + (int64_t)(j - p.zdim) * p.h;
+        reinterpret_cast<float4 *>(wl + j * ws)[k] = reinterpret_cast<const float4 *>(src)[k];
+    }
+    const int r = threadIdx.x >> 5, j = threadIdx.x & 31;
+    const int row = row0 + r;
+    const bool lat = j < p.zdim && row < p.batch;
+    const int64_t idx = lat ? (int64_t)row * p.zdim + j : 0;
+    const float e = p.eps[idx];
+    const int jc = j < 2 * p.zdim ? j : 0;
+    const float *bp = jc < p.zdim ? p.b_mu : p.b_ls;
+    const float bias = bp != nullptr ? bp[jc < p.zdim ? jc : jc - p.zdim] : 0.f;
+    __syncthreads();
+    {
+        const float4 *w = reinterpret_cast<const float4 *>(wl + jc * ws);
+        const float4 *x = reinterpret_cast<const float4 *>(hs + r * p.h);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+        for (int k = 0; k < h4; ++k) {
+            const float4 a = x[k], b = w[k];
+            acc.x = fmaf(a.x, b.x, acc.x); acc.y = fmaf(a.y, b.y, acc.y);
+            acc.z = fmaf(a.z, b.z, acc.z); acc.w = fmaf(a.w, b.w, acc.w);
+        }
+        outs[r * 32 + j] = (acc.x + acc.y) + (acc.z + acc.w) + bias;
+    }
+    __syncthreads();
+    if (lat) {
+        const float m = outs[r * 32 + j], l = outs[r * 32 + j + p.zdim];
+        const float s = expf(l);
+        p.mu[idx] = m;
+        p.log_std[idx] = l;
+        p.sigma[idx] = s;
+        p.z[idx] = fmaf(e, s, m);
+    }
+}
+
+struct HeadsBwdArgs {
+    const float *g_z, *dz_reg, *dz_extra, *mu, *sigma, *eps, *g_loss, *kl, *cap;
+    float beta, inv_batch, reg_scale;
+    const float *w_mu, *w_ls, *gate;
+    float *d_mu, *d_ls, *d_hidden;
+    int batch, h, zdim;
+};
+
+__global__ __launch_bounds__(256) void heads_latent_bwd_kernel(HeadsBwdArgs p) {
+    __shared__ float dm[HEAD_ROWS][HEAD_ZMAX], dl[HEAD_ROWS][HEAD_ZMAX];
+    const int row0 = blockIdx.x * HEAD_ROWS;
+    {
+        const int r = threadIdx.x >> 5, j = threadIdx.x & 31, row = row0 + r;
+        const bool on = j < p.zdim && row < p.batch;
+        const int64_t i = on ? (int64_t)row * p.zdim + j : 0;      // clamped: every load below is unconditional
+        const float g = p.g_loss[0];
+        const float diff = p.kl[0] - (p.cap != nullptr ? p.cap[0] : 0.f);
+        const float k = g * p.beta * (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f)) * p.inv_batch;
+        float gz = p.g_z[i];
+        if (p.dz_reg != nullptr) gz += g * p.reg_scale * p.dz_reg[i];
+        if (p.dz_extra != nullptr) gz += p.dz_extra[i];
+        const float s = p.sigma[i], mu = p.mu[i], e = p.eps[i];
+        const float a = gz + k * mu;
+        const float b = (gz * e + k * (s - 1.f / s)) * s;
+        if (on) {
+            p.d_mu[i] = a;
+            p.d_ls[i] = b;
+        }
+        if (j < HEAD_ZMAX) {
+            dm[r][j] = on ? a : 0.f;
+            dl[r][j] = on ? b : 0.f;
+        }
+    }
+    // weights and gate values of this thread's hidden column: issued before the barrier, used after it
+    for (int k0 = 0; k0 < p.h; k0 += 256) {                       // uniform trip count (barrier inside)
+        const int k = k0 + threadIdx.x;
+        const bool kok = k < p.h;
+        const int kc = kok ? k : 0;
+        float wm[HEAD_ZMAX], wl[HEAD_ZMAX], gv[HEAD_ROWS];
+#pragma unroll
+        for (int j = 0; j < HEAD_ZMAX; ++j) {
+            const int jc = j < p.zdim ? j : 0;
+            wm[j] = p.w_mu[(int64_t)jc * p.h + kc];
+            wl[j] = p.w_ls[(int64_t)jc * p.h + kc];
+        }
+#pragma unroll
+        for (int r = 0; r < HEAD_ROWS; ++r) {
+            const int rr = row0 + r < p.batch ? row0 + r : p.batch - 1;
+            gv[r] = p.gate != nullptr ? p.gate[(int64_t)rr * p.h + kc] : 1.f;
+        }
+        if (k0 == 0) __syncthreads();
+#pragma unroll
+        for (int r = 0; r < HEAD_ROWS; ++r) {
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < HEAD_ZMAX; ++j)
+                if (j < p.zdim) acc = fmaf(dm[r][j], wm[j], fmaf(dl[r][j], wl[j], acc));
+            if (kok && row0 + r < p.batch) p.d_hidden[(int64_t)(row0 + r) * p.h + k] = gv[r] > 0.f ? acc : 0.f;
+        }
+    }
+}
+
+// both heads are plain Linear layers on the same hidden vector, small enough for the fused kernels
+bool heads_fusable(const arvae_layer_t *hm, const arvae_layer_t *hl, int zdim) {
+    auto plain_dense = [](const arvae_layer_t *l) {
+        const arvae_link_t &k = l->link;
+        return !l->is_up && k.hh == 1 && k.hw == 1 && k.lh == 1 && k.lw == 1 && k.kh == 1 && k.kw == 1 &&
+               k.hi_perm_c == 0 && k.lo_perm_c == 0 && l->act == ARVAE_ACT_NONE && l->dropout == 0;
+    };
+    return plain_dense(hm) && plain_dense(hl) && hm->link.chi == hl->link.chi && hm->link.clo == zdim &&
+           hl->link.clo == zdim && zdim <= HEAD_ZMAX && (hm->link.chi & 3) == 0 && hm->link.chi <= HEAD_HMAX;
+}
+
+int heads_latent_fwd(const arvae_layer_t *hm, const arvae_layer_t *hl, int batch, int zdim, const float *params,
+                     const float *hidden, const float *eps, float *mu, float *log_std, float *sigma, float *z, hipStream_t s) {
+    HeadsFwdArgs p;
+    p.hidden = hidden;
+    p.w_mu = params + hm->w_off; p.b_mu = hm->b_off >= 0 ? params + hm->b_off : nullptr;
+    p.w_ls = params + hl->w_off; p.b_ls = hl->b_off >= 0 ? params + hl->b_off : nullptr;
+    p.eps = eps; p.mu = mu; p.log_std = log_std; p.sigma = sigma; p.z = z;
+    p.batch = batch; p.h = hm->link.chi; p.zdim = zdim;
+    const size_t lds = (size_t)(HEAD_ROWS * p.h + 2 * HEAD_ZMAX * (p.h + 4) + HEAD_ROWS * 32) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void *)heads_latent_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (HEAD_ROWS * HEAD_HMAX + 2 * HEAD_ZMAX * (HEAD_HMAX + 4) + HEAD_ROWS * 32) * (int)sizeof(float));
+        attr = true;
+    }
+    hipLaunchKernelGGL(heads_latent_fwd_kernel, dim3((batch + HEAD_ROWS - 1) / HEAD_ROWS), dim3(256), lds, s, p);
+    return check_launch("heads_latent_fwd");
+}
+
+int heads_latent_bwd(const arvae_layer_t *hm, const arvae_layer_t *hl, int batch, int zdim, const float *params,
+                     const float *g_z, const float *dz_reg, const float *dz_extra, const float *mu, const float *sigma,
+                     const float *eps, const float *g_loss, const float *kl, const float *cap, float beta, float reg_scale,
+                     const float *gate, float *d_mu, float *d_ls, float *d_hidden, hipStream_t s) {
+    HeadsBwdArgs p;
+    p.g_z = g_z; p.dz_reg = dz_reg; p.dz_extra = dz_extra; p.mu = mu; p.sigma = sigma; p.eps = eps;
+    p.g_loss = g_loss; p.kl = kl; p.cap = cap;
+    p.beta = beta; p.inv_batch = 1.f / (float)batch; p.reg_scale = reg_scale;
+    p.w_mu = params + hm->w_off; p.w_ls = params + hl->w_off; p.gate = gate;
+    p.d_mu = d_mu; p.d_ls = d_ls; p.d_hidden = d_hidden;
+    p.batch = batch; p.h = hm->link.chi; p.zdim = zdim;
+    hipLaunchKernelGGL(heads_latent_bwd_kernel, dim3((batch + HEAD_ROWS - 1) / HEAD_ROWS), dim3(256), 0, s, p);
+    return check_launch("heads_latent_bwd");
+}
+
+}  // namespace arvae

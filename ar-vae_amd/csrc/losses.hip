@@ -349,10 +349,12 @@ __global__ __launch_bounds__(1024) void vae_finish_kernel(VaeFinishArgs p) {
             for (int64_t i = threadIdx.x; i < p.n_rows * p.ldz; i += 1024) {
                 const int64_t row = i / p.ldz;
                 const int c = (int)(i - row * p.ldz);
-                float g = 0.f;
-                for (int k = 0; k < p.r; ++k)
-                    if (p.dims.d[k] == c) g = p.grad_scale * p.row_grad[(int64_t)k * p.n_rows + row];
-                p.dz[i] = g;
+                int k = -1;                                       // index arithmetic only, then ONE unconditional load
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    if (q < p.r && p.dims.d[q] == c) k = q;
+                const float g = p.row_grad[(int64_t)(k < 0 ? 0 : k) * p.n_rows + row];
+                p.dz[i] = k < 0 ? 0.f : p.grad_scale * g;
             }
         }
     }

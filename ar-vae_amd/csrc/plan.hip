@@ -16,6 +16,15 @@ int conv32_up(const arvae_link_t *l, const Operand &lo, const float *wt, const f
 int conv_c1_down(const arvae_link_t *l, const Operand &img, const float *wt, const float *bias, int relu,
                  const float *gate, float *out, hipStream_t s);
 
+// fused encoder heads + reparameterisation (heads.hip)
+bool heads_fusable(const arvae_layer_t *hm, const arvae_layer_t *hl, int zdim);
+int heads_latent_fwd(const arvae_layer_t *hm, const arvae_layer_t *hl, int batch, int zdim, const float *params,
+                     const float *hidden, const float *eps, float *mu, float *log_std, float *sigma, float *z, hipStream_t s);
+int heads_latent_bwd(const arvae_layer_t *hm, const arvae_layer_t *hl, int batch, int zdim, const float *params,
+                     const float *g_z, const float *dz_reg, const float *dz_extra, const float *mu, const float *sigma,
+                     const float *eps, const float *g_loss, const float *kl, const float *cap, float beta, float reg_scale,
+                     const float *gate, float *d_mu, float *d_ls, float *d_hidden, hipStream_t s);
+
 // loss-term pieces (losses.hip)
 int recon_partials(const float *logits, const float *x, int64_t count, int64_t batch, int32_t dist, float *ws,
                    float *dlogits, hipStream_t s, int *nb_out);
@@ -220,10 +229,16 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
         if (int rc = layer_forward(m->enc[i], batch, params, h, mask, ws + L.enc_out[i], stream)) return rc;
         h = ws + L.enc_out[i];
     }
-    if (int rc = layer_forward(m->head_mu, batch, params, h, nullptr, mu, stream)) return rc;
-    if (int rc = layer_forward(m->head_log_std, batch, params, h, nullptr, ws + L.log_std, stream)) return rc;
     const int64_t bz = (int64_t)batch * m->zdim;
-    if (int rc = arvae_latent_fwd(mu, ws + L.log_std, eps, bz, sigma, z, stream)) return rc;
+    if (heads_fusable(&m->head_mu, &m->head_log_std, m->zdim)) {
+        if (int rc = heads_latent_fwd(&m->head_mu, &m->head_log_std, batch, m->zdim, params, h, eps, mu, ws + L.log_std,
+                                      sigma, z, st))
+            return rc;
+    } else {
+        if (int rc = layer_forward(m->head_mu, batch, params, h, nullptr, mu, stream)) return rc;
+        if (int rc = layer_forward(m->head_log_std, batch, params, h, nullptr, ws + L.log_std, stream)) return rc;
+        if (int rc = arvae_latent_fwd(mu, ws + L.log_std, eps, bz, sigma, z, stream)) return rc;
+    }
     // decoder
     h = z;
     for (int i = 0; i < m->n_dec; ++i) {
@@ -304,34 +319,50 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
         pre = gated;
         cur = dst;
     }
-    // latent head (cur = gradient w.r.t. z from the decoder)
-    {
+    // latent head (cur = gradient w.r.t. z from the decoder) and the two encoder heads:
+    // d_hidden = W_mu^T d_mu + W_ls^T d_ls   (gated by the last encoder layer's ReLU when possible)
+    const float *hidden = ws + L.enc_out[m->n_enc - 1];
+    const float *dz_reg = (reg_fused && m->n_reg > 0) ? ws + L.dz_reg : nullptr;
+    const float *head_gate = relu_gate(m->enc[m->n_enc - 1], enc_mask[m->n_enc - 1], hidden);
+    float *d_hidden = grad_dst(L.enc_keep[m->n_enc - 1], nullptr);
+    if (heads_fusable(&m->head_mu, &m->head_log_std, m->zdim)) {
+        if (int rc = heads_latent_bwd(&m->head_mu, &m->head_log_std, batch, m->zdim, params, cur, dz_reg, dz_extra, mu, sigma,
+                                      eps, g_loss, ws + L.kld_out + 1, capacity, m->beta, reg_scale, head_gate, ws + L.d_mu,
+                                      ws + L.d_ls, d_hidden, st))
+            return rc;
+        const arvae_layer_t *heads[2] = {&m->head_mu, &m->head_log_std};
+        const float *hg[2] = {ws + L.d_mu, ws + L.d_ls};
+        for (int k = 0; k < 2; ++k) {                            // weight gradients of the heads join the grouped launch
+            arvae_link_t lk = heads[k]->link;
+            lk.n = batch;
+            float *dw = grads + heads[k]->w_off, *db = heads[k]->b_off >= 0 ? grads + heads[k]->b_off : nullptr;
+            const arvae_operand_t gop = plain(hg[k]), xin = plain(hidden);
+            if (!dense_wgrad_defer(&defer, &lk, make_operand(&gop), hidden, dw, db))
+                if (int rc = arvae_link_wgrad(&lk, &gop, &xin, dw, db, db ? 1 : 0, slab, stream)) return rc;
+        }
+        cur = d_hidden;
+        pre = head_gate != nullptr;
+    } else {
         int64_t blocks = (bz + 255) / 256;
         if (blocks > 1024) blocks = 1024;
-        hipLaunchKernelGGL(latent_bwd_full_kernel, dim3((unsigned)blocks), dim3(256), 0, st, cur,
-                           (reg_fused && m->n_reg > 0) ? ws + L.dz_reg : nullptr, dz_extra, mu, sigma, eps, g_loss,
-                           ws + L.kld_out + 1, capacity, m->beta, 1.f / (float)batch, reg_scale, bz, ws + L.d_mu,
-                           ws + L.d_ls);
+        hipLaunchKernelGGL(latent_bwd_full_kernel, dim3((unsigned)blocks), dim3(256), 0, st, cur, dz_reg, dz_extra, mu, sigma,
+                           eps, g_loss, ws + L.kld_out + 1, capacity, m->beta, 1.f / (float)batch, reg_scale, bz,
+                           ws + L.d_mu, ws + L.d_ls);
         if (int rc = check_launch("image_vae_backward(latent)")) return rc;
-    }
-    // heads: d_hidden = W_mu^T d_mu + W_ls^T d_ls   (gated by the last encoder layer's ReLU when possible)
-    const float *hidden = ws + L.enc_out[m->n_enc - 1];
-    cur = grad_dst(L.enc_keep[m->n_enc - 1], nullptr);
-    float *other = grad_dst(-1, cur);
-    if (int rc = layer_backward(m->head_mu, batch, params, grads, hidden, nullptr, nullptr, ws + L.d_mu, true, nullptr,
-                                cur, nullptr, slab, &defer, stream))
-        return rc;
-    if (int rc = layer_backward(m->head_log_std, batch, params, grads, hidden, nullptr, nullptr, ws + L.d_ls, true,
-                                nullptr, other, nullptr, slab, &defer, stream))
-        return rc;
-    {
-        const float *gate = relu_gate(m->enc[m->n_enc - 1], enc_mask[m->n_enc - 1], hidden);
+        cur = d_hidden;
+        float *other = grad_dst(-1, cur);
+        if (int rc = layer_backward(m->head_mu, batch, params, grads, hidden, nullptr, nullptr, ws + L.d_mu, true, nullptr,
+                                    cur, nullptr, slab, &defer, stream))
+            return rc;
+        if (int rc = layer_backward(m->head_log_std, batch, params, grads, hidden, nullptr, nullptr, ws + L.d_ls, true,
+                                    nullptr, other, nullptr, slab, &defer, stream))
+            return rc;
         const int64_t hn = in_elems(m->head_mu, batch);
-        int64_t blocks = (hn + 255) / 256;
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)blocks), dim3(256), 0, st, cur, other, gate, hn);
+        int64_t blocks2 = (hn + 255) / 256;
+        if (blocks2 > 2048) blocks2 = 2048;
+        hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)blocks2), dim3(256), 0, st, cur, other, head_gate, hn);
         if (int rc = check_launch("image_vae_backward(add)")) return rc;
-        pre = gate != nullptr;
+        pre = head_gate != nullptr;
     }
     // encoder, last layer first; the image itself needs no gradient
     for (int i = m->n_enc - 1; i >= 0; --i) {
