@@ -67,6 +67,7 @@ struct Operand {
     const float *y;
     const uint8_t *mask;
     int act;
+    const float *scale = nullptr;   // optional device scalar multiplying the operand; honoured by the conv_c1 kernels only
     __device__ __forceinline__ float at(int64_t i) const {
         float r = v[i];
         if (y != nullptr) {
@@ -81,6 +82,28 @@ struct Operand {
     }
 };
 static inline Operand make_operand(const arvae_operand_t *o) { return Operand{o->v, o->y, o->mask, o->act}; }
+
+// one pixel of the image reconstruction term (image_vae_trainer.py:623-655): loss and correct-count accumulate,
+// dl = d loss / d logit (already divided by the batch size)
+// Hardware exp2/log2/rcp based (about 1e-7 relative, ~25 instructions instead of ~120 with the libm versions, which
+// made the reconstruction term ALU-bound): log1p(e) = log(u) - ((u - 1) - e) / u with u = 1 + e keeps the bits
+// that 1 + e rounds away.
+template <int DIST>
+__device__ __forceinline__ void recon_elem(float l, float x, float inv_b, float &loss, float &corr, float &dl) {
+    const float e = __expf(-fabsf(l));
+    const float u = 1.f + e;
+    const float r = __frcp_rn(u);
+    const float sig = l >= 0.f ? r : e * r;
+    if (DIST == ARVAE_RECON_BERNOULLI) {
+        loss += fmaxf(l, 0.f) - l * x + (__logf(u) - ((u - 1.f) - e) * r);
+        dl = (sig - x) * inv_b;
+    } else {
+        const float df = sig - x;
+        loss += df * df;
+        dl = 2.f * df * sig * (1.f - sig) * inv_b;
+    }
+    corr += ((l >= 0.f) == (x >= 0.5f)) ? 1.f : 0.f;
+}
 
 // ---- reductions -------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

@@ -21,6 +21,7 @@
 //     committed to LDS (pixel stride 36 floats: <= 2-way bank conflicts for stride-1/2 pixel walks) between
 //     two barriers.
 #include "common.h"
+#include "reduce.h"
 
 #include <type_traits>
 
@@ -499,7 +500,7 @@ __global__ __launch_bounds__(256, 1) void up32_kernel(const float *__restrict__ 
 // slab layout per workgroup: [ky][kx][clo][chi] (16384 floats) + 32 bias sums.
 // BIAS: 0 none, 1 = sum of the lo operand per clo, 2 = sum of the hi operand per chi (interior pixels)
 // ================================================================================================
-constexpr int WG32_SLAB = 16 * C32 * C32 + C32;
+constexpr int WG32_SLAB = SLAB_C32_FLOATS;
 
 template <int LO, int BIAS>
 __global__ __launch_bounds__(256, 1) void wgrad32_kernel(const float *__restrict__ lo, const float *__restrict__ hi, float *__restrict__ slab, int n_img,
@@ -611,31 +612,6 @@ __global__ __launch_bounds__(256, 1) void wgrad32_kernel(const float *__restrict
     }
     STAMP_WAIT();
     STAMP(63);
-}
-
-// dwt[clo][chi][ky][kx] += sum_wg slab[wg][ky][kx][clo][chi];  dbias[c] += sum_wg slab[wg][16384 + c]
-// 16 outputs x 16 slab groups per workgroup: ~1000 workgroups keep enough loads in flight to stream the slab
-__global__ __launch_bounds__(256) void wgrad32_reduce_kernel(const float *__restrict__ slab, int n_wg,
-                                                              float *__restrict__ dwt, float *__restrict__ dbias) {
-    __shared__ float red[16][17];
-    const int il = threadIdx.x & 15, zg = threadIdx.x >> 4;
-    const int i = blockIdx.x * 16 + il;                    // 0 .. 16384+32
-    float s = 0.f;
-    if (i < WG32_SLAB)
-        for (int z = zg; z < n_wg; z += 16) s += slab[(int64_t)z * WG32_SLAB + i];
-    red[zg][il] = s;
-    __syncthreads();
-    if (zg == 0 && i < WG32_SLAB) {
-        float tot = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) tot += red[j][il];
-        if (i < 16 * C32 * C32) {
-            const int chi = i & 31, clo = (i >> 5) & 31, tap = i >> 10;
-            dwt[(clo * C32 + chi) * 16 + tap] += tot;
-        } else if (dbias != nullptr) {
-            dbias[i - 16 * C32 * C32] += tot;
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -757,9 +733,10 @@ template <int LO> static int launch_wgrad(const arvae_link_t *l, const Operand &
     return check_launch(LO == 16 ? "wgrad32_kernel<16>" : LO == 8 ? "wgrad32_kernel<8>" : "wgrad32_kernel<4>");
 }
 
+// per-workgroup partial sums into `slab`; the returned job describes the reduction that finishes the layer
 // bias_mode: 0 none, 1 dbias[clo] += sum lo, 2 dbias[chi] += sum hi
-int conv32_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *dwt, float *dbias, int bias_mode,
-                 float *slab, hipStream_t s) {
+int conv32_wgrad_partial(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *dwt, float *dbias, int bias_mode,
+                         float *slab, hipStream_t s, SlabJob *job) {
     const int grid = conv32_wgrad_groups(l);
     int rc;
     switch (l->lh) {
@@ -767,10 +744,15 @@ int conv32_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, fl
         case 8: rc = launch_wgrad<8>(l, lo, hi, slab, bias_mode, grid, s); break;
         default: rc = launch_wgrad<4>(l, lo, hi, slab, bias_mode, grid, s); break;
     }
-    if (rc) return rc;
-    hipLaunchKernelGGL(wgrad32_reduce_kernel, dim3((WG32_SLAB + 15) / 16), dim3(256), 0, s, slab, grid, dwt,
-                       bias_mode ? dbias : nullptr);
-    return check_launch("wgrad32_reduce_kernel");
+    *job = SlabJob{slab, dwt, bias_mode ? dbias : nullptr, grid, SLAB_C32, bias_mode};
+    return rc;
+}
+
+int conv32_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *dwt, float *dbias, int bias_mode,
+                 float *slab, hipStream_t s) {
+    SlabJob job;
+    if (int rc = conv32_wgrad_partial(l, lo, hi, dwt, dbias, bias_mode, slab, s, &job)) return rc;
+    return slab_reduce(job, s);
 }
 
 }  // namespace arvae

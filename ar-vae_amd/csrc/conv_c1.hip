@@ -9,6 +9,7 @@
 //                 from scalar registers
 //   wgrad_c1 : dwt[c][0][ky][kx] += sum_pixels lo[pix][c] * img[pix @ tap]; bias sums ride along
 #include "common.h"
+#include "reduce.h"
 
 namespace arvae {
 
@@ -30,12 +31,13 @@ struct Ep1 {
 // tile owns (rows 1..16, cols 1..64 of the patch) for the transposed-conv bias gradient
 __device__ __forceinline__ float load_img_patch(float *patch, const Operand &img, int n, int r0) {
     float own = 0.f;
+    const float gs = img.scale != nullptr ? img.scale[0] : 1.f;
     for (int idx = threadIdx.x; idx < IPR * 66; idx += 256) {
         const int pr = idx / 66, pc = idx - pr * 66;
         const int gy = 2 * r0 - 1 + pr, gx = pc - 1;
         float v = 0.f;
         if ((unsigned)gy < (unsigned)HI1 && (unsigned)gx < (unsigned)HI1) {
-            v = img.at(((int64_t)n * HI1 + gy) * HI1 + gx);
+            v = gs * img.at(((int64_t)n * HI1 + gy) * HI1 + gx);
             if (pr >= 1 && pr <= 2 * TR1) own += v;
         }
         patch[pr * IPC + pc] = v;
@@ -90,65 +92,118 @@ __global__ __launch_bounds__(256) void down_c1_kernel(Operand img, const float *
 }
 
 // ================================================================================================
-// one lane per lo position (yy, xx): outputs (2yy+py, 2xx+px); tap (ty,tx) of class (py,px) reads lo
-// (yy + py - ty, xx + px - tx) with weight wt[c][0][1 - py + 2 ty][1 - px + 2 tx]
-__global__ __launch_bounds__(256) void up_c1_kernel(const float *__restrict__ lo, const float *__restrict__ wt,
-                                                     const float *__restrict__ bias_p, float *__restrict__ out,
-                                                     int n_tiles) {
-    constexpr int PR = TR1 + 2, PC = LO1 + 2;
-    extern __shared__ __attribute__((aligned(16))) float patch[];          // PR*PC pixels x PS1
-    const int t = threadIdx.x;
-    const int yy = t >> 5, xx = t & 31;
+// up_c1: img[n,hy,hx] = bias + sum over the 2x2 valid taps and 32 channels of lo * wt, in two steps:
+//   T[pos][tap] = sum_c lo[pos][c] * wt[c][tap]        a dense [positions x 32] x [32 x 16] product on the 16x16x4
+//                                                        MFMA (all 16 columns useful, operands straight from HBM in
+//                                                        the MFMA's own lane layout: no LDS staging of lo)
+//   img(2y+py, 2x+px) = bias + sum_{ty,tx} T[(y+py-ty, x+px-tx)][(1-py+2ty)*4 + 1-px+2tx]        4 LDS reads / pixel
+// A tile is 16 lo rows of one image (+1 halo row each side, zero outside the image) = 36 groups of 16 positions,
+// 9 per wave; T is double-buffered in LDS so a tile needs one barrier.  With LOSS the reconstruction term of the
+// trainer (sum of the per-pixel loss, correct-pixel count, d/dlogits) is computed on the pixels as they are
+// produced: per-workgroup partial sums go to partial[2*blockIdx.x ..], the logits are still written.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr int TRU = 16;
+constexpr int UG_PER_WAVE = (TRU + 2) * 2 / 4;          // 9
+constexpr int TS1 = 17;                                 // floats per position in the LDS T tile
+constexpr int T_FLOATS = (TRU + 2) * LO1 * TS1;
+
+template <int DIST, bool LOSS>
+__global__ __launch_bounds__(256, 2) void up_c1_kernel(const float *__restrict__ lo, const float *__restrict__ wt,
+                                                        const float *__restrict__ bias_p, float *__restrict__ out,
+                                                        const float *__restrict__ x, float inv_b,
+                                                        float *__restrict__ partial, float *__restrict__ dlogits, int n_img,
+                                                        int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];                // 2 x T_FLOATS
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
+    float wreg[2][4];                                   // wt[c = 16s + 4g + j][tap = li]
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wreg[s][j] = wt[(16 * s + 4 * g + j) * 16 + li];
     const float bias = bias_p != nullptr ? bias_p[0] : 0.f;
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int n = tile / (LO1 / TR1), r0 = (tile % (LO1 / TR1)) * TR1;
-        __syncthreads();
-        for (int idx = t; idx < PR * PC * 8; idx += 256) {
-            const int q = idx & 7, pix = idx >> 3;
-            const int pc = pix % PC, pr = pix / PC;
-            const int gy = r0 - 1 + pr, gx = pc - 1;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((unsigned)gy < (unsigned)LO1 && (unsigned)gx < (unsigned)LO1)
-                v = *reinterpret_cast<const float4 *>(lo + (((int64_t)n * LO1 + gy) * LO1 + gx) * CC + q * 4);
-            *reinterpret_cast<float4 *>(patch + pix * PS1 + q * 4) = v;
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(lo), 0, n_img * LO1 * LO1 * CC * 4, 0x00020000);
+    auto load4 = [&](unsigned off) {
+        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
+        return v;
+    };
+    f32x4 v[UG_PER_WAVE][2];
+    // group i of this wave in tile `tile`: T-region row prow, columns col0 .. col0+15; lane = (position li, channel quad g)
+    auto issue = [&](int tile, int i) {
+        const int gidx = wave + 4 * i, prow = gidx >> 1, col0 = (gidx & 1) * 16;
+        const int n = tile >> 1, gy = (tile & 1) * TRU - 1 + prow;
+        const bool ok = tile < n_tiles && (unsigned)gy < (unsigned)LO1;
+        const unsigned off = ok ? (unsigned)((((n * LO1 + gy) * LO1 + col0 + li) * CC + g * 4) * 4) : 0x7fffffffu;
+        v[i][0] = load4(off);
+        v[i][1] = load4(off + 64);
+    };
+#pragma unroll
+    for (int i = 0; i < UG_PER_WAVE; ++i) issue(blockIdx.x, i);
+
+    float loss = 0.f, corr = 0.f;
+    int buf = 0;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, buf ^= 1) {
+        float *T = lds + buf * T_FLOATS;
+        const int n = tile >> 1, r0 = (tile & 1) * TRU;
+        // the image pixels this thread will score: fetched now, used after the barrier
+        float xv[8];
+        if (LOSS) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                xv[i] = x[((int64_t)n * HI1 + 2 * r0 + (threadIdx.x >> 6) + 4 * i) * HI1 + (threadIdx.x & 63)];
+        }
+#pragma unroll
+        for (int i = 0; i < UG_PER_WAVE; ++i) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v[i][s][j], wreg[s][j], acc, 0, 0, 0);
+            issue(tile + gridDim.x, i);                  // refill this group's registers for the next tile
+            const int gidx = wave + 4 * i, prow = gidx >> 1, col0 = (gidx & 1) * 16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) T[(prow * LO1 + col0 + 4 * g + r) * TS1 + li] = acc[r];   // D row = 4g + r, col = li
         }
         __syncthreads();
-        float acc[2][2] = {{bias, bias}, {bias, bias}};
-        // channel chunk outermost and NOT unrolled: only its 4 x 16 weights are live in scalar registers
-        // (all 512 at once spill through v_readlane)
-#pragma unroll 1
-        for (int q = 0; q < 8; ++q) {
-            const float *wq = wt + q * 64;                                  // wt[(q*4 + e)*16 + tap]
+        const int hx = threadIdx.x & 63, px = hx & 1, xq = hx >> 1;
 #pragma unroll
-            for (int dy = -1; dy <= 1; ++dy)
+        for (int i = 0; i < 8; ++i) {
+            const int hy = (threadIdx.x >> 6) + 4 * i, py = hy & 1, y = hy >> 1;       // tile-relative hi row / lo row
+            float sum = bias;
 #pragma unroll
-                for (int dx = -1; dx <= 1; ++dx) {
-                    const float4 a = *reinterpret_cast<const float4 *>(patch + ((yy + 1 + dy) * PC + xx + 1 + dx) * PS1 + q * 4);
-                    const float av[4] = {a.x, a.y, a.z, a.w};
+            for (int ty = 0; ty < 2; ++ty)
 #pragma unroll
-                    for (int py = 0; py < 2; ++py) {
-                        const int ty = py - dy;                       // compile-time after unrolling
-                        if (ty < 0 || ty > 1) continue;
-#pragma unroll
-                        for (int px = 0; px < 2; ++px) {
-                            const int tx = px - dx;
-                            if (tx < 0 || tx > 1) continue;
-                            const int tap = (1 - py + 2 * ty) * 4 + (1 - px + 2 * tx);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) acc[py][px] = fmaf(av[e], wq[e * 16 + tap], acc[py][px]);
-                        }
-                    }
+                for (int tx = 0; tx < 2; ++tx) {
+                    const int col = xq + px - tx;
+                    const bool ok = (unsigned)col < (unsigned)LO1;
+                    const int tap = (1 - py + 2 * ty) * 4 + 1 - px + 2 * tx;
+                    const float t = T[((y + py - ty + 1) * LO1 + (ok ? col : 0)) * TS1 + tap];
+                    sum += ok ? t : 0.f;
                 }
+            const int64_t o = ((int64_t)n * HI1 + 2 * r0 + hy) * HI1 + hx;
+            out[o] = sum;
+            if (LOSS) {
+                float d;
+                recon_elem<DIST>(sum, xv[i], inv_b, loss, corr, d);
+                if (dlogits != nullptr) dlogits[o] = d;
+            }
         }
-        const int64_t o = (((int64_t)n * HI1) + 2 * (r0 + yy)) * HI1 + 2 * xx;
-        *reinterpret_cast<float2 *>(out + o) = make_float2(acc[0][0], acc[0][1]);
-        *reinterpret_cast<float2 *>(out + o + HI1) = make_float2(acc[1][0], acc[1][1]);
+    }
+    if (LOSS) {
+        const float tl = block_sum_256(loss, red);
+        const float tc = block_sum_256(corr, red);
+        if (threadIdx.x == 0) {
+            partial[2 * blockIdx.x] = tl;
+            partial[2 * blockIdx.x + 1] = tc;
+        }
     }
 }
 
 // ================================================================================================
 // slab per workgroup: [32 clo][16 taps] + 32 lo sums + 1 image sum
-constexpr int WG1_SLAB = CC * 16 + CC + 1;
+constexpr int WG1_SLAB = SLAB_C1_FLOATS;
 
 __global__ __launch_bounds__(256) void wgrad_c1_kernel(Operand lo, Operand img, float *__restrict__ slab, int n_tiles) {
     __shared__ float patch[IPR * IPC];
@@ -159,6 +214,7 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(Operand lo, Operand img, 
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     float lo_sum = 0.f, img_sum = 0.f;
+    const float gs = img.scale != nullptr ? img.scale[0] : 1.f;
     // register-staged loads (issued for tile t+1 before the MFMAs of tile t)
     constexpr int IMG_ITERS = (IPR * 66 + 255) / 256;
     float4 lr[8];
@@ -184,7 +240,7 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(Operand lo, Operand img, 
             const int gy = 2 * r0 - 1 + pr, gx = pc - 1;
             ir[it] = 0.f;
             if (idx < IPR * 66 && (unsigned)gy < (unsigned)HI1 && (unsigned)gx < (unsigned)HI1)
-                ir[it] = img.at(((int64_t)n * HI1 + gy) * HI1 + gx);
+                ir[it] = gs * img.at(((int64_t)n * HI1 + gy) * HI1 + gx);
         }
     };
     if (blockIdx.x < n_tiles) issue(blockIdx.x);
@@ -246,30 +302,6 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(Operand lo, Operand img, 
     }
 }
 
-__global__ __launch_bounds__(256) void wgrad_c1_reduce_kernel(const float *__restrict__ slab, int n_wg,
-                                                               float *__restrict__ dwt, float *__restrict__ dbias,
-                                                               int bias_mode) {
-    __shared__ float red[16][17];
-    const int il = threadIdx.x & 15, zg = threadIdx.x >> 4;
-    const int i = blockIdx.x * 16 + il;
-    float s = 0.f;
-    if (i < WG1_SLAB)
-        for (int z = zg; z < n_wg; z += 16) s += slab[(int64_t)z * WG1_SLAB + i];
-    red[zg][il] = s;
-    __syncthreads();
-    if (zg == 0 && i < WG1_SLAB) {
-        float tot = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) tot += red[j][il];
-        if (i < CC * 16)
-            dwt[i] += tot;                                   // wt[clo][0][ky][kx] is exactly [clo][tap]
-        else if (i < CC * 16 + CC) {
-            if (bias_mode == 1) dbias[i - CC * 16] += tot;
-        } else if (bias_mode == 2)
-            dbias[0] += tot;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 bool conv_c1_fits(const arvae_link_t *l) {
     return l->chi == 1 && l->clo == CC && l->kh == 4 && l->kw == 4 && l->stride == 2 && l->pad == 1 && l->hh == HI1 &&
@@ -284,11 +316,50 @@ int conv_c1_down(const arvae_link_t *l, const Operand &img, const float *wt, con
     return check_launch("down_c1_kernel");
 }
 
+static int up_c1_grid(int tiles) {
+    int dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    static int cached = 0;
+    if (cached == 0) {
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        cached = cus > 0 ? cus : 256;
+    }
+    return tiles < 2 * cached ? tiles : 2 * cached;
+}
+
+template <class K> static void up_c1_lds(K kernel) {
+    (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T_FLOATS * 4);
+}
+
 int conv_c1_up(const arvae_link_t *l, const float *lo, const float *wt, const float *bias, float *out, hipStream_t s) {
-    const int tiles = l->n * (LO1 / TR1);
-    constexpr int LDS = (TR1 + 2) * (LO1 + 2) * PS1 * 4;
-    hipLaunchKernelGGL(up_c1_kernel, dim3(tiles < 768 ? tiles : 768), dim3(256), LDS, s, lo, wt, bias, out, tiles);
+    const int tiles = l->n * (LO1 / TRU);
+    static bool attr = false;
+    if (!attr) { up_c1_lds(up_c1_kernel<ARVAE_RECON_BERNOULLI, false>); attr = true; }
+    hipLaunchKernelGGL((up_c1_kernel<ARVAE_RECON_BERNOULLI, false>), dim3(up_c1_grid(tiles)), dim3(256), 2 * T_FLOATS * 4, s, lo,
+                       wt, bias, out, nullptr, 0.f, nullptr, nullptr, l->n, tiles);
     return check_launch("up_c1_kernel");
+}
+
+// the same link with the trainer's reconstruction term fused in: logits -> out, per-workgroup (loss, correct) partial
+// sums -> partial[2 * nb], d loss / d logits -> dlogits (may be null); *nb_out = number of partial pairs
+int conv_c1_up_recon(const arvae_link_t *l, const float *lo, const float *wt, const float *bias, float *out, const float *x,
+                     int dist, float *partial, float *dlogits, hipStream_t s, int *nb_out) {
+    const int tiles = l->n * (LO1 / TRU), grid = up_c1_grid(tiles);
+    const float inv_b = 1.f / (float)l->n;
+    static bool attr = false;
+    if (!attr) {
+        up_c1_lds(up_c1_kernel<ARVAE_RECON_BERNOULLI, true>);
+        up_c1_lds(up_c1_kernel<ARVAE_RECON_GAUSSIAN, true>);
+        attr = true;
+    }
+    if (dist == ARVAE_RECON_BERNOULLI)
+        hipLaunchKernelGGL((up_c1_kernel<ARVAE_RECON_BERNOULLI, true>), dim3(grid), dim3(256), 2 * T_FLOATS * 4, s, lo, wt, bias,
+                           out, x, inv_b, partial, dlogits, l->n, tiles);
+    else
+        hipLaunchKernelGGL((up_c1_kernel<ARVAE_RECON_GAUSSIAN, true>), dim3(grid), dim3(256), 2 * T_FLOATS * 4, s, lo, wt, bias,
+                           out, x, inv_b, partial, dlogits, l->n, tiles);
+    *nb_out = grid;
+    return check_launch("up_c1_kernel(recon)");
 }
 
 static int wgrad_c1_groups(const arvae_link_t *l) {
@@ -298,14 +369,19 @@ static int wgrad_c1_groups(const arvae_link_t *l) {
 
 int64_t conv_c1_wgrad_ws_floats(const arvae_link_t *l) { return (int64_t)wgrad_c1_groups(l) * WG1_SLAB; }
 
-int conv_c1_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &img, float *dwt, float *dbias, int bias_mode,
-                  float *slab, hipStream_t s) {
+int conv_c1_wgrad_partial(const arvae_link_t *l, const Operand &lo, const Operand &img, float *dwt, float *dbias,
+                          int bias_mode, float *slab, hipStream_t s, SlabJob *job) {
     const int tiles = l->n * (LO1 / TR1), grid = wgrad_c1_groups(l);
     hipLaunchKernelGGL(wgrad_c1_kernel, dim3(grid), dim3(256), 0, s, lo, img, slab, tiles);
-    if (int rc = check_launch("wgrad_c1_kernel")) return rc;
-    hipLaunchKernelGGL(wgrad_c1_reduce_kernel, dim3((WG1_SLAB + 15) / 16), dim3(256), 0, s, slab, grid, dwt, dbias,
-                       bias_mode);
-    return check_launch("wgrad_c1_reduce_kernel");
+    *job = SlabJob{slab, dwt, dbias, grid, SLAB_C1, bias_mode};
+    return check_launch("wgrad_c1_kernel");
+}
+
+int conv_c1_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &img, float *dwt, float *dbias, int bias_mode,
+                  float *slab, hipStream_t s) {
+    SlabJob job;
+    if (int rc = conv_c1_wgrad_partial(l, lo, img, dwt, dbias, bias_mode, slab, s, &job)) return rc;
+    return slab_reduce(job, s);
 }
 
 }  // namespace arvae

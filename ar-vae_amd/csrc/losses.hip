@@ -162,21 +162,6 @@ __global__ __launch_bounds__(256) void reg_finish_kernel(const float *__restrict
 constexpr int RECON_MAX_BLOCKS = 1024;
 
 template <int DIST>
-__device__ __forceinline__ void recon_elem(float l, float x, float inv_b, float &loss, float &corr, float &dl) {
-    const float e = expf(-fabsf(l));
-    const float sig = l >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
-    if (DIST == ARVAE_RECON_BERNOULLI) {
-        loss += fmaxf(l, 0.f) - l * x + log1pf(e);
-        dl = (sig - x) * inv_b;
-    } else {
-        const float df = sig - x;
-        loss += df * df;
-        dl = 2.f * df * sig * (1.f - sig) * inv_b;
-    }
-    corr += ((l >= 0.f) == (x >= 0.5f)) ? 1.f : 0.f;
-}
-
-template <int DIST>
 __global__ __launch_bounds__(256) void image_recon_kernel(const float *__restrict__ logits,
                                                            const float *__restrict__ x, int64_t count, float inv_b,
                                                            float *__restrict__ partial, float *__restrict__ dlogits) {

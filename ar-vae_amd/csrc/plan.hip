@@ -3,6 +3,7 @@
 // the link / dense / loss kernels, reached through the same C-ABI entry points a per-layer caller uses.
 #include "common.h"
 #include "dense.h"
+#include "reduce.h"
 
 namespace arvae {
 
@@ -13,6 +14,12 @@ int conv32_down(const arvae_link_t *l, const Operand &hi, const float *wt, const
                 const float *gate, float *out, hipStream_t s);
 int conv32_up(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, int relu,
               const float *gate, float *out, hipStream_t s);
+int conv_c1_up_recon(const arvae_link_t *l, const float *lo, const float *wt, const float *bias, float *out, const float *x,
+                     int dist, float *partial, float *dlogits, hipStream_t s, int *nb_out);
+int conv32_wgrad_partial(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *dwt, float *dbias, int bias_mode,
+                         float *slab, hipStream_t s, SlabJob *job);
+int conv_c1_wgrad_partial(const arvae_link_t *l, const Operand &lo, const Operand &img, float *dwt, float *dbias,
+                          int bias_mode, float *slab, hipStream_t s, SlabJob *job);
 int conv_c1_down(const arvae_link_t *l, const Operand &img, const float *wt, const float *bias, int relu,
                  const float *gate, float *out, hipStream_t s);
 
@@ -85,6 +92,8 @@ struct Layout {
     // Linear layers: the gradient w.r.t. the layer's output stays alive until the end of the backward pass, where
     // all their weight gradients run as one launch (-1: not a Linear layer, gradient lives in the ping-pong pair)
     int64_t enc_keep[ARVAE_MAX_LAYERS], dec_keep[ARVAE_MAX_LAYERS];
+    // conv layers with a slab kernel: their own slab, so that all the reductions can run as one launch at the end
+    int64_t enc_slab[ARVAE_MAX_LAYERS], dec_slab[ARVAE_MAX_LAYERS];
     int64_t log_std, dlogits, dz_reg, d_mu, d_ls, g_a, g_b, slab, rec_ws, reg_ws, rec_out, kld_out, reg_out, total;
     int64_t slab_floats;
 };
@@ -111,6 +120,13 @@ static int make_layout(const arvae_image_vae_t *m, int64_t n, int64_t n_cols, La
     }
     visit(m->head_mu);
     visit(m->head_log_std);
+    auto own_slab = [&](const arvae_layer_t &l) -> int64_t {
+        arvae_link_t lk = l.link;
+        lk.n = (int32_t)n;
+        return (conv32_fits(&lk) || conv_c1_fits(&lk)) ? take(arvae_link_wgrad_ws_floats(&lk)) : -1;
+    };
+    for (int i = 0; i < m->n_enc; ++i) L.enc_slab[i] = own_slab(m->enc[i]);
+    for (int i = 0; i < m->n_dec; ++i) L.dec_slab[i] = own_slab(m->dec[i]);
     for (int i = 0; i < m->n_enc; ++i) L.enc_keep[i] = dense_fits(&m->enc[i].link) ? take(out_elems(m->enc[i], n)) : -1;
     for (int i = 0; i < m->n_dec; ++i) L.dec_keep[i] = dense_fits(&m->dec[i].link) ? take(out_elems(m->dec[i], n)) : -1;
     const int64_t bz = n * m->zdim;
@@ -152,7 +168,8 @@ static int layer_forward(const arvae_layer_t &l, int32_t n, const float *params,
 //   *gated : set when the gate was applied (a fast kernel with a gated epilogue was available)
 static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params, float *grads, const float *in,
                           const float *out, const uint8_t *mask, const float *g, bool g_is_pre, const float *gate,
-                          float *d_in, bool *gated, float *slab, DenseWgradBatch *defer, arvae_stream_t st) {
+                          float *d_in, bool *gated, float *slab, DenseWgradBatch *defer, float *own_slab,
+                          SlabReduceBatch *rdefer, arvae_stream_t st, const float *g_scale = nullptr) {
     arvae_link_t lk = l.link;
     lk.n = n;
     const arvae_operand_t gop = g_is_pre ? plain(g) : arvae_operand_t{g, out, mask, l.act};
@@ -169,7 +186,9 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
                 rc = conv32_down(&lk, make_operand(&gop), w, nullptr, 0, gate, d_in, hs);
                 *gated = true;
             } else if (gate != nullptr && simple && conv_c1_fits(&lk)) {
-                rc = conv_c1_down(&lk, make_operand(&gop), w, nullptr, 0, gate, d_in, hs);
+                Operand g_op = make_operand(&gop);
+                g_op.scale = g_scale;
+                rc = conv_c1_down(&lk, g_op, w, nullptr, 0, gate, d_in, hs);
                 *gated = true;
             } else {
                 rc = arvae_link_down(&lk, &gop, w, nullptr, ARVAE_ACT_NONE, nullptr, d_in, st);
@@ -186,6 +205,19 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
             }
         }
         if (rc) return rc;
+    }
+    // conv layers with a slab kernel and plain operands: partial sums now, reduction queued for the end of the pass
+    if (rdefer != nullptr && own_slab != nullptr && gop.y == nullptr && rdefer->count < SLAB_BATCH_MAX &&
+        (conv32_fits(&lk) || conv_c1_fits(&lk))) {
+        Operand lo_op = make_operand(l.is_up ? &xin : &gop), hi_op = make_operand(l.is_up ? &gop : &xin);
+        (l.is_up ? hi_op : lo_op).scale = g_scale;                // only the conv_c1 kernels honour it (checked by the caller)
+        const int bias_mode = db ? (l.is_up ? 2 : 1) : 0;
+        SlabJob job;
+        const int rc = conv32_fits(&lk) ? conv32_wgrad_partial(&lk, lo_op, hi_op, dw, db, bias_mode, own_slab, hs, &job)
+                                        : conv_c1_wgrad_partial(&lk, lo_op, hi_op, dw, db, bias_mode, own_slab, hs, &job);
+        if (rc) return rc;
+        slab_reduce_defer(rdefer, job);
+        return ARVAE_OK;
     }
     if (l.is_up) return arvae_link_wgrad(&lk, &xin, &gop, dw, db, db ? 2 : 0, slab, st);
     if (defer != nullptr && dense_fits(&lk) && dense_wgrad_defer(defer, &lk, make_operand(&gop), in, dw, db)) return ARVAE_OK;
@@ -241,17 +273,30 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
     }
     // decoder
     h = z;
+    int nb = 0;
+    const arvae_layer_t &last = m->dec[m->n_dec - 1];
+    const bool recon_fused = last.is_up && last.act == ARVAE_ACT_NONE && last.dropout == 0 && conv_c1_fits(&last.link) &&
+                             arvae_recon_ws_floats(0) >= 2 * 1024;
     for (int i = 0; i < m->n_dec; ++i) {
         const uint8_t *mask = (masks != nullptr && m->dec[i].dropout) ? masks[mi] : nullptr;
         mi += m->dec[i].dropout != 0;
         float *out = (i + 1 < m->n_dec) ? ws + L.dec_out[i] : logits;
-        if (int rc = layer_forward(m->dec[i], batch, params, h, mask, out, stream)) return rc;
+        if (i + 1 == m->n_dec && recon_fused) {             // last layer: logits + reconstruction partials in one kernel
+            arvae_link_t lk = m->dec[i].link;
+            lk.n = batch;
+            const arvae_layer_t &l = m->dec[i];
+            if (int rc = conv_c1_up_recon(&lk, h, params + l.w_off, l.b_off >= 0 ? params + l.b_off : nullptr, logits, x,
+                                          m->recon_dist, ws + L.rec_ws, ws + L.dlogits, st, &nb))
+                return rc;
+        } else if (int rc = layer_forward(m->dec[i], batch, params, h, mask, out, stream)) {
+            return rc;
+        }
         h = out;
     }
     // loss terms: per-block partials of the reconstruction term and the regulariser, then one finishing workgroup
     const int64_t pix = out_elems(m->dec[m->n_dec - 1], batch);
-    int nb = 0;
-    if (int rc = recon_partials(logits, x, pix, batch, m->recon_dist, ws + L.rec_ws, ws + L.dlogits, st, &nb)) return rc;
+    if (!recon_fused)
+        if (int rc = recon_partials(logits, x, pix, batch, m->recon_dist, ws + L.rec_ws, ws + L.dlogits, st, &nb)) return rc;
     const bool reg_here = m->n_reg > 0 && n_cols >= 0;
     int64_t nc = batch;
     if (reg_here) {
@@ -290,6 +335,8 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
     float *const pp_a = ws + L.g_a, *const pp_b = ws + L.g_b, *slab = L.slab_floats ? ws + L.slab : nullptr;
     DenseWgradBatch defer;
     defer.count = 0;
+    SlabReduceBatch rdefer;
+    rdefer.count = 0;
     // where the gradient for `keep` (a Linear layer's output, or -1) is written: its own buffer, or the ping-pong
     // buffer that does not hold the gradient being consumed
     auto grad_dst = [&](int64_t keep, const float *busy) -> float * {
@@ -298,14 +345,31 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
     };
     const int64_t pix = out_elems(m->dec[m->n_dec - 1], batch);
     const int64_t bz = (int64_t)batch * m->zdim;
-    float *cur = grad_dst(L.dec_keep[m->n_dec - 1], nullptr);
-    if (int rc = arvae_scale_by_scalar(g_loss, ws + L.dlogits, pix, cur, stream)) return rc;
+    // d loss / d logits was left unscaled by the forward pass.  When the last layer runs on the conv_c1 kernels they
+    // multiply by the upstream gradient while loading it; otherwise one elementwise pass makes the scaled copy.
+    float *cur;
+    const float *first_scale = nullptr;
     // A layer's ReLU can be folded into the data-gradient epilogue of its consumer when no dropout mask sits
     // between them; the gradient handed down is then w.r.t. the pre-activation.
     auto relu_gate = [&](const arvae_layer_t &producer, int mask_idx, const float *saved) -> const float * {
         return (producer.act == ARVAE_ACT_RELU && mask_of(mask_idx) == nullptr) ? saved : nullptr;
     };
     bool pre = true;                                     // the last decoder layer has no activation
+    {
+        const int li = m->n_dec - 1;
+        const arvae_layer_t &last = m->dec[li];
+        arvae_link_t lk = last.link;
+        lk.n = batch;
+        const bool fold = last.is_up && conv_c1_fits(&lk) && mask_of(dec_mask[li]) == nullptr && li > 0 &&
+                          relu_gate(m->dec[li - 1], dec_mask[li - 1], ws + L.dec_out[li - 1]) != nullptr && L.dec_slab[li] >= 0;
+        if (fold) {
+            cur = ws + L.dlogits;
+            first_scale = g_loss;
+        } else {
+            cur = grad_dst(L.dec_keep[li], nullptr);
+            if (int rc = arvae_scale_by_scalar(g_loss, ws + L.dlogits, pix, cur, stream)) return rc;
+        }
+    }
     // decoder, last layer first
     for (int i = m->n_dec - 1; i >= 0; --i) {
         const float *in = i > 0 ? ws + L.dec_out[i - 1] : z;
@@ -314,7 +378,8 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
         float *dst = grad_dst(i > 0 ? L.dec_keep[i - 1] : -1, cur);
         bool gated = false;
         if (int rc = layer_backward(m->dec[i], batch, params, grads, in, out, mask_of(dec_mask[i]), cur, pre, gate, dst,
-                                    &gated, slab, &defer, stream))
+                                    &gated, slab, &defer, L.dec_slab[i] >= 0 ? ws + L.dec_slab[i] : nullptr, &rdefer, stream,
+                                    i == m->n_dec - 1 ? first_scale : nullptr))
             return rc;
         pre = gated;
         cur = dst;
@@ -352,10 +417,10 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
         cur = d_hidden;
         float *other = grad_dst(-1, cur);
         if (int rc = layer_backward(m->head_mu, batch, params, grads, hidden, nullptr, nullptr, ws + L.d_mu, true, nullptr,
-                                    cur, nullptr, slab, &defer, stream))
+                                    cur, nullptr, slab, &defer, nullptr, nullptr, stream))
             return rc;
         if (int rc = layer_backward(m->head_log_std, batch, params, grads, hidden, nullptr, nullptr, ws + L.d_ls, true,
-                                    nullptr, other, nullptr, slab, &defer, stream))
+                                    nullptr, other, nullptr, slab, &defer, nullptr, nullptr, stream))
             return rc;
         const int64_t hn = in_elems(m->head_mu, batch);
         int64_t blocks2 = (hn + 255) / 256;
@@ -371,11 +436,13 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
         float *dst = i > 0 ? grad_dst(L.enc_keep[i - 1], cur) : nullptr;
         bool gated = false;
         if (int rc = layer_backward(m->enc[i], batch, params, grads, in, ws + L.enc_out[i], mask_of(enc_mask[i]), cur, pre,
-                                    gate, dst, &gated, slab, &defer, stream))
+                                    gate, dst, &gated, slab, &defer, L.enc_slab[i] >= 0 ? ws + L.enc_slab[i] : nullptr, &rdefer,
+                                    stream))
             return rc;
         pre = gated;
         cur = dst;
     }
+    if (int rc = slab_reduce_flush(&rdefer, st)) return rc;
     if (int rc = dense_wgrad_flush(&defer, st)) return rc;
     return ARVAE_OK;
 }

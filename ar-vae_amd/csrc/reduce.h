@@ -1,0 +1,29 @@
+// Fixed-order reduction of the per-workgroup weight-gradient slabs written by the conv kernels (conv32.hip,
+// conv_c1.hip).  Several layers' reductions can be queued and run as ONE launch at the end of the backward pass.
+#pragma once
+#include "common.h"
+
+namespace arvae {
+
+enum { SLAB_C32 = 0, SLAB_C1 = 1 };
+constexpr int SLAB_C32_FLOATS = 16 * 32 * 32 + 32;      // [ky][kx][clo][chi] + 32 bias sums
+constexpr int SLAB_C1_FLOATS = 32 * 16 + 32 + 1;        // [clo][tap] + 32 lo sums + 1 image sum
+constexpr int SLAB_BATCH_MAX = 8;
+
+struct SlabJob {
+    const float *slab;
+    float *dwt, *dbias;
+    int n_wg, kind, bias_mode;
+};
+struct SlabReduceBatch {
+    int count;
+    int block_end[SLAB_BATCH_MAX];      // running number of workgroups after job j
+    SlabJob job[SLAB_BATCH_MAX];
+};
+
+// run one job now / queue it / run everything queued
+int slab_reduce(const SlabJob &job, hipStream_t s);
+bool slab_reduce_defer(SlabReduceBatch *b, const SlabJob &job);
+int slab_reduce_flush(SlabReduceBatch *b, hipStream_t s);
+
+}  // namespace arvae

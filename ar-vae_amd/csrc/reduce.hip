@@ -1,0 +1,84 @@
+#include "reduce.h"
+
+namespace arvae {
+
+// 64 outputs x 4 slab groups per workgroup: a wave reads 256 contiguous bytes of one slab per load, and ~1500
+// workgroups keep enough loads in flight to stream the slabs at HBM speed
+constexpr int RED_OUT = 64, RED_Z = 4;
+
+__device__ __forceinline__ void slab_reduce_block(const SlabJob &j, int block, float (*red)[RED_OUT]) {
+    const int slab_floats = j.kind == SLAB_C32 ? SLAB_C32_FLOATS : SLAB_C1_FLOATS;
+    const int il = threadIdx.x & (RED_OUT - 1), zg = threadIdx.x / RED_OUT;
+    const int i = block * RED_OUT + il;
+    const int ic = i < slab_floats ? i : 0;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;                 // four independent chains, fixed association
+    int z = zg;
+    for (; z + 3 * RED_Z < j.n_wg; z += 4 * RED_Z) {
+        s0 += j.slab[(int64_t)z * slab_floats + ic];
+        s1 += j.slab[(int64_t)(z + RED_Z) * slab_floats + ic];
+        s2 += j.slab[(int64_t)(z + 2 * RED_Z) * slab_floats + ic];
+        s3 += j.slab[(int64_t)(z + 3 * RED_Z) * slab_floats + ic];
+    }
+    for (; z < j.n_wg; z += RED_Z) s0 += j.slab[(int64_t)z * slab_floats + ic];
+    red[zg][il] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (zg == 0 && i < slab_floats) {
+        const float tot = (red[0][il] + red[1][il]) + (red[2][il] + red[3][il]);
+        if (j.kind == SLAB_C32) {
+            if (i < 16 * 32 * 32) {
+                const int chi = i & 31, clo = (i >> 5) & 31, tap = i >> 10;
+                j.dwt[(clo * 32 + chi) * 16 + tap] += tot;      // dwt[clo][chi][ky][kx]
+            } else if (j.dbias != nullptr) {
+                j.dbias[i - 16 * 32 * 32] += tot;
+            }
+        } else {
+            if (i < 32 * 16) j.dwt[i] += tot;                    // wt[clo][0][ky][kx] is exactly [clo][tap]
+            else if (i < 32 * 16 + 32) { if (j.bias_mode == 1) j.dbias[i - 32 * 16] += tot; }
+            else if (j.bias_mode == 2) j.dbias[0] += tot;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_kernel(SlabJob j) {
+    __shared__ float red[RED_Z][RED_OUT];
+    slab_reduce_block(j, blockIdx.x, red);
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_batch_kernel(SlabReduceBatch b) {
+    __shared__ float red[RED_Z][RED_OUT];
+    int j = 0, start = 0;
+#pragma unroll
+    for (int q = 0; q + 1 < SLAB_BATCH_MAX; ++q)
+        if (q + 1 < b.count && (int)blockIdx.x >= b.block_end[q]) { j = q + 1; start = b.block_end[q]; }
+    switch (j) {                         // constant indices into the by-value argument block
+#define ARVAE_JOB(J) case J: slab_reduce_block(b.job[J], blockIdx.x - start, red); break;
+        ARVAE_JOB(0) ARVAE_JOB(1) ARVAE_JOB(2) ARVAE_JOB(3) ARVAE_JOB(4) ARVAE_JOB(5) ARVAE_JOB(6) ARVAE_JOB(7)
+#undef ARVAE_JOB
+        default: break;
+    }
+}
+
+static int job_blocks(const SlabJob &j) {
+    return ((j.kind == SLAB_C32 ? SLAB_C32_FLOATS : SLAB_C1_FLOATS) + RED_OUT - 1) / RED_OUT;
+}
+
+int slab_reduce(const SlabJob &job, hipStream_t s) {
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(job_blocks(job)), dim3(256), 0, s, job);
+    return check_launch(job.kind == SLAB_C32 ? "wgrad32_reduce_kernel" : "wgrad_c1_reduce_kernel");
+}
+
+bool slab_reduce_defer(SlabReduceBatch *b, const SlabJob &job) {
+    if (b->count >= SLAB_BATCH_MAX) return false;
+    b->block_end[b->count] = (b->count > 0 ? b->block_end[b->count - 1] : 0) + job_blocks(job);
+    b->job[b->count++] = job;
+    return true;
+}
+
+int slab_reduce_flush(SlabReduceBatch *b, hipStream_t s) {
+    if (b->count == 0) return ARVAE_OK;
+    hipLaunchKernelGGL(slab_reduce_batch_kernel, dim3(b->block_end[b->count - 1]), dim3(256), 0, s, *b);
+    b->count = 0;
+    return check_launch("slab_reduce_batch_kernel");
+}
+
+}  // namespace arvae
