@@ -83,6 +83,10 @@ struct Operand {
 };
 static inline Operand make_operand(const arvae_operand_t *o) { return Operand{o->v, o->y, o->mask, o->act}; }
 
+// relu_bits16: sign bits of a 32-channel ReLU output, the compact form of a "gate" for the data-gradient kernels.
+// One uint16 per (pixel, half), index pixel * 2 + half; bit 4g + j <-> channel 8g + 4*half + j, i.e. exactly the 16
+// channels a lane (pixel, half) of the 32x32x2 MFMA holds when the weight is the A operand (conv32.hip, conv_c1.hip).
+
 // one pixel of the image reconstruction term (image_vae_trainer.py:623-655): loss and correct-count accumulate,
 // dl = d loss / d logit (already divided by the batch size)
 // Hardware exp2/log2/rcp based (about 1e-7 relative, ~25 instructions instead of ~120 with the libm versions, which

@@ -70,9 +70,13 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&
     }
 }
 
+// epilogue modes (one template parameter: a ReLU layer is never gated and vice versa)
+enum { EP_PLAIN = 0, EP_RELU = 1, EP_GATE_F = 2, EP_GATE_B = 3 };
 struct Ep32 {
-    const float *bias;   // per output channel or null
-    const float *gate;   // null, or saved activation of the OUTPUT location: result *= (gate > 0)
+    const float *bias;          // per output channel or null
+    const float *gate;          // EP_GATE_F: saved activation of the OUTPUT location: result *= (gate > 0)
+    const uint16_t *gate_bits;  // EP_GATE_B: the same as sign bits (common.h: relu_bits16)
+    uint16_t *bits_out;         // EP_RELU: sign bits of the result for a later gated kernel, may be null
     float *out;
 };
 
@@ -88,6 +92,15 @@ __device__ __forceinline__ void buf_store4(float4 v, __amdgpu_buffer_rsrc_t r, u
     q.x = v.x; q.y = v.y; q.z = v.z; q.w = v.w;
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4v, q), r, (int)off, 0, 0);
 }
+
+__device__ __forceinline__ unsigned buf_load_u16(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, (int)off, 0, 0);
+}
+__device__ __forceinline__ void buf_store_u16(unsigned v, __amdgpu_buffer_rsrc_t r, unsigned off) {
+    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, r, (int)off, 0, 0);
+}
+// byte offset of a lane's (pixel, half) entry in a relu_bits16 array, from its byte offset pixel*128 + half*16
+__device__ __forceinline__ unsigned bits_off(unsigned out_off, int half) { return (out_off >> 7) * 4 + half * 2; }
 
 // ------------------------------------------------------------------------------------------------
 // Register-staged patch loader for a [n_img, SZ, SZ, 32] fp32 tensor.
@@ -196,39 +209,45 @@ __device__ unsigned long long g_stamps[512 * 64 * 2];
     ACC = __builtin_amdgcn_mfma_f32_32x32x2f32((W)[2], (A).z, ACC, 0, 0, 0);            \
     ACC = __builtin_amdgcn_mfma_f32_32x32x2f32((W)[3], (A).w, ACC, 0, 0, 0);
 
-// bias -> ReLU -> gate on the four channel groups of one pixel, then 4 x 16-byte stores at byte offset off + g*32
-template <bool RELU, bool GATE>
+// one channel group g (4 channels) of one pixel: bias -> ReLU / gate -> one 16-byte store at off + g*32;
+// returns the group's four sign bits (for EP_RELU's bits_out)
+template <int MODE>
+__device__ __forceinline__ unsigned store_group(const f32x16 &acc, int g, const float4 &b, const float4 &gv, unsigned gbits,
+                                                __amdgpu_buffer_rsrc_t rs_out, unsigned off) {
+    float v[4] = {acc[4 * g] + b.x, acc[4 * g + 1] + b.y, acc[4 * g + 2] + b.z, acc[4 * g + 3] + b.w};
+    const float gf[4] = {gv.x, gv.y, gv.z, gv.w};
+    unsigned bits = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (MODE == EP_RELU) {
+            v[j] = fmaxf(v[j], 0.f);
+            bits |= (v[j] > 0.f ? 1u : 0u) << (4 * g + j);
+        }
+        if (MODE == EP_GATE_F) v[j] = gf[j] > 0.f ? v[j] : 0.f;
+        if (MODE == EP_GATE_B) v[j] = ((gbits >> (4 * g + j)) & 1u) ? v[j] : 0.f;
+    }
+    buf_store4(make_float4(v[0], v[1], v[2], v[3]), rs_out, off + g * 32);
+    return bits;
+}
+
+// all four groups of one pixel, gate fetched here (the non-pipelined epilogues)
+template <int MODE>
 __device__ __forceinline__ void store_pixel(const f32x16 &acc, const float4 (&b4)[4], __amdgpu_buffer_rsrc_t rs_out,
-                                            __amdgpu_buffer_rsrc_t rs_gate, unsigned off) {
+                                            __amdgpu_buffer_rsrc_t rs_gate, __amdgpu_buffer_rsrc_t rs_bits, bool want_bits,
+                                            unsigned off, int half) {
     float4 gv[4];
-    if (GATE) {
+    unsigned gb = 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) gv[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (MODE == EP_GATE_F) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) gv[g] = buf_load4(rs_gate, off + g * 32);
     }
+    if (MODE == EP_GATE_B) gb = buf_load_u16(rs_bits, bits_off(off, half));
+    unsigned bits = 0;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        float4 v = make_float4(acc[4 * g] + b4[g].x, acc[4 * g + 1] + b4[g].y, acc[4 * g + 2] + b4[g].z,
-                               acc[4 * g + 3] + b4[g].w);
-        if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        if (GATE) {
-            v.x = gv[g].x > 0.f ? v.x : 0.f; v.y = gv[g].y > 0.f ? v.y : 0.f;
-            v.z = gv[g].z > 0.f ? v.z : 0.f; v.w = gv[g].w > 0.f ? v.w : 0.f;
-        }
-        buf_store4(v, rs_out, off + g * 32);
-    }
-}
-
-// one channel group g (4 channels) of one pixel: bias -> ReLU -> gate -> one 16-byte store
-template <bool RELU, bool GATE>
-__device__ __forceinline__ void store_group(const f32x16 &acc, int g, const float4 &b, const float4 &gv,
-                                            __amdgpu_buffer_rsrc_t rs_out, unsigned off) {
-    float4 v = make_float4(acc[4 * g] + b.x, acc[4 * g + 1] + b.y, acc[4 * g + 2] + b.z, acc[4 * g + 3] + b.w);
-    if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    if (GATE) {
-        v.x = gv.x > 0.f ? v.x : 0.f; v.y = gv.y > 0.f ? v.y : 0.f;
-        v.z = gv.z > 0.f ? v.z : 0.f; v.w = gv.w > 0.f ? v.w : 0.f;
-    }
-    buf_store4(v, rs_out, off + g * 32);
+    for (int g = 0; g < 4; ++g) bits |= store_group<MODE>(acc, g, b4[g], gv[g], gb, rs_out, off);
+    if (MODE == EP_RELU && want_bits) buf_store_u16(bits, rs_bits, bits_off(off, half));
 }
 
 __device__ __forceinline__ void load_bias4(const float *bias, int half, float4 (&b4)[4]) {
@@ -252,7 +271,7 @@ constexpr int WSTAGE_UP = C32 * C32 * WROW_UP;
 // Down: lo[n,ly,lx,clo] = ep( sum_{ky,kx,chi} hi[n,2ly-1+ky,2lx-1+kx,chi] * wt[clo][chi][ky][kx] )
 // wave w owns lo pixels [32w, 32w+32) of the tile over the full K = 512.
 // ================================================================================================
-template <int LO, bool RELU, bool GATE>
+template <int LO, int MODE>
 __global__ __launch_bounds__(256, 1) void down32_kernel(const float *__restrict__ hi, const float *__restrict__ wt, Ep32 ep, int n_img,
                                                          int n_tiles) {
     using PL = PatchLoader<LO, 2>;
@@ -298,7 +317,11 @@ __global__ __launch_bounds__(256, 1) void down32_kernel(const float *__restrict_
     load_bias4(ep.bias, half, b4);
     const int64_t out_bytes = (int64_t)n_img * LO * LO * PIXB;
     const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(ep.out, out_bytes);
-    const __amdgpu_buffer_rsrc_t rs_gate = make_rsrc(GATE ? ep.gate : ep.out, out_bytes);
+    const __amdgpu_buffer_rsrc_t rs_gate = make_rsrc(MODE == EP_GATE_F ? ep.gate : ep.out, out_bytes);
+    const bool want_bits = MODE == EP_RELU && ep.bits_out != nullptr;
+    const __amdgpu_buffer_rsrc_t rs_bits =
+        make_rsrc(MODE == EP_GATE_B ? (const void *)ep.gate_bits : want_bits ? (const void *)ep.bits_out : (const void *)ep.out,
+                  (int64_t)n_img * LO * LO * 4);
     const unsigned out_lane = (unsigned)((wave * 32 + rc) * PIXB + half * 16);      // + tile start + g*32
 
     STAMP(1);
@@ -348,7 +371,7 @@ __global__ __launch_bounds__(256, 1) void down32_kernel(const float *__restrict_
         for (int i = 0; i < 16; ++i) acc[i] += acc1[i];
         STAMP(sidx + 4);
 
-        store_pixel<RELU, GATE>(acc, b4, rs_out, rs_gate, out_lane + (unsigned)(((img0 * LO + r0) * LO) * PIXB));
+        store_pixel<MODE>(acc, b4, rs_out, rs_gate, rs_bits, want_bits, out_lane + (unsigned)(((img0 * LO + r0) * LO) * PIXB), half);
         STAMP(sidx + 5);
         sidx += 6;
     }
@@ -365,7 +388,7 @@ __global__ __launch_bounds__(256, 1) void down32_kernel(const float *__restrict_
 // matrix pipes for ~4K clocks.  The stores of tile t are therefore issued between the MFMAs of tile t+1, one
 // 16-byte store per wave and 16-MFMA step, each wave in its own quarter of the step: the drain then hides
 // behind the wave's previous MFMA.  Gate values are fetched one tile ahead into registers.
-template <int LO, bool RELU, bool GATE>
+template <int LO, int MODE>
 __global__ __launch_bounds__(256, 1) void up32_kernel(const float *__restrict__ lo, const float *__restrict__ wt, Ep32 ep, int n_img,
                                                        int n_tiles) {
     using PL = PatchLoader<LO, 1>;
@@ -421,12 +444,17 @@ __global__ __launch_bounds__(256, 1) void up32_kernel(const float *__restrict__ 
     load_bias4(ep.bias, half, b4);
     const int64_t out_bytes = (int64_t)n_img * HI * HI * PIXB;
     const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(ep.out, out_bytes);
-    const __amdgpu_buffer_rsrc_t rs_gate = make_rsrc(GATE ? ep.gate : ep.out, out_bytes);
+    const __amdgpu_buffer_rsrc_t rs_gate = make_rsrc(MODE == EP_GATE_F ? ep.gate : ep.out, out_bytes);
+    const bool want_bits = MODE == EP_RELU && ep.bits_out != nullptr;
+    const __amdgpu_buffer_rsrc_t rs_bits =
+        make_rsrc(MODE == EP_GATE_B ? (const void *)ep.gate_bits : want_bits ? (const void *)ep.bits_out : (const void *)ep.out,
+                  (int64_t)n_img * HI * HI * 4);
 
     STAMP(1);
     float4 dummy;
     f32x16 prev[4];                                              // previous tile's accumulators, stored during this tile
-    float4 gq[16];                                               // its gate values (loaded while it was computed)
+    float4 gq[16];                                               // its gate values (loaded while it was computed), or
+    unsigned gqb[4] = {0, 0, 0, 0}, pbits[4] = {0, 0, 0, 0};     // its gate bits per 32-pixel tile / the sign bits being collected
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -470,8 +498,14 @@ __global__ __launch_bounds__(256, 1) void up32_kernel(const float *__restrict__ 
             static_for<0, 4>([&](auto mc) __attribute__((always_inline)) {
                 constexpr int mt = decltype(mc)::value;
                 if (wave == mt) {                                // this wave's quarter of the step
-                    store_group<RELU, GATE>(prev[step >> 2], step & 3, b4[step & 3], gq[step], rs_out, prev_base + orel[step >> 2]);
-                    if (GATE) gq[step] = buf_load4(rs_gate, obase + orel[step >> 2] + (step & 3) * 32);
+                    constexpr int em = step >> 2, eg = step & 3; // previous tile: 32-pixel tile em, channel group eg
+                    const unsigned poff = prev_base + orel[em];
+                    if (eg == 0) pbits[em] = 0;
+                    pbits[em] |= store_group<MODE>(prev[em], eg, b4[eg], gq[step], gqb[em], rs_out, poff);
+                    if (MODE == EP_RELU && eg == 3 && want_bits)
+                        buf_store_u16(pbits[em], rs_bits, prev_base == OOB ? OOB : bits_off(poff, half));
+                    if (MODE == EP_GATE_F) gq[step] = buf_load4(rs_gate, obase + orel[em] + eg * 32);
+                    if (MODE == EP_GATE_B && eg == 3) gqb[em] = buf_load_u16(rs_bits, bits_off(obase + orel[em], half));
                 }
                 MFMA4(acc[mt], a[mt], w[ty][tx][ch])
             });
@@ -486,10 +520,13 @@ __global__ __launch_bounds__(256, 1) void up32_kernel(const float *__restrict__ 
     }
     // the last tile's epilogue has nothing to hide behind
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < 4; ++mt) {
+        const unsigned poff = prev_base + orel[mt];
+        unsigned bits = 0;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            store_group<RELU, GATE>(prev[mt], g, b4[g], gq[mt * 4 + g], rs_out, prev_base + orel[mt]);
+        for (int g = 0; g < 4; ++g) bits |= store_group<MODE>(prev[mt], g, b4[g], gq[mt * 4 + g], gqb[mt], rs_out, poff);
+        if (MODE == EP_RELU && want_bits) buf_store_u16(bits, rs_bits, prev_base == OOB ? OOB : bits_off(poff, half));
+    }
     STAMP_WAIT();
     STAMP(63);
 }
@@ -646,34 +683,41 @@ template <class K> static void allow_lds(K kernel, int bytes) {
 
 template <int A, int B> struct MaxOf { static constexpr int value = A > B ? A : B; };
 
-template <int LO, bool RELU, bool GATE>
+template <int LO, int MODE>
 static void launch_down_v(int grid, const Operand &hi, const float *wt, const Ep32 &ep, int n, int tiles, hipStream_t s) {
     constexpr int LDS = MaxOf<PatchLoader<LO, 2>::PATCH_FLOATS, WSTAGE_DOWN>::value * 4;
     static bool attr = false;
-    if (!attr) { allow_lds(down32_kernel<LO, RELU, GATE>, LDS); attr = true; }
-    hipLaunchKernelGGL((down32_kernel<LO, RELU, GATE>), dim3(grid), dim3(256), LDS, s, hi.v, wt, ep, n, tiles);
+    if (!attr) { allow_lds(down32_kernel<LO, MODE>, LDS); attr = true; }
+    hipLaunchKernelGGL((down32_kernel<LO, MODE>), dim3(grid), dim3(256), LDS, s, hi.v, wt, ep, n, tiles);
 }
-template <int LO, bool RELU, bool GATE>
+template <int LO, int MODE>
 static void launch_up_v(int grid, const Operand &lo, const float *wt, const Ep32 &ep, int n, int tiles, hipStream_t s) {
     constexpr int LDS = MaxOf<PatchLoader<LO, 1>::PATCH_FLOATS, WSTAGE_UP>::value * 4;
     static bool attr = false;
-    if (!attr) { allow_lds(up32_kernel<LO, RELU, GATE>, LDS); attr = true; }
-    hipLaunchKernelGGL((up32_kernel<LO, RELU, GATE>), dim3(grid), dim3(256), LDS, s, lo.v, wt, ep, n, tiles);
+    if (!attr) { allow_lds(up32_kernel<LO, MODE>, LDS); attr = true; }
+    hipLaunchKernelGGL((up32_kernel<LO, MODE>), dim3(grid), dim3(256), LDS, s, lo.v, wt, ep, n, tiles);
+}
+
+static int ep_mode(const Ep32 &ep, int relu) {
+    return ep.gate_bits != nullptr ? EP_GATE_B : ep.gate != nullptr ? EP_GATE_F : relu ? EP_RELU : EP_PLAIN;
 }
 
 template <int LO> static int launch_down(const arvae_link_t *l, const Operand &hi, const float *wt, const Ep32 &ep, int relu, hipStream_t s) {
     const int tiles = tiles_for<LO>(l->n), grid = grid_for_tiles(tiles);
-    const bool gate = ep.gate != nullptr;
-    if (relu && gate) launch_down_v<LO, true, true>(grid, hi, wt, ep, l->n, tiles, s);
-    else if (relu) launch_down_v<LO, true, false>(grid, hi, wt, ep, l->n, tiles, s);
-    else if (gate) launch_down_v<LO, false, true>(grid, hi, wt, ep, l->n, tiles, s);
-    else launch_down_v<LO, false, false>(grid, hi, wt, ep, l->n, tiles, s);
+    switch (ep_mode(ep, relu)) {
+        case EP_GATE_B: launch_down_v<LO, EP_GATE_B>(grid, hi, wt, ep, l->n, tiles, s); break;
+        case EP_GATE_F: launch_down_v<LO, EP_GATE_F>(grid, hi, wt, ep, l->n, tiles, s); break;
+        case EP_RELU: launch_down_v<LO, EP_RELU>(grid, hi, wt, ep, l->n, tiles, s); break;
+        default: launch_down_v<LO, EP_PLAIN>(grid, hi, wt, ep, l->n, tiles, s); break;
+    }
     return check_launch(LO == 16 ? "down32_kernel<16>" : LO == 8 ? "down32_kernel<8>" : "down32_kernel<4>");
 }
 
+// gate (float activation) or gate_bits (relu_bits16) select a gated epilogue; with relu, bits_out (may be null) receives
+// the sign bits of the result
 int conv32_down(const arvae_link_t *l, const Operand &hi, const float *wt, const float *bias, int relu, const float *gate,
-                float *out, hipStream_t s) {
-    Ep32 ep{bias, gate, out};
+                const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s) {
+    Ep32 ep{bias, gate, gate_bits, bits_out, out};
     switch (l->lh) {
         case 16: return launch_down<16>(l, hi, wt, ep, relu, s);
         case 8: return launch_down<8>(l, hi, wt, ep, relu, s);
@@ -683,17 +727,18 @@ int conv32_down(const arvae_link_t *l, const Operand &hi, const float *wt, const
 
 template <int LO> static int launch_up(const arvae_link_t *l, const Operand &lo, const float *wt, const Ep32 &ep, int relu, hipStream_t s) {
     const int tiles = tiles_for<LO>(l->n), grid = grid_for_tiles(tiles);
-    const bool gate = ep.gate != nullptr;
-    if (relu && gate) launch_up_v<LO, true, true>(grid, lo, wt, ep, l->n, tiles, s);
-    else if (relu) launch_up_v<LO, true, false>(grid, lo, wt, ep, l->n, tiles, s);
-    else if (gate) launch_up_v<LO, false, true>(grid, lo, wt, ep, l->n, tiles, s);
-    else launch_up_v<LO, false, false>(grid, lo, wt, ep, l->n, tiles, s);
+    switch (ep_mode(ep, relu)) {
+        case EP_GATE_B: launch_up_v<LO, EP_GATE_B>(grid, lo, wt, ep, l->n, tiles, s); break;
+        case EP_GATE_F: launch_up_v<LO, EP_GATE_F>(grid, lo, wt, ep, l->n, tiles, s); break;
+        case EP_RELU: launch_up_v<LO, EP_RELU>(grid, lo, wt, ep, l->n, tiles, s); break;
+        default: launch_up_v<LO, EP_PLAIN>(grid, lo, wt, ep, l->n, tiles, s); break;
+    }
     return check_launch(LO == 16 ? "up32_kernel<16>" : LO == 8 ? "up32_kernel<8>" : "up32_kernel<4>");
 }
 
 int conv32_up(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, int relu, const float *gate,
-              float *out, hipStream_t s) {
-    Ep32 ep{bias, gate, out};
+              const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s) {
+    Ep32 ep{bias, gate, gate_bits, bits_out, out};
     switch (l->lh) {
         case 16: return launch_up<16>(l, lo, wt, ep, relu, s);
         case 8: return launch_up<8>(l, lo, wt, ep, relu, s);

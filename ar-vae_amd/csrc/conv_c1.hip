@@ -22,42 +22,81 @@ constexpr int PS1 = 36;                     // LDS pixel stride (floats) of 32-c
 
 struct Ep1 {
     const float *bias;
-    const float *gate;
+    const float *gate;          // saved activation of the output location (float), or
+    const uint16_t *gate_bits;  // its sign bits (common.h: relu_bits16), or neither
+    uint16_t *bits_out;         // with relu: sign bits of the result for a later gated kernel, may be null
     float *out;
     int relu;
 };
 
-// image rows [2*r0-1, 2*r0-1+IPR) x cols [-1, 65) of image n -> LDS; returns the sum of the pixels this
-// tile owns (rows 1..16, cols 1..64 of the patch) for the transposed-conv bias gradient
-__device__ __forceinline__ float load_img_patch(float *patch, const Operand &img, int n, int r0) {
-    float own = 0.f;
-    const float gs = img.scale != nullptr ? img.scale[0] : 1.f;
-    for (int idx = threadIdx.x; idx < IPR * 66; idx += 256) {
-        const int pr = idx / 66, pc = idx - pr * 66;
-        const int gy = 2 * r0 - 1 + pr, gx = pc - 1;
-        float v = 0.f;
-        if ((unsigned)gy < (unsigned)HI1 && (unsigned)gx < (unsigned)HI1) {
-            v = gs * img.at(((int64_t)n * HI1 + gy) * HI1 + gx);
-            if (pr >= 1 && pr <= 2 * TR1) own += v;
+// image rows [2*r0-1, 2*r0-1+IPR) x cols [-1, 65) of image n, register-staged: issue() loads, commit() writes the
+// LDS patch and returns the sum of the pixels this tile owns (rows 1..16, cols 1..64 of the patch) for the
+// transposed-conv bias gradient
+constexpr int IMG_SLOTS = (IPR * 66 + 255) / 256;
+struct ImgPatch {
+    float r[IMG_SLOTS];
+    __device__ __forceinline__ void issue(const Operand &img, float gs, int tile, int n_tiles) {
+        const int n = tile / (LO1 / TR1), r0 = (tile % (LO1 / TR1)) * TR1;
+#pragma unroll
+        for (int it = 0; it < IMG_SLOTS; ++it) {
+            const int idx = threadIdx.x + it * 256;
+            const int pr = idx / 66, pc = idx - pr * 66;
+            const int gy = 2 * r0 - 1 + pr, gx = pc - 1;
+            const bool ok = tile < n_tiles && idx < IPR * 66 && (unsigned)gy < (unsigned)HI1 && (unsigned)gx < (unsigned)HI1;
+            const float v = img.at(ok ? ((int64_t)n * HI1 + gy) * HI1 + gx : 0);       // unconditional load, clamped index
+            r[it] = ok ? gs * v : 0.f;
         }
-        patch[pr * IPC + pc] = v;
     }
-    return own;
-}
+    __device__ __forceinline__ float commit(float *patch) const {
+        float own = 0.f;
+#pragma unroll
+        for (int it = 0; it < IMG_SLOTS; ++it) {
+            const int idx = threadIdx.x + it * 256;
+            if (idx < IPR * 66) {
+                const int pr = idx / 66, pc = idx - pr * 66;
+                patch[pr * IPC + pc] = r[it];
+                if (pr >= 1 && pr <= 2 * TR1 && pc >= 1 && pc <= HI1) own += r[it];
+            }
+        }
+        return own;
+    }
+};
 
 // ================================================================================================
+// down_c1: the weight is the MFMA's A operand (row = channel) and the image value its B operand (column = lo pixel),
+// so a lane ends up with 4 x 4 consecutive channels of ONE pixel: four 16-byte stores per 32 pixels, and the ReLU
+// sign bits of a pixel-half fit one uint16 (relu_bits16).
 __global__ __launch_bounds__(256) void down_c1_kernel(Operand img, const float *__restrict__ wt, Ep1 ep, int n_tiles) {
     __shared__ float patch[IPR * IPC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, rc = lane & 31;
     float w8[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) w8[s] = wt[rc * 16 + 2 * s + half];
-    const float bias = ep.bias != nullptr ? ep.bias[rc] : 0.f;
+    float4 b4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        b4[g] = ep.bias != nullptr ? *reinterpret_cast<const float4 *>(ep.bias + 8 * g + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float gs = img.scale != nullptr ? img.scale[0] : 1.f;
+    ImgPatch ip;
+    ip.issue(img, gs, blockIdx.x, n_tiles);
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int n = tile / (LO1 / TR1), r0 = (tile % (LO1 / TR1)) * TR1;
         __syncthreads();
-        load_img_patch(patch, img, n, r0);
+        ip.commit(patch);
         __syncthreads();
+        ip.issue(img, gs, tile + gridDim.x, n_tiles);          // next tile's image rows fly during this tile's work
+        // gate values of both 32-pixel rows first (one round of memory latency)
+        float4 gv[2][4];
+        unsigned gb[2] = {0xffffu, 0xffffu};
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int pix = ((n * LO1) + r0 + 2 * wave + mt) * LO1 + rc;
+            if (ep.gate_bits != nullptr) gb[mt] = ep.gate_bits[pix * 2 + half];
+            else if (ep.gate != nullptr) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) gv[mt][g] = *reinterpret_cast<const float4 *>(ep.gate + (int64_t)pix * CC + 8 * g + 4 * half);
+            }
+        }
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const int r = 2 * wave + mt;              // lo row inside the tile; lane rc = lo column
@@ -67,26 +106,24 @@ __global__ __launch_bounds__(256) void down_c1_kernel(Operand img, const float *
 #pragma unroll
             for (int s = 0; s < 8; ++s) {             // k = 2s + half -> (ky, kx) = (s >> 1, 2 (s & 1) + half)
                 const float a = patch[(2 * r + (s >> 1)) * IPC + 2 * rc + 2 * (s & 1) + half];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w8[s], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w8[s], a, acc, 0, 0, 0);
             }
-            float gv[16];
+            const int pix = ((n * LO1) + r0 + r) * LO1 + rc;
+            unsigned bits = 0;
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) gv[reg] = 1.f;
-            if (ep.gate != nullptr) {
+            for (int g = 0; g < 4; ++g) {
+                float v[4] = {acc[4 * g] + b4[g].x, acc[4 * g + 1] + b4[g].y, acc[4 * g + 2] + b4[g].z, acc[4 * g + 3] + b4[g].w};
+                const float gf[4] = {gv[mt][g].x, gv[mt][g].y, gv[mt][g].z, gv[mt][g].w};
 #pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int ox = (reg & 3) + 8 * (reg >> 2) + 4 * half;
-                    gv[reg] = ep.gate[(((n * LO1) + r0 + r) * LO1 + ox) * CC + rc];
+                for (int j = 0; j < 4; ++j) {
+                    if (ep.relu) v[j] = fmaxf(v[j], 0.f);
+                    if (ep.gate_bits != nullptr) v[j] = ((gb[mt] >> (4 * g + j)) & 1u) ? v[j] : 0.f;
+                    else if (ep.gate != nullptr) v[j] = gf[j] > 0.f ? v[j] : 0.f;
+                    bits |= (v[j] > 0.f ? 1u : 0u) << (4 * g + j);
                 }
+                *reinterpret_cast<float4 *>(ep.out + (int64_t)pix * CC + 8 * g + 4 * half) = make_float4(v[0], v[1], v[2], v[3]);
             }
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int ox = (reg & 3) + 8 * (reg >> 2) + 4 * half;
-                const int idx = (((n * LO1) + r0 + r) * LO1 + ox) * CC + rc;
-                float v = acc[reg] + bias;
-                if (ep.relu) v = fmaxf(v, 0.f);
-                ep.out[idx] = gv[reg] > 0.f ? v : 0.f;
-            }
+            if (ep.bits_out != nullptr) ep.bits_out[pix * 2 + half] = (uint16_t)bits;
         }
     }
 }
@@ -309,10 +346,10 @@ bool conv_c1_fits(const arvae_link_t *l) {
 }
 
 int conv_c1_down(const arvae_link_t *l, const Operand &img, const float *wt, const float *bias, int relu,
-                 const float *gate, float *out, hipStream_t s) {
+                 const float *gate, const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s) {
     const int tiles = l->n * (LO1 / TR1);
-    Ep1 ep{bias, gate, out, relu};
-    hipLaunchKernelGGL(down_c1_kernel, dim3(tiles < 2048 ? tiles : 2048), dim3(256), 0, s, img, wt, ep, tiles);
+    Ep1 ep{bias, gate, gate_bits, bits_out, out, relu};
+    hipLaunchKernelGGL(down_c1_kernel, dim3(tiles < 1024 ? tiles : 1024), dim3(256), 0, s, img, wt, ep, tiles);
     return check_launch("down_c1_kernel");
 }
 

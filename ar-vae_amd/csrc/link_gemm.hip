@@ -29,7 +29,7 @@ int dense_wgrad(const arvae_link_t *l, const Operand &g, const float *x, float *
 // 1-channel 64x64 image links (conv_c1.hip)
 bool conv_c1_fits(const arvae_link_t *l);
 int conv_c1_down(const arvae_link_t *l, const Operand &img, const float *wt, const float *bias, int relu,
-                 const float *gate, float *out, hipStream_t s);
+                 const float *gate, const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s);
 int conv_c1_up(const arvae_link_t *l, const float *lo, const float *wt, const float *bias, float *out, hipStream_t s);
 int64_t conv_c1_wgrad_ws_floats(const arvae_link_t *l);
 int conv_c1_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &img, float *dwt, float *dbias, int bias_mode,
@@ -37,10 +37,10 @@ int conv_c1_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &img, 
 
 // specialised 32-channel k4/s2/p1 kernels (conv32.hip)
 bool conv32_fits(const arvae_link_t *l);
-int conv32_down(const arvae_link_t *l, const Operand &hi, const float *wt, const float *bias, int relu,
-                const float *gate, float *out, hipStream_t s);
-int conv32_up(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, int relu,
-              const float *gate, float *out, hipStream_t s);
+int conv32_down(const arvae_link_t *l, const Operand &hi, const float *wt, const float *bias, int relu, const float *gate,
+                const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s);
+int conv32_up(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, int relu, const float *gate,
+              const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s);
 int64_t conv32_wgrad_ws_floats(const arvae_link_t *l);
 int conv32_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *dwt, float *dbias, int bias_mode,
                  float *slab, hipStream_t s);
@@ -536,10 +536,10 @@ extern "C" int arvae_link_down(const arvae_link_t *link, const arvae_operand_t *
     if (dense_fits(link) && out_mask == nullptr && hi->y == nullptr)
         return dense_fwd(link, hi->v, wt, bias, out_act, lo, as_stream(stream));
     if (conv32_fits(link) && out_mask == nullptr && hi->y == nullptr && out_act != ARVAE_ACT_SELU)
-        return conv32_down(link, make_operand(hi), wt, bias, out_act == ARVAE_ACT_RELU, nullptr, lo, as_stream(stream));
+        return conv32_down(link, make_operand(hi), wt, bias, out_act == ARVAE_ACT_RELU, nullptr, nullptr, nullptr, lo, as_stream(stream));
     if (conv_c1_fits(link) && out_mask == nullptr && hi->mask == nullptr && out_act != ARVAE_ACT_SELU &&
         hi->act != ARVAE_ACT_SELU)
-        return conv_c1_down(link, make_operand(hi), wt, bias, out_act == ARVAE_ACT_RELU, nullptr, lo, as_stream(stream));
+        return conv_c1_down(link, make_operand(hi), wt, bias, out_act == ARVAE_ACT_RELU, nullptr, nullptr, nullptr, lo, as_stream(stream));
     p.hi = make_operand(hi);
     p.wt = wt;
     p.ep = Epilogue{bias, out_mask, lo, out_act};
@@ -568,10 +568,10 @@ extern "C" int arvae_link_up(const arvae_link_t *link, const arvae_operand_t *lo
         static const float *stamp_gate = nullptr;                // diagnostic build: time the gated variant too
         if (getenv("ARVAE_STAMP_GATE") != nullptr) {
             if (stamp_gate == nullptr) (void)hipMalloc((void **)&stamp_gate, (size_t)link->n * link->hh * link->hw * link->chi * 4);
-            return conv32_up(link, make_operand(lo), wt, nullptr, 0, stamp_gate, hi, st);
+            return conv32_up(link, make_operand(lo), wt, nullptr, 0, stamp_gate, nullptr, nullptr, hi, st);
         }
 #endif
-        return conv32_up(link, make_operand(lo), wt, bias, out_act == ARVAE_ACT_RELU, nullptr, hi, st);
+        return conv32_up(link, make_operand(lo), wt, bias, out_act == ARVAE_ACT_RELU, nullptr, nullptr, nullptr, hi, st);
     }
     if (conv_c1_fits(link) && lo->y == nullptr && out_mask == nullptr && out_act == ARVAE_ACT_NONE)
         return conv_c1_up(link, lo->v, wt, bias, hi, st);

@@ -10,10 +10,10 @@ namespace arvae {
 // fast kernels with a gated epilogue (conv32.hip / conv_c1.hip / dense.hip)
 bool conv32_fits(const arvae_link_t *l);
 bool conv_c1_fits(const arvae_link_t *l);
-int conv32_down(const arvae_link_t *l, const Operand &hi, const float *wt, const float *bias, int relu,
-                const float *gate, float *out, hipStream_t s);
-int conv32_up(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, int relu,
-              const float *gate, float *out, hipStream_t s);
+int conv32_down(const arvae_link_t *l, const Operand &hi, const float *wt, const float *bias, int relu, const float *gate,
+                const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s);
+int conv32_up(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, int relu, const float *gate,
+              const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s);
 int conv_c1_up_recon(const arvae_link_t *l, const float *lo, const float *wt, const float *bias, float *out, const float *x,
                      int dist, float *partial, float *dlogits, hipStream_t s, int *nb_out);
 int conv32_wgrad_partial(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *dwt, float *dbias, int bias_mode,
@@ -21,7 +21,7 @@ int conv32_wgrad_partial(const arvae_link_t *l, const Operand &lo, const Operand
 int conv_c1_wgrad_partial(const arvae_link_t *l, const Operand &lo, const Operand &img, float *dwt, float *dbias,
                           int bias_mode, float *slab, hipStream_t s, SlabJob *job);
 int conv_c1_down(const arvae_link_t *l, const Operand &img, const float *wt, const float *bias, int relu,
-                 const float *gate, float *out, hipStream_t s);
+                 const float *gate, const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s);
 
 // fused encoder heads + reparameterisation (heads.hip)
 bool heads_fusable(const arvae_layer_t *hm, const arvae_layer_t *hl, int zdim);
@@ -94,6 +94,9 @@ struct Layout {
     int64_t enc_keep[ARVAE_MAX_LAYERS], dec_keep[ARVAE_MAX_LAYERS];
     // conv layers with a slab kernel: their own slab, so that all the reductions can run as one launch at the end
     int64_t enc_slab[ARVAE_MAX_LAYERS], dec_slab[ARVAE_MAX_LAYERS];
+    // ReLU conv layers on the fast kernels also leave the sign bits of their output (relu_bits16, 4 bytes per pixel):
+    // the backward pass gates with those instead of re-reading the 128-byte-per-pixel activation
+    int64_t enc_bits[ARVAE_MAX_LAYERS], dec_bits[ARVAE_MAX_LAYERS];
     int64_t log_std, dlogits, dz_reg, d_mu, d_ls, g_a, g_b, slab, rec_ws, reg_ws, rec_out, kld_out, reg_out, total;
     int64_t slab_floats;
 };
@@ -125,6 +128,15 @@ static int make_layout(const arvae_image_vae_t *m, int64_t n, int64_t n_cols, La
         lk.n = (int32_t)n;
         return (conv32_fits(&lk) || conv_c1_fits(&lk)) ? take(arvae_link_wgrad_ws_floats(&lk)) : -1;
     };
+    auto own_bits = [&](const arvae_layer_t &l) -> int64_t {
+        arvae_link_t lk = l.link;
+        lk.n = (int32_t)n;
+        const bool fast = conv32_fits(&lk) || (conv_c1_fits(&lk) && !l.is_up);
+        static const bool off = getenv("ARVAE_NO_RELU_BITS") != nullptr;      // diagnostic: gate with the float activations
+        return (fast && !off && l.act == ARVAE_ACT_RELU && !l.dropout) ? take(out_elems(l, n) / 32) : -1;
+    };
+    for (int i = 0; i < m->n_enc; ++i) L.enc_bits[i] = own_bits(m->enc[i]);
+    for (int i = 0; i < m->n_dec; ++i) L.dec_bits[i] = own_bits(m->dec[i]);
     for (int i = 0; i < m->n_enc; ++i) L.enc_slab[i] = own_slab(m->enc[i]);
     for (int i = 0; i < m->n_dec; ++i) L.dec_slab[i] = own_slab(m->dec[i]);
     for (int i = 0; i < m->n_enc; ++i) L.enc_keep[i] = dense_fits(&m->enc[i].link) ? take(out_elems(m->enc[i], n)) : -1;
@@ -152,11 +164,18 @@ static int make_layout(const arvae_image_vae_t *m, int64_t n, int64_t n_cols, La
 static arvae_operand_t plain(const float *v) { return arvae_operand_t{v, nullptr, nullptr, ARVAE_ACT_NONE}; }
 
 static int layer_forward(const arvae_layer_t &l, int32_t n, const float *params, const float *in, const uint8_t *mask,
-                         float *out, arvae_stream_t st) {
+                         float *out, uint16_t *bits_out, arvae_stream_t st) {
     arvae_link_t lk = l.link;
     lk.n = n;
     const arvae_operand_t op = plain(in);
     const float *w = params + l.w_off, *b = l.b_off >= 0 ? params + l.b_off : nullptr;
+    if (bits_out != nullptr) {                           // make_layout grants bits only to ReLU layers on these kernels
+        hipStream_t hs = as_stream(st);
+        if (conv32_fits(&lk))
+            return l.is_up ? conv32_up(&lk, make_operand(&op), w, b, 1, nullptr, nullptr, bits_out, out, hs)
+                           : conv32_down(&lk, make_operand(&op), w, b, 1, nullptr, nullptr, bits_out, out, hs);
+        return conv_c1_down(&lk, make_operand(&op), w, b, 1, nullptr, nullptr, bits_out, out, hs);
+    }
     return l.is_up ? arvae_link_up(&lk, &op, w, b, l.act, mask, out, st) : arvae_link_down(&lk, &op, w, b, l.act, mask, out, st);
 }
 
@@ -169,7 +188,8 @@ static int layer_forward(const arvae_layer_t &l, int32_t n, const float *params,
 static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params, float *grads, const float *in,
                           const float *out, const uint8_t *mask, const float *g, bool g_is_pre, const float *gate,
                           float *d_in, bool *gated, float *slab, DenseWgradBatch *defer, float *own_slab,
-                          SlabReduceBatch *rdefer, arvae_stream_t st, const float *g_scale = nullptr) {
+                          SlabReduceBatch *rdefer, arvae_stream_t st, const float *g_scale = nullptr,
+                          const uint16_t *gate_bits = nullptr) {
     arvae_link_t lk = l.link;
     lk.n = n;
     const arvae_operand_t gop = g_is_pre ? plain(g) : arvae_operand_t{g, out, mask, l.act};
@@ -183,19 +203,19 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
         int rc;
         if (l.is_up) {                                   // forward UP  -> data gradient is a DOWN map
             if (gate != nullptr && gop.y == nullptr && conv32_fits(&lk)) {
-                rc = conv32_down(&lk, make_operand(&gop), w, nullptr, 0, gate, d_in, hs);
+                rc = conv32_down(&lk, make_operand(&gop), w, nullptr, 0, gate_bits ? nullptr : gate, gate_bits, nullptr, d_in, hs);
                 *gated = true;
             } else if (gate != nullptr && simple && conv_c1_fits(&lk)) {
                 Operand g_op = make_operand(&gop);
                 g_op.scale = g_scale;
-                rc = conv_c1_down(&lk, g_op, w, nullptr, 0, gate, d_in, hs);
+                rc = conv_c1_down(&lk, g_op, w, nullptr, 0, gate_bits ? nullptr : gate, gate_bits, nullptr, d_in, hs);
                 *gated = true;
             } else {
                 rc = arvae_link_down(&lk, &gop, w, nullptr, ARVAE_ACT_NONE, nullptr, d_in, st);
             }
         } else {                                         // forward DOWN -> data gradient is an UP map
             if (gate != nullptr && gop.y == nullptr && conv32_fits(&lk)) {
-                rc = conv32_up(&lk, make_operand(&gop), w, nullptr, 0, gate, d_in, hs);
+                rc = conv32_up(&lk, make_operand(&gop), w, nullptr, 0, gate_bits ? nullptr : gate, gate_bits, nullptr, d_in, hs);
                 *gated = true;
             } else if (gate != nullptr && dense_fits(&lk)) {
                 rc = dense_dgrad(&lk, make_operand(&gop), w, gate, d_in, hs);
@@ -258,7 +278,8 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
     for (int i = 0; i < m->n_enc; ++i) {
         const uint8_t *mask = (masks != nullptr && m->enc[i].dropout) ? masks[mi] : nullptr;
         mi += m->enc[i].dropout != 0;
-        if (int rc = layer_forward(m->enc[i], batch, params, h, mask, ws + L.enc_out[i], stream)) return rc;
+        uint16_t *bits = L.enc_bits[i] >= 0 ? reinterpret_cast<uint16_t *>(ws + L.enc_bits[i]) : nullptr;
+        if (int rc = layer_forward(m->enc[i], batch, params, h, mask, ws + L.enc_out[i], bits, stream)) return rc;
         h = ws + L.enc_out[i];
     }
     const int64_t bz = (int64_t)batch * m->zdim;
@@ -267,8 +288,8 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
                                       sigma, z, st))
             return rc;
     } else {
-        if (int rc = layer_forward(m->head_mu, batch, params, h, nullptr, mu, stream)) return rc;
-        if (int rc = layer_forward(m->head_log_std, batch, params, h, nullptr, ws + L.log_std, stream)) return rc;
+        if (int rc = layer_forward(m->head_mu, batch, params, h, nullptr, mu, nullptr, stream)) return rc;
+        if (int rc = layer_forward(m->head_log_std, batch, params, h, nullptr, ws + L.log_std, nullptr, stream)) return rc;
         if (int rc = arvae_latent_fwd(mu, ws + L.log_std, eps, bz, sigma, z, stream)) return rc;
     }
     // decoder
@@ -288,8 +309,9 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
             if (int rc = conv_c1_up_recon(&lk, h, params + l.w_off, l.b_off >= 0 ? params + l.b_off : nullptr, logits, x,
                                           m->recon_dist, ws + L.rec_ws, ws + L.dlogits, st, &nb))
                 return rc;
-        } else if (int rc = layer_forward(m->dec[i], batch, params, h, mask, out, stream)) {
-            return rc;
+        } else {
+            uint16_t *bits = L.dec_bits[i] >= 0 ? reinterpret_cast<uint16_t *>(ws + L.dec_bits[i]) : nullptr;
+            if (int rc = layer_forward(m->dec[i], batch, params, h, mask, out, bits, stream)) return rc;
         }
         h = out;
     }
@@ -379,7 +401,9 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
         bool gated = false;
         if (int rc = layer_backward(m->dec[i], batch, params, grads, in, out, mask_of(dec_mask[i]), cur, pre, gate, dst,
                                     &gated, slab, &defer, L.dec_slab[i] >= 0 ? ws + L.dec_slab[i] : nullptr, &rdefer, stream,
-                                    i == m->n_dec - 1 ? first_scale : nullptr))
+                                    i == m->n_dec - 1 ? first_scale : nullptr,
+                                    (gate != nullptr && i > 0 && L.dec_bits[i - 1] >= 0)
+                                        ? reinterpret_cast<const uint16_t *>(ws + L.dec_bits[i - 1]) : nullptr))
             return rc;
         pre = gated;
         cur = dst;
@@ -437,7 +461,9 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
         bool gated = false;
         if (int rc = layer_backward(m->enc[i], batch, params, grads, in, ws + L.enc_out[i], mask_of(enc_mask[i]), cur, pre,
                                     gate, dst, &gated, slab, &defer, L.enc_slab[i] >= 0 ? ws + L.enc_slab[i] : nullptr, &rdefer,
-                                    stream))
+                                    stream, nullptr,
+                                    (gate != nullptr && i > 0 && L.enc_bits[i - 1] >= 0)
+                                        ? reinterpret_cast<const uint16_t *>(ws + L.enc_bits[i - 1]) : nullptr))
             return rc;
         pre = gated;
         cur = dst;
