@@ -411,7 +411,13 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
     // latent head (cur = gradient w.r.t. z from the decoder) and the two encoder heads:
     // d_hidden = W_mu^T d_mu + W_ls^T d_ls   (gated by the last encoder layer's ReLU when possible)
     const float *hidden = ws + L.enc_out[m->n_enc - 1];
-    const float *dz_reg = (reg_fused && m->n_reg > 0) ? ws + L.dz_reg : nullptr;
+    // regulariser gradient w.r.t. z, unit upstream (scaled by g * reg_scale in the latent kernel): the forward's own
+    // (reg_fused 1), or the caller's row-block evaluation against gathered columns (reg_fused 2, in dz_extra)
+    const float *dz_reg = (reg_fused == 1 && m->n_reg > 0) ? ws + L.dz_reg : reg_fused == 2 ? dz_extra : nullptr;
+    if (reg_fused == 2) {
+        ARVAE_REQUIRE(dz_extra != nullptr, "image_vae_backward: reg_fused 2 needs the unit regulariser gradient in dz_extra");
+        dz_extra = nullptr;
+    }
     const float *head_gate = relu_gate(m->enc[m->n_enc - 1], enc_mask[m->n_enc - 1], hidden);
     float *d_hidden = grad_dst(L.enc_keep[m->n_enc - 1], nullptr);
     if (heads_fusable(&m->head_mu, &m->head_log_std, m->zdim)) {

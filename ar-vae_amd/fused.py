@@ -95,10 +95,14 @@ class FusedImageVAE:
             self._ws = {key: ws}                      # keep one (batch-sized) workspace alive
         return ws
 
-    def run(self, x, labels, eps, masks, capacity, external_reg=False, reg_scale=1.0):
-        """-> (loss[1] with grad_fn, scalars[8], acc, z, mu, sigma, logits); loss is scalars[LOSS:LOSS+1]."""
+    def run(self, x, labels, eps, masks, capacity, external_reg=False, reg_scale=1.0, dp=None):
+        """-> (loss[1] with grad_fn, scalars[8], acc, z, mu, sigma, logits); loss is scalars[LOSS:LOSS+1].
+
+        dp (arvae_amd.parallel.DataParallel): evaluate the regulariser on this rank's row block against the columns
+        gathered from every rank, inside the same autograd node (no torch ops on the hot path): the loss returned is
+        recon + beta|KL - c| + W * reg_rowblock and scalars[REG] = W * reg_rowblock."""
         anchor = self.optimizer.params[0]
-        return _FusedStepFn.apply(anchor, self, x, labels, eps, masks, capacity, bool(external_reg), float(reg_scale))
+        return _FusedStepFn.apply(anchor, self, x, labels, eps, masks, capacity, bool(external_reg), float(reg_scale), dp)
 
 
 def _mask_array(masks):
@@ -110,7 +114,7 @@ def _mask_array(masks):
 
 class _FusedStepFn(Function):
     @staticmethod
-    def forward(ctx, anchor, fused, x, labels, eps, masks, capacity, external_reg, reg_scale):
+    def forward(ctx, anchor, fused, x, labels, eps, masks, capacity, external_reg, reg_scale, dp=None):
         ops._dev(x, labels, eps, capacity)
         lib = _lib.load()
         desc = fused.descriptor()
@@ -124,12 +128,33 @@ class _FusedStepFn(Function):
         sigma, z = torch.empty_like(mu), torch.empty_like(mu)
         logits = torch.empty_like(x)
         marr, keep = _mask_array(masks)
+        rowblock = dp is not None and len(fused.reg_dims) > 0
+        if rowblock:                                             # the label columns do not depend on this pass: gather first
+            external_reg = True
+            labels = labels.contiguous()
+            lab_all = dp.gather_columns(labels)
         with ops._timed('image_vae_forward'):
             _lib.check(lib.arvae_image_vae_forward(
                 ctypes.byref(desc), b, ops._ptr(opt.param_arena), ops._ptr(x), ops._ptr(labels),
                 labels.shape[1] if labels is not None else 0, ops._ptr(eps), marr, ops._ptr(capacity), None, None,
                 -1 if external_reg else 0, reg_scale, ops._ptr(ws), ops._ptr(scalars), ops._ptr(mu), ops._ptr(sigma),
                 ops._ptr(z), ops._ptr(logits), ops._stream()), 'image_vae_forward')
+        ctx.dz_unit = None
+        if rowblock:
+            z_all = dp.gather_columns(z)
+            n, n_all, r = b, z_all.shape[0], len(fused.reg_dims)
+            ws_reg = torch.empty(int(lib.arvae_reg_loss_ws_floats(n, r)), device=dev, dtype=torch.float32)
+            reg_out = torch.empty(1, device=dev, dtype=torch.float32)
+            dz = torch.empty_like(z)
+            dims = (ctypes.c_int32 * r)(*fused.reg_dims)
+            with ops._timed('reg_loss(row block)'):
+                _lib.check(lib.arvae_reg_loss(ops._ptr(z), ops._ptr(labels), n, ops._ptr(z_all), ops._ptr(lab_all), n_all, zd,
+                                              labels.shape[1], dims, r, fused.gamma, fused.delta, ops._ptr(ws_reg),
+                                              ops._ptr(reg_out), ops._ptr(dz), ops._stream()), 'reg_loss')
+            w = float(dp.world_size)
+            scalars[REG:REG + 1].copy_(reg_out).mul_(w)
+            scalars[LOSS:LOSS + 1].add_(reg_out, alpha=w)
+            ctx.dz_unit, reg_scale = dz, w
         ctx.fused, ctx.masks, ctx.marr = fused, keep, marr
         ctx.external_reg, ctx.reg_scale = external_reg, reg_scale
         ctx.save_for_backward(x, eps, capacity, mu, sigma, z, logits)
@@ -139,7 +164,7 @@ class _FusedStepFn(Function):
         ctx.set_materialize_grads(False)
         loss, acc = scalars[LOSS:LOSS + 1], scalars[ACC]
         ctx.mark_non_differentiable(scalars, acc, mu, sigma, logits)
-        if not external_reg:
+        if rowblock or not external_reg:
             ctx.mark_non_differentiable(z)
         return loss, scalars, acc, z, mu, sigma, logits
 
@@ -153,12 +178,15 @@ class _FusedStepFn(Function):
         if g_loss is None:                                       # only z was differentiated (external regulariser)
             g_loss = torch.zeros(1, device=x.device, dtype=torch.float32)
         g_loss = g_loss.reshape(1).contiguous()
+        reg_mode = 0 if ctx.external_reg else 1
+        if ctx.dz_unit is not None:                              # row-block regulariser evaluated in forward (data parallel)
+            reg_mode, g_z = 2, ctx.dz_unit
         dz_extra = g_z.contiguous() if (ctx.external_reg and g_z is not None) else None
         ws = fused.workspace(x.shape[0], x.device)
         with ops._timed('image_vae_backward'):
             _lib.check(lib.arvae_image_vae_backward(
                 ctypes.byref(fused.descriptor()), x.shape[0], ops._ptr(opt.param_arena), ops._ptr(opt.grad_arena),
                 ops._ptr(x), ops._ptr(eps), ctx.marr, ops._ptr(capacity), ops._ptr(mu), ops._ptr(sigma), ops._ptr(z),
-                ops._ptr(logits), ops._ptr(g_loss), ops._ptr(dz_extra), 0 if ctx.external_reg else 1, ctx.reg_scale,
+                ops._ptr(logits), ops._ptr(g_loss), ops._ptr(dz_extra), reg_mode, ctx.reg_scale,
                 ops._ptr(ws), ops._stream()), 'image_vae_backward')
-        return (None,) * 9
+        return (None,) * 10

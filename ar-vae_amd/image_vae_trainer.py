@@ -129,13 +129,8 @@ class ImageVAETrainer(Trainer):
         masks = model._next_masks(n, inputs.device)
         eps = model._noise(torch.empty(n, model.z_dim, device=inputs.device))
         dp = self.data_parallel if self.use_reg_loss else None
-        loss, scalars, accuracy, z, mu, sigma, logits = self._fused.run(x, labels, eps, masks, self.capacity,
-                                                                        external_reg=dp is not None)
+        loss, scalars, accuracy, z, mu, sigma, logits = self._fused.run(x, labels, eps, masks, self.capacity, dp=dp)
         reg_loss = scalars[REG].detach() if self.use_reg_loss else None
-        if dp is not None:
-            reg_loss = dp.reg_loss(z, labels, self.reg_dim, self.gamma, self.delta)
-            loss = loss + reg_loss
-            reg_loss = reg_loss.detach()
         self.last_terms = {'recons': scalars[RECON].detach(), 'dist': scalars[DIST].detach(), 'reg': reg_loss}
         self.last_outputs = {'logits': logits.view(inputs.size()), 'z': z, 'mu': mu, 'sigma': sigma}
         if first_of_epoch and self.writer is not None:

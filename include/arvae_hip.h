@@ -294,9 +294,12 @@ int arvae_image_vae_forward(const arvae_image_vae_t *model, int32_t batch, const
 /* Backward of scalars[ARVAE_VAE_LOSS] times g_loss[0] (device scalar): parameter gradients ACCUMULATE into
  * grads at the layers' offsets.  Must follow arvae_image_vae_forward on the same ws, with the same
  * x / eps / masks / capacity and that call's mu / sigma / z / logits outputs.
- * reg_fused: 1 when the forward evaluated the regularisation term itself (n_cols >= 0);
- * dz_extra: optional extra gradient w.r.t. z [batch, zdim], ALREADY multiplied by the upstream gradient
- * (the data-parallel caller evaluates the row-block regularisation outside and feeds its gradient here). */
+ * reg_fused: 1 when the forward evaluated the regularisation term itself (n_cols >= 0); 0: no regulariser here;
+ *            2: dz_extra holds the regulariser's gradient w.r.t. z for UNIT upstream (arvae_reg_loss's dz, evaluated
+ *            by a data-parallel caller on its row block against the gathered columns): it is scaled by
+ *            g_loss[0] * reg_scale here.
+ * dz_extra: with reg_fused 0 or 1 an optional extra gradient w.r.t. z [batch, zdim], ALREADY multiplied by the
+ *            upstream gradient. */
 int arvae_image_vae_backward(const arvae_image_vae_t *model, int32_t batch, const float *params, float *grads,
                              const float *x, const float *eps, const uint8_t *const *masks,
                              const float *capacity, const float *mu, const float *sigma, const float *z,
