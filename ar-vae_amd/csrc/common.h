@@ -13,6 +13,7 @@ extern thread_local char g_last_error[512];
 
 int fail(int code, const char *fmt, ...);
 int check_launch(const char *what);
+bool profiling_active();   // arvae_profile_begin() is recording: keep every kernel on the caller's stream
 
 #define ARVAE_REQUIRE(cond, ...)                                   \
     do {                                                           \

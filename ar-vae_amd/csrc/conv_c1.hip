@@ -242,15 +242,16 @@ __global__ __launch_bounds__(256, 2) void up_c1_kernel(const float *__restrict__
 // slab per workgroup: [32 clo][16 taps] + 32 lo sums + 1 image sum
 constexpr int WG1_SLAB = SLAB_C1_FLOATS;
 
+// wgrad_c1 on the 16x16x4 MFMA: D[clo][tap] += sum over 4 positions of lo[pos][clo] * img[pos @ tap]; M = 32 channels
+// (two 16-row tiles), N = the 16 taps (every column useful), K = positions.  A lane is (row/col index lane & 15,
+// position-in-quad lane >> 4); a wave owns two lo rows of the tile = 16 quads.
 __global__ __launch_bounds__(256) void wgrad_c1_kernel(Operand lo, Operand img, float *__restrict__ slab, int n_tiles) {
     __shared__ float patch[IPR * IPC];
-    __shared__ __attribute__((aligned(16))) float lo_t[256 * PS1];     // reused as the reduce buffer (needs 4096 floats)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, rc = lane & 31;
-    const int ky = (rc >> 2) & 3, kx = rc & 3;        // lanes with rc >= 16 carry zeros in the B operand
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    float lo_sum = 0.f, img_sum = 0.f;
+    __shared__ __attribute__((aligned(16))) float lo_t[256 * PS1];     // reused as the reduce buffer
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
+    const int ky = li >> 2, kx = li & 3;
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float lo_sum[2] = {0.f, 0.f}, img_sum = 0.f;
     const float gs = img.scale != nullptr ? img.scale[0] : 1.f;
     // register-staged loads (issued for tile t+1 before the MFMAs of tile t)
     constexpr int IMG_ITERS = (IPR * 66 + 255) / 256;
@@ -261,10 +262,10 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(Operand lo, Operand img, 
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int idx = threadIdx.x + it * 256;
-            const int64_t g = (((int64_t)n * LO1 + r0) * LO1 + (idx >> 3)) * CC + (idx & 7) * 4;
-            float4 v = *reinterpret_cast<const float4 *>(lo.v + g);
+            const int64_t gi = (((int64_t)n * LO1 + r0) * LO1 + (idx >> 3)) * CC + (idx & 7) * 4;
+            float4 v = *reinterpret_cast<const float4 *>(lo.v + gi);
             if (lo.y != nullptr) {
-                const float4 y = *reinterpret_cast<const float4 *>(lo.y + g);
+                const float4 y = *reinterpret_cast<const float4 *>(lo.y + gi);
                 v.x *= act_bwd_from_out(y.x, lo.act); v.y *= act_bwd_from_out(y.y, lo.act);
                 v.z *= act_bwd_from_out(y.z, lo.act); v.w *= act_bwd_from_out(y.w, lo.act);
             }
@@ -275,9 +276,9 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(Operand lo, Operand img, 
             const int idx = threadIdx.x + it * 256;
             const int pr = idx / 66, pc = idx - pr * 66;
             const int gy = 2 * r0 - 1 + pr, gx = pc - 1;
-            ir[it] = 0.f;
-            if (idx < IPR * 66 && (unsigned)gy < (unsigned)HI1 && (unsigned)gx < (unsigned)HI1)
-                ir[it] = gs * img.at(((int64_t)n * HI1 + gy) * HI1 + gx);
+            const bool ok = idx < IPR * 66 && (unsigned)gy < (unsigned)HI1 && (unsigned)gx < (unsigned)HI1;
+            const float v = img.at(ok ? ((int64_t)n * HI1 + gy) * HI1 + gx : 0);        // unconditional, clamped
+            ir[it] = ok ? gs * v : 0.f;
         }
     };
     if (blockIdx.x < n_tiles) issue(blockIdx.x);
@@ -300,41 +301,46 @@ __global__ __launch_bounds__(256) void wgrad_c1_kernel(Operand lo, Operand img, 
         __syncthreads();
         if (tile + gridDim.x < n_tiles) issue(tile + gridDim.x);
 #pragma unroll
-        for (int s = 0; s < 32; ++s) {                  // wave's 64 positions: rows 2w, 2w+1; pair (2s, 2s+1)
-            const int r = 2 * wave + (s >> 4), c = (2 * s) & 31;
-            const float a = lo_t[(r * 32 + c + half) * PS1 + rc];
-            lo_sum += a;
-            float b = patch[(2 * r + ky) * IPC + 2 * (c + half) + kx];
-            b = rc < 16 ? b : 0.f;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        for (int q = 0; q < 16; ++q) {                  // quad q of this wave: lo row r, columns c0 .. c0+3; this lane takes c0 + g
+            const int r = 2 * wave + (q >> 3), c = (q & 7) * 4 + g;
+            const float b = patch[(2 * r + ky) * IPC + 2 * c + kx];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const float a = lo_t[(r * 32 + c) * PS1 + 16 * mt + li];
+                lo_sum[mt] += a;
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[mt], 0, 0, 0);
+            }
         }
     }
-    // reduce the 4 waves' tiles: red[wave][reg][lane]
+    // reduce the 4 waves' tiles: red[wave][mt*4 + r][lane]; D row = 4g + r -> clo = 16 mt + 4g + r, column = tap li
     __syncthreads();
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) lo_t[(wave * 16 + reg) * 64 + lane] = acc[reg];
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lo_t[(wave * 8 + mt * 4 + r) * 64 + lane] = acc[mt][r];
     __syncthreads();
     float *out = slab + (int64_t)blockIdx.x * WG1_SLAB;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int reg = 4 * wave + e;
-        const float tot = (lo_t[(0 * 16 + reg) * 64 + lane] + lo_t[(1 * 16 + reg) * 64 + lane]) +
-                          (lo_t[(2 * 16 + reg) * 64 + lane] + lo_t[(3 * 16 + reg) * 64 + lane]);
-        const int clo = (reg & 3) + 8 * (reg >> 2) + 4 * half;
-        if (rc < 16) out[clo * 16 + rc] = tot;
+    for (int e = 0; e < 2; ++e) {                       // wave w finishes registers 2w, 2w+1 of the 8
+        const int reg = 2 * wave + e, mt = reg >> 2, r = reg & 3;
+        const float tot = (lo_t[(0 * 8 + reg) * 64 + lane] + lo_t[(1 * 8 + reg) * 64 + lane]) +
+                          (lo_t[(2 * 8 + reg) * 64 + lane] + lo_t[(3 * 8 + reg) * 64 + lane]);
+        out[(16 * mt + 4 * g + r) * 16 + li] = tot;
     }
-    // bias sums
+    // bias sums: lo per channel (lane li of tile mt, over the 4 position slots and 4 waves), image total
     __syncthreads();
-    lo_t[threadIdx.x] = lo_sum;
-    lo_t[256 + threadIdx.x] = img_sum;
+    lo_t[threadIdx.x] = lo_sum[0];
+    lo_t[256 + threadIdx.x] = lo_sum[1];
+    lo_t[512 + threadIdx.x] = img_sum;
     __syncthreads();
     if (threadIdx.x < CC) {
+        const int mt = threadIdx.x >> 4, i = threadIdx.x & 15;
         float tot = 0.f;
-        for (int j = 0; j < 8; ++j) tot += lo_t[j * 32 + threadIdx.x];      // 4 waves x 2 halves
+        for (int j = 0; j < 16; ++j) tot += lo_t[mt * 256 + j * 16 + i];        // 4 waves x 4 position slots
         out[CC * 16 + threadIdx.x] = tot;
     } else if (threadIdx.x == 64) {
         float tot = 0.f;
-        for (int j = 0; j < 256; ++j) tot += lo_t[256 + j];
+        for (int j = 0; j < 256; ++j) tot += lo_t[512 + j];
         out[CC * 16 + CC] = tot;
     }
 }

@@ -89,8 +89,7 @@ static inline int64_t in_elems(const arvae_layer_t &l, int64_t n) {
 
 struct Layout {
     int64_t enc_out[ARVAE_MAX_LAYERS], dec_out[ARVAE_MAX_LAYERS];   // dec_out[last] unused (logits are external)
-    // Linear layers: the gradient w.r.t. the layer's output stays alive until the end of the backward pass, where
-    // all their weight gradients run as one launch (-1: not a Linear layer, gradient lives in the ping-pong pair)
+    // the gradient w.r.t. each layer's output (kept until the end of the backward pass)
     int64_t enc_keep[ARVAE_MAX_LAYERS], dec_keep[ARVAE_MAX_LAYERS];
     // conv layers with a slab kernel: their own slab, so that all the reductions can run as one launch at the end
     int64_t enc_slab[ARVAE_MAX_LAYERS], dec_slab[ARVAE_MAX_LAYERS];
@@ -139,8 +138,10 @@ static int make_layout(const arvae_image_vae_t *m, int64_t n, int64_t n_cols, La
     for (int i = 0; i < m->n_dec; ++i) L.dec_bits[i] = own_bits(m->dec[i]);
     for (int i = 0; i < m->n_enc; ++i) L.enc_slab[i] = own_slab(m->enc[i]);
     for (int i = 0; i < m->n_dec; ++i) L.dec_slab[i] = own_slab(m->dec[i]);
-    for (int i = 0; i < m->n_enc; ++i) L.enc_keep[i] = dense_fits(&m->enc[i].link) ? take(out_elems(m->enc[i], n)) : -1;
-    for (int i = 0; i < m->n_dec; ++i) L.dec_keep[i] = dense_fits(&m->dec[i].link) ? take(out_elems(m->dec[i], n)) : -1;
+    // every layer's output gradient has its own buffer: weight gradients run on a second stream (and the Linear ones
+    // at the very end), so a gradient must not be overwritten two layers later
+    for (int i = 0; i < m->n_enc; ++i) L.enc_keep[i] = take(out_elems(m->enc[i], n));
+    for (int i = 0; i < m->n_dec; ++i) L.dec_keep[i] = take(out_elems(m->dec[i], n));
     const int64_t bz = n * m->zdim;
     L.log_std = take(bz);
     L.dlogits = take(out_elems(m->dec[m->n_dec - 1], n));
@@ -179,6 +180,38 @@ static int layer_forward(const arvae_layer_t &l, int32_t n, const float *params,
     return l.is_up ? arvae_link_up(&lk, &op, w, b, l.act, mask, out, st) : arvae_link_down(&lk, &op, w, b, l.act, mask, out, st);
 }
 
+// ---- second stream for the weight gradients ---------------------------------------------------------
+// The data-gradient chain (main stream) is the critical path of the backward pass; the weight gradients only have to
+// be done before the optimizer.  They run on a helper stream forked from / joined to the caller's stream with
+// events, so that the many small, latency-bound kernels of either chain fill CUs the other leaves idle.
+struct SideStream {
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr, step[2 * ARVAE_MAX_LAYERS + 8] = {};
+    int device = -1, next = 0;
+    bool ok = false;
+};
+thread_local arvae_stream_t g_wgrad_stream = nullptr;   // non-null while a two-stream backward pass is being enqueued
+
+static SideStream *side_stream() {
+    static SideStream pool[16];
+    // Measured on MI355X (dSprites, B=512): the two-stream schedule is 1-2 % SLOWER than one stream -- the big kernels
+    // of both chains are one-workgroup-per-CU persistent kernels that cannot share a CU's LDS, so they serialise
+    // anyway and only add event traffic.  Kept as an experiment switch.
+    static const bool off = getenv("ARVAE_TWO_STREAMS") == nullptr;
+    int dev = 0;
+    if (off || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    SideStream &ss = pool[dev];
+    if (ss.device != dev) {
+        ss.device = dev;
+        ss.ok = hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) == hipSuccess &&
+                hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) == hipSuccess;
+        for (auto &e : ss.step) ss.ok = ss.ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        if (!ss.ok) (void)hipGetLastError();
+    }
+    return ss.ok ? &ss : nullptr;
+}
+
 // One layer of the backward pass.
 //   g      : gradient arriving at this layer: w.r.t. its pre-activation (g_is_pre) or w.r.t. its output
 //   gate   : when non-null, the saved ReLU output of the PRODUCER of `in`; the data gradient is then
@@ -197,6 +230,8 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
     const float *w = params + l.w_off;
     float *dw = grads + l.w_off, *db = l.b_off >= 0 ? grads + l.b_off : nullptr;
     hipStream_t hs = as_stream(st);
+    const arvae_stream_t wst = g_wgrad_stream != nullptr ? g_wgrad_stream : st;      // weight gradients: helper stream
+    hipStream_t whs = reinterpret_cast<hipStream_t>(wst);
     if (gated != nullptr) *gated = false;
     const bool simple = gop.mask == nullptr && gop.act != ARVAE_ACT_SELU;
     if (d_in != nullptr) {
@@ -233,15 +268,15 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
         (l.is_up ? hi_op : lo_op).scale = g_scale;                // only the conv_c1 kernels honour it (checked by the caller)
         const int bias_mode = db ? (l.is_up ? 2 : 1) : 0;
         SlabJob job;
-        const int rc = conv32_fits(&lk) ? conv32_wgrad_partial(&lk, lo_op, hi_op, dw, db, bias_mode, own_slab, hs, &job)
-                                        : conv_c1_wgrad_partial(&lk, lo_op, hi_op, dw, db, bias_mode, own_slab, hs, &job);
+        const int rc = conv32_fits(&lk) ? conv32_wgrad_partial(&lk, lo_op, hi_op, dw, db, bias_mode, own_slab, whs, &job)
+                                        : conv_c1_wgrad_partial(&lk, lo_op, hi_op, dw, db, bias_mode, own_slab, whs, &job);
         if (rc) return rc;
         slab_reduce_defer(rdefer, job);
         return ARVAE_OK;
     }
-    if (l.is_up) return arvae_link_wgrad(&lk, &xin, &gop, dw, db, db ? 2 : 0, slab, st);
+    if (l.is_up) return arvae_link_wgrad(&lk, &xin, &gop, dw, db, db ? 2 : 0, slab, wst);
     if (defer != nullptr && dense_fits(&lk) && dense_wgrad_defer(defer, &lk, make_operand(&gop), in, dw, db)) return ARVAE_OK;
-    return arvae_link_wgrad(&lk, &gop, &xin, dw, db, db ? 1 : 0, slab, st);
+    return arvae_link_wgrad(&lk, &gop, &xin, dw, db, db ? 1 : 0, slab, wst);
 }
 
 static int count_masks(const arvae_image_vae_t *m) {
@@ -359,6 +394,21 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
     defer.count = 0;
     SlabReduceBatch rdefer;
     rdefer.count = 0;
+    SideStream *side = profiling_active() ? nullptr : side_stream();
+    struct WgradStreamScope {                            // clears the thread-local on every return path
+        ~WgradStreamScope() { g_wgrad_stream = nullptr; }
+    } wgrad_scope;
+    int side_ev = 0;
+    // "everything enqueued on the main stream so far is visible to the helper stream"
+    auto sync_side = [&]() {
+        if (side == nullptr) return;
+        hipEvent_t e = side_ev == 0 ? side->fork : side->step[side_ev - 1];
+        ++side_ev;
+        (void)hipEventRecord(e, st);
+        (void)hipStreamWaitEvent(side->s, e, 0);
+    };
+    if (side != nullptr) g_wgrad_stream = reinterpret_cast<arvae_stream_t>(side->s);
+    hipStream_t flush_stream = side != nullptr ? side->s : st;
     // where the gradient for `keep` (a Linear layer's output, or -1) is written: its own buffer, or the ping-pong
     // buffer that does not hold the gradient being consumed
     auto grad_dst = [&](int64_t keep, const float *busy) -> float * {
@@ -399,6 +449,7 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
         const float *gate = i > 0 ? relu_gate(m->dec[i - 1], dec_mask[i - 1], in) : nullptr;
         float *dst = grad_dst(i > 0 ? L.dec_keep[i - 1] : -1, cur);
         bool gated = false;
+        sync_side();                                     // this layer's incoming gradient is ready
         if (int rc = layer_backward(m->dec[i], batch, params, grads, in, out, mask_of(dec_mask[i]), cur, pre, gate, dst,
                                     &gated, slab, &defer, L.dec_slab[i] >= 0 ? ws + L.dec_slab[i] : nullptr, &rdefer, stream,
                                     i == m->n_dec - 1 ? first_scale : nullptr,
@@ -465,6 +516,7 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
         const float *gate = i > 0 ? relu_gate(m->enc[i - 1], enc_mask[i - 1], in) : nullptr;
         float *dst = i > 0 ? grad_dst(L.enc_keep[i - 1], cur) : nullptr;
         bool gated = false;
+        sync_side();
         if (int rc = layer_backward(m->enc[i], batch, params, grads, in, ws + L.enc_out[i], mask_of(enc_mask[i]), cur, pre,
                                     gate, dst, &gated, slab, &defer, L.enc_slab[i] >= 0 ? ws + L.enc_slab[i] : nullptr, &rdefer,
                                     stream, nullptr,
@@ -474,7 +526,12 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
         pre = gated;
         cur = dst;
     }
-    if (int rc = slab_reduce_flush(&rdefer, st)) return rc;
-    if (int rc = dense_wgrad_flush(&defer, st)) return rc;
+    sync_side();                                         // every gradient the queued jobs read is complete
+    if (int rc = slab_reduce_flush(&rdefer, flush_stream)) return rc;
+    if (int rc = dense_wgrad_flush(&defer, flush_stream)) return rc;
+    if (side != nullptr) {                               // join: the caller's stream continues after the helper's work
+        (void)hipEventRecord(side->join, side->s);
+        (void)hipStreamWaitEvent(st, side->join, 0);
+    }
     return ARVAE_OK;
 }

@@ -41,6 +41,8 @@ int fail(int code, const char *fmt, ...) {
     return code;
 }
 
+bool profiling_active() { return g_prof_on; }
+
 int check_launch(const char *what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(ARVAE_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));

@@ -432,6 +432,51 @@ def test_three_steps_track_oracle(dev, fused):
         close(got['params'][name], cur[name], rtol=0, atol=5e-6)
 
 
+@pytest.mark.parametrize('b', [3, 37, 130])
+def test_image_step_ragged_batches_vs_oracle(dev, b):
+    """Batch sizes that leave partial tiles in every kernel (whole-image tiles of 2 / 8 images, 8-row head blocks)."""
+    state = syn.synth_state(o_vae.DSPRITES_SHAPES, 9, 1.6)
+    x, lab = syn.dsprites_batch(b, seed=50 + b)
+    eps = syn.normal_noise((b, 10), seed=60 + b)
+    got = run_hip_image_step(dev, 'dsprites', state, x, lab, eps, 4.0, 0.0, 'bernoulli', None)
+    ref = o_step.image_step('dsprites', state, x, lab, eps, (1, 2, 3, 4, 5), 4.0, 10.0, 1.0)
+    for k in ('recons', 'dist', 'reg', 'loss', 'acc'):
+        close(got['loss'] if k == 'loss' else got['acc'] if k == 'acc' else got['terms'][k], float(ref['terms'][k]), rtol=1e-4)
+    for name in state:
+        gr = got['grads'][name].astype(np.float64).ravel()
+        want = ref['grads'][name].astype(np.float64).ravel()
+        assert np.linalg.norm(gr - want) <= 2e-3 * np.linalg.norm(want) + 1e-9, name
+
+
+def _full_batch_grads(dev, scale, seed=7):
+    from arvae_amd.image_vae import DspritesVAE
+    from arvae_amd.image_vae_trainer import ImageVAETrainer
+    state = syn.synth_state(o_vae.DSPRITES_SHAPES, seed, 1.6)
+    model = DspritesVAE()
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    trainer = ImageVAETrainer(DspritesDataset(), model, lr=1e-4, reg_type=('all',), reg_dim=(1, 2, 3, 4, 5), beta=4.0,
+                              gamma=10.0, capacity=0.0, rand=0, delta=1.0)
+    trainer.cuda()
+    model.train()
+    x, lab = syn.dsprites_batch(512, seed=1234)
+    model.push_noise(torch.from_numpy(syn.normal_noise((512, 10), seed=1)))
+    trainer.zero_grad()
+    loss, _ = trainer.loss_and_acc_for_batch((torch.from_numpy(x).to(dev), torch.from_numpy(lab).to(dev)), 0, 0, True)
+    (loss * scale).backward()
+    return float(loss), trainer.optimizer.grad_arena.detach().clone()
+
+
+def test_full_batch_properties(dev):
+    """BASELINE's batch (512), size-independent properties: the step is bit-reproducible (no atomics anywhere) and the
+    whole backward pass is linear in the upstream gradient (it is folded into the first kernels' loads)."""
+    l1, g1 = _full_batch_grads(dev, 1.0)
+    l2, g2 = _full_batch_grads(dev, 1.0)
+    assert l1 == l2 and torch.equal(g1, g2)
+    _, g3 = _full_batch_grads(dev, 3.0)
+    assert np.isfinite(l1) and float(g1.abs().max()) > 0
+    close(g3, 3.0 * g1, rtol=2e-5, atol=1e-6 * float(g1.abs().max()))
+
+
 # ---------------------------------------------------------------- MeasureVAE (G6 / G7)
 class _FolkDataset:
     """the attributes MeasureVAE / MeasureVAETrainer read from the reference's FolkNBarDataset"""
