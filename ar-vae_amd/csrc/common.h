@@ -13,6 +13,7 @@ extern thread_local char g_last_error[512];
 
 int fail(int code, const char *fmt, ...);
 int check_launch(const char *what);
+void prof_gap();           // call right before launching a kernel whose profile time should exclude the launch gap
 bool profiling_active();   // arvae_profile_begin() is recording: keep every kernel on the caller's stream
 
 #define ARVAE_REQUIRE(cond, ...)                                   \

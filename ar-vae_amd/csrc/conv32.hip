@@ -688,6 +688,7 @@ static void launch_down_v(int grid, const Operand &hi, const float *wt, const Ep
     constexpr int LDS = MaxOf<PatchLoader<LO, 2>::PATCH_FLOATS, WSTAGE_DOWN>::value * 4;
     static bool attr = false;
     if (!attr) { allow_lds(down32_kernel<LO, MODE>, LDS); attr = true; }
+    prof_gap();
     hipLaunchKernelGGL((down32_kernel<LO, MODE>), dim3(grid), dim3(256), LDS, s, hi.v, wt, ep, n, tiles);
 }
 template <int LO, int MODE>
@@ -695,6 +696,7 @@ static void launch_up_v(int grid, const Operand &lo, const float *wt, const Ep32
     constexpr int LDS = MaxOf<PatchLoader<LO, 1>::PATCH_FLOATS, WSTAGE_UP>::value * 4;
     static bool attr = false;
     if (!attr) { allow_lds(up32_kernel<LO, MODE>, LDS); attr = true; }
+    prof_gap();
     hipLaunchKernelGGL((up32_kernel<LO, MODE>), dim3(grid), dim3(256), LDS, s, lo.v, wt, ep, n, tiles);
 }
 
@@ -769,6 +771,7 @@ template <int LO> static int launch_wgrad(const arvae_link_t *l, const Operand &
         allow_lds(wgrad32_kernel<LO, 2>, LDS);
         attr = true;
     }
+    prof_gap();
     if (bias_mode == 1)
         hipLaunchKernelGGL((wgrad32_kernel<LO, 1>), dim3(grid), dim3(256), LDS, s, lo.v, hi.v, slab, l->n, tiles);
     else if (bias_mode == 2)

@@ -43,6 +43,12 @@ int fail(int code, const char *fmt, ...) {
 
 bool profiling_active() { return g_prof_on; }
 
+// closes the interval since the previous mark under the name "(gap)", so that the next kernel's interval starts at
+// its own launch and the per-kernel times of arvae_profile_end() agree with a kernel trace
+void prof_gap() {
+    if (g_prof_on) prof_mark("(gap)");
+}
+
 int check_launch(const char *what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(ARVAE_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ARVAE_ABI_VERSION 1
+#define ARVAE_ABI_VERSION 2   /* 2: arvae_image_vae_backward reg_fused == 2 (unit regulariser gradient in dz_extra) */
 
 #define ARVAE_OK 0
 #define ARVAE_E_INVALID (-1)  /* bad argument (null pointer, size out of range, unsupported shape) */

@@ -1,0 +1,58 @@
+"""Build profiles/<tag>_pmc_traffic.json from two rocprofv3 counter-collection CSVs (--pmc FETCH_SIZE and --pmc WRITE_SIZE
+passes of the same bench.py command).  HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) KiB, the gfx950 correction of
+MI355X_MICROARCH.md (HBM section): FETCH_SIZE counts wide coalesced reads at half their size, WRITE_SIZE is exact.
+
+    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+"""
+import collections
+import csv
+import json
+import re
+import sys
+
+
+def label(kernel_name):
+    """rocprofv3 kernel name -> the label bench.py / arvae_profile_end use for that kernel family."""
+    n = kernel_name.replace('void ', '').split('(')[0].replace('arvae::', '')
+    m = re.match(r'(down32_kernel|up32_kernel|wgrad32_kernel)<(\d+),', n)
+    if m:
+        return f'{m.group(1)}<{m.group(2)}>'
+    if n.startswith('up_c1_kernel'):
+        return 'up_c1_kernel(recon)' if 'true' in n else 'up_c1_kernel'
+    return n.split('<')[0]
+
+
+def per_kernel(path, counter):
+    tot, cnt = collections.defaultdict(float), collections.defaultdict(int)
+    for row in csv.DictReader(open(path)):
+        if row['Counter_Name'] != counter:
+            continue
+        k = label(row['Kernel_Name'])
+        tot[k] += float(row['Counter_Value'])
+        cnt[k] += 1
+    return {k: (tot[k] / cnt[k], cnt[k]) for k in tot}
+
+
+def main():
+    fetch, write = per_kernel(sys.argv[1], 'FETCH_SIZE'), per_kernel(sys.argv[2], 'WRITE_SIZE')
+    out = {
+        'source': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate passes) of '
+                  '`python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline`, dSprites B=512, MI355X',
+        'correction': 'hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: on gfx950 FETCH_SIZE counts half the bytes of wide '
+                      '(16 B/lane) coalesced reads (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact',
+        'kernels': {},
+    }
+    for k in sorted(set(fetch) | set(write)):
+        f, nf = fetch.get(k, (0.0, 0))
+        w, _ = write.get(k, (0.0, 0))
+        if not k.startswith(('down', 'up', 'wgrad', 'slab', 'dense', 'heads', 'vae', 'reg', 'adam')):
+            continue
+        out['kernels'][k] = {'launches_sampled': nf, 'FETCH_SIZE_KB_per_launch': round(f, 1),
+                             'WRITE_SIZE_KB_per_launch': round(w, 1), 'hbm_bytes_per_launch': int((2 * f + w) * 1024)}
+    json.dump(out, open(sys.argv[3], 'w'), indent=1)
+    for k, v in sorted(out['kernels'].items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'])[:12]:
+        print(f"{k:28s} {v['hbm_bytes_per_launch'] / 1e6:8.1f} MB/launch")
+
+
+if __name__ == '__main__':
+    main()
