@@ -76,6 +76,7 @@ SIGNATURES = {
     'arvae_split_cols': (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp]),
     'arvae_scale_mask': (c_i32, [c_vp, c_vp, c_f32, c_i64, c_i32, c_vp, c_vp]),
     'arvae_broadcast_rows': (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp]),
+    'arvae_gather_rows_u8': (c_i32, [c_vp, c_i64, c_i64, c_vp, c_i64, c_f32, c_vp, c_vp]),
     'arvae_measure_attributes': (c_i32, [c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_f32, c_vp, c_vp]),
     'arvae_image_vae_ws_floats': (c_i64, [_P(ImageVaeDesc), c_i32, c_i64]),
     'arvae_image_vae_forward': (c_i32, [_P(ImageVaeDesc), c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, _P(c_vp), c_vp, c_vp,

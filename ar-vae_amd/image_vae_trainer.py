@@ -145,6 +145,53 @@ class ImageVAETrainer(Trainer):
             self.writer.add_image('reconstruction', image_grid(torch.cat([inputs[:k], recon]).cpu(), k), epoch_num)
         return loss, accuracy
 
+    # -- evaluation-only inference (image_vae_trainer.py:264-288,381-403): encoder / decoder passes on the forward
+    #    kernels; the metrics fed from here (utils/evaluation.py) stay host-side and are out of scope ---------------------
+    def _extract_relevant_attributes(self, attributes):
+        attr_list = [a for a in self.attr_dict if a not in ('digit_identity', 'color')]
+        return attributes[:, [self.attr_dict[a] for a in attr_list]], attr_list
+
+    def compute_representations(self, data_loader, num_batches=200):
+        """-> (latent codes (n, z_dim), attribute columns (n, k), attribute names); stops after num_batches + 1 batches
+        like the reference (`if sample_id == 200: break` comes after the append)."""
+        codes, attrs = [], []
+        self.model.eval()
+        with torch.no_grad():
+            for i, batch in enumerate(data_loader):
+                inputs, labels = self.process_batch_data(batch)
+                codes.append(self.model(inputs)[3])
+                attrs.append(labels)
+                if i == num_batches:
+                    break
+        codes = torch.cat(codes).cpu().numpy()             # one device->host copy for the whole sweep
+        attrs, names = self._extract_relevant_attributes(torch.cat(attrs).cpu().numpy())
+        return codes, attrs, names
+
+    def compute_latent_interpolations(self, latent_code, dim1=0, num_points=10):
+        """Decoder sweep of one latent dimension over [-4, 4]: (num_points, 1, H, W) probabilities on the device."""
+        dev = next(self.model.parameters()).device
+        z = torch.as_tensor(latent_code, dtype=torch.float32, device=dev).reshape(1, -1).repeat(num_points, 1)
+        z[:, dim1] = torch.linspace(-4.0, 4.0, num_points, device=dev)
+        with torch.no_grad():
+            return torch.sigmoid(self.model.decode(z.contiguous()))
+
+    def compute_latent_interpolations2d(self, latent_code, dim1=0, dim2=1, num_points=10):
+        dev = next(self.model.parameters()).device
+        x = torch.linspace(-4.0, 4.0, num_points, device=dev)
+        z1, z2 = torch.meshgrid([x, x], indexing='ij')
+        z = torch.as_tensor(latent_code, dtype=torch.float32, device=dev).reshape(1, -1).repeat(num_points * num_points, 1)
+        z[:, dim1], z[:, dim2] = z1.reshape(-1), z2.reshape(-1)
+        with torch.no_grad():
+            return torch.sigmoid(self.model.decode(z.contiguous()))
+
+    def test_model(self, batch_size):
+        """Mean loss / accuracy over the evaluation split (image_vae_trainer.py:333-343)."""
+        _, _, loader = self.dataset.data_loaders(batch_size)
+        self.model.eval()
+        with torch.no_grad():
+            loss, acc = self.loss_and_acc_on_epoch(loader, epoch_num=0, train=False)
+        return {'test_loss': loss, 'test_acc': acc}
+
     # -- static helpers (image_vae_trainer.py:623-655) ---------------------------------------------------
     @staticmethod
     def reconstruction_loss(x, x_recons, dist):

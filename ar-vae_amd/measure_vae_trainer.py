@@ -143,6 +143,30 @@ class MeasureVAETrainer(Trainer):
                 self.writer.add_scalar('loss_split/reg_loss', (reg_loss / self.gamma).item(), epoch_num)
         return loss, accuracy
 
+    # -- evaluation-only inference (measure_vae_trainer.py:188-212) ---------------------------------------------------
+    def compute_representations(self, data_loader, num_batches=None):
+        """-> (latent codes, attribute labels (n, 4), attribute names) over at most num_batches + 1 batches."""
+        num_batches = 200 if num_batches is None else num_batches
+        codes, attrs = [], []
+        self.model.eval()
+        with torch.no_grad():
+            for i, batch in enumerate(data_loader):
+                score, metadata = self.process_batch_data(batch)
+                codes.append(self.model(score, metadata, train=False)[4])
+                attrs.append(self.compute_attribute_labels(score))
+                if i == num_batches:
+                    break
+        if not codes:
+            raise ValueError('compute_representations: the loader produced no batch (split smaller than the batch size?)')
+        return torch.cat(codes).cpu().numpy(), torch.cat(attrs).cpu().numpy(), list(self.attr_dict)
+
+    def test_model(self, batch_size):
+        _, _, loader = self.dataset.data_loaders(batch_size)
+        self.model.eval()
+        with torch.no_grad():
+            loss, acc = self.loss_and_acc_on_epoch(loader, epoch_num=0, train=False)
+        return {'test_loss': loss, 'test_acc': acc}
+
     @staticmethod
     def reconstruction_loss(x, x_recons):
         return Trainer.mean_crossentropy_loss(weights=x_recons, targets=x)

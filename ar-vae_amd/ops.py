@@ -671,6 +671,20 @@ def broadcast_rows(v, rows):
     return _BroadcastFn.apply(v, int(rows))
 
 
+def gather_rows_u8(src, idx, scale=1.0):
+    """src (N, ...) uint8 on the device, idx (B,) int64 -> (B, ...) fp32 = scale * src[idx]."""
+    _dev(src, idx)
+    if src.dtype != torch.uint8 or idx.dtype != torch.int64:
+        raise TypeError('gather_rows_u8 needs a uint8 source and int64 indices')
+    lib = _lib.load()
+    src, idx = src.contiguous(), idx.contiguous()
+    row = src[0].numel()
+    out = torch.empty((idx.numel(),) + tuple(src.shape[1:]), device=src.device, dtype=torch.float32)
+    _lib.check(lib.arvae_gather_rows_u8(_ptr(src), src.shape[0], row, _ptr(idx), idx.numel(), float(scale), _ptr(out),
+                                        _stream()), 'gather_rows_u8')
+    return out
+
+
 def measure_attributes(score, tables, rhythm_weights, rhythm_norm):
     """(B, 24) int64 measures -> (B, 4) [rhythmic complexity, pitch range, note density, contour]."""
     _dev(score)

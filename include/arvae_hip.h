@@ -224,6 +224,13 @@ int arvae_scale_mask(const float *x, const uint8_t *mask, float alpha, int64_t c
 /* y[r][:] = v[:]  (the learned start vectors x_0 / b_0 expanded over the batch, decoder.py:459-463,485-489) */
 int arvae_broadcast_rows(const float *v, int64_t rows, int32_t cols, float *y, arvae_stream_t stream);
 
+/* Minibatch assembly from a device-resident uint8 image set: out[b][:] = scale * src[idx[b]][:] as fp32.
+ * Replaces the host-side float32 copy of the whole dSprites / MNIST set and the DataLoader's per-batch H2D copy
+ * (data/dataloaders/dsprites_dataset.py:38-53 `images.astype('float32')`, mnist_dataset.py:60-82 `/ 255.0`).
+ * src [n_rows, row_elems] uint8 (row_elems % 4 == 0), idx [count] int64 row numbers (out-of-range rows give zeros). */
+int arvae_gather_rows_u8(const uint8_t *src, int64_t n_rows, int64_t row_elems, const int64_t *idx, int64_t count,
+                         float scale, float *out, arvae_stream_t stream);
+
 /* Attribute labels of a batch of measures.  Replaces MeasureVAETrainer.compute_attribute_labels
  * (measurevae/measure_vae_trainer.py:167-186 -> data/dataloaders/bar_dataset.py:338-500):
  *   out[b] = [rhythmic complexity, pitch range/26, note density, contour/26]

@@ -1,0 +1,163 @@
+"""Device-resident datasets, the uint8 gather kernel, evaluation inference and the training CLIs on tiny synthetic files
+written in the reference's on-disk formats."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import arvae_amd  # noqa: E402,F401
+from arvae_amd import synthetic as syn  # noqa: E402
+from arvae_amd.data import formats  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    return torch.device('cuda:0')
+
+
+def write_dsprites(folder, n, seed=0):
+    x, lab = syn.dsprites_batch(n, seed=seed)
+    imgs = (x[:, 0] > 0.5).astype(np.uint8)
+    np.savez(os.path.join(folder, 'dsprites_ndarray_co1sh3sc6or40x32y32_64x64.npz'), imgs=imgs,
+             latents_values=lab.astype(np.float64))
+    return imgs, lab.astype(np.float32)
+
+
+def write_mnist(folder, n_train, n_test, seed=0):
+    plain = os.path.join(folder, 'mnist_data', 'plain')
+    os.makedirs(plain)
+    out = {}
+    for split, n in (('train', n_train), ('t10k', n_test)):
+        x, lab = syn.mnist_batch(n, seed=seed + len(split))
+        imgs = np.clip(np.rint(x[:, 0] * 255.0), 0, 255).astype(np.uint8)
+        digits = (np.arange(n) % 10).astype(np.uint8)
+        formats.save_idx(imgs, os.path.join(plain, split + '-images-idx3-ubyte.gz'))
+        formats.save_idx(digits, os.path.join(plain, split + '-labels-idx1-ubyte.gz'))
+        np.savetxt(os.path.join(plain, split + '-morpho.csv'), lab, delimiter=',', header='index,area,length,thickness,slant,width,height', comments='')
+        out[split] = (imgs, digits, lab.astype(np.float32))
+    return out
+
+
+def write_folk(folder, n, seed=0):
+    raw = os.path.join(folder, 'folk_raw_data')
+    os.makedirs(raw)
+    score = torch.from_numpy(syn.measure_batch(n, seed=seed)).int()
+    torch.save(torch.utils.data.TensorDataset(score, score), os.path.join(raw, '4by4_FolkNBarDataset_1_train'))
+    i2n, n2i = syn.measure_vocabulary()
+    with open(os.path.join(raw, 'index_dicts.txt'), 'w') as f:
+        f.write(repr(i2n) + '\n' + repr(n2i) + '\n')
+    return score.numpy()
+
+
+def test_gather_rows_u8_is_exact(dev):
+    from arvae_amd import ops
+    rs = np.random.RandomState(3)
+    src = rs.randint(0, 256, (97, 1, 28, 28)).astype(np.uint8)
+    idx = rs.randint(0, 97, 301)
+    got = ops.gather_rows_u8(torch.from_numpy(src).to(dev), torch.from_numpy(idx).to(dev), 1.0 / 255.0).cpu().numpy()
+    want = src[idx].astype(np.float32) * np.float32(1.0 / 255.0)
+    assert got.shape == (301, 1, 28, 28) and np.array_equal(got, want)
+    with pytest.raises(TypeError):
+        ops.gather_rows_u8(torch.zeros(4, 8, device=dev), torch.zeros(2, dtype=torch.int64, device=dev))
+
+
+def test_dsprites_loaders_split_and_content(dev, tmp_path):
+    from arvae_amd.data import DspritesDataset
+    imgs, lab = write_dsprites(str(tmp_path), 200)
+    ds = DspritesDataset(path=str(tmp_path / 'dsprites_ndarray_co1sh3sc6or40x32y32_64x64.npz'), device=dev)
+    tr, va, ev = ds.data_loaders(batch_size=32, split=(0.70, 0.20))
+    cut2 = int((0.70 + 0.20) * 200)                                  # 179, not 180: the reference's float arithmetic
+    assert (len(tr), len(va), len(ev)) == (5, 2, 1)                  # 140 / 39 / 21 rows
+    xs, ls = zip(*[(x.cpu().numpy(), l.cpu().numpy()) for x, l in ev])
+    assert np.array_equal(np.concatenate(xs)[:, 0], imgs[cut2:].astype(np.float32)) and np.array_equal(np.concatenate(ls), lab[cut2:])
+    seen = np.concatenate([l.cpu().numpy() for _, l in tr])
+    assert seen.shape == (140, 6)                                    # a permutation of the first 140 rows
+    assert np.array_equal(np.sort(seen.sum(1)), np.sort(lab[:140].sum(1)))
+    x0, l0 = next(iter(tr))
+    assert x0.dtype == torch.float32 and x0.shape == (32, 1, 64, 64) and set(np.unique(x0.cpu().numpy())) <= {0.0, 1.0}
+
+
+def test_mnist_and_folk_loaders(dev, tmp_path):
+    from arvae_amd.data import FolkNBarDataset, MorphoMnistDataset
+    ref = write_mnist(str(tmp_path), 50, 30)
+    ds = MorphoMnistDataset(root_dir=str(tmp_path / 'mnist_data' / 'plain'), device=dev)
+    tr, va, ev = ds.data_loaders(batch_size=16)
+    assert (len(tr), len(va), len(ev)) == (4, 2, 2)
+    x, d, m = next(iter(va))
+    imgs, digits, lab = ref['t10k']
+    assert np.array_equal(x.cpu().numpy()[:, 0], imgs[:16].astype(np.float32) * np.float32(1 / 255.0))
+    assert np.array_equal(d.cpu().numpy(), digits[:16].astype(np.int64)) and np.allclose(m.cpu().numpy(), lab[:16])
+    score = write_folk(str(tmp_path), 100)
+    fd = FolkNBarDataset(dataset_dir=str(tmp_path / 'folk_raw_data'), device=dev)
+    assert repr(fd) == '4by4_FolkNBarDataset_1_' and fd.index2note_dicts[0] == '__'
+    tr, va, ev = fd.data_loaders(batch_size=8, split=(0.70, 0.20))
+    assert (len(tr), len(va), len(ev)) == (8, 2, 1)                  # drop_last: 70 -> 8, 20 -> 2, 10 -> 1
+    s, meta = next(iter(va))
+    assert np.array_equal(s.cpu().numpy(), score[70:78]) and torch.equal(s, meta)
+
+
+def _run_cli(script, args, env_dir):
+    env = dict(os.environ, ARVAE_DATA_DIR=str(env_dir), ARVAE_MODEL_DIR=str(env_dir / 'models'))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, script)] + args, capture_output=True, text=True, timeout=600, env=env,
+                       cwd=str(env_dir))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    start = r.stdout.index('{\n')
+    return json.loads(r.stdout[start:]), r.stdout
+
+
+def test_train_image_cli_dsprites_end_to_end(dev, tmp_path):
+    write_dsprites(str(tmp_path), 400)
+    summary, out = _run_cli('train_image_vae.py', ['-d', 'dsprites', '--num_epochs', '2', '--batch_size', '64', '--rand', '3',
+                                                   '-r', 'all'], tmp_path)
+    assert 'Num Train Batches:  5' in out and out.count('saved') >= 2
+    assert summary['attributes'] == ['shape', 'scale', 'orientation', 'posx', 'posy'] and summary['num_codes'] == 400 - int((0.80 + 0.15) * 400)
+    assert np.isfinite(summary['test_loss']) and 0.0 <= summary['test_acc'] <= 1.0
+    name = summary['model']
+    assert os.path.exists(tmp_path / 'models' / name / (name + '.pt'))
+    # --test reloads the checkpoint without training
+    again, _ = _run_cli('train_image_vae.py', ['-d', 'dsprites', '--test', '--rand', '3', '-r', 'all'], tmp_path)
+    assert again['model'] == name and again['test_loss'] == pytest.approx(summary['test_loss'], rel=5e-2)    # eps is redrawn
+
+
+def test_train_image_cli_mnist_single_attribute(dev, tmp_path):
+    write_mnist(str(tmp_path), 96, 64)
+    summary, _ = _run_cli('train_image_vae.py', ['--num_epochs', '1', '--batch_size', '32', '--rand', '0', '-r', 'slant'], tmp_path)
+    assert summary['num_codes'] == 64 and len(summary['latent_mean_abs']) == 16 and np.isfinite(summary['test_loss'])
+
+
+def test_train_measure_cli_end_to_end(dev, tmp_path):
+    write_folk(str(tmp_path), 400)                   # evaluation split: 20 measures -> one batch of 16 (drop_last)
+    summary, _ = _run_cli('train_measure_vae.py', ['--num_epochs', '1', '--batch_size', '16', '--rand', '1', '-r', 'all'], tmp_path)
+    assert summary['attributes'] == ['rhy_complexity', 'pitch_range', 'note_density', 'contour']
+    assert summary['num_codes'] == 16 and np.isfinite(summary['test_loss'])
+
+
+def test_decoder_sweeps(dev):
+    from arvae_amd.image_vae import DspritesVAE
+    from arvae_amd.image_vae_trainer import ImageVAETrainer
+
+    class DspritesDataset:
+        pass
+    model = DspritesVAE()
+    trainer = ImageVAETrainer(DspritesDataset(), model, reg_type=('all',), reg_dim=(1, 2, 3, 4, 5))
+    trainer.cuda()
+    z = np.zeros(10, np.float32)
+    row = trainer.compute_latent_interpolations(z, dim1=2, num_points=7)
+    grid = trainer.compute_latent_interpolations2d(z, dim1=1, dim2=4, num_points=5)
+    assert row.shape == (7, 1, 64, 64) and grid.shape == (25, 1, 64, 64)
+    assert float(row.min()) >= 0.0 and float(row.max()) <= 1.0
+    # the middle of an odd sweep is the unperturbed code
+    mid = torch.sigmoid(model.decode(torch.zeros(1, 10, device=dev)))
+    assert torch.allclose(row[3], mid[0], atol=1e-6)
