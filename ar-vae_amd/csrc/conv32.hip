@@ -36,29 +36,31 @@ constexpr int PS = 36;                  // LDS pixel stride in floats
 constexpr int PIXB = C32 * 4;           // bytes of one 32-channel pixel
 constexpr unsigned OOB = 0x7fffffffu;   // byte offset beyond any tensor here: loads return 0, stores are dropped
 
-// tile geometry per lo-resolution size LO (hi = 2*LO): 128 lo pixels = four 32-row MFMA tiles, TC == LO
-template <int LO> struct Tile;
-template <> struct Tile<16> { static constexpr int TI = 1, TR = 8, TC = 16; };   // 8 rows x 16 cols of one image
-template <> struct Tile<8>  { static constexpr int TI = 2, TR = 8, TC = 8;  };   // two whole 8x8 images
-template <> struct Tile<4>  { static constexpr int TI = 8, TR = 4, TC = 4;  };   // eight whole 4x4 images
+// tile geometry per lo-resolution size LO (hi = 2*LO): PX lo pixels = PX/32 MFMA tiles of full-width rows (TC == LO):
+//   LO 16, PX 128: 8 rows of one image      LO 8, PX 128: two whole images      LO 4, PX 128: eight whole images
+//   LO 4, PX 32: two whole images (the small-problem variant: 4x more tiles when 128-pixel tiles leave CUs idle)
+template <int LO, int PX = 128> struct Tile {
+    static constexpr int ROWS = PX / LO;
+    static constexpr int TI = ROWS > LO ? ROWS / LO : 1, TR = ROWS > LO ? LO : ROWS, TC = LO;
+};
 
-// lo pixel p (0..127) of a tile -> (image, row, col) inside the tile; in memory pixel p sits p*PIXB after the tile start
-template <int LO> __device__ __forceinline__ constexpr void tile_pixel(int p, int &img, int &r, int &c) {
-    using T = Tile<LO>;
+// lo pixel p of a tile -> (image, row, col) inside the tile; in memory pixel p sits p*PIXB after the tile start
+template <int LO, int PX = 128> __device__ __forceinline__ constexpr void tile_pixel(int p, int &img, int &r, int &c) {
+    using T = Tile<LO, PX>;
     c = p % T::TC;
     r = (p / T::TC) % T::TR;
     img = p / (T::TC * T::TR);
 }
-template <int LO> __device__ __forceinline__ void tile_origin(int tile, int &img0, int &r0) {
-    using T = Tile<LO>;
+template <int LO, int PX = 128> __device__ __forceinline__ void tile_origin(int tile, int &img0, int &r0) {
+    using T = Tile<LO, PX>;
     constexpr int TILES_PER_IMG = LO / T::TR;
     img0 = (T::TI == 1) ? tile / TILES_PER_IMG : tile * T::TI;
     r0 = (T::TI == 1) ? (tile % TILES_PER_IMG) * T::TR : 0;
 }
 // byte offset of hi pixel (2r, 2c) of lo pixel p inside a [*, 2LO, 2LO, 32] tensor, relative to hi (img0, 2*r0, 0)
-template <int LO> __device__ __forceinline__ constexpr int hi_rel(int p) {
+template <int LO, int PX = 128> __device__ __forceinline__ constexpr int hi_rel(int p) {
     int img = 0, r = 0, c = 0;
-    tile_pixel<LO>(p, img, r, c);
+    tile_pixel<LO, PX>(p, img, r, c);
     return ((img * 2 * LO + 2 * r) * 2 * LO + 2 * c) * PIXB;
 }
 
@@ -111,9 +113,9 @@ __device__ __forceinline__ unsigned bits_off(unsigned out_off, int half) { retur
 // padding slots) and the patch row (the row halo at image borders is a compare + select per tile).
 // Slots are issued one at a time so that the callers can spread them between the MFMAs of the previous tile.
 // ------------------------------------------------------------------------------------------------
-template <int LO, int STRIDE>
+template <int LO, int STRIDE, int PX = 128>
 struct PatchLoader {
-    using T = Tile<LO>;
+    using T = Tile<LO, PX>;
     static constexpr int SZ = STRIDE * LO;
     static constexpr int PR = STRIDE * T::TR + 2, PC = STRIDE * T::TC + 2;
     static constexpr int SLOTS = T::TI * PR * PC * 8;
@@ -380,6 +382,86 @@ __global__ __launch_bounds__(256, 1) void down32_kernel(const float *__restrict_
 }
 
 // ================================================================================================
+// Down, small-problem variant (4x4 / 8x8 layers at batch 512: too few 128-pixel tiles to fill or pipeline the CUs):
+// a tile is 32 lo pixels, wave w takes kernel row ky = w (K split 4 ways, 64 weights per lane straight from
+// global memory), the four partial tiles meet in LDS and wave 0 runs the epilogue.
+template <int LO, int MODE>
+__global__ __launch_bounds__(256, 2) void down32s_kernel(const float *__restrict__ hi, const float *__restrict__ wt, Ep32 ep,
+                                                         int n_img, int n_tiles) {
+    constexpr int PX = 32;
+    using PL = PatchLoader<LO, 2, PX>;
+    constexpr int PC = PL::PC, PR = PL::PR;
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // PL::PATCH_FLOATS | red[4][16][64]
+    float *red = lds + PL::PATCH_FLOATS;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, rc = lane & 31;
+
+    PL pl;
+    pl.init(hi, n_img);
+    int img0, r0;
+    tile_origin<LO, PX>(blockIdx.x, img0, r0);
+    pl.set_tile(img0, r0, blockIdx.x < n_tiles);
+    pl.issue_all();
+
+    // w[kx][chunk][t] = wt[clo = rc][chi = chunk*8 + half*4 + t][ky = wave][kx]: the four kx are one 16-byte load
+    float w[4][4][4];
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float4 q = *reinterpret_cast<const float4 *>(wt + ((rc * C32) + ch * 8 + half * 4 + t) * 16 + wave * 4);
+            w[0][ch][t] = q.x; w[1][ch][t] = q.y; w[2][ch][t] = q.z; w[3][ch][t] = q.w;
+        }
+    int img, r, c;
+    tile_pixel<LO, PX>(rc, img, r, c);
+    const int aoff = ((img * PR + 2 * r + wave) * PC + 2 * c) * PS + half * 4;      // + kx*PS + chunk*8
+    float4 b4[4];
+    load_bias4(ep.bias, half, b4);
+    const int64_t out_bytes = (int64_t)n_img * LO * LO * PIXB;
+    const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(ep.out, out_bytes);
+    const __amdgpu_buffer_rsrc_t rs_gate = make_rsrc(MODE == EP_GATE_F ? ep.gate : ep.out, out_bytes);
+    const bool want_bits = MODE == EP_RELU && ep.bits_out != nullptr;
+    const __amdgpu_buffer_rsrc_t rs_bits =
+        make_rsrc(MODE == EP_GATE_B ? (const void *)ep.gate_bits : want_bits ? (const void *)ep.bits_out : (const void *)ep.out,
+                  (int64_t)n_img * LO * LO * 4);
+    const unsigned out_lane = (unsigned)(rc * PIXB + half * 16);
+    float4 dummy;
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        tile_origin<LO, PX>(tile, img0, r0);
+        __syncthreads();                                         // the previous tile's patch and partials have been read
+        pl.template commit<false>(lds, dummy);
+        __syncthreads();
+        {
+            int ni, nr;
+            tile_origin<LO, PX>(tile + gridDim.x, ni, nr);
+            pl.set_tile(ni, nr, tile + gridDim.x < n_tiles);
+            pl.issue_all();
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx)
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
+                const float4 a = *reinterpret_cast<const float4 *>(lds + aoff + kx * PS + ch * 8);
+                MFMA4(acc, a, w[kx][ch])
+            }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) red[(wave * 16 + reg) * 64 + lane] = acc[reg];
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg)
+                acc[reg] = (acc[reg] + red[(16 + reg) * 64 + lane]) + (red[(32 + reg) * 64 + lane] + red[(48 + reg) * 64 + lane]);
+            store_pixel<MODE>(acc, b4, rs_out, rs_gate, rs_bits, want_bits,
+                              out_lane + (unsigned)(((img0 * LO + r0) * LO) * PIXB), half);
+        }
+    }
+}
+
+// ================================================================================================
 // Up: hi[n,hy,hx,chi] = ep( sum over the 2x2 taps valid for (hy,hx)'s parity and clo of lo * wt )
 // wave w = parity class (py, px) = (w>>1, w&1) of the 4 x 128 hi pixels of a tile (four 32-pixel MFMA tiles)
 // ================================================================================================
@@ -388,10 +470,11 @@ __global__ __launch_bounds__(256, 1) void down32_kernel(const float *__restrict_
 // matrix pipes for ~4K clocks.  The stores of tile t are therefore issued between the MFMAs of tile t+1, one
 // 16-byte store per wave and 16-MFMA step, each wave in its own quarter of the step: the drain then hides
 // behind the wave's previous MFMA.  Gate values are fetched one tile ahead into registers.
-template <int LO, int MODE>
+template <int LO, int MODE, int PX = 128>
 __global__ __launch_bounds__(256, 1) void up32_kernel(const float *__restrict__ lo, const float *__restrict__ wt, Ep32 ep, int n_img,
                                                        int n_tiles) {
-    using PL = PatchLoader<LO, 1>;
+    using PL = PatchLoader<LO, 1, PX>;
+    constexpr int MT = PX / 32;                                  // 32-pixel MFMA tiles per wave (and parity class)
     constexpr int HI = 2 * LO, PC = PL::PC, PR = PL::PR;
     extern __shared__ __attribute__((aligned(16))) float lds[];  // max(PL::PATCH_FLOATS, WSTAGE_UP)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -403,7 +486,7 @@ __global__ __launch_bounds__(256, 1) void up32_kernel(const float *__restrict__ 
     PL pl;                                                       // first tile's loads fly while the weights are staged
     pl.init(lo, n_img);
     int img0, r0;
-    tile_origin<LO>(blockIdx.x, img0, r0);
+    tile_origin<LO, PX>(blockIdx.x, img0, r0);
     pl.set_tile(img0, r0, blockIdx.x < n_tiles);
     pl.issue_all();
 
@@ -431,12 +514,12 @@ __global__ __launch_bounds__(256, 1) void up32_kernel(const float *__restrict__ 
     }
 
     // patch origin is lo (r0-1, -1); tap (ty,tx) of class (py,px) reads lo (r + py - ty, c + px - tx)
-    int aoff[4];
-    unsigned orel[4];                                            // output byte offset of this lane's pixel in M-tile mt
+    int aoff[MT];
+    unsigned orel[MT];                                            // output byte offset of this lane's pixel in M-tile mt
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
         int img, r, c;
-        tile_pixel<LO>(mt * 32 + rc, img, r, c);
+        tile_pixel<LO, PX>(mt * 32 + rc, img, r, c);
         aoff[mt] = ((img * PR + r + 1 + py) * PC + c + 1 + px) * PS + half * 4;
         orel[mt] = (unsigned)(((img * HI + 2 * r + py) * HI + 2 * c + px) * PIXB + half * 16);
     }
@@ -452,22 +535,22 @@ __global__ __launch_bounds__(256, 1) void up32_kernel(const float *__restrict__ 
 
     STAMP(1);
     float4 dummy;
-    f32x16 prev[4];                                              // previous tile's accumulators, stored during this tile
-    float4 gq[16];                                               // its gate values (loaded while it was computed), or
-    unsigned gqb[4] = {0, 0, 0, 0}, pbits[4] = {0, 0, 0, 0};     // its gate bits per 32-pixel tile / the sign bits being collected
+    f32x16 prev[MT];                                              // previous tile's accumulators, stored during this tile
+    float4 gq[4 * MT];                                               // its gate values (loaded while it was computed), or
+    unsigned gqb[MT] = {}, pbits[MT] = {};     // its gate bits per 32-pixel tile / the sign bits being collected
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) prev[mt][i] = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) gq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < 4 * MT; ++i) gq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     unsigned prev_base = OOB;                                    // out of range: the first tile's "previous" stores are dropped
     STAMP(2);
     int sidx = 3;
     (void)sidx;
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        tile_origin<LO>(tile, img0, r0);
+        tile_origin<LO, PX>(tile, img0, r0);
         STAMP(sidx);
         __syncthreads();
         STAMP(sidx + 1);
@@ -476,35 +559,38 @@ __global__ __launch_bounds__(256, 1) void up32_kernel(const float *__restrict__ 
         STAMP(sidx + 2);
         {
             int ni, nr;
-            tile_origin<LO>(tile + gridDim.x, ni, nr);
+            tile_origin<LO, PX>(tile + gridDim.x, ni, nr);
             pl.set_tile(ni, nr, tile + gridDim.x < n_tiles);
         }
         STAMP(sidx + 3);
 
         const unsigned obase = (unsigned)(((img0 * HI + 2 * r0) * HI) * PIXB);
-        f32x16 acc[4];
+        f32x16 acc[MT];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
         static_for<0, 16>([&](auto sc) __attribute__((always_inline)) {
             constexpr int step = decltype(sc)::value, ty = step >> 3, tx = (step >> 2) & 1, ch = step & 3;
             constexpr int toff = -(ty * PC + tx) * PS + ch * 8;
-            float4 a[4];
+            float4 a[MT];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const float4 *>(lds + aoff[mt] + toff);
+            for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const float4 *>(lds + aoff[mt] + toff);
             pl.template issue_step<16, step>();
             __builtin_amdgcn_sched_barrier(0);
-            static_for<0, 4>([&](auto mc) __attribute__((always_inline)) {
+            static_for<0, MT>([&](auto mc) __attribute__((always_inline)) {
                 constexpr int mt = decltype(mc)::value;
-                if (wave == mt) {                                // this wave's quarter of the step
-                    constexpr int em = step >> 2, eg = step & 3; // previous tile: 32-pixel tile em, channel group eg
+                // epilogue slots: one per MFMA quad, 16 * MT per tile; wave w owns every fourth and walks the 4 * MT
+                // (32-pixel tile em, channel group eg) pieces of the previous tile through them
+                constexpr int slot = step * MT + mt;
+                if (wave == (slot & 3)) {
+                    constexpr int k = slot >> 2, em = k >> 2, eg = k & 3;
                     const unsigned poff = prev_base + orel[em];
                     if (eg == 0) pbits[em] = 0;
-                    pbits[em] |= store_group<MODE>(prev[em], eg, b4[eg], gq[step], gqb[em], rs_out, poff);
+                    pbits[em] |= store_group<MODE>(prev[em], eg, b4[eg], gq[k], gqb[em], rs_out, poff);
                     if (MODE == EP_RELU && eg == 3 && want_bits)
                         buf_store_u16(pbits[em], rs_bits, prev_base == OOB ? OOB : bits_off(poff, half));
-                    if (MODE == EP_GATE_F) gq[step] = buf_load4(rs_gate, obase + orel[em] + eg * 32);
+                    if (MODE == EP_GATE_F) gq[k] = buf_load4(rs_gate, obase + orel[em] + eg * 32);
                     if (MODE == EP_GATE_B && eg == 3) gqb[em] = buf_load_u16(rs_bits, bits_off(obase + orel[em], half));
                 }
                 MFMA4(acc[mt], a[mt], w[ty][tx][ch])
@@ -513,14 +599,14 @@ __global__ __launch_bounds__(256, 1) void up32_kernel(const float *__restrict__ 
         });
         STAMP(sidx + 4);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) prev[mt] = acc[mt];
+        for (int mt = 0; mt < MT; ++mt) prev[mt] = acc[mt];
         prev_base = obase;
         STAMP(sidx + 5);
         sidx += 6;
     }
     // the last tile's epilogue has nothing to hide behind
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
         const unsigned poff = prev_base + orel[mt];
         unsigned bits = 0;
 #pragma unroll
@@ -539,12 +625,13 @@ __global__ __launch_bounds__(256, 1) void up32_kernel(const float *__restrict__ 
 // ================================================================================================
 constexpr int WG32_SLAB = SLAB_C32_FLOATS;
 
-template <int LO, int BIAS>
+template <int LO, int BIAS, int PX = 128>
 __global__ __launch_bounds__(256, 1) void wgrad32_kernel(const float *__restrict__ lo, const float *__restrict__ hi, float *__restrict__ slab, int n_img,
                                                           int n_tiles) {
-    using PL = PatchLoader<LO, 2>;
+    using PL = PatchLoader<LO, 2, PX>;
+    constexpr int STEPS = PX / 2, LSLOTS = PX / 32;              // MFMA k-steps per tile; lo-tile load slots per thread
     constexpr int PC = PL::PC, PR = PL::PR;
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // hi patch | lo tile [128][PS]
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // hi patch | lo tile [PX][PS]
     float *lo_t = lds + PL::PATCH_FLOATS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int half = lane >> 5, rc = lane & 31;
@@ -560,10 +647,10 @@ __global__ __launch_bounds__(256, 1) void wgrad32_kernel(const float *__restrict
 
     PL pl;
     pl.init(hi, n_img);
-    // lo tile: 128 contiguous pixels x 8 float4 = 4 slots per thread
+    // lo tile: PX contiguous pixels x 8 float4 = PX / 32 slots per thread
     const int64_t lo_bytes = (int64_t)n_img * LO * LO * PIXB;
     const __amdgpu_buffer_rsrc_t rs_lo = make_rsrc(lo, lo_bytes);
-    float4 lr[4];
+    float4 lr[LSLOTS];
     unsigned lo_base = 0;
     auto issue_lo = [&](int it) {
         lr[it] = buf_load4(rs_lo, lo_base + it * 4096);
@@ -572,12 +659,12 @@ __global__ __launch_bounds__(256, 1) void wgrad32_kernel(const float *__restrict
         lo_base = ok ? (unsigned)(((i0 * LO + rr0) * LO) * PIXB) + threadIdx.x * 16 : OOB;
     };
     int img0, r0;
-    tile_origin<LO>(blockIdx.x, img0, r0);
+    tile_origin<LO, PX>(blockIdx.x, img0, r0);
     pl.set_tile(img0, r0, blockIdx.x < n_tiles);
     set_lo(img0, r0, blockIdx.x < n_tiles);
     pl.issue_all();
 #pragma unroll
-    for (int it = 0; it < 4; ++it) issue_lo(it);
+    for (int it = 0; it < LSLOTS; ++it) issue_lo(it);
     STAMP(1);
     STAMP(2);
     int sidx = 3;
@@ -589,7 +676,7 @@ __global__ __launch_bounds__(256, 1) void wgrad32_kernel(const float *__restrict
         STAMP(sidx + 1);
         pl.template commit<BIAS == 2>(lds, hi_sum);
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
+        for (int it = 0; it < LSLOTS; ++it) {
             const int idx = threadIdx.x + it * 256;
             *reinterpret_cast<float4 *>(lo_t + (idx >> 3) * PS + (idx & 7) * 4) = lr[it];
         }
@@ -597,21 +684,21 @@ __global__ __launch_bounds__(256, 1) void wgrad32_kernel(const float *__restrict
         STAMP(sidx + 2);
         {
             int ni, nr;
-            tile_origin<LO>(tile + gridDim.x, ni, nr);
+            tile_origin<LO, PX>(tile + gridDim.x, ni, nr);
             pl.set_tile(ni, nr, tile + gridDim.x < n_tiles);
             set_lo(ni, nr, tile + gridDim.x < n_tiles);
         }
         STAMP(sidx + 3);
 
-        static_for<0, 64>([&](auto sc) __attribute__((always_inline)) {
+        static_for<0, STEPS>([&](auto sc) __attribute__((always_inline)) {
             // k-pair s covers lo pixels 2s and 2s+1 (adjacent columns of one row); this lane takes 2s+half
             constexpr int s = decltype(sc)::value;
             int img = 0, r = 0, c = 0;
-            tile_pixel<LO>(2 * s, img, r, c);
+            tile_pixel<LO, PX>(2 * s, img, r, c);
             const float lv = lo_t[(2 * s + half) * PS + rc];
             if (BIAS == 1) lo_sum += lv;
             const int boff = ((img * PR + 2 * r + wave) * PC + 2 * (c + half)) * PS + rc;
-            pl.template issue_step<64, s>();
+            pl.template issue_step<STEPS, s>();
             if constexpr ((s & 15) == 8) issue_lo(s >> 4);
 #pragma unroll
             for (int kx = 0; kx < 4; ++kx)               // A row = chi, B column = clo
@@ -666,8 +753,9 @@ static int cu_count() {
     return n;
 }
 
-template <int LO> static constexpr int tiles_for(int n) {
-    return Tile<LO>::TI == 1 ? n * (LO / Tile<LO>::TR) : (n + Tile<LO>::TI - 1) / Tile<LO>::TI;
+template <int LO, int PX = 128> static constexpr int tiles_for(int n) {
+    using T = Tile<LO, PX>;
+    return T::TI == 1 ? n * (LO / T::TR) : (n + T::TI - 1) / T::TI;
 }
 static int grid_for_tiles(int tiles) { return tiles < cu_count() ? tiles : cu_count(); }
 
@@ -684,20 +772,43 @@ template <class K> static void allow_lds(K kernel, int bytes) {
 template <int A, int B> struct MaxOf { static constexpr int value = A > B ? A : B; };
 
 template <int LO, int MODE>
+static void launch_down_small(const Operand &hi, const float *wt, const Ep32 &ep, int n, hipStream_t s) {
+    constexpr int LDS = (PatchLoader<LO, 2, 32>::PATCH_FLOATS + 4 * 16 * 64) * 4;
+    const int tiles = tiles_for<LO, 32>(n);
+    const int grid = tiles < 2 * cu_count() ? tiles : 2 * cu_count();
+    static bool attr = false;
+    if (!attr) { allow_lds(down32s_kernel<LO, MODE>, LDS); attr = true; }
+    prof_gap();
+    hipLaunchKernelGGL((down32s_kernel<LO, MODE>), dim3(grid), dim3(256), LDS, s, hi.v, wt, ep, n, tiles);
+}
+template <int LO, int MODE>
 static void launch_down_v(int grid, const Operand &hi, const float *wt, const Ep32 &ep, int n, int tiles, hipStream_t s) {
+    static const bool small_ok = getenv("ARVAE_NO_SMALL_TILES") == nullptr;     // diagnostic switch
+    // (the 8x8 layers measured 2 us slower on this variant than on one full-K tile per CU)
+    if (LO == 4 && small_ok && 2 * tiles <= cu_count()) return launch_down_small<4, MODE>(hi, wt, ep, n, s);
     constexpr int LDS = MaxOf<PatchLoader<LO, 2>::PATCH_FLOATS, WSTAGE_DOWN>::value * 4;
     static bool attr = false;
     if (!attr) { allow_lds(down32_kernel<LO, MODE>, LDS); attr = true; }
     prof_gap();
     hipLaunchKernelGGL((down32_kernel<LO, MODE>), dim3(grid), dim3(256), LDS, s, hi.v, wt, ep, n, tiles);
 }
-template <int LO, int MODE>
-static void launch_up_v(int grid, const Operand &lo, const float *wt, const Ep32 &ep, int n, int tiles, hipStream_t s) {
-    constexpr int LDS = MaxOf<PatchLoader<LO, 1>::PATCH_FLOATS, WSTAGE_UP>::value * 4;
+template <int LO, int MODE, int PX>
+static void launch_up_px(const Operand &lo, const float *wt, const Ep32 &ep, int n, hipStream_t s) {
+    constexpr int LDS = MaxOf<PatchLoader<LO, 1, PX>::PATCH_FLOATS, WSTAGE_UP>::value * 4;
+    const int tiles = tiles_for<LO, PX>(n), grid = grid_for_tiles(tiles);
     static bool attr = false;
-    if (!attr) { allow_lds(up32_kernel<LO, MODE>, LDS); attr = true; }
+    if (!attr) { allow_lds(up32_kernel<LO, MODE, PX>, LDS); attr = true; }
     prof_gap();
-    hipLaunchKernelGGL((up32_kernel<LO, MODE>), dim3(grid), dim3(256), LDS, s, lo.v, wt, ep, n, tiles);
+    hipLaunchKernelGGL((up32_kernel<LO, MODE, PX>), dim3(grid), dim3(256), LDS, s, lo.v, wt, ep, n, tiles);
+}
+// 128-pixel tiles, or 32-pixel tiles when the former give a CU at most one tile (nothing to pipeline, or idle CUs:
+// the 8x8 and 4x4 layers at batch 512)
+template <int LO, int MODE>
+static void launch_up_v(int, const Operand &lo, const float *wt, const Ep32 &ep, int n, int, hipStream_t s) {
+    static const bool small_ok = getenv("ARVAE_NO_SMALL_TILES") == nullptr;     // diagnostic switch
+    if (LO == 4 && small_ok && 2 * tiles_for<LO, 128>(n) <= cu_count()) launch_up_px<4, MODE, 32>(lo, wt, ep, n, s);
+    else if (LO == 8 && small_ok && tiles_for<LO, 128>(n) <= cu_count()) launch_up_px<8, MODE, 32>(lo, wt, ep, n, s);
+    else launch_up_px<LO, MODE, 128>(lo, wt, ep, n, s);
 }
 
 static int ep_mode(const Ep32 &ep, int relu) {
@@ -748,36 +859,52 @@ int conv32_up(const arvae_link_t *l, const Operand &lo, const float *wt, const f
     }
 }
 
+// pixels per tile of the weight-gradient kernel: 128, or 64 for a 4x4 layer whose 128-pixel tiles would leave three
+// quarters of the CUs idle (64 halves the kernel at the price of twice the slabs to reduce; 32 measured no better)
+static int wgrad_px(const arvae_link_t *l) {
+    static const int forced = getenv("ARVAE_WG4_PX") != nullptr ? atoi(getenv("ARVAE_WG4_PX")) : 0;
+    if (l->lh != 4 || 2 * tiles_for<4, 128>(l->n) > cu_count()) return 128;
+    return forced == 32 || forced == 64 || forced == 128 ? forced : 64;
+}
+
 int conv32_wgrad_groups(const arvae_link_t *l) {
     int tiles;
     switch (l->lh) {
         case 16: tiles = tiles_for<16>(l->n); break;
         case 8: tiles = tiles_for<8>(l->n); break;
-        default: tiles = tiles_for<4>(l->n); break;
+        default: {
+            const int px = wgrad_px(l);
+            tiles = px == 32 ? tiles_for<4, 32>(l->n) : px == 64 ? tiles_for<4, 64>(l->n) : tiles_for<4>(l->n);
+            break;
+        }
     }
     return grid_for_tiles(tiles);          // one persistent workgroup per CU: one 64 KB partial each
 }
 
-int64_t conv32_wgrad_ws_floats(const arvae_link_t *l) { return (int64_t)conv32_wgrad_groups(l) * WG32_SLAB; }
+int64_t conv32_wgrad_ws_floats(const arvae_link_t *l) {
+    // sized for the smallest tile the 4x4 layers may use, so that the experiment switch cannot overrun the slab
+    const int64_t groups = l->lh == 4 ? grid_for_tiles(tiles_for<4, 32>(l->n)) : conv32_wgrad_groups(l);
+    return groups * WG32_SLAB;
+}
 
-template <int LO> static int launch_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *slab, int bias_mode,
-                                          int grid, hipStream_t s) {
-    constexpr int LDS = (PatchLoader<LO, 2>::PATCH_FLOATS + 128 * PS) * 4;
-    const int tiles = tiles_for<LO>(l->n);
+template <int LO, int PX> static int launch_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *slab, int bias_mode,
+                                                  int grid, hipStream_t s) {
+    constexpr int LDS = (PatchLoader<LO, 2, PX>::PATCH_FLOATS + PX * PS) * 4;
+    const int tiles = tiles_for<LO, PX>(l->n);
     static bool attr = false;
     if (!attr) {
-        allow_lds(wgrad32_kernel<LO, 0>, LDS);
-        allow_lds(wgrad32_kernel<LO, 1>, LDS);
-        allow_lds(wgrad32_kernel<LO, 2>, LDS);
+        allow_lds(wgrad32_kernel<LO, 0, PX>, LDS);
+        allow_lds(wgrad32_kernel<LO, 1, PX>, LDS);
+        allow_lds(wgrad32_kernel<LO, 2, PX>, LDS);
         attr = true;
     }
     prof_gap();
     if (bias_mode == 1)
-        hipLaunchKernelGGL((wgrad32_kernel<LO, 1>), dim3(grid), dim3(256), LDS, s, lo.v, hi.v, slab, l->n, tiles);
+        hipLaunchKernelGGL((wgrad32_kernel<LO, 1, PX>), dim3(grid), dim3(256), LDS, s, lo.v, hi.v, slab, l->n, tiles);
     else if (bias_mode == 2)
-        hipLaunchKernelGGL((wgrad32_kernel<LO, 2>), dim3(grid), dim3(256), LDS, s, lo.v, hi.v, slab, l->n, tiles);
+        hipLaunchKernelGGL((wgrad32_kernel<LO, 2, PX>), dim3(grid), dim3(256), LDS, s, lo.v, hi.v, slab, l->n, tiles);
     else
-        hipLaunchKernelGGL((wgrad32_kernel<LO, 0>), dim3(grid), dim3(256), LDS, s, lo.v, hi.v, slab, l->n, tiles);
+        hipLaunchKernelGGL((wgrad32_kernel<LO, 0, PX>), dim3(grid), dim3(256), LDS, s, lo.v, hi.v, slab, l->n, tiles);
     return check_launch(LO == 16 ? "wgrad32_kernel<16>" : LO == 8 ? "wgrad32_kernel<8>" : "wgrad32_kernel<4>");
 }
 
@@ -788,9 +915,15 @@ int conv32_wgrad_partial(const arvae_link_t *l, const Operand &lo, const Operand
     const int grid = conv32_wgrad_groups(l);
     int rc;
     switch (l->lh) {
-        case 16: rc = launch_wgrad<16>(l, lo, hi, slab, bias_mode, grid, s); break;
-        case 8: rc = launch_wgrad<8>(l, lo, hi, slab, bias_mode, grid, s); break;
-        default: rc = launch_wgrad<4>(l, lo, hi, slab, bias_mode, grid, s); break;
+        case 16: rc = launch_wgrad<16, 128>(l, lo, hi, slab, bias_mode, grid, s); break;
+        case 8: rc = launch_wgrad<8, 128>(l, lo, hi, slab, bias_mode, grid, s); break;
+        default: {
+            const int px = wgrad_px(l);
+            rc = px == 32 ? launch_wgrad<4, 32>(l, lo, hi, slab, bias_mode, grid, s)
+                          : px == 64 ? launch_wgrad<4, 64>(l, lo, hi, slab, bias_mode, grid, s)
+                                     : launch_wgrad<4, 128>(l, lo, hi, slab, bias_mode, grid, s);
+            break;
+        }
     }
     *job = SlabJob{slab, dwt, bias_mode ? dbias : nullptr, grid, SLAB_C32, bias_mode};
     return rc;
