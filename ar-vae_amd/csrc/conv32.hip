@@ -916,7 +916,7 @@ int conv32_wgrad_partial(const arvae_link_t *l, const Operand &lo, const Operand
     int rc;
     switch (l->lh) {
         case 16: rc = launch_wgrad<16, 128>(l, lo, hi, slab, bias_mode, grid, s); break;
-        case 8: rc = launch_wgrad<8, 128>(l, lo, hi, slab, bias_mode, grid, s); break;
+        case 8: rc = launch_wgrad<8, 128>(l, lo, hi, slab, bias_mode, grid, s); break;   // 64-pixel tiles: no gain here
         default: {
             const int px = wgrad_px(l);
             rc = px == 32 ? launch_wgrad<4, 32>(l, lo, hi, slab, bias_mode, grid, s)

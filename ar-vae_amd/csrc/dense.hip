@@ -88,9 +88,13 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_fwd_kernel(DenseArgs p) {
 __global__ __launch_bounds__(DENSE_THREADS) void dense_dgrad_kernel(DenseArgs p) {
     __shared__ float red[NW * 16 * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, rc = lane & 31;
-    const int m = blockIdx.x * 32 + rc, km = blockIdx.y * 32 + rc;      // km = memory column of dX
-    const bool mok = m < p.batch, kok = km < p.n_in;
-    const int kf = kok ? p.in_perm.to_feat(km) : 0;
+    // A tile owns 32 consecutive input FEATURES (columns of W, read coalesced in the reduction loop); with a channel
+    // permutation their dX columns are scattered, which costs one strided store per lane instead of a strided weight
+    // gather per reduction step.
+    const int m = blockIdx.x * 32 + rc, kfl = blockIdx.y * 32 + rc;
+    const bool mok = m < p.batch, kok = kfl < p.n_in;
+    const int kf = kok ? kfl : 0;
+    const int km = p.in_perm.to_mem(kf);                                 // memory column of dX
     const bool vec = (p.n_out & 3) == 0;
     const int64_t grow = (int64_t)(mok ? m : 0) * p.n_out;
     f32x16 acc;
