@@ -1,6 +1,9 @@
 """Parity of the HIP path (through the C-ABI) against the CPU oracle and the reference goldens.
 Needs a real MI355X: run with `pytest -m gpu`."""
+import json
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -475,6 +478,31 @@ def test_full_batch_properties(dev):
     _, g3 = _full_batch_grads(dev, 3.0)
     assert np.isfinite(l1) and float(g1.abs().max()) > 0
     close(g3, 3.0 * g1, rtol=2e-5, atol=1e-6 * float(g1.abs().max()))
+
+
+def test_split_bf16_experiment_keeps_loss_parity(dev):
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    """ARVAE_CONV32_BF16X2=1 (experimental split-bf16 MFMA for the Down kernels): the north-star outputs stay within 1e-4."""
+    code = (
+        "import sys, json; sys.path.insert(0, %r)\n"
+        "import numpy as np, torch\n"
+        "from tests.test_hip_parity import run_hip_image_step\n"
+        "from arvae_amd import synthetic as syn\n"
+        "from oracle import image_vae as o_vae\n"
+        "state = syn.synth_state(o_vae.DSPRITES_SHAPES, 9, 1.6)\n"
+        "x, lab = syn.dsprites_batch(64, seed=5); eps = syn.normal_noise((64, 10), seed=6)\n"
+        "got = run_hip_image_step(torch.device('cuda:0'), 'dsprites', state, x, lab, eps, 4.0, 0.0, 'bernoulli', None)\n"
+        "print(json.dumps({'loss': got['loss'], **got['terms']}))\n" % ROOT)
+    env = dict(os.environ, ARVAE_CONV32_BF16X2='1')
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    state = syn.synth_state(o_vae.DSPRITES_SHAPES, 9, 1.6)
+    x, lab = syn.dsprites_batch(64, seed=5)
+    eps = syn.normal_noise((64, 10), seed=6)
+    ref = o_step.image_step('dsprites', state, x, lab, eps, (1, 2, 3, 4, 5), 4.0, 10.0, 1.0)
+    for k in ('recons', 'dist', 'reg', 'loss'):
+        close(got[k], float(ref['terms'][k]), rtol=1e-4)
 
 
 # ---------------------------------------------------------------- MeasureVAE (G6 / G7)
