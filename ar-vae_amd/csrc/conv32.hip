@@ -114,6 +114,16 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned &hi, uns
     mid = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2v));
 }
 
+// three-term version: x = hi + mid + lo with a residual <= 2^-26 |x| (exact for all but the last bit or two of x)
+__device__ __forceinline__ void split_pair3(float x0, float x1, unsigned &hi, unsigned &mid, unsigned &lo) {
+    const f32x2v x = {x0, x1};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2v));
+    const f32x2v r = {x0 - __builtin_bit_cast(float, hi << 16), x1 - __builtin_bit_cast(float, hi & 0xffff0000u)};
+    mid = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2v));
+    const f32x2v q = {r.x - __builtin_bit_cast(float, mid << 16), r.y - __builtin_bit_cast(float, mid & 0xffff0000u)};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(q, bf16x2v));
+}
+
 // byte offset of a lane's (pixel, half) entry in a relu_bits16 array, from its byte offset pixel*128 + half*16
 __device__ __forceinline__ unsigned bits_off(unsigned out_off, int half) { return (out_off >> 7) * 4 + half * 2; }
 
@@ -195,6 +205,22 @@ struct PatchLoader {
                 split_pair(r[it].z, r[it].w, hv.y, mv.y);
                 *reinterpret_cast<uint2 *>(planes + pix * PSB + q * 2) = hv;
                 *reinterpret_cast<uint2 *>(planes + PLANE_DW + pix * PSB + q * 2) = mv;
+            }
+        }
+    }
+    // three planes (hi, mid, lo): the exact split used by the fp32-accurate bf16 kernels
+    __device__ __forceinline__ void commit_split3(unsigned *planes) const {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int idx = threadIdx.x + it * 256;
+            if (idx < SLOTS) {
+                const int q = idx & 7, pix = idx >> 3;
+                uint2 hv, mv, lv;
+                split_pair3(r[it].x, r[it].y, hv.x, mv.x, lv.x);
+                split_pair3(r[it].z, r[it].w, hv.y, mv.y, lv.y);
+                *reinterpret_cast<uint2 *>(planes + pix * PSB + q * 2) = hv;
+                *reinterpret_cast<uint2 *>(planes + PLANE_DW + pix * PSB + q * 2) = mv;
+                *reinterpret_cast<uint2 *>(planes + 2 * PLANE_DW + pix * PSB + q * 2) = lv;
             }
         }
     }
@@ -777,6 +803,168 @@ __global__ __launch_bounds__(256, 1) void up32_kernel(const float *__restrict__ 
 }
 
 // ================================================================================================
+// Up on the bf16 MFMA at fp32 accuracy: every fp32 operand is split into THREE bf16 numbers (hi + mid + lo, exact to
+// 2^-26) and a product is the six partial products of weight >= 2^-18, accumulated in fp32 smallest first -- the
+// result differs from the fp32 MFMA's by less than one fp32 rounding of the sum, so the parity bars do not move --
+// at 6 x 32 cycles per 16 channels instead of 8 x 64 (2.7x fewer MFMA cycles).  Same tiling, loader, staggered
+// epilogue and gating as up32_kernel; 64 weights x 3 terms live in 96 registers.
+__device__ __forceinline__ void split8x3(const float (&x)[8], bf16x8 &hi, bf16x8 &mid, bf16x8 &lo) {
+    i32x4v h, m, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned a, b, c;
+        split_pair3(x[2 * j], x[2 * j + 1], a, b, c);
+        h[j] = (int)a; m[j] = (int)b; l[j] = (int)c;
+    }
+    hi = __builtin_bit_cast(bf16x8, h); mid = __builtin_bit_cast(bf16x8, m); lo = __builtin_bit_cast(bf16x8, l);
+}
+#define MFMA_B(ACC, W, A) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W, A, ACC, 0, 0, 0)
+
+template <int LO, int MODE, int PX = 128>
+__global__ __launch_bounds__(256, 1) void up32x_kernel(const float *__restrict__ lo, const float *__restrict__ wt, Ep32 ep,
+                                                        int n_img, int n_tiles) {
+    using PL = PatchLoader<LO, 1, PX>;
+    constexpr int MT = PX / 32;
+    constexpr int HI = 2 * LO, PC = PL::PC, PR = PL::PR, PLANE = PL::PLANE_DW;
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // max(3 planes, WSTAGE_UP floats)
+    unsigned *ldsw = reinterpret_cast<unsigned *>(lds);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, rc = lane & 31;
+    const int py = wave >> 1, px = wave & 1;
+    const int ky0 = 1 - py, kx0 = 1 - px;
+
+    PL pl;                                                       // first tile's loads fly while the weights are staged
+    pl.init(lo, n_img);
+    int img0, r0;
+    tile_origin<LO, PX>(blockIdx.x, img0, r0);
+    pl.set_tile(img0, r0, blockIdx.x < n_tiles);
+    pl.issue_all();
+
+    // w3[ty][tx][c][term]: the 8 input channels c*16 + half*8 + j of wt[.][chi = rc][ky0 + 2ty][kx0 + 2tx], split in three
+    bf16x8 w3[2][2][2][3];
+    {
+        float4 v[16];
+        load_weights(wt, v);
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int idx4 = threadIdx.x + it * 256;             // row (clo*32 + chi) = idx4 >> 2, taps 4*(idx4 & 3)..+3
+            float *d = lds + (idx4 >> 2) * WROW_UP + (idx4 & 3) * 4;
+            d[0] = v[it].x; d[1] = v[it].y; d[2] = v[it].z; d[3] = v[it].w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ty = 0; ty < 2; ++ty)
+#pragma unroll
+            for (int tx = 0; tx < 2; ++tx)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    float x[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        x[j] = lds[((c * 16 + half * 8 + j) * C32 + rc) * WROW_UP + (ky0 + 2 * ty) * 4 + kx0 + 2 * tx];
+                    split8x3(x, w3[ty][tx][c][0], w3[ty][tx][c][1], w3[ty][tx][c][2]);
+                }
+    }
+
+    // patch origin is lo (r0-1, -1); tap (ty,tx) of class (py,px) reads lo (r + py - ty, c + px - tx)
+    int aoff[MT];                                                 // dwords into a plane
+    unsigned orel[MT];                                            // output byte offset of this lane's pixel in M-tile mt
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int img, r, c;
+        tile_pixel<LO, PX>(mt * 32 + rc, img, r, c);
+        aoff[mt] = ((img * PR + r + 1 + py) * PC + c + 1 + px) * PSB + half * 4;
+        orel[mt] = (unsigned)(((img * HI + 2 * r + py) * HI + 2 * c + px) * PIXB + half * 16);
+    }
+    float4 b4[4];
+    load_bias4(ep.bias, half, b4);
+    const int64_t out_bytes = (int64_t)n_img * HI * HI * PIXB;
+    const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(ep.out, out_bytes);
+    const __amdgpu_buffer_rsrc_t rs_gate = make_rsrc(MODE == EP_GATE_F ? ep.gate : ep.out, out_bytes);
+    const bool want_bits = MODE == EP_RELU && ep.bits_out != nullptr;
+    const __amdgpu_buffer_rsrc_t rs_bits =
+        make_rsrc(MODE == EP_GATE_B ? (const void *)ep.gate_bits : want_bits ? (const void *)ep.bits_out : (const void *)ep.out,
+                  (int64_t)n_img * HI * HI * 4);
+
+    f32x16 prev[MT];                                              // previous tile's accumulators, stored during this tile
+    float4 gq[4 * MT];
+    unsigned gqb[MT] = {}, pbits[MT] = {};
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) prev[mt][i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4 * MT; ++i) gq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned prev_base = OOB;
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        tile_origin<LO, PX>(tile, img0, r0);
+        __syncthreads();
+        pl.commit_split3(ldsw);
+        __syncthreads();
+        {
+            int ni, nr;
+            tile_origin<LO, PX>(tile + gridDim.x, ni, nr);
+            pl.set_tile(ni, nr, tile + gridDim.x < n_tiles);
+        }
+        const unsigned obase = (unsigned)(((img0 * HI + 2 * r0) * HI) * PIXB);
+        f32x16 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+        static_for<0, 8>([&](auto sc) __attribute__((always_inline)) {
+            constexpr int step = decltype(sc)::value, ty = step >> 2, tx = (step >> 1) & 1, c = step & 1;
+            constexpr int toff = -(ty * PC + tx) * PSB + c * 8;
+            bf16x8 a[MT][3];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) a[mt][t] = lds_bf16x8(ldsw + t * PLANE + aoff[mt] + toff);
+            pl.template issue_step<8, step>();
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, 2 * MT>([&](auto mc) __attribute__((always_inline)) {
+                constexpr int grp = decltype(mc)::value / MT, mt = decltype(mc)::value % MT;
+                // epilogue slots: 16 * MT per tile (one per group of three MFMAs); wave w owns every fourth
+                constexpr int slot = (step * 2 + grp) * MT + mt;
+                if (wave == (slot & 3)) {
+                    constexpr int k = slot >> 2, em = k >> 2, eg = k & 3;
+                    const unsigned poff = prev_base + orel[em];
+                    if (eg == 0) pbits[em] = 0;
+                    pbits[em] |= store_group<MODE>(prev[em], eg, b4[eg], gq[k], gqb[em], rs_out, poff);
+                    if (MODE == EP_RELU && eg == 3 && want_bits)
+                        buf_store_u16(pbits[em], rs_bits, prev_base == OOB ? OOB : bits_off(poff, half));
+                    if (MODE == EP_GATE_F) gq[k] = buf_load4(rs_gate, obase + orel[em] + eg * 32);
+                    if (MODE == EP_GATE_B && eg == 3) gqb[em] = buf_load_u16(rs_bits, bits_off(obase + orel[em], half));
+                }
+                if constexpr (grp == 0) {                        // the three smallest partial products first
+                    MFMA_B(acc[mt], w3[ty][tx][c][2], a[mt][0]);
+                    MFMA_B(acc[mt], w3[ty][tx][c][0], a[mt][2]);
+                    MFMA_B(acc[mt], w3[ty][tx][c][1], a[mt][1]);
+                } else {
+                    MFMA_B(acc[mt], w3[ty][tx][c][1], a[mt][0]);
+                    MFMA_B(acc[mt], w3[ty][tx][c][0], a[mt][1]);
+                    MFMA_B(acc[mt], w3[ty][tx][c][0], a[mt][0]);
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) prev[mt] = acc[mt];
+        prev_base = obase;
+    }
+    // the last tile's epilogue has nothing to hide behind
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const unsigned poff = prev_base + orel[mt];
+        unsigned bits = 0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bits |= store_group<MODE>(prev[mt], g, b4[g], gq[mt * 4 + g], gqb[mt], rs_out, poff);
+        if (MODE == EP_RELU && want_bits) buf_store_u16(bits, rs_bits, prev_base == OOB ? OOB : bits_off(poff, half));
+    }
+}
+
+// ================================================================================================
 // Wgrad: dwt[clo][chi][ky][kx] += sum_{n,ly,lx} lo[n,ly,lx,clo] * hi[n,2ly-1+ky,2lx-1+kx,chi]
 // wave w = ky; acc[kx] = 32(chi) x 32(clo); pixels are the MFMA K axis (2 per instruction, 64 steps per tile).
 // slab layout per workgroup: [ky][kx][clo][chi] (16384 floats) + 32 bias sums.
@@ -967,8 +1155,17 @@ static void launch_down_v(int grid, const Operand &hi, const float *wt, const Ep
 }
 template <int LO, int MODE, int PX>
 static void launch_up_px(const Operand &lo, const float *wt, const Ep32 &ep, int n, hipStream_t s) {
-    constexpr int LDS = MaxOf<PatchLoader<LO, 1, PX>::PATCH_FLOATS, WSTAGE_UP>::value * 4;
     const int tiles = tiles_for<LO, PX>(n), grid = grid_for_tiles(tiles);
+    static const bool fp32_mfma = getenv("ARVAE_CONV32_FP32") != nullptr;       // the fp32 MFMA kernel instead of the 3-term bf16 one
+    if (!fp32_mfma) {
+        constexpr int LDSX = MaxOf<3 * PatchLoader<LO, 1, PX>::PLANE_DW, WSTAGE_UP>::value * 4;
+        static bool attrx = false;
+        if (!attrx) { allow_lds(up32x_kernel<LO, MODE, PX>, LDSX); attrx = true; }
+        prof_gap();
+        hipLaunchKernelGGL((up32x_kernel<LO, MODE, PX>), dim3(grid), dim3(256), LDSX, s, lo.v, wt, ep, n, tiles);
+        return;
+    }
+    constexpr int LDS = MaxOf<PatchLoader<LO, 1, PX>::PATCH_FLOATS, WSTAGE_UP>::value * 4;
     static bool attr = false;
     if (!attr) { allow_lds(up32_kernel<LO, MODE, PX>, LDS); attr = true; }
     prof_gap();
