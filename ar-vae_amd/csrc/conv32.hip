@@ -566,6 +566,137 @@ __global__ __launch_bounds__(256, 1) void down32b_kernel(const float *__restrict
     }
 }
 
+__device__ __forceinline__ void split8x3(const float (&x)[8], bf16x8 &hi, bf16x8 &mid, bf16x8 &lo) {
+    i32x4v h, m, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned a, b, c;
+        split_pair3(x[2 * j], x[2 * j + 1], a, b, c);
+        h[j] = (int)a; m[j] = (int)b; l[j] = (int)c;
+    }
+    hi = __builtin_bit_cast(bf16x8, h); mid = __builtin_bit_cast(bf16x8, m); lo = __builtin_bit_cast(bf16x8, l);
+}
+#define MFMA_B(ACC, W, A) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W, A, ACC, 0, 0, 0)
+
+// ================================================================================================
+// Down on the bf16 MFMA at fp32 accuracy (three-term split, six partial products: see up32x_kernel).  Three terms of a
+// full output column (256 weights) do not fit the register file, so K is split two ways here: a tile is 64 lo pixels,
+// wave w takes pixel half w >> 1 and kernel rows ky = 2 (w & 1), 2 (w & 1) + 1 (128 weights x 3 terms = 192 registers);
+// the odd wave hands its partial tile to the even one through LDS, which runs the epilogue.
+template <int LO, int MODE>
+__global__ __launch_bounds__(256, 1) void down32x_kernel(const float *__restrict__ hi, const float *__restrict__ wt, Ep32 ep,
+                                                         int n_img, int n_tiles) {
+    constexpr int PX = 64;
+    using PL = PatchLoader<LO, 2, PX>;
+    constexpr int PC = PL::PC, PR = PL::PR, PLANE = PL::PLANE_DW;
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // max(3 planes + red[2][16][64], WSTAGE_DOWN floats)
+    unsigned *ldsw = reinterpret_cast<unsigned *>(lds);
+    float *red = lds + 3 * PLANE;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, rc = lane & 31;
+    const int mtile = wave >> 1, kh = wave & 1;
+
+    PL pl;                                                       // first tile's loads fly while the weights are staged
+    pl.init(hi, n_img);
+    int img0, r0;
+    tile_origin<LO, PX>(blockIdx.x, img0, r0);
+    pl.set_tile(img0, r0, blockIdx.x < n_tiles);
+    pl.issue_all();
+
+    // w3[tap][c][term], tap = kyl*4 + kx with ky = 2*kh + kyl: channels c*16 + half*8 + j of wt[clo = rc][.][ky][kx]
+    bf16x8 w3[8][2][3];
+    {
+        float4 v[16];
+        load_weights(wt, v);
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int idx4 = threadIdx.x + it * 256;             // (clo, chi, tap/4) = (idx4 >> 7, (idx4 >> 2) & 31, idx4 & 3)
+            *reinterpret_cast<float4 *>(lds + (idx4 >> 7) * WROW_DOWN + (idx4 & 127) * 4) = v[it];
+        }
+        __syncthreads();
+        static_for<0, 4>([&](auto gc) __attribute__((always_inline)) {
+            constexpr int c = decltype(gc)::value >> 1, kyl = decltype(gc)::value & 1;
+            float x[4][8];                                       // [kx][j]
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float4 q = *reinterpret_cast<const float4 *>(lds + rc * WROW_DOWN + (c * 16 + half * 8 + j) * 16 +
+                                                                     (2 * kh + kyl) * 4);
+                x[0][j] = q.x; x[1][j] = q.y; x[2][j] = q.z; x[3][j] = q.w;
+            }
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx) split8x3(x[kx], w3[kyl * 4 + kx][c][0], w3[kyl * 4 + kx][c][1], w3[kyl * 4 + kx][c][2]);
+        });
+    }
+
+    int img, r, c;
+    tile_pixel<LO, PX>(mtile * 32 + rc, img, r, c);
+    const int aoff = ((img * PR + 2 * r + 2 * kh) * PC + 2 * c) * PSB + half * 4;     // dwords; + (kyl*PC + kx)*PSB + c*8
+    float4 b4[4];
+    load_bias4(ep.bias, half, b4);
+    const int64_t out_bytes = (int64_t)n_img * LO * LO * PIXB;
+    const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(ep.out, out_bytes);
+    const __amdgpu_buffer_rsrc_t rs_gate = make_rsrc(MODE == EP_GATE_F ? ep.gate : ep.out, out_bytes);
+    const bool want_bits = MODE == EP_RELU && ep.bits_out != nullptr;
+    const __amdgpu_buffer_rsrc_t rs_bits =
+        make_rsrc(MODE == EP_GATE_B ? (const void *)ep.gate_bits : want_bits ? (const void *)ep.bits_out : (const void *)ep.out,
+                  (int64_t)n_img * LO * LO * 4);
+    const unsigned out_lane = (unsigned)((mtile * 32 + rc) * PIXB + half * 16);
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        tile_origin<LO, PX>(tile, img0, r0);
+        __syncthreads();                                         // previous tile's planes and partials have been read
+        pl.commit_split3(ldsw);
+        __syncthreads();
+        {
+            int ni, nr;
+            tile_origin<LO, PX>(tile + gridDim.x, ni, nr);
+            pl.set_tile(ni, nr, tile + gridDim.x < n_tiles);
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        bf16x8 a[2][2][3];                                       // [tap parity][c][term]
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) a[0][cc][t] = lds_bf16x8(ldsw + t * PLANE + aoff + cc * 8);
+        static_for<0, 8>([&](auto tc) __attribute__((always_inline)) {
+            constexpr int tap = decltype(tc)::value;
+            if constexpr (tap + 1 < 8) {                         // next tap's operands are in flight during these 12 MFMAs
+                constexpr int kyl = (tap + 1) >> 2, kx = (tap + 1) & 3;
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+                        a[(tap + 1) & 1][cc][t] = lds_bf16x8(ldsw + t * PLANE + aoff + (kyl * PC + kx) * PSB + cc * 8);
+            }
+            pl.template issue_step<8, tap>();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {                     // smallest partial products first
+                MFMA_B(acc, w3[tap][cc][2], a[tap & 1][cc][0]);
+                MFMA_B(acc, w3[tap][cc][0], a[tap & 1][cc][2]);
+                MFMA_B(acc, w3[tap][cc][1], a[tap & 1][cc][1]);
+                MFMA_B(acc, w3[tap][cc][1], a[tap & 1][cc][0]);
+                MFMA_B(acc, w3[tap][cc][0], a[tap & 1][cc][1]);
+                MFMA_B(acc, w3[tap][cc][0], a[tap & 1][cc][0]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (kh == 1) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) red[(mtile * 16 + reg) * 64 + lane] = acc[reg];
+        }
+        __syncthreads();
+        if (kh == 0) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) acc[reg] += red[(mtile * 16 + reg) * 64 + lane];
+            store_pixel<MODE>(acc, b4, rs_out, rs_gate, rs_bits, want_bits,
+                              out_lane + (unsigned)(((img0 * LO + r0) * LO) * PIXB), half);
+        }
+    }
+}
+
 // ================================================================================================
 // Down, small-problem variant (4x4 / 8x8 layers at batch 512: too few 128-pixel tiles to fill or pipeline the CUs):
 // a tile is 32 lo pixels, wave w takes kernel row ky = w (K split 4 ways, 64 weights per lane straight from
@@ -808,18 +939,6 @@ __global__ __launch_bounds__(256, 1) void up32_kernel(const float *__restrict__ 
 // result differs from the fp32 MFMA's by less than one fp32 rounding of the sum, so the parity bars do not move --
 // at 6 x 32 cycles per 16 channels instead of 8 x 64 (2.7x fewer MFMA cycles).  Same tiling, loader, staggered
 // epilogue and gating as up32_kernel; 64 weights x 3 terms live in 96 registers.
-__device__ __forceinline__ void split8x3(const float (&x)[8], bf16x8 &hi, bf16x8 &mid, bf16x8 &lo) {
-    i32x4v h, m, l;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        unsigned a, b, c;
-        split_pair3(x[2 * j], x[2 * j + 1], a, b, c);
-        h[j] = (int)a; m[j] = (int)b; l[j] = (int)c;
-    }
-    hi = __builtin_bit_cast(bf16x8, h); mid = __builtin_bit_cast(bf16x8, m); lo = __builtin_bit_cast(bf16x8, l);
-}
-#define MFMA_B(ACC, W, A) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W, A, ACC, 0, 0, 0)
-
 template <int LO, int MODE, int PX = 128>
 __global__ __launch_bounds__(256, 1) void up32x_kernel(const float *__restrict__ lo, const float *__restrict__ wt, Ep32 ep,
                                                         int n_img, int n_tiles) {
@@ -1138,7 +1257,17 @@ static void launch_down_v(int grid, const Operand &hi, const float *wt, const Ep
     // (2^-17).  The loss terms and z stay within the 1e-4 parity bar, but ReLU units whose pre-activation is within
     // that error of zero flip, which moves per-tensor gradients by up to 5e-3 (3 products) / 1e-3 (4 products) relative
     // L2: not switched on while the gradient parity bar is 2e-3 against an fp32 oracle.
+    static const bool fp32_mfma = getenv("ARVAE_CONV32_FP32") != nullptr;
     static const bool split = getenv("ARVAE_CONV32_BF16X2") != nullptr;
+    if (!fp32_mfma && !split) {                                  // default: three-term bf16 at fp32 accuracy, 64-pixel tiles
+        constexpr int LDSX = MaxOf<3 * PatchLoader<LO, 2, 64>::PLANE_DW + 2 * 16 * 64, WSTAGE_DOWN>::value * 4;
+        const int tiles64 = tiles_for<LO, 64>(n);
+        static bool attrx = false;
+        if (!attrx) { allow_lds(down32x_kernel<LO, MODE>, LDSX); attrx = true; }
+        prof_gap();
+        hipLaunchKernelGGL((down32x_kernel<LO, MODE>), dim3(grid_for_tiles(tiles64)), dim3(256), LDSX, s, hi.v, wt, ep, n, tiles64);
+        return;
+    }
     if (split) {
         constexpr int LDSB = MaxOf<2 * PatchLoader<LO, 2>::PLANE_DW, WSTAGE_DOWN>::value * 4;
         static bool attrb = false;
