@@ -208,8 +208,9 @@ struct PatchLoader {
             }
         }
     }
-    // three planes (hi, mid, lo): the exact split used by the fp32-accurate bf16 kernels
-    __device__ __forceinline__ void commit_split3(unsigned *planes) const {
+    // three planes (hi, mid, lo): the exact split used by the fp32-accurate bf16 kernels; BIAS_SUM as in commit()
+    template <bool BIAS_SUM = false>
+    __device__ __forceinline__ void commit_split3(unsigned *planes, float4 *bsum = nullptr) const {
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             const int idx = threadIdx.x + it * 256;
@@ -221,6 +222,12 @@ struct PatchLoader {
                 *reinterpret_cast<uint2 *>(planes + pix * PSB + q * 2) = hv;
                 *reinterpret_cast<uint2 *>(planes + PLANE_DW + pix * PSB + q * 2) = mv;
                 *reinterpret_cast<uint2 *>(planes + 2 * PLANE_DW + pix * PSB + q * 2) = lv;
+                if (BIAS_SUM) {
+                    const int pc = pix % PC, pr = (pix / PC) % PR;
+                    if (pr >= 1 && pr <= PR - 2 && pc >= 1 && pc <= PC - 2) {
+                        bsum->x += r[it].x; bsum->y += r[it].y; bsum->z += r[it].z; bsum->w += r[it].w;
+                    }
+                }
             }
         }
     }
@@ -1204,6 +1211,140 @@ __global__ __launch_bounds__(256, 1) void wgrad32_kernel(const float *__restrict
     STAMP(63);
 }
 
+// ================================================================================================
+// Wgrad on the bf16 MFMA at fp32 accuracy (three-term split, six partial products).  Pixels are the K axis, 16 per
+// MFMA with 8 consecutive pixels per lane, but LDS holds [pixel][channel] images: the operands come in through
+// ds_read_b64_tr_b16, the transposing read (4 pixels x 16 channels per 16-lane group, two reads per operand).
+// Tile = 64 lo pixels (three planes of the hi patch fit LDS only at this size); wave = ky, 4 accumulator tiles (kx).
+typedef short s16x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 lds_tr_bf16x8(const unsigned *p0, const unsigned *p1) {
+    typedef __attribute__((address_space(3))) s16x4v *lds_ptr;
+    const s16x4v a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)p0);
+    const s16x4v b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)p1);
+    typedef short s16x8v __attribute__((ext_vector_type(8)));
+    const s16x8v v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int LO, int BIAS>
+__global__ __launch_bounds__(256, 1) void wgrad32x_kernel(const float *__restrict__ lo, const float *__restrict__ hi,
+                                                          float *__restrict__ slab, int n_img, int n_tiles) {
+    constexpr int PX = 64, KB = PX / 16;                         // pixels per tile, 16-pixel K blocks per tile
+    using PL = PatchLoader<LO, 2, PX>;
+    constexpr int PC = PL::PC, PR = PL::PR, PLANE = PL::PLANE_DW, LPLANE = PX * PSB;
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // hi patch: 3 planes | lo tile: 3 planes
+    unsigned *ldsw = reinterpret_cast<unsigned *>(lds);
+    unsigned *lo_w = ldsw + 3 * PLANE;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, rc = lane & 31;
+
+    // transposed-read addresses (dwords into a plane): 16-lane group g16 reads channels 16 (g16 & 1) .. +15 of the pixels
+    // 16 b + 8 (g16 >> 1) + 4 i + q; lane 4q + p of the group points at channels 4p .. 4p+3 of pixel row q
+    int loff[KB][2], hoff[KB][2];
+    {
+        const int g16 = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+#pragma unroll
+        for (int b = 0; b < KB; ++b)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int P = 16 * b + 8 * (g16 >> 1) + 4 * i + q;
+                int img, r, c;
+                tile_pixel<LO, PX>(P, img, r, c);
+                loff[b][i] = P * PSB + 8 * (g16 & 1) + 2 * pp;
+                hoff[b][i] = ((img * PR + 2 * r + wave) * PC + 2 * c) * PSB + 8 * (g16 & 1) + 2 * pp;      // + kx * PSB
+            }
+    }
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[kx][i] = 0.f;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);             // BIAS 1: lo sums, BIAS 2: hi sums, channels 4 (tid & 7) .. +3
+
+    PL pl;
+    pl.init(hi, n_img);
+    const int64_t lo_bytes = (int64_t)n_img * LO * LO * PIXB;
+    const __amdgpu_buffer_rsrc_t rs_lo = make_rsrc(lo, lo_bytes);
+    float4 lr[2];                                                // lo tile: 64 contiguous pixels x 8 float4 = 2 slots per thread
+    unsigned lo_base = 0;
+    auto set_lo = [&](int i0, int rr0, bool ok) {
+        lo_base = ok ? (unsigned)(((i0 * LO + rr0) * LO) * PIXB) + threadIdx.x * 16 : OOB;
+    };
+    int img0, r0;
+    tile_origin<LO, PX>(blockIdx.x, img0, r0);
+    pl.set_tile(img0, r0, blockIdx.x < n_tiles);
+    set_lo(img0, r0, blockIdx.x < n_tiles);
+    pl.issue_all();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) lr[it] = buf_load4(rs_lo, lo_base + it * 4096);
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        __syncthreads();
+        pl.template commit_split3<BIAS == 2>(ldsw, &bias4);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = threadIdx.x + it * 256, pix = idx >> 3, q = idx & 7;
+            uint2 hv, mv, lv;
+            split_pair3(lr[it].x, lr[it].y, hv.x, mv.x, lv.x);
+            split_pair3(lr[it].z, lr[it].w, hv.y, mv.y, lv.y);
+            *reinterpret_cast<uint2 *>(lo_w + pix * PSB + q * 2) = hv;
+            *reinterpret_cast<uint2 *>(lo_w + LPLANE + pix * PSB + q * 2) = mv;
+            *reinterpret_cast<uint2 *>(lo_w + 2 * LPLANE + pix * PSB + q * 2) = lv;
+            if (BIAS == 1) { bias4.x += lr[it].x; bias4.y += lr[it].y; bias4.z += lr[it].z; bias4.w += lr[it].w; }
+        }
+        __syncthreads();
+        {
+            int ni, nr;
+            tile_origin<LO, PX>(tile + gridDim.x, ni, nr);
+            pl.set_tile(ni, nr, tile + gridDim.x < n_tiles);
+            set_lo(ni, nr, tile + gridDim.x < n_tiles);
+        }
+        static_for<0, KB>([&](auto bc) __attribute__((always_inline)) {
+            constexpr int b = decltype(bc)::value;
+            bf16x8 b3[3];                                        // lo values: B operand, column = clo
+#pragma unroll
+            for (int t = 0; t < 3; ++t) b3[t] = lds_tr_bf16x8(lo_w + t * LPLANE + loff[b][0], lo_w + t * LPLANE + loff[b][1]);
+            pl.template issue_step<KB, b>();
+            if constexpr (b < 2) lr[b] = buf_load4(rs_lo, lo_base + b * 4096);
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx) {
+                bf16x8 a3[3];                                    // hi values at tap (ky = wave, kx): A operand, row = chi
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+                    a3[t] = lds_tr_bf16x8(ldsw + t * PLANE + hoff[b][0] + kx * PSB, ldsw + t * PLANE + hoff[b][1] + kx * PSB);
+                MFMA_B(acc[kx], a3[2], b3[0]);                   // smallest partial products first
+                MFMA_B(acc[kx], a3[0], b3[2]);
+                MFMA_B(acc[kx], a3[1], b3[1]);
+                MFMA_B(acc[kx], a3[1], b3[0]);
+                MFMA_B(acc[kx], a3[0], b3[1]);
+                MFMA_B(acc[kx], a3[0], b3[0]);
+            }
+        });
+    }
+
+    // partial results -> slab[blockIdx][ky][kx][clo = rc][chi = 8g + 4*half + j]: 16-byte stores
+    float *out = slab + (int64_t)blockIdx.x * WG32_SLAB;
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4 *>(out + ((wave * 4 + kx) * C32 + rc) * C32 + 8 * g + 4 * half) =
+                make_float4(acc[kx][4 * g], acc[kx][4 * g + 1], acc[kx][4 * g + 2], acc[kx][4 * g + 3]);
+    if (BIAS != 0) {
+        __syncthreads();
+        // every thread summed channel chunk q = threadIdx.x & 7 (slot stride 256 keeps q fixed)
+        *reinterpret_cast<float4 *>(lds + threadIdx.x * 4) = bias4;
+        __syncthreads();
+        if (threadIdx.x < C32) {
+            const int q = threadIdx.x >> 2, e = threadIdx.x & 3;
+            float tot = 0.f;
+            for (int j = 0; j < 32; ++j) tot += lds[(j * 8 + q) * 4 + e];
+            out[16 * C32 * C32 + threadIdx.x] = tot;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -1366,8 +1507,17 @@ static int wgrad_px(const arvae_link_t *l) {
     return forced == 32 || forced == 64 || forced == 128 ? forced : 64;
 }
 
+static bool wgrad_fp32_mfma() {
+    static const bool on = getenv("ARVAE_CONV32_FP32") != nullptr;
+    return on;
+}
+
 int conv32_wgrad_groups(const arvae_link_t *l) {
     int tiles;
+    if (!wgrad_fp32_mfma()) {                // three-term bf16 kernel: 64-pixel tiles for every size
+        tiles = l->lh == 16 ? tiles_for<16, 64>(l->n) : l->lh == 8 ? tiles_for<8, 64>(l->n) : tiles_for<4, 64>(l->n);
+        return grid_for_tiles(tiles);
+    }
     switch (l->lh) {
         case 16: tiles = tiles_for<16>(l->n); break;
         case 8: tiles = tiles_for<8>(l->n); break;
@@ -1407,12 +1557,40 @@ template <int LO, int PX> static int launch_wgrad(const arvae_link_t *l, const O
     return check_launch(LO == 16 ? "wgrad32_kernel<16>" : LO == 8 ? "wgrad32_kernel<8>" : "wgrad32_kernel<4>");
 }
 
+template <int LO> static int launch_wgrad_x(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *slab, int bias_mode,
+                                            int grid, hipStream_t s) {
+    constexpr int LDS = 3 * (PatchLoader<LO, 2, 64>::PLANE_DW + 64 * PSB) * 4;
+    const int tiles = tiles_for<LO, 64>(l->n);
+    static bool attr = false;
+    if (!attr) {
+        allow_lds(wgrad32x_kernel<LO, 0>, LDS);
+        allow_lds(wgrad32x_kernel<LO, 1>, LDS);
+        allow_lds(wgrad32x_kernel<LO, 2>, LDS);
+        attr = true;
+    }
+    prof_gap();
+    if (bias_mode == 1)
+        hipLaunchKernelGGL((wgrad32x_kernel<LO, 1>), dim3(grid), dim3(256), LDS, s, lo.v, hi.v, slab, l->n, tiles);
+    else if (bias_mode == 2)
+        hipLaunchKernelGGL((wgrad32x_kernel<LO, 2>), dim3(grid), dim3(256), LDS, s, lo.v, hi.v, slab, l->n, tiles);
+    else
+        hipLaunchKernelGGL((wgrad32x_kernel<LO, 0>), dim3(grid), dim3(256), LDS, s, lo.v, hi.v, slab, l->n, tiles);
+    return check_launch(LO == 16 ? "wgrad32_kernel<16>" : LO == 8 ? "wgrad32_kernel<8>" : "wgrad32_kernel<4>");
+}
+
 // per-workgroup partial sums into `slab`; the returned job describes the reduction that finishes the layer
 // bias_mode: 0 none, 1 dbias[clo] += sum lo, 2 dbias[chi] += sum hi
 int conv32_wgrad_partial(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *dwt, float *dbias, int bias_mode,
                          float *slab, hipStream_t s, SlabJob *job) {
     const int grid = conv32_wgrad_groups(l);
     int rc;
+    if (!wgrad_fp32_mfma()) {
+        rc = l->lh == 16 ? launch_wgrad_x<16>(l, lo, hi, slab, bias_mode, grid, s)
+                         : l->lh == 8 ? launch_wgrad_x<8>(l, lo, hi, slab, bias_mode, grid, s)
+                                      : launch_wgrad_x<4>(l, lo, hi, slab, bias_mode, grid, s);
+        *job = SlabJob{slab, dwt, bias_mode ? dbias : nullptr, grid, SLAB_C32, bias_mode};
+        return rc;
+    }
     switch (l->lh) {
         case 16: rc = launch_wgrad<16, 128>(l, lo, hi, slab, bias_mode, grid, s); break;
         case 8: rc = launch_wgrad<8, 128>(l, lo, hi, slab, bias_mode, grid, s); break;   // 64-pixel tiles: no gain here

@@ -432,7 +432,8 @@ def test_three_steps_track_oracle(dev, fused):
         cur, adam = ref['params'], ref['adam']
     close(got['loss'], ref['terms']['loss'], rtol=1e-4)
     for name in state:
-        close(got['params'][name], cur[name], rtol=0, atol=5e-6)
+        # Adam divides by sqrt(v): an entry whose gradient is ~0 turns a last-bit gradient difference into a visible step
+        close(got['params'][name], cur[name], rtol=0, atol=1e-5)
 
 
 @pytest.mark.parametrize('b', [3, 37, 130])
