@@ -82,6 +82,7 @@ struct Ep32 {
     const uint16_t *gate_bits;  // EP_GATE_B: the same as sign bits (common.h: relu_bits16)
     uint16_t *bits_out;         // EP_RELU: sign bits of the result for a later gated kernel, may be null
     float *out;
+    const uint4 *wprep;         // null, or this layer's weights already split and laid out per lane (conv32_weight_prep)
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, int64_t bytes) {
@@ -590,6 +591,51 @@ __device__ __forceinline__ void split8x3(const float (&x)[8], bf16x8 &hi, bf16x8
 // full output column (256 weights) do not fit the register file, so K is split two ways here: a tile is 64 lo pixels,
 // wave w takes pixel half w >> 1 and kernel rows ky = 2 (w & 1), 2 (w & 1) + 1 (128 weights x 3 terms = 192 registers);
 // the odd wave hands its partial tile to the even one through LDS, which runs the epilogue.
+// Per-layer prepared weights (conv32_weight_prep, once per training step): the three-term split of wt in the exact
+// per-lane register order of down32x_kernel and up32x_kernel, 16 bytes per (slot, lane) with lanes contiguous, so
+// that a kernel starts with 48 / 24 coalesced loads instead of staging and splitting the tensor itself.
+//   DOWN part: [kh 2][slot 48 = (tap 8, c 2, term 3)][lane 64]      UP part: [class 4][slot 24 = (ty, tx, c, term)][lane 64]
+constexpr int PREP_DOWN_SLOTS = 48, PREP_UP_SLOTS = 24;
+constexpr int PREP_DOWN_UINT4 = 2 * PREP_DOWN_SLOTS * 64, PREP_UP_UINT4 = 4 * PREP_UP_SLOTS * 64;
+constexpr int PREP_FLOATS = (PREP_DOWN_UINT4 + PREP_UP_UINT4) * 4;
+constexpr int PREP_MAX_LAYERS = 8;
+struct PrepArgs {
+    const float *wt[PREP_MAX_LAYERS];
+    uint4 *out[PREP_MAX_LAYERS];
+};
+
+// 16 workgroups per layer: items 0..2047 build the DOWN part, 2048..4095 the UP part; an item = 8 weights -> 3 x 16 bytes
+__global__ __launch_bounds__(256) void conv32_weight_prep_kernel(PrepArgs p) {
+    const int layer = blockIdx.x >> 4, item = (blockIdx.x & 15) * 256 + threadIdx.x;
+    const float *wt = nullptr;
+    uint4 *out = nullptr;
+#pragma unroll
+    for (int q = 0; q < PREP_MAX_LAYERS; ++q)                    // constant indices into the by-value argument block
+        if (q == layer) { wt = p.wt[q]; out = p.out[q]; }
+    const int lane = item & 63, half = lane >> 5, rc = lane & 31;
+    float x[8];
+    uint4 *dst;
+    if (item < 2048) {                                           // DOWN: (kh, tap = kyl*4 + kx, c)
+        const int c = (item >> 6) & 1, tap = (item >> 7) & 7, kh = item >> 10;
+        const int ky = 2 * kh + (tap >> 2), kx = tap & 3;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = wt[((rc * C32) + c * 16 + half * 8 + j) * 16 + ky * 4 + kx];
+        dst = out + (kh * PREP_DOWN_SLOTS + (tap * 2 + c) * 3) * 64 + lane;
+    } else {                                                     // UP: (class = wave, ty, tx, c)
+        const int u = item - 2048;
+        const int c = (u >> 6) & 1, tx = (u >> 7) & 1, ty = (u >> 8) & 1, cls = u >> 9;
+        const int ky = 1 - (cls >> 1) + 2 * ty, kx = 1 - (cls & 1) + 2 * tx;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = wt[((c * 16 + half * 8 + j) * C32 + rc) * 16 + ky * 4 + kx];
+        dst = out + PREP_DOWN_UINT4 + (cls * PREP_UP_SLOTS + ((ty * 2 + tx) * 2 + c) * 3) * 64 + lane;
+    }
+    bf16x8 h, m, l;
+    split8x3(x, h, m, l);
+    dst[0] = __builtin_bit_cast(uint4, h);
+    dst[64] = __builtin_bit_cast(uint4, m);
+    dst[128] = __builtin_bit_cast(uint4, l);
+}
+
 template <int LO, int MODE>
 __global__ __launch_bounds__(256, 1) void down32x_kernel(const float *__restrict__ hi, const float *__restrict__ wt, Ep32 ep,
                                                          int n_img, int n_tiles) {
@@ -612,7 +658,15 @@ __global__ __launch_bounds__(256, 1) void down32x_kernel(const float *__restrict
 
     // w3[tap][c][term], tap = kyl*4 + kx with ky = 2*kh + kyl: channels c*16 + half*8 + j of wt[clo = rc][.][ky][kx]
     bf16x8 w3[8][2][3];
-    {
+    if (ep.wprep != nullptr) {                                   // split once per step by conv32_weight_prep: 48 coalesced loads
+        const uint4 *src = ep.wprep + (kh * PREP_DOWN_SLOTS) * 64 + lane;
+#pragma unroll
+        for (int tap = 0; tap < 8; ++tap)
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) w3[tap][cc][t] = __builtin_bit_cast(bf16x8, src[((tap * 2 + cc) * 3 + t) * 64]);
+    } else {
         float4 v[16];
         load_weights(wt, v);
 #pragma unroll
@@ -968,7 +1022,18 @@ __global__ __launch_bounds__(256, 1) void up32x_kernel(const float *__restrict__
 
     // w3[ty][tx][c][term]: the 8 input channels c*16 + half*8 + j of wt[.][chi = rc][ky0 + 2ty][kx0 + 2tx], split in three
     bf16x8 w3[2][2][2][3];
-    {
+    if (ep.wprep != nullptr) {                                   // split once per step by conv32_weight_prep: 24 coalesced loads
+        const uint4 *src = ep.wprep + PREP_DOWN_UINT4 + (wave * PREP_UP_SLOTS) * 64 + lane;
+#pragma unroll
+        for (int ty = 0; ty < 2; ++ty)
+#pragma unroll
+            for (int tx = 0; tx < 2; ++tx)
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+                        w3[ty][tx][cc][t] = __builtin_bit_cast(bf16x8, src[(((ty * 2 + tx) * 2 + cc) * 3 + t) * 64]);
+    } else {
         float4 v[16];
         load_weights(wt, v);
 #pragma unroll
@@ -1469,8 +1534,8 @@ template <int LO> static int launch_down(const arvae_link_t *l, const Operand &h
 // gate (float activation) or gate_bits (relu_bits16) select a gated epilogue; with relu, bits_out (may be null) receives
 // the sign bits of the result
 int conv32_down(const arvae_link_t *l, const Operand &hi, const float *wt, const float *bias, int relu, const float *gate,
-                const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s) {
-    Ep32 ep{bias, gate, gate_bits, bits_out, out};
+                const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s, const float *wprep) {
+    Ep32 ep{bias, gate, gate_bits, bits_out, out, reinterpret_cast<const uint4 *>(wprep)};
     switch (l->lh) {
         case 16: return launch_down<16>(l, hi, wt, ep, relu, s);
         case 8: return launch_down<8>(l, hi, wt, ep, relu, s);
@@ -1490,8 +1555,8 @@ template <int LO> static int launch_up(const arvae_link_t *l, const Operand &lo,
 }
 
 int conv32_up(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, int relu, const float *gate,
-              const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s) {
-    Ep32 ep{bias, gate, gate_bits, bits_out, out};
+              const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s, const float *wprep) {
+    Ep32 ep{bias, gate, gate_bits, bits_out, out, reinterpret_cast<const uint4 *>(wprep)};
     switch (l->lh) {
         case 16: return launch_up<16>(l, lo, wt, ep, relu, s);
         case 8: return launch_up<8>(l, lo, wt, ep, relu, s);
@@ -1510,6 +1575,21 @@ static int wgrad_px(const arvae_link_t *l) {
 static bool wgrad_fp32_mfma() {
     static const bool on = getenv("ARVAE_CONV32_FP32") != nullptr;
     return on;
+}
+
+// floats of workspace per layer for conv32_weight_prep, and the batched launch (up to 8 layers)
+int64_t conv32_prep_floats() { return PREP_FLOATS; }
+
+int conv32_weight_prep(const float *const *wts, float *const *preps, int n_layers, hipStream_t s) {
+    if (n_layers <= 0) return ARVAE_OK;
+    ARVAE_REQUIRE(n_layers <= PREP_MAX_LAYERS, "conv32_weight_prep: at most %d layers per launch", PREP_MAX_LAYERS);
+    PrepArgs p{};
+    for (int i = 0; i < n_layers; ++i) {
+        p.wt[i] = wts[i];
+        p.out[i] = reinterpret_cast<uint4 *>(preps[i]);
+    }
+    hipLaunchKernelGGL(conv32_weight_prep_kernel, dim3(16 * n_layers), dim3(256), 0, s, p);
+    return check_launch("conv32_weight_prep");
 }
 
 int conv32_wgrad_groups(const arvae_link_t *l) {

@@ -38,9 +38,9 @@ int conv_c1_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &img, 
 // specialised 32-channel k4/s2/p1 kernels (conv32.hip)
 bool conv32_fits(const arvae_link_t *l);
 int conv32_down(const arvae_link_t *l, const Operand &hi, const float *wt, const float *bias, int relu, const float *gate,
-                const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s);
+                const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s, const float *wprep = nullptr);
 int conv32_up(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, int relu, const float *gate,
-              const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s);
+              const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s, const float *wprep = nullptr);
 int64_t conv32_wgrad_ws_floats(const arvae_link_t *l);
 int conv32_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *dwt, float *dbias, int bias_mode,
                  float *slab, hipStream_t s);

@@ -11,11 +11,13 @@ namespace arvae {
 bool conv32_fits(const arvae_link_t *l);
 bool conv_c1_fits(const arvae_link_t *l);
 int conv32_down(const arvae_link_t *l, const Operand &hi, const float *wt, const float *bias, int relu, const float *gate,
-                const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s);
+                const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s, const float *wprep = nullptr);
 int conv32_up(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, int relu, const float *gate,
-              const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s);
+              const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s, const float *wprep = nullptr);
 int conv_c1_up_recon(const arvae_link_t *l, const float *lo, const float *wt, const float *bias, float *out, const float *x,
                      int dist, float *partial, float *dlogits, hipStream_t s, int *nb_out);
+int64_t conv32_prep_floats();
+int conv32_weight_prep(const float *const *wts, float *const *preps, int n_layers, hipStream_t s);
 int conv32_wgrad_partial(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *dwt, float *dbias, int bias_mode,
                          float *slab, hipStream_t s, SlabJob *job);
 int conv_c1_wgrad_partial(const arvae_link_t *l, const Operand &lo, const Operand &img, float *dwt, float *dbias,
@@ -96,6 +98,9 @@ struct Layout {
     // ReLU conv layers on the fast kernels also leave the sign bits of their output (relu_bits16, 4 bytes per pixel):
     // the backward pass gates with those instead of re-reading the 128-byte-per-pixel activation
     int64_t enc_bits[ARVAE_MAX_LAYERS], dec_bits[ARVAE_MAX_LAYERS];
+    // 32-channel conv layers: the weights split into bf16 terms in per-lane order, rebuilt at the start of every forward
+    // pass by ONE launch and used by the layer's forward and data-gradient kernels (-1: not such a layer)
+    int64_t enc_wprep[ARVAE_MAX_LAYERS], dec_wprep[ARVAE_MAX_LAYERS];
     int64_t log_std, dlogits, dz_reg, d_mu, d_ls, g_a, g_b, slab, rec_ws, reg_ws, rec_out, kld_out, reg_out, total;
     int64_t slab_floats;
 };
@@ -134,6 +139,15 @@ static int make_layout(const arvae_image_vae_t *m, int64_t n, int64_t n_cols, La
         static const bool off = getenv("ARVAE_NO_RELU_BITS") != nullptr;      // diagnostic: gate with the float activations
         return (fast && !off && l.act == ARVAE_ACT_RELU && !l.dropout) ? take(out_elems(l, n) / 32) : -1;
     };
+    int n_prep = 0;
+    auto own_prep = [&](const arvae_layer_t &l) -> int64_t {
+        arvae_link_t lk = l.link;
+        lk.n = (int32_t)n;
+        static const bool off = getenv("ARVAE_NO_WEIGHT_PREP") != nullptr;     // diagnostic switch
+        return (!off && conv32_fits(&lk) && n_prep++ < 8) ? take(conv32_prep_floats()) : -1;
+    };
+    for (int i = 0; i < m->n_enc; ++i) L.enc_wprep[i] = own_prep(m->enc[i]);
+    for (int i = 0; i < m->n_dec; ++i) L.dec_wprep[i] = own_prep(m->dec[i]);
     for (int i = 0; i < m->n_enc; ++i) L.enc_bits[i] = own_bits(m->enc[i]);
     for (int i = 0; i < m->n_dec; ++i) L.dec_bits[i] = own_bits(m->dec[i]);
     for (int i = 0; i < m->n_enc; ++i) L.enc_slab[i] = own_slab(m->enc[i]);
@@ -165,7 +179,7 @@ static int make_layout(const arvae_image_vae_t *m, int64_t n, int64_t n_cols, La
 static arvae_operand_t plain(const float *v) { return arvae_operand_t{v, nullptr, nullptr, ARVAE_ACT_NONE}; }
 
 static int layer_forward(const arvae_layer_t &l, int32_t n, const float *params, const float *in, const uint8_t *mask,
-                         float *out, uint16_t *bits_out, arvae_stream_t st) {
+                         float *out, uint16_t *bits_out, arvae_stream_t st, const float *wprep = nullptr) {
     arvae_link_t lk = l.link;
     lk.n = n;
     const arvae_operand_t op = plain(in);
@@ -173,8 +187,8 @@ static int layer_forward(const arvae_layer_t &l, int32_t n, const float *params,
     if (bits_out != nullptr) {                           // make_layout grants bits only to ReLU layers on these kernels
         hipStream_t hs = as_stream(st);
         if (conv32_fits(&lk))
-            return l.is_up ? conv32_up(&lk, make_operand(&op), w, b, 1, nullptr, nullptr, bits_out, out, hs)
-                           : conv32_down(&lk, make_operand(&op), w, b, 1, nullptr, nullptr, bits_out, out, hs);
+            return l.is_up ? conv32_up(&lk, make_operand(&op), w, b, 1, nullptr, nullptr, bits_out, out, hs, wprep)
+                           : conv32_down(&lk, make_operand(&op), w, b, 1, nullptr, nullptr, bits_out, out, hs, wprep);
         return conv_c1_down(&lk, make_operand(&op), w, b, 1, nullptr, nullptr, bits_out, out, hs);
     }
     return l.is_up ? arvae_link_up(&lk, &op, w, b, l.act, mask, out, st) : arvae_link_down(&lk, &op, w, b, l.act, mask, out, st);
@@ -222,7 +236,7 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
                           const float *out, const uint8_t *mask, const float *g, bool g_is_pre, const float *gate,
                           float *d_in, bool *gated, float *slab, DenseWgradBatch *defer, float *own_slab,
                           SlabReduceBatch *rdefer, arvae_stream_t st, const float *g_scale = nullptr,
-                          const uint16_t *gate_bits = nullptr) {
+                          const uint16_t *gate_bits = nullptr, const float *wprep = nullptr) {
     arvae_link_t lk = l.link;
     lk.n = n;
     const arvae_operand_t gop = g_is_pre ? plain(g) : arvae_operand_t{g, out, mask, l.act};
@@ -238,7 +252,8 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
         int rc;
         if (l.is_up) {                                   // forward UP  -> data gradient is a DOWN map
             if (gate != nullptr && gop.y == nullptr && conv32_fits(&lk)) {
-                rc = conv32_down(&lk, make_operand(&gop), w, nullptr, 0, gate_bits ? nullptr : gate, gate_bits, nullptr, d_in, hs);
+                rc = conv32_down(&lk, make_operand(&gop), w, nullptr, 0, gate_bits ? nullptr : gate, gate_bits, nullptr, d_in, hs,
+                                 wprep);
                 *gated = true;
             } else if (gate != nullptr && simple && conv_c1_fits(&lk)) {
                 Operand g_op = make_operand(&gop);
@@ -250,7 +265,8 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
             }
         } else {                                         // forward DOWN -> data gradient is an UP map
             if (gate != nullptr && gop.y == nullptr && conv32_fits(&lk)) {
-                rc = conv32_up(&lk, make_operand(&gop), w, nullptr, 0, gate_bits ? nullptr : gate, gate_bits, nullptr, d_in, hs);
+                rc = conv32_up(&lk, make_operand(&gop), w, nullptr, 0, gate_bits ? nullptr : gate, gate_bits, nullptr, d_in, hs,
+                               wprep);
                 *gated = true;
             } else if (gate != nullptr && dense_fits(&lk)) {
                 rc = dense_dgrad(&lk, make_operand(&gop), w, gate, d_in, hs);
@@ -308,13 +324,25 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
     ARVAE_REQUIRE(m->n_reg == 0 || n_cols < 0 || labels != nullptr, "image_vae_forward: labels needed for the reg loss");
     hipStream_t st = as_stream(stream);
     int mi = 0;
+    {   // split the 32-channel conv weights once for this step's forward and backward kernels
+        const float *wts[8];
+        float *preps[8];
+        int np = 0;
+        for (int i = 0; i < m->n_enc; ++i)
+            if (L.enc_wprep[i] >= 0) { wts[np] = params + m->enc[i].w_off; preps[np++] = ws + L.enc_wprep[i]; }
+        for (int i = 0; i < m->n_dec; ++i)
+            if (L.dec_wprep[i] >= 0) { wts[np] = params + m->dec[i].w_off; preps[np++] = ws + L.dec_wprep[i]; }
+        if (int rc = conv32_weight_prep(wts, preps, np, st)) return rc;
+    }
     // encoder
     const float *h = x;
     for (int i = 0; i < m->n_enc; ++i) {
         const uint8_t *mask = (masks != nullptr && m->enc[i].dropout) ? masks[mi] : nullptr;
         mi += m->enc[i].dropout != 0;
         uint16_t *bits = L.enc_bits[i] >= 0 ? reinterpret_cast<uint16_t *>(ws + L.enc_bits[i]) : nullptr;
-        if (int rc = layer_forward(m->enc[i], batch, params, h, mask, ws + L.enc_out[i], bits, stream)) return rc;
+        if (int rc = layer_forward(m->enc[i], batch, params, h, mask, ws + L.enc_out[i], bits, stream,
+                                   L.enc_wprep[i] >= 0 ? ws + L.enc_wprep[i] : nullptr))
+            return rc;
         h = ws + L.enc_out[i];
     }
     const int64_t bz = (int64_t)batch * m->zdim;
@@ -346,7 +374,9 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
                 return rc;
         } else {
             uint16_t *bits = L.dec_bits[i] >= 0 ? reinterpret_cast<uint16_t *>(ws + L.dec_bits[i]) : nullptr;
-            if (int rc = layer_forward(m->dec[i], batch, params, h, mask, out, bits, stream)) return rc;
+            if (int rc = layer_forward(m->dec[i], batch, params, h, mask, out, bits, stream,
+                                       L.dec_wprep[i] >= 0 ? ws + L.dec_wprep[i] : nullptr))
+                return rc;
         }
         h = out;
     }
@@ -454,7 +484,8 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
                                     &gated, slab, &defer, L.dec_slab[i] >= 0 ? ws + L.dec_slab[i] : nullptr, &rdefer, stream,
                                     i == m->n_dec - 1 ? first_scale : nullptr,
                                     (gate != nullptr && i > 0 && L.dec_bits[i - 1] >= 0)
-                                        ? reinterpret_cast<const uint16_t *>(ws + L.dec_bits[i - 1]) : nullptr))
+                                        ? reinterpret_cast<const uint16_t *>(ws + L.dec_bits[i - 1]) : nullptr,
+                                    L.dec_wprep[i] >= 0 ? ws + L.dec_wprep[i] : nullptr))
             return rc;
         pre = gated;
         cur = dst;
@@ -521,7 +552,8 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
                                     gate, dst, &gated, slab, &defer, L.enc_slab[i] >= 0 ? ws + L.enc_slab[i] : nullptr, &rdefer,
                                     stream, nullptr,
                                     (gate != nullptr && i > 0 && L.enc_bits[i - 1] >= 0)
-                                        ? reinterpret_cast<const uint16_t *>(ws + L.enc_bits[i - 1]) : nullptr))
+                                        ? reinterpret_cast<const uint16_t *>(ws + L.enc_bits[i - 1]) : nullptr,
+                                    L.enc_wprep[i] >= 0 ? ws + L.enc_wprep[i] : nullptr))
             return rc;
         pre = gated;
         cur = dst;
