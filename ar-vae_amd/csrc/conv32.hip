@@ -3,23 +3,28 @@
 // carry 85 % of the training step's FLOPs.  Same math and C-ABI as the
 // generic gather-GEMM (link_gemm.hip); arvae_link_down/up/wgrad dispatch here when the geometry fits.
 //
-// Design rule (measured, profiles/r1_down32_phase_stamps.txt): on gfx950 the fp32 MFMA
-// (v_mfma_f32_32x32x2_f32, 64 cycles each, runs at the fp32 vector rate) does NOT co-execute with VALU work of
-// another wave on the same SIMD, so SIMD time = MFMA cycles + VALU cycles.  The kernels therefore maximise MFMAs
-// per non-MFMA instruction:
-//   * one 256-thread workgroup per CU (one wave per SIMD), persistent over tiles of 128 lo pixels (full-width
-//     row blocks / whole images, so a tile is one contiguous span of the lo tensor);
-//   * 256 MFMAs per wave and tile; every operand read from LDS is one ds_read_b128 that feeds 4 MFMAs
-//     (K order = (tap, 8-channel chunk, lane half, t) matches the 32x32x2 lane layout k = 2s + half);
-//   * weights live in VGPRs for the whole kernel (Down: all 256 values of the wave's output column, so a
-//     wave owns its 32 output pixels over the full K = 512 and no cross-wave reduction exists;
-//     Up: the 64 values of the wave's stride-parity class; Wgrad: none, pixels are the K axis);
+// Two generations of kernels live here, same tiling ideas, selected at run time:
+//   *x kernels (default): the bf16 MFMA at fp32 accuracy.  Every fp32 operand is split into three bf16 terms when it
+//       enters LDS (weights: once per step, conv32_weight_prep) and every multiply-add is six partial products on
+//       v_mfma_f32_32x32x16_bf16 with fp32 accumulation: the result is within one fp32 rounding of the fp32 MFMA's
+//       at 2.7x fewer MFMA cycles, and the bf16 MFMA leaves the vector ALU free for the splitting.
+//   fp32 kernels (ARVAE_CONV32_FP32=1, and the K-split small-tile Down of the 4x4 layers): v_mfma_f32_32x32x2_f32.
+//
+// Design rules (measured, profiles/r1_down32_phase_stamps.txt, tools/stamp_conv32.py): on gfx950 the fp32 MFMA
+// (64 cycles each, runs at the fp32 vector rate) does NOT co-execute with VALU work of another wave on the same
+// SIMD, so SIMD time = MFMA cycles + VALU cycles; a CU moves store data at ~16 B/clk.  Hence:
+//   * one 256-thread workgroup per CU (one wave per SIMD), persistent over tiles of 128 / 64 / 32 lo pixels
+//     (full-width row blocks / whole images, so a tile is one contiguous span of the lo tensor);
+//   * every operand read from LDS is one 16-byte read that feeds several MFMAs;
+//   * weights live in registers for the whole kernel (Wgrad: none, pixels are the K axis);
 //   * global traffic uses raw buffer loads / stores: the hardware bounds check zero-fills everything outside
 //     the tensor (images past the end of the batch, rows before its start), per-thread offsets are computed
 //     once per kernel, per tile a slot costs an add, a compare and a select;
 //   * a tile's patch (+halo) is prefetched into registers while the previous tile's MFMAs run and is
-//     committed to LDS (pixel stride 36 floats: <= 2-way bank conflicts for stride-1/2 pixel walks) between
-//     two barriers.
+//     committed to LDS between two barriers (pixel strides 36 floats / 20 dwords per bf16 plane: conflict-free
+//     16-byte reads for stride-1/2 pixel walks);
+//   * epilogues are 16-byte stores of a lane's consecutive channels, in the Up kernels spread between the next
+//     tile's MFMAs with the waves staggered.
 #include "common.h"
 #include "reduce.h"
 

@@ -14,9 +14,9 @@ import sys
 def label(kernel_name):
     """rocprofv3 kernel name -> the label bench.py / arvae_profile_end use for that kernel family."""
     n = kernel_name.replace('void ', '').split('(')[0].replace('arvae::', '')
-    m = re.match(r'(down32_kernel|up32_kernel|wgrad32_kernel)<(\d+),', n)
+    m = re.match(r'(down32|up32|wgrad32)[xbs]?_kernel<(\d+),', n)       # fp32 / split-bf16 / small-tile variants share a label
     if m:
-        return f'{m.group(1)}<{m.group(2)}>'
+        return f'{m.group(1)}_kernel<{m.group(2)}>'
     if n.startswith('up_c1_kernel'):
         return 'up_c1_kernel(recon)' if 'true' in n else 'up_c1_kernel'
     return n.split('<')[0]
