@@ -206,14 +206,14 @@ struct SideStream {
 };
 thread_local arvae_stream_t g_wgrad_stream = nullptr;   // non-null while a two-stream backward pass is being enqueued
 
-static SideStream *side_stream() {
+static SideStream *side_stream(bool force = false) {
     static SideStream pool[16];
     // Measured on MI355X (dSprites, B=512): the two-stream schedule is 1-2 % SLOWER than one stream -- the big kernels
     // of both chains are one-workgroup-per-CU persistent kernels that cannot share a CU's LDS, so they serialise
     // anyway and only add event traffic.  Kept as an experiment switch.
     static const bool off = getenv("ARVAE_TWO_STREAMS") == nullptr;
     int dev = 0;
-    if (off || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if ((off && !force) || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     SideStream &ss = pool[dev];
     if (ss.device != dev) {
         ss.device = dev;
@@ -559,6 +559,22 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
         cur = dst;
     }
     sync_side();                                         // every gradient the queued jobs read is complete
+    // The two closing kernels are independent (disjoint gradients): the slab reduction streams ~90 MB from HBM while the
+    // grouped Linear weight gradients are latency-bound in L2.  Running them side by side on a second stream measured
+    // 22 us SLOWER per step than back to back (fork / join events cost more than the overlap returns), so this stays an
+    // experiment switch like ARVAE_TWO_STREAMS.
+    static const bool tail_overlap = getenv("ARVAE_TAIL_OVERLAP") != nullptr;
+    SideStream *tail = (side == nullptr && tail_overlap && !profiling_active() && defer.count > 0 && rdefer.count > 0)
+                           ? side_stream(true) : nullptr;
+    if (tail != nullptr) {
+        (void)hipEventRecord(tail->fork, st);
+        (void)hipStreamWaitEvent(tail->s, tail->fork, 0);
+        if (int rc = dense_wgrad_flush(&defer, tail->s)) return rc;
+        (void)hipEventRecord(tail->join, tail->s);
+        if (int rc = slab_reduce_flush(&rdefer, st)) return rc;
+        (void)hipStreamWaitEvent(st, tail->join, 0);
+        return ARVAE_OK;
+    }
     if (int rc = slab_reduce_flush(&rdefer, flush_stream)) return rc;
     if (int rc = dense_wgrad_flush(&defer, flush_stream)) return rc;
     if (side != nullptr) {                               // join: the caller's stream continues after the helper's work
