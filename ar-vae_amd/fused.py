@@ -152,8 +152,8 @@ class _FusedStepFn(Function):
                                               labels.shape[1], dims, r, fused.gamma, fused.delta, ops._ptr(ws_reg),
                                               ops._ptr(reg_out), ops._ptr(dz), ops._stream()), 'reg_loss')
             w = float(dp.world_size)
-            scalars[REG:REG + 1].copy_(reg_out).mul_(w)
-            scalars[LOSS:LOSS + 1].add_(reg_out, alpha=w)
+            # scalars[LOSS] += W * reg and scalars[REG] (0 so far) = W * reg: one kernel on the strided pair
+            scalars[LOSS:REG + 1:REG - LOSS].add_(reg_out, alpha=w)
             ctx.dz_unit, reg_scale = dz, w
         ctx.fused, ctx.masks, ctx.marr = fused, keep, marr
         ctx.external_reg, ctx.reg_scale = external_reg, reg_scale
