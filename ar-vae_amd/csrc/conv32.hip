@@ -38,6 +38,9 @@ typedef int i32x4v __attribute__((ext_vector_type(4)));
 
 constexpr int C32 = 32;
 constexpr int PS = 36;                  // LDS pixel stride in floats
+constexpr int PSB3 = 52;                // LDS pixel stride in dwords of the packed three-term image (terms at +0, +16, +32 dwords,
+                                        // 4 pad): conflict-free 16-byte reads for pixel walks of stride 1 and 2, 13 % smaller than
+                                        // three padded planes, which lets a second buffer fit
 constexpr int PSB = 20;                 // LDS pixel stride in dwords of one bf16 plane (16 payload + 4 pad: conflict-free
                                         // 16-byte reads for pixel walks of stride 1 and 2)
 constexpr int PIXB = C32 * 4;           // bytes of one 32-channel pixel
@@ -236,6 +239,35 @@ struct PatchLoader {
                 }
             }
         }
+    }
+    // packed three-term image (PSB3): one slot, all slots, or the slots of one of STEPS issue points followed by the
+    // load of the same slots for the next tile (the registers are free again once their values are in LDS)
+    static constexpr int BUF3_DW = T::TI * PR * PC * PSB3;
+    __device__ __forceinline__ void commit_slot3p(unsigned *buf, int it) const {
+        const int idx = threadIdx.x + it * 256;
+        if (idx < SLOTS) {
+            const int q = idx & 7, pix = idx >> 3;
+            uint2 hv, mv, lv;
+            split_pair3(r[it].x, r[it].y, hv.x, mv.x, lv.x);
+            split_pair3(r[it].z, r[it].w, hv.y, mv.y, lv.y);
+            unsigned *d = buf + pix * PSB3 + q * 2;
+            *reinterpret_cast<uint2 *>(d) = hv;
+            *reinterpret_cast<uint2 *>(d + 16) = mv;
+            *reinterpret_cast<uint2 *>(d + 32) = lv;
+        }
+    }
+    __device__ __forceinline__ void commit_all3p(unsigned *buf) const {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) commit_slot3p(buf, it);
+    }
+    template <int STEPS, int STEP> __device__ __forceinline__ void commit_issue_step3p(unsigned *buf) {
+        static_for<0, ITERS>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int it = decltype(ic)::value;
+            if constexpr (it * STEPS / ITERS == STEP) {
+                commit_slot3p(buf, it);
+                issue_slot(it);
+            }
+        });
     }
     // BIAS_SUM: also accumulate the pixels this tile owns (not the halo) per channel chunk q = threadIdx.x & 7
     template <bool BIAS_SUM>
@@ -646,10 +678,11 @@ __global__ __launch_bounds__(256, 1) void down32x_kernel(const float *__restrict
                                                          int n_img, int n_tiles) {
     constexpr int PX = 64;
     using PL = PatchLoader<LO, 2, PX>;
-    constexpr int PC = PL::PC, PR = PL::PR, PLANE = PL::PLANE_DW;
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // max(3 planes + red[2][16][64], WSTAGE_DOWN floats)
+    constexpr int PC = PL::PC, PR = PL::PR, BUF = PL::BUF3_DW;
+    // two packed three-term images (the next tile is split and written while this one is multiplied) | red[2][2][16][64]
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     unsigned *ldsw = reinterpret_cast<unsigned *>(lds);
-    float *red = lds + 3 * PLANE;
+    float *red = lds + 2 * BUF;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, rc = lane & 31;
     const int mtile = wave >> 1, kh = wave & 1;
@@ -696,7 +729,7 @@ __global__ __launch_bounds__(256, 1) void down32x_kernel(const float *__restrict
 
     int img, r, c;
     tile_pixel<LO, PX>(mtile * 32 + rc, img, r, c);
-    const int aoff = ((img * PR + 2 * r + 2 * kh) * PC + 2 * c) * PSB + half * 4;     // dwords; + (kyl*PC + kx)*PSB + c*8
+    const int aoff = ((img * PR + 2 * r + 2 * kh) * PC + 2 * c) * PSB3 + half * 4;    // dwords; + (kyl*PC + kx)*PSB3 + c*8 + term*16
     float4 b4[4];
     load_bias4(ep.bias, half, b4);
     const int64_t out_bytes = (int64_t)n_img * LO * LO * PIXB;
@@ -708,16 +741,27 @@ __global__ __launch_bounds__(256, 1) void down32x_kernel(const float *__restrict
                   (int64_t)n_img * LO * LO * 4);
     const unsigned out_lane = (unsigned)((mtile * 32 + rc) * PIXB + half * 16);
 
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // pipeline: registers hold tile t+1 (loaded during tile t-1); during tile t's MFMAs each slot is split, written to
+    // the other LDS image and refilled with tile t+2.  One barrier per tile.
+    __syncthreads();                                             // weight staging (if any) no longer needs the LDS
+    pl.commit_all3p(ldsw);                                       // first tile -> image 0
+    {
+        int ni, nr;
+        tile_origin<LO, PX>(blockIdx.x + gridDim.x, ni, nr);
+        pl.set_tile(ni, nr, blockIdx.x + gridDim.x < n_tiles);
+        pl.issue_all();
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, cur ^= 1) {
         tile_origin<LO, PX>(tile, img0, r0);
-        __syncthreads();                                         // previous tile's planes and partials have been read
-        pl.commit_split3(ldsw);
-        __syncthreads();
         {
             int ni, nr;
-            tile_origin<LO, PX>(tile + gridDim.x, ni, nr);
-            pl.set_tile(ni, nr, tile + gridDim.x < n_tiles);
+            tile_origin<LO, PX>(tile + 2 * gridDim.x, ni, nr);
+            pl.set_tile(ni, nr, tile + 2 * gridDim.x < n_tiles);
         }
+        const unsigned *img_cur = ldsw + cur * BUF;
+        unsigned *img_nxt = ldsw + (cur ^ 1) * BUF;
         f32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -725,7 +769,7 @@ __global__ __launch_bounds__(256, 1) void down32x_kernel(const float *__restrict
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) a[0][cc][t] = lds_bf16x8(ldsw + t * PLANE + aoff + cc * 8);
+            for (int t = 0; t < 3; ++t) a[0][cc][t] = lds_bf16x8(img_cur + aoff + cc * 8 + t * 16);
         static_for<0, 8>([&](auto tc) __attribute__((always_inline)) {
             constexpr int tap = decltype(tc)::value;
             if constexpr (tap + 1 < 8) {                         // next tap's operands are in flight during these 12 MFMAs
@@ -734,10 +778,9 @@ __global__ __launch_bounds__(256, 1) void down32x_kernel(const float *__restrict
                 for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
                     for (int t = 0; t < 3; ++t)
-                        a[(tap + 1) & 1][cc][t] = lds_bf16x8(ldsw + t * PLANE + aoff + (kyl * PC + kx) * PSB + cc * 8);
+                        a[(tap + 1) & 1][cc][t] = lds_bf16x8(img_cur + aoff + (kyl * PC + kx) * PSB3 + cc * 8 + t * 16);
             }
-            pl.template issue_step<8, tap>();
-            __builtin_amdgcn_sched_barrier(0);
+            pl.template commit_issue_step3p<8, tap>(img_nxt);
 #pragma unroll
             for (int cc = 0; cc < 2; ++cc) {                     // smallest partial products first
                 MFMA_B(acc, w3[tap][cc][2], a[tap & 1][cc][0]);
@@ -747,16 +790,16 @@ __global__ __launch_bounds__(256, 1) void down32x_kernel(const float *__restrict
                 MFMA_B(acc, w3[tap][cc][0], a[tap & 1][cc][1]);
                 MFMA_B(acc, w3[tap][cc][0], a[tap & 1][cc][0]);
             }
-            __builtin_amdgcn_sched_barrier(0);
         });
+        float *rd = red + cur * (2 * 16 * 64);
         if (kh == 1) {
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) red[(mtile * 16 + reg) * 64 + lane] = acc[reg];
+            for (int reg = 0; reg < 16; ++reg) rd[(mtile * 16 + reg) * 64 + lane] = acc[reg];
         }
-        __syncthreads();
+        __syncthreads();                                         // partial tiles and the next image are written; this image is free
         if (kh == 0) {
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) acc[reg] += red[(mtile * 16 + reg) * 64 + lane];
+            for (int reg = 0; reg < 16; ++reg) acc[reg] += rd[(mtile * 16 + reg) * 64 + lane];
             store_pixel<MODE>(acc, b4, rs_out, rs_gate, rs_bits, want_bits,
                               out_lane + (unsigned)(((img0 * LO + r0) * LO) * PIXB), half);
         }
@@ -1471,7 +1514,7 @@ static void launch_down_v(int grid, const Operand &hi, const float *wt, const Ep
     static const bool fp32_mfma = getenv("ARVAE_CONV32_FP32") != nullptr;
     static const bool split = getenv("ARVAE_CONV32_BF16X2") != nullptr;
     if (!fp32_mfma && !split) {                                  // default: three-term bf16 at fp32 accuracy, 64-pixel tiles
-        constexpr int LDSX = MaxOf<3 * PatchLoader<LO, 2, 64>::PLANE_DW + 2 * 16 * 64, WSTAGE_DOWN>::value * 4;
+        constexpr int LDSX = MaxOf<2 * PatchLoader<LO, 2, 64>::BUF3_DW + 2 * 2 * 16 * 64, WSTAGE_DOWN>::value * 4;
         const int tiles64 = tiles_for<LO, 64>(n);
         static bool attrx = false;
         if (!attrx) { allow_lds(down32x_kernel<LO, MODE>, LDSX); attrx = true; }
