@@ -506,6 +506,55 @@ def test_split_bf16_experiment_keeps_loss_parity(dev):
         close(got[k], float(ref['terms'][k]), rtol=1e-4)
 
 
+_CONV32_PROBE = """
+import sys; sys.path.insert(0, %r)
+import numpy as np, torch
+from arvae_amd import ops
+dev = torch.device('cuda:0')
+rs = np.random.RandomState(11)
+n = 24
+hi = torch.from_numpy(rs.standard_normal((n, 32, 32, 32)).astype(np.float32)).to(dev)
+lo = torch.from_numpy(rs.standard_normal((n, 16, 16, 32)).astype(np.float32)).to(dev)
+w = torch.from_numpy((rs.standard_normal((32, 32, 4, 4)) * 0.1).astype(np.float32)).to(dev)
+b = torch.from_numpy(rs.standard_normal(32).astype(np.float32)).to(dev)
+link = ops.Link(32, 32, 32, 16, 16, 32, 4, 4, 2, 1)
+down = ops.link_down(link, n, ops._operand(hi), w, b, ops.ACT_NONE, None)
+up = ops.link_up(link, n, ops._operand(lo), w, b, ops.ACT_NONE, None)
+dw = torch.zeros_like(w); db = torch.zeros_like(b)
+ops.link_wgrad(link, n, ops._operand(lo), ops._operand(hi), dw, db, 1)
+np.savez(sys.argv[1], down=down.cpu().numpy(), up=up.cpu().numpy(), dw=dw.cpu().numpy(), db=db.cpu().numpy())
+"""
+
+
+def test_bf16_three_term_kernels_match_fp32_mfma_kernels(dev, tmp_path):
+    """The default conv kernels (bf16 MFMA, three-term split, six products) against the fp32-MFMA kernels
+    (ARVAE_CONV32_FP32=1) on the same data: they differ by fp32 rounding noise only."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for mode, env in (('split', {}), ('fp32', {'ARVAE_CONV32_FP32': '1'})):
+        path = str(tmp_path / (mode + '.npz'))
+        r = subprocess.run([sys.executable, '-c', _CONV32_PROBE % root, path], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, **env), cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[mode] = np.load(path)
+    # float64 reference of the same three maps (torch CPU)
+    rs = np.random.RandomState(11)
+    n = 24
+    hi = torch.from_numpy(rs.standard_normal((n, 32, 32, 32)).astype(np.float32)).double().permute(0, 3, 1, 2)
+    lo = torch.from_numpy(rs.standard_normal((n, 16, 16, 32)).astype(np.float32)).double().permute(0, 3, 1, 2)
+    w = torch.from_numpy((rs.standard_normal((32, 32, 4, 4)) * 0.1).astype(np.float32)).double().requires_grad_(True)
+    b = torch.from_numpy(rs.standard_normal(32).astype(np.float32)).double().requires_grad_(True)
+    down = F.conv2d(hi, w, b, stride=2, padding=1)
+    up = F.conv_transpose2d(lo, w, b, stride=2, padding=1)
+    down.backward(lo)                                    # dW, db of the Conv2d for the upstream gradient `lo`
+    ref = {'down': down.detach().permute(0, 2, 3, 1).numpy(), 'up': up.detach().permute(0, 2, 3, 1).numpy(),
+           'dw': w.grad.numpy(), 'db': b.grad.numpy()}
+    for k in ('down', 'up', 'dw', 'db'):
+        err = {m: np.linalg.norm(outs[m][k].astype(np.float64) - ref[k]) / np.linalg.norm(ref[k]) for m in outs}
+        assert err['split'] < 5e-7 and err['fp32'] < 5e-7, (k, err)
+        assert err['split'] <= 2.0 * err['fp32'] + 2e-8, (k, err)     # no less accurate than the fp32 MFMA
+
+
 # ---------------------------------------------------------------- MeasureVAE (G6 / G7)
 class _FolkDataset:
     """the attributes MeasureVAE / MeasureVAETrainer read from the reference's FolkNBarDataset"""
