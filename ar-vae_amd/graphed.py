@@ -1,0 +1,66 @@
+"""Forward + backward of a training step replayed from HIP graphs (torch.cuda.CUDAGraph).
+
+The MeasureVAE step is ~2 000 small kernels issued from Python: eager, the host sets the pace (31 ms per step at
+B = 256).  Every launch of the library goes to torch's current stream and nothing in the step synchronises, so the whole
+forward + backward can be captured once and replayed: 7.6 ms per step on MI355X.  The optimizer stays outside (its
+bias corrections are host scalars), as does the host-side teacher-forcing coin: one graph per control-flow variant.
+
+    graphed = GraphedStep(trainer, example_batch)        # captures (after a few warm-up iterations)
+    for batch in loader:
+        loss, acc = graphed(batch)                       # zero_grad + loss + backward
+        trainer.step()
+
+Random numbers drawn on the device inside the step (reparameterisation noise, dropout masks) use torch's graph-safe
+Philox generator, so every replay sees fresh values.  Noise / masks pushed through the models' host-side queues are
+NOT visible to a captured graph (the queue is consumed at capture time).
+"""
+import torch
+
+
+class GraphedStep:
+    def __init__(self, trainer, example_batch, warmup=3):
+        if not torch.cuda.is_available():
+            raise RuntimeError('GraphedStep needs a GPU')
+        self.trainer = trainer
+        self.static = tuple(t.clone() for t in trainer.process_batch_data(example_batch))
+        self.decoder = getattr(trainer.model, 'decoder', None)
+        coin = self.decoder is not None and getattr(self.decoder, 'use_teacher_forcing', False)
+        self.variants = (True, False) if coin else (None,)
+        self.prob = self.decoder.teacher_forcing_prob if coin else None
+        self.graphs = {}
+        trainer.model.train()
+        for variant in self.variants:
+            self._pin(variant)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    self._eager()
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self._eager()
+            self.graphs[variant] = (graph, out)
+        self._pin(None)
+
+    def _pin(self, variant):
+        """force the decoder's host coin: 1.0 = always teacher-forced, 0.0 = never, None = restore"""
+        if self.prob is not None:
+            self.decoder.teacher_forcing_prob = self.prob if variant is None else (2.0 if variant else -1.0)
+
+    def _eager(self):
+        self.trainer.zero_grad()
+        loss, acc = self.trainer.loss_and_acc_for_batch(self.static, 0, 1, True)
+        loss.backward()
+        return loss.detach(), None if acc is None else acc.detach()
+
+    def __call__(self, batch):
+        data = self.trainer.process_batch_data(batch)
+        for dst, src in zip(self.static, data):
+            if dst.shape != src.shape:
+                raise ValueError(f'GraphedStep was captured for batches of shape {tuple(dst.shape)}, got {tuple(src.shape)}')
+            dst.copy_(src, non_blocking=True)
+        variant = None if self.prob is None else bool(torch.rand(1).item() < self.prob)
+        graph, out = self.graphs[variant]
+        graph.replay()
+        return out

@@ -115,11 +115,18 @@ class Encoder(Model):
         """use `eps` (B, z_dim) for the next reparameterised sample instead of drawing it."""
         self._eps_queue.append(eps)
 
+    static_eps = None                                        # tests: fixed noise buffer for eager-vs-graph comparisons
+
     def forward(self, score_tensor):
         """score (B, 24) int64 -> Normal(mu, exp(log_std)); the reparameterised sample computed by the same
         fused kernel travels with the distribution object (z_dist._arvae_sample)."""
         mu, log_std = self.encode_params(score_tensor)
-        eps = self._eps_queue.popleft().to(mu.device, torch.float32).contiguous() if self._eps_queue else torch.randn_like(mu)
+        if self._eps_queue:
+            eps = self._eps_queue.popleft().to(mu.device, torch.float32).contiguous()
+        elif self.static_eps is not None:                    # a device buffer read at run time (visible to a captured graph)
+            eps = self.static_eps
+        else:
+            eps = torch.randn_like(mu)
         sigma, z = ops.latent_head(mu, log_std, eps)
         z_dist = distributions.Normal(loc=mu, scale=sigma, validate_args=False)
         z_dist._arvae_sample = z

@@ -83,7 +83,7 @@ class FolkDataset:              # what MeasureVAE / MeasureVAETrainer read from 
         return self.class_name
 
 
-def build_side_workload(kind, device, batch):
+def build_side_workload(kind, device, batch, graphs=False):
     """(step function, unit) for the secondary workloads (not the headline metric): BASELINE.json configs[2], [4]."""
     from arvae_amd import synthetic as syn
     if kind == 'mnist':
@@ -107,6 +107,16 @@ def build_side_workload(kind, device, batch):
         trainer.cuda()
         score = torch.from_numpy(syn.measure_batch(batch, seed=5)).to(device)
         data = (score, score)
+        model.train()
+        if graphs:                                               # forward + backward replayed from HIP graphs (graphed.py)
+            from arvae_amd.graphed import GraphedStep
+            graphed = GraphedStep(trainer, data)
+
+            def gstep(i):
+                loss, _ = graphed(data)
+                trainer.step()
+                return loss
+            return gstep, 'measures/s'
     model.train()
 
     def step(i):
@@ -173,6 +183,7 @@ def main():
     ap.add_argument('--breakdown', action='store_true', help='print the per-kernel-family table to stderr')
     ap.add_argument('--force-dp', action='store_true',
                     help='run the data-parallel code path (RCCL all-gather + all-reduce) even with one rank')
+    ap.add_argument('--no-graphs', action='store_true', help='measure workload: eager launches instead of HIP-graph replay')
     ap.add_argument('--workload', default='dsprites', choices=['dsprites', 'mnist', 'measure'],
                     help='dsprites = the headline metric (default); mnist / measure = secondary single-GPU timings')
     args = ap.parse_args()
@@ -200,7 +211,7 @@ def main():
 
     if args.workload != 'dsprites':
         bsz = args.batch if args.batch != 512 else (1024 if args.workload == 'mnist' else 256)
-        side_step, unit = build_side_workload(args.workload, device, bsz)
+        side_step, unit = build_side_workload(args.workload, device, bsz, graphs=args.workload == 'measure' and not args.no_graphs)
         for i in range(args.warmup):
             side_step(i)
         torch.cuda.synchronize()
@@ -213,7 +224,8 @@ def main():
                           'value': bsz * args.steps / dt, 'unit': unit, 'n_gpus': 1, 'steps': args.steps,
                           'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
                           'dtype': 'f32', 'data': 'synthetic', 'final_loss': float(loss.detach()),
-                          'config': {'workload': args.workload, 'batch': bsz}}))
+                          'config': {'workload': args.workload, 'batch': bsz,
+                                     'launch': 'hip-graph replay of fwd+bwd' if args.workload == 'measure' and not args.no_graphs else 'eager'}}))
         return
 
     trainer, state = build_trainer(device, 2 if use_dp else 1)

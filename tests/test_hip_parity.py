@@ -716,6 +716,41 @@ def test_measure_forward_outputs_vs_golden(golden_dir, dev):
 
 
 # ---------------------------------------------------------------- data-parallel path on one GPU
+def test_graphed_measure_step_matches_eager(dev):
+    """HIP-graph replay of the MeasureVAE forward + backward (arvae_amd.graphed) against the eager step: same kernels
+    in the same order, so loss and gradients are bit-identical (dropout off, fixed noise buffer, coin pinned)."""
+    from arvae_amd.graphed import GraphedStep
+    from arvae_amd.measure_vae import MeasureVAE
+    from arvae_amd.measure_vae_trainer import MeasureVAETrainer
+    ds = _FolkDataset()
+    torch.manual_seed(0)
+    model = MeasureVAE(ds, 10, 2, 2, 64, 0.0, 16, 2, 64, 0.0, False, 'folk')
+    trainer = MeasureVAETrainer(ds, model, lr=1e-4, reg_type=('all',), reg_dim=(0, 1, 2, 3), beta=0.001, gamma=1.0,
+                                capacity=0.0, rand=0, delta=10.0)
+    trainer.cuda()
+    model.train()
+    b = 32
+    model.encoder.static_eps = torch.from_numpy(syn.normal_noise((b, 16), seed=3)).to(dev)
+    score = torch.from_numpy(syn.measure_batch(b, seed=8)).to(dev)
+    other = torch.from_numpy(syn.measure_batch(b, seed=9)).to(dev)
+    try:
+        graphed = GraphedStep(trainer, (other, other))           # captured on different data than it is replayed on
+        for forced in (True, False):
+            model.decoder.teacher_forcing_prob = 2.0 if forced else -1.0
+            trainer.zero_grad()
+            loss, _ = trainer.loss_and_acc_for_batch((score, score), 0, 1, True)
+            loss.backward()
+            want_loss, want_grad = float(loss), trainer.optimizer.grad_arena.clone()
+            graphed.prob = 2.0 if forced else -1.0
+            got_loss, _ = graphed((score, score))
+            torch.cuda.synchronize()
+            assert float(got_loss) == want_loss
+            assert torch.equal(trainer.optimizer.grad_arena, want_grad)
+    finally:
+        type(model.encoder).static_eps = None
+        model.encoder.static_eps = None
+
+
 def test_data_parallel_path_single_rank_rccl(dev):
     """world_size 1 over RCCL: the all-gather / all-reduce code path runs on the GPU and must give the same
     loss and gradients as the plain single-process step."""
