@@ -1,58 +1,31 @@
-"""Experiment: can the MeasureVAE forward + backward be captured in a HIP graph (torch.cuda.CUDAGraph)?"""
+"""Experiment: dSprites step with fwd+bwd replayed from a HIP graph vs eager."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from arvae_amd import synthetic as syn
-
+from arvae_amd.graphed import GraphedStep
 dev = torch.device('cuda:0')
-from arvae_amd.measure_vae import MeasureVAE
-from arvae_amd.measure_vae_trainer import MeasureVAETrainer
-ds = bench.FolkDataset()
-model = MeasureVAE(ds, 10, 2, 2, 128, 0.5, 32, 2, 128, 0.5, False, 'folk')
-trainer = MeasureVAETrainer(ds, model, lr=1e-4, reg_type=('all',), reg_dim=(0, 1, 2, 3), beta=0.001, gamma=1.0, capacity=0.0,
-                            rand=0, delta=10.0)
-trainer.cuda()
-model.train()
-score = torch.from_numpy(syn.measure_batch(256, seed=5)).to(dev)
+trainer, _ = bench.build_trainer(dev, 1)
+x, lab = syn.dsprites_batch(512, seed=1234)
+x, lab = torch.from_numpy(x).to(dev), torch.from_numpy(lab).to(dev)
 
 
-def fwd_bwd():
+def eager(i):
     trainer.zero_grad()
-    loss, _ = trainer.loss_and_acc_for_batch((score, score), 0, 0, True)
+    loss, _ = trainer.loss_and_acc_for_batch((x, lab), 0, i, True)
     loss.backward()
-    return loss
+    trainer.step()
 
 
-for _ in range(3):
-    fwd_bwd(); trainer.step()
-torch.cuda.synchronize()
-t = time.perf_counter()
-for _ in range(10):
-    fwd_bwd(); trainer.step()
-torch.cuda.synchronize()
-print('eager ms/step', (time.perf_counter() - t) / 10 * 1e3)
-
-model.decoder.use_teacher_forcing = False          # one control-flow variant for the experiment
-side = torch.cuda.Stream()
-side.wait_stream(torch.cuda.current_stream())
-with torch.cuda.stream(side):
-    for _ in range(3):
-        fwd_bwd()
-torch.cuda.current_stream().wait_stream(side)
-g = torch.cuda.CUDAGraph()
-try:
-    with torch.cuda.graph(g):
-        static_loss = fwd_bwd()
-except Exception as e:                                 # noqa: BLE001
-    print('capture failed:', type(e).__name__, str(e)[:400])
-    sys.exit(0)
-torch.cuda.synchronize()
-for _ in range(3):
-    g.replay(); trainer.step()
-torch.cuda.synchronize()
-t = time.perf_counter()
-for _ in range(20):
-    g.replay(); trainer.step()
-torch.cuda.synchronize()
-print('graph ms/step', (time.perf_counter() - t) / 20 * 1e3, 'loss', float(static_loss))
+for i in range(30): eager(i)
+torch.cuda.synchronize(); t = time.perf_counter()
+for i in range(200): eager(i)
+torch.cuda.synchronize(); print('eager ms/step', (time.perf_counter() - t) / 200 * 1e3)
+g = GraphedStep(trainer, (x, lab))
+for i in range(30):
+    g((x, lab)); trainer.step()
+torch.cuda.synchronize(); t = time.perf_counter()
+for i in range(200):
+    g((x, lab)); trainer.step()
+torch.cuda.synchronize(); print('graph ms/step', (time.perf_counter() - t) / 200 * 1e3)
