@@ -1505,7 +1505,10 @@ template <int LO, int MODE>
 static void launch_down_v(int grid, const Operand &hi, const float *wt, const Ep32 &ep, int n, int tiles, hipStream_t s) {
     static const bool small_ok = getenv("ARVAE_NO_SMALL_TILES") == nullptr;     // diagnostic switch
     // (the 8x8 layers measured 2 us slower on this variant than on one full-K tile per CU)
-    if (LO == 4 && small_ok && 2 * tiles <= cu_count()) return launch_down_small<4, MODE>(hi, wt, ep, n, s);
+    static const bool fp32_only = getenv("ARVAE_CONV32_FP32") != nullptr;
+    // 4x4 layers: the K-split 32-pixel kernel whenever the big tiles underfill the chip -- and always in the default
+    // precision mode, because two packed three-term images of eight 4x4 patches (166 KB) do not fit the LDS
+    if (LO == 4 && ((small_ok && 2 * tiles <= cu_count()) || !fp32_only)) return launch_down_small<4, MODE>(hi, wt, ep, n, s);
     // Experimental (off by default): the Down kernels on the split-bf16 MFMA.  Measured at B=512: down32<16> 45 -> 28.5 us
     // with three truncated products (2^-15 relative error), ~31 us with this four-product round-to-nearest version
     // (2^-17).  The loss terms and z stay within the 1e-4 parity bar, but ReLU units whose pre-activation is within

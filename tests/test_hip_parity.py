@@ -436,9 +436,10 @@ def test_three_steps_track_oracle(dev, fused):
         close(got['params'][name], cur[name], rtol=0, atol=1e-5)
 
 
-@pytest.mark.parametrize('b', [3, 37, 130])
+@pytest.mark.parametrize('b', [3, 37, 130, 1100])
 def test_image_step_ragged_batches_vs_oracle(dev, b):
-    """Batch sizes that leave partial tiles in every kernel (whole-image tiles of 2 / 8 images, 8-row head blocks)."""
+    """Batch sizes that leave partial tiles in every kernel (whole-image tiles of 2 / 8 images, 8-row head blocks); 1100
+    is past the size where the 8x8 / 4x4 layers switch from their small-tile to their 128-pixel kernels."""
     state = syn.synth_state(o_vae.DSPRITES_SHAPES, 9, 1.6)
     x, lab = syn.dsprites_batch(b, seed=50 + b)
     eps = syn.normal_noise((b, 10), seed=60 + b)
