@@ -138,19 +138,20 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_dgrad_kernel(DenseArgs p)
 }
 
 // ---- wgrad: dW[n][feat_in(km)] += sum_m G[m][mem_out(n)] * X[m][km] ;  db[n] += sum_m G[m][mem_out(n)] ------
-// KU chunks are fetched per wave before the first MFMA, with unconditional loads (clamped row, zeroed by a select):
-// the tile lives on memory latency and every separately awaited load costs a full round trip.
-constexpr int KU = 4;
+// KU chunks are fetched per wave before the first MFMA, with unconditional loads (clamped row, zeroed by a select): the
+// operands were written a whole pass ago and come from HBM with a row pitch of 1-2 KB, so a tile lives on memory
+// latency (a single tile takes ~16 us cold, 9 us when its input was just read: measured per job).
 
-template <bool PLAIN>
+template <bool PLAIN, int NWT>
 __device__ __forceinline__ void dense_wgrad_loop(const DenseArgs &p, int ncol, int kcol, bool nok, bool kok, int wave, int half,
                                                  f32x16 &acc, float &bsum) {
+    constexpr int KU = 4;                                        // 8 did not help (measured): the tile is not load-count bound
     const int chunks = (p.batch + 7) / 8;
-    for (int q0 = wave; q0 < chunks; q0 += KU * NW) {
+    for (int q0 = wave; q0 < chunks; q0 += KU * NWT) {
         float a[KU][4], b[KU][4];
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
-            const int m0 = (q0 + u * NW) * 8 + half * 4;
+            const int m0 = (q0 + u * NWT) * 8 + half * 4;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const bool ok = m0 + t < p.batch;
@@ -170,7 +171,10 @@ __device__ __forceinline__ void dense_wgrad_loop(const DenseArgs &p, int ncol, i
     }
 }
 
+// NWT waves split the batch (K) axis of one 32x32 tile of dW; wave w finishes accumulator registers w*16/NWT ...
+template <int NWT>
 __device__ __forceinline__ void dense_wgrad_tile(const DenseArgs &p, int bx, int by, float *red) {
+    constexpr int RPW = 16 / NWT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, rc = lane & 31;
     const int n = bx * 32 + rc, km = by * 32 + rc;
     const bool nok = n < p.n_out, kok = km < p.n_in;
@@ -179,15 +183,31 @@ __device__ __forceinline__ void dense_wgrad_tile(const DenseArgs &p, int bx, int
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     float bsum = 0.f;
-    // this lane's dW element: read early, added to after the reduction
-    const int out_row = bx * 32 + (wave & 3) + 8 * (wave >> 2) + 4 * half;      // n
-    const bool out_ok = kok && out_row < p.n_out;
-    float *outp = p.out + (out_ok ? (int64_t)out_row * p.n_in + p.in_perm.to_feat(km) : 0);
-    const float old = *outp;
-    if (p.a.y == nullptr) dense_wgrad_loop<true>(p, ncol, kcol, nok, kok, wave, half, acc, bsum);
-    else dense_wgrad_loop<false>(p, ncol, kcol, nok, kok, wave, half, acc, bsum);
-    const float v = reduce_waves(red, acc, wave, lane);
-    if (out_ok) *outp = old + v;
+    // this lane's dW elements: read early, added to after the reduction
+    float *outp[RPW];
+    float old[RPW];
+    bool out_ok[RPW];
+#pragma unroll
+    for (int e = 0; e < RPW; ++e) {
+        const int reg = wave * RPW + e;
+        const int out_row = bx * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;      // n
+        out_ok[e] = kok && out_row < p.n_out;
+        outp[e] = p.out + (out_ok[e] ? (int64_t)out_row * p.n_in + p.in_perm.to_feat(km) : 0);
+        old[e] = *outp[e];
+    }
+    if (p.a.y == nullptr) dense_wgrad_loop<true, NWT>(p, ncol, kcol, nok, kok, wave, half, acc, bsum);
+    else dense_wgrad_loop<false, NWT>(p, ncol, kcol, nok, kok, wave, half, acc, bsum);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < RPW; ++e) {
+        float v = 0.f;
+#pragma unroll
+        for (int ws = 0; ws < NWT; ++ws) v += red[(ws * 16 + wave * RPW + e) * 64 + lane];
+        if (out_ok[e]) *outp[e] = old[e] + v;
+    }
     if (p.dbias != nullptr && by == 0) {
         __syncthreads();
         red[wave * 64 + lane] = bsum;
@@ -195,7 +215,7 @@ __device__ __forceinline__ void dense_wgrad_tile(const DenseArgs &p, int bx, int
         if (wave == 0 && half == 0 && nok) {
             float tot = 0.f;
 #pragma unroll
-            for (int ws = 0; ws < NW; ++ws) tot += red[ws * 64 + rc] + red[ws * 64 + rc + 32];
+            for (int ws = 0; ws < NWT; ++ws) tot += red[ws * 64 + rc] + red[ws * 64 + rc + 32];
             p.dbias[n] += tot;
         }
     }
@@ -203,20 +223,22 @@ __device__ __forceinline__ void dense_wgrad_tile(const DenseArgs &p, int bx, int
 
 __global__ __launch_bounds__(DENSE_THREADS) void dense_wgrad_kernel(DenseArgs p) {
     __shared__ float red[NW * 16 * 64];
-    dense_wgrad_tile(p, blockIdx.x, blockIdx.y, red);
+    dense_wgrad_tile<NW>(p, blockIdx.x, blockIdx.y, red);
 }
 
 // Weight gradients of several Linear layers in ONE launch: they are independent once every layer's output gradient
 // exists, and each alone is a launch-latency-bound 8..128-tile problem.  Workgroup -> (job, tile) through the
-// running tile count.
-__global__ __launch_bounds__(DENSE_THREADS, 2) void dense_wgrad_batch_kernel(DenseWgradBatch b) {
-    __shared__ float red[NW * 16 * 64];
+// running tile count.  8 waves per tile here (32 KB of LDS): the ~400 tiles of the dSprites stack are then all
+// resident at once instead of in two rounds of 1024-thread workgroups.
+constexpr int NWB = 8;
+__global__ __launch_bounds__(64 * NWB, 2) void dense_wgrad_batch_kernel(DenseWgradBatch b) {
+    __shared__ float red[NWB * 16 * 64];
     int j = 0;
     while (j + 1 < b.count && (int)blockIdx.x >= b.tile_end[j]) ++j;
     const int tile = blockIdx.x - (j > 0 ? b.tile_end[j - 1] : 0);
     const DenseArgs &p = b.job[j];
     const int tx = (p.n_out + 31) / 32;
-    dense_wgrad_tile(p, tile % tx, tile / tx, red);
+    dense_wgrad_tile<NWB>(p, tile % tx, tile / tx, red);
 }
 
 bool dense_fits(const arvae_link_t *l) {
@@ -268,7 +290,19 @@ bool dense_wgrad_defer(DenseWgradBatch *b, const arvae_link_t *l, const Operand 
 
 int dense_wgrad_flush(DenseWgradBatch *b, hipStream_t s) {
     if (b->count == 0) return ARVAE_OK;
-    hipLaunchKernelGGL(dense_wgrad_batch_kernel, dim3(b->tile_end[b->count - 1]), dim3(DENSE_THREADS), 0, s, *b);
+    static const bool split = getenv("ARVAE_DENSE_BATCH_SPLIT") != nullptr;     // diagnostic: one launch per job
+    if (split) {
+        for (int j = 0; j < b->count; ++j) {
+            DenseWgradBatch one{};
+            one.count = 1;
+            one.job[0] = b->job[j];
+            one.tile_end[0] = b->tile_end[j] - (j > 0 ? b->tile_end[j - 1] : 0);
+            hipLaunchKernelGGL(dense_wgrad_batch_kernel, dim3(one.tile_end[0]), dim3(64 * NWB), 0, s, one);
+        }
+        b->count = 0;
+        return check_launch("dense_wgrad_batch_kernel");
+    }
+    hipLaunchKernelGGL(dense_wgrad_batch_kernel, dim3(b->tile_end[b->count - 1]), dim3(64 * NWB), 0, s, *b);
     b->count = 0;
     return check_launch("dense_wgrad_batch_kernel");
 }
