@@ -320,35 +320,40 @@ struct VaeFinishArgs {
 };
 
 __global__ __launch_bounds__(1024) void vae_finish_kernel(VaeFinishArgs p) {
-    __shared__ float red[16];
-    // every load first (one round of memory latency), then the four reductions
+    __shared__ float4 red4[16];
+    // every load first (one round of memory latency), then ONE four-wide reduction; 32-bit index math throughout
     float a = 0.f, b = 0.f, s = 0.f, t = 0.f;
     for (int i = threadIdx.x; i < p.nb; i += 1024) {
         a += p.rec_partial[2 * i];
         b += p.rec_partial[2 * i + 1];
     }
-    for (int64_t i = threadIdx.x; i < p.bz; i += 1024) s += kl_elem(p.mu[i], p.sigma[i], 0.f, 1.f);
+    const int bz = (int)p.bz;
+    for (int i = threadIdx.x; i < bz; i += 1024) s += kl_elem(p.mu[i], p.sigma[i], 0.f, 1.f);
     if (p.row_loss != nullptr) {
-        for (int64_t i = threadIdx.x; i < p.n_rows * p.r; i += 1024) t += p.row_loss[i];
+        const int n_rows = (int)p.n_rows, ldz = (int)p.ldz, nr = n_rows * p.r, nz = n_rows * ldz;
+        for (int i = threadIdx.x; i < nr; i += 1024) t += p.row_loss[i];
         if (p.dz != nullptr) {                                   // dz[row][c] = grad_scale * row_grad[k][row] for c = dims[k], else 0
-            for (int64_t i = threadIdx.x; i < p.n_rows * p.ldz; i += 1024) {
-                const int64_t row = i / p.ldz;
-                const int c = (int)(i - row * p.ldz);
+            for (int i = threadIdx.x; i < nz; i += 1024) {
+                const int row = i / ldz, c = i - row * ldz;
                 int k = -1;                                       // index arithmetic only, then ONE unconditional load
 #pragma unroll
                 for (int q = 0; q < 16; ++q)
                     if (q < p.r && p.dims.d[q] == c) k = q;
-                const float g = p.row_grad[(int64_t)(k < 0 ? 0 : k) * p.n_rows + row];
+                const float g = p.row_grad[(k < 0 ? 0 : k) * n_rows + row];
                 p.dz[i] = k < 0 ? 0.f : p.grad_scale * g;
             }
         }
     }
-    const float rec = block_sum_1024(a, red) * p.inv_batch;
-    const float acc = block_sum_1024(b, red) * p.inv_count;
-    const float kl = block_sum_1024(s, red) * p.inv_batch;
-    const float reg = block_sum_1024(t, red) * p.loss_scale;
-    const float dist = p.beta * fabsf(kl - (p.cap ? p.cap[0] : 0.f));
+    float4 v = make_float4(wave_sum(a), wave_sum(b), wave_sum(s), wave_sum(t));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) red4[wave] = v;
+    __syncthreads();
     if (threadIdx.x == 0) {
+        float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { tot.x += red4[w].x; tot.y += red4[w].y; tot.z += red4[w].z; tot.w += red4[w].w; }
+        const float rec = tot.x * p.inv_batch, acc = tot.y * p.inv_count, kl = tot.z * p.inv_batch, reg = tot.w * p.loss_scale;
+        const float dist = p.beta * fabsf(kl - (p.cap ? p.cap[0] : 0.f));
         p.rec_out[0] = rec; p.rec_out[1] = acc;
         p.kld_out[0] = dist; p.kld_out[1] = kl;
         if (p.row_loss != nullptr) p.reg_out[0] = reg;
