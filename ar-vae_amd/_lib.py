@@ -10,7 +10,7 @@ import threading
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libarvae_hip.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_i32, c_i64, c_f32, c_f64, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
 
@@ -42,6 +42,13 @@ class ImageVaeDesc(ctypes.Structure):
                 ('n_reg', c_i32), ('reg_dims', c_i32 * 16), ('beta', c_f32), ('gamma', c_f32), ('delta', c_f32)]
 
 
+class GruSeqDesc(ctypes.Structure):
+    """arvae_gru_seq_t"""
+    _fields_ = [('gi', c_vp), ('gi_tstride', c_i64), ('w_hh', c_vp), ('b_hh', c_vp), ('h0', c_vp), ('h_all', c_vp),
+                ('h_stride', c_i64), ('saved', c_vp), ('reverse', c_i32), ('reserved', c_i32), ('dh_all', c_vp),
+                ('dh_stride', c_i64), ('dgi', c_vp), ('dgh', c_vp), ('dh0', c_vp)]
+
+
 _P = ctypes.POINTER
 # name -> (restype, argtypes); must list every symbol declared in include/arvae_hip.h
 SIGNATURES = {
@@ -69,8 +76,12 @@ SIGNATURES = {
     'arvae_scale_by_scalar': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp]),
     'arvae_gru_gates_fwd': (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
     'arvae_gru_gates_bwd': (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    'arvae_gru_seq_supported': (c_i32, [c_i32]),
+    'arvae_gru_seq_fwd': (c_i32, [_P(GruSeqDesc), c_i32, c_i32, c_i32, c_i32, c_vp]),
+    'arvae_gru_seq_bwd': (c_i32, [_P(GruSeqDesc), c_i32, c_i32, c_i32, c_i32, c_vp]),
     'arvae_embed_fwd': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
-    'arvae_embed_bwd': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    'arvae_embed_bwd_ws_floats': (c_i64, [c_i32, c_i32, c_i32, c_i32]),
+    'arvae_embed_bwd': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     'arvae_row_argmax': (c_i32, [c_vp, c_i32, c_i32, c_vp, c_vp]),
     'arvae_concat_cols': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
     'arvae_split_cols': (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp]),

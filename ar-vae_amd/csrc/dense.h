@@ -20,7 +20,11 @@ struct DenseArgs {
     const float *gate;  // dgrad: optional saved activation of the dX location: dX *= (gate > 0)
     int batch, n_in, n_out, act;
     Perm in_perm, out_perm;
+    int store = 0;      // wgrad: write the tile (and bias sums) instead of adding to what is there
 };
+
+constexpr int DENSE_SPLIT_ROWS = 512;        // rows per workgroup slice of the row-split weight gradient
+constexpr int DENSE_SPLIT_MIN_ROWS = 2048;   // shorter reduction axes stay on the one-workgroup-per-tile kernel
 
 constexpr int DENSE_BATCH_MAX = 8;
 struct DenseWgradBatch {
@@ -32,7 +36,8 @@ struct DenseWgradBatch {
 bool dense_fits(const arvae_link_t *l);
 int dense_fwd(const arvae_link_t *l, const float *x, const float *w, const float *bias, int act, float *y, hipStream_t s);
 int dense_dgrad(const arvae_link_t *l, const Operand &g, const float *w, const float *gate, float *dx, hipStream_t s);
-int dense_wgrad(const arvae_link_t *l, const Operand &g, const float *x, float *dw, float *dbias, hipStream_t s);
+int64_t dense_wgrad_ws_floats(const arvae_link_t *l);
+int dense_wgrad(const arvae_link_t *l, const Operand &g, const float *x, float *dw, float *dbias, float *ws, hipStream_t s);
 bool dense_wgrad_defer(DenseWgradBatch *b, const arvae_link_t *l, const Operand &g, const float *x, float *dw, float *dbias);
 int dense_wgrad_flush(DenseWgradBatch *b, hipStream_t s);
 

@@ -193,7 +193,7 @@ __device__ __forceinline__ void dense_wgrad_tile(const DenseArgs &p, int bx, int
         const int out_row = bx * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;      // n
         out_ok[e] = kok && out_row < p.n_out;
         outp[e] = p.out + (out_ok[e] ? (int64_t)out_row * p.n_in + p.in_perm.to_feat(km) : 0);
-        old[e] = *outp[e];
+        old[e] = p.store ? 0.f : *outp[e];
     }
     if (p.a.y == nullptr) dense_wgrad_loop<true, NWT>(p, ncol, kcol, nok, kok, wave, half, acc, bsum);
     else dense_wgrad_loop<false, NWT>(p, ncol, kcol, nok, kok, wave, half, acc, bsum);
@@ -216,7 +216,7 @@ __device__ __forceinline__ void dense_wgrad_tile(const DenseArgs &p, int bx, int
             float tot = 0.f;
 #pragma unroll
             for (int ws = 0; ws < NWT; ++ws) tot += red[ws * 64 + rc] + red[ws * 64 + rc + 32];
-            p.dbias[n] += tot;
+            p.dbias[n] = (p.store ? 0.f : p.dbias[n]) + tot;
         }
     }
 }
@@ -224,6 +224,36 @@ __device__ __forceinline__ void dense_wgrad_tile(const DenseArgs &p, int bx, int
 __global__ __launch_bounds__(DENSE_THREADS) void dense_wgrad_kernel(DenseArgs p) {
     __shared__ float red[NW * 16 * 64];
     dense_wgrad_tile<NW>(p, blockIdx.x, blockIdx.y, red);
+}
+
+// Row-split weight gradient for long reduction axes (the MeasureVAE's whole-sequence GEMMs: 24 ticks x batch = 6144
+// rows).  blockIdx.z owns a slice of DENSE_SPLIT_ROWS rows and STORES its partial tile (and bias sums) into the
+// workspace; dense_split_reduce_kernel then adds the slices to dW / db in slice order (fixed summation order).
+__global__ __launch_bounds__(DENSE_THREADS) void dense_wgrad_split_kernel(DenseArgs p, float *ws, int64_t slice_floats) {
+    __shared__ float red[NW * 16 * 64];
+    const int m0 = blockIdx.z * DENSE_SPLIT_ROWS;
+    DenseArgs q = p;
+    q.a.v += (int64_t)m0 * p.n_out;
+    if (q.a.y != nullptr) q.a.y += (int64_t)m0 * p.n_out;
+    if (q.a.mask != nullptr) q.a.mask += (int64_t)m0 * p.n_out;
+    q.x += (int64_t)m0 * p.n_in;
+    q.batch = min(DENSE_SPLIT_ROWS, p.batch - m0);
+    q.out = ws + blockIdx.z * slice_floats;
+    q.dbias = p.dbias != nullptr ? q.out + (int64_t)p.n_out * p.n_in : nullptr;
+    q.store = 1;
+    dense_wgrad_tile<NW>(q, blockIdx.x, blockIdx.y, red);
+}
+
+__global__ __launch_bounds__(256) void dense_split_reduce_kernel(const float *__restrict__ ws, int64_t slice_floats, int slices,
+                                                                  int64_t w_floats, int n_out, float *__restrict__ dw,
+                                                                  float *__restrict__ dbias) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = w_floats + (dbias != nullptr ? n_out : 0);
+    if (i >= total) return;
+    float s = 0.f;
+    for (int z = 0; z < slices; ++z) s += ws[z * slice_floats + i];
+    if (i < w_floats) dw[i] += s;
+    else dbias[i - w_floats] += s;
 }
 
 // Weight gradients of several Linear layers in ONE launch: they are independent once every layer's output gradient
@@ -270,9 +300,25 @@ int dense_dgrad(const arvae_link_t *l, const Operand &g, const float *w, const f
     return check_launch("dense_dgrad_kernel");
 }
 
-int dense_wgrad(const arvae_link_t *l, const Operand &g, const float *x, float *dw, float *dbias, hipStream_t s) {
+int64_t dense_wgrad_ws_floats(const arvae_link_t *l) {
+    if (l->n < DENSE_SPLIT_MIN_ROWS) return 0;
+    const int64_t slices = (l->n + DENSE_SPLIT_ROWS - 1) / DENSE_SPLIT_ROWS;
+    return slices * ((int64_t)l->clo * l->chi + l->clo);
+}
+
+int dense_wgrad(const arvae_link_t *l, const Operand &g, const float *x, float *dw, float *dbias, float *ws, hipStream_t s) {
     DenseArgs p = dense_args(l);
     p.a = g; p.x = x; p.out = dw; p.dbias = dbias;
+    if (ws != nullptr && dense_wgrad_ws_floats(l) > 0) {
+        const int slices = (p.batch + DENSE_SPLIT_ROWS - 1) / DENSE_SPLIT_ROWS;
+        const int64_t w_floats = (int64_t)p.n_out * p.n_in, slice_floats = w_floats + p.n_out;
+        hipLaunchKernelGGL(dense_wgrad_split_kernel, dim3((p.n_out + 31) / 32, (p.n_in + 31) / 32, slices), dim3(DENSE_THREADS),
+                           0, s, p, ws, slice_floats);
+        const int64_t total = w_floats + (dbias != nullptr ? p.n_out : 0);
+        hipLaunchKernelGGL(dense_split_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws, slice_floats,
+                           slices, w_floats, p.n_out, dw, dbias);
+        return check_launch("dense_wgrad_split_kernel");
+    }
     hipLaunchKernelGGL(dense_wgrad_kernel, dim3((p.n_out + 31) / 32, (p.n_in + 31) / 32), dim3(DENSE_THREADS), 0, s, p);
     return check_launch("dense_wgrad_kernel");
 }

@@ -24,7 +24,8 @@ constexpr int BK = 32;
 bool dense_fits(const arvae_link_t *l);
 int dense_fwd(const arvae_link_t *l, const float *x, const float *w, const float *bias, int act, float *y, hipStream_t s);
 int dense_dgrad(const arvae_link_t *l, const Operand &g, const float *w, const float *gate, float *dx, hipStream_t s);
-int dense_wgrad(const arvae_link_t *l, const Operand &g, const float *x, float *dw, float *dbias, hipStream_t s);
+int64_t dense_wgrad_ws_floats(const arvae_link_t *l);
+int dense_wgrad(const arvae_link_t *l, const Operand &g, const float *x, float *dw, float *dbias, float *ws, hipStream_t s);
 
 // 1-channel 64x64 image links (conv_c1.hip)
 bool conv_c1_fits(const arvae_link_t *l);
@@ -633,6 +634,7 @@ extern "C" int64_t arvae_link_wgrad_ws_floats(const arvae_link_t *link) {
     if (blocks * link->clo > need) need = blocks * link->clo;
     channel_sum_split((int64_t)link->n * link->hh * link->hw, blocks, rpb);
     if (blocks * link->chi > need) need = blocks * link->chi;
+    if (dense_fits(link) && dense_wgrad_ws_floats(link) > need) need = dense_wgrad_ws_floats(link);
     if (conv32_fits(link) && conv32_wgrad_ws_floats(link) > need) need = conv32_wgrad_ws_floats(link);
     if (conv_c1_fits(link) && conv_c1_wgrad_ws_floats(link) > need) need = conv_c1_wgrad_ws_floats(link);
     return need;
@@ -648,7 +650,7 @@ extern "C" int arvae_link_wgrad(const arvae_link_t *link, const arvae_operand_t 
                   "link_wgrad: workspace of arvae_link_wgrad_ws_floats() floats needed");
     hipStream_t st = as_stream(stream);
     if (dense_fits(link) && hi->y == nullptr && bias_side != 2)
-        return dense_wgrad(link, make_operand(lo), hi->v, dwt, bias_side == 1 ? dbias : nullptr, st);
+        return dense_wgrad(link, make_operand(lo), hi->v, dwt, bias_side == 1 ? dbias : nullptr, ws, st);
     if (conv_c1_fits(link) && lo->mask == nullptr && hi->mask == nullptr && lo->act != ARVAE_ACT_SELU &&
         hi->act != ARVAE_ACT_SELU)
         return conv_c1_wgrad(link, make_operand(lo), make_operand(hi), dwt, dbias, bias_side, ws, st);

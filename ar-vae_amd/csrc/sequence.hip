@@ -72,31 +72,42 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t *__restric
     }
 }
 
-// dtable[v][d] += sum over positions with idx == v of g[row][d]; one workgroup per vocabulary row: fixed order
-__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t *__restrict__ idx, const float *__restrict__ g,
-                                                         int batch, int steps, int dim, int time_major,
-                                                         float *__restrict__ dtable) {
-    __shared__ float red[256];
-    const int v = blockIdx.x;
-    const int d = threadIdx.x % dim, lane_row = threadIdx.x / dim, rows_par = 256 / dim;
-    float s = 0.f;
-    if (lane_row < rows_par) {
-        const int64_t n = (int64_t)batch * steps;
-        for (int64_t pos = lane_row; pos < n; pos += rows_par) {           // pos = b*steps + t
-            if (idx[pos] == v) {
-                const int b = (int)(pos / steps), t = (int)(pos % steps);
-                const int64_t row = time_major ? (int64_t)t * batch + b : pos;
-                s += g[row * dim + d];
-            }
-        }
+// dtable[v][d] += sum over positions with idx == v of g[row][d], in two launches with a fixed summation order:
+// (1) a workgroup stages 256 positions (indices + gradient rows) in LDS and one thread per (v, d) pair sums the rows
+// whose index is v; (2) the per-workgroup partials are added in workgroup order.
+constexpr int EMBED_POS = 256;
+__global__ __launch_bounds__(256) void embed_bwd_partial_kernel(const int64_t *__restrict__ idx, const float *__restrict__ g,
+                                                                 int batch, int steps, int dim, int vocab, int time_major,
+                                                                 float *__restrict__ partial) {
+    extern __shared__ float sg[];                            // [EMBED_POS][dim + 1] then int sidx[EMBED_POS]
+    const int pitch = dim + 1;
+    int *sidx = reinterpret_cast<int *>(sg + EMBED_POS * pitch);
+    const int64_t n = (int64_t)batch * steps;
+    const int64_t pos = (int64_t)blockIdx.x * EMBED_POS + threadIdx.x;         // pos = b*steps + t
+    if (pos < n) {
+        const int b = (int)(pos / steps), t = (int)(pos % steps);
+        const int64_t row = time_major ? (int64_t)t * batch + b : pos;
+        sidx[threadIdx.x] = (int)idx[pos];
+        for (int d = 0; d < dim; ++d) sg[threadIdx.x * pitch + d] = g[row * dim + d];
+    } else {
+        sidx[threadIdx.x] = -1;
     }
-    red[threadIdx.x] = s;
     __syncthreads();
-    if (threadIdx.x < dim) {
-        float tot = 0.f;
-        for (int j = 0; j < rows_par; ++j) tot += red[j * dim + threadIdx.x];
-        dtable[(int64_t)v * dim + threadIdx.x] += tot;
+    for (int pair = threadIdx.x; pair < vocab * dim; pair += 256) {
+        const int v = pair / dim, d = pair - v * dim;
+        float s = 0.f;
+#pragma unroll 8
+        for (int p = 0; p < EMBED_POS; ++p) s += sidx[p] == v ? sg[p * pitch + d] : 0.f;
+        partial[(int64_t)blockIdx.x * vocab * dim + pair] = s;
     }
+}
+__global__ __launch_bounds__(256) void embed_bwd_reduce_kernel(const float *__restrict__ partial, int blocks, int count,
+                                                                float *__restrict__ dtable) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    float s = 0.f;
+    for (int z = 0; z < blocks; ++z) s += partial[(int64_t)z * count + i];
+    dtable[i] += s;
 }
 
 // idx[b] = argmax_j w[b][j], lowest index on ties (reference decoder.py:506-507 topk(1))
@@ -219,12 +230,20 @@ extern "C" int arvae_embed_fwd(const int64_t *idx, const float *table, int32_t b
     return check_launch("embed_fwd_kernel");
 }
 
+extern "C" int64_t arvae_embed_bwd_ws_floats(int32_t batch, int32_t steps, int32_t dim, int32_t vocab) {
+    const int64_t blocks = ((int64_t)batch * steps + EMBED_POS - 1) / EMBED_POS;
+    return blocks * vocab * dim;
+}
+
 extern "C" int arvae_embed_bwd(const int64_t *idx, const float *g, int32_t batch, int32_t steps, int32_t dim,
-                               int32_t vocab, int32_t time_major, float *dtable, arvae_stream_t stream) {
-    ARVAE_REQUIRE(idx && g && dtable && batch > 0 && steps > 0 && dim > 0 && dim <= 256 && vocab > 0,
-                  "embed_bwd: bad argument (dim must be <= 256)");
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(vocab), dim3(256), 0, as_stream(stream), idx, g, batch, steps, dim, time_major,
-                       dtable);
+                               int32_t vocab, int32_t time_major, float *dtable, float *ws, arvae_stream_t stream) {
+    ARVAE_REQUIRE(idx && g && dtable && ws && batch > 0 && steps > 0 && dim > 0 && dim <= 128 && vocab > 0,
+                  "embed_bwd: bad argument (dim must be <= 128, ws = arvae_embed_bwd_ws_floats() floats)");
+    const int blocks = (int)(((int64_t)batch * steps + EMBED_POS - 1) / EMBED_POS);
+    const size_t lds = (size_t)EMBED_POS * (dim + 1) * sizeof(float) + EMBED_POS * sizeof(int);
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(embed_bwd_partial_kernel, dim3(blocks), dim3(256), lds, st, idx, g, batch, steps, dim, vocab, time_major, ws);
+    hipLaunchKernelGGL(embed_bwd_reduce_kernel, dim3((vocab * dim + 255) / 256), dim3(256), 0, st, ws, blocks, vocab * dim, dtable);
     return check_launch("embed_bwd_kernel");
 }
 

@@ -6,6 +6,7 @@ Same class names, constructor arguments, forward contract and state_dict keys as
 The GEMMs of the GRUs run on the dense MFMA kernels, the gate math / embedding / argmax feedback on the
 sequence kernels (csrc/sequence.hip); autograd chains them (round 1: one autograd node per kernel).
 """
+import os
 from collections import deque
 
 import torch
@@ -59,6 +60,12 @@ def _gru_step(x_proj, h, w_hh, b_hh):
     """one GRU time step given the input projection gi = W_ih x + b_ih."""
     gh = ops.dense(h, w_hh, b_hh, Link.dense(w_hh.shape[1], w_hh.shape[0]), ACT_NONE)
     return ops.gru_gates(x_proj, gh, h)
+
+
+def _use_sequence_kernels(hidden):
+    """whole-sequence GRU launches (csrc/gru_seq.hip) when the hidden size is built; ARVAE_GRU_STEPWISE=1 keeps the
+    one-launch-per-time-step path (A/B measurements, and the only path for other hidden sizes)."""
+    return os.environ.get('ARVAE_GRU_STEPWISE', '0') != '1' and ops.gru_sequence_supported(hidden)
 
 
 class Encoder(Model):
@@ -132,18 +139,40 @@ class Encoder(Model):
         z_dist._arvae_sample = z
         return z_dist
 
+    def _layer_sequence(self, x_all, steps, b, layer):
+        """x_all (T*B, in), time-major rows -> (T, B, 2H): both directions of one layer in one sequence launch."""
+        dirs = []
+        for suffix in ('', '_reverse'):
+            w_ih, w_hh, b_ih, b_hh = self.lstm.cell(layer, suffix)
+            gi = ops.dense(x_all, w_ih, b_ih, Link.dense(w_ih.shape[1], w_ih.shape[0]), ACT_NONE)
+            dirs.append((gi.view(steps, b, -1), w_hh, b_hh, None, suffix != ''))
+        return ops.gru_sequence(steps, dirs)
+
     def encode_params(self, score_tensor):
         """-> (mu, log_std)"""
         b, steps = score_tensor.shape
+        hid = self.rnn_hidden_size
         emb = ops.embed(score_tensor, self.note_embedding_layer.weight, time_major=True)      # (T, B, E)
-        seq = list(torch.unbind(emb, 0))
-        seq, finals0 = self._layer(seq, 0)
-        if self.training and self.dropout > 0:
+        dropping = self.training and self.dropout > 0
+        mask = None
+        if dropping:
             mask = self._mask_queue.popleft().to(emb.device) if self._mask_queue else \
-                (torch.rand(steps, b, 2 * self.rnn_hidden_size, device=emb.device) >= self.dropout).to(torch.uint8)
-            seq = [ops.dropout_mask(s, m, self.dropout) for s, m in zip(seq, torch.unbind(mask.contiguous(), 0))]
-        _, finals1 = self._layer(seq, 1)
-        hidden = ops.concat_cols(ops.concat_cols(finals0[0], finals0[1]), ops.concat_cols(finals1[0], finals1[1]))
+                (torch.rand(steps, b, 2 * hid, device=emb.device) >= self.dropout).to(torch.uint8)
+        if _use_sequence_kernels(hid):
+            out0 = self._layer_sequence(emb.view(steps * b, -1), steps, b, 0)
+            mid = out0.view(steps * b, 2 * hid)
+            if dropping:
+                mid = ops.dropout_mask(mid, mask.contiguous().view(steps * b, 2 * hid), self.dropout)
+            out1 = self._layer_sequence(mid, steps, b, 1)
+            # h_n of nn.GRU: (layer 0 fwd, layer 0 rev, layer 1 fwd, layer 1 rev), each direction's LAST processed step
+            hidden = torch.cat((out0[steps - 1, :, :hid], out0[0, :, hid:], out1[steps - 1, :, :hid], out1[0, :, hid:]), 1)
+        else:
+            seq = list(torch.unbind(emb, 0))
+            seq, finals0 = self._layer(seq, 0)
+            if dropping:
+                seq = [ops.dropout_mask(s, m, self.dropout) for s, m in zip(seq, torch.unbind(mask.contiguous(), 0))]
+            _, finals1 = self._layer(seq, 1)
+            hidden = ops.concat_cols(ops.concat_cols(finals0[0], finals0[1]), ops.concat_cols(finals1[0], finals1[1]))
         mu = _lin(_lin(hidden, self.linear_mean[0], ACT_SELU), self.linear_mean[2], ACT_NONE)
         log_std = _lin(_lin(hidden, self.linear_log_std[0], ACT_SELU), self.linear_log_std[2], ACT_NONE)
         return mu, log_std
@@ -229,8 +258,85 @@ class HierarchicalDecoder(Decoder):
                 h = self.rnn_hidden_size
                 masks = ((torch.rand(4, b, h, device=z.device) >= self.dropout).to(torch.uint8),
                          (torch.rand(24, b, h, device=z.device) >= self.dropout).to(torch.uint8))
+        if _use_sequence_kernels(self.rnn_hidden_size):
+            beat_out = self.beat_rnn_sequence(z, 4, masks[0])
+            return self.tick_rnn_sequence(score_tensor, beat_out, 6, teacher_forced, masks[1])
         beat_out = self.forward_beat_rnn(z, 4, masks[0])
         return self.forward_tick_rnn(score_tensor, beat_out, 6, teacher_forced, 'argmax', masks[1])
+
+    # ---- whole-sequence path ------------------------------------------------------------------------------------
+    def _two_layer_sequence(self, rnn, steps, gi0, h0, mask):
+        """2-layer unidirectional GRU over `steps`: gi0 (T, R, 3H) or (R, 3H); h0 = [layer-0, layer-1] initial states;
+        mask (T*R, H) keep-mask on the layer-0 outputs (nn.GRU's inter-layer dropout).  -> layer-1 outputs (T, R, H)"""
+        hid = self.rnn_hidden_size
+        out0 = ops.gru_sequence(steps, [(gi0, rnn.cell(0)[1], rnn.cell(0)[3], h0[0], False)])
+        rows = out0.shape[1]
+        mid = out0.view(steps * rows, hid)
+        if mask is not None:
+            mid = ops.dropout_mask(mid, mask, self.dropout)
+        w_ih1, w_hh1, b_ih1, b_hh1 = rnn.cell(1)
+        gi1 = ops.dense(mid, w_ih1, b_ih1, Link.dense(w_ih1.shape[1], w_ih1.shape[0]), ACT_NONE).view(steps, rows, -1)
+        return ops.gru_sequence(steps, [(gi1, w_hh1, b_hh1, h0[1], False)])
+
+    def beat_rnn_sequence(self, z, seq_len, mask=None):
+        """-> (4, B, H) beat embeddings (decoder.py:436-457)"""
+        b = z.size(0)
+        h = self.hidden_init(z, 'beat')
+        w_ih0, _, b_ih0, _ = self.rnn_beat.cell(0)
+        x0 = ops.broadcast_rows(self.b_0, b)
+        gi0 = ops.dense(x0, w_ih0, b_ih0, Link.dense(1, w_ih0.shape[0]), ACT_NONE)           # the same input every beat
+        m = None if mask is None else mask.contiguous().view(seq_len * b, -1)
+        return self._two_layer_sequence(self.rnn_beat, seq_len, gi0, h, m)
+
+    def tick_rnn_sequence(self, score_tensor, beat_out, tick_seq_len, teacher_forced, mask=None):
+        """The tick RNN restarts from a beat-dependent hidden state at every beat (decoder.py:459-525), so given the
+        fed-back tokens the four beats are independent 6-step sequences: they run as ONE sequence launch per layer over
+        4*B rows (row = beat*B + b).  With teacher forcing the fed-back tokens are the score; otherwise they come from
+        the free-running pass `_free_running_tokens` (argmax is not differentiated, decoder.py:506-516), and the same
+        graph is then evaluated on those tokens."""
+        nb, b = beat_out.shape[0], beat_out.shape[1]
+        hid, steps = self.rnn_hidden_size, tick_seq_len
+        ticks = nb * steps
+        bo = beat_out.view(nb * b, hid)
+        h0 = self.hidden_init(bo, 'tick')
+        beat_emb = _lin(bo, self.beat_emb_to_tick_rnn_input[0], ACT_SELU)                      # (4B, H)
+        m = None
+        if mask is not None:                                                                   # (24, B, H) -> rows (j, beat, b)
+            m = mask.view(nb, steps, b, hid).transpose(0, 1).contiguous().view(steps * nb * b, hid)
+        if self.use_teacher_forcing and teacher_forced:
+            tokens = score_tensor
+        else:
+            with torch.no_grad():
+                tokens = self._free_running_tokens(beat_out.detach(), h0, beat_emb, mask)
+        emb_prev = ops.embed(tokens[:, :ticks - 1].contiguous(), self.note_embedding_layer.weight, time_major=True)
+        prev = torch.cat((ops.broadcast_rows(self.x_0, b)[None], emb_prev), 0)                 # (24, B, E), tick-major
+        prev = prev.view(nb, steps, b, -1).transpose(0, 1).reshape(steps * nb * b, -1)         # rows (j, beat, b)
+        inp = ops.concat_cols(prev, beat_emb[None].expand(steps, -1, -1).reshape(steps * nb * b, hid))
+        w_ih0, _, b_ih0, _ = self.rnn_tick.cell(0)
+        gi0 = ops.dense(inp, w_ih0, b_ih0, Link.dense(w_ih0.shape[1], w_ih0.shape[0]), ACT_NONE).view(steps, nb * b, -1)
+        out1 = self._two_layer_sequence(self.rnn_tick, steps, gi0, h0, m)                      # (6, 4B, H)
+        probs = _lin(out1.view(steps * nb * b, hid), self.tick_emb_to_note_emb[0], ACT_RELU)
+        weights = probs.view(steps, nb, b, -1).permute(2, 1, 0, 3).reshape(b, ticks, -1)       # tick = 6*beat + j
+        return weights, tokens[:, None, :]
+
+    def _free_running_tokens(self, beat_out, h0, beat_emb, mask):
+        """argmax-feedback pass (no autograd): the tokens the decoder feeds itself, int64 (B, 24)."""
+        nb, b = beat_out.shape[0], beat_out.shape[1]
+        hid = self.rnn_hidden_size
+        w_ih0, _, b_ih0, _ = self.rnn_tick.cell(0)
+        prev = self.x_0.detach()[None].expand(b, -1).contiguous()
+        tokens = []
+        for i in range(nb):
+            h = [h0[0].detach()[i * b:(i + 1) * b], h0[1].detach()[i * b:(i + 1) * b]]
+            be = beat_emb.detach()[i * b:(i + 1) * b]
+            for j in range(6):
+                t = i * 6 + j
+                gi0 = ops.dense(ops.concat_cols(prev, be), w_ih0, b_ih0, Link.dense(w_ih0.shape[1], w_ih0.shape[0]), ACT_NONE)
+                h = self._two_layer_step(self.rnn_tick, gi0, h, None if mask is None else mask[t].contiguous())
+                idx = ops.row_argmax(_lin(h[1], self.tick_emb_to_note_emb[0], ACT_RELU))
+                prev = ops.embed(idx.view(b, 1), self.note_embedding_layer.weight).view(b, -1)
+                tokens.append(idx)
+        return torch.stack(tokens, 1)
 
     def forward_beat_rnn(self, z, seq_len, mask=None):
         b = z.size(0)

@@ -512,6 +512,101 @@ def gru_gates(gi, gh, h_prev=None):
     return _GruGatesFn.apply(gi.contiguous(), gh.contiguous(), None if h_prev is None else h_prev.contiguous())
 
 
+def gru_sequence_supported(hidden):
+    return bool(_lib.load().arvae_gru_seq_supported(int(hidden)))
+
+
+def _gru_seq_descs(n):
+    return (_lib.GruSeqDesc * n)()
+
+
+class _GruSeqFn(Function):
+    """All time steps of one GRU layer (1..4 directions / parameter sets) in one launch; see csrc/gru_seq.hip.
+
+    per direction d the inputs are gi_d (T, R, 3H) -- or (R, 3H) when the same projection feeds every step --,
+    w_hh_d, b_hh_d, h0_d (R, H) or None; the output is (T, R, ndir*H) with direction d in columns [dH, (d+1)H)."""
+
+    @staticmethod
+    def forward(ctx, steps, reverse, *tensors):
+        ndir = len(reverse)
+        gis, whs, bhs, h0s = tensors[0::4], tensors[1::4], tensors[2::4], tensors[3::4]
+        _dev(*[t for t in tensors if t is not None])
+        lib = _lib.load()
+        rows, hid = gis[0].shape[-2], whs[0].shape[1]
+        dev = whs[0].device
+        out = torch.empty(steps, rows, ndir * hid, device=dev, dtype=torch.float32)
+        saved = torch.empty(ndir, steps, rows, 4 * hid, device=dev, dtype=torch.float32)
+        descs = _gru_seq_descs(ndir)
+        for d in range(ndir):
+            q = descs[d]
+            q.gi, q.gi_tstride = _ptr(gis[d]), (rows * 3 * hid if gis[d].dim() == 3 else 0)
+            q.w_hh, q.b_hh, q.h0 = _ptr(whs[d]), _ptr(bhs[d]), _ptr(h0s[d])
+            q.h_all, q.h_stride = out.data_ptr() + 4 * d * hid, ndir * hid
+            q.saved, q.reverse = saved[d].data_ptr(), int(reverse[d])
+        with _timed('gru_seq_fwd', 2.0 * ndir * steps * rows * 3 * hid * hid, 4.0 * ndir * steps * rows * 8 * hid):
+            _lib.check(lib.arvae_gru_seq_fwd(descs, ndir, steps, rows, hid, _stream()), 'gru_seq_fwd')
+        ctx.save_for_backward(out, saved, *whs, *[h for h in h0s if h is not None])
+        ctx.h0_present = [h is not None for h in h0s]
+        ctx.gi_const = [g.dim() == 2 for g in gis]
+        ctx.refs = (whs, bhs)
+        ctx.geom = (steps, rows, hid, tuple(reverse))
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d_out):
+        steps, rows, hid, reverse = ctx.geom
+        ndir = len(reverse)
+        out, saved = ctx.saved_tensors[:2]
+        whs = ctx.saved_tensors[2:2 + ndir]
+        h0_it = iter(ctx.saved_tensors[2 + ndir:])
+        h0s = [next(h0_it) if p else None for p in ctx.h0_present]
+        lib = _lib.load()
+        dev = out.device
+        d_out = d_out.contiguous()
+        dgi = torch.empty(ndir, steps, rows, 3 * hid, device=dev, dtype=torch.float32)
+        dgh = torch.empty_like(dgi)
+        dh0 = [torch.empty(rows, hid, device=dev, dtype=torch.float32)
+               if (h0s[d] is not None and ctx.needs_input_grad[2 + 4 * d + 3]) else None for d in range(ndir)]
+        descs = _gru_seq_descs(ndir)
+        for d in range(ndir):
+            q = descs[d]
+            q.w_hh, q.h0 = _ptr(whs[d]), _ptr(h0s[d])
+            q.h_all, q.h_stride = out.data_ptr() + 4 * d * hid, ndir * hid
+            q.saved, q.reverse = saved[d].data_ptr(), int(reverse[d])
+            q.dh_all, q.dh_stride = d_out.data_ptr() + 4 * d * hid, ndir * hid
+            q.dgi, q.dgh, q.dh0 = dgi[d].data_ptr(), dgh[d].data_ptr(), _ptr(dh0[d])
+        with _timed('gru_seq_bwd', 2.0 * ndir * steps * rows * 3 * hid * hid, 4.0 * ndir * steps * rows * 12 * hid):
+            _lib.check(lib.arvae_gru_seq_bwd(descs, ndir, steps, rows, hid, _stream()), 'gru_seq_bwd')
+        grads = [None, None]
+        link = Link.dense(hid, 3 * hid)
+        w_refs, b_refs = ctx.refs
+        for d in range(ndir):
+            first = h0s[d][None] if h0s[d] is not None else torch.zeros(1, rows, hid, device=dev)
+            hcol = out[:, :, d * hid:(d + 1) * hid]
+            h_prev = torch.cat((hcol[1:], first), 0) if reverse[d] else torch.cat((first, hcol[:-1]), 0)
+            d_w = d_b = None
+            if ctx.needs_input_grad[2 + 4 * d + 1]:
+                buf, direct = _grad_target(w_refs[d])
+                bbuf, bdirect = _grad_target(b_refs[d])
+                link_wgrad(link, steps * rows, _operand(dgh[d].view(steps * rows, 3 * hid)),
+                           _operand(h_prev.view(steps * rows, hid)), buf, bbuf, 1)
+                d_w, d_b = (None if direct else buf), (None if bdirect else bbuf)
+            g_gi = None
+            if ctx.needs_input_grad[2 + 4 * d]:
+                g_gi = dgi[d].sum(0) if ctx.gi_const[d] else dgi[d]
+            grads += [g_gi, d_w, d_b, dh0[d]]
+        return tuple(grads)
+
+
+def gru_sequence(steps, directions):
+    """directions: list of (gi, w_hh, b_hh, h0, reverse) -> (T, R, ndir*H); see _GruSeqFn."""
+    flat = []
+    for gi, w_hh, b_hh, h0, _ in directions:
+        flat += [gi.contiguous(), w_hh, b_hh, None if h0 is None else h0.contiguous()]
+    return _GruSeqFn.apply(int(steps), tuple(bool(d[4]) for d in directions), *flat)
+
+
 class _EmbedFn(Function):
     @staticmethod
     def forward(ctx, idx, table, time_major):
@@ -536,8 +631,9 @@ class _EmbedFn(Function):
         b, steps = idx.shape
         v, dim = table.shape
         buf, direct = _grad_target(table)
+        ws = torch.empty(lib.arvae_embed_bwd_ws_floats(b, steps, dim, v), device=buf.device, dtype=torch.float32)
         _lib.check(lib.arvae_embed_bwd(_ptr(idx), _ptr(g.contiguous()), b, steps, dim, v, int(ctx.time_major), _ptr(buf),
-                                       _stream()), 'embed_bwd')
+                                       _ptr(ws), _stream()), 'embed_bwd')
         return None, (None if direct else buf), None
 
 

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ARVAE_ABI_VERSION 2   /* 2: arvae_image_vae_backward reg_fused == 2 (unit regulariser gradient in dz_extra) */
+#define ARVAE_ABI_VERSION 3   /* 3: arvae_gru_seq_*, embed_bwd workspace; 2: arvae_image_vae_backward reg_fused == 2 (unit regulariser gradient in dz_extra) */
 
 #define ARVAE_OK 0
 #define ARVAE_E_INVALID (-1)  /* bad argument (null pointer, size out of range, unsupported shape) */
@@ -202,12 +202,43 @@ int arvae_gru_gates_fwd(const float *gi, const float *gh, const float *h_prev, i
 int arvae_gru_gates_bwd(const float *dh, const float *saved, const float *h_prev, int32_t batch, int32_t hidden,
                         float *dgi, float *dgh, float *dh_prev, arvae_stream_t stream);
 
+/* Whole-sequence GRU layer: all `steps` time steps of one nn.GRU layer (measurevae/encoder.py:27-34,113-118 two-layer
+ * bidirectional over 24 ticks; measurevae/decoder.py:338-368 beat RNN, :436-525 tick RNN) in one launch, forward and
+ * backward-through-time.  `gi` holds the input projections W_ih x + b_ih of every step (one dense launch beforehand);
+ * the recurrence h -> W_hh h + b_hh -> gates runs inside the kernel, 16 batch rows per workgroup with W_hh in registers.
+ * Up to 4 independent parameter sets / directions per launch (e.g. the forward and reverse directions of a layer).
+ * Built for hidden sizes 32, 64 and 128 (arvae_gru_seq_supported); the per-step kernels above serve any other size. */
+typedef struct arvae_gru_seq {
+    const float *gi;      /* [steps][rows][3*hidden], gi_tstride floats between steps (0: one block reused every step) */
+    int64_t gi_tstride;
+    const float *w_hh;    /* [3*hidden][hidden] */
+    const float *b_hh;    /* [3*hidden] */
+    const float *h0;      /* [rows][hidden] or NULL (zeros) */
+    float *h_all;         /* output: h of (step t, row r) at h_all[(t*rows + r) * h_stride + 0..hidden) */
+    int64_t h_stride;
+    float *saved;         /* [steps][rows][4][hidden] (r, z, n, gh_n): written by fwd, read by bwd */
+    int32_t reverse;      /* process t = steps-1 .. 0 (the `_reverse` direction of a bidirectional layer) */
+    int32_t reserved;
+    const float *dh_all;  /* bwd: gradient w.r.t. h_all, addressed like h_all with dh_stride; NULL = zeros */
+    int64_t dh_stride;
+    float *dgi;           /* bwd out: [steps][rows][3*hidden] gradient w.r.t. gi */
+    float *dgh;           /* bwd out: [steps][rows][3*hidden] gradient w.r.t. W_hh h + b_hh */
+    float *dh0;           /* bwd out: [rows][hidden] gradient w.r.t. h0, or NULL */
+} arvae_gru_seq_t;
+int arvae_gru_seq_supported(int32_t hidden);
+int arvae_gru_seq_fwd(const arvae_gru_seq_t *seqs, int32_t nseq, int32_t steps, int32_t rows, int32_t hidden,
+                      arvae_stream_t stream);
+int arvae_gru_seq_bwd(const arvae_gru_seq_t *seqs, int32_t nseq, int32_t steps, int32_t rows, int32_t hidden,
+                      arvae_stream_t stream);
+
 /* nn.Embedding (measurevae/encoder.py:36-37,111; decoder.py:18,516): out row (b,t) = table[idx[b][t]];
- * time_major: rows ordered (t, b) instead of (b, t).  embed_bwd ACCUMULATES dtable (fixed summation order). */
+ * time_major: rows ordered (t, b) instead of (b, t).  embed_bwd ACCUMULATES dtable (fixed summation order) and needs
+ * a workspace of arvae_embed_bwd_ws_floats() floats. */
 int arvae_embed_fwd(const int64_t *idx, const float *table, int32_t batch, int32_t steps, int32_t dim, int32_t vocab,
                     int32_t time_major, float *out, arvae_stream_t stream);
+int64_t arvae_embed_bwd_ws_floats(int32_t batch, int32_t steps, int32_t dim, int32_t vocab);
 int arvae_embed_bwd(const int64_t *idx, const float *g, int32_t batch, int32_t steps, int32_t dim, int32_t vocab,
-                    int32_t time_major, float *dtable, arvae_stream_t stream);
+                    int32_t time_major, float *dtable, float *ws, arvae_stream_t stream);
 
 /* top-1 index per row, lowest index on ties (the decoder's argmax feedback, measurevae/decoder.py:506-507) */
 int arvae_row_argmax(const float *w, int32_t rows, int32_t cols, int64_t *idx, arvae_stream_t stream);

@@ -611,6 +611,97 @@ def test_gru_cell_vs_torch(dev):
         close(prm[k].grad, v.grad, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize('rows,hid,steps', [(37, 128, 24), (16, 64, 6), (5, 32, 4)])
+def test_gru_sequence_vs_torch(dev, rows, hid, steps):
+    """whole-sequence GRU kernels (both directions in one launch, initial state, ragged row count) reproduce a
+    bidirectional torch.nn.GRU layer: outputs, input-projection / initial-state gradients, W_hh / b_hh gradients."""
+    from arvae_amd import ops
+    rs = np.random.RandomState(15)
+    fin = 10
+    gru = torch.nn.GRU(fin, hid, 1, bidirectional=True)
+    x = torch.from_numpy(rs.standard_normal((steps, rows, fin)).astype(np.float32)).requires_grad_(True)
+    h0 = torch.from_numpy(rs.standard_normal((2, rows, hid)).astype(np.float32)).requires_grad_(True)
+    gy = torch.from_numpy(rs.standard_normal((steps, rows, 2 * hid)).astype(np.float32))
+    y, hn = gru(x, h0)
+    (y * gy).sum().backward()
+    prm = {k: v.detach().clone().to(dev).requires_grad_(True) for k, v in gru.named_parameters()}
+    xd = x.detach().to(dev).requires_grad_(True)
+    hd = h0.detach().to(dev).requires_grad_(True)
+    dirs = []
+    for d, suf in enumerate(('', '_reverse')):
+        gi = ops.dense(xd.view(steps * rows, fin), prm['weight_ih_l0' + suf], prm['bias_ih_l0' + suf],
+                       ops.Link.dense(fin, 3 * hid), 0).view(steps, rows, 3 * hid)
+        dirs.append((gi, prm['weight_hh_l0' + suf], prm['bias_hh_l0' + suf], hd[d], d == 1))
+    yd = ops.gru_sequence(steps, dirs)
+    (yd * gy.to(dev)).sum().backward()
+    close(yd, y, rtol=1e-5, atol=2e-6)
+    close(yd[steps - 1, :, :hid], hn[0], rtol=1e-5, atol=2e-6)
+    close(yd[0, :, hid:], hn[1], rtol=1e-5, atol=2e-6)
+    close(xd.grad, x.grad, rtol=1e-4, atol=2e-6)
+    close(hd.grad, h0.grad, rtol=1e-4, atol=2e-6)
+    for k, v in gru.named_parameters():
+        close(prm[k].grad, v.grad, rtol=1e-4, atol=2e-5)
+
+
+def test_gru_sequence_constant_input(dev):
+    """one input projection reused at every step (the beat RNN's constant input) and no initial state."""
+    from arvae_amd import ops
+    rs = np.random.RandomState(16)
+    rows, hid, steps = 19, 128, 4
+    gru = torch.nn.GRU(1, hid, 1)
+    x1 = torch.from_numpy(rs.standard_normal((rows, 1)).astype(np.float32)).requires_grad_(True)
+    gy = torch.from_numpy(rs.standard_normal((steps, rows, hid)).astype(np.float32))
+    y, _ = gru(x1[None].expand(steps, -1, -1))
+    (y * gy).sum().backward()
+    prm = {k: v.detach().clone().to(dev).requires_grad_(True) for k, v in gru.named_parameters()}
+    xd = x1.detach().to(dev).requires_grad_(True)
+    gi = ops.dense(xd, prm['weight_ih_l0'], prm['bias_ih_l0'], ops.Link.dense(1, 3 * hid), 0)
+    yd = ops.gru_sequence(steps, [(gi, prm['weight_hh_l0'], prm['bias_hh_l0'], None, False)])
+    (yd * gy.to(dev)).sum().backward()
+    close(yd, y, rtol=1e-5, atol=2e-6)
+    close(xd.grad, x1.grad, rtol=1e-4, atol=2e-6)
+    for k, v in gru.named_parameters():
+        close(prm[k].grad, v.grad, rtol=1e-4, atol=2e-5)
+
+
+def test_measure_sequence_path_matches_stepwise(dev, monkeypatch):
+    """the whole-sequence MeasureVAE path and the one-launch-per-step path give the same losses and gradients
+    (teacher-forced and free-running decoder, dropout masks on)."""
+    from arvae_amd.measure_vae import MeasureVAE
+    from arvae_amd.measure_vae_trainer import MeasureVAETrainer
+    b = 21
+    score = torch.from_numpy(syn.measure_batch(b, seed=18)).to(dev)
+    eps = torch.from_numpy(syn.normal_noise((b, 32), seed=19))
+    gen = torch.Generator().manual_seed(3)
+    masks = [(torch.rand(24, b, 256, generator=gen) >= 0.5).to(torch.uint8),
+             (torch.rand(4, b, 128, generator=gen) >= 0.5).to(torch.uint8),
+             (torch.rand(24, b, 128, generator=gen) >= 0.5).to(torch.uint8)]
+    for teacher in (True, False):
+        res = {}
+        for mode in ('0', '1'):
+            monkeypatch.setenv('ARVAE_GRU_STEPWISE', mode)
+            torch.manual_seed(11)
+            ds = _FolkDataset()
+            model = MeasureVAE(ds, 10, 2, 2, 128, 0.5, 32, 2, 128, 0.5, False, 'folk')
+            trainer = MeasureVAETrainer(ds, model, lr=1e-4, reg_type=('all',), reg_dim=(0, 1, 2, 3), beta=0.001,
+                                        gamma=1.0, capacity=0.0, rand=0, delta=10.0)
+            trainer.cuda()
+            model.train()
+            model.decoder.teacher_forcing_prob = 1.0 if teacher else 0.0
+            model.push_noise(eps)
+            model.encoder.push_dropout_mask(masks[0].to(dev))
+            model.decoder.push_dropout_masks(masks[1].to(dev), masks[2].to(dev))
+            trainer.zero_grad()
+            loss, acc = trainer.loss_and_acc_for_batch((score, score), 0, 0, True)
+            loss.backward()
+            res[mode] = (float(loss), float(acc), {k: p.grad.detach().clone() for k, p in model.named_parameters()})
+        close(res['0'][0], res['1'][0], rtol=1e-5)
+        close(res['0'][1], res['1'][1], rtol=1e-6)
+        for k, gstep in res['1'][2].items():
+            gseq = res['0'][2][k]
+            assert float((gseq - gstep).norm()) <= 2e-4 * float(gstep.norm()) + 1e-9, (teacher, k)
+
+
 def test_embedding_concat_argmax(dev):
     from arvae_amd import ops
     rs = np.random.RandomState(6)
