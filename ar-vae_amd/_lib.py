@@ -49,6 +49,11 @@ class GruSeqDesc(ctypes.Structure):
                 ('dh_stride', c_i64), ('dgi', c_vp), ('dgh', c_vp), ('dh0', c_vp)]
 
 
+class TickWeights(ctypes.Structure):
+    """arvae_tick_weights_t"""
+    _fields_ = [(n, c_vp) for n in ('w_hh0', 'b_hh0', 'w_ih1', 'b_ih1', 'w_hh1', 'b_hh1', 'w_out', 'b_out')]
+
+
 _P = ctypes.POINTER
 # name -> (restype, argtypes); must list every symbol declared in include/arvae_hip.h
 SIGNATURES = {
@@ -63,6 +68,7 @@ SIGNATURES = {
     'arvae_link_wgrad': (c_i32, [_P(LinkDesc), _P(OperandDesc), _P(OperandDesc), c_vp, c_vp, c_i32, c_vp, c_vp]),
     'arvae_channel_sum_ws_floats': (c_i64, [c_i64, c_i32]),
     'arvae_channel_sum': (c_i32, [_P(OperandDesc), c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    'arvae_operand_apply': (c_i32, [_P(OperandDesc), c_i64, c_vp, c_vp]),
     'arvae_latent_fwd': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     'arvae_latent_bwd': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     'arvae_kld_fwd': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_f32, c_vp, c_vp, c_vp]),
@@ -79,6 +85,8 @@ SIGNATURES = {
     'arvae_gru_seq_supported': (c_i32, [c_i32]),
     'arvae_gru_seq_fwd': (c_i32, [_P(GruSeqDesc), c_i32, c_i32, c_i32, c_i32, c_vp]),
     'arvae_gru_seq_bwd': (c_i32, [_P(GruSeqDesc), c_i32, c_i32, c_i32, c_i32, c_vp]),
+    'arvae_tick_free_run': (c_i32, [_P(TickWeights), c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                    c_vp, c_vp]),
     'arvae_embed_fwd': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     'arvae_embed_bwd_ws_floats': (c_i64, [c_i32, c_i32, c_i32, c_i32]),
     'arvae_embed_bwd': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),

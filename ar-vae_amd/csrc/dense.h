@@ -23,7 +23,7 @@ struct DenseArgs {
     int store = 0;      // wgrad: write the tile (and bias sums) instead of adding to what is there
 };
 
-constexpr int DENSE_SPLIT_ROWS = 512;        // rows per workgroup slice of the row-split weight gradient
+constexpr int DENSE_SPLIT_ROWS = 128;        // rows per workgroup slice of the row-split weight gradient
 constexpr int DENSE_SPLIT_MIN_ROWS = 2048;   // shorter reduction axes stay on the one-workgroup-per-tile kernel
 
 constexpr int DENSE_BATCH_MAX = 8;

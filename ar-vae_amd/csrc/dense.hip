@@ -137,6 +137,132 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_dgrad_kernel(DenseArgs p)
     }
 }
 
+// ---- long-batch variants (M >= DENSE_SPLIT_MIN_ROWS rows: the MeasureVAE's whole-sequence GEMMs, 24 ticks x batch) --
+// Thousands of rows make these throughput problems: C[P][Q] = sum_r A(p,r) B(q,r) with both operand tiles staged
+// through LDS in reduction-major order [r][p] by coalesced 16-byte global loads (next chunk prefetched into registers
+// while the current one is multiplied), 64 x 64 outputs per workgroup = 2 x 2 waves on the 32x32x2 MFMA (small tiles: these
+// are 0.3-1.2 GFLOP problems, and two or three workgroups per CU hide each other's load latency).  An operand is either
+// "rows x K" (reduction index contiguous in memory: X, W and G of the forward / data-gradient products) or "K x rows"
+// (output index contiguous: W of the data gradient, G and X of the weight gradient); the weight gradient additionally
+// splits the row axis over blockIdx.z into workspace slices that dense_split_reduce_kernel adds up in slice order.
+constexpr int RG_TP = 64, RG_TQ = 64, RG_R = 32;
+constexpr int RG_PA = RG_TP + 4, RG_PB = RG_TQ + 4;
+enum { RG_ROWSK = 0, RG_KROWS = 1 };
+enum { RG_EP_FWD = 0, RG_EP_SLICE = 1 };
+
+struct RowsGemm {
+    const float *a, *b;
+    int64_t lda, ldb;
+    int P, Q, Rn;               // output rows (A side), output columns (B side), reduction length
+    int rslice;                 // reduction indices per blockIdx.z
+    const float *bias;          // FWD: per output column
+    int act;
+    float *out;                 // FWD: [P][ldo]; SLICE: ws, slice z at out + z*slice_floats, bias sums after the P*ldo tile
+    int64_t ldo, slice_floats;
+    int want_bias;              // SLICE: also write sum_r A(p, r)
+};
+
+// NV float4 (or 4 scalar) loads per thread for a TP x RG_R tile.  Every load is unconditional (clamped address, value
+// selected afterwards) so that the whole batch is in flight at once; VEC = 16-byte loads (leading dimension, extents
+// and base all multiples of 4 floats), otherwise dword loads.
+template <int LAY, int TP, bool VEC>
+struct TileLoader {
+    static constexpr int NV = TP * RG_R / 4 / 256;
+    float4 v[NV];
+    __device__ __forceinline__ void load(const float *base, int64_t ld, int p0, int pmax, int r0, int rmax) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = threadIdx.x + 256 * i;
+            // (row, first column) of this thread's 4 consecutive elements in memory; lim = end of the contiguous axis
+            int row, col, row_max, col_max;
+            if (LAY == RG_ROWSK) { row = p0 + idx / (RG_R / 4); col = r0 + 4 * (idx % (RG_R / 4)); row_max = pmax; col_max = rmax; }
+            else { row = r0 + idx / (TP / 4); col = p0 + 4 * (idx % (TP / 4)); row_max = rmax; col_max = pmax; }
+            const bool rok = row < row_max;
+            const float *src = base + (int64_t)(rok ? row : 0) * ld;
+            if (VEC) {
+                const bool ok = rok && col < col_max;
+                const float4 t = *reinterpret_cast<const float4 *>(src + (ok ? col : 0));
+                v[i] = ok ? t : float4{0.f, 0.f, 0.f, 0.f};
+            } else {
+                float e[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = rok && col + j < col_max;
+                    const float t = src[ok ? col + j : 0];
+                    e[j] = ok ? t : 0.f;
+                }
+                v[i] = float4{e[0], e[1], e[2], e[3]};
+            }
+        }
+    }
+    // LDS image [RG_R][pitch], reduction-major
+    __device__ __forceinline__ void commit(float *lds, int pitch) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = threadIdx.x + 256 * i;
+            if (LAY == RG_ROWSK) {
+                const int p = idx / (RG_R / 4), r = 4 * (idx % (RG_R / 4));
+                lds[(r + 0) * pitch + p] = v[i].x; lds[(r + 1) * pitch + p] = v[i].y;
+                lds[(r + 2) * pitch + p] = v[i].z; lds[(r + 3) * pitch + p] = v[i].w;
+            } else {
+                const int r = idx / (TP / 4), p = 4 * (idx % (TP / 4));
+                *reinterpret_cast<float4 *>(lds + r * pitch + p) = v[i];
+            }
+        }
+    }
+};
+
+template <int LA, int LB, int EP, bool VA, bool VB>
+__global__ __launch_bounds__(256) void rows_gemm_kernel(RowsGemm g) {
+    __shared__ float As[RG_R * RG_PA];
+    __shared__ float Bs[RG_R * RG_PB];
+    const int lane = threadIdx.x & 63, half = lane >> 5, rc = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p0 = blockIdx.x * RG_TP, q0 = blockIdx.y * RG_TQ;
+    const int rbeg = blockIdx.z * g.rslice, rend = min(g.Rn, rbeg + g.rslice);
+    TileLoader<LA, RG_TP, VA> la;
+    TileLoader<LB, RG_TQ, VB> lb;
+    const int wp = wave & 1, wq = wave >> 1;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float bsum = 0.f;
+    la.load(g.a, g.lda, p0, g.P, rbeg, rend);
+    lb.load(g.b, g.ldb, q0, g.Q, rbeg, rend);
+    for (int r0 = rbeg; r0 < rend; r0 += RG_R) {
+        __syncthreads();
+        la.commit(As, RG_PA);
+        lb.commit(Bs, RG_PB);
+        __syncthreads();
+        if (r0 + RG_R < rend) {
+            la.load(g.a, g.lda, p0, g.P, r0 + RG_R, rend);
+            lb.load(g.b, g.ldb, q0, g.Q, r0 + RG_R, rend);
+        }
+#pragma unroll
+        for (int s = 0; s < RG_R / 2; ++s) {
+            const float a = As[(2 * s + half) * RG_PA + 32 * wp + rc];
+            const float b = Bs[(2 * s + half) * RG_PB + 32 * wq + rc];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        if (EP == RG_EP_SLICE && g.want_bias && blockIdx.y == 0 && threadIdx.x < RG_TP) {
+#pragma unroll 8
+            for (int r = 0; r < RG_R; ++r) bsum += As[r * RG_PA + threadIdx.x];
+        }
+    }
+    float *out = g.out + (EP == RG_EP_SLICE ? blockIdx.z * g.slice_floats : 0);
+    const int q = q0 + 32 * wq + rc;
+    const float bias = (EP == RG_EP_FWD && g.bias != nullptr && q < g.Q) ? g.bias[q] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int p = p0 + 32 * wp + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float v = acc[r];
+        if (EP == RG_EP_FWD) v = act_fwd(v + bias, g.act);
+        if (p < g.P && q < g.Q) out[(int64_t)p * g.ldo + q] = v;
+    }
+    if (EP == RG_EP_SLICE && g.want_bias && blockIdx.y == 0 && threadIdx.x < RG_TP && p0 + (int)threadIdx.x < g.P)
+        out[(int64_t)g.P * g.ldo + p0 + threadIdx.x] = bsum;
+}
+
 // ---- wgrad: dW[n][feat_in(km)] += sum_m G[m][mem_out(n)] * X[m][km] ;  db[n] += sum_m G[m][mem_out(n)] ------
 // KU chunks are fetched per wave before the first MFMA, with unconditional loads (clamped row, zeroed by a select): the
 // operands were written a whole pass ago and come from HBM with a row pitch of 1-2 KB, so a tile lives on memory
@@ -226,32 +352,30 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_wgrad_kernel(DenseArgs p)
     dense_wgrad_tile<NW>(p, blockIdx.x, blockIdx.y, red);
 }
 
-// Row-split weight gradient for long reduction axes (the MeasureVAE's whole-sequence GEMMs: 24 ticks x batch = 6144
-// rows).  blockIdx.z owns a slice of DENSE_SPLIT_ROWS rows and STORES its partial tile (and bias sums) into the
-// workspace; dense_split_reduce_kernel then adds the slices to dW / db in slice order (fixed summation order).
-__global__ __launch_bounds__(DENSE_THREADS) void dense_wgrad_split_kernel(DenseArgs p, float *ws, int64_t slice_floats) {
-    __shared__ float red[NW * 16 * 64];
-    const int m0 = blockIdx.z * DENSE_SPLIT_ROWS;
-    DenseArgs q = p;
-    q.a.v += (int64_t)m0 * p.n_out;
-    if (q.a.y != nullptr) q.a.y += (int64_t)m0 * p.n_out;
-    if (q.a.mask != nullptr) q.a.mask += (int64_t)m0 * p.n_out;
-    q.x += (int64_t)m0 * p.n_in;
-    q.batch = min(DENSE_SPLIT_ROWS, p.batch - m0);
-    q.out = ws + blockIdx.z * slice_floats;
-    q.dbias = p.dbias != nullptr ? q.out + (int64_t)p.n_out * p.n_in : nullptr;
-    q.store = 1;
-    dense_wgrad_tile<NW>(q, blockIdx.x, blockIdx.y, red);
-}
-
+// Adds the row slices written by the long-batch weight gradient (rows_gemm_kernel, RG_EP_SLICE) to dW / db in slice order.
 __global__ __launch_bounds__(256) void dense_split_reduce_kernel(const float *__restrict__ ws, int64_t slice_floats, int slices,
                                                                   int64_t w_floats, int n_out, float *__restrict__ dw,
                                                                   float *__restrict__ dbias) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // 4 lanes per output element, lane q sums slices q, q+4, ... (8 loads in flight), then a fixed-order lane sum
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 2;
+    const int q = threadIdx.x & 3;
     const int64_t total = w_floats + (dbias != nullptr ? n_out : 0);
-    if (i >= total) return;
+    const int64_t ic = i < total ? i : 0;
     float s = 0.f;
-    for (int z = 0; z < slices; ++z) s += ws[z * slice_floats + i];
+    for (int z0 = q; z0 < slices; z0 += 32) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int z = z0 + 4 * u;
+            const float v = ws[(int64_t)(z < slices ? z : 0) * slice_floats + ic];
+            t[u] = z < slices ? v : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += t[u];
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (q != 0 || i >= total) return;
     if (i < w_floats) dw[i] += s;
     else dbias[i - w_floats] += s;
 }
@@ -275,6 +399,31 @@ bool dense_fits(const arvae_link_t *l) {
     return l->hh == 1 && l->hw == 1 && l->lh == 1 && l->lw == 1 && l->kh == 1 && l->kw == 1;
 }
 
+template <int LA, int LB, int EP>
+static void launch_rows_gemm(const RowsGemm &g, int slices, hipStream_t s) {
+    // 16-byte loads need the contiguous axis (the reduction for "rows x K", the output index for "K x rows"), the
+    // leading dimension and the base address in multiples of 4 floats
+    auto vec_ok = [&](const float *base, int64_t ld, int lay, int out_extent) {
+        const int contiguous = lay == RG_ROWSK ? g.Rn : out_extent;
+        const bool slice_ok = lay != RG_ROWSK || (g.rslice & 3) == 0;
+        return (ld & 3) == 0 && (contiguous & 3) == 0 && slice_ok && (reinterpret_cast<uintptr_t>(base) & 15) == 0;
+    };
+    const bool va = vec_ok(g.a, g.lda, LA, g.P), vb = vec_ok(g.b, g.ldb, LB, g.Q);
+    const dim3 grid((g.P + RG_TP - 1) / RG_TP, (g.Q + RG_TQ - 1) / RG_TQ, slices);
+    if (va && vb) hipLaunchKernelGGL((rows_gemm_kernel<LA, LB, EP, true, true>), grid, dim3(256), 0, s, g);
+    else if (va) hipLaunchKernelGGL((rows_gemm_kernel<LA, LB, EP, true, false>), grid, dim3(256), 0, s, g);
+    else if (vb) hipLaunchKernelGGL((rows_gemm_kernel<LA, LB, EP, false, true>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((rows_gemm_kernel<LA, LB, EP, false, false>), grid, dim3(256), 0, s, g);
+}
+
+// the operand needs no per-element work (no activation derivative, no keep-mask)
+static bool plain_operand(const Operand &g) { return g.y == nullptr || (g.act == ARVAE_ACT_NONE && g.mask == nullptr); }
+
+static bool dense_long_batch(const DenseArgs &p) {
+    static const bool off = getenv("ARVAE_DENSE_NO_ROWS") != nullptr;       // A/B switch
+    return !off && p.batch >= DENSE_SPLIT_MIN_ROWS && p.in_perm.c_count == 0 && p.out_perm.c_count == 0;
+}
+
 static DenseArgs dense_args(const arvae_link_t *l) {
     DenseArgs p{};
     p.batch = l->n;
@@ -289,6 +438,13 @@ int dense_fwd(const arvae_link_t *l, const float *x, const float *w, const float
     DenseArgs p = dense_args(l);
     p.a = Operand{x, nullptr, nullptr, ARVAE_ACT_NONE};
     p.w = w; p.bias = bias; p.act = act; p.out = y;
+    if (dense_long_batch(p)) {
+        RowsGemm g{};
+        g.a = x; g.lda = p.n_in; g.b = w; g.ldb = p.n_in; g.P = p.batch; g.Q = p.n_out; g.Rn = p.n_in; g.rslice = p.n_in;
+        g.bias = bias; g.act = act; g.out = y; g.ldo = p.n_out;
+        launch_rows_gemm<RG_ROWSK, RG_ROWSK, RG_EP_FWD>(g, 1, s);
+        return check_launch("rows_gemm_kernel<fwd>");
+    }
     hipLaunchKernelGGL(dense_fwd_kernel, dim3((p.batch + 31) / 32, (p.n_out + 31) / 32), dim3(DENSE_THREADS), 0, s, p);
     return check_launch("dense_fwd_kernel");
 }
@@ -296,28 +452,38 @@ int dense_fwd(const arvae_link_t *l, const float *x, const float *w, const float
 int dense_dgrad(const arvae_link_t *l, const Operand &g, const float *w, const float *gate, float *dx, hipStream_t s) {
     DenseArgs p = dense_args(l);
     p.a = g; p.w = w; p.out = dx; p.gate = gate;
+    if (dense_long_batch(p) && gate == nullptr && plain_operand(g)) {
+        RowsGemm r{};
+        r.a = g.v; r.lda = p.n_out; r.b = w; r.ldb = p.n_in; r.P = p.batch; r.Q = p.n_in; r.Rn = p.n_out; r.rslice = p.n_out;
+        r.out = dx; r.ldo = p.n_in;
+        launch_rows_gemm<RG_ROWSK, RG_KROWS, RG_EP_FWD>(r, 1, s);
+        return check_launch("rows_gemm_kernel<dgrad>");
+    }
     hipLaunchKernelGGL(dense_dgrad_kernel, dim3((p.batch + 31) / 32, (p.n_in + 31) / 32), dim3(DENSE_THREADS), 0, s, p);
     return check_launch("dense_dgrad_kernel");
 }
 
+static int wgrad_slices(int rows) { return (rows + DENSE_SPLIT_ROWS - 1) / DENSE_SPLIT_ROWS; }
+
 int64_t dense_wgrad_ws_floats(const arvae_link_t *l) {
     if (l->n < DENSE_SPLIT_MIN_ROWS) return 0;
-    const int64_t slices = (l->n + DENSE_SPLIT_ROWS - 1) / DENSE_SPLIT_ROWS;
-    return slices * ((int64_t)l->clo * l->chi + l->clo);
+    return (int64_t)wgrad_slices(l->n) * ((int64_t)l->clo * l->chi + l->clo);
 }
 
 int dense_wgrad(const arvae_link_t *l, const Operand &g, const float *x, float *dw, float *dbias, float *ws, hipStream_t s) {
     DenseArgs p = dense_args(l);
     p.a = g; p.x = x; p.out = dw; p.dbias = dbias;
-    if (ws != nullptr && dense_wgrad_ws_floats(l) > 0) {
-        const int slices = (p.batch + DENSE_SPLIT_ROWS - 1) / DENSE_SPLIT_ROWS;
+    if (ws != nullptr && dense_long_batch(p) && plain_operand(g)) {
+        const int slices = wgrad_slices(p.batch);
         const int64_t w_floats = (int64_t)p.n_out * p.n_in, slice_floats = w_floats + p.n_out;
-        hipLaunchKernelGGL(dense_wgrad_split_kernel, dim3((p.n_out + 31) / 32, (p.n_in + 31) / 32, slices), dim3(DENSE_THREADS),
-                           0, s, p, ws, slice_floats);
+        RowsGemm r{};
+        r.a = g.v; r.lda = p.n_out; r.b = x; r.ldb = p.n_in; r.P = p.n_out; r.Q = p.n_in; r.Rn = p.batch; r.rslice = DENSE_SPLIT_ROWS;
+        r.out = ws; r.ldo = p.n_in; r.slice_floats = slice_floats; r.want_bias = dbias != nullptr;
+        launch_rows_gemm<RG_KROWS, RG_KROWS, RG_EP_SLICE>(r, slices, s);
         const int64_t total = w_floats + (dbias != nullptr ? p.n_out : 0);
-        hipLaunchKernelGGL(dense_split_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ws, slice_floats,
+        hipLaunchKernelGGL(dense_split_reduce_kernel, dim3((unsigned)((total * 4 + 255) / 256)), dim3(256), 0, s, ws, slice_floats,
                            slices, w_floats, p.n_out, dw, dbias);
-        return check_launch("dense_wgrad_split_kernel");
+        return check_launch("rows_gemm_kernel<wgrad>");
     }
     hipLaunchKernelGGL(dense_wgrad_kernel, dim3((p.n_out + 31) / 32, (p.n_in + 31) / 32), dim3(DENSE_THREADS), 0, s, p);
     return check_launch("dense_wgrad_kernel");

@@ -240,6 +240,207 @@ static int fill_batch(GruSeqBatch *b, const arvae_gru_seq_t *seqs, int nseq) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Free-running tick decoder: the argmax-feedback pass of the hierarchical decoder (measurevae/decoder.py:459-525 with
+// teacher forcing off: the embedding of the previous tick's top-1 note is the next input) in ONE launch that returns
+// only the tokens.  The differentiable graph is then evaluated on those tokens by the whole-sequence kernels above
+// (argmax is not differentiated), so nothing else has to be saved here.
+//
+// Every batch row is an independent 24-tick recurrence: a workgroup owns 16 rows, H/16 waves, wave w owns hidden units
+// [16w, 16w+16).  Per tick:   gi0 = gib[beat][row] + ptab[previous token]      (both precomputed by dense launches)
+//   layer 0: gh0 = W_hh0 h0 (W_hh0 slice register-resident) -> gates -> h0' ; mid = h0' * keep-mask * scale
+//   layer 1: r,z: W_ih1 mid + W_hh1 h1 in one accumulator each; n: the two products apart (weights streamed from L2,
+//            two k-groups ahead) -> gates -> h1'
+//   logits = relu(W_out h1' + b_out) on waves 0..ceil(V/16)-1, row argmax (lowest index on ties) through lane shuffles
+//            and LDS -> token, fed back.
+struct TickFreeRun {
+    const float *w_hh0, *b_hh0, *w_ih1, *b_ih1, *w_hh1, *b_hh1, *w_out, *b_out;
+    const float *h0_l0, *h0_l1;    // [beats*B][H], row = beat*B + b
+    const float *gib;              // [beats*B][3H]
+    const float *ptab;             // [V+1][3H]; row V = the start token
+    const uint8_t *mask;           // [beats*tpb][B][H] or null
+    float keep_scale;
+    int batch, beats, tpb, vocab;
+    int64_t *tokens;               // [B][beats*tpb]
+};
+
+template <int H, int TICK_PF, bool MASKED>
+__global__ __launch_bounds__(H * 4) void tick_free_run_kernel(TickFreeRun p) {
+    constexpr int KQ = H / 16, HS = H + 4;
+    __shared__ float hA0[2][16][HS];
+    __shared__ float hA1[2][16][HS];
+    __shared__ float mid[16][HS];
+    __shared__ float cand_v[4][16];
+    __shared__ int cand_i[4][16];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = lane & 15, quad = lane >> 4;
+    const int unit = 16 * w + col;
+    const int row0 = blockIdx.x * 16;
+    const int B = p.batch;
+    const int ntile = (p.vocab + 15) / 16;          // waves that compute logits (<= 4)
+
+    f32x4 whh0[3][KQ];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int kq = 0; kq < KQ; ++kq)
+            whh0[g][kq] = *reinterpret_cast<const f32x4 *>(p.w_hh0 + (int64_t)(g * H + unit) * H + 16 * kq + 4 * quad);
+    const float b0r = p.b_hh0[unit], b0z = p.b_hh0[H + unit], b0n = p.b_hh0[2 * H + unit];
+    const float b1r = p.b_ih1[unit] + p.b_hh1[unit], b1z = p.b_ih1[H + unit] + p.b_hh1[H + unit];
+    const float b1in = p.b_ih1[2 * H + unit], b1hn = p.b_hh1[2 * H + unit];
+    // logits: wave w < ntile owns notes [16w, 16w+16)
+    const int note = 16 * w + col;
+    const bool note_ok = w < ntile && note < p.vocab;
+    f32x4 wout[KQ];
+#pragma unroll
+    for (int kq = 0; kq < KQ; ++kq) {
+        wout[kq] = *reinterpret_cast<const f32x4 *>(p.w_out + (int64_t)(note_ok ? note : 0) * H + 16 * kq + 4 * quad);
+        if (!note_ok) wout[kq] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float bout = note_ok ? p.b_out[note] : 0.f;
+
+    int rows[4];
+    bool live[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = row0 + 4 * quad + i;
+        live[i] = r < B;
+        rows[i] = live[i] ? r : B - 1;
+    }
+    float h0[4], h1[4], gb[4][3];
+    int tok[4] = {p.vocab, p.vocab, p.vocab, p.vocab};        // start token row of ptab
+    const int ticks = p.beats * p.tpb;
+
+    for (int t = 0; t < ticks; ++t) {
+        const int cur = t & 1;
+        const int beat = t / p.tpb;
+        if (t % p.tpb == 0) {                                 // the hidden state restarts at every beat
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t br = (int64_t)beat * B + rows[i];
+                h0[i] = p.h0_l0[br * H + unit];
+                h1[i] = p.h0_l1[br * H + unit];
+                hA0[cur][4 * quad + i][unit] = h0[i];
+                hA1[cur][4 * quad + i][unit] = h1[i];
+                const float *g = p.gib + br * 3 * H + unit;
+                gb[i][0] = g[0]; gb[i][1] = g[H]; gb[i][2] = g[2 * H];
+            }
+            __syncthreads();
+        }
+        // input projection of this tick: beat part + previous-token part
+        float gi[4][3];
+        float keep[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float *pt = p.ptab + (int64_t)tok[i] * 3 * H + unit;
+            gi[i][0] = gb[i][0] + pt[0]; gi[i][1] = gb[i][1] + pt[H]; gi[i][2] = gb[i][2] + pt[2 * H];
+            keep[i] = MASKED ? p.keep_scale * (float)p.mask[((int64_t)t * B + rows[i]) * H + unit] : 1.f;
+        }
+        // ---- layer 0
+        {
+            f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int kq = 0; kq < KQ; ++kq) {
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(&hA0[cur][col][16 * kq + 4 * quad]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int g = 0; g < 3; ++g)
+                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], whh0[g][kq][j], acc[g], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float r = fast_sigmoid(gi[i][0] + acc[0][i] + b0r);
+                const float z = fast_sigmoid(gi[i][1] + acc[1][i] + b0z);
+                const float n = fast_tanh(gi[i][2] + r * (acc[2][i] + b0n));
+                h0[i] = (1.f - z) * n + z * h0[i];
+                hA0[cur ^ 1][4 * quad + i][unit] = h0[i];
+                mid[4 * quad + i][unit] = h0[i] * keep[i];
+            }
+        }
+        __syncthreads();
+        // ---- layer 1: weights streamed, PF k-groups ahead
+        {
+            constexpr int PF = TICK_PF < KQ ? TICK_PF : KQ;
+            f32x4 wi[PF + 1][3], wh[PF + 1][3];
+            auto fetch = [&](int kq, int slot) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    const int64_t o = (int64_t)(g * H + unit) * H + 16 * kq + 4 * quad;
+                    wi[slot][g] = *reinterpret_cast<const f32x4 *>(p.w_ih1 + o);
+                    wh[slot][g] = *reinterpret_cast<const f32x4 *>(p.w_hh1 + o);
+                }
+            };
+            f32x4 ar = {0.f, 0.f, 0.f, 0.f}, az = ar, ain = ar, ahn = ar;
+            static_assert(KQ >= PF, "tick_free_run: hidden size too small for the prefetch depth");
+#pragma unroll
+            for (int k = 0; k < PF; ++k) fetch(k, k);
+#pragma unroll
+            for (int kq = 0; kq < KQ; ++kq) {
+                if (kq + PF < KQ) fetch(kq + PF, (kq + PF) % (PF + 1));
+                const int sl = kq % (PF + 1);
+                const f32x4 am = *reinterpret_cast<const f32x4 *>(&mid[col][16 * kq + 4 * quad]);
+                const f32x4 ah = *reinterpret_cast<const f32x4 *>(&hA1[cur][col][16 * kq + 4 * quad]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    ar = __builtin_amdgcn_mfma_f32_16x16x4f32(am[j], wi[sl][0][j], ar, 0, 0, 0);
+                    az = __builtin_amdgcn_mfma_f32_16x16x4f32(am[j], wi[sl][1][j], az, 0, 0, 0);
+                    ain = __builtin_amdgcn_mfma_f32_16x16x4f32(am[j], wi[sl][2][j], ain, 0, 0, 0);
+                    ar = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[j], wh[sl][0][j], ar, 0, 0, 0);
+                    az = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[j], wh[sl][1][j], az, 0, 0, 0);
+                    ahn = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[j], wh[sl][2][j], ahn, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float r = fast_sigmoid(ar[i] + b1r);
+                const float z = fast_sigmoid(az[i] + b1z);
+                const float n = fast_tanh(ain[i] + b1in + r * (ahn[i] + b1hn));
+                h1[i] = (1.f - z) * n + z * h1[i];
+                hA1[cur ^ 1][4 * quad + i][unit] = h1[i];
+            }
+        }
+        __syncthreads();
+        // ---- logits + row argmax
+        if (w < ntile) {
+            f32x4 lg = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kq = 0; kq < KQ; ++kq) {
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(&hA1[cur ^ 1][col][16 * kq + 4 * quad]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) lg = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], wout[kq][j], lg, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = note_ok ? fmaxf(lg[i] + bout, 0.f) : -1.f;
+                int ix = note;
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) {
+                    const float ov = __shfl_xor(v, off, 64);
+                    const int oi = __shfl_xor(ix, off, 64);
+                    if (ov > v || (ov == v && oi < ix)) { v = ov; ix = oi; }
+                }
+                if (col == 0) { cand_v[w][4 * quad + i] = v; cand_i[w][4 * quad + i] = ix; }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 4 * quad + i;
+            float v = cand_v[0][r];
+            int ix = cand_i[0][r];
+            for (int c = 1; c < ntile; ++c) {
+                const float ov = cand_v[c][r];
+                if (ov > v) { v = ov; ix = cand_i[c][r]; }          // later tiles hold larger indices: ties keep the earlier
+            }
+            tok[i] = ix;
+            if (w == 0 && col == 0 && live[i]) p.tokens[(int64_t)rows[i] * ticks + t] = ix;
+        }
+    }
+}
+
 }  // namespace arvae
 
 using namespace arvae;
@@ -280,4 +481,32 @@ extern "C" int arvae_gru_seq_bwd(const arvae_gru_seq_t *seqs, int32_t nseq, int3
     else if (hidden == 64) hipLaunchKernelGGL(gru_seq_bwd_kernel<64>, grid, dim3(256), 0, st, b, steps, rows);
     else hipLaunchKernelGGL(gru_seq_bwd_kernel<32>, grid, dim3(128), 0, st, b, steps, rows);
     return check_launch("gru_seq_bwd_kernel");
+}
+
+extern "C" int arvae_tick_free_run(const arvae_tick_weights_t *wts, const float *h0_l0, const float *h0_l1, const float *gib,
+                                   const float *ptab, const uint8_t *mask, float keep_scale, int32_t batch, int32_t beats,
+                                   int32_t ticks_per_beat, int32_t hidden, int32_t vocab, int64_t *tokens,
+                                   arvae_stream_t stream) {
+    ARVAE_REQUIRE(wts && h0_l0 && h0_l1 && gib && ptab && tokens, "tick_free_run: null pointer");
+    ARVAE_REQUIRE(wts->w_hh0 && wts->b_hh0 && wts->w_ih1 && wts->b_ih1 && wts->w_hh1 && wts->b_hh1 && wts->w_out && wts->b_out,
+                  "tick_free_run: null weight pointer");
+    ARVAE_REQUIRE(batch >= 1 && beats >= 1 && ticks_per_beat >= 1, "tick_free_run: empty problem");
+    ARVAE_REQUIRE(arvae_gru_seq_supported(hidden), "tick_free_run: hidden size %d is not built (32, 64, 128)", hidden);
+    ARVAE_REQUIRE(vocab >= 1 && vocab <= 16 * (hidden / 16) && vocab <= 64, "tick_free_run: vocabulary of %d notes not supported", vocab);
+    TickFreeRun p{};
+    p.w_hh0 = wts->w_hh0; p.b_hh0 = wts->b_hh0; p.w_ih1 = wts->w_ih1; p.b_ih1 = wts->b_ih1;
+    p.w_hh1 = wts->w_hh1; p.b_hh1 = wts->b_hh1; p.w_out = wts->w_out; p.b_out = wts->b_out;
+    p.h0_l0 = h0_l0; p.h0_l1 = h0_l1; p.gib = gib; p.ptab = ptab; p.mask = mask; p.keep_scale = keep_scale;
+    p.batch = batch; p.beats = beats; p.tpb = ticks_per_beat; p.vocab = vocab; p.tokens = tokens;
+    hipStream_t st = as_stream(stream);
+    const dim3 grid((batch + 15) / 16);
+    prof_gap();
+    const bool m = mask != nullptr;
+    if (hidden == 128 && m) hipLaunchKernelGGL((tick_free_run_kernel<128, 2, true>), grid, dim3(512), 0, st, p);
+    else if (hidden == 128) hipLaunchKernelGGL((tick_free_run_kernel<128, 2, false>), grid, dim3(512), 0, st, p);
+    else if (hidden == 64 && m) hipLaunchKernelGGL((tick_free_run_kernel<64, 2, true>), grid, dim3(256), 0, st, p);
+    else if (hidden == 64) hipLaunchKernelGGL((tick_free_run_kernel<64, 2, false>), grid, dim3(256), 0, st, p);
+    else if (m) hipLaunchKernelGGL((tick_free_run_kernel<32, 2, true>), grid, dim3(128), 0, st, p);
+    else hipLaunchKernelGGL((tick_free_run_kernel<32, 2, false>), grid, dim3(128), 0, st, p);
+    return check_launch("tick_free_run_kernel");
 }

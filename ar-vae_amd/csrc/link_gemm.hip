@@ -528,13 +528,19 @@ static int launch_gemm(const P &p, int M, int N, int zdim, bool wide_m, hipStrea
 
 using namespace arvae;
 
+// experiment switch: Linear layers over >= 2048 rows (the MeasureVAE's whole-sequence GEMMs) on the LDS-staged generic kernels
+static bool dense_rows_generic(const arvae_link_t *l, int which) {
+    static const int mode = getenv("ARVAE_DENSE_GENERIC") ? atoi(getenv("ARVAE_DENSE_GENERIC")) : 0;
+    return l->n >= 2048 && (mode & which) != 0;
+}
+
 extern "C" int arvae_link_down(const arvae_link_t *link, const arvae_operand_t *hi, const float *wt,
                                const float *bias, int32_t out_act, const uint8_t *out_mask, float *lo,
                                arvae_stream_t stream) {
     DownPolicy p;
     if (int rc = make_geom(link, p.g)) return rc;
     ARVAE_REQUIRE(hi && hi->v && wt && lo, "link_down: null pointer");
-    if (dense_fits(link) && out_mask == nullptr && hi->y == nullptr)
+    if (dense_fits(link) && out_mask == nullptr && hi->y == nullptr && !dense_rows_generic(link, 1))
         return dense_fwd(link, hi->v, wt, bias, out_act, lo, as_stream(stream));
     if (conv32_fits(link) && out_mask == nullptr && hi->y == nullptr && out_act != ARVAE_ACT_SELU)
         return conv32_down(link, make_operand(hi), wt, bias, out_act == ARVAE_ACT_RELU, nullptr, nullptr, nullptr, lo, as_stream(stream));
@@ -561,7 +567,7 @@ extern "C" int arvae_link_up(const arvae_link_t *link, const arvae_operand_t *lo
                   link->kh, link->kw, s);
     ARVAE_REQUIRE(link->hh % s == 0 && link->hw % s == 0, "link_up: hi extent not a multiple of the stride");
     hipStream_t st = as_stream(stream);
-    if (dense_fits(link) && out_mask == nullptr && bias == nullptr && out_act == ARVAE_ACT_NONE)
+    if (dense_fits(link) && out_mask == nullptr && bias == nullptr && out_act == ARVAE_ACT_NONE && !dense_rows_generic(link, 2))
         return dense_dgrad(link, make_operand(lo), wt, nullptr, hi, st);
     if (conv32_fits(link) && out_mask == nullptr && lo->y == nullptr && out_act != ARVAE_ACT_SELU)
     {
@@ -649,7 +655,7 @@ extern "C" int arvae_link_wgrad(const arvae_link_t *link, const arvae_operand_t 
     ARVAE_REQUIRE(ws != nullptr || arvae_link_wgrad_ws_floats(link) == 0,
                   "link_wgrad: workspace of arvae_link_wgrad_ws_floats() floats needed");
     hipStream_t st = as_stream(stream);
-    if (dense_fits(link) && hi->y == nullptr && bias_side != 2)
+    if (dense_fits(link) && hi->y == nullptr && bias_side != 2 && !dense_rows_generic(link, 4))
         return dense_wgrad(link, make_operand(lo), hi->v, dwt, bias_side == 1 ? dbias : nullptr, ws, st);
     if (conv_c1_fits(link) && lo->mask == nullptr && hi->mask == nullptr && lo->act != ARVAE_ACT_SELU &&
         hi->act != ARVAE_ACT_SELU)
@@ -712,4 +718,18 @@ extern "C" int arvae_channel_sum(const arvae_operand_t *g, int64_t rows, int32_t
     ARVAE_REQUIRE(rows > 0 && channels > 0, "channel_sum: empty tensor");
     ARVAE_REQUIRE(perm_c == 0 || perm_c * perm_hw == channels, "channel_sum: perm does not cover channels");
     return channel_sum_launch(make_operand(g), rows, channels, perm_c, perm_hw, out, ws, as_stream(stream));
+}
+
+// out[i] = operand value with the activation derivative / keep-mask folded in (a "plain" copy of a gradient operand,
+// for the long-batch Linear kernels that take plain operands only)
+__global__ __launch_bounds__(256) void operand_apply_kernel(Operand g, int64_t count, float *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) out[i] = g.at(i);
+}
+
+extern "C" int arvae_operand_apply(const arvae_operand_t *g, int64_t count, float *out, arvae_stream_t stream) {
+    ARVAE_REQUIRE(g && g->v && out && count > 0, "operand_apply: bad argument");
+    const int64_t blocks = (count + 255) / 256;
+    hipLaunchKernelGGL(operand_apply_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, as_stream(stream),
+                       make_operand(g), count, out);
+    return check_launch("operand_apply_kernel");
 }

@@ -73,9 +73,9 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t *__restric
 }
 
 // dtable[v][d] += sum over positions with idx == v of g[row][d], in two launches with a fixed summation order:
-// (1) a workgroup stages 256 positions (indices + gradient rows) in LDS and one thread per (v, d) pair sums the rows
+// (1) a workgroup stages EMBED_POS positions (indices + gradient rows) in LDS and one thread per (v, d) pair sums the rows
 // whose index is v; (2) the per-workgroup partials are added in workgroup order.
-constexpr int EMBED_POS = 256;
+constexpr int EMBED_POS = 64;
 __global__ __launch_bounds__(256) void embed_bwd_partial_kernel(const int64_t *__restrict__ idx, const float *__restrict__ g,
                                                                  int batch, int steps, int dim, int vocab, int time_major,
                                                                  float *__restrict__ partial) {
@@ -83,14 +83,20 @@ __global__ __launch_bounds__(256) void embed_bwd_partial_kernel(const int64_t *_
     const int pitch = dim + 1;
     int *sidx = reinterpret_cast<int *>(sg + EMBED_POS * pitch);
     const int64_t n = (int64_t)batch * steps;
-    const int64_t pos = (int64_t)blockIdx.x * EMBED_POS + threadIdx.x;         // pos = b*steps + t
-    if (pos < n) {
-        const int b = (int)(pos / steps), t = (int)(pos % steps);
-        const int64_t row = time_major ? (int64_t)t * batch + b : pos;
-        sidx[threadIdx.x] = (int)idx[pos];
-        for (int d = 0; d < dim; ++d) sg[threadIdx.x * pitch + d] = g[row * dim + d];
-    } else {
-        sidx[threadIdx.x] = -1;
+    // element e = (position slot, d): consecutive threads read consecutive floats of a gradient row
+    for (int e = threadIdx.x; e < EMBED_POS * dim; e += 256) {
+        const int slot = e / dim, d = e - slot * dim;
+        const int64_t pos = (int64_t)blockIdx.x * EMBED_POS + slot;            // pos = b*steps + t
+        float v = 0.f;
+        if (pos < n) {
+            const int b = (int)(pos / steps), t = (int)(pos % steps);
+            const int64_t row = time_major ? (int64_t)t * batch + b : pos;
+            v = g[row * dim + d];
+            if (d == 0) sidx[slot] = (int)idx[pos];
+        } else if (d == 0) {
+            sidx[slot] = -1;
+        }
+        sg[slot * pitch + d] = v;
     }
     __syncthreads();
     for (int pair = threadIdx.x; pair < vocab * dim; pair += 256) {
@@ -103,11 +109,24 @@ __global__ __launch_bounds__(256) void embed_bwd_partial_kernel(const int64_t *_
 }
 __global__ __launch_bounds__(256) void embed_bwd_reduce_kernel(const float *__restrict__ partial, int blocks, int count,
                                                                 float *__restrict__ dtable) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= count) return;
+    // 4 lanes per table element, lane q sums blocks q, q+4, ... with 8 loads in flight; fixed-order lane sum
+    const int i = (blockIdx.x * 256 + threadIdx.x) >> 2, q = threadIdx.x & 3;
+    const int ic = i < count ? i : 0;
     float s = 0.f;
-    for (int z = 0; z < blocks; ++z) s += partial[(int64_t)z * count + i];
-    dtable[i] += s;
+    for (int z0 = q; z0 < blocks; z0 += 32) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int z = z0 + 4 * u;
+            const float v = partial[(int64_t)(z < blocks ? z : 0) * count + ic];
+            t[u] = z < blocks ? v : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += t[u];
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (q == 0 && i < count) dtable[i] += s;
 }
 
 // idx[b] = argmax_j w[b][j], lowest index on ties (reference decoder.py:506-507 topk(1))
@@ -243,7 +262,7 @@ extern "C" int arvae_embed_bwd(const int64_t *idx, const float *g, int32_t batch
     const size_t lds = (size_t)EMBED_POS * (dim + 1) * sizeof(float) + EMBED_POS * sizeof(int);
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(embed_bwd_partial_kernel, dim3(blocks), dim3(256), lds, st, idx, g, batch, steps, dim, vocab, time_major, ws);
-    hipLaunchKernelGGL(embed_bwd_reduce_kernel, dim3((vocab * dim + 255) / 256), dim3(256), 0, st, ws, blocks, vocab * dim, dtable);
+    hipLaunchKernelGGL(embed_bwd_reduce_kernel, dim3((vocab * dim * 4 + 255) / 256), dim3(256), 0, st, ws, blocks, vocab * dim, dtable);
     return check_launch("embed_bwd_kernel");
 }
 

@@ -323,7 +323,20 @@ class HierarchicalDecoder(Decoder):
         """argmax-feedback pass (no autograd): the tokens the decoder feeds itself, int64 (B, 24)."""
         nb, b = beat_out.shape[0], beat_out.shape[1]
         hid = self.rnn_hidden_size
-        w_ih0, _, b_ih0, _ = self.rnn_tick.cell(0)
+        w_ih0, w_hh0, b_ih0, b_hh0 = self.rnn_tick.cell(0)
+        if os.environ.get('ARVAE_TICK_STEPWISE', '0') != '1' and self.num_notes <= 64:
+            # one launch (csrc/gru_seq.hip tick_free_run_kernel).  W_ih0 acts on [previous-note embedding | beat
+            # embedding]: the beat half is applied once per beat, the note half once per vocabulary entry (+ x_0).
+            emb_dim = self.note_embedding_dim
+            w_note, w_beat = w_ih0.detach()[:, :emb_dim].contiguous(), w_ih0.detach()[:, emb_dim:].contiguous()
+            gib = ops.dense(beat_emb.detach(), w_beat, b_ih0.detach(), Link.dense(hid, 3 * hid), ACT_NONE)
+            table = torch.cat((self.note_embedding_layer.weight.detach(), self.x_0.detach()[None]), 0)
+            ptab = ops.dense(table, w_note, None, Link.dense(emb_dim, 3 * hid), ACT_NONE)
+            w_ih1, w_hh1, b_ih1, b_hh1 = self.rnn_tick.cell(1)
+            out = self.tick_emb_to_note_emb[0]
+            weights = tuple(t.detach() for t in (w_hh0, b_hh0, w_ih1, b_ih1, w_hh1, b_hh1, out.weight, out.bias))
+            return ops.tick_free_run(weights, h0[0].detach(), h0[1].detach(), gib, ptab,
+                                     None if mask is None else mask.contiguous(), 1.0 / (1.0 - self.dropout), b, nb, 6)
         prev = self.x_0.detach()[None].expand(b, -1).contiguous()
         tokens = []
         for i in range(nb):

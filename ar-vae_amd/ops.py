@@ -173,6 +173,23 @@ def channel_sum(op, rows, channels, perm, out):
     return out
 
 
+LONG_BATCH_ROWS = 2048      # csrc/dense.h DENSE_SPLIT_MIN_ROWS: Linear layers over this many rows run on the rows-GEMM kernels
+
+
+def _plain_gradient(g, y, mask, act, link, n):
+    """operand of a Linear layer's output gradient; for long batches with an activation / mask to fold in, the folded
+    gradient is written out once so that both the data- and the weight-gradient run on the plain-operand kernels."""
+    if (act != ACT_NONE or mask is not None) and n >= LONG_BATCH_ROWS and link.hh == link.hw == link.lh == link.lw == 1:
+        lib = _lib.load()
+        out = torch.empty_like(g)
+        op = _operand(g, y, mask, act)
+        _lib.check(lib.arvae_operand_apply(ctypes.byref(op), g.numel(), _ptr(out), _stream()), 'operand_apply')
+        return _operand(out), out
+    if act == ACT_NONE and mask is None:
+        return _operand(g), g
+    return _operand(g, y, mask, act), g
+
+
 def _grad_target(param):
     """Where a parameter gradient is accumulated.  When the parameter already owns a `.grad` buffer (the
     trainer's flat gradient arena after zero_grad()), the kernels add straight into it and autograd gets
@@ -206,7 +223,7 @@ class _LinkDownFn(Function):
         hi, wt, lo, mask = ctx.saved_tensors
         link, n = ctx.link, ctx.n
         g_lo = g_lo.contiguous()
-        gop = _operand(g_lo, lo, mask, ctx.act)
+        gop, _keep = _plain_gradient(g_lo, lo, mask, ctx.act, link, n)
         d_hi = d_wt = d_bias = None
         if ctx.needs_input_grad[0]:
             d_hi = link_up(link, n, gop, wt, None, ACT_NONE, None)
@@ -605,6 +622,21 @@ def gru_sequence(steps, directions):
     for gi, w_hh, b_hh, h0, _ in directions:
         flat += [gi.contiguous(), w_hh, b_hh, None if h0 is None else h0.contiguous()]
     return _GruSeqFn.apply(int(steps), tuple(bool(d[4]) for d in directions), *flat)
+
+
+def tick_free_run(weights, h0_l0, h0_l1, gib, ptab, mask, keep_scale, batch, beats, ticks_per_beat):
+    """tokens (B, beats*ticks_per_beat) int64 of the free-running tick decoder; no autograd (csrc/gru_seq.hip).
+    weights = (w_hh0, b_hh0, w_ih1, b_ih1, w_hh1, b_hh1, w_out, b_out)."""
+    _dev(*weights, h0_l0, h0_l1, gib, ptab, mask)
+    lib = _lib.load()
+    hid, vocab = weights[0].shape[1], weights[6].shape[0]
+    tw = _lib.TickWeights(*[_ptr(t) for t in weights])
+    tokens = torch.empty(batch, beats * ticks_per_beat, device=gib.device, dtype=torch.int64)
+    with _timed('tick_free_run', 2.0 * batch * beats * ticks_per_beat * (9 * hid * hid + vocab * hid), 0.0):
+        _lib.check(lib.arvae_tick_free_run(ctypes.byref(tw), _ptr(h0_l0), _ptr(h0_l1), _ptr(gib), _ptr(ptab), _ptr(mask),
+                                           float(keep_scale), batch, beats, ticks_per_beat, hid, vocab, _ptr(tokens),
+                                           _stream()), 'tick_free_run')
+    return tokens
 
 
 class _EmbedFn(Function):

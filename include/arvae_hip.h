@@ -119,6 +119,9 @@ int64_t arvae_channel_sum_ws_floats(int64_t rows, int32_t channels);
 int arvae_channel_sum(const arvae_operand_t *g, int64_t rows, int32_t channels, int32_t perm_c,
                       int32_t perm_hw, float *out, float *ws, arvae_stream_t stream);
 
+/* out[i] = value of the operand with act'(y) and the keep-mask folded in: a plain copy of a gradient operand. */
+int arvae_operand_apply(const arvae_operand_t *g, int64_t count, float *out, arvae_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Latent head.  Replaces z_dist = Normal(mu, exp(log_std)); z = z_dist.rsample()
  * (imagevae/mnist_vae.py:65,74-87; measurevae/encoder.py:123, measure_vae.py:115-123) with the noise
@@ -230,6 +233,22 @@ int arvae_gru_seq_fwd(const arvae_gru_seq_t *seqs, int32_t nseq, int32_t steps, 
                       arvae_stream_t stream);
 int arvae_gru_seq_bwd(const arvae_gru_seq_t *seqs, int32_t nseq, int32_t steps, int32_t rows, int32_t hidden,
                       arvae_stream_t stream);
+
+/* Free-running pass of the tick decoder (measurevae/decoder.py:459-525 without teacher forcing): 2-layer GRU, note
+ * projection + ReLU, top-1 note (lowest index on ties) embedded as the next input, hidden state restarted from
+ * h0_l0 / h0_l1 [beats*batch][hidden] (row = beat*batch + b) at every beat.  One launch, returns only the tokens
+ * [batch][beats*ticks_per_beat]; the caller evaluates the differentiable graph on them with arvae_gru_seq_*.
+ * The layer-0 input projection arrives pre-multiplied: gib [beats*batch][3*hidden] = W_ih0[:, E:] beat_emb + b_ih0 and
+ * ptab [vocab+1][3*hidden] = W_ih0[:, :E] applied to the embedding table, row `vocab` = the learned start vector x_0.
+ * mask: optional keep-mask [beats*ticks_per_beat][batch][hidden] of nn.GRU's inter-layer dropout, scaled by keep_scale. */
+typedef struct arvae_tick_weights {
+    const float *w_hh0, *b_hh0;     /* rnn_tick layer 0 recurrent weights */
+    const float *w_ih1, *b_ih1, *w_hh1, *b_hh1;   /* layer 1 */
+    const float *w_out, *b_out;     /* tick_emb_to_note_emb [vocab][hidden] */
+} arvae_tick_weights_t;
+int arvae_tick_free_run(const arvae_tick_weights_t *weights, const float *h0_l0, const float *h0_l1, const float *gib,
+                        const float *ptab, const uint8_t *mask, float keep_scale, int32_t batch, int32_t beats,
+                        int32_t ticks_per_beat, int32_t hidden, int32_t vocab, int64_t *tokens, arvae_stream_t stream);
 
 /* nn.Embedding (measurevae/encoder.py:36-37,111; decoder.py:18,516): out row (b,t) = table[idx[b][t]];
  * time_major: rows ordered (t, b) instead of (b, t).  embed_bwd ACCUMULATES dtable (fixed summation order) and needs

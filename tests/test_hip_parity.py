@@ -702,6 +702,63 @@ def test_measure_sequence_path_matches_stepwise(dev, monkeypatch):
             assert float((gseq - gstep).norm()) <= 2e-4 * float(gstep.norm()) + 1e-9, (teacher, k)
 
 
+@pytest.mark.parametrize('b,dropout', [(256, 0.5), (21, 0.0)])
+def test_tick_free_run_tokens_match_stepwise(dev, monkeypatch, b, dropout):
+    """the one-launch free-running tick decoder feeds itself the same notes as the launch-per-tick pass."""
+    from arvae_amd.measure_vae import MeasureVAE
+    torch.manual_seed(23)
+    ds = _FolkDataset()
+    model = MeasureVAE(ds, 10, 2, 2, 128, dropout, 32, 2, 128, dropout, False, 'folk').cuda().train()
+    with torch.no_grad():                                     # spread the logits so that the argmax varies
+        model.decoder.tick_emb_to_note_emb[0].weight.mul_(4.0)
+        model.decoder.tick_emb_to_note_emb[0].bias.add_(0.3)
+    model.decoder.teacher_forcing_prob = 0.0
+    score = torch.from_numpy(syn.measure_batch(b, seed=28)).to(dev)
+    eps = torch.from_numpy(syn.normal_noise((b, 32), seed=29))
+    gen = torch.Generator().manual_seed(4)
+    masks = [(torch.rand(24, b, 256, generator=gen) >= 0.5).to(torch.uint8).to(dev),
+             (torch.rand(4, b, 128, generator=gen) >= 0.5).to(torch.uint8).to(dev),
+             (torch.rand(24, b, 128, generator=gen) >= 0.5).to(torch.uint8).to(dev)]
+    out = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('ARVAE_TICK_STEPWISE', mode)
+        model.push_noise(eps)
+        if dropout > 0:
+            model.encoder.push_dropout_mask(masks[0])
+            model.decoder.push_dropout_masks(masks[1], masks[2])
+        with torch.no_grad():
+            weights, samples, *_ = model(score, score, train=True)
+        out[mode] = (weights, samples)
+    assert out['0'][1].shape == (b, 1, 24) and out['0'][1].dtype == torch.int64
+    assert len(torch.unique(out['1'][1])) > 3                 # a non-trivial token stream
+    assert torch.equal(out['0'][1], out['1'][1])
+    close(out['0'][0], out['1'][0], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('rows,fin,fout,act', [(6144, 128, 384, 0), (2050, 138, 384, 0), (2311, 10, 384, 0),
+                                               (6144, 128, 35, 1), (2048, 256, 130, 2)])
+def test_dense_long_batch_vs_torch(dev, rows, fin, fout, act):
+    """Linear layers over thousands of rows (whole-sequence GEMMs) run on the LDS-staged rows-GEMM kernels:
+    forward, data gradient and the row-sliced weight / bias gradient against torch (fp64 reference)."""
+    from arvae_amd import ops
+    rs = np.random.RandomState(rows + fin)
+    x = torch.from_numpy(rs.standard_normal((rows, fin)).astype(np.float32))
+    w = torch.from_numpy((rs.standard_normal((fout, fin)) / np.sqrt(fin)).astype(np.float32))
+    b = torch.from_numpy(rs.standard_normal(fout).astype(np.float32))
+    gy = torch.from_numpy(rs.standard_normal((rows, fout)).astype(np.float32))
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    pre = xr @ wr.t() + br
+    y = [pre, torch.relu(pre), torch.nn.functional.selu(pre)][act]
+    (y * gy.double()).sum().backward()
+    xd, wd, bd = (t.to(dev).requires_grad_(True) for t in (x, w, b))
+    yd = ops.dense(xd, wd, bd, ops.Link.dense(fin, fout), act)
+    (yd * gy.to(dev)).sum().backward()
+    close(yd, y, rtol=1e-4, atol=1e-5)
+    close(xd.grad, xr.grad, rtol=1e-4, atol=1e-5)
+    close(wd.grad, wr.grad, rtol=1e-4, atol=2e-4)
+    close(bd.grad, br.grad, rtol=1e-4, atol=2e-4)
+
+
 def test_embedding_concat_argmax(dev):
     from arvae_amd import ops
     rs = np.random.RandomState(6)
