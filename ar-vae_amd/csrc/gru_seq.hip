@@ -30,7 +30,7 @@ struct GruSeq {
     const float *h0;        // [R][H] or null (zeros)
     float *h_all;           // h of step t, row r, unit j at h_all[(t*R + r) * h_stride + j]
     int64_t h_stride;
-    float *saved;           // [T][R][4][H] : r, z, n, gh_n
+    float *saved;           // [T][R][H][4] : r, z, n, gh_n
     int reverse;            // process t = T-1 .. 0
     // backward
     const float *dh_all;    // gradient w.r.t. h_all, same addressing with dh_stride; may be null
@@ -131,8 +131,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_kernel(GruSeqBatch batch, i
             if (live[i]) {
                 const int64_t tr = (int64_t)t * R + rows[i];
                 s.h_all[tr * s.h_stride + unit] = hn;
-                float *sv = s.saved + tr * 4 * H + unit;
-                sv[0] = r; sv[H] = z; sv[2 * H] = n; sv[3 * H] = ghn;
+                *reinterpret_cast<f32x4 *>(s.saved + (tr * H + unit) * 4) = f32x4{r, z, n, ghn};
             }
         }
         __syncthreads();
@@ -181,8 +180,8 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_kernel(GruSeqBatch batch, i
         for (int i = 0; i < 4; ++i) {
             const int64_t tr = (int64_t)t * R + rows[i];
             nx[i][0] = s.dh_all != nullptr ? s.dh_all[tr * s.dh_stride + unit] : 0.f;
-            const float *sv = s.saved + tr * 4 * H + unit;
-            nx[i][1] = sv[0]; nx[i][2] = sv[H]; nx[i][3] = sv[2 * H]; nx[i][4] = sv[3 * H];
+            const f32x4 sv = *reinterpret_cast<const f32x4 *>(s.saved + (tr * H + unit) * 4);
+            nx[i][1] = sv[0]; nx[i][2] = sv[1]; nx[i][3] = sv[2]; nx[i][4] = sv[3];
             if (has_prev) nx[i][5] = s.h_all[((int64_t)tp * R + rows[i]) * s.h_stride + unit];
             else nx[i][5] = s.h0 != nullptr ? s.h0[(int64_t)rows[i] * H + unit] : 0.f;
         }
@@ -219,6 +218,254 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_kernel(GruSeqBatch batch, i
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[kq % 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], wreg[kq][j], acc[kq % 3], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) carry[i] = gz[i] + (acc[0][i] + acc[1][i] + acc[2][i]);
+    }
+    if (s.dh0 != nullptr)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (live[i]) s.dh0[(int64_t)rows[i] * H + unit] = carry[i];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same two kernels on the bf16 MFMA at fp32 accuracy (the three-term split of conv32.hip): W_hh is split once into
+// hi + mid + lo bf16 terms per lane (144 VGPRs at H = 128), h (or dgh) is split when it is written to LDS as three
+// bf16 planes, and a multiply-add is the six partial products >= 2^-18 on v_mfma_f32_16x16x32_bf16 (16 cycles each
+// instead of 8 x 32 for the fp32 16x16x4), smallest first: 72 instead of 96 MFMAs per wave and step at half the
+// cycles each.  Results are within one fp32 rounding of the fp32-MFMA kernels' (same tests, same tolerances).
+typedef __bf16 bf16x8g __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2g __attribute__((ext_vector_type(2)));
+typedef float f32x2g __attribute__((ext_vector_type(2)));
+typedef int i32x4g __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned &hi, unsigned &mid, unsigned &lo) {
+    const f32x2g x = {x0, x1};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2g));
+    const f32x2g r = {x0 - __builtin_bit_cast(float, hi << 16), x1 - __builtin_bit_cast(float, hi & 0xffff0000u)};
+    mid = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2g));
+    const f32x2g q = {r.x - __builtin_bit_cast(float, mid << 16), r.y - __builtin_bit_cast(float, mid & 0xffff0000u)};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(q, bf16x2g));
+}
+__device__ __forceinline__ void split3_x8(const float (&x)[8], bf16x8g &hi, bf16x8g &mid, bf16x8g &lo) {
+    i32x4g h, m, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned a, b, c;
+        split3_pair(x[2 * j], x[2 * j + 1], a, b, c);
+        h[j] = (int)a; m[j] = (int)b; l[j] = (int)c;
+    }
+    hi = __builtin_bit_cast(bf16x8g, h); mid = __builtin_bit_cast(bf16x8g, m); lo = __builtin_bit_cast(bf16x8g, l);
+}
+// one value -> its three bf16 terms into the three LDS planes (plane stride in ushorts)
+__device__ __forceinline__ void store_split3(unsigned short *p, int plane, float x) {
+    unsigned a, b, c;
+    split3_pair(x, 0.f, a, b, c);
+    p[0] = (unsigned short)a; p[plane] = (unsigned short)b; p[2 * plane] = (unsigned short)c;
+}
+__device__ __forceinline__ bf16x8g lds_x8(const unsigned short *p) {
+    return __builtin_bit_cast(bf16x8g, *reinterpret_cast<const i32x4g *>(p));
+}
+// acc += a . w with a = (ah, am, al), w = (wh, wm, wl): the six products, smallest first
+#define GRU_MFMA6(ACC, AH, AM, AL, WH, WM, WL)                                         \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AL, WH, ACC, 0, 0, 0);               \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AH, WL, ACC, 0, 0, 0);               \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AM, WM, ACC, 0, 0, 0);               \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AM, WH, ACC, 0, 0, 0);               \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AH, WM, ACC, 0, 0, 0);               \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AH, WH, ACC, 0, 0, 0)
+
+template <int H>
+__global__ __launch_bounds__(H * 4) void gru_seq_fwd_x3_kernel(GruSeqBatch batch, int T, int R) {
+    constexpr int KS = H / 32;             // MFMA k-steps of 32
+    constexpr int HP = H + 8;              // LDS row pitch in bf16 elements (16 bytes of padding)
+    constexpr int PLANE = 16 * HP;
+    __shared__ __attribute__((aligned(16))) unsigned short hbuf[2][3 * PLANE];
+    const GruSeq &s = batch.seq[blockIdx.y];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = lane & 15, quad = lane >> 4;
+    const int unit = 16 * w + col;
+    const int row0 = blockIdx.x * 16;
+
+    bf16x8g wh[3][KS], wm[3][KS], wl[3][KS];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const float *src = s.w_hh + (int64_t)(g * H + unit) * H + 32 * ks + 8 * quad;
+            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(src), v1 = *reinterpret_cast<const f32x4 *>(src + 4);
+            const float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            split3_x8(x, wh[g][ks], wm[g][ks], wl[g][ks]);
+        }
+    const float bh_r = s.b_hh[unit], bh_z = s.b_hh[H + unit], bh_n = s.b_hh[2 * H + unit];
+
+    int rows[4];
+    bool live[4];
+    float h[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = row0 + 4 * quad + i;
+        live[i] = r < R;
+        rows[i] = live[i] ? r : R - 1;
+        h[i] = (s.h0 != nullptr && live[i]) ? s.h0[(int64_t)rows[i] * H + unit] : 0.f;
+        store_split3(&hbuf[0][(4 * quad + i) * HP + unit], PLANE, h[i]);
+    }
+    float gi_next[4][3];
+    {
+        const int t0 = s.reverse ? T - 1 : 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float *p = s.gi + t0 * s.gi_tstride + (int64_t)rows[i] * 3 * H + unit;
+            gi_next[i][0] = p[0]; gi_next[i][1] = p[H]; gi_next[i][2] = p[2 * H];
+        }
+    }
+    __syncthreads();
+    f32x4 keep_sv[4];                        // results of the previous step, stored after the barrier
+    float keep_h[4];
+    int keep_t = -1;
+
+    for (int step = 0; step < T; ++step) {
+        const int t = s.reverse ? T - 1 - step : step;
+        const int cur = step & 1;
+        float gi[4][3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) gi[i][g] = gi_next[i][g];
+        if (step + 1 < T) {
+            const int tn = s.reverse ? t - 1 : t + 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float *p = s.gi + tn * s.gi_tstride + (int64_t)rows[i] * 3 * H + unit;
+                gi_next[i][0] = p[0]; gi_next[i][1] = p[H]; gi_next[i][2] = p[2 * H];
+            }
+        }
+        if (keep_t >= 0) {                   // the previous step's outputs leave while this step's MFMAs run
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (live[i]) {
+                    const int64_t tr = (int64_t)keep_t * R + rows[i];
+                    s.h_all[tr * s.h_stride + unit] = keep_h[i];
+                    *reinterpret_cast<f32x4 *>(s.saved + (tr * H + unit) * 4) = keep_sv[i];
+                }
+        }
+        f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        const unsigned short *hb = &hbuf[cur][col * HP + 8 * quad];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8g ah = lds_x8(hb + 32 * ks), am = lds_x8(hb + PLANE + 32 * ks), al = lds_x8(hb + 2 * PLANE + 32 * ks);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) { GRU_MFMA6(acc[g], ah, am, al, wh[g][ks], wm[g][ks], wl[g][ks]); }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float r = fast_sigmoid(gi[i][0] + acc[0][i] + bh_r);
+            const float z = fast_sigmoid(gi[i][1] + acc[1][i] + bh_z);
+            const float ghn = acc[2][i] + bh_n;
+            const float n = fast_tanh(gi[i][2] + r * ghn);
+            const float hn = (1.f - z) * n + z * h[i];
+            h[i] = hn;
+            store_split3(&hbuf[cur ^ 1][(4 * quad + i) * HP + unit], PLANE, hn);
+            keep_h[i] = hn;
+            keep_sv[i] = f32x4{r, z, n, ghn};
+        }
+        keep_t = t;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (live[i]) {
+            const int64_t tr = (int64_t)keep_t * R + rows[i];
+            s.h_all[tr * s.h_stride + unit] = keep_h[i];
+            *reinterpret_cast<f32x4 *>(s.saved + (tr * H + unit) * 4) = keep_sv[i];
+        }
+}
+
+template <int H>
+__global__ __launch_bounds__(H * 4) void gru_seq_bwd_x3_kernel(GruSeqBatch batch, int T, int R) {
+    constexpr int KS = 3 * H / 32;
+    constexpr int DP = 3 * H + 8;           // LDS row pitch in bf16 elements
+    constexpr int PLANE = 16 * DP;
+    __shared__ __attribute__((aligned(16))) unsigned short dbuf[2][3 * PLANE];
+    const GruSeq &s = batch.seq[blockIdx.y];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = lane & 15, quad = lane >> 4;
+    const int unit = 16 * w + col;
+    const int row0 = blockIdx.x * 16;
+
+    // B[k = c][n = unit] = W_hh[c][unit], c = 32 ks + 8 quad + j
+    bf16x8g wh[KS], wm[KS], wl[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = s.w_hh[(int64_t)(32 * ks + 8 * quad + j) * H + unit];
+        split3_x8(x, wh[ks], wm[ks], wl[ks]);
+    }
+
+    int rows[4];
+    bool live[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = row0 + 4 * quad + i;
+        live[i] = r < R;
+        rows[i] = live[i] ? r : R - 1;
+    }
+    float carry[4] = {0.f, 0.f, 0.f, 0.f};
+
+    float nx[4][6];                          // dh, r, z, n, gh_n, h_prev of the next step
+    auto fetch = [&](int step) {
+        const int t = s.reverse ? step : T - 1 - step;
+        const bool has_prev = step + 1 < T;
+        const int tp = s.reverse ? t + 1 : t - 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t tr = (int64_t)t * R + rows[i];
+            nx[i][0] = s.dh_all != nullptr ? s.dh_all[tr * s.dh_stride + unit] : 0.f;
+            const f32x4 sv = *reinterpret_cast<const f32x4 *>(s.saved + (tr * H + unit) * 4);
+            nx[i][1] = sv[0]; nx[i][2] = sv[1]; nx[i][3] = sv[2]; nx[i][4] = sv[3];
+            if (has_prev) nx[i][5] = s.h_all[((int64_t)tp * R + rows[i]) * s.h_stride + unit];
+            else nx[i][5] = s.h0 != nullptr ? s.h0[(int64_t)rows[i] * H + unit] : 0.f;
+        }
+    };
+    fetch(0);
+
+    for (int step = 0; step < T; ++step) {
+        const int t = s.reverse ? step : T - 1 - step;
+        const int cur = step & 1;
+        float gz[4], o_gi[4][3], o_hn[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float g = live[i] ? nx[i][0] + carry[i] : 0.f;
+            const float r = nx[i][1], z = nx[i][2], n = nx[i][3], ghn = nx[i][4], hp = nx[i][5];
+            const float dpn = g * (1.f - z) * (1.f - n * n);
+            const float dpz = g * (hp - n) * z * (1.f - z);
+            const float dpr = dpn * ghn * r * (1.f - r);
+            const float dhn = dpn * r;
+            gz[i] = g * z;
+            unsigned short *d = &dbuf[cur][(4 * quad + i) * DP + unit];
+            store_split3(d, PLANE, dpr);
+            store_split3(d + H, PLANE, dpz);
+            store_split3(d + 2 * H, PLANE, dhn);
+            o_gi[i][0] = dpr; o_gi[i][1] = dpz; o_gi[i][2] = dpn; o_hn[i] = dhn;
+        }
+        if (step + 1 < T) fetch(step + 1);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i)          // the gradients of this step leave while its MFMAs run
+            if (live[i]) {
+                const int64_t o = ((int64_t)t * R + rows[i]) * 3 * H + unit;
+                s.dgi[o] = o_gi[i][0]; s.dgi[o + H] = o_gi[i][1]; s.dgi[o + 2 * H] = o_gi[i][2];
+                s.dgh[o] = o_gi[i][0]; s.dgh[o + H] = o_gi[i][1]; s.dgh[o + 2 * H] = o_hn[i];
+            }
+        f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        const unsigned short *db = &dbuf[cur][col * DP + 8 * quad];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8g ah = lds_x8(db + 32 * ks), am = lds_x8(db + PLANE + 32 * ks), al = lds_x8(db + 2 * PLANE + 32 * ks);
+            GRU_MFMA6(acc[ks % 3], ah, am, al, wh[ks], wm[ks], wl[ks]);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) carry[i] = gz[i] + (acc[0][i] + acc[1][i] + acc[2][i]);
@@ -445,6 +692,12 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_kernel(TickFreeRun p) {
 
 using namespace arvae;
 
+// ARVAE_GRU_FP32=1: the fp32-MFMA kernels (A/B measurements; the default is the three-term bf16 split)
+static bool gru_fp32_mfma() {
+    static const bool on = getenv("ARVAE_GRU_FP32") != nullptr;
+    return on;
+}
+
 extern "C" int arvae_gru_seq_supported(int32_t hidden) { return hidden == 32 || hidden == 64 || hidden == 128; }
 
 extern "C" int arvae_gru_seq_fwd(const arvae_gru_seq_t *seqs, int32_t nseq, int32_t steps, int32_t rows, int32_t hidden,
@@ -459,9 +712,15 @@ extern "C" int arvae_gru_seq_fwd(const arvae_gru_seq_t *seqs, int32_t nseq, int3
     hipStream_t st = as_stream(stream);
     const dim3 grid((rows + 15) / 16, nseq);
     prof_gap();
-    if (hidden == 128) hipLaunchKernelGGL(gru_seq_fwd_kernel<128>, grid, dim3(512), 0, st, b, steps, rows);
-    else if (hidden == 64) hipLaunchKernelGGL(gru_seq_fwd_kernel<64>, grid, dim3(256), 0, st, b, steps, rows);
-    else hipLaunchKernelGGL(gru_seq_fwd_kernel<32>, grid, dim3(128), 0, st, b, steps, rows);
+    if (gru_fp32_mfma()) {
+        if (hidden == 128) hipLaunchKernelGGL(gru_seq_fwd_kernel<128>, grid, dim3(512), 0, st, b, steps, rows);
+        else if (hidden == 64) hipLaunchKernelGGL(gru_seq_fwd_kernel<64>, grid, dim3(256), 0, st, b, steps, rows);
+        else hipLaunchKernelGGL(gru_seq_fwd_kernel<32>, grid, dim3(128), 0, st, b, steps, rows);
+    } else {
+        if (hidden == 128) hipLaunchKernelGGL(gru_seq_fwd_x3_kernel<128>, grid, dim3(512), 0, st, b, steps, rows);
+        else if (hidden == 64) hipLaunchKernelGGL(gru_seq_fwd_x3_kernel<64>, grid, dim3(256), 0, st, b, steps, rows);
+        else hipLaunchKernelGGL(gru_seq_fwd_x3_kernel<32>, grid, dim3(128), 0, st, b, steps, rows);
+    }
     return check_launch("gru_seq_fwd_kernel");
 }
 
@@ -477,9 +736,15 @@ extern "C" int arvae_gru_seq_bwd(const arvae_gru_seq_t *seqs, int32_t nseq, int3
     hipStream_t st = as_stream(stream);
     const dim3 grid((rows + 15) / 16, nseq);
     prof_gap();
-    if (hidden == 128) hipLaunchKernelGGL(gru_seq_bwd_kernel<128>, grid, dim3(512), 0, st, b, steps, rows);
-    else if (hidden == 64) hipLaunchKernelGGL(gru_seq_bwd_kernel<64>, grid, dim3(256), 0, st, b, steps, rows);
-    else hipLaunchKernelGGL(gru_seq_bwd_kernel<32>, grid, dim3(128), 0, st, b, steps, rows);
+    if (gru_fp32_mfma()) {
+        if (hidden == 128) hipLaunchKernelGGL(gru_seq_bwd_kernel<128>, grid, dim3(512), 0, st, b, steps, rows);
+        else if (hidden == 64) hipLaunchKernelGGL(gru_seq_bwd_kernel<64>, grid, dim3(256), 0, st, b, steps, rows);
+        else hipLaunchKernelGGL(gru_seq_bwd_kernel<32>, grid, dim3(128), 0, st, b, steps, rows);
+    } else {
+        if (hidden == 128) hipLaunchKernelGGL(gru_seq_bwd_x3_kernel<128>, grid, dim3(512), 0, st, b, steps, rows);
+        else if (hidden == 64) hipLaunchKernelGGL(gru_seq_bwd_x3_kernel<64>, grid, dim3(256), 0, st, b, steps, rows);
+        else hipLaunchKernelGGL(gru_seq_bwd_x3_kernel<32>, grid, dim3(128), 0, st, b, steps, rows);
+    }
     return check_launch("gru_seq_bwd_kernel");
 }
 

@@ -219,7 +219,7 @@ typedef struct arvae_gru_seq {
     const float *h0;      /* [rows][hidden] or NULL (zeros) */
     float *h_all;         /* output: h of (step t, row r) at h_all[(t*rows + r) * h_stride + 0..hidden) */
     int64_t h_stride;
-    float *saved;         /* [steps][rows][4][hidden] (r, z, n, gh_n): written by fwd, read by bwd */
+    float *saved;         /* [steps][rows][hidden][4] (layout private to the kernels): written by fwd, read by bwd */
     int32_t reverse;      /* process t = steps-1 .. 0 (the `_reverse` direction of a bidirectional layer) */
     int32_t reserved;
     const float *dh_all;  /* bwd: gradient w.r.t. h_all, addressed like h_all with dh_stride; NULL = zeros */
