@@ -46,7 +46,8 @@ class GruSeqDesc(ctypes.Structure):
     """arvae_gru_seq_t"""
     _fields_ = [('gi', c_vp), ('gi_tstride', c_i64), ('w_hh', c_vp), ('b_hh', c_vp), ('h0', c_vp), ('h_all', c_vp),
                 ('h_stride', c_i64), ('saved', c_vp), ('reverse', c_i32), ('reserved', c_i32), ('dh_all', c_vp),
-                ('dh_stride', c_i64), ('dgi', c_vp), ('dgh', c_vp), ('dh0', c_vp)]
+                ('dh_stride', c_i64), ('dgi', c_vp), ('dgh', c_vp), ('dh0', c_vp), ('dh_last', c_vp),
+                ('dh_last_stride', c_i64), ('h_prev_out', c_vp)]
 
 
 class TickWeights(ctypes.Structure):

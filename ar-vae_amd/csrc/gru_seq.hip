@@ -38,6 +38,9 @@ struct GruSeq {
     float *dgi;             // [T][R][3H]
     float *dgh;             // [T][R][3H]
     float *dh0;             // [R][H] or null
+    const float *dh_last;   // gradient w.r.t. the final state (h of the last processed step), [R] rows of dh_last_stride; may be null
+    int64_t dh_last_stride;
+    float *h_prev_out;      // [T][R][H]: h entering step t (the operand of the W_hh weight gradient); may be null
 };
 struct GruSeqBatch {
     GruSeq seq[GRU_SEQ_MAX];
@@ -168,7 +171,10 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_kernel(GruSeqBatch batch, i
         live[i] = r < R;
         rows[i] = live[i] ? r : R - 1;
     }
-    float carry[4] = {0.f, 0.f, 0.f, 0.f};
+    float carry[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        carry[i] = (s.dh_last != nullptr && live[i]) ? s.dh_last[(int64_t)rows[i] * s.dh_last_stride + unit] : 0.f;
 
     // operands of one step: dh, r, z, n, gh_n, h_prev
     float nx[4][6];
@@ -207,6 +213,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_kernel(GruSeqBatch batch, i
                 const int64_t o = ((int64_t)t * R + rows[i]) * 3 * H + unit;
                 s.dgi[o] = dpr; s.dgi[o + H] = dpz; s.dgi[o + 2 * H] = dpn;
                 s.dgh[o] = dpr; s.dgh[o + H] = dpz; s.dgh[o + 2 * H] = dhn;
+                if (s.h_prev_out != nullptr) s.h_prev_out[((int64_t)t * R + rows[i]) * H + unit] = hp;
             }
         }
         if (step + 1 < T) fetch(step + 1);
@@ -413,7 +420,10 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_x3_kernel(GruSeqBatch batch
         live[i] = r < R;
         rows[i] = live[i] ? r : R - 1;
     }
-    float carry[4] = {0.f, 0.f, 0.f, 0.f};
+    float carry[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        carry[i] = (s.dh_last != nullptr && live[i]) ? s.dh_last[(int64_t)rows[i] * s.dh_last_stride + unit] : 0.f;
 
     float nx[4][6];                          // dh, r, z, n, gh_n, h_prev of the next step
     auto fetch = [&](int step) {
@@ -435,7 +445,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_x3_kernel(GruSeqBatch batch
     for (int step = 0; step < T; ++step) {
         const int t = s.reverse ? step : T - 1 - step;
         const int cur = step & 1;
-        float gz[4], o_gi[4][3], o_hn[4];
+        float gz[4], o_gi[4][3], o_hn[4], o_hp[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float g = live[i] ? nx[i][0] + carry[i] : 0.f;
@@ -449,7 +459,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_x3_kernel(GruSeqBatch batch
             store_split3(d, PLANE, dpr);
             store_split3(d + H, PLANE, dpz);
             store_split3(d + 2 * H, PLANE, dhn);
-            o_gi[i][0] = dpr; o_gi[i][1] = dpz; o_gi[i][2] = dpn; o_hn[i] = dhn;
+            o_gi[i][0] = dpr; o_gi[i][1] = dpz; o_gi[i][2] = dpn; o_hn[i] = dhn; o_hp[i] = hp;
         }
         if (step + 1 < T) fetch(step + 1);
         __syncthreads();
@@ -459,6 +469,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_x3_kernel(GruSeqBatch batch
                 const int64_t o = ((int64_t)t * R + rows[i]) * 3 * H + unit;
                 s.dgi[o] = o_gi[i][0]; s.dgi[o + H] = o_gi[i][1]; s.dgi[o + 2 * H] = o_gi[i][2];
                 s.dgh[o] = o_gi[i][0]; s.dgh[o + H] = o_gi[i][1]; s.dgh[o + 2 * H] = o_hn[i];
+                if (s.h_prev_out != nullptr) s.h_prev_out[((int64_t)t * R + rows[i]) * H + unit] = o_hp[i];
             }
         f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         const unsigned short *db = &dbuf[cur][col * DP + 8 * quad];
@@ -483,6 +494,7 @@ static int fill_batch(GruSeqBatch *b, const arvae_gru_seq_t *seqs, int nseq) {
         s.gi = q.gi; s.gi_tstride = q.gi_tstride; s.w_hh = q.w_hh; s.b_hh = q.b_hh; s.h0 = q.h0;
         s.h_all = q.h_all; s.h_stride = q.h_stride; s.saved = q.saved; s.reverse = q.reverse;
         s.dh_all = q.dh_all; s.dh_stride = q.dh_stride; s.dgi = q.dgi; s.dgh = q.dgh; s.dh0 = q.dh0;
+        s.dh_last = q.dh_last; s.dh_last_stride = q.dh_last_stride; s.h_prev_out = q.h_prev_out;
     }
     return 0;
 }

@@ -159,13 +159,13 @@ class Encoder(Model):
             mask = self._mask_queue.popleft().to(emb.device) if self._mask_queue else \
                 (torch.rand(steps, b, 2 * hid, device=emb.device) >= self.dropout).to(torch.uint8)
         if _use_sequence_kernels(hid):
-            out0 = self._layer_sequence(emb.view(steps * b, -1), steps, b, 0)
+            out0, fin0 = self._layer_sequence(emb.view(steps * b, -1), steps, b, 0)
             mid = out0.view(steps * b, 2 * hid)
             if dropping:
                 mid = ops.dropout_mask(mid, mask.contiguous().view(steps * b, 2 * hid), self.dropout)
-            out1 = self._layer_sequence(mid, steps, b, 1)
+            _, fin1 = self._layer_sequence(mid, steps, b, 1)
             # h_n of nn.GRU: (layer 0 fwd, layer 0 rev, layer 1 fwd, layer 1 rev), each direction's LAST processed step
-            hidden = torch.cat((out0[steps - 1, :, :hid], out0[0, :, hid:], out1[steps - 1, :, :hid], out1[0, :, hid:]), 1)
+            hidden = ops.concat_cols(fin0, fin1)
         else:
             seq = list(torch.unbind(emb, 0))
             seq, finals0 = self._layer(seq, 0)
@@ -269,14 +269,14 @@ class HierarchicalDecoder(Decoder):
         """2-layer unidirectional GRU over `steps`: gi0 (T, R, 3H) or (R, 3H); h0 = [layer-0, layer-1] initial states;
         mask (T*R, H) keep-mask on the layer-0 outputs (nn.GRU's inter-layer dropout).  -> layer-1 outputs (T, R, H)"""
         hid = self.rnn_hidden_size
-        out0 = ops.gru_sequence(steps, [(gi0, rnn.cell(0)[1], rnn.cell(0)[3], h0[0], False)])
+        out0, _ = ops.gru_sequence(steps, [(gi0, rnn.cell(0)[1], rnn.cell(0)[3], h0[0], False)])
         rows = out0.shape[1]
         mid = out0.view(steps * rows, hid)
         if mask is not None:
             mid = ops.dropout_mask(mid, mask, self.dropout)
         w_ih1, w_hh1, b_ih1, b_hh1 = rnn.cell(1)
         gi1 = ops.dense(mid, w_ih1, b_ih1, Link.dense(w_ih1.shape[1], w_ih1.shape[0]), ACT_NONE).view(steps, rows, -1)
-        return ops.gru_sequence(steps, [(gi1, w_hh1, b_hh1, h0[1], False)])
+        return ops.gru_sequence(steps, [(gi1, w_hh1, b_hh1, h0[1], False)])[0]
 
     def beat_rnn_sequence(self, z, seq_len, mask=None):
         """-> (4, B, H) beat embeddings (decoder.py:436-457)"""

@@ -541,7 +541,8 @@ class _GruSeqFn(Function):
     """All time steps of one GRU layer (1..4 directions / parameter sets) in one launch; see csrc/gru_seq.hip.
 
     per direction d the inputs are gi_d (T, R, 3H) -- or (R, 3H) when the same projection feeds every step --,
-    w_hh_d, b_hh_d, h0_d (R, H) or None; the output is (T, R, ndir*H) with direction d in columns [dH, (d+1)H)."""
+    w_hh_d, b_hh_d, h0_d (R, H) or None.  Outputs: (T, R, ndir*H) with direction d in columns [dH, (d+1)H), and the
+    final states (R, ndir*H) = nn.GRU's h_n (each direction's last processed step)."""
 
     @staticmethod
     def forward(ctx, steps, reverse, *tensors):
@@ -562,16 +563,18 @@ class _GruSeqFn(Function):
             q.saved, q.reverse = saved[d].data_ptr(), int(reverse[d])
         with _timed('gru_seq_fwd', 2.0 * ndir * steps * rows * 3 * hid * hid, 4.0 * ndir * steps * rows * 8 * hid):
             _lib.check(lib.arvae_gru_seq_fwd(descs, ndir, steps, rows, hid, _stream()), 'gru_seq_fwd')
+        finals = torch.cat([out[0 if reverse[d] else steps - 1, :, d * hid:(d + 1) * hid] for d in range(ndir)], 1)
         ctx.save_for_backward(out, saved, *whs, *[h for h in h0s if h is not None])
         ctx.h0_present = [h is not None for h in h0s]
         ctx.gi_const = [g.dim() == 2 for g in gis]
         ctx.refs = (whs, bhs)
         ctx.geom = (steps, rows, hid, tuple(reverse))
-        return out
+        ctx.set_materialize_grads(False)
+        return out, finals
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, d_out):
+    def backward(ctx, d_out, d_fin):
         steps, rows, hid, reverse = ctx.geom
         ndir = len(reverse)
         out, saved = ctx.saved_tensors[:2]
@@ -580,9 +583,11 @@ class _GruSeqFn(Function):
         h0s = [next(h0_it) if p else None for p in ctx.h0_present]
         lib = _lib.load()
         dev = out.device
-        d_out = d_out.contiguous()
+        d_out = None if d_out is None else d_out.contiguous()
+        d_fin = None if d_fin is None else d_fin.contiguous()
         dgi = torch.empty(ndir, steps, rows, 3 * hid, device=dev, dtype=torch.float32)
         dgh = torch.empty_like(dgi)
+        h_prev = torch.empty(ndir, steps, rows, hid, device=dev, dtype=torch.float32)
         dh0 = [torch.empty(rows, hid, device=dev, dtype=torch.float32)
                if (h0s[d] is not None and ctx.needs_input_grad[2 + 4 * d + 3]) else None for d in range(ndir)]
         descs = _gru_seq_descs(ndir)
@@ -591,23 +596,24 @@ class _GruSeqFn(Function):
             q.w_hh, q.h0 = _ptr(whs[d]), _ptr(h0s[d])
             q.h_all, q.h_stride = out.data_ptr() + 4 * d * hid, ndir * hid
             q.saved, q.reverse = saved[d].data_ptr(), int(reverse[d])
-            q.dh_all, q.dh_stride = d_out.data_ptr() + 4 * d * hid, ndir * hid
+            if d_out is not None:
+                q.dh_all, q.dh_stride = d_out.data_ptr() + 4 * d * hid, ndir * hid
+            if d_fin is not None:
+                q.dh_last, q.dh_last_stride = d_fin.data_ptr() + 4 * d * hid, ndir * hid
             q.dgi, q.dgh, q.dh0 = dgi[d].data_ptr(), dgh[d].data_ptr(), _ptr(dh0[d])
+            q.h_prev_out = h_prev[d].data_ptr()
         with _timed('gru_seq_bwd', 2.0 * ndir * steps * rows * 3 * hid * hid, 4.0 * ndir * steps * rows * 12 * hid):
             _lib.check(lib.arvae_gru_seq_bwd(descs, ndir, steps, rows, hid, _stream()), 'gru_seq_bwd')
         grads = [None, None]
         link = Link.dense(hid, 3 * hid)
         w_refs, b_refs = ctx.refs
         for d in range(ndir):
-            first = h0s[d][None] if h0s[d] is not None else torch.zeros(1, rows, hid, device=dev)
-            hcol = out[:, :, d * hid:(d + 1) * hid]
-            h_prev = torch.cat((hcol[1:], first), 0) if reverse[d] else torch.cat((first, hcol[:-1]), 0)
             d_w = d_b = None
             if ctx.needs_input_grad[2 + 4 * d + 1]:
                 buf, direct = _grad_target(w_refs[d])
                 bbuf, bdirect = _grad_target(b_refs[d])
                 link_wgrad(link, steps * rows, _operand(dgh[d].view(steps * rows, 3 * hid)),
-                           _operand(h_prev.view(steps * rows, hid)), buf, bbuf, 1)
+                           _operand(h_prev[d].view(steps * rows, hid)), buf, bbuf, 1)
                 d_w, d_b = (None if direct else buf), (None if bdirect else bbuf)
             g_gi = None
             if ctx.needs_input_grad[2 + 4 * d]:
@@ -617,7 +623,7 @@ class _GruSeqFn(Function):
 
 
 def gru_sequence(steps, directions):
-    """directions: list of (gi, w_hh, b_hh, h0, reverse) -> (T, R, ndir*H); see _GruSeqFn."""
+    """directions: list of (gi, w_hh, b_hh, h0, reverse) -> (outputs (T, R, ndir*H), final states (R, ndir*H))."""
     flat = []
     for gi, w_hh, b_hh, h0, _ in directions:
         flat += [gi.contiguous(), w_hh, b_hh, None if h0 is None else h0.contiguous()]

@@ -227,6 +227,10 @@ typedef struct arvae_gru_seq {
     float *dgi;           /* bwd out: [steps][rows][3*hidden] gradient w.r.t. gi */
     float *dgh;           /* bwd out: [steps][rows][3*hidden] gradient w.r.t. W_hh h + b_hh */
     float *dh0;           /* bwd out: [rows][hidden] gradient w.r.t. h0, or NULL */
+    const float *dh_last; /* bwd: gradient w.r.t. the final state (h_n of nn.GRU: h of the last processed step), row r at
+                             dh_last + r*dh_last_stride; NULL = zeros */
+    int64_t dh_last_stride;
+    float *h_prev_out;    /* bwd out, optional: [steps][rows][hidden], the state entering each step (operand of dW_hh) */
 } arvae_gru_seq_t;
 int arvae_gru_seq_supported(int32_t hidden);
 int arvae_gru_seq_fwd(const arvae_gru_seq_t *seqs, int32_t nseq, int32_t steps, int32_t rows, int32_t hidden,

@@ -622,8 +622,9 @@ def test_gru_sequence_vs_torch(dev, rows, hid, steps):
     x = torch.from_numpy(rs.standard_normal((steps, rows, fin)).astype(np.float32)).requires_grad_(True)
     h0 = torch.from_numpy(rs.standard_normal((2, rows, hid)).astype(np.float32)).requires_grad_(True)
     gy = torch.from_numpy(rs.standard_normal((steps, rows, 2 * hid)).astype(np.float32))
+    gfin = torch.from_numpy(rs.standard_normal((rows, 2 * hid)).astype(np.float32))
     y, hn = gru(x, h0)
-    (y * gy).sum().backward()
+    ((y * gy).sum() + (torch.cat((hn[0], hn[1]), 1) * gfin).sum()).backward()
     prm = {k: v.detach().clone().to(dev).requires_grad_(True) for k, v in gru.named_parameters()}
     xd = x.detach().to(dev).requires_grad_(True)
     hd = h0.detach().to(dev).requires_grad_(True)
@@ -632,11 +633,11 @@ def test_gru_sequence_vs_torch(dev, rows, hid, steps):
         gi = ops.dense(xd.view(steps * rows, fin), prm['weight_ih_l0' + suf], prm['bias_ih_l0' + suf],
                        ops.Link.dense(fin, 3 * hid), 0).view(steps, rows, 3 * hid)
         dirs.append((gi, prm['weight_hh_l0' + suf], prm['bias_hh_l0' + suf], hd[d], d == 1))
-    yd = ops.gru_sequence(steps, dirs)
-    (yd * gy.to(dev)).sum().backward()
+    yd, fin = ops.gru_sequence(steps, dirs)
+    ((yd * gy.to(dev)).sum() + (fin * gfin.to(dev)).sum()).backward()
     close(yd, y, rtol=1e-5, atol=2e-6)
-    close(yd[steps - 1, :, :hid], hn[0], rtol=1e-5, atol=2e-6)
-    close(yd[0, :, hid:], hn[1], rtol=1e-5, atol=2e-6)
+    close(fin[:, :hid], hn[0], rtol=1e-5, atol=2e-6)
+    close(fin[:, hid:], hn[1], rtol=1e-5, atol=2e-6)
     close(xd.grad, x.grad, rtol=1e-4, atol=2e-6)
     close(hd.grad, h0.grad, rtol=1e-4, atol=2e-6)
     for k, v in gru.named_parameters():
@@ -656,7 +657,7 @@ def test_gru_sequence_constant_input(dev):
     prm = {k: v.detach().clone().to(dev).requires_grad_(True) for k, v in gru.named_parameters()}
     xd = x1.detach().to(dev).requires_grad_(True)
     gi = ops.dense(xd, prm['weight_ih_l0'], prm['bias_ih_l0'], ops.Link.dense(1, 3 * hid), 0)
-    yd = ops.gru_sequence(steps, [(gi, prm['weight_hh_l0'], prm['bias_hh_l0'], None, False)])
+    yd, _ = ops.gru_sequence(steps, [(gi, prm['weight_hh_l0'], prm['bias_hh_l0'], None, False)])
     (yd * gy.to(dev)).sum().backward()
     close(yd, y, rtol=1e-5, atol=2e-6)
     close(xd.grad, x1.grad, rtol=1e-4, atol=2e-6)
