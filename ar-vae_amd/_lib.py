@@ -86,8 +86,9 @@ SIGNATURES = {
     'arvae_gru_seq_supported': (c_i32, [c_i32]),
     'arvae_gru_seq_fwd': (c_i32, [_P(GruSeqDesc), c_i32, c_i32, c_i32, c_i32, c_vp]),
     'arvae_gru_seq_bwd': (c_i32, [_P(GruSeqDesc), c_i32, c_i32, c_i32, c_i32, c_vp]),
+    'arvae_tick_free_run_ws_floats': (c_i64, [c_i32]),
     'arvae_tick_free_run': (c_i32, [_P(TickWeights), c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_i32, c_i32, c_i32,
-                                    c_vp, c_vp]),
+                                    c_vp, c_vp, c_vp]),
     'arvae_embed_fwd': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     'arvae_embed_bwd_ws_floats': (c_i64, [c_i32, c_i32, c_i32, c_i32]),
     'arvae_embed_bwd': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),

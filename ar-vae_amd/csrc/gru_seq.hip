@@ -700,6 +700,227 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_kernel(TickFreeRun p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The free-running tick decoder on the bf16 MFMA (three-term split, fp32-accurate).  Three terms of the three
+// recurrent matrices do not fit any on-chip store (885 KB), so they are streamed: tick_weight_prep_kernel writes them
+// once per call in the exact per-lane register order (group = (matrix, k-step), 9 x 16 bytes per lane and group, lanes
+// contiguous), and every wave keeps a three-slot ring of groups in registers, always two groups (and across the tick
+// boundary) ahead of the MFMAs.  Per tick a workgroup pulls 885 KB from L2 against 3 x 72 MFMAs of 16 cycles per wave:
+// the kernel is L2-bandwidth bound (the fp32-MFMA version above was bound by its 288 x 32-cycle MFMAs and the exposed
+// latency of its unpipelined weight loads).
+struct TickPrep {
+    const float *w[3];           // w_hh0, w_ih1, w_hh1
+    uint4 *out;
+};
+
+template <int H>
+__global__ __launch_bounds__(256) void tick_weight_prep_kernel(TickPrep p) {
+    constexpr int NW = H / 16, KS = H / 32;
+    const int tid = blockIdx.x * 256 + threadIdx.x;
+    const int lane = tid & 63;
+    int rest = tid >> 6;
+    const int g = rest % 3; rest /= 3;
+    const int w = rest % NW; rest /= NW;
+    const int ks = rest % KS;
+    const int m = rest / KS;
+    if (m >= 3) return;
+    const int col = lane & 15, quad = lane >> 4;
+    const float *src = (m == 0 ? p.w[0] : m == 1 ? p.w[1] : p.w[2]) + (int64_t)(g * H + 16 * w + col) * H + 32 * ks + 8 * quad;
+    const f32x4 v0 = *reinterpret_cast<const f32x4 *>(src), v1 = *reinterpret_cast<const f32x4 *>(src + 4);
+    const float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    bf16x8g hi, mid, lo;
+    split3_x8(x, hi, mid, lo);
+    uint4 *dst = p.out + ((int64_t)((m * KS + ks) * NW + w) * 9 + g * 3) * 64 + lane;
+    dst[0] = __builtin_bit_cast(uint4, hi);
+    dst[64] = __builtin_bit_cast(uint4, mid);
+    dst[128] = __builtin_bit_cast(uint4, lo);
+}
+
+template <int H, bool MASKED>
+__global__ __launch_bounds__(H * 4) void tick_free_run_x3_kernel(TickFreeRun p, const uint4 *__restrict__ packed) {
+    constexpr int NW = H / 16, KS = H / 32, KQ = H / 16;
+    constexpr int NGG = 9 * KS;                    // weight groups per tick: (matrix, k-step, gate), 3 x 16 bytes per lane each
+    constexpr int RS = NGG % 6 == 0 ? 6 : 3;       // register ring of groups; RS - 1 groups are in flight
+    constexpr int PFD = RS - 1;
+    constexpr int HP = H + 8, PLANE = 16 * HP, HS = H + 4;
+    __shared__ __attribute__((aligned(16))) unsigned short hA0[2][3 * PLANE];
+    __shared__ __attribute__((aligned(16))) unsigned short hA1[2][3 * PLANE];
+    __shared__ __attribute__((aligned(16))) unsigned short midp[3 * PLANE];
+    __shared__ __attribute__((aligned(16))) float h1f[16][HS];
+    __shared__ __attribute__((aligned(16))) float wout_s[64][HS];
+    __shared__ float cand_v[4][16];
+    __shared__ int cand_i[4][16];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = lane & 15, quad = lane >> 4;
+    const int unit = 16 * w + col;
+    const int row0 = blockIdx.x * 16;
+    const int B = p.batch;
+    const int ntile = (p.vocab + 15) / 16;
+
+    // weight stream: one buffer resource, one per-lane byte offset, the group's offset as the scalar offset of each
+    // load -- per-load 64-bit addresses would be hoisted out of the tick loop into 200+ VGPRs
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(packed), 0, 3 * KS * NW * 9 * 64 * 16, 0x00020000);
+    const int wlane = (w * 9 * 64 + lane) * 16;
+    bf16x8g wb[RS][3];
+    auto fetch = [&](int gg) {                     // gg = (matrix * KS + ks) * 3 + gate, compile-time at every call site
+        const int g = gg / 3, gate = gg % 3;
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+            wb[gg % RS][term] = __builtin_bit_cast(bf16x8g, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlane, (g * NW * 9 + gate * 3 + term) * 64 * 16, 0));
+    };
+#pragma unroll
+    for (int d = 0; d < PFD; ++d) fetch(d % NGG);
+
+    for (int e = threadIdx.x; e < 64 * H; e += H * 4) {       // note projection weights -> LDS (rows >= vocab: zeros)
+        const int n = e / H, k = e - n * H;
+        wout_s[n][k] = n < p.vocab ? p.w_out[(int64_t)n * H + k] : 0.f;
+    }
+    const float b0r = p.b_hh0[unit], b0z = p.b_hh0[H + unit], b0n = p.b_hh0[2 * H + unit];
+    const float b1r = p.b_ih1[unit] + p.b_hh1[unit], b1z = p.b_ih1[H + unit] + p.b_hh1[H + unit];
+    const float b1in = p.b_ih1[2 * H + unit], b1hn = p.b_hh1[2 * H + unit];
+    const int note = 16 * w + col;
+    const bool note_ok = w < ntile && note < p.vocab;
+    const float bout = note_ok ? p.b_out[note] : 0.f;
+
+    int rows[4];
+    bool live[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = row0 + 4 * quad + i;
+        live[i] = r < B;
+        rows[i] = live[i] ? r : B - 1;
+    }
+    float h0[4], h1[4], gb[4][3];
+    int tok[4] = {p.vocab, p.vocab, p.vocab, p.vocab};
+    const int ticks = p.beats * p.tpb;
+    const int aoff = col * HP + 8 * quad;                     // this lane's A-operand offset inside a plane
+
+    for (int t = 0; t < ticks; ++t) {
+        const int cur = t & 1;
+        const int beat = t / p.tpb;
+        if (t % p.tpb == 0) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t br = (int64_t)beat * B + rows[i];
+                h0[i] = p.h0_l0[br * H + unit];
+                h1[i] = p.h0_l1[br * H + unit];
+                store_split3(&hA0[cur][(4 * quad + i) * HP + unit], PLANE, h0[i]);
+                store_split3(&hA1[cur][(4 * quad + i) * HP + unit], PLANE, h1[i]);
+                const float *g = p.gib + br * 3 * H + unit;
+                gb[i][0] = g[0]; gb[i][1] = g[H]; gb[i][2] = g[2 * H];
+            }
+            __syncthreads();
+        }
+        float gi[4][3], keep[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float *pt = p.ptab + (int64_t)tok[i] * 3 * H + unit;
+            gi[i][0] = gb[i][0] + pt[0]; gi[i][1] = gb[i][1] + pt[H]; gi[i][2] = gb[i][2] + pt[2 * H];
+            keep[i] = MASKED ? p.keep_scale * (float)p.mask[((int64_t)t * B + rows[i]) * H + unit] : 1.f;
+        }
+        // ---- layer 0: matrix 0
+        {
+            f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            const unsigned short *ab = &hA0[cur][aoff];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8g ah = lds_x8(ab + 32 * ks), am = lds_x8(ab + PLANE + 32 * ks), al = lds_x8(ab + 2 * PLANE + 32 * ks);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int gg = (0 * KS + ks) * 3 + q;
+                    fetch((gg + PFD) % NGG);
+                    __builtin_amdgcn_sched_barrier(0);
+                    GRU_MFMA6(acc[q], ah, am, al, wb[gg % RS][0], wb[gg % RS][1], wb[gg % RS][2]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float r = fast_sigmoid(gi[i][0] + acc[0][i] + b0r);
+                const float z = fast_sigmoid(gi[i][1] + acc[1][i] + b0z);
+                const float n = fast_tanh(gi[i][2] + r * (acc[2][i] + b0n));
+                h0[i] = (1.f - z) * n + z * h0[i];
+                store_split3(&hA0[cur ^ 1][(4 * quad + i) * HP + unit], PLANE, h0[i]);
+                store_split3(&midp[(4 * quad + i) * HP + unit], PLANE, h0[i] * keep[i]);
+            }
+        }
+        __syncthreads();
+        // ---- layer 1: matrix 1 (W_ih1 on mid), matrix 2 (W_hh1 on h1); r and z share an accumulator
+        {
+            f32x4 a1[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // r, z, i_n, h_n
+#pragma unroll
+            for (int m = 1; m <= 2; ++m) {
+                const unsigned short *ab = m == 1 ? &midp[aoff] : &hA1[cur][aoff];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8g ah = lds_x8(ab + 32 * ks), am = lds_x8(ab + PLANE + 32 * ks), al = lds_x8(ab + 2 * PLANE + 32 * ks);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const int gg = (m * KS + ks) * 3 + q;
+                        fetch((gg + PFD) % NGG);
+                        __builtin_amdgcn_sched_barrier(0);
+                        GRU_MFMA6(a1[q == 2 ? m + 1 : q], ah, am, al, wb[gg % RS][0], wb[gg % RS][1], wb[gg % RS][2]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float r = fast_sigmoid(a1[0][i] + b1r);
+                const float z = fast_sigmoid(a1[1][i] + b1z);
+                const float n = fast_tanh(a1[2][i] + b1in + r * (a1[3][i] + b1hn));
+                h1[i] = (1.f - z) * n + z * h1[i];
+                store_split3(&hA1[cur ^ 1][(4 * quad + i) * HP + unit], PLANE, h1[i]);
+                h1f[4 * quad + i][unit] = h1[i];
+            }
+        }
+        __syncthreads();
+        // ---- logits (fp32 MFMA, weights in LDS) + row argmax
+        if (w < ntile) {
+            f32x4 lg = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kq = 0; kq < KQ; ++kq) {
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(&h1f[col][16 * kq + 4 * quad]);
+                const f32x4 b = *reinterpret_cast<const f32x4 *>(&wout_s[note][16 * kq + 4 * quad]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) lg = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], lg, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = note_ok ? fmaxf(lg[i] + bout, 0.f) : -1.f;
+                int ix = note;
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) {
+                    const float ov = __shfl_xor(v, off, 64);
+                    const int oi = __shfl_xor(ix, off, 64);
+                    const bool take = ov > v || (ov == v && oi < ix);
+                    v = take ? ov : v;
+                    ix = take ? oi : ix;
+                }
+                if (col == 0) { cand_v[w][4 * quad + i] = v; cand_i[w][4 * quad + i] = ix; }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 4 * quad + i;
+            float v = cand_v[0][r];
+            int ix = cand_i[0][r];
+            for (int c = 1; c < ntile; ++c) {
+                const float ov = cand_v[c][r];
+                const int oi = cand_i[c][r];
+                const bool take = ov > v;                      // later tiles hold larger indices: ties keep the earlier
+                v = take ? ov : v;
+                ix = take ? oi : ix;
+            }
+            tok[i] = ix;
+            if (w == 0 && col == 0 && live[i]) p.tokens[(int64_t)rows[i] * ticks + t] = ix;
+        }
+    }
+}
+
 }  // namespace arvae
 
 using namespace arvae;
@@ -760,9 +981,14 @@ extern "C" int arvae_gru_seq_bwd(const arvae_gru_seq_t *seqs, int32_t nseq, int3
     return check_launch("gru_seq_bwd_kernel");
 }
 
+extern "C" int64_t arvae_tick_free_run_ws_floats(int32_t hidden) {
+    // three matrices [3H][H] as three bf16 terms each (tick_weight_prep_kernel)
+    return arvae_gru_seq_supported(hidden) ? (int64_t)3 * 3 * hidden * hidden * 3 / 2 : 0;
+}
+
 extern "C" int arvae_tick_free_run(const arvae_tick_weights_t *wts, const float *h0_l0, const float *h0_l1, const float *gib,
                                    const float *ptab, const uint8_t *mask, float keep_scale, int32_t batch, int32_t beats,
-                                   int32_t ticks_per_beat, int32_t hidden, int32_t vocab, int64_t *tokens,
+                                   int32_t ticks_per_beat, int32_t hidden, int32_t vocab, int64_t *tokens, float *ws,
                                    arvae_stream_t stream) {
     ARVAE_REQUIRE(wts && h0_l0 && h0_l1 && gib && ptab && tokens, "tick_free_run: null pointer");
     ARVAE_REQUIRE(wts->w_hh0 && wts->b_hh0 && wts->w_ih1 && wts->b_ih1 && wts->w_hh1 && wts->b_hh1 && wts->w_out && wts->b_out,
@@ -777,13 +1003,33 @@ extern "C" int arvae_tick_free_run(const arvae_tick_weights_t *wts, const float 
     p.batch = batch; p.beats = beats; p.tpb = ticks_per_beat; p.vocab = vocab; p.tokens = tokens;
     hipStream_t st = as_stream(stream);
     const dim3 grid((batch + 15) / 16);
-    prof_gap();
     const bool m = mask != nullptr;
-    if (hidden == 128 && m) hipLaunchKernelGGL((tick_free_run_kernel<128, 2, true>), grid, dim3(512), 0, st, p);
-    else if (hidden == 128) hipLaunchKernelGGL((tick_free_run_kernel<128, 2, false>), grid, dim3(512), 0, st, p);
-    else if (hidden == 64 && m) hipLaunchKernelGGL((tick_free_run_kernel<64, 2, true>), grid, dim3(256), 0, st, p);
-    else if (hidden == 64) hipLaunchKernelGGL((tick_free_run_kernel<64, 2, false>), grid, dim3(256), 0, st, p);
-    else if (m) hipLaunchKernelGGL((tick_free_run_kernel<32, 2, true>), grid, dim3(128), 0, st, p);
-    else hipLaunchKernelGGL((tick_free_run_kernel<32, 2, false>), grid, dim3(128), 0, st, p);
-    return check_launch("tick_free_run_kernel");
+    prof_gap();
+    if (gru_fp32_mfma() || ws == nullptr) {
+        if (hidden == 128 && m) hipLaunchKernelGGL((tick_free_run_kernel<128, 2, true>), grid, dim3(512), 0, st, p);
+        else if (hidden == 128) hipLaunchKernelGGL((tick_free_run_kernel<128, 2, false>), grid, dim3(512), 0, st, p);
+        else if (hidden == 64 && m) hipLaunchKernelGGL((tick_free_run_kernel<64, 2, true>), grid, dim3(256), 0, st, p);
+        else if (hidden == 64) hipLaunchKernelGGL((tick_free_run_kernel<64, 2, false>), grid, dim3(256), 0, st, p);
+        else if (m) hipLaunchKernelGGL((tick_free_run_kernel<32, 2, true>), grid, dim3(128), 0, st, p);
+        else hipLaunchKernelGGL((tick_free_run_kernel<32, 2, false>), grid, dim3(128), 0, st, p);
+        return check_launch("tick_free_run_kernel");
+    }
+    ARVAE_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0, "tick_free_run: workspace must be 16-byte aligned");
+    TickPrep tp{{wts->w_hh0, wts->w_ih1, wts->w_hh1}, reinterpret_cast<uint4 *>(ws)};
+    const int items = 3 * (hidden / 32) * (hidden / 16) * 3 * 64;
+    const uint4 *packed = reinterpret_cast<const uint4 *>(ws);
+    if (hidden == 128) {
+        hipLaunchKernelGGL(tick_weight_prep_kernel<128>, dim3((items + 255) / 256), dim3(256), 0, st, tp);
+        if (m) hipLaunchKernelGGL((tick_free_run_x3_kernel<128, true>), grid, dim3(512), 0, st, p, packed);
+        else hipLaunchKernelGGL((tick_free_run_x3_kernel<128, false>), grid, dim3(512), 0, st, p, packed);
+    } else if (hidden == 64) {
+        hipLaunchKernelGGL(tick_weight_prep_kernel<64>, dim3((items + 255) / 256), dim3(256), 0, st, tp);
+        if (m) hipLaunchKernelGGL((tick_free_run_x3_kernel<64, true>), grid, dim3(256), 0, st, p, packed);
+        else hipLaunchKernelGGL((tick_free_run_x3_kernel<64, false>), grid, dim3(256), 0, st, p, packed);
+    } else {
+        hipLaunchKernelGGL(tick_weight_prep_kernel<32>, dim3((items + 255) / 256), dim3(256), 0, st, tp);
+        if (m) hipLaunchKernelGGL((tick_free_run_x3_kernel<32, true>), grid, dim3(128), 0, st, p, packed);
+        else hipLaunchKernelGGL((tick_free_run_x3_kernel<32, false>), grid, dim3(128), 0, st, p, packed);
+    }
+    return check_launch("tick_free_run_x3_kernel");
 }

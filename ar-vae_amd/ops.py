@@ -638,10 +638,11 @@ def tick_free_run(weights, h0_l0, h0_l1, gib, ptab, mask, keep_scale, batch, bea
     hid, vocab = weights[0].shape[1], weights[6].shape[0]
     tw = _lib.TickWeights(*[_ptr(t) for t in weights])
     tokens = torch.empty(batch, beats * ticks_per_beat, device=gib.device, dtype=torch.int64)
+    ws = torch.empty(lib.arvae_tick_free_run_ws_floats(hid), device=gib.device, dtype=torch.float32)
     with _timed('tick_free_run', 2.0 * batch * beats * ticks_per_beat * (9 * hid * hid + vocab * hid), 0.0):
         _lib.check(lib.arvae_tick_free_run(ctypes.byref(tw), _ptr(h0_l0), _ptr(h0_l1), _ptr(gib), _ptr(ptab), _ptr(mask),
                                            float(keep_scale), batch, beats, ticks_per_beat, hid, vocab, _ptr(tokens),
-                                           _stream()), 'tick_free_run')
+                                           _ptr(ws), _stream()), 'tick_free_run')
     return tokens
 
 

@@ -244,15 +244,18 @@ int arvae_gru_seq_bwd(const arvae_gru_seq_t *seqs, int32_t nseq, int32_t steps, 
  * [batch][beats*ticks_per_beat]; the caller evaluates the differentiable graph on them with arvae_gru_seq_*.
  * The layer-0 input projection arrives pre-multiplied: gib [beats*batch][3*hidden] = W_ih0[:, E:] beat_emb + b_ih0 and
  * ptab [vocab+1][3*hidden] = W_ih0[:, :E] applied to the embedding table, row `vocab` = the learned start vector x_0.
- * mask: optional keep-mask [beats*ticks_per_beat][batch][hidden] of nn.GRU's inter-layer dropout, scaled by keep_scale. */
+ * mask: optional keep-mask [beats*ticks_per_beat][batch][hidden] of nn.GRU's inter-layer dropout, scaled by keep_scale.
+ * ws: arvae_tick_free_run_ws_floats(hidden) floats, 16-byte aligned (the recurrent weights re-laid out for streaming). */
 typedef struct arvae_tick_weights {
     const float *w_hh0, *b_hh0;     /* rnn_tick layer 0 recurrent weights */
     const float *w_ih1, *b_ih1, *w_hh1, *b_hh1;   /* layer 1 */
     const float *w_out, *b_out;     /* tick_emb_to_note_emb [vocab][hidden] */
 } arvae_tick_weights_t;
+int64_t arvae_tick_free_run_ws_floats(int32_t hidden);
 int arvae_tick_free_run(const arvae_tick_weights_t *weights, const float *h0_l0, const float *h0_l1, const float *gib,
                         const float *ptab, const uint8_t *mask, float keep_scale, int32_t batch, int32_t beats,
-                        int32_t ticks_per_beat, int32_t hidden, int32_t vocab, int64_t *tokens, arvae_stream_t stream);
+                        int32_t ticks_per_beat, int32_t hidden, int32_t vocab, int64_t *tokens, float *ws,
+                        arvae_stream_t stream);
 
 /* nn.Embedding (measurevae/encoder.py:36-37,111; decoder.py:18,516): out row (b,t) = table[idx[b][t]];
  * time_major: rows ordered (t, b) instead of (b, t).  embed_bwd ACCUMULATES dtable (fixed summation order) and needs
