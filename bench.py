@@ -146,6 +146,50 @@ def build_trainer(device, world):
     return trainer, state
 
 
+# algorithmic FLOP and layer-boundary bytes per image / measure and training step
+SIDE_WORK = {'mnist': (431466496.0, 3276816.0), 'measure': (93.7e6, 0.7e6)}
+
+
+def side_cpu_baseline(kind, batch, budget_s=20.0):
+    """the CPU oracle's training step on the secondary workloads, bounded to ~budget_s of CPU work."""
+    from arvae_amd import synthetic as syn
+    from oracle import step as o_step
+    cores = torch.get_num_threads()
+    if kind == 'mnist':
+        from arvae_amd.image_vae import MnistVAE
+        state = syn.synth_state({k: tuple(v.shape) for k, v in MnistVAE().state_dict().items()}, seed=3, gain=0.7)
+        x, lab = syn.mnist_batch(batch, seed=4321)
+        eps = syn.normal_noise((batch, 16), seed=1)
+        run = lambda cur, adam, n: o_step.image_step('mnist', cur, x, lab, eps, (1, 2, 3, 4, 5, 6), 1.0, 10.0, 1.0,
+                                                     adam_state=adam, step_no=n)
+        unit, what = 'images/s', 'Morpho-MNIST AR-VAE'
+    else:
+        from oracle import attributes as o_attr
+        from oracle import measure_vae as o_mvae
+        state = syn.synth_state(o_mvae.shapes(), 4)
+        score = syn.measure_batch(batch, seed=5)
+        eps = syn.normal_noise((batch, 32), seed=1)
+        attr = o_attr.attribute_labels(score, *syn.measure_tables())
+        run = lambda cur, adam, n: o_step.measure_step(cur, score, eps, attr, (0, 1, 2, 3), 0.001, 1.0, 10.0, n % 2 == 0,
+                                                       adam_state=adam, step_no=n)
+        unit, what = 'measures/s', 'MeasureVAE (teacher forcing on alternate steps)'
+    cur, adam, times, n = state, None, [], 0
+    t_start = time.perf_counter()
+    while True:
+        t0 = time.perf_counter()
+        res = run(cur, adam, n + 1)
+        cur, adam = res['params'], res['adam']
+        times.append(time.perf_counter() - t0)
+        n += 1
+        if n >= 3 and (time.perf_counter() - t_start > budget_s or n >= 40):
+            break
+    steady = sorted(times[1:])
+    med = steady[len(steady) // 2]
+    return {'value': batch / med, 'unit': unit, 'cores': cores, 'kind': 'port',
+            'sample': f'{n} full training steps (first discarded) of the {what} at batch {batch}, fp32, PyTorch-CPU oracle, '
+                      f'{cores} threads, median step {med * 1e3:.1f} ms'}
+
+
 def cpu_baseline(batch, state, budget_s=20.0):
     """CPU oracle on the same workload, bounded to ~budget_s of CPU work."""
     from arvae_amd import synthetic as syn
@@ -220,12 +264,22 @@ def main():
             loss = side_step(i)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        print(json.dumps({'metric': f'training {unit} ({args.workload} AR-VAE, batch {bsz}) -- secondary workload',
-                          'value': bsz * args.steps / dt, 'unit': unit, 'n_gpus': 1, 'steps': args.steps,
-                          'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
-                          'dtype': 'f32', 'data': 'synthetic', 'final_loss': float(loss.detach()),
-                          'config': {'workload': args.workload, 'batch': bsz,
-                                     'launch': 'hip-graph replay of fwd+bwd' if args.workload == 'measure' and not args.no_graphs else 'eager'}}))
+        rate = bsz * args.steps / dt
+        flop, byts = SIDE_WORK[args.workload]
+        line = {'metric': f'training {unit} ({args.workload} AR-VAE, batch {bsz}) -- secondary workload',
+                'value': rate, 'unit': unit, 'n_gpus': 1, 'steps': args.steps,
+                'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
+                'dtype': 'f32' if args.workload == 'mnist' else 'f32 (GRU MFMAs: 3-term bf16 split, fp32-accurate)',
+                'data': 'synthetic', 'final_loss': float(loss.detach()),
+                'config': {'workload': args.workload, 'batch': bsz,
+                           'launch': 'hip-graph replay of fwd+bwd' if args.workload == 'measure' and not args.no_graphs else 'eager'},
+                # whole-step fractions of the datasheet roofs (SURVEY 8(d) algorithmic FLOP / layer-boundary bytes per unit)
+                'step_roofline': {'flop_per_unit': flop, 'bytes_per_unit': byts,
+                                  'flop_frac_fp32': rate * flop / (PEAK_F32_MFMA_TFLOPS * 1e12),
+                                  'hbm_frac': rate * byts / (PEAK_HBM_GBS * 1e9)}}
+        if not args.no_cpu_baseline:
+            line['cpu_baseline'] = side_cpu_baseline(args.workload, bsz)
+        print(json.dumps(line))
         return
 
     trainer, state = build_trainer(device, 2 if use_dp else 1)
