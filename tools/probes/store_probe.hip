@@ -1,0 +1,49 @@
+// Store-pattern probe: 67 MB written either as contiguous 1 KB per wave instruction or as 32-byte pieces at a 128-byte
+// stride (the epilogue pattern of the transposed-MFMA conv kernels: 4 instructions fill a pixel's 128-byte line).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+__global__ __launch_bounds__(256) void st_contig(float4 *out, int64_t n16) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256)
+        out[i] = make_float4(1.f, 2.f, 3.f, (float)i);
+}
+// lane (px = lane&31, half = lane>>5), 4 instructions g: address = pixel*128 + 32 g + 16 half
+__global__ __launch_bounds__(256) void st_piece(float4 *out, int64_t npix) {
+    const int lane = threadIdx.x & 63, half = lane >> 5, rc = lane & 31;
+    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * 256) >> 6;
+    for (int64_t p0 = wave * 32; p0 < npix; p0 += nw * 32) {
+        const int64_t pix = p0 + rc;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) out[pix * 8 + 2 * g + half] = make_float4(1.f, 2.f, 3.f, (float)g);
+    }
+}
+// same bytes per lane, but a pixel's line is written by one instruction of 8 lanes: lane l -> pixel 8*i + l/8, piece l%8
+__global__ __launch_bounds__(256) void st_line(float4 *out, int64_t npix) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * 256) >> 6;
+    for (int64_t p0 = wave * 32; p0 < npix; p0 += nw * 32) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) out[(p0 + 8 * g + (lane >> 3)) * 8 + (lane & 7)] = make_float4(1.f, 2.f, 3.f, (float)g);
+    }
+}
+int main() {
+    const int64_t bytes = 67108864, n16 = bytes / 16, npix = bytes / 128;
+    float4 *buf; hipMalloc(&buf, bytes);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int grid : {256, 512, 1024, 2048, 4096}) {
+        for (int k = 0; k < 3; ++k) {
+            float best = 1e9f;
+            for (int rep = 0; rep < 6; ++rep) {
+                hipEventRecord(e0);
+                if (k == 0) hipLaunchKernelGGL(st_contig, dim3(grid), dim3(256), 0, 0, buf, n16);
+                else if (k == 1) hipLaunchKernelGGL(st_piece, dim3(grid), dim3(256), 0, 0, buf, npix);
+                else hipLaunchKernelGGL(st_line, dim3(grid), dim3(256), 0, 0, buf, npix);
+                hipEventRecord(e1); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                if (rep > 0 && ms < best) best = ms;
+            }
+            printf("grid %5d %-8s %7.1f us  %5.2f TB/s\n", grid, k == 0 ? "contig" : k == 1 ? "piece" : "line", best * 1e3, bytes / best / 1e9);
+        }
+    }
+    return 0;
+}
