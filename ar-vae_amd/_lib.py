@@ -55,6 +55,12 @@ class TickWeights(ctypes.Structure):
     _fields_ = [(n, c_vp) for n in ('w_hh0', 'b_hh0', 'w_ih1', 'b_ih1', 'w_hh1', 'b_hh1', 'w_out', 'b_out')]
 
 
+class DenseWgradJob(ctypes.Structure):
+    """arvae_dense_wgrad_job_t"""
+    _fields_ = [('g', OperandDesc), ('x', c_vp), ('dw', c_vp), ('dbias', c_vp), ('rows', c_i32), ('n_in', c_i32),
+                ('n_out', c_i32), ('reserved', c_i32)]
+
+
 _P = ctypes.POINTER
 # name -> (restype, argtypes); must list every symbol declared in include/arvae_hip.h
 SIGNATURES = {
@@ -69,6 +75,7 @@ SIGNATURES = {
     'arvae_link_wgrad': (c_i32, [_P(LinkDesc), _P(OperandDesc), _P(OperandDesc), c_vp, c_vp, c_i32, c_vp, c_vp]),
     'arvae_channel_sum_ws_floats': (c_i64, [c_i64, c_i32]),
     'arvae_channel_sum': (c_i32, [_P(OperandDesc), c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    'arvae_dense_wgrad_batch': (c_i32, [_P(DenseWgradJob), c_i32, c_vp]),
     'arvae_operand_apply': (c_i32, [_P(OperandDesc), c_i64, c_vp, c_vp]),
     'arvae_latent_fwd': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
     'arvae_latent_bwd': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),

@@ -26,7 +26,7 @@ struct DenseArgs {
 constexpr int DENSE_SPLIT_ROWS = 128;        // rows per workgroup slice of the row-split weight gradient
 constexpr int DENSE_SPLIT_MIN_ROWS = 2048;   // shorter reduction axes stay on the one-workgroup-per-tile kernel
 
-constexpr int DENSE_BATCH_MAX = 8;
+constexpr int DENSE_BATCH_MAX = 16;
 struct DenseWgradBatch {
     int count;
     int tile_end[DENSE_BATCH_MAX];      // running number of 32x32 tiles after job j

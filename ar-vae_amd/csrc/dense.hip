@@ -520,3 +520,24 @@ int dense_wgrad_flush(DenseWgradBatch *b, hipStream_t s) {
 }
 
 }  // namespace arvae
+
+// Several Linear weight gradients in one launch for callers outside the whole-model executor (the MeasureVAE's autograd
+// graph queues its batch-sized ones and flushes them at the end of the backward pass).
+extern "C" int arvae_dense_wgrad_batch(const arvae_dense_wgrad_job_t *jobs, int32_t njobs, arvae_stream_t stream) {
+    using namespace arvae;
+    ARVAE_REQUIRE(jobs != nullptr && njobs >= 1, "dense_wgrad_batch: no jobs");
+    hipStream_t st = as_stream(stream);
+    DenseWgradBatch b{};
+    for (int j = 0; j < njobs; ++j) {
+        const arvae_dense_wgrad_job_t &q = jobs[j];
+        ARVAE_REQUIRE(q.g.v && q.x && q.dw && q.rows > 0 && q.n_in > 0 && q.n_out > 0, "dense_wgrad_batch: bad job %d", j);
+        arvae_link_t l{};
+        l.n = q.rows; l.hh = l.hw = l.lh = l.lw = l.kh = l.kw = 1; l.stride = 1; l.chi = q.n_in; l.clo = q.n_out;
+        if (!dense_wgrad_defer(&b, &l, make_operand(&q.g), q.x, q.dw, q.dbias)) {
+            if (int rc = dense_wgrad_flush(&b, st)) return rc;
+            dense_wgrad_defer(&b, &l, make_operand(&q.g), q.x, q.dw, q.dbias);
+        }
+    }
+    return dense_wgrad_flush(&b, st);
+}
+

@@ -190,6 +190,45 @@ def _plain_gradient(g, y, mask, act, link, n):
     return _operand(g, y, mask, act), g
 
 
+# ------------------------------------------------------------------------------------------------
+# batch-sized Linear weight gradients of one backward pass, launched together when the pass ends
+# ------------------------------------------------------------------------------------------------
+_WGRAD_QUEUE = []
+DEFER_DENSE_WGRADS = True
+
+
+def _flush_dense_wgrads():
+    """one launch for every queued Linear weight gradient (csrc/dense.hip dense_wgrad_batch_kernel)."""
+    global _WGRAD_QUEUE
+    if not _WGRAD_QUEUE:
+        return
+    queue, _WGRAD_QUEUE = _WGRAD_QUEUE, []
+    lib = _lib.load()
+    jobs = (_lib.DenseWgradJob * len(queue))()
+    for j, (gop, x, dw, db, rows, n_in, n_out, _keep) in zip(jobs, queue):
+        j.g, j.x, j.dw, j.dbias = gop, _ptr(x), _ptr(dw), _ptr(db)
+        j.rows, j.n_in, j.n_out = rows, n_in, n_out
+    with _timed('dense_wgrad_batch', 0.0, 0.0):
+        _lib.check(lib.arvae_dense_wgrad_batch(jobs, len(queue), _stream()), 'dense_wgrad_batch')
+
+
+def _defer_dense_wgrad(link, n, gop, keep, x, dw, db):
+    """queue dw += g^T x (db += colsum g) until the running backward pass ends; False if it cannot be queued."""
+    if not DEFER_DENSE_WGRADS or n >= LONG_BATCH_ROWS or link.hi_perm[0] or link.lo_perm[0]:
+        return False
+    if not (link.hh == link.hw == link.lh == link.lw == link.kh == link.kw == 1):
+        return False
+    if any(q[2].data_ptr() == dw.data_ptr() for q in _WGRAD_QUEUE):
+        return False          # two jobs of one launch must not add into the same tensor (a weight used at several steps)
+    if not _WGRAD_QUEUE:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_flush_dense_wgrads)
+        except RuntimeError:                                  # not inside a backward pass
+            return False
+    _WGRAD_QUEUE.append((gop, x, dw, db, n, link.chi, link.clo, keep))
+    return True
+
+
 def _grad_target(param):
     """Where a parameter gradient is accumulated.  When the parameter already owns a `.grad` buffer (the
     trainer's flat gradient arena after zero_grad()), the kernels add straight into it and autograd gets
@@ -231,7 +270,10 @@ class _LinkDownFn(Function):
         if ctx.needs_input_grad[1]:
             buf, direct = _grad_target(ctx.wt_ref)
             bbuf, bdirect = _grad_target(ctx.bias_ref) if want_bias else (None, True)
-            link_wgrad(link, n, gop, _operand(hi), buf, bbuf, 1)
+            # queued launches add into the parameters' own .grad buffers; a gradient handed back through autograd
+            # must be complete when backward() returns it, so those go out immediately
+            if not (direct and bdirect and _defer_dense_wgrad(link, n, gop, (g_lo, _keep, lo, mask, hi), hi, buf, bbuf)):
+                link_wgrad(link, n, gop, _operand(hi), buf, bbuf, 1)
             d_wt = None if direct else buf
             d_bias = None if bdirect else bbuf
         elif want_bias:

@@ -119,6 +119,17 @@ int64_t arvae_channel_sum_ws_floats(int64_t rows, int32_t channels);
 int arvae_channel_sum(const arvae_operand_t *g, int64_t rows, int32_t channels, int32_t perm_c,
                       int32_t perm_hw, float *out, float *ws, arvae_stream_t stream);
 
+/* Weight (and bias) gradients of several nn.Linear layers in one launch: dw[n_out][n_in] += g^T x, dbias += column sums
+ * of g (NULL: skip), g = the layer's output gradient as an operand (activation derivative / keep-mask folded in). */
+typedef struct arvae_dense_wgrad_job {
+    arvae_operand_t g;        /* [rows][n_out] */
+    const float *x;           /* [rows][n_in] layer input */
+    float *dw;                /* accumulated */
+    float *dbias;             /* accumulated, or NULL */
+    int32_t rows, n_in, n_out, reserved;
+} arvae_dense_wgrad_job_t;
+int arvae_dense_wgrad_batch(const arvae_dense_wgrad_job_t *jobs, int32_t njobs, arvae_stream_t stream);
+
 /* out[i] = value of the operand with act'(y) and the keep-mask folded in: a plain copy of a gradient operand. */
 int arvae_operand_apply(const arvae_operand_t *g, int64_t count, float *out, arvae_stream_t stream);
 
