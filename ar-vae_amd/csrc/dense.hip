@@ -162,6 +162,24 @@ struct RowsGemm {
     int want_bias;              // SLICE: also write sum_r A(p, r)
 };
 
+// fp32 pair -> three bf16 terms each (hi + mid + lo exact to 2^-26), packed (first value in the low half)
+typedef __bf16 rg_bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 rg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float rg_f32x2 __attribute__((ext_vector_type(2)));
+typedef int rg_i32x4 __attribute__((ext_vector_type(4)));
+constexpr int RG_XP = RG_R + 8;              // bf16 row pitch of the split planes (16 bytes of padding)
+__device__ __forceinline__ void rg_split3(float x0, float x1, unsigned &hi, unsigned &mid, unsigned &lo) {
+    const rg_f32x2 x = {x0, x1};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(x, rg_bf16x2));
+    const rg_f32x2 r = {x0 - __builtin_bit_cast(float, hi << 16), x1 - __builtin_bit_cast(float, hi & 0xffff0000u)};
+    mid = __builtin_bit_cast(unsigned, __builtin_convertvector(r, rg_bf16x2));
+    const rg_f32x2 q = {r.x - __builtin_bit_cast(float, mid << 16), r.y - __builtin_bit_cast(float, mid & 0xffff0000u)};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(q, rg_bf16x2));
+}
+__device__ __forceinline__ rg_bf16x8 rg_lds_x8(const unsigned short *p) {
+    return __builtin_bit_cast(rg_bf16x8, *reinterpret_cast<const rg_i32x4 *>(p));
+}
+
 // NV float4 (or 4 scalar) loads per thread for a TP x RG_R tile.  Every load is unconditional (clamped address, value
 // selected afterwards) so that the whole batch is in flight at once; VEC = 16-byte loads (leading dimension, extents
 // and base all multiples of 4 floats), otherwise dword loads.
@@ -210,6 +228,33 @@ struct TileLoader {
             }
         }
     }
+    // three bf16 planes [TP][RG_XP] (reduction index contiguous: the 32x32x16 MFMA operand is 8 consecutive r per lane)
+    __device__ __forceinline__ void commit3(unsigned short *lds) const {
+        constexpr int PLANE = TP * RG_XP;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = threadIdx.x + 256 * i;
+            unsigned h0, m0, l0, h1, m1, l1;
+            rg_split3(v[i].x, v[i].y, h0, m0, l0);
+            rg_split3(v[i].z, v[i].w, h1, m1, l1);
+            if (LAY == RG_ROWSK) {
+                const int p = idx / (RG_R / 4), r = 4 * (idx % (RG_R / 4));
+                unsigned short *d = lds + p * RG_XP + r;
+                *reinterpret_cast<uint2 *>(d) = uint2{h0, h1};
+                *reinterpret_cast<uint2 *>(d + PLANE) = uint2{m0, m1};
+                *reinterpret_cast<uint2 *>(d + 2 * PLANE) = uint2{l0, l1};
+            } else {
+                const int r = idx / (TP / 4), p = 4 * (idx % (TP / 4));
+                unsigned short *d = lds + p * RG_XP + r;
+                d[0] = (unsigned short)h0; d[RG_XP] = (unsigned short)(h0 >> 16);
+                d[2 * RG_XP] = (unsigned short)h1; d[3 * RG_XP] = (unsigned short)(h1 >> 16);
+                d[PLANE] = (unsigned short)m0; d[PLANE + RG_XP] = (unsigned short)(m0 >> 16);
+                d[PLANE + 2 * RG_XP] = (unsigned short)m1; d[PLANE + 3 * RG_XP] = (unsigned short)(m1 >> 16);
+                d[2 * PLANE] = (unsigned short)l0; d[2 * PLANE + RG_XP] = (unsigned short)(l0 >> 16);
+                d[2 * PLANE + 2 * RG_XP] = (unsigned short)l1; d[2 * PLANE + 3 * RG_XP] = (unsigned short)(l1 >> 16);
+            }
+        }
+    }
 };
 
 template <int LA, int LB, int EP, bool VA, bool VB>
@@ -247,6 +292,72 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(RowsGemm g) {
         if (EP == RG_EP_SLICE && g.want_bias && blockIdx.y == 0 && threadIdx.x < RG_TP) {
 #pragma unroll 8
             for (int r = 0; r < RG_R; ++r) bsum += As[r * RG_PA + threadIdx.x];
+        }
+    }
+    float *out = g.out + (EP == RG_EP_SLICE ? blockIdx.z * g.slice_floats : 0);
+    const int q = q0 + 32 * wq + rc;
+    const float bias = (EP == RG_EP_FWD && g.bias != nullptr && q < g.Q) ? g.bias[q] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int p = p0 + 32 * wp + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float v = acc[r];
+        if (EP == RG_EP_FWD) v = act_fwd(v + bias, g.act);
+        if (p < g.P && q < g.Q) out[(int64_t)p * g.ldo + q] = v;
+    }
+    if (EP == RG_EP_SLICE && g.want_bias && blockIdx.y == 0 && threadIdx.x < RG_TP && p0 + (int)threadIdx.x < g.P)
+        out[(int64_t)g.P * g.ldo + p0 + threadIdx.x] = bsum;
+}
+
+// The same product on the bf16 MFMA at fp32 accuracy: operands split into three bf16 terms when they are committed to
+// LDS ([p][r] planes, r contiguous), six partial products per multiply-add on v_mfma_f32_32x32x16_bf16, smallest first
+// (2.7x fewer MFMA cycles than the fp32 32x32x2).  Used for the forward product; ARVAE_ROWS_GEMM_FP32=1 / _X3=1 force
+// one kernel or the other everywhere.
+template <int LA, int LB, int EP, bool VA, bool VB>
+__global__ __launch_bounds__(256) void rows_gemm_x3_kernel(RowsGemm g) {
+    constexpr int PLANE_A = RG_TP * RG_XP, PLANE_B = RG_TQ * RG_XP;
+    __shared__ __attribute__((aligned(16))) unsigned short As[3 * PLANE_A];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[3 * PLANE_B];
+    const int lane = threadIdx.x & 63, half = lane >> 5, rc = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p0 = blockIdx.x * RG_TP, q0 = blockIdx.y * RG_TQ;
+    const int rbeg = blockIdx.z * g.rslice, rend = min(g.Rn, rbeg + g.rslice);
+    TileLoader<LA, RG_TP, VA> la;
+    TileLoader<LB, RG_TQ, VB> lb;
+    const int wp = wave & 1, wq = wave >> 1;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float bsum = 0.f;
+    la.load(g.a, g.lda, p0, g.P, rbeg, rend);
+    lb.load(g.b, g.ldb, q0, g.Q, rbeg, rend);
+    const unsigned short *ap = As + (32 * wp + rc) * RG_XP + 8 * half;
+    const unsigned short *bp = Bs + (32 * wq + rc) * RG_XP + 8 * half;
+    for (int r0 = rbeg; r0 < rend; r0 += RG_R) {
+        __syncthreads();
+        la.commit3(As);
+        lb.commit3(Bs);
+        __syncthreads();
+        if (r0 + RG_R < rend) {
+            la.load(g.a, g.lda, p0, g.P, r0 + RG_R, rend);
+            lb.load(g.b, g.ldb, q0, g.Q, r0 + RG_R, rend);
+        }
+#pragma unroll
+        for (int s = 0; s < RG_R / 16; ++s) {
+            const rg_bf16x8 ah = rg_lds_x8(ap + 16 * s), am = rg_lds_x8(ap + PLANE_A + 16 * s), al = rg_lds_x8(ap + 2 * PLANE_A + 16 * s);
+            const rg_bf16x8 bh = rg_lds_x8(bp + 16 * s), bm = rg_lds_x8(bp + PLANE_B + 16 * s), bl = rg_lds_x8(bp + 2 * PLANE_B + 16 * s);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+        }
+        if (EP == RG_EP_SLICE && g.want_bias && blockIdx.y == 0 && threadIdx.x < RG_TP) {
+            const unsigned short *row = As + threadIdx.x * RG_XP;
+#pragma unroll 8
+            for (int r = 0; r < RG_R; ++r)
+                bsum += (__builtin_bit_cast(float, (unsigned)row[r] << 16) + __builtin_bit_cast(float, (unsigned)row[PLANE_A + r] << 16)) +
+                        __builtin_bit_cast(float, (unsigned)row[2 * PLANE_A + r] << 16);
         }
     }
     float *out = g.out + (EP == RG_EP_SLICE ? blockIdx.z * g.slice_floats : 0);
@@ -410,10 +521,21 @@ static void launch_rows_gemm(const RowsGemm &g, int slices, hipStream_t s) {
     };
     const bool va = vec_ok(g.a, g.lda, LA, g.P), vb = vec_ok(g.b, g.ldb, LB, g.Q);
     const dim3 grid((g.P + RG_TP - 1) / RG_TP, (g.Q + RG_TQ - 1) / RG_TQ, slices);
-    if (va && vb) hipLaunchKernelGGL((rows_gemm_kernel<LA, LB, EP, true, true>), grid, dim3(256), 0, s, g);
-    else if (va) hipLaunchKernelGGL((rows_gemm_kernel<LA, LB, EP, true, false>), grid, dim3(256), 0, s, g);
-    else if (vb) hipLaunchKernelGGL((rows_gemm_kernel<LA, LB, EP, false, true>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((rows_gemm_kernel<LA, LB, EP, false, false>), grid, dim3(256), 0, s, g);
+    // the bf16 three-term kernel pays for "K x rows" operands with a transposing 2-byte-store commit (measured: 28 vs
+    // 16 us for the weight gradient), so only the forward product (both operands "rows x K") runs on it
+    static const bool fp32_mfma = getenv("ARVAE_ROWS_GEMM_FP32") != nullptr;
+    static const bool x3_all = getenv("ARVAE_ROWS_GEMM_X3") != nullptr;
+    if (fp32_mfma || (!x3_all && (LA != RG_ROWSK || LB != RG_ROWSK))) {
+        if (va && vb) hipLaunchKernelGGL((rows_gemm_kernel<LA, LB, EP, true, true>), grid, dim3(256), 0, s, g);
+        else if (va) hipLaunchKernelGGL((rows_gemm_kernel<LA, LB, EP, true, false>), grid, dim3(256), 0, s, g);
+        else if (vb) hipLaunchKernelGGL((rows_gemm_kernel<LA, LB, EP, false, true>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((rows_gemm_kernel<LA, LB, EP, false, false>), grid, dim3(256), 0, s, g);
+        return;
+    }
+    if (va && vb) hipLaunchKernelGGL((rows_gemm_x3_kernel<LA, LB, EP, true, true>), grid, dim3(256), 0, s, g);
+    else if (va) hipLaunchKernelGGL((rows_gemm_x3_kernel<LA, LB, EP, true, false>), grid, dim3(256), 0, s, g);
+    else if (vb) hipLaunchKernelGGL((rows_gemm_x3_kernel<LA, LB, EP, false, true>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((rows_gemm_x3_kernel<LA, LB, EP, false, false>), grid, dim3(256), 0, s, g);
 }
 
 // the operand needs no per-element work (no activation derivative, no keep-mask)

@@ -157,7 +157,7 @@ class Encoder(Model):
         mask = None
         if dropping:
             mask = self._mask_queue.popleft().to(emb.device) if self._mask_queue else \
-                (torch.rand(steps, b, 2 * hid, device=emb.device) >= self.dropout).to(torch.uint8)
+                ops.keep_mask((steps, b, 2 * hid), self.dropout, emb.device)
         if _use_sequence_kernels(hid):
             out0, fin0 = self._layer_sequence(emb.view(steps * b, -1), steps, b, 0)
             mid = out0.view(steps * b, 2 * hid)
@@ -256,8 +256,7 @@ class HierarchicalDecoder(Decoder):
                 masks = tuple(m.to(z.device) for m in self._mask_queue.popleft())
             else:
                 h = self.rnn_hidden_size
-                masks = ((torch.rand(4, b, h, device=z.device) >= self.dropout).to(torch.uint8),
-                         (torch.rand(24, b, h, device=z.device) >= self.dropout).to(torch.uint8))
+                masks = (ops.keep_mask((4, b, h), self.dropout, z.device), ops.keep_mask((24, b, h), self.dropout, z.device))
         if _use_sequence_kernels(self.rnn_hidden_size):
             beat_out = self.beat_rnn_sequence(z, 4, masks[0])
             return self.tick_rnn_sequence(score_tensor, beat_out, 6, teacher_forced, masks[1])

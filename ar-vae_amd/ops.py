@@ -816,6 +816,11 @@ class _ScaleMaskFn(Function):
         return dx, None, None
 
 
+def keep_mask(shape, p, device):
+    """uint8 keep-mask (1 with probability 1 - p) drawn on the device in one kernel (graph-safe Philox generator)."""
+    return torch.empty(shape, dtype=torch.uint8, device=device).bernoulli_(1.0 - p)
+
+
 def dropout_mask(x, mask, p=0.5):
     """y = x * mask / (1 - p) for an explicit uint8 keep-mask (None: identity)."""
     if mask is None:
