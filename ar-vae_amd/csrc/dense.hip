@@ -168,6 +168,7 @@ typedef __bf16 rg_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float rg_f32x2 __attribute__((ext_vector_type(2)));
 typedef int rg_i32x4 __attribute__((ext_vector_type(4)));
 constexpr int RG_XP = RG_R + 8;              // bf16 row pitch of the split planes (16 bytes of padding)
+constexpr int RG_TRP = 96;                   // bf16 row pitch of a "K x rows" image (64 columns + padding: 192 bytes)
 __device__ __forceinline__ void rg_split3(float x0, float x1, unsigned &hi, unsigned &mid, unsigned &lo) {
     const rg_f32x2 x = {x0, x1};
     hi = __builtin_bit_cast(unsigned, __builtin_convertvector(x, rg_bf16x2));
@@ -228,32 +229,43 @@ struct TileLoader {
             }
         }
     }
-    // three bf16 planes [TP][RG_XP] (reduction index contiguous: the 32x32x16 MFMA operand is 8 consecutive r per lane)
+    // three bf16 planes.  "rows x K" operands: [TP][RG_XP], reduction index contiguous (the 32x32x16 MFMA operand is 8
+    // consecutive r per lane: one ds_read_b128).  "K x rows" operands keep their memory order, [RG_R][RG_TRP] with the
+    // output index contiguous (one 8-byte write per plane), and are read through ds_read_b64_tr_b16, the transposing
+    // read; the 192-byte row pitch puts the four rows of a transposed block on disjoint banks.
+    static constexpr int PLANE = LAY == RG_ROWSK ? TP * RG_XP : RG_R * RG_TRP;
     __device__ __forceinline__ void commit3(unsigned short *lds) const {
-        constexpr int PLANE = TP * RG_XP;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int idx = threadIdx.x + 256 * i;
             unsigned h0, m0, l0, h1, m1, l1;
             rg_split3(v[i].x, v[i].y, h0, m0, l0);
             rg_split3(v[i].z, v[i].w, h1, m1, l1);
-            if (LAY == RG_ROWSK) {
-                const int p = idx / (RG_R / 4), r = 4 * (idx % (RG_R / 4));
-                unsigned short *d = lds + p * RG_XP + r;
-                *reinterpret_cast<uint2 *>(d) = uint2{h0, h1};
-                *reinterpret_cast<uint2 *>(d + PLANE) = uint2{m0, m1};
-                *reinterpret_cast<uint2 *>(d + 2 * PLANE) = uint2{l0, l1};
-            } else {
-                const int r = idx / (TP / 4), p = 4 * (idx % (TP / 4));
-                unsigned short *d = lds + p * RG_XP + r;
-                d[0] = (unsigned short)h0; d[RG_XP] = (unsigned short)(h0 >> 16);
-                d[2 * RG_XP] = (unsigned short)h1; d[3 * RG_XP] = (unsigned short)(h1 >> 16);
-                d[PLANE] = (unsigned short)m0; d[PLANE + RG_XP] = (unsigned short)(m0 >> 16);
-                d[PLANE + 2 * RG_XP] = (unsigned short)m1; d[PLANE + 3 * RG_XP] = (unsigned short)(m1 >> 16);
-                d[2 * PLANE] = (unsigned short)l0; d[2 * PLANE + RG_XP] = (unsigned short)(l0 >> 16);
-                d[2 * PLANE + 2 * RG_XP] = (unsigned short)l1; d[2 * PLANE + 3 * RG_XP] = (unsigned short)(l1 >> 16);
-            }
+            unsigned short *d;
+            if (LAY == RG_ROWSK) d = lds + (idx / (RG_R / 4)) * RG_XP + 4 * (idx % (RG_R / 4));
+            else d = lds + (idx / (TP / 4)) * RG_TRP + 4 * (idx % (TP / 4));
+            *reinterpret_cast<uint2 *>(d) = uint2{h0, h1};
+            *reinterpret_cast<uint2 *>(d + PLANE) = uint2{m0, m1};
+            *reinterpret_cast<uint2 *>(d + 2 * PLANE) = uint2{l0, l1};
         }
+    }
+    // this lane's MFMA operand (8 consecutive reduction indices 16 s + 8 (lane >> 5) .. of output index 32 w + (lane & 31))
+    // of plane t; `base` = lane_base(w)
+    __device__ static __forceinline__ int lane_base(int w) {
+        const int lane = threadIdx.x & 63;
+        if (LAY == RG_ROWSK) return (32 * w + (lane & 31)) * RG_XP + 8 * (lane >> 5);
+        const int g16 = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;      // block row q, columns 4 pp .. 4 pp + 3
+        return (8 * (g16 >> 1) + q) * RG_TRP + 32 * w + 16 * (g16 & 1) + 4 * pp;
+    }
+    __device__ static __forceinline__ rg_bf16x8 operand(const unsigned short *lds, int base, int t, int s) {
+        if (LAY == RG_ROWSK) return rg_lds_x8(lds + t * PLANE + base + 16 * s);
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        typedef __attribute__((address_space(3))) s16x4 *lds_ptr;
+        const unsigned short *p = lds + t * PLANE + base + 16 * s * RG_TRP;
+        const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)p);
+        const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p + 4 * RG_TRP));
+        return __builtin_bit_cast(rg_bf16x8, (s16x8)__builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
     }
 };
 
@@ -310,19 +322,19 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(RowsGemm g) {
 
 // The same product on the bf16 MFMA at fp32 accuracy: operands split into three bf16 terms when they are committed to
 // LDS ([p][r] planes, r contiguous), six partial products per multiply-add on v_mfma_f32_32x32x16_bf16, smallest first
-// (2.7x fewer MFMA cycles than the fp32 32x32x2).  Used for the forward product; ARVAE_ROWS_GEMM_FP32=1 / _X3=1 force
-// one kernel or the other everywhere.
+// (2.7x fewer MFMA cycles than the fp32 32x32x2; ARVAE_ROWS_GEMM_FP32=1 selects the kernel above).
 template <int LA, int LB, int EP, bool VA, bool VB>
 __global__ __launch_bounds__(256) void rows_gemm_x3_kernel(RowsGemm g) {
-    constexpr int PLANE_A = RG_TP * RG_XP, PLANE_B = RG_TQ * RG_XP;
-    __shared__ __attribute__((aligned(16))) unsigned short As[3 * PLANE_A];
-    __shared__ __attribute__((aligned(16))) unsigned short Bs[3 * PLANE_B];
+    typedef TileLoader<LA, RG_TP, VA> LoadA;
+    typedef TileLoader<LB, RG_TQ, VB> LoadB;
+    __shared__ __attribute__((aligned(16))) unsigned short As[3 * LoadA::PLANE];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[3 * LoadB::PLANE];
     const int lane = threadIdx.x & 63, half = lane >> 5, rc = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int p0 = blockIdx.x * RG_TP, q0 = blockIdx.y * RG_TQ;
     const int rbeg = blockIdx.z * g.rslice, rend = min(g.Rn, rbeg + g.rslice);
-    TileLoader<LA, RG_TP, VA> la;
-    TileLoader<LB, RG_TQ, VB> lb;
+    LoadA la;
+    LoadB lb;
     const int wp = wave & 1, wq = wave >> 1;
     f32x16 acc;
 #pragma unroll
@@ -330,8 +342,7 @@ __global__ __launch_bounds__(256) void rows_gemm_x3_kernel(RowsGemm g) {
     float bsum = 0.f;
     la.load(g.a, g.lda, p0, g.P, rbeg, rend);
     lb.load(g.b, g.ldb, q0, g.Q, rbeg, rend);
-    const unsigned short *ap = As + (32 * wp + rc) * RG_XP + 8 * half;
-    const unsigned short *bp = Bs + (32 * wq + rc) * RG_XP + 8 * half;
+    const int abase = LoadA::lane_base(wp), bbase = LoadB::lane_base(wq);
     for (int r0 = rbeg; r0 < rend; r0 += RG_R) {
         __syncthreads();
         la.commit3(As);
@@ -343,8 +354,8 @@ __global__ __launch_bounds__(256) void rows_gemm_x3_kernel(RowsGemm g) {
         }
 #pragma unroll
         for (int s = 0; s < RG_R / 16; ++s) {
-            const rg_bf16x8 ah = rg_lds_x8(ap + 16 * s), am = rg_lds_x8(ap + PLANE_A + 16 * s), al = rg_lds_x8(ap + 2 * PLANE_A + 16 * s);
-            const rg_bf16x8 bh = rg_lds_x8(bp + 16 * s), bm = rg_lds_x8(bp + PLANE_B + 16 * s), bl = rg_lds_x8(bp + 2 * PLANE_B + 16 * s);
+            const rg_bf16x8 ah = LoadA::operand(As, abase, 0, s), am = LoadA::operand(As, abase, 1, s), al = LoadA::operand(As, abase, 2, s);
+            const rg_bf16x8 bh = LoadB::operand(Bs, bbase, 0, s), bm = LoadB::operand(Bs, bbase, 1, s), bl = LoadB::operand(Bs, bbase, 2, s);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
@@ -353,11 +364,13 @@ __global__ __launch_bounds__(256) void rows_gemm_x3_kernel(RowsGemm g) {
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
         }
         if (EP == RG_EP_SLICE && g.want_bias && blockIdx.y == 0 && threadIdx.x < RG_TP) {
-            const unsigned short *row = As + threadIdx.x * RG_XP;
+            // sum over the chunk's reduction indices of A(p = threadIdx.x, r), terms re-added exactly
 #pragma unroll 8
-            for (int r = 0; r < RG_R; ++r)
-                bsum += (__builtin_bit_cast(float, (unsigned)row[r] << 16) + __builtin_bit_cast(float, (unsigned)row[PLANE_A + r] << 16)) +
-                        __builtin_bit_cast(float, (unsigned)row[2 * PLANE_A + r] << 16);
+            for (int r = 0; r < RG_R; ++r) {
+                const unsigned short *e = As + (LA == RG_ROWSK ? threadIdx.x * RG_XP + r : r * RG_TRP + threadIdx.x);
+                bsum += (__builtin_bit_cast(float, (unsigned)e[0] << 16) + __builtin_bit_cast(float, (unsigned)e[LoadA::PLANE] << 16)) +
+                        __builtin_bit_cast(float, (unsigned)e[2 * LoadA::PLANE] << 16);
+            }
         }
     }
     float *out = g.out + (EP == RG_EP_SLICE ? blockIdx.z * g.slice_floats : 0);
@@ -521,11 +534,8 @@ static void launch_rows_gemm(const RowsGemm &g, int slices, hipStream_t s) {
     };
     const bool va = vec_ok(g.a, g.lda, LA, g.P), vb = vec_ok(g.b, g.ldb, LB, g.Q);
     const dim3 grid((g.P + RG_TP - 1) / RG_TP, (g.Q + RG_TQ - 1) / RG_TQ, slices);
-    // the bf16 three-term kernel pays for "K x rows" operands with a transposing 2-byte-store commit (measured: 28 vs
-    // 16 us for the weight gradient), so only the forward product (both operands "rows x K") runs on it
     static const bool fp32_mfma = getenv("ARVAE_ROWS_GEMM_FP32") != nullptr;
-    static const bool x3_all = getenv("ARVAE_ROWS_GEMM_X3") != nullptr;
-    if (fp32_mfma || (!x3_all && (LA != RG_ROWSK || LB != RG_ROWSK))) {
+    if (fp32_mfma) {
         if (va && vb) hipLaunchKernelGGL((rows_gemm_kernel<LA, LB, EP, true, true>), grid, dim3(256), 0, s, g);
         else if (va) hipLaunchKernelGGL((rows_gemm_kernel<LA, LB, EP, true, false>), grid, dim3(256), 0, s, g);
         else if (vb) hipLaunchKernelGGL((rows_gemm_kernel<LA, LB, EP, false, true>), grid, dim3(256), 0, s, g);
