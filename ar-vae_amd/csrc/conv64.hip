@@ -1,0 +1,210 @@
+// Stride-1 convolutions between wide layers (the Morpho-MNIST 64 <-> 64 channel k4 layers, imagevae/mnist_vae.py) as
+// implicit GEMMs on the split-bf16 MFMA (x3tile.h): rows = output pixels, columns = output channels, reduction =
+// (tap, source channel).  The A tile is GATHERED: a thread owns two (pixel, 4-channel) slots, works out its pixel's
+// coordinates once, and per 32-channel chunk adds the tap's offset -- a coalesced 16-byte load per slot, zero where the
+// tap falls outside the source (padding).  The weights are re-ordered to [out channel][tap][source channel] by a small
+// kernel first (in memory order the taps are innermost, and gathering them cost more than the MFMAs).  The same kernel serves
+//   Conv2d forward and ConvTranspose2d data gradient   (source pixel = output pixel + tap - pad), and
+//   ConvTranspose2d forward and Conv2d data gradient   (source pixel = output pixel + pad - tap),
+// with the activation derivative / dropout keep-mask of a gradient operand folded into the gather, and bias, activation
+// and keep-mask in the epilogue.  The weight gradient is the same tile machinery with both operands "K x rows" (pixels
+// are the reduction axis), sliced over pixels into a workspace and summed in fixed order.
+#include "common.h"
+#include "x3tile.h"
+
+namespace arvae {
+
+constexpr int C64_TP = 64, C64_TQ = 64;
+typedef float f32x16c __attribute__((ext_vector_type(16)));
+
+struct ConvRows {
+    Operand src;                 // [n][sh][sw][cs] channels-last
+    int n, sh, sw, cs;
+    int oh, ow, q;               // output grid and channels
+    int kh, kw, sgn, off;        // source coordinate = output coordinate + sgn * k + off
+    const float *wt;             // re-ordered weights [q][tap][c] (conv64_weight_prep_kernel): reduction index contiguous
+    const float *bias;
+    const uint8_t *mask;
+    int act;
+    float *out;                  // [n][oh][ow][q]
+};
+
+// value of a gradient operand (activation derivative of the saved output, keep-mask) for 4 consecutive channels
+template <bool PLAIN>
+__device__ __forceinline__ float4 load_src4(const Operand &o, int64_t at, bool ok) {
+    const int64_t a = ok ? at : 0;
+    float4 v = *reinterpret_cast<const float4 *>(o.v + a);
+    if (!PLAIN) {
+        float4 y = *reinterpret_cast<const float4 *>(o.y + a);
+        if (o.mask != nullptr) {
+            const uchar4 m = *reinterpret_cast<const uchar4 *>(o.mask + a);
+            v.x *= 2.f * (float)m.x; v.y *= 2.f * (float)m.y; v.z *= 2.f * (float)m.z; v.w *= 2.f * (float)m.w;
+            y.x *= 0.5f; y.y *= 0.5f; y.z *= 0.5f; y.w *= 0.5f;
+        }
+        v.x *= act_bwd_from_out(y.x, o.act); v.y *= act_bwd_from_out(y.y, o.act);
+        v.z *= act_bwd_from_out(y.z, o.act); v.w *= act_bwd_from_out(y.w, o.act);
+    }
+    return ok ? v : float4{0.f, 0.f, 0.f, 0.f};
+}
+
+template <bool PLAIN>
+__global__ __launch_bounds__(256) void conv_rows_x3_kernel(ConvRows g) {
+    typedef X3Plane<RG_ROWSK, C64_TP> PlaneA;
+    typedef X3Plane<RG_ROWSK, C64_TQ> PlaneB;
+    __shared__ __attribute__((aligned(16))) unsigned short As[3 * PlaneA::PLANE];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[3 * PlaneB::PLANE];
+    const int lane = threadIdx.x & 63, half = lane >> 5, rc = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wp = wave & 1, wq = wave >> 1;
+    const int p0 = blockIdx.x * C64_TP, q0 = blockIdx.y * C64_TQ;
+    const int M = g.n * g.oh * g.ow;
+    const int cpt = g.cs / RG_R;                               // chunks per tap
+    const int chunks = g.kh * g.kw * cpt;
+
+    // this thread's two gather slots: (pixel, 4 channels)
+    int oy[2], ox[2], c4[2];
+    int64_t img_base[2];
+    bool pok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        const int p = p0 + idx / (RG_R / 4);
+        c4[i] = 4 * (idx % (RG_R / 4));
+        pok[i] = p < M;
+        const int pc = pok[i] ? p : 0;
+        const int img = pc / (g.oh * g.ow), rem = pc - img * g.oh * g.ow;
+        oy[i] = rem / g.ow; ox[i] = rem - oy[i] * g.ow;
+        img_base[i] = (int64_t)img * g.sh * g.sw;
+    }
+    // weight slots: (output channel, 4 source channels)
+    int wq_row[2], wc4[2];
+    bool qok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        wq_row[i] = q0 + idx / (RG_R / 4);
+        wc4[i] = 4 * (idx % (RG_R / 4));
+        qok[i] = wq_row[i] < g.q;
+        if (!qok[i]) wq_row[i] = 0;
+    }
+    float4 va[2], vb[2];
+    auto load = [&](int chunk) {
+        const int tap = chunk / cpt, c0 = (chunk - tap * cpt) * RG_R;
+        const int ky = tap / g.kw, kx = tap - ky * g.kw;
+        const int dy = g.sgn * ky + g.off, dx = g.sgn * kx + g.off;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int sy = oy[i] + dy, sx = ox[i] + dx;
+            const bool ok = pok[i] && sy >= 0 && sy < g.sh && sx >= 0 && sx < g.sw;
+            va[i] = load_src4<PLAIN>(g.src, ((img_base[i] + (int64_t)sy * g.sw + sx) * g.cs + c0 + c4[i]), ok);
+            const float4 w = *reinterpret_cast<const float4 *>(g.wt + ((int64_t)wq_row[i] * g.kh * g.kw + tap) * g.cs + c0 + wc4[i]);
+            vb[i] = qok[i] ? w : float4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    f32x16c acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    load(0);
+    const int abase = PlaneA::lane_base(wp), bbase = PlaneB::lane_base(wq);
+    for (int chunk = 0; chunk < chunks; ++chunk) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            PlaneA::commit(As, threadIdx.x + 256 * i, va[i]);
+            PlaneB::commit(Bs, threadIdx.x + 256 * i, vb[i]);
+        }
+        __syncthreads();
+        if (chunk + 1 < chunks) load(chunk + 1);
+#pragma unroll
+        for (int s = 0; s < RG_R / 16; ++s) {
+            const rg_bf16x8 ah = PlaneA::operand(As, abase, 0, s), am = PlaneA::operand(As, abase, 1, s), al = PlaneA::operand(As, abase, 2, s);
+            const rg_bf16x8 bh = PlaneB::operand(Bs, bbase, 0, s), bm = PlaneB::operand(Bs, bbase, 1, s), bl = PlaneB::operand(Bs, bbase, 2, s);
+            X3_MFMA6(acc, ah, am, al, bh, bm, bl);
+        }
+    }
+    const int q = q0 + 32 * wq + rc;
+    const float bias = (g.bias != nullptr && q < g.q) ? g.bias[q] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int p = p0 + 32 * wp + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (p < M && q < g.q) {
+            const int64_t o = (int64_t)p * g.q + q;
+            float v = act_fwd(acc[r] + bias, g.act);
+            if (g.mask != nullptr) v *= 2.f * (float)g.mask[o];
+            g.out[o] = v;
+        }
+    }
+}
+
+// nn.Conv2d / nn.ConvTranspose2d weights [a][b][taps] -> [q][tap][c]; (q, c) = (a, b) for the Conv2d-forward direction,
+// (b, a) for the transposed one
+__global__ __launch_bounds__(256) void conv64_weight_prep_kernel(const float *__restrict__ wt, float *__restrict__ out, int q_count,
+                                                                  int c_count, int taps, int transposed) {
+    const int i = blockIdx.x * 256 + threadIdx.x;                      // output index (q, tap, c)
+    if (i >= q_count * taps * c_count) return;
+    const int c = i % c_count, tap = (i / c_count) % taps, q = i / (c_count * taps);
+    out[i] = transposed ? wt[((int64_t)c * q_count + q) * taps + tap] : wt[((int64_t)q * c_count + c) * taps + tap];
+}
+
+// The re-ordered copy lives in a process-wide scratch buffer (allocated on first use, 1 MB): every launch re-creates it on
+// the caller's stream right before the convolution, so calls must be stream-ordered with respect to each other (one
+// stream, as the trainers use).
+constexpr int64_t C64_SCRATCH_FLOATS = 16 * 128 * 128;
+static float *conv64_scratch() {
+    static float *buf = nullptr;
+    if (buf == nullptr && hipMalloc((void **)&buf, C64_SCRATCH_FLOATS * sizeof(float)) != hipSuccess) buf = nullptr;
+    return buf;
+}
+
+static bool plain_op(const Operand &o) { return o.y == nullptr || (o.act == ARVAE_ACT_NONE && o.mask == nullptr); }
+
+// links this file serves: k x k (<= 16 taps), stride 1, 32 | channels on the reduction side, channels-last, no permutation
+bool conv64_fits(const arvae_link_t *l, bool up) {
+    static const bool off = getenv("ARVAE_CONV64_GENERIC") != nullptr;
+    const int red = up ? l->clo : l->chi, outc = up ? l->chi : l->clo;
+    return !off && l->stride == 1 && l->kh * l->kw <= 16 && l->kh * l->kw > 1 && red % RG_R == 0 && outc >= 32 &&
+           red <= 128 && outc <= 128 && l->hi_perm_c == 0 && l->lo_perm_c == 0;
+}
+
+static int launch_conv_rows(ConvRows g, const float *wt, bool transposed, hipStream_t s, const char *what) {
+    float *packed = conv64_scratch();
+    const int taps = g.kh * g.kw, wcount = g.q * taps * g.cs;
+    if (packed == nullptr || wcount > C64_SCRATCH_FLOATS) return fail(ARVAE_E_INVALID, "%s: no scratch for the re-ordered weights", what);
+    hipLaunchKernelGGL(conv64_weight_prep_kernel, dim3((wcount + 255) / 256), dim3(256), 0, s, wt, packed, g.q, g.cs, taps, transposed ? 1 : 0);
+    g.wt = packed;
+    const int M = g.n * g.oh * g.ow;
+    const dim3 grid((M + C64_TP - 1) / C64_TP, (g.q + C64_TQ - 1) / C64_TQ);
+    prof_gap();
+    if (plain_op(g.src)) {
+        ConvRows p = g;
+        p.src.y = nullptr;
+        hipLaunchKernelGGL(conv_rows_x3_kernel<true>, grid, dim3(256), 0, s, p);
+    } else {
+        hipLaunchKernelGGL(conv_rows_x3_kernel<false>, grid, dim3(256), 0, s, g);
+    }
+    return check_launch(what);
+}
+
+// lo[n][lh][lw][clo] = act(conv(hi) + bias) * mask     (Conv2d forward / ConvTranspose2d data gradient)
+int conv64_down(const arvae_link_t *l, const Operand &hi, const float *wt, const float *bias, int act, const uint8_t *mask,
+                float *lo, hipStream_t s) {
+    ConvRows g{};
+    g.src = hi; g.n = l->n; g.sh = l->hh; g.sw = l->hw; g.cs = l->chi;
+    g.oh = l->lh; g.ow = l->lw; g.q = l->clo;
+    g.kh = l->kh; g.kw = l->kw; g.sgn = 1; g.off = -l->pad;
+    g.bias = bias; g.mask = mask; g.act = act; g.out = lo;
+    return launch_conv_rows(g, wt, false, s, "conv64_down");          // wt[clo][chi][ky][kx]: q = clo, c = chi
+}
+
+// hi[n][hh][hw][chi] = act(convT(lo) + bias) * mask    (ConvTranspose2d forward / Conv2d data gradient)
+int conv64_up(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, int act, const uint8_t *mask,
+              float *hi, hipStream_t s) {
+    ConvRows g{};
+    g.src = lo; g.n = l->n; g.sh = l->lh; g.sw = l->lw; g.cs = l->clo;
+    g.oh = l->hh; g.ow = l->hw; g.q = l->chi;
+    g.kh = l->kh; g.kw = l->kw; g.sgn = -1; g.off = l->pad;
+    g.bias = bias; g.mask = mask; g.act = act; g.out = hi;
+    return launch_conv_rows(g, wt, true, s, "conv64_up");             // wt[clo][chi][ky][kx]: q = chi, c = clo
+}
+
+}  // namespace arvae

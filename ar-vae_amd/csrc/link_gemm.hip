@@ -36,6 +36,13 @@ int64_t conv_c1_wgrad_ws_floats(const arvae_link_t *l);
 int conv_c1_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &img, float *dwt, float *dbias, int bias_mode,
                   float *slab, hipStream_t s);
 
+// stride-1 wide-channel convolutions on the split-bf16 MFMA (conv64.hip)
+bool conv64_fits(const arvae_link_t *l, bool up);
+int conv64_down(const arvae_link_t *l, const Operand &hi, const float *wt, const float *bias, int act, const uint8_t *mask,
+                float *lo, hipStream_t s);
+int conv64_up(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, int act, const uint8_t *mask,
+              float *hi, hipStream_t s);
+
 // specialised 32-channel k4/s2/p1 kernels (conv32.hip)
 bool conv32_fits(const arvae_link_t *l);
 int conv32_down(const arvae_link_t *l, const Operand &hi, const float *wt, const float *bias, int relu, const float *gate,
@@ -679,6 +686,8 @@ extern "C" int arvae_link_down(const arvae_link_t *link, const arvae_operand_t *
     if (conv_c1_fits(link) && out_mask == nullptr && hi->mask == nullptr && out_act != ARVAE_ACT_SELU &&
         hi->act != ARVAE_ACT_SELU)
         return conv_c1_down(link, make_operand(hi), wt, bias, out_act == ARVAE_ACT_RELU, nullptr, nullptr, nullptr, lo, as_stream(stream));
+    if (conv64_fits(link, false))
+        return conv64_down(link, make_operand(hi), wt, bias, out_act, out_mask, lo, as_stream(stream));
     if (single_channel_mfma_fits(link)) {
         hipLaunchKernelGGL(down_single_channel_mfma_kernel, dim3(link->n), dim3(256), sizeof(float) * link->hh * link->hw,
                            as_stream(stream), p.g, make_operand(hi), wt, Epilogue{bias, out_mask, lo, out_act});
@@ -719,6 +728,8 @@ extern "C" int arvae_link_up(const arvae_link_t *link, const arvae_operand_t *lo
     }
     if (conv_c1_fits(link) && lo->y == nullptr && out_mask == nullptr && out_act == ARVAE_ACT_NONE)
         return conv_c1_up(link, lo->v, wt, bias, hi, st);
+    if (conv64_fits(link, true))
+        return conv64_up(link, make_operand(lo), wt, bias, out_act, out_mask, hi, st);
     if (link->chi == 1 && lo->y == nullptr && link->clo % 4 == 0 && link->lo_perm_c == 0) {
         const int total = link->n * link->hh * link->hw;
         Epilogue ep{bias, out_mask, hi, out_act};
