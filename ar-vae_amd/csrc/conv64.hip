@@ -207,4 +207,137 @@ int conv64_up(const arvae_link_t *l, const Operand &lo, const float *wt, const f
     return launch_conv_rows(g, wt, true, s, "conv64_up");             // wt[clo][chi][ky][kx]: q = chi, c = clo
 }
 
+// ---- weight gradient ----------------------------------------------------------------------------------------------
+// dW[clo][chi][tap] = sum over lo pixels p of LO[p][clo] * HI[p + tap - pad][chi]  (LO / HI = the link's two operands,
+// either of which may be a gradient operand).  Per tap a [clo x chi] product with the pixels as the reduction axis: both
+// operands are "K x rows" tiles (32 pixels x 64 channels, coalesced 16-byte loads, HI rows gathered at the tap's
+// offset) read through the transposing LDS read.  blockIdx.x = tap, blockIdx.y = a slice of C64_WG_SLICE pixels whose
+// partial [taps][clo][chi] goes to the workspace; conv64_wgrad_reduce_kernel adds the slices in order.
+constexpr int C64_WG_SLICE = 4096;
+
+struct ConvWgrad {
+    Operand lo, hi;
+    int n, lh, lw, clo, hh, hw, chi, kh, kw, pad;
+    float *ws;                   // [slices][taps][clo][chi]
+};
+
+template <bool PLAIN_LO, bool PLAIN_HI>
+__global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(ConvWgrad g) {
+    typedef X3Plane<RG_KROWS, 64> Plane;
+    __shared__ __attribute__((aligned(16))) unsigned short As[3 * Plane::PLANE];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[3 * Plane::PLANE];
+    const int lane = threadIdx.x & 63, half = lane >> 5, rc = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wp = wave & 1, wq = wave >> 1;
+    const int tap = blockIdx.x, ky = tap / g.kw, kx = tap - ky * g.kw;
+    const int M = g.n * g.lh * g.lw;
+    const int pbeg = blockIdx.y * C64_WG_SLICE, pend = min(M, pbeg + C64_WG_SLICE);
+    // slot i: pixel row r = idx / 16 of the chunk, channels 4 (idx % 16) ..
+    int r_of[2], c4[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        r_of[i] = idx / 16; c4[i] = 4 * (idx % 16);
+    }
+    float4 va[2], vb[2];
+    auto load = [&](int pix0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int p = pix0 + r_of[i];
+            const bool pok = p < pend;
+            const int pc = pok ? p : pbeg;
+            va[i] = load_src4<PLAIN_LO>(g.lo, (int64_t)pc * g.clo + c4[i], pok && c4[i] < g.clo);
+            const int img = pc / (g.lh * g.lw), rem = pc - img * g.lh * g.lw;
+            const int ly = rem / g.lw, lx = rem - ly * g.lw;
+            const int hy = ly - g.pad + ky, hx = lx - g.pad + kx;
+            const bool ok = pok && hy >= 0 && hy < g.hh && hx >= 0 && hx < g.hw && c4[i] < g.chi;
+            vb[i] = load_src4<PLAIN_HI>(g.hi, (((int64_t)img * g.hh + hy) * g.hw + hx) * g.chi + c4[i], ok);
+        }
+    };
+    f32x16c acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    load(pbeg);
+    const int abase = Plane::lane_base(wp), bbase = Plane::lane_base(wq);
+    for (int pix0 = pbeg; pix0 < pend; pix0 += RG_R) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            Plane::commit(As, threadIdx.x + 256 * i, va[i]);
+            Plane::commit(Bs, threadIdx.x + 256 * i, vb[i]);
+        }
+        __syncthreads();
+        if (pix0 + RG_R < pend) load(pix0 + RG_R);
+#pragma unroll
+        for (int s = 0; s < RG_R / 16; ++s) {
+            const rg_bf16x8 ah = Plane::operand(As, abase, 0, s), am = Plane::operand(As, abase, 1, s), al = Plane::operand(As, abase, 2, s);
+            const rg_bf16x8 bh = Plane::operand(Bs, bbase, 0, s), bm = Plane::operand(Bs, bbase, 1, s), bl = Plane::operand(Bs, bbase, 2, s);
+            X3_MFMA6(acc, ah, am, al, bh, bm, bl);
+        }
+    }
+    float *out = g.ws + ((int64_t)blockIdx.y * g.kh * g.kw + tap) * g.clo * g.chi;
+    const int q = 32 * wq + rc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int p = 32 * wp + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (p < g.clo && q < g.chi) out[p * g.chi + q] = acc[r];
+    }
+}
+
+// dwt[clo][chi][tap] += sum_slices ws[slice][tap][clo][chi]; 4 lanes per element, fixed order
+__global__ __launch_bounds__(256) void conv64_wgrad_reduce_kernel(const float *__restrict__ ws, int slices, int taps, int clo, int chi,
+                                                                   float *__restrict__ dwt) {
+    const int count = taps * clo * chi;
+    const int i = (blockIdx.x * 256 + threadIdx.x) >> 2, q4 = threadIdx.x & 3;
+    const int ic = i < count ? i : 0;
+    float s = 0.f;
+    for (int z0 = q4; z0 < slices; z0 += 32) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int z = z0 + 4 * u;
+            const float v = ws[(int64_t)(z < slices ? z : 0) * count + ic];
+            t[u] = z < slices ? v : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += t[u];
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (q4 != 0 || i >= count) return;
+    const int c = i % chi, a = (i / chi) % clo, tap = i / (chi * clo);       // ws index (tap, clo, chi)
+    dwt[((int64_t)a * chi + c) * taps + tap] += s;
+}
+
+bool conv64_wgrad_fits(const arvae_link_t *l) {
+    static const bool off = getenv("ARVAE_CONV64_GENERIC") != nullptr;
+    return !off && l->stride == 1 && l->kh * l->kw <= 16 && l->kh * l->kw > 1 && l->clo % 4 == 0 && l->chi % 4 == 0 &&
+           l->clo >= 32 && l->chi >= 32 && l->clo <= 64 && l->chi <= 64 && l->hi_perm_c == 0 && l->lo_perm_c == 0;
+}
+
+int64_t conv64_wgrad_ws_floats(const arvae_link_t *l) {
+    const int64_t M = (int64_t)l->n * l->lh * l->lw;
+    return ((M + C64_WG_SLICE - 1) / C64_WG_SLICE) * l->kh * l->kw * l->clo * l->chi;
+}
+
+int conv64_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *dwt, float *ws, hipStream_t s) {
+    ConvWgrad g{};
+    g.lo = lo; g.hi = hi; g.n = l->n; g.lh = l->lh; g.lw = l->lw; g.clo = l->clo; g.hh = l->hh; g.hw = l->hw; g.chi = l->chi;
+    g.kh = l->kh; g.kw = l->kw; g.pad = l->pad; g.ws = ws;
+    const int taps = l->kh * l->kw;
+    const int slices = (int)(((int64_t)l->n * l->lh * l->lw + C64_WG_SLICE - 1) / C64_WG_SLICE);
+    const dim3 grid(taps, slices);
+    const bool pl = plain_op(lo), ph = plain_op(hi);
+    if (pl) g.lo.y = nullptr;
+    if (ph) g.hi.y = nullptr;
+    prof_gap();
+    if (pl && ph) hipLaunchKernelGGL((conv_wgrad_x3_kernel<true, true>), grid, dim3(256), 0, s, g);
+    else if (pl) hipLaunchKernelGGL((conv_wgrad_x3_kernel<true, false>), grid, dim3(256), 0, s, g);
+    else if (ph) hipLaunchKernelGGL((conv_wgrad_x3_kernel<false, true>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((conv_wgrad_x3_kernel<false, false>), grid, dim3(256), 0, s, g);
+    const int count = taps * l->clo * l->chi;
+    hipLaunchKernelGGL(conv64_wgrad_reduce_kernel, dim3((count * 4 + 255) / 256), dim3(256), 0, s, ws, slices, taps, l->clo, l->chi, dwt);
+    return check_launch("conv64_wgrad");
+}
+
 }  // namespace arvae

@@ -42,6 +42,9 @@ int conv64_down(const arvae_link_t *l, const Operand &hi, const float *wt, const
                 float *lo, hipStream_t s);
 int conv64_up(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, int act, const uint8_t *mask,
               float *hi, hipStream_t s);
+bool conv64_wgrad_fits(const arvae_link_t *l);
+int64_t conv64_wgrad_ws_floats(const arvae_link_t *l);
+int conv64_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *dwt, float *ws, hipStream_t s);
 
 // specialised 32-channel k4/s2/p1 kernels (conv32.hip)
 bool conv32_fits(const arvae_link_t *l);
@@ -796,6 +799,7 @@ extern "C" int64_t arvae_link_wgrad_ws_floats(const arvae_link_t *link) {
     channel_sum_split((int64_t)link->n * link->hh * link->hw, blocks, rpb);
     if (blocks * link->chi > need) need = blocks * link->chi;
     if (dense_fits(link) && dense_wgrad_ws_floats(link) > need) need = dense_wgrad_ws_floats(link);
+    if (conv64_wgrad_fits(link) && conv64_wgrad_ws_floats(link) > need) need = conv64_wgrad_ws_floats(link);
     if (conv32_fits(link) && conv32_wgrad_ws_floats(link) > need) need = conv32_wgrad_ws_floats(link);
     if (conv_c1_fits(link) && conv_c1_wgrad_ws_floats(link) > need) need = conv_c1_wgrad_ws_floats(link);
     return need;
@@ -819,6 +823,14 @@ extern "C" int arvae_link_wgrad(const arvae_link_t *link, const arvae_operand_t 
         return conv32_wgrad(link, make_operand(lo), make_operand(hi), dwt, dbias, bias_side, ws, st);
     p.lo = make_operand(lo);
     p.hi = make_operand(hi);
+    if (conv64_wgrad_fits(link)) {
+        if (int rc = conv64_wgrad(link, p.lo, p.hi, dwt, ws, st)) return rc;
+        if (bias_side == 1)
+            return channel_sum_launch(p.lo, (int64_t)link->n * link->lh * link->lw, link->clo, 0, 0, dbias, ws, st);
+        if (bias_side == 2)
+            return channel_sum_launch(p.hi, (int64_t)link->n * link->hh * link->hw, link->chi, 0, 0, dbias, ws, st);
+        return ARVAE_OK;
+    }
     p.dwt = dwt;
     p.slab = ws;
     wgrad_split(link, p.M, p.N, p.P, p.zsplit, p.chunk);
