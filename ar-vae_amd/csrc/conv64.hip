@@ -162,7 +162,8 @@ static bool plain_op(const Operand &o) { return o.y == nullptr || (o.act == ARVA
 bool conv64_fits(const arvae_link_t *l, bool up) {
     static const bool off = getenv("ARVAE_CONV64_GENERIC") != nullptr;
     const int red = up ? l->clo : l->chi, outc = up ? l->chi : l->clo;
-    return !off && l->stride == 1 && l->kh * l->kw <= 16 && l->kh * l->kw > 1 && red % RG_R == 0 && outc >= 32 &&
+    // narrow outputs (the 64 -> 8 layers) waste MFMA columns but these products are bound by the gather, not the MFMA
+    return !off && l->stride == 1 && l->kh * l->kw <= 16 && l->kh * l->kw > 1 && red % RG_R == 0 && outc >= 4 &&
            red <= 128 && outc <= 128 && l->hi_perm_c == 0 && l->lo_perm_c == 0;
 }
 
@@ -312,7 +313,8 @@ __global__ __launch_bounds__(256) void conv64_wgrad_reduce_kernel(const float *_
 bool conv64_wgrad_fits(const arvae_link_t *l) {
     static const bool off = getenv("ARVAE_CONV64_GENERIC") != nullptr;
     return !off && l->stride == 1 && l->kh * l->kw <= 16 && l->kh * l->kw > 1 && l->clo % 4 == 0 && l->chi % 4 == 0 &&
-           l->clo >= 32 && l->chi >= 32 && l->clo <= 64 && l->chi <= 64 && l->hi_perm_c == 0 && l->lo_perm_c == 0;
+           l->clo >= 4 && l->chi >= 4 && l->clo <= 64 && l->chi <= 64 && (l->clo >= 32 || l->chi >= 32) &&
+           l->hi_perm_c == 0 && l->lo_perm_c == 0;
 }
 
 int64_t conv64_wgrad_ws_floats(const arvae_link_t *l) {
