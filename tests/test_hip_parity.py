@@ -703,13 +703,13 @@ def test_measure_sequence_path_matches_stepwise(dev, monkeypatch):
             assert float((gseq - gstep).norm()) <= 2e-4 * float(gstep.norm()) + 1e-9, (teacher, k)
 
 
-@pytest.mark.parametrize('b,dropout', [(256, 0.5), (21, 0.0)])
-def test_tick_free_run_tokens_match_stepwise(dev, monkeypatch, b, dropout):
+@pytest.mark.parametrize('b,dropout,hid', [(256, 0.5, 128), (21, 0.0, 128), (37, 0.5, 64)])
+def test_tick_free_run_tokens_match_stepwise(dev, monkeypatch, b, dropout, hid):
     """the one-launch free-running tick decoder feeds itself the same notes as the launch-per-tick pass."""
     from arvae_amd.measure_vae import MeasureVAE
     torch.manual_seed(23)
     ds = _FolkDataset()
-    model = MeasureVAE(ds, 10, 2, 2, 128, dropout, 32, 2, 128, dropout, False, 'folk').cuda().train()
+    model = MeasureVAE(ds, 10, 2, 2, hid, dropout, 32, 2, hid, dropout, False, 'folk').cuda().train()
     with torch.no_grad():                                     # spread the logits so that the argmax varies
         model.decoder.tick_emb_to_note_emb[0].weight.mul_(4.0)
         model.decoder.tick_emb_to_note_emb[0].bias.add_(0.3)
@@ -717,9 +717,9 @@ def test_tick_free_run_tokens_match_stepwise(dev, monkeypatch, b, dropout):
     score = torch.from_numpy(syn.measure_batch(b, seed=28)).to(dev)
     eps = torch.from_numpy(syn.normal_noise((b, 32), seed=29))
     gen = torch.Generator().manual_seed(4)
-    masks = [(torch.rand(24, b, 256, generator=gen) >= 0.5).to(torch.uint8).to(dev),
-             (torch.rand(4, b, 128, generator=gen) >= 0.5).to(torch.uint8).to(dev),
-             (torch.rand(24, b, 128, generator=gen) >= 0.5).to(torch.uint8).to(dev)]
+    masks = [(torch.rand(24, b, 2 * hid, generator=gen) >= 0.5).to(torch.uint8).to(dev),
+             (torch.rand(4, b, hid, generator=gen) >= 0.5).to(torch.uint8).to(dev),
+             (torch.rand(24, b, hid, generator=gen) >= 0.5).to(torch.uint8).to(dev)]
     out = {}
     for mode in ('0', '1'):
         monkeypatch.setenv('ARVAE_TICK_STEPWISE', mode)
