@@ -356,7 +356,8 @@ int conv_c1_down(const arvae_link_t *l, const Operand &img, const float *wt, con
     const int tiles = l->n * (LO1 / TR1);
     Ep1 ep{bias, gate, gate_bits, bits_out, out, relu};
     prof_gap();
-    hipLaunchKernelGGL(down_c1_kernel, dim3(tiles < 1024 ? tiles : 1024), dim3(256), 0, s, img, wt, ep, tiles);
+    static const int cap = getenv("ARVAE_C1_DOWN_GRID") ? atoi(getenv("ARVAE_C1_DOWN_GRID")) : 512;      // 2 per CU, 4 tiles each: measured best of 256..4096
+    hipLaunchKernelGGL(down_c1_kernel, dim3(tiles < cap ? tiles : cap), dim3(256), 0, s, img, wt, ep, tiles);
     return check_launch("down_c1_kernel");
 }
 
