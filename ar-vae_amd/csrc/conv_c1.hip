@@ -369,6 +369,8 @@ static int up_c1_grid(int tiles) {
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
         cached = cus > 0 ? cus : 256;
     }
+    static const int cap = getenv("ARVAE_C1_UP_GRID") ? atoi(getenv("ARVAE_C1_UP_GRID")) : 0;
+    if (cap > 0) return tiles < cap ? tiles : cap;
     return tiles < 2 * cached ? tiles : 2 * cached;
 }
 
@@ -411,7 +413,8 @@ int conv_c1_up_recon(const arvae_link_t *l, const float *lo, const float *wt, co
 
 static int wgrad_c1_groups(const arvae_link_t *l) {
     const int tiles = l->n * (LO1 / TR1);
-    return tiles < 512 ? tiles : 512;
+    static const int cap = getenv("ARVAE_C1_WGRAD_GRID") ? atoi(getenv("ARVAE_C1_WGRAD_GRID")) : 512;
+    return tiles < cap ? tiles : cap;
 }
 
 int64_t conv_c1_wgrad_ws_floats(const arvae_link_t *l) { return (int64_t)wgrad_c1_groups(l) * WG1_SLAB; }
