@@ -310,6 +310,158 @@ __global__ __launch_bounds__(256) void conv64_wgrad_reduce_kernel(const float *_
     dwt[((int64_t)a * chi + c) * taps + tap] += s;
 }
 
+// ---- weight gradient, row-staged ------------------------------------------------------------------------------------
+// The kernel above fetches every operand value once per tap.  Here a workgroup walks whole images row by row: the
+// reduction chunk is ONE lo row (lw <= 32 pixels, zero padded), staged in LDS as the A image, and the hi rows it meets
+// (ly - pad + ky, ky < kh) live in a five-slot ring of row images that gains one row per step -- every operand value
+// is fetched and split once.  Wave = ky; the kx taps are the same hi row image read kx rows further down (the
+// transposing read takes any row offset), so a wave holds 2 x kw accumulator tiles: [clo half][kx] of 32 x 32, for one
+// 32-channel half of chi (blockIdx.x).  Next row's operands are fetched into registers while this row's MFMAs run; one
+// barrier per row.
+constexpr int WR_HROWS = 36;                                   // hi row image: 32 + kw - 1 pixel rows, padded
+constexpr int WR_RING = 5;
+constexpr int WR_APLANE = RG_R * RG_TRP, WR_HPLANE = WR_HROWS * RG_TRP;
+
+__device__ __forceinline__ rg_bf16x8 wr_tr_operand(const unsigned short *p) {
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    typedef __attribute__((address_space(3))) s16x4 *lds_ptr;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)p);
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p + 4 * RG_TRP));
+    return __builtin_bit_cast(rg_bf16x8, (s16x8)__builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+__device__ __forceinline__ void wr_commit(unsigned short *d, int plane, const float4 &v) {
+    unsigned h0, m0, l0, h1, m1, l1;
+    rg_split3(v.x, v.y, h0, m0, l0);
+    rg_split3(v.z, v.w, h1, m1, l1);
+    *reinterpret_cast<uint2 *>(d) = uint2{h0, h1};
+    *reinterpret_cast<uint2 *>(d + plane) = uint2{m0, m1};
+    *reinterpret_cast<uint2 *>(d + 2 * plane) = uint2{l0, l1};
+}
+
+template <bool PLAIN_LO, bool PLAIN_HI, int KW>
+__global__ __launch_bounds__(256) void conv_wgrad_rows_x3_kernel(ConvWgrad g, int img_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short wr_lds[];
+    unsigned short *lo_img = wr_lds;                            // [2][3][32][RG_TRP]
+    unsigned short *hi_ring = wr_lds + 2 * 3 * WR_APLANE;       // [WR_RING][3][WR_HROWS][RG_TRP]
+    const int lane = threadIdx.x & 63, half = lane >> 5, rc = lane & 31;
+    const int ky = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ch0 = 32 * blockIdx.x;                            // this workgroup's chi half
+    const int n0 = blockIdx.y * img_per_wg, n1 = min(g.n, n0 + img_per_wg);
+    const int na = g.clo > 32 ? 2 : 1;                          // clo halves in use
+
+    // gather slots.  lo row: pixel r = idx / 16, channels 4 (idx % 16); hi row: pixel row r = idx / 8, channels ch0 + 4 (idx % 8)
+    const int lo_r[2] = {(int)threadIdx.x / 16, (int)threadIdx.x / 16 + 16};
+    const int lo_c = 4 * (threadIdx.x % 16);
+    const int hi_r[2] = {(int)threadIdx.x / 8, (int)threadIdx.x / 8 + 32};
+    const int hi_c = 4 * (threadIdx.x % 8);
+    float4 vlo[2], vhi[2];
+    auto fetch_lo = [&](int n, int ly) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bool ok = lo_r[i] < g.lw && lo_c < g.clo;
+            vlo[i] = load_src4<PLAIN_LO>(g.lo, (((int64_t)n * g.lh + ly) * g.lw + lo_r[i]) * g.clo + lo_c, ok);
+        }
+    };
+    auto fetch_hi = [&](int n, int hy) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int hx = hi_r[i] - g.pad;
+            const bool ok = hi_r[i] < WR_HROWS && hy >= 0 && hy < g.hh && hx >= 0 && hx < g.hw && ch0 + hi_c < g.chi;
+            vhi[i] = load_src4<PLAIN_HI>(g.hi, (((int64_t)n * g.hh + hy) * g.hw + hx) * g.chi + ch0 + hi_c, ok);
+        }
+    };
+    auto commit_lo = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) wr_commit(lo_img + buf * 3 * WR_APLANE + lo_r[i] * RG_TRP + lo_c, WR_APLANE, vlo[i]);
+    };
+    auto commit_hi = [&](int hy) {
+        unsigned short *img = hi_ring + ((hy + 2 * WR_RING) % WR_RING) * 3 * WR_HPLANE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (hi_r[i] < WR_HROWS) wr_commit(img + hi_r[i] * RG_TRP + hi_c, WR_HPLANE, vhi[i]);
+    };
+
+    f32x16c acc[2][KW];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int k = 0; k < KW; ++k)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][k][i] = 0.f;
+    // transposed-read lane offsets inside an image (x3tile.h X3Plane<RG_KROWS>::lane_base with w = 0)
+    const int g16 = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+    const int tr_base = (8 * (g16 >> 1) + tq) * RG_TRP + 16 * (g16 & 1) + 4 * tp;
+
+    for (int n = n0; n < n1; ++n) {
+        __syncthreads();                                        // the previous image's last row is done with the ring
+        for (int k = 0; k < g.kh - 1; ++k) {                    // rows ky = 0 .. kh-2 of the first lo row, blocking
+            fetch_hi(n, -g.pad + k);
+            commit_hi(-g.pad + k);
+        }
+        fetch_lo(n, 0);
+        fetch_hi(n, -g.pad + g.kh - 1);
+        for (int ly = 0; ly < g.lh; ++ly) {
+            commit_lo(ly & 1);
+            commit_hi(ly - g.pad + g.kh - 1);
+            __syncthreads();
+            if (ly + 1 < g.lh) {
+                fetch_lo(n, ly + 1);
+                fetch_hi(n, ly + 1 - g.pad + g.kh - 1);
+            }
+            if (ky < g.kh) {
+                const unsigned short *ab = lo_img + (ly & 1) * 3 * WR_APLANE + tr_base;
+                const int hy = ly - g.pad + ky;
+                const unsigned short *hb = hi_ring + ((hy + 2 * WR_RING) % WR_RING) * 3 * WR_HPLANE + tr_base;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    rg_bf16x8 a3[2][3];
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        a3[0][t] = wr_tr_operand(ab + t * WR_APLANE + 16 * s * RG_TRP);
+                        a3[1][t] = wr_tr_operand(ab + t * WR_APLANE + 16 * s * RG_TRP + 32);
+                    }
+#pragma unroll
+                    for (int kx = 0; kx < KW; ++kx) {
+                        rg_bf16x8 b3[3];
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) b3[t] = wr_tr_operand(hb + t * WR_HPLANE + (16 * s + kx) * RG_TRP);
+                        X3_MFMA6(acc[0][kx], a3[0][0], a3[0][1], a3[0][2], b3[0], b3[1], b3[2]);
+                        if (na > 1) { X3_MFMA6(acc[1][kx], a3[1][0], a3[1][1], a3[1][2], b3[0], b3[1], b3[2]); }
+                    }
+                }
+            }
+        }
+    }
+    if (ky < g.kh) {
+        const int q = ch0 + rc;
+#pragma unroll
+        for (int kx = 0; kx < KW; ++kx) {
+            if (kx >= g.kw) break;
+            float *out = g.ws + ((int64_t)blockIdx.y * g.kh * g.kw + ky * g.kw + kx) * g.clo * g.chi;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int p = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (p < g.clo && q < g.chi) out[p * g.chi + q] = acc[a][kx][r];
+                }
+        }
+    }
+}
+
+// images per workgroup: one workgroup per CU (256) when the batch allows it
+static int wr_img_per_wg(const arvae_link_t *l) {
+    const int halves = (l->chi + 31) / 32;
+    const int per = l->n * halves / 256;
+    return per < 1 ? 1 : per;
+}
+
+static bool conv64_wgrad_rows_fits(const arvae_link_t *l) {
+    static const bool off = getenv("ARVAE_CONV64_WGRAD_TAPS") != nullptr;      // A/B: the per-tap kernel
+    return !off && l->kh <= 4 && l->kw == 4 && l->lw <= 32 && l->lw + l->kw - 1 <= WR_HROWS && l->pad <= 4;
+}
+
 bool conv64_wgrad_fits(const arvae_link_t *l) {
     static const bool off = getenv("ARVAE_CONV64_GENERIC") != nullptr;
     return !off && l->stride == 1 && l->kh * l->kw <= 16 && l->kh * l->kw > 1 && l->clo % 4 == 0 && l->chi % 4 == 0 &&
@@ -319,7 +471,10 @@ bool conv64_wgrad_fits(const arvae_link_t *l) {
 
 int64_t conv64_wgrad_ws_floats(const arvae_link_t *l) {
     const int64_t M = (int64_t)l->n * l->lh * l->lw;
-    return ((M + C64_WG_SLICE - 1) / C64_WG_SLICE) * l->kh * l->kw * l->clo * l->chi;
+    const int64_t per = (int64_t)l->kh * l->kw * l->clo * l->chi;
+    const int64_t taps_kernel = ((M + C64_WG_SLICE - 1) / C64_WG_SLICE) * per;
+    const int64_t rows_kernel = ((l->n + wr_img_per_wg(l) - 1) / wr_img_per_wg(l)) * per;
+    return taps_kernel > rows_kernel ? taps_kernel : rows_kernel;
 }
 
 int conv64_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *dwt, float *ws, hipStream_t s) {
@@ -327,11 +482,32 @@ int conv64_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, fl
     g.lo = lo; g.hi = hi; g.n = l->n; g.lh = l->lh; g.lw = l->lw; g.clo = l->clo; g.hh = l->hh; g.hw = l->hw; g.chi = l->chi;
     g.kh = l->kh; g.kw = l->kw; g.pad = l->pad; g.ws = ws;
     const int taps = l->kh * l->kw;
-    const int slices = (int)(((int64_t)l->n * l->lh * l->lw + C64_WG_SLICE - 1) / C64_WG_SLICE);
-    const dim3 grid(taps, slices);
     const bool pl = plain_op(lo), ph = plain_op(hi);
     if (pl) g.lo.y = nullptr;
     if (ph) g.hi.y = nullptr;
+    if (conv64_wgrad_rows_fits(l)) {
+        const int ipw = wr_img_per_wg(l), slices = (l->n + ipw - 1) / ipw;
+        const dim3 grid((l->chi + 31) / 32, slices);
+        const size_t lds = (2 * 3 * WR_APLANE + WR_RING * 3 * WR_HPLANE) * sizeof(unsigned short);
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_rows_x3_kernel<true, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_rows_x3_kernel<true, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_rows_x3_kernel<false, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_rows_x3_kernel<false, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr = true;
+        }
+        prof_gap();
+        if (pl && ph) hipLaunchKernelGGL((conv_wgrad_rows_x3_kernel<true, true, 4>), grid, dim3(256), lds, s, g, ipw);
+        else if (pl) hipLaunchKernelGGL((conv_wgrad_rows_x3_kernel<true, false, 4>), grid, dim3(256), lds, s, g, ipw);
+        else if (ph) hipLaunchKernelGGL((conv_wgrad_rows_x3_kernel<false, true, 4>), grid, dim3(256), lds, s, g, ipw);
+        else hipLaunchKernelGGL((conv_wgrad_rows_x3_kernel<false, false, 4>), grid, dim3(256), lds, s, g, ipw);
+        const int count = taps * l->clo * l->chi;
+        hipLaunchKernelGGL(conv64_wgrad_reduce_kernel, dim3((count * 4 + 255) / 256), dim3(256), 0, s, ws, slices, taps, l->clo, l->chi, dwt);
+        return check_launch("conv64_wgrad(rows)");
+    }
+    const int slices = (int)(((int64_t)l->n * l->lh * l->lw + C64_WG_SLICE - 1) / C64_WG_SLICE);
+    const dim3 grid(taps, slices);
     prof_gap();
     if (pl && ph) hipLaunchKernelGGL((conv_wgrad_x3_kernel<true, true>), grid, dim3(256), 0, s, g);
     else if (pl) hipLaunchKernelGGL((conv_wgrad_x3_kernel<true, false>), grid, dim3(256), 0, s, g);
