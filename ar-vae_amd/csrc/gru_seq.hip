@@ -282,6 +282,9 @@ __device__ __forceinline__ bf16x8g lds_x8(const unsigned short *p) {
     ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AH, WM, ACC, 0, 0, 0);               \
     ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AH, WH, ACC, 0, 0, 0)
 
+#ifdef ARVAE_GRU_STAMPS
+__device__ unsigned long long g_gru_stamps[8];
+#endif
 template <int H>
 __global__ __launch_bounds__(H * 4) void gru_seq_fwd_x3_kernel(GruSeqBatch batch, int T, int R) {
     constexpr int KS = H / 32;             // MFMA k-steps of 32
@@ -318,19 +321,32 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_x3_kernel(GruSeqBatch batch
         h[i] = (s.h0 != nullptr && live[i]) ? s.h0[(int64_t)rows[i] * H + unit] : 0.f;
         store_split3(&hbuf[0][(4 * quad + i) * HP + unit], PLANE, h[i]);
     }
+    // running per-row pointers, advanced by a signed stride every step (the address arithmetic of 12 loads and 8 stores
+    // per step was a quarter of the step: the kernel is vector-ALU bound around its MFMAs)
+    const int t0 = s.reverse ? T - 1 : 0;
+    const int64_t dir = s.reverse ? -1 : 1;
+    const int64_t gi_step = dir * s.gi_tstride, h_step = dir * (int64_t)R * s.h_stride, sv_step = dir * (int64_t)R * H * 4;
+    const float *gi_p[4];
+    float *h_p[4], *sv_p[4];
     float gi_next[4][3];
-    {
-        const int t0 = s.reverse ? T - 1 : 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float *p = s.gi + t0 * s.gi_tstride + (int64_t)rows[i] * 3 * H + unit;
-            gi_next[i][0] = p[0]; gi_next[i][1] = p[H]; gi_next[i][2] = p[2 * H];
-        }
+    for (int i = 0; i < 4; ++i) {
+        gi_p[i] = s.gi + t0 * s.gi_tstride + (int64_t)rows[i] * 3 * H + unit;
+        h_p[i] = s.h_all + ((int64_t)t0 * R + rows[i]) * s.h_stride + unit;
+        sv_p[i] = s.saved + (((int64_t)t0 * R + rows[i]) * H + unit) * 4;
+        gi_next[i][0] = gi_p[i][0]; gi_next[i][1] = gi_p[i][H]; gi_next[i][2] = gi_p[i][2 * H];
+        gi_p[i] += gi_step;
     }
     __syncthreads();
     f32x4 keep_sv[4];                        // results of the previous step, stored after the barrier
     float keep_h[4];
     int keep_t = -1;
+#ifdef ARVAE_GRU_STAMPS
+    unsigned long long ph[4] = {0, 0, 0, 0}, tc = __builtin_readcyclecounter();
+#define GSTAMP(k) { const unsigned long long now = __builtin_readcyclecounter(); ph[k] += now - tc; tc = now; }
+#else
+#define GSTAMP(k)
+#endif
 
     for (int step = 0; step < T; ++step) {
         const int t = s.reverse ? T - 1 - step : step;
@@ -341,22 +357,23 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_x3_kernel(GruSeqBatch batch
 #pragma unroll
             for (int g = 0; g < 3; ++g) gi[i][g] = gi_next[i][g];
         if (step + 1 < T) {
-            const int tn = s.reverse ? t - 1 : t + 1;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float *p = s.gi + tn * s.gi_tstride + (int64_t)rows[i] * 3 * H + unit;
-                gi_next[i][0] = p[0]; gi_next[i][1] = p[H]; gi_next[i][2] = p[2 * H];
+                gi_next[i][0] = gi_p[i][0]; gi_next[i][1] = gi_p[i][H]; gi_next[i][2] = gi_p[i][2 * H];
+                gi_p[i] += gi_step;
             }
         }
         if (keep_t >= 0) {                   // the previous step's outputs leave while this step's MFMAs run
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) {
                 if (live[i]) {
-                    const int64_t tr = (int64_t)keep_t * R + rows[i];
-                    s.h_all[tr * s.h_stride + unit] = keep_h[i];
-                    *reinterpret_cast<f32x4 *>(s.saved + (tr * H + unit) * 4) = keep_sv[i];
+                    *h_p[i] = keep_h[i];
+                    *reinterpret_cast<f32x4 *>(sv_p[i]) = keep_sv[i];
                 }
+                h_p[i] += h_step; sv_p[i] += sv_step;
+            }
         }
+        GSTAMP(0);
         f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         const unsigned short *hb = &hbuf[cur][col * HP + 8 * quad];
 #pragma unroll
@@ -365,6 +382,10 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_x3_kernel(GruSeqBatch batch
 #pragma unroll
             for (int g = 0; g < 3; ++g) { GRU_MFMA6(acc[g], ah, am, al, wh[g][ks], wm[g][ks], wl[g][ks]); }
         }
+#ifdef ARVAE_GRU_STAMPS
+        { float dep = acc[0][0] + acc[1][0] + acc[2][3]; asm volatile("" :: "v"(dep)); __builtin_amdgcn_s_waitcnt(0); }
+#endif
+        GSTAMP(1);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float r = fast_sigmoid(gi[i][0] + acc[0][i] + bh_r);
@@ -378,14 +399,24 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_x3_kernel(GruSeqBatch batch
             keep_sv[i] = f32x4{r, z, n, ghn};
         }
         keep_t = t;
+#ifdef ARVAE_GRU_STAMPS
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the LDS writes are done
+#endif
+        GSTAMP(2);
         __syncthreads();
+        GSTAMP(3);
     }
+#ifdef ARVAE_GRU_STAMPS
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        for (int k = 0; k < 4; ++k) g_gru_stamps[k] = ph[k];
+        g_gru_stamps[4] = T;
+    }
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i)
         if (live[i]) {
-            const int64_t tr = (int64_t)keep_t * R + rows[i];
-            s.h_all[tr * s.h_stride + unit] = keep_h[i];
-            *reinterpret_cast<f32x4 *>(s.saved + (tr * H + unit) * 4) = keep_sv[i];
+            *h_p[i] = keep_h[i];
+            *reinterpret_cast<f32x4 *>(sv_p[i]) = keep_sv[i];
         }
 }
 
@@ -1033,3 +1064,9 @@ extern "C" int arvae_tick_free_run(const arvae_tick_weights_t *wts, const float 
     }
     return check_launch("tick_free_run_x3_kernel");
 }
+
+#ifdef ARVAE_GRU_STAMPS
+extern "C" int arvae_debug_gru_stamps(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(arvae::g_gru_stamps), sizeof(unsigned long long) * 8);
+}
+#endif
