@@ -270,6 +270,14 @@ __device__ __forceinline__ void store_split3(unsigned short *p, int plane, float
     split3_pair(x, 0.f, a, b, c);
     p[0] = (unsigned short)a; p[plane] = (unsigned short)b; p[2 * plane] = (unsigned short)c;
 }
+// two values (rows `rowpitch` apart in every plane) for the price of one split
+__device__ __forceinline__ void store_split3_pair(unsigned short *p, int rowpitch, int plane, float x0, float x1) {
+    unsigned a, b, c;
+    split3_pair(x0, x1, a, b, c);
+    p[0] = (unsigned short)a; p[rowpitch] = (unsigned short)(a >> 16);
+    p[plane] = (unsigned short)b; p[plane + rowpitch] = (unsigned short)(b >> 16);
+    p[2 * plane] = (unsigned short)c; p[2 * plane + rowpitch] = (unsigned short)(c >> 16);
+}
 __device__ __forceinline__ bf16x8g lds_x8(const unsigned short *p) {
     return __builtin_bit_cast(bf16x8g, *reinterpret_cast<const i32x4g *>(p));
 }
@@ -394,10 +402,11 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_x3_kernel(GruSeqBatch batch
             const float n = fast_tanh(gi[i][2] + r * ghn);
             const float hn = (1.f - z) * n + z * h[i];
             h[i] = hn;
-            store_split3(&hbuf[cur ^ 1][(4 * quad + i) * HP + unit], PLANE, hn);
             keep_h[i] = hn;
             keep_sv[i] = f32x4{r, z, n, ghn};
         }
+        store_split3_pair(&hbuf[cur ^ 1][(4 * quad) * HP + unit], HP, PLANE, h[0], h[1]);
+        store_split3_pair(&hbuf[cur ^ 1][(4 * quad + 2) * HP + unit], HP, PLANE, h[2], h[3]);
         keep_t = t;
 #ifdef ARVAE_GRU_STAMPS
         __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the LDS writes are done
@@ -486,11 +495,14 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_x3_kernel(GruSeqBatch batch
             const float dpr = dpn * ghn * r * (1.f - r);
             const float dhn = dpn * r;
             gz[i] = g * z;
-            unsigned short *d = &dbuf[cur][(4 * quad + i) * DP + unit];
-            store_split3(d, PLANE, dpr);
-            store_split3(d + H, PLANE, dpz);
-            store_split3(d + 2 * H, PLANE, dhn);
             o_gi[i][0] = dpr; o_gi[i][1] = dpz; o_gi[i][2] = dpn; o_hn[i] = dhn; o_hp[i] = hp;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i += 2) {
+            unsigned short *d = &dbuf[cur][(4 * quad + i) * DP + unit];
+            store_split3_pair(d, DP, PLANE, o_gi[i][0], o_gi[i + 1][0]);
+            store_split3_pair(d + H, DP, PLANE, o_gi[i][1], o_gi[i + 1][1]);
+            store_split3_pair(d + 2 * H, DP, PLANE, o_hn[i], o_hn[i + 1]);
         }
         if (step + 1 < T) fetch(step + 1);
         __syncthreads();
