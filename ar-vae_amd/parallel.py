@@ -39,13 +39,15 @@ class DataParallel:
         for p in model.parameters():
             dist.broadcast(p.data, src=src, group=self.group)
 
-    def gather_columns(self, local):
-        """(B_local, R) -> (W * B_local, R), rank-major row order."""
+    def gather_columns(self, local, async_op=None):
+        """(B_local, R) -> (W * B_local, R), rank-major row order.  With async_op the collective is only enqueued:
+        -> (out, work); call work.wait() before the first kernel that reads `out` (it overlaps whatever is launched
+        in between)."""
         local = local.contiguous()
         out = torch.empty((self.world_size * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype,
                           device=local.device)
-        dist.all_gather_into_tensor(out, local, group=self.group)
-        return out
+        work = dist.all_gather_into_tensor(out, local, group=self.group, async_op=bool(async_op))
+        return out if async_op is None else (out, work if async_op else None)
 
     def reg_loss(self, z, labels, dims, gamma, delta):
         """W * (row-block regularisation loss of this rank's samples against the global batch)."""
