@@ -33,6 +33,35 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     assert sorted(_lib.SIGNATURES) == names
 
 
+def test_ctypes_structs_match_the_header(tmp_path):
+    """sizeof / field offsets of every struct in include/arvae_hip.h as gcc lays them out == the ctypes mirrors."""
+    import shutil
+    import subprocess
+    from arvae_amd import _lib
+    gcc = shutil.which('gcc')
+    if gcc is None:
+        pytest.skip('gcc not available')
+    structs = {'arvae_link_t': (_lib.LinkDesc, 'n', 'lo_perm_hw'), 'arvae_operand_t': (_lib.OperandDesc, 'v', 'act'),
+               'arvae_gru_seq_t': (_lib.GruSeqDesc, 'gi', 'h_prev_out'),
+               'arvae_tick_weights_t': (_lib.TickWeights, 'w_hh0', 'b_out'),
+               'arvae_dense_wgrad_job_t': (_lib.DenseWgradJob, 'g', 'n_out'),
+               'arvae_image_vae_t': (_lib.ImageVaeDesc, 'n_enc', 'delta')}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{ROOT}/include/arvae_hip.h"', 'int main(void) {']
+    for name, (_, first, last) in structs.items():
+        lines.append(f'printf("{name} %zu %zu %zu\\n", sizeof({name}), offsetof({name}, {first}), offsetof({name}, {last}));')
+    lines += ['return 0; }']
+    src = tmp_path / 'sizes.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'sizes'
+    subprocess.run([gcc, '-o', str(exe), str(src)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split('\n')
+    for line in filter(None, out):
+        name, size, off_first, off_last = line.split()
+        cls, first, last = structs[name]
+        assert ctypes.sizeof(cls) == int(size), name
+        assert getattr(cls, first).offset == int(off_first) and getattr(cls, last).offset == int(off_last), name
+
+
 def test_abi_version_and_error_string(lib):
     from arvae_amd import _lib
     assert lib.arvae_abi_version() == _lib.ABI_VERSION
