@@ -10,6 +10,7 @@ namespace arvae {
 // fast kernels with a gated epilogue (conv32.hip / conv_c1.hip / dense.hip)
 bool conv32_fits(const arvae_link_t *l);
 bool conv_c1_fits(const arvae_link_t *l);
+bool conv64_fits(const arvae_link_t *l, bool up);
 int conv32_down(const arvae_link_t *l, const Operand &hi, const float *wt, const float *bias, int relu, const float *gate,
                 const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s, const float *wprep = nullptr);
 int conv32_up(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, int relu, const float *gate,
@@ -239,7 +240,16 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
                           const uint16_t *gate_bits = nullptr, const float *wprep = nullptr) {
     arvae_link_t lk = l.link;
     lk.n = n;
-    const arvae_operand_t gop = g_is_pre ? plain(g) : arvae_operand_t{g, out, mask, l.act};
+    arvae_operand_t gop = g_is_pre ? plain(g) : arvae_operand_t{g, out, mask, l.act};
+    // The wide stride-1 convolutions gather their operands once per tap: fold the activation derivative / keep-mask into
+    // the upstream gradient once, in place (it is this executor's scratch and has no other reader), and hand the data
+    // gradient, the weight gradient and the bias sums ONE plain tensor instead of three tensors each (MNIST: 780 -> 520 us
+    // per data-gradient launch).
+    if (!g_is_pre && (mask != nullptr || l.act != ARVAE_ACT_NONE) && (conv64_fits(&lk, false) || conv64_fits(&lk, true))) {
+        const int64_t count = (int64_t)n * (l.is_up ? (int64_t)lk.hh * lk.hw * lk.chi : (int64_t)lk.lh * lk.lw * lk.clo);
+        if (int rc = arvae_operand_apply(&gop, count, const_cast<float *>(g), st)) return rc;
+        gop = plain(g);
+    }
     const arvae_operand_t xin = plain(in);
     const float *w = params + l.w_off;
     float *dw = grads + l.w_off, *db = l.b_off >= 0 ? grads + l.b_off : nullptr;
