@@ -179,7 +179,10 @@ LONG_BATCH_ROWS = 2048      # csrc/dense.h DENSE_SPLIT_MIN_ROWS: Linear layers o
 def _plain_gradient(g, y, mask, act, link, n):
     """operand of a Linear layer's output gradient; for long batches with an activation / mask to fold in, the folded
     gradient is written out once so that both the data- and the weight-gradient run on the plain-operand kernels."""
-    if (act != ACT_NONE or mask is not None) and n >= LONG_BATCH_ROWS and link.hh == link.hw == link.lh == link.lw == 1:
+    dense_long = n >= LONG_BATCH_ROWS and link.hh == link.hw == link.lh == link.lw == 1
+    # the wide stride-1 convolution kernels (csrc/conv64.hip) gather their operands once per tap
+    wide_conv = link.stride == 1 and link.kh * link.kw > 1 and (link.chi % 32 == 0 or link.clo % 32 == 0)
+    if (act != ACT_NONE or mask is not None) and (dense_long or wide_conv):
         lib = _lib.load()
         out = torch.empty_like(g)
         op = _operand(g, y, mask, act)
@@ -302,7 +305,7 @@ class _LinkUpFn(Function):
         lo, wt, hi, mask = ctx.saved_tensors
         link, n = ctx.link, ctx.n
         g_hi = g_hi.contiguous()
-        gop = _operand(g_hi, hi, mask, ctx.act)
+        gop, _keep = _plain_gradient(g_hi, hi, mask, ctx.act, link, n)
         d_lo = d_wt = d_bias = None
         if ctx.needs_input_grad[0]:
             d_lo = link_down(link, n, gop, wt, None, ACT_NONE, None)
