@@ -19,9 +19,12 @@ from ._lib import ImageVaeDesc, LayerDesc
 LOSS, RECON, DIST, REG, ACC, KL, NSCALARS = 0, 1, 2, 3, 4, 5, 8
 
 
-# opt-in: the label all-gather stays in flight during the forward pass (hides one collective's latency on several GPUs;
-# measured +15 us of host/stream overhead on a single rank, where there is nothing to hide)
-_ASYNC_LABEL_GATHER = os.environ.get('ARVAE_DP_ASYNC_GATHER', '0') == '1'
+# The label all-gather can stay in flight during the forward pass (it hides one collective's latency on several GPUs, but
+# costs +15 us of host / stream overhead on a single rank, where there is nothing to hide): on by default when there is
+# more than one rank; ARVAE_DP_ASYNC_GATHER=0 / 1 forces it.
+def _async_label_gather(dp):
+    forced = os.environ.get('ARVAE_DP_ASYNC_GATHER')
+    return forced == '1' if forced in ('0', '1') else dp.world_size > 1
 
 
 def _layer_desc(link, is_up, act, dropout, w_off, b_off):
@@ -139,7 +142,7 @@ class _FusedStepFn(Function):
         if rowblock:                                             # the label columns do not depend on this pass: gather first
             external_reg = True
             labels = labels.contiguous()
-            lab_all, lab_work = dp.gather_columns(labels, async_op=_ASYNC_LABEL_GATHER)   # in flight during the forward pass
+            lab_all, lab_work = dp.gather_columns(labels, async_op=_async_label_gather(dp))   # in flight during the forward pass
         with ops._timed('image_vae_forward'):
             _lib.check(lib.arvae_image_vae_forward(
                 ctypes.byref(desc), b, ops._ptr(opt.param_arena), ops._ptr(x), ops._ptr(labels),
