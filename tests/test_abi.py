@@ -80,6 +80,20 @@ def test_argument_validation_without_gpu(lib):
     assert rc == -1 and b'does not match' in lib.arvae_last_error_string()
     assert lib.arvae_reg_loss_ws_floats(512, 5) == 2 * 512 * 5
     assert lib.arvae_adam_step(None, None, None, None, 0, 0, 1e-4, 0.9, 0.999, 1e-8, 1.0, None) == -1
+    # the MeasureVAE sequence entry points
+    from arvae_amd._lib import GruSeqDesc, TickWeights, DenseWgradJob
+    assert lib.arvae_gru_seq_supported(128) == 1 and lib.arvae_gru_seq_supported(512) == 0
+    assert lib.arvae_gru_seq_fwd(None, 1, 24, 16, 128, None) == -1
+    seqs = (GruSeqDesc * 1)()
+    assert lib.arvae_gru_seq_fwd(seqs, 1, 24, 16, 128, None) == -1 and b'null' in lib.arvae_last_error_string()
+    assert lib.arvae_gru_seq_fwd(seqs, 1, 24, 16, 100, None) == -1 and b'hidden size' in lib.arvae_last_error_string()
+    assert lib.arvae_gru_seq_bwd(seqs, 5, 24, 16, 128, None) == -1
+    assert lib.arvae_tick_free_run(ctypes.byref(TickWeights()), None, None, None, None, None, 2.0, 8, 4, 6, 128, 35, None,
+                                   None, None) == -1
+    assert lib.arvae_tick_free_run_ws_floats(128) == 3 * 3 * 128 * 128 * 3 // 2
+    assert lib.arvae_embed_bwd_ws_floats(256, 24, 10, 35) == (256 * 24 // 64) * 35 * 10
+    assert lib.arvae_dense_wgrad_batch((DenseWgradJob * 1)(), 1, None) == -1
+    assert lib.arvae_operand_apply(None, 4, None, None) == -1
 
 
 def test_cpu_tensors_are_refused():
