@@ -3,8 +3,10 @@
 Same class names, constructor arguments, forward contract and state_dict keys as the reference
 (measurevae/encoder.py:8-124, measurevae/decoder.py:7-51,309-525, measurevae/measure_vae.py:11-131):
     MeasureVAE.forward(score, metadata, train) -> (weights (B,24,V), samples (B,1,24), z_dist, prior_dist, z_tilde, z_prior)
-The GEMMs of the GRUs run on the dense MFMA kernels, the gate math / embedding / argmax feedback on the
-sequence kernels (csrc/sequence.hip); autograd chains them (round 1: one autograd node per kernel).
+Every GRU layer runs as whole-sequence launches (csrc/gru_seq.hip: all time steps of a layer, both directions, in one
+kernel forward and one backward; input projections and weight gradients as whole-sequence GEMMs); the free-running
+decoder gets its tokens from one more launch.  Hidden sizes other than 32 / 64 / 128 (or ARVAE_GRU_STEPWISE=1) fall back
+to one launch per GRU cell and time step (csrc/sequence.hip + the dense kernels).  autograd only chains the launches.
 """
 import os
 from collections import deque
