@@ -1,9 +1,10 @@
 """Forward + backward of a training step replayed from HIP graphs (torch.cuda.CUDAGraph).
 
-The MeasureVAE step is ~2 000 small kernels issued from Python: eager, the host sets the pace (31 ms per step at
-B = 256).  Every launch of the library goes to torch's current stream and nothing in the step synchronises, so the whole
-forward + backward can be captured once and replayed: 7.6 ms per step on MI355X.  The optimizer stays outside (its
-bias corrections are host scalars), as does the host-side teacher-forcing coin: one graph per control-flow variant.
+The MeasureVAE step is a few hundred small launches issued from Python (whole-sequence GRU kernels, whole-sequence
+GEMMs, glue): eager, the host sets the pace (3.9 ms per step at B = 256).  Every launch of the library goes to torch's
+current stream and nothing in the step synchronises, so the whole forward + backward can be captured once and replayed:
+1.53 ms per step on MI355X.  The optimizer stays outside (its bias corrections are host scalars), as does the host-side
+teacher-forcing coin: one graph per control-flow variant.
 
     graphed = GraphedStep(trainer, example_batch)        # captures (after a few warm-up iterations)
     for batch in loader:
