@@ -43,6 +43,13 @@ constexpr int PSB3 = 52;                // LDS pixel stride in dwords of the pac
                                         // three padded planes, which lets a second buffer fit
 constexpr int PSB = 20;                 // LDS pixel stride in dwords of one bf16 plane (16 payload + 4 pad: conflict-free
                                         // 16-byte reads for pixel walks of stride 1 and 2)
+#ifndef ARVAE_WGRAD_PSB_H
+#define ARVAE_WGRAD_PSB_H 24
+#endif
+#ifndef ARVAE_WGRAD_PSB_L
+#define ARVAE_WGRAD_PSB_L 16
+#endif
+constexpr int WGRAD_PSB_H = ARVAE_WGRAD_PSB_H, WGRAD_PSB_L = ARVAE_WGRAD_PSB_L;   // plane pitches of wgrad32x_kernel (see there)
 constexpr int PIXB = C32 * 4;           // bytes of one 32-channel pixel
 constexpr unsigned OOB = 0x7fffffffu;   // byte offset beyond any tensor here: loads return 0, stores are dropped
 
@@ -217,9 +224,11 @@ struct PatchLoader {
             }
         }
     }
-    // three planes (hi, mid, lo): the exact split used by the fp32-accurate bf16 kernels; BIAS_SUM as in commit()
-    template <bool BIAS_SUM = false>
+    // three planes (hi, mid, lo): the exact split used by the fp32-accurate bf16 kernels; BIAS_SUM as in commit();
+    // PITCH = dwords per pixel and plane
+    template <bool BIAS_SUM = false, int PITCH = PSB>
     __device__ __forceinline__ void commit_split3(unsigned *planes, float4 *bsum = nullptr) const {
+        constexpr int PLANE_P = T::TI * PR * PC * PITCH;
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             const int idx = threadIdx.x + it * 256;
@@ -228,9 +237,9 @@ struct PatchLoader {
                 uint2 hv, mv, lv;
                 split_pair3(r[it].x, r[it].y, hv.x, mv.x, lv.x);
                 split_pair3(r[it].z, r[it].w, hv.y, mv.y, lv.y);
-                *reinterpret_cast<uint2 *>(planes + pix * PSB + q * 2) = hv;
-                *reinterpret_cast<uint2 *>(planes + PLANE_DW + pix * PSB + q * 2) = mv;
-                *reinterpret_cast<uint2 *>(planes + 2 * PLANE_DW + pix * PSB + q * 2) = lv;
+                *reinterpret_cast<uint2 *>(planes + pix * PITCH + q * 2) = hv;
+                *reinterpret_cast<uint2 *>(planes + PLANE_P + pix * PITCH + q * 2) = mv;
+                *reinterpret_cast<uint2 *>(planes + 2 * PLANE_P + pix * PITCH + q * 2) = lv;
                 if (BIAS_SUM) {
                     const int pc = pix % PC, pr = (pix / PC) % PR;
                     if (pr >= 1 && pr <= PR - 2 && pc >= 1 && pc <= PC - 2) {
@@ -1344,7 +1353,12 @@ __global__ __launch_bounds__(256, 1) void wgrad32x_kernel(const float *__restric
                                                           float *__restrict__ slab, int n_img, int n_tiles) {
     constexpr int PX = 64, KB = PX / 16;                         // pixels per tile, 16-pixel K blocks per tile
     using PL = PatchLoader<LO, 2, PX>;
-    constexpr int PC = PL::PC, PR = PL::PR, PLANE = PL::PLANE_DW, LPLANE = PX * PSB;
+    // plane pitches (dwords per pixel) chosen for the transposed reads: a block is 4 consecutive K pixels x 16 dwords and
+    // the 64-bank LDS serves it without conflicts when the four rows land on the four 16-dword quarters -- consecutive lo
+    // pixels are WG_PSB_L apart, the hi pixels under them 2 * WG_PSB_H (stride 2): 16 and 48 dwords.  (With the common
+    // pitch of 20 the fourth row wrapped onto the first: 17 % of the kernel's wave cycles were LDS bank conflicts.)
+    constexpr int WG_PSB_L = WGRAD_PSB_L, WG_PSB_H = WGRAD_PSB_H;
+    constexpr int PC = PL::PC, PR = PL::PR, PLANE = PL::PLANE_DW / PSB * WG_PSB_H, LPLANE = PX * WG_PSB_L;
     extern __shared__ __attribute__((aligned(16))) float lds[];  // hi patch: 3 planes | lo tile: 3 planes
     unsigned *ldsw = reinterpret_cast<unsigned *>(lds);
     unsigned *lo_w = ldsw + 3 * PLANE;
@@ -1363,8 +1377,8 @@ __global__ __launch_bounds__(256, 1) void wgrad32x_kernel(const float *__restric
                 const int P = 16 * b + 8 * (g16 >> 1) + 4 * i + q;
                 int img, r, c;
                 tile_pixel<LO, PX>(P, img, r, c);
-                loff[b][i] = P * PSB + 8 * (g16 & 1) + 2 * pp;
-                hoff[b][i] = ((img * PR + 2 * r + wave) * PC + 2 * c) * PSB + 8 * (g16 & 1) + 2 * pp;      // + kx * PSB
+                loff[b][i] = P * WG_PSB_L + 8 * (g16 & 1) + 2 * pp;
+                hoff[b][i] = ((img * PR + 2 * r + wave) * PC + 2 * c) * WG_PSB_H + 8 * (g16 & 1) + 2 * pp;      // + kx * WG_PSB_H
             }
     }
 
@@ -1394,16 +1408,16 @@ __global__ __launch_bounds__(256, 1) void wgrad32x_kernel(const float *__restric
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         __syncthreads();
-        pl.template commit_split3<BIAS == 2>(ldsw, &bias4);
+        pl.template commit_split3<BIAS == 2, WG_PSB_H>(ldsw, &bias4);
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int idx = threadIdx.x + it * 256, pix = idx >> 3, q = idx & 7;
             uint2 hv, mv, lv;
             split_pair3(lr[it].x, lr[it].y, hv.x, mv.x, lv.x);
             split_pair3(lr[it].z, lr[it].w, hv.y, mv.y, lv.y);
-            *reinterpret_cast<uint2 *>(lo_w + pix * PSB + q * 2) = hv;
-            *reinterpret_cast<uint2 *>(lo_w + LPLANE + pix * PSB + q * 2) = mv;
-            *reinterpret_cast<uint2 *>(lo_w + 2 * LPLANE + pix * PSB + q * 2) = lv;
+            *reinterpret_cast<uint2 *>(lo_w + pix * WG_PSB_L + q * 2) = hv;
+            *reinterpret_cast<uint2 *>(lo_w + LPLANE + pix * WG_PSB_L + q * 2) = mv;
+            *reinterpret_cast<uint2 *>(lo_w + 2 * LPLANE + pix * WG_PSB_L + q * 2) = lv;
             if (BIAS == 1) { bias4.x += lr[it].x; bias4.y += lr[it].y; bias4.z += lr[it].z; bias4.w += lr[it].w; }
         }
         __syncthreads();
@@ -1425,7 +1439,7 @@ __global__ __launch_bounds__(256, 1) void wgrad32x_kernel(const float *__restric
                 bf16x8 a3[3];                                    // hi values at tap (ky = wave, kx): A operand, row = chi
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
-                    a3[t] = lds_tr_bf16x8(ldsw + t * PLANE + hoff[b][0] + kx * PSB, ldsw + t * PLANE + hoff[b][1] + kx * PSB);
+                    a3[t] = lds_tr_bf16x8(ldsw + t * PLANE + hoff[b][0] + kx * WG_PSB_H, ldsw + t * PLANE + hoff[b][1] + kx * WG_PSB_H);
                 MFMA_B(acc[kx], a3[2], b3[0]);                   // smallest partial products first
                 MFMA_B(acc[kx], a3[0], b3[2]);
                 MFMA_B(acc[kx], a3[1], b3[1]);
@@ -1690,7 +1704,7 @@ template <int LO, int PX> static int launch_wgrad(const arvae_link_t *l, const O
 
 template <int LO> static int launch_wgrad_x(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *slab, int bias_mode,
                                             int grid, hipStream_t s) {
-    constexpr int LDS = 3 * (PatchLoader<LO, 2, 64>::PLANE_DW + 64 * PSB) * 4;
+    constexpr int LDS = 3 * (PatchLoader<LO, 2, 64>::PLANE_DW / PSB * WGRAD_PSB_H + 64 * WGRAD_PSB_L) * 4;
     const int tiles = tiles_for<LO, 64>(l->n);
     static bool attr = false;
     if (!attr) {
