@@ -853,7 +853,7 @@ extern "C" int arvae_link_wgrad(const arvae_link_t *link, const arvae_operand_t 
 
 static void channel_sum_split(int64_t rows, int64_t &blocks, int64_t &rpb) {
     blocks = (rows + 15) / 16;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 1024) blocks = 1024;          // measured: 2048 blocks made the one-workgroup finish stage as slow as the sums
     if (blocks < 1) blocks = 1;
     rpb = (rows + blocks - 1) / blocks;
     blocks = (rows + rpb - 1) / rpb;
