@@ -278,7 +278,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
     const int i = blockIdx.x * 64 + il;
     float s = 0.f;
     if (i < mn)
-        for (int z = zg; z < zsplit; z += 4) s += slab[(int64_t)z * mn + i];
+        for (int z0 = zg; z0 < zsplit; z0 += 32) {           // 8 loads in flight, added in slab order
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int z = z0 + 4 * u;
+                const float v = slab[(int64_t)(z < zsplit ? z : zg) * mn + i];
+                t[u] = z < zsplit ? v : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += t[u];
+        }
     red[zg][il] = s;
     __syncthreads();
     if (zg == 0 && i < mn) {
