@@ -58,8 +58,9 @@ __global__ __launch_bounds__(256) void conv_rows_x3_kernel(ConvRows g) {
     const int wp = wave & 1, wq = wave >> 1;
     const int p0 = blockIdx.x * C64_TP, q0 = blockIdx.y * C64_TQ;
     const int M = g.n * g.oh * g.ow;
-    const int cpt = g.cs / RG_R;                               // chunks per tap
-    const int chunks = g.kh * g.kw * cpt;
+    // reduction index kk = tap * cs + c, walked in chunks of RG_R; a chunk lies inside one tap when 32 | cs, and spans
+    // several taps for narrow sources (cs = 8: four taps per chunk), so the tap is worked out per gather slot
+    const int chunks = g.kh * g.kw * g.cs / RG_R;
 
     // this thread's two gather slots: (pixel, 4 channels)
     int oy[2], ox[2], c4[2];
@@ -88,16 +89,17 @@ __global__ __launch_bounds__(256) void conv_rows_x3_kernel(ConvRows g) {
         if (!qok[i]) wq_row[i] = 0;
     }
     float4 va[2], vb[2];
+    const int kwidth = g.kh * g.kw * g.cs;
     auto load = [&](int chunk) {
-        const int tap = chunk / cpt, c0 = (chunk - tap * cpt) * RG_R;
-        const int ky = tap / g.kw, kx = tap - ky * g.kw;
-        const int dy = g.sgn * ky + g.off, dx = g.sgn * kx + g.off;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int sy = oy[i] + dy, sx = ox[i] + dx;
+            const int kk = chunk * RG_R + c4[i];                 // c4[i] == wc4[i]: the slot's offset inside the chunk
+            const int tap = kk / g.cs, c = kk - tap * g.cs;
+            const int ky = tap / g.kw, kx = tap - ky * g.kw;
+            const int sy = oy[i] + g.sgn * ky + g.off, sx = ox[i] + g.sgn * kx + g.off;
             const bool ok = pok[i] && sy >= 0 && sy < g.sh && sx >= 0 && sx < g.sw;
-            va[i] = load_src4<PLAIN>(g.src, ((img_base[i] + (int64_t)sy * g.sw + sx) * g.cs + c0 + c4[i]), ok);
-            const float4 w = *reinterpret_cast<const float4 *>(g.wt + ((int64_t)wq_row[i] * g.kh * g.kw + tap) * g.cs + c0 + wc4[i]);
+            va[i] = load_src4<PLAIN>(g.src, ((img_base[i] + (int64_t)sy * g.sw + sx) * g.cs + c), ok);
+            const float4 w = *reinterpret_cast<const float4 *>(g.wt + (int64_t)wq_row[i] * kwidth + kk);
             vb[i] = qok[i] ? w : float4{0.f, 0.f, 0.f, 0.f};
         }
     };
@@ -163,8 +165,8 @@ bool conv64_fits(const arvae_link_t *l, bool up) {
     static const bool off = getenv("ARVAE_CONV64_GENERIC") != nullptr;
     const int red = up ? l->clo : l->chi, outc = up ? l->chi : l->clo;
     // narrow outputs (the 64 -> 8 layers) waste MFMA columns but these products are bound by the gather, not the MFMA
-    return !off && l->stride == 1 && l->kh * l->kw <= 16 && l->kh * l->kw > 1 && red % RG_R == 0 && outc >= 4 &&
-           red <= 128 && outc <= 128 && l->hi_perm_c == 0 && l->lo_perm_c == 0;
+    return !off && l->stride == 1 && l->kh * l->kw <= 16 && l->kh * l->kw > 1 && red % 4 == 0 && red >= 8 &&
+           (l->kh * l->kw * red) % RG_R == 0 && outc >= 4 && red <= 128 && outc <= 128 && l->hi_perm_c == 0 && l->lo_perm_c == 0;
 }
 
 static int launch_conv_rows(ConvRows g, const float *wt, bool transposed, hipStream_t s, const char *what) {
