@@ -84,6 +84,7 @@ class MeasureVAETrainer(Trainer):
         self.model.update_trainer_config(self.trainer_config)
         self._tables = None
         self.last_terms = {}
+        self.use_graph_replay = True          # a few hundred small launches per step: replayed from HIP graphs (trainer.py)
 
     def process_batch_data(self, batch):
         score, metadata = batch
@@ -136,12 +137,20 @@ class MeasureVAETrainer(Trainer):
             loss = loss + reg_loss
         self.last_terms = {'recons': recons_loss.detach(), 'dist': dist_loss.detach(),
                            'reg': None if reg_loss is None else reg_loss.detach()}
-        if first_of_epoch and self.writer is not None:
-            self.writer.add_scalar('loss_split/recons_loss', recons_loss.item(), epoch_num)
-            self.writer.add_scalar('loss_split/dist_loss', (dist_loss / self.beta).item(), epoch_num)
-            if reg_loss is not None:
-                self.writer.add_scalar('loss_split/reg_loss', (reg_loss / self.gamma).item(), epoch_num)
+        if first_of_epoch and self.writer is not None and not torch.cuda.is_current_stream_capturing():
+            self.log_loss_split(epoch_num)
         return loss, accuracy
+
+    def log_loss_split(self, epoch_num):
+        """the loss terms of the last step to the summary writer (measure_vae_trainer.py:116-127); also called by the
+        epoch loop after the first graph-replayed step of an epoch, whose terms live in the captured step's outputs."""
+        t = self.last_terms
+        if self.writer is None or not t:
+            return
+        self.writer.add_scalar('loss_split/recons_loss', t['recons'].item(), epoch_num)
+        self.writer.add_scalar('loss_split/dist_loss', (t['dist'] / self.beta).item(), epoch_num)
+        if t['reg'] is not None:
+            self.writer.add_scalar('loss_split/reg_loss', (t['reg'] / self.gamma).item(), epoch_num)
 
     # -- evaluation-only inference (measure_vae_trainer.py:188-212) ---------------------------------------------------
     def compute_representations(self, data_loader, num_batches=None):

@@ -58,16 +58,48 @@ class Trainer(ABC):
             self.print_epoch_stats(epoch, num_epochs, loss_tr, acc_tr, loss_va, acc_va)
             self.model.save()
 
+    # Training steps replayed from HIP graphs (ar-vae_amd/graphed.py).  Worth it where the step is many small launches and
+    # the host sets the pace (MeasureVAE: 3.9 -> 1.5 ms per step); subclasses switch it on.  Batches of another shape
+    # (the last one of an epoch), data-parallel runs and CPU models take the eager path.
+    use_graph_replay = False
+
+    def _replay_step(self, batch):
+        """-> (loss, accuracy) of zero_grad + loss + backward replayed from a captured graph, or None (run it eagerly)."""
+        if not self.use_graph_replay or self.data_parallel is not None or not torch.cuda.is_available():
+            return None
+        if not next(self.model.parameters()).is_cuda:
+            return None
+        graphed = getattr(self, '_graphed', None)
+        try:
+            if graphed is None:
+                from .graphed import GraphedStep
+                self.model.train()
+                graphed = self._graphed = GraphedStep(self, batch)
+            return graphed(batch)
+        except ValueError:                                     # a batch of another shape
+            return None
+        except RuntimeError as e:                              # capture not possible here: stay eager from now on
+            print(f'graph replay disabled: {e}')
+            self.use_graph_replay = False
+            return None
+
     def loss_and_acc_on_epoch(self, data_loader, epoch_num=None, train=True):
         loss_sum = acc_sum = None
         count = 0
         for batch_num, batch in enumerate(data_loader):
-            batch_data = self.process_batch_data(batch)
-            self.zero_grad()
-            loss, accuracy = self.loss_and_acc_for_batch(batch_data, epoch_num, batch_num, train=train)
-            if train:
-                loss.backward()
+            replayed = self._replay_step(batch) if train else None
+            if replayed is not None:
+                loss, accuracy = replayed
                 self.step()
+                if batch_num == 0 and hasattr(self, 'log_loss_split'):
+                    self.log_loss_split(epoch_num)
+            else:
+                batch_data = self.process_batch_data(batch)
+                self.zero_grad()
+                loss, accuracy = self.loss_and_acc_for_batch(batch_data, epoch_num, batch_num, train=train)
+                if train:
+                    loss.backward()
+                    self.step()
             l = loss.detach().mean()
             loss_sum = l if loss_sum is None else loss_sum + l
             if accuracy is not None:

@@ -901,6 +901,46 @@ def test_graphed_measure_step_matches_eager(dev):
         model.encoder.static_eps = None
 
 
+def test_measure_epoch_loop_replays_graphs(dev):
+    """Trainer.loss_and_acc_on_epoch of the MeasureVAE trainer replays captured graphs for full batches and runs the
+    odd-sized last batch eagerly; the weights after the epoch equal those of an all-eager epoch (dropout off, fixed noise
+    buffer, teacher forcing pinned on)."""
+    from arvae_amd.measure_vae import MeasureVAE
+    from arvae_amd.measure_vae_trainer import MeasureVAETrainer
+    b = 32
+    batches = [torch.from_numpy(syn.measure_batch(n, seed=40 + i)).to(dev) for i, n in enumerate((b, b, b, 20))]
+    loader = [(x, x) for x in batches]
+    final = {}
+    for replay in (True, False):
+        ds = _FolkDataset()
+        torch.manual_seed(0)
+        model = MeasureVAE(ds, 10, 2, 2, 64, 0.0, 16, 2, 64, 0.0, False, 'folk')
+        trainer = MeasureVAETrainer(ds, model, lr=1e-3, reg_type=('all',), reg_dim=(0, 1, 2, 3), beta=0.001, gamma=1.0,
+                                    capacity=0.0, rand=0, delta=10.0)
+        assert trainer.use_graph_replay
+        trainer.use_graph_replay = replay
+        trainer.cuda()
+        model.train()
+        model.decoder.teacher_forcing_prob = 2.0
+        try:
+            # one noise buffer for every batch size: rows [0, n) are used
+            noise = torch.from_numpy(syn.normal_noise((b, 16), seed=3)).to(dev)
+            losses = []
+            for x in loader:
+                model.encoder.static_eps = noise[:x[0].shape[0]].contiguous() if x[0].shape[0] != b else noise
+                l, _ = trainer.loss_and_acc_on_epoch([x], epoch_num=0, train=True)
+                losses.append(l)
+        finally:
+            type(model.encoder).static_eps = None
+            model.encoder.static_eps = None
+        assert (getattr(trainer, '_graphed', None) is not None) == replay
+        final[replay] = (losses, {k: v.detach().clone() for k, v in model.state_dict().items()})
+    for a, c in zip(final[True][0], final[False][0]):
+        close(a, c, rtol=1e-6)
+    for k, v in final[False][1].items():
+        assert torch.equal(final[True][1][k], v), k
+
+
 def test_data_parallel_path_single_rank_rccl(dev):
     """world_size 1 over RCCL: the all-gather / all-reduce code path runs on the GPU and must give the same
     loss and gradients as the plain single-process step."""
