@@ -10,7 +10,7 @@ import threading
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libarvae_hip.so')
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_i32, c_i64, c_f32, c_f64, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
 
@@ -94,6 +94,7 @@ SIGNATURES = {
     'arvae_gru_seq_fwd': (c_i32, [_P(GruSeqDesc), c_i32, c_i32, c_i32, c_i32, c_vp]),
     'arvae_gru_seq_bwd': (c_i32, [_P(GruSeqDesc), c_i32, c_i32, c_i32, c_i32, c_vp]),
     'arvae_tick_free_run_ws_floats': (c_i64, [c_i32]),
+    'arvae_tick_free_run_supported': (c_i32, [c_i32, c_i32]),
     'arvae_tick_free_run': (c_i32, [_P(TickWeights), c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_i32, c_i32, c_i32,
                                     c_vp, c_vp, c_vp]),
     'arvae_embed_fwd': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),

@@ -1029,6 +1029,10 @@ extern "C" int64_t arvae_tick_free_run_ws_floats(int32_t hidden) {
     return arvae_gru_seq_supported(hidden) ? (int64_t)3 * 3 * hidden * hidden * 3 / 2 : 0;
 }
 
+extern "C" int arvae_tick_free_run_supported(int32_t hidden, int32_t vocab) {
+    return arvae_gru_seq_supported(hidden) && vocab >= 1 && vocab <= 64 && vocab <= 16 * (hidden / 16);
+}
+
 extern "C" int arvae_tick_free_run(const arvae_tick_weights_t *wts, const float *h0_l0, const float *h0_l1, const float *gib,
                                    const float *ptab, const uint8_t *mask, float keep_scale, int32_t batch, int32_t beats,
                                    int32_t ticks_per_beat, int32_t hidden, int32_t vocab, int64_t *tokens, float *ws,
@@ -1038,7 +1042,8 @@ extern "C" int arvae_tick_free_run(const arvae_tick_weights_t *wts, const float 
                   "tick_free_run: null weight pointer");
     ARVAE_REQUIRE(batch >= 1 && beats >= 1 && ticks_per_beat >= 1, "tick_free_run: empty problem");
     ARVAE_REQUIRE(arvae_gru_seq_supported(hidden), "tick_free_run: hidden size %d is not built (32, 64, 128)", hidden);
-    ARVAE_REQUIRE(vocab >= 1 && vocab <= 16 * (hidden / 16) && vocab <= 64, "tick_free_run: vocabulary of %d notes not supported", vocab);
+    ARVAE_REQUIRE(arvae_tick_free_run_supported(hidden, vocab), "tick_free_run: vocabulary of %d notes not supported at hidden size %d",
+                  vocab, hidden);
     TickFreeRun p{};
     p.w_hh0 = wts->w_hh0; p.b_hh0 = wts->b_hh0; p.w_ih1 = wts->w_ih1; p.b_ih1 = wts->b_ih1;
     p.w_hh1 = wts->w_hh1; p.b_hh1 = wts->b_hh1; p.w_out = wts->w_out; p.b_out = wts->b_out;

@@ -6,6 +6,7 @@ Adam arena.  Autograd sees a single node: its backward accumulates every paramet
 gradient arena and returns nothing for the parameters.
 """
 import ctypes
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -42,6 +43,7 @@ class FusedImageVAE:
         self._desc = None
         self._arena_ptr = None
         self._ws = {}
+        self._ws_owner = None
 
     def _offset(self, param):
         opt = self.optimizer
@@ -94,25 +96,39 @@ class FusedImageVAE:
         self._desc, self._arena_ptr = d, arena.data_ptr()
         return d
 
-    def workspace(self, batch, device):
+    def workspace(self, batch, device, ctx=None):
+        """The activation workspace of one forward pass.  One batch-sized buffer is cached and lent to the pass that is in
+        flight; a forward that starts while an earlier pass still waits for its backward (two losses summed, a validation
+        forward in between, another batch size) gets a buffer of its own, so no pass can overwrite another's activations.
+        The buffer travels on the autograd ctx: backward reads exactly what its forward wrote."""
         key = (batch, str(device))
+        owner = self._ws_owner() if self._ws_owner is not None else None
+        busy = owner is not None and not getattr(owner, 'ws_released', True)
         ws = self._ws.get(key)
-        if ws is None:
+        if ws is None or busy:
             n = _lib.load().arvae_image_vae_ws_floats(ctypes.byref(self.descriptor()), batch, 0)
             if n < 0:
                 _lib.check(-1, 'image_vae_ws_floats')
-            ws = torch.empty(n, device=device, dtype=torch.float32)
+            fresh = torch.empty(n, device=device, dtype=torch.float32)
+            if busy:
+                return fresh                          # not cached: it lives and dies with this pass
+            ws = fresh
             self._ws = {key: ws}                      # keep one (batch-sized) workspace alive
+        if ctx is not None:
+            ctx.ws_released = False
+            self._ws_owner = weakref.ref(ctx)
         return ws
 
-    def run(self, x, labels, eps, masks, capacity, external_reg=False, reg_scale=1.0, dp=None):
+    def run(self, x, labels, eps, masks, capacity, external_reg=False, reg_scale=1.0, dp=None, capacity_nonzero=False):
         """-> (loss[1] with grad_fn, scalars[8], acc, z, mu, sigma, logits); loss is scalars[LOSS:LOSS+1].
 
         dp (arvae_amd.parallel.DataParallel): evaluate the regulariser on this rank's row block against the columns
         gathered from every rank, inside the same autograd node (no torch ops on the hot path): the loss returned is
-        recon + beta|KL - c| + W * reg_rowblock and scalars[REG] = W * reg_rowblock."""
+        recon + beta|KL - c| + W * reg_rowblock and scalars[REG] = W * reg_rowblock.  With capacity_nonzero the KL
+        mean is all-reduced first and the term becomes the global beta|KL_global - c| (parallel.py)."""
         anchor = self.optimizer.params[0]
-        return _FusedStepFn.apply(anchor, self, x, labels, eps, masks, capacity, bool(external_reg), float(reg_scale), dp)
+        return _FusedStepFn.apply(anchor, self, x, labels, eps, masks, capacity, bool(external_reg), float(reg_scale), dp,
+                                  bool(capacity_nonzero))
 
 
 def _mask_array(masks):
@@ -124,14 +140,14 @@ def _mask_array(masks):
 
 class _FusedStepFn(Function):
     @staticmethod
-    def forward(ctx, anchor, fused, x, labels, eps, masks, capacity, external_reg, reg_scale, dp=None):
+    def forward(ctx, anchor, fused, x, labels, eps, masks, capacity, external_reg, reg_scale, dp=None, capacity_nonzero=False):
         ops._dev(x, labels, eps, capacity)
         lib = _lib.load()
         desc = fused.descriptor()
         opt = fused.optimizer
         b = x.shape[0]
         dev = x.device
-        ws = fused.workspace(b, dev)
+        ws = ctx.ws = fused.workspace(b, dev, ctx)
         zd = fused.model.z_dim
         scalars = torch.empty(NSCALARS, device=dev, dtype=torch.float32)
         mu = torch.empty(b, zd, device=dev, dtype=torch.float32)
@@ -150,6 +166,14 @@ class _FusedStepFn(Function):
                 -1 if external_reg else 0, reg_scale, ops._ptr(ws), ops._ptr(scalars), ops._ptr(mu), ops._ptr(sigma),
                 ops._ptr(z), ops._ptr(logits), ops._stream()), 'image_vae_forward')
         ctx.dz_unit = None
+        if dp is not None and capacity_nonzero:
+            # beta*|KL - c| is not shard-linear for c != 0: use the global KL mean (one 4-byte all-reduce).  The backward
+            # pass takes sign(KL_local - c_r) with the shifted capacity c_r = c + KL_local - KL_global = sign(KL_global - c).
+            cap_r = dp.shifted_capacity(scalars[KL:KL + 1], capacity)
+            dist_g = fused.beta * (scalars[KL:KL + 1] - cap_r).abs()
+            scalars[LOSS:LOSS + 1].add_(dist_g - scalars[DIST:DIST + 1])
+            scalars[DIST:DIST + 1].copy_(dist_g)
+            capacity = cap_r
         if rowblock:
             z_all = dp.gather_columns(z)
             if lab_work is not None:
@@ -194,11 +218,12 @@ class _FusedStepFn(Function):
         if ctx.dz_unit is not None:                              # row-block regulariser evaluated in forward (data parallel)
             reg_mode, g_z = 2, ctx.dz_unit
         dz_extra = g_z.contiguous() if (ctx.external_reg and g_z is not None) else None
-        ws = fused.workspace(x.shape[0], x.device)
+        ws = ctx.ws
         with ops._timed('image_vae_backward'):
             _lib.check(lib.arvae_image_vae_backward(
                 ctypes.byref(fused.descriptor()), x.shape[0], ops._ptr(opt.param_arena), ops._ptr(opt.grad_arena),
                 ops._ptr(x), ops._ptr(eps), ctx.marr, ops._ptr(capacity), ops._ptr(mu), ops._ptr(sigma), ops._ptr(z),
                 ops._ptr(logits), ops._ptr(g_loss), ops._ptr(dz_extra), reg_mode, ctx.reg_scale,
                 ops._ptr(ws), ops._stream()), 'image_vae_backward')
-        return (None,) * 10
+        ctx.ws_released = True                                   # the cached workspace may serve the next forward
+        return (None,) * 11

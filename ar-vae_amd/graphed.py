@@ -23,6 +23,7 @@ class GraphedStep:
         if not torch.cuda.is_available():
             raise RuntimeError('GraphedStep needs a GPU')
         self.trainer = trainer
+        self.hyper = self.hyper_of(trainer)
         self.static = tuple(t.clone() for t in trainer.process_batch_data(example_batch))
         self.decoder = getattr(trainer.model, 'decoder', None)
         coin = self.decoder is not None and getattr(self.decoder, 'use_teacher_forcing', False)
@@ -30,22 +31,33 @@ class GraphedStep:
         self.prob = self.decoder.teacher_forcing_prob if coin else None
         self.graphs = {}
         trainer.model.train()
-        for variant in self.variants:
-            self._pin(variant)
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(warmup):
-                    self._eager()
-            torch.cuda.current_stream().wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = self._eager()
-            self.graphs[variant] = (graph, out)
-        self._pin(None)
+        try:                                                     # the decoder's coin is pinned only while capturing
+            for variant in self.variants:
+                self._pin(variant)
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(warmup):
+                        self._eager()
+                torch.cuda.current_stream().wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    out = self._eager()
+                # the loss terms of THIS variant's step live in its own static buffers (trainer.last_terms is rebound by
+                # every capture and by every eager step)
+                self.graphs[variant] = (graph, out, dict(getattr(trainer, 'last_terms', {}) or {}))
+        finally:
+            self._pin(None)
+
+    @staticmethod
+    def hyper_of(trainer):
+        """the hyper-parameters that are compiled into the captured launches as immediates"""
+        reg_dim = getattr(trainer, 'reg_dim', ())
+        return (float(getattr(trainer, 'beta', 0.0)), float(getattr(trainer, 'gamma', 0.0)),
+                float(getattr(trainer, 'delta', 0.0)), tuple(reg_dim) if isinstance(reg_dim, (tuple, list)) else reg_dim)
 
     def _pin(self, variant):
-        """force the decoder's host coin: 1.0 = always teacher-forced, 0.0 = never, None = restore"""
+        """force the decoder's host coin: 2.0 = always teacher-forced, -1.0 = never, None = restore"""
         if self.prob is not None:
             self.decoder.teacher_forcing_prob = self.prob if variant is None else (2.0 if variant else -1.0)
 
@@ -55,6 +67,11 @@ class GraphedStep:
         loss.backward()
         return loss.detach(), None if acc is None else acc.detach()
 
+    def accepts(self, batch):
+        """True when `batch` has the shapes this step was captured for"""
+        data = self.trainer.process_batch_data(batch)
+        return len(data) == len(self.static) and all(d.shape == s.shape for d, s in zip(data, self.static))
+
     def __call__(self, batch):
         data = self.trainer.process_batch_data(batch)
         for dst, src in zip(self.static, data):
@@ -62,6 +79,8 @@ class GraphedStep:
                 raise ValueError(f'GraphedStep was captured for batches of shape {tuple(dst.shape)}, got {tuple(src.shape)}')
             dst.copy_(src, non_blocking=True)
         variant = None if self.prob is None else bool(torch.rand(1).item() < self.prob)
-        graph, out = self.graphs[variant]
+        graph, out, terms = self.graphs[variant]
         graph.replay()
+        if terms:
+            self.trainer.last_terms = terms                      # what log_loss_split reads: the replayed variant's terms
         return out

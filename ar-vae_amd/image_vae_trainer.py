@@ -39,6 +39,7 @@ class ImageVAETrainer(Trainer):
         self.metrics = {}
         self.beta = beta
         self.capacity = torch.tensor([capacity], dtype=torch.float32)
+        self._capacity_nonzero = float(capacity) != 0.0
         self.gamma = 0.0
         self.delta = 0.0
         self.cur_epoch_num = 0
@@ -89,7 +90,11 @@ class ImageVAETrainer(Trainer):
 
         outputs, z_dist, prior_dist, z_tilde, _ = self.model(inputs)
         recons_loss, accuracy = ops.image_recon(outputs, inputs, self.dec_dist)
-        dist_loss = self.compute_kld_loss(z_dist, prior_dist, beta=self.beta, c=self.capacity)
+        cap = self.capacity
+        if self.data_parallel is not None and self._capacity_nonzero:   # |KL - c| needs the global KL mean (parallel.py)
+            kl_local = self.compute_kld_loss(z_dist, prior_dist, beta=1.0, c=0.0).detach()
+            cap = self.data_parallel.shifted_capacity(kl_local, self.capacity)
+        dist_loss = self.compute_kld_loss(z_dist, prior_dist, beta=self.beta, c=cap)
         loss = recons_loss + dist_loss
         reg_loss = None
         if self.use_reg_loss:
@@ -128,8 +133,9 @@ class ImageVAETrainer(Trainer):
         x = inputs.contiguous().view(n, model.image_hw, model.image_hw, 1)
         masks = model._next_masks(n, inputs.device)
         eps = model._noise(torch.empty(n, model.z_dim, device=inputs.device))
-        dp = self.data_parallel if self.use_reg_loss else None
-        loss, scalars, accuracy, z, mu, sigma, logits = self._fused.run(x, labels, eps, masks, self.capacity, dp=dp)
+        dp = self.data_parallel
+        loss, scalars, accuracy, z, mu, sigma, logits = self._fused.run(x, labels, eps, masks, self.capacity, dp=dp,
+                                                                       capacity_nonzero=self._capacity_nonzero)
         reg_loss = scalars[REG].detach() if self.use_reg_loss else None
         self.last_terms = {'recons': scalars[RECON].detach(), 'dist': scalars[DIST].detach(), 'reg': reg_loss}
         self.last_outputs = {'logits': logits.view(inputs.size()), 'z': z, 'mu': mu, 'sigma': sigma}

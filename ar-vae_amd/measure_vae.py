@@ -325,7 +325,7 @@ class HierarchicalDecoder(Decoder):
         nb, b = beat_out.shape[0], beat_out.shape[1]
         hid = self.rnn_hidden_size
         w_ih0, w_hh0, b_ih0, b_hh0 = self.rnn_tick.cell(0)
-        if os.environ.get('ARVAE_TICK_STEPWISE', '0') != '1' and self.num_notes <= 64:
+        if os.environ.get('ARVAE_TICK_STEPWISE', '0') != '1' and ops.tick_free_run_supported(hid, self.num_notes):
             # one launch (csrc/gru_seq.hip tick_free_run_kernel).  W_ih0 acts on [previous-note embedding | beat
             # embedding]: the beat half is applied once per beat, the note half once per vocabulary entry (+ x_0).
             emb_dim = self.note_embedding_dim

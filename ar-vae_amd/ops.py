@@ -675,6 +675,11 @@ def gru_sequence(steps, directions):
     return _GruSeqFn.apply(int(steps), tuple(bool(d[4]) for d in directions), *flat)
 
 
+def tick_free_run_supported(hidden, vocab):
+    """True when the one-launch free-running tick decoder is built for (hidden, vocab); else go tick by tick."""
+    return bool(_lib.load().arvae_tick_free_run_supported(int(hidden), int(vocab)))
+
+
 def tick_free_run(weights, h0_l0, h0_l1, gib, ptab, mask, keep_scale, batch, beats, ticks_per_beat):
     """tokens (B, beats*ticks_per_beat) int64 of the free-running tick decoder; no autograd (csrc/gru_seq.hip).
     weights = (w_hh0, b_hh0, w_ih1, b_ih1, w_hh1, b_hh1, w_out, b_out)."""

@@ -11,8 +11,12 @@ by rows; the model is replicated.  Per step there are exactly two collectives:
      scales by 1/world_size.
 
 Loss convention: rank r differentiates  L_r = recon_r + beta*|KL_r - c| + W * reg_rowblock_r ;
-mean_r(L_r) equals the single-process loss on the concatenated batch (exact for c = 0, the default),
-and mean_r(grad L_r) equals its gradient.
+mean_r(L_r) equals the single-process loss on the concatenated batch and mean_r(grad L_r) equals its gradient.
+For c = 0 (the default, train_image_vae.py:23) that holds as written, because KL_r >= 0.  For c != 0 the term
+beta*|mean_r(KL_r) - c| is not shard-linear (utils/trainer.py:354-367): the ranks all-reduce
+the scalar KL mean (4 bytes, a third collective) and each uses the shifted capacity c_r = c + KL_r - KL_global, so
+that KL_r - c_r = KL_global - c: the value of the term is the global one on every rank and its gradient carries the
+global sign (`shifted_capacity`).
 """
 import torch
 import torch.distributed as dist
@@ -59,6 +63,13 @@ class DataParallel:
         z_all, lab_all = packed[:, :r].contiguous(), packed[:, r:].contiguous()
         part = self._reg_fn(z_loc, lab_loc, tuple(range(r)), gamma, delta, z_cols=z_all, lab_cols=lab_all)
         return part * float(self.world_size)
+
+    def shifted_capacity(self, kl_local, capacity):
+        """c_r = c + KL_r - mean_r(KL_r) as a detached (1,) tensor: with it beta*|KL_r - c_r| equals the single-process
+        beta*|KL_global - c| in value, and its gradient beta*sign(KL_global - c)*dKL_r averages to the global gradient."""
+        kl_local = kl_local.detach().reshape(1)
+        kl_global = self.mean_scalar(kl_local)
+        return (capacity.detach().reshape(1).to(kl_local.dtype) + kl_local - kl_global)
 
     def reduce_gradients(self, optimizer):
         """SUM all-reduce of the flat gradient arena; Adam then applies 1/W."""

@@ -60,7 +60,8 @@ class Trainer(ABC):
 
     # Training steps replayed from HIP graphs (ar-vae_amd/graphed.py).  Worth it where the step is many small launches and
     # the host sets the pace (MeasureVAE: 3.9 -> 1.5 ms per step); subclasses switch it on.  Batches of another shape
-    # (the last one of an epoch), data-parallel runs and CPU models take the eager path.
+    # (the last one of an epoch), data-parallel runs and CPU models take the eager path; changing beta / gamma / delta /
+    # reg_dim (e.g. from update_scheduler) re-captures.
     use_graph_replay = False
 
     def _replay_step(self, batch):
@@ -69,19 +70,21 @@ class Trainer(ABC):
             return None
         if not next(self.model.parameters()).is_cuda:
             return None
+        from .graphed import GraphedStep
         graphed = getattr(self, '_graphed', None)
-        try:
-            if graphed is None:
-                from .graphed import GraphedStep
-                self.model.train()
+        if graphed is not None and graphed.hyper != GraphedStep.hyper_of(self):
+            graphed = self._graphed = None                     # beta / gamma / delta / reg_dim are baked into the captured kernels
+        if graphed is None:
+            self.model.train()
+            try:
                 graphed = self._graphed = GraphedStep(self, batch)
-            return graphed(batch)
-        except ValueError:                                     # a batch of another shape
+            except RuntimeError as e:                          # capture not possible here: stay eager from now on
+                print(f'graph replay disabled: {e}')
+                self.use_graph_replay = False
+                return None
+        if not graphed.accepts(batch):                         # a batch of another shape (the last one of an epoch)
             return None
-        except RuntimeError as e:                              # capture not possible here: stay eager from now on
-            print(f'graph replay disabled: {e}')
-            self.use_graph_replay = False
-            return None
+        return graphed(batch)                                  # errors of the step itself propagate
 
     def loss_and_acc_on_epoch(self, data_loader, epoch_num=None, train=True):
         loss_sum = acc_sum = None
@@ -100,11 +103,13 @@ class Trainer(ABC):
                 if train:
                     loss.backward()
                     self.step()
+            # the accumulators start from COPIES: under graph replay `loss` / `accuracy` are the captured step's static
+            # output buffers, which the next replay overwrites
             l = loss.detach().mean()
-            loss_sum = l if loss_sum is None else loss_sum + l
+            loss_sum = l.clone() if loss_sum is None else loss_sum + l
             if accuracy is not None:
                 a = accuracy.detach()
-                acc_sum = a if acc_sum is None else acc_sum + a
+                acc_sum = a.clone() if acc_sum is None else acc_sum + a
             count += 1
         n = max(count, 1)
         mean_loss = float(loss_sum) / n if loss_sum is not None else 0.0       # single sync per epoch

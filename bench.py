@@ -1,24 +1,37 @@
 #!/usr/bin/env python3
 """Throughput of the AR-VAE training step on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): dSprites AR-VAE, per-GPU batch 512, fp32,
-beta=4, gamma=10, delta=1, reg_dim=(1..5).  One step = zero_grad -> loss_and_acc_for_batch -> backward ->
-Adam, on synthetic dSprites-shaped inputs that are resident in HBM before the timed region; the
-reparameterisation noise is drawn on the device each step.  Prints ONE JSON line (rank 0).
+N > 1 runs one rank per GPU over RCCL.  Launched under torch.distributed.run the ranks read RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* from the environment; launched plainly (`python bench.py --gpus 8`) this process starts the N
+ranks itself as fresh child processes -- before anything here touches the GPU -- and prints rank 0's line.
 
-Extra objects in the line:
-  roofline      the dominant kernel of the step, timed live with HIP events on the launch stream in a
-                separate instrumented pass (algorithmic FLOP / average launch duration vs the fp32 MFMA
-                peak, or layer-boundary bytes vs the HBM peak for a memory-bound kernel)
-  cpu_baseline  the CPU oracle (oracle/step.py, a port: the reference's Python cannot travel) timed on
-                this box's host cores on a bounded sample of the same workload (rank 0, N = 1 only)
+Workload (BASELINE.json configs[1]): dSprites AR-VAE, per-GPU batch 512, fp32, beta=4, gamma=10,
+delta=1, reg_dim=(1..5).  One step = zero_grad -> loss_and_acc_for_batch -> backward -> (gradient all-reduce) -> Adam,
+on synthetic dSprites-shaped inputs resident in HBM before the timed region; the reparameterisation noise is drawn on
+the device each step.  `--workload mnist|measure` times BASELINE.json configs[2] / configs[4] the same way.
+
+Timing: W warm-up steps, then regions of EXACTLY K steps, each bracketed by barrier + torch.cuda.synchronize() on both
+sides and timed by the host clock (max over ranks) and by HIP events on the launch stream.  Regions repeat until
+>= 1 s has been timed (>= 3 regions); `ms_per_step` / `value` are the MEDIAN region, the spread is under `timing`.
+
+Prints ONE JSON line (rank 0).  Extra objects in the line:
+  roofline      the dominant kernel of the step, timed live with HIP events on the launch stream in a separate
+                instrumented pass (arvae_profile_begin/_end): algorithmic bytes (or executed MFMA FLOP) per launch /
+                average launch duration against the HBM (or MFMA) peak; `rocprof_names` = the kernel names a
+                rocprofv3 --kernel-trace of this command shows for that label
+  cpu_baseline  the CPU oracle (oracle/step.py, a port: the reference's Python cannot travel) timed on this box's host
+                cores on a bounded sample of the same workload (rank 0, N = 1 only), all cores and 8 threads
+  secondary     (default run, N = 1) the Morpho-MNIST B=1024 and MeasureVAE B=256 steps, same timing rules
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -53,18 +66,49 @@ KERNEL_WORK = {
     # last decoder layer with the reconstruction term fused in: lo in; logits, d/dlogits out; image in
     'up_c1_kernel(recon)': (524_288, 4 * (32768 + 3 * 4096)), 'up_c1_kernel': (524_288, 4 * (32768 + 4096)),
 }
+# the library's timeline labels one kernel FAMILY; these are the instantiations a rocprofv3 --kernel-trace of the
+# default build lists for it at B = 512 (profiles/*_kernel_stats.csv)
+ROCPROF_NAMES = {
+    'wgrad32_kernel<16>': ['arvae::wgrad32x_kernel<16, 1>', 'arvae::wgrad32x_kernel<16, 2>'],
+    'up32_kernel<16>': ['arvae::up32x_kernel<16, 1, 128>', 'arvae::up32x_kernel<16, 3, 128>'],
+    'down32_kernel<16>': ['arvae::down32x_kernel<16, 1>', 'arvae::down32x_kernel<16, 3>'],
+    'wgrad32_kernel<8>': ['arvae::wgrad32x_kernel<8, 1>', 'arvae::wgrad32x_kernel<8, 2>'],
+    'up32_kernel<8>': ['arvae::up32x_kernel<8, 1, 32>', 'arvae::up32x_kernel<8, 3, 32>'],
+    'down32_kernel<8>': ['arvae::down32x_kernel<8, 1>', 'arvae::down32x_kernel<8, 3>'],
+    'wgrad32_kernel<4>': ['arvae::wgrad32x_kernel<4, 1>', 'arvae::wgrad32x_kernel<4, 2>'],
+    'up32_kernel<4>': ['arvae::up32x_kernel<4, 1, 32>', 'arvae::up32x_kernel<4, 3, 32>'],
+    'down32_kernel<4>': ['arvae::down32s_kernel<4, 1>', 'arvae::down32s_kernel<4, 2>'],
+    'down_c1_kernel': ['arvae::down_c1_kernel'], 'wgrad_c1_kernel': ['arvae::wgrad_c1_kernel'],
+    'up_c1_kernel(recon)': ['arvae::up_c1_kernel<0, true>'],
+    'conv64_down': ['arvae::conv_rows_x3_kernel<true>', 'arvae::conv_rows_x3_kernel<false>'],
+    'conv64_up': ['arvae::conv_rows_x3_kernel<true>', 'arvae::conv_rows_x3_kernel<false>'],
+    'conv64_wgrad(rows)': ['arvae::conv_wgrad_rows_x3_kernel'],
+    'gru_seq_fwd_kernel': ['arvae::gru_seq_fwd_x3_kernel<128>'], 'gru_seq_bwd_kernel': ['arvae::gru_seq_bwd_x3_kernel<128>'],
+    'tick_free_run_x3_kernel': ['arvae::tick_free_run_x3_kernel<128>'],
+}
 
 REG_DIMS = (1, 2, 3, 4, 5)
 BETA, GAMMA, DELTA = 4.0, 10.0, 1.0
 
+# SURVEY.md 8(d): algorithmic FLOP and layer-boundary bytes per image / measure and training step
+SIDE_WORK = {'mnist': (431466496.0, 3276816.0), 'measure': (93.7e6, 0.7e6)}
+SIDE_BATCH = {'mnist': 1024, 'measure': 256}
+# Label families of the secondary workloads whose algorithmic work per training step is known (MACs per unit summed over
+# the family's launches in one step; SURVEY 8(d) per-layer tables): the wide Morpho-MNIST layers run conv2 / conv3 /
+# deconv1 / deconv2 once per direction in each of the three products (forward-type, data gradient, weight gradient);
+# MeasureVAE's recurrent products are 3*H*H MACs per row and time step over 152 row-steps per measure.
+SIDE_KERNEL_MACS = {
+    'mnist': {'conv64_down': 2 * (31_719_424 + 2_957_312), 'conv64_up': 2 * (31_719_424 + 2_957_312),
+              'conv64_wgrad(rows)': 2 * (31_719_424 + 2_957_312)},
+    'measure': {'gru_seq_fwd_kernel': 152 * 3 * 128 * 128, 'gru_seq_bwd_kernel': 2 * 152 * 3 * 128 * 128},
+}
+# families that do not launch in every step: MACs per unit and LAUNCH (the free-running decoder pass runs on the steps
+# whose teacher-forcing coin says no: 24 ticks x (W_hh0, W_ih1, W_hh1: 9 H^2; note projection H V))
+SIDE_KERNEL_MACS_PER_LAUNCH = {'measure': {'tick_free_run_x3_kernel': 24 * (9 * 128 * 128 + 128 * 35)}}
+
 
 class DspritesDataset:          # ImageVAETrainer sniffs the dataset's class name (reference image_vae_trainer.py:81-86)
     pass
-
-
-def dsprites_shapes():
-    from arvae_amd.image_vae import DspritesVAE
-    return {k: tuple(v.shape) for k, v in DspritesVAE().state_dict().items()}
 
 
 class MorphoMnistDataset:
@@ -83,52 +127,119 @@ class FolkDataset:              # what MeasureVAE / MeasureVAETrainer read from 
         return self.class_name
 
 
-def build_side_workload(kind, device, batch, graphs=False):
-    """(step function, unit) for the secondary workloads (not the headline metric): BASELINE.json configs[2], [4]."""
-    from arvae_amd import synthetic as syn
-    if kind == 'mnist':
-        from arvae_amd.image_vae import MnistVAE
-        from arvae_amd.image_vae_trainer import ImageVAETrainer
-        model = MnistVAE()
-        state = syn.synth_state({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=3, gain=0.7)
-        model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
-        trainer = ImageVAETrainer(MorphoMnistDataset(), model, lr=1e-4, reg_type=('all',), reg_dim=(1, 2, 3, 4, 5, 6),
-                                  beta=1.0, gamma=10.0, capacity=0.0, rand=0, delta=1.0)
-        trainer.cuda()
-        x, lab = syn.mnist_batch(batch, seed=4321)
-        data = (torch.from_numpy(x).to(device), torch.from_numpy(lab).to(device))
-    else:
-        from arvae_amd.measure_vae import MeasureVAE
-        from arvae_amd.measure_vae_trainer import MeasureVAETrainer
-        ds = FolkDataset()
-        model = MeasureVAE(ds, 10, 2, 2, 128, 0.5, 32, 2, 128, 0.5, False, 'folk')
-        trainer = MeasureVAETrainer(ds, model, lr=1e-4, reg_type=('all',), reg_dim=(0, 1, 2, 3), beta=0.001, gamma=1.0,
-                                    capacity=0.0, rand=0, delta=10.0)
-        trainer.cuda()
-        score = torch.from_numpy(syn.measure_batch(batch, seed=5)).to(device)
-        data = (score, score)
-        model.train()
-        if graphs:                                               # forward + backward replayed from HIP graphs (graphed.py)
-            from arvae_amd.graphed import GraphedStep
-            graphed = GraphedStep(trainer, data)
-
-            def gstep(i):
-                loss, _ = graphed(data)
-                trainer.step()
-                return loss
-            return gstep, 'measures/s'
-    model.train()
-
-    def step(i):
-        trainer.zero_grad()
-        loss, _ = trainer.loss_and_acc_for_batch(data, 0, i, True)
-        loss.backward()
-        trainer.step()
-        return loss
-    return step, ('images/s' if kind == 'mnist' else 'measures/s')
+# ---- N > 1 without a launcher: start the ranks here ------------------------------------------------------------------
+def spawn_ranks(n, argv):
+    """Run this script as n fresh child processes (one rank per GPU) and relay rank 0's line.  Nothing in this process has
+    touched the GPU yet (torch.cuda.device_count() does not initialise it on this image), so every child starts clean."""
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit(f'--gpus {n}: this node exposes {have} GPU(s)')
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    threads = max(1, (os.cpu_count() or n) // n)
+    procs = []
+    out0 = tempfile.TemporaryFile(mode='w+')
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')         # dmabuf IPC only on this pool (RCCL needs it)
+        env.setdefault('OMP_NUM_THREADS', str(threads))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        time.sleep(0.2)
+        for p in list(pending):
+            code = p.poll()
+            if code is None:
+                continue
+            pending.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in pending:                                  # a rank failed: the others would wait for it forever
+                    q.terminate()
+    out0.seek(0)
+    sys.stdout.write(out0.read())
+    sys.stdout.flush()
+    if rc != 0:
+        raise SystemExit(f'a rank exited with code {rc}')
 
 
-def build_trainer(device, world):
+# ---- timing -------------------------------------------------------------------------------------------------------------
+class Fence:
+    """barrier + torch.cuda.synchronize() on both sides; max over ranks of a host-measured duration."""
+
+    def __init__(self, device, use_dp):
+        self.device, self.use_dp = device, use_dp
+
+    def __call__(self):
+        torch.cuda.synchronize()
+        if self.use_dp:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def max_over_ranks(self, seconds):
+        if not self.use_dp:
+            return seconds
+        import torch.distributed as dist
+        t = torch.tensor([seconds], device=self.device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t)
+
+
+def timed_regions(step, steps, warmup, fence, min_total_s=1.0, min_regions=3, max_regions=400):
+    """-> (median region seconds, timing dict, last loss).  Every region is exactly `steps` steps between two fences."""
+    for i in range(warmup):
+        step(i)
+    host, dev = [], []
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    loss = None
+    while True:
+        fence()
+        e0.record()                                   # torch's current stream = the stream every library launch goes to
+        t0 = time.perf_counter()
+        for i in range(steps):
+            loss = step(i)
+        e1.record()
+        fence()
+        host.append(fence.max_over_ranks(time.perf_counter() - t0))
+        dev.append(e0.elapsed_time(e1) * 1e-3)
+        # the stopping rule reads only rank-reduced numbers, so every rank runs the same number of regions
+        if (len(host) >= min_regions and sum(host) >= min_total_s) or len(host) >= max_regions:
+            break
+    med = float(np.median(host))
+    k = 1e3 / steps
+    timing = {'regions': len(host), 'steps_per_region': steps, 'ms_per_step_median': med * k,
+              'ms_per_step_min': min(host) * k, 'ms_per_step_max': max(host) * k, 'ms_per_step_first_region': host[0] * k,
+              'hip_event_ms_per_step_median': float(np.median(dev)) * k, 'timed_seconds_total': sum(host),
+              'rule': 'regions of exactly K steps, barrier + synchronize on both sides, repeated until >= 1 s is timed; '
+                      'value and ms_per_step are the median region (host clock, max over ranks)'}
+    return med, timing, loss
+
+
+def kernel_profile(step, n_steps):
+    """per-label device time from the library's HIP-event timeline (one event after every kernel on the launch stream)"""
+    import ctypes
+    from arvae_amd import _lib
+    lib = _lib.load()
+    lib.arvae_profile_begin(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    for i in range(n_steps):
+        step(i)
+    buf = ctypes.create_string_buffer(1 << 16)
+    lib.arvae_profile_end(buf, len(buf))
+    prof = {}
+    for line in buf.value.decode().splitlines():
+        name, calls, ms = line.split('\t')
+        prof[name] = {'calls': int(calls), 'ms': float(ms)}
+    prof.pop('(gap)', None)          # launch gaps the library marks separately so that kernel times exclude them
+    return prof
+
+
+# ---- workloads ----------------------------------------------------------------------------------------------------------
+def build_trainer(device, use_dp):
     from arvae_amd import synthetic as syn
     from arvae_amd.image_vae import DspritesVAE
     from arvae_amd.image_vae_trainer import ImageVAETrainer
@@ -139,22 +250,147 @@ def build_trainer(device, world):
                               gamma=GAMMA, capacity=0.0, rand=0, delta=DELTA)
     model.to(device)
     trainer.capacity = trainer.capacity.to(device)
-    if world > 1:
+    if use_dp:
         from arvae_amd.parallel import DataParallel
         DataParallel().attach(trainer)
     model.train()
     return trainer, state
 
 
-# SURVEY.md 8(d): algorithmic FLOP and layer-boundary bytes per image / measure and training step
-SIDE_WORK = {'mnist': (431466496.0, 3276816.0), 'measure': (93.7e6, 0.7e6)}
+def build_side_workload(kind, device, batch, rank=0, use_dp=False, graphs=False):
+    """-> (timed step, eager step for the instrumented pass, unit) for BASELINE.json configs[2] / configs[4]."""
+    from arvae_amd import synthetic as syn
+    if kind == 'mnist':
+        from arvae_amd.image_vae import MnistVAE
+        from arvae_amd.image_vae_trainer import ImageVAETrainer
+        model = MnistVAE()
+        state = syn.synth_state({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=3, gain=0.7)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+        trainer = ImageVAETrainer(MorphoMnistDataset(), model, lr=1e-4, reg_type=('all',), reg_dim=(1, 2, 3, 4, 5, 6),
+                                  beta=1.0, gamma=10.0, capacity=0.0, rand=0, delta=1.0)
+        trainer.cuda()
+        x, lab = syn.mnist_batch(batch, seed=4321 + rank)
+        data = (torch.from_numpy(x).to(device), torch.from_numpy(lab).to(device))
+    else:
+        from arvae_amd.measure_vae import MeasureVAE
+        from arvae_amd.measure_vae_trainer import MeasureVAETrainer
+        ds = FolkDataset()
+        model = MeasureVAE(ds, 10, 2, 2, 128, 0.5, 32, 2, 128, 0.5, False, 'folk')
+        trainer = MeasureVAETrainer(ds, model, lr=1e-4, reg_type=('all',), reg_dim=(0, 1, 2, 3), beta=0.001, gamma=1.0,
+                                    capacity=0.0, rand=0, delta=10.0)
+        trainer.cuda()
+        score = torch.from_numpy(syn.measure_batch(batch, seed=5 + rank)).to(device)
+        data = (score, score)
+    if use_dp:
+        from arvae_amd.parallel import DataParallel
+        dp = DataParallel().attach(trainer)
+        dp.broadcast_parameters(model)
+    model.train()
+
+    def eager(i):
+        trainer.zero_grad()
+        loss, _ = trainer.loss_and_acc_for_batch(data, 0, i, True)
+        loss.backward()
+        trainer.step()
+        return loss
+
+    unit = 'images/s' if kind == 'mnist' else 'measures/s'
+    if kind == 'measure' and graphs:                             # forward + backward replayed from HIP graphs (graphed.py)
+        from arvae_amd.graphed import GraphedStep
+        graphed = GraphedStep(trainer, data)
+
+        def gstep(i):
+            loss, _ = graphed(data)
+            trainer.step()
+            return loss
+        return gstep, eager, unit
+    return eager, eager, unit
 
 
-def side_cpu_baseline(kind, batch, budget_s=20.0):
-    """the CPU oracle's training step on the secondary workloads, bounded to ~budget_s of CPU work."""
+def side_roofline(kind, prof, prof_steps, batch):
+    """dominant library kernel of a secondary workload: share of the step and, where the label's algorithmic work per
+    step is known, its achieved rate against the MFMA peak it runs on (three-term bf16 split: 6 products per MAC)."""
+    if not prof:
+        return None
+    total = sum(v['ms'] for v in prof.values())
+    name, dom = max(prof.items(), key=lambda kv: kv[1]['ms'])
+    out = {'kernel': name, 'rocprof_names': ROCPROF_NAMES.get(name), 'launches_per_step': dom['calls'] / prof_steps,
+           'avg_launch_us': 1e3 * dom['ms'] / dom['calls'], 'us_per_step': 1e3 * dom['ms'] / prof_steps,
+           'share_of_device_time': dom['ms'] / total, 'device_time_us_per_step': 1e3 * total / prof_steps}
+    macs = SIDE_KERNEL_MACS.get(kind, {}).get(name)
+    per_launch = SIDE_KERNEL_MACS_PER_LAUNCH.get(kind, {}).get(name)
+    if per_launch:
+        macs = per_launch * dom['calls'] / prof_steps
+    if macs:
+        tf = 2.0 * macs * batch * BF16X3_PRODUCTS / (dom['ms'] / prof_steps * 1e-3) / 1e12
+        out.update({'bound': 'mfma', 'achieved': tf, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': tf / PEAK_BF16_MFMA_TFLOPS, 'traffic': None, 'fp32_equivalent_tflops': tf / BF16X3_PRODUCTS,
+                    'mfma_work': 'executed bf16 MFMA FLOP = 6 partial products x algorithmic FLOP of all the label\'s '
+                                 'launches in one step'})
+    return out
+
+
+def run_side(kind, device, args, fence, rank, world, use_dp, with_cpu):
+    """one secondary workload -> its result dict (the main line when selected with --workload)"""
+    bsz = args.batch if (args.workload == kind and args.batch != 512) else SIDE_BATCH[kind]
+    graphs = kind == 'measure' and not args.no_graphs and not use_dp
+    step, eager, unit = build_side_workload(kind, device, bsz, rank, use_dp, graphs)
+    steps = args.steps if args.workload == kind else max(10, min(args.steps, 50))
+    med, timing, loss = timed_regions(step, steps, args.warmup, fence, args.min_seconds)
+    prof_steps = 4
+    prof = kernel_profile(eager, prof_steps)
+    fence()
+    rate = world * bsz * steps / med
+    flop, byts = SIDE_WORK[kind]
+    per_gpu = rate / world
+    res = {'metric': f'training {unit} ({kind} AR-VAE, per-GPU batch {bsz})', 'value': rate, 'unit': unit, 'n_gpus': world,
+           'steps': steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * med / steps, 'higher_is_better': True,
+           'scaling': 'weak', 'vs_baseline': None,
+           'dtype': 'f32 (MFMAs: 3-term bf16 split, 6 products, fp32-accurate)', 'data': 'synthetic',
+           'config': {'workload': ('Morpho-MNIST AR-VAE full training step, 1x28x28 inputs, z=16, reg_dim=(1..6), dropout 0.5'
+                                   if kind == 'mnist' else
+                                   'FolkNBar MeasureVAE full training step, 24-tick measures, V=35, z=32, reg_dim=(0..3), '
+                                   'dropout 0.5, teacher forcing p=0.5'),
+                      'per_gpu_batch': bsz, 'global_batch': bsz * world, 'parallelism': f'dp{world}',
+                      'launch': 'hip-graph replay of fwd+bwd' if graphs else 'eager', 'final_loss': float(loss.detach())},
+           'timing': timing,
+           # whole-step fractions of the datasheet roofs (SURVEY 8(d) algorithmic FLOP / layer-boundary bytes per unit)
+           'step_roofline': {'flop_per_unit': flop, 'bytes_per_unit': byts,
+                             'flop_frac_fp32': per_gpu * flop / (PEAK_F32_MFMA_TFLOPS * 1e12),
+                             'hbm_frac': per_gpu * byts / (PEAK_HBM_GBS * 1e9)},
+           'roofline': side_roofline(kind, prof, prof_steps, bsz)}
+    if with_cpu:
+        res['cpu_baseline'] = side_cpu_baseline(kind, bsz)
+    return res
+
+
+# ---- CPU oracle baselines (test infrastructure used as the reported baseline; never on the product path) ---------------
+def _cpu_steps(run, state, budget_s, threads):
+    old = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        cur, adam, times, n = state, None, [], 0
+        t_start = time.perf_counter()
+        while True:
+            t0 = time.perf_counter()
+            res = run(cur, adam, n + 1)
+            cur, adam = res['params'], res['adam']
+            times.append(time.perf_counter() - t0)
+            n += 1
+            if n >= 3 and (time.perf_counter() - t_start > budget_s or n >= 40):
+                break
+    finally:
+        torch.set_num_threads(old)
+    steady = sorted(times[1:])
+    return steady[len(steady) // 2], n
+
+
+def side_cpu_baseline(kind, batch, budget_s=10.0):
+    """the CPU oracle's training step on a secondary workload, ~budget_s of CPU work on 8 threads (the thread count of
+    SURVEY.md section 6's reference timings; more threads are slower for these step sizes)."""
     from arvae_amd import synthetic as syn
     from oracle import step as o_step
-    cores = torch.get_num_threads()
+    threads = min(8, os.cpu_count() or 8)
     if kind == 'mnist':
         from arvae_amd.image_vae import MnistVAE
         state = syn.synth_state({k: tuple(v.shape) for k, v in MnistVAE().state_dict().items()}, seed=3, gain=0.7)
@@ -173,116 +409,36 @@ def side_cpu_baseline(kind, batch, budget_s=20.0):
         run = lambda cur, adam, n: o_step.measure_step(cur, score, eps, attr, (0, 1, 2, 3), 0.001, 1.0, 10.0, n % 2 == 0,
                                                        adam_state=adam, step_no=n)
         unit, what = 'measures/s', 'MeasureVAE (teacher forcing on alternate steps)'
-    cur, adam, times, n = state, None, [], 0
-    t_start = time.perf_counter()
-    while True:
-        t0 = time.perf_counter()
-        res = run(cur, adam, n + 1)
-        cur, adam = res['params'], res['adam']
-        times.append(time.perf_counter() - t0)
-        n += 1
-        if n >= 3 and (time.perf_counter() - t_start > budget_s or n >= 40):
-            break
-    steady = sorted(times[1:])
-    med = steady[len(steady) // 2]
-    return {'value': batch / med, 'unit': unit, 'cores': cores, 'kind': 'port',
+    med, n = _cpu_steps(run, state, budget_s, threads)
+    return {'value': batch / med, 'unit': unit, 'cores': threads, 'kind': 'port',
             'sample': f'{n} full training steps (first discarded) of the {what} at batch {batch}, fp32, PyTorch-CPU oracle, '
-                      f'{cores} threads, median step {med * 1e3:.1f} ms'}
+                      f'{threads} threads, median step {med * 1e3:.1f} ms'}
 
 
-def cpu_baseline(batch, state, budget_s=20.0):
-    """CPU oracle on the same workload, bounded to ~budget_s of CPU work."""
+def cpu_baseline(batch, state, budget_s=18.0):
+    """CPU oracle on the headline workload: all host cores (~budget_s of CPU work), then 8 threads (~budget_s / 2)."""
     from arvae_amd import synthetic as syn
     from oracle import step as o_step
     x, lab = syn.dsprites_batch(batch, seed=1234)
     eps = syn.normal_noise((batch, 10), seed=1)
+    run = lambda cur, adam, n: o_step.image_step('dsprites', cur, x, lab, eps, REG_DIMS, BETA, GAMMA, DELTA,
+                                                 adam_state=adam, step_no=n)
     cores = torch.get_num_threads()
-    cur, adam = state, None
-    times = []
-    t_start = time.perf_counter()
-    n = 0
-    while True:
-        t0 = time.perf_counter()
-        res = o_step.image_step('dsprites', cur, x, lab, eps, REG_DIMS, BETA, GAMMA, DELTA, adam_state=adam,
-                                step_no=n + 1)
-        cur, adam = res['params'], res['adam']
-        times.append(time.perf_counter() - t0)
-        n += 1
-        if n >= 3 and (time.perf_counter() - t_start > budget_s or n >= 40):
-            break
-    steady = sorted(times[1:])
-    med = steady[len(steady) // 2]
-    return {'value': batch / med, 'unit': 'images/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{n} full training steps (first discarded) of the dSprites AR-VAE at batch {batch}, fp32, '
-                      f'PyTorch-CPU oracle, {cores} threads, median step {med * 1e3:.1f} ms'}
+    med, n = _cpu_steps(run, state, budget_s, cores)
+    out = {'value': batch / med, 'unit': 'images/s', 'cores': cores, 'kind': 'port',
+           'sample': f'{n} full training steps (first discarded) of the dSprites AR-VAE at batch {batch}, fp32, '
+                     f'PyTorch-CPU oracle, {cores} threads, median step {med * 1e3:.1f} ms'}
+    if cores != 8:
+        med8, n8 = _cpu_steps(run, state, budget_s / 2, 8)
+        out['value_8_threads'] = batch / med8
+        out['sample_8_threads'] = f'{n8} steps, 8 threads, median step {med8 * 1e3:.1f} ms'
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=30)
-    ap.add_argument('--batch', type=int, default=512, help='per-GPU batch')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--breakdown', action='store_true', help='print the per-kernel-family table to stderr')
-    ap.add_argument('--force-dp', action='store_true',
-                    help='run the data-parallel code path (RCCL all-gather + all-reduce) even with one rank')
-    ap.add_argument('--no-graphs', action='store_true', help='measure workload: eager launches instead of HIP-graph replay')
-    ap.add_argument('--workload', default='dsprites', choices=['dsprites', 'mnist', 'measure'],
-                    help='dsprites = the headline metric (default); mnist / measure = secondary single-GPU timings')
-    args = ap.parse_args()
-
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} '
-                         f'(WORLD_SIZE={world})')
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a GPU: the AR-VAE hot path has no CPU fallback')
-    device = torch.device('cuda', local_rank)
-    torch.cuda.set_device(device)
-    use_dp = world > 1 or args.force_dp
-    if use_dp:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29511')
-        os.environ.setdefault('RANK', '0')
-        os.environ.setdefault('WORLD_SIZE', '1')
-        dist.init_process_group('nccl', device_id=device)
-
+# ---- the headline workload ---------------------------------------------------------------------------------------------
+def run_dsprites(device, args, fence, rank, world, use_dp):
     from arvae_amd import synthetic as syn
-
-    if args.workload != 'dsprites':
-        bsz = args.batch if args.batch != 512 else (1024 if args.workload == 'mnist' else 256)
-        side_step, unit = build_side_workload(args.workload, device, bsz, graphs=args.workload == 'measure' and not args.no_graphs)
-        for i in range(args.warmup):
-            side_step(i)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            loss = side_step(i)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        rate = bsz * args.steps / dt
-        flop, byts = SIDE_WORK[args.workload]
-        line = {'metric': f'training {unit} ({args.workload} AR-VAE, batch {bsz}) -- secondary workload',
-                'value': rate, 'unit': unit, 'n_gpus': 1, 'steps': args.steps,
-                'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
-                'dtype': 'f32' if args.workload == 'mnist' else 'f32 (GRU MFMAs: 3-term bf16 split, fp32-accurate)',
-                'data': 'synthetic', 'final_loss': float(loss.detach()),
-                'config': {'workload': args.workload, 'batch': bsz,
-                           'launch': 'hip-graph replay of fwd+bwd' if args.workload == 'measure' and not args.no_graphs else 'eager'},
-                # whole-step fractions of the datasheet roofs (SURVEY 8(d) algorithmic FLOP / layer-boundary bytes per unit)
-                'step_roofline': {'flop_per_unit': flop, 'bytes_per_unit': byts,
-                                  'flop_frac_fp32': rate * flop / (PEAK_F32_MFMA_TFLOPS * 1e12),
-                                  'hbm_frac': rate * byts / (PEAK_HBM_GBS * 1e9)}}
-        if not args.no_cpu_baseline:
-            line['cpu_baseline'] = side_cpu_baseline(args.workload, bsz)
-        print(json.dumps(line))
-        return
-
-    trainer, state = build_trainer(device, 2 if use_dp else 1)
+    trainer, state = build_trainer(device, use_dp)
     if use_dp:
         trainer.data_parallel.broadcast_parameters(trainer.model)
     b = args.batch
@@ -297,55 +453,25 @@ def main():
         trainer.step()
         return loss
 
-    def fence():
-        torch.cuda.synchronize()
-        if use_dp:
-            import torch.distributed as dist
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        step(i)
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = step(i)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if use_dp:
-        import torch.distributed as dist
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax)
+    med, timing, loss = timed_regions(step, args.steps, args.warmup, fence, args.min_seconds)
     final_loss = float(loss.detach())
     if not np.isfinite(final_loss):
         raise SystemExit(f'non-finite loss {final_loss}')
 
-    # ---- instrumented pass: per-kernel device time from HIP events recorded by the library on the launch
-    # stream after every kernel (arvae_profile_begin/_end); a separate pass so the timed region is untouched
-    import ctypes
-    from arvae_amd import _lib
-    lib = _lib.load()
+    # ---- instrumented pass: per-kernel device time from HIP events recorded by the library on the launch stream after
+    # every kernel (arvae_profile_begin/_end); a separate pass so the timed regions are untouched
     prof_steps = 10
-    lib.arvae_profile_begin(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
-    for i in range(prof_steps):
-        step(i)
-    buf = ctypes.create_string_buffer(1 << 16)
-    lib.arvae_profile_end(buf, len(buf))
-    prof = {}
-    for line in buf.value.decode().splitlines():
-        name, calls, ms = line.split('\t')
+    prof = kernel_profile(step, prof_steps)
+    for name, v in prof.items():
         macs, nbytes = KERNEL_WORK.get(name, (0, 0))
-        prof[name] = dict(calls=int(calls), ms=float(ms), flop=2.0 * macs * b * int(calls),
-                          bytes=float(nbytes) * b * int(calls))
+        v['flop'] = 2.0 * macs * b * v['calls']
+        v['bytes'] = float(nbytes) * b * v['calls']
     fence()
-
     if rank != 0:
-        dist.destroy_process_group()
-        return
-    ms_per_step = 1e3 * elapsed / args.steps
-    value = world * b * args.steps / elapsed
-    prof.pop('(gap)', None)          # launch gaps the library marks separately so that kernel times exclude them
+        return None
+
+    ms_per_step = 1e3 * med / args.steps
+    value = world * b * args.steps / med
     dom_name, dom = max(((k, v) for k, v in prof.items() if v['flop'] > 0), key=lambda kv: kv[1]['ms'])
     avg_ms = dom['ms'] / dom['calls']
     split = dom_name.startswith(('down32', 'up32', 'wgrad32')) and not os.environ.get('ARVAE_CONV32_FP32')
@@ -366,15 +492,19 @@ def main():
     roof['other_roof_frac'] = {'mfma': mfma_tf / mfma_peak, 'hbm_algorithmic_bytes': hbm_gbs / PEAK_HBM_GBS}
     # HBM traffic of that kernel from the PMC counters: collected in separate rocprofv3 --pmc passes of this
     # same command (FETCH_SIZE / WRITE_SIZE cannot share a pass) and committed under profiles/
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'r1_pmc_traffic.json')) as f:
-            roof['traffic'] = json.load(f)['kernels'][dom_name]['hbm_bytes_per_launch']
-        roof['traffic_source'] = 'profiles/r1_pmc_traffic.json (rocprofv3 --pmc, 2*FETCH_SIZE + WRITE_SIZE, B=512)'
-    except (OSError, KeyError, ValueError):
-        roof['traffic'] = None
+    for tag in ('r2', 'r1'):
+        try:
+            with open(os.path.join(ROOT, 'profiles', f'{tag}_pmc_traffic.json')) as f:
+                roof['traffic'] = json.load(f)['kernels'][dom_name]['hbm_bytes_per_launch']
+            roof['traffic_source'] = f'profiles/{tag}_pmc_traffic.json (rocprofv3 --pmc, 2*FETCH_SIZE + WRITE_SIZE, B=512)'
+            break
+        except (OSError, KeyError, ValueError):
+            roof['traffic'] = None
     if b != 512:
         roof['traffic'] = None
-    roof.update({'kernel': dom_name, 'launches_per_step': dom['calls'] / prof_steps, 'avg_launch_us': avg_ms * 1e3,
+    roof.update({'kernel': dom_name, 'rocprof_names': ROCPROF_NAMES.get(dom_name),
+                 'launches_per_step': dom['calls'] / prof_steps, 'avg_launch_us': avg_ms * 1e3,
+                 'algorithmic_bytes_per_launch': dom['bytes'] / dom['calls'],
                  'share_of_device_time': dom['ms'] / sum(v['ms'] for v in prof.values())})
     per_gpu = value / world
     line = {
@@ -385,8 +515,11 @@ def main():
         'data': 'synthetic',
         'config': {'workload': 'dSprites AR-VAE full training step (fwd + bwd + Adam), 1x64x64 inputs, z=10, '
                                'reg_dim=(1,2,3,4,5), beta=4 gamma=10 delta=1',
-                   'per_gpu_batch': b, 'global_batch': b * world, 'parallelism': f'dp{world}' + (' (forced DP path)' if args.force_dp and world == 1 else ''),
+                   'per_gpu_batch': b, 'global_batch': b * world,
+                   'parallelism': f'dp{world}' + (' (forced DP path)' if args.force_dp and world == 1 else ''),
+                   'rccl_world_size': world if use_dp else None,
                    'images_per_sec_per_gpu': per_gpu, 'final_loss': final_loss},
+        'timing': timing,
         'roofline': roof,
         'step_roofline': {
             'flop_frac_fp32': per_gpu * FLOP_PER_IMAGE / (PEAK_F32_MFMA_TFLOPS * 1e12),
@@ -404,8 +537,66 @@ def main():
               file=sys.stderr)
     if world == 1 and not args.no_cpu_baseline:
         line['cpu_baseline'] = cpu_baseline(b, state)
-    print(json.dumps(line), flush=True)
+    return line
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=30)
+    ap.add_argument('--batch', type=int, default=512, help='per-GPU batch')
+    ap.add_argument('--min-seconds', type=float, default=1.0,
+                    help='keep timing K-step regions until this much time is covered (at least 3 regions)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the Morpho-MNIST / MeasureVAE timings of the default run')
+    ap.add_argument('--breakdown', action='store_true', help='print the per-kernel-family table to stderr')
+    ap.add_argument('--force-dp', action='store_true',
+                    help='run the data-parallel code path (RCCL all-gather + all-reduce) even with one rank')
+    ap.add_argument('--no-graphs', action='store_true', help='measure workload: eager launches instead of HIP-graph replay')
+    ap.add_argument('--workload', default='dsprites', choices=['dsprites', 'mnist', 'measure'],
+                    help='dsprites = the headline metric (default); mnist / measure = BASELINE.json configs[2] / configs[4]')
+    args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:             # no launcher: start the ranks (nothing has touched the GPU)
+        return spawn_ranks(args.gpus, sys.argv[1:])
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world and not (args.gpus == 1 and world == 1):
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the AR-VAE hot path has no CPU fallback')
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+    use_dp = world > 1 or args.force_dp
     if use_dp:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+        dist.init_process_group('nccl', device_id=device)
+    fence = Fence(device, use_dp)
+
+    if args.workload != 'dsprites':
+        line = run_side(args.workload, device, args, fence, rank, world, use_dp, with_cpu=world == 1 and not args.no_cpu_baseline)
+    else:
+        line = run_dsprites(device, args, fence, rank, world, use_dp)
+        if line is not None and world == 1 and not args.force_dp and not args.no_secondary and args.batch == 512:
+            sec = {}
+            for kind in ('mnist', 'measure'):
+                try:
+                    r = run_side(kind, device, args, fence, 0, 1, False, with_cpu=not args.no_cpu_baseline)
+                    sec[kind] = {k: r[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'config', 'timing',
+                                                   'step_roofline', 'roofline', 'cpu_baseline') if k in r}
+                except Exception as e:                              # the headline line must not depend on a side workload
+                    sec[kind] = {'error': f'{type(e).__name__}: {e}'}
+            line['secondary'] = sec
+    if rank == 0 and line is not None:
+        print(json.dumps(line), flush=True)
+    if use_dp:
+        import torch.distributed as dist
         dist.destroy_process_group()
 
 

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define ARVAE_ABI_VERSION 3   /* 3: arvae_gru_seq_*, embed_bwd workspace; 2: arvae_image_vae_backward reg_fused == 2 (unit regulariser gradient in dz_extra) */
+#define ARVAE_ABI_VERSION 4   /* 4: arvae_tick_free_run_supported; 3: arvae_gru_seq_*, embed_bwd workspace; 2: arvae_image_vae_backward reg_fused == 2 (unit regulariser gradient in dz_extra) */
 
 #define ARVAE_OK 0
 #define ARVAE_E_INVALID (-1)  /* bad argument (null pointer, size out of range, unsupported shape) */
@@ -263,6 +263,10 @@ typedef struct arvae_tick_weights {
     const float *w_out, *b_out;     /* tick_emb_to_note_emb [vocab][hidden] */
 } arvae_tick_weights_t;
 int64_t arvae_tick_free_run_ws_floats(int32_t hidden);
+/* 1 when arvae_tick_free_run is built for this (hidden, vocab): hidden in {32, 64, 128} and vocab <= min(64, 16*(hidden/16));
+ * otherwise the caller runs the decoder tick by tick (arvae_gru_gates_fwd + arvae_row_argmax), as the reference does
+ * (measurevae/decoder.py:469-525). */
+int arvae_tick_free_run_supported(int32_t hidden, int32_t vocab);
 int arvae_tick_free_run(const arvae_tick_weights_t *weights, const float *h0_l0, const float *h0_l1, const float *gib,
                         const float *ptab, const uint8_t *mask, float keep_scale, int32_t batch, int32_t beats,
                         int32_t ticks_per_beat, int32_t hidden, int32_t vocab, int64_t *tokens, float *ws,

@@ -951,7 +951,7 @@ def test_data_parallel_path_single_rank_rccl(dev):
     outs = []
     for extra in ([], ['--force-dp']):
         r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '3', '--warmup', '1', '--batch', '64',
-                            '--no-cpu-baseline'] + extra, capture_output=True, text=True, timeout=600)
+                            '--min-seconds', '0', '--no-cpu-baseline'] + extra, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
         assert lines, (r.stdout[-1000:], r.stderr[-2000:])

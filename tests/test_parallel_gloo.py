@@ -33,7 +33,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, b_total, out_path):
+def _worker(rank, world, port, b_total, out_path, capacity):
     import sys
     sys.path.insert(0, ROOT)
     from arvae_amd import synthetic as syn
@@ -55,7 +55,10 @@ def _worker(rank, world, port, b_total, out_path):
         dp = DataParallel(reg_fn=o_losses.reg_loss_row_block)
         logits, mu, sigma, z = o_vae.forward('dsprites', p, xt, et)
         recon = o_losses.bce_with_logits_per_batch(logits, xt)
-        kld = o_losses.kld_loss(mu, sigma, BETA, 0.0)
+        cap = 0.0
+        if capacity != 0.0:                                    # |KL - c| needs the global KL mean (parallel.py)
+            cap = dp.shifted_capacity(o_losses.kld_loss(mu, sigma, 1.0, 0.0), torch.tensor([capacity]))
+        kld = o_losses.kld_loss(mu, sigma, BETA, cap).reshape(())
         reg = dp.reg_loss(z, lt, DIMS, GAMMA, DELTA)           # = W * row-block share
         loss = recon + kld + reg
         loss.backward()
@@ -72,19 +75,22 @@ def _worker(rank, world, port, b_total, out_path):
         dist.destroy_process_group()
 
 
+# KL mean of this batch: 3.686 (shards 3.564 / 3.807): c = 3.7 lies BETWEEN the shard means, so the local signs disagree
+# and only the all-reduced mean gives the single-process gradient; c = 30 flips the sign on every rank
+@pytest.mark.parametrize('capacity', [0.0, 3.7, 30.0])
 @pytest.mark.parametrize('world', [2])
-def test_two_rank_step_equals_single_process(tmp_path, world):
+def test_two_rank_step_equals_single_process(tmp_path, world, capacity):
     from arvae_amd import synthetic as syn
     from oracle import image_vae as o_vae
     from oracle import step as o_step
     b_total = 16
     out = str(tmp_path / 'dp.npz')
-    mp.spawn(_worker, args=(world, _free_port(), b_total, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), b_total, out, capacity), nprocs=world, join=True)
     got = np.load(out)
     state = syn.synth_state(o_vae.DSPRITES_SHAPES, 1, 1.6)
     x, lab = syn.dsprites_batch(b_total, seed=1234)
     eps = syn.normal_noise((b_total, 10), seed=12)
-    ref = o_step.image_step('dsprites', state, x, lab, eps, DIMS, BETA, GAMMA, DELTA)
+    ref = o_step.image_step('dsprites', state, x, lab, eps, DIMS, BETA, GAMMA, DELTA, capacity=capacity)
     want = np.concatenate([ref['grads'][k].ravel() for k in state])
     assert got['scale'] == pytest.approx(1.0 / world)
     np.testing.assert_allclose(got['loss'], ref['terms']['loss'], rtol=1e-5)
