@@ -13,8 +13,16 @@ extern thread_local char g_last_error[512];
 
 int fail(int code, const char *fmt, ...);
 int check_launch(const char *what);
-void prof_gap();           // call right before launching a kernel whose profile time should exclude the launch gap
+void prof_gap();           // closes the interval before a launch, so that a kernel's profile time excludes the launch gap
 bool profiling_active();   // arvae_profile_begin() is recording: keep every kernel on the caller's stream
+
+// every kernel launch of the library: when the opt-in timeline is recording, an event right before the launch separates
+// the kernel's own time from whatever the stream was doing (or not doing) before it
+#define ARVAE_LAUNCH(...)                  \
+    do {                                   \
+        ::arvae::prof_gap();               \
+        hipLaunchKernelGGL(__VA_ARGS__);   \
+    } while (0)
 
 #define ARVAE_REQUIRE(cond, ...)                                   \
     do {                                                           \

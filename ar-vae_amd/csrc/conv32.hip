@@ -1512,8 +1512,7 @@ static void launch_down_small(const Operand &hi, const float *wt, const Ep32 &ep
     const int grid = tiles < 2 * cu_count() ? tiles : 2 * cu_count();
     static bool attr = false;
     if (!attr) { allow_lds(down32s_kernel<LO, MODE>, LDS); attr = true; }
-    prof_gap();
-    hipLaunchKernelGGL((down32s_kernel<LO, MODE>), dim3(grid), dim3(256), LDS, s, hi.v, wt, ep, n, tiles);
+    ARVAE_LAUNCH((down32s_kernel<LO, MODE>), dim3(grid), dim3(256), LDS, s, hi.v, wt, ep, n, tiles);
 }
 template <int LO, int MODE>
 static void launch_down_v(int grid, const Operand &hi, const float *wt, const Ep32 &ep, int n, int tiles, hipStream_t s) {
@@ -1535,23 +1534,20 @@ static void launch_down_v(int grid, const Operand &hi, const float *wt, const Ep
         const int tiles64 = tiles_for<LO, 64>(n);
         static bool attrx = false;
         if (!attrx) { allow_lds(down32x_kernel<LO, MODE>, LDSX); attrx = true; }
-        prof_gap();
-        hipLaunchKernelGGL((down32x_kernel<LO, MODE>), dim3(grid_for_tiles(tiles64)), dim3(256), LDSX, s, hi.v, wt, ep, n, tiles64);
+        ARVAE_LAUNCH((down32x_kernel<LO, MODE>), dim3(grid_for_tiles(tiles64)), dim3(256), LDSX, s, hi.v, wt, ep, n, tiles64);
         return;
     }
     if (split) {
         constexpr int LDSB = MaxOf<2 * PatchLoader<LO, 2>::PLANE_DW, WSTAGE_DOWN>::value * 4;
         static bool attrb = false;
         if (!attrb) { allow_lds(down32b_kernel<LO, MODE>, LDSB); attrb = true; }
-        prof_gap();
-        hipLaunchKernelGGL((down32b_kernel<LO, MODE>), dim3(grid), dim3(256), LDSB, s, hi.v, wt, ep, n, tiles);
+        ARVAE_LAUNCH((down32b_kernel<LO, MODE>), dim3(grid), dim3(256), LDSB, s, hi.v, wt, ep, n, tiles);
         return;
     }
     constexpr int LDS = MaxOf<PatchLoader<LO, 2>::PATCH_FLOATS, WSTAGE_DOWN>::value * 4;
     static bool attr = false;
     if (!attr) { allow_lds(down32_kernel<LO, MODE>, LDS); attr = true; }
-    prof_gap();
-    hipLaunchKernelGGL((down32_kernel<LO, MODE>), dim3(grid), dim3(256), LDS, s, hi.v, wt, ep, n, tiles);
+    ARVAE_LAUNCH((down32_kernel<LO, MODE>), dim3(grid), dim3(256), LDS, s, hi.v, wt, ep, n, tiles);
 }
 template <int LO, int MODE, int PX>
 static void launch_up_px(const Operand &lo, const float *wt, const Ep32 &ep, int n, hipStream_t s) {
@@ -1561,15 +1557,13 @@ static void launch_up_px(const Operand &lo, const float *wt, const Ep32 &ep, int
         constexpr int LDSX = MaxOf<3 * PatchLoader<LO, 1, PX>::PLANE_DW, WSTAGE_UP>::value * 4;
         static bool attrx = false;
         if (!attrx) { allow_lds(up32x_kernel<LO, MODE, PX>, LDSX); attrx = true; }
-        prof_gap();
-        hipLaunchKernelGGL((up32x_kernel<LO, MODE, PX>), dim3(grid), dim3(256), LDSX, s, lo.v, wt, ep, n, tiles);
+        ARVAE_LAUNCH((up32x_kernel<LO, MODE, PX>), dim3(grid), dim3(256), LDSX, s, lo.v, wt, ep, n, tiles);
         return;
     }
     constexpr int LDS = MaxOf<PatchLoader<LO, 1, PX>::PATCH_FLOATS, WSTAGE_UP>::value * 4;
     static bool attr = false;
     if (!attr) { allow_lds(up32_kernel<LO, MODE, PX>, LDS); attr = true; }
-    prof_gap();
-    hipLaunchKernelGGL((up32_kernel<LO, MODE, PX>), dim3(grid), dim3(256), LDS, s, lo.v, wt, ep, n, tiles);
+    ARVAE_LAUNCH((up32_kernel<LO, MODE, PX>), dim3(grid), dim3(256), LDS, s, lo.v, wt, ep, n, tiles);
 }
 // 128-pixel tiles, or 32-pixel tiles when the former give a CU at most one tile (nothing to pipeline, or idle CUs:
 // the 8x8 and 4x4 layers at batch 512)
@@ -1653,7 +1647,7 @@ int conv32_weight_prep(const float *const *wts, float *const *preps, int n_layer
         p.wt[i] = wts[i];
         p.out[i] = reinterpret_cast<uint4 *>(preps[i]);
     }
-    hipLaunchKernelGGL(conv32_weight_prep_kernel, dim3(16 * n_layers), dim3(256), 0, s, p);
+    ARVAE_LAUNCH(conv32_weight_prep_kernel, dim3(16 * n_layers), dim3(256), 0, s, p);
     return check_launch("conv32_weight_prep");
 }
 
@@ -1692,13 +1686,12 @@ template <int LO, int PX> static int launch_wgrad(const arvae_link_t *l, const O
         allow_lds(wgrad32_kernel<LO, 2, PX>, LDS);
         attr = true;
     }
-    prof_gap();
     if (bias_mode == 1)
-        hipLaunchKernelGGL((wgrad32_kernel<LO, 1, PX>), dim3(grid), dim3(256), LDS, s, lo.v, hi.v, slab, l->n, tiles);
+        ARVAE_LAUNCH((wgrad32_kernel<LO, 1, PX>), dim3(grid), dim3(256), LDS, s, lo.v, hi.v, slab, l->n, tiles);
     else if (bias_mode == 2)
-        hipLaunchKernelGGL((wgrad32_kernel<LO, 2, PX>), dim3(grid), dim3(256), LDS, s, lo.v, hi.v, slab, l->n, tiles);
+        ARVAE_LAUNCH((wgrad32_kernel<LO, 2, PX>), dim3(grid), dim3(256), LDS, s, lo.v, hi.v, slab, l->n, tiles);
     else
-        hipLaunchKernelGGL((wgrad32_kernel<LO, 0, PX>), dim3(grid), dim3(256), LDS, s, lo.v, hi.v, slab, l->n, tiles);
+        ARVAE_LAUNCH((wgrad32_kernel<LO, 0, PX>), dim3(grid), dim3(256), LDS, s, lo.v, hi.v, slab, l->n, tiles);
     return check_launch(LO == 16 ? "wgrad32_kernel<16>" : LO == 8 ? "wgrad32_kernel<8>" : "wgrad32_kernel<4>");
 }
 
@@ -1713,13 +1706,12 @@ template <int LO> static int launch_wgrad_x(const arvae_link_t *l, const Operand
         allow_lds(wgrad32x_kernel<LO, 2>, LDS);
         attr = true;
     }
-    prof_gap();
     if (bias_mode == 1)
-        hipLaunchKernelGGL((wgrad32x_kernel<LO, 1>), dim3(grid), dim3(256), LDS, s, lo.v, hi.v, slab, l->n, tiles);
+        ARVAE_LAUNCH((wgrad32x_kernel<LO, 1>), dim3(grid), dim3(256), LDS, s, lo.v, hi.v, slab, l->n, tiles);
     else if (bias_mode == 2)
-        hipLaunchKernelGGL((wgrad32x_kernel<LO, 2>), dim3(grid), dim3(256), LDS, s, lo.v, hi.v, slab, l->n, tiles);
+        ARVAE_LAUNCH((wgrad32x_kernel<LO, 2>), dim3(grid), dim3(256), LDS, s, lo.v, hi.v, slab, l->n, tiles);
     else
-        hipLaunchKernelGGL((wgrad32x_kernel<LO, 0>), dim3(grid), dim3(256), LDS, s, lo.v, hi.v, slab, l->n, tiles);
+        ARVAE_LAUNCH((wgrad32x_kernel<LO, 0>), dim3(grid), dim3(256), LDS, s, lo.v, hi.v, slab, l->n, tiles);
     return check_launch(LO == 16 ? "wgrad32_kernel<16>" : LO == 8 ? "wgrad32_kernel<8>" : "wgrad32_kernel<4>");
 }
 

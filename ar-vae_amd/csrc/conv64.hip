@@ -173,17 +173,16 @@ static int launch_conv_rows(ConvRows g, const float *wt, bool transposed, hipStr
     float *packed = conv64_scratch();
     const int taps = g.kh * g.kw, wcount = g.q * taps * g.cs;
     if (packed == nullptr || wcount > C64_SCRATCH_FLOATS) return fail(ARVAE_E_INVALID, "%s: no scratch for the re-ordered weights", what);
-    hipLaunchKernelGGL(conv64_weight_prep_kernel, dim3((wcount + 255) / 256), dim3(256), 0, s, wt, packed, g.q, g.cs, taps, transposed ? 1 : 0);
+    ARVAE_LAUNCH(conv64_weight_prep_kernel, dim3((wcount + 255) / 256), dim3(256), 0, s, wt, packed, g.q, g.cs, taps, transposed ? 1 : 0);
     g.wt = packed;
     const int M = g.n * g.oh * g.ow;
     const dim3 grid((M + C64_TP - 1) / C64_TP, (g.q + C64_TQ - 1) / C64_TQ);
-    prof_gap();
     if (plain_op(g.src)) {
         ConvRows p = g;
         p.src.y = nullptr;
-        hipLaunchKernelGGL(conv_rows_x3_kernel<true>, grid, dim3(256), 0, s, p);
+        ARVAE_LAUNCH(conv_rows_x3_kernel<true>, grid, dim3(256), 0, s, p);
     } else {
-        hipLaunchKernelGGL(conv_rows_x3_kernel<false>, grid, dim3(256), 0, s, g);
+        ARVAE_LAUNCH(conv_rows_x3_kernel<false>, grid, dim3(256), 0, s, g);
     }
     return check_launch(what);
 }
@@ -499,24 +498,22 @@ int conv64_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, fl
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_rows_x3_kernel<false, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr = true;
         }
-        prof_gap();
-        if (pl && ph) hipLaunchKernelGGL((conv_wgrad_rows_x3_kernel<true, true, 4>), grid, dim3(256), lds, s, g, ipw);
-        else if (pl) hipLaunchKernelGGL((conv_wgrad_rows_x3_kernel<true, false, 4>), grid, dim3(256), lds, s, g, ipw);
-        else if (ph) hipLaunchKernelGGL((conv_wgrad_rows_x3_kernel<false, true, 4>), grid, dim3(256), lds, s, g, ipw);
-        else hipLaunchKernelGGL((conv_wgrad_rows_x3_kernel<false, false, 4>), grid, dim3(256), lds, s, g, ipw);
+        if (pl && ph) ARVAE_LAUNCH((conv_wgrad_rows_x3_kernel<true, true, 4>), grid, dim3(256), lds, s, g, ipw);
+        else if (pl) ARVAE_LAUNCH((conv_wgrad_rows_x3_kernel<true, false, 4>), grid, dim3(256), lds, s, g, ipw);
+        else if (ph) ARVAE_LAUNCH((conv_wgrad_rows_x3_kernel<false, true, 4>), grid, dim3(256), lds, s, g, ipw);
+        else ARVAE_LAUNCH((conv_wgrad_rows_x3_kernel<false, false, 4>), grid, dim3(256), lds, s, g, ipw);
         const int count = taps * l->clo * l->chi;
-        hipLaunchKernelGGL(conv64_wgrad_reduce_kernel, dim3((count * 4 + 255) / 256), dim3(256), 0, s, ws, slices, taps, l->clo, l->chi, dwt);
+        ARVAE_LAUNCH(conv64_wgrad_reduce_kernel, dim3((count * 4 + 255) / 256), dim3(256), 0, s, ws, slices, taps, l->clo, l->chi, dwt);
         return check_launch("conv64_wgrad(rows)");
     }
     const int slices = (int)(((int64_t)l->n * l->lh * l->lw + C64_WG_SLICE - 1) / C64_WG_SLICE);
     const dim3 grid(taps, slices);
-    prof_gap();
-    if (pl && ph) hipLaunchKernelGGL((conv_wgrad_x3_kernel<true, true>), grid, dim3(256), 0, s, g);
-    else if (pl) hipLaunchKernelGGL((conv_wgrad_x3_kernel<true, false>), grid, dim3(256), 0, s, g);
-    else if (ph) hipLaunchKernelGGL((conv_wgrad_x3_kernel<false, true>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((conv_wgrad_x3_kernel<false, false>), grid, dim3(256), 0, s, g);
+    if (pl && ph) ARVAE_LAUNCH((conv_wgrad_x3_kernel<true, true>), grid, dim3(256), 0, s, g);
+    else if (pl) ARVAE_LAUNCH((conv_wgrad_x3_kernel<true, false>), grid, dim3(256), 0, s, g);
+    else if (ph) ARVAE_LAUNCH((conv_wgrad_x3_kernel<false, true>), grid, dim3(256), 0, s, g);
+    else ARVAE_LAUNCH((conv_wgrad_x3_kernel<false, false>), grid, dim3(256), 0, s, g);
     const int count = taps * l->clo * l->chi;
-    hipLaunchKernelGGL(conv64_wgrad_reduce_kernel, dim3((count * 4 + 255) / 256), dim3(256), 0, s, ws, slices, taps, l->clo, l->chi, dwt);
+    ARVAE_LAUNCH(conv64_wgrad_reduce_kernel, dim3((count * 4 + 255) / 256), dim3(256), 0, s, ws, slices, taps, l->clo, l->chi, dwt);
     return check_launch("conv64_wgrad");
 }
 

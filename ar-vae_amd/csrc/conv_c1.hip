@@ -355,9 +355,8 @@ int conv_c1_down(const arvae_link_t *l, const Operand &img, const float *wt, con
                  const float *gate, const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s) {
     const int tiles = l->n * (LO1 / TR1);
     Ep1 ep{bias, gate, gate_bits, bits_out, out, relu};
-    prof_gap();
     static const int cap = getenv("ARVAE_C1_DOWN_GRID") ? atoi(getenv("ARVAE_C1_DOWN_GRID")) : 512;      // 2 per CU, 4 tiles each: measured best of 256..4096
-    hipLaunchKernelGGL(down_c1_kernel, dim3(tiles < cap ? tiles : cap), dim3(256), 0, s, img, wt, ep, tiles);
+    ARVAE_LAUNCH(down_c1_kernel, dim3(tiles < cap ? tiles : cap), dim3(256), 0, s, img, wt, ep, tiles);
     return check_launch("down_c1_kernel");
 }
 
@@ -382,8 +381,7 @@ int conv_c1_up(const arvae_link_t *l, const float *lo, const float *wt, const fl
     const int tiles = l->n * (LO1 / TRU);
     static bool attr = false;
     if (!attr) { up_c1_lds(up_c1_kernel<ARVAE_RECON_BERNOULLI, false>); attr = true; }
-    prof_gap();
-    hipLaunchKernelGGL((up_c1_kernel<ARVAE_RECON_BERNOULLI, false>), dim3(up_c1_grid(tiles)), dim3(256), 2 * T_FLOATS * 4, s, lo,
+    ARVAE_LAUNCH((up_c1_kernel<ARVAE_RECON_BERNOULLI, false>), dim3(up_c1_grid(tiles)), dim3(256), 2 * T_FLOATS * 4, s, lo,
                        wt, bias, out, nullptr, 0.f, nullptr, nullptr, l->n, tiles);
     return check_launch("up_c1_kernel");
 }
@@ -400,12 +398,11 @@ int conv_c1_up_recon(const arvae_link_t *l, const float *lo, const float *wt, co
         up_c1_lds(up_c1_kernel<ARVAE_RECON_GAUSSIAN, true>);
         attr = true;
     }
-    prof_gap();
     if (dist == ARVAE_RECON_BERNOULLI)
-        hipLaunchKernelGGL((up_c1_kernel<ARVAE_RECON_BERNOULLI, true>), dim3(grid), dim3(256), 2 * T_FLOATS * 4, s, lo, wt, bias,
+        ARVAE_LAUNCH((up_c1_kernel<ARVAE_RECON_BERNOULLI, true>), dim3(grid), dim3(256), 2 * T_FLOATS * 4, s, lo, wt, bias,
                            out, x, inv_b, partial, dlogits, l->n, tiles);
     else
-        hipLaunchKernelGGL((up_c1_kernel<ARVAE_RECON_GAUSSIAN, true>), dim3(grid), dim3(256), 2 * T_FLOATS * 4, s, lo, wt, bias,
+        ARVAE_LAUNCH((up_c1_kernel<ARVAE_RECON_GAUSSIAN, true>), dim3(grid), dim3(256), 2 * T_FLOATS * 4, s, lo, wt, bias,
                            out, x, inv_b, partial, dlogits, l->n, tiles);
     *nb_out = grid;
     return check_launch("up_c1_kernel(recon)");
@@ -422,8 +419,7 @@ int64_t conv_c1_wgrad_ws_floats(const arvae_link_t *l) { return (int64_t)wgrad_c
 int conv_c1_wgrad_partial(const arvae_link_t *l, const Operand &lo, const Operand &img, float *dwt, float *dbias,
                           int bias_mode, float *slab, hipStream_t s, SlabJob *job) {
     const int tiles = l->n * (LO1 / TR1), grid = wgrad_c1_groups(l);
-    prof_gap();
-    hipLaunchKernelGGL(wgrad_c1_kernel, dim3(grid), dim3(256), 0, s, lo, img, slab, tiles);
+    ARVAE_LAUNCH(wgrad_c1_kernel, dim3(grid), dim3(256), 0, s, lo, img, slab, tiles);
     *job = SlabJob{slab, dwt, dbias, grid, SLAB_C1, bias_mode};
     return check_launch("wgrad_c1_kernel");
 }

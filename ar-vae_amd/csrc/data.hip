@@ -33,7 +33,7 @@ extern "C" int arvae_gather_rows_u8(const uint8_t *src, int64_t n_rows, int64_t 
     const int64_t total = count * (row_elems / 4);
     int64_t blocks = (total + 255) / 256;
     if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(gather_rows_u8_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), src, n_rows, row_elems / 4,
+    ARVAE_LAUNCH(gather_rows_u8_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), src, n_rows, row_elems / 4,
                        idx, count, scale, out);
     return check_launch("gather_rows_u8");
 }

@@ -490,16 +490,16 @@ static void launch_rows_gemm(const RowsGemm &g, int slices, hipStream_t s) {
     const dim3 grid((g.P + RG_TP - 1) / RG_TP, (g.Q + RG_TQ - 1) / RG_TQ, slices);
     static const bool fp32_mfma = getenv("ARVAE_ROWS_GEMM_FP32") != nullptr;
     if (fp32_mfma) {
-        if (va && vb) hipLaunchKernelGGL((rows_gemm_kernel<LA, LB, EP, true, true>), grid, dim3(256), 0, s, g);
-        else if (va) hipLaunchKernelGGL((rows_gemm_kernel<LA, LB, EP, true, false>), grid, dim3(256), 0, s, g);
-        else if (vb) hipLaunchKernelGGL((rows_gemm_kernel<LA, LB, EP, false, true>), grid, dim3(256), 0, s, g);
-        else hipLaunchKernelGGL((rows_gemm_kernel<LA, LB, EP, false, false>), grid, dim3(256), 0, s, g);
+        if (va && vb) ARVAE_LAUNCH((rows_gemm_kernel<LA, LB, EP, true, true>), grid, dim3(256), 0, s, g);
+        else if (va) ARVAE_LAUNCH((rows_gemm_kernel<LA, LB, EP, true, false>), grid, dim3(256), 0, s, g);
+        else if (vb) ARVAE_LAUNCH((rows_gemm_kernel<LA, LB, EP, false, true>), grid, dim3(256), 0, s, g);
+        else ARVAE_LAUNCH((rows_gemm_kernel<LA, LB, EP, false, false>), grid, dim3(256), 0, s, g);
         return;
     }
-    if (va && vb) hipLaunchKernelGGL((rows_gemm_x3_kernel<LA, LB, EP, true, true>), grid, dim3(256), 0, s, g);
-    else if (va) hipLaunchKernelGGL((rows_gemm_x3_kernel<LA, LB, EP, true, false>), grid, dim3(256), 0, s, g);
-    else if (vb) hipLaunchKernelGGL((rows_gemm_x3_kernel<LA, LB, EP, false, true>), grid, dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((rows_gemm_x3_kernel<LA, LB, EP, false, false>), grid, dim3(256), 0, s, g);
+    if (va && vb) ARVAE_LAUNCH((rows_gemm_x3_kernel<LA, LB, EP, true, true>), grid, dim3(256), 0, s, g);
+    else if (va) ARVAE_LAUNCH((rows_gemm_x3_kernel<LA, LB, EP, true, false>), grid, dim3(256), 0, s, g);
+    else if (vb) ARVAE_LAUNCH((rows_gemm_x3_kernel<LA, LB, EP, false, true>), grid, dim3(256), 0, s, g);
+    else ARVAE_LAUNCH((rows_gemm_x3_kernel<LA, LB, EP, false, false>), grid, dim3(256), 0, s, g);
 }
 
 // the operand needs no per-element work (no activation derivative, no keep-mask)
@@ -531,7 +531,7 @@ int dense_fwd(const arvae_link_t *l, const float *x, const float *w, const float
         launch_rows_gemm<RG_ROWSK, RG_ROWSK, RG_EP_FWD>(g, 1, s);
         return check_launch("rows_gemm_kernel<fwd>");
     }
-    hipLaunchKernelGGL(dense_fwd_kernel, dim3((p.batch + 31) / 32, (p.n_out + 31) / 32), dim3(DENSE_THREADS), 0, s, p);
+    ARVAE_LAUNCH(dense_fwd_kernel, dim3((p.batch + 31) / 32, (p.n_out + 31) / 32), dim3(DENSE_THREADS), 0, s, p);
     return check_launch("dense_fwd_kernel");
 }
 
@@ -545,7 +545,7 @@ int dense_dgrad(const arvae_link_t *l, const Operand &g, const float *w, const f
         launch_rows_gemm<RG_ROWSK, RG_KROWS, RG_EP_FWD>(r, 1, s);
         return check_launch("rows_gemm_kernel<dgrad>");
     }
-    hipLaunchKernelGGL(dense_dgrad_kernel, dim3((p.batch + 31) / 32, (p.n_in + 31) / 32), dim3(DENSE_THREADS), 0, s, p);
+    ARVAE_LAUNCH(dense_dgrad_kernel, dim3((p.batch + 31) / 32, (p.n_in + 31) / 32), dim3(DENSE_THREADS), 0, s, p);
     return check_launch("dense_dgrad_kernel");
 }
 
@@ -567,11 +567,11 @@ int dense_wgrad(const arvae_link_t *l, const Operand &g, const float *x, float *
         r.out = ws; r.ldo = p.n_in; r.slice_floats = slice_floats; r.want_bias = dbias != nullptr;
         launch_rows_gemm<RG_KROWS, RG_KROWS, RG_EP_SLICE>(r, slices, s);
         const int64_t total = w_floats + (dbias != nullptr ? p.n_out : 0);
-        hipLaunchKernelGGL(dense_split_reduce_kernel, dim3((unsigned)((total * 4 + 255) / 256)), dim3(256), 0, s, ws, slice_floats,
+        ARVAE_LAUNCH(dense_split_reduce_kernel, dim3((unsigned)((total * 4 + 255) / 256)), dim3(256), 0, s, ws, slice_floats,
                            slices, w_floats, p.n_out, dw, dbias);
         return check_launch("rows_gemm_kernel<wgrad>");
     }
-    hipLaunchKernelGGL(dense_wgrad_kernel, dim3((p.n_out + 31) / 32, (p.n_in + 31) / 32), dim3(DENSE_THREADS), 0, s, p);
+    ARVAE_LAUNCH(dense_wgrad_kernel, dim3((p.n_out + 31) / 32, (p.n_in + 31) / 32), dim3(DENSE_THREADS), 0, s, p);
     return check_launch("dense_wgrad_kernel");
 }
 
@@ -595,12 +595,12 @@ int dense_wgrad_flush(DenseWgradBatch *b, hipStream_t s) {
             one.count = 1;
             one.job[0] = b->job[j];
             one.tile_end[0] = b->tile_end[j] - (j > 0 ? b->tile_end[j - 1] : 0);
-            hipLaunchKernelGGL(dense_wgrad_batch_kernel, dim3(one.tile_end[0]), dim3(64 * NWB), 0, s, one);
+            ARVAE_LAUNCH(dense_wgrad_batch_kernel, dim3(one.tile_end[0]), dim3(64 * NWB), 0, s, one);
         }
         b->count = 0;
         return check_launch("dense_wgrad_batch_kernel");
     }
-    hipLaunchKernelGGL(dense_wgrad_batch_kernel, dim3(b->tile_end[b->count - 1]), dim3(64 * NWB), 0, s, *b);
+    ARVAE_LAUNCH(dense_wgrad_batch_kernel, dim3(b->tile_end[b->count - 1]), dim3(64 * NWB), 0, s, *b);
     b->count = 0;
     return check_launch("dense_wgrad_batch_kernel");
 }

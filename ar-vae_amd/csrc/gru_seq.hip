@@ -987,15 +987,14 @@ extern "C" int arvae_gru_seq_fwd(const arvae_gru_seq_t *seqs, int32_t nseq, int3
     fill_batch(&b, seqs, nseq);
     hipStream_t st = as_stream(stream);
     const dim3 grid((rows + 15) / 16, nseq);
-    prof_gap();
     if (gru_fp32_mfma()) {
-        if (hidden == 128) hipLaunchKernelGGL(gru_seq_fwd_kernel<128>, grid, dim3(512), 0, st, b, steps, rows);
-        else if (hidden == 64) hipLaunchKernelGGL(gru_seq_fwd_kernel<64>, grid, dim3(256), 0, st, b, steps, rows);
-        else hipLaunchKernelGGL(gru_seq_fwd_kernel<32>, grid, dim3(128), 0, st, b, steps, rows);
+        if (hidden == 128) ARVAE_LAUNCH(gru_seq_fwd_kernel<128>, grid, dim3(512), 0, st, b, steps, rows);
+        else if (hidden == 64) ARVAE_LAUNCH(gru_seq_fwd_kernel<64>, grid, dim3(256), 0, st, b, steps, rows);
+        else ARVAE_LAUNCH(gru_seq_fwd_kernel<32>, grid, dim3(128), 0, st, b, steps, rows);
     } else {
-        if (hidden == 128) hipLaunchKernelGGL(gru_seq_fwd_x3_kernel<128>, grid, dim3(512), 0, st, b, steps, rows);
-        else if (hidden == 64) hipLaunchKernelGGL(gru_seq_fwd_x3_kernel<64>, grid, dim3(256), 0, st, b, steps, rows);
-        else hipLaunchKernelGGL(gru_seq_fwd_x3_kernel<32>, grid, dim3(128), 0, st, b, steps, rows);
+        if (hidden == 128) ARVAE_LAUNCH(gru_seq_fwd_x3_kernel<128>, grid, dim3(512), 0, st, b, steps, rows);
+        else if (hidden == 64) ARVAE_LAUNCH(gru_seq_fwd_x3_kernel<64>, grid, dim3(256), 0, st, b, steps, rows);
+        else ARVAE_LAUNCH(gru_seq_fwd_x3_kernel<32>, grid, dim3(128), 0, st, b, steps, rows);
     }
     return check_launch("gru_seq_fwd_kernel");
 }
@@ -1011,15 +1010,14 @@ extern "C" int arvae_gru_seq_bwd(const arvae_gru_seq_t *seqs, int32_t nseq, int3
     fill_batch(&b, seqs, nseq);
     hipStream_t st = as_stream(stream);
     const dim3 grid((rows + 15) / 16, nseq);
-    prof_gap();
     if (gru_fp32_mfma()) {
-        if (hidden == 128) hipLaunchKernelGGL(gru_seq_bwd_kernel<128>, grid, dim3(512), 0, st, b, steps, rows);
-        else if (hidden == 64) hipLaunchKernelGGL(gru_seq_bwd_kernel<64>, grid, dim3(256), 0, st, b, steps, rows);
-        else hipLaunchKernelGGL(gru_seq_bwd_kernel<32>, grid, dim3(128), 0, st, b, steps, rows);
+        if (hidden == 128) ARVAE_LAUNCH(gru_seq_bwd_kernel<128>, grid, dim3(512), 0, st, b, steps, rows);
+        else if (hidden == 64) ARVAE_LAUNCH(gru_seq_bwd_kernel<64>, grid, dim3(256), 0, st, b, steps, rows);
+        else ARVAE_LAUNCH(gru_seq_bwd_kernel<32>, grid, dim3(128), 0, st, b, steps, rows);
     } else {
-        if (hidden == 128) hipLaunchKernelGGL(gru_seq_bwd_x3_kernel<128>, grid, dim3(512), 0, st, b, steps, rows);
-        else if (hidden == 64) hipLaunchKernelGGL(gru_seq_bwd_x3_kernel<64>, grid, dim3(256), 0, st, b, steps, rows);
-        else hipLaunchKernelGGL(gru_seq_bwd_x3_kernel<32>, grid, dim3(128), 0, st, b, steps, rows);
+        if (hidden == 128) ARVAE_LAUNCH(gru_seq_bwd_x3_kernel<128>, grid, dim3(512), 0, st, b, steps, rows);
+        else if (hidden == 64) ARVAE_LAUNCH(gru_seq_bwd_x3_kernel<64>, grid, dim3(256), 0, st, b, steps, rows);
+        else ARVAE_LAUNCH(gru_seq_bwd_x3_kernel<32>, grid, dim3(128), 0, st, b, steps, rows);
     }
     return check_launch("gru_seq_bwd_kernel");
 }
@@ -1052,14 +1050,13 @@ extern "C" int arvae_tick_free_run(const arvae_tick_weights_t *wts, const float 
     hipStream_t st = as_stream(stream);
     const dim3 grid((batch + 15) / 16);
     const bool m = mask != nullptr;
-    prof_gap();
     if (gru_fp32_mfma() || ws == nullptr) {
-        if (hidden == 128 && m) hipLaunchKernelGGL((tick_free_run_kernel<128, 2, true>), grid, dim3(512), 0, st, p);
-        else if (hidden == 128) hipLaunchKernelGGL((tick_free_run_kernel<128, 2, false>), grid, dim3(512), 0, st, p);
-        else if (hidden == 64 && m) hipLaunchKernelGGL((tick_free_run_kernel<64, 2, true>), grid, dim3(256), 0, st, p);
-        else if (hidden == 64) hipLaunchKernelGGL((tick_free_run_kernel<64, 2, false>), grid, dim3(256), 0, st, p);
-        else if (m) hipLaunchKernelGGL((tick_free_run_kernel<32, 2, true>), grid, dim3(128), 0, st, p);
-        else hipLaunchKernelGGL((tick_free_run_kernel<32, 2, false>), grid, dim3(128), 0, st, p);
+        if (hidden == 128 && m) ARVAE_LAUNCH((tick_free_run_kernel<128, 2, true>), grid, dim3(512), 0, st, p);
+        else if (hidden == 128) ARVAE_LAUNCH((tick_free_run_kernel<128, 2, false>), grid, dim3(512), 0, st, p);
+        else if (hidden == 64 && m) ARVAE_LAUNCH((tick_free_run_kernel<64, 2, true>), grid, dim3(256), 0, st, p);
+        else if (hidden == 64) ARVAE_LAUNCH((tick_free_run_kernel<64, 2, false>), grid, dim3(256), 0, st, p);
+        else if (m) ARVAE_LAUNCH((tick_free_run_kernel<32, 2, true>), grid, dim3(128), 0, st, p);
+        else ARVAE_LAUNCH((tick_free_run_kernel<32, 2, false>), grid, dim3(128), 0, st, p);
         return check_launch("tick_free_run_kernel");
     }
     ARVAE_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0, "tick_free_run: workspace must be 16-byte aligned");
@@ -1067,17 +1064,17 @@ extern "C" int arvae_tick_free_run(const arvae_tick_weights_t *wts, const float 
     const int items = 3 * (hidden / 32) * (hidden / 16) * 3 * 64;
     const uint4 *packed = reinterpret_cast<const uint4 *>(ws);
     if (hidden == 128) {
-        hipLaunchKernelGGL(tick_weight_prep_kernel<128>, dim3((items + 255) / 256), dim3(256), 0, st, tp);
-        if (m) hipLaunchKernelGGL((tick_free_run_x3_kernel<128, true>), grid, dim3(512), 0, st, p, packed);
-        else hipLaunchKernelGGL((tick_free_run_x3_kernel<128, false>), grid, dim3(512), 0, st, p, packed);
+        ARVAE_LAUNCH(tick_weight_prep_kernel<128>, dim3((items + 255) / 256), dim3(256), 0, st, tp);
+        if (m) ARVAE_LAUNCH((tick_free_run_x3_kernel<128, true>), grid, dim3(512), 0, st, p, packed);
+        else ARVAE_LAUNCH((tick_free_run_x3_kernel<128, false>), grid, dim3(512), 0, st, p, packed);
     } else if (hidden == 64) {
-        hipLaunchKernelGGL(tick_weight_prep_kernel<64>, dim3((items + 255) / 256), dim3(256), 0, st, tp);
-        if (m) hipLaunchKernelGGL((tick_free_run_x3_kernel<64, true>), grid, dim3(256), 0, st, p, packed);
-        else hipLaunchKernelGGL((tick_free_run_x3_kernel<64, false>), grid, dim3(256), 0, st, p, packed);
+        ARVAE_LAUNCH(tick_weight_prep_kernel<64>, dim3((items + 255) / 256), dim3(256), 0, st, tp);
+        if (m) ARVAE_LAUNCH((tick_free_run_x3_kernel<64, true>), grid, dim3(256), 0, st, p, packed);
+        else ARVAE_LAUNCH((tick_free_run_x3_kernel<64, false>), grid, dim3(256), 0, st, p, packed);
     } else {
-        hipLaunchKernelGGL(tick_weight_prep_kernel<32>, dim3((items + 255) / 256), dim3(256), 0, st, tp);
-        if (m) hipLaunchKernelGGL((tick_free_run_x3_kernel<32, true>), grid, dim3(128), 0, st, p, packed);
-        else hipLaunchKernelGGL((tick_free_run_x3_kernel<32, false>), grid, dim3(128), 0, st, p, packed);
+        ARVAE_LAUNCH(tick_weight_prep_kernel<32>, dim3((items + 255) / 256), dim3(256), 0, st, tp);
+        if (m) ARVAE_LAUNCH((tick_free_run_x3_kernel<32, true>), grid, dim3(128), 0, st, p, packed);
+        else ARVAE_LAUNCH((tick_free_run_x3_kernel<32, false>), grid, dim3(128), 0, st, p, packed);
     }
     return check_launch("tick_free_run_x3_kernel");
 }

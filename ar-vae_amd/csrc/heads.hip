@@ -157,7 +157,7 @@ int heads_latent_fwd(const arvae_layer_t *hm, const arvae_layer_t *hl, int batch
                                   (HEAD_ROWS * HEAD_HMAX + 2 * HEAD_ZMAX * (HEAD_HMAX + 4) + HEAD_ROWS * 32) * (int)sizeof(float));
         attr = true;
     }
-    hipLaunchKernelGGL(heads_latent_fwd_kernel, dim3((batch + HEAD_ROWS - 1) / HEAD_ROWS), dim3(256), lds, s, p);
+    ARVAE_LAUNCH(heads_latent_fwd_kernel, dim3((batch + HEAD_ROWS - 1) / HEAD_ROWS), dim3(256), lds, s, p);
     return check_launch("heads_latent_fwd");
 }
 
@@ -172,7 +172,7 @@ int heads_latent_bwd(const arvae_layer_t *hm, const arvae_layer_t *hl, int batch
     p.w_mu = params + hm->w_off; p.w_ls = params + hl->w_off; p.gate = gate;
     p.d_mu = d_mu; p.d_ls = d_ls; p.d_hidden = d_hidden;
     p.batch = batch; p.h = hm->link.chi; p.zdim = zdim;
-    hipLaunchKernelGGL(heads_latent_bwd_kernel, dim3((batch + HEAD_ROWS - 1) / HEAD_ROWS), dim3(256), 0, s, p);
+    ARVAE_LAUNCH(heads_latent_bwd_kernel, dim3((batch + HEAD_ROWS - 1) / HEAD_ROWS), dim3(256), 0, s, p);
     return check_launch("heads_latent_bwd");
 }
 

@@ -665,13 +665,13 @@ static int launch_gemm(const P &p, int M, int N, int zdim, bool wide_m, hipStrea
     // !wide_m (wgrad): few rows   -> 1x4 waves (32x128) when M<=32, else 2x2
     if (wide_m && N <= 32) {
         dim3 grid((M + 127) / 128, (N + 31) / 32, zdim);
-        hipLaunchKernelGGL((link_gemm_kernel<4, 1, P>), grid, dim3(256), 0, s, p);
+        ARVAE_LAUNCH((link_gemm_kernel<4, 1, P>), grid, dim3(256), 0, s, p);
     } else if (!wide_m && M <= 32) {
         dim3 grid((M + 31) / 32, (N + 127) / 128, zdim);
-        hipLaunchKernelGGL((link_gemm_kernel<1, 4, P>), grid, dim3(256), 0, s, p);
+        ARVAE_LAUNCH((link_gemm_kernel<1, 4, P>), grid, dim3(256), 0, s, p);
     } else {
         dim3 grid((M + 63) / 64, (N + 63) / 64, zdim);
-        hipLaunchKernelGGL((link_gemm_kernel<2, 2, P>), grid, dim3(256), 0, s, p);
+        ARVAE_LAUNCH((link_gemm_kernel<2, 2, P>), grid, dim3(256), 0, s, p);
     }
     return check_launch(what);
 }
@@ -702,7 +702,7 @@ extern "C" int arvae_link_down(const arvae_link_t *link, const arvae_operand_t *
     if (conv64_fits(link, false))
         return conv64_down(link, make_operand(hi), wt, bias, out_act, out_mask, lo, as_stream(stream));
     if (single_channel_mfma_fits(link)) {
-        hipLaunchKernelGGL(down_single_channel_mfma_kernel, dim3(link->n), dim3(256), sizeof(float) * link->hh * link->hw,
+        ARVAE_LAUNCH(down_single_channel_mfma_kernel, dim3(link->n), dim3(256), sizeof(float) * link->hh * link->hw,
                            as_stream(stream), p.g, make_operand(hi), wt, Epilogue{bias, out_mask, lo, out_act});
         return check_launch("link_down(single channel, mfma)");
     }
@@ -749,13 +749,13 @@ extern "C" int arvae_link_up(const arvae_link_t *link, const arvae_operand_t *lo
         const size_t t_bytes = sizeof(float) * 17 * link->lh * link->lw;
         if ((link->clo == 64 || link->clo == 32) && link->kh * link->kw <= 16 && t_bytes <= 96 * 1024 &&
             getenv("ARVAE_UP1_NAIVE") == nullptr) {
-            if (link->clo == 64) hipLaunchKernelGGL(up_single_channel_mfma_kernel<4>, dim3(link->n), dim3(256), t_bytes, st, p.g, lo->v, wt, ep);
-            else hipLaunchKernelGGL(up_single_channel_mfma_kernel<2>, dim3(link->n), dim3(256), t_bytes, st, p.g, lo->v, wt, ep);
+            if (link->clo == 64) ARVAE_LAUNCH(up_single_channel_mfma_kernel<4>, dim3(link->n), dim3(256), t_bytes, st, p.g, lo->v, wt, ep);
+            else ARVAE_LAUNCH(up_single_channel_mfma_kernel<2>, dim3(link->n), dim3(256), t_bytes, st, p.g, lo->v, wt, ep);
             return check_launch("link_up(single channel, mfma)");
         }
         const int blocks = min((total + 255) / 256, 256 * 8);
         const size_t lds = sizeof(float) * link->kh * link->kw * link->clo;
-        hipLaunchKernelGGL(up_single_channel_kernel, dim3(blocks), dim3(256), lds, st, p.g, lo->v, wt, ep, total);
+        ARVAE_LAUNCH(up_single_channel_kernel, dim3(blocks), dim3(256), lds, st, p.g, lo->v, wt, ep, total);
         return check_launch("link_up(single channel)");
     }
     p.lo = make_operand(lo);
@@ -848,7 +848,7 @@ extern "C" int arvae_link_wgrad(const arvae_link_t *link, const arvae_operand_t 
     if (int rc = launch_gemm(p, p.M, p.N, p.zsplit, false, st, "link_wgrad")) return rc;
     if (p.zsplit > 1) {
         const int mn = p.M * p.N;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((mn + 63) / 64), dim3(256), 0, st, ws, p.zsplit, mn, p.N,
+        ARVAE_LAUNCH(wgrad_reduce_kernel, dim3((mn + 63) / 64), dim3(256), 0, st, ws, p.zsplit, mn, p.N,
                            link->kh * link->kw, FastDiv(p.N), FastDiv(link->chi), dwt);
         if (int rc = check_launch("link_wgrad(reduce)")) return rc;
     }
@@ -880,11 +880,11 @@ static int channel_sum_launch(const Operand &g, int64_t rows, int channels, int 
                               float *ws, hipStream_t st) {
     int64_t blocks, rpb;
     channel_sum_split(rows, blocks, rpb);
-    hipLaunchKernelGGL(channel_sum_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, g, rows, channels, rpb, 0, 0,
+    ARVAE_LAUNCH(channel_sum_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, g, rows, channels, rpb, 0, 0,
                        ws);
     if (int rc = check_launch("channel_sum")) return rc;
     Operand part{ws, nullptr, nullptr, ARVAE_ACT_NONE};
-    hipLaunchKernelGGL(channel_sum_kernel<true>, dim3(1), dim3(256), 0, st, part, blocks, channels, blocks, perm_c,
+    ARVAE_LAUNCH(channel_sum_kernel<true>, dim3(1), dim3(256), 0, st, part, blocks, channels, blocks, perm_c,
                        perm_hw, out);
     return check_launch("channel_sum(finish)");
 }
@@ -906,7 +906,7 @@ __global__ __launch_bounds__(256) void operand_apply_kernel(Operand g, int64_t c
 extern "C" int arvae_operand_apply(const arvae_operand_t *g, int64_t count, float *out, arvae_stream_t stream) {
     ARVAE_REQUIRE(g && g->v && out && count > 0, "operand_apply: bad argument");
     const int64_t blocks = (count + 255) / 256;
-    hipLaunchKernelGGL(operand_apply_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, as_stream(stream),
+    ARVAE_LAUNCH(operand_apply_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, as_stream(stream),
                        make_operand(g), count, out);
     return check_launch("operand_apply_kernel");
 }

@@ -371,10 +371,10 @@ int recon_partials(const float *logits, const float *x, int64_t count, int64_t b
     const int nb = grid_for(count, 8, RECON_MAX_BLOCKS);
     const float inv_b = 1.f / (float)batch;
     if (dist == ARVAE_RECON_BERNOULLI)
-        hipLaunchKernelGGL(image_recon_kernel<ARVAE_RECON_BERNOULLI>, dim3(nb), dim3(256), 0, s, logits, x, count,
+        ARVAE_LAUNCH(image_recon_kernel<ARVAE_RECON_BERNOULLI>, dim3(nb), dim3(256), 0, s, logits, x, count,
                            inv_b, ws, dlogits);
     else
-        hipLaunchKernelGGL(image_recon_kernel<ARVAE_RECON_GAUSSIAN>, dim3(nb), dim3(256), 0, s, logits, x, count,
+        ARVAE_LAUNCH(image_recon_kernel<ARVAE_RECON_GAUSSIAN>, dim3(nb), dim3(256), 0, s, logits, x, count,
                            inv_b, ws, dlogits);
     *nb_out = nb;
     return check_launch("image_recon");
@@ -385,7 +385,7 @@ int reg_partials(const float *z_rows, const float *lab_rows, int64_t n_rows, con
                  int64_t n_cols, int64_t ldz, int64_t ldl, const RegDims &rd, int32_t r, float delta, float *ws,
                  hipStream_t s) {
     const unsigned bx = (unsigned)((n_rows + REG_ROWS_PER_BLOCK - 1) / REG_ROWS_PER_BLOCK);
-    hipLaunchKernelGGL(reg_loss_kernel, dim3(bx, r), dim3(256), 0, s, z_rows, lab_rows, n_rows, z_cols, lab_cols,
+    ARVAE_LAUNCH(reg_loss_kernel, dim3(bx, r), dim3(256), 0, s, z_rows, lab_rows, n_rows, z_cols, lab_cols,
                        n_cols, ldz, ldl, rd, delta, ws, ws + n_rows * r);
     return check_launch("reg_loss");
 }
@@ -406,7 +406,7 @@ int vae_finish(const float *rec_partial, int nb, int64_t batch, int64_t pix, con
     }
     p.reg_scale = reg_scale;
     p.rec_out = rec_out; p.kld_out = kld_out; p.reg_out = reg_out; p.scalars = scalars;
-    hipLaunchKernelGGL(vae_finish_kernel, dim3(1), dim3(1024), 0, s, p);
+    ARVAE_LAUNCH(vae_finish_kernel, dim3(1), dim3(1024), 0, s, p);
     return check_launch("image_vae_forward(finish)");
 }
 
@@ -417,7 +417,7 @@ using namespace arvae;
 extern "C" int arvae_latent_fwd(const float *mu, const float *log_std, const float *eps, int64_t count, float *sigma,
                                 float *z, arvae_stream_t stream) {
     ARVAE_REQUIRE(mu && log_std && eps && sigma && z && count > 0, "latent_fwd: bad argument");
-    hipLaunchKernelGGL(latent_fwd_kernel, dim3(grid_for(count)), dim3(256), 0, as_stream(stream), mu, log_std, eps,
+    ARVAE_LAUNCH(latent_fwd_kernel, dim3(grid_for(count)), dim3(256), 0, as_stream(stream), mu, log_std, eps,
                        count, sigma, z);
     return check_launch("latent_fwd");
 }
@@ -425,7 +425,7 @@ extern "C" int arvae_latent_fwd(const float *mu, const float *log_std, const flo
 extern "C" int arvae_latent_bwd(const float *g_z, const float *g_sigma, const float *eps, const float *sigma,
                                 int64_t count, float *d_mu, float *d_log_std, arvae_stream_t stream) {
     ARVAE_REQUIRE(eps && sigma && d_mu && d_log_std && count > 0, "latent_bwd: bad argument");
-    hipLaunchKernelGGL(latent_bwd_kernel, dim3(grid_for(count)), dim3(256), 0, as_stream(stream), g_z, g_sigma, eps,
+    ARVAE_LAUNCH(latent_bwd_kernel, dim3(grid_for(count)), dim3(256), 0, as_stream(stream), g_z, g_sigma, eps,
                        sigma, count, d_mu, d_log_std);
     return check_launch("latent_bwd");
 }
@@ -434,7 +434,7 @@ extern "C" int arvae_kld_fwd(const float *mu, const float *sigma, const float *p
                              int64_t batch, int64_t zdim, float beta, const float *capacity, float *out,
                              arvae_stream_t stream) {
     ARVAE_REQUIRE(mu && sigma && out && batch > 0 && zdim > 0, "kld_fwd: bad argument");
-    hipLaunchKernelGGL(kld_fwd_kernel, dim3(1), dim3(256), 0, as_stream(stream), mu, sigma, prior_mu, prior_sigma,
+    ARVAE_LAUNCH(kld_fwd_kernel, dim3(1), dim3(256), 0, as_stream(stream), mu, sigma, prior_mu, prior_sigma,
                        batch * zdim, 1.f / (float)batch, beta, capacity, out);
     return check_launch("kld_fwd");
 }
@@ -443,7 +443,7 @@ extern "C" int arvae_kld_bwd(const float *g, const float *mu, const float *sigma
                              const float *prior_sigma, int64_t batch, int64_t zdim, float beta, const float *kl_out,
                              const float *capacity, float *d_mu, float *d_sigma, arvae_stream_t stream) {
     ARVAE_REQUIRE(g && mu && sigma && kl_out && d_mu && d_sigma && batch > 0 && zdim > 0, "kld_bwd: bad argument");
-    hipLaunchKernelGGL(kld_bwd_kernel, dim3(grid_for(batch * zdim)), dim3(256), 0, as_stream(stream), g, mu, sigma,
+    ARVAE_LAUNCH(kld_bwd_kernel, dim3(grid_for(batch * zdim)), dim3(256), 0, as_stream(stream), g, mu, sigma,
                        prior_mu, prior_sigma, batch * zdim, 1.f / (float)batch, beta, kl_out, capacity, d_mu, d_sigma);
     return check_launch("kld_bwd");
 }
@@ -464,7 +464,7 @@ extern "C" int arvae_reg_loss(const float *z_rows, const float *lab_rows, int64_
     hipStream_t s = as_stream(stream);
     if (int rc = reg_partials(z_rows, lab_rows, n_rows, z_cols, lab_cols, n_cols, ldz, ldl, rd, r, delta, ws, s)) return rc;
     const double nn = (double)n_cols * (double)n_cols;
-    hipLaunchKernelGGL(reg_finish_kernel, dim3(1), dim3(256), 0, s, row_loss, row_grad, n_rows, r, rd, ldz,
+    ARVAE_LAUNCH(reg_finish_kernel, dim3(1), dim3(256), 0, s, row_loss, row_grad, n_rows, r, rd, ldz,
                        (float)(gamma / nn), (float)(2.0 * gamma * delta / nn), loss_out, dz);
     return check_launch("reg_loss(finish)");
 }
@@ -479,7 +479,7 @@ extern "C" int arvae_image_recon(const float *logits, const float *x, int64_t co
     const float inv_b = 1.f / (float)batch;
     int nb = 0;
     if (int rc = recon_partials(logits, x, count, batch, dist, ws, dlogits, s, &nb)) return rc;
-    hipLaunchKernelGGL(pair_finish_kernel, dim3(1), dim3(256), 0, s, ws, nb, inv_b, 1.f / (float)count, out);
+    ARVAE_LAUNCH(pair_finish_kernel, dim3(1), dim3(256), 0, s, ws, nb, inv_b, 1.f / (float)count, out);
     return check_launch("image_recon(finish)");
 }
 
@@ -489,15 +489,15 @@ extern "C" int arvae_token_recon(const float *weights, const int64_t *targets, i
     const int nb = grid_for(rows, 1, RECON_MAX_BLOCKS);
     hipStream_t s = as_stream(stream);
     const float inv = 1.f / (float)rows;
-    hipLaunchKernelGGL(token_recon_kernel, dim3(nb), dim3(256), 0, s, weights, targets, rows, vocab, inv, ws, dweights);
+    ARVAE_LAUNCH(token_recon_kernel, dim3(nb), dim3(256), 0, s, weights, targets, rows, vocab, inv, ws, dweights);
     if (int rc = check_launch("token_recon")) return rc;
-    hipLaunchKernelGGL(pair_finish_kernel, dim3(1), dim3(256), 0, s, ws, nb, inv, inv, out);
+    ARVAE_LAUNCH(pair_finish_kernel, dim3(1), dim3(256), 0, s, ws, nb, inv, inv, out);
     return check_launch("token_recon(finish)");
 }
 
 extern "C" int arvae_scale_by_scalar(const float *g, const float *x, int64_t count, float *y, arvae_stream_t stream) {
     ARVAE_REQUIRE(g && x && y && count > 0, "scale_by_scalar: bad argument");
-    hipLaunchKernelGGL(scale_by_scalar_kernel, dim3(grid_for(count, 4)), dim3(256), 0, as_stream(stream), g, x, count,
+    ARVAE_LAUNCH(scale_by_scalar_kernel, dim3(grid_for(count, 4)), dim3(256), 0, as_stream(stream), g, x, count,
                        y);
     return check_launch("scale_by_scalar");
 }
@@ -509,7 +509,7 @@ extern "C" int arvae_adam_step(float *p, const float *g, float *m, float *v, int
                   "adam_step: arenas must be 16-byte aligned");
     const double bc1 = 1.0 - pow(beta1, (double)step);
     const double bc2 = 1.0 - pow(beta2, (double)step);
-    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(count, 4)), dim3(256), 0, as_stream(stream), p, g, m, v, count,
+    ARVAE_LAUNCH(adam_kernel, dim3(grid_for(count, 4)), dim3(256), 0, as_stream(stream), p, g, m, v, count,
                        (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), (float)beta1, (float)beta2, (float)(1.0 - beta1),
                        (float)(1.0 - beta2), (float)eps, grad_scale);
     return check_launch("adam_step");

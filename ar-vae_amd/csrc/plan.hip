@@ -532,7 +532,7 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
     } else {
         int64_t blocks = (bz + 255) / 256;
         if (blocks > 1024) blocks = 1024;
-        hipLaunchKernelGGL(latent_bwd_full_kernel, dim3((unsigned)blocks), dim3(256), 0, st, cur, dz_reg, dz_extra, mu, sigma,
+        ARVAE_LAUNCH(latent_bwd_full_kernel, dim3((unsigned)blocks), dim3(256), 0, st, cur, dz_reg, dz_extra, mu, sigma,
                            eps, g_loss, ws + L.kld_out + 1, capacity, m->beta, 1.f / (float)batch, reg_scale, bz,
                            ws + L.d_mu, ws + L.d_ls);
         if (int rc = check_launch("image_vae_backward(latent)")) return rc;
@@ -547,7 +547,7 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
         const int64_t hn = in_elems(m->head_mu, batch);
         int64_t blocks2 = (hn + 255) / 256;
         if (blocks2 > 2048) blocks2 = 2048;
-        hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)blocks2), dim3(256), 0, st, cur, other, head_gate, hn);
+        ARVAE_LAUNCH(add_inplace_kernel, dim3((unsigned)blocks2), dim3(256), 0, st, cur, other, head_gate, hn);
         if (int rc = check_launch("image_vae_backward(add)")) return rc;
         pre = head_gate != nullptr;
     }

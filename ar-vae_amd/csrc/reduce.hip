@@ -63,7 +63,7 @@ static int job_blocks(const SlabJob &j) {
 }
 
 int slab_reduce(const SlabJob &job, hipStream_t s) {
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(job_blocks(job)), dim3(256), 0, s, job);
+    ARVAE_LAUNCH(slab_reduce_kernel, dim3(job_blocks(job)), dim3(256), 0, s, job);
     return check_launch(job.kind == SLAB_C32 ? "wgrad32_reduce_kernel" : "wgrad_c1_reduce_kernel");
 }
 
@@ -76,7 +76,7 @@ bool slab_reduce_defer(SlabReduceBatch *b, const SlabJob &job) {
 
 int slab_reduce_flush(SlabReduceBatch *b, hipStream_t s) {
     if (b->count == 0) return ARVAE_OK;
-    hipLaunchKernelGGL(slab_reduce_batch_kernel, dim3(b->block_end[b->count - 1]), dim3(256), 0, s, *b);
+    ARVAE_LAUNCH(slab_reduce_batch_kernel, dim3(b->block_end[b->count - 1]), dim3(256), 0, s, *b);
     b->count = 0;
     return check_launch("slab_reduce_batch_kernel");
 }

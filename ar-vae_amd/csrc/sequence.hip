@@ -228,7 +228,7 @@ using namespace arvae;
 extern "C" int arvae_gru_gates_fwd(const float *gi, const float *gh, const float *h_prev, int32_t batch, int32_t hidden,
                                    float *h_new, float *saved, arvae_stream_t stream) {
     ARVAE_REQUIRE(gi && gh && h_new && batch > 0 && hidden > 0, "gru_gates_fwd: bad argument");
-    hipLaunchKernelGGL(gru_gates_fwd_kernel, dim3(blocks_for((int64_t)batch * hidden)), dim3(256), 0, as_stream(stream), gi,
+    ARVAE_LAUNCH(gru_gates_fwd_kernel, dim3(blocks_for((int64_t)batch * hidden)), dim3(256), 0, as_stream(stream), gi,
                        gh, h_prev, batch, hidden, h_new, saved);
     return check_launch("gru_gates_fwd_kernel");
 }
@@ -236,7 +236,7 @@ extern "C" int arvae_gru_gates_fwd(const float *gi, const float *gh, const float
 extern "C" int arvae_gru_gates_bwd(const float *dh, const float *saved, const float *h_prev, int32_t batch, int32_t hidden,
                                    float *dgi, float *dgh, float *dh_prev, arvae_stream_t stream) {
     ARVAE_REQUIRE(dh && saved && dgi && dgh && dh_prev && batch > 0 && hidden > 0, "gru_gates_bwd: bad argument");
-    hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3(blocks_for((int64_t)batch * hidden)), dim3(256), 0, as_stream(stream), dh,
+    ARVAE_LAUNCH(gru_gates_bwd_kernel, dim3(blocks_for((int64_t)batch * hidden)), dim3(256), 0, as_stream(stream), dh,
                        saved, h_prev, batch, hidden, dgi, dgh, dh_prev);
     return check_launch("gru_gates_bwd_kernel");
 }
@@ -244,7 +244,7 @@ extern "C" int arvae_gru_gates_bwd(const float *dh, const float *saved, const fl
 extern "C" int arvae_embed_fwd(const int64_t *idx, const float *table, int32_t batch, int32_t steps, int32_t dim,
                                int32_t vocab, int32_t time_major, float *out, arvae_stream_t stream) {
     ARVAE_REQUIRE(idx && table && out && batch > 0 && steps > 0 && dim > 0 && vocab > 0, "embed_fwd: bad argument");
-    hipLaunchKernelGGL(embed_fwd_kernel, dim3(blocks_for((int64_t)batch * steps * dim)), dim3(256), 0, as_stream(stream), idx,
+    ARVAE_LAUNCH(embed_fwd_kernel, dim3(blocks_for((int64_t)batch * steps * dim)), dim3(256), 0, as_stream(stream), idx,
                        table, batch, steps, dim, vocab, time_major, out);
     return check_launch("embed_fwd_kernel");
 }
@@ -261,21 +261,21 @@ extern "C" int arvae_embed_bwd(const int64_t *idx, const float *g, int32_t batch
     const int blocks = (int)(((int64_t)batch * steps + EMBED_POS - 1) / EMBED_POS);
     const size_t lds = (size_t)EMBED_POS * (dim + 1) * sizeof(float) + EMBED_POS * sizeof(int);
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(embed_bwd_partial_kernel, dim3(blocks), dim3(256), lds, st, idx, g, batch, steps, dim, vocab, time_major, ws);
-    hipLaunchKernelGGL(embed_bwd_reduce_kernel, dim3((vocab * dim * 4 + 255) / 256), dim3(256), 0, st, ws, blocks, vocab * dim, dtable);
+    ARVAE_LAUNCH(embed_bwd_partial_kernel, dim3(blocks), dim3(256), lds, st, idx, g, batch, steps, dim, vocab, time_major, ws);
+    ARVAE_LAUNCH(embed_bwd_reduce_kernel, dim3((vocab * dim * 4 + 255) / 256), dim3(256), 0, st, ws, blocks, vocab * dim, dtable);
     return check_launch("embed_bwd_kernel");
 }
 
 extern "C" int arvae_row_argmax(const float *w, int32_t rows, int32_t cols, int64_t *idx, arvae_stream_t stream) {
     ARVAE_REQUIRE(w && idx && rows > 0 && cols > 0, "row_argmax: bad argument");
-    hipLaunchKernelGGL(row_argmax_kernel, dim3(blocks_for(rows)), dim3(256), 0, as_stream(stream), w, rows, cols, idx);
+    ARVAE_LAUNCH(row_argmax_kernel, dim3(blocks_for(rows)), dim3(256), 0, as_stream(stream), w, rows, cols, idx);
     return check_launch("row_argmax_kernel");
 }
 
 extern "C" int arvae_concat_cols(const float *a, const float *b, int64_t rows, int32_t ca, int32_t cb, float *out,
                                  arvae_stream_t stream) {
     ARVAE_REQUIRE(a && b && out && rows > 0 && ca > 0 && cb > 0, "concat_cols: bad argument");
-    hipLaunchKernelGGL(concat_cols_kernel, dim3(blocks_for(rows * (ca + cb))), dim3(256), 0, as_stream(stream), a, b, rows, ca,
+    ARVAE_LAUNCH(concat_cols_kernel, dim3(blocks_for(rows * (ca + cb))), dim3(256), 0, as_stream(stream), a, b, rows, ca,
                        cb, out);
     return check_launch("concat_cols_kernel");
 }
@@ -283,7 +283,7 @@ extern "C" int arvae_concat_cols(const float *a, const float *b, int64_t rows, i
 extern "C" int arvae_split_cols(const float *g, int64_t rows, int32_t ca, int32_t cb, float *da, float *db,
                                 int32_t accumulate_b, arvae_stream_t stream) {
     ARVAE_REQUIRE(g && rows > 0 && ca > 0 && cb > 0, "split_cols: bad argument");
-    hipLaunchKernelGGL(split_cols_kernel, dim3(blocks_for(rows * (ca + cb))), dim3(256), 0, as_stream(stream), g, rows, ca, cb,
+    ARVAE_LAUNCH(split_cols_kernel, dim3(blocks_for(rows * (ca + cb))), dim3(256), 0, as_stream(stream), g, rows, ca, cb,
                        da, db, accumulate_b);
     return check_launch("split_cols_kernel");
 }
@@ -291,14 +291,14 @@ extern "C" int arvae_split_cols(const float *g, int64_t rows, int32_t ca, int32_
 extern "C" int arvae_scale_mask(const float *x, const uint8_t *mask, float alpha, int64_t count, int32_t accumulate,
                                 float *y, arvae_stream_t stream) {
     ARVAE_REQUIRE(x && y && count > 0, "scale_mask: bad argument");
-    hipLaunchKernelGGL(scale_mask_kernel, dim3(blocks_for(count)), dim3(256), 0, as_stream(stream), x, mask, alpha, count,
+    ARVAE_LAUNCH(scale_mask_kernel, dim3(blocks_for(count)), dim3(256), 0, as_stream(stream), x, mask, alpha, count,
                        accumulate, y);
     return check_launch("scale_mask_kernel");
 }
 
 extern "C" int arvae_broadcast_rows(const float *v, int64_t rows, int32_t cols, float *y, arvae_stream_t stream) {
     ARVAE_REQUIRE(v && y && rows > 0 && cols > 0, "broadcast_rows: bad argument");
-    hipLaunchKernelGGL(broadcast_rows_kernel, dim3(blocks_for(rows * cols)), dim3(256), 0, as_stream(stream), v, rows, cols, y);
+    ARVAE_LAUNCH(broadcast_rows_kernel, dim3(blocks_for(rows * cols)), dim3(256), 0, as_stream(stream), v, rows, cols, y);
     return check_launch("broadcast_rows_kernel");
 }
 
@@ -308,7 +308,7 @@ extern "C" int arvae_measure_attributes(const int64_t *score, int32_t batch, int
                                              arvae_stream_t stream) {
     ARVAE_REQUIRE(score && midi_lut && is_note && is_density_note && rhythm_weights && out && batch > 0 && steps > 0 &&
                       vocab > 0 && rhythm_norm > 0.f, "measure_attributes: bad argument");
-    hipLaunchKernelGGL(measure_attributes_kernel, dim3(blocks_for(batch)), dim3(256), 0, as_stream(stream), score, batch, steps,
+    ARVAE_LAUNCH(measure_attributes_kernel, dim3(blocks_for(batch)), dim3(256), 0, as_stream(stream), score, batch, steps,
                        midi_lut, is_note, is_density_note, vocab, rhythm_weights, rhythm_norm, out);
     return check_launch("measure_attributes_kernel");
 }

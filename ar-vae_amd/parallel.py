@@ -35,8 +35,9 @@ class DataParallel:
         self._reg_fn = reg_fn
 
     def attach(self, trainer):
+        """make `trainer` data-parallel (its loss step gathers columns, its step() all-reduces); returns self"""
         trainer.data_parallel = self
-        return trainer
+        return self
 
     def broadcast_parameters(self, model, src=0):
         """Make every replica start from rank `src`'s weights."""

@@ -85,7 +85,16 @@ ROCPROF_NAMES = {
     'conv64_wgrad(rows)': ['arvae::conv_wgrad_rows_x3_kernel'],
     'gru_seq_fwd_kernel': ['arvae::gru_seq_fwd_x3_kernel<128>'], 'gru_seq_bwd_kernel': ['arvae::gru_seq_bwd_x3_kernel<128>'],
     'tick_free_run_x3_kernel': ['arvae::tick_free_run_x3_kernel<128>'],
+    'rows_gemm_kernel<fwd>': ['arvae::rows_gemm_x3_kernel'], 'rows_gemm_kernel<dgrad>': ['arvae::rows_gemm_x3_kernel'],
+    'rows_gemm_kernel<wgrad>': ['arvae::rows_gemm_x3_kernel'],
 }
+
+
+
+def rocprof_names(label):
+    """kernel names of a rocprofv3 trace behind a timeline label (labels that are not in the table are kernel names)"""
+    return ROCPROF_NAMES.get(label, ['arvae::' + label] if label.endswith('_kernel') else None)
+
 
 REG_DIMS = (1, 2, 3, 4, 5)
 BETA, GAMMA, DELTA = 4.0, 10.0, 1.0
@@ -283,7 +292,8 @@ def build_side_workload(kind, device, batch, rank=0, use_dp=False, graphs=False)
         data = (score, score)
     if use_dp:
         from arvae_amd.parallel import DataParallel
-        dp = DataParallel().attach(trainer)
+        dp = DataParallel()
+        dp.attach(trainer)
         dp.broadcast_parameters(model)
     model.train()
 
@@ -314,7 +324,7 @@ def side_roofline(kind, prof, prof_steps, batch):
         return None
     total = sum(v['ms'] for v in prof.values())
     name, dom = max(prof.items(), key=lambda kv: kv[1]['ms'])
-    out = {'kernel': name, 'rocprof_names': ROCPROF_NAMES.get(name), 'launches_per_step': dom['calls'] / prof_steps,
+    out = {'kernel': name, 'rocprof_names': rocprof_names(name), 'launches_per_step': dom['calls'] / prof_steps,
            'avg_launch_us': 1e3 * dom['ms'] / dom['calls'], 'us_per_step': 1e3 * dom['ms'] / prof_steps,
            'share_of_device_time': dom['ms'] / total, 'device_time_us_per_step': 1e3 * total / prof_steps}
     macs = SIDE_KERNEL_MACS.get(kind, {}).get(name)
@@ -502,7 +512,7 @@ def run_dsprites(device, args, fence, rank, world, use_dp):
             roof['traffic'] = None
     if b != 512:
         roof['traffic'] = None
-    roof.update({'kernel': dom_name, 'rocprof_names': ROCPROF_NAMES.get(dom_name),
+    roof.update({'kernel': dom_name, 'rocprof_names': rocprof_names(dom_name),
                  'launches_per_step': dom['calls'] / prof_steps, 'avg_launch_us': avg_ms * 1e3,
                  'algorithmic_bytes_per_launch': dom['bytes'] / dom['calls'],
                  'share_of_device_time': dom['ms'] / sum(v['ms'] for v in prof.values())})
@@ -570,7 +580,13 @@ def main():
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
     use_dp = world > 1 or args.force_dp
+    out_fd = None
     if use_dp:
+        # RCCL prints a version banner on stdout; the contract is ONE JSON line there.  Everything this process (and the
+        # libraries it loads) writes to fd 1 goes to stderr from here on; the line itself is written to the saved descriptor.
+        sys.stdout.flush()
+        out_fd = os.dup(1)
+        os.dup2(2, 1)
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
@@ -594,7 +610,10 @@ def main():
                     sec[kind] = {'error': f'{type(e).__name__}: {e}'}
             line['secondary'] = sec
     if rank == 0 and line is not None:
-        print(json.dumps(line), flush=True)
+        if out_fd is None:
+            print(json.dumps(line), flush=True)
+        else:
+            os.write(out_fd, (json.dumps(line) + '\n').encode())
     if use_dp:
         import torch.distributed as dist
         dist.destroy_process_group()

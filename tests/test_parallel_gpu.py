@@ -72,8 +72,12 @@ def test_rccl_ranks_equal_single_process(tmp_path, golden_dir, world, capacity, 
         gr = got['grad/' + name].astype(np.float64).ravel()
         want = ref['grads'][name].astype(np.float64).ravel()
         assert np.linalg.norm(gr - want) <= 2e-3 * np.linalg.norm(want) + 1e-9, name
-        d = got['param/' + name].astype(np.float64) - ref['params'][name].astype(np.float64)
-        assert np.abs(d).max() <= 2e-5, name               # one Adam step of lr 1e-4: |delta| <= 1e-4 per entry
+        # Adam's first step is -lr * g / (|g| + eps): an entry whose gradient is ~0 turns summation noise into a full-size
+        # step, so the update is compared by its norm (as the golden tests do) and by the share of entries that moved alike
+        d_got = got['param/' + name].astype(np.float64).ravel() - state[name].astype(np.float64).ravel()
+        d_ref = ref['params'][name].astype(np.float64).ravel() - state[name].astype(np.float64).ravel()
+        np.testing.assert_allclose(np.linalg.norm(d_got), np.linalg.norm(d_ref), rtol=2e-3, err_msg=name)
+        assert (np.abs(d_got - d_ref) > 2e-5).mean() <= 2e-3, name
 
 
 def _bench(*args):
