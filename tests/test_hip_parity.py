@@ -958,3 +958,160 @@ def test_data_parallel_path_single_rank_rccl(dev):
         outs.append(json.loads(lines[-1]))
     a, b = (o['config']['final_loss'] for o in outs)
     assert abs(a - b) <= 2e-3 * abs(a), (a, b)     # eps differs per run only through the shared torch seed -> identical draws
+
+
+# ---------------------------------------------------------------- BASELINE.json's full batch sizes, HIP vs the oracle
+def _compare_step(got_terms, got_loss, got_acc, got_grads, ref, grad_tol):
+    for k in ('recons', 'dist', 'reg'):
+        close(got_terms[k], float(ref['terms'][k]), rtol=1e-4)
+    close(got_loss, float(ref['terms']['loss']), rtol=1e-4)
+    close(got_acc, float(ref['terms']['acc']), rtol=1e-4)
+    for name, want in ref['grads'].items():
+        gr = got_grads[name].astype(np.float64).ravel()
+        want = want.astype(np.float64).ravel()
+        close(np.linalg.norm(gr), np.linalg.norm(want), rtol=1e-3)
+        assert np.linalg.norm(gr - want) <= grad_tol * np.linalg.norm(want) + 1e-9, name
+
+
+def test_dsprites_step_at_baseline_batch_512_vs_oracle(dev):
+    """BASELINE.json configs[1]: the headline batch, full training step against the oracle (loss terms rtol 1e-4, z / mu
+    atol 1e-4, every gradient tensor by norm and relative L2, the weights after Adam)."""
+    b = 512
+    state = syn.synth_state(o_vae.DSPRITES_SHAPES, 1, 1.6)
+    x, lab = syn.dsprites_batch(b, seed=1234)
+    eps = syn.normal_noise((b, 10), seed=1)
+    got = run_hip_image_step(dev, 'dsprites', state, x, lab, eps, 4.0, 0.0, 'bernoulli', None)
+    ref = o_step.image_step('dsprites', state, x, lab, eps, (1, 2, 3, 4, 5), 4.0, 10.0, 1.0)
+    _compare_step(got['terms'], got['loss'], got['acc'], got['grads'], ref, 2e-3)
+    outs = got['trainer'].last_outputs
+    close(outs['z'], ref['terms']['z'], rtol=0, atol=1e-4)
+    close(outs['mu'], ref['terms']['mu'], rtol=0, atol=1e-4)
+    close(outs['sigma'], ref['terms']['sigma'], rtol=1e-4, atol=1e-6)
+    for name in state:
+        d_got = (got['params'][name].astype(np.float64) - state[name]).ravel()
+        d_ref = (ref['params'][name].astype(np.float64) - state[name]).ravel()
+        close(np.linalg.norm(d_got), np.linalg.norm(d_ref), rtol=2e-3)
+
+
+def test_mnist_step_at_baseline_batch_1024_vs_oracle(dev):
+    """BASELINE.json configs[2]: Morpho-MNIST AR-VAE at batch 1024 in TRAIN mode with explicit dropout keep-masks (the five
+    Dropout(0.5) layers of imagevae/mnist_vae.py:16-47), conv64.hip path with its full grid of tiles."""
+    b = 1024
+    state = syn.synth_state(o_vae.SHAPES['mnist'], 3, 0.7)
+    x, lab = syn.mnist_batch(b, seed=4321)
+    eps = syn.normal_noise((b, 16), seed=15)
+    masks = syn.dropout_masks([(b,) + s for s in o_vae.MNIST_MASK_SHAPES], 21)
+    got = run_hip_image_step(dev, 'mnist', state, x, lab, eps, 1.0, 0.0, 'bernoulli', masks)
+    ref = o_step.image_step('mnist', state, x, lab, eps, (1, 2, 3, 4, 5, 6), 1.0, 10.0, 1.0, masks=masks)
+    _compare_step(got['terms'], got['loss'], got['acc'], got['grads'], ref, 2e-3)
+    outs = got['trainer'].last_outputs
+    close(outs['z'], ref['terms']['z'], rtol=0, atol=1e-4)
+    close(outs['mu'], ref['terms']['mu'], rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize('teacher', [True, False], ids=['teacher_forced', 'free_running'])
+def test_measure_step_at_baseline_batch_256_vs_oracle(dev, teacher):
+    """BASELINE.json configs[4]: MeasureVAE (H = 128, Z = 32, V = 35) training step at batch 256, forward AND backward,
+    teacher-forced and free-running; the sampled notes must equal the oracle's (the output layer is given a positive top-1
+    margin as in the golden cases, SURVEY.md section 7 'top-1 tie-breaking')."""
+    from arvae_amd.measure_vae import MeasureVAE
+    from arvae_amd.measure_vae_trainer import MeasureVAETrainer
+    from oracle import attributes as o_attr
+    from oracle import measure_vae as o_mvae
+    b = 256
+    state = syn.synth_state(o_mvae.shapes(), 4)
+    state['decoder.tick_emb_to_note_emb.0.bias'] = state['decoder.tick_emb_to_note_emb.0.bias'] + np.float32(0.5)
+    state['decoder.tick_emb_to_note_emb.0.weight'] = state['decoder.tick_emb_to_note_emb.0.weight'] * np.float32(3.0)
+    score = syn.measure_batch(b, seed=5)
+    eps = syn.normal_noise((b, 32), seed=1)
+    ds = _FolkDataset()
+    model = MeasureVAE(ds, 10, 2, 2, 128, 0.0, 32, 2, 128, 0.0, False, 'folk')
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    trainer = MeasureVAETrainer(ds, model, lr=1e-4, reg_type=('all',), reg_dim=(0, 1, 2, 3), beta=0.001, gamma=1.0,
+                                capacity=0.0, rand=0, delta=10.0)
+    trainer.cuda()
+    model.train()
+    model.decoder.teacher_forcing_prob = 2.0 if teacher else -1.0
+    model.push_noise(torch.from_numpy(eps))
+    st = torch.from_numpy(score).to(dev)
+    trainer.zero_grad()
+    weights, samples, z_dist, _, z, _ = model(st, st, train=True)
+    model.push_noise(torch.from_numpy(eps))
+    loss, acc = trainer.loss_and_acc_for_batch((st, st), 0, 0, True)
+    loss.backward()
+    grads = {k: p.grad.detach().cpu().numpy().copy() for k, p in model.named_parameters()}
+    attr = o_attr.attribute_labels(score, *syn.measure_tables())
+    ref = o_step.measure_step(state, score, eps, attr, (0, 1, 2, 3), 0.001, 1.0, 10.0, teacher)
+    np.testing.assert_array_equal(samples.cpu().numpy(), ref['terms']['samples'])
+    close(z, ref['terms']['z'], rtol=0, atol=1e-4)
+    close(z_dist.loc, ref['terms']['mu'], rtol=0, atol=1e-4)
+    close(weights, ref['terms']['weights'], rtol=1e-4, atol=1e-4)
+    terms = {k: v for k, v in trainer.last_terms.items()}
+    _compare_step(terms, loss, acc, grads, ref, 3e-3)
+
+
+def test_free_running_decoder_outside_the_one_launch_kernel(dev):
+    """--decoder_hidden_size 32 with a 35-note vocabulary: arvae_tick_free_run is not built for it (vocab > 16*(hidden/16)),
+    the decoder must fall back to the tick-by-tick pass and still return the oracle's notes (advisor finding, round 1)."""
+    from arvae_amd import ops
+    from arvae_amd.measure_vae import MeasureVAE
+    from oracle import measure_vae as o_mvae
+    assert not ops.tick_free_run_supported(32, 35) and ops.tick_free_run_supported(128, 35) and ops.tick_free_run_supported(32, 32)
+    ds = _FolkDataset()
+    torch.manual_seed(3)
+    model = MeasureVAE(ds, 10, 2, 2, 64, 0.0, 16, 2, 32, 0.0, False, 'folk')
+    with torch.no_grad():
+        model.decoder.tick_emb_to_note_emb[0].weight.mul_(3.0)
+        model.decoder.tick_emb_to_note_emb[0].bias.add_(0.5)
+    state = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+    model.cuda().eval()
+    b = 21
+    score = syn.measure_batch(b, seed=77)
+    eps = syn.normal_noise((b, 16), seed=78)
+    model.push_noise(torch.from_numpy(eps))
+    st = torch.from_numpy(score).to(dev)
+    with torch.no_grad():
+        weights, samples, _, _, z, _ = model(st, st, train=False)
+    p = {k: torch.from_numpy(v) for k, v in state.items()}
+    w_ref, s_ref, _, _, z_ref = o_mvae.forward(p, torch.from_numpy(score), torch.from_numpy(eps), False)
+    np.testing.assert_array_equal(samples.cpu().numpy(), s_ref.numpy())
+    close(z, z_ref.numpy(), rtol=0, atol=1e-4)
+    close(weights, w_ref.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_epoch_means_under_graph_replay_equal_eager(dev):
+    """A multi-batch epoch: the mean loss AND the mean accuracy reported by loss_and_acc_on_epoch are the same whether the
+    steps are replayed from HIP graphs or run eagerly (the replayed step's outputs are static buffers the next replay
+    overwrites, so the epoch accumulators must start from copies -- advisor finding, round 1), and changing beta
+    re-captures (the hyper-parameters are immediates of the captured launches)."""
+    from arvae_amd.measure_vae import MeasureVAE
+    from arvae_amd.measure_vae_trainer import MeasureVAETrainer
+    b = 32
+    loader = [(x, x) for x in (torch.from_numpy(syn.measure_batch(b, seed=70 + i)).to(dev) for i in range(4))]
+    got = {}
+    for replay in (True, False):
+        ds = _FolkDataset()
+        torch.manual_seed(0)
+        model = MeasureVAE(ds, 10, 2, 2, 64, 0.0, 16, 2, 64, 0.0, False, 'folk')
+        trainer = MeasureVAETrainer(ds, model, lr=1e-3, reg_type=('all',), reg_dim=(0, 1, 2, 3), beta=0.001, gamma=1.0,
+                                    capacity=0.0, rand=0, delta=10.0)
+        trainer.use_graph_replay = replay
+        trainer.cuda()
+        model.train()
+        model.decoder.teacher_forcing_prob = 2.0
+        try:
+            model.encoder.static_eps = torch.from_numpy(syn.normal_noise((b, 16), seed=3)).to(dev)
+            first = trainer.loss_and_acc_on_epoch(loader, epoch_num=0, train=True)
+            captured = getattr(trainer, '_graphed', None)
+            trainer.beta = 0.5                                  # e.g. an annealing schedule in update_scheduler
+            second = trainer.loss_and_acc_on_epoch(loader, epoch_num=1, train=True)
+            if replay:
+                assert captured is not None and trainer._graphed is not captured
+        finally:
+            type(model.encoder).static_eps = None
+            model.encoder.static_eps = None
+        got[replay] = (first, second)
+    for (l_a, a_a), (l_b, a_b) in zip(got[True], got[False]):
+        close(l_a, l_b, rtol=1e-6)
+        close(a_a, a_b, rtol=1e-6)
+    assert got[True][1][0] > got[True][0][0]                    # the larger beta shows in the loss
