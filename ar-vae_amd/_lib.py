@@ -69,8 +69,9 @@ SIGNATURES = {
     'arvae_device_count': (c_i32, []),
     'arvae_profile_begin': (c_i32, [c_vp]),
     'arvae_profile_end': (c_i64, [ctypes.c_char_p, c_i64]),
-    'arvae_link_down': (c_i32, [_P(LinkDesc), _P(OperandDesc), c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
-    'arvae_link_up': (c_i32, [_P(LinkDesc), _P(OperandDesc), c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
+    'arvae_link_ws_floats': (c_i64, [_P(LinkDesc)]),
+    'arvae_link_down': (c_i32, [_P(LinkDesc), _P(OperandDesc), c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    'arvae_link_up': (c_i32, [_P(LinkDesc), _P(OperandDesc), c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),
     'arvae_link_wgrad_ws_floats': (c_i64, [_P(LinkDesc)]),
     'arvae_link_wgrad': (c_i32, [_P(LinkDesc), _P(OperandDesc), _P(OperandDesc), c_vp, c_vp, c_i32, c_vp, c_vp]),
     'arvae_channel_sum_ws_floats': (c_i64, [c_i64, c_i32]),

@@ -148,15 +148,9 @@ __global__ __launch_bounds__(256) void conv64_weight_prep_kernel(const float *__
     out[i] = transposed ? wt[((int64_t)c * q_count + q) * taps + tap] : wt[((int64_t)q * c_count + c) * taps + tap];
 }
 
-// The re-ordered copy lives in a process-wide scratch buffer (allocated on first use, 1 MB): every launch re-creates it on
-// the caller's stream right before the convolution, so calls must be stream-ordered with respect to each other (one
-// stream, as the trainers use).
-constexpr int64_t C64_SCRATCH_FLOATS = 16 * 128 * 128;
-static float *conv64_scratch() {
-    static float *buf = nullptr;
-    if (buf == nullptr && hipMalloc((void **)&buf, C64_SCRATCH_FLOATS * sizeof(float)) != hipSuccess) buf = nullptr;
-    return buf;
-}
+// The re-ordered copy lives in the CALLER's workspace (arvae_link_ws_floats): every launch re-creates it on the caller's
+// stream right before the convolution.
+int64_t conv64_ws_floats(const arvae_link_t *l) { return ((int64_t)l->kh * l->kw * l->chi * l->clo + 3) / 4 * 4; }
 
 static bool plain_op(const Operand &o) { return o.y == nullptr || (o.act == ARVAE_ACT_NONE && o.mask == nullptr); }
 
@@ -169,10 +163,10 @@ bool conv64_fits(const arvae_link_t *l, bool up) {
            (l->kh * l->kw * red) % RG_R == 0 && outc >= 4 && red <= 128 && outc <= 128 && l->hi_perm_c == 0 && l->lo_perm_c == 0;
 }
 
-static int launch_conv_rows(ConvRows g, const float *wt, bool transposed, hipStream_t s, const char *what) {
-    float *packed = conv64_scratch();
+static int launch_conv_rows(ConvRows g, const float *wt, bool transposed, float *packed, hipStream_t s, const char *what) {
     const int taps = g.kh * g.kw, wcount = g.q * taps * g.cs;
-    if (packed == nullptr || wcount > C64_SCRATCH_FLOATS) return fail(ARVAE_E_INVALID, "%s: no scratch for the re-ordered weights", what);
+    if (packed == nullptr || (reinterpret_cast<uintptr_t>(packed) & 15) != 0)
+        return fail(ARVAE_E_INVALID, "%s: needs arvae_link_ws_floats() floats of 16-byte aligned workspace for the re-ordered weights", what);
     ARVAE_LAUNCH(conv64_weight_prep_kernel, dim3((wcount + 255) / 256), dim3(256), 0, s, wt, packed, g.q, g.cs, taps, transposed ? 1 : 0);
     g.wt = packed;
     const int M = g.n * g.oh * g.ow;
@@ -189,24 +183,24 @@ static int launch_conv_rows(ConvRows g, const float *wt, bool transposed, hipStr
 
 // lo[n][lh][lw][clo] = act(conv(hi) + bias) * mask     (Conv2d forward / ConvTranspose2d data gradient)
 int conv64_down(const arvae_link_t *l, const Operand &hi, const float *wt, const float *bias, int act, const uint8_t *mask,
-                float *lo, hipStream_t s) {
+                float *lo, float *ws, hipStream_t s) {
     ConvRows g{};
     g.src = hi; g.n = l->n; g.sh = l->hh; g.sw = l->hw; g.cs = l->chi;
     g.oh = l->lh; g.ow = l->lw; g.q = l->clo;
     g.kh = l->kh; g.kw = l->kw; g.sgn = 1; g.off = -l->pad;
     g.bias = bias; g.mask = mask; g.act = act; g.out = lo;
-    return launch_conv_rows(g, wt, false, s, "conv64_down");          // wt[clo][chi][ky][kx]: q = clo, c = chi
+    return launch_conv_rows(g, wt, false, ws, s, "conv64_down");          // wt[clo][chi][ky][kx]: q = clo, c = chi
 }
 
 // hi[n][hh][hw][chi] = act(convT(lo) + bias) * mask    (ConvTranspose2d forward / Conv2d data gradient)
 int conv64_up(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, int act, const uint8_t *mask,
-              float *hi, hipStream_t s) {
+              float *hi, float *ws, hipStream_t s) {
     ConvRows g{};
     g.src = lo; g.n = l->n; g.sh = l->lh; g.sw = l->lw; g.cs = l->clo;
     g.oh = l->hh; g.ow = l->hw; g.q = l->chi;
     g.kh = l->kh; g.kw = l->kw; g.sgn = -1; g.off = l->pad;
     g.bias = bias; g.mask = mask; g.act = act; g.out = hi;
-    return launch_conv_rows(g, wt, true, s, "conv64_up");             // wt[clo][chi][ky][kx]: q = chi, c = clo
+    return launch_conv_rows(g, wt, true, ws, s, "conv64_up");             // wt[clo][chi][ky][kx]: q = chi, c = clo
 }
 
 // ---- weight gradient ----------------------------------------------------------------------------------------------

@@ -102,7 +102,7 @@ struct Layout {
     // 32-channel conv layers: the weights split into bf16 terms in per-lane order, rebuilt at the start of every forward
     // pass by ONE launch and used by the layer's forward and data-gradient kernels (-1: not such a layer)
     int64_t enc_wprep[ARVAE_MAX_LAYERS], dec_wprep[ARVAE_MAX_LAYERS];
-    int64_t log_std, dlogits, dz_reg, d_mu, d_ls, g_a, g_b, slab, rec_ws, reg_ws, rec_out, kld_out, reg_out, total;
+    int64_t log_std, dlogits, dz_reg, d_mu, d_ls, g_a, g_b, slab, link_ws, rec_ws, reg_ws, rec_out, kld_out, reg_out, total;
     int64_t slab_floats;
 };
 
@@ -111,13 +111,14 @@ static int make_layout(const arvae_image_vae_t *m, int64_t n, int64_t n_cols, La
     ARVAE_REQUIRE(m->n_enc >= 1 && m->n_enc <= ARVAE_MAX_LAYERS && m->n_dec >= 1 && m->n_dec <= ARVAE_MAX_LAYERS,
                   "image_vae: layer counts out of range");
     ARVAE_REQUIRE(m->zdim > 0 && m->n_reg >= 0 && m->n_reg <= 16, "image_vae: bad zdim / n_reg");
-    int64_t off = 0, gmax = 0, slab = 0;
+    int64_t off = 0, gmax = 0, slab = 0, lws = 0;
     auto take = [&](int64_t count) { const int64_t o = off; off += up4(count); return o; };
     auto visit = [&](const arvae_layer_t &l) {
         arvae_link_t lk = l.link;
         lk.n = (int32_t)n;
         const int64_t s = arvae_link_wgrad_ws_floats(&lk);
         if (s > slab) slab = s;
+        if (arvae_link_ws_floats(&lk) > lws) lws = arvae_link_ws_floats(&lk);
         if (out_elems(l, n) > gmax) gmax = out_elems(l, n);
         if (in_elems(l, n) > gmax) gmax = in_elems(l, n);
     };
@@ -167,6 +168,7 @@ static int make_layout(const arvae_image_vae_t *m, int64_t n, int64_t n_cols, La
     L.g_b = take(gmax);
     L.slab_floats = slab;
     L.slab = take(slab);
+    L.link_ws = take(lws);               // scratch of one arvae_link_down / _up call at a time (stream-ordered)
     L.rec_ws = take(arvae_recon_ws_floats(out_elems(m->dec[m->n_dec - 1], n)));
     L.reg_ws = take(arvae_reg_loss_ws_floats(n, m->n_reg > 0 ? m->n_reg : 1));
     L.rec_out = take(4);
@@ -180,7 +182,7 @@ static int make_layout(const arvae_image_vae_t *m, int64_t n, int64_t n_cols, La
 static arvae_operand_t plain(const float *v) { return arvae_operand_t{v, nullptr, nullptr, ARVAE_ACT_NONE}; }
 
 static int layer_forward(const arvae_layer_t &l, int32_t n, const float *params, const float *in, const uint8_t *mask,
-                         float *out, uint16_t *bits_out, arvae_stream_t st, const float *wprep = nullptr) {
+                         float *out, uint16_t *bits_out, float *link_ws, arvae_stream_t st, const float *wprep = nullptr) {
     arvae_link_t lk = l.link;
     lk.n = n;
     const arvae_operand_t op = plain(in);
@@ -192,7 +194,8 @@ static int layer_forward(const arvae_layer_t &l, int32_t n, const float *params,
                            : conv32_down(&lk, make_operand(&op), w, b, 1, nullptr, nullptr, bits_out, out, hs, wprep);
         return conv_c1_down(&lk, make_operand(&op), w, b, 1, nullptr, nullptr, bits_out, out, hs);
     }
-    return l.is_up ? arvae_link_up(&lk, &op, w, b, l.act, mask, out, st) : arvae_link_down(&lk, &op, w, b, l.act, mask, out, st);
+    return l.is_up ? arvae_link_up(&lk, &op, w, b, l.act, mask, out, link_ws, st)
+                   : arvae_link_down(&lk, &op, w, b, l.act, mask, out, link_ws, st);
 }
 
 // ---- second stream for the weight gradients ---------------------------------------------------------
@@ -235,7 +238,7 @@ static SideStream *side_stream(bool force = false) {
 //   *gated : set when the gate was applied (a fast kernel with a gated epilogue was available)
 static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params, float *grads, const float *in,
                           const float *out, const uint8_t *mask, const float *g, bool g_is_pre, const float *gate,
-                          float *d_in, bool *gated, float *slab, DenseWgradBatch *defer, float *own_slab,
+                          float *d_in, bool *gated, float *slab, float *link_ws, DenseWgradBatch *defer, float *own_slab,
                           SlabReduceBatch *rdefer, arvae_stream_t st, const float *g_scale = nullptr,
                           const uint16_t *gate_bits = nullptr, const float *wprep = nullptr) {
     arvae_link_t lk = l.link;
@@ -271,7 +274,7 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
                 rc = conv_c1_down(&lk, g_op, w, nullptr, 0, gate_bits ? nullptr : gate, gate_bits, nullptr, d_in, hs);
                 *gated = true;
             } else {
-                rc = arvae_link_down(&lk, &gop, w, nullptr, ARVAE_ACT_NONE, nullptr, d_in, st);
+                rc = arvae_link_down(&lk, &gop, w, nullptr, ARVAE_ACT_NONE, nullptr, d_in, link_ws, st);
             }
         } else {                                         // forward DOWN -> data gradient is an UP map
             if (gate != nullptr && gop.y == nullptr && conv32_fits(&lk)) {
@@ -282,7 +285,7 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
                 rc = dense_dgrad(&lk, make_operand(&gop), w, gate, d_in, hs);
                 *gated = true;
             } else {
-                rc = arvae_link_up(&lk, &gop, w, nullptr, ARVAE_ACT_NONE, nullptr, d_in, st);
+                rc = arvae_link_up(&lk, &gop, w, nullptr, ARVAE_ACT_NONE, nullptr, d_in, link_ws, st);
             }
         }
         if (rc) return rc;
@@ -350,7 +353,7 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
         const uint8_t *mask = (masks != nullptr && m->enc[i].dropout) ? masks[mi] : nullptr;
         mi += m->enc[i].dropout != 0;
         uint16_t *bits = L.enc_bits[i] >= 0 ? reinterpret_cast<uint16_t *>(ws + L.enc_bits[i]) : nullptr;
-        if (int rc = layer_forward(m->enc[i], batch, params, h, mask, ws + L.enc_out[i], bits, stream,
+        if (int rc = layer_forward(m->enc[i], batch, params, h, mask, ws + L.enc_out[i], bits, ws + L.link_ws, stream,
                                    L.enc_wprep[i] >= 0 ? ws + L.enc_wprep[i] : nullptr))
             return rc;
         h = ws + L.enc_out[i];
@@ -361,8 +364,8 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
                                       sigma, z, st))
             return rc;
     } else {
-        if (int rc = layer_forward(m->head_mu, batch, params, h, nullptr, mu, nullptr, stream)) return rc;
-        if (int rc = layer_forward(m->head_log_std, batch, params, h, nullptr, ws + L.log_std, nullptr, stream)) return rc;
+        if (int rc = layer_forward(m->head_mu, batch, params, h, nullptr, mu, nullptr, ws + L.link_ws, stream)) return rc;
+        if (int rc = layer_forward(m->head_log_std, batch, params, h, nullptr, ws + L.log_std, nullptr, ws + L.link_ws, stream)) return rc;
         if (int rc = arvae_latent_fwd(mu, ws + L.log_std, eps, bz, sigma, z, stream)) return rc;
     }
     // decoder
@@ -384,7 +387,7 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
                 return rc;
         } else {
             uint16_t *bits = L.dec_bits[i] >= 0 ? reinterpret_cast<uint16_t *>(ws + L.dec_bits[i]) : nullptr;
-            if (int rc = layer_forward(m->dec[i], batch, params, h, mask, out, bits, stream,
+            if (int rc = layer_forward(m->dec[i], batch, params, h, mask, out, bits, ws + L.link_ws, stream,
                                        L.dec_wprep[i] >= 0 ? ws + L.dec_wprep[i] : nullptr))
                 return rc;
         }
@@ -491,7 +494,7 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
         bool gated = false;
         sync_side();                                     // this layer's incoming gradient is ready
         if (int rc = layer_backward(m->dec[i], batch, params, grads, in, out, mask_of(dec_mask[i]), cur, pre, gate, dst,
-                                    &gated, slab, &defer, L.dec_slab[i] >= 0 ? ws + L.dec_slab[i] : nullptr, &rdefer, stream,
+                                    &gated, slab, ws + L.link_ws, &defer, L.dec_slab[i] >= 0 ? ws + L.dec_slab[i] : nullptr, &rdefer, stream,
                                     i == m->n_dec - 1 ? first_scale : nullptr,
                                     (gate != nullptr && i > 0 && L.dec_bits[i - 1] >= 0)
                                         ? reinterpret_cast<const uint16_t *>(ws + L.dec_bits[i - 1]) : nullptr,
@@ -539,10 +542,10 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
         cur = d_hidden;
         float *other = grad_dst(-1, cur);
         if (int rc = layer_backward(m->head_mu, batch, params, grads, hidden, nullptr, nullptr, ws + L.d_mu, true, nullptr,
-                                    cur, nullptr, slab, &defer, nullptr, nullptr, stream))
+                                    cur, nullptr, slab, ws + L.link_ws, &defer, nullptr, nullptr, stream))
             return rc;
         if (int rc = layer_backward(m->head_log_std, batch, params, grads, hidden, nullptr, nullptr, ws + L.d_ls, true,
-                                    nullptr, other, nullptr, slab, &defer, nullptr, nullptr, stream))
+                                    nullptr, other, nullptr, slab, ws + L.link_ws, &defer, nullptr, nullptr, stream))
             return rc;
         const int64_t hn = in_elems(m->head_mu, batch);
         int64_t blocks2 = (hn + 255) / 256;
@@ -559,7 +562,7 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
         bool gated = false;
         sync_side();
         if (int rc = layer_backward(m->enc[i], batch, params, grads, in, ws + L.enc_out[i], mask_of(enc_mask[i]), cur, pre,
-                                    gate, dst, &gated, slab, &defer, L.enc_slab[i] >= 0 ? ws + L.enc_slab[i] : nullptr, &rdefer,
+                                    gate, dst, &gated, slab, ws + L.link_ws, &defer, L.enc_slab[i] >= 0 ? ws + L.enc_slab[i] : nullptr, &rdefer,
                                     stream, nullptr,
                                     (gate != nullptr && i > 0 && L.enc_bits[i - 1] >= 0)
                                         ? reinterpret_cast<const uint16_t *>(ws + L.enc_bits[i - 1]) : nullptr,

@@ -129,13 +129,20 @@ def _link_cost(link, n, op):
 # ------------------------------------------------------------------------------------------------
 # raw launches (no autograd)
 # ------------------------------------------------------------------------------------------------
+def _link_ws(lib, desc, device):
+    """the caller-owned scratch arvae_link_down / _up ask for (most links: none)"""
+    n = lib.arvae_link_ws_floats(ctypes.byref(desc))
+    return torch.empty(n, device=device, dtype=torch.float32) if n else None
+
+
 def link_down(link: Link, n, hi_op, wt, bias, act, out_mask, out=None):
     lib = _lib.load()
     lo = out if out is not None else torch.empty(link.lo_shape(n), device=wt.device, dtype=torch.float32)
     d = link.desc(n)
+    ws = _link_ws(lib, d, wt.device)
     with _timed('link_gemm<down>', *_link_cost(link, n, hi_op)):
         _lib.check(lib.arvae_link_down(ctypes.byref(d), ctypes.byref(hi_op), _ptr(wt), _ptr(bias), act,
-                                       _ptr(out_mask), _ptr(lo), _stream()), 'link_down')
+                                       _ptr(out_mask), _ptr(lo), _ptr(ws), _stream()), 'link_down')
     return lo
 
 
@@ -144,9 +151,10 @@ def link_up(link: Link, n, lo_op, wt, bias, act, out_mask, out=None):
     hi = out if out is not None else torch.empty(link.hi_shape(n), device=wt.device, dtype=torch.float32)
     d = link.desc(n)
     name = 'up_single_channel' if (link.chi == 1 and not lo_op.y) else 'link_gemm<up>'
+    ws = _link_ws(lib, d, wt.device)
     with _timed(name, *_link_cost(link, n, lo_op)):
         _lib.check(lib.arvae_link_up(ctypes.byref(d), ctypes.byref(lo_op), _ptr(wt), _ptr(bias), act,
-                                     _ptr(out_mask), _ptr(hi), _stream()), 'link_up')
+                                     _ptr(out_mask), _ptr(hi), _ptr(ws), _stream()), 'link_up')
     return hi
 
 

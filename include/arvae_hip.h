@@ -7,8 +7,11 @@
  *
  * Conventions
  *  - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller unless the
- *    parameter is documented as "host".  The library allocates nothing and keeps no mutable global
- *    state, so the forward (main thread) and backward (autograd thread) may call concurrently.
+ *    parameter is documented as "host".  The library allocates no device memory (every scratch buffer is a caller
+ *    workspace whose size an arvae_*_ws_floats function reports) and no call depends on state left by another, so the
+ *    forward (main thread) and backward (autograd thread) may call concurrently.  What is process-wide: diagnostic
+ *    environment switches read once on first use ("Run-time switches"), the once-per-kernel registration of
+ *    dynamic LDS sizes (hipFuncSetAttribute), and the opt-in timeline of arvae_profile_begin/_end.
  *  - `stream` is a hipStream_t passed as void*; calls only enqueue work and never synchronise.
  *  - return value: 0 = ok, <0 = error (ARVAE_E_*); arvae_last_error_string() gives the thread-local text.
  *  - tensors are fp32, contiguous, CHANNELS-LAST: activations [N, H, W, C]; a 1-channel image
@@ -24,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ARVAE_ABI_VERSION 4   /* 4: arvae_tick_free_run_supported; 3: arvae_gru_seq_*, embed_bwd workspace; 2: arvae_image_vae_backward reg_fused == 2 (unit regulariser gradient in dz_extra) */
+#define ARVAE_ABI_VERSION 4   /* 4: arvae_tick_free_run_supported, caller workspace for arvae_link_down/up (arvae_link_ws_floats); 3: arvae_gru_seq_*, embed_bwd workspace; 2: arvae_image_vae_backward reg_fused == 2 (unit regulariser gradient in dz_extra) */
 
 #define ARVAE_OK 0
 #define ARVAE_E_INVALID (-1)  /* bad argument (null pointer, size out of range, unsupported shape) */
@@ -92,15 +95,20 @@ typedef struct {
     int32_t act;
 } arvae_operand_t;
 
+/* Floats of caller workspace arvae_link_down / arvae_link_up need for this link (0 for most geometries; the wide stride-1
+ * convolutions re-order their weights to [out channel][tap][in channel] there before the product).  Independent of n. */
+int64_t arvae_link_ws_floats(const arvae_link_t *link);
+
 /* lo = epilogue( sum_{ky,kx,chi} hi * wt + bias[clo] );  epilogue = act, then *2*out_mask if given.
- * bias may be NULL. */
+ * bias may be NULL.  ws: arvae_link_ws_floats(link) floats, 16-byte aligned (may be NULL when that is 0); its contents are
+ * scratch of this call only. */
 int arvae_link_down(const arvae_link_t *link, const arvae_operand_t *hi, const float *wt,
-                    const float *bias, int32_t out_act, const uint8_t *out_mask, float *lo,
+                    const float *bias, int32_t out_act, const uint8_t *out_mask, float *lo, float *ws,
                     arvae_stream_t stream);
 
 /* hi = epilogue( sum_{ky,kx,clo} lo * wt + bias[chi] ), the adjoint map of arvae_link_down. */
 int arvae_link_up(const arvae_link_t *link, const arvae_operand_t *lo, const float *wt,
-                  const float *bias, int32_t out_act, const uint8_t *out_mask, float *hi,
+                  const float *bias, int32_t out_act, const uint8_t *out_mask, float *hi, float *ws,
                   arvae_stream_t stream);
 
 /* dwt[clo][chi][ky][kx] += sum_{n,ly,lx} lo * hi   (accumulates).  The batch is split over workgroups;

@@ -71,13 +71,16 @@ def test_abi_version_and_error_string(lib):
 def test_argument_validation_without_gpu(lib):
     """bad arguments are rejected before any launch (pure host code)."""
     from arvae_amd._lib import LinkDesc, OperandDesc
-    rc = lib.arvae_link_down(None, None, None, None, 0, None, None, None)
+    rc = lib.arvae_link_down(None, None, None, None, 0, None, None, None, None)
     assert rc == -1 and b'null' in lib.arvae_last_error_string()
     d = LinkDesc(1, 8, 8, 4, 5, 5, 4, 4, 4, 2, 1, 0, 0, 0, 0)       # lo extent should be 4x4
     op = OperandDesc(ctypes.c_void_p(16), None, None, 0)
     rc = lib.arvae_link_down(ctypes.byref(d), ctypes.byref(op), ctypes.c_void_p(16), None, 0, None,
-                             ctypes.c_void_p(16), None)
+                             ctypes.c_void_p(16), None, None)
     assert rc == -1 and b'does not match' in lib.arvae_last_error_string()
+    wide = LinkDesc(4, 25, 25, 64, 22, 22, 64, 4, 4, 1, 0, 0, 0, 0, 0)  # Morpho-MNIST 64 -> 64 k4 s1: re-ordered weights
+    assert lib.arvae_link_ws_floats(ctypes.byref(wide)) == 16 * 64 * 64
+    assert lib.arvae_link_ws_floats(ctypes.byref(LinkDesc(4, 32, 32, 32, 16, 16, 32, 4, 4, 2, 1, 0, 0, 0, 0))) == 0
     assert lib.arvae_reg_loss_ws_floats(512, 5) == 2 * 512 * 5
     assert lib.arvae_adam_step(None, None, None, None, 0, 0, 1e-4, 0.9, 0.999, 1e-8, 1.0, None) == -1
     # the MeasureVAE sequence entry points
