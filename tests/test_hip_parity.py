@@ -1115,3 +1115,30 @@ def test_epoch_means_under_graph_replay_equal_eager(dev):
         close(l_a, l_b, rtol=1e-6)
         close(a_a, a_b, rtol=1e-6)
     assert got[True][1][0] > got[True][0][0]                    # the larger beta shows in the loss
+
+
+# ---------------------------------------------------------------- row-stream weight gradient (conv32r.hip)
+@pytest.mark.parametrize('bias_side', [1, 2])
+@pytest.mark.parametrize('lo_size,n', [(16, 1), (16, 2), (16, 7), (16, 130), (16, 512), (8, 1), (8, 3), (8, 37), (8, 512)])
+def test_wgrad_row_stream_vs_float64(dev, lo_size, n, bias_side):
+    """wgrad32r_kernel (producer / consumer waves over a ring of hi rows) against a float64 conv backward: every batch
+    size splits the row stream differently over the workgroups (ranges that start inside an image, a last range that is
+    shorter, fewer steps than CUs), and the image borders are zeroed per tap row, so both ends are covered."""
+    from arvae_amd import ops
+    hi_size = 2 * lo_size
+    rs = np.random.RandomState(100 * lo_size + n)
+    hi = rs.standard_normal((n, hi_size, hi_size, 32)).astype(np.float32)
+    lo = rs.standard_normal((n, lo_size, lo_size, 32)).astype(np.float32)
+    link = ops.Link(hi_size, hi_size, 32, lo_size, lo_size, 32, 4, 4, 2, 1)
+    dw = torch.zeros(32, 32, 4, 4, device=dev)
+    db = torch.zeros(32, device=dev)
+    lo_d, hi_d = torch.from_numpy(lo).to(dev), torch.from_numpy(hi).to(dev)      # kept alive: an operand is a raw pointer
+    ops.link_wgrad(link, n, ops._operand(lo_d), ops._operand(hi_d), dw, db, bias_side)
+    x = torch.from_numpy(hi).double().permute(0, 3, 1, 2)
+    g = torch.from_numpy(lo).double().permute(0, 3, 1, 2)
+    w = torch.zeros(32, 32, 4, 4, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x, w, None, stride=2, padding=1).backward(g)
+    want_b = (g if bias_side == 1 else x).sum((0, 2, 3)).numpy()
+    err = np.linalg.norm(dw.cpu().numpy().astype(np.float64) - w.grad.numpy()) / np.linalg.norm(w.grad.numpy())
+    assert err < 6e-7, err                                   # three-term bf16 split: fp32-level accuracy
+    close(db, want_b, rtol=1e-5, atol=1e-5 * float(np.abs(want_b).max()))
