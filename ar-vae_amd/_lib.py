@@ -39,7 +39,9 @@ class ImageVaeDesc(ctypes.Structure):
     """arvae_image_vae_t"""
     _fields_ = [('n_enc', c_i32), ('n_dec', c_i32), ('enc', LayerDesc * MAX_LAYERS), ('dec', LayerDesc * MAX_LAYERS),
                 ('head_mu', LayerDesc), ('head_log_std', LayerDesc), ('zdim', c_i32), ('recon_dist', c_i32),
-                ('n_reg', c_i32), ('reg_dims', c_i32 * 16), ('beta', c_f32), ('gamma', c_f32), ('delta', c_f32)]
+                ('n_reg', c_i32), ('reg_dims', c_i32 * 16), ('beta', c_f32), ('gamma', c_f32), ('delta', c_f32),
+                ('rng_eps', c_i32), ('rng_offset', ctypes.c_uint32), ('rng_step', ctypes.c_uint32), ('rng_seed', ctypes.c_uint64),
+                ('rng_dev_step', c_vp)]
 
 
 class GruSeqDesc(ctypes.Structure):
@@ -113,6 +115,8 @@ SIGNATURES = {
                                         c_vp, c_i64, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'arvae_image_vae_backward': (c_i32, [_P(ImageVaeDesc), c_i32, c_vp, c_vp, c_vp, c_vp, _P(c_vp), c_vp, c_vp, c_vp,
                                          c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_vp, c_vp]),
+    'arvae_philox_normal': (c_i32, [c_vp, c_i64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp]),
+    'arvae_philox_keep_mask': (c_i32, [c_vp, c_i64, c_f32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp]),
     'arvae_adam_step': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_f64, c_f64, c_f64, c_f64, c_f32, c_vp]),
 }
 

@@ -5,6 +5,7 @@
 // per sample: a few MFLOP per batch, so the cost is the number of launches; plain FMA loops, 8 batch rows per
 // 256-thread workgroup.
 #include "common.h"
+#include "rng.h"
 
 namespace arvae {
 
@@ -16,6 +17,8 @@ struct HeadsFwdArgs {
     const float *hidden, *w_mu, *b_mu, *w_ls, *b_ls, *eps;
     float *mu, *log_std, *sigma, *z;
     int batch, h, zdim;
+    float *eps_out;              // non-null: draw eps here (rng) and write it for the backward pass
+    RngStream rng;
 };
 
 // LDS: HEAD_ROWS hidden rows | 2*zdim weight rows (stride h + 4: conflict-free float4 reads across rows) | outputs.
@@ -41,7 +44,7 @@ __global__ __launch_bounds__(256) void heads_latent_fwd_kernel(HeadsFwdArgs p) {
     const int row = row0 + r;
     const bool lat = j < p.zdim && row < p.batch;
     const int64_t idx = lat ? (int64_t)row * p.zdim + j : 0;
-    const float e = p.eps[idx];
+    const float e = p.eps_out != nullptr ? rng_normal(p.rng, (uint64_t)idx) : p.eps[idx];
     const int jc = j < 2 * p.zdim ? j : 0;
     const float *bp = jc < p.zdim ? p.b_mu : p.b_ls;
     const float bias = bp != nullptr ? bp[jc < p.zdim ? jc : jc - p.zdim] : 0.f;
@@ -66,6 +69,7 @@ __global__ __launch_bounds__(256) void heads_latent_fwd_kernel(HeadsFwdArgs p) {
         p.log_std[idx] = l;
         p.sigma[idx] = s;
         p.z[idx] = fmaf(e, s, m);
+        if (p.eps_out != nullptr) p.eps_out[idx] = e;
     }
 }
 
@@ -143,8 +147,15 @@ bool heads_fusable(const arvae_layer_t *hm, const arvae_layer_t *hl, int zdim) {
 }
 
 int heads_latent_fwd(const arvae_layer_t *hm, const arvae_layer_t *hl, int batch, int zdim, const float *params,
-                     const float *hidden, const float *eps, float *mu, float *log_std, float *sigma, float *z, hipStream_t s) {
+                     const float *hidden, const float *eps, float *mu, float *log_std, float *sigma, float *z, hipStream_t s,
+                     const arvae_image_vae_t *rng_model) {
     HeadsFwdArgs p;
+    p.eps_out = nullptr;
+    p.rng = RngStream{0, 0, nullptr, 0};
+    if (rng_model != nullptr && rng_model->rng_eps) {
+        p.eps_out = const_cast<float *>(eps);
+        p.rng = RngStream{rng_model->rng_seed, rng_model->rng_offset, rng_model->rng_dev_step, rng_model->rng_step};
+    }
     p.hidden = hidden;
     p.w_mu = params + hm->w_off; p.b_mu = hm->b_off >= 0 ? params + hm->b_off : nullptr;
     p.w_ls = params + hl->w_off; p.b_ls = hl->b_off >= 0 ? params + hl->b_off : nullptr;

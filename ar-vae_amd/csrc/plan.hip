@@ -29,7 +29,8 @@ int conv_c1_down(const arvae_link_t *l, const Operand &img, const float *wt, con
 // fused encoder heads + reparameterisation (heads.hip)
 bool heads_fusable(const arvae_layer_t *hm, const arvae_layer_t *hl, int zdim);
 int heads_latent_fwd(const arvae_layer_t *hm, const arvae_layer_t *hl, int batch, int zdim, const float *params,
-                     const float *hidden, const float *eps, float *mu, float *log_std, float *sigma, float *z, hipStream_t s);
+                     const float *hidden, const float *eps, float *mu, float *log_std, float *sigma, float *z, hipStream_t s,
+                     const arvae_image_vae_t *rng_model = nullptr);
 int heads_latent_bwd(const arvae_layer_t *hm, const arvae_layer_t *hl, int batch, int zdim, const float *params,
                      const float *g_z, const float *dz_reg, const float *dz_extra, const float *mu, const float *sigma,
                      const float *eps, const float *g_loss, const float *kl, const float *cap, float beta, float reg_scale,
@@ -361,9 +362,13 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
     const int64_t bz = (int64_t)batch * m->zdim;
     if (heads_fusable(&m->head_mu, &m->head_log_std, m->zdim)) {
         if (int rc = heads_latent_fwd(&m->head_mu, &m->head_log_std, batch, m->zdim, params, h, eps, mu, ws + L.log_std,
-                                      sigma, z, st))
+                                      sigma, z, st, m))
             return rc;
     } else {
+        if (m->rng_eps)                                      // no fused heads kernel for this model: draw eps first
+            if (int rc = arvae_philox_normal(const_cast<float *>(eps), bz, m->rng_seed, m->rng_offset, m->rng_step,
+                                             m->rng_dev_step, stream))
+                return rc;
         if (int rc = layer_forward(m->head_mu, batch, params, h, nullptr, mu, nullptr, ws + L.link_ws, stream)) return rc;
         if (int rc = layer_forward(m->head_log_std, batch, params, h, nullptr, ws + L.log_std, nullptr, ws + L.link_ws, stream)) return rc;
         if (int rc = arvae_latent_fwd(mu, ws + L.log_std, eps, bz, sigma, z, stream)) return rc;

@@ -119,13 +119,19 @@ class FusedImageVAE:
             self._ws_owner = weakref.ref(ctx)
         return ws
 
-    def run(self, x, labels, eps, masks, capacity, external_reg=False, reg_scale=1.0, dp=None, capacity_nonzero=False):
+    def run(self, x, labels, eps, masks, capacity, external_reg=False, reg_scale=1.0, dp=None, capacity_nonzero=False,
+            draw_eps=False):
         """-> (loss[1] with grad_fn, scalars[8], acc, z, mu, sigma, logits); loss is scalars[LOSS:LOSS+1].
 
         dp (arvae_amd.parallel.DataParallel): evaluate the regulariser on this rank's row block against the columns
         gathered from every rank, inside the same autograd node (no torch ops on the hot path): the loss returned is
         recon + beta|KL - c| + W * reg_rowblock and scalars[REG] = W * reg_rowblock.  With capacity_nonzero the KL
         mean is all-reduced first and the term becomes the global beta|KL_global - c| (parallel.py)."""
+        d = self.descriptor()                                    # where this pass's eps comes from (csrc/rng.h)
+        d.rng_eps = int(bool(draw_eps))
+        if draw_eps:
+            d.rng_seed, d.rng_offset, d.rng_step = ops.rng_seed(), ops.rng_next_offset(), 0
+            d.rng_dev_step = ops._ptr(ops.rng_device_step(x.device))
         anchor = self.optimizer.params[0]
         return _FusedStepFn.apply(anchor, self, x, labels, eps, masks, capacity, bool(external_reg), float(reg_scale), dp,
                                   bool(capacity_nonzero))

@@ -11,8 +11,9 @@ teacher-forcing coin: one graph per control-flow variant.
         loss, acc = graphed(batch)                       # zero_grad + loss + backward
         trainer.step()
 
-Random numbers drawn on the device inside the step (reparameterisation noise, dropout masks) use torch's graph-safe
-Philox generator, so every replay sees fresh values.  Noise / masks pushed through the models' host-side queues are
+Random numbers drawn on the device inside the step (reparameterisation noise, dropout masks) come from the library's
+counter-based Philox stream (csrc/rng.h): the captured launches read their stream position from a device word that the
+graph itself advances, so every replay sees fresh values.  Noise / masks pushed through the models' host-side queues are
 NOT visible to a captured graph (the queue is consumed at capture time).
 """
 import torch
@@ -31,6 +32,8 @@ class GraphedStep:
         self.prob = self.decoder.teacher_forcing_prob if coin else None
         self.graphs = {}
         trainer.model.train()
+        from . import ops
+        ops.rng_device_step(self.static[0].device, create=True)   # the captured draws read their stream position from the device
         try:                                                     # the decoder's coin is pinned only while capturing
             for variant in self.variants:
                 self._pin(variant)
@@ -62,6 +65,8 @@ class GraphedStep:
             self.decoder.teacher_forcing_prob = self.prob if variant is None else (2.0 if variant else -1.0)
 
     def _eager(self):
+        from . import ops
+        ops.rng_advance_device_step()                            # recorded: every replay moves on in the Philox stream
         self.trainer.zero_grad()
         loss, acc = self.trainer.loss_and_acc_for_batch(self.static, 0, 1, True)
         loss.backward()

@@ -85,7 +85,7 @@ class MnistVAE(Model):
     def _noise(self, like):
         if self._eps_queue:
             return self._eps_queue.popleft().to(like.device, torch.float32).contiguous()
-        return torch.randn_like(like)
+        return ops.normal_noise(like.shape, like.device)
 
     def _next_masks(self, n, device):
         count = sum(1 for _ in self.enc_conv_plan) + len(self.dec_conv_plan) - 1
@@ -149,7 +149,7 @@ class MnistVAE(Model):
         prior_dist = distributions.Normal(loc=torch.zeros_like(z_dist.loc), scale=torch.ones_like(z_dist.scale),
                                           validate_args=False)
         prior_dist._arvae_standard = True
-        z_prior = torch.randn_like(z_dist.loc)        # the reference's second, unused draw (mnist_vae.py:86)
+        z_prior = ops.normal_noise(z_dist.loc.shape, z_dist.loc.device)   # the reference's second, unused draw (mnist_vae.py:86)
         return z_tilde, z_prior, prior_dist
 
     def forward(self, x):

@@ -132,10 +132,13 @@ class ImageVAETrainer(Trainer):
         n = inputs.size(0)
         x = inputs.contiguous().view(n, model.image_hw, model.image_hw, 1)
         masks = model._next_masks(n, inputs.device)
-        eps = model._noise(torch.empty(n, model.z_dim, device=inputs.device))
+        if model._eps_queue:                                     # explicit noise (parity runs)
+            eps, draw = model._noise(torch.empty(n, model.z_dim, device=inputs.device)), False
+        else:                                                    # drawn inside the fused heads kernel, written for backward
+            eps, draw = torch.empty(n, model.z_dim, device=inputs.device), True
         dp = self.data_parallel
         loss, scalars, accuracy, z, mu, sigma, logits = self._fused.run(x, labels, eps, masks, self.capacity, dp=dp,
-                                                                       capacity_nonzero=self._capacity_nonzero)
+                                                                       capacity_nonzero=self._capacity_nonzero, draw_eps=draw)
         reg_loss = scalars[REG].detach() if self.use_reg_loss else None
         self.last_terms = {'recons': scalars[RECON].detach(), 'dist': scalars[DIST].detach(), 'reg': reg_loss}
         self.last_outputs = {'logits': logits.view(inputs.size()), 'z': z, 'mu': mu, 'sigma': sigma}

@@ -135,7 +135,7 @@ class Encoder(Model):
         elif self.static_eps is not None:                    # a device buffer read at run time (visible to a captured graph)
             eps = self.static_eps
         else:
-            eps = torch.randn_like(mu)
+            eps = ops.normal_noise(mu.shape, mu.device)
         sigma, z = ops.latent_head(mu, log_std, eps)
         z_dist = distributions.Normal(loc=mu, scale=sigma, validate_args=False)
         z_dist._arvae_sample = z
@@ -422,6 +422,6 @@ class MeasureVAE(Model):
         mu, sigma, z_tilde = z_dist.loc, z_dist.scale, z_dist._arvae_sample
         prior_dist = distributions.Normal(loc=torch.zeros_like(mu), scale=torch.ones_like(sigma), validate_args=False)
         prior_dist._arvae_standard = True
-        z_prior = torch.randn_like(mu)                       # the reference's second, unused draw (measure_vae.py:123)
+        z_prior = ops.normal_noise(mu.shape, mu.device)      # the reference's second, unused draw (measure_vae.py:123)
         weights, samples = self.decoder(z=z_tilde, score_tensor=measure_score_tensor, train=train)
         return weights, samples, z_dist, prior_dist, z_tilde, z_prior

@@ -832,9 +832,59 @@ class _ScaleMaskFn(Function):
         return dx, None, None
 
 
+# ------------------------------------------------------------------------------------------------
+# random draws: the library's counter-based Philox4x32-10 stream (csrc/rng.h), no torch RNG kernels
+# ------------------------------------------------------------------------------------------------
+class RngState:
+    """Every draw of the path (eps, dropout keep-masks) is element i of the stream keyed by
+    (seed, offset, step + *dev_step): seed = torch.initial_seed(), so the trainers' torch.manual_seed(rand)
+    (image_vae_trainer.py:103) selects the stream as it does in the reference; `offset` counts the draws of this process.
+    Under HIP-graph replay the host numbers are frozen into the captured launches, so graphed.GraphedStep advances the device
+    word `dev_step` inside the graph and every replay sees fresh values."""
+    offset = 0
+    dev_step = None                    # int32 tensor (1,) on the device, or None
+
+
+def rng_seed():
+    return torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
+
+
+def rng_next_offset():
+    off = RngState.offset
+    RngState.offset = (off + 1) & 0xFFFFFFFF
+    return off
+
+
+def rng_device_step(device, create=False):
+    """the device word a captured graph advances (None until a graph asked for one)"""
+    if create and (RngState.dev_step is None or RngState.dev_step.device != torch.device(device)):
+        RngState.dev_step = torch.zeros(1, dtype=torch.int32, device=device)
+    d = RngState.dev_step
+    return d if d is not None and d.device == torch.device(device) else None
+
+
+def rng_advance_device_step():
+    """one more step of the device-side stream position (recorded into a graph being captured)"""
+    if RngState.dev_step is not None:
+        RngState.dev_step.add_(1)
+
+
+def normal_noise(shape, device):
+    """eps ~ N(0, 1) for z_dist.rsample() (mnist_vae.py:79, measure_vae.py:116): one library launch"""
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    _dev(out)
+    _lib.check(_lib.load().arvae_philox_normal(_ptr(out), out.numel(), rng_seed(), rng_next_offset(), 0,
+                                                _ptr(rng_device_step(device)), _stream()), 'philox_normal')
+    return out
+
+
 def keep_mask(shape, p, device):
-    """uint8 keep-mask (1 with probability 1 - p) drawn on the device in one kernel (graph-safe Philox generator)."""
-    return torch.empty(shape, dtype=torch.uint8, device=device).bernoulli_(1.0 - p)
+    """uint8 keep-mask (1 with probability 1 - p) of nn.Dropout(p) / nn.GRU(dropout=p): one library launch"""
+    out = torch.empty(shape, dtype=torch.uint8, device=device)
+    _dev(out)
+    _lib.check(_lib.load().arvae_philox_keep_mask(_ptr(out), out.numel(), 1.0 - float(p), rng_seed(), rng_next_offset(), 0,
+                                                   _ptr(rng_device_step(device)), _stream()), 'philox_keep_mask')
+    return out
 
 
 def dropout_mask(x, mask, p=0.5):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ARVAE_ABI_VERSION 4   /* 4: arvae_tick_free_run_supported, caller workspace for arvae_link_down/up (arvae_link_ws_floats); 3: arvae_gru_seq_*, embed_bwd workspace; 2: arvae_image_vae_backward reg_fused == 2 (unit regulariser gradient in dz_extra) */
+#define ARVAE_ABI_VERSION 4   /* 4: arvae_philox_* and in-kernel eps (arvae_image_vae_t.rng_*), arvae_tick_free_run_supported, caller workspace for arvae_link_down/up (arvae_link_ws_floats); 3: arvae_gru_seq_*, embed_bwd workspace; 2: arvae_image_vae_backward reg_fused == 2 (unit regulariser gradient in dz_extra) */
 
 #define ARVAE_OK 0
 #define ARVAE_E_INVALID (-1)  /* bad argument (null pointer, size out of range, unsupported shape) */
@@ -352,6 +352,13 @@ typedef struct {
     int32_t n_reg;                        /* regularised dims (0: no attribute regularisation)         */
     int32_t reg_dims[16];
     float beta, gamma, delta;
+    /* rng_eps != 0: arvae_image_vae_forward DRAWS the reparameterisation noise itself (Philox4x32-10, arvae_philox_normal's
+     * stream for the same seed / offset / step / dev_step) inside the fused heads kernel and WRITES it to `eps`, which the
+     * backward pass then reads; 0: `eps` is an input (parity runs with explicit noise). */
+    int32_t rng_eps;
+    uint32_t rng_offset, rng_step;
+    uint64_t rng_seed;
+    const uint32_t *rng_dev_step;
 } arvae_image_vae_t;
 
 /* scalars written by the forward pass (device array of ARVAE_VAE_NSCALARS floats) */
@@ -365,7 +372,7 @@ typedef struct {
 
 int64_t arvae_image_vae_ws_floats(const arvae_image_vae_t *model, int32_t batch, int64_t n_cols);
 
-/* Forward + loss terms.  x [batch, H, W, 1]; labels [batch, ld_labels]; eps [batch, zdim];
+/* Forward + loss terms.  x [batch, H, W, 1]; labels [batch, ld_labels]; eps [batch, zdim] (WRITTEN when model->rng_eps);
  * masks: HOST array with one device uint8 keep-mask per dropout layer (encoder first), or NULL (eval).
  * z_cols/lab_cols [n_cols, ...]: all-gathered columns for the data-parallel row-block regularisation
  * (NULL: this batch is the whole batch); they index dims 0..n_reg-1 compactly when given.
@@ -392,6 +399,21 @@ int arvae_image_vae_backward(const arvae_image_vae_t *model, int32_t batch, cons
                              const float *capacity, const float *mu, const float *sigma, const float *z,
                              const float *logits, const float *g_loss, const float *dz_extra,
                              int32_t reg_fused, float reg_scale, float *ws, arvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Random draws of the path: eps of z_dist.rsample() (imagevae/mnist_vae.py:79, measurevae/measure_vae.py:116) and the
+ * keep-masks of nn.Dropout(0.5) / nn.GRU(dropout=0.5) (imagevae/mnist_vae.py:16-47, measurevae/encoder.py:27-34,
+ * decoder.py:338-368) from a counter-based Philox4x32-10 generator: element i of a draw is a pure function of
+ * (seed, offset = index of the draw inside the step, step + *dev_step, i).  dev_step (optional device word) lets a captured
+ * HIP graph advance the stream by itself.  The reference draws from torch's global generator instead; parity runs pass
+ * explicit eps / masks, so only the distribution has to agree (tests: known-answer vectors, moments, determinism).
+ * arvae_philox_normal: one N(0,1) value per element (Box-Muller).  arvae_philox_keep_mask: uint8 1 with probability
+ * keep_prob (quantised to 1/256), out 16-byte aligned.
+ * ------------------------------------------------------------------------------------------------ */
+int arvae_philox_normal(float *out, int64_t count, uint64_t seed, uint32_t offset, uint32_t step, const uint32_t *dev_step,
+                        arvae_stream_t stream);
+int arvae_philox_keep_mask(uint8_t *out, int64_t count, float keep_prob, uint64_t seed, uint32_t offset, uint32_t step,
+                           const uint32_t *dev_step, arvae_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1142,3 +1142,64 @@ def test_wgrad_row_stream_vs_float64(dev, lo_size, n, bias_side):
     err = np.linalg.norm(dw.cpu().numpy().astype(np.float64) - w.grad.numpy()) / np.linalg.norm(w.grad.numpy())
     assert err < 6e-7, err                                   # three-term bf16 split: fp32-level accuracy
     close(db, want_b, rtol=1e-5, atol=1e-5 * float(np.abs(want_b).max()))
+
+
+# ---------------------------------------------------------------- device RNG (csrc/rng.h) vs oracle/philox.py
+def test_philox_draws_vs_oracle(dev):
+    """arvae_philox_normal / arvae_philox_keep_mask reproduce the numpy restatement element for element (the uint32 stream
+    is pinned by Random123's known-answer vectors in test_oracle_golden.py); moments of a large draw; the stream moves with
+    seed, offset and the device step word."""
+    import ctypes
+    from arvae_amd import _lib, ops
+    from oracle import philox
+    lib = _lib.load()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    n = 100003
+    out = torch.empty(n, device=dev)
+    seed = 0x123456789abcdef
+    assert lib.arvae_philox_normal(ops._ptr(out), n, seed, 7, 2, None, st) == 0
+    want = philox.normal(n, seed, offset=7, step=2)
+    close(out, want, rtol=2e-5, atol=2e-6)                       # device logf / cosf vs numpy's
+    assert abs(float(out.mean())) < 0.02 and abs(float(out.std()) - 1.0) < 0.02
+    step = torch.tensor([5], dtype=torch.int32, device=dev)
+    out2 = torch.empty(n, device=dev)
+    assert lib.arvae_philox_normal(ops._ptr(out2), n, seed, 7, 0, ops._ptr(step), st) == 0
+    close(out2, philox.normal(n, seed, offset=7, step=5), rtol=2e-5, atol=2e-6)
+    mask = torch.empty(n, dtype=torch.uint8, device=dev)
+    assert lib.arvae_philox_keep_mask(ops._ptr(mask), n, 0.5, seed, 1, 0, None, st) == 0
+    np.testing.assert_array_equal(mask.cpu().numpy(), philox.keep_mask(n, 0.5, seed, offset=1))
+    assert lib.arvae_philox_keep_mask(ops._ptr(mask), n, 0.75, seed, 2, 0, None, st) == 0
+    np.testing.assert_array_equal(mask.cpu().numpy(), philox.keep_mask(n, 0.75, seed, offset=2))
+
+
+def test_fused_step_draws_its_own_noise(dev):
+    """without pushed noise the fused dSprites step draws eps inside the heads kernel: z = mu + eps * sigma with the eps
+    the oracle's Philox gives for (torch seed, this draw's offset), fresh on every step, reproducible under the same seed."""
+    from arvae_amd import ops
+    from arvae_amd.image_vae import DspritesVAE
+    from arvae_amd.image_vae_trainer import ImageVAETrainer
+    from oracle import philox
+    b = 37
+    state = syn.synth_state(o_vae.DSPRITES_SHAPES, 1, 1.6)
+    x, lab = syn.dsprites_batch(b, seed=5)
+    runs = []
+    for _ in range(2):
+        model = DspritesVAE()
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+        trainer = ImageVAETrainer(DspritesDataset(), model, lr=1e-4, reg_type=('all',), reg_dim=(1, 2, 3, 4, 5), beta=4.0,
+                                  gamma=10.0, capacity=0.0, rand=123, delta=1.0)     # torch.manual_seed(123)
+        trainer.cuda()
+        model.train()
+        ops.RngState.offset, ops.RngState.dev_step = 40, None     # (an earlier graph-replay test may have left a device step word)
+        zs = []
+        for step in range(2):
+            trainer.zero_grad()
+            loss, _ = trainer.loss_and_acc_for_batch((torch.from_numpy(x).to(dev), torch.from_numpy(lab).to(dev)), 0, step, True)
+            loss.backward()
+            o = trainer.last_outputs
+            eps = ((o['z'] - o['mu']) / o['sigma']).detach().cpu().numpy().ravel()
+            close(eps, philox.normal(b * 10, 123, offset=40 + step), rtol=0, atol=2e-3)    # (z - mu) / sigma loses bits
+            zs.append(o['z'].detach().clone())
+        assert not torch.equal(zs[0], zs[1])
+        runs.append(zs)
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])

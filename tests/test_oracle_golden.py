@@ -183,3 +183,18 @@ def test_attribute_labels(golden_dir):
     close(attr, g['attr'], rtol=1e-6, atol=1e-7)
     assert attr[0].tolist() == [0, 0, 0, 0]            # all slur
     assert attr[2, 2] == 1.0 and attr[2, 0] == 0.0     # all `None`: density counts them, rhythm does not
+
+
+# ---------------------------------------------------------------- Philox4x32-10 (device RNG of eps / dropout masks)
+def test_philox_known_answers():
+    """oracle/philox.py against the known-answer vectors of the Random123 distribution (kat_vectors: philox4x32, 10 rounds)"""
+    from oracle import philox
+    kat = [([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+           ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+           ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0], [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
+    for ctr, key, want in kat:
+        assert [int(v) for v in philox.philox4x32_10(ctr, key)] == want
+    n = philox.normal(1 << 16, seed=1234, offset=3)
+    assert abs(float(n.mean())) < 0.02 and abs(float(n.std()) - 1.0) < 0.02 and np.isfinite(n).all()
+    m = philox.keep_mask(1 << 16, 0.5, seed=9)
+    assert abs(float(m.mean()) - 0.5) < 0.01 and set(np.unique(m)) == {0, 1}
