@@ -37,12 +37,12 @@ class DspritesDataset:
             self.load_dataset()
         return self.images.shape[0]
 
-    def data_loaders(self, batch_size, split=(0.80, 0.15)):
+    def data_loaders(self, batch_size, split=(0.80, 0.15), shard=None):
         assert sum(split) < 1
         n = len(self)
         a, b = split
         cut1, cut2 = int(a * n), int((a + b) * n)
         cols = (self.images, self.latents)
-        return (DeviceLoader(cols, 0, cut1, batch_size, shuffle=True),
-                DeviceLoader(cols, cut1, cut2, batch_size, shuffle=True),
-                DeviceLoader(cols, cut2, n, batch_size, shuffle=False))
+        return (DeviceLoader(cols, 0, cut1, batch_size, shuffle=True, shard=shard),
+                DeviceLoader(cols, cut1, cut2, batch_size, shuffle=True, shard=shard),
+                DeviceLoader(cols, cut2, n, batch_size, shuffle=False, shard=shard))

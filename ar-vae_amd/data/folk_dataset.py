@@ -43,13 +43,13 @@ class FolkNBarDataset:
             self.score = torch.from_numpy(formats.load_measure_tensor(self.dataset_path)).to(dev)
         return self.score
 
-    def data_loaders(self, batch_size, split=(0.85, 0.10)):
+    def data_loaders(self, batch_size, split=(0.85, 0.10), shard=None):
         assert sum(split) < 1
         score = self.get_dataset()
         n = score.shape[0]
         a, b = split
         cut1, cut2 = int(a * n), int((a + b) * n)
         cols = (score, score)                        # (score, metadata placeholder), as the reference stores it
-        return (DeviceLoader(cols, 0, cut1, batch_size, shuffle=True, drop_last=True),
-                DeviceLoader(cols, cut1, cut2, batch_size, shuffle=False, drop_last=True),
-                DeviceLoader(cols, cut2, n, batch_size, shuffle=False, drop_last=True))
+        return (DeviceLoader(cols, 0, cut1, batch_size, shuffle=True, drop_last=True, shard=shard),
+                DeviceLoader(cols, cut1, cut2, batch_size, shuffle=False, drop_last=True, shard=shard),
+                DeviceLoader(cols, cut2, n, batch_size, shuffle=False, drop_last=True, shard=shard))

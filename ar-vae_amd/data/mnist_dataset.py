@@ -38,9 +38,9 @@ class MorphoMnistDataset:
                                   torch.from_numpy(morpho).to(dev))
         return self._splits[name]
 
-    def data_loaders(self, batch_size, split=(0.85, 0.10)):
+    def data_loaders(self, batch_size, split=(0.85, 0.10), shard=None):
         train, test = self._split('train'), self._split('t10k')
         scale = 1.0 / 255.0
-        return (DeviceLoader(train, 0, train[0].shape[0], batch_size, shuffle=True, u8_scale=scale),
-                DeviceLoader(test, 0, test[0].shape[0], batch_size, shuffle=False, u8_scale=scale),
-                DeviceLoader(test, 0, test[0].shape[0], batch_size, shuffle=False, u8_scale=scale))
+        return (DeviceLoader(train, 0, train[0].shape[0], batch_size, shuffle=True, u8_scale=scale, shard=shard),
+                DeviceLoader(test, 0, test[0].shape[0], batch_size, shuffle=False, u8_scale=scale, shard=shard),
+                DeviceLoader(test, 0, test[0].shape[0], batch_size, shuffle=False, u8_scale=scale, shard=shard))

@@ -193,13 +193,63 @@ class ImageVAETrainer(Trainer):
         with torch.no_grad():
             return torch.sigmoid(self.model.decode(z.contiguous()))
 
-    def test_model(self, batch_size):
-        """Mean loss / accuracy over the evaluation split (image_vae_trainer.py:333-343)."""
-        _, _, loader = self.dataset.data_loaders(batch_size)
-        self.model.eval()
+    def save_representations(self, path, data_loader=None, batch_size=128):
+        """Write the record the reference's compute_eval_metrics consumes (image_vae_trainer.py:289-317): latent codes,
+        attribute columns and attribute names as JSON, from the encoder-only pass.  The disentanglement metrics themselves
+        (utils/evaluation.py: sklearn / scipy on the host) are out of scope: they run unchanged on
+        this file's arrays."""
+        import json
+        if data_loader is None:
+            _, _, data_loader = self.dataset.data_loaders(batch_size=batch_size)
+        codes, attrs, names = self.compute_representations(data_loader)
+        with open(path, 'w') as f:
+            json.dump({'latent_codes': codes.tolist(), 'attributes': np.asarray(attrs).tolist(), 'attr_list': list(names)}, f)
+        return codes, attrs, names
+
+    def compute_eval_metrics(self, batch_size=128):
+        """results_dict.json next to the checkpoint, as in the reference (image_vae_trainer.py:289-317): loaded when it exists,
+        otherwise created with what this path computes on the device -- the test loss / accuracy -- and the file the host-side
+        metric suite reads (representations.json)."""
+        import json
+        import os
+        folder = os.path.dirname(self.model.filepath)
+        results_fp = os.path.join(folder, 'results_dict.json')
+        if os.path.exists(results_fp):
+            with open(results_fp) as f:
+                self.metrics = json.load(f)
+            return self.metrics
+        os.makedirs(folder, exist_ok=True)
+        rep_fp = os.path.join(folder, 'representations.json')
+        self.save_representations(rep_fp, batch_size=batch_size)
+        self.metrics = {'representations': rep_fp}
+        self.metrics.update(self.test_model(batch_size=batch_size))
+        with open(results_fp, 'w') as f:
+            json.dump(self.metrics, f, indent=2)
+        return self.metrics
+
+    def loss_and_acc_test(self, data_loader):
+        """mean RECONSTRUCTION loss (no KL / regulariser terms) and mean pixel accuracy over the loader's batches
+        (image_vae_trainer.py:595-621); accumulated on the device, one host sync at the end."""
+        loss_sum = acc_sum = None
+        count = 0
         with torch.no_grad():
-            loss, acc = self.loss_and_acc_on_epoch(loader, epoch_num=0, train=False)
-        return {'test_loss': loss, 'test_acc': acc}
+            for batch in data_loader:
+                inputs, _ = self.process_batch_data(batch)
+                outputs = self.model(inputs)[0]
+                loss, acc = ops.image_recon(outputs, inputs, self.dec_dist)
+                loss_sum = loss.detach().clone() if loss_sum is None else loss_sum + loss.detach()
+                acc_sum = acc.detach().clone() if acc_sum is None else acc_sum + acc.detach()
+                count += 1
+        n = max(count, 1)
+        return (float(loss_sum) / n if count else 0.0), (float(acc_sum) / n if count else 0.0)
+
+    def test_model(self, batch_size):
+        """Mean reconstruction loss / accuracy over the evaluation split (image_vae_trainer.py:582-593)."""
+        _, _, loader = self.dataset.data_loaders(batch_size)
+        mean_loss, mean_acc = self.loss_and_acc_test(loader)
+        print('Test Epoch:')
+        print('\tTest Loss: ', mean_loss, '\n\tTest Accuracy: ', mean_acc * 100)
+        return {'test_loss': mean_loss, 'test_acc': mean_acc}
 
     # -- static helpers (image_vae_trainer.py:623-655) ---------------------------------------------------
     @staticmethod

@@ -169,12 +169,94 @@ class MeasureVAETrainer(Trainer):
             raise ValueError('compute_representations: the loader produced no batch (split smaller than the batch size?)')
         return torch.cat(codes).cpu().numpy(), torch.cat(attrs).cpu().numpy(), list(self.attr_dict)
 
+    def save_representations(self, path, data_loader=None, batch_size=256, num_batches=None):
+        """Write the record the reference's compute_eval_metrics consumes (measure_vae_trainer.py:217-243): latent codes,
+        attribute labels and attribute names as JSON, from the encoder-only pass.  The disentanglement metrics themselves
+        (utils/evaluation.py: sklearn / scipy on the host) are out of scope: they run unchanged on
+        this file's arrays."""
+        import json
+        if data_loader is None:
+            _, _, data_loader = self.dataset.data_loaders(batch_size=batch_size)
+        codes, attrs, names = self.compute_representations(data_loader, num_batches)
+        with open(path, 'w') as f:
+            json.dump({'latent_codes': codes.tolist(), 'attributes': attrs.tolist(), 'attr_list': list(names)}, f)
+        return codes, attrs, names
+
+    def compute_eval_metrics(self, batch_size=256):
+        """results_dict.json next to the checkpoint, as in the reference (measure_vae_trainer.py:217-243): loaded when it exists,
+        otherwise created with what this path computes on the device -- the test loss / accuracy -- and the file the host-side
+        metric suite reads (representations.json)."""
+        import json
+        import os
+        folder = os.path.dirname(self.model.filepath)
+        results_fp = os.path.join(folder, 'results_dict.json')
+        if os.path.exists(results_fp):
+            with open(results_fp) as f:
+                self.metrics = json.load(f)
+            return self.metrics
+        os.makedirs(folder, exist_ok=True)
+        rep_fp = os.path.join(folder, 'representations.json')
+        self.save_representations(rep_fp, batch_size=batch_size)
+        self.metrics = {'representations': rep_fp}
+        self.metrics.update(self.test_model(batch_size=batch_size))
+        with open(results_fp, 'w') as f:
+            json.dump(self.metrics, f, indent=2)
+        return self.metrics
+
+    def decode_latent_codes(self, latent_codes):
+        """(n, z_dim) latent codes -> (music21 score or None, note indices (n, 1, 24) int64): the decoder alone, free-running
+        (measure_vae_trainer.py:281-288).  The score object needs the dataset's music21 converter (`tensor_to_m21score`);
+        datasets without one (the device-resident loaders here) give None."""
+        dev = next(self.model.parameters()).device
+        z = torch.as_tensor(latent_codes, dtype=torch.float32, device=dev).contiguous()
+        dummy = torch.zeros(z.size(0), self.model.num_ticks_per_measure, dtype=torch.int64, device=dev)
+        with torch.no_grad():
+            _, tensor_score = self.model.decoder(z, dummy, False)
+        to_score = getattr(self.dataset, 'tensor_to_m21score', None)
+        return (to_score(tensor_score) if callable(to_score) else None), tensor_score
+
+    def compute_latent_interpolations(self, latent_code, original_score=None, dim1=0, num_points=5):
+        """Sweep latent dimension dim1 over [-4, 4] (measure_vae_trainer.py:290-308): all num_points codes are decoded in ONE
+        batch instead of one decoder call per point.  -> (concatenated music21 score or None, note indices (num_points, 24))."""
+        if num_points % 2 != 1:
+            raise AssertionError('num_points must be odd')
+        dev = next(self.model.parameters()).device
+        z = torch.as_tensor(latent_code, dtype=torch.float32, device=dev).reshape(1, -1).repeat(num_points, 1)
+        z[:, dim1] = torch.linspace(-4.0, 4.0, num_points, device=dev)
+        scores, tensor_score = self.decode_latent_codes(z)
+        tensor_score = tensor_score.squeeze(1)
+        concat = getattr(self.dataset, 'concatenate_scores', None)
+        to_score = getattr(self.dataset, 'tensor_to_m21score', None)
+        score = None
+        if callable(concat) and callable(to_score):
+            parts = [to_score(tensor_score[i:i + 1, None, :]) for i in range(num_points)]
+            if original_score is not None:
+                parts[num_points // 2] = original_score
+            score = concat(parts)
+        return score, tensor_score
+
+    def loss_and_acc_test(self, data_loader):
+        """mean RECONSTRUCTION loss (no KL / regulariser terms) and mean top-1 accuracy over the loader's batches
+        (measure_vae_trainer.py:367-397); accumulated on the device, one host sync at the end."""
+        loss_sum = acc_sum = None
+        count = 0
+        with torch.no_grad():
+            for batch in data_loader:
+                score, metadata = self.process_batch_data(batch)
+                weights = self.model(measure_score_tensor=score, measure_metadata_tensor=metadata, train=False)[0]
+                loss, acc = ops.token_recon(weights, score)
+                loss_sum = loss.detach().clone() if loss_sum is None else loss_sum + loss.detach()
+                acc_sum = acc.detach().clone() if acc_sum is None else acc_sum + acc.detach()
+                count += 1
+        n = max(count, 1)
+        return (float(loss_sum) / n if count else 0.0), (float(acc_sum) / n if count else 0.0)
+
     def test_model(self, batch_size):
         _, _, loader = self.dataset.data_loaders(batch_size)
-        self.model.eval()
-        with torch.no_grad():
-            loss, acc = self.loss_and_acc_on_epoch(loader, epoch_num=0, train=False)
-        return {'test_loss': loss, 'test_acc': acc}
+        mean_loss, mean_acc = self.loss_and_acc_test(loader)
+        print('Test Epoch:')
+        print('\tTest Loss: ', mean_loss, '\n\tTest Accuracy: ', mean_acc * 100)
+        return {'test_loss': mean_loss, 'test_acc': mean_acc}
 
     @staticmethod
     def reconstruction_loss(x, x_recons):

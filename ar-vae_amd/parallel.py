@@ -22,6 +22,27 @@ import torch
 import torch.distributed as dist
 
 
+def init_from_env():
+    """Under torch.distributed.run (WORLD_SIZE > 1): bind this process to its GPU (LOCAL_RANK), join the RCCL process group
+    and return a DataParallel; otherwise None.  What the training CLIs call before they build the dataset and the model."""
+    import os
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world <= 1 and os.environ.get('ARVAE_FORCE_DP', '0') != '1':      # ARVAE_FORCE_DP=1: the same code path on one rank (tests)
+        return None
+    if world <= 1:
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC only on this pool (RCCL needs it)
+    device = torch.device('cuda', local)
+    torch.cuda.set_device(device)
+    if not dist.is_initialized():
+        dist.init_process_group('nccl', device_id=device)
+    return DataParallel()
+
+
 class DataParallel:
     def __init__(self, process_group=None, reg_fn=None):
         if not dist.is_initialized():

@@ -35,13 +35,23 @@ class Trainer(ABC):
 
     # -- epoch loop (reference utils/trainer.py:39-154) ------------------------------------------------
     def train_model(self, batch_size, num_epochs, log=False):
-        if log:
+        if log and (self.data_parallel is None or self.data_parallel.rank == 0):
             from .logging_utils import make_writer
             stamp = datetime.datetime.fromtimestamp(time.time()).strftime('%Y-%m-%d_%H:%M:%S')
             self.writer = make_writer(os.path.join('runs', repr(self.model) + stamp))
-        train_loader, val_loader, _ = self.dataset.data_loaders(batch_size=batch_size, split=(0.70, 0.20))
-        print('Num Train Batches: ', len(train_loader))
-        print('Num Valid Batches: ', len(val_loader))
+        dp = self.data_parallel
+        chief = dp is None or dp.rank == 0                      # one rank logs, prints and writes checkpoints
+        if dp is not None:
+            # batch_size is the PER-GPU batch (weak scaling, as bench.py): every rank iterates its own rows of the same
+            # shuffled global batches (data/loaders.py)
+            train_loader, val_loader, _ = self.dataset.data_loaders(batch_size=batch_size, split=(0.70, 0.20),
+                                                                    shard=(dp.rank, dp.world_size))
+            dp.broadcast_parameters(self.model)
+        else:
+            train_loader, val_loader, _ = self.dataset.data_loaders(batch_size=batch_size, split=(0.70, 0.20))
+        if chief:
+            print('Num Train Batches: ', len(train_loader))
+            print('Num Valid Batches: ', len(val_loader))
         for epoch in range(num_epochs):
             self.update_scheduler(epoch)
             self.model.train()
@@ -49,6 +59,14 @@ class Trainer(ABC):
             self.model.eval()
             with torch.no_grad():
                 loss_va, acc_va = self.loss_and_acc_on_epoch(val_loader, epoch_num=epoch, train=False)
+            if dp is not None:                                   # epoch means over the global batch
+                stats = torch.tensor([loss_tr, acc_tr, loss_va, acc_va], dtype=torch.float64,
+                                     device=next(self.model.parameters()).device)
+                import torch.distributed as dist
+                dist.all_reduce(stats, group=dp.group)
+                loss_tr, acc_tr, loss_va, acc_va = (stats / dp.world_size).tolist()
+            if not chief:
+                continue
             self.eval_model(data_loader=val_loader, epoch_num=epoch)
             if log and self.writer is not None:
                 self.writer.add_scalar('loss/train', loss_tr, epoch)

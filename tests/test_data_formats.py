@@ -106,3 +106,22 @@ def test_device_loader_refuses_cpu_tensors():
     from arvae_amd.data import DeviceLoader
     with pytest.raises(RuntimeError):
         DeviceLoader((torch.zeros(4, 2),), 0, 4, 2, shuffle=False)
+
+
+def test_sharded_loader_plan_partitions_the_rows():
+    """data-parallel loaders (data/loaders.py): the ranks' row ranges of every global batch are disjoint, equal in size and
+    cover the split except for a tail smaller than the world size; world = 1 is the plain ceil(n / batch) walk."""
+    from arvae_amd.data.loaders import DeviceLoader
+    for n, bs, world, drop in [(1000, 64, 1, False), (1000, 64, 1, True), (1003, 32, 4, False), (515, 64, 8, False), (515, 64, 8, True),
+                               (7, 8, 2, False)]:
+        plan = DeviceLoader.plan(n, bs, world, drop)
+        seen = []
+        for offset, rows in plan:
+            assert 0 < rows <= bs
+            for r in range(world):
+                seen.extend(range(offset + r * rows, offset + (r + 1) * rows))
+        assert len(seen) == len(set(seen)) and (not seen or max(seen) < n)
+        if world == 1:
+            assert len(plan) == (n // bs if drop else -(-n // bs)) and (drop or len(seen) == n)
+        elif not drop:
+            assert n - len(seen) < world

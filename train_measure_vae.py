@@ -69,6 +69,11 @@ def main(dataset_type, note_embedding_dim, metadata_embedding_dim, num_encoder_l
         raise ValueError('Invalid dataset_type. Choose between `folk` and `bach`')
     reg_dim = reg_dims_for(reg_type, MUSIC_REG_TYPE)
     seeds = range(0, 10) if rand is None else [int(rand)]
+    # launched by torch.distributed.run: one process per GPU, minibatch rows sharded over the ranks, gradients all-reduced
+    # over RCCL (arvae_amd.parallel); --batch_size is then the per-GPU batch
+    from arvae_amd.parallel import init_from_env
+    dp = init_from_env() if train else None
+    chief = dp is None or dp.rank == 0
     for seed in seeds:
         model = MeasureVAE(dataset=dataset, note_embedding_dim=note_embedding_dim,
                            metadata_embedding_dim=metadata_embedding_dim, num_encoder_layers=num_encoder_layers,
@@ -82,7 +87,12 @@ def main(dataset_type, note_embedding_dim, metadata_embedding_dim, num_encoder_l
             if not torch.cuda.is_available():
                 raise SystemExit('training needs a GPU: the AR-VAE path has no CPU fallback')
             trainer.cuda()
+            if dp is not None:
+                dp.attach(trainer)
             trainer.train_model(batch_size=batch_size, num_epochs=num_epochs, log=log)
+            trainer.data_parallel = None
+        if not chief:
+            continue
         trainer.load_model()
         trainer.writer = None
         eval_bs = min(256, batch_size)                  # the reference evaluates with 256; smaller runs keep their own size
