@@ -129,6 +129,8 @@ class Encoder(Model):
     def forward(self, score_tensor):
         """score (B, 24) int64 -> Normal(mu, exp(log_std)); the reparameterised sample computed by the same
         fused kernel travels with the distribution object (z_dist._arvae_sample)."""
+        if ops.checks_enabled():                             # the reference's NaN scan of the weights (encoder.py:101-106)
+            ops.check_finite([p for n, p in self.named_parameters() if 'weight' in n], 'Encoder')
         mu, log_std = self.encode_params(score_tensor)
         if self._eps_queue:
             eps = self._eps_queue.popleft().to(mu.device, torch.float32).contiguous()
@@ -245,6 +247,14 @@ class HierarchicalDecoder(Decoder):
     def forward(self, z, score_tensor, train):
         if z.size(1) != self.z_dim or z.size(0) != score_tensor.size(0):
             raise AssertionError('latent / score shape mismatch')
+        if ops.checks_enabled():                             # the reference's NaN scan of the weights (decoder.py:420-425)
+            ops.check_finite([p for n, p in self.named_parameters() if 'weight' in n], 'Decoder')
+        weights, samples = self._forward(z, score_tensor, train)
+        if ops.checks_enabled():                             # Decoder.check_index on every fed-back note (decoder.py:30-41)
+            ops.check_index(samples, self.num_notes)
+        return weights, samples
+
+    def _forward(self, z, score_tensor, train):
         if self.use_teacher_forcing and train:
             teacher_forced = torch.rand(1).item() < self.teacher_forcing_prob       # host coin (decoder.py:427-428)
         else:

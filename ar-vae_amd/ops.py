@@ -6,6 +6,7 @@ kernels on the current stream.  There is no CPU path: CPU tensors raise.
 Activation tensors are channels-last ([N, H, W, C]; [B, F] for dense layers).
 """
 import ctypes
+import os
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -830,6 +831,46 @@ class _ScaleMaskFn(Function):
         dx = torch.empty_like(g)
         _lib.check(lib.arvae_scale_mask(_ptr(g), _ptr(mask), ctx.alpha, g.numel(), 0, _ptr(dx), _stream()), 'scale_mask')
         return dx, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# debug-mode failure checks (ARVAE_CHECK=1): the reference's NaN-weight scan and note-index range check
+# ------------------------------------------------------------------------------------------------
+def checks_enabled():
+    return os.environ.get('ARVAE_CHECK', '0') == '1'
+
+
+def check_finite(params, what):
+    """raise ValueError when any tensor of `params` holds a NaN / infinity (measurevae/encoder.py:101-106, decoder.py:420-425):
+    one counting launch per tensor into one device word, ONE host sync (the reference syncs once per parameter)."""
+    params = [p for p in params if p is not None and p.numel() > 0]
+    if not params or torch.cuda.is_current_stream_capturing():
+        return
+    lib = _lib.load()
+    flag = torch.zeros(1, dtype=torch.int32, device=params[0].device)
+    for p in params:
+        t = p.detach().contiguous()
+        _dev(t)
+        _lib.check(lib.arvae_count_nonfinite(_ptr(t), t.numel(), _ptr(flag), _stream()), 'count_nonfinite')
+    bad = int(flag)
+    if bad:
+        print(f'{what} has become nan')
+        raise ValueError(f'{what}: {bad} non-finite weight value(s)')
+
+
+def check_index(indices, num_notes):
+    """raise ValueError unless every index is in [0, num_notes) (Decoder.check_index, measurevae/decoder.py:30-41)"""
+    if torch.cuda.is_current_stream_capturing():
+        return
+    idx = indices.contiguous()
+    _dev(idx)
+    flag = torch.zeros(1, dtype=torch.int32, device=idx.device)
+    _lib.check(_lib.load().arvae_count_out_of_range(_ptr(idx), idx.numel(), 0, int(num_notes), _ptr(flag), _stream()),
+               'count_out_of_range')
+    bad = int(flag)
+    if bad:
+        print('Invalid Values of Indices: ', int(idx.min()), int(idx.max()))
+        raise ValueError(f'{bad} note index(es) outside [0, {num_notes})')
 
 
 # ------------------------------------------------------------------------------------------------

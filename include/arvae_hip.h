@@ -415,6 +415,16 @@ int arvae_philox_normal(float *out, int64_t count, uint64_t seed, uint32_t offse
 int arvae_philox_keep_mask(uint8_t *out, int64_t count, float keep_prob, uint64_t seed, uint32_t offset, uint32_t step,
                            const uint32_t *dev_step, arvae_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Debug-mode failure checks (off by default; the Python side runs them with ARVAE_CHECK=1 and raises ValueError as the
+ * reference does): number of NaN / infinite values of a parameter arena (measurevae/encoder.py:101-106,
+ * decoder.py:420-425) and number of note indices outside [lo, hi) (Decoder.check_index, decoder.py:30-41), ADDED to the
+ * device word `flag` (the caller zeroes it; integer adds, so the count is exact).
+ * ------------------------------------------------------------------------------------------------ */
+int arvae_count_nonfinite(const float *values, int64_t count, int32_t *flag, arvae_stream_t stream);
+int arvae_count_out_of_range(const int64_t *indices, int64_t count, int64_t lo, int64_t hi, int32_t *flag,
+                             arvae_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

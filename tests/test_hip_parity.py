@@ -1203,3 +1203,34 @@ def test_fused_step_draws_its_own_noise(dev):
         assert not torch.equal(zs[0], zs[1])
         runs.append(zs)
     assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+
+
+def test_debug_checks_raise_like_the_reference(dev, monkeypatch):
+    """ARVAE_CHECK=1: a NaN in a weight raises ValueError at the top of the encoder / decoder forward (encoder.py:101-106,
+    decoder.py:420-425), a teacher-forced note outside the vocabulary raises from the index check (decoder.py:30-41); off
+    by default (no extra launches, no syncs)."""
+    from arvae_amd import ops
+    from arvae_amd.measure_vae import MeasureVAE
+    monkeypatch.setenv('ARVAE_CHECK', '1')
+    ds = _FolkDataset()
+    torch.manual_seed(1)
+    model = MeasureVAE(ds, 10, 2, 2, 64, 0.0, 16, 2, 64, 0.0, False, 'folk')
+    model.cuda().eval()
+    score = torch.from_numpy(syn.measure_batch(8, seed=3)).to(dev)
+    model(score, score, train=False)                         # clean weights, clean indices: passes
+    ops.check_finite([torch.ones(5, device=dev)], 'x')
+    with pytest.raises(ValueError):
+        ops.check_finite([torch.tensor([1.0, float('inf')], device=dev)], 'x')
+    with pytest.raises(ValueError):
+        ops.check_index(torch.tensor([0, 35], device=dev), 35)
+    with torch.no_grad():
+        model.decoder.tick_emb_to_note_emb[0].weight[3, 5] = float('nan')
+    with pytest.raises(ValueError):
+        model(score, score, train=False)
+    with torch.no_grad():
+        model.decoder.tick_emb_to_note_emb[0].weight[3, 5] = 0.0
+        model.encoder.lstm.weight_hh_l0[0, 0] = float('nan')
+    with pytest.raises(ValueError):
+        model(score, score, train=False)
+    monkeypatch.setenv('ARVAE_CHECK', '0')
+    model(score, score, train=False)                         # checks off: the NaN propagates silently, as without the scan
