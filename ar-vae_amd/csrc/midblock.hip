@@ -1,0 +1,546 @@
+// The latent block of the conv VAEs as ONE launch per pass (imagevae/mnist_vae.py:59-72, dsprites_vae.py:12-46):
+//   forward : conv features -> enc_lin (Linear + act)* -> enc_mean / enc_log_std -> z = mu + eps * exp(log_std)
+//             -> dec_lin (Linear + act)* -> first deconv's input
+//   backward: the same chain in reverse: d(dec_lin) -> d z (+ KL and regulariser gradients) -> d(mu, log_std) -> heads ->
+//             d(enc_lin) -> gradient for the last conv layer, leaving every layer's pre-activation gradient in memory for
+//             the grouped weight-gradient launch (dense.hip).
+// EXPERIMENT, off by default (see mid_fusable): it measured no faster than the per-layer launches.
+// Per layer these are a few MFLOP per batch: as separate launches (5 + 5 Linear kernels, 2 head kernels) they cost
+// ~6 us each of pure latency, 12 dependent launches per step.  A batch row never talks to another here, so a workgroup
+// takes R rows through the WHOLE chain with its activations in LDS; what it streams is the weights (L2-resident,
+// ~1.6 MB for dSprites), read as coalesced 16-byte loads because a prep launch (mid_prep) lays every matrix out
+// reduce-major for the direction that uses it ([k][n] for the forward product, [n][k] for the backward one), with the
+// NCHW-flatten permutations of the first / last layer folded in.  Exact fp32 FMA chains (no MFMA: at 4 rows a matrix tile
+// would be three quarters padding and the weight stream, not the arithmetic, sets the pace).
+#include "common.h"
+#include "dense.h"
+#include "rng.h"
+
+namespace arvae {
+
+
+constexpr int MID_T = 512;           // threads per workgroup
+constexpr int MID_MAX_LAYERS = 4;    // Linear layers on either side of the latent
+constexpr int MID_MAX_W = 3072;      // widest layer (Morpho-MNIST: 2888)
+constexpr int mid_red(int r) { return r * 4 * MID_T; }   // floats of cross-slice reduction scratch (slices * n <= 4 * MID_T)
+
+struct MidLayer {
+    const float *mf;     // [k][n] forward matrix   (memory order on both axes)
+    const float *mb;     // [n][k] backward matrix
+    const float *bias;   // [n] or null
+    float *y;            // saved output [batch][n]
+    float *gpre;         // gradient w.r.t. the pre-activation [batch][n] (backward writes it for the weight gradient)
+    int k, n, act;
+    int kb;              // row length of mb: k rounded up to a multiple of 4 (zero-padded: the decoder's first layer reads z)
+};
+
+struct MidArgs {
+    MidLayer enc[MID_MAX_LAYERS], dec[MID_MAX_LAYERS];
+    int ne, nd, batch, zdim, h, ld;                  // h = width of the encoder's hidden vector, ld = LDS row pitch
+    const float *x0;                                 // conv features [batch][enc[0].k]
+    const float *w_mu, *b_mu, *w_ls, *b_ls;          // heads, reference layout [zdim][h]
+    const float *hf, *hb, *hbias;                    // heads prepped: [h][2 zdim] (mu columns, then log_std), [2 zdim][h], [2 zdim]
+    float *mu, *log_std, *sigma, *z;
+    const float *eps;                                // forward: input unless eps_out; backward: input
+    float *eps_out;                                  // forward: draw eps (rng) and write it here
+    RngStream rng;
+    // backward only
+    const float *g_out;                              // gradient arriving at dec[nd-1]: w.r.t. its pre-activation (g_is_pre) or output
+    int g_is_pre;
+    const float *gate0;                              // saved ReLU output of the producer of x0, or null: d x0 *= (gate0 > 0)
+    float *d_x0;                                     // gradient handed to the last conv layer [batch][enc[0].k]
+    const float *dz_reg, *dz_extra, *g_loss, *kl, *cap;
+    float beta, inv_batch, reg_scale;
+    float *d_mu, *d_ls;
+};
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void fma4(float4 &a, float x, const float4 &w) {
+    a.x = fmaf(x, w.x, a.x); a.y = fmaf(x, w.y, a.y); a.z = fmaf(x, w.z, a.z); a.w = fmaf(x, w.w, a.w);
+}
+
+// rows of `in` (LDS, pitch ld) times M [ni][no] (global, no % 4 == 0) for columns 4q .. 4q+3, reduction range [i_lo, i_hi).
+// The weight stream is what this block waits for (an L2 round trip is ~1000 cycles, a 4-row step of 64 FMAs ~200), so the
+// reduction walks blocks of 8 rows of M with the NEXT block's eight 16-byte loads issued before the current block's FMAs:
+// two register sets, 16 loads in flight per thread at the block boundary (16-row blocks spill at 256 registers).
+template <int R>
+__device__ __forceinline__ void mid_step4(const float *in, int ld, int i, const float4 (&w)[4], float4 (&acc)[R]) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float4 x = ld4(in + r * ld + i);
+        fma4(acc[r], x.x, w[0]); fma4(acc[r], x.y, w[1]); fma4(acc[r], x.z, w[2]); fma4(acc[r], x.w, w[3]);
+    }
+}
+template <int R>
+__device__ __forceinline__ void mid_dot(const float *in, int ld, const float *__restrict__ M, int no, int q, int i_lo, int i_hi,
+                                        float4 (&acc)[R]) {
+    const float *mp = M + 4 * q;
+    int i = i_lo;
+    if (i + 8 <= i_hi) {
+        float4 wa[2][4], wb[2][4];
+        auto load8 = [&](float4 (&w)[2][4], int at) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) w[u][t] = ld4(mp + (int64_t)(at + 4 * u + t) * no);
+        };
+        auto fma8 = [&](const float4 (&w)[2][4], int at) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) mid_step4<R>(in, ld, at + 4 * u, w[u], acc);
+        };
+        load8(wa, i);
+        for (;;) {
+            if (i + 16 > i_hi) { fma8(wa, i); i += 8; break; }
+            load8(wb, i + 8);
+            fma8(wa, i);
+            i += 8;
+            if (i + 16 > i_hi) { fma8(wb, i); i += 8; break; }
+            load8(wa, i + 8);
+            fma8(wb, i);
+            i += 8;
+        }
+    }
+    for (; i + 4 <= i_hi; i += 4) {
+        float4 w[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) w[t] = ld4(mp + (int64_t)(i + t) * no);
+        mid_step4<R>(in, ld, i, w, acc);
+    }
+    for (; i < i_hi; ++i) {
+        const float4 w = ld4(mp + (int64_t)i * no);
+#pragma unroll
+        for (int r = 0; r < R; ++r) fma4(acc[r], in[r * ld + i], w);
+    }
+}
+
+// out[r][j] = fin(r, quad, sum_i in[r][i] * M[i][j], pre(r, quad)) for the R rows of this workgroup.  `pre` is called
+// BEFORE the reduction loop for every output the thread will finalise (its global loads fly during the loop).
+// Narrow layers (no / 4 < MID_T) split the reduction over MID_T / (no / 4) thread slices that meet in `red`.
+template <int R, class Pre, class Fin>
+__device__ __forceinline__ void mid_matmul(const float *in, int ld, int ni, const float *__restrict__ M, int no, float *red, Pre pre,
+                                           Fin fin) {
+    const int tid = threadIdx.x, nq = no >> 2;
+    if (nq >= MID_T) {
+        for (int q = tid; q < nq; q += MID_T) {
+            float4 pf[R], acc[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) { pf[r] = pre(r, q); acc[r] = make_float4(0.f, 0.f, 0.f, 0.f); }
+            mid_dot<R>(in, ld, M, no, q, 0, ni, acc);
+#pragma unroll
+            for (int r = 0; r < R; ++r) fin(r, q, acc[r], pf[r]);
+        }
+        return;
+    }
+    const int slices = min(MID_T / nq, 32), s = tid / nq, q = tid - s * nq;      // (a very narrow output keeps its final sum short)
+    const int chunk = (((ni + slices - 1) / slices) + 3) & ~3;
+    const int i_lo = min(s * chunk, ni), i_hi = min(i_lo + chunk, ni);
+    float4 pf[R];
+    bool mine[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {                            // the outputs this thread finalises: idx = tid + j * MID_T
+        const int idx = tid + j * MID_T;
+        mine[j] = idx < R * nq;
+        pf[j] = mine[j] ? pre(idx / nq, idx % nq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (s < slices) {
+        mid_dot<R>(in, ld, M, no, q, i_lo, i_hi, acc);
+#pragma unroll
+        for (int r = 0; r < R; ++r) *reinterpret_cast<float4 *>(red + (s * R + r) * no + 4 * q) = acc[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        if (!mine[j]) continue;
+        const int idx = tid + j * MID_T, r = idx / nq, qq = idx - r * nq;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int ss = 0; ss < slices; ++ss) {                    // fixed order
+            const float4 t = ld4(red + (ss * R + r) * no + 4 * qq);
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        fin(r, qq, v, pf[j]);
+    }
+}
+
+__device__ __forceinline__ float4 act4(float4 v, int act) {
+    return make_float4(act_fwd(v.x, act), act_fwd(v.y, act), act_fwd(v.z, act), act_fwd(v.w, act));
+}
+__device__ __forceinline__ float4 dact4(float4 g, float4 y, int act) {       // g * act'(.) from the saved output y
+    return make_float4(g.x * act_bwd_from_out(y.x, act), g.y * act_bwd_from_out(y.y, act), g.z * act_bwd_from_out(y.z, act),
+                       g.w * act_bwd_from_out(y.w, act));
+}
+
+#ifdef MID_STAMPS
+__device__ unsigned long long g_mid_stamps[128 * 16];
+#define MID_STAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 128) g_mid_stamps[blockIdx.x * 16 + (slot)] = wall_clock64(); } while (0)
+#else
+#define MID_STAMP(slot)
+#endif
+
+// ================================================================================================ forward
+template <int R>
+__global__ __launch_bounds__(MID_T) void mid_forward_kernel(MidArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // bufA | bufB | red | heads scratch (R * 32)
+    float *bufA = lds, *bufB = lds + R * p.ld, *red = bufB + R * p.ld, *outs = red + mid_red(R);
+    const int tid = threadIdx.x, row0 = blockIdx.x * R;
+    MID_STAMP(0);
+    {   // conv features of this workgroup's rows -> bufA (rows past the batch: zeros)
+        const int k4 = p.enc[0].k >> 2;
+        for (int i = tid; i < R * k4; i += MID_T) {
+            const int r = i / k4, c = i - r * k4;
+            const float4 v = row0 + r < p.batch ? ld4(p.x0 + (int64_t)(row0 + r) * p.enc[0].k + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<float4 *>(bufA + r * p.ld + 4 * c) = v;
+        }
+    }
+    __syncthreads();
+    MID_STAMP(1);
+    float *cur = bufA, *nxt = bufB;
+    int stamp_no = 2;
+    (void)stamp_no;
+    auto run_layer = [&](const MidLayer l) {
+        mid_matmul<R>(
+            cur, p.ld, l.k, l.mf, l.n, red,
+            [&](int, int q) { return l.bias != nullptr ? ld4(l.bias + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f); },
+            [&](int r, int q, float4 v, float4 b) {
+                v = act4(make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w), l.act);
+                *reinterpret_cast<float4 *>(nxt + r * p.ld + 4 * q) = v;
+                if (row0 + r < p.batch) *reinterpret_cast<float4 *>(l.y + (int64_t)(row0 + r) * l.n + 4 * q) = v;
+            });
+        __syncthreads();
+        MID_STAMP(stamp_no); ++stamp_no;
+        float *t = cur; cur = nxt; nxt = t;
+    };
+    for (int i = 0; i < p.ne; ++i) run_layer(p.enc[i]);
+    // heads: one more layer of the chain, (mu | log_std) = hidden x [h][2 zdim] + bias, into the scratch rows `outs`
+    mid_matmul<R>(
+        cur, p.ld, p.h, p.hf, 2 * p.zdim, red,
+        [&](int, int q) { return ld4(p.hbias + 4 * q); },
+        [&](int r, int q, float4 v, float4 b) {
+            *reinterpret_cast<float4 *>(outs + r * 32 + 4 * q) = make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w);
+        });
+    __syncthreads();
+    if (tid < R * p.zdim) {
+        const int r = tid / p.zdim, j = tid - r * p.zdim, row = row0 + r;
+        const int64_t idx = (int64_t)(row < p.batch ? row : 0) * p.zdim + j;
+        const float m = outs[r * 32 + j], l = outs[r * 32 + j + p.zdim], s = expf(l);
+        const float e = p.eps_out != nullptr ? rng_normal(p.rng, (uint64_t)idx) : p.eps[idx];
+        const float zv = fmaf(e, s, m);
+        nxt[r * p.ld + j] = row < p.batch ? zv : 0.f;
+        if (row < p.batch) {
+            p.mu[idx] = m; p.log_std[idx] = l; p.sigma[idx] = s; p.z[idx] = zv;
+            if (p.eps_out != nullptr) p.eps_out[idx] = e;
+        }
+    }
+    __syncthreads();
+    { float *t = cur; cur = nxt; nxt = t; }
+    MID_STAMP(stamp_no); ++stamp_no;
+    for (int i = 0; i < p.nd; ++i) run_layer(p.dec[i]);
+}
+
+// ================================================================================================ backward
+template <int R>
+__global__ __launch_bounds__(MID_T) void mid_backward_kernel(MidArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *bufA = lds, *bufB = lds + R * p.ld, *red = bufB + R * p.ld, *dm = red + mid_red(R), *dl = dm + R * 16;
+    const int tid = threadIdx.x, row0 = blockIdx.x * R;
+    {   // gradient arriving at the last decoder Linear layer -> bufA as a pre-activation gradient
+        const MidLayer l = p.dec[p.nd - 1];
+        const int n4 = l.n >> 2;
+        for (int i = tid; i < R * n4; i += MID_T) {
+            const int r = i / n4, c = i - r * n4, row = row0 + r;
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < p.batch) {
+                g = ld4(p.g_out + (int64_t)row * l.n + 4 * c);
+                if (!p.g_is_pre) {
+                    g = dact4(g, ld4(l.y + (int64_t)row * l.n + 4 * c), l.act);
+                    *reinterpret_cast<float4 *>(l.gpre + (int64_t)row * l.n + 4 * c) = g;
+                }
+            }
+            *reinterpret_cast<float4 *>(bufA + r * p.ld + 4 * c) = g;
+        }
+    }
+    __syncthreads();
+    float *cur = bufA, *nxt = bufB;
+    // d(input of layer l) from d(pre-activation of l): [n] -> [k]; prev = the layer that produced the input (null: no activation)
+    // y_prev / act_prev: saved output and activation of the layer that produced this layer's input (y_prev null: the input is
+    // the conv feature map, gated by gate_relu when given); dst: where the input's pre-activation gradient goes
+    auto back_layer = [&](const float *mb, int n, int k, const float *y_prev, int act_prev, const float *gate_relu, float *dst) {
+        mid_matmul<R>(
+            cur, p.ld, n, mb, k, red,
+            [&](int r, int q) {
+                const int row = row0 + r;
+                const float *src = y_prev != nullptr ? y_prev : gate_relu;
+                if (row >= p.batch || src == nullptr) return make_float4(1.f, 1.f, 1.f, 1.f);
+                return ld4(src + (int64_t)row * k + 4 * q);
+            },
+            [&](int r, int q, float4 v, float4 y) {
+                const int row = row0 + r;
+                if (y_prev != nullptr) v = dact4(v, y, act_prev);
+                else if (gate_relu != nullptr) v = make_float4(y.x > 0.f ? v.x : 0.f, y.y > 0.f ? v.y : 0.f, y.z > 0.f ? v.z : 0.f, y.w > 0.f ? v.w : 0.f);
+                *reinterpret_cast<float4 *>(nxt + r * p.ld + 4 * q) = v;
+                if (row < p.batch && dst != nullptr) *reinterpret_cast<float4 *>(dst + (int64_t)row * k + 4 * q) = v;
+            });
+        __syncthreads();
+        float *t = cur; cur = nxt; nxt = t;
+    };
+    for (int i = p.nd - 1; i >= 1; --i) back_layer(p.dec[i].mb, p.dec[i].n, p.dec[i].k, p.dec[i - 1].y, p.dec[i - 1].act, nullptr, p.dec[i - 1].gpre);
+    // dec[0]: its input is z (k = zdim, no activation; its backward matrix is zero-padded to a multiple of 4 columns)
+    {
+        const MidLayer l = p.dec[0];
+        mid_matmul<R>(
+            cur, p.ld, l.n, l.mb, l.kb, red, [&](int, int) { return make_float4(0.f, 0.f, 0.f, 0.f); },
+            [&](int r, int q, float4 v, float4) { *reinterpret_cast<float4 *>(nxt + r * p.ld + 4 * q) = v; });
+        __syncthreads();
+        if (tid < R * p.zdim) {
+            const int r = tid / p.zdim, j = tid - r * p.zdim, row = row0 + r;
+            float gz = nxt[r * p.ld + j];
+            // d(mu, log_std): decoder path + regulariser + KL (the formulas of heads_latent_bwd_kernel, heads.hip)
+            const int64_t i = (int64_t)(row < p.batch ? row : 0) * p.zdim + j;
+            const float g = p.g_loss[0];
+            const float diff = p.kl[0] - (p.cap != nullptr ? p.cap[0] : 0.f);
+            const float kk = g * p.beta * (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f)) * p.inv_batch;
+            if (p.dz_reg != nullptr) gz += g * p.reg_scale * p.dz_reg[i];
+            if (p.dz_extra != nullptr) gz += p.dz_extra[i];
+            const float s = p.sigma[i], mu = p.mu[i], e = p.eps[i];
+            const float a = gz + kk * mu, b = (gz * e + kk * (s - 1.f / s)) * s;
+            const bool on = row < p.batch;
+            if (on) { p.d_mu[i] = a; p.d_ls[i] = b; }
+            dm[r * 16 + j] = on ? a : 0.f;
+            dl[r * 16 + j] = on ? b : 0.f;
+        }
+    }
+    __syncthreads();
+    // d hidden = (d_mu | d_ls) x [2 zdim][h], times act' of the last encoder Linear layer
+    {
+        const MidLayer last = p.enc[p.ne - 1];
+        if (tid < R * 2 * p.zdim) {
+            const int r = tid / (2 * p.zdim), j = tid - r * 2 * p.zdim;
+            nxt[r * p.ld + j] = j < p.zdim ? dm[r * 16 + j] : dl[r * 16 + j - p.zdim];
+        }
+        __syncthreads();
+        { float *t = cur; cur = nxt; nxt = t; }
+        back_layer(p.hb, 2 * p.zdim, p.h, last.y, last.act, nullptr, last.gpre);
+    }
+    for (int i = p.ne - 1; i >= 1; --i) back_layer(p.enc[i].mb, p.enc[i].n, p.enc[i].k, p.enc[i - 1].y, p.enc[i - 1].act, nullptr, p.enc[i - 1].gpre);
+    back_layer(p.enc[0].mb, p.enc[0].n, p.enc[0].k, nullptr, 0, p.gate0, p.d_x0);
+}
+
+// ================================================================================================ weight layout prep
+struct MidPrepJob {
+    const float *w, *b;          // reference layout [n][k], bias [n]
+    const float *w2, *b2;        // rows n >= nsplit come from here (the two heads share one prepped matrix); null: one source
+    int nsplit;
+    float *mf, *mb, *bias;
+    int k, n, kb;                // kb: row length of mb (k rounded up to a multiple of 4, zero-padded)
+    Perm kp, np;                 // memory order <-> feature order of the input / output axis
+};
+struct MidPrepArgs {
+    MidPrepJob job[2 * MID_MAX_LAYERS + 1];
+    int count, blk_end[2 * MID_MAX_LAYERS + 1];
+};
+
+__global__ __launch_bounds__(256) void mid_prep_kernel(MidPrepArgs a) {
+    int j = 0, start = 0;
+#pragma unroll
+    for (int q = 0; q + 1 < 2 * MID_MAX_LAYERS + 1; ++q)
+        if (q + 1 < a.count && (int)blockIdx.x >= a.blk_end[q]) { j = q + 1; start = a.blk_end[q]; }
+    const MidPrepJob &p = a.job[j];
+    const int total = p.kb * p.n, stride = (a.blk_end[j] - start) * 256;
+    for (int e = ((int)blockIdx.x - start) * 256 + threadIdx.x; e < total; e += stride) {
+        auto src = [&](int nf, int kf) {                          // W[nf][kf] of the layer (two stacked sources for the heads)
+            return (p.w2 != nullptr && nf >= p.nsplit) ? p.w2[(int64_t)(nf - p.nsplit) * p.k + kf] : p.w[(int64_t)nf * p.k + kf];
+        };
+        if (e < p.k * p.n) {
+            const int km = e / p.n, nm = e - km * p.n;            // forward matrix [k][n], written in order
+            p.mf[e] = src(p.np.to_feat(nm), p.kp.to_feat(km));
+        }
+        const int nm2 = e / p.kb, km2 = e - nm2 * p.kb;          // backward matrix [n][kb], written in order
+        p.mb[e] = km2 < p.k ? src(p.np.to_feat(nm2), p.kp.to_feat(km2)) : 0.f;
+        if (e < p.n && p.bias != nullptr) {
+            const int nf = p.np.to_feat(e);
+            const float *bs = (p.w2 != nullptr && nf >= p.nsplit) ? p.b2 : p.b;
+            p.bias[e] = bs != nullptr ? bs[(p.w2 != nullptr && nf >= p.nsplit) ? nf - p.nsplit : nf] : 0.f;
+        }
+    }
+}
+
+// ================================================================================================ host side
+static bool mid_layer_ok(const arvae_layer_t &l) {
+    return dense_fits(&l.link) && !l.is_up && l.dropout == 0 && l.link.chi % 4 == 0 && l.link.clo % 4 == 0 && l.link.chi <= MID_MAX_W &&
+           l.link.clo <= MID_MAX_W;
+}
+
+// trailing Linear layers of the encoder / leading Linear layers of the decoder that the block covers (0: block not usable)
+bool mid_fusable(const arvae_image_vae_t *m, int *ne_out, int *nd_out) {
+    // OFF by default (ARVAE_MIDBLOCK=1 switches it on).  Measured at B = 512 on MI355X: forward 31-35 us, backward 36-42 us,
+    // prep 9-10 us against ~88 us for the twelve per-layer launches it replaces -- no gain.  Phase stamps
+    // (tools/stamp_mid.py): every layer of the chain costs >= 3.3 us however small (the 10 -> 256 layer included): a
+    // dependent round trip to the freshly written weights, two barriers and the saved-activation store per layer, on
+    // 128 of the 256 CUs; the per-layer launches pay a similar latency each but spread one layer over the whole chip.
+    static const bool off = getenv("ARVAE_MIDBLOCK") == nullptr || getenv("ARVAE_MIDBLOCK")[0] != '1';
+    int ne = 0, nd = 0;
+    while (ne < m->n_enc && ne < MID_MAX_LAYERS && mid_layer_ok(m->enc[m->n_enc - 1 - ne])) ++ne;
+    while (nd < m->n_dec && nd < MID_MAX_LAYERS) {
+        const arvae_layer_t &l = m->dec[nd];
+        // dec[0] reads z: its input width is zdim (any value); the others must be multiples of 4 on both sides
+        const bool ok = dense_fits(&l.link) && !l.is_up && l.dropout == 0 && l.link.clo % 4 == 0 && l.link.clo <= MID_MAX_W &&
+                        (nd == 0 ? l.link.chi == m->zdim : l.link.chi % 4 == 0);
+        if (!ok) break;
+        ++nd;
+    }
+    // the whole Linear stack of either side must be inside the block, the hidden vector feeds the heads
+    const bool enc_whole = ne >= 1 && (ne == m->n_enc || !dense_fits(&m->enc[m->n_enc - 1 - ne].link));
+    const bool dec_whole = nd >= 1 && nd < m->n_dec && !dense_fits(&m->dec[nd].link);
+    const arvae_link_t &hm = m->head_mu.link;
+    const bool heads_ok = dense_fits(&hm) && dense_fits(&m->head_log_std.link) && hm.clo == m->zdim && m->head_log_std.link.clo == m->zdim &&
+                          m->zdim <= 16 && m->zdim % 2 == 0 && hm.chi % 4 == 0 && hm.chi <= 512 && hm.hi_perm_c == 0 && hm.lo_perm_c == 0 &&
+                          m->head_mu.act == ARVAE_ACT_NONE && m->head_log_std.act == ARVAE_ACT_NONE &&
+                          m->head_log_std.link.hi_perm_c == 0 && m->head_log_std.link.lo_perm_c == 0;
+    const bool ok = !off && enc_whole && dec_whole && heads_ok && ne < m->n_enc && m->enc[m->n_enc - 1].link.clo == hm.chi &&
+                    m->dec[0].link.hi_perm_c == 0 && m->dec[0].link.lo_perm_c == 0;
+    if (ne_out) *ne_out = ok ? ne : 0;
+    if (nd_out) *nd_out = ok ? nd : 0;
+    return ok;
+}
+
+static int64_t mid_layer_floats(const arvae_layer_t &l) {
+    const int64_t k = l.link.chi, n = l.link.clo, kb = (k + 3) / 4 * 4;
+    return (k * n + 3) / 4 * 4 + kb * n + (n + 3) / 4 * 4;       // mf | mb | bias, each 16-byte aligned
+}
+
+// floats of workspace for the prepped matrices of the block's layers
+int64_t mid_prep_floats(const arvae_image_vae_t *m) {
+    int ne, nd;
+    if (!mid_fusable(m, &ne, &nd)) return 0;
+    int64_t total = 0;
+    for (int i = 0; i < ne; ++i) total += mid_layer_floats(m->enc[m->n_enc - ne + i]);
+    for (int i = 0; i < nd; ++i) total += mid_layer_floats(m->dec[i]);
+    const int64_t h = m->head_mu.link.chi, z2 = 2 * m->zdim;
+    return total + 2 * ((h * z2 + 3) / 4 * 4) + (z2 + 3) / 4 * 4;  // heads: [h][2z] | [2z][h] | bias
+}
+
+struct MidPlan {
+    MidArgs args;
+    MidPrepArgs prep;
+    size_t lds_bytes;
+    int rows;                    // batch rows per workgroup: 8 when two row buffers of that height fit LDS beside the scratch, else 4
+};
+
+// fills the layer tables from the model description; y / gpre buffers are given per layer by the caller afterwards
+static void mid_describe(const arvae_image_vae_t *m, const float *params, float *prep_ws, MidPlan &pl) {
+    int ne, nd;
+    mid_fusable(m, &ne, &nd);
+    MidArgs &a = pl.args;
+    a = MidArgs{};
+    a.ne = ne; a.nd = nd; a.zdim = m->zdim; a.h = m->head_mu.link.chi;
+    pl.prep.count = 0;
+    int64_t off = 0;
+    int blocks = 0, maxw = 0;
+    auto add = [&](const arvae_layer_t &l, MidLayer &ml) {
+        const int k = l.link.chi, n = l.link.clo, kb = (k + 3) / 4 * 4;
+        ml.k = k; ml.n = n; ml.act = l.act; ml.kb = kb;
+        float *mf = prep_ws + off, *mb = mf + ((int64_t)k * n + 3) / 4 * 4, *bias = mb + (int64_t)kb * n;
+        off += mid_layer_floats(l);
+        ml.mf = mf; ml.mb = mb; ml.bias = l.b_off >= 0 ? bias : nullptr;
+        MidPrepJob &j = pl.prep.job[pl.prep.count];
+        j = MidPrepJob{};
+        j.w = params + l.w_off; j.b = l.b_off >= 0 ? params + l.b_off : nullptr;
+        j.mf = mf; j.mb = mb; j.bias = l.b_off >= 0 ? bias : nullptr;
+        j.k = k; j.n = n; j.kb = kb;
+        j.kp = Perm{l.link.hi_perm_c, l.link.hi_perm_hw};
+        j.np = Perm{l.link.lo_perm_c, l.link.lo_perm_hw};
+        int b = (kb * n + 1023) / 1024;                           // ~4 elements per thread
+        if (b > 256) b = 256;
+        blocks += b;
+        pl.prep.blk_end[pl.prep.count++] = blocks;
+        if (k > maxw) maxw = k;
+        if (n > maxw) maxw = n;
+    };
+    for (int i = 0; i < ne; ++i) add(m->enc[m->n_enc - ne + i], a.enc[i]);
+    for (int i = 0; i < nd; ++i) add(m->dec[i], a.dec[i]);
+    {   // the two heads as one [h] -> [2 zdim] layer
+        const int h = m->head_mu.link.chi, z2 = 2 * m->zdim;
+        float *hf = prep_ws + off, *hb = hf + ((int64_t)h * z2 + 3) / 4 * 4, *hbias = hb + ((int64_t)h * z2 + 3) / 4 * 4;
+        a.hf = hf; a.hb = hb; a.hbias = hbias;
+        MidPrepJob &j = pl.prep.job[pl.prep.count];
+        j = MidPrepJob{};
+        j.w = params + m->head_mu.w_off; j.b = m->head_mu.b_off >= 0 ? params + m->head_mu.b_off : nullptr;
+        j.w2 = params + m->head_log_std.w_off; j.b2 = m->head_log_std.b_off >= 0 ? params + m->head_log_std.b_off : nullptr;
+        j.nsplit = m->zdim;
+        j.mf = hf; j.mb = hb; j.bias = hbias;
+        j.k = h; j.n = z2; j.kb = h;
+        j.kp = Perm{0, 0}; j.np = Perm{0, 0};
+        blocks += (h * z2 + 1023) / 1024;
+        pl.prep.blk_end[pl.prep.count++] = blocks;
+    }
+    a.ld = ((maxw + 3) / 4) * 4 + 4;
+    a.w_mu = params + m->head_mu.w_off; a.b_mu = m->head_mu.b_off >= 0 ? params + m->head_mu.b_off : nullptr;
+    a.w_ls = params + m->head_log_std.w_off; a.b_ls = m->head_log_std.b_off >= 0 ? params + m->head_log_std.b_off : nullptr;
+    pl.rows = 4;                 // 8 rows per workgroup measured slower (49 vs 36 us forward at B = 512: the FMA work per workgroup doubles)
+    pl.lds_bytes = (size_t)(2 * pl.rows * a.ld + mid_red(pl.rows) + pl.rows * 32) * sizeof(float);
+}
+
+static void mid_allow_lds() {
+    static bool done = false;
+    if (done) return;
+    const int bytes4 = (2 * 4 * (MID_MAX_W + 4) + mid_red(4) + 4 * 32) * (int)sizeof(float), bytes8 = 120 * 1024;
+    static_assert((2 * 4 * (MID_MAX_W + 4) + mid_red(4) + 4 * 32) * sizeof(float) <= 160 * 1024, "the 4-row block must fit the LDS");
+    (void)hipFuncSetAttribute((const void *)mid_forward_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes4);
+    (void)hipFuncSetAttribute((const void *)mid_backward_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes4);
+    (void)hipFuncSetAttribute((const void *)mid_forward_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes8);
+    (void)hipFuncSetAttribute((const void *)mid_backward_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes8);
+    done = true;
+}
+
+// (1) weight layout prep, (2) the forward block.  enc_y / dec_y: saved outputs of the block's layers.
+int mid_forward(const arvae_image_vae_t *m, int batch, const float *params, float *prep_ws, const float *x0, float *const *enc_y,
+                float *const *dec_y, const float *eps, float *mu, float *log_std, float *sigma, float *z, hipStream_t s) {
+    MidPlan pl;
+    mid_describe(m, params, prep_ws, pl);
+    MidArgs &a = pl.args;
+    for (int i = 0; i < a.ne; ++i) a.enc[i].y = enc_y[i];
+    for (int i = 0; i < a.nd; ++i) a.dec[i].y = dec_y[i];
+    a.batch = batch; a.x0 = x0;
+    a.mu = mu; a.log_std = log_std; a.sigma = sigma; a.z = z; a.eps = eps;
+    if (m->rng_eps) {
+        a.eps_out = const_cast<float *>(eps);
+        a.rng = RngStream{m->rng_seed, m->rng_offset, m->rng_dev_step, m->rng_step};
+    }
+    mid_allow_lds();
+    ARVAE_LAUNCH(mid_prep_kernel, dim3(pl.prep.blk_end[pl.prep.count - 1]), dim3(256), 0, s, pl.prep);
+    if (int rc = check_launch("mid_prep_kernel")) return rc;
+    if (pl.rows == 8) ARVAE_LAUNCH(mid_forward_kernel<8>, dim3((batch + 7) / 8), dim3(MID_T), pl.lds_bytes, s, a);
+    else ARVAE_LAUNCH(mid_forward_kernel<4>, dim3((batch + 3) / 4), dim3(MID_T), pl.lds_bytes, s, a);
+    return check_launch("mid_forward_kernel");
+}
+
+int mid_backward(const arvae_image_vae_t *m, int batch, const float *params, float *prep_ws, float *const *enc_y, float *const *dec_y,
+                 float *const *enc_g, float *const *dec_g, const float *g_out, int g_is_pre, const float *gate0, float *d_x0,
+                 const float *eps, const float *mu, const float *sigma, const float *dz_reg, const float *dz_extra, const float *g_loss,
+                 const float *kl, const float *cap, float beta, float reg_scale, float *d_mu, float *d_ls, hipStream_t s) {
+    MidPlan pl;
+    mid_describe(m, params, prep_ws, pl);
+    MidArgs &a = pl.args;
+    for (int i = 0; i < a.ne; ++i) { a.enc[i].y = enc_y[i]; a.enc[i].gpre = enc_g[i]; }
+    for (int i = 0; i < a.nd; ++i) { a.dec[i].y = dec_y[i]; a.dec[i].gpre = dec_g[i]; }
+    a.batch = batch;
+    a.g_out = g_out; a.g_is_pre = g_is_pre; a.gate0 = gate0; a.d_x0 = d_x0;
+    a.eps = eps; a.mu = const_cast<float *>(mu); a.sigma = const_cast<float *>(sigma);
+    a.dz_reg = dz_reg; a.dz_extra = dz_extra; a.g_loss = g_loss; a.kl = kl; a.cap = cap;
+    a.beta = beta; a.inv_batch = 1.f / (float)batch; a.reg_scale = reg_scale;
+    a.d_mu = d_mu; a.d_ls = d_ls;
+    mid_allow_lds();
+    if (pl.rows == 8) ARVAE_LAUNCH(mid_backward_kernel<8>, dim3((batch + 7) / 8), dim3(MID_T), pl.lds_bytes, s, a);
+    else ARVAE_LAUNCH(mid_backward_kernel<4>, dim3((batch + 3) / 4), dim3(MID_T), pl.lds_bytes, s, a);
+    return check_launch("mid_backward_kernel");
+}
+
+}  // namespace arvae
+
+#ifdef MID_STAMPS
+extern "C" int arvae_debug_mid_stamps(unsigned long long *out, int count) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(arvae::g_mid_stamps), sizeof(unsigned long long) * count);
+}
+#endif

@@ -36,6 +36,17 @@ int heads_latent_bwd(const arvae_layer_t *hm, const arvae_layer_t *hl, int batch
                      const float *eps, const float *g_loss, const float *kl, const float *cap, float beta, float reg_scale,
                      const float *gate, float *d_mu, float *d_ls, float *d_hidden, hipStream_t s);
 
+// the latent block (trailing Linear layers of the encoder, heads + reparameterisation, leading Linear layers of the
+// decoder) as one launch per pass (midblock.hip)
+bool mid_fusable(const arvae_image_vae_t *m, int *ne_out, int *nd_out);
+int64_t mid_prep_floats(const arvae_image_vae_t *m);
+int mid_forward(const arvae_image_vae_t *m, int batch, const float *params, float *prep_ws, const float *x0, float *const *enc_y,
+                float *const *dec_y, const float *eps, float *mu, float *log_std, float *sigma, float *z, hipStream_t s);
+int mid_backward(const arvae_image_vae_t *m, int batch, const float *params, float *prep_ws, float *const *enc_y, float *const *dec_y,
+                 float *const *enc_g, float *const *dec_g, const float *g_out, int g_is_pre, const float *gate0, float *d_x0,
+                 const float *eps, const float *mu, const float *sigma, const float *dz_reg, const float *dz_extra, const float *g_loss,
+                 const float *kl, const float *cap, float beta, float reg_scale, float *d_mu, float *d_ls, hipStream_t s);
+
 // loss-term pieces (losses.hip)
 int recon_partials(const float *logits, const float *x, int64_t count, int64_t batch, int32_t dist, float *ws,
                    float *dlogits, hipStream_t s, int *nb_out);
@@ -103,7 +114,7 @@ struct Layout {
     // 32-channel conv layers: the weights split into bf16 terms in per-lane order, rebuilt at the start of every forward
     // pass by ONE launch and used by the layer's forward and data-gradient kernels (-1: not such a layer)
     int64_t enc_wprep[ARVAE_MAX_LAYERS], dec_wprep[ARVAE_MAX_LAYERS];
-    int64_t log_std, dlogits, dz_reg, d_mu, d_ls, g_a, g_b, slab, link_ws, rec_ws, reg_ws, rec_out, kld_out, reg_out, total;
+    int64_t log_std, dlogits, dz_reg, d_mu, d_ls, g_a, g_b, slab, link_ws, mid_prep, rec_ws, reg_ws, rec_out, kld_out, reg_out, total;
     int64_t slab_floats;
 };
 
@@ -170,6 +181,7 @@ static int make_layout(const arvae_image_vae_t *m, int64_t n, int64_t n_cols, La
     L.slab_floats = slab;
     L.slab = take(slab);
     L.link_ws = take(lws);               // scratch of one arvae_link_down / _up call at a time (stream-ordered)
+    L.mid_prep = take(mid_prep_floats(m));   // the latent block's matrices in the layout its kernels stream (midblock.hip)
     L.rec_ws = take(arvae_recon_ws_floats(out_elems(m->dec[m->n_dec - 1], n)));
     L.reg_ws = take(arvae_reg_loss_ws_floats(n, m->n_reg > 0 ? m->n_reg : 1));
     L.rec_out = take(4);
@@ -349,8 +361,10 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
         if (int rc = conv32_weight_prep(wts, preps, np, st)) return rc;
     }
     // encoder
+    int mid_ne = 0, mid_nd = 0;
+    const bool mid = mid_fusable(m, &mid_ne, &mid_nd);
     const float *h = x;
-    for (int i = 0; i < m->n_enc; ++i) {
+    for (int i = 0; i < m->n_enc - mid_ne; ++i) {
         const uint8_t *mask = (masks != nullptr && m->enc[i].dropout) ? masks[mi] : nullptr;
         mi += m->enc[i].dropout != 0;
         uint16_t *bits = L.enc_bits[i] >= 0 ? reinterpret_cast<uint16_t *>(ws + L.enc_bits[i]) : nullptr;
@@ -360,7 +374,13 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
         h = ws + L.enc_out[i];
     }
     const int64_t bz = (int64_t)batch * m->zdim;
-    if (heads_fusable(&m->head_mu, &m->head_log_std, m->zdim)) {
+    if (mid) {                                               // Linear stack + heads + reparameterisation + Linear stack: one launch
+        float *enc_y[ARVAE_MAX_LAYERS], *dec_y[ARVAE_MAX_LAYERS];
+        for (int i = 0; i < mid_ne; ++i) enc_y[i] = ws + L.enc_out[m->n_enc - mid_ne + i];
+        for (int i = 0; i < mid_nd; ++i) dec_y[i] = ws + L.dec_out[i];
+        if (int rc = mid_forward(m, batch, params, ws + L.mid_prep, h, enc_y, dec_y, eps, mu, ws + L.log_std, sigma, z, st)) return rc;
+        h = dec_y[mid_nd - 1];
+    } else if (heads_fusable(&m->head_mu, &m->head_log_std, m->zdim)) {
         if (int rc = heads_latent_fwd(&m->head_mu, &m->head_log_std, batch, m->zdim, params, h, eps, mu, ws + L.log_std,
                                       sigma, z, st, m))
             return rc;
@@ -374,12 +394,12 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
         if (int rc = arvae_latent_fwd(mu, ws + L.log_std, eps, bz, sigma, z, stream)) return rc;
     }
     // decoder
-    h = z;
+    if (!mid) h = z;
     int nb = 0;
     const arvae_layer_t &last = m->dec[m->n_dec - 1];
     const bool recon_fused = last.is_up && last.act == ARVAE_ACT_NONE && last.dropout == 0 && conv_c1_fits(&last.link) &&
                              arvae_recon_ws_floats(0) >= 2 * 1024;
-    for (int i = 0; i < m->n_dec; ++i) {
+    for (int i = mid ? mid_nd : 0; i < m->n_dec; ++i) {
         const uint8_t *mask = (masks != nullptr && m->dec[i].dropout) ? masks[mi] : nullptr;
         mi += m->dec[i].dropout != 0;
         float *out = (i + 1 < m->n_dec) ? ws + L.dec_out[i] : logits;
@@ -490,8 +510,10 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
             if (int rc = arvae_scale_by_scalar(g_loss, ws + L.dlogits, pix, cur, stream)) return rc;
         }
     }
-    // decoder, last layer first
-    for (int i = m->n_dec - 1; i >= 0; --i) {
+    int mid_ne = 0, mid_nd = 0;
+    const bool mid = mid_fusable(m, &mid_ne, &mid_nd);
+    // decoder, last layer first (down to the latent block when that runs as one launch)
+    for (int i = m->n_dec - 1; i >= (mid ? mid_nd : 0); --i) {
         const float *in = i > 0 ? ws + L.dec_out[i - 1] : z;
         const float *out = (i + 1 < m->n_dec) ? ws + L.dec_out[i] : logits;
         const float *gate = i > 0 ? relu_gate(m->dec[i - 1], dec_mask[i - 1], in) : nullptr;
@@ -520,7 +542,41 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
     }
     const float *head_gate = relu_gate(m->enc[m->n_enc - 1], enc_mask[m->n_enc - 1], hidden);
     float *d_hidden = grad_dst(L.enc_keep[m->n_enc - 1], nullptr);
-    if (heads_fusable(&m->head_mu, &m->head_log_std, m->zdim)) {
+    int enc_from = m->n_enc - 1;                             // first encoder layer the per-layer loop below still has to visit
+    if (mid) {
+        // Linear stack of the decoder <- z <- heads <- Linear stack of the encoder: one launch (midblock.hip); it leaves each
+        // layer's pre-activation gradient in that layer's keep buffer for the grouped weight-gradient launch
+        const int e0 = m->n_enc - mid_ne;                    // index of the block's first encoder layer; e0 - 1 is a conv layer
+        float *enc_y[ARVAE_MAX_LAYERS], *dec_y[ARVAE_MAX_LAYERS], *enc_g[ARVAE_MAX_LAYERS], *dec_g[ARVAE_MAX_LAYERS];
+        for (int i = 0; i < mid_ne; ++i) { enc_y[i] = ws + L.enc_out[e0 + i]; enc_g[i] = ws + L.enc_keep[e0 + i]; }
+        for (int i = 0; i < mid_nd; ++i) { dec_y[i] = ws + L.dec_out[i]; dec_g[i] = ws + L.dec_keep[i]; }
+        const float *x0 = ws + L.enc_out[e0 - 1];
+        const float *gate0 = relu_gate(m->enc[e0 - 1], enc_mask[e0 - 1], x0);
+        float *d_x0 = ws + L.enc_keep[e0 - 1];
+        const float *g_last = cur;                           // gradient arriving at the last Linear layer of the decoder
+        if (int rc = mid_backward(m, batch, params, ws + L.mid_prep, enc_y, dec_y, enc_g, dec_g, g_last, pre ? 1 : 0, gate0, d_x0, eps,
+                                  mu, sigma, dz_reg, dz_extra, g_loss, ws + L.kld_out + 1, capacity, m->beta, reg_scale, ws + L.d_mu,
+                                  ws + L.d_ls, st))
+            return rc;
+        // weight gradients of the block's layers: (pre-activation gradient, layer input) pairs for the grouped launch
+        auto queue = [&](const arvae_layer_t &l, const float *g, const float *in) -> int {
+            arvae_link_t lk = l.link;
+            lk.n = batch;
+            float *dw = grads + l.w_off, *db = l.b_off >= 0 ? grads + l.b_off : nullptr;
+            const arvae_operand_t gop = plain(g), xin = plain(in);
+            if (dense_wgrad_defer(&defer, &lk, make_operand(&gop), in, dw, db)) return ARVAE_OK;
+            return arvae_link_wgrad(&lk, &gop, &xin, dw, db, db ? 1 : 0, slab, stream);
+        };
+        for (int i = mid_nd - 1; i >= 0; --i)
+            if (int rc = queue(m->dec[i], (i == mid_nd - 1 && pre) ? g_last : dec_g[i], i > 0 ? dec_y[i - 1] : z)) return rc;
+        if (int rc = queue(m->head_mu, ws + L.d_mu, hidden)) return rc;
+        if (int rc = queue(m->head_log_std, ws + L.d_ls, hidden)) return rc;
+        for (int i = mid_ne - 1; i >= 0; --i)
+            if (int rc = queue(m->enc[e0 + i], enc_g[i], i > 0 ? enc_y[i - 1] : x0)) return rc;
+        cur = d_x0;
+        pre = gate0 != nullptr;
+        enc_from = e0 - 1;
+    } else if (heads_fusable(&m->head_mu, &m->head_log_std, m->zdim)) {
         if (int rc = heads_latent_bwd(&m->head_mu, &m->head_log_std, batch, m->zdim, params, cur, dz_reg, dz_extra, mu, sigma,
                                       eps, g_loss, ws + L.kld_out + 1, capacity, m->beta, reg_scale, head_gate, ws + L.d_mu,
                                       ws + L.d_ls, d_hidden, st))
@@ -560,7 +616,7 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
         pre = head_gate != nullptr;
     }
     // encoder, last layer first; the image itself needs no gradient
-    for (int i = m->n_enc - 1; i >= 0; --i) {
+    for (int i = enc_from; i >= 0; --i) {
         const float *in = i > 0 ? ws + L.enc_out[i - 1] : x;
         const float *gate = i > 0 ? relu_gate(m->enc[i - 1], enc_mask[i - 1], in) : nullptr;
         float *dst = i > 0 ? grad_dst(L.enc_keep[i - 1], cur) : nullptr;

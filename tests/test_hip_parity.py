@@ -1234,3 +1234,31 @@ def test_debug_checks_raise_like_the_reference(dev, monkeypatch):
         model(score, score, train=False)
     monkeypatch.setenv('ARVAE_CHECK', '0')
     model(score, score, train=False)                         # checks off: the NaN propagates silently, as without the scan
+
+
+def test_latent_block_experiment_matches_the_per_layer_path(dev):
+    """ARVAE_MIDBLOCK=1 (csrc/midblock.hip, off by default: measured no faster): the Linear stack + heads + reparameterisation
+    as one launch per pass must give the per-layer path's losses and gradients (dSprites B = 37 and Morpho-MNIST B = 8)."""
+    code = (
+        "import sys, json; sys.path.insert(0, %r)\n"
+        "import numpy as np, torch\n"
+        "from tests.test_hip_parity import run_hip_image_step\n"
+        "from arvae_amd import synthetic as syn\n"
+        "from oracle import image_vae as o_vae\n"
+        "out = {}\n"
+        "for kind, b, gain in (('dsprites', 37, 1.6), ('mnist', 8, 0.7)):\n"
+        "    state = syn.synth_state(o_vae.SHAPES[kind], 9, gain)\n"
+        "    x, lab = (syn.dsprites_batch if kind == 'dsprites' else syn.mnist_batch)(b, seed=5)\n"
+        "    eps = syn.normal_noise((b, o_vae.Z_DIM[kind]), seed=6)\n"
+        "    got = run_hip_image_step(torch.device('cuda:0'), kind, state, x, lab, eps, 4.0, 0.0, 'bernoulli', None, train=(kind == 'dsprites'))\n"
+        "    out[kind] = {'loss': got['loss'], 'gn': {k: float(np.linalg.norm(v)) for k, v in got['grads'].items()}}\n"
+        "print(json.dumps(out))\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    res = {}
+    for flag in ('0', '1'):
+        r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=dict(os.environ, ARVAE_MIDBLOCK=flag))
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[flag] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    for kind in ('dsprites', 'mnist'):
+        close(res['1'][kind]['loss'], res['0'][kind]['loss'], rtol=1e-6)
+        for k, v in res['0'][kind]['gn'].items():
+            close(res['1'][kind]['gn'][k], v, rtol=1e-4, atol=1e-9)
