@@ -14,7 +14,7 @@ import sys
 def label(kernel_name):
     """rocprofv3 kernel name -> the label bench.py / arvae_profile_end use for that kernel family."""
     n = kernel_name.replace('void ', '').split('(')[0].replace('arvae::', '')
-    m = re.match(r'(down32|up32|wgrad32)[xbs]?_kernel<(\d+),', n)       # fp32 / split-bf16 / small-tile variants share a label
+    m = re.match(r'(down32|up32|wgrad32)[xbsr]?_kernel<(\d+),', n)       # fp32 / split-bf16 / small-tile variants share a label
     if m:
         return f'{m.group(1)}_kernel<{m.group(2)}>'
     if n.startswith('up_c1_kernel'):
@@ -37,7 +37,7 @@ def main():
     fetch, write = per_kernel(sys.argv[1], 'FETCH_SIZE'), per_kernel(sys.argv[2], 'WRITE_SIZE')
     out = {
         'source': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate passes) of '
-                  '`python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline`, dSprites B=512, MI355X',
+                  '`python3 bench.py --steps 3 --warmup 2 --min-seconds 0 --no-cpu-baseline --no-secondary`, dSprites B=512, MI355X',
         'correction': 'hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: on gfx950 FETCH_SIZE counts half the bytes of wide '
                       '(16 B/lane) coalesced reads (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact',
         'kernels': {},
