@@ -957,6 +957,7 @@ __global__ __launch_bounds__(256, 1) void up32x_kernel(const float *__restrict__
     const int half = lane >> 5, rc = lane & 31;
     const int py = wave >> 1, px = wave & 1;
     const int ky0 = 1 - py, kx0 = 1 - px;
+    STAMP(0);
 
     PL pl;                                                       // first tile's loads fly while the weights are staged
     pl.init(lo, n_img);
@@ -1002,6 +1003,7 @@ __global__ __launch_bounds__(256, 1) void up32x_kernel(const float *__restrict__
                 }
     }
 
+    STAMP(1);
     // patch origin is lo (r0-1, -1); tap (ty,tx) of class (py,px) reads lo (r + py - ty, c + px - tx)
     int aoff[MT];                                                 // dwords into a plane
     unsigned orel[MT];                                            // output byte offset of this lane's pixel in M-tile mt
@@ -1032,35 +1034,47 @@ __global__ __launch_bounds__(256, 1) void up32x_kernel(const float *__restrict__
 #pragma unroll
     for (int i = 0; i < 4 * MT; ++i) gq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     unsigned prev_base = OOB;
+    STAMP(2);
+    int stamp_t = 0;
+    (void)stamp_t;
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        STAMP(3 + 6 * stamp_t);
         tile_origin<LO, PX>(tile, img0, r0);
         __syncthreads();
+        STAMP(4 + 6 * stamp_t);
         pl.commit_split3(ldsw);
         __syncthreads();
+        STAMP(5 + 6 * stamp_t);
         {
             int ni, nr;
             tile_origin<LO, PX>(tile + gridDim.x, ni, nr);
             pl.set_tile(ni, nr, tile + gridDim.x < n_tiles);
         }
+        STAMP(6 + 6 * stamp_t);
         const unsigned obase = (unsigned)(((img0 * HI + 2 * r0) * HI) * PIXB);
         f32x16 acc[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+        // operands of step 0; every later step's 3 * MT reads are issued one or two at a time behind the MFMA triples of the
+        // step before (two operand sets): a burst of LDS reads in front of a step costs the matrix pipe ~10 idle cycles per
+        // read plus the LDS round trip (tools/probes/mfma_barrier.hip)
+        bf16x8 a[2][MT][3];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) a[0][mt][t] = lds_bf16x8(ldsw + t * PLANE + aoff[mt]);
         static_for<0, 8>([&](auto sc) __attribute__((always_inline)) {
             constexpr int step = decltype(sc)::value, ty = step >> 2, tx = (step >> 1) & 1, c = step & 1;
-            constexpr int toff = -(ty * PC + tx) * PSB + c * 8;
-            bf16x8 a[MT][3];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int t = 0; t < 3; ++t) a[mt][t] = lds_bf16x8(ldsw + t * PLANE + aoff[mt] + toff);
+            constexpr int cur = step & 1, nxt = cur ^ 1;
+            constexpr int nstep = step + 1, nty = nstep >> 2, ntx = (nstep >> 1) & 1, nc = nstep & 1;
+            constexpr int ntoff = -(nty * PC + ntx) * PSB + nc * 8;
             pl.template issue_step<8, step>();
             __builtin_amdgcn_sched_barrier(0);
             static_for<0, 2 * MT>([&](auto mc) __attribute__((always_inline)) {
-                constexpr int grp = decltype(mc)::value / MT, mt = decltype(mc)::value % MT;
+                constexpr int sub = decltype(mc)::value, grp = sub / MT, mt = sub % MT;
                 // epilogue slots: 16 * MT per tile (one per group of three MFMAs); wave w owns every fourth
                 constexpr int slot = (step * 2 + grp) * MT + mt;
                 if (wave == (slot & 3)) {
@@ -1074,20 +1088,30 @@ __global__ __launch_bounds__(256, 1) void up32x_kernel(const float *__restrict__
                     if (MODE == EP_GATE_B && eg == 3) gqb[em] = buf_load_u16(rs_bits, bits_off(obase + orel[em], half));
                 }
                 if constexpr (grp == 0) {                        // the three smallest partial products first
-                    MFMA_B(acc[mt], w3[ty][tx][c][2], a[mt][0]);
-                    MFMA_B(acc[mt], w3[ty][tx][c][0], a[mt][2]);
-                    MFMA_B(acc[mt], w3[ty][tx][c][1], a[mt][1]);
+                    MFMA_B(acc[mt], w3[ty][tx][c][2], a[cur][mt][0]);
+                    MFMA_B(acc[mt], w3[ty][tx][c][0], a[cur][mt][2]);
+                    MFMA_B(acc[mt], w3[ty][tx][c][1], a[cur][mt][1]);
                 } else {
-                    MFMA_B(acc[mt], w3[ty][tx][c][1], a[mt][0]);
-                    MFMA_B(acc[mt], w3[ty][tx][c][0], a[mt][1]);
-                    MFMA_B(acc[mt], w3[ty][tx][c][0], a[mt][0]);
+                    MFMA_B(acc[mt], w3[ty][tx][c][1], a[cur][mt][0]);
+                    MFMA_B(acc[mt], w3[ty][tx][c][0], a[cur][mt][1]);
+                    MFMA_B(acc[mt], w3[ty][tx][c][0], a[cur][mt][0]);
+                }
+                if constexpr (nstep < 8) {                       // this sub-step's share of the next step's operand reads
+                    constexpr int r_lo = sub * (3 * MT) / (2 * MT), r_hi = (sub + 1) * (3 * MT) / (2 * MT);
+                    static_for<r_lo, r_hi>([&](auto rc_) __attribute__((always_inline)) {
+                        constexpr int ri = decltype(rc_)::value, rmt = ri / 3, rt = ri % 3;
+                        a[nxt][rmt][rt] = lds_bf16x8(ldsw + rt * PLANE + aoff[rmt] + ntoff);
+                    });
                 }
             });
             __builtin_amdgcn_sched_barrier(0);
         });
+        STAMP(7 + 6 * stamp_t);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) prev[mt] = acc[mt];
         prev_base = obase;
+        STAMP(8 + 6 * stamp_t);
+        ++stamp_t;
     }
     // the last tile's epilogue has nothing to hide behind
 #pragma unroll
@@ -1098,6 +1122,8 @@ __global__ __launch_bounds__(256, 1) void up32x_kernel(const float *__restrict__
         for (int g = 0; g < 4; ++g) bits |= store_group<MODE>(prev[mt], g, b4[g], gq[mt * 4 + g], gqb[mt], rs_out, poff);
         if (MODE == EP_RELU && want_bits) buf_store_u16(bits, rs_bits, prev_base == OOB ? OOB : bits_off(poff, half));
     }
+    STAMP_WAIT();
+    STAMP(63);
 }
 
 // ================================================================================================
