@@ -69,7 +69,7 @@ class GraphedStep:
         ops.rng_advance_device_step()                            # recorded: every replay moves on in the Philox stream
         self.trainer.zero_grad()
         loss, acc = self.trainer.loss_and_acc_for_batch(self.static, 0, 1, True)
-        loss.backward()
+        self.trainer.backward(loss)
         return loss.detach(), None if acc is None else acc.detach()
 
     def accepts(self, batch):

@@ -119,7 +119,7 @@ class Trainer(ABC):
                 self.zero_grad()
                 loss, accuracy = self.loss_and_acc_for_batch(batch_data, epoch_num, batch_num, train=train)
                 if train:
-                    loss.backward()
+                    self.backward(loss)
                     self.step()
             # the accumulators start from COPIES: under graph replay `loss` / `accuracy` are the captured step's static
             # output buffers, which the next replay overwrites
@@ -133,6 +133,14 @@ class Trainer(ABC):
         mean_loss = float(loss_sum) / n if loss_sum is not None else 0.0       # single sync per epoch
         mean_acc = float(acc_sum) / n if acc_sum is not None else 0.0
         return mean_loss, mean_acc
+
+    def backward(self, loss):
+        """loss.backward() (utils/trainer.py:140) with a cached unit seed gradient: a bare `loss.backward()` makes torch fill a
+        ones tensor on the device first, one more launch per step."""
+        seed = getattr(self, '_seed_grad', None)
+        if seed is None or seed.shape != loss.shape or seed.device != loss.device or seed.dtype != loss.dtype:
+            seed = self._seed_grad = torch.ones_like(loss)
+        torch.autograd.backward(loss, grad_tensors=seed)
 
     def cuda(self):
         self.model.cuda()

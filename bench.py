@@ -300,7 +300,7 @@ def build_side_workload(kind, device, batch, rank=0, use_dp=False, graphs=False)
     def eager(i):
         trainer.zero_grad()
         loss, _ = trainer.loss_and_acc_for_batch(data, 0, i, True)
-        loss.backward()
+        trainer.backward(loss)
         trainer.step()
         return loss
 
@@ -459,7 +459,7 @@ def run_dsprites(device, args, fence, rank, world, use_dp):
     def step(i):
         trainer.zero_grad()
         loss, _ = trainer.loss_and_acc_for_batch((x, lab), 0, i, True)
-        loss.backward()
+        trainer.backward(loss)                        # = loss.backward() with a cached seed gradient (Trainer.backward)
         trainer.step()
         return loss
 
