@@ -90,6 +90,20 @@ struct Operand {
         }
         return r;
     }
+    // elements i and i + 1 (i even, the arrays 8-byte aligned) with one load per array
+    __device__ __forceinline__ float2 at2(int64_t i) const {
+        float2 r = *reinterpret_cast<const float2 *>(v + i);
+        if (y != nullptr) {
+            float2 yy = *reinterpret_cast<const float2 *>(y + i);
+            if (mask != nullptr) {
+                const uchar2 m = *reinterpret_cast<const uchar2 *>(mask + i);
+                r.x *= 2.f * (float)m.x; r.y *= 2.f * (float)m.y;
+                yy.x *= 0.5f; yy.y *= 0.5f;
+            }
+            r.x *= act_bwd_from_out(yy.x, act); r.y *= act_bwd_from_out(yy.y, act);
+        }
+        return r;
+    }
 };
 static inline Operand make_operand(const arvae_operand_t *o) { return Operand{o->v, o->y, o->mask, o->act}; }
 

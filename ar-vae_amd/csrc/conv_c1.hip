@@ -129,6 +129,93 @@ __global__ __launch_bounds__(256) void down_c1_kernel(Operand img, const float *
 }
 
 // ================================================================================================
+// down_c1, streaming form (default).  The kernel writes 128 KB per image and reads 16 KB: what it must do is keep the
+// store path busy (tools/probes/store_probe.hip: a bare 67 MB fill takes 13.7 us on this chip; 16-byte pieces at a 128-byte
+// stride, the MFMA accumulator layout stored as it is, 16 us; eight dword image loads per lane per row in the same
+// memory queue as the stores, 19-21 us).  So:
+//   * a WAVE owns one output row (32 pixels x 32 channels = 4 KB) at a time and shares nothing: no barrier;
+//   * the reduction index is ordered k = (ky, kx) with ky = 2 (s >> 2) + half, kx = s & 3, so that a lane's eight B values
+//     are the four consecutive pixels 2 rc - 1 .. 2 rc + 2 of two image rows: ONE aligned float2 load per image row (two per
+//     output row instead of eight) and the two neighbours from the adjacent lanes by ds_bpermute;
+//   * the finished row goes through a padded per-wave LDS tile and leaves as four 1 KB contiguous stores.
+// GATE: 0 none, 1 sign bits, 2 saved float activation
+template <int GATE>
+__global__ __launch_bounds__(256) void down_c1s_kernel(Operand img, const float *__restrict__ wt, Ep1 ep, int n_rows) {
+    __shared__ __attribute__((aligned(16))) float stage[4][LO1 * PS1];
+    const int lane = threadIdx.x & 63, half = lane >> 5, rc = lane & 31;
+    float *tile = stage[threadIdx.x >> 6];
+    float w8[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) w8[s] = wt[rc * 16 + 4 * (2 * (s >> 2) + half) + (s & 3)];
+    float4 b4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        b4[g] = ep.bias != nullptr ? *reinterpret_cast<const float4 *>(ep.bias + 8 * g + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float gs = img.scale != nullptr ? img.scale[0] : 1.f;
+    const int wave0 = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+    // image rows 2 r - 1 + half and 2 r + 1 + half, pixels 2 rc and 2 rc + 1
+    auto fetch = [&](int row, float2 (&v)[2]) __attribute__((always_inline)) {
+        const int n = row >> 5, r = row & 31;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int gy = 2 * r - 1 + 2 * q + half;
+            const bool ok = row < n_rows && (unsigned)gy < (unsigned)HI1;
+            const int64_t at = ok ? ((int64_t)n * HI1 + gy) * HI1 + 2 * rc : 0;        // unconditional load, clamped index
+            const float2 xy = img.at2(at);
+            v[q] = make_float2(ok ? gs * xy.x : 0.f, ok ? gs * xy.y : 0.f);
+        }
+    };
+    float2 v[2], vn[2];
+    fetch(wave0, v);
+    for (int row = wave0; row < n_rows; row += n_waves) {
+        fetch(row + n_waves, vn);                               // next row's pixels fly during this row's MFMAs and stores
+        const int pix = row * LO1 + rc;
+        float4 gv[4];
+        unsigned gb = 0xffffu;
+        if (GATE == 1) gb = ep.gate_bits[pix * 2 + half];
+        else if (GATE == 2) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gv[g] = *reinterpret_cast<const float4 *>(ep.gate + (int64_t)pix * CC + 8 * g + 4 * half);
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float left = __shfl_up(v[q].y, 1, 32), right = __shfl_down(v[q].x, 1, 32);
+            const float a4[4] = {rc == 0 ? 0.f : left, v[q].x, v[q].y, rc == 31 ? 0.f : right};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w8[4 * q + t], a4[t], acc, 0, 0, 0);
+        }
+        unsigned bits = 0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float o[4] = {acc[4 * g] + b4[g].x, acc[4 * g + 1] + b4[g].y, acc[4 * g + 2] + b4[g].z, acc[4 * g + 3] + b4[g].w};
+            const float gf[4] = {gv[g].x, gv[g].y, gv[g].z, gv[g].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (ep.relu) o[j] = fmaxf(o[j], 0.f);
+                if (GATE == 1) o[j] = ((gb >> (4 * g + j)) & 1u) ? o[j] : 0.f;
+                else if (GATE == 2) o[j] = gf[j] > 0.f ? o[j] : 0.f;
+                bits |= (o[j] > 0.f ? 1u : 0u) << (4 * g + j);
+            }
+            *reinterpret_cast<float4 *>(tile + rc * PS1 + 8 * g + 4 * half) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        if (ep.bits_out != nullptr) ep.bits_out[pix * 2 + half] = (uint16_t)bits;
+        // the wave's LDS operations execute in order: no barrier, only keep the compiler from moving them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float4 *dst = reinterpret_cast<float4 *>(ep.out + (int64_t)row * LO1 * CC);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            dst[64 * i + lane] = *reinterpret_cast<const float4 *>(tile + (8 * i + (lane >> 3)) * PS1 + 4 * (lane & 7));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        v[0] = vn[0]; v[1] = vn[1];
+    }
+}
+
+// ================================================================================================
 // up_c1: img[n,hy,hx] = bias + sum over the 2x2 valid taps and 32 channels of lo * wt, in two steps:
 //   T[pos][tap] = sum_c lo[pos][c] * wt[c][tap]        a dense [positions x 32] x [32 x 16] product on the 16x16x4
 //                                                        MFMA (all 16 columns useful, operands straight from HBM in
@@ -355,6 +442,17 @@ int conv_c1_down(const arvae_link_t *l, const Operand &img, const float *wt, con
                  const float *gate, const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s) {
     const int tiles = l->n * (LO1 / TR1);
     Ep1 ep{bias, gate, gate_bits, bits_out, out, relu};
+    static const bool tiled = getenv("ARVAE_C1_DOWN_TILED") != nullptr;                                  // diagnostic: the LDS-staged kernel
+    if (!tiled) {
+        static const int waves_per_cu = getenv("ARVAE_C1_DOWN_WAVES") ? atoi(getenv("ARVAE_C1_DOWN_WAVES")) : 16;
+        const int n_rows = l->n * LO1;
+        int grid = 256 * waves_per_cu / 4;                       // workgroups of four independent waves
+        if (grid > (n_rows + 3) / 4) grid = (n_rows + 3) / 4;
+        if (gate_bits != nullptr) ARVAE_LAUNCH(down_c1s_kernel<1>, dim3(grid), dim3(256), 0, s, img, wt, ep, n_rows);
+        else if (gate != nullptr) ARVAE_LAUNCH(down_c1s_kernel<2>, dim3(grid), dim3(256), 0, s, img, wt, ep, n_rows);
+        else ARVAE_LAUNCH(down_c1s_kernel<0>, dim3(grid), dim3(256), 0, s, img, wt, ep, n_rows);
+        return check_launch("down_c1_kernel");
+    }
     static const int cap = getenv("ARVAE_C1_DOWN_GRID") ? atoi(getenv("ARVAE_C1_DOWN_GRID")) : 512;      // 2 per CU, 4 tiles each: measured best of 256..4096
     ARVAE_LAUNCH(down_c1_kernel, dim3(tiles < cap ? tiles : cap), dim3(256), 0, s, img, wt, ep, tiles);
     return check_launch("down_c1_kernel");

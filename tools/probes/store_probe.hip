@@ -26,6 +26,42 @@ __global__ __launch_bounds__(256) void st_line(float4 *out, int64_t npix) {
         for (int g = 0; g < 4; ++g) out[(p0 + 8 * g + (lane >> 3)) * 8 + (lane & 7)] = make_float4(1.f, 2.f, 3.f, (float)g);
     }
 }
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// the piece pattern with the down_c1 work added level by level: LV 1 = + 8 fp32 MFMAs per 32-pixel row, 2 = + the 8 image
+// loads per lane per row (stride-2 4x4 patch reads of a 64x64 fp32 image), 3 = + the uint16 sign-bit store per lane
+template <int LV>
+__global__ __launch_bounds__(256) void st_work(float4 *out, const float *img, uint16_t *bits, int n_rows) {
+    const int lane = threadIdx.x & 63, half = lane >> 5, rc = lane & 31;
+    const int wave0 = (blockIdx.x * 256 + threadIdx.x) >> 6, nw = (gridDim.x * 256) >> 6;
+    float w8[8];
+    for (int s = 0; s < 8; ++s) w8[s] = 0.01f * (rc + s + half);
+    for (int row = wave0; row < n_rows; row += nw) {
+        const int n = row >> 5, r = row & 31;
+        float a[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (LV >= 2) {
+                const int gy = 2 * r - 1 + (s >> 1), gx = 2 * rc - 1 + 2 * (s & 1) + half;
+                const bool ok = (unsigned)gy < 64u && (unsigned)gx < 64u;
+                const float v = img[ok ? (n * 64 + gy) * 64 + gx : 0];
+                a[s] = ok ? v : 0.f;
+            } else a[s] = (float)(row + s);
+        }
+        f32x16 acc;
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w8[s], a[s], acc, 0, 0, 0);
+        const int64_t pix = (int64_t)row * 32 + rc;
+        unsigned b = 0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float v[4];
+            for (int j = 0; j < 4; ++j) { v[j] = fmaxf(acc[4 * g + j], 0.f); b |= (v[j] > 0.f ? 1u : 0u) << (4 * g + j); }
+            out[pix * 8 + 2 * g + half] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        if (LV >= 3) bits[pix * 2 + half] = (uint16_t)b;
+    }
+}
 int main() {
     const int64_t bytes = 67108864, n16 = bytes / 16, npix = bytes / 128;
     float4 *buf; hipMalloc(&buf, bytes);
@@ -43,6 +79,23 @@ int main() {
                 if (rep > 0 && ms < best) best = ms;
             }
             printf("grid %5d %-8s %7.1f us  %5.2f TB/s\n", grid, k == 0 ? "contig" : k == 1 ? "piece" : "line", best * 1e3, bytes / best / 1e9);
+        }
+    }
+    float *img; hipMalloc(&img, 512 * 4096 * 4); hipMemset(img, 0, 512 * 4096 * 4);
+    uint16_t *bits; hipMalloc(&bits, npix * 4);
+    for (int grid : {512, 2048, 4096}) {
+        for (int lv = 1; lv <= 3; ++lv) {
+            float best = 1e9f;
+            for (int rep = 0; rep < 6; ++rep) {
+                hipEventRecord(e0);
+                if (lv == 1) hipLaunchKernelGGL(st_work<1>, dim3(grid), dim3(256), 0, 0, buf, img, bits, (int)(npix / 32));
+                else if (lv == 2) hipLaunchKernelGGL(st_work<2>, dim3(grid), dim3(256), 0, 0, buf, img, bits, (int)(npix / 32));
+                else hipLaunchKernelGGL(st_work<3>, dim3(grid), dim3(256), 0, 0, buf, img, bits, (int)(npix / 32));
+                hipEventRecord(e1); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                if (rep > 0 && ms < best) best = ms;
+            }
+            printf("grid %5d work level %d %7.1f us  %5.2f TB/s\n", grid, lv, best * 1e3, bytes / best / 1e9);
         }
     }
     return 0;
