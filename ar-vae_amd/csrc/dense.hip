@@ -51,30 +51,54 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_fwd_kernel(DenseArgs p) {
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     const int chunks = (p.n_in + 7) / 8;
 
-    for (int q = wave; q < chunks; q += NW) {
-        const int k0 = q * 8 + half * 4;
-        float a[4], b[4];
-        if (vec && k0 + 3 < p.n_in) {
-            const float4 av = *reinterpret_cast<const float4 *>(xrow + k0);
-            a[0] = av.x; a[1] = av.y; a[2] = av.z; a[3] = av.w;
-            if (p.in_perm.c_count == 0) {
-                const float4 bv = *reinterpret_cast<const float4 *>(wrow + k0);
-                b[0] = bv.x; b[1] = bv.y; b[2] = bv.z; b[3] = bv.w;
-            } else {
+    // FU reduction chunks per wave and round, every load of a round issued before the first MFMA (unconditional loads from
+    // clamped addresses, zeroed by selects): a wave's share of the reduction is 1-4 chunks, so a layer is one memory round
+    // trip instead of one per chunk
+    constexpr int FU = 4;
+    for (int q0 = wave; q0 < chunks; q0 += FU * NW) {
+        float a[FU][4], b[FU][4];
+        if (vec && p.in_perm.c_count == 0) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) b[t] = wrow[p.in_perm.to_feat(k0 + t)];
+            for (int u = 0; u < FU; ++u) {
+                const int k0 = (q0 + u * NW) * 8 + half * 4;
+                const bool ok = k0 < p.n_in;                     // n_in is a multiple of 4 here: the whole quad is inside
+                const float4 av = *reinterpret_cast<const float4 *>(xrow + (ok ? k0 : 0));
+                const float4 bv = *reinterpret_cast<const float4 *>(wrow + (ok ? k0 : 0));
+                a[u][0] = ok ? av.x : 0.f; a[u][1] = ok ? av.y : 0.f; a[u][2] = ok ? av.z : 0.f; a[u][3] = ok ? av.w : 0.f;
+                b[u][0] = bv.x; b[u][1] = bv.y; b[u][2] = bv.z; b[u][3] = bv.w;
+            }
+        } else if (vec) {
+#pragma unroll
+            for (int u = 0; u < FU; ++u) {
+                const int k0 = (q0 + u * NW) * 8 + half * 4;
+                const bool ok = k0 < p.n_in;
+                const float4 av = *reinterpret_cast<const float4 *>(xrow + (ok ? k0 : 0));
+                a[u][0] = ok ? av.x : 0.f; a[u][1] = ok ? av.y : 0.f; a[u][2] = ok ? av.z : 0.f; a[u][3] = ok ? av.w : 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) b[u][t] = wrow[p.in_perm.to_feat(ok ? k0 + t : 0)];
             }
         } else {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const bool ok = k0 + t < p.n_in;
-                a[t] = ok ? xrow[k0 + t] : 0.f;
-                b[t] = ok ? wrow[p.in_perm.to_feat(k0 + t)] : 0.f;
+            for (int u = 0; u < FU; ++u) {
+                const int k0 = (q0 + u * NW) * 8 + half * 4;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const bool ok = k0 + t < p.n_in;
+                    const float av = xrow[ok ? k0 + t : 0];
+                    a[u][t] = ok ? av : 0.f;
+                    b[u][t] = wrow[p.in_perm.to_feat(ok ? k0 + t : 0)];
+                }
             }
         }
-        if (!mok) a[0] = a[1] = a[2] = a[3] = 0.f;
-        if (!nok) b[0] = b[1] = b[2] = b[3] = 0.f;
-        mfma4(acc, a, b);
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                a[u][t] = mok ? a[u][t] : 0.f;
+                b[u][t] = nok ? b[u][t] : 0.f;
+            }
+            mfma4(acc, a[u], b[u]);
+        }
     }
     const float v = reduce_waves(red, acc, wave, lane);
     if (nok) {
@@ -86,6 +110,61 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_fwd_kernel(DenseArgs p) {
 }
 
 // ---- dgrad: dX[m][in_mem] = sum_{nm} G[m][nm] * W[feat_out(nm)][feat_in(in_mem)]  ---------------------------
+// reduction loop: FU chunks per wave and round, loads first (see dense_fwd_kernel); MODE = Operand::mode() of G
+template <int MODE>
+__device__ __forceinline__ void dense_dgrad_loop(const DenseArgs &p, int64_t grow, int kf, bool mok, bool kok, bool vec, int wave,
+                                                 int half, f32x16 &acc) {
+    constexpr int FU = 4;
+    const int chunks = (p.n_out + 7) / 8;
+    for (int q0 = wave; q0 < chunks; q0 += FU * NW) {
+        float a[FU][4], ay[FU][4], am[FU][4], b[FU][4];
+        bool okt[FU][4];
+        if (vec && MODE <= 1) {
+#pragma unroll
+            for (int u = 0; u < FU; ++u) {
+                const int n0 = (q0 + u * NW) * 8 + half * 4;
+                const bool ok = n0 < p.n_out;                    // n_out is a multiple of 4 here
+                const int nc = ok ? n0 : 0;
+                const float4 av = *reinterpret_cast<const float4 *>(p.a.v + grow + nc);
+                a[u][0] = av.x; a[u][1] = av.y; a[u][2] = av.z; a[u][3] = av.w;
+                if (MODE == 1) {
+                    const float4 yv = *reinterpret_cast<const float4 *>(p.a.y + grow + nc);
+                    ay[u][0] = yv.x; ay[u][1] = yv.y; ay[u][2] = yv.z; ay[u][3] = yv.w;
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    okt[u][t] = ok;
+                    am[u][t] = 1.f;
+                    if (MODE == 0) ay[u][t] = 0.f;
+                    b[u][t] = p.w[(int64_t)p.out_perm.to_feat(nc + t) * p.n_in + kf];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < FU; ++u) {
+                const int n0 = (q0 + u * NW) * 8 + half * 4;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    okt[u][t] = n0 + t < p.n_out;
+                    const int nc = okt[u][t] ? n0 + t : 0;
+                    p.a.template fetch<MODE>(grow + nc, a[u][t], ay[u][t], am[u][t]);
+                    b[u][t] = p.w[(int64_t)p.out_perm.to_feat(nc) * p.n_in + kf];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float g = p.a.template apply<MODE>(a[u][t], ay[u][t], am[u][t]);
+                a[u][t] = (okt[u][t] && mok) ? g : 0.f;
+                b[u][t] = (okt[u][t] && kok) ? b[u][t] : 0.f;
+            }
+            mfma4(acc, a[u], b[u]);
+        }
+    }
+}
+
 __global__ __launch_bounds__(DENSE_THREADS) void dense_dgrad_kernel(DenseArgs p) {
     __shared__ float red[NW * 16 * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, rc = lane & 31;
@@ -101,33 +180,10 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_dgrad_kernel(DenseArgs p)
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    const int chunks = (p.n_out + 7) / 8;
 
-    for (int q = wave; q < chunks; q += NW) {
-        const int n0 = q * 8 + half * 4;
-        float a[4], b[4];
-        if (vec && p.a.mask == nullptr && n0 + 3 < p.n_out) {
-            float4 av = *reinterpret_cast<const float4 *>(p.a.v + grow + n0);
-            if (p.a.y != nullptr) {
-                const float4 yv = *reinterpret_cast<const float4 *>(p.a.y + grow + n0);
-                av.x *= act_bwd_from_out(yv.x, p.a.act); av.y *= act_bwd_from_out(yv.y, p.a.act);
-                av.z *= act_bwd_from_out(yv.z, p.a.act); av.w *= act_bwd_from_out(yv.w, p.a.act);
-            }
-            a[0] = av.x; a[1] = av.y; a[2] = av.z; a[3] = av.w;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) b[t] = p.w[(int64_t)p.out_perm.to_feat(n0 + t) * p.n_in + kf];
-        } else {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const bool ok = n0 + t < p.n_out;
-                a[t] = ok ? p.a.at(grow + n0 + t) : 0.f;
-                b[t] = ok ? p.w[(int64_t)p.out_perm.to_feat(n0 + t) * p.n_in + kf] : 0.f;
-            }
-        }
-        if (!mok) a[0] = a[1] = a[2] = a[3] = 0.f;
-        if (!kok) b[0] = b[1] = b[2] = b[3] = 0.f;
-        mfma4(acc, a, b);
-    }
+    if (p.a.mode() == 0) dense_dgrad_loop<0>(p, grow, kf, mok, kok, vec, wave, half, acc);
+    else if (p.a.mode() == 1) dense_dgrad_loop<1>(p, grow, kf, mok, kok, vec, wave, half, acc);
+    else dense_dgrad_loop<2>(p, grow, kf, mok, kok, vec, wave, half, acc);
     const float v = reduce_waves(red, acc, wave, lane);
     if (kok) {
         const int row = blockIdx.x * 32 + (wave & 3) + 8 * (wave >> 2) + 4 * half;
@@ -346,24 +402,41 @@ __global__ __launch_bounds__(256) void rows_gemm_x3_kernel(RowsGemm g) {
 // operands were written a whole pass ago and come from HBM with a row pitch of 1-2 KB, so a tile lives on memory
 // latency (a single tile takes ~16 us cold, 9 us when its input was just read: measured per job).
 
-template <bool PLAIN, int NWT>
+#ifdef DW_STAMPS
+// diagnostic build only (tools/stamp_dw.py): phase timeline of the first 512 weight-gradient tiles, 100 MHz wall clock
+__device__ unsigned long long g_dw_stamps[512 * 8];
+#define DW_STAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 512) g_dw_stamps[blockIdx.x * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define DW_STAMP(slot)
+#endif
+
+template <int MODE, int NWT>
 __device__ __forceinline__ void dense_wgrad_loop(const DenseArgs &p, int ncol, int kcol, bool nok, bool kok, int wave, int half,
                                                  f32x16 &acc, float &bsum) {
     constexpr int KU = 4;                                        // 8 did not help (measured): the tile is not load-count bound
     const int chunks = (p.batch + 7) / 8;
     for (int q0 = wave; q0 < chunks; q0 += KU * NWT) {
-        float a[KU][4], b[KU][4];
+        float a[KU][4], ay[KU][4], am[KU][4], b[KU][4];
+        // loads only (Operand::fetch): with Operand::at() here every element was its own memory round trip
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const int m0 = (q0 + u * NWT) * 8 + half * 4;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int mc = m0 + t < p.batch ? m0 + t : 0;
+                p.a.template fetch<MODE>((int64_t)mc * p.n_out + ncol, a[u][t], ay[u][t], am[u][t]);
+                b[u][t] = p.x[(int64_t)mc * p.n_in + kcol];
+            }
+        }
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
             const int m0 = (q0 + u * NWT) * 8 + half * 4;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const bool ok = m0 + t < p.batch;
-                const int mc = ok ? m0 + t : 0;
-                const int64_t gi = (int64_t)mc * p.n_out + ncol;
-                const float av = PLAIN ? p.a.v[gi] : p.a.at(gi), bv = p.x[(int64_t)mc * p.n_in + kcol];
-                a[u][t] = (ok && nok) ? av : 0.f;
-                b[u][t] = (ok && kok) ? bv : 0.f;
+                const float g = p.a.template apply<MODE>(a[u][t], ay[u][t], am[u][t]);
+                a[u][t] = (ok && nok) ? g : 0.f;
+                b[u][t] = (ok && kok) ? b[u][t] : 0.f;
             }
         }
 #pragma unroll
@@ -372,6 +445,9 @@ __device__ __forceinline__ void dense_wgrad_loop(const DenseArgs &p, int ncol, i
             for (int t = 0; t < 4; ++t) bsum += a[u][t];
             mfma4(acc, a[u], b[u]);
         }
+#ifdef DW_STAMPS
+        if (q0 == wave) { __builtin_amdgcn_s_waitcnt(0); DW_STAMP(2); }
+#endif
     }
 }
 
@@ -380,13 +456,18 @@ template <int NWT>
 __device__ __forceinline__ void dense_wgrad_tile(const DenseArgs &p, int bx, int by, float *red) {
     constexpr int RPW = 16 / NWT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, rc = lane & 31;
-    const int n = bx * 32 + rc, km = by * 32 + rc;
-    const bool nok = n < p.n_out, kok = km < p.n_in;
-    const int ncol = nok ? p.out_perm.to_mem(n) : 0, kcol = kok ? km : 0;
+    // a tile owns 32 consecutive MEMORY columns of G (coalesced loads in the reduction loop); with a channel permutation
+    // (out_perm) its rows of dW are scattered instead, which only moves the 16 stores per lane at the end: the permuted
+    // layer's tile took 19 us with feature-ordered lanes (64 cache lines per load instruction) against 8 us for the others
+    const int nm = bx * 32 + rc, km = by * 32 + rc;
+    const bool nok = nm < p.n_out, kok = km < p.n_in;
+    const int ncol = nok ? nm : 0, kcol = kok ? km : 0;
+    const int n = p.out_perm.to_feat(ncol);
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     float bsum = 0.f;
+    DW_STAMP(0);
     // this lane's dW elements: read early, added to after the reduction
     float *outp[RPW];
     float old[RPW];
@@ -394,17 +475,21 @@ __device__ __forceinline__ void dense_wgrad_tile(const DenseArgs &p, int bx, int
 #pragma unroll
     for (int e = 0; e < RPW; ++e) {
         const int reg = wave * RPW + e;
-        const int out_row = bx * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;      // n
-        out_ok[e] = kok && out_row < p.n_out;
-        outp[e] = p.out + (out_ok[e] ? (int64_t)out_row * p.n_in + p.in_perm.to_feat(km) : 0);
+        const int out_mem = bx * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;      // memory column of G = lane rc of this row
+        out_ok[e] = kok && out_mem < p.n_out;
+        outp[e] = p.out + (out_ok[e] ? (int64_t)p.out_perm.to_feat(out_mem) * p.n_in + p.in_perm.to_feat(km) : 0);
         old[e] = p.store ? 0.f : *outp[e];
     }
-    if (p.a.y == nullptr) dense_wgrad_loop<true, NWT>(p, ncol, kcol, nok, kok, wave, half, acc, bsum);
-    else dense_wgrad_loop<false, NWT>(p, ncol, kcol, nok, kok, wave, half, acc, bsum);
+    if (p.a.mode() == 0) dense_wgrad_loop<0, NWT>(p, ncol, kcol, nok, kok, wave, half, acc, bsum);
+    else if (p.a.mode() == 1) dense_wgrad_loop<1, NWT>(p, ncol, kcol, nok, kok, wave, half, acc, bsum);
+    else dense_wgrad_loop<2, NWT>(p, ncol, kcol, nok, kok, wave, half, acc, bsum);
+    DW_STAMP(3);
     __syncthreads();
+    DW_STAMP(4);
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
     __syncthreads();
+    DW_STAMP(5);
 #pragma unroll
     for (int e = 0; e < RPW; ++e) {
         float v = 0.f;
@@ -423,6 +508,10 @@ __device__ __forceinline__ void dense_wgrad_tile(const DenseArgs &p, int bx, int
             p.dbias[n] = (p.store ? 0.f : p.dbias[n]) + tot;
         }
     }
+#ifdef DW_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);
+    DW_STAMP(6);
+#endif
 }
 
 __global__ __launch_bounds__(DENSE_THREADS) void dense_wgrad_kernel(DenseArgs p) {
@@ -606,6 +695,12 @@ int dense_wgrad_flush(DenseWgradBatch *b, hipStream_t s) {
 }
 
 }  // namespace arvae
+
+#ifdef DW_STAMPS
+extern "C" int arvae_debug_dw_stamps(unsigned long long *out, int count) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(arvae::g_dw_stamps), sizeof(unsigned long long) * count);
+}
+#endif
 
 // Several Linear weight gradients in one launch for callers outside the whole-model executor (the MeasureVAE's autograd
 // graph queues its batch-sized ones and flushes them at the end of the backward pass).
