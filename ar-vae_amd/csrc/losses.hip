@@ -321,28 +321,55 @@ struct VaeFinishArgs {
 
 __global__ __launch_bounds__(1024) void vae_finish_kernel(VaeFinishArgs p) {
     __shared__ float4 red4[16];
-    // every load first (one round of memory latency), then ONE four-wide reduction; 32-bit index math throughout
+    // One workgroup, so the kernel is as long as its chain of dependent memory round trips: the first FU * 1024 elements of
+    // every array (all of them at the sizes of this repo's models) are loaded before anything is summed -- one round trip --
+    // and only what is left beyond that runs as plain loops.  Fixed summation order; 32-bit index math throughout.
+    constexpr int FU = 8;
     float a = 0.f, b = 0.f, s = 0.f, t = 0.f;
-    for (int i = threadIdx.x; i < p.nb; i += 1024) {
+    const int bz = (int)p.bz;
+    const bool reg = p.row_loss != nullptr, want_dz = reg && p.dz != nullptr;
+    const int n_rows = (int)p.n_rows, ldz = (int)p.ldz, nr = reg ? n_rows * p.r : 0, nz = want_dz ? n_rows * ldz : 0;
+    float2 rp[FU];
+    float mu[FU], sg[FU], rl[FU], rg[FU];
+    int dk[FU];
+#pragma unroll
+    for (int u = 0; u < FU; ++u) {
+        const int i = threadIdx.x + u * 1024;
+        rp[u] = reinterpret_cast<const float2 *>(p.rec_partial)[i < p.nb ? i : 0];
+        mu[u] = p.mu[i < bz ? i : 0];
+        sg[u] = p.sigma[i < bz ? i : 0];
+        rl[u] = reg ? p.row_loss[i < nr ? i : 0] : 0.f;
+        // dz[row][c] = grad_scale * row_grad[k][row] for c = dims[k], else 0: index arithmetic, then ONE unconditional load
+        const int ic = i < nz ? i : 0, row = ic / (ldz > 0 ? ldz : 1), c = ic - row * ldz;
+        int k = -1;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            if (q < p.r && p.dims.d[q] == c) k = q;
+        dk[u] = k;
+        rg[u] = want_dz ? p.row_grad[(k < 0 ? 0 : k) * n_rows + row] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < FU; ++u) {
+        const int i = threadIdx.x + u * 1024;
+        if (i < p.nb) { a += rp[u].x; b += rp[u].y; }
+        if (i < bz) s += kl_elem(mu[u], sg[u], 0.f, 1.f);
+        if (i < nr) t += rl[u];
+        if (i < nz) p.dz[i] = dk[u] < 0 ? 0.f : p.grad_scale * rg[u];
+    }
+    for (int i = threadIdx.x + FU * 1024; i < p.nb; i += 1024) {
         a += p.rec_partial[2 * i];
         b += p.rec_partial[2 * i + 1];
     }
-    const int bz = (int)p.bz;
-    for (int i = threadIdx.x; i < bz; i += 1024) s += kl_elem(p.mu[i], p.sigma[i], 0.f, 1.f);
-    if (p.row_loss != nullptr) {
-        const int n_rows = (int)p.n_rows, ldz = (int)p.ldz, nr = n_rows * p.r, nz = n_rows * ldz;
-        for (int i = threadIdx.x; i < nr; i += 1024) t += p.row_loss[i];
-        if (p.dz != nullptr) {                                   // dz[row][c] = grad_scale * row_grad[k][row] for c = dims[k], else 0
-            for (int i = threadIdx.x; i < nz; i += 1024) {
-                const int row = i / ldz, c = i - row * ldz;
-                int k = -1;                                       // index arithmetic only, then ONE unconditional load
+    for (int i = threadIdx.x + FU * 1024; i < bz; i += 1024) s += kl_elem(p.mu[i], p.sigma[i], 0.f, 1.f);
+    for (int i = threadIdx.x + FU * 1024; i < nr; i += 1024) t += p.row_loss[i];
+    for (int i = threadIdx.x + FU * 1024; i < nz; i += 1024) {
+        const int row = i / ldz, c = i - row * ldz;
+        int k = -1;
 #pragma unroll
-                for (int q = 0; q < 16; ++q)
-                    if (q < p.r && p.dims.d[q] == c) k = q;
-                const float g = p.row_grad[(k < 0 ? 0 : k) * n_rows + row];
-                p.dz[i] = k < 0 ? 0.f : p.grad_scale * g;
-            }
-        }
+        for (int q = 0; q < 16; ++q)
+            if (q < p.r && p.dims.d[q] == c) k = q;
+        const float g = p.row_grad[(k < 0 ? 0 : k) * n_rows + row];
+        p.dz[i] = k < 0 ? 0.f : p.grad_scale * g;
     }
     float4 v = make_float4(wave_sum(a), wave_sum(b), wave_sum(s), wave_sum(t));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
