@@ -1,0 +1,386 @@
+// Stride-1 4x4 convolutions between 64-channel layers (the Morpho-MNIST 64 <-> 64 layers, imagevae/mnist_vae.py:16-47),
+// ROW-STAGED: the source rows an output row group meets are fetched from HBM, turned into three bf16 terms and written to
+// LDS exactly ONCE, and all 16 taps x 64 channels of the reduction are served from there.  conv_rows_x3_kernel (conv64.hip)
+// re-gathers its 64-pixel A tile from L2 for each of its 32 reduction chunks (~4 GB per launch at B = 1024, 16x re-read) and
+// runs load -> split -> LDS -> MFMA serially between two barriers per chunk (MFMA pipe ~30 % busy).
+//
+//   out[n][oy][ox][q] = ep( bias[q] + sum_{ky,kx,c} W(q, c, ky, kx) * src[n][oy + sgn ky + off][ox + sgn kx + off][c] )
+//     sgn = +1: Conv2d forward / ConvTranspose2d data gradient      sgn = -1: ConvTranspose2d forward / Conv2d data gradient
+//
+// One 256-thread workgroup per CU, persistent over tiles; a tile = G output rows of one image (G * ow <= 32 MT pixels,
+// MT = 3 or 4 MFMA column tiles) and needs G + 3 source rows: <= 176 pixels x (3 x 64 bf16 + pad) = 70 KB, two buffers.
+//   * MFMA orientation as in conv32.hip: the WEIGHTS are the A operand (row = output channel), the pixels the B operand, so a
+//     lane ends up with consecutive channels of one pixel (16-byte stores).  32x32x16 bf16, six partial products per
+//     multiply-add, smallest first (fp32-accurate: x3tile.h).
+//   * wave = kernel row (K split four ways); a wave holds MT x 2 accumulator tiles (all 64 output channels of the group's
+//     pixels for its four taps) -- each pixel operand read from LDS feeds 12 MFMAs, each weight operand MT x 3: the LDS pipe
+//     is ~25 % busy.  The four partial sums meet through the tile's own (now free) LDS buffer, each wave finishing a quarter
+//     of every accumulator tile and storing it.
+//   * weights: split once per launch by conv64s_weight_prep_kernel into the exact per-lane operand order,
+//     [ky][kx][16-channel chunk][column tile][term][lane] x 16 bytes (393 KB, L2 resident); a wave streams its 6 KB per
+//     reduction step straight into registers, one step ahead.
+//   * pipeline as down32x_kernel: registers hold tile t+1 (loaded during tile t-1); during tile t's MFMAs each loader slot
+//     is split, written to the other buffer and refilled with tile t+2.  The activation derivative / keep-mask of a
+//     gradient operand is applied at that point -- once per value instead of once per tap.
+//   * padding: source columns outside [0, sw) are not stored; a lane whose tap falls there reads one shared zero pixel
+//     (a select on the LDS address).  Source rows outside the image are staged as zeros.
+#include "common.h"
+#include "conv32_common.h"
+#include "x3tile.h"
+
+namespace arvae {
+
+constexpr int S_PITCH = 100;                     // dwords per staged pixel: terms at +0, +32, +64, 4 pad (conflict-free 16-byte
+                                                 // reads for lanes walking consecutive pixels)
+constexpr int S_PIX = 176;                       // staged source pixels per tile
+constexpr int S_BUF = (S_PIX + 1) * S_PITCH;     // + the zero pixel
+constexpr int S_SLOTS = S_PIX * 16 / 256;        // 16-byte loader slots per thread (11)
+constexpr int S_WSTEP = 6 * 64;                  // uint4 per (ky, kx, channel chunk): [column tile 2][term 3][lane 64]
+constexpr int S_PREP_UINT4 = 16 * 4 * S_WSTEP;   // 393 216 bytes
+
+struct ConvStage {
+    Operand src;                 // [n][sh][sw][64]
+    int n, sh, sw, oh, ow;
+    int sgn, dmin;               // source coordinate = output coordinate + dmin + j, j = tap index if sgn > 0 else 3 - tap index
+    int rows, groups;            // output rows per tile, tiles per image
+    const uint4 *wprep;
+    const float *bias;
+    const uint8_t *mask;
+    int act;
+    float *out;                  // [n][oh][ow][64]
+};
+
+// wt = nn.Conv2d / nn.ConvTranspose2d weights [a][b][ky][kx]; (q, c) = (a, b) for the Conv2d-forward direction, (b, a) for
+// the transposed one.  One thread = one (ky, kx, chunk, column tile, lane) = 8 reduction channels of one output channel.
+__global__ __launch_bounds__(256) void conv64s_weight_prep_kernel(const float *__restrict__ wt, uint4 *__restrict__ out, int transposed) {
+    const int i = blockIdx.x * 256 + threadIdx.x;              // ((tap * 4 + c16) * 2 + nt) * 64 + lane
+    const int lane = i & 63, nt = (i >> 6) & 1, c16 = (i >> 7) & 3, tap = i >> 9;
+    const int q = nt * 32 + (lane & 31), c0 = c16 * 16 + 8 * (lane >> 5);
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = transposed ? wt[((c0 + j) * 64 + q) * 16 + tap] : wt[(q * 64 + c0 + j) * 16 + tap];
+    uint4 h, m, l;
+    rg_split3(x[0], x[1], h.x, m.x, l.x);
+    rg_split3(x[2], x[3], h.y, m.y, l.y);
+    rg_split3(x[4], x[5], h.z, m.z, l.z);
+    rg_split3(x[6], x[7], h.w, m.w, l.w);
+    uint4 *d = out + ((tap * 4 + c16) * 2 + nt) * 3 * 64 + lane;
+    d[0] = h; d[64] = m; d[128] = l;
+}
+
+// act_fwd with the SELU exponential on v_exp_f32 (1 ulp): the epilogue runs while the matrix pipe idles, and 32 expf() calls
+// per lane and tile were 16 % of a tile's time
+__device__ __forceinline__ float act_fwd_hw(float x, int act) {
+    const float relu = fmaxf(x, 0.f);
+    const float selu = x > 0.f ? kSeluScale * x : (kSeluScale * kSeluAlpha) * (__builtin_amdgcn_exp2f(x * 1.4426950408889634f) - 1.f);
+    return act == ARVAE_ACT_RELU ? relu : (act == ARVAE_ACT_SELU ? selu : x);
+}
+
+// MODE = Operand::mode() of the source: 0 plain, 1 activation derivative from the saved output, 2 also the keep-mask
+template <int MT, int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv64s_kernel(ConvStage g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned lds[];          // 2 x S_BUF
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, rc = lane & 31;
+    const int n_tiles = g.n * g.groups;
+    const int src_rows = g.rows + 3, src_pix = src_rows * g.sw;
+
+    // ---- loader: slot s of this thread = (staged pixel, channels 4 q4 .. + 3) -------------------------------------------
+    float4 lv[S_SLOTS], ly[S_SLOTS];
+    unsigned lm[S_SLOTS];
+    // slot s: staged pixel pix0 + 16 s.  q4 / pix0 / wlane are laundered through an empty asm at the top of every tile: the
+    // addresses derived from them are loop invariant, LLVM hoists all ~100 of them out of the tile loop and the kernel,
+    // whose register file is full by design, spills; recomputing them per tile is a few hundred cheap instructions
+    int q4 = threadIdx.x & 15, pix0 = threadIdx.x >> 4, wlane = lane;
+    const int inv_sw = 65536 / g.sw + 1;
+    auto issue = [&](int s, int tile) __attribute__((always_inline)) {
+        const int img = tile / g.groups, oy0 = (tile - img * g.groups) * g.rows;
+        const int l_pix = pix0 + 16 * s, l_row = (l_pix * inv_sw) >> 16;     // l_pix / sw for l_pix < 256, sw <= 64 (recomputed per tile:
+                                                                             // registers are what this kernel lacks)
+        const int sy = oy0 + g.dmin + l_row, sx = l_pix - l_row * g.sw;
+        const bool ok = tile < n_tiles && l_pix < src_pix && (unsigned)sy < (unsigned)g.sh;
+        const int64_t at = ok ? (((int64_t)img * g.sh + sy) * g.sw + sx) * 64 + 4 * q4 : 0;
+        float4 v = *reinterpret_cast<const float4 *>(g.src.v + at);
+        if (MODE >= 1) ly[s] = *reinterpret_cast<const float4 *>(g.src.y + at);
+        if (MODE == 2) lm[s] = *reinterpret_cast<const unsigned *>(g.src.mask + at);
+        lv[s] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto commit = [&](int s, unsigned *buf) __attribute__((always_inline)) {
+        float4 v = lv[s];
+        if (MODE >= 1) {
+            float4 y = ly[s];
+            if (MODE == 2) {
+                const unsigned m = lm[s];
+                v.x *= 2.f * (float)(m & 255u); v.y *= 2.f * (float)((m >> 8) & 255u);
+                v.z *= 2.f * (float)((m >> 16) & 255u); v.w *= 2.f * (float)(m >> 24);
+                y.x *= 0.5f; y.y *= 0.5f; y.z *= 0.5f; y.w *= 0.5f;
+            }
+            v.x *= act_bwd_from_out_sel(y.x, g.src.act); v.y *= act_bwd_from_out_sel(y.y, g.src.act);
+            v.z *= act_bwd_from_out_sel(y.z, g.src.act); v.w *= act_bwd_from_out_sel(y.w, g.src.act);
+        }
+        uint2 h, m, l;
+        rg_split3(v.x, v.y, h.x, m.x, l.x);
+        rg_split3(v.z, v.w, h.y, m.y, l.y);
+        unsigned *d = buf + (pix0 + 16 * s) * S_PITCH + q4 * 2;
+        *reinterpret_cast<uint2 *>(d) = h;
+        *reinterpret_cast<uint2 *>(d + 32) = m;
+        *reinterpret_cast<uint2 *>(d + 64) = l;
+    };
+
+#pragma unroll
+    for (int s = 0; s < S_SLOTS; ++s) issue(s, blockIdx.x);
+    // zero pixel of both buffers, once
+    if (threadIdx.x < 2 * S_PITCH) lds[(threadIdx.x / S_PITCH) * S_BUF + S_PIX * S_PITCH + threadIdx.x % S_PITCH] = 0u;
+
+    // ---- consumer geometry: wave = kernel row index jy (source row oy + dmin + jy); pixel of (mt, lane) ------------------
+    // xoff[mt][jx]: dword offset of this lane's pixel at tap column jx in a buffer (the zero pixel where that column is
+    // outside the source), + half * 4
+    int xoff[MT][4];
+    int opix[MT];                                // output offset of the lane's pixel inside the tile, or -1
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int P = mt * 32 + rc, r = P / g.ow, c = P - r * g.ow;
+        opix[mt] = (P < g.rows * g.ow) ? P : -1;
+#pragma unroll
+        for (int jx = 0; jx < 4; ++jx) {
+            const int sx = c + g.dmin + jx;
+            const bool ok = r < g.rows && (unsigned)sx < (unsigned)g.sw;
+            xoff[mt][jx] = (ok ? ((r + wave) * g.sw + sx) : S_PIX) * S_PITCH + half * 4;
+        }
+    }
+    const int ky = g.sgn > 0 ? wave : 3 - wave;
+    float4 b4[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+        b4[nt] = g.bias != nullptr ? *reinterpret_cast<const float4 *>(g.bias + nt * 32 + 8 * wave + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // first tile -> buffer 0
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < S_SLOTS; ++s) commit(s, lds);
+    __syncthreads();
+    // weight operands: a ring of three register sets, two reduction steps ahead of the MFMAs (the 393 KB of split weights live
+    // in L2: one step = ~0.75 us is not enough to cover that round trip under load)
+    bf16x8 w3[3][2][3];
+    auto load_w = [&](auto rc_, int kx, int c16) __attribute__((always_inline)) {
+        constexpr int r = decltype(rc_)::value;
+        const uint4 *wp = g.wprep + ((ky * 4 + kx) * 4 + c16) * S_WSTEP + wlane;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) w3[r][nt][t] = __builtin_bit_cast(bf16x8, wp[(nt * 3 + t) * 64]);
+    };
+    const int kx_first = g.sgn > 0 ? 0 : 3;
+    load_w(std::integral_constant<int, 0>{}, kx_first, 0);
+    load_w(std::integral_constant<int, 1>{}, kx_first, 1);
+
+    int cur = 0;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, cur ^= 1) {
+        asm volatile("" : "+v"(q4), "+v"(pix0), "+v"(wlane));
+        const unsigned *xb = lds + cur * S_BUF;
+        unsigned *nb = lds + (cur ^ 1) * S_BUF;
+        f32x16 acc[MT][2];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+        bf16x8 x3[2][MT][3];
+        // pixel operands of reduction step 0 (jx = 0, chunk 0)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                x3[0][mt][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4v *>(xb + xoff[mt][0] + t * 32));
+        static_for<0, 16>([&](auto kc) __attribute__((always_inline)) {
+            constexpr int step = decltype(kc)::value, jx = step >> 2, c16 = step & 3;
+            constexpr int cu = step & 1, nx = cu ^ 1, wr = step % 3;
+            (void)jx; (void)c16;
+            __builtin_amdgcn_sched_barrier(0);                   // nothing moves across a step (the register file is full)
+            if constexpr (step + 2 < 16) {
+                constexpr int njx = (step + 2) >> 2, nc16 = (step + 2) & 3;
+                load_w(std::integral_constant<int, (step + 2) % 3>{}, g.sgn > 0 ? njx : 3 - njx, nc16);
+            }
+            if constexpr (step + 1 < 16) {                       // next step's pixel operands fly during this step's MFMAs
+                constexpr int njx = (step + 1) >> 2, nc16 = (step + 1) & 3;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+                        x3[nx][mt][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4v *>(xb + xoff[mt][njx] + t * 32 + nc16 * 8));
+            }
+            // this step's share of the loader: the next tile's slot s is requested in step s * 12 / 11 and split + written to the
+            // other buffer four steps (~3 us) later -- a handful of slots in flight instead of a tile's worth of registers
+            static_for<0, S_SLOTS>([&](auto sc) __attribute__((always_inline)) {
+                constexpr int s = decltype(sc)::value;
+                if constexpr (s * 12 / S_SLOTS == step) issue(s, tile + gridDim.x);
+                if constexpr (s * 12 / S_SLOTS + 4 == step) commit(s, nb);
+            });
+            // (weight term, pixel term) of the six partial products, smallest first, round-robin over the accumulators
+#define ARVAE_C64S_PRODUCT(TW, TX)                                                                   \
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                        \
+                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) MFMA_B(acc[mt][nt], w3[wr][nt][TW], x3[cu][mt][TX]);
+            ARVAE_C64S_PRODUCT(2, 0)
+            ARVAE_C64S_PRODUCT(0, 2)
+            ARVAE_C64S_PRODUCT(1, 1)
+            ARVAE_C64S_PRODUCT(1, 0)
+            ARVAE_C64S_PRODUCT(0, 1)
+            ARVAE_C64S_PRODUCT(0, 0)
+#undef ARVAE_C64S_PRODUCT
+            // issue order: an MFMA, then one of the next step's operand reads (a burst of LDS reads in front of a block of MFMAs
+            // costs the matrix pipe ~10 idle cycles per read: tools/probes/mfma_barrier.hip), then the loader's share
+            if constexpr (step + 1 < 16) {
+#pragma unroll
+                for (int i_ = 0; i_ < 3 * MT; ++i_) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
+            if constexpr (step + 2 < 16) {
+#pragma unroll
+                for (int i_ = 0; i_ < 6; ++i_) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+            }
+            // the loader's vector-ALU work (address arithmetic, three-term split) and LDS writes: a few per MFMA
+            {
+                constexpr int used = (step + 1 < 16 ? 3 * MT : 0) + (step + 2 < 16 ? 6 : 0);
+#pragma unroll
+                for (int i_ = used; i_ < 12 * MT; ++i_) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        load_w(std::integral_constant<int, 0>{}, kx_first, 0);   // the next tile's first two steps: the exchange hides them
+        load_w(std::integral_constant<int, 1>{}, kx_first, 1);
+        // keep-mask bytes of this wave's share of the outputs: fetched now, used after the exchange
+        const int img = tile / g.groups, oy0 = (tile - img * g.groups) * g.rows;
+        unsigned km[MT][2];
+        if (g.mask != nullptr) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int P = opix[mt];
+                    const bool ok = P >= 0 && oy0 + P / g.ow < g.oh;
+                    const int64_t o = ok ? (((int64_t)img * g.oh + oy0) * g.ow + P) * 64 + nt * 32 + 8 * wave + 4 * half : 0;
+                    km[mt][nt] = *reinterpret_cast<const unsigned *>(g.mask + o);
+                }
+        }
+        __syncthreads();                                         // every read of this buffer is done; the next tile is staged
+
+        // ---- the four kernel rows' partial sums meet in this tile's buffer: wave w finishes accumulator registers
+        //      4 w .. 4 w + 3 (channels 8 w + 4 half + j) of every tile; one column tile at a time (the buffer is 70 KB)
+        float4 *xch = reinterpret_cast<float4 *>(lds + cur * S_BUF);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+            for (int o = 1; o < 4; ++o) {                        // to owner gw = (wave + o) & 3, as its source number 3 - o
+                const int gw = (wave + o) & 3;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    xch[((gw * 3 + (3 - o)) * MT + mt) * 64 + lane] =
+                        make_float4(acc[mt][nt][4 * gw], acc[mt][nt][4 * gw + 1], acc[mt][nt][4 * gw + 2], acc[mt][nt][4 * gw + 3]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float4 v = make_float4(acc[mt][nt][4 * wave], acc[mt][nt][4 * wave + 1], acc[mt][nt][4 * wave + 2], acc[mt][nt][4 * wave + 3]);
+#pragma unroll
+                for (int sidx = 0; sidx < 3; ++sidx) {           // fixed order: the waves wave + 1, wave + 2, wave + 3 (mod 4)
+                    const float4 p = xch[((wave * 3 + sidx) * MT + mt) * 64 + lane];
+                    v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+                }
+                const int P = opix[mt];
+                const int r = P / g.ow;
+                if (P >= 0 && oy0 + r < g.oh) {
+                    const int64_t o = (((int64_t)img * g.oh + oy0) * g.ow + P) * 64 + nt * 32 + 8 * wave + 4 * half;
+                    v.x = act_fwd_hw(v.x + b4[nt].x, g.act); v.y = act_fwd_hw(v.y + b4[nt].y, g.act);
+                    v.z = act_fwd_hw(v.z + b4[nt].z, g.act); v.w = act_fwd_hw(v.w + b4[nt].w, g.act);
+                    if (g.mask != nullptr) {
+                        const unsigned m = km[mt][nt];
+                        v.x *= 2.f * (float)(m & 255u); v.y *= 2.f * (float)((m >> 8) & 255u);
+                        v.z *= 2.f * (float)((m >> 16) & 255u); v.w *= 2.f * (float)(m >> 24);
+                    }
+                    *reinterpret_cast<float4 *>(g.out + o) = v;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------
+static int cu_count_s() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+// rows per tile and column tiles for an output width / source width, or false
+static bool stage_geometry(int ow, int sw, int &rows, int &mt) {
+    for (int m = 4; m >= 3; --m) {
+        const int r = 32 * m / ow;
+        if (r >= 1 && (r + 3) * sw <= S_PIX) { rows = r; mt = m; return true; }
+    }
+    return false;
+}
+
+int64_t conv64s_ws_floats() { return S_PREP_UINT4 * 4; }
+
+// 64 -> 64 channels, 4x4 taps, stride 1, channels-last without permutation, a row group that fits the staging buffers
+bool conv64s_fits(const arvae_link_t *l, bool up) {
+    static const bool off = getenv("ARVAE_CONV64_NO_STAGE") != nullptr;      // diagnostic: the gathering kernel instead
+    int rows, mt;
+    const int ow = up ? l->hw : l->lw, sw = up ? l->lw : l->hw;
+    return !off && l->stride == 1 && l->kh == 4 && l->kw == 4 && l->chi == 64 && l->clo == 64 && l->hi_perm_c == 0 &&
+           l->lo_perm_c == 0 && stage_geometry(ow, sw, rows, mt);
+}
+
+template <int MT> static void launch_stage(const ConvStage &g, int grid, hipStream_t s) {
+    constexpr int LDS = 2 * S_BUF * 4;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void *)conv64s_kernel<MT, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void *)conv64s_kernel<MT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void *)conv64s_kernel<MT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr = true;
+    }
+    const int mode = (g.src.y == nullptr || (g.src.act == ARVAE_ACT_NONE && g.src.mask == nullptr)) ? 0 : g.src.mode();
+    if (mode == 0) ARVAE_LAUNCH((conv64s_kernel<MT, 0>), dim3(grid), dim3(256), LDS, s, g);
+    else if (mode == 1) ARVAE_LAUNCH((conv64s_kernel<MT, 1>), dim3(grid), dim3(256), LDS, s, g);
+    else ARVAE_LAUNCH((conv64s_kernel<MT, 2>), dim3(grid), dim3(256), LDS, s, g);
+}
+
+// src [n][sh][sw][64] -> out [n][oh][ow][64]; source coordinate = output coordinate + sgn * k + off
+int conv64s_run(const Operand &src, int n, int sh, int sw, int oh, int ow, int sgn, int off, const float *wt, bool transposed,
+                const float *bias, int act, const uint8_t *mask, float *out, float *ws, hipStream_t s, const char *what) {
+    if (ws == nullptr || (reinterpret_cast<uintptr_t>(ws) & 15) != 0)
+        return fail(ARVAE_E_INVALID, "%s: needs arvae_link_ws_floats() floats of 16-byte aligned workspace for the split weights", what);
+    ConvStage g{};
+    int mt = 0;
+    if (!stage_geometry(ow, sw, g.rows, mt)) return fail(ARVAE_E_INVALID, "%s: no staging geometry", what);
+    g.src = src; g.n = n; g.sh = sh; g.sw = sw; g.oh = oh; g.ow = ow;
+    g.sgn = sgn; g.dmin = sgn > 0 ? off : off - 3;
+    g.groups = (oh + g.rows - 1) / g.rows;
+    g.wprep = reinterpret_cast<const uint4 *>(ws);
+    g.bias = bias; g.mask = mask; g.act = act; g.out = out;
+    ARVAE_LAUNCH(conv64s_weight_prep_kernel, dim3(16 * 4 * 2 * 64 / 256), dim3(256), 0, s, wt, reinterpret_cast<uint4 *>(ws), transposed ? 1 : 0);
+    const int tiles = n * g.groups, cus = cu_count_s();
+    const int grid = tiles < cus ? tiles : cus;
+    if (mt == 4) launch_stage<4>(g, grid, s);
+    else launch_stage<3>(g, grid, s);
+    return check_launch(what);
+}
+
+}  // namespace arvae
