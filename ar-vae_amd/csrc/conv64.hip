@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void conv64_weight_prep_kernel(const float *__
 // (conv64s.hip: the row-staged kernel of the 64 <-> 64 channel layers and its split weights)
 int64_t conv64s_ws_floats();
 bool conv64s_fits(const arvae_link_t *l, bool up);
-int conv64s_run(const Operand &src, int n, int sh, int sw, int oh, int ow, int sgn, int off, const float *wt, bool transposed,
+int conv64s_run(const Operand &src, int n, int sh, int sw, int oh, int ow, int q, int sgn, int off, const float *wt, bool transposed,
                 const float *bias, int act, const uint8_t *mask, float *out, float *ws, hipStream_t s, const char *what);
 
 int64_t conv64_ws_floats(const arvae_link_t *l) {
@@ -195,7 +195,7 @@ static int launch_conv_rows(ConvRows g, const float *wt, bool transposed, float 
 int conv64_down(const arvae_link_t *l, const Operand &hi, const float *wt, const float *bias, int act, const uint8_t *mask,
                 float *lo, float *ws, hipStream_t s) {
     if (conv64s_fits(l, false))
-        return conv64s_run(hi, l->n, l->hh, l->hw, l->lh, l->lw, 1, -l->pad, wt, false, bias, act, mask, lo, ws, s, "conv64_down");
+        return conv64s_run(hi, l->n, l->hh, l->hw, l->lh, l->lw, l->clo, 1, -l->pad, wt, false, bias, act, mask, lo, ws, s, "conv64_down");
     ConvRows g{};
     g.src = hi; g.n = l->n; g.sh = l->hh; g.sw = l->hw; g.cs = l->chi;
     g.oh = l->lh; g.ow = l->lw; g.q = l->clo;
@@ -208,7 +208,7 @@ int conv64_down(const arvae_link_t *l, const Operand &hi, const float *wt, const
 int conv64_up(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, int act, const uint8_t *mask,
               float *hi, float *ws, hipStream_t s) {
     if (conv64s_fits(l, true))
-        return conv64s_run(lo, l->n, l->lh, l->lw, l->hh, l->hw, -1, l->pad, wt, true, bias, act, mask, hi, ws, s, "conv64_up");
+        return conv64s_run(lo, l->n, l->lh, l->lw, l->hh, l->hw, l->chi, -1, l->pad, wt, true, bias, act, mask, hi, ws, s, "conv64_up");
     ConvRows g{};
     g.src = lo; g.n = l->n; g.sh = l->lh; g.sw = l->lw; g.cs = l->clo;
     g.oh = l->hh; g.ow = l->hw; g.q = l->chi;

@@ -35,12 +35,12 @@ constexpr int S_PITCH = 100;                     // dwords per staged pixel: ter
 constexpr int S_PIX = 176;                       // staged source pixels per tile
 constexpr int S_BUF = (S_PIX + 1) * S_PITCH;     // + the zero pixel
 constexpr int S_SLOTS = S_PIX * 16 / 256;        // 16-byte loader slots per thread (11)
-constexpr int S_WSTEP = 6 * 64;                  // uint4 per (ky, kx, channel chunk): [column tile 2][term 3][lane 64]
-constexpr int S_PREP_UINT4 = 16 * 4 * S_WSTEP;   // 393 216 bytes
+constexpr int S_WSTEP2 = 6 * 64;                 // uint4 per (ky, kx, channel chunk) with two row tiles: [row tile][term 3][lane 64]
+constexpr int S_PREP_UINT4 = 16 * 4 * S_WSTEP2;  // 393 216 bytes (half of it for narrow outputs, one row tile)
 
 struct ConvStage {
     Operand src;                 // [n][sh][sw][64]
-    int n, sh, sw, oh, ow;
+    int n, sh, sw, oh, ow, q;    // q output channels: 64 (two 32-row MFMA tiles) or <= 32 (one, rows >= q are zero weights)
     int sgn, dmin;               // source coordinate = output coordinate + dmin + j, j = tap index if sgn > 0 else 3 - tap index
     int rows, groups;            // output rows per tile, tiles per image
     const uint4 *wprep;
@@ -52,19 +52,24 @@ struct ConvStage {
 
 // wt = nn.Conv2d / nn.ConvTranspose2d weights [a][b][ky][kx]; (q, c) = (a, b) for the Conv2d-forward direction, (b, a) for
 // the transposed one.  One thread = one (ky, kx, chunk, column tile, lane) = 8 reduction channels of one output channel.
-__global__ __launch_bounds__(256) void conv64s_weight_prep_kernel(const float *__restrict__ wt, uint4 *__restrict__ out, int transposed) {
-    const int i = blockIdx.x * 256 + threadIdx.x;              // ((tap * 4 + c16) * 2 + nt) * 64 + lane
-    const int lane = i & 63, nt = (i >> 6) & 1, c16 = (i >> 7) & 3, tap = i >> 9;
+__global__ __launch_bounds__(256) void conv64s_weight_prep_kernel(const float *__restrict__ wt, uint4 *__restrict__ out, int transposed,
+                                                                   int q_count, int nt_count) {
+    const int i = blockIdx.x * 256 + threadIdx.x;              // ((tap * 4 + c16) * nt_count + nt) * 64 + lane
+    const int lane = i & 63, rest = i >> 6, nt = rest % nt_count, c16 = (rest / nt_count) & 3, tap = rest / (4 * nt_count);
     const int q = nt * 32 + (lane & 31), c0 = c16 * 16 + 8 * (lane >> 5);
+    const int qc = q < q_count ? q : 0;
     float x[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = transposed ? wt[((c0 + j) * 64 + q) * 16 + tap] : wt[(q * 64 + c0 + j) * 16 + tap];
+    for (int j = 0; j < 8; ++j) {
+        const float v = transposed ? wt[((c0 + j) * q_count + qc) * 16 + tap] : wt[(qc * 64 + c0 + j) * 16 + tap];
+        x[j] = q < q_count ? v : 0.f;
+    }
     uint4 h, m, l;
     rg_split3(x[0], x[1], h.x, m.x, l.x);
     rg_split3(x[2], x[3], h.y, m.y, l.y);
     rg_split3(x[4], x[5], h.z, m.z, l.z);
     rg_split3(x[6], x[7], h.w, m.w, l.w);
-    uint4 *d = out + ((tap * 4 + c16) * 2 + nt) * 3 * 64 + lane;
+    uint4 *d = out + ((tap * 4 + c16) * nt_count + nt) * 3 * 64 + lane;
     d[0] = h; d[64] = m; d[128] = l;
 }
 
@@ -77,8 +82,9 @@ __device__ __forceinline__ float act_fwd_hw(float x, int act) {
 }
 
 // MODE = Operand::mode() of the source: 0 plain, 1 activation derivative from the saved output, 2 also the keep-mask
-template <int MT, int MODE>
+template <int MT, int NT, int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv64s_kernel(ConvStage g) {
+    constexpr int S_WSTEP = NT * 3 * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned lds[];          // 2 x S_BUF
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, rc = lane & 31;
@@ -149,10 +155,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
     }
     const int ky = g.sgn > 0 ? wave : 3 - wave;
-    float4 b4[2];
+    // this wave's share of the outputs after the exchange: channels nt * 32 + 8 wave + 4 half + j
+    float4 b4[NT];
+    bool ch_ok[NT];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-        b4[nt] = g.bias != nullptr ? *reinterpret_cast<const float4 *>(g.bias + nt * 32 + 8 * wave + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int nt = 0; nt < NT; ++nt) {
+        ch_ok[nt] = nt * 32 + 8 * wave + 4 * half < g.q;
+        b4[nt] = (g.bias != nullptr && ch_ok[nt]) ? *reinterpret_cast<const float4 *>(g.bias + nt * 32 + 8 * wave + 4 * half)
+                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 
     // first tile -> buffer 0
     __syncthreads();
@@ -161,12 +172,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __syncthreads();
     // weight operands: a ring of three register sets, two reduction steps ahead of the MFMAs (the 393 KB of split weights live
     // in L2: one step = ~0.75 us is not enough to cover that round trip under load)
-    bf16x8 w3[3][2][3];
+    bf16x8 w3[3][NT][3];
     auto load_w = [&](auto rc_, int kx, int c16) __attribute__((always_inline)) {
         constexpr int r = decltype(rc_)::value;
         const uint4 *wp = g.wprep + ((ky * 4 + kx) * 4 + c16) * S_WSTEP + wlane;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int t = 0; t < 3; ++t) w3[r][nt][t] = __builtin_bit_cast(bf16x8, wp[(nt * 3 + t) * 64]);
     };
@@ -179,11 +190,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         asm volatile("" : "+v"(q4), "+v"(pix0), "+v"(wlane));
         const unsigned *xb = lds + cur * S_BUF;
         unsigned *nb = lds + (cur ^ 1) * S_BUF;
-        f32x16 acc[MT][2];
+        f32x16 acc[MT][NT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
         bf16x8 x3[2][MT][3];
@@ -220,7 +231,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             // (weight term, pixel term) of the six partial products, smallest first, round-robin over the accumulators
 #define ARVAE_C64S_PRODUCT(TW, TX)                                                                   \
             _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                        \
-                _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) MFMA_B(acc[mt][nt], w3[wr][nt][TW], x3[cu][mt][TX]);
+                _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) MFMA_B(acc[mt][nt], w3[wr][nt][TW], x3[cu][mt][TX]);
             ARVAE_C64S_PRODUCT(2, 0)
             ARVAE_C64S_PRODUCT(0, 2)
             ARVAE_C64S_PRODUCT(1, 1)
@@ -239,16 +250,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
             if constexpr (step + 2 < 16) {
 #pragma unroll
-                for (int i_ = 0; i_ < 6; ++i_) {
+                for (int i_ = 0; i_ < 3 * NT; ++i_) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 }
             }
             // the loader's vector-ALU work (address arithmetic, three-term split) and LDS writes: a few per MFMA
             {
-                constexpr int used = (step + 1 < 16 ? 3 * MT : 0) + (step + 2 < 16 ? 6 : 0);
+                constexpr int used = (step + 1 < 16 ? 3 * MT : 0) + (step + 2 < 16 ? 3 * NT : 0);
 #pragma unroll
-                for (int i_ = used; i_ < 12 * MT; ++i_) {
+                for (int i_ = used; i_ < 6 * NT * MT; ++i_) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
                     __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
@@ -260,15 +271,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         load_w(std::integral_constant<int, 1>{}, kx_first, 1);
         // keep-mask bytes of this wave's share of the outputs: fetched now, used after the exchange
         const int img = tile / g.groups, oy0 = (tile - img * g.groups) * g.rows;
-        unsigned km[MT][2];
+        unsigned km[MT][NT];
         if (g.mask != nullptr) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
+                for (int nt = 0; nt < NT; ++nt) {
                     const int P = opix[mt];
-                    const bool ok = P >= 0 && oy0 + P / g.ow < g.oh;
-                    const int64_t o = ok ? (((int64_t)img * g.oh + oy0) * g.ow + P) * 64 + nt * 32 + 8 * wave + 4 * half : 0;
+                    const bool ok = P >= 0 && oy0 + P / g.ow < g.oh && ch_ok[nt];
+                    const int64_t o = ok ? (((int64_t)img * g.oh + oy0) * g.ow + P) * g.q + nt * 32 + 8 * wave + 4 * half : 0;
                     km[mt][nt] = *reinterpret_cast<const unsigned *>(g.mask + o);
                 }
         }
@@ -278,7 +289,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         //      4 w .. 4 w + 3 (channels 8 w + 4 half + j) of every tile; one column tile at a time (the buffer is 70 KB)
         float4 *xch = reinterpret_cast<float4 *>(lds + cur * S_BUF);
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
             for (int o = 1; o < 4; ++o) {                        // to owner gw = (wave + o) & 3, as its source number 3 - o
                 const int gw = (wave + o) & 3;
@@ -298,8 +309,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
                 const int P = opix[mt];
                 const int r = P / g.ow;
-                if (P >= 0 && oy0 + r < g.oh) {
-                    const int64_t o = (((int64_t)img * g.oh + oy0) * g.ow + P) * 64 + nt * 32 + 8 * wave + 4 * half;
+                if (P >= 0 && oy0 + r < g.oh && ch_ok[nt]) {
+                    const int64_t o = (((int64_t)img * g.oh + oy0) * g.ow + P) * g.q + nt * 32 + 8 * wave + 4 * half;
                     v.x = act_fwd_hw(v.x + b4[nt].x, g.act); v.y = act_fwd_hw(v.y + b4[nt].y, g.act);
                     v.z = act_fwd_hw(v.z + b4[nt].z, g.act); v.w = act_fwd_hw(v.w + b4[nt].w, g.act);
                     if (g.mask != nullptr) {
@@ -338,48 +349,53 @@ static bool stage_geometry(int ow, int sw, int &rows, int &mt) {
 
 int64_t conv64s_ws_floats() { return S_PREP_UINT4 * 4; }
 
-// 64 -> 64 channels, 4x4 taps, stride 1, channels-last without permutation, a row group that fits the staging buffers
+// 64 source channels, 64 or 4..32 (a multiple of 4) output channels, 4x4 taps, stride 1, channels-last without permutation,
+// a row group that fits the staging buffers
 bool conv64s_fits(const arvae_link_t *l, bool up) {
     static const bool off = getenv("ARVAE_CONV64_NO_STAGE") != nullptr;      // diagnostic: the gathering kernel instead
     int rows, mt;
-    const int ow = up ? l->hw : l->lw, sw = up ? l->lw : l->hw;
-    return !off && l->stride == 1 && l->kh == 4 && l->kw == 4 && l->chi == 64 && l->clo == 64 && l->hi_perm_c == 0 &&
-           l->lo_perm_c == 0 && stage_geometry(ow, sw, rows, mt);
+    const int ow = up ? l->hw : l->lw, sw = up ? l->lw : l->hw, cs = up ? l->clo : l->chi, q = up ? l->chi : l->clo;
+    return !off && l->stride == 1 && l->kh == 4 && l->kw == 4 && cs == 64 && (q == 64 || (q <= 32 && q >= 4 && (q & 3) == 0)) &&
+           l->hi_perm_c == 0 && l->lo_perm_c == 0 && stage_geometry(ow, sw, rows, mt);
 }
 
-template <int MT> static void launch_stage(const ConvStage &g, int grid, hipStream_t s) {
+template <int MT, int NT> static void launch_stage(const ConvStage &g, int grid, hipStream_t s) {
     constexpr int LDS = 2 * S_BUF * 4;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void *)conv64s_kernel<MT, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        (void)hipFuncSetAttribute((const void *)conv64s_kernel<MT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        (void)hipFuncSetAttribute((const void *)conv64s_kernel<MT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void *)conv64s_kernel<MT, NT, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void *)conv64s_kernel<MT, NT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void *)conv64s_kernel<MT, NT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr = true;
     }
     const int mode = (g.src.y == nullptr || (g.src.act == ARVAE_ACT_NONE && g.src.mask == nullptr)) ? 0 : g.src.mode();
-    if (mode == 0) ARVAE_LAUNCH((conv64s_kernel<MT, 0>), dim3(grid), dim3(256), LDS, s, g);
-    else if (mode == 1) ARVAE_LAUNCH((conv64s_kernel<MT, 1>), dim3(grid), dim3(256), LDS, s, g);
-    else ARVAE_LAUNCH((conv64s_kernel<MT, 2>), dim3(grid), dim3(256), LDS, s, g);
+    if (mode == 0) ARVAE_LAUNCH((conv64s_kernel<MT, NT, 0>), dim3(grid), dim3(256), LDS, s, g);
+    else if (mode == 1) ARVAE_LAUNCH((conv64s_kernel<MT, NT, 1>), dim3(grid), dim3(256), LDS, s, g);
+    else ARVAE_LAUNCH((conv64s_kernel<MT, NT, 2>), dim3(grid), dim3(256), LDS, s, g);
 }
 
-// src [n][sh][sw][64] -> out [n][oh][ow][64]; source coordinate = output coordinate + sgn * k + off
-int conv64s_run(const Operand &src, int n, int sh, int sw, int oh, int ow, int sgn, int off, const float *wt, bool transposed,
+// src [n][sh][sw][64] -> out [n][oh][ow][q]; source coordinate = output coordinate + sgn * k + off
+int conv64s_run(const Operand &src, int n, int sh, int sw, int oh, int ow, int q, int sgn, int off, const float *wt, bool transposed,
                 const float *bias, int act, const uint8_t *mask, float *out, float *ws, hipStream_t s, const char *what) {
     if (ws == nullptr || (reinterpret_cast<uintptr_t>(ws) & 15) != 0)
         return fail(ARVAE_E_INVALID, "%s: needs arvae_link_ws_floats() floats of 16-byte aligned workspace for the split weights", what);
     ConvStage g{};
     int mt = 0;
     if (!stage_geometry(ow, sw, g.rows, mt)) return fail(ARVAE_E_INVALID, "%s: no staging geometry", what);
-    g.src = src; g.n = n; g.sh = sh; g.sw = sw; g.oh = oh; g.ow = ow;
+    g.src = src; g.n = n; g.sh = sh; g.sw = sw; g.oh = oh; g.ow = ow; g.q = q;
     g.sgn = sgn; g.dmin = sgn > 0 ? off : off - 3;
     g.groups = (oh + g.rows - 1) / g.rows;
     g.wprep = reinterpret_cast<const uint4 *>(ws);
     g.bias = bias; g.mask = mask; g.act = act; g.out = out;
-    ARVAE_LAUNCH(conv64s_weight_prep_kernel, dim3(16 * 4 * 2 * 64 / 256), dim3(256), 0, s, wt, reinterpret_cast<uint4 *>(ws), transposed ? 1 : 0);
+    const int nt = q > 32 ? 2 : 1;
+    ARVAE_LAUNCH(conv64s_weight_prep_kernel, dim3(16 * 4 * nt * 64 / 256), dim3(256), 0, s, wt, reinterpret_cast<uint4 *>(ws),
+                 transposed ? 1 : 0, q, nt);
     const int tiles = n * g.groups, cus = cu_count_s();
     const int grid = tiles < cus ? tiles : cus;
-    if (mt == 4) launch_stage<4>(g, grid, s);
-    else launch_stage<3>(g, grid, s);
+    if (mt == 4 && nt == 2) launch_stage<4, 2>(g, grid, s);
+    else if (mt == 3 && nt == 2) launch_stage<3, 2>(g, grid, s);
+    else if (mt == 4) launch_stage<4, 1>(g, grid, s);
+    else launch_stage<3, 1>(g, grid, s);
     return check_launch(what);
 }
 
