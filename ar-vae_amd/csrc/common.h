@@ -140,6 +140,14 @@ struct Operand {
     }
     __host__ __device__ __forceinline__ int mode() const { return y == nullptr ? 0 : (mask == nullptr ? 1 : 2); }
 };
+// "gate" of a data-gradient epilogue in the general form: the saved OUTPUT y of the layer that produced the tensor the gradient
+// belongs to, that layer's activation and its dropout keep-mask.  result *= act'(y) * (mask ? 2 mask : 1): the gradient leaves
+// the kernel already w.r.t. the producer's pre-activation.
+struct GateOp {
+    const float *y = nullptr;
+    const uint8_t *mask = nullptr;
+    int act = 0;
+};
 static inline Operand make_operand(const arvae_operand_t *o) { return Operand{o->v, o->y, o->mask, o->act}; }
 
 // relu_bits16: sign bits of a 32-channel ReLU output, the compact form of a "gate" for the data-gradient kernels.

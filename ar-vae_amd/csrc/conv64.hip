@@ -27,6 +27,7 @@ struct ConvRows {
     const uint8_t *mask;
     int act;
     float *out;                  // [n][oh][ow][q]
+    GateOp gate;                 // data-gradient launches: result *= act'(gate.y) * 2 gate.mask at the output location
 };
 
 // value of a gradient operand (activation derivative of the saved output, keep-mask) for 4 consecutive channels
@@ -133,6 +134,11 @@ __global__ __launch_bounds__(256) void conv_rows_x3_kernel(ConvRows g) {
             const int64_t o = (int64_t)p * g.q + q;
             float v = act_fwd(acc[r] + bias, g.act);
             if (g.mask != nullptr) v *= 2.f * (float)g.mask[o];
+            if (g.gate.y != nullptr) {
+                // (the saved output of a dropout layer is the kept activation times two: Operand::apply)
+                v *= act_bwd_from_out_sel(g.gate.mask != nullptr ? 0.5f * g.gate.y[o] : g.gate.y[o], g.gate.act);
+                if (g.gate.mask != nullptr) v *= 2.f * (float)g.gate.mask[o];
+            }
             g.out[o] = v;
         }
     }
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(256) void conv64_weight_prep_kernel(const float *__
 int64_t conv64s_ws_floats();
 bool conv64s_fits(const arvae_link_t *l, bool up);
 int conv64s_run(const Operand &src, int n, int sh, int sw, int oh, int ow, int q, int sgn, int off, const float *wt, bool transposed,
-                const float *bias, int act, const uint8_t *mask, float *out, float *ws, hipStream_t s, const char *what);
+                const float *bias, int act, const uint8_t *mask, float *out, float *ws, hipStream_t s, const char *what, const GateOp *gate);
 
 int64_t conv64_ws_floats(const arvae_link_t *l) {
     const int64_t packed = ((int64_t)l->kh * l->kw * l->chi * l->clo + 3) / 4 * 4;
@@ -193,10 +199,11 @@ static int launch_conv_rows(ConvRows g, const float *wt, bool transposed, float 
 
 // lo[n][lh][lw][clo] = act(conv(hi) + bias) * mask     (Conv2d forward / ConvTranspose2d data gradient)
 int conv64_down(const arvae_link_t *l, const Operand &hi, const float *wt, const float *bias, int act, const uint8_t *mask,
-                float *lo, float *ws, hipStream_t s) {
+                float *lo, float *ws, hipStream_t s, const GateOp *gate) {
     if (conv64s_fits(l, false))
-        return conv64s_run(hi, l->n, l->hh, l->hw, l->lh, l->lw, l->clo, 1, -l->pad, wt, false, bias, act, mask, lo, ws, s, "conv64_down");
+        return conv64s_run(hi, l->n, l->hh, l->hw, l->lh, l->lw, l->clo, 1, -l->pad, wt, false, bias, act, mask, lo, ws, s, "conv64_down", gate);
     ConvRows g{};
+    if (gate != nullptr) g.gate = *gate;
     g.src = hi; g.n = l->n; g.sh = l->hh; g.sw = l->hw; g.cs = l->chi;
     g.oh = l->lh; g.ow = l->lw; g.q = l->clo;
     g.kh = l->kh; g.kw = l->kw; g.sgn = 1; g.off = -l->pad;
@@ -206,10 +213,11 @@ int conv64_down(const arvae_link_t *l, const Operand &hi, const float *wt, const
 
 // hi[n][hh][hw][chi] = act(convT(lo) + bias) * mask    (ConvTranspose2d forward / Conv2d data gradient)
 int conv64_up(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, int act, const uint8_t *mask,
-              float *hi, float *ws, hipStream_t s) {
+              float *hi, float *ws, hipStream_t s, const GateOp *gate) {
     if (conv64s_fits(l, true))
-        return conv64s_run(lo, l->n, l->lh, l->lw, l->hh, l->hw, l->chi, -1, l->pad, wt, true, bias, act, mask, hi, ws, s, "conv64_up");
+        return conv64s_run(lo, l->n, l->lh, l->lw, l->hh, l->hw, l->chi, -1, l->pad, wt, true, bias, act, mask, hi, ws, s, "conv64_up", gate);
     ConvRows g{};
+    if (gate != nullptr) g.gate = *gate;
     g.src = lo; g.n = l->n; g.sh = l->lh; g.sw = l->lw; g.cs = l->clo;
     g.oh = l->hh; g.ow = l->hw; g.q = l->chi;
     g.kh = l->kh; g.kw = l->kw; g.sgn = -1; g.off = l->pad;

@@ -47,7 +47,8 @@ struct ConvStage {
     const float *bias;
     const uint8_t *mask;
     int act;
-    float *out;                  // [n][oh][ow][64]
+    float *out;                  // [n][oh][ow][q]
+    GateOp gate;                 // data-gradient launches: result *= act'(gate.y) * 2 gate.mask at the output location
 };
 
 // wt = nn.Conv2d / nn.ConvTranspose2d weights [a][b][ky][kx]; (q, c) = (a, b) for the Conv2d-forward direction, (b, a) for
@@ -197,6 +198,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+        // keep-mask bytes / gate values of this wave's share of the outputs: requested in reduction step 11 (a lane's 16 bytes
+        // sit 256 bytes from its neighbour's: slow, scattered requests with a full memory round trip), used after the exchange
+        const int img = tile / g.groups, oy0 = (tile - img * g.groups) * g.rows;
+        unsigned km[MT][NT];
+        float4 gy[MT][NT];
+        auto fetch_epilogue = [&]() __attribute__((always_inline)) {
+            if (g.gate.y != nullptr) {                               // gate values too (the keep-mask slot then holds the gate's mask)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int P = opix[mt];
+                        const bool ok = P >= 0 && oy0 + P / g.ow < g.oh && ch_ok[nt];
+                        const int64_t o = ok ? (((int64_t)img * g.oh + oy0) * g.ow + P) * g.q + nt * 32 + 8 * wave + 4 * half : 0;
+                        gy[mt][nt] = *reinterpret_cast<const float4 *>(g.gate.y + o);
+                        km[mt][nt] = g.gate.mask != nullptr ? *reinterpret_cast<const unsigned *>(g.gate.mask + o) : 0x01010101u;
+                    }
+            } else if (g.mask != nullptr) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int P = opix[mt];
+                        const bool ok = P >= 0 && oy0 + P / g.ow < g.oh && ch_ok[nt];
+                        const int64_t o = ok ? (((int64_t)img * g.oh + oy0) * g.ow + P) * g.q + nt * 32 + 8 * wave + 4 * half : 0;
+                        km[mt][nt] = *reinterpret_cast<const unsigned *>(g.mask + o);
+                    }
+            }
+        };
         bf16x8 x3[2][MT][3];
         // pixel operands of reduction step 0 (jx = 0, chunk 0)
 #pragma unroll
@@ -228,6 +258,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 if constexpr (s * 12 / S_SLOTS == step) issue(s, tile + gridDim.x);
                 if constexpr (s * 12 / S_SLOTS + 4 == step) commit(s, nb);
             });
+            if constexpr (step == 11) fetch_epilogue();
             // (weight term, pixel term) of the six partial products, smallest first, round-robin over the accumulators
 #define ARVAE_C64S_PRODUCT(TW, TX)                                                                   \
             _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                        \
@@ -269,20 +300,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         });
         load_w(std::integral_constant<int, 0>{}, kx_first, 0);   // the next tile's first two steps: the exchange hides them
         load_w(std::integral_constant<int, 1>{}, kx_first, 1);
-        // keep-mask bytes of this wave's share of the outputs: fetched now, used after the exchange
-        const int img = tile / g.groups, oy0 = (tile - img * g.groups) * g.rows;
-        unsigned km[MT][NT];
-        if (g.mask != nullptr) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const int P = opix[mt];
-                    const bool ok = P >= 0 && oy0 + P / g.ow < g.oh && ch_ok[nt];
-                    const int64_t o = ok ? (((int64_t)img * g.oh + oy0) * g.ow + P) * g.q + nt * 32 + 8 * wave + 4 * half : 0;
-                    km[mt][nt] = *reinterpret_cast<const unsigned *>(g.mask + o);
-                }
-        }
         __syncthreads();                                         // every read of this buffer is done; the next tile is staged
 
         // ---- the four kernel rows' partial sums meet in this tile's buffer: wave w finishes accumulator registers
@@ -313,7 +330,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     const int64_t o = (((int64_t)img * g.oh + oy0) * g.ow + P) * g.q + nt * 32 + 8 * wave + 4 * half;
                     v.x = act_fwd_hw(v.x + b4[nt].x, g.act); v.y = act_fwd_hw(v.y + b4[nt].y, g.act);
                     v.z = act_fwd_hw(v.z + b4[nt].z, g.act); v.w = act_fwd_hw(v.w + b4[nt].w, g.act);
-                    if (g.mask != nullptr) {
+                    if (g.gate.y != nullptr) {
+                        const unsigned m = km[mt][nt];
+                        // (the saved output of a dropout layer is the kept activation times two: Operand::apply)
+                        const float k2 = g.gate.mask != nullptr ? 2.f : 1.f, ys = g.gate.mask != nullptr ? 0.5f : 1.f;
+                        v.x *= act_bwd_from_out_sel(ys * gy[mt][nt].x, g.gate.act) * k2 * (float)(m & 255u);
+                        v.y *= act_bwd_from_out_sel(ys * gy[mt][nt].y, g.gate.act) * k2 * (float)((m >> 8) & 255u);
+                        v.z *= act_bwd_from_out_sel(ys * gy[mt][nt].z, g.gate.act) * k2 * (float)((m >> 16) & 255u);
+                        v.w *= act_bwd_from_out_sel(ys * gy[mt][nt].w, g.gate.act) * k2 * (float)(m >> 24);
+                    } else if (g.mask != nullptr) {
                         const unsigned m = km[mt][nt];
                         v.x *= 2.f * (float)(m & 255u); v.y *= 2.f * (float)((m >> 8) & 255u);
                         v.z *= 2.f * (float)((m >> 16) & 255u); v.w *= 2.f * (float)(m >> 24);
@@ -376,7 +401,7 @@ template <int MT, int NT> static void launch_stage(const ConvStage &g, int grid,
 
 // src [n][sh][sw][64] -> out [n][oh][ow][q]; source coordinate = output coordinate + sgn * k + off
 int conv64s_run(const Operand &src, int n, int sh, int sw, int oh, int ow, int q, int sgn, int off, const float *wt, bool transposed,
-                const float *bias, int act, const uint8_t *mask, float *out, float *ws, hipStream_t s, const char *what) {
+                const float *bias, int act, const uint8_t *mask, float *out, float *ws, hipStream_t s, const char *what, const GateOp *gate) {
     if (ws == nullptr || (reinterpret_cast<uintptr_t>(ws) & 15) != 0)
         return fail(ARVAE_E_INVALID, "%s: needs arvae_link_ws_floats() floats of 16-byte aligned workspace for the split weights", what);
     ConvStage g{};
@@ -387,6 +412,7 @@ int conv64s_run(const Operand &src, int n, int sh, int sw, int oh, int ow, int q
     g.groups = (oh + g.rows - 1) / g.rows;
     g.wprep = reinterpret_cast<const uint4 *>(ws);
     g.bias = bias; g.mask = mask; g.act = act; g.out = out;
+    if (gate != nullptr) g.gate = *gate;
     const int nt = q > 32 ? 2 : 1;
     ARVAE_LAUNCH(conv64s_weight_prep_kernel, dim3(16 * 4 * nt * 64 / 256), dim3(256), 0, s, wt, reinterpret_cast<uint4 *>(ws),
                  transposed ? 1 : 0, q, nt);

@@ -40,9 +40,9 @@ int conv_c1_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &img, 
 bool conv64_fits(const arvae_link_t *l, bool up);
 int64_t conv64_ws_floats(const arvae_link_t *l);
 int conv64_down(const arvae_link_t *l, const Operand &hi, const float *wt, const float *bias, int act, const uint8_t *mask,
-                float *lo, float *ws, hipStream_t s);
+                float *lo, float *ws, hipStream_t s, const GateOp *gate);
 int conv64_up(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, int act, const uint8_t *mask,
-              float *hi, float *ws, hipStream_t s);
+              float *hi, float *ws, hipStream_t s, const GateOp *gate);
 bool conv64_wgrad_fits(const arvae_link_t *l);
 int64_t conv64_wgrad_ws_floats(const arvae_link_t *l);
 int conv64_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *dwt, float *ws, hipStream_t s);
@@ -706,7 +706,7 @@ extern "C" int arvae_link_down(const arvae_link_t *link, const arvae_operand_t *
         hi->act != ARVAE_ACT_SELU)
         return conv_c1_down(link, make_operand(hi), wt, bias, out_act == ARVAE_ACT_RELU, nullptr, nullptr, nullptr, lo, as_stream(stream));
     if (conv64_fits(link, false))
-        return conv64_down(link, make_operand(hi), wt, bias, out_act, out_mask, lo, ws, as_stream(stream));
+        return conv64_down(link, make_operand(hi), wt, bias, out_act, out_mask, lo, ws, as_stream(stream), nullptr);
     if (single_channel_mfma_fits(link)) {
         ARVAE_LAUNCH(down_single_channel_mfma_kernel, dim3(link->n), dim3(256), sizeof(float) * link->hh * link->hw,
                            as_stream(stream), p.g, make_operand(hi), wt, Epilogue{bias, out_mask, lo, out_act});
@@ -748,7 +748,7 @@ extern "C" int arvae_link_up(const arvae_link_t *link, const arvae_operand_t *lo
     if (conv_c1_fits(link) && lo->y == nullptr && out_mask == nullptr && out_act == ARVAE_ACT_NONE)
         return conv_c1_up(link, lo->v, wt, bias, hi, st);
     if (conv64_fits(link, true))
-        return conv64_up(link, make_operand(lo), wt, bias, out_act, out_mask, hi, ws, st);
+        return conv64_up(link, make_operand(lo), wt, bias, out_act, out_mask, hi, ws, st, nullptr);
     if (link->chi == 1 && lo->y == nullptr && link->clo % 4 == 0 && link->lo_perm_c == 0) {
         const int total = link->n * link->hh * link->hw;
         Epilogue ep{bias, out_mask, hi, out_act};

@@ -11,6 +11,11 @@ namespace arvae {
 bool conv32_fits(const arvae_link_t *l);
 bool conv_c1_fits(const arvae_link_t *l);
 bool conv64_fits(const arvae_link_t *l, bool up);
+bool conv64s_fits(const arvae_link_t *l, bool up);
+int conv64_down(const arvae_link_t *l, const Operand &hi, const float *wt, const float *bias, int act, const uint8_t *mask,
+                float *lo, float *ws, hipStream_t s, const GateOp *gate);
+int conv64_up(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, int act, const uint8_t *mask,
+              float *hi, float *ws, hipStream_t s, const GateOp *gate);
 int conv32_down(const arvae_link_t *l, const Operand &hi, const float *wt, const float *bias, int relu, const float *gate,
                 const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s, const float *wprep = nullptr);
 int conv32_up(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, int relu, const float *gate,
@@ -248,12 +253,14 @@ static SideStream *side_stream(bool force = false) {
 //   gate   : when non-null, the saved ReLU output of the PRODUCER of `in`; the data gradient is then
 //            written as d_in * (gate > 0), i.e. already w.r.t. the producer's pre-activation, so that the
 //            producer's dgrad and wgrad read ONE plain tensor instead of re-deriving ReLU' twice.
+//   gate_op: the same for any activation / dropout mask of that producer (GateOp, common.h); honoured by the wide stride-1
+//            convolution kernels (conv64.hip), which then also spare the next layer its in-place operand pass
 //   *gated : set when the gate was applied (a fast kernel with a gated epilogue was available)
 static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params, float *grads, const float *in,
                           const float *out, const uint8_t *mask, const float *g, bool g_is_pre, const float *gate,
                           float *d_in, bool *gated, float *slab, float *link_ws, DenseWgradBatch *defer, float *own_slab,
                           SlabReduceBatch *rdefer, arvae_stream_t st, const float *g_scale = nullptr,
-                          const uint16_t *gate_bits = nullptr, const float *wprep = nullptr) {
+                          const uint16_t *gate_bits = nullptr, const float *wprep = nullptr, const GateOp *gate_op = nullptr) {
     arvae_link_t lk = l.link;
     lk.n = n;
     arvae_operand_t gop = g_is_pre ? plain(g) : arvae_operand_t{g, out, mask, l.act};
@@ -286,6 +293,9 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
                 g_op.scale = g_scale;
                 rc = conv_c1_down(&lk, g_op, w, nullptr, 0, gate_bits ? nullptr : gate, gate_bits, nullptr, d_in, hs);
                 *gated = true;
+            } else if (gate_op != nullptr && conv64s_fits(&lk, false)) {       // (the gathering kernel's scattered epilogue loses more than the operand pass costs)
+                rc = conv64_down(&lk, make_operand(&gop), w, nullptr, ARVAE_ACT_NONE, nullptr, d_in, link_ws, hs, gate_op);
+                *gated = true;
             } else {
                 rc = arvae_link_down(&lk, &gop, w, nullptr, ARVAE_ACT_NONE, nullptr, d_in, link_ws, st);
             }
@@ -296,6 +306,9 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
                 *gated = true;
             } else if (gate != nullptr && dense_fits(&lk)) {
                 rc = dense_dgrad(&lk, make_operand(&gop), w, gate, d_in, hs);
+                *gated = true;
+            } else if (gate_op != nullptr && conv64s_fits(&lk, true)) {
+                rc = conv64_up(&lk, make_operand(&gop), w, nullptr, ARVAE_ACT_NONE, nullptr, d_in, link_ws, hs, gate_op);
                 *gated = true;
             } else {
                 rc = arvae_link_up(&lk, &gop, w, nullptr, ARVAE_ACT_NONE, nullptr, d_in, link_ws, st);
@@ -494,6 +507,13 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
     auto relu_gate = [&](const arvae_layer_t &producer, int mask_idx, const float *saved) -> const float * {
         return (producer.act == ARVAE_ACT_RELU && mask_of(mask_idx) == nullptr) ? saved : nullptr;
     };
+    // the general form (any activation, dropout): used where relu_gate() has nothing to offer
+    auto general_gate = [&](const arvae_layer_t &producer, int mask_idx, const float *saved, GateOp &go) -> const GateOp * {
+        if (producer.act == ARVAE_ACT_NONE && mask_of(mask_idx) == nullptr) return nullptr;
+        if (producer.act == ARVAE_ACT_RELU && mask_of(mask_idx) == nullptr) return nullptr;      // relu_gate covers it
+        go.y = saved; go.mask = mask_of(mask_idx); go.act = producer.act;
+        return &go;
+    };
     bool pre = true;                                     // the last decoder layer has no activation
     {
         const int li = m->n_dec - 1;
@@ -517,6 +537,8 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
         const float *in = i > 0 ? ws + L.dec_out[i - 1] : z;
         const float *out = (i + 1 < m->n_dec) ? ws + L.dec_out[i] : logits;
         const float *gate = i > 0 ? relu_gate(m->dec[i - 1], dec_mask[i - 1], in) : nullptr;
+        GateOp go;
+        const GateOp *gate_op = i > 0 ? general_gate(m->dec[i - 1], dec_mask[i - 1], in, go) : nullptr;
         float *dst = grad_dst(i > 0 ? L.dec_keep[i - 1] : -1, cur);
         bool gated = false;
         sync_side();                                     // this layer's incoming gradient is ready
@@ -525,7 +547,7 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
                                     i == m->n_dec - 1 ? first_scale : nullptr,
                                     (gate != nullptr && i > 0 && L.dec_bits[i - 1] >= 0)
                                         ? reinterpret_cast<const uint16_t *>(ws + L.dec_bits[i - 1]) : nullptr,
-                                    L.dec_wprep[i] >= 0 ? ws + L.dec_wprep[i] : nullptr))
+                                    L.dec_wprep[i] >= 0 ? ws + L.dec_wprep[i] : nullptr, gate_op))
             return rc;
         pre = gated;
         cur = dst;
@@ -619,6 +641,8 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
     for (int i = enc_from; i >= 0; --i) {
         const float *in = i > 0 ? ws + L.enc_out[i - 1] : x;
         const float *gate = i > 0 ? relu_gate(m->enc[i - 1], enc_mask[i - 1], in) : nullptr;
+        GateOp go;
+        const GateOp *gate_op = i > 0 ? general_gate(m->enc[i - 1], enc_mask[i - 1], in, go) : nullptr;
         float *dst = i > 0 ? grad_dst(L.enc_keep[i - 1], cur) : nullptr;
         bool gated = false;
         sync_side();
@@ -627,7 +651,7 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
                                     stream, nullptr,
                                     (gate != nullptr && i > 0 && L.enc_bits[i - 1] >= 0)
                                         ? reinterpret_cast<const uint16_t *>(ws + L.enc_bits[i - 1]) : nullptr,
-                                    L.enc_wprep[i] >= 0 ? ws + L.enc_wprep[i] : nullptr))
+                                    L.enc_wprep[i] >= 0 ? ws + L.enc_wprep[i] : nullptr, gate_op))
             return rc;
         pre = gated;
         cur = dst;
