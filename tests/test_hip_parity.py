@@ -171,6 +171,8 @@ def test_token_recon_golden(golden_dir, dev, b):
 CONV_CASES = [  # (n, hi, chi, clo, k, s, p, act)
     (3, 64, 1, 32, 4, 2, 1, 'relu'), (5, 32, 32, 32, 4, 2, 1, 'relu'), (9, 8, 32, 32, 4, 2, 1, 'relu'),
     (2, 28, 1, 64, 4, 1, 0, 'selu'), (2, 25, 64, 64, 4, 1, 0, 'selu'), (3, 22, 64, 8, 4, 1, 0, 'selu'),
+    # more row-group tiles than CUs: the persistent loop of the row-staged kernel (conv64s.hip), both of its tile shapes
+    (47, 25, 64, 64, 4, 1, 0, 'selu'), (70, 22, 64, 8, 4, 1, 0, 'none'), (3, 21, 64, 16, 4, 1, 0, 'relu'),
 ]
 
 
@@ -216,6 +218,7 @@ def test_conv_down_vs_torch(dev, case, use_mask):
 DECONV_CASES = [  # (n, lo, clo(in), chi(out), k, s, p, act)
     (4, 4, 32, 32, 4, 2, 1, 'relu'), (3, 16, 32, 32, 4, 2, 1, 'relu'), (2, 32, 32, 1, 4, 2, 1, 'none'),
     (2, 19, 8, 64, 4, 1, 0, 'selu'), (2, 22, 64, 64, 4, 1, 0, 'selu'), (3, 25, 64, 1, 4, 1, 0, 'none'),
+    (55, 22, 64, 64, 4, 1, 0, 'selu'), (3, 17, 64, 12, 4, 1, 0, 'relu'),
 ]
 
 
