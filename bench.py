@@ -69,19 +69,19 @@ KERNEL_WORK = {
 # the library's timeline labels one kernel FAMILY; these are the instantiations a rocprofv3 --kernel-trace of the
 # default build lists for it at B = 512 (profiles/*_kernel_stats.csv)
 ROCPROF_NAMES = {
-    'wgrad32_kernel<16>': ['arvae::wgrad32x_kernel<16, 1>', 'arvae::wgrad32x_kernel<16, 2>'],
+    'wgrad32_kernel<16>': ['arvae::wgrad32r_kernel<16, 1>', 'arvae::wgrad32r_kernel<16, 2>'],
     'up32_kernel<16>': ['arvae::up32x_kernel<16, 1, 128>', 'arvae::up32x_kernel<16, 3, 128>'],
     'down32_kernel<16>': ['arvae::down32x_kernel<16, 1>', 'arvae::down32x_kernel<16, 3>'],
-    'wgrad32_kernel<8>': ['arvae::wgrad32x_kernel<8, 1>', 'arvae::wgrad32x_kernel<8, 2>'],
+    'wgrad32_kernel<8>': ['arvae::wgrad32r_kernel<8, 1>', 'arvae::wgrad32r_kernel<8, 2>'],
     'up32_kernel<8>': ['arvae::up32x_kernel<8, 1, 32>', 'arvae::up32x_kernel<8, 3, 32>'],
     'down32_kernel<8>': ['arvae::down32x_kernel<8, 1>', 'arvae::down32x_kernel<8, 3>'],
     'wgrad32_kernel<4>': ['arvae::wgrad32x_kernel<4, 1>', 'arvae::wgrad32x_kernel<4, 2>'],
     'up32_kernel<4>': ['arvae::up32x_kernel<4, 1, 32>', 'arvae::up32x_kernel<4, 3, 32>'],
     'down32_kernel<4>': ['arvae::down32s_kernel<4, 1>', 'arvae::down32s_kernel<4, 2>'],
-    'down_c1_kernel': ['arvae::down_c1_kernel'], 'wgrad_c1_kernel': ['arvae::wgrad_c1_kernel'],
+    'down_c1_kernel': ['arvae::down_c1s_kernel<0>', 'arvae::down_c1s_kernel<1>'], 'wgrad_c1_kernel': ['arvae::wgrad_c1s_kernel'],
     'up_c1_kernel(recon)': ['arvae::up_c1_kernel<0, true>'],
-    'conv64_down': ['arvae::conv_rows_x3_kernel<true>', 'arvae::conv_rows_x3_kernel<false>'],
-    'conv64_up': ['arvae::conv_rows_x3_kernel<true>', 'arvae::conv_rows_x3_kernel<false>'],
+    'conv64_down': ['arvae::conv64s_kernel<3, 2, 0>', 'arvae::conv64s_kernel<3, 1, 0>'],
+    'conv64_up': ['arvae::conv64s_kernel<4, 2, 0>', 'arvae::conv_rows_x3_kernel<true>'],
     'conv64_wgrad(rows)': ['arvae::conv_wgrad_rows_x3_kernel'],
     'gru_seq_fwd_kernel': ['arvae::gru_seq_fwd_x3_kernel<128>'], 'gru_seq_bwd_kernel': ['arvae::gru_seq_bwd_x3_kernel<128>'],
     'tick_free_run_x3_kernel': ['arvae::tick_free_run_x3_kernel<128>'],

@@ -78,8 +78,12 @@ def test_argument_validation_without_gpu(lib):
     rc = lib.arvae_link_down(ctypes.byref(d), ctypes.byref(op), ctypes.c_void_p(16), None, 0, None,
                              ctypes.c_void_p(16), None, None)
     assert rc == -1 and b'does not match' in lib.arvae_last_error_string()
-    wide = LinkDesc(4, 25, 25, 64, 22, 22, 64, 4, 4, 1, 0, 0, 0, 0, 0)  # Morpho-MNIST 64 -> 64 k4 s1: re-ordered weights
-    assert lib.arvae_link_ws_floats(ctypes.byref(wide)) == 16 * 64 * 64
+    # Morpho-MNIST 64 -> 64 k4 s1: the row-staged kernel's weights as three bf16 terms in per-lane operand order (conv64s.hip)
+    wide = LinkDesc(4, 25, 25, 64, 22, 22, 64, 4, 4, 1, 0, 0, 0, 0, 0)
+    assert lib.arvae_link_ws_floats(ctypes.byref(wide)) == 16 * 64 * 64 * 3 // 2
+    # 8 -> 64 channels (reduction side 8): the gathering kernel's re-ordered fp32 copy
+    narrow = LinkDesc(4, 22, 22, 8, 19, 19, 64, 4, 4, 1, 0, 0, 0, 0, 0)
+    assert lib.arvae_link_ws_floats(ctypes.byref(narrow)) in (16 * 8 * 64, 16 * 64 * 64 * 3 // 2)
     assert lib.arvae_link_ws_floats(ctypes.byref(LinkDesc(4, 32, 32, 32, 16, 16, 32, 4, 4, 2, 1, 0, 0, 0, 0))) == 0
     assert lib.arvae_reg_loss_ws_floats(512, 5) == 2 * 512 * 5
     assert lib.arvae_adam_step(None, None, None, None, 0, 0, 1e-4, 0.9, 0.999, 1e-8, 1.0, None) == -1
