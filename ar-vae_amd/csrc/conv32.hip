@@ -529,9 +529,7 @@ __device__ __forceinline__ void split8x3(const float (&x)[8], bf16x8 &hi, bf16x8
 // per-lane register order of down32x_kernel and up32x_kernel, 16 bytes per (slot, lane) with lanes contiguous, so
 // that a kernel starts with 48 / 24 coalesced loads instead of staging and splitting the tensor itself.
 //   DOWN part: [kh 2][slot 48 = (tap 8, c 2, term 3)][lane 64]      UP part: [class 4][slot 24 = (ty, tx, c, term)][lane 64]
-constexpr int PREP_DOWN_SLOTS = 48, PREP_UP_SLOTS = 24;
-constexpr int PREP_DOWN_UINT4 = 2 * PREP_DOWN_SLOTS * 64, PREP_UP_UINT4 = 4 * PREP_UP_SLOTS * 64;
-constexpr int PREP_FLOATS = (PREP_DOWN_UINT4 + PREP_UP_UINT4) * 4;
+// (PREP_DOWN_SLOTS, PREP_UP_SLOTS, PREP_*_UINT4, PREP_FLOATS: conv32_common.h, shared with conv32k.hip)
 constexpr int PREP_MAX_LAYERS = 8;
 struct PrepArgs {
     const float *wt[PREP_MAX_LAYERS];
@@ -1483,8 +1481,17 @@ static int ep_mode(const Ep32 &ep, int relu) {
     return ep.gate_bits != nullptr ? EP_GATE_B : ep.gate != nullptr ? EP_GATE_F : relu ? EP_RELU : EP_PLAIN;
 }
 
+// (conv32k.hip: the weight-streaming kernel of the 16x16 / 8x8 layers; needs the prepared weights)
+bool conv32_down_stream_fits(const arvae_link_t *l, const Ep32 &ep);
+void conv32_down_stream(const arvae_link_t *l, const float *hi, const Ep32 &ep, int mode, hipStream_t s);
+
 template <int LO> static int launch_down(const arvae_link_t *l, const Operand &hi, const float *wt, const Ep32 &ep, int relu, hipStream_t s) {
     const int tiles = tiles_for<LO>(l->n), grid = grid_for_tiles(tiles);
+    static const bool other = getenv("ARVAE_CONV32_FP32") != nullptr || getenv("ARVAE_CONV32_BF16X2") != nullptr;
+    if (LO != 4 && !other && conv32_down_stream_fits(l, ep)) {
+        conv32_down_stream(l, hi.v, ep, ep_mode(ep, relu), s);
+        return check_launch(LO == 16 ? "down32_kernel<16>" : "down32_kernel<8>");
+    }
     switch (ep_mode(ep, relu)) {
         case EP_GATE_B: launch_down_v<LO, EP_GATE_B>(grid, hi, wt, ep, l->n, tiles, s); break;
         case EP_GATE_F: launch_down_v<LO, EP_GATE_F>(grid, hi, wt, ep, l->n, tiles, s); break;

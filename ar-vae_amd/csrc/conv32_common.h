@@ -115,6 +115,15 @@ __device__ __forceinline__ void split_pair3(float x0, float x1, unsigned &hi, un
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(q, bf16x2v));
 }
 
+// Per-layer prepared weights (conv32_weight_prep_kernel, conv32.hip, once per training step): the three-term split of wt in
+// per-lane MFMA operand order, 16 bytes per (slot, lane) with lanes contiguous.
+//   DOWN part: [kh 2][slot 48 = (tap 8 = kyl*4 + kx, c 2, term 3)][lane 64], ky = 2 kh + kyl: lane (rc, half) holds the input
+//              channels c*16 + half*8 + j of wt[clo = rc][.][ky][kx]
+//   UP part:   [class 4][slot 24 = (ty, tx, c, term)][lane 64]
+constexpr int PREP_DOWN_SLOTS = 48, PREP_UP_SLOTS = 24;
+constexpr int PREP_DOWN_UINT4 = 2 * PREP_DOWN_SLOTS * 64, PREP_UP_UINT4 = 4 * PREP_UP_SLOTS * 64;
+constexpr int PREP_FLOATS = (PREP_DOWN_UINT4 + PREP_UP_UINT4) * 4;
+
 // byte offset of a lane's (pixel, half) entry in a relu_bits16 array, from its byte offset pixel*128 + half*16
 __device__ __forceinline__ unsigned bits_off(unsigned out_off, int half) { return (out_off >> 7) * 4 + half * 2; }
 

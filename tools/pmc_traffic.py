@@ -17,6 +17,8 @@ def label(kernel_name):
     m = re.match(r'(down32|up32|wgrad32)[xbsr]?_kernel<(\d+),', n)       # fp32 / split-bf16 / small-tile variants share a label
     if m:
         return f'{m.group(1)}_kernel<{m.group(2)}>'
+    if n.startswith(('down_c1s_kernel', 'wgrad_c1s_kernel')):           # streaming forms: same label as the tiled kernels
+        return n.split('<')[0].replace('c1s', 'c1')
     if n.startswith('up_c1_kernel'):
         return 'up_c1_kernel(recon)' if 'true' in n else 'up_c1_kernel'
     return n.split('<')[0]
