@@ -943,6 +943,10 @@ __global__ __launch_bounds__(256, 1) void up32_kernel(const float *__restrict__ 
 // result differs from the fp32 MFMA's by less than one fp32 rounding of the sum, so the parity bars do not move --
 // at 6 x 32 cycles per 16 channels instead of 8 x 64 (2.7x fewer MFMA cycles).  Same tiling, loader, staggered
 // epilogue and gating as up32_kernel; 64 weights x 3 terms live in 96 registers.
+#ifndef ARVAE_UP_ISSUE_STEPS
+#define ARVAE_UP_ISSUE_STEPS 4
+#endif
+constexpr int UP_ISSUE_STEPS = ARVAE_UP_ISSUE_STEPS;
 template <int LO, int MODE, int PX = 128>
 __global__ __launch_bounds__(256, 1) void up32x_kernel(const float *__restrict__ lo, const float *__restrict__ wt, Ep32 ep,
                                                         int n_img, int n_tiles) {
@@ -1069,7 +1073,9 @@ __global__ __launch_bounds__(256, 1) void up32x_kernel(const float *__restrict__
             constexpr int cur = step & 1, nxt = cur ^ 1;
             constexpr int nstep = step + 1, nty = nstep >> 2, ntx = (nstep >> 1) & 1, nc = nstep & 1;
             constexpr int ntoff = -(nty * PC + ntx) * PSB + nc * 8;
-            pl.template issue_step<8, step>();
+            // the next tile's loads all leave in the first half of this tile: the commit at the top of the next tile waits for
+            // them (in-order vmcnt), and a load issued in the last step would expose its whole HBM round trip there
+            if constexpr (step < UP_ISSUE_STEPS) pl.template issue_step<UP_ISSUE_STEPS, step>();
             __builtin_amdgcn_sched_barrier(0);
             static_for<0, 2 * MT>([&](auto mc) __attribute__((always_inline)) {
                 constexpr int sub = decltype(mc)::value, grp = sub / MT, mt = sub % MT;
