@@ -1091,15 +1091,17 @@ __global__ __launch_bounds__(256, 1) void up32x_kernel(const float *__restrict__
                     if (MODE == EP_GATE_F) gq[k] = buf_load4(rs_gate, obase + orel[em] + eg * 32);
                     if (MODE == EP_GATE_B && eg == 3) gqb[em] = buf_load_u16(rs_bits, bits_off(obase + orel[em], half));
                 }
-                if constexpr (grp == 0) {                        // the three smallest partial products first
-                    MFMA_B(acc[mt], w3[ty][tx][c][2], a[cur][mt][0]);
-                    MFMA_B(acc[mt], w3[ty][tx][c][0], a[cur][mt][2]);
-                    MFMA_B(acc[mt], w3[ty][tx][c][1], a[cur][mt][1]);
-                } else {
-                    MFMA_B(acc[mt], w3[ty][tx][c][1], a[cur][mt][0]);
-                    MFMA_B(acc[mt], w3[ty][tx][c][0], a[cur][mt][1]);
-                    MFMA_B(acc[mt], w3[ty][tx][c][0], a[cur][mt][0]);
-                }
+                // Three of the step's 6 * MT MFMAs, taken in ROUND-ROBIN order over the MT accumulators (product-major: every
+                // accumulator still sees its six partial products smallest first, so the sums are bit-identical): back-to-back
+                // MFMAs into the same accumulator cost ~48 cycles each instead of the 32-cycle issue rate (conv32r.hip), which
+                // was the whole gap between this phase's 8800 cycles per tile and the 6144 its MFMAs need.
+                static_for<3 * sub, 3 * sub + 3>([&](auto qc) __attribute__((always_inline)) {
+                    constexpr int m = decltype(qc)::value, prod = m / MT, pm = m % MT;
+                    constexpr int tw = prod == 0 ? 2 : prod == 1 ? 0 : prod == 2 ? 1 : prod == 3 ? 1 : 0;
+                    constexpr int ta = prod == 0 ? 0 : prod == 1 ? 2 : prod == 2 ? 1 : prod == 3 ? 0 : prod == 4 ? 1 : 0;
+                    MFMA_B(acc[pm], w3[ty][tx][c][tw], a[cur][pm][ta]);
+                });
+                (void)grp; (void)mt;
                 if constexpr (nstep < 8) {                       // this sub-step's share of the next step's operand reads
                     constexpr int r_lo = sub * (3 * MT) / (2 * MT), r_hi = (sub + 1) * (3 * MT) / (2 * MT);
                     static_for<r_lo, r_hi>([&](auto rc_) __attribute__((always_inline)) {
