@@ -290,6 +290,22 @@ __device__ __forceinline__ bf16x8g lds_x8(const unsigned short *p) {
     ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AH, WM, ACC, 0, 0, 0);               \
     ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AH, WH, ACC, 0, 0, 0)
 
+// three independent accumulators, product-major: consecutive MFMAs never hit the same accumulator (a dependent 16x16x32 MFMA
+// waits for its predecessor's result, about twice the issue interval), every accumulator still sees its six products in order
+#define GRU_MFMA6X3(A0, A1, A2, H0, M0, L0, H1, M1, L1, H2, M2, L2, WH0, WM0, WL0, WH1, WM1, WL1, WH2, WM2, WL2)                 \
+    A0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(L0, WH0, A0, 0, 0, 0); A1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(L1, WH1, A1, 0, 0, 0); \
+    A2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(L2, WH2, A2, 0, 0, 0);                                                          \
+    A0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(H0, WL0, A0, 0, 0, 0); A1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(H1, WL1, A1, 0, 0, 0); \
+    A2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(H2, WL2, A2, 0, 0, 0);                                                          \
+    A0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(M0, WM0, A0, 0, 0, 0); A1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(M1, WM1, A1, 0, 0, 0); \
+    A2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(M2, WM2, A2, 0, 0, 0);                                                          \
+    A0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(M0, WH0, A0, 0, 0, 0); A1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(M1, WH1, A1, 0, 0, 0); \
+    A2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(M2, WH2, A2, 0, 0, 0);                                                          \
+    A0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(H0, WM0, A0, 0, 0, 0); A1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(H1, WM1, A1, 0, 0, 0); \
+    A2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(H2, WM2, A2, 0, 0, 0);                                                          \
+    A0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(H0, WH0, A0, 0, 0, 0); A1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(H1, WH1, A1, 0, 0, 0); \
+    A2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(H2, WH2, A2, 0, 0, 0)
+
 #ifdef ARVAE_GRU_STAMPS
 __device__ unsigned long long g_gru_stamps[8];
 #endif
@@ -387,8 +403,8 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_x3_kernel(GruSeqBatch batch
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const bf16x8g ah = lds_x8(hb + 32 * ks), am = lds_x8(hb + PLANE + 32 * ks), al = lds_x8(hb + 2 * PLANE + 32 * ks);
-#pragma unroll
-            for (int g = 0; g < 3; ++g) { GRU_MFMA6(acc[g], ah, am, al, wh[g][ks], wm[g][ks], wl[g][ks]); }
+            GRU_MFMA6X3(acc[0], acc[1], acc[2], ah, am, al, ah, am, al, ah, am, al, wh[0][ks], wm[0][ks], wl[0][ks], wh[1][ks], wm[1][ks],
+                        wl[1][ks], wh[2][ks], wm[2][ks], wl[2][ks]);
         }
 #ifdef ARVAE_GRU_STAMPS
         { float dep = acc[0][0] + acc[1][0] + acc[2][3]; asm volatile("" :: "v"(dep)); __builtin_amdgcn_s_waitcnt(0); }
@@ -516,10 +532,14 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_x3_kernel(GruSeqBatch batch
             }
         f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         const unsigned short *db = &dbuf[cur][col * DP + 8 * quad];
+        static_assert(KS % 3 == 0, "three k-steps at a time, one per accumulator");
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8g ah = lds_x8(db + 32 * ks), am = lds_x8(db + PLANE + 32 * ks), al = lds_x8(db + 2 * PLANE + 32 * ks);
-            GRU_MFMA6(acc[ks % 3], ah, am, al, wh[ks], wm[ks], wl[ks]);
+        for (int ks = 0; ks < KS; ks += 3) {
+            const bf16x8g ah0 = lds_x8(db + 32 * ks), am0 = lds_x8(db + PLANE + 32 * ks), al0 = lds_x8(db + 2 * PLANE + 32 * ks);
+            const bf16x8g ah1 = lds_x8(db + 32 * (ks + 1)), am1 = lds_x8(db + PLANE + 32 * (ks + 1)), al1 = lds_x8(db + 2 * PLANE + 32 * (ks + 1));
+            const bf16x8g ah2 = lds_x8(db + 32 * (ks + 2)), am2 = lds_x8(db + PLANE + 32 * (ks + 2)), al2 = lds_x8(db + 2 * PLANE + 32 * (ks + 2));
+            GRU_MFMA6X3(acc[0], acc[1], acc[2], ah0, am0, al0, ah1, am1, al1, ah2, am2, al2, wh[ks], wm[ks], wl[ks], wh[ks + 1], wm[ks + 1],
+                        wl[ks + 1], wh[ks + 2], wm[ks + 2], wl[ks + 2]);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) carry[i] = gz[i] + (acc[0][i] + acc[1][i] + acc[2][i]);
