@@ -380,32 +380,38 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_x3_kernel(GruSeqBatch batch
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int g = 0; g < 3; ++g) gi[i][g] = gi_next[i][g];
-        if (step + 1 < T) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
+        GSTAMP(0);
+        f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        const unsigned short *hb = &hbuf[cur][col * HP + 8 * quad];
+        // Row i's share of the step's memory traffic (next step's three input projections in, the previous step's h and saved
+        // gates out) is issued BEHIND the MFMAs of k-step i, with a scheduling barrier pinning it there: as one block in front
+        // of the MFMAs it was 1200 of the step's 6000 cycles (tools/stamp_gru.py), all of it issue time of an in-order wave
+        // while the matrix pipe sat idle.
+        auto row_traffic = [&](int i) __attribute__((always_inline)) {
+            if (step + 1 < T) {
                 gi_next[i][0] = gi_p[i][0]; gi_next[i][1] = gi_p[i][H]; gi_next[i][2] = gi_p[i][2 * H];
                 gi_p[i] += gi_step;
             }
-        }
-        if (keep_t >= 0) {                   // the previous step's outputs leave while this step's MFMAs run
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            if (keep_t >= 0) {
                 if (live[i]) {
                     *h_p[i] = keep_h[i];
                     *reinterpret_cast<f32x4 *>(sv_p[i]) = keep_sv[i];
                 }
                 h_p[i] += h_step; sv_p[i] += sv_step;
             }
-        }
-        GSTAMP(0);
-        f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        const unsigned short *hb = &hbuf[cur][col * HP + 8 * quad];
+        };
+        static_assert(KS <= 4, "one row's traffic per k-step; rows left over go last");
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const bf16x8g ah = lds_x8(hb + 32 * ks), am = lds_x8(hb + PLANE + 32 * ks), al = lds_x8(hb + 2 * PLANE + 32 * ks);
             GRU_MFMA6X3(acc[0], acc[1], acc[2], ah, am, al, ah, am, al, ah, am, al, wh[0][ks], wm[0][ks], wl[0][ks], wh[1][ks], wm[1][ks],
                         wl[1][ks], wh[2][ks], wm[2][ks], wl[2][ks]);
+            __builtin_amdgcn_sched_barrier(0);
+            row_traffic(ks);
+            __builtin_amdgcn_sched_barrier(0);
         }
+#pragma unroll
+        for (int i = KS; i < 4; ++i) row_traffic(i);
 #ifdef ARVAE_GRU_STAMPS
         { float dep = acc[0][0] + acc[1][0] + acc[2][3]; asm volatile("" :: "v"(dep)); __builtin_amdgcn_s_waitcnt(0); }
 #endif
@@ -522,17 +528,18 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_x3_kernel(GruSeqBatch batch
         }
         if (step + 1 < T) fetch(step + 1);
         __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 4; ++i)          // the gradients of this step leave while its MFMAs run
+        f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        const unsigned short *db = &dbuf[cur][col * DP + 8 * quad];
+        static_assert(KS % 3 == 0 && KS / 3 <= 4, "three k-steps at a time, one per accumulator; one row's stores behind each group");
+        // row i's gradients of this step leave BEHIND the MFMAs of k-step group i (pinned: see gru_seq_fwd_x3_kernel)
+        auto row_stores = [&](int i) __attribute__((always_inline)) {
             if (live[i]) {
                 const int64_t o = ((int64_t)t * R + rows[i]) * 3 * H + unit;
                 s.dgi[o] = o_gi[i][0]; s.dgi[o + H] = o_gi[i][1]; s.dgi[o + 2 * H] = o_gi[i][2];
                 s.dgh[o] = o_gi[i][0]; s.dgh[o + H] = o_gi[i][1]; s.dgh[o + 2 * H] = o_hn[i];
                 if (s.h_prev_out != nullptr) s.h_prev_out[((int64_t)t * R + rows[i]) * H + unit] = o_hp[i];
             }
-        f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        const unsigned short *db = &dbuf[cur][col * DP + 8 * quad];
-        static_assert(KS % 3 == 0, "three k-steps at a time, one per accumulator");
+        };
 #pragma unroll
         for (int ks = 0; ks < KS; ks += 3) {
             const bf16x8g ah0 = lds_x8(db + 32 * ks), am0 = lds_x8(db + PLANE + 32 * ks), al0 = lds_x8(db + 2 * PLANE + 32 * ks);
@@ -540,7 +547,12 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_x3_kernel(GruSeqBatch batch
             const bf16x8g ah2 = lds_x8(db + 32 * (ks + 2)), am2 = lds_x8(db + PLANE + 32 * (ks + 2)), al2 = lds_x8(db + 2 * PLANE + 32 * (ks + 2));
             GRU_MFMA6X3(acc[0], acc[1], acc[2], ah0, am0, al0, ah1, am1, al1, ah2, am2, al2, wh[ks], wm[ks], wl[ks], wh[ks + 1], wm[ks + 1],
                         wl[ks + 1], wh[ks + 2], wm[ks + 2], wl[ks + 2]);
+            __builtin_amdgcn_sched_barrier(0);
+            row_stores(ks / 3);
+            __builtin_amdgcn_sched_barrier(0);
         }
+#pragma unroll
+        for (int i = KS / 3; i < 4; ++i) row_stores(i);
 #pragma unroll
         for (int i = 0; i < 4; ++i) carry[i] = gz[i] + (acc[0][i] + acc[1][i] + acc[2][i]);
     }
