@@ -234,69 +234,100 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int t = 0; t < 3; ++t)
                 x3[0][mt][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4v *>(xb + xoff[mt][0] + t * 32));
+        // Issue order pinned by hand (one scheduling barrier after every MFMA; see conv32k.hip and DESIGN.md section 4, item 15c):
+        // the step's other work -- the next step's 3 MT pixel operand reads, the weight loads of the step after that, and the
+        // loader's pieces (address, loads; derivative / mask, split in two halves per value pair, LDS writes) -- sits between the
+        // MFMAs in order.  Left to the scheduler a step was a block of MFMAs followed by a block of vector instructions.
+        uint2 c_h, c_m, c_l;                                     // a slot's values between its pieces
+        float4 c_v;
+        f32x2v c_r;
+        int64_t c_at = 0;
+        bool c_ok = false;
+        auto split_a = [&](float x0, float x1, unsigned &h) __attribute__((always_inline)) {
+            const f32x2v x = {x0, x1};
+            h = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2v));
+            c_r = f32x2v{x0 - __builtin_bit_cast(float, h << 16), x1 - __builtin_bit_cast(float, h & 0xffff0000u)};
+        };
+        auto split_b = [&](unsigned &m, unsigned &l) __attribute__((always_inline)) {
+            m = __builtin_bit_cast(unsigned, __builtin_convertvector(c_r, bf16x2v));
+            const f32x2v qq = {c_r.x - __builtin_bit_cast(float, m << 16), c_r.y - __builtin_bit_cast(float, m & 0xffff0000u)};
+            l = __builtin_bit_cast(unsigned, __builtin_convertvector(qq, bf16x2v));
+        };
         static_for<0, 16>([&](auto kc) __attribute__((always_inline)) {
-            constexpr int step = decltype(kc)::value, jx = step >> 2, c16 = step & 3;
-            constexpr int cu = step & 1, nx = cu ^ 1, wr = step % 3;
-            (void)jx; (void)c16;
-            __builtin_amdgcn_sched_barrier(0);                   // nothing moves across a step (the register file is full)
-            if constexpr (step + 2 < 16) {
-                constexpr int njx = (step + 2) >> 2, nc16 = (step + 2) & 3;
-                load_w(std::integral_constant<int, (step + 2) % 3>{}, g.sgn > 0 ? njx : 3 - njx, nc16);
-            }
-            if constexpr (step + 1 < 16) {                       // next step's pixel operands fly during this step's MFMAs
-                constexpr int njx = (step + 1) >> 2, nc16 = (step + 1) & 3;
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int t = 0; t < 3; ++t)
-                        x3[nx][mt][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4v *>(xb + xoff[mt][njx] + t * 32 + nc16 * 8));
-            }
-            // this step's share of the loader: the next tile's slot s is requested in step s * 12 / 11 and split + written to the
-            // other buffer four steps (~3 us) later -- a handful of slots in flight instead of a tile's worth of registers
-            static_for<0, S_SLOTS>([&](auto sc) __attribute__((always_inline)) {
-                constexpr int s = decltype(sc)::value;
-                if constexpr (s * 12 / S_SLOTS == step) issue(s, tile + gridDim.x);
-                if constexpr (s * 12 / S_SLOTS + 4 == step) commit(s, nb);
-            });
-            if constexpr (step == 11) fetch_epilogue();
-            // (weight term, pixel term) of the six partial products, smallest first, round-robin over the accumulators
-#define ARVAE_C64S_PRODUCT(TW, TX)                                                                   \
-            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                        \
-                _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) MFMA_B(acc[mt][nt], w3[wr][nt][TW], x3[cu][mt][TX]);
-            ARVAE_C64S_PRODUCT(2, 0)
-            ARVAE_C64S_PRODUCT(0, 2)
-            ARVAE_C64S_PRODUCT(1, 1)
-            ARVAE_C64S_PRODUCT(1, 0)
-            ARVAE_C64S_PRODUCT(0, 1)
-            ARVAE_C64S_PRODUCT(0, 0)
-#undef ARVAE_C64S_PRODUCT
-            // issue order: an MFMA, then one of the next step's operand reads (a burst of LDS reads in front of a block of MFMAs
-            // costs the matrix pipe ~10 idle cycles per read: tools/probes/mfma_barrier.hip), then the loader's share
-            if constexpr (step + 1 < 16) {
-#pragma unroll
-                for (int i_ = 0; i_ < 3 * MT; ++i_) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            constexpr int step = decltype(kc)::value, cu = step & 1, nx = cu ^ 1, wr = step % 3;
+            // loader slots of this step: requested in step s * 12 / 11, split + written four steps (~3 us) later
+            constexpr int is_lo = (step * S_SLOTS + 11) / 12, is_hi = step < 12 ? ((step + 1) * S_SLOTS + 11) / 12 : is_lo;
+            constexpr int cs = step - 4;
+            constexpr int cm_lo = cs >= 0 ? (cs * S_SLOTS + 11) / 12 : 0, cm_hi = (cs >= 0 && cs < 12) ? ((cs + 1) * S_SLOTS + 11) / 12 : cm_lo;
+            constexpr int n_read = step + 1 < 16 ? 3 * MT : 0, n_w = step + 2 < 16 ? 3 * NT : 0;
+            constexpr int n_issue = 2 * (is_hi - is_lo), n_commit = 6 * (cm_hi - cm_lo), n_ep = step == 11 ? 1 : 0;
+            constexpr int n_items = n_read + n_w + n_issue + n_commit + n_ep, n_mfma = 6 * MT * NT;
+            auto item = [&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (i < n_read) {
+                    constexpr int njx = (step + 1) >> 2, nc16 = (step + 1) & 3, mt = i / 3, t = i % 3;
+                    x3[nx][mt][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4v *>(xb + xoff[mt][njx] + t * 32 + nc16 * 8));
+                } else if constexpr (i < n_read + n_w) {
+                    constexpr int k = i - n_read, nt = k / 3, t = k % 3, njx = (step + 2) >> 2, nc16 = (step + 2) & 3;
+                    const int nkx = g.sgn > 0 ? njx : 3 - njx;
+                    const uint4 *wp = g.wprep + ((ky * 4 + nkx) * 4 + nc16) * S_WSTEP + wlane;
+                    w3[(step + 2) % 3][nt][t] = __builtin_bit_cast(bf16x8, wp[(nt * 3 + t) * 64]);
+                } else if constexpr (i < n_read + n_w + n_issue) {
+                    constexpr int k = i - n_read - n_w, s = is_lo + k / 2, piece = k % 2;
+                    if constexpr (piece == 0) {                  // address of slot s of the next tile
+                        const int nt_ = tile + gridDim.x;
+                        const int img = nt_ / g.groups, oy0 = (nt_ - img * g.groups) * g.rows;
+                        const int l_pix = pix0 + 16 * s, l_row = (l_pix * inv_sw) >> 16;
+                        const int sy = oy0 + g.dmin + l_row, sx = l_pix - l_row * g.sw;
+                        c_ok = nt_ < n_tiles && l_pix < src_pix && (unsigned)sy < (unsigned)g.sh;
+                        c_at = c_ok ? (((int64_t)img * g.sh + sy) * g.sw + sx) * 64 + 4 * q4 : 0;
+                    } else {
+                        const float4 v = *reinterpret_cast<const float4 *>(g.src.v + c_at);
+                        if (MODE >= 1) ly[s] = *reinterpret_cast<const float4 *>(g.src.y + c_at);
+                        if (MODE == 2) lm[s] = *reinterpret_cast<const unsigned *>(g.src.mask + c_at);
+                        lv[s] = c_ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                } else if constexpr (i < n_read + n_w + n_issue + n_commit) {
+                    constexpr int k = i - n_read - n_w - n_issue, s = cm_lo + k / 6, piece = k % 6;
+                    if constexpr (piece == 0) {                  // the value with a gradient operand's derivative / keep-mask
+                        c_v = lv[s];
+                        if (MODE >= 1) {
+                            float4 y = ly[s];
+                            if (MODE == 2) {
+                                const unsigned m = lm[s];
+                                c_v.x *= 2.f * (float)(m & 255u); c_v.y *= 2.f * (float)((m >> 8) & 255u);
+                                c_v.z *= 2.f * (float)((m >> 16) & 255u); c_v.w *= 2.f * (float)(m >> 24);
+                                y.x *= 0.5f; y.y *= 0.5f; y.z *= 0.5f; y.w *= 0.5f;
+                            }
+                            c_v.x *= act_bwd_from_out_sel(y.x, g.src.act); c_v.y *= act_bwd_from_out_sel(y.y, g.src.act);
+                            c_v.z *= act_bwd_from_out_sel(y.z, g.src.act); c_v.w *= act_bwd_from_out_sel(y.w, g.src.act);
+                        }
+                    }
+                    if constexpr (piece == 1) split_a(c_v.x, c_v.y, c_h.x);
+                    if constexpr (piece == 2) split_b(c_m.x, c_l.x);
+                    if constexpr (piece == 3) split_a(c_v.z, c_v.w, c_h.y);
+                    if constexpr (piece == 4) split_b(c_m.y, c_l.y);
+                    if constexpr (piece == 5) {
+                        unsigned *d = nb + (pix0 + 16 * s) * S_PITCH + q4 * 2;
+                        *reinterpret_cast<uint2 *>(d) = c_h;
+                        *reinterpret_cast<uint2 *>(d + 32) = c_m;
+                        *reinterpret_cast<uint2 *>(d + 64) = c_l;
+                    }
+                } else if constexpr (i < n_items) {
+                    fetch_epilogue();
                 }
-            }
-            if constexpr (step + 2 < 16) {
-#pragma unroll
-                for (int i_ = 0; i_ < 3 * NT; ++i_) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                }
-            }
-            // the loader's vector-ALU work (address arithmetic, three-term split) and LDS writes: a few per MFMA
-            {
-                constexpr int used = (step + 1 < 16 ? 3 * MT : 0) + (step + 2 < 16 ? 3 * NT : 0);
-#pragma unroll
-                for (int i_ = used; i_ < 6 * NT * MT; ++i_) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-                }
-            }
+            };
             __builtin_amdgcn_sched_barrier(0);
+            // (weight term, pixel term) of the six partial products, smallest first, round-robin over the accumulators
+            static_for<0, n_mfma>([&](auto mc) __attribute__((always_inline)) {
+                constexpr int m = decltype(mc)::value, prod = m / (MT * NT), mt = (m % (MT * NT)) / NT, nt = m % NT;
+                constexpr int tw = prod == 0 ? 2 : prod == 1 ? 0 : prod == 2 ? 1 : prod == 3 ? 1 : 0;
+                constexpr int tx = prod == 0 ? 0 : prod == 1 ? 2 : prod == 2 ? 1 : prod == 3 ? 0 : prod == 4 ? 1 : 0;
+                MFMA_B(acc[mt][nt], w3[wr][nt][tw], x3[cu][mt][tx]);
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<m * n_items / n_mfma, (m + 1) * n_items / n_mfma>(item);
+                __builtin_amdgcn_sched_barrier(0);
+            });
         });
         load_w(std::integral_constant<int, 0>{}, kx_first, 0);   // the next tile's first two steps: the exchange hides them
         load_w(std::integral_constant<int, 1>{}, kx_first, 1);
