@@ -14,7 +14,7 @@ import sys
 def label(kernel_name):
     """rocprofv3 kernel name -> the label bench.py / arvae_profile_end use for that kernel family."""
     n = kernel_name.replace('void ', '').split('(')[0].replace('arvae::', '')
-    m = re.match(r'(down32|up32|wgrad32)[xbsr]?_kernel<(\d+),', n)       # fp32 / split-bf16 / small-tile variants share a label
+    m = re.match(r'(down32|up32|wgrad32)[xbsrk]?_kernel<(\d+),', n)       # fp32 / split-bf16 / small-tile variants share a label
     if m:
         return f'{m.group(1)}_kernel<{m.group(2)}>'
     if n.startswith(('down_c1s_kernel', 'wgrad_c1s_kernel')):           # streaming forms: same label as the tiled kernels
