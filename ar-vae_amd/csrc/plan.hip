@@ -35,11 +35,13 @@ int conv_c1_down(const arvae_link_t *l, const Operand &img, const float *wt, con
 bool heads_fusable(const arvae_layer_t *hm, const arvae_layer_t *hl, int zdim);
 int heads_latent_fwd(const arvae_layer_t *hm, const arvae_layer_t *hl, int batch, int zdim, const float *params,
                      const float *hidden, const float *eps, float *mu, float *log_std, float *sigma, float *z, hipStream_t s,
-                     const arvae_image_vae_t *rng_model = nullptr);
+                     const arvae_image_vae_t *rng_model = nullptr, const arvae_layer_t *next = nullptr, float *next_out = nullptr);
+bool heads_next_fusable(const arvae_layer_t *l, int zdim);
 int heads_latent_bwd(const arvae_layer_t *hm, const arvae_layer_t *hl, int batch, int zdim, const float *params,
                      const float *g_z, const float *dz_reg, const float *dz_extra, const float *mu, const float *sigma,
                      const float *eps, const float *g_loss, const float *kl, const float *cap, float beta, float reg_scale,
-                     const float *gate, float *d_mu, float *d_ls, float *d_hidden, hipStream_t s);
+                     const float *gate, float *d_mu, float *d_ls, float *d_hidden, hipStream_t s, const arvae_layer_t *next = nullptr,
+                     const float *next_g = nullptr);
 
 // the latent block (trailing Linear layers of the encoder, heads + reparameterisation, leading Linear layers of the
 // decoder) as one launch per pass (midblock.hip)
@@ -387,6 +389,7 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
         h = ws + L.enc_out[i];
     }
     const int64_t bz = (int64_t)batch * m->zdim;
+    bool heads_next = false;
     if (mid) {                                               // Linear stack + heads + reparameterisation + Linear stack: one launch
         float *enc_y[ARVAE_MAX_LAYERS], *dec_y[ARVAE_MAX_LAYERS];
         for (int i = 0; i < mid_ne; ++i) enc_y[i] = ws + L.enc_out[m->n_enc - mid_ne + i];
@@ -394,8 +397,10 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
         if (int rc = mid_forward(m, batch, params, ws + L.mid_prep, h, enc_y, dec_y, eps, mu, ws + L.log_std, sigma, z, st)) return rc;
         h = dec_y[mid_nd - 1];
     } else if (heads_fusable(&m->head_mu, &m->head_log_std, m->zdim)) {
+        // the decoder's first Linear layer rides in the heads kernel when it can (heads.hip)
+        heads_next = m->n_dec > 1 && heads_next_fusable(&m->dec[0], m->zdim) && !(masks != nullptr && m->dec[0].dropout);
         if (int rc = heads_latent_fwd(&m->head_mu, &m->head_log_std, batch, m->zdim, params, h, eps, mu, ws + L.log_std,
-                                      sigma, z, st, m))
+                                      sigma, z, st, m, heads_next ? &m->dec[0] : nullptr, heads_next ? ws + L.dec_out[0] : nullptr))
             return rc;
     } else {
         if (m->rng_eps)                                      // no fused heads kernel for this model: draw eps first
@@ -407,12 +412,12 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
         if (int rc = arvae_latent_fwd(mu, ws + L.log_std, eps, bz, sigma, z, stream)) return rc;
     }
     // decoder
-    if (!mid) h = z;
+    if (!mid) h = heads_next ? ws + L.dec_out[0] : z;
     int nb = 0;
     const arvae_layer_t &last = m->dec[m->n_dec - 1];
     const bool recon_fused = last.is_up && last.act == ARVAE_ACT_NONE && last.dropout == 0 && conv_c1_fits(&last.link) &&
                              arvae_recon_ws_floats(0) >= 2 * 1024;
-    for (int i = mid ? mid_nd : 0; i < m->n_dec; ++i) {
+    for (int i = mid ? mid_nd : (heads_next ? 1 : 0); i < m->n_dec; ++i) {
         const uint8_t *mask = (masks != nullptr && m->dec[i].dropout) ? masks[mi] : nullptr;
         mi += m->dec[i].dropout != 0;
         float *out = (i + 1 < m->n_dec) ? ws + L.dec_out[i] : logits;
@@ -533,6 +538,7 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
     int mid_ne = 0, mid_nd = 0;
     const bool mid = mid_fusable(m, &mid_ne, &mid_nd);
     // decoder, last layer first (down to the latent block when that runs as one launch)
+    const float *heads_next_g = nullptr;
     for (int i = m->n_dec - 1; i >= (mid ? mid_nd : 0); --i) {
         const float *in = i > 0 ? ws + L.dec_out[i - 1] : z;
         const float *out = (i + 1 < m->n_dec) ? ws + L.dec_out[i] : logits;
@@ -542,6 +548,13 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
         float *dst = grad_dst(i > 0 ? L.dec_keep[i - 1] : -1, cur);
         bool gated = false;
         sync_side();                                     // this layer's incoming gradient is ready
+        // the first decoder layer's data gradient (d z) is computed inside the heads kernel (heads.hip) when the gradient
+        // that arrives here is already w.r.t. the layer's pre-activation: only its weight gradient is queued
+        if (i == 0 && !mid && pre && m->n_dec > 1 && heads_fusable(&m->head_mu, &m->head_log_std, m->zdim) &&
+            heads_next_fusable(&m->dec[0], m->zdim) && mask_of(dec_mask[0]) == nullptr) {
+            heads_next_g = cur;
+            dst = nullptr;
+        }
         if (int rc = layer_backward(m->dec[i], batch, params, grads, in, out, mask_of(dec_mask[i]), cur, pre, gate, dst,
                                     &gated, slab, ws + L.link_ws, &defer, L.dec_slab[i] >= 0 ? ws + L.dec_slab[i] : nullptr, &rdefer, stream,
                                     i == m->n_dec - 1 ? first_scale : nullptr,
@@ -550,7 +563,7 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
                                     L.dec_wprep[i] >= 0 ? ws + L.dec_wprep[i] : nullptr, gate_op))
             return rc;
         pre = gated;
-        cur = dst;
+        if (heads_next_g == nullptr) cur = dst;
     }
     // latent head (cur = gradient w.r.t. z from the decoder) and the two encoder heads:
     // d_hidden = W_mu^T d_mu + W_ls^T d_ls   (gated by the last encoder layer's ReLU when possible)
@@ -599,9 +612,10 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
         pre = gate0 != nullptr;
         enc_from = e0 - 1;
     } else if (heads_fusable(&m->head_mu, &m->head_log_std, m->zdim)) {
-        if (int rc = heads_latent_bwd(&m->head_mu, &m->head_log_std, batch, m->zdim, params, cur, dz_reg, dz_extra, mu, sigma,
-                                      eps, g_loss, ws + L.kld_out + 1, capacity, m->beta, reg_scale, head_gate, ws + L.d_mu,
-                                      ws + L.d_ls, d_hidden, st))
+        if (int rc = heads_latent_bwd(&m->head_mu, &m->head_log_std, batch, m->zdim, params, heads_next_g != nullptr ? nullptr : cur,
+                                      dz_reg, dz_extra, mu, sigma, eps, g_loss, ws + L.kld_out + 1, capacity, m->beta, reg_scale,
+                                      head_gate, ws + L.d_mu, ws + L.d_ls, d_hidden, st,
+                                      heads_next_g != nullptr ? &m->dec[0] : nullptr, heads_next_g))
             return rc;
         const arvae_layer_t *heads[2] = {&m->head_mu, &m->head_log_std};
         const float *hg[2] = {ws + L.d_mu, ws + L.d_ls};
