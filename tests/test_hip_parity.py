@@ -1257,11 +1257,14 @@ def test_latent_block_experiment_matches_the_per_layer_path(dev):
         "    out[kind] = {'loss': got['loss'], 'gn': {k: float(np.linalg.norm(v)) for k, v in got['grads'].items()}}\n"
         "print(json.dumps(out))\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     res = {}
-    for flag in ('0', '1'):
-        r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=dict(os.environ, ARVAE_MIDBLOCK=flag))
+    # '0': the default path; '1': the latent-block launch; 'heads': ARVAE_HEADS_NEXT=1 (csrc/heads.hip: the decoder's first Linear
+    # layer and its data gradient inside the heads kernels, also off by default: measured slower)
+    for flag, env in (('0', {}), ('1', {'ARVAE_MIDBLOCK': '1'}), ('heads', {'ARVAE_HEADS_NEXT': '1'})):
+        r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
         assert r.returncode == 0, r.stderr[-2000:]
         res[flag] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
-    for kind in ('dsprites', 'mnist'):
-        close(res['1'][kind]['loss'], res['0'][kind]['loss'], rtol=1e-6)
-        for k, v in res['0'][kind]['gn'].items():
-            close(res['1'][kind]['gn'][k], v, rtol=1e-4, atol=1e-9)
+    for flag in ('1', 'heads'):
+        for kind in ('dsprites', 'mnist'):
+            close(res[flag][kind]['loss'], res['0'][kind]['loss'], rtol=1e-6)
+            for k, v in res['0'][kind]['gn'].items():
+                close(res[flag][kind]['gn'][k], v, rtol=1e-4, atol=1e-9)
