@@ -633,6 +633,42 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(Operand g, int64_t row
     }
 }
 
+// stage 2 with the parallelism the partials allow: 16 channels per workgroup, 16 row lanes per channel, eight loads in flight
+// per thread (one workgroup walking all the partials four loads at a time took 23 us for 1024 x 64 partials: five such launches
+// per Morpho-MNIST step)
+__global__ __launch_bounds__(256) void channel_sum_finish_kernel(const float *__restrict__ part, int blocks, int channels, int perm_c,
+                                                                  int perm_hw, float *__restrict__ dst) {
+    __shared__ float red[256];
+    const int t = threadIdx.x, cl = t & 15, rsub = t >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    const bool cok = c < channels;
+    const float *base = part + (cok ? c : 0);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int r = rsub; r < blocks; r += 16 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int rr = r + 16 * u;
+            const float x = base[(int64_t)(rr < blocks ? rr : 0) * channels];
+            v[u] = rr < blocks ? x : 0.f;
+        }
+        s0 += v[0] + v[4];
+        s1 += v[1] + v[5];
+        s2 += v[2] + v[6];
+        s3 += v[3] + v[7];
+    }
+    red[t] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (t < 16 && cok) {
+        float tot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) tot += red[j * 16 + t];
+        int f = c;                               // memory channel -> flattened NCHW feature
+        if (perm_c > 0) f = (c % perm_c) * perm_hw + c / perm_c;
+        dst[f] += tot;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 static int make_geom(const arvae_link_t *l, Geom &g) {
     ARVAE_REQUIRE(l != nullptr, "link: null descriptor");
@@ -889,9 +925,8 @@ static int channel_sum_launch(const Operand &g, int64_t rows, int channels, int 
     ARVAE_LAUNCH(channel_sum_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, g, rows, channels, rpb, 0, 0,
                        ws);
     if (int rc = check_launch("channel_sum")) return rc;
-    Operand part{ws, nullptr, nullptr, ARVAE_ACT_NONE};
-    ARVAE_LAUNCH(channel_sum_kernel<true>, dim3(1), dim3(256), 0, st, part, blocks, channels, blocks, perm_c,
-                       perm_hw, out);
+    ARVAE_LAUNCH(channel_sum_finish_kernel, dim3((unsigned)((channels + 15) / 16)), dim3(256), 0, st, ws, (int)blocks, channels, perm_c,
+                 perm_hw, out);
     return check_launch("channel_sum(finish)");
 }
 
