@@ -54,6 +54,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, rc = lane & 31;
     const __amdgpu_buffer_rsrc_t rs_hi = make_rsrc(hi, (int64_t)n_img * HI * HI * PIXB);
+    // a workgroup owns a CONTIGUOUS run of tiles (consecutive row groups of the same images): the halo rows two tiles share
+    // are then fetched by the same CU / XCD a tile apart and come from its L2 instead of from HBM again
+    const int per_wg = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x, t_first = blockIdx.x * per_wg;
+    const int t_end = min(n_tiles, t_first + per_wg);
 
     // ---- loader: slot s of this thread = staged pixel pix0 + 32 s, channels 4 q .. 4 q + 3 ------------------------------------
     // (q / pix0 are laundered through an empty asm once per tile pair: the addresses derived from them are loop
@@ -66,7 +70,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         tile_origin<LO, 64>(tile, img0, r0);
         const int pix = pix0 + 32 * s, pr = pix / HW, px = pix - pr * HW;
         const int gy = 2 * r0 - 1 + pr;
-        const bool ok = tile < n_tiles && pix < PIX && (unsigned)gy < (unsigned)HI;
+        const bool ok = tile < t_end && pix < PIX && (unsigned)gy < (unsigned)HI;
         lv[set][s] = buf_load4(rs_hi, ok ? (unsigned)((((img0 * HI + gy) * HI + px) * C32 + 4 * q) * 4) : OOB);
     };
     auto commit = [&](auto set_, int s, unsigned *buf) __attribute__((always_inline)) {
@@ -84,9 +88,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
 #pragma unroll
-    for (int s = 0; s < SLOTS; ++s) issue(S0{}, s, blockIdx.x);
+    for (int s = 0; s < SLOTS; ++s) issue(S0{}, s, t_first);
 #pragma unroll
-    for (int s = 0; s < SLOTS; ++s) issue(S1{}, s, blockIdx.x + gridDim.x);
+    for (int s = 0; s < SLOTS; ++s) issue(S1{}, s, t_first + 1);
     if (threadIdx.x < 2 * PSB3) lds[(threadIdx.x / PSB3) * K::BUF + PIX * PSB3 + threadIdx.x % PSB3] = 0u;   // the zero pixels
 
     // ---- consumer geometry: wave = kernel row ky; pixel of (mt, lane) -------------------------------------------------------
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) commit(S0{}, s, lds);        // first tile -> buffer 0
 #pragma unroll
-    for (int s = 0; s < SLOTS; ++s) issue(S0{}, s, blockIdx.x + 2 * gridDim.x);
+    for (int s = 0; s < SLOTS; ++s) issue(S0{}, s, t_first + 2);
     __syncthreads();
 
     int kst = 0;
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // gate values / sign bits of this wave's outputs: requested now, used after the exchange
         int img0, r0;
         tile_origin<LO, 64>(tile, img0, r0);
-        const unsigned obase = tile < n_tiles ? (unsigned)(((img0 * LO + r0) * LO) * PIXB) + out_lane : OOB;
+        const unsigned obase = tile < t_end ? (unsigned)(((img0 * LO + r0) * LO) * PIXB) + out_lane : OOB;
         float4 gq[2];
         unsigned gb = 0;
         if (MODE == EP_GATE_F) {
@@ -211,12 +215,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         *reinterpret_cast<uint2 *>(d + 32) = c_l;
                     }
                     if constexpr (piece == 5) {                  // address of the slot's next load (tile + 3 strides)
-                        const int nt = tile + 3 * gridDim.x;
+                        const int nt = tile + 3;
                         int ni, nr;
                         tile_origin<LO, 64>(nt, ni, nr);
                         const int pix = pix0 + 32 * s, pr = pix / HW, px = pix - pr * HW;
                         const int gy = 2 * nr - 1 + pr;
-                        const bool ok = nt < n_tiles && (unsigned)gy < (unsigned)HI;
+                        const bool ok = nt < t_end && (unsigned)gy < (unsigned)HI;
                         c_off = ok ? (unsigned)((((ni * HI + gy) * HI + px) * C32 + 4 * q) * 4) : OOB;
                     }
                     if constexpr (piece == 6) lv[set][s] = buf_load4(rs_hi, c_off);
@@ -291,9 +295,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // two tiles per iteration, both halves always executed (a tile past the end multiplies zeros and its stores are dropped):
     // with a conditional second half the compiler's vmcnt bookkeeping merges the paths and waits for the loads it has just
     // issued, which exposes a full HBM round trip per loader slot
-    for (int tile = blockIdx.x; tile < n_tiles; tile += 2 * gridDim.x) {
-        do_tile(S1{}, tile, 0);                                  // set 1 holds tile + stride
-        do_tile(S0{}, tile + gridDim.x, 1);                      // set 0 holds tile + 2 stride
+    for (int tile = t_first; tile < t_end; tile += 2) {
+        do_tile(S1{}, tile, 0);                                  // set 1 holds tile + 1
+        do_tile(S0{}, tile + 1, 1);                              // set 0 holds tile + 2
     }
 }
 
