@@ -964,8 +964,12 @@ __global__ __launch_bounds__(256, 1) void up32x_kernel(const float *__restrict__
     PL pl;                                                       // first tile's loads fly while the weights are staged
     pl.init(lo, n_img);
     int img0, r0;
-    tile_origin<LO, PX>(blockIdx.x, img0, r0);
-    pl.set_tile(img0, r0, blockIdx.x < n_tiles);
+    // a workgroup owns a contiguous run of tiles (the row groups of the same images): the halo rows two tiles share come from
+    // this XCD's L2 the second time
+    const int per_wg = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x, t_first = blockIdx.x * per_wg;
+    const int t_end = min(n_tiles, t_first + per_wg);
+    tile_origin<LO, PX>(t_first, img0, r0);
+    pl.set_tile(img0, r0, t_first < t_end);
     pl.issue_all();
 
     // w3[ty][tx][c][term]: the 8 input channels c*16 + half*8 + j of wt[.][chi = rc][ky0 + 2ty][kx0 + 2tx], split in three
@@ -1040,7 +1044,7 @@ __global__ __launch_bounds__(256, 1) void up32x_kernel(const float *__restrict__
     int stamp_t = 0;
     (void)stamp_t;
 
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (int tile = t_first; tile < t_end; ++tile) {
         STAMP(3 + 6 * stamp_t);
         tile_origin<LO, PX>(tile, img0, r0);
         __syncthreads();
@@ -1050,8 +1054,8 @@ __global__ __launch_bounds__(256, 1) void up32x_kernel(const float *__restrict__
         STAMP(5 + 6 * stamp_t);
         {
             int ni, nr;
-            tile_origin<LO, PX>(tile + gridDim.x, ni, nr);
-            pl.set_tile(ni, nr, tile + gridDim.x < n_tiles);
+            tile_origin<LO, PX>(tile + 1, ni, nr);
+            pl.set_tile(ni, nr, tile + 1 < t_end);
         }
         STAMP(6 + 6 * stamp_t);
         const unsigned obase = (unsigned)(((img0 * HI + 2 * r0) * HI) * PIXB);

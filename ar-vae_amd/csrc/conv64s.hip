@@ -90,6 +90,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, rc = lane & 31;
     const int n_tiles = g.n * g.groups;
+    // a workgroup owns a contiguous run of tiles: consecutive row groups of an image share three source rows, which then come
+    // from this XCD's L2 the second time
+    const int per_wg = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x, t_first = blockIdx.x * per_wg;
+    const int t_end = min(n_tiles, t_first + per_wg);
     const int src_rows = g.rows + 3, src_pix = src_rows * g.sw;
 
     // ---- loader: slot s of this thread = (staged pixel, channels 4 q4 .. + 3) -------------------------------------------
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int l_pix = pix0 + 16 * s, l_row = (l_pix * inv_sw) >> 16;     // l_pix / sw for l_pix < 256, sw <= 64 (recomputed per tile:
                                                                              // registers are what this kernel lacks)
         const int sy = oy0 + g.dmin + l_row, sx = l_pix - l_row * g.sw;
-        const bool ok = tile < n_tiles && l_pix < src_pix && (unsigned)sy < (unsigned)g.sh;
+        const bool ok = tile < t_end && l_pix < src_pix && (unsigned)sy < (unsigned)g.sh;
         const int64_t at = ok ? (((int64_t)img * g.sh + sy) * g.sw + sx) * 64 + 4 * q4 : 0;
         float4 v = *reinterpret_cast<const float4 *>(g.src.v + at);
         if (MODE >= 1) ly[s] = *reinterpret_cast<const float4 *>(g.src.y + at);
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     };
 
 #pragma unroll
-    for (int s = 0; s < S_SLOTS; ++s) issue(s, blockIdx.x);
+    for (int s = 0; s < S_SLOTS; ++s) issue(s, t_first);
     // zero pixel of both buffers, once
     if (threadIdx.x < 2 * S_PITCH) lds[(threadIdx.x / S_PITCH) * S_BUF + S_PIX * S_PITCH + threadIdx.x % S_PITCH] = 0u;
 
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     load_w(std::integral_constant<int, 1>{}, kx_first, 1);
 
     int cur = 0;
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, cur ^= 1) {
+    for (int tile = t_first; tile < t_end; ++tile, cur ^= 1) {
         asm volatile("" : "+v"(q4), "+v"(pix0), "+v"(wlane));
         const unsigned *xb = lds + cur * S_BUF;
         unsigned *nb = lds + (cur ^ 1) * S_BUF;
@@ -275,11 +279,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 } else if constexpr (i < n_read + n_w + n_issue) {
                     constexpr int k = i - n_read - n_w, s = is_lo + k / 2, piece = k % 2;
                     if constexpr (piece == 0) {                  // address of slot s of the next tile
-                        const int nt_ = tile + gridDim.x;
+                        const int nt_ = tile + 1;
                         const int img = nt_ / g.groups, oy0 = (nt_ - img * g.groups) * g.rows;
                         const int l_pix = pix0 + 16 * s, l_row = (l_pix * inv_sw) >> 16;
                         const int sy = oy0 + g.dmin + l_row, sx = l_pix - l_row * g.sw;
-                        c_ok = nt_ < n_tiles && l_pix < src_pix && (unsigned)sy < (unsigned)g.sh;
+                        c_ok = nt_ < t_end && l_pix < src_pix && (unsigned)sy < (unsigned)g.sh;
                         c_at = c_ok ? (((int64_t)img * g.sh + sy) * g.sw + sx) * 64 + 4 * q4 : 0;
                     } else {
                         const float4 v = *reinterpret_cast<const float4 *>(g.src.v + c_at);
