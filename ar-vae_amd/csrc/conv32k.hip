@@ -1,13 +1,14 @@
 // Down map of the 32-channel k4/s2/p1 links (Conv2d forward, ConvTranspose2d data gradient) at 16x16 and 8x8 output size,
-// WEIGHT-STREAMING form (gfx950).
+// FOUR-WAY REDUCTION-SPLIT form (gfx950).
 //
 //   lo[n,ly,lx,clo] = ep( sum_{ky,kx,chi} hi[n,2ly-1+ky,2lx-1+kx,chi] * wt[clo][chi][ky][kx] )
 //
-// down32x_kernel (conv32.hip) keeps a wave's 128 weights x 3 bf16 terms in 192 registers.  What is left holds ONE tile of
-// input in flight per CU: 43 KB per ~4 us tile = 2.8 TB/s over the chip, and that -- not the 12 us of MFMA work, not the HBM
-// roof -- is what its 33-36 us at B = 512 come from (98 MB per launch).  Here the split weights stay in L2 (conv32_weight_prep's
-// DOWN part, 98 KB per layer) and a wave streams the 3 KB it needs per reduction step straight into registers, two steps
-// ahead; the registers freed hold TWO tiles of input in flight.
+// down32x_kernel (conv32.hip) splits the reduction two ways: a wave keeps 128 weights x 3 bf16 terms in 192 registers, one
+// accumulator tile, and what is left holds one tile of input in flight.  Here the reduction is split FOUR ways (wave = kernel
+// row): a wave's weights are 96 registers (resident for the whole launch, 24 coalesced loads from conv32_weight_prep's DOWN
+// part), it owns two accumulator tiles (its MFMAs alternate between them: no dependent chains) and two tiles of input are in
+// flight.  (A first version streamed the weights from L2 instead; at 12 MFMAs per reduction step two steps of lookahead do not
+// cover an L2 round trip.)
 //   * a tile = 64 lo pixels (4 rows at 16x16, one image at 8x8) = two 32-pixel MFMA column tiles; weight = A operand
 //     (row = output channel), pixels = B operand, 32x32x16 bf16, six partial products per multiply-add, smallest first;
 //   * wave = kernel row ky (K split four ways): 8 reduction steps (kx, 16-channel chunk) of 12 MFMAs per tile.  The four
@@ -47,8 +48,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                                                                                                  int n_img, int n_tiles) {
     KSTAMP(0);
     using K = DownK<LO>;
-    using T = typename K::T;
-    constexpr int HW = K::HW, PR = K::PR, PIX = K::PIX, SLOTS = K::SLOTS, HI = 2 * LO;
+    constexpr int HW = K::HW, PIX = K::PIX, SLOTS = K::SLOTS, HI = 2 * LO;
     extern __shared__ __attribute__((aligned(16))) unsigned lds[];
     unsigned *xch = lds + 2 * K::BUF;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
