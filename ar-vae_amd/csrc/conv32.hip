@@ -1493,15 +1493,15 @@ static int ep_mode(const Ep32 &ep, int relu) {
     return ep.gate_bits != nullptr ? EP_GATE_B : ep.gate != nullptr ? EP_GATE_F : relu ? EP_RELU : EP_PLAIN;
 }
 
-// (conv32k.hip: the weight-streaming kernel of the 16x16 / 8x8 layers; needs the prepared weights)
-bool conv32_down_stream_fits(const arvae_link_t *l, const Ep32 &ep);
-void conv32_down_stream(const arvae_link_t *l, const float *hi, const Ep32 &ep, int mode, hipStream_t s);
+// (conv32k.hip: the four-way reduction-split kernel of the 16x16 / 8x8 layers; needs the prepared weights)
+bool conv32_down_ksplit_fits(const arvae_link_t *l, const Ep32 &ep);
+void conv32_down_ksplit(const arvae_link_t *l, const float *hi, const Ep32 &ep, int mode, hipStream_t s);
 
 template <int LO> static int launch_down(const arvae_link_t *l, const Operand &hi, const float *wt, const Ep32 &ep, int relu, hipStream_t s) {
     const int tiles = tiles_for<LO>(l->n), grid = grid_for_tiles(tiles);
     static const bool other = getenv("ARVAE_CONV32_FP32") != nullptr || getenv("ARVAE_CONV32_BF16X2") != nullptr;
-    if (LO != 4 && !other && conv32_down_stream_fits(l, ep)) {
-        conv32_down_stream(l, hi.v, ep, ep_mode(ep, relu), s);
+    if (LO != 4 && !other && conv32_down_ksplit_fits(l, ep)) {
+        conv32_down_ksplit(l, hi.v, ep, ep_mode(ep, relu), s);
         return check_launch(LO == 16 ? "down32_kernel<16>" : "down32_kernel<8>");
     }
     switch (ep_mode(ep, relu)) {

@@ -313,7 +313,7 @@ static int cu_count_k() {
     return n;
 }
 
-bool conv32_down_stream_fits(const arvae_link_t *l, const Ep32 &ep) {
+bool conv32_down_ksplit_fits(const arvae_link_t *l, const Ep32 &ep) {
     static const bool off = getenv("ARVAE_DOWN32_REGW") != nullptr;          // diagnostic: the register-resident-weight kernel
     static const bool only16 = getenv("ARVAE_D32K_ONLY16") != nullptr;      // diagnostic (stamps of the 16x16 launch)
     return !off && ep.wprep != nullptr && (l->lh == 16 || (l->lh == 8 && !only16));
@@ -339,7 +339,7 @@ template <int LO> static void launch_down_k_mode(const float *hi, const Ep32 &ep
     }
 }
 
-void conv32_down_stream(const arvae_link_t *l, const float *hi, const Ep32 &ep, int mode, hipStream_t s) {
+void conv32_down_ksplit(const arvae_link_t *l, const float *hi, const Ep32 &ep, int mode, hipStream_t s) {
     if (l->lh == 16) launch_down_k_mode<16>(hi, ep, mode, l->n, s);
     else launch_down_k_mode<8>(hi, ep, mode, l->n, s);
 }
