@@ -528,6 +528,130 @@ __global__ __launch_bounds__(64 * WGS_WAVES) void wgrad_c1s_kernel(Operand lo, O
 }
 static_assert(WGS_WAVES == 8, "the reduce step gives one of the 8 accumulator registers to each wave");
 
+// ================================================================================================
+// wgrad_c1w: the same per-wave streaming weight gradient for the STRIDE-1 single-channel links with 64 channels on the other
+// side (Morpho-MNIST Conv2d(1, 64, 4) and ConvTranspose2d(64, 1, 4), imagevae/mnist_vae.py:16-47):
+//     dwt[c][ky][kx] += sum over (n, r, col) of lo[n][r][col][c] * img[n][r + ky][col + kx]
+// The generic gather-GEMM took 104 us + a 17 us slice reduce + 33 us of bias sums per launch for 164 MB of operands.  A wave
+// owns one lo row (lw <= 28 positions x 64 channels) and the four image rows it meets; 16x16x4 fp32 MFMAs with N = the 16 taps
+// and four channel tiles; positions beyond lw are zero slots of the row buffer.  Bias sums ride along (slab [64][16] + 64 + 1).
+constexpr int W1_CH = 64, W1_SLOTS = 28;        // channels; position slots per row (seven quads)
+constexpr int W1_PS = 80;                       // LDS position stride: the A reads of the four position slots (g * 80 + li) fall on
+                                                // four disjoint bank groups
+constexpr int W1_IMS = 32;                      // LDS pitch of an image row (hw <= 31)
+constexpr int W1_WAVES = 8;
+constexpr int W1_LO_LOADS = (W1_SLOTS * W1_CH / 4 + 63) / 64;       // 16-byte loads per lane and lo row (7)
+
+__global__ __launch_bounds__(64 * W1_WAVES) void wgrad_c1w_kernel(Operand lo, Operand img, float *__restrict__ slab, int n_img, int lh,
+                                                                 int lw, int hw) {
+    __shared__ __attribute__((aligned(16))) float lo_s[W1_WAVES][W1_SLOTS * W1_PS];     // reused as the reduce buffer
+    __shared__ float im_s[W1_WAVES][4 * W1_IMS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
+    const int ky = li >> 2, kx = li & 3;
+    float *lw_s = lo_s[wave], *iw = im_s[wave];
+    for (int i = lane; i < W1_SLOTS * W1_PS; i += 64) lw_s[i] = 0.f;          // slots >= lw stay zero for the whole launch
+    for (int i = lane; i < 4 * W1_IMS; i += 64) iw[i] = 0.f;
+    f32x4 acc[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float lo_sum[4] = {0.f, 0.f, 0.f, 0.f}, img_sum = 0.f;
+    const float gs = img.scale != nullptr ? img.scale[0] : 1.f;
+    const int n_rows = n_img * lh, hh = lh + 3;
+    const int wave0 = blockIdx.x * W1_WAVES + wave, n_waves = gridDim.x * W1_WAVES;
+    const int row_f4 = lw * (W1_CH / 4);                                     // 16-byte pieces of a lo row
+    float4 lr[W1_LO_LOADS];
+    float ir[2];
+    auto issue = [&](int row) __attribute__((always_inline)) {
+        const bool in = row < n_rows;
+        const int n = row / lh, r = row - n * lh;
+#pragma unroll
+        for (int i = 0; i < W1_LO_LOADS; ++i) {
+            const int e = 64 * i + lane;
+            const bool ok = in && e < row_f4;
+            const float4 v = lo.at4(ok ? (int64_t)row * lw * W1_CH + 4 * e : 0);
+            lr[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {                            // image rows r .. r + 3, hw pixels each
+            const int e = 64 * i + lane, pr = e / hw, px = e - pr * hw;
+            const bool ok = in && pr < 4;
+            const float v = img.at(ok ? ((int64_t)n * hh + r + pr) * hw + px : 0);
+            ir[i] = ok ? gs * v : 0.f;
+        }
+    };
+    issue(wave0);
+    for (int row = wave0; row < n_rows; row += n_waves) {
+        const int r = row % lh;
+#pragma unroll
+        for (int i = 0; i < W1_LO_LOADS; ++i) {
+            const int e = 64 * i + lane;
+            if (e < row_f4) *reinterpret_cast<float4 *>(lw_s + (e >> 4) * W1_PS + 4 * (e & 15)) = lr[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int e = 64 * i + lane, pr = e / hw, px = e - pr * hw;
+            if (pr < 4) {
+                iw[pr * W1_IMS + px] = ir[i];
+                if (pr == 0 || r == lh - 1) img_sum += ir[i];    // every image pixel once: row r, and the last lo row's three extra rows
+            }
+        }
+        // the wave's LDS operations execute in order: no barrier, only keep the compiler from moving them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        issue(row + n_waves);
+#pragma unroll
+        for (int q = 0; q < W1_SLOTS / 4; ++q) {                 // positions 4 q .. 4 q + 3, this lane's slot: c = 4 q + g
+            const int c = 4 * q + g;
+            const float b = iw[ky * W1_IMS + c + kx];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const float a = lw_s[c * W1_PS + 16 * ct + li];
+                lo_sum[ct] += a;
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[ct], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // reduce the waves' tiles: red[wave][ct*4 + r][lane]; D row = 4g + r -> channel 16 ct + 4g + r, column = tap li
+    float *red = &lo_s[0][0];
+    __syncthreads();
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(wave * 16 + ct * 4 + r) * 64 + lane] = acc[ct][r];
+    __syncthreads();
+    float *out = slab + (int64_t)blockIdx.x * SLAB_C1W_FLOATS;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {                                // wave w finishes registers 2w, 2w + 1 of the 16
+        const int reg = 2 * wave + e, ct = reg >> 2, r = reg & 3;
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < W1_WAVES; ++w) tot += red[(w * 16 + reg) * 64 + lane];
+        out[(16 * ct + 4 * g + r) * 16 + li] = tot;
+    }
+    // bias sums: lo per channel (lane li of tile ct, over the 4 position slots and the waves), image total
+    __syncthreads();
+    constexpr int T = 64 * W1_WAVES;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) red[ct * T + threadIdx.x] = lo_sum[ct];
+    red[4 * T + threadIdx.x] = img_sum;
+    __syncthreads();
+    if (threadIdx.x < W1_CH) {
+        const int ct = threadIdx.x >> 4, i = threadIdx.x & 15;
+        float tot = 0.f;
+        for (int j = 0; j < T / 16; ++j) tot += red[ct * T + j * 16 + i];
+        out[W1_CH * 16 + threadIdx.x] = tot;
+    } else if (threadIdx.x < 128) {
+        float tot = 0.f;
+        for (int j = lane; j < T; j += 64) tot += red[4 * T + j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+        if (lane == 0) out[W1_CH * 16 + W1_CH] = tot;
+    }
+}
+static_assert(W1_WAVES == 8 && W1_WAVES * W1_SLOTS * W1_PS >= W1_WAVES * 16 * 64, "wgrad_c1w_kernel: the row buffers hold the reduce tiles");
+
 // ------------------------------------------------------------------------------------------------
 bool conv_c1_fits(const arvae_link_t *l) {
     return l->chi == 1 && l->clo == CC && l->kh == 4 && l->kw == 4 && l->stride == 2 && l->pad == 1 && l->hh == HI1 &&
@@ -628,6 +752,26 @@ int conv_c1_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &img, 
     SlabJob job;
     if (int rc = conv_c1_wgrad_partial(l, lo, img, dwt, dbias, bias_mode, slab, s, &job)) return rc;
     return slab_reduce(job, s);
+}
+
+// ---- the stride-1 64-channel single-channel links (Morpho-MNIST) ----------------------------------------------------
+bool conv_c1w_fits(const arvae_link_t *l) {
+    static const bool off = getenv("ARVAE_C1W_GENERIC") != nullptr;            // diagnostic: the generic gather-GEMM instead
+    return !off && l->chi == 1 && l->clo == W1_CH && l->kh == 4 && l->kw == 4 && l->stride == 1 && l->pad == 0 && l->lw <= W1_SLOTS &&
+           l->hw == l->lw + 3 && l->hh == l->lh + 3 && l->hw < W1_IMS && 4 * l->hw <= 128 && l->hi_perm_c == 0 && l->lo_perm_c == 0;
+}
+static int wgrad_c1w_groups(const arvae_link_t *l) {
+    const int units = (l->n * l->lh + W1_WAVES - 1) / W1_WAVES;
+    return units < 256 ? units : 256;
+}
+int64_t conv_c1w_wgrad_ws_floats(const arvae_link_t *l) { return (int64_t)wgrad_c1w_groups(l) * SLAB_C1W_FLOATS; }
+
+int conv_c1w_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &img, float *dwt, float *dbias, int bias_mode,
+                   float *slab, hipStream_t s) {
+    const int grid = wgrad_c1w_groups(l);
+    ARVAE_LAUNCH(wgrad_c1w_kernel, dim3(grid), dim3(64 * W1_WAVES), 0, s, lo, img, slab, l->n, l->lh, l->lw, l->hw);
+    if (int rc = check_launch("wgrad_c1w_kernel")) return rc;
+    return slab_reduce(SlabJob{slab, dwt, dbias, grid, SLAB_C1W, bias_mode}, s);
 }
 
 }  // namespace arvae

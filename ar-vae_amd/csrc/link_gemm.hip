@@ -29,6 +29,10 @@ int dense_wgrad(const arvae_link_t *l, const Operand &g, const float *x, float *
 
 // 1-channel 64x64 image links (conv_c1.hip)
 bool conv_c1_fits(const arvae_link_t *l);
+bool conv_c1w_fits(const arvae_link_t *l);
+int64_t conv_c1w_wgrad_ws_floats(const arvae_link_t *l);
+int conv_c1w_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &img, float *dwt, float *dbias, int bias_mode,
+                   float *slab, hipStream_t s);
 int conv_c1_down(const arvae_link_t *l, const Operand &img, const float *wt, const float *bias, int relu,
                  const float *gate, const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s);
 int conv_c1_up(const arvae_link_t *l, const float *lo, const float *wt, const float *bias, float *out, hipStream_t s);
@@ -854,6 +858,7 @@ extern "C" int64_t arvae_link_wgrad_ws_floats(const arvae_link_t *link) {
     if (conv64_wgrad_fits(link) && conv64_wgrad_ws_floats(link) > need) need = conv64_wgrad_ws_floats(link);
     if (conv32_fits(link) && conv32_wgrad_ws_floats(link) > need) need = conv32_wgrad_ws_floats(link);
     if (conv_c1_fits(link) && conv_c1_wgrad_ws_floats(link) > need) need = conv_c1_wgrad_ws_floats(link);
+    if (conv_c1w_fits(link) && conv_c1w_wgrad_ws_floats(link) > need) need = conv_c1w_wgrad_ws_floats(link);
     return need;
 }
 
@@ -871,6 +876,8 @@ extern "C" int arvae_link_wgrad(const arvae_link_t *link, const arvae_operand_t 
     if (conv_c1_fits(link) && lo->mask == nullptr && hi->mask == nullptr && lo->act != ARVAE_ACT_SELU &&
         hi->act != ARVAE_ACT_SELU)
         return conv_c1_wgrad(link, make_operand(lo), make_operand(hi), dwt, dbias, bias_side, ws, st);
+    if (conv_c1w_fits(link))
+        return conv_c1w_wgrad(link, make_operand(lo), make_operand(hi), dwt, dbias, bias_side, ws, st);
     if (wgrad_fast(link, lo, hi))
         return conv32_wgrad(link, make_operand(lo), make_operand(hi), dwt, dbias, bias_side, ws, st);
     p.lo = make_operand(lo);

@@ -7,7 +7,8 @@ namespace arvae {
 constexpr int RED_OUT = 64, RED_Z = 4;
 
 __device__ __forceinline__ void slab_reduce_block(const SlabJob &j, int block, float (*red)[RED_OUT]) {
-    const int slab_floats = j.kind == SLAB_C32 ? SLAB_C32_FLOATS : SLAB_C1_FLOATS;
+    const int slab_floats = j.kind == SLAB_C32 ? SLAB_C32_FLOATS : j.kind == SLAB_C1 ? SLAB_C1_FLOATS : SLAB_C1W_FLOATS;
+    const int c1_ch = j.kind == SLAB_C1 ? 32 : 64;
     const int il = threadIdx.x & (RED_OUT - 1), zg = threadIdx.x / RED_OUT;
     const int i = block * RED_OUT + il;
     const int ic = i < slab_floats ? i : 0;
@@ -38,8 +39,8 @@ __device__ __forceinline__ void slab_reduce_block(const SlabJob &j, int block, f
                 j.dbias[i - 16 * 32 * 32] += tot;
             }
         } else {
-            if (i < 32 * 16) j.dwt[i] += tot;                    // wt[clo][0][ky][kx] is exactly [clo][tap]
-            else if (i < 32 * 16 + 32) { if (j.bias_mode == 1) j.dbias[i - 32 * 16] += tot; }
+            if (i < c1_ch * 16) j.dwt[i] += tot;                 // wt[clo][0][ky][kx] is exactly [clo][tap]
+            else if (i < c1_ch * 16 + c1_ch) { if (j.bias_mode == 1) j.dbias[i - c1_ch * 16] += tot; }
             else if (j.bias_mode == 2) j.dbias[0] += tot;
         }
     }
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void slab_reduce_batch_kernel(SlabReduceBatch 
 }
 
 static int job_blocks(const SlabJob &j) {
-    return ((j.kind == SLAB_C32 ? SLAB_C32_FLOATS : SLAB_C1_FLOATS) + RED_OUT - 1) / RED_OUT;
+    return ((j.kind == SLAB_C32 ? SLAB_C32_FLOATS : j.kind == SLAB_C1 ? SLAB_C1_FLOATS : SLAB_C1W_FLOATS) + RED_OUT - 1) / RED_OUT;
 }
 
 int slab_reduce(const SlabJob &job, hipStream_t s) {
