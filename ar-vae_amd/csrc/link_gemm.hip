@@ -564,6 +564,17 @@ __global__ __launch_bounds__(256) void down_single_channel_mfma_kernel(Geom g, O
         g.d_lw.divmod((uint32_t)(pos < npos ? pos : npos - 1), ly, lx);
         const int y0 = (int)ly * g.stride - g.pad, x0 = (int)lx * g.stride - g.pad;
         f32x4t acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        // keep-mask bytes of this lane's 16 outputs: requested before the MFMAs (one load -> multiply -> store chain per output
+        // was 58 of this kernel's 95 us on the first Morpho-MNIST layer)
+        unsigned char mk[4][4];
+        if (ep.mask != nullptr) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int p = 16 * mt + 4 * quad + i, pc = p < npos ? p : npos - 1;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) mk[i][nt] = ep.mask[((int64_t)img * npos + pc) * 64 + 16 * nt + col];
+            }
+        }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int y = y0 + tky[kk], x = x0 + tkx[kk];
@@ -580,7 +591,7 @@ __global__ __launch_bounds__(256) void down_single_channel_mfma_kernel(Geom g, O
             for (int nt = 0; nt < 4; ++nt) {
                 const int64_t o = ((int64_t)img * npos + p) * 64 + 16 * nt + col;
                 float v = act_fwd(acc[nt][i] + bias[nt], ep.act);
-                if (ep.mask != nullptr) v *= 2.f * (float)ep.mask[o];
+                if (ep.mask != nullptr) v *= 2.f * (float)mk[i][nt];
                 ep.out[o] = v;
             }
         }
