@@ -25,20 +25,33 @@ __device__ __forceinline__ void mfma4(f32x16 &acc, const float (&a)[4], const fl
 constexpr int NW = 16;                       // wavefronts per workgroup = reduction split
 constexpr int DENSE_THREADS = 64 * NW;
 
-// sum the NW waves' 32x32 partial tiles through LDS; wave w returns accumulator register w of the total
-__device__ __forceinline__ float reduce_waves(float *red, const f32x16 &acc, int wave, int lane) {
+// sum the NWT waves' 32x32 partial tiles through LDS; wave w returns accumulator registers w * RPW .. + RPW - 1 of the total
+template <int NWT>
+__device__ __forceinline__ void reduce_waves(float *red, const f32x16 &acc, int wave, int lane, float (&out)[16 / NWT]) {
+    constexpr int RPW = 16 / NWT;
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[r];
     __syncthreads();
-    float s = 0.f;
 #pragma unroll
-    for (int ws = 0; ws < NW; ++ws) s += red[(ws * 16 + wave) * 64 + lane];
-    return s;
+    for (int e = 0; e < RPW; ++e) {
+        float s = 0.f;
+#pragma unroll
+        for (int ws = 0; ws < NWT; ++ws) s += red[(ws * 16 + wave * RPW + e) * 64 + lane];
+        out[e] = s;
+    }
+}
+// a tile is split over 16 waves when the reduction is long (one or two rounds of loads per wave: the kernels are latency-bound)
+// and over 4 when it is short and the tiles are many (K <= 512 with >= 512 tiles: the 16-way LDS reduction of 16 accumulator
+// registers per wave then costs more than the 8 MFMAs each wave contributes -- Morpho-MNIST's 256 <-> 2888 layers)
+static bool dense_short_k(int k, int tiles) {
+    static const bool off = getenv("ARVAE_DENSE_NW16") != nullptr;
+    return !off && k <= 512 && tiles >= 512;
 }
 
 // ---- forward: Y[m][out_perm(n)] = act( sum_k X[m][km] * W[n][feat(km)] + b[n] ),  km = memory column ----------
-__global__ __launch_bounds__(DENSE_THREADS) void dense_fwd_kernel(DenseArgs p) {
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void dense_fwd_kernel(DenseArgs p) {
     __shared__ float red[NW * 16 * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, rc = lane & 31;
     const int m = blockIdx.x * 32 + rc, n = blockIdx.y * 32 + rc;
@@ -98,14 +111,23 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_fwd_kernel(DenseArgs p) {
                 b[u][0] = bv.x; b[u][1] = bv.y; b[u][2] = bv.z; b[u][3] = bv.w;
             }
         } else if (vec) {
+            // channel-permuted input that the 4 x 4 block path cannot take (Morpho-MNIST: 8 channels x 361 positions): the reduction
+            // runs in FEATURE order, so W is one 16-byte load per lane and the four X values of a lane sit 4 c_count bytes apart in
+            // one cache line of its row -- the other way round (X contiguous, W gathered at a stride of hw floats) every W load
+            // touched its own line (93 us for the 2888 -> 256 layer at B = 1024)
+            const unsigned inv_hw = (1u << 24) / (unsigned)p.in_perm.hw + 1u;          // f / hw = (f * inv_hw) >> 24 for f * hw < 2^24
 #pragma unroll
             for (int u = 0; u < FU; ++u) {
-                const int k0 = (q0 + u * NW) * 8 + half * 4;
-                const bool ok = k0 < p.n_in;
-                const float4 av = *reinterpret_cast<const float4 *>(xrow + (ok ? k0 : 0));
-                a[u][0] = ok ? av.x : 0.f; a[u][1] = ok ? av.y : 0.f; a[u][2] = ok ? av.z : 0.f; a[u][3] = ok ? av.w : 0.f;
+                const int f0 = (q0 + u * NW) * 8 + half * 4;
+                const bool ok = f0 < p.n_in;
+                const float4 bv = *reinterpret_cast<const float4 *>(wrow + (ok ? f0 : 0));
+                b[u][0] = bv.x; b[u][1] = bv.y; b[u][2] = bv.z; b[u][3] = bv.w;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) b[u][t] = wrow[p.in_perm.to_feat(ok ? k0 + t : 0)];
+                for (int t = 0; t < 4; ++t) {
+                    const unsigned f = ok ? (unsigned)(f0 + t) : 0u, c = (f * inv_hw) >> 24, pp = f - c * (unsigned)p.in_perm.hw;
+                    const float av = xrow[pp * (unsigned)p.in_perm.c_count + c];
+                    a[u][t] = ok ? av : 0.f;
+                }
             }
         } else {
 #pragma unroll
@@ -130,18 +152,23 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_fwd_kernel(DenseArgs p) {
             mfma4(acc, a[u], b[u]);
         }
     }
-    const float v = reduce_waves(red, acc, wave, lane);
+    float v[16 / NW];
+    reduce_waves<NW>(red, acc, wave, lane, v);
     if (nok) {
         const float bias = p.bias != nullptr ? p.bias[n] : 0.f;
         const int col = p.out_perm.to_mem(n);
-        const int row = blockIdx.x * 32 + (wave & 3) + 8 * (wave >> 2) + 4 * half;      // accumulator register = wave
-        if (row < p.batch) p.out[(int64_t)row * p.n_out + col] = act_fwd(v + bias, p.act);
+#pragma unroll
+        for (int e = 0; e < 16 / NW; ++e) {
+            const int reg = wave * (16 / NW) + e;                                        // accumulator register
+            const int row = blockIdx.x * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+            if (row < p.batch) p.out[(int64_t)row * p.n_out + col] = act_fwd(v[e] + bias, p.act);
+        }
     }
 }
 
 // ---- dgrad: dX[m][in_mem] = sum_{nm} G[m][nm] * W[feat_out(nm)][feat_in(in_mem)]  ---------------------------
 // reduction loop: FU chunks per wave and round, loads first (see dense_fwd_kernel); MODE = Operand::mode() of G
-template <int MODE>
+template <int MODE, int NW>
 __device__ __forceinline__ void dense_dgrad_loop(const DenseArgs &p, int64_t grow, int kf, bool mok, bool kok, bool vec, int wave,
                                                  int half, f32x16 &acc) {
     constexpr int FU = 4;
@@ -195,7 +222,8 @@ __device__ __forceinline__ void dense_dgrad_loop(const DenseArgs &p, int64_t gro
     }
 }
 
-__global__ __launch_bounds__(DENSE_THREADS) void dense_dgrad_kernel(DenseArgs p) {
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void dense_dgrad_kernel(DenseArgs p) {
     __shared__ float red[NW * 16 * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, rc = lane & 31;
     // A tile owns 32 consecutive input FEATURES (columns of W, read coalesced in the reduction loop); with a channel
@@ -211,15 +239,20 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_dgrad_kernel(DenseArgs p)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
-    if (p.a.mode() == 0) dense_dgrad_loop<0>(p, grow, kf, mok, kok, vec, wave, half, acc);
-    else if (p.a.mode() == 1) dense_dgrad_loop<1>(p, grow, kf, mok, kok, vec, wave, half, acc);
-    else dense_dgrad_loop<2>(p, grow, kf, mok, kok, vec, wave, half, acc);
-    const float v = reduce_waves(red, acc, wave, lane);
+    if (p.a.mode() == 0) dense_dgrad_loop<0, NW>(p, grow, kf, mok, kok, vec, wave, half, acc);
+    else if (p.a.mode() == 1) dense_dgrad_loop<1, NW>(p, grow, kf, mok, kok, vec, wave, half, acc);
+    else dense_dgrad_loop<2, NW>(p, grow, kf, mok, kok, vec, wave, half, acc);
+    float v[16 / NW];
+    reduce_waves<NW>(red, acc, wave, lane, v);
     if (kok) {
-        const int row = blockIdx.x * 32 + (wave & 3) + 8 * (wave >> 2) + 4 * half;
-        if (row < p.batch) {
-            const int64_t idx = (int64_t)row * p.n_in + km;
-            p.out[idx] = (p.gate == nullptr || p.gate[idx] > 0.f) ? v : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16 / NW; ++e) {
+            const int reg = wave * (16 / NW) + e;
+            const int row = blockIdx.x * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+            if (row < p.batch) {
+                const int64_t idx = (int64_t)row * p.n_in + km;
+                p.out[idx] = (p.gate == nullptr || p.gate[idx] > 0.f) ? v[e] : 0.f;
+            }
         }
     }
 }
@@ -650,7 +683,9 @@ int dense_fwd(const arvae_link_t *l, const float *x, const float *w, const float
         launch_rows_gemm<RG_ROWSK, RG_ROWSK, RG_EP_FWD>(g, 1, s);
         return check_launch("rows_gemm_kernel<fwd>");
     }
-    ARVAE_LAUNCH(dense_fwd_kernel, dim3((p.batch + 31) / 32, (p.n_out + 31) / 32), dim3(DENSE_THREADS), 0, s, p);
+    const dim3 grid((p.batch + 31) / 32, (p.n_out + 31) / 32);
+    if (dense_short_k(p.n_in, (int)(grid.x * grid.y))) ARVAE_LAUNCH(dense_fwd_kernel<4>, grid, dim3(256), 0, s, p);
+    else ARVAE_LAUNCH(dense_fwd_kernel<16>, grid, dim3(1024), 0, s, p);
     return check_launch("dense_fwd_kernel");
 }
 
@@ -664,7 +699,9 @@ int dense_dgrad(const arvae_link_t *l, const Operand &g, const float *w, const f
         launch_rows_gemm<RG_ROWSK, RG_KROWS, RG_EP_FWD>(r, 1, s);
         return check_launch("rows_gemm_kernel<dgrad>");
     }
-    ARVAE_LAUNCH(dense_dgrad_kernel, dim3((p.batch + 31) / 32, (p.n_in + 31) / 32), dim3(DENSE_THREADS), 0, s, p);
+    const dim3 grid((p.batch + 31) / 32, (p.n_in + 31) / 32);
+    if (dense_short_k(p.n_out, (int)(grid.x * grid.y))) ARVAE_LAUNCH(dense_dgrad_kernel<4>, grid, dim3(256), 0, s, p);
+    else ARVAE_LAUNCH(dense_dgrad_kernel<16>, grid, dim3(1024), 0, s, p);
     return check_launch("dense_dgrad_kernel");
 }
 
