@@ -88,6 +88,7 @@ struct Epilogue {
     const uint8_t *mask;
     float *out;
     int act;
+    GateOp gate = GateOp{};      // down_single_channel_mfma_kernel only: result *= act'(gate.y) * 2 gate.mask at the output location
 };
 
 // gather context of a tensor position (n, y0, x0) and of a (ky, kx, channel) tap
@@ -567,12 +568,18 @@ __global__ __launch_bounds__(256) void down_single_channel_mfma_kernel(Geom g, O
         // keep-mask bytes of this lane's 16 outputs: requested before the MFMAs (one load -> multiply -> store chain per output
         // was 58 of this kernel's 95 us on the first Morpho-MNIST layer)
         unsigned char mk[4][4];
-        if (ep.mask != nullptr) {
+        float gy[4][4];
+        if (ep.mask != nullptr || ep.gate.y != nullptr) {
+            const uint8_t *mp = ep.gate.y != nullptr ? ep.gate.mask : ep.mask;      // (a gated launch has no forward keep-mask)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int p = 16 * mt + 4 * quad + i, pc = p < npos ? p : npos - 1;
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) mk[i][nt] = ep.mask[((int64_t)img * npos + pc) * 64 + 16 * nt + col];
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int64_t o = ((int64_t)img * npos + pc) * 64 + 16 * nt + col;
+                    mk[i][nt] = mp != nullptr ? mp[o] : (unsigned char)1;
+                    if (ep.gate.y != nullptr) gy[i][nt] = ep.gate.y[o];
+                }
             }
         }
 #pragma unroll
@@ -591,7 +598,13 @@ __global__ __launch_bounds__(256) void down_single_channel_mfma_kernel(Geom g, O
             for (int nt = 0; nt < 4; ++nt) {
                 const int64_t o = ((int64_t)img * npos + p) * 64 + 16 * nt + col;
                 float v = act_fwd(acc[nt][i] + bias[nt], ep.act);
-                if (ep.mask != nullptr) v *= 2.f * (float)mk[i][nt];
+                if (ep.gate.y != nullptr) {
+                    // (the saved output of a dropout layer is the kept activation times two: Operand::apply)
+                    const float ys = ep.gate.mask != nullptr ? 0.5f : 1.f, k2 = ep.gate.mask != nullptr ? 2.f : 1.f;
+                    v *= act_bwd_from_out_sel(ys * gy[i][nt], ep.gate.act) * k2 * (float)mk[i][nt];
+                } else if (ep.mask != nullptr) {
+                    v *= 2.f * (float)mk[i][nt];
+                }
                 ep.out[o] = v;
             }
         }
@@ -742,6 +755,20 @@ extern "C" int64_t arvae_link_ws_floats(const arvae_link_t *link) {
     if (link == nullptr) return 0;
     return (conv64_fits(link, false) || conv64_fits(link, true)) ? conv64_ws_floats(link) : 0;
 }
+
+namespace arvae {
+// data gradient of ConvTranspose2d(64 -> 1) with the producing layer's activation derivative / keep-mask in the epilogue
+// (plan.hip: the next layer then reads a plain pre-activation gradient and needs no operand pass)
+bool single_channel_down_gated_fits(const arvae_link_t *l) { return single_channel_mfma_fits(l); }
+int single_channel_down_gated(const arvae_link_t *link, const Operand &hi, const float *wt, const GateOp *gate, float *lo, hipStream_t s) {
+    DownPolicy p;
+    if (int rc = make_geom(link, p.g)) return rc;
+    Epilogue ep{nullptr, nullptr, lo, ARVAE_ACT_NONE};
+    ep.gate = *gate;
+    ARVAE_LAUNCH(down_single_channel_mfma_kernel, dim3(link->n), dim3(256), sizeof(float) * link->hh * link->hw, s, p.g, hi, wt, ep);
+    return check_launch("link_down(single channel, mfma)");
+}
+}  // namespace arvae
 
 extern "C" int arvae_link_down(const arvae_link_t *link, const arvae_operand_t *hi, const float *wt,
                                const float *bias, int32_t out_act, const uint8_t *out_mask, float *lo, float *ws,

@@ -12,6 +12,8 @@ bool conv32_fits(const arvae_link_t *l);
 bool conv_c1_fits(const arvae_link_t *l);
 bool conv64_fits(const arvae_link_t *l, bool up);
 bool conv64s_fits(const arvae_link_t *l, bool up);
+bool single_channel_down_gated_fits(const arvae_link_t *l);
+int single_channel_down_gated(const arvae_link_t *link, const Operand &hi, const float *wt, const GateOp *gate, float *lo, hipStream_t s);
 int conv64_down(const arvae_link_t *l, const Operand &hi, const float *wt, const float *bias, int act, const uint8_t *mask,
                 float *lo, float *ws, hipStream_t s, const GateOp *gate);
 int conv64_up(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, int act, const uint8_t *mask,
@@ -294,6 +296,9 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
                 Operand g_op = make_operand(&gop);
                 g_op.scale = g_scale;
                 rc = conv_c1_down(&lk, g_op, w, nullptr, 0, gate_bits ? nullptr : gate, gate_bits, nullptr, d_in, hs);
+                *gated = true;
+            } else if (gate_op != nullptr && !conv64_fits(&lk, false) && !conv_c1_fits(&lk) && single_channel_down_gated_fits(&lk)) {
+                rc = single_channel_down_gated(&lk, make_operand(&gop), w, gate_op, d_in, hs);
                 *gated = true;
             } else if (gate_op != nullptr && conv64s_fits(&lk, false)) {       // (the gathering kernel's scattered epilogue loses more than the operand pass costs)
                 rc = conv64_down(&lk, make_operand(&gop), w, nullptr, ARVAE_ACT_NONE, nullptr, d_in, link_ws, hs, gate_op);
