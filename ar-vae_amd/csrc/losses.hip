@@ -45,8 +45,20 @@ __global__ __launch_bounds__(256) void kld_fwd_kernel(const float *__restrict__ 
                                                        const float *__restrict__ cap, float *__restrict__ out) {
     __shared__ float red[4];
     float s = 0.f;
-    for (int64_t i = threadIdx.x; i < count; i += 256)
-        s += kl_elem(mu[i], sg[i], pm ? pm[i] : 0.f, ps ? ps[i] : 1.f);
+    // one workgroup: eight elements per thread in flight (one element per iteration was a memory round trip each: 13 us for the
+    // MeasureVAE's 8192 latent values)
+    for (int64_t i0 = threadIdx.x; i0 < count; i0 += 256 * 8) {
+        float m[8], g[8], qm[8], qs[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t i = i0 + 256 * u, ic = i < count ? i : 0;
+            m[u] = mu[ic]; g[u] = sg[ic];
+            qm[u] = pm ? pm[ic] : 0.f; qs[u] = ps ? ps[ic] : 1.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + 256 * u < count) s += kl_elem(m[u], g[u], qm[u], qs[u]);
+    }
     const float tot = block_sum_256(s, red);
     if (threadIdx.x == 0) {
         const float kl = tot * inv_batch;
@@ -214,29 +226,55 @@ __global__ __launch_bounds__(256) void pair_finish_kernel(const float *__restric
 // token reconstruction: mean cross entropy + top-1 accuracy over [rows, V]   (utils/trainer.py:247-282)
 // one lane per row (V ~ 35 floats)
 // =================================================================================================
+constexpr int TOK_VMAX = 48;                 // widest vocabulary the staged path takes (256 rows x 48 floats of LDS)
 __global__ __launch_bounds__(256) void token_recon_kernel(const float *__restrict__ w, const int64_t *__restrict__ tgt,
                                                            int64_t rows, int vocab, float inv_rows,
                                                            float *__restrict__ partial, float *__restrict__ dw) {
     __shared__ float red[4];
+    __shared__ float stage[256 * TOK_VMAX];
     float loss = 0.f, corr = 0.f;
-    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < rows; r += (int64_t)gridDim.x * 256) {
+    const bool staged = vocab <= TOK_VMAX;
+    for (int64_t r0 = (int64_t)blockIdx.x * 256; r0 < rows; r0 += (int64_t)gridDim.x * 256) {
+        const int64_t r = r0 + threadIdx.x;
+        const int nrow = (int)(rows - r0 < 256 ? rows - r0 : 256);
         const float *row = w + r * vocab;
-        float mx = row[0];
-        int arg = 0;
-        for (int j = 1; j < vocab; ++j) {
-            const float v = row[j];
-            if (v > mx) { mx = v; arg = j; }
+        if (staged) {
+            // the 256 rows of this pass are contiguous in memory: coalesced into LDS, then a lane walks its own row there (one
+            // lane per row straight from memory is a 4-byte load at a 140-byte stride per instruction, three passes of them)
+            __syncthreads();
+            const int total = nrow * vocab;
+            for (int i = threadIdx.x; i < total; i += 256) stage[i] = w[r0 * vocab + i];
+            __syncthreads();
+            row = stage + threadIdx.x * vocab;
         }
-        float se = 0.f;
-        for (int j = 0; j < vocab; ++j) se += expf(row[j] - mx);
-        const int t = (int)tgt[r];
-        const float lse = mx + logf(se);
-        loss += lse - row[t];
-        corr += (arg == t) ? 1.f : 0.f;
-        if (dw != nullptr) {
-            const float inv = 1.f / se;
-            for (int j = 0; j < vocab; ++j)
-                dw[r * vocab + j] = (expf(row[j] - mx) * inv - (j == t ? 1.f : 0.f)) * inv_rows;
+        if (r < rows) {
+            float mx = row[0];
+            int arg = 0;
+            for (int j = 1; j < vocab; ++j) {
+                const float v = row[j];
+                if (v > mx) { mx = v; arg = j; }
+            }
+            float se = 0.f;
+            for (int j = 0; j < vocab; ++j) se += expf(row[j] - mx);
+            const int t = (int)tgt[r];
+            const float lse = mx + logf(se);
+            loss += lse - row[t];
+            corr += (arg == t) ? 1.f : 0.f;
+            if (dw != nullptr) {
+                const float inv = 1.f / se;
+                if (staged) {                                    // gradient row built in place, written out coalesced below
+                    float *srow = stage + threadIdx.x * vocab;
+                    for (int j = 0; j < vocab; ++j) srow[j] = (expf(srow[j] - mx) * inv - (j == t ? 1.f : 0.f)) * inv_rows;
+                } else {
+                    for (int j = 0; j < vocab; ++j)
+                        dw[r * vocab + j] = (expf(row[j] - mx) * inv - (j == t ? 1.f : 0.f)) * inv_rows;
+                }
+            }
+        }
+        if (staged && dw != nullptr) {
+            __syncthreads();
+            const int total = nrow * vocab;
+            for (int i = threadIdx.x; i < total; i += 256) dw[r0 * vocab + i] = stage[i];
         }
     }
     const float tl = block_sum_256(loss, red);
