@@ -467,6 +467,176 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_x3_kernel(ConvWgrad g, in
     }
 }
 
+// ---- weight gradient, row-staged, TWO lo rows per step --------------------------------------------------------------
+// conv_wgrad_rows_x3_kernel's reduction chunk is one lo row padded to 32 pixels: at lw = 22 (Morpho-MNIST) 31 % of its MFMAs
+// multiply zeros.  Here a step is a PAIR of lo rows laid side by side in one 48-slot image (slots [0, lw) and [lw, 2 lw), the
+// rest zero: three 16-pixel k-steps instead of four), for lw <= 24.  The hi operand of slot p is pixel p + kx of hi row
+// ly - pad + ky for the first row and pixel p - lw + kx of the next hi row for the second: the transposing read takes a
+// per-lane address, so a lane picks its ring image by slot.  The ring holds 8 hi row images of 32 channels (96-byte pitch:
+// 83 KB); two lo rows and two hi rows are fetched into registers while a pair's 144 MFMAs per wave run; one barrier per pair;
+// the three hi rows an image starts with arrive in ONE round trip.
+constexpr int WP_SLOTS = 48, WP_RING = 8, WP_HTRP = 48;
+constexpr int WP_APLANE = WP_SLOTS * RG_TRP, WP_HPLANE = WR_HROWS * WP_HTRP;
+
+__device__ __forceinline__ rg_bf16x8 wp_tr_operand(const unsigned short *p0, const unsigned short *p1) {
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    typedef __attribute__((address_space(3))) s16x4 *lds_ptr;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)p0);
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)p1);
+    return __builtin_bit_cast(rg_bf16x8, (s16x8)__builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+template <bool PLAIN_LO, bool PLAIN_HI>
+__global__ __launch_bounds__(256) void conv_wgrad_pairs_x3_kernel(ConvWgrad g, int img_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short wp_lds[];
+    unsigned short *lo_img = wp_lds;                            // [2][3][WP_SLOTS][RG_TRP]
+    unsigned short *hi_ring = wp_lds + 2 * 3 * WP_APLANE;       // [WP_RING][3][WR_HROWS][WP_HTRP]
+    const int lane = threadIdx.x & 63, half = lane >> 5, rc = lane & 31;
+    const int ky = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ch0 = 32 * blockIdx.x;                            // this workgroup's chi half
+    const int n0 = blockIdx.y * img_per_wg, n1 = min(g.n, n0 + img_per_wg);
+    const int na = g.clo > 32 ? 2 : 1;                          // clo halves in use
+    const int pairs = (g.lh + 1) >> 1;
+
+    // zero both lo pair images once: slots >= 2 lw are never written again
+    for (int i = threadIdx.x; i < 2 * 3 * WP_APLANE / 2; i += 256) reinterpret_cast<unsigned *>(lo_img)[i] = 0u;
+
+    // gather slots.  lo row: pixel idx / 16, channels 4 (idx % 16); hi row: pixel row idx / 8, channels ch0 + 4 (idx % 8)
+    const int lo_r[2] = {(int)threadIdx.x / 16, (int)threadIdx.x / 16 + 16};
+    const int lo_c = 4 * (threadIdx.x % 16);
+    const int hi_r[2] = {(int)threadIdx.x / 8, (int)threadIdx.x / 8 + 32};
+    const int hi_c = 4 * (threadIdx.x % 8);
+    float4 vlo[2][2], vhi[2][2];
+    auto fetch_lo = [&](int which, int n, int ly) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bool ok = ly < g.lh && lo_r[i] < g.lw && lo_c < g.clo;
+            vlo[which][i] = load_src4<PLAIN_LO>(g.lo, (((int64_t)n * g.lh + ly) * g.lw + lo_r[i]) * g.clo + lo_c, ok);
+        }
+    };
+    auto fetch_hi = [&](int which, int n, int hy) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int hx = hi_r[i] - g.pad;
+            const bool ok = hi_r[i] < WR_HROWS && hy >= 0 && hy < g.hh && hx >= 0 && hx < g.hw && ch0 + hi_c < g.chi;
+            vhi[which][i] = load_src4<PLAIN_HI>(g.hi, (((int64_t)n * g.hh + hy) * g.hw + hx) * g.chi + ch0 + hi_c, ok);
+        }
+    };
+    auto commit_lo = [&](int which, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (lo_r[i] < g.lw)
+                wr_commit(lo_img + buf * 3 * WP_APLANE + (which * g.lw + lo_r[i]) * RG_TRP + lo_c, WP_APLANE, vlo[which][i]);
+    };
+    auto ring_of = [&](int hy) { return hi_ring + ((hy + 4 * WP_RING) & (WP_RING - 1)) * 3 * WP_HPLANE; };
+    auto commit_hi = [&](int which, int hy) __attribute__((always_inline)) {
+        unsigned short *img = ring_of(hy);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (hi_r[i] < WR_HROWS) wr_commit(img + hi_r[i] * WP_HTRP + hi_c, WP_HPLANE, vhi[which][i]);
+    };
+
+    f32x16c acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][k][i] = 0.f;
+    // transposed-read lane geometry: a lane addresses pixel slot 16 s + 8 (g16 >> 1) + tq (+ 4 for the second read) and
+    // columns 16 (g16 & 1) + 4 tp
+    const int g16 = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+    const int a_base = (8 * (g16 >> 1) + tq) * RG_TRP + 16 * (g16 & 1) + 4 * tp;
+    int h_off[3][2];                                            // bf16 offset of the slot's pixel inside ITS hi row image (+ kx rows)
+    unsigned h_sel = 0;                                         // bit 2 s + r: the slot belongs to the pair's second row
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int slot = 16 * s + 8 * (g16 >> 1) + tq + 4 * r;
+            const bool second = slot >= g.lw && slot < 2 * g.lw;
+            const int px = slot < g.lw ? slot : (second ? slot - g.lw : 0);             // slots >= 2 lw: lo is zero, any finite pixel will do
+            h_off[s][r] = px * WP_HTRP + 16 * (g16 & 1) + 4 * tp;
+            h_sel |= (second ? 1u : 0u) << (2 * s + r);
+        }
+
+    for (int n = n0; n < n1; ++n) {
+        __syncthreads();                                        // the previous image's last pair is done with the ring and the lo buffers
+        // hi rows -pad .. -pad + 2 of the image: one round trip, then the first pair's own two rows + its lo rows in flight
+        {
+            float4 v3[3][2];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                fetch_hi(0, n, -g.pad + k);
+                v3[k][0] = vhi[0][0]; v3[k][1] = vhi[0][1];
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                vhi[0][0] = v3[k][0]; vhi[0][1] = v3[k][1];
+                commit_hi(0, -g.pad + k);
+            }
+        }
+        fetch_lo(0, n, 0);
+        fetch_lo(1, n, 1);
+        fetch_hi(0, n, -g.pad + 3);
+        fetch_hi(1, n, -g.pad + 4);
+        for (int pi = 0; pi < pairs; ++pi) {
+            const int ly = 2 * pi;
+            commit_lo(0, pi & 1);
+            commit_lo(1, pi & 1);
+            commit_hi(0, ly - g.pad + 3);
+            commit_hi(1, ly - g.pad + 4);
+            __syncthreads();
+            if (pi + 1 < pairs) {
+                fetch_lo(0, n, ly + 2);
+                fetch_lo(1, n, ly + 3);
+                fetch_hi(0, n, ly + 2 - g.pad + 3);
+                fetch_hi(1, n, ly + 2 - g.pad + 4);
+            }
+            if (ky < g.kh) {
+                const unsigned short *ab = lo_img + (pi & 1) * 3 * WP_APLANE + a_base;
+                const unsigned short *hbA = ring_of(ly - g.pad + ky), *hbB = ring_of(ly + 1 - g.pad + ky);
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    rg_bf16x8 a3[2][3];
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        const unsigned short *ap = ab + t * WP_APLANE + 16 * s * RG_TRP;
+                        a3[0][t] = wp_tr_operand(ap, ap + 4 * RG_TRP);
+                        a3[1][t] = wp_tr_operand(ap + 32, ap + 32 + 4 * RG_TRP);
+                    }
+                    const unsigned short *h0 = ((h_sel >> (2 * s)) & 1u) ? hbB : hbA, *h1 = ((h_sel >> (2 * s + 1)) & 1u) ? hbB : hbA;
+#pragma unroll
+                    for (int kx = 0; kx < 4; ++kx) {
+                        rg_bf16x8 b3[3];
+#pragma unroll
+                        for (int t = 0; t < 3; ++t)
+                            b3[t] = wp_tr_operand(h0 + t * WP_HPLANE + h_off[s][0] + kx * WP_HTRP, h1 + t * WP_HPLANE + h_off[s][1] + kx * WP_HTRP);
+                        X3_MFMA6(acc[0][kx], a3[0][0], a3[0][1], a3[0][2], b3[0], b3[1], b3[2]);
+                        if (na > 1) { X3_MFMA6(acc[1][kx], a3[1][0], a3[1][1], a3[1][2], b3[0], b3[1], b3[2]); }
+                    }
+                }
+            }
+        }
+    }
+    if (ky < g.kh) {
+        const int q = ch0 + rc;
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+            if (kx >= g.kw) break;
+            float *out = g.ws + ((int64_t)blockIdx.y * g.kh * g.kw + ky * g.kw + kx) * g.clo * g.chi;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int p = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (p < g.clo && q < g.chi) out[p * g.chi + q] = acc[a][kx][r];
+                }
+        }
+    }
+}
+
 // images per workgroup: one workgroup per CU (256) when the batch allows it
 static int wr_img_per_wg(const arvae_link_t *l) {
     const int halves = (l->chi + 31) / 32;
@@ -502,6 +672,27 @@ int conv64_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, fl
     const bool pl = plain_op(lo), ph = plain_op(hi);
     if (pl) g.lo.y = nullptr;
     if (ph) g.hi.y = nullptr;
+    static const bool no_pairs = getenv("ARVAE_CONV64_WGRAD_ROWS") != nullptr;     // diagnostic: one lo row per step
+    if (conv64_wgrad_rows_fits(l) && !no_pairs && l->lw <= 24 && l->kh == 4) {
+        const int ipw = wr_img_per_wg(l), slices = (l->n + ipw - 1) / ipw;
+        const dim3 grid((l->chi + 31) / 32, slices);
+        const size_t lds = (2 * 3 * WP_APLANE + WP_RING * 3 * WP_HPLANE) * sizeof(unsigned short);
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_pairs_x3_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_pairs_x3_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_pairs_x3_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_pairs_x3_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr = true;
+        }
+        if (pl && ph) ARVAE_LAUNCH((conv_wgrad_pairs_x3_kernel<true, true>), grid, dim3(256), lds, s, g, ipw);
+        else if (pl) ARVAE_LAUNCH((conv_wgrad_pairs_x3_kernel<true, false>), grid, dim3(256), lds, s, g, ipw);
+        else if (ph) ARVAE_LAUNCH((conv_wgrad_pairs_x3_kernel<false, true>), grid, dim3(256), lds, s, g, ipw);
+        else ARVAE_LAUNCH((conv_wgrad_pairs_x3_kernel<false, false>), grid, dim3(256), lds, s, g, ipw);
+        const int count = taps * l->clo * l->chi;
+        ARVAE_LAUNCH(conv64_wgrad_reduce_kernel, dim3((count * 4 + 255) / 256), dim3(256), 0, s, ws, slices, taps, l->clo, l->chi, dwt);
+        return check_launch("conv64_wgrad(rows)");
+    }
     if (conv64_wgrad_rows_fits(l)) {
         const int ipw = wr_img_per_wg(l), slices = (l->n + ipw - 1) / ipw;
         const dim3 grid((l->chi + 31) / 32, slices);
