@@ -314,7 +314,7 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
             } else if (gate != nullptr && dense_fits(&lk)) {
                 rc = dense_dgrad(&lk, make_operand(&gop), w, gate, d_in, hs);
                 *gated = true;
-            } else if (gate_op != nullptr && conv64s_fits(&lk, true)) {
+            } else if (gate_op != nullptr && conv64_fits(&lk, true)) {         // (conv64s.hip or the gathering kernel: both take the gate)
                 rc = conv64_up(&lk, make_operand(&gop), w, nullptr, ARVAE_ACT_NONE, nullptr, d_in, link_ws, hs, gate_op);
                 *gated = true;
             } else {
