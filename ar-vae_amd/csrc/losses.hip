@@ -367,47 +367,39 @@ __global__ __launch_bounds__(1024) void vae_finish_kernel(VaeFinishArgs p) {
     const int bz = (int)p.bz;
     const bool reg = p.row_loss != nullptr, want_dz = reg && p.dz != nullptr;
     const int n_rows = (int)p.n_rows, ldz = (int)p.ldz, nr = reg ? n_rows * p.r : 0, nz = want_dz ? n_rows * ldz : 0;
-    float2 rp[FU];
-    float mu[FU], sg[FU], rl[FU], rg[FU];
-    int dk[FU];
+    int n_max = p.nb > bz ? p.nb : bz;
+    n_max = n_max > nr ? n_max : nr;
+    n_max = n_max > nz ? n_max : nz;
+    // passes of FU * 1024 elements of every array, all loads of a pass before its sums (one pass at the dSprites sizes, two for
+    // Morpho-MNIST's 1024 x 16 latent values)
+    for (int base = 0; base < n_max; base += FU * 1024) {
+        float2 rp[FU];
+        float mu[FU], sg[FU], rl[FU], rg[FU];
+        int dk[FU];
 #pragma unroll
-    for (int u = 0; u < FU; ++u) {
-        const int i = threadIdx.x + u * 1024;
-        rp[u] = reinterpret_cast<const float2 *>(p.rec_partial)[i < p.nb ? i : 0];
-        mu[u] = p.mu[i < bz ? i : 0];
-        sg[u] = p.sigma[i < bz ? i : 0];
-        rl[u] = reg ? p.row_loss[i < nr ? i : 0] : 0.f;
-        // dz[row][c] = grad_scale * row_grad[k][row] for c = dims[k], else 0: index arithmetic, then ONE unconditional load
-        const int ic = i < nz ? i : 0, row = ic / (ldz > 0 ? ldz : 1), c = ic - row * ldz;
-        int k = -1;
+        for (int u = 0; u < FU; ++u) {
+            const int i = base + threadIdx.x + u * 1024;
+            rp[u] = reinterpret_cast<const float2 *>(p.rec_partial)[i < p.nb ? i : 0];
+            mu[u] = p.mu[i < bz ? i : 0];
+            sg[u] = p.sigma[i < bz ? i : 0];
+            rl[u] = reg ? p.row_loss[i < nr ? i : 0] : 0.f;
+            // dz[row][c] = grad_scale * row_grad[k][row] for c = dims[k], else 0: index arithmetic, then ONE unconditional load
+            const int ic = i < nz ? i : 0, row = ic / (ldz > 0 ? ldz : 1), c = ic - row * ldz;
+            int k = -1;
 #pragma unroll
-        for (int q = 0; q < 16; ++q)
-            if (q < p.r && p.dims.d[q] == c) k = q;
-        dk[u] = k;
-        rg[u] = want_dz ? p.row_grad[(k < 0 ? 0 : k) * n_rows + row] : 0.f;
-    }
+            for (int q = 0; q < 16; ++q)
+                if (q < p.r && p.dims.d[q] == c) k = q;
+            dk[u] = k;
+            rg[u] = want_dz ? p.row_grad[(k < 0 ? 0 : k) * n_rows + row] : 0.f;
+        }
 #pragma unroll
-    for (int u = 0; u < FU; ++u) {
-        const int i = threadIdx.x + u * 1024;
-        if (i < p.nb) { a += rp[u].x; b += rp[u].y; }
-        if (i < bz) s += kl_elem(mu[u], sg[u], 0.f, 1.f);
-        if (i < nr) t += rl[u];
-        if (i < nz) p.dz[i] = dk[u] < 0 ? 0.f : p.grad_scale * rg[u];
-    }
-    for (int i = threadIdx.x + FU * 1024; i < p.nb; i += 1024) {
-        a += p.rec_partial[2 * i];
-        b += p.rec_partial[2 * i + 1];
-    }
-    for (int i = threadIdx.x + FU * 1024; i < bz; i += 1024) s += kl_elem(p.mu[i], p.sigma[i], 0.f, 1.f);
-    for (int i = threadIdx.x + FU * 1024; i < nr; i += 1024) t += p.row_loss[i];
-    for (int i = threadIdx.x + FU * 1024; i < nz; i += 1024) {
-        const int row = i / ldz, c = i - row * ldz;
-        int k = -1;
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
-            if (q < p.r && p.dims.d[q] == c) k = q;
-        const float g = p.row_grad[(k < 0 ? 0 : k) * n_rows + row];
-        p.dz[i] = k < 0 ? 0.f : p.grad_scale * g;
+        for (int u = 0; u < FU; ++u) {
+            const int i = base + threadIdx.x + u * 1024;
+            if (i < p.nb) { a += rp[u].x; b += rp[u].y; }
+            if (i < bz) s += kl_elem(mu[u], sg[u], 0.f, 1.f);
+            if (i < nr) t += rl[u];
+            if (i < nz) p.dz[i] = dk[u] < 0 ? 0.f : p.grad_scale * rg[u];
+        }
     }
     float4 v = make_float4(wave_sum(a), wave_sum(b), wave_sum(s), wave_sum(t));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
