@@ -706,8 +706,7 @@ __global__ __launch_bounds__(256, 1) void down32x_kernel(const float *__restrict
 // a tile is 32 lo pixels, wave w takes kernel row ky = w (K split 4 ways, 64 weights per lane straight from
 // global memory), the four partial tiles meet in LDS and wave 0 runs the epilogue.
 template <int LO, int MODE>
-__global__ __launch_bounds__(256, 2) void down32s_kernel(const float *__restrict__ hi, const float *__restrict__ wt, Ep32 ep,
-                                                         int n_img, int n_tiles) {
+__device__ __forceinline__ void down32s_body(const float *__restrict__ hi, const float *__restrict__ wt, Ep32 ep, int n_img, int n_tiles, const int BID, const int NBLK) {
     constexpr int PX = 32;
     using PL = PatchLoader<LO, 2, PX>;
     constexpr int PC = PL::PC, PR = PL::PR;
@@ -719,8 +718,8 @@ __global__ __launch_bounds__(256, 2) void down32s_kernel(const float *__restrict
     PL pl;
     pl.init(hi, n_img);
     int img0, r0;
-    tile_origin<LO, PX>(blockIdx.x, img0, r0);
-    pl.set_tile(img0, r0, blockIdx.x < n_tiles);
+    tile_origin<LO, PX>(BID, img0, r0);
+    pl.set_tile(img0, r0, BID < n_tiles);
     pl.issue_all();
 
     // w[kx][chunk][t] = wt[clo = rc][chi = chunk*8 + half*4 + t][ky = wave][kx]: the four kx are one 16-byte load
@@ -747,15 +746,15 @@ __global__ __launch_bounds__(256, 2) void down32s_kernel(const float *__restrict
     const unsigned out_lane = (unsigned)(rc * PIXB + half * 16);
     float4 dummy;
 
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (int tile = BID; tile < n_tiles; tile += NBLK) {
         tile_origin<LO, PX>(tile, img0, r0);
         __syncthreads();                                         // the previous tile's patch and partials have been read
         pl.template commit<false>(lds, dummy);
         __syncthreads();
         {
             int ni, nr;
-            tile_origin<LO, PX>(tile + gridDim.x, ni, nr);
-            pl.set_tile(ni, nr, tile + gridDim.x < n_tiles);
+            tile_origin<LO, PX>(tile + NBLK, ni, nr);
+            pl.set_tile(ni, nr, tile + NBLK < n_tiles);
             pl.issue_all();
         }
         f32x16 acc;
@@ -780,6 +779,11 @@ __global__ __launch_bounds__(256, 2) void down32s_kernel(const float *__restrict
         }
     }
 }
+template <int LO, int MODE>
+__global__ __launch_bounds__(256, 2) void down32s_kernel(const float *__restrict__ hi, const float *__restrict__ wt, Ep32 ep, int n_img, int n_tiles) {
+    down32s_body<LO, MODE>(hi, wt, ep, n_img, n_tiles, blockIdx.x, gridDim.x);
+}
+
 
 // ================================================================================================
 // Up: hi[n,hy,hx,chi] = ep( sum over the 2x2 taps valid for (hy,hx)'s parity and clo of lo * wt )
@@ -948,8 +952,7 @@ __global__ __launch_bounds__(256, 1) void up32_kernel(const float *__restrict__ 
 #endif
 constexpr int UP_ISSUE_STEPS = ARVAE_UP_ISSUE_STEPS;
 template <int LO, int MODE, int PX = 128>
-__global__ __launch_bounds__(256, 1) void up32x_kernel(const float *__restrict__ lo, const float *__restrict__ wt, Ep32 ep,
-                                                        int n_img, int n_tiles) {
+__device__ __forceinline__ void up32x_body(const float *__restrict__ lo, const float *__restrict__ wt, Ep32 ep, int n_img, int n_tiles, const int BID, const int NBLK) {
     using PL = PatchLoader<LO, 1, PX>;
     constexpr int MT = PX / 32;
     constexpr int HI = 2 * LO, PC = PL::PC, PR = PL::PR, PLANE = PL::PLANE_DW;
@@ -966,7 +969,7 @@ __global__ __launch_bounds__(256, 1) void up32x_kernel(const float *__restrict__
     int img0, r0;
     // a workgroup owns a contiguous run of tiles (the row groups of the same images): the halo rows two tiles share come from
     // this XCD's L2 the second time
-    const int per_wg = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x, t_first = blockIdx.x * per_wg;
+    const int per_wg = (n_tiles + (int)NBLK - 1) / (int)NBLK, t_first = BID * per_wg;
     const int t_end = min(n_tiles, t_first + per_wg);
     tile_origin<LO, PX>(t_first, img0, r0);
     pl.set_tile(img0, r0, t_first < t_end);
@@ -1135,6 +1138,11 @@ __global__ __launch_bounds__(256, 1) void up32x_kernel(const float *__restrict__
     STAMP_WAIT();
     STAMP(63);
 }
+template <int LO, int MODE, int PX = 128>
+__global__ __launch_bounds__(256, 1) void up32x_kernel(const float *__restrict__ lo, const float *__restrict__ wt, Ep32 ep, int n_img, int n_tiles) {
+    up32x_body<LO, MODE, PX>(lo, wt, ep, n_img, n_tiles, blockIdx.x, gridDim.x);
+}
+
 
 // ================================================================================================
 // Wgrad: dwt[clo][chi][ky][kx] += sum_{n,ly,lx} lo[n,ly,lx,clo] * hi[n,2ly-1+ky,2lx-1+kx,chi]
@@ -1263,8 +1271,8 @@ __global__ __launch_bounds__(256, 1) void wgrad32_kernel(const float *__restrict
 // ds_read_b64_tr_b16, the transposing read (4 pixels x 16 channels per 16-lane group, two reads per operand).
 // Tile = 64 lo pixels (three planes of the hi patch fit LDS only at this size); wave = ky, 4 accumulator tiles (kx).
 template <int LO, int BIAS>
-__global__ __launch_bounds__(256, 1) void wgrad32x_kernel(const float *__restrict__ lo, const float *__restrict__ hi,
-                                                          float *__restrict__ slab, int n_img, int n_tiles) {
+__device__ __forceinline__ void wgrad32x_body(const float *__restrict__ lo, const float *__restrict__ hi, float *__restrict__ slab, int n_img,
+                                              int n_tiles, const int BID, const int NBLK) {
     constexpr int PX = 64, KB = PX / 16;                         // pixels per tile, 16-pixel K blocks per tile
     using PL = PatchLoader<LO, 2, PX>;
     // plane pitches (dwords per pixel) chosen for the transposed reads: a block is 4 consecutive K pixels x 16 dwords and
@@ -1313,14 +1321,14 @@ __global__ __launch_bounds__(256, 1) void wgrad32x_kernel(const float *__restric
         lo_base = ok ? (unsigned)(((i0 * LO + rr0) * LO) * PIXB) + threadIdx.x * 16 : OOB;
     };
     int img0, r0;
-    tile_origin<LO, PX>(blockIdx.x, img0, r0);
-    pl.set_tile(img0, r0, blockIdx.x < n_tiles);
-    set_lo(img0, r0, blockIdx.x < n_tiles);
+    tile_origin<LO, PX>(BID, img0, r0);
+    pl.set_tile(img0, r0, BID < n_tiles);
+    set_lo(img0, r0, BID < n_tiles);
     pl.issue_all();
 #pragma unroll
     for (int it = 0; it < 2; ++it) lr[it] = buf_load4(rs_lo, lo_base + it * 4096);
 
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (int tile = BID; tile < n_tiles; tile += NBLK) {
         __syncthreads();
         pl.template commit_split3<BIAS == 2, WG_PSB_H>(ldsw, &bias4);
 #pragma unroll
@@ -1337,9 +1345,9 @@ __global__ __launch_bounds__(256, 1) void wgrad32x_kernel(const float *__restric
         __syncthreads();
         {
             int ni, nr;
-            tile_origin<LO, PX>(tile + gridDim.x, ni, nr);
-            pl.set_tile(ni, nr, tile + gridDim.x < n_tiles);
-            set_lo(ni, nr, tile + gridDim.x < n_tiles);
+            tile_origin<LO, PX>(tile + NBLK, ni, nr);
+            pl.set_tile(ni, nr, tile + NBLK < n_tiles);
+            set_lo(ni, nr, tile + NBLK < n_tiles);
         }
         static_for<0, KB>([&](auto bc) __attribute__((always_inline)) {
             constexpr int b = decltype(bc)::value;
@@ -1365,7 +1373,7 @@ __global__ __launch_bounds__(256, 1) void wgrad32x_kernel(const float *__restric
     }
 
     // partial results -> slab[blockIdx][ky][kx][clo = rc][chi = 8g + 4*half + j]: 16-byte stores
-    float *out = slab + (int64_t)blockIdx.x * WG32_SLAB;
+    float *out = slab + (int64_t)BID * WG32_SLAB;
 #pragma unroll
     for (int kx = 0; kx < 4; ++kx)
 #pragma unroll
@@ -1385,6 +1393,31 @@ __global__ __launch_bounds__(256, 1) void wgrad32x_kernel(const float *__restric
         }
     }
 }
+template <int LO, int BIAS>
+__global__ __launch_bounds__(256, 1) void wgrad32x_kernel(const float *__restrict__ lo, const float *__restrict__ hi,
+                                                          float *__restrict__ slab, int n_img, int n_tiles) {
+    wgrad32x_body<LO, BIAS>(lo, hi, slab, n_img, n_tiles, blockIdx.x, gridDim.x);
+}
+
+// ---- the 4x4 layers: data gradient and weight gradient of a layer in ONE launch ---------------------------------------
+// Both read the same incoming gradient and neither needs the other; alone each fills half the chip (128 workgroups) for
+// 7-11 us, most of it launch ramp and one memory round trip.  Workgroups [0, grid_a) run the data-gradient body over two
+// 32-pixel tiles each, the rest the weight-gradient body (one 64-pixel tile and one slab each): 256 workgroups, one per CU.
+template <int MODE, int BIAS>
+__global__ __launch_bounds__(256, 1) void pair4_down_kernel(const float *__restrict__ g_hi, const float *__restrict__ wt, Ep32 ep,
+                                                           const float *__restrict__ w_lo, const float *__restrict__ w_hi,
+                                                           float *__restrict__ slab, int n_img, int tiles_a, int tiles_b, int grid_a) {
+    if ((int)blockIdx.x < grid_a) down32s_body<4, MODE>(g_hi, wt, ep, n_img, tiles_a, blockIdx.x, grid_a);
+    else wgrad32x_body<4, BIAS>(w_lo, w_hi, slab, n_img, tiles_b, blockIdx.x - grid_a, gridDim.x - grid_a);
+}
+template <int MODE, int BIAS>
+__global__ __launch_bounds__(256, 1) void pair4_up_kernel(const float *__restrict__ g_lo, const float *__restrict__ wt, Ep32 ep,
+                                                         const float *__restrict__ w_lo, const float *__restrict__ w_hi,
+                                                         float *__restrict__ slab, int n_img, int tiles_a, int tiles_b, int grid_a) {
+    if ((int)blockIdx.x < grid_a) up32x_body<4, MODE, 32>(g_lo, wt, ep, n_img, tiles_a, blockIdx.x, grid_a);
+    else wgrad32x_body<4, BIAS>(w_lo, w_hi, slab, n_img, tiles_b, blockIdx.x - grid_a, gridDim.x - grid_a);
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -1675,6 +1708,48 @@ int conv32_wgrad_partial(const arvae_link_t *l, const Operand &lo, const Operand
     }
     *job = SlabJob{slab, dwt, bias_mode ? dbias : nullptr, grid, SLAB_C32, bias_mode};
     return rc;
+}
+
+// ---- 4x4 layers: gated data gradient + weight-gradient partials of one layer in one launch (pair4_*_kernel) ---------------
+// up == true: the layer is a forward UP link (data gradient = DOWN map on g, weight gradient with g on the hi side, bias mode 2);
+// up == false: a forward DOWN link (data gradient = UP map, g on the lo side, bias mode 1).  Only the combinations the image
+// executor produces are instantiated; everything else (and the experiment switches) goes the two-launch way.
+bool conv32_pair4_fits(const arvae_link_t *l, bool up, const float *gate, const uint16_t *gate_bits, const float *wprep, int bias_mode) {
+    static const bool off = getenv("ARVAE_NO_PAIR4") != nullptr || getenv("ARVAE_CONV32_FP32") != nullptr ||
+                            getenv("ARVAE_CONV32_BF16X2") != nullptr || getenv("ARVAE_NO_SMALL_TILES") != nullptr;
+    if (off || l->lh != 4 || (gate == nullptr && gate_bits == nullptr) || bias_mode != (up ? 2 : 1)) return false;
+    if (!up && wprep == nullptr) return false;                   // (the UP kernel would stage its weights through LDS)
+    const int wg_tiles = tiles_for<4, 64>(l->n), dg_tiles = tiles_for<4, 32>(l->n);
+    return wg_tiles >= 8 && wg_tiles + (dg_tiles + 1) / 2 <= cu_count() && conv32_wgrad_groups(l) == wg_tiles;
+}
+
+int conv32_pair4(const arvae_link_t *l, bool up, const float *g, const float *x_in, const float *wt, const float *gate,
+                 const uint16_t *gate_bits, float *d_in, const float *wprep, float *dwt, float *dbias, float *slab, hipStream_t s,
+                 SlabJob *job) {
+    constexpr int LDS_W = 3 * (PatchLoader<4, 2, 64>::PLANE_DW / PSB * WGRAD_PSB_H + 64 * WGRAD_PSB_L) * 4;
+    constexpr int LDS_D = (PatchLoader<4, 2, 32>::PATCH_FLOATS + 4 * 16 * 64) * 4;
+    constexpr int LDS_U = MaxOf<3 * PatchLoader<4, 1, 32>::PLANE_DW, WSTAGE_UP>::value * 4;
+    constexpr int LDS = MaxOf<LDS_W, MaxOf<LDS_D, LDS_U>::value>::value;
+    const int wg_tiles = tiles_for<4, 64>(l->n), dg_tiles = tiles_for<4, 32>(l->n), grid_a = (dg_tiles + 1) / 2;
+    Ep32 ep{nullptr, gate_bits ? nullptr : gate, gate_bits, nullptr, d_in, reinterpret_cast<const uint4 *>(wprep)};
+    static bool attr = false;
+    if (!attr) {
+        allow_lds(pair4_down_kernel<EP_GATE_F, 2>, LDS);
+        allow_lds(pair4_down_kernel<EP_GATE_B, 2>, LDS);
+        allow_lds(pair4_up_kernel<EP_GATE_F, 1>, LDS);
+        allow_lds(pair4_up_kernel<EP_GATE_B, 1>, LDS);
+        attr = true;
+    }
+    const dim3 grid(grid_a + wg_tiles);
+    if (up) {                                                    // DOWN map of g (hi side); weight gradient: lo = layer input, hi = g
+        if (gate_bits) ARVAE_LAUNCH((pair4_down_kernel<EP_GATE_B, 2>), grid, dim3(256), LDS, s, g, wt, ep, x_in, g, slab, l->n, dg_tiles, wg_tiles, grid_a);
+        else ARVAE_LAUNCH((pair4_down_kernel<EP_GATE_F, 2>), grid, dim3(256), LDS, s, g, wt, ep, x_in, g, slab, l->n, dg_tiles, wg_tiles, grid_a);
+    } else {                                                     // UP map of g (lo side); weight gradient: lo = g, hi = layer input
+        if (gate_bits) ARVAE_LAUNCH((pair4_up_kernel<EP_GATE_B, 1>), grid, dim3(256), LDS, s, g, wt, ep, g, x_in, slab, l->n, dg_tiles, wg_tiles, grid_a);
+        else ARVAE_LAUNCH((pair4_up_kernel<EP_GATE_F, 1>), grid, dim3(256), LDS, s, g, wt, ep, g, x_in, slab, l->n, dg_tiles, wg_tiles, grid_a);
+    }
+    *job = SlabJob{slab, dwt, dbias, wg_tiles, SLAB_C32, up ? 2 : 1};
+    return check_launch(up ? "pair4(down32 + wgrad32)" : "pair4(up32 + wgrad32)");
 }
 
 int conv32_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *dwt, float *dbias, int bias_mode,

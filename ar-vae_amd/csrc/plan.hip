@@ -26,6 +26,10 @@ int conv_c1_up_recon(const arvae_link_t *l, const float *lo, const float *wt, co
                      int dist, float *partial, float *dlogits, hipStream_t s, int *nb_out);
 int64_t conv32_prep_floats();
 int conv32_weight_prep(const float *const *wts, float *const *preps, int n_layers, hipStream_t s);
+bool conv32_pair4_fits(const arvae_link_t *l, bool up, const float *gate, const uint16_t *gate_bits, const float *wprep, int bias_mode);
+int conv32_pair4(const arvae_link_t *l, bool up, const float *g, const float *x_in, const float *wt, const float *gate,
+                 const uint16_t *gate_bits, float *d_in, const float *wprep, float *dwt, float *dbias, float *slab, hipStream_t s,
+                 SlabJob *job);
 int conv32_wgrad_partial(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *dwt, float *dbias, int bias_mode,
                          float *slab, hipStream_t s, SlabJob *job);
 int conv_c1_wgrad_partial(const arvae_link_t *l, const Operand &lo, const Operand &img, float *dwt, float *dbias,
@@ -284,6 +288,16 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
     const arvae_stream_t wst = g_wgrad_stream != nullptr ? g_wgrad_stream : st;      // weight gradients: helper stream
     hipStream_t whs = reinterpret_cast<hipStream_t>(wst);
     if (gated != nullptr) *gated = false;
+    // 4x4 32-channel layers: gated data gradient and weight-gradient partials in one launch (conv32.hip, pair4_*_kernel)
+    if (d_in != nullptr && gated != nullptr && rdefer != nullptr && own_slab != nullptr && gop.y == nullptr && g_scale == nullptr &&
+        rdefer->count < SLAB_BATCH_MAX && conv32_fits(&lk) &&
+        conv32_pair4_fits(&lk, l.is_up != 0, gate, gate_bits, wprep, db ? (l.is_up ? 2 : 1) : 0)) {
+        SlabJob job;
+        if (int rc = conv32_pair4(&lk, l.is_up != 0, gop.v, in, w, gate, gate_bits, d_in, wprep, dw, db, own_slab, hs, &job)) return rc;
+        slab_reduce_defer(rdefer, job);
+        *gated = true;
+        return ARVAE_OK;
+    }
     const bool simple = gop.mask == nullptr && gop.act != ARVAE_ACT_SELU;
     if (d_in != nullptr) {
         int rc;
