@@ -139,11 +139,12 @@ __global__ __launch_bounds__(256) void down_c1_kernel(Operand img, const float *
 //     output row instead of eight) and the two neighbours from the adjacent lanes by ds_bpermute;
 //   * the finished row goes through a padded per-wave LDS tile and leaves as four 1 KB contiguous stores.
 // GATE: 0 none, 1 sign bits, 2 saved float activation
-template <int GATE>
-__global__ __launch_bounds__(256) void down_c1s_kernel(Operand img, const float *__restrict__ wt, Ep1 ep, int n_rows) {
-    __shared__ __attribute__((aligned(16))) float stage[4][LO1 * PS1];
+// (body + wrappers: the pair kernel below runs it next to the weight gradient in one grid)
+template <int GATE, int WAVES>
+__device__ __forceinline__ void down_c1s_body(Operand img, const float *__restrict__ wt, Ep1 ep, int n_rows, const int BID,
+                                              const int NBLK, float *stage) {
     const int lane = threadIdx.x & 63, half = lane >> 5, rc = lane & 31;
-    float *tile = stage[threadIdx.x >> 6];
+    float *tile = stage + (threadIdx.x >> 6) * (LO1 * PS1);
     float w8[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) w8[s] = wt[rc * 16 + 4 * (2 * (s >> 2) + half) + (s & 3)];
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(256) void down_c1s_kernel(Operand img, const float 
     for (int g = 0; g < 4; ++g)
         b4[g] = ep.bias != nullptr ? *reinterpret_cast<const float4 *>(ep.bias + 8 * g + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float gs = img.scale != nullptr ? img.scale[0] : 1.f;
-    const int wave0 = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+    const int wave0 = BID * WAVES + (threadIdx.x >> 6), n_waves = NBLK * WAVES;
     // image rows 2 r - 1 + half and 2 r + 1 + half, pixels 2 rc and 2 rc + 1
     auto fetch = [&](int row, float2 (&v)[2]) __attribute__((always_inline)) {
         const int n = row >> 5, r = row & 31;
@@ -214,6 +215,12 @@ __global__ __launch_bounds__(256) void down_c1s_kernel(Operand img, const float 
         v[0] = vn[0]; v[1] = vn[1];
     }
 }
+template <int GATE>
+__global__ __launch_bounds__(256) void down_c1s_kernel(Operand img, const float *__restrict__ wt, Ep1 ep, int n_rows) {
+    __shared__ __attribute__((aligned(16))) float stage[4 * LO1 * PS1];
+    down_c1s_body<GATE, 4>(img, wt, ep, n_rows, blockIdx.x, gridDim.x, stage);
+}
+
 
 // ================================================================================================
 // up_c1: img[n,hy,hx] = bias + sum over the 2x2 valid taps and 32 channels of lo * wt, in two steps:
@@ -443,17 +450,16 @@ constexpr int WS1 = 48;                     // LDS position stride of the lo row
 constexpr int IMS = 72;                     // LDS row stride of the image rows: pixel gx at 4 + gx, zero pads at 3 and 68
 constexpr int WGS_WAVES = 8;
 
-__global__ __launch_bounds__(64 * WGS_WAVES) void wgrad_c1s_kernel(Operand lo, Operand img, float *__restrict__ slab, int n_rows) {
-    __shared__ __attribute__((aligned(16))) float lo_s[WGS_WAVES][LO1 * WS1];      // reused as the reduce buffer
-    __shared__ __attribute__((aligned(16))) float im_s[WGS_WAVES][4 * IMS];
+__device__ __forceinline__ void wgrad_c1s_body(Operand lo, Operand img, float *__restrict__ slab, int n_rows, const int BID, const int NBLK,
+                                               float *lo_s, float *im_s) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
     const int ky = li >> 2, kx = li & 3;
-    float *lw = lo_s[wave], *iw = im_s[wave];
+    float *lw = lo_s + wave * (LO1 * WS1), *iw = im_s + wave * (4 * IMS);
     if (lane < 8) iw[(lane >> 1) * IMS + ((lane & 1) ? 68 : 3)] = 0.f;            // pixels -1 and 64
     f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     float lo_sum[2] = {0.f, 0.f}, img_sum = 0.f;
     const float gs = img.scale != nullptr ? img.scale[0] : 1.f;
-    const int wave0 = blockIdx.x * WGS_WAVES + wave, n_waves = gridDim.x * WGS_WAVES;
+    const int wave0 = BID * WGS_WAVES + wave, n_waves = NBLK * WGS_WAVES;
     float4 lr[4], ir;
     // lo row `row` as 4 x 1 KB; image rows 2 r - 1 .. 2 r + 2 (lane >> 4), pixels 4 (lane & 15) .. + 3
     auto issue = [&](int row) __attribute__((always_inline)) {
@@ -491,14 +497,14 @@ __global__ __launch_bounds__(64 * WGS_WAVES) void wgrad_c1s_kernel(Operand lo, O
         __builtin_amdgcn_wave_barrier();
     }
     // reduce the waves' tiles: red[wave][mt*4 + r][lane]; D row = 4g + r -> clo = 16 mt + 4g + r, column = tap li
-    float *red = &lo_s[0][0];
+    float *red = lo_s;
     __syncthreads();
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[(wave * 8 + mt * 4 + r) * 64 + lane] = acc[mt][r];
     __syncthreads();
-    float *out = slab + (int64_t)blockIdx.x * WG1_SLAB;
+    float *out = slab + (int64_t)BID * WG1_SLAB;
     {                                                   // wave w finishes register w of the 8
         const int reg = wave, mt = reg >> 2, r = reg & 3;
         float tot = 0.f;
@@ -526,6 +532,25 @@ __global__ __launch_bounds__(64 * WGS_WAVES) void wgrad_c1s_kernel(Operand lo, O
         if (lane == 0) out[CC * 16 + CC] = tot;
     }
 }
+__global__ __launch_bounds__(64 * WGS_WAVES) void wgrad_c1s_kernel(Operand lo, Operand img, float *__restrict__ slab, int n_rows) {
+    __shared__ __attribute__((aligned(16))) float lo_s[WGS_WAVES * LO1 * WS1];     // reused as the reduce buffer
+    __shared__ __attribute__((aligned(16))) float im_s[WGS_WAVES * 4 * IMS];
+    wgrad_c1s_body(lo, img, slab, n_rows, blockIdx.x, gridDim.x, lo_s, im_s);
+}
+
+// ---- the last decoder layer's backward in ONE grid: its data gradient (down_c1s: writes 67 MB) next to its weight gradient
+// (wgrad_c1s: reads 75 MB).  Workgroups [0, grid_a) run the first body, the rest the second; both are 8-wave workgroups sharing
+// one LDS allocation (58 KB: two per CU, so every CU holds one of each): a write stream and a read stream side by side move
+// more bytes than either alone, and a launch ramp and a tail are saved.
+template <int GATE>
+__global__ __launch_bounds__(64 * WGS_WAVES) void pair_c1_kernel(Operand d_img, const float *__restrict__ wt, Ep1 ep, int n_rows_d,
+                                                                 Operand w_lo, Operand w_img, float *__restrict__ slab, int n_rows_w, int grid_a) {
+    __shared__ __attribute__((aligned(16))) float raw[WGS_WAVES * LO1 * WS1 + WGS_WAVES * 4 * IMS];
+    if ((int)blockIdx.x < grid_a) down_c1s_body<GATE, WGS_WAVES>(d_img, wt, ep, n_rows_d, blockIdx.x, grid_a, raw);
+    else wgrad_c1s_body(w_lo, w_img, slab, n_rows_w, blockIdx.x - grid_a, gridDim.x - grid_a, raw, raw + WGS_WAVES * LO1 * WS1);
+}
+static_assert(WGS_WAVES * LO1 * PS1 <= WGS_WAVES * LO1 * WS1, "pair_c1_kernel: the down body's row tiles fit the shared allocation");
+
 static_assert(WGS_WAVES == 8, "the reduce step gives one of the 8 accumulator registers to each wave");
 
 // ================================================================================================
@@ -745,6 +770,24 @@ int conv_c1_wgrad_partial(const arvae_link_t *l, const Operand &lo, const Operan
     else ARVAE_LAUNCH(wgrad_c1s_kernel, dim3(grid), dim3(64 * WGS_WAVES), 0, s, lo, img, slab, l->n * LO1);
     *job = SlabJob{slab, dwt, dbias, grid, SLAB_C1, bias_mode};
     return check_launch("wgrad_c1_kernel");
+}
+
+// gated data gradient of the forward-UP single-channel link + its weight-gradient partials in one launch (pair_c1_kernel)
+bool conv_c1_pair_fits(const arvae_link_t *l) {
+    static const bool off = getenv("ARVAE_NO_PAIR_C1") != nullptr || getenv("ARVAE_C1_DOWN_TILED") != nullptr ||
+                            getenv("ARVAE_C1_WGRAD_TILED") != nullptr;
+    return !off && conv_c1_fits(l) && l->n * LO1 >= 8 * 256 && wgrad_c1_groups(l) == 256;
+}
+int conv_c1_pair(const arvae_link_t *l, const Operand &g_img, const float *wt, const float *gate, const uint16_t *gate_bits, float *d_lo,
+                 const Operand &w_lo, float *dwt, float *dbias, int bias_mode, float *slab, hipStream_t s, SlabJob *job) {
+    Ep1 ep{nullptr, gate, gate_bits, nullptr, d_lo, 0};
+    const int n_rows = l->n * LO1, grid_a = 256, grid_b = wgrad_c1_groups(l);
+    const dim3 grid(grid_a + grid_b);
+    if (gate_bits != nullptr) ARVAE_LAUNCH(pair_c1_kernel<1>, grid, dim3(64 * WGS_WAVES), 0, s, g_img, wt, ep, n_rows, w_lo, g_img, slab, n_rows, grid_a);
+    else if (gate != nullptr) ARVAE_LAUNCH(pair_c1_kernel<2>, grid, dim3(64 * WGS_WAVES), 0, s, g_img, wt, ep, n_rows, w_lo, g_img, slab, n_rows, grid_a);
+    else ARVAE_LAUNCH(pair_c1_kernel<0>, grid, dim3(64 * WGS_WAVES), 0, s, g_img, wt, ep, n_rows, w_lo, g_img, slab, n_rows, grid_a);
+    *job = SlabJob{slab, dwt, dbias, grid_b, SLAB_C1, bias_mode};
+    return check_launch("pair_c1(down_c1 + wgrad_c1)");
 }
 
 int conv_c1_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &img, float *dwt, float *dbias, int bias_mode,

@@ -32,6 +32,9 @@ int conv32_pair4(const arvae_link_t *l, bool up, const float *g, const float *x_
                  SlabJob *job);
 int conv32_wgrad_partial(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *dwt, float *dbias, int bias_mode,
                          float *slab, hipStream_t s, SlabJob *job);
+bool conv_c1_pair_fits(const arvae_link_t *l);
+int conv_c1_pair(const arvae_link_t *l, const Operand &g_img, const float *wt, const float *gate, const uint16_t *gate_bits, float *d_lo,
+                 const Operand &w_lo, float *dwt, float *dbias, int bias_mode, float *slab, hipStream_t s, SlabJob *job);
 int conv_c1_wgrad_partial(const arvae_link_t *l, const Operand &lo, const Operand &img, float *dwt, float *dbias,
                           int bias_mode, float *slab, hipStream_t s, SlabJob *job);
 int conv_c1_down(const arvae_link_t *l, const Operand &img, const float *wt, const float *bias, int relu,
@@ -299,6 +302,19 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
         return ARVAE_OK;
     }
     const bool simple = gop.mask == nullptr && gop.act != ARVAE_ACT_SELU;
+    // the single-channel forward-UP link (last decoder layer): gated data gradient and weight-gradient partials in one launch
+    if (d_in != nullptr && gated != nullptr && l.is_up && gate != nullptr && simple && gop.y == nullptr && rdefer != nullptr &&
+        own_slab != nullptr && rdefer->count < SLAB_BATCH_MAX && conv_c1_pair_fits(&lk)) {
+        Operand g_op = make_operand(&gop);
+        g_op.scale = g_scale;
+        SlabJob job;
+        if (int rc = conv_c1_pair(&lk, g_op, w, gate_bits ? nullptr : gate, gate_bits, d_in, make_operand(&xin), dw, db, db ? 2 : 0, own_slab,
+                                  hs, &job))
+            return rc;
+        slab_reduce_defer(rdefer, job);
+        *gated = true;
+        return ARVAE_OK;
+    }
     if (d_in != nullptr) {
         int rc;
         if (l.is_up) {                                   // forward UP  -> data gradient is a DOWN map

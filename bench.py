@@ -65,19 +65,24 @@ KERNEL_WORK = {
     'down_c1_kernel': (524_288, 4 * (4096 + 32768)), 'wgrad_c1_kernel': (524_288, 4 * (32768 + 4096)),
     # last decoder layer with the reconstruction term fused in: lo in; logits, d/dlogits out; image in
     'up_c1_kernel(recon)': (524_288, 4 * (32768 + 3 * 4096)), 'up_c1_kernel': (524_288, 4 * (32768 + 4096)),
+    # a layer's data gradient and weight gradient in one launch: the upstream gradient is read by both halves
+    'pair4(down32 + wgrad32)': (2 * 262_144, 4 * (2 * 2048 + 2 * 512)), 'pair4(up32 + wgrad32)': (2 * 262_144, 4 * (2 * 512 + 2 * 2048)),
+    'pair_c1(down_c1 + wgrad_c1)': (2 * 524_288, 4 * (2 * 4096 + 2 * 32768)),
 }
 # the library's timeline labels one kernel FAMILY; these are the instantiations a rocprofv3 --kernel-trace of the
 # default build lists for it at B = 512 (profiles/*_kernel_stats.csv)
 ROCPROF_NAMES = {
     'wgrad32_kernel<16>': ['arvae::wgrad32r_kernel<16, 1>', 'arvae::wgrad32r_kernel<16, 2>'],
     'up32_kernel<16>': ['arvae::up32x_kernel<16, 1, 128>', 'arvae::up32x_kernel<16, 3, 128>'],
-    'down32_kernel<16>': ['arvae::down32x_kernel<16, 1>', 'arvae::down32x_kernel<16, 3>'],
+    'down32_kernel<16>': ['arvae::down32k_kernel<16, 1>', 'arvae::down32k_kernel<16, 3>'],
     'wgrad32_kernel<8>': ['arvae::wgrad32r_kernel<8, 1>', 'arvae::wgrad32r_kernel<8, 2>'],
     'up32_kernel<8>': ['arvae::up32x_kernel<8, 1, 32>', 'arvae::up32x_kernel<8, 3, 32>'],
-    'down32_kernel<8>': ['arvae::down32x_kernel<8, 1>', 'arvae::down32x_kernel<8, 3>'],
+    'down32_kernel<8>': ['arvae::down32k_kernel<8, 1>', 'arvae::down32k_kernel<8, 3>'],
     'wgrad32_kernel<4>': ['arvae::wgrad32x_kernel<4, 1>', 'arvae::wgrad32x_kernel<4, 2>'],
     'up32_kernel<4>': ['arvae::up32x_kernel<4, 1, 32>', 'arvae::up32x_kernel<4, 3, 32>'],
     'down32_kernel<4>': ['arvae::down32s_kernel<4, 1>', 'arvae::down32s_kernel<4, 2>'],
+    'pair4(down32 + wgrad32)': ['arvae::pair4_down_kernel<1, 2>'], 'pair4(up32 + wgrad32)': ['arvae::pair4_up_kernel<1, 1>'],
+    'pair_c1(down_c1 + wgrad_c1)': ['arvae::pair_c1_kernel<1>'],
     'down_c1_kernel': ['arvae::down_c1s_kernel<0>', 'arvae::down_c1s_kernel<1>'], 'wgrad_c1_kernel': ['arvae::wgrad_c1s_kernel'],
     'up_c1_kernel(recon)': ['arvae::up_c1_kernel<0, true>'],
     'conv64_down': ['arvae::conv64s_kernel<3, 2, 0>', 'arvae::conv64s_kernel<3, 1, 0>'],

@@ -19,6 +19,12 @@ def label(kernel_name):
         return f'{m.group(1)}_kernel<{m.group(2)}>'
     if n.startswith(('down_c1s_kernel', 'wgrad_c1s_kernel')):           # streaming forms: same label as the tiled kernels
         return n.split('<')[0].replace('c1s', 'c1')
+    if n.startswith('pair4_down_kernel'):
+        return 'pair4(down32 + wgrad32)'
+    if n.startswith('pair4_up_kernel'):
+        return 'pair4(up32 + wgrad32)'
+    if n.startswith('pair_c1_kernel'):
+        return 'pair_c1(down_c1 + wgrad_c1)'
     if n.startswith('up_c1_kernel'):
         return 'up_c1_kernel(recon)' if 'true' in n else 'up_c1_kernel'
     return n.split('<')[0]
