@@ -122,18 +122,23 @@ struct PatchLoader {
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             const int idx = threadIdx.x + it * 256;
+            // every lane "uses" the slot's registers, also those past SLOTS: a load whose only use sits under a branch is never
+            // waited for on the path around it, and the compiler then drains the whole queue (vmcnt(0): every store of the
+            // previous tile's epilogue as well) before it reuses the register
+            float4 v = r[it];
+            asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
             if (idx < SLOTS) {
                 const int q = idx & 7, pix = idx >> 3;
                 uint2 hv, mv, lv;
-                split_pair3(r[it].x, r[it].y, hv.x, mv.x, lv.x);
-                split_pair3(r[it].z, r[it].w, hv.y, mv.y, lv.y);
+                split_pair3(v.x, v.y, hv.x, mv.x, lv.x);
+                split_pair3(v.z, v.w, hv.y, mv.y, lv.y);
                 *reinterpret_cast<uint2 *>(planes + pix * PITCH + q * 2) = hv;
                 *reinterpret_cast<uint2 *>(planes + PLANE_P + pix * PITCH + q * 2) = mv;
                 *reinterpret_cast<uint2 *>(planes + 2 * PLANE_P + pix * PITCH + q * 2) = lv;
                 if (BIAS_SUM) {
                     const int pc = pix % PC, pr = (pix / PC) % PR;
                     if (pr >= 1 && pr <= PR - 2 && pc >= 1 && pc <= PC - 2) {
-                        bsum->x += r[it].x; bsum->y += r[it].y; bsum->z += r[it].z; bsum->w += r[it].w;
+                        bsum->x += v.x; bsum->y += v.y; bsum->z += v.z; bsum->w += v.w;
                     }
                 }
             }
@@ -1035,7 +1040,7 @@ __device__ __forceinline__ void up32x_body(const float *__restrict__ lo, const f
 
     f32x16 prev[MT];                                              // previous tile's accumulators, stored during this tile
     float4 gq[4 * MT];
-    unsigned gqb[MT] = {}, pbits[MT] = {};
+    unsigned gqb[MT] = {}, gqn[MT] = {}, pbits[MT] = {};
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -1047,13 +1052,15 @@ __device__ __forceinline__ void up32x_body(const float *__restrict__ lo, const f
     int stamp_t = 0;
     (void)stamp_t;
 
+    // The commit of tile t + 1 closes the body of tile t (the first one is peeled): at the loop header the entry path (loads
+    // youngest) and the back edge (stores youngest) would otherwise merge into a vmcnt count that waits for the stores too.
+    __syncthreads();
+    pl.commit_split3(ldsw);
+    __syncthreads();
     for (int tile = t_first; tile < t_end; ++tile) {
         STAMP(3 + 6 * stamp_t);
         tile_origin<LO, PX>(tile, img0, r0);
-        __syncthreads();
         STAMP(4 + 6 * stamp_t);
-        pl.commit_split3(ldsw);
-        __syncthreads();
         STAMP(5 + 6 * stamp_t);
         {
             int ni, nr;
@@ -1077,27 +1084,43 @@ __device__ __forceinline__ void up32x_body(const float *__restrict__ lo, const f
             for (int t = 0; t < 3; ++t) a[0][mt][t] = lds_bf16x8(ldsw + t * PLANE + aoff[mt]);
         static_for<0, 8>([&](auto sc) __attribute__((always_inline)) {
             constexpr int step = decltype(sc)::value, ty = step >> 2, tx = (step >> 1) & 1, c = step & 1;
+#ifdef UPX_NO_LDSR
+            constexpr int cur = 0, nxt = 1;
+#else
             constexpr int cur = step & 1, nxt = cur ^ 1;
+#endif
             constexpr int nstep = step + 1, nty = nstep >> 2, ntx = (nstep >> 1) & 1, nc = nstep & 1;
             constexpr int ntoff = -(nty * PC + ntx) * PSB + nc * 8;
             // the next tile's loads all leave in the first half of this tile: the commit at the top of the next tile waits for
             // them (in-order vmcnt), and a load issued in the last step would expose its whole HBM round trip there
+#ifndef UPX_NO_ISSUE
             if constexpr (step < UP_ISSUE_STEPS) pl.template issue_step<UP_ISSUE_STEPS, step>();
+#endif
             __builtin_amdgcn_sched_barrier(0);
             static_for<0, 2 * MT>([&](auto mc) __attribute__((always_inline)) {
                 constexpr int sub = decltype(mc)::value, grp = sub / MT, mt = sub % MT;
                 // epilogue slots: 16 * MT per tile (one per group of three MFMAs); wave w owns every fourth
                 constexpr int slot = (step * 2 + grp) * MT + mt;
+#ifndef UPX_NO_EPI
+#ifdef UPX_STAGGER
                 if (wave == (slot & 3)) {
+#else
+                if constexpr ((slot & 3) == 0) {
+#endif
                     constexpr int k = slot >> 2, em = k >> 2, eg = k & 3;
                     const unsigned poff = prev_base + orel[em];
                     if (eg == 0) pbits[em] = 0;
                     pbits[em] |= store_group<MODE>(prev[em], eg, b4[eg], gq[k], gqb[em], rs_out, poff);
-                    if (MODE == EP_RELU && eg == 3 && want_bits)
-                        buf_store_u16(pbits[em], rs_bits, prev_base == OOB ? OOB : bits_off(poff, half));
+                    // (unconditional: a store under a run-time branch makes the compiler's vmcnt count at the next tile's
+                    // commit conservative -- it then waits for every store of this tile; without bits_out the offset is out of range)
+                    if (MODE == EP_RELU && eg == 3)
+                        buf_store_u16(pbits[em], rs_bits, (prev_base == OOB || !want_bits) ? OOB : bits_off(poff, half));
                     if (MODE == EP_GATE_F) gq[k] = buf_load4(rs_gate, obase + orel[em] + eg * 32);
-                    if (MODE == EP_GATE_B && eg == 3) gqb[em] = buf_load_u16(rs_bits, bits_off(obase + orel[em], half));
+                    // this tile's sign bits are requested in its first slots: the copies into gqb at the bottom of the loop then
+                    // wait for loads that are two steps old, not for the one issued in the last step (plus every store before it)
+                    if constexpr (MODE == EP_GATE_B && k < MT) gqn[k] = buf_load_u16(rs_bits, bits_off(obase + orel[k], half));
                 }
+#endif
                 // Three of the step's 6 * MT MFMAs, taken in ROUND-ROBIN order over the MT accumulators (product-major: every
                 // accumulator still sees its six partial products smallest first, so the sums are bit-identical): back-to-back
                 // MFMAs into the same accumulator cost ~48 cycles each instead of the 32-cycle issue rate (conv32r.hip), which
@@ -1109,6 +1132,7 @@ __device__ __forceinline__ void up32x_body(const float *__restrict__ lo, const f
                     MFMA_B(acc[pm], w3[ty][tx][c][tw], a[cur][pm][ta]);
                 });
                 (void)grp; (void)mt;
+#ifndef UPX_NO_LDSR
                 if constexpr (nstep < 8) {                       // this sub-step's share of the next step's operand reads
                     constexpr int r_lo = sub * (3 * MT) / (2 * MT), r_hi = (sub + 1) * (3 * MT) / (2 * MT);
                     static_for<r_lo, r_hi>([&](auto rc_) __attribute__((always_inline)) {
@@ -1116,13 +1140,24 @@ __device__ __forceinline__ void up32x_body(const float *__restrict__ lo, const f
                         a[nxt][rmt][rt] = lds_bf16x8(ldsw + rt * PLANE + aoff[rmt] + ntoff);
                     });
                 }
+#endif
+                (void)nxt;
             });
             __builtin_amdgcn_sched_barrier(0);
         });
         STAMP(7 + 6 * stamp_t);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) prev[mt] = acc[mt];
+        if (MODE == EP_GATE_B) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) gqb[mt] = gqn[mt];
+        }
         prev_base = obase;
+        // (unconditional, also behind the last tile, where it stages zeros: with the commit on one side of a branch the
+        // compiler sinks the loads of the whole tile down to it)
+        __syncthreads();
+        pl.commit_split3(ldsw);
+        __syncthreads();
         STAMP(8 + 6 * stamp_t);
         ++stamp_t;
     }
@@ -1133,7 +1168,7 @@ __device__ __forceinline__ void up32x_body(const float *__restrict__ lo, const f
         unsigned bits = 0;
 #pragma unroll
         for (int g = 0; g < 4; ++g) bits |= store_group<MODE>(prev[mt], g, b4[g], gq[mt * 4 + g], gqb[mt], rs_out, poff);
-        if (MODE == EP_RELU && want_bits) buf_store_u16(bits, rs_bits, prev_base == OOB ? OOB : bits_off(poff, half));
+        if (MODE == EP_RELU) buf_store_u16(bits, rs_bits, (prev_base == OOB || !want_bits) ? OOB : bits_off(poff, half));
     }
     STAMP_WAIT();
     STAMP(63);

@@ -286,8 +286,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             buf_store4(make_float4(o4[0], o4[1], o4[2], o4[3]), rs_out, obase + e * 32);
         }
         // sign bits: byte og of the (pixel, half) entry (bit 4 g + j <-> channel 8 g + 4 half + j)
-        if (MODE == EP_RELU && want_bits)
-            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)bits, rs_bits, (int)(obase == OOB ? OOB : bits_off(obase, half) + og), 0, 0);
+        if (MODE == EP_RELU)            // unconditional (exact vmcnt counts in the loop); dropped through its offset without bits_out
+            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)bits, rs_bits, (int)((obase == OOB || !want_bits) ? OOB : bits_off(obase, half) + og), 0, 0);
         KSTAMP(8 + 5 * kst);
         ++kst;
     };
