@@ -85,6 +85,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         *reinterpret_cast<uint2 *>(d + 16) = mv;
         *reinterpret_cast<uint2 *>(d + 32) = lw;
     };
+    // per thread, for the loads issued inside the tile loop: byte offset of slot 0 in a patch and the slots (bit s) that sit in
+    // the patch's first / last row or past its end
+    const unsigned rel0 = (unsigned)(pix0 * PIXB + q * 16);
+    unsigned first_row = 0, last_row = 0, no_slot = 0;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int pix = pix0 + 32 * s, pr = pix / HW;
+        if (pr == 0) first_row |= 1u << s;
+        if (pr == PIX / HW - 1) last_row |= 1u << s;
+        if (pix >= PIX) no_slot |= 1u << s;
+    }
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
 #pragma unroll
@@ -177,6 +188,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // MFMAs in small pieces.  Left to the scheduler (with or without sched_group_barrier masks) a step came out as a block
         // of 12 MFMAs followed by a block of ~50 vector instructions, i.e. the pipe idle half of the time, and with runs of
         // dependent MFMAs on one accumulator (48 instead of 32 cycles each).
+        // next load of this register set: tile + 3 (per-tile part of the addresses; an invalid tile stays out of range: OOB + 4096 s
+        // wraps past any tensor size)
+        unsigned n_base, n_bad;
+        {
+            const int nt = tile + 3;
+            int ni, nr;
+            tile_origin<LO, 64>(nt, ni, nr);
+            const int gy0 = 2 * nr - 1;
+            n_base = nt < t_end ? (unsigned)(((ni * HI + gy0) * HI) * PIXB) + rel0 : OOB;
+            n_bad = (gy0 < 0 ? first_row : 0u) | (gy0 + PIX / HW - 1 >= HI ? last_row : 0u) | no_slot;
+        }
         uint2 c_h, c_m, c_l;                                     // a slot's three terms, residuals and next address between its pieces
         f32x2v c_r;
         unsigned c_off = OOB;
@@ -214,15 +236,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         *reinterpret_cast<uint2 *>(d + 16) = c_m;
                         *reinterpret_cast<uint2 *>(d + 32) = c_l;
                     }
-                    if constexpr (piece == 5) {                  // address of the slot's next load (tile + 3 strides)
-                        const int nt = tile + 3;
-                        int ni, nr;
-                        tile_origin<LO, 64>(nt, ni, nr);
-                        const int pix = pix0 + 32 * s, pr = pix / HW, px = pix - pr * HW;
-                        const int gy = 2 * nr - 1 + pr;
-                        const bool ok = nt < t_end && (unsigned)gy < (unsigned)HI;
-                        c_off = ok ? (unsigned)((((ni * HI + gy) * HI + px) * C32 + 4 * q) * 4) : OOB;
-                    }
+                    // address of the slot's next load (tile + 3 strides): the staged rows are whole image rows, so slot s is
+                    // 32 pixels = 4096 bytes behind slot 0, and only the patch's first / last row can fall outside the image
+                    if constexpr (piece == 5) c_off = (n_bad & (1u << s)) != 0 ? OOB : n_base + 4096u * s;
                     if constexpr (piece == 6) lv[set][s] = buf_load4(rs_hi, c_off);
                 }
             };

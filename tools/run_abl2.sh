@@ -1,2 +1,3 @@
-python -m pytest tests/test_hip_parity.py -x -q -m gpu -k "image_step or baseline or conv_up or fused or ragged" 2>&1 | tail -2
-bash tools/trace_kernels.sh up32x | tail -8
+python -m pytest tests/test_hip_parity.py -x -q -m gpu -k "image_step or baseline or conv_down or fused or ragged" 2>&1 | tail -2
+bash tools/trace_kernels.sh down32k | tail -6
+bash tools/ab_libs.sh tools/bin/lib_new.so tools/bin/lib_new2.so
