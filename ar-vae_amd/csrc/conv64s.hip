@@ -187,8 +187,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int t = 0; t < 3; ++t) w3[r][nt][t] = __builtin_bit_cast(bf16x8, wp[(nt * 3 + t) * 64]);
     };
     const int kx_first = g.sgn > 0 ? 0 : 3;
+    // epilogue operands and the result as buffer resources (conv64s_fits bounds the tensor at 2 GB): absent operands get an empty
+    // range (loads return zero) and lanes without an output an out-of-range offset, so that no load or store sits under a branch
+    const int64_t out_elems = (int64_t)g.n * g.oh * g.ow * g.q;
+    const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(g.out, out_elems * 4);
+    const __amdgpu_buffer_rsrc_t rs_gy = make_rsrc(g.gate.y != nullptr ? (const void *)g.gate.y : (const void *)g.out, g.gate.y != nullptr ? out_elems * 4 : 0);
+    const uint8_t *km_ptr = g.gate.y != nullptr ? g.gate.mask : g.mask;
+    const __amdgpu_buffer_rsrc_t rs_km = make_rsrc(km_ptr != nullptr ? (const void *)km_ptr : (const void *)g.out, km_ptr != nullptr ? out_elems : 0);
+    const bool km_ones = g.gate.y != nullptr && g.gate.mask == nullptr;
+
     load_w(std::integral_constant<int, 0>{}, kx_first, 0);
     load_w(std::integral_constant<int, 1>{}, kx_first, 1);
+    // as many (dropped) stores behind the first weight requests as an epilogue leaves behind the later ones: the loop header then
+    // sees the same queue on its entry edge and on its back edge, and the first MFMAs of a tile wait for their weights only
+    // (vmcnt(19) ...) instead of draining the epilogue's stores as well (vmcnt(0))
+#pragma unroll
+    for (int i = 0; i < MT * NT; ++i) buf_store4(make_float4(0.f, 0.f, 0.f, 0.f), rs_out, OOB);
 
     int cur = 0;
     for (int tile = t_first; tile < t_end; ++tile, cur ^= 1) {
@@ -207,29 +221,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int img = tile / g.groups, oy0 = (tile - img * g.groups) * g.rows;
         unsigned km[MT][NT];
         float4 gy[MT][NT];
+        // (buffer loads through possibly EMPTY resources and no branch: a memory operation under a run-time condition makes the
+        // compiler's vmcnt counts conservative everywhere after it -- see the stores below)
         auto fetch_epilogue = [&]() __attribute__((always_inline)) {
-            if (g.gate.y != nullptr) {                               // gate values too (the keep-mask slot then holds the gate's mask)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        const int P = opix[mt];
-                        const bool ok = P >= 0 && oy0 + P / g.ow < g.oh && ch_ok[nt];
-                        const int64_t o = ok ? (((int64_t)img * g.oh + oy0) * g.ow + P) * g.q + nt * 32 + 8 * wave + 4 * half : 0;
-                        gy[mt][nt] = *reinterpret_cast<const float4 *>(g.gate.y + o);
-                        km[mt][nt] = g.gate.mask != nullptr ? *reinterpret_cast<const unsigned *>(g.gate.mask + o) : 0x01010101u;
-                    }
-            } else if (g.mask != nullptr) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        const int P = opix[mt];
-                        const bool ok = P >= 0 && oy0 + P / g.ow < g.oh && ch_ok[nt];
-                        const int64_t o = ok ? (((int64_t)img * g.oh + oy0) * g.ow + P) * g.q + nt * 32 + 8 * wave + 4 * half : 0;
-                        km[mt][nt] = *reinterpret_cast<const unsigned *>(g.mask + o);
-                    }
-            }
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int P = opix[mt];
+                    const bool ok = P >= 0 && oy0 + P / g.ow < g.oh && ch_ok[nt];
+                    const unsigned o = ok ? (unsigned)((((int64_t)img * g.oh + oy0) * g.ow + P) * g.q + nt * 32 + 8 * wave + 4 * half) : 0u;
+                    gy[mt][nt] = buf_load4(rs_gy, o * 4u);
+                    const unsigned m = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs_km, (int)o, 0, 0);
+                    km[mt][nt] = km_ones ? 0x01010101u : m;
+                }
         };
         bf16x8 x3[2][MT][3];
         // pixel operands of reduction step 0 (jx = 0, chunk 0)
@@ -361,7 +366,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
                 const int P = opix[mt];
                 const int r = P / g.ow;
-                if (P >= 0 && oy0 + r < g.oh && ch_ok[nt]) {
+                {
+                    const bool ok = P >= 0 && oy0 + r < g.oh && ch_ok[nt];
                     const int64_t o = (((int64_t)img * g.oh + oy0) * g.ow + P) * g.q + nt * 32 + 8 * wave + 4 * half;
                     v.x = act_fwd_hw(v.x + b4[nt].x, g.act); v.y = act_fwd_hw(v.y + b4[nt].y, g.act);
                     v.z = act_fwd_hw(v.z + b4[nt].z, g.act); v.w = act_fwd_hw(v.w + b4[nt].w, g.act);
@@ -378,7 +384,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         v.x *= 2.f * (float)(m & 255u); v.y *= 2.f * (float)((m >> 8) & 255u);
                         v.z *= 2.f * (float)((m >> 16) & 255u); v.w *= 2.f * (float)(m >> 24);
                     }
-                    *reinterpret_cast<float4 *>(g.out + o) = v;
+                    // unconditional: under the lane test the stores sat behind a branch, and the next tile's first weight operands
+                    // (requested before the exchange) were then waited for with vmcnt(0) -- every store of this epilogue included
+                    buf_store4(v, rs_out, ok ? (unsigned)o * 4u : OOB);
                 }
             }
             __syncthreads();
@@ -415,8 +423,10 @@ bool conv64s_fits(const arvae_link_t *l, bool up) {
     static const bool off = getenv("ARVAE_CONV64_NO_STAGE") != nullptr;      // diagnostic: the gathering kernel instead
     int rows, mt;
     const int ow = up ? l->hw : l->lw, sw = up ? l->lw : l->hw, cs = up ? l->clo : l->chi, q = up ? l->chi : l->clo;
+    const int oh = up ? l->hh : l->lh;
     return !off && l->stride == 1 && l->kh == 4 && l->kw == 4 && cs == 64 && (q == 64 || (q <= 32 && q >= 4 && (q & 3) == 0)) &&
-           l->hi_perm_c == 0 && l->lo_perm_c == 0 && stage_geometry(ow, sw, rows, mt);
+           l->hi_perm_c == 0 && l->lo_perm_c == 0 && stage_geometry(ow, sw, rows, mt) &&
+           (int64_t)l->n * oh * ow * q * 4 < ((int64_t)1 << 31) - 65536;      // the result is addressed through a buffer resource
 }
 
 template <int MT, int NT> static void launch_stage(const ConvStage &g, int grid, hipStream_t s) {
