@@ -1084,29 +1084,19 @@ __device__ __forceinline__ void up32x_body(const float *__restrict__ lo, const f
             for (int t = 0; t < 3; ++t) a[0][mt][t] = lds_bf16x8(ldsw + t * PLANE + aoff[mt]);
         static_for<0, 8>([&](auto sc) __attribute__((always_inline)) {
             constexpr int step = decltype(sc)::value, ty = step >> 2, tx = (step >> 1) & 1, c = step & 1;
-#ifdef UPX_NO_LDSR
-            constexpr int cur = 0, nxt = 1;
-#else
             constexpr int cur = step & 1, nxt = cur ^ 1;
-#endif
             constexpr int nstep = step + 1, nty = nstep >> 2, ntx = (nstep >> 1) & 1, nc = nstep & 1;
             constexpr int ntoff = -(nty * PC + ntx) * PSB + nc * 8;
             // the next tile's loads all leave in the first half of this tile: the commit at the top of the next tile waits for
             // them (in-order vmcnt), and a load issued in the last step would expose its whole HBM round trip there
-#ifndef UPX_NO_ISSUE
             if constexpr (step < UP_ISSUE_STEPS) pl.template issue_step<UP_ISSUE_STEPS, step>();
-#endif
             __builtin_amdgcn_sched_barrier(0);
             static_for<0, 2 * MT>([&](auto mc) __attribute__((always_inline)) {
                 constexpr int sub = decltype(mc)::value, grp = sub / MT, mt = sub % MT;
-                // epilogue slots: 16 * MT per tile (one per group of three MFMAs); wave w owns every fourth
+                // epilogue slots: one per four groups of three MFMAs, at the same program point in every wave (a wave-index
+                // branch around them made every vmcnt count behind it conservative)
                 constexpr int slot = (step * 2 + grp) * MT + mt;
-#ifndef UPX_NO_EPI
-#ifdef UPX_STAGGER
-                if (wave == (slot & 3)) {
-#else
                 if constexpr ((slot & 3) == 0) {
-#endif
                     constexpr int k = slot >> 2, em = k >> 2, eg = k & 3;
                     const unsigned poff = prev_base + orel[em];
                     if (eg == 0) pbits[em] = 0;
@@ -1120,7 +1110,6 @@ __device__ __forceinline__ void up32x_body(const float *__restrict__ lo, const f
                     // wait for loads that are two steps old, not for the one issued in the last step (plus every store before it)
                     if constexpr (MODE == EP_GATE_B && k < MT) gqn[k] = buf_load_u16(rs_bits, bits_off(obase + orel[k], half));
                 }
-#endif
                 // Three of the step's 6 * MT MFMAs, taken in ROUND-ROBIN order over the MT accumulators (product-major: every
                 // accumulator still sees its six partial products smallest first, so the sums are bit-identical): back-to-back
                 // MFMAs into the same accumulator cost ~48 cycles each instead of the 32-cycle issue rate (conv32r.hip), which
@@ -1132,7 +1121,6 @@ __device__ __forceinline__ void up32x_body(const float *__restrict__ lo, const f
                     MFMA_B(acc[pm], w3[ty][tx][c][tw], a[cur][pm][ta]);
                 });
                 (void)grp; (void)mt;
-#ifndef UPX_NO_LDSR
                 if constexpr (nstep < 8) {                       // this sub-step's share of the next step's operand reads
                     constexpr int r_lo = sub * (3 * MT) / (2 * MT), r_hi = (sub + 1) * (3 * MT) / (2 * MT);
                     static_for<r_lo, r_hi>([&](auto rc_) __attribute__((always_inline)) {
@@ -1140,7 +1128,6 @@ __device__ __forceinline__ void up32x_body(const float *__restrict__ lo, const f
                         a[nxt][rmt][rt] = lds_bf16x8(ldsw + rt * PLANE + aoff[rmt] + ntoff);
                     });
                 }
-#endif
                 (void)nxt;
             });
             __builtin_amdgcn_sched_barrier(0);

@@ -53,7 +53,7 @@ def main():
     for k in sorted(set(fetch) | set(write)):
         f, nf = fetch.get(k, (0.0, 0))
         w, _ = write.get(k, (0.0, 0))
-        if not k.startswith(('down', 'up', 'wgrad', 'slab', 'dense', 'heads', 'vae', 'reg', 'adam')):
+        if not k.startswith(('down', 'up', 'wgrad', 'pair', 'slab', 'dense', 'heads', 'vae', 'reg', 'adam')):
             continue
         out['kernels'][k] = {'launches_sampled': nf, 'FETCH_SIZE_KB_per_launch': round(f, 1),
                              'WRITE_SIZE_KB_per_launch': round(w, 1), 'hbm_bytes_per_launch': int((2 * f + w) * 1024)}
