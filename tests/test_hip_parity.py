@@ -1242,6 +1242,34 @@ def test_debug_checks_raise_like_the_reference(dev, monkeypatch):
     model(score, score, train=False)                         # checks off: the NaN propagates silently, as without the scan
 
 
+def test_paired_launches_match_the_separate_launches(dev):
+    """A layer's gated data gradient and its weight-gradient partials as ONE grid (conv32.hip pair4_*_kernel, conv_c1.hip
+    pair_c1_kernel; dSprites B = 512, where both apply) against ARVAE_NO_PAIR4=1 ARVAE_NO_PAIR_C1=1 (two launches each): the
+    halves are the same device functions, so losses and gradients must agree to rounding of the final sums."""
+    code = (
+        "import sys, json; sys.path.insert(0, %r)\n"
+        "import numpy as np, torch\n"
+        "from tests.test_hip_parity import run_hip_image_step\n"
+        "from arvae_amd import synthetic as syn\n"
+        "from oracle import image_vae as o_vae\n"
+        "state = syn.synth_state(o_vae.SHAPES['dsprites'], 9, 1.6)\n"
+        "x, lab = syn.dsprites_batch(512, seed=5)\n"
+        "eps = syn.normal_noise((512, o_vae.Z_DIM['dsprites']), seed=6)\n"
+        "got = run_hip_image_step(torch.device('cuda:0'), 'dsprites', state, x, lab, eps, 4.0, 0.0, 'bernoulli', None, train=True)\n"
+        "print(json.dumps({'loss': got['loss'], 'gn': {k: float(np.linalg.norm(v)) for k, v in got['grads'].items()},\n"
+        "                  'g0': {k: float(np.asarray(v).ravel()[0]) for k, v in got['grads'].items()}}))\n"
+        % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    res = {}
+    for flag, env in (('pair', {}), ('split', {'ARVAE_NO_PAIR4': '1', 'ARVAE_NO_PAIR_C1': '1'})):
+        r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[flag] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    close(res['pair']['loss'], res['split']['loss'], rtol=1e-7)
+    for k, v in res['split']['gn'].items():
+        close(res['pair']['gn'][k], v, rtol=1e-6, atol=1e-12)
+        close(res['pair']['g0'][k], res['split']['g0'][k], rtol=1e-5, atol=1e-9)
+
+
 def test_latent_block_experiment_matches_the_per_layer_path(dev):
     """ARVAE_MIDBLOCK=1 (csrc/midblock.hip, off by default: measured no faster): the Linear stack + heads + reparameterisation
     as one launch per pass must give the per-layer path's losses and gradients (dSprites B = 37 and Morpho-MNIST B = 8)."""
