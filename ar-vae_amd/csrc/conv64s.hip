@@ -28,6 +28,14 @@
 #include "conv32_common.h"
 #include "x3tile.h"
 
+#ifdef C64S_STAMPS
+// diagnostic build only (tools/stamp_c64s.py): phase timeline of the first 64 workgroups, 100 MHz wall clock
+namespace arvae { __device__ unsigned long long g_c64s_stamps[64 * 64]; }
+#define CSTAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 64 && (slot) < 64) ::arvae::g_c64s_stamps[blockIdx.x * 64 + (slot)] = wall_clock64(); } while (0)
+#else
+#define CSTAMP(slot)
+#endif
+
 namespace arvae {
 
 constexpr int S_PITCH = 100;                     // dwords per staged pixel: terms at +0, +32, +64, 4 pad (conflict-free 16-byte
@@ -85,6 +93,7 @@ __device__ __forceinline__ float act_fwd_hw(float x, int act) {
 // MODE = Operand::mode() of the source: 0 plain, 1 activation derivative from the saved output, 2 also the keep-mask
 template <int MT, int NT, int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv64s_kernel(ConvStage g) {
+    CSTAMP(0);
     constexpr int S_WSTEP = NT * 3 * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned lds[];          // 2 x S_BUF
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -205,7 +214,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int i = 0; i < MT * NT; ++i) buf_store4(make_float4(0.f, 0.f, 0.f, 0.f), rs_out, OOB);
 
     int cur = 0;
+    int cst = 0;
+    (void)cst;
+    CSTAMP(1);
     for (int tile = t_first; tile < t_end; ++tile, cur ^= 1) {
+        CSTAMP(2 + 6 * cst);
         asm volatile("" : "+v"(q4), "+v"(pix0), "+v"(wlane));
         const unsigned *xb = lds + cur * S_BUF;
         unsigned *nb = lds + (cur ^ 1) * S_BUF;
@@ -338,9 +351,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 __builtin_amdgcn_sched_barrier(0);
             });
         });
+        CSTAMP(3 + 6 * cst);
         load_w(std::integral_constant<int, 0>{}, kx_first, 0);   // the next tile's first two steps: the exchange hides them
         load_w(std::integral_constant<int, 1>{}, kx_first, 1);
         __syncthreads();                                         // every read of this buffer is done; the next tile is staged
+        CSTAMP(4 + 6 * cst);
 
         // ---- the four kernel rows' partial sums meet in this tile's buffer: wave w finishes accumulator registers
         //      4 w .. 4 w + 3 (channels 8 w + 4 half + j) of every tile; one column tile at a time (the buffer is 70 KB)
@@ -356,6 +371,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         make_float4(acc[mt][nt][4 * gw], acc[mt][nt][4 * gw + 1], acc[mt][nt][4 * gw + 2], acc[mt][nt][4 * gw + 3]);
             }
             __syncthreads();
+            CSTAMP(5 + 6 * cst + 2 * nt);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 float4 v = make_float4(acc[mt][nt][4 * wave], acc[mt][nt][4 * wave + 1], acc[mt][nt][4 * wave + 2], acc[mt][nt][4 * wave + 3]);
@@ -390,7 +406,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 }
             }
             __syncthreads();
+            CSTAMP(6 + 6 * cst + 2 * nt);
         }
+        ++cst;
     }
 }
 
@@ -471,3 +489,9 @@ int conv64s_run(const Operand &src, int n, int sh, int sw, int oh, int ow, int q
 }
 
 }  // namespace arvae
+
+#ifdef C64S_STAMPS
+extern "C" int arvae_debug_c64s_stamps(unsigned long long *out, int count) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(arvae::g_c64s_stamps), sizeof(unsigned long long) * count);
+}
+#endif
