@@ -396,8 +396,18 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(RowsGemm g) {
 // The same product on the bf16 MFMA at fp32 accuracy: operands split into three bf16 terms when they are committed to
 // LDS ([p][r] planes, r contiguous), six partial products per multiply-add on v_mfma_f32_32x32x16_bf16, smallest first
 // (2.7x fewer MFMA cycles than the fp32 32x32x2; ARVAE_ROWS_GEMM_FP32=1 selects the kernel above).
+#ifdef RG_STAMPS
+// diagnostic build only (tools/stamp_rg.py): phase timeline of the first 512 workgroups of a rows-GEMM launch, 100 MHz wall clock
+__device__ unsigned long long g_rg_stamps[512 * 32];
+#define RGSTAMP(slot) do { if (threadIdx.x == 0 && (slot) < 32) { const int wg_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; if (wg_ < 512) g_rg_stamps[wg_ * 32 + (slot)] = wall_clock64(); } } while (0)
+#define RGWAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define RGSTAMP(slot)
+#define RGWAIT()
+#endif
 template <int LA, int LB, int EP, bool VA, bool VB>
 __global__ __launch_bounds__(256) void rows_gemm_x3_kernel(RowsGemm g) {
+    RGSTAMP(0);
     typedef TileLoader<LA, RG_TP, VA> LoadA;
     typedef TileLoader<LB, RG_TQ, VB> LoadB;
     __shared__ __attribute__((aligned(16))) unsigned short As[3 * LoadA::PLANE];
@@ -416,11 +426,19 @@ __global__ __launch_bounds__(256) void rows_gemm_x3_kernel(RowsGemm g) {
     la.load(g.a, g.lda, p0, g.P, rbeg, rend);
     lb.load(g.b, g.ldb, q0, g.Q, rbeg, rend);
     const int abase = LoadA::lane_base(wp), bbase = LoadB::lane_base(wq);
+    RGSTAMP(1);
+    int rgc = 0;
+    (void)rgc;
     for (int r0 = rbeg; r0 < rend; r0 += RG_R) {
         __syncthreads();
+        RGSTAMP(2 + 5 * rgc);
+        RGWAIT();
+        RGSTAMP(3 + 5 * rgc);
         la.commit3(As);
         lb.commit3(Bs);
+        RGSTAMP(4 + 5 * rgc);
         __syncthreads();
+        RGSTAMP(5 + 5 * rgc);
         if (r0 + RG_R < rend) {
             la.load(g.a, g.lda, p0, g.P, r0 + RG_R, rend);
             lb.load(g.b, g.ldb, q0, g.Q, r0 + RG_R, rend);
@@ -436,6 +454,8 @@ __global__ __launch_bounds__(256) void rows_gemm_x3_kernel(RowsGemm g) {
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
         }
+        RGSTAMP(6 + 5 * rgc);
+        ++rgc;
         if (EP == RG_EP_SLICE && g.want_bias && blockIdx.y == 0 && threadIdx.x < RG_TP) {
             // sum over the chunk's reduction indices of A(p = threadIdx.x, r), terms re-added exactly
 #pragma unroll 8
@@ -446,6 +466,7 @@ __global__ __launch_bounds__(256) void rows_gemm_x3_kernel(RowsGemm g) {
             }
         }
     }
+    RGSTAMP(30);
     float *out = g.out + (EP == RG_EP_SLICE ? blockIdx.z * g.slice_floats : 0);
     const int q = q0 + 32 * wq + rc;
     const float bias = (EP == RG_EP_FWD && g.bias != nullptr && q < g.Q) ? g.bias[q] : 0.f;
@@ -458,6 +479,8 @@ __global__ __launch_bounds__(256) void rows_gemm_x3_kernel(RowsGemm g) {
     }
     if (EP == RG_EP_SLICE && g.want_bias && blockIdx.y == 0 && threadIdx.x < RG_TP && p0 + (int)threadIdx.x < g.P)
         out[(int64_t)g.P * g.ldo + p0 + threadIdx.x] = bsum;
+    RGWAIT();
+    RGSTAMP(31);
 }
 
 // ---- wgrad: dW[n][feat_in(km)] += sum_m G[m][mem_out(n)] * X[m][km] ;  db[n] += sum_m G[m][mem_out(n)] ------
@@ -789,3 +812,8 @@ extern "C" int arvae_dense_wgrad_batch(const arvae_dense_wgrad_job_t *jobs, int3
     return dense_wgrad_flush(&b, st);
 }
 
+#ifdef RG_STAMPS
+extern "C" int arvae_debug_rg_stamps(unsigned long long *out, int count) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(arvae::g_rg_stamps), sizeof(unsigned long long) * count);
+}
+#endif
