@@ -4,7 +4,7 @@
 //   backward: the same chain in reverse: d(dec_lin) -> d z (+ KL and regulariser gradients) -> d(mu, log_std) -> heads ->
 //             d(enc_lin) -> gradient for the last conv layer, leaving every layer's pre-activation gradient in memory for
 //             the grouped weight-gradient launch (dense.hip).
-// EXPERIMENT, off by default (see mid_fusable): it measured no faster than the per-layer launches.
+// On by default (see mid_fusable; ARVAE_MIDBLOCK=0 for the per-layer launches).
 // Per layer these are a few MFLOP per batch: as separate launches (5 + 5 Linear kernels, 2 head kernels) they cost
 // ~6 us each of pure latency, 12 dependent launches per step.  A batch row never talks to another here, so a workgroup
 // takes R rows through the WHOLE chain with its activations in LDS; what it streams is the weights (L2-resident,
@@ -374,12 +374,13 @@ static bool mid_layer_ok(const arvae_layer_t &l) {
 
 // trailing Linear layers of the encoder / leading Linear layers of the decoder that the block covers (0: block not usable)
 bool mid_fusable(const arvae_image_vae_t *m, int *ne_out, int *nd_out) {
-    // OFF by default (ARVAE_MIDBLOCK=1 switches it on).  Measured at B = 512 on MI355X: forward 31-35 us, backward 36-42 us,
-    // prep 9-10 us against ~88 us for the twelve per-layer launches it replaces -- no gain.  Phase stamps
-    // (tools/stamp_mid.py): every layer of the chain costs >= 3.3 us however small (the 10 -> 256 layer included): a
-    // dependent round trip to the freshly written weights, two barriers and the saved-activation store per layer, on
-    // 128 of the 256 CUs; the per-layer launches pay a similar latency each but spread one layer over the whole chip.
-    static const bool off = getenv("ARVAE_MIDBLOCK") == nullptr || getenv("ARVAE_MIDBLOCK")[0] != '1';
+    // ON by default since the end of round 2 (ARVAE_MIDBLOCK=0 selects the twelve per-layer launches).  At B = 512 on MI355X:
+    // forward 32 us, backward 39 us, prep 8 us against ~87 us for the launches it replaces -- the kernel time is a wash, but
+    // the step has nine launches fewer and is 2.2 % faster in a same-box A/B (it measured equal while the step still had 44
+    // launches).  Phase stamps (tools/stamp_mid.py): every layer of the chain costs >= 3.3 us however small (the 10 -> 256
+    // layer included): a dependent round trip to the freshly written weights, two barriers and the saved-activation store per
+    // layer, on 128 of the 256 CUs.
+    static const bool off = getenv("ARVAE_MIDBLOCK") != nullptr && getenv("ARVAE_MIDBLOCK")[0] == '0';
     int ne = 0, nd = 0;
     while (ne < m->n_enc && ne < MID_MAX_LAYERS && mid_layer_ok(m->enc[m->n_enc - 1 - ne])) ++ne;
     while (nd < m->n_dec && nd < MID_MAX_LAYERS) {

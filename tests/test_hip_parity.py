@@ -1271,8 +1271,8 @@ def test_paired_launches_match_the_separate_launches(dev):
 
 
 def test_latent_block_experiment_matches_the_per_layer_path(dev):
-    """ARVAE_MIDBLOCK=1 (csrc/midblock.hip, off by default: measured no faster): the Linear stack + heads + reparameterisation
-    as one launch per pass must give the per-layer path's losses and gradients (dSprites B = 37 and Morpho-MNIST B = 8)."""
+    """The latent block (csrc/midblock.hip, the default: the Linear stack + heads + reparameterisation as one launch per pass)
+    must give the losses and gradients of the per-layer path (ARVAE_MIDBLOCK=0), dSprites B = 37 and Morpho-MNIST B = 8."""
     code = (
         "import sys, json; sys.path.insert(0, %r)\n"
         "import numpy as np, torch\n"
@@ -1288,9 +1288,9 @@ def test_latent_block_experiment_matches_the_per_layer_path(dev):
         "    out[kind] = {'loss': got['loss'], 'gn': {k: float(np.linalg.norm(v)) for k, v in got['grads'].items()}}\n"
         "print(json.dumps(out))\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     res = {}
-    # '0': the default path; '1': the latent-block launch; 'heads': ARVAE_HEADS_NEXT=1 (csrc/heads.hip: the decoder's first Linear
-    # layer and its data gradient inside the heads kernels, also off by default: measured slower)
-    for flag, env in (('0', {}), ('1', {'ARVAE_MIDBLOCK': '1'}), ('heads', {'ARVAE_HEADS_NEXT': '1'})):
+    # '0': one launch per layer; '1': the latent-block launches (default); 'heads': per layer with ARVAE_HEADS_NEXT=1 (csrc/heads.hip:
+    # the decoder's first Linear layer and its data gradient inside the heads kernels, off by default: measured slower)
+    for flag, env in (('0', {'ARVAE_MIDBLOCK': '0'}), ('1', {}), ('heads', {'ARVAE_MIDBLOCK': '0', 'ARVAE_HEADS_NEXT': '1'})):
         r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
         assert r.returncode == 0, r.stderr[-2000:]
         res[flag] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
