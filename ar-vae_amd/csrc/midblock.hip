@@ -52,7 +52,38 @@ struct MidArgs {
     const float *dz_reg, *dz_extra, *g_loss, *kl, *cap;
     float beta, inv_batch, reg_scale;
     float *d_mu, *d_ls;
+    // the matrices this pass streams, except the first one: requested once per XCD at the top of the kernel (mid_warm)
+    const float *warm_ptr[2 * MID_MAX_LAYERS + 1];
+    int warm_lines[2 * MID_MAX_LAYERS + 1];          // 128-byte lines
+    int n_warm;
 };
+
+// The prep launch wrote the matrices from other XCDs, so a layer's first weight loads miss this XCD's L2 and every layer of the
+// chain pays a round trip to memory (>= 3.3 us per layer however small).  Workgroups are dispatched round-robin over the 8 XCDs,
+// so workgroup b shares its L2 with the workgroups b' = b (mod 8): each of them touches its 1/n-th of the lines the later layers
+// will stream -- ONE dword per 128-byte line and lane, MID_WARM loads per thread, nobody waits for them (their registers are
+// consumed by an empty asm at the very end of the kernel) -- and by the time the second layer starts its matrix is in L2.
+constexpr int MID_WARM = 2;
+__device__ __forceinline__ void mid_warm(const MidArgs &p, float (&w)[MID_WARM]) {
+    const int xw = blockIdx.x >> 3, nxw = ((int)gridDim.x + 7) >> 3;
+    int total = 0;
+    for (int j = 0; j < p.n_warm; ++j) total += p.warm_lines[j];
+    const int share = (total + nxw - 1) / nxw;
+#pragma unroll
+    for (int k = 0; k < MID_WARM; ++k) {
+        const int mine = k * MID_T + (int)threadIdx.x;
+        int f = xw * share + mine;
+        const bool ok = p.n_warm > 0 && mine < share && f < total;
+        if (!ok) f = 0;
+        const float *ptr = p.warm_ptr[0];
+        for (int j = 0; j + 1 < p.n_warm && f >= p.warm_lines[j]; ++j) { f -= p.warm_lines[j]; ptr = p.warm_ptr[j + 1]; }
+        w[k] = p.n_warm > 0 ? ptr[(int64_t)f * 32] : 0.f;
+    }
+}
+__device__ __forceinline__ void mid_warm_done(float (&w)[MID_WARM]) {
+#pragma unroll
+    for (int k = 0; k < MID_WARM; ++k) asm volatile("" ::"v"(w[k]));
+}
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void fma4(float4 &a, float x, const float4 &w) {
@@ -186,6 +217,8 @@ __global__ __launch_bounds__(MID_T) void mid_forward_kernel(MidArgs p) {
     float *bufA = lds, *bufB = lds + R * p.ld, *red = bufB + R * p.ld, *outs = red + mid_red(R);
     const int tid = threadIdx.x, row0 = blockIdx.x * R;
     MID_STAMP(0);
+    float warm[MID_WARM];
+    mid_warm(p, warm);
     {   // conv features of this workgroup's rows -> bufA (rows past the batch: zeros)
         const int k4 = p.enc[0].k >> 2;
         for (int i = tid; i < R * k4; i += MID_T) {
@@ -237,6 +270,7 @@ __global__ __launch_bounds__(MID_T) void mid_forward_kernel(MidArgs p) {
     { float *t = cur; cur = nxt; nxt = t; }
     MID_STAMP(stamp_no); ++stamp_no;
     for (int i = 0; i < p.nd; ++i) run_layer(p.dec[i]);
+    mid_warm_done(warm);
 }
 
 // ================================================================================================ backward
@@ -245,6 +279,8 @@ __global__ __launch_bounds__(MID_T) void mid_backward_kernel(MidArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *bufA = lds, *bufB = lds + R * p.ld, *red = bufB + R * p.ld, *dm = red + mid_red(R), *dl = dm + R * 16;
     const int tid = threadIdx.x, row0 = blockIdx.x * R;
+    float warm[MID_WARM];
+    mid_warm(p, warm);
     {   // gradient arriving at the last decoder Linear layer -> bufA as a pre-activation gradient
         const MidLayer l = p.dec[p.nd - 1];
         const int n4 = l.n >> 2;
@@ -325,6 +361,7 @@ __global__ __launch_bounds__(MID_T) void mid_backward_kernel(MidArgs p) {
     }
     for (int i = p.ne - 1; i >= 1; --i) back_layer(p.enc[i].mb, p.enc[i].n, p.enc[i].k, p.enc[i - 1].y, p.enc[i - 1].act, nullptr, p.enc[i - 1].gpre);
     back_layer(p.enc[0].mb, p.enc[0].n, p.enc[0].k, nullptr, 0, p.gate0, p.d_x0);
+    mid_warm_done(warm);
 }
 
 // ================================================================================================ weight layout prep
@@ -509,6 +546,15 @@ int mid_forward(const arvae_image_vae_t *m, int batch, const float *params, floa
         a.eps_out = const_cast<float *>(eps);
         a.rng = RngStream{m->rng_seed, m->rng_offset, m->rng_dev_step, m->rng_step};
     }
+    {   // forward streams enc[0].mf first; everything after it is requested up front
+        auto lines = [](int64_t floats) { return (int)((floats + 31) / 32); };
+        int &nw = a.n_warm;
+        nw = 0;
+        for (int i = 1; i < a.ne; ++i) { a.warm_ptr[nw] = a.enc[i].mf; a.warm_lines[nw++] = lines((int64_t)a.enc[i].k * a.enc[i].n); }
+        a.warm_ptr[nw] = a.hf; a.warm_lines[nw++] = lines((int64_t)a.h * 2 * a.zdim);
+        for (int i = 0; i < a.nd; ++i) { a.warm_ptr[nw] = a.dec[i].mf; a.warm_lines[nw++] = lines((int64_t)a.dec[i].k * a.dec[i].n); }
+        if (getenv("ARVAE_MID_NO_WARM") != nullptr) nw = 0;
+    }
     mid_allow_lds();
     ARVAE_LAUNCH(mid_prep_kernel, dim3(pl.prep.blk_end[pl.prep.count - 1]), dim3(256), 0, s, pl.prep);
     if (int rc = check_launch("mid_prep_kernel")) return rc;
@@ -532,6 +578,15 @@ int mid_backward(const arvae_image_vae_t *m, int batch, const float *params, flo
     a.dz_reg = dz_reg; a.dz_extra = dz_extra; a.g_loss = g_loss; a.kl = kl; a.cap = cap;
     a.beta = beta; a.inv_batch = 1.f / (float)batch; a.reg_scale = reg_scale;
     a.d_mu = d_mu; a.d_ls = d_ls;
+    {   // backward streams dec[nd-1].mb first (dec[0].mb only when it is not that one), then the heads' and the encoder's matrices
+        auto lines = [](int64_t floats) { return (int)((floats + 31) / 32); };
+        int &nw = a.n_warm;
+        nw = 0;
+        for (int i = a.nd - 2; i >= 0; --i) { a.warm_ptr[nw] = a.dec[i].mb; a.warm_lines[nw++] = lines((int64_t)a.dec[i].kb * a.dec[i].n); }
+        a.warm_ptr[nw] = a.hb; a.warm_lines[nw++] = lines((int64_t)a.h * 2 * a.zdim);
+        for (int i = a.ne - 1; i >= 0; --i) { a.warm_ptr[nw] = a.enc[i].mb; a.warm_lines[nw++] = lines((int64_t)a.enc[i].kb * a.enc[i].n); }
+        if (getenv("ARVAE_MID_NO_WARM") != nullptr) nw = 0;
+    }
     mid_allow_lds();
     if (pl.rows == 8) ARVAE_LAUNCH(mid_backward_kernel<8>, dim3((batch + 7) / 8), dim3(MID_T), pl.lds_bytes, s, a);
     else ARVAE_LAUNCH(mid_backward_kernel<4>, dim3((batch + 3) / 4), dim3(MID_T), pl.lds_bytes, s, a);

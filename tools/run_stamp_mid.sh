@@ -1,6 +1,7 @@
 #!/bin/bash
+# phase stamps of the latent block's forward launch (diagnostic library tools/bin/lib_midst.so: midblock.hip built with -DMID_STAMPS)
 cd "$(dirname "$0")/.."
-touch ar-vae_amd/csrc/midblock.hip
-ARVAE_HIPCC_FLAGS="-DMID_STAMPS $1" python ar-vae_amd/build.py > /dev/null 2>&1
+cp ar-vae_amd/libarvae_hip.so /tmp/lib_keep.so
+cp tools/bin/lib_midst.so ar-vae_amd/libarvae_hip.so
 python tools/stamp_mid.py 2>/dev/null
-touch ar-vae_amd/csrc/midblock.hip; python ar-vae_amd/build.py > /dev/null 2>&1
+cp /tmp/lib_keep.so ar-vae_amd/libarvae_hip.so
