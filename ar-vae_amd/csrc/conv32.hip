@@ -28,6 +28,7 @@
 #include "common.h"
 #include "conv32_common.h"
 #include "reduce.h"
+#include "midprep.h"
 
 #include <type_traits>
 
@@ -542,8 +543,8 @@ struct PrepArgs {
 };
 
 // 16 workgroups per layer: items 0..2047 build the DOWN part, 2048..4095 the UP part; an item = 8 weights -> 3 x 16 bytes
-__global__ __launch_bounds__(256) void conv32_weight_prep_kernel(PrepArgs p) {
-    const int layer = blockIdx.x >> 4, item = (blockIdx.x & 15) * 256 + threadIdx.x;
+__device__ __forceinline__ void conv32_prep_block(const PrepArgs &p, const int block) {
+    const int layer = block >> 4, item = (block & 15) * 256 + threadIdx.x;
     const float *wt = nullptr;
     uint4 *out = nullptr;
 #pragma unroll
@@ -571,6 +572,15 @@ __global__ __launch_bounds__(256) void conv32_weight_prep_kernel(PrepArgs p) {
     dst[0] = __builtin_bit_cast(uint4, h);
     dst[64] = __builtin_bit_cast(uint4, m);
     dst[128] = __builtin_bit_cast(uint4, l);
+}
+
+__global__ __launch_bounds__(256) void conv32_weight_prep_kernel(PrepArgs p) { conv32_prep_block(p, blockIdx.x); }
+
+// the step's two weight preps as one launch: workgroups [0, conv_blocks) split the 32-channel conv weights, the rest lay out the
+// latent block's matrices (midprep.h)
+__global__ __launch_bounds__(256) void prep_all_kernel(PrepArgs p, MidPrepArgs mid, int conv_blocks) {
+    if ((int)blockIdx.x < conv_blocks) conv32_prep_block(p, blockIdx.x);
+    else mid_prep_block(mid, blockIdx.x - conv_blocks);
 }
 
 template <int LO, int MODE>
@@ -1627,6 +1637,19 @@ int conv32_weight_prep(const float *const *wts, float *const *preps, int n_layer
     }
     ARVAE_LAUNCH(conv32_weight_prep_kernel, dim3(16 * n_layers), dim3(256), 0, s, p);
     return check_launch("conv32_weight_prep");
+}
+
+// the same together with the latent block's layout prep (mid_prep_args, midblock.hip): one launch
+int conv32_weight_prep_with_mid(const float *const *wts, float *const *preps, int n_layers, const MidPrepArgs &mid, hipStream_t s) {
+    ARVAE_REQUIRE(n_layers > 0 && n_layers <= PREP_MAX_LAYERS && mid.count > 0, "conv32_weight_prep_with_mid: nothing to prepare");
+    PrepArgs p{};
+    for (int i = 0; i < n_layers; ++i) {
+        p.wt[i] = wts[i];
+        p.out[i] = reinterpret_cast<uint4 *>(preps[i]);
+    }
+    const int conv_blocks = 16 * n_layers;
+    ARVAE_LAUNCH(prep_all_kernel, dim3(conv_blocks + mid.blk_end[mid.count - 1]), dim3(256), 0, s, p, mid, conv_blocks);
+    return check_launch("weight_prep(conv32 + latent block)");
 }
 
 // row-stream weight gradient with producer / consumer waves (conv32r.hip): the 16x16 and 8x8 layers

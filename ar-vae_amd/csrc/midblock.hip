@@ -15,12 +15,12 @@
 #include "common.h"
 #include "dense.h"
 #include "rng.h"
+#include "midprep.h"
 
 namespace arvae {
 
 
 constexpr int MID_T = 512;           // threads per workgroup
-constexpr int MID_MAX_LAYERS = 4;    // Linear layers on either side of the latent
 constexpr int MID_MAX_W = 3072;      // widest layer (Morpho-MNIST: 2888)
 constexpr int mid_red(int r) { return r * 4 * MID_T; }   // floats of cross-slice reduction scratch (slices * n <= 4 * MID_T)
 
@@ -365,43 +365,7 @@ __global__ __launch_bounds__(MID_T) void mid_backward_kernel(MidArgs p) {
 }
 
 // ================================================================================================ weight layout prep
-struct MidPrepJob {
-    const float *w, *b;          // reference layout [n][k], bias [n]
-    const float *w2, *b2;        // rows n >= nsplit come from here (the two heads share one prepped matrix); null: one source
-    int nsplit;
-    float *mf, *mb, *bias;
-    int k, n, kb;                // kb: row length of mb (k rounded up to a multiple of 4, zero-padded)
-    Perm kp, np;                 // memory order <-> feature order of the input / output axis
-};
-struct MidPrepArgs {
-    MidPrepJob job[2 * MID_MAX_LAYERS + 1];
-    int count, blk_end[2 * MID_MAX_LAYERS + 1];
-};
-
-__global__ __launch_bounds__(256) void mid_prep_kernel(MidPrepArgs a) {
-    int j = 0, start = 0;
-#pragma unroll
-    for (int q = 0; q + 1 < 2 * MID_MAX_LAYERS + 1; ++q)
-        if (q + 1 < a.count && (int)blockIdx.x >= a.blk_end[q]) { j = q + 1; start = a.blk_end[q]; }
-    const MidPrepJob &p = a.job[j];
-    const int total = p.kb * p.n, stride = (a.blk_end[j] - start) * 256;
-    for (int e = ((int)blockIdx.x - start) * 256 + threadIdx.x; e < total; e += stride) {
-        auto src = [&](int nf, int kf) {                          // W[nf][kf] of the layer (two stacked sources for the heads)
-            return (p.w2 != nullptr && nf >= p.nsplit) ? p.w2[(int64_t)(nf - p.nsplit) * p.k + kf] : p.w[(int64_t)nf * p.k + kf];
-        };
-        if (e < p.k * p.n) {
-            const int km = e / p.n, nm = e - km * p.n;            // forward matrix [k][n], written in order
-            p.mf[e] = src(p.np.to_feat(nm), p.kp.to_feat(km));
-        }
-        const int nm2 = e / p.kb, km2 = e - nm2 * p.kb;          // backward matrix [n][kb], written in order
-        p.mb[e] = km2 < p.k ? src(p.np.to_feat(nm2), p.kp.to_feat(km2)) : 0.f;
-        if (e < p.n && p.bias != nullptr) {
-            const int nf = p.np.to_feat(e);
-            const float *bs = (p.w2 != nullptr && nf >= p.nsplit) ? p.b2 : p.b;
-            p.bias[e] = bs != nullptr ? bs[(p.w2 != nullptr && nf >= p.nsplit) ? nf - p.nsplit : nf] : 0.f;
-        }
-    }
-}
+__global__ __launch_bounds__(256) void mid_prep_kernel(MidPrepArgs a) { mid_prep_block(a, blockIdx.x); }
 
 // ================================================================================================ host side
 static bool mid_layer_ok(const arvae_layer_t &l) {
@@ -532,9 +496,16 @@ static void mid_allow_lds() {
     done = true;
 }
 
-// (1) weight layout prep, (2) the forward block.  enc_y / dec_y: saved outputs of the block's layers.
+// the prep launch's arguments alone (plan.hip hands them to conv32_weight_prep, which runs both preps as one launch)
+void mid_prep_args(const arvae_image_vae_t *m, const float *params, float *prep_ws, MidPrepArgs *out) {
+    MidPlan pl;
+    mid_describe(m, params, prep_ws, pl);
+    *out = pl.prep;
+}
+
+// (1) weight layout prep unless prep_done, (2) the forward block.  enc_y / dec_y: saved outputs of the block's layers.
 int mid_forward(const arvae_image_vae_t *m, int batch, const float *params, float *prep_ws, const float *x0, float *const *enc_y,
-                float *const *dec_y, const float *eps, float *mu, float *log_std, float *sigma, float *z, hipStream_t s) {
+                float *const *dec_y, const float *eps, float *mu, float *log_std, float *sigma, float *z, hipStream_t s, bool prep_done) {
     MidPlan pl;
     mid_describe(m, params, prep_ws, pl);
     MidArgs &a = pl.args;
@@ -556,8 +527,10 @@ int mid_forward(const arvae_image_vae_t *m, int batch, const float *params, floa
         if (getenv("ARVAE_MID_NO_WARM") != nullptr) nw = 0;
     }
     mid_allow_lds();
-    ARVAE_LAUNCH(mid_prep_kernel, dim3(pl.prep.blk_end[pl.prep.count - 1]), dim3(256), 0, s, pl.prep);
-    if (int rc = check_launch("mid_prep_kernel")) return rc;
+    if (!prep_done) {
+        ARVAE_LAUNCH(mid_prep_kernel, dim3(pl.prep.blk_end[pl.prep.count - 1]), dim3(256), 0, s, pl.prep);
+        if (int rc = check_launch("mid_prep_kernel")) return rc;
+    }
     if (pl.rows == 8) ARVAE_LAUNCH(mid_forward_kernel<8>, dim3((batch + 7) / 8), dim3(MID_T), pl.lds_bytes, s, a);
     else ARVAE_LAUNCH(mid_forward_kernel<4>, dim3((batch + 3) / 4), dim3(MID_T), pl.lds_bytes, s, a);
     return check_launch("mid_forward_kernel");

@@ -4,6 +4,7 @@
 #include "common.h"
 #include "dense.h"
 #include "reduce.h"
+#include "midprep.h"
 
 namespace arvae {
 
@@ -26,6 +27,8 @@ int conv_c1_up_recon(const arvae_link_t *l, const float *lo, const float *wt, co
                      int dist, float *partial, float *dlogits, hipStream_t s, int *nb_out);
 int64_t conv32_prep_floats();
 int conv32_weight_prep(const float *const *wts, float *const *preps, int n_layers, hipStream_t s);
+int conv32_weight_prep_with_mid(const float *const *wts, float *const *preps, int n_layers, const MidPrepArgs &mid, hipStream_t s);
+void mid_prep_args(const arvae_image_vae_t *m, const float *params, float *prep_ws, MidPrepArgs *out);
 bool conv32_pair4_fits(const arvae_link_t *l, bool up, const float *gate, const uint16_t *gate_bits, const float *wprep, int bias_mode);
 int conv32_pair4(const arvae_link_t *l, bool up, const float *g, const float *x_in, const float *wt, const float *gate,
                  const uint16_t *gate_bits, float *d_in, const float *wprep, float *dwt, float *dbias, float *slab, hipStream_t s,
@@ -57,7 +60,7 @@ int heads_latent_bwd(const arvae_layer_t *hm, const arvae_layer_t *hl, int batch
 bool mid_fusable(const arvae_image_vae_t *m, int *ne_out, int *nd_out);
 int64_t mid_prep_floats(const arvae_image_vae_t *m);
 int mid_forward(const arvae_image_vae_t *m, int batch, const float *params, float *prep_ws, const float *x0, float *const *enc_y,
-                float *const *dec_y, const float *eps, float *mu, float *log_std, float *sigma, float *z, hipStream_t s);
+                float *const *dec_y, const float *eps, float *mu, float *log_std, float *sigma, float *z, hipStream_t s, bool prep_done);
 int mid_backward(const arvae_image_vae_t *m, int batch, const float *params, float *prep_ws, float *const *enc_y, float *const *dec_y,
                  float *const *enc_g, float *const *dec_g, const float *g_out, int g_is_pre, const float *gate0, float *d_x0,
                  const float *eps, const float *mu, const float *sigma, const float *dz_reg, const float *dz_extra, const float *g_loss,
@@ -400,6 +403,7 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
     ARVAE_REQUIRE(m->n_reg == 0 || n_cols < 0 || labels != nullptr, "image_vae_forward: labels needed for the reg loss");
     hipStream_t st = as_stream(stream);
     int mi = 0;
+    bool mid_prepped = false;
     {   // split the 32-channel conv weights once for this step's forward and backward kernels
         const float *wts[8];
         float *preps[8];
@@ -408,7 +412,13 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
             if (L.enc_wprep[i] >= 0) { wts[np] = params + m->enc[i].w_off; preps[np++] = ws + L.enc_wprep[i]; }
         for (int i = 0; i < m->n_dec; ++i)
             if (L.dec_wprep[i] >= 0) { wts[np] = params + m->dec[i].w_off; preps[np++] = ws + L.dec_wprep[i]; }
-        if (int rc = conv32_weight_prep(wts, preps, np, st)) return rc;
+        // (together with the latent block's matrix layouts when that block runs: one prep launch per step)
+        if (np > 0 && mid_fusable(m, nullptr, nullptr) && getenv("ARVAE_SPLIT_PREP") == nullptr) {
+            MidPrepArgs margs;
+            mid_prep_args(m, params, ws + L.mid_prep, &margs);
+            if (int rc = conv32_weight_prep_with_mid(wts, preps, np, margs, st)) return rc;
+            mid_prepped = true;
+        } else if (int rc = conv32_weight_prep(wts, preps, np, st)) return rc;
     }
     // encoder
     int mid_ne = 0, mid_nd = 0;
@@ -429,7 +439,7 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
         float *enc_y[ARVAE_MAX_LAYERS], *dec_y[ARVAE_MAX_LAYERS];
         for (int i = 0; i < mid_ne; ++i) enc_y[i] = ws + L.enc_out[m->n_enc - mid_ne + i];
         for (int i = 0; i < mid_nd; ++i) dec_y[i] = ws + L.dec_out[i];
-        if (int rc = mid_forward(m, batch, params, ws + L.mid_prep, h, enc_y, dec_y, eps, mu, ws + L.log_std, sigma, z, st)) return rc;
+        if (int rc = mid_forward(m, batch, params, ws + L.mid_prep, h, enc_y, dec_y, eps, mu, ws + L.log_std, sigma, z, st, mid_prepped)) return rc;
         h = dec_y[mid_nd - 1];
     } else if (heads_fusable(&m->head_mu, &m->head_log_std, m->zdim)) {
         // the decoder's first Linear layer rides in the heads kernel when it can (heads.hip)
