@@ -431,7 +431,18 @@ struct MidPlan {
 };
 
 // fills the layer tables from the model description; y / gpre buffers are given per layer by the caller afterwards
-static void mid_describe(const arvae_image_vae_t *m, const float *params, float *prep_ws, MidPlan &pl) {
+static int mid_cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+static void mid_describe(const arvae_image_vae_t *m, const float *params, float *prep_ws, MidPlan &pl, int batch = 512) {
     int ne, nd;
     mid_fusable(m, &ne, &nd);
     MidArgs &a = pl.args;
@@ -480,7 +491,16 @@ static void mid_describe(const arvae_image_vae_t *m, const float *params, float 
     a.ld = ((maxw + 3) / 4) * 4 + 4;
     a.w_mu = params + m->head_mu.w_off; a.b_mu = m->head_mu.b_off >= 0 ? params + m->head_mu.b_off : nullptr;
     a.w_ls = params + m->head_log_std.w_off; a.b_ls = m->head_log_std.b_off >= 0 ? params + m->head_log_std.b_off : nullptr;
-    pl.rows = 4;                 // 8 rows per workgroup measured slower (49 vs 36 us forward at B = 512: the FMA work per workgroup doubles)
+    // Batch rows per workgroup: every workgroup streams every matrix (~115 GB/s, the L2 -> CU rate of one CU), so the layer time is
+    // that stream plus the FMA / LDS work of its rows -- as few rows as still give every CU at most ONE workgroup: 1 / 2 / 4 rows
+    // for B <= 256 / 512 / more on 256 CUs (B = 512: forward 32.0 -> 28.8 us, backward 34.6 -> 31.0 us against 4 rows; 8 rows per
+    // workgroup measured 49 vs 36 us forward: the FMA work per workgroup doubles).  ARVAE_MID_ROWS=n overrides.
+    {
+        static const int forced = getenv("ARVAE_MID_ROWS") != nullptr ? atoi(getenv("ARVAE_MID_ROWS")) : 0;
+        const int cus = mid_cu_count();
+        pl.rows = batch > 2 * cus ? 4 : batch > cus ? 2 : 1;
+        if (forced == 1 || forced == 2 || forced == 4) pl.rows = forced;
+    }
     pl.lds_bytes = (size_t)(2 * pl.rows * a.ld + mid_red(pl.rows) + pl.rows * 32) * sizeof(float);
 }
 
@@ -491,6 +511,10 @@ static void mid_allow_lds() {
     static_assert((2 * 4 * (MID_MAX_W + 4) + mid_red(4) + 4 * 32) * sizeof(float) <= 160 * 1024, "the 4-row block must fit the LDS");
     (void)hipFuncSetAttribute((const void *)mid_forward_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes4);
     (void)hipFuncSetAttribute((const void *)mid_backward_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes4);
+    (void)hipFuncSetAttribute((const void *)mid_forward_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes4);
+    (void)hipFuncSetAttribute((const void *)mid_backward_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes4);
+    (void)hipFuncSetAttribute((const void *)mid_forward_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes4);
+    (void)hipFuncSetAttribute((const void *)mid_backward_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes4);
     (void)hipFuncSetAttribute((const void *)mid_forward_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes8);
     (void)hipFuncSetAttribute((const void *)mid_backward_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes8);
     done = true;
@@ -507,7 +531,7 @@ void mid_prep_args(const arvae_image_vae_t *m, const float *params, float *prep_
 int mid_forward(const arvae_image_vae_t *m, int batch, const float *params, float *prep_ws, const float *x0, float *const *enc_y,
                 float *const *dec_y, const float *eps, float *mu, float *log_std, float *sigma, float *z, hipStream_t s, bool prep_done) {
     MidPlan pl;
-    mid_describe(m, params, prep_ws, pl);
+    mid_describe(m, params, prep_ws, pl, batch);
     MidArgs &a = pl.args;
     for (int i = 0; i < a.ne; ++i) a.enc[i].y = enc_y[i];
     for (int i = 0; i < a.nd; ++i) a.dec[i].y = dec_y[i];
@@ -531,7 +555,9 @@ int mid_forward(const arvae_image_vae_t *m, int batch, const float *params, floa
         ARVAE_LAUNCH(mid_prep_kernel, dim3(pl.prep.blk_end[pl.prep.count - 1]), dim3(256), 0, s, pl.prep);
         if (int rc = check_launch("mid_prep_kernel")) return rc;
     }
-    if (pl.rows == 8) ARVAE_LAUNCH(mid_forward_kernel<8>, dim3((batch + 7) / 8), dim3(MID_T), pl.lds_bytes, s, a);
+    if (pl.rows == 1) ARVAE_LAUNCH(mid_forward_kernel<1>, dim3(batch), dim3(MID_T), pl.lds_bytes, s, a);
+    else if (pl.rows == 2) ARVAE_LAUNCH(mid_forward_kernel<2>, dim3((batch + 1) / 2), dim3(MID_T), pl.lds_bytes, s, a);
+    else if (pl.rows == 8) ARVAE_LAUNCH(mid_forward_kernel<8>, dim3((batch + 7) / 8), dim3(MID_T), pl.lds_bytes, s, a);
     else ARVAE_LAUNCH(mid_forward_kernel<4>, dim3((batch + 3) / 4), dim3(MID_T), pl.lds_bytes, s, a);
     return check_launch("mid_forward_kernel");
 }
@@ -541,7 +567,7 @@ int mid_backward(const arvae_image_vae_t *m, int batch, const float *params, flo
                  const float *eps, const float *mu, const float *sigma, const float *dz_reg, const float *dz_extra, const float *g_loss,
                  const float *kl, const float *cap, float beta, float reg_scale, float *d_mu, float *d_ls, hipStream_t s) {
     MidPlan pl;
-    mid_describe(m, params, prep_ws, pl);
+    mid_describe(m, params, prep_ws, pl, batch);
     MidArgs &a = pl.args;
     for (int i = 0; i < a.ne; ++i) { a.enc[i].y = enc_y[i]; a.enc[i].gpre = enc_g[i]; }
     for (int i = 0; i < a.nd; ++i) { a.dec[i].y = dec_y[i]; a.dec[i].gpre = dec_g[i]; }
@@ -561,7 +587,9 @@ int mid_backward(const arvae_image_vae_t *m, int batch, const float *params, flo
         if (getenv("ARVAE_MID_NO_WARM") != nullptr) nw = 0;
     }
     mid_allow_lds();
-    if (pl.rows == 8) ARVAE_LAUNCH(mid_backward_kernel<8>, dim3((batch + 7) / 8), dim3(MID_T), pl.lds_bytes, s, a);
+    if (pl.rows == 1) ARVAE_LAUNCH(mid_backward_kernel<1>, dim3(batch), dim3(MID_T), pl.lds_bytes, s, a);
+    else if (pl.rows == 2) ARVAE_LAUNCH(mid_backward_kernel<2>, dim3((batch + 1) / 2), dim3(MID_T), pl.lds_bytes, s, a);
+    else if (pl.rows == 8) ARVAE_LAUNCH(mid_backward_kernel<8>, dim3((batch + 7) / 8), dim3(MID_T), pl.lds_bytes, s, a);
     else ARVAE_LAUNCH(mid_backward_kernel<4>, dim3((batch + 3) / 4), dim3(MID_T), pl.lds_bytes, s, a);
     return check_launch("mid_backward_kernel");
 }
