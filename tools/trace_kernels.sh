@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 pat=$1; shift
 for kv in "$@"; do export "$kv"; done
 rm -rf /tmp/tr_k
-rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_k -o p -- python3 bench.py --workload ${WORKLOAD:-dsprites} --steps ${STEPS:-30} --warmup 5 --min-seconds 0 --no-cpu-baseline --no-secondary --no-graphs > /dev/null 2> /tmp/tr_k.err
+rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_k -o p -- python3 bench.py --workload ${WORKLOAD:-dsprites} --steps ${STEPS:-30} --warmup 5 --min-seconds 0 --no-cpu-baseline --no-secondary --no-graphs ${BENCH_ARGS:-} > /dev/null 2> /tmp/tr_k.err
 PAT="$pat" python3 - <<'P'
 import csv, glob, os, collections
 f = glob.glob('/tmp/tr_k/**/*kernel_trace.csv', recursive=True)[0]
