@@ -134,16 +134,17 @@ def load():
     with _lock:
         if _lib is not None:
             return _lib
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get('ARVAE_LIB') or LIB_PATH      # ARVAE_LIB: a diagnostic build of the same sources (tools/bin/*.so)
+        if not os.path.exists(path):
             raise RuntimeError(
-                f'{LIB_PATH} is missing: the AR-VAE HIP kernels are not built and there is no CPU '
+                f'{path} is missing: the AR-VAE HIP kernels are not built and there is no CPU '
                 f'fallback. Run `python __graft_entry__.py` (or `python ar-vae_amd/build.py`) first.')
         # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so, soname libamdhip64.so.7).
         # It must be the ONE runtime in the process: import torch first so that our NEEDED
         # libamdhip64.so.7 resolves to the copy torch already loaded.  Loading this library first would
         # pull in /opt/rocm's runtime as a second instance, which then sees no device.
         import torch  # noqa: F401
-        lib = ctypes.CDLL(LIB_PATH)
+        lib = ctypes.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)          # AttributeError if the .so does not export it
             fn.restype = res

@@ -215,29 +215,32 @@ static int launch_conv_rows(ConvRows g, const float *wt, bool transposed, float 
 // lo[n][lh][lw][clo] = act(conv(hi) + bias) * mask     (Conv2d forward / ConvTranspose2d data gradient)
 int conv64_down(const arvae_link_t *l, const Operand &hi, const float *wt, const float *bias, int act, const uint8_t *mask,
                 float *lo, float *ws, hipStream_t s, const GateOp *gate) {
+    // timeline labels tell the 64 -> 64 launches from the ones with a narrow side (64 -> 8): different kernels, 3x apart
+    const char *what = (l->chi >= 64 && l->clo >= 64) ? "conv64_down(wide)" : "conv64_down(narrow)";
     if (conv64s_fits(l, false))
-        return conv64s_run(hi, l->n, l->hh, l->hw, l->lh, l->lw, l->clo, 1, -l->pad, wt, false, bias, act, mask, lo, ws, s, "conv64_down", gate);
+        return conv64s_run(hi, l->n, l->hh, l->hw, l->lh, l->lw, l->clo, 1, -l->pad, wt, false, bias, act, mask, lo, ws, s, what, gate);
     ConvRows g{};
     if (gate != nullptr) g.gate = *gate;
     g.src = hi; g.n = l->n; g.sh = l->hh; g.sw = l->hw; g.cs = l->chi;
     g.oh = l->lh; g.ow = l->lw; g.q = l->clo;
     g.kh = l->kh; g.kw = l->kw; g.sgn = 1; g.off = -l->pad;
     g.bias = bias; g.mask = mask; g.act = act; g.out = lo;
-    return launch_conv_rows(g, wt, false, ws, s, "conv64_down");          // wt[clo][chi][ky][kx]: q = clo, c = chi
+    return launch_conv_rows(g, wt, false, ws, s, what);          // wt[clo][chi][ky][kx]: q = clo, c = chi
 }
 
 // hi[n][hh][hw][chi] = act(convT(lo) + bias) * mask    (ConvTranspose2d forward / Conv2d data gradient)
 int conv64_up(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, int act, const uint8_t *mask,
               float *hi, float *ws, hipStream_t s, const GateOp *gate) {
+    const char *what = (l->chi >= 64 && l->clo >= 64) ? "conv64_up(wide)" : "conv64_up(narrow)";
     if (conv64s_fits(l, true))
-        return conv64s_run(lo, l->n, l->lh, l->lw, l->hh, l->hw, l->chi, -1, l->pad, wt, true, bias, act, mask, hi, ws, s, "conv64_up", gate);
+        return conv64s_run(lo, l->n, l->lh, l->lw, l->hh, l->hw, l->chi, -1, l->pad, wt, true, bias, act, mask, hi, ws, s, what, gate);
     ConvRows g{};
     if (gate != nullptr) g.gate = *gate;
     g.src = lo; g.n = l->n; g.sh = l->lh; g.sw = l->lw; g.cs = l->clo;
     g.oh = l->hh; g.ow = l->hw; g.q = l->chi;
     g.kh = l->kh; g.kw = l->kw; g.sgn = -1; g.off = l->pad;
     g.bias = bias; g.mask = mask; g.act = act; g.out = hi;
-    return launch_conv_rows(g, wt, true, ws, s, "conv64_up");             // wt[clo][chi][ky][kx]: q = chi, c = clo
+    return launch_conv_rows(g, wt, true, ws, s, what);             // wt[clo][chi][ky][kx]: q = chi, c = clo
 }
 
 // ---- weight gradient ----------------------------------------------------------------------------------------------
@@ -706,7 +709,7 @@ int conv64_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, fl
         else ARVAE_LAUNCH((conv_wgrad_pairs_x3_kernel<false, false>), grid, dim3(256), lds, s, g, ipw);
         const int count = taps * l->clo * l->chi;
         ARVAE_LAUNCH(conv64_wgrad_reduce_kernel, dim3((count * 4 + 255) / 256), dim3(256), 0, s, ws, slices, taps, l->clo, l->chi, dwt);
-        return check_launch("conv64_wgrad(rows)");
+        return check_launch((l->chi >= 64 && l->clo >= 64) ? "conv64_wgrad(pairs, wide)" : "conv64_wgrad(pairs, narrow)");
     }
     if (conv64_wgrad_rows_fits(l)) {
         const int ipw = wr_img_per_wg(l), slices = (l->n + ipw - 1) / ipw;

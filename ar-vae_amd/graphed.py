@@ -73,12 +73,14 @@ class GraphedStep:
         return loss.detach(), None if acc is None else acc.detach()
 
     def accepts(self, batch):
-        """True when `batch` has the shapes this step was captured for"""
+        """the processed batch when it has the shapes this step was captured for (hand it to __call__ as `data`), else None"""
         data = self.trainer.process_batch_data(batch)
-        return len(data) == len(self.static) and all(d.shape == s.shape for d, s in zip(data, self.static))
+        ok = len(data) == len(self.static) and all(d.shape == s.shape for d, s in zip(data, self.static))
+        return data if ok else None
 
-    def __call__(self, batch):
-        data = self.trainer.process_batch_data(batch)
+    def __call__(self, batch=None, data=None):
+        if data is None:
+            data = self.trainer.process_batch_data(batch)
         for dst, src in zip(self.static, data):
             if dst.shape != src.shape:
                 raise ValueError(f'GraphedStep was captured for batches of shape {tuple(dst.shape)}, got {tuple(src.shape)}')

@@ -70,7 +70,7 @@ class MeasureVAETrainer(Trainer):
         self.reg_dim = ()
         self.use_reg_loss = False
         self.rand_seed = rand
-        torch.manual_seed(self.rand_seed)
+        ops.rng_reseed(self.rand_seed)                 # torch.manual_seed + restart of the library's Philox stream position
         np.random.seed(self.rand_seed)
         self.trainer_config = f'_r_{self.rand_seed}_b_{self.beta}_'
         if capacity != 0.0:

@@ -878,16 +878,37 @@ def check_index(indices, num_notes):
 # ------------------------------------------------------------------------------------------------
 class RngState:
     """Every draw of the path (eps, dropout keep-masks) is element i of the stream keyed by
-    (seed, offset, step + *dev_step): seed = torch.initial_seed(), so the trainers' torch.manual_seed(rand)
-    (image_vae_trainer.py:103) selects the stream as it does in the reference; `offset` counts the draws of this process.
+    (seed, offset, step + *dev_step): seed = torch.initial_seed() salted with the data-parallel rank, so the trainers'
+    torch.manual_seed(rand) (image_vae_trainer.py:103) selects the stream as it does in the reference and every rank of a
+    data-parallel run draws DIFFERENT noise and keep-masks for its rows ("RNG under DP": rank 0's
+    stream is the single-process one); `offset` counts the draws since the stream was last selected (`rng_reseed`, called
+    where the trainers call torch.manual_seed, restarts it -- the reference's generator reset).
     Under HIP-graph replay the host numbers are frozen into the captured launches, so graphed.GraphedStep advances the device
     word `dev_step` inside the graph and every replay sees fresh values."""
     offset = 0
+    rank = 0                           # data-parallel rank (parallel.DataParallel sets it)
     dev_step = None                    # int32 tensor (1,) on the device, or None
 
 
+RANK_SALT = 0x9E3779B97F4A7C15         # odd 64-bit constant: rank r's key = seed + r * RANK_SALT (mod 2^64)
+
+
 def rng_seed():
-    return torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
+    return (torch.initial_seed() + RngState.rank * RANK_SALT) & 0xFFFFFFFFFFFFFFFF
+
+
+def rng_set_rank(rank):
+    """select this process's sub-stream (0 = the single-process stream)"""
+    RngState.rank = int(rank)
+
+
+def rng_reseed(seed):
+    """torch.manual_seed(seed) + restart of the library's stream position: what the trainers' constructors call, so that
+    training seed k in a loop over seeds draws what a fresh process with --rand k draws"""
+    torch.manual_seed(seed)
+    RngState.offset = 0
+    if RngState.dev_step is not None:
+        RngState.dev_step.zero_()
 
 
 def rng_next_offset():

@@ -50,15 +50,25 @@ class DataParallel:
         self.group = process_group
         self.world_size = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
+        from . import ops
         if reg_fn is None:
-            from . import ops
             reg_fn = ops.reg_loss
         self._reg_fn = reg_fn
+        ops.rng_set_rank(self.rank)          # per-rank eps / dropout streams ("RNG under DP")
 
     def attach(self, trainer):
         """make `trainer` data-parallel (its loss step gathers columns, its step() all-reduces); returns self"""
+        from . import ops
         trainer.data_parallel = self
+        ops.rng_set_rank(self.rank)
         return self
+
+    def finish(self):
+        """all ranks are done training: leave the process group (after this, rank 0 may evaluate for as long as it likes --
+        nobody waits in a collective that the group's watchdog would time out)"""
+        dist.barrier(group=self.group)
+        if self.group is None:
+            dist.destroy_process_group()
 
     def broadcast_parameters(self, model, src=0):
         """Make every replica start from rank `src`'s weights."""

@@ -45,7 +45,7 @@ class Trainer(ABC):
             # batch_size is the PER-GPU batch (weak scaling, as bench.py): every rank iterates its own rows of the same
             # shuffled global batches (data/loaders.py)
             train_loader, val_loader, _ = self.dataset.data_loaders(batch_size=batch_size, split=(0.70, 0.20),
-                                                                    shard=(dp.rank, dp.world_size))
+                                                                    shard=(dp.rank, dp.world_size, dp.group))
             dp.broadcast_parameters(self.model)
         else:
             train_loader, val_loader, _ = self.dataset.data_loaders(batch_size=batch_size, split=(0.70, 0.20))
@@ -100,9 +100,10 @@ class Trainer(ABC):
                 print(f'graph replay disabled: {e}')
                 self.use_graph_replay = False
                 return None
-        if not graphed.accepts(batch):                         # a batch of another shape (the last one of an epoch)
+        data = graphed.accepts(batch)                          # processed once; None = a batch of another shape (the last one
+        if data is None:                                       # of an epoch): eager
             return None
-        return graphed(batch)                                  # errors of the step itself propagate
+        return graphed(data=data)                              # errors of the step itself propagate
 
     def loss_and_acc_on_epoch(self, data_loader, epoch_num=None, train=True):
         loss_sum = acc_sum = None

@@ -68,6 +68,15 @@ KERNEL_WORK = {
     # a layer's data gradient and weight gradient in one launch: the upstream gradient is read by both halves
     'pair4(down32 + wgrad32)': (2 * 262_144, 4 * (2 * 2048 + 2 * 512)), 'pair4(up32 + wgrad32)': (2 * 262_144, 4 * (2 * 512 + 2 * 2048)),
     'pair_c1(down_c1 + wgrad_c1)': (2 * 524_288, 4 * (2 * 4096 + 2 * 32768)),
+    # the latent block (six Linear layers + heads, one launch per pass): MACs of SURVEY 8(d)'s per-layer table; bytes =
+    # every layer's input and output once (forward), upstream gradient + activation derivative + input gradient (backward),
+    # upstream gradient + saved input (weight gradients); the third number is bytes per LAUNCH that do not scale with the
+    # batch: the 1.6 MB of fp32 matrices read (forward, backward) or written (weight gradients) once
+    'mid_forward_kernel': (400_896, 4 * 3102, 4 * 400_896), 'mid_backward_kernel': (400_896, 4 * (3102 + 1556), 4 * 400_896),
+    'dense_wgrad_batch_kernel': (400_896, 4 * 3102, 4 * 400_896),
+    # fixed-order sum of the conv layers' weight-gradient slabs: 4 x 256 slabs of 64 KB (16x16 and 8x8 layers), 2 x 128
+    # (4x4 layers), 2 x 256 x 2 KB (single-channel layers) + bias partials read, 2 MB of gradients written
+    'slab_reduce_batch_kernel': (0, 0, 4 * 256 * 65664 + 2 * 128 * 65664 + 2 * 256 * 2176 + 2_000_000),
 }
 # the library's timeline labels one kernel FAMILY; these are the instantiations a rocprofv3 --kernel-trace of the
 # default build lists for it at B = 512 (profiles/*_kernel_stats.csv)
@@ -85,8 +94,9 @@ ROCPROF_NAMES = {
     'pair_c1(down_c1 + wgrad_c1)': ['arvae::pair_c1_kernel<1>'],
     'down_c1_kernel': ['arvae::down_c1s_kernel<0>', 'arvae::down_c1s_kernel<1>'], 'wgrad_c1_kernel': ['arvae::wgrad_c1s_kernel'],
     'up_c1_kernel(recon)': ['arvae::up_c1_kernel<0, true>'],
-    'conv64_down': ['arvae::conv64s_kernel<3, 2, 0>', 'arvae::conv64s_kernel<3, 1, 0>'],
-    'conv64_up': ['arvae::conv64s_kernel<4, 2, 0>', 'arvae::conv_rows_x3_kernel<true>'],
+    'conv64_down(wide)': ['arvae::conv64s_kernel<3, 2, 0>'], 'conv64_down(narrow)': ['arvae::conv64s_kernel<3, 1, 0>'],
+    'conv64_up(wide)': ['arvae::conv64s_kernel<4, 2, 0>'], 'conv64_up(narrow)': ['arvae::conv_rows_x3_kernel<true>'],
+    'conv64_wgrad(pairs, wide)': ['arvae::conv_wgrad_pairs_x3_kernel'], 'conv64_wgrad(pairs, narrow)': ['arvae::conv_wgrad_pairs_x3_kernel'],
     'conv64_wgrad(rows)': ['arvae::conv_wgrad_rows_x3_kernel'],
     'gru_seq_fwd_kernel': ['arvae::gru_seq_fwd_x3_kernel<128>'], 'gru_seq_bwd_kernel': ['arvae::gru_seq_bwd_x3_kernel<128>'],
     'tick_free_run_x3_kernel': ['arvae::tick_free_run_x3_kernel<128>'],
@@ -112,7 +122,9 @@ SIDE_BATCH = {'mnist': 1024, 'measure': 256}
 # deconv1 / deconv2 once per direction in each of the three products (forward-type, data gradient, weight gradient);
 # MeasureVAE's recurrent products are 3*H*H MACs per row and time step over 152 row-steps per measure.
 SIDE_KERNEL_MACS = {
-    'mnist': {'conv64_down': 2 * (31_719_424 + 2_957_312), 'conv64_up': 2 * (31_719_424 + 2_957_312),
+    'mnist': {'conv64_down(wide)': 2 * 31_719_424, 'conv64_down(narrow)': 2 * 2_957_312,
+              'conv64_up(wide)': 2 * 31_719_424, 'conv64_up(narrow)': 2 * 2_957_312,
+              'conv64_wgrad(pairs, wide)': 2 * 31_719_424, 'conv64_wgrad(pairs, narrow)': 2 * 2_957_312,
               'conv64_wgrad(rows)': 2 * (31_719_424 + 2_957_312)},
     'measure': {'gru_seq_fwd_kernel': 152 * 3 * 128 * 128, 'gru_seq_bwd_kernel': 2 * 152 * 3 * 128 * 128},
 }
@@ -142,11 +154,31 @@ class FolkDataset:              # what MeasureVAE / MeasureVAETrainer read from 
 
 
 # ---- N > 1 without a launcher: start the ranks here ------------------------------------------------------------------
-def spawn_ranks(n, argv):
-    """Run this script as n fresh child processes (one rank per GPU) and relay rank 0's line.  Nothing in this process has
-    touched the GPU yet (torch.cuda.device_count() does not initialise it on this image), so every child starts clean."""
-    have = torch.cuda.device_count()
-    if have < n:
+def visible_gpu_count():
+    """GPUs this process's children would see, counted WITHOUT touching the HIP runtime: a *_VISIBLE_DEVICES list when one is
+    set, otherwise the KFD topology nodes that have SIMDs (CPU nodes report simd_count 0).  None when neither is readable."""
+    for var in ('HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES'):
+        val = os.environ.get(var)
+        if val is not None:
+            return len([v for v in val.split(',') if v.strip() != ''])
+    nodes = '/sys/class/kfd/kfd/topology/nodes'
+    try:
+        count = 0
+        for node in os.listdir(nodes):
+            with open(os.path.join(nodes, node, 'properties')) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            count += int(props.get('simd_count', '0')) > 0
+        return count
+    except (OSError, ValueError):
+        return None
+
+
+def spawn_ranks(n, argv, script=None, gpu_count=visible_gpu_count, out=None):
+    """Run this script (or `script`) as n fresh child processes (one rank per GPU) and relay rank 0's stdout.  This process
+    never touches the GPU: the device count comes from sysfs / the environment (visible_gpu_count), so every child starts
+    clean.  A rank that exits non-zero ends the others and its code is re-raised here."""
+    have = gpu_count() if callable(gpu_count) else gpu_count
+    if have is not None and have < n:
         raise SystemExit(f'--gpus {n}: this node exposes {have} GPU(s)')
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
@@ -159,12 +191,12 @@ def spawn_ranks(n, argv):
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')         # dmabuf IPC only on this pool (RCCL needs it)
         env.setdefault('OMP_NUM_THREADS', str(threads))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=out0 if r == 0 else subprocess.DEVNULL))
     rc = 0
     pending = list(procs)
     while pending:
-        time.sleep(0.2)
+        time.sleep(0.05)
         for p in list(pending):
             code = p.poll()
             if code is None:
@@ -175,8 +207,8 @@ def spawn_ranks(n, argv):
                 for q in pending:                                  # a rank failed: the others would wait for it forever
                     q.terminate()
     out0.seek(0)
-    sys.stdout.write(out0.read())
-    sys.stdout.flush()
+    (out or sys.stdout).write(out0.read())
+    (out or sys.stdout).flush()
     if rc != 0:
         raise SystemExit(f'a rank exited with code {rc}')
 
@@ -332,6 +364,17 @@ def side_roofline(kind, prof, prof_steps, batch):
     out = {'kernel': name, 'rocprof_names': rocprof_names(name), 'launches_per_step': dom['calls'] / prof_steps,
            'avg_launch_us': 1e3 * dom['ms'] / dom['calls'], 'us_per_step': 1e3 * dom['ms'] / prof_steps,
            'share_of_device_time': dom['ms'] / total, 'device_time_us_per_step': 1e3 * total / prof_steps}
+    for tag in ('r3', 'r2'):            # the top kernel of the committed rocprofv3 --kernel-trace --stats summary of this workload
+        try:
+            import csv
+            with open(os.path.join(ROOT, 'profiles', f'{tag}_{kind}_kernel_stats.csv')) as f:
+                top = max(csv.DictReader(f), key=lambda r: float(r['TotalDurationNs']))
+            out['rocprof_top_kernel'] = {'name': top['Name'].split('(')[0].replace('void ', ''), 'avg_launch_us': float(top['AverageNs']) / 1e3,
+                                         'share_of_kernel_time': float(top['Percentage']) / 100.0,
+                                         'source': f'profiles/{tag}_{kind}_kernel_stats.csv'}
+            break
+        except (OSError, KeyError, ValueError):
+            continue
     macs = SIDE_KERNEL_MACS.get(kind, {}).get(name)
     per_launch = SIDE_KERNEL_MACS_PER_LAUNCH.get(kind, {}).get(name)
     if per_launch:
@@ -478,16 +521,18 @@ def run_dsprites(device, args, fence, rank, world, use_dp):
     prof_steps = 10
     prof = kernel_profile(step, prof_steps)
     for name, v in prof.items():
-        macs, nbytes = KERNEL_WORK.get(name, (0, 0))
+        macs, nbytes, fixed = (KERNEL_WORK.get(name, (0, 0)) + (0,))[:3]
         v['flop'] = 2.0 * macs * b * v['calls']
-        v['bytes'] = float(nbytes) * b * v['calls']
+        v['bytes'] = (float(nbytes) * b + fixed) * v['calls']
     fence()
     if rank != 0:
         return None
 
     ms_per_step = 1e3 * med / args.steps
     value = world * b * args.steps / med
-    dom_name, dom = max(((k, v) for k, v in prof.items() if v['flop'] > 0), key=lambda kv: kv[1]['ms'])
+    # the dominant kernel = the label with the most device time among ALL labels whose algorithmic work is known
+    # (every kernel of the step above 2 % of its device time has a KERNEL_WORK entry; `unaccounted_labels` lists the rest)
+    dom_name, dom = max(((k, v) for k, v in prof.items() if v['bytes'] > 0), key=lambda kv: kv[1]['ms'])
     avg_ms = dom['ms'] / dom['calls']
     split = dom_name.startswith(('down32', 'up32', 'wgrad32')) and not os.environ.get('ARVAE_CONV32_FP32')
     mfma_peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
@@ -507,32 +552,42 @@ def run_dsprites(device, args, fence, rank, world, use_dp):
     roof['other_roof_frac'] = {'mfma': mfma_tf / mfma_peak, 'hbm_algorithmic_bytes': hbm_gbs / PEAK_HBM_GBS}
     # HBM traffic of that kernel from the PMC counters: collected in separate rocprofv3 --pmc passes of this
     # same command (FETCH_SIZE / WRITE_SIZE cannot share a pass) and committed under profiles/
-    for tag in ('r2', 'r1'):
+    step_traffic = None
+    for tag in ('r3', 'r2', 'r1'):
         try:
             with open(os.path.join(ROOT, 'profiles', f'{tag}_pmc_traffic.json')) as f:
-                roof['traffic'] = json.load(f)['kernels'][dom_name]['hbm_bytes_per_launch']
+                pmc = json.load(f)
+            roof['traffic'] = pmc['kernels'][dom_name]['hbm_bytes_per_launch']
             roof['traffic_source'] = f'profiles/{tag}_pmc_traffic.json (rocprofv3 --pmc, 2*FETCH_SIZE + WRITE_SIZE, B=512)'
+            # PMC bytes of one whole step: the file's own sum over every kernel it traced, or (older files, which list
+            # only the big kernels) the per-launch figures times this run's launches per step
+            step_traffic = pmc.get('step_hbm_bytes') or sum(
+                pmc['kernels'][k]['hbm_bytes_per_launch'] * v['calls'] / prof_steps for k, v in prof.items() if k in pmc['kernels'])
             break
         except (OSError, KeyError, ValueError):
             roof['traffic'] = None
     if b != 512:
-        roof['traffic'] = None
+        roof['traffic'] = step_traffic = None
+    roof['step_traffic_bytes'] = step_traffic
+    roof['step_algorithmic_bytes'] = BYTES_PER_IMAGE * b + PARAM_BYTES_PER_STEP
     # the same kernels in the committed rocprofv3 --kernel-trace --stats summary (launches there run back to back; the live
     # figure above brackets every launch with its own events, which costs each kernel the overlap with its neighbours' tails)
     try:
         import csv
-        with open(os.path.join(ROOT, 'profiles', 'r2_dsprites_kernel_stats.csv')) as f:
+        stats_csv = next(t for t in ('r3', 'r2') if os.path.exists(os.path.join(ROOT, 'profiles', f'{t}_dsprites_kernel_stats.csv')))
+        with open(os.path.join(ROOT, 'profiles', f'{stats_csv}_dsprites_kernel_stats.csv')) as f:
             rows = [r for r in csv.DictReader(f) if any(nm in r['Name'] for nm in (rocprof_names(dom_name) or []))]
         calls = sum(int(r['Calls']) for r in rows)
         if calls and b == 512:
             roof['rocprof_avg_launch_us'] = sum(float(r['TotalDurationNs']) for r in rows) / calls / 1e3
-            roof['rocprof_source'] = 'profiles/r2_dsprites_kernel_stats.csv'
-    except (OSError, KeyError, ValueError):
+            roof['rocprof_source'] = f'profiles/{stats_csv}_dsprites_kernel_stats.csv'
+    except (OSError, KeyError, ValueError, StopIteration):
         pass
     roof.update({'kernel': dom_name, 'rocprof_names': rocprof_names(dom_name),
                  'launches_per_step': dom['calls'] / prof_steps, 'avg_launch_us': avg_ms * 1e3,
                  'algorithmic_bytes_per_launch': dom['bytes'] / dom['calls'],
-                 'share_of_device_time': dom['ms'] / sum(v['ms'] for v in prof.values())})
+                 'share_of_device_time': dom['ms'] / sum(v['ms'] for v in prof.values()),
+                 'unaccounted_labels': sorted(k for k, v in prof.items() if v['bytes'] <= 0)})
     per_gpu = value / world
     line = {
         'metric': 'training images/sec (dSprites beta-VAE+AR, per-GPU batch 512)', 'value': value,
@@ -584,7 +639,8 @@ def main():
     ap.add_argument('--workload', default='dsprites', choices=['dsprites', 'mnist', 'measure'],
                     help='dsprites = the headline metric (default); mnist / measure = BASELINE.json configs[2] / configs[4]')
     args = ap.parse_args()
-
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # before anything touches the GPU: dmabuf IPC only on this pool
+                                                                 # (RCCL under `torch.distributed.run bench.py` needs it too)
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:             # no launcher: start the ranks (nothing has touched the GPU)
         return spawn_ranks(args.gpus, sys.argv[1:])
     world = int(os.environ.get('WORLD_SIZE', '1'))

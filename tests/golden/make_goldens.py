@@ -28,6 +28,11 @@ What is written:
   G5 mnist_step_{eval,train}.npz full step, dropout off / explicit masks
   G6 measure_step_{tf,free,eval}.npz  MeasureVAETrainer step (V=35)
   G7 attributes.npz    compute_attribute_labels                   (measure_vae_trainer.py:167-186)
+  G9 inference_{dsprites,mnist,measure}.npz   the evaluation-only entry points:
+                       compute_representations, loss_and_acc_test, compute_latent_interpolations{,2d}
+                       (image_vae_trainer.py:274-287,381-403,595-621), decode_latent_codes,
+                       compute_latent_interpolations (measure_vae_trainer.py:188-206,281-308,367-397)
+                       on synthetic loaders; make_grid / the music21 converters are replaced by pass-throughs
 """
 import os
 import sys
@@ -415,6 +420,97 @@ def gen_attributes():
     save('attributes.npz', score=score, attr=attr.numpy())
 
 
+# ----------------------------------------------------------------------------
+# G9: evaluation-only inference (N4)
+# ----------------------------------------------------------------------------
+INFER_BATCHES, INFER_BATCH = 3, 16
+
+
+def image_inference(kind, wseed, xseed, eseed):
+    import imagevae.image_vae_trainer as ivt
+    if kind == 'dsprites':
+        model, dataset, mk = DspritesVAE(), DspritesDataset(), syn.dsprites_batch
+        reg_dim = (1, 2, 3, 4, 5)
+    else:
+        model, dataset, mk = MnistVAE(), MorphoMnistDataset(), syn.mnist_batch
+        reg_dim = (1, 2, 3, 4, 5, 6)
+    load_synth_weights(model, wseed, gain=GAIN[kind])
+    trainer = ImageVAETrainer(dataset, model, lr=1e-4, reg_type=('all',), reg_dim=reg_dim, beta=1.0,
+                              gamma=10.0, capacity=0.0, rand=0, delta=1.0)
+    model.eval()
+    loader = []
+    for i in range(INFER_BATCHES):
+        x, lab = mk(INFER_BATCH, seed=xseed + i)
+        if kind == 'mnist':                          # (inputs, digit labels, morpho labels): image_vae_trainer.py:126-130
+            loader.append((t(x), torch.zeros(INFER_BATCH, dtype=torch.int64), t(lab)))
+        else:
+            loader.append((t(x), t(lab)))
+    eps = [syn.normal_noise((INFER_BATCH, model.z_dim), seed=eseed + i) for i in range(INFER_BATCHES)]
+    out = {}
+    with torch.no_grad():
+        for e in eps:
+            EPS.push(e)
+        codes, attrs, names = trainer.compute_representations(loader)
+        for e in eps:
+            EPS.push(e)
+        loss, acc = trainer.loss_and_acc_test(loader)
+        # the sweeps return make_grid(...) of the decoded probabilities: the (absent) torchvision helper only tiles
+        # images for plotting, so it is replaced by a pass-through and the fixture holds the decoded batch itself
+        keep = ivt.make_grid
+        ivt.make_grid = lambda tensor, **kw: tensor
+        try:
+            row = trainer.compute_latent_interpolations(codes[3], dim1=2, num_points=5)
+            grid = trainer.compute_latent_interpolations2d(codes[5], dim1=1, dim2=4, num_points=3)
+        finally:
+            ivt.make_grid = keep
+    assert not EPS.queue
+    g2 = grid.numpy().reshape(grid.shape[0], -1)          # 9 images: every 4th pixel + per-image sums keep the file small
+    out.update(codes=codes, attrs=attrs, names=np.array(names), test_loss=float(loss), test_acc=float(acc),
+               row=row.numpy(), grid_samp=g2[:, ::4].copy(), grid_sum=g2.astype(np.float64).sum(1))
+    return out
+
+
+def measure_inference(wseed, sseed, eseed):
+    ds = folk_dataset()
+    ds.beat_subdivisions, ds.seq_size_in_beats = 6, 4
+    ds.tensor_to_m21score = lambda tensor_score: None          # music21 rendering: not on the path
+    ds.concatenate_scores = lambda scores: None
+    model = MeasureVAE(dataset=ds, note_embedding_dim=10, metadata_embedding_dim=2,
+                       num_encoder_layers=2, encoder_hidden_size=128, encoder_dropout_prob=0.5,
+                       latent_space_dim=32, num_decoder_layers=2, decoder_hidden_size=128,
+                       decoder_dropout_prob=0.5, has_metadata=False, dataset_type='folk')
+    load_synth_weights(model, wseed)
+    with torch.no_grad():
+        model.decoder.tick_emb_to_note_emb[0].bias.add_(0.5)
+        model.decoder.tick_emb_to_note_emb[0].weight.mul_(3.0)
+    trainer = MeasureVAETrainer(ds, model, lr=1e-4, reg_type=('all',), reg_dim=(0, 1, 2, 3),
+                                beta=0.001, gamma=1.0, capacity=0.0, rand=0, delta=10.0)
+    model.eval()
+    loader = []
+    for i in range(INFER_BATCHES):
+        sc = t(syn.measure_batch(INFER_BATCH, seed=sseed + i))
+        loader.append((sc, sc))
+    eps = [syn.normal_noise((INFER_BATCH, 32), seed=eseed + i) for i in range(INFER_BATCHES)]
+    with torch.no_grad():
+        for e in eps:
+            EPS.push(e)
+        codes, attrs, names = trainer.compute_representations(loader)
+        for e in eps:
+            EPS.push(e)
+        loss, acc = trainer.loss_and_acc_test(loader)
+        _, notes = trainer.decode_latent_codes(t(codes[:8]))
+        _, sweep = trainer.compute_latent_interpolations(codes[3], None, dim1=3, num_points=5)
+    assert not EPS.queue
+    return dict(codes=codes, attrs=attrs, names=np.array(names), test_loss=float(loss), test_acc=float(acc),
+                notes=notes.numpy(), sweep=sweep.numpy())
+
+
+def gen_inference():
+    save('inference_dsprites.npz', **image_inference('dsprites', wseed=1, xseed=600, eseed=40))
+    save('inference_mnist.npz', **image_inference('mnist', wseed=3, xseed=700, eseed=50))
+    save('inference_measure.npz', **measure_inference(wseed=4, sseed=800, eseed=60))
+
+
 if __name__ == '__main__':
     gen_reg_loss()
     gen_latent_head()
@@ -422,3 +518,4 @@ if __name__ == '__main__':
     gen_image_steps()
     gen_measure_steps()
     gen_attributes()
+    gen_inference()

@@ -1015,11 +1015,14 @@ def test_mnist_step_at_baseline_batch_1024_vs_oracle(dev):
     close(outs['mu'], ref['terms']['mu'], rtol=0, atol=1e-4)
 
 
+@pytest.mark.parametrize('dropout', [0.0, 0.5], ids=['p0', 'p0.5'])
 @pytest.mark.parametrize('teacher', [True, False], ids=['teacher_forced', 'free_running'])
-def test_measure_step_at_baseline_batch_256_vs_oracle(dev, teacher):
+def test_measure_step_at_baseline_batch_256_vs_oracle(dev, teacher, dropout):
     """BASELINE.json configs[4]: MeasureVAE (H = 128, Z = 32, V = 35) training step at batch 256, forward AND backward,
     teacher-forced and free-running; the sampled notes must equal the oracle's (the output layer is given a positive top-1
-    margin as in the golden cases, SURVEY.md section 7 'top-1 tie-breaking')."""
+    margin as in the golden cases, SURVEY.md section 7 'top-1 tie-breaking').  dropout 0.5 is the configuration bench.py
+    times: the three inter-layer keep-masks (encoder layer 0 outputs, beat / tick layer-0 hidden states) are explicit and
+    go through oracle.measure_vae.forward(..., masks=...) and the HIP path's mask queues alike."""
     from arvae_amd.measure_vae import MeasureVAE
     from arvae_amd.measure_vae_trainer import MeasureVAETrainer
     from oracle import attributes as o_attr
@@ -1031,23 +1034,34 @@ def test_measure_step_at_baseline_batch_256_vs_oracle(dev, teacher):
     score = syn.measure_batch(b, seed=5)
     eps = syn.normal_noise((b, 32), seed=1)
     ds = _FolkDataset()
-    model = MeasureVAE(ds, 10, 2, 2, 128, 0.0, 32, 2, 128, 0.0, False, 'folk')
+    model = MeasureVAE(ds, 10, 2, 2, 128, dropout, 32, 2, 128, dropout, False, 'folk')
     model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
     trainer = MeasureVAETrainer(ds, model, lr=1e-4, reg_type=('all',), reg_dim=(0, 1, 2, 3), beta=0.001, gamma=1.0,
                                 capacity=0.0, rand=0, delta=10.0)
     trainer.cuda()
     model.train()
     model.decoder.teacher_forcing_prob = 2.0 if teacher else -1.0
-    model.push_noise(torch.from_numpy(eps))
+    masks = None
+    if dropout > 0:                     # oracle layout (B, T, H); the HIP queues take (T, B, H) uint8
+        m_enc, m_beat, m_tick = syn.dropout_masks([(b, 24, 256), (b, 4, 128), (b, 24, 128)], 31, dropout)
+        masks = dict(enc=torch.from_numpy(m_enc), beat=torch.from_numpy(m_beat), tick=torch.from_numpy(m_tick))
+
+    def push():
+        model.push_noise(torch.from_numpy(eps))
+        if masks is not None:
+            model.encoder.push_dropout_mask(masks['enc'].transpose(0, 1).contiguous().to(dev))
+            model.decoder.push_dropout_masks(masks['beat'].transpose(0, 1).contiguous().to(dev),
+                                             masks['tick'].transpose(0, 1).contiguous().to(dev))
     st = torch.from_numpy(score).to(dev)
     trainer.zero_grad()
+    push()
     weights, samples, z_dist, _, z, _ = model(st, st, train=True)
-    model.push_noise(torch.from_numpy(eps))
+    push()
     loss, acc = trainer.loss_and_acc_for_batch((st, st), 0, 0, True)
     loss.backward()
     grads = {k: p.grad.detach().cpu().numpy().copy() for k, p in model.named_parameters()}
     attr = o_attr.attribute_labels(score, *syn.measure_tables())
-    ref = o_step.measure_step(state, score, eps, attr, (0, 1, 2, 3), 0.001, 1.0, 10.0, teacher)
+    ref = o_step.measure_step(state, score, eps, attr, (0, 1, 2, 3), 0.001, 1.0, 10.0, teacher, masks=masks)
     np.testing.assert_array_equal(samples.cpu().numpy(), ref['terms']['samples'])
     close(z, ref['terms']['z'], rtol=0, atol=1e-4)
     close(z_dist.loc, ref['terms']['mu'], rtol=0, atol=1e-4)
@@ -1178,6 +1192,30 @@ def test_philox_draws_vs_oracle(dev):
     np.testing.assert_array_equal(mask.cpu().numpy(), philox.keep_mask(n, 0.75, seed, offset=2))
 
 
+def test_device_draws_follow_the_data_parallel_rank(dev):
+    """the stream ops.normal_noise / ops.keep_mask draw from is keyed by (torch seed, data-parallel rank): rank 0 = the
+    single-process stream, rank 1 = the oracle's Philox under the salted key; a re-seed restarts the draw counter."""
+    from arvae_amd import ops
+    from oracle import philox
+    try:
+        draws = {}
+        for rank in (0, 1):
+            ops.rng_reseed(99)
+            ops.RngState.dev_step = None
+            ops.rng_set_rank(rank)
+            eps = ops.normal_noise((64, 10), dev).cpu().numpy().ravel()
+            mask = ops.keep_mask((24, 64, 128), 0.5, dev).cpu().numpy().ravel()
+            key = (99 + rank * ops.RANK_SALT) & 0xFFFFFFFFFFFFFFFF
+            assert ops.rng_seed() == key and ops.RngState.offset == 2
+            close(eps, philox.normal(640, key, offset=0), rtol=2e-5, atol=2e-6)
+            np.testing.assert_array_equal(mask, philox.keep_mask(mask.size, 0.5, key, offset=1))
+            draws[rank] = (eps, mask)
+        assert np.abs(draws[0][0] - draws[1][0]).max() > 0.5
+        assert 0.4 < (draws[0][1] != draws[1][1]).mean() < 0.6
+    finally:
+        ops.rng_set_rank(0)
+
+
 def test_fused_step_draws_its_own_noise(dev):
     """without pushed noise the fused dSprites step draws eps inside the heads kernel: z = mu + eps * sigma with the eps
     the oracle's Philox gives for (torch seed, this draw's offset), fresh on every step, reproducible under the same seed."""
@@ -1299,3 +1337,168 @@ def test_latent_block_experiment_matches_the_per_layer_path(dev):
             close(res[flag][kind]['loss'], res['0'][kind]['loss'], rtol=1e-6)
             for k, v in res['0'][kind]['gn'].items():
                 close(res[flag][kind]['gn'][k], v, rtol=1e-4, atol=1e-9)
+
+
+# ---------------------------------------------------------------- the epoch loop itself (Trainer.train_model) vs the oracle's trajectory
+class _ListLoaders:
+    """a dataset whose data_loaders() hands out fixed lists of batches (train, validation, test)"""
+
+    def __init__(self, train, val):
+        self.train, self.val = train, val
+
+    def data_loaders(self, batch_size, split=(0.70, 0.20), **_):
+        return self.train, self.val, self.val
+
+
+def test_image_train_model_two_epochs_track_the_oracle(dev, tmp_path, monkeypatch):
+    """utils/trainer.py:39-154 through the build's own epoch loop: train_model for 2 epochs x 3 batches (+ one validation
+    batch per epoch, which must not move the weights) ends on the weights of the oracle's six chained steps (atol 1e-5),
+    and the per-epoch mean training loss it computes on the device is the mean of the oracle's step losses."""
+    from arvae_amd.image_vae import DspritesVAE
+    from arvae_amd.image_vae_trainer import ImageVAETrainer
+    monkeypatch.setenv('ARVAE_MODEL_DIR', str(tmp_path))
+
+    class DspritesDataset(_ListLoaders):
+        pass
+    b = 16
+    state = syn.synth_state(o_vae.DSPRITES_SHAPES, 5, 1.6)
+    train = [syn.dsprites_batch(b, seed=300 + i) for i in range(3)]
+    val = [syn.dsprites_batch(b, seed=310)]
+    eps_t = [syn.normal_noise((b, 10), seed=320 + i) for i in range(6)]
+    eps_v = [syn.normal_noise((b, 10), seed=330 + i) for i in range(2)]
+    to_t = lambda xs: [(torch.from_numpy(x), torch.from_numpy(lab)) for x, lab in xs]
+    model = DspritesVAE()
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    trainer = ImageVAETrainer(DspritesDataset(to_t(train), to_t(val)), model, lr=1e-4, reg_type=('all',),
+                              reg_dim=(1, 2, 3, 4, 5), beta=4.0, gamma=10.0, capacity=0.0, rand=0, delta=1.0)
+    trainer.cuda()
+    for epoch in range(2):                      # the order the loop draws: three training steps, then the validation batch
+        for e in eps_t[3 * epoch:3 * epoch + 3] + [eps_v[epoch]]:
+            model.push_noise(torch.from_numpy(e))
+    means = []
+    keep = trainer.print_epoch_stats
+    trainer.print_epoch_stats = lambda *a: (means.append(a[2:]), keep(*a))[1]
+    trainer.train_model(batch_size=b, num_epochs=2, log=False)
+    assert not model._eps_queue and os.path.exists(model.filepath)
+    cur, adam, losses_ref = state, None, []
+    for k in range(6):
+        x, lab = train[k % 3]
+        ref = o_step.image_step('dsprites', cur, x, lab, eps_t[k], (1, 2, 3, 4, 5), 4.0, 10.0, 1.0, adam_state=adam,
+                                step_no=k + 1)
+        cur, adam = ref['params'], ref['adam']
+        losses_ref.append(ref['terms']['loss'])
+    for name, p in model.named_parameters():
+        close(p, cur[name], rtol=0, atol=1e-5)
+    assert len(means) == 2
+    for epoch in range(2):
+        close(means[epoch][0], np.mean(losses_ref[3 * epoch:3 * epoch + 3]), rtol=1e-4)
+    # the validation pass used the weights after the epoch's last step and did not touch them
+    ref_val = o_step.image_step('dsprites', cur, *val[0], eps_v[1], (1, 2, 3, 4, 5), 4.0, 10.0, 1.0)
+    close(means[1][2], ref_val['terms']['loss'], rtol=1e-4)
+    saved = torch.load(model.filepath, map_location='cpu')
+    for name in state:
+        close(saved[name], cur[name], rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize('replay', [False, True], ids=['eager', 'graph_replay'])
+def test_measure_train_model_two_epochs_track_the_oracle(dev, tmp_path, monkeypatch, replay):
+    """the same for MeasureVAETrainer, whose epoch loop replays its steps from HIP graphs by default: 2 epochs x 3 batches,
+    eager and replayed, against the oracle's six chained steps (teacher-forced, no dropout; the noise of step k reaches
+    the captured graph through a device buffer the loader refreshes before handing out batch k)."""
+    from arvae_amd.measure_vae import MeasureVAE
+    from arvae_amd.measure_vae_trainer import MeasureVAETrainer
+    from oracle import attributes as o_attr
+    from oracle import measure_vae as o_mvae
+    monkeypatch.setenv('ARVAE_MODEL_DIR', str(tmp_path))
+    b = 32
+    state = syn.synth_state(o_mvae.shapes(), 4)
+    scores = [syn.measure_batch(b, seed=400 + i) for i in range(3)]
+    val = syn.measure_batch(b, seed=410)
+    eps_t = [syn.normal_noise((b, 32), seed=420 + i) for i in range(6)]
+    static = torch.zeros(b, 32, device=dev)
+
+    class _Loader:
+        """hands out the batches and, just before each, moves that step's noise into the static device buffer"""
+
+        def __init__(self, batches, noise, counter):
+            self.batches, self.noise, self.counter = batches, noise, counter
+
+        def __len__(self):
+            return len(self.batches)
+
+        def __iter__(self):
+            for s in self.batches:
+                if self.noise is not None:
+                    static.copy_(torch.from_numpy(self.noise[self.counter[0]]))
+                    self.counter[0] += 1
+                yield torch.from_numpy(s), torch.from_numpy(s)
+
+    class FolkData(_FolkDataset):
+        def data_loaders(self, batch_size, split=(0.70, 0.20), **_):
+            return self.loaders
+
+    ds = FolkData()
+    counter = [0]
+    ds.loaders = (_Loader(scores, eps_t, counter), _Loader([val], None, counter), None)
+    model = MeasureVAE(ds, 10, 2, 2, 128, 0.0, 32, 2, 128, 0.0, False, 'folk')
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    trainer = MeasureVAETrainer(ds, model, lr=1e-4, reg_type=('all',), reg_dim=(0, 1, 2, 3), beta=0.001, gamma=1.0,
+                                capacity=0.0, rand=0, delta=10.0)
+    trainer.use_graph_replay = replay
+    trainer.cuda()
+    model.decoder.teacher_forcing_prob = 2.0
+    means = []
+    keep = trainer.print_epoch_stats
+    trainer.print_epoch_stats = lambda *a: (means.append(a[2:]), keep(*a))[1]
+    try:
+        model.encoder.static_eps = static
+        trainer.train_model(batch_size=b, num_epochs=2, log=False)
+    finally:
+        type(model.encoder).static_eps = None
+        model.encoder.static_eps = None
+    assert counter[0] == 6
+    if replay:
+        assert getattr(trainer, '_graphed', None) is not None and trainer.use_graph_replay, 'the steps were not replayed'
+    cur, adam, losses_ref = state, None, []
+    tables = syn.measure_tables()
+    for k in range(6):
+        sc = scores[k % 3]
+        attr = o_attr.attribute_labels(sc, *tables)
+        ref = o_step.measure_step(cur, sc, eps_t[k], attr, (0, 1, 2, 3), 0.001, 1.0, 10.0, True, adam_state=adam,
+                                  step_no=k + 1)
+        cur, adam = ref['params'], ref['adam']
+        losses_ref.append(ref['terms']['loss'])
+    for name, p in model.named_parameters():
+        close(p, cur[name], rtol=0, atol=1e-5)
+    for epoch in range(2):
+        close(means[epoch][0], np.mean(losses_ref[3 * epoch:3 * epoch + 3]), rtol=1e-4)
+
+
+# ---------------------------------------------------------------- what the 2e-3 gradient tolerance hides: an error budget in float64
+def test_gradient_error_budget_vs_float64(dev):
+    """The step tests above allow whole-tensor relative L2 2e-3 against the fp32 CPU oracle, because a ReLU whose
+    pre-activation is ~0 may land on the other side in another fp32 summation order.  This test measures instead of assuming:
+    the oracle's own step is run in float64 and in float32 on the same tensors, and per gradient tensor the HIP path's
+    distance to the float64 result must stay within 2x the fp32 CPU path's distance to it (+ a 2e-6 floor for tensors the
+    CPU happens to get almost exactly) -- a genuine 1e-3 kernel error would fail here while flipped units, which hit both
+    fp32 paths alike, do not."""
+    b = 64
+    state = syn.synth_state(o_vae.DSPRITES_SHAPES, 1, 1.6)
+    x, lab = syn.dsprites_batch(b, seed=1234)
+    eps = syn.normal_noise((b, 10), seed=12)
+    got = run_hip_image_step(dev, 'dsprites', state, x, lab, eps, 4.0, 0.0, 'bernoulli', None)
+    ref32 = o_step.image_step('dsprites', state, x, lab, eps, (1, 2, 3, 4, 5), 4.0, 10.0, 1.0)
+    st64 = {k: v.astype(np.float64) for k, v in state.items()}
+    ref64 = o_step.image_step('dsprites', st64, x.astype(np.float64), lab.astype(np.float64), eps.astype(np.float64),
+                              (1, 2, 3, 4, 5), 4.0, 10.0, 1.0)
+    worst = 0.0
+    for name in state:
+        want = ref64['grads'][name].ravel()
+        scale = np.linalg.norm(want) + 1e-30
+        e_hip = np.linalg.norm(got['grads'][name].astype(np.float64).ravel() - want) / scale
+        e_cpu = np.linalg.norm(ref32['grads'][name].astype(np.float64).ravel() - want) / scale
+        worst = max(worst, e_hip / max(e_cpu, 1e-12))
+        assert e_hip <= 2.0 * e_cpu + 2e-6, (name, e_hip, e_cpu)
+    for k in ('recons', 'dist', 'reg', 'loss'):
+        close(got['loss'] if k == 'loss' else got['terms'][k], ref64['terms'][k], rtol=1e-5)
+    print(f'worst HIP / fp32-CPU error ratio vs float64: {worst:.2f}')

@@ -185,6 +185,62 @@ def test_attribute_labels(golden_dir):
     assert attr[2, 2] == 1.0 and attr[2, 0] == 0.0     # all `None`: density counts them, rhythm does not
 
 
+# ---------------------------------------------------------------- G9: evaluation-only inference (N4)
+INFER = {'dsprites': dict(wseed=1, gain=1.6, xseed=600, eseed=40, mk=syn.dsprites_batch),
+         'mnist': dict(wseed=3, gain=0.7, xseed=700, eseed=50, mk=syn.mnist_batch)}
+
+
+def image_inference_inputs(kind):
+    """the synthetic loader make_goldens.py::image_inference ran the reference on (3 batches of 16)."""
+    c = INFER[kind]
+    state = syn.synth_state(image_vae.SHAPES[kind], c['wseed'], c['gain'])
+    batches = [c['mk'](16, seed=c['xseed'] + i) for i in range(3)]
+    eps = [syn.normal_noise((16, image_vae.Z_DIM[kind]), seed=c['eseed'] + i) for i in range(3)]
+    return state, batches, eps
+
+
+def measure_inference_inputs():
+    state = measure_state(4)
+    scores = [syn.measure_batch(16, seed=800 + i) for i in range(3)]
+    eps = [syn.normal_noise((16, 32), seed=60 + i) for i in range(3)]
+    return state, scores, eps
+
+
+@pytest.mark.parametrize('kind', ['dsprites', 'mnist'])
+def test_image_inference_entry_points(golden_dir, kind):
+    from oracle import inference
+    g = G(golden_dir, f'inference_{kind}.npz')
+    state, batches, eps = image_inference_inputs(kind)
+    codes, attrs, names = inference.image_representations(kind, state, batches, eps)
+    close(codes, g['codes'], rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(attrs, g['attrs'])
+    assert list(names) == [str(n) for n in g['names']]
+    loss, acc = inference.image_test_loss(kind, state, batches, eps)
+    close(loss, g['test_loss'], rtol=1e-5)
+    close(acc, g['test_acc'], rtol=1e-6)
+    row = inference.image_interpolations(kind, state, g['codes'][3], 2, 5)
+    close(row, g['row'], rtol=1e-4, atol=1e-6)
+    grid = inference.image_interpolations2d(kind, state, g['codes'][5], 1, 4, 3).reshape(9, -1)
+    close(grid[:, ::4], g['grid_samp'], rtol=1e-4, atol=1e-6)
+    close(grid.astype(np.float64).sum(1), g['grid_sum'], rtol=1e-5)
+
+
+def test_measure_inference_entry_points(golden_dir):
+    from oracle import inference
+    g = G(golden_dir, 'inference_measure.npz')
+    state, scores, eps = measure_inference_inputs()
+    codes, attrs, names = inference.measure_representations(state, scores, eps, syn.measure_tables())
+    close(codes, g['codes'], rtol=1e-5, atol=1e-5)
+    close(attrs, g['attrs'], rtol=1e-6, atol=1e-7)
+    assert list(names) == [str(n) for n in g['names']]
+    loss, acc = inference.measure_test_loss(state, scores, eps)
+    close(loss, g['test_loss'], rtol=1e-5)
+    close(acc, g['test_acc'], rtol=1e-6)
+    np.testing.assert_array_equal(inference.measure_decode(state, g['codes'][:8]), g['notes'])
+    np.testing.assert_array_equal(inference.measure_interpolations(state, g['codes'][3], 3, 5), g['sweep'])
+    assert len(np.unique(g['sweep'])) > 2 and len(np.unique(g['notes'])) > 3      # non-trivial decodes
+
+
 # ---------------------------------------------------------------- Philox4x32-10 (device RNG of eps / dropout masks)
 def test_philox_known_answers():
     """oracle/philox.py against the known-answer vectors of the Random123 distribution (kat_vectors: philox4x32, 10 rounds)"""

@@ -98,3 +98,43 @@ def test_two_rank_step_equals_single_process(tmp_path, world, capacity):
     # all_gather_into_tensor is rank-major: rows of rank 0 first
     bl = b_total // world
     assert (got['gathered'][:bl] == 0).all() and (got['gathered'][bl:] == 1).all()
+
+
+def _rng_worker(rank, world, port, out_path):
+    import sys
+    sys.path.insert(0, ROOT)
+    from arvae_amd import ops
+    from arvae_amd.parallel import DataParallel
+    from oracle import philox
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        ops.rng_reseed(7)                                       # every rank seeds alike, as the trainers' constructors do
+        DataParallel(reg_fn=lambda *a, **k: None)
+        seed = ops.rng_seed()
+        eps = torch.from_numpy(philox.normal(640, seed, offset=ops.rng_next_offset()))
+        mask = torch.from_numpy(philox.keep_mask(640, 0.5, seed, offset=ops.rng_next_offset()).astype(np.float32))
+        rows = [torch.zeros(2, 640) for _ in range(world)]
+        dist.all_gather(rows, torch.stack([eps, mask]))
+        seeds = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(seeds, torch.tensor([seed & 0x7FFFFFFFFFFFFFFF]))
+        if rank == 0:
+            np.savez(out_path, rows=torch.stack(rows).numpy(), seeds=torch.cat(seeds).numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_draw_different_noise_and_masks(tmp_path):
+    """advisor finding, round 2: all ranks seed torch alike (torch.manual_seed(rand)), so the library's Philox key must carry
+    the rank or a global batch of W*B rows holds only B distinct eps / keep-mask rows.  Two gloo ranks select their stream
+    as a data-parallel run does and draw (with the oracle's restatement of the device generator, keyed by ops.rng_seed()):
+    rank 0 keeps the single-process stream, rank 1 draws something else."""
+    from oracle import philox
+    out = str(tmp_path / 'rng.npz')
+    mp.spawn(_rng_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    assert got['seeds'][0] == 7 and got['seeds'][1] != 7
+    np.testing.assert_array_equal(got['rows'][0, 0], philox.normal(640, 7, offset=0))
+    assert np.abs(got['rows'][0, 0] - got['rows'][1, 0]).max() > 0.5              # eps differ
+    assert 0.3 < (got['rows'][0, 1] != got['rows'][1, 1]).mean() < 0.7            # keep-masks differ like independent coins

@@ -53,11 +53,16 @@ def main():
     for k in sorted(set(fetch) | set(write)):
         f, nf = fetch.get(k, (0.0, 0))
         w, _ = write.get(k, (0.0, 0))
-        if not k.startswith(('down', 'up', 'wgrad', 'pair', 'slab', 'dense', 'heads', 'vae', 'reg', 'adam')):
-            continue
         out['kernels'][k] = {'launches_sampled': nf, 'FETCH_SIZE_KB_per_launch': round(f, 1),
                              'WRITE_SIZE_KB_per_launch': round(w, 1), 'hbm_bytes_per_launch': int((2 * f + w) * 1024)}
+    # every kernel of the traced process is listed (torch fills included); a training step = one adam_kernel launch
+    steps = max(1, out['kernels'].get('adam_kernel', {}).get('launches_sampled', 1))
+    for v in out['kernels'].values():
+        v['launches_per_step'] = round(v['launches_sampled'] / steps, 3)
+    out['steps_traced'] = steps
+    out['step_hbm_bytes'] = int(sum(v['hbm_bytes_per_launch'] * v['launches_sampled'] for v in out['kernels'].values()) / steps)
     json.dump(out, open(sys.argv[3], 'w'), indent=1)
+    print(f"HBM bytes per training step (all kernels): {out['step_hbm_bytes'] / 1e6:.1f} MB over {steps} steps")
     for k, v in sorted(out['kernels'].items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'])[:12]:
         print(f"{k:28s} {v['hbm_bytes_per_launch'] / 1e6:8.1f} MB/launch")
 

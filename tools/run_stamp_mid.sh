@@ -1,7 +1,7 @@
 #!/bin/bash
 # phase stamps of the latent block's forward launch (diagnostic library tools/bin/lib_midst.so: midblock.hip built with -DMID_STAMPS)
+set -euo pipefail
 cd "$(dirname "$0")/.."
-cp ar-vae_amd/libarvae_hip.so /tmp/lib_keep.so
-cp tools/bin/lib_midst.so ar-vae_amd/libarvae_hip.so
+test -f tools/bin/lib_midst.so || { echo "tools/bin/lib_midst.so is missing: build the diagnostic library first (tools/README.md)" >&2; exit 1; }
+export ARVAE_LIB=$PWD/tools/bin/lib_midst.so          # _lib.py loads this build instead of the product library
 python tools/stamp_mid.py 2>/dev/null
-cp /tmp/lib_keep.so ar-vae_amd/libarvae_hip.so

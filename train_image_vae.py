@@ -70,20 +70,31 @@ def main(dataset_type, batch_size, num_epochs, lr, beta, capacity, gamma, delta,
     from arvae_amd.parallel import init_from_env
     dp = init_from_env() if train else None
     chief = dp is None or dp.rank == 0
-    for seed in seeds:
+
+    def build(seed):
         model = MnistVAE() if dataset_type == 'mnist' else DspritesVAE()
         trainer = ImageVAETrainer(dataset=dataset, model=model, lr=lr, reg_type=reg_type, reg_dim=reg_dim, beta=beta,
                                   capacity=capacity, gamma=gamma, delta=delta, dec_dist=dec_dist, rand=seed)
-        if train:
-            if not torch.cuda.is_available():
-                raise SystemExit('training needs a GPU: the AR-VAE path has no CPU fallback')
+        return model, trainer
+
+    # every rank trains every seed first; rank 0 evaluates afterwards, once the process group is gone -- a rank that waits in
+    # a pending RCCL collective while rank 0 evaluates would be killed by the group's watchdog timeout (advisor, round 2)
+    if train:
+        if not torch.cuda.is_available():
+            raise SystemExit('training needs a GPU: the AR-VAE path has no CPU fallback')
+        for seed in seeds:
+            model, trainer = build(seed)
             trainer.cuda()
             if dp is not None:
                 dp.attach(trainer)
             trainer.train_model(batch_size=batch_size, num_epochs=num_epochs, log=log)
             trainer.data_parallel = None
-        if not chief:
-            continue
+        if dp is not None:
+            dp.finish()
+    if not chief:
+        return
+    for seed in seeds:
+        model, trainer = build(seed)
         trainer.load_model()
         trainer.writer = None
         eval_bs = min(128, batch_size)                  # the reference evaluates with 128; smaller runs keep their own size
