@@ -211,6 +211,11 @@ static int make_layout(const arvae_image_vae_t *m, int64_t n, int64_t n_cols, La
     return ARVAE_OK;
 }
 
+// milestones (include/arvae_hip.h): record the caller's event on the pass's stream
+static inline void mark(void *event, hipStream_t st) {
+    if (event != nullptr) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(event), st);
+}
+
 static arvae_operand_t plain(const float *v) { return arvae_operand_t{v, nullptr, nullptr, ARVAE_ACT_NONE}; }
 
 static int layer_forward(const arvae_layer_t &l, int32_t n, const float *params, const float *in, const uint8_t *mask,
@@ -456,6 +461,7 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
         if (int rc = layer_forward(m->head_log_std, batch, params, h, nullptr, ws + L.log_std, nullptr, ws + L.link_ws, stream)) return rc;
         if (int rc = arvae_latent_fwd(mu, ws + L.log_std, eps, bz, sigma, z, stream)) return rc;
     }
+    if (m->milestones != nullptr) mark(m->milestones->z_ready, st);   // mu / sigma / z are final: the caller's all-gather may start
     // decoder
     if (!mid) h = heads_next ? ws + L.dec_out[0] : z;
     int nb = 0;
@@ -610,6 +616,15 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
         pre = gated;
         if (heads_next_g == nullptr) cur = dst;
     }
+    // data-parallel caller: finish the decoder's conv gradients now (their all-reduce then runs under the rest of the pass)
+    const arvae_milestones *ms = m->milestones;
+    bool dec_marked = false, lin_marked = false;
+    if (ms != nullptr && ms->dec_grads != nullptr && side == nullptr && defer.count == 0) {
+        // (defer.count == 0: no Linear layer of the decoder went the per-layer way, so "decoder conv layers" is what is queued)
+        if (int rc = slab_reduce_flush(&rdefer, st)) return rc;
+        mark(ms->dec_grads, st);
+        dec_marked = true;
+    }
     // latent head (cur = gradient w.r.t. z from the decoder) and the two encoder heads:
     // d_hidden = W_mu^T d_mu + W_ls^T d_ls   (gated by the last encoder layer's ReLU when possible)
     const float *hidden = ws + L.enc_out[m->n_enc - 1];
@@ -656,6 +671,11 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
         cur = d_x0;
         pre = gate0 != nullptr;
         enc_from = e0 - 1;
+        if (ms != nullptr && ms->linear_grads != nullptr && side == nullptr) {   // every Linear weight gradient is queued
+            if (int rc = dense_wgrad_flush(&defer, st)) return rc;
+            mark(ms->linear_grads, st);
+            lin_marked = true;
+        }
     } else if (heads_fusable(&m->head_mu, &m->head_log_std, m->zdim)) {
         if (int rc = heads_latent_bwd(&m->head_mu, &m->head_log_std, batch, m->zdim, params, heads_next_g != nullptr ? nullptr : cur,
                                       dz_reg, dz_extra, mu, sigma, eps, g_loss, ws + L.kld_out + 1, capacity, m->beta, reg_scale,
@@ -730,6 +750,7 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
         (void)hipEventRecord(tail->join, tail->s);
         if (int rc = slab_reduce_flush(&rdefer, st)) return rc;
         (void)hipStreamWaitEvent(st, tail->join, 0);
+        if (m->milestones != nullptr) { mark(m->milestones->dec_grads, st); mark(m->milestones->linear_grads, st); }
         return ARVAE_OK;
     }
     if (int rc = slab_reduce_flush(&rdefer, flush_stream)) return rc;
@@ -737,6 +758,10 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
     if (side != nullptr) {                               // join: the caller's stream continues after the helper's work
         (void)hipEventRecord(side->join, side->s);
         (void)hipStreamWaitEvent(st, side->join, 0);
+    }
+    if (ms != nullptr) {                                 // milestones with no earlier point: everything is final here
+        if (!dec_marked) mark(ms->dec_grads, st);
+        if (!lin_marked) mark(ms->linear_grads, st);
     }
     return ARVAE_OK;
 }

@@ -28,6 +28,29 @@ def _async_label_gather(dp):
     return forced == '1' if forced in ('0', '1') else dp.world_size > 1
 
 
+# Data-parallel overlap: the executors record events where z / the decoder's conv gradients / the
+# Linear gradients are final (arvae_image_vae_t.milestones), and the collectives that need them are enqueued on a side
+# stream behind those events, so they run under the rest of the pass.  ARVAE_DP_OVERLAP=0: everything on the launch stream,
+# one all-reduce of the whole arena after backward (the round-2 schedule).
+def _dp_overlap():
+    return os.environ.get('ARVAE_DP_OVERLAP', '1') != '0'
+
+
+class _Overlap:
+    """the side stream, the three milestone events and their C descriptor for one device"""
+
+    def __init__(self, device):
+        self.stream = torch.cuda.Stream(device=device)
+        self.events = [torch.cuda.Event() for _ in range(3)]
+        for e in self.events:                        # torch creates the HIP event on its first record
+            e.record(torch.cuda.current_stream(device))
+        self.z_ready, self.dec_grads, self.linear_grads = self.events
+        self.struct = _lib.Milestones(*[ctypes.c_void_p(e.cuda_event) for e in self.events])
+
+    def pointer(self):
+        return ctypes.cast(ctypes.pointer(self.struct), ctypes.c_void_p)
+
+
 def _layer_desc(link, is_up, act, dropout, w_off, b_off):
     return LayerDesc(link.desc(0), int(is_up), int(act), int(dropout), 0, int(w_off), int(b_off))
 
@@ -44,6 +67,42 @@ class FusedImageVAE:
         self._arena_ptr = None
         self._ws = {}
         self._ws_owner = None
+        self._overlap = None
+        self._buckets = None
+
+    def overlap(self, device):
+        if self._overlap is None:
+            self._overlap = _Overlap(device)
+        return self._overlap
+
+    def grad_buckets(self):
+        """float ranges of the gradient arena that become final together: -> (decoder conv layers, Linear layers + heads,
+        [the rest]) or None when the arena is not laid out in three contiguous runs (then one all-reduce at the end)."""
+        if self._buckets is not None:
+            return self._buckets or None
+        m, opt = self.model, self.optimizer
+        opt.ensure_arena()
+        size = {id(p): (p.numel() + 3) // 4 * 4 for p in opt.params}
+        off = {id(p): o for p, o in zip(opt.params, opt._offsets)}
+
+        def span(params):
+            lo = min(off[id(p)] for p in params)
+            hi = max(off[id(p)] + size[id(p)] for p in params)
+            return (lo, hi) if hi - lo == sum(size[id(p)] for p in params) else None
+
+        def params_of(layers):
+            return [p for lay in layers for p in (lay.weight, lay.bias) if p is not None]
+        dec = span(params_of([m.dec_conv[i] for i, _ in m.dec_conv_plan]))
+        lin = span(params_of([m.enc_lin[i] for i, _ in m.enc_lin_plan] + [m.enc_mean, m.enc_log_std] +
+                             [m.dec_lin[i] for i, _ in m.dec_lin_plan]))
+        total = opt.grad_arena.numel()
+        if dec is None or lin is None or not (lin[1] <= dec[0] or dec[1] <= lin[0]):
+            self._buckets = ()
+            return None
+        cuts = sorted([dec, lin])
+        rest = [(a, b) for a, b in zip([0] + [c[1] for c in cuts], [c[0] for c in cuts] + [total]) if b > a]
+        self._buckets = (dec, lin, rest)
+        return self._buckets
 
     def _offset(self, param):
         opt = self.optimizer
@@ -161,6 +220,9 @@ class _FusedStepFn(Function):
         logits = torch.empty_like(x)
         marr, keep = _mask_array(masks)
         rowblock = dp is not None and len(fused.reg_dims) > 0
+        ov = fused.overlap(dev) if (dp is not None and _dp_overlap()) else None
+        desc.milestones = ov.pointer() if ov is not None else None
+        ctx.overlap = ov
         if rowblock:                                             # the label columns do not depend on this pass: gather first
             external_reg = True
             labels = labels.contiguous()
@@ -181,7 +243,16 @@ class _FusedStepFn(Function):
             scalars[DIST:DIST + 1].copy_(dist_g)
             capacity = cap_r
         if rowblock:
-            z_all = dp.gather_columns(z)
+            if ov is not None:
+                # z is final long before the pass ends (the decoder's launches follow the latent block): its all-gather waits
+                # for the executor's event on the side stream and runs under the decoder
+                z_all = torch.empty((dp.world_size * b, zd), dtype=z.dtype, device=dev)
+                with torch.cuda.stream(ov.stream):
+                    ov.stream.wait_event(ov.z_ready)
+                    _, z_work = dp.gather_columns(z, async_op=True, out=z_all)
+                z_work.wait()                                    # the launch stream continues after the collective
+            else:
+                z_all = dp.gather_columns(z)
             if lab_work is not None:
                 lab_work.wait()
             n, n_all, r = b, z_all.shape[0], len(fused.reg_dims)
@@ -197,7 +268,7 @@ class _FusedStepFn(Function):
             # scalars[LOSS] += W * reg and scalars[REG] (0 so far) = W * reg: one kernel on the strided pair
             scalars[LOSS:REG + 1:REG - LOSS].add_(reg_out, alpha=w)
             ctx.dz_unit, reg_scale = dz, w
-        ctx.fused, ctx.masks, ctx.marr = fused, keep, marr
+        ctx.fused, ctx.masks, ctx.marr, ctx.dp = fused, keep, marr, dp
         ctx.external_reg, ctx.reg_scale = external_reg, reg_scale
         ctx.save_for_backward(x, eps, capacity, mu, sigma, z, logits)
         # the loss is handed out as its own output (a 1-element view of the scalars) so that backward receives
@@ -232,4 +303,16 @@ class _FusedStepFn(Function):
                 ops._ptr(logits), ops._ptr(g_loss), ops._ptr(dz_extra), reg_mode, ctx.reg_scale,
                 ops._ptr(ws), ops._stream()), 'image_vae_backward')
         ctx.ws_released = True                                   # the cached workspace may serve the next forward
+        ov, dp = ctx.overlap, ctx.dp
+        buckets = fused.grad_buckets() if (ov is not None and dp is not None) else None
+        if buckets is not None:
+            # the decoder's conv gradients and the Linear gradients are final well before the pass ends: their all-reduces
+            # wait for the executor's events on the side stream and run under the encoder's backward kernels; what is
+            # left (the encoder's conv gradients) goes with DataParallel.reduce_gradients
+            dec, lin, rest = buckets
+            with torch.cuda.stream(ov.stream):
+                for event, (lo, hi) in ((ov.dec_grads, dec), (ov.linear_grads, lin)):
+                    ov.stream.wait_event(event)
+                    dp.start_bucket(opt.grad_arena, lo, hi)
+            dp.remaining_buckets = rest
         return (None,) * 11

@@ -54,6 +54,9 @@ class DataParallel:
         if reg_fn is None:
             reg_fn = ops.reg_loss
         self._reg_fn = reg_fn
+        self.capture_splitter = None         # graphed.Segments while a step is being captured: collectives cut the capture
+        self._pending = []                   # all-reduces of gradient buckets started during the backward pass (fused.py)
+        self.remaining_buckets = None        # float ranges of the arena those do not cover
         ops.rng_set_rank(self.rank)          # per-rank eps / dropout streams ("RNG under DP")
 
     def attach(self, trainer):
@@ -75,13 +78,19 @@ class DataParallel:
         for p in model.parameters():
             dist.broadcast(p.data, src=src, group=self.group)
 
-    def gather_columns(self, local, async_op=None):
+    def gather_columns(self, local, async_op=None, out=None):
         """(B_local, R) -> (W * B_local, R), rank-major row order.  With async_op the collective is only enqueued:
         -> (out, work); call work.wait() before the first kernel that reads `out` (it overlaps whatever is launched
-        in between)."""
+        in between).  `out`: a caller-allocated result (e.g. allocated on another stream than the one enqueuing)."""
         local = local.contiguous()
-        out = torch.empty((self.world_size * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype,
-                          device=local.device)
+        if out is None:
+            out = torch.empty((self.world_size * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype,
+                              device=local.device)
+        if self.capture_splitter is not None and self.capture_splitter.capturing:
+            # a step is being captured into HIP graphs (graphed.py): the collective is not recorded; the capture is cut here
+            # and the collective runs eagerly between the two graphs, now and on every replay, on these same buffers
+            self.capture_splitter.split(lambda: dist.all_gather_into_tensor(out, local, group=self.group))
+            return out if async_op is None else (out, None)
         work = dist.all_gather_into_tensor(out, local, group=self.group, async_op=bool(async_op))
         return out if async_op is None else (out, work if async_op else None)
 
@@ -103,14 +112,30 @@ class DataParallel:
         kl_global = self.mean_scalar(kl_local)
         return (capacity.detach().reshape(1).to(kl_local.dtype) + kl_local - kl_global)
 
+    def start_bucket(self, arena, lo, hi):
+        """enqueue the SUM all-reduce of arena[lo:hi] on the CURRENT stream without waiting for it (the fused backward calls
+        this on its side stream, behind the event that says the bucket is final); reduce_gradients() joins it"""
+        self._pending.append(dist.all_reduce(arena[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
     def reduce_gradients(self, optimizer):
-        """SUM all-reduce of the flat gradient arena; Adam then applies 1/W."""
+        """SUM all-reduce of the flat gradient arena; Adam then applies 1/W.  Buckets whose all-reduce was started during
+        the backward pass (start_bucket) are joined here and only the ranges they do not cover are reduced now."""
         optimizer.ensure_arena()
-        dist.all_reduce(optimizer.grad_arena, op=dist.ReduceOp.SUM, group=self.group)
+        if self._pending:
+            for lo, hi in self.remaining_buckets or ():
+                dist.all_reduce(optimizer.grad_arena[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+            for work in self._pending:
+                work.wait()                                      # the launch stream waits for the side stream's collectives
+            self._pending, self.remaining_buckets = [], None
+        else:
+            dist.all_reduce(optimizer.grad_arena, op=dist.ReduceOp.SUM, group=self.group)
         optimizer.grad_scale = 1.0 / self.world_size
 
     def mean_scalar(self, value):
-        """average a scalar tensor over ranks (reporting only)."""
+        """average a scalar tensor over ranks."""
         v = value.detach().clone().reshape(1)
-        dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
+        if self.capture_splitter is not None and self.capture_splitter.capturing:       # see gather_columns
+            self.capture_splitter.split(lambda: dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group))
+        else:
+            dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
         return v / self.world_size

@@ -78,13 +78,13 @@ class Trainer(ABC):
 
     # Training steps replayed from HIP graphs (ar-vae_amd/graphed.py).  Worth it where the step is many small launches and
     # the host sets the pace (MeasureVAE: 3.9 -> 1.5 ms per step); subclasses switch it on.  Batches of another shape
-    # (the last one of an epoch), data-parallel runs and CPU models take the eager path; changing beta / gamma / delta /
-    # reg_dim (e.g. from update_scheduler) re-captures.
+    # (the last one of an epoch) and CPU models take the eager path; changing beta / gamma / delta / reg_dim (e.g. from
+    # update_scheduler) re-captures.  Data-parallel steps replay too: the capture is cut at their collectives (graphed.py).
     use_graph_replay = False
 
     def _replay_step(self, batch):
         """-> (loss, accuracy) of zero_grad + loss + backward replayed from a captured graph, or None (run it eagerly)."""
-        if not self.use_graph_replay or self.data_parallel is not None or not torch.cuda.is_available():
+        if not self.use_graph_replay or not torch.cuda.is_available():
             return None
         if not next(self.model.parameters()).is_cuda:
             return None

@@ -391,7 +391,7 @@ def side_roofline(kind, prof, prof_steps, batch):
 def run_side(kind, device, args, fence, rank, world, use_dp, with_cpu):
     """one secondary workload -> its result dict (the main line when selected with --workload)"""
     bsz = args.batch if (args.workload == kind and args.batch != 512) else SIDE_BATCH[kind]
-    graphs = kind == 'measure' and not args.no_graphs and not use_dp
+    graphs = kind == 'measure' and not args.no_graphs         # (data-parallel steps replay too: graphed.Segments)
     step, eager, unit = build_side_workload(kind, device, bsz, rank, use_dp, graphs)
     steps = args.steps if args.workload == kind else max(10, min(args.steps, 50))
     med, timing, loss = timed_regions(step, steps, args.warmup, fence, args.min_seconds)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ARVAE_ABI_VERSION 4   /* 4: arvae_philox_* and in-kernel eps (arvae_image_vae_t.rng_*), arvae_tick_free_run_supported, caller workspace for arvae_link_down/up (arvae_link_ws_floats); 3: arvae_gru_seq_*, embed_bwd workspace; 2: arvae_image_vae_backward reg_fused == 2 (unit regulariser gradient in dz_extra) */
+#define ARVAE_ABI_VERSION 5   /* 5: arvae_image_vae_t.milestones (events the executors record for the data-parallel caller's collectives); 4: arvae_philox_* and in-kernel eps (arvae_image_vae_t.rng_*), arvae_tick_free_run_supported, caller workspace for arvae_link_down/up (arvae_link_ws_floats); 3: arvae_gru_seq_*, embed_bwd workspace; 2: arvae_image_vae_backward reg_fused == 2 (unit regulariser gradient in dz_extra) */
 
 #define ARVAE_OK 0
 #define ARVAE_E_INVALID (-1)  /* bad argument (null pointer, size out of range, unsupported shape) */
@@ -342,6 +342,7 @@ typedef struct {
     int64_t w_off, b_off; /* float offsets of weight and bias in the parameter / gradient arenas       */
 } arvae_layer_t;
 
+struct arvae_milestones;
 typedef struct {
     int32_t n_enc, n_dec;                 /* encoder layers up to the hidden vector; decoder layers z -> logits */
     arvae_layer_t enc[ARVAE_MAX_LAYERS];
@@ -359,7 +360,23 @@ typedef struct {
     uint32_t rng_offset, rng_step;
     uint64_t rng_seed;
     const uint32_t *rng_dev_step;
+    /* Optional (NULL: none).  hipEvent_t handles, created by the caller, which the executors RECORD on `stream` as soon as a
+     * result that other work may start from is complete -- so that a data-parallel caller can start its RCCL collectives on
+     * a side stream while the rest of the pass still runs (the reference is single-process: SURVEY.md section 8(e), "one
+     * all-gather between encoder forward and the reg kernel", "all-reduce overlapped with the tail of backward").  Every
+     * non-NULL event is recorded exactly once per call (at the end of the pass if the executor has no earlier point for it).
+     *   z_ready       arvae_image_vae_forward : mu / sigma / z are final (the decoder's launches follow)
+     *   dec_grads     arvae_image_vae_backward: the gradients of every conv layer of the DECODER are final in `grads`
+     *   linear_grads  arvae_image_vae_backward: the gradients of every Linear layer and of the two heads are final
+     * With dec_grads / linear_grads set, the backward pass finishes those gradients early (the decoder layers' slab
+     * reduction and the grouped Linear weight gradients are launched where their inputs are complete instead of at the end
+     * of the pass: one launch more). */
+    const struct arvae_milestones *milestones;
 } arvae_image_vae_t;
+
+typedef struct arvae_milestones {
+    void *z_ready, *dec_grads, *linear_grads;
+} arvae_milestones_t;
 
 /* scalars written by the forward pass (device array of ARVAE_VAE_NSCALARS floats) */
 #define ARVAE_VAE_LOSS 0   /* recon + dist + reg_scale*reg                                              */

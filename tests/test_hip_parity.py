@@ -1340,6 +1340,15 @@ def test_latent_block_experiment_matches_the_per_layer_path(dev):
 
 
 # ---------------------------------------------------------------- the epoch loop itself (Trainer.train_model) vs the oracle's trajectory
+def _close_after_adam(got, want, steps):
+    """weights after `steps` Adam updates (lr 1e-4): atol 1e-5 for all but a handful of entries.  Adam moves an entry by up
+    to lr per step whatever the gradient's size, so an entry whose gradient is ~0 turns a last-bit gradient difference into
+    a visible step: at most 1e-4 of the entries may exceed 1e-5, none may be off by more than half a step per update."""
+    d = np.abs(np.asarray(got.detach().cpu() if hasattr(got, 'detach') else got, np.float64) - np.asarray(want, np.float64))
+    assert d.max() <= 0.5e-4 * steps, d.max()
+    assert (d > 1e-5).mean() <= 1e-4, ((d > 1e-5).sum(), d.size)
+
+
 class _ListLoaders:
     """a dataset whose data_loaders() hands out fixed lists of batches (train, validation, test)"""
 
@@ -1388,7 +1397,7 @@ def test_image_train_model_two_epochs_track_the_oracle(dev, tmp_path, monkeypatc
         cur, adam = ref['params'], ref['adam']
         losses_ref.append(ref['terms']['loss'])
     for name, p in model.named_parameters():
-        close(p, cur[name], rtol=0, atol=1e-5)
+        _close_after_adam(p, cur[name], 6)
     assert len(means) == 2
     for epoch in range(2):
         close(means[epoch][0], np.mean(losses_ref[3 * epoch:3 * epoch + 3]), rtol=1e-4)
@@ -1397,7 +1406,7 @@ def test_image_train_model_two_epochs_track_the_oracle(dev, tmp_path, monkeypatc
     close(means[1][2], ref_val['terms']['loss'], rtol=1e-4)
     saved = torch.load(model.filepath, map_location='cpu')
     for name in state:
-        close(saved[name], cur[name], rtol=0, atol=1e-5)
+        _close_after_adam(saved[name], cur[name], 6)
 
 
 @pytest.mark.parametrize('replay', [False, True], ids=['eager', 'graph_replay'])
@@ -1469,7 +1478,7 @@ def test_measure_train_model_two_epochs_track_the_oracle(dev, tmp_path, monkeypa
         cur, adam = ref['params'], ref['adam']
         losses_ref.append(ref['terms']['loss'])
     for name, p in model.named_parameters():
-        close(p, cur[name], rtol=0, atol=1e-5)
+        _close_after_adam(p, cur[name], 6)
     for epoch in range(2):
         close(means[epoch][0], np.mean(losses_ref[3 * epoch:3 * epoch + 3]), rtol=1e-4)
 

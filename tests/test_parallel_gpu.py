@@ -27,11 +27,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_ranks(world, out, capacity, fused):
+def _run_ranks(world, out, capacity, fused, overlap=True, worker='dp_worker.py', args=None):
     port = _free_port()
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'dp_worker.py'), str(r), str(world), str(port), out,
-                               str(capacity), str(int(fused)), str(B_TOTAL)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                              text=True) for r in range(world)]
+    env = dict(os.environ, ARVAE_DP_OVERLAP='1' if overlap else '0')
+    tail = [str(capacity), str(int(fused)), str(B_TOTAL)] if args is None else [str(a) for a in args]
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', worker), str(r), str(world), str(port), out] + tail,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env) for r in range(world)]
     logs = []
     for p in procs:
         try:
@@ -78,6 +79,49 @@ def test_rccl_ranks_equal_single_process(tmp_path, golden_dir, world, capacity, 
         d_ref = ref['params'][name].astype(np.float64).ravel() - state[name].astype(np.float64).ravel()
         np.testing.assert_allclose(np.linalg.norm(d_got), np.linalg.norm(d_ref), rtol=2e-3, err_msg=name)
         assert (np.abs(d_got - d_ref) > 2e-5).mean() <= 2e-3, name
+
+
+@pytest.mark.parametrize('world', [1, 2])
+def test_rccl_overlapped_collectives_change_nothing(tmp_path, world):
+    """the z all-gather behind the forward pass's z_ready event and the two gradient buckets all-reduced behind the backward
+    pass's events on a side stream (fused.py, arvae_image_vae_t.milestones) against the same step with every collective on
+    the launch stream after the pass (ARVAE_DP_OVERLAP=0): the all-reduced gradients and the weights after Adam are
+    bit-identical (the same sums, only issued earlier)."""
+    if torch.cuda.device_count() < world:
+        pytest.skip(f'needs {world} GPUs, this box has {torch.cuda.device_count()}')
+    on = _run_ranks(world, str(tmp_path / 'on.npz'), 0.0, True, overlap=True)
+    off = _run_ranks(world, str(tmp_path / 'off.npz'), 0.0, True, overlap=False)
+    assert float(on['loss']) == float(off['loss'])
+    for k in on.files:
+        if k.startswith(('grad/', 'param/')):
+            np.testing.assert_array_equal(on[k], off[k], err_msg=k)
+
+
+@pytest.mark.parametrize('world', [1, 2])
+def test_measure_data_parallel_step_replays_from_graphs(tmp_path, world):
+    """a data-parallel MeasureVAE step replayed from HIP graphs cut at its collective (graphed.Segments: graph, eager
+    all-gather, graph) gives the eager data-parallel step's loss and all-reduced gradients, and those are the oracle's
+    single-process step on the whole batch."""
+    if torch.cuda.device_count() < world:
+        pytest.skip(f'needs {world} GPUs, this box has {torch.cuda.device_count()}')
+    from oracle import attributes as o_attr
+    from oracle import measure_vae as o_mvae
+    b_total = 32
+    got = _run_ranks(world, str(tmp_path / 'm.npz'), 0.0, True, worker='dp_measure_worker.py', args=[b_total])
+    assert int(got['world']) == world
+    assert all(tuple(s) == (2, 1) for s in got['segments'])          # two graphs with one eager collective between them
+    np.testing.assert_allclose(got['loss_replay'], got['loss_eager'], rtol=1e-6)
+    ge, gr = got['grad_eager'].astype(np.float64), got['grad_replay'].astype(np.float64)
+    assert np.linalg.norm(ge - gr) <= 1e-6 * np.linalg.norm(ge)
+    state = syn.synth_state(o_mvae.shapes(), 4)
+    score = syn.measure_batch(b_total, seed=5)
+    eps = syn.normal_noise((b_total, 32), seed=1)
+    attr = o_attr.attribute_labels(score, *syn.measure_tables())
+    ref = o_step.measure_step(state, score, eps, attr, (0, 1, 2, 3), 0.001, 1.0, 10.0, True)
+    np.testing.assert_allclose(got['loss_replay'], ref['terms']['loss'], rtol=1e-4)
+    for name, (off, n) in zip(got['names'], got['spans']):
+        want = ref['grads'][str(name)].astype(np.float64).ravel()
+        assert np.linalg.norm(gr[off:off + n] - want) <= 3e-3 * np.linalg.norm(want) + 1e-9, name
 
 
 def _bench(*args):
