@@ -29,6 +29,8 @@
 #include "conv32_common.h"
 #include "reduce.h"
 #include "midprep.h"
+#include "prep32.h"
+#include "regloss.h"
 
 #include <type_traits>
 
@@ -515,17 +517,6 @@ __global__ __launch_bounds__(256, 1) void down32b_kernel(const float *__restrict
     }
 }
 
-__device__ __forceinline__ void split8x3(const float (&x)[8], bf16x8 &hi, bf16x8 &mid, bf16x8 &lo) {
-    i32x4v h, m, l;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        unsigned a, b, c;
-        split_pair3(x[2 * j], x[2 * j + 1], a, b, c);
-        h[j] = (int)a; m[j] = (int)b; l[j] = (int)c;
-    }
-    hi = __builtin_bit_cast(bf16x8, h); mid = __builtin_bit_cast(bf16x8, m); lo = __builtin_bit_cast(bf16x8, l);
-}
-
 // ================================================================================================
 // Down on the bf16 MFMA at fp32 accuracy (three-term split, six partial products: see up32x_kernel).  Three terms of a
 // full output column (256 weights) do not fit the register file, so K is split two ways here: a tile is 64 lo pixels,
@@ -536,51 +527,12 @@ __device__ __forceinline__ void split8x3(const float (&x)[8], bf16x8 &hi, bf16x8
 // that a kernel starts with 48 / 24 coalesced loads instead of staging and splitting the tensor itself.
 //   DOWN part: [kh 2][slot 48 = (tap 8, c 2, term 3)][lane 64]      UP part: [class 4][slot 24 = (ty, tx, c, term)][lane 64]
 // (PREP_DOWN_SLOTS, PREP_UP_SLOTS, PREP_*_UINT4, PREP_FLOATS: conv32_common.h, shared with conv32k.hip)
-constexpr int PREP_MAX_LAYERS = 8;
-struct PrepArgs {
-    const float *wt[PREP_MAX_LAYERS];
-    uint4 *out[PREP_MAX_LAYERS];
-};
-
-// 16 workgroups per layer: items 0..2047 build the DOWN part, 2048..4095 the UP part; an item = 8 weights -> 3 x 16 bytes
-__device__ __forceinline__ void conv32_prep_block(const PrepArgs &p, const int block) {
-    const int layer = block >> 4, item = (block & 15) * 256 + threadIdx.x;
-    const float *wt = nullptr;
-    uint4 *out = nullptr;
-#pragma unroll
-    for (int q = 0; q < PREP_MAX_LAYERS; ++q)                    // constant indices into the by-value argument block
-        if (q == layer) { wt = p.wt[q]; out = p.out[q]; }
-    const int lane = item & 63, half = lane >> 5, rc = lane & 31;
-    float x[8];
-    uint4 *dst;
-    if (item < 2048) {                                           // DOWN: (kh, tap = kyl*4 + kx, c)
-        const int c = (item >> 6) & 1, tap = (item >> 7) & 7, kh = item >> 10;
-        const int ky = 2 * kh + (tap >> 2), kx = tap & 3;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = wt[((rc * C32) + c * 16 + half * 8 + j) * 16 + ky * 4 + kx];
-        dst = out + (kh * PREP_DOWN_SLOTS + (tap * 2 + c) * 3) * 64 + lane;
-    } else {                                                     // UP: (class = wave, ty, tx, c)
-        const int u = item - 2048;
-        const int c = (u >> 6) & 1, tx = (u >> 7) & 1, ty = (u >> 8) & 1, cls = u >> 9;
-        const int ky = 1 - (cls >> 1) + 2 * ty, kx = 1 - (cls & 1) + 2 * tx;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = wt[((c * 16 + half * 8 + j) * C32 + rc) * 16 + ky * 4 + kx];
-        dst = out + PREP_DOWN_UINT4 + (cls * PREP_UP_SLOTS + ((ty * 2 + tx) * 2 + c) * 3) * 64 + lane;
-    }
-    bf16x8 h, m, l;
-    split8x3(x, h, m, l);
-    dst[0] = __builtin_bit_cast(uint4, h);
-    dst[64] = __builtin_bit_cast(uint4, m);
-    dst[128] = __builtin_bit_cast(uint4, l);
-}
-
 __global__ __launch_bounds__(256) void conv32_weight_prep_kernel(PrepArgs p) { conv32_prep_block(p, blockIdx.x); }
 
 // the step's two weight preps as one launch: workgroups [0, conv_blocks) split the 32-channel conv weights, the rest lay out the
 // latent block's matrices (midprep.h)
 __global__ __launch_bounds__(256) void prep_all_kernel(PrepArgs p, MidPrepArgs mid, int conv_blocks) {
-    if ((int)blockIdx.x < conv_blocks) conv32_prep_block(p, blockIdx.x);
-    else mid_prep_block(mid, blockIdx.x - conv_blocks);
+    prep_all_block(p, mid, conv_blocks, blockIdx.x);
 }
 
 template <int LO, int MODE>
@@ -1175,6 +1127,21 @@ __global__ __launch_bounds__(256, 1) void up32x_kernel(const float *__restrict__
     up32x_body<LO, MODE, PX>(lo, wt, ep, n_img, n_tiles, blockIdx.x, gridDim.x);
 }
 
+// The decoder's first convolution (4x4 -> 8x8: a few tiles per CU, 6.5 us) and the all-pairs attribute regularisation of the
+// same forward pass (regloss.h: ~65 workgroups, 6.3 us, needs only z and the labels) in ONE grid: workgroups [0, grid_up) run
+// the convolution, the rest the regulariser's (row block, dim) pairs, staging their columns in the launch's dynamic LDS.
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void up32x_reg_kernel(const float *__restrict__ lo, const float *__restrict__ wt, Ep32 ep, int n_img,
+                                                            int n_tiles, int grid_up, RegArgs reg, int reg_bx) {
+    if ((int)blockIdx.x < grid_up) {
+        up32x_body<4, MODE, 32>(lo, wt, ep, n_img, n_tiles, blockIdx.x, grid_up);
+        return;
+    }
+    extern __shared__ __attribute__((aligned(16))) float reg_lds[];
+    const int b = blockIdx.x - grid_up;
+    reg_loss_block(reg, b % reg_bx, b / reg_bx, reg_lds, reg_lds + REG_CHUNK);
+}
+
 
 // ================================================================================================
 // Wgrad: dwt[clo][chi][ky][kx] += sum_{n,ly,lx} lo[n,ly,lx,clo] * hi[n,2ly-1+ky,2lx-1+kx,chi]
@@ -1599,6 +1566,25 @@ template <int LO> static int launch_up(const arvae_link_t *l, const Operand &lo,
         default: launch_up_v<LO, EP_PLAIN>(grid, lo, wt, ep, l->n, tiles, s); break;
     }
     return check_launch(LO == 16 ? "up32_kernel<16>" : LO == 8 ? "up32_kernel<8>" : "up32_kernel<4>");
+}
+
+// conv32_up of a 4x4 -> 8x8 ReLU layer (forward pass, prepared weights, small tiles) with the regulariser's workgroups riding in
+// the same grid (up32x_reg_kernel); false: not that case, launch the two separately
+bool conv32_up_reg_fits(const arvae_link_t *l, const float *wprep) {
+    static const bool off = getenv("ARVAE_NO_PAIR_REG") != nullptr || getenv("ARVAE_CONV32_FP32") != nullptr ||
+                            getenv("ARVAE_NO_SMALL_TILES") != nullptr;
+    return !off && conv32_fits(l) && l->lh == 4 && wprep != nullptr && 2 * tiles_for<4, 128>(l->n) <= cu_count();
+}
+int conv32_up_reg(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, uint16_t *bits_out, float *out,
+                  const float *wprep, const RegArgs &reg, int r, hipStream_t s) {
+    Ep32 ep{bias, nullptr, nullptr, bits_out, out, reinterpret_cast<const uint4 *>(wprep)};
+    const int tiles = tiles_for<4, 32>(l->n), grid_up = grid_for_tiles(tiles);
+    constexpr int LDSX = MaxOf<MaxOf<3 * PatchLoader<4, 1, 32>::PLANE_DW, WSTAGE_UP>::value, 2 * REG_CHUNK>::value * 4;
+    static bool attr = false;
+    if (!attr) { allow_lds(up32x_reg_kernel<EP_RELU>, LDSX); attr = true; }
+    const int reg_bx = (int)((reg.n_rows + REG_ROWS_PER_BLOCK - 1) / REG_ROWS_PER_BLOCK);
+    ARVAE_LAUNCH((up32x_reg_kernel<EP_RELU>), dim3(grid_up + reg_bx * r), dim3(256), LDSX, s, lo.v, wt, ep, l->n, tiles, grid_up, reg, reg_bx);
+    return check_launch("up32_kernel<4>(+ reg_loss)");
 }
 
 int conv32_up(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, int relu, const float *gate,

@@ -10,6 +10,7 @@
 //   wgrad_c1 : dwt[c][0][ky][kx] += sum_pixels lo[pix][c] * img[pix @ tap]; bias sums ride along
 #include "common.h"
 #include "reduce.h"
+#include "prep32.h"
 
 namespace arvae {
 
@@ -219,6 +220,19 @@ template <int GATE>
 __global__ __launch_bounds__(256) void down_c1s_kernel(Operand img, const float *__restrict__ wt, Ep1 ep, int n_rows) {
     __shared__ __attribute__((aligned(16))) float stage[4 * LO1 * PS1];
     down_c1s_body<GATE, 4>(img, wt, ep, n_rows, blockIdx.x, gridDim.x, stage);
+}
+
+// The first encoder layer and the step's weight preparation in ONE grid (horizontal pair, as pair_c1_kernel): the prep's few
+// hundred short workgroups (prep32.h: nothing this layer reads) are dispatched first and finish under the convolution's
+// 67 MB output stream; what they write is first read by the NEXT launch.  One launch and ~8 us less per training step.
+__global__ __launch_bounds__(256) void down_c1s_prep_kernel(Operand img, const float *__restrict__ wt, Ep1 ep, int n_rows, PrepArgs prep,
+                                                             MidPrepArgs mid, int conv_blocks, int prep_blocks) {
+    __shared__ __attribute__((aligned(16))) float stage[4 * LO1 * PS1];
+    if ((int)blockIdx.x < prep_blocks) {
+        prep_all_block(prep, mid, conv_blocks, blockIdx.x);
+        return;
+    }
+    down_c1s_body<0, 4>(img, wt, ep, n_rows, blockIdx.x - prep_blocks, gridDim.x - prep_blocks, stage);
 }
 
 
@@ -681,6 +695,25 @@ static_assert(W1_WAVES == 8 && W1_WAVES * W1_SLOTS * W1_PS >= W1_WAVES * 16 * 64
 bool conv_c1_fits(const arvae_link_t *l) {
     return l->chi == 1 && l->clo == CC && l->kh == 4 && l->kw == 4 && l->stride == 2 && l->pad == 1 && l->hh == HI1 &&
            l->hw == HI1 && l->lh == LO1 && l->lw == LO1 && l->hi_perm_c == 0 && l->lo_perm_c == 0;
+}
+
+// conv_c1_down (plain input, no gate) with the step's weight preparation riding in the same grid (down_c1s_prep_kernel)
+int conv_c1_down_with_prep(const arvae_link_t *l, const Operand &img, const float *wt, const float *bias, int relu, uint16_t *bits_out,
+                           float *out, const float *const *prep_wts, float *const *preps, int n_prep, const MidPrepArgs &mid,
+                           hipStream_t s) {
+    ARVAE_REQUIRE(n_prep > 0 && n_prep <= PREP_MAX_LAYERS && mid.count > 0, "conv_c1_down_with_prep: nothing to prepare");
+    Ep1 ep{bias, nullptr, nullptr, bits_out, out, relu};
+    PrepArgs p{};
+    for (int i = 0; i < n_prep; ++i) {
+        p.wt[i] = prep_wts[i];
+        p.out[i] = reinterpret_cast<uint4 *>(preps[i]);
+    }
+    const int conv_blocks = 16 * n_prep, prep_blocks = conv_blocks + mid.blk_end[mid.count - 1];
+    const int n_rows = l->n * LO1;
+    int grid = 256 * 16 / 4;                                     // as conv_c1_down: workgroups of four independent waves
+    if (grid > (n_rows + 3) / 4) grid = (n_rows + 3) / 4;
+    ARVAE_LAUNCH(down_c1s_prep_kernel, dim3(prep_blocks + grid), dim3(256), 0, s, img, wt, ep, n_rows, p, mid, conv_blocks, prep_blocks);
+    return check_launch("down_c1_kernel(+ weight prep)");
 }
 
 int conv_c1_down(const arvae_link_t *l, const Operand &img, const float *wt, const float *bias, int relu,

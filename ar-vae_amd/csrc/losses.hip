@@ -3,6 +3,7 @@
 // wavefront (64-lane) shuffle reductions, per-workgroup partials in a caller-provided workspace and a
 // fixed-order finishing pass (bitwise reproducible: no float atomics on the loss values).
 #include "common.h"
+#include "regloss.h"
 
 namespace arvae {
 
@@ -90,60 +91,10 @@ __global__ __launch_bounds__(256) void kld_bwd_kernel(const float *__restrict__ 
 // (zero N x N traffic to HBM); each wavefront owns ROWS_PER_WAVE rows, its 64 lanes stride over the
 // staged columns and the two sums (|t-s| and (1-t^2) sgn(t-s)) are reduced with wave shuffles.
 // =================================================================================================
-constexpr int REG_ROWS_PER_WAVE = 2;
-constexpr int REG_ROWS_PER_BLOCK = 4 * REG_ROWS_PER_WAVE;
-constexpr int REG_CHUNK = 2048;   // columns staged per pass: 2 * 8 KB of LDS
-
-struct RegDims { int d[16]; };
-
-__global__ __launch_bounds__(256) void reg_loss_kernel(const float *__restrict__ zr, const float *__restrict__ lr,
-                                                        int64_t n_rows, const float *__restrict__ zc,
-                                                        const float *__restrict__ lc, int64_t n_cols, int64_t ldz,
-                                                        int64_t ldl, RegDims dims, float delta,
-                                                        float *__restrict__ row_loss, float *__restrict__ row_grad) {
+__global__ __launch_bounds__(256) void reg_loss_kernel(RegArgs p) {
     __shared__ float xs[REG_CHUNK];
     __shared__ float as[REG_CHUNK];
-    const int d = dims.d[blockIdx.y];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t row0 = (int64_t)blockIdx.x * REG_ROWS_PER_BLOCK + wave * REG_ROWS_PER_WAVE;
-    float xi[REG_ROWS_PER_WAVE], ai[REG_ROWS_PER_WAVE], sl[REG_ROWS_PER_WAVE], sg[REG_ROWS_PER_WAVE];
-#pragma unroll
-    for (int r = 0; r < REG_ROWS_PER_WAVE; ++r) {
-        const int64_t row = row0 + r;
-        xi[r] = row < n_rows ? zr[row * ldz + d] : 0.f;
-        ai[r] = row < n_rows ? lr[row * ldl + d] : 0.f;
-        sl[r] = sg[r] = 0.f;
-    }
-    for (int64_t c0 = 0; c0 < n_cols; c0 += REG_CHUNK) {
-        const int cn = (int)min((int64_t)REG_CHUNK, n_cols - c0);
-        __syncthreads();
-        for (int j = threadIdx.x; j < cn; j += 256) {
-            xs[j] = zc[(c0 + j) * ldz + d];
-            as[j] = lc[(c0 + j) * ldl + d];
-        }
-        __syncthreads();
-        for (int j = lane; j < cn; j += 64) {
-            const float xj = xs[j], aj = as[j];
-#pragma unroll
-            for (int r = 0; r < REG_ROWS_PER_WAVE; ++r) {
-                const float t = tanhf(delta * (xi[r] - xj));
-                const float da = ai[r] - aj;
-                const float s = da > 0.f ? 1.f : (da < 0.f ? -1.f : 0.f);
-                const float e = t - s;
-                sl[r] += fabsf(e);
-                sg[r] += (1.f - t * t) * (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f));
-            }
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < REG_ROWS_PER_WAVE; ++r) {
-        const float l = wave_sum(sl[r]), g = wave_sum(sg[r]);
-        const int64_t row = row0 + r;
-        if (lane == 0 && row < n_rows) {
-            row_loss[(int64_t)blockIdx.y * n_rows + row] = l;
-            row_grad[(int64_t)blockIdx.y * n_rows + row] = g;
-        }
-    }
+    reg_loss_block(p, blockIdx.x, blockIdx.y, xs, as);
 }
 
 // fixed-order finish: loss scalar + dense dz rows.  One workgroup, so what it costs is its chain of memory round trips: every
@@ -466,8 +417,8 @@ int reg_partials(const float *z_rows, const float *lab_rows, int64_t n_rows, con
                  int64_t n_cols, int64_t ldz, int64_t ldl, const RegDims &rd, int32_t r, float delta, float *ws,
                  hipStream_t s) {
     const unsigned bx = (unsigned)((n_rows + REG_ROWS_PER_BLOCK - 1) / REG_ROWS_PER_BLOCK);
-    ARVAE_LAUNCH(reg_loss_kernel, dim3(bx, r), dim3(256), 0, s, z_rows, lab_rows, n_rows, z_cols, lab_cols,
-                       n_cols, ldz, ldl, rd, delta, ws, ws + n_rows * r);
+    RegArgs p{z_rows, lab_rows, n_rows, z_cols, lab_cols, n_cols, ldz, ldl, rd, delta, ws, ws + n_rows * r};
+    ARVAE_LAUNCH(reg_loss_kernel, dim3(bx, r), dim3(256), 0, s, p);
     return check_launch("reg_loss");
 }
 

@@ -5,6 +5,7 @@
 #include "dense.h"
 #include "reduce.h"
 #include "midprep.h"
+#include "regloss.h"
 
 namespace arvae {
 
@@ -25,6 +26,9 @@ int conv32_up(const arvae_link_t *l, const Operand &lo, const float *wt, const f
               const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s, const float *wprep = nullptr);
 int conv_c1_up_recon(const arvae_link_t *l, const float *lo, const float *wt, const float *bias, float *out, const float *x,
                      int dist, float *partial, float *dlogits, hipStream_t s, int *nb_out);
+bool conv32_up_reg_fits(const arvae_link_t *l, const float *wprep);
+int conv32_up_reg(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, uint16_t *bits_out, float *out,
+                  const float *wprep, const RegArgs &reg, int r, hipStream_t s);
 int64_t conv32_prep_floats();
 int conv32_weight_prep(const float *const *wts, float *const *preps, int n_layers, hipStream_t s);
 int conv32_weight_prep_with_mid(const float *const *wts, float *const *preps, int n_layers, const MidPrepArgs &mid, hipStream_t s);
@@ -42,6 +46,9 @@ int conv_c1_wgrad_partial(const arvae_link_t *l, const Operand &lo, const Operan
                           int bias_mode, float *slab, hipStream_t s, SlabJob *job);
 int conv_c1_down(const arvae_link_t *l, const Operand &img, const float *wt, const float *bias, int relu,
                  const float *gate, const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s);
+int conv_c1_down_with_prep(const arvae_link_t *l, const Operand &img, const float *wt, const float *bias, int relu, uint16_t *bits_out,
+                           float *out, const float *const *prep_wts, float *const *preps, int n_prep, const MidPrepArgs &mid,
+                           hipStream_t s);
 
 // fused encoder heads + reparameterisation (heads.hip)
 bool heads_fusable(const arvae_layer_t *hm, const arvae_layer_t *hl, int zdim);
@@ -69,7 +76,6 @@ int mid_backward(const arvae_image_vae_t *m, int batch, const float *params, flo
 // loss-term pieces (losses.hip)
 int recon_partials(const float *logits, const float *x, int64_t count, int64_t batch, int32_t dist, float *ws,
                    float *dlogits, hipStream_t s, int *nb_out);
-struct RegDims { int d[16]; };
 int reg_partials(const float *z_rows, const float *lab_rows, int64_t n_rows, const float *z_cols, const float *lab_cols,
                  int64_t n_cols, int64_t ldz, int64_t ldl, const RegDims &rd, int32_t r, float delta, float *ws,
                  hipStream_t s);
@@ -409,6 +415,9 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
     hipStream_t st = as_stream(stream);
     int mi = 0;
     bool mid_prepped = false;
+    int mid_ne = 0, mid_nd = 0;
+    const bool mid = mid_fusable(m, &mid_ne, &mid_nd);
+    int first = 0;                                           // first encoder layer the loop below still has to run
     {   // split the 32-channel conv weights once for this step's forward and backward kernels
         const float *wts[8];
         float *preps[8];
@@ -417,19 +426,31 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
             if (L.enc_wprep[i] >= 0) { wts[np] = params + m->enc[i].w_off; preps[np++] = ws + L.enc_wprep[i]; }
         for (int i = 0; i < m->n_dec; ++i)
             if (L.dec_wprep[i] >= 0) { wts[np] = params + m->dec[i].w_off; preps[np++] = ws + L.dec_wprep[i]; }
-        // (together with the latent block's matrix layouts when that block runs: one prep launch per step)
-        if (np > 0 && mid_fusable(m, nullptr, nullptr) && getenv("ARVAE_SPLIT_PREP") == nullptr) {
+        // (together with the latent block's matrix layouts when that block runs: one prep launch per step -- or none: when
+        // the first encoder layer is the single-channel convolution, the prep rides in ITS grid, conv_c1.hip)
+        if (np > 0 && mid && getenv("ARVAE_SPLIT_PREP") == nullptr) {
             MidPrepArgs margs;
             mid_prep_args(m, params, ws + L.mid_prep, &margs);
-            if (int rc = conv32_weight_prep_with_mid(wts, preps, np, margs, st)) return rc;
+            const arvae_layer_t &l0 = m->enc[0];
+            arvae_link_t lk0 = l0.link;
+            lk0.n = batch;
+            static const bool no_pair = getenv("ARVAE_NO_PAIR_PREP") != nullptr;     // diagnostic: the prep as its own launch
+            if (!no_pair && m->n_enc - mid_ne > 1 && L.enc_bits[0] >= 0 && L.enc_wprep[0] < 0 && !l0.is_up && conv_c1_fits(&lk0) &&
+                !(masks != nullptr && l0.dropout)) {
+                const arvae_operand_t op = plain(x);
+                if (int rc = conv_c1_down_with_prep(&lk0, make_operand(&op), params + l0.w_off, l0.b_off >= 0 ? params + l0.b_off : nullptr,
+                                                    1, reinterpret_cast<uint16_t *>(ws + L.enc_bits[0]), ws + L.enc_out[0], wts, preps, np,
+                                                    margs, st))
+                    return rc;
+                first = 1;
+            } else if (int rc = conv32_weight_prep_with_mid(wts, preps, np, margs, st)) return rc;
             mid_prepped = true;
         } else if (int rc = conv32_weight_prep(wts, preps, np, st)) return rc;
     }
     // encoder
-    int mid_ne = 0, mid_nd = 0;
-    const bool mid = mid_fusable(m, &mid_ne, &mid_nd);
-    const float *h = x;
-    for (int i = 0; i < m->n_enc - mid_ne; ++i) {
+    const float *h = first ? ws + L.enc_out[0] : x;
+    mi += first ? (m->enc[0].dropout != 0) : 0;
+    for (int i = first; i < m->n_enc - mid_ne; ++i) {
         const uint8_t *mask = (masks != nullptr && m->enc[i].dropout) ? masks[mi] : nullptr;
         mi += m->enc[i].dropout != 0;
         uint16_t *bits = L.enc_bits[i] >= 0 ? reinterpret_cast<uint16_t *>(ws + L.enc_bits[i]) : nullptr;
@@ -468,11 +489,36 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
     const arvae_layer_t &last = m->dec[m->n_dec - 1];
     const bool recon_fused = last.is_up && last.act == ARVAE_ACT_NONE && last.dropout == 0 && conv_c1_fits(&last.link) &&
                              arvae_recon_ws_floats(0) >= 2 * 1024;
+    // the regulariser needs z and the labels only: when this rank's batch is the whole batch its workgroups ride in the grid
+    // of the first decoder convolution (conv32.hip, up32x_reg_kernel) instead of a launch of their own after the decoder
+    const bool reg_here = m->n_reg > 0 && n_cols >= 0;
+    bool reg_done = false;
+    RegArgs reg_args{};
+    if (reg_here) {
+        for (int i = 0; i < m->n_reg; ++i)
+            ARVAE_REQUIRE(m->reg_dims[i] >= 0 && m->reg_dims[i] < m->zdim && m->reg_dims[i] < ld_labels,
+                          "image_vae_forward: reg dim %d outside z/labels", m->reg_dims[i]);
+        const float *zc = z_cols != nullptr ? z_cols : z;
+        const float *lc = lab_cols != nullptr ? lab_cols : labels;
+        reg_args = RegArgs{z, labels, batch, zc, lc, z_cols != nullptr ? n_cols : (int64_t)batch, m->zdim, ld_labels, RegDims{},
+                           m->delta, ws + L.reg_ws, ws + L.reg_ws + (int64_t)batch * m->n_reg};
+        for (int i = 0; i < 16; ++i) reg_args.dims.d[i] = i < m->n_reg ? m->reg_dims[i] : 0;
+    }
     for (int i = mid ? mid_nd : (heads_next ? 1 : 0); i < m->n_dec; ++i) {
         const uint8_t *mask = (masks != nullptr && m->dec[i].dropout) ? masks[mi] : nullptr;
         mi += m->dec[i].dropout != 0;
         float *out = (i + 1 < m->n_dec) ? ws + L.dec_out[i] : logits;
-        if (i + 1 == m->n_dec && recon_fused) {             // last layer: logits + reconstruction partials in one kernel
+        arvae_link_t lki = m->dec[i].link;
+        lki.n = batch;
+        if (reg_here && !reg_done && z_cols == nullptr && i + 1 < m->n_dec && m->dec[i].is_up && m->dec[i].act == ARVAE_ACT_RELU &&
+            mask == nullptr && L.dec_bits[i] >= 0 && L.dec_wprep[i] >= 0 && conv32_up_reg_fits(&lki, ws + L.dec_wprep[i])) {
+            const arvae_layer_t &l = m->dec[i];
+            const arvae_operand_t op = plain(h);
+            if (int rc = conv32_up_reg(&lki, make_operand(&op), params + l.w_off, l.b_off >= 0 ? params + l.b_off : nullptr,
+                                       reinterpret_cast<uint16_t *>(ws + L.dec_bits[i]), out, ws + L.dec_wprep[i], reg_args, m->n_reg, st))
+                return rc;
+            reg_done = true;
+        } else if (i + 1 == m->n_dec && recon_fused) {             // last layer: logits + reconstruction partials in one kernel
             arvae_link_t lk = m->dec[i].link;
             lk.n = batch;
             const arvae_layer_t &l = m->dec[i];
@@ -491,20 +537,11 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
     const int64_t pix = out_elems(m->dec[m->n_dec - 1], batch);
     if (!recon_fused)
         if (int rc = recon_partials(logits, x, pix, batch, m->recon_dist, ws + L.rec_ws, ws + L.dlogits, st, &nb)) return rc;
-    const bool reg_here = m->n_reg > 0 && n_cols >= 0;
-    int64_t nc = batch;
-    if (reg_here) {
-        const float *zc = z_cols != nullptr ? z_cols : z;
-        const float *lc = lab_cols != nullptr ? lab_cols : labels;
-        nc = z_cols != nullptr ? n_cols : batch;
-        RegDims rd;
-        for (int i = 0; i < 16; ++i) rd.d[i] = i < m->n_reg ? m->reg_dims[i] : 0;
-        for (int i = 0; i < m->n_reg; ++i)
-            ARVAE_REQUIRE(m->reg_dims[i] >= 0 && m->reg_dims[i] < m->zdim && m->reg_dims[i] < ld_labels,
-                          "image_vae_forward: reg dim %d outside z/labels", m->reg_dims[i]);
-        if (int rc = reg_partials(z, labels, batch, zc, lc, nc, m->zdim, ld_labels, rd, m->n_reg, m->delta, ws + L.reg_ws, st))
+    const int64_t nc = reg_here ? reg_args.n_cols : (int64_t)batch;
+    if (reg_here && !reg_done)
+        if (int rc = reg_partials(z, labels, batch, reg_args.zc, reg_args.lc, nc, m->zdim, ld_labels, reg_args.dims, m->n_reg, m->delta,
+                                  ws + L.reg_ws, st))
             return rc;
-    }
     return vae_finish(ws + L.rec_ws, nb, batch, pix, mu, sigma, m->zdim, m->beta, capacity,
                       reg_here ? ws + L.reg_ws : nullptr, nc, m->zdim, m->reg_dims, m->n_reg, m->gamma, m->delta, reg_scale,
                       ws + L.dz_reg, ws + L.rec_out, ws + L.kld_out, ws + L.reg_out, scalars, st);

@@ -30,10 +30,14 @@ def _async_label_gather(dp):
 
 # Data-parallel overlap: the executors record events where z / the decoder's conv gradients / the
 # Linear gradients are final (arvae_image_vae_t.milestones), and the collectives that need them are enqueued on a side
-# stream behind those events, so they run under the rest of the pass.  ARVAE_DP_OVERLAP=0: everything on the launch stream,
-# one all-reduce of the whole arena after backward (the round-2 schedule).
+# stream behind those events, so they run under the rest of the pass.  OPT-IN (ARVAE_DP_OVERLAP=1).  Measured on one MI355X
+# with one RCCL rank (bench.py --force-dp, B = 512): plain step 0.513 ms, data-parallel step with every collective on the
+# launch stream 0.551 ms, with the overlap schedule 0.645 ms -- on this stack every cross-stream dependency (event record on
+# the launch stream, wait on the side stream, join before Adam) costs the launch stream 5-25 us of dispatch gap
+# (profiles/r3_dp_timeline.txt), more than a one-rank collective takes.  Across GPUs, where an all-reduce of the 1.6 MB
+# Linear bucket takes tens of microseconds, the trade may go the other way: no multi-GPU box was available to measure it.
 def _dp_overlap():
-    return os.environ.get('ARVAE_DP_OVERLAP', '1') != '0'
+    return os.environ.get('ARVAE_DP_OVERLAP', '0') == '1'
 
 
 class _Overlap:

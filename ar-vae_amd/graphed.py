@@ -38,7 +38,12 @@ class Segments:
 
     def _begin(self):
         g = torch.cuda.CUDAGraph()
-        g.capture_begin(pool=self.pool)
+        # with a process group alive, its watchdog thread polls events while we capture: 'global' mode would turn that into
+        # hipErrorStreamCaptureUnsupported; only this thread's (and the autograd thread's launches, which target the capturing
+        # stream) matter here
+        import torch.distributed as dist
+        mode = 'thread_local' if dist.is_available() and dist.is_initialized() else 'global'
+        g.capture_begin(pool=self.pool, capture_error_mode=mode)
         self.graphs.append(g)
 
     def capture(self, fn):

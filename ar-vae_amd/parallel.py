@@ -54,6 +54,7 @@ class DataParallel:
         if reg_fn is None:
             reg_fn = ops.reg_loss
         self._reg_fn = reg_fn
+        self._dims_cache = {}
         self.capture_splitter = None         # graphed.Segments while a step is being captured: collectives cut the capture
         self._pending = []                   # all-reduces of gradient buckets started during the backward pass (fused.py)
         self.remaining_buckets = None        # float ranges of the arena those do not cover
@@ -96,7 +97,10 @@ class DataParallel:
 
     def reg_loss(self, z, labels, dims, gamma, delta):
         """W * (row-block regularisation loss of this rank's samples against the global batch)."""
-        idx = torch.as_tensor(list(dims), device=z.device, dtype=torch.long)
+        key = (tuple(dims), z.device)
+        idx = self._dims_cache.get(key)          # cached: a host -> device copy is not allowed while a step is being captured
+        if idx is None:
+            idx = self._dims_cache[key] = torch.as_tensor(list(dims), device=z.device, dtype=torch.long)
         z_loc = z.index_select(1, idx)                       # differentiable compaction (B_local, R)
         lab_loc = labels.index_select(1, idx).to(torch.float32)
         packed = self.gather_columns(torch.cat([z_loc.detach(), lab_loc], dim=1))

@@ -27,6 +27,11 @@ def dev():
     return torch.device('cuda:0')
 
 
+def nchw(t):
+    """the HIP models hand out images as (B, 1, H, W) tensors; host copy for numpy"""
+    return t.detach().cpu().reshape(t.shape[0], 1, t.shape[-2], t.shape[-1]) if t.dim() == 4 else t.detach().cpu()
+
+
 class DspritesDataset:
     pass
 
@@ -84,12 +89,12 @@ def test_image_inference_vs_reference_golden_and_oracle(dev, golden_dir, kind):
     p = {k: torch.from_numpy(v) for k, v in state.items()}
     z = torch.from_numpy(g['codes'][:7].copy())
     with torch.no_grad():
-        close(model.decode(z.to(dev)), o_vae.decode(kind, p, z).numpy(), rtol=1e-4, atol=1e-4)
+        close(nchw(model.decode(z.to(dev))), o_vae.decode(kind, p, z).numpy(), rtol=1e-4, atol=1e-4)
         x = torch.from_numpy(batches[1][0])
         dist = model.encode(x.to(dev))
         mu, log_std = o_vae.encode(kind, p, x)
-        close(dist.loc, mu.numpy(), rtol=1e-4, atol=1e-4)
-        close(dist.scale, torch.exp(log_std).numpy(), rtol=1e-4, atol=1e-6)
+        close(dist.loc.cpu(), mu.numpy(), rtol=1e-4, atol=1e-4)
+        close(dist.scale.cpu(), torch.exp(log_std).numpy(), rtol=1e-4, atol=1e-6)
 
 
 class _FolkDataset:

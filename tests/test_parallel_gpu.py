@@ -27,7 +27,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_ranks(world, out, capacity, fused, overlap=True, worker='dp_worker.py', args=None):
+def _run_ranks(world, out, capacity, fused, overlap=False, worker='dp_worker.py', args=None):
     port = _free_port()
     env = dict(os.environ, ARVAE_DP_OVERLAP='1' if overlap else '0')
     tail = [str(capacity), str(int(fused)), str(B_TOTAL)] if args is None else [str(a) for a in args]
@@ -43,7 +43,7 @@ def _run_ranks(world, out, capacity, fused, overlap=True, worker='dp_worker.py',
             raise
         logs.append(o)
     for p, o in zip(procs, logs):
-        assert p.returncode == 0, o[-3000:]
+        assert p.returncode == 0, o[-6000:]
     return np.load(out)
 
 
