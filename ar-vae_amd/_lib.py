@@ -118,13 +118,15 @@ SIGNATURES = {
     'arvae_image_vae_ws_floats': (c_i64, [_P(ImageVaeDesc), c_i32, c_i64]),
     'arvae_image_vae_forward': (c_i32, [_P(ImageVaeDesc), c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, _P(c_vp), c_vp, c_vp,
                                         c_vp, c_i64, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'arvae_image_vae_finish': (c_i32, [_P(ImageVaeDesc), c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp, c_vp, c_vp,
+                                       c_vp, c_vp]),
     'arvae_image_vae_backward': (c_i32, [_P(ImageVaeDesc), c_i32, c_vp, c_vp, c_vp, c_vp, _P(c_vp), c_vp, c_vp, c_vp,
                                          c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_vp, c_vp]),
     'arvae_philox_normal': (c_i32, [c_vp, c_i64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp]),
     'arvae_philox_keep_mask': (c_i32, [c_vp, c_i64, c_f32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp]),
     'arvae_count_nonfinite': (c_i32, [c_vp, c_i64, c_vp, c_vp]),
     'arvae_count_out_of_range': (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
-    'arvae_adam_step': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_f64, c_f64, c_f64, c_f64, c_f32, c_vp]),
+    'arvae_adam_step': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_f64, c_f64, c_f64, c_f64, c_f32, c_i32, c_vp]),
 }
 
 _lock = threading.Lock()

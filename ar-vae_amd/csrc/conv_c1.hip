@@ -764,6 +764,9 @@ int conv_c1_up(const arvae_link_t *l, const float *lo, const float *wt, const fl
 
 // the same link with the trainer's reconstruction term fused in: logits -> out, per-workgroup (loss, correct) partial
 // sums -> partial[2 * nb], d loss / d logits -> dlogits (may be null); *nb_out = number of partial pairs
+// workgroups (= reconstruction partial pairs) of conv_c1_up_recon for this batch
+int conv_c1_up_recon_blocks(const arvae_link_t *l) { return up_c1_grid(l->n * (LO1 / TRU)); }
+
 int conv_c1_up_recon(const arvae_link_t *l, const float *lo, const float *wt, const float *bias, float *out, const float *x,
                      int dist, float *partial, float *dlogits, hipStream_t s, int *nb_out) {
     const int tiles = l->n * (LO1 / TRU), grid = up_c1_grid(tiles);

@@ -269,13 +269,16 @@ __global__ __launch_bounds__(256) void scale_by_scalar_kernel(const float *__res
 // =================================================================================================
 // Adam over the flat arena                                         (utils/trainer.py:31-34,170-174)
 // =================================================================================================
-__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const float *__restrict__ g,
+// ZERO_G: the gradient is consumed here, so the arena is cleared on the way out (2 MB more of stores in a kernel that moves
+// 14 MB) and the next step's zero_grad() has nothing left to do: one fill launch less per training step
+template <bool ZERO_G>
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float *__restrict__ g,
                                                     float *__restrict__ m, float *__restrict__ v, int64_t count,
                                                     float step_size, float inv_bc2_sqrt, float beta1, float beta2,
                                                     float omb1, float omb2, float eps, float gscale) {
     const int64_t n4 = count >> 2;
     float4 *p4 = reinterpret_cast<float4 *>(p);
-    const float4 *g4 = reinterpret_cast<const float4 *>(g);
+    float4 *g4 = reinterpret_cast<float4 *>(g);
     float4 *m4 = reinterpret_cast<float4 *>(m);
     float4 *v4 = reinterpret_cast<float4 *>(v);
     auto upd = [&](float &pp, float gg, float &mm, float &vv) {
@@ -292,10 +295,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, const 
         upd(pp.z, gg.z, mm.z, vv.z);
         upd(pp.w, gg.w, mm.w, vv.w);
         p4[i] = pp; m4[i] = mm; v4[i] = vv;
+        if (ZERO_G) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (blockIdx.x == 0 && threadIdx.x < (count & 3)) {
         const int64_t i = (n4 << 2) + threadIdx.x;
         upd(p[i], g[i], m[i], v[i]);
+        if (ZERO_G) g[i] = 0.f;
     }
 }
 
@@ -396,6 +401,8 @@ __global__ __launch_bounds__(1024) void vae_finish_kernel(VaeFinishArgs p) {
         o[6] = o[7] = 0.f;
     }
 }
+
+int recon_partial_blocks(int64_t count) { return grid_for(count, 8, RECON_MAX_BLOCKS); }
 
 // per-block partial sums of the reconstruction term (+ d/dlogits); returns the block count through *nb
 int recon_partials(const float *logits, const float *x, int64_t count, int64_t batch, int32_t dist, float *ws,
@@ -534,15 +541,21 @@ extern "C" int arvae_scale_by_scalar(const float *g, const float *x, int64_t cou
     return check_launch("scale_by_scalar");
 }
 
-extern "C" int arvae_adam_step(float *p, const float *g, float *m, float *v, int64_t count, int64_t step, double lr,
-                               double beta1, double beta2, double eps, float grad_scale, arvae_stream_t stream) {
+extern "C" int arvae_adam_step(float *p, float *g, float *m, float *v, int64_t count, int64_t step, double lr,
+                               double beta1, double beta2, double eps, float grad_scale, int32_t zero_grad,
+                               arvae_stream_t stream) {
     ARVAE_REQUIRE(p && g && m && v && count > 0 && step >= 1, "adam_step: bad argument");
     ARVAE_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
                   "adam_step: arenas must be 16-byte aligned");
     const double bc1 = 1.0 - pow(beta1, (double)step);
     const double bc2 = 1.0 - pow(beta2, (double)step);
-    ARVAE_LAUNCH(adam_kernel, dim3(grid_for(count, 4)), dim3(256), 0, as_stream(stream), p, g, m, v, count,
-                       (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), (float)beta1, (float)beta2, (float)(1.0 - beta1),
-                       (float)(1.0 - beta2), (float)eps, grad_scale);
+    if (zero_grad)
+        ARVAE_LAUNCH(adam_kernel<true>, dim3(grid_for(count, 4)), dim3(256), 0, as_stream(stream), p, g, m, v, count,
+                           (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), (float)beta1, (float)beta2, (float)(1.0 - beta1),
+                           (float)(1.0 - beta2), (float)eps, grad_scale);
+    else
+        ARVAE_LAUNCH(adam_kernel<false>, dim3(grid_for(count, 4)), dim3(256), 0, as_stream(stream), p, g, m, v, count,
+                           (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), (float)beta1, (float)beta2, (float)(1.0 - beta1),
+                           (float)(1.0 - beta2), (float)eps, grad_scale);
     return check_launch("adam_step");
 }

@@ -29,6 +29,8 @@ int conv_c1_up_recon(const arvae_link_t *l, const float *lo, const float *wt, co
 bool conv32_up_reg_fits(const arvae_link_t *l, const float *wprep);
 int conv32_up_reg(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, uint16_t *bits_out, float *out,
                   const float *wprep, const RegArgs &reg, int r, hipStream_t s);
+int conv_c1_up_recon_blocks(const arvae_link_t *l);
+int recon_partial_blocks(int64_t count);
 int64_t conv32_prep_floats();
 int conv32_weight_prep(const float *const *wts, float *const *preps, int n_layers, hipStream_t s);
 int conv32_weight_prep_with_mid(const float *const *wts, float *const *preps, int n_layers, const MidPrepArgs &mid, hipStream_t s);
@@ -38,7 +40,8 @@ int conv32_pair4(const arvae_link_t *l, bool up, const float *g, const float *x_
                  const uint16_t *gate_bits, float *d_in, const float *wprep, float *dwt, float *dbias, float *slab, hipStream_t s,
                  SlabJob *job);
 int conv32_wgrad_partial(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *dwt, float *dbias, int bias_mode,
-                         float *slab, hipStream_t s, SlabJob *job);
+                         float *slab, hipStream_t s, SlabJob *job, WgradStreamBatch *wdefer);
+int conv32_wgrad_stream_flush(WgradStreamBatch *b, hipStream_t s);
 bool conv_c1_pair_fits(const arvae_link_t *l);
 int conv_c1_pair(const arvae_link_t *l, const Operand &g_img, const float *wt, const float *gate, const uint16_t *gate_bits, float *d_lo,
                  const Operand &w_lo, float *dwt, float *dbias, int bias_mode, float *slab, hipStream_t s, SlabJob *job);
@@ -285,7 +288,8 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
                           const float *out, const uint8_t *mask, const float *g, bool g_is_pre, const float *gate,
                           float *d_in, bool *gated, float *slab, float *link_ws, DenseWgradBatch *defer, float *own_slab,
                           SlabReduceBatch *rdefer, arvae_stream_t st, const float *g_scale = nullptr,
-                          const uint16_t *gate_bits = nullptr, const float *wprep = nullptr, const GateOp *gate_op = nullptr) {
+                          const uint16_t *gate_bits = nullptr, const float *wprep = nullptr, const GateOp *gate_op = nullptr,
+                          WgradStreamBatch *wdefer = nullptr) {
     arvae_link_t lk = l.link;
     lk.n = n;
     arvae_operand_t gop = g_is_pre ? plain(g) : arvae_operand_t{g, out, mask, l.act};
@@ -374,7 +378,8 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
         (l.is_up ? hi_op : lo_op).scale = g_scale;                // only the conv_c1 kernels honour it (checked by the caller)
         const int bias_mode = db ? (l.is_up ? 2 : 1) : 0;
         SlabJob job;
-        const int rc = conv32_fits(&lk) ? conv32_wgrad_partial(&lk, lo_op, hi_op, dw, db, bias_mode, own_slab, whs, &job)
+        const int rc = conv32_fits(&lk) ? conv32_wgrad_partial(&lk, lo_op, hi_op, dw, db, bias_mode, own_slab, whs, &job,
+                                                               g_wgrad_stream == nullptr ? wdefer : nullptr)
                                         : conv_c1_wgrad_partial(&lk, lo_op, hi_op, dw, db, bias_mode, own_slab, whs, &job);
         if (rc) return rc;
         slab_reduce_defer(rdefer, job);
@@ -537,6 +542,7 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
     const int64_t pix = out_elems(m->dec[m->n_dec - 1], batch);
     if (!recon_fused)
         if (int rc = recon_partials(logits, x, pix, batch, m->recon_dist, ws + L.rec_ws, ws + L.dlogits, st, &nb)) return rc;
+    if (n_cols == -2) return ARVAE_OK;                       // the caller finishes the pass itself: arvae_image_vae_finish
     const int64_t nc = reg_here ? reg_args.n_cols : (int64_t)batch;
     if (reg_here && !reg_done)
         if (int rc = reg_partials(z, labels, batch, reg_args.zc, reg_args.lc, nc, m->zdim, ld_labels, reg_args.dims, m->n_reg, m->delta,
@@ -545,6 +551,39 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
     return vae_finish(ws + L.rec_ws, nb, batch, pix, mu, sigma, m->zdim, m->beta, capacity,
                       reg_here ? ws + L.reg_ws : nullptr, nc, m->zdim, m->reg_dims, m->n_reg, m->gamma, m->delta, reg_scale,
                       ws + L.dz_reg, ws + L.rec_out, ws + L.kld_out, ws + L.reg_out, scalars, st);
+}
+
+extern "C" int arvae_image_vae_finish(const arvae_image_vae_t *m, int32_t batch, const float *labels, int64_t ld_labels,
+                                      const float *capacity, const float *z_cols, const float *lab_cols, int64_t n_cols,
+                                      float reg_scale, float *ws, float *scalars, const float *mu, const float *sigma,
+                                      const float *z, arvae_stream_t stream) {
+    Layout L;
+    if (int rc = make_layout(m, batch, n_cols, L)) return rc;
+    ARVAE_REQUIRE(ws && scalars && mu && sigma && z, "image_vae_finish: null pointer");
+    ARVAE_REQUIRE(m->n_reg == 0 || (labels && z_cols && lab_cols && n_cols >= batch), "image_vae_finish: gathered columns needed");
+    hipStream_t st = as_stream(stream);
+    const arvae_layer_t &last = m->dec[m->n_dec - 1];
+    arvae_link_t lk = last.link;
+    lk.n = batch;
+    const int64_t pix = out_elems(last, batch);
+    // as arvae_image_vae_forward decides: the last layer's own reconstruction partials, or the stand-alone kernel's
+    const bool recon_fused = last.is_up && last.act == ARVAE_ACT_NONE && last.dropout == 0 && conv_c1_fits(&lk) &&
+                             arvae_recon_ws_floats(0) >= 2 * 1024;
+    const int nb = recon_fused ? conv_c1_up_recon_blocks(&lk) : recon_partial_blocks(pix);
+    const bool reg = m->n_reg > 0;
+    if (reg) {
+        RegDims rd;
+        for (int i = 0; i < 16; ++i) rd.d[i] = i < m->n_reg ? m->reg_dims[i] : 0;
+        for (int i = 0; i < m->n_reg; ++i)
+            ARVAE_REQUIRE(m->reg_dims[i] >= 0 && m->reg_dims[i] < m->zdim && m->reg_dims[i] < ld_labels,
+                          "image_vae_finish: reg dim %d outside z/labels", m->reg_dims[i]);
+        // the gathered columns index dims 0 .. zdim-1 / 0 .. ld_labels-1 like the local arrays (whole rows are gathered)
+        if (int rc = reg_partials(z, labels, batch, z_cols, lab_cols, n_cols, m->zdim, ld_labels, rd, m->n_reg, m->delta, ws + L.reg_ws, st))
+            return rc;
+    }
+    return vae_finish(ws + L.rec_ws, nb, batch, pix, mu, sigma, m->zdim, m->beta, capacity, reg ? ws + L.reg_ws : nullptr,
+                      reg ? n_cols : (int64_t)batch, m->zdim, m->reg_dims, m->n_reg, m->gamma, m->delta, reg_scale, ws + L.dz_reg,
+                      ws + L.rec_out, ws + L.kld_out, ws + L.reg_out, scalars, st);
 }
 
 extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batch, const float *params, float *grads,
@@ -568,6 +607,8 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
     defer.count = 0;
     SlabReduceBatch rdefer;
     rdefer.count = 0;
+    WgradStreamBatch wdefer;                             // row-stream weight gradients of the conv layers: one launch (conv32r.hip)
+    wdefer.count = 0;
     SideStream *side = profiling_active() ? nullptr : side_stream();
     struct WgradStreamScope {                            // clears the thread-local on every return path
         ~WgradStreamScope() { g_wgrad_stream = nullptr; }
@@ -648,7 +689,7 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
                                     i == m->n_dec - 1 ? first_scale : nullptr,
                                     (gate != nullptr && i > 0 && L.dec_bits[i - 1] >= 0)
                                         ? reinterpret_cast<const uint16_t *>(ws + L.dec_bits[i - 1]) : nullptr,
-                                    L.dec_wprep[i] >= 0 ? ws + L.dec_wprep[i] : nullptr, gate_op))
+                                    L.dec_wprep[i] >= 0 ? ws + L.dec_wprep[i] : nullptr, gate_op, &wdefer))
             return rc;
         pre = gated;
         if (heads_next_g == nullptr) cur = dst;
@@ -658,6 +699,7 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
     bool dec_marked = false, lin_marked = false;
     if (ms != nullptr && ms->dec_grads != nullptr && side == nullptr && defer.count == 0) {
         // (defer.count == 0: no Linear layer of the decoder went the per-layer way, so "decoder conv layers" is what is queued)
+        if (int rc = conv32_wgrad_stream_flush(&wdefer, st)) return rc;
         if (int rc = slab_reduce_flush(&rdefer, st)) return rc;
         mark(ms->dec_grads, st);
         dec_marked = true;
@@ -767,7 +809,7 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
                                     stream, nullptr,
                                     (gate != nullptr && i > 0 && L.enc_bits[i - 1] >= 0)
                                         ? reinterpret_cast<const uint16_t *>(ws + L.enc_bits[i - 1]) : nullptr,
-                                    L.enc_wprep[i] >= 0 ? ws + L.enc_wprep[i] : nullptr, gate_op))
+                                    L.enc_wprep[i] >= 0 ? ws + L.enc_wprep[i] : nullptr, gate_op, &wdefer))
             return rc;
         pre = gated;
         cur = dst;
@@ -780,6 +822,7 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
     static const bool tail_overlap = getenv("ARVAE_TAIL_OVERLAP") != nullptr;
     SideStream *tail = (side == nullptr && tail_overlap && !profiling_active() && defer.count > 0 && rdefer.count > 0)
                            ? side_stream(true) : nullptr;
+    if (int rc = conv32_wgrad_stream_flush(&wdefer, flush_stream)) return rc;
     if (tail != nullptr) {
         (void)hipEventRecord(tail->fork, st);
         (void)hipStreamWaitEvent(tail->s, tail->fork, 0);

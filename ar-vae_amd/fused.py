@@ -231,12 +231,15 @@ class _FusedStepFn(Function):
             external_reg = True
             labels = labels.contiguous()
             lab_all, lab_work = dp.gather_columns(labels, async_op=_async_label_gather(dp))   # in flight during the forward pass
+        # data parallel, capacity 0: the library finishes the pass itself once the columns are gathered (arvae_image_vae_finish:
+        # row-block regulariser + scalars, two launches) instead of three launches and a torch add from here
+        finish_in_lib = rowblock and not (dp is not None and capacity_nonzero)
         with ops._timed('image_vae_forward'):
             _lib.check(lib.arvae_image_vae_forward(
                 ctypes.byref(desc), b, ops._ptr(opt.param_arena), ops._ptr(x), ops._ptr(labels),
                 labels.shape[1] if labels is not None else 0, ops._ptr(eps), marr, ops._ptr(capacity), None, None,
-                -1 if external_reg else 0, reg_scale, ops._ptr(ws), ops._ptr(scalars), ops._ptr(mu), ops._ptr(sigma),
-                ops._ptr(z), ops._ptr(logits), ops._stream()), 'image_vae_forward')
+                -2 if finish_in_lib else (-1 if external_reg else 0), reg_scale, ops._ptr(ws), ops._ptr(scalars), ops._ptr(mu),
+                ops._ptr(sigma), ops._ptr(z), ops._ptr(logits), ops._stream()), 'image_vae_forward')
         ctx.dz_unit = None
         if dp is not None and capacity_nonzero:
             # beta*|KL - c| is not shard-linear for c != 0: use the global KL mean (one 4-byte all-reduce).  The backward
@@ -259,6 +262,15 @@ class _FusedStepFn(Function):
                 z_all = dp.gather_columns(z)
             if lab_work is not None:
                 lab_work.wait()
+        if finish_in_lib:
+            w = float(dp.world_size)
+            with ops._timed('image_vae_finish'):
+                _lib.check(lib.arvae_image_vae_finish(
+                    ctypes.byref(desc), b, ops._ptr(labels), labels.shape[1], ops._ptr(capacity), ops._ptr(z_all), ops._ptr(lab_all),
+                    z_all.shape[0], w, ops._ptr(ws), ops._ptr(scalars), ops._ptr(mu), ops._ptr(sigma), ops._ptr(z), ops._stream()),
+                    'image_vae_finish')
+            external_reg, reg_scale = False, w                   # backward: the pass's own regulariser gradient (reg_fused 1)
+        elif rowblock:
             n, n_all, r = b, z_all.shape[0], len(fused.reg_dims)
             ws_reg = torch.empty(int(lib.arvae_reg_loss_ws_floats(n, r)), device=dev, dtype=torch.float32)
             reg_out = torch.empty(1, device=dev, dtype=torch.float32)
@@ -300,6 +312,7 @@ class _FusedStepFn(Function):
             reg_mode, g_z = 2, ctx.dz_unit
         dz_extra = g_z.contiguous() if (ctx.external_reg and g_z is not None) else None
         ws = ctx.ws
+        opt.mark_dirty()                                         # gradients land in the arena without torch's accumulation
         with ops._timed('image_vae_backward'):
             _lib.check(lib.arvae_image_vae_backward(
                 ctypes.byref(fused.descriptor()), x.shape[0], ops._ptr(opt.param_arena), ops._ptr(opt.grad_arena),

@@ -151,6 +151,7 @@ class GraphedStep:
         variant = None if self.prob is None else bool(torch.rand(1).item() < self.prob)
         graph, out, terms = self.graphs[variant]
         graph.replay()
+        self.trainer.optimizer.mark_dirty()                      # the replayed backward wrote gradients (no autograd hooks ran)
         if terms:
             self.trainer.last_terms = terms                      # what log_loss_split reads: the replayed variant's terms
         return out

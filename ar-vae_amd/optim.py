@@ -5,7 +5,13 @@ Replaces torch.optim.Adam as constructed by the reference's Trainer
 decay, no amsgrad.  Parameters stay ordinary nn.Parameters (same state_dict);
 their storage is re-pointed into a contiguous arena, and `.grad` of each is a
 view into a matching gradient arena, so
-  zero_grad()  = one memset,
+  zero_grad()  = one memset -- or nothing: step() clears the gradient arena in the kernel that consumes it
+                 (`zero_grads_in_step`, on by default), and the zero_grad() that follows a step has nothing left to do
+                 unless a backward pass ran in between (every backward marks the arena dirty: the fused executor
+                 directly, torch's own accumulation through a post-accumulate hook on each parameter).
+                 NOTE for callers that look at gradients AFTER step(): they read zeros, where torch.optim.Adam leaves
+                 the last gradient in place (the reference never does: utils/trainer.py:126-147 reads nothing after
+                 step()); FlatAdam(..., zero_grads_in_step=False) keeps torch's behaviour.
   all-reduce   = one collective on `grad_arena`,
   step()       = one multi-tensor kernel (arvae_adam_step).
 """
@@ -15,13 +21,16 @@ from . import ops
 
 
 class FlatAdam:
-    def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, zero_grads_in_step=True):
         self.params = [p for p in params]
         if not self.params:
             raise ValueError('optimizer got an empty parameter list')
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         self.step_count = 0
         self.grad_scale = 1.0          # set to 1/world_size when gradients are SUM all-reduced
+        self.zero_grads_in_step = bool(zero_grads_in_step)
+        self._arena_clean = False      # the gradient arena is all zeros (set by step(), cleared by any backward pass)
+        self._hooked = False
         self.param_arena = self.grad_arena = self.exp_avg = self.exp_avg_sq = None
         self._offsets = []
 
@@ -56,6 +65,18 @@ class FlatAdam:
                     self.exp_avg[off:off + n].copy_(old_m[old_off[i]:old_off[i] + n])
                     self.exp_avg_sq[off:off + n].copy_(old_v[old_off[i]:old_off[i] + n])
         self.param_arena, self.grad_arena, self._offsets = arena, grads, offsets
+        self._arena_clean = True
+        if not self._hooked:           # torch's own gradient accumulation (per-layer autograd path) dirties the arena
+            for p in self.params:
+                p.register_post_accumulate_grad_hook(self._on_accumulate)
+            self._hooked = True
+
+    def _on_accumulate(self, _param):
+        self._arena_clean = False
+
+    def mark_dirty(self):
+        """a backward pass wrote into the gradient arena without going through torch's accumulation (fused.py)"""
+        self._arena_clean = False
 
     def ensure_arena(self):
         if not self._arena_valid():
@@ -65,7 +86,9 @@ class FlatAdam:
     # -- torch.optim.Optimizer surface used by the trainer --------------------------------------
     def zero_grad(self, set_to_none=False):
         self.ensure_arena()
-        self.grad_arena.zero_()
+        if not (self._arena_clean and not torch.cuda.is_current_stream_capturing()):
+            self.grad_arena.zero_()    # (a step being captured always records the memset: replays must not depend on what
+        self._arena_clean = False      # ran before them; and whoever follows may write gradients without telling us)
         for p, off in zip(self.params, self._offsets):     # re-attach views dropped by zero_grad(None) users
             if p.grad is None or p.grad.data_ptr() != self.grad_arena.data_ptr() + 4 * off:
                 p.grad = self.grad_arena[off:off + p.numel()].view(p.shape)
@@ -79,7 +102,8 @@ class FlatAdam:
                 p.grad = self.grad_arena[off:off + p.numel()].view(p.shape)
         self.step_count += 1
         ops.adam_step(self.param_arena, self.grad_arena, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
-                      self.betas[0], self.betas[1], self.eps, self.grad_scale)
+                      self.betas[0], self.betas[1], self.eps, self.grad_scale, zero_grad=self.zero_grads_in_step)
+        self._arena_clean = self.zero_grads_in_step
 
     def state_dict(self):
         return {'step': self.step_count, 'lr': self.lr, 'betas': self.betas, 'eps': self.eps,

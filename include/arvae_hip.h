@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ARVAE_ABI_VERSION 5   /* 5: arvae_image_vae_t.milestones (events the executors record for the data-parallel caller's collectives); 4: arvae_philox_* and in-kernel eps (arvae_image_vae_t.rng_*), arvae_tick_free_run_supported, caller workspace for arvae_link_down/up (arvae_link_ws_floats); 3: arvae_gru_seq_*, embed_bwd workspace; 2: arvae_image_vae_backward reg_fused == 2 (unit regulariser gradient in dz_extra) */
+#define ARVAE_ABI_VERSION 5   /* 5: arvae_adam_step(zero_grad), arvae_image_vae_finish, arvae_image_vae_t.milestones (events the executors record for the data-parallel caller's collectives); 4: arvae_philox_* and in-kernel eps (arvae_image_vae_t.rng_*), arvae_tick_free_run_supported, caller workspace for arvae_link_down/up (arvae_link_ws_floats); 3: arvae_gru_seq_*, embed_bwd workspace; 2: arvae_image_vae_backward reg_fused == 2 (unit regulariser gradient in dz_extra) */
 
 #define ARVAE_OK 0
 #define ARVAE_E_INVALID (-1)  /* bad argument (null pointer, size out of range, unsupported shape) */
@@ -206,10 +206,11 @@ int arvae_scale_by_scalar(const float *g, const float *x, int64_t count, float *
  *   m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;  p -= (lr/(1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
  * Hyper-parameters are doubles (as torch holds them: 1-beta2 is formed in double, then rounded).
  * `step` is the 1-based step number t.  grad_scale multiplies g first (1/world_size after a SUM
- * all-reduce; 1 otherwise).
+ * all-reduce; 1 otherwise).  zero_grad != 0: g is cleared once it has been consumed, i.e. the update and the NEXT
+ * step's Trainer.zero_grad() (utils/trainer.py:136) are one kernel.
  * ------------------------------------------------------------------------------------------------ */
-int arvae_adam_step(float *p, const float *g, float *m, float *v, int64_t count, int64_t step, double lr,
-                    double beta1, double beta2, double eps, float grad_scale, arvae_stream_t stream);
+int arvae_adam_step(float *p, float *g, float *m, float *v, int64_t count, int64_t step, double lr, double beta1,
+                    double beta2, double eps, float grad_scale, int32_t zero_grad, arvae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * MeasureVAE building blocks (GRU encoder / hierarchical GRU decoder over 24-tick measures).
@@ -393,6 +394,8 @@ int64_t arvae_image_vae_ws_floats(const arvae_image_vae_t *model, int32_t batch,
  * masks: HOST array with one device uint8 keep-mask per dropout layer (encoder first), or NULL (eval).
  * z_cols/lab_cols [n_cols, ...]: all-gathered columns for the data-parallel row-block regularisation
  * (NULL: this batch is the whole batch); they index dims 0..n_reg-1 compactly when given.
+ * n_cols: 0 = the regulariser runs on this batch alone; > 0 with z_cols/lab_cols; -1 = no regulariser in this call (the
+ * caller evaluates it on z); -2 = neither the regulariser nor the scalars: arvae_image_vae_finish completes the pass.
  * reg_scale multiplies the regularisation term (world size under data parallelism, else 1).
  * Outputs: scalars[ARVAE_VAE_NSCALARS], mu/sigma/z [batch, zdim], logits [batch, H, W, 1].
  * Everything the backward pass needs stays in ws. */
@@ -401,6 +404,16 @@ int arvae_image_vae_forward(const arvae_image_vae_t *model, int32_t batch, const
                             const uint8_t *const *masks, const float *capacity, const float *z_cols,
                             const float *lab_cols, int64_t n_cols, float reg_scale, float *ws, float *scalars,
                             float *mu, float *sigma, float *z, float *logits, arvae_stream_t stream);
+
+/* Data-parallel completion of a forward pass that was called with n_cols == -2 ("the caller finishes"): the regulariser of
+ * this rank's rows against the columns GATHERED from every rank (whole rows: z_cols [n_cols, zdim], lab_cols [n_cols,
+ * ld_labels], n_cols = world size x batch), then the pass's scalars exactly as the forward pass
+ * would have written them: scalars[ARVAE_VAE_REG] = reg_scale x the row-block term.  The backward pass follows with
+ * reg_fused == 1 and the same reg_scale.  (The reference evaluates the term on one process: utils/trainer.py:369-403.) */
+int arvae_image_vae_finish(const arvae_image_vae_t *model, int32_t batch, const float *labels, int64_t ld_labels,
+                           const float *capacity, const float *z_cols, const float *lab_cols, int64_t n_cols,
+                           float reg_scale, float *ws, float *scalars, const float *mu, const float *sigma, const float *z,
+                           arvae_stream_t stream);
 
 /* Backward of scalars[ARVAE_VAE_LOSS] times g_loss[0] (device scalar): parameter gradients ACCUMULATE into
  * grads at the layers' offsets.  Must follow arvae_image_vae_forward on the same ws, with the same

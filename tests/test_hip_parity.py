@@ -1511,3 +1511,32 @@ def test_gradient_error_budget_vs_float64(dev):
     for k in ('recons', 'dist', 'reg', 'loss'):
         close(got['loss'] if k == 'loss' else got['terms'][k], ref64['terms'][k], rtol=1e-5)
     print(f'worst HIP / fp32-CPU error ratio vs float64: {worst:.2f}')
+
+
+def test_adam_clears_the_gradient_arena_and_zero_grad_knows(dev):
+    """FlatAdam.step() clears the gradient arena in the kernel that consumes it, so the zero_grad() of the next step
+    launches nothing -- unless a backward pass ran in between (fused executor: mark_dirty; torch's own accumulation: the
+    post-accumulate hooks), and never while a step is being captured.  The update itself is the plain kernel's."""
+    from arvae_amd.optim import FlatAdam
+    torch.manual_seed(0)
+    results = []
+    for zero_in_step in (True, False):
+        params = [torch.nn.Parameter(torch.linspace(-1, 1, n, device=dev).clone()) for n in (37, 1024, 5)]
+        opt = FlatAdam(params, lr=1e-3, zero_grads_in_step=zero_in_step)
+        for step in range(3):
+            opt.zero_grad()
+            assert float(opt.grad_arena.abs().max()) == 0.0
+            loss = sum((p * p).sum() * (i + 1) for i, p in enumerate(params))
+            loss.backward()                                  # torch accumulates into the arena views: hooks mark it dirty
+            assert not opt._arena_clean and float(opt.grad_arena.abs().max()) > 0.0
+            opt.step()
+            assert opt._arena_clean == zero_in_step
+            assert (float(opt.grad_arena.abs().max()) == 0.0) == zero_in_step
+        results.append(torch.cat([p.detach().reshape(-1) for p in params]).clone())
+        # a backward pass between step() and zero_grad(): the arena is dirty again and zero_grad() must clear it
+        loss = sum((p * p).sum() for p in params)
+        loss.backward()
+        assert not opt._arena_clean
+        opt.zero_grad()
+        assert float(opt.grad_arena.abs().max()) == 0.0
+    assert torch.equal(results[0], results[1])
