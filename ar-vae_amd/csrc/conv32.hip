@@ -1710,19 +1710,10 @@ template <int LO> static int launch_wgrad_x(const arvae_link_t *l, const Operand
 
 // per-workgroup partial sums into `slab`; the returned job describes the reduction that finishes the layer
 // bias_mode: 0 none, 1 dbias[clo] += sum lo, 2 dbias[chi] += sum hi
-bool conv32_wgrad_stream_defer(WgradStreamBatch *b, const arvae_link_t *l, const Operand &lo, const Operand &hi, float *slab,
-                               int bias_mode);
-
-// wdefer: the layer's launch may be queued there instead (conv32r.hip, wgrad32r_batch_kernel); the caller flushes the queue
-// before it reduces the slabs
 int conv32_wgrad_partial(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *dwt, float *dbias, int bias_mode,
-                         float *slab, hipStream_t s, SlabJob *job, WgradStreamBatch *wdefer) {
+                         float *slab, hipStream_t s, SlabJob *job) {
     const int grid = conv32_wgrad_groups(l);
     int rc;
-    if (!wgrad_fp32_mfma() && conv32_wgrad_stream_fits(l) && conv32_wgrad_stream_defer(wdefer, l, lo, hi, slab, bias_mode)) {
-        *job = SlabJob{slab, dwt, bias_mode ? dbias : nullptr, grid, SLAB_C32, bias_mode};
-        return ARVAE_OK;
-    }
     if (!wgrad_fp32_mfma() && conv32_wgrad_stream_fits(l)) {
         rc = conv32_wgrad_stream(l, lo, hi, slab, bias_mode, s);
         *job = SlabJob{slab, dwt, bias_mode ? dbias : nullptr, grid, SLAB_C32, bias_mode};
@@ -1795,7 +1786,7 @@ int conv32_pair4(const arvae_link_t *l, bool up, const float *g, const float *x_
 int conv32_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *dwt, float *dbias, int bias_mode,
                  float *slab, hipStream_t s) {
     SlabJob job;
-    if (int rc = conv32_wgrad_partial(l, lo, hi, dwt, dbias, bias_mode, slab, s, &job, nullptr)) return rc;
+    if (int rc = conv32_wgrad_partial(l, lo, hi, dwt, dbias, bias_mode, slab, s, &job)) return rc;
     return slab_reduce(job, s);
 }
 

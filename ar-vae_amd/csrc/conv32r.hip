@@ -53,8 +53,7 @@ __device__ unsigned long long g_wgr_stamps[256 * 2 * 64 * 2];
 
 constexpr int WGR_DEPTH = 3;                             // steps of global loads in flight per producer thread
 
-// BID: the workgroup's index in the job's grid (a stand-alone launch passes blockIdx.x; the batched launch below runs several
-// jobs one after the other in every workgroup)
+// BID: the workgroup's index in the grid
 template <int LO, int BIAS>
 __device__ __forceinline__ void wgrad32r_body(const float *__restrict__ lo, const float *__restrict__ hi, float *__restrict__ slab,
                                               int n_img, int total_steps, int steps_per_wg, const int BID) {
@@ -351,28 +350,6 @@ __global__ __launch_bounds__(512, 2) void wgrad32r_kernel(const float *__restric
     wgrad32r_body<LO, BIAS>(lo, hi, slab, n_img, total_steps, steps_per_wg, blockIdx.x);
 }
 
-// ---- several layers' weight gradients in ONE launch ----------------------------------------------------------------------
-// The weight gradients of a backward pass are independent of its data-gradient chain and of each other (every layer's
-// upstream gradient keeps its own buffer, plan.hip): queued while the chain runs and launched together at the end of the pass,
-// every workgroup walks its share of layer after layer.  What that removes is each launch's fixed part -- dispatch, the cold
-// first round trip with the chip idle behind it, the tail where the last workgroups finish alone -- which is two thirds of an
-// 8x8 layer's 14.5 us (3 us of MFMA issue).  Same per-layer step ranges, slabs and summation order as the stand-alone
-// launches: bit-identical results.
-__global__ __launch_bounds__(512, 2) void wgrad32r_batch_kernel(WgradStreamBatch b) {
-    for (int j = 0; j < b.count; ++j) {
-        const WgradStreamJob &q = b.job[j];
-        if ((int)blockIdx.x < q.grid) {
-            switch (q.kind) {
-                case 0: wgrad32r_body<16, 1>(q.lo, q.hi, q.slab, q.n_img, q.total_steps, q.steps_per_wg, blockIdx.x); break;
-                case 1: wgrad32r_body<16, 2>(q.lo, q.hi, q.slab, q.n_img, q.total_steps, q.steps_per_wg, blockIdx.x); break;
-                case 2: wgrad32r_body<8, 1>(q.lo, q.hi, q.slab, q.n_img, q.total_steps, q.steps_per_wg, blockIdx.x); break;
-                default: wgrad32r_body<8, 2>(q.lo, q.hi, q.slab, q.n_img, q.total_steps, q.steps_per_wg, blockIdx.x); break;
-            }
-        }
-        __syncthreads();                                     // the job's last LDS reads (bias sums) precede the next job's writes
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -428,34 +405,6 @@ template <int LO> static int launch_stream(const arvae_link_t *l, const float *l
 
 int conv32_wgrad_stream(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *slab, int bias_mode, hipStream_t s) {
     return l->lh == 16 ? launch_stream<16>(l, lo.v, hi.v, slab, bias_mode, s) : launch_stream<8>(l, lo.v, hi.v, slab, bias_mode, s);
-}
-
-// queue a layer for the batched launch: false when it is not one of the batch kernel's cases or the batch is full
-bool conv32_wgrad_stream_defer(WgradStreamBatch *b, const arvae_link_t *l, const Operand &lo, const Operand &hi, float *slab,
-                               int bias_mode) {
-    static const bool off = getenv("ARVAE_NO_WGRAD_BATCH") != nullptr;      // diagnostic: one launch per layer
-    if (off || b == nullptr || b->count >= WGRAD_BATCH_MAX || !conv32_wgrad_stream_fits(l) || (bias_mode != 1 && bias_mode != 2) ||
-        lo.y != nullptr || hi.y != nullptr || lo.scale != nullptr || hi.scale != nullptr)
-        return false;
-    int total, spw, grid;
-    stream_geometry(l, total, spw, grid);
-    b->job[b->count++] = WgradStreamJob{lo.v, hi.v, slab, l->n, total, spw, grid, (l->lh == 16 ? 0 : 2) + (bias_mode - 1)};
-    return true;
-}
-
-int conv32_wgrad_stream_flush(WgradStreamBatch *b, hipStream_t s) {
-    if (b == nullptr || b->count == 0) return ARVAE_OK;
-    constexpr int LDS = (RowStream<16>::LDS_DW > RowStream<8>::LDS_DW ? RowStream<16>::LDS_DW : RowStream<8>::LDS_DW) * 4;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void *)wgrad32r_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr = true;
-    }
-    int grid = 0;
-    for (int j = 0; j < b->count; ++j) grid = b->job[j].grid > grid ? b->job[j].grid : grid;
-    ARVAE_LAUNCH(wgrad32r_batch_kernel, dim3(grid), dim3(512), LDS, s, *b);
-    b->count = 0;
-    return check_launch("wgrad32_batch_kernel");
 }
 
 }  // namespace arvae

@@ -40,8 +40,7 @@ int conv32_pair4(const arvae_link_t *l, bool up, const float *g, const float *x_
                  const uint16_t *gate_bits, float *d_in, const float *wprep, float *dwt, float *dbias, float *slab, hipStream_t s,
                  SlabJob *job);
 int conv32_wgrad_partial(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *dwt, float *dbias, int bias_mode,
-                         float *slab, hipStream_t s, SlabJob *job, WgradStreamBatch *wdefer);
-int conv32_wgrad_stream_flush(WgradStreamBatch *b, hipStream_t s);
+                         float *slab, hipStream_t s, SlabJob *job);
 bool conv_c1_pair_fits(const arvae_link_t *l);
 int conv_c1_pair(const arvae_link_t *l, const Operand &g_img, const float *wt, const float *gate, const uint16_t *gate_bits, float *d_lo,
                  const Operand &w_lo, float *dwt, float *dbias, int bias_mode, float *slab, hipStream_t s, SlabJob *job);
@@ -288,8 +287,7 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
                           const float *out, const uint8_t *mask, const float *g, bool g_is_pre, const float *gate,
                           float *d_in, bool *gated, float *slab, float *link_ws, DenseWgradBatch *defer, float *own_slab,
                           SlabReduceBatch *rdefer, arvae_stream_t st, const float *g_scale = nullptr,
-                          const uint16_t *gate_bits = nullptr, const float *wprep = nullptr, const GateOp *gate_op = nullptr,
-                          WgradStreamBatch *wdefer = nullptr) {
+                          const uint16_t *gate_bits = nullptr, const float *wprep = nullptr, const GateOp *gate_op = nullptr) {
     arvae_link_t lk = l.link;
     lk.n = n;
     arvae_operand_t gop = g_is_pre ? plain(g) : arvae_operand_t{g, out, mask, l.act};
@@ -378,8 +376,7 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
         (l.is_up ? hi_op : lo_op).scale = g_scale;                // only the conv_c1 kernels honour it (checked by the caller)
         const int bias_mode = db ? (l.is_up ? 2 : 1) : 0;
         SlabJob job;
-        const int rc = conv32_fits(&lk) ? conv32_wgrad_partial(&lk, lo_op, hi_op, dw, db, bias_mode, own_slab, whs, &job,
-                                                               g_wgrad_stream == nullptr ? wdefer : nullptr)
+        const int rc = conv32_fits(&lk) ? conv32_wgrad_partial(&lk, lo_op, hi_op, dw, db, bias_mode, own_slab, whs, &job)
                                         : conv_c1_wgrad_partial(&lk, lo_op, hi_op, dw, db, bias_mode, own_slab, whs, &job);
         if (rc) return rc;
         slab_reduce_defer(rdefer, job);
@@ -607,8 +604,6 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
     defer.count = 0;
     SlabReduceBatch rdefer;
     rdefer.count = 0;
-    WgradStreamBatch wdefer;                             // row-stream weight gradients of the conv layers: one launch (conv32r.hip)
-    wdefer.count = 0;
     SideStream *side = profiling_active() ? nullptr : side_stream();
     struct WgradStreamScope {                            // clears the thread-local on every return path
         ~WgradStreamScope() { g_wgrad_stream = nullptr; }
@@ -689,7 +684,7 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
                                     i == m->n_dec - 1 ? first_scale : nullptr,
                                     (gate != nullptr && i > 0 && L.dec_bits[i - 1] >= 0)
                                         ? reinterpret_cast<const uint16_t *>(ws + L.dec_bits[i - 1]) : nullptr,
-                                    L.dec_wprep[i] >= 0 ? ws + L.dec_wprep[i] : nullptr, gate_op, &wdefer))
+                                    L.dec_wprep[i] >= 0 ? ws + L.dec_wprep[i] : nullptr, gate_op))
             return rc;
         pre = gated;
         if (heads_next_g == nullptr) cur = dst;
@@ -699,7 +694,6 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
     bool dec_marked = false, lin_marked = false;
     if (ms != nullptr && ms->dec_grads != nullptr && side == nullptr && defer.count == 0) {
         // (defer.count == 0: no Linear layer of the decoder went the per-layer way, so "decoder conv layers" is what is queued)
-        if (int rc = conv32_wgrad_stream_flush(&wdefer, st)) return rc;
         if (int rc = slab_reduce_flush(&rdefer, st)) return rc;
         mark(ms->dec_grads, st);
         dec_marked = true;
@@ -809,7 +803,7 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
                                     stream, nullptr,
                                     (gate != nullptr && i > 0 && L.enc_bits[i - 1] >= 0)
                                         ? reinterpret_cast<const uint16_t *>(ws + L.enc_bits[i - 1]) : nullptr,
-                                    L.enc_wprep[i] >= 0 ? ws + L.enc_wprep[i] : nullptr, gate_op, &wdefer))
+                                    L.enc_wprep[i] >= 0 ? ws + L.enc_wprep[i] : nullptr, gate_op))
             return rc;
         pre = gated;
         cur = dst;
@@ -822,7 +816,6 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
     static const bool tail_overlap = getenv("ARVAE_TAIL_OVERLAP") != nullptr;
     SideStream *tail = (side == nullptr && tail_overlap && !profiling_active() && defer.count > 0 && rdefer.count > 0)
                            ? side_stream(true) : nullptr;
-    if (int rc = conv32_wgrad_stream_flush(&wdefer, flush_stream)) return rc;
     if (tail != nullptr) {
         (void)hipEventRecord(tail->fork, st);
         (void)hipStreamWaitEvent(tail->s, tail->fork, 0);

@@ -22,18 +22,6 @@ struct SlabReduceBatch {
     SlabJob job[SLAB_BATCH_MAX];
 };
 
-// Row-stream weight gradients of the 32-channel conv layers (conv32r.hip) queued for ONE launch at the end of a backward pass
-struct WgradStreamJob {
-    const float *lo, *hi;
-    float *slab;
-    int n_img, total_steps, steps_per_wg, grid, kind;        // kind = (LO == 16 ? 0 : 2) + (BIAS - 1): the four combinations a
-};                                                           // conv stack produces (BIAS 1: forward DOWN layer, 2: forward UP)
-constexpr int WGRAD_BATCH_MAX = 6;
-struct WgradStreamBatch {
-    int count;
-    WgradStreamJob job[WGRAD_BATCH_MAX];
-};
-
 // run one job now / queue it / run everything queued
 int slab_reduce(const SlabJob &job, hipStream_t s);
 bool slab_reduce_defer(SlabReduceBatch *b, const SlabJob &job);

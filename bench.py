@@ -68,8 +68,6 @@ KERNEL_WORK = {
     # a layer's data gradient and weight gradient in one launch: the upstream gradient is read by both halves
     'pair4(down32 + wgrad32)': (2 * 262_144, 4 * (2 * 2048 + 2 * 512)), 'pair4(up32 + wgrad32)': (2 * 262_144, 4 * (2 * 512 + 2 * 2048)),
     'pair_c1(down_c1 + wgrad_c1)': (2 * 524_288, 4 * (2 * 4096 + 2 * 32768)),
-    # the four row-stream weight gradients of the 16x16 and 8x8 layers queued into one launch (conv32r.hip)
-    'wgrad32_batch_kernel': (2 * 4_194_304 + 2 * 1_048_576, 2 * 4 * (8192 + 32768) + 2 * 4 * (2048 + 8192)),
     # the first encoder layer with the step's weight preparation riding in its grid; the decoder's first convolution with
     # the regulariser's workgroups riding in its grid
     'down_c1_kernel(+ weight prep)': (524_288, 4 * (4096 + 32768), 8_000_000), 'up32_kernel<4>(+ reg_loss)': (262_144, 4 * (512 + 2048)),
@@ -96,7 +94,7 @@ ROCPROF_NAMES = {
     'up32_kernel<4>': ['arvae::up32x_kernel<4, 1, 32>', 'arvae::up32x_kernel<4, 3, 32>'],
     'down32_kernel<4>': ['arvae::down32s_kernel<4, 1>', 'arvae::down32s_kernel<4, 2>'],
     'pair4(down32 + wgrad32)': ['arvae::pair4_down_kernel<2, 2>'], 'pair4(up32 + wgrad32)': ['arvae::pair4_up_kernel<3, 1>'],
-    'pair_c1(down_c1 + wgrad_c1)': ['arvae::pair_c1_kernel<1>'], 'wgrad32_batch_kernel': ['arvae::wgrad32r_batch_kernel'],
+    'pair_c1(down_c1 + wgrad_c1)': ['arvae::pair_c1_kernel<1>'],
     'down_c1_kernel(+ weight prep)': ['arvae::down_c1s_prep_kernel'], 'up32_kernel<4>(+ reg_loss)': ['arvae::up32x_reg_kernel<1>'],
     'down_c1_kernel': ['arvae::down_c1s_kernel<0>', 'arvae::down_c1s_kernel<1>'], 'wgrad_c1_kernel': ['arvae::wgrad_c1s_kernel'],
     'up_c1_kernel(recon)': ['arvae::up_c1_kernel<0, true>'],

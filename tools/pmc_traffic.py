@@ -19,8 +19,6 @@ def label(kernel_name):
         return f'{m.group(1)}_kernel<{m.group(2)}>'
     if n.startswith(('down_c1s_kernel', 'wgrad_c1s_kernel')):           # streaming forms: same label as the tiled kernels
         return n.split('<')[0].replace('c1s', 'c1')
-    if n.startswith('wgrad32r_batch_kernel'):
-        return 'wgrad32_batch_kernel'
     if n.startswith('down_c1s_prep_kernel'):
         return 'down_c1_kernel(+ weight prep)'
     if n.startswith('up32x_reg_kernel'):
