@@ -3,12 +3,12 @@
 // carry 85 % of the training step's FLOPs.  Same math and C-ABI as the
 // generic gather-GEMM (link_gemm.hip); arvae_link_down/up/wgrad dispatch here when the geometry fits.
 //
-// Two generations of kernels live here, same tiling ideas, selected at run time:
-//   *x kernels (default): the bf16 MFMA at fp32 accuracy.  Every fp32 operand is split into three bf16 terms when it
-//       enters LDS (weights: once per step, conv32_weight_prep) and every multiply-add is six partial products on
-//       v_mfma_f32_32x32x16_bf16 with fp32 accumulation: the result is within one fp32 rounding of the fp32 MFMA's
-//       at 2.7x fewer MFMA cycles, and the bf16 MFMA leaves the vector ALU free for the splitting.
-//   fp32 kernels (ARVAE_CONV32_FP32=1, and the K-split small-tile Down of the 4x4 layers): v_mfma_f32_32x32x2_f32.
+// The kernels run the bf16 MFMA at fp32 accuracy: every fp32 operand is split into three bf16 terms when it enters LDS
+// (weights: once per step, conv32_weight_prep) and every multiply-add is six partial products on v_mfma_f32_32x32x16_bf16
+// with fp32 accumulation: the result is within one fp32 rounding of the fp32 MFMA's at 2.7x fewer MFMA cycles, and the bf16
+// MFMA leaves the vector ALU free for the splitting.  (The first generation -- the same tilings on v_mfma_f32_32x32x2_f32,
+// 45-50 us per 16x16-layer launch against 29-33 -- and a two-term experiment were removed in round 3; the K-split small-tile
+// Down kernel of the 4x4 layers, down32s, is the one fp32-MFMA kernel left.)
 //
 // Design rules (measured, profiles/r1_down32_phase_stamps.txt, tools/stamp_conv32.py): on gfx950 the fp32 MFMA
 // (64 cycles each, runs at the fp32 vector rate) does NOT co-execute with VALU work of another wave on the same
@@ -280,242 +280,7 @@ constexpr int WROW_UP = 17;                      // LDS floats per (clo, chi) ro
 constexpr int WSTAGE_DOWN = C32 * WROW_DOWN;     // floats of LDS needed while staging
 constexpr int WSTAGE_UP = C32 * C32 * WROW_UP;
 
-// ================================================================================================
-// Down: lo[n,ly,lx,clo] = ep( sum_{ky,kx,chi} hi[n,2ly-1+ky,2lx-1+kx,chi] * wt[clo][chi][ky][kx] )
-// wave w owns lo pixels [32w, 32w+32) of the tile over the full K = 512.
-// ================================================================================================
-template <int LO, int MODE>
-__global__ __launch_bounds__(256, 1) void down32_kernel(const float *__restrict__ hi, const float *__restrict__ wt, Ep32 ep, int n_img,
-                                                         int n_tiles) {
-    using PL = PatchLoader<LO, 2>;
-    constexpr int PC = PL::PC, PR = PL::PR;
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // max(PL::PATCH_FLOATS, WSTAGE_DOWN)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int half = lane >> 5, rc = lane & 31;
-    STAMP(0);
 
-    PL pl;                                                       // first tile's loads fly while the weights are staged
-    pl.init(hi, n_img);
-    int img0, r0;
-    tile_origin<LO>(blockIdx.x, img0, r0);
-    pl.set_tile(img0, r0, blockIdx.x < n_tiles);
-    pl.issue_all();
-
-    // w[tap][chunk][t] = wt[clo = rc][chi = chunk*8 + half*4 + t][ky][kx], tap = ky*4 + kx; staged through LDS
-    float w[16][4][4];
-    {
-        float4 v[16];
-        load_weights(wt, v);
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int idx4 = threadIdx.x + it * 256;             // (clo, chi, tap/4) = (idx4 >> 7, (idx4 >> 2) & 31, idx4 & 3)
-            *reinterpret_cast<float4 *>(lds + (idx4 >> 7) * WROW_DOWN + (idx4 & 127) * 4) = v[it];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int ch = 0; ch < 4; ++ch)
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float4 q = *reinterpret_cast<const float4 *>(lds + rc * WROW_DOWN + (ch * 8 + half * 4 + t) * 16 + k * 4);
-                    w[4 * k][ch][t] = q.x; w[4 * k + 1][ch][t] = q.y; w[4 * k + 2][ch][t] = q.z; w[4 * k + 3][ch][t] = q.w;
-                }
-    }
-
-    int img, r, c;
-    tile_pixel<LO>(wave * 32 + rc, img, r, c);
-    const int aoff = ((img * PR + 2 * r) * PC + 2 * c) * PS + half * 4;      // + (ky*PC + kx)*PS + chunk*8
-    float4 b4[4];
-    load_bias4(ep.bias, half, b4);
-    const int64_t out_bytes = (int64_t)n_img * LO * LO * PIXB;
-    const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(ep.out, out_bytes);
-    const __amdgpu_buffer_rsrc_t rs_gate = make_rsrc(MODE == EP_GATE_F ? ep.gate : ep.out, out_bytes);
-    const bool want_bits = MODE == EP_RELU && ep.bits_out != nullptr;
-    const __amdgpu_buffer_rsrc_t rs_bits =
-        make_rsrc(MODE == EP_GATE_B ? (const void *)ep.gate_bits : want_bits ? (const void *)ep.bits_out : (const void *)ep.out,
-                  (int64_t)n_img * LO * LO * 4);
-    const unsigned out_lane = (unsigned)((wave * 32 + rc) * PIXB + half * 16);      // + tile start + g*32
-
-    STAMP(1);
-    float4 dummy;
-    STAMP(2);
-    int sidx = 3;
-    (void)sidx;
-
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        tile_origin<LO>(tile, img0, r0);
-        STAMP(sidx);
-        __syncthreads();                                         // previous tile's (or the weights') LDS reads are done
-        STAMP(sidx + 1);
-        pl.template commit<false>(lds, dummy);
-        __syncthreads();
-        STAMP(sidx + 2);
-        {                                                        // next tile's loads are spread between this tile's MFMAs
-            int ni, nr;
-            tile_origin<LO>(tile + gridDim.x, ni, nr);
-            pl.set_tile(ni, nr, tile + gridDim.x < n_tiles);
-        }
-        STAMP(sidx + 3);
-
-        f32x16 acc, acc1;                                        // two dependency chains: even / odd taps
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = acc1[i] = 0.f;
-        float4 a[2][4];
-#pragma unroll
-        for (int ch = 0; ch < 4; ++ch) a[0][ch] = *reinterpret_cast<const float4 *>(lds + aoff + ch * 8);
-        static_for<0, 16>([&](auto tc) __attribute__((always_inline)) {
-            constexpr int tap = decltype(tc)::value;
-            if constexpr (tap + 1 < 16) {                        // next tap's operands are in flight during these 16 MFMAs
-                constexpr int ky = (tap + 1) >> 2, kx = (tap + 1) & 3;
-#pragma unroll
-                for (int ch = 0; ch < 4; ++ch)
-                    a[(tap + 1) & 1][ch] = *reinterpret_cast<const float4 *>(lds + aoff + (ky * PC + kx) * PS + ch * 8);
-            }
-            pl.template issue_step<16, tap>();
-            __builtin_amdgcn_sched_barrier(0);                   // keep the prefetch ahead of the 16 MFMAs that hide it
-#pragma unroll
-            for (int ch = 0; ch < 4; ++ch) {
-                if constexpr (tap & 1) { MFMA4(acc1, a[tap & 1][ch], w[tap][ch]) } else { MFMA4(acc, a[tap & 1][ch], w[tap][ch]) }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        });
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] += acc1[i];
-        STAMP(sidx + 4);
-
-        store_pixel<MODE>(acc, b4, rs_out, rs_gate, rs_bits, want_bits, out_lane + (unsigned)(((img0 * LO + r0) * LO) * PIXB), half);
-        STAMP(sidx + 5);
-        sidx += 6;
-    }
-    STAMP_WAIT();
-    STAMP(63);
-}
-
-// ================================================================================================
-// Split-bf16 MFMA (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA rate): an fp32 operand is carried as two bf16 numbers
-// hi + mid, both rounded to nearest (residual <= 2^-18 relative), and a product as all four partial products
-// accumulated in fp32, small ones first: <= 2^-17 relative error per product, random in sign (the scheme known from
-// 3xTF32 GEMMs, one level finer).  EXPERIMENTAL, enabled with ARVAE_CONV32_BF16X2=1: see launch_down_v for the
-// accuracy / speed measurements.  Lane layout of the 32x32x16 instruction: row / column = lane & 31 and the lane's
-// 8 consecutive k = 8 * (lane >> 5) + j, i.e. 8 consecutive channels = one 16-byte LDS read per plane.
-
-__device__ __forceinline__ bf16x8 lds_bf16x8(const unsigned *p) {
-    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4v *>(p));
-}
-// eight fp32 values -> (hi, mid) bf16x8, element j from x[j]
-__device__ __forceinline__ void split8(const float (&x)[8], bf16x8 &hi, bf16x8 &mid) {
-    i32x4v h, m;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        unsigned a, b;
-        split_pair(x[2 * j], x[2 * j + 1], a, b);
-        h[j] = (int)a;
-        m[j] = (int)b;
-    }
-    hi = __builtin_bit_cast(bf16x8, h);
-    mid = __builtin_bit_cast(bf16x8, m);
-}
-#define MFMA3(ACC, WH, WM, AH, AM)                                              \
-    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WM, AM, ACC, 0, 0, 0);        \
-    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WM, AH, ACC, 0, 0, 0);        \
-    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WH, AM, ACC, 0, 0, 0);        \
-    ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WH, AH, ACC, 0, 0, 0);
-
-// Down on the split-bf16 MFMA: same tiling, loader, weight residency and epilogue as down32_kernel
-template <int LO, int MODE>
-__global__ __launch_bounds__(256, 1) void down32b_kernel(const float *__restrict__ hi, const float *__restrict__ wt, Ep32 ep,
-                                                         int n_img, int n_tiles) {
-    using PL = PatchLoader<LO, 2>;
-    constexpr int PC = PL::PC, PR = PL::PR, PLANE = PL::PLANE_DW;
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // max(2 planes, WSTAGE_DOWN floats)
-    unsigned *ldsw = reinterpret_cast<unsigned *>(lds);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int half = lane >> 5, rc = lane & 31;
-
-    PL pl;                                                       // first tile's loads fly while the weights are staged
-    pl.init(hi, n_img);
-    int img0, r0;
-    tile_origin<LO>(blockIdx.x, img0, r0);
-    pl.set_tile(img0, r0, blockIdx.x < n_tiles);
-    pl.issue_all();
-
-    // wh / wm [tap][c]: the 8 channels c*16 + half*8 + j of wt[clo = rc][.][ky][kx], split; staged through LDS as fp32
-    bf16x8 wh[16][2], wm[16][2];
-    {
-        float4 v[16];
-        load_weights(wt, v);
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int idx4 = threadIdx.x + it * 256;             // (clo, chi, tap/4) = (idx4 >> 7, (idx4 >> 2) & 31, idx4 & 3)
-            *reinterpret_cast<float4 *>(lds + (idx4 >> 7) * WROW_DOWN + (idx4 & 127) * 4) = v[it];
-        }
-        __syncthreads();
-        static_for<0, 8>([&](auto gc) __attribute__((always_inline)) {       // (c, tap quad k): 32 temporaries at a time
-            constexpr int c = decltype(gc)::value >> 2, k = decltype(gc)::value & 3;
-            float x[4][8];                                       // [tap 4k + e][j]
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float4 q = *reinterpret_cast<const float4 *>(lds + rc * WROW_DOWN + (c * 16 + half * 8 + j) * 16 + k * 4);
-                x[0][j] = q.x; x[1][j] = q.y; x[2][j] = q.z; x[3][j] = q.w;
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) split8(x[e], wh[4 * k + e][c], wm[4 * k + e][c]);
-        });
-    }
-
-    int img, r, c;
-    tile_pixel<LO>(wave * 32 + rc, img, r, c);
-    const int aoff = ((img * PR + 2 * r) * PC + 2 * c) * PSB + half * 4;     // dwords; + (ky*PC + kx)*PSB + c*8 (+ PLANE)
-    float4 b4[4];
-    load_bias4(ep.bias, half, b4);
-    const int64_t out_bytes = (int64_t)n_img * LO * LO * PIXB;
-    const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(ep.out, out_bytes);
-    const __amdgpu_buffer_rsrc_t rs_gate = make_rsrc(MODE == EP_GATE_F ? ep.gate : ep.out, out_bytes);
-    const bool want_bits = MODE == EP_RELU && ep.bits_out != nullptr;
-    const __amdgpu_buffer_rsrc_t rs_bits =
-        make_rsrc(MODE == EP_GATE_B ? (const void *)ep.gate_bits : want_bits ? (const void *)ep.bits_out : (const void *)ep.out,
-                  (int64_t)n_img * LO * LO * 4);
-    const unsigned out_lane = (unsigned)((wave * 32 + rc) * PIXB + half * 16);      // + tile start + g*32
-
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        tile_origin<LO>(tile, img0, r0);
-        __syncthreads();                                         // previous tile's (or the weights') LDS reads are done
-        pl.commit_split(ldsw);
-        __syncthreads();
-        {                                                        // next tile's loads are spread between this tile's MFMAs
-            int ni, nr;
-            tile_origin<LO>(tile + gridDim.x, ni, nr);
-            pl.set_tile(ni, nr, tile + gridDim.x < n_tiles);
-        }
-        f32x16 acc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-        bf16x8 ah[2][2], am[2][2];                               // [tap parity][c]
-#pragma unroll
-        for (int cc = 0; cc < 2; ++cc) {
-            ah[0][cc] = lds_bf16x8(ldsw + aoff + cc * 8);
-            am[0][cc] = lds_bf16x8(ldsw + PLANE + aoff + cc * 8);
-        }
-        static_for<0, 16>([&](auto tc) __attribute__((always_inline)) {
-            constexpr int tap = decltype(tc)::value;
-            if constexpr (tap + 1 < 16) {                        // next tap's operands are in flight during these 6 MFMAs
-                constexpr int ky = (tap + 1) >> 2, kx = (tap + 1) & 3;
-#pragma unroll
-                for (int cc = 0; cc < 2; ++cc) {
-                    ah[(tap + 1) & 1][cc] = lds_bf16x8(ldsw + aoff + (ky * PC + kx) * PSB + cc * 8);
-                    am[(tap + 1) & 1][cc] = lds_bf16x8(ldsw + PLANE + aoff + (ky * PC + kx) * PSB + cc * 8);
-                }
-            }
-            pl.template issue_step<16, tap>();
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int cc = 0; cc < 2; ++cc) { MFMA3(acc, wh[tap][cc], wm[tap][cc], ah[tap & 1][cc], am[tap & 1][cc]) }
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        store_pixel<MODE>(acc, b4, rs_out, rs_gate, rs_bits, want_bits, out_lane + (unsigned)(((img0 * LO + r0) * LO) * PIXB), half);
-    }
-}
 
 // ================================================================================================
 // Down on the bf16 MFMA at fp32 accuracy (three-term split, six partial products: see up32x_kernel).  Three terms of a
@@ -527,6 +292,10 @@ __global__ __launch_bounds__(256, 1) void down32b_kernel(const float *__restrict
 // that a kernel starts with 48 / 24 coalesced loads instead of staging and splitting the tensor itself.
 //   DOWN part: [kh 2][slot 48 = (tap 8, c 2, term 3)][lane 64]      UP part: [class 4][slot 24 = (ty, tx, c, term)][lane 64]
 // (PREP_DOWN_SLOTS, PREP_UP_SLOTS, PREP_*_UINT4, PREP_FLOATS: conv32_common.h, shared with conv32k.hip)
+__device__ __forceinline__ bf16x8 lds_bf16x8(const unsigned *p) {
+    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4v *>(p));
+}
+
 __global__ __launch_bounds__(256) void conv32_weight_prep_kernel(PrepArgs p) { conv32_prep_block(p, blockIdx.x); }
 
 // the step's two weight preps as one launch: workgroups [0, conv_blocks) split the 32-channel conv weights, the rest lay out the
@@ -761,152 +530,6 @@ __global__ __launch_bounds__(256, 2) void down32s_kernel(const float *__restrict
 // matrix pipes for ~4K clocks.  The stores of tile t are therefore issued between the MFMAs of tile t+1, one
 // 16-byte store per wave and 16-MFMA step, each wave in its own quarter of the step: the drain then hides
 // behind the wave's previous MFMA.  Gate values are fetched one tile ahead into registers.
-template <int LO, int MODE, int PX = 128>
-__global__ __launch_bounds__(256, 1) void up32_kernel(const float *__restrict__ lo, const float *__restrict__ wt, Ep32 ep, int n_img,
-                                                       int n_tiles) {
-    using PL = PatchLoader<LO, 1, PX>;
-    constexpr int MT = PX / 32;                                  // 32-pixel MFMA tiles per wave (and parity class)
-    constexpr int HI = 2 * LO, PC = PL::PC, PR = PL::PR;
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // max(PL::PATCH_FLOATS, WSTAGE_UP)
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int half = lane >> 5, rc = lane & 31;
-    const int py = wave >> 1, px = wave & 1;
-    const int ky0 = 1 - py, kx0 = 1 - px;
-    STAMP(0);
-
-    PL pl;                                                       // first tile's loads fly while the weights are staged
-    pl.init(lo, n_img);
-    int img0, r0;
-    tile_origin<LO, PX>(blockIdx.x, img0, r0);
-    pl.set_tile(img0, r0, blockIdx.x < n_tiles);
-    pl.issue_all();
-
-    // w[ty][tx][chunk][t] = wt[clo = chunk*8 + half*4 + t][chi = rc][ky0 + 2ty][kx0 + 2tx]; staged through LDS
-    float w[2][2][4][4];
-    {
-        float4 v[16];
-        load_weights(wt, v);
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int idx4 = threadIdx.x + it * 256;             // row (clo*32 + chi) = idx4 >> 2, taps 4*(idx4 & 3)..+3
-            float *d = lds + (idx4 >> 2) * WROW_UP + (idx4 & 3) * 4;
-            d[0] = v[it].x; d[1] = v[it].y; d[2] = v[it].z; d[3] = v[it].w;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int ty = 0; ty < 2; ++ty)
-#pragma unroll
-            for (int tx = 0; tx < 2; ++tx)
-#pragma unroll
-                for (int ch = 0; ch < 4; ++ch)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        w[ty][tx][ch][t] = lds[((ch * 8 + half * 4 + t) * C32 + rc) * WROW_UP + (ky0 + 2 * ty) * 4 + kx0 + 2 * tx];
-    }
-
-    // patch origin is lo (r0-1, -1); tap (ty,tx) of class (py,px) reads lo (r + py - ty, c + px - tx)
-    int aoff[MT];
-    unsigned orel[MT];                                            // output byte offset of this lane's pixel in M-tile mt
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        int img, r, c;
-        tile_pixel<LO, PX>(mt * 32 + rc, img, r, c);
-        aoff[mt] = ((img * PR + r + 1 + py) * PC + c + 1 + px) * PS + half * 4;
-        orel[mt] = (unsigned)(((img * HI + 2 * r + py) * HI + 2 * c + px) * PIXB + half * 16);
-    }
-    float4 b4[4];
-    load_bias4(ep.bias, half, b4);
-    const int64_t out_bytes = (int64_t)n_img * HI * HI * PIXB;
-    const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(ep.out, out_bytes);
-    const __amdgpu_buffer_rsrc_t rs_gate = make_rsrc(MODE == EP_GATE_F ? ep.gate : ep.out, out_bytes);
-    const bool want_bits = MODE == EP_RELU && ep.bits_out != nullptr;
-    const __amdgpu_buffer_rsrc_t rs_bits =
-        make_rsrc(MODE == EP_GATE_B ? (const void *)ep.gate_bits : want_bits ? (const void *)ep.bits_out : (const void *)ep.out,
-                  (int64_t)n_img * HI * HI * 4);
-
-    STAMP(1);
-    float4 dummy;
-    f32x16 prev[MT];                                              // previous tile's accumulators, stored during this tile
-    float4 gq[4 * MT];                                               // its gate values (loaded while it was computed), or
-    unsigned gqb[MT] = {}, pbits[MT] = {};     // its gate bits per 32-pixel tile / the sign bits being collected
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) prev[mt][i] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4 * MT; ++i) gq[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    unsigned prev_base = OOB;                                    // out of range: the first tile's "previous" stores are dropped
-    STAMP(2);
-    int sidx = 3;
-    (void)sidx;
-
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        tile_origin<LO, PX>(tile, img0, r0);
-        STAMP(sidx);
-        __syncthreads();
-        STAMP(sidx + 1);
-        pl.template commit<false>(lds, dummy);
-        __syncthreads();
-        STAMP(sidx + 2);
-        {
-            int ni, nr;
-            tile_origin<LO, PX>(tile + gridDim.x, ni, nr);
-            pl.set_tile(ni, nr, tile + gridDim.x < n_tiles);
-        }
-        STAMP(sidx + 3);
-
-        const unsigned obase = (unsigned)(((img0 * HI + 2 * r0) * HI) * PIXB);
-        f32x16 acc[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
-        static_for<0, 16>([&](auto sc) __attribute__((always_inline)) {
-            constexpr int step = decltype(sc)::value, ty = step >> 3, tx = (step >> 2) & 1, ch = step & 3;
-            constexpr int toff = -(ty * PC + tx) * PS + ch * 8;
-            float4 a[MT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const float4 *>(lds + aoff[mt] + toff);
-            pl.template issue_step<16, step>();
-            __builtin_amdgcn_sched_barrier(0);
-            static_for<0, MT>([&](auto mc) __attribute__((always_inline)) {
-                constexpr int mt = decltype(mc)::value;
-                // epilogue slots: one per MFMA quad, 16 * MT per tile; wave w owns every fourth and walks the 4 * MT
-                // (32-pixel tile em, channel group eg) pieces of the previous tile through them
-                constexpr int slot = step * MT + mt;
-                if (wave == (slot & 3)) {
-                    constexpr int k = slot >> 2, em = k >> 2, eg = k & 3;
-                    const unsigned poff = prev_base + orel[em];
-                    if (eg == 0) pbits[em] = 0;
-                    pbits[em] |= store_group<MODE>(prev[em], eg, b4[eg], gq[k], gqb[em], rs_out, poff);
-                    if (MODE == EP_RELU && eg == 3 && want_bits)
-                        buf_store_u16(pbits[em], rs_bits, prev_base == OOB ? OOB : bits_off(poff, half));
-                    if (MODE == EP_GATE_F) gq[k] = buf_load4(rs_gate, obase + orel[em] + eg * 32);
-                    if (MODE == EP_GATE_B && eg == 3) gqb[em] = buf_load_u16(rs_bits, bits_off(obase + orel[em], half));
-                }
-                MFMA4(acc[mt], a[mt], w[ty][tx][ch])
-            });
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        STAMP(sidx + 4);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) prev[mt] = acc[mt];
-        prev_base = obase;
-        STAMP(sidx + 5);
-        sidx += 6;
-    }
-    // the last tile's epilogue has nothing to hide behind
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const unsigned poff = prev_base + orel[mt];
-        unsigned bits = 0;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bits |= store_group<MODE>(prev[mt], g, b4[g], gq[mt * 4 + g], gqb[mt], rs_out, poff);
-        if (MODE == EP_RELU && want_bits) buf_store_u16(bits, rs_bits, prev_base == OOB ? OOB : bits_off(poff, half));
-    }
-    STAMP_WAIT();
-    STAMP(63);
-}
 
 // ================================================================================================
 // Up on the bf16 MFMA at fp32 accuracy: every fp32 operand is split into THREE bf16 numbers (hi + mid + lo, exact to
@@ -1151,118 +774,6 @@ __global__ __launch_bounds__(256, 1) void up32x_reg_kernel(const float *__restri
 // ================================================================================================
 constexpr int WG32_SLAB = SLAB_C32_FLOATS;
 
-template <int LO, int BIAS, int PX = 128>
-__global__ __launch_bounds__(256, 1) void wgrad32_kernel(const float *__restrict__ lo, const float *__restrict__ hi, float *__restrict__ slab, int n_img,
-                                                          int n_tiles) {
-    using PL = PatchLoader<LO, 2, PX>;
-    constexpr int STEPS = PX / 2, LSLOTS = PX / 32;              // MFMA k-steps per tile; lo-tile load slots per thread
-    constexpr int PC = PL::PC, PR = PL::PR;
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // hi patch | lo tile [PX][PS]
-    float *lo_t = lds + PL::PATCH_FLOATS;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int half = lane >> 5, rc = lane & 31;
-    STAMP(0);
-
-    f32x16 acc[4];
-#pragma unroll
-    for (int kx = 0; kx < 4; ++kx)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[kx][i] = 0.f;
-    float lo_sum = 0.f;
-    float4 hi_sum = make_float4(0.f, 0.f, 0.f, 0.f);
-
-    PL pl;
-    pl.init(hi, n_img);
-    // lo tile: PX contiguous pixels x 8 float4 = PX / 32 slots per thread
-    const int64_t lo_bytes = (int64_t)n_img * LO * LO * PIXB;
-    const __amdgpu_buffer_rsrc_t rs_lo = make_rsrc(lo, lo_bytes);
-    float4 lr[LSLOTS];
-    unsigned lo_base = 0;
-    auto issue_lo = [&](int it) {
-        lr[it] = buf_load4(rs_lo, lo_base + it * 4096);
-    };
-    auto set_lo = [&](int i0, int rr0, bool ok) {
-        lo_base = ok ? (unsigned)(((i0 * LO + rr0) * LO) * PIXB) + threadIdx.x * 16 : OOB;
-    };
-    int img0, r0;
-    tile_origin<LO, PX>(blockIdx.x, img0, r0);
-    pl.set_tile(img0, r0, blockIdx.x < n_tiles);
-    set_lo(img0, r0, blockIdx.x < n_tiles);
-    pl.issue_all();
-#pragma unroll
-    for (int it = 0; it < LSLOTS; ++it) issue_lo(it);
-    STAMP(1);
-    STAMP(2);
-    int sidx = 3;
-    (void)sidx;
-
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        STAMP(sidx);
-        __syncthreads();
-        STAMP(sidx + 1);
-        pl.template commit<BIAS == 2>(lds, hi_sum);
-#pragma unroll
-        for (int it = 0; it < LSLOTS; ++it) {
-            const int idx = threadIdx.x + it * 256;
-            *reinterpret_cast<float4 *>(lo_t + (idx >> 3) * PS + (idx & 7) * 4) = lr[it];
-        }
-        __syncthreads();
-        STAMP(sidx + 2);
-        {
-            int ni, nr;
-            tile_origin<LO, PX>(tile + gridDim.x, ni, nr);
-            pl.set_tile(ni, nr, tile + gridDim.x < n_tiles);
-            set_lo(ni, nr, tile + gridDim.x < n_tiles);
-        }
-        STAMP(sidx + 3);
-
-        static_for<0, STEPS>([&](auto sc) __attribute__((always_inline)) {
-            // k-pair s covers lo pixels 2s and 2s+1 (adjacent columns of one row); this lane takes 2s+half
-            constexpr int s = decltype(sc)::value;
-            int img = 0, r = 0, c = 0;
-            tile_pixel<LO, PX>(2 * s, img, r, c);
-            const float lv = lo_t[(2 * s + half) * PS + rc];
-            if (BIAS == 1) lo_sum += lv;
-            const int boff = ((img * PR + 2 * r + wave) * PC + 2 * (c + half)) * PS + rc;
-            pl.template issue_step<STEPS, s>();
-            if constexpr ((s & 15) == 8) issue_lo(s >> 4);
-#pragma unroll
-            for (int kx = 0; kx < 4; ++kx)               // A row = chi, B column = clo
-                acc[kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[boff + kx * PS], lv, acc[kx], 0, 0, 0);
-        });
-        STAMP(sidx + 4);
-        STAMP(sidx + 5);
-        sidx += 6;
-    }
-
-    // partial results -> slab[blockIdx][ky][kx][clo = rc][chi = 8g + 4*half + j]: 16-byte stores
-    float *out = slab + (int64_t)blockIdx.x * WG32_SLAB;
-#pragma unroll
-    for (int kx = 0; kx < 4; ++kx)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<float4 *>(out + ((wave * 4 + kx) * C32 + rc) * C32 + 8 * g + 4 * half) =
-                make_float4(acc[kx][4 * g], acc[kx][4 * g + 1], acc[kx][4 * g + 2], acc[kx][4 * g + 3]);
-    if (BIAS == 1) {
-        if (wave == 0) {
-            const float tot = lo_sum + __shfl_xor(lo_sum, 32, 64);
-            if (half == 0) out[16 * C32 * C32 + rc] = tot;
-        }
-    } else if (BIAS == 2) {
-        __syncthreads();
-        // every thread summed channel chunk q = threadIdx.x & 7 (slot stride 256 keeps q fixed)
-        *reinterpret_cast<float4 *>(lds + threadIdx.x * 4) = hi_sum;
-        __syncthreads();
-        if (threadIdx.x < C32) {
-            const int q = threadIdx.x >> 2, e = threadIdx.x & 3;
-            float tot = 0.f;
-            for (int j = 0; j < 32; ++j) tot += lds[(j * 8 + q) * 4 + e];
-            out[16 * C32 * C32 + threadIdx.x] = tot;
-        }
-    }
-    STAMP_WAIT();
-    STAMP(63);
-}
 
 // ================================================================================================
 // Wgrad on the bf16 MFMA at fp32 accuracy (three-term split, six partial products).  Pixels are the K axis, 16 per
@@ -1461,55 +972,25 @@ static void launch_down_small(const Operand &hi, const float *wt, const Ep32 &ep
     ARVAE_LAUNCH((down32s_kernel<LO, MODE>), dim3(grid), dim3(256), LDS, s, hi.v, wt, ep, n, tiles);
 }
 template <int LO, int MODE>
-static void launch_down_v(int grid, const Operand &hi, const float *wt, const Ep32 &ep, int n, int tiles, hipStream_t s) {
-    static const bool small_ok = getenv("ARVAE_NO_SMALL_TILES") == nullptr;     // diagnostic switch
-    // (the 8x8 layers measured 2 us slower on this variant than on one full-K tile per CU)
-    static const bool fp32_only = getenv("ARVAE_CONV32_FP32") != nullptr;
-    // 4x4 layers: the K-split 32-pixel kernel whenever the big tiles underfill the chip -- and always in the default
-    // precision mode, because two packed three-term images of eight 4x4 patches (166 KB) do not fit the LDS
-    if (LO == 4 && ((small_ok && 2 * tiles <= cu_count()) || !fp32_only)) return launch_down_small<4, MODE>(hi, wt, ep, n, s);
-    // Experimental (off by default): the Down kernels on the split-bf16 MFMA.  Measured at B=512: down32<16> 45 -> 28.5 us
-    // with three truncated products (2^-15 relative error), ~31 us with this four-product round-to-nearest version
-    // (2^-17).  The loss terms and z stay within the 1e-4 parity bar, but ReLU units whose pre-activation is within
-    // that error of zero flip, which moves per-tensor gradients by up to 5e-3 (3 products) / 1e-3 (4 products) relative
-    // L2: not switched on while the gradient parity bar is 2e-3 against an fp32 oracle.
-    static const bool fp32_mfma = getenv("ARVAE_CONV32_FP32") != nullptr;
-    static const bool split = getenv("ARVAE_CONV32_BF16X2") != nullptr;
-    if (!fp32_mfma && !split) {                                  // default: three-term bf16 at fp32 accuracy, 64-pixel tiles
-        constexpr int LDSX = MaxOf<2 * PatchLoader<LO, 2, 64>::BUF3_DW + 2 * 2 * 16 * 64, WSTAGE_DOWN>::value * 4;
-        const int tiles64 = tiles_for<LO, 64>(n);
-        static bool attrx = false;
-        if (!attrx) { allow_lds(down32x_kernel<LO, MODE>, LDSX); attrx = true; }
-        ARVAE_LAUNCH((down32x_kernel<LO, MODE>), dim3(grid_for_tiles(tiles64)), dim3(256), LDSX, s, hi.v, wt, ep, n, tiles64);
-        return;
-    }
-    if (split) {
-        constexpr int LDSB = MaxOf<2 * PatchLoader<LO, 2>::PLANE_DW, WSTAGE_DOWN>::value * 4;
-        static bool attrb = false;
-        if (!attrb) { allow_lds(down32b_kernel<LO, MODE>, LDSB); attrb = true; }
-        ARVAE_LAUNCH((down32b_kernel<LO, MODE>), dim3(grid), dim3(256), LDSB, s, hi.v, wt, ep, n, tiles);
-        return;
-    }
-    constexpr int LDS = MaxOf<PatchLoader<LO, 2>::PATCH_FLOATS, WSTAGE_DOWN>::value * 4;
-    static bool attr = false;
-    if (!attr) { allow_lds(down32_kernel<LO, MODE>, LDS); attr = true; }
-    ARVAE_LAUNCH((down32_kernel<LO, MODE>), dim3(grid), dim3(256), LDS, s, hi.v, wt, ep, n, tiles);
+static void launch_down_v(int, const Operand &hi, const float *wt, const Ep32 &ep, int n, int, hipStream_t s) {
+    // 4x4 layers: the K-split 32-pixel kernel (two packed three-term images of eight 4x4 patches, 166 KB, do not fit the LDS)
+    if (LO == 4) return launch_down_small<4, MODE>(hi, wt, ep, n, s);
+    // three-term bf16 at fp32 accuracy, 64-pixel tiles.  (A two-term / four-product variant measured 28.5-31 us against 45 for
+    // the fp32 MFMA at the 16x16 layers in round 1, but flipped ReLU units moved per-tensor gradients by up to 5e-3 relative
+    // L2: removed in round 3 together with the fp32-MFMA generation of these kernels.)
+    constexpr int LDSX = MaxOf<2 * PatchLoader<LO, 2, 64>::BUF3_DW + 2 * 2 * 16 * 64, WSTAGE_DOWN>::value * 4;
+    const int tiles64 = tiles_for<LO, 64>(n);
+    static bool attrx = false;
+    if (!attrx) { allow_lds(down32x_kernel<LO, MODE>, LDSX); attrx = true; }
+    ARVAE_LAUNCH((down32x_kernel<LO, MODE>), dim3(grid_for_tiles(tiles64)), dim3(256), LDSX, s, hi.v, wt, ep, n, tiles64);
 }
 template <int LO, int MODE, int PX>
 static void launch_up_px(const Operand &lo, const float *wt, const Ep32 &ep, int n, hipStream_t s) {
     const int tiles = tiles_for<LO, PX>(n), grid = grid_for_tiles(tiles);
-    static const bool fp32_mfma = getenv("ARVAE_CONV32_FP32") != nullptr;       // the fp32 MFMA kernel instead of the 3-term bf16 one
-    if (!fp32_mfma) {
-        constexpr int LDSX = MaxOf<3 * PatchLoader<LO, 1, PX>::PLANE_DW, WSTAGE_UP>::value * 4;
-        static bool attrx = false;
-        if (!attrx) { allow_lds(up32x_kernel<LO, MODE, PX>, LDSX); attrx = true; }
-        ARVAE_LAUNCH((up32x_kernel<LO, MODE, PX>), dim3(grid), dim3(256), LDSX, s, lo.v, wt, ep, n, tiles);
-        return;
-    }
-    constexpr int LDS = MaxOf<PatchLoader<LO, 1, PX>::PATCH_FLOATS, WSTAGE_UP>::value * 4;
-    static bool attr = false;
-    if (!attr) { allow_lds(up32_kernel<LO, MODE, PX>, LDS); attr = true; }
-    ARVAE_LAUNCH((up32_kernel<LO, MODE, PX>), dim3(grid), dim3(256), LDS, s, lo.v, wt, ep, n, tiles);
+    constexpr int LDSX = MaxOf<3 * PatchLoader<LO, 1, PX>::PLANE_DW, WSTAGE_UP>::value * 4;
+    static bool attrx = false;
+    if (!attrx) { allow_lds(up32x_kernel<LO, MODE, PX>, LDSX); attrx = true; }
+    ARVAE_LAUNCH((up32x_kernel<LO, MODE, PX>), dim3(grid), dim3(256), LDSX, s, lo.v, wt, ep, n, tiles);
 }
 // 128-pixel tiles, or 32-pixel tiles when the former give a CU at most one tile (nothing to pipeline, or idle CUs:
 // the 8x8 and 4x4 layers at batch 512)
@@ -1531,8 +1012,7 @@ void conv32_down_ksplit(const arvae_link_t *l, const float *hi, const Ep32 &ep, 
 
 template <int LO> static int launch_down(const arvae_link_t *l, const Operand &hi, const float *wt, const Ep32 &ep, int relu, hipStream_t s) {
     const int tiles = tiles_for<LO>(l->n), grid = grid_for_tiles(tiles);
-    static const bool other = getenv("ARVAE_CONV32_FP32") != nullptr || getenv("ARVAE_CONV32_BF16X2") != nullptr;
-    if (LO != 4 && !other && conv32_down_ksplit_fits(l, ep)) {
+    if (LO != 4 && conv32_down_ksplit_fits(l, ep)) {
         conv32_down_ksplit(l, hi.v, ep, ep_mode(ep, relu), s);
         return check_launch(LO == 16 ? "down32_kernel<16>" : "down32_kernel<8>");
     }
@@ -1571,8 +1051,7 @@ template <int LO> static int launch_up(const arvae_link_t *l, const Operand &lo,
 // conv32_up of a 4x4 -> 8x8 ReLU layer (forward pass, prepared weights, small tiles) with the regulariser's workgroups riding in
 // the same grid (up32x_reg_kernel); false: not that case, launch the two separately
 bool conv32_up_reg_fits(const arvae_link_t *l, const float *wprep) {
-    static const bool off = getenv("ARVAE_NO_PAIR_REG") != nullptr || getenv("ARVAE_CONV32_FP32") != nullptr ||
-                            getenv("ARVAE_NO_SMALL_TILES") != nullptr;
+    static const bool off = getenv("ARVAE_NO_PAIR_REG") != nullptr || getenv("ARVAE_NO_SMALL_TILES") != nullptr;
     return !off && conv32_fits(l) && l->lh == 4 && wprep != nullptr && 2 * tiles_for<4, 128>(l->n) <= cu_count();
 }
 int conv32_up_reg(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, uint16_t *bits_out, float *out,
@@ -1595,19 +1074,6 @@ int conv32_up(const arvae_link_t *l, const Operand &lo, const float *wt, const f
         case 8: return launch_up<8>(l, lo, wt, ep, relu, s);
         default: return launch_up<4>(l, lo, wt, ep, relu, s);
     }
-}
-
-// pixels per tile of the weight-gradient kernel: 128, or 64 for a 4x4 layer whose 128-pixel tiles would leave three
-// quarters of the CUs idle (64 halves the kernel at the price of twice the slabs to reduce; 32 measured no better)
-static int wgrad_px(const arvae_link_t *l) {
-    static const int forced = getenv("ARVAE_WG4_PX") != nullptr ? atoi(getenv("ARVAE_WG4_PX")) : 0;
-    if (l->lh != 4 || 2 * tiles_for<4, 128>(l->n) > cu_count()) return 128;
-    return forced == 32 || forced == 64 || forced == 128 ? forced : 64;
-}
-
-static bool wgrad_fp32_mfma() {
-    static const bool on = getenv("ARVAE_CONV32_FP32") != nullptr;
-    return on;
 }
 
 // floats of workspace per layer for conv32_weight_prep, and the batched launch (up to 8 layers)
@@ -1644,48 +1110,15 @@ int conv32_wgrad_stream_groups(const arvae_link_t *l);
 int conv32_wgrad_stream(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *slab, int bias_mode, hipStream_t s);
 
 int conv32_wgrad_groups(const arvae_link_t *l) {
-    int tiles;
-    if (!wgrad_fp32_mfma() && conv32_wgrad_stream_fits(l)) return conv32_wgrad_stream_groups(l);
-    if (!wgrad_fp32_mfma()) {                // three-term bf16 kernel: 64-pixel tiles for every size
-        tiles = l->lh == 16 ? tiles_for<16, 64>(l->n) : l->lh == 8 ? tiles_for<8, 64>(l->n) : tiles_for<4, 64>(l->n);
-        return grid_for_tiles(tiles);
-    }
-    switch (l->lh) {
-        case 16: tiles = tiles_for<16>(l->n); break;
-        case 8: tiles = tiles_for<8>(l->n); break;
-        default: {
-            const int px = wgrad_px(l);
-            tiles = px == 32 ? tiles_for<4, 32>(l->n) : px == 64 ? tiles_for<4, 64>(l->n) : tiles_for<4>(l->n);
-            break;
-        }
-    }
-    return grid_for_tiles(tiles);          // one persistent workgroup per CU: one 64 KB partial each
+    if (conv32_wgrad_stream_fits(l)) return conv32_wgrad_stream_groups(l);
+    // the patch-staged three-term kernel (4x4 layers; every size with ARVAE_WGRAD_NO_STREAM): 64-pixel tiles, one persistent
+    // workgroup per CU, one 64 KB partial each
+    const int tiles = l->lh == 16 ? tiles_for<16, 64>(l->n) : l->lh == 8 ? tiles_for<8, 64>(l->n) : tiles_for<4, 64>(l->n);
+    return grid_for_tiles(tiles);
 }
 
 int64_t conv32_wgrad_ws_floats(const arvae_link_t *l) {
-    // sized for the smallest tile the 4x4 layers may use, so that the experiment switch cannot overrun the slab
-    const int64_t groups = l->lh == 4 ? grid_for_tiles(tiles_for<4, 32>(l->n)) : conv32_wgrad_groups(l);
-    return groups * WG32_SLAB;
-}
-
-template <int LO, int PX> static int launch_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *slab, int bias_mode,
-                                                  int grid, hipStream_t s) {
-    constexpr int LDS = (PatchLoader<LO, 2, PX>::PATCH_FLOATS + PX * PS) * 4;
-    const int tiles = tiles_for<LO, PX>(l->n);
-    static bool attr = false;
-    if (!attr) {
-        allow_lds(wgrad32_kernel<LO, 0, PX>, LDS);
-        allow_lds(wgrad32_kernel<LO, 1, PX>, LDS);
-        allow_lds(wgrad32_kernel<LO, 2, PX>, LDS);
-        attr = true;
-    }
-    if (bias_mode == 1)
-        ARVAE_LAUNCH((wgrad32_kernel<LO, 1, PX>), dim3(grid), dim3(256), LDS, s, lo.v, hi.v, slab, l->n, tiles);
-    else if (bias_mode == 2)
-        ARVAE_LAUNCH((wgrad32_kernel<LO, 2, PX>), dim3(grid), dim3(256), LDS, s, lo.v, hi.v, slab, l->n, tiles);
-    else
-        ARVAE_LAUNCH((wgrad32_kernel<LO, 0, PX>), dim3(grid), dim3(256), LDS, s, lo.v, hi.v, slab, l->n, tiles);
-    return check_launch(LO == 16 ? "wgrad32_kernel<16>" : LO == 8 ? "wgrad32_kernel<8>" : "wgrad32_kernel<4>");
+    return (int64_t)conv32_wgrad_groups(l) * WG32_SLAB;
 }
 
 template <int LO> static int launch_wgrad_x(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *slab, int bias_mode,
@@ -1713,30 +1146,10 @@ template <int LO> static int launch_wgrad_x(const arvae_link_t *l, const Operand
 int conv32_wgrad_partial(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *dwt, float *dbias, int bias_mode,
                          float *slab, hipStream_t s, SlabJob *job) {
     const int grid = conv32_wgrad_groups(l);
-    int rc;
-    if (!wgrad_fp32_mfma() && conv32_wgrad_stream_fits(l)) {
-        rc = conv32_wgrad_stream(l, lo, hi, slab, bias_mode, s);
-        *job = SlabJob{slab, dwt, bias_mode ? dbias : nullptr, grid, SLAB_C32, bias_mode};
-        return rc;
-    }
-    if (!wgrad_fp32_mfma()) {
-        rc = l->lh == 16 ? launch_wgrad_x<16>(l, lo, hi, slab, bias_mode, grid, s)
-                         : l->lh == 8 ? launch_wgrad_x<8>(l, lo, hi, slab, bias_mode, grid, s)
-                                      : launch_wgrad_x<4>(l, lo, hi, slab, bias_mode, grid, s);
-        *job = SlabJob{slab, dwt, bias_mode ? dbias : nullptr, grid, SLAB_C32, bias_mode};
-        return rc;
-    }
-    switch (l->lh) {
-        case 16: rc = launch_wgrad<16, 128>(l, lo, hi, slab, bias_mode, grid, s); break;
-        case 8: rc = launch_wgrad<8, 128>(l, lo, hi, slab, bias_mode, grid, s); break;   // 64-pixel tiles: no gain here
-        default: {
-            const int px = wgrad_px(l);
-            rc = px == 32 ? launch_wgrad<4, 32>(l, lo, hi, slab, bias_mode, grid, s)
-                          : px == 64 ? launch_wgrad<4, 64>(l, lo, hi, slab, bias_mode, grid, s)
-                                     : launch_wgrad<4, 128>(l, lo, hi, slab, bias_mode, grid, s);
-            break;
-        }
-    }
+    const int rc = conv32_wgrad_stream_fits(l) ? conv32_wgrad_stream(l, lo, hi, slab, bias_mode, s)
+                   : l->lh == 16             ? launch_wgrad_x<16>(l, lo, hi, slab, bias_mode, grid, s)
+                   : l->lh == 8              ? launch_wgrad_x<8>(l, lo, hi, slab, bias_mode, grid, s)
+                                             : launch_wgrad_x<4>(l, lo, hi, slab, bias_mode, grid, s);
     *job = SlabJob{slab, dwt, bias_mode ? dbias : nullptr, grid, SLAB_C32, bias_mode};
     return rc;
 }
@@ -1746,8 +1159,7 @@ int conv32_wgrad_partial(const arvae_link_t *l, const Operand &lo, const Operand
 // up == false: a forward DOWN link (data gradient = UP map, g on the lo side, bias mode 1).  Only the combinations the image
 // executor produces are instantiated; everything else (and the experiment switches) goes the two-launch way.
 bool conv32_pair4_fits(const arvae_link_t *l, bool up, const float *gate, const uint16_t *gate_bits, const float *wprep, int bias_mode) {
-    static const bool off = getenv("ARVAE_NO_PAIR4") != nullptr || getenv("ARVAE_CONV32_FP32") != nullptr ||
-                            getenv("ARVAE_CONV32_BF16X2") != nullptr || getenv("ARVAE_NO_SMALL_TILES") != nullptr;
+    static const bool off = getenv("ARVAE_NO_PAIR4") != nullptr || getenv("ARVAE_NO_SMALL_TILES") != nullptr;
     if (off || l->lh != 4 || (gate == nullptr && gate_bits == nullptr) || bias_mode != (up ? 2 : 1)) return false;
     if (!up && wprep == nullptr) return false;                   // (the UP kernel would stage its weights through LDS)
     const int wg_tiles = tiles_for<4, 64>(l->n), dg_tiles = tiles_for<4, 32>(l->n);

@@ -17,8 +17,6 @@ namespace arvae {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int HI1 = 64, LO1 = 32, CC = 32;
-constexpr int TR1 = 8;                      // lo rows per tile (x 32 cols = 256 lo positions)
-constexpr int IPR = 2 * TR1 + 2, IPC = 68;  // image patch: 18 rows x 66 cols (+2 pad)
 constexpr int PS1 = 36;                     // LDS pixel stride (floats) of 32-channel pixels
 
 struct Ep1 {
@@ -30,107 +28,10 @@ struct Ep1 {
     int relu;
 };
 
-// image rows [2*r0-1, 2*r0-1+IPR) x cols [-1, 65) of image n, register-staged: issue() loads, commit() writes the
-// LDS patch and returns the sum of the pixels this tile owns (rows 1..16, cols 1..64 of the patch) for the
-// transposed-conv bias gradient
-constexpr int IMG_SLOTS = (IPR * 66 + 255) / 256;
-struct ImgPatch {
-    float r[IMG_SLOTS];
-    __device__ __forceinline__ void issue(const Operand &img, float gs, int tile, int n_tiles) {
-        const int n = tile / (LO1 / TR1), r0 = (tile % (LO1 / TR1)) * TR1;
-#pragma unroll
-        for (int it = 0; it < IMG_SLOTS; ++it) {
-            const int idx = threadIdx.x + it * 256;
-            const int pr = idx / 66, pc = idx - pr * 66;
-            const int gy = 2 * r0 - 1 + pr, gx = pc - 1;
-            const bool ok = tile < n_tiles && idx < IPR * 66 && (unsigned)gy < (unsigned)HI1 && (unsigned)gx < (unsigned)HI1;
-            const float v = img.at(ok ? ((int64_t)n * HI1 + gy) * HI1 + gx : 0);       // unconditional load, clamped index
-            r[it] = ok ? gs * v : 0.f;
-        }
-    }
-    __device__ __forceinline__ float commit(float *patch) const {
-        float own = 0.f;
-#pragma unroll
-        for (int it = 0; it < IMG_SLOTS; ++it) {
-            const int idx = threadIdx.x + it * 256;
-            if (idx < IPR * 66) {
-                const int pr = idx / 66, pc = idx - pr * 66;
-                patch[pr * IPC + pc] = r[it];
-                if (pr >= 1 && pr <= 2 * TR1 && pc >= 1 && pc <= HI1) own += r[it];
-            }
-        }
-        return own;
-    }
-};
-
 // ================================================================================================
-// down_c1: the weight is the MFMA's A operand (row = channel) and the image value its B operand (column = lo pixel),
-// so a lane ends up with 4 x 4 consecutive channels of ONE pixel: four 16-byte stores per 32 pixels, and the ReLU
-// sign bits of a pixel-half fit one uint16 (relu_bits16).
-__global__ __launch_bounds__(256) void down_c1_kernel(Operand img, const float *__restrict__ wt, Ep1 ep, int n_tiles) {
-    __shared__ float patch[IPR * IPC];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, rc = lane & 31;
-    float w8[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) w8[s] = wt[rc * 16 + 2 * s + half];
-    float4 b4[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-        b4[g] = ep.bias != nullptr ? *reinterpret_cast<const float4 *>(ep.bias + 8 * g + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const float gs = img.scale != nullptr ? img.scale[0] : 1.f;
-    ImgPatch ip;
-    ip.issue(img, gs, blockIdx.x, n_tiles);
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int n = tile / (LO1 / TR1), r0 = (tile % (LO1 / TR1)) * TR1;
-        __syncthreads();
-        ip.commit(patch);
-        __syncthreads();
-        ip.issue(img, gs, tile + gridDim.x, n_tiles);          // next tile's image rows fly during this tile's work
-        // gate values of both 32-pixel rows first (one round of memory latency)
-        float4 gv[2][4];
-        unsigned gb[2] = {0xffffu, 0xffffu};
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int pix = ((n * LO1) + r0 + 2 * wave + mt) * LO1 + rc;
-            if (ep.gate_bits != nullptr) gb[mt] = ep.gate_bits[pix * 2 + half];
-            else if (ep.gate != nullptr) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) gv[mt][g] = *reinterpret_cast<const float4 *>(ep.gate + (int64_t)pix * CC + 8 * g + 4 * half);
-            }
-        }
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int r = 2 * wave + mt;              // lo row inside the tile; lane rc = lo column
-            f32x16 acc;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {             // k = 2s + half -> (ky, kx) = (s >> 1, 2 (s & 1) + half)
-                const float a = patch[(2 * r + (s >> 1)) * IPC + 2 * rc + 2 * (s & 1) + half];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w8[s], a, acc, 0, 0, 0);
-            }
-            const int pix = ((n * LO1) + r0 + r) * LO1 + rc;
-            unsigned bits = 0;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float v[4] = {acc[4 * g] + b4[g].x, acc[4 * g + 1] + b4[g].y, acc[4 * g + 2] + b4[g].z, acc[4 * g + 3] + b4[g].w};
-                const float gf[4] = {gv[mt][g].x, gv[mt][g].y, gv[mt][g].z, gv[mt][g].w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (ep.relu) v[j] = fmaxf(v[j], 0.f);
-                    if (ep.gate_bits != nullptr) v[j] = ((gb[mt] >> (4 * g + j)) & 1u) ? v[j] : 0.f;
-                    else if (ep.gate != nullptr) v[j] = gf[j] > 0.f ? v[j] : 0.f;
-                    bits |= (v[j] > 0.f ? 1u : 0u) << (4 * g + j);
-                }
-                *reinterpret_cast<float4 *>(ep.out + (int64_t)pix * CC + 8 * g + 4 * half) = make_float4(v[0], v[1], v[2], v[3]);
-            }
-            if (ep.bits_out != nullptr) ep.bits_out[pix * 2 + half] = (uint16_t)bits;
-        }
-    }
-}
-
-// ================================================================================================
-// down_c1, streaming form (default).  The kernel writes 128 KB per image and reads 16 KB: what it must do is keep the
+// down_c1: the weight is the MFMA's A operand (row = channel) and the image value its B operand (column = lo pixel), so a lane
+// ends up with 4 x 4 consecutive channels of ONE pixel and the ReLU sign bits of a pixel-half fit one uint16 (relu_bits16).
+// Streaming form (a tiled, barrier-per-tile first generation was removed in round 3).  The kernel writes 128 KB per image and reads 16 KB: what it must do is keep the
 // store path busy (tools/probes/store_probe.hip: a bare 67 MB fill takes 13.7 us on this chip; 16-byte pieces at a 128-byte
 // stride, the MFMA accumulator layout stored as it is, 16 us; eight dword image loads per lane per row in the same
 // memory queue as the stores, 19-21 us).  So:
@@ -352,109 +253,11 @@ constexpr int WG1_SLAB = SLAB_C1_FLOATS;
 
 // wgrad_c1 on the 16x16x4 MFMA: D[clo][tap] += sum over 4 positions of lo[pos][clo] * img[pos @ tap]; M = 32 channels
 // (two 16-row tiles), N = the 16 taps (every column useful), K = positions.  A lane is (row/col index lane & 15,
-// position-in-quad lane >> 4); a wave owns two lo rows of the tile = 16 quads.
-__global__ __launch_bounds__(256) void wgrad_c1_kernel(Operand lo, Operand img, float *__restrict__ slab, int n_tiles) {
-    __shared__ float patch[IPR * IPC];
-    __shared__ __attribute__((aligned(16))) float lo_t[256 * PS1];     // reused as the reduce buffer
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
-    const int ky = li >> 2, kx = li & 3;
-    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    float lo_sum[2] = {0.f, 0.f}, img_sum = 0.f;
-    const float gs = img.scale != nullptr ? img.scale[0] : 1.f;
-    // register-staged loads (issued for tile t+1 before the MFMAs of tile t)
-    constexpr int IMG_ITERS = (IPR * 66 + 255) / 256;
-    float4 lr[8];
-    float ir[IMG_ITERS];
-    auto issue = [&](int tile) {
-        const int n = tile / (LO1 / TR1), r0 = (tile % (LO1 / TR1)) * TR1;
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int idx = threadIdx.x + it * 256;
-            const int64_t gi = (((int64_t)n * LO1 + r0) * LO1 + (idx >> 3)) * CC + (idx & 7) * 4;
-            float4 v = *reinterpret_cast<const float4 *>(lo.v + gi);
-            if (lo.y != nullptr) {
-                const float4 y = *reinterpret_cast<const float4 *>(lo.y + gi);
-                v.x *= act_bwd_from_out(y.x, lo.act); v.y *= act_bwd_from_out(y.y, lo.act);
-                v.z *= act_bwd_from_out(y.z, lo.act); v.w *= act_bwd_from_out(y.w, lo.act);
-            }
-            lr[it] = v;
-        }
-#pragma unroll
-        for (int it = 0; it < IMG_ITERS; ++it) {
-            const int idx = threadIdx.x + it * 256;
-            const int pr = idx / 66, pc = idx - pr * 66;
-            const int gy = 2 * r0 - 1 + pr, gx = pc - 1;
-            const bool ok = idx < IPR * 66 && (unsigned)gy < (unsigned)HI1 && (unsigned)gx < (unsigned)HI1;
-            const float v = img.at(ok ? ((int64_t)n * HI1 + gy) * HI1 + gx : 0);        // unconditional, clamped
-            ir[it] = ok ? gs * v : 0.f;
-        }
-    };
-    if (blockIdx.x < n_tiles) issue(blockIdx.x);
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int idx = threadIdx.x + it * 256;
-            *reinterpret_cast<float4 *>(lo_t + (idx >> 3) * PS1 + (idx & 7) * 4) = lr[it];
-        }
-#pragma unroll
-        for (int it = 0; it < IMG_ITERS; ++it) {
-            const int idx = threadIdx.x + it * 256;
-            if (idx < IPR * 66) {
-                const int pr = idx / 66, pc = idx - pr * 66;
-                patch[pr * IPC + pc] = ir[it];
-                if (pr >= 1 && pr <= 2 * TR1 && pc >= 1 && pc <= HI1) img_sum += ir[it];
-            }
-        }
-        __syncthreads();
-        if (tile + gridDim.x < n_tiles) issue(tile + gridDim.x);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {                  // quad q of this wave: lo row r, columns c0 .. c0+3; this lane takes c0 + g
-            const int r = 2 * wave + (q >> 3), c = (q & 7) * 4 + g;
-            const float b = patch[(2 * r + ky) * IPC + 2 * c + kx];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const float a = lo_t[(r * 32 + c) * PS1 + 16 * mt + li];
-                lo_sum[mt] += a;
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[mt], 0, 0, 0);
-            }
-        }
-    }
-    // reduce the 4 waves' tiles: red[wave][mt*4 + r][lane]; D row = 4g + r -> clo = 16 mt + 4g + r, column = tap li
-    __syncthreads();
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) lo_t[(wave * 8 + mt * 4 + r) * 64 + lane] = acc[mt][r];
-    __syncthreads();
-    float *out = slab + (int64_t)blockIdx.x * WG1_SLAB;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {                       // wave w finishes registers 2w, 2w+1 of the 8
-        const int reg = 2 * wave + e, mt = reg >> 2, r = reg & 3;
-        const float tot = (lo_t[(0 * 8 + reg) * 64 + lane] + lo_t[(1 * 8 + reg) * 64 + lane]) +
-                          (lo_t[(2 * 8 + reg) * 64 + lane] + lo_t[(3 * 8 + reg) * 64 + lane]);
-        out[(16 * mt + 4 * g + r) * 16 + li] = tot;
-    }
-    // bias sums: lo per channel (lane li of tile mt, over the 4 position slots and 4 waves), image total
-    __syncthreads();
-    lo_t[threadIdx.x] = lo_sum[0];
-    lo_t[256 + threadIdx.x] = lo_sum[1];
-    lo_t[512 + threadIdx.x] = img_sum;
-    __syncthreads();
-    if (threadIdx.x < CC) {
-        const int mt = threadIdx.x >> 4, i = threadIdx.x & 15;
-        float tot = 0.f;
-        for (int j = 0; j < 16; ++j) tot += lo_t[mt * 256 + j * 16 + i];        // 4 waves x 4 position slots
-        out[CC * 16 + threadIdx.x] = tot;
-    } else if (threadIdx.x == 64) {
-        float tot = 0.f;
-        for (int j = 0; j < 256; ++j) tot += lo_t[512 + j];
-        out[CC * 16 + CC] = tot;
-    }
-}
+// position-in-quad lane >> 4).
 
 // ================================================================================================
-// wgrad_c1, streaming form (default): the same MFMA tiling as wgrad_c1_kernel, but a WAVE owns one lo row (32 positions x 32
+// wgrad_c1, streaming form (the tiled first generation, eight waves marching between two barriers per tile at 2.9 TB/s, was
+// removed in round 3): a WAVE owns one lo row (32 positions x 32
 // channels = 4 KB) at a time and stages it, with the four image rows it meets, in LDS of its own: no workgroup barrier in the
 // loop, five fully coalesced 1 KB loads per row (four of lo, one of the image) issued one row ahead, and enough independent
 // waves per CU (two workgroups of eight) that somebody is always loading.  The tiled kernel's eight waves march between two
@@ -718,21 +521,14 @@ int conv_c1_down_with_prep(const arvae_link_t *l, const Operand &img, const floa
 
 int conv_c1_down(const arvae_link_t *l, const Operand &img, const float *wt, const float *bias, int relu,
                  const float *gate, const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s) {
-    const int tiles = l->n * (LO1 / TR1);
     Ep1 ep{bias, gate, gate_bits, bits_out, out, relu};
-    static const bool tiled = getenv("ARVAE_C1_DOWN_TILED") != nullptr;                                  // diagnostic: the LDS-staged kernel
-    if (!tiled) {
-        static const int waves_per_cu = getenv("ARVAE_C1_DOWN_WAVES") ? atoi(getenv("ARVAE_C1_DOWN_WAVES")) : 16;
-        const int n_rows = l->n * LO1;
-        int grid = 256 * waves_per_cu / 4;                       // workgroups of four independent waves
-        if (grid > (n_rows + 3) / 4) grid = (n_rows + 3) / 4;
-        if (gate_bits != nullptr) ARVAE_LAUNCH(down_c1s_kernel<1>, dim3(grid), dim3(256), 0, s, img, wt, ep, n_rows);
-        else if (gate != nullptr) ARVAE_LAUNCH(down_c1s_kernel<2>, dim3(grid), dim3(256), 0, s, img, wt, ep, n_rows);
-        else ARVAE_LAUNCH(down_c1s_kernel<0>, dim3(grid), dim3(256), 0, s, img, wt, ep, n_rows);
-        return check_launch("down_c1_kernel");
-    }
-    static const int cap = getenv("ARVAE_C1_DOWN_GRID") ? atoi(getenv("ARVAE_C1_DOWN_GRID")) : 512;      // 2 per CU, 4 tiles each: measured best of 256..4096
-    ARVAE_LAUNCH(down_c1_kernel, dim3(tiles < cap ? tiles : cap), dim3(256), 0, s, img, wt, ep, tiles);
+    static const int waves_per_cu = getenv("ARVAE_C1_DOWN_WAVES") ? atoi(getenv("ARVAE_C1_DOWN_WAVES")) : 16;
+    const int n_rows = l->n * LO1;
+    int grid = 256 * waves_per_cu / 4;                           // workgroups of four independent waves
+    if (grid > (n_rows + 3) / 4) grid = (n_rows + 3) / 4;
+    if (gate_bits != nullptr) ARVAE_LAUNCH(down_c1s_kernel<1>, dim3(grid), dim3(256), 0, s, img, wt, ep, n_rows);
+    else if (gate != nullptr) ARVAE_LAUNCH(down_c1s_kernel<2>, dim3(grid), dim3(256), 0, s, img, wt, ep, n_rows);
+    else ARVAE_LAUNCH(down_c1s_kernel<0>, dim3(grid), dim3(256), 0, s, img, wt, ep, n_rows);
     return check_launch("down_c1_kernel");
 }
 
@@ -787,13 +583,9 @@ int conv_c1_up_recon(const arvae_link_t *l, const float *lo, const float *wt, co
     return check_launch("up_c1_kernel(recon)");
 }
 
-static bool wgrad_c1_tiled() {
-    static const bool tiled = getenv("ARVAE_C1_WGRAD_TILED") != nullptr;          // diagnostic: the barrier-per-tile kernel
-    return tiled;
-}
 static int wgrad_c1_groups(const arvae_link_t *l) {
     static const int cap = getenv("ARVAE_C1_WGRAD_GRID") ? atoi(getenv("ARVAE_C1_WGRAD_GRID")) : 256;       // streaming form: one 8-wave workgroup per CU (256 / 512 / 1024 measured: 19.3 / 19.0 / 21.8 us, and the slab reduce grows with it)
-    const int units = wgrad_c1_tiled() ? l->n * (LO1 / TR1) : (l->n * LO1 + WGS_WAVES - 1) / WGS_WAVES;
+    const int units = (l->n * LO1 + WGS_WAVES - 1) / WGS_WAVES;
     return units < cap ? units : cap;
 }
 
@@ -801,17 +593,15 @@ int64_t conv_c1_wgrad_ws_floats(const arvae_link_t *l) { return (int64_t)wgrad_c
 
 int conv_c1_wgrad_partial(const arvae_link_t *l, const Operand &lo, const Operand &img, float *dwt, float *dbias,
                           int bias_mode, float *slab, hipStream_t s, SlabJob *job) {
-    const int tiles = l->n * (LO1 / TR1), grid = wgrad_c1_groups(l);
-    if (wgrad_c1_tiled()) ARVAE_LAUNCH(wgrad_c1_kernel, dim3(grid), dim3(256), 0, s, lo, img, slab, tiles);
-    else ARVAE_LAUNCH(wgrad_c1s_kernel, dim3(grid), dim3(64 * WGS_WAVES), 0, s, lo, img, slab, l->n * LO1);
+    const int grid = wgrad_c1_groups(l);
+    ARVAE_LAUNCH(wgrad_c1s_kernel, dim3(grid), dim3(64 * WGS_WAVES), 0, s, lo, img, slab, l->n * LO1);
     *job = SlabJob{slab, dwt, dbias, grid, SLAB_C1, bias_mode};
     return check_launch("wgrad_c1_kernel");
 }
 
 // gated data gradient of the forward-UP single-channel link + its weight-gradient partials in one launch (pair_c1_kernel)
 bool conv_c1_pair_fits(const arvae_link_t *l) {
-    static const bool off = getenv("ARVAE_NO_PAIR_C1") != nullptr || getenv("ARVAE_C1_DOWN_TILED") != nullptr ||
-                            getenv("ARVAE_C1_WGRAD_TILED") != nullptr;
+    static const bool off = getenv("ARVAE_NO_PAIR_C1") != nullptr;
     return !off && conv_c1_fits(l) && l->n * LO1 >= 8 * 256 && wgrad_c1_groups(l) == 256;
 }
 int conv_c1_pair(const arvae_link_t *l, const Operand &g_img, const float *wt, const float *gate, const uint16_t *gate_bits, float *d_lo,

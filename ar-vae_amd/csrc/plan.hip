@@ -243,38 +243,6 @@ static int layer_forward(const arvae_layer_t &l, int32_t n, const float *params,
                    : arvae_link_down(&lk, &op, w, b, l.act, mask, out, link_ws, st);
 }
 
-// ---- second stream for the weight gradients ---------------------------------------------------------
-// The data-gradient chain (main stream) is the critical path of the backward pass; the weight gradients only have to
-// be done before the optimizer.  They run on a helper stream forked from / joined to the caller's stream with
-// events, so that the many small, latency-bound kernels of either chain fill CUs the other leaves idle.
-struct SideStream {
-    hipStream_t s = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr, step[2 * ARVAE_MAX_LAYERS + 8] = {};
-    int device = -1, next = 0;
-    bool ok = false;
-};
-thread_local arvae_stream_t g_wgrad_stream = nullptr;   // non-null while a two-stream backward pass is being enqueued
-
-static SideStream *side_stream(bool force = false) {
-    static SideStream pool[16];
-    // Measured on MI355X (dSprites, B=512): the two-stream schedule is 1-2 % SLOWER than one stream -- the big kernels
-    // of both chains are one-workgroup-per-CU persistent kernels that cannot share a CU's LDS, so they serialise
-    // anyway and only add event traffic.  Kept as an experiment switch.
-    static const bool off = getenv("ARVAE_TWO_STREAMS") == nullptr;
-    int dev = 0;
-    if ((off && !force) || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    SideStream &ss = pool[dev];
-    if (ss.device != dev) {
-        ss.device = dev;
-        ss.ok = hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking) == hipSuccess &&
-                hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) == hipSuccess &&
-                hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) == hipSuccess;
-        for (auto &e : ss.step) ss.ok = ss.ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
-        if (!ss.ok) (void)hipGetLastError();
-    }
-    return ss.ok ? &ss : nullptr;
-}
-
 // One layer of the backward pass.
 //   g      : gradient arriving at this layer: w.r.t. its pre-activation (g_is_pre) or w.r.t. its output
 //   gate   : when non-null, the saved ReLU output of the PRODUCER of `in`; the data gradient is then
@@ -304,8 +272,9 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
     const float *w = params + l.w_off;
     float *dw = grads + l.w_off, *db = l.b_off >= 0 ? grads + l.b_off : nullptr;
     hipStream_t hs = as_stream(st);
-    const arvae_stream_t wst = g_wgrad_stream != nullptr ? g_wgrad_stream : st;      // weight gradients: helper stream
-    hipStream_t whs = reinterpret_cast<hipStream_t>(wst);
+    const arvae_stream_t wst = st;
+    hipStream_t whs = hs;                               // (a second stream for the weight gradients measured 1-9 % slower in
+                                                        // rounds 1 and 2 -- the big kernels cannot share a CU -- and was removed)
     if (gated != nullptr) *gated = false;
     // 4x4 32-channel layers: gated data gradient and weight-gradient partials in one launch (conv32.hip, pair4_*_kernel)
     if (d_in != nullptr && gated != nullptr && rdefer != nullptr && own_slab != nullptr && gop.y == nullptr && g_scale == nullptr &&
@@ -604,21 +573,7 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
     defer.count = 0;
     SlabReduceBatch rdefer;
     rdefer.count = 0;
-    SideStream *side = profiling_active() ? nullptr : side_stream();
-    struct WgradStreamScope {                            // clears the thread-local on every return path
-        ~WgradStreamScope() { g_wgrad_stream = nullptr; }
-    } wgrad_scope;
-    int side_ev = 0;
-    // "everything enqueued on the main stream so far is visible to the helper stream"
-    auto sync_side = [&]() {
-        if (side == nullptr) return;
-        hipEvent_t e = side_ev == 0 ? side->fork : side->step[side_ev - 1];
-        ++side_ev;
-        (void)hipEventRecord(e, st);
-        (void)hipStreamWaitEvent(side->s, e, 0);
-    };
-    if (side != nullptr) g_wgrad_stream = reinterpret_cast<arvae_stream_t>(side->s);
-    hipStream_t flush_stream = side != nullptr ? side->s : st;
+    hipStream_t flush_stream = st;
     // where the gradient for `keep` (a Linear layer's output, or -1) is written: its own buffer, or the ping-pong
     // buffer that does not hold the gradient being consumed
     auto grad_dst = [&](int64_t keep, const float *busy) -> float * {
@@ -671,7 +626,6 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
         const GateOp *gate_op = i > 0 ? general_gate(m->dec[i - 1], dec_mask[i - 1], in, go) : nullptr;
         float *dst = grad_dst(i > 0 ? L.dec_keep[i - 1] : -1, cur);
         bool gated = false;
-        sync_side();                                     // this layer's incoming gradient is ready
         // the first decoder layer's data gradient (d z) is computed inside the heads kernel (heads.hip) when the gradient
         // that arrives here is already w.r.t. the layer's pre-activation: only its weight gradient is queued
         if (i == 0 && !mid && pre && m->n_dec > 1 && heads_fusable(&m->head_mu, &m->head_log_std, m->zdim) &&
@@ -692,7 +646,7 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
     // data-parallel caller: finish the decoder's conv gradients now (their all-reduce then runs under the rest of the pass)
     const arvae_milestones *ms = m->milestones;
     bool dec_marked = false, lin_marked = false;
-    if (ms != nullptr && ms->dec_grads != nullptr && side == nullptr && defer.count == 0) {
+    if (ms != nullptr && ms->dec_grads != nullptr && defer.count == 0) {
         // (defer.count == 0: no Linear layer of the decoder went the per-layer way, so "decoder conv layers" is what is queued)
         if (int rc = slab_reduce_flush(&rdefer, st)) return rc;
         mark(ms->dec_grads, st);
@@ -744,7 +698,7 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
         cur = d_x0;
         pre = gate0 != nullptr;
         enc_from = e0 - 1;
-        if (ms != nullptr && ms->linear_grads != nullptr && side == nullptr) {   // every Linear weight gradient is queued
+        if (ms != nullptr && ms->linear_grads != nullptr) {   // every Linear weight gradient is queued
             if (int rc = dense_wgrad_flush(&defer, st)) return rc;
             mark(ms->linear_grads, st);
             lin_marked = true;
@@ -797,7 +751,6 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
         const GateOp *gate_op = i > 0 ? general_gate(m->enc[i - 1], enc_mask[i - 1], in, go) : nullptr;
         float *dst = i > 0 ? grad_dst(L.enc_keep[i - 1], cur) : nullptr;
         bool gated = false;
-        sync_side();
         if (int rc = layer_backward(m->enc[i], batch, params, grads, in, ws + L.enc_out[i], mask_of(enc_mask[i]), cur, pre,
                                     gate, dst, &gated, slab, ws + L.link_ws, &defer, L.enc_slab[i] >= 0 ? ws + L.enc_slab[i] : nullptr, &rdefer,
                                     stream, nullptr,
@@ -808,30 +761,12 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
         pre = gated;
         cur = dst;
     }
-    sync_side();                                         // every gradient the queued jobs read is complete
     // The two closing kernels are independent (disjoint gradients): the slab reduction streams ~90 MB from HBM while the
-    // grouped Linear weight gradients are latency-bound in L2.  Running them side by side on a second stream measured
-    // 22 us SLOWER per step than back to back (fork / join events cost more than the overlap returns), so this stays an
-    // experiment switch like ARVAE_TWO_STREAMS.
-    static const bool tail_overlap = getenv("ARVAE_TAIL_OVERLAP") != nullptr;
-    SideStream *tail = (side == nullptr && tail_overlap && !profiling_active() && defer.count > 0 && rdefer.count > 0)
-                           ? side_stream(true) : nullptr;
-    if (tail != nullptr) {
-        (void)hipEventRecord(tail->fork, st);
-        (void)hipStreamWaitEvent(tail->s, tail->fork, 0);
-        if (int rc = dense_wgrad_flush(&defer, tail->s)) return rc;
-        (void)hipEventRecord(tail->join, tail->s);
-        if (int rc = slab_reduce_flush(&rdefer, st)) return rc;
-        (void)hipStreamWaitEvent(st, tail->join, 0);
-        if (m->milestones != nullptr) { mark(m->milestones->dec_grads, st); mark(m->milestones->linear_grads, st); }
-        return ARVAE_OK;
-    }
+    // grouped Linear weight gradients are latency-bound in L2.  Side by side on a second stream they measured 22 us SLOWER
+    // per step than back to back (fork / join events cost more than the overlap returns; round 2), as one grid 40.8 us
+    // against 31.2: back to back it is.
     if (int rc = slab_reduce_flush(&rdefer, flush_stream)) return rc;
     if (int rc = dense_wgrad_flush(&defer, flush_stream)) return rc;
-    if (side != nullptr) {                               // join: the caller's stream continues after the helper's work
-        (void)hipEventRecord(side->join, side->s);
-        (void)hipStreamWaitEvent(st, side->join, 0);
-    }
     if (ms != nullptr) {                                 // milestones with no earlier point: everything is final here
         if (!dec_marked) mark(ms->dec_grads, st);
         if (!lin_marked) mark(ms->linear_grads, st);

@@ -538,7 +538,7 @@ def run_dsprites(device, args, fence, rank, world, use_dp):
     # (every kernel of the step above 2 % of its device time has a KERNEL_WORK entry; `unaccounted_labels` lists the rest)
     dom_name, dom = max(((k, v) for k, v in prof.items() if v['bytes'] > 0), key=lambda kv: kv[1]['ms'])
     avg_ms = dom['ms'] / dom['calls']
-    split = dom_name.startswith(('down32', 'up32', 'wgrad32', 'pair4')) and not os.environ.get('ARVAE_CONV32_FP32')
+    split = dom_name.startswith(('down32', 'up32', 'wgrad32', 'pair4'))
     mfma_peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
     mfma_work = dom['flop'] * (BF16X3_PRODUCTS if split else 1)
     mfma_tf = mfma_work / dom['calls'] / (avg_ms * 1e-3) / 1e12
@@ -597,7 +597,7 @@ def run_dsprites(device, args, fence, rank, world, use_dp):
         'metric': 'training images/sec (dSprites beta-VAE+AR, per-GPU batch 512)', 'value': value,
         'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32' if os.environ.get('ARVAE_CONV32_FP32') else 'f32 (conv MFMAs: 3-term bf16 split, 6 products, fp32-accurate)',
+        'dtype': 'f32 (conv MFMAs: 3-term bf16 split, 6 products, fp32-accurate)',
         'data': 'synthetic',
         'config': {'workload': 'dSprites AR-VAE full training step (fwd + bwd + Adam), 1x64x64 inputs, z=10, '
                                'reg_dim=(1,2,3,4,5), beta=4 gamma=10 delta=1',

@@ -488,78 +488,37 @@ def test_full_batch_properties(dev):
     close(g3, 3.0 * g1, rtol=2e-5, atol=1e-6 * float(g1.abs().max()))
 
 
-def test_split_bf16_experiment_keeps_loss_parity(dev):
-    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    """ARVAE_CONV32_BF16X2=1 (experimental split-bf16 MFMA for the Down kernels): the north-star outputs stay within 1e-4."""
-    code = (
-        "import sys, json; sys.path.insert(0, %r)\n"
-        "import numpy as np, torch\n"
-        "from tests.test_hip_parity import run_hip_image_step\n"
-        "from arvae_amd import synthetic as syn\n"
-        "from oracle import image_vae as o_vae\n"
-        "state = syn.synth_state(o_vae.DSPRITES_SHAPES, 9, 1.6)\n"
-        "x, lab = syn.dsprites_batch(64, seed=5); eps = syn.normal_noise((64, 10), seed=6)\n"
-        "got = run_hip_image_step(torch.device('cuda:0'), 'dsprites', state, x, lab, eps, 4.0, 0.0, 'bernoulli', None)\n"
-        "print(json.dumps({'loss': got['loss'], **got['terms']}))\n" % ROOT)
-    env = dict(os.environ, ARVAE_CONV32_BF16X2='1')
-    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
-    assert r.returncode == 0, r.stderr[-2000:]
-    got = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
-    state = syn.synth_state(o_vae.DSPRITES_SHAPES, 9, 1.6)
-    x, lab = syn.dsprites_batch(64, seed=5)
-    eps = syn.normal_noise((64, 10), seed=6)
-    ref = o_step.image_step('dsprites', state, x, lab, eps, (1, 2, 3, 4, 5), 4.0, 10.0, 1.0)
-    for k in ('recons', 'dist', 'reg', 'loss'):
-        close(got[k], float(ref['terms'][k]), rtol=1e-4)
-
-
-_CONV32_PROBE = """
-import sys; sys.path.insert(0, %r)
-import numpy as np, torch
-from arvae_amd import ops
-dev = torch.device('cuda:0')
-rs = np.random.RandomState(11)
-n = 24
-hi = torch.from_numpy(rs.standard_normal((n, 32, 32, 32)).astype(np.float32)).to(dev)
-lo = torch.from_numpy(rs.standard_normal((n, 16, 16, 32)).astype(np.float32)).to(dev)
-w = torch.from_numpy((rs.standard_normal((32, 32, 4, 4)) * 0.1).astype(np.float32)).to(dev)
-b = torch.from_numpy(rs.standard_normal(32).astype(np.float32)).to(dev)
-link = ops.Link(32, 32, 32, 16, 16, 32, 4, 4, 2, 1)
-down = ops.link_down(link, n, ops._operand(hi), w, b, ops.ACT_NONE, None)
-up = ops.link_up(link, n, ops._operand(lo), w, b, ops.ACT_NONE, None)
-dw = torch.zeros_like(w); db = torch.zeros_like(b)
-ops.link_wgrad(link, n, ops._operand(lo), ops._operand(hi), dw, db, 1)
-np.savez(sys.argv[1], down=down.cpu().numpy(), up=up.cpu().numpy(), dw=dw.cpu().numpy(), db=db.cpu().numpy())
-"""
-
-
-def test_bf16_three_term_kernels_match_fp32_mfma_kernels(dev, tmp_path):
-    """The default conv kernels (bf16 MFMA, three-term split, six products) against the fp32-MFMA kernels
-    (ARVAE_CONV32_FP32=1) on the same data: they differ by fp32 rounding noise only."""
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = {}
-    for mode, env in (('split', {}), ('fp32', {'ARVAE_CONV32_FP32': '1'})):
-        path = str(tmp_path / (mode + '.npz'))
-        r = subprocess.run([sys.executable, '-c', _CONV32_PROBE % root, path], capture_output=True, text=True, timeout=600,
-                           env=dict(os.environ, **env), cwd=root)
-        assert r.returncode == 0, r.stderr[-2000:]
-        outs[mode] = np.load(path)
-    # float64 reference of the same three maps (torch CPU)
+def test_bf16_three_term_kernels_hold_fp32_accuracy_vs_float64(dev):
+    """The 32-channel conv kernels run the bf16 MFMA on three-term splits (six partial products, fp32 accumulation): against a
+    float64 reference of the same three maps (forward Conv2d, forward ConvTranspose2d, weight / bias gradient) their
+    relative L2 error stays below 5e-7, i.e. fp32 rounding noise -- the level the removed fp32-MFMA generation of these
+    kernels measured (<= 2x apart on every map while both existed, rounds 1-2)."""
+    from arvae_amd import ops
     rs = np.random.RandomState(11)
     n = 24
-    hi = torch.from_numpy(rs.standard_normal((n, 32, 32, 32)).astype(np.float32)).double().permute(0, 3, 1, 2)
-    lo = torch.from_numpy(rs.standard_normal((n, 16, 16, 32)).astype(np.float32)).double().permute(0, 3, 1, 2)
-    w = torch.from_numpy((rs.standard_normal((32, 32, 4, 4)) * 0.1).astype(np.float32)).double().requires_grad_(True)
-    b = torch.from_numpy(rs.standard_normal(32).astype(np.float32)).double().requires_grad_(True)
+    hi_np = rs.standard_normal((n, 32, 32, 32)).astype(np.float32)
+    lo_np = rs.standard_normal((n, 16, 16, 32)).astype(np.float32)
+    w_np = (rs.standard_normal((32, 32, 4, 4)) * 0.1).astype(np.float32)
+    b_np = rs.standard_normal(32).astype(np.float32)
+    hi_d, lo_d, w_d, b_d = (torch.from_numpy(a).to(dev) for a in (hi_np, lo_np, w_np, b_np))
+    link = ops.Link(32, 32, 32, 16, 16, 32, 4, 4, 2, 1)
+    got = {'down': ops.link_down(link, n, ops._operand(hi_d), w_d, b_d, ops.ACT_NONE, None),
+           'up': ops.link_up(link, n, ops._operand(lo_d), w_d, b_d, ops.ACT_NONE, None)}
+    dw, db = torch.zeros_like(w_d), torch.zeros_like(b_d)
+    ops.link_wgrad(link, n, ops._operand(lo_d), ops._operand(hi_d), dw, db, 1)
+    got.update(dw=dw, db=db)
+    hi = torch.from_numpy(hi_np).double().permute(0, 3, 1, 2)
+    lo = torch.from_numpy(lo_np).double().permute(0, 3, 1, 2)
+    w = torch.from_numpy(w_np).double().requires_grad_(True)
+    b = torch.from_numpy(b_np).double().requires_grad_(True)
     down = F.conv2d(hi, w, b, stride=2, padding=1)
     up = F.conv_transpose2d(lo, w, b, stride=2, padding=1)
     down.backward(lo)                                    # dW, db of the Conv2d for the upstream gradient `lo`
     ref = {'down': down.detach().permute(0, 2, 3, 1).numpy(), 'up': up.detach().permute(0, 2, 3, 1).numpy(),
            'dw': w.grad.numpy(), 'db': b.grad.numpy()}
     for k in ('down', 'up', 'dw', 'db'):
-        err = {m: np.linalg.norm(outs[m][k].astype(np.float64) - ref[k]) / np.linalg.norm(ref[k]) for m in outs}
-        assert err['split'] < 5e-7 and err['fp32'] < 5e-7, (k, err)
-        assert err['split'] <= 2.0 * err['fp32'] + 2e-8, (k, err)     # no less accurate than the fp32 MFMA
+        err = np.linalg.norm(got[k].cpu().numpy().astype(np.float64) - ref[k]) / np.linalg.norm(ref[k])
+        assert err < 5e-7, (k, err)
 
 
 # ---------------------------------------------------------------- MeasureVAE (G6 / G7)
