@@ -115,6 +115,22 @@ __device__ __forceinline__ void split_pair3(float x0, float x1, unsigned &hi, un
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(q, bf16x2v));
 }
 
+// x = hi + mid + lo EXACTLY by truncation (8 + 8 + 8 significant bits; every subtraction is exact), packed in pairs with
+// v_perm_b32: 11 single-issue vector instructions per two values.  What a PRODUCER wave beside an MFMA wave uses: the
+// round-to-nearest split above compiles to v_cvt_pk_bf16_f32 + v_pk_add_f32, and a packed-f32 instruction costs the partner
+// wave of an MFMA wave three of the ~3.5 issue slots it gets per MFMA (tools/probes/coissue.hip).
+__device__ __forceinline__ void trunc_pair3(float x0, float x1, unsigned &hi, unsigned &mid, unsigned &lo) {
+    const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
+    float r0 = x0 - __builtin_bit_cast(float, u0 & 0xffff0000u), r1 = x1 - __builtin_bit_cast(float, u1 & 0xffff0000u);
+    asm volatile("" : "+v"(r0), "+v"(r1));                // keep the two subtractions scalar (no v_pk_add_f32)
+    const unsigned m0 = __builtin_bit_cast(unsigned, r0), m1 = __builtin_bit_cast(unsigned, r1);
+    float q0 = r0 - __builtin_bit_cast(float, m0 & 0xffff0000u), q1 = r1 - __builtin_bit_cast(float, m1 & 0xffff0000u);
+    asm volatile("" : "+v"(q0), "+v"(q1));
+    hi = __builtin_amdgcn_perm(u1, u0, 0x07060302u);     // upper halves: {x1.hi16, x0.hi16}
+    mid = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
+    lo = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, q1), __builtin_bit_cast(unsigned, q0), 0x07060302u);
+}
+
 // Per-layer prepared weights (conv32_weight_prep_kernel, conv32.hip, once per training step): the three-term split of wt in
 // per-lane MFMA operand order, 16 bytes per (slot, lane) with lanes contiguous.
 //   DOWN part: [kh 2][slot 48 = (tap 8 = kyl*4 + kx, c 2, term 3)][lane 64], ky = 2 kh + kyl: lane (rc, half) holds the input

@@ -317,6 +317,219 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
+// ================================================================================================================================
+// Producer / consumer form (round 3).  In down32k_kernel every wave is loader AND multiplier: per reduction step a wave issues 12
+// MFMAs and ~90 vector instructions of loading, splitting and LDS writing between them, and one wave per SIMD hides at most ~5 per
+// MFMA: the step takes 1.5x its MFMA issue time (stamps: 2.3 us per tile for 1.54 us of MFMA).  Here, as in wgrad32r_kernel, the
+// two jobs live in different waves of the same SIMD: waves 0-3 (consumers, wave = kernel row) keep the weights, read their
+// operands from LDS and issue MFMAs -- 6 LDS reads per 12 MFMAs and nothing else in the reduction loop; waves 4-7 (producers)
+// fetch tile t+1 .. t+3, split by truncation (single-issue instructions: they co-issue beside the partner's MFMAs) and write
+// tile t+1's LDS image while tile t is multiplied.  Same tiles, LDS images, exchange, epilogue and barriers per tile as
+// down32k_kernel; the split is the exact three-term truncation of wgrad32r_kernel instead of round-to-nearest (both reproduce
+// the fp32 operand to its last bit or two: results differ by fp32 rounding noise only).
+template <int LO, int MODE>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void down32p_kernel(const float *__restrict__ hi, Ep32 ep,
+                                                                                                 int n_img, int n_tiles) {
+    using K = DownK<LO>;
+    constexpr int HW = K::HW, PIX = K::PIX, SLOTS = K::SLOTS, HI = 2 * LO;
+    extern __shared__ __attribute__((aligned(16))) unsigned lds[];
+    unsigned *xch = lds + 2 * K::BUF;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int per_wg = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x, t_first = blockIdx.x * per_wg;
+    const int t_end = min(n_tiles, t_first + per_wg);
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+
+    if (wave >= 4) {
+        // ============================================================================================ producers
+        const int pt = threadIdx.x - 256;
+        const __amdgpu_buffer_rsrc_t rs_hi = make_rsrc(hi, (int64_t)n_img * HI * HI * PIXB);
+        int q = pt & 7, pix0 = pt >> 3;                          // slot s of this thread = staged pixel pix0 + 32 s, channels 4 q .. 4 q + 3
+        float4 lv[2][SLOTS];
+        auto issue = [&](auto set_, int s, int tile) __attribute__((always_inline)) {
+            constexpr int set = decltype(set_)::value;
+            int img0, r0;
+            tile_origin<LO, 64>(tile, img0, r0);
+            const int pix = pix0 + 32 * s, pr = pix / HW, px = pix - pr * HW;
+            const int gy = 2 * r0 - 1 + pr;
+            const bool ok = tile < t_end && pix < PIX && (unsigned)gy < (unsigned)HI;
+            lv[set][s] = buf_load4(rs_hi, ok ? (unsigned)((((img0 * HI + gy) * HI + px) * C32 + 4 * q) * 4) : OOB);
+        };
+        auto commit = [&](auto set_, int s, unsigned *buf) __attribute__((always_inline)) {
+            constexpr int set = decltype(set_)::value;
+            const int pix = pix0 + 32 * s;
+            if (SLOTS * 32 > PIX && pix >= PIX) return;
+            uint2 hv, mv, lw;
+            trunc_pair3(lv[set][s].x, lv[set][s].y, hv.x, mv.x, lw.x);
+            trunc_pair3(lv[set][s].z, lv[set][s].w, hv.y, mv.y, lw.y);
+            unsigned *d = buf + pix * PSB3 + q * 2;
+            *reinterpret_cast<uint2 *>(d) = hv;
+            *reinterpret_cast<uint2 *>(d + 16) = mv;
+            *reinterpret_cast<uint2 *>(d + 32) = lw;
+        };
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) issue(S0{}, s, t_first);
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) issue(S1{}, s, t_first + 1);
+        if (pt < 2 * PSB3) lds[(pt / PSB3) * K::BUF + PIX * PSB3 + pt % PSB3] = 0u;   // the zero pixels
+        __syncthreads();                                         // (the consumers' prologue barrier)
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) commit(S0{}, s, lds);    // first tile -> buffer 0
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) issue(S0{}, s, t_first + 2);
+        __syncthreads();
+        // tile `tile` is being multiplied from buffer cur: register set SET (tile + 1) goes to the other buffer and is refilled
+        // with tile + 3
+        auto do_tile = [&](auto set_, int tile, int cur) __attribute__((always_inline)) {
+            asm volatile("" : "+v"(q), "+v"(pix0));              // keep the slot addresses out of loop-invariant hoisting (spills)
+            unsigned *nb = lds + (cur ^ 1) * K::BUF;
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                commit(set_, s, nb);
+                issue(set_, s, tile + 3);
+            }
+            __syncthreads();                                     // exchange area free
+            __syncthreads();                                     // every read of `cur` is done, `cur ^ 1` is staged
+        };
+        for (int tile = t_first; tile < t_end; tile += 2) {
+            do_tile(S1{}, tile, 0);
+            do_tile(S0{}, tile + 1, 1);
+        }
+        return;
+    }
+
+    // ================================================================================================ consumers (wave = kernel row)
+    const int half = lane >> 5, rc = lane & 31;
+    int xoff[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        int img, r, c;
+        tile_pixel<LO, 64>(mt * 32 + rc, img, r, c);
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+            const int col = 2 * c - 1 + kx;
+            xoff[mt][kx] = ((unsigned)col < (unsigned)HW ? (2 * r + wave) * HW + col : PIX) * PSB3 + half * 4;
+        }
+    }
+    const int om = wave & 1, og = wave >> 1;
+    float4 b4[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+        b4[e] = ep.bias != nullptr ? *reinterpret_cast<const float4 *>(ep.bias + 8 * (2 * og + e) + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t out_bytes = (int64_t)n_img * LO * LO * PIXB;
+    const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(ep.out, out_bytes);
+    const __amdgpu_buffer_rsrc_t rs_gate = make_rsrc(MODE == EP_GATE_F ? ep.gate : ep.out, out_bytes);
+    const bool want_bits = MODE == EP_RELU && ep.bits_out != nullptr;
+    const __amdgpu_buffer_rsrc_t rs_bits =
+        make_rsrc(MODE == EP_GATE_B ? (const void *)ep.gate_bits : want_bits ? (const void *)ep.bits_out : (const void *)ep.out,
+                  (int64_t)n_img * LO * LO * 4);
+    const unsigned out_lane = (unsigned)((om * 32 + rc) * PIXB + (2 * og) * 32 + half * 16);
+    bf16x8 w3[8][3];
+    {
+        const uint4 *wp = ep.wprep + ((wave >> 1) * PREP_DOWN_SLOTS + ((wave & 1) * 4) * 2 * 3) * 64 + lane;
+#pragma unroll
+        for (int st = 0; st < 8; ++st)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) w3[st][t] = __builtin_bit_cast(bf16x8, wp[(st * 3 + t) * 64]);
+    }
+    __syncthreads();                                             // zero pixels written
+    __syncthreads();                                             // first tile staged
+
+    auto do_tile = [&](int tile, int cur) __attribute__((always_inline)) {
+        const unsigned *xb = lds + cur * K::BUF;
+        f32x16 acc[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+        bf16x8 x3[2][2][3];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                x3[0][mt][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4v *>(xb + xoff[mt][0] + t * 16));
+        int img0, r0;
+        tile_origin<LO, 64>(tile, img0, r0);
+        const unsigned obase = tile < t_end ? (unsigned)(((img0 * LO + r0) * LO) * PIXB) + out_lane : OOB;
+        float4 gq[2];
+        unsigned gb = 0;
+        if (MODE == EP_GATE_F) {
+            gq[0] = buf_load4(rs_gate, obase);
+            gq[1] = buf_load4(rs_gate, obase + 32);
+        }
+        if (MODE == EP_GATE_B) gb = buf_load_u16(rs_bits, bits_off(obase, half));
+        // one LDS read of the next step's operands behind every second MFMA (issue order pinned as in down32k_kernel)
+        static_for<0, 8>([&](auto kc) __attribute__((always_inline)) {
+            constexpr int step = decltype(kc)::value, cu = step & 1, nx = cu ^ 1;
+            auto item = [&](auto ic) __attribute__((always_inline)) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (step + 1 < 8) {
+                    constexpr int nkx = (step + 1) >> 1, nc = (step + 1) & 1, mt = i / 3, t = i % 3;
+                    x3[nx][mt][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4v *>(xb + xoff[mt][nkx] + t * 16 + nc * 8));
+                }
+            };
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, 12>([&](auto mc) __attribute__((always_inline)) {
+                constexpr int m = decltype(mc)::value, prod = m >> 1, mt = m & 1;
+                constexpr int tw = prod == 0 ? 2 : prod == 1 ? 0 : prod == 2 ? 1 : prod == 3 ? 1 : 0;
+                constexpr int tx = prod == 0 ? 0 : prod == 1 ? 2 : prod == 2 ? 1 : prod == 3 ? 0 : prod == 4 ? 1 : 0;
+                MFMA_B(acc[mt], w3[step][tw], x3[cu][mt][tx]);
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<m * 6 / 12, (m + 1) * 6 / 12>(item);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+        __syncthreads();                                         // the previous tile's exchange has been read by everybody
+        float4 *xq = reinterpret_cast<float4 *>(xch);
+        auto piece = [&](auto m_, auto g_, int e) __attribute__((always_inline)) -> float4 {
+            constexpr int M = decltype(m_)::value, G = decltype(g_)::value;
+            return e == 0 ? make_float4(acc[M][8 * G], acc[M][8 * G + 1], acc[M][8 * G + 2], acc[M][8 * G + 3])
+                          : make_float4(acc[M][8 * G + 4], acc[M][8 * G + 5], acc[M][8 * G + 6], acc[M][8 * G + 7]);
+        };
+        static_for<0, 4>([&](auto oc) __attribute__((always_inline)) {      // owner ow receives this wave's piece as source (wave - ow - 1) & 3
+            constexpr int ow = decltype(oc)::value;
+            if (ow != wave) {
+                const int src = (wave - ow - 1) & 3;
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+                    xq[((ow * 3 + src) * 2 + e) * 64 + lane] = piece(std::integral_constant<int, (ow & 1)>{}, std::integral_constant<int, (ow >> 1)>{}, e);
+            }
+        });
+        __syncthreads();                                         // partial sums written; every read of `cur` is done, `cur ^ 1` is staged
+        unsigned bits = 0;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            float4 v = wave == 0 ? piece(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, e)
+                     : wave == 1 ? piece(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, e)
+                     : wave == 2 ? piece(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, e)
+                                 : piece(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, e);
+#pragma unroll
+            for (int sidx = 0; sidx < 3; ++sidx) {               // fixed order: the waves wave + 1, wave + 2, wave + 3 (mod 4)
+                const float4 p = xq[((wave * 3 + sidx) * 2 + e) * 64 + lane];
+                v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+            }
+            float o4[4] = {v.x + b4[e].x, v.y + b4[e].y, v.z + b4[e].z, v.w + b4[e].w};
+            const float gf[4] = {gq[e].x, gq[e].y, gq[e].z, gq[e].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (MODE == EP_RELU) {
+                    o4[j] = fmaxf(o4[j], 0.f);
+                    bits |= (o4[j] > 0.f ? 1u : 0u) << (4 * e + j);
+                }
+                if (MODE == EP_GATE_F) o4[j] = gf[j] > 0.f ? o4[j] : 0.f;
+                if (MODE == EP_GATE_B) o4[j] = ((gb >> (8 * og + 4 * e + j)) & 1u) ? o4[j] : 0.f;
+            }
+            buf_store4(make_float4(o4[0], o4[1], o4[2], o4[3]), rs_out, obase + e * 32);
+        }
+        if (MODE == EP_RELU)
+            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)bits, rs_bits, (int)((obase == OOB || !want_bits) ? OOB : bits_off(obase, half) + og), 0, 0);
+    };
+    for (int tile = t_first; tile < t_end; tile += 2) {
+        do_tile(tile, 0);
+        do_tile(tile + 1, 1);
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------------
 static int cu_count_k() {
     static int n = 0;
@@ -340,10 +553,13 @@ template <int LO, int MODE> static void launch_down_k(const float *hi, const Ep3
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void *)down32k_kernel<LO, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void *)down32p_kernel<LO, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr = true;
     }
     const int tiles = n * DownK<LO>::TILES_PER_IMG, cus = cu_count_k();
-    ARVAE_LAUNCH((down32k_kernel<LO, MODE>), dim3(tiles < cus ? tiles : cus), dim3(256), LDS, s, hi, ep, n, tiles);
+    static const bool pc = getenv("ARVAE_D32K_NO_PC") == nullptr;           // A/B: every wave loader and multiplier (round 2)
+    if (pc) ARVAE_LAUNCH((down32p_kernel<LO, MODE>), dim3(tiles < cus ? tiles : cus), dim3(512), LDS, s, hi, ep, n, tiles);
+    else ARVAE_LAUNCH((down32k_kernel<LO, MODE>), dim3(tiles < cus ? tiles : cus), dim3(256), LDS, s, hi, ep, n, tiles);
 }
 
 template <int LO> static void launch_down_k_mode(const float *hi, const Ep32 &ep, int mode, int n, hipStream_t s) {

@@ -73,21 +73,7 @@ __device__ __forceinline__ void wgrad32r_body(const float *__restrict__ lo, cons
         const __amdgpu_buffer_rsrc_t rs_hi = make_rsrc(hi, (int64_t)n_img * RS::HW * RB);
         const __amdgpu_buffer_rsrc_t rs_lo = make_rsrc(lo, (int64_t)n_img * LO * LO * PIXB);
         float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);         // BIAS 1: lo sums, BIAS 2: hi sums, channels 4 chunk .. +3
-        // x = hi + mid + lo EXACTLY by truncation (8 + 8 + 8 significant bits; every subtraction is exact), packed in pairs
-        // with v_perm_b32: 11 single-issue vector instructions per two values.  (The round-to-nearest split of
-        // conv32_common.h compiles to v_cvt_pk_bf16_f32 + v_pk_add_f32, and a packed-f32 instruction costs the partner wave
-        // of an MFMA wave three of the ~3.5 issue slots it gets per MFMA: tools/probes/coissue.hip.)
-        auto trunc_pair3 = [&](float x0, float x1, unsigned &hi, unsigned &mid, unsigned &lo) __attribute__((always_inline)) {
-            const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
-            float r0 = x0 - __builtin_bit_cast(float, u0 & 0xffff0000u), r1 = x1 - __builtin_bit_cast(float, u1 & 0xffff0000u);
-            asm volatile("" : "+v"(r0), "+v"(r1));                // keep the two subtractions scalar (no v_pk_add_f32)
-            const unsigned m0 = __builtin_bit_cast(unsigned, r0), m1 = __builtin_bit_cast(unsigned, r1);
-            float q0 = r0 - __builtin_bit_cast(float, m0 & 0xffff0000u), q1 = r1 - __builtin_bit_cast(float, m1 & 0xffff0000u);
-            asm volatile("" : "+v"(q0), "+v"(q1));
-            hi = __builtin_amdgcn_perm(u1, u0, 0x07060302u);     // upper halves: {x1.hi16, x0.hi16}
-            mid = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
-            lo = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, q1), __builtin_bit_cast(unsigned, q0), 0x07060302u);
-        };
+        // (the split: trunc_pair3, conv32_common.h -- exact three-term truncation, single-issue instructions only)
         auto put = [&](unsigned *dst, int plane, const float4 &v) __attribute__((always_inline)) {
             uint2 hv, mv, lv;
 #ifdef WGR_FAKE_2TERM

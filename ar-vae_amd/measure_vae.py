@@ -267,8 +267,9 @@ class HierarchicalDecoder(Decoder):
             if self._mask_queue:
                 masks = tuple(m.to(z.device) for m in self._mask_queue.popleft())
             else:
-                h = self.rnn_hidden_size
-                masks = (ops.keep_mask((4, b, h), self.dropout, z.device), ops.keep_mask((24, b, h), self.dropout, z.device))
+                h = self.rnn_hidden_size                    # one draw for the beat (4 steps) and the tick (24 steps) masks
+                both = ops.keep_mask((4 + 24, b, h), self.dropout, z.device)
+                masks = (both[:4], both[4:])
         if _use_sequence_kernels(self.rnn_hidden_size):
             beat_out = self.beat_rnn_sequence(z, 4, masks[0])
             return self.tick_rnn_sequence(score_tensor, beat_out, 6, teacher_forced, masks[1])
@@ -398,6 +399,21 @@ class HierarchicalDecoder(Decoder):
         return torch.stack(weights, 1), torch.stack(samples, 1)[:, None, :]
 
 
+_PRIOR_CONSTANTS = {}
+
+
+def _standard_normal_like(mu):
+    """N(0, I) of mu's shape without a launch: loc / scale are expanded views of two cached device scalars (the reference
+    fills two tensors per step: measure_vae.py:118-121); `_arvae_standard` lets compute_kld_loss use the closed form."""
+    key = (mu.device, mu.dtype)
+    if key not in _PRIOR_CONSTANTS:
+        _PRIOR_CONSTANTS[key] = (torch.zeros((), device=mu.device, dtype=mu.dtype), torch.ones((), device=mu.device, dtype=mu.dtype))
+    zero, one = _PRIOR_CONSTANTS[key]
+    prior = distributions.Normal(loc=zero.expand(mu.shape), scale=one.expand(mu.shape), validate_args=False)
+    prior._arvae_standard = True
+    return prior
+
+
 class MeasureVAE(Model):
     def __init__(self, dataset, note_embedding_dim=10, metadata_embedding_dim=2, num_encoder_layers=2,
                  encoder_hidden_size=512, encoder_dropout_prob=0.5, latent_space_dim=256, num_decoder_layers=2,
@@ -425,13 +441,15 @@ class MeasureVAE(Model):
     def push_noise(self, eps):
         self.encoder.push_noise(eps)
 
-    def forward(self, measure_score_tensor, measure_metadata_tensor=None, train=True):
+    def forward(self, measure_score_tensor, measure_metadata_tensor=None, train=True, *, need_prior_sample=True):
+        """-> (weights, samples, z_dist, prior_dist, z_tilde, z_prior) as the reference (measure_vae.py:97-131).
+        need_prior_sample=False (what this build's trainer passes: it never looks at z_prior, nor does the reference's):
+        z_prior is None and the launch that would draw it is skipped."""
         if measure_score_tensor.size(1) != self.num_ticks_per_measure:
             raise AssertionError('a measure has 24 ticks')
         z_dist = self.encoder(measure_score_tensor)
-        mu, sigma, z_tilde = z_dist.loc, z_dist.scale, z_dist._arvae_sample
-        prior_dist = distributions.Normal(loc=torch.zeros_like(mu), scale=torch.ones_like(sigma), validate_args=False)
-        prior_dist._arvae_standard = True
-        z_prior = ops.normal_noise(mu.shape, mu.device)      # the reference's second, unused draw (measure_vae.py:123)
+        mu, z_tilde = z_dist.loc, z_dist._arvae_sample
+        prior_dist = _standard_normal_like(mu)
+        z_prior = ops.normal_noise(mu.shape, mu.device) if need_prior_sample else None     # the reference's second, unused draw
         weights, samples = self.decoder(z=z_tilde, score_tensor=measure_score_tensor, train=train)
         return weights, samples, z_dist, prior_dist, z_tilde, z_prior

@@ -120,8 +120,8 @@ class MeasureVAETrainer(Trainer):
         if first_of_epoch:
             self.cur_epoch_num = epoch_num
         score, metadata = batch
-        weights, samples, z_dist, prior_dist, z_tilde, _ = self.model(measure_score_tensor=score,
-                                                                       measure_metadata_tensor=metadata, train=train)
+        weights, samples, z_dist, prior_dist, z_tilde, _ = self.model(measure_score_tensor=score, measure_metadata_tensor=metadata,
+                                                                       train=train, need_prior_sample=False)
         recons_loss, accuracy = ops.token_recon(weights, score)
         dist_loss = self.compute_kld_loss(z_dist, prior_dist, self.beta)
         loss = recons_loss + dist_loss
