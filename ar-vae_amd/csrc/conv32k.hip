@@ -27,8 +27,11 @@ namespace arvae {
 // diagnostic build only (tools/stamp_d32k.py): phase timeline of the first 64 workgroups, 100 MHz wall clock
 __device__ unsigned long long g_d32k_stamps[64 * 64];
 #define KSTAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 64 && (slot) < 64) g_d32k_stamps[blockIdx.x * 64 + (slot)] = wall_clock64(); } while (0)
+// down32p_kernel: rows 0..31 = the consumers of workgroups 0..31 (thread 0), rows 32..63 = their producers (thread 256)
+#define PSTAMP(role, slot) do { if (threadIdx.x == 256 * (role) && blockIdx.x < 32 && (slot) < 64) g_d32k_stamps[(blockIdx.x + 32 * (role)) * 64 + (slot)] = wall_clock64(); } while (0)
 #else
 #define KSTAMP(slot)
+#define PSTAMP(role, slot)
 #endif
 
 template <int LO> struct DownK {
@@ -342,6 +345,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     if (wave >= 4) {
         // ============================================================================================ producers
+        PSTAMP(1, 0);
+        int pst = 0;
+        (void)pst;
         const int pt = threadIdx.x - 256;
         const __amdgpu_buffer_rsrc_t rs_hi = make_rsrc(hi, (int64_t)n_img * HI * HI * PIXB);
         int q = pt & 7, pix0 = pt >> 3;                          // slot s of this thread = staged pixel pix0 + 32 s, channels 4 q .. 4 q + 3
@@ -378,18 +384,44 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) issue(S0{}, s, t_first + 2);
         __syncthreads();
+        // per thread, for the loads issued inside the tile loop (as down32k_kernel): byte offset of slot 0 in a patch and the slots
+        // (bit s) that sit in the patch's first / last row or past its end -- a slot then costs a test, an add and a select
+        const unsigned rel0 = (unsigned)(pix0 * PIXB + q * 16);
+        unsigned first_row = 0, last_row = 0, no_slot = 0;
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            const int pix = pix0 + 32 * s, pr = pix / HW;
+            if (pr == 0) first_row |= 1u << s;
+            if (pr == PIX / HW - 1) last_row |= 1u << s;
+            if (pix >= PIX) no_slot |= 1u << s;
+        }
         // tile `tile` is being multiplied from buffer cur: register set SET (tile + 1) goes to the other buffer and is refilled
         // with tile + 3
         auto do_tile = [&](auto set_, int tile, int cur) __attribute__((always_inline)) {
+            constexpr int set = decltype(set_)::value;
             asm volatile("" : "+v"(q), "+v"(pix0));              // keep the slot addresses out of loop-invariant hoisting (spills)
+            PSTAMP(1, 4 + 5 * pst);
             unsigned *nb = lds + (cur ^ 1) * K::BUF;
+            unsigned n_base, n_bad;
+            {
+                const int nt = tile + 3;
+                int ni, nr;
+                tile_origin<LO, 64>(nt, ni, nr);
+                const int gy0 = 2 * nr - 1;
+                n_base = nt < t_end ? (unsigned)(((ni * HI + gy0) * HI) * PIXB) + rel0 : OOB;
+                n_bad = (gy0 < 0 ? first_row : 0u) | (gy0 + PIX / HW - 1 >= HI ? last_row : 0u) | no_slot;
+            }
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s) {
                 commit(set_, s, nb);
-                issue(set_, s, tile + 3);
+                lv[set][s] = buf_load4(rs_hi, (n_bad & (1u << s)) != 0 ? OOB : n_base + 4096u * s);
             }
+            PSTAMP(1, 5 + 5 * pst);
             __syncthreads();                                     // exchange area free
+            PSTAMP(1, 6 + 5 * pst);
             __syncthreads();                                     // every read of `cur` is done, `cur ^ 1` is staged
+            PSTAMP(1, 7 + 5 * pst);
+            ++pst;
         };
         for (int tile = t_first; tile < t_end; tile += 2) {
             do_tile(S1{}, tile, 0);
@@ -399,6 +431,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 
     // ================================================================================================ consumers (wave = kernel row)
+    PSTAMP(0, 0);
+    int cst = 0;
+    (void)cst;
     const int half = lane >> 5, rc = lane & 31;
     int xoff[2][4];
 #pragma unroll
@@ -434,8 +469,48 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     __syncthreads();                                             // zero pixels written
     __syncthreads();                                             // first tile staged
+    PSTAMP(0, 1);
 
+    // The epilogue of tile t (sum of the four kernel rows' partial tiles, bias, ReLU / gate, stores) is DEFERRED into the
+    // reduction loop of tile t + 1, one small piece behind an MFMA at a time: between two tiles the matrix pipe then waits for
+    // the exchange alone (stamps, B = 512, 16x16 layer: k-loop 1.9 us, exchange 0.3 us, epilogue 0.4 us per tile before).
+    float4 own[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};     // this wave's share of the previous tile
+    float4 gq_prev[2] = {own[0], own[0]};
+    unsigned obase_prev = OOB, gb_prev = 0;
+    const float4 *xq_own = reinterpret_cast<const float4 *>(xch) + (wave * 3) * 2 * 64 + lane;
+    unsigned bits_acc = 0;
+    // piece i of the deferred epilogue: 0-2 / 4-6: add the partial of source i (mod 4) to half e = i / 4; 3 / 7: finish + store
+    // half e; 8: the sign bits
+    auto epi_item = [&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (i < 8) {
+            constexpr int e = i / 4, k = i % 4;
+            if constexpr (k < 3) {
+                const float4 p = xq_own[(k * 2 + e) * 64];
+                own[e].x += p.x; own[e].y += p.y; own[e].z += p.z; own[e].w += p.w;
+            } else {
+                float o4[4] = {own[e].x + b4[e].x, own[e].y + b4[e].y, own[e].z + b4[e].z, own[e].w + b4[e].w};
+                const float gf[4] = {gq_prev[e].x, gq_prev[e].y, gq_prev[e].z, gq_prev[e].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (MODE == EP_RELU) {
+                        o4[j] = fmaxf(o4[j], 0.f);
+                        bits_acc |= (o4[j] > 0.f ? 1u : 0u) << (4 * e + j);
+                    }
+                    if (MODE == EP_GATE_F) o4[j] = gf[j] > 0.f ? o4[j] : 0.f;
+                    if (MODE == EP_GATE_B) o4[j] = ((gb_prev >> (8 * og + 4 * e + j)) & 1u) ? o4[j] : 0.f;
+                }
+                buf_store4(make_float4(o4[0], o4[1], o4[2], o4[3]), rs_out, obase_prev + e * 32);
+            }
+        } else if constexpr (i == 8) {
+            if (MODE == EP_RELU)        // unconditional (exact vmcnt counts in the loop); dropped through its offset without bits_out
+                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)bits_acc, rs_bits,
+                                                     (int)((obase_prev == OOB || !want_bits) ? OOB : bits_off(obase_prev, half) + og), 0, 0);
+            bits_acc = 0;
+        }
+    };
     auto do_tile = [&](int tile, int cur) __attribute__((always_inline)) {
+        PSTAMP(0, 4 + 5 * cst);
         const unsigned *xb = lds + cur * K::BUF;
         f32x16 acc[2];
 #pragma unroll
@@ -451,6 +526,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         int img0, r0;
         tile_origin<LO, 64>(tile, img0, r0);
         const unsigned obase = tile < t_end ? (unsigned)(((img0 * LO + r0) * LO) * PIXB) + out_lane : OOB;
+        // gate values / sign bits of this tile's outputs: requested now, used one tile later
         float4 gq[2];
         unsigned gb = 0;
         if (MODE == EP_GATE_F) {
@@ -458,16 +534,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             gq[1] = buf_load4(rs_gate, obase + 32);
         }
         if (MODE == EP_GATE_B) gb = buf_load_u16(rs_bits, bits_off(obase, half));
-        // one LDS read of the next step's operands behind every second MFMA (issue order pinned as in down32k_kernel)
+        // issue order pinned as in down32k_kernel: behind every MFMA at most one operand read of the next step or one piece of
+        // the previous tile's epilogue (steps 1 .. 3: three pieces each)
         static_for<0, 8>([&](auto kc) __attribute__((always_inline)) {
             constexpr int step = decltype(kc)::value, cu = step & 1, nx = cu ^ 1;
             auto item = [&](auto ic) __attribute__((always_inline)) {
                 constexpr int i = decltype(ic)::value;
-                if constexpr (step + 1 < 8) {
-                    constexpr int nkx = (step + 1) >> 1, nc = (step + 1) & 1, mt = i / 3, t = i % 3;
-                    x3[nx][mt][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4v *>(xb + xoff[mt][nkx] + t * 16 + nc * 8));
+                if constexpr (i < 6) {
+                    if constexpr (step + 1 < 8) {
+                        constexpr int nkx = (step + 1) >> 1, nc = (step + 1) & 1, mt = i / 3, t = i % 3;
+                        x3[nx][mt][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4v *>(xb + xoff[mt][nkx] + t * 16 + nc * 8));
+                    }
+                } else if constexpr (step >= 1 && step <= 3) {
+                    epi_item(std::integral_constant<int, (step - 1) * 3 + (i - 6)>{});
                 }
             };
+            constexpr int n_items = (step >= 1 && step <= 3) ? 9 : 6;
             __builtin_amdgcn_sched_barrier(0);
             static_for<0, 12>([&](auto mc) __attribute__((always_inline)) {
                 constexpr int m = decltype(mc)::value, prod = m >> 1, mt = m & 1;
@@ -475,12 +557,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 constexpr int tx = prod == 0 ? 0 : prod == 1 ? 2 : prod == 2 ? 1 : prod == 3 ? 0 : prod == 4 ? 1 : 0;
                 MFMA_B(acc[mt], w3[step][tw], x3[cu][mt][tx]);
                 __builtin_amdgcn_sched_barrier(0);
-                static_for<m * 6 / 12, (m + 1) * 6 / 12>(item);
+                static_for<m * n_items / 12, (m + 1) * n_items / 12>(item);
                 __builtin_amdgcn_sched_barrier(0);
             });
         });
+        PSTAMP(0, 5 + 5 * cst);
         __syncthreads();                                         // the previous tile's exchange has been read by everybody
+        PSTAMP(0, 6 + 5 * cst);
         float4 *xq = reinterpret_cast<float4 *>(xch);
+        // acc registers 4 (2 G + e) + j of column tile M: owner (M, G) = wave M + 2 G
         auto piece = [&](auto m_, auto g_, int e) __attribute__((always_inline)) -> float4 {
             constexpr int M = decltype(m_)::value, G = decltype(g_)::value;
             return e == 0 ? make_float4(acc[M][8 * G], acc[M][8 * G + 1], acc[M][8 * G + 2], acc[M][8 * G + 3])
@@ -495,39 +580,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     xq[((ow * 3 + src) * 2 + e) * 64 + lane] = piece(std::integral_constant<int, (ow & 1)>{}, std::integral_constant<int, (ow >> 1)>{}, e);
             }
         });
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            own[e] = wave == 0 ? piece(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, e)
+                   : wave == 1 ? piece(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, e)
+                   : wave == 2 ? piece(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, e)
+                               : piece(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, e);
+        obase_prev = obase;
+        gb_prev = gb;
+        if (MODE == EP_GATE_F) { gq_prev[0] = gq[0]; gq_prev[1] = gq[1]; }
         __syncthreads();                                         // partial sums written; every read of `cur` is done, `cur ^ 1` is staged
-        unsigned bits = 0;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            float4 v = wave == 0 ? piece(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, e)
-                     : wave == 1 ? piece(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, e)
-                     : wave == 2 ? piece(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, e)
-                                 : piece(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, e);
-#pragma unroll
-            for (int sidx = 0; sidx < 3; ++sidx) {               // fixed order: the waves wave + 1, wave + 2, wave + 3 (mod 4)
-                const float4 p = xq[((wave * 3 + sidx) * 2 + e) * 64 + lane];
-                v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
-            }
-            float o4[4] = {v.x + b4[e].x, v.y + b4[e].y, v.z + b4[e].z, v.w + b4[e].w};
-            const float gf[4] = {gq[e].x, gq[e].y, gq[e].z, gq[e].w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (MODE == EP_RELU) {
-                    o4[j] = fmaxf(o4[j], 0.f);
-                    bits |= (o4[j] > 0.f ? 1u : 0u) << (4 * e + j);
-                }
-                if (MODE == EP_GATE_F) o4[j] = gf[j] > 0.f ? o4[j] : 0.f;
-                if (MODE == EP_GATE_B) o4[j] = ((gb >> (8 * og + 4 * e + j)) & 1u) ? o4[j] : 0.f;
-            }
-            buf_store4(make_float4(o4[0], o4[1], o4[2], o4[3]), rs_out, obase + e * 32);
-        }
-        if (MODE == EP_RELU)
-            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)bits, rs_bits, (int)((obase == OOB || !want_bits) ? OOB : bits_off(obase, half) + og), 0, 0);
+        PSTAMP(0, 7 + 5 * cst);
+        PSTAMP(0, 8 + 5 * cst);
+        ++cst;
     };
     for (int tile = t_first; tile < t_end; tile += 2) {
         do_tile(tile, 0);
         do_tile(tile + 1, 1);
     }
+    static_for<0, 9>(epi_item);                                  // the last tile's epilogue
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------

@@ -1,0 +1,11 @@
+#!/bin/bash
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
+python -m pytest tests/test_hip_parity.py -x -q -m gpu 2>&1 | tail -8 > gpurun_out/b8_tests.txt
+ARVAE_LIB=$PWD/tools/bin/lib_d32pst.so ARVAE_D32K_ONLY16=1 python tools/stamp_d32p.py > gpurun_out/b8_stamps.txt 2>&1
+q() { python -c 'import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d["value"]), round(d["ms_per_step"],4), d["config"].get("launch",""))'; }
+for rep in 1 2; do
+  echo "down32p      $(python bench.py --no-cpu-baseline --no-secondary 2>/dev/null | q)"
+  echo "down32k      $(ARVAE_D32K_NO_PC=1 python bench.py --no-cpu-baseline --no-secondary 2>/dev/null | q)"
+done > gpurun_out/b8_bench.txt 2>&1
+bash tools/trace_kernels.sh down32 > gpurun_out/b8_trace.txt 2>&1
