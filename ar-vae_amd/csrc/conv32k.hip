@@ -1,36 +1,32 @@
 // Down map of the 32-channel k4/s2/p1 links (Conv2d forward, ConvTranspose2d data gradient) at 16x16 and 8x8 output size,
-// FOUR-WAY REDUCTION-SPLIT form (gfx950).
+// FOUR-WAY REDUCTION-SPLIT form with PRODUCER / CONSUMER waves (gfx950).
 //
 //   lo[n,ly,lx,clo] = ep( sum_{ky,kx,chi} hi[n,2ly-1+ky,2lx-1+kx,chi] * wt[clo][chi][ky][kx] )
 //
 // down32x_kernel (conv32.hip) splits the reduction two ways: a wave keeps 128 weights x 3 bf16 terms in 192 registers, one
-// accumulator tile, and what is left holds one tile of input in flight.  Here the reduction is split FOUR ways (wave = kernel
-// row): a wave's weights are 96 registers (resident for the whole launch, 24 coalesced loads from conv32_weight_prep's DOWN
-// part), it owns two accumulator tiles (its MFMAs alternate between them: no dependent chains) and two tiles of input are in
-// flight.  (A first version streamed the weights from L2 instead; at 12 MFMAs per reduction step two steps of lookahead do not
-// cover an L2 round trip.)
+// accumulator tile, and what is left holds one tile of input in flight.  Here the reduction is split FOUR ways (consumer wave
+// = kernel row): a wave's weights are 96 registers (resident for the whole launch, 24 coalesced loads from
+// conv32_weight_prep's DOWN part) and it owns two accumulator tiles (its MFMAs alternate between them).
 //   * a tile = 64 lo pixels (4 rows at 16x16, one image at 8x8) = two 32-pixel MFMA column tiles; weight = A operand
 //     (row = output channel), pixels = B operand, 32x32x16 bf16, six partial products per multiply-add, smallest first;
-//   * wave = kernel row ky (K split four ways): 8 reduction steps (kx, 16-channel chunk) of 12 MFMAs per tile.  The four
-//     partial sums meet through a 24 KB LDS area; wave w finishes column tile w & 1, channel groups 2 (w >> 1), 2 (w >> 1) + 1
-//     (16-byte stores, one byte of ReLU sign bits per lane);
+//   * consumer wave = kernel row ky (K split four ways): 8 reduction steps (kx, 16-channel chunk) of 12 MFMAs per tile.  The
+//     four partial sums meet through a 24 KB LDS area; wave w finishes column tile w & 1, channel groups 2 (w >> 1),
+//     2 (w >> 1) + 1 (16-byte stores, one byte of ReLU sign bits per lane);
 //   * the input patch (2 TR + 2 rows x 2 LO columns, no column halo: a tap outside reads one shared zero pixel) is split into
-//     three bf16 terms once and packed per pixel (PSB3), two LDS buffers; loader slots of tile t+1 are split and written
-//     during tile t's MFMAs and refilled with tile t+3, the registers of tile t+2 stay in flight.
-// Same numerics as down32x_kernel except for the association of the four kernel rows' partial sums.
+//     three bf16 terms once and packed per pixel (PSB3), two LDS buffers: the producer waves write tile t+1's image while tile t
+//     is multiplied and keep the loads of tiles t+2, t+3 in flight.
+// Round 2's form of this kernel (every wave loader AND multiplier, 256 threads) is gone: see the comment at the kernel.
 #include "common.h"
 #include "conv32_common.h"
 
 namespace arvae {
 
 #ifdef D32K_STAMPS
-// diagnostic build only (tools/stamp_d32k.py): phase timeline of the first 64 workgroups, 100 MHz wall clock
+// diagnostic build only (tools/stamp_d32p.py): phase timeline of the first 32 workgroups, 100 MHz wall clock
 __device__ unsigned long long g_d32k_stamps[64 * 64];
-#define KSTAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 64 && (slot) < 64) g_d32k_stamps[blockIdx.x * 64 + (slot)] = wall_clock64(); } while (0)
 // down32p_kernel: rows 0..31 = the consumers of workgroups 0..31 (thread 0), rows 32..63 = their producers (thread 256)
 #define PSTAMP(role, slot) do { if (threadIdx.x == 256 * (role) && blockIdx.x < 32 && (slot) < 64) g_d32k_stamps[(blockIdx.x + 32 * (role)) * 64 + (slot)] = wall_clock64(); } while (0)
 #else
-#define KSTAMP(slot)
 #define PSTAMP(role, slot)
 #endif
 
@@ -46,290 +42,16 @@ template <int LO> struct DownK {
     static constexpr int TILES_PER_IMG = LO / T::TR;
 };
 
-template <int LO, int MODE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void down32k_kernel(const float *__restrict__ hi, Ep32 ep,
-                                                                                                 int n_img, int n_tiles) {
-    KSTAMP(0);
-    using K = DownK<LO>;
-    constexpr int HW = K::HW, PIX = K::PIX, SLOTS = K::SLOTS, HI = 2 * LO;
-    extern __shared__ __attribute__((aligned(16))) unsigned lds[];
-    unsigned *xch = lds + 2 * K::BUF;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int half = lane >> 5, rc = lane & 31;
-    const __amdgpu_buffer_rsrc_t rs_hi = make_rsrc(hi, (int64_t)n_img * HI * HI * PIXB);
-    // a workgroup owns a CONTIGUOUS run of tiles (consecutive row groups of the same images): the halo rows two tiles share
-    // are then fetched by the same CU / XCD a tile apart and come from its L2 instead of from HBM again
-    const int per_wg = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x, t_first = blockIdx.x * per_wg;
-    const int t_end = min(n_tiles, t_first + per_wg);
-
-    // ---- loader: slot s of this thread = staged pixel pix0 + 32 s, channels 4 q .. 4 q + 3 ------------------------------------
-    // (q / pix0 are laundered through an empty asm once per tile pair: the addresses derived from them are loop
-    // invariant, LLVM would hoist all of them out of the tile loop and spill -- see conv64s.hip)
-    int q = threadIdx.x & 7, pix0 = threadIdx.x >> 3;
-    float4 lv[2][SLOTS];
-    auto issue = [&](auto set_, int s, int tile) __attribute__((always_inline)) {
-        constexpr int set = decltype(set_)::value;
-        int img0, r0;
-        tile_origin<LO, 64>(tile, img0, r0);
-        const int pix = pix0 + 32 * s, pr = pix / HW, px = pix - pr * HW;
-        const int gy = 2 * r0 - 1 + pr;
-        const bool ok = tile < t_end && pix < PIX && (unsigned)gy < (unsigned)HI;
-        lv[set][s] = buf_load4(rs_hi, ok ? (unsigned)((((img0 * HI + gy) * HI + px) * C32 + 4 * q) * 4) : OOB);
-    };
-    auto commit = [&](auto set_, int s, unsigned *buf) __attribute__((always_inline)) {
-        constexpr int set = decltype(set_)::value;
-        const int pix = pix0 + 32 * s;
-        if (SLOTS * 32 > PIX && pix >= PIX) return;
-        uint2 hv, mv, lw;
-        split_pair3(lv[set][s].x, lv[set][s].y, hv.x, mv.x, lw.x);
-        split_pair3(lv[set][s].z, lv[set][s].w, hv.y, mv.y, lw.y);
-        unsigned *d = buf + pix * PSB3 + q * 2;
-        *reinterpret_cast<uint2 *>(d) = hv;
-        *reinterpret_cast<uint2 *>(d + 16) = mv;
-        *reinterpret_cast<uint2 *>(d + 32) = lw;
-    };
-    // per thread, for the loads issued inside the tile loop: byte offset of slot 0 in a patch and the slots (bit s) that sit in
-    // the patch's first / last row or past its end
-    const unsigned rel0 = (unsigned)(pix0 * PIXB + q * 16);
-    unsigned first_row = 0, last_row = 0, no_slot = 0;
-#pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-        const int pix = pix0 + 32 * s, pr = pix / HW;
-        if (pr == 0) first_row |= 1u << s;
-        if (pr == PIX / HW - 1) last_row |= 1u << s;
-        if (pix >= PIX) no_slot |= 1u << s;
-    }
-    using S0 = std::integral_constant<int, 0>;
-    using S1 = std::integral_constant<int, 1>;
-#pragma unroll
-    for (int s = 0; s < SLOTS; ++s) issue(S0{}, s, t_first);
-#pragma unroll
-    for (int s = 0; s < SLOTS; ++s) issue(S1{}, s, t_first + 1);
-    if (threadIdx.x < 2 * PSB3) lds[(threadIdx.x / PSB3) * K::BUF + PIX * PSB3 + threadIdx.x % PSB3] = 0u;   // the zero pixels
-
-    // ---- consumer geometry: wave = kernel row ky; pixel of (mt, lane) -------------------------------------------------------
-    // xoff[mt][kx]: dword offset of the lane's tap pixel (2 r + ky, 2 c - 1 + kx) in a buffer (+ half * 4), or the zero pixel
-    int xoff[2][4];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        int img, r, c;
-        tile_pixel<LO, 64>(mt * 32 + rc, img, r, c);
-#pragma unroll
-        for (int kx = 0; kx < 4; ++kx) {
-            const int col = 2 * c - 1 + kx;
-            xoff[mt][kx] = ((unsigned)col < (unsigned)HW ? (2 * r + wave) * HW + col : PIX) * PSB3 + half * 4;
-        }
-    }
-    // this wave's share of the outputs after the exchange: column tile om, channel groups 2 og, 2 og + 1
-    const int om = wave & 1, og = wave >> 1;
-    float4 b4[2];
-#pragma unroll
-    for (int e = 0; e < 2; ++e)
-        b4[e] = ep.bias != nullptr ? *reinterpret_cast<const float4 *>(ep.bias + 8 * (2 * og + e) + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const int64_t out_bytes = (int64_t)n_img * LO * LO * PIXB;
-    const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(ep.out, out_bytes);
-    const __amdgpu_buffer_rsrc_t rs_gate = make_rsrc(MODE == EP_GATE_F ? ep.gate : ep.out, out_bytes);
-    const bool want_bits = MODE == EP_RELU && ep.bits_out != nullptr;
-    const __amdgpu_buffer_rsrc_t rs_bits =
-        make_rsrc(MODE == EP_GATE_B ? (const void *)ep.gate_bits : want_bits ? (const void *)ep.bits_out : (const void *)ep.out,
-                  (int64_t)n_img * LO * LO * 4);
-    const unsigned out_lane = (unsigned)((om * 32 + rc) * PIXB + (2 * og) * 32 + half * 16);
-
-    // weight operands: with the reduction split four ways a wave's share is 8 steps x 3 terms = 96 registers, resident for
-    // the whole launch (24 coalesced 16-byte loads from conv32_weight_prep's DOWN part)
-    bf16x8 w3[8][3];
-    {
-        const uint4 *wp = ep.wprep + ((wave >> 1) * PREP_DOWN_SLOTS + ((wave & 1) * 4) * 2 * 3) * 64 + lane;
-#pragma unroll
-        for (int st = 0; st < 8; ++st)
-#pragma unroll
-            for (int t = 0; t < 3; ++t) w3[st][t] = __builtin_bit_cast(bf16x8, wp[(st * 3 + t) * 64]);
-    }
-
-    __syncthreads();                                             // zero pixels written
-#pragma unroll
-    for (int s = 0; s < SLOTS; ++s) commit(S0{}, s, lds);        // first tile -> buffer 0
-#pragma unroll
-    for (int s = 0; s < SLOTS; ++s) issue(S0{}, s, t_first + 2);
-    __syncthreads();
-
-    int kst = 0;
-    (void)kst;
-    KSTAMP(1);
-    // one tile: buffer `cur` is multiplied, register set SET (tile + stride) is committed to the other buffer and refilled
-    // with tile + 3 stride
-    auto do_tile = [&](auto set_, int tile, int cur) __attribute__((always_inline)) {
-        asm volatile("" : "+v"(q), "+v"(pix0));
-        KSTAMP(4 + 5 * kst);
-        const unsigned *xb = lds + cur * K::BUF;
-        unsigned *nb = lds + (cur ^ 1) * K::BUF;
-        f32x16 acc[2];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
-        bf16x8 x3[2][2][3];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int t = 0; t < 3; ++t)
-                x3[0][mt][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4v *>(xb + xoff[mt][0] + t * 16));
-        // gate values / sign bits of this wave's outputs: requested now, used after the exchange
-        int img0, r0;
-        tile_origin<LO, 64>(tile, img0, r0);
-        const unsigned obase = tile < t_end ? (unsigned)(((img0 * LO + r0) * LO) * PIXB) + out_lane : OOB;
-        float4 gq[2];
-        unsigned gb = 0;
-        if (MODE == EP_GATE_F) {
-            gq[0] = buf_load4(rs_gate, obase);
-            gq[1] = buf_load4(rs_gate, obase + 32);
-        }
-        if (MODE == EP_GATE_B) gb = buf_load_u16(rs_bits, bits_off(obase, half));
-        // Issue order, pinned by hand with a scheduling barrier after every MFMA: the matrix pipe takes one 32x32x16 MFMA per
-        // 32 cycles and the wave issues in order, so whatever else the wave has to do (the next step's six operand reads, and the
-        // loader's split / LDS writes / address arithmetic / next load: ~46 vector instructions per slot) must sit BETWEEN the
-        // MFMAs in small pieces.  Left to the scheduler (with or without sched_group_barrier masks) a step came out as a block
-        // of 12 MFMAs followed by a block of ~50 vector instructions, i.e. the pipe idle half of the time, and with runs of
-        // dependent MFMAs on one accumulator (48 instead of 32 cycles each).
-        // next load of this register set: tile + 3 (per-tile part of the addresses; an invalid tile stays out of range: OOB + 4096 s
-        // wraps past any tensor size)
-        unsigned n_base, n_bad;
-        {
-            const int nt = tile + 3;
-            int ni, nr;
-            tile_origin<LO, 64>(nt, ni, nr);
-            const int gy0 = 2 * nr - 1;
-            n_base = nt < t_end ? (unsigned)(((ni * HI + gy0) * HI) * PIXB) + rel0 : OOB;
-            n_bad = (gy0 < 0 ? first_row : 0u) | (gy0 + PIX / HW - 1 >= HI ? last_row : 0u) | no_slot;
-        }
-        uint2 c_h, c_m, c_l;                                     // a slot's three terms, residuals and next address between its pieces
-        f32x2v c_r;
-        unsigned c_off = OOB;
-        // the round-to-nearest three-term split of conv32_common.h (split_pair3) in two pieces
-        auto split_a = [&](float x0, float x1, unsigned &h) __attribute__((always_inline)) {
-            const f32x2v x = {x0, x1};
-            h = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2v));
-            c_r = f32x2v{x0 - __builtin_bit_cast(float, h << 16), x1 - __builtin_bit_cast(float, h & 0xffff0000u)};
-        };
-        auto split_b = [&](unsigned &m, unsigned &l) __attribute__((always_inline)) {
-            m = __builtin_bit_cast(unsigned, __builtin_convertvector(c_r, bf16x2v));
-            const f32x2v qq = {c_r.x - __builtin_bit_cast(float, m << 16), c_r.y - __builtin_bit_cast(float, m & 0xffff0000u)};
-            l = __builtin_bit_cast(unsigned, __builtin_convertvector(qq, bf16x2v));
-        };
-        static_for<0, 8>([&](auto kc) __attribute__((always_inline)) {
-            constexpr int step = decltype(kc)::value, cu = step & 1, nx = cu ^ 1;
-            constexpr int s_lo = (step * SLOTS + 7) / 8, s_hi = ((step + 1) * SLOTS + 7) / 8;     // this step's loader slots
-            constexpr int n_items = 6 + 7 * (s_hi - s_lo);
-            auto item = [&](auto ic) __attribute__((always_inline)) {
-                constexpr int i = decltype(ic)::value;
-                if constexpr (i < 6) {
-                    if constexpr (step + 1 < 8) {
-                        constexpr int nkx = (step + 1) >> 1, nc = (step + 1) & 1, mt = i / 3, t = i % 3;
-                        x3[nx][mt][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4v *>(xb + xoff[mt][nkx] + t * 16 + nc * 8));
-                    }
-                } else if constexpr (i < n_items) {
-                    constexpr int j = i - 6, s = s_lo + j / 7, piece = j % 7, set = decltype(set_)::value;
-                    if constexpr (piece == 0) split_a(lv[set][s].x, lv[set][s].y, c_h.x);
-                    if constexpr (piece == 1) split_b(c_m.x, c_l.x);
-                    if constexpr (piece == 2) split_a(lv[set][s].z, lv[set][s].w, c_h.y);
-                    if constexpr (piece == 3) split_b(c_m.y, c_l.y);
-                    if constexpr (piece == 4) {
-                        unsigned *d = nb + (pix0 + 32 * s) * PSB3 + q * 2;
-                        *reinterpret_cast<uint2 *>(d) = c_h;
-                        *reinterpret_cast<uint2 *>(d + 16) = c_m;
-                        *reinterpret_cast<uint2 *>(d + 32) = c_l;
-                    }
-                    // address of the slot's next load (tile + 3 strides): the staged rows are whole image rows, so slot s is
-                    // 32 pixels = 4096 bytes behind slot 0, and only the patch's first / last row can fall outside the image
-                    if constexpr (piece == 5) c_off = (n_bad & (1u << s)) != 0 ? OOB : n_base + 4096u * s;
-                    if constexpr (piece == 6) lv[set][s] = buf_load4(rs_hi, c_off);
-                }
-            };
-            __builtin_amdgcn_sched_barrier(0);
-            // (weight term, pixel term) of the six partial products, smallest first; the two column tiles alternate
-            static_for<0, 12>([&](auto mc) __attribute__((always_inline)) {
-                constexpr int m = decltype(mc)::value, prod = m >> 1, mt = m & 1;
-                constexpr int tw = prod == 0 ? 2 : prod == 1 ? 0 : prod == 2 ? 1 : prod == 3 ? 1 : 0;
-                constexpr int tx = prod == 0 ? 0 : prod == 1 ? 2 : prod == 2 ? 1 : prod == 3 ? 0 : prod == 4 ? 1 : 0;
-                MFMA_B(acc[mt], w3[step][tw], x3[cu][mt][tx]);
-                __builtin_amdgcn_sched_barrier(0);
-                static_for<m * n_items / 12, (m + 1) * n_items / 12>(item);      // the items in order, spread over the 12 shadows
-                __builtin_amdgcn_sched_barrier(0);
-            });
-        });
-        KSTAMP(5 + 5 * kst);
-        // ---- the four kernel rows' partial sums: to owner (column tile, channel-group pair) -------------------------------
-        __syncthreads();                                         // the previous tile's exchange has been read by everybody
-        KSTAMP(6 + 5 * kst);
-        float4 *xq = reinterpret_cast<float4 *>(xch);
-        // acc registers 4 (2 G + e) + j of column tile M: owner (M, G) = wave M + 2 G
-        auto piece = [&](auto m_, auto g_, int e) __attribute__((always_inline)) -> float4 {
-            constexpr int M = decltype(m_)::value, G = decltype(g_)::value;
-            return e == 0 ? make_float4(acc[M][8 * G], acc[M][8 * G + 1], acc[M][8 * G + 2], acc[M][8 * G + 3])
-                          : make_float4(acc[M][8 * G + 4], acc[M][8 * G + 5], acc[M][8 * G + 6], acc[M][8 * G + 7]);
-        };
-        static_for<0, 4>([&](auto oc) __attribute__((always_inline)) {      // owner ow receives this wave's piece as source (wave - ow - 1) & 3
-            constexpr int ow = decltype(oc)::value;
-            if (ow != wave) {
-                const int src = (wave - ow - 1) & 3;
-#pragma unroll
-                for (int e = 0; e < 2; ++e)
-                    xq[((ow * 3 + src) * 2 + e) * 64 + lane] = piece(std::integral_constant<int, (ow & 1)>{}, std::integral_constant<int, (ow >> 1)>{}, e);
-            }
-        });
-        __syncthreads();                                         // partial sums written; every read of `cur` is done, `cur ^ 1` is staged
-        KSTAMP(7 + 5 * kst);
-        unsigned bits = 0;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            float4 v = wave == 0 ? piece(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, e)
-                     : wave == 1 ? piece(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, e)
-                     : wave == 2 ? piece(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, e)
-                                 : piece(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, e);
-#pragma unroll
-            for (int sidx = 0; sidx < 3; ++sidx) {               // fixed order: the waves wave + 1, wave + 2, wave + 3 (mod 4)
-                const float4 p = xq[((wave * 3 + sidx) * 2 + e) * 64 + lane];
-                v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
-            }
-            float o4[4] = {v.x + b4[e].x, v.y + b4[e].y, v.z + b4[e].z, v.w + b4[e].w};
-            const float gf[4] = {gq[e].x, gq[e].y, gq[e].z, gq[e].w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (MODE == EP_RELU) {
-                    o4[j] = fmaxf(o4[j], 0.f);
-                    bits |= (o4[j] > 0.f ? 1u : 0u) << (4 * e + j);
-                }
-                if (MODE == EP_GATE_F) o4[j] = gf[j] > 0.f ? o4[j] : 0.f;
-                if (MODE == EP_GATE_B) o4[j] = ((gb >> (8 * og + 4 * e + j)) & 1u) ? o4[j] : 0.f;
-            }
-            buf_store4(make_float4(o4[0], o4[1], o4[2], o4[3]), rs_out, obase + e * 32);
-        }
-        // sign bits: byte og of the (pixel, half) entry (bit 4 g + j <-> channel 8 g + 4 half + j)
-        if (MODE == EP_RELU)            // unconditional (exact vmcnt counts in the loop); dropped through its offset without bits_out
-            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)bits, rs_bits, (int)((obase == OOB || !want_bits) ? OOB : bits_off(obase, half) + og), 0, 0);
-        KSTAMP(8 + 5 * kst);
-        ++kst;
-    };
-
-    // two tiles per iteration, both halves always executed (a tile past the end multiplies zeros and its stores are dropped):
-    // with a conditional second half the compiler's vmcnt bookkeeping merges the paths and waits for the loads it has just
-    // issued, which exposes a full HBM round trip per loader slot
-    for (int tile = t_first; tile < t_end; tile += 2) {
-        do_tile(S1{}, tile, 0);                                  // set 1 holds tile + 1
-        do_tile(S0{}, tile + 1, 1);                              // set 0 holds tile + 2
-    }
-}
-
 // ================================================================================================================================
-// Producer / consumer form (round 3).  In down32k_kernel every wave is loader AND multiplier: per reduction step a wave issues 12
-// MFMAs and ~90 vector instructions of loading, splitting and LDS writing between them, and one wave per SIMD hides at most ~5 per
-// MFMA: the step takes 1.5x its MFMA issue time (stamps: 2.3 us per tile for 1.54 us of MFMA).  Here, as in wgrad32r_kernel, the
-// two jobs live in different waves of the same SIMD: waves 0-3 (consumers, wave = kernel row) keep the weights, read their
+// Producer / consumer waves (round 3).  In round 2's down32k_kernel every wave was loader AND multiplier: per reduction step a
+// wave issued 12 MFMAs and ~90 vector instructions of loading, splitting and LDS writing between them, and one wave per SIMD hides
+// at most ~5 per MFMA: the step took 1.5x its MFMA issue time (stamps: 2.3 us per tile for 1.54 us of MFMA; 29-33 us per 16x16
+// launch).  Here, as in wgrad32r_kernel, the two jobs live in different waves of the same SIMD (same-box A/B, three boxes:
+// 1.5 / 3.5 / 7.4 us per training step in favour of this form; stamps: tools/stamp_d32p.py, profiles/r3_phase_stamps.txt): waves 0-3 (consumers, wave = kernel row) keep the weights, read their
 // operands from LDS and issue MFMAs -- 6 LDS reads per 12 MFMAs and nothing else in the reduction loop; waves 4-7 (producers)
 // fetch tile t+1 .. t+3, split by truncation (single-issue instructions: they co-issue beside the partner's MFMAs) and write
-// tile t+1's LDS image while tile t is multiplied.  Same tiles, LDS images, exchange, epilogue and barriers per tile as
-// down32k_kernel; the split is the exact three-term truncation of wgrad32r_kernel instead of round-to-nearest (both reproduce
-// the fp32 operand to its last bit or two: results differ by fp32 rounding noise only).
+// tile t+1's LDS image while tile t is multiplied.  The split is the exact three-term truncation of wgrad32r_kernel (the fp32
+// operand is reproduced to its last bit; the three dropped partial products are <= 2^-24 relative).
 template <int LO, int MODE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void down32p_kernel(const float *__restrict__ hi, Ep32 ep,
                                                                                                  int n_img, int n_tiles) {
@@ -384,7 +106,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) issue(S0{}, s, t_first + 2);
         __syncthreads();
-        // per thread, for the loads issued inside the tile loop (as down32k_kernel): byte offset of slot 0 in a patch and the slots
+        // per thread, for the loads issued inside the tile loop (hand-reduced): byte offset of slot 0 in a patch and the slots
         // (bit s) that sit in the patch's first / last row or past its end -- a slot then costs a test, an add and a select
         const unsigned rel0 = (unsigned)(pix0 * PIXB + q * 16);
         unsigned first_row = 0, last_row = 0, no_slot = 0;
@@ -534,7 +256,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             gq[1] = buf_load4(rs_gate, obase + 32);
         }
         if (MODE == EP_GATE_B) gb = buf_load_u16(rs_bits, bits_off(obase, half));
-        // issue order pinned as in down32k_kernel: behind every MFMA at most one operand read of the next step or one piece of
+        // issue order pinned by hand (a scheduling barrier after every MFMA; left to the scheduler a step came out as a block of MFMAs followed by a block of vector instructions): behind every MFMA at most one operand read of the next step or one piece of
         // the previous tile's epilogue (steps 1 .. 3: three pieces each)
         static_for<0, 8>([&](auto kc) __attribute__((always_inline)) {
             constexpr int step = decltype(kc)::value, cu = step & 1, nx = cu ^ 1;
@@ -623,14 +345,11 @@ template <int LO, int MODE> static void launch_down_k(const float *hi, const Ep3
     constexpr int LDS = DownK<LO>::LDS_DW * 4;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void *)down32k_kernel<LO, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         (void)hipFuncSetAttribute((const void *)down32p_kernel<LO, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr = true;
     }
     const int tiles = n * DownK<LO>::TILES_PER_IMG, cus = cu_count_k();
-    static const bool pc = getenv("ARVAE_D32K_NO_PC") == nullptr;           // A/B: every wave loader and multiplier (round 2)
-    if (pc) ARVAE_LAUNCH((down32p_kernel<LO, MODE>), dim3(tiles < cus ? tiles : cus), dim3(512), LDS, s, hi, ep, n, tiles);
-    else ARVAE_LAUNCH((down32k_kernel<LO, MODE>), dim3(tiles < cus ? tiles : cus), dim3(256), LDS, s, hi, ep, n, tiles);
+    ARVAE_LAUNCH((down32p_kernel<LO, MODE>), dim3(tiles < cus ? tiles : cus), dim3(512), LDS, s, hi, ep, n, tiles);
 }
 
 template <int LO> static void launch_down_k_mode(const float *hi, const Ep32 &ep, int mode, int n, hipStream_t s) {

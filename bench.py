@@ -86,10 +86,10 @@ KERNEL_WORK = {
 ROCPROF_NAMES = {
     'wgrad32_kernel<16>': ['arvae::wgrad32r_kernel<16, 1>', 'arvae::wgrad32r_kernel<16, 2>'],
     'up32_kernel<16>': ['arvae::up32x_kernel<16, 1, 128>', 'arvae::up32x_kernel<16, 3, 128>'],
-    'down32_kernel<16>': ['arvae::down32k_kernel<16, 1>', 'arvae::down32k_kernel<16, 3>'],
+    'down32_kernel<16>': ['arvae::down32p_kernel<16, 1>', 'arvae::down32p_kernel<16, 3>'],
     'wgrad32_kernel<8>': ['arvae::wgrad32r_kernel<8, 1>', 'arvae::wgrad32r_kernel<8, 2>'],
     'up32_kernel<8>': ['arvae::up32x_kernel<8, 1, 32>', 'arvae::up32x_kernel<8, 3, 32>'],
-    'down32_kernel<8>': ['arvae::down32k_kernel<8, 1>', 'arvae::down32k_kernel<8, 3>'],
+    'down32_kernel<8>': ['arvae::down32p_kernel<8, 1>', 'arvae::down32p_kernel<8, 3>'],
     'wgrad32_kernel<4>': ['arvae::wgrad32x_kernel<4, 1>', 'arvae::wgrad32x_kernel<4, 2>'],
     'up32_kernel<4>': ['arvae::up32x_kernel<4, 1, 32>', 'arvae::up32x_kernel<4, 3, 32>'],
     'down32_kernel<4>': ['arvae::down32s_kernel<4, 1>', 'arvae::down32s_kernel<4, 2>'],
