@@ -207,9 +207,18 @@ __device__ unsigned long long g_stamps[512 * 64 * 2];
         }                                                                                \
     } while (0)
 #define STAMP_WAIT() __builtin_amdgcn_s_waitcnt(0)
+// up32p_kernel: row blockIdx.x = its consumers (thread 0), row 256 + blockIdx.x = its producers (thread 256)
+#define PSTAMP(role, slot)                                                               \
+    do {                                                                                 \
+        if (threadIdx.x == 256 * (role) && blockIdx.x < 256 && (slot) < 64) {            \
+            g_stamps[((blockIdx.x + 256 * (role)) * 64 + (slot)) * 2] = __builtin_readcyclecounter();     \
+            g_stamps[((blockIdx.x + 256 * (role)) * 64 + (slot)) * 2 + 1] = wall_clock64();               \
+        }                                                                                \
+    } while (0)
 #else
 #define STAMP(slot)
 #define STAMP_WAIT()
+#define PSTAMP(role, slot)
 #endif
 
 // The weight value is the MFMA's A operand (row = output channel = lane & 31) and the pixel value its B operand
@@ -750,6 +759,226 @@ __global__ __launch_bounds__(256, 1) void up32x_kernel(const float *__restrict__
     up32x_body<LO, MODE, PX>(lo, wt, ep, n_img, n_tiles, blockIdx.x, gridDim.x);
 }
 
+// ================================================================================================================================
+// Up map of the 16x16 layers with PRODUCER / CONSUMER waves (round 3; the prepared weights must exist, i.e. the fused step).
+// In up32x_kernel every wave loads, splits, multiplies and stores: per 128-pixel tile 1190 cycles of commit between two barriers
+// and an MFMA phase of 8650-9050 cycles for 6144 of MFMA issue (the next tile's loads, the operand reads and the previous tile's
+// 64 KB of stores are issued between its MFMAs; profiles/r2_phase_stamps.txt).  Here waves 0-3 (consumers, wave = parity class)
+// keep the weights and issue MFMAs with the operand reads of the next step between them and nothing else; when a tile is done
+// they park its four accumulator tiles in LDS (64 KB).  Waves 4-7 (producers) meanwhile run the PREVIOUS tile's epilogue from
+// there (bias, ReLU / gate, 16-byte stores, sign bits), split the NEXT tile's patch (exact truncation, single-issue
+// instructions) into the other LDS image and issue the loads of the tile after that.  Two barriers per tile.
+template <int MODE>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void up32p_kernel(const float *__restrict__ lo, Ep32 ep,
+                                                                                               int n_img, int n_tiles) {
+    constexpr int LO = 16, PX = 128, HI = 2 * LO, MT = PX / 32;
+    using PL = PatchLoader<LO, 1, PX>;
+    constexpr int PR = PL::PR, PC = PL::PC, PLANE = PL::PLANE_DW, SLOTS = PL::SLOTS, ITERS = PL::ITERS;
+    constexpr int BUF = 3 * PLANE;                               // dwords of one three-plane patch image
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];                 // [2][BUF] patch images | handoff
+    unsigned *lds = reinterpret_cast<unsigned *>(lds_f);
+    float4 *hand = reinterpret_cast<float4 *>(lds + 2 * BUF);    // [wave][mt][group][lane]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, rc = lane & 31;
+    const int per_wg = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x, t_first = blockIdx.x * per_wg;
+    const int t_end = min(n_tiles, t_first + per_wg);
+    const int cls = wave & 3, py = cls >> 1, px = cls & 1;       // parity class of a consumer wave / of the producer that finishes it
+    unsigned orel[MT];                                           // output byte offset of this lane's pixel in M-tile mt
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int img, r, c;
+        tile_pixel<LO, PX>(mt * 32 + rc, img, r, c);
+        orel[mt] = (unsigned)(((img * HI + 2 * r + py) * HI + 2 * c + px) * PIXB + half * 16);
+    }
+
+    if (wave >= 4) {
+        // ============================================================================================ producers
+        PSTAMP(1, 0);
+        int pst = 0;
+        (void)pst;
+        const int pt = threadIdx.x - 256;
+        const __amdgpu_buffer_rsrc_t rs_lo = make_rsrc(lo, (int64_t)n_img * LO * LO * PIXB);
+        const int64_t out_bytes = (int64_t)n_img * HI * HI * PIXB;
+        const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(ep.out, out_bytes);
+        const bool want_bits = MODE == EP_RELU && ep.bits_out != nullptr;
+        const __amdgpu_buffer_rsrc_t rs_bits = make_rsrc(want_bits ? (const void *)ep.bits_out : (const void *)ep.out, (int64_t)n_img * HI * HI * 4);
+        float4 b4[4];
+        load_bias4(ep.bias, half, b4);
+        // patch slots of this thread (as PatchLoader, with the producers' thread index): byte offset relative to the tile's first
+        // patch row | bit 0: first patch row, bit 1: last patch row (the only rows that can fall outside the image)
+        unsigned rel[ITERS];
+        float4 rv[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int idx = pt + it * 256;
+            const int q = idx & 7, pix = idx >> 3;
+            const int pc = pix % PC, pr = (pix / PC) % PR;
+            const int gx = pc - 1;
+            const bool ok = idx < SLOTS && (unsigned)gx < (unsigned)LO;
+            rel[it] = ok ? (unsigned)((pr * LO + gx) * PIXB + q * 16) | (pr == 0 ? 1u : 0u) | (pr == PR - 1 ? 2u : 0u) : OOB;
+        }
+        auto issue_tile = [&](int tile) __attribute__((always_inline)) {
+            int img0, r0;
+            tile_origin<LO, PX>(tile, img0, r0);
+            const int gy0 = r0 - 1;
+            const int base = ((img0 * LO + gy0) * LO) * PIXB;    // negative for the very first patch row of the tensor
+            const unsigned bad = (gy0 < 0 ? 1u : 0u) | (gy0 + PR - 1 >= LO ? 2u : 0u);
+            const bool valid = tile < t_end;
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const bool row_ok = valid && (rel[it] & bad) == 0;
+                rv[it] = buf_load4(rs_lo, row_ok ? (rel[it] & ~3u) + (unsigned)base : OOB);
+            }
+        };
+        auto commit_tile = [&](unsigned *planes) __attribute__((always_inline)) {
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int idx = pt + it * 256;
+                float4 v = rv[it];
+                asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));      // every lane uses the slot's registers (exact vmcnt)
+                if (idx < SLOTS) {
+                    const int q = idx & 7, pix = idx >> 3;
+                    uint2 hv, mv, lv;
+                    trunc_pair3(v.x, v.y, hv.x, mv.x, lv.x);
+                    trunc_pair3(v.z, v.w, hv.y, mv.y, lv.y);
+                    *reinterpret_cast<uint2 *>(planes + pix * PSB + q * 2) = hv;
+                    *reinterpret_cast<uint2 *>(planes + PLANE + pix * PSB + q * 2) = mv;
+                    *reinterpret_cast<uint2 *>(planes + 2 * PLANE + pix * PSB + q * 2) = lv;
+                }
+            }
+        };
+        // epilogue of the tile whose accumulators sit in the handoff area: this thread = lane `lane` of consumer wave `cls`
+        unsigned prev_base = OOB;
+        auto epilogue = [&]() __attribute__((always_inline)) {
+            const float4 no_gate = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                f32x16 acc;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 v = hand[((cls * MT + mt) * 4 + g) * 64 + lane];
+                    acc[4 * g] = v.x; acc[4 * g + 1] = v.y; acc[4 * g + 2] = v.z; acc[4 * g + 3] = v.w;
+                }
+                const unsigned poff = prev_base + orel[mt];
+                unsigned bits = 0;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bits |= store_group<MODE>(acc, g, b4[g], no_gate, 0u, rs_out, poff);
+                if (MODE == EP_RELU) buf_store_u16(bits, rs_bits, (prev_base == OOB || !want_bits) ? OOB : bits_off(poff, half));
+            }
+        };
+        issue_tile(t_first);
+        __syncthreads();                                         // (the consumers' prologue barrier)
+        commit_tile(lds);
+        issue_tile(t_first + 1);
+        __syncthreads();                                         // first tile staged
+        for (int tile = t_first; tile < t_end; ++tile) {
+            const int cur = (tile - t_first) & 1;
+            PSTAMP(1, 3 + 6 * pst);
+            epilogue();                                          // tile - 1 (nothing the first time: prev_base is out of range)
+            PSTAMP(1, 4 + 6 * pst);
+            commit_tile(lds + (cur ^ 1) * BUF);                  // tile + 1
+            PSTAMP(1, 5 + 6 * pst);
+            int img0, r0;
+            tile_origin<LO, PX>(tile, img0, r0);
+            prev_base = (unsigned)(((img0 * HI + 2 * r0) * HI) * PIXB);
+            issue_tile(tile + 2);
+            PSTAMP(1, 6 + 6 * pst);
+            __syncthreads();                                     // A: handoff area free, tile + 1 staged
+            PSTAMP(1, 7 + 6 * pst);
+            __syncthreads();                                     // B: this tile's accumulators are in the handoff area
+            PSTAMP(1, 8 + 6 * pst);
+            ++pst;
+        }
+        epilogue();                                              // the last tile
+        PSTAMP(1, 63);
+        return;
+    }
+
+    // ================================================================================================ consumers (wave = parity class)
+    // w3[ty][tx][c][term]: the 8 input channels c*16 + half*8 + j of wt[.][chi = rc][ky0 + 2ty][kx0 + 2tx], split in three
+    PSTAMP(0, 0);
+    int cst = 0;
+    (void)cst;
+    bf16x8 w3[2][2][2][3];
+    {
+        const uint4 *src = ep.wprep + PREP_DOWN_UINT4 + (wave * PREP_UP_SLOTS) * 64 + lane;
+#pragma unroll
+        for (int ty = 0; ty < 2; ++ty)
+#pragma unroll
+            for (int tx = 0; tx < 2; ++tx)
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                    for (int t = 0; t < 3; ++t)
+                        w3[ty][tx][cc][t] = __builtin_bit_cast(bf16x8, src[(((ty * 2 + tx) * 2 + cc) * 3 + t) * 64]);
+    }
+    // patch origin is lo (r0-1, -1); tap (ty,tx) of class (py,px) reads lo (r + py - ty, c + px - tx)
+    int aoff[MT];                                                // dwords into a plane
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int img, r, c;
+        tile_pixel<LO, PX>(mt * 32 + rc, img, r, c);
+        aoff[mt] = ((img * PR + r + 1 + py) * PC + c + 1 + px) * PSB + half * 4;
+    }
+    __syncthreads();
+    __syncthreads();                                             // first tile staged
+    PSTAMP(0, 1);
+    for (int tile = t_first; tile < t_end; ++tile) {
+        PSTAMP(0, 3 + 6 * cst);
+        const unsigned *ldsw = lds + ((tile - t_first) & 1) * BUF;
+        f32x16 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+        bf16x8 a[2][MT][3];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) a[0][mt][t] = lds_bf16x8(ldsw + t * PLANE + aoff[mt]);
+        static_for<0, 8>([&](auto sc) __attribute__((always_inline)) {
+            constexpr int step = decltype(sc)::value, ty = step >> 2, tx = (step >> 1) & 1, c = step & 1;
+            constexpr int cur = step & 1, nxt = cur ^ 1;
+            constexpr int nstep = step + 1, nty = nstep >> 2, ntx = (nstep >> 1) & 1, nc = nstep & 1;
+            constexpr int ntoff = -(nty * PC + ntx) * PSB + nc * 8;
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, 2 * MT>([&](auto mc) __attribute__((always_inline)) {
+                constexpr int sub = decltype(mc)::value;
+                // three of the step's 6 * MT MFMAs, round-robin over the MT accumulators (product-major: every accumulator
+                // sees its six partial products smallest first), then this sub-step's share of the next step's operand reads
+                static_for<3 * sub, 3 * sub + 3>([&](auto qc) __attribute__((always_inline)) {
+                    constexpr int m = decltype(qc)::value, prod = m / MT, pm = m % MT;
+                    constexpr int tw = prod == 0 ? 2 : prod == 1 ? 0 : prod == 2 ? 1 : prod == 3 ? 1 : 0;
+                    constexpr int ta = prod == 0 ? 0 : prod == 1 ? 2 : prod == 2 ? 1 : prod == 3 ? 0 : prod == 4 ? 1 : 0;
+                    MFMA_B(acc[pm], w3[ty][tx][c][tw], a[cur][pm][ta]);
+                });
+                if constexpr (nstep < 8) {
+                    constexpr int r_lo = sub * (3 * MT) / (2 * MT), r_hi = (sub + 1) * (3 * MT) / (2 * MT);
+                    static_for<r_lo, r_hi>([&](auto rc_) __attribute__((always_inline)) {
+                        constexpr int ri = decltype(rc_)::value, rmt = ri / 3, rt = ri % 3;
+                        a[nxt][rmt][rt] = lds_bf16x8(ldsw + rt * PLANE + aoff[rmt] + ntoff);
+                    });
+                }
+                (void)nxt;
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+        PSTAMP(0, 4 + 6 * cst);
+        __syncthreads();                                         // A: the producers are done with the previous tile's accumulators
+        PSTAMP(0, 5 + 6 * cst);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                hand[((wave * MT + mt) * 4 + g) * 64 + lane] = make_float4(acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]);
+        PSTAMP(0, 6 + 6 * cst);
+        __syncthreads();                                         // B
+        PSTAMP(0, 7 + 6 * cst);
+        ++cst;
+    }
+    PSTAMP(0, 63);
+}
+
 // The decoder's first convolution (4x4 -> 8x8: a few tiles per CU, 6.5 us) and the all-pairs attribute regularisation of the
 // same forward pass (regloss.h: ~65 workgroups, 6.3 us, needs only z and the labels) in ONE grid: workgroups [0, grid_up) run
 // the convolution, the rest the regulariser's (row block, dim) pairs, staging their columns in the launch's dynamic LDS.
@@ -987,6 +1216,16 @@ static void launch_down_v(int, const Operand &hi, const float *wt, const Ep32 &e
 template <int LO, int MODE, int PX>
 static void launch_up_px(const Operand &lo, const float *wt, const Ep32 &ep, int n, hipStream_t s) {
     const int tiles = tiles_for<LO, PX>(n), grid = grid_for_tiles(tiles);
+    if constexpr (LO == 16 && PX == 128) {                      // producer / consumer form (needs the step's prepared weights)
+        static const bool pc = getenv("ARVAE_UP32_NO_PC") == nullptr;       // A/B: up32x_kernel
+        if (pc && ep.wprep != nullptr && (MODE == EP_PLAIN || MODE == EP_RELU)) {
+            constexpr int LDSP = (2 * 3 * PatchLoader<16, 1, 128>::PLANE_DW) * 4 + 4 * 4 * 4 * 64 * 16;
+            static bool attrp = false;
+            if (!attrp) { allow_lds(up32p_kernel<MODE>, LDSP); attrp = true; }
+            ARVAE_LAUNCH((up32p_kernel<MODE>), dim3(grid), dim3(512), LDSP, s, lo.v, ep, n, tiles);
+            return;
+        }
+    }
     constexpr int LDSX = MaxOf<3 * PatchLoader<LO, 1, PX>::PLANE_DW, WSTAGE_UP>::value * 4;
     static bool attrx = false;
     if (!attrx) { allow_lds(up32x_kernel<LO, MODE, PX>, LDSX); attrx = true; }
