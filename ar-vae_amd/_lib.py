@@ -10,7 +10,7 @@ import threading
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libarvae_hip.so')
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 c_i32, c_i64, c_f32, c_f64, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
 

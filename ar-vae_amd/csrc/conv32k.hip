@@ -3,18 +3,18 @@
 //
 //   lo[n,ly,lx,clo] = ep( sum_{ky,kx,chi} hi[n,2ly-1+ky,2lx-1+kx,chi] * wt[clo][chi][ky][kx] )
 //
-// down32x_kernel (conv32.hip) splits the reduction two ways: a wave keeps 128 weights x 3 bf16 terms in 192 registers, one
-// accumulator tile, and what is left holds one tile of input in flight.  Here the reduction is split FOUR ways (consumer wave
-// = kernel row): a wave's weights are 96 registers (resident for the whole launch, 24 coalesced loads from
-// conv32_weight_prep's DOWN part) and it owns two accumulator tiles (its MFMAs alternate between them).
+// down32x_kernel (conv32.hip) splits the reduction two ways with every wave loader and multiplier.  Here the reduction is split
+// FOUR ways (consumer wave = kernel row): a wave's weights are 64 registers (resident for the whole launch, 16 coalesced loads
+// from the prepared DOWN part, prep32.h) and it owns two accumulator tiles (its MFMAs alternate between them).
 //   * a tile = 64 lo pixels (4 rows at 16x16, one image at 8x8) = two 32-pixel MFMA column tiles; weight = A operand
-//     (row = output channel), pixels = B operand, 32x32x16 bf16, six partial products per multiply-add, smallest first;
-//   * consumer wave = kernel row ky (K split four ways): 8 reduction steps (kx, 16-channel chunk) of 12 MFMAs per tile.  The
+//     (row = output channel), pixels = B operand, 32x32x16 fp16 on scaled two-term operands, three partial products per
+//     multiply-add, smallest first (conv32_common.h);
+//   * consumer wave = kernel row ky (K split four ways): 8 reduction steps (kx, 16-channel chunk) of 6 MFMAs per tile.  The
 //     four partial sums meet through a 24 KB LDS area; wave w finishes column tile w & 1, channel groups 2 (w >> 1),
 //     2 (w >> 1) + 1 (16-byte stores, one byte of ReLU sign bits per lane);
-//   * the input patch (2 TR + 2 rows x 2 LO columns, no column halo: a tap outside reads one shared zero pixel) is split into
-//     three bf16 terms once and packed per pixel (PSB3), two LDS buffers: the producer waves write tile t+1's image while tile t
-//     is multiplied and keep the loads of tiles t+2, t+3 in flight.
+//   * the input patch (2 TR + 2 rows x 2 LO columns, no column halo: a tap outside reads one shared zero pixel) is scaled and
+//     split into two fp16 terms once and packed per pixel (PSB2), two LDS buffers: the producer waves write tile t+1's image
+//     while tile t is multiplied and keep the loads of tiles t+2, t+3 in flight.
 // Round 2's form of this kernel (every wave loader AND multiplier, 256 threads) is gone: see the comment at the kernel.
 #include "common.h"
 #include "conv32_common.h"
@@ -24,8 +24,8 @@ namespace arvae {
 #ifdef D32K_STAMPS
 // diagnostic build only (tools/stamp_d32p.py): phase timeline of the first 32 workgroups, 100 MHz wall clock
 __device__ unsigned long long g_d32k_stamps[64 * 64];
-// down32p_kernel: rows 0..31 = the consumers of workgroups 0..31 (thread 0), rows 32..63 = their producers (thread 256)
-#define PSTAMP(role, slot) do { if (threadIdx.x == 256 * (role) && blockIdx.x < 32 && (slot) < 64) g_d32k_stamps[(blockIdx.x + 32 * (role)) * 64 + (slot)] = wall_clock64(); } while (0)
+// down32p_kernel<16, *>: rows 0..31 = the consumers of workgroups 0..31 (thread 0), rows 32..63 = their producers (thread 256)
+#define PSTAMP(role, slot) do { if (LO == 16 && threadIdx.x == 256 * (role) && blockIdx.x < 32 && (slot) < 64) g_d32k_stamps[(blockIdx.x + 32 * (role)) * 64 + (slot)] = wall_clock64(); } while (0)
 #else
 #define PSTAMP(role, slot)
 #endif
@@ -35,7 +35,7 @@ template <int LO> struct DownK {
     static constexpr int HW = 2 * LO;                          // hi pixels per row
     static constexpr int PR = 2 * T::TR + 2;                   // patch rows
     static constexpr int PIX = PR * HW;                        // staged pixels (320 / 288)
-    static constexpr int BUF = (PIX + 1) * PSB3;               // dwords, + the zero pixel
+    static constexpr int BUF = (PIX + 1) * PSB2;               // dwords, + the zero pixel
     static constexpr int SLOTS = (PIX * 8 + 255) / 256;        // 16-byte loader slots per thread and tile (10 / 9)
     static constexpr int XCH = 4 * 3 * 2 * 64 * 4;             // exchange area, dwords: [owner][source][8 regs as 2 x float4][lane]
     static constexpr int LDS_DW = 2 * BUF + XCH;
@@ -49,9 +49,9 @@ template <int LO> struct DownK {
 // launch).  Here, as in wgrad32r_kernel, the two jobs live in different waves of the same SIMD (same-box A/B, three boxes:
 // 1.5 / 3.5 / 7.4 us per training step in favour of this form; stamps: tools/stamp_d32p.py, profiles/r3_phase_stamps.txt): waves 0-3 (consumers, wave = kernel row) keep the weights, read their
 // operands from LDS and issue MFMAs -- 6 LDS reads per 12 MFMAs and nothing else in the reduction loop; waves 4-7 (producers)
-// fetch tile t+1 .. t+3, split by truncation (single-issue instructions: they co-issue beside the partner's MFMAs) and write
-// tile t+1's LDS image while tile t is multiplied.  The split is the exact three-term truncation of wgrad32r_kernel (the fp32
-// operand is reproduced to its last bit; the three dropped partial products are <= 2^-24 relative).
+// fetch tile t+1 .. t+3, scale and split (single-issue instructions: they co-issue beside the partner's MFMAs) and write
+// tile t+1's LDS image while tile t is multiplied.  (Round 3 measured this with six bf16 products per multiply-add: 1.9-2.1 us
+// per tile for 1.54 us of MFMA issue, the producers done after 1.4 us; with three fp16 products the MFMA issue is 0.77 us.)
 template <int LO, int MODE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void down32p_kernel(const float *__restrict__ hi, Ep32 ep,
                                                                                                  int n_img, int n_tiles) {
@@ -74,6 +74,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const __amdgpu_buffer_rsrc_t rs_hi = make_rsrc(hi, (int64_t)n_img * HI * HI * PIXB);
         int q = pt & 7, pix0 = pt >> 3;                          // slot s of this thread = staged pixel pix0 + 32 s, channels 4 q .. 4 q + 3
         float4 lv[2][SLOTS];
+        float sc_in = 1.f;                                       // the input tensor's scale (set behind the first tiles' loads)
+        const AmaxLoad al = amax_issue(ep.amax_in);
         auto issue = [&](auto set_, int s, int tile) __attribute__((always_inline)) {
             constexpr int set = decltype(set_)::value;
             int img0, r0;
@@ -87,19 +89,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             constexpr int set = decltype(set_)::value;
             const int pix = pix0 + 32 * s;
             if (SLOTS * 32 > PIX && pix >= PIX) return;
-            uint2 hv, mv, lw;
-            trunc_pair3(lv[set][s].x, lv[set][s].y, hv.x, mv.x, lw.x);
-            trunc_pair3(lv[set][s].z, lv[set][s].w, hv.y, mv.y, lw.y);
-            unsigned *d = buf + pix * PSB3 + q * 2;
+            uint2 hv, lw;
+            split_pair_h2(lv[set][s].x, lv[set][s].y, sc_in, hv.x, lw.x);
+            split_pair_h2(lv[set][s].z, lv[set][s].w, sc_in, hv.y, lw.y);
+            unsigned *d = buf + pix * PSB2 + q * 2;
             *reinterpret_cast<uint2 *>(d) = hv;
-            *reinterpret_cast<uint2 *>(d + 16) = mv;
-            *reinterpret_cast<uint2 *>(d + 32) = lw;
+            *reinterpret_cast<uint2 *>(d + 16) = lw;
         };
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) issue(S0{}, s, t_first);
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) issue(S1{}, s, t_first + 1);
-        if (pt < 2 * PSB3) lds[(pt / PSB3) * K::BUF + PIX * PSB3 + pt % PSB3] = 0u;   // the zero pixels
+        if (pt < 2 * PSB2) lds[(pt / PSB2) * K::BUF + PIX * PSB2 + pt % PSB2] = 0u;   // the zero pixels
+        sc_in = amax_scale(al).s;
         __syncthreads();                                         // (the consumers' prologue barrier)
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) commit(S0{}, s, lds);    // first tile -> buffer 0
@@ -157,6 +159,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int cst = 0;
     (void)cst;
     const int half = lane >> 5, rc = lane & 31;
+    const AmaxLoad al = amax_issue(ep.amax_in);
     int xoff[2][4];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int kx = 0; kx < 4; ++kx) {
             const int col = 2 * c - 1 + kx;
-            xoff[mt][kx] = ((unsigned)col < (unsigned)HW ? (2 * r + wave) * HW + col : PIX) * PSB3 + half * 4;
+            xoff[mt][kx] = ((unsigned)col < (unsigned)HW ? (2 * r + wave) * HW + col : PIX) * PSB2 + half * 4;
         }
     }
     const int om = wave & 1, og = wave >> 1;
@@ -181,14 +184,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         make_rsrc(MODE == EP_GATE_B ? (const void *)ep.gate_bits : want_bits ? (const void *)ep.bits_out : (const void *)ep.out,
                   (int64_t)n_img * LO * LO * 4);
     const unsigned out_lane = (unsigned)((om * 32 + rc) * PIXB + (2 * og) * 32 + half * 16);
-    bf16x8 w3[8][3];
+    f16x8 w2[8][2];
     {
-        const uint4 *wp = ep.wprep + ((wave >> 1) * PREP_DOWN_SLOTS + ((wave & 1) * 4) * 2 * 3) * 64 + lane;
+        const uint4 *wp = ep.wprep + ((wave >> 1) * PREP_DOWN_SLOTS + ((wave & 1) * 4) * 2 * 2) * 64 + lane;
 #pragma unroll
         for (int st = 0; st < 8; ++st)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) w3[st][t] = __builtin_bit_cast(bf16x8, wp[(st * 3 + t) * 64]);
+            for (int t = 0; t < 2; ++t) w2[st][t] = __builtin_bit_cast(f16x8, wp[(st * 2 + t) * 64]);
     }
+    const float inv = amax_scale(al).inv * prep_inv_scale(ep.wprep);      // accumulators -> fp32 results (exact)
+    float amax_run = 0.f;                                        // maximum magnitude of what this wave stores
     __syncthreads();                                             // zero pixels written
     __syncthreads();                                             // first tile staged
     PSTAMP(0, 1);
@@ -201,6 +206,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     unsigned obase_prev = OOB, gb_prev = 0;
     const float4 *xq_own = reinterpret_cast<const float4 *>(xch) + (wave * 3) * 2 * 64 + lane;
     unsigned bits_acc = 0;
+    // the three other kernel rows' partial sums of this wave's share, requested at the top of a tile (an LDS read whose value
+    // is used by the next instruction stalls the wave's MFMA stream for the whole round trip)
+    float4 part[2][3];
+    auto load_parts = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) part[e][k] = xq_own[(k * 2 + e) * 64];
+    };
     // piece i of the deferred epilogue: 0-2 / 4-6: add the partial of source i (mod 4) to half e = i / 4; 3 / 7: finish + store
     // half e; 8: the sign bits
     auto epi_item = [&](auto ic) __attribute__((always_inline)) {
@@ -208,10 +222,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if constexpr (i < 8) {
             constexpr int e = i / 4, k = i % 4;
             if constexpr (k < 3) {
-                const float4 p = xq_own[(k * 2 + e) * 64];
+                const float4 p = part[e][k];
                 own[e].x += p.x; own[e].y += p.y; own[e].z += p.z; own[e].w += p.w;
             } else {
-                float o4[4] = {own[e].x + b4[e].x, own[e].y + b4[e].y, own[e].z + b4[e].z, own[e].w + b4[e].w};
+                float o4[4] = {fmaf(own[e].x, inv, b4[e].x), fmaf(own[e].y, inv, b4[e].y), fmaf(own[e].z, inv, b4[e].z), fmaf(own[e].w, inv, b4[e].w)};
                 const float gf[4] = {gq_prev[e].x, gq_prev[e].y, gq_prev[e].z, gq_prev[e].w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -222,7 +236,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     if (MODE == EP_GATE_F) o4[j] = gf[j] > 0.f ? o4[j] : 0.f;
                     if (MODE == EP_GATE_B) o4[j] = ((gb_prev >> (8 * og + 4 * e + j)) & 1u) ? o4[j] : 0.f;
                 }
-                buf_store4(make_float4(o4[0], o4[1], o4[2], o4[3]), rs_out, obase_prev + e * 32);
+                const float4 ov = make_float4(o4[0], o4[1], o4[2], o4[3]);
+                amax_run = obase_prev != OOB ? fmaxf(amax_run, amax4(ov)) : amax_run;
+                buf_store4(ov, rs_out, obase_prev + e * 32);
             }
         } else if constexpr (i == 8) {
             if (MODE == EP_RELU)        // unconditional (exact vmcnt counts in the loop); dropped through its offset without bits_out
@@ -234,17 +250,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto do_tile = [&](int tile, int cur) __attribute__((always_inline)) {
         PSTAMP(0, 4 + 5 * cst);
         const unsigned *xb = lds + cur * K::BUF;
-        f32x16 acc[2];
+        // two accumulator sets per column tile: an MFMA that accumulates into the result of the one issued two slots earlier
+        // waits for it (~44 cycles per MFMA measured with one set, 32 is the issue rate); the sets swap roles every step so
+        // that four MFMAs always lie between two into the same registers
+        f32x16 acc[2], accb[2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
-        bf16x8 x3[2][2][3];
+            for (int i = 0; i < 16; ++i) { acc[mt][i] = 0.f; accb[mt][i] = 0.f; }
+        f16x8 x2[2][2][2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int t = 0; t < 3; ++t)
-                x3[0][mt][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4v *>(xb + xoff[mt][0] + t * 16));
+            for (int t = 0; t < 2; ++t)
+                x2[0][mt][t] = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4v *>(xb + xoff[mt][0] + t * 16));
+        load_parts();
         int img0, r0;
         tile_origin<LO, 64>(tile, img0, r0);
         const unsigned obase = tile < t_end ? (unsigned)(((img0 * LO + r0) * LO) * PIXB) + out_lane : OOB;
@@ -256,33 +276,40 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             gq[1] = buf_load4(rs_gate, obase + 32);
         }
         if (MODE == EP_GATE_B) gb = buf_load_u16(rs_bits, bits_off(obase, half));
-        // issue order pinned by hand (a scheduling barrier after every MFMA; left to the scheduler a step came out as a block of MFMAs followed by a block of vector instructions): behind every MFMA at most one operand read of the next step or one piece of
-        // the previous tile's epilogue (steps 1 .. 3: three pieces each)
+        // issue order pinned by hand (a scheduling barrier after every MFMA; left to the scheduler a step came out as a block of
+        // MFMAs followed by a block of vector instructions): behind every MFMA at most one operand read of the next step or one
+        // piece of the previous tile's epilogue (steps 1 .. 5: two pieces each, the sign bits last)
         static_for<0, 8>([&](auto kc) __attribute__((always_inline)) {
             constexpr int step = decltype(kc)::value, cu = step & 1, nx = cu ^ 1;
+            constexpr int e_lo = step >= 1 ? 2 * (step - 1) : 0, e_hi = step >= 1 ? (2 * step < 9 ? 2 * step : 9) : 0;
+            constexpr int n_epi = e_hi > e_lo ? e_hi - e_lo : 0, n_items = 4 + n_epi;
             auto item = [&](auto ic) __attribute__((always_inline)) {
                 constexpr int i = decltype(ic)::value;
-                if constexpr (i < 6) {
+                if constexpr (i < 4) {
                     if constexpr (step + 1 < 8) {
-                        constexpr int nkx = (step + 1) >> 1, nc = (step + 1) & 1, mt = i / 3, t = i % 3;
-                        x3[nx][mt][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4v *>(xb + xoff[mt][nkx] + t * 16 + nc * 8));
+                        constexpr int nkx = (step + 1) >> 1, nc = (step + 1) & 1, mt = i / 2, t = i % 2;
+                        x2[nx][mt][t] = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4v *>(xb + xoff[mt][nkx] + t * 16 + nc * 8));
                     }
-                } else if constexpr (step >= 1 && step <= 3) {
-                    epi_item(std::integral_constant<int, (step - 1) * 3 + (i - 6)>{});
+                } else {
+                    epi_item(std::integral_constant<int, e_lo + (i - 4)>{});
                 }
             };
-            constexpr int n_items = (step >= 1 && step <= 3) ? 9 : 6;
             __builtin_amdgcn_sched_barrier(0);
-            static_for<0, 12>([&](auto mc) __attribute__((always_inline)) {
+            static_for<0, 6>([&](auto mc) __attribute__((always_inline)) {
                 constexpr int m = decltype(mc)::value, prod = m >> 1, mt = m & 1;
-                constexpr int tw = prod == 0 ? 2 : prod == 1 ? 0 : prod == 2 ? 1 : prod == 3 ? 1 : 0;
-                constexpr int tx = prod == 0 ? 0 : prod == 1 ? 2 : prod == 2 ? 1 : prod == 3 ? 0 : prod == 4 ? 1 : 0;
-                MFMA_B(acc[mt], w3[step][tw], x3[cu][mt][tx]);
+                constexpr int tw = prod == 0 ? 1 : 0;            // (weight term, pixel term): (l, h), (h, l), (h, h)
+                constexpr int tx = prod == 1 ? 1 : 0;
+                if constexpr ((prod == 1) == ((step & 1) == 0)) MFMA_H(accb[mt], w2[step][tw], x2[cu][mt][tx]);
+                else MFMA_H(acc[mt], w2[step][tw], x2[cu][mt][tx]);
                 __builtin_amdgcn_sched_barrier(0);
-                static_for<m * n_items / 12, (m + 1) * n_items / 12>(item);
+                static_for<m * n_items / 6, (m + 1) * n_items / 6>(item);
                 __builtin_amdgcn_sched_barrier(0);
             });
         });
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][i] += accb[mt][i];
         PSTAMP(0, 5 + 5 * cst);
         __syncthreads();                                         // the previous tile's exchange has been read by everybody
         PSTAMP(0, 6 + 5 * cst);
@@ -320,7 +347,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         do_tile(tile, 0);
         do_tile(tile + 1, 1);
     }
+    load_parts();
     static_for<0, 9>(epi_item);                                  // the last tile's epilogue
+    amax_publish(ep.amax_out, blockIdx.x * 4 + wave, gridDim.x * 4, amax_run);
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
@@ -335,12 +364,6 @@ static int cu_count_k() {
     return n;
 }
 
-bool conv32_down_ksplit_fits(const arvae_link_t *l, const Ep32 &ep) {
-    static const bool off = getenv("ARVAE_DOWN32_REGW") != nullptr;          // diagnostic: the register-resident-weight kernel
-    static const bool only16 = getenv("ARVAE_D32K_ONLY16") != nullptr;      // diagnostic (stamps of the 16x16 launch)
-    return !off && ep.wprep != nullptr && (l->lh == 16 || (l->lh == 8 && !only16));
-}
-
 template <int LO, int MODE> static void launch_down_k(const float *hi, const Ep32 &ep, int n, hipStream_t s) {
     constexpr int LDS = DownK<LO>::LDS_DW * 4;
     static bool attr = false;
@@ -348,7 +371,7 @@ template <int LO, int MODE> static void launch_down_k(const float *hi, const Ep3
         (void)hipFuncSetAttribute((const void *)down32p_kernel<LO, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr = true;
     }
-    const int tiles = n * DownK<LO>::TILES_PER_IMG, cus = cu_count_k();
+    const int tiles = n * DownK<LO>::TILES_PER_IMG, cus = cu_count_k() < AMAX_N / 4 ? cu_count_k() : AMAX_N / 4;
     ARVAE_LAUNCH((down32p_kernel<LO, MODE>), dim3(tiles < cus ? tiles : cus), dim3(512), LDS, s, hi, ep, n, tiles);
 }
 

@@ -26,6 +26,7 @@
 //     (a select on the LDS address).  Source rows outside the image are staged as zeros.
 #include "common.h"
 #include "conv32_common.h"
+#include "bf16x3.h"
 #include "x3tile.h"
 
 #ifdef C64S_STAMPS

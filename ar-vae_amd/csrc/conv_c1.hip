@@ -26,6 +26,7 @@ struct Ep1 {
     uint16_t *bits_out;         // with relu: sign bits of the result for a later gated kernel, may be null
     float *out;
     int relu;
+    unsigned *amax_out = nullptr;   // AMAX array of `out` (conv32_common.h) for the 32-channel kernel that reads it next, or null
 };
 
 // ================================================================================================
@@ -69,6 +70,7 @@ __device__ __forceinline__ void down_c1s_body(Operand img, const float *__restri
         }
     };
     float2 v[2], vn[2];
+    float amax_run = 0.f;
     fetch(wave0, v);
     for (int row = wave0; row < n_rows; row += n_waves) {
         fetch(row + n_waves, vn);                               // next row's pixels fly during this row's MFMAs and stores
@@ -102,7 +104,9 @@ __device__ __forceinline__ void down_c1s_body(Operand img, const float *__restri
                 else if (GATE == 2) o[j] = gf[j] > 0.f ? o[j] : 0.f;
                 bits |= (o[j] > 0.f ? 1u : 0u) << (4 * g + j);
             }
-            *reinterpret_cast<float4 *>(tile + rc * PS1 + 8 * g + 4 * half) = make_float4(o[0], o[1], o[2], o[3]);
+            const float4 ov = make_float4(o[0], o[1], o[2], o[3]);
+            amax_run = fmaxf(amax_run, amax4(ov));
+            *reinterpret_cast<float4 *>(tile + rc * PS1 + 8 * g + 4 * half) = ov;
         }
         if (ep.bits_out != nullptr) ep.bits_out[pix * 2 + half] = (uint16_t)bits;
         // the wave's LDS operations execute in order: no barrier, only keep the compiler from moving them
@@ -115,6 +119,18 @@ __device__ __forceinline__ void down_c1s_body(Operand img, const float *__restri
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         v[0] = vn[0]; v[1] = vn[1];
+    }
+    if (ep.amax_out != nullptr) {                               // one writer unit per workgroup
+        __shared__ float wmax[WAVES];
+        amax_run = wave_max(amax_run);
+        if (lane == 0) wmax[threadIdx.x >> 6] = amax_run;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            float m = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) m = fmaxf(m, wmax[w]);
+            amax_publish(ep.amax_out, BID, NBLK, m);
+        }
     }
 }
 template <int GATE>
@@ -503,9 +519,9 @@ bool conv_c1_fits(const arvae_link_t *l) {
 // conv_c1_down (plain input, no gate) with the step's weight preparation riding in the same grid (down_c1s_prep_kernel)
 int conv_c1_down_with_prep(const arvae_link_t *l, const Operand &img, const float *wt, const float *bias, int relu, uint16_t *bits_out,
                            float *out, const float *const *prep_wts, float *const *preps, int n_prep, const MidPrepArgs &mid,
-                           hipStream_t s) {
+                           hipStream_t s, unsigned *amax_out) {
     ARVAE_REQUIRE(n_prep > 0 && n_prep <= PREP_MAX_LAYERS && mid.count > 0, "conv_c1_down_with_prep: nothing to prepare");
-    Ep1 ep{bias, nullptr, nullptr, bits_out, out, relu};
+    Ep1 ep{bias, nullptr, nullptr, bits_out, out, relu, amax_out};
     PrepArgs p{};
     for (int i = 0; i < n_prep; ++i) {
         p.wt[i] = prep_wts[i];
@@ -515,17 +531,19 @@ int conv_c1_down_with_prep(const arvae_link_t *l, const Operand &img, const floa
     const int n_rows = l->n * LO1;
     int grid = 256 * 16 / 4;                                     // as conv_c1_down: workgroups of four independent waves
     if (grid > (n_rows + 3) / 4) grid = (n_rows + 3) / 4;
+    if (grid > AMAX_N) grid = AMAX_N;                            // one AMAX writer unit per workgroup
     ARVAE_LAUNCH(down_c1s_prep_kernel, dim3(prep_blocks + grid), dim3(256), 0, s, img, wt, ep, n_rows, p, mid, conv_blocks, prep_blocks);
     return check_launch("down_c1_kernel(+ weight prep)");
 }
 
 int conv_c1_down(const arvae_link_t *l, const Operand &img, const float *wt, const float *bias, int relu,
-                 const float *gate, const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s) {
-    Ep1 ep{bias, gate, gate_bits, bits_out, out, relu};
+                 const float *gate, const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s, unsigned *amax_out) {
+    Ep1 ep{bias, gate, gate_bits, bits_out, out, relu, amax_out};
     static const int waves_per_cu = getenv("ARVAE_C1_DOWN_WAVES") ? atoi(getenv("ARVAE_C1_DOWN_WAVES")) : 16;
     const int n_rows = l->n * LO1;
     int grid = 256 * waves_per_cu / 4;                           // workgroups of four independent waves
     if (grid > (n_rows + 3) / 4) grid = (n_rows + 3) / 4;
+    if (amax_out != nullptr && grid > AMAX_N) grid = AMAX_N;     // one AMAX writer unit per workgroup
     if (gate_bits != nullptr) ARVAE_LAUNCH(down_c1s_kernel<1>, dim3(grid), dim3(256), 0, s, img, wt, ep, n_rows);
     else if (gate != nullptr) ARVAE_LAUNCH(down_c1s_kernel<2>, dim3(grid), dim3(256), 0, s, img, wt, ep, n_rows);
     else ARVAE_LAUNCH(down_c1s_kernel<0>, dim3(grid), dim3(256), 0, s, img, wt, ep, n_rows);
@@ -605,8 +623,9 @@ bool conv_c1_pair_fits(const arvae_link_t *l) {
     return !off && conv_c1_fits(l) && l->n * LO1 >= 8 * 256 && wgrad_c1_groups(l) == 256;
 }
 int conv_c1_pair(const arvae_link_t *l, const Operand &g_img, const float *wt, const float *gate, const uint16_t *gate_bits, float *d_lo,
-                 const Operand &w_lo, float *dwt, float *dbias, int bias_mode, float *slab, hipStream_t s, SlabJob *job) {
-    Ep1 ep{nullptr, gate, gate_bits, nullptr, d_lo, 0};
+                 const Operand &w_lo, float *dwt, float *dbias, int bias_mode, float *slab, hipStream_t s, SlabJob *job,
+                 unsigned *amax_out) {
+    Ep1 ep{nullptr, gate, gate_bits, nullptr, d_lo, 0, amax_out};
     const int n_rows = l->n * LO1, grid_a = 256, grid_b = wgrad_c1_groups(l);
     const dim3 grid(grid_a + grid_b);
     if (gate_bits != nullptr) ARVAE_LAUNCH(pair_c1_kernel<1>, grid, dim3(64 * WGS_WAVES), 0, s, g_img, wt, ep, n_rows, w_lo, g_img, slab, n_rows, grid_a);

@@ -34,7 +34,7 @@ int64_t conv_c1w_wgrad_ws_floats(const arvae_link_t *l);
 int conv_c1w_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &img, float *dwt, float *dbias, int bias_mode,
                    float *slab, hipStream_t s);
 int conv_c1_down(const arvae_link_t *l, const Operand &img, const float *wt, const float *bias, int relu,
-                 const float *gate, const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s);
+                 const float *gate, const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s, unsigned *amax_out);
 int conv_c1_up(const arvae_link_t *l, const float *lo, const float *wt, const float *bias, float *out, hipStream_t s);
 int64_t conv_c1_wgrad_ws_floats(const arvae_link_t *l);
 int conv_c1_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &img, float *dwt, float *dbias, int bias_mode,
@@ -53,13 +53,19 @@ int conv64_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, fl
 
 // specialised 32-channel k4/s2/p1 kernels (conv32.hip)
 bool conv32_fits(const arvae_link_t *l);
-int conv32_down(const arvae_link_t *l, const Operand &hi, const float *wt, const float *bias, int relu, const float *gate,
-                const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s, const float *wprep = nullptr);
-int conv32_up(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, int relu, const float *gate,
-              const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s, const float *wprep = nullptr);
+// (operands come with AMAX arrays and prepared weights: conv32_common.h; a per-layer caller has neither and makes them in `ws`)
+int conv32_down(const arvae_link_t *l, const Operand &hi, const float *bias, int relu, const float *gate, const uint16_t *gate_bits,
+                uint16_t *bits_out, float *out, hipStream_t s, const float *wprep, const unsigned *amax_in, unsigned *amax_out);
+int conv32_up(const arvae_link_t *l, const Operand &lo, const float *bias, int relu, const float *gate, const uint16_t *gate_bits,
+              uint16_t *bits_out, float *out, hipStream_t s, const float *wprep, const unsigned *amax_in, unsigned *amax_out);
 int64_t conv32_wgrad_ws_floats(const arvae_link_t *l);
 int conv32_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *dwt, float *dbias, int bias_mode,
-                 float *slab, hipStream_t s);
+                 float *slab, hipStream_t s, const unsigned *amax_lo, const unsigned *amax_hi);
+int64_t conv32_prep_floats();
+int64_t conv32_scratch_floats();
+int conv32_weight_prep(const float *const *wts, float *const *preps, int n_layers, hipStream_t s);
+int conv32_amax(const float *x, int64_t count, unsigned *out, hipStream_t s);
+constexpr int64_t CONV32_AMAX_FLOATS = 1024;          // AMAX_N (conv32_common.h)
 
 struct Geom {
     int n, hh, hw, chi, lh, lw, clo, kh, kw, stride, pad;
@@ -753,8 +759,24 @@ static bool dense_rows_generic(const arvae_link_t *l, int which) {
 
 extern "C" int64_t arvae_link_ws_floats(const arvae_link_t *link) {
     if (link == nullptr) return 0;
+    if (conv32_fits(link)) return conv32_scratch_floats();       // one layer's prepared weights + the input's AMAX array
     return (conv64_fits(link, false) || conv64_fits(link, true)) ? conv64_ws_floats(link) : 0;
 }
+
+namespace arvae {
+// a per-layer call on the 32-channel kernels: split this layer's weights and take the input's maxima into the caller's scratch
+static int conv32_make_operands(const float *wt, const float *x, int64_t count, float *ws, hipStream_t st, const float **wprep,
+                                const unsigned **amax) {
+    ARVAE_REQUIRE(ws != nullptr, "link_down / link_up: workspace of arvae_link_ws_floats() floats needed");
+    float *prep = ws;
+    unsigned *am = reinterpret_cast<unsigned *>(ws + (conv32_prep_floats() + 3) / 4 * 4);
+    if (int rc = conv32_weight_prep(&wt, &prep, 1, st)) return rc;
+    if (int rc = conv32_amax(x, count, am, st)) return rc;
+    *wprep = prep;
+    *amax = am;
+    return ARVAE_OK;
+}
+}  // namespace arvae
 
 namespace arvae {
 // data gradient of ConvTranspose2d(64 -> 1) with the producing layer's activation derivative / keep-mask in the epilogue
@@ -778,11 +800,17 @@ extern "C" int arvae_link_down(const arvae_link_t *link, const arvae_operand_t *
     ARVAE_REQUIRE(hi && hi->v && wt && lo, "link_down: null pointer");
     if (dense_fits(link) && out_mask == nullptr && hi->y == nullptr && !dense_rows_generic(link, 1))
         return dense_fwd(link, hi->v, wt, bias, out_act, lo, as_stream(stream));
-    if (conv32_fits(link) && out_mask == nullptr && hi->y == nullptr && out_act != ARVAE_ACT_SELU)
-        return conv32_down(link, make_operand(hi), wt, bias, out_act == ARVAE_ACT_RELU, nullptr, nullptr, nullptr, lo, as_stream(stream));
+    if (conv32_fits(link) && out_mask == nullptr && hi->y == nullptr && out_act != ARVAE_ACT_SELU) {
+        const float *wprep;
+        const unsigned *amax;
+        if (int rc = conv32_make_operands(wt, hi->v, (int64_t)link->n * link->hh * link->hw * link->chi, ws, as_stream(stream), &wprep, &amax))
+            return rc;
+        return conv32_down(link, make_operand(hi), bias, out_act == ARVAE_ACT_RELU, nullptr, nullptr, nullptr, lo, as_stream(stream), wprep,
+                           amax, nullptr);
+    }
     if (conv_c1_fits(link) && out_mask == nullptr && hi->mask == nullptr && out_act != ARVAE_ACT_SELU &&
         hi->act != ARVAE_ACT_SELU)
-        return conv_c1_down(link, make_operand(hi), wt, bias, out_act == ARVAE_ACT_RELU, nullptr, nullptr, nullptr, lo, as_stream(stream));
+        return conv_c1_down(link, make_operand(hi), wt, bias, out_act == ARVAE_ACT_RELU, nullptr, nullptr, nullptr, lo, as_stream(stream), nullptr);
     if (conv64_fits(link, false))
         return conv64_down(link, make_operand(hi), wt, bias, out_act, out_mask, lo, ws, as_stream(stream), nullptr);
     if (single_channel_mfma_fits(link)) {
@@ -812,16 +840,18 @@ extern "C" int arvae_link_up(const arvae_link_t *link, const arvae_operand_t *lo
     hipStream_t st = as_stream(stream);
     if (dense_fits(link) && out_mask == nullptr && bias == nullptr && out_act == ARVAE_ACT_NONE && !dense_rows_generic(link, 2))
         return dense_dgrad(link, make_operand(lo), wt, nullptr, hi, st);
-    if (conv32_fits(link) && out_mask == nullptr && lo->y == nullptr && out_act != ARVAE_ACT_SELU)
-    {
+    if (conv32_fits(link) && out_mask == nullptr && lo->y == nullptr && out_act != ARVAE_ACT_SELU) {
+        const float *wprep;
+        const unsigned *amax;
+        if (int rc = conv32_make_operands(wt, lo->v, (int64_t)link->n * link->lh * link->lw * link->clo, ws, st, &wprep, &amax)) return rc;
 #ifdef ARVAE_STAMPS
         static const float *stamp_gate = nullptr;                // diagnostic build: time the gated variant too
         if (getenv("ARVAE_STAMP_GATE") != nullptr) {
             if (stamp_gate == nullptr) (void)hipMalloc((void **)&stamp_gate, (size_t)link->n * link->hh * link->hw * link->chi * 4);
-            return conv32_up(link, make_operand(lo), wt, nullptr, 0, stamp_gate, nullptr, nullptr, hi, st);
+            return conv32_up(link, make_operand(lo), nullptr, 0, stamp_gate, nullptr, nullptr, hi, st, wprep, amax, nullptr);
         }
 #endif
-        return conv32_up(link, make_operand(lo), wt, bias, out_act == ARVAE_ACT_RELU, nullptr, nullptr, nullptr, hi, st);
+        return conv32_up(link, make_operand(lo), bias, out_act == ARVAE_ACT_RELU, nullptr, nullptr, nullptr, hi, st, wprep, amax, nullptr);
     }
     if (conv_c1_fits(link) && lo->y == nullptr && out_mask == nullptr && out_act == ARVAE_ACT_NONE)
         return conv_c1_up(link, lo->v, wt, bias, hi, st);
@@ -894,7 +924,8 @@ extern "C" int64_t arvae_link_wgrad_ws_floats(const arvae_link_t *link) {
     if (blocks * link->chi > need) need = blocks * link->chi;
     if (dense_fits(link) && dense_wgrad_ws_floats(link) > need) need = dense_wgrad_ws_floats(link);
     if (conv64_wgrad_fits(link) && conv64_wgrad_ws_floats(link) > need) need = conv64_wgrad_ws_floats(link);
-    if (conv32_fits(link) && conv32_wgrad_ws_floats(link) > need) need = conv32_wgrad_ws_floats(link);
+    if (conv32_fits(link) && conv32_wgrad_ws_floats(link) + 2 * CONV32_AMAX_FLOATS > need)        // slabs + the operands' AMAX arrays
+        need = conv32_wgrad_ws_floats(link) + 2 * CONV32_AMAX_FLOATS;
     if (conv_c1_fits(link) && conv_c1_wgrad_ws_floats(link) > need) need = conv_c1_wgrad_ws_floats(link);
     if (conv_c1w_fits(link) && conv_c1w_wgrad_ws_floats(link) > need) need = conv_c1w_wgrad_ws_floats(link);
     return need;
@@ -916,8 +947,12 @@ extern "C" int arvae_link_wgrad(const arvae_link_t *link, const arvae_operand_t 
         return conv_c1_wgrad(link, make_operand(lo), make_operand(hi), dwt, dbias, bias_side, ws, st);
     if (conv_c1w_fits(link))
         return conv_c1w_wgrad(link, make_operand(lo), make_operand(hi), dwt, dbias, bias_side, ws, st);
-    if (wgrad_fast(link, lo, hi))
-        return conv32_wgrad(link, make_operand(lo), make_operand(hi), dwt, dbias, bias_side, ws, st);
+    if (wgrad_fast(link, lo, hi)) {
+        unsigned *am = reinterpret_cast<unsigned *>(ws + conv32_wgrad_ws_floats(link));
+        if (int rc = conv32_amax(lo->v, (int64_t)link->n * link->lh * link->lw * link->clo, am, st)) return rc;
+        if (int rc = conv32_amax(hi->v, (int64_t)link->n * link->hh * link->hw * link->chi, am + CONV32_AMAX_FLOATS, st)) return rc;
+        return conv32_wgrad(link, make_operand(lo), make_operand(hi), dwt, dbias, bias_side, ws, st, am, am + CONV32_AMAX_FLOATS);
+    }
     p.lo = make_operand(lo);
     p.hi = make_operand(hi);
     if (conv64_wgrad_fits(link)) {

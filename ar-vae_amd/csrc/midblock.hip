@@ -16,8 +16,11 @@
 #include "dense.h"
 #include "rng.h"
 #include "midprep.h"
+#include "conv32_common.h"
 
 namespace arvae {
+
+int conv32_amax(const float *x, int64_t count, unsigned *out, hipStream_t s);      // conv32.hip
 
 
 constexpr int MID_T = 512;           // threads per workgroup
@@ -53,6 +56,8 @@ struct MidArgs {
     float beta, inv_batch, reg_scale;
     float *d_mu, *d_ls;
     // the matrices this pass streams, except the first one: requested once per XCD at the top of the kernel (mid_warm)
+    unsigned *amax_out;                              // AMAX array (conv32_common.h) of the pass's last output -- dec[nd-1].y forward,
+                                                     // d_x0 backward -- for the 32-channel conv kernel that reads it next, or null
     const float *warm_ptr[2 * MID_MAX_LAYERS + 1];
     int warm_lines[2 * MID_MAX_LAYERS + 1];          // 128-byte lines
     int n_warm;
@@ -203,6 +208,24 @@ __device__ __forceinline__ float4 dact4(float4 g, float4 y, int act) {       // 
                        g.w * act_bwd_from_out(y.w, act));
 }
 
+// maximum magnitude of the R x n block a pass leaves in LDS (rows past the batch hold zeros): one AMAX writer unit per workgroup
+template <int R>
+__device__ __forceinline__ void mid_amax(const float *rows, int ld, int n, float *scratch, unsigned *out) {
+    if (out == nullptr) return;
+    float m = 0.f;
+    const int n4 = n >> 2;
+    for (int i = threadIdx.x; i < R * n4; i += MID_T) m = fmaxf(m, amax4(ld4(rows + (i / n4) * ld + 4 * (i % n4))));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < MID_T / 64; ++w) t = fmaxf(t, scratch[w]);
+        amax_publish(out, blockIdx.x, gridDim.x, t);
+    }
+}
+
 #ifdef MID_STAMPS
 __device__ unsigned long long g_mid_stamps[128 * 16];
 #define MID_STAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 128) g_mid_stamps[blockIdx.x * 16 + (slot)] = wall_clock64(); } while (0)
@@ -270,6 +293,7 @@ __global__ __launch_bounds__(MID_T) void mid_forward_kernel(MidArgs p) {
     { float *t = cur; cur = nxt; nxt = t; }
     MID_STAMP(stamp_no); ++stamp_no;
     for (int i = 0; i < p.nd; ++i) run_layer(p.dec[i]);
+    mid_amax<R>(cur, p.ld, p.dec[p.nd - 1].n, red, p.amax_out);
     mid_warm_done(warm);
 }
 
@@ -361,6 +385,7 @@ __global__ __launch_bounds__(MID_T) void mid_backward_kernel(MidArgs p) {
     }
     for (int i = p.ne - 1; i >= 1; --i) back_layer(p.enc[i].mb, p.enc[i].n, p.enc[i].k, p.enc[i - 1].y, p.enc[i - 1].act, nullptr, p.enc[i - 1].gpre);
     back_layer(p.enc[0].mb, p.enc[0].n, p.enc[0].k, nullptr, 0, p.gate0, p.d_x0);
+    mid_amax<R>(cur, p.ld, p.enc[0].k, red, p.amax_out);
     mid_warm_done(warm);
 }
 
@@ -529,10 +554,14 @@ void mid_prep_args(const arvae_image_vae_t *m, const float *params, float *prep_
 
 // (1) weight layout prep unless prep_done, (2) the forward block.  enc_y / dec_y: saved outputs of the block's layers.
 int mid_forward(const arvae_image_vae_t *m, int batch, const float *params, float *prep_ws, const float *x0, float *const *enc_y,
-                float *const *dec_y, const float *eps, float *mu, float *log_std, float *sigma, float *z, hipStream_t s, bool prep_done) {
+                float *const *dec_y, const float *eps, float *mu, float *log_std, float *sigma, float *z, hipStream_t s, bool prep_done,
+                unsigned *amax_out) {
     MidPlan pl;
     mid_describe(m, params, prep_ws, pl, batch);
     MidArgs &a = pl.args;
+    // AMAX of the last output: one writer unit per workgroup when they fit the array, else a reduction launch of its own
+    const bool amax_in_kernel = (batch + pl.rows - 1) / pl.rows <= AMAX_N;
+    a.amax_out = amax_in_kernel ? amax_out : nullptr;
     for (int i = 0; i < a.ne; ++i) a.enc[i].y = enc_y[i];
     for (int i = 0; i < a.nd; ++i) a.dec[i].y = dec_y[i];
     a.batch = batch; a.x0 = x0;
@@ -559,16 +588,21 @@ int mid_forward(const arvae_image_vae_t *m, int batch, const float *params, floa
     else if (pl.rows == 2) ARVAE_LAUNCH(mid_forward_kernel<2>, dim3((batch + 1) / 2), dim3(MID_T), pl.lds_bytes, s, a);
     else if (pl.rows == 8) ARVAE_LAUNCH(mid_forward_kernel<8>, dim3((batch + 7) / 8), dim3(MID_T), pl.lds_bytes, s, a);
     else ARVAE_LAUNCH(mid_forward_kernel<4>, dim3((batch + 3) / 4), dim3(MID_T), pl.lds_bytes, s, a);
-    return check_launch("mid_forward_kernel");
+    if (int rc = check_launch("mid_forward_kernel")) return rc;
+    if (amax_out != nullptr && !amax_in_kernel) return conv32_amax(dec_y[a.nd - 1], (int64_t)batch * a.dec[a.nd - 1].n, amax_out, s);
+    return ARVAE_OK;
 }
 
 int mid_backward(const arvae_image_vae_t *m, int batch, const float *params, float *prep_ws, float *const *enc_y, float *const *dec_y,
                  float *const *enc_g, float *const *dec_g, const float *g_out, int g_is_pre, const float *gate0, float *d_x0,
                  const float *eps, const float *mu, const float *sigma, const float *dz_reg, const float *dz_extra, const float *g_loss,
-                 const float *kl, const float *cap, float beta, float reg_scale, float *d_mu, float *d_ls, hipStream_t s) {
+                 const float *kl, const float *cap, float beta, float reg_scale, float *d_mu, float *d_ls, hipStream_t s,
+                 unsigned *amax_out) {
     MidPlan pl;
     mid_describe(m, params, prep_ws, pl, batch);
     MidArgs &a = pl.args;
+    const bool amax_in_kernel = (batch + pl.rows - 1) / pl.rows <= AMAX_N;
+    a.amax_out = amax_in_kernel ? amax_out : nullptr;
     for (int i = 0; i < a.ne; ++i) { a.enc[i].y = enc_y[i]; a.enc[i].gpre = enc_g[i]; }
     for (int i = 0; i < a.nd; ++i) { a.dec[i].y = dec_y[i]; a.dec[i].gpre = dec_g[i]; }
     a.batch = batch;
@@ -591,7 +625,9 @@ int mid_backward(const arvae_image_vae_t *m, int batch, const float *params, flo
     else if (pl.rows == 2) ARVAE_LAUNCH(mid_backward_kernel<2>, dim3((batch + 1) / 2), dim3(MID_T), pl.lds_bytes, s, a);
     else if (pl.rows == 8) ARVAE_LAUNCH(mid_backward_kernel<8>, dim3((batch + 7) / 8), dim3(MID_T), pl.lds_bytes, s, a);
     else ARVAE_LAUNCH(mid_backward_kernel<4>, dim3((batch + 3) / 4), dim3(MID_T), pl.lds_bytes, s, a);
-    return check_launch("mid_backward_kernel");
+    if (int rc = check_launch("mid_backward_kernel")) return rc;
+    if (amax_out != nullptr && !amax_in_kernel) return conv32_amax(d_x0, (int64_t)batch * a.enc[0].k, amax_out, s);
+    return ARVAE_OK;
 }
 
 }  // namespace arvae

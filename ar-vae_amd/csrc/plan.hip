@@ -6,6 +6,7 @@
 #include "reduce.h"
 #include "midprep.h"
 #include "regloss.h"
+#include "conv32_common.h"
 
 namespace arvae {
 
@@ -20,37 +21,40 @@ int conv64_down(const arvae_link_t *l, const Operand &hi, const float *wt, const
                 float *lo, float *ws, hipStream_t s, const GateOp *gate);
 int conv64_up(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, int act, const uint8_t *mask,
               float *hi, float *ws, hipStream_t s, const GateOp *gate);
-int conv32_down(const arvae_link_t *l, const Operand &hi, const float *wt, const float *bias, int relu, const float *gate,
-                const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s, const float *wprep = nullptr);
-int conv32_up(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, int relu, const float *gate,
-              const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s, const float *wprep = nullptr);
+// (32-channel conv kernels, conv32.hip: operands come with their AMAX arrays, conv32_common.h)
+int conv32_down(const arvae_link_t *l, const Operand &hi, const float *bias, int relu, const float *gate, const uint16_t *gate_bits,
+                uint16_t *bits_out, float *out, hipStream_t s, const float *wprep, const unsigned *amax_in, unsigned *amax_out);
+int conv32_up(const arvae_link_t *l, const Operand &lo, const float *bias, int relu, const float *gate, const uint16_t *gate_bits,
+              uint16_t *bits_out, float *out, hipStream_t s, const float *wprep, const unsigned *amax_in, unsigned *amax_out);
+int conv32_amax(const float *x, int64_t count, unsigned *out, hipStream_t s);
 int conv_c1_up_recon(const arvae_link_t *l, const float *lo, const float *wt, const float *bias, float *out, const float *x,
                      int dist, float *partial, float *dlogits, hipStream_t s, int *nb_out);
-bool conv32_up_reg_fits(const arvae_link_t *l, const float *wprep);
-int conv32_up_reg(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, uint16_t *bits_out, float *out,
-                  const float *wprep, const RegArgs &reg, int r, hipStream_t s);
+bool conv32_up_reg_fits(const arvae_link_t *l);
+int conv32_up_reg(const arvae_link_t *l, const Operand &lo, const float *bias, uint16_t *bits_out, float *out, const float *wprep,
+                  const unsigned *amax_in, unsigned *amax_out, const RegArgs &reg, int r, hipStream_t s);
 int conv_c1_up_recon_blocks(const arvae_link_t *l);
 int recon_partial_blocks(int64_t count);
 int64_t conv32_prep_floats();
 int conv32_weight_prep(const float *const *wts, float *const *preps, int n_layers, hipStream_t s);
 int conv32_weight_prep_with_mid(const float *const *wts, float *const *preps, int n_layers, const MidPrepArgs &mid, hipStream_t s);
 void mid_prep_args(const arvae_image_vae_t *m, const float *params, float *prep_ws, MidPrepArgs *out);
-bool conv32_pair4_fits(const arvae_link_t *l, bool up, const float *gate, const uint16_t *gate_bits, const float *wprep, int bias_mode);
-int conv32_pair4(const arvae_link_t *l, bool up, const float *g, const float *x_in, const float *wt, const float *gate,
-                 const uint16_t *gate_bits, float *d_in, const float *wprep, float *dwt, float *dbias, float *slab, hipStream_t s,
-                 SlabJob *job);
+bool conv32_pair4_fits(const arvae_link_t *l, bool up, const float *gate, const uint16_t *gate_bits, int bias_mode);
+int conv32_pair4(const arvae_link_t *l, bool up, const float *g, const float *x_in, const float *gate, const uint16_t *gate_bits,
+                 float *d_in, const float *wprep, float *dwt, float *dbias, float *slab, hipStream_t s, SlabJob *job,
+                 const unsigned *amax_g, const unsigned *amax_x, unsigned *amax_out);
 int conv32_wgrad_partial(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *dwt, float *dbias, int bias_mode,
-                         float *slab, hipStream_t s, SlabJob *job);
+                         float *slab, hipStream_t s, SlabJob *job, const unsigned *amax_lo, const unsigned *amax_hi);
 bool conv_c1_pair_fits(const arvae_link_t *l);
 int conv_c1_pair(const arvae_link_t *l, const Operand &g_img, const float *wt, const float *gate, const uint16_t *gate_bits, float *d_lo,
-                 const Operand &w_lo, float *dwt, float *dbias, int bias_mode, float *slab, hipStream_t s, SlabJob *job);
+                 const Operand &w_lo, float *dwt, float *dbias, int bias_mode, float *slab, hipStream_t s, SlabJob *job,
+                 unsigned *amax_out);
 int conv_c1_wgrad_partial(const arvae_link_t *l, const Operand &lo, const Operand &img, float *dwt, float *dbias,
                           int bias_mode, float *slab, hipStream_t s, SlabJob *job);
 int conv_c1_down(const arvae_link_t *l, const Operand &img, const float *wt, const float *bias, int relu,
-                 const float *gate, const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s);
+                 const float *gate, const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s, unsigned *amax_out);
 int conv_c1_down_with_prep(const arvae_link_t *l, const Operand &img, const float *wt, const float *bias, int relu, uint16_t *bits_out,
                            float *out, const float *const *prep_wts, float *const *preps, int n_prep, const MidPrepArgs &mid,
-                           hipStream_t s);
+                           hipStream_t s, unsigned *amax_out);
 
 // fused encoder heads + reparameterisation (heads.hip)
 bool heads_fusable(const arvae_layer_t *hm, const arvae_layer_t *hl, int zdim);
@@ -69,11 +73,13 @@ int heads_latent_bwd(const arvae_layer_t *hm, const arvae_layer_t *hl, int batch
 bool mid_fusable(const arvae_image_vae_t *m, int *ne_out, int *nd_out);
 int64_t mid_prep_floats(const arvae_image_vae_t *m);
 int mid_forward(const arvae_image_vae_t *m, int batch, const float *params, float *prep_ws, const float *x0, float *const *enc_y,
-                float *const *dec_y, const float *eps, float *mu, float *log_std, float *sigma, float *z, hipStream_t s, bool prep_done);
+                float *const *dec_y, const float *eps, float *mu, float *log_std, float *sigma, float *z, hipStream_t s, bool prep_done,
+                unsigned *amax_out);
 int mid_backward(const arvae_image_vae_t *m, int batch, const float *params, float *prep_ws, float *const *enc_y, float *const *dec_y,
                  float *const *enc_g, float *const *dec_g, const float *g_out, int g_is_pre, const float *gate0, float *d_x0,
                  const float *eps, const float *mu, const float *sigma, const float *dz_reg, const float *dz_extra, const float *g_loss,
-                 const float *kl, const float *cap, float beta, float reg_scale, float *d_mu, float *d_ls, hipStream_t s);
+                 const float *kl, const float *cap, float beta, float reg_scale, float *d_mu, float *d_ls, hipStream_t s,
+                 unsigned *amax_out);
 
 // loss-term pieces (losses.hip)
 int recon_partials(const float *logits, const float *x, int64_t count, int64_t batch, int32_t dist, float *ws,
@@ -141,6 +147,11 @@ struct Layout {
     // 32-channel conv layers: the weights split into bf16 terms in per-lane order, rebuilt at the start of every forward
     // pass by ONE launch and used by the layer's forward and data-gradient kernels (-1: not such a layer)
     int64_t enc_wprep[ARVAE_MAX_LAYERS], dec_wprep[ARVAE_MAX_LAYERS];
+    // AMAX arrays (conv32_common.h: the partial maxima a tensor carries for the 32-channel kernels that scale it into fp16) of
+    // every layer's output, of the gradient w.r.t. it, of the two ping-pong gradient buffers, and one for a tensor that arrives
+    // without (the image, or what a kernel outside the conv32 / conv_c1 / latent-block family wrote)
+    int64_t enc_amax[ARVAE_MAX_LAYERS], dec_amax[ARVAE_MAX_LAYERS], enc_gamax[ARVAE_MAX_LAYERS], dec_gamax[ARVAE_MAX_LAYERS];
+    int64_t ga_amax, gb_amax, tmp_amax, tmp2_amax;
     int64_t log_std, dlogits, dz_reg, d_mu, d_ls, g_a, g_b, slab, link_ws, mid_prep, rec_ws, reg_ws, rec_out, kld_out, reg_out, total;
     int64_t slab_floats;
 };
@@ -173,10 +184,10 @@ static int make_layout(const arvae_image_vae_t *m, int64_t n, int64_t n_cols, La
         lk.n = (int32_t)n;
         return (conv32_fits(&lk) || conv_c1_fits(&lk)) ? take(arvae_link_wgrad_ws_floats(&lk)) : -1;
     };
-    auto own_bits = [&](const arvae_layer_t &l) -> int64_t {
+    auto own_bits = [&](const arvae_layer_t &l, int64_t wprep) -> int64_t {
         arvae_link_t lk = l.link;
         lk.n = (int32_t)n;
-        const bool fast = conv32_fits(&lk) || (conv_c1_fits(&lk) && !l.is_up);
+        const bool fast = (conv32_fits(&lk) && wprep >= 0) || (conv_c1_fits(&lk) && !l.is_up);
         static const bool off = getenv("ARVAE_NO_RELU_BITS") != nullptr;      // diagnostic: gate with the float activations
         return (fast && !off && l.act == ARVAE_ACT_RELU && !l.dropout) ? take(out_elems(l, n) / 32) : -1;
     };
@@ -184,19 +195,24 @@ static int make_layout(const arvae_image_vae_t *m, int64_t n, int64_t n_cols, La
     auto own_prep = [&](const arvae_layer_t &l) -> int64_t {
         arvae_link_t lk = l.link;
         lk.n = (int32_t)n;
-        static const bool off = getenv("ARVAE_NO_WEIGHT_PREP") != nullptr;     // diagnostic switch
-        return (!off && conv32_fits(&lk) && n_prep++ < 8) ? take(conv32_prep_floats()) : -1;
+        return (conv32_fits(&lk) && n_prep++ < 8) ? take(conv32_prep_floats()) : -1;
     };
     for (int i = 0; i < m->n_enc; ++i) L.enc_wprep[i] = own_prep(m->enc[i]);
     for (int i = 0; i < m->n_dec; ++i) L.dec_wprep[i] = own_prep(m->dec[i]);
-    for (int i = 0; i < m->n_enc; ++i) L.enc_bits[i] = own_bits(m->enc[i]);
-    for (int i = 0; i < m->n_dec; ++i) L.dec_bits[i] = own_bits(m->dec[i]);
+    for (int i = 0; i < m->n_enc; ++i) L.enc_bits[i] = own_bits(m->enc[i], L.enc_wprep[i]);
+    for (int i = 0; i < m->n_dec; ++i) L.dec_bits[i] = own_bits(m->dec[i], L.dec_wprep[i]);
     for (int i = 0; i < m->n_enc; ++i) L.enc_slab[i] = own_slab(m->enc[i]);
     for (int i = 0; i < m->n_dec; ++i) L.dec_slab[i] = own_slab(m->dec[i]);
     // every layer's output gradient has its own buffer: weight gradients run on a second stream (and the Linear ones
     // at the very end), so a gradient must not be overwritten two layers later
     for (int i = 0; i < m->n_enc; ++i) L.enc_keep[i] = take(out_elems(m->enc[i], n));
     for (int i = 0; i < m->n_dec; ++i) L.dec_keep[i] = take(out_elems(m->dec[i], n));
+    for (int i = 0; i < m->n_enc; ++i) { L.enc_amax[i] = take(AMAX_N); L.enc_gamax[i] = take(AMAX_N); }
+    for (int i = 0; i < m->n_dec; ++i) { L.dec_amax[i] = take(AMAX_N); L.dec_gamax[i] = take(AMAX_N); }
+    L.ga_amax = take(AMAX_N);
+    L.gb_amax = take(AMAX_N);
+    L.tmp_amax = take(AMAX_N);
+    L.tmp2_amax = take(AMAX_N);
     const int64_t bz = n * m->zdim;
     L.log_std = take(bz);
     L.dlogits = take(out_elems(m->dec[m->n_dec - 1], n));
@@ -226,18 +242,28 @@ static inline void mark(void *event, hipStream_t st) {
 
 static arvae_operand_t plain(const float *v) { return arvae_operand_t{v, nullptr, nullptr, ARVAE_ACT_NONE}; }
 
+// in_amax: AMAX array of `in` or null (then one is made in tmp_amax when a 32-channel kernel needs it); out_amax: where the
+// maxima of `out` go when the kernel that runs can deliver them (*out_has tells)
 static int layer_forward(const arvae_layer_t &l, int32_t n, const float *params, const float *in, const uint8_t *mask,
-                         float *out, uint16_t *bits_out, float *link_ws, arvae_stream_t st, const float *wprep = nullptr) {
+                         float *out, uint16_t *bits_out, float *link_ws, arvae_stream_t st, const float *wprep,
+                         const unsigned *in_amax, unsigned *tmp_amax, unsigned *out_amax, bool *out_has) {
     arvae_link_t lk = l.link;
     lk.n = n;
     const arvae_operand_t op = plain(in);
     const float *w = params + l.w_off, *b = l.b_off >= 0 ? params + l.b_off : nullptr;
+    *out_has = false;
     if (bits_out != nullptr) {                           // make_layout grants bits only to ReLU layers on these kernels
         hipStream_t hs = as_stream(st);
-        if (conv32_fits(&lk))
-            return l.is_up ? conv32_up(&lk, make_operand(&op), w, b, 1, nullptr, nullptr, bits_out, out, hs, wprep)
-                           : conv32_down(&lk, make_operand(&op), w, b, 1, nullptr, nullptr, bits_out, out, hs, wprep);
-        return conv_c1_down(&lk, make_operand(&op), w, b, 1, nullptr, nullptr, bits_out, out, hs);
+        *out_has = true;
+        if (conv32_fits(&lk)) {
+            if (in_amax == nullptr) {
+                if (int rc = conv32_amax(in, in_elems(l, n), tmp_amax, hs)) return rc;
+                in_amax = tmp_amax;
+            }
+            return l.is_up ? conv32_up(&lk, make_operand(&op), b, 1, nullptr, nullptr, bits_out, out, hs, wprep, in_amax, out_amax)
+                           : conv32_down(&lk, make_operand(&op), b, 1, nullptr, nullptr, bits_out, out, hs, wprep, in_amax, out_amax);
+        }
+        return conv_c1_down(&lk, make_operand(&op), w, b, 1, nullptr, nullptr, bits_out, out, hs, out_amax);
     }
     return l.is_up ? arvae_link_up(&lk, &op, w, b, l.act, mask, out, link_ws, st)
                    : arvae_link_down(&lk, &op, w, b, l.act, mask, out, link_ws, st);
@@ -255,9 +281,27 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
                           const float *out, const uint8_t *mask, const float *g, bool g_is_pre, const float *gate,
                           float *d_in, bool *gated, float *slab, float *link_ws, DenseWgradBatch *defer, float *own_slab,
                           SlabReduceBatch *rdefer, arvae_stream_t st, const float *g_scale = nullptr,
-                          const uint16_t *gate_bits = nullptr, const float *wprep = nullptr, const GateOp *gate_op = nullptr) {
+                          const uint16_t *gate_bits = nullptr, const float *wprep = nullptr, const GateOp *gate_op = nullptr,
+                          const unsigned *g_amax = nullptr, const unsigned *in_amax = nullptr, unsigned *tmp_amax = nullptr,
+                          unsigned *tmp2_amax = nullptr, unsigned *din_amax = nullptr, bool *din_has = nullptr) {
+    // g_amax / in_amax: AMAX arrays (conv32_common.h) of g and of `in`, or null -- a 32-channel kernel that needs one then gets it
+    // made in tmp_amax / tmp2_amax; din_amax: where the maxima of d_in go when the kernel that writes it delivers them (*din_has)
     arvae_link_t lk = l.link;
     lk.n = n;
+    bool din_has_local = false;
+    if (din_has == nullptr) din_has = &din_has_local;
+    *din_has = false;
+    const bool c32 = conv32_fits(&lk) && wprep != nullptr && tmp_amax != nullptr && tmp2_amax != nullptr;
+    auto need_g = [&]() -> int {
+        if (g_amax != nullptr) return ARVAE_OK;
+        g_amax = tmp_amax;
+        return conv32_amax(g, out_elems(l, n), tmp_amax, as_stream(st));
+    };
+    auto need_in = [&]() -> int {
+        if (in_amax != nullptr) return ARVAE_OK;
+        in_amax = tmp2_amax;
+        return conv32_amax(in, in_elems(l, n), tmp2_amax, as_stream(st));
+    };
     arvae_operand_t gop = g_is_pre ? plain(g) : arvae_operand_t{g, out, mask, l.act};
     // The wide stride-1 convolutions gather their operands once per tap: fold the activation derivative / keep-mask into
     // the upstream gradient once, in place (it is this executor's scratch and has no other reader), and hand the data
@@ -278,12 +322,17 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
     if (gated != nullptr) *gated = false;
     // 4x4 32-channel layers: gated data gradient and weight-gradient partials in one launch (conv32.hip, pair4_*_kernel)
     if (d_in != nullptr && gated != nullptr && rdefer != nullptr && own_slab != nullptr && gop.y == nullptr && g_scale == nullptr &&
-        rdefer->count < SLAB_BATCH_MAX && conv32_fits(&lk) &&
-        conv32_pair4_fits(&lk, l.is_up != 0, gate, gate_bits, wprep, db ? (l.is_up ? 2 : 1) : 0)) {
+        rdefer->count < SLAB_BATCH_MAX && c32 &&
+        conv32_pair4_fits(&lk, l.is_up != 0, gate, gate_bits, db ? (l.is_up ? 2 : 1) : 0)) {
         SlabJob job;
-        if (int rc = conv32_pair4(&lk, l.is_up != 0, gop.v, in, w, gate, gate_bits, d_in, wprep, dw, db, own_slab, hs, &job)) return rc;
+        if (int rc = need_g()) return rc;
+        if (int rc = need_in()) return rc;
+        if (int rc = conv32_pair4(&lk, l.is_up != 0, gop.v, in, gate, gate_bits, d_in, wprep, dw, db, own_slab, hs, &job, g_amax, in_amax,
+                                  din_amax))
+            return rc;
         slab_reduce_defer(rdefer, job);
         *gated = true;
+        *din_has = din_amax != nullptr;
         return ARVAE_OK;
     }
     const bool simple = gop.mask == nullptr && gop.act != ARVAE_ACT_SELU;
@@ -294,24 +343,28 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
         g_op.scale = g_scale;
         SlabJob job;
         if (int rc = conv_c1_pair(&lk, g_op, w, gate_bits ? nullptr : gate, gate_bits, d_in, make_operand(&xin), dw, db, db ? 2 : 0, own_slab,
-                                  hs, &job))
+                                  hs, &job, din_amax))
             return rc;
         slab_reduce_defer(rdefer, job);
         *gated = true;
+        *din_has = din_amax != nullptr;
         return ARVAE_OK;
     }
     if (d_in != nullptr) {
         int rc;
         if (l.is_up) {                                   // forward UP  -> data gradient is a DOWN map
-            if (gate != nullptr && gop.y == nullptr && conv32_fits(&lk)) {
-                rc = conv32_down(&lk, make_operand(&gop), w, nullptr, 0, gate_bits ? nullptr : gate, gate_bits, nullptr, d_in, hs,
-                                 wprep);
+            if (gate != nullptr && gop.y == nullptr && c32) {
+                if (int rc2 = need_g()) return rc2;
+                rc = conv32_down(&lk, make_operand(&gop), nullptr, 0, gate_bits ? nullptr : gate, gate_bits, nullptr, d_in, hs, wprep,
+                                 g_amax, din_amax);
                 *gated = true;
+                *din_has = din_amax != nullptr;
             } else if (gate != nullptr && simple && conv_c1_fits(&lk)) {
                 Operand g_op = make_operand(&gop);
                 g_op.scale = g_scale;
-                rc = conv_c1_down(&lk, g_op, w, nullptr, 0, gate_bits ? nullptr : gate, gate_bits, nullptr, d_in, hs);
+                rc = conv_c1_down(&lk, g_op, w, nullptr, 0, gate_bits ? nullptr : gate, gate_bits, nullptr, d_in, hs, din_amax);
                 *gated = true;
+                *din_has = din_amax != nullptr;
             } else if (gate_op != nullptr && !conv64_fits(&lk, false) && !conv_c1_fits(&lk) && single_channel_down_gated_fits(&lk)) {
                 rc = single_channel_down_gated(&lk, make_operand(&gop), w, gate_op, d_in, hs);
                 *gated = true;
@@ -322,10 +375,12 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
                 rc = arvae_link_down(&lk, &gop, w, nullptr, ARVAE_ACT_NONE, nullptr, d_in, link_ws, st);
             }
         } else {                                         // forward DOWN -> data gradient is an UP map
-            if (gate != nullptr && gop.y == nullptr && conv32_fits(&lk)) {
-                rc = conv32_up(&lk, make_operand(&gop), w, nullptr, 0, gate_bits ? nullptr : gate, gate_bits, nullptr, d_in, hs,
-                               wprep);
+            if (gate != nullptr && gop.y == nullptr && c32) {
+                if (int rc2 = need_g()) return rc2;
+                rc = conv32_up(&lk, make_operand(&gop), nullptr, 0, gate_bits ? nullptr : gate, gate_bits, nullptr, d_in, hs, wprep,
+                               g_amax, din_amax);
                 *gated = true;
+                *din_has = din_amax != nullptr;
             } else if (gate != nullptr && dense_fits(&lk)) {
                 rc = dense_dgrad(&lk, make_operand(&gop), w, gate, d_in, hs);
                 *gated = true;
@@ -340,12 +395,17 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
     }
     // conv layers with a slab kernel and plain operands: partial sums now, reduction queued for the end of the pass
     if (rdefer != nullptr && own_slab != nullptr && gop.y == nullptr && rdefer->count < SLAB_BATCH_MAX &&
-        (conv32_fits(&lk) || conv_c1_fits(&lk))) {
+        ((conv32_fits(&lk) && tmp_amax != nullptr && tmp2_amax != nullptr) || conv_c1_fits(&lk))) {
         Operand lo_op = make_operand(l.is_up ? &xin : &gop), hi_op = make_operand(l.is_up ? &gop : &xin);
         (l.is_up ? hi_op : lo_op).scale = g_scale;                // only the conv_c1 kernels honour it (checked by the caller)
         const int bias_mode = db ? (l.is_up ? 2 : 1) : 0;
         SlabJob job;
-        const int rc = conv32_fits(&lk) ? conv32_wgrad_partial(&lk, lo_op, hi_op, dw, db, bias_mode, own_slab, whs, &job)
+        if (conv32_fits(&lk)) {
+            if (int rc = need_g()) return rc;
+            if (int rc = need_in()) return rc;
+        }
+        const int rc = conv32_fits(&lk) ? conv32_wgrad_partial(&lk, lo_op, hi_op, dw, db, bias_mode, own_slab, whs, &job,
+                                                               l.is_up ? in_amax : g_amax, l.is_up ? g_amax : in_amax)
                                         : conv_c1_wgrad_partial(&lk, lo_op, hi_op, dw, db, bias_mode, own_slab, whs, &job);
         if (rc) return rc;
         slab_reduce_defer(rdefer, job);
@@ -384,6 +444,7 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
     ARVAE_REQUIRE(params && x && eps && ws && scalars && mu && sigma && z && logits, "image_vae_forward: null pointer");
     ARVAE_REQUIRE(m->n_reg == 0 || n_cols < 0 || labels != nullptr, "image_vae_forward: labels needed for the reg loss");
     hipStream_t st = as_stream(stream);
+    auto U = [&](int64_t off) { return reinterpret_cast<unsigned *>(ws + off); };
     int mi = 0;
     bool mid_prepped = false;
     int mid_ne = 0, mid_nd = 0;
@@ -411,7 +472,7 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
                 const arvae_operand_t op = plain(x);
                 if (int rc = conv_c1_down_with_prep(&lk0, make_operand(&op), params + l0.w_off, l0.b_off >= 0 ? params + l0.b_off : nullptr,
                                                     1, reinterpret_cast<uint16_t *>(ws + L.enc_bits[0]), ws + L.enc_out[0], wts, preps, np,
-                                                    margs, st))
+                                                    margs, st, U(L.enc_amax[0])))
                     return rc;
                 first = 1;
             } else if (int rc = conv32_weight_prep_with_mid(wts, preps, np, margs, st)) return rc;
@@ -420,15 +481,20 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
     }
     // encoder
     const float *h = first ? ws + L.enc_out[0] : x;
+    const unsigned *h_amax = first ? U(L.enc_amax[0]) : nullptr;   // AMAX array of h, when the kernel that wrote h delivered one
     mi += first ? (m->enc[0].dropout != 0) : 0;
     for (int i = first; i < m->n_enc - mid_ne; ++i) {
         const uint8_t *mask = (masks != nullptr && m->enc[i].dropout) ? masks[mi] : nullptr;
         mi += m->enc[i].dropout != 0;
         uint16_t *bits = L.enc_bits[i] >= 0 ? reinterpret_cast<uint16_t *>(ws + L.enc_bits[i]) : nullptr;
+        bool has = false;
+        // (a 32-channel layer's input keeps its AMAX array for the weight gradient: a missing one is made in the input's own slot)
         if (int rc = layer_forward(m->enc[i], batch, params, h, mask, ws + L.enc_out[i], bits, ws + L.link_ws, stream,
-                                   L.enc_wprep[i] >= 0 ? ws + L.enc_wprep[i] : nullptr))
+                                   L.enc_wprep[i] >= 0 ? ws + L.enc_wprep[i] : nullptr, h_amax, i > 0 ? U(L.enc_amax[i - 1]) : U(L.tmp_amax),
+                                   U(L.enc_amax[i]), &has))
             return rc;
         h = ws + L.enc_out[i];
+        h_amax = has ? U(L.enc_amax[i]) : nullptr;
     }
     const int64_t bz = (int64_t)batch * m->zdim;
     bool heads_next = false;
@@ -436,8 +502,11 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
         float *enc_y[ARVAE_MAX_LAYERS], *dec_y[ARVAE_MAX_LAYERS];
         for (int i = 0; i < mid_ne; ++i) enc_y[i] = ws + L.enc_out[m->n_enc - mid_ne + i];
         for (int i = 0; i < mid_nd; ++i) dec_y[i] = ws + L.dec_out[i];
-        if (int rc = mid_forward(m, batch, params, ws + L.mid_prep, h, enc_y, dec_y, eps, mu, ws + L.log_std, sigma, z, st, mid_prepped)) return rc;
+        if (int rc = mid_forward(m, batch, params, ws + L.mid_prep, h, enc_y, dec_y, eps, mu, ws + L.log_std, sigma, z, st, mid_prepped,
+                                 U(L.dec_amax[mid_nd - 1])))
+            return rc;
         h = dec_y[mid_nd - 1];
+        h_amax = U(L.dec_amax[mid_nd - 1]);
     } else if (heads_fusable(&m->head_mu, &m->head_log_std, m->zdim)) {
         // the decoder's first Linear layer rides in the heads kernel when it can (heads.hip)
         heads_next = m->n_dec > 1 && heads_next_fusable(&m->dec[0], m->zdim) && !(masks != nullptr && m->dec[0].dropout);
@@ -449,13 +518,14 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
             if (int rc = arvae_philox_normal(const_cast<float *>(eps), bz, m->rng_seed, m->rng_offset, m->rng_step,
                                              m->rng_dev_step, stream))
                 return rc;
-        if (int rc = layer_forward(m->head_mu, batch, params, h, nullptr, mu, nullptr, ws + L.link_ws, stream)) return rc;
-        if (int rc = layer_forward(m->head_log_std, batch, params, h, nullptr, ws + L.log_std, nullptr, ws + L.link_ws, stream)) return rc;
+        bool has = false;
+        if (int rc = layer_forward(m->head_mu, batch, params, h, nullptr, mu, nullptr, ws + L.link_ws, stream, nullptr, nullptr, nullptr, nullptr, &has)) return rc;
+        if (int rc = layer_forward(m->head_log_std, batch, params, h, nullptr, ws + L.log_std, nullptr, ws + L.link_ws, stream, nullptr, nullptr, nullptr, nullptr, &has)) return rc;
         if (int rc = arvae_latent_fwd(mu, ws + L.log_std, eps, bz, sigma, z, stream)) return rc;
     }
     if (m->milestones != nullptr) mark(m->milestones->z_ready, st);   // mu / sigma / z are final: the caller's all-gather may start
     // decoder
-    if (!mid) h = heads_next ? ws + L.dec_out[0] : z;
+    if (!mid) { h = heads_next ? ws + L.dec_out[0] : z; h_amax = nullptr; }
     int nb = 0;
     const arvae_layer_t &last = m->dec[m->n_dec - 1];
     const bool recon_fused = last.is_up && last.act == ARVAE_ACT_NONE && last.dropout == 0 && conv_c1_fits(&last.link) &&
@@ -482,13 +552,15 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
         arvae_link_t lki = m->dec[i].link;
         lki.n = batch;
         if (reg_here && !reg_done && z_cols == nullptr && i + 1 < m->n_dec && m->dec[i].is_up && m->dec[i].act == ARVAE_ACT_RELU &&
-            mask == nullptr && L.dec_bits[i] >= 0 && L.dec_wprep[i] >= 0 && conv32_up_reg_fits(&lki, ws + L.dec_wprep[i])) {
+            mask == nullptr && L.dec_bits[i] >= 0 && L.dec_wprep[i] >= 0 && h_amax != nullptr && conv32_up_reg_fits(&lki)) {
             const arvae_layer_t &l = m->dec[i];
             const arvae_operand_t op = plain(h);
-            if (int rc = conv32_up_reg(&lki, make_operand(&op), params + l.w_off, l.b_off >= 0 ? params + l.b_off : nullptr,
-                                       reinterpret_cast<uint16_t *>(ws + L.dec_bits[i]), out, ws + L.dec_wprep[i], reg_args, m->n_reg, st))
+            if (int rc = conv32_up_reg(&lki, make_operand(&op), l.b_off >= 0 ? params + l.b_off : nullptr,
+                                       reinterpret_cast<uint16_t *>(ws + L.dec_bits[i]), out, ws + L.dec_wprep[i], h_amax, U(L.dec_amax[i]),
+                                       reg_args, m->n_reg, st))
                 return rc;
             reg_done = true;
+            h_amax = U(L.dec_amax[i]);
         } else if (i + 1 == m->n_dec && recon_fused) {             // last layer: logits + reconstruction partials in one kernel
             arvae_link_t lk = m->dec[i].link;
             lk.n = batch;
@@ -496,11 +568,15 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
             if (int rc = conv_c1_up_recon(&lk, h, params + l.w_off, l.b_off >= 0 ? params + l.b_off : nullptr, logits, x,
                                           m->recon_dist, ws + L.rec_ws, ws + L.dlogits, st, &nb))
                 return rc;
+            h_amax = nullptr;
         } else {
             uint16_t *bits = L.dec_bits[i] >= 0 ? reinterpret_cast<uint16_t *>(ws + L.dec_bits[i]) : nullptr;
+            bool has = false;
             if (int rc = layer_forward(m->dec[i], batch, params, h, mask, out, bits, ws + L.link_ws, stream,
-                                       L.dec_wprep[i] >= 0 ? ws + L.dec_wprep[i] : nullptr))
+                                       L.dec_wprep[i] >= 0 ? ws + L.dec_wprep[i] : nullptr, h_amax, i > 0 ? U(L.dec_amax[i - 1]) : U(L.tmp_amax),
+                                       U(L.dec_amax[i]), &has))
                 return rc;
+            h_amax = has ? U(L.dec_amax[i]) : nullptr;
         }
         h = out;
     }
@@ -562,6 +638,21 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
     ARVAE_REQUIRE(params && grads && x && eps && mu && sigma && z && logits && g_loss && ws,
                   "image_vae_backward: null pointer");
     hipStream_t st = as_stream(stream);
+    auto U = [&](int64_t off) { return reinterpret_cast<unsigned *>(ws + off); };
+    // AMAX array (conv32_common.h) that belongs to a gradient buffer of this pass
+    auto grad_amax = [&](const float *p) -> unsigned * {
+        if (p == nullptr) return nullptr;
+        for (int i = 0; i < m->n_enc; ++i) if (p == ws + L.enc_keep[i]) return U(L.enc_gamax[i]);
+        for (int i = 0; i < m->n_dec; ++i) if (p == ws + L.dec_keep[i]) return U(L.dec_gamax[i]);
+        return p == ws + L.g_a ? U(L.ga_amax) : p == ws + L.g_b ? U(L.gb_amax) : nullptr;
+    };
+    // the forward pass left a valid AMAX array with the input of every 32-channel layer that ran on the fast kernels
+    auto in_amax_of = [&](bool dec, int i) -> const unsigned * {
+        if (i == 0) return nullptr;
+        const bool fast = (dec ? L.dec_bits[i] : L.enc_bits[i]) >= 0 && (dec ? L.dec_wprep[i] : L.enc_wprep[i]) >= 0;
+        return fast ? U(dec ? L.dec_amax[i - 1] : L.enc_amax[i - 1]) : nullptr;
+    };
+    const unsigned *cur_amax = nullptr;                   // AMAX array of `cur`, when the kernel that wrote it delivered one
     // keep-mask index of every dropout layer, in forward order
     int enc_mask[ARVAE_MAX_LAYERS], dec_mask[ARVAE_MAX_LAYERS], mi = 0;
     for (int i = 0; i < m->n_enc; ++i) enc_mask[i] = m->enc[i].dropout ? mi++ : -1;
@@ -633,15 +724,17 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
             heads_next_g = cur;
             dst = nullptr;
         }
+        bool din_has = false;
         if (int rc = layer_backward(m->dec[i], batch, params, grads, in, out, mask_of(dec_mask[i]), cur, pre, gate, dst,
                                     &gated, slab, ws + L.link_ws, &defer, L.dec_slab[i] >= 0 ? ws + L.dec_slab[i] : nullptr, &rdefer, stream,
                                     i == m->n_dec - 1 ? first_scale : nullptr,
                                     (gate != nullptr && i > 0 && L.dec_bits[i - 1] >= 0)
                                         ? reinterpret_cast<const uint16_t *>(ws + L.dec_bits[i - 1]) : nullptr,
-                                    L.dec_wprep[i] >= 0 ? ws + L.dec_wprep[i] : nullptr, gate_op))
+                                    L.dec_wprep[i] >= 0 ? ws + L.dec_wprep[i] : nullptr, gate_op, cur_amax, in_amax_of(true, i),
+                                    U(L.tmp_amax), U(L.tmp2_amax), grad_amax(dst), &din_has))
             return rc;
         pre = gated;
-        if (heads_next_g == nullptr) cur = dst;
+        if (heads_next_g == nullptr) { cur = dst; cur_amax = din_has ? grad_amax(dst) : nullptr; }
     }
     // data-parallel caller: finish the decoder's conv gradients now (their all-reduce then runs under the rest of the pass)
     const arvae_milestones *ms = m->milestones;
@@ -678,7 +771,7 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
         const float *g_last = cur;                           // gradient arriving at the last Linear layer of the decoder
         if (int rc = mid_backward(m, batch, params, ws + L.mid_prep, enc_y, dec_y, enc_g, dec_g, g_last, pre ? 1 : 0, gate0, d_x0, eps,
                                   mu, sigma, dz_reg, dz_extra, g_loss, ws + L.kld_out + 1, capacity, m->beta, reg_scale, ws + L.d_mu,
-                                  ws + L.d_ls, st))
+                                  ws + L.d_ls, st, grad_amax(d_x0)))
             return rc;
         // weight gradients of the block's layers: (pre-activation gradient, layer input) pairs for the grouped launch
         auto queue = [&](const arvae_layer_t &l, const float *g, const float *in) -> int {
@@ -696,6 +789,7 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
         for (int i = mid_ne - 1; i >= 0; --i)
             if (int rc = queue(m->enc[e0 + i], enc_g[i], i > 0 ? enc_y[i - 1] : x0)) return rc;
         cur = d_x0;
+        cur_amax = grad_amax(d_x0);
         pre = gate0 != nullptr;
         enc_from = e0 - 1;
         if (ms != nullptr && ms->linear_grads != nullptr) {   // every Linear weight gradient is queued
@@ -720,6 +814,7 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
                 if (int rc = arvae_link_wgrad(&lk, &gop, &xin, dw, db, db ? 1 : 0, slab, stream)) return rc;
         }
         cur = d_hidden;
+        cur_amax = nullptr;
         pre = head_gate != nullptr;
     } else {
         int64_t blocks = (bz + 255) / 256;
@@ -742,6 +837,7 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
         ARVAE_LAUNCH(add_inplace_kernel, dim3((unsigned)blocks2), dim3(256), 0, st, cur, other, head_gate, hn);
         if (int rc = check_launch("image_vae_backward(add)")) return rc;
         pre = head_gate != nullptr;
+        cur_amax = nullptr;
     }
     // encoder, last layer first; the image itself needs no gradient
     for (int i = enc_from; i >= 0; --i) {
@@ -751,15 +847,18 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
         const GateOp *gate_op = i > 0 ? general_gate(m->enc[i - 1], enc_mask[i - 1], in, go) : nullptr;
         float *dst = i > 0 ? grad_dst(L.enc_keep[i - 1], cur) : nullptr;
         bool gated = false;
+        bool din_has = false;
         if (int rc = layer_backward(m->enc[i], batch, params, grads, in, ws + L.enc_out[i], mask_of(enc_mask[i]), cur, pre,
                                     gate, dst, &gated, slab, ws + L.link_ws, &defer, L.enc_slab[i] >= 0 ? ws + L.enc_slab[i] : nullptr, &rdefer,
                                     stream, nullptr,
                                     (gate != nullptr && i > 0 && L.enc_bits[i - 1] >= 0)
                                         ? reinterpret_cast<const uint16_t *>(ws + L.enc_bits[i - 1]) : nullptr,
-                                    L.enc_wprep[i] >= 0 ? ws + L.enc_wprep[i] : nullptr, gate_op))
+                                    L.enc_wprep[i] >= 0 ? ws + L.enc_wprep[i] : nullptr, gate_op, cur_amax, in_amax_of(false, i),
+                                    U(L.tmp_amax), U(L.tmp2_amax), grad_amax(dst), &din_has))
             return rc;
         pre = gated;
         cur = dst;
+        cur_amax = din_has ? grad_amax(dst) : nullptr;
     }
     // The two closing kernels are independent (disjoint gradients): the slab reduction streams ~90 MB from HBM while the
     // grouped Linear weight gradients are latency-bound in L2.  Side by side on a second stream they measured 22 us SLOWER

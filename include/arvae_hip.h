@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ARVAE_ABI_VERSION 5   /* 5: arvae_adam_step(zero_grad), arvae_image_vae_finish, arvae_image_vae_t.milestones (events the executors record for the data-parallel caller's collectives); 4: arvae_philox_* and in-kernel eps (arvae_image_vae_t.rng_*), arvae_tick_free_run_supported, caller workspace for arvae_link_down/up (arvae_link_ws_floats); 3: arvae_gru_seq_*, embed_bwd workspace; 2: arvae_image_vae_backward reg_fused == 2 (unit regulariser gradient in dz_extra) */
+#define ARVAE_ABI_VERSION 6   /* 6: the 32-channel k4 s2 p1 links need caller workspace too (arvae_link_ws_floats / arvae_link_wgrad_ws_floats: the layer's weights as scaled fp16 terms and the operands' maxima); 5: arvae_adam_step(zero_grad), arvae_image_vae_finish, arvae_image_vae_t.milestones (events the executors record for the data-parallel caller's collectives); 4: arvae_philox_* and in-kernel eps (arvae_image_vae_t.rng_*), arvae_tick_free_run_supported, caller workspace for arvae_link_down/up (arvae_link_ws_floats); 3: arvae_gru_seq_*, embed_bwd workspace; 2: arvae_image_vae_backward reg_fused == 2 (unit regulariser gradient in dz_extra) */
 
 #define ARVAE_OK 0
 #define ARVAE_E_INVALID (-1)  /* bad argument (null pointer, size out of range, unsupported shape) */
@@ -96,7 +96,8 @@ typedef struct {
 } arvae_operand_t;
 
 /* Floats of caller workspace arvae_link_down / arvae_link_up need for this link (0 for most geometries; the wide stride-1
- * convolutions re-order their weights to [out channel][tap][in channel] there before the product).  Independent of n. */
+ * convolutions re-order their weights to [out channel][tap][in channel] there before the product; the 32-channel k4 s2 p1
+ * links split their weights into scaled fp16 terms there and keep the input's per-workgroup maxima).  Independent of n. */
 int64_t arvae_link_ws_floats(const arvae_link_t *link);
 
 /* lo = epilogue( sum_{ky,kx,chi} hi * wt + bias[clo] );  epilogue = act, then *2*out_mask if given.

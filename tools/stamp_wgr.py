@@ -12,7 +12,7 @@ link = ops.Link(2 * lo_sz, 2 * lo_sz, 32, lo_sz, lo_sz, 32, 4, 4, 2, 1)
 hi = torch.randn(n, 2 * lo_sz, 2 * lo_sz, 32, device=dev)
 lo = torch.randn(n, lo_sz, lo_sz, 32, device=dev)
 dw = torch.zeros(32, 32, 4, 4, device=dev); db = torch.zeros(32, device=dev)
-fn = ctypes.CDLL(_lib.LIB_PATH).arvae_debug_wgr_stamps
+fn = ctypes.CDLL(os.environ.get('ARVAE_LIB') or _lib.LIB_PATH).arvae_debug_wgr_stamps
 fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
 for _ in range(20):
     ops.link_wgrad(link, n, ops._operand(lo), ops._operand(hi), dw, db, 1)
