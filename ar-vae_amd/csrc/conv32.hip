@@ -31,6 +31,8 @@
 #include "midprep.h"
 #include "prep32.h"
 #include "regloss.h"
+#include "down32p.h"
+#include "wgrad32r.h"
 
 #include <type_traits>
 
@@ -153,18 +155,18 @@ struct PatchLoader {
 __device__ unsigned long long g_stamps[512 * 64 * 2];
 #define STAMP(slot)                                                                      \
     do {                                                                                 \
-        if (LO == 16 && threadIdx.x == 0 && blockIdx.x < 512 && (slot) < 64) {           \
-            g_stamps[(blockIdx.x * 64 + (slot)) * 2] = __builtin_readcyclecounter();     \
-            g_stamps[(blockIdx.x * 64 + (slot)) * 2 + 1] = wall_clock64();               \
+        if (LO == 16 && threadIdx.x == 0 && BID < 512 && (slot) < 64) {                  \
+            g_stamps[(BID * 64 + (slot)) * 2] = __builtin_readcyclecounter();            \
+            g_stamps[(BID * 64 + (slot)) * 2 + 1] = wall_clock64();                      \
         }                                                                                \
     } while (0)
 #define STAMP_WAIT() __builtin_amdgcn_s_waitcnt(0)
 // up32p_kernel: row blockIdx.x = its consumers (thread 0), row 256 + blockIdx.x = its producers (thread 256)
 #define PSTAMP(role, slot)                                                               \
     do {                                                                                 \
-        if (threadIdx.x == 256 * (role) && blockIdx.x < 256 && (slot) < 64) {            \
-            g_stamps[((blockIdx.x + 256 * (role)) * 64 + (slot)) * 2] = __builtin_readcyclecounter();     \
-            g_stamps[((blockIdx.x + 256 * (role)) * 64 + (slot)) * 2 + 1] = wall_clock64();               \
+        if (threadIdx.x == 256 * (role) && BID < 256 && (slot) < 64) {                   \
+            g_stamps[((BID + 256 * (role)) * 64 + (slot)) * 2] = __builtin_readcyclecounter();            \
+            g_stamps[((BID + 256 * (role)) * 64 + (slot)) * 2 + 1] = wall_clock64();                      \
         }                                                                                \
     } while (0)
 #else
@@ -563,8 +565,7 @@ __global__ __launch_bounds__(256, 1) void up32x_kernel(const float *__restrict__
 // per tile, the compute waves 2.4 -- and as a gated data gradient its loader waited for the far patch loads, which the compute
 // waves now request a whole tile ahead.)  profiles/r3_phase_stamps.txt
 template <int MODE>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void up32p_kernel(const float *__restrict__ lo, Ep32 ep,
-                                                                                               int n_img, int n_tiles) {
+__device__ __forceinline__ void up32p_body(const float *__restrict__ lo, Ep32 ep, int n_img, int n_tiles, const int BID, const int NBLK) {
     static_assert(MODE != EP_GATE_F, "up32p_kernel: float gates stay on up32x_kernel");
     constexpr int LO = 16, PX = 128, HI = 2 * LO, MT = PX / 32;
     using PL = PatchLoader<LO, 1, PX>;
@@ -575,7 +576,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float4 *hand = reinterpret_cast<float4 *>(lds + 2 * BUF);    // [wave][mt][group][lane]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, rc = lane & 31;
-    const int per_wg = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x, t_first = blockIdx.x * per_wg;
+    const int per_wg = (n_tiles + NBLK - 1) / NBLK, t_first = BID * per_wg;
     const int t_end = min(n_tiles, t_first + per_wg);
     const int cls = wave & 3, py = cls >> 1, px = cls & 1;       // parity class of a compute wave / of the store wave that finishes it
 
@@ -652,7 +653,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             PSTAMP(1, 8 + 6 * pst);
             ++pst;
         }
-        amax_publish(ep.amax_out, blockIdx.x * 4 + cls, gridDim.x * 4, amax_run);
+        amax_publish(ep.amax_out, BID * 4 + cls, NBLK * 4, amax_run);
         PSTAMP(1, 63);
         return;
     }
@@ -790,6 +791,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         ++cst;
     }
     PSTAMP(0, 63);
+}
+template <int MODE>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void up32p_kernel(const float *__restrict__ lo, Ep32 ep,
+                                                                                               int n_img, int n_tiles) {
+    up32p_body<MODE>(lo, ep, n_img, n_tiles, blockIdx.x, gridDim.x);
 }
 
 // The decoder's first convolution (4x4 -> 8x8: a few tiles per CU, 6.5 us) and the all-pairs attribute regularisation of the
@@ -973,6 +979,35 @@ __global__ __launch_bounds__(256, 1) void pair4_up_kernel(const float *__restric
 }
 
 
+// ---- the 16x16 and 8x8 layers: the same horizontal pair (the two products of a layer's backward pass both read the incoming
+// gradient and neither needs the other).  Alone each is a persistent one-workgroup-per-CU launch of 11-26 us of which 5-8 us
+// are launch ramp, cold first loads and drain; side by side on disjoint CUs those overlap, and the weight gradient leaves
+// half as many slabs for the closing reduction.
+template <int LO, int MODE, int BIAS>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void pair_down_wgrad_kernel(
+    const float *__restrict__ g_hi, Ep32 ep, int n_img, int tiles_a, int grid_a, const float *__restrict__ w_lo, const float *__restrict__ w_hi,
+    float *__restrict__ slab, int total_steps, int steps_per_wg, const unsigned *amax_lo, const unsigned *amax_hi) {
+    if ((int)blockIdx.x < grid_a) down32p_body<LO, MODE>(g_hi, ep, n_img, tiles_a, blockIdx.x, grid_a);
+    else wgrad32r_body<LO, BIAS>(w_lo, w_hi, slab, n_img, total_steps, steps_per_wg, amax_lo, amax_hi, blockIdx.x - grid_a);
+}
+template <int MODE, int BIAS>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void pair_up16_wgrad_kernel(
+    const float *__restrict__ g_lo, Ep32 ep, int n_img, int tiles_a, int grid_a, const float *__restrict__ w_lo, const float *__restrict__ w_hi,
+    float *__restrict__ slab, int total_steps, int steps_per_wg, const unsigned *amax_lo, const unsigned *amax_hi) {
+    if ((int)blockIdx.x < grid_a) up32p_body<MODE>(g_lo, ep, n_img, tiles_a, blockIdx.x, grid_a);
+    else wgrad32r_body<16, BIAS>(w_lo, w_hi, slab, n_img, total_steps, steps_per_wg, amax_lo, amax_hi, blockIdx.x - grid_a);
+}
+// (the 8x8 Up body is a 256-thread workgroup: its launch-mates' other four waves leave at once)
+template <int MODE, int BIAS>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void pair_up8_wgrad_kernel(
+    const float *__restrict__ g_lo, Ep32 ep, int n_img, int tiles_a, int grid_a, const float *__restrict__ w_lo, const float *__restrict__ w_hi,
+    float *__restrict__ slab, int total_steps, int steps_per_wg, const unsigned *amax_lo, const unsigned *amax_hi) {
+    if ((int)blockIdx.x < grid_a) {
+        if (threadIdx.x >= 256) return;
+        up32x_body<8, MODE, 32>(g_lo, ep, n_img, tiles_a, blockIdx.x, grid_a);
+    } else wgrad32r_body<8, BIAS>(w_lo, w_hi, slab, n_img, total_steps, steps_per_wg, amax_lo, amax_hi, blockIdx.x - grid_a);
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -1054,8 +1089,26 @@ static int ep_mode(const Ep32 &ep, int relu) {
     return ep.gate_bits != nullptr ? EP_GATE_B : ep.gate != nullptr ? EP_GATE_F : relu ? EP_RELU : EP_PLAIN;
 }
 
-// (conv32k.hip: the four-way reduction-split producer / consumer kernel of the 16x16 / 8x8 layers)
-void conv32_down_ksplit(const arvae_link_t *l, const float *hi, const Ep32 &ep, int mode, hipStream_t s);
+// the four-way reduction-split producer / consumer kernel of the 16x16 / 8x8 layers (down32p.h)
+template <int LO, int MODE> static void launch_down_p(const float *hi, const Ep32 &ep, int n, hipStream_t s) {
+    constexpr int LDS = DownK<LO>::LDS_DW * 4;
+    static bool attr = false;
+    if (!attr) { allow_lds(down32p_kernel<LO, MODE>, LDS); attr = true; }
+    const int tiles = n * DownK<LO>::TILES_PER_IMG;
+    ARVAE_LAUNCH((down32p_kernel<LO, MODE>), dim3(grid_for_tiles(tiles)), dim3(512), LDS, s, hi, ep, n, tiles);
+}
+template <int LO> static void launch_down_p_mode(const float *hi, const Ep32 &ep, int mode, int n, hipStream_t s) {
+    switch (mode) {
+        case EP_GATE_B: launch_down_p<LO, EP_GATE_B>(hi, ep, n, s); break;
+        case EP_GATE_F: launch_down_p<LO, EP_GATE_F>(hi, ep, n, s); break;
+        case EP_RELU: launch_down_p<LO, EP_RELU>(hi, ep, n, s); break;
+        default: launch_down_p<LO, EP_PLAIN>(hi, ep, n, s); break;
+    }
+}
+static void conv32_down_ksplit(const arvae_link_t *l, const float *hi, const Ep32 &ep, int mode, hipStream_t s) {
+    if (l->lh == 16) launch_down_p_mode<16>(hi, ep, mode, l->n, s);
+    else launch_down_p_mode<8>(hi, ep, mode, l->n, s);
+}
 
 // The operands of every entry point below: plain fp32 tensors that come with the AMAX array of their values (conv32_common.h;
 // conv32_amax makes one for a tensor that has none), the layer's prepared weights (conv32_weight_prep), and -- when somebody
@@ -1160,11 +1213,47 @@ int conv32_amax(const float *x, int64_t count, unsigned *out, hipStream_t s) {
     return check_launch("conv32_amax");
 }
 
-// row-stream weight gradient with producer / consumer waves (conv32r.hip): the 16x16 and 8x8 layers
-bool conv32_wgrad_stream_fits(const arvae_link_t *l);
-int conv32_wgrad_stream_groups(const arvae_link_t *l);
-int conv32_wgrad_stream(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *slab, int bias_mode, const unsigned *amax_lo,
-                        const unsigned *amax_hi, hipStream_t s);
+// row-stream weight gradient with producer / consumer waves (wgrad32r.h): the 16x16 and 8x8 layers
+static bool conv32_wgrad_stream_fits(const arvae_link_t *l) {
+    static const bool off = getenv("ARVAE_WGRAD_NO_STREAM") != nullptr;     // diagnostic: the patch-staged wgrad32x_kernel instead
+    return !off && (l->lh == 16 || l->lh == 8);
+}
+// steps of the whole launch, steps per workgroup and workgroups when `groups` workgroups (at most) share the stream
+static void stream_geometry(const arvae_link_t *l, int groups, int &total, int &spw, int &grid) {
+    total = l->n * (l->lh * l->lh / 32);
+    spw = (total + groups - 1) / groups;
+    static const int forced = getenv("ARVAE_WGR_SPW") != nullptr ? atoi(getenv("ARVAE_WGR_SPW")) : 0;   // diagnostic: steps per workgroup
+    if (forced > 0) spw = forced;
+    if (spw < 1) spw = 1;
+    grid = (total + spw - 1) / spw;
+}
+static int conv32_wgrad_stream_groups(const arvae_link_t *l) {
+    int total, spw, grid;
+    stream_geometry(l, cu_count(), total, spw, grid);
+    return grid;
+}
+template <int LO> static int launch_stream(const arvae_link_t *l, const float *lo, const float *hi, float *slab, int bias_mode,
+                                           const unsigned *amax_lo, const unsigned *amax_hi, hipStream_t s) {
+    constexpr int LDS = RowStream<LO>::LDS_DW * 4;
+    int total, spw, grid;
+    stream_geometry(l, cu_count(), total, spw, grid);
+    static bool attr = false;
+    if (!attr) {
+        allow_lds(wgrad32r_kernel<LO, 0>, LDS);
+        allow_lds(wgrad32r_kernel<LO, 1>, LDS);
+        allow_lds(wgrad32r_kernel<LO, 2>, LDS);
+        attr = true;
+    }
+    if (bias_mode == 1) ARVAE_LAUNCH((wgrad32r_kernel<LO, 1>), dim3(grid), dim3(512), LDS, s, lo, hi, slab, l->n, total, spw, amax_lo, amax_hi);
+    else if (bias_mode == 2) ARVAE_LAUNCH((wgrad32r_kernel<LO, 2>), dim3(grid), dim3(512), LDS, s, lo, hi, slab, l->n, total, spw, amax_lo, amax_hi);
+    else ARVAE_LAUNCH((wgrad32r_kernel<LO, 0>), dim3(grid), dim3(512), LDS, s, lo, hi, slab, l->n, total, spw, amax_lo, amax_hi);
+    return check_launch(LO == 16 ? "wgrad32_kernel<16>" : "wgrad32_kernel<8>");
+}
+static int conv32_wgrad_stream(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *slab, int bias_mode, const unsigned *amax_lo,
+                               const unsigned *amax_hi, hipStream_t s) {
+    return l->lh == 16 ? launch_stream<16>(l, lo.v, hi.v, slab, bias_mode, amax_lo, amax_hi, s)
+                       : launch_stream<8>(l, lo.v, hi.v, slab, bias_mode, amax_lo, amax_hi, s);
+}
 
 int conv32_wgrad_groups(const arvae_link_t *l) {
     if (conv32_wgrad_stream_fits(l)) return conv32_wgrad_stream_groups(l);
@@ -1213,26 +1302,87 @@ int conv32_wgrad_partial(const arvae_link_t *l, const Operand &lo, const Operand
     return rc;
 }
 
-// ---- 4x4 layers: gated data gradient + weight-gradient partials of one layer in one launch (pair4_*_kernel) ---------------
+// ---- gated data gradient + weight-gradient partials of one layer in ONE launch (pair4_*_kernel, pair_*_wgrad_kernel) ------------
 // up == true: the layer is a forward UP link (data gradient = DOWN map on g, weight gradient with g on the hi side, bias mode 2);
 // up == false: a forward DOWN link (data gradient = UP map, g on the lo side, bias mode 1).  Only the combinations the image
 // executor produces are instantiated; everything else (and the experiment switches) goes the two-launch way.
-bool conv32_pair4_fits(const arvae_link_t *l, bool up, const float *gate, const uint16_t *gate_bits, int bias_mode) {
-    static const bool off = getenv("ARVAE_NO_PAIR4") != nullptr || getenv("ARVAE_NO_SMALL_TILES") != nullptr;
-    if (off || l->lh != 4 || (gate == nullptr && gate_bits == nullptr) || bias_mode != (up ? 2 : 1)) return false;
-    const int wg_tiles = tiles_for<4, 64>(l->n), dg_tiles = tiles_for<4, 32>(l->n);
-    return wg_tiles >= 8 && wg_tiles + (dg_tiles + 1) / 2 <= cu_count() && conv32_wgrad_groups(l) == wg_tiles;
+static int pair_split_percent(int lh, bool up) {              // share of the workgroups that runs the data gradient
+    static const int e16 = getenv("ARVAE_PAIR_SPLIT16") ? atoi(getenv("ARVAE_PAIR_SPLIT16")) : 0;
+    static const int e8 = getenv("ARVAE_PAIR_SPLIT8") ? atoi(getenv("ARVAE_PAIR_SPLIT8")) : 0;
+    const int forced = lh == 16 ? e16 : e8;
+    if (forced > 0 && forced < 100) return forced;
+    return lh == 16 ? (up ? 48 : 50) : 50;             // (same-box sweeps at B = 512: flat within 1 % from 48 to 52)
+}
+bool conv32_pair_fits(const arvae_link_t *l, bool up, const float *gate, const uint16_t *gate_bits, int bias_mode) {
+    static const bool off4 = getenv("ARVAE_NO_PAIR4") != nullptr || getenv("ARVAE_NO_SMALL_TILES") != nullptr;
+    static const bool off = getenv("ARVAE_NO_PAIR32") != nullptr;
+    if ((gate == nullptr && gate_bits == nullptr) || bias_mode != (up ? 2 : 1)) return false;
+    if (l->lh == 4) {
+        const int wg_tiles = tiles_for<4, 64>(l->n), dg_tiles = tiles_for<4, 32>(l->n);
+        return !off4 && wg_tiles >= 8 && wg_tiles + (dg_tiles + 1) / 2 <= cu_count() && conv32_wgrad_groups(l) == wg_tiles;
+    }
+    // the larger layers: sign-bit gates only; both halves must keep several tiles / steps per workgroup; the 8x8 Up body is the
+    // 32-pixel-tile kernel (what launch_up_v picks at this batch)
+    if (off || gate_bits == nullptr || !conv32_wgrad_stream_fits(l)) return false;
+    if (l->n * (l->lh * l->lh / 32) < 4 * cu_count()) return false;
+    if (!up && l->lh == 8 && !(getenv("ARVAE_NO_SMALL_TILES") == nullptr && tiles_for<8, 128>(l->n) <= cu_count())) return false;
+    if (!up && l->lh == 16 && getenv("ARVAE_UP32_NO_PC") != nullptr) return false;
+    return true;
+}
+
+template <int LO> static int launch_pair_big(const arvae_link_t *l, bool up, const float *g, const float *x_in, const Ep32 &ep, float *slab,
+                                             const unsigned *amax_g, const unsigned *amax_x, hipStream_t s, int *grid_b_out) {
+    const int cus = cu_count() < AMAX_N / 4 ? cu_count() : AMAX_N / 4;
+    int grid_a = cus * pair_split_percent(LO, up) / 100;
+    if (grid_a < 1) grid_a = 1;
+    int total, spw, grid_b;
+    stream_geometry(l, cus - grid_a, total, spw, grid_b);
+    *grid_b_out = grid_b;
+    constexpr int LDS_W = RowStream<LO>::LDS_DW * 4;
+    const dim3 grid(grid_a + grid_b);
+    if (up) {                                                    // DOWN map of g (hi side); weight gradient: lo = layer input, hi = g
+        constexpr int LDS = MaxOf<LDS_W, DownK<LO>::LDS_DW * 4>::value;
+        static bool attr = false;
+        if (!attr) { allow_lds(pair_down_wgrad_kernel<LO, EP_GATE_B, 2>, LDS); attr = true; }
+        const int tiles = l->n * DownK<LO>::TILES_PER_IMG;
+        ARVAE_LAUNCH((pair_down_wgrad_kernel<LO, EP_GATE_B, 2>), grid, dim3(512), LDS, s, g, ep, l->n, tiles, grid_a, x_in, g, slab, total, spw,
+                     amax_x, amax_g);
+        return check_launch(LO == 16 ? "pair(down32<16> + wgrad32<16>)" : "pair(down32<8> + wgrad32<8>)");
+    }
+    if constexpr (LO == 16) {                                    // UP map of g (lo side); weight gradient: lo = g, hi = layer input
+        constexpr int LDS_U = (2 * 2 * PatchLoader<16, 1, 128>::PLANE_DW) * 4 + 4 * 4 * 4 * 64 * 16;
+        constexpr int LDS = MaxOf<LDS_W, LDS_U>::value;
+        static bool attr = false;
+        if (!attr) { allow_lds(pair_up16_wgrad_kernel<EP_GATE_B, 1>, LDS); attr = true; }
+        ARVAE_LAUNCH((pair_up16_wgrad_kernel<EP_GATE_B, 1>), grid, dim3(512), LDS, s, g, ep, l->n, tiles_for<16, 128>(l->n), grid_a, g, x_in, slab,
+                     total, spw, amax_g, amax_x);
+        return check_launch("pair(up32<16> + wgrad32<16>)");
+    } else {
+        constexpr int LDS = MaxOf<LDS_W, 2 * PatchLoader<8, 1, 32>::PLANE_DW * 4>::value;
+        static bool attr = false;
+        if (!attr) { allow_lds(pair_up8_wgrad_kernel<EP_GATE_B, 1>, LDS); attr = true; }
+        ARVAE_LAUNCH((pair_up8_wgrad_kernel<EP_GATE_B, 1>), grid, dim3(512), LDS, s, g, ep, l->n, tiles_for<8, 32>(l->n), grid_a, g, x_in, slab, total,
+                     spw, amax_g, amax_x);
+        return check_launch("pair(up32<8> + wgrad32<8>)");
+    }
 }
 
 // amax_g / amax_x: AMAX arrays of the incoming gradient and of the layer's input; amax_out: of d_in (may be null)
-int conv32_pair4(const arvae_link_t *l, bool up, const float *g, const float *x_in, const float *gate, const uint16_t *gate_bits,
-                 float *d_in, const float *wprep, float *dwt, float *dbias, float *slab, hipStream_t s, SlabJob *job,
-                 const unsigned *amax_g, const unsigned *amax_x, unsigned *amax_out) {
-    ARVAE_REQUIRE(wprep != nullptr && amax_g != nullptr && amax_x != nullptr, "conv32_pair4: prepared weights and the operands' maxima are needed");
+int conv32_pair(const arvae_link_t *l, bool up, const float *g, const float *x_in, const float *gate, const uint16_t *gate_bits,
+                float *d_in, const float *wprep, float *dwt, float *dbias, float *slab, hipStream_t s, SlabJob *job,
+                const unsigned *amax_g, const unsigned *amax_x, unsigned *amax_out) {
+    ARVAE_REQUIRE(wprep != nullptr && amax_g != nullptr && amax_x != nullptr, "conv32_pair: prepared weights and the operands' maxima are needed");
+    Ep32 ep{nullptr, gate_bits ? nullptr : gate, gate_bits, nullptr, d_in, reinterpret_cast<const uint4 *>(wprep), amax_g, amax_out};
+    if (l->lh != 4) {
+        int grid_b = 0;
+        const int rc = l->lh == 16 ? launch_pair_big<16>(l, up, g, x_in, ep, slab, amax_g, amax_x, s, &grid_b)
+                                   : launch_pair_big<8>(l, up, g, x_in, ep, slab, amax_g, amax_x, s, &grid_b);
+        *job = SlabJob{slab, dwt, dbias, grid_b, SLAB_C32, up ? 2 : 1};
+        return rc;
+    }
     constexpr int LDS_U = 2 * PatchLoader<4, 1, 32>::PLANE_DW * 4;
     constexpr int LDS = MaxOf<LDS_WGRAD_X4, MaxOf<LDS_DOWN_S, LDS_U>::value>::value;
     const int wg_tiles = tiles_for<4, 64>(l->n), dg_tiles = tiles_for<4, 32>(l->n), grid_a = (dg_tiles + 1) / 2;
-    Ep32 ep{nullptr, gate_bits ? nullptr : gate, gate_bits, nullptr, d_in, reinterpret_cast<const uint4 *>(wprep), amax_g, amax_out};
     static bool attr = false;
     if (!attr) {
         allow_lds(pair4_down_kernel<EP_GATE_F, 2>, LDS);
@@ -1265,5 +1415,15 @@ int conv32_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, fl
 #ifdef ARVAE_STAMPS
 extern "C" int arvae_debug_stamps(unsigned long long *out, int count) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(arvae::g_stamps), sizeof(unsigned long long) * count);
+}
+#endif
+#ifdef D32K_STAMPS
+extern "C" int arvae_debug_d32k_stamps(unsigned long long *out, int count) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(arvae::g_d32k_stamps), sizeof(unsigned long long) * count);
+}
+#endif
+#ifdef WGR_STAMPS
+extern "C" int arvae_debug_wgr_stamps(unsigned long long *out, int count) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(arvae::g_wgr_stamps), sizeof(unsigned long long) * count);
 }
 #endif

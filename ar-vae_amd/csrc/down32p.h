@@ -16,6 +16,7 @@
 //     split into two fp16 terms once and packed per pixel (PSB2), two LDS buffers: the producer waves write tile t+1's image
 //     while tile t is multiplied and keep the loads of tiles t+2, t+3 in flight.
 // Round 2's form of this kernel (every wave loader AND multiplier, 256 threads) is gone: see the comment at the kernel.
+#pragma once
 #include "common.h"
 #include "conv32_common.h"
 
@@ -25,9 +26,9 @@ namespace arvae {
 // diagnostic build only (tools/stamp_d32p.py): phase timeline of the first 32 workgroups, 100 MHz wall clock
 __device__ unsigned long long g_d32k_stamps[64 * 64];
 // down32p_kernel<16, *>: rows 0..31 = the consumers of workgroups 0..31 (thread 0), rows 32..63 = their producers (thread 256)
-#define PSTAMP(role, slot) do { if (LO == 16 && threadIdx.x == 256 * (role) && blockIdx.x < 32 && (slot) < 64) g_d32k_stamps[(blockIdx.x + 32 * (role)) * 64 + (slot)] = wall_clock64(); } while (0)
+#define DSTAMP(role, slot) do { if (LO == 16 && threadIdx.x == 256 * (role) && BID < 32 && (slot) < 64) g_d32k_stamps[(BID + 32 * (role)) * 64 + (slot)] = wall_clock64(); } while (0)
 #else
-#define PSTAMP(role, slot)
+#define DSTAMP(role, slot)
 #endif
 
 template <int LO> struct DownK {
@@ -52,22 +53,22 @@ template <int LO> struct DownK {
 // fetch tile t+1 .. t+3, scale and split (single-issue instructions: they co-issue beside the partner's MFMAs) and write
 // tile t+1's LDS image while tile t is multiplied.  (Round 3 measured this with six bf16 products per multiply-add: 1.9-2.1 us
 // per tile for 1.54 us of MFMA issue, the producers done after 1.4 us; with three fp16 products the MFMA issue is 0.77 us.)
+// (a body: the launch may carry another kernel's workgroups beside these -- BID / NBLK: this workgroup's index and their number)
 template <int LO, int MODE>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void down32p_kernel(const float *__restrict__ hi, Ep32 ep,
-                                                                                                 int n_img, int n_tiles) {
+__device__ __forceinline__ void down32p_body(const float *__restrict__ hi, Ep32 ep, int n_img, int n_tiles, const int BID, const int NBLK) {
     using K = DownK<LO>;
     constexpr int HW = K::HW, PIX = K::PIX, SLOTS = K::SLOTS, HI = 2 * LO;
-    extern __shared__ __attribute__((aligned(16))) unsigned lds[];
-    unsigned *xch = lds + 2 * K::BUF;
+    extern __shared__ __attribute__((aligned(16))) unsigned ldsd[];
+    unsigned *xch = ldsd + 2 * K::BUF;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int per_wg = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x, t_first = blockIdx.x * per_wg;
+    const int per_wg = (n_tiles + NBLK - 1) / NBLK, t_first = BID * per_wg;
     const int t_end = min(n_tiles, t_first + per_wg);
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
 
     if (wave >= 4) {
         // ============================================================================================ producers
-        PSTAMP(1, 0);
+        DSTAMP(1, 0);
         int pst = 0;
         (void)pst;
         const int pt = threadIdx.x - 256;
@@ -100,11 +101,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int s = 0; s < SLOTS; ++s) issue(S0{}, s, t_first);
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) issue(S1{}, s, t_first + 1);
-        if (pt < 2 * PSB2) lds[(pt / PSB2) * K::BUF + PIX * PSB2 + pt % PSB2] = 0u;   // the zero pixels
+        if (pt < 2 * PSB2) ldsd[(pt / PSB2) * K::BUF + PIX * PSB2 + pt % PSB2] = 0u;   // the zero pixels
         sc_in = amax_scale(al).s;
         __syncthreads();                                         // (the consumers' prologue barrier)
 #pragma unroll
-        for (int s = 0; s < SLOTS; ++s) commit(S0{}, s, lds);    // first tile -> buffer 0
+        for (int s = 0; s < SLOTS; ++s) commit(S0{}, s, ldsd);    // first tile -> buffer 0
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) issue(S0{}, s, t_first + 2);
         __syncthreads();
@@ -124,8 +125,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         auto do_tile = [&](auto set_, int tile, int cur) __attribute__((always_inline)) {
             constexpr int set = decltype(set_)::value;
             asm volatile("" : "+v"(q), "+v"(pix0));              // keep the slot addresses out of loop-invariant hoisting (spills)
-            PSTAMP(1, 4 + 5 * pst);
-            unsigned *nb = lds + (cur ^ 1) * K::BUF;
+            DSTAMP(1, 4 + 5 * pst);
+            unsigned *nb = ldsd + (cur ^ 1) * K::BUF;
             unsigned n_base, n_bad;
             {
                 const int nt = tile + 3;
@@ -140,11 +141,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 commit(set_, s, nb);
                 lv[set][s] = buf_load4(rs_hi, (n_bad & (1u << s)) != 0 ? OOB : n_base + 4096u * s);
             }
-            PSTAMP(1, 5 + 5 * pst);
+            DSTAMP(1, 5 + 5 * pst);
             __syncthreads();                                     // exchange area free
-            PSTAMP(1, 6 + 5 * pst);
+            DSTAMP(1, 6 + 5 * pst);
             __syncthreads();                                     // every read of `cur` is done, `cur ^ 1` is staged
-            PSTAMP(1, 7 + 5 * pst);
+            DSTAMP(1, 7 + 5 * pst);
             ++pst;
         };
         for (int tile = t_first; tile < t_end; tile += 2) {
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 
     // ================================================================================================ consumers (wave = kernel row)
-    PSTAMP(0, 0);
+    DSTAMP(0, 0);
     int cst = 0;
     (void)cst;
     const int half = lane >> 5, rc = lane & 31;
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float amax_run = 0.f;                                        // maximum magnitude of what this wave stores
     __syncthreads();                                             // zero pixels written
     __syncthreads();                                             // first tile staged
-    PSTAMP(0, 1);
+    DSTAMP(0, 1);
 
     // The epilogue of tile t (sum of the four kernel rows' partial tiles, bias, ReLU / gate, stores) is DEFERRED into the
     // reduction loop of tile t + 1, one small piece behind an MFMA at a time: between two tiles the matrix pipe then waits for
@@ -248,8 +249,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     };
     auto do_tile = [&](int tile, int cur) __attribute__((always_inline)) {
-        PSTAMP(0, 4 + 5 * cst);
-        const unsigned *xb = lds + cur * K::BUF;
+        DSTAMP(0, 4 + 5 * cst);
+        const unsigned *xb = ldsd + cur * K::BUF;
         // two accumulator sets per column tile: an MFMA that accumulates into the result of the one issued two slots earlier
         // waits for it (~44 cycles per MFMA measured with one set, 32 is the issue rate); the sets swap roles every step so
         // that four MFMAs always lie between two into the same registers
@@ -310,9 +311,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mt][i] += accb[mt][i];
-        PSTAMP(0, 5 + 5 * cst);
+        DSTAMP(0, 5 + 5 * cst);
         __syncthreads();                                         // the previous tile's exchange has been read by everybody
-        PSTAMP(0, 6 + 5 * cst);
+        DSTAMP(0, 6 + 5 * cst);
         float4 *xq = reinterpret_cast<float4 *>(xch);
         // acc registers 4 (2 G + e) + j of column tile M: owner (M, G) = wave M + 2 G
         auto piece = [&](auto m_, auto g_, int e) __attribute__((always_inline)) -> float4 {
@@ -339,8 +340,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         gb_prev = gb;
         if (MODE == EP_GATE_F) { gq_prev[0] = gq[0]; gq_prev[1] = gq[1]; }
         __syncthreads();                                         // partial sums written; every read of `cur` is done, `cur ^ 1` is staged
-        PSTAMP(0, 7 + 5 * cst);
-        PSTAMP(0, 8 + 5 * cst);
+        DSTAMP(0, 7 + 5 * cst);
+        DSTAMP(0, 8 + 5 * cst);
         ++cst;
     };
     for (int tile = t_first; tile < t_end; tile += 2) {
@@ -349,50 +350,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     load_parts();
     static_for<0, 9>(epi_item);                                  // the last tile's epilogue
-    amax_publish(ep.amax_out, blockIdx.x * 4 + wave, gridDim.x * 4, amax_run);
+    amax_publish(ep.amax_out, BID * 4 + wave, NBLK * 4, amax_run);
 }
-
-// ---- host side ---------------------------------------------------------------------------------------------------------
-static int cu_count_k() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
-}
-
-template <int LO, int MODE> static void launch_down_k(const float *hi, const Ep32 &ep, int n, hipStream_t s) {
-    constexpr int LDS = DownK<LO>::LDS_DW * 4;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void *)down32p_kernel<LO, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr = true;
-    }
-    const int tiles = n * DownK<LO>::TILES_PER_IMG, cus = cu_count_k() < AMAX_N / 4 ? cu_count_k() : AMAX_N / 4;
-    ARVAE_LAUNCH((down32p_kernel<LO, MODE>), dim3(tiles < cus ? tiles : cus), dim3(512), LDS, s, hi, ep, n, tiles);
-}
-
-template <int LO> static void launch_down_k_mode(const float *hi, const Ep32 &ep, int mode, int n, hipStream_t s) {
-    switch (mode) {
-        case EP_GATE_B: launch_down_k<LO, EP_GATE_B>(hi, ep, n, s); break;
-        case EP_GATE_F: launch_down_k<LO, EP_GATE_F>(hi, ep, n, s); break;
-        case EP_RELU: launch_down_k<LO, EP_RELU>(hi, ep, n, s); break;
-        default: launch_down_k<LO, EP_PLAIN>(hi, ep, n, s); break;
-    }
-}
-
-void conv32_down_ksplit(const arvae_link_t *l, const float *hi, const Ep32 &ep, int mode, hipStream_t s) {
-    if (l->lh == 16) launch_down_k_mode<16>(hi, ep, mode, l->n, s);
-    else launch_down_k_mode<8>(hi, ep, mode, l->n, s);
+template <int LO, int MODE>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void down32p_kernel(const float *__restrict__ hi, Ep32 ep,
+                                                                                                 int n_img, int n_tiles) {
+    down32p_body<LO, MODE>(hi, ep, n_img, n_tiles, blockIdx.x, gridDim.x);
 }
 
 }  // namespace arvae
-
-#ifdef D32K_STAMPS
-extern "C" int arvae_debug_d32k_stamps(unsigned long long *out, int count) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(arvae::g_d32k_stamps), sizeof(unsigned long long) * count);
-}
-#endif

@@ -38,8 +38,8 @@ int64_t conv32_prep_floats();
 int conv32_weight_prep(const float *const *wts, float *const *preps, int n_layers, hipStream_t s);
 int conv32_weight_prep_with_mid(const float *const *wts, float *const *preps, int n_layers, const MidPrepArgs &mid, hipStream_t s);
 void mid_prep_args(const arvae_image_vae_t *m, const float *params, float *prep_ws, MidPrepArgs *out);
-bool conv32_pair4_fits(const arvae_link_t *l, bool up, const float *gate, const uint16_t *gate_bits, int bias_mode);
-int conv32_pair4(const arvae_link_t *l, bool up, const float *g, const float *x_in, const float *gate, const uint16_t *gate_bits,
+bool conv32_pair_fits(const arvae_link_t *l, bool up, const float *gate, const uint16_t *gate_bits, int bias_mode);
+int conv32_pair(const arvae_link_t *l, bool up, const float *g, const float *x_in, const float *gate, const uint16_t *gate_bits,
                  float *d_in, const float *wprep, float *dwt, float *dbias, float *slab, hipStream_t s, SlabJob *job,
                  const unsigned *amax_g, const unsigned *amax_x, unsigned *amax_out);
 int conv32_wgrad_partial(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *dwt, float *dbias, int bias_mode,
@@ -320,14 +320,14 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
     hipStream_t whs = hs;                               // (a second stream for the weight gradients measured 1-9 % slower in
                                                         // rounds 1 and 2 -- the big kernels cannot share a CU -- and was removed)
     if (gated != nullptr) *gated = false;
-    // 4x4 32-channel layers: gated data gradient and weight-gradient partials in one launch (conv32.hip, pair4_*_kernel)
+    // 32-channel layers: gated data gradient and weight-gradient partials in one launch (conv32.hip, pair4_* / pair_*_wgrad_kernel)
     if (d_in != nullptr && gated != nullptr && rdefer != nullptr && own_slab != nullptr && gop.y == nullptr && g_scale == nullptr &&
         rdefer->count < SLAB_BATCH_MAX && c32 &&
-        conv32_pair4_fits(&lk, l.is_up != 0, gate, gate_bits, db ? (l.is_up ? 2 : 1) : 0)) {
+        conv32_pair_fits(&lk, l.is_up != 0, gate, gate_bits, db ? (l.is_up ? 2 : 1) : 0)) {
         SlabJob job;
         if (int rc = need_g()) return rc;
         if (int rc = need_in()) return rc;
-        if (int rc = conv32_pair4(&lk, l.is_up != 0, gop.v, in, gate, gate_bits, d_in, wprep, dw, db, own_slab, hs, &job, g_amax, in_amax,
+        if (int rc = conv32_pair(&lk, l.is_up != 0, gop.v, in, gate, gate_bits, d_in, wprep, dw, db, own_slab, hs, &job, g_amax, in_amax,
                                   din_amax))
             return rc;
         slab_reduce_defer(rdefer, job);

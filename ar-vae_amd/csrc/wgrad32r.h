@@ -17,6 +17,7 @@
 //     whose tap row falls outside their image instead (ky = 0 on an image's first lo row, ky = 3 on its last).
 // Same numerics as wgrad32x_kernel: scaled two-term fp16 operands (conv32_common.h), three partial products, smallest first,
 // fp32 accumulation, the inverse scales applied to the slab, per-workgroup slabs reduced in fixed order (reduce.hip).
+#pragma once
 #include "common.h"
 #include "conv32_common.h"
 #include "reduce.h"
@@ -43,9 +44,9 @@ template <int LO> struct RowStream {
 __device__ unsigned long long g_wgr_stamps[256 * 2 * 64 * 2];
 #define WGR_STAMP(role, slot)                                                                             \
     do {                                                                                                  \
-        if ((threadIdx.x & 255) == 0 && blockIdx.x < 256 && (slot) < 64) {                                \
-            g_wgr_stamps[((blockIdx.x * 2 + (role)) * 64 + (slot)) * 2] = __builtin_readcyclecounter();   \
-            g_wgr_stamps[((blockIdx.x * 2 + (role)) * 64 + (slot)) * 2 + 1] = wall_clock64();             \
+        if ((threadIdx.x & 255) == 0 && BID < 256 && (slot) < 64) {                                \
+            g_wgr_stamps[((BID * 2 + (role)) * 64 + (slot)) * 2] = __builtin_readcyclecounter();   \
+            g_wgr_stamps[((BID * 2 + (role)) * 64 + (slot)) * 2 + 1] = wall_clock64();             \
         }                                                                                                 \
     } while (0)
 #else
@@ -325,69 +326,4 @@ __global__ __launch_bounds__(512, 2) void wgrad32r_kernel(const float *__restric
     wgrad32r_body<LO, BIAS>(lo, hi, slab, n_img, total_steps, steps_per_wg, amax_lo, amax_hi, blockIdx.x);
 }
 
-// ------------------------------------------------------------------------------------------------
-// host side
-// ------------------------------------------------------------------------------------------------
-static int cu_count_r() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
-}
-
-bool conv32_wgrad_stream_fits(const arvae_link_t *l) {
-    static const bool off = getenv("ARVAE_WGRAD_NO_STREAM") != nullptr;     // diagnostic: the patch-staged wgrad32x_kernel instead
-    return !off && (l->lh == 16 || l->lh == 8);
-}
-
-static void stream_geometry(const arvae_link_t *l, int &total, int &spw, int &grid) {
-    total = l->n * (l->lh * l->lh / 32);
-    const int cus = cu_count_r();
-    spw = (total + cus - 1) / cus;
-    static const int forced = getenv("ARVAE_WGR_SPW") != nullptr ? atoi(getenv("ARVAE_WGR_SPW")) : 0;   // diagnostic: steps per workgroup
-    if (forced > 0) spw = forced;
-    if (spw < 1) spw = 1;
-    grid = (total + spw - 1) / spw;
-}
-
-int conv32_wgrad_stream_groups(const arvae_link_t *l) {
-    int total, spw, grid;
-    stream_geometry(l, total, spw, grid);
-    return grid;
-}
-
-template <int LO> static int launch_stream(const arvae_link_t *l, const float *lo, const float *hi, float *slab, int bias_mode,
-                                           const unsigned *amax_lo, const unsigned *amax_hi, hipStream_t s) {
-    constexpr int LDS = RowStream<LO>::LDS_DW * 4;
-    int total, spw, grid;
-    stream_geometry(l, total, spw, grid);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void *)wgrad32r_kernel<LO, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        (void)hipFuncSetAttribute((const void *)wgrad32r_kernel<LO, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        (void)hipFuncSetAttribute((const void *)wgrad32r_kernel<LO, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr = true;
-    }
-    if (bias_mode == 1) ARVAE_LAUNCH((wgrad32r_kernel<LO, 1>), dim3(grid), dim3(512), LDS, s, lo, hi, slab, l->n, total, spw, amax_lo, amax_hi);
-    else if (bias_mode == 2) ARVAE_LAUNCH((wgrad32r_kernel<LO, 2>), dim3(grid), dim3(512), LDS, s, lo, hi, slab, l->n, total, spw, amax_lo, amax_hi);
-    else ARVAE_LAUNCH((wgrad32r_kernel<LO, 0>), dim3(grid), dim3(512), LDS, s, lo, hi, slab, l->n, total, spw, amax_lo, amax_hi);
-    return check_launch(LO == 16 ? "wgrad32_kernel<16>" : "wgrad32_kernel<8>");
-}
-
-int conv32_wgrad_stream(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *slab, int bias_mode, const unsigned *amax_lo,
-                        const unsigned *amax_hi, hipStream_t s) {
-    return l->lh == 16 ? launch_stream<16>(l, lo.v, hi.v, slab, bias_mode, amax_lo, amax_hi, s)
-                       : launch_stream<8>(l, lo.v, hi.v, slab, bias_mode, amax_lo, amax_hi, s);
-}
-
 }  // namespace arvae
-
-#ifdef WGR_STAMPS
-extern "C" int arvae_debug_wgr_stamps(unsigned long long *out, int count) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(arvae::g_wgr_stamps), sizeof(unsigned long long) * count);
-}
-#endif

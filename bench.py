@@ -68,6 +68,10 @@ KERNEL_WORK = {
     # a layer's data gradient and weight gradient in one launch: the upstream gradient is read by both halves
     'pair4(down32 + wgrad32)': (2 * 262_144, 4 * (2 * 2048 + 2 * 512)), 'pair4(up32 + wgrad32)': (2 * 262_144, 4 * (2 * 512 + 2 * 2048)),
     'pair_c1(down_c1 + wgrad_c1)': (2 * 524_288, 4 * (2 * 4096 + 2 * 32768)),
+    # the same pair for the 16x16 / 8x8 layers: data gradient (gradient in, input gradient out) + weight gradient (gradient and
+    # saved input in)
+    'pair(down32<16> + wgrad32<16>)': (2 * 4_194_304, 4 * (2 * 32768 + 2 * 8192)), 'pair(up32<16> + wgrad32<16>)': (2 * 4_194_304, 4 * (2 * 8192 + 2 * 32768)),
+    'pair(down32<8> + wgrad32<8>)': (2 * 1_048_576, 4 * (2 * 8192 + 2 * 2048)), 'pair(up32<8> + wgrad32<8>)': (2 * 1_048_576, 4 * (2 * 2048 + 2 * 8192)),
     # the first encoder layer with the step's weight preparation riding in its grid; the decoder's first convolution with
     # the regulariser's workgroups riding in its grid
     'down_c1_kernel(+ weight prep)': (524_288, 4 * (4096 + 32768), 8_000_000), 'up32_kernel<4>(+ reg_loss)': (262_144, 4 * (512 + 2048)),
@@ -85,7 +89,7 @@ KERNEL_WORK = {
 # default build lists for it at B = 512 (profiles/*_kernel_stats.csv)
 ROCPROF_NAMES = {
     'wgrad32_kernel<16>': ['arvae::wgrad32r_kernel<16, 1>', 'arvae::wgrad32r_kernel<16, 2>'],
-    'up32_kernel<16>': ['arvae::up32x_kernel<16, 1, 128>', 'arvae::up32x_kernel<16, 3, 128>'],
+    'up32_kernel<16>': ['arvae::up32p_kernel<1>', 'arvae::up32p_kernel<3>'],
     'down32_kernel<16>': ['arvae::down32p_kernel<16, 1>', 'arvae::down32p_kernel<16, 3>'],
     'wgrad32_kernel<8>': ['arvae::wgrad32r_kernel<8, 1>', 'arvae::wgrad32r_kernel<8, 2>'],
     'up32_kernel<8>': ['arvae::up32x_kernel<8, 1, 32>', 'arvae::up32x_kernel<8, 3, 32>'],
@@ -95,6 +99,8 @@ ROCPROF_NAMES = {
     'down32_kernel<4>': ['arvae::down32s_kernel<4, 1>', 'arvae::down32s_kernel<4, 2>'],
     'pair4(down32 + wgrad32)': ['arvae::pair4_down_kernel<2, 2>'], 'pair4(up32 + wgrad32)': ['arvae::pair4_up_kernel<3, 1>'],
     'pair_c1(down_c1 + wgrad_c1)': ['arvae::pair_c1_kernel<1>'],
+    'pair(down32<16> + wgrad32<16>)': ['arvae::pair_down_wgrad_kernel<16, 3, 2>'], 'pair(down32<8> + wgrad32<8>)': ['arvae::pair_down_wgrad_kernel<8, 3, 2>'],
+    'pair(up32<16> + wgrad32<16>)': ['arvae::pair_up16_wgrad_kernel<3, 1>'], 'pair(up32<8> + wgrad32<8>)': ['arvae::pair_up8_wgrad_kernel<3, 1>'],
     'down_c1_kernel(+ weight prep)': ['arvae::down_c1s_prep_kernel'], 'up32_kernel<4>(+ reg_loss)': ['arvae::up32x_reg_kernel<1>'],
     'down_c1_kernel': ['arvae::down_c1s_kernel<0>', 'arvae::down_c1s_kernel<1>'], 'wgrad_c1_kernel': ['arvae::wgrad_c1s_kernel'],
     'up_c1_kernel(recon)': ['arvae::up_c1_kernel<0, true>'],

@@ -1,5 +1,5 @@
 #!/bin/bash
-# per-step timeline of wgrad32r (diagnostic library tools/bin/lib_wgrst.so: conv32r.hip built with -DWGR_STAMPS): [lo size] [batch]
+# per-step timeline of wgrad32r (diagnostic library tools/bin/lib_wgrst.so: conv32.hip built with -DWGR_STAMPS): [lo size] [batch]
 set -euo pipefail
 cd "$(dirname "$0")/.."
 test -f tools/bin/lib_wgrst.so || { echo "tools/bin/lib_wgrst.so is missing: build the diagnostic library first (tools/README.md)" >&2; exit 1; }

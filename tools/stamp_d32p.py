@@ -1,4 +1,4 @@
-"""Diagnostic (tools/build_diag.sh lib_d32pst conv32k.hip -DD32K_STAMPS; ARVAE_LIB=tools/bin/lib_d32pst.so): phase timeline of the
+"""Diagnostic (tools/build_diag.sh lib_d32pst conv32.hip -DD32K_STAMPS; ARVAE_LIB=tools/bin/lib_d32pst.so): phase timeline of the
 LAST down32p launch of a forward pass -- consumers (thread 0) and producers (thread 256) of workgroups 0..31."""
 import ctypes, sys, os
 import numpy as np

@@ -1,4 +1,4 @@
-"""Diagnostic (build conv32r.hip with ARVAE_HIPCC_FLAGS=-DWGR_STAMPS): per-step timeline of wgrad32r_kernel<16>."""
+"""Diagnostic (tools/build_diag.sh lib_wgrst conv32.hip -DWGR_STAMPS; ARVAE_LIB=tools/bin/lib_wgrst.so): per-step timeline of wgrad32r_kernel<16>."""
 import ctypes, sys, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
