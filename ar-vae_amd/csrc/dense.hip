@@ -12,6 +12,7 @@
 #include "common.h"
 #include "dense.h"
 #include "x3tile.h"
+#include "wgrad_c1s.h"
 
 namespace arvae {
 
@@ -648,6 +649,27 @@ __global__ __launch_bounds__(64 * NWB, 2) void dense_wgrad_batch_kernel(DenseWgr
     dense_wgrad_tile<NWB>(p, tile % tx, tile / tx, red);
 }
 
+// The grouped Linear weight gradients (latency-bound in L2, ~400 tiles of 14 us) beside the single-channel first layer's weight
+// gradient (wgrad_c1s.h: 256 workgroups streaming 75 MB from HBM, 17 us): the two close the backward pass and need nothing
+// from each other; both are 8-wave workgroups of ~100 registers, so a CU holds one of each.  Workgroups [0, grid_c1) run the
+// streaming body (dispatched first: it is the longer one), the rest one Linear tile each.
+__global__ __launch_bounds__(64 * NWB, 2) void dense_wgrad_c1_kernel(DenseWgradBatch b, Operand c1_lo, Operand c1_img, float *__restrict__ c1_slab,
+                                                                      int c1_rows, int grid_c1) {
+    __shared__ __attribute__((aligned(16))) float raw[WGS_WAVES * LO1 * WS1 + WGS_WAVES * 4 * IMS];
+    static_assert(WGS_WAVES == NWB && WGS_WAVES * LO1 * WS1 >= NWB * 16 * 64, "dense_wgrad_c1_kernel: one workgroup shape, one LDS block");
+    if ((int)blockIdx.x < grid_c1) {
+        wgrad_c1s_body(c1_lo, c1_img, c1_slab, c1_rows, blockIdx.x, grid_c1, raw, raw + WGS_WAVES * LO1 * WS1);
+        return;
+    }
+    const int bid = blockIdx.x - grid_c1;
+    int j = 0;
+    while (j + 1 < b.count && bid >= b.tile_end[j]) ++j;
+    const int tile = bid - (j > 0 ? b.tile_end[j - 1] : 0);
+    const DenseArgs &p = b.job[j];
+    const int tx = (p.n_out + 31) / 32;
+    dense_wgrad_tile<NWB>(p, tile % tx, tile / tx, raw);
+}
+
 bool dense_fits(const arvae_link_t *l) {
     return l->hh == 1 && l->hw == 1 && l->lh == 1 && l->lw == 1 && l->kh == 1 && l->kw == 1;
 }
@@ -782,6 +804,21 @@ int dense_wgrad_flush(DenseWgradBatch *b, hipStream_t s) {
     ARVAE_LAUNCH(dense_wgrad_batch_kernel, dim3(b->tile_end[b->count - 1]), dim3(64 * NWB), 0, s, *b);
     b->count = 0;
     return check_launch("dense_wgrad_batch_kernel");
+}
+
+// the queued Linear weight gradients and the single-channel layer's weight-gradient partials (conv_c1.hip) in one launch
+int wgrad_c1_groups(const arvae_link_t *l);
+bool dense_wgrad_c1_fits(const DenseWgradBatch *b) {
+    static const bool off = getenv("ARVAE_NO_PAIR_TAIL") != nullptr || getenv("ARVAE_DENSE_BATCH_SPLIT") != nullptr;
+    return !off && b != nullptr && b->count > 0;
+}
+int dense_wgrad_flush_with_c1(DenseWgradBatch *b, const arvae_link_t *l, const Operand &lo, const Operand &img, float *dwt, float *dbias,
+                              int bias_mode, float *slab, hipStream_t s, SlabJob *job) {
+    const int grid_c1 = wgrad_c1_groups(l);
+    ARVAE_LAUNCH(dense_wgrad_c1_kernel, dim3(grid_c1 + b->tile_end[b->count - 1]), dim3(64 * NWB), 0, s, *b, lo, img, slab, l->n * LO1, grid_c1);
+    b->count = 0;
+    *job = SlabJob{slab, dwt, dbias, grid_c1, SLAB_C1, bias_mode};
+    return check_launch("pair(wgrad_c1 + dense_wgrad_batch)");
 }
 
 }  // namespace arvae

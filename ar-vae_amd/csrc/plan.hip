@@ -50,6 +50,9 @@ int conv_c1_pair(const arvae_link_t *l, const Operand &g_img, const float *wt, c
                  unsigned *amax_out);
 int conv_c1_wgrad_partial(const arvae_link_t *l, const Operand &lo, const Operand &img, float *dwt, float *dbias,
                           int bias_mode, float *slab, hipStream_t s, SlabJob *job);
+bool dense_wgrad_c1_fits(const DenseWgradBatch *b);
+int dense_wgrad_flush_with_c1(DenseWgradBatch *b, const arvae_link_t *l, const Operand &lo, const Operand &img, float *dwt, float *dbias,
+                              int bias_mode, float *slab, hipStream_t s, SlabJob *job);
 int conv_c1_down(const arvae_link_t *l, const Operand &img, const float *wt, const float *bias, int relu,
                  const float *gate, const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s, unsigned *amax_out);
 int conv_c1_down_with_prep(const arvae_link_t *l, const Operand &img, const float *wt, const float *bias, int relu, uint16_t *bits_out,
@@ -404,9 +407,12 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
             if (int rc = need_g()) return rc;
             if (int rc = need_in()) return rc;
         }
+        // (the single-channel FIRST layer closes the pass: the Linear weight gradients queued so far ride in its launch, dense.hip)
         const int rc = conv32_fits(&lk) ? conv32_wgrad_partial(&lk, lo_op, hi_op, dw, db, bias_mode, own_slab, whs, &job,
                                                                l.is_up ? in_amax : g_amax, l.is_up ? g_amax : in_amax)
-                                        : conv_c1_wgrad_partial(&lk, lo_op, hi_op, dw, db, bias_mode, own_slab, whs, &job);
+                       : (d_in == nullptr && !l.is_up && dense_wgrad_c1_fits(defer))
+                           ? dense_wgrad_flush_with_c1(defer, &lk, lo_op, hi_op, dw, db, bias_mode, own_slab, whs, &job)
+                           : conv_c1_wgrad_partial(&lk, lo_op, hi_op, dw, db, bias_mode, own_slab, whs, &job);
         if (rc) return rc;
         slab_reduce_defer(rdefer, job);
         return ARVAE_OK;

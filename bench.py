@@ -68,6 +68,8 @@ KERNEL_WORK = {
     # a layer's data gradient and weight gradient in one launch: the upstream gradient is read by both halves
     'pair4(down32 + wgrad32)': (2 * 262_144, 4 * (2 * 2048 + 2 * 512)), 'pair4(up32 + wgrad32)': (2 * 262_144, 4 * (2 * 512 + 2 * 2048)),
     'pair_c1(down_c1 + wgrad_c1)': (2 * 524_288, 4 * (2 * 4096 + 2 * 32768)),
+    # the first layer's weight gradient with the grouped Linear weight gradients riding in its grid
+    'pair(wgrad_c1 + dense_wgrad_batch)': (524_288 + 400_896, 4 * (32768 + 4096) + 4 * 3102, 4 * 400_896),
     # the same pair for the 16x16 / 8x8 layers: data gradient (gradient in, input gradient out) + weight gradient (gradient and
     # saved input in)
     'pair(down32<16> + wgrad32<16>)': (2 * 4_194_304, 4 * (2 * 32768 + 2 * 8192)), 'pair(up32<16> + wgrad32<16>)': (2 * 4_194_304, 4 * (2 * 8192 + 2 * 32768)),
@@ -98,7 +100,7 @@ ROCPROF_NAMES = {
     'up32_kernel<4>': ['arvae::up32x_kernel<4, 1, 32>', 'arvae::up32x_kernel<4, 3, 32>'],
     'down32_kernel<4>': ['arvae::down32s_kernel<4, 1>', 'arvae::down32s_kernel<4, 2>'],
     'pair4(down32 + wgrad32)': ['arvae::pair4_down_kernel<2, 2>'], 'pair4(up32 + wgrad32)': ['arvae::pair4_up_kernel<3, 1>'],
-    'pair_c1(down_c1 + wgrad_c1)': ['arvae::pair_c1_kernel<1>'],
+    'pair_c1(down_c1 + wgrad_c1)': ['arvae::pair_c1_kernel<1>'], 'pair(wgrad_c1 + dense_wgrad_batch)': ['arvae::dense_wgrad_c1_kernel'],
     'pair(down32<16> + wgrad32<16>)': ['arvae::pair_down_wgrad_kernel<16, 3, 2>'], 'pair(down32<8> + wgrad32<8>)': ['arvae::pair_down_wgrad_kernel<8, 3, 2>'],
     'pair(up32<16> + wgrad32<16>)': ['arvae::pair_up16_wgrad_kernel<3, 1>'], 'pair(up32<8> + wgrad32<8>)': ['arvae::pair_up8_wgrad_kernel<3, 1>'],
     'down_c1_kernel(+ weight prep)': ['arvae::down_c1s_prep_kernel'], 'up32_kernel<4>(+ reg_loss)': ['arvae::up32x_reg_kernel<1>'],

@@ -8,4 +8,4 @@ for rep in 1 2 3; do
   echo "A (default)  $(python bench.py --no-cpu-baseline --no-secondary 2>/dev/null | q)"
   echo "B ($1)  $(env $1 python bench.py --no-cpu-baseline --no-secondary 2>/dev/null | q)"
 done > gpurun_out/ab_bench.txt 2>&1
-bash tools/trace_kernels.sh 32 > gpurun_out/ab_trace.txt 2>&1
+bash tools/trace_kernels.sh all > gpurun_out/ab_trace.txt 2>&1
