@@ -45,8 +45,11 @@ import torch  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
-# The 32-channel conv kernels run at fp32 accuracy on the bf16 MFMA: every operand is three bf16 terms and every
-# multiply-add six partial products (conv32.hip), so their MFMA work is 6x the algorithmic FLOP at the bf16 rate.
+# The 32-channel conv kernels (dSprites) run at fp32 accuracy on the fp16 MFMA: every operand is two scaled fp16 terms and every
+# multiply-add three partial products (conv32_common.h), so their MFMA work is 3x the algorithmic FLOP at the fp16 rate (the
+# same dense peak as bf16).  The wide conv / GRU / rows-GEMM kernels of the secondary workloads still run the three-term bf16
+# split: six partial products.
+F16X2_PRODUCTS = 3
 BF16X3_PRODUCTS = 6
 # algorithmic work per image per step, SURVEY.md section 8(d) (dSprites)
 FLOP_PER_IMAGE = 73_708_544
@@ -546,9 +549,9 @@ def run_dsprites(device, args, fence, rank, world, use_dp):
     # (every kernel of the step above 2 % of its device time has a KERNEL_WORK entry; `unaccounted_labels` lists the rest)
     dom_name, dom = max(((k, v) for k, v in prof.items() if v['bytes'] > 0), key=lambda kv: kv[1]['ms'])
     avg_ms = dom['ms'] / dom['calls']
-    split = dom_name.startswith(('down32', 'up32', 'wgrad32', 'pair4'))
+    split = dom_name.startswith(('down32', 'up32', 'wgrad32', 'pair4', 'pair(down32', 'pair(up32'))
     mfma_peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
-    mfma_work = dom['flop'] * (BF16X3_PRODUCTS if split else 1)
+    mfma_work = dom['flop'] * (F16X2_PRODUCTS if split else 1)
     mfma_tf = mfma_work / dom['calls'] / (avg_ms * 1e-3) / 1e12
     hbm_gbs = dom['bytes'] / dom['calls'] / (avg_ms * 1e-3) / 1e9
     # the roof this kernel sits closer to binds it
@@ -556,8 +559,8 @@ def run_dsprites(device, args, fence, rank, world, use_dp):
         roof = {'bound': 'mfma', 'achieved': mfma_tf, 'peak': mfma_peak, 'unit': 'TFLOP/s', 'frac': mfma_tf / mfma_peak,
                 'traffic': None}
         if split:
-            roof['mfma_work'] = 'executed bf16 MFMA FLOP = 6 partial products x algorithmic FLOP (fp32-accurate split)'
-            roof['fp32_equivalent_tflops'] = mfma_tf / BF16X3_PRODUCTS
+            roof['mfma_work'] = 'executed fp16 MFMA FLOP = 3 partial products x algorithmic FLOP (scaled two-term split, fp32-accurate)'
+            roof['fp32_equivalent_tflops'] = mfma_tf / F16X2_PRODUCTS
     else:
         roof = {'bound': 'hbm', 'achieved': hbm_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': hbm_gbs / PEAK_HBM_GBS,
                 'traffic': None}
@@ -605,7 +608,7 @@ def run_dsprites(device, args, fence, rank, world, use_dp):
         'metric': 'training images/sec (dSprites beta-VAE+AR, per-GPU batch 512)', 'value': value,
         'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32 (conv MFMAs: 3-term bf16 split, 6 products, fp32-accurate)',
+        'dtype': 'f32 (conv MFMAs: scaled 2-term fp16 split, 3 products, fp32-accurate)',
         'data': 'synthetic',
         'config': {'workload': 'dSprites AR-VAE full training step (fwd + bwd + Adam), 1x64x64 inputs, z=10, '
                                'reg_dim=(1,2,3,4,5), beta=4 gamma=10 delta=1',
@@ -619,7 +622,7 @@ def run_dsprites(device, args, fence, rank, world, use_dp):
             'flop_frac_fp32': per_gpu * FLOP_PER_IMAGE / (PEAK_F32_MFMA_TFLOPS * 1e12),
             'hbm_frac': per_gpu * (BYTES_PER_IMAGE + PARAM_BYTES_PER_STEP / b) / (PEAK_HBM_GBS * 1e9),
             'binding': 'HBM roof 4.2 M img/s; fp32-MFMA roof 2.13 M img/s (no longer binding: the conv layers run on '
-                       'the bf16 MFMA at 6 products per multiply-add, a 5.6 M img/s roof)'},
+                       'the fp16 MFMA at 3 products per multiply-add, an 11 M img/s roof)'},
     }
     if args.breakdown:
         tot = sum(v['ms'] for v in prof.values())

@@ -488,25 +488,22 @@ def test_full_batch_properties(dev):
     close(g3, 3.0 * g1, rtol=2e-5, atol=1e-6 * float(g1.abs().max()))
 
 
-def test_bf16_three_term_kernels_hold_fp32_accuracy_vs_float64(dev):
-    """The 32-channel conv kernels run the bf16 MFMA on three-term splits (six partial products, fp32 accumulation): against a
-    float64 reference of the same three maps (forward Conv2d, forward ConvTranspose2d, weight / bias gradient) their
-    relative L2 error stays below 5e-7, i.e. fp32 rounding noise -- the level the removed fp32-MFMA generation of these
-    kernels measured (<= 2x apart on every map while both existed, rounds 1-2)."""
+def _conv32_maps(dev, hi_np, lo_np, w_np, b_np):
+    """the three maps of a 32-channel k4 s2 p1 link through the per-layer C-ABI (weights split and maxima taken in the caller's
+    workspace): forward Conv2d of hi, forward ConvTranspose2d of lo, weight / bias gradient of the Conv2d for upstream `lo`"""
     from arvae_amd import ops
-    rs = np.random.RandomState(11)
-    n = 24
-    hi_np = rs.standard_normal((n, 32, 32, 32)).astype(np.float32)
-    lo_np = rs.standard_normal((n, 16, 16, 32)).astype(np.float32)
-    w_np = (rs.standard_normal((32, 32, 4, 4)) * 0.1).astype(np.float32)
-    b_np = rs.standard_normal(32).astype(np.float32)
+    n, size = hi_np.shape[0], lo_np.shape[1]
     hi_d, lo_d, w_d, b_d = (torch.from_numpy(a).to(dev) for a in (hi_np, lo_np, w_np, b_np))
-    link = ops.Link(32, 32, 32, 16, 16, 32, 4, 4, 2, 1)
+    link = ops.Link(2 * size, 2 * size, 32, size, size, 32, 4, 4, 2, 1)
     got = {'down': ops.link_down(link, n, ops._operand(hi_d), w_d, b_d, ops.ACT_NONE, None),
            'up': ops.link_up(link, n, ops._operand(lo_d), w_d, b_d, ops.ACT_NONE, None)}
     dw, db = torch.zeros_like(w_d), torch.zeros_like(b_d)
     ops.link_wgrad(link, n, ops._operand(lo_d), ops._operand(hi_d), dw, db, 1)
     got.update(dw=dw, db=db)
+    return {k: v.cpu().numpy() for k, v in got.items()}
+
+
+def _conv32_maps_float64(hi_np, lo_np, w_np, b_np):
     hi = torch.from_numpy(hi_np).double().permute(0, 3, 1, 2)
     lo = torch.from_numpy(lo_np).double().permute(0, 3, 1, 2)
     w = torch.from_numpy(w_np).double().requires_grad_(True)
@@ -514,11 +511,58 @@ def test_bf16_three_term_kernels_hold_fp32_accuracy_vs_float64(dev):
     down = F.conv2d(hi, w, b, stride=2, padding=1)
     up = F.conv_transpose2d(lo, w, b, stride=2, padding=1)
     down.backward(lo)                                    # dW, db of the Conv2d for the upstream gradient `lo`
-    ref = {'down': down.detach().permute(0, 2, 3, 1).numpy(), 'up': up.detach().permute(0, 2, 3, 1).numpy(),
-           'dw': w.grad.numpy(), 'db': b.grad.numpy()}
+    return {'down': down.detach().permute(0, 2, 3, 1).numpy(), 'up': up.detach().permute(0, 2, 3, 1).numpy(),
+            'dw': w.grad.numpy(), 'db': b.grad.numpy()}
+
+
+@pytest.mark.parametrize('size', [16, 8, 4])
+def test_scaled_two_term_fp16_kernels_hold_fp32_accuracy_vs_float64(dev, size):
+    """The 32-channel conv kernels run the fp16 MFMA on scaled two-term operands (three partial products, fp32 accumulation;
+    conv32_common.h): against a float64 reference of the same three maps their relative L2 error stays below 5e-7, i.e. fp32
+    rounding noise -- the bar the three-term bf16 generation (rounds 1-3) and the fp32-MFMA generation before it were held to."""
+    rs = np.random.RandomState(11)
+    n = 24 if size == 16 else 64
+    hi_np = rs.standard_normal((n, 2 * size, 2 * size, 32)).astype(np.float32)
+    lo_np = rs.standard_normal((n, size, size, 32)).astype(np.float32)
+    w_np = (rs.standard_normal((32, 32, 4, 4)) * 0.1).astype(np.float32)
+    b_np = rs.standard_normal(32).astype(np.float32)
+    got, ref = _conv32_maps(dev, hi_np, lo_np, w_np, b_np), _conv32_maps_float64(hi_np, lo_np, w_np, b_np)
     for k in ('down', 'up', 'dw', 'db'):
-        err = np.linalg.norm(got[k].cpu().numpy().astype(np.float64) - ref[k]) / np.linalg.norm(ref[k])
+        err = np.linalg.norm(got[k].astype(np.float64) - ref[k]) / np.linalg.norm(ref[k])
         assert err < 5e-7, (k, err)
+
+
+def test_conv32_scaling_is_exact_and_survives_outliers(dev):
+    """What the per-tensor power-of-two scales must guarantee.  (1) Results do not depend on the magnitude of the operands:
+    a tensor times 2^k gives bit for bit the result times 2^k (gradients of 1e-7 are as good as activations of 1e+3).
+    (2) A tensor whose maximum sits far above its bulk (one value 10^4 times the rest: the low terms of the bulk then fall
+    into the fp16 subnormal range, absolute error <= 2^-40 of the maximum) still meets the float64 bar relative to the result's
+    norm, and the outputs the outlier does not reach keep an error of a few 1e-7 relative to their own norm."""
+    rs = np.random.RandomState(5)
+    n, size = 16, 16
+    hi_np = np.maximum(rs.standard_normal((n, 32, 32, 32)), 0).astype(np.float32)      # ReLU-like: half zeros
+    lo_np = rs.standard_normal((n, 16, 16, 32)).astype(np.float32)
+    w_np = (rs.standard_normal((32, 32, 4, 4)) * 0.1).astype(np.float32)
+    b0 = np.zeros(32, np.float32)
+    base = _conv32_maps(dev, hi_np, lo_np, w_np, b0)
+    for k_hi, k_lo, k_w in ((-23, 0, 0), (9, -30, 0), (0, 0, -7), (-12, 14, 5)):
+        s_hi, s_lo, s_w = np.float32(2.0 ** k_hi), np.float32(2.0 ** k_lo), np.float32(2.0 ** k_w)
+        got = _conv32_maps(dev, hi_np * s_hi, lo_np * s_lo, w_np * s_w, b0)
+        np.testing.assert_array_equal(got['down'], base['down'] * (s_hi * s_w))
+        np.testing.assert_array_equal(got['up'], base['up'] * (s_lo * s_w))
+        np.testing.assert_array_equal(got['dw'], base['dw'] * (s_hi * s_lo))
+    hi_out, lo_out = hi_np.copy(), lo_np.copy()
+    hi_out[3, 7, 9, 11] = 1.0e4 * np.abs(hi_np).max()
+    lo_out[5, 2, 3, 4] = -1.0e4 * np.abs(lo_np).max()
+    got, ref = _conv32_maps(dev, hi_out, lo_out, w_np, b0), _conv32_maps_float64(hi_out, lo_out, w_np, b0)
+    for k in ('down', 'up', 'dw', 'db'):
+        err = np.linalg.norm(got[k].astype(np.float64) - ref[k]) / np.linalg.norm(ref[k])
+        assert err < 5e-7, (k, err)
+    # and what the outlier does NOT touch keeps its accuracy: output pixels away from it, against float64, relative to THEIR norm
+    far = np.ones(got['down'].shape[:3], bool)
+    far[3, 2:6, 3:7] = False
+    err = np.linalg.norm(got['down'][far].astype(np.float64) - ref['down'][far]) / np.linalg.norm(ref['down'][far])
+    assert err < 5e-6, err
 
 
 # ---------------------------------------------------------------- MeasureVAE (G6 / G7)

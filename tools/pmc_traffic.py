@@ -14,9 +14,20 @@ import sys
 def label(kernel_name):
     """rocprofv3 kernel name -> the label bench.py / arvae_profile_end use for that kernel family."""
     n = kernel_name.replace('void ', '').split('(')[0].replace('arvae::', '')
-    m = re.match(r'(down32|up32|wgrad32)[xbsrk]?_kernel<(\d+),', n)       # fp32 / split-bf16 / small-tile variants share a label
+    m = re.match(r'(down32|up32|wgrad32)[xsrp]?_kernel<(\d+),', n)        # the variants of a map share a label
     if m:
         return f'{m.group(1)}_kernel<{m.group(2)}>'
+    if n.startswith('up32p_kernel'):
+        return 'up32_kernel<16>'
+    m = re.match(r'pair_down_wgrad_kernel<(\d+),', n)
+    if m:
+        return f'pair(down32<{m.group(1)}> + wgrad32<{m.group(1)}>)'
+    if n.startswith('pair_up16_wgrad_kernel'):
+        return 'pair(up32<16> + wgrad32<16>)'
+    if n.startswith('pair_up8_wgrad_kernel'):
+        return 'pair(up32<8> + wgrad32<8>)'
+    if n.startswith('dense_wgrad_c1_kernel'):
+        return 'pair(wgrad_c1 + dense_wgrad_batch)'
     if n.startswith(('down_c1s_kernel', 'wgrad_c1s_kernel')):           # streaming forms: same label as the tiled kernels
         return n.split('<')[0].replace('c1s', 'c1')
     if n.startswith('down_c1s_prep_kernel'):
