@@ -11,6 +11,7 @@
 // are the reduction axis), sliced over pixels into a workspace and summed in fixed order.
 #include "common.h"
 #include "x3tile.h"
+#include "conv32_common.h"
 
 namespace arvae {
 
@@ -175,7 +176,8 @@ __global__ __launch_bounds__(256) void conv64_weight_prep_kernel(const float *__
 int64_t conv64s_ws_floats();
 bool conv64s_fits(const arvae_link_t *l, bool up);
 int conv64s_run(const Operand &src, int n, int sh, int sw, int oh, int ow, int q, int sgn, int off, const float *wt, bool transposed,
-                const float *bias, int act, const uint8_t *mask, float *out, float *ws, hipStream_t s, const char *what, const GateOp *gate);
+                const float *bias, int act, const uint8_t *mask, float *out, float *ws, hipStream_t s, const char *what, const GateOp *gate,
+                const unsigned *amax_in, unsigned *amax_out);
 
 int64_t conv64_ws_floats(const arvae_link_t *l) {
     const int64_t packed = ((int64_t)l->kh * l->kw * l->chi * l->clo + 3) / 4 * 4;
@@ -214,11 +216,11 @@ static int launch_conv_rows(ConvRows g, const float *wt, bool transposed, float 
 
 // lo[n][lh][lw][clo] = act(conv(hi) + bias) * mask     (Conv2d forward / ConvTranspose2d data gradient)
 int conv64_down(const arvae_link_t *l, const Operand &hi, const float *wt, const float *bias, int act, const uint8_t *mask,
-                float *lo, float *ws, hipStream_t s, const GateOp *gate) {
+                float *lo, float *ws, hipStream_t s, const GateOp *gate, const unsigned *amax_in, unsigned *amax_out) {
     // timeline labels tell the 64 -> 64 launches from the ones with a narrow side (64 -> 8): different kernels, 3x apart
     const char *what = (l->chi >= 64 && l->clo >= 64) ? "conv64_down(wide)" : "conv64_down(narrow)";
     if (conv64s_fits(l, false))
-        return conv64s_run(hi, l->n, l->hh, l->hw, l->lh, l->lw, l->clo, 1, -l->pad, wt, false, bias, act, mask, lo, ws, s, what, gate);
+        return conv64s_run(hi, l->n, l->hh, l->hw, l->lh, l->lw, l->clo, 1, -l->pad, wt, false, bias, act, mask, lo, ws, s, what, gate, amax_in, amax_out);
     ConvRows g{};
     if (gate != nullptr) g.gate = *gate;
     g.src = hi; g.n = l->n; g.sh = l->hh; g.sw = l->hw; g.cs = l->chi;
@@ -230,10 +232,10 @@ int conv64_down(const arvae_link_t *l, const Operand &hi, const float *wt, const
 
 // hi[n][hh][hw][chi] = act(convT(lo) + bias) * mask    (ConvTranspose2d forward / Conv2d data gradient)
 int conv64_up(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, int act, const uint8_t *mask,
-              float *hi, float *ws, hipStream_t s, const GateOp *gate) {
+              float *hi, float *ws, hipStream_t s, const GateOp *gate, const unsigned *amax_in, unsigned *amax_out) {
     const char *what = (l->chi >= 64 && l->clo >= 64) ? "conv64_up(wide)" : "conv64_up(narrow)";
     if (conv64s_fits(l, true))
-        return conv64s_run(lo, l->n, l->lh, l->lw, l->hh, l->hw, l->chi, -1, l->pad, wt, true, bias, act, mask, hi, ws, s, what, gate);
+        return conv64s_run(lo, l->n, l->lh, l->lw, l->hh, l->hw, l->chi, -1, l->pad, wt, true, bias, act, mask, hi, ws, s, what, gate, amax_in, amax_out);
     ConvRows g{};
     if (gate != nullptr) g.gate = *gate;
     g.src = lo; g.n = l->n; g.sh = l->lh; g.sw = l->lw; g.cs = l->clo;
@@ -505,11 +507,27 @@ __device__ __forceinline__ rg_bf16x8 wp_tr_operand(const unsigned short *p0, con
     return __builtin_bit_cast(rg_bf16x8, (s16x8)__builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
+// (on the fp16 MFMA with scaled two-term operands, conv32_common.h: three partial products, the operands' maxima in AMAX
+// arrays; 339 / 217 us per launch with six bf16 products through round 3)
+__device__ __forceinline__ void wp_commit_h2(unsigned short *d, int plane, const float4 &v, float sc) {
+    unsigned h0, l0, h1, l1;
+    split_pair_h2(v.x, v.y, sc, h0, l0);
+    split_pair_h2(v.z, v.w, sc, h1, l1);
+    *reinterpret_cast<uint2 *>(d) = uint2{h0, h1};
+    *reinterpret_cast<uint2 *>(d + plane) = uint2{l0, l1};
+}
+// acc += A . B for one 16-deep k-step: (l, h), (h, l), (h, h)
+#define H2_MFMA3(ACC, AH, AL, BH, BL)                                              \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL, BH, ACC, 0, 0, 0);            \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, BL, ACC, 0, 0, 0);            \
+    ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, BH, ACC, 0, 0, 0)
+
 template <bool PLAIN_LO, bool PLAIN_HI>
-__global__ __launch_bounds__(256) void conv_wgrad_pairs_x3_kernel(ConvWgrad g, int img_per_wg) {
+__global__ __launch_bounds__(256) void conv_wgrad_pairs_h2_kernel(ConvWgrad g, int img_per_wg, const unsigned *amax_lo, const unsigned *amax_hi) {
     extern __shared__ __attribute__((aligned(16))) unsigned short wp_lds[];
-    unsigned short *lo_img = wp_lds;                            // [2][3][WP_SLOTS][RG_TRP]
-    unsigned short *hi_ring = wp_lds + 2 * 3 * WP_APLANE;       // [WP_RING][3][WR_HROWS][WP_HTRP]
+    unsigned short *lo_img = wp_lds;                            // [2][2][WP_SLOTS][RG_TRP]
+    unsigned short *hi_ring = wp_lds + 2 * 2 * WP_APLANE;       // [WP_RING][2][WR_HROWS][WP_HTRP]
+    const AmaxLoad al_l = amax_issue(amax_lo), al_h = amax_issue(amax_hi);
     const int lane = threadIdx.x & 63, half = lane >> 5, rc = lane & 31;
     const int ky = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ch0 = 32 * blockIdx.x;                            // this workgroup's chi half
@@ -518,7 +536,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_pairs_x3_kernel(ConvWgrad g, i
     const int pairs = (g.lh + 1) >> 1;
 
     // zero both lo pair images once: slots >= 2 lw are never written again
-    for (int i = threadIdx.x; i < 2 * 3 * WP_APLANE / 2; i += 256) reinterpret_cast<unsigned *>(lo_img)[i] = 0u;
+    for (int i = threadIdx.x; i < 2 * 2 * WP_APLANE / 2; i += 256) reinterpret_cast<unsigned *>(lo_img)[i] = 0u;
+    const Pow2 sc_l = amax_scale(al_l), sc_h = amax_scale(al_h);
 
     // gather slots.  lo row: pixel idx / 16, channels 4 (idx % 16); hi row: pixel row idx / 8, channels ch0 + 4 (idx % 8)
     const int lo_r[2] = {(int)threadIdx.x / 16, (int)threadIdx.x / 16 + 16};
@@ -545,14 +564,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_pairs_x3_kernel(ConvWgrad g, i
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             if (lo_r[i] < g.lw)
-                wr_commit(lo_img + buf * 3 * WP_APLANE + (which * g.lw + lo_r[i]) * RG_TRP + lo_c, WP_APLANE, vlo[which][i]);
+                wp_commit_h2(lo_img + buf * 2 * WP_APLANE + (which * g.lw + lo_r[i]) * RG_TRP + lo_c, WP_APLANE, vlo[which][i], sc_l.s);
     };
-    auto ring_of = [&](int hy) { return hi_ring + ((hy + 4 * WP_RING) & (WP_RING - 1)) * 3 * WP_HPLANE; };
+    auto ring_of = [&](int hy) { return hi_ring + ((hy + 4 * WP_RING) & (WP_RING - 1)) * 2 * WP_HPLANE; };
     auto commit_hi = [&](int which, int hy) __attribute__((always_inline)) {
         unsigned short *img = ring_of(hy);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            if (hi_r[i] < WR_HROWS) wr_commit(img + hi_r[i] * WP_HTRP + hi_c, WP_HPLANE, vhi[which][i]);
+            if (hi_r[i] < WR_HROWS) wp_commit_h2(img + hi_r[i] * WP_HTRP + hi_c, WP_HPLANE, vhi[which][i], sc_h.s);
     };
 
     f32x16c acc[2][4];
@@ -613,26 +632,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_pairs_x3_kernel(ConvWgrad g, i
                 fetch_hi(1, n, ly + 2 - g.pad + 4);
             }
             if (ky < g.kh) {
-                const unsigned short *ab = lo_img + (pi & 1) * 3 * WP_APLANE + a_base;
+                const unsigned short *ab = lo_img + (pi & 1) * 2 * WP_APLANE + a_base;
                 const unsigned short *hbA = ring_of(ly - g.pad + ky), *hbB = ring_of(ly + 1 - g.pad + ky);
 #pragma unroll
                 for (int s = 0; s < 3; ++s) {
-                    rg_bf16x8 a3[2][3];
+                    f16x8 a2[2][2];
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) {
+                    for (int t = 0; t < 2; ++t) {
                         const unsigned short *ap = ab + t * WP_APLANE + 16 * s * RG_TRP;
-                        a3[0][t] = wp_tr_operand(ap, ap + 4 * RG_TRP);
-                        a3[1][t] = wp_tr_operand(ap + 32, ap + 32 + 4 * RG_TRP);
+                        a2[0][t] = __builtin_bit_cast(f16x8, wp_tr_operand(ap, ap + 4 * RG_TRP));
+                        a2[1][t] = __builtin_bit_cast(f16x8, wp_tr_operand(ap + 32, ap + 32 + 4 * RG_TRP));
                     }
                     const unsigned short *h0 = ((h_sel >> (2 * s)) & 1u) ? hbB : hbA, *h1 = ((h_sel >> (2 * s + 1)) & 1u) ? hbB : hbA;
 #pragma unroll
                     for (int kx = 0; kx < 4; ++kx) {
-                        rg_bf16x8 b3[3];
+                        f16x8 b2[2];
 #pragma unroll
-                        for (int t = 0; t < 3; ++t)
-                            b3[t] = wp_tr_operand(h0 + t * WP_HPLANE + h_off[s][0] + kx * WP_HTRP, h1 + t * WP_HPLANE + h_off[s][1] + kx * WP_HTRP);
-                        X3_MFMA6(acc[0][kx], a3[0][0], a3[0][1], a3[0][2], b3[0], b3[1], b3[2]);
-                        if (na > 1) { X3_MFMA6(acc[1][kx], a3[1][0], a3[1][1], a3[1][2], b3[0], b3[1], b3[2]); }
+                        for (int t = 0; t < 2; ++t)
+                            b2[t] = __builtin_bit_cast(f16x8, wp_tr_operand(h0 + t * WP_HPLANE + h_off[s][0] + kx * WP_HTRP, h1 + t * WP_HPLANE + h_off[s][1] + kx * WP_HTRP));
+                        H2_MFMA3(acc[0][kx], a2[0][0], a2[0][1], b2[0], b2[1]);
+                        if (na > 1) { H2_MFMA3(acc[1][kx], a2[1][0], a2[1][1], b2[0], b2[1]); }
                     }
                 }
             }
@@ -640,6 +659,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_pairs_x3_kernel(ConvWgrad g, i
     }
     if (ky < g.kh) {
         const int q = ch0 + rc;
+        const float inv = sc_l.inv * sc_h.inv;                  // accumulators -> fp32 partial sums (exact)
 #pragma unroll
         for (int kx = 0; kx < 4; ++kx) {
             if (kx >= g.kw) break;
@@ -649,7 +669,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_pairs_x3_kernel(ConvWgrad g, i
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int p = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (p < g.clo && q < g.chi) out[p * g.chi + q] = acc[a][kx][r];
+                    if (p < g.clo && q < g.chi) out[p * g.chi + q] = acc[a][kx][r] * inv;
                 }
         }
     }
@@ -679,10 +699,13 @@ int64_t conv64_wgrad_ws_floats(const arvae_link_t *l) {
     const int64_t per = (int64_t)l->kh * l->kw * l->clo * l->chi;
     const int64_t taps_kernel = ((M + C64_WG_SLICE - 1) / C64_WG_SLICE) * per;
     const int64_t rows_kernel = ((l->n + wr_img_per_wg(l) - 1) / wr_img_per_wg(l)) * per;
-    return taps_kernel > rows_kernel ? taps_kernel : rows_kernel;
+    return (taps_kernel > rows_kernel ? taps_kernel : rows_kernel) + 2 * AMAX_N;     // + the two operands' AMAX arrays (pairs kernel)
 }
 
-int conv64_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *dwt, float *ws, hipStream_t s) {
+int conv64_operand_amax(const Operand &x, int64_t count, unsigned *out, hipStream_t s);      // conv64s.hip
+
+int conv64_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *dwt, float *ws, hipStream_t s,
+                 const unsigned *amax_lo, const unsigned *amax_hi) {
     ConvWgrad g{};
     g.lo = lo; g.hi = hi; g.n = l->n; g.lh = l->lh; g.lw = l->lw; g.clo = l->clo; g.hh = l->hh; g.hw = l->hw; g.chi = l->chi;
     g.kh = l->kh; g.kw = l->kw; g.pad = l->pad; g.ws = ws;
@@ -694,19 +717,29 @@ int conv64_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, fl
     if (conv64_wgrad_rows_fits(l) && !no_pairs && l->lw <= 24 && l->kh == 4) {
         const int ipw = wr_img_per_wg(l), slices = (l->n + ipw - 1) / ipw;
         const dim3 grid((l->chi + 31) / 32, slices);
-        const size_t lds = (2 * 3 * WP_APLANE + WP_RING * 3 * WP_HPLANE) * sizeof(unsigned short);
+        const size_t lds = (2 * 2 * WP_APLANE + WP_RING * 2 * WP_HPLANE) * sizeof(unsigned short);
         static bool attr = false;
         if (!attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_pairs_x3_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_pairs_x3_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_pairs_x3_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_pairs_x3_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_pairs_h2_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_pairs_h2_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_pairs_h2_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_pairs_h2_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr = true;
         }
-        if (pl && ph) ARVAE_LAUNCH((conv_wgrad_pairs_x3_kernel<true, true>), grid, dim3(256), lds, s, g, ipw);
-        else if (pl) ARVAE_LAUNCH((conv_wgrad_pairs_x3_kernel<true, false>), grid, dim3(256), lds, s, g, ipw);
-        else if (ph) ARVAE_LAUNCH((conv_wgrad_pairs_x3_kernel<false, true>), grid, dim3(256), lds, s, g, ipw);
-        else ARVAE_LAUNCH((conv_wgrad_pairs_x3_kernel<false, false>), grid, dim3(256), lds, s, g, ipw);
+        // maxima of the operands AS MULTIPLIED: the caller's (plain tensors only) or taken here, behind the partial sums in ws
+        unsigned *am = reinterpret_cast<unsigned *>(ws + conv64_wgrad_ws_floats(l) - 2 * AMAX_N);
+        if (amax_lo == nullptr || !pl) {
+            if (int rc = conv64_operand_amax(g.lo, (int64_t)l->n * l->lh * l->lw * l->clo, am, s)) return rc;
+            amax_lo = am;
+        }
+        if (amax_hi == nullptr || !ph) {
+            if (int rc = conv64_operand_amax(g.hi, (int64_t)l->n * l->hh * l->hw * l->chi, am + AMAX_N, s)) return rc;
+            amax_hi = am + AMAX_N;
+        }
+        if (pl && ph) ARVAE_LAUNCH((conv_wgrad_pairs_h2_kernel<true, true>), grid, dim3(256), lds, s, g, ipw, amax_lo, amax_hi);
+        else if (pl) ARVAE_LAUNCH((conv_wgrad_pairs_h2_kernel<true, false>), grid, dim3(256), lds, s, g, ipw, amax_lo, amax_hi);
+        else if (ph) ARVAE_LAUNCH((conv_wgrad_pairs_h2_kernel<false, true>), grid, dim3(256), lds, s, g, ipw, amax_lo, amax_hi);
+        else ARVAE_LAUNCH((conv_wgrad_pairs_h2_kernel<false, false>), grid, dim3(256), lds, s, g, ipw, amax_lo, amax_hi);
         const int count = taps * l->clo * l->chi;
         ARVAE_LAUNCH(conv64_wgrad_reduce_kernel, dim3((count * 4 + 255) / 256), dim3(256), 0, s, ws, slices, taps, l->clo, l->chi, dwt);
         return check_launch((l->chi >= 64 && l->clo >= 64) ? "conv64_wgrad(pairs, wide)" : "conv64_wgrad(pairs, narrow)");

@@ -1,5 +1,6 @@
 // Stride-1 4x4 convolutions between 64-channel layers (the Morpho-MNIST 64 <-> 64 layers, imagevae/mnist_vae.py:16-47),
-// ROW-STAGED: the source rows an output row group meets are fetched from HBM, turned into three bf16 terms and written to
+// ROW-STAGED: the source rows an output row group meets are fetched from HBM, scaled, turned into two fp16 terms
+// (conv32_common.h: the arithmetic of the 32-channel kernels, three partial products per multiply-add) and written to
 // LDS exactly ONCE, and all 16 taps x 64 channels of the reduction are served from there.  conv_rows_x3_kernel (conv64.hip)
 // re-gathers its 64-pixel A tile from L2 for each of its 32 reduction chunks (~4 GB per launch at B = 1024, 16x re-read) and
 // runs load -> split -> LDS -> MFMA serially between two barriers per chunk (MFMA pipe ~30 % busy).
@@ -8,17 +9,19 @@
 //     sgn = +1: Conv2d forward / ConvTranspose2d data gradient      sgn = -1: ConvTranspose2d forward / Conv2d data gradient
 //
 // One 256-thread workgroup per CU, persistent over tiles; a tile = G output rows of one image (G * ow <= 32 MT pixels,
-// MT = 3 or 4 MFMA column tiles) and needs G + 3 source rows: <= 176 pixels x (3 x 64 bf16 + pad) = 70 KB, two buffers.
+// MT = 3 or 4 MFMA column tiles) and needs G + 3 source rows: <= 176 pixels x (2 x 64 fp16 + pad) = 50 KB, two buffers.
 //   * MFMA orientation as in conv32.hip: the WEIGHTS are the A operand (row = output channel), the pixels the B operand, so a
-//     lane ends up with consecutive channels of one pixel (16-byte stores).  32x32x16 bf16, six partial products per
-//     multiply-add, smallest first (fp32-accurate: x3tile.h).
+//     lane ends up with consecutive channels of one pixel (16-byte stores).  32x32x16 fp16, three partial products per
+//     multiply-add, smallest first (fp32-accurate: conv32_common.h; six bf16 products through round 3: 357-378 us per
+//     64 -> 64 launch at two thirds of the MFMA issue rate).
 //   * wave = kernel row (K split four ways); a wave holds MT x 2 accumulator tiles (all 64 output channels of the group's
-//     pixels for its four taps) -- each pixel operand read from LDS feeds 12 MFMAs, each weight operand MT x 3: the LDS pipe
-//     is ~25 % busy.  The four partial sums meet through the tile's own (now free) LDS buffer, each wave finishing a quarter
+//     pixels for its four taps) -- each pixel operand read from LDS feeds 6 MFMAs, each weight operand MT x 3.  The four partial sums meet through the tile's own (now free) LDS buffer, each wave finishing a quarter
 //     of every accumulator tile and storing it.
 //   * weights: split once per launch by conv64s_weight_prep_kernel into the exact per-lane operand order,
-//     [ky][kx][16-channel chunk][column tile][term][lane] x 16 bytes (393 KB, L2 resident); a wave streams its 6 KB per
-//     reduction step straight into registers, one step ahead.
+//     [ky][kx][16-channel chunk][column tile][term][lane] x 16 bytes (262 KB, L2 resident) + the inverse weight scale; a wave
+//     streams its 4 KB per reduction step straight into registers, two steps ahead.
+//   * the source tensor's maxima (AMAX array, conv32_common.h) come with it or are taken by operand_amax_kernel first; the
+//     result's are published by the epilogue.
 //   * pipeline as down32x_kernel: registers hold tile t+1 (loaded during tile t-1); during tile t's MFMAs each loader slot
 //     is split, written to the other buffer and refilled with tile t+2.  The activation derivative / keep-mask of a
 //     gradient operand is applied at that point -- once per value instead of once per tap.
@@ -26,8 +29,6 @@
 //     (a select on the LDS address).  Source rows outside the image are staged as zeros.
 #include "common.h"
 #include "conv32_common.h"
-#include "bf16x3.h"
-#include "x3tile.h"
 
 #ifdef C64S_STAMPS
 // diagnostic build only (tools/stamp_c64s.py): phase timeline of the first 64 workgroups, 100 MHz wall clock
@@ -39,13 +40,15 @@ namespace arvae { __device__ unsigned long long g_c64s_stamps[64 * 64]; }
 
 namespace arvae {
 
-constexpr int S_PITCH = 100;                     // dwords per staged pixel: terms at +0, +32, +64, 4 pad (conflict-free 16-byte
-                                                 // reads for lanes walking consecutive pixels)
+constexpr int S_PITCH = 72;                      // dwords per staged pixel: terms at +0, +32, 8 pad (conflict-free 16-byte reads for
+                                                 // lanes walking consecutive pixels; a buffer also holds the 48 KB exchange)
 constexpr int S_PIX = 176;                       // staged source pixels per tile
 constexpr int S_BUF = (S_PIX + 1) * S_PITCH;     // + the zero pixel
 constexpr int S_SLOTS = S_PIX * 16 / 256;        // 16-byte loader slots per thread (11)
-constexpr int S_WSTEP2 = 6 * 64;                 // uint4 per (ky, kx, channel chunk) with two row tiles: [row tile][term 3][lane 64]
-constexpr int S_PREP_UINT4 = 16 * 4 * S_WSTEP2;  // 393 216 bytes (half of it for narrow outputs, one row tile)
+constexpr int S_WSTEP2 = 4 * 64;                 // uint4 per (ky, kx, channel chunk) with two row tiles: [row tile][term 2][lane 64]
+constexpr int S_PREP_UINT4 = 16 * 4 * S_WSTEP2;  // 262 144 bytes (half of it for narrow outputs, one row tile); then one uint4 whose
+                                                 // first dword is the inverse weight scale
+static_assert((S_PIX + 1) * S_PITCH * 4 >= 4 * 3 * 4 * 64 * 16, "a staging buffer also serves as the exchange area of the four kernel rows");
 
 struct ConvStage {
     Operand src;                 // [n][sh][sw][64]
@@ -58,13 +61,31 @@ struct ConvStage {
     int act;
     float *out;                  // [n][oh][ow][q]
     GateOp gate;                 // data-gradient launches: result *= act'(gate.y) * 2 gate.mask at the output location
+    const unsigned *amax_in;     // AMAX array of the source operand AS MULTIPLIED (derivative / keep-mask applied)
+    unsigned *amax_out;          // AMAX array of `out`, or null
 };
 
 // wt = nn.Conv2d / nn.ConvTranspose2d weights [a][b][ky][kx]; (q, c) = (a, b) for the Conv2d-forward direction, (b, a) for
 // the transposed one.  One thread = one (ky, kx, chunk, column tile, lane) = 8 reduction channels of one output channel.
+// Every workgroup first takes the maximum magnitude of the whole tensor itself (q_count x 64 x 16 weights from L2).
 __global__ __launch_bounds__(256) void conv64s_weight_prep_kernel(const float *__restrict__ wt, uint4 *__restrict__ out, int transposed,
                                                                    int q_count, int nt_count) {
+    __shared__ float wmax[4];
+    float m = 0.f;
+    const int n4 = q_count * 64 * 4;                             // float4s of the tensor; eight loads in flight per thread
+    for (int i4 = threadIdx.x; i4 < n4; i4 += 8 * 256) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4 *>(wt + 4 * min(i4 + u * 256, n4 - 1));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) m = fmaxf(m, amax4(v[u]));
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    const Pow2 sc = pow2_for(__builtin_bit_cast(unsigned, fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
     const int i = blockIdx.x * 256 + threadIdx.x;              // ((tap * 4 + c16) * nt_count + nt) * 64 + lane
+    if (i == 0) out[16 * 4 * nt_count * 2 * 64] = make_uint4(__builtin_bit_cast(unsigned, sc.inv), 0u, 0u, 0u);
     const int lane = i & 63, rest = i >> 6, nt = rest % nt_count, c16 = (rest / nt_count) & 3, tap = rest / (4 * nt_count);
     const int q = nt * 32 + (lane & 31), c0 = c16 * 16 + 8 * (lane >> 5);
     const int qc = q < q_count ? q : 0;
@@ -74,13 +95,25 @@ __global__ __launch_bounds__(256) void conv64s_weight_prep_kernel(const float *_
         const float v = transposed ? wt[((c0 + j) * q_count + qc) * 16 + tap] : wt[(qc * 64 + c0 + j) * 16 + tap];
         x[j] = q < q_count ? v : 0.f;
     }
-    uint4 h, m, l;
-    rg_split3(x[0], x[1], h.x, m.x, l.x);
-    rg_split3(x[2], x[3], h.y, m.y, l.y);
-    rg_split3(x[4], x[5], h.z, m.z, l.z);
-    rg_split3(x[6], x[7], h.w, m.w, l.w);
-    uint4 *d = out + ((tap * 4 + c16) * nt_count + nt) * 3 * 64 + lane;
-    d[0] = h; d[64] = m; d[128] = l;
+    uint4 h, l;
+    split_pair_h2(x[0], x[1], sc.s, h.x, l.x);
+    split_pair_h2(x[2], x[3], sc.s, h.y, l.y);
+    split_pair_h2(x[4], x[5], sc.s, h.z, l.z);
+    split_pair_h2(x[6], x[7], sc.s, h.w, l.w);
+    uint4 *d = out + ((tap * 4 + c16) * nt_count + nt) * 2 * 64 + lane;
+    d[0] = h; d[64] = l;
+}
+
+// AMAX array of an operand as a kernel multiplies it: value x activation derivative x keep-mask (Operand::at4); for the caller
+// whose source tensor comes without one
+__global__ __launch_bounds__(256) void operand_amax_kernel(Operand x, int64_t count4, unsigned *__restrict__ out) {
+    __shared__ float wm[4];
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count4; i += (int64_t)gridDim.x * 256) m = fmaxf(m, amax4(x.at4(4 * i)));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x < 64) amax_publish(out, blockIdx.x, gridDim.x, fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])));
 }
 
 // act_fwd with the SELU exponential on v_exp_f32 (1 ulp): the epilogue runs while the matrix pipe idles, and 32 expf() calls
@@ -95,7 +128,7 @@ __device__ __forceinline__ float act_fwd_hw(float x, int act) {
 template <int MT, int NT, int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv64s_kernel(ConvStage g) {
     CSTAMP(0);
-    constexpr int S_WSTEP = NT * 3 * 64;
+    constexpr int S_WSTEP = NT * 2 * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned lds[];          // 2 x S_BUF
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, rc = lane & 31;
@@ -105,6 +138,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int per_wg = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x, t_first = blockIdx.x * per_wg;
     const int t_end = min(n_tiles, t_first + per_wg);
     const int src_rows = g.rows + 3, src_pix = src_rows * g.sw;
+    const AmaxLoad al = amax_issue(g.amax_in);
+    float sc_in = 1.f;                                           // the source's scale (set behind the first tile's loads)
 
     // ---- loader: slot s of this thread = (staged pixel, channels 4 q4 .. + 3) -------------------------------------------
     float4 lv[S_SLOTS], ly[S_SLOTS];
@@ -139,13 +174,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             v.x *= act_bwd_from_out_sel(y.x, g.src.act); v.y *= act_bwd_from_out_sel(y.y, g.src.act);
             v.z *= act_bwd_from_out_sel(y.z, g.src.act); v.w *= act_bwd_from_out_sel(y.w, g.src.act);
         }
-        uint2 h, m, l;
-        rg_split3(v.x, v.y, h.x, m.x, l.x);
-        rg_split3(v.z, v.w, h.y, m.y, l.y);
+        uint2 h, l;
+        split_pair_h2(v.x, v.y, sc_in, h.x, l.x);
+        split_pair_h2(v.z, v.w, sc_in, h.y, l.y);
         unsigned *d = buf + (pix0 + 16 * s) * S_PITCH + q4 * 2;
         *reinterpret_cast<uint2 *>(d) = h;
-        *reinterpret_cast<uint2 *>(d + 32) = m;
-        *reinterpret_cast<uint2 *>(d + 64) = l;
+        *reinterpret_cast<uint2 *>(d + 32) = l;
     };
 
 #pragma unroll
@@ -181,20 +215,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 
     // first tile -> buffer 0
+    {
+        const Pow2 sc = amax_scale(al);
+        sc_in = sc.s;
+    }
+    const float inv = amax_scale(al).inv * __builtin_bit_cast(float, g.wprep[16 * 4 * NT * 2 * 64].x);     // accumulators -> fp32 results
+    float amax_run = 0.f;
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < S_SLOTS; ++s) commit(s, lds);
     __syncthreads();
-    // weight operands: a ring of three register sets, two reduction steps ahead of the MFMAs (the 393 KB of split weights live
-    // in L2: one step = ~0.75 us is not enough to cover that round trip under load)
-    bf16x8 w3[3][NT][3];
+    // weight operands: a ring of three register sets, two reduction steps ahead of the MFMAs (the split weights live in L2: one
+    // step is not enough to cover that round trip under load)
+    f16x8 w2[3][NT][2];
     auto load_w = [&](auto rc_, int kx, int c16) __attribute__((always_inline)) {
         constexpr int r = decltype(rc_)::value;
         const uint4 *wp = g.wprep + ((ky * 4 + kx) * 4 + c16) * S_WSTEP + wlane;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) w3[r][nt][t] = __builtin_bit_cast(bf16x8, wp[(nt * 3 + t) * 64]);
+            for (int t = 0; t < 2; ++t) w2[r][nt][t] = __builtin_bit_cast(f16x8, wp[(nt * 2 + t) * 64]);
     };
     const int kx_first = g.sgn > 0 ? 0 : 3;
     // epilogue operands and the result as buffer resources (conv64s_fits bounds the tensor at 2 GB): absent operands get an empty
@@ -250,51 +290,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     km[mt][nt] = km_ones ? 0x01010101u : m;
                 }
         };
-        bf16x8 x3[2][MT][3];
+        f16x8 x2[2][MT][2];
         // pixel operands of reduction step 0 (jx = 0, chunk 0)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int t = 0; t < 3; ++t)
-                x3[0][mt][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4v *>(xb + xoff[mt][0] + t * 32));
+            for (int t = 0; t < 2; ++t)
+                x2[0][mt][t] = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4v *>(xb + xoff[mt][0] + t * 32));
         // Issue order pinned by hand (one scheduling barrier after every MFMA; see conv32k.hip and DESIGN.md section 4, item 15c):
         // the step's other work -- the next step's 3 MT pixel operand reads, the weight loads of the step after that, and the
         // loader's pieces (address, loads; derivative / mask, split in two halves per value pair, LDS writes) -- sits between the
         // MFMAs in order.  Left to the scheduler a step was a block of MFMAs followed by a block of vector instructions.
-        uint2 c_h, c_m, c_l;                                     // a slot's values between its pieces
+        uint2 c_h, c_l;                                          // a slot's values between its pieces
         float4 c_v;
-        f32x2v c_r;
         int64_t c_at = 0;
         bool c_ok = false;
-        auto split_a = [&](float x0, float x1, unsigned &h) __attribute__((always_inline)) {
-            const f32x2v x = {x0, x1};
-            h = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2v));
-            c_r = f32x2v{x0 - __builtin_bit_cast(float, h << 16), x1 - __builtin_bit_cast(float, h & 0xffff0000u)};
-        };
-        auto split_b = [&](unsigned &m, unsigned &l) __attribute__((always_inline)) {
-            m = __builtin_bit_cast(unsigned, __builtin_convertvector(c_r, bf16x2v));
-            const f32x2v qq = {c_r.x - __builtin_bit_cast(float, m << 16), c_r.y - __builtin_bit_cast(float, m & 0xffff0000u)};
-            l = __builtin_bit_cast(unsigned, __builtin_convertvector(qq, bf16x2v));
-        };
         static_for<0, 16>([&](auto kc) __attribute__((always_inline)) {
             constexpr int step = decltype(kc)::value, cu = step & 1, nx = cu ^ 1, wr = step % 3;
             // loader slots of this step: requested in step s * 12 / 11, split + written four steps (~3 us) later
             constexpr int is_lo = (step * S_SLOTS + 11) / 12, is_hi = step < 12 ? ((step + 1) * S_SLOTS + 11) / 12 : is_lo;
             constexpr int cs = step - 4;
             constexpr int cm_lo = cs >= 0 ? (cs * S_SLOTS + 11) / 12 : 0, cm_hi = (cs >= 0 && cs < 12) ? ((cs + 1) * S_SLOTS + 11) / 12 : cm_lo;
-            constexpr int n_read = step + 1 < 16 ? 3 * MT : 0, n_w = step + 2 < 16 ? 3 * NT : 0;
-            constexpr int n_issue = 2 * (is_hi - is_lo), n_commit = 6 * (cm_hi - cm_lo), n_ep = step == 11 ? 1 : 0;
-            constexpr int n_items = n_read + n_w + n_issue + n_commit + n_ep, n_mfma = 6 * MT * NT;
+            constexpr int n_read = step + 1 < 16 ? 2 * MT : 0, n_w = step + 2 < 16 ? 2 * NT : 0;
+            constexpr int n_issue = 2 * (is_hi - is_lo), n_commit = 4 * (cm_hi - cm_lo), n_ep = step == 11 ? 1 : 0;
+            constexpr int n_items = n_read + n_w + n_issue + n_commit + n_ep, n_mfma = 3 * MT * NT;
             auto item = [&](auto ic) __attribute__((always_inline)) {
                 constexpr int i = decltype(ic)::value;
                 if constexpr (i < n_read) {
-                    constexpr int njx = (step + 1) >> 2, nc16 = (step + 1) & 3, mt = i / 3, t = i % 3;
-                    x3[nx][mt][t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4v *>(xb + xoff[mt][njx] + t * 32 + nc16 * 8));
+                    constexpr int njx = (step + 1) >> 2, nc16 = (step + 1) & 3, mt = i / 2, t = i % 2;
+                    x2[nx][mt][t] = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4v *>(xb + xoff[mt][njx] + t * 32 + nc16 * 8));
                 } else if constexpr (i < n_read + n_w) {
-                    constexpr int k = i - n_read, nt = k / 3, t = k % 3, njx = (step + 2) >> 2, nc16 = (step + 2) & 3;
+                    constexpr int k = i - n_read, nt = k / 2, t = k % 2, njx = (step + 2) >> 2, nc16 = (step + 2) & 3;
                     const int nkx = g.sgn > 0 ? njx : 3 - njx;
                     const uint4 *wp = g.wprep + ((ky * 4 + nkx) * 4 + nc16) * S_WSTEP + wlane;
-                    w3[(step + 2) % 3][nt][t] = __builtin_bit_cast(bf16x8, wp[(nt * 3 + t) * 64]);
+                    w2[(step + 2) % 3][nt][t] = __builtin_bit_cast(f16x8, wp[(nt * 2 + t) * 64]);
                 } else if constexpr (i < n_read + n_w + n_issue) {
                     constexpr int k = i - n_read - n_w, s = is_lo + k / 2, piece = k % 2;
                     if constexpr (piece == 0) {                  // address of slot s of the next tile
@@ -311,7 +340,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         lv[s] = c_ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
                     }
                 } else if constexpr (i < n_read + n_w + n_issue + n_commit) {
-                    constexpr int k = i - n_read - n_w - n_issue, s = cm_lo + k / 6, piece = k % 6;
+                    constexpr int k = i - n_read - n_w - n_issue, s = cm_lo + k / 4, piece = k % 4;
                     if constexpr (piece == 0) {                  // the value with a gradient operand's derivative / keep-mask
                         c_v = lv[s];
                         if (MODE >= 1) {
@@ -326,27 +355,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                             c_v.z *= act_bwd_from_out_sel(y.z, g.src.act); c_v.w *= act_bwd_from_out_sel(y.w, g.src.act);
                         }
                     }
-                    if constexpr (piece == 1) split_a(c_v.x, c_v.y, c_h.x);
-                    if constexpr (piece == 2) split_b(c_m.x, c_l.x);
-                    if constexpr (piece == 3) split_a(c_v.z, c_v.w, c_h.y);
-                    if constexpr (piece == 4) split_b(c_m.y, c_l.y);
-                    if constexpr (piece == 5) {
+                    if constexpr (piece == 1) split_pair_h2(c_v.x, c_v.y, sc_in, c_h.x, c_l.x);
+                    if constexpr (piece == 2) split_pair_h2(c_v.z, c_v.w, sc_in, c_h.y, c_l.y);
+                    if constexpr (piece == 3) {
                         unsigned *d = nb + (pix0 + 16 * s) * S_PITCH + q4 * 2;
                         *reinterpret_cast<uint2 *>(d) = c_h;
-                        *reinterpret_cast<uint2 *>(d + 32) = c_m;
-                        *reinterpret_cast<uint2 *>(d + 64) = c_l;
+                        *reinterpret_cast<uint2 *>(d + 32) = c_l;
                     }
                 } else if constexpr (i < n_items) {
                     fetch_epilogue();
                 }
             };
             __builtin_amdgcn_sched_barrier(0);
-            // (weight term, pixel term) of the six partial products, smallest first, round-robin over the accumulators
+            // (weight term, pixel term) of the three partial products (l, h), (h, l), (h, h), round-robin over the accumulators
             static_for<0, n_mfma>([&](auto mc) __attribute__((always_inline)) {
                 constexpr int m = decltype(mc)::value, prod = m / (MT * NT), mt = (m % (MT * NT)) / NT, nt = m % NT;
-                constexpr int tw = prod == 0 ? 2 : prod == 1 ? 0 : prod == 2 ? 1 : prod == 3 ? 1 : 0;
-                constexpr int tx = prod == 0 ? 0 : prod == 1 ? 2 : prod == 2 ? 1 : prod == 3 ? 0 : prod == 4 ? 1 : 0;
-                MFMA_B(acc[mt][nt], w3[wr][nt][tw], x3[cu][mt][tx]);
+                constexpr int tw = prod == 0 ? 1 : 0, tx = prod == 1 ? 1 : 0;
+                MFMA_H(acc[mt][nt], w2[wr][nt][tw], x2[cu][mt][tx]);
                 __builtin_amdgcn_sched_barrier(0);
                 static_for<m * n_items / n_mfma, (m + 1) * n_items / n_mfma>(item);
                 __builtin_amdgcn_sched_barrier(0);
@@ -386,8 +411,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 {
                     const bool ok = P >= 0 && oy0 + r < g.oh && ch_ok[nt];
                     const int64_t o = (((int64_t)img * g.oh + oy0) * g.ow + P) * g.q + nt * 32 + 8 * wave + 4 * half;
-                    v.x = act_fwd_hw(v.x + b4[nt].x, g.act); v.y = act_fwd_hw(v.y + b4[nt].y, g.act);
-                    v.z = act_fwd_hw(v.z + b4[nt].z, g.act); v.w = act_fwd_hw(v.w + b4[nt].w, g.act);
+                    v.x = act_fwd_hw(fmaf(v.x, inv, b4[nt].x), g.act); v.y = act_fwd_hw(fmaf(v.y, inv, b4[nt].y), g.act);
+                    v.z = act_fwd_hw(fmaf(v.z, inv, b4[nt].z), g.act); v.w = act_fwd_hw(fmaf(v.w, inv, b4[nt].w), g.act);
                     if (g.gate.y != nullptr) {
                         const unsigned m = km[mt][nt];
                         // (the saved output of a dropout layer is the kept activation times two: Operand::apply)
@@ -403,6 +428,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     }
                     // unconditional: under the lane test the stores sat behind a branch, and the next tile's first weight operands
                     // (requested before the exchange) were then waited for with vmcnt(0) -- every store of this epilogue included
+                    amax_run = ok ? fmaxf(amax_run, amax4(v)) : amax_run;
                     buf_store4(v, rs_out, ok ? (unsigned)o * 4u : OOB);
                 }
             }
@@ -411,9 +437,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         }
         ++cst;
     }
+    amax_publish(g.amax_out, blockIdx.x * 4 + wave, gridDim.x * 4, amax_run);
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
+// AMAX array of an operand as multiplied (count floats, a multiple of 4)
+int conv64_operand_amax(const Operand &x, int64_t count, unsigned *out, hipStream_t s) {
+    int64_t blocks = (count / 4 + 255) / 256;
+    if (blocks > AMAX_N) blocks = AMAX_N;
+    if (blocks < 1) blocks = 1;
+    ARVAE_LAUNCH(operand_amax_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, count / 4, out);
+    return check_launch("operand_amax");
+}
+
 static int cu_count_s() {
     static int n = 0;
     if (n == 0) {
@@ -434,7 +470,7 @@ static bool stage_geometry(int ow, int sw, int &rows, int &mt) {
     return false;
 }
 
-int64_t conv64s_ws_floats() { return S_PREP_UINT4 * 4; }
+int64_t conv64s_ws_floats() { return (S_PREP_UINT4 + 1) * 4 + AMAX_N; }      // split weights + their inverse scale | the source's AMAX array
 
 // 64 source channels, 64 or 4..32 (a multiple of 4) output channels, 4x4 taps, stride 1, channels-last without permutation,
 // a row group that fits the staging buffers
@@ -465,7 +501,8 @@ template <int MT, int NT> static void launch_stage(const ConvStage &g, int grid,
 
 // src [n][sh][sw][64] -> out [n][oh][ow][q]; source coordinate = output coordinate + sgn * k + off
 int conv64s_run(const Operand &src, int n, int sh, int sw, int oh, int ow, int q, int sgn, int off, const float *wt, bool transposed,
-                const float *bias, int act, const uint8_t *mask, float *out, float *ws, hipStream_t s, const char *what, const GateOp *gate) {
+                const float *bias, int act, const uint8_t *mask, float *out, float *ws, hipStream_t s, const char *what, const GateOp *gate,
+                const unsigned *amax_in, unsigned *amax_out) {
     if (ws == nullptr || (reinterpret_cast<uintptr_t>(ws) & 15) != 0)
         return fail(ARVAE_E_INVALID, "%s: needs arvae_link_ws_floats() floats of 16-byte aligned workspace for the split weights", what);
     ConvStage g{};
@@ -480,7 +517,15 @@ int conv64s_run(const Operand &src, int n, int sh, int sw, int oh, int ow, int q
     const int nt = q > 32 ? 2 : 1;
     ARVAE_LAUNCH(conv64s_weight_prep_kernel, dim3(16 * 4 * nt * 64 / 256), dim3(256), 0, s, wt, reinterpret_cast<uint4 *>(ws),
                  transposed ? 1 : 0, q, nt);
-    const int tiles = n * g.groups, cus = cu_count_s();
+    const bool plain = src.y == nullptr || (src.act == ARVAE_ACT_NONE && src.mask == nullptr);
+    if (amax_in == nullptr || !plain) {                         // no maxima with the tensor, or not of what is multiplied
+        unsigned *am = reinterpret_cast<unsigned *>(ws + (S_PREP_UINT4 + 1) * 4);
+        if (int rc = conv64_operand_amax(src, (int64_t)n * sh * sw * 64, am, s)) return rc;
+        amax_in = am;
+    }
+    g.amax_in = amax_in;
+    g.amax_out = amax_out;
+    const int tiles = n * g.groups, cus = cu_count_s() < AMAX_N / 4 ? cu_count_s() : AMAX_N / 4;
     const int grid = tiles < cus ? tiles : cus;
     if (mt == 4 && nt == 2) launch_stage<4, 2>(g, grid, s);
     else if (mt == 3 && nt == 2) launch_stage<3, 2>(g, grid, s);

@@ -13,6 +13,7 @@
 // LDS in k-major order [BK][BM+1], from where each lane reads the single A and B value the
 // 32x32x2 MFMA wants (lane = (row|col) + 32 * k-parity) with conflict-free ds_read_b32.
 #include "common.h"
+#include "conv32_common.h"
 
 namespace arvae {
 
@@ -44,12 +45,13 @@ int conv_c1_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &img, 
 bool conv64_fits(const arvae_link_t *l, bool up);
 int64_t conv64_ws_floats(const arvae_link_t *l);
 int conv64_down(const arvae_link_t *l, const Operand &hi, const float *wt, const float *bias, int act, const uint8_t *mask,
-                float *lo, float *ws, hipStream_t s, const GateOp *gate);
+                float *lo, float *ws, hipStream_t s, const GateOp *gate, const unsigned *amax_in = nullptr, unsigned *amax_out = nullptr);
 int conv64_up(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, int act, const uint8_t *mask,
-              float *hi, float *ws, hipStream_t s, const GateOp *gate);
+              float *hi, float *ws, hipStream_t s, const GateOp *gate, const unsigned *amax_in = nullptr, unsigned *amax_out = nullptr);
 bool conv64_wgrad_fits(const arvae_link_t *l);
 int64_t conv64_wgrad_ws_floats(const arvae_link_t *l);
-int conv64_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *dwt, float *ws, hipStream_t s);
+int conv64_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *dwt, float *ws, hipStream_t s,
+                 const unsigned *amax_lo = nullptr, const unsigned *amax_hi = nullptr);
 
 // specialised 32-channel k4/s2/p1 kernels (conv32.hip)
 bool conv32_fits(const arvae_link_t *l);
@@ -95,6 +97,7 @@ struct Epilogue {
     float *out;
     int act;
     GateOp gate = GateOp{};      // down_single_channel_mfma_kernel only: result *= act'(gate.y) * 2 gate.mask at the output location
+    unsigned *amax_out = nullptr;    // down_single_channel_mfma_kernel only: AMAX array of `out` (conv32_common.h), one writer unit per image
 };
 
 // gather context of a tensor position (n, y0, x0) and of a (ky, kx, channel) tap
@@ -565,6 +568,7 @@ __global__ __launch_bounds__(256) void down_single_channel_mfma_kernel(Geom g, O
     }
     __syncthreads();
     const int mtiles = (npos + 15) / 16;
+    float amax_run = 0.f;
     for (int mt = wave; mt < mtiles; mt += 4) {
         const int pos = 16 * mt + col;                       // A row = position
         uint32_t ly, lx;
@@ -611,9 +615,17 @@ __global__ __launch_bounds__(256) void down_single_channel_mfma_kernel(Geom g, O
                 } else if (ep.mask != nullptr) {
                     v *= 2.f * (float)mk[i][nt];
                 }
+                amax_run = fmaxf(amax_run, fabsf(v));
                 ep.out[o] = v;
             }
         }
+    }
+    if (ep.amax_out != nullptr) {                               // the wide convolution that reads `out` next scales it into fp16
+        __shared__ float wm[4];
+        amax_run = wave_max(amax_run);
+        if (lane == 0) wm[wave] = amax_run;
+        __syncthreads();
+        if (threadIdx.x < 64) amax_publish(ep.amax_out, blockIdx.x, gridDim.x, fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])));
     }
 }
 
@@ -782,11 +794,24 @@ namespace arvae {
 // data gradient of ConvTranspose2d(64 -> 1) with the producing layer's activation derivative / keep-mask in the epilogue
 // (plan.hip: the next layer then reads a plain pre-activation gradient and needs no operand pass)
 bool single_channel_down_gated_fits(const arvae_link_t *l) { return single_channel_mfma_fits(l); }
-int single_channel_down_gated(const arvae_link_t *link, const Operand &hi, const float *wt, const GateOp *gate, float *lo, hipStream_t s) {
+int single_channel_down_gated(const arvae_link_t *link, const Operand &hi, const float *wt, const GateOp *gate, float *lo, hipStream_t s,
+                              unsigned *amax_out) {
     DownPolicy p;
     if (int rc = make_geom(link, p.g)) return rc;
     Epilogue ep{nullptr, nullptr, lo, ARVAE_ACT_NONE};
     ep.gate = *gate;
+    ep.amax_out = link->n <= 1024 ? amax_out : nullptr;         // (AMAX_N writer units)
+    ARVAE_LAUNCH(down_single_channel_mfma_kernel, dim3(link->n), dim3(256), sizeof(float) * link->hh * link->hw, s, p.g, hi, wt, ep);
+    return check_launch("link_down(single channel, mfma)");
+}
+// the forward form (bias, activation, keep-mask) for the whole-model executor, which wants the result's maxima published
+bool single_channel_down_fits(const arvae_link_t *l) { return single_channel_mfma_fits(l) && l->n <= 1024; }
+int single_channel_down(const arvae_link_t *link, const Operand &hi, const float *wt, const float *bias, int act, const uint8_t *mask,
+                        float *lo, hipStream_t s, unsigned *amax_out) {
+    DownPolicy p;
+    if (int rc = make_geom(link, p.g)) return rc;
+    Epilogue ep{bias, mask, lo, act};
+    ep.amax_out = amax_out;
     ARVAE_LAUNCH(down_single_channel_mfma_kernel, dim3(link->n), dim3(256), sizeof(float) * link->hh * link->hw, s, p.g, hi, wt, ep);
     return check_launch("link_down(single channel, mfma)");
 }
@@ -906,6 +931,18 @@ static void channel_sum_split(int64_t rows, int64_t &blocks, int64_t &rpb);
 static int channel_sum_launch(const Operand &g, int64_t rows, int channels, int perm_c, int perm_hw, float *out,
                               float *ws, hipStream_t st);
 
+namespace arvae {
+// weight + bias gradients of a wide stride-1 link (conv64.hip); amax_*: AMAX arrays of the operands when the caller has them
+// (plain operands only), else null
+int link_wgrad_conv64(const arvae_link_t *link, const Operand &lo, const Operand &hi, float *dwt, float *dbias, int bias_side, float *ws,
+                      hipStream_t st, const unsigned *amax_lo, const unsigned *amax_hi) {
+    if (int rc = conv64_wgrad(link, lo, hi, dwt, ws, st, amax_lo, amax_hi)) return rc;
+    if (bias_side == 1) return channel_sum_launch(lo, (int64_t)link->n * link->lh * link->lw, link->clo, 0, 0, dbias, ws, st);
+    if (bias_side == 2) return channel_sum_launch(hi, (int64_t)link->n * link->hh * link->hw, link->chi, 0, 0, dbias, ws, st);
+    return ARVAE_OK;
+}
+}  // namespace arvae
+
 static bool wgrad_fast(const arvae_link_t *l, const arvae_operand_t *lo, const arvae_operand_t *hi) {
     // the 32-channel kernels take plain operands only (a gradient that still needs act'(y) goes the generic way)
     return conv32_fits(l) && (lo == nullptr || lo->y == nullptr) && (hi == nullptr || hi->y == nullptr);
@@ -955,14 +992,7 @@ extern "C" int arvae_link_wgrad(const arvae_link_t *link, const arvae_operand_t 
     }
     p.lo = make_operand(lo);
     p.hi = make_operand(hi);
-    if (conv64_wgrad_fits(link)) {
-        if (int rc = conv64_wgrad(link, p.lo, p.hi, dwt, ws, st)) return rc;
-        if (bias_side == 1)
-            return channel_sum_launch(p.lo, (int64_t)link->n * link->lh * link->lw, link->clo, 0, 0, dbias, ws, st);
-        if (bias_side == 2)
-            return channel_sum_launch(p.hi, (int64_t)link->n * link->hh * link->hw, link->chi, 0, 0, dbias, ws, st);
-        return ARVAE_OK;
-    }
+    if (conv64_wgrad_fits(link)) return link_wgrad_conv64(link, p.lo, p.hi, dwt, dbias, bias_side, ws, st, nullptr, nullptr);
     p.dwt = dwt;
     p.slab = ws;
     wgrad_split(link, p.M, p.N, p.P, p.zsplit, p.chunk);

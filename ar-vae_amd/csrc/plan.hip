@@ -15,12 +15,19 @@ bool conv32_fits(const arvae_link_t *l);
 bool conv_c1_fits(const arvae_link_t *l);
 bool conv64_fits(const arvae_link_t *l, bool up);
 bool conv64s_fits(const arvae_link_t *l, bool up);
+bool conv64_wgrad_fits(const arvae_link_t *l);
+int link_wgrad_conv64(const arvae_link_t *link, const Operand &lo, const Operand &hi, float *dwt, float *dbias, int bias_side, float *ws,
+                      hipStream_t st, const unsigned *amax_lo, const unsigned *amax_hi);
 bool single_channel_down_gated_fits(const arvae_link_t *l);
-int single_channel_down_gated(const arvae_link_t *link, const Operand &hi, const float *wt, const GateOp *gate, float *lo, hipStream_t s);
+int single_channel_down_gated(const arvae_link_t *link, const Operand &hi, const float *wt, const GateOp *gate, float *lo, hipStream_t s,
+                              unsigned *amax_out);
+bool single_channel_down_fits(const arvae_link_t *l);
+int single_channel_down(const arvae_link_t *link, const Operand &hi, const float *wt, const float *bias, int act, const uint8_t *mask,
+                        float *lo, hipStream_t s, unsigned *amax_out);
 int conv64_down(const arvae_link_t *l, const Operand &hi, const float *wt, const float *bias, int act, const uint8_t *mask,
-                float *lo, float *ws, hipStream_t s, const GateOp *gate);
+                float *lo, float *ws, hipStream_t s, const GateOp *gate, const unsigned *amax_in = nullptr, unsigned *amax_out = nullptr);
 int conv64_up(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, int act, const uint8_t *mask,
-              float *hi, float *ws, hipStream_t s, const GateOp *gate);
+              float *hi, float *ws, hipStream_t s, const GateOp *gate, const unsigned *amax_in = nullptr, unsigned *amax_out = nullptr);
 // (32-channel conv kernels, conv32.hip: operands come with their AMAX arrays, conv32_common.h)
 int conv32_down(const arvae_link_t *l, const Operand &hi, const float *bias, int relu, const float *gate, const uint16_t *gate_bits,
                 uint16_t *bits_out, float *out, hipStream_t s, const float *wprep, const unsigned *amax_in, unsigned *amax_out);
@@ -268,6 +275,25 @@ static int layer_forward(const arvae_layer_t &l, int32_t n, const float *params,
         }
         return conv_c1_down(&lk, make_operand(&op), w, b, 1, nullptr, nullptr, bits_out, out, hs, out_amax);
     }
+    // the wide stride-1 convolutions (conv64s.hip runs the two-term fp16 arithmetic too): the input's maxima come along or are
+    // taken once, into the input's own array (the layer's weight gradient reads them again); the row-staged kernel publishes
+    // the output's
+    if (conv64_fits(&lk, l.is_up != 0) && tmp_amax != nullptr && !dense_fits(&lk) && !conv32_fits(&lk) && !conv_c1_fits(&lk)) {
+        hipStream_t hs = as_stream(st);
+        if (in_amax == nullptr && conv64s_fits(&lk, l.is_up != 0)) {
+            if (int rc = conv32_amax(in, in_elems(l, n), tmp_amax, hs)) return rc;
+            in_amax = tmp_amax;
+        }
+        *out_has = out_amax != nullptr && conv64s_fits(&lk, l.is_up != 0);
+        return l.is_up ? conv64_up(&lk, make_operand(&op), w, b, l.act, mask, out, link_ws, hs, nullptr, in_amax, *out_has ? out_amax : nullptr)
+                       : conv64_down(&lk, make_operand(&op), w, b, l.act, mask, out, link_ws, hs, nullptr, in_amax, *out_has ? out_amax : nullptr);
+    }
+    // the single-channel first layer of the wide stack (Conv2d(1, 64)): the same kernel arvae_link_down picks, with the maxima
+    if (!l.is_up && out_amax != nullptr && !dense_fits(&lk) && !conv32_fits(&lk) && !conv_c1_fits(&lk) && !conv64_fits(&lk, false) &&
+        single_channel_down_fits(&lk)) {
+        *out_has = true;
+        return single_channel_down(&lk, make_operand(&op), w, b, l.act, mask, out, as_stream(st), out_amax);
+    }
     return l.is_up ? arvae_link_up(&lk, &op, w, b, l.act, mask, out, link_ws, st)
                    : arvae_link_down(&lk, &op, w, b, l.act, mask, out, link_ws, st);
 }
@@ -314,6 +340,7 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
         const int64_t count = (int64_t)n * (l.is_up ? (int64_t)lk.hh * lk.hw * lk.chi : (int64_t)lk.lh * lk.lw * lk.clo);
         if (int rc = arvae_operand_apply(&gop, count, const_cast<float *>(g), st)) return rc;
         gop = plain(g);
+        g_amax = nullptr;                                    // (of what was there before)
     }
     const arvae_operand_t xin = plain(in);
     const float *w = params + l.w_off;
@@ -369,11 +396,16 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
                 *gated = true;
                 *din_has = din_amax != nullptr;
             } else if (gate_op != nullptr && !conv64_fits(&lk, false) && !conv_c1_fits(&lk) && single_channel_down_gated_fits(&lk)) {
-                rc = single_channel_down_gated(&lk, make_operand(&gop), w, gate_op, d_in, hs);
+                rc = single_channel_down_gated(&lk, make_operand(&gop), w, gate_op, d_in, hs, din_amax);
                 *gated = true;
+                *din_has = din_amax != nullptr && lk.n <= 1024;
             } else if (gate_op != nullptr && conv64s_fits(&lk, false)) {       // (the gathering kernel's scattered epilogue loses more than the operand pass costs)
-                rc = conv64_down(&lk, make_operand(&gop), w, nullptr, ARVAE_ACT_NONE, nullptr, d_in, link_ws, hs, gate_op);
+                if (gop.y == nullptr && tmp_amax != nullptr)
+                    if (int rc2 = need_g()) return rc2;
+                rc = conv64_down(&lk, make_operand(&gop), w, nullptr, ARVAE_ACT_NONE, nullptr, d_in, link_ws, hs, gate_op,
+                                 gop.y == nullptr ? g_amax : nullptr, din_amax);
                 *gated = true;
+                *din_has = din_amax != nullptr;
             } else {
                 rc = arvae_link_down(&lk, &gop, w, nullptr, ARVAE_ACT_NONE, nullptr, d_in, link_ws, st);
             }
@@ -388,8 +420,13 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
                 rc = dense_dgrad(&lk, make_operand(&gop), w, gate, d_in, hs);
                 *gated = true;
             } else if (gate_op != nullptr && conv64_fits(&lk, true)) {         // (conv64s.hip or the gathering kernel: both take the gate)
-                rc = conv64_up(&lk, make_operand(&gop), w, nullptr, ARVAE_ACT_NONE, nullptr, d_in, link_ws, hs, gate_op);
+                const bool staged = conv64s_fits(&lk, true);
+                if (staged && gop.y == nullptr && tmp_amax != nullptr)
+                    if (int rc2 = need_g()) return rc2;
+                rc = conv64_up(&lk, make_operand(&gop), w, nullptr, ARVAE_ACT_NONE, nullptr, d_in, link_ws, hs, gate_op,
+                               (staged && gop.y == nullptr) ? g_amax : nullptr, staged ? din_amax : nullptr);
                 *gated = true;
+                *din_has = staged && din_amax != nullptr;
             } else {
                 rc = arvae_link_up(&lk, &gop, w, nullptr, ARVAE_ACT_NONE, nullptr, d_in, link_ws, st);
             }
@@ -416,6 +453,16 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
         if (rc) return rc;
         slab_reduce_defer(rdefer, job);
         return ARVAE_OK;
+    }
+    // the wide stride-1 layers' weight gradient (conv64.hip) takes the operands' maxima when they are plain tensors
+    if (conv64_wgrad_fits(&lk) && !dense_fits(&lk) && !conv_c1_fits(&lk) && !conv32_fits(&lk) && tmp_amax != nullptr && tmp2_amax != nullptr) {
+        const bool g_plain = gop.y == nullptr;
+        if (g_plain)
+            if (int rc = need_g()) return rc;
+        if (int rc = need_in()) return rc;
+        const unsigned *ga = g_plain ? g_amax : nullptr;
+        return l.is_up ? link_wgrad_conv64(&lk, make_operand(&xin), make_operand(&gop), dw, db, db ? 2 : 0, slab, whs, in_amax, ga)
+                       : link_wgrad_conv64(&lk, make_operand(&gop), make_operand(&xin), dw, db, db ? 1 : 0, slab, whs, ga, in_amax);
     }
     if (l.is_up) return arvae_link_wgrad(&lk, &xin, &gop, dw, db, db ? 2 : 0, slab, wst);
     if (defer != nullptr && dense_fits(&lk) && dense_wgrad_defer(defer, &lk, make_operand(&gop), in, dw, db)) return ARVAE_OK;
@@ -656,7 +703,11 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
     auto in_amax_of = [&](bool dec, int i) -> const unsigned * {
         if (i == 0) return nullptr;
         const bool fast = (dec ? L.dec_bits[i] : L.enc_bits[i]) >= 0 && (dec ? L.dec_wprep[i] : L.enc_wprep[i]) >= 0;
-        return fast ? U(dec ? L.dec_amax[i - 1] : L.enc_amax[i - 1]) : nullptr;
+        const arvae_layer_t &l = dec ? m->dec[i] : m->enc[i];
+        arvae_link_t lk = l.link;
+        lk.n = batch;
+        const bool wide = conv64s_fits(&lk, l.is_up != 0) && !dense_fits(&lk) && !conv32_fits(&lk) && !conv_c1_fits(&lk);
+        return (fast || wide) ? U(dec ? L.dec_amax[i - 1] : L.enc_amax[i - 1]) : nullptr;
     };
     const unsigned *cur_amax = nullptr;                   // AMAX array of `cur`, when the kernel that wrote it delivered one
     // keep-mask index of every dropout layer, in forward order
