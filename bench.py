@@ -111,7 +111,7 @@ ROCPROF_NAMES = {
     'up_c1_kernel(recon)': ['arvae::up_c1_kernel<0, true>'],
     'conv64_down(wide)': ['arvae::conv64s_kernel<3, 2, 0>'], 'conv64_down(narrow)': ['arvae::conv64s_kernel<3, 1, 0>'],
     'conv64_up(wide)': ['arvae::conv64s_kernel<4, 2, 0>'], 'conv64_up(narrow)': ['arvae::conv_rows_x3_kernel<true>'],
-    'conv64_wgrad(pairs, wide)': ['arvae::conv_wgrad_pairs_x3_kernel'], 'conv64_wgrad(pairs, narrow)': ['arvae::conv_wgrad_pairs_x3_kernel'],
+    'conv64_wgrad(pairs, wide)': ['arvae::conv_wgrad_pairs_h2_kernel'], 'conv64_wgrad(pairs, narrow)': ['arvae::conv_wgrad_pairs_h2_kernel'],
     'conv64_wgrad(rows)': ['arvae::conv_wgrad_rows_x3_kernel'],
     'gru_seq_fwd_kernel': ['arvae::gru_seq_fwd_x3_kernel<128>'], 'gru_seq_bwd_kernel': ['arvae::gru_seq_bwd_x3_kernel<128>'],
     'tick_free_run_x3_kernel': ['arvae::tick_free_run_x3_kernel<128>'],
@@ -395,11 +395,13 @@ def side_roofline(kind, prof, prof_steps, batch):
     if per_launch:
         macs = per_launch * dom['calls'] / prof_steps
     if macs:
-        tf = 2.0 * macs * batch * BF16X3_PRODUCTS / (dom['ms'] / prof_steps * 1e-3) / 1e12
+        # (the wide 64-channel convolutions and their weight gradient moved to the two-term fp16 arithmetic in round 3)
+        products = F16X2_PRODUCTS if (kind == 'mnist' and ('wide' in name or 'pairs' in name)) else BF16X3_PRODUCTS
+        tf = 2.0 * macs * batch * products / (dom['ms'] / prof_steps * 1e-3) / 1e12
         out.update({'bound': 'mfma', 'achieved': tf, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': tf / PEAK_BF16_MFMA_TFLOPS, 'traffic': None, 'fp32_equivalent_tflops': tf / BF16X3_PRODUCTS,
-                    'mfma_work': 'executed bf16 MFMA FLOP = 6 partial products x algorithmic FLOP of all the label\'s '
-                                 'launches in one step'})
+                    'frac': tf / PEAK_BF16_MFMA_TFLOPS, 'traffic': None, 'fp32_equivalent_tflops': tf / products,
+                    'mfma_work': 'executed 16-bit MFMA FLOP = %d partial products x algorithmic FLOP of all the label\'s '
+                                 'launches in one step' % products})
     return out
 
 
@@ -419,7 +421,8 @@ def run_side(kind, device, args, fence, rank, world, use_dp, with_cpu):
     res = {'metric': f'training {unit} ({kind} AR-VAE, per-GPU batch {bsz})', 'value': rate, 'unit': unit, 'n_gpus': world,
            'steps': steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * med / steps, 'higher_is_better': True,
            'scaling': 'weak', 'vs_baseline': None,
-           'dtype': 'f32 (MFMAs: 3-term bf16 split, 6 products, fp32-accurate)', 'data': 'synthetic',
+           'dtype': ('f32 (wide conv MFMAs: scaled 2-term fp16 split, 3 products; narrow conv / Linear: 3-term bf16 split, 6 products; fp32-accurate)'
+                     if kind == 'mnist' else 'f32 (MFMAs: 3-term bf16 split, 6 products, fp32-accurate)'), 'data': 'synthetic',
            'config': {'workload': ('Morpho-MNIST AR-VAE full training step, 1x28x28 inputs, z=16, reg_dim=(1..6), dropout 0.5'
                                    if kind == 'mnist' else
                                    'FolkNBar MeasureVAE full training step, 24-tick measures, V=35, z=32, reg_dim=(0..3), '
