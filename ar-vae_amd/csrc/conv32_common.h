@@ -100,7 +100,7 @@ __device__ __forceinline__ void buf_store_u16(unsigned v, __amdgpu_buffer_rsrc_t
 // Every fp32 operand tensor X enters the matrix pipe as s X = h + l, h = fp16(s X) and l = fp16(s X - h), both round-to-nearest,
 // where s is the power of two that brings max |X| into [2^14, 2^15) (an fp16 below 2^16; the per-tensor maximum comes with the
 // tensor, see AMAX below).  h + l reproduces s X to 2^-22 relative for every element within 2^16 of the tensor's maximum and to
-// 2^-40 of that maximum below; a product is the THREE partial products l h', h l', h h' (l l' <= 2^-22 is dropped) on
+// 2^-39 of that maximum below; a product is the THREE partial products l h', h l', h h' (l l' <= 2^-22 is dropped) on
 // v_mfma_f32_32x32x16_f16 with fp32 accumulation, smallest first, and the epilogue multiplies by the two inverse scales (exact).
 // Measured against float64 the results sit at 0.7e-7 relative L2 for K = 512 dot products -- the three-term bf16 split these
 // kernels used through round 3 (six partial products) measured 0.6e-7, an fp32 FMA chain 2-3e-7 -- at half the MFMAs and two

@@ -536,7 +536,7 @@ def test_conv32_scaling_is_exact_and_survives_outliers(dev):
     """What the per-tensor power-of-two scales must guarantee.  (1) Results do not depend on the magnitude of the operands:
     a tensor times 2^k gives bit for bit the result times 2^k (gradients of 1e-7 are as good as activations of 1e+3).
     (2) A tensor whose maximum sits far above its bulk (one value 10^4 times the rest: the low terms of the bulk then fall
-    into the fp16 subnormal range, absolute error <= 2^-40 of the maximum) still meets the float64 bar relative to the result's
+    into the fp16 subnormal range, absolute error <= 2^-39 of the maximum) still meets the float64 bar relative to the result's
     norm, and the outputs the outlier does not reach keep an error of a few 1e-7 relative to their own norm."""
     rs = np.random.RandomState(5)
     n, size = 16, 16

@@ -15,7 +15,7 @@ b = torch.zeros(64, device=dev)
 for _ in range(3):
     ops.link_down(link, n, ops._operand(hi), w, b, 2, None)
 torch.cuda.synchronize()
-fn = ctypes.CDLL(_lib.LIB_PATH).arvae_debug_c64s_stamps
+fn = ctypes.CDLL(os.environ.get('ARVAE_LIB') or _lib.LIB_PATH).arvae_debug_c64s_stamps
 fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
 buf = (ctypes.c_ulonglong * (64 * 64))()
 assert fn(buf, 64 * 64) == 0

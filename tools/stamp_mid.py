@@ -12,7 +12,7 @@ x, lab = torch.from_numpy(x).to(dev), torch.from_numpy(lab).to(dev)
 for i in range(5):
     trainer.zero_grad(); loss, _ = trainer.loss_and_acc_for_batch((x, lab), 0, i, True); loss.backward(); trainer.step()
 torch.cuda.synchronize()
-fn = ctypes.CDLL(_lib.LIB_PATH).arvae_debug_mid_stamps
+fn = ctypes.CDLL(os.environ.get('ARVAE_LIB') or _lib.LIB_PATH).arvae_debug_mid_stamps
 fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
 buf = (ctypes.c_ulonglong * (128 * 16))()
 assert fn(buf, 128 * 16) == 0
