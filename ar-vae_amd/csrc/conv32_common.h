@@ -157,7 +157,7 @@ __device__ __forceinline__ float wave_max(float m) {
 __device__ __forceinline__ void amax_publish(unsigned *p, int unit, int units, float m) {
     if (p == nullptr) return;
     m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) {
+    if ((threadIdx.x & 63) == 0 && unit < AMAX_N) {              // (units <= AMAX_N is the launcher's promise; never write past the array)
         p[unit] = __builtin_bit_cast(unsigned, m);
         for (int e = unit + units; e < AMAX_N; e += units) p[e] = 0u;
     }

@@ -25,11 +25,12 @@ assert fn(buf, cnt) == 0
 st = np.array(buf, dtype=np.uint64).reshape(512, 64, 2).astype(np.int64)
 con, pro = st[:256, :, 1], st[256:, :, 1]          # 100 MHz wall clock
 us = lambda v: v.mean() / 100
-print('consumer entry -> loop start %.2f us ; whole kernel (consumer) %.2f us, (producer incl. last epilogue) %.2f us' %
+print('compute entry -> loop start %.2f us ; whole kernel (compute waves) %.2f us, (store waves incl. last epilogue) %.2f us' %
       (us(con[:, 1] - con[:, 0]), us(con[:, 63] - con[:, 0]), us(pro[:, 63] - con[:, 0])))
 for k in range(4):
     s = 3 + 6 * k
-    print('tile %d consumer: k-loop %.2f, wait A %.2f, handoff %.2f, wait B %.2f | producer: epilogue %.2f, commit %.2f, issue %.2f, wait A %.2f, wait B %.2f | start %.2f us'
+    print('tile %d compute: request + k-loop %.2f, split next patch %.2f, wait A %.2f, handoff %.2f, wait B %.2f | store: wait A %.2f, wait B %.2f, '
+          'gate request %.2f, epilogue %.2f | start %.2f us'
           % (k, us(con[:, s + 1] - con[:, s]), us(con[:, s + 2] - con[:, s + 1]), us(con[:, s + 3] - con[:, s + 2]), us(con[:, s + 4] - con[:, s + 3]),
-             us(pro[:, s + 1] - pro[:, s]), us(pro[:, s + 2] - pro[:, s + 1]), us(pro[:, s + 3] - pro[:, s + 2]), us(pro[:, s + 4] - pro[:, s + 3]),
-             us(pro[:, s + 5] - pro[:, s + 4]), us(con[:, s] - con[:, 0])))
+             us(con[:, s + 5] - con[:, s + 4]), us(pro[:, s + 1] - pro[:, s]), us(pro[:, s + 2] - pro[:, s + 1]), us(pro[:, s + 3] - pro[:, s + 2]),
+             us(pro[:, s + 4] - pro[:, s + 3]), us(con[:, s] - con[:, 0])))
