@@ -1307,9 +1307,13 @@ int conv32_wgrad_partial(const arvae_link_t *l, const Operand &lo, const Operand
 // up == false: a forward DOWN link (data gradient = UP map, g on the lo side, bias mode 1).  Only the combinations the image
 // executor produces are instantiated; everything else (and the experiment switches) goes the two-launch way.
 static int pair_split_percent(int lh, bool up) {              // share of the workgroups that runs the data gradient
-    static const int e16 = getenv("ARVAE_PAIR_SPLIT16") ? atoi(getenv("ARVAE_PAIR_SPLIT16")) : 0;
-    static const int e8 = getenv("ARVAE_PAIR_SPLIT8") ? atoi(getenv("ARVAE_PAIR_SPLIT8")) : 0;
-    const int forced = lh == 16 ? e16 : e8;
+    // ARVAE_PAIR_SPLIT16 / _SPLIT8: both pairs of that size; ..._SPLIT16U / 16D / 8U / 8D: the pair whose data gradient is the Up
+    // (forward Down layer) / Down map
+    auto env = [](const char *name) { const char *v = getenv(name); return v != nullptr ? atoi(v) : 0; };
+    static const int e16 = env("ARVAE_PAIR_SPLIT16"), e8 = env("ARVAE_PAIR_SPLIT8");
+    static const int e16u = env("ARVAE_PAIR_SPLIT16U"), e16d = env("ARVAE_PAIR_SPLIT16D"), e8u = env("ARVAE_PAIR_SPLIT8U"), e8d = env("ARVAE_PAIR_SPLIT8D");
+    const int one = lh == 16 ? (up ? e16d : e16u) : (up ? e8d : e8u), both = lh == 16 ? e16 : e8;
+    const int forced = one > 0 ? one : both;
     if (forced > 0 && forced < 100) return forced;
     return lh == 16 ? (up ? 48 : 50) : 50;             // (same-box sweeps at B = 512: flat within 1 % from 48 to 52)
 }
