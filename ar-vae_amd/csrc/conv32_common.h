@@ -12,7 +12,6 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef int i32x4v __attribute__((ext_vector_type(4)));
 
 constexpr int C32 = 32;
-constexpr int PS = 36;                  // LDS pixel stride in floats
 constexpr int PSB2 = 36;                // LDS pixel stride in dwords of the packed two-term image (terms at +0, +16 dwords, 4 pad):
                                         // conflict-free 16-byte reads for pixel walks of stride 1 and 2 (eight lanes per clock:
                                         // 36 rc and 72 rc mod 64 are eight disjoint groups of four banks)
@@ -49,13 +48,6 @@ template <int LO, int PX = 128> __device__ __forceinline__ void tile_origin(int 
     img0 = (T::TI == 1) ? tile / TILES_PER_IMG : tile * T::TI;
     r0 = (T::TI == 1) ? (tile % TILES_PER_IMG) * T::TR : 0;
 }
-// byte offset of hi pixel (2r, 2c) of lo pixel p inside a [*, 2LO, 2LO, 32] tensor, relative to hi (img0, 2*r0, 0)
-template <int LO, int PX = 128> __device__ __forceinline__ constexpr int hi_rel(int p) {
-    int img = 0, r = 0, c = 0;
-    tile_pixel<LO, PX>(p, img, r, c);
-    return ((img * 2 * LO + 2 * r) * 2 * LO + 2 * c) * PIXB;
-}
-
 // compile-time loop: f(std::integral_constant<int, I>) for I in [0, N); keeps every register-array index static
 template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&f) {
     if constexpr (I < N) {
@@ -182,7 +174,6 @@ __device__ __forceinline__ Pow2 amax_scale(const AmaxLoad &a) {
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
     return pow2_for((unsigned)__builtin_amdgcn_readfirstlane((int)m));
 }
-__device__ __forceinline__ Pow2 tensor_scale(const unsigned *p) { return amax_scale(amax_issue(p)); }
 
 // Per-layer prepared weights (conv32_prep_block, prep32.h, once per training step): the scaled two-term split of wt in per-lane
 // MFMA operand order, 16 bytes per (slot, lane) with lanes contiguous, followed by the inverse of the layer's weight scale.
