@@ -1301,7 +1301,12 @@ def test_paired_launches_match_the_separate_launches(dev):
         "                  'g0': {k: float(np.asarray(v).ravel()[0]) for k, v in got['grads'].items()}}))\n"
         % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     res = {}
-    for flag, env in (('pair', {}), ('split', {'ARVAE_NO_PAIR4': '1', 'ARVAE_NO_PAIR_C1': '1'})):
+    # every horizontal pair of the step against the same work as separate launches: data gradient + weight gradient of the 4x4 /
+    # 8x8 and 16x16 / last decoder layers, first layer's weight gradient + Linear weight gradients, weight prep + first conv,
+    # regulariser + first decoder conv
+    split_env = {k: '1' for k in ('ARVAE_NO_PAIR4', 'ARVAE_NO_PAIR32', 'ARVAE_NO_PAIR_C1', 'ARVAE_NO_PAIR_TAIL', 'ARVAE_NO_PAIR_PREP',
+                                  'ARVAE_NO_PAIR_REG')}
+    for flag, env in (('pair', {}), ('split', split_env)):
         r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
         assert r.returncode == 0, r.stderr[-2000:]
         res[flag] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
