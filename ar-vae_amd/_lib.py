@@ -10,7 +10,7 @@ import threading
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libarvae_hip.so')
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_i32, c_i64, c_f32, c_f64, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
 
@@ -127,6 +127,19 @@ SIGNATURES = {
     'arvae_count_nonfinite': (c_i32, [c_vp, c_i64, c_vp, c_vp]),
     'arvae_count_out_of_range': (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
     'arvae_adam_step': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_f64, c_f64, c_f64, c_f64, c_f32, c_i32, c_vp]),
+    'arvae_comm_available': (c_i32, []),
+    'arvae_comm_unique_id': (c_i32, [c_vp]),
+    'arvae_comm_init': (c_i32, [c_vp, c_i32, c_i32, _P(c_vp)]),
+    'arvae_comm_destroy': (c_i32, [c_vp]),
+    'arvae_comm_abort': (c_i32, [c_vp]),
+    'arvae_comm_rank': (c_i32, [c_vp]),
+    'arvae_comm_world': (c_i32, [c_vp]),
+    'arvae_comm_async_error': (c_i32, [c_vp]),
+    'arvae_comm_all_gather': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_vp]),
+    'arvae_comm_all_reduce': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
+    'arvae_comm_broadcast': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
+    'arvae_comm_group_begin': (c_i32, []),
+    'arvae_comm_group_end': (c_i32, []),
 }
 
 _lock = threading.Lock()

@@ -26,7 +26,7 @@ class DeviceLoader:
         # slices of the (rank-0) shuffled order, of which this loader yields its own; a trailing global batch that does
         # not divide evenly is cut to the largest size every rank can take (equal shards keep mean-of-ranks == global mean)
         self.rank, self.world = (int(shard[0]), int(shard[1])) if shard is not None else (0, 1)
-        self.group = shard[2] if shard is not None and len(shard) > 2 else None      # shard = (rank, world[, process group])
+        self.comm = shard[2] if shard is not None and len(shard) > 2 else None       # shard = (rank, world[, communicator])
         if not (0 <= self.rank < self.world):
             raise ValueError('shard = (rank, world) with 0 <= rank < world')
 
@@ -50,8 +50,9 @@ class DeviceLoader:
         if self.shuffle:
             order = torch.randperm(n, device=dev, generator=self.generator) + self.lo
             if self.world > 1:                           # every rank walks rank 0's permutation
-                import torch.distributed as dist
-                dist.broadcast(order, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+                if self.comm is None:
+                    raise RuntimeError('a sharded, shuffling loader needs the communicator: shard = (rank, world, comm)')
+                self.comm.broadcast(order, src=0)        # parallel.LibraryComm / TorchComm
         else:
             order = torch.arange(self.lo, self.hi, device=dev)
         for offset, rows in self.plan(n, self.batch_size, self.world, self.drop_last):

@@ -20,14 +20,6 @@ from ._lib import ImageVaeDesc, LayerDesc
 LOSS, RECON, DIST, REG, ACC, KL, NSCALARS = 0, 1, 2, 3, 4, 5, 8
 
 
-# The label all-gather can stay in flight during the forward pass (it hides one collective's latency on several GPUs, but
-# costs +15 us of host / stream overhead on a single rank, where there is nothing to hide): on by default when there is
-# more than one rank; ARVAE_DP_ASYNC_GATHER=0 / 1 forces it.
-def _async_label_gather(dp):
-    forced = os.environ.get('ARVAE_DP_ASYNC_GATHER')
-    return forced == '1' if forced in ('0', '1') else dp.world_size > 1
-
-
 # Data-parallel overlap: the executors record events where z / the decoder's conv gradients / the
 # Linear gradients are final (arvae_image_vae_t.milestones), and the collectives that need them are enqueued on a side
 # stream behind those events, so they run under the rest of the pass.  OPT-IN (ARVAE_DP_OVERLAP=1).  Measured on one MI355X
@@ -224,13 +216,13 @@ class _FusedStepFn(Function):
         logits = torch.empty_like(x)
         marr, keep = _mask_array(masks)
         rowblock = dp is not None and len(fused.reg_dims) > 0
-        ov = fused.overlap(dev) if (dp is not None and _dp_overlap()) else None
+        # the overlap schedule lives on a side stream with its own events: not inside a stream capture
+        ov = fused.overlap(dev) if (dp is not None and _dp_overlap() and not torch.cuda.is_current_stream_capturing()) else None
         desc.milestones = ov.pointer() if ov is not None else None
         ctx.overlap = ov
-        if rowblock:                                             # the label columns do not depend on this pass: gather first
+        if rowblock:
             external_reg = True
             labels = labels.contiguous()
-            lab_all, lab_work = dp.gather_columns(labels, async_op=_async_label_gather(dp))   # in flight during the forward pass
         # data parallel, capacity 0: the library finishes the pass itself once the columns are gathered (arvae_image_vae_finish:
         # row-block regulariser + scalars, two launches) instead of three launches and a torch add from here
         finish_in_lib = rowblock and not (dp is not None and capacity_nonzero)
@@ -254,14 +246,15 @@ class _FusedStepFn(Function):
                 # z is final long before the pass ends (the decoder's launches follow the latent block): its all-gather waits
                 # for the executor's event on the side stream and runs under the decoder
                 z_all = torch.empty((dp.world_size * b, zd), dtype=z.dtype, device=dev)
+                lab_all = torch.empty((dp.world_size * b, labels.shape[1]), dtype=labels.dtype, device=dev)
                 with torch.cuda.stream(ov.stream):
                     ov.stream.wait_event(ov.z_ready)
+                    _, lab_work = dp.gather_columns(labels, async_op=True, out=lab_all)
                     _, z_work = dp.gather_columns(z, async_op=True, out=z_all)
-                z_work.wait()                                    # the launch stream continues after the collective
-            else:
-                z_all = dp.gather_columns(z)
-            if lab_work is not None:
                 lab_work.wait()
+                z_work.wait()                                    # the launch stream continues after the collectives
+            else:
+                z_all, lab_all = dp.gather_many([z, labels])     # one RCCL launch on the launch stream
         if finish_in_lib:
             w = float(dp.world_size)
             with ops._timed('image_vae_finish'):

@@ -11,10 +11,14 @@ teacher-forcing coin: one graph per control-flow variant.
         loss, acc = graphed(batch)                       # zero_grad + loss + backward
         trainer.step()
 
-Data-parallel runs: a collective inside the step (the all-gather of the regularised latent / label columns, parallel.py) is
-NOT captured.  The capture is cut there instead: the step becomes a chain of graphs with the collectives issued eagerly
-between them (`Segments`), on the same static buffers every replay, so that a data-parallel MeasureVAE step also runs at
-the replay rate instead of the eager one (1.5 vs 3.9 ms).  The gradient all-reduce and Adam stay outside, in trainer.step().
+Data-parallel runs: the step's collectives (the all-gather of the regularised latent / label columns, parallel.py) are RCCL
+calls the library enqueues on the launch stream (arvae_comm_*), so the capture RECORDS them like the kernels around them: a
+data-parallel MeasureVAE step is ONE graph as well.  There is no torch process group in such a run (no watchdog thread
+polling events next to the capture: round 3's chain of graphs cut at eager torch.distributed collectives could be aborted
+by exactly that thread).  Over a transport that cannot be captured (parallel.TorchComm) the step stays eager.  Whether a
+capture succeeded is decided by ALL ranks together (a MIN all-reduce of a flag after each attempt): either every rank
+replays or every rank runs eagerly -- the collective sequences never diverge.  The gradient all-reduce and Adam stay
+outside, in trainer.step().
 
 Random numbers drawn on the device inside the step (reparameterisation noise, dropout masks) come from the library's
 counter-based Philox stream (csrc/rng.h): the captured launches read their stream position from a device word that the
@@ -24,62 +28,34 @@ NOT visible to a captured graph (the queue is consumed at capture time).
 import torch
 
 
-class Segments:
-    """A step captured as a chain of HIP graphs cut at the points where something must run eagerly (a collective).
-    While `capture(fn)` runs fn, `split(eager_fn)` ends the graph being captured, runs eager_fn, remembers it and starts the
-    next graph from the same memory pool; `replay()` replays graph, eager_fn, graph, ... in that order on the current stream.
-    eager_fn must work on tensors it keeps alive (allocated during the capture: their addresses are what the graphs use)."""
+class Capture:
+    """forward + backward of one control-flow variant as one HIP graph, captured on a stream of its own"""
 
-    def __init__(self, device=None):
-        self.graphs, self.between = [], []
-        self.pool = torch.cuda.graph_pool_handle()
+    def __init__(self, device=None, thread_local=False):
+        self.graph = torch.cuda.CUDAGraph()
         self.stream = torch.cuda.Stream(device=device)
-        self.capturing = False
-
-    def _begin(self):
-        g = torch.cuda.CUDAGraph()
-        # with a process group alive, its watchdog thread polls events while we capture: 'global' mode would turn that into
-        # hipErrorStreamCaptureUnsupported; only this thread's (and the autograd thread's launches, which target the capturing
-        # stream) matter here
-        import torch.distributed as dist
-        mode = 'thread_local' if dist.is_available() and dist.is_initialized() else 'global'
-        g.capture_begin(pool=self.pool, capture_error_mode=mode)
-        self.graphs.append(g)
+        # 'global' (the default) lets ANY thread's capture-unsafe call invalidate the capture; a data-parallel process has
+        # RCCL's helper threads next to us, whose calls are none of the capture's business: only this thread's (and the
+        # autograd thread's launches, which target the capturing stream) matter then
+        self.mode = 'thread_local' if thread_local else 'global'
 
     def capture(self, fn):
         torch.cuda.synchronize()
-        self.stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.stream):
-            self._begin()
-            self.capturing = True
-            try:
-                out = fn()
-            finally:
-                self.capturing = False
-                self.graphs[-1].capture_end()
-        torch.cuda.current_stream().wait_stream(self.stream)
+        with torch.cuda.graph(self.graph, stream=self.stream, capture_error_mode=self.mode):
+            out = fn()                         # an exception ends the capture (torch.cuda.graph.__exit__) and propagates
         return out
 
-    def split(self, eager_fn):
-        if not self.capturing:
-            raise RuntimeError('Segments.split outside capture')
-        self.graphs[-1].capture_end()
-        result = eager_fn()                    # for real, on the capture stream: its inputs are not computed yet (capture
-        self.between.append(eager_fn)          # records, it does not run), only the call sequence and the buffers matter
-        self._begin()
-        return result
-
     def replay(self):
-        for i, g in enumerate(self.graphs):
-            g.replay()
-            if i < len(self.between):
-                self.between[i]()
+        self.graph.replay()
 
 
 class GraphedStep:
     def __init__(self, trainer, example_batch, warmup=3):
         if not torch.cuda.is_available():
             raise RuntimeError('GraphedStep needs a GPU')
+        dp = getattr(trainer, 'data_parallel', None)
+        if dp is not None and not dp.capturable:
+            raise RuntimeError('the data-parallel transport of this trainer cannot be captured into a HIP graph')
         self.trainer = trainer
         self.hyper = self.hyper_of(trainer)
         self.static = tuple(t.clone() for t in trainer.process_batch_data(example_batch))
@@ -100,15 +76,16 @@ class GraphedStep:
                     for _ in range(warmup):
                         self._eager()
                 torch.cuda.current_stream().wait_stream(side)
-                graph = Segments(self.static[0].device)
-                dp = getattr(trainer, 'data_parallel', None)
-                if dp is not None:
-                    dp.capture_splitter = graph              # its collectives cut the capture instead of being recorded
+                graph = Capture(self.static[0].device, thread_local=dp is not None)
+                error = None
                 try:
                     out = graph.capture(self._eager)
-                finally:
-                    if dp is not None:
-                        dp.capture_splitter = None
+                except RuntimeError as e:
+                    error = e
+                if dp is not None and not dp.all_agree(error is None):       # every rank replays, or none does
+                    raise RuntimeError(f'graph capture failed on {"this" if error is not None else "another"} rank: {error}')
+                if error is not None:
+                    raise error
                 # the loss terms of THIS variant's step live in its own static buffers (trainer.last_terms is rebound by
                 # every capture and by every eager step)
                 self.graphs[variant] = (graph, out, dict(getattr(trainer, 'last_terms', {}) or {}))

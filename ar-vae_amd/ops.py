@@ -241,6 +241,11 @@ def _defer_dense_wgrad(link, n, gop, keep, x, dw, db):
     return True
 
 
+# bumped by every gradient the kernels add straight into a parameter's `.grad` buffer (autograd gets None back, so the
+# optimizer's post-accumulate hooks do not fire): FlatAdam compares it with the value it saw at its last step()
+GRAD_WRITE_EPOCH = [0]
+
+
 def _grad_target(param):
     """Where a parameter gradient is accumulated.  When the parameter already owns a `.grad` buffer (the
     trainer's flat gradient arena after zero_grad()), the kernels add straight into it and autograd gets
@@ -248,6 +253,7 @@ def _grad_target(param):
     returned through autograd as usual."""
     g = param.grad
     if g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.device == param.device:
+        GRAD_WRITE_EPOCH[0] += 1          # no AccumulateGrad (hence no hook) will run for this write: optim.FlatAdam looks here
         return g, True
     return torch.zeros_like(param), False
 

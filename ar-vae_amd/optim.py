@@ -8,7 +8,8 @@ view into a matching gradient arena, so
   zero_grad()  = one memset -- or nothing: step() clears the gradient arena in the kernel that consumes it
                  (`zero_grads_in_step`, on by default), and the zero_grad() that follows a step has nothing left to do
                  unless a backward pass ran in between (every backward marks the arena dirty: the fused executor
-                 directly, torch's own accumulation through a post-accumulate hook on each parameter).
+                 through mark_dirty(), torch's own accumulation through a post-accumulate hook on each parameter, the
+                 per-layer kernels that add straight into `.grad` through ops.GRAD_WRITE_EPOCH).
                  NOTE for callers that look at gradients AFTER step(): they read zeros, where torch.optim.Adam leaves
                  the last gradient in place (the reference never does: utils/trainer.py:126-147 reads nothing after
                  step()); FlatAdam(..., zero_grads_in_step=False) keeps torch's behaviour.
@@ -30,6 +31,7 @@ class FlatAdam:
         self.grad_scale = 1.0          # set to 1/world_size when gradients are SUM all-reduced
         self.zero_grads_in_step = bool(zero_grads_in_step)
         self._arena_clean = False      # the gradient arena is all zeros (set by step(), cleared by any backward pass)
+        self._write_epoch = -1         # ops.GRAD_WRITE_EPOCH at the last step(): direct writes since then dirty the arena
         self._hooked = False
         self.param_arena = self.grad_arena = self.exp_avg = self.exp_avg_sq = None
         self._offsets = []
@@ -65,7 +67,7 @@ class FlatAdam:
                     self.exp_avg[off:off + n].copy_(old_m[old_off[i]:old_off[i] + n])
                     self.exp_avg_sq[off:off + n].copy_(old_v[old_off[i]:old_off[i] + n])
         self.param_arena, self.grad_arena, self._offsets = arena, grads, offsets
-        self._arena_clean = True
+        self._arena_clean, self._write_epoch = True, ops.GRAD_WRITE_EPOCH[0]
         if not self._hooked:           # torch's own gradient accumulation (per-layer autograd path) dirties the arena
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._on_accumulate)
@@ -86,7 +88,8 @@ class FlatAdam:
     # -- torch.optim.Optimizer surface used by the trainer --------------------------------------
     def zero_grad(self, set_to_none=False):
         self.ensure_arena()
-        if not (self._arena_clean and not torch.cuda.is_current_stream_capturing()):
+        clean = self._arena_clean and self._write_epoch == ops.GRAD_WRITE_EPOCH[0]
+        if not (clean and not torch.cuda.is_current_stream_capturing()):
             self.grad_arena.zero_()    # (a step being captured always records the memset: replays must not depend on what
         self._arena_clean = False      # ran before them; and whoever follows may write gradients without telling us)
         for p, off in zip(self.params, self._offsets):     # re-attach views dropped by zero_grad(None) users
@@ -104,6 +107,7 @@ class FlatAdam:
         ops.adam_step(self.param_arena, self.grad_arena, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
                       self.betas[0], self.betas[1], self.eps, self.grad_scale, zero_grad=self.zero_grads_in_step)
         self._arena_clean = self.zero_grads_in_step
+        self._write_epoch = ops.GRAD_WRITE_EPOCH[0]
 
     def state_dict(self):
         return {'step': self.step_count, 'lr': self.lr, 'betas': self.betas, 'eps': self.eps,

@@ -1,7 +1,7 @@
-"""Data-parallel AR-VAE step: one process per GPU, RCCL (torch.distributed 'nccl') over xGMI.
+"""Data-parallel AR-VAE step: one process per GPU, RCCL over xGMI, the collectives owned by libarvae_hip.so.
 
 The reference is single-process; this layer is new.  The minibatch is sharded
-by rows; the model is replicated.  Per step there are exactly two collectives:
+by rows; the model is replicated.  Per step there are exactly two exchanges:
 
   1. all-gather of the regularised latent/label columns (2 * B_local * R floats per rank, ~20 KB): the
      attribute-regularisation loss averages over ALL N_global^2 pairs (utils/trainer.py:390-401), so
@@ -17,15 +17,232 @@ beta*|mean_r(KL_r) - c| is not shard-linear (utils/train
 the scalar KL mean (4 bytes, a third collective) and each uses the shifted capacity c_r = c + KL_r - KL_global, so
 that KL_r - c_r = KL_global - c: the value of the term is the global one on every rank and its gradient carries the
 global sign (`shifted_capacity`).
+
+Transport.  `LibraryComm` (the default on GPUs) issues every collective through the library's C-ABI (`arvae_comm_*`,
+include/arvae_hip.h): plain RCCL calls on the launch stream, like the kernels around them.  There is no torch process
+group in such a run, hence no watchdog thread next to a HIP-graph capture, no Work objects to poll, and the collectives
+are RECORDED by a capture (ar-vae_amd/graphed.py: a data-parallel MeasureVAE step is one graph).  Ranks find each other
+through the launcher's TCP store (MASTER_ADDR / MASTER_PORT, `torch.distributed.rendezvous('env://')`), used once to hand
+out RCCL's unique id.  `TorchComm` wraps an initialised torch.distributed group instead: what the CPU tests run on (gloo),
+and an alternative on GPUs (`ARVAE_DP_TRANSPORT=torch`); its collectives cannot be captured, so steps stay eager there.
 """
+import ctypes
+import os
+
 import torch
-import torch.distributed as dist
+
+from . import _lib
+
+_DTYPES = {torch.float32: 0, torch.float64: 1, torch.int64: 2, torch.uint8: 3}
+_OPS = {'sum': 0, 'max': 1, 'min': 2}
+
+
+class _StreamJoin:
+    """what an asynchronous collective of LibraryComm returns: work enqueued on the stream that was current at the call;
+    wait() makes the stream current THEN wait for it (same meaning as torch's Work.wait() for a device collective)"""
+
+    def __init__(self):
+        self.event = torch.cuda.Event()
+        self.event.record(torch.cuda.current_stream())
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
+
+
+class LibraryComm:
+    """RCCL communicator owned through libarvae_hip.so (arvae_comm_*).  Collectives take contiguous device tensors and are
+    enqueued on torch's CURRENT stream; nothing here synchronises except barrier()."""
+    capturable = True
+
+    def __init__(self, rank, world, store=None, device=None, key='arvae/comm/0'):
+        if not torch.cuda.is_available():
+            raise RuntimeError('LibraryComm needs a GPU: the collectives of the HIP path have no CPU fallback')
+        self.lib = _lib.load()
+        version = self.lib.arvae_comm_available()
+        if version < 0:
+            _lib.check(version, 'comm_available')
+        self.rccl_version = version
+        self.rank, self.world_size = int(rank), int(world)
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        torch.cuda.set_device(self.device)
+        nbytes = 128
+        if self.rank == 0:
+            buf = (ctypes.c_char * nbytes)()
+            _lib.check(self.lib.arvae_comm_unique_id(buf), 'comm_unique_id')
+            ident = bytes(buf)
+            if self.world_size > 1:
+                store.set(key, ident)
+        else:
+            ident = bytes(store.get(key))                       # blocks until rank 0 has published it
+        if len(ident) != nbytes:
+            raise RuntimeError('bad RCCL unique id from the store')
+        handle = ctypes.c_void_p()
+        _lib.check(self.lib.arvae_comm_init(ident, self.rank, self.world_size, ctypes.byref(handle)), 'comm_init')
+        self.handle = handle
+        self.store = store                                      # rank 0 hosts it: alive as long as the communicator
+
+    # -- collectives ---------------------------------------------------------------------------------------------
+    @staticmethod
+    def _stream():
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def _typed(self, t):
+        if not t.is_cuda or not t.is_contiguous():
+            raise ValueError('collectives take contiguous device tensors')
+        code = _DTYPES.get(t.dtype)
+        if code is None:                                        # moved as bytes (all-gather / broadcast only)
+            return t.view(torch.uint8), 3, False
+        return t, code, True
+
+    def all_gather(self, out, local):
+        """out[W * n, ...] (rank-major) <- every rank's local[n, ...]"""
+        if out.numel() != self.world_size * local.numel() or out.dtype != local.dtype:
+            raise ValueError('all_gather: out must hold world_size x local')
+        src, code, _ = self._typed(local)
+        dst, _, _ = self._typed(out)
+        _lib.check(self.lib.arvae_comm_all_gather(self.handle, src.data_ptr(), dst.data_ptr(), src.numel(), code,
+                                                  self._stream()), 'comm_all_gather')
+        return out
+
+    def all_gather_many(self, pairs):
+        """[(out, local), ...] as ONE RCCL launch"""
+        _lib.check(self.lib.arvae_comm_group_begin(), 'comm_group_begin')
+        try:
+            for out, local in pairs:
+                self.all_gather(out, local)
+        finally:
+            _lib.check(self.lib.arvae_comm_group_end(), 'comm_group_end')
+
+    def all_reduce(self, t, op='sum'):
+        buf, code, arithmetic = self._typed(t)
+        if not arithmetic:
+            raise ValueError(f'all_reduce: unsupported dtype {t.dtype}')
+        _lib.check(self.lib.arvae_comm_all_reduce(self.handle, buf.data_ptr(), buf.numel(), code, _OPS[op], self._stream()),
+                   'comm_all_reduce')
+        return t
+
+    def all_reduce_async(self, t, op='sum'):
+        self.all_reduce(t, op)
+        return _StreamJoin()
+
+    def all_gather_async(self, out, local):
+        self.all_gather(out, local)
+        return _StreamJoin()
+
+    def broadcast(self, t, src=0):
+        buf, code, _ = self._typed(t)
+        _lib.check(self.lib.arvae_comm_broadcast(self.handle, buf.data_ptr(), buf.numel(), code, int(src), self._stream()),
+                   'comm_broadcast')
+        return t
+
+    def barrier(self):
+        """every rank has reached this point and this device is idle"""
+        token = torch.zeros(1, device=self.device, dtype=torch.float32)
+        self.all_reduce(token)
+        torch.cuda.synchronize(self.device)
+        self.check()
+
+    def check(self):
+        """raises once the communicator has failed asynchronously (a peer died mid-collective)"""
+        _lib.check(self.lib.arvae_comm_async_error(self.handle), 'communicator')
+
+    def close(self):
+        if self.handle is not None:
+            torch.cuda.synchronize(self.device)
+            handle, self.handle = self.handle, None
+            _lib.check(self.lib.arvae_comm_destroy(handle), 'comm_destroy')
+
+
+class TorchComm:
+    """the same collectives over an initialised torch.distributed process group (gloo on CPU in tests/test_parallel_gloo.py,
+    'nccl' = RCCL as an alternative on GPUs).  Not capturable: a step over this transport runs eagerly."""
+    capturable = False
+
+    def __init__(self, process_group=None):
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError('torch.distributed is not initialised')
+        self.dist, self.group = dist, process_group
+        self.world_size, self.rank = dist.get_world_size(process_group), dist.get_rank(process_group)
+        on_gpu = dist.get_backend(process_group) == 'nccl'
+        self.device = torch.device('cuda', torch.cuda.current_device()) if on_gpu else torch.device('cpu')
+        self._owns_group = False
+
+    def _op(self, op):
+        return {'sum': self.dist.ReduceOp.SUM, 'max': self.dist.ReduceOp.MAX, 'min': self.dist.ReduceOp.MIN}[op]
+
+    def all_gather(self, out, local):
+        self.dist.all_gather_into_tensor(out, local, group=self.group)
+        return out
+
+    def all_gather_async(self, out, local):
+        return self.dist.all_gather_into_tensor(out, local, group=self.group, async_op=True)
+
+    def all_gather_many(self, pairs):
+        for out, local in pairs:
+            self.all_gather(out, local)
+
+    def all_reduce(self, t, op='sum'):
+        self.dist.all_reduce(t, op=self._op(op), group=self.group)
+        return t
+
+    def all_reduce_async(self, t, op='sum'):
+        return self.dist.all_reduce(t, op=self._op(op), group=self.group, async_op=True)
+
+    def broadcast(self, t, src=0):
+        self.dist.broadcast(t, src=self.dist.get_global_rank(self.group, src) if self.group is not None else src, group=self.group)
+        return t
+
+    def barrier(self):
+        self.dist.barrier(group=self.group)
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    def check(self):
+        pass
+
+    def close(self):
+        if self._owns_group and self.group is None and self.dist.is_initialized():
+            self.dist.destroy_process_group()
+
+
+def _rendezvous_store(rank, world):
+    """the launcher's key-value store: torch.distributed.run's agent store when there is one (TORCHELASTIC_USE_AGENT_STORE),
+    else a TCP store rank 0 hosts at MASTER_ADDR:MASTER_PORT.  No process group is created."""
+    from torch.distributed import rendezvous
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    store, got_rank, got_world = next(iter(rendezvous('env://', rank=rank, world_size=world)))
+    return store
+
+
+def connect(rank=None, world=None, device=None, transport=None, key='arvae/comm/0'):
+    """-> LibraryComm (default) or TorchComm for this process's rank; RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the
+    environment when not given.  Binds the process to its GPU first."""
+    rank = int(os.environ.get('RANK', '0')) if rank is None else int(rank)
+    world = int(os.environ.get('WORLD_SIZE', '1')) if world is None else int(world)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC only on this pool (RCCL needs it)
+    if device is None:
+        device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+    torch.cuda.set_device(device)
+    transport = transport or os.environ.get('ARVAE_DP_TRANSPORT', 'library')
+    if transport == 'torch':
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if not dist.is_initialized():
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(device))
+        comm = TorchComm()
+        comm._owns_group = True
+        return comm
+    if transport != 'library':
+        raise ValueError(f'unknown data-parallel transport {transport!r}')
+    store = _rendezvous_store(rank, world) if world > 1 else None
+    return LibraryComm(rank, world, store, device, key=key)
 
 
 def init_from_env():
-    """Under torch.distributed.run (WORLD_SIZE > 1): bind this process to its GPU (LOCAL_RANK), join the RCCL process group
-    and return a DataParallel; otherwise None.  What the training CLIs call before they build the dataset and the model."""
-    import os
+    """Under torch.distributed.run (WORLD_SIZE > 1): bind this process to its GPU (LOCAL_RANK), join the job's RCCL
+    communicator and return a DataParallel; otherwise None.  What the training CLIs call before they build the dataset and
+    the model."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world <= 1 and os.environ.get('ARVAE_FORCE_DP', '0') != '1':      # ARVAE_FORCE_DP=1: the same code path on one rank (tests)
         return None
@@ -33,32 +250,28 @@ def init_from_env():
         os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
-    local = int(os.environ.get('LOCAL_RANK', '0'))
-    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC only on this pool (RCCL needs it)
-    device = torch.device('cuda', local)
-    torch.cuda.set_device(device)
-    if not dist.is_initialized():
-        dist.init_process_group('nccl', device_id=device)
-    return DataParallel()
+    return DataParallel(comm=connect())
 
 
 class DataParallel:
-    def __init__(self, process_group=None, reg_fn=None):
-        if not dist.is_initialized():
-            raise RuntimeError('torch.distributed is not initialised')
-        self.group = process_group
-        self.world_size = dist.get_world_size(process_group)
-        self.rank = dist.get_rank(process_group)
+    def __init__(self, process_group=None, reg_fn=None, comm=None):
+        """comm: a LibraryComm / TorchComm (`connect()`); without one, the initialised torch.distributed group
+        `process_group` (None = the default group) is wrapped in a TorchComm."""
+        self.comm = comm if comm is not None else TorchComm(process_group)
+        self.world_size, self.rank = self.comm.world_size, self.comm.rank
         from . import ops
         if reg_fn is None:
             reg_fn = ops.reg_loss
         self._reg_fn = reg_fn
         self._dims_cache = {}
-        self.capture_splitter = None         # graphed.Segments while a step is being captured: collectives cut the capture
         self._pending = []                   # all-reduces of gradient buckets started during the backward pass (fused.py)
         self.remaining_buckets = None        # float ranges of the arena those do not cover
         ops.rng_set_rank(self.rank)          # per-rank eps / dropout streams (SURVEY.md section 8(e), "RNG under DP")
+
+    @property
+    def capturable(self):
+        """may a step with this object's collectives be captured into a HIP graph?"""
+        return self.comm.capturable
 
     def attach(self, trainer):
         """make `trainer` data-parallel (its loss step gathers columns, its step() all-reduces); returns self"""
@@ -68,16 +281,21 @@ class DataParallel:
         return self
 
     def finish(self):
-        """all ranks are done training: leave the process group (after this, rank 0 may evaluate for as long as it likes --
-        nobody waits in a collective that the group's watchdog would time out)"""
-        dist.barrier(group=self.group)
-        if self.group is None:
-            dist.destroy_process_group()
+        """all ranks are done training: leave the job (after this, rank 0 may evaluate for as long as it likes -- nobody
+        waits in a collective)"""
+        self.comm.barrier()
+        self.comm.close()
 
     def broadcast_parameters(self, model, src=0):
         """Make every replica start from rank `src`'s weights."""
         for p in model.parameters():
-            dist.broadcast(p.data, src=src, group=self.group)
+            self.comm.broadcast(p.data, src=src)
+
+    def all_agree(self, ok):
+        """True iff `ok` holds on EVERY rank (one MIN all-reduce of a flag): how ranks take a decision together"""
+        flag = torch.full((1,), 1.0 if ok else 0.0, dtype=torch.float32, device=self.comm.device)
+        self.comm.all_reduce(flag, 'min')
+        return bool(flag.item() > 0.5)
 
     def gather_columns(self, local, async_op=None, out=None):
         """(B_local, R) -> (W * B_local, R), rank-major row order.  With async_op the collective is only enqueued:
@@ -87,13 +305,17 @@ class DataParallel:
         if out is None:
             out = torch.empty((self.world_size * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype,
                               device=local.device)
-        if self.capture_splitter is not None and self.capture_splitter.capturing:
-            # a step is being captured into HIP graphs (graphed.py): the collective is not recorded; the capture is cut here
-            # and the collective runs eagerly between the two graphs, now and on every replay, on these same buffers
-            self.capture_splitter.split(lambda: dist.all_gather_into_tensor(out, local, group=self.group))
-            return out if async_op is None else (out, None)
-        work = dist.all_gather_into_tensor(out, local, group=self.group, async_op=bool(async_op))
-        return out if async_op is None else (out, work if async_op else None)
+        if async_op:
+            return out, self.comm.all_gather_async(out, local)
+        self.comm.all_gather(out, local)
+        return out if async_op is None else (out, None)
+
+    def gather_many(self, locals_):
+        """several (B_local, *) tensors -> their (W * B_local, *) gathers, one launch where the transport can"""
+        locals_ = [t.contiguous() for t in locals_]
+        outs = [torch.empty((self.world_size * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in locals_]
+        self.comm.all_gather_many(list(zip(outs, locals_)))
+        return outs
 
     def reg_loss(self, z, labels, dims, gamma, delta):
         """W * (row-block regularisation loss of this rank's samples against the global batch)."""
@@ -119,7 +341,7 @@ class DataParallel:
     def start_bucket(self, arena, lo, hi):
         """enqueue the SUM all-reduce of arena[lo:hi] on the CURRENT stream without waiting for it (the fused backward calls
         this on its side stream, behind the event that says the bucket is final); reduce_gradients() joins it"""
-        self._pending.append(dist.all_reduce(arena[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._pending.append(self.comm.all_reduce_async(arena[lo:hi]))
 
     def reduce_gradients(self, optimizer):
         """SUM all-reduce of the flat gradient arena; Adam then applies 1/W.  Buckets whose all-reduce was started during
@@ -127,19 +349,22 @@ class DataParallel:
         optimizer.ensure_arena()
         if self._pending:
             for lo, hi in self.remaining_buckets or ():
-                dist.all_reduce(optimizer.grad_arena[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+                self.comm.all_reduce(optimizer.grad_arena[lo:hi])
             for work in self._pending:
                 work.wait()                                      # the launch stream waits for the side stream's collectives
             self._pending, self.remaining_buckets = [], None
         else:
-            dist.all_reduce(optimizer.grad_arena, op=dist.ReduceOp.SUM, group=self.group)
+            self.comm.all_reduce(optimizer.grad_arena)
         optimizer.grad_scale = 1.0 / self.world_size
 
     def mean_scalar(self, value):
         """average a scalar tensor over ranks."""
         v = value.detach().clone().reshape(1)
-        if self.capture_splitter is not None and self.capture_splitter.capturing:       # see gather_columns
-            self.capture_splitter.split(lambda: dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group))
-        else:
-            dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
+        self.comm.all_reduce(v)
         return v / self.world_size
+
+    def mean_stats(self, values, device):
+        """host floats -> their means over ranks (epoch statistics: one float64 all-reduce)"""
+        stats = torch.tensor(list(values), dtype=torch.float64, device=device)
+        self.comm.all_reduce(stats)
+        return (stats / self.world_size).tolist()

@@ -45,7 +45,7 @@ class Trainer(ABC):
             # batch_size is the PER-GPU batch (weak scaling, as bench.py): every rank iterates its own rows of the same
             # shuffled global batches (data/loaders.py)
             train_loader, val_loader, _ = self.dataset.data_loaders(batch_size=batch_size, split=(0.70, 0.20),
-                                                                    shard=(dp.rank, dp.world_size, dp.group))
+                                                                    shard=(dp.rank, dp.world_size, dp.comm))
             dp.broadcast_parameters(self.model)
         else:
             train_loader, val_loader, _ = self.dataset.data_loaders(batch_size=batch_size, split=(0.70, 0.20))
@@ -60,11 +60,8 @@ class Trainer(ABC):
             with torch.no_grad():
                 loss_va, acc_va = self.loss_and_acc_on_epoch(val_loader, epoch_num=epoch, train=False)
             if dp is not None:                                   # epoch means over the global batch
-                stats = torch.tensor([loss_tr, acc_tr, loss_va, acc_va], dtype=torch.float64,
-                                     device=next(self.model.parameters()).device)
-                import torch.distributed as dist
-                dist.all_reduce(stats, group=dp.group)
-                loss_tr, acc_tr, loss_va, acc_va = (stats / dp.world_size).tolist()
+                loss_tr, acc_tr, loss_va, acc_va = dp.mean_stats([loss_tr, acc_tr, loss_va, acc_va],
+                                                                 next(self.model.parameters()).device)
             if not chief:
                 continue
             self.eval_model(data_loader=val_loader, epoch_num=epoch)
@@ -79,7 +76,8 @@ class Trainer(ABC):
     # Training steps replayed from HIP graphs (ar-vae_amd/graphed.py).  Worth it where the step is many small launches and
     # the host sets the pace (MeasureVAE: 3.9 -> 1.5 ms per step); subclasses switch it on.  Batches of another shape
     # (the last one of an epoch) and CPU models take the eager path; changing beta / gamma / delta / reg_dim (e.g. from
-    # update_scheduler) re-captures.  Data-parallel steps replay too: the capture is cut at their collectives (graphed.py).
+    # update_scheduler) re-captures.  Data-parallel steps replay too when their collectives are the library's (recorded by
+    # the capture like any launch, parallel.LibraryComm); over torch.distributed (parallel.TorchComm) they stay eager.
     use_graph_replay = False
 
     def _replay_step(self, batch):
@@ -87,6 +85,8 @@ class Trainer(ABC):
         if not self.use_graph_replay or not torch.cuda.is_available():
             return None
         if not next(self.model.parameters()).is_cuda:
+            return None
+        if self.data_parallel is not None and not self.data_parallel.capturable:
             return None
         from .graphed import GraphedStep
         graphed = getattr(self, '_graphed', None)
@@ -96,8 +96,8 @@ class Trainer(ABC):
             self.model.train()
             try:
                 graphed = self._graphed = GraphedStep(self, batch)
-            except RuntimeError as e:                          # capture not possible here: stay eager from now on
-                print(f'graph replay disabled: {e}')
+            except RuntimeError as e:                          # capture not possible here: stay eager from now on (under data
+                print(f'graph replay disabled: {e}')           # parallelism GraphedStep raises on EVERY rank or on none)
                 self.use_graph_replay = False
                 return None
         data = graphed.accepts(batch)                          # processed once; None = a batch of another shape (the last one

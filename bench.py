@@ -232,22 +232,23 @@ def spawn_ranks(n, argv, script=None, gpu_count=visible_gpu_count, out=None):
 class Fence:
     """barrier + torch.cuda.synchronize() on both sides; max over ranks of a host-measured duration."""
 
-    def __init__(self, device, use_dp):
-        self.device, self.use_dp = device, use_dp
+    def __init__(self, device, comm):
+        self.device, self.comm = device, comm            # comm: arvae_amd.parallel.LibraryComm / TorchComm, None = one process
+
+    @property
+    def use_dp(self):
+        return self.comm is not None
 
     def __call__(self):
         torch.cuda.synchronize()
-        if self.use_dp:
-            import torch.distributed as dist
-            dist.barrier()
-            torch.cuda.synchronize()
+        if self.comm is not None:
+            self.comm.barrier()                          # a one-element all-reduce + synchronize: every rank is here and idle
 
     def max_over_ranks(self, seconds):
-        if not self.use_dp:
+        if self.comm is None:
             return seconds
-        import torch.distributed as dist
         t = torch.tensor([seconds], device=self.device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        self.comm.all_reduce(t, 'max')
         return float(t)
 
 
@@ -300,6 +301,9 @@ def kernel_profile(step, n_steps):
 
 
 # ---- workloads ----------------------------------------------------------------------------------------------------------
+COMM = None            # the job's communicator (main() connects it when there is more than one rank or --force-dp)
+
+
 def build_trainer(device, use_dp):
     from arvae_amd import synthetic as syn
     from arvae_amd.image_vae import DspritesVAE
@@ -313,7 +317,7 @@ def build_trainer(device, use_dp):
     trainer.capacity = trainer.capacity.to(device)
     if use_dp:
         from arvae_amd.parallel import DataParallel
-        DataParallel().attach(trainer)
+        DataParallel(comm=COMM).attach(trainer)
     model.train()
     return trainer, state
 
@@ -344,7 +348,7 @@ def build_side_workload(kind, device, batch, rank=0, use_dp=False, graphs=False)
         data = (score, score)
     if use_dp:
         from arvae_amd.parallel import DataParallel
-        dp = DataParallel()
+        dp = DataParallel(comm=COMM)
         dp.attach(trainer)
         dp.broadcast_parameters(model)
     model.train()
@@ -618,6 +622,7 @@ def run_dsprites(device, args, fence, rank, world, use_dp):
                    'per_gpu_batch': b, 'global_batch': b * world,
                    'parallelism': f'dp{world}' + (' (forced DP path)' if args.force_dp and world == 1 else ''),
                    'rccl_world_size': world if use_dp else None,
+                   'collectives': None if COMM is None else type(COMM).__name__ + (' (RCCL %d via libarvae_hip.so, launch stream)' % COMM.rccl_version if hasattr(COMM, 'rccl_version') else ' (torch.distributed nccl group)'),
                    'images_per_sec_per_gpu': per_gpu, 'final_loss': final_loss},
         'timing': timing,
         'roofline': roof,
@@ -678,13 +683,15 @@ def main():
         sys.stdout.flush()
         out_fd = os.dup(1)
         os.dup2(2, 1)
-        import torch.distributed as dist
+        # the job's RCCL communicator, owned through libarvae_hip.so (arvae_comm_*): the ranks meet at the launcher's TCP
+        # store (MASTER_ADDR / MASTER_PORT) to hand out RCCL's unique id; no torch process group (ARVAE_DP_TRANSPORT=torch
+        # selects torch.distributed's 'nccl' group instead)
+        global COMM
+        from arvae_amd import parallel
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
-        os.environ.setdefault('RANK', '0')
-        os.environ.setdefault('WORLD_SIZE', '1')
-        dist.init_process_group('nccl', device_id=device)
-    fence = Fence(device, use_dp)
+        COMM = parallel.connect(rank, world, device)
+    fence = Fence(device, COMM)
 
     if args.workload != 'dsprites':
         line = run_side(args.workload, device, args, fence, rank, world, use_dp, with_cpu=world == 1 and not args.no_cpu_baseline)
@@ -705,9 +712,9 @@ def main():
             print(json.dumps(line), flush=True)
         else:
             os.write(out_fd, (json.dumps(line) + '\n').encode())
-    if use_dp:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    if COMM is not None:
+        COMM.barrier()
+        COMM.close()
 
 
 if __name__ == '__main__':

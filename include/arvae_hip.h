@@ -27,12 +27,13 @@
 extern "C" {
 #endif
 
-#define ARVAE_ABI_VERSION 6   /* 6: the 32-channel k4 s2 p1 links need caller workspace too (arvae_link_ws_floats / arvae_link_wgrad_ws_floats: the layer's weights as scaled fp16 terms and the operands' maxima); 5: arvae_adam_step(zero_grad), arvae_image_vae_finish, arvae_image_vae_t.milestones (events the executors record for the data-parallel caller's collectives); 4: arvae_philox_* and in-kernel eps (arvae_image_vae_t.rng_*), arvae_tick_free_run_supported, caller workspace for arvae_link_down/up (arvae_link_ws_floats); 3: arvae_gru_seq_*, embed_bwd workspace; 2: arvae_image_vae_backward reg_fused == 2 (unit regulariser gradient in dz_extra) */
+#define ARVAE_ABI_VERSION 7   /* 7: arvae_comm_* (the data-parallel step's collectives: RCCL on the launch stream, owned by the library); 6: the 32-channel k4 s2 p1 links need caller workspace too (arvae_link_ws_floats / arvae_link_wgrad_ws_floats: the layer's weights as scaled fp16 terms and the operands' maxima); 5: arvae_adam_step(zero_grad), arvae_image_vae_finish, arvae_image_vae_t.milestones (events the executors record for the data-parallel caller's collectives); 4: arvae_philox_* and in-kernel eps (arvae_image_vae_t.rng_*), arvae_tick_free_run_supported, caller workspace for arvae_link_down/up (arvae_link_ws_floats); 3: arvae_gru_seq_*, embed_bwd workspace; 2: arvae_image_vae_backward reg_fused == 2 (unit regulariser gradient in dz_extra) */
 
 #define ARVAE_OK 0
 #define ARVAE_E_INVALID (-1)  /* bad argument (null pointer, size out of range, unsupported shape) */
 #define ARVAE_E_LAUNCH (-2)   /* hipLaunch / runtime error; text in arvae_last_error_string()        */
 #define ARVAE_E_NODEVICE (-3) /* no HIP device visible to this process                              */
+#define ARVAE_E_COMM (-4)     /* RCCL missing or a collective / communicator call failed            */
 
 /* activation fused into a producing kernel / differentiated in a consuming one */
 #define ARVAE_ACT_NONE 0
@@ -455,6 +456,55 @@ int arvae_philox_keep_mask(uint8_t *out, int64_t count, float keep_prob, uint64_
 int arvae_count_nonfinite(const float *values, int64_t count, int32_t *flag, arvae_stream_t stream);
 int arvae_count_out_of_range(const int64_t *indices, int64_t count, int64_t lo, int64_t hi, int32_t *flag,
                              arvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Data-parallel exchange of a row-sharded training step (the reference is single-process, so
+ * there is no call site to replace -- these run where the sharded step needs what the reference reads from one batch):
+ *   - all-gather of the regularised latent / label columns: the attribute term averages over ALL pairs of the global batch
+ *     (Trainer.reg_loss_sign, utils/trainer.py:378-403), each rank evaluates its row block against the gathered columns;
+ *   - SUM all-reduce of the flat gradient arena between loss.backward() and optimizer.step() (utils/trainer.py:140-147),
+ *     arvae_adam_step then applies 1 / world through grad_scale;
+ *   - broadcast of rank 0's parameters / shuffling order when training starts (utils/trainer.py:39-64 builds them on one
+ *     process), MAX / MIN reductions for timing and for agreeing on a fallback.
+ * The collectives are RCCL calls enqueued on `stream` like any kernel of this library: nothing synchronises, nothing is
+ * polled by a helper thread, and a stream capture records them into the same HIP graph as the kernels around them.
+ * RCCL is resolved at run time (the librccl.so.1 already loaded in the process, else the system one): a single-GPU
+ * process never loads it.  One communicator = one device; every rank of the job calls arvae_comm_init together.
+ * A communicator is caller-owned state (create / destroy), not library state.
+ *
+ *   arvae_comm_available  -> RCCL's version code (> 0) or ARVAE_E_COMM with the reason in arvae_last_error_string()
+ *   arvae_comm_unique_id  -> ARVAE_COMM_ID_BYTES host bytes; rank 0 creates them, the caller's launcher (a TCP store, MPI, a
+ *                            file) hands them to every other rank
+ *   arvae_comm_init       -> blocks until all `world` ranks have joined, on the CURRENT HIP device
+ *   arvae_comm_async_error-> 0, or ARVAE_E_COMM once the communicator has failed asynchronously (a peer died)
+ * dtype: ARVAE_COMM_*; `count` in elements (per rank for the all-gather: recv holds world x count, rank-major).
+ * all_reduce and broadcast work in place.
+ * ------------------------------------------------------------------------------------------------ */
+#define ARVAE_COMM_ID_BYTES 128
+#define ARVAE_COMM_F32 0
+#define ARVAE_COMM_F64 1
+#define ARVAE_COMM_I64 2
+#define ARVAE_COMM_U8 3
+#define ARVAE_COMM_SUM 0
+#define ARVAE_COMM_MAX 1
+#define ARVAE_COMM_MIN 2
+typedef struct arvae_comm_s *arvae_comm_t;
+int arvae_comm_available(void);
+int arvae_comm_unique_id(void *id_out /* host */);
+int arvae_comm_init(const void *id /* host */, int32_t rank, int32_t world, arvae_comm_t *out /* host */);
+int arvae_comm_destroy(arvae_comm_t comm);
+int arvae_comm_abort(arvae_comm_t comm);
+int arvae_comm_rank(arvae_comm_t comm);
+int arvae_comm_world(arvae_comm_t comm);
+int arvae_comm_async_error(arvae_comm_t comm);
+int arvae_comm_all_gather(arvae_comm_t comm, const void *send, void *recv, int64_t count, int32_t dtype,
+                          arvae_stream_t stream);
+int arvae_comm_all_reduce(arvae_comm_t comm, void *buf, int64_t count, int32_t dtype, int32_t op, arvae_stream_t stream);
+int arvae_comm_broadcast(arvae_comm_t comm, void *buf, int64_t count, int32_t dtype, int32_t root, arvae_stream_t stream);
+/* the collectives enqueued by this thread between the two calls go out as ONE RCCL launch (ncclGroupStart / ncclGroupEnd):
+ * the z and the label all-gather of a step */
+int arvae_comm_group_begin(void);
+int arvae_comm_group_end(void);
 
 #ifdef __cplusplus
 }

@@ -1,8 +1,10 @@
 """One rank of the data-parallel MeasureVAE graph-replay test (tests/test_parallel_gpu.py): the rank's rows of a fixed batch go
-through ONE training step twice -- eagerly and replayed from HIP graphs cut at the step's collective (graphed.Segments) --
-with arvae_amd.parallel attached; rank 0 saves both results.
+through ONE training step twice -- eagerly and replayed from a HIP graph that holds the step's collective (the library's RCCL
+all-gather, recorded like a kernel) -- with arvae_amd.parallel attached; rank 0 saves both results.
 
-    python tests/dp_measure_worker.py <rank> <world> <port> <out.npz> <batch_total>
+    python tests/dp_measure_worker.py <rank> <world> <port> <out.npz> <batch_total> [<repeats>]
+
+repeats > 1: capture + replay that many times in this process (the stress loop of tools/dp_replay_loop.sh).
 """
 import os
 import sys
@@ -22,11 +24,12 @@ class FolkDataset:
 
 def main():
     rank, world, port, out, b_total = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5])
+    repeats = int(sys.argv[6]) if len(sys.argv) > 6 else 1
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     import numpy as np
     import torch
-    import torch.distributed as dist
+    from arvae_amd import parallel
     from arvae_amd import synthetic as syn
     from arvae_amd.graphed import GraphedStep
     from arvae_amd.measure_vae import MeasureVAE
@@ -35,7 +38,7 @@ def main():
     from oracle import measure_vae as o_mvae
     dev = torch.device('cuda', rank)
     torch.cuda.set_device(dev)
-    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    comm = parallel.connect(rank, world, dev)
     try:
         ds = FolkDataset()
         state = syn.synth_state(o_mvae.shapes(), 4)
@@ -44,7 +47,7 @@ def main():
         trainer = MeasureVAETrainer(ds, model, lr=1e-4, reg_type=('all',), reg_dim=(0, 1, 2, 3), beta=0.001, gamma=1.0,
                                     capacity=0.0, rand=0, delta=10.0)
         trainer.cuda()
-        dp = DataParallel().attach(trainer)
+        dp = DataParallel(comm=comm).attach(trainer)
         model.train()
         model.decoder.teacher_forcing_prob = 2.0
         bl = b_total // world
@@ -61,11 +64,12 @@ def main():
             dp.reduce_gradients(trainer.optimizer)
             res['eager'] = (float(dp.mean_scalar(loss.detach())), trainer.optimizer.grad_arena.clone() * trainer.optimizer.grad_scale)
             # the same step replayed from graphs (twice: a replay must not depend on what the capture left behind)
-            graphed = GraphedStep(trainer, (score, score))
-            segs = {k: (len(v[0].graphs), len(v[0].between)) for k, v in graphed.graphs.items()}
-            for _ in range(2):
-                loss_g, _ = graphed((score, score))
-                dp.reduce_gradients(trainer.optimizer)
+            for _ in range(repeats):
+                graphed = GraphedStep(trainer, (score, score))
+                for _ in range(2):
+                    loss_g, _ = graphed((score, score))
+                    dp.reduce_gradients(trainer.optimizer)
+            variants = len(graphed.graphs)
             res['replay'] = (float(dp.mean_scalar(loss_g.detach())), trainer.optimizer.grad_arena.clone() * trainer.optimizer.grad_scale)
         finally:
             type(model.encoder).static_eps = None
@@ -76,11 +80,12 @@ def main():
             for p, off in zip(trainer.optimizer.params, trainer.optimizer._offsets):
                 sizes.append((off, p.numel()))
             names = [k for k, _ in model.named_parameters()]
-            np.savez(out, world=dist.get_world_size(), loss_eager=res['eager'][0], loss_replay=res['replay'][0],
+            np.savez(out, world=dp.world_size, variants=variants, transport=type(comm).__name__, loss_eager=res['eager'][0], loss_replay=res['replay'][0],
                      grad_eager=res['eager'][1].cpu().numpy(), grad_replay=res['replay'][1].cpu().numpy(),
-                     names=np.array(names), spans=np.array(sizes), segments=np.array(sorted(segs.values())))
+                     names=np.array(names), spans=np.array(sizes))
+        comm.barrier()
     finally:
-        dist.destroy_process_group()
+        comm.close()
 
 
 if __name__ == '__main__':

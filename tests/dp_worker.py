@@ -22,14 +22,14 @@ def main():
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     import numpy as np
     import torch
-    import torch.distributed as dist
+    from arvae_amd import parallel
     from arvae_amd import synthetic as syn
     from arvae_amd.image_vae import DspritesVAE
     from arvae_amd.image_vae_trainer import ImageVAETrainer
     from arvae_amd.parallel import DataParallel
     dev = torch.device('cuda', rank)
-    torch.cuda.set_device(dev)
-    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    # ARVAE_DP_TRANSPORT: 'library' (default: RCCL through libarvae_hip.so, no torch process group) | 'torch'
+    comm = parallel.connect(rank, world, dev)
     try:
         model = DspritesVAE()
         shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
@@ -39,7 +39,7 @@ def main():
                                   gamma=10.0, capacity=capacity, rand=0, delta=1.0)
         trainer.cuda()
         trainer.use_fused = fused
-        dp = DataParallel().attach(trainer)
+        dp = DataParallel(comm=comm).attach(trainer)
         dp.broadcast_parameters(model)
         model.train()
         x, lab = syn.dsprites_batch(b_total, seed=1234)
@@ -58,11 +58,12 @@ def main():
         terms = {k: float(dp.mean_scalar(v)) for k, v in trainer.last_terms.items() if v is not None}
         torch.cuda.synchronize()
         if rank == 0:
-            np.savez(out, loss=mean_loss, acc=mean_acc, world=dist.get_world_size(),
+            np.savez(out, loss=mean_loss, acc=mean_acc, world=dp.world_size, transport=type(comm).__name__,
                      **{'term/' + k: v for k, v in terms.items()}, **{'grad/' + k: v for k, v in grads.items()},
                      **{'param/' + k: p.detach().cpu().numpy() for k, p in model.named_parameters()})
+        comm.barrier()
     finally:
-        dist.destroy_process_group()
+        comm.close()
 
 
 if __name__ == '__main__':

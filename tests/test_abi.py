@@ -145,3 +145,34 @@ def test_state_dict_keys_match_reference_layout():
         assert all(tuple(sd[k].shape) == tuple(v) for k, v in shapes.items())
         assert sum(p.numel() for p in m.parameters()) == nparam
         assert [k for k, _ in m.named_parameters()] == list(shapes.keys())
+
+
+def test_comm_entry_points_without_a_gpu(lib):
+    """the data-parallel collectives' ABI (arvae_comm_*): RCCL is found at run time (the copy torch already loaded), a unique
+    id can be made on the host, and bad arguments / non-communicators are refused with a message -- no GPU is touched."""
+    version = lib.arvae_comm_available()
+    assert version > 20000, lib.arvae_last_error_string()                     # RCCL 2.x.y as 2xxyy
+    a, b = (ctypes.c_char * 128)(), (ctypes.c_char * 128)()
+    assert lib.arvae_comm_unique_id(a) == 0 and lib.arvae_comm_unique_id(b) == 0
+    assert bytes(a) != bytes(b) and bytes(a) != bytes(128)
+    assert lib.arvae_comm_unique_id(None) == -1
+    handle = ctypes.c_void_p()
+    assert lib.arvae_comm_init(bytes(a), 2, 2, ctypes.byref(handle)) == -1     # rank out of range: refused before RCCL is called
+    assert b'rank 2 of 2' in lib.arvae_last_error_string()
+    assert lib.arvae_comm_init(None, 0, 1, ctypes.byref(handle)) == -1
+    fake = ctypes.create_string_buffer(64)                                     # not a communicator: the magic word is missing
+    for call in (lambda: lib.arvae_comm_destroy(fake), lambda: lib.arvae_comm_rank(fake), lambda: lib.arvae_comm_world(fake),
+                 lambda: lib.arvae_comm_async_error(fake),
+                 lambda: lib.arvae_comm_all_reduce(fake, None, 0, 0, 0, None),
+                 lambda: lib.arvae_comm_all_gather(fake, None, None, 0, 0, None),
+                 lambda: lib.arvae_comm_broadcast(fake, None, 0, 0, 0, None)):
+        assert call() == -1
+
+
+def test_library_transport_needs_a_gpu():
+    """parallel.LibraryComm is the HIP path's transport: no CPU stand-in"""
+    if torch.cuda.is_available():
+        pytest.skip('CPU-only check')
+    from arvae_amd import parallel
+    with pytest.raises(RuntimeError, match='needs a GPU'):
+        parallel.LibraryComm(0, 1)
