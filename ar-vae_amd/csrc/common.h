@@ -75,6 +75,11 @@ __device__ __forceinline__ float act_bwd_from_out(float y, int act) {
 }
 
 // the same without control flow (selects on the wave-uniform `act`): for code that must keep many loads in flight
+__device__ __forceinline__ float act_fwd_sel(float x, int act) {
+    const float relu = fmaxf(x, 0.f);
+    const float selu = x > 0.f ? kSeluScale * x : (kSeluScale * kSeluAlpha) * (__builtin_amdgcn_exp2f(fminf(x, 0.f) * 1.4426950408889634f) - 1.f);
+    return act == ARVAE_ACT_RELU ? relu : (act == ARVAE_ACT_SELU ? selu : x);
+}
 __device__ __forceinline__ float act_bwd_from_out_sel(float y, int act) {
     const float relu = y > 0.f ? 1.f : 0.f, selu = y > 0.f ? kSeluScale : y + kSeluScale * kSeluAlpha;
     return act == ARVAE_ACT_RELU ? relu : (act == ARVAE_ACT_SELU ? selu : 1.f);

@@ -16,6 +16,7 @@
 #include "dense.h"
 #include "rng.h"
 #include "midprep.h"
+#include "midcluster.h"
 #include "conv32_common.h"
 
 namespace arvae {
@@ -437,6 +438,27 @@ static int64_t mid_layer_floats(const arvae_layer_t &l) {
     return (k * n + 3) / 4 * 4 + kb * n + (n + 3) / 4 * 4;       // mf | mb | bias, each 16-byte aligned
 }
 
+// The clustered kernels (midcluster.hip) cover the dSprites-shaped block: Linear K0 -> H -> H, heads H -> zdim, decoder
+// zdim -> H -> H -> K0 with K0 = 512, H = 256, zdim <= 16 (imagevae/dsprites_vae.py:22-37)
+static bool midc_topology(const arvae_image_vae_t *m, int ne, int nd) {
+    if (ne != 2 || nd != 3 || m->zdim > 16) return false;
+    const arvae_link_t &e0 = m->enc[m->n_enc - 2].link, &e1 = m->enc[m->n_enc - 1].link;
+    const arvae_link_t &d0 = m->dec[0].link, &d1 = m->dec[1].link, &d2 = m->dec[2].link;
+    return e0.chi == MC_K0 && e0.clo == MC_H && e1.chi == MC_H && e1.clo == MC_H && m->head_mu.link.chi == MC_H && d0.chi == m->zdim &&
+           d0.clo == MC_H && d1.chi == MC_H && d1.clo == MC_H && d2.chi == MC_H && d2.clo == MC_K0 && m->head_mu.b_off >= 0 &&
+           m->head_log_std.b_off >= 0;
+}
+constexpr int64_t MIDC_COUNTER_WORDS = 1024;         // 32 clusters x 32 words: more than a device's CUs can host
+// cluster-layout floats of one matrix: both axes rounded up to 16 (the reduce axis of the z-sized ones to 16, the heads' to 32)
+static int64_t midc_mat_floats(int k, int n) { return (int64_t)((k + 15) / 16 * 16) * ((n + 15) / 16 * 16); }
+static int64_t midc_floats(const arvae_image_vae_t *m, int ne, int nd) {
+    if (!midc_topology(m, ne, nd)) return 0;
+    int64_t total = MIDC_COUNTER_WORDS;
+    for (int i = 0; i < ne; ++i) total += 2 * midc_mat_floats(m->enc[m->n_enc - ne + i].link.chi, m->enc[m->n_enc - ne + i].link.clo);
+    for (int i = 0; i < nd; ++i) total += 2 * midc_mat_floats(m->dec[i].link.chi, m->dec[i].link.clo);
+    return total + 2 * midc_mat_floats(m->head_mu.link.chi, 32);
+}
+
 // floats of workspace for the prepped matrices of the block's layers
 int64_t mid_prep_floats(const arvae_image_vae_t *m) {
     int ne, nd;
@@ -445,12 +467,14 @@ int64_t mid_prep_floats(const arvae_image_vae_t *m) {
     for (int i = 0; i < ne; ++i) total += mid_layer_floats(m->enc[m->n_enc - ne + i]);
     for (int i = 0; i < nd; ++i) total += mid_layer_floats(m->dec[i]);
     const int64_t h = m->head_mu.link.chi, z2 = 2 * m->zdim;
-    return total + 2 * ((h * z2 + 3) / 4 * 4) + (z2 + 3) / 4 * 4;  // heads: [h][2z] | [2z][h] | bias
+    return total + 2 * ((h * z2 + 3) / 4 * 4) + (z2 + 3) / 4 * 4 + midc_floats(m, ne, nd);  // heads: [h][2z] | [2z][h] | bias; cluster layouts
 }
 
 struct MidPlan {
     MidArgs args;
     MidPrepArgs prep;
+    bool cluster;                // the clustered kernels can take this model (and `cl` holds their matrices)
+    McArgs cl;
     size_t lds_bytes;
     int rows;                    // batch rows per workgroup: 8 when two row buffers of that height fit LDS beside the scratch, else 4
 };
@@ -512,6 +536,35 @@ static void mid_describe(const arvae_image_vae_t *m, const float *params, float 
         j.kp = Perm{0, 0}; j.np = Perm{0, 0};
         blocks += (h * z2 + 1023) / 1024;
         pl.prep.blk_end[pl.prep.count++] = blocks;
+        off += 2 * (((int64_t)h * z2 + 3) / 4 * 4) + (z2 + 3) / 4 * 4;
+    }
+    pl.prep.counters = nullptr;
+    pl.prep.counter_words = 0;
+    pl.cluster = midc_topology(m, ne, nd);
+    pl.cl = McArgs{};
+    if (pl.cluster) {
+        // cluster layouts behind everything else in the prep workspace; job order: enc0, enc1, dec0, dec1, dec2, heads
+        McMat *fw[6] = {&pl.cl.e0f, &pl.cl.e1f, &pl.cl.d0f, &pl.cl.d1f, &pl.cl.d2f, &pl.cl.hdf};
+        McMat *bw[6] = {&pl.cl.e0b, &pl.cl.e1b, &pl.cl.d0b, &pl.cl.d1b, &pl.cl.d2b, &pl.cl.hdb};
+        for (int q = 0; q < 6; ++q) {
+            MidPrepJob &j = pl.prep.job[q];
+            const bool heads = q == 5, first_dec = q == 2;
+            const int kp = (j.k + 15) / 16 * 16, np = heads ? 32 : (j.n + 15) / 16 * 16;
+            // partitioned over the 16 members where the output axis is wide; the z-sized products are whole in every member
+            j.cf = prep_ws + off; off += (int64_t)kp * np;
+            j.cb = prep_ws + off; off += (int64_t)kp * np;
+            j.cf_kb = kp / 16; j.cf_s = (heads || first_dec) ? 1 : MC_S; j.cf_ct = np / 16 / j.cf_s;
+            j.cb_kb = np / 16; j.cb_s = (heads || first_dec) ? 1 : MC_S; j.cb_ct = kp / 16 / j.cb_s;
+            fw[q]->w = j.cf; fw[q]->bias = j.bias;
+            bw[q]->w = j.cb; bw[q]->bias = nullptr;
+        }
+        pl.prep.counters = reinterpret_cast<unsigned *>(prep_ws + off);
+        pl.prep.counter_words = (int)MIDC_COUNTER_WORDS;
+        pl.cl.counters = pl.prep.counters;
+        off += MIDC_COUNTER_WORDS;
+        pl.cl.zdim = m->zdim;
+        pl.cl.act_e0 = a.enc[0].act; pl.cl.act_e1 = a.enc[1].act;
+        pl.cl.act_d0 = a.dec[0].act; pl.cl.act_d1 = a.dec[1].act; pl.cl.act_d2 = a.dec[2].act;
     }
     a.ld = ((maxw + 3) / 4) * 4 + 4;
     a.w_mu = params + m->head_mu.w_off; a.b_mu = m->head_mu.b_off >= 0 ? params + m->head_mu.b_off : nullptr;
@@ -527,6 +580,19 @@ static void mid_describe(const arvae_image_vae_t *m, const float *params, float 
         if (forced == 1 || forced == 2 || forced == 4) pl.rows = forced;
     }
     pl.lds_bytes = (size_t)(2 * pl.rows * a.ld + mid_red(pl.rows) + pl.rows * 32) * sizeof(float);
+}
+
+// the clustered kernels take the pass when the model has their shape AND every cluster's 16 workgroups can be resident at once
+// (they wait for each other: one 512-thread workgroup with ~117 KB of LDS per CU)
+static bool midc_use(const MidPlan &pl, int batch) {
+    return pl.cluster && (int64_t)((batch + MC_R - 1) / MC_R) * MC_S <= mid_cu_count();
+}
+static void midc_common(McArgs &c, const MidArgs &a, int batch) {
+    c.batch = batch;
+    c.clusters = (batch + MC_R - 1) / MC_R;
+    c.xcd_map = c.clusters % 8 == 0;
+    c.y_e0 = a.enc[0].y; c.y_e1 = a.enc[1].y; c.y_d0 = a.dec[0].y; c.y_d1 = a.dec[1].y; c.y_d2 = a.dec[2].y;
+    c.g_e0 = a.enc[0].gpre; c.g_e1 = a.enc[1].gpre; c.g_d0 = a.dec[0].gpre; c.g_d1 = a.dec[1].gpre; c.g_d2 = a.dec[2].gpre;
 }
 
 static void mid_allow_lds() {
@@ -584,6 +650,14 @@ int mid_forward(const arvae_image_vae_t *m, int batch, const float *params, floa
         ARVAE_LAUNCH(mid_prep_kernel, dim3(pl.prep.blk_end[pl.prep.count - 1]), dim3(256), 0, s, pl.prep);
         if (int rc = check_launch("mid_prep_kernel")) return rc;
     }
+    if (midc_use(pl, batch)) {
+        McArgs &c = pl.cl;
+        midc_common(c, a, batch);
+        c.x0 = x0; c.mu = mu; c.log_std = log_std; c.sigma = sigma; c.z = z; c.eps = eps;
+        c.eps_out = a.eps_out; c.rng = a.rng;
+        c.amax_out = amax_out;                               // one writer unit per workgroup: at most 256 of them
+        return midc_forward(c, s);
+    }
     if (pl.rows == 1) ARVAE_LAUNCH(mid_forward_kernel<1>, dim3(batch), dim3(MID_T), pl.lds_bytes, s, a);
     else if (pl.rows == 2) ARVAE_LAUNCH(mid_forward_kernel<2>, dim3((batch + 1) / 2), dim3(MID_T), pl.lds_bytes, s, a);
     else if (pl.rows == 8) ARVAE_LAUNCH(mid_forward_kernel<8>, dim3((batch + 7) / 8), dim3(MID_T), pl.lds_bytes, s, a);
@@ -621,6 +695,16 @@ int mid_backward(const arvae_image_vae_t *m, int batch, const float *params, flo
         if (getenv("ARVAE_MID_NO_WARM") != nullptr) nw = 0;
     }
     mid_allow_lds();
+    if (midc_use(pl, batch)) {
+        McArgs &c = pl.cl;
+        midc_common(c, a, batch);
+        c.g_out = g_out; c.g_is_pre = g_is_pre; c.gate0 = gate0; c.d_x0 = d_x0;
+        c.eps = eps; c.mu = a.mu; c.sigma = a.sigma;
+        c.dz_reg = dz_reg; c.dz_extra = dz_extra; c.g_loss = g_loss; c.kl = kl; c.cap = cap;
+        c.beta = beta; c.inv_batch = a.inv_batch; c.reg_scale = reg_scale; c.d_mu = d_mu; c.d_ls = d_ls;
+        c.amax_out = amax_out;
+        return midc_backward(c, s);
+    }
     if (pl.rows == 1) ARVAE_LAUNCH(mid_backward_kernel<1>, dim3(batch), dim3(MID_T), pl.lds_bytes, s, a);
     else if (pl.rows == 2) ARVAE_LAUNCH(mid_backward_kernel<2>, dim3((batch + 1) / 2), dim3(MID_T), pl.lds_bytes, s, a);
     else if (pl.rows == 8) ARVAE_LAUNCH(mid_backward_kernel<8>, dim3((batch + 7) / 8), dim3(MID_T), pl.lds_bytes, s, a);

@@ -1,0 +1,55 @@
+// The latent block of the dSprites-shaped conv VAE on CLUSTERS of workgroups (midcluster.hip): argument block and entry points.
+#pragma once
+#include "common.h"
+#include "rng.h"
+
+namespace arvae {
+
+constexpr int MC_S = 16;        // workgroups per cluster = column slices of a partitioned layer
+constexpr int MC_R = 32;        // batch rows per cluster
+constexpr int MC_K0 = 512;      // conv feature width on both sides of the block (dsprites_vae.py:22,33: 32 x 4 x 4)
+constexpr int MC_H = 256;       // hidden width of the Linear stacks
+
+// One matrix in CLUSTER LAYOUT: the product out[rows][o] = sum_r in[rows][r] * M[r][o] with the reduce axis padded to KB
+// blocks of 16 and the output axis cut into S slices of CT column tiles of 16.  Stored so that the B operand of
+// v_mfma_f32_16x16x4_f32 for four consecutive steps is ONE 16-byte load per lane, lanes contiguous (1 KB per wave load):
+//     w[(((slice * CT + ct) * KB + b) * 64 + lane) * 4 + j] = M[16 b + 4 (lane / 16) + j][slice * 16 CT + 16 ct + lane % 16]
+// (zero where the indices pass the matrix).  midprep.h writes it.
+struct McMat {
+    const float *w;
+    const float *bias;          // [o] in memory order, or null
+};
+
+struct McArgs {
+    int batch, zdim, clusters;
+    int xcd_map;                // 1: the 16 members of a cluster have equal blockIdx.x % 8 (one XCD under round-robin dispatch:
+                                // speed only, never correctness); needs clusters % 8 == 0
+    unsigned *counters;         // one arrival counter per cluster, 32 words apart; multiples of MC_S between phases
+    // forward matrices: enc0 [K0 -> H], enc1 [H -> H], heads [H -> 2 zdim (32)], dec0 [zdim (16) -> H], dec1 [H -> H], dec2 [H -> K0]
+    McMat e0f, e1f, hdf, d0f, d1f, d2f;
+    // backward matrices: dec2^T [K0 -> H], dec1^T [H -> H], dec0^T [H -> zdim (16)], heads^T [2 zdim (32) -> H], enc1^T, enc0^T [H -> K0]
+    McMat d2b, d1b, d0b, hdb, e1b, e0b;
+    int act_e0, act_e1, act_d0, act_d1, act_d2;
+    float *y_e0, *y_e1, *y_d0, *y_d1, *y_d2;       // saved outputs [batch][width]
+    float *g_e0, *g_e1, *g_d0, *g_d1, *g_d2;       // backward: pre-activation gradients (for the grouped weight-gradient launch)
+    const float *x0;                               // conv features [batch][K0]
+    float *mu, *log_std, *sigma, *z;
+    const float *eps;
+    float *eps_out;
+    RngStream rng;
+    unsigned *amax_out;
+    // backward only
+    const float *g_out;
+    int g_is_pre;
+    const float *gate0;
+    float *d_x0;
+    const float *dz_reg, *dz_extra, *g_loss, *kl, *cap;
+    float beta, inv_batch, reg_scale;
+    float *d_mu, *d_ls;
+};
+
+int64_t midc_counter_words(int batch);             // uint32 words of arrival counters a batch needs (zeroed by the prep launch)
+int midc_forward(const McArgs &a, hipStream_t s);
+int midc_backward(const McArgs &a, hipStream_t s);
+
+}  // namespace arvae

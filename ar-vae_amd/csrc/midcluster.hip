@@ -1,0 +1,587 @@
+// The latent block of the dSprites-shaped conv VAE (imagevae/dsprites_vae.py:22-37 as executed by imagevae/mnist_vae.py:59-72:
+// Linear 512 -> 256 -> 256 -> (mu | log_std) -> z -> 256 -> 256 -> 512, and its backward) on CLUSTERS of workgroups.
+//
+// midblock.hip gives every workgroup a few batch rows and lets it stream EVERY matrix (1.6 MB) through its own CU's L2 port:
+// ~20 us per pass however the arithmetic is done.  Here a cluster of MC_S = 16 workgroups owns MC_R = 32 batch rows, and
+// each member owns 1/16 of every wide layer's output columns: a workgroup reads ~100 KB of weights per pass (each value
+// once, straight into the B operand registers of v_mfma_f32_16x16x4_f32 -- 16-byte loads in the cluster layout midprep.h
+// writes), the products are exact-fp32 MFMAs, and what the members exchange between two layers is the 32 x 256 activation
+// block (32 KB), through memory: every member stores its 32 x 16 slice write-through (sc1), arrives on the cluster's counter,
+// polls it, and gathers the block with sc1 loads (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup
+// visibility": the first row of the hand-off table; the exchanged tensors ARE the saved activations / pre-activation gradients
+// the other pass and the weight-gradient launch need anyway).  The narrow middle of the chain (heads, z, decoder's first layer;
+// their transposes in backward) is computed by every member for its cluster's rows, so a pass has three exchanges, not six.
+// Forward: 3 exchanges; backward: 3.  256 workgroups at B = 512, one per CU; a cluster's members have equal blockIdx % 8
+// (one XCD under round-robin dispatch: speed only).  Correctness needs the 16 members of a cluster co-resident: the
+// launcher (midblock.hip) uses this kernel only when the whole grid fits the device's CUs.
+#include <mutex>
+
+#include "conv32_common.h"
+#include "midcluster.h"
+
+namespace arvae {
+namespace {
+
+constexpr int MC_T = 512;                 // 8 waves
+constexpr int PA = MC_K0 + 4;             // LDS row pitches (floats): pitch % 64 == 4 keeps the 16-byte A-operand reads of 16 rows
+constexpr int PB = MC_H + 4;              // on disjoint bank quartets
+constexpr int PZ = 20, PO = 36;           // z rows (16 + 4); heads outputs / (d_mu | d_ls) rows (32 + 4)
+constexpr int RED_FLOATS = 4 * MC_R * 20; // partial tiles: 4 k-quarters x 32 rows x (16 + 4), or 2 halves x 32 x (32 + 4)
+constexpr int LDS_FLOATS = MC_R * PA + MC_R * PB + RED_FLOATS + MC_R * PZ + MC_R * PO;
+constexpr int AUX_SC1 = 16;               // cache-policy bit of the raw buffer intrinsics: sc1 (agent scope: bypass L1 / write through)
+
+#ifdef MIDC_STAMPS
+__device__ unsigned long long g_midc_stamps[2 * 256 * 16];     // [pass][workgroup][slot]: wall clock (100 MHz) at phase boundaries
+#define MC_STAMP(pass, slot) do { if (threadIdx.x == 0 && blockIdx.x < 256) g_midc_stamps[((pass) * 256 + blockIdx.x) * 16 + (slot)] = wall_clock64(); } while (0)
+#else
+#define MC_STAMP(pass, slot)
+#endif
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// KB: blocks of 16 along the reduce axis; CT: 16-column tiles of this workgroup's output columns
+template <int KB_, int CT_>
+struct Shape {
+    static constexpr int KB = KB_, CT = CT_;
+    static constexpr int T = 2 * CT;                        // 16 x 16 tiles of the 32-row block
+    static constexpr int KS = T <= 8 ? 8 / T : 1;           // waves sharing a tile (the reduce axis split between them)
+    static constexpr int TPW = T <= 8 ? 1 : T / 8;          // tiles per wave
+    static constexpr int NKB = KB / KS;                     // k blocks per wave and tile
+    static constexpr int NW = TPW * NKB;                    // 16-byte weight loads per lane
+    static constexpr int NS = 16 * CT;                      // output columns of the slice
+    static constexpr int P = NS + 4;                        // pitch of the partial tiles
+    static constexpr int SLICE = CT * KB * 256;             // floats of one slice in cluster layout
+    static_assert(KB % KS == 0 && NW <= 8 && (T > 8 || NKB % 2 == 0) && (T > 8 || KS * MC_R * P <= RED_FLOATS), "shape");
+};
+using ShE0 = Shape<MC_K0 / 16, 1>;        // 512 -> 16 of 256
+using ShHH = Shape<MC_H / 16, 1>;         // 256 -> 16 of 256
+using ShHD = Shape<MC_H / 16, 2>;         // 256 -> 32 (mu | log_std), every member
+using ShD0 = Shape<1, 16>;                // 16 (z) -> 256, every member
+using ShD2 = Shape<MC_H / 16, 2>;         // 256 -> 32 of 512
+using ShZB = Shape<MC_H / 16, 1>;         // 256 -> 16 (d z), every member
+using ShHB = Shape<2, 16>;                // 32 (d_mu | d_ls) -> 256, every member
+
+// this wave's weights of one product: issued early, consumed by mc_mma
+template <class S>
+__device__ __forceinline__ void mc_load(const float *__restrict__ w, float4 (&wr)[8]) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (S::T <= 8) {
+        const int tile = wave % S::T, ct = tile >> 1, kq = wave / S::T;
+#pragma unroll
+        for (int u = 0; u < S::NKB; ++u) wr[u] = ld4(w + ((int64_t)((ct * S::KB + kq * S::NKB + u) * 64 + lane)) * 4);
+    } else {
+#pragma unroll
+        for (int t = 0; t < S::TPW; ++t) {
+            const int ct = (wave * S::TPW + t) >> 1;
+#pragma unroll
+            for (int u = 0; u < S::KB; ++u) wr[t * S::KB + u] = ld4(w + ((int64_t)((ct * S::KB + u) * 64 + lane)) * 4);
+        }
+    }
+}
+
+// acc[t] = rows of `in` (LDS, pitch ld) x this wave's weights, for its tile(s) and its part of the reduce axis.
+// A operand: lane (g = lane / 16, r = lane % 16) holds in[row r][16 b + 4 g + j] for step j of block b (one 16-byte LDS read);
+// D: lane holds rows 4 g + j, column lane % 16.
+template <class S>
+__device__ __forceinline__ void mc_mma(const float *in, int ld, const float4 (&wr)[8], f32x4v (&acc)[4]) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, r = lane & 15;
+    if (S::T <= 8) {
+        const int tile = wave % S::T, rt = tile & 1, kq = wave / S::T;
+        const float *ap = in + (16 * rt + r) * ld + 16 * kq * S::NKB + 4 * g;
+        // two interleaved chains (a 16x16x4 MFMA's result is 8 passes away): even / odd k blocks, summed at the end
+        acc[0] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        f32x4v odd = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < S::NKB; u += 2) {
+            const float4 a = ld4(ap + 16 * u), b = ld4(ap + 16 * (u + 1));
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wr[u].x, acc[0], 0, 0, 0);
+            odd = __builtin_amdgcn_mfma_f32_16x16x4f32(b.x, wr[u + 1].x, odd, 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wr[u].y, acc[0], 0, 0, 0);
+            odd = __builtin_amdgcn_mfma_f32_16x16x4f32(b.y, wr[u + 1].y, odd, 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wr[u].z, acc[0], 0, 0, 0);
+            odd = __builtin_amdgcn_mfma_f32_16x16x4f32(b.z, wr[u + 1].z, odd, 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wr[u].w, acc[0], 0, 0, 0);
+            odd = __builtin_amdgcn_mfma_f32_16x16x4f32(b.w, wr[u + 1].w, odd, 0, 0, 0);
+        }
+        acc[0] += odd;
+    } else {
+#pragma unroll
+        for (int t = 0; t < S::TPW; ++t) {
+            const int rt = (wave * S::TPW + t) & 1;
+            const float *ap = in + (16 * rt + r) * ld + 4 * g;
+            acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < S::KB; ++u) {
+                const float4 a = ld4(ap + 16 * u);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, wr[t * S::KB + u].x, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, wr[t * S::KB + u].y, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, wr[t * S::KB + u].z, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, wr[t * S::KB + u].w, acc[t], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// split products (T <= 8): this wave's partial tile -> red[kq][row][col]
+template <class S>
+__device__ __forceinline__ void mc_partials(const f32x4v &acc, float *red) {
+    static_assert(S::T <= 8, "split products only");
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+    const int tile = wave % S::T, ct = tile >> 1, rt = tile & 1, kq = wave / S::T;
+    float *dst = red + (kq * MC_R + 16 * rt + 4 * g) * S::P + 16 * ct + c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dst[j * S::P] = acc[j];
+}
+// the k-parts of one output, summed in a fixed order
+template <class S>
+__device__ __forceinline__ float mc_sum(const float *red, int row, int col) {
+    float v = red[row * S::P + col];
+#pragma unroll
+    for (int q = 1; q < S::KS; ++q) v += red[(q * MC_R + row) * S::P + col];
+    return v;
+}
+
+__device__ __forceinline__ void mc_place(const McArgs &p, int &cl, int &m) {
+    const int b = blockIdx.x;
+    if (p.xcd_map) { cl = (b & 7) + 8 * (b >> 7); m = (b >> 3) & (MC_S - 1); }
+    else { cl = b / MC_S; m = b % MC_S; }
+}
+
+// Hand-off, producer side then consumer side (every member is both).  mc_publish: all of this workgroup's sc1 stores have left
+// (each storing wave drains its own queue), then ONE lane arrives on the cluster's counter.  mc_wait: that lane polls the counter
+// until the phase is complete; the barrier releases the other waves, whose loads of the exchanged block are sc1 loads
+// (mc_gather).  Whatever is requested BETWEEN the two (the next products' weights) is in flight during the poll instead of being
+// waited for by the drain.  The counter only ever holds multiples of MC_S between phases (the prep launch zeroes it every step), so
+// the phase's target follows from the value the arrival returned: any number of forward / backward passes may follow one prep.
+__device__ __forceinline__ unsigned mc_publish(unsigned *ctr) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned target = 0;
+    if (threadIdx.x == 0) target = (__hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / MC_S + 1u) * MC_S;
+    return target;
+}
+__device__ __forceinline__ void mc_wait(unsigned *ctr, unsigned target) {
+    if (threadIdx.x == 0)
+        while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(1);
+    __syncthreads();
+}
+
+// the cluster's 32 x 256 block of a tensor every member has just stored a slice of -> LDS (pitch PB); rows past the batch: zeros
+__device__ __forceinline__ void mc_gather(const float *src, int row0, int valid, float *dst) {
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(src + (int64_t)row0 * MC_H, (int64_t)valid * MC_H * 4);
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int e = (int)threadIdx.x + MC_T * u;           // float4 index: row e / 64, quad e % 64 (rows past `valid`: out of
+        v[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, e * 16, 0, AUX_SC1));   // range -> zeros)
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int e = (int)threadIdx.x + MC_T * u;
+        *reinterpret_cast<float4 *>(dst + (e >> 6) * PB + 4 * (e & 63)) = v[u];
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void st_sc1(float v, float *base, int64_t index) {
+    __hip_atomic_store(base + index, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // global_store_dword sc1
+}
+
+// Epilogue of a whole-width product (every member holds all 256 columns of its cluster's rows): value -> LDS block `dst` (pitch
+// PB), this member's own 16 columns also to `own` in memory.  FWD: v = act(acc + bias); else v = acc * act'(y).  The activation
+// is a template parameter: two waves share a SIMD and 16 values per lane go through here, so every instruction per value
+// costs ~0.05 us of the pass.
+template <class S, int ACT, bool FWD>
+__device__ __forceinline__ void mc_wide_epilogue(const f32x4v (&acc)[4], const float (&bias)[4], const float (&y)[4][4], float *dst, float *own,
+                                                 int m, int row0, int valid) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int t = 0; t < S::TPW; ++t) {
+        const int tile = wave * S::TPW + t, ct = tile >> 1, rt = tile & 1, col = 16 * ct + c;
+        float *d = dst + (16 * rt + 4 * g) * PB + col;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x = FWD ? acc[t][j] + bias[t] : acc[t][j];
+            if (FWD) v[j] = ACT == ARVAE_ACT_RELU ? fmaxf(x, 0.f) : (ACT == ARVAE_ACT_SELU ? act_fwd(x, ARVAE_ACT_SELU) : x);
+            else v[j] = x * (ACT == ARVAE_ACT_NONE ? 1.f : act_bwd_from_out(y[t][j], ACT));
+            v[j] = 16 * rt + 4 * g + j < valid ? v[j] : 0.f;
+            d[j * PB] = v[j];
+        }
+        if (ct == m) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 16 * rt + 4 * g + j;
+                if (r < valid) own[(int64_t)(row0 + r) * MC_H + col] = v[j];
+            }
+        }
+    }
+}
+template <class S, bool FWD>
+__device__ __forceinline__ void mc_wide_epilogue_act(int act, const f32x4v (&acc)[4], const float (&bias)[4], const float (&y)[4][4], float *dst,
+                                                     float *own, int m, int row0, int valid) {
+    if (act == ARVAE_ACT_RELU) mc_wide_epilogue<S, ARVAE_ACT_RELU, FWD>(acc, bias, y, dst, own, m, row0, valid);
+    else if (act == ARVAE_ACT_SELU) mc_wide_epilogue<S, ARVAE_ACT_SELU, FWD>(acc, bias, y, dst, own, m, row0, valid);
+    else mc_wide_epilogue<S, ARVAE_ACT_NONE, FWD>(acc, bias, y, dst, own, m, row0, valid);
+}
+
+// ================================================================================================ forward
+__global__ __launch_bounds__(MC_T) void midc_forward_kernel(McArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *bufA = lds, *bufB = bufA + MC_R * PA, *red = bufB + MC_R * PB, *zbuf = red + RED_FLOATS, *outs = zbuf + MC_R * PZ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15;
+    int cl, m;
+    mc_place(p, cl, m);
+    const int row0 = cl * MC_R, valid = min(MC_R, p.batch - row0), zd = p.zdim;
+    unsigned *ctr = p.counters + cl * 32;
+    const int frow = tid >> 4, fc = tid & 15;                 // the output a thread finalises in a 16-column slice
+    MC_STAMP(0, 0);
+    float4 wa[8], wb[8];
+    f32x4v acc[4];
+    // Requests in the order their data is needed (memory returns loads in order): the conv features of the cluster's rows
+    // (64 KB, eight 16-byte loads per thread), enc0's weights, then everything the later phases would otherwise wait for
+    float4 xv[MC_R * (MC_K0 / 4) / MC_T];
+#pragma unroll
+    for (int u = 0; u < MC_R * (MC_K0 / 4) / MC_T; ++u) {
+        const int i = tid + MC_T * u, r = i / (MC_K0 / 4), q = i % (MC_K0 / 4);
+        xv[u] = r < valid ? ld4(p.x0 + (int64_t)(row0 + r) * MC_K0 + 4 * q) : zero4();
+    }
+    mc_load<ShE0>(p.e0f.w + (int64_t)m * ShE0::SLICE, wa);
+    mc_load<ShHH>(p.e1f.w + (int64_t)m * ShHH::SLICE, wb);
+#pragma unroll
+    for (int u = 0; u < MC_R * (MC_K0 / 4) / MC_T; ++u) {
+        const int i = tid + MC_T * u, r = i / (MC_K0 / 4), q = i % (MC_K0 / 4);
+        *reinterpret_cast<float4 *>(bufA + r * PA + 4 * q) = xv[u];
+    }
+    const float b_e0 = p.e0f.bias != nullptr ? p.e0f.bias[16 * m + fc] : 0.f;
+    const float b_e1 = p.e1f.bias != nullptr ? p.e1f.bias[16 * m + fc] : 0.f;
+    const float b_d1 = p.d1f.bias != nullptr ? p.d1f.bias[16 * m + fc] : 0.f;
+    const float b_h0 = 2 * fc < 2 * zd ? p.hdf.bias[2 * fc] : 0.f, b_h1 = 2 * fc + 1 < 2 * zd ? p.hdf.bias[2 * fc + 1] : 0.f;
+    float b_d0[ShD0::TPW];
+#pragma unroll
+    for (int t = 0; t < ShD0::TPW; ++t) b_d0[t] = p.d0f.bias != nullptr ? p.d0f.bias[16 * ((wave * ShD0::TPW + t) >> 1) + c] : 0.f;
+    // this thread's element of the reparameterisation (threads below 32 x zdim): its noise is drawn / requested now
+    const int zr = tid / zd, zj = tid - zr * zd;
+    const bool z_mine = tid < MC_R * zd, z_on = z_mine && zr < valid;
+    const int64_t zidx = (int64_t)(z_on ? row0 + zr : 0) * zd + zj;
+    float z_eps = 0.f;
+    if (z_mine) z_eps = p.eps_out != nullptr ? rng_normal(p.rng, (uint64_t)zidx) : p.eps[zidx];
+    __syncthreads();
+    MC_STAMP(0, 1);
+    // ---- enc0: 512 -> this member's 16 of 256
+    mc_mma<ShE0>(bufA, PA, wa, acc);
+    mc_partials<ShE0>(acc[0], red);
+    __syncthreads();
+    {
+        const float v = act_fwd_sel(mc_sum<ShE0>(red, frow, fc) + b_e0, p.act_e0);
+        if (frow < valid) st_sc1(v, p.y_e0, (int64_t)(row0 + frow) * MC_H + 16 * m + fc);
+    }
+    MC_STAMP(0, 2);
+    const unsigned t0 = mc_publish(ctr);
+    mc_load<ShHD>(p.hdf.w, wa);
+    mc_wait(ctr, t0);
+    MC_STAMP(0, 3);
+    mc_gather(p.y_e0, row0, valid, bufB);
+    MC_STAMP(0, 4);
+    // ---- enc1: 256 -> 16 of 256
+    mc_mma<ShHH>(bufB, PB, wb, acc);
+    mc_partials<ShHH>(acc[0], red);
+    __syncthreads();
+    {
+        const float v = act_fwd_sel(mc_sum<ShHH>(red, frow, fc) + b_e1, p.act_e1);
+        if (frow < valid) st_sc1(v, p.y_e1, (int64_t)(row0 + frow) * MC_H + 16 * m + fc);
+    }
+    MC_STAMP(0, 5);
+    const unsigned t1 = mc_publish(ctr);
+    mc_load<ShD0>(p.d0f.w, wb);
+    mc_wait(ctr, t1);
+    MC_STAMP(0, 6);
+    mc_gather(p.y_e1, row0, valid, bufA);                     // (bufA with pitch PB from here on)
+    MC_STAMP(0, 7);
+    // ---- heads: 256 -> (mu | log_std), every member for its cluster's rows
+    mc_mma<ShHD>(bufA, PB, wa, acc);
+    mc_partials<ShHD>(acc[0], red);
+    if (tid < MC_R * 16) zbuf[frow * PZ + fc] = 0.f;          // z rows, padded to 16 columns
+    __syncthreads();
+    {
+        const int o = 2 * fc;
+        outs[frow * PO + o] = mc_sum<ShHD>(red, frow, o) + b_h0;
+        outs[frow * PO + o + 1] = mc_sum<ShHD>(red, frow, o + 1) + b_h1;
+    }
+    mc_load<ShHH>(p.d1f.w + (int64_t)m * ShHH::SLICE, wa);
+    __syncthreads();
+    if (z_mine) {
+        const int r = zr, j = zj;
+        const bool on = z_on;
+        const int64_t idx = zidx;
+        const float mv = outs[r * PO + j], lv = outs[r * PO + zd + j], sv = expf(lv);
+        const float e = z_eps;
+        const float zv = fmaf(e, sv, mv);
+        zbuf[r * PZ + j] = on ? zv : 0.f;
+        if (on && (r & (MC_S - 1)) == m) {                    // every member holds the same values: member r % 16 stores row r
+            p.mu[idx] = mv; p.log_std[idx] = lv; p.sigma[idx] = sv; p.z[idx] = zv;
+            if (p.eps_out != nullptr) p.eps_out[idx] = e;
+        }
+    }
+    __syncthreads();
+    MC_STAMP(0, 8);
+    // ---- dec0: z (16) -> 256, every member; its own 16 columns go to memory (saved activation)
+    mc_mma<ShD0>(zbuf, PZ, wb, acc);
+    MC_STAMP(0, 14);
+    {
+        const float no_y[4][4] = {};
+        mc_wide_epilogue_act<ShD0, true>(p.act_d0, acc, b_d0, no_y, bufB, p.y_d0, m, row0, valid);
+    }
+    MC_STAMP(0, 15);
+    mc_load<ShD2>(p.d2f.w + (int64_t)m * ShD2::SLICE, wb);
+    __syncthreads();
+    MC_STAMP(0, 9);
+    // ---- dec1: 256 -> 16 of 256
+    mc_mma<ShHH>(bufB, PB, wa, acc);
+    mc_partials<ShHH>(acc[0], red);
+    __syncthreads();
+    {
+        const float v = act_fwd_sel(mc_sum<ShHH>(red, frow, fc) + b_d1, p.act_d1);
+        if (frow < valid) st_sc1(v, p.y_d1, (int64_t)(row0 + frow) * MC_H + 16 * m + fc);
+    }
+    const unsigned t_last = mc_publish(ctr);
+    const float2 b_d2 = p.d2f.bias != nullptr ? *reinterpret_cast<const float2 *>(p.d2f.bias + 32 * m + 2 * fc) : make_float2(0.f, 0.f);
+    mc_wait(ctr, t_last);
+    MC_STAMP(0, 10);
+    mc_gather(p.y_d1, row0, valid, bufA);
+    MC_STAMP(0, 11);
+    // ---- dec2: 256 -> 32 of 512: the first deconv's input
+    mc_mma<ShD2>(bufA, PB, wb, acc);
+    mc_partials<ShD2>(acc[0], red);
+    __syncthreads();
+    MC_STAMP(0, 12);
+    float am = 0.f;
+    {
+        const int o = 2 * fc;
+        float2 v;
+        v.x = act_fwd_sel(mc_sum<ShD2>(red, frow, o) + b_d2.x, p.act_d2);
+        v.y = act_fwd_sel(mc_sum<ShD2>(red, frow, o + 1) + b_d2.y, p.act_d2);
+        if (frow < valid) {
+            *reinterpret_cast<float2 *>(p.y_d2 + (int64_t)(row0 + frow) * MC_K0 + 32 * m + o) = v;
+            am = fmaxf(fabsf(v.x), fabsf(v.y));
+        }
+    }
+    if (p.amax_out != nullptr) {                              // one AMAX writer unit per workgroup
+        float *slot = red + RED_FLOATS;                       // the z rows' LDS: read by nobody at this point
+        am = wave_max(am);
+        if (lane == 0) slot[wave] = am;
+        __syncthreads();
+        if (tid < 64) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < MC_T / 64; ++w) t = fmaxf(t, slot[w]);
+            amax_publish(p.amax_out, blockIdx.x, gridDim.x, t);
+        }
+    }
+    MC_STAMP(0, 13);
+}
+
+// ================================================================================================ backward
+__global__ __launch_bounds__(MC_T) void midc_backward_kernel(McArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *bufA = lds, *bufB = bufA + MC_R * PA, *red = bufB + MC_R * PB, *dml = red + RED_FLOATS + MC_R * PZ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
+    int cl, m;
+    mc_place(p, cl, m);
+    const int row0 = cl * MC_R, valid = min(MC_R, p.batch - row0), zd = p.zdim;
+    unsigned *ctr = p.counters + cl * 32;
+    const int frow = tid >> 4, fc = tid & 15;
+    const bool fon = frow < valid;
+    const int64_t fidx = (int64_t)(row0 + (fon ? frow : 0)) * MC_H + 16 * m + fc;     // this thread's element of a 256-wide tensor
+    MC_STAMP(1, 0);
+    float4 wa[8], wb[8];
+    f32x4v acc[4];
+    // requests in the order of need: the arriving gradient (and, where it still has to be taken through the activation, the saved
+    // output), the first product's weights, then what the later phases would otherwise wait for
+    constexpr int NG = MC_R * (MC_K0 / 4) / MC_T;
+    float4 gv[NG], yv[NG];
+#pragma unroll
+    for (int u = 0; u < NG; ++u) {
+        const int i = tid + MC_T * u, r = i / (MC_K0 / 4), q = i % (MC_K0 / 4);
+        const int64_t at = (int64_t)(row0 + (r < valid ? r : 0)) * MC_K0 + 4 * q;
+        gv[u] = r < valid ? ld4(p.g_out + at) : zero4();
+        yv[u] = (r < valid && !p.g_is_pre) ? ld4(p.y_d2 + at) : zero4();
+    }
+    mc_load<ShE0>(p.d2b.w + (int64_t)m * ShE0::SLICE, wa);
+    mc_load<ShHH>(p.d1b.w + (int64_t)m * ShHH::SLICE, wb);
+    const float y_d1 = p.y_d1[fidx], y_d0 = p.y_d0[fidx], y_e0 = p.y_e0[fidx];
+    // the latent arithmetic's operands (threads with fc < zdim: element (frow, fc) of the cluster's rows)
+    const int64_t li = (int64_t)(row0 + (fon ? frow : 0)) * zd + (fc < zd ? fc : 0);
+    const float l_gl = p.g_loss[0], l_kl = p.kl[0], l_cap = p.cap != nullptr ? p.cap[0] : 0.f;
+    const float l_reg = p.dz_reg != nullptr ? p.dz_reg[li] : 0.f, l_ext = p.dz_extra != nullptr ? p.dz_extra[li] : 0.f;
+    const float l_s = p.sigma[li], l_mu = p.mu[li], l_e = p.eps[li];
+#pragma unroll
+    for (int u = 0; u < NG; ++u) {          // -> bufA as a pre-activation gradient
+        const int i = tid + MC_T * u, r = i / (MC_K0 / 4), q = i % (MC_K0 / 4);
+        float4 g4 = gv[u];
+        if (r < valid && !p.g_is_pre) {
+            const float4 y = yv[u];
+            g4 = make_float4(g4.x * act_bwd_from_out_sel(y.x, p.act_d2), g4.y * act_bwd_from_out_sel(y.y, p.act_d2),
+                             g4.z * act_bwd_from_out_sel(y.z, p.act_d2), g4.w * act_bwd_from_out_sel(y.w, p.act_d2));
+            if ((q >> 3) == m) *reinterpret_cast<float4 *>(p.g_d2 + (int64_t)(row0 + r) * MC_K0 + 4 * q) = g4;   // this member's 32 columns
+        }
+        *reinterpret_cast<float4 *>(bufA + r * PA + 4 * q) = g4;
+    }
+    __syncthreads();
+    MC_STAMP(1, 1);
+    // ---- through dec2: 512 -> 16 of 256, times act'(dec1's output)
+    mc_mma<ShE0>(bufA, PA, wa, acc);
+    mc_partials<ShE0>(acc[0], red);
+    __syncthreads();
+    {
+        const float v = mc_sum<ShE0>(red, frow, fc) * act_bwd_from_out_sel(y_d1, p.act_d1);
+        if (fon) st_sc1(v, p.g_d1, fidx);
+    }
+    MC_STAMP(1, 2);
+    const unsigned t2 = mc_publish(ctr);
+    mc_load<ShZB>(p.d0b.w, wa);
+    mc_wait(ctr, t2);
+    MC_STAMP(1, 3);
+    mc_gather(p.g_d1, row0, valid, bufB);
+    MC_STAMP(1, 4);
+    // ---- through dec1: 256 -> 16 of 256, times act'(dec0's output)
+    mc_mma<ShHH>(bufB, PB, wb, acc);
+    mc_partials<ShHH>(acc[0], red);
+    __syncthreads();
+    {
+        const float v = mc_sum<ShHH>(red, frow, fc) * act_bwd_from_out_sel(y_d0, p.act_d0);
+        if (fon) st_sc1(v, p.g_d0, fidx);
+    }
+    MC_STAMP(1, 5);
+    const unsigned t3 = mc_publish(ctr);
+    mc_load<ShHB>(p.hdb.w, wb);
+    mc_wait(ctr, t3);
+    MC_STAMP(1, 6);
+    mc_gather(p.g_d0, row0, valid, bufA);                     // (bufA with pitch PB from here on)
+    MC_STAMP(1, 7);
+    // ---- through dec0: 256 -> d z (16), every member; then d(mu, log_std): decoder path + regulariser + KL
+    //      (the formulas of heads_latent_bwd_kernel, heads.hip)
+    mc_mma<ShZB>(bufA, PB, wa, acc);
+    mc_partials<ShZB>(acc[0], red);
+    dml[frow * PO + fc] = 0.f;
+    dml[frow * PO + 16 + fc] = 0.f;
+    // saved output of enc1 at this wave's tiles of the NEXT product (16 loads in flight during the latent arithmetic)
+    float y_e1[ShHB::TPW][4];
+#pragma unroll
+    for (int t = 0; t < ShHB::TPW; ++t) {
+        const int tile = wave * ShHB::TPW + t, ct = tile >> 1, rt = tile & 1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = 16 * rt + 4 * g + j;
+            y_e1[t][j] = r < valid ? p.y_e1[(int64_t)(row0 + r) * MC_H + 16 * ct + c] : 0.f;
+        }
+    }
+    mc_load<ShHH>(p.e1b.w + (int64_t)m * ShHH::SLICE, wa);
+    __syncthreads();
+    if (fc < zd) {
+        const int j = fc;
+        float gz = mc_sum<ShZB>(red, frow, j);
+        const int64_t i = li;
+        const float gl = l_gl;
+        const float diff = l_kl - l_cap;
+        const float kk = gl * p.beta * (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f)) * p.inv_batch;
+        if (p.dz_reg != nullptr) gz += gl * p.reg_scale * l_reg;
+        if (p.dz_extra != nullptr) gz += l_ext;
+        const float s = l_s, mu = l_mu, e = l_e;
+        const float a = gz + kk * mu, b = (gz * e + kk * (s - 1.f / s)) * s;
+        if (fon) {
+            dml[frow * PO + j] = a;
+            dml[frow * PO + zd + j] = b;
+            if ((frow & (MC_S - 1)) == m) { p.d_mu[i] = a; p.d_ls[i] = b; }
+        }
+    }
+    __syncthreads();
+    MC_STAMP(1, 8);
+    // ---- through the heads: (d_mu | d_ls) (32) -> 256, every member, times act'(enc1's output); own 16 columns to memory
+    mc_mma<ShHB>(dml, PO, wb, acc);
+    {
+        const float no_bias[4] = {};
+        mc_wide_epilogue_act<ShHB, false>(p.act_e1, acc, no_bias, y_e1, bufB, p.g_e1, m, row0, valid);
+    }
+    mc_load<ShD2>(p.e0b.w + (int64_t)m * ShD2::SLICE, wb);
+    __syncthreads();
+    MC_STAMP(1, 9);
+    // ---- through enc1: 256 -> 16 of 256, times act'(enc0's output)
+    mc_mma<ShHH>(bufB, PB, wa, acc);
+    mc_partials<ShHH>(acc[0], red);
+    __syncthreads();
+    {
+        const float v = mc_sum<ShHH>(red, frow, fc) * act_bwd_from_out_sel(y_e0, p.act_e0);
+        if (fon) st_sc1(v, p.g_e0, fidx);
+    }
+    const unsigned t_last = mc_publish(ctr);
+    const int64_t xat = (int64_t)(row0 + (fon ? frow : 0)) * MC_K0 + 32 * m + 2 * fc;
+    const float2 gate = p.gate0 != nullptr ? *reinterpret_cast<const float2 *>(p.gate0 + xat) : make_float2(1.f, 1.f);
+    mc_wait(ctr, t_last);
+    MC_STAMP(1, 10);
+    mc_gather(p.g_e0, row0, valid, bufA);
+    MC_STAMP(1, 11);
+    // ---- through enc0: 256 -> 32 of 512, gated by the last conv layer's ReLU: the gradient that layer's backward reads
+    mc_mma<ShD2>(bufA, PB, wb, acc);
+    mc_partials<ShD2>(acc[0], red);
+    __syncthreads();
+    MC_STAMP(1, 12);
+    float am = 0.f;
+    {
+        const int o = 2 * fc;
+        float2 v;
+        v.x = mc_sum<ShD2>(red, frow, o);
+        v.y = mc_sum<ShD2>(red, frow, o + 1);
+        if (p.gate0 != nullptr) { v.x = gate.x > 0.f ? v.x : 0.f; v.y = gate.y > 0.f ? v.y : 0.f; }
+        if (fon) {
+            *reinterpret_cast<float2 *>(p.d_x0 + xat) = v;
+            am = fmaxf(fabsf(v.x), fabsf(v.y));
+        }
+    }
+    if (p.amax_out != nullptr) {
+        float *slot = red + RED_FLOATS;                       // the z rows' LDS: read by nobody at this point
+        am = wave_max(am);
+        if (lane == 0) slot[wave] = am;
+        __syncthreads();
+        if (tid < 64) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < MC_T / 64; ++w) t = fmaxf(t, slot[w]);
+            amax_publish(p.amax_out, blockIdx.x, gridDim.x, t);
+        }
+    }
+    MC_STAMP(1, 13);
+}
+
+std::once_flag g_lds_once;
+void allow_lds() {
+    std::call_once(g_lds_once, [] {
+        (void)hipFuncSetAttribute((const void *)midc_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FLOATS * 4);
+        (void)hipFuncSetAttribute((const void *)midc_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FLOATS * 4);
+    });
+}
+
+}  // namespace
+
+int64_t midc_counter_words(int batch) { return (int64_t)((batch + MC_R - 1) / MC_R) * 32; }
+
+int midc_forward(const McArgs &a, hipStream_t s) {
+    allow_lds();
+    ARVAE_LAUNCH(midc_forward_kernel, dim3(a.clusters * MC_S), dim3(MC_T), LDS_FLOATS * sizeof(float), s, a);
+    return check_launch("midc_forward_kernel");
+}
+
+int midc_backward(const McArgs &a, hipStream_t s) {
+    allow_lds();
+    ARVAE_LAUNCH(midc_backward_kernel, dim3(a.clusters * MC_S), dim3(MC_T), LDS_FLOATS * sizeof(float), s, a);
+    return check_launch("midc_backward_kernel");
+}
+
+}  // namespace arvae
+
+#ifdef MIDC_STAMPS
+extern "C" int arvae_debug_midc_stamps(unsigned long long *out, int count) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(arvae::g_midc_stamps), sizeof(unsigned long long) * count);
+}
+#endif

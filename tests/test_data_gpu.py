@@ -169,11 +169,20 @@ def test_train_cli_data_parallel_code_path(dev, tmp_path):
     write_dsprites(str(tmp_path), 400)
     args = ['-d', 'dsprites', '--num_epochs', '1', '--batch_size', '64', '--rand', '3', '-r', 'all']
     plain, _ = _run_cli('train_image_vae.py', args, tmp_path)
+    name = plain['model']
+    ckpt = tmp_path / 'models' / name / (name + '.pt')
+    w_plain = {k: v.clone() for k, v in torch.load(ckpt, map_location='cpu').items()}
     forced, out = _run_cli('train_image_vae.py', args, tmp_path, ARVAE_FORCE_DP='1')
-    assert 'Num Train Batches:  5' in out and forced['num_codes'] == plain['num_codes']
-    # 20 evaluation images of a barely trained model with freshly drawn eps: the two runs agree in magnitude only (the step's
-    # equality with the single-process one is held by tests/test_parallel_gpu.py)
-    assert np.isfinite(forced['test_loss']) and forced['test_loss'] == pytest.approx(plain['test_loss'], rel=0.5)
+    assert 'Num Train Batches:  5' in out and forced['num_codes'] == plain['num_codes'] and forced['model'] == name
+    # same seed, rank 0 of 1: the device's Philox streams (eps of every training / evaluation step), the shuffling order and
+    # the batches are the same in both runs, so the five Adam steps and the evaluation must agree to rounding -- the
+    # data-parallel run takes the row-block regulariser, the all-gathers and the all-reduce (identities on one rank)
+    w_forced = torch.load(ckpt, map_location='cpu')
+    for k, v in w_plain.items():
+        d = (w_forced[k].double() - v.double()).norm()
+        assert d <= 1e-5 * v.double().norm() + 1e-7, k
+    assert forced['test_loss'] == pytest.approx(plain['test_loss'], rel=1e-4)
+    assert forced['test_acc'] == pytest.approx(plain['test_acc'], abs=1e-4)
 
 
 def test_measure_inference_for_evaluation(dev, tmp_path):

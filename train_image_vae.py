@@ -72,6 +72,9 @@ def main(dataset_type, batch_size, num_epochs, lr, beta, capacity, gamma, delta,
     chief = dp is None or dp.rank == 0
 
     def build(seed):
+        # the reference builds the model BEFORE the trainer seeds torch (train_image_vae.py:97-109, image_vae_trainer.py:103):
+        # its initial weights differ from run to run.  Here the run's seed covers them too (same run, same weights)
+        torch.manual_seed(seed)
         model = MnistVAE() if dataset_type == 'mnist' else DspritesVAE()
         trainer = ImageVAETrainer(dataset=dataset, model=model, lr=lr, reg_type=reg_type, reg_dim=reg_dim, beta=beta,
                                   capacity=capacity, gamma=gamma, delta=delta, dec_dist=dec_dist, rand=seed)

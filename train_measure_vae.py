@@ -76,6 +76,9 @@ def main(dataset_type, note_embedding_dim, metadata_embedding_dim, num_encoder_l
     chief = dp is None or dp.rank == 0
 
     def build(seed):
+        # the reference builds the model BEFORE the trainer seeds torch (train_image_vae.py:97-109, image_vae_trainer.py:103):
+        # its initial weights differ from run to run.  Here the run's seed covers them too (same run, same weights)
+        torch.manual_seed(seed)
         model = MeasureVAE(dataset=dataset, note_embedding_dim=note_embedding_dim,
                            metadata_embedding_dim=metadata_embedding_dim, num_encoder_layers=num_encoder_layers,
                            encoder_hidden_size=encoder_hidden_size, encoder_dropout_prob=encoder_dropout_prob,
