@@ -25,6 +25,8 @@
 //     16-byte reads for stride-1/2 pixel walks);
 //   * epilogues are 16-byte stores of a lane's consecutive channels, in the Up kernels spread between the next
 //     tile's MFMAs with the waves staggered.
+#include <mutex>
+#include "diag.h"
 #include "common.h"
 #include "conv32_common.h"
 #include "reduce.h"
@@ -1011,17 +1013,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-static int cu_count() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
-}
+static int cu_count() { return device_cu_count(); }
 
 template <int LO, int PX = 128> static constexpr int tiles_for(int n) {
     using T = Tile<LO, PX>;
@@ -1053,33 +1045,33 @@ static int down_small_grid(int tiles) {                          // two workgrou
 
 template <int MODE> static void launch_down_small(const Operand &hi, const Ep32 &ep, int n, hipStream_t s) {
     const int tiles = tiles_for<4, 32>(n);
-    static bool attr = false;
-    if (!attr) { allow_lds(down32s_kernel<4, MODE>, LDS_DOWN_S); attr = true; }
+    static std::once_flag attr;
+    std::call_once(attr, [&] { allow_lds(down32s_kernel<4, MODE>, LDS_DOWN_S); });
     ARVAE_LAUNCH((down32s_kernel<4, MODE>), dim3(down_small_grid(tiles)), dim3(256), LDS_DOWN_S, s, hi.v, ep, n, tiles);
 }
 template <int LO, int MODE, int PX>
 static void launch_up_px(const Operand &lo, const Ep32 &ep, int n, hipStream_t s) {
     const int tiles = tiles_for<LO, PX>(n), grid = grid_for_tiles(tiles);
     if constexpr (LO == 16 && PX == 128) {                      // compute / store waves
-        static const bool pc = getenv("ARVAE_UP32_NO_PC") == nullptr;       // A/B: up32x_kernel
+        static const bool pc = diag_env("ARVAE_UP32_NO_PC") == nullptr;       // A/B: up32x_kernel
         if constexpr (MODE != EP_GATE_F) if (pc) {
             constexpr int LDSP = (2 * 2 * PatchLoader<16, 1, 128>::PLANE_DW) * 4 + 4 * 4 * 4 * 64 * 16;
-            static bool attrp = false;
-            if (!attrp) { allow_lds(up32p_kernel<MODE>, LDSP); attrp = true; }
+            static std::once_flag attrp;
+            std::call_once(attrp, [&] { allow_lds(up32p_kernel<MODE>, LDSP); });
             ARVAE_LAUNCH((up32p_kernel<MODE>), dim3(grid), dim3(512), LDSP, s, lo.v, ep, n, tiles);
             return;
         }
     }
     constexpr int LDSX = 2 * PatchLoader<LO, 1, PX>::PLANE_DW * 4;
-    static bool attrx = false;
-    if (!attrx) { allow_lds(up32x_kernel<LO, MODE, PX>, LDSX); attrx = true; }
+    static std::once_flag attrx;
+    std::call_once(attrx, [&] { allow_lds(up32x_kernel<LO, MODE, PX>, LDSX); });
     ARVAE_LAUNCH((up32x_kernel<LO, MODE, PX>), dim3(grid), dim3(256), LDSX, s, lo.v, ep, n, tiles);
 }
 // 128-pixel tiles, or 32-pixel tiles when the former give a CU at most one tile (nothing to pipeline, or idle CUs:
 // the 8x8 and 4x4 layers at batch 512)
 template <int LO, int MODE>
 static void launch_up_v(const Operand &lo, const Ep32 &ep, int n, hipStream_t s) {
-    static const bool small_ok = getenv("ARVAE_NO_SMALL_TILES") == nullptr;     // diagnostic switch
+    static const bool small_ok = diag_env("ARVAE_NO_SMALL_TILES") == nullptr;     // diagnostic switch
     if (LO == 4 && small_ok && 2 * tiles_for<LO, 128>(n) <= cu_count()) launch_up_px<4, MODE, 32>(lo, ep, n, s);
     else if (LO == 8 && small_ok && tiles_for<LO, 128>(n) <= cu_count()) launch_up_px<8, MODE, 32>(lo, ep, n, s);
     else launch_up_px<LO, MODE, 128>(lo, ep, n, s);
@@ -1092,8 +1084,8 @@ static int ep_mode(const Ep32 &ep, int relu) {
 // the four-way reduction-split producer / consumer kernel of the 16x16 / 8x8 layers (down32p.h)
 template <int LO, int MODE> static void launch_down_p(const float *hi, const Ep32 &ep, int n, hipStream_t s) {
     constexpr int LDS = DownK<LO>::LDS_DW * 4;
-    static bool attr = false;
-    if (!attr) { allow_lds(down32p_kernel<LO, MODE>, LDS); attr = true; }
+    static std::once_flag attr;
+    std::call_once(attr, [&] { allow_lds(down32p_kernel<LO, MODE>, LDS); });
     const int tiles = n * DownK<LO>::TILES_PER_IMG;
     ARVAE_LAUNCH((down32p_kernel<LO, MODE>), dim3(grid_for_tiles(tiles)), dim3(512), LDS, s, hi, ep, n, tiles);
 }
@@ -1146,7 +1138,7 @@ template <int LO> static int launch_up(const arvae_link_t *l, const Operand &lo,
 // conv32_up of a 4x4 -> 8x8 ReLU layer (forward pass, small tiles) with the regulariser's workgroups riding in
 // the same grid (up32x_reg_kernel); false: not that case, launch the two separately
 bool conv32_up_reg_fits(const arvae_link_t *l) {
-    static const bool off = getenv("ARVAE_NO_PAIR_REG") != nullptr || getenv("ARVAE_NO_SMALL_TILES") != nullptr;
+    static const bool off = diag_env("ARVAE_NO_PAIR_REG") != nullptr || diag_env("ARVAE_NO_SMALL_TILES") != nullptr;
     return !off && conv32_fits(l) && l->lh == 4 && 2 * tiles_for<4, 128>(l->n) <= cu_count();
 }
 int conv32_up_reg(const arvae_link_t *l, const Operand &lo, const float *bias, uint16_t *bits_out, float *out, const float *wprep,
@@ -1155,8 +1147,8 @@ int conv32_up_reg(const arvae_link_t *l, const Operand &lo, const float *bias, u
     Ep32 ep{bias, nullptr, nullptr, bits_out, out, reinterpret_cast<const uint4 *>(wprep), amax_in, amax_out};
     const int tiles = tiles_for<4, 32>(l->n), grid_up = grid_for_tiles(tiles);
     constexpr int LDSX = MaxOf<2 * PatchLoader<4, 1, 32>::PLANE_DW, 2 * REG_CHUNK>::value * 4;
-    static bool attr = false;
-    if (!attr) { allow_lds(up32x_reg_kernel<EP_RELU>, LDSX); attr = true; }
+    static std::once_flag attr;
+    std::call_once(attr, [&] { allow_lds(up32x_reg_kernel<EP_RELU>, LDSX); });
     const int reg_bx = (int)((reg.n_rows + REG_ROWS_PER_BLOCK - 1) / REG_ROWS_PER_BLOCK);
     ARVAE_LAUNCH((up32x_reg_kernel<EP_RELU>), dim3(grid_up + reg_bx * r), dim3(256), LDSX, s, lo.v, ep, l->n, tiles, grid_up, reg, reg_bx);
     return check_launch("up32_kernel<4>(+ reg_loss)");
@@ -1215,14 +1207,14 @@ int conv32_amax(const float *x, int64_t count, unsigned *out, hipStream_t s) {
 
 // row-stream weight gradient with producer / consumer waves (wgrad32r.h): the 16x16 and 8x8 layers
 static bool conv32_wgrad_stream_fits(const arvae_link_t *l) {
-    static const bool off = getenv("ARVAE_WGRAD_NO_STREAM") != nullptr;     // diagnostic: the patch-staged wgrad32x_kernel instead
+    static const bool off = diag_env("ARVAE_WGRAD_NO_STREAM") != nullptr;     // diagnostic: the patch-staged wgrad32x_kernel instead
     return !off && (l->lh == 16 || l->lh == 8);
 }
 // steps of the whole launch, steps per workgroup and workgroups when `groups` workgroups (at most) share the stream
 static void stream_geometry(const arvae_link_t *l, int groups, int &total, int &spw, int &grid) {
     total = l->n * (l->lh * l->lh / 32);
     spw = (total + groups - 1) / groups;
-    static const int forced = getenv("ARVAE_WGR_SPW") != nullptr ? atoi(getenv("ARVAE_WGR_SPW")) : 0;   // diagnostic: steps per workgroup
+    static const int forced = diag_env("ARVAE_WGR_SPW") != nullptr ? atoi(diag_env("ARVAE_WGR_SPW")) : 0;   // diagnostic: steps per workgroup
     if (forced > 0) spw = forced;
     if (spw < 1) spw = 1;
     grid = (total + spw - 1) / spw;
@@ -1237,13 +1229,12 @@ template <int LO> static int launch_stream(const arvae_link_t *l, const float *l
     constexpr int LDS = RowStream<LO>::LDS_DW * 4;
     int total, spw, grid;
     stream_geometry(l, cu_count(), total, spw, grid);
-    static bool attr = false;
-    if (!attr) {
+    static std::once_flag attr;
+    std::call_once(attr, [&] {
         allow_lds(wgrad32r_kernel<LO, 0>, LDS);
         allow_lds(wgrad32r_kernel<LO, 1>, LDS);
         allow_lds(wgrad32r_kernel<LO, 2>, LDS);
-        attr = true;
-    }
+    });
     if (bias_mode == 1) ARVAE_LAUNCH((wgrad32r_kernel<LO, 1>), dim3(grid), dim3(512), LDS, s, lo, hi, slab, l->n, total, spw, amax_lo, amax_hi);
     else if (bias_mode == 2) ARVAE_LAUNCH((wgrad32r_kernel<LO, 2>), dim3(grid), dim3(512), LDS, s, lo, hi, slab, l->n, total, spw, amax_lo, amax_hi);
     else ARVAE_LAUNCH((wgrad32r_kernel<LO, 0>), dim3(grid), dim3(512), LDS, s, lo, hi, slab, l->n, total, spw, amax_lo, amax_hi);
@@ -1272,13 +1263,12 @@ template <int LO> static int launch_wgrad_x(const arvae_link_t *l, const Operand
                                             int grid, const unsigned *amax_lo, const unsigned *amax_hi, hipStream_t s) {
     constexpr int LDS = 2 * (PatchLoader<LO, 2, 64>::PLANE_DW / PSB * WGRAD_PSB_H + 64 * WGRAD_PSB_L) * 4;
     const int tiles = tiles_for<LO, 64>(l->n);
-    static bool attr = false;
-    if (!attr) {
+    static std::once_flag attr;
+    std::call_once(attr, [&] {
         allow_lds(wgrad32x_kernel<LO, 0>, LDS);
         allow_lds(wgrad32x_kernel<LO, 1>, LDS);
         allow_lds(wgrad32x_kernel<LO, 2>, LDS);
-        attr = true;
-    }
+    });
     if (bias_mode == 1)
         ARVAE_LAUNCH((wgrad32x_kernel<LO, 1>), dim3(grid), dim3(256), LDS, s, lo.v, hi.v, slab, l->n, tiles, amax_lo, amax_hi);
     else if (bias_mode == 2)
@@ -1309,7 +1299,7 @@ int conv32_wgrad_partial(const arvae_link_t *l, const Operand &lo, const Operand
 static int pair_split_percent(int lh, bool up) {              // share of the workgroups that runs the data gradient
     // ARVAE_PAIR_SPLIT16 / _SPLIT8: both pairs of that size; ..._SPLIT16U / 16D / 8U / 8D: the pair whose data gradient is the Up
     // (forward Down layer) / Down map
-    auto env = [](const char *name) { const char *v = getenv(name); return v != nullptr ? atoi(v) : 0; };
+    auto env = [](const char *name) { const char *v = diag_env(name); return v != nullptr ? atoi(v) : 0; };
     static const int e16 = env("ARVAE_PAIR_SPLIT16"), e8 = env("ARVAE_PAIR_SPLIT8");
     static const int e16u = env("ARVAE_PAIR_SPLIT16U"), e16d = env("ARVAE_PAIR_SPLIT16D"), e8u = env("ARVAE_PAIR_SPLIT8U"), e8d = env("ARVAE_PAIR_SPLIT8D");
     const int one = lh == 16 ? (up ? e16d : e16u) : (up ? e8d : e8u), both = lh == 16 ? e16 : e8;
@@ -1318,8 +1308,8 @@ static int pair_split_percent(int lh, bool up) {              // share of the wo
     return lh == 16 ? (up ? 48 : 50) : 50;             // (same-box sweeps at B = 512: flat within 1 % from 48 to 52)
 }
 bool conv32_pair_fits(const arvae_link_t *l, bool up, const float *gate, const uint16_t *gate_bits, int bias_mode) {
-    static const bool off4 = getenv("ARVAE_NO_PAIR4") != nullptr || getenv("ARVAE_NO_SMALL_TILES") != nullptr;
-    static const bool off = getenv("ARVAE_NO_PAIR32") != nullptr;
+    static const bool off4 = diag_env("ARVAE_NO_PAIR4") != nullptr || diag_env("ARVAE_NO_SMALL_TILES") != nullptr;
+    static const bool off = diag_env("ARVAE_NO_PAIR32") != nullptr;
     if ((gate == nullptr && gate_bits == nullptr) || bias_mode != (up ? 2 : 1)) return false;
     if (l->lh == 4) {
         const int wg_tiles = tiles_for<4, 64>(l->n), dg_tiles = tiles_for<4, 32>(l->n);
@@ -1329,8 +1319,8 @@ bool conv32_pair_fits(const arvae_link_t *l, bool up, const float *gate, const u
     // 32-pixel-tile kernel (what launch_up_v picks at this batch)
     if (off || gate_bits == nullptr || !conv32_wgrad_stream_fits(l)) return false;
     if (l->n * (l->lh * l->lh / 32) < 4 * cu_count()) return false;
-    if (!up && l->lh == 8 && !(getenv("ARVAE_NO_SMALL_TILES") == nullptr && tiles_for<8, 128>(l->n) <= cu_count())) return false;
-    if (!up && l->lh == 16 && getenv("ARVAE_UP32_NO_PC") != nullptr) return false;
+    if (!up && l->lh == 8 && !(diag_env("ARVAE_NO_SMALL_TILES") == nullptr && tiles_for<8, 128>(l->n) <= cu_count())) return false;
+    if (!up && l->lh == 16 && diag_env("ARVAE_UP32_NO_PC") != nullptr) return false;
     return true;
 }
 
@@ -1346,8 +1336,8 @@ template <int LO> static int launch_pair_big(const arvae_link_t *l, bool up, con
     const dim3 grid(grid_a + grid_b);
     if (up) {                                                    // DOWN map of g (hi side); weight gradient: lo = layer input, hi = g
         constexpr int LDS = MaxOf<LDS_W, DownK<LO>::LDS_DW * 4>::value;
-        static bool attr = false;
-        if (!attr) { allow_lds(pair_down_wgrad_kernel<LO, EP_GATE_B, 2>, LDS); attr = true; }
+        static std::once_flag attr;
+        std::call_once(attr, [&] { allow_lds(pair_down_wgrad_kernel<LO, EP_GATE_B, 2>, LDS); });
         const int tiles = l->n * DownK<LO>::TILES_PER_IMG;
         ARVAE_LAUNCH((pair_down_wgrad_kernel<LO, EP_GATE_B, 2>), grid, dim3(512), LDS, s, g, ep, l->n, tiles, grid_a, x_in, g, slab, total, spw,
                      amax_x, amax_g);
@@ -1356,15 +1346,15 @@ template <int LO> static int launch_pair_big(const arvae_link_t *l, bool up, con
     if constexpr (LO == 16) {                                    // UP map of g (lo side); weight gradient: lo = g, hi = layer input
         constexpr int LDS_U = (2 * 2 * PatchLoader<16, 1, 128>::PLANE_DW) * 4 + 4 * 4 * 4 * 64 * 16;
         constexpr int LDS = MaxOf<LDS_W, LDS_U>::value;
-        static bool attr = false;
-        if (!attr) { allow_lds(pair_up16_wgrad_kernel<EP_GATE_B, 1>, LDS); attr = true; }
+        static std::once_flag attr;
+        std::call_once(attr, [&] { allow_lds(pair_up16_wgrad_kernel<EP_GATE_B, 1>, LDS); });
         ARVAE_LAUNCH((pair_up16_wgrad_kernel<EP_GATE_B, 1>), grid, dim3(512), LDS, s, g, ep, l->n, tiles_for<16, 128>(l->n), grid_a, g, x_in, slab,
                      total, spw, amax_g, amax_x);
         return check_launch("pair(up32<16> + wgrad32<16>)");
     } else {
         constexpr int LDS = MaxOf<LDS_W, 2 * PatchLoader<8, 1, 32>::PLANE_DW * 4>::value;
-        static bool attr = false;
-        if (!attr) { allow_lds(pair_up8_wgrad_kernel<EP_GATE_B, 1>, LDS); attr = true; }
+        static std::once_flag attr;
+        std::call_once(attr, [&] { allow_lds(pair_up8_wgrad_kernel<EP_GATE_B, 1>, LDS); });
         ARVAE_LAUNCH((pair_up8_wgrad_kernel<EP_GATE_B, 1>), grid, dim3(512), LDS, s, g, ep, l->n, tiles_for<8, 32>(l->n), grid_a, g, x_in, slab, total,
                      spw, amax_g, amax_x);
         return check_launch("pair(up32<8> + wgrad32<8>)");
@@ -1387,14 +1377,13 @@ int conv32_pair(const arvae_link_t *l, bool up, const float *g, const float *x_i
     constexpr int LDS_U = 2 * PatchLoader<4, 1, 32>::PLANE_DW * 4;
     constexpr int LDS = MaxOf<LDS_WGRAD_X4, MaxOf<LDS_DOWN_S, LDS_U>::value>::value;
     const int wg_tiles = tiles_for<4, 64>(l->n), dg_tiles = tiles_for<4, 32>(l->n), grid_a = (dg_tiles + 1) / 2;
-    static bool attr = false;
-    if (!attr) {
+    static std::once_flag attr;
+    std::call_once(attr, [&] {
         allow_lds(pair4_down_kernel<EP_GATE_F, 2>, LDS);
         allow_lds(pair4_down_kernel<EP_GATE_B, 2>, LDS);
         allow_lds(pair4_up_kernel<EP_GATE_F, 1>, LDS);
         allow_lds(pair4_up_kernel<EP_GATE_B, 1>, LDS);
-        attr = true;
-    }
+    });
     const dim3 grid(grid_a + wg_tiles);
     if (up) {                                                    // DOWN map of g (hi side); weight gradient: lo = layer input, hi = g
         if (gate_bits) ARVAE_LAUNCH((pair4_down_kernel<EP_GATE_B, 2>), grid, dim3(256), LDS, s, g, ep, x_in, g, slab, l->n, dg_tiles, wg_tiles, grid_a, amax_x, amax_g);

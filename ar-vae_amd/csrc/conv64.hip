@@ -9,6 +9,8 @@
 // with the activation derivative / dropout keep-mask of a gradient operand folded into the gather, and bias, activation
 // and keep-mask in the epilogue.  The weight gradient is the same tile machinery with both operands "K x rows" (pixels
 // are the reduction axis), sliced over pixels into a workspace and summed in fixed order.
+#include <mutex>
+#include "diag.h"
 #include "common.h"
 #include "x3tile.h"
 #include "conv32_common.h"
@@ -189,7 +191,7 @@ static bool plain_op(const Operand &o) { return o.y == nullptr || (o.act == ARVA
 
 // links this file serves: k x k (<= 16 taps), stride 1, 32 | channels on the reduction side, channels-last, no permutation
 bool conv64_fits(const arvae_link_t *l, bool up) {
-    static const bool off = getenv("ARVAE_CONV64_GENERIC") != nullptr;
+    static const bool off = diag_env("ARVAE_CONV64_GENERIC") != nullptr;
     const int red = up ? l->clo : l->chi, outc = up ? l->chi : l->clo;
     // narrow outputs (the 64 -> 8 layers) waste MFMA columns but these products are bound by the gather, not the MFMA
     return !off && l->stride == 1 && l->kh * l->kw <= 16 && l->kh * l->kw > 1 && red % 4 == 0 && red >= 8 &&
@@ -683,12 +685,12 @@ static int wr_img_per_wg(const arvae_link_t *l) {
 }
 
 static bool conv64_wgrad_rows_fits(const arvae_link_t *l) {
-    static const bool off = getenv("ARVAE_CONV64_WGRAD_TAPS") != nullptr;      // A/B: the per-tap kernel
+    static const bool off = diag_env("ARVAE_CONV64_WGRAD_TAPS") != nullptr;      // A/B: the per-tap kernel
     return !off && l->kh <= 4 && l->kw == 4 && l->lw <= 32 && l->lw + l->kw - 1 <= WR_HROWS && l->pad <= 4;
 }
 
 bool conv64_wgrad_fits(const arvae_link_t *l) {
-    static const bool off = getenv("ARVAE_CONV64_GENERIC") != nullptr;
+    static const bool off = diag_env("ARVAE_CONV64_GENERIC") != nullptr;
     return !off && l->stride == 1 && l->kh * l->kw <= 16 && l->kh * l->kw > 1 && l->clo % 4 == 0 && l->chi % 4 == 0 &&
            l->clo >= 4 && l->chi >= 4 && l->clo <= 64 && l->chi <= 64 && (l->clo >= 32 || l->chi >= 32) &&
            l->hi_perm_c == 0 && l->lo_perm_c == 0;
@@ -713,19 +715,18 @@ int conv64_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, fl
     const bool pl = plain_op(lo), ph = plain_op(hi);
     if (pl) g.lo.y = nullptr;
     if (ph) g.hi.y = nullptr;
-    static const bool no_pairs = getenv("ARVAE_CONV64_WGRAD_ROWS") != nullptr;     // diagnostic: one lo row per step
+    static const bool no_pairs = diag_env("ARVAE_CONV64_WGRAD_ROWS") != nullptr;     // diagnostic: one lo row per step
     if (conv64_wgrad_rows_fits(l) && !no_pairs && l->lw <= 24 && l->kh == 4) {
         const int ipw = wr_img_per_wg(l), slices = (l->n + ipw - 1) / ipw;
         const dim3 grid((l->chi + 31) / 32, slices);
         const size_t lds = (2 * 2 * WP_APLANE + WP_RING * 2 * WP_HPLANE) * sizeof(unsigned short);
-        static bool attr = false;
-        if (!attr) {
+        static std::once_flag attr;
+        std::call_once(attr, [&] {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_pairs_h2_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_pairs_h2_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_pairs_h2_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_pairs_h2_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr = true;
-        }
+        });
         // maxima of the operands AS MULTIPLIED: the caller's (plain tensors only) or taken here, behind the partial sums in ws
         unsigned *am = reinterpret_cast<unsigned *>(ws + conv64_wgrad_ws_floats(l) - 2 * AMAX_N);
         if (amax_lo == nullptr || !pl) {
@@ -748,14 +749,13 @@ int conv64_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, fl
         const int ipw = wr_img_per_wg(l), slices = (l->n + ipw - 1) / ipw;
         const dim3 grid((l->chi + 31) / 32, slices);
         const size_t lds = (2 * 3 * WR_APLANE + WR_RING * 3 * WR_HPLANE) * sizeof(unsigned short);
-        static bool attr = false;
-        if (!attr) {
+        static std::once_flag attr;
+        std::call_once(attr, [&] {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_rows_x3_kernel<true, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_rows_x3_kernel<true, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_rows_x3_kernel<false, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_rows_x3_kernel<false, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr = true;
-        }
+        });
         if (pl && ph) ARVAE_LAUNCH((conv_wgrad_rows_x3_kernel<true, true, 4>), grid, dim3(256), lds, s, g, ipw);
         else if (pl) ARVAE_LAUNCH((conv_wgrad_rows_x3_kernel<true, false, 4>), grid, dim3(256), lds, s, g, ipw);
         else if (ph) ARVAE_LAUNCH((conv_wgrad_rows_x3_kernel<false, true, 4>), grid, dim3(256), lds, s, g, ipw);

@@ -27,6 +27,8 @@
 //     gradient operand is applied at that point -- once per value instead of once per tap.
 //   * padding: source columns outside [0, sw) are not stored; a lane whose tap falls there reads one shared zero pixel
 //     (a select on the LDS address).  Source rows outside the image are staged as zeros.
+#include <mutex>
+#include "diag.h"
 #include "common.h"
 #include "conv32_common.h"
 
@@ -450,16 +452,7 @@ int conv64_operand_amax(const Operand &x, int64_t count, unsigned *out, hipStrea
     return check_launch("operand_amax");
 }
 
-static int cu_count_s() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
-}
+static int cu_count_s() { return device_cu_count(); }
 
 // rows per tile and column tiles for an output width / source width, or false
 static bool stage_geometry(int ow, int sw, int &rows, int &mt) {
@@ -475,7 +468,7 @@ int64_t conv64s_ws_floats() { return (S_PREP_UINT4 + 1) * 4 + AMAX_N; }      // 
 // 64 source channels, 64 or 4..32 (a multiple of 4) output channels, 4x4 taps, stride 1, channels-last without permutation,
 // a row group that fits the staging buffers
 bool conv64s_fits(const arvae_link_t *l, bool up) {
-    static const bool off = getenv("ARVAE_CONV64_NO_STAGE") != nullptr;      // diagnostic: the gathering kernel instead
+    static const bool off = diag_env("ARVAE_CONV64_NO_STAGE") != nullptr;      // diagnostic: the gathering kernel instead
     int rows, mt;
     const int ow = up ? l->hw : l->lw, sw = up ? l->lw : l->hw, cs = up ? l->clo : l->chi, q = up ? l->chi : l->clo;
     const int oh = up ? l->hh : l->lh;
@@ -486,13 +479,12 @@ bool conv64s_fits(const arvae_link_t *l, bool up) {
 
 template <int MT, int NT> static void launch_stage(const ConvStage &g, int grid, hipStream_t s) {
     constexpr int LDS = 2 * S_BUF * 4;
-    static bool attr = false;
-    if (!attr) {
+    static std::once_flag attr;
+    std::call_once(attr, [&] {
         (void)hipFuncSetAttribute((const void *)conv64s_kernel<MT, NT, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         (void)hipFuncSetAttribute((const void *)conv64s_kernel<MT, NT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         (void)hipFuncSetAttribute((const void *)conv64s_kernel<MT, NT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr = true;
-    }
+    });
     const int mode = (g.src.y == nullptr || (g.src.act == ARVAE_ACT_NONE && g.src.mask == nullptr)) ? 0 : g.src.mode();
     if (mode == 0) ARVAE_LAUNCH((conv64s_kernel<MT, NT, 0>), dim3(grid), dim3(256), LDS, s, g);
     else if (mode == 1) ARVAE_LAUNCH((conv64s_kernel<MT, NT, 1>), dim3(grid), dim3(256), LDS, s, g);

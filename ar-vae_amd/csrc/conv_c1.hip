@@ -8,6 +8,8 @@
 //                 producing its 2x2 output pixels from the 3x3 lo neighbourhood staged in LDS, weights
 //                 from scalar registers
 //   wgrad_c1 : dwt[c][0][ky][kx] += sum_pixels lo[pix][c] * img[pix @ tap]; bias sums ride along
+#include <mutex>
+#include "diag.h"
 #include "common.h"
 #include "reduce.h"
 #include "prep32.h"
@@ -434,7 +436,7 @@ int conv_c1_down_with_prep(const arvae_link_t *l, const Operand &img, const floa
 int conv_c1_down(const arvae_link_t *l, const Operand &img, const float *wt, const float *bias, int relu,
                  const float *gate, const uint16_t *gate_bits, uint16_t *bits_out, float *out, hipStream_t s, unsigned *amax_out) {
     Ep1 ep{bias, gate, gate_bits, bits_out, out, relu, amax_out};
-    static const int waves_per_cu = getenv("ARVAE_C1_DOWN_WAVES") ? atoi(getenv("ARVAE_C1_DOWN_WAVES")) : 16;
+    static const int waves_per_cu = diag_env("ARVAE_C1_DOWN_WAVES") ? atoi(diag_env("ARVAE_C1_DOWN_WAVES")) : 16;
     const int n_rows = l->n * LO1;
     int grid = 256 * waves_per_cu / 4;                           // workgroups of four independent waves
     if (grid > (n_rows + 3) / 4) grid = (n_rows + 3) / 4;
@@ -453,7 +455,7 @@ static int up_c1_grid(int tiles) {
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
         cached = cus > 0 ? cus : 256;
     }
-    static const int cap = getenv("ARVAE_C1_UP_GRID") ? atoi(getenv("ARVAE_C1_UP_GRID")) : 0;
+    static const int cap = diag_env("ARVAE_C1_UP_GRID") ? atoi(diag_env("ARVAE_C1_UP_GRID")) : 0;
     if (cap > 0) return tiles < cap ? tiles : cap;
     return tiles < 2 * cached ? tiles : 2 * cached;
 }
@@ -464,8 +466,8 @@ template <class K> static void up_c1_lds(K kernel) {
 
 int conv_c1_up(const arvae_link_t *l, const float *lo, const float *wt, const float *bias, float *out, hipStream_t s) {
     const int tiles = l->n * (LO1 / TRU);
-    static bool attr = false;
-    if (!attr) { up_c1_lds(up_c1_kernel<ARVAE_RECON_BERNOULLI, false>); attr = true; }
+    static std::once_flag attr;
+    std::call_once(attr, [&] { up_c1_lds(up_c1_kernel<ARVAE_RECON_BERNOULLI, false>); });
     ARVAE_LAUNCH((up_c1_kernel<ARVAE_RECON_BERNOULLI, false>), dim3(up_c1_grid(tiles)), dim3(256), 2 * T_FLOATS * 4, s, lo,
                        wt, bias, out, nullptr, 0.f, nullptr, nullptr, l->n, tiles);
     return check_launch("up_c1_kernel");
@@ -480,12 +482,11 @@ int conv_c1_up_recon(const arvae_link_t *l, const float *lo, const float *wt, co
                      int dist, float *partial, float *dlogits, hipStream_t s, int *nb_out) {
     const int tiles = l->n * (LO1 / TRU), grid = up_c1_grid(tiles);
     const float inv_b = 1.f / (float)l->n;
-    static bool attr = false;
-    if (!attr) {
+    static std::once_flag attr;
+    std::call_once(attr, [&] {
         up_c1_lds(up_c1_kernel<ARVAE_RECON_BERNOULLI, true>);
         up_c1_lds(up_c1_kernel<ARVAE_RECON_GAUSSIAN, true>);
-        attr = true;
-    }
+    });
     if (dist == ARVAE_RECON_BERNOULLI)
         ARVAE_LAUNCH((up_c1_kernel<ARVAE_RECON_BERNOULLI, true>), dim3(grid), dim3(256), 2 * T_FLOATS * 4, s, lo, wt, bias,
                            out, x, inv_b, partial, dlogits, l->n, tiles);
@@ -497,7 +498,7 @@ int conv_c1_up_recon(const arvae_link_t *l, const float *lo, const float *wt, co
 }
 
 int wgrad_c1_groups(const arvae_link_t *l) {
-    static const int cap = getenv("ARVAE_C1_WGRAD_GRID") ? atoi(getenv("ARVAE_C1_WGRAD_GRID")) : 256;       // streaming form: one 8-wave workgroup per CU (256 / 512 / 1024 measured: 19.3 / 19.0 / 21.8 us, and the slab reduce grows with it)
+    static const int cap = diag_env("ARVAE_C1_WGRAD_GRID") ? atoi(diag_env("ARVAE_C1_WGRAD_GRID")) : 256;       // streaming form: one 8-wave workgroup per CU (256 / 512 / 1024 measured: 19.3 / 19.0 / 21.8 us, and the slab reduce grows with it)
     const int units = (l->n * LO1 + WGS_WAVES - 1) / WGS_WAVES;
     return units < cap ? units : cap;
 }
@@ -514,7 +515,7 @@ int conv_c1_wgrad_partial(const arvae_link_t *l, const Operand &lo, const Operan
 
 // gated data gradient of the forward-UP single-channel link + its weight-gradient partials in one launch (pair_c1_kernel)
 bool conv_c1_pair_fits(const arvae_link_t *l) {
-    static const bool off = getenv("ARVAE_NO_PAIR_C1") != nullptr;
+    static const bool off = diag_env("ARVAE_NO_PAIR_C1") != nullptr;
     return !off && conv_c1_fits(l) && l->n * LO1 >= 8 * 256 && wgrad_c1_groups(l) == 256;
 }
 int conv_c1_pair(const arvae_link_t *l, const Operand &g_img, const float *wt, const float *gate, const uint16_t *gate_bits, float *d_lo,
@@ -539,7 +540,7 @@ int conv_c1_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &img, 
 
 // ---- the stride-1 64-channel single-channel links (Morpho-MNIST) ----------------------------------------------------
 bool conv_c1w_fits(const arvae_link_t *l) {
-    static const bool off = getenv("ARVAE_C1W_GENERIC") != nullptr;            // diagnostic: the generic gather-GEMM instead
+    static const bool off = diag_env("ARVAE_C1W_GENERIC") != nullptr;            // diagnostic: the generic gather-GEMM instead
     return !off && l->chi == 1 && l->clo == W1_CH && l->kh == 4 && l->kw == 4 && l->stride == 1 && l->pad == 0 && l->lw <= W1_SLOTS &&
            l->hw == l->lw + 3 && l->hh == l->lh + 3 && l->hw < W1_IMS && 4 * l->hw <= 128 && l->hi_perm_c == 0 && l->lo_perm_c == 0;
 }

@@ -9,6 +9,7 @@
 //
 // Channel permutations (hi_perm / lo_perm of arvae_link_t: the NCHW flatten between conv and dense
 // stacks over channels-last activations) are index remaps on the feature axis.
+#include "diag.h"
 #include "common.h"
 #include "dense.h"
 #include "x3tile.h"
@@ -46,7 +47,7 @@ __device__ __forceinline__ void reduce_waves(float *red, const f32x16 &acc, int 
 // and over 4 when it is short and the tiles are many (K <= 512 with >= 512 tiles: the 16-way LDS reduction of 16 accumulator
 // registers per wave then costs more than the 8 MFMAs each wave contributes -- Morpho-MNIST's 256 <-> 2888 layers)
 static bool dense_short_k(int k, int tiles) {
-    static const bool off = getenv("ARVAE_DENSE_NW16") != nullptr;
+    static const bool off = diag_env("ARVAE_DENSE_NW16") != nullptr;
     return !off && k <= 512 && tiles >= 512;
 }
 
@@ -685,7 +686,7 @@ static void launch_rows_gemm(const RowsGemm &g, int slices, hipStream_t s) {
     };
     const bool va = vec_ok(g.a, g.lda, LA, g.P), vb = vec_ok(g.b, g.ldb, LB, g.Q);
     const dim3 grid((g.P + RG_TP - 1) / RG_TP, (g.Q + RG_TQ - 1) / RG_TQ, slices);
-    static const bool fp32_mfma = getenv("ARVAE_ROWS_GEMM_FP32") != nullptr;
+    static const bool fp32_mfma = diag_env("ARVAE_ROWS_GEMM_FP32") != nullptr;
     if (fp32_mfma) {
         if (va && vb) ARVAE_LAUNCH((rows_gemm_kernel<LA, LB, EP, true, true>), grid, dim3(256), 0, s, g);
         else if (va) ARVAE_LAUNCH((rows_gemm_kernel<LA, LB, EP, true, false>), grid, dim3(256), 0, s, g);
@@ -703,7 +704,7 @@ static void launch_rows_gemm(const RowsGemm &g, int slices, hipStream_t s) {
 static bool plain_operand(const Operand &g) { return g.y == nullptr || (g.act == ARVAE_ACT_NONE && g.mask == nullptr); }
 
 static bool dense_long_batch(const DenseArgs &p) {
-    static const bool off = getenv("ARVAE_DENSE_NO_ROWS") != nullptr;       // A/B switch
+    static const bool off = diag_env("ARVAE_DENSE_NO_ROWS") != nullptr;       // A/B switch
     return !off && p.batch >= DENSE_SPLIT_MIN_ROWS && p.in_perm.c_count == 0 && p.out_perm.c_count == 0;
 }
 
@@ -789,7 +790,7 @@ bool dense_wgrad_defer(DenseWgradBatch *b, const arvae_link_t *l, const Operand 
 
 int dense_wgrad_flush(DenseWgradBatch *b, hipStream_t s) {
     if (b->count == 0) return ARVAE_OK;
-    static const bool split = getenv("ARVAE_DENSE_BATCH_SPLIT") != nullptr;     // diagnostic: one launch per job
+    static const bool split = diag_env("ARVAE_DENSE_BATCH_SPLIT") != nullptr;     // diagnostic: one launch per job
     if (split) {
         for (int j = 0; j < b->count; ++j) {
             DenseWgradBatch one{};
@@ -809,7 +810,7 @@ int dense_wgrad_flush(DenseWgradBatch *b, hipStream_t s) {
 // the queued Linear weight gradients and the single-channel layer's weight-gradient partials (conv_c1.hip) in one launch
 int wgrad_c1_groups(const arvae_link_t *l);
 bool dense_wgrad_c1_fits(const DenseWgradBatch *b) {
-    static const bool off = getenv("ARVAE_NO_PAIR_TAIL") != nullptr || getenv("ARVAE_DENSE_BATCH_SPLIT") != nullptr;
+    static const bool off = diag_env("ARVAE_NO_PAIR_TAIL") != nullptr || diag_env("ARVAE_DENSE_BATCH_SPLIT") != nullptr;
     return !off && b != nullptr && b->count > 0;
 }
 int dense_wgrad_flush_with_c1(DenseWgradBatch *b, const arvae_link_t *l, const Operand &lo, const Operand &img, float *dwt, float *dbias,

@@ -15,6 +15,7 @@
 //
 // The weight gradients (dW_hh = dgh^T h_prev, dW_ih = dgi^T x) and the input gradients are ordinary dense launches
 // over all T*R rows afterwards (ops.py).
+#include "diag.h"
 #include "common.h"
 
 namespace arvae {
@@ -1002,7 +1003,7 @@ using namespace arvae;
 
 // ARVAE_GRU_FP32=1: the fp32-MFMA kernels (A/B measurements; the default is the three-term bf16 split)
 static bool gru_fp32_mfma() {
-    static const bool on = getenv("ARVAE_GRU_FP32") != nullptr;
+    static const bool on = diag_env("ARVAE_GRU_FP32") != nullptr;
     return on;
 }
 

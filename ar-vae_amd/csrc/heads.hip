@@ -4,6 +4,8 @@
 // d_hidden = W_mu^T d_mu + W_ls^T d_ls (gated by the hidden layer's ReLU).  The heads are [zdim <= 16] x [h] GEMVs
 // per sample: a few MFLOP per batch, so the cost is the number of launches; plain FMA loops, 8 batch rows per
 // 256-thread workgroup.
+#include <mutex>
+#include "diag.h"
 #include "common.h"
 #include "rng.h"
 
@@ -217,7 +219,7 @@ bool heads_fusable(const arvae_layer_t *hm, const arvae_layer_t *hl, int zdim) {
 bool heads_next_fusable(const arvae_layer_t *l, int zdim) {
     // Measured at B = 512 (dSprites): the two heads kernels grow by 6.2 + 8.4 us (64 workgroups of 8 rows do the layer's work
     // behind their own dependency chain) while the two launches they replace cost 4.7 + 6.5 us: off unless ARVAE_HEADS_NEXT=1.
-    static const bool on = getenv("ARVAE_HEADS_NEXT") != nullptr;
+    static const bool on = diag_env("ARVAE_HEADS_NEXT") != nullptr;
     const arvae_link_t &k = l->link;
     return on && !l->is_up && k.hh == 1 && k.hw == 1 && k.lh == 1 && k.lw == 1 && k.kh == 1 && k.kw == 1 && k.hi_perm_c == 0 &&
            k.lo_perm_c == 0 && l->dropout == 0 && k.chi == zdim && k.clo <= HEAD_NEXT_MAX && (k.clo & 3) == 0;
@@ -244,12 +246,11 @@ int heads_latent_fwd(const arvae_layer_t *hm, const arvae_layer_t *hl, int batch
     p.eps = eps; p.mu = mu; p.log_std = log_std; p.sigma = sigma; p.z = z;
     p.batch = batch; p.h = hm->link.chi; p.zdim = zdim;
     const size_t lds = (size_t)(HEAD_ROWS * p.h + 2 * HEAD_ZMAX * (p.h + 4) + HEAD_ROWS * 32) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
+    static std::once_flag attr;
+    std::call_once(attr, [&] {
         (void)hipFuncSetAttribute((const void *)heads_latent_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (HEAD_ROWS * HEAD_HMAX + 2 * HEAD_ZMAX * (HEAD_HMAX + 4) + HEAD_ROWS * 32) * (int)sizeof(float));
-        attr = true;
-    }
+    });
     ARVAE_LAUNCH(heads_latent_fwd_kernel, dim3((batch + HEAD_ROWS - 1) / HEAD_ROWS), dim3(256), lds, s, p);
     return check_launch("heads_latent_fwd");
 }

@@ -12,6 +12,7 @@
 // gathered global -> registers (prefetched one K-tile ahead so the loads fly under the MFMAs) ->
 // LDS in k-major order [BK][BM+1], from where each lane reads the single A and B value the
 // 32x32x2 MFMA wants (lane = (row|col) + 32 * k-parity) with conflict-free ds_read_b32.
+#include "diag.h"
 #include "common.h"
 #include "conv32_common.h"
 
@@ -631,7 +632,7 @@ __global__ __launch_bounds__(256) void down_single_channel_mfma_kernel(Geom g, O
 
 static bool single_channel_mfma_fits(const arvae_link_t *l) {
     return l->chi == 1 && l->clo == 64 && l->kh * l->kw <= 16 && l->hi_perm_c == 0 && l->lo_perm_c == 0 &&
-           (size_t)l->hh * l->hw * sizeof(float) <= 64 * 1024 && getenv("ARVAE_C1_GENERIC") == nullptr;
+           (size_t)l->hh * l->hw * sizeof(float) <= 64 * 1024 && diag_env("ARVAE_C1_GENERIC") == nullptr;
 }
 
 // bias gradients: out[feature(c)] += sum_rows g[row, c], two fixed-order stages (no float atomics)
@@ -765,7 +766,7 @@ using namespace arvae;
 
 // experiment switch: Linear layers over >= 2048 rows (the MeasureVAE's whole-sequence GEMMs) on the LDS-staged generic kernels
 static bool dense_rows_generic(const arvae_link_t *l, int which) {
-    static const int mode = getenv("ARVAE_DENSE_GENERIC") ? atoi(getenv("ARVAE_DENSE_GENERIC")) : 0;
+    static const int mode = diag_env("ARVAE_DENSE_GENERIC") ? atoi(diag_env("ARVAE_DENSE_GENERIC")) : 0;
     return l->n >= 2048 && (mode & which) != 0;
 }
 
@@ -871,7 +872,7 @@ extern "C" int arvae_link_up(const arvae_link_t *link, const arvae_operand_t *lo
         if (int rc = conv32_make_operands(wt, lo->v, (int64_t)link->n * link->lh * link->lw * link->clo, ws, st, &wprep, &amax)) return rc;
 #ifdef ARVAE_STAMPS
         static const float *stamp_gate = nullptr;                // diagnostic build: time the gated variant too
-        if (getenv("ARVAE_STAMP_GATE") != nullptr) {
+        if (diag_env("ARVAE_STAMP_GATE") != nullptr) {
             if (stamp_gate == nullptr) (void)hipMalloc((void **)&stamp_gate, (size_t)link->n * link->hh * link->hw * link->chi * 4);
             return conv32_up(link, make_operand(lo), nullptr, 0, stamp_gate, nullptr, nullptr, hi, st, wprep, amax, nullptr);
         }
@@ -887,7 +888,7 @@ extern "C" int arvae_link_up(const arvae_link_t *link, const arvae_operand_t *lo
         Epilogue ep{bias, out_mask, hi, out_act};
         const size_t t_bytes = sizeof(float) * 17 * link->lh * link->lw;
         if ((link->clo == 64 || link->clo == 32) && link->kh * link->kw <= 16 && t_bytes <= 96 * 1024 &&
-            getenv("ARVAE_UP1_NAIVE") == nullptr) {
+            diag_env("ARVAE_UP1_NAIVE") == nullptr) {
             if (link->clo == 64) ARVAE_LAUNCH(up_single_channel_mfma_kernel<4>, dim3(link->n), dim3(256), t_bytes, st, p.g, lo->v, wt, ep);
             else ARVAE_LAUNCH(up_single_channel_mfma_kernel<2>, dim3(link->n), dim3(256), t_bytes, st, p.g, lo->v, wt, ep);
             return check_launch("link_up(single channel, mfma)");

@@ -12,6 +12,8 @@
 // reduce-major for the direction that uses it ([k][n] for the forward product, [n][k] for the backward one), with the
 // NCHW-flatten permutations of the first / last layer folded in.  Exact fp32 FMA chains (no MFMA: at 4 rows a matrix tile
 // would be three quarters padding and the weight stream, not the arithmetic, sets the pace).
+#include <mutex>
+#include "diag.h"
 #include "common.h"
 #include "dense.h"
 #include "rng.h"
@@ -407,7 +409,7 @@ bool mid_fusable(const arvae_image_vae_t *m, int *ne_out, int *nd_out) {
     // launches).  Phase stamps (tools/stamp_mid.py): every layer of the chain costs >= 3.3 us however small (the 10 -> 256
     // layer included): a dependent round trip to the freshly written weights, two barriers and the saved-activation store per
     // layer, on 128 of the 256 CUs.
-    static const bool off = getenv("ARVAE_MIDBLOCK") != nullptr && getenv("ARVAE_MIDBLOCK")[0] == '0';
+    static const bool off = diag_env("ARVAE_MIDBLOCK") != nullptr && diag_env("ARVAE_MIDBLOCK")[0] == '0';
     int ne = 0, nd = 0;
     while (ne < m->n_enc && ne < MID_MAX_LAYERS && mid_layer_ok(m->enc[m->n_enc - 1 - ne])) ++ne;
     while (nd < m->n_dec && nd < MID_MAX_LAYERS) {
@@ -480,16 +482,7 @@ struct MidPlan {
 };
 
 // fills the layer tables from the model description; y / gpre buffers are given per layer by the caller afterwards
-static int mid_cu_count() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
-}
+static int mid_cu_count() { return device_cu_count(); }
 
 static void mid_describe(const arvae_image_vae_t *m, const float *params, float *prep_ws, MidPlan &pl, int batch = 512) {
     int ne, nd;
@@ -574,7 +567,7 @@ static void mid_describe(const arvae_image_vae_t *m, const float *params, float 
     // for B <= 256 / 512 / more on 256 CUs (B = 512: forward 32.0 -> 28.8 us, backward 34.6 -> 31.0 us against 4 rows; 8 rows per
     // workgroup measured 49 vs 36 us forward: the FMA work per workgroup doubles).  ARVAE_MID_ROWS=n overrides.
     {
-        static const int forced = getenv("ARVAE_MID_ROWS") != nullptr ? atoi(getenv("ARVAE_MID_ROWS")) : 0;
+        static const int forced = diag_env("ARVAE_MID_ROWS") != nullptr ? atoi(diag_env("ARVAE_MID_ROWS")) : 0;
         const int cus = mid_cu_count();
         pl.rows = batch > 2 * cus ? 4 : batch > cus ? 2 : 1;
         if (forced == 1 || forced == 2 || forced == 4) pl.rows = forced;
@@ -585,7 +578,8 @@ static void mid_describe(const arvae_image_vae_t *m, const float *params, float 
 // the clustered kernels take the pass when the model has their shape AND every cluster's 16 workgroups can be resident at once
 // (they wait for each other: one 512-thread workgroup with ~117 KB of LDS per CU)
 static bool midc_use(const MidPlan &pl, int batch) {
-    return pl.cluster && (int64_t)((batch + MC_R - 1) / MC_R) * MC_S <= mid_cu_count();
+    static const bool rows_only = diag_env("ARVAE_MID_NO_CLUSTER") != nullptr;       // diagnostic build: the row kernels of this file
+    return !rows_only && pl.cluster && (int64_t)((batch + MC_R - 1) / MC_R) * MC_S <= mid_cu_count();
 }
 static void midc_common(McArgs &c, const MidArgs &a, int batch) {
     c.batch = batch;
@@ -596,19 +590,19 @@ static void midc_common(McArgs &c, const MidArgs &a, int batch) {
 }
 
 static void mid_allow_lds() {
-    static bool done = false;
-    if (done) return;
-    const int bytes4 = (2 * 4 * (MID_MAX_W + 4) + mid_red(4) + 4 * 32) * (int)sizeof(float), bytes8 = 120 * 1024;
-    static_assert((2 * 4 * (MID_MAX_W + 4) + mid_red(4) + 4 * 32) * sizeof(float) <= 160 * 1024, "the 4-row block must fit the LDS");
-    (void)hipFuncSetAttribute((const void *)mid_forward_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes4);
-    (void)hipFuncSetAttribute((const void *)mid_backward_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes4);
-    (void)hipFuncSetAttribute((const void *)mid_forward_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes4);
-    (void)hipFuncSetAttribute((const void *)mid_backward_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes4);
-    (void)hipFuncSetAttribute((const void *)mid_forward_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes4);
-    (void)hipFuncSetAttribute((const void *)mid_backward_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes4);
-    (void)hipFuncSetAttribute((const void *)mid_forward_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes8);
-    (void)hipFuncSetAttribute((const void *)mid_backward_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes8);
-    done = true;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const int bytes4 = (2 * 4 * (MID_MAX_W + 4) + mid_red(4) + 4 * 32) * (int)sizeof(float), bytes8 = 120 * 1024;
+        static_assert((2 * 4 * (MID_MAX_W + 4) + mid_red(4) + 4 * 32) * sizeof(float) <= 160 * 1024, "the 4-row block must fit the LDS");
+        (void)hipFuncSetAttribute((const void *)mid_forward_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes4);
+        (void)hipFuncSetAttribute((const void *)mid_backward_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes4);
+        (void)hipFuncSetAttribute((const void *)mid_forward_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes4);
+        (void)hipFuncSetAttribute((const void *)mid_backward_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes4);
+        (void)hipFuncSetAttribute((const void *)mid_forward_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes4);
+        (void)hipFuncSetAttribute((const void *)mid_backward_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes4);
+        (void)hipFuncSetAttribute((const void *)mid_forward_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes8);
+        (void)hipFuncSetAttribute((const void *)mid_backward_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes8);
+    });
 }
 
 // the prep launch's arguments alone (plan.hip hands them to conv32_weight_prep, which runs both preps as one launch)
@@ -643,7 +637,7 @@ int mid_forward(const arvae_image_vae_t *m, int batch, const float *params, floa
         for (int i = 1; i < a.ne; ++i) { a.warm_ptr[nw] = a.enc[i].mf; a.warm_lines[nw++] = lines((int64_t)a.enc[i].k * a.enc[i].n); }
         a.warm_ptr[nw] = a.hf; a.warm_lines[nw++] = lines((int64_t)a.h * 2 * a.zdim);
         for (int i = 0; i < a.nd; ++i) { a.warm_ptr[nw] = a.dec[i].mf; a.warm_lines[nw++] = lines((int64_t)a.dec[i].k * a.dec[i].n); }
-        if (getenv("ARVAE_MID_NO_WARM") != nullptr) nw = 0;
+        if (diag_env("ARVAE_MID_NO_WARM") != nullptr) nw = 0;
     }
     mid_allow_lds();
     if (!prep_done) {
@@ -692,7 +686,7 @@ int mid_backward(const arvae_image_vae_t *m, int batch, const float *params, flo
         for (int i = a.nd - 2; i >= 0; --i) { a.warm_ptr[nw] = a.dec[i].mb; a.warm_lines[nw++] = lines((int64_t)a.dec[i].kb * a.dec[i].n); }
         a.warm_ptr[nw] = a.hb; a.warm_lines[nw++] = lines((int64_t)a.h * 2 * a.zdim);
         for (int i = a.ne - 1; i >= 0; --i) { a.warm_ptr[nw] = a.enc[i].mb; a.warm_lines[nw++] = lines((int64_t)a.enc[i].kb * a.enc[i].n); }
-        if (getenv("ARVAE_MID_NO_WARM") != nullptr) nw = 0;
+        if (diag_env("ARVAE_MID_NO_WARM") != nullptr) nw = 0;
     }
     mid_allow_lds();
     if (midc_use(pl, batch)) {

@@ -1,6 +1,7 @@
 // Whole-model forward / backward executors for the conv AR-VAEs (see include/arvae_hip.h): one host call
 // enqueues every kernel of a pass on the caller's stream.  Host-side sequencing only -- the math lives in
 // the link / dense / loss kernels, reached through the same C-ABI entry points a per-layer caller uses.
+#include "diag.h"
 #include "common.h"
 #include "dense.h"
 #include "reduce.h"
@@ -198,7 +199,7 @@ static int make_layout(const arvae_image_vae_t *m, int64_t n, int64_t n_cols, La
         arvae_link_t lk = l.link;
         lk.n = (int32_t)n;
         const bool fast = (conv32_fits(&lk) && wprep >= 0) || (conv_c1_fits(&lk) && !l.is_up);
-        static const bool off = getenv("ARVAE_NO_RELU_BITS") != nullptr;      // diagnostic: gate with the float activations
+        static const bool off = diag_env("ARVAE_NO_RELU_BITS") != nullptr;      // diagnostic: gate with the float activations
         return (fast && !off && l.act == ARVAE_ACT_RELU && !l.dropout) ? take(out_elems(l, n) / 32) : -1;
     };
     int n_prep = 0;
@@ -513,13 +514,13 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
             if (L.dec_wprep[i] >= 0) { wts[np] = params + m->dec[i].w_off; preps[np++] = ws + L.dec_wprep[i]; }
         // (together with the latent block's matrix layouts when that block runs: one prep launch per step -- or none: when
         // the first encoder layer is the single-channel convolution, the prep rides in ITS grid, conv_c1.hip)
-        if (np > 0 && mid && getenv("ARVAE_SPLIT_PREP") == nullptr) {
+        if (np > 0 && mid && diag_env("ARVAE_SPLIT_PREP") == nullptr) {
             MidPrepArgs margs;
             mid_prep_args(m, params, ws + L.mid_prep, &margs);
             const arvae_layer_t &l0 = m->enc[0];
             arvae_link_t lk0 = l0.link;
             lk0.n = batch;
-            static const bool no_pair = getenv("ARVAE_NO_PAIR_PREP") != nullptr;     // diagnostic: the prep as its own launch
+            static const bool no_pair = diag_env("ARVAE_NO_PAIR_PREP") != nullptr;     // diagnostic: the prep as its own launch
             if (!no_pair && m->n_enc - mid_ne > 1 && L.enc_bits[0] >= 0 && L.enc_wprep[0] < 0 && !l0.is_up && conv_c1_fits(&lk0) &&
                 !(masks != nullptr && l0.dropout)) {
                 const arvae_operand_t op = plain(x);

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "common.h"
+#include "diag.h"
 
 namespace arvae {
 
@@ -54,6 +55,16 @@ int check_launch(const char *what) {
     if (e != hipSuccess) return fail(ARVAE_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
     if (g_prof_on) prof_mark(what);
     return ARVAE_OK;
+}
+
+int device_cu_count() {
+    static const int n = [] {                   // (thread-safe initialisation; the forward and the autograd thread both come here)
+        int dev = 0, cus = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        return cus > 0 ? cus : 256;
+    }();
+    return n;
 }
 
 }  // namespace arvae

@@ -68,15 +68,15 @@ KERNEL_WORK = {
     'down_c1_kernel': (524_288, 4 * (4096 + 32768)), 'wgrad_c1_kernel': (524_288, 4 * (32768 + 4096)),
     # last decoder layer with the reconstruction term fused in: lo in; logits, d/dlogits out; image in
     'up_c1_kernel(recon)': (524_288, 4 * (32768 + 3 * 4096)), 'up_c1_kernel': (524_288, 4 * (32768 + 4096)),
-    # a layer's data gradient and weight gradient in one launch: the upstream gradient is read by both halves
-    'pair4(down32 + wgrad32)': (2 * 262_144, 4 * (2 * 2048 + 2 * 512)), 'pair4(up32 + wgrad32)': (2 * 262_144, 4 * (2 * 512 + 2 * 2048)),
-    'pair_c1(down_c1 + wgrad_c1)': (2 * 524_288, 4 * (2 * 4096 + 2 * 32768)),
+    # A layer's two backward products in one launch: SURVEY 8(d)'s layer-boundary bytes of a layer's BACKWARD -- the upstream
+    # gradient read ONCE, the saved input once, the input gradient written once.  (Both halves of a paired launch stream the
+    # upstream gradient on disjoint CUs: the second read is TRAFFIC -- roofline.traffic, profiles/*_pmc_traffic.json --, not work.)
+    'pair4(down32 + wgrad32)': (2 * 262_144, 4 * (2048 + 512 + 512)), 'pair4(up32 + wgrad32)': (2 * 262_144, 4 * (512 + 2048 + 2048)),
+    'pair_c1(down_c1 + wgrad_c1)': (2 * 524_288, 4 * (4096 + 32768 + 32768)),
     # the first layer's weight gradient with the grouped Linear weight gradients riding in its grid
     'pair(wgrad_c1 + dense_wgrad_batch)': (524_288 + 400_896, 4 * (32768 + 4096) + 4 * 3102, 4 * 400_896),
-    # the same pair for the 16x16 / 8x8 layers: data gradient (gradient in, input gradient out) + weight gradient (gradient and
-    # saved input in)
-    'pair(down32<16> + wgrad32<16>)': (2 * 4_194_304, 4 * (2 * 32768 + 2 * 8192)), 'pair(up32<16> + wgrad32<16>)': (2 * 4_194_304, 4 * (2 * 8192 + 2 * 32768)),
-    'pair(down32<8> + wgrad32<8>)': (2 * 1_048_576, 4 * (2 * 8192 + 2 * 2048)), 'pair(up32<8> + wgrad32<8>)': (2 * 1_048_576, 4 * (2 * 2048 + 2 * 8192)),
+    'pair(down32<16> + wgrad32<16>)': (2 * 4_194_304, 4 * (32768 + 8192 + 8192)), 'pair(up32<16> + wgrad32<16>)': (2 * 4_194_304, 4 * (8192 + 32768 + 32768)),
+    'pair(down32<8> + wgrad32<8>)': (2 * 1_048_576, 4 * (8192 + 2048 + 2048)), 'pair(up32<8> + wgrad32<8>)': (2 * 1_048_576, 4 * (2048 + 8192 + 8192)),
     # the first encoder layer with the step's weight preparation riding in its grid; the decoder's first convolution with
     # the regulariser's workgroups riding in its grid
     'down_c1_kernel(+ weight prep)': (524_288, 4 * (4096 + 32768), 8_000_000), 'up32_kernel<4>(+ reg_loss)': (262_144, 4 * (512 + 2048)),
@@ -85,6 +85,8 @@ KERNEL_WORK = {
     # upstream gradient + saved input (weight gradients); the third number is bytes per LAUNCH that do not scale with the
     # batch: the 1.6 MB of fp32 matrices read (forward, backward) or written (weight gradients) once
     'mid_forward_kernel': (400_896, 4 * 3102, 4 * 400_896), 'mid_backward_kernel': (400_896, 4 * (3102 + 1556), 4 * 400_896),
+    # the same block on clusters of workgroups (midcluster.hip: the default for this model since round 4)
+    'midc_forward_kernel': (400_896, 4 * 3102, 4 * 400_896), 'midc_backward_kernel': (400_896, 4 * (3102 + 1556), 4 * 400_896),
     'dense_wgrad_batch_kernel': (400_896, 4 * 3102, 4 * 400_896),
     # fixed-order sum of the conv layers' weight-gradient slabs: 4 x 256 slabs of 64 KB (16x16 and 8x8 layers), 2 x 128
     # (4x4 layers), 2 x 256 x 2 KB (single-channel layers) + bias partials read, 2 MB of gradients written
@@ -379,11 +381,22 @@ def side_roofline(kind, prof, prof_steps, batch):
     if not prof:
         return None
     total = sum(v['ms'] for v in prof.values())
-    name, dom = max(prof.items(), key=lambda kv: kv[1]['ms'])
-    out = {'kernel': name, 'rocprof_names': rocprof_names(name), 'launches_per_step': dom['calls'] / prof_steps,
+    # the timeline labels one launch SITE; a rocprofv3 trace lists kernels: labels that are instantiations of one kernel are
+    # one family here (e.g. the wide and the narrow paired-row weight gradients), and the family with the largest TOTAL time
+    # in a step is the dominant one -- the same ranking a --kernel-trace --stats summary gives
+    fams = {}
+    for label, v in prof.items():
+        key = tuple(rocprof_names(label) or [label])
+        f = fams.setdefault(key, {'labels': [], 'ms': 0.0, 'calls': 0})
+        f['labels'].append(label)
+        f['ms'] += v['ms']
+        f['calls'] += v['calls']
+    key, dom = max(fams.items(), key=lambda kv: kv[1]['ms'])
+    name = ' + '.join(sorted(dom['labels']))
+    out = {'kernel': name, 'rocprof_names': list(key), 'launches_per_step': dom['calls'] / prof_steps,
            'avg_launch_us': 1e3 * dom['ms'] / dom['calls'], 'us_per_step': 1e3 * dom['ms'] / prof_steps,
            'share_of_device_time': dom['ms'] / total, 'device_time_us_per_step': 1e3 * total / prof_steps}
-    for tag in ('r3', 'r2'):            # the top kernel of the committed rocprofv3 --kernel-trace --stats summary of this workload
+    for tag in ('r4', 'r3', 'r2'):      # the top kernel of the committed rocprofv3 --kernel-trace --stats summary of this workload
         try:
             import csv
             with open(os.path.join(ROOT, 'profiles', f'{tag}_{kind}_kernel_stats.csv')) as f:
@@ -394,10 +407,11 @@ def side_roofline(kind, prof, prof_steps, batch):
             break
         except (OSError, KeyError, ValueError):
             continue
-    macs = SIDE_KERNEL_MACS.get(kind, {}).get(name)
-    per_launch = SIDE_KERNEL_MACS_PER_LAUNCH.get(kind, {}).get(name)
-    if per_launch:
-        macs = per_launch * dom['calls'] / prof_steps
+    macs = sum(SIDE_KERNEL_MACS.get(kind, {}).get(lb, 0) for lb in dom['labels'])
+    for lb in dom['labels']:
+        per_launch = SIDE_KERNEL_MACS_PER_LAUNCH.get(kind, {}).get(lb)
+        if per_launch:
+            macs += per_launch * prof[lb]['calls'] / prof_steps
     if macs:
         # (the wide 64-channel convolutions and their weight gradient moved to the two-term fp16 arithmetic in round 3)
         products = F16X2_PRODUCTS if (kind == 'mnist' and ('wide' in name or 'pairs' in name)) else BF16X3_PRODUCTS
@@ -575,7 +589,7 @@ def run_dsprites(device, args, fence, rank, world, use_dp):
     # HBM traffic of that kernel from the PMC counters: collected in separate rocprofv3 --pmc passes of this
     # same command (FETCH_SIZE / WRITE_SIZE cannot share a pass) and committed under profiles/
     step_traffic = None
-    for tag in ('r3', 'r2', 'r1'):
+    for tag in ('r4', 'r3', 'r2', 'r1'):
         try:
             with open(os.path.join(ROOT, 'profiles', f'{tag}_pmc_traffic.json')) as f:
                 pmc = json.load(f)
@@ -596,15 +610,21 @@ def run_dsprites(device, args, fence, rank, world, use_dp):
     # figure above brackets every launch with its own events, which costs each kernel the overlap with its neighbours' tails)
     try:
         import csv
-        stats_csv = next(t for t in ('r3', 'r2') if os.path.exists(os.path.join(ROOT, 'profiles', f'{t}_dsprites_kernel_stats.csv')))
+        stats_csv = next(t for t in ('r4', 'r3', 'r2') if os.path.exists(os.path.join(ROOT, 'profiles', f'{t}_dsprites_kernel_stats.csv')))
         with open(os.path.join(ROOT, 'profiles', f'{stats_csv}_dsprites_kernel_stats.csv')) as f:
             rows = [r for r in csv.DictReader(f) if any(nm in r['Name'] for nm in (rocprof_names(dom_name) or []))]
         calls = sum(int(r['Calls']) for r in rows)
         if calls and b == 512:
             roof['rocprof_avg_launch_us'] = sum(float(r['TotalDurationNs']) for r in rows) / calls / 1e3
             roof['rocprof_source'] = f'profiles/{stats_csv}_dsprites_kernel_stats.csv'
+            # the same algorithmic work over the trace's duration (launches back to back, no event between them)
+            work = (mfma_work if roof['bound'] == 'mfma' else dom['bytes']) / dom['calls']
+            roof['achieved_rocprof'] = work / (roof['rocprof_avg_launch_us'] * 1e-6) / (1e12 if roof['bound'] == 'mfma' else 1e9)
+            roof['frac_rocprof'] = roof['achieved_rocprof'] / roof['peak']
     except (OSError, KeyError, ValueError, StopIteration):
         pass
+    roof['timing_source'] = ('achieved / frac: HIP events around every launch of the kernel, this run (avg_launch_us); achieved_rocprof / '
+                             'frac_rocprof: the committed rocprofv3 --kernel-trace --stats average of the same kernel (rocprof_avg_launch_us)')
     roof.update({'kernel': dom_name, 'rocprof_names': rocprof_names(dom_name),
                  'launches_per_step': dom['calls'] / prof_steps, 'avg_launch_us': avg_ms * 1e3,
                  'algorithmic_bytes_per_launch': dom['bytes'] / dom['calls'],

@@ -9,9 +9,10 @@
  *  - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller unless the
  *    parameter is documented as "host".  The library allocates no device memory (every scratch buffer is a caller
  *    workspace whose size an arvae_*_ws_floats function reports) and no call depends on state left by another, so the
- *    forward (main thread) and backward (autograd thread) may call concurrently.  What is process-wide: diagnostic
- *    environment switches read once on first use ("Run-time switches"), the once-per-kernel registration of
- *    dynamic LDS sizes (hipFuncSetAttribute), and the opt-in timeline of arvae_profile_begin/_end.
+ *    forward (main thread) and backward (autograd thread) may call concurrently.  What is process-wide: the once-per-kernel
+ *    registration of dynamic LDS sizes (hipFuncSetAttribute behind std::call_once), the device's CU count (queried once), the
+ *    run-time binding of RCCL (arvae_comm_*) and the opt-in timeline of arvae_profile_begin/_end.  The library reads NO
+ *    environment variable: its diagnostic switches exist only in the -DARVAE_DIAG build (libarvae_hip_diag.so, csrc/diag.h).
  *  - `stream` is a hipStream_t passed as void*; calls only enqueue work and never synchronise.
  *  - return value: 0 = ok, <0 = error (ARVAE_E_*); arvae_last_error_string() gives the thread-local text.
  *  - tensors are fp32, contiguous, CHANNELS-LAST: activations [N, H, W, C]; a 1-channel image

@@ -176,3 +176,25 @@ def test_library_transport_needs_a_gpu():
     from arvae_amd import parallel
     with pytest.raises(RuntimeError, match='needs a GPU'):
         parallel.LibraryComm(0, 1)
+
+
+def test_product_library_reads_no_environment(lib):
+    """the product library has no run-time switches (csrc/diag.h): it does not even import getenv; the diagnostic build of the
+    same sources does, and both export the same ABI"""
+    import shutil
+    import subprocess
+    from arvae_amd import build
+    nm = shutil.which('nm')
+    if nm is None:
+        pytest.skip('nm not available')
+
+    def undefined(path):
+        out = subprocess.run([nm, '-D', '--undefined-only', path], check=True, capture_output=True, text=True).stdout
+        return {ln.split()[-1].split('@')[0] for ln in out.splitlines() if ln.strip()}
+
+    def exported(path):
+        out = subprocess.run([nm, '-D', '--defined-only', path], check=True, capture_output=True, text=True).stdout
+        return {ln.split()[-1] for ln in out.splitlines() if ' T ' in ln and 'arvae_' in ln}
+    assert 'getenv' not in undefined(build.LIB_PATH) and 'secure_getenv' not in undefined(build.LIB_PATH)
+    assert 'getenv' in undefined(build.DIAG_LIB_PATH)
+    assert exported(build.LIB_PATH) == exported(build.DIAG_LIB_PATH)

@@ -18,6 +18,9 @@ from oracle import image_vae as o_vae          # noqa: E402
 from oracle import losses as o_losses          # noqa: E402
 from oracle import step as o_step              # noqa: E402
 
+# the diagnostic build of the library (csrc/diag.h: its environment switches are live; the product library has none)
+DIAG_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'ar-vae_amd', 'libarvae_hip_diag.so')
+
 
 @pytest.fixture(scope='module')
 def dev():
@@ -1306,6 +1309,8 @@ def test_paired_launches_match_the_separate_launches(dev):
     # regulariser + first decoder conv
     split_env = {k: '1' for k in ('ARVAE_NO_PAIR4', 'ARVAE_NO_PAIR32', 'ARVAE_NO_PAIR_C1', 'ARVAE_NO_PAIR_TAIL', 'ARVAE_NO_PAIR_PREP',
                                   'ARVAE_NO_PAIR_REG')}
+    # (the switches exist in the diagnostic build of the library only; 'pair' runs the product library)
+    split_env['ARVAE_LIB'] = DIAG_LIB
     for flag, env in (('pair', {}), ('split', split_env)):
         r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
         assert r.returncode == 0, r.stderr[-2000:]
@@ -1336,11 +1341,15 @@ def test_latent_block_experiment_matches_the_per_layer_path(dev):
     res = {}
     # '0': one launch per layer; '1': the latent-block launches (default); 'heads': per layer with ARVAE_HEADS_NEXT=1 (csrc/heads.hip:
     # the decoder's first Linear layer and its data gradient inside the heads kernels, off by default: measured slower)
-    for flag, env in (('0', {'ARVAE_MIDBLOCK': '0'}), ('1', {}), ('heads', {'ARVAE_MIDBLOCK': '0', 'ARVAE_HEADS_NEXT': '1'})):
+    # 'rows': the latent block on the row kernels of midblock.hip instead of the clustered ones (midcluster.hip: the default
+    # for the dSprites-shaped block); the switches exist in the diagnostic build of the library only, '1' runs the product library
+    for flag, env in (('0', {'ARVAE_MIDBLOCK': '0', 'ARVAE_LIB': DIAG_LIB}), ('1', {}),
+                      ('rows', {'ARVAE_MID_NO_CLUSTER': '1', 'ARVAE_LIB': DIAG_LIB}),
+                      ('heads', {'ARVAE_MIDBLOCK': '0', 'ARVAE_HEADS_NEXT': '1', 'ARVAE_LIB': DIAG_LIB})):
         r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
         assert r.returncode == 0, r.stderr[-2000:]
         res[flag] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
-    for flag in ('1', 'heads'):
+    for flag in ('1', 'rows', 'heads'):
         for kind in ('dsprites', 'mnist'):
             close(res[flag][kind]['loss'], res['0'][kind]['loss'], rtol=1e-6)
             for k, v in res['0'][kind]['gn'].items():
