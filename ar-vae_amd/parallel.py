@@ -25,6 +25,8 @@ are RECORDED by a capture (ar-vae_amd/graphed.py: a data-parallel MeasureVAE ste
 through the launcher's TCP store (MASTER_ADDR / MASTER_PORT, `torch.distributed.rendezvous('env://')`), used once to hand
 out RCCL's unique id.  `TorchComm` wraps an initialised torch.distributed group instead: what the CPU tests run on (gloo),
 and an alternative on GPUs (`ARVAE_DP_TRANSPORT=torch`); its collectives cannot be captured, so steps stay eager there.
+`StagedComm` moves device tensors through a gloo group on the host (`ARVAE_DP_TRANSPORT=staged`): several ranks can then share
+one GPU, which is how the world-2 tests of the HIP path run on one-GPU boxes.
 """
 import ctypes
 import os
@@ -206,6 +208,53 @@ class TorchComm:
             self.dist.destroy_process_group()
 
 
+class StagedComm(TorchComm):
+    """Device tensors through a CPU process group (gloo): every collective copies to host memory, runs there and copies back,
+    synchronising the stream.  Slow by construction and never the default; it exists so that the MULTI-RANK logic of the HIP
+    path (row-block regulariser against gathered columns, gradient all-reduce + 1/W, shifted capacity, per-rank random
+    streams, sharded loaders) can run with more ranks than the box has GPUs -- several ranks on one device --, which RCCL
+    refuses.  tests/test_parallel_gpu.py runs its world-2 cases over it on one-GPU boxes."""
+    capturable = False
+
+    def __init__(self, process_group=None, device=None):
+        super().__init__(process_group)
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+
+    def _host(self, t):
+        return t.detach().to('cpu')
+
+    def all_gather(self, out, local):
+        host = torch.empty(out.shape, dtype=out.dtype)
+        self.dist.all_gather_into_tensor(host, self._host(local), group=self.group)
+        out.copy_(host)
+        return out
+
+    def all_gather_async(self, out, local):
+        self.all_gather(out, local)
+        return _Done()
+
+    def all_reduce(self, t, op='sum'):
+        host = self._host(t)
+        self.dist.all_reduce(host, op=self._op(op), group=self.group)
+        t.copy_(host)
+        return t
+
+    def all_reduce_async(self, t, op='sum'):
+        self.all_reduce(t, op)
+        return _Done()
+
+    def broadcast(self, t, src=0):
+        host = self._host(t)
+        self.dist.broadcast(host, src=src, group=self.group)
+        t.copy_(host)
+        return t
+
+
+class _Done:
+    def wait(self):
+        pass
+
+
 def _rendezvous_store(rank, world):
     """the launcher's key-value store: torch.distributed.run's agent store when there is one (TORCHELASTIC_USE_AGENT_STORE),
     else a TCP store rank 0 hosts at MASTER_ADDR:MASTER_PORT.  No process group is created."""
@@ -231,6 +280,14 @@ def connect(rank=None, world=None, device=None, transport=None, key='arvae/comm/
         if not dist.is_initialized():
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(device))
         comm = TorchComm()
+        comm._owns_group = True
+        return comm
+    if transport == 'staged':                                       # several ranks may share one device (tests)
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if not dist.is_initialized():
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        comm = StagedComm(device=device)
         comm._owns_group = True
         return comm
     if transport != 'library':

@@ -36,7 +36,7 @@ def main():
     from arvae_amd.measure_vae_trainer import MeasureVAETrainer
     from arvae_amd.parallel import DataParallel
     from oracle import measure_vae as o_mvae
-    dev = torch.device('cuda', rank)
+    dev = torch.device('cuda', rank % torch.cuda.device_count())       # (transport 'staged': ranks may share a device)
     torch.cuda.set_device(dev)
     comm = parallel.connect(rank, world, dev)
     try:
@@ -64,13 +64,17 @@ def main():
             dp.reduce_gradients(trainer.optimizer)
             res['eager'] = (float(dp.mean_scalar(loss.detach())), trainer.optimizer.grad_arena.clone() * trainer.optimizer.grad_scale)
             # the same step replayed from graphs (twice: a replay must not depend on what the capture left behind)
-            for _ in range(repeats):
-                graphed = GraphedStep(trainer, (score, score))
-                for _ in range(2):
-                    loss_g, _ = graphed((score, score))
-                    dp.reduce_gradients(trainer.optimizer)
-            variants = len(graphed.graphs)
-            res['replay'] = (float(dp.mean_scalar(loss_g.detach())), trainer.optimizer.grad_arena.clone() * trainer.optimizer.grad_scale)
+            variants = 0
+            if dp.capturable:
+                for _ in range(repeats):
+                    graphed = GraphedStep(trainer, (score, score))
+                    for _ in range(2):
+                        loss_g, _ = graphed((score, score))
+                        dp.reduce_gradients(trainer.optimizer)
+                variants = len(graphed.graphs)
+                res['replay'] = (float(dp.mean_scalar(loss_g.detach())), trainer.optimizer.grad_arena.clone() * trainer.optimizer.grad_scale)
+            else:                                                    # a transport that cannot be captured: the eager step only
+                res['replay'] = res['eager']
         finally:
             type(model.encoder).static_eps = None
             model.encoder.static_eps = None

@@ -27,7 +27,8 @@ def main():
     from arvae_amd.image_vae import DspritesVAE
     from arvae_amd.image_vae_trainer import ImageVAETrainer
     from arvae_amd.parallel import DataParallel
-    dev = torch.device('cuda', rank)
+    # 'staged' (a gloo group on the host under device tensors): ranks may share a device -- world 2 on a one-GPU box
+    dev = torch.device('cuda', rank % torch.cuda.device_count())
     # ARVAE_DP_TRANSPORT: 'library' (default: RCCL through libarvae_hip.so, no torch process group) | 'torch'
     comm = parallel.connect(rank, world, dev)
     try:

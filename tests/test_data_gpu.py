@@ -185,6 +185,34 @@ def test_train_cli_data_parallel_code_path(dev, tmp_path):
     assert forced['test_acc'] == pytest.approx(plain['test_acc'], abs=1e-4)
 
 
+def test_train_cli_two_ranks_on_this_box(dev, tmp_path):
+    """train_image_vae.py as TWO ranks (RANK / WORLD_SIZE / LOCAL_RANK as torch.distributed.run sets them; both ranks on cuda:0
+    when the box has one GPU, collectives staged through the host: ARVAE_DP_TRANSPORT=staged): every rank walks its half of
+    rank 0's shuffled global batches, the epoch statistics are the ranks' means, rank 0 saves and evaluates alone."""
+    import socket
+    write_dsprites(str(tmp_path), 400)
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    args = ['-d', 'dsprites', '--num_epochs', '1', '--batch_size', '32', '--rand', '3', '-r', 'all']
+    n_gpu = torch.cuda.device_count()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, ARVAE_DATA_DIR=str(tmp_path), ARVAE_MODEL_DIR=str(tmp_path / 'models'), RANK=str(r), WORLD_SIZE='2',
+                   LOCAL_RANK=str(r % n_gpu), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   ARVAE_DP_TRANSPORT='staged' if n_gpu < 2 else 'library')
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'train_image_vae.py')] + args, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True, env=env, cwd=str(tmp_path)))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    # 280 training rows, global batch 2 x 32: four full global batches + a tail of 24 -> 12 rows per rank
+    assert 'Num Train Batches:  5' in outs[0] and 'Num Train Batches' not in outs[1]
+    summary = json.JSONDecoder().raw_decode(outs[0][outs[0].index('{\n'):])[0]
+    assert summary['num_codes'] == 400 - int((0.80 + 0.15) * 400) and np.isfinite(summary['test_loss'])
+    assert '{\n' not in outs[1]                                      # the other rank neither evaluates nor prints a summary
+
+
 def test_measure_inference_for_evaluation(dev, tmp_path):
     """N4, measure side (measure_vae_trainer.py:281-308,367-397): decoder-only passes, the reconstruction-only test loss and
     the representation record the host-side metric suite reads."""

@@ -59,18 +59,29 @@ def _run_ranks(world, out, capacity, fused, overlap=False, worker='dp_worker.py'
 
 # capacity 3.7 lies between the two shards' KL means of this batch (test_parallel_gloo.py): beta*|KL - c| then needs the
 # all-reduced KL mean; 25 is the golden's value (dsprites_step_b8_cap_gauss uses it at B = 8)
-@pytest.mark.parametrize('transport', ['library', 'torch'])
+def _needs(world, transport):
+    """RCCL wants one GPU per rank; the host-staged transport (parallel.StagedComm) lets the ranks share a device"""
+    if transport == 'staged':
+        if world == 1:
+            pytest.skip('the host-staged transport is for more ranks than GPUs')
+    elif torch.cuda.device_count() < world:
+        pytest.skip(f'needs {world} GPUs, this box has {torch.cuda.device_count()}')
+
+
+@pytest.mark.parametrize('transport', ['library', 'torch', 'staged'])
 @pytest.mark.parametrize('fused', [True, False], ids=['fused', 'per_layer'])
 @pytest.mark.parametrize('capacity', [0.0, 3.7])
 @pytest.mark.parametrize('world', [1, 2])
 def test_rccl_ranks_equal_single_process(tmp_path, golden_dir, world, capacity, fused, transport):
-    if torch.cuda.device_count() < world:
-        pytest.skip(f'needs {world} GPUs, this box has {torch.cuda.device_count()}')
+    """(transport 'staged', world 2: TWO ranks of the HIP path on whatever GPUs the box has -- both on cuda:0 on a one-GPU box --
+    with the collectives staged through a gloo group on the host: the multi-rank LOGIC of the HIP path against the oracle's
+    single-process step, where RCCL itself cannot run for want of a second GPU)"""
+    _needs(world, transport)
     if transport == 'torch' and not (fused and capacity == 0.0):
         pytest.skip('the torch.distributed transport is covered on the default step only')
     got = _run_ranks(world, str(tmp_path / 'dp.npz'), capacity, fused, transport=transport)
     assert int(got['world']) == world
-    assert str(got['transport']) == {'library': 'LibraryComm', 'torch': 'TorchComm'}[transport]
+    assert str(got['transport']) == {'library': 'LibraryComm', 'torch': 'TorchComm', 'staged': 'StagedComm'}[transport]
     state = syn.synth_state(o_vae.DSPRITES_SHAPES, 1, 1.6)
     x, lab = syn.dsprites_batch(B_TOTAL, seed=1234)
     eps = syn.normal_noise((B_TOTAL, 10), seed=12)
@@ -111,19 +122,21 @@ def test_rccl_overlapped_collectives_change_nothing(tmp_path, world):
             np.testing.assert_array_equal(on[k], off[k], err_msg=k)
 
 
-@pytest.mark.parametrize('world', [1, 2])
-def test_measure_data_parallel_step_replays_from_graphs(tmp_path, world):
+@pytest.mark.parametrize('world,transport', [(1, 'library'), (2, 'library'), (2, 'staged')])
+def test_measure_data_parallel_step_replays_from_graphs(tmp_path, world, transport):
     """a data-parallel MeasureVAE step replayed from a HIP graph that holds its collective (the library's RCCL all-gather,
     recorded like the kernels around it; no torch process group, no watchdog thread in the worker) gives the eager
     data-parallel step's loss and all-reduced gradients, and those are the oracle's single-process step on the whole batch."""
-    if torch.cuda.device_count() < world:
-        pytest.skip(f'needs {world} GPUs, this box has {torch.cuda.device_count()}')
+    _needs(world, transport)
     from oracle import attributes as o_attr
     from oracle import measure_vae as o_mvae
     b_total = 32
-    got = _run_ranks(world, str(tmp_path / 'm.npz'), 0.0, True, worker='dp_measure_worker.py', args=[b_total])
+    got = _run_ranks(world, str(tmp_path / 'm.npz'), 0.0, True, worker='dp_measure_worker.py', args=[b_total], transport=transport)
     assert int(got['world']) == world
-    assert int(got['variants']) == 2 and str(got['transport']) == 'LibraryComm'     # one graph per teacher-forcing variant, collective inside
+    if transport == 'library':
+        assert int(got['variants']) == 2 and str(got['transport']) == 'LibraryComm'     # one graph per teacher-forcing variant, collective inside
+    else:                                       # host-staged collectives cannot be captured: the eager data-parallel step vs the oracle
+        assert int(got['variants']) == 0 and str(got['transport']) == 'StagedComm'
     np.testing.assert_allclose(got['loss_replay'], got['loss_eager'], rtol=1e-6)
     ge, gr = got['grad_eager'].astype(np.float64), got['grad_replay'].astype(np.float64)
     assert np.linalg.norm(ge - gr) <= 1e-6 * np.linalg.norm(ge)
