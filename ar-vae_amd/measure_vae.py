@@ -281,14 +281,14 @@ class HierarchicalDecoder(Decoder):
         """2-layer unidirectional GRU over `steps`: gi0 (T, R, 3H) or (R, 3H); h0 = [layer-0, layer-1] initial states;
         mask (T*R, H) keep-mask on the layer-0 outputs (nn.GRU's inter-layer dropout).  -> layer-1 outputs (T, R, H)"""
         hid = self.rnn_hidden_size
-        out0, _ = ops.gru_sequence(steps, [(gi0, rnn.cell(0)[1], rnn.cell(0)[3], h0[0], False)])
+        out0, _ = ops.gru_sequence(steps, [(gi0, rnn.cell(0)[1], rnn.cell(0)[3], h0[0], False)], finals=False)
         rows = out0.shape[1]
         mid = out0.view(steps * rows, hid)
         if mask is not None:
             mid = ops.dropout_mask(mid, mask, self.dropout)
         w_ih1, w_hh1, b_ih1, b_hh1 = rnn.cell(1)
         gi1 = ops.dense(mid, w_ih1, b_ih1, Link.dense(w_ih1.shape[1], w_ih1.shape[0]), ACT_NONE).view(steps, rows, -1)
-        return ops.gru_sequence(steps, [(gi1, w_hh1, b_hh1, h0[1], False)])[0]
+        return ops.gru_sequence(steps, [(gi1, w_hh1, b_hh1, h0[1], False)], finals=False)[0]
 
     def beat_rnn_sequence(self, z, seq_len, mask=None):
         """-> (4, B, H) beat embeddings (decoder.py:436-457)"""

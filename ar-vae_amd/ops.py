@@ -606,7 +606,7 @@ class _GruSeqFn(Function):
     final states (R, ndir*H) = nn.GRU's h_n (each direction's last processed step)."""
 
     @staticmethod
-    def forward(ctx, steps, reverse, *tensors):
+    def forward(ctx, steps, reverse, want_finals, *tensors):
         ndir = len(reverse)
         gis, whs, bhs, h0s = tensors[0::4], tensors[1::4], tensors[2::4], tensors[3::4]
         _dev(*[t for t in tensors if t is not None])
@@ -624,13 +624,20 @@ class _GruSeqFn(Function):
             q.saved, q.reverse = saved[d].data_ptr(), int(reverse[d])
         with _timed('gru_seq_fwd', 2.0 * ndir * steps * rows * 3 * hid * hid, 4.0 * ndir * steps * rows * 8 * hid):
             _lib.check(lib.arvae_gru_seq_fwd(descs, ndir, steps, rows, hid, _stream()), 'gru_seq_fwd')
-        finals = torch.cat([out[0 if reverse[d] else steps - 1, :, d * hid:(d + 1) * hid] for d in range(ndir)], 1)
+        # (a copy launch per call: only for callers that read the final states -- the encoder; the decoder's four sequence
+        # launches per step used to pay it for nothing)
+        finals = (torch.cat([out[0 if reverse[d] else steps - 1, :, d * hid:(d + 1) * hid] for d in range(ndir)], 1)
+                  if want_finals else None)
         ctx.save_for_backward(out, saved, *whs, *[h for h in h0s if h is not None])
         ctx.h0_present = [h is not None for h in h0s]
         ctx.gi_const = [g.dim() == 2 for g in gis]
         ctx.refs = (whs, bhs)
         ctx.geom = (steps, rows, hid, tuple(reverse))
         ctx.set_materialize_grads(False)
+        if not want_finals:
+            none = out.new_empty(0)                              # (an empty tensor: no launch)
+            ctx.mark_non_differentiable(none)
+            return out, none
         return out, finals
 
     @staticmethod
@@ -645,12 +652,12 @@ class _GruSeqFn(Function):
         lib = _lib.load()
         dev = out.device
         d_out = None if d_out is None else d_out.contiguous()
-        d_fin = None if d_fin is None else d_fin.contiguous()
+        d_fin = None if (d_fin is None or d_fin.numel() == 0) else d_fin.contiguous()
         dgi = torch.empty(ndir, steps, rows, 3 * hid, device=dev, dtype=torch.float32)
         dgh = torch.empty_like(dgi)
         h_prev = torch.empty(ndir, steps, rows, hid, device=dev, dtype=torch.float32)
         dh0 = [torch.empty(rows, hid, device=dev, dtype=torch.float32)
-               if (h0s[d] is not None and ctx.needs_input_grad[2 + 4 * d + 3]) else None for d in range(ndir)]
+               if (h0s[d] is not None and ctx.needs_input_grad[3 + 4 * d + 3]) else None for d in range(ndir)]
         descs = _gru_seq_descs(ndir)
         for d in range(ndir):
             q = descs[d]
@@ -665,30 +672,32 @@ class _GruSeqFn(Function):
             q.h_prev_out = h_prev[d].data_ptr()
         with _timed('gru_seq_bwd', 2.0 * ndir * steps * rows * 3 * hid * hid, 4.0 * ndir * steps * rows * 12 * hid):
             _lib.check(lib.arvae_gru_seq_bwd(descs, ndir, steps, rows, hid, _stream()), 'gru_seq_bwd')
-        grads = [None, None]
+        grads = [None, None, None]
         link = Link.dense(hid, 3 * hid)
         w_refs, b_refs = ctx.refs
         for d in range(ndir):
             d_w = d_b = None
-            if ctx.needs_input_grad[2 + 4 * d + 1]:
+            if ctx.needs_input_grad[3 + 4 * d + 1]:
                 buf, direct = _grad_target(w_refs[d])
                 bbuf, bdirect = _grad_target(b_refs[d])
                 link_wgrad(link, steps * rows, _operand(dgh[d].view(steps * rows, 3 * hid)),
                            _operand(h_prev[d].view(steps * rows, hid)), buf, bbuf, 1)
                 d_w, d_b = (None if direct else buf), (None if bdirect else bbuf)
             g_gi = None
-            if ctx.needs_input_grad[2 + 4 * d]:
+            if ctx.needs_input_grad[3 + 4 * d]:
                 g_gi = dgi[d].sum(0) if ctx.gi_const[d] else dgi[d]
             grads += [g_gi, d_w, d_b, dh0[d]]
         return tuple(grads)
 
 
-def gru_sequence(steps, directions):
-    """directions: list of (gi, w_hh, b_hh, h0, reverse) -> (outputs (T, R, ndir*H), final states (R, ndir*H))."""
+def gru_sequence(steps, directions, finals=True):
+    """directions: list of (gi, w_hh, b_hh, h0, reverse) -> (outputs (T, R, ndir*H), final states (R, ndir*H) or, with
+    finals=False, None)."""
     flat = []
     for gi, w_hh, b_hh, h0, _ in directions:
         flat += [gi.contiguous(), w_hh, b_hh, None if h0 is None else h0.contiguous()]
-    return _GruSeqFn.apply(int(steps), tuple(bool(d[4]) for d in directions), *flat)
+    out, fin = _GruSeqFn.apply(int(steps), tuple(bool(d[4]) for d in directions), bool(finals), *flat)
+    return out, (fin if finals else None)
 
 
 def tick_free_run_supported(hidden, vocab):
