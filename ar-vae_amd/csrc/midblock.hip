@@ -484,6 +484,12 @@ struct MidPlan {
 // fills the layer tables from the model description; y / gpre buffers are given per layer by the caller afterwards
 static int mid_cu_count() { return device_cu_count(); }
 
+// the clustered kernels take the pass when the model has their shape AND every cluster's 16 workgroups can be resident at once
+// (they wait for each other: one 512-thread workgroup with ~117 KB of LDS per CU)
+static bool midc_use(bool cluster_ok, int batch) {
+    static const bool rows_only = diag_env("ARVAE_MID_NO_CLUSTER") != nullptr;       // diagnostic build: the row kernels of this file
+    return !rows_only && cluster_ok && (int64_t)((batch + MC_R - 1) / MC_R) * MC_S <= mid_cu_count();
+}
 static void mid_describe(const arvae_image_vae_t *m, const float *params, float *prep_ws, MidPlan &pl, int batch = 512) {
     int ne, nd;
     mid_fusable(m, &ne, &nd);
@@ -556,6 +562,14 @@ static void mid_describe(const arvae_image_vae_t *m, const float *params, float 
         pl.cl.counters = pl.prep.counters;
         off += MIDC_COUNTER_WORDS;
         pl.cl.zdim = m->zdim;
+        // one family of layouts per step: the cluster layouts when the clustered kernels take this batch, else the row kernels'
+        const bool use_c = midc_use(true, batch);
+        for (int q = 0; q < 6; ++q) {
+            MidPrepJob &j = pl.prep.job[q];
+            if (use_c) j.mf = j.mb = nullptr;
+            else j.cf = j.cb = nullptr;
+        }
+        if (!use_c) { pl.prep.counters = nullptr; pl.prep.counter_words = 0; }
         pl.cl.act_e0 = a.enc[0].act; pl.cl.act_e1 = a.enc[1].act;
         pl.cl.act_d0 = a.dec[0].act; pl.cl.act_d1 = a.dec[1].act; pl.cl.act_d2 = a.dec[2].act;
     }
@@ -575,12 +589,6 @@ static void mid_describe(const arvae_image_vae_t *m, const float *params, float 
     pl.lds_bytes = (size_t)(2 * pl.rows * a.ld + mid_red(pl.rows) + pl.rows * 32) * sizeof(float);
 }
 
-// the clustered kernels take the pass when the model has their shape AND every cluster's 16 workgroups can be resident at once
-// (they wait for each other: one 512-thread workgroup with ~117 KB of LDS per CU)
-static bool midc_use(const MidPlan &pl, int batch) {
-    static const bool rows_only = diag_env("ARVAE_MID_NO_CLUSTER") != nullptr;       // diagnostic build: the row kernels of this file
-    return !rows_only && pl.cluster && (int64_t)((batch + MC_R - 1) / MC_R) * MC_S <= mid_cu_count();
-}
 static void midc_common(McArgs &c, const MidArgs &a, int batch) {
     c.batch = batch;
     c.clusters = (batch + MC_R - 1) / MC_R;
@@ -606,9 +614,9 @@ static void mid_allow_lds() {
 }
 
 // the prep launch's arguments alone (plan.hip hands them to conv32_weight_prep, which runs both preps as one launch)
-void mid_prep_args(const arvae_image_vae_t *m, const float *params, float *prep_ws, MidPrepArgs *out) {
+void mid_prep_args(const arvae_image_vae_t *m, const float *params, float *prep_ws, MidPrepArgs *out, int batch) {
     MidPlan pl;
-    mid_describe(m, params, prep_ws, pl);
+    mid_describe(m, params, prep_ws, pl, batch);
     *out = pl.prep;
 }
 
@@ -644,7 +652,7 @@ int mid_forward(const arvae_image_vae_t *m, int batch, const float *params, floa
         ARVAE_LAUNCH(mid_prep_kernel, dim3(pl.prep.blk_end[pl.prep.count - 1]), dim3(256), 0, s, pl.prep);
         if (int rc = check_launch("mid_prep_kernel")) return rc;
     }
-    if (midc_use(pl, batch)) {
+    if (midc_use(pl.cluster, batch)) {
         McArgs &c = pl.cl;
         midc_common(c, a, batch);
         c.x0 = x0; c.mu = mu; c.log_std = log_std; c.sigma = sigma; c.z = z; c.eps = eps;
@@ -689,7 +697,7 @@ int mid_backward(const arvae_image_vae_t *m, int batch, const float *params, flo
         if (diag_env("ARVAE_MID_NO_WARM") != nullptr) nw = 0;
     }
     mid_allow_lds();
-    if (midc_use(pl, batch)) {
+    if (midc_use(pl.cluster, batch)) {
         McArgs &c = pl.cl;
         midc_common(c, a, batch);
         c.g_out = g_out; c.g_is_pre = g_is_pre; c.gate0 = gate0; c.d_x0 = d_x0;

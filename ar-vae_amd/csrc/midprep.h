@@ -39,13 +39,16 @@ __device__ __forceinline__ void mid_prep_block(const MidPrepArgs &a, int block) 
     auto src = [&](int nf, int kf) {                              // W[nf][kf] of the layer (two stacked sources for the heads)
         return (p.w2 != nullptr && nf >= p.nsplit) ? p.w2[(int64_t)(nf - p.nsplit) * p.k + kf] : p.w[(int64_t)nf * p.k + kf];
     };
-    for (int e = (block - start) * 256 + threadIdx.x; e < total; e += stride) {
-        if (e < p.k * p.n) {
-            const int km = e / p.n, nm = e - km * p.n;            // forward matrix [k][n], written in order
-            p.mf[e] = src(p.np.to_feat(nm), p.kp.to_feat(km));
+    // (a job carries the row-kernel layouts mf / mb or the cluster layouts cf / cb, whichever kernels will run: never both)
+    for (int e = (block - start) * 256 + threadIdx.x; e < (p.mf != nullptr ? total : p.n); e += stride) {
+        if (p.mf != nullptr) {
+            if (e < p.k * p.n) {
+                const int km = e / p.n, nm = e - km * p.n;        // forward matrix [k][n], written in order
+                p.mf[e] = src(p.np.to_feat(nm), p.kp.to_feat(km));
+            }
+            const int nm2 = e / p.kb, km2 = e - nm2 * p.kb;      // backward matrix [n][kb], written in order
+            p.mb[e] = km2 < p.k ? src(p.np.to_feat(nm2), p.kp.to_feat(km2)) : 0.f;
         }
-        const int nm2 = e / p.kb, km2 = e - nm2 * p.kb;          // backward matrix [n][kb], written in order
-        p.mb[e] = km2 < p.k ? src(p.np.to_feat(nm2), p.kp.to_feat(km2)) : 0.f;
         if (e < p.n && p.bias != nullptr) {
             const int nf = p.np.to_feat(e);
             const float *bs = (p.w2 != nullptr && nf >= p.nsplit) ? p.b2 : p.b;

@@ -45,7 +45,7 @@ int recon_partial_blocks(int64_t count);
 int64_t conv32_prep_floats();
 int conv32_weight_prep(const float *const *wts, float *const *preps, int n_layers, hipStream_t s);
 int conv32_weight_prep_with_mid(const float *const *wts, float *const *preps, int n_layers, const MidPrepArgs &mid, hipStream_t s);
-void mid_prep_args(const arvae_image_vae_t *m, const float *params, float *prep_ws, MidPrepArgs *out);
+void mid_prep_args(const arvae_image_vae_t *m, const float *params, float *prep_ws, MidPrepArgs *out, int batch);
 bool conv32_pair_fits(const arvae_link_t *l, bool up, const float *gate, const uint16_t *gate_bits, int bias_mode);
 int conv32_pair(const arvae_link_t *l, bool up, const float *g, const float *x_in, const float *gate, const uint16_t *gate_bits,
                  float *d_in, const float *wprep, float *dwt, float *dbias, float *slab, hipStream_t s, SlabJob *job,
@@ -516,7 +516,7 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
         // the first encoder layer is the single-channel convolution, the prep rides in ITS grid, conv_c1.hip)
         if (np > 0 && mid && diag_env("ARVAE_SPLIT_PREP") == nullptr) {
             MidPrepArgs margs;
-            mid_prep_args(m, params, ws + L.mid_prep, &margs);
+            mid_prep_args(m, params, ws + L.mid_prep, &margs, batch);
             const arvae_layer_t &l0 = m->enc[0];
             arvae_link_t lk0 = l0.link;
             lk0.n = batch;

@@ -491,6 +491,47 @@ def test_full_batch_properties(dev):
     close(g3, 3.0 * g1, rtol=2e-5, atol=1e-6 * float(g1.abs().max()))
 
 
+@pytest.mark.parametrize('batch', [512, 200])
+def test_clustered_latent_block_handoffs_under_load(dev, batch):
+    """The clustered latent block (csrc/midcluster.hip) hands activations between workgroups through memory inside ONE launch
+    (sc1 stores, a counter, sc1 loads): a stale or torn read would show as a changed bit somewhere.  300 forward + backward
+    passes over the same weights, inputs and noise -- the exchanged buffers are the same addresses every pass, so every
+    consumer's caches are warm with the previous pass's bytes -- while a second stream keeps the memory system busy with an
+    uneven load (copies of changing sizes): the loss, z, every saved latent tensor's checksum and the whole gradient arena must
+    be bit-identical in every pass.  batch 200: seven clusters, the last one with eight valid rows (cross-XCD clusters:
+    the cluster count is not a multiple of eight)."""
+    from arvae_amd.image_vae import DspritesVAE
+    from arvae_amd.image_vae_trainer import ImageVAETrainer
+    state = syn.synth_state(o_vae.DSPRITES_SHAPES, 7, 1.6)
+    model = DspritesVAE()
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    trainer = ImageVAETrainer(DspritesDataset(), model, lr=1e-4, reg_type=('all',), reg_dim=(1, 2, 3, 4, 5), beta=4.0,
+                              gamma=10.0, capacity=0.0, rand=0, delta=1.0)
+    trainer.cuda()
+    model.train()
+    x, lab = syn.dsprites_batch(batch, seed=1234)
+    xt, lt = torch.from_numpy(x).to(dev), torch.from_numpy(lab).to(dev)
+    eps = torch.from_numpy(syn.normal_noise((batch, 10), seed=1)).to(dev)
+    side = torch.cuda.Stream()
+    junk_a, junk_b = torch.empty(48 << 20, device=dev), torch.empty(48 << 20, device=dev)
+    first = None
+    for it in range(300):
+        with torch.cuda.stream(side):                          # uneven competing traffic: 4 .. 192 MB copies
+            n = (1 + (it * 7) % 48) << 20
+            junk_b[:n].copy_(junk_a[:n])
+        model.push_noise(eps)
+        trainer.zero_grad()
+        loss, _ = trainer.loss_and_acc_for_batch((xt, lt), 0, 0, True)
+        trainer.backward(loss)
+        got = torch.cat([loss.detach().reshape(1), trainer.optimizer.grad_arena.detach()])
+        if first is None:
+            first = got.clone()
+            assert torch.isfinite(first).all() and float(first[1:].abs().max()) > 0
+        else:
+            assert torch.equal(got, first), f'pass {it}: {int((got != first).sum())} words differ'
+    torch.cuda.synchronize()
+
+
 def _conv32_maps(dev, hi_np, lo_np, w_np, b_np):
     """the three maps of a 32-channel k4 s2 p1 link through the per-layer C-ABI (weights split and maxima taken in the caller's
     workspace): forward Conv2d of hi, forward ConvTranspose2d of lo, weight / bias gradient of the Conv2d for upstream `lo`"""
