@@ -10,7 +10,7 @@ import threading
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libarvae_hip.so')
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_i32, c_i64, c_f32, c_f64, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
 
@@ -54,7 +54,8 @@ class GruSeqDesc(ctypes.Structure):
     _fields_ = [('gi', c_vp), ('gi_tstride', c_i64), ('w_hh', c_vp), ('b_hh', c_vp), ('h0', c_vp), ('h_all', c_vp),
                 ('h_stride', c_i64), ('saved', c_vp), ('reverse', c_i32), ('reserved', c_i32), ('dh_all', c_vp),
                 ('dh_stride', c_i64), ('dgi', c_vp), ('dgh', c_vp), ('dh0', c_vp), ('dh_last', c_vp),
-                ('dh_last_stride', c_i64), ('h_prev_out', c_vp)]
+                ('dh_last_stride', c_i64), ('h_prev_out', c_vp), ('gi_rstride', c_i64), ('dgi_rstride', c_i64), ('h_fin', c_vp),
+                ('h_fin_stride', c_i64)]
 
 
 class TickWeights(ctypes.Structure):

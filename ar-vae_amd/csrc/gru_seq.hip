@@ -42,6 +42,11 @@ struct GruSeq {
     const float *dh_last;   // gradient w.r.t. the final state (h of the last processed step), [R] rows of dh_last_stride; may be null
     int64_t dh_last_stride;
     float *h_prev_out;      // [T][R][H]: h entering step t (the operand of the W_hh weight gradient); may be null
+    // merged projections (both directions of a layer as ONE GEMM write / read [T][R][ndir * 3H]): floats between two rows of gi /
+    // of dgi (fill_batch sets 3H when the caller leaves them 0)
+    int64_t gi_rstride, dgi_rstride;
+    float *h_fin;           // forward, optional: the state after the last processed step, row r at h_fin + r * h_fin_stride
+    int64_t h_fin_stride;
 };
 struct GruSeqBatch {
     GruSeq seq[GRU_SEQ_MAX];
@@ -91,7 +96,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_kernel(GruSeqBatch batch, i
         const int t0 = s.reverse ? T - 1 : 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float *p = s.gi + t0 * s.gi_tstride + (int64_t)rows[i] * 3 * H + unit;
+            const float *p = s.gi + t0 * s.gi_tstride + (int64_t)rows[i] * s.gi_rstride + unit;
             gi_next[i][0] = p[0]; gi_next[i][1] = p[H]; gi_next[i][2] = p[2 * H];
         }
     }
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_kernel(GruSeqBatch batch, i
             const int tn = s.reverse ? t - 1 : t + 1;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float *p = s.gi + tn * s.gi_tstride + (int64_t)rows[i] * 3 * H + unit;
+                const float *p = s.gi + tn * s.gi_tstride + (int64_t)rows[i] * s.gi_rstride + unit;
                 gi_next[i][0] = p[0]; gi_next[i][1] = p[H]; gi_next[i][2] = p[2 * H];
             }
         }
@@ -136,6 +141,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_kernel(GruSeqBatch batch, i
                 const int64_t tr = (int64_t)t * R + rows[i];
                 s.h_all[tr * s.h_stride + unit] = hn;
                 *reinterpret_cast<f32x4 *>(s.saved + (tr * H + unit) * 4) = f32x4{r, z, n, ghn};
+                if (step == T - 1 && s.h_fin != nullptr) s.h_fin[(int64_t)rows[i] * s.h_fin_stride + unit] = hn;
             }
         }
         __syncthreads();
@@ -212,7 +218,8 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_kernel(GruSeqBatch batch, i
             d[0] = dpr; d[H] = dpz; d[2 * H] = dhn;
             if (live[i]) {
                 const int64_t o = ((int64_t)t * R + rows[i]) * 3 * H + unit;
-                s.dgi[o] = dpr; s.dgi[o + H] = dpz; s.dgi[o + 2 * H] = dpn;
+                const int64_t og = ((int64_t)t * R + rows[i]) * s.dgi_rstride + unit;
+                s.dgi[og] = dpr; s.dgi[og + H] = dpz; s.dgi[og + 2 * H] = dpn;
                 s.dgh[o] = dpr; s.dgh[o + H] = dpz; s.dgh[o + 2 * H] = dhn;
                 if (s.h_prev_out != nullptr) s.h_prev_out[((int64_t)t * R + rows[i]) * H + unit] = hp;
             }
@@ -356,7 +363,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_x3_kernel(GruSeqBatch batch
     float gi_next[4][3];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        gi_p[i] = s.gi + t0 * s.gi_tstride + (int64_t)rows[i] * 3 * H + unit;
+        gi_p[i] = s.gi + t0 * s.gi_tstride + (int64_t)rows[i] * s.gi_rstride + unit;
         h_p[i] = s.h_all + ((int64_t)t0 * R + rows[i]) * s.h_stride + unit;
         sv_p[i] = s.saved + (((int64_t)t0 * R + rows[i]) * H + unit) * 4;
         gi_next[i][0] = gi_p[i][0]; gi_next[i][1] = gi_p[i][H]; gi_next[i][2] = gi_p[i][2 * H];
@@ -449,6 +456,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_x3_kernel(GruSeqBatch batch
         if (live[i]) {
             *h_p[i] = keep_h[i];
             *reinterpret_cast<f32x4 *>(sv_p[i]) = keep_sv[i];
+            if (s.h_fin != nullptr) s.h_fin[(int64_t)rows[i] * s.h_fin_stride + unit] = keep_h[i];
         }
 }
 
@@ -536,7 +544,8 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_x3_kernel(GruSeqBatch batch
         auto row_stores = [&](int i) __attribute__((always_inline)) {
             if (live[i]) {
                 const int64_t o = ((int64_t)t * R + rows[i]) * 3 * H + unit;
-                s.dgi[o] = o_gi[i][0]; s.dgi[o + H] = o_gi[i][1]; s.dgi[o + 2 * H] = o_gi[i][2];
+                const int64_t og = ((int64_t)t * R + rows[i]) * s.dgi_rstride + unit;
+                s.dgi[og] = o_gi[i][0]; s.dgi[og + H] = o_gi[i][1]; s.dgi[og + 2 * H] = o_gi[i][2];
                 s.dgh[o] = o_gi[i][0]; s.dgh[o + H] = o_gi[i][1]; s.dgh[o + 2 * H] = o_hn[i];
                 if (s.h_prev_out != nullptr) s.h_prev_out[((int64_t)t * R + rows[i]) * H + unit] = o_hp[i];
             }
@@ -563,7 +572,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_x3_kernel(GruSeqBatch batch
             if (live[i]) s.dh0[(int64_t)rows[i] * H + unit] = carry[i];
 }
 
-static int fill_batch(GruSeqBatch *b, const arvae_gru_seq_t *seqs, int nseq) {
+static int fill_batch(GruSeqBatch *b, const arvae_gru_seq_t *seqs, int nseq, int hidden) {
     for (int i = 0; i < nseq; ++i) {
         const arvae_gru_seq_t &q = seqs[i];
         GruSeq &s = b->seq[i];
@@ -571,6 +580,9 @@ static int fill_batch(GruSeqBatch *b, const arvae_gru_seq_t *seqs, int nseq) {
         s.h_all = q.h_all; s.h_stride = q.h_stride; s.saved = q.saved; s.reverse = q.reverse;
         s.dh_all = q.dh_all; s.dh_stride = q.dh_stride; s.dgi = q.dgi; s.dgh = q.dgh; s.dh0 = q.dh0;
         s.dh_last = q.dh_last; s.dh_last_stride = q.dh_last_stride; s.h_prev_out = q.h_prev_out;
+        s.gi_rstride = q.gi_rstride != 0 ? q.gi_rstride : 3 * hidden;
+        s.dgi_rstride = q.dgi_rstride != 0 ? q.dgi_rstride : 3 * hidden;
+        s.h_fin = q.h_fin; s.h_fin_stride = q.h_fin_stride;
     }
     return 0;
 }
@@ -1017,7 +1029,7 @@ extern "C" int arvae_gru_seq_fwd(const arvae_gru_seq_t *seqs, int32_t nseq, int3
     for (int i = 0; i < nseq; ++i)
         ARVAE_REQUIRE(seqs[i].gi && seqs[i].w_hh && seqs[i].b_hh && seqs[i].h_all && seqs[i].saved, "gru_seq_fwd: null pointer");
     GruSeqBatch b{};
-    fill_batch(&b, seqs, nseq);
+    fill_batch(&b, seqs, nseq, hidden);
     hipStream_t st = as_stream(stream);
     const dim3 grid((rows + 15) / 16, nseq);
     if (gru_fp32_mfma()) {
@@ -1040,7 +1052,7 @@ extern "C" int arvae_gru_seq_bwd(const arvae_gru_seq_t *seqs, int32_t nseq, int3
     for (int i = 0; i < nseq; ++i)
         ARVAE_REQUIRE(seqs[i].w_hh && seqs[i].h_all && seqs[i].saved && seqs[i].dgi && seqs[i].dgh, "gru_seq_bwd: null pointer");
     GruSeqBatch b{};
-    fill_batch(&b, seqs, nseq);
+    fill_batch(&b, seqs, nseq, hidden);
     hipStream_t st = as_stream(stream);
     const dim3 grid((rows + 15) / 16, nseq);
     if (gru_fp32_mfma()) {

@@ -145,6 +145,12 @@ class Encoder(Model):
 
     def _layer_sequence(self, x_all, steps, b, layer):
         """x_all (T*B, in), time-major rows -> (T, B, 2H): both directions of one layer in one sequence launch."""
+        wf, whf, bf, bhf = self.lstm.cell(layer, '')
+        wr, whr, br, bhr = self.lstm.cell(layer, '_reverse')
+        gi_all = ops.dense_pair(x_all, wf, bf, wr, br)           # (T*B, 2 * 3H) when the two projections are adjacent in memory
+        if gi_all is not None:
+            return ops.gru_sequence(steps, [(None, whf, bhf, None, False), (None, whr, bhr, None, True)],
+                                    merged_gi=gi_all.view(steps, b, -1))
         dirs = []
         for suffix in ('', '_reverse'):
             w_ih, w_hh, b_ih, b_hh = self.lstm.cell(layer, suffix)
@@ -437,6 +443,19 @@ class MeasureVAE(Model):
 
     def __repr__(self):
         return self.dataset_type + '_MeasureVAE' + self.trainer_config
+
+    def arena_parameters(self):
+        """every parameter once, in the order the trainer's flat arena should hold them: per encoder GRU layer the input
+        projections of both directions side by side (weight_ih_l*, weight_ih_l*_reverse, then the two bias_ih), so that ONE
+        whole-sequence GEMM applies both (Encoder._layer_sequence); everything else in module order.  state_dict keys and
+        shapes are untouched (measurevae/encoder.py:27-34)."""
+        gru = self.encoder.lstm
+        first = []
+        for layer in range(gru.num_layers):
+            g = lambda n, suf: getattr(gru, f'{n}_l{layer}{suf}')
+            first += [g('weight_ih', ''), g('weight_ih', '_reverse'), g('bias_ih', ''), g('bias_ih', '_reverse')]
+        taken = {id(p) for p in first}
+        return first + [p for p in self.parameters() if id(p) not in taken]
 
     def push_noise(self, eps):
         self.encoder.push_noise(eps)

@@ -602,35 +602,43 @@ class _GruSeqFn(Function):
     """All time steps of one GRU layer (1..4 directions / parameter sets) in one launch; see csrc/gru_seq.hip.
 
     per direction d the inputs are gi_d (T, R, 3H) -- or (R, 3H) when the same projection feeds every step --,
-    w_hh_d, b_hh_d, h0_d (R, H) or None.  Outputs: (T, R, ndir*H) with direction d in columns [dH, (d+1)H), and the
-    final states (R, ndir*H) = nn.GRU's h_n (each direction's last processed step)."""
+    w_hh_d, b_hh_d, h0_d (R, H) or None.  With gi_merged (T, R, ndir*3H) the directions read their input projection from
+    columns [3H d, 3H (d+1)) of that ONE tensor (both directions of a bidirectional layer projected by one GEMM,
+    dense_pair) and the per-direction gi_d are None; its gradient comes back as one tensor as well.
+    Outputs: (T, R, ndir*H) with direction d in columns [dH, (d+1)H), and the final states (R, ndir*H) = nn.GRU's h_n (each
+    direction's last processed step), written by the sequence launch itself."""
 
     @staticmethod
-    def forward(ctx, steps, reverse, want_finals, *tensors):
+    def forward(ctx, steps, reverse, want_finals, gi_merged, *tensors):
         ndir = len(reverse)
         gis, whs, bhs, h0s = tensors[0::4], tensors[1::4], tensors[2::4], tensors[3::4]
         _dev(*[t for t in tensors if t is not None])
         lib = _lib.load()
-        rows, hid = gis[0].shape[-2], whs[0].shape[1]
+        hid = whs[0].shape[1]
+        rows = gi_merged.shape[1] if gi_merged is not None else gis[0].shape[-2]
         dev = whs[0].device
         out = torch.empty(steps, rows, ndir * hid, device=dev, dtype=torch.float32)
         saved = torch.empty(ndir, steps, rows, 4 * hid, device=dev, dtype=torch.float32)
+        finals = torch.empty(rows, ndir * hid, device=dev, dtype=torch.float32) if want_finals else None
         descs = _gru_seq_descs(ndir)
         for d in range(ndir):
             q = descs[d]
-            q.gi, q.gi_tstride = _ptr(gis[d]), (rows * 3 * hid if gis[d].dim() == 3 else 0)
+            if gi_merged is not None:
+                q.gi = gi_merged.data_ptr() + 4 * d * 3 * hid
+                q.gi_tstride, q.gi_rstride = rows * ndir * 3 * hid, ndir * 3 * hid
+            else:
+                q.gi, q.gi_tstride = _ptr(gis[d]), (rows * 3 * hid if gis[d].dim() == 3 else 0)
             q.w_hh, q.b_hh, q.h0 = _ptr(whs[d]), _ptr(bhs[d]), _ptr(h0s[d])
             q.h_all, q.h_stride = out.data_ptr() + 4 * d * hid, ndir * hid
             q.saved, q.reverse = saved[d].data_ptr(), int(reverse[d])
+            if finals is not None:
+                q.h_fin, q.h_fin_stride = finals.data_ptr() + 4 * d * hid, ndir * hid
         with _timed('gru_seq_fwd', 2.0 * ndir * steps * rows * 3 * hid * hid, 4.0 * ndir * steps * rows * 8 * hid):
             _lib.check(lib.arvae_gru_seq_fwd(descs, ndir, steps, rows, hid, _stream()), 'gru_seq_fwd')
-        # (a copy launch per call: only for callers that read the final states -- the encoder; the decoder's four sequence
-        # launches per step used to pay it for nothing)
-        finals = (torch.cat([out[0 if reverse[d] else steps - 1, :, d * hid:(d + 1) * hid] for d in range(ndir)], 1)
-                  if want_finals else None)
         ctx.save_for_backward(out, saved, *whs, *[h for h in h0s if h is not None])
         ctx.h0_present = [h is not None for h in h0s]
-        ctx.gi_const = [g.dim() == 2 for g in gis]
+        ctx.gi_const = [g is not None and g.dim() == 2 for g in gis]
+        ctx.merged = gi_merged is not None
         ctx.refs = (whs, bhs)
         ctx.geom = (steps, rows, hid, tuple(reverse))
         ctx.set_materialize_grads(False)
@@ -653,11 +661,17 @@ class _GruSeqFn(Function):
         dev = out.device
         d_out = None if d_out is None else d_out.contiguous()
         d_fin = None if (d_fin is None or d_fin.numel() == 0) else d_fin.contiguous()
-        dgi = torch.empty(ndir, steps, rows, 3 * hid, device=dev, dtype=torch.float32)
-        dgh = torch.empty_like(dgi)
+        if ctx.merged:                                           # one (T, R, ndir * 3H) gradient for the one projection
+            dgi_all = torch.empty(steps, rows, ndir * 3 * hid, device=dev, dtype=torch.float32)
+            dgi = None
+        else:
+            dgi_all = None
+            dgi = torch.empty(ndir, steps, rows, 3 * hid, device=dev, dtype=torch.float32)
+        dgh = torch.empty(ndir, steps, rows, 3 * hid, device=dev, dtype=torch.float32)
         h_prev = torch.empty(ndir, steps, rows, hid, device=dev, dtype=torch.float32)
+        base = 4                                                 # inputs: steps, reverse, want_finals, gi_merged, then 4 per direction
         dh0 = [torch.empty(rows, hid, device=dev, dtype=torch.float32)
-               if (h0s[d] is not None and ctx.needs_input_grad[3 + 4 * d + 3]) else None for d in range(ndir)]
+               if (h0s[d] is not None and ctx.needs_input_grad[base + 4 * d + 3]) else None for d in range(ndir)]
         descs = _gru_seq_descs(ndir)
         for d in range(ndir):
             q = descs[d]
@@ -668,36 +682,94 @@ class _GruSeqFn(Function):
                 q.dh_all, q.dh_stride = d_out.data_ptr() + 4 * d * hid, ndir * hid
             if d_fin is not None:
                 q.dh_last, q.dh_last_stride = d_fin.data_ptr() + 4 * d * hid, ndir * hid
-            q.dgi, q.dgh, q.dh0 = dgi[d].data_ptr(), dgh[d].data_ptr(), _ptr(dh0[d])
+            if ctx.merged:
+                q.dgi, q.dgi_rstride = dgi_all.data_ptr() + 4 * d * 3 * hid, ndir * 3 * hid
+            else:
+                q.dgi = dgi[d].data_ptr()
+            q.dgh, q.dh0 = dgh[d].data_ptr(), _ptr(dh0[d])
             q.h_prev_out = h_prev[d].data_ptr()
         with _timed('gru_seq_bwd', 2.0 * ndir * steps * rows * 3 * hid * hid, 4.0 * ndir * steps * rows * 12 * hid):
             _lib.check(lib.arvae_gru_seq_bwd(descs, ndir, steps, rows, hid, _stream()), 'gru_seq_bwd')
-        grads = [None, None, None]
+        grads = [None, None, None, dgi_all if (ctx.merged and ctx.needs_input_grad[3]) else None]
         link = Link.dense(hid, 3 * hid)
         w_refs, b_refs = ctx.refs
         for d in range(ndir):
             d_w = d_b = None
-            if ctx.needs_input_grad[3 + 4 * d + 1]:
+            if ctx.needs_input_grad[base + 4 * d + 1]:
                 buf, direct = _grad_target(w_refs[d])
                 bbuf, bdirect = _grad_target(b_refs[d])
                 link_wgrad(link, steps * rows, _operand(dgh[d].view(steps * rows, 3 * hid)),
                            _operand(h_prev[d].view(steps * rows, hid)), buf, bbuf, 1)
                 d_w, d_b = (None if direct else buf), (None if bdirect else bbuf)
             g_gi = None
-            if ctx.needs_input_grad[3 + 4 * d]:
+            if not ctx.merged and ctx.needs_input_grad[base + 4 * d]:
                 g_gi = dgi[d].sum(0) if ctx.gi_const[d] else dgi[d]
             grads += [g_gi, d_w, d_b, dh0[d]]
         return tuple(grads)
 
 
-def gru_sequence(steps, directions, finals=True):
+def gru_sequence(steps, directions, finals=True, merged_gi=None):
     """directions: list of (gi, w_hh, b_hh, h0, reverse) -> (outputs (T, R, ndir*H), final states (R, ndir*H) or, with
-    finals=False, None)."""
+    finals=False, None).  merged_gi (T, R, ndir*3H): the directions' input projections as one tensor (their gi entries None)."""
     flat = []
     for gi, w_hh, b_hh, h0, _ in directions:
-        flat += [gi.contiguous(), w_hh, b_hh, None if h0 is None else h0.contiguous()]
-    out, fin = _GruSeqFn.apply(int(steps), tuple(bool(d[4]) for d in directions), bool(finals), *flat)
+        flat += [None if gi is None else gi.contiguous(), w_hh, b_hh, None if h0 is None else h0.contiguous()]
+    out, fin = _GruSeqFn.apply(int(steps), tuple(bool(d[4]) for d in directions), bool(finals),
+                               None if merged_gi is None else merged_gi.contiguous(), *flat)
     return out, (fin if finals else None)
+
+
+def _adjacent(a, b):
+    """b starts where a ends, in the same allocation (two parameters of the trainer's flat arena laid out back to back)"""
+    return (a is not None and b is not None and a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype and a.device == b.device
+            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+            and a.data_ptr() + a.numel() * a.element_size() == b.data_ptr())
+
+
+class _DensePairFn(Function):
+    """two Linear layers on the same input whose weights (and biases) are adjacent in memory, as one [out_a + out_b, in] layer"""
+
+    @staticmethod
+    def forward(ctx, x, w_a, w_b, b_a, b_b):
+        _dev(x, w_a, w_b, b_a, b_b)
+        n, n_in, n_out = x.shape[0], w_a.shape[1], w_a.shape[0] + w_b.shape[0]
+        link = Link.dense(n_in, n_out)
+        w_cat = w_a.detach().as_strided((n_out, n_in), (n_in, 1))
+        b_cat = b_a.detach().as_strided((n_out,), (1,))
+        out = link_down(link, n, _operand(x), w_cat, b_cat, ACT_NONE, None)
+        ctx.link, ctx.n = link, n
+        ctx.save_for_backward(x, w_cat)
+        ctx.refs = (w_a, w_b, b_a, b_b)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, w_cat = ctx.saved_tensors
+        link, n = ctx.link, ctx.n
+        g = g.contiguous()
+        gop = _operand(g)
+        d_x = link_up(link, n, gop, w_cat, None, ACT_NONE, None) if ctx.needs_input_grad[0] else None
+        w_a, w_b, b_a, b_b = ctx.refs
+        if ctx.needs_input_grad[1]:
+            _grad_target(w_a), _grad_target(b_a)                 # (the arena is written without autograd's accumulation)
+            n_out, n_in = w_cat.shape
+            gw = w_a.grad.as_strided((n_out, n_in), (n_in, 1))
+            gb = b_a.grad.as_strided((n_out,), (1,))
+            link_wgrad(link, n, gop, _operand(x), gw, gb, 1)
+        return d_x, None, None, None, None
+
+
+def dense_pair(x, w_a, b_a, w_b, b_b):
+    """x (n, in) times [w_a; w_b]^T + [b_a; b_b] as ONE product -> (n, out_a + out_b) when the two layers' weights, biases and
+    (when gradients are on) gradient buffers sit back to back in memory -- the trainer's flat arena in Model.arena_parameters()
+    order -- ; None when they do not (the caller runs the layers one by one)."""
+    if not (_adjacent(w_a, w_b) and _adjacent(b_a, b_b) and w_a.shape[1] == w_b.shape[1]):
+        return None
+    if torch.is_grad_enabled() and (w_a.requires_grad or w_b.requires_grad):
+        if not (w_a.requires_grad and w_b.requires_grad and _adjacent(w_a.grad, w_b.grad) and _adjacent(b_a.grad, b_b.grad)):
+            return None
+    return _DensePairFn.apply(x, w_a, w_b, b_a, b_b)
 
 
 def tick_free_run_supported(hidden, vocab):

@@ -27,7 +27,10 @@ class Trainer(ABC):
     def __init__(self, dataset, model, lr=1e-4):
         self.dataset = dataset
         self.model = model
-        self.optimizer = FlatAdam((p for p in self.model.parameters() if p.requires_grad), lr=lr)
+        # the order of the flat arena is the model's to choose (Model.arena_parameters: tensors that one launch reads as ONE
+        # matrix sit side by side -- the two directions' input projections of MeasureVAE's encoder); default: parameters()
+        order = self.model.arena_parameters() if hasattr(self.model, 'arena_parameters') else self.model.parameters()
+        self.optimizer = FlatAdam((p for p in order if p.requires_grad), lr=lr)
         self.global_iter = 0
         self.trainer_config = ''
         self.writer = None

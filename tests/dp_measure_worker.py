@@ -80,10 +80,10 @@ def main():
             model.encoder.static_eps = None
         torch.cuda.synchronize()
         if rank == 0:
-            names, sizes = [], []
-            for p, off in zip(trainer.optimizer.params, trainer.optimizer._offsets):
-                sizes.append((off, p.numel()))
+            # (the arena's order is the optimizer's business -- arena_parameters() -- : spans are looked up by parameter)
+            where = {id(p): off for p, off in zip(trainer.optimizer.params, trainer.optimizer._offsets)}
             names = [k for k, _ in model.named_parameters()]
+            sizes = [(where[id(p)], p.numel()) for _, p in model.named_parameters()]
             np.savez(out, world=dp.world_size, variants=variants, transport=type(comm).__name__, loss_eager=res['eager'][0], loss_replay=res['replay'][0],
                      grad_eager=res['eager'][1].cpu().numpy(), grad_replay=res['replay'][1].cpu().numpy(),
                      names=np.array(names), spans=np.array(sizes))

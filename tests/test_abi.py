@@ -42,7 +42,7 @@ def test_ctypes_structs_match_the_header(tmp_path):
     if gcc is None:
         pytest.skip('gcc not available')
     structs = {'arvae_link_t': (_lib.LinkDesc, 'n', 'lo_perm_hw'), 'arvae_operand_t': (_lib.OperandDesc, 'v', 'act'),
-               'arvae_gru_seq_t': (_lib.GruSeqDesc, 'gi', 'h_prev_out'),
+               'arvae_gru_seq_t': (_lib.GruSeqDesc, 'gi', 'h_fin_stride'),
                'arvae_tick_weights_t': (_lib.TickWeights, 'w_hh0', 'b_out'),
                'arvae_dense_wgrad_job_t': (_lib.DenseWgradJob, 'g', 'n_out'),
                'arvae_image_vae_t': (_lib.ImageVaeDesc, 'n_enc', 'milestones'),

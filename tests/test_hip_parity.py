@@ -697,6 +697,58 @@ def test_gru_sequence_vs_torch(dev, rows, hid, steps):
         close(prm[k].grad, v.grad, rtol=1e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize('rows,hid,steps,fin', [(256, 128, 24, 10), (37, 128, 24, 256), (9, 32, 5, 12)])
+def test_merged_bidirectional_projection_vs_torch(dev, rows, hid, steps, fin):
+    """Both directions' input projections as ONE product (ops.dense_pair over weights / biases / gradient buffers laid out
+    back to back, as the trainer's arena holds them: MeasureVAE.arena_parameters) feeding ONE sequence launch that reads its
+    two gi blocks with a row stride and returns ONE gradient for the projection: outputs, final states (written by the launch:
+    arvae_gru_seq_t.h_fin) and every gradient against a bidirectional torch.nn.GRU layer."""
+    from arvae_amd import ops
+    rs = np.random.RandomState(23)
+    gru = torch.nn.GRU(fin, hid, 1, bidirectional=True)
+    x = torch.from_numpy(rs.standard_normal((steps, rows, fin)).astype(np.float32)).requires_grad_(True)
+    gy = torch.from_numpy(rs.standard_normal((steps, rows, 2 * hid)).astype(np.float32))
+    gfin = torch.from_numpy(rs.standard_normal((rows, 2 * hid)).astype(np.float32))
+    y, hn = gru(x)
+    ((y * gy).sum() + (torch.cat((hn[0], hn[1]), 1) * gfin).sum()).backward()
+    ref = dict(gru.named_parameters())
+    # the four input-projection tensors side by side in one buffer (values and gradients), everything else on its own
+    nw, nb = 3 * hid * fin, 3 * hid
+    flat = torch.zeros(2 * nw + 2 * nb, device=dev)
+    gflat = torch.zeros_like(flat)
+    prm = {}
+    for i, (name, off, shape) in enumerate((('weight_ih_l0', 0, (3 * hid, fin)), ('weight_ih_l0_reverse', nw, (3 * hid, fin)),
+                                            ('bias_ih_l0', 2 * nw, (3 * hid,)), ('bias_ih_l0_reverse', 2 * nw + nb, (3 * hid,)))):
+        n = int(np.prod(shape))
+        flat[off:off + n].copy_(ref[name].detach().reshape(-1))
+        p = torch.nn.Parameter(flat[off:off + n].view(shape))
+        p.grad = gflat[off:off + n].view(shape)
+        prm[name] = p
+    for name in ('weight_hh_l0', 'bias_hh_l0', 'weight_hh_l0_reverse', 'bias_hh_l0_reverse'):
+        prm[name] = ref[name].detach().clone().to(dev).requires_grad_(True)
+    xd = x.detach().to(dev).requires_grad_(True)
+    gi_all = ops.dense_pair(xd.view(steps * rows, fin), prm['weight_ih_l0'], prm['bias_ih_l0'], prm['weight_ih_l0_reverse'],
+                            prm['bias_ih_l0_reverse'])
+    assert gi_all is not None and gi_all.shape == (steps * rows, 6 * hid)
+    yd, fin_d = ops.gru_sequence(steps, [(None, prm['weight_hh_l0'], prm['bias_hh_l0'], None, False),
+                                         (None, prm['weight_hh_l0_reverse'], prm['bias_hh_l0_reverse'], None, True)],
+                                 merged_gi=gi_all.view(steps, rows, -1))
+    ((yd * gy.to(dev)).sum() + (fin_d * gfin.to(dev)).sum()).backward()
+    close(yd, y, rtol=1e-5, atol=2e-6)
+    close(fin_d[:, :hid], hn[0], rtol=1e-5, atol=2e-6)
+    close(fin_d[:, hid:], hn[1], rtol=1e-5, atol=2e-6)
+    close(xd.grad, x.grad, rtol=1e-4, atol=2e-6)
+    for k, v in gru.named_parameters():
+        # sums over steps x rows terms (6144 at the encoder's size) in two different fp32 orders: whole-tensor relative L2, and
+        # no single entry further off than a few ulps of the tensor's largest
+        got, want = prm[k].grad.detach().cpu().double(), v.grad.double()
+        assert float((got - want).norm()) <= 1e-5 * float(want.norm()), k
+        close(prm[k].grad, v.grad, rtol=1e-4, atol=1e-5 * float(want.abs().max()) + 3e-5)
+    # not adjacent -> the caller is told to run the layers one by one
+    lone = torch.nn.Parameter(prm['weight_ih_l0_reverse'].detach().clone())
+    assert ops.dense_pair(xd.view(steps * rows, fin), prm['weight_ih_l0'], prm['bias_ih_l0'], lone, prm['bias_ih_l0_reverse']) is None
+
+
 def test_gru_sequence_constant_input(dev):
     """one input projection reused at every step (the beat RNN's constant input) and no initial state."""
     from arvae_amd import ops
