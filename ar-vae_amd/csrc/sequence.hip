@@ -71,6 +71,23 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t *__restric
         out[i] = table[v * dim + d];
     }
 }
+// the same for rows that are multiples of four floats (wide per-vocabulary projection tables): a wave per output row, 16 bytes
+// per lane and step, the row's index read once
+__global__ __launch_bounds__(256) void embed_fwd4_kernel(const int64_t *__restrict__ idx, const float4 *__restrict__ table,
+                                                          int batch, int steps, int dim4, int vocab, int time_major,
+                                                          float4 *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t rows = (int64_t)batch * steps, nw = (int64_t)gridDim.x * 4;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += nw) {
+        const int b = time_major ? (int)(row % batch) : (int)(row / steps);
+        const int t = time_major ? (int)(row / batch) : (int)(row % steps);
+        int64_t v = idx[(int64_t)b * steps + t];
+        v = v < 0 ? 0 : (v >= vocab ? vocab - 1 : v);
+        const float4 *src = table + v * dim4;
+        float4 *dst = out + row * dim4;
+        for (int d = lane; d < dim4; d += 64) dst[d] = src[d];
+    }
+}
 
 // dtable[v][d] += sum over positions with idx == v of g[row][d], in two launches with a fixed summation order:
 // (1) a workgroup stages EMBED_POS positions (indices + gradient rows) in LDS and one thread per (v, d) pair sums the rows
@@ -108,7 +125,7 @@ __global__ __launch_bounds__(256) void embed_bwd_partial_kernel(const int64_t *_
     }
 }
 __global__ __launch_bounds__(256) void embed_bwd_reduce_kernel(const float *__restrict__ partial, int blocks, int count,
-                                                                float *__restrict__ dtable) {
+                                                                float *__restrict__ dtable, int accumulate) {
     // 4 lanes per table element, lane q sums blocks q, q+4, ... with 8 loads in flight; fixed-order lane sum
     const int i = (blockIdx.x * 256 + threadIdx.x) >> 2, q = threadIdx.x & 3;
     const int ic = i < count ? i : 0;
@@ -126,7 +143,59 @@ __global__ __launch_bounds__(256) void embed_bwd_reduce_kernel(const float *__re
     }
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
-    if (q == 0 && i < count) dtable[i] += s;
+    if (q == 0 && i < count) dtable[i] = accumulate ? dtable[i] + s : s;
+}
+
+// The same for WIDE rows (dim > 128: a gradient w.r.t. rows that were looked up from a per-vocabulary projection table, e.g. the
+// encoder's layer-0 input projection P = table W_ih^T + b of both directions, 768 columns).  Workgroup (column slice of 32,
+// position group of EMBED_WSPLIT): thread = (column, one of 8 position lanes) walks its positions -- 128-byte segments per
+// lane group, EMBED_WFLY rows in flight --, adding into its own LDS cell acc[v][thread] (no conflicts, position order); the
+// eight lanes of a column are then summed in lane order: partial [group][v][dim], EMBED_WSPLIT of them for
+// embed_bwd_reduce_kernel (1.7 MB at 35 x 768, where one partial per 32 positions was 20 MB).
+constexpr int EMBED_WSPLIT = 16, EMBED_WCOLS = 32, EMBED_WLANES = 8, EMBED_WFLY = 16;
+__global__ __launch_bounds__(256) void embed_bwd_wide_kernel(const int64_t *__restrict__ idx, const float *__restrict__ g,
+                                                              int batch, int steps, int dim, int vocab, int time_major,
+                                                              float *__restrict__ partial) {
+    extern __shared__ float acc[];                           // [vocab][256] | int srow[per] | int sidx[per]
+    const int n = batch * steps;
+    const int col = threadIdx.x & (EMBED_WCOLS - 1), pl = threadIdx.x / EMBED_WCOLS;
+    const int d = blockIdx.x * EMBED_WCOLS + col;
+    const bool dok = d < dim;
+    // this group's positions: [p_lo, p_hi), lane pl takes p_lo + pl, + 8, ...; their gradient rows and (clamped) tokens are worked
+    // out once per workgroup (the divisions), not once per thread and position
+    const int per = (n + EMBED_WSPLIT - 1) / EMBED_WSPLIT;
+    const int p_lo = (int)blockIdx.y * per, p_hi = min(p_lo + per, n), cnt = max(p_hi - p_lo, 0);
+    int *srow = reinterpret_cast<int *>(acc + vocab * 256), *sidx = srow + per;
+    for (int i = threadIdx.x; i < cnt; i += 256) {
+        const int pos = p_lo + i, b = pos / steps, t = pos - b * steps;
+        srow[i] = time_major ? t * batch + b : pos;
+        const int v = (int)idx[pos];
+        sidx[i] = v < 0 ? 0 : (v >= vocab ? vocab - 1 : v);
+    }
+    for (int v = 0; v < vocab; ++v) acc[v * 256 + threadIdx.x] = 0.f;
+    __syncthreads();
+    for (int i0 = pl; i0 < cnt; i0 += EMBED_WLANES * EMBED_WFLY) {
+        float gv[EMBED_WFLY];
+#pragma unroll
+        for (int u = 0; u < EMBED_WFLY; ++u) {
+            const int i = i0 + u * EMBED_WLANES;
+            gv[u] = (dok && i < cnt) ? g[(int64_t)srow[i < cnt ? i : 0] * dim + d] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < EMBED_WFLY; ++u) {
+            const int i = i0 + u * EMBED_WLANES;
+            if (i < cnt) acc[sidx[i] * 256 + threadIdx.x] += gv[u];
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < vocab * EMBED_WCOLS; e += 256) {
+        const int v = e / EMBED_WCOLS, c = e - v * EMBED_WCOLS;
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < EMBED_WLANES; ++q) s += acc[v * 256 + q * EMBED_WCOLS + c];
+        const int dd = blockIdx.x * EMBED_WCOLS + c;
+        if (dd < dim) partial[((int64_t)blockIdx.y * vocab + v) * dim + dd] = s;
+    }
 }
 
 // idx[b] = argmax_j w[b][j], lowest index on ties (reference decoder.py:506-507 topk(1))
@@ -244,26 +313,44 @@ extern "C" int arvae_gru_gates_bwd(const float *dh, const float *saved, const fl
 extern "C" int arvae_embed_fwd(const int64_t *idx, const float *table, int32_t batch, int32_t steps, int32_t dim,
                                int32_t vocab, int32_t time_major, float *out, arvae_stream_t stream) {
     ARVAE_REQUIRE(idx && table && out && batch > 0 && steps > 0 && dim > 0 && vocab > 0, "embed_fwd: bad argument");
+    if (dim % 4 == 0 && dim >= 64 && (reinterpret_cast<uintptr_t>(table) | reinterpret_cast<uintptr_t>(out)) % 16 == 0) {
+        ARVAE_LAUNCH(embed_fwd4_kernel, dim3((unsigned)(((int64_t)batch * steps + 3) / 4)), dim3(256), 0, as_stream(stream), idx,
+                     reinterpret_cast<const float4 *>(table), batch, steps, dim / 4, vocab, time_major, reinterpret_cast<float4 *>(out));
+        return check_launch("embed_fwd4_kernel");
+    }
     ARVAE_LAUNCH(embed_fwd_kernel, dim3(blocks_for((int64_t)batch * steps * dim)), dim3(256), 0, as_stream(stream), idx,
                        table, batch, steps, dim, vocab, time_major, out);
     return check_launch("embed_fwd_kernel");
 }
 
 extern "C" int64_t arvae_embed_bwd_ws_floats(int32_t batch, int32_t steps, int32_t dim, int32_t vocab) {
+    if (dim > 128) return (int64_t)EMBED_WSPLIT * vocab * dim;
     const int64_t blocks = ((int64_t)batch * steps + EMBED_POS - 1) / EMBED_POS;
     return blocks * vocab * dim;
 }
 
 extern "C" int arvae_embed_bwd(const int64_t *idx, const float *g, int32_t batch, int32_t steps, int32_t dim,
-                               int32_t vocab, int32_t time_major, float *dtable, float *ws, arvae_stream_t stream) {
-    ARVAE_REQUIRE(idx && g && dtable && ws && batch > 0 && steps > 0 && dim > 0 && dim <= 128 && vocab > 0,
-                  "embed_bwd: bad argument (dim must be <= 128, ws = arvae_embed_bwd_ws_floats() floats)");
-    const int blocks = (int)(((int64_t)batch * steps + EMBED_POS - 1) / EMBED_POS);
-    const size_t lds = (size_t)EMBED_POS * (dim + 1) * sizeof(float) + EMBED_POS * sizeof(int);
+                               int32_t vocab, int32_t time_major, float *dtable, int32_t accumulate, float *ws, arvae_stream_t stream) {
+    ARVAE_REQUIRE(idx && g && dtable && ws && batch > 0 && steps > 0 && dim > 0 && vocab > 0,
+                  "embed_bwd: bad argument (ws = arvae_embed_bwd_ws_floats() floats)");
     hipStream_t st = as_stream(stream);
-    ARVAE_LAUNCH(embed_bwd_partial_kernel, dim3(blocks), dim3(256), lds, st, idx, g, batch, steps, dim, vocab, time_major, ws);
-    ARVAE_LAUNCH(embed_bwd_reduce_kernel, dim3((vocab * dim * 4 + 255) / 256), dim3(256), 0, st, ws, blocks, vocab * dim, dtable);
-    return check_launch("embed_bwd_kernel");
+    if (dim <= 128) {
+        const int blocks = (int)(((int64_t)batch * steps + EMBED_POS - 1) / EMBED_POS);
+        const size_t lds = (size_t)EMBED_POS * (dim + 1) * sizeof(float) + EMBED_POS * sizeof(int);
+        ARVAE_LAUNCH(embed_bwd_partial_kernel, dim3(blocks), dim3(256), lds, st, idx, g, batch, steps, dim, vocab, time_major, ws);
+        ARVAE_LAUNCH(embed_bwd_reduce_kernel, dim3((vocab * dim * 4 + 255) / 256), dim3(256), 0, st, ws, blocks, vocab * dim, dtable, accumulate);
+        return check_launch("embed_bwd_kernel");
+    }
+    // wide rows (lookups of a per-vocabulary projection table): column-parallel segment sums
+    const int per = (int)(((int64_t)batch * steps + EMBED_WSPLIT - 1) / EMBED_WSPLIT);
+    const size_t lds = (size_t)vocab * 256 * sizeof(float) + (size_t)per * 2 * sizeof(int);
+    ARVAE_REQUIRE(lds <= 64 * 1024 && (int64_t)batch * steps < (1 << 30),
+                  "embed_bwd: %d vocabulary entries x %d positions do not fit the wide-row kernel", vocab, batch * steps);
+    ARVAE_LAUNCH(embed_bwd_wide_kernel, dim3((dim + EMBED_WCOLS - 1) / EMBED_WCOLS, EMBED_WSPLIT), dim3(256), lds, st, idx, g, batch, steps,
+                 dim, vocab, time_major, ws);
+    ARVAE_LAUNCH(embed_bwd_reduce_kernel, dim3((vocab * dim * 4 + 255) / 256), dim3(256), 0, st, ws, EMBED_WSPLIT, vocab * dim, dtable,
+                 accumulate);
+    return check_launch("embed_bwd_wide_kernel");
 }
 
 extern "C" int arvae_row_argmax(const float *w, int32_t rows, int32_t cols, int64_t *idx, arvae_stream_t stream) {

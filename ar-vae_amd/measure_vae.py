@@ -158,18 +158,37 @@ class Encoder(Model):
             dirs.append((gi.view(steps, b, -1), w_hh, b_hh, None, suffix != ''))
         return ops.gru_sequence(steps, dirs)
 
+    def _first_layer_by_lookup(self, score_tensor, steps, b):
+        """Layer 0 sees embedded tokens, so its input projection takes only `num_notes` distinct values: P = table W_ih^T + b_ih
+        (both directions side by side, num_notes x 6H: one small product) and gi[t, b] = P[score[b, t]] (a lookup, no
+        whole-sequence GEMM); backward the per-position gradients are summed per token into dP (a segment sum) and the
+        weight / bias / embedding gradients follow from dP on num_notes rows instead of T*B.  The same algebra as
+        encoder.py:111-114 (embedding, then nn.GRU's W_ih x + b_ih), re-associated.  -> (out, finals) or (None, None) when the
+        two directions' projections are not adjacent in memory (ops.dense_pair)."""
+        wf, whf, bf, bhf = self.lstm.cell(0, '')
+        wr, whr, br, bhr = self.lstm.cell(0, '_reverse')
+        ptab = ops.dense_pair(self.note_embedding_layer.weight, wf, bf, wr, br)            # (num_notes, 2 * 3H)
+        if ptab is None:
+            return None, None
+        gi_all = ops.embed(score_tensor, ptab, time_major=True)                            # (T, B, 2 * 3H)
+        return ops.gru_sequence(steps, [(None, whf, bhf, None, False), (None, whr, bhr, None, True)], merged_gi=gi_all)
+
     def encode_params(self, score_tensor):
         """-> (mu, log_std)"""
         b, steps = score_tensor.shape
         hid = self.rnn_hidden_size
-        emb = ops.embed(score_tensor, self.note_embedding_layer.weight, time_major=True)      # (T, B, E)
+        # (T, B, E); with the lookup path of layer 0 nothing reads it and autograd drops the launch's backward
+        emb = None if _use_sequence_kernels(hid) else ops.embed(score_tensor, self.note_embedding_layer.weight, time_major=True)
         dropping = self.training and self.dropout > 0
         mask = None
         if dropping:
-            mask = self._mask_queue.popleft().to(emb.device) if self._mask_queue else \
-                ops.keep_mask((steps, b, 2 * hid), self.dropout, emb.device)
+            dev = score_tensor.device
+            mask = self._mask_queue.popleft().to(dev) if self._mask_queue else ops.keep_mask((steps, b, 2 * hid), self.dropout, dev)
         if _use_sequence_kernels(hid):
-            out0, fin0 = self._layer_sequence(emb.view(steps * b, -1), steps, b, 0)
+            out0, fin0 = self._first_layer_by_lookup(score_tensor, steps, b)
+            if out0 is None:
+                emb = ops.embed(score_tensor, self.note_embedding_layer.weight, time_major=True)
+                out0, fin0 = self._layer_sequence(emb.view(steps * b, -1), steps, b, 0)
             mid = out0.view(steps * b, 2 * hid)
             if dropping:
                 mid = ops.dropout_mask(mid, mask.contiguous().view(steps * b, 2 * hid), self.dropout)

@@ -740,6 +740,7 @@ class _DensePairFn(Function):
         ctx.link, ctx.n = link, n
         ctx.save_for_backward(x, w_cat)
         ctx.refs = (w_a, w_b, b_a, b_b)
+        ctx.x_ref = x if (x.is_leaf and x.requires_grad) else None
         return out
 
     @staticmethod
@@ -750,6 +751,13 @@ class _DensePairFn(Function):
         g = g.contiguous()
         gop = _operand(g)
         d_x = link_up(link, n, gop, w_cat, None, ACT_NONE, None) if ctx.needs_input_grad[0] else None
+        x_ref = ctx.x_ref
+        if d_x is not None and x_ref is not None and x_ref.grad is not None and x_ref.grad.shape == d_x.shape:
+            # the input is itself a parameter with a gradient buffer (an embedding table projected as a whole): added here, on
+            # this stream, instead of by an AccumulateGrad node (whose stream is not the capture's: graphed.py)
+            _grad_target(x_ref)
+            x_ref.grad.add_(d_x)
+            d_x = None
         w_a, w_b, b_a, b_b = ctx.refs
         if ctx.needs_input_grad[1]:
             _grad_target(w_a), _grad_target(b_a)                 # (the arena is written without autograd's accumulation)
@@ -816,10 +824,13 @@ class _EmbedFn(Function):
         table = ctx.table_ref
         b, steps = idx.shape
         v, dim = table.shape
-        buf, direct = _grad_target(table)
+        if table.is_leaf and table.grad is not None:
+            buf, direct = _grad_target(table)                    # the parameter's own gradient buffer: add into it
+        else:                                                    # (a projection table computed upstream: a fresh, overwritten tensor)
+            buf, direct = torch.empty_like(table), False
         ws = torch.empty(lib.arvae_embed_bwd_ws_floats(b, steps, dim, v), device=buf.device, dtype=torch.float32)
         _lib.check(lib.arvae_embed_bwd(_ptr(idx), _ptr(g.contiguous()), b, steps, dim, v, int(ctx.time_major), _ptr(buf),
-                                       _ptr(ws), _stream()), 'embed_bwd')
+                                       int(direct), _ptr(ws), _stream()), 'embed_bwd')
         return None, (None if direct else buf), None
 
 

@@ -290,13 +290,17 @@ int arvae_tick_free_run(const arvae_tick_weights_t *weights, const float *h0_l0,
                         arvae_stream_t stream);
 
 /* nn.Embedding (measurevae/encoder.py:36-37,111; decoder.py:18,516): out row (b,t) = table[idx[b][t]];
- * time_major: rows ordered (t, b) instead of (b, t).  embed_bwd ACCUMULATES dtable (fixed summation order) and needs
- * a workspace of arvae_embed_bwd_ws_floats() floats. */
+ * time_major: rows ordered (t, b) instead of (b, t).  embed_bwd adds to (accumulate != 0) or overwrites dtable, in a fixed summation order, and needs
+ * a workspace of arvae_embed_bwd_ws_floats() floats.  `table` may also be a per-vocabulary PROJECTION table: a Linear layer
+ * applied to embedded tokens is a lookup of table W^T + b (the encoder's layer-0 input projection of both directions,
+ * 768 columns at hidden 128: encoder.py:27-37,111-114 computes it per position) -- any `dim`; rows wider than 128 take a
+ * column-parallel segment-sum kernel in embed_bwd (vocab * 1 KB + 256 B of LDS <= 64 KB). */
 int arvae_embed_fwd(const int64_t *idx, const float *table, int32_t batch, int32_t steps, int32_t dim, int32_t vocab,
                     int32_t time_major, float *out, arvae_stream_t stream);
 int64_t arvae_embed_bwd_ws_floats(int32_t batch, int32_t steps, int32_t dim, int32_t vocab);
 int arvae_embed_bwd(const int64_t *idx, const float *g, int32_t batch, int32_t steps, int32_t dim, int32_t vocab,
-                    int32_t time_major, float *dtable, float *ws, arvae_stream_t stream);
+                    int32_t time_major, float *dtable, int32_t accumulate /* 0: dtable is overwritten */, float *ws,
+                    arvae_stream_t stream);
 
 /* top-1 index per row, lowest index on ties (the decoder's argmax feedback, measurevae/decoder.py:506-507) */
 int arvae_row_argmax(const float *w, int32_t rows, int32_t cols, int64_t *idx, arvae_stream_t stream);

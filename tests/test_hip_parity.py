@@ -890,6 +890,32 @@ def test_embedding_concat_argmax(dev):
     assert ops.row_argmax(w).tolist() == [0, 1, 0]              # lowest index on ties
 
 
+@pytest.mark.parametrize('batch,dim', [(256, 768), (37, 384), (5, 132)])
+def test_wide_lookup_tables(dev, batch, dim):
+    """lookups of a per-vocabulary PROJECTION table (rows of hundreds of columns: the encoder's layer-0 input projection of
+    both directions applied to the embedding table once, MeasureVAE Encoder._first_layer_by_lookup) and the segment sums that
+    take the per-position gradients back to the table's rows (embed_bwd_wide_kernel), against torch indexing; a non-leaf
+    table (the usual case: it is computed from parameters) and a leaf one with a gradient buffer to add into."""
+    from arvae_amd import ops
+    rs = np.random.RandomState(31)
+    vocab, steps = 35, 24
+    table = torch.from_numpy(rs.standard_normal((vocab, dim)).astype(np.float32))
+    idx = torch.from_numpy(rs.randint(0, vocab, (batch, steps)).astype(np.int64))
+    gy = torch.from_numpy(rs.standard_normal((steps, batch, dim)).astype(np.float32))
+    tt = table.clone().double().requires_grad_(True)
+    ref = tt[idx].permute(1, 0, 2)
+    ref.backward(gy.double())
+    base = table.to(dev).requires_grad_(True)
+    out = ops.embed(idx.to(dev), base * 1.0, time_major=True)           # non-leaf table
+    out.backward(gy.to(dev))
+    close(out, ref.float(), rtol=0, atol=0)
+    assert float((base.grad.cpu().double() - tt.grad).norm()) <= 2e-6 * float(tt.grad.norm())
+    leaf = table.to(dev).requires_grad_(True)
+    leaf.grad = torch.ones_like(leaf)                                   # an existing buffer: the gradient is ADDED
+    ops.embed(idx.to(dev), leaf, time_major=True).backward(gy.to(dev))
+    assert float((leaf.grad.cpu().double() - 1.0 - tt.grad).norm()) <= 2e-6 * float(tt.grad.norm())
+
+
 MEASURE_CASES = [('measure_step_tf.npz', 5, 31, True, True), ('measure_step_free.npz', 5, 32, False, True),
                  ('measure_step_eval.npz', 6, 33, False, False)]
 
