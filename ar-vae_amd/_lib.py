@@ -109,6 +109,11 @@ SIGNATURES = {
     'arvae_embed_fwd': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     'arvae_embed_bwd_ws_floats': (c_i64, [c_i32, c_i32, c_i32, c_i32]),
     'arvae_embed_bwd': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp]),
+    'arvae_tick_rows_fwd': (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    'arvae_tick_rows_bwd': (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    'arvae_tick_gi_fwd': (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    'arvae_tick_gi_bwd_ws_floats': (c_i64, [c_i32, c_i32]),
+    'arvae_tick_gi_bwd': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     'arvae_row_argmax': (c_i32, [c_vp, c_i32, c_i32, c_vp, c_vp]),
     'arvae_concat_cols': (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
     'arvae_split_cols': (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp]),

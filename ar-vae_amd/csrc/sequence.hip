@@ -153,9 +153,11 @@ __global__ __launch_bounds__(256) void embed_bwd_reduce_kernel(const float *__re
 // eight lanes of a column are then summed in lane order: partial [group][v][dim], EMBED_WSPLIT of them for
 // embed_bwd_reduce_kernel (1.7 MB at 35 x 768, where one partial per 32 positions was 20 MB).
 constexpr int EMBED_WSPLIT = 16, EMBED_WCOLS = 32, EMBED_WLANES = 8, EMBED_WFLY = 16;
+// (time_major 2 = TICK ORDER, arvae_tick_gi_bwd: position i IS gradient row i = (j, beat, b) of [tpb][beats][batch], its token the
+// PREVIOUS tick's note idx[b][tpb*beat + j - 1], or the extra entry `vocab - 1` -- the learned start vector -- at tick 0)
 __global__ __launch_bounds__(256) void embed_bwd_wide_kernel(const int64_t *__restrict__ idx, const float *__restrict__ g,
                                                               int batch, int steps, int dim, int vocab, int time_major,
-                                                              float *__restrict__ partial) {
+                                                              float *__restrict__ partial, int beats, int tpb) {
     extern __shared__ float acc[];                           // [vocab][256] | int srow[per] | int sidx[per]
     const int n = batch * steps;
     const int col = threadIdx.x & (EMBED_WCOLS - 1), pl = threadIdx.x / EMBED_WCOLS;
@@ -167,10 +169,21 @@ __global__ __launch_bounds__(256) void embed_bwd_wide_kernel(const int64_t *__re
     const int p_lo = (int)blockIdx.y * per, p_hi = min(p_lo + per, n), cnt = max(p_hi - p_lo, 0);
     int *srow = reinterpret_cast<int *>(acc + vocab * 256), *sidx = srow + per;
     for (int i = threadIdx.x; i < cnt; i += 256) {
-        const int pos = p_lo + i, b = pos / steps, t = pos - b * steps;
-        srow[i] = time_major ? t * batch + b : pos;
-        const int v = (int)idx[pos];
-        sidx[i] = v < 0 ? 0 : (v >= vocab ? vocab - 1 : v);
+        const int pos = p_lo + i;
+        int v;
+        if (time_major == 2) {
+            const int j = pos / (beats * batch), rem = pos - j * beats * batch, beat = rem / batch, b = rem - beat * batch;
+            const int t = tpb * beat + j;
+            srow[i] = pos;
+            v = t == 0 ? vocab - 1 : (int)idx[b * steps + t - 1];
+            v = v < 0 ? 0 : (v >= vocab - 1 && t != 0 ? vocab - 2 : v);
+        } else {
+            const int b = pos / steps, t = pos - b * steps;
+            srow[i] = time_major ? t * batch + b : pos;
+            v = (int)idx[pos];
+            v = v < 0 ? 0 : (v >= vocab ? vocab - 1 : v);
+        }
+        sidx[i] = v;
     }
     for (int v = 0; v < vocab; ++v) acc[v * 256 + threadIdx.x] = 0.f;
     __syncthreads();
@@ -197,6 +210,83 @@ __global__ __launch_bounds__(256) void embed_bwd_wide_kernel(const int64_t *__re
         if (dd < dim) partial[((int64_t)blockIdx.y * vocab + v) * dim + dd] = s;
     }
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// The tick RNN's layer-0 input projection, re-associated (measurevae/decoder.py:459-505: per tick W_ih0 [embedding of the
+// previous note | beat embedding] + b_ih0, 24 ticks x batch rows of 138 inputs).  The note half takes only vocab + 1 distinct
+// values (the vocabulary's embeddings and the learned start vector x_0), the beat half one per (beat, measure): ONE small product
+//     G = X W_ih0^T,   X = [ table | 0 ]  (vocab rows)
+//                          [  x_0  | 0 ]  (1 row)
+//                          [   0   | beat_emb ]  (beats*batch rows)
+// and per tick gi = G[previous note] + G[vocab + 1 + beat*batch + b] + b_ih0 (tick_gi_fwd).  Backward: the per-tick gradients are
+// summed over the ticks of a beat (beat rows) and per previous note (the wide segment sum above, tick order) into dG; dX = dG W_ih0
+// splits into the embedding table's, x_0's and the beat embedding's gradients (tick_rows_bwd).
+__global__ __launch_bounds__(256) void tick_rows_fwd_kernel(const float *__restrict__ table, const float *__restrict__ x0,
+                                                             const float *__restrict__ beat_emb, int vocab, int emb, int hidden, int rows,
+                                                             float *__restrict__ x) {
+    const int cols = emb + hidden;
+    const int64_t total = (int64_t)(vocab + 1 + rows) * cols;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+        float v = 0.f;
+        if (r < vocab) v = c < emb ? table[r * emb + c] : 0.f;
+        else if (r == vocab) v = c < emb ? x0[c] : 0.f;
+        else v = c >= emb ? beat_emb[(int64_t)(r - vocab - 1) * hidden + c - emb] : 0.f;
+        x[i] = v;
+    }
+}
+__global__ __launch_bounds__(256) void tick_rows_bwd_kernel(const float *__restrict__ dx, int vocab, int emb, int hidden, int rows,
+                                                             float *__restrict__ dtable, float *__restrict__ dx0,
+                                                             float *__restrict__ dbeat) {
+    const int cols = emb + hidden;
+    const int64_t n_tab = (int64_t)(vocab + 1) * emb, total = n_tab + (int64_t)rows * hidden;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        if (i < n_tab) {
+            const int r = (int)(i / emb), c = (int)(i - (int64_t)r * emb);
+            const float v = dx[(int64_t)r * cols + c];
+            if (r < vocab) { if (dtable != nullptr) dtable[r * emb + c] += v; }
+            else if (dx0 != nullptr) dx0[c] += v;
+        } else {
+            const int64_t k = i - n_tab;
+            const int r = (int)(k / hidden), c = (int)(k - (int64_t)r * hidden);
+            dbeat[k] = dx[(int64_t)(vocab + 1 + r) * cols + emb + c];
+        }
+    }
+}
+// gi[(j*beats + beat)*batch + b] = G[prev(b, tpb*beat + j)] + G[vocab + 1 + beat*batch + b] + bias: a wave per output row
+__global__ __launch_bounds__(256) void tick_gi_fwd_kernel(const float4 *__restrict__ gs, const int64_t *__restrict__ tokens,
+                                                           const float4 *__restrict__ bias, int batch, int beats, int tpb, int vocab,
+                                                           int cols4, float4 *__restrict__ gi) {
+    const int lane = threadIdx.x & 63, steps = beats * tpb, rows_b = beats * batch;
+    const int64_t rows = (int64_t)tpb * rows_b, nw = (int64_t)gridDim.x * 4;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += nw) {
+        const int j = (int)(row / rows_b), rem = (int)(row - (int64_t)j * rows_b), beat = rem / batch, b = rem - beat * batch;
+        const int t = tpb * beat + j;
+        int64_t v = t == 0 ? vocab : tokens[(int64_t)b * steps + t - 1];
+        v = v < 0 ? 0 : (v > vocab ? vocab : v);
+        if (t != 0 && v == vocab) v = vocab - 1;
+        const float4 *pn = gs + v * cols4, *pb = gs + (int64_t)(vocab + 1 + rem) * cols4;
+        float4 *dst = gi + row * cols4;
+        for (int d = lane; d < cols4; d += 64) {
+            const float4 a = pn[d], c = pb[d], e = bias != nullptr ? bias[d] : make_float4(0.f, 0.f, 0.f, 0.f);
+            dst[d] = make_float4(a.x + c.x + e.x, a.y + c.y + e.y, a.z + c.z + e.z, a.w + c.w + e.w);
+        }
+    }
+}
+// beat rows of dG: the sum over a beat's ticks, dG[vocab + 1 + r] = sum_j dgi[j*rows_b + r] (tick order of the sum: fixed)
+__global__ __launch_bounds__(256) void tick_gi_bwd_beat_kernel(const float4 *__restrict__ dgi, int rows_b, int tpb, int cols4,
+                                                                float4 *__restrict__ dg_beat) {
+    const int64_t total = (int64_t)rows_b * cols4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        float4 s = dgi[i];
+        for (int j = 1; j < tpb; ++j) {
+            const float4 v = dgi[(int64_t)j * total + i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        dg_beat[i] = s;
+    }
+}
+
 
 // idx[b] = argmax_j w[b][j], lowest index on ties (reference decoder.py:506-507 topk(1))
 __global__ __launch_bounds__(256) void row_argmax_kernel(const float *__restrict__ w, int rows, int cols,
@@ -347,10 +437,60 @@ extern "C" int arvae_embed_bwd(const int64_t *idx, const float *g, int32_t batch
     ARVAE_REQUIRE(lds <= 64 * 1024 && (int64_t)batch * steps < (1 << 30),
                   "embed_bwd: %d vocabulary entries x %d positions do not fit the wide-row kernel", vocab, batch * steps);
     ARVAE_LAUNCH(embed_bwd_wide_kernel, dim3((dim + EMBED_WCOLS - 1) / EMBED_WCOLS, EMBED_WSPLIT), dim3(256), lds, st, idx, g, batch, steps,
-                 dim, vocab, time_major, ws);
+                 dim, vocab, time_major, ws, 0, 0);
     ARVAE_LAUNCH(embed_bwd_reduce_kernel, dim3((vocab * dim * 4 + 255) / 256), dim3(256), 0, st, ws, EMBED_WSPLIT, vocab * dim, dtable,
                  accumulate);
     return check_launch("embed_bwd_wide_kernel");
+}
+
+extern "C" int arvae_tick_rows_fwd(const float *table, const float *x0, const float *beat_emb, int32_t vocab, int32_t emb,
+                                   int32_t hidden, int32_t rows, float *x_small, arvae_stream_t stream) {
+    ARVAE_REQUIRE(table && x0 && beat_emb && x_small && vocab > 0 && emb > 0 && hidden > 0 && rows > 0, "tick_rows_fwd: bad argument");
+    ARVAE_LAUNCH(tick_rows_fwd_kernel, dim3(blocks_for((int64_t)(vocab + 1 + rows) * (emb + hidden))), dim3(256), 0, as_stream(stream), table,
+                 x0, beat_emb, vocab, emb, hidden, rows, x_small);
+    return check_launch("tick_rows_fwd_kernel");
+}
+
+extern "C" int arvae_tick_rows_bwd(const float *dx_small, int32_t vocab, int32_t emb, int32_t hidden, int32_t rows, float *dtable,
+                                   float *dx0, float *dbeat_emb, arvae_stream_t stream) {
+    ARVAE_REQUIRE(dx_small && dbeat_emb && vocab > 0 && emb > 0 && hidden > 0 && rows > 0, "tick_rows_bwd: bad argument");
+    ARVAE_LAUNCH(tick_rows_bwd_kernel, dim3(blocks_for((int64_t)(vocab + 1) * emb + (int64_t)rows * hidden)), dim3(256), 0,
+                 as_stream(stream), dx_small, vocab, emb, hidden, rows, dtable, dx0, dbeat_emb);
+    return check_launch("tick_rows_bwd_kernel");
+}
+
+extern "C" int arvae_tick_gi_fwd(const float *g_small, const int64_t *tokens, const float *bias, int32_t batch, int32_t beats,
+                                 int32_t ticks_per_beat, int32_t vocab, int32_t cols, float *gi, arvae_stream_t stream) {
+    ARVAE_REQUIRE(g_small && tokens && gi && batch > 0 && beats > 0 && ticks_per_beat > 0 && vocab > 0 && cols > 0 && cols % 4 == 0,
+                  "tick_gi_fwd: bad argument (cols must be a multiple of 4)");
+    const int64_t rows = (int64_t)ticks_per_beat * beats * batch;
+    ARVAE_LAUNCH(tick_gi_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream),
+                 reinterpret_cast<const float4 *>(g_small), tokens, reinterpret_cast<const float4 *>(bias), batch, beats, ticks_per_beat,
+                 vocab, cols / 4, reinterpret_cast<float4 *>(gi));
+    return check_launch("tick_gi_fwd_kernel");
+}
+
+extern "C" int64_t arvae_tick_gi_bwd_ws_floats(int32_t vocab, int32_t cols) { return (int64_t)EMBED_WSPLIT * (vocab + 1) * cols; }
+
+extern "C" int arvae_tick_gi_bwd(const float *dgi, const int64_t *tokens, int32_t batch, int32_t beats, int32_t ticks_per_beat,
+                                 int32_t vocab, int32_t cols, float *dg_small, float *ws, arvae_stream_t stream) {
+    ARVAE_REQUIRE(dgi && tokens && dg_small && ws && batch > 0 && beats > 0 && ticks_per_beat > 0 && vocab > 0 && cols > 0 && cols % 4 == 0,
+                  "tick_gi_bwd: bad argument (cols must be a multiple of 4)");
+    hipStream_t st = as_stream(stream);
+    const int rows_b = beats * batch, nv = vocab + 1;
+    const int64_t n = (int64_t)ticks_per_beat * rows_b;
+    const int per = (int)((n + EMBED_WSPLIT - 1) / EMBED_WSPLIT);
+    const size_t lds = (size_t)nv * 256 * sizeof(float) + (size_t)per * 2 * sizeof(int);
+    ARVAE_REQUIRE(lds <= 64 * 1024 && n < (1 << 30), "tick_gi_bwd: %d vocabulary entries x %lld rows do not fit the segment-sum kernel", nv,
+                  (long long)n);
+    ARVAE_LAUNCH(tick_gi_bwd_beat_kernel, dim3(blocks_for((int64_t)rows_b * (cols / 4))), dim3(256), 0, st,
+                 reinterpret_cast<const float4 *>(dgi), rows_b, ticks_per_beat, cols / 4,
+                 reinterpret_cast<float4 *>(dg_small + (int64_t)nv * cols));
+    // (positions = gradient rows in tick order; `batch`/`steps` as the token array has them)
+    ARVAE_LAUNCH(embed_bwd_wide_kernel, dim3((cols + EMBED_WCOLS - 1) / EMBED_WCOLS, EMBED_WSPLIT), dim3(256), lds, st, tokens, dgi,
+                 batch, beats * ticks_per_beat, cols, nv, 2, ws, beats, ticks_per_beat);
+    ARVAE_LAUNCH(embed_bwd_reduce_kernel, dim3((nv * cols * 4 + 255) / 256), dim3(256), 0, st, ws, EMBED_WSPLIT, nv * cols, dg_small, 0);
+    return check_launch("tick_gi_bwd_kernel");
 }
 
 extern "C" int arvae_row_argmax(const float *w, int32_t rows, int32_t cols, int64_t *idx, arvae_stream_t stream) {

@@ -345,12 +345,17 @@ class HierarchicalDecoder(Decoder):
         else:
             with torch.no_grad():
                 tokens = self._free_running_tokens(beat_out.detach(), h0, beat_emb, mask)
-        emb_prev = ops.embed(tokens[:, :ticks - 1].contiguous(), self.note_embedding_layer.weight, time_major=True)
-        prev = torch.cat((ops.broadcast_rows(self.x_0, b)[None], emb_prev), 0)                 # (24, B, E), tick-major
-        prev = prev.view(nb, steps, b, -1).transpose(0, 1).reshape(steps * nb * b, -1)         # rows (j, beat, b)
-        inp = ops.concat_cols(prev, beat_emb[None].expand(steps, -1, -1).reshape(steps * nb * b, hid))
         w_ih0, _, b_ih0, _ = self.rnn_tick.cell(0)
-        gi0 = ops.dense(inp, w_ih0, b_ih0, Link.dense(w_ih0.shape[1], w_ih0.shape[0]), ACT_NONE).view(steps, nb * b, -1)
+        if (3 * hid) % 4 == 0 and (self.num_notes + 1) * 1024 + (steps * nb * b + 15) // 16 * 8 <= 65536:    # (the segment sum's LDS)
+            # layer-0 input projection by lookup: W_ih0 applied once to the vocabulary's embeddings, x_0 and the beat embeddings
+            # (num_notes + 1 + 4B rows), each tick's row gathered and added (ops.tick_input_projection)
+            gi0 = ops.tick_input_projection(self.note_embedding_layer.weight, self.x_0, beat_emb, w_ih0, b_ih0, tokens, nb, steps)
+        else:
+            emb_prev = ops.embed(tokens[:, :ticks - 1].contiguous(), self.note_embedding_layer.weight, time_major=True)
+            prev = torch.cat((ops.broadcast_rows(self.x_0, b)[None], emb_prev), 0)             # (24, B, E), tick-major
+            prev = prev.view(nb, steps, b, -1).transpose(0, 1).reshape(steps * nb * b, -1)     # rows (j, beat, b)
+            inp = ops.concat_cols(prev, beat_emb[None].expand(steps, -1, -1).reshape(steps * nb * b, hid))
+            gi0 = ops.dense(inp, w_ih0, b_ih0, Link.dense(w_ih0.shape[1], w_ih0.shape[0]), ACT_NONE).view(steps, nb * b, -1)
         out1 = self._two_layer_sequence(self.rnn_tick, steps, gi0, h0, m)                      # (6, 4B, H)
         probs = _lin(out1.view(steps * nb * b, hid), self.tick_emb_to_note_emb[0], ACT_RELU)
         weights = probs.view(steps, nb, b, -1).permute(2, 1, 0, 3).reshape(b, ticks, -1)       # tick = 6*beat + j

@@ -841,6 +841,76 @@ def embed(idx, table, time_major=False):
     return _EmbedFn.apply(idx.contiguous(), table, bool(time_major))
 
 
+class _TickInputFn(Function):
+    """gi0 (ticks_per_beat, beats*batch, 3H) of the tick RNN's first layer from (embedding table, x_0, beat embeddings, W_ih0,
+    b_ih0, fed-back tokens): one small product over vocab + 1 + beats*batch rows and a gather, instead of a whole-sequence GEMM
+    over 24*batch rows of concatenated inputs (include/arvae_hip.h, arvae_tick_*; measurevae/decoder.py:459-505)."""
+
+    @staticmethod
+    def forward(ctx, table, x0, beat_emb, w_ih, b_ih, tokens, beats, tpb):
+        _dev(table, x0, beat_emb, w_ih, b_ih, tokens)
+        lib = _lib.load()
+        vocab, emb = table.shape
+        rows, hid = beat_emb.shape
+        batch = rows // beats
+        cols = w_ih.shape[0]
+        n = vocab + 1 + rows
+        dev = table.device
+        x_small = torch.empty(n, emb + hid, device=dev, dtype=torch.float32)
+        _lib.check(lib.arvae_tick_rows_fwd(_ptr(table), _ptr(x0), _ptr(beat_emb), vocab, emb, hid, rows, _ptr(x_small), _stream()),
+                   'tick_rows_fwd')
+        link = Link.dense(emb + hid, cols)
+        g_small = link_down(link, n, _operand(x_small), w_ih, None, ACT_NONE, None)
+        gi = torch.empty(tpb, rows, cols, device=dev, dtype=torch.float32)
+        with _timed('tick_gi_fwd'):
+            _lib.check(lib.arvae_tick_gi_fwd(_ptr(g_small), _ptr(tokens), _ptr(b_ih), batch, beats, tpb, vocab, cols, _ptr(gi), _stream()),
+                       'tick_gi_fwd')
+        ctx.save_for_backward(x_small, tokens, w_ih)
+        ctx.refs = (table, x0, w_ih, b_ih)
+        ctx.geom = (vocab, emb, hid, rows, batch, beats, tpb, cols, link, n)
+        return gi
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d_gi):
+        x_small, tokens, w_ih = ctx.saved_tensors
+        table, x0, w_ref, b_ref = ctx.refs
+        vocab, emb, hid, rows, batch, beats, tpb, cols, link, n = ctx.geom
+        lib = _lib.load()
+        dev = x_small.device
+        d_gi = d_gi.contiguous()
+        dg = torch.empty(n, cols, device=dev, dtype=torch.float32)
+        ws = torch.empty(lib.arvae_tick_gi_bwd_ws_floats(vocab, cols), device=dev, dtype=torch.float32)
+        with _timed('tick_gi_bwd'):
+            _lib.check(lib.arvae_tick_gi_bwd(_ptr(d_gi), _ptr(tokens), batch, beats, tpb, vocab, cols, _ptr(dg), _ptr(ws), _stream()),
+                       'tick_gi_bwd')
+        gop = _operand(dg)
+        # every tick row carries the bias once and exactly one note entry: db = the column sums of the vocab + 1 note rows of dG
+        d_b = None
+        if ctx.needs_input_grad[4]:
+            bbuf, bdirect = _grad_target(b_ref)
+            channel_sum(_operand(dg[:vocab + 1]), vocab + 1, cols, (0, 0), bbuf)
+            d_b = None if bdirect else bbuf
+        d_w = None
+        if ctx.needs_input_grad[3]:
+            buf, direct = _grad_target(w_ref)
+            if not (direct and _defer_dense_wgrad(link, n, gop, (dg, x_small), x_small, buf, None)):
+                link_wgrad(link, n, gop, _operand(x_small), buf, None, 0)
+            d_w = None if direct else buf
+        dx = link_up(link, n, gop, w_ih, None, ACT_NONE, None)
+        tbuf, tdirect = _grad_target(table) if ctx.needs_input_grad[0] else (None, True)
+        xbuf, xdirect = _grad_target(x0) if ctx.needs_input_grad[1] else (None, True)
+        d_beat = torch.empty(rows, hid, device=dev, dtype=torch.float32)
+        _lib.check(lib.arvae_tick_rows_bwd(_ptr(dx), vocab, emb, hid, rows, _ptr(tbuf), _ptr(xbuf), _ptr(d_beat), _stream()),
+                   'tick_rows_bwd')
+        return (None if tdirect else tbuf), (None if xdirect else xbuf), d_beat, d_w, d_b, None, None, None
+
+
+def tick_input_projection(table, x0, beat_emb, w_ih, b_ih, tokens, beats, ticks_per_beat):
+    """-> gi0 (ticks_per_beat, beats*batch, 3H); tokens (batch, beats*ticks_per_beat) int64, beat_emb (beats*batch, H)"""
+    return _TickInputFn.apply(table, x0, beat_emb.contiguous(), w_ih, b_ih, tokens.contiguous(), int(beats), int(ticks_per_beat))
+
+
 def row_argmax(w):
     """top-1 index per row of a [rows, cols] tensor, lowest index on ties; int64 [rows]."""
     _dev(w)

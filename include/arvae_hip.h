@@ -302,6 +302,28 @@ int arvae_embed_bwd(const int64_t *idx, const float *g, int32_t batch, int32_t s
                     int32_t time_major, float *dtable, int32_t accumulate /* 0: dtable is overwritten */, float *ws,
                     arvae_stream_t stream);
 
+/* The tick RNN's layer-0 input projection, re-associated (measurevae/decoder.py:459-505 applies W_ih0 to [embedding of the previous
+ * note | beat embedding] at each of the 24 ticks x batch positions).  The note half takes vocab + 1 distinct values (the vocabulary's
+ * embeddings and the learned start vector x_0), the beat half one per (beat, measure), so ONE small product G = X W_ih0^T over
+ *     x_small [vocab + 1 + rows][emb + hidden] = [table | 0] (vocab rows), [x_0 | 0] (1 row), [0 | beat_emb] (rows = beats*batch)
+ * (arvae_tick_rows_fwd builds it; G by arvae_link_down) gives every tick's projection as a gather:
+ *     gi[(j*beats + beat)*batch + b][:] = G[prev][:] + G[vocab + 1 + beat*batch + b][:] + bias[:],
+ *     prev = tokens[b][ticks_per_beat*beat + j - 1], or row `vocab` (x_0) at tick 0            (arvae_tick_gi_fwd)
+ * in the row order the tick RNN's sequence launches take (arvae_gru_seq_*: ticks_per_beat steps over beats*batch rows).
+ * Backward: arvae_tick_gi_bwd sums the per-tick gradients dgi into dg_small [vocab + 1 + rows][cols] (OVERWRITTEN: per previous
+ * note in a fixed order, per beat row over its ticks); dx_small = dg_small W_ih0 (arvae_link_up) is split by arvae_tick_rows_bwd
+ * into the table's and x_0's gradients (ADDED; either may be NULL) and the beat embedding's (written).
+ * cols (= 3 * hidden of the tick RNN) must be a multiple of 4; ws: arvae_tick_gi_bwd_ws_floats(vocab, cols) floats. */
+int arvae_tick_rows_fwd(const float *table, const float *x0, const float *beat_emb, int32_t vocab, int32_t emb, int32_t hidden,
+                        int32_t rows, float *x_small, arvae_stream_t stream);
+int arvae_tick_rows_bwd(const float *dx_small, int32_t vocab, int32_t emb, int32_t hidden, int32_t rows, float *dtable, float *dx0,
+                        float *dbeat_emb, arvae_stream_t stream);
+int arvae_tick_gi_fwd(const float *g_small, const int64_t *tokens, const float *bias, int32_t batch, int32_t beats,
+                      int32_t ticks_per_beat, int32_t vocab, int32_t cols, float *gi, arvae_stream_t stream);
+int64_t arvae_tick_gi_bwd_ws_floats(int32_t vocab, int32_t cols);
+int arvae_tick_gi_bwd(const float *dgi, const int64_t *tokens, int32_t batch, int32_t beats, int32_t ticks_per_beat, int32_t vocab,
+                      int32_t cols, float *dg_small, float *ws, arvae_stream_t stream);
+
 /* top-1 index per row, lowest index on ties (the decoder's argmax feedback, measurevae/decoder.py:506-507) */
 int arvae_row_argmax(const float *w, int32_t rows, int32_t cols, int64_t *idx, arvae_stream_t stream);
 
