@@ -48,7 +48,9 @@ __device__ __forceinline__ void reduce_waves(float *red, const f32x16 &acc, int 
 // registers per wave then costs more than the 8 MFMAs each wave contributes -- Morpho-MNIST's 256 <-> 2888 layers)
 static bool dense_short_k(int k, int tiles) {
     static const bool off = diag_env("ARVAE_DENSE_NW16") != nullptr;
-    return !off && k <= 512 && tiles >= 512;
+    // (and whenever the reduction is at most 160 long: 16 waves would contribute one or two MFMAs each to a tile and then spend
+    // longer reducing it -- the tick RNN's vocab + 1 + 4B rows x 138 inputs: 24 us on sixteen waves)
+    return !off && k <= 512 && (tiles >= 512 || k <= 160);
 }
 
 // ---- forward: Y[m][out_perm(n)] = act( sum_k X[m][km] * W[n][feat(km)] + b[n] ),  km = memory column ----------
