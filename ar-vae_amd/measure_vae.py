@@ -202,8 +202,14 @@ class Encoder(Model):
                 seq = [ops.dropout_mask(s, m, self.dropout) for s, m in zip(seq, torch.unbind(mask.contiguous(), 0))]
             _, finals1 = self._layer(seq, 1)
             hidden = ops.concat_cols(ops.concat_cols(finals0[0], finals0[1]), ops.concat_cols(finals1[0], finals1[1]))
-        mu = _lin(_lin(hidden, self.linear_mean[0], ACT_SELU), self.linear_mean[2], ACT_NONE)
-        log_std = _lin(_lin(hidden, self.linear_log_std[0], ACT_SELU), self.linear_log_std[2], ACT_NONE)
+        la, lb = self.linear_mean[0], self.linear_log_std[0]
+        both = ops.dense_pair(hidden, la.weight, la.bias, lb.weight, lb.bias, ACT_SELU)      # (B, 2 * 2H) or None
+        if both is not None:
+            h_mu, h_ls = ops.split_cols(both, la.weight.shape[0])
+        else:
+            h_mu, h_ls = _lin(hidden, la, ACT_SELU), _lin(hidden, lb, ACT_SELU)
+        mu = _lin(h_mu, self.linear_mean[2], ACT_NONE)
+        log_std = _lin(h_ls, self.linear_log_std[2], ACT_NONE)
         return mu, log_std
 
 
@@ -335,8 +341,14 @@ class HierarchicalDecoder(Decoder):
         hid, steps = self.rnn_hidden_size, tick_seq_len
         ticks = nb * steps
         bo = beat_out.view(nb * b, hid)
-        h0 = self.hidden_init(bo, 'tick')
-        beat_emb = _lin(bo, self.beat_emb_to_tick_rnn_input[0], ACT_SELU)                      # (4B, H)
+        la, lb = self.beat_emb_to_tick_rnn_hidden[0], self.beat_emb_to_tick_rnn_input[0]
+        both = ops.dense_pair(bo, la.weight, la.bias, lb.weight, lb.bias, ACT_SELU)           # (4B, 2H + H) or None
+        if both is not None:
+            flat, beat_emb = ops.split_cols(both, la.weight.shape[0])
+            h0 = list(ops.split_cols(flat, hid))
+        else:
+            h0 = self.hidden_init(bo, 'tick')
+            beat_emb = _lin(bo, lb, ACT_SELU)                                                  # (4B, H)
         m = None
         if mask is not None:                                                                   # (24, B, H) -> rows (j, beat, b)
             m = mask.view(nb, steps, b, hid).transpose(0, 1).contiguous().view(steps * nb * b, hid)
@@ -478,6 +490,11 @@ class MeasureVAE(Model):
         for layer in range(gru.num_layers):
             g = lambda n, suf: getattr(gru, f'{n}_l{layer}{suf}')
             first += [g('weight_ih', ''), g('weight_ih', '_reverse'), g('bias_ih', ''), g('bias_ih', '_reverse')]
+        # the two heads' first layers read the same hidden vector; the tick RNN's initial state and its beat-embedding input are
+        # two layers on the same beat output: each pair as one product (ops.dense_pair)
+        enc, dec = self.encoder, self.decoder
+        for la, lb in ((enc.linear_mean[0], enc.linear_log_std[0]), (dec.beat_emb_to_tick_rnn_hidden[0], dec.beat_emb_to_tick_rnn_input[0])):
+            first += [la.weight, lb.weight, la.bias, lb.bias]
         taken = {id(p) for p in first}
         return first + [p for p in self.parameters() if id(p) not in taken]
 

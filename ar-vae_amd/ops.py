@@ -727,18 +727,19 @@ def _adjacent(a, b):
 
 
 class _DensePairFn(Function):
-    """two Linear layers on the same input whose weights (and biases) are adjacent in memory, as one [out_a + out_b, in] layer"""
+    """two Linear layers (+ one activation) on the same input whose weights (and biases) are adjacent in memory, as one
+    [out_a + out_b, in] layer"""
 
     @staticmethod
-    def forward(ctx, x, w_a, w_b, b_a, b_b):
+    def forward(ctx, x, w_a, w_b, b_a, b_b, act):
         _dev(x, w_a, w_b, b_a, b_b)
         n, n_in, n_out = x.shape[0], w_a.shape[1], w_a.shape[0] + w_b.shape[0]
         link = Link.dense(n_in, n_out)
         w_cat = w_a.detach().as_strided((n_out, n_in), (n_in, 1))
         b_cat = b_a.detach().as_strided((n_out,), (1,))
-        out = link_down(link, n, _operand(x), w_cat, b_cat, ACT_NONE, None)
-        ctx.link, ctx.n = link, n
-        ctx.save_for_backward(x, w_cat)
+        out = link_down(link, n, _operand(x), w_cat, b_cat, act, None)
+        ctx.link, ctx.n, ctx.act = link, n, act
+        ctx.save_for_backward(x, w_cat, out)
         ctx.refs = (w_a, w_b, b_a, b_b)
         ctx.x_ref = x if (x.is_leaf and x.requires_grad) else None
         return out
@@ -746,10 +747,10 @@ class _DensePairFn(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, g):
-        x, w_cat = ctx.saved_tensors
+        x, w_cat, out = ctx.saved_tensors
         link, n = ctx.link, ctx.n
         g = g.contiguous()
-        gop = _operand(g)
+        gop, keep = _plain_gradient(g, out, None, ctx.act, link, n)
         d_x = link_up(link, n, gop, w_cat, None, ACT_NONE, None) if ctx.needs_input_grad[0] else None
         x_ref = ctx.x_ref
         if d_x is not None and x_ref is not None and x_ref.grad is not None and x_ref.grad.shape == d_x.shape:
@@ -764,20 +765,21 @@ class _DensePairFn(Function):
             n_out, n_in = w_cat.shape
             gw = w_a.grad.as_strided((n_out, n_in), (n_in, 1))
             gb = b_a.grad.as_strided((n_out,), (1,))
-            link_wgrad(link, n, gop, _operand(x), gw, gb, 1)
-        return d_x, None, None, None, None
+            if not _defer_dense_wgrad(link, n, gop, (g, keep, out, x), x, gw, gb):
+                link_wgrad(link, n, gop, _operand(x), gw, gb, 1)
+        return d_x, None, None, None, None, None
 
 
-def dense_pair(x, w_a, b_a, w_b, b_b):
-    """x (n, in) times [w_a; w_b]^T + [b_a; b_b] as ONE product -> (n, out_a + out_b) when the two layers' weights, biases and
-    (when gradients are on) gradient buffers sit back to back in memory -- the trainer's flat arena in Model.arena_parameters()
-    order -- ; None when they do not (the caller runs the layers one by one)."""
+def dense_pair(x, w_a, b_a, w_b, b_b, act=ACT_NONE):
+    """act(x (n, in) times [w_a; w_b]^T + [b_a; b_b]) as ONE product -> (n, out_a + out_b) when the two layers' weights, biases
+    and (when gradients are on) gradient buffers sit back to back in memory -- the trainer's flat arena in
+    Model.arena_parameters() order -- ; None when they do not (the caller runs the layers one by one)."""
     if not (_adjacent(w_a, w_b) and _adjacent(b_a, b_b) and w_a.shape[1] == w_b.shape[1]):
         return None
     if torch.is_grad_enabled() and (w_a.requires_grad or w_b.requires_grad):
         if not (w_a.requires_grad and w_b.requires_grad and _adjacent(w_a.grad, w_b.grad) and _adjacent(b_a.grad, b_b.grad)):
             return None
-    return _DensePairFn.apply(x, w_a, w_b, b_a, b_b)
+    return _DensePairFn.apply(x, w_a, w_b, b_a, b_b, int(act))
 
 
 def tick_free_run_supported(hidden, vocab):
