@@ -68,9 +68,17 @@ def _worker(rank, world, port, b_total, out_path, capacity):
         dp.reduce_gradients(opt)
         mean_loss = float(dp.mean_scalar(loss))
         gathered = dp.gather_columns(torch.full((bl, 2), float(rank)))
+        # the rest of the transport's surface (what the HIP path calls on its communicator: several gathers as one call, a
+        # decision taken by all ranks, epoch statistics, a broadcast)
+        many = dp.gather_many([torch.full((bl, 3), float(rank)), torch.full((bl, 1), float(10 + rank))])
+        agree = (dp.all_agree(True), dp.all_agree(rank == 0))
+        stats = dp.mean_stats([float(rank), 2.0 * rank], 'cpu')
+        sent = torch.full((5,), float(rank + 7))
+        dp.comm.broadcast(sent, src=0)
         if rank == 0:
             np.savez(out_path, grad=(opt.grad_arena * opt.grad_scale).numpy(), loss=mean_loss,
-                     gathered=gathered.numpy(), scale=opt.grad_scale)
+                     gathered=gathered.numpy(), scale=opt.grad_scale, many0=many[0].numpy(), many1=many[1].numpy(),
+                     agree=np.array(agree), stats=np.array(stats), sent=sent.numpy(), capturable=dp.capturable)
     finally:
         dist.destroy_process_group()
 
@@ -98,6 +106,10 @@ def test_two_rank_step_equals_single_process(tmp_path, world, capacity):
     # all_gather_into_tensor is rank-major: rows of rank 0 first
     bl = b_total // world
     assert (got['gathered'][:bl] == 0).all() and (got['gathered'][bl:] == 1).all()
+    assert (got['many0'][:bl] == 0).all() and (got['many0'][bl:] == 1).all() and (got['many1'][:bl] == 10).all() and (got['many1'][bl:] == 11).all()
+    assert got['agree'].tolist() == [True, False]               # one rank saying no is everybody's no
+    np.testing.assert_allclose(got['stats'], [0.5, 1.0])
+    assert (got['sent'] == 7).all() and not bool(got['capturable'])   # torch.distributed collectives are not captured into graphs
 
 
 def _rng_worker(rank, world, port, out_path):
