@@ -642,7 +642,9 @@ def run_dsprites(device, args, fence, rank, world, use_dp):
                    'per_gpu_batch': b, 'global_batch': b * world,
                    'parallelism': f'dp{world}' + (' (forced DP path)' if args.force_dp and world == 1 else ''),
                    'rccl_world_size': world if use_dp else None,
-                   'collectives': None if COMM is None else type(COMM).__name__ + (' (RCCL %d via libarvae_hip.so, launch stream)' % COMM.rccl_version if hasattr(COMM, 'rccl_version') else ' (torch.distributed nccl group)'),
+                   'collectives': None if COMM is None else type(COMM).__name__ + (
+                       ' (RCCL %d via libarvae_hip.so, launch stream)' % COMM.rccl_version if hasattr(COMM, 'rccl_version') else
+                       ' (gloo on the host under device tensors: tests)' if type(COMM).__name__ == 'StagedComm' else ' (torch.distributed nccl group)'),
                    'images_per_sec_per_gpu': per_gpu, 'final_loss': final_loss},
         'timing': timing,
         'roofline': roof,
@@ -693,6 +695,8 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the AR-VAE hot path has no CPU fallback')
+    if os.environ.get('ARVAE_DP_TRANSPORT') == 'staged':        # (tests: host-staged collectives, several ranks may share a device)
+        local_rank %= torch.cuda.device_count()
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
     use_dp = world > 1 or args.force_dp

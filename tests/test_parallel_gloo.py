@@ -150,3 +150,29 @@ def test_ranks_draw_different_noise_and_masks(tmp_path):
     np.testing.assert_array_equal(got['rows'][0, 0], philox.normal(640, 7, offset=0))
     assert np.abs(got['rows'][0, 0] - got['rows'][1, 0]).max() > 0.5              # eps differ
     assert 0.3 < (got['rows'][0, 1] != got['rows'][1, 1]).mean() < 0.7            # keep-masks differ like independent coins
+
+
+@pytest.mark.parametrize('launcher', ['torchrun', 'env'])
+def test_ranks_meet_at_the_launchers_store(launcher):
+    """The HIP path's data-parallel runs have no torch process group: the ranks meet once at the launcher's key-value store to
+    hand out RCCL's unique id (parallel.connect -> parallel._rendezvous_store).  'torchrun': under
+    `python -m torch.distributed.run --master-addr 127.0.0.1` (what the driver's multi-GPU bench uses) the store is the
+    agent's (TORCHELASTIC_USE_AGENT_STORE); 'env': with RANK / WORLD_SIZE / MASTER_* alone (bench.py's own rank launcher) rank 0
+    hosts it."""
+    import subprocess
+    import sys
+    worker = os.path.join(ROOT, 'tests', 'rdzv_worker.py')
+    port = _free_port()
+    if launcher == 'torchrun':
+        r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                            '127.0.0.1', '--master-port', str(port), worker], capture_output=True, text=True, timeout=300)
+        out = r.stdout + r.stderr
+        assert r.returncode == 0, out[-3000:]
+        assert 'rank 0 of 2 ok agent_store=True' in out and 'rank 1 of 2 ok agent_store=True' in out
+    else:
+        procs = [subprocess.Popen([sys.executable, worker], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                                  env=dict(os.environ, RANK=str(rk), WORLD_SIZE='2', LOCAL_RANK=str(rk), MASTER_ADDR='127.0.0.1',
+                                           MASTER_PORT=str(port))) for rk in range(2)]
+        outs = [p.communicate(timeout=300)[0] for p in procs]
+        for rk, (p, o) in enumerate(zip(procs, outs)):
+            assert p.returncode == 0 and f'rank {rk} of 2 ok' in o, o[-3000:]

@@ -179,6 +179,27 @@ def test_bench_starts_its_own_ranks(workload):
     assert line['scaling'] == 'weak' and np.isfinite(line['value']) and line['value'] > 0
 
 
+def test_bench_under_the_drivers_launcher_with_two_ranks():
+    """the driver's command line for N = 2 -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1
+    --master-port P bench.py --gpus 2 ...` -- on whatever this box has: with two GPUs over the library's RCCL communicator, with one
+    GPU both ranks share it and the collectives are staged through the host (ARVAE_DP_TRANSPORT=staged).  Rank 0 prints ONE JSON
+    line that says two ranks, weak scaling, twice the per-GPU batch."""
+    port = _free_port()
+    env = dict(os.environ)
+    if torch.cuda.device_count() < 2:
+        env['ARVAE_DP_TRANSPORT'] = 'staged'
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                        '--min-seconds', '0', '--no-cpu-baseline'], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['config']['global_batch'] == 2 * line['config']['per_gpu_batch']
+    assert np.isfinite(line['value']) and line['value'] > 0 and line['config']['rccl_world_size'] == 2
+    assert line['config']['collectives'].startswith('StagedComm' if torch.cuda.device_count() < 2 else 'LibraryComm')
+
+
 def test_bench_refuses_more_ranks_than_gpus():
     have = torch.cuda.device_count()
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(have + 1), '--steps', '1', '--warmup', '0'],
