@@ -82,6 +82,24 @@ class LibraryComm:
         _lib.check(self.lib.arvae_comm_init(ident, self.rank, self.world_size, ctypes.byref(handle)), 'comm_init')
         self.handle = handle
         self.store = store                                      # rank 0 hosts it: alive as long as the communicator
+        self._self_test()
+
+    def _self_test(self):
+        """three tiny collectives with known answers, once, right after the communicator is built: a mis-wired job (ranks on
+        the wrong devices, a transport that moves nothing) fails HERE with a message, not as a wrong gradient later"""
+        w, r = self.world_size, self.rank
+        one = torch.full((4,), float(r + 1), device=self.device)
+        self.all_reduce(one)
+        gathered = torch.empty(4 * w, device=self.device)
+        self.all_gather(gathered, torch.full((4,), float(r), device=self.device))
+        sent = torch.full((4,), float(r + 3), device=self.device)
+        self.broadcast(sent, src=0)
+        torch.cuda.synchronize(self.device)
+        want = torch.arange(w, dtype=torch.float32).repeat_interleave(4)
+        if not (bool((one == w * (w + 1) / 2).all()) and torch.equal(gathered.cpu(), want) and bool((sent == 3.0).all())):
+            raise RuntimeError(f'RCCL self-test failed on rank {r} of {w}: all_reduce {one.tolist()}, all_gather {gathered.tolist()}, '
+                               f'broadcast {sent.tolist()}')
+        self.check()
 
     # -- collectives ---------------------------------------------------------------------------------------------
     @staticmethod
