@@ -3,8 +3,9 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-N > 1 runs one rank per GPU over RCCL.  Launched under torch.distributed.run the ranks read RANK / LOCAL_RANK /
-WORLD_SIZE / MASTER_* from the environment; launched plainly (`python bench.py --gpus 8`) this process starts the N
+N > 1 runs one rank per GPU over RCCL -- the library's own communicator (arvae_comm_*: RCCL calls on the launch stream; the
+ranks meet once at the launcher's TCP store to hand out RCCL's unique id; no torch process group).  Launched under
+torch.distributed.run the ranks read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment; launched plainly (`python bench.py --gpus 8`) this process starts the N
 ranks itself as fresh child processes -- before anything here touches the GPU -- and prints rank 0's line.
 
 Workload (BASELINE.json configs[1]): dSprites AR-VAE, per-GPU batch 512, fp32, beta=4, gamma=10,
@@ -426,7 +427,7 @@ def side_roofline(kind, prof, prof_steps, batch):
 def run_side(kind, device, args, fence, rank, world, use_dp, with_cpu):
     """one secondary workload -> its result dict (the main line when selected with --workload)"""
     bsz = args.batch if (args.workload == kind and args.batch != 512) else SIDE_BATCH[kind]
-    graphs = kind == 'measure' and not args.no_graphs         # (data-parallel steps replay too: graphed.Segments)
+    graphs = kind == 'measure' and not args.no_graphs         # (data-parallel steps replay too: their collectives are recorded, graphed.py)
     step, eager, unit = build_side_workload(kind, device, bsz, rank, use_dp, graphs)
     steps = args.steps if args.workload == kind else max(10, min(args.steps, 50))
     med, timing, loss = timed_regions(step, steps, args.warmup, fence, args.min_seconds)
