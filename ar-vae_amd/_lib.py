@@ -10,7 +10,7 @@ import threading
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libarvae_hip.so')
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 c_i32, c_i64, c_f32, c_f64, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
 
@@ -61,6 +61,25 @@ class GruSeqDesc(ctypes.Structure):
 class TickWeights(ctypes.Structure):
     """arvae_tick_weights_t"""
     _fields_ = [(n, c_vp) for n in ('w_hh0', 'b_hh0', 'w_ih1', 'b_ih1', 'w_hh1', 'b_hh1', 'w_out', 'b_out')]
+
+
+class MeasureVaeDesc(ctypes.Structure):
+    """arvae_measure_vae_t"""
+    _fields_ = ([(n, c_i32) for n in ('vocab', 'emb', 'enc_hidden', 'dec_hidden', 'zdim', 'steps', 'beats', 'ticks_per_beat')] +
+                [('enc_table', c_i64), ('enc_w_ih', c_i64 * 2), ('enc_b_ih', c_i64 * 2), ('enc_w_hh', (c_i64 * 2) * 2),
+                 ('enc_b_hh', (c_i64 * 2) * 2), ('head_w0', c_i64), ('head_b0', c_i64), ('mean_w2', c_i64), ('mean_b2', c_i64),
+                 ('lstd_w2', c_i64), ('lstd_b2', c_i64), ('dec_table', c_i64), ('x0', c_i64), ('b0', c_i64), ('z2beat_w', c_i64),
+                 ('z2beat_b', c_i64), ('beat_w_ih', c_i64 * 2), ('beat_b_ih', c_i64 * 2), ('beat_w_hh', c_i64 * 2),
+                 ('beat_b_hh', c_i64 * 2), ('tick_init_w', c_i64), ('tick_init_b', c_i64), ('tick_w_ih', c_i64 * 2),
+                 ('tick_b_ih', c_i64 * 2), ('tick_w_hh', c_i64 * 2), ('tick_b_hh', c_i64 * 2), ('out_w', c_i64), ('out_b', c_i64),
+                 ('enc_dropout', c_f32), ('dec_dropout', c_f32), ('n_reg', c_i32), ('reg_dims', c_i32 * 16), ('beta', c_f32),
+                 ('gamma', c_f32), ('delta', c_f32), ('rng_draw', c_i32), ('rng_offset', ctypes.c_uint32 * 3),
+                 ('rng_step', ctypes.c_uint32), ('rng_seed', ctypes.c_uint64), ('rng_dev_step', c_vp)])
+
+
+class MeasureTables(ctypes.Structure):
+    """arvae_measure_tables_t"""
+    _fields_ = [('midi_lut', c_vp), ('is_note', c_vp), ('is_density_note', c_vp), ('rhythm_weights', c_vp), ('rhythm_norm', c_f32)]
 
 
 class DenseWgradJob(ctypes.Structure):
@@ -128,6 +147,11 @@ SIGNATURES = {
                                        c_vp, c_vp]),
     'arvae_image_vae_backward': (c_i32, [_P(ImageVaeDesc), c_i32, c_vp, c_vp, c_vp, c_vp, _P(c_vp), c_vp, c_vp, c_vp,
                                          c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_vp, c_vp]),
+    'arvae_measure_vae_ws_floats': (c_i64, [_P(MeasureVaeDesc), c_i32]),
+    'arvae_measure_vae_forward': (c_i32, [_P(MeasureVaeDesc), c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, _P(MeasureTables), c_vp,
+                                          c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'arvae_measure_vae_backward': (c_i32, [_P(MeasureVaeDesc), c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                           c_vp, c_vp, c_vp, c_vp]),
     'arvae_philox_normal': (c_i32, [c_vp, c_i64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp]),
     'arvae_philox_keep_mask': (c_i32, [c_vp, c_i64, c_f32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp]),
     'arvae_count_nonfinite': (c_i32, [c_vp, c_i64, c_vp, c_vp]),

@@ -1,0 +1,652 @@
+// Whole-model forward / backward executors for MeasureVAE (see include/arvae_hip.h, arvae_measure_vae_*): one host call
+// enqueues every kernel of a pass on the caller's stream -- the GRU encoder, the latent head, the hierarchical decoder and
+// all loss terms forward; the hand-chained adjoints of the same launches backward, parameter gradients accumulating straight
+// into the gradient arena.  Host-side sequencing only: the math lives in the sequence / dense / loss kernels, reached through
+// the entry points a per-layer caller uses (the Python path of ar-vae_amd/measure_vae.py issues the same launches one by one
+// through autograd; tests/test_measure_executor.py holds the two against each other).
+//
+// Reference graph: measurevae/encoder.py:8-124, measurevae/decoder.py:309-525, measurevae/measure_vae.py:97-131,
+// measurevae/measure_vae_trainer.py:85-140 (loss), utils/trainer.py:140 (backward).
+#include "diag.h"
+#include "common.h"
+#include "dense.h"
+
+namespace arvae {
+
+static inline int64_t up4(int64_t v) { return (v + 3) / 4 * 4; }
+
+static arvae_link_t dense_link(int n, int n_in, int n_out) {
+    arvae_link_t l{};
+    l.n = n;
+    l.hh = l.hw = l.lh = l.lw = l.kh = l.kw = 1;
+    l.stride = 1;
+    l.chi = n_in;
+    l.clo = n_out;
+    return l;
+}
+
+// ---- glue kernels ----------------------------------------------------------------------------------
+// rows of the tick RNN's sequence launches are ordered (tick-in-beat j, beat, measure b); the reference's tensors are ordered
+// (tick t = tpb*beat + j, b) or (b, t).  y = alpha * x * mask with x in sequence order and the keep-mask in (t, b) order.
+__global__ __launch_bounds__(256) void scale_mask_tick_kernel(const float *__restrict__ x, const uint8_t *__restrict__ mask, float alpha,
+                                                               int batch, int beats, int tpb, int hid4, float *__restrict__ y) {
+    const int64_t total = (int64_t)tpb * beats * batch * hid4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % hid4);
+        int64_t r = i / hid4;
+        const int b = (int)(r % batch);
+        r /= batch;
+        const int beat = (int)(r % beats), j = (int)(r / beats);
+        const int64_t mrow = ((int64_t)(beat * tpb + j) * batch + b) * hid4 + c;
+        const float4 v = reinterpret_cast<const float4 *>(x)[i];
+        const uchar4 m = reinterpret_cast<const uchar4 *>(mask)[mrow];
+        reinterpret_cast<float4 *>(y)[i] = make_float4(alpha * v.x * (float)m.x, alpha * v.y * (float)m.y, alpha * v.z * (float)m.z,
+                                                       alpha * v.w * (float)m.w);
+    }
+}
+
+// targets in sequence order: out[(j*beats + beat)*batch + b] = score[b][tpb*beat + j]
+__global__ __launch_bounds__(256) void tick_order_i64_kernel(const int64_t *__restrict__ score, int batch, int beats, int tpb,
+                                                              int64_t *__restrict__ out) {
+    const int total = tpb * beats * batch;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int b = i % batch, r = i / batch;
+        const int beat = r % beats, j = r / beats;
+        out[i] = score[(int64_t)b * (beats * tpb) + beat * tpb + j];
+    }
+}
+
+// out = g[0] * d * (y > 0): the upstream scalar and the ReLU of the note projection folded into the cross-entropy gradient
+__global__ __launch_bounds__(256) void relu_gate_scale_kernel(const float *__restrict__ d, const float *__restrict__ y,
+                                                               const float *__restrict__ g, int64_t count4, float *__restrict__ out) {
+    const float s = g[0];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4 *>(d)[i], a = reinterpret_cast<const float4 *>(y)[i];
+        reinterpret_cast<float4 *>(out)[i] = make_float4(a.x > 0.f ? s * v.x : 0.f, a.y > 0.f ? s * v.y : 0.f, a.z > 0.f ? s * v.z : 0.f,
+                                                         a.w > 0.f ? s * v.w : 0.f);
+    }
+}
+__global__ __launch_bounds__(256) void relu_gate_scale1_kernel(const float *__restrict__ d, const float *__restrict__ y,
+                                                                const float *__restrict__ g, int64_t count, float *__restrict__ out) {
+    const float s = g[0];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
+        out[i] = y[i] > 0.f ? s * d[i] : 0.f;
+}
+
+// out[r] = [a[r] | b[r] | c[r]] (c may be null with cc == 0); all widths multiples of 4
+__global__ __launch_bounds__(256) void concat3_kernel(const float4 *__restrict__ a, const float4 *__restrict__ b, const float4 *__restrict__ c,
+                                                       int64_t rows, int ca4, int cb4, int cc4, float4 *__restrict__ out) {
+    const int w = ca4 + cb4 + cc4;
+    const int64_t total = rows * w;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / w;
+        const int col = (int)(i - r * w);
+        out[i] = col < ca4 ? a[r * ca4 + col] : (col < ca4 + cb4 ? b[r * cb4 + (col - ca4)] : c[r * cc4 + (col - ca4 - cb4)]);
+    }
+}
+
+// y[r][:] = x[r][:] + bias[:]
+__global__ __launch_bounds__(256) void add_bias_rows_kernel(const float4 *__restrict__ x, const float4 *__restrict__ bias, int64_t rows,
+                                                             int cols4, float4 *__restrict__ y) {
+    const int64_t total = rows * cols4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const float4 v = x[i], bb = bias[i % cols4];
+        y[i] = make_float4(v.x + bb.x, v.y + bb.y, v.z + bb.z, v.w + bb.w);
+    }
+}
+
+// gradient of the loss w.r.t. (mu, log_std): the decoder path g_z (already times the upstream scalar), the regulariser's unit
+// gradient dz_reg and the beta-KL term; sigma = exp(log_std), z = mu + eps * sigma (measure_vae.py:115-123, utils/trainer.py:354-367)
+__global__ __launch_bounds__(256) void measure_latent_bwd_kernel(const float *__restrict__ g_z, const float *__restrict__ dz_reg,
+                                                                  const float *__restrict__ mu, const float *__restrict__ sigma,
+                                                                  const float *__restrict__ eps, const float *__restrict__ g_loss,
+                                                                  const float *__restrict__ kl, const float *__restrict__ cap, float beta,
+                                                                  float inv_batch, int64_t count, float *__restrict__ d_mu,
+                                                                  float *__restrict__ d_ls) {
+    const float g = g_loss[0];
+    const float diff = kl[0] - (cap != nullptr ? cap[0] : 0.f);
+    const float k = g * beta * (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f)) * inv_batch;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+        float gz = g_z[i];
+        if (dz_reg != nullptr) gz += g * dz_reg[i];
+        const float s = sigma[i];
+        d_mu[i] = gz + k * mu[i];
+        d_ls[i] = (gz * eps[i] + k * (s - 1.f / s)) * s;
+    }
+}
+
+// scalars of the pass from the three terms' own outputs
+__global__ void measure_scalars_kernel(const float *__restrict__ ce, const float *__restrict__ kld, const float *__restrict__ reg,
+                                       float *__restrict__ scalars) {
+    if (threadIdx.x != 0) return;
+    const float r = reg != nullptr ? reg[0] : 0.f;
+    scalars[ARVAE_VAE_RECON] = ce[0];
+    scalars[ARVAE_VAE_ACC] = ce[1];
+    scalars[ARVAE_VAE_DIST] = kld[0];
+    scalars[ARVAE_VAE_KL] = kld[1];
+    scalars[ARVAE_VAE_REG] = r;
+    scalars[ARVAE_VAE_LOSS] = ce[0] + kld[0] + r;
+    scalars[6] = scalars[7] = 0.f;
+}
+
+static inline unsigned blocks_for(int64_t items, int cap = 2048) {
+    const int64_t b = (items + 255) / 256;
+    return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+// ---- workspace layout ------------------------------------------------------------------------------
+struct MvWs {
+    // encoder
+    float *ptab, *gi0, *out0, *sv0, *mid, *gi1, *out1, *sv1, *hidden, *h12, *hmu, *hls, *log_std;
+    // decoder
+    float *flatb, *h0b0, *h0b1, *x0b, *gi0b, *out0b, *svb0, *midb, *gi1b, *beat_out, *svb1;
+    float *both, *flatt, *beat_emb, *h0t0, *h0t1, *xs, *gsm, *gib, *frws;
+    float *gi0t, *out0t, *svt0, *midt, *gi1t, *out1t, *svt1, *probs;
+    int64_t *tgt;
+    // loss terms
+    float *dprobs, *rec_ws, *ce_out, *kld_out, *labels, *reg_ws, *reg_out, *dz_reg;
+    // backward
+    float *gpre, *d_seq_h, *dgi_t1, *dgh_t1, *hprev_t1, *dgi_t0, *dgh_t0, *hprev_t0, *d_mid_t, *dh0a, *dh0b, *dg_small, *tick_ws, *dx_small, *d_beat_emb, *d_both;
+    float *d_rows_h, *d_mid_b, *dgi_b1, *dgh_b1, *hprev_b1, *dgi_b0, *dgh_b0, *hprev_b0, *d_x0, *d_flatb, *d_z, *d_mu, *d_ls, *d_hmu, *d_hls, *d_h12, *d_hidden;
+    float *dgi_e1, *dgh_e1, *hprev_e1, *dgi_e0, *dgh_e0, *hprev_e0, *d_mid_e, *d_out0_e, *dptab, *embed_ws, *d_table, *wg_ws, *cs_ws;
+};
+
+struct MvDims {
+    int b, t, nb, tpb, v, e, he, hd, z;
+    int tb, rb, rt, ns;      // encoder rows T*B, beat rows nb*B, tick rows tpb*nb*B, rows of the small tick product
+};
+
+static MvDims dims_of(const arvae_measure_vae_t *m, int batch) {
+    MvDims d{};
+    d.b = batch; d.t = m->steps; d.nb = m->beats; d.tpb = m->ticks_per_beat; d.v = m->vocab; d.e = m->emb;
+    d.he = m->enc_hidden; d.hd = m->dec_hidden; d.z = m->zdim;
+    d.tb = d.t * batch; d.rb = d.nb * batch; d.rt = d.tpb * d.nb * batch; d.ns = d.v + 1 + d.rb;
+    return d;
+}
+
+static int64_t long_wgrad_ws(int rows, int n_in, int n_out) {
+    const arvae_link_t l = dense_link(rows, n_in, n_out);
+    return dense_wgrad_ws_floats(&l);
+}
+
+static int64_t carve(const arvae_measure_vae_t *m, int batch, float *base, MvWs *w) {
+    const MvDims d = dims_of(m, batch);
+    int64_t off = 0;
+    auto take = [&](int64_t n) {
+        float *p = base != nullptr ? base + off : nullptr;
+        off += up4(n);
+        return p;
+    };
+    const int64_t TB = d.tb, RB = d.rb, RT = d.rt, B = d.b;
+    w->ptab = take((int64_t)d.v * 6 * d.he);
+    w->gi0 = take(TB * 6 * d.he);
+    w->out0 = take(TB * 2 * d.he);
+    w->sv0 = take(2 * TB * 4 * d.he);
+    w->mid = take(TB * 2 * d.he);
+    w->gi1 = take(TB * 6 * d.he);
+    w->out1 = take(TB * 2 * d.he);
+    w->sv1 = take(2 * TB * 4 * d.he);
+    w->hidden = take(B * 4 * d.he);
+    w->h12 = take(B * 4 * d.he);
+    w->hmu = take(B * 2 * d.he);
+    w->hls = take(B * 2 * d.he);
+    w->log_std = take(B * d.z);
+    w->flatb = take(B * 2 * d.hd);
+    w->h0b0 = take(B * d.hd);
+    w->h0b1 = take(B * d.hd);
+    w->x0b = take(RB);
+    w->gi0b = take(B * 3 * d.hd);
+    w->out0b = take(RB * d.hd);
+    w->svb0 = take(RB * 4 * d.hd);
+    w->midb = take(RB * d.hd);
+    w->gi1b = take(RB * 3 * d.hd);
+    w->beat_out = take(RB * d.hd);
+    w->svb1 = take(RB * 4 * d.hd);
+    w->both = take(RB * 3 * d.hd);
+    w->flatt = take(RB * 2 * d.hd);
+    w->beat_emb = take(RB * d.hd);
+    w->h0t0 = take(RB * d.hd);
+    w->h0t1 = take(RB * d.hd);
+    w->xs = take((int64_t)d.ns * (d.e + d.hd));
+    w->gsm = take((int64_t)d.ns * 3 * d.hd);
+    w->gib = take(RB * 3 * d.hd);
+    w->frws = take(arvae_tick_free_run_ws_floats(d.hd));
+    w->gi0t = take(RT * 3 * d.hd);
+    w->out0t = take(RT * d.hd);
+    w->svt0 = take(RT * 4 * d.hd);
+    w->midt = take(RT * d.hd);
+    w->gi1t = take(RT * 3 * d.hd);
+    w->out1t = take(RT * d.hd);
+    w->svt1 = take(RT * 4 * d.hd);
+    w->probs = take(RT * d.v);
+    w->tgt = reinterpret_cast<int64_t *>(take(2 * RT));
+    w->dprobs = take(RT * d.v);
+    w->rec_ws = take(arvae_recon_ws_floats(RT));
+    w->ce_out = take(4);
+    w->kld_out = take(4);
+    w->labels = take(B * 4);
+    w->reg_ws = take(arvae_reg_loss_ws_floats(B, m->n_reg > 0 ? m->n_reg : 1));
+    w->reg_out = take(4);
+    w->dz_reg = take(B * d.z);
+    // backward
+    w->gpre = take(RT * d.v);
+    w->d_seq_h = take(RT * d.hd);
+    w->dgi_t1 = take(RT * 3 * d.hd);
+    w->dgh_t1 = take(RT * 3 * d.hd);
+    w->hprev_t1 = take(RT * d.hd);
+    w->dgi_t0 = take(RT * 3 * d.hd);
+    w->dgh_t0 = take(RT * 3 * d.hd);
+    w->hprev_t0 = take(RT * d.hd);
+    w->d_mid_t = take(RT * d.hd);
+    w->dh0a = take(RB * d.hd);
+    w->dh0b = take(RB * d.hd);
+    w->dg_small = take((int64_t)d.ns * 3 * d.hd);
+    w->tick_ws = take(arvae_tick_gi_bwd_ws_floats(d.v, 3 * d.hd));
+    w->dx_small = take((int64_t)d.ns * (d.e + d.hd));
+    w->d_beat_emb = take(RB * d.hd);
+    w->d_both = take(RB * 3 * d.hd);
+    w->d_rows_h = take(RB * d.hd);
+    w->d_mid_b = take(RB * d.hd);
+    w->dgi_b1 = take(RB * 3 * d.hd);
+    w->dgh_b1 = take(RB * 3 * d.hd);
+    w->hprev_b1 = take(RB * d.hd);
+    w->dgi_b0 = take(RB * 3 * d.hd);
+    w->dgh_b0 = take(RB * 3 * d.hd);
+    w->hprev_b0 = take(RB * d.hd);
+    w->d_x0 = take(RB);
+    w->d_flatb = take(B * 2 * d.hd);
+    w->d_z = take(B * d.z);
+    w->d_mu = take(B * d.z);
+    w->d_ls = take(B * d.z);
+    w->d_hmu = take(B * 2 * d.he);
+    w->d_hls = take(B * 2 * d.he);
+    w->d_h12 = take(B * 4 * d.he);
+    w->d_hidden = take(B * 4 * d.he);
+    w->dgi_e1 = take(TB * 6 * d.he);
+    w->dgh_e1 = take(2 * TB * 3 * d.he);
+    w->hprev_e1 = take(2 * TB * d.he);
+    w->dgi_e0 = take(TB * 6 * d.he);
+    w->dgh_e0 = take(2 * TB * 3 * d.he);
+    w->hprev_e0 = take(2 * TB * d.he);
+    w->d_mid_e = take(TB * 2 * d.he);
+    w->d_out0_e = take(TB * 2 * d.he);
+    w->dptab = take((int64_t)d.v * 6 * d.he);
+    w->embed_ws = take(arvae_embed_bwd_ws_floats(d.b, d.t, 6 * d.he, d.v));
+    w->d_table = take((int64_t)d.v * d.e);
+    int64_t wg = 0;
+    auto wmax = [&](int64_t v) { if (v > wg) wg = v; };
+    wmax(long_wgrad_ws(d.tb, d.he, 3 * d.he));
+    wmax(long_wgrad_ws(d.tb, 2 * d.he, 6 * d.he));
+    wmax(long_wgrad_ws(d.rt, d.hd, 3 * d.hd));
+    wmax(long_wgrad_ws(d.rt, d.hd, d.v));
+    wmax(long_wgrad_ws(d.rb, d.hd, 3 * d.hd));
+    wmax(long_wgrad_ws(d.ns, d.e + d.hd, 3 * d.hd));
+    w->wg_ws = take(wg);
+    int64_t cs = arvae_channel_sum_ws_floats(d.v + 1, 3 * d.hd);
+    if (arvae_channel_sum_ws_floats(d.rb, 1) > cs) cs = arvae_channel_sum_ws_floats(d.rb, 1);
+    w->cs_ws = take(cs);
+    return off;
+}
+
+static int check_model(const arvae_measure_vae_t *m, int batch, const char *what) {
+    ARVAE_REQUIRE(m != nullptr && batch >= 1, "%s: null model or empty batch", what);
+    ARVAE_REQUIRE(m->steps == m->beats * m->ticks_per_beat && m->steps >= 1, "%s: steps must be beats * ticks_per_beat", what);
+    ARVAE_REQUIRE(arvae_gru_seq_supported(m->enc_hidden) && arvae_gru_seq_supported(m->dec_hidden),
+                  "%s: hidden sizes %d / %d are not built as sequence kernels (32, 64, 128)", what, m->enc_hidden, m->dec_hidden);
+    ARVAE_REQUIRE(m->vocab >= 1 && m->emb >= 1 && m->zdim >= 1, "%s: empty vocabulary / embedding / latent", what);
+    ARVAE_REQUIRE(m->n_reg >= 0 && m->n_reg <= 16, "%s: at most 16 regularised dims", what);
+    ARVAE_REQUIRE((int64_t)(m->vocab + 1) * 1024 + ((int64_t)m->steps * batch + 15) / 16 * 8 <= 65536,
+                  "%s: vocabulary of %d notes at batch %d exceeds the segment sums' LDS", what, m->vocab, batch);
+    return ARVAE_OK;
+}
+
+#define MV_TRY(expr)                 \
+    do {                             \
+        if (int rc_ = (expr)) return rc_; \
+    } while (0)
+
+static arvae_operand_t plain(const float *v) { return arvae_operand_t{v, nullptr, nullptr, ARVAE_ACT_NONE}; }
+static arvae_operand_t gated(const float *v, const float *y, int act) { return arvae_operand_t{v, y, nullptr, act}; }
+
+// y = act(x W^T + b) for `rows` rows
+static int lin_fwd(int rows, int n_in, int n_out, const float *x, const float *w, const float *bias, int act, float *y, hipStream_t s) {
+    const arvae_link_t l = dense_link(rows, n_in, n_out);
+    return dense_fwd(&l, x, w, bias, act, y, s);
+}
+// dx = g W
+static int lin_dgrad(int rows, int n_in, int n_out, const arvae_operand_t &g, const float *w, float *dx, hipStream_t s) {
+    const arvae_link_t l = dense_link(rows, n_in, n_out);
+    return dense_dgrad(&l, make_operand(&g), w, nullptr, dx, s);
+}
+// dw += g^T x, db += column sums of g: queued for the pass's one batched launch when the batch is short, else launched now
+static int lin_wgrad(DenseWgradBatch *q, int rows, int n_in, int n_out, const arvae_operand_t &g, const float *x, float *dw, float *db,
+                     float *ws, hipStream_t s) {
+    const arvae_link_t l = dense_link(rows, n_in, n_out);
+    if (rows >= DENSE_SPLIT_MIN_ROWS) return dense_wgrad(&l, make_operand(&g), x, dw, db, ws, s);
+    if (dense_wgrad_defer(q, &l, make_operand(&g), x, dw, db)) return ARVAE_OK;
+    if (int rc = dense_wgrad_flush(q, s)) return rc;            // the queue is full: launch what it holds, start the next one
+    q->count = 0;
+    return dense_wgrad_defer(q, &l, make_operand(&g), x, dw, db) ? ARVAE_OK : fail(ARVAE_E_INVALID, "measure_vae_backward: weight-gradient queue");
+}
+
+}  // namespace arvae
+
+using namespace arvae;
+
+extern "C" int64_t arvae_measure_vae_ws_floats(const arvae_measure_vae_t *model, int32_t batch) {
+    if (check_model(model, batch, "measure_vae_ws_floats") != ARVAE_OK) return -1;
+    MvWs w{};
+    return carve(model, batch, nullptr, &w);
+}
+
+extern "C" int arvae_measure_vae_forward(const arvae_measure_vae_t *m, int32_t batch, const float *params, const int64_t *score,
+                                         float *eps, uint8_t *enc_mask, uint8_t *dec_mask, int32_t teacher_forced,
+                                         const float *capacity, const arvae_measure_tables_t *tables, float *ws, float *scalars,
+                                         float *mu, float *sigma, float *z, int64_t *tokens, arvae_stream_t stream) {
+    MV_TRY(check_model(m, batch, "measure_vae_forward"));
+    ARVAE_REQUIRE(params && score && eps && ws && scalars && mu && sigma && z && tokens, "measure_vae_forward: null pointer");
+    ARVAE_REQUIRE((enc_mask == nullptr) == (dec_mask == nullptr), "measure_vae_forward: give both keep-masks (training) or neither (evaluation)");
+    ARVAE_REQUIRE(m->n_reg == 0 || tables != nullptr, "measure_vae_forward: the regulariser needs the attribute tables");
+    ARVAE_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0, "measure_vae_forward: workspace must be 16-byte aligned");
+    const bool dropping = enc_mask != nullptr;
+    ARVAE_REQUIRE(!dropping || (m->enc_dropout >= 0.f && m->enc_dropout < 1.f && m->dec_dropout >= 0.f && m->dec_dropout < 1.f),
+                  "measure_vae_forward: dropout probabilities must be in [0, 1)");
+    hipStream_t s = as_stream(stream);
+    MvWs w{};
+    carve(m, batch, ws, &w);
+    const MvDims d = dims_of(m, batch);
+    const float *P = params;
+    const int He = d.he, Hd = d.hd;
+
+    // ---- draws (csrc/rng.h): keep-masks and eps exactly as ops.keep_mask / ops.normal_noise make them, in the Python path's order
+    if (m->rng_draw) {
+        if (dropping)
+            MV_TRY(arvae_philox_keep_mask(enc_mask, (int64_t)d.tb * 2 * He, 1.f - m->enc_dropout, m->rng_seed, m->rng_offset[0], m->rng_step,
+                                          m->rng_dev_step, stream));
+        MV_TRY(arvae_philox_normal(eps, (int64_t)d.b * d.z, m->rng_seed, m->rng_offset[1], m->rng_step, m->rng_dev_step, stream));
+        if (dropping)
+            MV_TRY(arvae_philox_keep_mask(dec_mask, (int64_t)(d.nb + d.t) * d.b * Hd, 1.f - m->dec_dropout, m->rng_seed, m->rng_offset[2],
+                                          m->rng_step, m->rng_dev_step, stream));
+    }
+    const float enc_keep = dropping ? 1.f / (1.f - m->enc_dropout) : 1.f, dec_keep = dropping ? 1.f / (1.f - m->dec_dropout) : 1.f;
+    const uint8_t *beat_mask = dec_mask, *tick_mask = dropping ? dec_mask + (int64_t)d.nb * d.b * Hd : nullptr;
+
+    // ---- encoder (encoder.py:108-124): layer 0's input projection by lookup, both directions side by side
+    MV_TRY(lin_fwd(d.v, d.e, 6 * He, P + m->enc_table, P + m->enc_w_ih[0], P + m->enc_b_ih[0], ARVAE_ACT_NONE, w.ptab, s));
+    MV_TRY(arvae_embed_fwd(score, w.ptab, d.b, d.t, 6 * He, d.v, 1, w.gi0, stream));
+    arvae_gru_seq_t q[2];
+    for (int layer = 0; layer < 2; ++layer) {
+        const float *gi = layer == 0 ? w.gi0 : w.gi1;
+        float *out = layer == 0 ? w.out0 : w.out1, *sv = layer == 0 ? w.sv0 : w.sv1;
+        if (layer == 1) {
+            const float *src = w.out0;
+            if (dropping) {
+                MV_TRY(arvae_scale_mask(w.out0, enc_mask, enc_keep, (int64_t)d.tb * 2 * He, 0, w.mid, stream));
+                src = w.mid;
+            }
+            MV_TRY(lin_fwd(d.tb, 2 * He, 6 * He, src, P + m->enc_w_ih[1], P + m->enc_b_ih[1], ARVAE_ACT_NONE, w.gi1, s));
+        }
+        for (int dir = 0; dir < 2; ++dir) {
+            arvae_gru_seq_t &g = q[dir];
+            g = arvae_gru_seq_t{};
+            g.gi = gi + dir * 3 * He;
+            g.gi_tstride = (int64_t)d.b * 6 * He;
+            g.gi_rstride = 6 * He;
+            g.w_hh = P + m->enc_w_hh[layer][dir];
+            g.b_hh = P + m->enc_b_hh[layer][dir];
+            g.h_all = out + dir * He;
+            g.h_stride = 2 * He;
+            g.saved = sv + (int64_t)dir * d.tb * 4 * He;
+            g.reverse = dir;
+            g.h_fin = w.hidden + (2 * layer + dir) * He;      // h_n of nn.GRU: (l0 fwd, l0 rev, l1 fwd, l1 rev)
+            g.h_fin_stride = 4 * He;
+        }
+        MV_TRY(arvae_gru_seq_fwd(q, 2, d.t, d.b, He, stream));
+    }
+    // the two heads' first layers as one product, then mu / log_std and the reparameterised sample
+    MV_TRY(lin_fwd(d.b, 4 * He, 4 * He, w.hidden, P + m->head_w0, P + m->head_b0, ARVAE_ACT_SELU, w.h12, s));
+    MV_TRY(arvae_split_cols(w.h12, d.b, 2 * He, 2 * He, w.hmu, w.hls, 0, stream));
+    MV_TRY(lin_fwd(d.b, 2 * He, d.z, w.hmu, P + m->mean_w2, P + m->mean_b2, ARVAE_ACT_NONE, mu, s));
+    MV_TRY(lin_fwd(d.b, 2 * He, d.z, w.hls, P + m->lstd_w2, P + m->lstd_b2, ARVAE_ACT_NONE, w.log_std, s));
+    MV_TRY(arvae_latent_fwd(mu, w.log_std, eps, (int64_t)d.b * d.z, sigma, z, stream));
+
+    // ---- beat RNN (decoder.py:436-457): the same input b_0 at every beat
+    MV_TRY(lin_fwd(d.b, d.z, 2 * Hd, z, P + m->z2beat_w, P + m->z2beat_b, ARVAE_ACT_SELU, w.flatb, s));
+    MV_TRY(arvae_split_cols(w.flatb, d.b, Hd, Hd, w.h0b0, w.h0b1, 0, stream));
+    MV_TRY(arvae_broadcast_rows(P + m->b0, d.rb, 1, w.x0b, stream));
+    MV_TRY(lin_fwd(d.b, 1, 3 * Hd, w.x0b, P + m->beat_w_ih[0], P + m->beat_b_ih[0], ARVAE_ACT_NONE, w.gi0b, s));
+    arvae_gru_seq_t g{};
+    g.gi = w.gi0b; g.gi_tstride = 0;
+    g.w_hh = P + m->beat_w_hh[0]; g.b_hh = P + m->beat_b_hh[0]; g.h0 = w.h0b0;
+    g.h_all = w.out0b; g.h_stride = Hd; g.saved = w.svb0;
+    MV_TRY(arvae_gru_seq_fwd(&g, 1, d.nb, d.b, Hd, stream));
+    const float *midb = w.out0b;
+    if (dropping) {
+        MV_TRY(arvae_scale_mask(w.out0b, beat_mask, dec_keep, (int64_t)d.rb * Hd, 0, w.midb, stream));
+        midb = w.midb;
+    }
+    MV_TRY(lin_fwd(d.rb, Hd, 3 * Hd, midb, P + m->beat_w_ih[1], P + m->beat_b_ih[1], ARVAE_ACT_NONE, w.gi1b, s));
+    g = arvae_gru_seq_t{};
+    g.gi = w.gi1b; g.gi_tstride = (int64_t)d.b * 3 * Hd;
+    g.w_hh = P + m->beat_w_hh[1]; g.b_hh = P + m->beat_b_hh[1]; g.h0 = w.h0b1;
+    g.h_all = w.beat_out; g.h_stride = Hd; g.saved = w.svb1;
+    MV_TRY(arvae_gru_seq_fwd(&g, 1, d.nb, d.b, Hd, stream));
+
+    // ---- tick RNN (decoder.py:459-525): the four beats as one 6-step sequence over beats*batch rows
+    MV_TRY(lin_fwd(d.rb, Hd, 3 * Hd, w.beat_out, P + m->tick_init_w, P + m->tick_init_b, ARVAE_ACT_SELU, w.both, s));
+    MV_TRY(arvae_split_cols(w.both, d.rb, 2 * Hd, Hd, w.flatt, w.beat_emb, 0, stream));
+    MV_TRY(arvae_split_cols(w.flatt, d.rb, Hd, Hd, w.h0t0, w.h0t1, 0, stream));
+    // layer 0's input projection by lookup: W_ih0 applied once to the vocabulary's embeddings, x_0 and the beat embeddings
+    MV_TRY(arvae_tick_rows_fwd(P + m->dec_table, P + m->x0, w.beat_emb, d.v, d.e, Hd, d.rb, w.xs, stream));
+    MV_TRY(lin_fwd(d.ns, d.e + Hd, 3 * Hd, w.xs, P + m->tick_w_ih[0], nullptr, ARVAE_ACT_NONE, w.gsm, s));
+    if (teacher_forced) {
+        MV_TRY((int)hipMemcpyAsync(tokens, score, sizeof(int64_t) * d.b * d.t, hipMemcpyDeviceToDevice, s) == 0 ? ARVAE_OK
+                   : fail(ARVAE_E_LAUNCH, "measure_vae_forward: token copy failed"));
+    } else {
+        // argmax feedback (not differentiated, decoder.py:506-516): the same small product holds the note table's and the beat
+        // embeddings' projections the free-running launch reads
+        ARVAE_REQUIRE(arvae_tick_free_run_supported(Hd, d.v), "measure_vae_forward: free-running decoder not built for hidden %d / %d notes",
+                      Hd, d.v);
+        ARVAE_LAUNCH(add_bias_rows_kernel, dim3(blocks_for((int64_t)d.rb * 3 * Hd / 4)), dim3(256), 0, s,
+                     reinterpret_cast<const float4 *>(w.gsm + (int64_t)(d.v + 1) * 3 * Hd),
+                     reinterpret_cast<const float4 *>(P + m->tick_b_ih[0]), (int64_t)d.rb, 3 * Hd / 4, reinterpret_cast<float4 *>(w.gib));
+        MV_TRY(check_launch("add_bias_rows_kernel"));
+        arvae_tick_weights_t tw{P + m->tick_w_hh[0], P + m->tick_b_hh[0], P + m->tick_w_ih[1], P + m->tick_b_ih[1],
+                                P + m->tick_w_hh[1], P + m->tick_b_hh[1], P + m->out_w, P + m->out_b};
+        MV_TRY(arvae_tick_free_run(&tw, w.h0t0, w.h0t1, w.gib, w.gsm, tick_mask, dec_keep, d.b, d.nb, d.tpb, Hd, d.v, tokens, w.frws, stream));
+    }
+    MV_TRY(arvae_tick_gi_fwd(w.gsm, tokens, P + m->tick_b_ih[0], d.b, d.nb, d.tpb, d.v, 3 * Hd, w.gi0t, stream));
+    g = arvae_gru_seq_t{};
+    g.gi = w.gi0t; g.gi_tstride = (int64_t)d.rb * 3 * Hd;
+    g.w_hh = P + m->tick_w_hh[0]; g.b_hh = P + m->tick_b_hh[0]; g.h0 = w.h0t0;
+    g.h_all = w.out0t; g.h_stride = Hd; g.saved = w.svt0;
+    MV_TRY(arvae_gru_seq_fwd(&g, 1, d.tpb, d.rb, Hd, stream));
+    const float *midt = w.out0t;
+    if (dropping) {
+        ARVAE_LAUNCH(scale_mask_tick_kernel, dim3(blocks_for((int64_t)d.rt * Hd / 4)), dim3(256), 0, s, w.out0t, tick_mask, dec_keep, d.b,
+                     d.nb, d.tpb, Hd / 4, w.midt);
+        MV_TRY(check_launch("scale_mask_tick_kernel"));
+        midt = w.midt;
+    }
+    MV_TRY(lin_fwd(d.rt, Hd, 3 * Hd, midt, P + m->tick_w_ih[1], P + m->tick_b_ih[1], ARVAE_ACT_NONE, w.gi1t, s));
+    g = arvae_gru_seq_t{};
+    g.gi = w.gi1t; g.gi_tstride = (int64_t)d.rb * 3 * Hd;
+    g.w_hh = P + m->tick_w_hh[1]; g.b_hh = P + m->tick_b_hh[1]; g.h0 = w.h0t1;
+    g.h_all = w.out1t; g.h_stride = Hd; g.saved = w.svt1;
+    MV_TRY(arvae_gru_seq_fwd(&g, 1, d.tpb, d.rb, Hd, stream));
+    MV_TRY(lin_fwd(d.rt, Hd, d.v, w.out1t, P + m->out_w, P + m->out_b, ARVAE_ACT_RELU, w.probs, s));
+
+    // ---- loss terms (measure_vae_trainer.py:85-140): cross entropy over the 24*B rows (any row order), beta-KL, regulariser
+    ARVAE_LAUNCH(tick_order_i64_kernel, dim3(blocks_for(d.rt)), dim3(256), 0, s, score, d.b, d.nb, d.tpb, w.tgt);
+    MV_TRY(check_launch("tick_order_i64_kernel"));
+    MV_TRY(arvae_token_recon(w.probs, w.tgt, d.rt, d.v, w.rec_ws, w.ce_out, w.dprobs, stream));
+    MV_TRY(arvae_kld_fwd(mu, sigma, nullptr, nullptr, d.b, d.z, m->beta, capacity, w.kld_out, stream));
+    if (m->n_reg > 0) {
+        MV_TRY(arvae_measure_attributes(score, d.b, d.t, tables->midi_lut, tables->is_note, tables->is_density_note, d.v,
+                                        tables->rhythm_weights, tables->rhythm_norm, w.labels, stream));
+        MV_TRY(arvae_reg_loss(z, w.labels, d.b, z, w.labels, d.b, d.z, 4, m->reg_dims, m->n_reg, m->gamma, m->delta, w.reg_ws, w.reg_out,
+                              w.dz_reg, stream));
+    }
+    ARVAE_LAUNCH(measure_scalars_kernel, dim3(1), dim3(64), 0, s, w.ce_out, w.kld_out, m->n_reg > 0 ? w.reg_out : nullptr, scalars);
+    return check_launch("measure_scalars_kernel");
+}
+
+extern "C" int arvae_measure_vae_backward(const arvae_measure_vae_t *m, int32_t batch, const float *params, float *grads,
+                                          const int64_t *score, const float *eps, const uint8_t *enc_mask, const uint8_t *dec_mask,
+                                          const float *capacity, const float *mu, const float *sigma, const float *z,
+                                          const int64_t *tokens, const float *scalars, const float *g_loss, float *ws, arvae_stream_t stream) {
+    MV_TRY(check_model(m, batch, "measure_vae_backward"));
+    ARVAE_REQUIRE(params && grads && score && eps && mu && sigma && z && tokens && scalars && g_loss && ws, "measure_vae_backward: null pointer");
+    ARVAE_REQUIRE((enc_mask == nullptr) == (dec_mask == nullptr), "measure_vae_backward: give both keep-masks or neither");
+    hipStream_t s = as_stream(stream);
+    MvWs w{};
+    carve(m, batch, ws, &w);
+    const MvDims d = dims_of(m, batch);
+    const float *P = params;
+    float *G = grads;
+    const int He = d.he, Hd = d.hd;
+    const bool dropping = enc_mask != nullptr;
+    const float enc_keep = dropping ? 1.f / (1.f - m->enc_dropout) : 1.f, dec_keep = dropping ? 1.f / (1.f - m->dec_dropout) : 1.f;
+    const uint8_t *beat_mask = dec_mask, *tick_mask = dropping ? dec_mask + (int64_t)d.nb * d.b * Hd : nullptr;
+    DenseWgradBatch queue{};
+
+    // ---- note projection: d probs (cross entropy, unit upstream) times the upstream scalar, through the ReLU
+    const int64_t np = (int64_t)d.rt * d.v;
+    if (np % 4 == 0)
+        ARVAE_LAUNCH(relu_gate_scale_kernel, dim3(blocks_for(np / 4)), dim3(256), 0, s, w.dprobs, w.probs, g_loss, np / 4, w.gpre);
+    else
+        ARVAE_LAUNCH(relu_gate_scale1_kernel, dim3(blocks_for(np)), dim3(256), 0, s, w.dprobs, w.probs, g_loss, np, w.gpre);
+    MV_TRY(check_launch("relu_gate_scale_kernel"));
+    MV_TRY(lin_dgrad(d.rt, Hd, d.v, plain(w.gpre), P + m->out_w, w.d_seq_h, s));
+    MV_TRY(lin_wgrad(&queue, d.rt, Hd, d.v, plain(w.gpre), w.out1t, G + m->out_w, G + m->out_b, w.wg_ws, s));
+
+    // ---- tick RNN, layer 1 then layer 0
+    const float *midt = dropping ? w.midt : w.out0t;
+    arvae_gru_seq_t g{};
+    g.w_hh = P + m->tick_w_hh[1]; g.h0 = w.h0t1; g.h_all = w.out1t; g.h_stride = Hd; g.saved = w.svt1;
+    g.dh_all = w.d_seq_h; g.dh_stride = Hd; g.dgi = w.dgi_t1; g.dgh = w.dgh_t1; g.dh0 = w.dh0b; g.h_prev_out = w.hprev_t1;
+    MV_TRY(arvae_gru_seq_bwd(&g, 1, d.tpb, d.rb, Hd, stream));
+    MV_TRY(lin_wgrad(&queue, d.rt, Hd, 3 * Hd, plain(w.dgh_t1), w.hprev_t1, G + m->tick_w_hh[1], G + m->tick_b_hh[1], w.wg_ws, s));
+    MV_TRY(lin_dgrad(d.rt, Hd, 3 * Hd, plain(w.dgi_t1), P + m->tick_w_ih[1], w.d_mid_t, s));
+    MV_TRY(lin_wgrad(&queue, d.rt, Hd, 3 * Hd, plain(w.dgi_t1), midt, G + m->tick_w_ih[1], G + m->tick_b_ih[1], w.wg_ws, s));
+    const float *d_out0t = w.d_mid_t;
+    if (dropping) {
+        ARVAE_LAUNCH(scale_mask_tick_kernel, dim3(blocks_for((int64_t)d.rt * Hd / 4)), dim3(256), 0, s, w.d_mid_t, tick_mask, dec_keep, d.b,
+                     d.nb, d.tpb, Hd / 4, w.d_seq_h);
+        MV_TRY(check_launch("scale_mask_tick_kernel"));
+        d_out0t = w.d_seq_h;
+    }
+    g = arvae_gru_seq_t{};
+    g.w_hh = P + m->tick_w_hh[0]; g.h0 = w.h0t0; g.h_all = w.out0t; g.h_stride = Hd; g.saved = w.svt0;
+    g.dh_all = d_out0t; g.dh_stride = Hd; g.dgi = w.dgi_t0; g.dgh = w.dgh_t0; g.dh0 = w.dh0a; g.h_prev_out = w.hprev_t0;
+    MV_TRY(arvae_gru_seq_bwd(&g, 1, d.tpb, d.rb, Hd, stream));
+    MV_TRY(lin_wgrad(&queue, d.rt, Hd, 3 * Hd, plain(w.dgh_t0), w.hprev_t0, G + m->tick_w_hh[0], G + m->tick_b_hh[0], w.wg_ws, s));
+    // layer 0's input projection: per-tick gradients summed per previous note and per beat row, then the small product's adjoints
+    MV_TRY(arvae_tick_gi_bwd(w.dgi_t0, tokens, d.b, d.nb, d.tpb, d.v, 3 * Hd, w.dg_small, w.tick_ws, stream));
+    {
+        const arvae_operand_t note_rows = plain(w.dg_small);      // every tick row carries the bias once and exactly one note entry
+        MV_TRY(arvae_channel_sum(&note_rows, d.v + 1, 3 * Hd, 0, 0, G + m->tick_b_ih[0], w.cs_ws, stream));
+    }
+    MV_TRY(lin_wgrad(&queue, d.ns, d.e + Hd, 3 * Hd, plain(w.dg_small), w.xs, G + m->tick_w_ih[0], nullptr, w.wg_ws, s));
+    MV_TRY(lin_dgrad(d.ns, d.e + Hd, 3 * Hd, plain(w.dg_small), P + m->tick_w_ih[0], w.dx_small, s));
+    MV_TRY(arvae_tick_rows_bwd(w.dx_small, d.v, d.e, Hd, d.rb, G + m->dec_table, G + m->x0, w.d_beat_emb, stream));
+    // initial states + beat-embedding input: one SELU layer on the beat outputs
+    ARVAE_LAUNCH(concat3_kernel, dim3(blocks_for((int64_t)d.rb * 3 * Hd / 4)), dim3(256), 0, s, reinterpret_cast<const float4 *>(w.dh0a),
+                 reinterpret_cast<const float4 *>(w.dh0b), reinterpret_cast<const float4 *>(w.d_beat_emb), (int64_t)d.rb, Hd / 4, Hd / 4,
+                 Hd / 4, reinterpret_cast<float4 *>(w.d_both));
+    MV_TRY(check_launch("concat3_kernel"));
+    MV_TRY(lin_dgrad(d.rb, Hd, 3 * Hd, gated(w.d_both, w.both, ARVAE_ACT_SELU), P + m->tick_init_w, w.d_rows_h, s));
+    MV_TRY(lin_wgrad(&queue, d.rb, Hd, 3 * Hd, gated(w.d_both, w.both, ARVAE_ACT_SELU), w.beat_out, G + m->tick_init_w, G + m->tick_init_b,
+                     w.wg_ws, s));
+
+    // ---- beat RNN, layer 1 then layer 0 (their batch-sized weight gradients wait in the queue: separate buffers per layer)
+    const float *midb = dropping ? w.midb : w.out0b;
+    g = arvae_gru_seq_t{};
+    g.w_hh = P + m->beat_w_hh[1]; g.h0 = w.h0b1; g.h_all = w.beat_out; g.h_stride = Hd; g.saved = w.svb1;
+    g.dh_all = w.d_rows_h; g.dh_stride = Hd; g.dgi = w.dgi_b1; g.dgh = w.dgh_b1; g.dh0 = w.dh0b; g.h_prev_out = w.hprev_b1;
+    MV_TRY(arvae_gru_seq_bwd(&g, 1, d.nb, d.b, Hd, stream));
+    MV_TRY(lin_wgrad(&queue, d.rb, Hd, 3 * Hd, plain(w.dgh_b1), w.hprev_b1, G + m->beat_w_hh[1], G + m->beat_b_hh[1], w.wg_ws, s));
+    MV_TRY(lin_dgrad(d.rb, Hd, 3 * Hd, plain(w.dgi_b1), P + m->beat_w_ih[1], w.d_mid_b, s));
+    MV_TRY(lin_wgrad(&queue, d.rb, Hd, 3 * Hd, plain(w.dgi_b1), midb, G + m->beat_w_ih[1], G + m->beat_b_ih[1], w.wg_ws, s));
+    const float *d_out0b = w.d_mid_b;
+    if (dropping) {
+        MV_TRY(arvae_scale_mask(w.d_mid_b, beat_mask, dec_keep, (int64_t)d.rb * Hd, 0, w.d_rows_h, stream));
+        d_out0b = w.d_rows_h;
+    }
+    g = arvae_gru_seq_t{};
+    g.w_hh = P + m->beat_w_hh[0]; g.h0 = w.h0b0; g.h_all = w.out0b; g.h_stride = Hd; g.saved = w.svb0;
+    g.dh_all = d_out0b; g.dh_stride = Hd; g.dgi = w.dgi_b0; g.dgh = w.dgh_b0; g.dh0 = w.dh0a; g.h_prev_out = w.hprev_b0;
+    MV_TRY(arvae_gru_seq_bwd(&g, 1, d.nb, d.b, Hd, stream));
+    MV_TRY(lin_wgrad(&queue, d.rb, Hd, 3 * Hd, plain(w.dgh_b0), w.hprev_b0, G + m->beat_w_hh[0], G + m->beat_b_hh[0], w.wg_ws, s));
+    // the constant input b_0 (decoder.py:436-440): the projection's gradients over all beats*batch rows (x0b holds b_0 once per row)
+    MV_TRY(lin_wgrad(&queue, d.rb, 1, 3 * Hd, plain(w.dgi_b0), w.x0b, G + m->beat_w_ih[0], G + m->beat_b_ih[0], w.wg_ws, s));
+    MV_TRY(lin_dgrad(d.rb, 1, 3 * Hd, plain(w.dgi_b0), P + m->beat_w_ih[0], w.d_x0, s));
+    {
+        const arvae_operand_t dx0 = plain(w.d_x0);
+        MV_TRY(arvae_channel_sum(&dx0, d.rb, 1, 0, 0, G + m->b0, w.cs_ws, stream));
+    }
+    MV_TRY(arvae_concat_cols(w.dh0a, w.dh0b, d.b, Hd, Hd, w.d_flatb, stream));
+    MV_TRY(lin_dgrad(d.b, d.z, 2 * Hd, gated(w.d_flatb, w.flatb, ARVAE_ACT_SELU), P + m->z2beat_w, w.d_z, s));
+    MV_TRY(lin_wgrad(&queue, d.b, d.z, 2 * Hd, gated(w.d_flatb, w.flatb, ARVAE_ACT_SELU), z, G + m->z2beat_w, G + m->z2beat_b, w.wg_ws, s));
+
+    // ---- latent head: decoder path + regulariser + beta-KL -> (d mu, d log_std), then the heads' two layers
+    ARVAE_LAUNCH(measure_latent_bwd_kernel, dim3(blocks_for((int64_t)d.b * d.z)), dim3(256), 0, s, w.d_z, m->n_reg > 0 ? w.dz_reg : nullptr, mu,
+                 sigma, eps, g_loss, scalars + ARVAE_VAE_KL, capacity, m->beta, 1.f / (float)d.b, (int64_t)d.b * d.z, w.d_mu, w.d_ls);
+    MV_TRY(check_launch("measure_latent_bwd_kernel"));
+    MV_TRY(lin_dgrad(d.b, 2 * He, d.z, plain(w.d_mu), P + m->mean_w2, w.d_hmu, s));
+    MV_TRY(lin_dgrad(d.b, 2 * He, d.z, plain(w.d_ls), P + m->lstd_w2, w.d_hls, s));
+    MV_TRY(lin_wgrad(&queue, d.b, 2 * He, d.z, plain(w.d_mu), w.hmu, G + m->mean_w2, G + m->mean_b2, w.wg_ws, s));
+    MV_TRY(lin_wgrad(&queue, d.b, 2 * He, d.z, plain(w.d_ls), w.hls, G + m->lstd_w2, G + m->lstd_b2, w.wg_ws, s));
+    MV_TRY(arvae_concat_cols(w.d_hmu, w.d_hls, d.b, 2 * He, 2 * He, w.d_h12, stream));
+    MV_TRY(lin_dgrad(d.b, 4 * He, 4 * He, gated(w.d_h12, w.h12, ARVAE_ACT_SELU), P + m->head_w0, w.d_hidden, s));
+    MV_TRY(lin_wgrad(&queue, d.b, 4 * He, 4 * He, gated(w.d_h12, w.h12, ARVAE_ACT_SELU), w.hidden, G + m->head_w0, G + m->head_b0, w.wg_ws, s));
+
+    // ---- encoder, layer 1 then layer 0: the final states' gradients enter each direction at its last processed step
+    arvae_gru_seq_t q[2];
+    for (int layer = 1; layer >= 0; --layer) {
+        const float *out = layer == 0 ? w.out0 : w.out1, *sv = layer == 0 ? w.sv0 : w.sv1;
+        float *dgi = layer == 0 ? w.dgi_e0 : w.dgi_e1, *dgh = layer == 0 ? w.dgh_e0 : w.dgh_e1, *hprev = layer == 0 ? w.hprev_e0 : w.hprev_e1;
+        const float *d_out = nullptr;
+        if (layer == 0) {
+            d_out = w.d_mid_e;
+            if (dropping) {
+                MV_TRY(arvae_scale_mask(w.d_mid_e, enc_mask, enc_keep, (int64_t)d.tb * 2 * He, 0, w.d_out0_e, stream));
+                d_out = w.d_out0_e;
+            }
+        }
+        for (int dir = 0; dir < 2; ++dir) {
+            arvae_gru_seq_t &e = q[dir];
+            e = arvae_gru_seq_t{};
+            e.w_hh = P + m->enc_w_hh[layer][dir];
+            e.h_all = const_cast<float *>(out) + dir * He;
+            e.h_stride = 2 * He;
+            e.saved = const_cast<float *>(sv) + (int64_t)dir * d.tb * 4 * He;
+            e.reverse = dir;
+            if (d_out != nullptr) {
+                e.dh_all = d_out + dir * He;
+                e.dh_stride = 2 * He;
+            }
+            e.dh_last = w.d_hidden + (2 * layer + dir) * He;
+            e.dh_last_stride = 4 * He;
+            e.dgi = dgi + dir * 3 * He;
+            e.dgi_rstride = 6 * He;
+            e.dgh = dgh + (int64_t)dir * d.tb * 3 * He;
+            e.h_prev_out = hprev + (int64_t)dir * d.tb * He;
+        }
+        MV_TRY(arvae_gru_seq_bwd(q, 2, d.t, d.b, He, stream));
+        for (int dir = 0; dir < 2; ++dir)
+            MV_TRY(lin_wgrad(&queue, d.tb, He, 3 * He, plain(dgh + (int64_t)dir * d.tb * 3 * He), hprev + (int64_t)dir * d.tb * He,
+                             G + m->enc_w_hh[layer][dir], G + m->enc_b_hh[layer][dir], w.wg_ws, s));
+        if (layer == 1) {
+            const float *src = dropping ? w.mid : w.out0;
+            MV_TRY(lin_wgrad(&queue, d.tb, 2 * He, 6 * He, plain(dgi), src, G + m->enc_w_ih[1], G + m->enc_b_ih[1], w.wg_ws, s));
+            MV_TRY(lin_dgrad(d.tb, 2 * He, 6 * He, plain(dgi), P + m->enc_w_ih[1], w.d_mid_e, s));
+        }
+    }
+    // layer 0's projection table: per-position gradients summed per token, then the small product's adjoints
+    MV_TRY(arvae_embed_bwd(score, w.dgi_e0, d.b, d.t, 6 * He, d.v, 1, w.dptab, 0, w.embed_ws, stream));
+    MV_TRY(lin_dgrad(d.v, d.e, 6 * He, plain(w.dptab), P + m->enc_w_ih[0], w.d_table, s));
+    MV_TRY(arvae_scale_mask(w.d_table, nullptr, 1.f, (int64_t)d.v * d.e, 1, G + m->enc_table, stream));
+    MV_TRY(lin_wgrad(&queue, d.v, d.e, 6 * He, plain(w.dptab), P + m->enc_table, G + m->enc_w_ih[0], G + m->enc_b_ih[0], w.wg_ws, s));
+    return dense_wgrad_flush(&queue, s);
+}

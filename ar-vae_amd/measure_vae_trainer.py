@@ -84,7 +84,11 @@ class MeasureVAETrainer(Trainer):
         self.model.update_trainer_config(self.trainer_config)
         self._tables = None
         self.last_terms = {}
-        self.use_graph_replay = True          # a few hundred small launches per step: replayed from HIP graphs (trainer.py)
+        self.use_graph_replay = True          # about a hundred small launches per step: replayed from HIP graphs (trainer.py)
+        # forward + loss terms and backward as one library call each (fused_measure.py, csrc/plan_measure.hip) where the executor
+        # is built for the model; False keeps the per-layer autograd path (the same launches issued one by one)
+        self.use_fused_step = True
+        self._fused = None
 
     def process_batch_data(self, batch):
         score, metadata = batch
@@ -115,11 +119,51 @@ class MeasureVAETrainer(Trainer):
             cols.append(self.attr_dict[name])
         return labels[:, cols]
 
+    def fused_executor(self, score):
+        """the whole-model executor bound to this trainer's arena, or None when this step takes the per-layer path: data
+        parallel runs (their collectives sit between the layers), debug checks, CPU models, unsupported shapes."""
+        if not self.use_fused_step or self.data_parallel is not None or not score.is_cuda or ops.checks_enabled():
+            return None
+        if self.use_reg_loss and type(self.reg_dim) != tuple:
+            return None                                            # (the per-layer path raises the reference's TypeError)
+        from .fused_measure import FusedMeasureVAE
+        from .measure_vae import _use_sequence_kernels
+        reg_dims = tuple(self.reg_dim) if self.use_reg_loss else ()
+        key = (reg_dims, float(self.beta), float(self.gamma), float(self.delta))
+        if self._fused is None or self._fused[0] != key:
+            usable = (_use_sequence_kernels(self.model.encoder.rnn_hidden_size) and next(self.model.parameters()).is_cuda
+                      and FusedMeasureVAE.supports(self.model, self.optimizer, reg_dims) is None)
+            self._fused = (key, FusedMeasureVAE(self.model, self.optimizer, reg_dims, self.beta, self.gamma, self.delta) if usable else None)
+        fused = self._fused[1]
+        if fused is None or not fused.fits(score.shape[0]):
+            return None
+        enc, dec = self.model.encoder, self.model.decoder
+        if bool(enc._mask_queue) != bool(dec._mask_queue):
+            return None                                            # explicit keep-masks for one half only: per-layer path
+        return fused
+
+    def _fused_loss_and_acc(self, fused, score, epoch_num, first_of_epoch, train):
+        from .fused_measure import ACC, DIST, RECON, REG
+        enc, dec = self.model.encoder, self.model.decoder
+        eps = enc._eps_queue.popleft() if enc._eps_queue else enc.static_eps
+        masks = None
+        if self.model.training and enc._mask_queue:
+            masks = (enc._mask_queue.popleft(),) + tuple(dec._mask_queue.popleft())
+        tables = fused.tables(self, score.device) if self.use_reg_loss else None
+        loss, scalars, accuracy, *_ = fused.run(score, train, None, tables, eps, masks)
+        self.last_terms = {'recons': scalars[RECON], 'dist': scalars[DIST], 'reg': scalars[REG] if self.use_reg_loss else None}
+        if first_of_epoch and self.writer is not None and not torch.cuda.is_current_stream_capturing():
+            self.log_loss_split(epoch_num)
+        return loss.reshape(()), accuracy
+
     def loss_and_acc_for_batch(self, batch, epoch_num=None, batch_num=None, train=True):
         first_of_epoch = self.cur_epoch_num != epoch_num
         if first_of_epoch:
             self.cur_epoch_num = epoch_num
         score, metadata = batch
+        fused = self.fused_executor(score)
+        if fused is not None:
+            return self._fused_loss_and_acc(fused, score, epoch_num, first_of_epoch, train)
         weights, samples, z_dist, prior_dist, z_tilde, _ = self.model(measure_score_tensor=score, measure_metadata_tensor=metadata,
                                                                        train=train, need_prior_sample=False)
         recons_loss, accuracy = ops.token_recon(weights, score)

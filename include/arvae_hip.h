@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ARVAE_ABI_VERSION 8   /* 8: arvae_gru_seq_t.gi_rstride / dgi_rstride / h_fin (merged input projections of a bidirectional layer, final states written by the sequence launch); 7: arvae_comm_* (the data-parallel step's collectives: RCCL on the launch stream, owned by the library); 6: the 32-channel k4 s2 p1 links need caller workspace too (arvae_link_ws_floats / arvae_link_wgrad_ws_floats: the layer's weights as scaled fp16 terms and the operands' maxima); 5: arvae_adam_step(zero_grad), arvae_image_vae_finish, arvae_image_vae_t.milestones (events the executors record for the data-parallel caller's collectives); 4: arvae_philox_* and in-kernel eps (arvae_image_vae_t.rng_*), arvae_tick_free_run_supported, caller workspace for arvae_link_down/up (arvae_link_ws_floats); 3: arvae_gru_seq_*, embed_bwd workspace; 2: arvae_image_vae_backward reg_fused == 2 (unit regulariser gradient in dz_extra) */
+#define ARVAE_ABI_VERSION 9   /* 9: arvae_measure_vae_* (whole-model MeasureVAE step); 8: arvae_gru_seq_t.gi_rstride / dgi_rstride / h_fin (merged input projections of a bidirectional layer, final states written by the sequence launch); 7: arvae_comm_* (the data-parallel step's collectives: RCCL on the launch stream, owned by the library); 6: the 32-channel k4 s2 p1 links need caller workspace too (arvae_link_ws_floats / arvae_link_wgrad_ws_floats: the layer's weights as scaled fp16 terms and the operands' maxima); 5: arvae_adam_step(zero_grad), arvae_image_vae_finish, arvae_image_vae_t.milestones (events the executors record for the data-parallel caller's collectives); 4: arvae_philox_* and in-kernel eps (arvae_image_vae_t.rng_*), arvae_tick_free_run_supported, caller workspace for arvae_link_down/up (arvae_link_ws_floats); 3: arvae_gru_seq_*, embed_bwd workspace; 2: arvae_image_vae_backward reg_fused == 2 (unit regulariser gradient in dz_extra) */
 
 #define ARVAE_OK 0
 #define ARVAE_E_INVALID (-1)  /* bad argument (null pointer, size out of range, unsupported shape) */
@@ -463,6 +463,81 @@ int arvae_image_vae_backward(const arvae_image_vae_t *model, int32_t batch, cons
                              const float *capacity, const float *mu, const float *sigma, const float *z,
                              const float *logits, const float *g_loss, const float *dz_extra,
                              int32_t reg_fused, float reg_scale, float *ws, arvae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Whole-model step for MeasureVAE: ONE call enqueues every kernel of the forward pass (+ loss terms) or of the backward pass
+ * (about 45 / 45 launches at the reference configuration), so the host does no per-layer work.  Replaces, as a unit,
+ *   MeasureVAETrainer.loss_and_acc_for_batch (measurevae/measure_vae_trainer.py:85-140)
+ *     = MeasureVAE.forward (measurevae/measure_vae.py:97-131: Encoder.forward, encoder.py:108-124; HierarchicalDecoder.forward,
+ *       decoder.py:408-525) + mean_crossentropy_loss + compute_kld_loss + compute_attribute_labels + the compute_reg_loss loop
+ *       + mean_accuracy,
+ *   and loss.backward() (utils/trainer.py:140) for that graph.
+ * The model is the reference configuration's shape: a 2-layer bidirectional GRU encoder, two 2-layer heads, a 2-layer beat GRU and
+ * a 2-layer tick GRU with teacher-forced or argmax-fed inputs.  Parameters are float offsets into ONE parameter arena, gradients
+ * ACCUMULATE at the same offsets of a gradient arena (the trainer's flat Adam arenas).  Three pairs of tensors must lie back to
+ * back in the arenas, because one product applies both (ar-vae_amd/measure_vae.py MeasureVAE.arena_parameters):
+ *   per encoder layer  weight_ih_l{k} | weight_ih_l{k}_reverse   and   bias_ih_l{k} | bias_ih_l{k}_reverse,
+ *   linear_mean.0 | linear_log_std.0 (weights, biases),  beat_emb_to_tick_rnn_hidden.0 | beat_emb_to_tick_rnn_input.0.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t vocab, emb;                       /* note vocabulary, note_embedding_dim                                         */
+    int32_t enc_hidden, dec_hidden, zdim;     /* hidden sizes must be built as sequence kernels (arvae_gru_seq_supported)     */
+    int32_t steps, beats, ticks_per_beat;     /* 24 = 4 * 6 in the reference; steps == beats * ticks_per_beat                 */
+    /* float offsets into the parameter / gradient arenas */
+    int64_t enc_table;                        /* encoder.note_embedding_layer.weight [vocab][emb]                             */
+    int64_t enc_w_ih[2], enc_b_ih[2];         /* per layer: the forward direction's; the reverse direction's follows directly  */
+    int64_t enc_w_hh[2][2], enc_b_hh[2][2];   /* [layer][direction]                                                           */
+    int64_t head_w0, head_b0;                 /* linear_mean.0 followed directly by linear_log_std.0                          */
+    int64_t mean_w2, mean_b2, lstd_w2, lstd_b2;
+    int64_t dec_table, x0, b0;                /* decoder.note_embedding_layer.weight, x_0 [emb], b_0 [1]                       */
+    int64_t z2beat_w, z2beat_b;               /* z_to_beat_rnn_input.0                                                        */
+    int64_t beat_w_ih[2], beat_b_ih[2], beat_w_hh[2], beat_b_hh[2];
+    int64_t tick_init_w, tick_init_b;         /* beat_emb_to_tick_rnn_hidden.0 followed directly by beat_emb_to_tick_rnn_input.0 */
+    int64_t tick_w_ih[2], tick_b_ih[2], tick_w_hh[2], tick_b_hh[2];
+    int64_t out_w, out_b;                     /* tick_emb_to_note_emb.0                                                       */
+    float enc_dropout, dec_dropout;           /* p of nn.GRU(dropout = p); applied when the call is given keep-masks          */
+    int32_t n_reg;                            /* regularised dims (0: no attribute regularisation)                            */
+    int32_t reg_dims[16];                     /* z[:, d] pairs with attribute column d (d < 4)                                */
+    float beta, gamma, delta;
+    /* rng_draw != 0: the forward pass DRAWS the encoder keep-mask, eps and the decoder keep-masks itself (arvae_philox_* streams
+     * rng_offset[0..2] of rng_seed / rng_step / rng_dev_step) and WRITES them to the caller's buffers, which the backward pass then
+     * reads; 0: they are inputs (parity runs with explicit noise and masks). */
+    int32_t rng_draw;
+    uint32_t rng_offset[3], rng_step;
+    uint64_t rng_seed;
+    const uint32_t *rng_dev_step;
+} arvae_measure_vae_t;
+
+/* the per-vocabulary tables of arvae_measure_attributes */
+typedef struct {
+    const int32_t *midi_lut;
+    const uint8_t *is_note, *is_density_note;
+    const float *rhythm_weights;
+    float rhythm_norm;
+} arvae_measure_tables_t;
+
+int64_t arvae_measure_vae_ws_floats(const arvae_measure_vae_t *model, int32_t batch);
+
+/* Forward + loss terms.  score [batch][steps] int64; eps [batch][zdim]; enc_mask [steps][batch][2*enc_hidden] and dec_mask
+ * [beats + steps][batch][dec_hidden] uint8 keep-masks of the GRUs' inter-layer dropout (beat RNN's first), both NULL = evaluation
+ * mode (no dropout); eps / masks are WRITTEN when model->rng_draw.  teacher_forced: the tick RNN is fed the score's notes
+ * (decoder.py:427-428,510-512), else its own argmax (one free-running launch, not differentiated: decoder.py:506-516).
+ * capacity: 1-element device tensor or NULL (c = 0).  tables: needed when model->n_reg > 0.
+ * Outputs: scalars[ARVAE_VAE_NSCALARS] (loss = cross entropy + beta |KL - c| + sum_d gamma reg_d; ARVAE_VAE_ACC = top-1 accuracy),
+ * mu / sigma / z [batch][zdim], tokens [batch][steps] = the notes fed back (the score when teacher_forced).
+ * Everything the backward pass needs stays in ws (arvae_measure_vae_ws_floats floats, 16-byte aligned). */
+int arvae_measure_vae_forward(const arvae_measure_vae_t *model, int32_t batch, const float *params, const int64_t *score,
+                              float *eps, uint8_t *enc_mask, uint8_t *dec_mask, int32_t teacher_forced, const float *capacity,
+                              const arvae_measure_tables_t *tables, float *ws, float *scalars, float *mu, float *sigma, float *z,
+                              int64_t *tokens, arvae_stream_t stream);
+
+/* Backward of scalars[ARVAE_VAE_LOSS] times g_loss[0] (device scalar): parameter gradients ACCUMULATE into grads at the model's
+ * offsets.  Must follow arvae_measure_vae_forward on the same ws, with the same score / eps / masks / capacity and that call's
+ * mu / sigma / z / tokens / scalars outputs. */
+int arvae_measure_vae_backward(const arvae_measure_vae_t *model, int32_t batch, const float *params, float *grads,
+                               const int64_t *score, const float *eps, const uint8_t *enc_mask, const uint8_t *dec_mask,
+                               const float *capacity, const float *mu, const float *sigma, const float *z, const int64_t *tokens,
+                               const float *scalars, const float *g_loss, float *ws, arvae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Random draws of the path: eps of z_dist.rsample() (imagevae/mnist_vae.py:79, measurevae/measure_vae.py:116) and the

@@ -46,7 +46,9 @@ def test_ctypes_structs_match_the_header(tmp_path):
                'arvae_tick_weights_t': (_lib.TickWeights, 'w_hh0', 'b_out'),
                'arvae_dense_wgrad_job_t': (_lib.DenseWgradJob, 'g', 'n_out'),
                'arvae_image_vae_t': (_lib.ImageVaeDesc, 'n_enc', 'milestones'),
-               'arvae_milestones_t': (_lib.Milestones, 'z_ready', 'linear_grads')}
+               'arvae_milestones_t': (_lib.Milestones, 'z_ready', 'linear_grads'),
+               'arvae_measure_vae_t': (_lib.MeasureVaeDesc, 'vocab', 'rng_dev_step'),
+               'arvae_measure_tables_t': (_lib.MeasureTables, 'midi_lut', 'rhythm_norm')}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{ROOT}/include/arvae_hip.h"', 'int main(void) {']
     for name, (_, first, last) in structs.items():
         lines.append(f'printf("{name} %zu %zu %zu\\n", sizeof({name}), offsetof({name}, {first}), offsetof({name}, {last}));')

@@ -1,0 +1,188 @@
+"""The whole-model MeasureVAE executor (arvae_measure_vae_forward / _backward, csrc/plan_measure.hip) against the per-layer
+autograd path that issues the same launches one by one (ar-vae_amd/measure_vae.py): loss terms, notes fed back and every
+parameter gradient, teacher-forced and free-running, with and without dropout, explicit and library-drawn noise.
+The per-layer path itself is held against the oracle and the reference's goldens in tests/test_hip_parity.py -- and so is the
+executor, which those tests reach through MeasureVAETrainer.loss_and_acc_for_batch.  Needs a real MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from arvae_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail('gpu-marked test needs a GPU (the HIP path has no CPU fallback)')
+    return torch.device('cuda:0')
+
+
+class _FolkDataset:
+    class_name = '4by4_FolkNBarDataset_1_'
+    n_bars = 1
+
+    def __init__(self):
+        self.index2note_dicts, self.note2index_dicts = syn.measure_vocabulary()
+
+    def __repr__(self):
+        return self.class_name
+
+
+def _trainer(hid, zdim, dropout, reg=True, seed=11):
+    from arvae_amd.measure_vae import MeasureVAE
+    from arvae_amd.measure_vae_trainer import MeasureVAETrainer
+    torch.manual_seed(seed)
+    ds = _FolkDataset()
+    model = MeasureVAE(ds, 10, 2, 2, hid, dropout, zdim, 2, hid, dropout, False, 'folk')
+    with torch.no_grad():                                     # spread the logits so that the argmax varies
+        model.decoder.tick_emb_to_note_emb[0].weight.mul_(3.0)
+        model.decoder.tick_emb_to_note_emb[0].bias.add_(0.4)
+    kw = dict(reg_type=('all',), reg_dim=(0, 1, 2, 3)) if reg else {}
+    trainer = MeasureVAETrainer(ds, model, lr=1e-4, beta=0.001, gamma=1.0, capacity=0.0, rand=0, delta=10.0, **kw)
+    trainer.cuda()
+    return trainer, model
+
+
+def _masks(b, hid, seed):
+    gen = torch.Generator().manual_seed(seed)
+    return [(torch.rand(24, b, 2 * hid, generator=gen) >= 0.5).to(torch.uint8),
+            (torch.rand(4, b, hid, generator=gen) >= 0.5).to(torch.uint8),
+            (torch.rand(24, b, hid, generator=gen) >= 0.5).to(torch.uint8)]
+
+
+def _one_step(trainer, model, score, fused, teacher, eps=None, masks=None, train=True):
+    trainer.use_fused_step = fused
+    model.train(train)
+    model.decoder.teacher_forcing_prob = 2.0 if teacher else -1.0
+    if eps is not None:
+        model.push_noise(eps)
+    if masks is not None and train:
+        model.encoder.push_dropout_mask(masks[0].to(score.device))
+        model.decoder.push_dropout_masks(masks[1].to(score.device), masks[2].to(score.device))
+    trainer.zero_grad()
+    assert (trainer.fused_executor(score) is not None) == fused
+    if train:
+        loss, acc = trainer.loss_and_acc_for_batch((score, score), 0, 0, True)
+        trainer.backward(loss)
+    else:
+        with torch.no_grad():
+            loss, acc = trainer.loss_and_acc_for_batch((score, score), 0, 0, False)
+    torch.cuda.synchronize()
+    terms = {k: (None if v is None else float(v)) for k, v in trainer.last_terms.items()}
+    grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()} if train else {}
+    return float(loss.detach()), float(acc), terms, grads
+
+
+def _same(a, b, what, rel=2e-5):
+    la, aa, ta, ga = a
+    lb, ab, tb, gb = b
+    assert abs(la - lb) <= 1e-5 * abs(lb) + 1e-7, (what, la, lb)
+    assert abs(aa - ab) <= 1e-6, (what, aa, ab)
+    for k in tb:
+        if tb[k] is None:
+            assert ta[k] is None
+        else:
+            assert abs(ta[k] - tb[k]) <= 1e-5 * abs(tb[k]) + 1e-8, (what, k, ta[k], tb[k])
+    assert ga.keys() == gb.keys()
+    for k, want in gb.items():
+        got = ga[k]
+        assert torch.isfinite(got).all(), (what, k)
+        err, ref = float((got - want).norm()), float(want.norm())
+        assert err <= rel * ref + 1e-9, (what, k, err, ref)
+
+
+@pytest.mark.parametrize('b,hid,zdim,dropout', [(256, 128, 32, 0.5), (21, 128, 32, 0.5), (5, 64, 16, 0.0), (37, 64, 32, 0.5),
+                                                (96, 128, 32, 0.0)])
+@pytest.mark.parametrize('teacher', [True, False], ids=['teacher_forced', 'free_running'])
+def test_executor_step_matches_the_per_layer_path(dev, b, hid, zdim, dropout, teacher):
+    """same explicit noise and keep-masks: the two paths' loss terms, accuracy and all gradients agree (the launches are the
+    same; only a few summation orders differ: the constant beat input's gradients, the cross entropy's row order)"""
+    trainer, model = _trainer(hid, zdim, dropout)
+    score = torch.from_numpy(syn.measure_batch(b, seed=18 + b)).to(dev)
+    eps = torch.from_numpy(syn.normal_noise((b, zdim), seed=19))
+    masks = _masks(b, hid, 3) if dropout > 0 else None
+    ref = _one_step(trainer, model, score, False, teacher, eps, masks)
+    got = _one_step(trainer, model, score, True, teacher, eps, masks)
+    _same(got, ref, (b, hid, teacher))
+    assert ref[2]['reg'] is not None and ref[2]['reg'] > 0
+
+
+def test_executor_without_regulariser_and_in_eval_mode(dev):
+    trainer, model = _trainer(128, 32, 0.5, reg=False)
+    b = 64
+    score = torch.from_numpy(syn.measure_batch(b, seed=5)).to(dev)
+    eps = torch.from_numpy(syn.normal_noise((b, 32), seed=6))
+    masks = _masks(b, 128, 7)
+    _same(_one_step(trainer, model, score, True, True, eps, masks), _one_step(trainer, model, score, False, True, eps, masks), 'no reg')
+    # evaluation: no dropout, free-running (measure_vae_trainer.py:367-397 calls the model with train=False)
+    _same(_one_step(trainer, model, score, True, False, eps, None, train=False),
+          _one_step(trainer, model, score, False, False, eps, None, train=False), 'eval')
+
+
+def test_executor_draws_the_per_layer_paths_noise(dev):
+    """no explicit noise: the executor draws the encoder keep-mask, eps and the decoder keep-masks from the same Philox streams,
+    in the same order, as the per-layer path's ops.keep_mask / ops.normal_noise launches -- the steps agree draw for draw"""
+    from arvae_amd import ops
+    b = 48
+    score = torch.from_numpy(syn.measure_batch(b, seed=9)).to(dev)
+    res = {}
+    for fused in (False, True):
+        trainer, model = _trainer(128, 32, 0.5)
+        ops.rng_reseed(123)
+        steps = []
+        for teacher in (True, False, True):
+            steps.append(_one_step(trainer, model, score, fused, teacher))
+        res[fused] = steps
+    for i, (got, ref) in enumerate(zip(res[True], res[False])):
+        _same(got, ref, ('rng', i))
+    assert res[True][0][0] != res[True][2][0]                 # (a fresh draw per step)
+
+
+def test_executor_pass_in_flight_keeps_its_workspace(dev):
+    """two forwards before the first backward (two losses summed): each pass reads the activations its own forward wrote"""
+    trainer, model = _trainer(128, 32, 0.0)
+    b = 32
+    s1 = torch.from_numpy(syn.measure_batch(b, seed=1)).to(dev)
+    s2 = torch.from_numpy(syn.measure_batch(b, seed=2)).to(dev)
+    e1 = torch.from_numpy(syn.normal_noise((b, 32), seed=3))
+    e2 = torch.from_numpy(syn.normal_noise((b, 32), seed=4))
+    model.train()
+    model.decoder.teacher_forcing_prob = 2.0
+    out = {}
+    for fused in (False, True):
+        trainer.use_fused_step = fused
+        trainer.zero_grad()
+        model.push_noise(e1)
+        l1, _ = trainer.loss_and_acc_for_batch((s1, s1), 0, 0, True)
+        model.push_noise(e2)
+        l2, _ = trainer.loss_and_acc_for_batch((s2, s2), 0, 1, True)
+        trainer.backward(l1 + l2)
+        torch.cuda.synchronize()
+        out[fused] = (float(l1.detach()), float(l2.detach()), {k: p.grad.detach().clone() for k, p in model.named_parameters()})
+    assert abs(out[True][0] - out[False][0]) <= 1e-5 * abs(out[False][0]) and abs(out[True][1] - out[False][1]) <= 1e-5 * abs(out[False][1])
+    for k, want in out[False][2].items():
+        assert float((out[True][2][k] - want).norm()) <= 2e-5 * float(want.norm()) + 1e-9, k
+
+
+def test_executor_rejects_bad_arguments(dev):
+    import ctypes
+    from arvae_amd import _lib
+    from arvae_amd.fused_measure import FusedMeasureVAE
+    trainer, model = _trainer(128, 32, 0.5)
+    lib = _lib.load()
+    assert FusedMeasureVAE.supports(model, trainer.optimizer, (0, 1, 2, 3)) is None
+    assert FusedMeasureVAE.supports(model, trainer.optimizer, (0, 7)) is not None
+    fused = FusedMeasureVAE(model, trainer.optimizer, (0, 1, 2, 3), 0.001, 1.0, 10.0)
+    d = fused.descriptor()
+    assert lib.arvae_measure_vae_ws_floats(ctypes.byref(d), 256) > 0
+    assert lib.arvae_measure_vae_ws_floats(ctypes.byref(d), 0) == -1
+    assert lib.arvae_measure_vae_forward(ctypes.byref(d), 8, None, None, None, None, None, 1, None, None, None, None, None, None, None,
+                                         None, None) == -1
+    assert b'null pointer' in lib.arvae_last_error_string()
+    assert not fused.fits(4096) and fused.fits(1024)
+    # a model whose paired layers are NOT back to back in the arena (torch's parameters() order): per-layer path
+    from arvae_amd.optim import FlatAdam
+    other = FlatAdam(model.parameters(), lr=1e-4)
+    assert 'adjacent' in FusedMeasureVAE.supports(model, other, ())
