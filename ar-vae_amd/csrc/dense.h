@@ -38,6 +38,14 @@ int dense_fwd(const arvae_link_t *l, const float *x, const float *w, const float
 int dense_dgrad(const arvae_link_t *l, const Operand &g, const float *w, const float *gate, float *dx, hipStream_t s);
 int64_t dense_wgrad_ws_floats(const arvae_link_t *l);
 int dense_wgrad(const arvae_link_t *l, const Operand &g, const float *x, float *dw, float *dbias, float *ws, hipStream_t s);
+// long-batch weight gradients of one pass as one launch + one reduction (dense.hip); the queue is opaque to callers
+struct LongWgradQueue;
+LongWgradQueue *dense_wgrad_long_new();
+void dense_wgrad_long_delete(LongWgradQueue *q);
+void dense_wgrad_long_begin(LongWgradQueue *q, float *ws, int64_t ws_cap);
+int64_t dense_wgrad_long_ws_floats(const arvae_link_t *l);
+bool dense_wgrad_long_defer(LongWgradQueue *q, const arvae_link_t *l, const Operand &g, const float *x, float *dw, float *dbias);
+int dense_wgrad_long_flush(LongWgradQueue *q, hipStream_t s);
 bool dense_wgrad_defer(DenseWgradBatch *b, const arvae_link_t *l, const Operand &g, const float *x, float *dw, float *dbias);
 int dense_wgrad_flush(DenseWgradBatch *b, hipStream_t s);
 

@@ -410,7 +410,7 @@ __device__ unsigned long long g_rg_stamps[512 * 32];
 #define RGWAIT()
 #endif
 template <int LA, int LB, int EP, bool VA, bool VB>
-__global__ __launch_bounds__(256) void rows_gemm_x3_kernel(RowsGemm g) {
+__device__ __forceinline__ void rows_gemm_x3_body(const RowsGemm &g, const int bx, const int by, const int bz) {
     RGSTAMP(0);
     typedef TileLoader<LA, RG_TP, VA> LoadA;
     typedef TileLoader<LB, RG_TQ, VB> LoadB;
@@ -418,8 +418,8 @@ __global__ __launch_bounds__(256) void rows_gemm_x3_kernel(RowsGemm g) {
     __shared__ __attribute__((aligned(16))) unsigned short Bs[3 * LoadB::PLANE];
     const int lane = threadIdx.x & 63, half = lane >> 5, rc = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int p0 = blockIdx.x * RG_TP, q0 = blockIdx.y * RG_TQ;
-    const int rbeg = blockIdx.z * g.rslice, rend = min(g.Rn, rbeg + g.rslice);
+    const int p0 = bx * RG_TP, q0 = by * RG_TQ;
+    const int rbeg = bz * g.rslice, rend = min(g.Rn, rbeg + g.rslice);
     LoadA la;
     LoadB lb;
     const int wp = wave & 1, wq = wave >> 1;
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256) void rows_gemm_x3_kernel(RowsGemm g) {
         }
         RGSTAMP(6 + 5 * rgc);
         ++rgc;
-        if (EP == RG_EP_SLICE && g.want_bias && blockIdx.y == 0 && threadIdx.x < RG_TP) {
+        if (EP == RG_EP_SLICE && g.want_bias && by == 0 && threadIdx.x < RG_TP) {
             // sum over the chunk's reduction indices of A(p = threadIdx.x, r), terms re-added exactly
 #pragma unroll 8
             for (int r = 0; r < RG_R; ++r) {
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(256) void rows_gemm_x3_kernel(RowsGemm g) {
         }
     }
     RGSTAMP(30);
-    float *out = g.out + (EP == RG_EP_SLICE ? blockIdx.z * g.slice_floats : 0);
+    float *out = g.out + (EP == RG_EP_SLICE ? bz * g.slice_floats : 0);
     const int q = q0 + 32 * wq + rc;
     const float bias = (EP == RG_EP_FWD && g.bias != nullptr && q < g.Q) ? g.bias[q] : 0.f;
 #pragma unroll
@@ -481,10 +481,39 @@ __global__ __launch_bounds__(256) void rows_gemm_x3_kernel(RowsGemm g) {
         if (EP == RG_EP_FWD) v = act_fwd(v + bias, g.act);
         if (p < g.P && q < g.Q) out[(int64_t)p * g.ldo + q] = v;
     }
-    if (EP == RG_EP_SLICE && g.want_bias && blockIdx.y == 0 && threadIdx.x < RG_TP && p0 + (int)threadIdx.x < g.P)
+    if (EP == RG_EP_SLICE && g.want_bias && by == 0 && threadIdx.x < RG_TP && p0 + (int)threadIdx.x < g.P)
         out[(int64_t)g.P * g.ldo + p0 + threadIdx.x] = bsum;
     RGWAIT();
     RGSTAMP(31);
+}
+
+template <int LA, int LB, int EP, bool VA, bool VB>
+__global__ __launch_bounds__(256) void rows_gemm_x3_kernel(RowsGemm g) {
+    rows_gemm_x3_body<LA, LB, EP, VA, VB>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Several long-batch weight gradients (RG_KROWS x RG_KROWS operands, slice epilogue) in ONE launch: the whole-sequence layers
+// of a backward pass each leave a 0.6-2.4 GFLOP product that nothing on the pass's critical path waits for, and alone each
+// is a 15-35 us launch that fills a fraction of the chip; together (workgroup -> (job, tile, slice) through the running
+// workgroup count) they are one full-chip launch and one reduction.
+constexpr int RG_BATCH_MAX = 12;
+struct RowsGemmBatch {
+    int count;
+    int wg_end[RG_BATCH_MAX];
+    RowsGemm job[RG_BATCH_MAX];
+};
+__global__ __launch_bounds__(256) void rows_wgrad_batch_kernel(RowsGemmBatch b) {
+    // consecutive workgroup ids go round the 8 XCDs; the tiles of one row slice read the same operand rows, so logical
+    // workgroup w runs as physical id (w % per_xcd) * 8 + w / per_xcd: a slice's tiles share an XCD's L2 (grid: a multiple of 8)
+    const int per_xcd = gridDim.x >> 3;
+    const int wg = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (wg >= b.wg_end[b.count - 1]) return;
+    int j = 0;
+    while (j + 1 < b.count && wg >= b.wg_end[j]) ++j;
+    const int local = wg - (j > 0 ? b.wg_end[j - 1] : 0);
+    const RowsGemm &g = b.job[j];
+    const int tp = (g.P + RG_TP - 1) / RG_TP, tq = (g.Q + RG_TQ - 1) / RG_TQ;
+    rows_gemm_x3_body<RG_KROWS, RG_KROWS, RG_EP_SLICE, true, true>(g, local % tp, (local / tp) % tq, local / (tp * tq));
 }
 
 // ---- wgrad: dW[n][feat_in(km)] += sum_m G[m][mem_out(n)] * X[m][km] ;  db[n] += sum_m G[m][mem_out(n)] ------
@@ -637,6 +666,46 @@ __global__ __launch_bounds__(256) void dense_split_reduce_kernel(const float *__
     else dbias[i - w_floats] += s;
 }
 
+// the same for every job of a rows_wgrad_batch_kernel launch
+struct SplitReduceJob {
+    const float *ws;
+    int64_t slice_floats, w_floats;
+    int slices, n_out;
+    float *dw, *dbias;
+};
+struct SplitReduceBatch {
+    int count;
+    int wg_end[RG_BATCH_MAX];
+    SplitReduceJob job[RG_BATCH_MAX];
+};
+__global__ __launch_bounds__(256) void dense_split_reduce_batch_kernel(SplitReduceBatch b) {
+    int j = 0;
+    while (j + 1 < b.count && (int)blockIdx.x >= b.wg_end[j]) ++j;
+    const int local = blockIdx.x - (j > 0 ? b.wg_end[j - 1] : 0);
+    const SplitReduceJob &r = b.job[j];
+    const int64_t i = ((int64_t)local * 256 + threadIdx.x) >> 2;
+    const int q = threadIdx.x & 3;
+    const int64_t total = r.w_floats + (r.dbias != nullptr ? r.n_out : 0);
+    const int64_t ic = i < total ? i : 0;
+    float s = 0.f;
+    for (int z0 = q; z0 < r.slices; z0 += 32) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int z = z0 + 4 * u;
+            const float v = r.ws[(int64_t)(z < r.slices ? z : 0) * r.slice_floats + ic];
+            t[u] = z < r.slices ? v : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += t[u];
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (q != 0 || i >= total) return;
+    if (i < r.w_floats) r.dw[i] += s;
+    else r.dbias[i - r.w_floats] += s;
+}
+
 // Weight gradients of several Linear layers in ONE launch: they are independent once every layer's output gradient
 // exists, and each alone is a launch-latency-bound 8..128-tile problem.  Workgroup -> (job, tile) through the
 // running tile count.  8 waves per tile here (32 KB of LDS): the ~400 tiles of the dSprites stack are then all
@@ -777,6 +846,65 @@ int dense_wgrad(const arvae_link_t *l, const Operand &g, const float *x, float *
     }
     ARVAE_LAUNCH(dense_wgrad_kernel, dim3((p.n_out + 31) / 32, (p.n_in + 31) / 32), dim3(DENSE_THREADS), 0, s, p);
     return check_launch("dense_wgrad_kernel");
+}
+
+// long-batch weight gradients queued for one launch (plan_measure.hip).  The queue owns a workspace [ws, ws + ws_cap): every job
+// takes its slices from it; a job that does not qualify (short batch, folded operand, unaligned operands, queue or workspace
+// full) is refused and the caller launches it by itself.
+struct LongWgradQueue {
+    RowsGemmBatch gemm;
+    SplitReduceBatch red;
+    float *ws;
+    int64_t ws_cap, ws_used;
+};
+LongWgradQueue *dense_wgrad_long_new() { return new LongWgradQueue(); }
+void dense_wgrad_long_delete(LongWgradQueue *q) { delete q; }
+void dense_wgrad_long_begin(LongWgradQueue *q, float *ws, int64_t ws_cap) {
+    q->gemm.count = q->red.count = 0;
+    q->ws = ws;
+    q->ws_cap = ws_cap;
+    q->ws_used = 0;
+}
+static int long_rslice(int rows) { return rows >= 4096 ? 512 : 256; }
+int64_t dense_wgrad_long_ws_floats(const arvae_link_t *l) {
+    if (l->n < DENSE_SPLIT_MIN_ROWS) return 0;
+    const int rs = long_rslice(l->n);
+    return (int64_t)((l->n + rs - 1) / rs) * (((int64_t)l->clo * l->chi + l->clo + 3) / 4 * 4);
+}
+bool dense_wgrad_long_defer(LongWgradQueue *q, const arvae_link_t *l, const Operand &g, const float *x, float *dw, float *dbias) {
+    static const bool off = diag_env("ARVAE_NO_LONG_BATCH") != nullptr;       // A/B switch
+    DenseArgs p = dense_args(l);
+    p.a = g;
+    if (off || q == nullptr || q->ws == nullptr || q->gemm.count >= RG_BATCH_MAX || !dense_long_batch(p) || !plain_operand(g)) return false;
+    auto aligned = [](const float *ptr, int ld, int extent) { return (ld & 3) == 0 && (extent & 3) == 0 && (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; };
+    if (!aligned(g.v, p.n_out, p.n_out) || !aligned(x, p.n_in, p.n_in)) return false;
+    const int rs = long_rslice(p.batch), slices = (p.batch + rs - 1) / rs;
+    const int64_t w_floats = (int64_t)p.n_out * p.n_in, slice_floats = (w_floats + p.n_out + 3) / 4 * 4;
+    if (q->ws_used + slices * slice_floats > q->ws_cap) return false;
+    float *ws = q->ws + q->ws_used;
+    q->ws_used += slices * slice_floats;
+    const int k = q->gemm.count;
+    RowsGemm &r = q->gemm.job[k];
+    r = RowsGemm{};
+    r.a = g.v; r.lda = p.n_out; r.b = x; r.ldb = p.n_in; r.P = p.n_out; r.Q = p.n_in; r.Rn = p.batch; r.rslice = rs;
+    r.out = ws; r.ldo = p.n_in; r.slice_floats = slice_floats; r.want_bias = dbias != nullptr;
+    const int wgs = ((p.n_out + RG_TP - 1) / RG_TP) * ((p.n_in + RG_TQ - 1) / RG_TQ) * slices;
+    q->gemm.wg_end[k] = (k > 0 ? q->gemm.wg_end[k - 1] : 0) + wgs;
+    q->gemm.count = k + 1;
+    const int64_t total = w_floats + (dbias != nullptr ? p.n_out : 0);
+    q->red.job[k] = SplitReduceJob{ws, slice_floats, w_floats, slices, p.n_out, dw, dbias};
+    q->red.wg_end[k] = (k > 0 ? q->red.wg_end[k - 1] : 0) + (int)((total * 4 + 255) / 256);
+    q->red.count = k + 1;
+    return true;
+}
+int dense_wgrad_long_flush(LongWgradQueue *q, hipStream_t s) {
+    if (q == nullptr || q->gemm.count == 0) return ARVAE_OK;
+    ARVAE_LAUNCH(rows_wgrad_batch_kernel, dim3((q->gemm.wg_end[q->gemm.count - 1] + 7) / 8 * 8), dim3(256), 0, s, q->gemm);
+    if (int rc = check_launch("rows_wgrad_batch_kernel")) return rc;
+    ARVAE_LAUNCH(dense_split_reduce_batch_kernel, dim3(q->red.wg_end[q->red.count - 1]), dim3(256), 0, s, q->red);
+    q->gemm.count = q->red.count = 0;
+    q->ws_used = 0;
+    return check_launch("dense_split_reduce_batch_kernel");
 }
 
 // deferred weight gradients (plan.hip): add a job / launch all of them

@@ -148,7 +148,8 @@ struct MvWs {
     // backward
     float *gpre, *d_seq_h, *dgi_t1, *dgh_t1, *hprev_t1, *dgi_t0, *dgh_t0, *hprev_t0, *d_mid_t, *dh0a, *dh0b, *dg_small, *tick_ws, *dx_small, *d_beat_emb, *d_both;
     float *d_rows_h, *d_mid_b, *dgi_b1, *dgh_b1, *hprev_b1, *dgi_b0, *dgh_b0, *hprev_b0, *d_x0, *d_flatb, *d_z, *d_mu, *d_ls, *d_hmu, *d_hls, *d_h12, *d_hidden;
-    float *dgi_e1, *dgh_e1, *hprev_e1, *dgi_e0, *dgh_e0, *hprev_e0, *d_mid_e, *d_out0_e, *dptab, *embed_ws, *d_table, *wg_ws, *cs_ws;
+    float *dgi_e1, *dgh_e1, *hprev_e1, *dgi_e0, *dgh_e0, *hprev_e0, *d_mid_e, *d_out0_e, *dptab, *embed_ws, *d_table, *wg_ws, *wg_long, *cs_ws;
+    int64_t wg_long_floats;
 };
 
 struct MvDims {
@@ -282,6 +283,20 @@ static int64_t carve(const arvae_measure_vae_t *m, int batch, float *base, MvWs 
     wmax(long_wgrad_ws(d.rb, d.hd, 3 * d.hd));
     wmax(long_wgrad_ws(d.ns, d.e + d.hd, 3 * d.hd));
     w->wg_ws = take(wg);
+    // every whole-sequence weight gradient of the pass keeps its row slices until the one reduction at the end
+    int64_t lw = 0;
+    auto ladd = [&](int rows, int n_in, int n_out, int times) {
+        const arvae_link_t l = dense_link(rows, n_in, n_out);
+        lw += times * dense_wgrad_long_ws_floats(&l);
+    };
+    ladd(d.tb, d.he, 3 * d.he, 4);
+    ladd(d.tb, 2 * d.he, 6 * d.he, 1);
+    ladd(d.rt, d.hd, 3 * d.hd, 3);
+    ladd(d.rt, d.hd, d.v, 1);
+    ladd(d.rb, d.hd, 3 * d.hd, 5);
+    ladd(d.ns, d.e + d.hd, 3 * d.hd, 1);
+    w->wg_long_floats = lw;
+    w->wg_long = take(lw);
     int64_t cs = arvae_channel_sum_ws_floats(d.v + 1, 3 * d.hd);
     if (arvae_channel_sum_ws_floats(d.rb, 1) > cs) cs = arvae_channel_sum_ws_floats(d.rb, 1);
     w->cs_ws = take(cs);
@@ -319,10 +334,21 @@ static int lin_dgrad(int rows, int n_in, int n_out, const arvae_operand_t &g, co
     return dense_dgrad(&l, make_operand(&g), w, nullptr, dx, s);
 }
 // dw += g^T x, db += column sums of g: queued for the pass's one batched launch when the batch is short, else launched now
-static int lin_wgrad(DenseWgradBatch *q, int rows, int n_in, int n_out, const arvae_operand_t &g, const float *x, float *dw, float *db,
-                     float *ws, hipStream_t s) {
+struct WgradQueues {
+    DenseWgradBatch batch{};             // batch-sized layers: one launch of 32 x 32 tiles (dense_wgrad_batch_kernel)
+    LongWgradQueue *rows = nullptr;      // whole-sequence layers: one row-sliced launch + one reduction
+    float *ws = nullptr;                 // workspace of a long-batch gradient the row queue refuses
+    WgradQueues() : rows(dense_wgrad_long_new()) {}
+    ~WgradQueues() { dense_wgrad_long_delete(rows); }
+};
+static int lin_wgrad(WgradQueues *wq, int rows, int n_in, int n_out, const arvae_operand_t &g, const float *x, float *dw, float *db,
+                     hipStream_t s) {
     const arvae_link_t l = dense_link(rows, n_in, n_out);
-    if (rows >= DENSE_SPLIT_MIN_ROWS) return dense_wgrad(&l, make_operand(&g), x, dw, db, ws, s);
+    DenseWgradBatch *q = &wq->batch;
+    if (rows >= DENSE_SPLIT_MIN_ROWS) {
+        if (dense_wgrad_long_defer(wq->rows, &l, make_operand(&g), x, dw, db)) return ARVAE_OK;
+        return dense_wgrad(&l, make_operand(&g), x, dw, db, wq->ws, s);
+    }
     if (dense_wgrad_defer(q, &l, make_operand(&g), x, dw, db)) return ARVAE_OK;
     if (int rc = dense_wgrad_flush(q, s)) return rc;            // the queue is full: launch what it holds, start the next one
     q->count = 0;
@@ -508,7 +534,9 @@ extern "C" int arvae_measure_vae_backward(const arvae_measure_vae_t *m, int32_t 
     const bool dropping = enc_mask != nullptr;
     const float enc_keep = dropping ? 1.f / (1.f - m->enc_dropout) : 1.f, dec_keep = dropping ? 1.f / (1.f - m->dec_dropout) : 1.f;
     const uint8_t *beat_mask = dec_mask, *tick_mask = dropping ? dec_mask + (int64_t)d.nb * d.b * Hd : nullptr;
-    DenseWgradBatch queue{};
+    WgradQueues queue;
+    dense_wgrad_long_begin(queue.rows, w.wg_long, w.wg_long_floats);
+    queue.ws = w.wg_ws;
 
     // ---- note projection: d probs (cross entropy, unit upstream) times the upstream scalar, through the ReLU
     const int64_t np = (int64_t)d.rt * d.v;
@@ -518,7 +546,7 @@ extern "C" int arvae_measure_vae_backward(const arvae_measure_vae_t *m, int32_t 
         ARVAE_LAUNCH(relu_gate_scale1_kernel, dim3(blocks_for(np)), dim3(256), 0, s, w.dprobs, w.probs, g_loss, np, w.gpre);
     MV_TRY(check_launch("relu_gate_scale_kernel"));
     MV_TRY(lin_dgrad(d.rt, Hd, d.v, plain(w.gpre), P + m->out_w, w.d_seq_h, s));
-    MV_TRY(lin_wgrad(&queue, d.rt, Hd, d.v, plain(w.gpre), w.out1t, G + m->out_w, G + m->out_b, w.wg_ws, s));
+    MV_TRY(lin_wgrad(&queue, d.rt, Hd, d.v, plain(w.gpre), w.out1t, G + m->out_w, G + m->out_b, s));
 
     // ---- tick RNN, layer 1 then layer 0
     const float *midt = dropping ? w.midt : w.out0t;
@@ -526,9 +554,9 @@ extern "C" int arvae_measure_vae_backward(const arvae_measure_vae_t *m, int32_t 
     g.w_hh = P + m->tick_w_hh[1]; g.h0 = w.h0t1; g.h_all = w.out1t; g.h_stride = Hd; g.saved = w.svt1;
     g.dh_all = w.d_seq_h; g.dh_stride = Hd; g.dgi = w.dgi_t1; g.dgh = w.dgh_t1; g.dh0 = w.dh0b; g.h_prev_out = w.hprev_t1;
     MV_TRY(arvae_gru_seq_bwd(&g, 1, d.tpb, d.rb, Hd, stream));
-    MV_TRY(lin_wgrad(&queue, d.rt, Hd, 3 * Hd, plain(w.dgh_t1), w.hprev_t1, G + m->tick_w_hh[1], G + m->tick_b_hh[1], w.wg_ws, s));
+    MV_TRY(lin_wgrad(&queue, d.rt, Hd, 3 * Hd, plain(w.dgh_t1), w.hprev_t1, G + m->tick_w_hh[1], G + m->tick_b_hh[1], s));
     MV_TRY(lin_dgrad(d.rt, Hd, 3 * Hd, plain(w.dgi_t1), P + m->tick_w_ih[1], w.d_mid_t, s));
-    MV_TRY(lin_wgrad(&queue, d.rt, Hd, 3 * Hd, plain(w.dgi_t1), midt, G + m->tick_w_ih[1], G + m->tick_b_ih[1], w.wg_ws, s));
+    MV_TRY(lin_wgrad(&queue, d.rt, Hd, 3 * Hd, plain(w.dgi_t1), midt, G + m->tick_w_ih[1], G + m->tick_b_ih[1], s));
     const float *d_out0t = w.d_mid_t;
     if (dropping) {
         ARVAE_LAUNCH(scale_mask_tick_kernel, dim3(blocks_for((int64_t)d.rt * Hd / 4)), dim3(256), 0, s, w.d_mid_t, tick_mask, dec_keep, d.b,
@@ -540,14 +568,14 @@ extern "C" int arvae_measure_vae_backward(const arvae_measure_vae_t *m, int32_t 
     g.w_hh = P + m->tick_w_hh[0]; g.h0 = w.h0t0; g.h_all = w.out0t; g.h_stride = Hd; g.saved = w.svt0;
     g.dh_all = d_out0t; g.dh_stride = Hd; g.dgi = w.dgi_t0; g.dgh = w.dgh_t0; g.dh0 = w.dh0a; g.h_prev_out = w.hprev_t0;
     MV_TRY(arvae_gru_seq_bwd(&g, 1, d.tpb, d.rb, Hd, stream));
-    MV_TRY(lin_wgrad(&queue, d.rt, Hd, 3 * Hd, plain(w.dgh_t0), w.hprev_t0, G + m->tick_w_hh[0], G + m->tick_b_hh[0], w.wg_ws, s));
+    MV_TRY(lin_wgrad(&queue, d.rt, Hd, 3 * Hd, plain(w.dgh_t0), w.hprev_t0, G + m->tick_w_hh[0], G + m->tick_b_hh[0], s));
     // layer 0's input projection: per-tick gradients summed per previous note and per beat row, then the small product's adjoints
     MV_TRY(arvae_tick_gi_bwd(w.dgi_t0, tokens, d.b, d.nb, d.tpb, d.v, 3 * Hd, w.dg_small, w.tick_ws, stream));
     {
         const arvae_operand_t note_rows = plain(w.dg_small);      // every tick row carries the bias once and exactly one note entry
         MV_TRY(arvae_channel_sum(&note_rows, d.v + 1, 3 * Hd, 0, 0, G + m->tick_b_ih[0], w.cs_ws, stream));
     }
-    MV_TRY(lin_wgrad(&queue, d.ns, d.e + Hd, 3 * Hd, plain(w.dg_small), w.xs, G + m->tick_w_ih[0], nullptr, w.wg_ws, s));
+    MV_TRY(lin_wgrad(&queue, d.ns, d.e + Hd, 3 * Hd, plain(w.dg_small), w.xs, G + m->tick_w_ih[0], nullptr, s));
     MV_TRY(lin_dgrad(d.ns, d.e + Hd, 3 * Hd, plain(w.dg_small), P + m->tick_w_ih[0], w.dx_small, s));
     MV_TRY(arvae_tick_rows_bwd(w.dx_small, d.v, d.e, Hd, d.rb, G + m->dec_table, G + m->x0, w.d_beat_emb, stream));
     // initial states + beat-embedding input: one SELU layer on the beat outputs
@@ -557,7 +585,7 @@ extern "C" int arvae_measure_vae_backward(const arvae_measure_vae_t *m, int32_t 
     MV_TRY(check_launch("concat3_kernel"));
     MV_TRY(lin_dgrad(d.rb, Hd, 3 * Hd, gated(w.d_both, w.both, ARVAE_ACT_SELU), P + m->tick_init_w, w.d_rows_h, s));
     MV_TRY(lin_wgrad(&queue, d.rb, Hd, 3 * Hd, gated(w.d_both, w.both, ARVAE_ACT_SELU), w.beat_out, G + m->tick_init_w, G + m->tick_init_b,
-                     w.wg_ws, s));
+                     s));
 
     // ---- beat RNN, layer 1 then layer 0 (their batch-sized weight gradients wait in the queue: separate buffers per layer)
     const float *midb = dropping ? w.midb : w.out0b;
@@ -565,9 +593,9 @@ extern "C" int arvae_measure_vae_backward(const arvae_measure_vae_t *m, int32_t 
     g.w_hh = P + m->beat_w_hh[1]; g.h0 = w.h0b1; g.h_all = w.beat_out; g.h_stride = Hd; g.saved = w.svb1;
     g.dh_all = w.d_rows_h; g.dh_stride = Hd; g.dgi = w.dgi_b1; g.dgh = w.dgh_b1; g.dh0 = w.dh0b; g.h_prev_out = w.hprev_b1;
     MV_TRY(arvae_gru_seq_bwd(&g, 1, d.nb, d.b, Hd, stream));
-    MV_TRY(lin_wgrad(&queue, d.rb, Hd, 3 * Hd, plain(w.dgh_b1), w.hprev_b1, G + m->beat_w_hh[1], G + m->beat_b_hh[1], w.wg_ws, s));
+    MV_TRY(lin_wgrad(&queue, d.rb, Hd, 3 * Hd, plain(w.dgh_b1), w.hprev_b1, G + m->beat_w_hh[1], G + m->beat_b_hh[1], s));
     MV_TRY(lin_dgrad(d.rb, Hd, 3 * Hd, plain(w.dgi_b1), P + m->beat_w_ih[1], w.d_mid_b, s));
-    MV_TRY(lin_wgrad(&queue, d.rb, Hd, 3 * Hd, plain(w.dgi_b1), midb, G + m->beat_w_ih[1], G + m->beat_b_ih[1], w.wg_ws, s));
+    MV_TRY(lin_wgrad(&queue, d.rb, Hd, 3 * Hd, plain(w.dgi_b1), midb, G + m->beat_w_ih[1], G + m->beat_b_ih[1], s));
     const float *d_out0b = w.d_mid_b;
     if (dropping) {
         MV_TRY(arvae_scale_mask(w.d_mid_b, beat_mask, dec_keep, (int64_t)d.rb * Hd, 0, w.d_rows_h, stream));
@@ -577,9 +605,9 @@ extern "C" int arvae_measure_vae_backward(const arvae_measure_vae_t *m, int32_t 
     g.w_hh = P + m->beat_w_hh[0]; g.h0 = w.h0b0; g.h_all = w.out0b; g.h_stride = Hd; g.saved = w.svb0;
     g.dh_all = d_out0b; g.dh_stride = Hd; g.dgi = w.dgi_b0; g.dgh = w.dgh_b0; g.dh0 = w.dh0a; g.h_prev_out = w.hprev_b0;
     MV_TRY(arvae_gru_seq_bwd(&g, 1, d.nb, d.b, Hd, stream));
-    MV_TRY(lin_wgrad(&queue, d.rb, Hd, 3 * Hd, plain(w.dgh_b0), w.hprev_b0, G + m->beat_w_hh[0], G + m->beat_b_hh[0], w.wg_ws, s));
+    MV_TRY(lin_wgrad(&queue, d.rb, Hd, 3 * Hd, plain(w.dgh_b0), w.hprev_b0, G + m->beat_w_hh[0], G + m->beat_b_hh[0], s));
     // the constant input b_0 (decoder.py:436-440): the projection's gradients over all beats*batch rows (x0b holds b_0 once per row)
-    MV_TRY(lin_wgrad(&queue, d.rb, 1, 3 * Hd, plain(w.dgi_b0), w.x0b, G + m->beat_w_ih[0], G + m->beat_b_ih[0], w.wg_ws, s));
+    MV_TRY(lin_wgrad(&queue, d.rb, 1, 3 * Hd, plain(w.dgi_b0), w.x0b, G + m->beat_w_ih[0], G + m->beat_b_ih[0], s));
     MV_TRY(lin_dgrad(d.rb, 1, 3 * Hd, plain(w.dgi_b0), P + m->beat_w_ih[0], w.d_x0, s));
     {
         const arvae_operand_t dx0 = plain(w.d_x0);
@@ -587,7 +615,7 @@ extern "C" int arvae_measure_vae_backward(const arvae_measure_vae_t *m, int32_t 
     }
     MV_TRY(arvae_concat_cols(w.dh0a, w.dh0b, d.b, Hd, Hd, w.d_flatb, stream));
     MV_TRY(lin_dgrad(d.b, d.z, 2 * Hd, gated(w.d_flatb, w.flatb, ARVAE_ACT_SELU), P + m->z2beat_w, w.d_z, s));
-    MV_TRY(lin_wgrad(&queue, d.b, d.z, 2 * Hd, gated(w.d_flatb, w.flatb, ARVAE_ACT_SELU), z, G + m->z2beat_w, G + m->z2beat_b, w.wg_ws, s));
+    MV_TRY(lin_wgrad(&queue, d.b, d.z, 2 * Hd, gated(w.d_flatb, w.flatb, ARVAE_ACT_SELU), z, G + m->z2beat_w, G + m->z2beat_b, s));
 
     // ---- latent head: decoder path + regulariser + beta-KL -> (d mu, d log_std), then the heads' two layers
     ARVAE_LAUNCH(measure_latent_bwd_kernel, dim3(blocks_for((int64_t)d.b * d.z)), dim3(256), 0, s, w.d_z, m->n_reg > 0 ? w.dz_reg : nullptr, mu,
@@ -595,11 +623,11 @@ extern "C" int arvae_measure_vae_backward(const arvae_measure_vae_t *m, int32_t 
     MV_TRY(check_launch("measure_latent_bwd_kernel"));
     MV_TRY(lin_dgrad(d.b, 2 * He, d.z, plain(w.d_mu), P + m->mean_w2, w.d_hmu, s));
     MV_TRY(lin_dgrad(d.b, 2 * He, d.z, plain(w.d_ls), P + m->lstd_w2, w.d_hls, s));
-    MV_TRY(lin_wgrad(&queue, d.b, 2 * He, d.z, plain(w.d_mu), w.hmu, G + m->mean_w2, G + m->mean_b2, w.wg_ws, s));
-    MV_TRY(lin_wgrad(&queue, d.b, 2 * He, d.z, plain(w.d_ls), w.hls, G + m->lstd_w2, G + m->lstd_b2, w.wg_ws, s));
+    MV_TRY(lin_wgrad(&queue, d.b, 2 * He, d.z, plain(w.d_mu), w.hmu, G + m->mean_w2, G + m->mean_b2, s));
+    MV_TRY(lin_wgrad(&queue, d.b, 2 * He, d.z, plain(w.d_ls), w.hls, G + m->lstd_w2, G + m->lstd_b2, s));
     MV_TRY(arvae_concat_cols(w.d_hmu, w.d_hls, d.b, 2 * He, 2 * He, w.d_h12, stream));
     MV_TRY(lin_dgrad(d.b, 4 * He, 4 * He, gated(w.d_h12, w.h12, ARVAE_ACT_SELU), P + m->head_w0, w.d_hidden, s));
-    MV_TRY(lin_wgrad(&queue, d.b, 4 * He, 4 * He, gated(w.d_h12, w.h12, ARVAE_ACT_SELU), w.hidden, G + m->head_w0, G + m->head_b0, w.wg_ws, s));
+    MV_TRY(lin_wgrad(&queue, d.b, 4 * He, 4 * He, gated(w.d_h12, w.h12, ARVAE_ACT_SELU), w.hidden, G + m->head_w0, G + m->head_b0, s));
 
     // ---- encoder, layer 1 then layer 0: the final states' gradients enter each direction at its last processed step
     arvae_gru_seq_t q[2];
@@ -636,10 +664,10 @@ extern "C" int arvae_measure_vae_backward(const arvae_measure_vae_t *m, int32_t 
         MV_TRY(arvae_gru_seq_bwd(q, 2, d.t, d.b, He, stream));
         for (int dir = 0; dir < 2; ++dir)
             MV_TRY(lin_wgrad(&queue, d.tb, He, 3 * He, plain(dgh + (int64_t)dir * d.tb * 3 * He), hprev + (int64_t)dir * d.tb * He,
-                             G + m->enc_w_hh[layer][dir], G + m->enc_b_hh[layer][dir], w.wg_ws, s));
+                             G + m->enc_w_hh[layer][dir], G + m->enc_b_hh[layer][dir], s));
         if (layer == 1) {
             const float *src = dropping ? w.mid : w.out0;
-            MV_TRY(lin_wgrad(&queue, d.tb, 2 * He, 6 * He, plain(dgi), src, G + m->enc_w_ih[1], G + m->enc_b_ih[1], w.wg_ws, s));
+            MV_TRY(lin_wgrad(&queue, d.tb, 2 * He, 6 * He, plain(dgi), src, G + m->enc_w_ih[1], G + m->enc_b_ih[1], s));
             MV_TRY(lin_dgrad(d.tb, 2 * He, 6 * He, plain(dgi), P + m->enc_w_ih[1], w.d_mid_e, s));
         }
     }
@@ -647,6 +675,7 @@ extern "C" int arvae_measure_vae_backward(const arvae_measure_vae_t *m, int32_t 
     MV_TRY(arvae_embed_bwd(score, w.dgi_e0, d.b, d.t, 6 * He, d.v, 1, w.dptab, 0, w.embed_ws, stream));
     MV_TRY(lin_dgrad(d.v, d.e, 6 * He, plain(w.dptab), P + m->enc_w_ih[0], w.d_table, s));
     MV_TRY(arvae_scale_mask(w.d_table, nullptr, 1.f, (int64_t)d.v * d.e, 1, G + m->enc_table, stream));
-    MV_TRY(lin_wgrad(&queue, d.v, d.e, 6 * He, plain(w.dptab), P + m->enc_table, G + m->enc_w_ih[0], G + m->enc_b_ih[0], w.wg_ws, s));
-    return dense_wgrad_flush(&queue, s);
+    MV_TRY(lin_wgrad(&queue, d.v, d.e, 6 * He, plain(w.dptab), P + m->enc_table, G + m->enc_w_ih[0], G + m->enc_b_ih[0], s));
+    MV_TRY(dense_wgrad_long_flush(queue.rows, s));
+    return dense_wgrad_flush(&queue.batch, s);
 }
