@@ -248,8 +248,17 @@ __global__ __launch_bounds__(256) void prep_all_kernel(PrepArgs p, MidPrepArgs m
 __global__ __launch_bounds__(256) void amax_kernel(const float *__restrict__ x, int64_t count4, unsigned *__restrict__ out) {
     __shared__ float wm[4];
     float m = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count4; i += (int64_t)gridDim.x * 256)
-        m = fmaxf(m, amax4(reinterpret_cast<const float4 *>(x)[i]));
+    // four loads in flight per lane (one at a time, a 25 MB tensor took 21 us: 1.2 TB/s)
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count4; i += 4 * stride) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t j = i + u * stride;
+            v[u] = reinterpret_cast<const float4 *>(x)[j < count4 ? j : i];
+        }
+        m = fmaxf(fmaxf(m, amax4(v[0])), fmaxf(fmaxf(amax4(v[1]), amax4(v[2])), amax4(v[3])));
+    }
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
     __syncthreads();

@@ -460,6 +460,201 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_x3_kernel(GruSeqBatch batch
         }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The forward recurrence on the fp16 MFMA with SCALED TWO-TERM operands (the arithmetic of conv32_common.h): s x = h + l with
+// h = fp16(s x), l = fp16(s x - h), a product = the three partial products l h', h l', h h' on v_mfma_f32_16x16x32_f16, smallest
+// first -- half the MFMAs and two thirds of the LDS operand bytes of the three-term bf16 split at the same accuracy (2^-22 per
+// product; measured against float64: conv32_common.h).  fp16 has 5 exponent bits, so the scales must place the operands: the
+// hidden state is bounded (a convex combination of tanh outputs and h0; the decoder's h0 is a SELU layer's output) and takes the
+// fixed scale 2^4 (|h| < 4094 before fp16 overflows, absolute resolution 2^-29 for small h), W_hh the fixed scale 2^8 (|w| < 255,
+// absolute resolution 2^-33).  The BACKWARD recurrence stays on the three-term bf16 split: its operand is a gradient, whose
+// magnitude is not bounded a priori and moves over time steps, and bf16 carries fp32's exponent range.
+typedef _Float16 f16x8g __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2g __attribute__((ext_vector_type(2)));
+constexpr float GRU_SH = 16.f, GRU_SW = 256.f, GRU_UNSCALE = 1.f / (16.f * 256.f);
+__device__ __forceinline__ void split2_pair(float x0, float x1, float s, unsigned &hi, unsigned &lo) {
+    const float y0 = x0 * s, y1 = x1 * s;
+    const f32x2g y = {y0, y1};
+    const f16x2g h = __builtin_convertvector(y, f16x2g);
+    hi = __builtin_bit_cast(unsigned, h);
+    const f32x2g r = {y0 - (float)h.x, y1 - (float)h.y};
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2g));
+}
+__device__ __forceinline__ void split2_x8(const float (&x)[8], float s, f16x8g &hi, f16x8g &lo) {
+    i32x4g h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned a, b;
+        split2_pair(x[2 * j], x[2 * j + 1], s, a, b);
+        h[j] = (int)a; l[j] = (int)b;
+    }
+    hi = __builtin_bit_cast(f16x8g, h); lo = __builtin_bit_cast(f16x8g, l);
+}
+__device__ __forceinline__ void store_split2(unsigned short *p, int plane, float x) {
+    unsigned a, b;
+    split2_pair(x, 0.f, GRU_SH, a, b);
+    p[0] = (unsigned short)a; p[plane] = (unsigned short)b;
+}
+__device__ __forceinline__ void store_split2_pair(unsigned short *p, int rowpitch, int plane, float x0, float x1) {
+    unsigned a, b;
+    split2_pair(x0, x1, GRU_SH, a, b);
+    p[0] = (unsigned short)a; p[rowpitch] = (unsigned short)(a >> 16);
+    p[plane] = (unsigned short)b; p[plane + rowpitch] = (unsigned short)(b >> 16);
+}
+__device__ __forceinline__ f16x8g lds_h8(const unsigned short *p) {
+    return __builtin_bit_cast(f16x8g, *reinterpret_cast<const i32x4g *>(p));
+}
+// three accumulators (the gates), product-major as GRU_MFMA6X3: l h', h l', h h'
+#define GRU_MFMA3X3(A0, A1, A2, AH, AL, WH0, WL0, WH1, WL1, WH2, WL2)                                                             \
+    A0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(AL, WH0, A0, 0, 0, 0); A1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(AL, WH1, A1, 0, 0, 0); \
+    A2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(AL, WH2, A2, 0, 0, 0);                                                            \
+    A0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(AH, WL0, A0, 0, 0, 0); A1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(AH, WL1, A1, 0, 0, 0); \
+    A2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(AH, WL2, A2, 0, 0, 0);                                                            \
+    A0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(AH, WH0, A0, 0, 0, 0); A1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(AH, WH1, A1, 0, 0, 0); \
+    A2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(AH, WH2, A2, 0, 0, 0)
+
+template <int H>
+__global__ __launch_bounds__(H * 4) void gru_seq_fwd_h2_kernel(GruSeqBatch batch, int T, int R) {
+    constexpr int KS = H / 32;             // MFMA k-steps of 32
+    constexpr int HP = H + 8;              // LDS row pitch in bf16 elements (16 bytes of padding)
+    constexpr int PLANE = 16 * HP;
+    __shared__ __attribute__((aligned(16))) unsigned short hbuf[2][2 * PLANE];
+    const GruSeq &s = batch.seq[blockIdx.y];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = lane & 15, quad = lane >> 4;
+    const int unit = 16 * w + col;
+    const int row0 = blockIdx.x * 16;
+
+    f16x8g wh[3][KS], wl[3][KS];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const float *src = s.w_hh + (int64_t)(g * H + unit) * H + 32 * ks + 8 * quad;
+            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(src), v1 = *reinterpret_cast<const f32x4 *>(src + 4);
+            const float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            split2_x8(x, GRU_SW, wh[g][ks], wl[g][ks]);
+        }
+    const float bh_r = s.b_hh[unit], bh_z = s.b_hh[H + unit], bh_n = s.b_hh[2 * H + unit];
+
+    int rows[4];
+    bool live[4];
+    float h[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = row0 + 4 * quad + i;
+        live[i] = r < R;
+        rows[i] = live[i] ? r : R - 1;
+        h[i] = (s.h0 != nullptr && live[i]) ? s.h0[(int64_t)rows[i] * H + unit] : 0.f;
+        store_split2(&hbuf[0][(4 * quad + i) * HP + unit], PLANE, h[i]);
+    }
+    // running per-row pointers, advanced by a signed stride every step (the address arithmetic of 12 loads and 8 stores
+    // per step was a quarter of the step: the kernel is vector-ALU bound around its MFMAs)
+    const int t0 = s.reverse ? T - 1 : 0;
+    const int64_t dir = s.reverse ? -1 : 1;
+    const int64_t gi_step = dir * s.gi_tstride, h_step = dir * (int64_t)R * s.h_stride, sv_step = dir * (int64_t)R * H * 4;
+    const float *gi_p[4];
+    float *h_p[4], *sv_p[4];
+    float gi_next[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        gi_p[i] = s.gi + t0 * s.gi_tstride + (int64_t)rows[i] * s.gi_rstride + unit;
+        h_p[i] = s.h_all + ((int64_t)t0 * R + rows[i]) * s.h_stride + unit;
+        sv_p[i] = s.saved + (((int64_t)t0 * R + rows[i]) * H + unit) * 4;
+        gi_next[i][0] = gi_p[i][0]; gi_next[i][1] = gi_p[i][H]; gi_next[i][2] = gi_p[i][2 * H];
+        gi_p[i] += gi_step;
+    }
+    __syncthreads();
+    f32x4 keep_sv[4];                        // results of the previous step, stored after the barrier
+    float keep_h[4];
+    int keep_t = -1;
+#ifdef ARVAE_GRU_STAMPS
+    unsigned long long ph[4] = {0, 0, 0, 0}, tc = __builtin_readcyclecounter();
+#define GSTAMP(k) { const unsigned long long now = __builtin_readcyclecounter(); ph[k] += now - tc; tc = now; }
+#else
+#define GSTAMP(k)
+#endif
+
+    for (int step = 0; step < T; ++step) {
+        const int t = s.reverse ? T - 1 - step : step;
+        const int cur = step & 1;
+        float gi[4][3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) gi[i][g] = gi_next[i][g];
+        GSTAMP(0);
+        f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        const unsigned short *hb = &hbuf[cur][col * HP + 8 * quad];
+        // Row i's share of the step's memory traffic (next step's three input projections in, the previous step's h and saved
+        // gates out) is issued BEHIND the MFMAs of k-step i, with a scheduling barrier pinning it there: as one block in front
+        // of the MFMAs it was 1200 of the step's 6000 cycles (tools/stamp_gru.py), all of it issue time of an in-order wave
+        // while the matrix pipe sat idle.
+        auto row_traffic = [&](int i) __attribute__((always_inline)) {
+            if (step + 1 < T) {
+                gi_next[i][0] = gi_p[i][0]; gi_next[i][1] = gi_p[i][H]; gi_next[i][2] = gi_p[i][2 * H];
+                gi_p[i] += gi_step;
+            }
+            if (keep_t >= 0) {
+                if (live[i]) {
+                    *h_p[i] = keep_h[i];
+                    *reinterpret_cast<f32x4 *>(sv_p[i]) = keep_sv[i];
+                }
+                h_p[i] += h_step; sv_p[i] += sv_step;
+            }
+        };
+        static_assert(KS <= 4, "one row's traffic per k-step; rows left over go last");
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const f16x8g ah = lds_h8(hb + 32 * ks), al = lds_h8(hb + PLANE + 32 * ks);
+            GRU_MFMA3X3(acc[0], acc[1], acc[2], ah, al, wh[0][ks], wl[0][ks], wh[1][ks], wl[1][ks], wh[2][ks], wl[2][ks]);
+            __builtin_amdgcn_sched_barrier(0);
+            row_traffic(ks);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = KS; i < 4; ++i) row_traffic(i);
+#ifdef ARVAE_GRU_STAMPS
+        { float dep = acc[0][0] + acc[1][0] + acc[2][3]; asm volatile("" :: "v"(dep)); __builtin_amdgcn_s_waitcnt(0); }
+#endif
+        GSTAMP(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float r = fast_sigmoid(gi[i][0] + acc[0][i] * GRU_UNSCALE + bh_r);
+            const float z = fast_sigmoid(gi[i][1] + acc[1][i] * GRU_UNSCALE + bh_z);
+            const float ghn = acc[2][i] * GRU_UNSCALE + bh_n;
+            const float n = fast_tanh(gi[i][2] + r * ghn);
+            const float hn = (1.f - z) * n + z * h[i];
+            h[i] = hn;
+            keep_h[i] = hn;
+            keep_sv[i] = f32x4{r, z, n, ghn};
+        }
+        store_split2_pair(&hbuf[cur ^ 1][(4 * quad) * HP + unit], HP, PLANE, h[0], h[1]);
+        store_split2_pair(&hbuf[cur ^ 1][(4 * quad + 2) * HP + unit], HP, PLANE, h[2], h[3]);
+        keep_t = t;
+#ifdef ARVAE_GRU_STAMPS
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the LDS writes are done
+#endif
+        GSTAMP(2);
+        __syncthreads();
+        GSTAMP(3);
+    }
+#ifdef ARVAE_GRU_STAMPS
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        for (int k = 0; k < 4; ++k) g_gru_stamps[k] = ph[k];
+        g_gru_stamps[4] = T;
+    }
+#endif
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (live[i]) {
+            *h_p[i] = keep_h[i];
+            *reinterpret_cast<f32x4 *>(sv_p[i]) = keep_sv[i];
+            if (s.h_fin != nullptr) s.h_fin[(int64_t)rows[i] * s.h_fin_stride + unit] = keep_h[i];
+        }
+}
+
 template <int H>
 __global__ __launch_bounds__(H * 4) void gru_seq_bwd_x3_kernel(GruSeqBatch batch, int T, int R) {
     constexpr int KS = 3 * H / 32;
@@ -1009,6 +1204,221 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_x3_kernel(TickFreeRun p, 
     }
 }
 
+// one accumulator: l h', h l', h h'
+#define GRU_MFMA3(ACC, AH, AL, WH, WL)                                                 \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(AL, WH, ACC, 0, 0, 0);                \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(AH, WL, ACC, 0, 0, 0);                \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(AH, WH, ACC, 0, 0, 0)
+
+// the same free-running pass on the scaled two-term fp16 operands of gru_seq_fwd_h2_kernel: two thirds of the weight stream
+// (590 instead of 885 KB per tick and workgroup, the kernel's bound) and half the MFMAs
+template <int H>
+__global__ __launch_bounds__(256) void tick_weight_prep_h2_kernel(TickPrep p) {
+    constexpr int NW = H / 16, KS = H / 32;
+    const int tid = blockIdx.x * 256 + threadIdx.x;
+    const int lane = tid & 63;
+    int rest = tid >> 6;
+    const int g = rest % 3; rest /= 3;
+    const int w = rest % NW; rest /= NW;
+    const int ks = rest % KS;
+    const int m = rest / KS;
+    if (m >= 3) return;
+    const int col = lane & 15, quad = lane >> 4;
+    const float *src = (m == 0 ? p.w[0] : m == 1 ? p.w[1] : p.w[2]) + (int64_t)(g * H + 16 * w + col) * H + 32 * ks + 8 * quad;
+    const f32x4 v0 = *reinterpret_cast<const f32x4 *>(src), v1 = *reinterpret_cast<const f32x4 *>(src + 4);
+    const float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    f16x8g hi, lo;
+    split2_x8(x, GRU_SW, hi, lo);
+    uint4 *dst = p.out + ((int64_t)((m * KS + ks) * NW + w) * 6 + g * 2) * 64 + lane;
+    dst[0] = __builtin_bit_cast(uint4, hi);
+    dst[64] = __builtin_bit_cast(uint4, lo);
+}
+
+template <int H, bool MASKED>
+__global__ __launch_bounds__(H * 4) void tick_free_run_h2_kernel(TickFreeRun p, const uint4 *__restrict__ packed) {
+    constexpr int NW = H / 16, KS = H / 32, KQ = H / 16;
+    constexpr int NGG = 9 * KS;                    // weight groups per tick: (matrix, k-step, gate), 3 x 16 bytes per lane each
+    constexpr int RS = NGG % 6 == 0 ? 6 : 3;       // register ring of groups; RS - 1 groups are in flight
+    constexpr int PFD = RS - 1;
+    constexpr int HP = H + 8, PLANE = 16 * HP, HS = H + 4;
+    __shared__ __attribute__((aligned(16))) unsigned short hA0[2][2 * PLANE];
+    __shared__ __attribute__((aligned(16))) unsigned short hA1[2][2 * PLANE];
+    __shared__ __attribute__((aligned(16))) unsigned short midp[2 * PLANE];
+    __shared__ __attribute__((aligned(16))) float h1f[16][HS];
+    __shared__ __attribute__((aligned(16))) float wout_s[64][HS];
+    __shared__ float cand_v[4][16];
+    __shared__ int cand_i[4][16];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = lane & 15, quad = lane >> 4;
+    const int unit = 16 * w + col;
+    const int row0 = blockIdx.x * 16;
+    const int B = p.batch;
+    const int ntile = (p.vocab + 15) / 16;
+
+    // weight stream: one buffer resource, one per-lane byte offset, the group's offset as the scalar offset of each
+    // load -- per-load 64-bit addresses would be hoisted out of the tick loop into 200+ VGPRs
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4 *>(packed), 0, 3 * KS * NW * 6 * 64 * 16, 0x00020000);
+    const int wlane = (w * 6 * 64 + lane) * 16;
+    f16x8g wb[RS][2];
+    auto fetch = [&](int gg) {                     // gg = (matrix * KS + ks) * 3 + gate, compile-time at every call site
+        const int g = gg / 3, gate = gg % 3;
+#pragma unroll
+        for (int term = 0; term < 2; ++term)
+            wb[gg % RS][term] = __builtin_bit_cast(f16x8g, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlane, (g * NW * 6 + gate * 2 + term) * 64 * 16, 0));
+    };
+#pragma unroll
+    for (int d = 0; d < PFD; ++d) fetch(d % NGG);
+
+    for (int e = threadIdx.x; e < 64 * H; e += H * 4) {       // note projection weights -> LDS (rows >= vocab: zeros)
+        const int n = e / H, k = e - n * H;
+        wout_s[n][k] = n < p.vocab ? p.w_out[(int64_t)n * H + k] : 0.f;
+    }
+    const float b0r = p.b_hh0[unit], b0z = p.b_hh0[H + unit], b0n = p.b_hh0[2 * H + unit];
+    const float b1r = p.b_ih1[unit] + p.b_hh1[unit], b1z = p.b_ih1[H + unit] + p.b_hh1[H + unit];
+    const float b1in = p.b_ih1[2 * H + unit], b1hn = p.b_hh1[2 * H + unit];
+    const int note = 16 * w + col;
+    const bool note_ok = w < ntile && note < p.vocab;
+    const float bout = note_ok ? p.b_out[note] : 0.f;
+
+    int rows[4];
+    bool live[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = row0 + 4 * quad + i;
+        live[i] = r < B;
+        rows[i] = live[i] ? r : B - 1;
+    }
+    float h0[4], h1[4], gb[4][3];
+    int tok[4] = {p.vocab, p.vocab, p.vocab, p.vocab};
+    const int ticks = p.beats * p.tpb;
+    const int aoff = col * HP + 8 * quad;                     // this lane's A-operand offset inside a plane
+
+    for (int t = 0; t < ticks; ++t) {
+        const int cur = t & 1;
+        const int beat = t / p.tpb;
+        if (t % p.tpb == 0) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t br = (int64_t)beat * B + rows[i];
+                h0[i] = p.h0_l0[br * H + unit];
+                h1[i] = p.h0_l1[br * H + unit];
+                store_split2(&hA0[cur][(4 * quad + i) * HP + unit], PLANE, h0[i]);
+                store_split2(&hA1[cur][(4 * quad + i) * HP + unit], PLANE, h1[i]);
+                const float *g = p.gib + br * 3 * H + unit;
+                gb[i][0] = g[0]; gb[i][1] = g[H]; gb[i][2] = g[2 * H];
+            }
+            __syncthreads();
+        }
+        float gi[4][3], keep[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float *pt = p.ptab + (int64_t)tok[i] * 3 * H + unit;
+            gi[i][0] = gb[i][0] + pt[0]; gi[i][1] = gb[i][1] + pt[H]; gi[i][2] = gb[i][2] + pt[2 * H];
+            keep[i] = MASKED ? p.keep_scale * (float)p.mask[((int64_t)t * B + rows[i]) * H + unit] : 1.f;
+        }
+        // ---- layer 0: matrix 0
+        {
+            f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            const unsigned short *ab = &hA0[cur][aoff];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const f16x8g ah = lds_h8(ab + 32 * ks), al = lds_h8(ab + PLANE + 32 * ks);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int gg = (0 * KS + ks) * 3 + q;
+                    fetch((gg + PFD) % NGG);
+                    __builtin_amdgcn_sched_barrier(0);
+                    GRU_MFMA3(acc[q], ah, al, wb[gg % RS][0], wb[gg % RS][1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float r = fast_sigmoid(gi[i][0] + acc[0][i] * GRU_UNSCALE + b0r);
+                const float z = fast_sigmoid(gi[i][1] + acc[1][i] * GRU_UNSCALE + b0z);
+                const float n = fast_tanh(gi[i][2] + r * (acc[2][i] * GRU_UNSCALE + b0n));
+                h0[i] = (1.f - z) * n + z * h0[i];
+                store_split2(&hA0[cur ^ 1][(4 * quad + i) * HP + unit], PLANE, h0[i]);
+                store_split2(&midp[(4 * quad + i) * HP + unit], PLANE, h0[i] * keep[i]);
+            }
+        }
+        __syncthreads();
+        // ---- layer 1: matrix 1 (W_ih1 on mid), matrix 2 (W_hh1 on h1); r and z share an accumulator
+        {
+            f32x4 a1[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // r, z, i_n, h_n
+#pragma unroll
+            for (int m = 1; m <= 2; ++m) {
+                const unsigned short *ab = m == 1 ? &midp[aoff] : &hA1[cur][aoff];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const f16x8g ah = lds_h8(ab + 32 * ks), al = lds_h8(ab + PLANE + 32 * ks);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const int gg = (m * KS + ks) * 3 + q;
+                        fetch((gg + PFD) % NGG);
+                        __builtin_amdgcn_sched_barrier(0);
+                        GRU_MFMA3(a1[q == 2 ? m + 1 : q], ah, al, wb[gg % RS][0], wb[gg % RS][1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float r = fast_sigmoid(a1[0][i] * GRU_UNSCALE + b1r);
+                const float z = fast_sigmoid(a1[1][i] * GRU_UNSCALE + b1z);
+                const float n = fast_tanh(a1[2][i] * GRU_UNSCALE + b1in + r * (a1[3][i] * GRU_UNSCALE + b1hn));
+                h1[i] = (1.f - z) * n + z * h1[i];
+                store_split2(&hA1[cur ^ 1][(4 * quad + i) * HP + unit], PLANE, h1[i]);
+                h1f[4 * quad + i][unit] = h1[i];
+            }
+        }
+        __syncthreads();
+        // ---- logits (fp32 MFMA, weights in LDS) + row argmax
+        if (w < ntile) {
+            f32x4 lg = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kq = 0; kq < KQ; ++kq) {
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(&h1f[col][16 * kq + 4 * quad]);
+                const f32x4 b = *reinterpret_cast<const f32x4 *>(&wout_s[note][16 * kq + 4 * quad]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) lg = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], lg, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = note_ok ? fmaxf(lg[i] + bout, 0.f) : -1.f;
+                int ix = note;
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) {
+                    const float ov = __shfl_xor(v, off, 64);
+                    const int oi = __shfl_xor(ix, off, 64);
+                    const bool take = ov > v || (ov == v && oi < ix);
+                    v = take ? ov : v;
+                    ix = take ? oi : ix;
+                }
+                if (col == 0) { cand_v[w][4 * quad + i] = v; cand_i[w][4 * quad + i] = ix; }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 4 * quad + i;
+            float v = cand_v[0][r];
+            int ix = cand_i[0][r];
+            for (int c = 1; c < ntile; ++c) {
+                const float ov = cand_v[c][r];
+                const int oi = cand_i[c][r];
+                const bool take = ov > v;                      // later tiles hold larger indices: ties keep the earlier
+                v = take ? ov : v;
+                ix = take ? oi : ix;
+            }
+            tok[i] = ix;
+            if (w == 0 && col == 0 && live[i]) p.tokens[(int64_t)rows[i] * ticks + t] = ix;
+        }
+    }
+}
+
 }  // namespace arvae
 
 using namespace arvae;
@@ -1016,6 +1426,12 @@ using namespace arvae;
 // ARVAE_GRU_FP32=1: the fp32-MFMA kernels (A/B measurements; the default is the three-term bf16 split)
 static bool gru_fp32_mfma() {
     static const bool on = diag_env("ARVAE_GRU_FP32") != nullptr;
+    return on;
+}
+
+// ARVAE_GRU_BF16_FWD=1 (diagnostic build): the forward recurrence on the three-term bf16 split, as through round 3
+static bool gru_bf16_forward() {
+    static const bool on = diag_env("ARVAE_GRU_BF16_FWD") != nullptr;
     return on;
 }
 
@@ -1036,10 +1452,14 @@ extern "C" int arvae_gru_seq_fwd(const arvae_gru_seq_t *seqs, int32_t nseq, int3
         if (hidden == 128) ARVAE_LAUNCH(gru_seq_fwd_kernel<128>, grid, dim3(512), 0, st, b, steps, rows);
         else if (hidden == 64) ARVAE_LAUNCH(gru_seq_fwd_kernel<64>, grid, dim3(256), 0, st, b, steps, rows);
         else ARVAE_LAUNCH(gru_seq_fwd_kernel<32>, grid, dim3(128), 0, st, b, steps, rows);
-    } else {
+    } else if (gru_bf16_forward()) {
         if (hidden == 128) ARVAE_LAUNCH(gru_seq_fwd_x3_kernel<128>, grid, dim3(512), 0, st, b, steps, rows);
         else if (hidden == 64) ARVAE_LAUNCH(gru_seq_fwd_x3_kernel<64>, grid, dim3(256), 0, st, b, steps, rows);
         else ARVAE_LAUNCH(gru_seq_fwd_x3_kernel<32>, grid, dim3(128), 0, st, b, steps, rows);
+    } else {
+        if (hidden == 128) ARVAE_LAUNCH(gru_seq_fwd_h2_kernel<128>, grid, dim3(512), 0, st, b, steps, rows);
+        else if (hidden == 64) ARVAE_LAUNCH(gru_seq_fwd_h2_kernel<64>, grid, dim3(256), 0, st, b, steps, rows);
+        else ARVAE_LAUNCH(gru_seq_fwd_h2_kernel<32>, grid, dim3(128), 0, st, b, steps, rows);
     }
     return check_launch("gru_seq_fwd_kernel");
 }
@@ -1108,6 +1528,22 @@ extern "C" int arvae_tick_free_run(const arvae_tick_weights_t *wts, const float 
     TickPrep tp{{wts->w_hh0, wts->w_ih1, wts->w_hh1}, reinterpret_cast<uint4 *>(ws)};
     const int items = 3 * (hidden / 32) * (hidden / 16) * 3 * 64;
     const uint4 *packed = reinterpret_cast<const uint4 *>(ws);
+    if (!gru_bf16_forward()) {
+        if (hidden == 128) {
+            ARVAE_LAUNCH(tick_weight_prep_h2_kernel<128>, dim3((items + 255) / 256), dim3(256), 0, st, tp);
+            if (m) ARVAE_LAUNCH((tick_free_run_h2_kernel<128, true>), grid, dim3(512), 0, st, p, packed);
+            else ARVAE_LAUNCH((tick_free_run_h2_kernel<128, false>), grid, dim3(512), 0, st, p, packed);
+        } else if (hidden == 64) {
+            ARVAE_LAUNCH(tick_weight_prep_h2_kernel<64>, dim3((items + 255) / 256), dim3(256), 0, st, tp);
+            if (m) ARVAE_LAUNCH((tick_free_run_h2_kernel<64, true>), grid, dim3(256), 0, st, p, packed);
+            else ARVAE_LAUNCH((tick_free_run_h2_kernel<64, false>), grid, dim3(256), 0, st, p, packed);
+        } else {
+            ARVAE_LAUNCH(tick_weight_prep_h2_kernel<32>, dim3((items + 255) / 256), dim3(256), 0, st, tp);
+            if (m) ARVAE_LAUNCH((tick_free_run_h2_kernel<32, true>), grid, dim3(128), 0, st, p, packed);
+            else ARVAE_LAUNCH((tick_free_run_h2_kernel<32, false>), grid, dim3(128), 0, st, p, packed);
+        }
+        return check_launch("tick_free_run_h2_kernel");
+    }
     if (hidden == 128) {
         ARVAE_LAUNCH(tick_weight_prep_kernel<128>, dim3((items + 255) / 256), dim3(256), 0, st, tp);
         if (m) ARVAE_LAUNCH((tick_free_run_x3_kernel<128, true>), grid, dim3(512), 0, st, p, packed);
