@@ -55,7 +55,7 @@ class GruSeqDesc(ctypes.Structure):
                 ('h_stride', c_i64), ('saved', c_vp), ('reverse', c_i32), ('reserved', c_i32), ('dh_all', c_vp),
                 ('dh_stride', c_i64), ('dgi', c_vp), ('dgh', c_vp), ('dh0', c_vp), ('dh_last', c_vp),
                 ('dh_last_stride', c_i64), ('h_prev_out', c_vp), ('gi_rstride', c_i64), ('dgi_rstride', c_i64), ('h_fin', c_vp),
-                ('h_fin_stride', c_i64)]
+                ('h_fin_stride', c_i64), ('h0_stride', c_i64), ('dh0_stride', c_i64)]
 
 
 class TickWeights(ctypes.Structure):
@@ -123,13 +123,13 @@ SIGNATURES = {
     'arvae_gru_seq_bwd': (c_i32, [_P(GruSeqDesc), c_i32, c_i32, c_i32, c_i32, c_vp]),
     'arvae_tick_free_run_ws_floats': (c_i64, [c_i32]),
     'arvae_tick_free_run_supported': (c_i32, [c_i32, c_i32]),
-    'arvae_tick_free_run': (c_i32, [_P(TickWeights), c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_i32, c_i32, c_i32,
+    'arvae_tick_free_run': (c_i32, [_P(TickWeights), c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_i32, c_i32, c_i32,
                                     c_vp, c_vp, c_vp]),
     'arvae_embed_fwd': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     'arvae_embed_bwd_ws_floats': (c_i64, [c_i32, c_i32, c_i32, c_i32]),
     'arvae_embed_bwd': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp]),
-    'arvae_tick_rows_fwd': (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
-    'arvae_tick_rows_bwd': (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    'arvae_tick_rows_fwd': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    'arvae_tick_rows_bwd': (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp]),
     'arvae_tick_gi_fwd': (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     'arvae_tick_gi_bwd_ws_floats': (c_i64, [c_i32, c_i32]),
     'arvae_tick_gi_bwd': (c_i32, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),

@@ -47,6 +47,7 @@ struct GruSeq {
     int64_t gi_rstride, dgi_rstride;
     float *h_fin;           // forward, optional: the state after the last processed step, row r at h_fin + r * h_fin_stride
     int64_t h_fin_stride;
+    int64_t h0_stride, dh0_stride;   // floats between two rows of h0 / dh0 (fill_batch: H when the caller leaves them 0)
 };
 struct GruSeqBatch {
     GruSeq seq[GRU_SEQ_MAX];
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_kernel(GruSeqBatch batch, i
         const int r = row0 + 4 * quad + i;
         live[i] = r < R;
         rows[i] = live[i] ? r : R - 1;
-        h[i] = (s.h0 != nullptr && live[i]) ? s.h0[(int64_t)rows[i] * H + unit] : 0.f;
+        h[i] = (s.h0 != nullptr && live[i]) ? s.h0[(int64_t)rows[i] * s.h0_stride + unit] : 0.f;
         hbuf[0][4 * quad + i][unit] = h[i];
     }
     float gi_next[4][3];
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_kernel(GruSeqBatch batch, i
             const f32x4 sv = *reinterpret_cast<const f32x4 *>(s.saved + (tr * H + unit) * 4);
             nx[i][1] = sv[0]; nx[i][2] = sv[1]; nx[i][3] = sv[2]; nx[i][4] = sv[3];
             if (has_prev) nx[i][5] = s.h_all[((int64_t)tp * R + rows[i]) * s.h_stride + unit];
-            else nx[i][5] = s.h0 != nullptr ? s.h0[(int64_t)rows[i] * H + unit] : 0.f;
+            else nx[i][5] = s.h0 != nullptr ? s.h0[(int64_t)rows[i] * s.h0_stride + unit] : 0.f;
         }
     };
     fetch(0);
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_kernel(GruSeqBatch batch, i
     if (s.dh0 != nullptr)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (live[i]) s.dh0[(int64_t)rows[i] * H + unit] = carry[i];
+            if (live[i]) s.dh0[(int64_t)rows[i] * s.dh0_stride + unit] = carry[i];
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_x3_kernel(GruSeqBatch batch
         const int r = row0 + 4 * quad + i;
         live[i] = r < R;
         rows[i] = live[i] ? r : R - 1;
-        h[i] = (s.h0 != nullptr && live[i]) ? s.h0[(int64_t)rows[i] * H + unit] : 0.f;
+        h[i] = (s.h0 != nullptr && live[i]) ? s.h0[(int64_t)rows[i] * s.h0_stride + unit] : 0.f;
         store_split3(&hbuf[0][(4 * quad + i) * HP + unit], PLANE, h[i]);
     }
     // running per-row pointers, advanced by a signed stride every step (the address arithmetic of 12 loads and 8 stores
@@ -546,7 +547,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_h2_kernel(GruSeqBatch batch
         const int r = row0 + 4 * quad + i;
         live[i] = r < R;
         rows[i] = live[i] ? r : R - 1;
-        h[i] = (s.h0 != nullptr && live[i]) ? s.h0[(int64_t)rows[i] * H + unit] : 0.f;
+        h[i] = (s.h0 != nullptr && live[i]) ? s.h0[(int64_t)rows[i] * s.h0_stride + unit] : 0.f;
         store_split2(&hbuf[0][(4 * quad + i) * HP + unit], PLANE, h[i]);
     }
     // running per-row pointers, advanced by a signed stride every step (the address arithmetic of 12 loads and 8 stores
@@ -703,7 +704,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_x3_kernel(GruSeqBatch batch
             const f32x4 sv = *reinterpret_cast<const f32x4 *>(s.saved + (tr * H + unit) * 4);
             nx[i][1] = sv[0]; nx[i][2] = sv[1]; nx[i][3] = sv[2]; nx[i][4] = sv[3];
             if (has_prev) nx[i][5] = s.h_all[((int64_t)tp * R + rows[i]) * s.h_stride + unit];
-            else nx[i][5] = s.h0 != nullptr ? s.h0[(int64_t)rows[i] * H + unit] : 0.f;
+            else nx[i][5] = s.h0 != nullptr ? s.h0[(int64_t)rows[i] * s.h0_stride + unit] : 0.f;
         }
     };
     fetch(0);
@@ -764,7 +765,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_x3_kernel(GruSeqBatch batch
     if (s.dh0 != nullptr)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (live[i]) s.dh0[(int64_t)rows[i] * H + unit] = carry[i];
+            if (live[i]) s.dh0[(int64_t)rows[i] * s.dh0_stride + unit] = carry[i];
 }
 
 static int fill_batch(GruSeqBatch *b, const arvae_gru_seq_t *seqs, int nseq, int hidden) {
@@ -778,6 +779,8 @@ static int fill_batch(GruSeqBatch *b, const arvae_gru_seq_t *seqs, int nseq, int
         s.gi_rstride = q.gi_rstride != 0 ? q.gi_rstride : 3 * hidden;
         s.dgi_rstride = q.dgi_rstride != 0 ? q.dgi_rstride : 3 * hidden;
         s.h_fin = q.h_fin; s.h_fin_stride = q.h_fin_stride;
+        s.h0_stride = q.h0_stride != 0 ? q.h0_stride : hidden;
+        s.dh0_stride = q.dh0_stride != 0 ? q.dh0_stride : hidden;
     }
     return 0;
 }
@@ -797,7 +800,8 @@ static int fill_batch(GruSeqBatch *b, const arvae_gru_seq_t *seqs, int nseq, int
 //            and LDS -> token, fed back.
 struct TickFreeRun {
     const float *w_hh0, *b_hh0, *w_ih1, *b_ih1, *w_hh1, *b_hh1, *w_out, *b_out;
-    const float *h0_l0, *h0_l1;    // [beats*B][H], row = beat*B + b
+    const float *h0_l0, *h0_l1;    // [beats*B] rows of H values h0_stride floats apart, row = beat*B + b
+    int64_t h0_stride;
     const float *gib;              // [beats*B][3H]
     const float *ptab;             // [V+1][3H]; row V = the start token
     const uint8_t *mask;           // [beats*tpb][B][H] or null
@@ -862,8 +866,8 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_kernel(TickFreeRun p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int64_t br = (int64_t)beat * B + rows[i];
-                h0[i] = p.h0_l0[br * H + unit];
-                h1[i] = p.h0_l1[br * H + unit];
+                h0[i] = p.h0_l0[br * p.h0_stride + unit];
+                h1[i] = p.h0_l1[br * p.h0_stride + unit];
                 hA0[cur][4 * quad + i][unit] = h0[i];
                 hA1[cur][4 * quad + i][unit] = h1[i];
                 const float *g = p.gib + br * 3 * H + unit;
@@ -1087,8 +1091,8 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_x3_kernel(TickFreeRun p, 
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int64_t br = (int64_t)beat * B + rows[i];
-                h0[i] = p.h0_l0[br * H + unit];
-                h1[i] = p.h0_l1[br * H + unit];
+                h0[i] = p.h0_l0[br * p.h0_stride + unit];
+                h1[i] = p.h0_l1[br * p.h0_stride + unit];
                 store_split3(&hA0[cur][(4 * quad + i) * HP + unit], PLANE, h0[i]);
                 store_split3(&hA1[cur][(4 * quad + i) * HP + unit], PLANE, h1[i]);
                 const float *g = p.gib + br * 3 * H + unit;
@@ -1302,8 +1306,8 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_h2_kernel(TickFreeRun p, 
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int64_t br = (int64_t)beat * B + rows[i];
-                h0[i] = p.h0_l0[br * H + unit];
-                h1[i] = p.h0_l1[br * H + unit];
+                h0[i] = p.h0_l0[br * p.h0_stride + unit];
+                h1[i] = p.h0_l1[br * p.h0_stride + unit];
                 store_split2(&hA0[cur][(4 * quad + i) * HP + unit], PLANE, h0[i]);
                 store_split2(&hA1[cur][(4 * quad + i) * HP + unit], PLANE, h1[i]);
                 const float *g = p.gib + br * 3 * H + unit;
@@ -1496,7 +1500,7 @@ extern "C" int arvae_tick_free_run_supported(int32_t hidden, int32_t vocab) {
     return arvae_gru_seq_supported(hidden) && vocab >= 1 && vocab <= 64 && vocab <= 16 * (hidden / 16);
 }
 
-extern "C" int arvae_tick_free_run(const arvae_tick_weights_t *wts, const float *h0_l0, const float *h0_l1, const float *gib,
+extern "C" int arvae_tick_free_run(const arvae_tick_weights_t *wts, const float *h0_l0, const float *h0_l1, int64_t h0_stride, const float *gib,
                                    const float *ptab, const uint8_t *mask, float keep_scale, int32_t batch, int32_t beats,
                                    int32_t ticks_per_beat, int32_t hidden, int32_t vocab, int64_t *tokens, float *ws,
                                    arvae_stream_t stream) {
@@ -1510,7 +1514,7 @@ extern "C" int arvae_tick_free_run(const arvae_tick_weights_t *wts, const float 
     TickFreeRun p{};
     p.w_hh0 = wts->w_hh0; p.b_hh0 = wts->b_hh0; p.w_ih1 = wts->w_ih1; p.b_ih1 = wts->b_ih1;
     p.w_hh1 = wts->w_hh1; p.b_hh1 = wts->b_hh1; p.w_out = wts->w_out; p.b_out = wts->b_out;
-    p.h0_l0 = h0_l0; p.h0_l1 = h0_l1; p.gib = gib; p.ptab = ptab; p.mask = mask; p.keep_scale = keep_scale;
+    p.h0_l0 = h0_l0; p.h0_l1 = h0_l1; p.h0_stride = h0_stride != 0 ? h0_stride : hidden; p.gib = gib; p.ptab = ptab; p.mask = mask; p.keep_scale = keep_scale;
     p.batch = batch; p.beats = beats; p.tpb = ticks_per_beat; p.vocab = vocab; p.tokens = tokens;
     hipStream_t st = as_stream(stream);
     const dim3 grid((batch + 15) / 16);

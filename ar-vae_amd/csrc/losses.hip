@@ -206,7 +206,10 @@ constexpr int TOK_LPR = 4;                   // lanes per row: a 256-thread work
 constexpr int TOK_ROWS = 256 / TOK_LPR;      // workgroups instead of 24 (13.8 -> ~6 us at B = 256)
 __global__ __launch_bounds__(256) void token_recon_kernel(const float *__restrict__ w, const int64_t *__restrict__ tgt,
                                                            int64_t rows, int vocab, float inv_rows,
-                                                           float *__restrict__ partial, float *__restrict__ dw) {
+                                                           float *__restrict__ partial, float *__restrict__ dw, int tk_batch = 0,
+                                                           int tk_beats = 0, int tk_tpb = 0) {
+    // tk_beats > 0: the rows are in the tick RNN's sequence order (tick-in-beat j, beat, measure b) and tgt is the score
+    // [batch][beats * tpb]: row r = (j * beats + beat) * batch + b reads tgt[b][tpb * beat + j]
     __shared__ float red[4];
     __shared__ float stage[TOK_ROWS * TOK_VMAX];
     float loss = 0.f, corr = 0.f;
@@ -246,7 +249,12 @@ __global__ __launch_bounds__(256) void token_recon_kernel(const float *__restric
 #pragma unroll
         for (int o = 1; o < TOK_LPR; o <<= 1) se += __shfl_xor(se, o);
         if (live) {
-            const int t = (int)tgt[r];
+            int64_t ti = r;
+            if (tk_beats > 0) {
+                const int b = (int)(r % tk_batch), jb = (int)(r / tk_batch);
+                ti = (int64_t)b * (tk_beats * tk_tpb) + (jb % tk_beats) * tk_tpb + jb / tk_beats;
+            }
+            const int t = (int)tgt[ti];
             if (part == 0) {
                 loss += mx + logf(se) - row[t];
                 corr += (arg == t) ? 1.f : 0.f;
@@ -346,7 +354,7 @@ __device__ __forceinline__ float block_sum_1024(float v, float *red) {       // 
 }
 
 struct VaeFinishArgs {
-    const float *rec_partial; int nb; float inv_batch, inv_count;              // reconstruction
+    const float *rec_partial; int nb; float inv_batch, inv_count, inv_rec;     // reconstruction (inv_rec scales the summed term)
     const float *mu, *sigma; int64_t bz; float beta; const float *cap;         // KL
     const float *row_loss, *row_grad; int64_t n_rows; int r; RegDims dims;     // regulariser (row_loss null: none)
     int64_t ldz; float loss_scale, grad_scale, reg_scale; float *dz;
@@ -405,7 +413,7 @@ __global__ __launch_bounds__(1024) void vae_finish_kernel(VaeFinishArgs p) {
         float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int w = 0; w < 16; ++w) { tot.x += red4[w].x; tot.y += red4[w].y; tot.z += red4[w].z; tot.w += red4[w].w; }
-        const float rec = tot.x * p.inv_batch, acc = tot.y * p.inv_count, kl = tot.z * p.inv_batch, reg = tot.w * p.loss_scale;
+        const float rec = tot.x * p.inv_rec, acc = tot.y * p.inv_count, kl = tot.z * p.inv_batch, reg = tot.w * p.loss_scale;
         const float dist = p.beta * fabsf(kl - (p.cap ? p.cap[0] : 0.f));
         p.rec_out[0] = rec; p.rec_out[1] = acc;
         p.kld_out[0] = dist; p.kld_out[1] = kl;
@@ -419,6 +427,17 @@ __global__ __launch_bounds__(1024) void vae_finish_kernel(VaeFinishArgs p) {
 }
 
 int recon_partial_blocks(int64_t count) { return grid_for(count, 8, RECON_MAX_BLOCKS); }
+
+// per-block partial sums (cross entropy, correct top-1) of the token term, rows in the tick RNN's sequence order against the
+// score's (batch, tick) targets (+ d/dweights for a unit upstream gradient of the MEAN); the block count through *nb_out
+int token_recon_partials(const float *weights, const int64_t *score, int batch, int beats, int tpb, int32_t vocab, float *ws,
+                         float *dweights, hipStream_t s, int *nb_out) {
+    const int64_t rows = (int64_t)batch * beats * tpb;
+    const int nb = grid_for(rows * TOK_LPR, 1, RECON_MAX_BLOCKS);
+    ARVAE_LAUNCH(token_recon_kernel, dim3(nb), dim3(256), 0, s, weights, score, rows, vocab, 1.f / (float)rows, ws, dweights, batch, beats, tpb);
+    *nb_out = nb;
+    return check_launch("token_recon");
+}
 
 // per-block partial sums of the reconstruction term (+ d/dlogits); returns the block count through *nb
 int recon_partials(const float *logits, const float *x, int64_t count, int64_t batch, int32_t dist, float *ws,
@@ -448,9 +467,10 @@ int reg_partials(const float *z_rows, const float *lab_rows, int64_t n_rows, con
 int vae_finish(const float *rec_partial, int nb, int64_t batch, int64_t pix, const float *mu, const float *sigma,
                int64_t zdim, float beta, const float *cap, const float *reg_ws, int64_t n_cols, int64_t ldz,
                const int32_t *dims, int32_t r, float gamma, float delta, float reg_scale, float *dz, float *rec_out,
-               float *kld_out, float *reg_out, float *scalars, hipStream_t s) {
+               float *kld_out, float *reg_out, float *scalars, hipStream_t s, int64_t rec_rows) {
     VaeFinishArgs p{};
     p.rec_partial = rec_partial; p.nb = nb; p.inv_batch = 1.f / (float)batch; p.inv_count = 1.f / (float)pix;
+    p.inv_rec = rec_rows > 0 ? 1.f / (float)rec_rows : p.inv_batch;     // (a mean over rows instead of a per-sample sum: the token term)
     p.mu = mu; p.sigma = sigma; p.bz = batch * zdim; p.beta = beta; p.cap = cap;
     if (reg_ws != nullptr) {
         p.row_loss = reg_ws; p.row_grad = reg_ws + batch * r; p.n_rows = batch; p.r = r;

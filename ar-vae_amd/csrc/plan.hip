@@ -101,7 +101,7 @@ int reg_partials(const float *z_rows, const float *lab_rows, int64_t n_rows, con
 int vae_finish(const float *rec_partial, int nb, int64_t batch, int64_t pix, const float *mu, const float *sigma,
                int64_t zdim, float beta, const float *cap, const float *reg_ws, int64_t n_cols, int64_t ldz,
                const int32_t *dims, int32_t r, float gamma, float delta, float reg_scale, float *dz, float *rec_out,
-               float *kld_out, float *reg_out, float *scalars, hipStream_t s);
+               float *kld_out, float *reg_out, float *scalars, hipStream_t s, int64_t rec_rows = 0);
 
 // ---- small glue kernels ---------------------------------------------------------------------------
 // gradient of the loss w.r.t. (mu, log_std) from: the decoder path g_z (already times g), the

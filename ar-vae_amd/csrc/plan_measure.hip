@@ -10,8 +10,20 @@
 #include "diag.h"
 #include "common.h"
 #include "dense.h"
+#include "regloss.h"
 
 namespace arvae {
+
+// loss-term pieces (losses.hip)
+int token_recon_partials(const float *weights, const int64_t *score, int batch, int beats, int tpb, int32_t vocab, float *ws,
+                         float *dweights, hipStream_t s, int *nb_out);
+int reg_partials(const float *z_rows, const float *lab_rows, int64_t n_rows, const float *z_cols, const float *lab_cols,
+                 int64_t n_cols, int64_t ldz, int64_t ldl, const RegDims &rd, int32_t r, float delta, float *ws,
+                 hipStream_t s);
+int vae_finish(const float *rec_partial, int nb, int64_t batch, int64_t pix, const float *mu, const float *sigma,
+               int64_t zdim, float beta, const float *cap, const float *reg_ws, int64_t n_cols, int64_t ldz,
+               const int32_t *dims, int32_t r, float gamma, float delta, float reg_scale, float *dz, float *rec_out,
+               float *kld_out, float *reg_out, float *scalars, hipStream_t s, int64_t rec_rows = 0);
 
 static inline int64_t up4(int64_t v) { return (v + 3) / 4 * 4; }
 
@@ -45,17 +57,6 @@ __global__ __launch_bounds__(256) void scale_mask_tick_kernel(const float *__res
     }
 }
 
-// targets in sequence order: out[(j*beats + beat)*batch + b] = score[b][tpb*beat + j]
-__global__ __launch_bounds__(256) void tick_order_i64_kernel(const int64_t *__restrict__ score, int batch, int beats, int tpb,
-                                                              int64_t *__restrict__ out) {
-    const int total = tpb * beats * batch;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        const int b = i % batch, r = i / batch;
-        const int beat = r % beats, j = r / beats;
-        out[i] = score[(int64_t)b * (beats * tpb) + beat * tpb + j];
-    }
-}
-
 // out = g[0] * d * (y > 0): the upstream scalar and the ReLU of the note projection folded into the cross-entropy gradient
 __global__ __launch_bounds__(256) void relu_gate_scale_kernel(const float *__restrict__ d, const float *__restrict__ y,
                                                                const float *__restrict__ g, int64_t count4, float *__restrict__ out) {
@@ -71,18 +72,6 @@ __global__ __launch_bounds__(256) void relu_gate_scale1_kernel(const float *__re
     const float s = g[0];
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
         out[i] = y[i] > 0.f ? s * d[i] : 0.f;
-}
-
-// out[r] = [a[r] | b[r] | c[r]] (c may be null with cc == 0); all widths multiples of 4
-__global__ __launch_bounds__(256) void concat3_kernel(const float4 *__restrict__ a, const float4 *__restrict__ b, const float4 *__restrict__ c,
-                                                       int64_t rows, int ca4, int cb4, int cc4, float4 *__restrict__ out) {
-    const int w = ca4 + cb4 + cc4;
-    const int64_t total = rows * w;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t r = i / w;
-        const int col = (int)(i - r * w);
-        out[i] = col < ca4 ? a[r * ca4 + col] : (col < ca4 + cb4 ? b[r * cb4 + (col - ca4)] : c[r * cc4 + (col - ca4 - cb4)]);
-    }
 }
 
 // y[r][:] = x[r][:] + bias[:]
@@ -115,20 +104,6 @@ __global__ __launch_bounds__(256) void measure_latent_bwd_kernel(const float *__
     }
 }
 
-// scalars of the pass from the three terms' own outputs
-__global__ void measure_scalars_kernel(const float *__restrict__ ce, const float *__restrict__ kld, const float *__restrict__ reg,
-                                       float *__restrict__ scalars) {
-    if (threadIdx.x != 0) return;
-    const float r = reg != nullptr ? reg[0] : 0.f;
-    scalars[ARVAE_VAE_RECON] = ce[0];
-    scalars[ARVAE_VAE_ACC] = ce[1];
-    scalars[ARVAE_VAE_DIST] = kld[0];
-    scalars[ARVAE_VAE_KL] = kld[1];
-    scalars[ARVAE_VAE_REG] = r;
-    scalars[ARVAE_VAE_LOSS] = ce[0] + kld[0] + r;
-    scalars[6] = scalars[7] = 0.f;
-}
-
 static inline unsigned blocks_for(int64_t items, int cap = 2048) {
     const int64_t b = (items + 255) / 256;
     return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -139,14 +114,14 @@ struct MvWs {
     // encoder
     float *ptab, *gi0, *out0, *sv0, *mid, *gi1, *out1, *sv1, *hidden, *h12, *hmu, *hls, *log_std;
     // decoder
-    float *flatb, *h0b0, *h0b1, *x0b, *gi0b, *out0b, *svb0, *midb, *gi1b, *beat_out, *svb1;
-    float *both, *flatt, *beat_emb, *h0t0, *h0t1, *xs, *gsm, *gib, *frws;
+    float *flatb, *x0b, *gi0b, *out0b, *svb0, *midb, *gi1b, *beat_out, *svb1;
+    float *both, *xs, *gsm, *gib, *frws;
     float *gi0t, *out0t, *svt0, *midt, *gi1t, *out1t, *svt1, *probs;
     int64_t *tgt;
     // loss terms
     float *dprobs, *rec_ws, *ce_out, *kld_out, *labels, *reg_ws, *reg_out, *dz_reg;
     // backward
-    float *gpre, *d_seq_h, *dgi_t1, *dgh_t1, *hprev_t1, *dgi_t0, *dgh_t0, *hprev_t0, *d_mid_t, *dh0a, *dh0b, *dg_small, *tick_ws, *dx_small, *d_beat_emb, *d_both;
+    float *gpre, *d_seq_h, *dgi_t1, *dgh_t1, *hprev_t1, *dgi_t0, *dgh_t0, *hprev_t0, *d_mid_t, *dg_small, *tick_ws, *dx_small, *d_both;
     float *d_rows_h, *d_mid_b, *dgi_b1, *dgh_b1, *hprev_b1, *dgi_b0, *dgh_b0, *hprev_b0, *d_x0, *d_flatb, *d_z, *d_mu, *d_ls, *d_hmu, *d_hls, *d_h12, *d_hidden;
     float *dgi_e1, *dgh_e1, *hprev_e1, *dgi_e0, *dgh_e0, *hprev_e0, *d_mid_e, *d_out0_e, *dptab, *embed_ws, *d_table, *wg_ws, *wg_long, *cs_ws;
     int64_t wg_long_floats;
@@ -193,8 +168,6 @@ static int64_t carve(const arvae_measure_vae_t *m, int batch, float *base, MvWs 
     w->hls = take(B * 2 * d.he);
     w->log_std = take(B * d.z);
     w->flatb = take(B * 2 * d.hd);
-    w->h0b0 = take(B * d.hd);
-    w->h0b1 = take(B * d.hd);
     w->x0b = take(RB);
     w->gi0b = take(B * 3 * d.hd);
     w->out0b = take(RB * d.hd);
@@ -204,10 +177,6 @@ static int64_t carve(const arvae_measure_vae_t *m, int batch, float *base, MvWs 
     w->beat_out = take(RB * d.hd);
     w->svb1 = take(RB * 4 * d.hd);
     w->both = take(RB * 3 * d.hd);
-    w->flatt = take(RB * 2 * d.hd);
-    w->beat_emb = take(RB * d.hd);
-    w->h0t0 = take(RB * d.hd);
-    w->h0t1 = take(RB * d.hd);
     w->xs = take((int64_t)d.ns * (d.e + d.hd));
     w->gsm = take((int64_t)d.ns * 3 * d.hd);
     w->gib = take(RB * 3 * d.hd);
@@ -239,12 +208,9 @@ static int64_t carve(const arvae_measure_vae_t *m, int batch, float *base, MvWs 
     w->dgh_t0 = take(RT * 3 * d.hd);
     w->hprev_t0 = take(RT * d.hd);
     w->d_mid_t = take(RT * d.hd);
-    w->dh0a = take(RB * d.hd);
-    w->dh0b = take(RB * d.hd);
     w->dg_small = take((int64_t)d.ns * 3 * d.hd);
     w->tick_ws = take(arvae_tick_gi_bwd_ws_floats(d.v, 3 * d.hd));
     w->dx_small = take((int64_t)d.ns * (d.e + d.hd));
-    w->d_beat_emb = take(RB * d.hd);
     w->d_both = take(RB * 3 * d.hd);
     w->d_rows_h = take(RB * d.hd);
     w->d_mid_b = take(RB * d.hd);
@@ -438,12 +404,11 @@ extern "C" int arvae_measure_vae_forward(const arvae_measure_vae_t *m, int32_t b
 
     // ---- beat RNN (decoder.py:436-457): the same input b_0 at every beat
     MV_TRY(lin_fwd(d.b, d.z, 2 * Hd, z, P + m->z2beat_w, P + m->z2beat_b, ARVAE_ACT_SELU, w.flatb, s));
-    MV_TRY(arvae_split_cols(w.flatb, d.b, Hd, Hd, w.h0b0, w.h0b1, 0, stream));
     MV_TRY(arvae_broadcast_rows(P + m->b0, d.rb, 1, w.x0b, stream));
     MV_TRY(lin_fwd(d.b, 1, 3 * Hd, w.x0b, P + m->beat_w_ih[0], P + m->beat_b_ih[0], ARVAE_ACT_NONE, w.gi0b, s));
     arvae_gru_seq_t g{};
     g.gi = w.gi0b; g.gi_tstride = 0;
-    g.w_hh = P + m->beat_w_hh[0]; g.b_hh = P + m->beat_b_hh[0]; g.h0 = w.h0b0;
+    g.w_hh = P + m->beat_w_hh[0]; g.b_hh = P + m->beat_b_hh[0]; g.h0 = w.flatb; g.h0_stride = 2 * Hd;   // view(B, 2, H)[:, 0]
     g.h_all = w.out0b; g.h_stride = Hd; g.saved = w.svb0;
     MV_TRY(arvae_gru_seq_fwd(&g, 1, d.nb, d.b, Hd, stream));
     const float *midb = w.out0b;
@@ -454,16 +419,17 @@ extern "C" int arvae_measure_vae_forward(const arvae_measure_vae_t *m, int32_t b
     MV_TRY(lin_fwd(d.rb, Hd, 3 * Hd, midb, P + m->beat_w_ih[1], P + m->beat_b_ih[1], ARVAE_ACT_NONE, w.gi1b, s));
     g = arvae_gru_seq_t{};
     g.gi = w.gi1b; g.gi_tstride = (int64_t)d.b * 3 * Hd;
-    g.w_hh = P + m->beat_w_hh[1]; g.b_hh = P + m->beat_b_hh[1]; g.h0 = w.h0b1;
+    g.w_hh = P + m->beat_w_hh[1]; g.b_hh = P + m->beat_b_hh[1]; g.h0 = w.flatb + Hd; g.h0_stride = 2 * Hd;
     g.h_all = w.beat_out; g.h_stride = Hd; g.saved = w.svb1;
     MV_TRY(arvae_gru_seq_fwd(&g, 1, d.nb, d.b, Hd, stream));
 
     // ---- tick RNN (decoder.py:459-525): the four beats as one 6-step sequence over beats*batch rows
     MV_TRY(lin_fwd(d.rb, Hd, 3 * Hd, w.beat_out, P + m->tick_init_w, P + m->tick_init_b, ARVAE_ACT_SELU, w.both, s));
-    MV_TRY(arvae_split_cols(w.both, d.rb, 2 * Hd, Hd, w.flatt, w.beat_emb, 0, stream));
-    MV_TRY(arvae_split_cols(w.flatt, d.rb, Hd, Hd, w.h0t0, w.h0t1, 0, stream));
+    // its columns: [layer-0 initial state | layer-1 initial state | beat embedding], read in place through row strides
+    const float *h0t0 = w.both, *h0t1 = w.both + Hd, *beat_emb = w.both + 2 * Hd;
+    const int64_t both_ld = 3 * Hd;
     // layer 0's input projection by lookup: W_ih0 applied once to the vocabulary's embeddings, x_0 and the beat embeddings
-    MV_TRY(arvae_tick_rows_fwd(P + m->dec_table, P + m->x0, w.beat_emb, d.v, d.e, Hd, d.rb, w.xs, stream));
+    MV_TRY(arvae_tick_rows_fwd(P + m->dec_table, P + m->x0, beat_emb, both_ld, d.v, d.e, Hd, d.rb, w.xs, stream));
     MV_TRY(lin_fwd(d.ns, d.e + Hd, 3 * Hd, w.xs, P + m->tick_w_ih[0], nullptr, ARVAE_ACT_NONE, w.gsm, s));
     if (teacher_forced) {
         MV_TRY((int)hipMemcpyAsync(tokens, score, sizeof(int64_t) * d.b * d.t, hipMemcpyDeviceToDevice, s) == 0 ? ARVAE_OK
@@ -479,12 +445,12 @@ extern "C" int arvae_measure_vae_forward(const arvae_measure_vae_t *m, int32_t b
         MV_TRY(check_launch("add_bias_rows_kernel"));
         arvae_tick_weights_t tw{P + m->tick_w_hh[0], P + m->tick_b_hh[0], P + m->tick_w_ih[1], P + m->tick_b_ih[1],
                                 P + m->tick_w_hh[1], P + m->tick_b_hh[1], P + m->out_w, P + m->out_b};
-        MV_TRY(arvae_tick_free_run(&tw, w.h0t0, w.h0t1, w.gib, w.gsm, tick_mask, dec_keep, d.b, d.nb, d.tpb, Hd, d.v, tokens, w.frws, stream));
+        MV_TRY(arvae_tick_free_run(&tw, h0t0, h0t1, both_ld, w.gib, w.gsm, tick_mask, dec_keep, d.b, d.nb, d.tpb, Hd, d.v, tokens, w.frws, stream));
     }
     MV_TRY(arvae_tick_gi_fwd(w.gsm, tokens, P + m->tick_b_ih[0], d.b, d.nb, d.tpb, d.v, 3 * Hd, w.gi0t, stream));
     g = arvae_gru_seq_t{};
     g.gi = w.gi0t; g.gi_tstride = (int64_t)d.rb * 3 * Hd;
-    g.w_hh = P + m->tick_w_hh[0]; g.b_hh = P + m->tick_b_hh[0]; g.h0 = w.h0t0;
+    g.w_hh = P + m->tick_w_hh[0]; g.b_hh = P + m->tick_b_hh[0]; g.h0 = h0t0; g.h0_stride = both_ld;
     g.h_all = w.out0t; g.h_stride = Hd; g.saved = w.svt0;
     MV_TRY(arvae_gru_seq_fwd(&g, 1, d.tpb, d.rb, Hd, stream));
     const float *midt = w.out0t;
@@ -497,24 +463,28 @@ extern "C" int arvae_measure_vae_forward(const arvae_measure_vae_t *m, int32_t b
     MV_TRY(lin_fwd(d.rt, Hd, 3 * Hd, midt, P + m->tick_w_ih[1], P + m->tick_b_ih[1], ARVAE_ACT_NONE, w.gi1t, s));
     g = arvae_gru_seq_t{};
     g.gi = w.gi1t; g.gi_tstride = (int64_t)d.rb * 3 * Hd;
-    g.w_hh = P + m->tick_w_hh[1]; g.b_hh = P + m->tick_b_hh[1]; g.h0 = w.h0t1;
+    g.w_hh = P + m->tick_w_hh[1]; g.b_hh = P + m->tick_b_hh[1]; g.h0 = h0t1; g.h0_stride = both_ld;
     g.h_all = w.out1t; g.h_stride = Hd; g.saved = w.svt1;
     MV_TRY(arvae_gru_seq_fwd(&g, 1, d.tpb, d.rb, Hd, stream));
     MV_TRY(lin_fwd(d.rt, Hd, d.v, w.out1t, P + m->out_w, P + m->out_b, ARVAE_ACT_RELU, w.probs, s));
 
-    // ---- loss terms (measure_vae_trainer.py:85-140): cross entropy over the 24*B rows (any row order), beta-KL, regulariser
-    ARVAE_LAUNCH(tick_order_i64_kernel, dim3(blocks_for(d.rt)), dim3(256), 0, s, score, d.b, d.nb, d.tpb, w.tgt);
-    MV_TRY(check_launch("tick_order_i64_kernel"));
-    MV_TRY(arvae_token_recon(w.probs, w.tgt, d.rt, d.v, w.rec_ws, w.ce_out, w.dprobs, stream));
-    MV_TRY(arvae_kld_fwd(mu, sigma, nullptr, nullptr, d.b, d.z, m->beta, capacity, w.kld_out, stream));
+    // ---- loss terms (measure_vae_trainer.py:85-140): cross entropy over the 24*B rows (in the sequence launches' row order, targets
+    // looked up through it), the attribute labels and the regulariser's pair sums, then ONE finishing launch: the partial sums,
+    // beta-KL, the regulariser's gradient and the pass's scalars
+    int nb = 0;
+    MV_TRY(token_recon_partials(w.probs, score, d.b, d.nb, d.tpb, d.v, w.rec_ws, w.dprobs, s, &nb));
     if (m->n_reg > 0) {
         MV_TRY(arvae_measure_attributes(score, d.b, d.t, tables->midi_lut, tables->is_note, tables->is_density_note, d.v,
                                         tables->rhythm_weights, tables->rhythm_norm, w.labels, stream));
-        MV_TRY(arvae_reg_loss(z, w.labels, d.b, z, w.labels, d.b, d.z, 4, m->reg_dims, m->n_reg, m->gamma, m->delta, w.reg_ws, w.reg_out,
-                              w.dz_reg, stream));
+        RegDims rd;
+        for (int i = 0; i < 16; ++i) rd.d[i] = i < m->n_reg ? m->reg_dims[i] : 0;
+        for (int i = 0; i < m->n_reg; ++i)
+            ARVAE_REQUIRE(m->reg_dims[i] >= 0 && m->reg_dims[i] < d.z && m->reg_dims[i] < 4, "measure_vae_forward: regularised dim %d outside z / the attributes",
+                          m->reg_dims[i]);
+        MV_TRY(reg_partials(z, w.labels, d.b, z, w.labels, d.b, d.z, 4, rd, m->n_reg, m->delta, w.reg_ws, s));
     }
-    ARVAE_LAUNCH(measure_scalars_kernel, dim3(1), dim3(64), 0, s, w.ce_out, w.kld_out, m->n_reg > 0 ? w.reg_out : nullptr, scalars);
-    return check_launch("measure_scalars_kernel");
+    return vae_finish(w.rec_ws, nb, d.b, d.rt, mu, sigma, d.z, m->beta, capacity, m->n_reg > 0 ? w.reg_ws : nullptr, d.b, d.z, m->reg_dims,
+                      m->n_reg, m->gamma, m->delta, 1.f, w.dz_reg, w.ce_out, w.kld_out, w.reg_out, scalars, s, d.rt);
 }
 
 extern "C" int arvae_measure_vae_backward(const arvae_measure_vae_t *m, int32_t batch, const float *params, float *grads,
@@ -551,8 +521,9 @@ extern "C" int arvae_measure_vae_backward(const arvae_measure_vae_t *m, int32_t 
     // ---- tick RNN, layer 1 then layer 0
     const float *midt = dropping ? w.midt : w.out0t;
     arvae_gru_seq_t g{};
-    g.w_hh = P + m->tick_w_hh[1]; g.h0 = w.h0t1; g.h_all = w.out1t; g.h_stride = Hd; g.saved = w.svt1;
-    g.dh_all = w.d_seq_h; g.dh_stride = Hd; g.dgi = w.dgi_t1; g.dgh = w.dgh_t1; g.dh0 = w.dh0b; g.h_prev_out = w.hprev_t1;
+    g.w_hh = P + m->tick_w_hh[1]; g.h0 = w.both + Hd; g.h0_stride = 3 * Hd; g.h_all = w.out1t; g.h_stride = Hd; g.saved = w.svt1;
+    g.dh_all = w.d_seq_h; g.dh_stride = Hd; g.dgi = w.dgi_t1; g.dgh = w.dgh_t1; g.h_prev_out = w.hprev_t1;
+    g.dh0 = w.d_both + Hd; g.dh0_stride = 3 * Hd;           // the initial states' gradients land in their columns of d_both
     MV_TRY(arvae_gru_seq_bwd(&g, 1, d.tpb, d.rb, Hd, stream));
     MV_TRY(lin_wgrad(&queue, d.rt, Hd, 3 * Hd, plain(w.dgh_t1), w.hprev_t1, G + m->tick_w_hh[1], G + m->tick_b_hh[1], s));
     MV_TRY(lin_dgrad(d.rt, Hd, 3 * Hd, plain(w.dgi_t1), P + m->tick_w_ih[1], w.d_mid_t, s));
@@ -565,8 +536,9 @@ extern "C" int arvae_measure_vae_backward(const arvae_measure_vae_t *m, int32_t 
         d_out0t = w.d_seq_h;
     }
     g = arvae_gru_seq_t{};
-    g.w_hh = P + m->tick_w_hh[0]; g.h0 = w.h0t0; g.h_all = w.out0t; g.h_stride = Hd; g.saved = w.svt0;
-    g.dh_all = d_out0t; g.dh_stride = Hd; g.dgi = w.dgi_t0; g.dgh = w.dgh_t0; g.dh0 = w.dh0a; g.h_prev_out = w.hprev_t0;
+    g.w_hh = P + m->tick_w_hh[0]; g.h0 = w.both; g.h0_stride = 3 * Hd; g.h_all = w.out0t; g.h_stride = Hd; g.saved = w.svt0;
+    g.dh_all = d_out0t; g.dh_stride = Hd; g.dgi = w.dgi_t0; g.dgh = w.dgh_t0; g.h_prev_out = w.hprev_t0;
+    g.dh0 = w.d_both; g.dh0_stride = 3 * Hd;
     MV_TRY(arvae_gru_seq_bwd(&g, 1, d.tpb, d.rb, Hd, stream));
     MV_TRY(lin_wgrad(&queue, d.rt, Hd, 3 * Hd, plain(w.dgh_t0), w.hprev_t0, G + m->tick_w_hh[0], G + m->tick_b_hh[0], s));
     // layer 0's input projection: per-tick gradients summed per previous note and per beat row, then the small product's adjoints
@@ -577,12 +549,8 @@ extern "C" int arvae_measure_vae_backward(const arvae_measure_vae_t *m, int32_t 
     }
     MV_TRY(lin_wgrad(&queue, d.ns, d.e + Hd, 3 * Hd, plain(w.dg_small), w.xs, G + m->tick_w_ih[0], nullptr, s));
     MV_TRY(lin_dgrad(d.ns, d.e + Hd, 3 * Hd, plain(w.dg_small), P + m->tick_w_ih[0], w.dx_small, s));
-    MV_TRY(arvae_tick_rows_bwd(w.dx_small, d.v, d.e, Hd, d.rb, G + m->dec_table, G + m->x0, w.d_beat_emb, stream));
-    // initial states + beat-embedding input: one SELU layer on the beat outputs
-    ARVAE_LAUNCH(concat3_kernel, dim3(blocks_for((int64_t)d.rb * 3 * Hd / 4)), dim3(256), 0, s, reinterpret_cast<const float4 *>(w.dh0a),
-                 reinterpret_cast<const float4 *>(w.dh0b), reinterpret_cast<const float4 *>(w.d_beat_emb), (int64_t)d.rb, Hd / 4, Hd / 4,
-                 Hd / 4, reinterpret_cast<float4 *>(w.d_both));
-    MV_TRY(check_launch("concat3_kernel"));
+    MV_TRY(arvae_tick_rows_bwd(w.dx_small, d.v, d.e, Hd, d.rb, G + m->dec_table, G + m->x0, w.d_both + 2 * Hd, 3 * Hd, stream));
+    // initial states + beat-embedding input: one SELU layer on the beat outputs (d_both is complete: three column blocks)
     MV_TRY(lin_dgrad(d.rb, Hd, 3 * Hd, gated(w.d_both, w.both, ARVAE_ACT_SELU), P + m->tick_init_w, w.d_rows_h, s));
     MV_TRY(lin_wgrad(&queue, d.rb, Hd, 3 * Hd, gated(w.d_both, w.both, ARVAE_ACT_SELU), w.beat_out, G + m->tick_init_w, G + m->tick_init_b,
                      s));
@@ -590,8 +558,9 @@ extern "C" int arvae_measure_vae_backward(const arvae_measure_vae_t *m, int32_t 
     // ---- beat RNN, layer 1 then layer 0 (their batch-sized weight gradients wait in the queue: separate buffers per layer)
     const float *midb = dropping ? w.midb : w.out0b;
     g = arvae_gru_seq_t{};
-    g.w_hh = P + m->beat_w_hh[1]; g.h0 = w.h0b1; g.h_all = w.beat_out; g.h_stride = Hd; g.saved = w.svb1;
-    g.dh_all = w.d_rows_h; g.dh_stride = Hd; g.dgi = w.dgi_b1; g.dgh = w.dgh_b1; g.dh0 = w.dh0b; g.h_prev_out = w.hprev_b1;
+    g.w_hh = P + m->beat_w_hh[1]; g.h0 = w.flatb + Hd; g.h0_stride = 2 * Hd; g.h_all = w.beat_out; g.h_stride = Hd; g.saved = w.svb1;
+    g.dh_all = w.d_rows_h; g.dh_stride = Hd; g.dgi = w.dgi_b1; g.dgh = w.dgh_b1; g.h_prev_out = w.hprev_b1;
+    g.dh0 = w.d_flatb + Hd; g.dh0_stride = 2 * Hd;
     MV_TRY(arvae_gru_seq_bwd(&g, 1, d.nb, d.b, Hd, stream));
     MV_TRY(lin_wgrad(&queue, d.rb, Hd, 3 * Hd, plain(w.dgh_b1), w.hprev_b1, G + m->beat_w_hh[1], G + m->beat_b_hh[1], s));
     MV_TRY(lin_dgrad(d.rb, Hd, 3 * Hd, plain(w.dgi_b1), P + m->beat_w_ih[1], w.d_mid_b, s));
@@ -602,8 +571,9 @@ extern "C" int arvae_measure_vae_backward(const arvae_measure_vae_t *m, int32_t 
         d_out0b = w.d_rows_h;
     }
     g = arvae_gru_seq_t{};
-    g.w_hh = P + m->beat_w_hh[0]; g.h0 = w.h0b0; g.h_all = w.out0b; g.h_stride = Hd; g.saved = w.svb0;
-    g.dh_all = d_out0b; g.dh_stride = Hd; g.dgi = w.dgi_b0; g.dgh = w.dgh_b0; g.dh0 = w.dh0a; g.h_prev_out = w.hprev_b0;
+    g.w_hh = P + m->beat_w_hh[0]; g.h0 = w.flatb; g.h0_stride = 2 * Hd; g.h_all = w.out0b; g.h_stride = Hd; g.saved = w.svb0;
+    g.dh_all = d_out0b; g.dh_stride = Hd; g.dgi = w.dgi_b0; g.dgh = w.dgh_b0; g.h_prev_out = w.hprev_b0;
+    g.dh0 = w.d_flatb; g.dh0_stride = 2 * Hd;
     MV_TRY(arvae_gru_seq_bwd(&g, 1, d.nb, d.b, Hd, stream));
     MV_TRY(lin_wgrad(&queue, d.rb, Hd, 3 * Hd, plain(w.dgh_b0), w.hprev_b0, G + m->beat_w_hh[0], G + m->beat_b_hh[0], s));
     // the constant input b_0 (decoder.py:436-440): the projection's gradients over all beats*batch rows (x0b holds b_0 once per row)
@@ -613,7 +583,6 @@ extern "C" int arvae_measure_vae_backward(const arvae_measure_vae_t *m, int32_t 
         const arvae_operand_t dx0 = plain(w.d_x0);
         MV_TRY(arvae_channel_sum(&dx0, d.rb, 1, 0, 0, G + m->b0, w.cs_ws, stream));
     }
-    MV_TRY(arvae_concat_cols(w.dh0a, w.dh0b, d.b, Hd, Hd, w.d_flatb, stream));
     MV_TRY(lin_dgrad(d.b, d.z, 2 * Hd, gated(w.d_flatb, w.flatb, ARVAE_ACT_SELU), P + m->z2beat_w, w.d_z, s));
     MV_TRY(lin_wgrad(&queue, d.b, d.z, 2 * Hd, gated(w.d_flatb, w.flatb, ARVAE_ACT_SELU), z, G + m->z2beat_w, G + m->z2beat_b, s));
 

@@ -222,8 +222,8 @@ __global__ __launch_bounds__(256) void embed_bwd_wide_kernel(const int64_t *__re
 // summed over the ticks of a beat (beat rows) and per previous note (the wide segment sum above, tick order) into dG; dX = dG W_ih0
 // splits into the embedding table's, x_0's and the beat embedding's gradients (tick_rows_bwd).
 __global__ __launch_bounds__(256) void tick_rows_fwd_kernel(const float *__restrict__ table, const float *__restrict__ x0,
-                                                             const float *__restrict__ beat_emb, int vocab, int emb, int hidden, int rows,
-                                                             float *__restrict__ x) {
+                                                             const float *__restrict__ beat_emb, int64_t beat_stride, int vocab, int emb,
+                                                             int hidden, int rows, float *__restrict__ x) {
     const int cols = emb + hidden;
     const int64_t total = (int64_t)(vocab + 1 + rows) * cols;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -231,13 +231,13 @@ __global__ __launch_bounds__(256) void tick_rows_fwd_kernel(const float *__restr
         float v = 0.f;
         if (r < vocab) v = c < emb ? table[r * emb + c] : 0.f;
         else if (r == vocab) v = c < emb ? x0[c] : 0.f;
-        else v = c >= emb ? beat_emb[(int64_t)(r - vocab - 1) * hidden + c - emb] : 0.f;
+        else v = c >= emb ? beat_emb[(int64_t)(r - vocab - 1) * beat_stride + c - emb] : 0.f;
         x[i] = v;
     }
 }
 __global__ __launch_bounds__(256) void tick_rows_bwd_kernel(const float *__restrict__ dx, int vocab, int emb, int hidden, int rows,
                                                              float *__restrict__ dtable, float *__restrict__ dx0,
-                                                             float *__restrict__ dbeat) {
+                                                             float *__restrict__ dbeat, int64_t dbeat_stride) {
     const int cols = emb + hidden;
     const int64_t n_tab = (int64_t)(vocab + 1) * emb, total = n_tab + (int64_t)rows * hidden;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void tick_rows_bwd_kernel(const float *__restr
         } else {
             const int64_t k = i - n_tab;
             const int r = (int)(k / hidden), c = (int)(k - (int64_t)r * hidden);
-            dbeat[k] = dx[(int64_t)(vocab + 1 + r) * cols + emb + c];
+            dbeat[(int64_t)r * dbeat_stride + c] = dx[(int64_t)(vocab + 1 + r) * cols + emb + c];
         }
     }
 }
@@ -459,19 +459,19 @@ extern "C" int arvae_embed_bwd(const int64_t *idx, const float *g, int32_t batch
     return check_launch("embed_bwd_wide_kernel");
 }
 
-extern "C" int arvae_tick_rows_fwd(const float *table, const float *x0, const float *beat_emb, int32_t vocab, int32_t emb,
+extern "C" int arvae_tick_rows_fwd(const float *table, const float *x0, const float *beat_emb, int64_t beat_emb_stride, int32_t vocab, int32_t emb,
                                    int32_t hidden, int32_t rows, float *x_small, arvae_stream_t stream) {
     ARVAE_REQUIRE(table && x0 && beat_emb && x_small && vocab > 0 && emb > 0 && hidden > 0 && rows > 0, "tick_rows_fwd: bad argument");
     ARVAE_LAUNCH(tick_rows_fwd_kernel, dim3(blocks_for((int64_t)(vocab + 1 + rows) * (emb + hidden))), dim3(256), 0, as_stream(stream), table,
-                 x0, beat_emb, vocab, emb, hidden, rows, x_small);
+                 x0, beat_emb, beat_emb_stride != 0 ? beat_emb_stride : (int64_t)hidden, vocab, emb, hidden, rows, x_small);
     return check_launch("tick_rows_fwd_kernel");
 }
 
 extern "C" int arvae_tick_rows_bwd(const float *dx_small, int32_t vocab, int32_t emb, int32_t hidden, int32_t rows, float *dtable,
-                                   float *dx0, float *dbeat_emb, arvae_stream_t stream) {
+                                   float *dx0, float *dbeat_emb, int64_t dbeat_emb_stride, arvae_stream_t stream) {
     ARVAE_REQUIRE(dx_small && dbeat_emb && vocab > 0 && emb > 0 && hidden > 0 && rows > 0, "tick_rows_bwd: bad argument");
     ARVAE_LAUNCH(tick_rows_bwd_kernel, dim3(blocks_for((int64_t)(vocab + 1) * emb + (int64_t)rows * hidden)), dim3(256), 0,
-                 as_stream(stream), dx_small, vocab, emb, hidden, rows, dtable, dx0, dbeat_emb);
+                 as_stream(stream), dx_small, vocab, emb, hidden, rows, dtable, dx0, dbeat_emb, dbeat_emb_stride != 0 ? dbeat_emb_stride : (int64_t)hidden);
     return check_launch("tick_rows_bwd_kernel");
 }
 

@@ -119,10 +119,10 @@ class MeasureVAETrainer(Trainer):
             cols.append(self.attr_dict[name])
         return labels[:, cols]
 
-    def fused_executor(self, score):
-        """the whole-model executor bound to this trainer's arena, or None when this step takes the per-layer path: data
-        parallel runs (their collectives sit between the layers), debug checks, CPU models, unsupported shapes."""
-        if not self.use_fused_step or self.data_parallel is not None or not score.is_cuda or ops.checks_enabled():
+    def _fused_binding(self):
+        """the whole-model executor bound to this trainer's arena and hyper-parameters, or None when the steps take the per-layer
+        path: data parallel runs (their collectives sit between the layers), debug checks, CPU models, unsupported shapes."""
+        if not self.use_fused_step or self.data_parallel is not None or ops.checks_enabled():
             return None
         if self.use_reg_loss and type(self.reg_dim) != tuple:
             return None                                            # (the per-layer path raises the reference's TypeError)
@@ -134,13 +134,24 @@ class MeasureVAETrainer(Trainer):
             usable = (_use_sequence_kernels(self.model.encoder.rnn_hidden_size) and next(self.model.parameters()).is_cuda
                       and FusedMeasureVAE.supports(self.model, self.optimizer, reg_dims) is None)
             self._fused = (key, FusedMeasureVAE(self.model, self.optimizer, reg_dims, self.beta, self.gamma, self.delta) if usable else None)
-        fused = self._fused[1]
+        return self._fused[1]
+
+    def fused_executor(self, score):
+        """-> the executor for a step on `score` (B, 24), or None: this step takes the per-layer path"""
+        fused = self._fused_binding() if score.is_cuda else None
         if fused is None or not fused.fits(score.shape[0]):
             return None
         enc, dec = self.model.encoder, self.model.decoder
         if bool(enc._mask_queue) != bool(dec._mask_queue):
             return None                                            # explicit keep-masks for one half only: per-layer path
         return fused
+
+    def _replay_step(self, batch):
+        # the executor issues a step's launches from two library calls: a captured graph has no host work left to save and its
+        # nodes cost more than the stream launches they replace (B = 256: 1.09 ms eager, 1.11 ms replayed)
+        if self._fused_binding() is not None:
+            return None
+        return super()._replay_step(batch)
 
     def _fused_loss_and_acc(self, fused, score, epoch_num, first_of_epoch, train):
         from .fused_measure import ACC, DIST, RECON, REG

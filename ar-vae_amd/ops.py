@@ -797,7 +797,7 @@ def tick_free_run(weights, h0_l0, h0_l1, gib, ptab, mask, keep_scale, batch, bea
     tokens = torch.empty(batch, beats * ticks_per_beat, device=gib.device, dtype=torch.int64)
     ws = torch.empty(lib.arvae_tick_free_run_ws_floats(hid), device=gib.device, dtype=torch.float32)
     with _timed('tick_free_run', 2.0 * batch * beats * ticks_per_beat * (9 * hid * hid + vocab * hid), 0.0):
-        _lib.check(lib.arvae_tick_free_run(ctypes.byref(tw), _ptr(h0_l0), _ptr(h0_l1), _ptr(gib), _ptr(ptab), _ptr(mask),
+        _lib.check(lib.arvae_tick_free_run(ctypes.byref(tw), _ptr(h0_l0), _ptr(h0_l1), 0, _ptr(gib), _ptr(ptab), _ptr(mask),
                                            float(keep_scale), batch, beats, ticks_per_beat, hid, vocab, _ptr(tokens),
                                            _ptr(ws), _stream()), 'tick_free_run')
     return tokens
@@ -859,7 +859,7 @@ class _TickInputFn(Function):
         n = vocab + 1 + rows
         dev = table.device
         x_small = torch.empty(n, emb + hid, device=dev, dtype=torch.float32)
-        _lib.check(lib.arvae_tick_rows_fwd(_ptr(table), _ptr(x0), _ptr(beat_emb), vocab, emb, hid, rows, _ptr(x_small), _stream()),
+        _lib.check(lib.arvae_tick_rows_fwd(_ptr(table), _ptr(x0), _ptr(beat_emb), 0, vocab, emb, hid, rows, _ptr(x_small), _stream()),
                    'tick_rows_fwd')
         link = Link.dense(emb + hid, cols)
         g_small = link_down(link, n, _operand(x_small), w_ih, None, ACT_NONE, None)
@@ -903,7 +903,7 @@ class _TickInputFn(Function):
         tbuf, tdirect = _grad_target(table) if ctx.needs_input_grad[0] else (None, True)
         xbuf, xdirect = _grad_target(x0) if ctx.needs_input_grad[1] else (None, True)
         d_beat = torch.empty(rows, hid, device=dev, dtype=torch.float32)
-        _lib.check(lib.arvae_tick_rows_bwd(_ptr(dx), vocab, emb, hid, rows, _ptr(tbuf), _ptr(xbuf), _ptr(d_beat), _stream()),
+        _lib.check(lib.arvae_tick_rows_bwd(_ptr(dx), vocab, emb, hid, rows, _ptr(tbuf), _ptr(xbuf), _ptr(d_beat), 0, _stream()),
                    'tick_rows_bwd')
         return (None if tdirect else tbuf), (None if xdirect else xbuf), d_beat, d_w, d_b, None, None, None
 

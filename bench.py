@@ -427,7 +427,9 @@ def side_roofline(kind, prof, prof_steps, batch):
 def run_side(kind, device, args, fence, rank, world, use_dp, with_cpu):
     """one secondary workload -> its result dict (the main line when selected with --workload)"""
     bsz = args.batch if (args.workload == kind and args.batch != 512) else SIDE_BATCH[kind]
-    graphs = kind == 'measure' and not args.no_graphs         # (data-parallel steps replay too: their collectives are recorded, graphed.py)
+    # MeasureVAE: a single-process step is two library calls (the whole-model executor): eager.  Data-parallel steps take the
+    # per-layer path, a hundred launches the host must issue: replayed from HIP graphs, their collectives recorded with them
+    graphs = kind == 'measure' and not args.no_graphs and (use_dp or args.graphs)
     step, eager, unit = build_side_workload(kind, device, bsz, rank, use_dp, graphs)
     steps = args.steps if args.workload == kind else max(10, min(args.steps, 50))
     med, timing, loss = timed_regions(step, steps, args.warmup, fence, args.min_seconds)
@@ -441,13 +443,16 @@ def run_side(kind, device, args, fence, rank, world, use_dp, with_cpu):
            'steps': steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * med / steps, 'higher_is_better': True,
            'scaling': 'weak', 'vs_baseline': None,
            'dtype': ('f32 (wide conv MFMAs: scaled 2-term fp16 split, 3 products; narrow conv / Linear: 3-term bf16 split, 6 products; fp32-accurate)'
-                     if kind == 'mnist' else 'f32 (MFMAs: 3-term bf16 split, 6 products, fp32-accurate)'), 'data': 'synthetic',
+                     if kind == 'mnist' else
+                     'f32 (forward recurrences: scaled 2-term fp16 split, 3 products; backward recurrences, Linear layers: 3-term bf16 split, 6 products; fp32-accurate)'),
+           'data': 'synthetic',
            'config': {'workload': ('Morpho-MNIST AR-VAE full training step, 1x28x28 inputs, z=16, reg_dim=(1..6), dropout 0.5'
                                    if kind == 'mnist' else
                                    'FolkNBar MeasureVAE full training step, 24-tick measures, V=35, z=32, reg_dim=(0..3), '
                                    'dropout 0.5, teacher forcing p=0.5'),
                       'per_gpu_batch': bsz, 'global_batch': bsz * world, 'parallelism': f'dp{world}',
-                      'launch': 'hip-graph replay of fwd+bwd' if graphs else 'eager', 'final_loss': float(loss.detach())},
+                      'launch': 'hip-graph replay of fwd+bwd' if graphs else ('eager' if (kind == 'mnist' or use_dp) else 'eager, whole-model executor (two library calls per step)'),
+                      'final_loss': float(loss.detach())},
            'timing': timing,
            # whole-step fractions of the datasheet roofs (SURVEY 8(d) algorithmic FLOP / layer-boundary bytes per unit)
            'step_roofline': {'flop_per_unit': flop, 'bytes_per_unit': byts,
@@ -681,7 +686,8 @@ def main():
     ap.add_argument('--breakdown', action='store_true', help='print the per-kernel-family table to stderr')
     ap.add_argument('--force-dp', action='store_true',
                     help='run the data-parallel code path (RCCL all-gather + all-reduce) even with one rank')
-    ap.add_argument('--no-graphs', action='store_true', help='measure workload: eager launches instead of HIP-graph replay')
+    ap.add_argument('--no-graphs', action='store_true', help='measure workload: eager launches also under data parallelism')
+    ap.add_argument('--graphs', action='store_true', help='measure workload: HIP-graph replay of the single-process step as well')
     ap.add_argument('--workload', default='dsprites', choices=['dsprites', 'mnist', 'measure'],
                     help='dsprites = the headline metric (default); mnist / measure = BASELINE.json configs[2] / configs[4]')
     args = ap.parse_args()

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ARVAE_ABI_VERSION 9   /* 9: arvae_measure_vae_* (whole-model MeasureVAE step); 8: arvae_gru_seq_t.gi_rstride / dgi_rstride / h_fin (merged input projections of a bidirectional layer, final states written by the sequence launch); 7: arvae_comm_* (the data-parallel step's collectives: RCCL on the launch stream, owned by the library); 6: the 32-channel k4 s2 p1 links need caller workspace too (arvae_link_ws_floats / arvae_link_wgrad_ws_floats: the layer's weights as scaled fp16 terms and the operands' maxima); 5: arvae_adam_step(zero_grad), arvae_image_vae_finish, arvae_image_vae_t.milestones (events the executors record for the data-parallel caller's collectives); 4: arvae_philox_* and in-kernel eps (arvae_image_vae_t.rng_*), arvae_tick_free_run_supported, caller workspace for arvae_link_down/up (arvae_link_ws_floats); 3: arvae_gru_seq_*, embed_bwd workspace; 2: arvae_image_vae_backward reg_fused == 2 (unit regulariser gradient in dz_extra) */
+#define ARVAE_ABI_VERSION 9   /* 9: arvae_measure_vae_* (whole-model MeasureVAE step), row strides for h0 / dh0 / the beat embeddings (arvae_gru_seq_t, arvae_tick_*); 8: arvae_gru_seq_t.gi_rstride / dgi_rstride / h_fin (merged input projections of a bidirectional layer, final states written by the sequence launch); 7: arvae_comm_* (the data-parallel step's collectives: RCCL on the launch stream, owned by the library); 6: the 32-channel k4 s2 p1 links need caller workspace too (arvae_link_ws_floats / arvae_link_wgrad_ws_floats: the layer's weights as scaled fp16 terms and the operands' maxima); 5: arvae_adam_step(zero_grad), arvae_image_vae_finish, arvae_image_vae_t.milestones (events the executors record for the data-parallel caller's collectives); 4: arvae_philox_* and in-kernel eps (arvae_image_vae_t.rng_*), arvae_tick_free_run_supported, caller workspace for arvae_link_down/up (arvae_link_ws_floats); 3: arvae_gru_seq_*, embed_bwd workspace; 2: arvae_image_vae_backward reg_fused == 2 (unit regulariser gradient in dz_extra) */
 
 #define ARVAE_OK 0
 #define ARVAE_E_INVALID (-1)  /* bad argument (null pointer, size out of range, unsupported shape) */
@@ -259,6 +259,9 @@ typedef struct arvae_gru_seq {
     int64_t gi_rstride, dgi_rstride;
     float *h_fin;         /* fwd out, optional: the state after the last processed step (nn.GRU's h_n), row r at h_fin + r*h_fin_stride */
     int64_t h_fin_stride;
+    /* floats between two rows of h0 / of dh0; 0 = hidden.  Lets the initial states be column blocks of the Linear layer's output that
+     * makes them (measurevae/decoder.py:388-406 view(B, 2, H)) and their gradients column blocks of that layer's output gradient */
+    int64_t h0_stride, dh0_stride;
 } arvae_gru_seq_t;
 int arvae_gru_seq_supported(int32_t hidden);
 int arvae_gru_seq_fwd(const arvae_gru_seq_t *seqs, int32_t nseq, int32_t steps, int32_t rows, int32_t hidden,
@@ -284,7 +287,8 @@ int64_t arvae_tick_free_run_ws_floats(int32_t hidden);
  * otherwise the caller runs the decoder tick by tick (arvae_gru_gates_fwd + arvae_row_argmax), as the reference does
  * (measurevae/decoder.py:469-525). */
 int arvae_tick_free_run_supported(int32_t hidden, int32_t vocab);
-int arvae_tick_free_run(const arvae_tick_weights_t *weights, const float *h0_l0, const float *h0_l1, const float *gib,
+int arvae_tick_free_run(const arvae_tick_weights_t *weights, const float *h0_l0, const float *h0_l1, int64_t h0_stride /* 0 = hidden */,
+                        const float *gib,
                         const float *ptab, const uint8_t *mask, float keep_scale, int32_t batch, int32_t beats,
                         int32_t ticks_per_beat, int32_t hidden, int32_t vocab, int64_t *tokens, float *ws,
                         arvae_stream_t stream);
@@ -314,10 +318,10 @@ int arvae_embed_bwd(const int64_t *idx, const float *g, int32_t batch, int32_t s
  * note in a fixed order, per beat row over its ticks); dx_small = dg_small W_ih0 (arvae_link_up) is split by arvae_tick_rows_bwd
  * into the table's and x_0's gradients (ADDED; either may be NULL) and the beat embedding's (written).
  * cols (= 3 * hidden of the tick RNN) must be a multiple of 4; ws: arvae_tick_gi_bwd_ws_floats(vocab, cols) floats. */
-int arvae_tick_rows_fwd(const float *table, const float *x0, const float *beat_emb, int32_t vocab, int32_t emb, int32_t hidden,
-                        int32_t rows, float *x_small, arvae_stream_t stream);
+int arvae_tick_rows_fwd(const float *table, const float *x0, const float *beat_emb, int64_t beat_emb_stride /* floats between rows, 0 = hidden */,
+                        int32_t vocab, int32_t emb, int32_t hidden, int32_t rows, float *x_small, arvae_stream_t stream);
 int arvae_tick_rows_bwd(const float *dx_small, int32_t vocab, int32_t emb, int32_t hidden, int32_t rows, float *dtable, float *dx0,
-                        float *dbeat_emb, arvae_stream_t stream);
+                        float *dbeat_emb, int64_t dbeat_emb_stride /* 0 = hidden */, arvae_stream_t stream);
 int arvae_tick_gi_fwd(const float *g_small, const int64_t *tokens, const float *bias, int32_t batch, int32_t beats,
                       int32_t ticks_per_beat, int32_t vocab, int32_t cols, float *gi, arvae_stream_t stream);
 int64_t arvae_tick_gi_bwd_ws_floats(int32_t vocab, int32_t cols);

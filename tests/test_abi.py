@@ -42,7 +42,7 @@ def test_ctypes_structs_match_the_header(tmp_path):
     if gcc is None:
         pytest.skip('gcc not available')
     structs = {'arvae_link_t': (_lib.LinkDesc, 'n', 'lo_perm_hw'), 'arvae_operand_t': (_lib.OperandDesc, 'v', 'act'),
-               'arvae_gru_seq_t': (_lib.GruSeqDesc, 'gi', 'h_fin_stride'),
+               'arvae_gru_seq_t': (_lib.GruSeqDesc, 'gi', 'dh0_stride'),
                'arvae_tick_weights_t': (_lib.TickWeights, 'w_hh0', 'b_out'),
                'arvae_dense_wgrad_job_t': (_lib.DenseWgradJob, 'g', 'n_out'),
                'arvae_image_vae_t': (_lib.ImageVaeDesc, 'n_enc', 'milestones'),
@@ -102,7 +102,7 @@ def test_argument_validation_without_gpu(lib):
     assert lib.arvae_gru_seq_fwd(seqs, 1, 24, 16, 128, None) == -1 and b'null' in lib.arvae_last_error_string()
     assert lib.arvae_gru_seq_fwd(seqs, 1, 24, 16, 100, None) == -1 and b'hidden size' in lib.arvae_last_error_string()
     assert lib.arvae_gru_seq_bwd(seqs, 5, 24, 16, 128, None) == -1
-    assert lib.arvae_tick_free_run(ctypes.byref(TickWeights()), None, None, None, None, None, 2.0, 8, 4, 6, 128, 35, None,
+    assert lib.arvae_tick_free_run(ctypes.byref(TickWeights()), None, None, 0, None, None, None, 2.0, 8, 4, 6, 128, 35, None,
                                    None, None) == -1
     assert lib.arvae_tick_free_run_ws_floats(128) == 3 * 3 * 128 * 128 * 3 // 2
     assert lib.arvae_embed_bwd_ws_floats(256, 24, 10, 35) == (256 * 24 // 64) * 35 * 10

@@ -997,9 +997,11 @@ def test_measure_forward_outputs_vs_golden(golden_dir, dev):
 
 
 # ---------------------------------------------------------------- data-parallel path on one GPU
-def test_graphed_measure_step_matches_eager(dev):
+@pytest.mark.parametrize('fused', [False, True], ids=['per_layer', 'executor'])
+def test_graphed_measure_step_matches_eager(dev, fused):
     """HIP-graph replay of the MeasureVAE forward + backward (arvae_amd.graphed) against the eager step: same kernels
-    in the same order, so loss and gradients are bit-identical (dropout off, fixed noise buffer, coin pinned)."""
+    in the same order, so loss and gradients are bit-identical (dropout off, fixed noise buffer, coin pinned).  Both the per-layer
+    path (a hundred launches: what the trainers replay under data parallelism) and the whole-model executor's two calls."""
     from arvae_amd.graphed import GraphedStep
     from arvae_amd.measure_vae import MeasureVAE
     from arvae_amd.measure_vae_trainer import MeasureVAETrainer
@@ -1009,6 +1011,7 @@ def test_graphed_measure_step_matches_eager(dev):
     trainer = MeasureVAETrainer(ds, model, lr=1e-4, reg_type=('all',), reg_dim=(0, 1, 2, 3), beta=0.001, gamma=1.0,
                                 capacity=0.0, rand=0, delta=10.0)
     trainer.cuda()
+    trainer.use_fused_step = fused
     model.train()
     b = 32
     model.encoder.static_eps = torch.from_numpy(syn.normal_noise((b, 16), seed=3)).to(dev)
@@ -1050,6 +1053,7 @@ def test_measure_epoch_loop_replays_graphs(dev):
                                     capacity=0.0, rand=0, delta=10.0)
         assert trainer.use_graph_replay
         trainer.use_graph_replay = replay
+        trainer.use_fused_step = False        # the per-layer path (what data-parallel steps run): the whole-model executor is not replayed
         trainer.cuda()
         model.train()
         model.decoder.teacher_forcing_prob = 2.0
@@ -1241,6 +1245,7 @@ def test_epoch_means_under_graph_replay_equal_eager(dev):
         trainer = MeasureVAETrainer(ds, model, lr=1e-3, reg_type=('all',), reg_dim=(0, 1, 2, 3), beta=0.001, gamma=1.0,
                                     capacity=0.0, rand=0, delta=10.0)
         trainer.use_graph_replay = replay
+        trainer.use_fused_step = False
         trainer.cuda()
         model.train()
         model.decoder.teacher_forcing_prob = 2.0
@@ -1591,6 +1596,7 @@ def test_measure_train_model_two_epochs_track_the_oracle(dev, tmp_path, monkeypa
     trainer = MeasureVAETrainer(ds, model, lr=1e-4, reg_type=('all',), reg_dim=(0, 1, 2, 3), beta=0.001, gamma=1.0,
                                 capacity=0.0, rand=0, delta=10.0)
     trainer.use_graph_replay = replay
+    trainer.use_fused_step = not replay       # replayed: the per-layer path from HIP graphs; eager: the whole-model executor
     trainer.cuda()
     model.decoder.teacher_forcing_prob = 2.0
     means = []
