@@ -259,6 +259,10 @@ struct ConvWgrad {
     Operand lo, hi;
     int n, lh, lw, clo, hh, hw, chi, kh, kw, pad;
     float *ws;                   // [slices][taps][clo][chi]
+    // the paired-rows kernel only: bias gradient riding along.  bias_side 1: column sums of lo (the workgroups of chi half 0),
+    // 2: of hi (each chi half its own 32 channels); partials at bias_ws[slice][64], added to dbias by the reduction launch
+    float *bias_ws;
+    int bias_side;
 };
 
 template <bool PLAIN_LO, bool PLAIN_HI>
@@ -326,17 +330,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_x3_kernel(ConvWgrad g) {
 
 // dwt[clo][chi][tap] += sum_slices ws[slice][tap][clo][chi]; 4 lanes per element, fixed order
 __global__ __launch_bounds__(256) void conv64_wgrad_reduce_kernel(const float *__restrict__ ws, int slices, int taps, int clo, int chi,
-                                                                   float *__restrict__ dwt) {
-    const int count = taps * clo * chi;
+                                                                   float *__restrict__ dwt, const float *__restrict__ bias_ws = nullptr,
+                                                                   int nbias = 0, float *__restrict__ dbias = nullptr) {
+    // elements [count, count + nbias): the bias partials the paired-rows kernel left at bias_ws[slice][64]
+    const int count = taps * clo * chi, total = count + nbias;
     const int i = (blockIdx.x * 256 + threadIdx.x) >> 2, q4 = threadIdx.x & 3;
-    const int ic = i < count ? i : 0;
+    const bool is_bias = i >= count;
+    const int ic = i < total ? (is_bias ? i - count : i) : 0;
+    const float *src = is_bias ? bias_ws : ws;
+    const int64_t pitch = is_bias ? 64 : count;
     float s = 0.f;
     for (int z0 = q4; z0 < slices; z0 += 32) {
         float t[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int z = z0 + 4 * u;
-            const float v = ws[(int64_t)(z < slices ? z : 0) * count + ic];
+            const float v = src[(int64_t)(z < slices ? z : 0) * pitch + ic];
             t[u] = z < slices ? v : 0.f;
         }
 #pragma unroll
@@ -344,7 +353,11 @@ __global__ __launch_bounds__(256) void conv64_wgrad_reduce_kernel(const float *_
     }
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
-    if (q4 != 0 || i >= count) return;
+    if (q4 != 0 || i >= total) return;
+    if (is_bias) {
+        dbias[ic] += s;
+        return;
+    }
     const int c = i % chi, a = (i / chi) % clo, tap = i / (chi * clo);       // ws index (tap, clo, chi)
     dwt[((int64_t)a * chi + c) * taps + tap] += s;
 }
@@ -562,7 +575,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_pairs_h2_kernel(ConvWgrad g, i
             vhi[which][i] = load_src4<PLAIN_HI>(g.hi, (((int64_t)n * g.hh + hy) * g.hw + hx) * g.chi + ch0 + hi_c, ok);
         }
     };
+    // bias gradient riding along: every lo / hi row passes through a commit exactly once (rows outside the tensor as zeros)
+    float4 bsum[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const bool bias_lo = g.bias_side == 1 && blockIdx.x == 0, bias_hi = g.bias_side == 2;
     auto commit_lo = [&](int which, int buf) __attribute__((always_inline)) {
+        if (bias_lo) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                bsum[i].x += vlo[which][i].x; bsum[i].y += vlo[which][i].y; bsum[i].z += vlo[which][i].z; bsum[i].w += vlo[which][i].w;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             if (lo_r[i] < g.lw)
@@ -571,6 +593,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_pairs_h2_kernel(ConvWgrad g, i
     auto ring_of = [&](int hy) { return hi_ring + ((hy + 4 * WP_RING) & (WP_RING - 1)) * 2 * WP_HPLANE; };
     auto commit_hi = [&](int which, int hy) __attribute__((always_inline)) {
         unsigned short *img = ring_of(hy);
+        if (bias_hi) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                bsum[i].x += vhi[which][i].x; bsum[i].y += vhi[which][i].y; bsum[i].z += vhi[which][i].z; bsum[i].w += vhi[which][i].w;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             if (hi_r[i] < WR_HROWS) wp_commit_h2(img + hi_r[i] * WP_HTRP + hi_c, WP_HPLANE, vhi[which][i], sc_h.s);
@@ -675,6 +703,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_pairs_h2_kernel(ConvWgrad g, i
                 }
         }
     }
+    if (bias_lo || bias_hi) {
+        // a thread holds 4 channels of its pixel rows: lo 16 channel groups x 16 row groups, hi 8 x 32; summed in a fixed order
+        __syncthreads();
+        float4 *red = reinterpret_cast<float4 *>(wp_lds);
+        red[threadIdx.x] = float4{bsum[0].x + bsum[1].x, bsum[0].y + bsum[1].y, bsum[0].z + bsum[1].z, bsum[0].w + bsum[1].w};
+        __syncthreads();
+        const int groups = bias_lo ? 16 : 8, rows = 256 / groups;
+        if ((int)threadIdx.x < groups) {
+            float4 tot = red[threadIdx.x];
+            for (int j = 1; j < rows; ++j) {
+                const float4 v = red[j * groups + threadIdx.x];
+                tot.x += v.x; tot.y += v.y; tot.z += v.z; tot.w += v.w;
+            }
+            const int c = (bias_lo ? 0 : ch0) + 4 * threadIdx.x;
+            const int cmax = bias_lo ? g.clo : g.chi;
+            float *dst = g.bias_ws + (int64_t)blockIdx.y * 64 + c;
+            if (c + 3 < cmax) *reinterpret_cast<float4 *>(dst) = tot;
+            else { if (c < cmax) dst[0] = tot.x; if (c + 1 < cmax) dst[1] = tot.y; if (c + 2 < cmax) dst[2] = tot.z; }
+        }
+    }
 }
 
 // images per workgroup: one workgroup per CU (256) when the batch allows it
@@ -701,13 +749,15 @@ int64_t conv64_wgrad_ws_floats(const arvae_link_t *l) {
     const int64_t per = (int64_t)l->kh * l->kw * l->clo * l->chi;
     const int64_t taps_kernel = ((M + C64_WG_SLICE - 1) / C64_WG_SLICE) * per;
     const int64_t rows_kernel = ((l->n + wr_img_per_wg(l) - 1) / wr_img_per_wg(l)) * per;
-    return (taps_kernel > rows_kernel ? taps_kernel : rows_kernel) + 2 * AMAX_N;     // + the two operands' AMAX arrays (pairs kernel)
+    const int64_t bias_partials = ((l->n + wr_img_per_wg(l) - 1) / wr_img_per_wg(l)) * 64;    // (pairs kernel: bias sums riding along)
+    return (taps_kernel > rows_kernel ? taps_kernel : rows_kernel) + bias_partials + 2 * AMAX_N;     // + the two operands' AMAX arrays
 }
 
 int conv64_operand_amax(const Operand &x, int64_t count, unsigned *out, hipStream_t s);      // conv64s.hip
 
 int conv64_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *dwt, float *ws, hipStream_t s,
-                 const unsigned *amax_lo, const unsigned *amax_hi) {
+                 const unsigned *amax_lo, const unsigned *amax_hi, float *dbias, int bias_side, bool *bias_done) {
+    if (bias_done != nullptr) *bias_done = false;
     ConvWgrad g{};
     g.lo = lo; g.hi = hi; g.n = l->n; g.lh = l->lh; g.lw = l->lw; g.clo = l->clo; g.hh = l->hh; g.hw = l->hw; g.chi = l->chi;
     g.kh = l->kh; g.kw = l->kw; g.pad = l->pad; g.ws = ws;
@@ -729,6 +779,15 @@ int conv64_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, fl
         });
         // maxima of the operands AS MULTIPLIED: the caller's (plain tensors only) or taken here, behind the partial sums in ws
         unsigned *am = reinterpret_cast<unsigned *>(ws + conv64_wgrad_ws_floats(l) - 2 * AMAX_N);
+        // the bias gradient (column sums of lo or of hi) rides in the kernel: both tensors pass through its registers anyway
+        static const bool bias_apart = diag_env("ARVAE_CONV64_BIAS_APART") != nullptr;     // A/B: the separate channel-sum launches
+        const bool ride = dbias != nullptr && (bias_side == 1 || bias_side == 2) && bias_done != nullptr && !bias_apart &&
+                          (bias_side == 1 ? l->clo : l->chi) <= 64;
+        if (ride) {
+            g.bias_ws = reinterpret_cast<float *>(am) - (int64_t)slices * 64;
+            g.bias_side = bias_side;
+            *bias_done = true;
+        }
         if (amax_lo == nullptr || !pl) {
             if (int rc = conv64_operand_amax(g.lo, (int64_t)l->n * l->lh * l->lw * l->clo, am, s)) return rc;
             amax_lo = am;
@@ -741,8 +800,9 @@ int conv64_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, fl
         else if (pl) ARVAE_LAUNCH((conv_wgrad_pairs_h2_kernel<true, false>), grid, dim3(256), lds, s, g, ipw, amax_lo, amax_hi);
         else if (ph) ARVAE_LAUNCH((conv_wgrad_pairs_h2_kernel<false, true>), grid, dim3(256), lds, s, g, ipw, amax_lo, amax_hi);
         else ARVAE_LAUNCH((conv_wgrad_pairs_h2_kernel<false, false>), grid, dim3(256), lds, s, g, ipw, amax_lo, amax_hi);
-        const int count = taps * l->clo * l->chi;
-        ARVAE_LAUNCH(conv64_wgrad_reduce_kernel, dim3((count * 4 + 255) / 256), dim3(256), 0, s, ws, slices, taps, l->clo, l->chi, dwt);
+        const int count = taps * l->clo * l->chi, nbias = ride ? (bias_side == 1 ? l->clo : l->chi) : 0;
+        ARVAE_LAUNCH(conv64_wgrad_reduce_kernel, dim3(((count + nbias) * 4 + 255) / 256), dim3(256), 0, s, ws, slices, taps, l->clo, l->chi, dwt,
+                     g.bias_ws, nbias, dbias);
         return check_launch((l->chi >= 64 && l->clo >= 64) ? "conv64_wgrad(pairs, wide)" : "conv64_wgrad(pairs, narrow)");
     }
     if (conv64_wgrad_rows_fits(l)) {

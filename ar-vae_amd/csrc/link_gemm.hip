@@ -52,7 +52,7 @@ int conv64_up(const arvae_link_t *l, const Operand &lo, const float *wt, const f
 bool conv64_wgrad_fits(const arvae_link_t *l);
 int64_t conv64_wgrad_ws_floats(const arvae_link_t *l);
 int conv64_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, float *dwt, float *ws, hipStream_t s,
-                 const unsigned *amax_lo = nullptr, const unsigned *amax_hi = nullptr);
+                 const unsigned *amax_lo, const unsigned *amax_hi, float *dbias, int bias_side, bool *bias_done);
 
 // specialised 32-channel k4/s2/p1 kernels (conv32.hip)
 bool conv32_fits(const arvae_link_t *l);
@@ -977,7 +977,9 @@ namespace arvae {
 // (plain operands only), else null
 int link_wgrad_conv64(const arvae_link_t *link, const Operand &lo, const Operand &hi, float *dwt, float *dbias, int bias_side, float *ws,
                       hipStream_t st, const unsigned *amax_lo, const unsigned *amax_hi) {
-    if (int rc = conv64_wgrad(link, lo, hi, dwt, ws, st, amax_lo, amax_hi)) return rc;
+    bool bias_done = false;
+    if (int rc = conv64_wgrad(link, lo, hi, dwt, ws, st, amax_lo, amax_hi, dbias, bias_side, &bias_done)) return rc;
+    if (bias_done) return ARVAE_OK;
     if (bias_side == 1) return channel_sum_launch(lo, (int64_t)link->n * link->lh * link->lw, link->clo, 0, 0, dbias, ws, st);
     if (bias_side == 2) return channel_sum_launch(hi, (int64_t)link->n * link->hh * link->hw, link->chi, 0, 0, dbias, ws, st);
     return ARVAE_OK;
