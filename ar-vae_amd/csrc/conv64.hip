@@ -31,6 +31,9 @@ struct ConvRows {
     int act;
     float *out;                  // [n][oh][ow][q]
     GateOp gate;                 // data-gradient launches: result *= act'(gate.y) * 2 gate.mask at the output location
+    unsigned *amax_out;          // AMAX array of the output (conv32_common.h) or null: zeroed by the weight-prep launch in front, every
+                                 // wave folds its maximum into entry (workgroup % AMAX_N) with an integer atomic max (bit patterns of
+                                 // non-negative floats order like the floats: exact, order-independent)
 };
 
 // value of a gradient operand (activation derivative of the saved output, keep-mask) for 4 consecutive channels
@@ -144,6 +147,7 @@ __global__ __launch_bounds__(256) void conv_rows_x3_kernel(ConvRows g) {
             gy[r] = g.gate.y != nullptr ? g.gate.y[o] : 0.f;
         }
     }
+    float vmax = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int p = p0 + 32 * wp + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -158,15 +162,29 @@ __global__ __launch_bounds__(256) void conv_rows_x3_kernel(ConvRows g) {
                 v *= 2.f * (float)gm[r];
             }
             g.out[o] = v;
+            vmax = fmaxf(vmax, fabsf(v));
         }
+    }
+    if (g.amax_out != nullptr) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+        float *wmax = reinterpret_cast<float *>(As);
+        __syncthreads();
+        if (lane == 0) wmax[wave] = vmax;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            __hip_atomic_fetch_max(g.amax_out + ((blockIdx.y * gridDim.x + blockIdx.x) & (AMAX_N - 1)),
+                                   __builtin_bit_cast(unsigned, fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
 // nn.Conv2d / nn.ConvTranspose2d weights [a][b][taps] -> [q][tap][c]; (q, c) = (a, b) for the Conv2d-forward direction,
 // (b, a) for the transposed one
 __global__ __launch_bounds__(256) void conv64_weight_prep_kernel(const float *__restrict__ wt, float *__restrict__ out, int q_count,
-                                                                  int c_count, int taps, int transposed) {
+                                                                  int c_count, int taps, int transposed, unsigned *__restrict__ amax_zero) {
     const int i = blockIdx.x * 256 + threadIdx.x;                      // output index (q, tap, c)
+    if (amax_zero != nullptr && i < AMAX_N) amax_zero[i] = 0u;          // (the convolution behind this launch folds its maxima in)
     if (i >= q_count * taps * c_count) return;
     const int c = i % c_count, tap = (i / c_count) % taps, q = i / (c_count * taps);
     out[i] = transposed ? wt[((int64_t)c * q_count + q) * taps + tap] : wt[((int64_t)q * c_count + c) * taps + tap];
@@ -198,11 +216,14 @@ bool conv64_fits(const arvae_link_t *l, bool up) {
            (l->kh * l->kw * red) % RG_R == 0 && outc >= 4 && red <= 128 && outc <= 128 && l->hi_perm_c == 0 && l->lo_perm_c == 0;
 }
 
-static int launch_conv_rows(ConvRows g, const float *wt, bool transposed, float *packed, hipStream_t s, const char *what) {
+static int launch_conv_rows(ConvRows g, const float *wt, bool transposed, float *packed, hipStream_t s, const char *what,
+                            unsigned *amax_out = nullptr) {
     const int taps = g.kh * g.kw, wcount = g.q * taps * g.cs;
+    g.amax_out = amax_out;
     if (packed == nullptr || (reinterpret_cast<uintptr_t>(packed) & 15) != 0)
         return fail(ARVAE_E_INVALID, "%s: needs arvae_link_ws_floats() floats of 16-byte aligned workspace for the re-ordered weights", what);
-    ARVAE_LAUNCH(conv64_weight_prep_kernel, dim3((wcount + 255) / 256), dim3(256), 0, s, wt, packed, g.q, g.cs, taps, transposed ? 1 : 0);
+    ARVAE_LAUNCH(conv64_weight_prep_kernel, dim3(((wcount > AMAX_N ? wcount : AMAX_N) + 255) / 256), dim3(256), 0, s, wt, packed, g.q, g.cs, taps,
+                 transposed ? 1 : 0, amax_out);
     g.wt = packed;
     const int M = g.n * g.oh * g.ow;
     const dim3 grid((M + C64_TP - 1) / C64_TP, (g.q + C64_TQ - 1) / C64_TQ);
@@ -229,7 +250,7 @@ int conv64_down(const arvae_link_t *l, const Operand &hi, const float *wt, const
     g.oh = l->lh; g.ow = l->lw; g.q = l->clo;
     g.kh = l->kh; g.kw = l->kw; g.sgn = 1; g.off = -l->pad;
     g.bias = bias; g.mask = mask; g.act = act; g.out = lo;
-    return launch_conv_rows(g, wt, false, ws, s, what);          // wt[clo][chi][ky][kx]: q = clo, c = chi
+    return launch_conv_rows(g, wt, false, ws, s, what, amax_out);          // wt[clo][chi][ky][kx]: q = clo, c = chi
 }
 
 // hi[n][hh][hw][chi] = act(convT(lo) + bias) * mask    (ConvTranspose2d forward / Conv2d data gradient)
@@ -244,7 +265,7 @@ int conv64_up(const arvae_link_t *l, const Operand &lo, const float *wt, const f
     g.oh = l->hh; g.ow = l->hw; g.q = l->chi;
     g.kh = l->kh; g.kw = l->kw; g.sgn = -1; g.off = l->pad;
     g.bias = bias; g.mask = mask; g.act = act; g.out = hi;
-    return launch_conv_rows(g, wt, true, ws, s, what);             // wt[clo][chi][ky][kx]: q = chi, c = clo
+    return launch_conv_rows(g, wt, true, ws, s, what, amax_out);             // wt[clo][chi][ky][kx]: q = chi, c = clo
 }
 
 // ---- weight gradient ----------------------------------------------------------------------------------------------

@@ -285,7 +285,7 @@ static int layer_forward(const arvae_layer_t &l, int32_t n, const float *params,
             if (int rc = conv32_amax(in, in_elems(l, n), tmp_amax, hs)) return rc;
             in_amax = tmp_amax;
         }
-        *out_has = out_amax != nullptr && conv64s_fits(&lk, l.is_up != 0);
+        *out_has = out_amax != nullptr;                  // (both the row-staged and the gathering kernel publish their output's maxima)
         return l.is_up ? conv64_up(&lk, make_operand(&op), w, b, l.act, mask, out, link_ws, hs, nullptr, in_amax, *out_has ? out_amax : nullptr)
                        : conv64_down(&lk, make_operand(&op), w, b, l.act, mask, out, link_ws, hs, nullptr, in_amax, *out_has ? out_amax : nullptr);
     }
@@ -425,9 +425,9 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
                 if (staged && gop.y == nullptr && tmp_amax != nullptr)
                     if (int rc2 = need_g()) return rc2;
                 rc = conv64_up(&lk, make_operand(&gop), w, nullptr, ARVAE_ACT_NONE, nullptr, d_in, link_ws, hs, gate_op,
-                               (staged && gop.y == nullptr) ? g_amax : nullptr, staged ? din_amax : nullptr);
+                               (staged && gop.y == nullptr) ? g_amax : nullptr, din_amax);
                 *gated = true;
-                *din_has = staged && din_amax != nullptr;
+                *din_has = din_amax != nullptr;
             } else {
                 rc = arvae_link_up(&lk, &gop, w, nullptr, ARVAE_ACT_NONE, nullptr, d_in, link_ws, st);
             }
