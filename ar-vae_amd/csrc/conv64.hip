@@ -558,11 +558,14 @@ __device__ __forceinline__ void wp_commit_h2(unsigned short *d, int plane, const
     ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, BL, ACC, 0, 0, 0);            \
     ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, BH, ACC, 0, 0, 0)
 
+// TWO workgroups per CU (72 KB of LDS and <= 128 + 128 registers each): with one, a SIMD held a single wave and every transposed
+// operand read stalled its MFMAs -- the launch ran at 13 % of the fp16 MFMA rate.  The lo pair image is single-buffered for that
+// (a second barrier per pair keeps the next pair's commit off the image still being read).
 template <bool PLAIN_LO, bool PLAIN_HI>
-__global__ __launch_bounds__(256) void conv_wgrad_pairs_h2_kernel(ConvWgrad g, int img_per_wg, const unsigned *amax_lo, const unsigned *amax_hi) {
+__global__ __launch_bounds__(256, 2) void conv_wgrad_pairs_h2_kernel(ConvWgrad g, int img_per_wg, const unsigned *amax_lo, const unsigned *amax_hi) {
     extern __shared__ __attribute__((aligned(16))) unsigned short wp_lds[];
-    unsigned short *lo_img = wp_lds;                            // [2][2][WP_SLOTS][RG_TRP]
-    unsigned short *hi_ring = wp_lds + 2 * 2 * WP_APLANE;       // [WP_RING][2][WR_HROWS][WP_HTRP]
+    unsigned short *lo_img = wp_lds;                            // [2][WP_SLOTS][RG_TRP]
+    unsigned short *hi_ring = wp_lds + 2 * WP_APLANE;           // [WP_RING][2][WR_HROWS][WP_HTRP]
     const AmaxLoad al_l = amax_issue(amax_lo), al_h = amax_issue(amax_hi);
     const int lane = threadIdx.x & 63, half = lane >> 5, rc = lane & 31;
     const int ky = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -572,7 +575,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_pairs_h2_kernel(ConvWgrad g, i
     const int pairs = (g.lh + 1) >> 1;
 
     // zero both lo pair images once: slots >= 2 lw are never written again
-    for (int i = threadIdx.x; i < 2 * 2 * WP_APLANE / 2; i += 256) reinterpret_cast<unsigned *>(lo_img)[i] = 0u;
+    for (int i = threadIdx.x; i < 2 * WP_APLANE / 2; i += 256) reinterpret_cast<unsigned *>(lo_img)[i] = 0u;
     const Pow2 sc_l = amax_scale(al_l), sc_h = amax_scale(al_h);
 
     // gather slots.  lo row: pixel idx / 16, channels 4 (idx % 16); hi row: pixel row idx / 8, channels ch0 + 4 (idx % 8)
@@ -609,7 +612,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_pairs_h2_kernel(ConvWgrad g, i
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             if (lo_r[i] < g.lw)
-                wp_commit_h2(lo_img + buf * 2 * WP_APLANE + (which * g.lw + lo_r[i]) * RG_TRP + lo_c, WP_APLANE, vlo[which][i], sc_l.s);
+                wp_commit_h2(lo_img + (which * g.lw + lo_r[i]) * RG_TRP + lo_c, WP_APLANE, vlo[which][i], sc_l.s);
     };
     auto ring_of = [&](int hy) { return hi_ring + ((hy + 4 * WP_RING) & (WP_RING - 1)) * 2 * WP_HPLANE; };
     auto commit_hi = [&](int which, int hy) __attribute__((always_inline)) {
@@ -671,8 +674,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_pairs_h2_kernel(ConvWgrad g, i
         fetch_hi(1, n, -g.pad + 4);
         for (int pi = 0; pi < pairs; ++pi) {
             const int ly = 2 * pi;
-            commit_lo(0, pi & 1);
-            commit_lo(1, pi & 1);
+            if (pi > 0) __syncthreads();                        // the previous pair's MFMAs are done with the lo image
+            commit_lo(0, 0);
+            commit_lo(1, 0);
             commit_hi(0, ly - g.pad + 3);
             commit_hi(1, ly - g.pad + 4);
             __syncthreads();
@@ -683,7 +687,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_pairs_h2_kernel(ConvWgrad g, i
                 fetch_hi(1, n, ly + 2 - g.pad + 4);
             }
             if (ky < g.kh) {
-                const unsigned short *ab = lo_img + (pi & 1) * 2 * WP_APLANE + a_base;
+                const unsigned short *ab = lo_img + a_base;
                 const unsigned short *hbA = ring_of(ly - g.pad + ky), *hbB = ring_of(ly + 1 - g.pad + ky);
 #pragma unroll
                 for (int s = 0; s < 3; ++s) {
@@ -769,8 +773,9 @@ int64_t conv64_wgrad_ws_floats(const arvae_link_t *l) {
     const int64_t M = (int64_t)l->n * l->lh * l->lw;
     const int64_t per = (int64_t)l->kh * l->kw * l->clo * l->chi;
     const int64_t taps_kernel = ((M + C64_WG_SLICE - 1) / C64_WG_SLICE) * per;
-    const int64_t rows_kernel = ((l->n + wr_img_per_wg(l) - 1) / wr_img_per_wg(l)) * per;
-    const int64_t bias_partials = ((l->n + wr_img_per_wg(l) - 1) / wr_img_per_wg(l)) * 64;    // (pairs kernel: bias sums riding along)
+    const int ipw_pairs = (wr_img_per_wg(l) + 1) / 2;                                        // (the paired-rows kernel: two workgroups per CU)
+    const int64_t rows_kernel = ((l->n + ipw_pairs - 1) / ipw_pairs) * per;
+    const int64_t bias_partials = ((l->n + ipw_pairs - 1) / ipw_pairs) * 64;                  // (its bias sums riding along)
     return (taps_kernel > rows_kernel ? taps_kernel : rows_kernel) + bias_partials + 2 * AMAX_N;     // + the two operands' AMAX arrays
 }
 
@@ -788,9 +793,9 @@ int conv64_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, fl
     if (ph) g.hi.y = nullptr;
     static const bool no_pairs = diag_env("ARVAE_CONV64_WGRAD_ROWS") != nullptr;     // diagnostic: one lo row per step
     if (conv64_wgrad_rows_fits(l) && !no_pairs && l->lw <= 24 && l->kh == 4) {
-        const int ipw = wr_img_per_wg(l), slices = (l->n + ipw - 1) / ipw;
+        const int ipw = (wr_img_per_wg(l) + 1) / 2, slices = (l->n + ipw - 1) / ipw;      // two workgroups per CU
         const dim3 grid((l->chi + 31) / 32, slices);
-        const size_t lds = (2 * 2 * WP_APLANE + WP_RING * 2 * WP_HPLANE) * sizeof(unsigned short);
+        const size_t lds = (2 * WP_APLANE + WP_RING * 2 * WP_HPLANE) * sizeof(unsigned short);
         static std::once_flag attr;
         std::call_once(attr, [&] {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_pairs_h2_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
