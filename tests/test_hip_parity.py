@@ -671,6 +671,7 @@ def test_gru_sequence_vs_torch(dev, rows, hid, steps):
     from arvae_amd import ops
     rs = np.random.RandomState(15)
     fin = 10
+    torch.manual_seed(15)                # (nn.GRU draws its parameters from torch's generator: pinned, whatever ran before)
     gru = torch.nn.GRU(fin, hid, 1, bidirectional=True)
     x = torch.from_numpy(rs.standard_normal((steps, rows, fin)).astype(np.float32)).requires_grad_(True)
     h0 = torch.from_numpy(rs.standard_normal((2, rows, hid)).astype(np.float32)).requires_grad_(True)
@@ -705,6 +706,7 @@ def test_merged_bidirectional_projection_vs_torch(dev, rows, hid, steps, fin):
     arvae_gru_seq_t.h_fin) and every gradient against a bidirectional torch.nn.GRU layer."""
     from arvae_amd import ops
     rs = np.random.RandomState(23)
+    torch.manual_seed(23)
     gru = torch.nn.GRU(fin, hid, 1, bidirectional=True)
     x = torch.from_numpy(rs.standard_normal((steps, rows, fin)).astype(np.float32)).requires_grad_(True)
     gy = torch.from_numpy(rs.standard_normal((steps, rows, 2 * hid)).astype(np.float32))
