@@ -149,9 +149,11 @@ SIGNATURES = {
                                          c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_vp, c_vp]),
     'arvae_measure_vae_ws_floats': (c_i64, [_P(MeasureVaeDesc), c_i32]),
     'arvae_measure_vae_forward': (c_i32, [_P(MeasureVaeDesc), c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, _P(MeasureTables), c_vp,
-                                          c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+                                          c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
+    'arvae_measure_vae_finish': (c_i32, [_P(MeasureVaeDesc), c_i32, c_vp, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                         c_vp]),
     'arvae_measure_vae_backward': (c_i32, [_P(MeasureVaeDesc), c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
-                                           c_vp, c_vp, c_vp, c_vp]),
+                                           c_vp, c_vp, c_f32, c_vp, c_vp]),
     'arvae_philox_normal': (c_i32, [c_vp, c_i64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp]),
     'arvae_philox_keep_mask': (c_i32, [c_vp, c_i64, c_f32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp]),
     'arvae_count_nonfinite': (c_i32, [c_vp, c_i64, c_vp, c_vp]),

@@ -430,10 +430,11 @@ int recon_partial_blocks(int64_t count) { return grid_for(count, 8, RECON_MAX_BL
 
 // per-block partial sums (cross entropy, correct top-1) of the token term, rows in the tick RNN's sequence order against the
 // score's (batch, tick) targets (+ d/dweights for a unit upstream gradient of the MEAN); the block count through *nb_out
+int token_recon_blocks(int64_t rows) { return grid_for(rows * TOK_LPR, 1, RECON_MAX_BLOCKS); }
 int token_recon_partials(const float *weights, const int64_t *score, int batch, int beats, int tpb, int32_t vocab, float *ws,
                          float *dweights, hipStream_t s, int *nb_out) {
     const int64_t rows = (int64_t)batch * beats * tpb;
-    const int nb = grid_for(rows * TOK_LPR, 1, RECON_MAX_BLOCKS);
+    const int nb = token_recon_blocks(rows);
     ARVAE_LAUNCH(token_recon_kernel, dim3(nb), dim3(256), 0, s, weights, score, rows, vocab, 1.f / (float)rows, ws, dweights, batch, beats, tpb);
     *nb_out = nb;
     return check_launch("token_recon");

@@ -17,6 +17,7 @@ namespace arvae {
 // loss-term pieces (losses.hip)
 int token_recon_partials(const float *weights, const int64_t *score, int batch, int beats, int tpb, int32_t vocab, float *ws,
                          float *dweights, hipStream_t s, int *nb_out);
+int token_recon_blocks(int64_t rows);
 int reg_partials(const float *z_rows, const float *lab_rows, int64_t n_rows, const float *z_cols, const float *lab_cols,
                  int64_t n_cols, int64_t ldz, int64_t ldl, const RegDims &rd, int32_t r, float delta, float *ws,
                  hipStream_t s);
@@ -90,14 +91,14 @@ __global__ __launch_bounds__(256) void measure_latent_bwd_kernel(const float *__
                                                                   const float *__restrict__ mu, const float *__restrict__ sigma,
                                                                   const float *__restrict__ eps, const float *__restrict__ g_loss,
                                                                   const float *__restrict__ kl, const float *__restrict__ cap, float beta,
-                                                                  float inv_batch, int64_t count, float *__restrict__ d_mu,
+                                                                  float inv_batch, float reg_scale, int64_t count, float *__restrict__ d_mu,
                                                                   float *__restrict__ d_ls) {
     const float g = g_loss[0];
     const float diff = kl[0] - (cap != nullptr ? cap[0] : 0.f);
     const float k = g * beta * (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f)) * inv_batch;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
         float gz = g_z[i];
-        if (dz_reg != nullptr) gz += g * dz_reg[i];
+        if (dz_reg != nullptr) gz += g * reg_scale * dz_reg[i];
         const float s = sigma[i];
         d_mu[i] = gz + k * mu[i];
         d_ls[i] = (gz * eps[i] + k * (s - 1.f / s)) * s;
@@ -334,7 +335,8 @@ extern "C" int64_t arvae_measure_vae_ws_floats(const arvae_measure_vae_t *model,
 extern "C" int arvae_measure_vae_forward(const arvae_measure_vae_t *m, int32_t batch, const float *params, const int64_t *score,
                                          float *eps, uint8_t *enc_mask, uint8_t *dec_mask, int32_t teacher_forced,
                                          const float *capacity, const arvae_measure_tables_t *tables, float *ws, float *scalars,
-                                         float *mu, float *sigma, float *z, int64_t *tokens, arvae_stream_t stream) {
+                                         float *mu, float *sigma, float *z, int64_t *tokens, float *labels, int32_t defer_finish,
+                                         arvae_stream_t stream) {
     MV_TRY(check_model(m, batch, "measure_vae_forward"));
     ARVAE_REQUIRE(params && score && eps && ws && scalars && mu && sigma && z && tokens, "measure_vae_forward: null pointer");
     ARVAE_REQUIRE((enc_mask == nullptr) == (dec_mask == nullptr), "measure_vae_forward: give both keep-masks (training) or neither (evaluation)");
@@ -473,24 +475,51 @@ extern "C" int arvae_measure_vae_forward(const arvae_measure_vae_t *m, int32_t b
     // beta-KL, the regulariser's gradient and the pass's scalars
     int nb = 0;
     MV_TRY(token_recon_partials(w.probs, score, d.b, d.nb, d.tpb, d.v, w.rec_ws, w.dprobs, s, &nb));
-    if (m->n_reg > 0) {
+    float *lab = labels != nullptr ? labels : w.labels;
+    if (m->n_reg > 0)
         MV_TRY(arvae_measure_attributes(score, d.b, d.t, tables->midi_lut, tables->is_note, tables->is_density_note, d.v,
-                                        tables->rhythm_weights, tables->rhythm_norm, w.labels, stream));
+                                        tables->rhythm_weights, tables->rhythm_norm, lab, stream));
+    if (defer_finish) return ARVAE_OK;                   // data parallel: arvae_measure_vae_finish, once z and the labels are gathered
+    if (m->n_reg > 0) {
         RegDims rd;
         for (int i = 0; i < 16; ++i) rd.d[i] = i < m->n_reg ? m->reg_dims[i] : 0;
         for (int i = 0; i < m->n_reg; ++i)
             ARVAE_REQUIRE(m->reg_dims[i] >= 0 && m->reg_dims[i] < d.z && m->reg_dims[i] < 4, "measure_vae_forward: regularised dim %d outside z / the attributes",
                           m->reg_dims[i]);
-        MV_TRY(reg_partials(z, w.labels, d.b, z, w.labels, d.b, d.z, 4, rd, m->n_reg, m->delta, w.reg_ws, s));
+        MV_TRY(reg_partials(z, lab, d.b, z, lab, d.b, d.z, 4, rd, m->n_reg, m->delta, w.reg_ws, s));
     }
     return vae_finish(w.rec_ws, nb, d.b, d.rt, mu, sigma, d.z, m->beta, capacity, m->n_reg > 0 ? w.reg_ws : nullptr, d.b, d.z, m->reg_dims,
                       m->n_reg, m->gamma, m->delta, 1.f, w.dz_reg, w.ce_out, w.kld_out, w.reg_out, scalars, s, d.rt);
 }
 
+extern "C" int arvae_measure_vae_finish(const arvae_measure_vae_t *m, int32_t batch, const float *capacity, const float *z_cols,
+                                        const float *lab_cols, int64_t n_cols, float reg_scale, float *ws, float *scalars, const float *mu,
+                                        const float *sigma, const float *z, const float *labels, arvae_stream_t stream) {
+    MV_TRY(check_model(m, batch, "measure_vae_finish"));
+    ARVAE_REQUIRE(ws && scalars && mu && sigma && z, "measure_vae_finish: null pointer");
+    ARVAE_REQUIRE(m->n_reg == 0 || (z_cols && lab_cols && labels && n_cols >= batch), "measure_vae_finish: the regulariser needs the gathered columns");
+    hipStream_t s = as_stream(stream);
+    MvWs w{};
+    carve(m, batch, ws, &w);
+    const MvDims d = dims_of(m, batch);
+    if (m->n_reg > 0) {
+        RegDims rd;
+        for (int i = 0; i < 16; ++i) rd.d[i] = i < m->n_reg ? m->reg_dims[i] : 0;
+        for (int i = 0; i < m->n_reg; ++i)
+            ARVAE_REQUIRE(m->reg_dims[i] >= 0 && m->reg_dims[i] < d.z && m->reg_dims[i] < 4, "measure_vae_finish: regularised dim %d outside z / the attributes",
+                          m->reg_dims[i]);
+        MV_TRY(reg_partials(z, labels, d.b, z_cols, lab_cols, n_cols, d.z, 4, rd, m->n_reg, m->delta, w.reg_ws, s));
+    }
+    const int nb = token_recon_blocks(d.rt);
+    return vae_finish(w.rec_ws, nb, d.b, d.rt, mu, sigma, d.z, m->beta, capacity, m->n_reg > 0 ? w.reg_ws : nullptr, n_cols, d.z, m->reg_dims,
+                      m->n_reg, m->gamma, m->delta, reg_scale, w.dz_reg, w.ce_out, w.kld_out, w.reg_out, scalars, s, d.rt);
+}
+
 extern "C" int arvae_measure_vae_backward(const arvae_measure_vae_t *m, int32_t batch, const float *params, float *grads,
                                           const int64_t *score, const float *eps, const uint8_t *enc_mask, const uint8_t *dec_mask,
                                           const float *capacity, const float *mu, const float *sigma, const float *z,
-                                          const int64_t *tokens, const float *scalars, const float *g_loss, float *ws, arvae_stream_t stream) {
+                                          const int64_t *tokens, const float *scalars, const float *g_loss, float reg_scale, float *ws,
+                                          arvae_stream_t stream) {
     MV_TRY(check_model(m, batch, "measure_vae_backward"));
     ARVAE_REQUIRE(params && grads && score && eps && mu && sigma && z && tokens && scalars && g_loss && ws, "measure_vae_backward: null pointer");
     ARVAE_REQUIRE((enc_mask == nullptr) == (dec_mask == nullptr), "measure_vae_backward: give both keep-masks or neither");
@@ -588,7 +617,7 @@ extern "C" int arvae_measure_vae_backward(const arvae_measure_vae_t *m, int32_t 
 
     // ---- latent head: decoder path + regulariser + beta-KL -> (d mu, d log_std), then the heads' two layers
     ARVAE_LAUNCH(measure_latent_bwd_kernel, dim3(blocks_for((int64_t)d.b * d.z)), dim3(256), 0, s, w.d_z, m->n_reg > 0 ? w.dz_reg : nullptr, mu,
-                 sigma, eps, g_loss, scalars + ARVAE_VAE_KL, capacity, m->beta, 1.f / (float)d.b, (int64_t)d.b * d.z, w.d_mu, w.d_ls);
+                 sigma, eps, g_loss, scalars + ARVAE_VAE_KL, capacity, m->beta, 1.f / (float)d.b, reg_scale, (int64_t)d.b * d.z, w.d_mu, w.d_ls);
     MV_TRY(check_launch("measure_latent_bwd_kernel"));
     MV_TRY(lin_dgrad(d.b, 2 * He, d.z, plain(w.d_mu), P + m->mean_w2, w.d_hmu, s));
     MV_TRY(lin_dgrad(d.b, 2 * He, d.z, plain(w.d_ls), P + m->lstd_w2, w.d_hls, s));

@@ -144,8 +144,12 @@ class FusedMeasureVAE:
             self._tables = (MeasureTables(ops._ptr(midi), ops._ptr(is_note), ops._ptr(is_dens), ops._ptr(w), float(norm)), t)
         return self._tables[0]
 
-    def run(self, score, train, capacity, tables, eps=None, masks=None):
+    def run(self, score, train, capacity, tables, eps=None, masks=None, dp=None):
         """-> (loss[1] with grad_fn, scalars[8], acc, z, mu, sigma, tokens (B, 24)).
+
+        dp (arvae_amd.parallel.DataParallel): the regulariser of this rank's rows against the z / label columns gathered from every
+        rank, inside the same autograd node: the forward pass stops before the regulariser, one grouped all-gather, then
+        arvae_measure_vae_finish; loss = recon + beta |KL| + W * reg_rowblock (parallel.py).
 
         train: dropout keep-masks are applied (the model is in training mode) and the decoder tosses its teacher-forcing coin.
         eps / masks = (encoder mask, beat mask, tick mask): explicit noise and keep-masks (parity runs); None: drawn by the pass
@@ -158,12 +162,12 @@ class FusedMeasureVAE:
             teacher_forced = False
         dropping = m.training and (m.encoder.dropout > 0 or dec.dropout > 0)
         anchor = self.optimizer.params[0]
-        return _MeasureStepFn.apply(anchor, self, score, bool(teacher_forced), bool(dropping), capacity, tables, eps, masks)
+        return _MeasureStepFn.apply(anchor, self, score, bool(teacher_forced), bool(dropping), capacity, tables, eps, masks, dp)
 
 
 class _MeasureStepFn(Function):
     @staticmethod
-    def forward(ctx, anchor, fused, score, teacher_forced, dropping, capacity, tables, eps, masks):
+    def forward(ctx, anchor, fused, score, teacher_forced, dropping, capacity, tables, eps, masks, dp=None):
         ops._dev(score, capacity)
         lib = _lib.load()
         desc = fused.descriptor()
@@ -209,11 +213,23 @@ class _MeasureStepFn(Function):
         mu = torch.empty(b, zd, device=dev, dtype=torch.float32)
         sigma, z = torch.empty_like(mu), torch.empty_like(mu)
         tokens = torch.empty(b, steps, device=dev, dtype=torch.int64)
+        rowblock = dp is not None and len(fused.reg_dims) > 0
+        labels = torch.empty(b, 4, device=dev, dtype=torch.float32) if rowblock else None
         with ops._timed('measure_vae_forward'):
             _lib.check(lib.arvae_measure_vae_forward(
                 ctypes.byref(desc), b, ops._ptr(opt.param_arena), ops._ptr(score), ops._ptr(eps), ops._ptr(enc_mask), ops._ptr(dec_mask),
                 int(teacher_forced), ops._ptr(capacity), ctypes.byref(tables) if tables is not None else None, ops._ptr(ws),
-                ops._ptr(scalars), ops._ptr(mu), ops._ptr(sigma), ops._ptr(z), ops._ptr(tokens), ops._stream()), 'measure_vae_forward')
+                ops._ptr(scalars), ops._ptr(mu), ops._ptr(sigma), ops._ptr(z), ops._ptr(tokens), ops._ptr(labels), int(rowblock),
+                ops._stream()), 'measure_vae_forward')
+        ctx.reg_scale = 1.0
+        if rowblock:
+            z_all, lab_all = dp.gather_many([z, labels])         # one RCCL launch on the launch stream
+            ctx.reg_scale = float(dp.world_size)
+            with ops._timed('measure_vae_finish'):
+                _lib.check(lib.arvae_measure_vae_finish(
+                    ctypes.byref(desc), b, ops._ptr(capacity), ops._ptr(z_all), ops._ptr(lab_all), z_all.shape[0], ctx.reg_scale,
+                    ops._ptr(ws), ops._ptr(scalars), ops._ptr(mu), ops._ptr(sigma), ops._ptr(z), ops._ptr(labels), ops._stream()),
+                    'measure_vae_finish')
         ctx.fused, ctx.masks = fused, (enc_mask, dec_mask)
         ctx.save_for_backward(score, eps, capacity, mu, sigma, z, tokens, scalars)
         ctx.set_materialize_grads(False)
@@ -229,7 +245,7 @@ class _MeasureStepFn(Function):
         lib = _lib.load()
         opt = fused.optimizer
         if g_loss is None:
-            return (None,) * 9
+            return (None,) * 10
         g_loss = g_loss.reshape(1).contiguous()
         enc_mask, dec_mask = ctx.masks
         opt.mark_dirty()                                         # gradients land in the arena without torch's accumulation
@@ -237,6 +253,6 @@ class _MeasureStepFn(Function):
             _lib.check(lib.arvae_measure_vae_backward(
                 ctypes.byref(fused.descriptor()), score.shape[0], ops._ptr(opt.param_arena), ops._ptr(opt.grad_arena), ops._ptr(score),
                 ops._ptr(eps), ops._ptr(enc_mask), ops._ptr(dec_mask), ops._ptr(capacity), ops._ptr(mu), ops._ptr(sigma), ops._ptr(z),
-                ops._ptr(tokens), ops._ptr(scalars), ops._ptr(g_loss), ops._ptr(ctx.ws), ops._stream()), 'measure_vae_backward')
+                ops._ptr(tokens), ops._ptr(scalars), ops._ptr(g_loss), ctx.reg_scale, ops._ptr(ctx.ws), ops._stream()), 'measure_vae_backward')
         ctx.ws_released = True
-        return (None,) * 9
+        return (None,) * 10

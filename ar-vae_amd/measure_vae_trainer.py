@@ -121,8 +121,9 @@ class MeasureVAETrainer(Trainer):
 
     def _fused_binding(self):
         """the whole-model executor bound to this trainer's arena and hyper-parameters, or None when the steps take the per-layer
-        path: data parallel runs (their collectives sit between the layers), debug checks, CPU models, unsupported shapes."""
-        if not self.use_fused_step or self.data_parallel is not None or ops.checks_enabled():
+        path: debug checks, CPU models, unsupported shapes.  Data-parallel steps run it too (forward, one grouped all-gather of z
+        and the attribute labels, arvae_measure_vae_finish)."""
+        if not self.use_fused_step or ops.checks_enabled():
             return None
         if self.use_reg_loss and type(self.reg_dim) != tuple:
             return None                                            # (the per-layer path raises the reference's TypeError)
@@ -147,8 +148,9 @@ class MeasureVAETrainer(Trainer):
         return fused
 
     def _replay_step(self, batch):
-        # the executor issues a step's launches from two library calls: a captured graph has no host work left to save and its
-        # nodes cost more than the stream launches they replace (B = 256: 1.09 ms eager, 1.11 ms replayed)
+        # the executor issues a step's launches from two library calls (three and one collective under data parallelism): a captured
+        # graph has no host work left to save and its nodes cost more than the stream launches they replace (B = 256: 1.09 ms eager,
+        # 1.11 ms replayed)
         if self._fused_binding() is not None:
             return None
         return super()._replay_step(batch)
@@ -161,7 +163,7 @@ class MeasureVAETrainer(Trainer):
         if self.model.training and enc._mask_queue:
             masks = (enc._mask_queue.popleft(),) + tuple(dec._mask_queue.popleft())
         tables = fused.tables(self, score.device) if self.use_reg_loss else None
-        loss, scalars, accuracy, *_ = fused.run(score, train, None, tables, eps, masks)
+        loss, scalars, accuracy, *_ = fused.run(score, train, None, tables, eps, masks, self.data_parallel)
         self.last_terms = {'recons': scalars[RECON], 'dist': scalars[DIST], 'reg': scalars[REG] if self.use_reg_loss else None}
         if first_of_epoch and self.writer is not None and not torch.cuda.is_current_stream_capturing():
             self.log_loss_split(epoch_num)

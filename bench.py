@@ -427,9 +427,9 @@ def side_roofline(kind, prof, prof_steps, batch):
 def run_side(kind, device, args, fence, rank, world, use_dp, with_cpu):
     """one secondary workload -> its result dict (the main line when selected with --workload)"""
     bsz = args.batch if (args.workload == kind and args.batch != 512) else SIDE_BATCH[kind]
-    # MeasureVAE: a single-process step is two library calls (the whole-model executor): eager.  Data-parallel steps take the
-    # per-layer path, a hundred launches the host must issue: replayed from HIP graphs, their collectives recorded with them
-    graphs = kind == 'measure' and not args.no_graphs and (use_dp or args.graphs)
+    # MeasureVAE: a step is two library calls (the whole-model executor; three and one grouped all-gather under data parallelism):
+    # eager.  --graphs replays it from a HIP graph, collectives recorded with the kernels
+    graphs = kind == 'measure' and not args.no_graphs and args.graphs
     step, eager, unit = build_side_workload(kind, device, bsz, rank, use_dp, graphs)
     steps = args.steps if args.workload == kind else max(10, min(args.steps, 50))
     med, timing, loss = timed_regions(step, steps, args.warmup, fence, args.min_seconds)
@@ -451,7 +451,7 @@ def run_side(kind, device, args, fence, rank, world, use_dp, with_cpu):
                                    'FolkNBar MeasureVAE full training step, 24-tick measures, V=35, z=32, reg_dim=(0..3), '
                                    'dropout 0.5, teacher forcing p=0.5'),
                       'per_gpu_batch': bsz, 'global_batch': bsz * world, 'parallelism': f'dp{world}',
-                      'launch': 'hip-graph replay of fwd+bwd' if graphs else ('eager' if (kind == 'mnist' or use_dp) else 'eager, whole-model executor (two library calls per step)'),
+                      'launch': 'hip-graph replay of fwd+bwd' if graphs else ('eager' if kind == 'mnist' else 'eager, whole-model executor (two library calls per step)'),
                       'final_loss': float(loss.detach())},
            'timing': timing,
            # whole-step fractions of the datasheet roofs (SURVEY 8(d) algorithmic FLOP / layer-boundary bytes per unit)
@@ -686,8 +686,8 @@ def main():
     ap.add_argument('--breakdown', action='store_true', help='print the per-kernel-family table to stderr')
     ap.add_argument('--force-dp', action='store_true',
                     help='run the data-parallel code path (RCCL all-gather + all-reduce) even with one rank')
-    ap.add_argument('--no-graphs', action='store_true', help='measure workload: eager launches also under data parallelism')
-    ap.add_argument('--graphs', action='store_true', help='measure workload: HIP-graph replay of the single-process step as well')
+    ap.add_argument('--no-graphs', action='store_true', help='(accepted for older scripts: the measure workload runs eagerly by default)')
+    ap.add_argument('--graphs', action='store_true', help='measure workload: HIP-graph replay of the step')
     ap.add_argument('--workload', default='dsprites', choices=['dsprites', 'mnist', 'measure'],
                     help='dsprites = the headline metric (default); mnist / measure = BASELINE.json configs[2] / configs[4]')
     args = ap.parse_args()

@@ -533,7 +533,17 @@ int64_t arvae_measure_vae_ws_floats(const arvae_measure_vae_t *model, int32_t ba
 int arvae_measure_vae_forward(const arvae_measure_vae_t *model, int32_t batch, const float *params, const int64_t *score,
                               float *eps, uint8_t *enc_mask, uint8_t *dec_mask, int32_t teacher_forced, const float *capacity,
                               const arvae_measure_tables_t *tables, float *ws, float *scalars, float *mu, float *sigma, float *z,
-                              int64_t *tokens, arvae_stream_t stream);
+                              int64_t *tokens, float *labels /* [batch][4] attribute labels out, or NULL */, int32_t defer_finish,
+                              arvae_stream_t stream);
+
+/* Data-parallel completion of a forward pass called with defer_finish != 0 (which stops before the regulariser and the scalars): the
+ * regulariser of this rank's rows against the columns GATHERED from every rank (z_cols [n_cols][zdim], lab_cols [n_cols][4],
+ * n_cols = world size x batch: SURVEY.md section 8(e)), then the pass's scalars exactly as the forward pass would have written them,
+ * scalars[ARVAE_VAE_REG] = reg_scale x the row-block term (reg_scale = world size).  The backward pass follows with the same reg_scale.
+ * (The reference evaluates the term on one process: utils/trainer.py:369-403, measurevae/measure_vae_trainer.py:129-137.) */
+int arvae_measure_vae_finish(const arvae_measure_vae_t *model, int32_t batch, const float *capacity, const float *z_cols,
+                             const float *lab_cols, int64_t n_cols, float reg_scale, float *ws, float *scalars, const float *mu,
+                             const float *sigma, const float *z, const float *labels, arvae_stream_t stream);
 
 /* Backward of scalars[ARVAE_VAE_LOSS] times g_loss[0] (device scalar): parameter gradients ACCUMULATE into grads at the model's
  * offsets.  Must follow arvae_measure_vae_forward on the same ws, with the same score / eps / masks / capacity and that call's
@@ -541,7 +551,8 @@ int arvae_measure_vae_forward(const arvae_measure_vae_t *model, int32_t batch, c
 int arvae_measure_vae_backward(const arvae_measure_vae_t *model, int32_t batch, const float *params, float *grads,
                                const int64_t *score, const float *eps, const uint8_t *enc_mask, const uint8_t *dec_mask,
                                const float *capacity, const float *mu, const float *sigma, const float *z, const int64_t *tokens,
-                               const float *scalars, const float *g_loss, float *ws, arvae_stream_t stream);
+                               const float *scalars, const float *g_loss, float reg_scale /* 1, or the world size after _finish */,
+                               float *ws, arvae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Random draws of the path: eps of z_dist.rsample() (imagevae/mnist_vae.py:79, measurevae/measure_vae.py:116) and the

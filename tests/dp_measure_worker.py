@@ -2,9 +2,11 @@
 through ONE training step twice -- eagerly and replayed from a HIP graph that holds the step's collective (the library's RCCL
 all-gather, recorded like a kernel) -- with arvae_amd.parallel attached; rank 0 saves both results.
 
-    python tests/dp_measure_worker.py <rank> <world> <port> <out.npz> <batch_total> [<repeats>]
+    python tests/dp_measure_worker.py <rank> <world> <port> <out.npz> <batch_total> [<repeats> [<path>]]
 
 repeats > 1: capture + replay that many times in this process (the stress loop of tools/dp_replay_loop.sh).
+path: 'executor' (default: the whole-model executor, arvae_measure_vae_forward / _finish / _backward around one grouped all-gather)
+or 'layers' (the per-layer autograd path with the all-gather between encoder and regulariser).
 """
 import os
 import sys
@@ -25,6 +27,7 @@ class FolkDataset:
 def main():
     rank, world, port, out, b_total = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5])
     repeats = int(sys.argv[6]) if len(sys.argv) > 6 else 1
+    path = sys.argv[7] if len(sys.argv) > 7 else 'executor'
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     import numpy as np
@@ -47,7 +50,9 @@ def main():
         trainer = MeasureVAETrainer(ds, model, lr=1e-4, reg_type=('all',), reg_dim=(0, 1, 2, 3), beta=0.001, gamma=1.0,
                                     capacity=0.0, rand=0, delta=10.0)
         trainer.cuda()
+        trainer.use_fused_step = path == 'executor'
         dp = DataParallel(comm=comm).attach(trainer)
+        assert (trainer._fused_binding() is not None) == (path == 'executor')
         model.train()
         model.decoder.teacher_forcing_prob = 2.0
         bl = b_total // world

@@ -122,16 +122,19 @@ def test_rccl_overlapped_collectives_change_nothing(tmp_path, world):
             np.testing.assert_array_equal(on[k], off[k], err_msg=k)
 
 
+@pytest.mark.parametrize('path', ['executor', 'layers'])
 @pytest.mark.parametrize('world,transport', [(1, 'library'), (2, 'library'), (2, 'staged')])
-def test_measure_data_parallel_step_replays_from_graphs(tmp_path, world, transport):
+def test_measure_data_parallel_step_replays_from_graphs(tmp_path, world, transport, path):
     """a data-parallel MeasureVAE step replayed from a HIP graph that holds its collective (the library's RCCL all-gather,
     recorded like the kernels around it; no torch process group, no watchdog thread in the worker) gives the eager
-    data-parallel step's loss and all-reduced gradients, and those are the oracle's single-process step on the whole batch."""
+    data-parallel step's loss and all-reduced gradients, and those are the oracle's single-process step on the whole batch.
+    Both ways the step is built: the whole-model executor (forward, grouped all-gather of z and the labels, arvae_measure_vae_finish,
+    backward) and the per-layer autograd path."""
     _needs(world, transport)
     from oracle import attributes as o_attr
     from oracle import measure_vae as o_mvae
     b_total = 32
-    got = _run_ranks(world, str(tmp_path / 'm.npz'), 0.0, True, worker='dp_measure_worker.py', args=[b_total], transport=transport)
+    got = _run_ranks(world, str(tmp_path / 'm.npz'), 0.0, True, worker='dp_measure_worker.py', args=[b_total, 1, path], transport=transport)
     assert int(got['world']) == world
     if transport == 'library':
         assert int(got['variants']) == 2 and str(got['transport']) == 'LibraryComm'     # one graph per teacher-forcing variant, collective inside
@@ -220,4 +223,6 @@ def test_bench_line_has_the_contract_fields():
     for kind in ('mnist', 'measure'):
         sec = line['secondary'][kind]
         assert 'error' not in sec, sec
-        assert sec['value'] > 0 and sec['roofline']['kernel'] and 0 < sec['step_roofline']['flop_frac_fp32'] < 1
+        # (the fraction is of the fp32-MFMA roof; the Morpho-MNIST step multiplies on the fp16 MFMA -- three products per MAC on a pipe
+        # 16x as fast -- and sits at 0.95-1.0 of the fp32 roof since round 4: not bounded by 1)
+        assert sec['value'] > 0 and sec['roofline']['kernel'] and 0 < sec['step_roofline']['flop_frac_fp32'] < 4
