@@ -179,7 +179,7 @@ def test_executor_rejects_bad_arguments(dev):
     assert lib.arvae_measure_vae_ws_floats(ctypes.byref(d), 256) > 0
     assert lib.arvae_measure_vae_ws_floats(ctypes.byref(d), 0) == -1
     assert lib.arvae_measure_vae_forward(ctypes.byref(d), 8, None, None, None, None, None, 1, None, None, None, None, None, None, None,
-                                         None, None) == -1
+                                         None, None, 0, None) == -1
     assert b'null pointer' in lib.arvae_last_error_string()
     assert not fused.fits(4096) and fused.fits(1024)
     # a model whose paired layers are NOT back to back in the arena (torch's parameters() order): per-layer path
