@@ -197,7 +197,7 @@ int64_t conv64s_ws_floats();
 bool conv64s_fits(const arvae_link_t *l, bool up);
 int conv64s_run(const Operand &src, int n, int sh, int sw, int oh, int ow, int q, int sgn, int off, const float *wt, bool transposed,
                 const float *bias, int act, const uint8_t *mask, float *out, float *ws, hipStream_t s, const char *what, const GateOp *gate,
-                const unsigned *amax_in, unsigned *amax_out);
+                const unsigned *amax_in, unsigned *amax_out, bool prepped);
 
 int64_t conv64_ws_floats(const arvae_link_t *l) {
     const int64_t packed = ((int64_t)l->kh * l->kw * l->chi * l->clo + 3) / 4 * 4;
@@ -239,11 +239,12 @@ static int launch_conv_rows(ConvRows g, const float *wt, bool transposed, float 
 
 // lo[n][lh][lw][clo] = act(conv(hi) + bias) * mask     (Conv2d forward / ConvTranspose2d data gradient)
 int conv64_down(const arvae_link_t *l, const Operand &hi, const float *wt, const float *bias, int act, const uint8_t *mask,
-                float *lo, float *ws, hipStream_t s, const GateOp *gate, const unsigned *amax_in, unsigned *amax_out) {
+                float *lo, float *ws, hipStream_t s, const GateOp *gate, const unsigned *amax_in, unsigned *amax_out, float *prepped) {
     // timeline labels tell the 64 -> 64 launches from the ones with a narrow side (64 -> 8): different kernels, 3x apart
     const char *what = (l->chi >= 64 && l->clo >= 64) ? "conv64_down(wide)" : "conv64_down(narrow)";
     if (conv64s_fits(l, false))
-        return conv64s_run(hi, l->n, l->hh, l->hw, l->lh, l->lw, l->clo, 1, -l->pad, wt, false, bias, act, mask, lo, ws, s, what, gate, amax_in, amax_out);
+        return conv64s_run(hi, l->n, l->hh, l->hw, l->lh, l->lw, l->clo, 1, -l->pad, wt, false, bias, act, mask, lo, prepped ? prepped : ws, s, what, gate,
+                           amax_in, amax_out, prepped != nullptr);
     ConvRows g{};
     if (gate != nullptr) g.gate = *gate;
     g.src = hi; g.n = l->n; g.sh = l->hh; g.sw = l->hw; g.cs = l->chi;
@@ -255,10 +256,11 @@ int conv64_down(const arvae_link_t *l, const Operand &hi, const float *wt, const
 
 // hi[n][hh][hw][chi] = act(convT(lo) + bias) * mask    (ConvTranspose2d forward / Conv2d data gradient)
 int conv64_up(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, int act, const uint8_t *mask,
-              float *hi, float *ws, hipStream_t s, const GateOp *gate, const unsigned *amax_in, unsigned *amax_out) {
+              float *hi, float *ws, hipStream_t s, const GateOp *gate, const unsigned *amax_in, unsigned *amax_out, float *prepped) {
     const char *what = (l->chi >= 64 && l->clo >= 64) ? "conv64_up(wide)" : "conv64_up(narrow)";
     if (conv64s_fits(l, true))
-        return conv64s_run(lo, l->n, l->lh, l->lw, l->hh, l->hw, l->chi, -1, l->pad, wt, true, bias, act, mask, hi, ws, s, what, gate, amax_in, amax_out);
+        return conv64s_run(lo, l->n, l->lh, l->lw, l->hh, l->hw, l->chi, -1, l->pad, wt, true, bias, act, mask, hi, prepped ? prepped : ws, s, what, gate,
+                           amax_in, amax_out, prepped != nullptr);
     ConvRows g{};
     if (gate != nullptr) g.gate = *gate;
     g.src = lo; g.n = l->n; g.sh = l->lh; g.sw = l->lw; g.cs = l->clo;

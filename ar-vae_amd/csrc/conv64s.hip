@@ -47,6 +47,7 @@ constexpr int S_PITCH = 72;                      // dwords per staged pixel: ter
 constexpr int S_PIX = 176;                       // staged source pixels per tile
 constexpr int S_BUF = (S_PIX + 1) * S_PITCH;     // + the zero pixel
 constexpr int S_SLOTS = S_PIX * 16 / 256;        // 16-byte loader slots per thread (11)
+constexpr int C64S_PREP_MAX = 2 * 2 * ARVAE_MAX_LAYERS;   // jobs of one batched weight prep: every layer of a model, both orientations
 constexpr int S_WSTEP2 = 4 * 64;                 // uint4 per (ky, kx, channel chunk) with two row tiles: [row tile][term 2][lane 64]
 constexpr int S_PREP_UINT4 = 16 * 4 * S_WSTEP2;  // 262 144 bytes (half of it for narrow outputs, one row tile); then one uint4 whose
                                                  // first dword is the inverse weight scale
@@ -70,8 +71,8 @@ struct ConvStage {
 // wt = nn.Conv2d / nn.ConvTranspose2d weights [a][b][ky][kx]; (q, c) = (a, b) for the Conv2d-forward direction, (b, a) for
 // the transposed one.  One thread = one (ky, kx, chunk, column tile, lane) = 8 reduction channels of one output channel.
 // Every workgroup first takes the maximum magnitude of the whole tensor itself (q_count x 64 x 16 weights from L2).
-__global__ __launch_bounds__(256) void conv64s_weight_prep_kernel(const float *__restrict__ wt, uint4 *__restrict__ out, int transposed,
-                                                                   int q_count, int nt_count) {
+__device__ __forceinline__ void conv64s_prep_block(const float *__restrict__ wt, uint4 *__restrict__ out, int transposed, int q_count,
+                                                   int nt_count, const int block) {
     __shared__ float wmax[4];
     float m = 0.f;
     const int n4 = q_count * 64 * 4;                             // float4s of the tensor; eight loads in flight per thread
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void conv64s_weight_prep_kernel(const float *_
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
     __syncthreads();
     const Pow2 sc = pow2_for(__builtin_bit_cast(unsigned, fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
-    const int i = blockIdx.x * 256 + threadIdx.x;              // ((tap * 4 + c16) * nt_count + nt) * 64 + lane
+    const int i = block * 256 + threadIdx.x;                   // ((tap * 4 + c16) * nt_count + nt) * 64 + lane
     if (i == 0) out[16 * 4 * nt_count * 2 * 64] = make_uint4(__builtin_bit_cast(unsigned, sc.inv), 0u, 0u, 0u);
     const int lane = i & 63, rest = i >> 6, nt = rest % nt_count, c16 = (rest / nt_count) & 3, tap = rest / (4 * nt_count);
     const int q = nt * 32 + (lane & 31), c0 = c16 * 16 + 8 * (lane >> 5);
@@ -104,6 +105,23 @@ __global__ __launch_bounds__(256) void conv64s_weight_prep_kernel(const float *_
     split_pair_h2(x[6], x[7], sc.s, h.w, l.w);
     uint4 *d = out + ((tap * 4 + c16) * nt_count + nt) * 2 * 64 + lane;
     d[0] = h; d[64] = l;
+}
+__global__ __launch_bounds__(256) void conv64s_weight_prep_kernel(const float *__restrict__ wt, uint4 *__restrict__ out, int transposed,
+                                                                   int q_count, int nt_count) {
+    conv64s_prep_block(wt, out, transposed, q_count, nt_count, blockIdx.x);
+}
+// every wide layer of a model in both orientations as ONE launch at the start of a training step (plan.hip): blockIdx.y = job.
+// (Six per-launch preps of 5-9 us each sat in front of the Morpho-MNIST step's convolutions with the chip idle around them.)
+struct C64sPrepJobs {
+    int count;
+    const float *wt[C64S_PREP_MAX];
+    uint4 *out[C64S_PREP_MAX];
+    int transposed[C64S_PREP_MAX], q[C64S_PREP_MAX];
+};
+__global__ __launch_bounds__(256) void conv64s_weight_prep_batch_kernel(C64sPrepJobs j) {
+    const int k = blockIdx.y, nt = j.q[k] > 32 ? 2 : 1;
+    if ((int)blockIdx.x >= 16 * 4 * nt * 64 / 256) return;
+    conv64s_prep_block(j.wt[k], j.out[k], j.transposed[k], j.q[k], nt, blockIdx.x);
 }
 
 // AMAX array of an operand as a kernel multiplies it: value x activation derivative x keep-mask (Operand::at4); for the caller
@@ -492,9 +510,22 @@ template <int MT, int NT> static void launch_stage(const ConvStage &g, int grid,
 }
 
 // src [n][sh][sw][64] -> out [n][oh][ow][q]; source coordinate = output coordinate + sgn * k + off
+int conv64s_prep_batch(const float *const *wts, float *const *outs, const int *transposed, const int *q, int count, hipStream_t s) {
+    if (count <= 0) return ARVAE_OK;
+    ARVAE_REQUIRE(count <= C64S_PREP_MAX, "conv64s_prep_batch: at most %d jobs", C64S_PREP_MAX);
+    C64sPrepJobs j{};
+    j.count = count;
+    for (int k = 0; k < count; ++k) {
+        j.wt[k] = wts[k]; j.out[k] = reinterpret_cast<uint4 *>(outs[k]); j.transposed[k] = transposed[k]; j.q[k] = q[k];
+    }
+    ARVAE_LAUNCH(conv64s_weight_prep_batch_kernel, dim3(16 * 4 * 2 * 64 / 256, count), dim3(256), 0, s, j);
+    return check_launch("conv64s_weight_prep_batch_kernel");
+}
+
+// prepped: ws already holds the split weights (conv64s_prep_batch on this stream, this step)
 int conv64s_run(const Operand &src, int n, int sh, int sw, int oh, int ow, int q, int sgn, int off, const float *wt, bool transposed,
                 const float *bias, int act, const uint8_t *mask, float *out, float *ws, hipStream_t s, const char *what, const GateOp *gate,
-                const unsigned *amax_in, unsigned *amax_out) {
+                const unsigned *amax_in, unsigned *amax_out, bool prepped) {
     if (ws == nullptr || (reinterpret_cast<uintptr_t>(ws) & 15) != 0)
         return fail(ARVAE_E_INVALID, "%s: needs arvae_link_ws_floats() floats of 16-byte aligned workspace for the split weights", what);
     ConvStage g{};
@@ -507,8 +538,9 @@ int conv64s_run(const Operand &src, int n, int sh, int sw, int oh, int ow, int q
     g.bias = bias; g.mask = mask; g.act = act; g.out = out;
     if (gate != nullptr) g.gate = *gate;
     const int nt = q > 32 ? 2 : 1;
-    ARVAE_LAUNCH(conv64s_weight_prep_kernel, dim3(16 * 4 * nt * 64 / 256), dim3(256), 0, s, wt, reinterpret_cast<uint4 *>(ws),
-                 transposed ? 1 : 0, q, nt);
+    if (!prepped)
+        ARVAE_LAUNCH(conv64s_weight_prep_kernel, dim3(16 * 4 * nt * 64 / 256), dim3(256), 0, s, wt, reinterpret_cast<uint4 *>(ws),
+                     transposed ? 1 : 0, q, nt);
     const bool plain = src.y == nullptr || (src.act == ARVAE_ACT_NONE && src.mask == nullptr);
     if (amax_in == nullptr || !plain) {                         // no maxima with the tensor, or not of what is multiplied
         unsigned *am = reinterpret_cast<unsigned *>(ws + (S_PREP_UINT4 + 1) * 4);

@@ -16,6 +16,8 @@ bool conv32_fits(const arvae_link_t *l);
 bool conv_c1_fits(const arvae_link_t *l);
 bool conv64_fits(const arvae_link_t *l, bool up);
 bool conv64s_fits(const arvae_link_t *l, bool up);
+int64_t conv64s_ws_floats();
+int conv64s_prep_batch(const float *const *wts, float *const *outs, const int *transposed, const int *q, int count, hipStream_t s);
 bool conv64_wgrad_fits(const arvae_link_t *l);
 int link_wgrad_conv64(const arvae_link_t *link, const Operand &lo, const Operand &hi, float *dwt, float *dbias, int bias_side, float *ws,
                       hipStream_t st, const unsigned *amax_lo, const unsigned *amax_hi);
@@ -26,9 +28,11 @@ bool single_channel_down_fits(const arvae_link_t *l);
 int single_channel_down(const arvae_link_t *link, const Operand &hi, const float *wt, const float *bias, int act, const uint8_t *mask,
                         float *lo, hipStream_t s, unsigned *amax_out);
 int conv64_down(const arvae_link_t *l, const Operand &hi, const float *wt, const float *bias, int act, const uint8_t *mask,
-                float *lo, float *ws, hipStream_t s, const GateOp *gate, const unsigned *amax_in = nullptr, unsigned *amax_out = nullptr);
+                float *lo, float *ws, hipStream_t s, const GateOp *gate, const unsigned *amax_in = nullptr, unsigned *amax_out = nullptr,
+                float *prepped = nullptr);
 int conv64_up(const arvae_link_t *l, const Operand &lo, const float *wt, const float *bias, int act, const uint8_t *mask,
-              float *hi, float *ws, hipStream_t s, const GateOp *gate, const unsigned *amax_in = nullptr, unsigned *amax_out = nullptr);
+              float *hi, float *ws, hipStream_t s, const GateOp *gate, const unsigned *amax_in = nullptr, unsigned *amax_out = nullptr,
+              float *prepped = nullptr);
 // (32-channel conv kernels, conv32.hip: operands come with their AMAX arrays, conv32_common.h)
 int conv32_down(const arvae_link_t *l, const Operand &hi, const float *bias, int relu, const float *gate, const uint16_t *gate_bits,
                 uint16_t *bits_out, float *out, hipStream_t s, const float *wprep, const unsigned *amax_in, unsigned *amax_out);
@@ -158,6 +162,9 @@ struct Layout {
     // 32-channel conv layers: the weights split into bf16 terms in per-lane order, rebuilt at the start of every forward
     // pass by ONE launch and used by the layer's forward and data-gradient kernels (-1: not such a layer)
     int64_t enc_wprep[ARVAE_MAX_LAYERS], dec_wprep[ARVAE_MAX_LAYERS];
+    // wide (64-channel, row-staged) conv layers: the split weights of both orientations ([0] Conv2d-forward, [1] transposed), made by
+    // ONE launch at the start of the forward pass and used by the layer's forward and data-gradient launches (-1: not such a layer)
+    int64_t enc_wide[ARVAE_MAX_LAYERS][2], dec_wide[ARVAE_MAX_LAYERS][2];
     // AMAX arrays (conv32_common.h: the partial maxima a tensor carries for the 32-channel kernels that scale it into fp16) of
     // every layer's output, of the gradient w.r.t. it, of the two ping-pong gradient buffers, and one for a tensor that arrives
     // without (the image, or what a kernel outside the conv32 / conv_c1 / latent-block family wrote)
@@ -183,6 +190,15 @@ static int make_layout(const arvae_image_vae_t *m, int64_t n, int64_t n_cols, La
         if (out_elems(l, n) > gmax) gmax = out_elems(l, n);
         if (in_elems(l, n) > gmax) gmax = in_elems(l, n);
     };
+    auto wide = [&](const arvae_layer_t &l, int64_t (&slot)[2]) {
+        arvae_link_t lk = l.link;
+        lk.n = (int32_t)n;
+        const bool other = dense_fits(&lk) || conv32_fits(&lk) || conv_c1_fits(&lk);
+        for (int t = 0; t < 2; ++t) slot[t] = (!other && conv64_fits(&lk, t == 1) && conv64s_fits(&lk, t == 1)) ? take(conv64s_ws_floats()) : -1;
+    };
+    for (int i = 0; i < ARVAE_MAX_LAYERS; ++i) L.enc_wide[i][0] = L.enc_wide[i][1] = L.dec_wide[i][0] = L.dec_wide[i][1] = -1;
+    for (int i = 0; i < m->n_enc; ++i) wide(m->enc[i], L.enc_wide[i]);
+    for (int i = 0; i < m->n_dec; ++i) wide(m->dec[i], L.dec_wide[i]);
     for (int i = 0; i < m->n_enc; ++i) { L.enc_out[i] = take(out_elems(m->enc[i], n)); visit(m->enc[i]); }
     for (int i = 0; i < m->n_dec; ++i) {
         L.dec_out[i] = (i + 1 < m->n_dec) ? take(out_elems(m->dec[i], n)) : -1;
@@ -257,7 +273,7 @@ static arvae_operand_t plain(const float *v) { return arvae_operand_t{v, nullptr
 // maxima of `out` go when the kernel that runs can deliver them (*out_has tells)
 static int layer_forward(const arvae_layer_t &l, int32_t n, const float *params, const float *in, const uint8_t *mask,
                          float *out, uint16_t *bits_out, float *link_ws, arvae_stream_t st, const float *wprep,
-                         const unsigned *in_amax, unsigned *tmp_amax, unsigned *out_amax, bool *out_has) {
+                         const unsigned *in_amax, unsigned *tmp_amax, unsigned *out_amax, bool *out_has, float *wide_prep = nullptr) {
     arvae_link_t lk = l.link;
     lk.n = n;
     const arvae_operand_t op = plain(in);
@@ -286,8 +302,9 @@ static int layer_forward(const arvae_layer_t &l, int32_t n, const float *params,
             in_amax = tmp_amax;
         }
         *out_has = out_amax != nullptr;                  // (both the row-staged and the gathering kernel publish their output's maxima)
-        return l.is_up ? conv64_up(&lk, make_operand(&op), w, b, l.act, mask, out, link_ws, hs, nullptr, in_amax, *out_has ? out_amax : nullptr)
-                       : conv64_down(&lk, make_operand(&op), w, b, l.act, mask, out, link_ws, hs, nullptr, in_amax, *out_has ? out_amax : nullptr);
+        return l.is_up ? conv64_up(&lk, make_operand(&op), w, b, l.act, mask, out, link_ws, hs, nullptr, in_amax, *out_has ? out_amax : nullptr, wide_prep)
+                       : conv64_down(&lk, make_operand(&op), w, b, l.act, mask, out, link_ws, hs, nullptr, in_amax, *out_has ? out_amax : nullptr,
+                                     wide_prep);
     }
     // the single-channel first layer of the wide stack (Conv2d(1, 64)): the same kernel arvae_link_down picks, with the maxima
     if (!l.is_up && out_amax != nullptr && !dense_fits(&lk) && !conv32_fits(&lk) && !conv_c1_fits(&lk) && !conv64_fits(&lk, false) &&
@@ -313,7 +330,7 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
                           SlabReduceBatch *rdefer, arvae_stream_t st, const float *g_scale = nullptr,
                           const uint16_t *gate_bits = nullptr, const float *wprep = nullptr, const GateOp *gate_op = nullptr,
                           const unsigned *g_amax = nullptr, const unsigned *in_amax = nullptr, unsigned *tmp_amax = nullptr,
-                          unsigned *tmp2_amax = nullptr, unsigned *din_amax = nullptr, bool *din_has = nullptr) {
+                          unsigned *tmp2_amax = nullptr, unsigned *din_amax = nullptr, bool *din_has = nullptr, float *wide_prep = nullptr) {
     // g_amax / in_amax: AMAX arrays (conv32_common.h) of g and of `in`, or null -- a 32-channel kernel that needs one then gets it
     // made in tmp_amax / tmp2_amax; din_amax: where the maxima of d_in go when the kernel that writes it delivers them (*din_has)
     arvae_link_t lk = l.link;
@@ -404,7 +421,7 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
                 if (gop.y == nullptr && tmp_amax != nullptr)
                     if (int rc2 = need_g()) return rc2;
                 rc = conv64_down(&lk, make_operand(&gop), w, nullptr, ARVAE_ACT_NONE, nullptr, d_in, link_ws, hs, gate_op,
-                                 gop.y == nullptr ? g_amax : nullptr, din_amax);
+                                 gop.y == nullptr ? g_amax : nullptr, din_amax, wide_prep);
                 *gated = true;
                 *din_has = din_amax != nullptr;
             } else {
@@ -425,7 +442,7 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
                 if (staged && gop.y == nullptr && tmp_amax != nullptr)
                     if (int rc2 = need_g()) return rc2;
                 rc = conv64_up(&lk, make_operand(&gop), w, nullptr, ARVAE_ACT_NONE, nullptr, d_in, link_ws, hs, gate_op,
-                               (staged && gop.y == nullptr) ? g_amax : nullptr, din_amax);
+                               (staged && gop.y == nullptr) ? g_amax : nullptr, din_amax, wide_prep);
                 *gated = true;
                 *din_has = din_amax != nullptr;
             } else {
@@ -533,6 +550,18 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
             mid_prepped = true;
         } else if (int rc = conv32_weight_prep(wts, preps, np, st)) return rc;
     }
+    {   // split the wide conv layers' weights, both orientations, once for this step's forward and data-gradient launches
+        const float *wts[4 * ARVAE_MAX_LAYERS];
+        float *outs[4 * ARVAE_MAX_LAYERS];
+        int tr[4 * ARVAE_MAX_LAYERS], qs[4 * ARVAE_MAX_LAYERS], nj = 0;
+        auto add = [&](const arvae_layer_t &l, const int64_t (&slot)[2]) {
+            for (int t = 0; t < 2; ++t)
+                if (slot[t] >= 0) { wts[nj] = params + l.w_off; outs[nj] = ws + slot[t]; tr[nj] = t; qs[nj] = t ? l.link.chi : l.link.clo; ++nj; }
+        };
+        for (int i = 0; i < m->n_enc; ++i) add(m->enc[i], L.enc_wide[i]);
+        for (int i = 0; i < m->n_dec; ++i) add(m->dec[i], L.dec_wide[i]);
+        if (int rc = conv64s_prep_batch(wts, outs, tr, qs, nj, st)) return rc;
+    }
     // encoder
     const float *h = first ? ws + L.enc_out[0] : x;
     const unsigned *h_amax = first ? U(L.enc_amax[0]) : nullptr;   // AMAX array of h, when the kernel that wrote h delivered one
@@ -545,7 +574,7 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
         // (a 32-channel layer's input keeps its AMAX array for the weight gradient: a missing one is made in the input's own slot)
         if (int rc = layer_forward(m->enc[i], batch, params, h, mask, ws + L.enc_out[i], bits, ws + L.link_ws, stream,
                                    L.enc_wprep[i] >= 0 ? ws + L.enc_wprep[i] : nullptr, h_amax, i > 0 ? U(L.enc_amax[i - 1]) : U(L.tmp_amax),
-                                   U(L.enc_amax[i]), &has))
+                                   U(L.enc_amax[i]), &has, L.enc_wide[i][m->enc[i].is_up ? 1 : 0] >= 0 ? ws + L.enc_wide[i][m->enc[i].is_up ? 1 : 0] : nullptr))
             return rc;
         h = ws + L.enc_out[i];
         h_amax = has ? U(L.enc_amax[i]) : nullptr;
@@ -628,7 +657,7 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
             bool has = false;
             if (int rc = layer_forward(m->dec[i], batch, params, h, mask, out, bits, ws + L.link_ws, stream,
                                        L.dec_wprep[i] >= 0 ? ws + L.dec_wprep[i] : nullptr, h_amax, i > 0 ? U(L.dec_amax[i - 1]) : U(L.tmp_amax),
-                                       U(L.dec_amax[i]), &has))
+                                       U(L.dec_amax[i]), &has, L.dec_wide[i][m->dec[i].is_up ? 1 : 0] >= 0 ? ws + L.dec_wide[i][m->dec[i].is_up ? 1 : 0] : nullptr))
                 return rc;
             h_amax = has ? U(L.dec_amax[i]) : nullptr;
         }
@@ -789,7 +818,8 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
                                     (gate != nullptr && i > 0 && L.dec_bits[i - 1] >= 0)
                                         ? reinterpret_cast<const uint16_t *>(ws + L.dec_bits[i - 1]) : nullptr,
                                     L.dec_wprep[i] >= 0 ? ws + L.dec_wprep[i] : nullptr, gate_op, cur_amax, in_amax_of(true, i),
-                                    U(L.tmp_amax), U(L.tmp2_amax), grad_amax(dst), &din_has))
+                                    U(L.tmp_amax), U(L.tmp2_amax), grad_amax(dst), &din_has,
+                                    L.dec_wide[i][m->dec[i].is_up ? 0 : 1] >= 0 ? ws + L.dec_wide[i][m->dec[i].is_up ? 0 : 1] : nullptr))
             return rc;
         pre = gated;
         if (heads_next_g == nullptr) { cur = dst; cur_amax = din_has ? grad_amax(dst) : nullptr; }
@@ -912,7 +942,8 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
                                     (gate != nullptr && i > 0 && L.enc_bits[i - 1] >= 0)
                                         ? reinterpret_cast<const uint16_t *>(ws + L.enc_bits[i - 1]) : nullptr,
                                     L.enc_wprep[i] >= 0 ? ws + L.enc_wprep[i] : nullptr, gate_op, cur_amax, in_amax_of(false, i),
-                                    U(L.tmp_amax), U(L.tmp2_amax), grad_amax(dst), &din_has))
+                                    U(L.tmp_amax), U(L.tmp2_amax), grad_amax(dst), &din_has,
+                                    L.enc_wide[i][m->enc[i].is_up ? 0 : 1] >= 0 ? ws + L.enc_wide[i][m->enc[i].is_up ? 0 : 1] : nullptr))
             return rc;
         pre = gated;
         cur = dst;
