@@ -186,3 +186,31 @@ def test_executor_rejects_bad_arguments(dev):
     from arvae_amd.optim import FlatAdam
     other = FlatAdam(model.parameters(), lr=1e-4)
     assert 'adjacent' in FusedMeasureVAE.supports(model, other, ())
+
+
+def test_trainer_falls_back_to_the_per_layer_path(dev):
+    """shapes the executor is not built for (a 35-note vocabulary at decoder hidden size 32: no one-launch free-running decoder) and
+    debug checks keep the per-layer path; a single measure (B = 1) and the largest batch whose positions fit the segment sums run
+    through the executor"""
+    from arvae_amd.measure_vae import MeasureVAE
+    from arvae_amd.measure_vae_trainer import MeasureVAETrainer
+    torch.manual_seed(2)
+    ds = _FolkDataset()
+    model = MeasureVAE(ds, 10, 2, 2, 64, 0.0, 16, 2, 32, 0.0, False, 'folk')
+    trainer = MeasureVAETrainer(ds, model, lr=1e-4, reg_type=('all',), reg_dim=(0, 1), beta=0.001, gamma=1.0, capacity=0.0, rand=0, delta=10.0)
+    trainer.cuda()
+    model.train()
+    score = torch.from_numpy(syn.measure_batch(8, seed=3)).to(dev)
+    assert trainer.fused_executor(score) is None
+    trainer.zero_grad()
+    loss, _ = trainer.loss_and_acc_for_batch((score, score), 0, 0, True)
+    trainer.backward(loss)
+    assert torch.isfinite(loss) and trainer.optimizer.grad_arena.abs().sum() > 0
+    # B = 1 and B = 1024 through the executor, against the per-layer path
+    trainer2, model2 = _trainer(128, 32, 0.0)
+    for b in (1, 1024):
+        sc = torch.from_numpy(syn.measure_batch(b, seed=40 + b)).to(dev)
+        eps = torch.from_numpy(syn.normal_noise((b, 32), seed=41))
+        _same(_one_step(trainer2, model2, sc, True, True, eps), _one_step(trainer2, model2, sc, False, True, eps), ('edge', b))
+    big = torch.from_numpy(syn.measure_batch(2048, seed=1)).to(dev)
+    assert trainer2.fused_executor(big) is None               # (24 x 2048 positions do not fit the segment sums' LDS: per-layer path)
