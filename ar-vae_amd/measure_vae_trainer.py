@@ -151,9 +151,13 @@ class MeasureVAETrainer(Trainer):
         # the executor issues a step's launches from two library calls (three and one collective under data parallelism): a captured
         # graph has no host work left to save and its nodes cost more than the stream launches they replace (B = 256: 1.09 ms eager,
         # 1.11 ms replayed)
-        if self._fused_binding() is not None:
-            return None
-        return super()._replay_step(batch)
+        fused = self._fused_binding()
+        if fused is not None:
+            score = batch[0]
+            rows = score.shape[0] * (getattr(self.dataset, 'n_bars', None) or 1) if torch.is_tensor(score) else -1
+            if rows > 0 and fused.fits(rows):
+                return None
+        return super()._replay_step(batch)                   # (a batch the executor does not take: the per-layer path, replayed)
 
     def _fused_loss_and_acc(self, fused, score, epoch_num, first_of_epoch, train):
         from .fused_measure import ACC, DIST, RECON, REG

@@ -14,7 +14,7 @@ g = torch.randn(rows, n_out, device=dev)
 w = torch.randn(n_out, n_in, device=dev) * 0.05
 b = torch.zeros(n_out, device=dev)
 dw, db = torch.zeros_like(w), torch.zeros_like(b)
-fn = ctypes.CDLL(_lib.LIB_PATH).arvae_debug_rg_stamps
+fn = ctypes.CDLL(os.environ.get('ARVAE_LIB') or _lib.LIB_PATH).arvae_debug_rg_stamps
 fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
 
 
