@@ -200,3 +200,53 @@ def test_product_library_reads_no_environment(lib):
     assert 'getenv' not in undefined(build.LIB_PATH) and 'secure_getenv' not in undefined(build.LIB_PATH)
     assert 'getenv' in undefined(build.DIAG_LIB_PATH)
     assert exported(build.LIB_PATH) == exported(build.DIAG_LIB_PATH)
+
+
+def test_measure_executor_descriptor_without_gpu(lib):
+    """the whole-model MeasureVAE executor's host side on a CPU-only box: the descriptor FusedMeasureVAE builds over a FlatAdam arena
+    (offsets inside the arena, the three pairs of tensors back to back), the workspace size the library reports for it, and the
+    argument checks of the three entry points (pure host code: nothing is launched)."""
+    import torch
+    from arvae_amd import synthetic as syn
+    from arvae_amd.fused_measure import FusedMeasureVAE
+    from arvae_amd.measure_vae import MeasureVAE
+    from arvae_amd.optim import FlatAdam
+
+    class Folk:
+        class_name = '4by4_FolkNBarDataset_1_'
+        n_bars = 1
+
+        def __init__(self):
+            self.index2note_dicts, self.note2index_dicts = syn.measure_vocabulary()
+
+        def __repr__(self):
+            return self.class_name
+    torch.manual_seed(0)
+    model = MeasureVAE(Folk(), 10, 2, 2, 128, 0.5, 32, 2, 128, 0.5, False, 'folk')
+    opt = FlatAdam(model.arena_parameters(), lr=1e-4)
+    fused = FusedMeasureVAE(model, opt, (0, 1, 2, 3), 0.001, 1.0, 10.0)
+    d = fused.descriptor()
+    total = opt.param_arena.numel()
+    offs = [d.enc_table, d.enc_w_ih[0], d.enc_w_ih[1], d.enc_b_ih[0], d.enc_w_hh[1][1], d.head_w0, d.mean_w2, d.dec_table, d.x0, d.b0, d.z2beat_w,
+            d.beat_w_ih[0], d.tick_init_w, d.tick_w_ih[0], d.tick_w_hh[1], d.out_w, d.out_b]
+    assert all(0 <= o < total and o % 4 == 0 for o in offs) and len(set(offs)) == len(offs)
+    # the reverse direction's projection follows the forward direction's; the paired heads / tick-initialisation layers likewise
+    gru = model.encoder.lstm
+    assert d.enc_w_ih[0] + gru.weight_ih_l0.numel() == fused._offset(gru.weight_ih_l0_reverse)
+    assert d.head_w0 + model.encoder.linear_mean[0].weight.numel() == fused._offset(model.encoder.linear_log_std[0].weight)
+    assert d.tick_init_w + model.decoder.beat_emb_to_tick_rnn_hidden[0].weight.numel() == fused._offset(model.decoder.beat_emb_to_tick_rnn_input[0].weight)
+    assert (d.vocab, d.emb, d.enc_hidden, d.dec_hidden, d.zdim, d.steps, d.beats, d.ticks_per_beat, d.n_reg) == (35, 10, 128, 128, 32, 24, 4, 6, 4)
+    ws256, ws8 = lib.arvae_measure_vae_ws_floats(ctypes.byref(d), 256), lib.arvae_measure_vae_ws_floats(ctypes.byref(d), 8)
+    assert ws256 > ws8 > 0 and ws256 % 4 == 0 and ws256 * 4 < 2 ** 31          # (some 400 MB at the benchmark batch)
+    assert lib.arvae_measure_vae_ws_floats(ctypes.byref(d), 0) == -1 and lib.arvae_measure_vae_ws_floats(None, 8) == -1
+    assert lib.arvae_measure_vae_ws_floats(ctypes.byref(d), 4096) == -1 and b'segment sums' in lib.arvae_last_error_string()
+    assert lib.arvae_measure_vae_forward(ctypes.byref(d), 8, None, None, None, None, None, 1, None, None, None, None, None, None, None, None,
+                                         None, 0, None) == -1 and b'null pointer' in lib.arvae_last_error_string()
+    assert lib.arvae_measure_vae_finish(ctypes.byref(d), 8, None, None, None, 16, 2.0, None, None, None, None, None, None, None) == -1
+    assert lib.arvae_measure_vae_backward(ctypes.byref(d), 8, None, None, None, None, None, None, None, None, None, None, None, None, None,
+                                          1.0, None, None) == -1
+    d.steps = 23
+    assert lib.arvae_measure_vae_ws_floats(ctypes.byref(d), 8) == -1 and b'beats * ticks_per_beat' in lib.arvae_last_error_string()
+    # torch's parameters() order does not put the pairs side by side: the trainer then keeps the per-layer path
+    other = FlatAdam(model.parameters(), lr=1e-4)
+    assert 'adjacent' in FusedMeasureVAE.supports(model, other, ())
