@@ -492,6 +492,86 @@ __global__ __launch_bounds__(256) void rows_gemm_x3_kernel(RowsGemm g) {
     rows_gemm_x3_body<LA, LB, EP, VA, VB>(g, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
+// The weight-gradient product on 128 x 128 output tiles (2 x 2 waves of 2 x 2 MFMA tiles each): four times the multiply-adds per
+// staged operand byte and per barrier of the 64 x 64 body above.  Stamped, a 64 x 64 workgroup spent 2.45 us per 32-row chunk
+// (0.8 in its two barriers, 0.3 waiting for loads, 0.45 splitting) on 0.16 us of MFMA issue, and the batched launch moved 405 MB
+// through L2 for 113 MB of operands.  "K x rows" operands, slice epilogue, 16-byte loads only.
+__device__ __forceinline__ void rows_wgrad128_body(const RowsGemm &g, const int bx, const int by, const int bz) {
+    typedef TileLoader<RG_KROWS, 128, true> Load;
+    __shared__ __attribute__((aligned(16))) unsigned short As[3 * Load::PLANE];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[3 * Load::PLANE];
+    const int lane = threadIdx.x & 63, half = lane >> 5, rc = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p0 = bx * 128, q0 = by * 128;
+    const int rbeg = bz * g.rslice, rend = min(g.Rn, rbeg + g.rslice);
+    Load la, lb;
+    const int wp = wave & 1, wq = wave >> 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    float bsum = 0.f;
+    la.load(g.a, g.lda, p0, g.P, rbeg, rend);
+    lb.load(g.b, g.ldb, q0, g.Q, rbeg, rend);
+    int abase[2], bbase[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { abase[i] = Load::lane_base(2 * wp + i); bbase[i] = Load::lane_base(2 * wq + i); }
+    for (int r0 = rbeg; r0 < rend; r0 += RG_R) {
+        __syncthreads();
+        la.commit3(As);
+        lb.commit3(Bs);
+        __syncthreads();
+        if (r0 + RG_R < rend) {
+            la.load(g.a, g.lda, p0, g.P, r0 + RG_R, rend);
+            lb.load(g.b, g.ldb, q0, g.Q, r0 + RG_R, rend);
+        }
+#pragma unroll
+        for (int s = 0; s < RG_R / 16; ++s) {
+            rg_bf16x8 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = Load::operand(As, abase[i], 0, s); am[i] = Load::operand(As, abase[i], 1, s); al[i] = Load::operand(As, abase[i], 2, s);
+                bh[i] = Load::operand(Bs, bbase[i], 0, s); bm[i] = Load::operand(Bs, bbase[i], 1, s); bl[i] = Load::operand(Bs, bbase[i], 2, s);
+            }
+            // product-major over the four accumulators: consecutive MFMAs never wait for each other's result
+#pragma unroll
+            for (int prod = 0; prod < 6; ++prod)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const rg_bf16x8 x = prod == 0 ? al[a] : ((prod == 2 || prod == 3) ? am[a] : ah[a]);
+                        const rg_bf16x8 y = prod == 1 ? bl[b] : ((prod == 2 || prod == 4) ? bm[b] : bh[b]);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc[a][b], 0, 0, 0);
+                    }
+        }
+        if (g.want_bias && by == 0 && threadIdx.x < 128) {
+#pragma unroll 8
+            for (int r = 0; r < RG_R; ++r) {
+                const unsigned short *e = As + r * Load::Plane::TRP + threadIdx.x;
+                bsum += (__builtin_bit_cast(float, (unsigned)e[0] << 16) + __builtin_bit_cast(float, (unsigned)e[Load::PLANE] << 16)) +
+                        __builtin_bit_cast(float, (unsigned)e[2 * Load::PLANE] << 16);
+            }
+        }
+    }
+    float *out = g.out + bz * g.slice_floats;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int q = q0 + 64 * wq + 32 * b + rc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p = p0 + 64 * wp + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (p < g.P && q < g.Q) out[(int64_t)p * g.ldo + q] = acc[a][b][r];
+            }
+        }
+    if (g.want_bias && by == 0 && threadIdx.x < 128 && p0 + (int)threadIdx.x < g.P) out[(int64_t)g.P * g.ldo + p0 + threadIdx.x] = bsum;
+}
+
 // Several long-batch weight gradients (RG_KROWS x RG_KROWS operands, slice epilogue) in ONE launch: the whole-sequence layers
 // of a backward pass each leave a 0.6-2.4 GFLOP product that nothing on the pass's critical path waits for, and alone each
 // is a 15-35 us launch that fills a fraction of the chip; together (workgroup -> (job, tile, slice) through the running
@@ -512,8 +592,8 @@ __global__ __launch_bounds__(256) void rows_wgrad_batch_kernel(RowsGemmBatch b) 
     while (j + 1 < b.count && wg >= b.wg_end[j]) ++j;
     const int local = wg - (j > 0 ? b.wg_end[j - 1] : 0);
     const RowsGemm &g = b.job[j];
-    const int tp = (g.P + RG_TP - 1) / RG_TP, tq = (g.Q + RG_TQ - 1) / RG_TQ;
-    rows_gemm_x3_body<RG_KROWS, RG_KROWS, RG_EP_SLICE, true, true>(g, local % tp, (local / tp) % tq, local / (tp * tq));
+    const int tp = (g.P + 127) / 128, tq = (g.Q + 127) / 128;
+    rows_wgrad128_body(g, local % tp, (local / tp) % tq, local / (tp * tq));
 }
 
 // ---- wgrad: dW[n][feat_in(km)] += sum_m G[m][mem_out(n)] * X[m][km] ;  db[n] += sum_m G[m][mem_out(n)] ------
@@ -865,7 +945,11 @@ void dense_wgrad_long_begin(LongWgradQueue *q, float *ws, int64_t ws_cap) {
     q->ws_cap = ws_cap;
     q->ws_used = 0;
 }
-static int long_rslice(int rows) { return rows >= 4096 ? 512 : 256; }
+// Rows per slice.  Workspace is reserved for the finest slicing (256 rows); the launch itself slices so that all its workgroups are
+// resident at once -- two per CU -- as nearly as the jobs' tile counts allow (dense_wgrad_long_flush): with one workgroup more than
+// the chip holds the launch takes two rounds (measured: 528 workgroups 90 us, 396 workgroups 72 us for the same products).
+constexpr int LONG_RSLICE_MIN = 256;
+static int long_rslice(int) { return LONG_RSLICE_MIN; }
 int64_t dense_wgrad_long_ws_floats(const arvae_link_t *l) {
     if (l->n < DENSE_SPLIT_MIN_ROWS) return 0;
     const int rs = long_rslice(l->n);
@@ -888,7 +972,7 @@ bool dense_wgrad_long_defer(LongWgradQueue *q, const arvae_link_t *l, const Oper
     r = RowsGemm{};
     r.a = g.v; r.lda = p.n_out; r.b = x; r.ldb = p.n_in; r.P = p.n_out; r.Q = p.n_in; r.Rn = p.batch; r.rslice = rs;
     r.out = ws; r.ldo = p.n_in; r.slice_floats = slice_floats; r.want_bias = dbias != nullptr;
-    const int wgs = ((p.n_out + RG_TP - 1) / RG_TP) * ((p.n_in + RG_TQ - 1) / RG_TQ) * slices;
+    const int wgs = ((p.n_out + 127) / 128) * ((p.n_in + 127) / 128) * slices;
     q->gemm.wg_end[k] = (k > 0 ? q->gemm.wg_end[k - 1] : 0) + wgs;
     q->gemm.count = k + 1;
     const int64_t total = w_floats + (dbias != nullptr ? p.n_out : 0);
@@ -899,6 +983,24 @@ bool dense_wgrad_long_defer(LongWgradQueue *q, const arvae_link_t *l, const Oper
 }
 int dense_wgrad_long_flush(LongWgradQueue *q, hipStream_t s) {
     if (q == nullptr || q->gemm.count == 0) return ARVAE_OK;
+    {   // one round of workgroups: slices per job = resident slots / tiles of all jobs (never finer than the workspace allows)
+        int tiles = 0;
+        for (int k = 0; k < q->gemm.count; ++k) tiles += ((q->gemm.job[k].P + 127) / 128) * ((q->gemm.job[k].Q + 127) / 128);
+        const int slots = 2 * device_cu_count();
+        int target = slots / (tiles > 0 ? tiles : 1);
+        if (target < 1) target = 1;
+        int wg = 0;
+        for (int k = 0; k < q->gemm.count; ++k) {
+            RowsGemm &r = q->gemm.job[k];
+            int rs = ((r.Rn + target - 1) / target + RG_R - 1) / RG_R * RG_R;
+            if (rs < LONG_RSLICE_MIN) rs = LONG_RSLICE_MIN;
+            const int slices = (r.Rn + rs - 1) / rs;
+            r.rslice = rs;
+            q->red.job[k].slices = slices;
+            wg += ((r.P + 127) / 128) * ((r.Q + 127) / 128) * slices;
+            q->gemm.wg_end[k] = wg;
+        }
+    }
     ARVAE_LAUNCH(rows_wgrad_batch_kernel, dim3((q->gemm.wg_end[q->gemm.count - 1] + 7) / 8 * 8), dim3(256), 0, s, q->gemm);
     if (int rc = check_launch("rows_wgrad_batch_kernel")) return rc;
     ARVAE_LAUNCH(dense_split_reduce_batch_kernel, dim3(q->red.wg_end[q->red.count - 1]), dim3(256), 0, s, q->red);

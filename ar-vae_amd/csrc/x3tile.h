@@ -35,7 +35,10 @@ __device__ __forceinline__ rg_bf16x8 rg_lds_x8(const unsigned short *p) {
 //   of a transposed block on disjoint banks.
 template <int LAY, int TP>
 struct X3Plane {
-    static constexpr int PLANE = LAY == RG_ROWSK ? TP * RG_XP : RG_R * RG_TRP;
+    // row pitch of a "K x rows" image: TP columns + padding that keeps the four rows of a transposed block on disjoint bank
+    // quarters (192 bytes for 64 columns, 320 for 128: both 16 banks past a multiple of 32)
+    static constexpr int TRP = (LAY == RG_KROWS && TP > 64) ? TP + 32 : RG_TRP;
+    static constexpr int PLANE = LAY == RG_ROWSK ? TP * RG_XP : RG_R * TRP;
     // element idx of the tile's float4 grid (TP * RG_R / 4 of them): 4 values consecutive along the contiguous axis
     __device__ static __forceinline__ void commit(unsigned short *lds, int idx, const float4 &v) {
         unsigned h0, m0, l0, h1, m1, l1;
@@ -43,7 +46,7 @@ struct X3Plane {
         rg_split3(v.z, v.w, h1, m1, l1);
         unsigned short *d;
         if (LAY == RG_ROWSK) d = lds + (idx / (RG_R / 4)) * RG_XP + 4 * (idx % (RG_R / 4));
-        else d = lds + (idx / (TP / 4)) * RG_TRP + 4 * (idx % (TP / 4));
+        else d = lds + (idx / (TP / 4)) * TRP + 4 * (idx % (TP / 4));
         *reinterpret_cast<uint2 *>(d) = uint2{h0, h1};
         *reinterpret_cast<uint2 *>(d + PLANE) = uint2{m0, m1};
         *reinterpret_cast<uint2 *>(d + 2 * PLANE) = uint2{l0, l1};
@@ -54,16 +57,16 @@ struct X3Plane {
         const int lane = threadIdx.x & 63;
         if (LAY == RG_ROWSK) return (32 * w + (lane & 31)) * RG_XP + 8 * (lane >> 5);
         const int g16 = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;      // block row q, columns 4 pp .. 4 pp + 3
-        return (8 * (g16 >> 1) + q) * RG_TRP + 32 * w + 16 * (g16 & 1) + 4 * pp;
+        return (8 * (g16 >> 1) + q) * TRP + 32 * w + 16 * (g16 & 1) + 4 * pp;
     }
     __device__ static __forceinline__ rg_bf16x8 operand(const unsigned short *lds, int base, int t, int s) {
         if (LAY == RG_ROWSK) return rg_lds_x8(lds + t * PLANE + base + 16 * s);
         typedef short s16x4 __attribute__((ext_vector_type(4)));
         typedef short s16x8 __attribute__((ext_vector_type(8)));
         typedef __attribute__((address_space(3))) s16x4 *lds_ptr;
-        const unsigned short *p = lds + t * PLANE + base + 16 * s * RG_TRP;
+        const unsigned short *p = lds + t * PLANE + base + 16 * s * TRP;
         const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)p);
-        const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p + 4 * RG_TRP));
+        const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p + 4 * TRP));
         return __builtin_bit_cast(rg_bf16x8, (s16x8)__builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
     }
 };
