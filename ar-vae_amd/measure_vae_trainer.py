@@ -304,8 +304,17 @@ class MeasureVAETrainer(Trainer):
         with torch.no_grad():
             for batch in data_loader:
                 score, metadata = self.process_batch_data(batch)
-                weights = self.model(measure_score_tensor=score, measure_metadata_tensor=metadata, train=False)[0]
-                loss, acc = ops.token_recon(weights, score)
+                fused = self.fused_executor(score)
+                if fused is not None:                          # the executor's forward pass leaves both numbers in its scalars
+                    from .fused_measure import ACC, RECON
+                    enc = self.model.encoder
+                    eps = enc._eps_queue.popleft() if enc._eps_queue else enc.static_eps
+                    tables = fused.tables(self, score.device) if self.use_reg_loss else None
+                    scalars = fused.run(score, False, None, tables, eps, None)[1]
+                    loss, acc = scalars[RECON], scalars[ACC]
+                else:
+                    weights = self.model(measure_score_tensor=score, measure_metadata_tensor=metadata, train=False)[0]
+                    loss, acc = ops.token_recon(weights, score)
                 loss_sum = loss.detach().clone() if loss_sum is None else loss_sum + loss.detach()
                 acc_sum = acc.detach().clone() if acc_sum is None else acc_sum + acc.detach()
                 count += 1
