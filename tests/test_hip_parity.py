@@ -698,6 +698,45 @@ def test_gru_sequence_vs_torch(dev, rows, hid, steps):
         close(prm[k].grad, v.grad, rtol=1e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize('seed', [0, 6, 8])
+def test_fp16_forward_recurrence_holds_fp32_accuracy_vs_float64(dev, seed):
+    """the forward recurrence multiplies on the fp16 MFMA (scaled two-term operands, three products: gru_seq.hip) and the backward one
+    on the three-term bf16 split: against a FLOAT64 bidirectional nn.GRU (24 steps, 37 rows, H = 128, non-zero initial states) the
+    outputs stay as close as torch's own fp32 CPU layer does (measured over twelve draws: 2.3-3.1e-7 against 3.0-5.8e-7,
+    tools/probes/gru_error.py), and the gradients agree with the float64 ones to a few 1e-6 of their largest element."""
+    from arvae_amd import ops
+    rows, hid, steps, fin = 37, 128, 24, 10
+    torch.manual_seed(seed)
+    rs = np.random.RandomState(15 + seed)
+    gru = torch.nn.GRU(fin, hid, 1, bidirectional=True)
+    x = torch.from_numpy(rs.standard_normal((steps, rows, fin)).astype(np.float32))
+    h0 = torch.from_numpy(rs.standard_normal((2, rows, hid)).astype(np.float32))
+    gy = torch.from_numpy(rs.standard_normal((steps, rows, 2 * hid)).astype(np.float32))
+    with torch.no_grad():
+        y32, _ = gru(x, h0)
+    g64 = torch.nn.GRU(fin, hid, 1, bidirectional=True).double()
+    g64.load_state_dict({k: v.double() for k, v in gru.state_dict().items()})
+    x64, h64 = x.double().requires_grad_(True), h0.double().requires_grad_(True)
+    y64, _ = g64(x64, h64)
+    (y64 * gy.double()).sum().backward()
+    prm = {k: v.detach().clone().to(dev).requires_grad_(True) for k, v in gru.named_parameters()}
+    xd, hd = x.to(dev).requires_grad_(True), h0.to(dev).requires_grad_(True)
+    dirs = []
+    for d, suf in enumerate(('', '_reverse')):
+        gi = ops.dense(xd.view(steps * rows, fin), prm['weight_ih_l0' + suf], prm['bias_ih_l0' + suf],
+                       ops.Link.dense(fin, 3 * hid), 0).view(steps, rows, 3 * hid)
+        dirs.append((gi, prm['weight_hh_l0' + suf], prm['bias_hh_l0' + suf], hd[d], d == 1))
+    yd, _ = ops.gru_sequence(steps, dirs)
+    (yd * gy.to(dev)).sum().backward()
+    e_hip = float((yd.detach().cpu().double() - y64.detach()).abs().max())
+    e_cpu = float((y32.double() - y64.detach()).abs().max())
+    assert e_hip <= 1.5 * e_cpu + 1e-7 and e_hip <= 1e-6, (e_hip, e_cpu)
+    for name, got, want in [('x', xd.grad, x64.grad), ('h0', hd.grad, h64.grad)] + \
+            [(k, prm[k].grad, v.grad) for k, v in g64.named_parameters()]:
+        err = float((got.detach().cpu().double() - want).abs().max()) / float(want.abs().max())
+        assert err <= 5e-6, (name, err)
+
+
 @pytest.mark.parametrize('rows,hid,steps,fin', [(256, 128, 24, 10), (37, 128, 24, 256), (9, 32, 5, 12)])
 def test_merged_bidirectional_projection_vs_torch(dev, rows, hid, steps, fin):
     """Both directions' input projections as ONE product (ops.dense_pair over weights / biases / gradient buffers laid out
