@@ -184,6 +184,17 @@ __device__ __forceinline__ void recon_elem(float l, float x, float inv_b, float 
     corr += ((l >= 0.f) == (x >= 0.5f)) ? 1.f : 0.f;
 }
 
+// ---- a barrier for LDS traffic only ------------------------------------------------------------
+// __syncthreads() is a workgroup-scope release / acquire of ALL memory: the compiler puts s_waitcnt vmcnt(0) in front of the
+// s_barrier, i.e. every wave first waits for its outstanding GLOBAL loads and stores -- including the operands it has just
+// prefetched for the next step of a recurrence (stamped in gru_seq_bwd_x3_kernel: 3000 of a step's 8500 cycles sat there).  Where
+// the waves of a workgroup exchange data through LDS only, this waits for the LDS queue alone.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // ---- reductions -------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

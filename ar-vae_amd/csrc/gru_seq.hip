@@ -101,7 +101,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_kernel(GruSeqBatch batch, i
             gi_next[i][0] = p[0]; gi_next[i][1] = p[H]; gi_next[i][2] = p[2 * H];
         }
     }
-    __syncthreads();
+    lds_barrier();
 
     for (int step = 0; step < T; ++step) {
         const int t = s.reverse ? T - 1 - step : step;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_kernel(GruSeqBatch batch, i
                 if (step == T - 1 && s.h_fin != nullptr) s.h_fin[(int64_t)rows[i] * s.h_fin_stride + unit] = hn;
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_kernel(GruSeqBatch batch, i
             }
         }
         if (step + 1 < T) fetch(step + 1);
-        __syncthreads();
+        lds_barrier();
         f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int kq = 0; kq < KQ; ++kq) {
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_x3_kernel(GruSeqBatch batch
         gi_next[i][0] = gi_p[i][0]; gi_next[i][1] = gi_p[i][H]; gi_next[i][2] = gi_p[i][2 * H];
         gi_p[i] += gi_step;
     }
-    __syncthreads();
+    lds_barrier();
     f32x4 keep_sv[4];                        // results of the previous step, stored after the barrier
     float keep_h[4];
     int keep_t = -1;
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_x3_kernel(GruSeqBatch batch
         __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the LDS writes are done
 #endif
         GSTAMP(2);
-        __syncthreads();
+        lds_barrier();
         GSTAMP(3);
     }
 #ifdef ARVAE_GRU_STAMPS
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_h2_kernel(GruSeqBatch batch
         gi_next[i][0] = gi_p[i][0]; gi_next[i][1] = gi_p[i][H]; gi_next[i][2] = gi_p[i][2 * H];
         gi_p[i] += gi_step;
     }
-    __syncthreads();
+    lds_barrier();
     f32x4 keep_sv[4];                        // results of the previous step, stored after the barrier
     float keep_h[4];
     int keep_t = -1;
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_h2_kernel(GruSeqBatch batch
         __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the LDS writes are done
 #endif
         GSTAMP(2);
-        __syncthreads();
+        lds_barrier();
         GSTAMP(3);
     }
 #ifdef ARVAE_GRU_STAMPS
@@ -708,11 +708,18 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_x3_kernel(GruSeqBatch batch
         }
     };
     fetch(0);
+#ifdef ARVAE_GRU_STAMPS
+    unsigned long long ph[4] = {0, 0, 0, 0}, tc = __builtin_readcyclecounter();
+#endif
 
     for (int step = 0; step < T; ++step) {
         const int t = s.reverse ? step : T - 1 - step;
         const int cur = step & 1;
         float gz[4], o_gi[4][3], o_hn[4], o_hp[4];
+#ifdef ARVAE_GRU_STAMPS
+        { float dep = nx[0][0] + nx[3][5] + nx[1][3]; asm volatile("" :: "v"(dep)); __builtin_amdgcn_s_waitcnt(0); }
+#endif
+        GSTAMP(0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float g = live[i] ? nx[i][0] + carry[i] : 0.f;
@@ -731,8 +738,13 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_x3_kernel(GruSeqBatch batch
             store_split3_pair(d + H, DP, PLANE, o_gi[i][1], o_gi[i + 1][1]);
             store_split3_pair(d + 2 * H, DP, PLANE, o_hn[i], o_hn[i + 1]);
         }
+#ifdef ARVAE_GRU_STAMPS
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+#endif
+        GSTAMP(1);
         if (step + 1 < T) fetch(step + 1);
-        __syncthreads();
+        lds_barrier();
+        GSTAMP(2);
         f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         const unsigned short *db = &dbuf[cur][col * DP + 8 * quad];
         static_assert(KS % 3 == 0 && KS / 3 <= 4, "three k-steps at a time, one per accumulator; one row's stores behind each group");
@@ -761,7 +773,20 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_x3_kernel(GruSeqBatch batch
         for (int i = KS / 3; i < 4; ++i) row_stores(i);
 #pragma unroll
         for (int i = 0; i < 4; ++i) carry[i] = gz[i] + (acc[0][i] + acc[1][i] + acc[2][i]);
+#ifdef ARVAE_GRU_STAMPS
+        { float dep = carry[0] + carry[3]; asm volatile("" :: "v"(dep)); }
+#endif
+        GSTAMP(3);
     }
+#ifdef ARVAE_GRU_STAMPS
+#ifndef GRU_STAMP_WAVE
+#define GRU_STAMP_WAVE 0
+#endif
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 64 * GRU_STAMP_WAVE) {
+        for (int q = 0; q < 4; ++q) g_gru_stamps[q] = ph[q];
+        g_gru_stamps[4] = T;
+    }
+#endif
     if (s.dh0 != nullptr)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -862,7 +887,7 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_kernel(TickFreeRun p) {
         const int cur = t & 1;
         const int beat = t / p.tpb;
         if (t % p.tpb == 0) {                                 // the hidden state restarts at every beat
-            __syncthreads();
+            lds_barrier();
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int64_t br = (int64_t)beat * B + rows[i];
@@ -873,7 +898,7 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_kernel(TickFreeRun p) {
                 const float *g = p.gib + br * 3 * H + unit;
                 gb[i][0] = g[0]; gb[i][1] = g[H]; gb[i][2] = g[2 * H];
             }
-            __syncthreads();
+            lds_barrier();
         }
         // input projection of this tick: beat part + previous-token part
         float gi[4][3];
@@ -906,7 +931,7 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_kernel(TickFreeRun p) {
                 mid[4 * quad + i][unit] = h0[i] * keep[i];
             }
         }
-        __syncthreads();
+        lds_barrier();
         // ---- layer 1: weights streamed, PF k-groups ahead
         {
             constexpr int PF = TICK_PF < KQ ? TICK_PF : KQ;
@@ -948,7 +973,7 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_kernel(TickFreeRun p) {
                 hA1[cur ^ 1][4 * quad + i][unit] = h1[i];
             }
         }
-        __syncthreads();
+        lds_barrier();
         // ---- logits + row argmax
         if (w < ntile) {
             f32x4 lg = {0.f, 0.f, 0.f, 0.f};
@@ -971,7 +996,7 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_kernel(TickFreeRun p) {
                 if (col == 0) { cand_v[w][4 * quad + i] = v; cand_i[w][4 * quad + i] = ix; }
             }
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = 4 * quad + i;
@@ -1087,7 +1112,7 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_x3_kernel(TickFreeRun p, 
         const int cur = t & 1;
         const int beat = t / p.tpb;
         if (t % p.tpb == 0) {
-            __syncthreads();
+            lds_barrier();
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int64_t br = (int64_t)beat * B + rows[i];
@@ -1098,7 +1123,7 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_x3_kernel(TickFreeRun p, 
                 const float *g = p.gib + br * 3 * H + unit;
                 gb[i][0] = g[0]; gb[i][1] = g[H]; gb[i][2] = g[2 * H];
             }
-            __syncthreads();
+            lds_barrier();
         }
         float gi[4][3], keep[4];
 #pragma unroll
@@ -1133,7 +1158,7 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_x3_kernel(TickFreeRun p, 
                 store_split3(&midp[(4 * quad + i) * HP + unit], PLANE, h0[i] * keep[i]);
             }
         }
-        __syncthreads();
+        lds_barrier();
         // ---- layer 1: matrix 1 (W_ih1 on mid), matrix 2 (W_hh1 on h1); r and z share an accumulator
         {
             f32x4 a1[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // r, z, i_n, h_n
@@ -1163,7 +1188,7 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_x3_kernel(TickFreeRun p, 
                 h1f[4 * quad + i][unit] = h1[i];
             }
         }
-        __syncthreads();
+        lds_barrier();
         // ---- logits (fp32 MFMA, weights in LDS) + row argmax
         if (w < ntile) {
             f32x4 lg = {0.f, 0.f, 0.f, 0.f};
@@ -1189,7 +1214,7 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_x3_kernel(TickFreeRun p, 
                 if (col == 0) { cand_v[w][4 * quad + i] = v; cand_i[w][4 * quad + i] = ix; }
             }
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = 4 * quad + i;
@@ -1302,7 +1327,7 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_h2_kernel(TickFreeRun p, 
         const int cur = t & 1;
         const int beat = t / p.tpb;
         if (t % p.tpb == 0) {
-            __syncthreads();
+            lds_barrier();
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int64_t br = (int64_t)beat * B + rows[i];
@@ -1313,7 +1338,7 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_h2_kernel(TickFreeRun p, 
                 const float *g = p.gib + br * 3 * H + unit;
                 gb[i][0] = g[0]; gb[i][1] = g[H]; gb[i][2] = g[2 * H];
             }
-            __syncthreads();
+            lds_barrier();
         }
         float gi[4][3], keep[4];
 #pragma unroll
@@ -1348,7 +1373,7 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_h2_kernel(TickFreeRun p, 
                 store_split2(&midp[(4 * quad + i) * HP + unit], PLANE, h0[i] * keep[i]);
             }
         }
-        __syncthreads();
+        lds_barrier();
         // ---- layer 1: matrix 1 (W_ih1 on mid), matrix 2 (W_hh1 on h1); r and z share an accumulator
         {
             f32x4 a1[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // r, z, i_n, h_n
@@ -1378,7 +1403,7 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_h2_kernel(TickFreeRun p, 
                 h1f[4 * quad + i][unit] = h1[i];
             }
         }
-        __syncthreads();
+        lds_barrier();
         // ---- logits (fp32 MFMA, weights in LDS) + row argmax
         if (w < ntile) {
             f32x4 lg = {0.f, 0.f, 0.f, 0.f};
@@ -1404,7 +1429,7 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_h2_kernel(TickFreeRun p, 
                 if (col == 0) { cand_v[w][4 * quad + i] = v; cand_i[w][4 * quad + i] = ix; }
             }
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = 4 * quad + i;
