@@ -34,6 +34,8 @@ struct ConvRows {
     unsigned *amax_out;          // AMAX array of the output (conv32_common.h) or null: zeroed by the weight-prep launch in front, every
                                  // wave folds its maximum into entry (workgroup % AMAX_N) with an integer atomic max (bit patterns of
                                  // non-negative floats order like the floats: exact, order-independent)
+    const unsigned *amax_in;     // conv_rows_h2_kernel: AMAX array of the (plain) source
+    const unsigned *w_amax;      // conv_rows_h2_kernel: bit pattern of max |wt| (written by the weight-prep launch behind the packed weights)
 };
 
 // value of a gradient operand (activation derivative of the saved output, keep-mask) for 4 consecutive channels
@@ -179,12 +181,165 @@ __global__ __launch_bounds__(256) void conv_rows_x3_kernel(ConvRows g) {
     }
 }
 
+// The same product on the fp16 MFMA with scaled two-term operands (conv32_common.h: three partial products, two LDS planes per
+// operand, the scales from the source's AMAX array and the weights' maximum): for PLAIN sources that come with their maxima -- the
+// 8 -> 64 products of the Morpho-MNIST step, which ran six bf16 products per multiply-add here through most of round 4.
+template <int TP> struct H2PlaneRows {          // [TP][RG_XP] fp16, reduction index contiguous; planes h | l
+    static constexpr int PLANE = TP * RG_XP;
+    __device__ static __forceinline__ void commit(unsigned short *lds, int idx, const float4 &v, float sc) {
+        unsigned h0, l0, h1, l1;
+        split_pair_h2(v.x, v.y, sc, h0, l0);
+        split_pair_h2(v.z, v.w, sc, h1, l1);
+        unsigned short *d = lds + (idx / (RG_R / 4)) * RG_XP + 4 * (idx % (RG_R / 4));
+        *reinterpret_cast<uint2 *>(d) = uint2{h0, h1};
+        *reinterpret_cast<uint2 *>(d + PLANE) = uint2{l0, l1};
+    }
+    __device__ static __forceinline__ int lane_base(int w) {
+        const int lane = threadIdx.x & 63;
+        return (32 * w + (lane & 31)) * RG_XP + 8 * (lane >> 5);
+    }
+    __device__ static __forceinline__ f16x8 operand(const unsigned short *lds, int base, int t, int s) {
+        return __builtin_bit_cast(f16x8, *reinterpret_cast<const rg_i32x4 *>(lds + t * PLANE + base + 16 * s));
+    }
+};
+
+__global__ __launch_bounds__(256) void conv_rows_h2_kernel(ConvRows g) {
+    typedef H2PlaneRows<C64_TP> PlaneA;
+    typedef H2PlaneRows<C64_TQ> PlaneB;
+    __shared__ __attribute__((aligned(16))) unsigned short As[2 * PlaneA::PLANE];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[2 * PlaneB::PLANE];
+    const AmaxLoad al = amax_issue(g.amax_in);
+    const unsigned wbits = *g.w_amax;
+    const int lane = threadIdx.x & 63, half = lane >> 5, rc = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wp = wave & 1, wq = wave >> 1;
+    const int p0 = blockIdx.x * C64_TP, q0 = blockIdx.y * C64_TQ;
+    const int M = g.n * g.oh * g.ow;
+    const int chunks = g.kh * g.kw * g.cs / RG_R;
+    int oy[2], ox[2], c4[2];
+    int64_t img_base[2];
+    bool pok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        const int p = p0 + idx / (RG_R / 4);
+        c4[i] = 4 * (idx % (RG_R / 4));
+        pok[i] = p < M;
+        const int pc = pok[i] ? p : 0;
+        const int img = pc / (g.oh * g.ow), rem = pc - img * g.oh * g.ow;
+        oy[i] = rem / g.ow; ox[i] = rem - oy[i] * g.ow;
+        img_base[i] = (int64_t)img * g.sh * g.sw;
+    }
+    int wq_row[2];
+    bool qok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = threadIdx.x + 256 * i;
+        wq_row[i] = q0 + idx / (RG_R / 4);
+        qok[i] = wq_row[i] < g.q;
+        if (!qok[i]) wq_row[i] = 0;
+    }
+    float4 va[2], vb[2];
+    const int kwidth = g.kh * g.kw * g.cs;
+    auto load = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int kk = chunk * RG_R + c4[i];
+            const int tap = kk / g.cs, c = kk - tap * g.cs;
+            const int ky = tap / g.kw, kx = tap - ky * g.kw;
+            const int sy = oy[i] + g.sgn * ky + g.off, sx = ox[i] + g.sgn * kx + g.off;
+            const bool ok = pok[i] && sy >= 0 && sy < g.sh && sx >= 0 && sx < g.sw;
+            va[i] = load_src4<true>(g.src, ((img_base[i] + (int64_t)sy * g.sw + sx) * g.cs + c), ok);
+            const float4 w = *reinterpret_cast<const float4 *>(g.wt + (int64_t)wq_row[i] * kwidth + kk);
+            vb[i] = qok[i] ? w : float4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    f32x16c acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    load(0);
+    const Pow2 sc_a = amax_scale(al), sc_w = pow2_for(wbits);
+    const int abase = PlaneA::lane_base(wp), bbase = PlaneB::lane_base(wq);
+    for (int chunk = 0; chunk < chunks; ++chunk) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            PlaneA::commit(As, threadIdx.x + 256 * i, va[i], sc_a.s);
+            PlaneB::commit(Bs, threadIdx.x + 256 * i, vb[i], sc_w.s);
+        }
+        __syncthreads();
+        if (chunk + 1 < chunks) load(chunk + 1);
+#pragma unroll
+        for (int s = 0; s < RG_R / 16; ++s) {
+            const f16x8 ah = PlaneA::operand(As, abase, 0, s), al2 = PlaneA::operand(As, abase, 1, s);
+            const f16x8 bh = PlaneB::operand(Bs, bbase, 0, s), bl = PlaneB::operand(Bs, bbase, 1, s);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al2, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+        }
+    }
+    const float inv = sc_a.inv * sc_w.inv;
+    const int q = q0 + 32 * wq + rc;
+    const float bias = (g.bias != nullptr && q < g.q) ? g.bias[q] : 0.f;
+    float gy[16];
+    unsigned char gm[16];
+    const uint8_t *mp = g.gate.y != nullptr ? g.gate.mask : g.mask;
+    if (mp != nullptr || g.gate.y != nullptr) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int p = p0 + 32 * wp + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int64_t o = (p < M && q < g.q) ? (int64_t)p * g.q + q : 0;
+            gm[r] = mp != nullptr ? mp[o] : (unsigned char)1;
+            gy[r] = g.gate.y != nullptr ? g.gate.y[o] : 0.f;
+        }
+    }
+    float vmax = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int p = p0 + 32 * wp + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (p < M && q < g.q) {
+            const int64_t o = (int64_t)p * g.q + q;
+            float v = act_fwd(fmaf(acc[r], inv, bias), g.act);
+            if (g.gate.y != nullptr) {
+                const float ys = g.gate.mask != nullptr ? 0.5f : 1.f, k2 = g.gate.mask != nullptr ? 2.f : 1.f;
+                v *= act_bwd_from_out_sel(ys * gy[r], g.gate.act) * k2 * (float)gm[r];
+            } else if (g.mask != nullptr) {
+                v *= 2.f * (float)gm[r];
+            }
+            g.out[o] = v;
+            vmax = fmaxf(vmax, fabsf(v));
+        }
+    }
+    if (g.amax_out != nullptr) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+        float *wmax = reinterpret_cast<float *>(As);
+        __syncthreads();
+        if (lane == 0) wmax[wave] = vmax;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            __hip_atomic_fetch_max(g.amax_out + ((blockIdx.y * gridDim.x + blockIdx.x) & (AMAX_N - 1)),
+                                   __builtin_bit_cast(unsigned, fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // nn.Conv2d / nn.ConvTranspose2d weights [a][b][taps] -> [q][tap][c]; (q, c) = (a, b) for the Conv2d-forward direction,
 // (b, a) for the transposed one
 __global__ __launch_bounds__(256) void conv64_weight_prep_kernel(const float *__restrict__ wt, float *__restrict__ out, int q_count,
-                                                                  int c_count, int taps, int transposed, unsigned *__restrict__ amax_zero) {
+                                                                  int c_count, int taps, int transposed, unsigned *__restrict__ amax_zero,
+                                                                  unsigned *__restrict__ w_amax) {
     const int i = blockIdx.x * 256 + threadIdx.x;                      // output index (q, tap, c)
     if (amax_zero != nullptr && i < AMAX_N) amax_zero[i] = 0u;          // (the convolution behind this launch folds its maxima in)
+    if (w_amax != nullptr && blockIdx.x == 0) {                         // max |wt| for the fp16 kernel's weight scale: workgroup 0 walks the tensor
+        __shared__ float wm[4];
+        float m = 0.f;
+        for (int e = threadIdx.x; e < q_count * taps * c_count; e += 256) m = fmaxf(m, fabsf(wt[e]));
+        m = wave_max(m);
+        if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) *w_amax = __builtin_bit_cast(unsigned, fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])));
+    }
     if (i >= q_count * taps * c_count) return;
     const int c = i % c_count, tap = (i / c_count) % taps, q = i / (c_count * taps);
     out[i] = transposed ? wt[((int64_t)c * q_count + q) * taps + tap] : wt[((int64_t)q * c_count + c) * taps + tap];
@@ -200,7 +355,7 @@ int conv64s_run(const Operand &src, int n, int sh, int sw, int oh, int ow, int q
                 const unsigned *amax_in, unsigned *amax_out, bool prepped);
 
 int64_t conv64_ws_floats(const arvae_link_t *l) {
-    const int64_t packed = ((int64_t)l->kh * l->kw * l->chi * l->clo + 3) / 4 * 4;
+    const int64_t packed = ((int64_t)l->kh * l->kw * l->chi * l->clo + 3) / 4 * 4 + 4;     // (+ the weights' maximum, conv_rows_h2_kernel)
     const bool staged = conv64s_fits(l, false) || conv64s_fits(l, true);
     return staged && conv64s_ws_floats() > packed ? conv64s_ws_floats() : packed;
 }
@@ -217,17 +372,25 @@ bool conv64_fits(const arvae_link_t *l, bool up) {
 }
 
 static int launch_conv_rows(ConvRows g, const float *wt, bool transposed, float *packed, hipStream_t s, const char *what,
-                            unsigned *amax_out = nullptr) {
+                            unsigned *amax_out = nullptr, const unsigned *amax_in = nullptr) {
     const int taps = g.kh * g.kw, wcount = g.q * taps * g.cs;
     g.amax_out = amax_out;
+    static const bool no_h2 = diag_env("ARVAE_CONV_ROWS_X3") != nullptr;        // A/B: the three-term bf16 kernel
+    const bool h2 = !no_h2 && amax_in != nullptr && plain_op(g.src);            // (one float behind the packed weights holds max |wt|)
+    g.amax_in = amax_in;
+    g.w_amax = reinterpret_cast<const unsigned *>(packed + wcount);
     if (packed == nullptr || (reinterpret_cast<uintptr_t>(packed) & 15) != 0)
         return fail(ARVAE_E_INVALID, "%s: needs arvae_link_ws_floats() floats of 16-byte aligned workspace for the re-ordered weights", what);
     ARVAE_LAUNCH(conv64_weight_prep_kernel, dim3(((wcount > AMAX_N ? wcount : AMAX_N) + 255) / 256), dim3(256), 0, s, wt, packed, g.q, g.cs, taps,
-                 transposed ? 1 : 0, amax_out);
+                 transposed ? 1 : 0, amax_out, h2 ? reinterpret_cast<unsigned *>(packed + wcount) : nullptr);
     g.wt = packed;
     const int M = g.n * g.oh * g.ow;
     const dim3 grid((M + C64_TP - 1) / C64_TP, (g.q + C64_TQ - 1) / C64_TQ);
-    if (plain_op(g.src)) {
+    if (h2) {
+        ConvRows p = g;
+        p.src.y = nullptr;
+        ARVAE_LAUNCH(conv_rows_h2_kernel, grid, dim3(256), 0, s, p);
+    } else if (plain_op(g.src)) {
         ConvRows p = g;
         p.src.y = nullptr;
         ARVAE_LAUNCH(conv_rows_x3_kernel<true>, grid, dim3(256), 0, s, p);
@@ -251,7 +414,7 @@ int conv64_down(const arvae_link_t *l, const Operand &hi, const float *wt, const
     g.oh = l->lh; g.ow = l->lw; g.q = l->clo;
     g.kh = l->kh; g.kw = l->kw; g.sgn = 1; g.off = -l->pad;
     g.bias = bias; g.mask = mask; g.act = act; g.out = lo;
-    return launch_conv_rows(g, wt, false, ws, s, what, amax_out);          // wt[clo][chi][ky][kx]: q = clo, c = chi
+    return launch_conv_rows(g, wt, false, ws, s, what, amax_out, amax_in);          // wt[clo][chi][ky][kx]: q = clo, c = chi
 }
 
 // hi[n][hh][hw][chi] = act(convT(lo) + bias) * mask    (ConvTranspose2d forward / Conv2d data gradient)
@@ -267,7 +430,7 @@ int conv64_up(const arvae_link_t *l, const Operand &lo, const float *wt, const f
     g.oh = l->hh; g.ow = l->hw; g.q = l->chi;
     g.kh = l->kh; g.kw = l->kw; g.sgn = -1; g.off = l->pad;
     g.bias = bias; g.mask = mask; g.act = act; g.out = hi;
-    return launch_conv_rows(g, wt, true, ws, s, what, amax_out);             // wt[clo][chi][ky][kx]: q = chi, c = clo
+    return launch_conv_rows(g, wt, true, ws, s, what, amax_out, amax_in);             // wt[clo][chi][ky][kx]: q = chi, c = clo
 }
 
 // ---- weight gradient ----------------------------------------------------------------------------------------------

@@ -438,11 +438,11 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
                 rc = dense_dgrad(&lk, make_operand(&gop), w, gate, d_in, hs);
                 *gated = true;
             } else if (gate_op != nullptr && conv64_fits(&lk, true)) {         // (conv64s.hip or the gathering kernel: both take the gate)
-                const bool staged = conv64s_fits(&lk, true);
-                if (staged && gop.y == nullptr && tmp_amax != nullptr)
+                // (both kernels scale a plain source by its maxima: the row-staged one and, since round 4, the gathering one)
+                if (gop.y == nullptr && tmp_amax != nullptr)
                     if (int rc2 = need_g()) return rc2;
                 rc = conv64_up(&lk, make_operand(&gop), w, nullptr, ARVAE_ACT_NONE, nullptr, d_in, link_ws, hs, gate_op,
-                               (staged && gop.y == nullptr) ? g_amax : nullptr, din_amax, wide_prep);
+                               gop.y == nullptr ? g_amax : nullptr, din_amax, wide_prep);
                 *gated = true;
                 *din_has = din_amax != nullptr;
             } else {

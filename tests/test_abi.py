@@ -88,7 +88,7 @@ def test_argument_validation_without_gpu(lib):
     assert lib.arvae_link_ws_floats(ctypes.byref(wide)) == staged
     # 8 -> 64 channels (reduction side 8): the gathering kernel's re-ordered fp32 copy
     narrow = LinkDesc(4, 22, 22, 8, 19, 19, 64, 4, 4, 1, 0, 0, 0, 0, 0)
-    assert lib.arvae_link_ws_floats(ctypes.byref(narrow)) in (16 * 8 * 64, staged)
+    assert lib.arvae_link_ws_floats(ctypes.byref(narrow)) in (16 * 8 * 64 + 4, staged)      # (+ the weights' maximum for the fp16 kernel)
     # 32 <-> 32 channels k4 s2 p1: the layer's weights as two scaled fp16 terms per value in per-lane operand order (Down and
     # Up parts, + the inverse scale), and the input's 1024 partial maxima
     assert lib.arvae_link_ws_floats(ctypes.byref(LinkDesc(4, 32, 32, 32, 16, 16, 32, 4, 4, 2, 1, 0, 0, 0, 0))) == (2 * 32 * 64 + 4 * 16 * 64 + 1) * 4 + 2 * 1024
