@@ -324,6 +324,143 @@ __global__ __launch_bounds__(256) void conv_rows_h2_kernel(ConvRows g) {
     }
 }
 
+// ---- 8 source channels, 4 x 4 taps: the whole reduction (K = 128) is eight MFMA k-steps --------------------------------------------
+// The Morpho-MNIST 8 -> 64 products (ConvTranspose2d(8, 64) forward, Conv2d(64, 8) data gradient) on the gathering kernels above
+// were bound by their gather: every 64 x 64 tile re-read its 64 x 128 operand from L2, four chunks with two barriers each.  Here
+//   * a lane's MFMA A operand for k-step s is the 8 channels of ONE tap (2 s + lane half) of its pixel: 32 contiguous bytes of the
+//     source -- so the source rows a tile touches are staged ONCE in LDS as two fp16 terms (16 + 16 bytes per pixel, <= 7 rows) and
+//     every operand is a single 16-byte LDS read per term at a per-lane pixel address (out-of-image taps read a zero pixel);
+//   * the wave's 32 x 128 weight slice lives in registers (two terms, 64 VGPRs) for the whole launch;
+//   * a tile is 64 consecutive output pixels of an image in row-major order (94 % of the MFMA rows at 22 x 22), workgroups walk
+//     tiles persistently, four workgroups per CU hide each other's staging round trip.
+// Arithmetic: scaled two-term fp16, three products (conv32_common.h); plain sources that come with their maxima.
+constexpr int S8_PIX = 255;                                      // staged source pixels per tile (one per thread; 255 = the zero pixel)
+__device__ __forceinline__ void s8_split8(const float (&x)[8], float sc, f16x8 &hi, f16x8 &lo) {
+    uint4 h, l;
+    split_pair_h2(x[0], x[1], sc, h.x, l.x);
+    split_pair_h2(x[2], x[3], sc, h.y, l.y);
+    split_pair_h2(x[4], x[5], sc, h.z, l.z);
+    split_pair_h2(x[6], x[7], sc, h.w, l.w);
+    hi = __builtin_bit_cast(f16x8, h); lo = __builtin_bit_cast(f16x8, l);
+}
+__global__ __launch_bounds__(256) void conv_s8_h2_kernel(ConvRows g, int tiles_per_img, int n_tiles) {
+    __shared__ uint4 src_h[S8_PIX + 1], src_l[S8_PIX + 1];
+    __shared__ __attribute__((aligned(16))) float otile[64][68];   // the tile's results, so that the epilogue is 16-byte loads and stores
+    __shared__ float wmax[4];
+    const AmaxLoad al = amax_issue(g.amax_in);
+    const unsigned wbits = *g.w_amax;
+    const int lane = threadIdx.x & 63, half = lane >> 5, rc = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wp = wave & 1, wq = wave >> 1;
+    const int q = 32 * wq + rc;
+    const Pow2 sc_w = pow2_for(wbits);
+    f16x8 wh[8], wl[8];
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) {
+        const float *wsrc = g.wt + ((int64_t)(q < g.q ? q : 0) * 16 + 2 * s8 + half) * 8;
+        const float4 a = *reinterpret_cast<const float4 *>(wsrc), b = *reinterpret_cast<const float4 *>(wsrc + 4);
+        const float z = q < g.q ? 1.f : 0.f;
+        const float x[8] = {a.x * z, a.y * z, a.z * z, a.w * z, b.x * z, b.y * z, b.z * z, b.w * z};
+        s8_split8(x, sc_w.s, wh[s8], wl[s8]);
+    }
+    // epilogue slot of this thread: pixel (threadIdx.x / 16) + 16 k of the tile, channels 4 (threadIdx.x % 16) ..
+    const int e_px = threadIdx.x >> 4, e_c = 4 * (threadIdx.x & 15);
+    const bool e_ok = e_c < g.q;
+    const float4 bias4 = (g.bias != nullptr && e_ok) ? *reinterpret_cast<const float4 *>(g.bias + e_c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const Pow2 sc_a = amax_scale(al);
+    const float inv = sc_a.inv * sc_w.inv;
+    (void)q;
+    if (threadIdx.x == 255) { src_h[S8_PIX] = make_uint4(0u, 0u, 0u, 0u); src_l[S8_PIX] = make_uint4(0u, 0u, 0u, 0u); }
+    const int opix = g.oh * g.ow;
+    const uint8_t *mp = g.gate.y != nullptr ? g.gate.mask : g.mask;
+    float vmax = 0.f;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int img = tile / tiles_per_img, P0 = (tile - img * tiles_per_img) * 64;
+        const int y_first = P0 / g.ow, y_last = min(P0 + 63, opix - 1) / g.ow;
+        const int sy0 = g.sgn < 0 ? y_first - 3 + g.off : y_first + g.off, nrows = y_last - y_first + 4;
+        __syncthreads();                                         // the previous tile's operand reads are done
+        if ((int)threadIdx.x < nrows * g.sw) {
+            const int r = threadIdx.x / g.sw, x = threadIdx.x - r * g.sw, sy = sy0 + r;
+            const bool ok = sy >= 0 && sy < g.sh;
+            const float *p = g.src.v + (((int64_t)img * g.sh + (ok ? sy : 0)) * g.sw + x) * 8;
+            const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
+            const float z = ok ? 1.f : 0.f;
+            const float v[8] = {a.x * z, a.y * z, a.z * z, a.w * z, b.x * z, b.y * z, b.z * z, b.w * z};
+            f16x8 h, l;
+            s8_split8(v, sc_a.s, h, l);
+            src_h[threadIdx.x] = __builtin_bit_cast(uint4, h);
+            src_l[threadIdx.x] = __builtin_bit_cast(uint4, l);
+        }
+        __syncthreads();
+        const int P = P0 + 32 * wp + rc;
+        const bool pok = P < opix;
+        const int y = P / g.ow, x = P - y * g.ow;
+        f32x16c acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) {
+            const int tap = 2 * s8 + half, ky = tap >> 2, kx = tap & 3;
+            const int sy = y + g.sgn * ky + g.off, sx = x + g.sgn * kx + g.off;
+            const bool ok = pok && (unsigned)sy < (unsigned)g.sh && (unsigned)sx < (unsigned)g.sw;
+            const int idx = ok ? (sy - sy0) * g.sw + sx : S8_PIX;
+            const f16x8 ah = __builtin_bit_cast(f16x8, src_h[idx]), al2 = __builtin_bit_cast(f16x8, src_l[idx]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al2, wh[s8], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl[s8], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh[s8], acc, 0, 0, 0);
+        }
+        // the accumulators meet in LDS ([pixel][channel]); then every thread finishes four (pixel, 4 channels) slots: keep-mask bytes /
+        // gate values requested first, bias, activation, gate, one 16-byte store (the 16 dword stores per lane of the gathering kernels
+        // moved 256 bytes per instruction: the launch ran at 1.7 TB/s of output)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) otile[32 * wp + (r & 3) + 8 * (r >> 2) + 4 * half][q] = acc[r];
+        __syncthreads();
+        const int64_t obase = (int64_t)img * opix;
+        unsigned gm[4];
+        float4 gy[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int pr = P0 + e_px + 16 * u;
+            const int64_t o = (pr < opix && e_ok) ? (obase + pr) * g.q + e_c : 0;
+            gm[u] = mp != nullptr ? *reinterpret_cast<const unsigned *>(mp + o) : 0x01010101u;
+            gy[u] = g.gate.y != nullptr ? *reinterpret_cast<const float4 *>(g.gate.y + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int pr = P0 + e_px + 16 * u;
+            if (pr < opix && e_ok) {
+                const int64_t o = (obase + pr) * g.q + e_c;
+                const float4 a4 = *reinterpret_cast<const float4 *>(&otile[e_px + 16 * u][e_c]);
+                float4 v = make_float4(act_fwd(fmaf(a4.x, inv, bias4.x), g.act), act_fwd(fmaf(a4.y, inv, bias4.y), g.act),
+                                       act_fwd(fmaf(a4.z, inv, bias4.z), g.act), act_fwd(fmaf(a4.w, inv, bias4.w), g.act));
+                const unsigned m = gm[u];
+                if (g.gate.y != nullptr) {
+                    const float ys = g.gate.mask != nullptr ? 0.5f : 1.f, k2 = g.gate.mask != nullptr ? 2.f : 1.f;
+                    v.x *= act_bwd_from_out_sel(ys * gy[u].x, g.gate.act) * k2 * (float)(m & 255u);
+                    v.y *= act_bwd_from_out_sel(ys * gy[u].y, g.gate.act) * k2 * (float)((m >> 8) & 255u);
+                    v.z *= act_bwd_from_out_sel(ys * gy[u].z, g.gate.act) * k2 * (float)((m >> 16) & 255u);
+                    v.w *= act_bwd_from_out_sel(ys * gy[u].w, g.gate.act) * k2 * (float)(m >> 24);
+                } else if (g.mask != nullptr) {
+                    v.x *= 2.f * (float)(m & 255u); v.y *= 2.f * (float)((m >> 8) & 255u);
+                    v.z *= 2.f * (float)((m >> 16) & 255u); v.w *= 2.f * (float)(m >> 24);
+                }
+                *reinterpret_cast<float4 *>(g.out + o) = v;
+                vmax = fmaxf(vmax, amax4(v));
+            }
+        }
+    }
+    if (g.amax_out != nullptr) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
+        if (lane == 0) wmax[wave] = vmax;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            __hip_atomic_fetch_max(g.amax_out + (blockIdx.x & (AMAX_N - 1)),
+                                   __builtin_bit_cast(unsigned, fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // nn.Conv2d / nn.ConvTranspose2d weights [a][b][taps] -> [q][tap][c]; (q, c) = (a, b) for the Conv2d-forward direction,
 // (b, a) for the transposed one
 __global__ __launch_bounds__(256) void conv64_weight_prep_kernel(const float *__restrict__ wt, float *__restrict__ out, int q_count,
@@ -386,7 +523,16 @@ static int launch_conv_rows(ConvRows g, const float *wt, bool transposed, float 
     g.wt = packed;
     const int M = g.n * g.oh * g.ow;
     const dim3 grid((M + C64_TP - 1) / C64_TP, (g.q + C64_TQ - 1) / C64_TQ);
-    if (h2) {
+    static const bool no_s8 = diag_env("ARVAE_CONV_S8_GATHER") != nullptr;      // A/B: the gathering kernel for 8-channel sources too
+    const int span_rows = 63 / g.ow + 2 + 3;                                    // source rows a 64-pixel tile can touch
+    if (h2 && !no_s8 && g.cs == 8 && g.kh == 4 && g.kw == 4 && g.q <= 64 && (g.q & 3) == 0 && span_rows * g.sw <= S8_PIX &&
+        (reinterpret_cast<uintptr_t>(g.out) & 15) == 0) {
+        ConvRows p = g;
+        p.src.y = nullptr;
+        const int tiles_per_img = (g.oh * g.ow + 63) / 64, n_tiles = g.n * tiles_per_img;
+        const int slots = 3 * device_cu_count();                                // (146 + 16 registers: three workgroups per CU)
+        ARVAE_LAUNCH(conv_s8_h2_kernel, dim3(n_tiles < slots ? n_tiles : slots), dim3(256), 0, s, p, tiles_per_img, n_tiles);
+    } else if (h2) {
         ConvRows p = g;
         p.src.y = nullptr;
         ARVAE_LAUNCH(conv_rows_h2_kernel, grid, dim3(256), 0, s, p);
