@@ -549,6 +549,10 @@ __global__ __launch_bounds__(256) void up_single_channel_mfma_kernel(Geom g, con
 __global__ __launch_bounds__(256) void down_single_channel_mfma_kernel(Geom g, Operand hi, const float *__restrict__ wt,
                                                                         Epilogue ep) {
     extern __shared__ __attribute__((aligned(16))) float img_lds[];   // [hh*hw]
+    // a wave's 16 positions x 64 channels meet here, so that the epilogue is 16-byte loads (gate values, four keep-mask bytes) and
+    // 16-byte stores, a position's 256 bytes contiguous per 16 lanes -- with one dword store per (position, channel) and lane the
+    // launch wrote its 164 MB at 2.5 TB/s
+    __shared__ __attribute__((aligned(16))) float otile[4][16][68];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, quad = lane >> 4;
     const int taps = g.kh * g.kw, npos = g.lh * g.lw, hpix = g.hh * g.hw;
     const int img = blockIdx.x;
@@ -578,22 +582,17 @@ __global__ __launch_bounds__(256) void down_single_channel_mfma_kernel(Geom g, O
         g.d_lw.divmod((uint32_t)(pos < npos ? pos : npos - 1), ly, lx);
         const int y0 = (int)ly * g.stride - g.pad, x0 = (int)lx * g.stride - g.pad;
         f32x4t acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        // keep-mask bytes of this lane's 16 outputs: requested before the MFMAs (one load -> multiply -> store chain per output
-        // was 58 of this kernel's 95 us on the first Morpho-MNIST layer)
-        unsigned char mk[4][4];
-        float gy[4][4];
-        if (ep.mask != nullptr || ep.gate.y != nullptr) {
-            const uint8_t *mp = ep.gate.y != nullptr ? ep.gate.mask : ep.mask;      // (a gated launch has no forward keep-mask)
+        // keep-mask bytes / gate values of this lane's four (position, 4 channels) slots: requested before the MFMAs
+        const int e_pos = lane >> 4, e_c = 4 * (lane & 15);
+        unsigned mk[4];
+        float4 gy[4];
+        const uint8_t *mp = ep.gate.y != nullptr ? ep.gate.mask : ep.mask;      // (a gated launch has no forward keep-mask)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int p = 16 * mt + 4 * quad + i, pc = p < npos ? p : npos - 1;
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    const int64_t o = ((int64_t)img * npos + pc) * 64 + 16 * nt + col;
-                    mk[i][nt] = mp != nullptr ? mp[o] : (unsigned char)1;
-                    if (ep.gate.y != nullptr) gy[i][nt] = ep.gate.y[o];
-                }
-            }
+        for (int u = 0; u < 4; ++u) {
+            const int p = 16 * mt + e_pos + 4 * u, pc = p < npos ? p : npos - 1;
+            const int64_t o = ((int64_t)img * npos + pc) * 64 + e_c;
+            mk[u] = mp != nullptr ? *reinterpret_cast<const unsigned *>(mp + o) : 0x01010101u;
+            gy[u] = ep.gate.y != nullptr ? *reinterpret_cast<const float4 *>(ep.gate.y + o) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -604,24 +603,33 @@ __global__ __launch_bounds__(256) void down_single_channel_mfma_kernel(Geom g, O
             for (int nt = 0; nt < 4; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[nt][kk], acc[nt], 0, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int p = 16 * mt + 4 * quad + i;
-            if (p >= npos) continue;
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const int64_t o = ((int64_t)img * npos + p) * 64 + 16 * nt + col;
-                float v = act_fwd(acc[nt][i] + bias[nt], ep.act);
-                if (ep.gate.y != nullptr) {
-                    // (the saved output of a dropout layer is the kept activation times two: Operand::apply)
-                    const float ys = ep.gate.mask != nullptr ? 0.5f : 1.f, k2 = ep.gate.mask != nullptr ? 2.f : 1.f;
-                    v *= act_bwd_from_out_sel(ys * gy[i][nt], ep.gate.act) * k2 * (float)mk[i][nt];
-                } else if (ep.mask != nullptr) {
-                    v *= 2.f * (float)mk[i][nt];
-                }
-                amax_run = fmaxf(amax_run, fabsf(v));
-                ep.out[o] = v;
+            for (int nt = 0; nt < 4; ++nt) otile[wave][4 * quad + i][16 * nt + col] = acc[nt][i] + bias[nt];
+        // (the tile is this wave's own: LDS operations of a wave complete in order)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = 16 * mt + e_pos + 4 * u;
+            const float4 a4 = *reinterpret_cast<const float4 *>(&otile[wave][e_pos + 4 * u][e_c]);
+            if (p >= npos) continue;
+            const int64_t o = ((int64_t)img * npos + p) * 64 + e_c;
+            float4 v = make_float4(act_fwd(a4.x, ep.act), act_fwd(a4.y, ep.act), act_fwd(a4.z, ep.act), act_fwd(a4.w, ep.act));
+            const unsigned m = mk[u];
+            if (ep.gate.y != nullptr) {
+                // (the saved output of a dropout layer is the kept activation times two: Operand::apply)
+                const float ys = ep.gate.mask != nullptr ? 0.5f : 1.f, k2 = ep.gate.mask != nullptr ? 2.f : 1.f;
+                v.x *= act_bwd_from_out_sel(ys * gy[u].x, ep.gate.act) * k2 * (float)(m & 255u);
+                v.y *= act_bwd_from_out_sel(ys * gy[u].y, ep.gate.act) * k2 * (float)((m >> 8) & 255u);
+                v.z *= act_bwd_from_out_sel(ys * gy[u].z, ep.gate.act) * k2 * (float)((m >> 16) & 255u);
+                v.w *= act_bwd_from_out_sel(ys * gy[u].w, ep.gate.act) * k2 * (float)(m >> 24);
+            } else if (ep.mask != nullptr) {
+                v.x *= 2.f * (float)(m & 255u); v.y *= 2.f * (float)((m >> 8) & 255u);
+                v.z *= 2.f * (float)((m >> 16) & 255u); v.w *= 2.f * (float)(m >> 24);
             }
+            amax_run = fmaxf(amax_run, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+            *reinterpret_cast<float4 *>(ep.out + o) = v;
         }
+        __builtin_amdgcn_wave_barrier();
     }
     if (ep.amax_out != nullptr) {                               // the wide convolution that reads `out` next scales it into fp16
         __shared__ float wm[4];
