@@ -136,19 +136,51 @@ __global__ __launch_bounds__(256) void operand_amax_kernel(Operand x, int64_t co
     if (threadIdx.x < 64) amax_publish(out, blockIdx.x, gridDim.x, fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])));
 }
 
-// act_fwd with the SELU exponential on v_exp_f32 (1 ulp): the epilogue runs while the matrix pipe idles, and 32 expf() calls
-// per lane and tile were 16 % of a tile's time
-__device__ __forceinline__ float act_fwd_hw(float x, int act) {
-    const float relu = fmaxf(x, 0.f);
-    const float selu = x > 0.f ? kSeluScale * x : (kSeluScale * kSeluAlpha) * (__builtin_amdgcn_exp2f(x * 1.4426950408889634f) - 1.f);
-    return act == ARVAE_ACT_RELU ? relu : (act == ARVAE_ACT_SELU ? selu : x);
+// The epilogue runs with the matrix pipe idle and ONE wave per SIMD: it is bound by its own vector instruction count.  The
+// activation and the gate's derivative are therefore written without selects on the (launch-uniform) activation kind and
+// without a branch on the sign (the compiler turned `x > 0 ? a : b(exp)` into an exec-mask branch per value):
+//   act(x)  = pos * max(x, 0) + neg * (exp2(min(x, 0) * log2 e) - 1)            [none: x itself, one select]
+//   act'(y) = y > 0 ? dpos : y * dslope + dneg          (from the saved output; the keep-mask's factor 2 folded in)
+// with the same roundings as common.h's act_fwd / act_bwd_from_out_sel (SELU exponential on v_exp_f32, 1 ulp).
+struct ActCoef {
+    float pos, neg;
+    bool none;
+};
+__device__ __forceinline__ ActCoef act_coef(int act) {
+    return ActCoef{act == ARVAE_ACT_SELU ? kSeluScale : 1.f, act == ARVAE_ACT_SELU ? kSeluScale * kSeluAlpha : 0.f,
+                   act != ARVAE_ACT_SELU && act != ARVAE_ACT_RELU};
 }
+__device__ __forceinline__ float act_fwd_coef(float x, const ActCoef &a) {
+    const float e = __builtin_amdgcn_exp2f(fminf(x, 0.f) * 1.4426950408889634f) - 1.f;
+    const float r = fmaf(a.neg, e, a.pos * fmaxf(x, 0.f));
+    return a.none ? x : r;
+}
+struct GateCoef { float pos, slope, neg; };
+// k2 = 2 with a keep-mask (the saved output is then the kept activation times two: Operand::apply), else 1
+__device__ __forceinline__ GateCoef gate_coef(int act, bool masked) {
+    const float k2 = masked ? 2.f : 1.f;
+    if (act == ARVAE_ACT_SELU) return GateCoef{k2 * kSeluScale, 1.f, k2 * (kSeluScale * kSeluAlpha)};   // (y / k2 + sa) * k2
+    if (act == ARVAE_ACT_RELU) return GateCoef{k2, 0.f, 0.f};
+    return GateCoef{k2, 0.f, k2};
+}
+__device__ __forceinline__ float gate_deriv(float y, const GateCoef &c) { return y > 0.f ? c.pos : fmaf(y, c.slope, c.neg); }
 
 // MODE = Operand::mode() of the source: 0 plain, 1 activation derivative from the saved output, 2 also the keep-mask
 template <int MT, int NT, int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv64s_kernel(ConvStage g) {
     CSTAMP(0);
     constexpr int S_WSTEP = NT * 2 * 64;
+#ifndef C64S_EP_STEPS
+#define C64S_EP_STEPS 3
+#endif
+    // the epilogue operands (keep-mask bytes / gate values: scattered requests from HBM) are requested in the LAST reduction steps,
+    // behind the tile's last weight request (step 13): memory operations return in order, and a weight request queued behind
+    // one of these waits out an HBM round trip instead of an L2 hit
+#ifndef C64S_W_AHEAD
+#define C64S_W_AHEAD (NT == 1 ? 3 : 2)
+#endif
+    constexpr int W_AHEAD = C64S_W_AHEAD;        // reduction steps between a weight operand's request and its MFMAs
+    constexpr int EP_STEPS = C64S_EP_STEPS, EP_FIRST = 16 - EP_STEPS, EP_PER = (MT * NT + EP_STEPS - 1) / EP_STEPS;
     extern __shared__ __attribute__((aligned(16))) unsigned lds[];          // 2 x S_BUF
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, rc = lane & 31;
@@ -247,7 +279,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     __syncthreads();
     // weight operands: a ring of three register sets, two reduction steps ahead of the MFMAs (the split weights live in L2: one
     // step is not enough to cover that round trip under load)
-    f16x8 w2[3][NT][2];
+    f16x8 w2[W_AHEAD + 1][NT][2];
     auto load_w = [&](auto rc_, int kx, int c16) __attribute__((always_inline)) {
         constexpr int r = decltype(rc_)::value;
         const uint4 *wp = g.wprep + ((ky * 4 + kx) * 4 + c16) * S_WSTEP + wlane;
@@ -265,9 +297,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const uint8_t *km_ptr = g.gate.y != nullptr ? g.gate.mask : g.mask;
     const __amdgpu_buffer_rsrc_t rs_km = make_rsrc(km_ptr != nullptr ? (const void *)km_ptr : (const void *)g.out, km_ptr != nullptr ? out_elems : 0);
     const bool km_ones = g.gate.y != nullptr && g.gate.mask == nullptr;
+    const ActCoef ac = act_coef(g.act);
+    const GateCoef gc = gate_coef(g.gate.act, g.gate.mask != nullptr);
 
-    load_w(std::integral_constant<int, 0>{}, kx_first, 0);
-    load_w(std::integral_constant<int, 1>{}, kx_first, 1);
+    static_for<0, W_AHEAD>([&](auto r_) __attribute__((always_inline)) { load_w(r_, kx_first, decltype(r_)::value); });
     // as many (dropped) stores behind the first weight requests as an epilogue leaves behind the later ones: the loop header then
     // sees the same queue on its entry edge and on its back edge, and the first MFMAs of a tile wait for their weights only
     // (vmcnt(19) ...) instead of draining the epilogue's stores as well (vmcnt(0))
@@ -297,13 +330,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         float4 gy[MT][NT];
         // (buffer loads through possibly EMPTY resources and no branch: a memory operation under a run-time condition makes the
         // compiler's vmcnt counts conservative everywhere after it -- see the stores below)
-        auto fetch_epilogue = [&]() __attribute__((always_inline)) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
+        auto fetch_epilogue = [&](auto kc_) __attribute__((always_inline)) {
+            constexpr int mt = decltype(kc_)::value / NT, nt = decltype(kc_)::value % NT;
+                {
                     const int P = opix[mt];
+#ifdef C64S_ABL_NOEPLOAD
+                    const bool ok = false;
+#else
                     const bool ok = P >= 0 && oy0 + P / g.ow < g.oh && ch_ok[nt];
+#endif
                     const unsigned o = ok ? (unsigned)((((int64_t)img * g.oh + oy0) * g.ow + P) * g.q + nt * 32 + 8 * wave + 4 * half) : 0u;
                     gy[mt][nt] = buf_load4(rs_gy, o * 4u);
                     const unsigned m = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs_km, (int)o, 0, 0);
@@ -326,13 +361,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         int64_t c_at = 0;
         bool c_ok = false;
         static_for<0, 16>([&](auto kc) __attribute__((always_inline)) {
-            constexpr int step = decltype(kc)::value, cu = step & 1, nx = cu ^ 1, wr = step % 3;
+            constexpr int step = decltype(kc)::value, cu = step & 1, nx = cu ^ 1, wr = step % (W_AHEAD + 1);
             // loader slots of this step: requested in step s * 12 / 11, split + written four steps (~3 us) later
             constexpr int is_lo = (step * S_SLOTS + 11) / 12, is_hi = step < 12 ? ((step + 1) * S_SLOTS + 11) / 12 : is_lo;
             constexpr int cs = step - 4;
             constexpr int cm_lo = cs >= 0 ? (cs * S_SLOTS + 11) / 12 : 0, cm_hi = (cs >= 0 && cs < 12) ? ((cs + 1) * S_SLOTS + 11) / 12 : cm_lo;
-            constexpr int n_read = step + 1 < 16 ? 2 * MT : 0, n_w = step + 2 < 16 ? 2 * NT : 0;
-            constexpr int n_issue = 2 * (is_hi - is_lo), n_commit = 4 * (cm_hi - cm_lo), n_ep = step == 11 ? 1 : 0;
+            constexpr int n_read = step + 1 < 16 ? 2 * MT : 0, n_w = step + W_AHEAD < 16 ? 2 * NT : 0;
+            constexpr int n_issue = 2 * (is_hi - is_lo), n_commit = 4 * (cm_hi - cm_lo), ep_lo = step >= EP_FIRST ? (step - EP_FIRST) * EP_PER : 0;
+            constexpr int ep_hi = step >= EP_FIRST ? (ep_lo + EP_PER < MT * NT ? ep_lo + EP_PER : MT * NT) : 0, n_ep = ep_hi > ep_lo ? ep_hi - ep_lo : 0;
             constexpr int n_items = n_read + n_w + n_issue + n_commit + n_ep, n_mfma = 3 * MT * NT;
             auto item = [&](auto ic) __attribute__((always_inline)) {
                 constexpr int i = decltype(ic)::value;
@@ -340,10 +376,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     constexpr int njx = (step + 1) >> 2, nc16 = (step + 1) & 3, mt = i / 2, t = i % 2;
                     x2[nx][mt][t] = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4v *>(xb + xoff[mt][njx] + t * 32 + nc16 * 8));
                 } else if constexpr (i < n_read + n_w) {
-                    constexpr int k = i - n_read, nt = k / 2, t = k % 2, njx = (step + 2) >> 2, nc16 = (step + 2) & 3;
+                    constexpr int k = i - n_read, nt = k / 2, t = k % 2, njx = (step + W_AHEAD) >> 2, nc16 = (step + W_AHEAD) & 3;
                     const int nkx = g.sgn > 0 ? njx : 3 - njx;
                     const uint4 *wp = g.wprep + ((ky * 4 + nkx) * 4 + nc16) * S_WSTEP + wlane;
-                    w2[(step + 2) % 3][nt][t] = __builtin_bit_cast(f16x8, wp[(nt * 2 + t) * 64]);
+                    w2[(step + W_AHEAD) % (W_AHEAD + 1)][nt][t] = __builtin_bit_cast(f16x8, wp[(nt * 2 + t) * 64]);
                 } else if constexpr (i < n_read + n_w + n_issue) {
                     constexpr int k = i - n_read - n_w, s = is_lo + k / 2, piece = k % 2;
                     if constexpr (piece == 0) {                  // address of slot s of the next tile
@@ -383,7 +419,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                         *reinterpret_cast<uint2 *>(d + 32) = c_l;
                     }
                 } else if constexpr (i < n_items) {
-                    fetch_epilogue();
+                    fetch_epilogue(std::integral_constant<int, n_ep ? ep_lo + (i - (n_items - n_ep)) : 0>{});
                 }
             };
             __builtin_amdgcn_sched_barrier(0);
@@ -398,8 +434,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             });
         });
         CSTAMP(3 + 6 * cst);
-        load_w(std::integral_constant<int, 0>{}, kx_first, 0);   // the next tile's first two steps: the exchange hides them
-        load_w(std::integral_constant<int, 1>{}, kx_first, 1);
+        // the next tile's first steps: the exchange hides them
+        static_for<0, W_AHEAD>([&](auto r_) __attribute__((always_inline)) { load_w(r_, kx_first, decltype(r_)::value); });
         __syncthreads();                                         // every read of this buffer is done; the next tile is staged
         CSTAMP(4 + 6 * cst);
 
@@ -431,16 +467,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 {
                     const bool ok = P >= 0 && oy0 + r < g.oh && ch_ok[nt];
                     const int64_t o = (((int64_t)img * g.oh + oy0) * g.ow + P) * g.q + nt * 32 + 8 * wave + 4 * half;
-                    v.x = act_fwd_hw(fmaf(v.x, inv, b4[nt].x), g.act); v.y = act_fwd_hw(fmaf(v.y, inv, b4[nt].y), g.act);
-                    v.z = act_fwd_hw(fmaf(v.z, inv, b4[nt].z), g.act); v.w = act_fwd_hw(fmaf(v.w, inv, b4[nt].w), g.act);
+                    v.x = act_fwd_coef(fmaf(v.x, inv, b4[nt].x), ac); v.y = act_fwd_coef(fmaf(v.y, inv, b4[nt].y), ac);
+                    v.z = act_fwd_coef(fmaf(v.z, inv, b4[nt].z), ac); v.w = act_fwd_coef(fmaf(v.w, inv, b4[nt].w), ac);
                     if (g.gate.y != nullptr) {
                         const unsigned m = km[mt][nt];
-                        // (the saved output of a dropout layer is the kept activation times two: Operand::apply)
-                        const float k2 = g.gate.mask != nullptr ? 2.f : 1.f, ys = g.gate.mask != nullptr ? 0.5f : 1.f;
-                        v.x *= act_bwd_from_out_sel(ys * gy[mt][nt].x, g.gate.act) * k2 * (float)(m & 255u);
-                        v.y *= act_bwd_from_out_sel(ys * gy[mt][nt].y, g.gate.act) * k2 * (float)((m >> 8) & 255u);
-                        v.z *= act_bwd_from_out_sel(ys * gy[mt][nt].z, g.gate.act) * k2 * (float)((m >> 16) & 255u);
-                        v.w *= act_bwd_from_out_sel(ys * gy[mt][nt].w, g.gate.act) * k2 * (float)(m >> 24);
+                        v.x *= gate_deriv(gy[mt][nt].x, gc) * (float)(m & 255u);
+                        v.y *= gate_deriv(gy[mt][nt].y, gc) * (float)((m >> 8) & 255u);
+                        v.z *= gate_deriv(gy[mt][nt].z, gc) * (float)((m >> 16) & 255u);
+                        v.w *= gate_deriv(gy[mt][nt].w, gc) * (float)(m >> 24);
                     } else if (g.mask != nullptr) {
                         const unsigned m = km[mt][nt];
                         v.x *= 2.f * (float)(m & 255u); v.y *= 2.f * (float)((m >> 8) & 255u);
@@ -449,7 +483,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     // unconditional: under the lane test the stores sat behind a branch, and the next tile's first weight operands
                     // (requested before the exchange) were then waited for with vmcnt(0) -- every store of this epilogue included
                     amax_run = ok ? fmaxf(amax_run, amax4(v)) : amax_run;
+#ifdef C64S_ABL_NOSTORE
+                    buf_store4(v, rs_out, (ok && v.x == 1234.5f) ? (unsigned)o * 4u : OOB);
+#else
                     buf_store4(v, rs_out, ok ? (unsigned)o * 4u : OOB);
+#endif
                 }
             }
             __syncthreads();
