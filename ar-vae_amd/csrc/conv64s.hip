@@ -90,7 +90,12 @@ __device__ __forceinline__ void conv64s_prep_block(const float *__restrict__ wt,
     const int i = block * 256 + threadIdx.x;                   // ((tap * 4 + c16) * nt_count + nt) * 64 + lane
     if (i == 0) out[16 * 4 * nt_count * 2 * 64] = make_uint4(__builtin_bit_cast(unsigned, sc.inv), 0u, 0u, 0u);
     const int lane = i & 63, rest = i >> 6, nt = rest % nt_count, c16 = (rest / nt_count) & 3, tap = rest / (4 * nt_count);
-    const int q = nt * 32 + (lane & 31), c0 = c16 * 16 + 8 * (lane >> 5);
+    // MFMA row i of kernel row ky's operand = output channel 8 ((i / 8 + wave) & 3) + i % 8 of the column tile, wave = the wave
+    // that runs this kernel row (conv64s_kernel: ky for the Conv2d-forward orientation, 3 - ky for the transposed one): every wave
+    // then finds ITS share of the outputs (channels 8 wave ..) in accumulator registers 0-3 and wave + o's in 4 o .. 4 o + 3 --
+    // compile-time register numbers (indexed with the wave number they cost three instructions per register read)
+    const int wave = transposed ? 3 - (tap >> 2) : (tap >> 2), row = lane & 31;
+    const int q = nt * 32 + 8 * (((row >> 3) + wave) & 3) + (row & 7), c0 = c16 * 16 + 8 * (lane >> 5);
     const int qc = q < q_count ? q : 0;
     float x[8];
 #pragma unroll
@@ -439,8 +444,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         __syncthreads();                                         // every read of this buffer is done; the next tile is staged
         CSTAMP(4 + 6 * cst);
 
-        // ---- the four kernel rows' partial sums meet in this tile's buffer: wave w finishes accumulator registers
-        //      4 w .. 4 w + 3 (channels 8 w + 4 half + j) of every tile; one column tile at a time (the buffer is 70 KB)
+        // ---- the four kernel rows' partial sums meet in this tile's buffer: wave w finishes channels 8 w + 4 half + j of every
+        //      tile -- ITS accumulator registers 0-3 (the weight prep rotates each kernel row's output channels) -- and hands
+        //      registers 4 o .. 4 o + 3 to wave w + o; one column tile at a time
         float4 *xch = reinterpret_cast<float4 *>(lds + cur * S_BUF);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -450,13 +456,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
                     xch[((gw * 3 + (3 - o)) * MT + mt) * 64 + lane] =
-                        make_float4(acc[mt][nt][4 * gw], acc[mt][nt][4 * gw + 1], acc[mt][nt][4 * gw + 2], acc[mt][nt][4 * gw + 3]);
+                        make_float4(acc[mt][nt][4 * o], acc[mt][nt][4 * o + 1], acc[mt][nt][4 * o + 2], acc[mt][nt][4 * o + 3]);
             }
             __syncthreads();
             CSTAMP(5 + 6 * cst + 2 * nt);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                float4 v = make_float4(acc[mt][nt][4 * wave], acc[mt][nt][4 * wave + 1], acc[mt][nt][4 * wave + 2], acc[mt][nt][4 * wave + 3]);
+                float4 v = make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
 #pragma unroll
                 for (int sidx = 0; sidx < 3; ++sidx) {           // fixed order: the waves wave + 1, wave + 2, wave + 3 (mod 4)
                     const float4 p = xch[((wave * 3 + sidx) * MT + mt) * 64 + lane];
@@ -566,6 +572,8 @@ int conv64s_run(const Operand &src, int n, int sh, int sw, int oh, int ow, int q
                 const unsigned *amax_in, unsigned *amax_out, bool prepped) {
     if (ws == nullptr || (reinterpret_cast<uintptr_t>(ws) & 15) != 0)
         return fail(ARVAE_E_INVALID, "%s: needs arvae_link_ws_floats() floats of 16-byte aligned workspace for the split weights", what);
+    // (the weight prep rotates a kernel row's output channels by the number of the wave that runs it: sgn > 0 <-> wave = ky)
+    ARVAE_REQUIRE((sgn > 0) == !transposed, "%s: the row-staged kernel runs Conv2d-forward weights with sgn > 0 and transposed ones with sgn < 0", what);
     ConvStage g{};
     int mt = 0;
     if (!stage_geometry(ow, sw, g.rows, mt)) return fail(ARVAE_E_INVALID, "%s: no staging geometry", what);
