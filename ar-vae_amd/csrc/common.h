@@ -85,6 +85,42 @@ __device__ __forceinline__ float act_bwd_from_out_sel(float y, int act) {
     return act == ARVAE_ACT_RELU ? relu : (act == ARVAE_ACT_SELU ? selu : 1.f);
 }
 
+// Epilogue arithmetic in coefficient form, for kernels whose epilogue is bound by its vector instruction count (conv64s.hip,
+// conv64.hip's 8-channel kernel, link_gemm.hip's single-channel kernel): no selects on the (launch-uniform) activation kind and
+// no branch on the sign (the compiler turns `x > 0 ? a : b(exp)` into an exec-mask branch per value):
+//   act(x)  = pos * max(x, 0) + neg * (exp2(min(x, 0) * log2 e) - 1)            [none: x itself, one select]
+//   act'(y) = y > 0 ? dpos : y * dslope + dneg          (from the saved output; the keep-mask's factor 2 folded in)
+// with the same roundings as common.h's act_fwd / act_bwd_from_out_sel (SELU exponential on v_exp_f32, 1 ulp).
+struct ActCoef {
+    float pos, neg;
+    bool none;
+};
+__device__ __forceinline__ ActCoef act_coef(int act) {
+    return ActCoef{act == ARVAE_ACT_SELU ? kSeluScale : 1.f, act == ARVAE_ACT_SELU ? kSeluScale * kSeluAlpha : 0.f,
+                   act != ARVAE_ACT_SELU && act != ARVAE_ACT_RELU};
+}
+__device__ __forceinline__ float act_fwd_coef(float x, const ActCoef &a) {
+    const float e = __builtin_amdgcn_exp2f(fminf(x, 0.f) * 1.4426950408889634f) - 1.f;
+    const float r = fmaf(a.neg, e, a.pos * fmaxf(x, 0.f));
+    return a.none ? x : r;
+}
+struct GateCoef { float pos, slope, neg; };
+// k2 = 2 with a keep-mask (the saved output is then the kept activation times two: Operand::apply), else 1
+__device__ __forceinline__ GateCoef gate_coef(int act, bool masked) {
+    const float k2 = masked ? 2.f : 1.f;
+    if (act == ARVAE_ACT_SELU) return GateCoef{k2 * kSeluScale, 1.f, k2 * (kSeluScale * kSeluAlpha)};   // (y / k2 + sa) * k2
+    if (act == ARVAE_ACT_RELU) return GateCoef{k2, 0.f, 0.f};
+    return GateCoef{k2, 0.f, k2};
+}
+__device__ __forceinline__ float gate_deriv(float y, const GateCoef &c) { return y > 0.f ? c.pos : fmaf(y, c.slope, c.neg); }
+
+// one form for the three epilogues, result *= gate_deriv(y, c) * keep byte: a data gradient's gate (gate_coef), a forward keep-mask
+// (d = 2; y reads as zero), neither (d = 1, keep bytes of ones)
+__device__ __forceinline__ GateCoef epilogue_coef(const float *gate_y, int gate_act, const uint8_t *gate_mask, const uint8_t *fwd_mask) {
+    if (gate_y != nullptr) return gate_coef(gate_act, gate_mask != nullptr);
+    return fwd_mask != nullptr ? GateCoef{2.f, 0.f, 2.f} : GateCoef{1.f, 0.f, 1.f};
+}
+
 // device view of arvae_operand_t
 struct Operand {
     const float *v;

@@ -373,6 +373,8 @@ __global__ __launch_bounds__(256) void conv_s8_h2_kernel(ConvRows g, int tiles_p
     if (threadIdx.x == 255) { src_h[S8_PIX] = make_uint4(0u, 0u, 0u, 0u); src_l[S8_PIX] = make_uint4(0u, 0u, 0u, 0u); }
     const int opix = g.oh * g.ow;
     const uint8_t *mp = g.gate.y != nullptr ? g.gate.mask : g.mask;
+    const ActCoef ac = act_coef(g.act);
+    const GateCoef gc = epilogue_coef(g.gate.y, g.gate.act, g.gate.mask, g.mask);
     float vmax = 0.f;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int img = tile / tiles_per_img, P0 = (tile - img * tiles_per_img) * 64;
@@ -431,19 +433,14 @@ __global__ __launch_bounds__(256) void conv_s8_h2_kernel(ConvRows g, int tiles_p
             if (pr < opix && e_ok) {
                 const int64_t o = (obase + pr) * g.q + e_c;
                 const float4 a4 = *reinterpret_cast<const float4 *>(&otile[e_px + 16 * u][e_c]);
-                float4 v = make_float4(act_fwd(fmaf(a4.x, inv, bias4.x), g.act), act_fwd(fmaf(a4.y, inv, bias4.y), g.act),
-                                       act_fwd(fmaf(a4.z, inv, bias4.z), g.act), act_fwd(fmaf(a4.w, inv, bias4.w), g.act));
+                // (common.h's coefficient form: result = act(..) * d(y) * keep byte)
+                float4 v = make_float4(act_fwd_coef(fmaf(a4.x, inv, bias4.x), ac), act_fwd_coef(fmaf(a4.y, inv, bias4.y), ac),
+                                       act_fwd_coef(fmaf(a4.z, inv, bias4.z), ac), act_fwd_coef(fmaf(a4.w, inv, bias4.w), ac));
                 const unsigned m = gm[u];
-                if (g.gate.y != nullptr) {
-                    const float ys = g.gate.mask != nullptr ? 0.5f : 1.f, k2 = g.gate.mask != nullptr ? 2.f : 1.f;
-                    v.x *= act_bwd_from_out_sel(ys * gy[u].x, g.gate.act) * k2 * (float)(m & 255u);
-                    v.y *= act_bwd_from_out_sel(ys * gy[u].y, g.gate.act) * k2 * (float)((m >> 8) & 255u);
-                    v.z *= act_bwd_from_out_sel(ys * gy[u].z, g.gate.act) * k2 * (float)((m >> 16) & 255u);
-                    v.w *= act_bwd_from_out_sel(ys * gy[u].w, g.gate.act) * k2 * (float)(m >> 24);
-                } else if (g.mask != nullptr) {
-                    v.x *= 2.f * (float)(m & 255u); v.y *= 2.f * (float)((m >> 8) & 255u);
-                    v.z *= 2.f * (float)((m >> 16) & 255u); v.w *= 2.f * (float)(m >> 24);
-                }
+                v.x *= gate_deriv(gy[u].x, gc) * (float)(m & 255u);
+                v.y *= gate_deriv(gy[u].y, gc) * (float)((m >> 8) & 255u);
+                v.z *= gate_deriv(gy[u].z, gc) * (float)((m >> 16) & 255u);
+                v.w *= gate_deriv(gy[u].w, gc) * (float)(m >> 24);
                 *reinterpret_cast<float4 *>(g.out + o) = v;
                 vmax = fmaxf(vmax, amax4(v));
             }

@@ -141,35 +141,8 @@ __global__ __launch_bounds__(256) void operand_amax_kernel(Operand x, int64_t co
     if (threadIdx.x < 64) amax_publish(out, blockIdx.x, gridDim.x, fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])));
 }
 
-// The epilogue runs with the matrix pipe idle and ONE wave per SIMD: it is bound by its own vector instruction count.  The
-// activation and the gate's derivative are therefore written without selects on the (launch-uniform) activation kind and
-// without a branch on the sign (the compiler turned `x > 0 ? a : b(exp)` into an exec-mask branch per value):
-//   act(x)  = pos * max(x, 0) + neg * (exp2(min(x, 0) * log2 e) - 1)            [none: x itself, one select]
-//   act'(y) = y > 0 ? dpos : y * dslope + dneg          (from the saved output; the keep-mask's factor 2 folded in)
-// with the same roundings as common.h's act_fwd / act_bwd_from_out_sel (SELU exponential on v_exp_f32, 1 ulp).
-struct ActCoef {
-    float pos, neg;
-    bool none;
-};
-__device__ __forceinline__ ActCoef act_coef(int act) {
-    return ActCoef{act == ARVAE_ACT_SELU ? kSeluScale : 1.f, act == ARVAE_ACT_SELU ? kSeluScale * kSeluAlpha : 0.f,
-                   act != ARVAE_ACT_SELU && act != ARVAE_ACT_RELU};
-}
-__device__ __forceinline__ float act_fwd_coef(float x, const ActCoef &a) {
-    const float e = __builtin_amdgcn_exp2f(fminf(x, 0.f) * 1.4426950408889634f) - 1.f;
-    const float r = fmaf(a.neg, e, a.pos * fmaxf(x, 0.f));
-    return a.none ? x : r;
-}
-struct GateCoef { float pos, slope, neg; };
-// k2 = 2 with a keep-mask (the saved output is then the kept activation times two: Operand::apply), else 1
-__device__ __forceinline__ GateCoef gate_coef(int act, bool masked) {
-    const float k2 = masked ? 2.f : 1.f;
-    if (act == ARVAE_ACT_SELU) return GateCoef{k2 * kSeluScale, 1.f, k2 * (kSeluScale * kSeluAlpha)};   // (y / k2 + sa) * k2
-    if (act == ARVAE_ACT_RELU) return GateCoef{k2, 0.f, 0.f};
-    return GateCoef{k2, 0.f, k2};
-}
-__device__ __forceinline__ float gate_deriv(float y, const GateCoef &c) { return y > 0.f ? c.pos : fmaf(y, c.slope, c.neg); }
-
+// The epilogue runs with the matrix pipe idle and ONE wave per SIMD: it is bound by its own vector instruction count; activation and
+// gate in common.h's coefficient form (ActCoef / GateCoef: no select on the activation kind, no branch on the sign).
 // MODE = Operand::mode() of the source: 0 plain, 1 activation derivative from the saved output, 2 also the keep-mask
 template <int MT, int NT, int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv64s_kernel(ConvStage g) {

@@ -576,6 +576,8 @@ __global__ __launch_bounds__(256) void down_single_channel_mfma_kernel(Geom g, O
     __syncthreads();
     const int mtiles = (npos + 15) / 16;
     float amax_run = 0.f;
+    const ActCoef ac = act_coef(ep.act);
+    const GateCoef gc = epilogue_coef(ep.gate.y, ep.gate.act, ep.gate.mask, ep.mask);
     for (int mt = wave; mt < mtiles; mt += 4) {
         const int pos = 16 * mt + col;                       // A row = position
         uint32_t ly, lx;
@@ -613,19 +615,14 @@ __global__ __launch_bounds__(256) void down_single_channel_mfma_kernel(Geom g, O
             const float4 a4 = *reinterpret_cast<const float4 *>(&otile[wave][e_pos + 4 * u][e_c]);
             if (p >= npos) continue;
             const int64_t o = ((int64_t)img * npos + p) * 64 + e_c;
-            float4 v = make_float4(act_fwd(a4.x, ep.act), act_fwd(a4.y, ep.act), act_fwd(a4.z, ep.act), act_fwd(a4.w, ep.act));
+            // activation, then gate / keep-mask in common.h's coefficient form (result *= d(y) * keep byte; no gate: d = 2 with a
+            // keep-mask, else 1 with bytes of ones)
+            float4 v = make_float4(act_fwd_coef(a4.x, ac), act_fwd_coef(a4.y, ac), act_fwd_coef(a4.z, ac), act_fwd_coef(a4.w, ac));
             const unsigned m = mk[u];
-            if (ep.gate.y != nullptr) {
-                // (the saved output of a dropout layer is the kept activation times two: Operand::apply)
-                const float ys = ep.gate.mask != nullptr ? 0.5f : 1.f, k2 = ep.gate.mask != nullptr ? 2.f : 1.f;
-                v.x *= act_bwd_from_out_sel(ys * gy[u].x, ep.gate.act) * k2 * (float)(m & 255u);
-                v.y *= act_bwd_from_out_sel(ys * gy[u].y, ep.gate.act) * k2 * (float)((m >> 8) & 255u);
-                v.z *= act_bwd_from_out_sel(ys * gy[u].z, ep.gate.act) * k2 * (float)((m >> 16) & 255u);
-                v.w *= act_bwd_from_out_sel(ys * gy[u].w, ep.gate.act) * k2 * (float)(m >> 24);
-            } else if (ep.mask != nullptr) {
-                v.x *= 2.f * (float)(m & 255u); v.y *= 2.f * (float)((m >> 8) & 255u);
-                v.z *= 2.f * (float)((m >> 16) & 255u); v.w *= 2.f * (float)(m >> 24);
-            }
+            v.x *= gate_deriv(gy[u].x, gc) * (float)(m & 255u);
+            v.y *= gate_deriv(gy[u].y, gc) * (float)((m >> 8) & 255u);
+            v.z *= gate_deriv(gy[u].z, gc) * (float)((m >> 16) & 255u);
+            v.w *= gate_deriv(gy[u].w, gc) * (float)(m >> 24);
             amax_run = fmaxf(amax_run, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
             *reinterpret_cast<float4 *>(ep.out + o) = v;
         }
