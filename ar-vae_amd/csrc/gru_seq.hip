@@ -63,6 +63,26 @@ __device__ __forceinline__ float fast_tanh(float x) {
     return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x));
 }
 
+// Addressing of the recurrences' per-step memory operations: raw buffer operations, byte offset = a SCALAR part (the step's
+// t * R * row pitch: one s_mul per array and step) + a per-lane part (row * pitch + unit: one v_mad_u32_u24 per operation).  With
+// 64-bit pointer arithmetic each of a step's ~40 loads and stores cost 6-10 vector instructions -- half of what a wave executes
+// per step in kernels that are bound by exactly that (16-32 workgroups on the chip, every step a chain of dependent phases).
+// A null array is an empty range: its loads return zero and its stores are dropped, no branch.  (gru_seq_check bounds the
+// arrays at 2 GB.)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t gru_rsrc(const void *p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, p != nullptr ? 0x7fffffff : 0, 0x00020000);
+}
+__device__ __forceinline__ float gru_ld(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ f32x4 gru_ld4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void gru_st(float v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, voff, soff, 0);
+}
+__device__ __forceinline__ int gru_off(int row, int pitch_bytes, int base_bytes) { return (int)__umul24(row, pitch_bytes) + base_bytes; }
+
 template <int H>
 __global__ __launch_bounds__(H * 4) void gru_seq_fwd_kernel(GruSeqBatch batch, int T, int R) {
     constexpr int KQ = H / 16;             // groups of 16 k values (4 MFMAs each)
@@ -694,19 +714,24 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_x3_kernel(GruSeqBatch batch
     for (int i = 0; i < 4; ++i)
         carry[i] = (s.dh_last != nullptr && live[i]) ? s.dh_last[(int64_t)rows[i] * s.dh_last_stride + unit] : 0.f;
 
+    // the step's arrays as buffer resources (gru_rsrc), their row pitches in bytes
+    const __amdgpu_buffer_rsrc_t rs_dh = gru_rsrc(s.dh_all), rs_sv = gru_rsrc(s.saved), rs_hall = gru_rsrc(s.h_all), rs_h0 = gru_rsrc(s.h0);
+    const __amdgpu_buffer_rsrc_t rs_dgi = gru_rsrc(s.dgi), rs_dgh = gru_rsrc(s.dgh), rs_hpo = gru_rsrc(s.h_prev_out);
+    const int reverse = s.reverse, unit4 = 4 * unit;
+    const int dh_p = 4 * (int)s.dh_stride, h_p = 4 * (int)s.h_stride, h0_p = 4 * (int)s.h0_stride, dgi_p = 4 * (int)s.dgi_rstride;
     float nx[4][6];                          // dh, r, z, n, gh_n, h_prev of the next step
     auto fetch = [&](int step) {
-        const int t = s.reverse ? step : T - 1 - step;
+        const int t = reverse ? step : T - 1 - step;
         const bool has_prev = step + 1 < T;
-        const int tp = s.reverse ? t + 1 : t - 1;
+        const int tp = reverse ? t + 1 : t - 1;
+        const __amdgpu_buffer_rsrc_t rs_hp = has_prev ? rs_hall : rs_h0;
+        const int hp_p = has_prev ? h_p : h0_p, hp_s = has_prev ? tp * R * h_p : 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int64_t tr = (int64_t)t * R + rows[i];
-            nx[i][0] = s.dh_all != nullptr ? s.dh_all[tr * s.dh_stride + unit] : 0.f;
-            const f32x4 sv = *reinterpret_cast<const f32x4 *>(s.saved + (tr * H + unit) * 4);
+            nx[i][0] = gru_ld(rs_dh, gru_off(rows[i], dh_p, unit4), t * R * dh_p);
+            const f32x4 sv = gru_ld4(rs_sv, gru_off(rows[i], 16 * H, 4 * unit4), t * R * (16 * H));
             nx[i][1] = sv[0]; nx[i][2] = sv[1]; nx[i][3] = sv[2]; nx[i][4] = sv[3];
-            if (has_prev) nx[i][5] = s.h_all[((int64_t)tp * R + rows[i]) * s.h_stride + unit];
-            else nx[i][5] = s.h0 != nullptr ? s.h0[(int64_t)rows[i] * s.h0_stride + unit] : 0.f;
+            nx[i][5] = gru_ld(rs_hp, gru_off(rows[i], hp_p, unit4), hp_s);
         }
     };
     fetch(0);
@@ -715,7 +740,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_x3_kernel(GruSeqBatch batch
 #endif
 
     for (int step = 0; step < T; ++step) {
-        const int t = s.reverse ? step : T - 1 - step;
+        const int t = reverse ? step : T - 1 - step;
         const int cur = step & 1;
         float gz[4], o_gi[4][3], o_hn[4], o_hp[4];
 #ifdef ARVAE_GRU_STAMPS
@@ -753,11 +778,11 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_x3_kernel(GruSeqBatch batch
         // row i's gradients of this step leave BEHIND the MFMAs of k-step group i (pinned: see gru_seq_fwd_x3_kernel)
         auto row_stores = [&](int i) __attribute__((always_inline)) {
             if (live[i]) {
-                const int64_t o = ((int64_t)t * R + rows[i]) * 3 * H + unit;
-                const int64_t og = ((int64_t)t * R + rows[i]) * s.dgi_rstride + unit;
-                s.dgi[og] = o_gi[i][0]; s.dgi[og + H] = o_gi[i][1]; s.dgi[og + 2 * H] = o_gi[i][2];
-                s.dgh[o] = o_gi[i][0]; s.dgh[o + H] = o_gi[i][1]; s.dgh[o + 2 * H] = o_hn[i];
-                if (s.h_prev_out != nullptr) s.h_prev_out[((int64_t)t * R + rows[i]) * H + unit] = o_hp[i];
+                const int og = gru_off(rows[i], dgi_p, unit4), sg = t * R * dgi_p;
+                const int o = gru_off(rows[i], 12 * H, unit4), so = t * R * (12 * H);
+                gru_st(o_gi[i][0], rs_dgi, og, sg); gru_st(o_gi[i][1], rs_dgi, og + 4 * H, sg); gru_st(o_gi[i][2], rs_dgi, og + 8 * H, sg);
+                gru_st(o_gi[i][0], rs_dgh, o, so); gru_st(o_gi[i][1], rs_dgh, o + 4 * H, so); gru_st(o_hn[i], rs_dgh, o + 8 * H, so);
+                gru_st(o_hp[i], rs_hpo, gru_off(rows[i], 4 * H, unit4), t * R * (4 * H));
             }
         };
 #pragma unroll
