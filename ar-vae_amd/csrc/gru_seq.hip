@@ -15,6 +15,7 @@
 //
 // The weight gradients (dW_hh = dgh^T h_prev, dW_ih = dgi^T x) and the input gradients are ordinary dense launches
 // over all T*R rows afterwards (ops.py).
+#include <algorithm>
 #include "diag.h"
 #include "common.h"
 
@@ -67,7 +68,7 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // t * R * row pitch: one s_mul per array and step) + a per-lane part (row * pitch + unit: one v_mad_u32_u24 per operation).  With
 // 64-bit pointer arithmetic each of a step's ~40 loads and stores cost 6-10 vector instructions -- half of what a wave executes
 // per step in kernels that are bound by exactly that (16-32 workgroups on the chip, every step a chain of dependent phases).
-// A null array is an empty range: its loads return zero and its stores are dropped, no branch.  (gru_seq_check bounds the
+// A null array is an empty range: its loads return zero and its stores are dropped, no branch.  (arvae_gru_seq_bwd bounds the
 // arrays at 2 GB.)
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t gru_rsrc(const void *p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, p != nullptr ? 0x7fffffff : 0, 0x00020000);
@@ -1529,6 +1530,14 @@ extern "C" int arvae_gru_seq_bwd(const arvae_gru_seq_t *seqs, int32_t nseq, int3
         ARVAE_REQUIRE(seqs[i].w_hh && seqs[i].h_all && seqs[i].saved && seqs[i].dgi && seqs[i].dgh, "gru_seq_bwd: null pointer");
     GruSeqBatch b{};
     fill_batch(&b, seqs, nseq, hidden);
+    // (the recurrence addresses its arrays with 32-bit byte offsets: gru_rsrc)
+    const int64_t span = (int64_t)steps * rows * 4;
+    for (int i = 0; i < nseq; ++i) {
+        const GruSeq &q = b.seq[i];
+        const int64_t widest = std::max<int64_t>({q.dh_stride, q.h_stride, q.h0_stride, q.dgi_rstride, 4 * (int64_t)hidden});
+        ARVAE_REQUIRE(span * widest < ((int64_t)1 << 31), "gru_seq_bwd: %d steps x %d rows of %lld floats do not fit 2 GB per array", steps, rows,
+                      (long long)widest);
+    }
     hipStream_t st = as_stream(stream);
     const dim3 grid((rows + 15) / 16, nseq);
     if (gru_fp32_mfma()) {
