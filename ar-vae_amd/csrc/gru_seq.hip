@@ -68,10 +68,13 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // t * R * row pitch: one s_mul per array and step) + a per-lane part (row * pitch + unit: one v_mad_u32_u24 per operation).  With
 // 64-bit pointer arithmetic each of a step's ~40 loads and stores cost 6-10 vector instructions -- half of what a wave executes
 // per step in kernels that are bound by exactly that (16-32 workgroups on the chip, every step a chain of dependent phases).
-// A null array is an empty range: its loads return zero and its stores are dropped, no branch.  (arvae_gru_seq_bwd bounds the
-// arrays at 2 GB.)
+// A null array is an empty range: its loads return zero and its stores are dropped, no branch; a lane drops a store with the
+// per-lane offset GRU_DEAD (the hardware checks the per-lane offset + the instruction's immediate against the range; the scalar
+// offset is NOT checked -- a step without an operation selects the empty range instead).  The entry points bound the arrays at
+// GRU_RANGE bytes.
+constexpr int GRU_RANGE = 0x7fff0000, GRU_DEAD = 0x7fff0000;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t gru_rsrc(const void *p) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, p != nullptr ? 0x7fffffff : 0, 0x00020000);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, p != nullptr ? GRU_RANGE : 0, 0x00020000);
 }
 __device__ __forceinline__ float gru_ld(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
@@ -573,21 +576,21 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_h2_kernel(GruSeqBatch batch
         h[i] = (s.h0 != nullptr && live[i]) ? s.h0[(int64_t)rows[i] * s.h0_stride + unit] : 0.f;
         store_split2(&hbuf[0][(4 * quad + i) * HP + unit], PLANE, h[i]);
     }
-    // running per-row pointers, advanced by a signed stride every step (the address arithmetic of 12 loads and 8 stores
-    // per step was a quarter of the step: the kernel is vector-ALU bound around its MFMAs)
-    const int t0 = s.reverse ? T - 1 : 0;
-    const int64_t dir = s.reverse ? -1 : 1;
-    const int64_t gi_step = dir * s.gi_tstride, h_step = dir * (int64_t)R * s.h_stride, sv_step = dir * (int64_t)R * H * 4;
-    const float *gi_p[4];
-    float *h_p[4], *sv_p[4];
+    // per-step memory operations as raw buffer operations (gru_rsrc): a scalar step offset + one per-lane offset per array and row
+    // (the running 64-bit pointers this kernel had cost 24 registers and a 64-bit add each per step; the first and last step's
+    // missing operations were branches).  A dead row's stores go beyond the range.
+    const __amdgpu_buffer_rsrc_t rs_gi = gru_rsrc(s.gi), rs_h = gru_rsrc(s.h_all), rs_sv = gru_rsrc(s.saved), rs_none = gru_rsrc(nullptr);
+    const int reverse = s.reverse, unit4 = 4 * unit;
+    const int gi_tp = 4 * (int)s.gi_tstride, h_tp = 4 * R * (int)s.h_stride;
+    int gi_o[4], h_o[4], sv_o[4];
     float gi_next[4][3];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        gi_p[i] = s.gi + t0 * s.gi_tstride + (int64_t)rows[i] * s.gi_rstride + unit;
-        h_p[i] = s.h_all + ((int64_t)t0 * R + rows[i]) * s.h_stride + unit;
-        sv_p[i] = s.saved + (((int64_t)t0 * R + rows[i]) * H + unit) * 4;
-        gi_next[i][0] = gi_p[i][0]; gi_next[i][1] = gi_p[i][H]; gi_next[i][2] = gi_p[i][2 * H];
-        gi_p[i] += gi_step;
+        gi_o[i] = gru_off(rows[i], 4 * (int)s.gi_rstride, unit4);
+        h_o[i] = live[i] ? gru_off(rows[i], 4 * (int)s.h_stride, unit4) : GRU_DEAD;
+        sv_o[i] = live[i] ? gru_off(rows[i], 16 * H, 4 * unit4) : GRU_DEAD;
+        const int so = (reverse ? T - 1 : 0) * gi_tp;
+        gi_next[i][0] = gru_ld(rs_gi, gi_o[i], so); gi_next[i][1] = gru_ld(rs_gi, gi_o[i] + 4 * H, so); gi_next[i][2] = gru_ld(rs_gi, gi_o[i] + 8 * H, so);
     }
     lds_barrier();
     f32x4 keep_sv[4];                        // results of the previous step, stored after the barrier
@@ -615,18 +618,16 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_h2_kernel(GruSeqBatch batch
         // gates out) is issued BEHIND the MFMAs of k-step i, with a scheduling barrier pinning it there: as one block in front
         // of the MFMAs it was 1200 of the step's 6000 cycles (tools/stamp_gru.py), all of it issue time of an in-order wave
         // while the matrix pipe sat idle.
+        // next step's projections (the last step reads its own again); the previous step's results (none in step 0: the empty range)
+        const int tn = step + 1 < T ? (reverse ? t - 1 : t + 1) : t;
+        const int kt = keep_t >= 0 ? keep_t : 0;
+        const int so_gi = tn * gi_tp, so_h = kt * h_tp, so_sv = kt * R * (16 * H);
+        const __amdgpu_buffer_rsrc_t rs_hs = keep_t >= 0 ? rs_h : rs_none, rs_svs = keep_t >= 0 ? rs_sv : rs_none;
         auto row_traffic = [&](int i) __attribute__((always_inline)) {
-            if (step + 1 < T) {
-                gi_next[i][0] = gi_p[i][0]; gi_next[i][1] = gi_p[i][H]; gi_next[i][2] = gi_p[i][2 * H];
-                gi_p[i] += gi_step;
-            }
-            if (keep_t >= 0) {
-                if (live[i]) {
-                    *h_p[i] = keep_h[i];
-                    *reinterpret_cast<f32x4 *>(sv_p[i]) = keep_sv[i];
-                }
-                h_p[i] += h_step; sv_p[i] += sv_step;
-            }
+            gi_next[i][0] = gru_ld(rs_gi, gi_o[i], so_gi); gi_next[i][1] = gru_ld(rs_gi, gi_o[i] + 4 * H, so_gi);
+            gi_next[i][2] = gru_ld(rs_gi, gi_o[i] + 8 * H, so_gi);
+            gru_st(keep_h[i], rs_hs, h_o[i], so_h);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4g, keep_sv[i]), rs_svs, sv_o[i], so_sv, 0);
         };
         static_assert(KS <= 4, "one row's traffic per k-step; rows left over go last");
 #pragma unroll
@@ -673,8 +674,8 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_h2_kernel(GruSeqBatch batch
 #pragma unroll
     for (int i = 0; i < 4; ++i)
         if (live[i]) {
-            *h_p[i] = keep_h[i];
-            *reinterpret_cast<f32x4 *>(sv_p[i]) = keep_sv[i];
+            gru_st(keep_h[i], rs_h, h_o[i], keep_t * h_tp);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4g, keep_sv[i]), rs_sv, sv_o[i], keep_t * R * (16 * H), 0);
             if (s.h_fin != nullptr) s.h_fin[(int64_t)rows[i] * s.h_fin_stride + unit] = keep_h[i];
         }
 }
@@ -1503,6 +1504,13 @@ extern "C" int arvae_gru_seq_fwd(const arvae_gru_seq_t *seqs, int32_t nseq, int3
         ARVAE_REQUIRE(seqs[i].gi && seqs[i].w_hh && seqs[i].b_hh && seqs[i].h_all && seqs[i].saved, "gru_seq_fwd: null pointer");
     GruSeqBatch b{};
     fill_batch(&b, seqs, nseq, hidden);
+    // (the recurrence addresses its arrays with 32-bit byte offsets: gru_rsrc)
+    for (int i = 0; i < nseq; ++i) {
+        const GruSeq &q = b.seq[i];
+        const int64_t gi_bytes = 4 * ((int64_t)steps * q.gi_tstride + (int64_t)rows * q.gi_rstride);
+        const int64_t h_bytes = 4 * (int64_t)steps * rows * std::max<int64_t>(q.h_stride, 4 * (int64_t)hidden);
+        ARVAE_REQUIRE(gi_bytes < GRU_RANGE && h_bytes < GRU_RANGE, "gru_seq_fwd: %d steps x %d rows do not fit 2 GB per array", steps, rows);
+    }
     hipStream_t st = as_stream(stream);
     const dim3 grid((rows + 15) / 16, nseq);
     if (gru_fp32_mfma()) {
@@ -1535,7 +1543,7 @@ extern "C" int arvae_gru_seq_bwd(const arvae_gru_seq_t *seqs, int32_t nseq, int3
     for (int i = 0; i < nseq; ++i) {
         const GruSeq &q = b.seq[i];
         const int64_t widest = std::max<int64_t>({q.dh_stride, q.h_stride, q.h0_stride, q.dgi_rstride, 4 * (int64_t)hidden});
-        ARVAE_REQUIRE(span * widest < ((int64_t)1 << 31), "gru_seq_bwd: %d steps x %d rows of %lld floats do not fit 2 GB per array", steps, rows,
+        ARVAE_REQUIRE(span * widest < GRU_RANGE, "gru_seq_bwd: %d steps x %d rows of %lld floats do not fit 2 GB per array", steps, rows,
                       (long long)widest);
     }
     hipStream_t st = as_stream(stream);
