@@ -6,7 +6,7 @@ from arvae_amd import ops, _lib
 lib = _lib.load()
 dev = torch.device('cuda:0')
 T, R, H = 24, 256, 128
-fn = ctypes.CDLL(_lib.LIB_PATH).arvae_debug_gru_stamps
+fn = ctypes.CDLL(os.environ.get('ARVAE_LIB') or _lib.LIB_PATH).arvae_debug_gru_stamps
 fn.argtypes = [ctypes.c_void_p]
 gi = [torch.randn(T, R, 3 * H, device=dev) for _ in range(2)]
 w = [torch.randn(3 * H, H, device=dev) * 0.05 for _ in range(2)]
