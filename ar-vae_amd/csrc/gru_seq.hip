@@ -1292,6 +1292,18 @@ __global__ __launch_bounds__(256) void tick_weight_prep_h2_kernel(TickPrep p) {
     dst[64] = __builtin_bit_cast(uint4, lo);
 }
 
+// one stage of a (value, index) argmax inside a 16-lane DPP row: the partner lane's pair through a DPP move, larger value wins,
+// equal values keep the lower index (commutative and associative: any sequence of pairings that connects the 16 lanes gives the
+// row's maximum with its lowest index in every lane)
+template <int CTRL>
+__device__ __forceinline__ void tick_argmax_stage(float &v, int &ix) {
+    const float ov = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+    const int oi = __builtin_amdgcn_update_dpp(0, ix, CTRL, 0xf, 0xf, true);
+    const bool take = ov > v || (ov == v && oi < ix);
+    v = take ? ov : v;
+    ix = take ? oi : ix;
+}
+
 template <int H, bool MASKED>
 __global__ __launch_bounds__(H * 4) void tick_free_run_h2_kernel(TickFreeRun p, const uint4 *__restrict__ packed) {
     constexpr int NW = H / 16, KS = H / 32, KQ = H / 16;
@@ -1352,10 +1364,36 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_h2_kernel(TickFreeRun p, 
     const int ticks = p.beats * p.tpb;
     const int aoff = col * HP + 8 * quad;                     // this lane's A-operand offset inside a plane
 
+    // layer 0's recurrent product W_hh0 h0 of a tick does not wait for the tick's token: it is multiplied at the END of the previous
+    // tick, under the logits and the argmax (three waves' latency chain of ~3500 cycles, during which the workgroup's weight
+    // stream -- what bounds the layers: 590 KB per tick at the CU's 64 bytes per clock -- stood still; tools/stamp_tick.py).
+    // A beat's first tick starts from the beat's own state and multiplies at its top, as every tick did.
+    f32x4 acc0[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    // the 3 KS weight groups of matrix 0 against the state image `ab`; piece(g) runs behind group g
+    auto layer0 = [&](const unsigned short *ab, auto piece) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) acc0[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const f16x8g ah = lds_h8(ab + 32 * ks), al = lds_h8(ab + PLANE + 32 * ks);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int gg = (0 * KS + ks) * 3 + q;
+                fetch((gg + PFD) % NGG);
+                __builtin_amdgcn_sched_barrier(0);
+                GRU_MFMA3(acc0[q], ah, al, wb[gg % RS][0], wb[gg % RS][1]);
+                __builtin_amdgcn_sched_barrier(0);
+                piece(gg);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    auto no_piece = [](int) __attribute__((always_inline)) {};
     for (int t = 0; t < ticks; ++t) {
         const int cur = t & 1;
         const int beat = t / p.tpb;
-        if (t % p.tpb == 0) {
+        const bool beat_start = t % p.tpb == 0;
+        if (beat_start) {
             lds_barrier();
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -1376,27 +1414,14 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_h2_kernel(TickFreeRun p, 
             gi[i][0] = gb[i][0] + pt[0]; gi[i][1] = gb[i][1] + pt[H]; gi[i][2] = gb[i][2] + pt[2 * H];
             keep[i] = MASKED ? p.keep_scale * (float)p.mask[((int64_t)t * B + rows[i]) * H + unit] : 1.f;
         }
-        // ---- layer 0: matrix 0
+        // ---- layer 0: matrix 0 (multiplied at the end of the previous tick unless a beat starts)
         {
-            f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-            const unsigned short *ab = &hA0[cur][aoff];
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const f16x8g ah = lds_h8(ab + 32 * ks), al = lds_h8(ab + PLANE + 32 * ks);
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const int gg = (0 * KS + ks) * 3 + q;
-                    fetch((gg + PFD) % NGG);
-                    __builtin_amdgcn_sched_barrier(0);
-                    GRU_MFMA3(acc[q], ah, al, wb[gg % RS][0], wb[gg % RS][1]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
+            if (beat_start) layer0(&hA0[cur][aoff], no_piece);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float r = fast_sigmoid(gi[i][0] + acc[0][i] * GRU_UNSCALE + b0r);
-                const float z = fast_sigmoid(gi[i][1] + acc[1][i] * GRU_UNSCALE + b0z);
-                const float n = fast_tanh(gi[i][2] + r * (acc[2][i] * GRU_UNSCALE + b0n));
+                const float r = fast_sigmoid(gi[i][0] + acc0[0][i] * GRU_UNSCALE + b0r);
+                const float z = fast_sigmoid(gi[i][1] + acc0[1][i] * GRU_UNSCALE + b0z);
+                const float n = fast_tanh(gi[i][2] + r * (acc0[2][i] * GRU_UNSCALE + b0n));
                 h0[i] = (1.f - z) * n + z * h0[i];
                 store_split2(&hA0[cur ^ 1][(4 * quad + i) * HP + unit], PLANE, h0[i]);
                 store_split2(&midp[(4 * quad + i) * HP + unit], PLANE, h0[i] * keep[i]);
@@ -1433,29 +1458,46 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_h2_kernel(TickFreeRun p, 
             }
         }
         lds_barrier();
-        // ---- logits (fp32 MFMA, weights in LDS) + row argmax
-        if (w < ntile) {
-            f32x4 lg = {0.f, 0.f, 0.f, 0.f};
+        // ---- logits (fp32 MFMA, weights in LDS) + row argmax on the first waves; on every wave the NEXT tick's layer 0
+        {
+            const bool pre = t + 1 < ticks && (t + 1) % p.tpb != 0;
+            const unsigned short *ab_next = &hA0[cur ^ 1][aoff];
+            if (w < ntile) {
+                f32x4 lg = {0.f, 0.f, 0.f, 0.f};
+                auto logits_step = [&](int kq) __attribute__((always_inline)) {
+                    const f32x4 a = *reinterpret_cast<const f32x4 *>(&h1f[col][16 * kq + 4 * quad]);
+                    const f32x4 b = *reinterpret_cast<const f32x4 *>(&wout_s[note][16 * kq + 4 * quad]);
 #pragma unroll
-            for (int kq = 0; kq < KQ; ++kq) {
-                const f32x4 a = *reinterpret_cast<const f32x4 *>(&h1f[col][16 * kq + 4 * quad]);
-                const f32x4 b = *reinterpret_cast<const f32x4 *>(&wout_s[note][16 * kq + 4 * quad]);
+                    for (int j = 0; j < 4; ++j) lg = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], lg, 0, 0, 0);
+                };
+                auto argmax_row = [&](int i) __attribute__((always_inline)) {
+                    float v = note_ok ? fmaxf(lg[i] + bout, 0.f) : -1.f;
+                    int ix = note;
+                    // (value, lowest index) maximum over the tile's 16 notes = one DPP row: lane pairings on the vector ALU (quad
+                    // permutes, then the half-row and the row mirrored) instead of four ds_bpermute round trips per row
+                    tick_argmax_stage<0xB1>(v, ix);
+                    tick_argmax_stage<0x4E>(v, ix);
+                    tick_argmax_stage<0x141>(v, ix);
+                    tick_argmax_stage<0x140>(v, ix);
+                    if (col == 0) { cand_v[w][4 * quad + i] = v; cand_i[w][4 * quad + i] = ix; }
+                };
+                constexpr int NG0 = 3 * KS;
+                if (pre) {
+                    // the logits' k-steps behind matrix 0's first groups, the rows' argmax behind the next ones
+                    layer0(ab_next, [&](int g) __attribute__((always_inline)) {
+                        if (g < KQ) logits_step(g);
+                        else if (g < KQ + 4) argmax_row(g - KQ);
+                    });
 #pragma unroll
-                for (int j = 0; j < 4; ++j) lg = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], lg, 0, 0, 0);
-            }
+                    for (int i = (NG0 > KQ ? NG0 - KQ : 0); i < 4; ++i) argmax_row(i);
+                } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float v = note_ok ? fmaxf(lg[i] + bout, 0.f) : -1.f;
-                int ix = note;
+                    for (int kq = 0; kq < KQ; ++kq) logits_step(kq);
 #pragma unroll
-                for (int off = 1; off < 16; off <<= 1) {
-                    const float ov = __shfl_xor(v, off, 64);
-                    const int oi = __shfl_xor(ix, off, 64);
-                    const bool take = ov > v || (ov == v && oi < ix);
-                    v = take ? ov : v;
-                    ix = take ? oi : ix;
+                    for (int i = 0; i < 4; ++i) argmax_row(i);
                 }
-                if (col == 0) { cand_v[w][4 * quad + i] = v; cand_i[w][4 * quad + i] = ix; }
+            } else if (pre) {
+                layer0(ab_next, no_piece);
             }
         }
         lds_barrier();
