@@ -343,6 +343,7 @@ __device__ __forceinline__ bf16x8g lds_x8(const unsigned short *p) {
 
 #ifdef ARVAE_GRU_STAMPS
 __device__ unsigned long long g_gru_stamps[8];
+__device__ unsigned long long g_tick_stamps[9];
 #endif
 template <int H>
 __global__ __launch_bounds__(H * 4) void gru_seq_fwd_x3_kernel(GruSeqBatch batch, int T, int R) {
@@ -1389,6 +1390,13 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_h2_kernel(TickFreeRun p, 
         }
     };
     auto no_piece = [](int) __attribute__((always_inline)) {};
+#ifdef ARVAE_GRU_STAMPS
+    // diagnostic build (tools/stamp_tick.py): cycles per phase of a tick, wave GRU_STAMP_WAVE of workgroup 0
+    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ttc = __builtin_readcyclecounter();
+#define TSTAMP(k) { __builtin_amdgcn_s_waitcnt(0xc07f); const unsigned long long now = __builtin_readcyclecounter(); tph[k] += now - ttc; ttc = now; }
+#else
+#define TSTAMP(k)
+#endif
     for (int t = 0; t < ticks; ++t) {
         const int cur = t & 1;
         const int beat = t / p.tpb;
@@ -1414,9 +1422,14 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_h2_kernel(TickFreeRun p, 
             gi[i][0] = gb[i][0] + pt[0]; gi[i][1] = gb[i][1] + pt[H]; gi[i][2] = gb[i][2] + pt[2 * H];
             keep[i] = MASKED ? p.keep_scale * (float)p.mask[((int64_t)t * B + rows[i]) * H + unit] : 1.f;
         }
+        TSTAMP(0);                                             // tick top: a beat's state; the token's projections requested
         // ---- layer 0: matrix 0 (multiplied at the end of the previous tick unless a beat starts)
         {
             if (beat_start) layer0(&hA0[cur][aoff], no_piece);
+#ifdef ARVAE_GRU_STAMPS
+            { float dep = acc0[0][0] + acc0[1][1] + acc0[2][3]; asm volatile("" :: "v"(dep)); }
+#endif
+            TSTAMP(1);                                         // layer 0 at the top (a beat's first tick only)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float r = fast_sigmoid(gi[i][0] + acc0[0][i] * GRU_UNSCALE + b0r);
@@ -1427,7 +1440,9 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_h2_kernel(TickFreeRun p, 
                 store_split2(&midp[(4 * quad + i) * HP + unit], PLANE, h0[i] * keep[i]);
             }
         }
+        TSTAMP(2);                                             // layer 0 gates (wait for the projections) + LDS writes
         lds_barrier();
+        TSTAMP(3);
         // ---- layer 1: matrix 1 (W_ih1 on mid), matrix 2 (W_hh1 on h1); r and z share an accumulator
         {
             f32x4 a1[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // r, z, i_n, h_n
@@ -1447,6 +1462,10 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_h2_kernel(TickFreeRun p, 
                     }
                 }
             }
+#ifdef ARVAE_GRU_STAMPS
+            { float dep = a1[0][0] + a1[1][1] + a1[2][3] + a1[3][2]; asm volatile("" :: "v"(dep)); }
+#endif
+            TSTAMP(4);                                         // layer 1: operand reads + MFMAs behind the weight stream
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float r = fast_sigmoid(a1[0][i] * GRU_UNSCALE + b1r);
@@ -1457,6 +1476,7 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_h2_kernel(TickFreeRun p, 
                 h1f[4 * quad + i][unit] = h1[i];
             }
         }
+        TSTAMP(5);                                             // layer 1 gates + LDS writes
         lds_barrier();
         // ---- logits (fp32 MFMA, weights in LDS) + row argmax on the first waves; on every wave the NEXT tick's layer 0
         {
@@ -1470,36 +1490,48 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_h2_kernel(TickFreeRun p, 
 #pragma unroll
                     for (int j = 0; j < 4; ++j) lg = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], lg, 0, 0, 0);
                 };
-                auto argmax_row = [&](int i) __attribute__((always_inline)) {
-                    float v = note_ok ? fmaxf(lg[i] + bout, 0.f) : -1.f;
-                    int ix = note;
-                    // (value, lowest index) maximum over the tile's 16 notes = one DPP row: lane pairings on the vector ALU (quad
-                    // permutes, then the half-row and the row mirrored) instead of four ds_bpermute round trips per row
-                    tick_argmax_stage<0xB1>(v, ix);
-                    tick_argmax_stage<0x4E>(v, ix);
-                    tick_argmax_stage<0x141>(v, ix);
-                    tick_argmax_stage<0x140>(v, ix);
-                    if (col == 0) { cand_v[w][4 * quad + i] = v; cand_i[w][4 * quad + i] = ix; }
+                // the four rows' (value, lowest index) maxima over the tile's 16 notes = one DPP row each: lane pairings on the
+                // vector ALU (quad permutes, then the half-row and the row mirrored) instead of four ds_bpermute round trips per
+                // row; stage by stage over the four rows (four independent chains), one block of candidate writes
+                auto argmax_rows = [&]() __attribute__((always_inline)) {
+                    float v[4];
+                    int ix[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { v[i] = note_ok ? fmaxf(lg[i] + bout, 0.f) : -1.f; ix[i] = note; }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) tick_argmax_stage<0xB1>(v[i], ix[i]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) tick_argmax_stage<0x4E>(v[i], ix[i]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) tick_argmax_stage<0x141>(v[i], ix[i]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) tick_argmax_stage<0x140>(v[i], ix[i]);
+                    if (col == 0) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { cand_v[w][4 * quad + i] = v[i]; cand_i[w][4 * quad + i] = ix[i]; }
+                    }
                 };
                 constexpr int NG0 = 3 * KS;
                 if (pre) {
-                    // the logits' k-steps behind matrix 0's first groups, the rows' argmax behind the next ones
+                    // the logits' k-steps behind matrix 0's first groups, the rows' argmax behind the next one
                     layer0(ab_next, [&](int g) __attribute__((always_inline)) {
                         if (g < KQ) logits_step(g);
-                        else if (g < KQ + 4) argmax_row(g - KQ);
+                        else if (g == KQ) argmax_rows();
                     });
-#pragma unroll
-                    for (int i = (NG0 > KQ ? NG0 - KQ : 0); i < 4; ++i) argmax_row(i);
+                    if (NG0 <= KQ) argmax_rows();
                 } else {
 #pragma unroll
                     for (int kq = 0; kq < KQ; ++kq) logits_step(kq);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) argmax_row(i);
+                    argmax_rows();
                 }
             } else if (pre) {
                 layer0(ab_next, no_piece);
             }
+#ifdef ARVAE_GRU_STAMPS
+            { float dep = acc0[0][0] + acc0[1][1] + acc0[2][3]; asm volatile("" :: "v"(dep)); }
+#endif
         }
+        TSTAMP(6);                                             // barrier + logits / argmax (first waves) + the next tick's layer 0
         lds_barrier();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1516,7 +1548,17 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_h2_kernel(TickFreeRun p, 
             tok[i] = ix;
             if (w == 0 && col == 0 && live[i]) p.tokens[(int64_t)rows[i] * ticks + t] = ix;
         }
+        TSTAMP(7);                                             // barrier + the tiles' candidates -> token
     }
+#ifdef ARVAE_GRU_STAMPS
+#ifndef GRU_STAMP_WAVE
+#define GRU_STAMP_WAVE 0
+#endif
+    if (blockIdx.x == 0 && threadIdx.x == 64 * GRU_STAMP_WAVE) {
+        for (int q = 0; q < 8; ++q) g_tick_stamps[q] = tph[q];
+        g_tick_stamps[8] = ticks;
+    }
+#endif
 }
 
 }  // namespace arvae
@@ -1676,6 +1718,9 @@ extern "C" int arvae_tick_free_run(const arvae_tick_weights_t *wts, const float 
 }
 
 #ifdef ARVAE_GRU_STAMPS
+extern "C" int arvae_debug_tick_stamps(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(arvae::g_tick_stamps), sizeof(unsigned long long) * 9);
+}
 extern "C" int arvae_debug_gru_stamps(unsigned long long *out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(arvae::g_gru_stamps), sizeof(unsigned long long) * 8);
 }
