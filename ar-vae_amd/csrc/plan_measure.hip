@@ -18,6 +18,12 @@ namespace arvae {
 int token_recon_partials(const float *weights, const int64_t *score, int batch, int beats, int tpb, int32_t vocab, float *ws,
                          float *dweights, hipStream_t s, int *nb_out);
 int token_recon_blocks(int64_t rows);
+// arvae_tick_gi_fwd that also copies the tokens it reads (sequence.hip)
+int tick_gi_fwd_copy(const float *g_small, const int64_t *tokens, const float *bias, int32_t batch, int32_t beats, int32_t ticks_per_beat,
+                     int32_t vocab, int32_t cols, float *gi, int64_t *copy_to, hipStream_t s);
+// several draws as one launch (rng.hip)
+int philox_draws(int n_draws, const int *kind, void *const *out, const int64_t *count, const float *keep_prob, const uint32_t *offset,
+                 uint64_t seed, uint32_t step, const uint32_t *dev_step, hipStream_t s);
 int reg_partials(const float *z_rows, const float *lab_rows, int64_t n_rows, const float *z_cols, const float *lab_cols,
                  int64_t n_cols, int64_t ldz, int64_t ldl, const RegDims &rd, int32_t r, float delta, float *ws,
                  hipStream_t s);
@@ -353,14 +359,17 @@ extern "C" int arvae_measure_vae_forward(const arvae_measure_vae_t *m, int32_t b
     const int He = d.he, Hd = d.hd;
 
     // ---- draws (csrc/rng.h): keep-masks and eps exactly as ops.keep_mask / ops.normal_noise make them, in the Python path's order
-    if (m->rng_draw) {
-        if (dropping)
-            MV_TRY(arvae_philox_keep_mask(enc_mask, (int64_t)d.tb * 2 * He, 1.f - m->enc_dropout, m->rng_seed, m->rng_offset[0], m->rng_step,
-                                          m->rng_dev_step, stream));
-        MV_TRY(arvae_philox_normal(eps, (int64_t)d.b * d.z, m->rng_seed, m->rng_offset[1], m->rng_step, m->rng_dev_step, stream));
-        if (dropping)
-            MV_TRY(arvae_philox_keep_mask(dec_mask, (int64_t)(d.nb + d.t) * d.b * Hd, 1.f - m->dec_dropout, m->rng_seed, m->rng_offset[2],
-                                          m->rng_step, m->rng_dev_step, stream));
+    if (m->rng_draw) {                                         // one launch (rng.hip: philox_draws)
+        int kind[3], n = 0;
+        void *out[3];
+        int64_t cnt[3];
+        float keep[3];
+        uint32_t off[3];
+        auto add = [&](int k, void *o, int64_t c, float kp, uint32_t of) { kind[n] = k; out[n] = o; cnt[n] = c; keep[n] = kp; off[n] = of; ++n; };
+        if (dropping) add(1, enc_mask, (int64_t)d.tb * 2 * He, 1.f - m->enc_dropout, m->rng_offset[0]);
+        add(0, eps, (int64_t)d.b * d.z, 1.f, m->rng_offset[1]);
+        if (dropping) add(1, dec_mask, (int64_t)(d.nb + d.t) * d.b * Hd, 1.f - m->dec_dropout, m->rng_offset[2]);
+        MV_TRY(philox_draws(n, kind, out, cnt, keep, off, m->rng_seed, m->rng_step, m->rng_dev_step, s));
     }
     const float enc_keep = dropping ? 1.f / (1.f - m->enc_dropout) : 1.f, dec_keep = dropping ? 1.f / (1.f - m->dec_dropout) : 1.f;
     const uint8_t *beat_mask = dec_mask, *tick_mask = dropping ? dec_mask + (int64_t)d.nb * d.b * Hd : nullptr;
@@ -433,10 +442,7 @@ extern "C" int arvae_measure_vae_forward(const arvae_measure_vae_t *m, int32_t b
     // layer 0's input projection by lookup: W_ih0 applied once to the vocabulary's embeddings, x_0 and the beat embeddings
     MV_TRY(arvae_tick_rows_fwd(P + m->dec_table, P + m->x0, beat_emb, both_ld, d.v, d.e, Hd, d.rb, w.xs, stream));
     MV_TRY(lin_fwd(d.ns, d.e + Hd, 3 * Hd, w.xs, P + m->tick_w_ih[0], nullptr, ARVAE_ACT_NONE, w.gsm, s));
-    if (teacher_forced) {
-        MV_TRY((int)hipMemcpyAsync(tokens, score, sizeof(int64_t) * d.b * d.t, hipMemcpyDeviceToDevice, s) == 0 ? ARVAE_OK
-                   : fail(ARVAE_E_LAUNCH, "measure_vae_forward: token copy failed"));
-    } else {
+    if (!teacher_forced) {
         // argmax feedback (not differentiated, decoder.py:506-516): the same small product holds the note table's and the beat
         // embeddings' projections the free-running launch reads
         ARVAE_REQUIRE(arvae_tick_free_run_supported(Hd, d.v), "measure_vae_forward: free-running decoder not built for hidden %d / %d notes",
@@ -449,7 +455,13 @@ extern "C" int arvae_measure_vae_forward(const arvae_measure_vae_t *m, int32_t b
                                 P + m->tick_w_hh[1], P + m->tick_b_hh[1], P + m->out_w, P + m->out_b};
         MV_TRY(arvae_tick_free_run(&tw, h0t0, h0t1, both_ld, w.gib, w.gsm, tick_mask, dec_keep, d.b, d.nb, d.tpb, Hd, d.v, tokens, w.frws, stream));
     }
-    MV_TRY(arvae_tick_gi_fwd(w.gsm, tokens, P + m->tick_b_ih[0], d.b, d.nb, d.tpb, d.v, 3 * Hd, w.gi0t, stream));
+    // (teacher forcing: the notes fed back are the score's; their copy into `tokens` rides in the lookup launch)
+    if (teacher_forced) {
+        ARVAE_REQUIRE(tokens != score, "measure_vae_forward: tokens must not alias the score");
+        MV_TRY(tick_gi_fwd_copy(w.gsm, score, P + m->tick_b_ih[0], d.b, d.nb, d.tpb, d.v, 3 * Hd, w.gi0t, tokens, s));
+    } else {
+        MV_TRY(arvae_tick_gi_fwd(w.gsm, tokens, P + m->tick_b_ih[0], d.b, d.nb, d.tpb, d.v, 3 * Hd, w.gi0t, stream));
+    }
     g = arvae_gru_seq_t{};
     g.gi = w.gi0t; g.gi_tstride = (int64_t)d.rb * 3 * Hd;
     g.w_hh = P + m->tick_w_hh[0]; g.b_hh = P + m->tick_b_hh[0]; g.h0 = h0t0; g.h0_stride = both_ld;

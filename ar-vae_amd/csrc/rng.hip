@@ -1,3 +1,4 @@
+#include <algorithm>
 // Standalone draws of the Philox generator (rng.h): reparameterisation noise and dropout keep-masks as ONE library launch
 // each, for the callers that do not generate them inside a consuming kernel (heads.hip does for the conv VAEs' eps).
 #include "rng.h"
@@ -28,6 +29,79 @@ __global__ __launch_bounds__(256) void philox_keep_mask_kernel(uint8_t *__restri
             for (int64_t e = 16 * b; e < count; ++e) out[e] = (uint8_t)((m[(e - 16 * b) >> 2] >> (8 * ((e - 16 * b) & 3))) & 0xffu);
         }
     }
+}
+
+// several draws of a step as ONE launch (the MeasureVAE executor's encoder keep-mask, eps and decoder keep-masks were three ~5 us
+// launches in a row): blockIdx.x walks the jobs' block ranges; a draw is a pure function of (stream, element index), so the values
+// are those of the separate launches
+constexpr int RNG_BATCH_MAX = 4;
+struct RngBatch {
+    int count;
+    int first_block[RNG_BATCH_MAX + 1];
+    int kind[RNG_BATCH_MAX];            // 0: standard normals (float), 1: keep-mask bytes
+    void *out[RNG_BATCH_MAX];
+    int64_t n[RNG_BATCH_MAX];
+    uint32_t threshold[RNG_BATCH_MAX];
+    RngStream stream[RNG_BATCH_MAX];
+};
+__global__ __launch_bounds__(256) void philox_batch_kernel(RngBatch b) {
+    int j = 0;
+    while (j + 1 < b.count && (int)blockIdx.x >= b.first_block[j + 1]) ++j;
+    const int64_t blk = (int)blockIdx.x - b.first_block[j], nblk = b.first_block[j + 1] - b.first_block[j];
+    const RngStream s = b.stream[j];
+    const int64_t count = b.n[j];
+    if (b.kind[j] == 0) {
+        float *out = static_cast<float *>(b.out[j]);
+        for (int64_t i = blk * 256 + threadIdx.x; i < count; i += nblk * 256) out[i] = rng_normal(s, (uint64_t)i);
+        return;
+    }
+    uint8_t *out = static_cast<uint8_t *>(b.out[j]);
+    const uint32_t threshold = b.threshold[j];
+    const int64_t blocks = (count + 15) / 16;
+    for (int64_t q = blk * 256 + threadIdx.x; q < blocks; q += nblk * 256) {
+        const uint4 r = rng_block(s, (uint64_t)q);
+        const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+        uint32_t m[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            m[k] = 0;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) m[k] |= (((w[k] >> (8 * jj)) & 0xffu) < threshold ? 1u : 0u) << (8 * jj);
+        }
+        if (16 * q + 16 <= count) {
+            *reinterpret_cast<uint4 *>(out + 16 * q) = make_uint4(m[0], m[1], m[2], m[3]);
+        } else {
+            for (int64_t e = 16 * q; e < count; ++e) out[e] = (uint8_t)((m[(e - 16 * q) >> 2] >> (8 * ((e - 16 * q) & 3))) & 0xffu);
+        }
+    }
+}
+
+// kinds / outs / counts / keep probabilities (masks) / call offsets of up to RNG_BATCH_MAX draws that share seed, step and device step
+int philox_draws(int n_draws, const int *kind, void *const *out, const int64_t *count, const float *keep_prob, const uint32_t *offset,
+                 uint64_t seed, uint32_t step, const uint32_t *dev_step, hipStream_t s) {
+    ARVAE_REQUIRE(n_draws >= 1 && n_draws <= RNG_BATCH_MAX, "philox_draws: 1..%d draws per launch", RNG_BATCH_MAX);
+    RngBatch b{};
+    b.count = n_draws;
+    int total = 0;
+    for (int j = 0; j < n_draws; ++j) {
+        ARVAE_REQUIRE(out[j] != nullptr && count[j] > 0, "philox_draws: bad argument");
+        int64_t blocks;
+        if (kind[j] == 0) {
+            blocks = std::min<int64_t>((count[j] + 255) / 256, 2048);
+        } else {
+            ARVAE_REQUIRE(keep_prob[j] > 0.f && keep_prob[j] <= 1.f, "philox_draws: keep probability %f outside (0, 1]", keep_prob[j]);
+            ARVAE_REQUIRE((reinterpret_cast<uintptr_t>(out[j]) & 15) == 0, "philox_draws: mask output must be 16-byte aligned");
+            b.threshold[j] = (uint32_t)(keep_prob[j] * 256.0f + 0.5f);
+            blocks = std::min<int64_t>(((count[j] + 15) / 16 + 255) / 256, 4096);
+        }
+        b.first_block[j] = total;
+        total += (int)blocks;
+        b.kind[j] = kind[j]; b.out[j] = out[j]; b.n[j] = count[j];
+        b.stream[j] = RngStream{seed, offset[j], dev_step, step};
+    }
+    b.first_block[n_draws] = total;
+    ARVAE_LAUNCH(philox_batch_kernel, dim3((unsigned)total), dim3(256), 0, s, b);
+    return check_launch("philox_batch_kernel");
 }
 
 }  // namespace arvae

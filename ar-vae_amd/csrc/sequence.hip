@@ -256,13 +256,15 @@ __global__ __launch_bounds__(256) void tick_rows_bwd_kernel(const float *__restr
 // gi[(j*beats + beat)*batch + b] = G[prev(b, tpb*beat + j)] + G[vocab + 1 + beat*batch + b] + bias: a wave per output row
 __global__ __launch_bounds__(256) void tick_gi_fwd_kernel(const float4 *__restrict__ gs, const int64_t *__restrict__ tokens,
                                                            const float4 *__restrict__ bias, int batch, int beats, int tpb, int vocab,
-                                                           int cols4, float4 *__restrict__ gi) {
+                                                           int cols4, float4 *__restrict__ gi, int64_t *__restrict__ copy_to) {
     const int lane = threadIdx.x & 63, steps = beats * tpb, rows_b = beats * batch;
     const int64_t rows = (int64_t)tpb * rows_b, nw = (int64_t)gridDim.x * 4;
     for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += nw) {
         const int j = (int)(row / rows_b), rem = (int)(row - (int64_t)j * rows_b), beat = rem / batch, b = rem - beat * batch;
         const int t = tpb * beat + j;
         int64_t v = t == 0 ? vocab : tokens[(int64_t)b * steps + t - 1];
+        // (teacher forcing in the whole-model executor: the notes fed back ARE the score; its copy rides here, one element per row)
+        if (copy_to != nullptr && lane == 0) copy_to[(int64_t)b * steps + t] = tokens[(int64_t)b * steps + t];
         v = v < 0 ? 0 : (v > vocab ? vocab : v);
         if (t != 0 && v == vocab) v = vocab - 1;
         const float4 *pn = gs + v * cols4, *pb = gs + (int64_t)(vocab + 1 + rem) * cols4;
@@ -475,15 +477,24 @@ extern "C" int arvae_tick_rows_bwd(const float *dx_small, int32_t vocab, int32_t
     return check_launch("tick_rows_bwd_kernel");
 }
 
-extern "C" int arvae_tick_gi_fwd(const float *g_small, const int64_t *tokens, const float *bias, int32_t batch, int32_t beats,
-                                 int32_t ticks_per_beat, int32_t vocab, int32_t cols, float *gi, arvae_stream_t stream) {
+// arvae_tick_gi_fwd with the tokens also copied to `copy_to` (may be null; must not alias `tokens`)
+namespace arvae {
+int tick_gi_fwd_copy(const float *g_small, const int64_t *tokens, const float *bias, int32_t batch, int32_t beats, int32_t ticks_per_beat,
+                     int32_t vocab, int32_t cols, float *gi, int64_t *copy_to, hipStream_t s) {
     ARVAE_REQUIRE(g_small && tokens && gi && batch > 0 && beats > 0 && ticks_per_beat > 0 && vocab > 0 && cols > 0 && cols % 4 == 0,
                   "tick_gi_fwd: bad argument (cols must be a multiple of 4)");
+    ARVAE_REQUIRE(copy_to != tokens, "tick_gi_fwd: the token copy must not alias its source");
     const int64_t rows = (int64_t)ticks_per_beat * beats * batch;
-    ARVAE_LAUNCH(tick_gi_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream),
+    ARVAE_LAUNCH(tick_gi_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s,
                  reinterpret_cast<const float4 *>(g_small), tokens, reinterpret_cast<const float4 *>(bias), batch, beats, ticks_per_beat,
-                 vocab, cols / 4, reinterpret_cast<float4 *>(gi));
+                 vocab, cols / 4, reinterpret_cast<float4 *>(gi), copy_to);
     return check_launch("tick_gi_fwd_kernel");
+}
+}  // namespace arvae
+
+extern "C" int arvae_tick_gi_fwd(const float *g_small, const int64_t *tokens, const float *bias, int32_t batch, int32_t beats,
+                                 int32_t ticks_per_beat, int32_t vocab, int32_t cols, float *gi, arvae_stream_t stream) {
+    return arvae::tick_gi_fwd_copy(g_small, tokens, bias, batch, beats, ticks_per_beat, vocab, cols, gi, nullptr, as_stream(stream));
 }
 
 extern "C" int64_t arvae_tick_gi_bwd_ws_floats(int32_t vocab, int32_t cols) { return (int64_t)EMBED_WSPLIT * (vocab + 1) * cols; }
