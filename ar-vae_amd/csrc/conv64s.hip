@@ -167,29 +167,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // from this XCD's L2 the second time
     const int per_wg = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x, t_first = blockIdx.x * per_wg;
     const int t_end = min(n_tiles, t_first + per_wg);
-    const int src_rows = g.rows + 3, src_pix = src_rows * g.sw;
+    const int src_rows = g.rows + 3;
     const AmaxLoad al = amax_issue(g.amax_in);
     float sc_in = 1.f;                                           // the source's scale (set behind the first tile's loads)
 
     // ---- loader: slot s of this thread = (staged pixel, channels 4 q4 .. + 3) -------------------------------------------
     float4 lv[S_SLOTS], ly[S_SLOTS];
     unsigned lm[S_SLOTS];
-    // slot s: staged pixel pix0 + 16 s.  q4 / pix0 / wlane are laundered through an empty asm at the top of every tile: the
-    // addresses derived from them are loop invariant, LLVM hoists all ~100 of them out of the tile loop and the kernel,
-    // whose register file is full by design, spills; recomputing them per tile is a few hundred cheap instructions
+    // slot s: staged pixel pix0 + 16 s.  A tile's source rows are ONE contiguous run of pixels in memory, so the slot's address is
+    // the tile's first source row (a scalar offset, + 4096 s) + this thread's (pix0, q4) (one per-lane offset for all slots), and a
+    // staged pixel is inside the image when its number lies in [lo_pix, lo_pix + span): raw buffer loads, the per-lane offset
+    // sent beyond the range for the others (they read as zero).  No division, no 64-bit address per slot, no load under a lane
+    // test -- the generic-pointer form cost ~20 vector instructions per slot (two quarter-rate multiplies among them) and an
+    // exec-mask branch, eleven times per tile.  The resource starts pad_b bytes BEFORE the tensor: a first tile's scalar offset
+    // (source rows above the image) stays non-negative, and nothing is read there.
     int q4 = threadIdx.x & 15, pix0 = threadIdx.x >> 4, wlane = lane;
-    const int inv_sw = 65536 / g.sw + 1;
+    const int pad_b = (g.dmin < 0 ? -g.dmin : 0) * g.sw * 256;
+    const int64_t src_bytes = (int64_t)g.n * g.sh * g.sw * 256 + pad_b;
+    const __amdgpu_buffer_rsrc_t rs_v = make_rsrc(reinterpret_cast<const char *>(g.src.v) - pad_b, src_bytes);
+    const __amdgpu_buffer_rsrc_t rs_y = make_rsrc(MODE >= 1 ? reinterpret_cast<const char *>(g.src.y) - pad_b : reinterpret_cast<const char *>(g.src.v), MODE >= 1 ? src_bytes : 0);
+    const __amdgpu_buffer_rsrc_t rs_m = make_rsrc(MODE == 2 ? reinterpret_cast<const char *>(g.src.mask) - pad_b / 4 : reinterpret_cast<const char *>(g.src.v), MODE == 2 ? src_bytes / 4 : 0);
+    constexpr unsigned OOBV = 0xfffffff0u;
+    struct TileSrc { int soff, lo, span; };                      // scalar byte offset of the tile's first source row; valid staged pixels
+    auto tile_src = [&](int tile) __attribute__((always_inline)) {
+        const int img = tile / g.groups, oy0 = (tile - img * g.groups) * g.rows, sy0 = oy0 + g.dmin;
+        const int lo = max(0, -sy0) * g.sw, hi = tile < t_end ? min(src_rows, g.sh - sy0) * g.sw : 0;
+        return TileSrc{((img * g.sh + sy0) * g.sw) * 256 + pad_b, lo, hi > lo ? hi - lo : 0};
+    };
+    auto slot_offset = [&](int s, const TileSrc &ts) __attribute__((always_inline)) {
+        return (unsigned)(pix0 + 16 * s - ts.lo) < (unsigned)ts.span ? (unsigned)(pix0 * 256 + q4 * 16) : OOBV;
+    };
+    auto slot_load = [&](int s, unsigned off, const TileSrc &ts) __attribute__((always_inline)) {
+        const f32x4v v = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_v, (int)off, ts.soff + 4096 * s, 0));
+        lv[s] = make_float4(v.x, v.y, v.z, v.w);
+        if (MODE >= 1) {
+            const f32x4v y = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs_y, (int)off, ts.soff + 4096 * s, 0));
+            ly[s] = make_float4(y.x, y.y, y.z, y.w);
+        }
+        if (MODE == 2) lm[s] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs_m, (int)(off == OOBV ? OOBV : off >> 2), (ts.soff + 4096 * s) >> 2, 0);
+    };
     auto issue = [&](int s, int tile) __attribute__((always_inline)) {
-        const int img = tile / g.groups, oy0 = (tile - img * g.groups) * g.rows;
-        const int l_pix = pix0 + 16 * s, l_row = (l_pix * inv_sw) >> 16;     // l_pix / sw for l_pix < 256, sw <= 64 (recomputed per tile:
-                                                                             // registers are what this kernel lacks)
-        const int sy = oy0 + g.dmin + l_row, sx = l_pix - l_row * g.sw;
-        const bool ok = tile < t_end && l_pix < src_pix && (unsigned)sy < (unsigned)g.sh;
-        const int64_t at = ok ? (((int64_t)img * g.sh + sy) * g.sw + sx) * 64 + 4 * q4 : 0;
-        float4 v = *reinterpret_cast<const float4 *>(g.src.v + at);
-        if (MODE >= 1) ly[s] = *reinterpret_cast<const float4 *>(g.src.y + at);
-        if (MODE == 2) lm[s] = *reinterpret_cast<const unsigned *>(g.src.mask + at);
-        lv[s] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        const TileSrc ts = tile_src(tile);
+        slot_load(s, slot_offset(s, ts), ts);
     };
     auto commit = [&](int s, unsigned *buf) __attribute__((always_inline)) {
         float4 v = lv[s];
@@ -258,13 +277,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // weight operands: a ring of three register sets, two reduction steps ahead of the MFMAs (the split weights live in L2: one
     // step is not enough to cover that round trip under load)
     f16x8 w2[W_AHEAD + 1][NT][2];
+    // (one resource, the lane's 16 bytes as the per-lane offset, the (tap, chunk) block as the scalar offset, the row tile / term as
+    // the instruction's immediate: no vector instruction per weight request)
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(g.wprep, (int64_t)(16 * 4 * S_WSTEP + 1) * 16);
     auto load_w = [&](auto rc_, int kx, int c16) __attribute__((always_inline)) {
         constexpr int r = decltype(rc_)::value;
-        const uint4 *wp = g.wprep + ((ky * 4 + kx) * 4 + c16) * S_WSTEP + wlane;
+        const int so = ((ky * 4 + kx) * 4 + c16) * S_WSTEP * 16;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) w2[r][nt][t] = __builtin_bit_cast(f16x8, wp[(nt * 2 + t) * 64]);
+            for (int t = 0; t < 2; ++t)
+                w2[r][nt][t] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane * 16 + (nt * 2 + t) * 1024, so, 0));
     };
     const int kx_first = g.sgn > 0 ? 0 : 3;
     // epilogue operands and the result as buffer resources (conv64s_fits bounds the tensor at 2 GB): absent operands get an empty
@@ -336,8 +359,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // MFMAs in order.  Left to the scheduler a step was a block of MFMAs followed by a block of vector instructions.
         uint2 c_h, c_l;                                          // a slot's values between its pieces
         float4 c_v;
-        int64_t c_at = 0;
-        bool c_ok = false;
+        unsigned c_off = OOBV;
+        const TileSrc next_src = tile_src(tile + 1);
         static_for<0, 16>([&](auto kc) __attribute__((always_inline)) {
             constexpr int step = decltype(kc)::value, cu = step & 1, nx = cu ^ 1, wr = step % (W_AHEAD + 1);
             // loader slots of this step: requested in step s * 12 / 11, split + written four steps (~3 us) later
@@ -356,23 +379,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 } else if constexpr (i < n_read + n_w) {
                     constexpr int k = i - n_read, nt = k / 2, t = k % 2, njx = (step + W_AHEAD) >> 2, nc16 = (step + W_AHEAD) & 3;
                     const int nkx = g.sgn > 0 ? njx : 3 - njx;
-                    const uint4 *wp = g.wprep + ((ky * 4 + nkx) * 4 + nc16) * S_WSTEP + wlane;
-                    w2[(step + W_AHEAD) % (W_AHEAD + 1)][nt][t] = __builtin_bit_cast(f16x8, wp[(nt * 2 + t) * 64]);
+                    w2[(step + W_AHEAD) % (W_AHEAD + 1)][nt][t] = __builtin_bit_cast(
+                        f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, wlane * 16 + (nt * 2 + t) * 1024, ((ky * 4 + nkx) * 4 + nc16) * S_WSTEP * 16, 0));
                 } else if constexpr (i < n_read + n_w + n_issue) {
                     constexpr int k = i - n_read - n_w, s = is_lo + k / 2, piece = k % 2;
-                    if constexpr (piece == 0) {                  // address of slot s of the next tile
-                        const int nt_ = tile + 1;
-                        const int img = nt_ / g.groups, oy0 = (nt_ - img * g.groups) * g.rows;
-                        const int l_pix = pix0 + 16 * s, l_row = (l_pix * inv_sw) >> 16;
-                        const int sy = oy0 + g.dmin + l_row, sx = l_pix - l_row * g.sw;
-                        c_ok = nt_ < t_end && l_pix < src_pix && (unsigned)sy < (unsigned)g.sh;
-                        c_at = c_ok ? (((int64_t)img * g.sh + sy) * g.sw + sx) * 64 + 4 * q4 : 0;
-                    } else {
-                        const float4 v = *reinterpret_cast<const float4 *>(g.src.v + c_at);
-                        if (MODE >= 1) ly[s] = *reinterpret_cast<const float4 *>(g.src.y + c_at);
-                        if (MODE == 2) lm[s] = *reinterpret_cast<const unsigned *>(g.src.mask + c_at);
-                        lv[s] = c_ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
+                    if constexpr (piece == 0) c_off = slot_offset(s, next_src);     // slot s of the next tile
+                    else slot_load(s, c_off, next_src);
                 } else if constexpr (i < n_read + n_w + n_issue + n_commit) {
                     constexpr int k = i - n_read - n_w - n_issue, s = cm_lo + k / 4, piece = k % 4;
                     if constexpr (piece == 0) {                  // the value with a gradient operand's derivative / keep-mask
