@@ -38,6 +38,11 @@ struct ConvRows {
     const unsigned *w_amax;      // conv_rows_h2_kernel: bit pattern of max |wt| (written by the weight-prep launch behind the packed weights)
 };
 
+// 16 bytes through a buffer resource at per-lane offset + scalar offset (the scalar part is not range-checked)
+__device__ __forceinline__ float4 buf_load4s(__amdgpu_buffer_rsrc_t r, unsigned off, int soff) {
+    const f32x4v v = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, soff, 0));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 // value of a gradient operand (activation derivative of the saved output, keep-mask) for 4 consecutive channels
 template <bool PLAIN>
 __device__ __forceinline__ float4 load_src4(const Operand &o, int64_t at, bool ok) {
@@ -892,7 +897,28 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_pairs_h2_kernel(ConvWgrad g
     const int hi_r[2] = {(int)threadIdx.x / 8, (int)threadIdx.x / 8 + 32};
     const int hi_c = 4 * (threadIdx.x % 8);
     float4 vlo[2][2], vhi[2][2];
+    // A plain operand's rows come through raw buffer loads: the row (image, y) is a scalar byte offset -- an absent row selects the
+    // empty range --, the thread's place in the row one per-lane offset fixed for the launch (beyond the range for a slot outside
+    // the row): no 64-bit address and no lane test per load (conv64_wgrad bounds the tensors at 2 GB).
+    constexpr unsigned OOBV = 0xfffffff0u;
+    const __amdgpu_buffer_rsrc_t rs_none = make_rsrc(g.lo.v, 0);
+    const __amdgpu_buffer_rsrc_t rs_lo = make_rsrc(g.lo.v, (int64_t)g.n * g.lh * g.lw * g.clo * 4);
+    const __amdgpu_buffer_rsrc_t rs_hi = make_rsrc(g.hi.v, (int64_t)g.n * g.hh * g.hw * g.chi * 4);
+    unsigned lo_off[2], hi_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        lo_off[i] = (lo_r[i] < g.lw && lo_c < g.clo) ? (unsigned)((lo_r[i] * g.clo + lo_c) * 4) : OOBV;
+        const int hx = hi_r[i] - g.pad;
+        hi_off[i] = (hi_r[i] < WR_HROWS && hx >= 0 && hx < g.hw && ch0 + hi_c < g.chi) ? (unsigned)((hx * g.chi + ch0 + hi_c) * 4) : OOBV;
+    }
     auto fetch_lo = [&](int which, int n, int ly) __attribute__((always_inline)) {
+        if (PLAIN_LO) {
+            const __amdgpu_buffer_rsrc_t rs = ly < g.lh ? rs_lo : rs_none;
+            const int so = ((n * g.lh + ly) * g.lw * g.clo) * 4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) vlo[which][i] = buf_load4s(rs, lo_off[i], so);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const bool ok = ly < g.lh && lo_r[i] < g.lw && lo_c < g.clo;
@@ -900,6 +926,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_pairs_h2_kernel(ConvWgrad g
         }
     };
     auto fetch_hi = [&](int which, int n, int hy) __attribute__((always_inline)) {
+        if (PLAIN_HI) {
+            const bool row = hy >= 0 && hy < g.hh;
+            const __amdgpu_buffer_rsrc_t rs = row ? rs_hi : rs_none;
+            const int so = row ? ((n * g.hh + hy) * g.hw * g.chi) * 4 : 0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) vhi[which][i] = buf_load4s(rs, hi_off[i], so);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int hx = hi_r[i] - g.pad;
@@ -1074,7 +1108,9 @@ bool conv64_wgrad_fits(const arvae_link_t *l) {
     static const bool off = diag_env("ARVAE_CONV64_GENERIC") != nullptr;
     return !off && l->stride == 1 && l->kh * l->kw <= 16 && l->kh * l->kw > 1 && l->clo % 4 == 0 && l->chi % 4 == 0 &&
            l->clo >= 4 && l->chi >= 4 && l->clo <= 64 && l->chi <= 64 && (l->clo >= 32 || l->chi >= 32) &&
-           l->hi_perm_c == 0 && l->lo_perm_c == 0;
+           l->hi_perm_c == 0 && l->lo_perm_c == 0 &&
+           // (the paired-rows kernel addresses plain operands with 32-bit byte offsets)
+           (int64_t)l->n * l->lh * l->lw * l->clo * 4 < ((int64_t)1 << 31) && (int64_t)l->n * l->hh * l->hw * l->chi * 4 < ((int64_t)1 << 31);
 }
 
 int64_t conv64_wgrad_ws_floats(const arvae_link_t *l) {
