@@ -301,12 +301,21 @@ struct TileLoader {
             if (LAY == RG_ROWSK) { row = p0 + idx / (RG_R / 4); col = r0 + 4 * (idx % (RG_R / 4)); row_max = pmax; col_max = rmax; }
             else { row = r0 + idx / (TP / 4); col = p0 + 4 * (idx % (TP / 4)); row_max = rmax; col_max = pmax; }
             const bool rok = row < row_max;
-            const float *src = base + (int64_t)(rok ? row : 0) * ld;
             if (VEC) {
+                // raw buffer load: the chunk's position along the reduction axis is the SCALAR offset (r0 elements or r0 rows), the
+                // thread's place in the tile a per-lane offset that does not change from chunk to chunk (sent beyond the range
+                // for an element outside the matrix: reads as zero) -- the generic-pointer form cost a 64-bit address, two selects
+                // and a load under a lane test per 16 bytes (rows_gemm_fits_32 bounds the matrices at 2 GB)
                 const bool ok = rok && col < col_max;
-                const float4 t = *reinterpret_cast<const float4 *>(src + (ok ? col : 0));
-                v[i] = ok ? t : float4{0.f, 0.f, 0.f, 0.f};
+                const int rel_row = LAY == RG_ROWSK ? row : row - r0, rel_col = LAY == RG_ROWSK ? col - r0 : col;
+                const unsigned off = ok ? (unsigned)((rel_row * (int)ld + rel_col) * 4) : 0xfffffff0u;
+                const int so = LAY == RG_ROWSK ? r0 * 4 : r0 * (int)ld * 4;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, 0x7fffffff, 0x00020000);
+                typedef float f32x4t_ __attribute__((ext_vector_type(4)));
+                const f32x4t_ t = __builtin_bit_cast(f32x4t_, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, so, 0));
+                v[i] = float4{t.x, t.y, t.z, t.w};
             } else {
+                const float *src = base + (int64_t)(rok ? row : 0) * ld;
                 float e[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -833,7 +842,10 @@ static void launch_rows_gemm(const RowsGemm &g, int slices, hipStream_t s) {
     auto vec_ok = [&](const float *base, int64_t ld, int lay, int out_extent) {
         const int contiguous = lay == RG_ROWSK ? g.Rn : out_extent;
         const bool slice_ok = lay != RG_ROWSK || (g.rslice & 3) == 0;
-        return (ld & 3) == 0 && (contiguous & 3) == 0 && slice_ok && (reinterpret_cast<uintptr_t>(base) & 15) == 0;
+        // (and the matrix within 2 GB: the 16-byte form addresses it with 32-bit byte offsets)
+        const int64_t rows = lay == RG_ROWSK ? out_extent : g.Rn;
+        return (ld & 3) == 0 && (contiguous & 3) == 0 && slice_ok && (reinterpret_cast<uintptr_t>(base) & 15) == 0 &&
+               rows * ld * 4 < ((int64_t)1 << 31);
     };
     const bool va = vec_ok(g.a, g.lda, LA, g.P), vb = vec_ok(g.b, g.ldb, LB, g.Q);
     const dim3 grid((g.P + RG_TP - 1) / RG_TP, (g.Q + RG_TQ - 1) / RG_TQ, slices);
@@ -962,6 +974,8 @@ bool dense_wgrad_long_defer(LongWgradQueue *q, const arvae_link_t *l, const Oper
     if (off || q == nullptr || q->ws == nullptr || q->gemm.count >= RG_BATCH_MAX || !dense_long_batch(p) || !plain_operand(g)) return false;
     auto aligned = [](const float *ptr, int ld, int extent) { return (ld & 3) == 0 && (extent & 3) == 0 && (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; };
     if (!aligned(g.v, p.n_out, p.n_out) || !aligned(x, p.n_in, p.n_in)) return false;
+    // (the tile loaders address a matrix with 32-bit byte offsets)
+    if ((int64_t)p.batch * p.n_out * 4 >= ((int64_t)1 << 31) || (int64_t)p.batch * p.n_in * 4 >= ((int64_t)1 << 31)) return false;
     const int rs = long_rslice(p.batch), slices = (p.batch + rs - 1) / rs;
     const int64_t w_floats = (int64_t)p.n_out * p.n_in, slice_floats = (w_floats + p.n_out + 3) / 4 * 4;
     if (q->ws_used + slices * slice_floats > q->ws_cap) return false;
