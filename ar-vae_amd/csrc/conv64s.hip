@@ -521,7 +521,8 @@ bool conv64s_fits(const arvae_link_t *l, bool up) {
     const int oh = up ? l->hh : l->lh;
     return !off && l->stride == 1 && l->kh == 4 && l->kw == 4 && cs == 64 && (q == 64 || (q <= 32 && q >= 4 && (q & 3) == 0)) &&
            l->hi_perm_c == 0 && l->lo_perm_c == 0 && stage_geometry(ow, sw, rows, mt) &&
-           (int64_t)l->n * oh * ow * q * 4 < ((int64_t)1 << 31) - 65536;      // the result is addressed through a buffer resource
+           (int64_t)l->n * oh * ow * q * 4 < ((int64_t)1 << 31) - 65536 &&    // the result and the source are addressed through
+           (int64_t)l->n * (up ? l->lh : l->hh) * sw * 64 * 4 < ((int64_t)1 << 31) - (1 << 20);   // buffer resources (32-bit byte offsets)
 }
 
 template <int MT, int NT> static void launch_stage(const ConvStage &g, int grid, hipStream_t s) {

@@ -176,6 +176,8 @@ CONV_CASES = [  # (n, hi, chi, clo, k, s, p, act)
     (2, 28, 1, 64, 4, 1, 0, 'selu'), (2, 25, 64, 64, 4, 1, 0, 'selu'), (3, 22, 64, 8, 4, 1, 0, 'selu'),
     # more row-group tiles than CUs: the persistent loop of the row-staged kernel (conv64s.hip), both of its tile shapes
     (47, 25, 64, 64, 4, 1, 0, 'selu'), (70, 22, 64, 8, 4, 1, 0, 'none'), (3, 21, 64, 16, 4, 1, 0, 'relu'),
+    # the row-staged kernel with padding: source rows above / below the image (its tiles' scalar row offsets start before the tensor)
+    (5, 12, 64, 64, 4, 1, 1, 'relu'), (3, 9, 64, 8, 4, 1, 2, 'selu'),
     # single-channel stride-1 links with 64 channels: the per-wave streaming weight gradient (conv_c1.hip, wgrad_c1w)
     (5, 28, 1, 64, 4, 1, 0, 'none'), (90, 28, 1, 64, 4, 1, 0, 'relu'), (3, 19, 1, 64, 4, 1, 0, 'none'),
 ]
@@ -223,7 +225,7 @@ def test_conv_down_vs_torch(dev, case, use_mask):
 DECONV_CASES = [  # (n, lo, clo(in), chi(out), k, s, p, act)
     (4, 4, 32, 32, 4, 2, 1, 'relu'), (3, 16, 32, 32, 4, 2, 1, 'relu'), (2, 32, 32, 1, 4, 2, 1, 'none'),
     (2, 19, 8, 64, 4, 1, 0, 'selu'), (2, 22, 64, 64, 4, 1, 0, 'selu'), (3, 25, 64, 1, 4, 1, 0, 'none'),
-    (55, 22, 64, 64, 4, 1, 0, 'selu'), (3, 17, 64, 12, 4, 1, 0, 'relu'),
+    (55, 22, 64, 64, 4, 1, 0, 'selu'), (3, 17, 64, 12, 4, 1, 0, 'relu'), (5, 11, 64, 64, 4, 1, 1, 'selu'), (2, 10, 64, 8, 4, 1, 2, 'none'),
     (4, 25, 64, 1, 4, 1, 0, 'none'), (85, 25, 64, 1, 4, 1, 0, 'none'), (2, 14, 64, 1, 4, 1, 0, 'relu'),
 ]
 
