@@ -9,6 +9,7 @@
 // measurevae/measure_vae_trainer.py:85-140 (loss), utils/trainer.py:140 (backward).
 #include "diag.h"
 #include "common.h"
+#include <mutex>
 #include "dense.h"
 #include "regloss.h"
 
@@ -110,6 +111,125 @@ __global__ __launch_bounds__(256) void measure_latent_bwd_kernel(const float *__
         d_ls[i] = (gz * eps[i] + k * (s - 1.f / s)) * s;
     }
 }
+
+// ---- the latent head's second layers + the reparameterised sample as ONE launch (forward), and their data gradients (backward).
+// The two heads' first layers are one product h12 = [hmu | hls] (rows of 2 * hw floats); per row
+//     mu = W_mu hmu + b_mu,   log_std = W_ls hls + b_ls,   sigma = exp(log_std),   z = mu + eps * sigma      (measure_vae.py:100-123)
+// were a column split, two 5 us Linear launches and the sample; backward, the (d mu, d log_std) kernel, two data-gradient launches
+// and a column concatenation.  MH_ROWS rows per workgroup, the 2 zdim weight rows in LDS (forward) or a thread's two weight
+// columns in registers (backward); exact fp32 FMA chains.
+constexpr int MH_ROWS = 4, MH_ZMAX = 32;
+struct MeasureHeadsFwd {
+    const float *h12, *w_mu, *b_mu, *w_ls, *b_ls, *eps;
+    float *hmu, *hls, *mu, *log_std, *sigma, *z;      // hmu / hls: the halves of h12 as the weight gradients read them
+    int batch, hw, zdim;                               // hw = width of one head's hidden vector (a multiple of 4)
+};
+__global__ __launch_bounds__(256) void measure_heads_fwd_kernel(MeasureHeadsFwd p) {
+    extern __shared__ __attribute__((aligned(16))) float mh_lds[];
+    const int ld = 2 * p.hw, ws = p.hw + 4, h4 = p.hw >> 2;
+    float *hs = mh_lds, *wl = hs + MH_ROWS * ld, *outs = wl + 2 * p.zdim * ws;       // rows | 2 zdim weight rows | products
+    const int row0 = blockIdx.x * MH_ROWS;
+    for (int i = threadIdx.x; i < MH_ROWS * 2 * h4; i += 256) {
+        const int r = i / (2 * h4), c4 = i - r * 2 * h4, row = row0 + r;
+        const int rr = row < p.batch ? row : p.batch - 1;                               // clamped: unconditional load
+        const float4 v = reinterpret_cast<const float4 *>(p.h12 + (int64_t)rr * ld)[c4];
+        reinterpret_cast<float4 *>(hs + r * ld)[c4] = v;
+        if (row < p.batch) {
+            float *dst = c4 < h4 ? p.hmu + (int64_t)row * p.hw + 4 * c4 : p.hls + (int64_t)row * p.hw + 4 * (c4 - h4);
+            *reinterpret_cast<float4 *>(dst) = v;
+        }
+    }
+    for (int i = threadIdx.x; i < 2 * p.zdim * h4; i += 256) {
+        const int j = i / h4, k = i - j * h4;
+        const float *src = j < p.zdim ? p.w_mu + (int64_t)j * p.hw : p.w_ls + (int64_t)(j - p.zdim) * p.hw;
+        reinterpret_cast<float4 *>(wl + j * ws)[k] = reinterpret_cast<const float4 *>(src)[k];
+    }
+    const int r = threadIdx.x >> 6, j = threadIdx.x & 63, row = row0 + r;
+    const bool col_ok = j < 2 * p.zdim, lat = j < p.zdim && row < p.batch;
+    const int64_t idx = lat ? (int64_t)row * p.zdim + j : 0;
+    const float e = p.eps[idx];
+    const int jc = col_ok ? j : 0;
+    const float *bp = jc < p.zdim ? p.b_mu : p.b_ls;
+    const float bias = bp != nullptr ? bp[jc < p.zdim ? jc : jc - p.zdim] : 0.f;
+    __syncthreads();
+    {
+        const float4 *w = reinterpret_cast<const float4 *>(wl + jc * ws);
+        const float4 *x = reinterpret_cast<const float4 *>(hs + r * ld + (jc < p.zdim ? 0 : p.hw));
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+        for (int k = 0; k < h4; ++k) {
+            const float4 a = x[k], b = w[k];
+            acc.x = fmaf(a.x, b.x, acc.x); acc.y = fmaf(a.y, b.y, acc.y);
+            acc.z = fmaf(a.z, b.z, acc.z); acc.w = fmaf(a.w, b.w, acc.w);
+        }
+        outs[r * 64 + j] = (acc.x + acc.y) + (acc.z + acc.w) + bias;
+    }
+    __syncthreads();
+    if (lat) {
+        const float m = outs[r * 64 + j], l = outs[r * 64 + j + p.zdim];
+        const float sg = expf(l);
+        p.mu[idx] = m;
+        p.log_std[idx] = l;
+        p.sigma[idx] = sg;
+        p.z[idx] = fmaf(e, sg, m);
+    }
+}
+
+struct MeasureHeadsBwd {
+    const float *g_z, *dz_reg, *mu, *sigma, *eps, *g_loss, *kl, *cap, *w_mu, *w_ls;
+    float beta, inv_batch, reg_scale;
+    float *d_mu, *d_ls, *d_h12;                        // d_h12 rows: [d hmu | d hls]
+    int batch, hw, zdim;
+};
+// thread = one column of each head's hidden vector (hw <= 256 columns): its two weight columns in registers, the rows'
+// (d mu, d log_std) through LDS
+__global__ __launch_bounds__(256) void measure_heads_bwd_kernel(MeasureHeadsBwd p) {
+    __shared__ float dm[MH_ROWS][MH_ZMAX], dl[MH_ROWS][MH_ZMAX];
+    const int row0 = blockIdx.x * MH_ROWS, k = threadIdx.x;
+    const bool kok = k < p.hw;
+    float wm[MH_ZMAX], wls[MH_ZMAX];
+#pragma unroll
+    for (int j = 0; j < MH_ZMAX; ++j) {
+        const bool ok = kok && j < p.zdim;
+        wm[j] = ok ? p.w_mu[(int64_t)j * p.hw + k] : 0.f;
+        wls[j] = ok ? p.w_ls[(int64_t)j * p.hw + k] : 0.f;
+    }
+    if (threadIdx.x < MH_ROWS * MH_ZMAX) {
+        const int r = threadIdx.x / MH_ZMAX, j = threadIdx.x % MH_ZMAX, row = row0 + r;
+        float a = 0.f, b = 0.f;
+        if (row < p.batch && j < p.zdim) {
+            const int64_t i = (int64_t)row * p.zdim + j;
+            const float g = p.g_loss[0];
+            const float diff = p.kl[0] - (p.cap != nullptr ? p.cap[0] : 0.f);
+            const float kk = g * p.beta * (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f)) * p.inv_batch;
+            float gz = p.g_z[i];
+            if (p.dz_reg != nullptr) gz += g * p.reg_scale * p.dz_reg[i];
+            const float sg = p.sigma[i];
+            a = gz + kk * p.mu[i];
+            b = (gz * p.eps[i] + kk * (sg - 1.f / sg)) * sg;
+            p.d_mu[i] = a;
+            p.d_ls[i] = b;
+        }
+        dm[r][j] = a;
+        dl[r][j] = b;
+    }
+    __syncthreads();
+    if (!kok) return;
+#pragma unroll
+    for (int r = 0; r < MH_ROWS; ++r) {
+        if (row0 + r >= p.batch) break;
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int j = 0; j < MH_ZMAX; ++j) {
+            a = fmaf(dm[r][j], wm[j], a);
+            b = fmaf(dl[r][j], wls[j], b);
+        }
+        float *dst = p.d_h12 + (int64_t)(row0 + r) * 2 * p.hw;
+        dst[k] = a;
+        dst[p.hw + k] = b;
+    }
+}
+static bool measure_heads_fit(int hw, int zdim) { return hw >= 4 && hw <= 256 && (hw & 3) == 0 && zdim >= 1 && zdim <= MH_ZMAX; }
 
 static inline unsigned blocks_for(int64_t items, int cap = 2048) {
     const int64_t b = (items + 255) / 256;
@@ -408,10 +528,20 @@ extern "C" int arvae_measure_vae_forward(const arvae_measure_vae_t *m, int32_t b
     }
     // the two heads' first layers as one product, then mu / log_std and the reparameterised sample
     MV_TRY(lin_fwd(d.b, 4 * He, 4 * He, w.hidden, P + m->head_w0, P + m->head_b0, ARVAE_ACT_SELU, w.h12, s));
-    MV_TRY(arvae_split_cols(w.h12, d.b, 2 * He, 2 * He, w.hmu, w.hls, 0, stream));
-    MV_TRY(lin_fwd(d.b, 2 * He, d.z, w.hmu, P + m->mean_w2, P + m->mean_b2, ARVAE_ACT_NONE, mu, s));
-    MV_TRY(lin_fwd(d.b, 2 * He, d.z, w.hls, P + m->lstd_w2, P + m->lstd_b2, ARVAE_ACT_NONE, w.log_std, s));
-    MV_TRY(arvae_latent_fwd(mu, w.log_std, eps, (int64_t)d.b * d.z, sigma, z, stream));
+    if (measure_heads_fit(2 * He, d.z)) {                    // one launch (measure_heads_fwd_kernel)
+        MeasureHeadsFwd hf{w.h12, P + m->mean_w2, P + m->mean_b2, P + m->lstd_w2, P + m->lstd_b2, eps, w.hmu, w.hls, mu, w.log_std, sigma, z,
+                           d.b, 2 * He, d.z};
+        const int lds = (MH_ROWS * 4 * He + 2 * d.z * (2 * He + 4) + MH_ROWS * 64) * 4;
+        static std::once_flag attr;
+        std::call_once(attr, [] { (void)hipFuncSetAttribute((const void *)measure_heads_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); });
+        ARVAE_LAUNCH(measure_heads_fwd_kernel, dim3((d.b + MH_ROWS - 1) / MH_ROWS), dim3(256), lds, s, hf);
+        MV_TRY(check_launch("measure_heads_fwd_kernel"));
+    } else {
+        MV_TRY(arvae_split_cols(w.h12, d.b, 2 * He, 2 * He, w.hmu, w.hls, 0, stream));
+        MV_TRY(lin_fwd(d.b, 2 * He, d.z, w.hmu, P + m->mean_w2, P + m->mean_b2, ARVAE_ACT_NONE, mu, s));
+        MV_TRY(lin_fwd(d.b, 2 * He, d.z, w.hls, P + m->lstd_w2, P + m->lstd_b2, ARVAE_ACT_NONE, w.log_std, s));
+        MV_TRY(arvae_latent_fwd(mu, w.log_std, eps, (int64_t)d.b * d.z, sigma, z, stream));
+    }
 
     // ---- beat RNN (decoder.py:436-457): the same input b_0 at every beat
     MV_TRY(lin_fwd(d.b, d.z, 2 * Hd, z, P + m->z2beat_w, P + m->z2beat_b, ARVAE_ACT_SELU, w.flatb, s));
@@ -628,14 +758,22 @@ extern "C" int arvae_measure_vae_backward(const arvae_measure_vae_t *m, int32_t 
     MV_TRY(lin_wgrad(&queue, d.b, d.z, 2 * Hd, gated(w.d_flatb, w.flatb, ARVAE_ACT_SELU), z, G + m->z2beat_w, G + m->z2beat_b, s));
 
     // ---- latent head: decoder path + regulariser + beta-KL -> (d mu, d log_std), then the heads' two layers
-    ARVAE_LAUNCH(measure_latent_bwd_kernel, dim3(blocks_for((int64_t)d.b * d.z)), dim3(256), 0, s, w.d_z, m->n_reg > 0 ? w.dz_reg : nullptr, mu,
-                 sigma, eps, g_loss, scalars + ARVAE_VAE_KL, capacity, m->beta, 1.f / (float)d.b, reg_scale, (int64_t)d.b * d.z, w.d_mu, w.d_ls);
-    MV_TRY(check_launch("measure_latent_bwd_kernel"));
-    MV_TRY(lin_dgrad(d.b, 2 * He, d.z, plain(w.d_mu), P + m->mean_w2, w.d_hmu, s));
-    MV_TRY(lin_dgrad(d.b, 2 * He, d.z, plain(w.d_ls), P + m->lstd_w2, w.d_hls, s));
+    const bool heads_fused = measure_heads_fit(2 * He, d.z);
+    if (heads_fused) {                                        // (d mu, d log_std) and both heads' data gradients: one launch
+        MeasureHeadsBwd hb{w.d_z, m->n_reg > 0 ? w.dz_reg : nullptr, mu, sigma, eps, g_loss, scalars + ARVAE_VAE_KL, capacity,
+                           P + m->mean_w2, P + m->lstd_w2, m->beta, 1.f / (float)d.b, reg_scale, w.d_mu, w.d_ls, w.d_h12, d.b, 2 * He, d.z};
+        ARVAE_LAUNCH(measure_heads_bwd_kernel, dim3((d.b + MH_ROWS - 1) / MH_ROWS), dim3(256), 0, s, hb);
+        MV_TRY(check_launch("measure_heads_bwd_kernel"));
+    } else {
+        ARVAE_LAUNCH(measure_latent_bwd_kernel, dim3(blocks_for((int64_t)d.b * d.z)), dim3(256), 0, s, w.d_z, m->n_reg > 0 ? w.dz_reg : nullptr, mu,
+                     sigma, eps, g_loss, scalars + ARVAE_VAE_KL, capacity, m->beta, 1.f / (float)d.b, reg_scale, (int64_t)d.b * d.z, w.d_mu, w.d_ls);
+        MV_TRY(check_launch("measure_latent_bwd_kernel"));
+        MV_TRY(lin_dgrad(d.b, 2 * He, d.z, plain(w.d_mu), P + m->mean_w2, w.d_hmu, s));
+        MV_TRY(lin_dgrad(d.b, 2 * He, d.z, plain(w.d_ls), P + m->lstd_w2, w.d_hls, s));
+    }
     MV_TRY(lin_wgrad(&queue, d.b, 2 * He, d.z, plain(w.d_mu), w.hmu, G + m->mean_w2, G + m->mean_b2, s));
     MV_TRY(lin_wgrad(&queue, d.b, 2 * He, d.z, plain(w.d_ls), w.hls, G + m->lstd_w2, G + m->lstd_b2, s));
-    MV_TRY(arvae_concat_cols(w.d_hmu, w.d_hls, d.b, 2 * He, 2 * He, w.d_h12, stream));
+    if (!heads_fused) MV_TRY(arvae_concat_cols(w.d_hmu, w.d_hls, d.b, 2 * He, 2 * He, w.d_h12, stream));
     MV_TRY(lin_dgrad(d.b, 4 * He, 4 * He, gated(w.d_h12, w.h12, ARVAE_ACT_SELU), P + m->head_w0, w.d_hidden, s));
     MV_TRY(lin_wgrad(&queue, d.b, 4 * He, 4 * He, gated(w.d_h12, w.h12, ARVAE_ACT_SELU), w.hidden, G + m->head_w0, G + m->head_b0, s));
 
