@@ -231,6 +231,35 @@ __global__ __launch_bounds__(256) void measure_heads_bwd_kernel(MeasureHeadsBwd 
 }
 static bool measure_heads_fit(int hw, int zdim) { return hw >= 4 && hw <= 256 && (hw & 3) == 0 && zdim >= 1 && zdim <= MH_ZMAX; }
 
+// the beat RNN's constant input b_0 (decoder.py:436-440): its copies x0b[rows] (what the weight gradient reads) and its projection
+// gi[b][c] = b_0 * w[c] + bias[c], the same row for every measure -- one launch instead of a broadcast and a 1-wide Linear layer
+__global__ __launch_bounds__(256) void beat_input_kernel(const float *__restrict__ b0, const float *__restrict__ w, const float *__restrict__ bias,
+                                                          int batch, int cols, int rows, float *__restrict__ x0b, float *__restrict__ gi) {
+    const float v = b0[0];
+    const int64_t n_gi = (int64_t)batch * cols, total = n_gi + rows;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        if (i < n_gi) {
+            const int c = (int)(i % cols);
+            gi[i] = fmaf(v, w[c], bias[c]);
+        } else {
+            x0b[i - n_gi] = v;
+        }
+    }
+}
+// dst[0] += sum of x[0 .. n): one workgroup, fixed order (the gradient of b_0 from its per-row gradients)
+__global__ __launch_bounds__(256) void sum_into_kernel(const float *__restrict__ x, int n, float *__restrict__ dst) {
+    __shared__ float red[256];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) a += x[i];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) dst[0] += red[0];
+}
+
 static inline unsigned blocks_for(int64_t items, int cap = 2048) {
     const int64_t b = (items + 255) / 256;
     return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -545,8 +574,9 @@ extern "C" int arvae_measure_vae_forward(const arvae_measure_vae_t *m, int32_t b
 
     // ---- beat RNN (decoder.py:436-457): the same input b_0 at every beat
     MV_TRY(lin_fwd(d.b, d.z, 2 * Hd, z, P + m->z2beat_w, P + m->z2beat_b, ARVAE_ACT_SELU, w.flatb, s));
-    MV_TRY(arvae_broadcast_rows(P + m->b0, d.rb, 1, w.x0b, stream));
-    MV_TRY(lin_fwd(d.b, 1, 3 * Hd, w.x0b, P + m->beat_w_ih[0], P + m->beat_b_ih[0], ARVAE_ACT_NONE, w.gi0b, s));
+    ARVAE_LAUNCH(beat_input_kernel, dim3(blocks_for((int64_t)d.b * 3 * Hd + d.rb)), dim3(256), 0, s, P + m->b0, P + m->beat_w_ih[0],
+                 P + m->beat_b_ih[0], d.b, 3 * Hd, d.rb, w.x0b, w.gi0b);
+    MV_TRY(check_launch("beat_input_kernel"));
     arvae_gru_seq_t g{};
     g.gi = w.gi0b; g.gi_tstride = 0;
     g.w_hh = P + m->beat_w_hh[0]; g.b_hh = P + m->beat_b_hh[0]; g.h0 = w.flatb; g.h0_stride = 2 * Hd;   // view(B, 2, H)[:, 0]
@@ -750,10 +780,8 @@ extern "C" int arvae_measure_vae_backward(const arvae_measure_vae_t *m, int32_t 
     // the constant input b_0 (decoder.py:436-440): the projection's gradients over all beats*batch rows (x0b holds b_0 once per row)
     MV_TRY(lin_wgrad(&queue, d.rb, 1, 3 * Hd, plain(w.dgi_b0), w.x0b, G + m->beat_w_ih[0], G + m->beat_b_ih[0], s));
     MV_TRY(lin_dgrad(d.rb, 1, 3 * Hd, plain(w.dgi_b0), P + m->beat_w_ih[0], w.d_x0, s));
-    {
-        const arvae_operand_t dx0 = plain(w.d_x0);
-        MV_TRY(arvae_channel_sum(&dx0, d.rb, 1, 0, 0, G + m->b0, w.cs_ws, stream));
-    }
+    ARVAE_LAUNCH(sum_into_kernel, dim3(1), dim3(256), 0, s, w.d_x0, d.rb, G + m->b0);
+    MV_TRY(check_launch("sum_into_kernel"));
     MV_TRY(lin_dgrad(d.b, d.z, 2 * Hd, gated(w.d_flatb, w.flatb, ARVAE_ACT_SELU), P + m->z2beat_w, w.d_z, s));
     MV_TRY(lin_wgrad(&queue, d.b, d.z, 2 * Hd, gated(w.d_flatb, w.flatb, ARVAE_ACT_SELU), z, G + m->z2beat_w, G + m->z2beat_b, s));
 
