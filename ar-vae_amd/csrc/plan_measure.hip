@@ -246,6 +246,14 @@ __global__ __launch_bounds__(256) void beat_input_kernel(const float *__restrict
         }
     }
 }
+// dst[c] += sum over the (few) rows of x[rows][cols]: a thread per column, fixed order (the note table's rows of the lookup gradient)
+__global__ __launch_bounds__(256) void colsum_into_kernel(const float *__restrict__ x, int rows, int cols, float *__restrict__ dst) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float a = 0.f;
+    for (int r = 0; r < rows; ++r) a += x[(int64_t)r * cols + c];
+    dst[c] += a;
+}
 // dst[0] += sum of x[0 .. n): one workgroup, fixed order (the gradient of b_0 from its per-row gradients)
 __global__ __launch_bounds__(256) void sum_into_kernel(const float *__restrict__ x, int n, float *__restrict__ dst) {
     __shared__ float red[256];
@@ -744,10 +752,9 @@ extern "C" int arvae_measure_vae_backward(const arvae_measure_vae_t *m, int32_t 
     MV_TRY(lin_wgrad(&queue, d.rt, Hd, 3 * Hd, plain(w.dgh_t0), w.hprev_t0, G + m->tick_w_hh[0], G + m->tick_b_hh[0], s));
     // layer 0's input projection: per-tick gradients summed per previous note and per beat row, then the small product's adjoints
     MV_TRY(arvae_tick_gi_bwd(w.dgi_t0, tokens, d.b, d.nb, d.tpb, d.v, 3 * Hd, w.dg_small, w.tick_ws, stream));
-    {
-        const arvae_operand_t note_rows = plain(w.dg_small);      // every tick row carries the bias once and exactly one note entry
-        MV_TRY(arvae_channel_sum(&note_rows, d.v + 1, 3 * Hd, 0, 0, G + m->tick_b_ih[0], w.cs_ws, stream));
-    }
+    // (every tick row carries the bias once and exactly one note entry: the bias gradient is the column sum of the note rows)
+    ARVAE_LAUNCH(colsum_into_kernel, dim3((3 * Hd + 255) / 256), dim3(256), 0, s, w.dg_small, d.v + 1, 3 * Hd, G + m->tick_b_ih[0]);
+    MV_TRY(check_launch("colsum_into_kernel"));
     MV_TRY(lin_wgrad(&queue, d.ns, d.e + Hd, 3 * Hd, plain(w.dg_small), w.xs, G + m->tick_w_ih[0], nullptr, s));
     MV_TRY(lin_dgrad(d.ns, d.e + Hd, 3 * Hd, plain(w.dg_small), P + m->tick_w_ih[0], w.dx_small, s));
     MV_TRY(arvae_tick_rows_bwd(w.dx_small, d.v, d.e, Hd, d.rb, G + m->dec_table, G + m->x0, w.d_both + 2 * Hd, 3 * Hd, stream));
