@@ -139,10 +139,19 @@ __global__ __launch_bounds__(256) void measure_heads_fwd_kernel(MeasureHeadsFwd 
             *reinterpret_cast<float4 *>(dst) = v;
         }
     }
-    for (int i = threadIdx.x; i < 2 * p.zdim * h4; i += 256) {
-        const int j = i / h4, k = i - j * h4;
-        const float *src = j < p.zdim ? p.w_mu + (int64_t)j * p.hw : p.w_ls + (int64_t)(j - p.zdim) * p.hw;
-        reinterpret_cast<float4 *>(wl + j * ws)[k] = reinterpret_cast<const float4 *>(src)[k];
+    for (int base = 0; base < 2 * p.zdim * h4; base += 8 * 256) {       // eight independent 16-byte loads per thread and round trip
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = min(base + u * 256 + (int)threadIdx.x, 2 * p.zdim * h4 - 1), j = i / h4, k = i - j * h4;
+            const float *src = j < p.zdim ? p.w_mu + (int64_t)j * p.hw : p.w_ls + (int64_t)(j - p.zdim) * p.hw;
+            v[u] = reinterpret_cast<const float4 *>(src)[k];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * 256 + (int)threadIdx.x, j = i / h4, k = i - j * h4;
+            if (i < 2 * p.zdim * h4) reinterpret_cast<float4 *>(wl + j * ws)[k] = v[u];
+        }
     }
     const int r = threadIdx.x >> 6, j = threadIdx.x & 63, row = row0 + r;
     const bool col_ok = j < 2 * p.zdim, lat = j < p.zdim && row < p.batch;
@@ -251,7 +260,13 @@ __global__ __launch_bounds__(256) void colsum_into_kernel(const float *__restric
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= cols) return;
     float a = 0.f;
-    for (int r = 0; r < rows; ++r) a += x[(int64_t)r * cols + c];
+    for (int r0 = 0; r0 < rows; r0 += 16) {                      // sixteen independent loads per round trip, summed in row order
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = x[(int64_t)min(r0 + u, rows - 1) * cols + c];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) a += r0 + u < rows ? v[u] : 0.f;
+    }
     dst[c] += a;
 }
 // dst[0] += sum of x[0 .. n): one workgroup, fixed order (the gradient of b_0 from its per-row gradients)
