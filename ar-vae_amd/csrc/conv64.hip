@@ -1031,25 +1031,35 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_pairs_h2_kernel(ConvWgrad g
             if (ky < g.kh) {
                 const unsigned short *ab = lo_img + a_base;
                 const unsigned short *hbA = ring_of(ly - g.pad + ky), *hbB = ring_of(ly + 1 - g.pad + ky);
-#pragma unroll
-                for (int s = 0; s < 3; ++s) {
-                    f16x8 a2[2][2];
+                // the hi operand of (s, kx) is read ONE step ahead of its MFMAs (the compiler placed every group of transposed reads
+                // right in front of the MFMAs that use it, with a wait: twelve exposed LDS round trips per pair), the lo operand of
+                // s + 1 behind the last MFMAs of s
+                f16x8 a2[2][2], b2[2][2];
+                auto load_a = [&](int s) __attribute__((always_inline)) {
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
                         const unsigned short *ap = ab + t * WP_APLANE + 16 * s * RG_TRP;
                         a2[0][t] = __builtin_bit_cast(f16x8, wp_tr_operand(ap, ap + 4 * RG_TRP));
                         a2[1][t] = __builtin_bit_cast(f16x8, wp_tr_operand(ap + 32, ap + 32 + 4 * RG_TRP));
                     }
+                };
+                auto load_b = [&](int buf, int s, int kx) __attribute__((always_inline)) {
                     const unsigned short *h0 = ((h_sel >> (2 * s)) & 1u) ? hbB : hbA, *h1 = ((h_sel >> (2 * s + 1)) & 1u) ? hbB : hbA;
 #pragma unroll
-                    for (int kx = 0; kx < 4; ++kx) {
-                        f16x8 b2[2];
+                    for (int t = 0; t < 2; ++t)
+                        b2[buf][t] = __builtin_bit_cast(f16x8, wp_tr_operand(h0 + t * WP_HPLANE + h_off[s][0] + kx * WP_HTRP, h1 + t * WP_HPLANE + h_off[s][1] + kx * WP_HTRP));
+                };
+                load_a(0);
+                load_b(0, 0, 0);
 #pragma unroll
-                        for (int t = 0; t < 2; ++t)
-                            b2[t] = __builtin_bit_cast(f16x8, wp_tr_operand(h0 + t * WP_HPLANE + h_off[s][0] + kx * WP_HTRP, h1 + t * WP_HPLANE + h_off[s][1] + kx * WP_HTRP));
-                        H2_MFMA3(acc[0][kx], a2[0][0], a2[0][1], b2[0], b2[1]);
-                        if (na > 1) { H2_MFMA3(acc[1][kx], a2[1][0], a2[1][1], b2[0], b2[1]); }
-                    }
+                for (int step = 0; step < 12; ++step) {
+                    const int s = step >> 2, kx = step & 3, cur = step & 1;
+                    if (step + 1 < 12) load_b(cur ^ 1, (step + 1) >> 2, (step + 1) & 3);
+                    __builtin_amdgcn_sched_barrier(0);
+                    H2_MFMA3(acc[0][kx], a2[0][0], a2[0][1], b2[cur][0], b2[cur][1]);
+                    if (na > 1) { H2_MFMA3(acc[1][kx], a2[1][0], a2[1][1], b2[cur][0], b2[cur][1]); }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (kx == 3 && s + 1 < 3) load_a(s + 1);
                 }
             }
         }
