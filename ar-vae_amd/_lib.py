@@ -10,7 +10,7 @@ import threading
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libarvae_hip.so')
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 c_i32, c_i64, c_f32, c_f64, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
 
@@ -41,7 +41,7 @@ class ImageVaeDesc(ctypes.Structure):
                 ('head_mu', LayerDesc), ('head_log_std', LayerDesc), ('zdim', c_i32), ('recon_dist', c_i32),
                 ('n_reg', c_i32), ('reg_dims', c_i32 * 16), ('beta', c_f32), ('gamma', c_f32), ('delta', c_f32),
                 ('rng_eps', c_i32), ('rng_offset', ctypes.c_uint32), ('rng_step', ctypes.c_uint32), ('rng_seed', ctypes.c_uint64),
-                ('rng_dev_step', c_vp), ('milestones', c_vp)]
+                ('rng_dev_step', c_vp), ('milestones', c_vp), ('status', c_vp), ('flags', c_i32), ('reserved', c_i32)]
 
 
 class Milestones(ctypes.Structure):

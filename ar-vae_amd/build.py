@@ -37,8 +37,9 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force=False, verbose=True, diag=True):
-    """Compile every csrc/*.hip for gfx950 and link ar-vae_amd/libarvae_hip.so (and, with diag, libarvae_hip_diag.so)."""
+def build_library(force=False, verbose=True, diag=False):
+    """Compile every csrc/*.hip for gfx950 and link ar-vae_amd/libarvae_hip.so (and, with diag, libarvae_hip_diag.so: the
+    diagnostic twin is built only on request -- `python ar-vae_amd/build.py --diag`, __graft_entry__.build(), tools/)."""
     path = _build(force, verbose, LIB_PATH, 'build', [])
     if diag:
         _build(force, verbose, DIAG_LIB_PATH, 'build_diag', ['-DARVAE_DIAG'])
@@ -76,4 +77,4 @@ def _build(force, verbose, lib_path, objdir_name, extra_flags):
 
 
 if __name__ == '__main__':
-    build_library(force='--force' in sys.argv)
+    build_library(force='--force' in sys.argv, diag='--diag' in sys.argv or '--force' in sys.argv)

@@ -450,7 +450,7 @@ static bool midc_topology(const arvae_image_vae_t *m, int ne, int nd) {
            d0.clo == MC_H && d1.chi == MC_H && d1.clo == MC_H && d2.chi == MC_H && d2.clo == MC_K0 && m->head_mu.b_off >= 0 &&
            m->head_log_std.b_off >= 0;
 }
-constexpr int64_t MIDC_COUNTER_WORDS = 1024;         // 32 clusters x 32 words: more than a device's CUs can host
+constexpr int64_t MIDC_COUNTER_WORDS = MC_COUNTER_WORDS;     // arrival counters of 32 clusters + the ticket heads (midcluster.h)
 // cluster-layout floats of one matrix: both axes rounded up to 16 (the reduce axis of the z-sized ones to 16, the heads' to 32)
 static int64_t midc_mat_floats(int k, int n) { return (int64_t)((k + 15) / 16 * 16) * ((n + 15) / 16 * 16); }
 static int64_t midc_floats(const arvae_image_vae_t *m, int ne, int nd) {
@@ -484,11 +484,16 @@ struct MidPlan {
 // fills the layer tables from the model description; y / gpre buffers are given per layer by the caller afterwards
 static int mid_cu_count() { return device_cu_count(); }
 
-// the clustered kernels take the pass when the model has their shape AND every cluster's 16 workgroups can be resident at once
-// (they wait for each other: one 512-thread workgroup with ~117 KB of LDS per CU)
-static bool midc_use(bool cluster_ok, int batch) {
+// The clustered kernels take the pass when the model has their shape, the caller has not switched them off
+// (ARVAE_VAE_NO_CLUSTER: a hand-off gave up earlier in this run, arvae_image_vae_t.status) and the whole grid can be resident at
+// once by the runtime's own occupancy answer for these kernels (one 512-thread workgroup with ~117 KB of LDS per CU).  Residency
+// is a matter of speed, not of correctness: places are handed out by tickets (midcluster.hip), so a grid that finds part of the
+// device taken still completes.
+static bool midc_use(bool cluster_ok, int batch, int flags) {
     static const bool rows_only = diag_env("ARVAE_MID_NO_CLUSTER") != nullptr;       // diagnostic build: the row kernels of this file
-    return !rows_only && cluster_ok && (int64_t)((batch + MC_R - 1) / MC_R) * MC_S <= mid_cu_count();
+    const int64_t clusters = (batch + MC_R - 1) / MC_R;
+    return !rows_only && cluster_ok && !(flags & ARVAE_VAE_NO_CLUSTER) && clusters <= MC_MAX_CLUSTERS &&
+           clusters * MC_S <= midc_resident_capacity();
 }
 static void mid_describe(const arvae_image_vae_t *m, const float *params, float *prep_ws, MidPlan &pl, int batch = 512) {
     int ne, nd;
@@ -560,10 +565,11 @@ static void mid_describe(const arvae_image_vae_t *m, const float *params, float 
         pl.prep.counters = reinterpret_cast<unsigned *>(prep_ws + off);
         pl.prep.counter_words = (int)MIDC_COUNTER_WORDS;
         pl.cl.counters = pl.prep.counters;
+        pl.cl.status = m->status;
         off += MIDC_COUNTER_WORDS;
         pl.cl.zdim = m->zdim;
         // one family of layouts per step: the cluster layouts when the clustered kernels take this batch, else the row kernels'
-        const bool use_c = midc_use(true, batch);
+        const bool use_c = midc_use(true, batch, m->flags);
         for (int q = 0; q < 6; ++q) {
             MidPrepJob &j = pl.prep.job[q];
             if (use_c) j.mf = j.mb = nullptr;
@@ -593,6 +599,8 @@ static void midc_common(McArgs &c, const MidArgs &a, int batch) {
     c.batch = batch;
     c.clusters = (batch + MC_R - 1) / MC_R;
     c.xcd_map = c.clusters % 8 == 0;
+    c.debug_drop = diag_env("ARVAE_MIDC_DROP_ARRIVAL") != nullptr;
+    c.debug_static = diag_env("ARVAE_MIDC_STATIC") != nullptr;
     c.y_e0 = a.enc[0].y; c.y_e1 = a.enc[1].y; c.y_d0 = a.dec[0].y; c.y_d1 = a.dec[1].y; c.y_d2 = a.dec[2].y;
     c.g_e0 = a.enc[0].gpre; c.g_e1 = a.enc[1].gpre; c.g_d0 = a.dec[0].gpre; c.g_d1 = a.dec[1].gpre; c.g_d2 = a.dec[2].gpre;
 }
@@ -652,7 +660,7 @@ int mid_forward(const arvae_image_vae_t *m, int batch, const float *params, floa
         ARVAE_LAUNCH(mid_prep_kernel, dim3(pl.prep.blk_end[pl.prep.count - 1]), dim3(256), 0, s, pl.prep);
         if (int rc = check_launch("mid_prep_kernel")) return rc;
     }
-    if (midc_use(pl.cluster, batch)) {
+    if (midc_use(pl.cluster, batch, m->flags)) {
         McArgs &c = pl.cl;
         midc_common(c, a, batch);
         c.x0 = x0; c.mu = mu; c.log_std = log_std; c.sigma = sigma; c.z = z; c.eps = eps;
@@ -697,7 +705,7 @@ int mid_backward(const arvae_image_vae_t *m, int batch, const float *params, flo
         if (diag_env("ARVAE_MID_NO_WARM") != nullptr) nw = 0;
     }
     mid_allow_lds();
-    if (midc_use(pl.cluster, batch)) {
+    if (midc_use(pl.cluster, batch, m->flags)) {
         McArgs &c = pl.cl;
         midc_common(c, a, batch);
         c.g_out = g_out; c.g_is_pre = g_is_pre; c.gate0 = gate0; c.d_x0 = d_x0;

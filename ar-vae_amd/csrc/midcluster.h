@@ -10,6 +10,13 @@ constexpr int MC_R = 32;        // batch rows per cluster
 constexpr int MC_K0 = 512;      // conv feature width on both sides of the block (dsprites_vae.py:22,33: 32 x 4 x 4)
 constexpr int MC_H = 256;       // hidden width of the Linear stacks
 
+// Words [0, MC_TICKET_BASE) of McArgs.counters are the arrival counters (32 clusters x 32 words); the ticket heads follow,
+// one 128-byte line each: 8 per-XCD heads, the exit counter, the global head (grids that are not a multiple of 8 clusters).
+constexpr int MC_MAX_CLUSTERS = 32;
+constexpr int MC_TICKET_BASE = MC_MAX_CLUSTERS * 32;
+constexpr int MC_TICKET_DONE = MC_TICKET_BASE + 8 * 32, MC_TICKET_GLOBAL = MC_TICKET_BASE + 9 * 32;
+constexpr int MC_COUNTER_WORDS = MC_TICKET_BASE + 10 * 32;
+
 // One matrix in CLUSTER LAYOUT: the product out[rows][o] = sum_r in[rows][r] * M[r][o] with the reduce axis padded to KB
 // blocks of 16 and the output axis cut into S slices of CT column tiles of 16.  Stored so that the B operand of
 // v_mfma_f32_16x16x4_f32 for four consecutive steps is ONE 16-byte load per lane, lanes contiguous (1 KB per wave load):
@@ -22,9 +29,14 @@ struct McMat {
 
 struct McArgs {
     int batch, zdim, clusters;
+    int debug_static;           // diagnostic build only (ARVAE_MIDC_STATIC): places by blockIdx instead of tickets
+    int debug_drop;             // diagnostic build only (ARVAE_MIDC_DROP_ARRIVAL): one member never arrives at the first hand-off
     int xcd_map;                // 1: the 16 members of a cluster have equal blockIdx.x % 8 (one XCD under round-robin dispatch:
                                 // speed only, never correctness); needs clusters % 8 == 0
-    unsigned *counters;         // one arrival counter per cluster, 32 words apart; multiples of MC_S between phases
+    unsigned *counters;         // one arrival counter per cluster, 32 words apart; multiples of MC_S between phases; behind
+                                // them (MC_TICKET_BASE) the ticket heads a pass hands its cluster places out from
+    unsigned *status;           // sticky error word of the caller (arvae_image_vae_t.status) or null: a hand-off that
+                                // gives up ORs ARVAE_STATUS_HANDOFF_* into it and the workgroup leaves
     // forward matrices: enc0 [K0 -> H], enc1 [H -> H], heads [H -> 2 zdim (32)], dec0 [zdim (16) -> H], dec1 [H -> H], dec2 [H -> K0]
     McMat e0f, e1f, hdf, d0f, d1f, d2f;
     // backward matrices: dec2^T [K0 -> H], dec1^T [H -> H], dec0^T [H -> zdim (16)], heads^T [2 zdim (32) -> H], enc1^T, enc0^T [H -> K0]
@@ -49,6 +61,7 @@ struct McArgs {
 };
 
 int64_t midc_counter_words(int batch);             // uint32 words of arrival counters a batch needs (zeroed by the prep launch)
+int midc_resident_capacity();                      // clustered-kernel workgroups the device holds at once (occupancy x CUs)
 int midc_forward(const McArgs &a, hipStream_t s);
 int midc_backward(const McArgs &a, hipStream_t s);
 

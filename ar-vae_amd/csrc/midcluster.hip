@@ -11,11 +11,20 @@
 // visibility": the first row of the hand-off table; the exchanged tensors ARE the saved activations / pre-activation gradients
 // the other pass and the weight-gradient launch need anyway).  The narrow middle of the chain (heads, z, decoder's first layer;
 // their transposes in backward) is computed by every member for its cluster's rows, so a pass has three exchanges, not six.
-// Forward: 3 exchanges; backward: 3.  256 workgroups at B = 512, one per CU; a cluster's members have equal blockIdx % 8
-// (one XCD under round-robin dispatch: speed only).  Correctness needs the 16 members of a cluster co-resident: the
-// launcher (midblock.hip) uses this kernel only when the whole grid fits the device's CUs.
+// Forward: 3 exchanges; backward: 3.  256 workgroups at B = 512, one per CU.
+//
+// Membership is decided AT RUN TIME, by tickets (mc_ticket): a workgroup that has started takes the next free place of a
+// cluster on the XCD it really runs on (HW_REG_XCC_ID; a head per XCD, a place on another XCD when its own has handed out its
+// share).  Members wait for each other, so what matters is that the workgroups that are RESIDENT form complete clusters: with
+// places handed out in order of arrival every 16 arrivals complete one, whichever 16 they are -- a grid that only partly fits
+// the device (another process holds CUs, a larger batch) runs cluster after cluster instead of waiting for workgroups that
+// cannot start.  (With places fixed by blockIdx, as through round 4, two processes sharing the device could each hold half of
+// every cluster: a hang.)  What is left -- fewer than 16 places can ever be resident -- ends in mc_wait's bound: the poll gives
+// up after MC_WAIT_TICKS of its own running time, ORs a code into the caller's status word (arvae_image_vae_t.status) and the
+// workgroup leaves; the host raises on that word where it synchronises anyway and stays on the row kernels (midblock.hip).
 #include <mutex>
 
+#include "diag.h"
 #include "conv32_common.h"
 #include "midcluster.h"
 
@@ -142,10 +151,66 @@ __device__ __forceinline__ float mc_sum(const float *red, int row, int col) {
     return v;
 }
 
-__device__ __forceinline__ void mc_place(const McArgs &p, int &cl, int &m) {
-    const int b = blockIdx.x;
+// place b of the grid -> (cluster, member)
+__device__ __forceinline__ void mc_place(const McArgs &p, int b, int &cl, int &m) {
     if (p.xcd_map) { cl = (b & 7) + 8 * (b >> 7); m = (b >> 3) & (MC_S - 1); }
     else { cl = b / MC_S; m = b % MC_S; }
+}
+
+// This workgroup's place in the grid, handed out in order of arrival (see the top of the file); -1: none could be had (the
+// heads are corrupt: status word set).  xcd_map grids (a multiple of 8 clusters: every XCD hosts grid / 8 places, all members
+// of a cluster on one XCD): place = x + 8 t with t the ticket of head x, x the XCD this workgroup runs on while that head
+// has places left, else the next head that has.  Other grids: one global head.  The heads are zero at the start of a pass:
+// the pass clears them itself once every cluster is placed (mc_placed / mc_clear_heads), the step's prep launch clears everything.
+constexpr unsigned MC_E_FWD = 1u, MC_E_BWD = 2u, MC_E_TICKET = 4u;     // = ARVAE_STATUS_HANDOFF_FWD / _BWD / _TICKET (arvae_hip.h)
+__device__ __forceinline__ int mc_ticket(const McArgs &p) {
+    if (p.debug_static) return (int)blockIdx.x;          // diagnostic build, ARVAE_MIDC_STATIC: places by blockIdx (what tickets cost)
+    __shared__ int place;
+    if (threadIdx.x == 0) {
+        unsigned *tk = p.counters;
+        int b = -1;
+        if (!p.xcd_map) {
+            b = (int)__hip_atomic_fetch_add(tk + MC_TICKET_GLOBAL, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (b >= (int)gridDim.x) b = -1;
+        } else {
+            const unsigned cap = gridDim.x / 8;
+            unsigned x;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+            x &= 7u;
+            unsigned t = __hip_atomic_fetch_add(tk + MC_TICKET_BASE + 32 * x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (dispatch is round-robin over the XCDs, so this loop normally never runs; a head above cap reads as "full")
+            for (int tries = 0; t >= cap && tries < (1 << 16); ++tries) {
+                x = (x + 1) & 7u;
+                unsigned *head = tk + MC_TICKET_BASE + 32 * x;
+                unsigned cur = __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                while (cur < cap && !__hip_atomic_compare_exchange_strong(head, &cur, cur + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                         __HIP_MEMORY_SCOPE_AGENT)) {}
+                if (cur < cap) t = cur;
+            }
+            if (t < cap) b = (int)(x + 8u * t);
+        }
+        if (b < 0 && p.status != nullptr) __hip_atomic_fetch_or(p.status, MC_E_TICKET, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        place = b;
+    }
+    __syncthreads();
+    return place;
+}
+// The heads are cleared for the next pass by the pass itself, without a wait of its own: behind a cluster's LAST hand-off (every
+// member has arrived, so every member holds its place) member 0 counts its cluster as placed (mc_placed: a returning atomic whose
+// result nobody needs for the ~3 us the last product takes), and at the end of the kernel the member that counted last clears the
+// heads (mc_clear_heads).  A pass in which a cluster gave up leaves them as they are: the next pass of that step then finds no
+// place (status word), the next step's prep launch clears everything.
+__device__ __forceinline__ unsigned mc_placed(const McArgs &p, int m) {
+    unsigned before = 0;
+    if (m == 0 && threadIdx.x == 0)
+        before = __hip_atomic_fetch_add(p.counters + MC_TICKET_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return before;
+}
+__device__ __forceinline__ void mc_clear_heads(const McArgs &p, int m, unsigned before) {
+    if (m == 0 && threadIdx.x == 0 && before == (unsigned)p.clusters - 1u) {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) __hip_atomic_store(p.counters + MC_TICKET_BASE + 32 * i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // Hand-off, producer side then consumer side (every member is both).  mc_publish: all of this workgroup's sc1 stores have left
@@ -154,17 +219,37 @@ __device__ __forceinline__ void mc_place(const McArgs &p, int &cl, int &m) {
 // (mc_gather).  Whatever is requested BETWEEN the two (the next products' weights) is in flight during the poll instead of being
 // waited for by the drain.  The counter only ever holds multiples of MC_S between phases (the prep launch zeroes it every step), so
 // the phase's target follows from the value the arrival returned: any number of forward / backward passes may follow one prep.
-__device__ __forceinline__ unsigned mc_publish(unsigned *ctr) {
+__device__ __forceinline__ unsigned mc_publish(unsigned *ctr, bool arrive = true) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     unsigned target = 0;
-    if (threadIdx.x == 0) target = (__hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / MC_S + 1u) * MC_S;
+    // (arrive == false: the diagnostic build's way to make a hand-off fail -- McArgs.debug_drop -- so that the bound is tested)
+    if (threadIdx.x == 0) target = (__hip_atomic_fetch_add(ctr, arrive ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / MC_S + 1u) * MC_S;
     return target;
 }
-__device__ __forceinline__ void mc_wait(unsigned *ctr, unsigned target) {
-    if (threadIdx.x == 0)
-        while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(1);
+// The poll is BOUNDED: by the time this wave has spent polling (wall clock, 100 MHz; a gap of more than MC_GAP_TICKS between
+// two polls is time the wave was not running -- a context switch under a shared device -- and does not count).  On expiry the
+// status word takes `code` and every thread of the workgroup gets false: the caller returns.  The other members of the cluster
+// run into the same bound within microseconds of this one (they wait for the same arrivals).
+constexpr unsigned long long MC_WAIT_TICKS = 10ull * 1000 * 1000;      // 100 ms of polling
+constexpr unsigned long long MC_GAP_TICKS = 5000;                      // 50 us
+__device__ __forceinline__ bool mc_wait(unsigned *ctr, unsigned target, unsigned *status, unsigned code) {
+    __shared__ int arrived;
+    if (threadIdx.x == 0) {
+        bool ok = true;
+        unsigned long long last = wall_clock64(), spent = 0;
+        while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+            __builtin_amdgcn_s_sleep(1);
+            const unsigned long long now = wall_clock64(), dt = now - last;
+            last = now;
+            spent += dt < MC_GAP_TICKS ? dt : 0ull;
+            if (spent > MC_WAIT_TICKS) { ok = false; break; }
+        }
+        if (!ok && status != nullptr) __hip_atomic_fetch_or(status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        arrived = ok ? 1 : 0;
+    }
     __syncthreads();
+    return arrived != 0;
 }
 
 // the cluster's 32 x 256 block of a tensor every member has just stored a slice of -> LDS (pitch PB); rows past the batch: zeros
@@ -227,12 +312,12 @@ __device__ __forceinline__ void mc_wide_epilogue_act(int act, const f32x4v (&acc
 }
 
 // ================================================================================================ forward
-__global__ __launch_bounds__(MC_T) void midc_forward_kernel(McArgs p) {
+__device__ __forceinline__ void midc_forward_body(const McArgs &p, int place) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *bufA = lds, *bufB = bufA + MC_R * PA, *red = bufB + MC_R * PB, *zbuf = red + RED_FLOATS, *outs = zbuf + MC_R * PZ;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15;
     int cl, m;
-    mc_place(p, cl, m);
+    mc_place(p, place, cl, m);
     const int row0 = cl * MC_R, valid = min(MC_R, p.batch - row0), zd = p.zdim;
     unsigned *ctr = p.counters + cl * 32;
     const int frow = tid >> 4, fc = tid & 15;                 // the output a thread finalises in a 16-column slice
@@ -278,9 +363,9 @@ __global__ __launch_bounds__(MC_T) void midc_forward_kernel(McArgs p) {
         if (frow < valid) st_sc1(v, p.y_e0, (int64_t)(row0 + frow) * MC_H + 16 * m + fc);
     }
     MC_STAMP(0, 2);
-    const unsigned t0 = mc_publish(ctr);
+    const unsigned t0 = mc_publish(ctr, !(p.debug_drop != 0 && cl == 0 && m == 0));
     mc_load<ShHD>(p.hdf.w, wa);
-    mc_wait(ctr, t0);
+    if (!mc_wait(ctr, t0, p.status, MC_E_FWD)) return;
     MC_STAMP(0, 3);
     mc_gather(p.y_e0, row0, valid, bufB);
     MC_STAMP(0, 4);
@@ -295,7 +380,7 @@ __global__ __launch_bounds__(MC_T) void midc_forward_kernel(McArgs p) {
     MC_STAMP(0, 5);
     const unsigned t1 = mc_publish(ctr);
     mc_load<ShD0>(p.d0f.w, wb);
-    mc_wait(ctr, t1);
+    if (!mc_wait(ctr, t1, p.status, MC_E_FWD)) return;
     MC_STAMP(0, 6);
     mc_gather(p.y_e1, row0, valid, bufA);                     // (bufA with pitch PB from here on)
     MC_STAMP(0, 7);
@@ -347,7 +432,8 @@ __global__ __launch_bounds__(MC_T) void midc_forward_kernel(McArgs p) {
     }
     const unsigned t_last = mc_publish(ctr);
     const float2 b_d2 = p.d2f.bias != nullptr ? *reinterpret_cast<const float2 *>(p.d2f.bias + 32 * m + 2 * fc) : make_float2(0.f, 0.f);
-    mc_wait(ctr, t_last);
+    if (!mc_wait(ctr, t_last, p.status, MC_E_FWD)) return;
+    const unsigned placed_before = mc_placed(p, m);
     MC_STAMP(0, 10);
     mc_gather(p.y_d1, row0, valid, bufA);
     MC_STAMP(0, 11);
@@ -379,16 +465,22 @@ __global__ __launch_bounds__(MC_T) void midc_forward_kernel(McArgs p) {
             amax_publish(p.amax_out, blockIdx.x, gridDim.x, t);
         }
     }
+    mc_clear_heads(p, m, placed_before);
     MC_STAMP(0, 13);
 }
 
 // ================================================================================================ backward
-__global__ __launch_bounds__(MC_T) void midc_backward_kernel(McArgs p) {
+__global__ __launch_bounds__(MC_T) void midc_forward_kernel(McArgs p) {
+    const int place = mc_ticket(p);
+    if (place >= 0) midc_forward_body(p, place);
+}
+
+__device__ __forceinline__ void midc_backward_body(const McArgs &p, int place) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *bufA = lds, *bufB = bufA + MC_R * PA, *red = bufB + MC_R * PB, *dml = red + RED_FLOATS + MC_R * PZ;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, c = lane & 15;
     int cl, m;
-    mc_place(p, cl, m);
+    mc_place(p, place, cl, m);
     const int row0 = cl * MC_R, valid = min(MC_R, p.batch - row0), zd = p.zdim;
     unsigned *ctr = p.counters + cl * 32;
     const int frow = tid >> 4, fc = tid & 15;
@@ -441,7 +533,7 @@ __global__ __launch_bounds__(MC_T) void midc_backward_kernel(McArgs p) {
     MC_STAMP(1, 2);
     const unsigned t2 = mc_publish(ctr);
     mc_load<ShZB>(p.d0b.w, wa);
-    mc_wait(ctr, t2);
+    if (!mc_wait(ctr, t2, p.status, MC_E_BWD)) return;
     MC_STAMP(1, 3);
     mc_gather(p.g_d1, row0, valid, bufB);
     MC_STAMP(1, 4);
@@ -456,7 +548,7 @@ __global__ __launch_bounds__(MC_T) void midc_backward_kernel(McArgs p) {
     MC_STAMP(1, 5);
     const unsigned t3 = mc_publish(ctr);
     mc_load<ShHB>(p.hdb.w, wb);
-    mc_wait(ctr, t3);
+    if (!mc_wait(ctr, t3, p.status, MC_E_BWD)) return;
     MC_STAMP(1, 6);
     mc_gather(p.g_d0, row0, valid, bufA);                     // (bufA with pitch PB from here on)
     MC_STAMP(1, 7);
@@ -518,7 +610,8 @@ __global__ __launch_bounds__(MC_T) void midc_backward_kernel(McArgs p) {
     const unsigned t_last = mc_publish(ctr);
     const int64_t xat = (int64_t)(row0 + (fon ? frow : 0)) * MC_K0 + 32 * m + 2 * fc;
     const float2 gate = p.gate0 != nullptr ? *reinterpret_cast<const float2 *>(p.gate0 + xat) : make_float2(1.f, 1.f);
-    mc_wait(ctr, t_last);
+    if (!mc_wait(ctr, t_last, p.status, MC_E_BWD)) return;
+    const unsigned placed_before = mc_placed(p, m);
     MC_STAMP(1, 10);
     mc_gather(p.g_e0, row0, valid, bufA);
     MC_STAMP(1, 11);
@@ -551,7 +644,13 @@ __global__ __launch_bounds__(MC_T) void midc_backward_kernel(McArgs p) {
             amax_publish(p.amax_out, blockIdx.x, gridDim.x, t);
         }
     }
+    mc_clear_heads(p, m, placed_before);
     MC_STAMP(1, 13);
+}
+
+__global__ __launch_bounds__(MC_T) void midc_backward_kernel(McArgs p) {
+    const int place = mc_ticket(p);
+    if (place >= 0) midc_backward_body(p, place);
 }
 
 std::once_flag g_lds_once;
@@ -564,7 +663,24 @@ void allow_lds() {
 
 }  // namespace
 
-int64_t midc_counter_words(int batch) { return (int64_t)((batch + MC_R - 1) / MC_R) * 32; }
+int64_t midc_counter_words(int) { return MC_COUNTER_WORDS; }
+
+// workgroups of the clustered kernels the device can hold at once: the occupancy the runtime reports for the heavier of the two
+// (512 threads, LDS_FLOATS of dynamic LDS) x the CU count.  The launcher takes the clustered kernels when the whole grid fits --
+// a question of speed since the tickets (a grid that does not fit still completes, cluster after cluster).
+int midc_resident_capacity() {
+    static const int cap = [] {
+        allow_lds();
+        int fwd = 0, bwd = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fwd, (const void *)midc_forward_kernel, MC_T, LDS_FLOATS * sizeof(float)) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&bwd, (const void *)midc_backward_kernel, MC_T, LDS_FLOATS * sizeof(float)) != hipSuccess) {
+            (void)hipGetLastError();
+            return 0;
+        }
+        return (fwd < bwd ? fwd : bwd) * device_cu_count();
+    }();
+    return cap;
+}
 
 int midc_forward(const McArgs &a, hipStream_t s) {
     allow_lds();

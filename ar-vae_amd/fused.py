@@ -65,6 +65,30 @@ class FusedImageVAE:
         self._ws_owner = None
         self._overlap = None
         self._buckets = None
+        self._status = None              # the sticky device status word of this model's passes (arvae_image_vae_t.status)
+        self.no_cluster = False          # set once a hand-off has given up: the latent block stays on the row kernels
+
+    def status_word(self, device):
+        if self._status is None or self._status.device != device:
+            self._status = torch.zeros(1, dtype=torch.int32, device=device)
+        return self._status
+
+    def check_status(self):
+        """Reads the status word (ONE device sync: call it where the host synchronises anyway -- Trainer.loss_and_acc_on_epoch
+        does, next to the epoch means).  A hand-off between the workgroups of the clustered latent block that gave up (its
+        partners could not all become resident: csrc/midcluster.hip) left the results of that pass undefined: raise, and keep
+        every later pass on the kernels without in-launch hand-offs."""
+        if self._status is None:
+            return
+        bits = int(self._status.item())
+        if bits:
+            self.no_cluster = True
+            self._status.zero_()
+            raise RuntimeError(
+                f'libarvae_hip: an in-launch hand-off of the clustered latent block gave up (status {bits:#x}: '
+                f'{"forward " if bits & 1 else ""}{"backward " if bits & 2 else ""}{"tickets " if bits & 4 else ""}pass); the results of '
+                f'that training step are undefined.  The device is probably shared with other processes; later passes of this '
+                f'trainer use the row kernels (no hand-offs).')
 
     def overlap(self, device):
         if self._overlap is None:
@@ -183,6 +207,8 @@ class FusedImageVAE:
         recon + beta|KL - c| + W * reg_rowblock and scalars[REG] = W * reg_rowblock.  With capacity_nonzero the KL
         mean is all-reduced first and the term becomes the global beta|KL_global - c| (parallel.py)."""
         d = self.descriptor()                                    # where this pass's eps comes from (csrc/rng.h)
+        d.status = ops._ptr(self.status_word(x.device))
+        d.flags = 1 if self.no_cluster else 0                    # ARVAE_VAE_NO_CLUSTER
         d.rng_eps = int(bool(draw_eps))
         if draw_eps:
             d.rng_seed, d.rng_offset, d.rng_step = ops.rng_seed(), ops.rng_next_offset(), 0

@@ -136,7 +136,15 @@ class Trainer(ABC):
         n = max(count, 1)
         mean_loss = float(loss_sum) / n if loss_sum is not None else 0.0       # single sync per epoch
         mean_acc = float(acc_sum) / n if acc_sum is not None else 0.0
+        self.check_device_status()                                             # (the stream is idle here: no extra wait)
         return mean_loss, mean_acc
+
+    def check_device_status(self):
+        """Raises RuntimeError when a pass of this trainer reported a device-side failure in its status word (the reference
+        reads its loss on the host every step, utils/trainer.py:145-147; this build once per epoch, here)."""
+        fused = getattr(self, '_fused', None)
+        if fused is not None and hasattr(fused, 'check_status'):
+            fused.check_status()
 
     def backward(self, loss):
         """loss.backward() (utils/trainer.py:140) with a cached unit seed gradient: a bare `loss.backward()` makes torch fill a

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ARVAE_ABI_VERSION 9   /* 9: arvae_measure_vae_* (whole-model MeasureVAE step), row strides for h0 / dh0 / the beat embeddings (arvae_gru_seq_t, arvae_tick_*); 8: arvae_gru_seq_t.gi_rstride / dgi_rstride / h_fin (merged input projections of a bidirectional layer, final states written by the sequence launch); 7: arvae_comm_* (the data-parallel step's collectives: RCCL on the launch stream, owned by the library); 6: the 32-channel k4 s2 p1 links need caller workspace too (arvae_link_ws_floats / arvae_link_wgrad_ws_floats: the layer's weights as scaled fp16 terms and the operands' maxima); 5: arvae_adam_step(zero_grad), arvae_image_vae_finish, arvae_image_vae_t.milestones (events the executors record for the data-parallel caller's collectives); 4: arvae_philox_* and in-kernel eps (arvae_image_vae_t.rng_*), arvae_tick_free_run_supported, caller workspace for arvae_link_down/up (arvae_link_ws_floats); 3: arvae_gru_seq_*, embed_bwd workspace; 2: arvae_image_vae_backward reg_fused == 2 (unit regulariser gradient in dz_extra) */
+#define ARVAE_ABI_VERSION 10  /* 10: arvae_image_vae_t.status / .flags (a sticky device status word: an in-launch hand-off between workgroups that gives up says so there instead of hanging; ARVAE_VAE_NO_CLUSTER keeps the pass on kernels without such hand-offs); 9: arvae_measure_vae_* (whole-model MeasureVAE step), row strides for h0 / dh0 / the beat embeddings (arvae_gru_seq_t, arvae_tick_*); 8: arvae_gru_seq_t.gi_rstride / dgi_rstride / h_fin (merged input projections of a bidirectional layer, final states written by the sequence launch); 7: arvae_comm_* (the data-parallel step's collectives: RCCL on the launch stream, owned by the library); 6: the 32-channel k4 s2 p1 links need caller workspace too (arvae_link_ws_floats / arvae_link_wgrad_ws_floats: the layer's weights as scaled fp16 terms and the operands' maxima); 5: arvae_adam_step(zero_grad), arvae_image_vae_finish, arvae_image_vae_t.milestones (events the executors record for the data-parallel caller's collectives); 4: arvae_philox_* and in-kernel eps (arvae_image_vae_t.rng_*), arvae_tick_free_run_supported, caller workspace for arvae_link_down/up (arvae_link_ws_floats); 3: arvae_gru_seq_*, embed_bwd workspace; 2: arvae_image_vae_backward reg_fused == 2 (unit regulariser gradient in dz_extra) */
 
 #define ARVAE_OK 0
 #define ARVAE_E_INVALID (-1)  /* bad argument (null pointer, size out of range, unsupported shape) */
@@ -411,7 +411,22 @@ typedef struct {
      * reduction and the grouped Linear weight gradients are launched where their inputs are complete instead of at the end
      * of the pass: one launch more). */
     const struct arvae_milestones *milestones;
+    /* Optional (NULL: none).  ONE device word the caller owns and zeroes once; the passes only ever OR bits into it
+     * (ARVAE_STATUS_*).  The latent block of the dSprites-shaped model runs on clusters of workgroups that hand activations to
+     * each other inside a launch (csrc/midcluster.hip); a hand-off whose partners never arrive -- they cannot all become
+     * resident, e.g. many processes on one device -- gives up after a bounded poll, sets its bit and the launch ends: the
+     * results of THAT pass are then undefined.  The caller reads the word where it synchronises anyway (the reference reads
+     * its loss every step, utils/trainer.py:145-147; this build once per epoch), raises, and sets ARVAE_VAE_NO_CLUSTER in
+     * `flags` for every later call. */
+    uint32_t *status;
+    int32_t flags;        /* ARVAE_VAE_* */
+    int32_t reserved;
 } arvae_image_vae_t;
+
+#define ARVAE_STATUS_HANDOFF_FWD 1u    /* a hand-off of the clustered latent block's forward launch gave up  */
+#define ARVAE_STATUS_HANDOFF_BWD 2u    /* ... of its backward launch                                          */
+#define ARVAE_STATUS_HANDOFF_TICKET 4u /* a workgroup found no place in any cluster (corrupt ticket heads)    */
+#define ARVAE_VAE_NO_CLUSTER 1         /* flags: the latent block on the row kernels (no in-launch hand-offs)  */
 
 typedef struct arvae_milestones {
     void *z_ready, *dec_grads, *linear_grads;

@@ -45,7 +45,7 @@ def test_ctypes_structs_match_the_header(tmp_path):
                'arvae_gru_seq_t': (_lib.GruSeqDesc, 'gi', 'dh0_stride'),
                'arvae_tick_weights_t': (_lib.TickWeights, 'w_hh0', 'b_out'),
                'arvae_dense_wgrad_job_t': (_lib.DenseWgradJob, 'g', 'n_out'),
-               'arvae_image_vae_t': (_lib.ImageVaeDesc, 'n_enc', 'milestones'),
+               'arvae_image_vae_t': (_lib.ImageVaeDesc, 'n_enc', 'flags'),
                'arvae_milestones_t': (_lib.Milestones, 'z_ready', 'linear_grads'),
                'arvae_measure_vae_t': (_lib.MeasureVaeDesc, 'vocab', 'rng_dev_step'),
                'arvae_measure_tables_t': (_lib.MeasureTables, 'midi_lut', 'rhythm_norm')}
