@@ -161,7 +161,7 @@ SIGNATURES = {
     'arvae_adam_step': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_f64, c_f64, c_f64, c_f64, c_f32, c_i32, c_vp]),
     'arvae_comm_available': (c_i32, []),
     'arvae_comm_unique_id': (c_i32, [c_vp]),
-    'arvae_comm_init': (c_i32, [c_vp, c_i32, c_i32, _P(c_vp)]),
+    'arvae_comm_init': (c_i32, [c_vp, c_i32, c_i32, c_i32, _P(c_vp)]),
     'arvae_comm_destroy': (c_i32, [c_vp]),
     'arvae_comm_abort': (c_i32, [c_vp]),
     'arvae_comm_rank': (c_i32, [c_vp]),

@@ -8,12 +8,31 @@
 //
 // RCCL is resolved at run time (dlopen / dlsym): a process that already holds an RCCL (PyTorch-ROCm ships its own
 // librccl.so.1 next to its HIP runtime) gets THAT copy, so one RCCL and one HIP runtime serve the process; single-GPU
-// users never load it.  The header <rccl/rccl.h> is used for its types only.
+// users never load it.  The header <rccl/rccl.h> is used for its types only; a host without RCCL's development files (a
+// single-GPU or cross-compile box) builds the same library from the handful of declarations below -- RCCL's ABI for the entry
+// points bound here (NCCL 2.x: opaque ncclComm_t, 128-byte unique id, the enum values of nccl.h).
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 #include <string.h>
 
+#include <chrono>
+#include <future>
+#include <memory>
 #include <mutex>
+#include <thread>
+
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0, ncclUnhandledCudaError = 1, ncclSystemError = 2, ncclInternalError = 3, ncclInvalidArgument = 4,
+               ncclInvalidUsage = 5, ncclRemoteError = 6, ncclInProgress = 7 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5, ncclFloat16 = 6, ncclFloat32 = 7,
+               ncclFloat64 = 8 } ncclDataType_t;
+typedef enum { ncclSum = 0, ncclProd = 1, ncclMax = 2, ncclMin = 3, ncclAvg = 4 } ncclRedOp_t;
+}
+#endif
 
 #include "common.h"
 
@@ -132,17 +151,35 @@ extern "C" int arvae_comm_unique_id(void *id_out) {
     return ARVAE_OK;
 }
 
-extern "C" int arvae_comm_init(const void *id_bytes, int32_t rank, int32_t world, arvae_comm_t *out) {
+// ncclCommInitRank is a collective: it returns when EVERY rank of the job is in it.  A rank that died after the unique id went
+// out would leave the others in it forever, so the call runs on a helper thread (bound to the caller's device) and this thread
+// waits for it with a deadline.  After a timeout the helper is still inside RCCL and cannot be cancelled: the call returns
+// ARVAE_E_COMM and the PROCESS must exit (the launcher ends the job); nothing of the half-built communicator is touched again.
+extern "C" int arvae_comm_init(const void *id_bytes, int32_t rank, int32_t world, int32_t timeout_ms, arvae_comm_t *out) {
     const Rccl *r = rccl();
     if (r == nullptr) return fail(ARVAE_E_COMM, "%s", g_rccl.why);
-    if (id_bytes == nullptr || out == nullptr || world < 1 || rank < 0 || rank >= world)
+    if (id_bytes == nullptr || out == nullptr || world < 1 || rank < 0 || rank >= world || timeout_ms < 0)
         return fail(ARVAE_E_INVALID, "arvae_comm_init: bad arguments (rank %d of %d)", rank, world);
     ncclUniqueId id;
     memcpy(&id, id_bytes, sizeof(id));
-    ncclComm_t c = nullptr;
-    const ncclResult_t e = r->CommInitRank(&c, world, id, rank);    // collective: every rank of the job is in this call
-    if (e != ncclSuccess) return nccl_fail(r, "ncclCommInitRank", e);
-    Comm *p = new Comm{COMM_MAGIC, c, rank, world};
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return fail(ARVAE_E_NODEVICE, "arvae_comm_init: no current HIP device");
+    struct Result { ncclComm_t comm = nullptr; ncclResult_t rc = ncclSuccess; hipError_t hip = hipSuccess; };
+    auto result = std::make_shared<Result>();                       // outlives this frame if the helper never returns
+    auto done = std::make_shared<std::promise<void>>();
+    std::future<void> ready = done->get_future();
+    std::thread([=] {
+        result->hip = hipSetDevice(device);
+        if (result->hip == hipSuccess) result->rc = r->CommInitRank(&result->comm, world, id, rank);
+        done->set_value();
+    }).detach();
+    if (timeout_ms == 0) ready.wait();                               // 0: no deadline (the caller has its own)
+    else if (ready.wait_for(std::chrono::milliseconds(timeout_ms)) != std::future_status::ready)
+        return fail(ARVAE_E_COMM, "ncclCommInitRank: rank %d of %d waited %d ms for the other ranks; the job cannot continue "
+                                  "(this process must exit)", rank, world, timeout_ms);
+    if (result->hip != hipSuccess) return fail(ARVAE_E_LAUNCH, "arvae_comm_init: hipSetDevice(%d) failed on the helper thread", device);
+    if (result->rc != ncclSuccess) return nccl_fail(r, "ncclCommInitRank", result->rc);
+    Comm *p = new Comm{COMM_MAGIC, result->comm, rank, world};
     *out = reinterpret_cast<arvae_comm_t>(p);
     return ARVAE_OK;
 }

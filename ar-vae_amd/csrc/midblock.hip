@@ -598,9 +598,12 @@ static void mid_describe(const arvae_image_vae_t *m, const float *params, float 
 static void midc_common(McArgs &c, const MidArgs &a, int batch) {
     c.batch = batch;
     c.clusters = (batch + MC_R - 1) / MC_R;
-    c.xcd_map = c.clusters % 8 == 0;
+    c.heads = c.clusters % 4 == 0 ? 4 : (c.clusters % 2 == 0 ? 2 : 1);
+    if (const char *hd = diag_env("ARVAE_MIDC_HEADS")) { const int v = atoi(hd); if (v >= 1 && v <= 8 && c.clusters % v == 0) c.heads = v; }
     c.debug_drop = diag_env("ARVAE_MIDC_DROP_ARRIVAL") != nullptr;
     c.debug_static = diag_env("ARVAE_MIDC_STATIC") != nullptr;
+    c.wait_ticks = midc_wait_ticks();
+    if (const char *ms = diag_env("ARVAE_MIDC_WAIT_MS")) c.wait_ticks = (unsigned long long)atoll(ms) * 100000ull;
     c.y_e0 = a.enc[0].y; c.y_e1 = a.enc[1].y; c.y_d0 = a.dec[0].y; c.y_d1 = a.dec[1].y; c.y_d2 = a.dec[2].y;
     c.g_e0 = a.enc[0].gpre; c.g_e1 = a.enc[1].gpre; c.g_d0 = a.dec[0].gpre; c.g_d1 = a.dec[1].gpre; c.g_d2 = a.dec[2].gpre;
 }

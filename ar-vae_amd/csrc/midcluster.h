@@ -11,7 +11,7 @@ constexpr int MC_K0 = 512;      // conv feature width on both sides of the block
 constexpr int MC_H = 256;       // hidden width of the Linear stacks
 
 // Words [0, MC_TICKET_BASE) of McArgs.counters are the arrival counters (32 clusters x 32 words); the ticket heads follow,
-// one 128-byte line each: 8 per-XCD heads, the exit counter, the global head (grids that are not a multiple of 8 clusters).
+// one 128-byte line each: up to 8 heads, the placed-clusters counter, one spare.
 constexpr int MC_MAX_CLUSTERS = 32;
 constexpr int MC_TICKET_BASE = MC_MAX_CLUSTERS * 32;
 constexpr int MC_TICKET_DONE = MC_TICKET_BASE + 8 * 32, MC_TICKET_GLOBAL = MC_TICKET_BASE + 9 * 32;
@@ -29,10 +29,10 @@ struct McMat {
 
 struct McArgs {
     int batch, zdim, clusters;
+    unsigned long long wait_ticks;   // bound of a hand-off poll, in 10 ns ticks of the polling wave's own running time
     int debug_static;           // diagnostic build only (ARVAE_MIDC_STATIC): places by blockIdx instead of tickets
     int debug_drop;             // diagnostic build only (ARVAE_MIDC_DROP_ARRIVAL): one member never arrives at the first hand-off
-    int xcd_map;                // 1: the 16 members of a cluster have equal blockIdx.x % 8 (one XCD under round-robin dispatch:
-                                // speed only, never correctness); needs clusters % 8 == 0
+    int heads;                  // ticket heads the places of a pass are dealt from (4, 2 or 1; divides `clusters`): midcluster.hip
     unsigned *counters;         // one arrival counter per cluster, 32 words apart; multiples of MC_S between phases; behind
                                 // them (MC_TICKET_BASE) the ticket heads a pass hands its cluster places out from
     unsigned *status;           // sticky error word of the caller (arvae_image_vae_t.status) or null: a hand-off that
@@ -61,6 +61,7 @@ struct McArgs {
 };
 
 int64_t midc_counter_words(int batch);             // uint32 words of arrival counters a batch needs (zeroed by the prep launch)
+unsigned long long midc_wait_ticks();              // the default bound of a hand-off poll (10 ns ticks)
 int midc_resident_capacity();                      // clustered-kernel workgroups the device holds at once (occupancy x CUs)
 int midc_forward(const McArgs &a, hipStream_t s);
 int midc_backward(const McArgs &a, hipStream_t s);

@@ -13,14 +13,13 @@
 // their transposes in backward) is computed by every member for its cluster's rows, so a pass has three exchanges, not six.
 // Forward: 3 exchanges; backward: 3.  256 workgroups at B = 512, one per CU.
 //
-// Membership is decided AT RUN TIME, by tickets (mc_ticket): a workgroup that has started takes the next free place of a
-// cluster on the XCD it really runs on (HW_REG_XCC_ID; a head per XCD, a place on another XCD when its own has handed out its
-// share).  Members wait for each other, so what matters is that the workgroups that are RESIDENT form complete clusters: with
-// places handed out in order of arrival every 16 arrivals complete one, whichever 16 they are -- a grid that only partly fits
-// the device (another process holds CUs, a larger batch) runs cluster after cluster instead of waiting for workgroups that
-// cannot start.  (With places fixed by blockIdx, as through round 4, two processes sharing the device could each hold half of
+// Membership is decided AT RUN TIME, by tickets (mc_ticket): a workgroup that has started takes the next free place of the
+// next cluster (a few ticket heads, each serving every heads-th workgroup).  Members wait for each other, so what matters is
+// that the workgroups that are RESIDENT form complete clusters: with places handed out in order of arrival every 16 arrivals
+// on a head complete one, whichever 16 they are -- a grid that only partly fits the device (another process holds CUs, a larger
+// batch) runs cluster after cluster instead of waiting for workgroups that cannot start.  (With places fixed by blockIdx, as through round 4, two processes sharing the device could each hold half of
 // every cluster: a hang.)  What is left -- fewer than 16 places can ever be resident -- ends in mc_wait's bound: the poll gives
-// up after MC_WAIT_TICKS of its own running time, ORs a code into the caller's status word (arvae_image_vae_t.status) and the
+// up after MC_WAIT_TICKS (1 s) of its own running time, ORs a code into the caller's status word (arvae_image_vae_t.status) and the
 // workgroup leaves; the host raises on that word where it synchronises anyway and stays on the row kernels (midblock.hip).
 #include <mutex>
 
@@ -44,6 +43,18 @@ __device__ unsigned long long g_midc_stamps[2 * 256 * 16];     // [pass][workgro
 #define MC_STAMP(pass, slot) do { if (threadIdx.x == 0 && blockIdx.x < 256) g_midc_stamps[((pass) * 256 + blockIdx.x) * 16 + (slot)] = wall_clock64(); } while (0)
 #else
 #define MC_STAMP(pass, slot)
+#endif
+
+#ifdef ARVAE_DIAG
+// diagnostic build: what the first workgroups that gave up saw (arvae_debug_midc_failures)
+__device__ unsigned g_mc_fail_count;
+__device__ unsigned g_mc_fail[64][8];
+#define MC_FAIL_RECORD(code, target, seen, tk) do { const unsigned slot_ = atomicAdd(&g_mc_fail_count, 1u); if (slot_ < 64) { \
+    unsigned xcc_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_)); \
+    g_mc_fail[slot_][0] = (code); g_mc_fail[slot_][1] = blockIdx.x; g_mc_fail[slot_][2] = xcc_; g_mc_fail[slot_][3] = (target); \
+    g_mc_fail[slot_][4] = (seen); g_mc_fail[slot_][5] = (unsigned)wall_clock64(); g_mc_fail[slot_][6] = (tk); g_mc_fail[slot_][7] = 0; } } while (0)
+#else
+#define MC_FAIL_RECORD(code, target, seen, tk)
 #endif
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
@@ -151,45 +162,34 @@ __device__ __forceinline__ float mc_sum(const float *red, int row, int col) {
     return v;
 }
 
-// place b of the grid -> (cluster, member)
+// place b of the grid -> (cluster, member): b = h + heads * t
 __device__ __forceinline__ void mc_place(const McArgs &p, int b, int &cl, int &m) {
-    if (p.xcd_map) { cl = (b & 7) + 8 * (b >> 7); m = (b >> 3) & (MC_S - 1); }
-    else { cl = b / MC_S; m = b % MC_S; }
+    const int heads = p.heads, h = b % heads, t = b / heads;
+    cl = h + heads * (t / MC_S);
+    m = t % MC_S;
 }
 
-// This workgroup's place in the grid, handed out in order of arrival (see the top of the file); -1: none could be had (the
-// heads are corrupt: status word set).  xcd_map grids (a multiple of 8 clusters: every XCD hosts grid / 8 places, all members
-// of a cluster on one XCD): place = x + 8 t with t the ticket of head x, x the XCD this workgroup runs on while that head
-// has places left, else the next head that has.  Other grids: one global head.  The heads are zero at the start of a pass:
-// the pass clears them itself once every cluster is placed (mc_placed / mc_clear_heads), the step's prep launch clears everything.
+// This workgroup's place in the grid, handed out in order of arrival (see the top of the file); -1: none could be had (the heads
+// are corrupt: status word set).  The grid's places are dealt from p.heads heads (4, 2 or 1: the largest that divides the number
+// of clusters); a workgroup draws from head blockIdx % heads, so every head serves exactly grid / heads workgroups = whole
+// clusters, and ticket t of head h is place h + heads * t: cluster h + heads * (t / 16), member t % 16.  More heads = fewer
+// workgroups per atomic word (256 arrivals on ONE word take 2.8 us to serve, MI355X_MICROARCH.md "dequeue"; measured on the
+// kernels: one head +1.3 us per pass over places by blockIdx, four heads +0.5); fewer heads = progress with fewer resident
+// workgroups: a pass moves whenever one head has 16 resident drawers, i.e. with 15 * heads + 1 resident workgroups at the latest.
+// EIGHT heads (one per XCD) is what round 5 measured too few for: two processes at B = 512 on one device were each held to 15
+// workgroups per XCD for > 300 ms (the 16th member of every cluster not dispatched) in 1 of ~8 runs; with four heads a cluster
+// draws on two XCDs.  The heads are zero at the start of a pass: the pass clears them itself once every cluster is placed
+// (mc_placed / mc_clear_heads), the step's prep launch clears everything.
 constexpr unsigned MC_E_FWD = 1u, MC_E_BWD = 2u, MC_E_TICKET = 4u;     // = ARVAE_STATUS_HANDOFF_FWD / _BWD / _TICKET (arvae_hip.h)
 __device__ __forceinline__ int mc_ticket(const McArgs &p) {
     if (p.debug_static) return (int)blockIdx.x;          // diagnostic build, ARVAE_MIDC_STATIC: places by blockIdx (what tickets cost)
     __shared__ int place;
     if (threadIdx.x == 0) {
-        unsigned *tk = p.counters;
-        int b = -1;
-        if (!p.xcd_map) {
-            b = (int)__hip_atomic_fetch_add(tk + MC_TICKET_GLOBAL, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (b >= (int)gridDim.x) b = -1;
-        } else {
-            const unsigned cap = gridDim.x / 8;
-            unsigned x;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
-            x &= 7u;
-            unsigned t = __hip_atomic_fetch_add(tk + MC_TICKET_BASE + 32 * x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // (dispatch is round-robin over the XCDs, so this loop normally never runs; a head above cap reads as "full")
-            for (int tries = 0; t >= cap && tries < (1 << 16); ++tries) {
-                x = (x + 1) & 7u;
-                unsigned *head = tk + MC_TICKET_BASE + 32 * x;
-                unsigned cur = __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                while (cur < cap && !__hip_atomic_compare_exchange_strong(head, &cur, cur + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                                         __HIP_MEMORY_SCOPE_AGENT)) {}
-                if (cur < cap) t = cur;
-            }
-            if (t < cap) b = (int)(x + 8u * t);
-        }
+        const unsigned heads = (unsigned)p.heads, h = blockIdx.x % heads;
+        const unsigned t = __hip_atomic_fetch_add(p.counters + MC_TICKET_BASE + 32 * h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int b = t < gridDim.x / heads ? (int)(h + heads * t) : -1;
         if (b < 0 && p.status != nullptr) __hip_atomic_fetch_or(p.status, MC_E_TICKET, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (b < 0) MC_FAIL_RECORD(MC_E_TICKET, 0u, t, h);
         place = b;
     }
     __syncthreads();
@@ -231,9 +231,9 @@ __device__ __forceinline__ unsigned mc_publish(unsigned *ctr, bool arrive = true
 // two polls is time the wave was not running -- a context switch under a shared device -- and does not count).  On expiry the
 // status word takes `code` and every thread of the workgroup gets false: the caller returns.  The other members of the cluster
 // run into the same bound within microseconds of this one (they wait for the same arrivals).
-constexpr unsigned long long MC_WAIT_TICKS = 10ull * 1000 * 1000;      // 100 ms of polling
+constexpr unsigned long long MC_WAIT_TICKS = 100ull * 1000 * 1000;     // 1 s of polling
 constexpr unsigned long long MC_GAP_TICKS = 5000;                      // 50 us
-__device__ __forceinline__ bool mc_wait(unsigned *ctr, unsigned target, unsigned *status, unsigned code) {
+__device__ __forceinline__ bool mc_wait(unsigned *ctr, unsigned target, unsigned *status, unsigned code, unsigned long long limit = MC_WAIT_TICKS) {
     __shared__ int arrived;
     if (threadIdx.x == 0) {
         bool ok = true;
@@ -243,9 +243,10 @@ __device__ __forceinline__ bool mc_wait(unsigned *ctr, unsigned target, unsigned
             const unsigned long long now = wall_clock64(), dt = now - last;
             last = now;
             spent += dt < MC_GAP_TICKS ? dt : 0ull;
-            if (spent > MC_WAIT_TICKS) { ok = false; break; }
+            if (spent > limit) { ok = false; break; }
         }
         if (!ok && status != nullptr) __hip_atomic_fetch_or(status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!ok) MC_FAIL_RECORD(code, target, __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), (unsigned)(ctr - (unsigned *)nullptr));
         arrived = ok ? 1 : 0;
     }
     __syncthreads();
@@ -365,7 +366,7 @@ __device__ __forceinline__ void midc_forward_body(const McArgs &p, int place) {
     MC_STAMP(0, 2);
     const unsigned t0 = mc_publish(ctr, !(p.debug_drop != 0 && cl == 0 && m == 0));
     mc_load<ShHD>(p.hdf.w, wa);
-    if (!mc_wait(ctr, t0, p.status, MC_E_FWD)) return;
+    if (!mc_wait(ctr, t0, p.status, MC_E_FWD, p.wait_ticks)) return;
     MC_STAMP(0, 3);
     mc_gather(p.y_e0, row0, valid, bufB);
     MC_STAMP(0, 4);
@@ -380,7 +381,7 @@ __device__ __forceinline__ void midc_forward_body(const McArgs &p, int place) {
     MC_STAMP(0, 5);
     const unsigned t1 = mc_publish(ctr);
     mc_load<ShD0>(p.d0f.w, wb);
-    if (!mc_wait(ctr, t1, p.status, MC_E_FWD)) return;
+    if (!mc_wait(ctr, t1, p.status, MC_E_FWD, p.wait_ticks)) return;
     MC_STAMP(0, 6);
     mc_gather(p.y_e1, row0, valid, bufA);                     // (bufA with pitch PB from here on)
     MC_STAMP(0, 7);
@@ -432,7 +433,7 @@ __device__ __forceinline__ void midc_forward_body(const McArgs &p, int place) {
     }
     const unsigned t_last = mc_publish(ctr);
     const float2 b_d2 = p.d2f.bias != nullptr ? *reinterpret_cast<const float2 *>(p.d2f.bias + 32 * m + 2 * fc) : make_float2(0.f, 0.f);
-    if (!mc_wait(ctr, t_last, p.status, MC_E_FWD)) return;
+    if (!mc_wait(ctr, t_last, p.status, MC_E_FWD, p.wait_ticks)) return;
     const unsigned placed_before = mc_placed(p, m);
     MC_STAMP(0, 10);
     mc_gather(p.y_d1, row0, valid, bufA);
@@ -533,7 +534,7 @@ __device__ __forceinline__ void midc_backward_body(const McArgs &p, int place) {
     MC_STAMP(1, 2);
     const unsigned t2 = mc_publish(ctr);
     mc_load<ShZB>(p.d0b.w, wa);
-    if (!mc_wait(ctr, t2, p.status, MC_E_BWD)) return;
+    if (!mc_wait(ctr, t2, p.status, MC_E_BWD, p.wait_ticks)) return;
     MC_STAMP(1, 3);
     mc_gather(p.g_d1, row0, valid, bufB);
     MC_STAMP(1, 4);
@@ -548,7 +549,7 @@ __device__ __forceinline__ void midc_backward_body(const McArgs &p, int place) {
     MC_STAMP(1, 5);
     const unsigned t3 = mc_publish(ctr);
     mc_load<ShHB>(p.hdb.w, wb);
-    if (!mc_wait(ctr, t3, p.status, MC_E_BWD)) return;
+    if (!mc_wait(ctr, t3, p.status, MC_E_BWD, p.wait_ticks)) return;
     MC_STAMP(1, 6);
     mc_gather(p.g_d0, row0, valid, bufA);                     // (bufA with pitch PB from here on)
     MC_STAMP(1, 7);
@@ -610,7 +611,7 @@ __device__ __forceinline__ void midc_backward_body(const McArgs &p, int place) {
     const unsigned t_last = mc_publish(ctr);
     const int64_t xat = (int64_t)(row0 + (fon ? frow : 0)) * MC_K0 + 32 * m + 2 * fc;
     const float2 gate = p.gate0 != nullptr ? *reinterpret_cast<const float2 *>(p.gate0 + xat) : make_float2(1.f, 1.f);
-    if (!mc_wait(ctr, t_last, p.status, MC_E_BWD)) return;
+    if (!mc_wait(ctr, t_last, p.status, MC_E_BWD, p.wait_ticks)) return;
     const unsigned placed_before = mc_placed(p, m);
     MC_STAMP(1, 10);
     mc_gather(p.g_e0, row0, valid, bufA);
@@ -664,6 +665,7 @@ void allow_lds() {
 }  // namespace
 
 int64_t midc_counter_words(int) { return MC_COUNTER_WORDS; }
+unsigned long long midc_wait_ticks() { return MC_WAIT_TICKS; }
 
 // workgroups of the clustered kernels the device can hold at once: the occupancy the runtime reports for the heavier of the two
 // (512 threads, LDS_FLOATS of dynamic LDS) x the CU count.  The launcher takes the clustered kernels when the whole grid fits --
@@ -695,6 +697,13 @@ int midc_backward(const McArgs &a, hipStream_t s) {
 }
 
 }  // namespace arvae
+
+#ifdef ARVAE_DIAG
+extern "C" int arvae_debug_midc_failures(unsigned *out /* [1 + 64 * 8] */) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(arvae::g_mc_fail_count), sizeof(unsigned)) != hipSuccess) return -1;
+    return (int)hipMemcpyFromSymbol(out + 1, HIP_SYMBOL(arvae::g_mc_fail), sizeof(unsigned) * 64 * 8);
+}
+#endif
 
 #ifdef MIDC_STAMPS
 extern "C" int arvae_debug_midc_stamps(unsigned long long *out, int count) {

@@ -165,6 +165,10 @@ class Encoder(Model):
         weight / bias / embedding gradients follow from dP on num_notes rows instead of T*B.  The same algebra as
         encoder.py:111-114 (embedding, then nn.GRU's W_ih x + b_ih), re-associated.  -> (out, finals) or (None, None) when the
         two directions' projections are not adjacent in memory (ops.dense_pair)."""
+        # the lookup's backward is the wide-row segment sum (csrc/sequence.hip, embed_bwd_wide_kernel): its per-token accumulators
+        # and this batch's positions must fit 64 KB of LDS -- the decoder's lookup and FusedMeasureVAE.fits() test the same bound
+        if self.num_notes * 1024 + (steps * b + 15) // 16 * 8 > 65536:
+            return None, None
         wf, whf, bf, bhf = self.lstm.cell(0, '')
         wr, whr, br, bhr = self.lstm.cell(0, '_reverse')
         ptab = ops.dense_pair(self.note_embedding_layer.weight, wf, bf, wr, br)            # (num_notes, 2 * 3H)

@@ -30,10 +30,26 @@ one GPU, which is how the world-2 tests of the HIP path run on one-GPU boxes.
 """
 import ctypes
 import os
+import time
 
 import torch
 
 from . import _lib
+
+def _seconds(var, default):
+    try:
+        return float(os.environ.get(var, default))
+    except ValueError:
+        return float(default)
+
+
+# Deadlines of the multi-rank path (seconds; environment overrides for slow launchers).  Nothing in a data-parallel run waits
+# without one: the ranks' rendezvous at the store, ncclCommInitRank (arvae_comm_init's timeout), and every host wait for the
+# stream behind a collective (LibraryComm.wait_idle) -- a peer that died shows as RuntimeError on the survivors, which abort
+# their communicator and exit non-zero, so that the launcher (torch.distributed.run, bench.py's spawn_ranks: both end the
+# job when one rank fails) does not keep a hung job alive.
+JOIN_TIMEOUT_S = _seconds('ARVAE_DP_JOIN_TIMEOUT', 180)          # all ranks present at the store / inside ncclCommInitRank
+IDLE_TIMEOUT_S = _seconds('ARVAE_DP_TIMEOUT', 300)               # the stream behind a collective drains
 
 _DTYPES = {torch.float32: 0, torch.float64: 1, torch.int64: 2, torch.uint8: 3}
 _OPS = {'sum': 0, 'max': 1, 'min': 2}
@@ -49,6 +65,33 @@ class _StreamJoin:
 
     def wait(self):
         torch.cuda.current_stream().wait_event(self.event)
+
+
+def store_get(store, key, rank, timeout):
+    """store.get(key) with a deadline: RuntimeError when nobody has set the key within `timeout` seconds"""
+    deadline = time.monotonic() + timeout
+    while True:
+        try:
+            if store.check([key]):
+                return store.get(key)
+        except RuntimeError:
+            pass
+        if time.monotonic() > deadline:
+            raise RuntimeError(f'rank {rank}: rank 0 did not publish the RCCL id within {timeout:.0f} s')
+        time.sleep(0.01)
+
+
+def all_present(store, key, rank, world, timeout):
+    """every rank adds itself to the counter `key` and waits until all `world` have: RuntimeError after `timeout` seconds"""
+    store.add(key, 1)
+    deadline = time.monotonic() + timeout
+    while True:
+        here = int(store.add(key, 0))
+        if here >= world:
+            return
+        if time.monotonic() > deadline:
+            raise RuntimeError(f'rank {rank}: only {here} of {world} ranks reached the communicator set-up within {timeout:.0f} s')
+        time.sleep(0.01)
 
 
 class LibraryComm:
@@ -68,6 +111,7 @@ class LibraryComm:
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         torch.cuda.set_device(self.device)
         nbytes = 128
+        self.handle = None
         if self.rank == 0:
             buf = (ctypes.c_char * nbytes)()
             _lib.check(self.lib.arvae_comm_unique_id(buf), 'comm_unique_id')
@@ -75,14 +119,26 @@ class LibraryComm:
             if self.world_size > 1:
                 store.set(key, ident)
         else:
-            ident = bytes(store.get(key))                       # blocks until rank 0 has published it
+            ident = bytes(self._store_get(store, key))          # waits (with a deadline) until rank 0 has published it
         if len(ident) != nbytes:
             raise RuntimeError('bad RCCL unique id from the store')
+        if self.world_size > 1:
+            # every rank confirms that it holds the id and is about to enter ncclCommInitRank; nobody enters before all have
+            # confirmed -- a rank that died on the way here fails the others at THIS deadline, with a message, instead of leaving
+            # them inside RCCL
+            self._all_present(store, key + '/present')
         handle = ctypes.c_void_p()
-        _lib.check(self.lib.arvae_comm_init(ident, self.rank, self.world_size, ctypes.byref(handle)), 'comm_init')
+        _lib.check(self.lib.arvae_comm_init(ident, self.rank, self.world_size, int(JOIN_TIMEOUT_S * 1000), ctypes.byref(handle)),
+                   'comm_init')
         self.handle = handle
         self.store = store                                      # rank 0 hosts it: alive as long as the communicator
         self._self_test()
+
+    def _store_get(self, store, key):
+        return store_get(store, key, self.rank, JOIN_TIMEOUT_S)
+
+    def _all_present(self, store, key):
+        all_present(store, key, self.rank, self.world_size, JOIN_TIMEOUT_S)
 
     def _self_test(self):
         """three tiny collectives with known answers, once, right after the communicator is built: a mis-wired job (ranks on
@@ -94,7 +150,7 @@ class LibraryComm:
         self.all_gather(gathered, torch.full((4,), float(r), device=self.device))
         sent = torch.full((4,), float(r + 3), device=self.device)
         self.broadcast(sent, src=0)
-        torch.cuda.synchronize(self.device)
+        self.wait_idle()
         want = torch.arange(w, dtype=torch.float32).repeat_interleave(4)
         if not (bool((one == w * (w + 1) / 2).all()) and torch.equal(gathered.cpu(), want) and bool((sent == 3.0).all())):
             raise RuntimeError(f'RCCL self-test failed on rank {r} of {w}: all_reduce {one.tolist()}, all_gather {gathered.tolist()}, '
@@ -159,16 +215,46 @@ class LibraryComm:
         """every rank has reached this point and this device is idle"""
         token = torch.zeros(1, device=self.device, dtype=torch.float32)
         self.all_reduce(token)
-        torch.cuda.synchronize(self.device)
+        self.wait_idle()
+
+    def wait_idle(self, timeout=None):
+        """Host wait for everything enqueued on the current stream so far -- what torch.cuda.synchronize() does, except that it
+        cannot wait forever behind a collective whose peer has died: an event is recorded and polled, the communicator's
+        asynchronous error state is read BETWEEN the polls (RCCL reports a lost peer there), and a deadline bounds the rest.
+        On either, the communicator is aborted (its kernels leave the stream) and RuntimeError is raised."""
+        timeout = IDLE_TIMEOUT_S if timeout is None else timeout
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(self.device))
+        deadline = time.monotonic() + timeout
+        pause = 0.0
+        while not done.query():
+            try:
+                self.check()
+            except RuntimeError:
+                self.abort()
+                raise
+            if time.monotonic() > deadline:
+                self.abort()
+                raise RuntimeError(f'rank {self.rank}: the stream did not drain within {timeout:.0f} s behind a collective '
+                                   f'(a peer rank is gone or stuck); communicator aborted')
+            time.sleep(pause)
+            pause = min(0.002, pause + 0.0001)                  # the first polls spin: a step is a fraction of a millisecond
         self.check()
 
     def check(self):
         """raises once the communicator has failed asynchronously (a peer died mid-collective)"""
-        _lib.check(self.lib.arvae_comm_async_error(self.handle), 'communicator')
+        if self.handle is not None:
+            _lib.check(self.lib.arvae_comm_async_error(self.handle), 'communicator')
+
+    def abort(self):
+        """tear the communicator down without waiting for its peers (ncclCommAbort): after an error, before the process exits"""
+        handle, self.handle = self.handle, None
+        if handle is not None:
+            self.lib.arvae_comm_abort(handle)
 
     def close(self):
         if self.handle is not None:
-            torch.cuda.synchronize(self.device)
+            self.wait_idle()
             handle, self.handle = self.handle, None
             _lib.check(self.lib.arvae_comm_destroy(handle), 'comm_destroy')
 
@@ -219,6 +305,13 @@ class TorchComm:
             torch.cuda.synchronize()
 
     def check(self):
+        pass
+
+    def wait_idle(self, timeout=None):
+        if torch.cuda.is_available() and self.device.type == 'cuda':
+            torch.cuda.synchronize()
+
+    def abort(self):
         pass
 
     def close(self):
@@ -357,9 +450,16 @@ class DataParallel:
 
     def finish(self):
         """all ranks are done training: leave the job (after this, rank 0 may evaluate for as long as it likes -- nobody
-        waits in a collective)"""
+        waits in a collective).  The communicator's error state is read first and while the last barrier drains: a rank
+        that lost a peer raises here instead of waiting."""
+        self.comm.check()
         self.comm.barrier()
         self.comm.close()
+
+    def abort(self):
+        """after an exception in the training loop: give up the communicator without waiting for the other ranks; the caller
+        then exits non-zero and the launcher ends the job"""
+        self.comm.abort()
 
     def broadcast_parameters(self, model, src=0):
         """Make every replica start from rank `src`'s weights."""
@@ -442,4 +542,5 @@ class DataParallel:
         """host floats -> their means over ranks (epoch statistics: one float64 all-reduce)"""
         stats = torch.tensor(list(values), dtype=torch.float64, device=device)
         self.comm.all_reduce(stats)
+        self.comm.wait_idle()                                    # once per epoch: the bounded wait + the communicator's error state
         return (stats / self.world_size).tolist()

@@ -24,7 +24,10 @@ Prints ONE JSON line (rank 0).  Extra objects in the line:
                 rocprofv3 --kernel-trace of this command shows for that label
   cpu_baseline  the CPU oracle (oracle/step.py, a port: the reference's Python cannot travel) timed on this box's host
                 cores on a bounded sample of the same workload (rank 0, N = 1 only), all cores and 8 threads
-  secondary     (default run, N = 1) the Morpho-MNIST B=1024 and MeasureVAE B=256 steps, same timing rules
+  secondary     (default run, N = 1) the Morpho-MNIST B=1024 and MeasureVAE B=256 steps, same timing rules; N > 1: the MeasureVAE
+                step, 256 measures per rank (BASELINE.json configs[4], weak scaling)
+  dp            (N > 1 or --force-dp) HIP-event cost of the step's gradient all-reduce and grouped all-gather in isolation,
+                and (N > 1) ms per step with the collectives on the launch stream vs the overlap schedule
 """
 import argparse
 import json
@@ -243,9 +246,13 @@ class Fence:
         return self.comm is not None
 
     def __call__(self):
+        if self.comm is not None and hasattr(self.comm, 'wait_idle'):
+            self.comm.wait_idle()                        # = synchronize, but bounded and watching the communicator's error state
+            self.comm.barrier()                          # a one-element all-reduce + (bounded) wait: every rank is here and idle
+            return
         torch.cuda.synchronize()
         if self.comm is not None:
-            self.comm.barrier()                          # a one-element all-reduce + synchronize: every rank is here and idle
+            self.comm.barrier()
 
     def max_over_ranks(self, seconds):
         if self.comm is None:
@@ -535,6 +542,58 @@ def cpu_baseline(batch, state, budget_s=18.0):
     return out
 
 
+# ---- data-parallel extras (N > 1, or --force-dp): where a multi-rank step's time goes ---------------------------------
+def dp_collective_costs(trainer, batch, device, reps=20):
+    """HIP-event time of the step's two exchanges in isolation, back to back on the launch stream: the SUM all-reduce of a
+    gradient-arena-sized buffer and the grouped all-gather of z and the labels (us per call, max over ranks)."""
+    dp = trainer.data_parallel
+    arena = torch.zeros_like(trainer.optimizer.grad_arena)
+    z = torch.zeros(batch, trainer.model.z_dim, device=device)
+    lab = torch.zeros(batch, 6, device=device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    out = {'grad_arena_bytes': arena.numel() * 4, 'gathered_bytes_per_rank': (z.numel() + lab.numel()) * 4}
+    for name, call in (('all_reduce_us', lambda: COMM.all_reduce(arena)), ('all_gather_us', lambda: dp.gather_many([z, lab]))):
+        for _ in range(3):
+            call()
+        COMM.barrier()
+        e0.record()
+        for _ in range(reps):
+            call()
+        e1.record()
+        COMM.wait_idle()
+        t = torch.tensor([e0.elapsed_time(e1) * 1e3 / reps], device=device, dtype=torch.float64)
+        COMM.all_reduce(t, 'max')
+        out[name] = float(t)
+    return out
+
+
+def dp_overlap_trial(step, fence, steps=60, warm=10):
+    """ms per step with the gradient all-reduce / column all-gather on the launch stream (the default) and with the overlap
+    schedule (ARVAE_DP_OVERLAP=1: per-bucket all-reduces on a side stream behind the executor's milestone events), same
+    ranks, same inputs, a few dozen steps each way -- the numbers that decide the default at W >= 2."""
+    res = {}
+    old = os.environ.get('ARVAE_DP_OVERLAP')
+    try:
+        for tag, val in (('launch_stream', '0'), ('overlap', '1'), ('launch_stream_again', '0')):
+            os.environ['ARVAE_DP_OVERLAP'] = val
+            for i in range(warm):
+                step(i)
+            fence()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                step(i)
+            fence()
+            res[tag + '_ms_per_step'] = 1e3 * fence.max_over_ranks(time.perf_counter() - t0) / steps
+    finally:
+        if old is None:
+            os.environ.pop('ARVAE_DP_OVERLAP', None)
+        else:
+            os.environ['ARVAE_DP_OVERLAP'] = old
+    base = min(res['launch_stream_ms_per_step'], res['launch_stream_again_ms_per_step'])
+    res['overlap_faster'] = bool(res['overlap_ms_per_step'] < 0.98 * base)
+    return res
+
+
 # ---- the headline workload ---------------------------------------------------------------------------------------------
 def run_dsprites(device, args, fence, rank, world, use_dp):
     from arvae_amd import synthetic as syn
@@ -567,6 +626,17 @@ def run_dsprites(device, args, fence, rank, world, use_dp):
         v['flop'] = 2.0 * macs * b * v['calls']
         v['bytes'] = (float(nbytes) * b + fixed) * v['calls']
     fence()
+    dp_info = None
+    if use_dp and hasattr(COMM, 'wait_idle') and b == 512:
+        # (every rank runs these: they are collectives)  The trial comes LAST and under a short deadline: the overlap schedule has
+        # never met a second rank on hardware available to this build, and a failure there must not cost the headline line
+        dp_info = {'world': world, 'collectives_on': 'launch stream (ARVAE_DP_OVERLAP unset)' if os.environ.get('ARVAE_DP_OVERLAP', '0') != '1' else 'side stream (ARVAE_DP_OVERLAP=1)'}
+        try:
+            dp_info.update(dp_collective_costs(trainer, b, device))
+            dp_info['share_of_step'] = (dp_info['all_reduce_us'] + dp_info['all_gather_us']) / (1e6 * med / args.steps)
+        except Exception as e:
+            dp_info['collective_costs_error'] = f'{type(e).__name__}: {e}'
+    run_dsprites.trial = (lambda: dp_overlap_trial(step, fence)) if dp_info is not None and world > 1 else None
     if rank != 0:
         return None
 
@@ -652,6 +722,7 @@ def run_dsprites(device, args, fence, rank, world, use_dp):
                        ' (RCCL %d via libarvae_hip.so, launch stream)' % COMM.rccl_version if hasattr(COMM, 'rccl_version') else
                        ' (gloo on the host under device tensors: tests)' if type(COMM).__name__ == 'StagedComm' else ' (torch.distributed nccl group)'),
                    'images_per_sec_per_gpu': per_gpu, 'final_loss': final_loss},
+        'dp': dp_info,
         'timing': timing,
         'roofline': roof,
         'step_roofline': {
@@ -738,14 +809,43 @@ def main():
                 except Exception as e:                              # the headline line must not depend on a side workload
                     sec[kind] = {'error': f'{type(e).__name__}: {e}'}
             line['secondary'] = sec
+    comm_ok = True
+    if args.workload == 'dsprites' and use_dp and world > 1 and not args.no_secondary and args.batch == 512:
+        # BASELINE.json configs[4] ("MeasureVAE batch = 256, 1 -> 8 MI355X DP"): weak scaling, 256 measures per rank, the executor's
+        # data-parallel path (forward to z, grouped all-gather, arvae_measure_vae_finish, backward, all-reduce, Adam) -- every
+        # rank runs it, rank 0 reports it beside the headline
+        try:
+            r = run_side('measure', device, args, fence, rank, world, True, with_cpu=False)
+            if line is not None:
+                line['secondary'] = {'measure': {k: r[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'ms_per_step', 'steps', 'config', 'timing',
+                                                                  'step_roofline', 'roofline') if k in r}}
+        except Exception as e:
+            comm_ok = COMM is not None and getattr(COMM, 'handle', True) is not None
+            if line is not None:
+                line['secondary'] = {'measure': {'error': f'{type(e).__name__}: {e}'}}
+    trial = getattr(run_dsprites, 'trial', None) if args.workload == 'dsprites' else None
+    if trial is not None and comm_ok:
+        from arvae_amd import parallel
+        parallel.IDLE_TIMEOUT_S = min(parallel.IDLE_TIMEOUT_S, 60.0)
+        try:
+            res = trial()
+        except Exception as e:                                       # (wait_idle has aborted the communicator by now)
+            res = {'error': f'{type(e).__name__}: {e}'}
+            comm_ok = False
+        if line is not None and line.get('dp') is not None:
+            line['dp']['overlap_trial'] = res
     if rank == 0 and line is not None:
         if out_fd is None:
             print(json.dumps(line), flush=True)
         else:
             os.write(out_fd, (json.dumps(line) + '\n').encode())
-    if COMM is not None:
+    if COMM is not None and comm_ok:
         COMM.barrier()
         COMM.close()
+    elif COMM is not None:
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)                           # the communicator is gone: do not wait for anybody on the way out (the line says why)
 
 
 if __name__ == '__main__':

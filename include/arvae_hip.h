@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ARVAE_ABI_VERSION 10  /* 10: arvae_image_vae_t.status / .flags (a sticky device status word: an in-launch hand-off between workgroups that gives up says so there instead of hanging; ARVAE_VAE_NO_CLUSTER keeps the pass on kernels without such hand-offs); 9: arvae_measure_vae_* (whole-model MeasureVAE step), row strides for h0 / dh0 / the beat embeddings (arvae_gru_seq_t, arvae_tick_*); 8: arvae_gru_seq_t.gi_rstride / dgi_rstride / h_fin (merged input projections of a bidirectional layer, final states written by the sequence launch); 7: arvae_comm_* (the data-parallel step's collectives: RCCL on the launch stream, owned by the library); 6: the 32-channel k4 s2 p1 links need caller workspace too (arvae_link_ws_floats / arvae_link_wgrad_ws_floats: the layer's weights as scaled fp16 terms and the operands' maxima); 5: arvae_adam_step(zero_grad), arvae_image_vae_finish, arvae_image_vae_t.milestones (events the executors record for the data-parallel caller's collectives); 4: arvae_philox_* and in-kernel eps (arvae_image_vae_t.rng_*), arvae_tick_free_run_supported, caller workspace for arvae_link_down/up (arvae_link_ws_floats); 3: arvae_gru_seq_*, embed_bwd workspace; 2: arvae_image_vae_backward reg_fused == 2 (unit regulariser gradient in dz_extra) */
+#define ARVAE_ABI_VERSION 10  /* 10: arvae_comm_init(timeout_ms); arvae_image_vae_t.status / .flags (a sticky device status word: an in-launch hand-off between workgroups that gives up says so there instead of hanging; ARVAE_VAE_NO_CLUSTER keeps the pass on kernels without such hand-offs); 9: arvae_measure_vae_* (whole-model MeasureVAE step), row strides for h0 / dh0 / the beat embeddings (arvae_gru_seq_t, arvae_tick_*); 8: arvae_gru_seq_t.gi_rstride / dgi_rstride / h_fin (merged input projections of a bidirectional layer, final states written by the sequence launch); 7: arvae_comm_* (the data-parallel step's collectives: RCCL on the launch stream, owned by the library); 6: the 32-channel k4 s2 p1 links need caller workspace too (arvae_link_ws_floats / arvae_link_wgrad_ws_floats: the layer's weights as scaled fp16 terms and the operands' maxima); 5: arvae_adam_step(zero_grad), arvae_image_vae_finish, arvae_image_vae_t.milestones (events the executors record for the data-parallel caller's collectives); 4: arvae_philox_* and in-kernel eps (arvae_image_vae_t.rng_*), arvae_tick_free_run_supported, caller workspace for arvae_link_down/up (arvae_link_ws_floats); 3: arvae_gru_seq_*, embed_bwd workspace; 2: arvae_image_vae_backward reg_fused == 2 (unit regulariser gradient in dz_extra) */
 
 #define ARVAE_OK 0
 #define ARVAE_E_INVALID (-1)  /* bad argument (null pointer, size out of range, unsupported shape) */
@@ -612,7 +612,9 @@ int arvae_count_out_of_range(const int64_t *indices, int64_t count, int64_t lo, 
  *   arvae_comm_available  -> RCCL's version code (> 0) or ARVAE_E_COMM with the reason in arvae_last_error_string()
  *   arvae_comm_unique_id  -> ARVAE_COMM_ID_BYTES host bytes; rank 0 creates them, the caller's launcher (a TCP store, MPI, a
  *                            file) hands them to every other rank
- *   arvae_comm_init       -> blocks until all `world` ranks have joined, on the CURRENT HIP device
+ *   arvae_comm_init       -> waits until all `world` ranks have joined, on the CURRENT HIP device, for at most timeout_ms
+ *                            (0: no deadline); ARVAE_E_COMM after the deadline: RCCL cannot be called back from a half-built
+ *                            communicator, so the process must exit then
  *   arvae_comm_async_error-> 0, or ARVAE_E_COMM once the communicator has failed asynchronously (a peer died)
  * dtype: ARVAE_COMM_*; `count` in elements (per rank for the all-gather: recv holds world x count, rank-major).
  * all_reduce and broadcast work in place.
@@ -628,7 +630,7 @@ int arvae_count_out_of_range(const int64_t *indices, int64_t count, int64_t lo, 
 typedef struct arvae_comm_s *arvae_comm_t;
 int arvae_comm_available(void);
 int arvae_comm_unique_id(void *id_out /* host */);
-int arvae_comm_init(const void *id /* host */, int32_t rank, int32_t world, arvae_comm_t *out /* host */);
+int arvae_comm_init(const void *id /* host */, int32_t rank, int32_t world, int32_t timeout_ms, arvae_comm_t *out /* host */);
 int arvae_comm_destroy(arvae_comm_t comm);
 int arvae_comm_abort(arvae_comm_t comm);
 int arvae_comm_rank(arvae_comm_t comm);

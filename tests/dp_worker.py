@@ -58,6 +58,7 @@ def main():
         mean_acc = float(dp.mean_scalar(acc.detach()))
         terms = {k: float(dp.mean_scalar(v)) for k, v in trainer.last_terms.items() if v is not None}
         torch.cuda.synchronize()
+        trainer.check_device_status()                          # (a hand-off of the clustered latent block that gave up raises here)
         if rank == 0:
             np.savez(out, loss=mean_loss, acc=mean_acc, world=dp.world_size, transport=type(comm).__name__,
                      **{'term/' + k: v for k, v in terms.items()}, **{'grad/' + k: v for k, v in grads.items()},

@@ -89,6 +89,16 @@ def main():
         same &= (loss.detach() == ref_loss).all() & (trainer.optimizer.grad_arena == ref_grad).all()
     torch.cuda.synchronize()
     seconds = time.time() - t0
+    if os.environ.get('ARVAE_MIDC_DUMP'):                     # diagnostic library: what the workgroups that gave up saw
+        import ctypes
+        from arvae_amd import _lib
+        buf = (ctypes.c_uint32 * (1 + 64 * 8))()
+        if _lib.load().arvae_debug_midc_failures(buf) == 0 and buf[0]:
+            rows = [list(buf[1 + 8 * i:1 + 8 * i + 7]) for i in range(min(int(buf[0]), 64))]
+            t0 = min(r[5] for r in rows)
+            print(f'{buf[0]} give-ups; (code, block, xcc, target, seen, t - t0 [10 ns], ctr index):', file=sys.stderr)
+            for r in sorted(rows, key=lambda r: (r[5] - t0) & 0xffffffff):
+                print('   ', r[0], r[1], r[2] & 0xf, r[3], r[4], (r[5] - t0) & 0xffffffff, r[6] % 4096, file=sys.stderr)
     trainer.check_device_status()                             # raises (exit 1) if a hand-off gave up
     grads = {k: p.grad.detach().cpu().numpy() for k, p in model.named_parameters()}
     np.savez(out, loss=float(ref_loss), acc=float(one.acc), same=bool(same), seconds=seconds, first_seconds=first_seconds, raised=raised,

@@ -159,9 +159,9 @@ def test_comm_entry_points_without_a_gpu(lib):
     assert bytes(a) != bytes(b) and bytes(a) != bytes(128)
     assert lib.arvae_comm_unique_id(None) == -1
     handle = ctypes.c_void_p()
-    assert lib.arvae_comm_init(bytes(a), 2, 2, ctypes.byref(handle)) == -1     # rank out of range: refused before RCCL is called
+    assert lib.arvae_comm_init(bytes(a), 2, 2, 1000, ctypes.byref(handle)) == -1     # rank out of range: refused before RCCL is called
     assert b'rank 2 of 2' in lib.arvae_last_error_string()
-    assert lib.arvae_comm_init(None, 0, 1, ctypes.byref(handle)) == -1
+    assert lib.arvae_comm_init(None, 0, 1, 1000, ctypes.byref(handle)) == -1
     fake = ctypes.create_string_buffer(64)                                     # not a communicator: the magic word is missing
     for call in (lambda: lib.arvae_comm_destroy(fake), lambda: lib.arvae_comm_rank(fake), lambda: lib.arvae_comm_world(fake),
                  lambda: lib.arvae_comm_async_error(fake),

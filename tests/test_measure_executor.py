@@ -212,5 +212,16 @@ def test_trainer_falls_back_to_the_per_layer_path(dev):
         sc = torch.from_numpy(syn.measure_batch(b, seed=40 + b)).to(dev)
         eps = torch.from_numpy(syn.normal_noise((b, 32), seed=41))
         _same(_one_step(trainer2, model2, sc, True, True, eps), _one_step(trainer2, model2, sc, False, True, eps), ('edge', b))
-    big = torch.from_numpy(syn.measure_batch(2048, seed=1)).to(dev)
-    assert trainer2.fused_executor(big) is None               # (24 x 2048 positions do not fit the segment sums' LDS: per-layer path)
+    # 24 x 4096 positions do not fit the segment sums' LDS (V = 35: fits() turns false above B = 2389): the executor declines and
+    # the per-layer path must take the whole step -- both lookups fall back to embedding + GEMM (the encoder's did not)
+    big = torch.from_numpy(syn.measure_batch(4096, seed=1)).to(dev)
+    trainer2.use_fused_step = True
+    assert trainer2._fused_binding() is not None and not trainer2._fused_binding().fits(4096)
+    assert trainer2.fused_executor(big) is None
+    model2.train()
+    model2.decoder.teacher_forcing_prob = 2.0
+    trainer2.zero_grad()
+    loss, _ = trainer2.loss_and_acc_for_batch((big, big), 0, 0, True)
+    trainer2.backward(loss)
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss) and torch.isfinite(trainer2.optimizer.grad_arena).all() and trainer2.optimizer.grad_arena.abs().sum() > 0

@@ -176,3 +176,26 @@ def test_ranks_meet_at_the_launchers_store(launcher):
         outs = [p.communicate(timeout=300)[0] for p in procs]
         for rk, (p, o) in enumerate(zip(procs, outs)):
             assert p.returncode == 0 and f'rank {rk} of 2 ok' in o, o[-3000:]
+
+
+def test_rendezvous_waits_are_bounded():
+    """The two waits in front of ncclCommInitRank (parallel.LibraryComm.__init__) end by themselves: a rank whose peers never
+    arrive gets RuntimeError after the deadline instead of waiting in the store (or, later, inside RCCL) forever."""
+    import socket
+    from datetime import timedelta
+    from torch.distributed import TCPStore
+    from arvae_amd import parallel
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    store = TCPStore('127.0.0.1', port, 1, True, timeout=timedelta(seconds=30), wait_for_workers=False)
+    import time
+    t0 = time.monotonic()
+    with pytest.raises(RuntimeError, match='only 1 of 2 ranks'):
+        parallel.all_present(store, 'k/present', 0, 2, 0.5)
+    with pytest.raises(RuntimeError, match='did not publish'):
+        parallel.store_get(store, 'k/id', 1, 0.5)
+    assert time.monotonic() - t0 < 10
+    parallel.all_present(store, 'k/alone', 0, 1, 0.5)                 # complete groups pass
+    store.set('k/id', b'x' * 128)
+    assert bytes(parallel.store_get(store, 'k/id', 1, 0.5)) == b'x' * 128

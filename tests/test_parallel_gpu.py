@@ -106,6 +106,35 @@ def test_rccl_ranks_equal_single_process(tmp_path, golden_dir, world, capacity, 
         assert (np.abs(d_got - d_ref) > 2e-5).mean() <= 2e-3, name
 
 
+@pytest.mark.parametrize('world,transport', [(2, 'staged'), (2, 'library')])
+def test_ranks_at_the_headline_batch_equal_single_process(tmp_path, world, transport):
+    """BASELINE.json configs[3] as far as a box allows: every rank holds the HEADLINE per-GPU batch of 512 rows (global batch
+    1024) -- the clustered latent block (16 clusters per rank), arvae_image_vae_finish and a regulariser whose gathered columns
+    reach beyond one rank's batch, in one step -- against the oracle's single-process step on the whole batch.  'staged': both
+    ranks on whatever GPUs the box has (one: they share cuda:0 -- two processes in the clustered kernels at once, as in
+    tests/test_hip_parity.py::test_two_processes_share_the_device); 'library': RCCL, needs two GPUs."""
+    _needs(world, transport)
+    b_total = 512 * world
+    got = _run_ranks(world, str(tmp_path / 'dp512.npz'), 0.0, True, transport=transport, args=[0.0, 1, b_total])
+    assert int(got['world']) == world
+    state = syn.synth_state(o_vae.DSPRITES_SHAPES, 1, 1.6)
+    x, lab = syn.dsprites_batch(b_total, seed=1234)
+    eps = syn.normal_noise((b_total, 10), seed=12)
+    ref = o_step.image_step('dsprites', state, x, lab, eps, (1, 2, 3, 4, 5), 4.0, 10.0, 1.0)
+    np.testing.assert_allclose(got['loss'], float(ref['terms']['loss']), rtol=1e-4)
+    np.testing.assert_allclose(got['acc'], float(ref['terms']['acc']), rtol=1e-4)
+    for k in ('recons', 'dist', 'reg'):
+        np.testing.assert_allclose(got['term/' + k], float(ref['terms'][k]), rtol=1e-4)
+    for name in state:
+        gr = got['grad/' + name].astype(np.float64).ravel()
+        want = ref['grads'][name].astype(np.float64).ravel()
+        np.testing.assert_allclose(np.linalg.norm(gr), np.linalg.norm(want), rtol=1e-3, err_msg=name)
+        assert np.linalg.norm(gr - want) <= 2e-3 * np.linalg.norm(want) + 1e-9, name
+        d_got = got['param/' + name].astype(np.float64).ravel() - state[name].astype(np.float64).ravel()
+        d_ref = ref['params'][name].astype(np.float64).ravel() - state[name].astype(np.float64).ravel()
+        np.testing.assert_allclose(np.linalg.norm(d_got), np.linalg.norm(d_ref), rtol=2e-3, err_msg=name)
+
+
 @pytest.mark.parametrize('world', [1, 2])
 def test_rccl_overlapped_collectives_change_nothing(tmp_path, world):
     """the z all-gather behind the forward pass's z_ready event and the two gradient buckets all-reduced behind the backward

@@ -85,15 +85,23 @@ def main(dataset_type, batch_size, num_epochs, lr, beta, capacity, gamma, delta,
     if train:
         if not torch.cuda.is_available():
             raise SystemExit('training needs a GPU: the AR-VAE path has no CPU fallback')
-        for seed in seeds:
-            model, trainer = build(seed)
-            trainer.cuda()
+        try:
+            for seed in seeds:
+                model, trainer = build(seed)
+                trainer.cuda()
+                if dp is not None:
+                    dp.attach(trainer)
+                trainer.train_model(batch_size=batch_size, num_epochs=num_epochs, log=log)
+                trainer.data_parallel = None
             if dp is not None:
-                dp.attach(trainer)
-            trainer.train_model(batch_size=batch_size, num_epochs=num_epochs, log=log)
-            trainer.data_parallel = None
-        if dp is not None:
-            dp.finish()
+                dp.finish()
+        except BaseException:
+            # a rank that fails must not leave its peers waiting in a collective: give the communicator up without waiting for
+            # them (ncclCommAbort) and let the error end this process non-zero -- the launcher then ends the other ranks, whose
+            # own bounded waits (parallel.LibraryComm.wait_idle) raise in the meantime
+            if dp is not None:
+                dp.abort()
+            raise
     if not chief:
         return
     for seed in seeds:
