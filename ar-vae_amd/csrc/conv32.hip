@@ -812,11 +812,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // The decoder's first convolution (4x4 -> 8x8: a few tiles per CU, 6.5 us) and the all-pairs attribute regularisation of the
 // same forward pass (regloss.h: ~65 workgroups, 6.3 us, needs only z and the labels) in ONE grid: workgroups [0, grid_up) run
 // the convolution, the rest the regulariser's (row block, dim) pairs, staging their columns in the launch's dynamic LDS.
-template <int MODE>
+// (LO = 8 since round 5: when the latent block computes the 4x4 -> 8x8 layer itself, the regulariser rides with the next one)
+template <int LO, int MODE>
 __global__ __launch_bounds__(256, 1) void up32x_reg_kernel(const float *__restrict__ lo, Ep32 ep, int n_img,
                                                             int n_tiles, int grid_up, RegArgs reg, int reg_bx) {
     if ((int)blockIdx.x < grid_up) {
-        up32x_body<4, MODE, 32>(lo, ep, n_img, n_tiles, blockIdx.x, grid_up);
+        up32x_body<LO, MODE, 32>(lo, ep, n_img, n_tiles, blockIdx.x, grid_up);
         return;
     }
     extern __shared__ __attribute__((aligned(16))) float reg_lds[];
@@ -1148,18 +1149,27 @@ template <int LO> static int launch_up(const arvae_link_t *l, const Operand &lo,
 // the same grid (up32x_reg_kernel); false: not that case, launch the two separately
 bool conv32_up_reg_fits(const arvae_link_t *l) {
     static const bool off = diag_env("ARVAE_NO_PAIR_REG") != nullptr || diag_env("ARVAE_NO_SMALL_TILES") != nullptr;
-    return !off && conv32_fits(l) && l->lh == 4 && 2 * tiles_for<4, 128>(l->n) <= cu_count();
+    return !off && conv32_fits(l) && ((l->lh == 4 && 2 * tiles_for<4, 128>(l->n) <= cu_count()) ||
+                                      (l->lh == 8 && tiles_for<8, 128>(l->n) <= cu_count()));      // (the cases launch_up_v runs on 32-pixel tiles)
 }
 int conv32_up_reg(const arvae_link_t *l, const Operand &lo, const float *bias, uint16_t *bits_out, float *out, const float *wprep,
                   const unsigned *amax_in, unsigned *amax_out, const RegArgs &reg, int r, hipStream_t s) {
     ARVAE_REQUIRE(wprep != nullptr && amax_in != nullptr, "conv32_up_reg: prepared weights and the input's maxima are needed");
     Ep32 ep{bias, nullptr, nullptr, bits_out, out, reinterpret_cast<const uint4 *>(wprep), amax_in, amax_out};
+    const int reg_bx = (int)((reg.n_rows + REG_ROWS_PER_BLOCK - 1) / REG_ROWS_PER_BLOCK);
+    if (l->lh == 8) {
+        const int tiles = tiles_for<8, 32>(l->n), grid_up = grid_for_tiles(tiles);
+        constexpr int LDSX8 = MaxOf<2 * PatchLoader<8, 1, 32>::PLANE_DW, 2 * REG_CHUNK>::value * 4;
+        static std::once_flag attr8;
+        std::call_once(attr8, [&] { allow_lds(up32x_reg_kernel<8, EP_RELU>, LDSX8); });
+        ARVAE_LAUNCH((up32x_reg_kernel<8, EP_RELU>), dim3(grid_up + reg_bx * r), dim3(256), LDSX8, s, lo.v, ep, l->n, tiles, grid_up, reg, reg_bx);
+        return check_launch("up32_kernel<8>(+ reg_loss)");
+    }
     const int tiles = tiles_for<4, 32>(l->n), grid_up = grid_for_tiles(tiles);
     constexpr int LDSX = MaxOf<2 * PatchLoader<4, 1, 32>::PLANE_DW, 2 * REG_CHUNK>::value * 4;
     static std::once_flag attr;
-    std::call_once(attr, [&] { allow_lds(up32x_reg_kernel<EP_RELU>, LDSX); });
-    const int reg_bx = (int)((reg.n_rows + REG_ROWS_PER_BLOCK - 1) / REG_ROWS_PER_BLOCK);
-    ARVAE_LAUNCH((up32x_reg_kernel<EP_RELU>), dim3(grid_up + reg_bx * r), dim3(256), LDSX, s, lo.v, ep, l->n, tiles, grid_up, reg, reg_bx);
+    std::call_once(attr, [&] { allow_lds(up32x_reg_kernel<4, EP_RELU>, LDSX); });
+    ARVAE_LAUNCH((up32x_reg_kernel<4, EP_RELU>), dim3(grid_up + reg_bx * r), dim3(256), LDSX, s, lo.v, ep, l->n, tiles, grid_up, reg, reg_bx);
     return check_launch("up32_kernel<4>(+ reg_loss)");
 }
 
@@ -1200,7 +1210,7 @@ int conv32_weight_prep_with_mid(const float *const *wts, float *const *preps, in
         p.out[i] = reinterpret_cast<uint4 *>(preps[i]);
     }
     const int conv_blocks = 16 * n_layers;
-    ARVAE_LAUNCH(prep_all_kernel, dim3(conv_blocks + mid.blk_end[mid.count - 1]), dim3(256), 0, s, p, mid, conv_blocks);
+    ARVAE_LAUNCH(prep_all_kernel, dim3(conv_blocks + mid_prep_blocks(mid)), dim3(256), 0, s, p, mid, conv_blocks);
     return check_launch("weight_prep(conv32 + latent block)");
 }
 

@@ -424,7 +424,7 @@ int conv_c1_down_with_prep(const arvae_link_t *l, const Operand &img, const floa
         p.wt[i] = prep_wts[i];
         p.out[i] = reinterpret_cast<uint4 *>(preps[i]);
     }
-    const int conv_blocks = 16 * n_prep, prep_blocks = conv_blocks + mid.blk_end[mid.count - 1];
+    const int conv_blocks = 16 * n_prep, prep_blocks = conv_blocks + mid_prep_blocks(mid);
     const int n_rows = l->n * LO1;
     int grid = 256 * 16 / 4;                                     // as conv_c1_down: workgroups of four independent waves
     if (grid > (n_rows + 3) / 4) grid = (n_rows + 3) / 4;

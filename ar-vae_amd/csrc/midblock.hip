@@ -458,7 +458,38 @@ static int64_t midc_floats(const arvae_image_vae_t *m, int ne, int nd) {
     int64_t total = MIDC_COUNTER_WORDS;
     for (int i = 0; i < ne; ++i) total += 2 * midc_mat_floats(m->enc[m->n_enc - ne + i].link.chi, m->enc[m->n_enc - ne + i].link.clo);
     for (int i = 0; i < nd; ++i) total += 2 * midc_mat_floats(m->dec[i].link.chi, m->dec[i].link.clo);
-    return total + 2 * midc_mat_floats(m->head_mu.link.chi, 32);
+    return total + 2 * midc_mat_floats(m->head_mu.link.chi, 32) + 2 * 2 * 16384;     // + the two folded conv layers' matrices
+}
+
+static bool midc_use(bool cluster_ok, int batch, int flags);
+
+// The conv layers on either side of the block that the clustered kernels can compute themselves (midcluster.h, McArgs.fold): the
+// encoder's last conv layer (Conv2d 8x8 -> 4x4, 32 <-> 32 channels, ReLU, no dropout) whose input is a ReLU layer's output too,
+// and the decoder's first transposed one (4x4 -> 8x8, ReLU, no dropout), on the block's 512-wide edges (imagevae/dsprites_vae.py:
+// 18-20, 38-39).  Both or none.
+static bool conv_fold_layer_ok(const arvae_layer_t &l, bool up) {
+    const arvae_link_t &k = l.link;
+    return (l.is_up != 0) == up && k.chi == 32 && k.clo == 32 && k.kh == 4 && k.kw == 4 && k.stride == 2 && k.pad == 1 && k.hh == 8 &&
+           k.hw == 8 && k.lh == 4 && k.lw == 4 && k.hi_perm_c == 0 && k.lo_perm_c == 0 && l.act == ARVAE_ACT_RELU && l.dropout == 0;
+}
+static bool midc_fold_topology(const arvae_image_vae_t *m, int ne, int nd) {
+    static const bool off = diag_env("ARVAE_MIDC_NO_FOLD") != nullptr;       // diagnostic build: the four launches of round 4
+    const int e = m->n_enc - ne - 1;                             // the conv layer in front of the block
+    if (off || !midc_topology(m, ne, nd) || e < 1 || nd + 1 >= m->n_dec) return false;
+    const arvae_layer_t &before = m->enc[e - 1];
+    return conv_fold_layer_ok(m->enc[e], false) && conv_fold_layer_ok(m->dec[nd], true) && before.act == ARVAE_ACT_RELU &&
+           before.dropout == 0 && m->dec[nd - 1].act == ARVAE_ACT_RELU;
+}
+bool mid_fold_fits(const arvae_image_vae_t *m, int batch) {
+    int ne, nd;
+    if (!mid_fusable(m, &ne, &nd) || !midc_fold_topology(m, ne, nd)) return false;
+    return midc_use(true, batch, m->flags);
+}
+// floats of weight-gradient slabs each folded layer needs: one per workgroup of the clustered grid
+int64_t mid_fold_slab_floats(const arvae_image_vae_t *m, int batch) {
+    int ne, nd;
+    if (!mid_fusable(m, &ne, &nd) || !midc_fold_topology(m, ne, nd)) return 0;
+    return (int64_t)((batch + MC_R - 1) / MC_R) * MC_S * (32 * 32 + 32);    // (a tap block + bias sums per member: reduce.h, SLAB_C32T)
 }
 
 // floats of workspace for the prepped matrices of the block's layers
@@ -476,6 +507,7 @@ struct MidPlan {
     MidArgs args;
     MidPrepArgs prep;
     bool cluster;                // the clustered kernels can take this model (and `cl` holds their matrices)
+    bool fold;                   // ... and compute the conv layers on either side of the block too (cl.cv_e / cl.cv_d are set)
     McArgs cl;
     size_t lds_bytes;
     int rows;                    // batch rows per workgroup: 8 when two row buffers of that height fit LDS beside the scratch, else 4
@@ -546,6 +578,10 @@ static void mid_describe(const arvae_image_vae_t *m, const float *params, float 
     pl.prep.counter_words = 0;
     pl.cluster = midc_topology(m, ne, nd);
     pl.cl = McArgs{};
+    pl.fold = false;
+    pl.prep.n_conv = 0;
+    pl.prep.conv[0] = pl.prep.conv[1] = McConvPrep{nullptr, nullptr, nullptr};
+    const bool use_c_early = pl.cluster && midc_use(true, batch, m->flags);
     if (pl.cluster) {
         // cluster layouts behind everything else in the prep workspace; job order: enc0, enc1, dec0, dec1, dec2, heads
         McMat *fw[6] = {&pl.cl.e0f, &pl.cl.e1f, &pl.cl.d0f, &pl.cl.d1f, &pl.cl.d2f, &pl.cl.hdf};
@@ -561,6 +597,22 @@ static void mid_describe(const arvae_image_vae_t *m, const float *params, float 
             j.cb_kb = np / 16; j.cb_s = (heads || first_dec) ? 1 : MC_S; j.cb_ct = kp / 16 / j.cb_s;
             fw[q]->w = j.cf; fw[q]->bias = j.bias;
             bw[q]->w = j.cb; bw[q]->bias = nullptr;
+        }
+        // the folded conv layers' matrices (made whenever the clustered kernels run and the model has the layers)
+        pl.fold = use_c_early && midc_fold_topology(m, ne, nd);
+        pl.prep.n_conv = 0;
+        pl.prep.conv[0] = pl.prep.conv[1] = McConvPrep{nullptr, nullptr, nullptr};
+        {
+            const arvae_layer_t *cl[2] = {&m->enc[m->n_enc - ne - 1], &m->dec[nd]};
+            McConv *cv[2] = {&pl.cl.cv_e, &pl.cl.cv_d};
+            for (int q = 0; q < 2; ++q) {
+                float *down = prep_ws + off, *up = down + 16384;
+                off += 2 * 16384;
+                if (!pl.fold) continue;
+                pl.prep.conv[q] = McConvPrep{params + cl[q]->w_off, down, up};
+                *cv[q] = McConv{down, up, cl[q]->b_off >= 0 ? params + cl[q]->b_off : nullptr};
+            }
+            if (pl.fold) pl.prep.n_conv = 2;
         }
         pl.prep.counters = reinterpret_cast<unsigned *>(prep_ws + off);
         pl.prep.counter_words = (int)MIDC_COUNTER_WORDS;
@@ -634,7 +686,7 @@ void mid_prep_args(const arvae_image_vae_t *m, const float *params, float *prep_
 // (1) weight layout prep unless prep_done, (2) the forward block.  enc_y / dec_y: saved outputs of the block's layers.
 int mid_forward(const arvae_image_vae_t *m, int batch, const float *params, float *prep_ws, const float *x0, float *const *enc_y,
                 float *const *dec_y, const float *eps, float *mu, float *log_std, float *sigma, float *z, hipStream_t s, bool prep_done,
-                unsigned *amax_out) {
+                unsigned *amax_out, const MidFold *fold) {
     MidPlan pl;
     mid_describe(m, params, prep_ws, pl, batch);
     MidArgs &a = pl.args;
@@ -660,7 +712,7 @@ int mid_forward(const arvae_image_vae_t *m, int batch, const float *params, floa
     }
     mid_allow_lds();
     if (!prep_done) {
-        ARVAE_LAUNCH(mid_prep_kernel, dim3(pl.prep.blk_end[pl.prep.count - 1]), dim3(256), 0, s, pl.prep);
+        ARVAE_LAUNCH(mid_prep_kernel, dim3(mid_prep_blocks(pl.prep)), dim3(256), 0, s, pl.prep);
         if (int rc = check_launch("mid_prep_kernel")) return rc;
     }
     if (midc_use(pl.cluster, batch, m->flags)) {
@@ -669,8 +721,15 @@ int mid_forward(const arvae_image_vae_t *m, int batch, const float *params, floa
         c.x0 = x0; c.mu = mu; c.log_std = log_std; c.sigma = sigma; c.z = z; c.eps = eps;
         c.eps_out = a.eps_out; c.rng = a.rng;
         c.amax_out = amax_out;                               // one writer unit per workgroup: at most 256 of them
+        ARVAE_REQUIRE((fold != nullptr) == pl.fold, "mid_forward: the executor and the latent block disagree about the folded conv layers");
+        if (fold != nullptr) {                               // x0 is written by this launch, y_d2 goes on to hi_d
+            c.fold = 1;
+            c.hi_e = fold->hi_e; c.x0_out = const_cast<float *>(x0);
+            c.hi_d = fold->hi_d; c.hi_d_bits = fold->hi_d_bits; c.hi_d_amax = fold->hi_d_amax;
+        }
         return midc_forward(c, s);
     }
+    ARVAE_REQUIRE(fold == nullptr, "mid_forward: folded conv layers need the clustered kernels");
     if (pl.rows == 1) ARVAE_LAUNCH(mid_forward_kernel<1>, dim3(batch), dim3(MID_T), pl.lds_bytes, s, a);
     else if (pl.rows == 2) ARVAE_LAUNCH(mid_forward_kernel<2>, dim3((batch + 1) / 2), dim3(MID_T), pl.lds_bytes, s, a);
     else if (pl.rows == 8) ARVAE_LAUNCH(mid_forward_kernel<8>, dim3((batch + 7) / 8), dim3(MID_T), pl.lds_bytes, s, a);
@@ -684,7 +743,7 @@ int mid_backward(const arvae_image_vae_t *m, int batch, const float *params, flo
                  float *const *enc_g, float *const *dec_g, const float *g_out, int g_is_pre, const float *gate0, float *d_x0,
                  const float *eps, const float *mu, const float *sigma, const float *dz_reg, const float *dz_extra, const float *g_loss,
                  const float *kl, const float *cap, float beta, float reg_scale, float *d_mu, float *d_ls, hipStream_t s,
-                 unsigned *amax_out) {
+                 unsigned *amax_out, const MidFold *fold) {
     MidPlan pl;
     mid_describe(m, params, prep_ws, pl, batch);
     MidArgs &a = pl.args;
@@ -716,8 +775,15 @@ int mid_backward(const arvae_image_vae_t *m, int batch, const float *params, flo
         c.dz_reg = dz_reg; c.dz_extra = dz_extra; c.g_loss = g_loss; c.kl = kl; c.cap = cap;
         c.beta = beta; c.inv_batch = a.inv_batch; c.reg_scale = reg_scale; c.d_mu = d_mu; c.d_ls = d_ls;
         c.amax_out = amax_out;
+        ARVAE_REQUIRE((fold != nullptr) == pl.fold, "mid_backward: the executor and the latent block disagree about the folded conv layers");
+        if (fold != nullptr) {
+            c.fold = 1;
+            c.hi_e = fold->hi_e; c.g_hi_d = fold->g_hi_d; c.d_hi_e = fold->d_hi_e; c.d_hi_e_amax = fold->d_hi_e_amax;
+            c.slab_e = fold->slab_e; c.slab_d = fold->slab_d;
+        }
         return midc_backward(c, s);
     }
+    ARVAE_REQUIRE(fold == nullptr, "mid_backward: folded conv layers need the clustered kernels");
     if (pl.rows == 1) ARVAE_LAUNCH(mid_backward_kernel<1>, dim3(batch), dim3(MID_T), pl.lds_bytes, s, a);
     else if (pl.rows == 2) ARVAE_LAUNCH(mid_backward_kernel<2>, dim3((batch + 1) / 2), dim3(MID_T), pl.lds_bytes, s, a);
     else if (pl.rows == 8) ARVAE_LAUNCH(mid_backward_kernel<8>, dim3((batch + 7) / 8), dim3(MID_T), pl.lds_bytes, s, a);

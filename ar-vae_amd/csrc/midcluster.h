@@ -27,6 +27,12 @@ struct McMat {
     const float *bias;          // [o] in memory order, or null
 };
 
+// A 32-channel k4 / s2 / p1 conv link between the 4x4 map at the block's edge and the 8x8 map beyond it, computed by the block
+// itself (McArgs.fold): its matrices in cluster layout (midprep.h, McConvPrep) and its bias in the reference's order.
+struct McConv {
+    const float *down, *up, *bias;
+};
+
 struct McArgs {
     int batch, zdim, clusters;
     unsigned long long wait_ticks;   // bound of a hand-off poll, in 10 ns ticks of the polling wave's own running time
@@ -58,6 +64,24 @@ struct McArgs {
     const float *dz_reg, *dz_extra, *g_loss, *kl, *cap;
     float beta, inv_batch, reg_scale;
     float *d_mu, *d_ls;
+    // ---- fold != 0 (round 5): the conv layer in front of the block (cv_e: Conv2d 8x8 -> 4x4, imagevae/dsprites_vae.py:19) and
+    // the transposed one behind it (cv_d: ConvTranspose2d 4x4 -> 8x8, dsprites_vae.py:38) run inside these launches -- member m
+    // of a cluster owns lo pixel (m / 4, m % 4) of its cluster's 32 images, i.e. columns [32 m, 32 m + 32) of the 512-wide
+    // tensors, which is the slice it owns anyway.  Forward: x0 is WRITTEN (from hi_e), y_d2 goes on to hi_d (+ sign bits and
+    // maxima: what the next conv kernel reads).  Backward: g_out is not read; the gradient arrives at hi_d's pre-activation
+    // (g_hi_d), leaves at hi_e's (d_hi_e, gated by hi_e's saved output), and both layers' weight-gradient partials go to one
+    // slab per workgroup (reduce.h, SLAB_C32).
+    int fold;
+    McConv cv_e, cv_d;
+    const float *hi_e;             // [batch][8][8][32]: conv input (saved activation of the layer before)
+    float *x0_out;                 // = x0, writable
+    float *hi_d;                   // [batch][8][8][32]: the transposed conv's output (post-ReLU)
+    unsigned char *hi_d_bits;      // relu_bits16 of hi_d (common.h), addressed by bytes
+    unsigned *hi_d_amax;           // AMAX array of hi_d
+    const float *g_hi_d;           // backward: gradient w.r.t. hi_d's pre-activation
+    float *d_hi_e;                 // backward: gradient w.r.t. hi_e's pre-activation
+    unsigned *d_hi_e_amax;
+    float *slab_e, *slab_d;        // [grid][SLAB_C32_FLOATS]
 };
 
 int64_t midc_counter_words(int batch);             // uint32 words of arrival counters a batch needs (zeroed by the prep launch)

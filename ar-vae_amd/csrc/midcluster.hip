@@ -72,7 +72,7 @@ struct Shape {
     static constexpr int NS = 16 * CT;                      // output columns of the slice
     static constexpr int P = NS + 4;                        // pitch of the partial tiles
     static constexpr int SLICE = CT * KB * 256;             // floats of one slice in cluster layout
-    static_assert(KB % KS == 0 && NW <= 8 && (T > 8 || NKB % 2 == 0) && (T > 8 || KS * MC_R * P <= RED_FLOATS), "shape");
+    static_assert(KB % KS == 0 && NW <= 16 && (T > 8 || NKB % 2 == 0) && (T > 8 || KS * MC_R * P <= RED_FLOATS), "shape");
 };
 using ShE0 = Shape<MC_K0 / 16, 1>;        // 512 -> 16 of 256
 using ShHH = Shape<MC_H / 16, 1>;         // 256 -> 16 of 256
@@ -81,10 +81,14 @@ using ShD0 = Shape<1, 16>;                // 16 (z) -> 256, every member
 using ShD2 = Shape<MC_H / 16, 2>;         // 256 -> 32 of 512
 using ShZB = Shape<MC_H / 16, 1>;         // 256 -> 16 (d z), every member
 using ShHB = Shape<2, 16>;                // 32 (d_mu | d_ls) -> 256, every member
+constexpr int MC_TAP_SLAB = 32 * 32 + 32; // a member's weight-gradient partial of a folded layer: its tap's [clo][chi] block + its bias sums
+using ShCD = Shape<32, 2>;                // a folded conv layer's DOWN map: 512 (16 taps x 32 channels) -> the 32 channels of this member's lo pixel
+constexpr int UW = 9 * 32, PU = UW + 4;   // an UP window: the 3 x 3 lo pixels around this member's, 32 channels each; its LDS pitch
 
 // this wave's weights of one product: issued early, consumed by mc_mma
-template <class S>
-__device__ __forceinline__ void mc_load(const float *__restrict__ w, float4 (&wr)[8]) {
+template <class S, int N>
+__device__ __forceinline__ void mc_load(const float *__restrict__ w, float4 (&wr)[N]) {
+    static_assert(S::NW <= N, "weight registers");
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (S::T <= 8) {
         const int tile = wave % S::T, ct = tile >> 1, kq = wave / S::T;
@@ -103,8 +107,8 @@ __device__ __forceinline__ void mc_load(const float *__restrict__ w, float4 (&wr
 // acc[t] = rows of `in` (LDS, pitch ld) x this wave's weights, for its tile(s) and its part of the reduce axis.
 // A operand: lane (g = lane / 16, r = lane % 16) holds in[row r][16 b + 4 g + j] for step j of block b (one 16-byte LDS read);
 // D: lane holds rows 4 g + j, column lane % 16.
-template <class S>
-__device__ __forceinline__ void mc_mma(const float *in, int ld, const float4 (&wr)[8], f32x4v (&acc)[4]) {
+template <class S, int N>
+__device__ __forceinline__ void mc_mma(const float *in, int ld, const float4 (&wr)[N], f32x4v (&acc)[4]) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, r = lane & 15;
     if (S::T <= 8) {
         const int tile = wave % S::T, rt = tile & 1, kq = wave / S::T;
@@ -312,7 +316,157 @@ __device__ __forceinline__ void mc_wide_epilogue_act(int act, const f32x4v (&acc
     else mc_wide_epilogue<S, ARVAE_ACT_NONE, FWD>(acc, bias, y, dst, own, m, row0, valid);
 }
 
+
+// ================================================================================================ folded conv layers (round 5)
+// Member m of a cluster owns lo pixel (i, j) = (m / 4, m % 4) of the 4 x 4 map for its cluster's 32 images.
+// DOWN window of that pixel: the 4 x 4 hi pixels (2 i - 1 + ky, 2 j - 1 + kx) x 32 channels of each image, zero outside the 8 x 8
+// map: 32 x 512 floats -> LDS rows of pitch PA.  `hi`: [batch][8][8][32].
+__device__ __forceinline__ void mc_down_window_issue(const float *__restrict__ hi, int row0, int valid, int m, float4 (&xv)[8]) {
+    const int i = m >> 2, j = m & 3;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int e = (int)threadIdx.x + MC_T * u, r = e >> 7, q = e & 127, tap = q >> 3, c4 = q & 7;
+        const int y = 2 * i - 1 + (tap >> 2), x = 2 * j - 1 + (tap & 3);
+        const bool ok = r < valid && (unsigned)y < 8u && (unsigned)x < 8u;
+        xv[u] = ok ? ld4(hi + ((int64_t)(row0 + r) * 64 + y * 8 + x) * 32 + 4 * c4) : zero4();
+    }
+}
+__device__ __forceinline__ void mc_down_window_commit(const float4 (&xv)[8], float *dst) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int e = (int)threadIdx.x + MC_T * u;
+        *reinterpret_cast<float4 *>(dst + (e >> 7) * PA + 4 * (e & 127)) = xv[u];
+    }
+}
+// the cluster's 32 x 512 block of a tensor every member has just stored 32 columns of -> LDS (pitch PA)
+__device__ __forceinline__ void mc_gather_wide(const float *src, int row0, int valid, float *dst) {
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(src + (int64_t)row0 * MC_K0, (int64_t)valid * MC_K0 * 4);
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int e = (int)threadIdx.x + MC_T * u;           // float4 index: row e / 128, quad e % 128
+        v[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, e * 16, 0, AUX_SC1));
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int e = (int)threadIdx.x + MC_T * u;
+        *reinterpret_cast<float4 *>(dst + (e >> 7) * PA + 4 * (e & 127)) = v[u];
+    }
+    __syncthreads();
+}
+// UP window: the 3 x 3 lo pixels (i - 1 + wy, j - 1 + wx) x 32 channels of the cluster's rows from a 512-wide tensor whose
+// slices the members have just stored (sc1 loads) -> LDS rows of pitch PU; zero outside the 4 x 4 map / past the batch
+__device__ __forceinline__ void mc_up_window(const float *src, int row0, int valid, int m, float *dst) {
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(src + (int64_t)row0 * MC_K0, (int64_t)valid * MC_K0 * 4);
+    const int i = m >> 2, j = m & 3;
+    float4 v[5];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+        const int e = (int)threadIdx.x + MC_T * u, r = e / 72, q = e - r * 72, w = q >> 3, c4 = q & 7;
+        const int y = i - 1 + w / 3, x = j - 1 + w % 3;
+        const bool ok = e < MC_R * 72 && (unsigned)y < 4u && (unsigned)x < 4u;
+        v[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (r * MC_K0 + (y * 4 + x) * 32 + 4 * c4) * 4 : 0x7fffffff, 0, AUX_SC1));
+    }
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+        const int e = (int)threadIdx.x + MC_T * u, r = e / 72, q = e - r * 72;
+        if (e < MC_R * 72) *reinterpret_cast<float4 *>(dst + r * PU + 4 * q) = v[u];
+    }
+    __syncthreads();
+}
+// UP product: wave w = (class (a, b) = w >> 1, column tile ct = w & 1), both 16-row tiles; its 8 k blocks of the class's
+// 128 x 32 matrix: [class][ct][b] = blocks 8 w .. 8 w + 7 of McConv.up
+__device__ __forceinline__ void mc_up_load(const float *__restrict__ up, float4 (&wr)[8]) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) wr[u] = ld4(up + ((int64_t)((wave * 8 + u) * 64 + lane)) * 4);
+}
+__device__ __forceinline__ void mc_up_mma(const float *win, const float4 (&wr)[8], f32x4v (&acc)[2]) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, r = lane & 15;
+    const int a = wave >> 2, b = (wave >> 1) & 1;
+    acc[0] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    acc[1] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int t = u >> 1, ty = t >> 1, tx = t & 1;
+        const int wy = ty == 0 ? 1 : (a ? 2 : 0), wx = tx == 0 ? 1 : (b ? 2 : 0);
+        const float *ap = win + r * PU + (wy * 3 + wx) * 32 + 16 * (u & 1) + 4 * g;
+        const float4 a0 = ld4(ap), a1 = ld4(ap + 16 * PU);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, wr[u].x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, wr[u].x, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, wr[u].y, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, wr[u].y, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, wr[u].z, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, wr[u].z, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, wr[u].w, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, wr[u].w, acc[1], 0, 0, 0);
+    }
+}
+// Weight gradient of a folded layer, partitioned by TAPS over the cluster: member m = tap (ky, kx) = (m / 4, m % 4) computes
+//     part[clo][chi] = sum over the cluster's rows n and the 16 lo pixels (i, j) of lo[n][(i, j)][clo] * hi[n][2 i - 1 + ky][2 j - 1 + kx][chi]
+// -- a 32 x 32 block with K = 512 -- and leaves 4 KB (a workgroup that took its own lo pixel's share of every tap instead, as the
+// first build of this fold did, left 64 KB: 2 us of stores per layer and sixteen times the slab traffic).  Neither operand is
+// reused beyond two MFMAs, so both come straight from L2 (one dword per lane and MFMA pair); wave w takes lo pixels 2 w, 2 w + 1,
+// the eight partial blocks meet in `red` (8192 floats).  lo512: [batch][512] (SC1: freshly handed-off slices), hi: [batch][8][8][32].
+template <bool SC1>
+__device__ __forceinline__ void mc_wgrad_tap(const float *lo512, const float *__restrict__ hi, int row0, int valid, int m, float *red,
+                                             float *__restrict__ out) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+    const int ky = m >> 2, kx = m & 3;
+    const __amdgpu_buffer_rsrc_t rs_lo = make_rsrc(lo512 + (int64_t)row0 * MC_K0, (int64_t)valid * MC_K0 * 4);
+    const __amdgpu_buffer_rsrc_t rs_hi = make_rsrc(hi + (int64_t)row0 * 2048, (int64_t)valid * 2048 * 4);
+    f32x4v acc[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+        const int px = 2 * wave + pi, y = 2 * (px >> 2) - 1 + ky, x = 2 * (px & 3) - 1 + kx;
+        if ((unsigned)y >= 8u || (unsigned)x >= 8u) continue;    // (wave-uniform: the tap falls outside the 8 x 8 map)
+        float av[8][2], bv[8][2];
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+            const int n = 4 * st + g;                            // rows past `valid`: out of range -> zeros
+            const int ao = (n * MC_K0 + px * 32 + c) * 4, bo = (n * 2048 + (y * 8 + x) * 32 + c) * 4;
+            av[st][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_lo, ao, 0, SC1 ? AUX_SC1 : 0));
+            av[st][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_lo, ao + 64, 0, SC1 ? AUX_SC1 : 0));
+            bv[st][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_hi, bo, 0, 0));
+            bv[st][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_hi, bo + 64, 0, 0));
+        }
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st][0], bv[st][0], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st][0], bv[st][1], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st][1], bv[st][0], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st][1], bv[st][1], acc[1][1], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+            *reinterpret_cast<float4 *>(red + ((wave * 4 + mt * 2 + nt) * 64 + lane) * 4) =
+                make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
+    __syncthreads();
+    // D: lane (g, c) of tile (mt, nt) holds rows (clo) 16 mt + 4 g + j, column (chi) 16 nt + c; thread t finishes elements 2 t, 2 t + 1
+    // of [tile][lane][j], the eight waves' partials in wave order
+    {
+        const int e = 2 * (int)threadIdx.x, tile = e >> 8, ln = (e >> 2) & 63, j0 = e & 3;
+        float2 t = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const float2 v = *reinterpret_cast<const float2 *>(red + (w * 4 + tile) * 256 + (e & 255));
+            t.x += v.x; t.y += v.y;
+        }
+        const int clo = 16 * (tile >> 1) + 4 * (ln >> 4) + j0, chi = 16 * (tile & 1) + (ln & 15);
+        out[clo * 32 + chi] = t.x;
+        out[(clo + 1) * 32 + chi] = t.y;
+    }
+}
+
 // ================================================================================================ forward
+template <bool FOLD>
 __device__ __forceinline__ void midc_forward_body(const McArgs &p, int place) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *bufA = lds, *bufB = bufA + MC_R * PA, *red = bufB + MC_R * PB, *zbuf = red + RED_FLOATS, *outs = zbuf + MC_R * PZ;
@@ -326,12 +480,21 @@ __device__ __forceinline__ void midc_forward_body(const McArgs &p, int place) {
     float4 wa[8], wb[8];
     f32x4v acc[4];
     // Requests in the order their data is needed (memory returns loads in order): the conv features of the cluster's rows
-    // (64 KB, eight 16-byte loads per thread), enc0's weights, then everything the later phases would otherwise wait for
+    // (64 KB, eight 16-byte loads per thread) -- FOLD: the window of the conv layer that makes them, and its matrix --, enc0's
+    // weights, then everything the later phases would otherwise wait for
     float4 xv[MC_R * (MC_K0 / 4) / MC_T];
+    float4 wc[16];
+    float2 b_cv = make_float2(0.f, 0.f);
+    if constexpr (FOLD) {
+        mc_down_window_issue(p.hi_e, row0, valid, m, xv);
+        mc_load<ShCD>(p.cv_e.down, wc);
+        if (p.cv_e.bias != nullptr) b_cv = *reinterpret_cast<const float2 *>(p.cv_e.bias + 2 * fc);
+    } else {
 #pragma unroll
-    for (int u = 0; u < MC_R * (MC_K0 / 4) / MC_T; ++u) {
-        const int i = tid + MC_T * u, r = i / (MC_K0 / 4), q = i % (MC_K0 / 4);
-        xv[u] = r < valid ? ld4(p.x0 + (int64_t)(row0 + r) * MC_K0 + 4 * q) : zero4();
+        for (int u = 0; u < MC_R * (MC_K0 / 4) / MC_T; ++u) {
+            const int i = tid + MC_T * u, r = i / (MC_K0 / 4), q = i % (MC_K0 / 4);
+            xv[u] = r < valid ? ld4(p.x0 + (int64_t)(row0 + r) * MC_K0 + 4 * q) : zero4();
+        }
     }
     mc_load<ShE0>(p.e0f.w + (int64_t)m * ShE0::SLICE, wa);
     mc_load<ShHH>(p.e1f.w + (int64_t)m * ShHH::SLICE, wb);
@@ -355,6 +518,24 @@ __device__ __forceinline__ void midc_forward_body(const McArgs &p, int place) {
     if (z_mine) z_eps = p.eps_out != nullptr ? rng_normal(p.rng, (uint64_t)zidx) : p.eps[zidx];
     __syncthreads();
     MC_STAMP(0, 1);
+    if constexpr (FOLD) {
+        // ---- the conv layer in front of the block: this member's lo pixel of the cluster's rows = its 32 columns of x0 (ReLU is what
+        //      dsprites_vae.py:19-20 puts there; the launcher folds no other activation), handed to the cluster like any slice
+        mc_mma<ShCD>(bufA, PA, wc, acc);
+        mc_partials<ShCD>(acc[0], red);
+        __syncthreads();
+        {
+            const int o = 2 * fc;
+            const float v0 = fmaxf(mc_sum<ShCD>(red, frow, o) + b_cv.x, 0.f), v1 = fmaxf(mc_sum<ShCD>(red, frow, o + 1) + b_cv.y, 0.f);
+            if (frow < valid) {
+                st_sc1(v0, p.x0_out, (int64_t)(row0 + frow) * MC_K0 + 32 * m + o);
+                st_sc1(v1, p.x0_out, (int64_t)(row0 + frow) * MC_K0 + 32 * m + o + 1);
+            }
+        }
+        const unsigned tc = mc_publish(ctr);
+        if (!mc_wait(ctr, tc, p.status, MC_E_FWD, p.wait_ticks)) return;
+        mc_gather_wide(p.x0_out, row0, valid, bufA);
+    }
     // ---- enc0: 512 -> this member's 16 of 256
     mc_mma<ShE0>(bufA, PA, wa, acc);
     mc_partials<ShE0>(acc[0], red);
@@ -434,7 +615,7 @@ __device__ __forceinline__ void midc_forward_body(const McArgs &p, int place) {
     const unsigned t_last = mc_publish(ctr);
     const float2 b_d2 = p.d2f.bias != nullptr ? *reinterpret_cast<const float2 *>(p.d2f.bias + 32 * m + 2 * fc) : make_float2(0.f, 0.f);
     if (!mc_wait(ctr, t_last, p.status, MC_E_FWD, p.wait_ticks)) return;
-    const unsigned placed_before = mc_placed(p, m);
+    const unsigned placed_early = FOLD ? 0u : mc_placed(p, m);     // (FOLD: the pass's LAST hand-off comes later)
     MC_STAMP(0, 10);
     mc_gather(p.y_d1, row0, valid, bufA);
     MC_STAMP(0, 11);
@@ -450,11 +631,53 @@ __device__ __forceinline__ void midc_forward_body(const McArgs &p, int place) {
         v.x = act_fwd_sel(mc_sum<ShD2>(red, frow, o) + b_d2.x, p.act_d2);
         v.y = act_fwd_sel(mc_sum<ShD2>(red, frow, o + 1) + b_d2.y, p.act_d2);
         if (frow < valid) {
-            *reinterpret_cast<float2 *>(p.y_d2 + (int64_t)(row0 + frow) * MC_K0 + 32 * m + o) = v;
-            am = fmaxf(fabsf(v.x), fabsf(v.y));
+            if constexpr (FOLD) {                             // a hand-off follows: write through
+                st_sc1(v.x, p.y_d2, (int64_t)(row0 + frow) * MC_K0 + 32 * m + o);
+                st_sc1(v.y, p.y_d2, (int64_t)(row0 + frow) * MC_K0 + 32 * m + o + 1);
+            } else {
+                *reinterpret_cast<float2 *>(p.y_d2 + (int64_t)(row0 + frow) * MC_K0 + 32 * m + o) = v;
+                am = fmaxf(fabsf(v.x), fabsf(v.y));
+            }
         }
     }
-    if (p.amax_out != nullptr) {                              // one AMAX writer unit per workgroup
+    unsigned placed_before = 0;
+    if constexpr (FOLD) {
+        // ---- the transposed conv layer behind the block (4x4 -> 8x8, ReLU): the 2 x 2 hi pixels over this member's lo pixel for the
+        //      cluster's rows, from the 3 x 3 lo pixels around it -- other members' columns of y_d2: the pass's last hand-off
+        const unsigned tu = mc_publish(ctr);
+        float4 wu[8];
+        mc_up_load(p.cv_d.up, wu);
+        const float b_up = p.cv_d.bias != nullptr ? p.cv_d.bias[16 * (wave & 1) + c] : 0.f;
+        if (!mc_wait(ctr, tu, p.status, MC_E_FWD, p.wait_ticks)) return;
+        placed_before = mc_placed(p, m);
+        mc_up_window(p.y_d2, row0, valid, m, bufA);
+        f32x4v au[2];
+        mc_up_mma(bufA, wu, au);
+        const int g = lane >> 4, a = wave >> 2, b = (wave >> 1) & 1, ct = wave & 1;
+        const int pix = (2 * (m >> 2) + a) * 8 + 2 * (m & 3) + b;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 16 * rt + 4 * g + j;
+                const float v = fmaxf(au[rt][j] + b_up, 0.f);
+                const bool on = r < valid;
+                // sign bits (relu_bits16, common.h): bit 4 (ch >> 3) + (ch & 3) of the pixel's half (ch >> 2) & 1; this wave holds
+                // channels 16 ct + c of (row, pixel): one byte of each half, bits 8 ct .. 8 ct + 7
+                const unsigned long long bal = __ballot(on && v > 0.f);
+                const unsigned my = (unsigned)(bal >> (16 * g)) & 0xffffu;
+                if (on) {
+                    const int64_t at = ((int64_t)(row0 + r) * 64 + pix);
+                    p.hi_d[at * 32 + 16 * ct + c] = v;
+                    am = fmaxf(am, v);
+                    if (c < 2) {
+                        const unsigned sh = 4 * c, byte = ((my >> sh) & 0xfu) | (((my >> (8 + sh)) & 0xfu) << 4);
+                        p.hi_d_bits[at * 4 + 2 * c + ct] = (unsigned char)byte;
+                    }
+                }
+            }
+    }
+    if (unsigned *amax_to = FOLD ? p.hi_d_amax : p.amax_out) {   // one AMAX writer unit per workgroup
         float *slot = red + RED_FLOATS;                       // the z rows' LDS: read by nobody at this point
         am = wave_max(am);
         if (lane == 0) slot[wave] = am;
@@ -463,19 +686,47 @@ __device__ __forceinline__ void midc_forward_body(const McArgs &p, int place) {
             float t = 0.f;
 #pragma unroll
             for (int w = 0; w < MC_T / 64; ++w) t = fmaxf(t, slot[w]);
-            amax_publish(p.amax_out, blockIdx.x, gridDim.x, t);
+            amax_publish(amax_to, blockIdx.x, gridDim.x, t);
         }
     }
-    mc_clear_heads(p, m, placed_before);
+    mc_clear_heads(p, m, FOLD ? placed_before : placed_early);
     MC_STAMP(0, 13);
 }
 
 // ================================================================================================ backward
 __global__ __launch_bounds__(MC_T) void midc_forward_kernel(McArgs p) {
     const int place = mc_ticket(p);
-    if (place >= 0) midc_forward_body(p, place);
+    if (place < 0) return;
+    if (p.fold) midc_forward_body<true>(p, place);
+    else midc_forward_body<false>(p, place);
 }
 
+// bias sums of a folded layer (this member's share: its own lo pixel / its own 2 x 2 hi pixels; slab floats 1024 .. 1055):
+// two-stage column sums over the 32 rows (partials in `red`, finished by
+// the first 32 threads BEHIND the caller's next barrier): mc_wgrad_bias_part, barrier, mc_wgrad_bias_finish
+//   UPSIDE (the transposed conv: bias per hi channel): the window's interior taps (ky, kx in {1, 2}) = this member's own 2 x 2 hi pixels
+//   else (the conv: bias per lo channel): the lo-side operand's columns
+template <bool UPSIDE>
+__device__ __forceinline__ void mc_wgrad_bias_part(const float *sop, const float *win, float *red) {
+    const int ch = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    float t = 0.f;
+#pragma unroll
+    for (int r = 2 * rg; r < 2 * rg + 2; ++r) {
+        if (UPSIDE) t += (win[r * PA + 5 * 32 + ch] + win[r * PA + 6 * 32 + ch]) + (win[r * PA + 9 * 32 + ch] + win[r * PA + 10 * 32 + ch]);
+        else t += sop[r * PO + ch];
+    }
+    red[rg * 32 + ch] = t;
+}
+__device__ __forceinline__ void mc_wgrad_bias_finish(const float *red, float *__restrict__ slab) {
+    if (threadIdx.x < 32) {
+        float t = 0.f;
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) t += red[rg * 32 + threadIdx.x];
+        slab[32 * 32 + threadIdx.x] = t;
+    }
+}
+
+template <bool FOLD>
 __device__ __forceinline__ void midc_backward_body(const McArgs &p, int place) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *bufA = lds, *bufB = bufA + MC_R * PA, *red = bufB + MC_R * PB, *dml = red + RED_FLOATS + MC_R * PZ;
@@ -494,12 +745,22 @@ __device__ __forceinline__ void midc_backward_body(const McArgs &p, int place) {
     // output), the first product's weights, then what the later phases would otherwise wait for
     constexpr int NG = MC_R * (MC_K0 / 4) / MC_T;
     float4 gv[NG], yv[NG];
+    float4 wc[16];
+    float2 ys = make_float2(0.f, 0.f);
+    float *slab_d = FOLD ? p.slab_d + (int64_t)(cl * MC_S + m) * MC_TAP_SLAB : nullptr;       // (by place: a fixed summation order)
+    if constexpr (FOLD) {
+        // the gradient arrives at the transposed conv layer's (pre-activation) output: this member's lo pixel needs its 4 x 4 window
+        mc_down_window_issue(p.g_hi_d, row0, valid, m, gv);
+        mc_load<ShCD>(p.cv_d.down, wc);
+        if (fon) ys = *reinterpret_cast<const float2 *>(p.y_d2 + (int64_t)(row0 + frow) * MC_K0 + 32 * m + 2 * fc);
+    } else {
 #pragma unroll
-    for (int u = 0; u < NG; ++u) {
-        const int i = tid + MC_T * u, r = i / (MC_K0 / 4), q = i % (MC_K0 / 4);
-        const int64_t at = (int64_t)(row0 + (r < valid ? r : 0)) * MC_K0 + 4 * q;
-        gv[u] = r < valid ? ld4(p.g_out + at) : zero4();
-        yv[u] = (r < valid && !p.g_is_pre) ? ld4(p.y_d2 + at) : zero4();
+        for (int u = 0; u < NG; ++u) {
+            const int i = tid + MC_T * u, r = i / (MC_K0 / 4), q = i % (MC_K0 / 4);
+            const int64_t at = (int64_t)(row0 + (r < valid ? r : 0)) * MC_K0 + 4 * q;
+            gv[u] = r < valid ? ld4(p.g_out + at) : zero4();
+            yv[u] = (r < valid && !p.g_is_pre) ? ld4(p.y_d2 + at) : zero4();
+        }
     }
     mc_load<ShE0>(p.d2b.w + (int64_t)m * ShE0::SLICE, wa);
     mc_load<ShHH>(p.d1b.w + (int64_t)m * ShHH::SLICE, wb);
@@ -509,20 +770,50 @@ __device__ __forceinline__ void midc_backward_body(const McArgs &p, int place) {
     const float l_gl = p.g_loss[0], l_kl = p.kl[0], l_cap = p.cap != nullptr ? p.cap[0] : 0.f;
     const float l_reg = p.dz_reg != nullptr ? p.dz_reg[li] : 0.f, l_ext = p.dz_extra != nullptr ? p.dz_extra[li] : 0.f;
     const float l_s = p.sigma[li], l_mu = p.mu[li], l_e = p.eps[li];
-#pragma unroll
-    for (int u = 0; u < NG; ++u) {          // -> bufA as a pre-activation gradient
-        const int i = tid + MC_T * u, r = i / (MC_K0 / 4), q = i % (MC_K0 / 4);
-        float4 g4 = gv[u];
-        if (r < valid && !p.g_is_pre) {
-            const float4 y = yv[u];
-            g4 = make_float4(g4.x * act_bwd_from_out_sel(y.x, p.act_d2), g4.y * act_bwd_from_out_sel(y.y, p.act_d2),
-                             g4.z * act_bwd_from_out_sel(y.z, p.act_d2), g4.w * act_bwd_from_out_sel(y.w, p.act_d2));
-            if ((q >> 3) == m) *reinterpret_cast<float4 *>(p.g_d2 + (int64_t)(row0 + r) * MC_K0 + 4 * q) = g4;   // this member's 32 columns
+    if constexpr (FOLD) {
+        mc_down_window_commit(gv, bufA);
+        dml[frow * PO + 2 * fc] = ys.x;                       // the lo-side operand of the layer's weight gradient: its saved input,
+        dml[frow * PO + 2 * fc + 1] = ys.y;                   // this member's 32 columns of y_d2 (zero rows past the batch)
+        __syncthreads();
+        MC_STAMP(1, 1);
+        // ---- data gradient of the transposed conv layer (a DOWN map) -> this member's 32 columns of the gradient at y_d2, times
+        //      act'(y_d2): a slice like any other, handed to the cluster
+        mc_mma<ShCD>(bufA, PA, wc, acc);
+        mc_partials<ShCD>(acc[0], red);
+        __syncthreads();
+        {
+            const int o = 2 * fc;
+            const float v0 = mc_sum<ShCD>(red, frow, o) * act_bwd_from_out_sel(ys.x, p.act_d2);
+            const float v1 = mc_sum<ShCD>(red, frow, o + 1) * act_bwd_from_out_sel(ys.y, p.act_d2);
+            if (fon) {
+                st_sc1(v0, p.g_d2, (int64_t)(row0 + frow) * MC_K0 + 32 * m + o);
+                st_sc1(v1, p.g_d2, (int64_t)(row0 + frow) * MC_K0 + 32 * m + o + 1);
+            }
         }
-        *reinterpret_cast<float4 *>(bufA + r * PA + 4 * q) = g4;
+        const unsigned tg = mc_publish(ctr);
+        // its weight gradient's tap m over the cluster's rows while the others arrive (both operands are old: the saved input and
+        // the arriving gradient)
+        mc_wgrad_bias_part<true>(dml, bufA, red);
+        mc_wgrad_tap<false>(p.y_d2, p.g_hi_d, row0, valid, m, bufB, slab_d);
+        if (!mc_wait(ctr, tg, p.status, MC_E_BWD, p.wait_ticks)) return;
+        mc_wgrad_bias_finish(red, slab_d);
+        mc_gather_wide(p.g_d2, row0, valid, bufA);
+    } else {
+#pragma unroll
+        for (int u = 0; u < NG; ++u) {          // -> bufA as a pre-activation gradient
+            const int i = tid + MC_T * u, r = i / (MC_K0 / 4), q = i % (MC_K0 / 4);
+            float4 g4 = gv[u];
+            if (r < valid && !p.g_is_pre) {
+                const float4 y = yv[u];
+                g4 = make_float4(g4.x * act_bwd_from_out_sel(y.x, p.act_d2), g4.y * act_bwd_from_out_sel(y.y, p.act_d2),
+                                 g4.z * act_bwd_from_out_sel(y.z, p.act_d2), g4.w * act_bwd_from_out_sel(y.w, p.act_d2));
+                if ((q >> 3) == m) *reinterpret_cast<float4 *>(p.g_d2 + (int64_t)(row0 + r) * MC_K0 + 4 * q) = g4;   // this member's 32 columns
+            }
+            *reinterpret_cast<float4 *>(bufA + r * PA + 4 * q) = g4;
+        }
+        __syncthreads();
+        MC_STAMP(1, 1);
     }
-    __syncthreads();
-    MC_STAMP(1, 1);
     // ---- through dec2: 512 -> 16 of 256, times act'(dec1's output)
     mc_mma<ShE0>(bufA, PA, wa, acc);
     mc_partials<ShE0>(acc[0], red);
@@ -612,7 +903,7 @@ __device__ __forceinline__ void midc_backward_body(const McArgs &p, int place) {
     const int64_t xat = (int64_t)(row0 + (fon ? frow : 0)) * MC_K0 + 32 * m + 2 * fc;
     const float2 gate = p.gate0 != nullptr ? *reinterpret_cast<const float2 *>(p.gate0 + xat) : make_float2(1.f, 1.f);
     if (!mc_wait(ctr, t_last, p.status, MC_E_BWD, p.wait_ticks)) return;
-    const unsigned placed_before = mc_placed(p, m);
+    unsigned placed_before = FOLD ? 0u : mc_placed(p, m);       // (FOLD: the pass's LAST hand-off comes later)
     MC_STAMP(1, 10);
     mc_gather(p.g_e0, row0, valid, bufA);
     MC_STAMP(1, 11);
@@ -628,12 +919,58 @@ __device__ __forceinline__ void midc_backward_body(const McArgs &p, int place) {
         v.x = mc_sum<ShD2>(red, frow, o);
         v.y = mc_sum<ShD2>(red, frow, o + 1);
         if (p.gate0 != nullptr) { v.x = gate.x > 0.f ? v.x : 0.f; v.y = gate.y > 0.f ? v.y : 0.f; }
-        if (fon) {
+        if constexpr (FOLD) {
+            if (fon) {                                            // a hand-off follows: write through
+                st_sc1(v.x, p.d_x0, xat);
+                st_sc1(v.y, p.d_x0, xat + 1);
+            }
+            dml[frow * PO + o] = fon ? v.x : 0.f;                 // the lo-side operand of the conv layer's weight gradient
+            dml[frow * PO + o + 1] = fon ? v.y : 0.f;
+        } else if (fon) {
             *reinterpret_cast<float2 *>(p.d_x0 + xat) = v;
             am = fmaxf(fabsf(v.x), fabsf(v.y));
         }
     }
-    if (p.amax_out != nullptr) {
+    if constexpr (FOLD) {
+        // ---- the conv layer in front of the block, backwards: its weight-gradient partial (this member's slice of the gradient x
+        //      the window of its saved input) while the slices are handed over, then its data gradient (an UP map: the 2 x 2 hi
+        //      pixels over this member's lo pixel from the 3 x 3 lo pixels around it), gated by the saved input's sign
+        float *slab_e = p.slab_e + (int64_t)(cl * MC_S + m) * MC_TAP_SLAB;
+        const unsigned tx = mc_publish(ctr);                      // (its barrier: the operand of the bias sums is staged)
+        float4 wu[8];
+        mc_up_load(p.cv_e.up, wu);
+        const int a = wave >> 2, b = (wave >> 1) & 1, ct = wave & 1;
+        const int pix = (2 * (m >> 2) + a) * 8 + 2 * (m & 3) + b;
+        float gt[2][4];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 16 * rt + 4 * g + j;
+                gt[rt][j] = r < valid ? p.hi_e[((int64_t)(row0 + r) * 64 + pix) * 32 + 16 * ct + c] : 0.f;
+            }
+        mc_wgrad_bias_part<false>(dml, bufA, red);
+        if (!mc_wait(ctr, tx, p.status, MC_E_BWD, p.wait_ticks)) return;
+        placed_before = mc_placed(p, m);
+        mc_wgrad_bias_finish(red, slab_e);
+        mc_up_window(p.d_x0, row0, valid, m, bufA);
+        f32x4v au[2];
+        mc_up_mma(bufA, wu, au);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 16 * rt + 4 * g + j;
+                const float v = gt[rt][j] > 0.f ? au[rt][j] : 0.f;
+                if (r < valid) {
+                    p.d_hi_e[((int64_t)(row0 + r) * 64 + pix) * 32 + 16 * ct + c] = v;
+                    am = fmaxf(am, fabsf(v));
+                }
+            }
+        // its weight gradient's tap m: the gradient slices every member has handed over x the layer's saved input
+        mc_wgrad_tap<true>(p.d_x0, p.hi_e, row0, valid, m, bufB, slab_e);
+    }
+    if (unsigned *amax_to = FOLD ? p.d_hi_e_amax : p.amax_out) {
         float *slot = red + RED_FLOATS;                       // the z rows' LDS: read by nobody at this point
         am = wave_max(am);
         if (lane == 0) slot[wave] = am;
@@ -642,7 +979,7 @@ __device__ __forceinline__ void midc_backward_body(const McArgs &p, int place) {
             float t = 0.f;
 #pragma unroll
             for (int w = 0; w < MC_T / 64; ++w) t = fmaxf(t, slot[w]);
-            amax_publish(p.amax_out, blockIdx.x, gridDim.x, t);
+            amax_publish(amax_to, blockIdx.x, gridDim.x, t);
         }
     }
     mc_clear_heads(p, m, placed_before);
@@ -651,7 +988,9 @@ __device__ __forceinline__ void midc_backward_body(const McArgs &p, int place) {
 
 __global__ __launch_bounds__(MC_T) void midc_backward_kernel(McArgs p) {
     const int place = mc_ticket(p);
-    if (place >= 0) midc_backward_body(p, place);
+    if (place < 0) return;
+    if (p.fold) midc_backward_body<true>(p, place);
+    else midc_backward_body<false>(p, place);
 }
 
 std::once_flag g_lds_once;

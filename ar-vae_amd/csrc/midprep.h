@@ -20,14 +20,69 @@ struct MidPrepJob {
     float *cf, *cb;
     int cf_kb, cf_ct, cf_s, cb_kb, cb_ct, cb_s;
 };
+// A 32-channel k4 / s2 / p1 link between a 4x4 and an 8x8 map that the clustered latent block computes itself (round 5: the conv
+// layer in front of the block and the transposed one behind it, midcluster.hip): its weight wt[clo][chi][ky][kx] as the two
+// matrices of that kernel, each 512 x 32 in CLUSTER LAYOUT (one slice, two column tiles, 32 k blocks):
+//   down[k][clo], k = (ky * 4 + kx) * 32 + chi                    the DOWN map: a lo pixel from its 4 x 4 window of hi pixels
+//   up[k][chi],   k = ((a * 2 + b) * 4 + ty * 2 + tx) * 32 + clo  the UP map, per parity class (a, b) of the hi pixel (2 i + a,
+//                 2 j + b): tap t = 0 is lo row i (ky = a + 1), t = 1 the other contributing row (ky = a ? 0 : 3); columns alike;
+//                 stored class after class: [class][ct][b 8][lane][4]
+struct McConvPrep {
+    const float *wt;             // null: no such layer
+    float *down, *up;            // 16384 floats each
+};
+constexpr int MC_CONV_PREP_BLOCKS = 16;      // per layer: 2 x 16384 values, 8 per thread
+__device__ __forceinline__ int mc_up_k(int a, int t) { return t == 0 ? a + 1 : (a ? 0 : 3); }       // kernel row / column of tap t
+
 struct MidPrepArgs {
     MidPrepJob job[2 * MID_MAX_LAYERS + 1];
     int count, blk_end[2 * MID_MAX_LAYERS + 1];
     unsigned *counters;          // arrival counters of the clustered latent block (midcluster.hip): zeroed here, every step
     int counter_words;
+    McConvPrep conv[2];          // blocks behind the jobs': MC_CONV_PREP_BLOCKS per layer that is present
+    int n_conv;
+};
+inline int mid_prep_blocks(const MidPrepArgs &a) { return a.blk_end[a.count - 1] + MC_CONV_PREP_BLOCKS * a.n_conv; }
+
+// what the executor (plan.hip) hands the latent block when the clustered kernels also compute the conv layers on either side of
+// it (midblock.hip mid_fold_fits; midcluster.h McArgs.fold): the tensors beyond those layers
+struct MidFold {
+    const float *hi_e;           // forward + backward: the conv layer's input [batch][8][8][32] (a ReLU layer's saved output)
+    float *hi_d;                 // forward: the transposed conv layer's output [batch][8][8][32], its sign bits and its AMAX array
+    unsigned char *hi_d_bits;
+    unsigned *hi_d_amax;
+    const float *g_hi_d;         // backward: gradient w.r.t. hi_d's pre-activation
+    float *d_hi_e;               // backward: gradient w.r.t. hi_e's pre-activation, and its AMAX array
+    unsigned *d_hi_e_amax;
+    float *slab_e, *slab_d;      // backward: the two layers' weight-gradient slabs (mid_fold_slab_floats each)
 };
 
+__device__ __forceinline__ void mc_conv_prep_block(const McConvPrep &c, int block) {
+    for (int e = block * 256 + threadIdx.x; e < 2 * 16384; e += MC_CONV_PREP_BLOCKS * 256) {
+        const bool up = e >= 16384;
+        const int f = e & 16383, j = f & 3, lane = (f >> 2) & 63, blk = f >> 8;
+        if (!up) {
+            const int b = blk & 31, ct = blk >> 5;
+            const int k = 16 * b + 4 * (lane >> 4) + j, n = 16 * ct + (lane & 15);
+            const int tap = k >> 5, chi = k & 31;
+            c.down[f] = c.wt[(n * 32 + chi) * 16 + tap];
+        } else {
+            const int b = blk & 7, ct = (blk >> 3) & 1, cls = blk >> 4;
+            const int k = 16 * b + 4 * (lane >> 4) + j, n = 16 * ct + (lane & 15);
+            const int t = k >> 5, clo = k & 31;
+            const int ky = mc_up_k(cls >> 1, t >> 1), kx = mc_up_k(cls & 1, t & 1);
+            c.up[f] = c.wt[(clo * 32 + n) * 16 + ky * 4 + kx];
+        }
+    }
+}
+
 __device__ __forceinline__ void mid_prep_block(const MidPrepArgs &a, int block) {
+    if (block >= a.blk_end[a.count - 1]) {                      // the folded conv layers' matrices
+        const int cb = block - a.blk_end[a.count - 1];
+        if (cb / MC_CONV_PREP_BLOCKS == 0) mc_conv_prep_block(a.conv[0], cb);
+        else mc_conv_prep_block(a.conv[1], cb - MC_CONV_PREP_BLOCKS);
+        return;
+    }
     int j = 0, start = 0;
 #pragma unroll
     for (int q = 0; q + 1 < 2 * MID_MAX_LAYERS + 1; ++q)

@@ -89,12 +89,15 @@ bool mid_fusable(const arvae_image_vae_t *m, int *ne_out, int *nd_out);
 int64_t mid_prep_floats(const arvae_image_vae_t *m);
 int mid_forward(const arvae_image_vae_t *m, int batch, const float *params, float *prep_ws, const float *x0, float *const *enc_y,
                 float *const *dec_y, const float *eps, float *mu, float *log_std, float *sigma, float *z, hipStream_t s, bool prep_done,
-                unsigned *amax_out);
+                unsigned *amax_out, const MidFold *fold);
+// the conv layers on either side of the latent block computed by the block's clustered kernels (midblock.hip)
+bool mid_fold_fits(const arvae_image_vae_t *m, int batch);
+int64_t mid_fold_slab_floats(const arvae_image_vae_t *m, int batch);
 int mid_backward(const arvae_image_vae_t *m, int batch, const float *params, float *prep_ws, float *const *enc_y, float *const *dec_y,
                  float *const *enc_g, float *const *dec_g, const float *g_out, int g_is_pre, const float *gate0, float *d_x0,
                  const float *eps, const float *mu, const float *sigma, const float *dz_reg, const float *dz_extra, const float *g_loss,
                  const float *kl, const float *cap, float beta, float reg_scale, float *d_mu, float *d_ls, hipStream_t s,
-                 unsigned *amax_out);
+                 unsigned *amax_out, const MidFold *fold);
 
 // loss-term pieces (losses.hip)
 int recon_partials(const float *logits, const float *x, int64_t count, int64_t batch, int32_t dist, float *ws,
@@ -206,10 +209,14 @@ static int make_layout(const arvae_image_vae_t *m, int64_t n, int64_t n_cols, La
     }
     visit(m->head_mu);
     visit(m->head_log_std);
+    // (a layer the clustered latent block may compute itself leaves one slab per workgroup of that grid: mid_fold_slab_floats)
+    const int64_t fold_slab = mid_fold_slab_floats(m, (int)n);
     auto own_slab = [&](const arvae_layer_t &l) -> int64_t {
         arvae_link_t lk = l.link;
         lk.n = (int32_t)n;
-        return (conv32_fits(&lk) || conv_c1_fits(&lk)) ? take(arvae_link_wgrad_ws_floats(&lk)) : -1;
+        if (!(conv32_fits(&lk) || conv_c1_fits(&lk))) return -1;
+        const int64_t need = arvae_link_wgrad_ws_floats(&lk);
+        return take((conv32_fits(&lk) && lk.lh == 4 && fold_slab > need) ? fold_slab : need);
     };
     auto own_bits = [&](const arvae_layer_t &l, int64_t wprep) -> int64_t {
         arvae_link_t lk = l.link;
@@ -487,6 +494,15 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
     return arvae_link_wgrad(&lk, &gop, &xin, dw, db, db ? 1 : 0, slab, wst);
 }
 
+// Do the latent block's clustered kernels also compute the conv layers on either side of it in this pass (midblock.hip
+// mid_fold_fits)?  One answer for the forward and the backward pass of a step: it depends on the model, the batch, the caller's
+// flags and the workspace layout only.
+static bool fold_conv_layers(const arvae_image_vae_t *m, const Layout &L, int batch, const uint8_t *const *masks, int mid_ne, int mid_nd) {
+    const int e = m->n_enc - mid_ne - 1;
+    return masks == nullptr && e >= 1 && mid_nd + 1 < m->n_dec && mid_fold_fits(m, batch) && L.dec_bits[mid_nd] >= 0 &&
+           L.enc_slab[e] >= 0 && L.dec_slab[mid_nd] >= 0 && L.dec_wprep[mid_nd + 1] >= 0;
+}
+
 static int count_masks(const arvae_image_vae_t *m) {
     int c = 0;
     for (int i = 0; i < m->n_enc; ++i) c += m->enc[i].dropout != 0;
@@ -562,11 +578,14 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
         for (int i = 0; i < m->n_dec; ++i) add(m->dec[i], L.dec_wide[i]);
         if (int rc = conv64s_prep_batch(wts, outs, tr, qs, nj, st)) return rc;
     }
+    // the conv layers on either side of the latent block inside its launches (midcluster.hip): the encoder loop stops one layer
+    // earlier, the decoder loop starts one layer later
+    const bool fold = mid && fold_conv_layers(m, L, batch, masks, mid_ne, mid_nd);
     // encoder
     const float *h = first ? ws + L.enc_out[0] : x;
     const unsigned *h_amax = first ? U(L.enc_amax[0]) : nullptr;   // AMAX array of h, when the kernel that wrote h delivered one
     mi += first ? (m->enc[0].dropout != 0) : 0;
-    for (int i = first; i < m->n_enc - mid_ne; ++i) {
+    for (int i = first; i < m->n_enc - mid_ne - (fold ? 1 : 0); ++i) {
         const uint8_t *mask = (masks != nullptr && m->enc[i].dropout) ? masks[mi] : nullptr;
         mi += m->enc[i].dropout != 0;
         uint16_t *bits = L.enc_bits[i] >= 0 ? reinterpret_cast<uint16_t *>(ws + L.enc_bits[i]) : nullptr;
@@ -585,11 +604,18 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
         float *enc_y[ARVAE_MAX_LAYERS], *dec_y[ARVAE_MAX_LAYERS];
         for (int i = 0; i < mid_ne; ++i) enc_y[i] = ws + L.enc_out[m->n_enc - mid_ne + i];
         for (int i = 0; i < mid_nd; ++i) dec_y[i] = ws + L.dec_out[i];
-        if (int rc = mid_forward(m, batch, params, ws + L.mid_prep, h, enc_y, dec_y, eps, mu, ws + L.log_std, sigma, z, st, mid_prepped,
-                                 U(L.dec_amax[mid_nd - 1])))
+        MidFold mf{};
+        if (fold) {
+            mf.hi_e = h;                                         // the conv layer's input; its output is the block's x0
+            mf.hi_d = ws + L.dec_out[mid_nd];
+            mf.hi_d_bits = reinterpret_cast<unsigned char *>(ws + L.dec_bits[mid_nd]);
+            mf.hi_d_amax = U(L.dec_amax[mid_nd]);
+        }
+        if (int rc = mid_forward(m, batch, params, ws + L.mid_prep, fold ? ws + L.enc_out[m->n_enc - mid_ne - 1] : h, enc_y, dec_y, eps, mu,
+                                 ws + L.log_std, sigma, z, st, mid_prepped, U(L.dec_amax[mid_nd - 1]), fold ? &mf : nullptr))
             return rc;
-        h = dec_y[mid_nd - 1];
-        h_amax = U(L.dec_amax[mid_nd - 1]);
+        h = fold ? ws + L.dec_out[mid_nd] : dec_y[mid_nd - 1];
+        h_amax = fold ? U(L.dec_amax[mid_nd]) : U(L.dec_amax[mid_nd - 1]);
     } else if (heads_fusable(&m->head_mu, &m->head_log_std, m->zdim)) {
         // the decoder's first Linear layer rides in the heads kernel when it can (heads.hip)
         heads_next = m->n_dec > 1 && heads_next_fusable(&m->dec[0], m->zdim) && !(masks != nullptr && m->dec[0].dropout);
@@ -628,7 +654,7 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
                            m->delta, ws + L.reg_ws, ws + L.reg_ws + (int64_t)batch * m->n_reg};
         for (int i = 0; i < 16; ++i) reg_args.dims.d[i] = i < m->n_reg ? m->reg_dims[i] : 0;
     }
-    for (int i = mid ? mid_nd : (heads_next ? 1 : 0); i < m->n_dec; ++i) {
+    for (int i = mid ? mid_nd + (fold ? 1 : 0) : (heads_next ? 1 : 0); i < m->n_dec; ++i) {
         const uint8_t *mask = (masks != nullptr && m->dec[i].dropout) ? masks[mi] : nullptr;
         mi += m->dec[i].dropout != 0;
         float *out = (i + 1 < m->n_dec) ? ws + L.dec_out[i] : logits;
@@ -794,9 +820,11 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
     }
     int mid_ne = 0, mid_nd = 0;
     const bool mid = mid_fusable(m, &mid_ne, &mid_nd);
+    // (as the forward pass decided: the conv layers on either side of the latent block inside its launches)
+    const bool fold = mid && fold_conv_layers(m, L, batch, masks, mid_ne, mid_nd);
     // decoder, last layer first (down to the latent block when that runs as one launch)
     const float *heads_next_g = nullptr;
-    for (int i = m->n_dec - 1; i >= (mid ? mid_nd : 0); --i) {
+    for (int i = m->n_dec - 1; i >= (mid ? mid_nd + (fold ? 1 : 0) : 0); --i) {
         const float *in = i > 0 ? ws + L.dec_out[i - 1] : z;
         const float *out = (i + 1 < m->n_dec) ? ws + L.dec_out[i] : logits;
         const float *gate = i > 0 ? relu_gate(m->dec[i - 1], dec_mask[i - 1], in) : nullptr;
@@ -857,10 +885,30 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
         const float *gate0 = relu_gate(m->enc[e0 - 1], enc_mask[e0 - 1], x0);
         float *d_x0 = ws + L.enc_keep[e0 - 1];
         const float *g_last = cur;                           // gradient arriving at the last Linear layer of the decoder
-        if (int rc = mid_backward(m, batch, params, ws + L.mid_prep, enc_y, dec_y, enc_g, dec_g, g_last, pre ? 1 : 0, gate0, d_x0, eps,
+        MidFold mf{};
+        if (fold) {
+            // `cur` is the gradient at the transposed conv layer's output, left by the layer behind it: the block takes it from
+            // there (it must be w.r.t. the pre-activation: that layer's data-gradient kernel gates with the sign bits the
+            // forward launch wrote) and hands the gradient at the conv layer's INPUT on
+            ARVAE_REQUIRE(pre, "image_vae_backward: the folded conv layer needs a gated upstream gradient");
+            mf.hi_e = ws + L.enc_out[e0 - 2];
+            mf.g_hi_d = cur;
+            mf.d_hi_e = ws + L.enc_keep[e0 - 2];
+            mf.d_hi_e_amax = grad_amax(mf.d_hi_e);
+            mf.slab_e = ws + L.enc_slab[e0 - 1];
+            mf.slab_d = ws + L.dec_slab[mid_nd];
+        }
+        if (int rc = mid_backward(m, batch, params, ws + L.mid_prep, enc_y, dec_y, enc_g, dec_g, g_last, (pre || fold) ? 1 : 0, gate0, d_x0, eps,
                                   mu, sigma, dz_reg, dz_extra, g_loss, ws + L.kld_out + 1, capacity, m->beta, reg_scale, ws + L.d_mu,
-                                  ws + L.d_ls, st, grad_amax(d_x0)))
+                                  ws + L.d_ls, st, grad_amax(d_x0), fold ? &mf : nullptr))
             return rc;
+        if (fold) {                                          // the two layers' weight-gradient slabs: one per workgroup of the block's grid
+            const int n_wg = (batch + 31) / 32;                  // one slab of sixteen tap blocks per cluster (reduce.h, SLAB_C32T)
+            const arvae_layer_t &ce = m->enc[e0 - 1], &cd = m->dec[mid_nd];
+            SlabJob je{mf.slab_e, grads + ce.w_off, ce.b_off >= 0 ? grads + ce.b_off : nullptr, n_wg, SLAB_C32T, ce.b_off >= 0 ? 1 : 0};
+            SlabJob jd{mf.slab_d, grads + cd.w_off, cd.b_off >= 0 ? grads + cd.b_off : nullptr, n_wg, SLAB_C32T, cd.b_off >= 0 ? 2 : 0};
+            ARVAE_REQUIRE(slab_reduce_defer(&rdefer, jd) && slab_reduce_defer(&rdefer, je), "image_vae_backward: too many slab reductions queued");
+        }
         // weight gradients of the block's layers: (pre-activation gradient, layer input) pairs for the grouped launch
         auto queue = [&](const arvae_layer_t &l, const float *g, const float *in) -> int {
             arvae_link_t lk = l.link;
@@ -871,15 +919,15 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
             return arvae_link_wgrad(&lk, &gop, &xin, dw, db, db ? 1 : 0, slab, stream);
         };
         for (int i = mid_nd - 1; i >= 0; --i)
-            if (int rc = queue(m->dec[i], (i == mid_nd - 1 && pre) ? g_last : dec_g[i], i > 0 ? dec_y[i - 1] : z)) return rc;
+            if (int rc = queue(m->dec[i], (i == mid_nd - 1 && pre && !fold) ? g_last : dec_g[i], i > 0 ? dec_y[i - 1] : z)) return rc;
         if (int rc = queue(m->head_mu, ws + L.d_mu, hidden)) return rc;
         if (int rc = queue(m->head_log_std, ws + L.d_ls, hidden)) return rc;
         for (int i = mid_ne - 1; i >= 0; --i)
             if (int rc = queue(m->enc[e0 + i], enc_g[i], i > 0 ? enc_y[i - 1] : x0)) return rc;
-        cur = d_x0;
-        cur_amax = grad_amax(d_x0);
-        pre = gate0 != nullptr;
-        enc_from = e0 - 1;
+        cur = fold ? mf.d_hi_e : d_x0;
+        cur_amax = grad_amax(cur);
+        pre = fold ? true : gate0 != nullptr;                // (folded: gated by the conv layer's saved input inside the launch)
+        enc_from = fold ? e0 - 2 : e0 - 1;
         if (ms != nullptr && ms->linear_grads != nullptr) {   // every Linear weight gradient is queued
             if (int rc = dense_wgrad_flush(&defer, st)) return rc;
             mark(ms->linear_grads, st);
