@@ -1026,13 +1026,13 @@ int midc_resident_capacity() {
 int midc_forward(const McArgs &a, hipStream_t s) {
     allow_lds();
     ARVAE_LAUNCH(midc_forward_kernel, dim3(a.clusters * MC_S), dim3(MC_T), LDS_FLOATS * sizeof(float), s, a);
-    return check_launch("midc_forward_kernel");
+    return check_launch(a.fold ? "midc_forward_kernel(+ conv4, deconv1)" : "midc_forward_kernel");
 }
 
 int midc_backward(const McArgs &a, hipStream_t s) {
     allow_lds();
     ARVAE_LAUNCH(midc_backward_kernel, dim3(a.clusters * MC_S), dim3(MC_T), LDS_FLOATS * sizeof(float), s, a);
-    return check_launch("midc_backward_kernel");
+    return check_launch(a.fold ? "midc_backward_kernel(+ conv4, deconv1)" : "midc_backward_kernel");
 }
 
 }  // namespace arvae

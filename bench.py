@@ -91,6 +91,11 @@ KERNEL_WORK = {
     'mid_forward_kernel': (400_896, 4 * 3102, 4 * 400_896), 'mid_backward_kernel': (400_896, 4 * (3102 + 1556), 4 * 400_896),
     # the same block on clusters of workgroups (midcluster.hip: the default for this model since round 4)
     'midc_forward_kernel': (400_896, 4 * 3102, 4 * 400_896), 'midc_backward_kernel': (400_896, 4 * (3102 + 1556), 4 * 400_896),
+    # ... with the 4x4 conv layers on either side of the block inside the launch (round 5): + conv4 and deconv1 forward (262 144 MACs
+    # and 2048 + 512 elements each) / their data and weight gradients (4 x 262 144 MACs; upstream gradient, saved input, input gradient)
+    'midc_forward_kernel(+ conv4, deconv1)': (400_896 + 2 * 262_144, 4 * (3102 + 2 * (2048 + 512)), 4 * (400_896 + 2 * 16_416)),
+    'midc_backward_kernel(+ conv4, deconv1)': (400_896 + 4 * 262_144, 4 * (3102 + 1556 + (2048 + 512 + 512) + (512 + 2048 + 2048)), 4 * (400_896 + 2 * 16_416)),
+    'up32_kernel<8>(+ reg_loss)': (1_048_576, 4 * (2048 + 8192)),
     'dense_wgrad_batch_kernel': (400_896, 4 * 3102, 4 * 400_896),
     # fixed-order sum of the conv layers' weight-gradient slabs: 4 x 256 slabs of 64 KB (16x16 and 8x8 layers), 2 x 128
     # (4x4 layers), 2 x 256 x 2 KB (single-channel layers) + bias partials read, 2 MB of gradients written
@@ -112,7 +117,9 @@ ROCPROF_NAMES = {
     'pair_c1(down_c1 + wgrad_c1)': ['arvae::pair_c1_kernel<1>'], 'pair(wgrad_c1 + dense_wgrad_batch)': ['arvae::dense_wgrad_c1_kernel'],
     'pair(down32<16> + wgrad32<16>)': ['arvae::pair_down_wgrad_kernel<16, 3, 2>'], 'pair(down32<8> + wgrad32<8>)': ['arvae::pair_down_wgrad_kernel<8, 3, 2>'],
     'pair(up32<16> + wgrad32<16>)': ['arvae::pair_up16_wgrad_kernel<3, 1>'], 'pair(up32<8> + wgrad32<8>)': ['arvae::pair_up8_wgrad_kernel<3, 1>'],
-    'down_c1_kernel(+ weight prep)': ['arvae::down_c1s_prep_kernel'], 'up32_kernel<4>(+ reg_loss)': ['arvae::up32x_reg_kernel<1>'],
+    'down_c1_kernel(+ weight prep)': ['arvae::down_c1s_prep_kernel'], 'up32_kernel<4>(+ reg_loss)': ['arvae::up32x_reg_kernel<4, 1>'],
+    'up32_kernel<8>(+ reg_loss)': ['arvae::up32x_reg_kernel<8, 1>'],
+    'midc_forward_kernel(+ conv4, deconv1)': ['midc_forward_kernel'], 'midc_backward_kernel(+ conv4, deconv1)': ['midc_backward_kernel'],
     'down_c1_kernel': ['arvae::down_c1s_kernel<0>', 'arvae::down_c1s_kernel<1>'], 'wgrad_c1_kernel': ['arvae::wgrad_c1s_kernel'],
     'up_c1_kernel(recon)': ['arvae::up_c1_kernel<0, true>'],
     'conv64_down(wide)': ['arvae::conv64s_kernel<3, 2, 0>'], 'conv64_down(narrow)': ['arvae::conv64s_kernel<3, 1, 0>'],
@@ -404,7 +411,7 @@ def side_roofline(kind, prof, prof_steps, batch):
     out = {'kernel': name, 'rocprof_names': list(key), 'launches_per_step': dom['calls'] / prof_steps,
            'avg_launch_us': 1e3 * dom['ms'] / dom['calls'], 'us_per_step': 1e3 * dom['ms'] / prof_steps,
            'share_of_device_time': dom['ms'] / total, 'device_time_us_per_step': 1e3 * total / prof_steps}
-    for tag in ('r4', 'r3', 'r2'):      # the top kernel of the committed rocprofv3 --kernel-trace --stats summary of this workload
+    for tag in ('r5', 'r4', 'r3', 'r2'):      # the top kernel of the committed rocprofv3 --kernel-trace --stats summary of this workload
         try:
             import csv
             with open(os.path.join(ROOT, 'profiles', f'{tag}_{kind}_kernel_stats.csv')) as f:
@@ -646,7 +653,7 @@ def run_dsprites(device, args, fence, rank, world, use_dp):
     # (every kernel of the step above 2 % of its device time has a KERNEL_WORK entry; `unaccounted_labels` lists the rest)
     dom_name, dom = max(((k, v) for k, v in prof.items() if v['bytes'] > 0), key=lambda kv: kv[1]['ms'])
     avg_ms = dom['ms'] / dom['calls']
-    split = dom_name.startswith(('down32', 'up32', 'wgrad32', 'pair4', 'pair(down32', 'pair(up32'))
+    split = dom_name.startswith(('down32', 'up32', 'wgrad32', 'pair4', 'pair(down32', 'pair(up32'))      # (fp16 two-term MFMA kernels)
     mfma_peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
     mfma_work = dom['flop'] * (F16X2_PRODUCTS if split else 1)
     mfma_tf = mfma_work / dom['calls'] / (avg_ms * 1e-3) / 1e12
@@ -665,7 +672,7 @@ def run_dsprites(device, args, fence, rank, world, use_dp):
     # HBM traffic of that kernel from the PMC counters: collected in separate rocprofv3 --pmc passes of this
     # same command (FETCH_SIZE / WRITE_SIZE cannot share a pass) and committed under profiles/
     step_traffic = None
-    for tag in ('r4', 'r3', 'r2', 'r1'):
+    for tag in ('r5', 'r4', 'r3', 'r2', 'r1'):
         try:
             with open(os.path.join(ROOT, 'profiles', f'{tag}_pmc_traffic.json')) as f:
                 pmc = json.load(f)
@@ -686,7 +693,7 @@ def run_dsprites(device, args, fence, rank, world, use_dp):
     # figure above brackets every launch with its own events, which costs each kernel the overlap with its neighbours' tails)
     try:
         import csv
-        stats_csv = next(t for t in ('r4', 'r3', 'r2') if os.path.exists(os.path.join(ROOT, 'profiles', f'{t}_dsprites_kernel_stats.csv')))
+        stats_csv = next(t for t in ('r5', 'r4', 'r3', 'r2') if os.path.exists(os.path.join(ROOT, 'profiles', f'{t}_dsprites_kernel_stats.csv')))
         with open(os.path.join(ROOT, 'profiles', f'{stats_csv}_dsprites_kernel_stats.csv')) as f:
             rows = [r for r in csv.DictReader(f) if any(nm in r['Name'] for nm in (rocprof_names(dom_name) or []))]
         calls = sum(int(r['Calls']) for r in rows)
