@@ -139,6 +139,24 @@ def rocprof_names(label):
     return ROCPROF_NAMES.get(label, ['arvae::' + label] if label.endswith('_kernel') else None)
 
 
+def sq_counters(workload, names):
+    """rocprofv3 SQ counters of a kernel from the committed summary (profiles/r5_sq_counters.json, tools/pmc_sq_round.sh): the
+    counter-derived share of SIMD-cycles with the matrix pipe busy, beside the FLOP / time arithmetic of this run."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r5_sq_counters.json')) as f:
+            table = json.load(f).get(workload, {})
+    except (OSError, ValueError):
+        return None
+    for nm in names or []:
+        key = nm.replace('arvae::', '')
+        for k, v in table.items():
+            if k.startswith(key) or key in k:
+                return {'kernel': k, 'mfma_busy_frac': v['mfma_busy_frac'], 'valu_per_mfma': v.get('valu_per_mfma'),
+                        'avg_launch_us_profiled': v['avg_launch_us_profiled'],
+                        'source': 'profiles/r5_sq_counters.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / (1024 x GRBM_GUI_ACTIVE / 8))'}
+    return None
+
+
 REG_DIMS = (1, 2, 3, 4, 5)
 BETA, GAMMA, DELTA = 4.0, 10.0, 1.0
 
@@ -422,6 +440,7 @@ def side_roofline(kind, prof, prof_steps, batch):
             break
         except (OSError, KeyError, ValueError):
             continue
+    out['sq_counters'] = sq_counters(kind, list(key))
     macs = sum(SIDE_KERNEL_MACS.get(kind, {}).get(lb, 0) for lb in dom['labels'])
     for lb in dom['labels']:
         per_launch = SIDE_KERNEL_MACS_PER_LAUNCH.get(kind, {}).get(lb)
@@ -469,8 +488,11 @@ def run_side(kind, device, args, fence, rank, world, use_dp, with_cpu):
                       'final_loss': float(loss.detach())},
            'timing': timing,
            # whole-step fractions of the datasheet roofs (SURVEY 8(d) algorithmic FLOP / layer-boundary bytes per unit)
+           # (round 5: against the roof the arithmetic runs under -- the 16-bit MFMA peak divided by the partial products of the split
+           # that keeps fp32 accuracy, 3 for the scaled two-term fp16 kernels -- not against the fp32-MFMA peak this path left in round 3)
            'step_roofline': {'flop_per_unit': flop, 'bytes_per_unit': byts,
-                             'flop_frac_fp32': per_gpu * flop / (PEAK_F32_MFMA_TFLOPS * 1e12),
+                             'flop_frac_mfma16_3products': per_gpu * flop / (PEAK_BF16_MFMA_TFLOPS / F16X2_PRODUCTS * 1e12),
+                             'roof_tflops_fp32_equivalent': PEAK_BF16_MFMA_TFLOPS / F16X2_PRODUCTS,
                              'hbm_frac': per_gpu * byts / (PEAK_HBM_GBS * 1e9)},
            'roofline': side_roofline(kind, prof, prof_steps, bsz)}
     if with_cpu:
@@ -708,6 +730,7 @@ def run_dsprites(device, args, fence, rank, world, use_dp):
         pass
     roof['timing_source'] = ('achieved / frac: HIP events around every launch of the kernel, this run (avg_launch_us); achieved_rocprof / '
                              'frac_rocprof: the committed rocprofv3 --kernel-trace --stats average of the same kernel (rocprof_avg_launch_us)')
+    roof['sq_counters'] = sq_counters('dsprites', rocprof_names(dom_name))
     roof.update({'kernel': dom_name, 'rocprof_names': rocprof_names(dom_name),
                  'launches_per_step': dom['calls'] / prof_steps, 'avg_launch_us': avg_ms * 1e3,
                  'algorithmic_bytes_per_launch': dom['bytes'] / dom['calls'],
@@ -733,7 +756,7 @@ def run_dsprites(device, args, fence, rank, world, use_dp):
         'timing': timing,
         'roofline': roof,
         'step_roofline': {
-            'flop_frac_fp32': per_gpu * FLOP_PER_IMAGE / (PEAK_F32_MFMA_TFLOPS * 1e12),
+            'flop_frac_mfma16_3products': per_gpu * FLOP_PER_IMAGE / (PEAK_BF16_MFMA_TFLOPS / F16X2_PRODUCTS * 1e12),
             'hbm_frac': per_gpu * (BYTES_PER_IMAGE + PARAM_BYTES_PER_STEP / b) / (PEAK_HBM_GBS * 1e9),
             'binding': 'HBM roof 4.2 M img/s; fp32-MFMA roof 2.13 M img/s (no longer binding: the conv layers run on '
                        'the fp16 MFMA at 3 products per multiply-add, an 11 M img/s roof)'},

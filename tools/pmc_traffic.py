@@ -32,8 +32,14 @@ def label(kernel_name):
         return n.split('<')[0].replace('c1s', 'c1')
     if n.startswith('down_c1s_prep_kernel'):
         return 'down_c1_kernel(+ weight prep)'
+    if n.startswith('up32x_reg_kernel<8'):
+        return 'up32_kernel<8>(+ reg_loss)'
     if n.startswith('up32x_reg_kernel'):
         return 'up32_kernel<4>(+ reg_loss)'
+    if 'midc_forward_kernel' in n:                                       # (the default dSprites step folds the 4x4 conv layers into the block)
+        return 'midc_forward_kernel(+ conv4, deconv1)'
+    if 'midc_backward_kernel' in n:
+        return 'midc_backward_kernel(+ conv4, deconv1)'
     if n.startswith('pair4_down_kernel'):
         return 'pair4(down32 + wgrad32)'
     if n.startswith('pair4_up_kernel'):

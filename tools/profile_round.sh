@@ -4,7 +4,7 @@
 # 1. kernel-trace stats of the default bench command (dSprites) and of the two secondary workloads,
 # 2. separate --pmc passes (FETCH_SIZE, WRITE_SIZE cannot share a pass) for the HBM traffic of the dSprites kernels.
 cd "$(dirname "$0")/.."
-tag=${1:-r4}
+tag=${1:-r5}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
@@ -17,3 +17,5 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_write -o p -- python3
 python3 tools/pmc_traffic.py $(find /tmp/pmc_fetch -name '*counter_collection.csv' | head -1) $(find /tmp/pmc_write -name '*counter_collection.csv' | head -1) $out/pmc_traffic.json > $out/pmc_traffic.txt
 python3 bench.py > $out/bench_default.json 2> $out/bench_default.err
 python3 bench.py --breakdown --no-cpu-baseline --no-secondary > /dev/null 2> $out/breakdown.txt
+bash tools/pmc_sq_round.sh $tag
+for wl in dsprites mnist measure; do bash tools/trace_kernels.sh all WORKLOAD=$wl > $out/${wl}_launch_trace.txt 2>&1; done
