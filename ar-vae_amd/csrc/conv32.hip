@@ -575,9 +575,26 @@ __global__ __launch_bounds__(256, 1) void up32x_kernel(const float *__restrict__
 // Two barriers per tile.  (Round 3's first form had the patch loading and splitting on the store waves: they were busy 3.2 us
 // per tile, the compute waves 2.4 -- and as a gated data gradient its loader waited for the far patch loads, which the compute
 // waves now request a whole tile ahead.)  profiles/r3_phase_stamps.txt
-template <int MODE>
-__device__ __forceinline__ void up32p_body(const float *__restrict__ lo, Ep32 ep, int n_img, int n_tiles, const int BID, const int NBLK) {
+// C1W (round 5): this map is the data gradient of the layer BEHIND a single-channel first layer (Conv2d(1, 32, 4, 2, 1),
+// imagevae/dsprites_vae.py:12-13), and all that layer's backward pass wants from the 67 MB this map would write is its own weight
+// gradient dwt1[c][ky][kx] = sum over images and hi pixels (Y, X) of out[Y][X][c] * img[2 Y - 1 + ky][2 X - 1 + kx] (+ the bias sums).
+// The store waves then store NOTHING: each takes the gated results it holds (a 32-pixel x 32-channel block per M-tile) through a
+// wave-private LDS image into the fp16 MFMA with pixels as the K axis -- two-term operands, three products, the block's scale the
+// running maximum of what the wave has seen (a power of two: the accumulator is rescaled exactly when it grows) -- against the
+// image taps of those pixels, and leaves one [32][16] + 32 partial per workgroup (reduce.h, SLAB_C1).
+struct C1Wgrad {
+    const float *img;            // [n_img][64][64]: the first layer's input; |img| < 64 (a fixed operand scale of 2^10)
+    float *slab;                 // [workgroups of this body][SLAB_C1_FLOATS]
+};
+constexpr int C1W_VP = 16, C1W_XP = 16;                         // dwords per pixel of a wave's result / tap image (one fp16 term; taps 0-15, the constant 1 as "tap" 16, zeros)
+constexpr int C1W_WAVE_DW = 2 * 32 * C1W_VP + 2 * 32 * C1W_XP;   // per store wave: two terms of each
+constexpr float C1W_SX = 1024.f, C1W_SX_INV = 1.f / 1024.f;
+
+template <int MODE, bool C1W = false>
+__device__ __forceinline__ void up32p_body(const float *__restrict__ lo, Ep32 ep, int n_img, int n_tiles, const int BID, const int NBLK,
+                                           C1Wgrad c1 = C1Wgrad{nullptr, nullptr}) {
     static_assert(MODE != EP_GATE_F, "up32p_kernel: float gates stay on up32x_kernel");
+    static_assert(!C1W || MODE == EP_GATE_B, "the fused first-layer weight gradient takes the sign-bit gated data gradient");
     constexpr int LO = 16, PX = 128, HI = 2 * LO, MT = PX / 32;
     using PL = PatchLoader<LO, 1, PX>;
     constexpr int PR = PL::PR, PC = PL::PC, PLANE = PL::PLANE_DW, SLOTS = PL::SLOTS, ITERS = PL::ITERS;
@@ -646,7 +663,126 @@ __device__ __forceinline__ void up32p_body(const float *__restrict__ lo, Ep32 ep
                 if (MODE == EP_RELU) buf_store_u16(bits, rs_bits, (base == OOB || !want_bits) ? OOB : bits_off(poff, half));
             }
         };
+        // ---- C1W: the first layer's weight gradient from the results this wave holds (see C1Wgrad) ----
+        unsigned *c1_v = lds + 2 * BUF + 4 * MT * 4 * 64 * 4 + (wave - 4) * C1W_WAVE_DW;     // behind the handoff area: [term][pixel][C1W_VP]
+        unsigned *c1_x = c1_v + 2 * 32 * C1W_VP;                                             //                          [term][pixel][C1W_XP]
+        f32x16 c1_acc, c1_acc2;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { c1_acc[i] = 0.f; c1_acc2[i] = 0.f; }
+        const __amdgpu_buffer_rsrc_t rs_img = make_rsrc(C1W ? c1.img : ep.out, C1W ? (int64_t)n_img * 4 * HI * HI * 4 : 0);
+        // transposed-read addresses (wgrad32x_body): 16-lane group g16 reads pixels 16 b + 8 (g16 >> 1) + 4 i + q; lane 4 q + p of
+        // the group points at channels 4 p .. 4 p + 3 (+ 16 (g16 & 1)) of pixel row q; the tap image's "channels" 16-31 are the constant 1
+        // and zeros: accumulator column 16 collects the bias sums
+        int c1_voff[2][2], c1_xoff[2][2];
+        const int c1_sw = 2 * ((rc >> 2) & 7);                   // this lane's row swizzle (its pixel row is rc)
+        {
+            const int g16 = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int P = 16 * b + 8 * (g16 >> 1) + 4 * i + q;
+                    // (rows are 16 dwords = a quarter of the banks apart, so the WRITES -- every lane its own pixel row -- would meet
+                    // eight to a bank; the dword offset inside a row is XORed with 2 ((P >> 2) & 7): the four rows of a transposed
+                    // read share P >> 2 and stay on their four quarters, the 64 row pieces of a write spread over all banks)
+                    const int sw = 2 * ((P >> 2) & 7);
+                    c1_voff[b][i] = P * C1W_VP + ((8 * (g16 & 1) + 2 * pp) ^ sw);
+                    c1_xoff[b][i] = P * C1W_XP + ((8 * (g16 & 1) + 2 * pp) ^ sw);
+                }
+            if constexpr (C1W) {                                 // the constant half of the tap image: column 16 = 1 (x C1W_SX = 1024 = 0x6400), 17-31 = 0
+                const int csw = 2 * ((rc >> 2) & 7);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int col = 8 + 4 * half + d;
+                    c1_x[rc * C1W_XP + (col ^ csw)] = col == 8 ? 0x6400u : 0u;
+                    c1_x[32 * C1W_XP + rc * C1W_XP + (col ^ csw)] = 0u;
+                }
+            }
+        }
+        // the image taps of this lane's hi pixel in M-tile mt: rows ky = 2 half, 2 half + 1, columns 2 X - 1 .. 2 X + 2, requested one
+        // tile ahead.  Column -1 (X = 0) and column 64 (X = 31) are outside the image: the first is fetched from column 0 and
+        // shifted, the second masked; rows outside read nothing.
+        float4 c1_tap[MT][2], c1_tapn[MT][2];
+        auto c1_request = [&](int tile) __attribute__((always_inline)) {
+            if constexpr (C1W) {
+                int img0, r0;
+                tile_origin<LO, PX>(tile, img0, r0);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    int im, r, c;
+                    tile_pixel<LO, PX>(mt * 32 + rc, im, r, c);
+                    const int Y = 2 * (r0 + r) + py, X = 2 * c + px;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int iy = 2 * Y - 1 + 2 * half + e, ix = X == 0 ? 0 : 2 * X - 1;
+                        const bool ok = tile < t_end && (unsigned)iy < (unsigned)(2 * HI);
+                        c1_tapn[mt][e] = buf_load4(rs_img, ok ? (unsigned)((((img0 + im) * 2 * HI + iy) * 2 * HI + ix) * 4) : OOB);
+                    }
+                }
+            }
+        };
+        // The results' scale is STATIC: an accumulator is a sum of 128 products of operands below 2^15 each, so acc * 2^-23 is below
+        // 2^14 whatever the data (typical blocks sit ~2^10 lower: the second fp16 term still has its bits there), and the factor
+        // 2^23 * inv goes into the final scaling.  The bias sums ride in the MFMA: the tap image's column 16 is the constant 1
+        // (1024 / C1W_SX in its scale), so accumulator column 16 is the sum of the results.
+        auto c1_tile = [&](unsigned base) __attribute__((always_inline)) {
+            if constexpr (C1W) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    // results -> [pixel rc][channel] (even channel in the low half of a dword), taps -> [pixel rc][tap]
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 a = hand[((cls * MT + mt) * 4 + g) * 64 + lane];
+                        const unsigned bits = base != OOB ? gb[mt] >> (4 * g) : 0u;
+                        const float v0 = (bits & 1u) ? a.x : 0.f, v1 = (bits & 2u) ? a.y : 0.f, v2 = (bits & 4u) ? a.z : 0.f, v3 = (bits & 8u) ? a.w : 0.f;
+                        uint2 hv, lv;
+                        split_pair_h2(v0, v1, 0x1p-23f, hv.x, lv.x);
+                        split_pair_h2(v2, v3, 0x1p-23f, hv.y, lv.y);
+                        const int vd = (4 * g + 2 * half) ^ c1_sw;                     // (an even XOR keeps the dword pair together)
+                        *reinterpret_cast<uint2 *>(c1_v + rc * C1W_VP + vd) = hv;
+                        *reinterpret_cast<uint2 *>(c1_v + 32 * C1W_VP + rc * C1W_VP + vd) = lv;
+                    }
+                    {
+                        int im, r, c;
+                        tile_pixel<LO, PX>(mt * 32 + rc, im, r, c);
+                        const int X = 2 * c + px;
+                        uint4 hx, lx;
+                        unsigned *hp = &hx.x, *lp = &lx.x;
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            float4 t = c1_tap[mt][e];
+                            if (X == 0) t = make_float4(0.f, t.x, t.y, t.z);
+                            if (X == HI - 1) t.w = 0.f;
+                            split_pair_h2(t.x, t.y, C1W_SX, hp[2 * e], lp[2 * e]);
+                            split_pair_h2(t.z, t.w, C1W_SX, hp[2 * e + 1], lp[2 * e + 1]);
+                        }
+                        // (dword pairs: the XOR moves pairs, not quads)
+                        *reinterpret_cast<uint2 *>(c1_x + rc * C1W_XP + ((4 * half) ^ c1_sw)) = make_uint2(hx.x, hx.y);
+                        *reinterpret_cast<uint2 *>(c1_x + rc * C1W_XP + ((4 * half + 2) ^ c1_sw)) = make_uint2(hx.z, hx.w);
+                        *reinterpret_cast<uint2 *>(c1_x + 32 * C1W_XP + rc * C1W_XP + ((4 * half) ^ c1_sw)) = make_uint2(lx.x, lx.y);
+                        *reinterpret_cast<uint2 *>(c1_x + 32 * C1W_XP + rc * C1W_XP + ((4 * half + 2) ^ c1_sw)) = make_uint2(lx.z, lx.w);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (wave-private image: its own writes, in order)
+                    f16x8 a2[2][2], b2[2][2];
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            a2[b][t] = lds_tr_f16x8(c1_v + t * 32 * C1W_VP + c1_voff[b][0], c1_v + t * 32 * C1W_VP + c1_voff[b][1]);
+                            b2[b][t] = lds_tr_f16x8(c1_x + t * 32 * C1W_XP + c1_xoff[b][0], c1_x + t * 32 * C1W_XP + c1_xoff[b][1]);
+                        }
+                    // (two accumulators: an MFMA into the result of the previous one waits for it)
+                    MFMA_H(c1_acc, a2[0][1], b2[0][0]);          // smallest partial products first
+                    MFMA_H(c1_acc2, a2[1][1], b2[1][0]);
+                    MFMA_H(c1_acc, a2[0][0], b2[0][1]);
+                    MFMA_H(c1_acc2, a2[1][0], b2[1][1]);
+                    MFMA_H(c1_acc, a2[0][0], b2[0][0]);
+                    MFMA_H(c1_acc2, a2[1][0], b2[1][0]);
+                }
+            }
+        };
         request_gates(tile_base(t_first));
+        c1_request(t_first);
         __syncthreads();                                         // (the compute waves' prologue barriers)
         __syncthreads();
         for (int tile = t_first; tile < t_end; ++tile) {
@@ -658,11 +794,39 @@ __device__ __forceinline__ void up32p_body(const float *__restrict__ lo, Ep32 ep
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) gb[mt] = gbn[mt];
             request_gates(tile_base(tile + 1));
+            if constexpr (C1W) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) { c1_tap[mt][0] = c1_tapn[mt][0]; c1_tap[mt][1] = c1_tapn[mt][1]; }
+                c1_request(tile + 1);
+            }
             PSTAMP(1, 6 + 6 * pst);
-            epilogue(tile_base(tile));
+            if constexpr (C1W) c1_tile(tile_base(tile));
+            else epilogue(tile_base(tile));
             PSTAMP(1, 7 + 6 * pst);
             PSTAMP(1, 8 + 6 * pst);
             ++pst;
+        }
+        if constexpr (C1W) {
+            // the four classes' partials meet in the handoff area (free: the compute waves have left their loop); wave 4 finishes.
+            // accumulator register i of lane (tap = rc, half): channel 8 (i >> 2) + 4 half + (i & 3); columns (taps) 16-31 are repeats.
+            __syncthreads();                                     // (pairs with the compute waves' closing barrier)
+            float *fin = reinterpret_cast<float *>(hand);
+            const float k = inv * 0x1p+23f * C1W_SX_INV;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) fin[((wave - 4) * 16 + i) * 64 + lane] = (c1_acc[i] + c1_acc2[i]) * k;
+            __syncthreads();
+            if (wave == 4) {
+                float *out = c1.slab + (int64_t)BID * SLAB_C1_FLOATS;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float t = (fin[(0 * 16 + i) * 64 + lane] + fin[(1 * 16 + i) * 64 + lane]) + (fin[(2 * 16 + i) * 64 + lane] + fin[(3 * 16 + i) * 64 + lane]);
+                    const int ch = 8 * (i >> 2) + 4 * half + (i & 3);
+                    if (rc < 16) out[ch * 16 + rc] = t;
+                    if (rc == 16) out[32 * 16 + ch] = t;         // (column 16: the results times the constant 1)
+                }
+                if (lane == 0) out[32 * 16 + 32] = 0.f;
+            }
+            return;
         }
         amax_publish(ep.amax_out, BID * 4 + cls, NBLK * 4, amax_run);
         PSTAMP(1, 63);
@@ -802,6 +966,10 @@ __device__ __forceinline__ void up32p_body(const float *__restrict__ lo, Ep32 ep
         ++cst;
     }
     PSTAMP(0, 63);
+    if constexpr (C1W) {                                         // (the store waves' closing exchange)
+        __syncthreads();
+        __syncthreads();
+    }
 }
 template <int MODE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void up32p_kernel(const float *__restrict__ lo, Ep32 ep,
@@ -1002,11 +1170,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if ((int)blockIdx.x < grid_a) down32p_body<LO, MODE>(g_hi, ep, n_img, tiles_a, blockIdx.x, grid_a);
     else wgrad32r_body<LO, BIAS>(w_lo, w_hi, slab, n_img, total_steps, steps_per_wg, amax_lo, amax_hi, blockIdx.x - grid_a);
 }
-template <int MODE, int BIAS>
+template <int MODE, int BIAS, bool C1W = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void pair_up16_wgrad_kernel(
     const float *__restrict__ g_lo, Ep32 ep, int n_img, int tiles_a, int grid_a, const float *__restrict__ w_lo, const float *__restrict__ w_hi,
-    float *__restrict__ slab, int total_steps, int steps_per_wg, const unsigned *amax_lo, const unsigned *amax_hi) {
-    if ((int)blockIdx.x < grid_a) up32p_body<MODE>(g_lo, ep, n_img, tiles_a, blockIdx.x, grid_a);
+    float *__restrict__ slab, int total_steps, int steps_per_wg, const unsigned *amax_lo, const unsigned *amax_hi, C1Wgrad c1) {
+    if ((int)blockIdx.x < grid_a) up32p_body<MODE, C1W>(g_lo, ep, n_img, tiles_a, blockIdx.x, grid_a, c1);
     else wgrad32r_body<16, BIAS>(w_lo, w_hi, slab, n_img, total_steps, steps_per_wg, amax_lo, amax_hi, blockIdx.x - grid_a);
 }
 // (the 8x8 Up body is a 256-thread workgroup: its launch-mates' other four waves leave at once)
@@ -1315,6 +1483,11 @@ int conv32_wgrad_partial(const arvae_link_t *l, const Operand &lo, const Operand
 // up == true: the layer is a forward UP link (data gradient = DOWN map on g, weight gradient with g on the hi side, bias mode 2);
 // up == false: a forward DOWN link (data gradient = UP map, g on the lo side, bias mode 1).  Only the combinations the image
 // executor produces are instantiated; everything else (and the experiment switches) goes the two-launch way.
+// ... when the Up half of the 16x16 pair stores nothing (C1Wgrad: the first layer's weight gradient in its store waves)
+static int pair_split_c1_percent() {
+    static const int forced = diag_env("ARVAE_PAIR_SPLIT_C1") != nullptr ? atoi(diag_env("ARVAE_PAIR_SPLIT_C1")) : 0;
+    return (forced > 0 && forced < 100) ? forced : 62;        // (same-box sweep at B = 512: 38 / 44 / 50 / 56 / 62 / 68 % -> 55.1 / 50.8 / 43.6 / 43.8 / 39.1 / 43.3 us)
+}
 static int pair_split_percent(int lh, bool up) {              // share of the workgroups that runs the data gradient
     // ARVAE_PAIR_SPLIT16 / _SPLIT8: both pairs of that size; ..._SPLIT16U / 16D / 8U / 8D: the pair whose data gradient is the Up
     // (forward Down layer) / Down map
@@ -1344,9 +1517,11 @@ bool conv32_pair_fits(const arvae_link_t *l, bool up, const float *gate, const u
 }
 
 template <int LO> static int launch_pair_big(const arvae_link_t *l, bool up, const float *g, const float *x_in, const Ep32 &ep, float *slab,
-                                             const unsigned *amax_g, const unsigned *amax_x, hipStream_t s, int *grid_b_out) {
+                                             const unsigned *amax_g, const unsigned *amax_x, hipStream_t s, int *grid_b_out,
+                                             const C1Wgrad *c1 = nullptr, int *grid_a_out = nullptr) {
     const int cus = cu_count() < AMAX_N / 4 ? cu_count() : AMAX_N / 4;
-    int grid_a = cus * pair_split_percent(LO, up) / 100;
+    int grid_a = cus * (c1 != nullptr ? pair_split_c1_percent() : pair_split_percent(LO, up)) / 100;
+    if (grid_a_out != nullptr) *grid_a_out = grid_a;
     if (grid_a < 1) grid_a = 1;
     int total, spw, grid_b;
     stream_geometry(l, cus - grid_a, total, spw, grid_b);
@@ -1366,9 +1541,17 @@ template <int LO> static int launch_pair_big(const arvae_link_t *l, bool up, con
         constexpr int LDS_U = (2 * 2 * PatchLoader<16, 1, 128>::PLANE_DW) * 4 + 4 * 4 * 4 * 64 * 16;
         constexpr int LDS = MaxOf<LDS_W, LDS_U>::value;
         static std::once_flag attr;
+        if (c1 != nullptr) {                                     // + the first layer's weight gradient in the Up half's store waves
+            constexpr int LDS_C = MaxOf<LDS_W, LDS_U + 4 * C1W_WAVE_DW * 4>::value;
+            static std::once_flag attr_c;
+            std::call_once(attr_c, [&] { allow_lds(pair_up16_wgrad_kernel<EP_GATE_B, 1, true>, LDS_C); });
+            ARVAE_LAUNCH((pair_up16_wgrad_kernel<EP_GATE_B, 1, true>), grid, dim3(512), LDS_C, s, g, ep, l->n, tiles_for<16, 128>(l->n), grid_a, g, x_in,
+                         slab, total, spw, amax_g, amax_x, *c1);
+            return check_launch("pair(up32<16> + wgrad32<16> + wgrad_c1)");
+        }
         std::call_once(attr, [&] { allow_lds(pair_up16_wgrad_kernel<EP_GATE_B, 1>, LDS); });
         ARVAE_LAUNCH((pair_up16_wgrad_kernel<EP_GATE_B, 1>), grid, dim3(512), LDS, s, g, ep, l->n, tiles_for<16, 128>(l->n), grid_a, g, x_in, slab,
-                     total, spw, amax_g, amax_x);
+                     total, spw, amax_g, amax_x, C1Wgrad{nullptr, nullptr});
         return check_launch("pair(up32<16> + wgrad32<16>)");
     } else {
         constexpr int LDS = MaxOf<LDS_W, 2 * PatchLoader<8, 1, 32>::PLANE_DW * 4>::value;
@@ -1381,16 +1564,26 @@ template <int LO> static int launch_pair_big(const arvae_link_t *l, bool up, con
 }
 
 // amax_g / amax_x: AMAX arrays of the incoming gradient and of the layer's input; amax_out: of d_in (may be null)
+// c1_img / c1_slab / c1_job (all or none; the 16x16 layer behind a single-channel first layer, sign-bit gates): the first
+// layer's weight gradient comes out of this launch too (up32p_body, C1Wgrad) and the data gradient is NOT stored (d_in unused)
+bool conv32_pair_c1_fits(const arvae_link_t *l, bool up, const uint16_t *gate_bits) {
+    static const bool off = diag_env("ARVAE_NO_PAIR_C1W") != nullptr;
+    return !off && !up && l->lh == 16 && gate_bits != nullptr && diag_env("ARVAE_UP32_NO_PC") == nullptr;
+}
 int conv32_pair(const arvae_link_t *l, bool up, const float *g, const float *x_in, const float *gate, const uint16_t *gate_bits,
                 float *d_in, const float *wprep, float *dwt, float *dbias, float *slab, hipStream_t s, SlabJob *job,
-                const unsigned *amax_g, const unsigned *amax_x, unsigned *amax_out) {
+                const unsigned *amax_g, const unsigned *amax_x, unsigned *amax_out, const float *c1_img, float *c1_slab, SlabJob *c1_job) {
     ARVAE_REQUIRE(wprep != nullptr && amax_g != nullptr && amax_x != nullptr, "conv32_pair: prepared weights and the operands' maxima are needed");
     Ep32 ep{nullptr, gate_bits ? nullptr : gate, gate_bits, nullptr, d_in, reinterpret_cast<const uint4 *>(wprep), amax_g, amax_out};
     if (l->lh != 4) {
-        int grid_b = 0;
-        const int rc = l->lh == 16 ? launch_pair_big<16>(l, up, g, x_in, ep, slab, amax_g, amax_x, s, &grid_b)
+        int grid_b = 0, grid_a = 0;
+        C1Wgrad c1{c1_img, c1_slab};
+        const bool fuse = c1_img != nullptr && c1_slab != nullptr && c1_job != nullptr && conv32_pair_c1_fits(l, up, gate_bits);
+        ARVAE_REQUIRE(fuse || c1_img == nullptr, "conv32_pair: this layer cannot carry the first layer's weight gradient");
+        const int rc = l->lh == 16 ? launch_pair_big<16>(l, up, g, x_in, ep, slab, amax_g, amax_x, s, &grid_b, fuse ? &c1 : nullptr, &grid_a)
                                    : launch_pair_big<8>(l, up, g, x_in, ep, slab, amax_g, amax_x, s, &grid_b);
         *job = SlabJob{slab, dwt, dbias, grid_b, SLAB_C32, up ? 2 : 1};
+        if (fuse) *c1_job = SlabJob{c1_slab, nullptr, nullptr, grid_a, SLAB_C1, 1};       // (dwt / dbias: the caller's)
         return rc;
     }
     constexpr int LDS_U = 2 * PatchLoader<4, 1, 32>::PLANE_DW * 4;

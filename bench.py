@@ -81,6 +81,9 @@ KERNEL_WORK = {
     'pair(wgrad_c1 + dense_wgrad_batch)': (524_288 + 400_896, 4 * (32768 + 4096) + 4 * 3102, 4 * 400_896),
     'pair(down32<16> + wgrad32<16>)': (2 * 4_194_304, 4 * (32768 + 8192 + 8192)), 'pair(up32<16> + wgrad32<16>)': (2 * 4_194_304, 4 * (8192 + 32768 + 32768)),
     'pair(down32<8> + wgrad32<8>)': (2 * 1_048_576, 4 * (8192 + 2048 + 2048)), 'pair(up32<8> + wgrad32<8>)': (2 * 1_048_576, 4 * (2048 + 8192 + 8192)),
+    # round 5: conv2's backward with conv1's weight gradient in the Up half's store waves (the data gradient in between is never
+    # stored): the layer-boundary bytes of BOTH layers' backward passes (SURVEY 8(d) counts the gradient between them written and read)
+    'pair(up32<16> + wgrad32<16> + wgrad_c1)': (2 * 4_194_304 + 524_288, 4 * (8192 + 32768 + 32768) + 4 * (32768 + 4096)),
     # the first encoder layer with the step's weight preparation riding in its grid; the decoder's first convolution with
     # the regulariser's workgroups riding in its grid
     'down_c1_kernel(+ weight prep)': (524_288, 4 * (4096 + 32768), 8_000_000), 'up32_kernel<4>(+ reg_loss)': (262_144, 4 * (512 + 2048)),
@@ -117,6 +120,7 @@ ROCPROF_NAMES = {
     'pair_c1(down_c1 + wgrad_c1)': ['arvae::pair_c1_kernel<1>'], 'pair(wgrad_c1 + dense_wgrad_batch)': ['arvae::dense_wgrad_c1_kernel'],
     'pair(down32<16> + wgrad32<16>)': ['arvae::pair_down_wgrad_kernel<16, 3, 2>'], 'pair(down32<8> + wgrad32<8>)': ['arvae::pair_down_wgrad_kernel<8, 3, 2>'],
     'pair(up32<16> + wgrad32<16>)': ['arvae::pair_up16_wgrad_kernel<3, 1>'], 'pair(up32<8> + wgrad32<8>)': ['arvae::pair_up8_wgrad_kernel<3, 1>'],
+    'pair(up32<16> + wgrad32<16> + wgrad_c1)': ['arvae::pair_up16_wgrad_kernel<3, 1, true>'],
     'down_c1_kernel(+ weight prep)': ['arvae::down_c1s_prep_kernel'], 'up32_kernel<4>(+ reg_loss)': ['arvae::up32x_reg_kernel<4, 1>'],
     'up32_kernel<8>(+ reg_loss)': ['arvae::up32x_reg_kernel<8, 1>'],
     'midc_forward_kernel(+ conv4, deconv1)': ['midc_forward_kernel'], 'midc_backward_kernel(+ conv4, deconv1)': ['midc_backward_kernel'],

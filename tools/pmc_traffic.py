@@ -22,6 +22,8 @@ def label(kernel_name):
     m = re.match(r'pair_down_wgrad_kernel<(\d+),', n)
     if m:
         return f'pair(down32<{m.group(1)}> + wgrad32<{m.group(1)}>)'
+    if n.startswith('pair_up16_wgrad_kernel') and 'true' in n:
+        return 'pair(up32<16> + wgrad32<16> + wgrad_c1)'
     if n.startswith('pair_up16_wgrad_kernel'):
         return 'pair(up32<16> + wgrad32<16>)'
     if n.startswith('pair_up8_wgrad_kernel'):
