@@ -541,8 +541,34 @@ __device__ __forceinline__ f16x8g lds_h8(const unsigned short *p) {
     A0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(AH, WH0, A0, 0, 0, 0); A1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(AH, WH1, A1, 0, 0, 0); \
     A2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(AH, WH2, A2, 0, 0, 0)
 
-template <int H>
+// Quad q's lanes receive element q of the f32x4 their column's lane in quad 0 holds (three swaps of register halves / quarters): the
+// four live rows of a 16 x 16 MFMA result, one per lane.
+// (inline assembly: through __builtin_amdgcn_permlane16_swap / _permlane32_swap this compiler fed the first swap the SAME register
+// twice when only one half of the builtin's result pair was used, and declared the other three accumulator registers dead -- quads 1-3
+// then received element 0; tools/probes/permlane_swap.hip shows the instructions themselves do what the ISA says.  The s_nop in front
+// covers an MFMA result read by a vector instruction the compiler's hazard recogniser does not see: 8 passes + 2.)
+__device__ __forceinline__ float spread_rows(const f32x4 &a) {
+    float x0 = a[0], x1 = a[1], x2 = a[2], x3 = a[3];
+    asm volatile("s_nop 15\n\t"
+                 "v_permlane16_swap_b32 %0, %1\n\t"              // x0 = [a0.q0 | a1.q0 | a0.q2 | a1.q2]
+                 "v_permlane16_swap_b32 %2, %3\n\t"              // x2 = [a2.q0 | a3.q0 | a2.q2 | a3.q2]
+                 "s_nop 1\n\t"
+                 "v_permlane32_swap_b32 %0, %2\n\t"              // x0 = [a0.q0 | a1.q0 | a2.q0 | a3.q0]
+                 "s_nop 1"
+                 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+    return x0;
+}
+
+// RW: batch rows per workgroup, 16 or 4.  A recurrence is a chain of T dependent steps whose length is the instruction stream of one
+// wave between two barriers, and most of that stream is per (row, hidden unit) ELEMENT work: projections in,
+// gates, the state's split and its LDS writes, h and the saved gates out -- four elements per lane when a workgroup owns 16 rows.
+// With 4 rows per workgroup the 16 x 16 MFMA tile is three quarters empty (the matrix pipe was idle anyway), the four live rows of
+// a result go out to the four quads (spread_rows) and every lane does ONE element per step; four times the workgroups, on a chip
+// that the recurrences of a 256-measure batch fill to an eighth.  The host picks 4 when those workgroups still fit the chip at once.
+template <int H, int RW>
 __global__ __launch_bounds__(H * 4) void gru_seq_fwd_h2_kernel(GruSeqBatch batch, int T, int R) {
+    static_assert(RW == 16 || RW == 4, "16 rows (four per lane) or 4 rows (one per lane)");
+    constexpr int E = RW / 4;              // elements (rows) per lane
     constexpr int KS = H / 32;             // MFMA k-steps of 32
     constexpr int HP = H + 8;              // LDS row pitch in bf16 elements (16 bytes of padding)
     constexpr int PLANE = 16 * HP;
@@ -552,7 +578,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_h2_kernel(GruSeqBatch batch
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int col = lane & 15, quad = lane >> 4;
     const int unit = 16 * w + col;
-    const int row0 = blockIdx.x * 16;
+    const int row0 = blockIdx.x * RW;
 
     f16x8g wh[3][KS], wl[3][KS];
 #pragma unroll
@@ -566,16 +592,17 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_h2_kernel(GruSeqBatch batch
         }
     const float bh_r = s.b_hh[unit], bh_z = s.b_hh[H + unit], bh_n = s.b_hh[2 * H + unit];
 
-    int rows[4];
-    bool live[4];
-    float h[4];
+    int rows[E];
+    bool live[E];
+    float h[E];
+    auto lrow = [&](int i) { return E == 4 ? 4 * quad + i : quad; };          // the tile row of this lane's element i
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = row0 + 4 * quad + i;
+    for (int i = 0; i < E; ++i) {
+        const int r = row0 + lrow(i);
         live[i] = r < R;
         rows[i] = live[i] ? r : R - 1;
         h[i] = (s.h0 != nullptr && live[i]) ? s.h0[(int64_t)rows[i] * s.h0_stride + unit] : 0.f;
-        store_split2(&hbuf[0][(4 * quad + i) * HP + unit], PLANE, h[i]);
+        store_split2(&hbuf[0][lrow(i) * HP + unit], PLANE, h[i]);
     }
     // per-step memory operations as raw buffer operations (gru_rsrc): a scalar step offset + one per-lane offset per array and row
     // (the running 64-bit pointers this kernel had cost 24 registers and a 64-bit add each per step; the first and last step's
@@ -583,10 +610,10 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_h2_kernel(GruSeqBatch batch
     const __amdgpu_buffer_rsrc_t rs_gi = gru_rsrc(s.gi), rs_h = gru_rsrc(s.h_all), rs_sv = gru_rsrc(s.saved), rs_none = gru_rsrc(nullptr);
     const int reverse = s.reverse, unit4 = 4 * unit;
     const int gi_tp = 4 * (int)s.gi_tstride, h_tp = 4 * R * (int)s.h_stride;
-    int gi_o[4], h_o[4], sv_o[4];
-    float gi_next[4][3];
+    int gi_o[E], h_o[E], sv_o[E];
+    float gi_next[E][3];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < E; ++i) {
         gi_o[i] = gru_off(rows[i], 4 * (int)s.gi_rstride, unit4);
         h_o[i] = live[i] ? gru_off(rows[i], 4 * (int)s.h_stride, unit4) : GRU_DEAD;
         sv_o[i] = live[i] ? gru_off(rows[i], 16 * H, 4 * unit4) : GRU_DEAD;
@@ -594,8 +621,8 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_h2_kernel(GruSeqBatch batch
         gi_next[i][0] = gru_ld(rs_gi, gi_o[i], so); gi_next[i][1] = gru_ld(rs_gi, gi_o[i] + 4 * H, so); gi_next[i][2] = gru_ld(rs_gi, gi_o[i] + 8 * H, so);
     }
     lds_barrier();
-    f32x4 keep_sv[4];                        // results of the previous step, stored after the barrier
-    float keep_h[4];
+    f32x4 keep_sv[E];                        // results of the previous step, stored after the barrier
+    float keep_h[E];
     int keep_t = -1;
 #ifdef ARVAE_GRU_STAMPS
     unsigned long long ph[4] = {0, 0, 0, 0}, tc = __builtin_readcyclecounter();
@@ -607,14 +634,14 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_h2_kernel(GruSeqBatch batch
     for (int step = 0; step < T; ++step) {
         const int t = s.reverse ? T - 1 - step : step;
         const int cur = step & 1;
-        float gi[4][3];
+        float gi[E][3];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < E; ++i)
 #pragma unroll
             for (int g = 0; g < 3; ++g) gi[i][g] = gi_next[i][g];
         GSTAMP(0);
         f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        const unsigned short *hb = &hbuf[cur][col * HP + 8 * quad];
+        const unsigned short *hb = &hbuf[cur][(RW == 16 ? col : (col & 3)) * HP + 8 * quad];   // (RW 4: tile rows 4 .. 15 repeat the live ones)
         // Row i's share of the step's memory traffic (next step's three input projections in, the previous step's h and saved
         // gates out) is issued BEHIND the MFMAs of k-step i, with a scheduling barrier pinning it there: as one block in front
         // of the MFMAs it was 1200 of the step's 6000 cycles (tools/stamp_gru.py), all of it issue time of an in-order wave
@@ -636,28 +663,42 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_h2_kernel(GruSeqBatch batch
             const f16x8g ah = lds_h8(hb + 32 * ks), al = lds_h8(hb + PLANE + 32 * ks);
             GRU_MFMA3X3(acc[0], acc[1], acc[2], ah, al, wh[0][ks], wl[0][ks], wh[1][ks], wl[1][ks], wh[2][ks], wl[2][ks]);
             __builtin_amdgcn_sched_barrier(0);
-            row_traffic(ks);
+            if (ks < E) row_traffic(ks);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int i = KS; i < 4; ++i) row_traffic(i);
+        for (int i = KS; i < E; ++i) row_traffic(i);
 #ifdef ARVAE_GRU_STAMPS
         { float dep = acc[0][0] + acc[1][0] + acc[2][3]; asm volatile("" :: "v"(dep)); __builtin_amdgcn_s_waitcnt(0); }
 #endif
         GSTAMP(1);
+        float av[3][E];                      // the gates' products of this lane's elements
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float r = fast_sigmoid(gi[i][0] + acc[0][i] * GRU_UNSCALE + bh_r);
-            const float z = fast_sigmoid(gi[i][1] + acc[1][i] * GRU_UNSCALE + bh_z);
-            const float ghn = acc[2][i] * GRU_UNSCALE + bh_n;
+        for (int g = 0; g < 3; ++g) {
+            if constexpr (E == 4) {
+#pragma unroll
+                for (int i = 0; i < E; ++i) av[g][i] = acc[g][i];
+            } else {
+                av[g][0] = spread_rows(acc[g]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const float r = fast_sigmoid(gi[i][0] + av[0][i] * GRU_UNSCALE + bh_r);
+            const float z = fast_sigmoid(gi[i][1] + av[1][i] * GRU_UNSCALE + bh_z);
+            const float ghn = av[2][i] * GRU_UNSCALE + bh_n;
             const float n = fast_tanh(gi[i][2] + r * ghn);
             const float hn = (1.f - z) * n + z * h[i];
             h[i] = hn;
             keep_h[i] = hn;
             keep_sv[i] = f32x4{r, z, n, ghn};
         }
-        store_split2_pair(&hbuf[cur ^ 1][(4 * quad) * HP + unit], HP, PLANE, h[0], h[1]);
-        store_split2_pair(&hbuf[cur ^ 1][(4 * quad + 2) * HP + unit], HP, PLANE, h[2], h[3]);
+        if constexpr (E == 4) {
+            store_split2_pair(&hbuf[cur ^ 1][(4 * quad) * HP + unit], HP, PLANE, h[0], h[1]);
+            store_split2_pair(&hbuf[cur ^ 1][(4 * quad + 2) * HP + unit], HP, PLANE, h[2], h[3]);
+        } else {
+            store_split2(&hbuf[cur ^ 1][quad * HP + unit], PLANE, h[0]);
+        }
         keep_t = t;
 #ifdef ARVAE_GRU_STAMPS
         __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the LDS writes are done
@@ -673,7 +714,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_h2_kernel(GruSeqBatch batch
     }
 #endif
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < E; ++i)
         if (live[i]) {
             gru_st(keep_h[i], rs_h, h_o[i], keep_t * h_tp);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4g, keep_sv[i]), rs_sv, sv_o[i], keep_t * R * (16 * H), 0);
@@ -681,8 +722,11 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_h2_kernel(GruSeqBatch batch
         }
 }
 
-template <int H>
+// (RW: batch rows per workgroup, 16 or 4 -- see gru_seq_fwd_h2_kernel)
+template <int H, int RW>
 __global__ __launch_bounds__(H * 4) void gru_seq_bwd_x3_kernel(GruSeqBatch batch, int T, int R) {
+    static_assert(RW == 16 || RW == 4, "16 rows (four per lane) or 4 rows (one per lane)");
+    constexpr int E = RW / 4;              // elements (rows) per lane
     constexpr int KS = 3 * H / 32;
     constexpr int DP = 3 * H + 8;           // LDS row pitch in bf16 elements
     constexpr int PLANE = 16 * DP;
@@ -692,7 +736,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_x3_kernel(GruSeqBatch batch
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int col = lane & 15, quad = lane >> 4;
     const int unit = 16 * w + col;
-    const int row0 = blockIdx.x * 16;
+    const int row0 = blockIdx.x * RW;
 
     // B[k = c][n = unit] = W_hh[c][unit], c = 32 ks + 8 quad + j
     bf16x8g wh[KS], wm[KS], wl[KS];
@@ -704,17 +748,17 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_x3_kernel(GruSeqBatch batch
         split3_x8(x, wh[ks], wm[ks], wl[ks]);
     }
 
-    int rows[4];
-    bool live[4];
+    int rows[E];
+    bool live[E];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = row0 + 4 * quad + i;
+    for (int i = 0; i < E; ++i) {
+        const int r = row0 + (E == 4 ? 4 * quad + i : quad);
         live[i] = r < R;
         rows[i] = live[i] ? r : R - 1;
     }
-    float carry[4];
+    float carry[E];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < E; ++i)
         carry[i] = (s.dh_last != nullptr && live[i]) ? s.dh_last[(int64_t)rows[i] * s.dh_last_stride + unit] : 0.f;
 
     // the step's arrays as buffer resources (gru_rsrc), their row pitches in bytes
@@ -722,7 +766,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_x3_kernel(GruSeqBatch batch
     const __amdgpu_buffer_rsrc_t rs_dgi = gru_rsrc(s.dgi), rs_dgh = gru_rsrc(s.dgh), rs_hpo = gru_rsrc(s.h_prev_out);
     const int reverse = s.reverse, unit4 = 4 * unit;
     const int dh_p = 4 * (int)s.dh_stride, h_p = 4 * (int)s.h_stride, h0_p = 4 * (int)s.h0_stride, dgi_p = 4 * (int)s.dgi_rstride;
-    float nx[4][6];                          // dh, r, z, n, gh_n, h_prev of the next step
+    float nx[E][6];                          // dh, r, z, n, gh_n, h_prev of the next step
     auto fetch = [&](int step) {
         const int t = reverse ? step : T - 1 - step;
         const bool has_prev = step + 1 < T;
@@ -730,7 +774,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_x3_kernel(GruSeqBatch batch
         const __amdgpu_buffer_rsrc_t rs_hp = has_prev ? rs_hall : rs_h0;
         const int hp_p = has_prev ? h_p : h0_p, hp_s = has_prev ? tp * R * h_p : 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < E; ++i) {
             nx[i][0] = gru_ld(rs_dh, gru_off(rows[i], dh_p, unit4), t * R * dh_p);
             const f32x4 sv = gru_ld4(rs_sv, gru_off(rows[i], 16 * H, 4 * unit4), t * R * (16 * H));
             nx[i][1] = sv[0]; nx[i][2] = sv[1]; nx[i][3] = sv[2]; nx[i][4] = sv[3];
@@ -745,13 +789,13 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_x3_kernel(GruSeqBatch batch
     for (int step = 0; step < T; ++step) {
         const int t = reverse ? step : T - 1 - step;
         const int cur = step & 1;
-        float gz[4], o_gi[4][3], o_hn[4], o_hp[4];
+        float gz[E], o_gi[E][3], o_hn[E], o_hp[E];
 #ifdef ARVAE_GRU_STAMPS
-        { float dep = nx[0][0] + nx[3][5] + nx[1][3]; asm volatile("" :: "v"(dep)); __builtin_amdgcn_s_waitcnt(0); }
+        { float dep = nx[0][0] + nx[E - 1][5] + nx[E / 2][3]; asm volatile("" :: "v"(dep)); __builtin_amdgcn_s_waitcnt(0); }
 #endif
         GSTAMP(0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < E; ++i) {
             const float g = live[i] ? nx[i][0] + carry[i] : 0.f;
             const float r = nx[i][1], z = nx[i][2], n = nx[i][3], ghn = nx[i][4], hp = nx[i][5];
             const float dpn = g * (1.f - z) * (1.f - n * n);
@@ -761,12 +805,19 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_x3_kernel(GruSeqBatch batch
             gz[i] = g * z;
             o_gi[i][0] = dpr; o_gi[i][1] = dpz; o_gi[i][2] = dpn; o_hn[i] = dhn; o_hp[i] = hp;
         }
+        if constexpr (E == 4) {
 #pragma unroll
-        for (int i = 0; i < 4; i += 2) {
-            unsigned short *d = &dbuf[cur][(4 * quad + i) * DP + unit];
-            store_split3_pair(d, DP, PLANE, o_gi[i][0], o_gi[i + 1][0]);
-            store_split3_pair(d + H, DP, PLANE, o_gi[i][1], o_gi[i + 1][1]);
-            store_split3_pair(d + 2 * H, DP, PLANE, o_hn[i], o_hn[i + 1]);
+            for (int i = 0; i < 4; i += 2) {
+                unsigned short *d = &dbuf[cur][(4 * quad + i) * DP + unit];
+                store_split3_pair(d, DP, PLANE, o_gi[i][0], o_gi[i + 1][0]);
+                store_split3_pair(d + H, DP, PLANE, o_gi[i][1], o_gi[i + 1][1]);
+                store_split3_pair(d + 2 * H, DP, PLANE, o_hn[i], o_hn[i + 1]);
+            }
+        } else {
+            unsigned short *d = &dbuf[cur][quad * DP + unit];
+            store_split3(d, PLANE, o_gi[0][0]);
+            store_split3(d + H, PLANE, o_gi[0][1]);
+            store_split3(d + 2 * H, PLANE, o_hn[0]);
         }
 #ifdef ARVAE_GRU_STAMPS
         __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -776,7 +827,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_x3_kernel(GruSeqBatch batch
         lds_barrier();
         GSTAMP(2);
         f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        const unsigned short *db = &dbuf[cur][col * DP + 8 * quad];
+        const unsigned short *db = &dbuf[cur][(RW == 16 ? col : (col & 3)) * DP + 8 * quad];    // (RW 4: tile rows 4 .. 15 repeat the live ones)
         static_assert(KS % 3 == 0 && KS / 3 <= 4, "three k-steps at a time, one per accumulator; one row's stores behind each group");
         // row i's gradients of this step leave BEHIND the MFMAs of k-step group i (pinned: see gru_seq_fwd_x3_kernel)
         auto row_stores = [&](int i) __attribute__((always_inline)) {
@@ -796,15 +847,21 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_x3_kernel(GruSeqBatch batch
             GRU_MFMA6X3(acc[0], acc[1], acc[2], ah0, am0, al0, ah1, am1, al1, ah2, am2, al2, wh[ks], wm[ks], wl[ks], wh[ks + 1], wm[ks + 1],
                         wl[ks + 1], wh[ks + 2], wm[ks + 2], wl[ks + 2]);
             __builtin_amdgcn_sched_barrier(0);
-            row_stores(ks / 3);
+            if (ks / 3 < E) row_stores(ks / 3);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int i = KS / 3; i < 4; ++i) row_stores(i);
+        for (int i = KS / 3; i < E; ++i) row_stores(i);
+        if constexpr (E == 4) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) carry[i] = gz[i] + (acc[0][i] + acc[1][i] + acc[2][i]);
+            for (int i = 0; i < 4; ++i) carry[i] = gz[i] + (acc[0][i] + acc[1][i] + acc[2][i]);
+        } else {
+            const f32x4 sum = {acc[0][0] + acc[1][0] + acc[2][0], acc[0][1] + acc[1][1] + acc[2][1], acc[0][2] + acc[1][2] + acc[2][2],
+                               acc[0][3] + acc[1][3] + acc[2][3]};
+            carry[0] = gz[0] + spread_rows(sum);
+        }
 #ifdef ARVAE_GRU_STAMPS
-        { float dep = carry[0] + carry[3]; asm volatile("" :: "v"(dep)); }
+        { float dep = carry[0] + carry[E - 1]; asm volatile("" :: "v"(dep)); }
 #endif
         GSTAMP(3);
     }
@@ -819,7 +876,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_x3_kernel(GruSeqBatch batch
 #endif
     if (s.dh0 != nullptr)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < E; ++i)
             if (live[i]) s.dh0[(int64_t)rows[i] * s.dh0_stride + unit] = carry[i];
 }
 
@@ -1577,6 +1634,13 @@ static bool gru_bf16_forward() {
     return on;
 }
 
+// Four batch rows per workgroup instead of sixteen (gru_seq_fwd_h2_kernel): when those workgroups are all on the chip at once.
+// ARVAE_GRU_WIDE=1 (diagnostic build): always sixteen, as through round 4
+static bool gru_narrow(int rows, int nseq) {
+    static const bool wide = diag_env("ARVAE_GRU_WIDE") != nullptr;
+    return !wide && (int64_t)((rows + 3) / 4) * nseq <= device_cu_count();
+}
+
 extern "C" int arvae_gru_seq_supported(int32_t hidden) { return hidden == 32 || hidden == 64 || hidden == 128; }
 
 extern "C" int arvae_gru_seq_fwd(const arvae_gru_seq_t *seqs, int32_t nseq, int32_t steps, int32_t rows, int32_t hidden,
@@ -1605,10 +1669,15 @@ extern "C" int arvae_gru_seq_fwd(const arvae_gru_seq_t *seqs, int32_t nseq, int3
         if (hidden == 128) ARVAE_LAUNCH(gru_seq_fwd_x3_kernel<128>, grid, dim3(512), 0, st, b, steps, rows);
         else if (hidden == 64) ARVAE_LAUNCH(gru_seq_fwd_x3_kernel<64>, grid, dim3(256), 0, st, b, steps, rows);
         else ARVAE_LAUNCH(gru_seq_fwd_x3_kernel<32>, grid, dim3(128), 0, st, b, steps, rows);
+    } else if (gru_narrow(rows, nseq)) {
+        const dim3 g4((rows + 3) / 4, nseq);
+        if (hidden == 128) ARVAE_LAUNCH((gru_seq_fwd_h2_kernel<128, 4>), g4, dim3(512), 0, st, b, steps, rows);
+        else if (hidden == 64) ARVAE_LAUNCH((gru_seq_fwd_h2_kernel<64, 4>), g4, dim3(256), 0, st, b, steps, rows);
+        else ARVAE_LAUNCH((gru_seq_fwd_h2_kernel<32, 4>), g4, dim3(128), 0, st, b, steps, rows);
     } else {
-        if (hidden == 128) ARVAE_LAUNCH(gru_seq_fwd_h2_kernel<128>, grid, dim3(512), 0, st, b, steps, rows);
-        else if (hidden == 64) ARVAE_LAUNCH(gru_seq_fwd_h2_kernel<64>, grid, dim3(256), 0, st, b, steps, rows);
-        else ARVAE_LAUNCH(gru_seq_fwd_h2_kernel<32>, grid, dim3(128), 0, st, b, steps, rows);
+        if (hidden == 128) ARVAE_LAUNCH((gru_seq_fwd_h2_kernel<128, 16>), grid, dim3(512), 0, st, b, steps, rows);
+        else if (hidden == 64) ARVAE_LAUNCH((gru_seq_fwd_h2_kernel<64, 16>), grid, dim3(256), 0, st, b, steps, rows);
+        else ARVAE_LAUNCH((gru_seq_fwd_h2_kernel<32, 16>), grid, dim3(128), 0, st, b, steps, rows);
     }
     return check_launch("gru_seq_fwd_kernel");
 }
@@ -1636,10 +1705,15 @@ extern "C" int arvae_gru_seq_bwd(const arvae_gru_seq_t *seqs, int32_t nseq, int3
         if (hidden == 128) ARVAE_LAUNCH(gru_seq_bwd_kernel<128>, grid, dim3(512), 0, st, b, steps, rows);
         else if (hidden == 64) ARVAE_LAUNCH(gru_seq_bwd_kernel<64>, grid, dim3(256), 0, st, b, steps, rows);
         else ARVAE_LAUNCH(gru_seq_bwd_kernel<32>, grid, dim3(128), 0, st, b, steps, rows);
+    } else if (gru_narrow(rows, nseq)) {
+        const dim3 g4((rows + 3) / 4, nseq);
+        if (hidden == 128) ARVAE_LAUNCH((gru_seq_bwd_x3_kernel<128, 4>), g4, dim3(512), 0, st, b, steps, rows);
+        else if (hidden == 64) ARVAE_LAUNCH((gru_seq_bwd_x3_kernel<64, 4>), g4, dim3(256), 0, st, b, steps, rows);
+        else ARVAE_LAUNCH((gru_seq_bwd_x3_kernel<32, 4>), g4, dim3(128), 0, st, b, steps, rows);
     } else {
-        if (hidden == 128) ARVAE_LAUNCH(gru_seq_bwd_x3_kernel<128>, grid, dim3(512), 0, st, b, steps, rows);
-        else if (hidden == 64) ARVAE_LAUNCH(gru_seq_bwd_x3_kernel<64>, grid, dim3(256), 0, st, b, steps, rows);
-        else ARVAE_LAUNCH(gru_seq_bwd_x3_kernel<32>, grid, dim3(128), 0, st, b, steps, rows);
+        if (hidden == 128) ARVAE_LAUNCH((gru_seq_bwd_x3_kernel<128, 16>), grid, dim3(512), 0, st, b, steps, rows);
+        else if (hidden == 64) ARVAE_LAUNCH((gru_seq_bwd_x3_kernel<64, 16>), grid, dim3(256), 0, st, b, steps, rows);
+        else ARVAE_LAUNCH((gru_seq_bwd_x3_kernel<32, 16>), grid, dim3(128), 0, st, b, steps, rows);
     }
     return check_launch("gru_seq_bwd_kernel");
 }
