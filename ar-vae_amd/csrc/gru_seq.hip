@@ -541,6 +541,36 @@ __device__ __forceinline__ f16x8g lds_h8(const unsigned short *p) {
     A0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(AH, WH0, A0, 0, 0, 0); A1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(AH, WH1, A1, 0, 0, 0); \
     A2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(AH, WH2, A2, 0, 0, 0)
 
+// power-of-two scales found at run time (the backward recurrence's per-row scales, both recurrences' per-wave weight scales, the
+// forward recurrence's state scale)
+struct GruPow2 { float s, inv; };
+__device__ __forceinline__ GruPow2 gru_pow2(float amax) {        // 2^k with amax * 2^k in [2^14, 2^15), and 2^-k (amax 0: 2^125)
+    int e = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu);
+    e = e < 16 ? 16 : e;
+    return GruPow2{__builtin_bit_cast(float, (unsigned)(268 - e) << 23), __builtin_bit_cast(float, (unsigned)(e - 14) << 23)};
+}
+template <int CTRL> __device__ __forceinline__ float dpp_max(float v) {
+    const float o = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+    return fmaxf(v, o);
+}
+// maximum over the 16 lanes of a quad (a DPP row), in every lane: quad permutes, the half row and the row mirrored
+__device__ __forceinline__ float row16_max(float v) {
+    v = dpp_max<0xB1>(v);
+    v = dpp_max<0x4E>(v);
+    v = dpp_max<0x141>(v);
+    return dpp_max<0x140>(v);
+}
+__device__ __forceinline__ void store_split2_pair_s(unsigned short *p, int rowpitch, int plane, float x0, float x1, float sc) {
+    unsigned a, b;
+    split2_pair(x0, x1, sc, a, b);
+    p[0] = (unsigned short)a; p[rowpitch] = (unsigned short)(a >> 16);
+    p[plane] = (unsigned short)b; p[plane + rowpitch] = (unsigned short)(b >> 16);
+}
+__device__ __forceinline__ void store_split2_s(unsigned short *p, int plane, float x, float sc) {
+    unsigned a, b;
+    split2_pair(x, 0.f, sc, a, b);
+    p[0] = (unsigned short)a; p[plane] = (unsigned short)b;
+}
 // Quad q's lanes receive element q of the f32x4 their column's lane in quad 0 holds (three swaps of register halves / quarters): the
 // four live rows of a 16 x 16 MFMA result, one per lane.
 // (inline assembly: through __builtin_amdgcn_permlane16_swap / _permlane32_swap this compiler fed the first swap the SAME register
@@ -573,6 +603,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_h2_kernel(GruSeqBatch batch
     constexpr int HP = H + 8;              // LDS row pitch in bf16 elements (16 bytes of padding)
     constexpr int PLANE = 16 * HP;
     __shared__ __attribute__((aligned(16))) unsigned short hbuf[2][2 * PLANE];
+    __shared__ float h0max[H / 16];
     const GruSeq &s = batch.seq[blockIdx.y];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -580,16 +611,34 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_h2_kernel(GruSeqBatch batch
     const int unit = 16 * w + col;
     const int row0 = blockIdx.x * RW;
 
+    // W_hh's slice of this wave as two fp16 terms at the wave's own scale (round 5: the slice's largest magnitude just below 2^15;
+    // through round 4 a fixed 2^8, which overflowed fp16 for |w| >= 255)
     f16x8g wh[3][KS], wl[3][KS];
+    float w_inv;
+    {
+        float x[3][KS][8], m = 0.f;
 #pragma unroll
-    for (int g = 0; g < 3; ++g)
+        for (int g = 0; g < 3; ++g)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const float *src = s.w_hh + (int64_t)(g * H + unit) * H + 32 * ks + 8 * quad;
-            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(src), v1 = *reinterpret_cast<const f32x4 *>(src + 4);
-            const float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            split2_x8(x, GRU_SW, wh[g][ks], wl[g][ks]);
-        }
+            for (int ks = 0; ks < KS; ++ks) {
+                const float *src = s.w_hh + (int64_t)(g * H + unit) * H + 32 * ks + 8 * quad;
+                const f32x4 v0 = *reinterpret_cast<const f32x4 *>(src), v1 = *reinterpret_cast<const f32x4 *>(src + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    x[g][ks][j] = v0[j]; x[g][ks][4 + j] = v1[j];
+                    m = fmaxf(m, fmaxf(fabsf(v0[j]), fabsf(v1[j])));
+                }
+            }
+        m = row16_max(m);
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        const GruPow2 sw = gru_pow2(m);
+        w_inv = sw.inv;
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) split2_x8(x[g][ks], sw.s, wh[g][ks], wl[g][ks]);
+    }
     const float bh_r = s.b_hh[unit], bh_z = s.b_hh[H + unit], bh_n = s.b_hh[2 * H + unit];
 
     int rows[E];
@@ -602,8 +651,28 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_h2_kernel(GruSeqBatch batch
         live[i] = r < R;
         rows[i] = live[i] ? r : R - 1;
         h[i] = (s.h0 != nullptr && live[i]) ? s.h0[(int64_t)rows[i] * s.h0_stride + unit] : 0.f;
-        store_split2(&hbuf[0][lrow(i) * HP + unit], PLANE, h[i]);
     }
+    // The state's scale: every h_t is a convex combination of a tanh output and h_(t-1), so |h_t| <= max(1, max |h0|) for the whole
+    // sequence -- the workgroup's rows' largest |h0| (or 1) goes just below 2^15 (through round 4 a fixed 2^4: fp16 overflow for an
+    // initial state beyond 4094, and the decoder's comes out of a SELU layer)
+    float h_s, unscale;
+    {
+        float m = 1.f;
+#pragma unroll
+        for (int i = 0; i < E; ++i) m = fmaxf(m, fabsf(h[i]));
+        m = row16_max(m);
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        if (lane == 0) h0max[w] = m;
+        lds_barrier();
+#pragma unroll
+        for (int q = 0; q < H / 16; ++q) m = fmaxf(m, h0max[q]);
+        const GruPow2 sh = gru_pow2(m);
+        h_s = sh.s;
+        unscale = sh.inv * w_inv;
+    }
+#pragma unroll
+    for (int i = 0; i < E; ++i) store_split2_s(&hbuf[0][lrow(i) * HP + unit], PLANE, h[i], h_s);
     // per-step memory operations as raw buffer operations (gru_rsrc): a scalar step offset + one per-lane offset per array and row
     // (the running 64-bit pointers this kernel had cost 24 registers and a 64-bit add each per step; the first and last step's
     // missing operations were branches).  A dead row's stores go beyond the range.
@@ -684,9 +753,9 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_h2_kernel(GruSeqBatch batch
         }
 #pragma unroll
         for (int i = 0; i < E; ++i) {
-            const float r = fast_sigmoid(gi[i][0] + av[0][i] * GRU_UNSCALE + bh_r);
-            const float z = fast_sigmoid(gi[i][1] + av[1][i] * GRU_UNSCALE + bh_z);
-            const float ghn = av[2][i] * GRU_UNSCALE + bh_n;
+            const float r = fast_sigmoid(gi[i][0] + av[0][i] * unscale + bh_r);
+            const float z = fast_sigmoid(gi[i][1] + av[1][i] * unscale + bh_z);
+            const float ghn = av[2][i] * unscale + bh_n;
             const float n = fast_tanh(gi[i][2] + r * ghn);
             const float hn = (1.f - z) * n + z * h[i];
             h[i] = hn;
@@ -694,10 +763,10 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_h2_kernel(GruSeqBatch batch
             keep_sv[i] = f32x4{r, z, n, ghn};
         }
         if constexpr (E == 4) {
-            store_split2_pair(&hbuf[cur ^ 1][(4 * quad) * HP + unit], HP, PLANE, h[0], h[1]);
-            store_split2_pair(&hbuf[cur ^ 1][(4 * quad + 2) * HP + unit], HP, PLANE, h[2], h[3]);
+            store_split2_pair_s(&hbuf[cur ^ 1][(4 * quad) * HP + unit], HP, PLANE, h[0], h[1], h_s);
+            store_split2_pair_s(&hbuf[cur ^ 1][(4 * quad + 2) * HP + unit], HP, PLANE, h[2], h[3], h_s);
         } else {
-            store_split2(&hbuf[cur ^ 1][quad * HP + unit], PLANE, h[0]);
+            store_split2_s(&hbuf[cur ^ 1][quad * HP + unit], PLANE, h[0], h_s);
         }
         keep_t = t;
 #ifdef ARVAE_GRU_STAMPS
@@ -874,6 +943,174 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_x3_kernel(GruSeqBatch batch
         g_gru_stamps[4] = T;
     }
 #endif
+    if (s.dh0 != nullptr)
+#pragma unroll
+        for (int i = 0; i < E; ++i)
+            if (live[i]) s.dh0[(int64_t)rows[i] * s.dh0_stride + unit] = carry[i];
+}
+
+// The backward recurrence on scaled two-term fp16 (round 5).  Its operand -- a step's (dpr, dpz, dhn) per batch row -- is a gradient:
+// no magnitude known beforehand, and it moves over the time steps (what kept this kernel on the three-term bf16 split in round 4).
+// With one element per lane (RW 4) the recurrence became MFMA-bound -- 72 dependent-free 16x16x32 MFMAs per wave and step at 32
+// cycles, two waves per SIMD: 4600 of a step's cycles -- so half the products are worth a second barrier: every batch ROW gets its own
+// power-of-two scale each step (a row's scale factors out of its dot products), the largest magnitude of the row's 3 H values brought
+// to [2^14, 2^15): a 16-lane butterfly per wave, one LDS slot per (row, wave), a barrier, NW slots read back.  Nothing can overflow
+// (the scaled maximum is below 2^15 by construction), a row whose gradient is 1e-9 keeps the same 22 bits as one at 1e+3, and W_hh^T
+// gets a per-wave scale from its own slice's maximum in the prologue (a column's scale factors out as well) instead of the fixed 2^8.
+// three accumulators, one k-step each, product-major (l h', h l', h h'): consecutive MFMAs never hit the same accumulator
+#define GRU_MFMA3K3(A0, A1, A2, H0, L0, H1, L1, H2, L2, WH0, WL0, WH1, WL1, WH2, WL2)                                              \
+    A0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(L0, WH0, A0, 0, 0, 0); A1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(L1, WH1, A1, 0, 0, 0); \
+    A2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(L2, WH2, A2, 0, 0, 0);                                                            \
+    A0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(H0, WL0, A0, 0, 0, 0); A1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(H1, WL1, A1, 0, 0, 0); \
+    A2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(H2, WL2, A2, 0, 0, 0);                                                            \
+    A0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(H0, WH0, A0, 0, 0, 0); A1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(H1, WH1, A1, 0, 0, 0); \
+    A2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(H2, WH2, A2, 0, 0, 0)
+
+template <int H, int RW>
+__global__ __launch_bounds__(H * 4) void gru_seq_bwd_h2_kernel(GruSeqBatch batch, int T, int R) {
+    static_assert(RW == 16 || RW == 4, "16 rows (four per lane) or 4 rows (one per lane)");
+    constexpr int E = RW / 4;              // elements (rows) per lane
+    constexpr int NW = H / 16;             // waves
+    constexpr int KS = 3 * H / 32;
+    constexpr int DP = 3 * H + 8;           // LDS row pitch in fp16 elements
+    constexpr int PLANE = 16 * DP;
+    constexpr int MW = NW < 4 ? 4 : NW;     // slots per row of the maxima (16-byte reads)
+    __shared__ __attribute__((aligned(16))) unsigned short dbuf[2 * PLANE];
+    __shared__ __attribute__((aligned(16))) float rmax[16][MW];
+    const GruSeq &s = batch.seq[blockIdx.y];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = lane & 15, quad = lane >> 4;
+    const int unit = 16 * w + col;
+    const int row0 = blockIdx.x * RW;
+
+    // B[k = c][n = unit] = W_hh[c][unit], c = 32 ks + 8 quad + j: two fp16 terms at this wave's own scale
+    f16x8g wh[KS], wl[KS];
+    float w_inv;
+    {
+        float x[KS][8], m = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                x[ks][j] = s.w_hh[(int64_t)(32 * ks + 8 * quad + j) * H + unit];
+                m = fmaxf(m, fabsf(x[ks][j]));
+            }
+        m = row16_max(m);
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        const GruPow2 sw = gru_pow2(m);
+        w_inv = sw.inv;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) split2_x8(x[ks], sw.s, wh[ks], wl[ks]);
+    }
+    if (MW > NW && threadIdx.x < 16 * (MW - NW)) rmax[threadIdx.x / (MW - NW)][NW + threadIdx.x % (MW - NW)] = 0.f;   // (slots no wave writes)
+
+    auto lrow = [&](int i) { return E == 4 ? 4 * quad + i : quad; };          // the tile row of this lane's element i
+    int rows[E];
+    bool live[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        const int r = row0 + lrow(i);
+        live[i] = r < R;
+        rows[i] = live[i] ? r : R - 1;
+    }
+    float carry[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i)
+        carry[i] = (s.dh_last != nullptr && live[i]) ? s.dh_last[(int64_t)rows[i] * s.dh_last_stride + unit] : 0.f;
+
+    // the step's arrays as buffer resources (gru_rsrc), their row pitches in bytes
+    const __amdgpu_buffer_rsrc_t rs_dh = gru_rsrc(s.dh_all), rs_sv = gru_rsrc(s.saved), rs_hall = gru_rsrc(s.h_all), rs_h0 = gru_rsrc(s.h0);
+    const __amdgpu_buffer_rsrc_t rs_dgi = gru_rsrc(s.dgi), rs_dgh = gru_rsrc(s.dgh), rs_hpo = gru_rsrc(s.h_prev_out);
+    const int reverse = s.reverse, unit4 = 4 * unit;
+    const int dh_p = 4 * (int)s.dh_stride, h_p = 4 * (int)s.h_stride, h0_p = 4 * (int)s.h0_stride, dgi_p = 4 * (int)s.dgi_rstride;
+    float nx[E][6];                          // dh, r, z, n, gh_n, h_prev of the next step
+    auto fetch = [&](int step) {
+        const int t = reverse ? step : T - 1 - step;
+        const bool has_prev = step + 1 < T;
+        const int tp = reverse ? t + 1 : t - 1;
+        const __amdgpu_buffer_rsrc_t rs_hp = has_prev ? rs_hall : rs_h0;
+        const int hp_p = has_prev ? h_p : h0_p, hp_s = has_prev ? tp * R * h_p : 0;
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            nx[i][0] = gru_ld(rs_dh, gru_off(rows[i], dh_p, unit4), t * R * dh_p);
+            const f32x4 sv = gru_ld4(rs_sv, gru_off(rows[i], 16 * H, 4 * unit4), t * R * (16 * H));
+            nx[i][1] = sv[0]; nx[i][2] = sv[1]; nx[i][3] = sv[2]; nx[i][4] = sv[3];
+            nx[i][5] = gru_ld(rs_hp, gru_off(rows[i], hp_p, unit4), hp_s);
+        }
+    };
+    fetch(0);
+
+    for (int step = 0; step < T; ++step) {
+        const int t = reverse ? step : T - 1 - step;
+        float gz[E], o_gi[E][3], o_hn[E], o_hp[E];
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const float g = live[i] ? nx[i][0] + carry[i] : 0.f;
+            const float r = nx[i][1], z = nx[i][2], n = nx[i][3], ghn = nx[i][4], hp = nx[i][5];
+            const float dpn = g * (1.f - z) * (1.f - n * n);
+            const float dpz = g * (hp - n) * z * (1.f - z);
+            const float dpr = dpn * ghn * r * (1.f - r);
+            const float dhn = dpn * r;
+            gz[i] = g * z;
+            o_gi[i][0] = dpr; o_gi[i][1] = dpz; o_gi[i][2] = dpn; o_hn[i] = dhn; o_hp[i] = hp;
+            const float m = row16_max(fmaxf(fmaxf(fabsf(dpr), fabsf(dpz)), fabsf(dhn)));
+            if (col == 0) rmax[lrow(i)][w] = m;
+        }
+        if (step + 1 < T) fetch(step + 1);
+        lds_barrier();                       // the rows' maxima are in LDS; every read of the previous step's operand image is done
+        float unscale[E];
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            float m = 0.f;
+#pragma unroll
+            for (int q = 0; q < MW; q += 4) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(&rmax[lrow(i)][q]);
+                m = fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+            }
+            const GruPow2 sc = gru_pow2(m);
+            unscale[i] = sc.inv * w_inv;
+            unsigned short *d = &dbuf[lrow(i) * DP + unit];
+            store_split2_s(d, PLANE, o_gi[i][0], sc.s);
+            store_split2_s(d + H, PLANE, o_gi[i][1], sc.s);
+            store_split2_s(d + 2 * H, PLANE, o_hn[i], sc.s);
+        }
+        lds_barrier();                       // the operand image is written; the maxima have been read
+        f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        const unsigned short *db = &dbuf[(RW == 16 ? col : (col & 3)) * DP + 8 * quad];    // (RW 4: tile rows 4 .. 15 repeat the live ones)
+        static_assert(KS % 3 == 0 && KS / 3 <= 4, "three k-steps at a time, one per accumulator; one row's stores behind each group");
+        // row i's gradients of this step leave BEHIND the MFMAs of k-step group i (pinned: see gru_seq_fwd_x3_kernel)
+        auto row_stores = [&](int i) __attribute__((always_inline)) {
+            if (live[i]) {
+                const int og = gru_off(rows[i], dgi_p, unit4), sg = t * R * dgi_p;
+                const int o = gru_off(rows[i], 12 * H, unit4), so = t * R * (12 * H);
+                gru_st(o_gi[i][0], rs_dgi, og, sg); gru_st(o_gi[i][1], rs_dgi, og + 4 * H, sg); gru_st(o_gi[i][2], rs_dgi, og + 8 * H, sg);
+                gru_st(o_gi[i][0], rs_dgh, o, so); gru_st(o_gi[i][1], rs_dgh, o + 4 * H, so); gru_st(o_hn[i], rs_dgh, o + 8 * H, so);
+                gru_st(o_hp[i], rs_hpo, gru_off(rows[i], 4 * H, unit4), t * R * (4 * H));
+            }
+        };
+#pragma unroll
+        for (int ks = 0; ks < KS; ks += 3) {
+            const f16x8g ah0 = lds_h8(db + 32 * ks), al0 = lds_h8(db + PLANE + 32 * ks);
+            const f16x8g ah1 = lds_h8(db + 32 * (ks + 1)), al1 = lds_h8(db + PLANE + 32 * (ks + 1));
+            const f16x8g ah2 = lds_h8(db + 32 * (ks + 2)), al2 = lds_h8(db + PLANE + 32 * (ks + 2));
+            GRU_MFMA3K3(acc[0], acc[1], acc[2], ah0, al0, ah1, al1, ah2, al2, wh[ks], wl[ks], wh[ks + 1], wl[ks + 1], wh[ks + 2], wl[ks + 2]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks / 3 < E) row_stores(ks / 3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = KS / 3; i < E; ++i) row_stores(i);
+        if constexpr (E == 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) carry[i] = gz[i] + (acc[0][i] + acc[1][i] + acc[2][i]) * unscale[i];
+        } else {
+            const f32x4 sum = {acc[0][0] + acc[1][0] + acc[2][0], acc[0][1] + acc[1][1] + acc[2][1], acc[0][2] + acc[1][2] + acc[2][2],
+                               acc[0][3] + acc[1][3] + acc[2][3]};
+            carry[0] = gz[0] + spread_rows(sum) * unscale[0];
+        }
+    }
     if (s.dh0 != nullptr)
 #pragma unroll
         for (int i = 0; i < E; ++i)
@@ -1641,6 +1878,12 @@ static bool gru_narrow(int rows, int nseq) {
     return !wide && (int64_t)((rows + 3) / 4) * nseq <= device_cu_count();
 }
 
+// ARVAE_GRU_BF16_BWD=1 (diagnostic build): the backward recurrence on the three-term bf16 split, as through round 4
+static bool gru_bf16_backward() {
+    static const bool on = diag_env("ARVAE_GRU_BF16_BWD") != nullptr;
+    return on;
+}
+
 extern "C" int arvae_gru_seq_supported(int32_t hidden) { return hidden == 32 || hidden == 64 || hidden == 128; }
 
 extern "C" int arvae_gru_seq_fwd(const arvae_gru_seq_t *seqs, int32_t nseq, int32_t steps, int32_t rows, int32_t hidden,
@@ -1705,15 +1948,26 @@ extern "C" int arvae_gru_seq_bwd(const arvae_gru_seq_t *seqs, int32_t nseq, int3
         if (hidden == 128) ARVAE_LAUNCH(gru_seq_bwd_kernel<128>, grid, dim3(512), 0, st, b, steps, rows);
         else if (hidden == 64) ARVAE_LAUNCH(gru_seq_bwd_kernel<64>, grid, dim3(256), 0, st, b, steps, rows);
         else ARVAE_LAUNCH(gru_seq_bwd_kernel<32>, grid, dim3(128), 0, st, b, steps, rows);
+    } else if (gru_bf16_backward()) {
+        if (gru_narrow(rows, nseq)) {
+            const dim3 g4((rows + 3) / 4, nseq);
+            if (hidden == 128) ARVAE_LAUNCH((gru_seq_bwd_x3_kernel<128, 4>), g4, dim3(512), 0, st, b, steps, rows);
+            else if (hidden == 64) ARVAE_LAUNCH((gru_seq_bwd_x3_kernel<64, 4>), g4, dim3(256), 0, st, b, steps, rows);
+            else ARVAE_LAUNCH((gru_seq_bwd_x3_kernel<32, 4>), g4, dim3(128), 0, st, b, steps, rows);
+        } else {
+            if (hidden == 128) ARVAE_LAUNCH((gru_seq_bwd_x3_kernel<128, 16>), grid, dim3(512), 0, st, b, steps, rows);
+            else if (hidden == 64) ARVAE_LAUNCH((gru_seq_bwd_x3_kernel<64, 16>), grid, dim3(256), 0, st, b, steps, rows);
+            else ARVAE_LAUNCH((gru_seq_bwd_x3_kernel<32, 16>), grid, dim3(128), 0, st, b, steps, rows);
+        }
     } else if (gru_narrow(rows, nseq)) {
         const dim3 g4((rows + 3) / 4, nseq);
-        if (hidden == 128) ARVAE_LAUNCH((gru_seq_bwd_x3_kernel<128, 4>), g4, dim3(512), 0, st, b, steps, rows);
-        else if (hidden == 64) ARVAE_LAUNCH((gru_seq_bwd_x3_kernel<64, 4>), g4, dim3(256), 0, st, b, steps, rows);
-        else ARVAE_LAUNCH((gru_seq_bwd_x3_kernel<32, 4>), g4, dim3(128), 0, st, b, steps, rows);
+        if (hidden == 128) ARVAE_LAUNCH((gru_seq_bwd_h2_kernel<128, 4>), g4, dim3(512), 0, st, b, steps, rows);
+        else if (hidden == 64) ARVAE_LAUNCH((gru_seq_bwd_h2_kernel<64, 4>), g4, dim3(256), 0, st, b, steps, rows);
+        else ARVAE_LAUNCH((gru_seq_bwd_h2_kernel<32, 4>), g4, dim3(128), 0, st, b, steps, rows);
     } else {
-        if (hidden == 128) ARVAE_LAUNCH((gru_seq_bwd_x3_kernel<128, 16>), grid, dim3(512), 0, st, b, steps, rows);
-        else if (hidden == 64) ARVAE_LAUNCH((gru_seq_bwd_x3_kernel<64, 16>), grid, dim3(256), 0, st, b, steps, rows);
-        else ARVAE_LAUNCH((gru_seq_bwd_x3_kernel<32, 16>), grid, dim3(128), 0, st, b, steps, rows);
+        if (hidden == 128) ARVAE_LAUNCH((gru_seq_bwd_h2_kernel<128, 16>), grid, dim3(512), 0, st, b, steps, rows);
+        else if (hidden == 64) ARVAE_LAUNCH((gru_seq_bwd_h2_kernel<64, 16>), grid, dim3(256), 0, st, b, steps, rows);
+        else ARVAE_LAUNCH((gru_seq_bwd_h2_kernel<32, 16>), grid, dim3(128), 0, st, b, steps, rows);
     }
     return check_launch("gru_seq_bwd_kernel");
 }

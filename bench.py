@@ -481,7 +481,7 @@ def run_side(kind, device, args, fence, rank, world, use_dp, with_cpu):
            'scaling': 'weak', 'vs_baseline': None,
            'dtype': ('f32 (wide conv MFMAs: scaled 2-term fp16 split, 3 products; narrow conv / Linear: 3-term bf16 split, 6 products; fp32-accurate)'
                      if kind == 'mnist' else
-                     'f32 (forward recurrences: scaled 2-term fp16 split, 3 products; backward recurrences, Linear layers: 3-term bf16 split, 6 products; fp32-accurate)'),
+                     'f32 (recurrences: scaled 2-term fp16 split, 3 products, scales taken from the data; Linear layers: 3-term bf16 split, 6 products; fp32-accurate)'),
            'data': 'synthetic',
            'config': {'workload': ('Morpho-MNIST AR-VAE full training step, 1x28x28 inputs, z=16, reg_dim=(1..6), dropout 0.5'
                                    if kind == 'mnist' else

@@ -701,6 +701,56 @@ def test_gru_sequence_vs_torch(dev, rows, hid, steps):
         close(prm[k].grad, v.grad, rtol=1e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize('w_scale,h_scale,g_scale', [(1.0, 1.0, 1.0), (40.0, 6000.0, 1.0), (1.0, 1.0, 1e-9), (1.0, 1.0, 1e+6),
+                                                      (3000.0, 1.0, 1e-4)])
+def test_fp16_recurrences_scale_themselves(dev, w_scale, h_scale, g_scale):
+    """both recurrences multiply on the fp16 MFMA with scales taken from the data (round 5: per-wave scales for W_hh, the workgroup's
+    largest |h0| for the state, per batch row and step for the backward pass's gradients): recurrent weights beyond 255 and initial
+    states beyond 4094 overflowed the fixed scales of round 4, and upstream gradients of 1e-9 or 1e+6 would leave the
+    useful range of a fixed gradient scale.  Against a FLOAT64 nn.GRU the outputs and every gradient keep fp32 accuracy relative
+    to their largest element, and nothing is inf or nan."""
+    from arvae_amd import ops
+    rows, hid, steps, fin = 21, 128, 12, 10
+    torch.manual_seed(3)
+    rs = np.random.RandomState(33)
+    gru = torch.nn.GRU(fin, hid, 1, bidirectional=True)
+    with torch.no_grad():
+        for k, v in gru.named_parameters():
+            if 'weight_hh' in k:
+                v.mul_(w_scale)
+    x = torch.from_numpy(rs.standard_normal((steps, rows, fin)).astype(np.float32))
+    h0 = torch.from_numpy((h_scale * rs.standard_normal((2, rows, hid))).astype(np.float32))
+    gy = torch.from_numpy((g_scale * rs.standard_normal((steps, rows, 2 * hid))).astype(np.float32))
+    g64 = torch.nn.GRU(fin, hid, 1, bidirectional=True).double()
+    g64.load_state_dict({k: v.double() for k, v in gru.state_dict().items()})
+    x64, h64 = x.double().requires_grad_(True), h0.double().requires_grad_(True)
+    y64, _ = g64(x64, h64)
+    (y64 * gy.double()).sum().backward()
+    # torch's own fp32 CPU layer on the same problem: the yardstick (saturated gates make some of these draws ill-conditioned)
+    x32, h32 = x.clone().requires_grad_(True), h0.clone().requires_grad_(True)
+    y32, _ = gru(x32, h32)
+    (y32 * gy).sum().backward()
+    prm = {k: v.detach().clone().to(dev).requires_grad_(True) for k, v in gru.named_parameters()}
+    xd, hd = x.to(dev).requires_grad_(True), h0.to(dev).requires_grad_(True)
+    dirs = []
+    for d, suf in enumerate(('', '_reverse')):
+        gi = ops.dense(xd.view(steps * rows, fin), prm['weight_ih_l0' + suf], prm['bias_ih_l0' + suf],
+                       ops.Link.dense(fin, 3 * hid), 0).view(steps, rows, 3 * hid)
+        dirs.append((gi, prm['weight_hh_l0' + suf], prm['bias_hh_l0' + suf], hd[d], d == 1))
+    yd, _ = ops.gru_sequence(steps, dirs)
+    (yd * gy.to(dev)).sum().backward()
+    assert bool(torch.isfinite(yd).all())
+
+    def rel(got, want):
+        return float((got.detach().cpu().double() - want.detach()).abs().max()) / max(float(want.detach().abs().max()), 1e-300)
+
+    assert rel(yd, y64) <= max(2e-6, 3 * rel(y32, y64)), ('y', rel(yd, y64), rel(y32, y64))
+    for name, got, ref32, want in [('x', xd.grad, x32.grad, x64.grad), ('h0', hd.grad, h32.grad, h64.grad)] + \
+            [(k, prm[k].grad, dict(gru.named_parameters())[k].grad, v.grad) for k, v in g64.named_parameters()]:
+        assert bool(torch.isfinite(got).all()), name
+        assert rel(got, want) <= max(2e-5, 5 * rel(ref32, want)), (name, rel(got, want), rel(ref32, want))
+
+
 @pytest.mark.parametrize('seed', [0, 6, 8])
 def test_fp16_forward_recurrence_holds_fp32_accuracy_vs_float64(dev, seed):
     """the forward recurrence multiplies on the fp16 MFMA (scaled two-term operands, three products: gru_seq.hip) and the backward one
