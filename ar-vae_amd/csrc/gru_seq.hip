@@ -1599,8 +1599,12 @@ __device__ __forceinline__ void tick_argmax_stage(float &v, int &ix) {
     ix = take ? oi : ix;
 }
 
-template <int H, bool MASKED>
+// (RW: batch rows per workgroup, 16 or 4 -- one element per lane and four times the workgroups, as gru_seq_fwd_h2_kernel: the gates,
+// the token's projections, the state splits and the rows' argmax are per-element work; the weight stream per workgroup is unchanged)
+template <int H, bool MASKED, int RW>
 __global__ __launch_bounds__(H * 4) void tick_free_run_h2_kernel(TickFreeRun p, const uint4 *__restrict__ packed) {
+    static_assert(RW == 16 || RW == 4, "16 rows (four per lane) or 4 rows (one per lane)");
+    constexpr int E = RW / 4;
     constexpr int NW = H / 16, KS = H / 32, KQ = H / 16;
     constexpr int NGG = 9 * KS;                    // weight groups per tick: (matrix, k-step, gate), 3 x 16 bytes per lane each
     constexpr int RS = NGG % 6 == 0 ? 6 : 3;       // register ring of groups; RS - 1 groups are in flight
@@ -1617,7 +1621,7 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_h2_kernel(TickFreeRun p, 
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int col = lane & 15, quad = lane >> 4;
     const int unit = 16 * w + col;
-    const int row0 = blockIdx.x * 16;
+    const int row0 = blockIdx.x * RW;
     const int B = p.batch;
     const int ntile = (p.vocab + 15) / 16;
 
@@ -1646,18 +1650,31 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_h2_kernel(TickFreeRun p, 
     const bool note_ok = w < ntile && note < p.vocab;
     const float bout = note_ok ? p.b_out[note] : 0.f;
 
-    int rows[4];
-    bool live[4];
+    auto lrow = [&](int i) { return E == 4 ? 4 * quad + i : quad; };          // the tile row of this lane's element i
+    int rows[E];
+    bool live[E];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = row0 + 4 * quad + i;
+    for (int i = 0; i < E; ++i) {
+        const int r = row0 + lrow(i);
         live[i] = r < B;
         rows[i] = live[i] ? r : B - 1;
     }
-    float h0[4], h1[4], gb[4][3];
-    int tok[4] = {p.vocab, p.vocab, p.vocab, p.vocab};
+    float h0[E], h1[E], gb[E][3];
+    int tok[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) tok[i] = p.vocab;
     const int ticks = p.beats * p.tpb;
-    const int aoff = col * HP + 8 * quad;                     // this lane's A-operand offset inside a plane
+    const int arow = RW == 16 ? col : (col & 3);              // (RW 4: tile rows 4 .. 15 repeat the live ones)
+    const int aoff = arow * HP + 8 * quad;                    // this lane's A-operand offset inside a plane
+    // the gates' products of this lane's elements out of a 16 x 16 result
+    auto elems = [&](const f32x4 &acc, float (&out)[E]) __attribute__((always_inline)) {
+        if constexpr (E == 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) out[i] = acc[i];
+        } else {
+            out[0] = spread_rows(acc);
+        }
+    };
 
     // layer 0's recurrent product W_hh0 h0 of a tick does not wait for the tick's token: it is multiplied at the END of the previous
     // tick, under the logits and the argmax (three waves' latency chain of ~3500 cycles, during which the workgroup's weight
@@ -1698,20 +1715,20 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_h2_kernel(TickFreeRun p, 
         if (beat_start) {
             lds_barrier();
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < E; ++i) {
                 const int64_t br = (int64_t)beat * B + rows[i];
                 h0[i] = p.h0_l0[br * p.h0_stride + unit];
                 h1[i] = p.h0_l1[br * p.h0_stride + unit];
-                store_split2(&hA0[cur][(4 * quad + i) * HP + unit], PLANE, h0[i]);
-                store_split2(&hA1[cur][(4 * quad + i) * HP + unit], PLANE, h1[i]);
+                store_split2(&hA0[cur][lrow(i) * HP + unit], PLANE, h0[i]);
+                store_split2(&hA1[cur][lrow(i) * HP + unit], PLANE, h1[i]);
                 const float *g = p.gib + br * 3 * H + unit;
                 gb[i][0] = g[0]; gb[i][1] = g[H]; gb[i][2] = g[2 * H];
             }
             lds_barrier();
         }
-        float gi[4][3], keep[4];
+        float gi[E][3], keep[E];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < E; ++i) {
             const float *pt = p.ptab + (int64_t)tok[i] * 3 * H + unit;
             gi[i][0] = gb[i][0] + pt[0]; gi[i][1] = gb[i][1] + pt[H]; gi[i][2] = gb[i][2] + pt[2 * H];
             keep[i] = MASKED ? p.keep_scale * (float)p.mask[((int64_t)t * B + rows[i]) * H + unit] : 1.f;
@@ -1724,14 +1741,16 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_h2_kernel(TickFreeRun p, 
             { float dep = acc0[0][0] + acc0[1][1] + acc0[2][3]; asm volatile("" :: "v"(dep)); }
 #endif
             TSTAMP(1);                                         // layer 0 at the top (a beat's first tick only)
+            float ar[E], az[E], an[E];
+            elems(acc0[0], ar); elems(acc0[1], az); elems(acc0[2], an);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float r = fast_sigmoid(gi[i][0] + acc0[0][i] * GRU_UNSCALE + b0r);
-                const float z = fast_sigmoid(gi[i][1] + acc0[1][i] * GRU_UNSCALE + b0z);
-                const float n = fast_tanh(gi[i][2] + r * (acc0[2][i] * GRU_UNSCALE + b0n));
+            for (int i = 0; i < E; ++i) {
+                const float r = fast_sigmoid(gi[i][0] + ar[i] * GRU_UNSCALE + b0r);
+                const float z = fast_sigmoid(gi[i][1] + az[i] * GRU_UNSCALE + b0z);
+                const float n = fast_tanh(gi[i][2] + r * (an[i] * GRU_UNSCALE + b0n));
                 h0[i] = (1.f - z) * n + z * h0[i];
-                store_split2(&hA0[cur ^ 1][(4 * quad + i) * HP + unit], PLANE, h0[i]);
-                store_split2(&midp[(4 * quad + i) * HP + unit], PLANE, h0[i] * keep[i]);
+                store_split2(&hA0[cur ^ 1][lrow(i) * HP + unit], PLANE, h0[i]);
+                store_split2(&midp[lrow(i) * HP + unit], PLANE, h0[i] * keep[i]);
             }
         }
         TSTAMP(2);                                             // layer 0 gates (wait for the projections) + LDS writes
@@ -1760,14 +1779,16 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_h2_kernel(TickFreeRun p, 
             { float dep = a1[0][0] + a1[1][1] + a1[2][3] + a1[3][2]; asm volatile("" :: "v"(dep)); }
 #endif
             TSTAMP(4);                                         // layer 1: operand reads + MFMAs behind the weight stream
+            float ar[E], az[E], ai[E], ah[E];
+            elems(a1[0], ar); elems(a1[1], az); elems(a1[2], ai); elems(a1[3], ah);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float r = fast_sigmoid(a1[0][i] * GRU_UNSCALE + b1r);
-                const float z = fast_sigmoid(a1[1][i] * GRU_UNSCALE + b1z);
-                const float n = fast_tanh(a1[2][i] * GRU_UNSCALE + b1in + r * (a1[3][i] * GRU_UNSCALE + b1hn));
+            for (int i = 0; i < E; ++i) {
+                const float r = fast_sigmoid(ar[i] * GRU_UNSCALE + b1r);
+                const float z = fast_sigmoid(az[i] * GRU_UNSCALE + b1z);
+                const float n = fast_tanh(ai[i] * GRU_UNSCALE + b1in + r * (ah[i] * GRU_UNSCALE + b1hn));
                 h1[i] = (1.f - z) * n + z * h1[i];
-                store_split2(&hA1[cur ^ 1][(4 * quad + i) * HP + unit], PLANE, h1[i]);
-                h1f[4 * quad + i][unit] = h1[i];
+                store_split2(&hA1[cur ^ 1][lrow(i) * HP + unit], PLANE, h1[i]);
+                h1f[lrow(i)][unit] = h1[i];
             }
         }
         TSTAMP(5);                                             // layer 1 gates + LDS writes
@@ -1779,7 +1800,7 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_h2_kernel(TickFreeRun p, 
             if (w < ntile) {
                 f32x4 lg = {0.f, 0.f, 0.f, 0.f};
                 auto logits_step = [&](int kq) __attribute__((always_inline)) {
-                    const f32x4 a = *reinterpret_cast<const f32x4 *>(&h1f[col][16 * kq + 4 * quad]);
+                    const f32x4 a = *reinterpret_cast<const f32x4 *>(&h1f[arow][16 * kq + 4 * quad]);
                     const f32x4 b = *reinterpret_cast<const f32x4 *>(&wout_s[note][16 * kq + 4 * quad]);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) lg = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], lg, 0, 0, 0);
@@ -1788,21 +1809,22 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_h2_kernel(TickFreeRun p, 
                 // vector ALU (quad permutes, then the half-row and the row mirrored) instead of four ds_bpermute round trips per
                 // row; stage by stage over the four rows (four independent chains), one block of candidate writes
                 auto argmax_rows = [&]() __attribute__((always_inline)) {
-                    float v[4];
-                    int ix[4];
+                    float v[E], lv[E];
+                    int ix[E];
+                    elems(lg, lv);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { v[i] = note_ok ? fmaxf(lg[i] + bout, 0.f) : -1.f; ix[i] = note; }
+                    for (int i = 0; i < E; ++i) { v[i] = note_ok ? fmaxf(lv[i] + bout, 0.f) : -1.f; ix[i] = note; }
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) tick_argmax_stage<0xB1>(v[i], ix[i]);
+                    for (int i = 0; i < E; ++i) tick_argmax_stage<0xB1>(v[i], ix[i]);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) tick_argmax_stage<0x4E>(v[i], ix[i]);
+                    for (int i = 0; i < E; ++i) tick_argmax_stage<0x4E>(v[i], ix[i]);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) tick_argmax_stage<0x141>(v[i], ix[i]);
+                    for (int i = 0; i < E; ++i) tick_argmax_stage<0x141>(v[i], ix[i]);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) tick_argmax_stage<0x140>(v[i], ix[i]);
+                    for (int i = 0; i < E; ++i) tick_argmax_stage<0x140>(v[i], ix[i]);
                     if (col == 0) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) { cand_v[w][4 * quad + i] = v[i]; cand_i[w][4 * quad + i] = ix[i]; }
+                        for (int i = 0; i < E; ++i) { cand_v[w][lrow(i)] = v[i]; cand_i[w][lrow(i)] = ix[i]; }
                     }
                 };
                 constexpr int NG0 = 3 * KS;
@@ -1828,8 +1850,8 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_h2_kernel(TickFreeRun p, 
         TSTAMP(6);                                             // barrier + logits / argmax (first waves) + the next tick's layer 0
         lds_barrier();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = 4 * quad + i;
+        for (int i = 0; i < E; ++i) {
+            const int r = lrow(i);
             float v = cand_v[0][r];
             int ix = cand_i[0][r];
             for (int c = 1; c < ntile; ++c) {
@@ -2014,19 +2036,20 @@ extern "C" int arvae_tick_free_run(const arvae_tick_weights_t *wts, const float 
     const int items = 3 * (hidden / 32) * (hidden / 16) * 3 * 64;
     const uint4 *packed = reinterpret_cast<const uint4 *>(ws);
     if (!gru_bf16_forward()) {
-        if (hidden == 128) {
-            ARVAE_LAUNCH(tick_weight_prep_h2_kernel<128>, dim3((items + 255) / 256), dim3(256), 0, st, tp);
-            if (m) ARVAE_LAUNCH((tick_free_run_h2_kernel<128, true>), grid, dim3(512), 0, st, p, packed);
-            else ARVAE_LAUNCH((tick_free_run_h2_kernel<128, false>), grid, dim3(512), 0, st, p, packed);
-        } else if (hidden == 64) {
-            ARVAE_LAUNCH(tick_weight_prep_h2_kernel<64>, dim3((items + 255) / 256), dim3(256), 0, st, tp);
-            if (m) ARVAE_LAUNCH((tick_free_run_h2_kernel<64, true>), grid, dim3(256), 0, st, p, packed);
-            else ARVAE_LAUNCH((tick_free_run_h2_kernel<64, false>), grid, dim3(256), 0, st, p, packed);
-        } else {
-            ARVAE_LAUNCH(tick_weight_prep_h2_kernel<32>, dim3((items + 255) / 256), dim3(256), 0, st, tp);
-            if (m) ARVAE_LAUNCH((tick_free_run_h2_kernel<32, true>), grid, dim3(128), 0, st, p, packed);
-            else ARVAE_LAUNCH((tick_free_run_h2_kernel<32, false>), grid, dim3(128), 0, st, p, packed);
+        const bool narrow = gru_narrow(batch, 1);
+        const dim3 g4((batch + 3) / 4);
+#define TICK_H2(HH, TH)                                                                                                          \
+        {                                                                                                                        \
+            ARVAE_LAUNCH(tick_weight_prep_h2_kernel<HH>, dim3((items + 255) / 256), dim3(256), 0, st, tp);                       \
+            if (narrow && m) ARVAE_LAUNCH((tick_free_run_h2_kernel<HH, true, 4>), g4, dim3(TH), 0, st, p, packed);               \
+            else if (narrow) ARVAE_LAUNCH((tick_free_run_h2_kernel<HH, false, 4>), g4, dim3(TH), 0, st, p, packed);              \
+            else if (m) ARVAE_LAUNCH((tick_free_run_h2_kernel<HH, true, 16>), grid, dim3(TH), 0, st, p, packed);                 \
+            else ARVAE_LAUNCH((tick_free_run_h2_kernel<HH, false, 16>), grid, dim3(TH), 0, st, p, packed);                       \
         }
+        if (hidden == 128) TICK_H2(128, 512)
+        else if (hidden == 64) TICK_H2(64, 256)
+        else TICK_H2(32, 128)
+#undef TICK_H2
         return check_launch("tick_free_run_h2_kernel");
     }
     if (hidden == 128) {
