@@ -492,11 +492,14 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_x3_kernel(GruSeqBatch batch
 // The forward recurrence on the fp16 MFMA with SCALED TWO-TERM operands (the arithmetic of conv32_common.h): s x = h + l with
 // h = fp16(s x), l = fp16(s x - h), a product = the three partial products l h', h l', h h' on v_mfma_f32_16x16x32_f16, smallest
 // first -- half the MFMAs and two thirds of the LDS operand bytes of the three-term bf16 split at the same accuracy (2^-22 per
-// product; measured against float64: conv32_common.h).  fp16 has 5 exponent bits, so the scales must place the operands: the
-// hidden state is bounded (a convex combination of tanh outputs and h0; the decoder's h0 is a SELU layer's output) and takes the
-// fixed scale 2^4 (|h| < 4094 before fp16 overflows, absolute resolution 2^-29 for small h), W_hh the fixed scale 2^8 (|w| < 255,
-// absolute resolution 2^-33).  The BACKWARD recurrence stays on the three-term bf16 split: its operand is a gradient, whose
-// magnitude is not bounded a priori and moves over time steps, and bf16 carries fp32's exponent range.
+// product; measured against float64: conv32_common.h).  fp16 has 5 exponent bits, so the scales must place the operands.
+// The SEQUENCE kernels take every scale from the data (round 5): W_hh's slice of a wave its own power of two (a column's scale
+// factors out of the dot product), the state the workgroup's max(1, max |h0|) -- a bound for the whole sequence, h_t being a convex
+// combination of a tanh output and h_(t-1) --, the backward pass's gradients a scale per batch row and step (gru_seq_bwd_h2_kernel):
+// nothing can overflow.  The FREE-RUNNING decoder (tick_free_run_h2_kernel) still uses the fixed scales of round 4, 2^4 for the
+// states (|h| < 4094 before fp16 overflows, absolute resolution 2^-29) and 2^8 for its three matrices (|w| < 255, resolution
+// 2^-33): two of its products share an accumulator, so their scales are tied, and its states are re-seeded every beat; the host
+// checks the ranges when run-time checks are on (ops.tick_free_run).
 typedef _Float16 f16x8g __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2g __attribute__((ext_vector_type(2)));
 constexpr float GRU_SH = 16.f, GRU_SW = 256.f, GRU_UNSCALE = 1.f / (16.f * 256.f);
