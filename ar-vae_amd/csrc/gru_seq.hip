@@ -592,15 +592,44 @@ __device__ __forceinline__ float spread_rows(const f32x4 &a) {
     return x0;
 }
 
-// RW: batch rows per workgroup, 16 or 4.  A recurrence is a chain of T dependent steps whose length is the instruction stream of one
+// RW 8: quads 0 and 1 hold the eight live rows; their elements 2 and 3 go to quads 2 and 3 (one swap of register halves each)
+__device__ __forceinline__ void spread_pairs(const f32x4 &a, float &o0, float &o1) {
+    float x0 = a[0], x1 = a[1], x2 = a[2], x3 = a[3];
+    asm volatile("s_nop 15\n\t"
+                 "v_permlane32_swap_b32 %0, %2\n\t"              // x0 = [a0.q0 | a0.q1 | a2.q0 | a2.q1]
+                 "v_permlane32_swap_b32 %1, %3\n\t"              // x1 = [a1.q0 | a1.q1 | a3.q0 | a3.q1]
+                 "s_nop 1"
+                 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+    o0 = x0;
+    o1 = x1;
+}
+// E = RW / 4 elements per lane: the tile row of a lane's element i, the tile row a lane reads its A operand from (rows past the live
+// ones repeat them), a 16 x 16 result's values for the lane's elements
+template <int E> __device__ __forceinline__ int gru_lrow(int quad, int i) {
+    return E == 4 ? 4 * quad + i : E == 2 ? 4 * (quad & 1) + 2 * (quad >> 1) + i : quad;
+}
+template <int E> __device__ __forceinline__ int gru_arow(int col) { return E == 4 ? col : E == 2 ? (col & 7) : (col & 3); }
+template <int E> __device__ __forceinline__ void gru_elems(const f32x4 &acc, float (&out)[E]) {
+    if constexpr (E == 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out[i] = acc[i];
+    } else if constexpr (E == 2) {
+        spread_pairs(acc, out[0], out[1]);
+    } else {
+        out[0] = spread_rows(acc);
+    }
+}
+
+// RW: batch rows per workgroup, 16, 8 or 4.  A recurrence is a chain of T dependent steps whose length is the instruction stream of one
 // wave between two barriers, and most of that stream is per (row, hidden unit) ELEMENT work: projections in,
 // gates, the state's split and its LDS writes, h and the saved gates out -- four elements per lane when a workgroup owns 16 rows.
 // With 4 rows per workgroup the 16 x 16 MFMA tile is three quarters empty (the matrix pipe was idle anyway), the four live rows of
 // a result go out to the four quads (spread_rows) and every lane does ONE element per step; four times the workgroups, on a chip
-// that the recurrences of a 256-measure batch fill to an eighth.  The host picks 4 when those workgroups still fit the chip at once.
+// that the recurrences of a 256-measure batch fill to an eighth.  The host picks the smallest of 4, 8, 16 whose workgroups are all on
+// the chip at once (8: two elements per lane, the live rows in quads 0 and 1).
 template <int H, int RW>
 __global__ __launch_bounds__(H * 4) void gru_seq_fwd_h2_kernel(GruSeqBatch batch, int T, int R) {
-    static_assert(RW == 16 || RW == 4, "16 rows (four per lane) or 4 rows (one per lane)");
+    static_assert(RW == 16 || RW == 8 || RW == 4, "16, 8 or 4 rows: four, two or one per lane");
     constexpr int E = RW / 4;              // elements (rows) per lane
     constexpr int KS = H / 32;             // MFMA k-steps of 32
     constexpr int HP = H + 8;              // LDS row pitch in bf16 elements (16 bytes of padding)
@@ -647,7 +676,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_h2_kernel(GruSeqBatch batch
     int rows[E];
     bool live[E];
     float h[E];
-    auto lrow = [&](int i) { return E == 4 ? 4 * quad + i : quad; };          // the tile row of this lane's element i
+    auto lrow = [&](int i) { return gru_lrow<E>(quad, i); };                  // the tile row of this lane's element i
 #pragma unroll
     for (int i = 0; i < E; ++i) {
         const int r = row0 + lrow(i);
@@ -713,7 +742,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_h2_kernel(GruSeqBatch batch
             for (int g = 0; g < 3; ++g) gi[i][g] = gi_next[i][g];
         GSTAMP(0);
         f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        const unsigned short *hb = &hbuf[cur][(RW == 16 ? col : (col & 3)) * HP + 8 * quad];   // (RW 4: tile rows 4 .. 15 repeat the live ones)
+        const unsigned short *hb = &hbuf[cur][gru_arow<E>(col) * HP + 8 * quad];
         // Row i's share of the step's memory traffic (next step's three input projections in, the previous step's h and saved
         // gates out) is issued BEHIND the MFMAs of k-step i, with a scheduling barrier pinning it there: as one block in front
         // of the MFMAs it was 1200 of the step's 6000 cycles (tools/stamp_gru.py), all of it issue time of an in-order wave
@@ -746,14 +775,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_h2_kernel(GruSeqBatch batch
         GSTAMP(1);
         float av[3][E];                      // the gates' products of this lane's elements
 #pragma unroll
-        for (int g = 0; g < 3; ++g) {
-            if constexpr (E == 4) {
-#pragma unroll
-                for (int i = 0; i < E; ++i) av[g][i] = acc[g][i];
-            } else {
-                av[g][0] = spread_rows(acc[g]);
-            }
-        }
+        for (int g = 0; g < 3; ++g) gru_elems<E>(acc[g], av[g]);
 #pragma unroll
         for (int i = 0; i < E; ++i) {
             const float r = fast_sigmoid(gi[i][0] + av[0][i] * unscale + bh_r);
@@ -765,9 +787,9 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_h2_kernel(GruSeqBatch batch
             keep_h[i] = hn;
             keep_sv[i] = f32x4{r, z, n, ghn};
         }
-        if constexpr (E == 4) {
-            store_split2_pair_s(&hbuf[cur ^ 1][(4 * quad) * HP + unit], HP, PLANE, h[0], h[1], h_s);
-            store_split2_pair_s(&hbuf[cur ^ 1][(4 * quad + 2) * HP + unit], HP, PLANE, h[2], h[3], h_s);
+        if constexpr (E >= 2) {
+#pragma unroll
+            for (int i = 0; i < E; i += 2) store_split2_pair_s(&hbuf[cur ^ 1][lrow(i) * HP + unit], HP, PLANE, h[i], h[i + 1], h_s);
         } else {
             store_split2_s(&hbuf[cur ^ 1][quad * HP + unit], PLANE, h[0], h_s);
         }
@@ -797,7 +819,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_h2_kernel(GruSeqBatch batch
 // (RW: batch rows per workgroup, 16 or 4 -- see gru_seq_fwd_h2_kernel)
 template <int H, int RW>
 __global__ __launch_bounds__(H * 4) void gru_seq_bwd_x3_kernel(GruSeqBatch batch, int T, int R) {
-    static_assert(RW == 16 || RW == 4, "16 rows (four per lane) or 4 rows (one per lane)");
+    static_assert(RW == 16 || RW == 8 || RW == 4, "16, 8 or 4 rows: four, two or one per lane");
     constexpr int E = RW / 4;              // elements (rows) per lane
     constexpr int KS = 3 * H / 32;
     constexpr int DP = 3 * H + 8;           // LDS row pitch in bf16 elements
@@ -824,7 +846,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_x3_kernel(GruSeqBatch batch
     bool live[E];
 #pragma unroll
     for (int i = 0; i < E; ++i) {
-        const int r = row0 + (E == 4 ? 4 * quad + i : quad);
+        const int r = row0 + gru_lrow<E>(quad, i);
         live[i] = r < R;
         rows[i] = live[i] ? r : R - 1;
     }
@@ -877,10 +899,10 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_x3_kernel(GruSeqBatch batch
             gz[i] = g * z;
             o_gi[i][0] = dpr; o_gi[i][1] = dpz; o_gi[i][2] = dpn; o_hn[i] = dhn; o_hp[i] = hp;
         }
-        if constexpr (E == 4) {
+        if constexpr (E >= 2) {
 #pragma unroll
-            for (int i = 0; i < 4; i += 2) {
-                unsigned short *d = &dbuf[cur][(4 * quad + i) * DP + unit];
+            for (int i = 0; i < E; i += 2) {
+                unsigned short *d = &dbuf[cur][gru_lrow<E>(quad, i) * DP + unit];
                 store_split3_pair(d, DP, PLANE, o_gi[i][0], o_gi[i + 1][0]);
                 store_split3_pair(d + H, DP, PLANE, o_gi[i][1], o_gi[i + 1][1]);
                 store_split3_pair(d + 2 * H, DP, PLANE, o_hn[i], o_hn[i + 1]);
@@ -899,7 +921,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_x3_kernel(GruSeqBatch batch
         lds_barrier();
         GSTAMP(2);
         f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        const unsigned short *db = &dbuf[cur][(RW == 16 ? col : (col & 3)) * DP + 8 * quad];    // (RW 4: tile rows 4 .. 15 repeat the live ones)
+        const unsigned short *db = &dbuf[cur][gru_arow<E>(col) * DP + 8 * quad];
         static_assert(KS % 3 == 0 && KS / 3 <= 4, "three k-steps at a time, one per accumulator; one row's stores behind each group");
         // row i's gradients of this step leave BEHIND the MFMAs of k-step group i (pinned: see gru_seq_fwd_x3_kernel)
         auto row_stores = [&](int i) __attribute__((always_inline)) {
@@ -924,13 +946,13 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_x3_kernel(GruSeqBatch batch
         }
 #pragma unroll
         for (int i = KS / 3; i < E; ++i) row_stores(i);
-        if constexpr (E == 4) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) carry[i] = gz[i] + (acc[0][i] + acc[1][i] + acc[2][i]);
-        } else {
+        {
             const f32x4 sum = {acc[0][0] + acc[1][0] + acc[2][0], acc[0][1] + acc[1][1] + acc[2][1], acc[0][2] + acc[1][2] + acc[2][2],
                                acc[0][3] + acc[1][3] + acc[2][3]};
-            carry[0] = gz[0] + spread_rows(sum);
+            float cs[E];
+            gru_elems<E>(sum, cs);
+#pragma unroll
+            for (int i = 0; i < E; ++i) carry[i] = gz[i] + cs[i];
         }
 #ifdef ARVAE_GRU_STAMPS
         { float dep = carry[0] + carry[E - 1]; asm volatile("" :: "v"(dep)); }
@@ -971,7 +993,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_x3_kernel(GruSeqBatch batch
 
 template <int H, int RW>
 __global__ __launch_bounds__(H * 4) void gru_seq_bwd_h2_kernel(GruSeqBatch batch, int T, int R) {
-    static_assert(RW == 16 || RW == 4, "16 rows (four per lane) or 4 rows (one per lane)");
+    static_assert(RW == 16 || RW == 8 || RW == 4, "16, 8 or 4 rows: four, two or one per lane");
     constexpr int E = RW / 4;              // elements (rows) per lane
     constexpr int NW = H / 16;             // waves
     constexpr int KS = 3 * H / 32;
@@ -1009,7 +1031,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_h2_kernel(GruSeqBatch batch
     }
     if (MW > NW && threadIdx.x < 16 * (MW - NW)) rmax[threadIdx.x / (MW - NW)][NW + threadIdx.x % (MW - NW)] = 0.f;   // (slots no wave writes)
 
-    auto lrow = [&](int i) { return E == 4 ? 4 * quad + i : quad; };          // the tile row of this lane's element i
+    auto lrow = [&](int i) { return gru_lrow<E>(quad, i); };                  // the tile row of this lane's element i
     int rows[E];
     bool live[E];
 #pragma unroll
@@ -1081,7 +1103,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_h2_kernel(GruSeqBatch batch
         }
         lds_barrier();                       // the operand image is written; the maxima have been read
         f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        const unsigned short *db = &dbuf[(RW == 16 ? col : (col & 3)) * DP + 8 * quad];    // (RW 4: tile rows 4 .. 15 repeat the live ones)
+        const unsigned short *db = &dbuf[gru_arow<E>(col) * DP + 8 * quad];
         static_assert(KS % 3 == 0 && KS / 3 <= 4, "three k-steps at a time, one per accumulator; one row's stores behind each group");
         // row i's gradients of this step leave BEHIND the MFMAs of k-step group i (pinned: see gru_seq_fwd_x3_kernel)
         auto row_stores = [&](int i) __attribute__((always_inline)) {
@@ -1105,13 +1127,13 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_h2_kernel(GruSeqBatch batch
         }
 #pragma unroll
         for (int i = KS / 3; i < E; ++i) row_stores(i);
-        if constexpr (E == 4) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) carry[i] = gz[i] + (acc[0][i] + acc[1][i] + acc[2][i]) * unscale[i];
-        } else {
+        {
             const f32x4 sum = {acc[0][0] + acc[1][0] + acc[2][0], acc[0][1] + acc[1][1] + acc[2][1], acc[0][2] + acc[1][2] + acc[2][2],
                                acc[0][3] + acc[1][3] + acc[2][3]};
-            carry[0] = gz[0] + spread_rows(sum) * unscale[0];
+            float cs[E];
+            gru_elems<E>(sum, cs);
+#pragma unroll
+            for (int i = 0; i < E; ++i) carry[i] = gz[i] + cs[i] * unscale[i];
         }
     }
     if (s.dh0 != nullptr)
@@ -1606,7 +1628,7 @@ __device__ __forceinline__ void tick_argmax_stage(float &v, int &ix) {
 // the token's projections, the state splits and the rows' argmax are per-element work; the weight stream per workgroup is unchanged)
 template <int H, bool MASKED, int RW>
 __global__ __launch_bounds__(H * 4) void tick_free_run_h2_kernel(TickFreeRun p, const uint4 *__restrict__ packed) {
-    static_assert(RW == 16 || RW == 4, "16 rows (four per lane) or 4 rows (one per lane)");
+    static_assert(RW == 16 || RW == 8 || RW == 4, "16, 8 or 4 rows: four, two or one per lane");
     constexpr int E = RW / 4;
     constexpr int NW = H / 16, KS = H / 32, KQ = H / 16;
     constexpr int NGG = 9 * KS;                    // weight groups per tick: (matrix, k-step, gate), 3 x 16 bytes per lane each
@@ -1653,7 +1675,7 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_h2_kernel(TickFreeRun p, 
     const bool note_ok = w < ntile && note < p.vocab;
     const float bout = note_ok ? p.b_out[note] : 0.f;
 
-    auto lrow = [&](int i) { return E == 4 ? 4 * quad + i : quad; };          // the tile row of this lane's element i
+    auto lrow = [&](int i) { return gru_lrow<E>(quad, i); };                  // the tile row of this lane's element i
     int rows[E];
     bool live[E];
 #pragma unroll
@@ -1667,18 +1689,9 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_h2_kernel(TickFreeRun p, 
 #pragma unroll
     for (int i = 0; i < E; ++i) tok[i] = p.vocab;
     const int ticks = p.beats * p.tpb;
-    const int arow = RW == 16 ? col : (col & 3);              // (RW 4: tile rows 4 .. 15 repeat the live ones)
+    const int arow = gru_arow<E>(col);
     const int aoff = arow * HP + 8 * quad;                    // this lane's A-operand offset inside a plane
-    // the gates' products of this lane's elements out of a 16 x 16 result
-    auto elems = [&](const f32x4 &acc, float (&out)[E]) __attribute__((always_inline)) {
-        if constexpr (E == 4) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) out[i] = acc[i];
-        } else {
-            out[0] = spread_rows(acc);
-        }
-    };
-
+    auto elems = [&](const f32x4 &acc, float (&out)[E]) __attribute__((always_inline)) { gru_elems<E>(acc, out); };
     // layer 0's recurrent product W_hh0 h0 of a tick does not wait for the tick's token: it is multiplied at the END of the previous
     // tick, under the logits and the argmax (three waves' latency chain of ~3500 cycles, during which the workgroup's weight
     // stream -- what bounds the layers: 590 KB per tick at the CU's 64 bytes per clock -- stood still; tools/stamp_tick.py).
@@ -1896,12 +1909,31 @@ static bool gru_bf16_forward() {
     return on;
 }
 
-// Four batch rows per workgroup instead of sixteen (gru_seq_fwd_h2_kernel): when those workgroups are all on the chip at once.
-// ARVAE_GRU_WIDE=1 (diagnostic build): always sixteen, as through round 4
-static bool gru_narrow(int rows, int nseq) {
+// Batch rows per workgroup (gru_seq_fwd_h2_kernel): the smallest of 4, 8, 16 whose workgroups are all on the chip at once.
+// ARVAE_GRU_WIDE=1 (diagnostic build): always sixteen, as through round 4; ARVAE_GRU_ROWS=4|8|16: that many
+static int gru_rows_per_wg(int rows, int nseq) {
     static const bool wide = diag_env("ARVAE_GRU_WIDE") != nullptr;
-    return !wide && (int64_t)((rows + 3) / 4) * nseq <= device_cu_count();
+    static const int forced = diag_env("ARVAE_GRU_ROWS") != nullptr ? atoi(diag_env("ARVAE_GRU_ROWS")) : 0;
+    if (wide) return 16;
+    if (forced == 4 || forced == 8 || forced == 16) return forced;
+    for (int rw = 4; rw < 16; rw *= 2)
+        if ((int64_t)((rows + rw - 1) / rw) * nseq <= device_cu_count()) return rw;
+    return 16;
 }
+// launch KERNEL<hidden, ..., rows per workgroup> for the hidden size and row width at hand
+#define GRU_LAUNCH_RW(KERNEL, HH, RWV, ...)                                                                                       \
+    {                                                                                                                            \
+        const dim3 g_((rows + (RWV) - 1) / (RWV), nseq);                                                                          \
+        if ((RWV) == 4) ARVAE_LAUNCH((KERNEL<HH, 4>), g_, dim3(4 * HH), 0, st, __VA_ARGS__);                                      \
+        else if ((RWV) == 8) ARVAE_LAUNCH((KERNEL<HH, 8>), g_, dim3(4 * HH), 0, st, __VA_ARGS__);                                 \
+        else ARVAE_LAUNCH((KERNEL<HH, 16>), g_, dim3(4 * HH), 0, st, __VA_ARGS__);                                                \
+    }
+#define GRU_LAUNCH(KERNEL, RWV, ...)                                                                                             \
+    {                                                                                                                            \
+        if (hidden == 128) GRU_LAUNCH_RW(KERNEL, 128, RWV, __VA_ARGS__)                                                           \
+        else if (hidden == 64) GRU_LAUNCH_RW(KERNEL, 64, RWV, __VA_ARGS__)                                                        \
+        else GRU_LAUNCH_RW(KERNEL, 32, RWV, __VA_ARGS__)                                                                          \
+    }
 
 // ARVAE_GRU_BF16_BWD=1 (diagnostic build): the backward recurrence on the three-term bf16 split, as through round 4
 static bool gru_bf16_backward() {
@@ -1937,15 +1969,9 @@ extern "C" int arvae_gru_seq_fwd(const arvae_gru_seq_t *seqs, int32_t nseq, int3
         if (hidden == 128) ARVAE_LAUNCH(gru_seq_fwd_x3_kernel<128>, grid, dim3(512), 0, st, b, steps, rows);
         else if (hidden == 64) ARVAE_LAUNCH(gru_seq_fwd_x3_kernel<64>, grid, dim3(256), 0, st, b, steps, rows);
         else ARVAE_LAUNCH(gru_seq_fwd_x3_kernel<32>, grid, dim3(128), 0, st, b, steps, rows);
-    } else if (gru_narrow(rows, nseq)) {
-        const dim3 g4((rows + 3) / 4, nseq);
-        if (hidden == 128) ARVAE_LAUNCH((gru_seq_fwd_h2_kernel<128, 4>), g4, dim3(512), 0, st, b, steps, rows);
-        else if (hidden == 64) ARVAE_LAUNCH((gru_seq_fwd_h2_kernel<64, 4>), g4, dim3(256), 0, st, b, steps, rows);
-        else ARVAE_LAUNCH((gru_seq_fwd_h2_kernel<32, 4>), g4, dim3(128), 0, st, b, steps, rows);
     } else {
-        if (hidden == 128) ARVAE_LAUNCH((gru_seq_fwd_h2_kernel<128, 16>), grid, dim3(512), 0, st, b, steps, rows);
-        else if (hidden == 64) ARVAE_LAUNCH((gru_seq_fwd_h2_kernel<64, 16>), grid, dim3(256), 0, st, b, steps, rows);
-        else ARVAE_LAUNCH((gru_seq_fwd_h2_kernel<32, 16>), grid, dim3(128), 0, st, b, steps, rows);
+        const int rw = gru_rows_per_wg(rows, nseq);
+        GRU_LAUNCH(gru_seq_fwd_h2_kernel, rw, b, steps, rows)
     }
     return check_launch("gru_seq_fwd_kernel");
 }
@@ -1974,25 +2000,11 @@ extern "C" int arvae_gru_seq_bwd(const arvae_gru_seq_t *seqs, int32_t nseq, int3
         else if (hidden == 64) ARVAE_LAUNCH(gru_seq_bwd_kernel<64>, grid, dim3(256), 0, st, b, steps, rows);
         else ARVAE_LAUNCH(gru_seq_bwd_kernel<32>, grid, dim3(128), 0, st, b, steps, rows);
     } else if (gru_bf16_backward()) {
-        if (gru_narrow(rows, nseq)) {
-            const dim3 g4((rows + 3) / 4, nseq);
-            if (hidden == 128) ARVAE_LAUNCH((gru_seq_bwd_x3_kernel<128, 4>), g4, dim3(512), 0, st, b, steps, rows);
-            else if (hidden == 64) ARVAE_LAUNCH((gru_seq_bwd_x3_kernel<64, 4>), g4, dim3(256), 0, st, b, steps, rows);
-            else ARVAE_LAUNCH((gru_seq_bwd_x3_kernel<32, 4>), g4, dim3(128), 0, st, b, steps, rows);
-        } else {
-            if (hidden == 128) ARVAE_LAUNCH((gru_seq_bwd_x3_kernel<128, 16>), grid, dim3(512), 0, st, b, steps, rows);
-            else if (hidden == 64) ARVAE_LAUNCH((gru_seq_bwd_x3_kernel<64, 16>), grid, dim3(256), 0, st, b, steps, rows);
-            else ARVAE_LAUNCH((gru_seq_bwd_x3_kernel<32, 16>), grid, dim3(128), 0, st, b, steps, rows);
-        }
-    } else if (gru_narrow(rows, nseq)) {
-        const dim3 g4((rows + 3) / 4, nseq);
-        if (hidden == 128) ARVAE_LAUNCH((gru_seq_bwd_h2_kernel<128, 4>), g4, dim3(512), 0, st, b, steps, rows);
-        else if (hidden == 64) ARVAE_LAUNCH((gru_seq_bwd_h2_kernel<64, 4>), g4, dim3(256), 0, st, b, steps, rows);
-        else ARVAE_LAUNCH((gru_seq_bwd_h2_kernel<32, 4>), g4, dim3(128), 0, st, b, steps, rows);
+        const int rw = gru_rows_per_wg(rows, nseq);
+        GRU_LAUNCH(gru_seq_bwd_x3_kernel, rw, b, steps, rows)
     } else {
-        if (hidden == 128) ARVAE_LAUNCH((gru_seq_bwd_h2_kernel<128, 16>), grid, dim3(512), 0, st, b, steps, rows);
-        else if (hidden == 64) ARVAE_LAUNCH((gru_seq_bwd_h2_kernel<64, 16>), grid, dim3(256), 0, st, b, steps, rows);
-        else ARVAE_LAUNCH((gru_seq_bwd_h2_kernel<32, 16>), grid, dim3(128), 0, st, b, steps, rows);
+        const int rw = gru_rows_per_wg(rows, nseq);
+        GRU_LAUNCH(gru_seq_bwd_h2_kernel, rw, b, steps, rows)
     }
     return check_launch("gru_seq_bwd_kernel");
 }
@@ -2039,20 +2051,25 @@ extern "C" int arvae_tick_free_run(const arvae_tick_weights_t *wts, const float 
     const int items = 3 * (hidden / 32) * (hidden / 16) * 3 * 64;
     const uint4 *packed = reinterpret_cast<const uint4 *>(ws);
     if (!gru_bf16_forward()) {
-        const bool narrow = gru_narrow(batch, 1);
-        const dim3 g4((batch + 3) / 4);
-#define TICK_H2(HH, TH)                                                                                                          \
+        const int rw = gru_rows_per_wg(batch, 1);
+        const dim3 gr((batch + rw - 1) / rw);
+#define TICK_H2_RW(HH, MM, RWV)                                                                                                  \
+        {                                                                                                                        \
+            if ((RWV) == 4) ARVAE_LAUNCH((tick_free_run_h2_kernel<HH, MM, 4>), gr, dim3(4 * HH), 0, st, p, packed);               \
+            else if ((RWV) == 8) ARVAE_LAUNCH((tick_free_run_h2_kernel<HH, MM, 8>), gr, dim3(4 * HH), 0, st, p, packed);          \
+            else ARVAE_LAUNCH((tick_free_run_h2_kernel<HH, MM, 16>), gr, dim3(4 * HH), 0, st, p, packed);                         \
+        }
+#define TICK_H2(HH)                                                                                                              \
         {                                                                                                                        \
             ARVAE_LAUNCH(tick_weight_prep_h2_kernel<HH>, dim3((items + 255) / 256), dim3(256), 0, st, tp);                       \
-            if (narrow && m) ARVAE_LAUNCH((tick_free_run_h2_kernel<HH, true, 4>), g4, dim3(TH), 0, st, p, packed);               \
-            else if (narrow) ARVAE_LAUNCH((tick_free_run_h2_kernel<HH, false, 4>), g4, dim3(TH), 0, st, p, packed);              \
-            else if (m) ARVAE_LAUNCH((tick_free_run_h2_kernel<HH, true, 16>), grid, dim3(TH), 0, st, p, packed);                 \
-            else ARVAE_LAUNCH((tick_free_run_h2_kernel<HH, false, 16>), grid, dim3(TH), 0, st, p, packed);                       \
+            if (m) TICK_H2_RW(HH, true, rw)                                                                                      \
+            else TICK_H2_RW(HH, false, rw)                                                                                       \
         }
-        if (hidden == 128) TICK_H2(128, 512)
-        else if (hidden == 64) TICK_H2(64, 256)
-        else TICK_H2(32, 128)
+        if (hidden == 128) TICK_H2(128)
+        else if (hidden == 64) TICK_H2(64)
+        else TICK_H2(32)
 #undef TICK_H2
+#undef TICK_H2_RW
         return check_launch("tick_free_run_h2_kernel");
     }
     if (hidden == 128) {

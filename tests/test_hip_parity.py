@@ -667,10 +667,12 @@ def test_gru_cell_vs_torch(dev):
         close(prm[k].grad, v.grad, rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize('rows,hid,steps', [(37, 128, 24), (16, 64, 6), (5, 32, 4)])
+@pytest.mark.parametrize('rows,hid,steps', [(37, 128, 24), (16, 64, 6), (5, 32, 4), (602, 128, 4), (1301, 64, 3)])
 def test_gru_sequence_vs_torch(dev, rows, hid, steps):
     """whole-sequence GRU kernels (both directions in one launch, initial state, ragged row count) reproduce a
-    bidirectional torch.nn.GRU layer: outputs, input-projection / initial-state gradients, W_hh / b_hh gradients."""
+    bidirectional torch.nn.GRU layer: outputs, input-projection / initial-state gradients, W_hh / b_hh gradients.
+    (The kernels own 4, 8 or 16 batch rows per workgroup, whichever fills the chip in one round: 37, 602 and 1301 rows x 2
+    directions select the three widths on a 256-CU device.)"""
     from arvae_amd import ops
     rs = np.random.RandomState(15)
     fin = 10
@@ -697,8 +699,8 @@ def test_gru_sequence_vs_torch(dev, rows, hid, steps):
     close(fin[:, hid:], hn[1], rtol=1e-5, atol=2e-6)
     close(xd.grad, x.grad, rtol=1e-4, atol=2e-6)
     close(hd.grad, h0.grad, rtol=1e-4, atol=2e-6)
-    for k, v in gru.named_parameters():
-        close(prm[k].grad, v.grad, rtol=1e-4, atol=2e-5)
+    for k, v in gru.named_parameters():                  # (sums over steps x rows terms, against torch's own fp32 sums)
+        close(prm[k].grad, v.grad, rtol=1e-4, atol=2e-5 if rows < 100 else 2e-4)
 
 
 @pytest.mark.parametrize('w_scale,h_scale,g_scale', [(1.0, 1.0, 1.0), (40.0, 6000.0, 1.0), (1.0, 1.0, 1e-9), (1.0, 1.0, 1e+6),
@@ -902,7 +904,7 @@ def test_measure_sequence_path_matches_stepwise(dev, monkeypatch):
             assert float((gseq - gstep).norm()) <= 2e-4 * float(gstep.norm()) + 1e-9, (teacher, k)
 
 
-@pytest.mark.parametrize('b,dropout,hid', [(256, 0.5, 128), (21, 0.0, 128), (37, 0.5, 64)])
+@pytest.mark.parametrize('b,dropout,hid', [(256, 0.5, 128), (21, 0.0, 128), (37, 0.5, 64), (1501, 0.5, 128), (2101, 0.0, 64)])
 def test_tick_free_run_tokens_match_stepwise(dev, monkeypatch, b, dropout, hid):
     """the one-launch free-running tick decoder feeds itself the same notes as the launch-per-tick pass."""
     from arvae_amd.measure_vae import MeasureVAE
