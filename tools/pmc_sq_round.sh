@@ -23,7 +23,7 @@ for wl in ('dsprites', 'mnist', 'measure'):
     disp = collections.defaultdict(dict)                  # dispatch -> counters, name, duration
     for r in csv.DictReader(open(fs[0])):
         d = disp[r['Dispatch_Id']]
-        d['name'] = r['Kernel_Name'].replace('void ', '').split('(')[0].replace('arvae::', '').replace('(anonymous namespace)::', '')
+        d['name'] = r['Kernel_Name'].replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0].replace('arvae::', '')
         d['ns'] = int(r['End_Timestamp']) - int(r['Start_Timestamp'])
         d[r['Counter_Name']] = float(r['Counter_Value'])
     fam = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -41,7 +41,7 @@ for wl in ('dsprites', 'mnist', 'measure'):
              'launches of the pass).  mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): the share of SIMD-cycles in which the',
              'matrix pipe was busy (GRBM_GUI_ACTIVE sums the 8 XCDs; SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD, 32 per 32x32x16 16-bit MFMA).', '']
     summary[wl] = {}
-    for name, f in rows[:8]:
+    for name, f in rows[:12]:
         n = f['launches']
         cyc = f.get('GRBM_GUI_ACTIVE', 0.0) / 8.0
         busy = f.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0)

@@ -13,7 +13,7 @@ import sys
 
 def label(kernel_name):
     """rocprofv3 kernel name -> the label bench.py / arvae_profile_end use for that kernel family."""
-    n = kernel_name.replace('void ', '').split('(')[0].replace('arvae::', '')
+    n = kernel_name.replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0].replace('arvae::', '')
     m = re.match(r'(down32|up32|wgrad32)[xsrp]?_kernel<(\d+),', n)        # the variants of a map share a label
     if m:
         return f'{m.group(1)}_kernel<{m.group(2)}>'

@@ -3,9 +3,9 @@
 #   1. bench.py plain and --force-dp interleaved three times on this box (same build, same box: the ratio is what counts);
 #   2. launch-ordered kernel trace of the forced data-parallel step (library collectives: RCCL on the launch stream);
 #   3. the stress loop of the data-parallel MeasureVAE graph-replay path (tools/dp_replay_loop.sh).
-#   bash tools/run_dp_check.sh [tag=r4]   -> gpurun_out/dp_check_<tag>.txt, gpurun_out/<tag>_dp_timeline.txt
+#   bash tools/run_dp_check.sh [tag=r5]   -> gpurun_out/dp_check_<tag>.txt, gpurun_out/<tag>_dp_timeline.txt
 cd "$(dirname "$0")/.."
-tag=${1:-r4}
+tag=${1:-r5}
 out=gpurun_out/dp_check_$tag.txt
 mkdir -p gpurun_out
 : > $out
@@ -17,7 +17,13 @@ for i in 1 2 3; do
 done
 python3 bench.py --workload measure --no-cpu-baseline > /tmp/dpc_m.json 2> /dev/null
 python3 bench.py --workload measure --no-cpu-baseline --force-dp > /tmp/dpc_mdp.json 2> /dev/null
-echo "MeasureVAE (graph replay): plain $(ms /tmp/dpc_m.json) | forced DP $(ms /tmp/dpc_mdp.json)" >> $out
+echo "MeasureVAE (whole-model executor, eager): plain $(ms /tmp/dpc_m.json) | forced DP (one rank) $(ms /tmp/dpc_mdp.json)" >> $out
+python3 - >> $out <<'P'
+import json
+for name, f in (('dSprites', '/tmp/dpc_dp.json'), ('MeasureVAE', '/tmp/dpc_mdp.json')):
+    d = json.load(open(f))
+    print(f'{name}, forced DP: measured cost of the step\'s collectives and the overlap decision (bench.py dp object): {json.dumps(d.get("dp"))}')
+P
 {
   echo "== forced data-parallel step on ONE rank (bench.py --force-dp, B = 512), launch-ordered kernel medians under rocprofv3 --kernel-trace =="
   echo "-- every collective is an RCCL call of libarvae_hip.so on the launch stream (arvae_comm_*); the library finishes the pass (arvae_image_vae_finish) --"
