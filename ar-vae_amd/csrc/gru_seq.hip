@@ -18,6 +18,7 @@
 #include <algorithm>
 #include "diag.h"
 #include "common.h"
+#include "gru_mask.h"
 
 namespace arvae {
 
@@ -49,6 +50,11 @@ struct GruSeq {
     float *h_fin;           // forward, optional: the state after the last processed step, row r at h_fin + r * h_fin_stride
     int64_t h_fin_stride;
     int64_t h0_stride, dh0_stride;   // floats between two rows of h0 / dh0 (fill_batch: H when the caller leaves them 0)
+    // dropout on the sequence's output (gru_mask.h; the fp16 two-term kernels only): mask null = none
+    const uint8_t *mask;
+    float keep;
+    float *h_masked;
+    int hm_stride, mk_tstride, mk_rstride, mk_gstride, mk_group;
 };
 struct GruSeqBatch {
     GruSeq seq[GRU_SEQ_MAX];
@@ -711,6 +717,14 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_h2_kernel(GruSeqBatch batch
     const __amdgpu_buffer_rsrc_t rs_gi = gru_rsrc(s.gi), rs_h = gru_rsrc(s.h_all), rs_sv = gru_rsrc(s.saved), rs_none = gru_rsrc(nullptr);
     const int reverse = s.reverse, unit4 = 4 * unit;
     const int gi_tp = 4 * (int)s.gi_tstride, h_tp = 4 * R * (int)s.h_stride;
+    // dropout on the output (gru_mask.h): the keep byte of the CURRENT step is requested with the step's other traffic, the masked
+    // copy of a step's h leaves one step later beside h.  No mask: an empty range (loads return 0, the stores are dropped).
+    const __amdgpu_buffer_rsrc_t rs_mk = gru_rsrc(s.mask), rs_hm = gru_rsrc(s.mask != nullptr ? s.h_masked : nullptr);
+    const int mk_tp = s.mk_tstride, hm_tp = 4 * R * s.hm_stride;
+    const float keep_scale = s.keep;
+    int mk_o[E], hm_o[E];
+    unsigned mk_cur[E];
+    float keep_hm[E];
     int gi_o[E], h_o[E], sv_o[E];
     float gi_next[E][3];
 #pragma unroll
@@ -718,6 +732,10 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_h2_kernel(GruSeqBatch batch
         gi_o[i] = gru_off(rows[i], 4 * (int)s.gi_rstride, unit4);
         h_o[i] = live[i] ? gru_off(rows[i], 4 * (int)s.h_stride, unit4) : GRU_DEAD;
         sv_o[i] = live[i] ? gru_off(rows[i], 16 * H, 4 * unit4) : GRU_DEAD;
+        mk_o[i] = s.mk_group > 0 ? (rows[i] / s.mk_group) * s.mk_gstride + (rows[i] % s.mk_group) * s.mk_rstride + unit : rows[i] * s.mk_rstride + unit;
+        hm_o[i] = live[i] ? gru_off(rows[i], 4 * s.hm_stride, unit4) : GRU_DEAD;
+        mk_cur[i] = 0;
+        keep_hm[i] = 0.f;
         const int so = (reverse ? T - 1 : 0) * gi_tp;
         gi_next[i][0] = gru_ld(rs_gi, gi_o[i], so); gi_next[i][1] = gru_ld(rs_gi, gi_o[i] + 4 * H, so); gi_next[i][2] = gru_ld(rs_gi, gi_o[i] + 8 * H, so);
     }
@@ -752,11 +770,15 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_h2_kernel(GruSeqBatch batch
         const int kt = keep_t >= 0 ? keep_t : 0;
         const int so_gi = tn * gi_tp, so_h = kt * h_tp, so_sv = kt * R * (16 * H);
         const __amdgpu_buffer_rsrc_t rs_hs = keep_t >= 0 ? rs_h : rs_none, rs_svs = keep_t >= 0 ? rs_sv : rs_none;
+        const __amdgpu_buffer_rsrc_t rs_hms = keep_t >= 0 ? rs_hm : rs_none;
+        const int so_mk = t * mk_tp, so_hm = kt * hm_tp;
         auto row_traffic = [&](int i) __attribute__((always_inline)) {
             gi_next[i][0] = gru_ld(rs_gi, gi_o[i], so_gi); gi_next[i][1] = gru_ld(rs_gi, gi_o[i] + 4 * H, so_gi);
             gi_next[i][2] = gru_ld(rs_gi, gi_o[i] + 8 * H, so_gi);
             gru_st(keep_h[i], rs_hs, h_o[i], so_h);
+            gru_st(keep_hm[i], rs_hms, hm_o[i], so_hm);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4g, keep_sv[i]), rs_svs, sv_o[i], so_sv, 0);
+            mk_cur[i] = __builtin_amdgcn_raw_buffer_load_b8(rs_mk, mk_o[i], so_mk, 0);
         };
         static_assert(KS <= 4, "one row's traffic per k-step; rows left over go last");
 #pragma unroll
@@ -785,6 +807,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_h2_kernel(GruSeqBatch batch
             const float hn = (1.f - z) * n + z * h[i];
             h[i] = hn;
             keep_h[i] = hn;
+            keep_hm[i] = mk_cur[i] != 0 ? keep_scale * hn : 0.f;
             keep_sv[i] = f32x4{r, z, n, ghn};
         }
         if constexpr (E >= 2) {
@@ -811,6 +834,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_h2_kernel(GruSeqBatch batch
     for (int i = 0; i < E; ++i)
         if (live[i]) {
             gru_st(keep_h[i], rs_h, h_o[i], keep_t * h_tp);
+            gru_st(keep_hm[i], rs_hm, hm_o[i], keep_t * hm_tp);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4g, keep_sv[i]), rs_sv, sv_o[i], keep_t * R * (16 * H), 0);
             if (s.h_fin != nullptr) s.h_fin[(int64_t)rows[i] * s.h_fin_stride + unit] = keep_h[i];
         }
@@ -1051,6 +1075,15 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_h2_kernel(GruSeqBatch batch
     const int reverse = s.reverse, unit4 = 4 * unit;
     const int dh_p = 4 * (int)s.dh_stride, h_p = 4 * (int)s.h_stride, h0_p = 4 * (int)s.h0_stride, dgi_p = 4 * (int)s.dgi_rstride;
     float nx[E][6];                          // dh, r, z, n, gh_n, h_prev of the next step
+    // dropout on the sequence's output (gru_mask.h): dh_all is then the gradient w.r.t. keep * mask * h
+    const bool masked = s.mask != nullptr;
+    const __amdgpu_buffer_rsrc_t rs_mk = gru_rsrc(s.mask);
+    const float keep_scale = s.keep;
+    int mk_o[E];
+    unsigned mk_nx[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i)
+        mk_o[i] = s.mk_group > 0 ? (rows[i] / s.mk_group) * s.mk_gstride + (rows[i] % s.mk_group) * s.mk_rstride + unit : rows[i] * s.mk_rstride + unit;
     auto fetch = [&](int step) {
         const int t = reverse ? step : T - 1 - step;
         const bool has_prev = step + 1 < T;
@@ -1060,6 +1093,7 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_h2_kernel(GruSeqBatch batch
 #pragma unroll
         for (int i = 0; i < E; ++i) {
             nx[i][0] = gru_ld(rs_dh, gru_off(rows[i], dh_p, unit4), t * R * dh_p);
+            mk_nx[i] = __builtin_amdgcn_raw_buffer_load_b8(rs_mk, mk_o[i], t * s.mk_tstride, 0);
             const f32x4 sv = gru_ld4(rs_sv, gru_off(rows[i], 16 * H, 4 * unit4), t * R * (16 * H));
             nx[i][1] = sv[0]; nx[i][2] = sv[1]; nx[i][3] = sv[2]; nx[i][4] = sv[3];
             nx[i][5] = gru_ld(rs_hp, gru_off(rows[i], hp_p, unit4), hp_s);
@@ -1072,7 +1106,8 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_h2_kernel(GruSeqBatch batch
         float gz[E], o_gi[E][3], o_hn[E], o_hp[E];
 #pragma unroll
         for (int i = 0; i < E; ++i) {
-            const float g = live[i] ? nx[i][0] + carry[i] : 0.f;
+            const float dh = masked ? (mk_nx[i] != 0 ? keep_scale * nx[i][0] : 0.f) : nx[i][0];
+            const float g = live[i] ? dh + carry[i] : 0.f;
             const float r = nx[i][1], z = nx[i][2], n = nx[i][3], ghn = nx[i][4], hp = nx[i][5];
             const float dpn = g * (1.f - z) * (1.f - n * n);
             const float dpz = g * (hp - n) * z * (1.f - z);
@@ -1142,10 +1177,15 @@ __global__ __launch_bounds__(H * 4) void gru_seq_bwd_h2_kernel(GruSeqBatch batch
             if (live[i]) s.dh0[(int64_t)rows[i] * s.dh0_stride + unit] = carry[i];
 }
 
-static int fill_batch(GruSeqBatch *b, const arvae_gru_seq_t *seqs, int nseq, int hidden) {
+static int fill_batch(GruSeqBatch *b, const arvae_gru_seq_t *seqs, int nseq, int hidden, const GruSeqMask *masks = nullptr) {
     for (int i = 0; i < nseq; ++i) {
         const arvae_gru_seq_t &q = seqs[i];
         GruSeq &s = b->seq[i];
+        if (masks != nullptr && masks[i].mask != nullptr) {
+            const GruSeqMask &k = masks[i];
+            s.mask = k.mask; s.keep = k.keep; s.h_masked = k.h_masked; s.hm_stride = (int)k.hm_stride;
+            s.mk_tstride = (int)k.tstride; s.mk_rstride = (int)k.rstride; s.mk_gstride = (int)k.gstride; s.mk_group = k.group;
+        }
         s.gi = q.gi; s.gi_tstride = q.gi_tstride; s.w_hh = q.w_hh; s.b_hh = q.b_hh; s.h0 = q.h0;
         s.h_all = q.h_all; s.h_stride = q.h_stride; s.saved = q.saved; s.reverse = q.reverse;
         s.dh_all = q.dh_all; s.dh_stride = q.dh_stride; s.dgi = q.dgi; s.dgh = q.dgh; s.dh0 = q.dh0;
@@ -1943,15 +1983,33 @@ static bool gru_bf16_backward() {
 
 extern "C" int arvae_gru_seq_supported(int32_t hidden) { return hidden == 32 || hidden == 64 || hidden == 128; }
 
+static bool any_mask(const GruSeqMask *masks, int nseq) {
+    for (int i = 0; masks != nullptr && i < nseq; ++i)
+        if (masks[i].mask != nullptr) return true;
+    return false;
+}
+namespace arvae {
+bool gru_seq_masks_supported() { return !gru_fp32_mfma() && !gru_bf16_forward() && !gru_bf16_backward(); }
+}  // namespace arvae
+
 extern "C" int arvae_gru_seq_fwd(const arvae_gru_seq_t *seqs, int32_t nseq, int32_t steps, int32_t rows, int32_t hidden,
                                  arvae_stream_t stream) {
+    return gru_seq_fwd_masked(seqs, nullptr, nseq, steps, rows, hidden, stream);
+}
+
+int arvae::gru_seq_fwd_masked(const arvae_gru_seq_t *seqs, const GruSeqMask *masks, int32_t nseq, int32_t steps, int32_t rows, int32_t hidden,
+                              arvae_stream_t stream) {
     ARVAE_REQUIRE(seqs != nullptr && nseq >= 1 && nseq <= GRU_SEQ_MAX, "gru_seq_fwd: 1..%d sequences per launch", GRU_SEQ_MAX);
+    ARVAE_REQUIRE(!any_mask(masks, nseq) || gru_seq_masks_supported(), "gru_seq_fwd: output dropout needs the fp16 two-term kernels");
+    for (int i = 0; masks != nullptr && i < nseq; ++i)
+        ARVAE_REQUIRE(masks[i].mask == nullptr || (masks[i].h_masked != nullptr && masks[i].hm_stride >= hidden && masks[i].group >= 0),
+                      "gru_seq_fwd: a masked sequence needs its output buffer");
     ARVAE_REQUIRE(steps >= 1 && rows >= 1, "gru_seq_fwd: empty sequence");
     ARVAE_REQUIRE(arvae_gru_seq_supported(hidden), "gru_seq_fwd: hidden size %d is not built (32, 64, 128)", hidden);
     for (int i = 0; i < nseq; ++i)
         ARVAE_REQUIRE(seqs[i].gi && seqs[i].w_hh && seqs[i].b_hh && seqs[i].h_all && seqs[i].saved, "gru_seq_fwd: null pointer");
     GruSeqBatch b{};
-    fill_batch(&b, seqs, nseq, hidden);
+    fill_batch(&b, seqs, nseq, hidden, masks);
     // (the recurrence addresses its arrays with 32-bit byte offsets: gru_rsrc)
     for (int i = 0; i < nseq; ++i) {
         const GruSeq &q = b.seq[i];
@@ -1978,13 +2036,21 @@ extern "C" int arvae_gru_seq_fwd(const arvae_gru_seq_t *seqs, int32_t nseq, int3
 
 extern "C" int arvae_gru_seq_bwd(const arvae_gru_seq_t *seqs, int32_t nseq, int32_t steps, int32_t rows, int32_t hidden,
                                  arvae_stream_t stream) {
+    return gru_seq_bwd_masked(seqs, nullptr, nseq, steps, rows, hidden, stream);
+}
+
+int arvae::gru_seq_bwd_masked(const arvae_gru_seq_t *seqs, const GruSeqMask *masks, int32_t nseq, int32_t steps, int32_t rows, int32_t hidden,
+                              arvae_stream_t stream) {
     ARVAE_REQUIRE(seqs != nullptr && nseq >= 1 && nseq <= GRU_SEQ_MAX, "gru_seq_bwd: 1..%d sequences per launch", GRU_SEQ_MAX);
+    ARVAE_REQUIRE(!any_mask(masks, nseq) || gru_seq_masks_supported(), "gru_seq_bwd: output dropout needs the fp16 two-term kernels");
+    for (int i = 0; masks != nullptr && i < nseq; ++i)
+        ARVAE_REQUIRE(masks[i].mask == nullptr || seqs[i].dh_all != nullptr, "gru_seq_bwd: a masked sequence needs the gradient of its output");
     ARVAE_REQUIRE(steps >= 1 && rows >= 1, "gru_seq_bwd: empty sequence");
     ARVAE_REQUIRE(arvae_gru_seq_supported(hidden), "gru_seq_bwd: hidden size %d is not built (32, 64, 128)", hidden);
     for (int i = 0; i < nseq; ++i)
         ARVAE_REQUIRE(seqs[i].w_hh && seqs[i].h_all && seqs[i].saved && seqs[i].dgi && seqs[i].dgh, "gru_seq_bwd: null pointer");
     GruSeqBatch b{};
-    fill_batch(&b, seqs, nseq, hidden);
+    fill_batch(&b, seqs, nseq, hidden, masks);
     // (the recurrence addresses its arrays with 32-bit byte offsets: gru_rsrc)
     const int64_t span = (int64_t)steps * rows * 4;
     for (int i = 0; i < nseq; ++i) {

@@ -12,6 +12,7 @@
 #include <mutex>
 #include "dense.h"
 #include "regloss.h"
+#include "gru_mask.h"
 
 namespace arvae {
 
@@ -545,6 +546,8 @@ extern "C" int arvae_measure_vae_forward(const arvae_measure_vae_t *m, int32_t b
     }
     const float enc_keep = dropping ? 1.f / (1.f - m->enc_dropout) : 1.f, dec_keep = dropping ? 1.f / (1.f - m->dec_dropout) : 1.f;
     const uint8_t *beat_mask = dec_mask, *tick_mask = dropping ? dec_mask + (int64_t)d.nb * d.b * Hd : nullptr;
+    // the dropout between two stacked GRU layers inside the lower layer's launches (gru_mask.h) instead of a launch of its own
+    const bool fuse_masks = dropping && gru_seq_masks_supported() && diag_env("ARVAE_GRU_MASK_APART") == nullptr;
 
     // ---- encoder (encoder.py:108-124): layer 0's input projection by lookup, both directions side by side
     MV_TRY(lin_fwd(d.v, d.e, 6 * He, P + m->enc_table, P + m->enc_w_ih[0], P + m->enc_b_ih[0], ARVAE_ACT_NONE, w.ptab, s));
@@ -555,12 +558,13 @@ extern "C" int arvae_measure_vae_forward(const arvae_measure_vae_t *m, int32_t b
         float *out = layer == 0 ? w.out0 : w.out1, *sv = layer == 0 ? w.sv0 : w.sv1;
         if (layer == 1) {
             const float *src = w.out0;
-            if (dropping) {
-                MV_TRY(arvae_scale_mask(w.out0, enc_mask, enc_keep, (int64_t)d.tb * 2 * He, 0, w.mid, stream));
+            if (dropping) {                                   // (fused: layer 0's recurrence wrote the masked copy itself, gru_mask.h)
+                if (!fuse_masks) MV_TRY(arvae_scale_mask(w.out0, enc_mask, enc_keep, (int64_t)d.tb * 2 * He, 0, w.mid, stream));
                 src = w.mid;
             }
             MV_TRY(lin_fwd(d.tb, 2 * He, 6 * He, src, P + m->enc_w_ih[1], P + m->enc_b_ih[1], ARVAE_ACT_NONE, w.gi1, s));
         }
+        GruSeqMask qm[2] = {};
         for (int dir = 0; dir < 2; ++dir) {
             arvae_gru_seq_t &g = q[dir];
             g = arvae_gru_seq_t{};
@@ -575,8 +579,10 @@ extern "C" int arvae_measure_vae_forward(const arvae_measure_vae_t *m, int32_t b
             g.reverse = dir;
             g.h_fin = w.hidden + (2 * layer + dir) * He;      // h_n of nn.GRU: (l0 fwd, l0 rev, l1 fwd, l1 rev)
             g.h_fin_stride = 4 * He;
+            if (layer == 0 && fuse_masks)                     // the dropout in front of layer 1: keep bytes (t, b, 2 He), this direction's half
+                qm[dir] = GruSeqMask{enc_mask + dir * He, enc_keep, w.mid + dir * He, 2 * He, (int64_t)d.b * 2 * He, 2 * He, 0, 0};
         }
-        MV_TRY(arvae_gru_seq_fwd(q, 2, d.t, d.b, He, stream));
+        MV_TRY(gru_seq_fwd_masked(q, qm, 2, d.t, d.b, He, stream));
     }
     // the two heads' first layers as one product, then mu / log_std and the reparameterised sample
     MV_TRY(lin_fwd(d.b, 4 * He, 4 * He, w.hidden, P + m->head_w0, P + m->head_b0, ARVAE_ACT_SELU, w.h12, s));
@@ -604,10 +610,12 @@ extern "C" int arvae_measure_vae_forward(const arvae_measure_vae_t *m, int32_t b
     g.gi = w.gi0b; g.gi_tstride = 0;
     g.w_hh = P + m->beat_w_hh[0]; g.b_hh = P + m->beat_b_hh[0]; g.h0 = w.flatb; g.h0_stride = 2 * Hd;   // view(B, 2, H)[:, 0]
     g.h_all = w.out0b; g.h_stride = Hd; g.saved = w.svb0;
-    MV_TRY(arvae_gru_seq_fwd(&g, 1, d.nb, d.b, Hd, stream));
+    GruSeqMask gm{};
+    if (fuse_masks) gm = GruSeqMask{beat_mask, dec_keep, w.midb, Hd, (int64_t)d.b * Hd, Hd, 0, 0};
+    MV_TRY(gru_seq_fwd_masked(&g, &gm, 1, d.nb, d.b, Hd, stream));
     const float *midb = w.out0b;
     if (dropping) {
-        MV_TRY(arvae_scale_mask(w.out0b, beat_mask, dec_keep, (int64_t)d.rb * Hd, 0, w.midb, stream));
+        if (!fuse_masks) MV_TRY(arvae_scale_mask(w.out0b, beat_mask, dec_keep, (int64_t)d.rb * Hd, 0, w.midb, stream));
         midb = w.midb;
     }
     MV_TRY(lin_fwd(d.rb, Hd, 3 * Hd, midb, P + m->beat_w_ih[1], P + m->beat_b_ih[1], ARVAE_ACT_NONE, w.gi1b, s));
@@ -649,12 +657,17 @@ extern "C" int arvae_measure_vae_forward(const arvae_measure_vae_t *m, int32_t b
     g.gi = w.gi0t; g.gi_tstride = (int64_t)d.rb * 3 * Hd;
     g.w_hh = P + m->tick_w_hh[0]; g.b_hh = P + m->tick_b_hh[0]; g.h0 = h0t0; g.h0_stride = both_ld;
     g.h_all = w.out0t; g.h_stride = Hd; g.saved = w.svt0;
-    MV_TRY(arvae_gru_seq_fwd(&g, 1, d.tpb, d.rb, Hd, stream));
+    // (the tick sequences' rows are (beat, measure) over ticks-in-beat steps; the keep bytes are ordered (tick = tpb * beat + j, measure))
+    gm = GruSeqMask{};
+    if (fuse_masks) gm = GruSeqMask{tick_mask, dec_keep, w.midt, Hd, (int64_t)d.b * Hd, Hd, (int64_t)d.tpb * d.b * Hd, d.b};
+    MV_TRY(gru_seq_fwd_masked(&g, &gm, 1, d.tpb, d.rb, Hd, stream));
     const float *midt = w.out0t;
     if (dropping) {
-        ARVAE_LAUNCH(scale_mask_tick_kernel, dim3(blocks_for((int64_t)d.rt * Hd / 4)), dim3(256), 0, s, w.out0t, tick_mask, dec_keep, d.b,
-                     d.nb, d.tpb, Hd / 4, w.midt);
-        MV_TRY(check_launch("scale_mask_tick_kernel"));
+        if (!fuse_masks) {
+            ARVAE_LAUNCH(scale_mask_tick_kernel, dim3(blocks_for((int64_t)d.rt * Hd / 4)), dim3(256), 0, s, w.out0t, tick_mask, dec_keep, d.b,
+                         d.nb, d.tpb, Hd / 4, w.midt);
+            MV_TRY(check_launch("scale_mask_tick_kernel"));
+        }
         midt = w.midt;
     }
     MV_TRY(lin_fwd(d.rt, Hd, 3 * Hd, midt, P + m->tick_w_ih[1], P + m->tick_b_ih[1], ARVAE_ACT_NONE, w.gi1t, s));
@@ -728,6 +741,8 @@ extern "C" int arvae_measure_vae_backward(const arvae_measure_vae_t *m, int32_t 
     const bool dropping = enc_mask != nullptr;
     const float enc_keep = dropping ? 1.f / (1.f - m->enc_dropout) : 1.f, dec_keep = dropping ? 1.f / (1.f - m->dec_dropout) : 1.f;
     const uint8_t *beat_mask = dec_mask, *tick_mask = dropping ? dec_mask + (int64_t)d.nb * d.b * Hd : nullptr;
+    // the lower layers' recurrences multiply the gradient they load by keep * mask themselves (gru_mask.h)
+    const bool fuse_masks = dropping && gru_seq_masks_supported() && diag_env("ARVAE_GRU_MASK_APART") == nullptr;
     WgradQueues queue;
     dense_wgrad_long_begin(queue.rows, w.wg_long, w.wg_long_floats);
     queue.ws = w.wg_ws;
@@ -753,7 +768,10 @@ extern "C" int arvae_measure_vae_backward(const arvae_measure_vae_t *m, int32_t 
     MV_TRY(lin_dgrad(d.rt, Hd, 3 * Hd, plain(w.dgi_t1), P + m->tick_w_ih[1], w.d_mid_t, s));
     MV_TRY(lin_wgrad(&queue, d.rt, Hd, 3 * Hd, plain(w.dgi_t1), midt, G + m->tick_w_ih[1], G + m->tick_b_ih[1], s));
     const float *d_out0t = w.d_mid_t;
-    if (dropping) {
+    GruSeqMask gm{};
+    if (fuse_masks) {
+        gm = GruSeqMask{tick_mask, dec_keep, nullptr, 0, (int64_t)d.b * Hd, Hd, (int64_t)d.tpb * d.b * Hd, d.b};
+    } else if (dropping) {
         ARVAE_LAUNCH(scale_mask_tick_kernel, dim3(blocks_for((int64_t)d.rt * Hd / 4)), dim3(256), 0, s, w.d_mid_t, tick_mask, dec_keep, d.b,
                      d.nb, d.tpb, Hd / 4, w.d_seq_h);
         MV_TRY(check_launch("scale_mask_tick_kernel"));
@@ -763,7 +781,7 @@ extern "C" int arvae_measure_vae_backward(const arvae_measure_vae_t *m, int32_t 
     g.w_hh = P + m->tick_w_hh[0]; g.h0 = w.both; g.h0_stride = 3 * Hd; g.h_all = w.out0t; g.h_stride = Hd; g.saved = w.svt0;
     g.dh_all = d_out0t; g.dh_stride = Hd; g.dgi = w.dgi_t0; g.dgh = w.dgh_t0; g.h_prev_out = w.hprev_t0;
     g.dh0 = w.d_both; g.dh0_stride = 3 * Hd;
-    MV_TRY(arvae_gru_seq_bwd(&g, 1, d.tpb, d.rb, Hd, stream));
+    MV_TRY(gru_seq_bwd_masked(&g, &gm, 1, d.tpb, d.rb, Hd, stream));
     MV_TRY(lin_wgrad(&queue, d.rt, Hd, 3 * Hd, plain(w.dgh_t0), w.hprev_t0, G + m->tick_w_hh[0], G + m->tick_b_hh[0], s));
     // layer 0's input projection: per-tick gradients summed per previous note and per beat row, then the small product's adjoints
     MV_TRY(arvae_tick_gi_bwd(w.dgi_t0, tokens, d.b, d.nb, d.tpb, d.v, 3 * Hd, w.dg_small, w.tick_ws, stream));
@@ -789,7 +807,10 @@ extern "C" int arvae_measure_vae_backward(const arvae_measure_vae_t *m, int32_t 
     MV_TRY(lin_dgrad(d.rb, Hd, 3 * Hd, plain(w.dgi_b1), P + m->beat_w_ih[1], w.d_mid_b, s));
     MV_TRY(lin_wgrad(&queue, d.rb, Hd, 3 * Hd, plain(w.dgi_b1), midb, G + m->beat_w_ih[1], G + m->beat_b_ih[1], s));
     const float *d_out0b = w.d_mid_b;
-    if (dropping) {
+    gm = GruSeqMask{};
+    if (fuse_masks) {
+        gm = GruSeqMask{beat_mask, dec_keep, nullptr, 0, (int64_t)d.b * Hd, Hd, 0, 0};
+    } else if (dropping) {
         MV_TRY(arvae_scale_mask(w.d_mid_b, beat_mask, dec_keep, (int64_t)d.rb * Hd, 0, w.d_rows_h, stream));
         d_out0b = w.d_rows_h;
     }
@@ -797,7 +818,7 @@ extern "C" int arvae_measure_vae_backward(const arvae_measure_vae_t *m, int32_t 
     g.w_hh = P + m->beat_w_hh[0]; g.h0 = w.flatb; g.h0_stride = 2 * Hd; g.h_all = w.out0b; g.h_stride = Hd; g.saved = w.svb0;
     g.dh_all = d_out0b; g.dh_stride = Hd; g.dgi = w.dgi_b0; g.dgh = w.dgh_b0; g.h_prev_out = w.hprev_b0;
     g.dh0 = w.d_flatb; g.dh0_stride = 2 * Hd;
-    MV_TRY(arvae_gru_seq_bwd(&g, 1, d.nb, d.b, Hd, stream));
+    MV_TRY(gru_seq_bwd_masked(&g, &gm, 1, d.nb, d.b, Hd, stream));
     MV_TRY(lin_wgrad(&queue, d.rb, Hd, 3 * Hd, plain(w.dgh_b0), w.hprev_b0, G + m->beat_w_hh[0], G + m->beat_b_hh[0], s));
     // the constant input b_0 (decoder.py:436-440): the projection's gradients over all beats*batch rows (x0b holds b_0 once per row)
     MV_TRY(lin_wgrad(&queue, d.rb, 1, 3 * Hd, plain(w.dgi_b0), w.x0b, G + m->beat_w_ih[0], G + m->beat_b_ih[0], s));
@@ -833,9 +854,13 @@ extern "C" int arvae_measure_vae_backward(const arvae_measure_vae_t *m, int32_t 
         const float *out = layer == 0 ? w.out0 : w.out1, *sv = layer == 0 ? w.sv0 : w.sv1;
         float *dgi = layer == 0 ? w.dgi_e0 : w.dgi_e1, *dgh = layer == 0 ? w.dgh_e0 : w.dgh_e1, *hprev = layer == 0 ? w.hprev_e0 : w.hprev_e1;
         const float *d_out = nullptr;
+        GruSeqMask qm[2] = {};
         if (layer == 0) {
             d_out = w.d_mid_e;
-            if (dropping) {
+            if (fuse_masks) {
+                for (int dir = 0; dir < 2; ++dir)
+                    qm[dir] = GruSeqMask{enc_mask + dir * He, enc_keep, nullptr, 0, (int64_t)d.b * 2 * He, 2 * He, 0, 0};
+            } else if (dropping) {
                 MV_TRY(arvae_scale_mask(w.d_mid_e, enc_mask, enc_keep, (int64_t)d.tb * 2 * He, 0, w.d_out0_e, stream));
                 d_out = w.d_out0_e;
             }
@@ -859,7 +884,7 @@ extern "C" int arvae_measure_vae_backward(const arvae_measure_vae_t *m, int32_t 
             e.dgh = dgh + (int64_t)dir * d.tb * 3 * He;
             e.h_prev_out = hprev + (int64_t)dir * d.tb * He;
         }
-        MV_TRY(arvae_gru_seq_bwd(q, 2, d.t, d.b, He, stream));
+        MV_TRY(gru_seq_bwd_masked(q, qm, 2, d.t, d.b, He, stream));
         for (int dir = 0; dir < 2; ++dir)
             MV_TRY(lin_wgrad(&queue, d.tb, He, 3 * He, plain(dgh + (int64_t)dir * d.tb * 3 * He), hprev + (int64_t)dir * d.tb * He,
                              G + m->enc_w_hh[layer][dir], G + m->enc_b_hh[layer][dir], s));
