@@ -130,8 +130,10 @@ ROCPROF_NAMES = {
     'conv64_up(wide)': ['arvae::conv64s_kernel<4, 2, 0>'], 'conv64_up(narrow)': ['arvae::conv_rows_x3_kernel<true>'],
     'conv64_wgrad(pairs, wide)': ['arvae::conv_wgrad_pairs_h2_kernel'], 'conv64_wgrad(pairs, narrow)': ['arvae::conv_wgrad_pairs_h2_kernel'],
     'conv64_wgrad(rows)': ['arvae::conv_wgrad_rows_x3_kernel'],
-    'gru_seq_fwd_kernel': ['arvae::gru_seq_fwd_x3_kernel<128>'], 'gru_seq_bwd_kernel': ['arvae::gru_seq_bwd_x3_kernel<128>'],
+    # (round 5: the recurrences own 4 / 8 / 16 batch rows per workgroup -- the instantiation a B = 256 step runs is the 4-row one)
+    'gru_seq_fwd_kernel': ['arvae::gru_seq_fwd_h2_kernel<128, 4>'], 'gru_seq_bwd_kernel': ['arvae::gru_seq_bwd_h2_kernel<128, 4>'],
     'tick_free_run_x3_kernel': ['arvae::tick_free_run_x3_kernel<128>'],
+    'tick_free_run_h2_kernel': ['arvae::tick_free_run_h2_kernel<128, true, 4>', 'arvae::tick_free_run_h2_kernel<128, false, 4>'],
     'rows_gemm_kernel<fwd>': ['arvae::rows_gemm_x3_kernel'], 'rows_gemm_kernel<dgrad>': ['arvae::rows_gemm_x3_kernel'],
     'rows_gemm_kernel<wgrad>': ['arvae::rows_gemm_x3_kernel'],
 }
@@ -180,7 +182,8 @@ SIDE_KERNEL_MACS = {
 }
 # families that do not launch in every step: MACs per unit and LAUNCH (the free-running decoder pass runs on the steps
 # whose teacher-forcing coin says no: 24 ticks x (W_hh0, W_ih1, W_hh1: 9 H^2; note projection H V))
-SIDE_KERNEL_MACS_PER_LAUNCH = {'measure': {'tick_free_run_x3_kernel': 24 * (9 * 128 * 128 + 128 * 35)}}
+SIDE_KERNEL_MACS_PER_LAUNCH = {'measure': {'tick_free_run_x3_kernel': 24 * (9 * 128 * 128 + 128 * 35),
+                                           'tick_free_run_h2_kernel': 24 * (9 * 128 * 128 + 128 * 35)}}
 
 
 class DspritesDataset:          # ImageVAETrainer sniffs the dataset's class name (reference image_vae_trainer.py:81-86)
@@ -451,8 +454,10 @@ def side_roofline(kind, prof, prof_steps, batch):
         if per_launch:
             macs += per_launch * prof[lb]['calls'] / prof_steps
     if macs:
-        # (the wide 64-channel convolutions and their weight gradient moved to the two-term fp16 arithmetic in round 3)
-        products = F16X2_PRODUCTS if (kind == 'mnist' and ('wide' in name or 'pairs' in name)) else BF16X3_PRODUCTS
+        # (the wide 64-channel convolutions and their weight gradient moved to the two-term fp16 arithmetic in round 3, the GRU
+        # recurrences in rounds 4 (forward, free-running) and 5 (backward))
+        products = F16X2_PRODUCTS if ((kind == 'mnist' and ('wide' in name or 'pairs' in name)) or
+                                      (kind == 'measure' and ('gru_seq' in name or 'tick_free_run_h2' in name))) else BF16X3_PRODUCTS
         tf = 2.0 * macs * batch * products / (dom['ms'] / prof_steps * 1e-3) / 1e12
         out.update({'bound': 'mfma', 'achieved': tf, 'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': tf / PEAK_BF16_MFMA_TFLOPS, 'traffic': None, 'fp32_equivalent_tflops': tf / products,
