@@ -94,7 +94,9 @@ def _same(a, b, what, rel=2e-5):
 
 
 @pytest.mark.parametrize('b,hid,zdim,dropout', [(256, 128, 32, 0.5), (21, 128, 32, 0.5), (5, 64, 16, 0.0), (37, 64, 32, 0.5),
-                                                (96, 128, 32, 0.0), (100, 64, 16, 0.5)])
+                                                (96, 128, 32, 0.0), (100, 64, 16, 0.5),
+                                                # (the recurrences at 8 and 16 rows per workgroup, with dropout between their layers)
+                                                (700, 64, 32, 0.5), (1400, 64, 16, 0.5)])
 @pytest.mark.parametrize('teacher', [True, False], ids=['teacher_forced', 'free_running'])
 def test_executor_step_matches_the_per_layer_path(dev, b, hid, zdim, dropout, teacher):
     """same explicit noise and keep-masks: the two paths' loss terms, accuracy and all gradients agree (the launches are the
