@@ -348,7 +348,7 @@ __device__ __forceinline__ void s8_split8(const float (&x)[8], float sc, f16x8 &
     split_pair_h2(x[6], x[7], sc, h.w, l.w);
     hi = __builtin_bit_cast(f16x8, h); lo = __builtin_bit_cast(f16x8, l);
 }
-__global__ __launch_bounds__(256) void conv_s8_h2_kernel(ConvRows g, int tiles_per_img, int n_tiles) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void conv_s8_h2_kernel(ConvRows g, int tiles_per_img, int n_tiles) {
     __shared__ uint4 src_h[S8_PIX + 1], src_l[S8_PIX + 1];
     __shared__ __attribute__((aligned(16))) float otile[64][68];   // the tile's results, so that the epilogue is 16-byte loads and stores
     __shared__ float wmax[4];
@@ -381,24 +381,58 @@ __global__ __launch_bounds__(256) void conv_s8_h2_kernel(ConvRows g, int tiles_p
     const ActCoef ac = act_coef(g.act);
     const GateCoef gc = epilogue_coef(g.gate.y, g.gate.act, g.gate.mask, g.mask);
     float vmax = 0.f;
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int img = tile / tiles_per_img, P0 = (tile - img * tiles_per_img) * 64;
+    // A tile's global round trips are requested a phase ahead (round 5): the NEXT tile's source pixels while this tile is multiplied,
+    // this tile's keep bytes / gate values before its MFMAs instead of behind them.  As a chain -- load the source, split, multiply,
+    // then load the epilogue's operands -- a tile cost ~6.5 us per workgroup and the launch wrote its 127 MB at 1.8 TB/s.
+    auto geom = [&](int tile, int &img, int &P0, int &sy0, int &nrows) {
+        img = tile / tiles_per_img;
+        P0 = (tile - img * tiles_per_img) * 64;
         const int y_first = P0 / g.ow, y_last = min(P0 + 63, opix - 1) / g.ow;
-        const int sy0 = g.sgn < 0 ? y_first - 3 + g.off : y_first + g.off, nrows = y_last - y_first + 4;
-        __syncthreads();                                         // the previous tile's operand reads are done
+        sy0 = g.sgn < 0 ? y_first - 3 + g.off : y_first + g.off;
+        nrows = y_last - y_first + 4;
+    };
+    float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa;           // this thread's staged pixel of the coming tile (zeros outside)
+    auto fetch_src = [&](int tile) {
+        sa = sb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tile >= n_tiles) return;
+        int img, P0, sy0, nrows;
+        geom(tile, img, P0, sy0, nrows);
         if ((int)threadIdx.x < nrows * g.sw) {
             const int r = threadIdx.x / g.sw, x = threadIdx.x - r * g.sw, sy = sy0 + r;
-            const bool ok = sy >= 0 && sy < g.sh;
-            const float *p = g.src.v + (((int64_t)img * g.sh + (ok ? sy : 0)) * g.sw + x) * 8;
-            const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
-            const float z = ok ? 1.f : 0.f;
-            const float v[8] = {a.x * z, a.y * z, a.z * z, a.w * z, b.x * z, b.y * z, b.z * z, b.w * z};
+            if (sy >= 0 && sy < g.sh) {
+                const float *p = g.src.v + (((int64_t)img * g.sh + sy) * g.sw + x) * 8;
+                sa = *reinterpret_cast<const float4 *>(p);
+                sb = *reinterpret_cast<const float4 *>(p + 4);
+            }
+        }
+    };
+    fetch_src(blockIdx.x);
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        int img, P0, sy0, nrows;
+        geom(tile, img, P0, sy0, nrows);
+        // (LDS-only barriers, common.h: __syncthreads() would also wait for the previous tile's STORES and for the loads just
+        // requested ahead)
+        lds_barrier();                                           // the previous tile's operand reads are done
+        if ((int)threadIdx.x < nrows * g.sw) {
+            const float v[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
             f16x8 h, l;
             s8_split8(v, sc_a.s, h, l);
             src_h[threadIdx.x] = __builtin_bit_cast(uint4, h);
             src_l[threadIdx.x] = __builtin_bit_cast(uint4, l);
         }
-        __syncthreads();
+        lds_barrier();
+        // this tile's epilogue operands and the next tile's source pixels: in flight under the MFMAs
+        const int64_t obase = (int64_t)img * opix;
+        unsigned gm[4];
+        float4 gy[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int pr = P0 + e_px + 16 * u;
+            const int64_t o = (pr < opix && e_ok) ? (obase + pr) * g.q + e_c : 0;
+            gm[u] = mp != nullptr ? *reinterpret_cast<const unsigned *>(mp + o) : 0x01010101u;
+            gy[u] = g.gate.y != nullptr ? *reinterpret_cast<const float4 *>(g.gate.y + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        fetch_src(tile + gridDim.x);
         const int P = P0 + 32 * wp + rc;
         const bool pok = P < opix;
         const int y = P / g.ow, x = P - y * g.ow;
@@ -416,22 +450,12 @@ __global__ __launch_bounds__(256) void conv_s8_h2_kernel(ConvRows g, int tiles_p
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl[s8], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh[s8], acc, 0, 0, 0);
         }
-        // the accumulators meet in LDS ([pixel][channel]); then every thread finishes four (pixel, 4 channels) slots: keep-mask bytes /
-        // gate values requested first, bias, activation, gate, one 16-byte store (the 16 dword stores per lane of the gathering kernels
-        // moved 256 bytes per instruction: the launch ran at 1.7 TB/s of output)
+        // the accumulators meet in LDS ([pixel][channel]); then every thread finishes four (pixel, 4 channels) slots: bias, activation,
+        // gate, one 16-byte store (the 16 dword stores per lane of the gathering kernels moved 256 bytes per instruction: the launch
+        // ran at 1.7 TB/s of output)
 #pragma unroll
         for (int r = 0; r < 16; ++r) otile[32 * wp + (r & 3) + 8 * (r >> 2) + 4 * half][q] = acc[r];
-        __syncthreads();
-        const int64_t obase = (int64_t)img * opix;
-        unsigned gm[4];
-        float4 gy[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int pr = P0 + e_px + 16 * u;
-            const int64_t o = (pr < opix && e_ok) ? (obase + pr) * g.q + e_c : 0;
-            gm[u] = mp != nullptr ? *reinterpret_cast<const unsigned *>(mp + o) : 0x01010101u;
-            gy[u] = g.gate.y != nullptr ? *reinterpret_cast<const float4 *>(g.gate.y + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        lds_barrier();
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int pr = P0 + e_px + 16 * u;
