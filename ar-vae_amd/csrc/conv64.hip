@@ -339,6 +339,12 @@ __global__ __launch_bounds__(256) void conv_rows_h2_kernel(ConvRows g) {
 //   * a tile is 64 consecutive output pixels of an image in row-major order (94 % of the MFMA rows at 22 x 22), workgroups walk
 //     tiles persistently, four workgroups per CU hide each other's staging round trip.
 // Arithmetic: scaled two-term fp16, three products (conv32_common.h); plain sources that come with their maxima.
+#ifdef S8_STAMPS
+__device__ unsigned long long g_s8_stamps[8];
+#define S8STAMP(k) { const unsigned long long now_ = __builtin_readcyclecounter(); s8ph[k] += now_ - s8tc; s8tc = now_; }
+#else
+#define S8STAMP(k)
+#endif
 constexpr int S8_PIX = 255;                                      // staged source pixels per tile (one per thread; 255 = the zero pixel)
 __device__ __forceinline__ void s8_split8(const float (&x)[8], float sc, f16x8 &hi, f16x8 &lo) {
     uint4 h, l;
@@ -392,24 +398,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         nrows = y_last - y_first + 4;
     };
     float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa;           // this thread's staged pixel of the coming tile (zeros outside)
+    // (raw buffer loads and stores with an out-of-range offset for "none": a load under a run-time branch makes the compiler drain the
+    // wave's memory queue at the join -- stamped here: half of a tile's 8600 cycles sat in the phase that only REQUESTS operands)
+    const int64_t out_bytes = (int64_t)g.n * opix * g.q * 4;
+    const __amdgpu_buffer_rsrc_t rs_src = make_rsrc(g.src.v, (int64_t)g.n * g.sh * g.sw * 32), rs_out = make_rsrc(g.out, out_bytes);
+    const __amdgpu_buffer_rsrc_t rs_mask = make_rsrc(mp != nullptr ? (const void *)mp : (const void *)g.out, mp != nullptr ? out_bytes / 4 : 0);
+    const __amdgpu_buffer_rsrc_t rs_gate = make_rsrc(g.gate.y != nullptr ? (const void *)g.gate.y : (const void *)g.out, g.gate.y != nullptr ? out_bytes : 0);
+    const bool has_mask = mp != nullptr;
     auto fetch_src = [&](int tile) {
-        sa = sb = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tile >= n_tiles) return;
         int img, P0, sy0, nrows;
-        geom(tile, img, P0, sy0, nrows);
-        if ((int)threadIdx.x < nrows * g.sw) {
-            const int r = threadIdx.x / g.sw, x = threadIdx.x - r * g.sw, sy = sy0 + r;
-            if (sy >= 0 && sy < g.sh) {
-                const float *p = g.src.v + (((int64_t)img * g.sh + sy) * g.sw + x) * 8;
-                sa = *reinterpret_cast<const float4 *>(p);
-                sb = *reinterpret_cast<const float4 *>(p + 4);
-            }
-        }
+        geom(tile < n_tiles ? tile : 0, img, P0, sy0, nrows);
+        const int r = threadIdx.x / g.sw, x = threadIdx.x - r * g.sw, sy = sy0 + r;
+        const bool ok = tile < n_tiles && (int)threadIdx.x < nrows * g.sw && sy >= 0 && sy < g.sh;
+        const unsigned off = ok ? (unsigned)((((img * g.sh + sy) * g.sw) + x) * 32) : OOB;
+        sa = buf_load4(rs_src, off);
+        sb = buf_load4(rs_src, ok ? off + 16u : OOB);
     };
     fetch_src(blockIdx.x);
+#ifdef S8_STAMPS
+    unsigned long long s8ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s8tc = __builtin_readcyclecounter();
+#endif
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         int img, P0, sy0, nrows;
         geom(tile, img, P0, sy0, nrows);
+        S8STAMP(0);
         // (LDS-only barriers, common.h: __syncthreads() would also wait for the previous tile's STORES and for the loads just
         // requested ahead)
         lds_barrier();                                           // the previous tile's operand reads are done
@@ -420,48 +432,64 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             src_h[threadIdx.x] = __builtin_bit_cast(uint4, h);
             src_l[threadIdx.x] = __builtin_bit_cast(uint4, l);
         }
+        S8STAMP(1);
         lds_barrier();
+        S8STAMP(2);
         // this tile's epilogue operands and the next tile's source pixels: in flight under the MFMAs
         const int64_t obase = (int64_t)img * opix;
-        unsigned gm[4];
+        unsigned gm[4], oo[4];                                    // (oo: the slot's element offset in the output, OOB / 4 for none)
         float4 gy[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int pr = P0 + e_px + 16 * u;
-            const int64_t o = (pr < opix && e_ok) ? (obase + pr) * g.q + e_c : 0;
-            gm[u] = mp != nullptr ? *reinterpret_cast<const unsigned *>(mp + o) : 0x01010101u;
-            gy[u] = g.gate.y != nullptr ? *reinterpret_cast<const float4 *>(g.gate.y + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+            oo[u] = (pr < opix && e_ok) ? (unsigned)((obase + pr) * g.q + e_c) : OOB / 4;
+            const unsigned mk = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs_mask, (int)oo[u], 0, 0);
+            gm[u] = has_mask ? mk : 0x01010101u;
+            gy[u] = buf_load4(rs_gate, oo[u] == OOB / 4 ? OOB : oo[u] * 4u);
         }
         fetch_src(tile + gridDim.x);
+        S8STAMP(3);
         const int P = P0 + 32 * wp + rc;
         const bool pok = P < opix;
         const int y = P / g.ow, x = P - y * g.ow;
         f32x16c acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-        for (int s8 = 0; s8 < 8; ++s8) {
+        // a k-step's two operand reads are requested one step ahead of its MFMAs (pinned: left to the scheduler every read was
+        // followed by a wait for it, sixteen exposed LDS round trips per tile)
+        auto operand = [&](int s8, f16x8 &ah, f16x8 &al2) __attribute__((always_inline)) {
             const int tap = 2 * s8 + half, ky = tap >> 2, kx = tap & 3;
             const int sy = y + g.sgn * ky + g.off, sx = x + g.sgn * kx + g.off;
             const bool ok = pok && (unsigned)sy < (unsigned)g.sh && (unsigned)sx < (unsigned)g.sw;
             const int idx = ok ? (sy - sy0) * g.sw + sx : S8_PIX;
-            const f16x8 ah = __builtin_bit_cast(f16x8, src_h[idx]), al2 = __builtin_bit_cast(f16x8, src_l[idx]);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al2, wh[s8], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl[s8], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh[s8], acc, 0, 0, 0);
+            ah = __builtin_bit_cast(f16x8, src_h[idx]);
+            al2 = __builtin_bit_cast(f16x8, src_l[idx]);
+        };
+        f16x8 ah_c, al_c, ah_n, al_n;
+        operand(0, ah_c, al_c);
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) {
+            if (s8 + 1 < 8) operand(s8 + 1, ah_n, al_n);
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al_c, wh[s8], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_c, wl[s8], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_c, wh[s8], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            ah_c = ah_n;
+            al_c = al_n;
         }
         // the accumulators meet in LDS ([pixel][channel]); then every thread finishes four (pixel, 4 channels) slots: bias, activation,
         // gate, one 16-byte store (the 16 dword stores per lane of the gathering kernels moved 256 bytes per instruction: the launch
         // ran at 1.7 TB/s of output)
 #pragma unroll
         for (int r = 0; r < 16; ++r) otile[32 * wp + (r & 3) + 8 * (r >> 2) + 4 * half][q] = acc[r];
+        S8STAMP(4);
         lds_barrier();
+        S8STAMP(5);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int pr = P0 + e_px + 16 * u;
-            if (pr < opix && e_ok) {
-                const int64_t o = (obase + pr) * g.q + e_c;
-                const float4 a4 = *reinterpret_cast<const float4 *>(&otile[e_px + 16 * u][e_c]);
+            {
+                const float4 a4 = *reinterpret_cast<const float4 *>(&otile[e_px + 16 * u][e_ok ? e_c : 0]);
                 // (common.h's coefficient form: result = act(..) * d(y) * keep byte)
                 float4 v = make_float4(act_fwd_coef(fmaf(a4.x, inv, bias4.x), ac), act_fwd_coef(fmaf(a4.y, inv, bias4.y), ac),
                                        act_fwd_coef(fmaf(a4.z, inv, bias4.z), ac), act_fwd_coef(fmaf(a4.w, inv, bias4.w), ac));
@@ -470,11 +498,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 v.y *= gate_deriv(gy[u].y, gc) * (float)((m >> 8) & 255u);
                 v.z *= gate_deriv(gy[u].z, gc) * (float)((m >> 16) & 255u);
                 v.w *= gate_deriv(gy[u].w, gc) * (float)(m >> 24);
-                *reinterpret_cast<float4 *>(g.out + o) = v;
-                vmax = fmaxf(vmax, amax4(v));
+                const bool live = oo[u] != OOB / 4;
+                buf_store4(v, rs_out, live ? oo[u] * 4u : OOB);
+                vmax = live ? fmaxf(vmax, amax4(v)) : vmax;
             }
         }
+        S8STAMP(6);
     }
+#ifdef S8_STAMPS
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        for (int k = 0; k < 7; ++k) g_s8_stamps[k] = s8ph[k];
+        g_s8_stamps[7] = (n_tiles - 1) / gridDim.x + 1;
+    }
+#endif
     if (g.amax_out != nullptr) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, off, 64));
@@ -552,11 +588,22 @@ static int launch_conv_rows(ConvRows g, const float *wt, bool transposed, float 
     static const bool no_s8 = diag_env("ARVAE_CONV_S8_GATHER") != nullptr;      // A/B: the gathering kernel for 8-channel sources too
     const int span_rows = 63 / g.ow + 2 + 3;                                    // source rows a 64-pixel tile can touch
     if (h2 && !no_s8 && g.cs == 8 && g.kh == 4 && g.kw == 4 && g.q <= 64 && (g.q & 3) == 0 && span_rows * g.sw <= S8_PIX &&
-        (reinterpret_cast<uintptr_t>(g.out) & 15) == 0) {
+        (reinterpret_cast<uintptr_t>(g.out) & 15) == 0 && (int64_t)M * g.q * 4 < 0x7fff0000ll) {       // (32-bit byte offsets into the output)
         ConvRows p = g;
         p.src.y = nullptr;
         const int tiles_per_img = (g.oh * g.ow + 63) / 64, n_tiles = g.n * tiles_per_img;
-        const int slots = 3 * device_cu_count();                                // (146 + 16 registers: three workgroups per CU)
+        // as many persistent workgroups as the chip holds AT ONCE (asked of the runtime: a grid of three per CU ran as two rounds when
+        // only two were resident -- workgroup 0 was done after 33 of the launch's 56 us)
+        static const int per_cu = [] {
+            int n = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)conv_s8_h2_kernel, 256, 0) != hipSuccess || n < 1) {
+                (void)hipGetLastError();
+                n = 2;
+            }
+            if (const char *e = diag_env("ARVAE_S8_PER_CU")) n = atoi(e) > 0 ? atoi(e) : n;
+            return n;
+        }();
+        const int slots = per_cu * device_cu_count();
         ARVAE_LAUNCH(conv_s8_h2_kernel, dim3(n_tiles < slots ? n_tiles : slots), dim3(256), 0, s, p, tiles_per_img, n_tiles);
     } else if (h2) {
         ConvRows p = g;
@@ -1240,3 +1287,9 @@ int conv64_wgrad(const arvae_link_t *l, const Operand &lo, const Operand &hi, fl
 }
 
 }  // namespace arvae
+
+#ifdef S8_STAMPS
+extern "C" int arvae_debug_s8_stamps(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(arvae::g_s8_stamps), sizeof(unsigned long long) * 8) == hipSuccess ? 0 : -1;
+}
+#endif
