@@ -556,7 +556,22 @@ __global__ __launch_bounds__(256) void down_single_channel_mfma_kernel(Geom g, O
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, quad = lane >> 4;
     const int taps = g.kh * g.kw, npos = g.lh * g.lw, hpix = g.hh * g.hw;
     const int img = blockIdx.x;
-    for (int i = threadIdx.x; i < hpix; i += 256) img_lds[i] = hi.at((int64_t)img * hpix + i);
+    if (hi.y == nullptr && hpix <= 4 * 256) {
+        // a plain image: all of a thread's pixels requested at once (Operand::at's conditions make every iteration of the loop below
+        // a round trip of its own)
+        const __amdgpu_buffer_rsrc_t rs_img = make_rsrc(hi.v, (int64_t)gridDim.x * hpix * 4);
+        float px[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = threadIdx.x + 256 * u;
+            px[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_img, i < hpix ? (int)((img * hpix + i) * 4) : (int)OOB, 0, 0));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (threadIdx.x + 256 * u < hpix) img_lds[threadIdx.x + 256 * u] = px[u];
+    } else {
+        for (int i = threadIdx.x; i < hpix; i += 256) img_lds[i] = hi.at((int64_t)img * hpix + i);
+    }
     // B[k = tap][n = channel]: lane (col = channel in tile, quad), k-step kk <-> tap = 4 kk + quad
     float b[4][4], bias[4];
 #pragma unroll
@@ -578,6 +593,15 @@ __global__ __launch_bounds__(256) void down_single_channel_mfma_kernel(Geom g, O
     float amax_run = 0.f;
     const ActCoef ac = act_coef(ep.act);
     const GateCoef gc = epilogue_coef(ep.gate.y, ep.gate.act, ep.gate.mask, ep.mask);
+    // the epilogue's operands and stores as raw buffer operations with an out-of-range offset for "none" (round 5): under run-time
+    // conditions (a mask? a gate? a position past the end?) every load sat in a block of its own and the compiler put a wait for the
+    // wave's whole memory queue -- these requests and the previous tile's stores -- in front of the tile's first MFMA
+    const uint8_t *mp = ep.gate.y != nullptr ? ep.gate.mask : ep.mask;          // (a gated launch has no forward keep-mask)
+    const int64_t out_bytes = (int64_t)gridDim.x * npos * 64 * 4;
+    const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(ep.out, out_bytes);
+    const __amdgpu_buffer_rsrc_t rs_mask = make_rsrc(mp != nullptr ? (const void *)mp : (const void *)ep.out, mp != nullptr ? out_bytes / 4 : 0);
+    const __amdgpu_buffer_rsrc_t rs_gate = make_rsrc(ep.gate.y != nullptr ? (const void *)ep.gate.y : (const void *)ep.out, ep.gate.y != nullptr ? out_bytes : 0);
+    const bool has_mask = mp != nullptr;
     for (int mt = wave; mt < mtiles; mt += 4) {
         const int pos = 16 * mt + col;                       // A row = position
         uint32_t ly, lx;
@@ -586,15 +610,15 @@ __global__ __launch_bounds__(256) void down_single_channel_mfma_kernel(Geom g, O
         f32x4t acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         // keep-mask bytes / gate values of this lane's four (position, 4 channels) slots: requested before the MFMAs
         const int e_pos = lane >> 4, e_c = 4 * (lane & 15);
-        unsigned mk[4];
+        unsigned mk[4], oo[4];                               // (oo: the slot's element offset in the output, OOB / 4 for none)
         float4 gy[4];
-        const uint8_t *mp = ep.gate.y != nullptr ? ep.gate.mask : ep.mask;      // (a gated launch has no forward keep-mask)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int p = 16 * mt + e_pos + 4 * u, pc = p < npos ? p : npos - 1;
-            const int64_t o = ((int64_t)img * npos + pc) * 64 + e_c;
-            mk[u] = mp != nullptr ? *reinterpret_cast<const unsigned *>(mp + o) : 0x01010101u;
-            gy[u] = ep.gate.y != nullptr ? *reinterpret_cast<const float4 *>(ep.gate.y + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int p = 16 * mt + e_pos + 4 * u;
+            oo[u] = p < npos ? (unsigned)((img * npos + p) * 64 + e_c) : OOB / 4;
+            const unsigned m = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs_mask, (int)oo[u], 0, 0);
+            mk[u] = has_mask ? m : 0x01010101u;
+            gy[u] = buf_load4(rs_gate, oo[u] == OOB / 4 ? OOB : oo[u] * 4u);
         }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -611,10 +635,8 @@ __global__ __launch_bounds__(256) void down_single_channel_mfma_kernel(Geom g, O
         // (the tile is this wave's own: LDS operations of a wave complete in order)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int p = 16 * mt + e_pos + 4 * u;
             const float4 a4 = *reinterpret_cast<const float4 *>(&otile[wave][e_pos + 4 * u][e_c]);
-            if (p >= npos) continue;
-            const int64_t o = ((int64_t)img * npos + p) * 64 + e_c;
+            const bool live = oo[u] != OOB / 4;
             // activation, then gate / keep-mask in common.h's coefficient form (result *= d(y) * keep byte; no gate: d = 2 with a
             // keep-mask, else 1 with bytes of ones)
             float4 v = make_float4(act_fwd_coef(a4.x, ac), act_fwd_coef(a4.y, ac), act_fwd_coef(a4.z, ac), act_fwd_coef(a4.w, ac));
@@ -623,8 +645,8 @@ __global__ __launch_bounds__(256) void down_single_channel_mfma_kernel(Geom g, O
             v.y *= gate_deriv(gy[u].y, gc) * (float)((m >> 8) & 255u);
             v.z *= gate_deriv(gy[u].z, gc) * (float)((m >> 16) & 255u);
             v.w *= gate_deriv(gy[u].w, gc) * (float)(m >> 24);
-            amax_run = fmaxf(amax_run, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-            *reinterpret_cast<float4 *>(ep.out + o) = v;
+            amax_run = live ? fmaxf(amax_run, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)))) : amax_run;
+            buf_store4(v, rs_out, live ? oo[u] * 4u : OOB);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -639,7 +661,8 @@ __global__ __launch_bounds__(256) void down_single_channel_mfma_kernel(Geom g, O
 
 static bool single_channel_mfma_fits(const arvae_link_t *l) {
     return l->chi == 1 && l->clo == 64 && l->kh * l->kw <= 16 && l->hi_perm_c == 0 && l->lo_perm_c == 0 &&
-           (size_t)l->hh * l->hw * sizeof(float) <= 64 * 1024 && diag_env("ARVAE_C1_GENERIC") == nullptr;
+           (size_t)l->hh * l->hw * sizeof(float) <= 64 * 1024 && diag_env("ARVAE_C1_GENERIC") == nullptr &&
+           (int64_t)l->n * l->lh * l->lw * 64 * 4 < 0x7fff0000ll;       // (32-bit byte offsets into the 64-channel tensor)
 }
 
 // bias gradients: out[feature(c)] += sum_rows g[row, c], two fixed-order stages (no float atomics)
