@@ -494,15 +494,21 @@ __global__ __launch_bounds__(256) void up_single_channel_mfma_kernel(Geom g, con
         for (int j = 0; j < 4; ++j) b[kq][j] = col < taps ? wt[(16 * kq + 4 * quad + j) * taps + col] : 0.f;
     const float *lo_img = lo + (int64_t)img * npos * clo;
     const int mtiles = (npos + 15) / 16;
-    for (int mt0 = wave; mt0 < mtiles; mt0 += 8) {            // two M-tiles per round: 2 * KQ loads in flight
-        f32x4t a[2][KQ];
+    // two M-tiles per round, the NEXT round's 2 * KQ loads requested before this round's MFMAs (round 5: a wave's five rounds were
+    // five exposed round trips to HBM; positions past the end clamp to the last one, so the requests need no condition)
+    f32x4t a[2][KQ], an[2][KQ];
+    auto request = [&](int mt0, f32x4t (&dst)[2][KQ]) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int pos = 16 * (mt0 + 4 * u) + col;
             const float *src = lo_img + (int64_t)(pos < npos ? pos : npos - 1) * clo + 4 * quad;
 #pragma unroll
-            for (int kq = 0; kq < KQ; ++kq) a[u][kq] = *reinterpret_cast<const f32x4t *>(src + 16 * kq);
+            for (int kq = 0; kq < KQ; ++kq) dst[u][kq] = *reinterpret_cast<const f32x4t *>(src + 16 * kq);
         }
+    };
+    request(wave, a);
+    for (int mt0 = wave; mt0 < mtiles; mt0 += 8) {
+        request(mt0 + 8, an);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int mt = mt0 + 4 * u;
@@ -518,6 +524,10 @@ __global__ __launch_bounds__(256) void up_single_channel_mfma_kernel(Geom g, con
                 if (pos < npos) t_lds[pos * TP + col] = acc[i];
             }
         }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int kq = 0; kq < KQ; ++kq) a[u][kq] = an[u][kq];
     }
     __syncthreads();
     const float bias = ep.bias != nullptr ? ep.bias[0] : 0.f;
