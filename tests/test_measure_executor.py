@@ -227,3 +227,44 @@ def test_trainer_falls_back_to_the_per_layer_path(dev):
     trainer2.backward(loss)
     torch.cuda.synchronize()
     assert torch.isfinite(loss) and torch.isfinite(trainer2.optimizer.grad_arena).all() and trainer2.optimizer.grad_arena.abs().sum() > 0
+
+
+def test_round5_recurrences_match_the_round4_kernels(dev):
+    """The executor's step under the default recurrences -- 4 batch rows per workgroup, the backward pass on per-row-scaled two-term
+    fp16, the dropout between stacked layers inside the launches -- against the diagnostic library's round-4 forms of all three
+    (ARVAE_GRU_WIDE: 16 rows; ARVAE_GRU_BF16_BWD: three-term bf16; ARVAE_GRU_MASK_APART: mask launches): the same loss terms, and
+    gradients that agree to the arithmetic's 1e-5."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, json; sys.path.insert(0, %r)\n"
+        "import torch\n"
+        "from arvae_amd import synthetic as syn\n"
+        "from tests.test_measure_executor import _trainer, _masks, _one_step\n"
+        "dev = torch.device('cuda:0')\n"
+        "out = {}\n"
+        "for teacher in (True, False):\n"
+        "    trainer, model = _trainer(128, 32, 0.5)\n"
+        "    score = torch.from_numpy(syn.measure_batch(256, seed=77)).to(dev)\n"
+        "    eps = torch.from_numpy(syn.normal_noise((256, 32), seed=78))\n"
+        "    loss, acc, terms, grads = _one_step(trainer, model, score, True, teacher, eps, _masks(256, 128, 5))\n"
+        "    out[str(teacher)] = {'loss': loss, 'acc': acc, 'gn': {k: float(v.norm()) for k, v in grads.items()},\n"
+        "                         'g0': {k: float(v.flatten()[0]) for k, v in grads.items()}}\n"
+        "print(json.dumps(out))\n" % root)
+    diag = os.path.join(root, 'ar-vae_amd', 'libarvae_hip_diag.so')
+    old = {'ARVAE_LIB': diag, 'ARVAE_GRU_WIDE': '1', 'ARVAE_GRU_BF16_BWD': '1', 'ARVAE_GRU_MASK_APART': '1'}
+    res = {}
+    for name, env in (('round5', {}), ('round4', old)):
+        r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[name] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    for teacher in ('True', 'False'):
+        a, b = res['round5'][teacher], res['round4'][teacher]
+        assert abs(a['loss'] - b['loss']) <= 1e-5 * abs(b['loss']), (teacher, a['loss'], b['loss'])
+        assert abs(a['acc'] - b['acc']) <= 1e-6
+        for k, v in b['gn'].items():
+            assert abs(a['gn'][k] - v) <= 2e-5 * v + 1e-10, (teacher, k, a['gn'][k], v)
+            assert abs(a['g0'][k] - b['g0'][k]) <= 1e-4 * abs(b['g0'][k]) + 2e-5 * v / max(1.0, v) + 1e-9, (teacher, k, a['g0'][k], b['g0'][k])
