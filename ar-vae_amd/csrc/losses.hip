@@ -3,6 +3,7 @@
 // wavefront (64-lane) shuffle reductions, per-workgroup partials in a caller-provided workspace and a
 // fixed-order finishing pass (bitwise reproducible: no float atomics on the loss values).
 #include "common.h"
+#include "attributes.h"
 #include "regloss.h"
 
 namespace arvae {
@@ -204,10 +205,10 @@ __global__ __launch_bounds__(256) void pair_finish_kernel(const float *__restric
 constexpr int TOK_VMAX = 48;                 // widest vocabulary the staged path takes (64 rows x 48 floats of LDS)
 constexpr int TOK_LPR = 4;                   // lanes per row: a 256-thread workgroup takes 64 rows, so B * 24 = 6144 rows are 96
 constexpr int TOK_ROWS = 256 / TOK_LPR;      // workgroups instead of 24 (13.8 -> ~6 us at B = 256)
-__global__ __launch_bounds__(256) void token_recon_kernel(const float *__restrict__ w, const int64_t *__restrict__ tgt,
-                                                           int64_t rows, int vocab, float inv_rows,
-                                                           float *__restrict__ partial, float *__restrict__ dw, int tk_batch = 0,
-                                                           int tk_beats = 0, int tk_tpb = 0) {
+// (a body: the launch may carry the attribute labels' workgroups behind these -- BID / NBLK: this workgroup's index and their number)
+__device__ __forceinline__ void token_recon_body(const float *__restrict__ w, const int64_t *__restrict__ tgt, int64_t rows, int vocab,
+                                                 float inv_rows, float *__restrict__ partial, float *__restrict__ dw, int tk_batch,
+                                                 int tk_beats, int tk_tpb, const int BID, const int NBLK) {
     // tk_beats > 0: the rows are in the tick RNN's sequence order (tick-in-beat j, beat, measure b) and tgt is the score
     // [batch][beats * tpb]: row r = (j * beats + beat) * batch + b reads tgt[b][tpb * beat + j]
     __shared__ float red[4];
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(256) void token_recon_kernel(const float *__restric
     float loss = 0.f, corr = 0.f;
     const bool staged = vocab <= TOK_VMAX;
     const int rl = threadIdx.x / TOK_LPR, part = threadIdx.x % TOK_LPR;       // row of this pass, lane's share of its columns
-    for (int64_t r0 = (int64_t)blockIdx.x * TOK_ROWS; r0 < rows; r0 += (int64_t)gridDim.x * TOK_ROWS) {
+    for (int64_t r0 = (int64_t)BID * TOK_ROWS; r0 < rows; r0 += (int64_t)NBLK * TOK_ROWS) {
         const int64_t r = r0 + rl;
         const int nrow = (int)(rows - r0 < TOK_ROWS ? rows - r0 : TOK_ROWS);
         const float *row = w + r * vocab;
@@ -279,9 +280,29 @@ __global__ __launch_bounds__(256) void token_recon_kernel(const float *__restric
     const float tl = block_sum_256(loss, red);
     const float tc = block_sum_256(corr, red);
     if (threadIdx.x == 0) {
-        partial[2 * blockIdx.x] = tl;
-        partial[2 * blockIdx.x + 1] = tc;
+        partial[2 * BID] = tl;
+        partial[2 * BID + 1] = tc;
     }
+}
+
+__global__ __launch_bounds__(256) void token_recon_kernel(const float *__restrict__ w, const int64_t *__restrict__ tgt,
+                                                           int64_t rows, int vocab, float inv_rows,
+                                                           float *__restrict__ partial, float *__restrict__ dw, int tk_batch = 0,
+                                                           int tk_beats = 0, int tk_tpb = 0) {
+    token_recon_body(w, tgt, rows, vocab, inv_rows, partial, dw, tk_batch, tk_beats, tk_tpb, blockIdx.x, gridDim.x);
+}
+// the MeasureVAE executor's cross entropy with the attribute labels riding in its grid (attributes.h: they depend on the score
+// alone; a launch of their own was ~5 us of latency for 256 lanes of table look-ups): workgroups [0, nb) the token term, the rest
+// one measure per lane
+__global__ __launch_bounds__(256) void token_recon_attr_kernel(const float *__restrict__ w, const int64_t *__restrict__ tgt,
+                                                                int64_t rows, int vocab, float inv_rows,
+                                                                float *__restrict__ partial, float *__restrict__ dw, int tk_batch,
+                                                                int tk_beats, int tk_tpb, AttrArgs attr, int nb) {
+    if ((int)blockIdx.x >= nb) {
+        measure_attributes_rows(attr, ((int)blockIdx.x - nb) * 256 + threadIdx.x, ((int)gridDim.x - nb) * 256);
+        return;
+    }
+    token_recon_body(w, tgt, rows, vocab, inv_rows, partial, dw, tk_batch, tk_beats, tk_tpb, blockIdx.x, nb);
 }
 
 __global__ __launch_bounds__(256) void scale_by_scalar_kernel(const float *__restrict__ g, const float *__restrict__ x,
@@ -432,10 +453,14 @@ int recon_partial_blocks(int64_t count) { return grid_for(count, 8, RECON_MAX_BL
 // score's (batch, tick) targets (+ d/dweights for a unit upstream gradient of the MEAN); the block count through *nb_out
 int token_recon_blocks(int64_t rows) { return grid_for(rows * TOK_LPR, 1, RECON_MAX_BLOCKS); }
 int token_recon_partials(const float *weights, const int64_t *score, int batch, int beats, int tpb, int32_t vocab, float *ws,
-                         float *dweights, hipStream_t s, int *nb_out) {
+                         float *dweights, hipStream_t s, int *nb_out, const AttrArgs *attr) {
     const int64_t rows = (int64_t)batch * beats * tpb;
     const int nb = token_recon_blocks(rows);
-    ARVAE_LAUNCH(token_recon_kernel, dim3(nb), dim3(256), 0, s, weights, score, rows, vocab, 1.f / (float)rows, ws, dweights, batch, beats, tpb);
+    if (attr != nullptr && attr->out != nullptr)          // (+ the attribute labels: one measure per lane in the grid's last workgroups)
+        ARVAE_LAUNCH(token_recon_attr_kernel, dim3(nb + (attr->batch + 255) / 256), dim3(256), 0, s, weights, score, rows, vocab,
+                     1.f / (float)rows, ws, dweights, batch, beats, tpb, *attr, nb);
+    else
+        ARVAE_LAUNCH(token_recon_kernel, dim3(nb), dim3(256), 0, s, weights, score, rows, vocab, 1.f / (float)rows, ws, dweights, batch, beats, tpb);
     *nb_out = nb;
     return check_launch("token_recon");
 }

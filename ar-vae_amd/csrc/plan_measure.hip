@@ -13,12 +13,13 @@
 #include "dense.h"
 #include "regloss.h"
 #include "gru_mask.h"
+#include "attributes.h"
 
 namespace arvae {
 
 // loss-term pieces (losses.hip)
 int token_recon_partials(const float *weights, const int64_t *score, int batch, int beats, int tpb, int32_t vocab, float *ws,
-                         float *dweights, hipStream_t s, int *nb_out);
+                         float *dweights, hipStream_t s, int *nb_out, const AttrArgs *attr);
 int token_recon_blocks(int64_t rows);
 // arvae_tick_gi_fwd that also copies the tokens it reads (sequence.hip)
 int tick_gi_fwd_copy(const float *g_small, const int64_t *tokens, const float *bias, int32_t batch, int32_t beats, int32_t ticks_per_beat,
@@ -682,11 +683,12 @@ extern "C" int arvae_measure_vae_forward(const arvae_measure_vae_t *m, int32_t b
     // looked up through it), the attribute labels and the regulariser's pair sums, then ONE finishing launch: the partial sums,
     // beta-KL, the regulariser's gradient and the pass's scalars
     int nb = 0;
-    MV_TRY(token_recon_partials(w.probs, score, d.b, d.nb, d.tpb, d.v, w.rec_ws, w.dprobs, s, &nb));
     float *lab = labels != nullptr ? labels : w.labels;
-    if (m->n_reg > 0)
-        MV_TRY(arvae_measure_attributes(score, d.b, d.t, tables->midi_lut, tables->is_note, tables->is_density_note, d.v,
-                                        tables->rhythm_weights, tables->rhythm_norm, lab, stream));
+    // (the attribute labels -- a function of the score alone -- ride in the cross-entropy launch's grid: attributes.h)
+    const AttrArgs attr{score, d.b, d.t, tables != nullptr ? tables->midi_lut : nullptr, tables != nullptr ? tables->is_note : nullptr,
+                        tables != nullptr ? tables->is_density_note : nullptr, d.v, tables != nullptr ? tables->rhythm_weights : nullptr,
+                        tables != nullptr ? tables->rhythm_norm : 1.f, m->n_reg > 0 ? lab : nullptr};
+    MV_TRY(token_recon_partials(w.probs, score, d.b, d.nb, d.tpb, d.v, w.rec_ws, w.dprobs, s, &nb, &attr));
     if (defer_finish) return ARVAE_OK;                   // data parallel: arvae_measure_vae_finish, once z and the labels are gathered
     if (m->n_reg > 0) {
         RegDims rd;

@@ -6,6 +6,7 @@
 // measurevae/decoder.py:338-368 via nn.GRU):
 //     r = sigmoid(gi_r + gh_r);  z = sigmoid(gi_z + gh_z);  n = tanh(gi_n + r * gh_n);  h' = (1-z)*n + z*h
 #include "common.h"
+#include "attributes.h"
 
 namespace arvae {
 
@@ -347,50 +348,8 @@ __global__ __launch_bounds__(256) void broadcast_rows_kernel(const float *__rest
 
 // measure attributes (reference bar_dataset.py:338-500 via measure_vae_trainer.py:167-186): one lane per measure
 //   out[b] = [rhythmic complexity, pitch range / 26, note density, contour / 26]
-__global__ __launch_bounds__(64) void measure_attributes_kernel(const int64_t *__restrict__ score, int batch, int steps,
-                                                                  const int32_t *__restrict__ midi, const uint8_t *__restrict__ is_note,
-                                                                  const uint8_t *__restrict__ is_dens, int vocab,
-                                                                  const float *__restrict__ rhy_w, float rhy_norm,
-                                                                  float *__restrict__ out) {
-    // (the walk along a measure is a dependent chain of table look-ups: a measure's notes are requested first, then every
-    // table entry they select -- two memory round trips per chunk of 8 ticks instead of two per tick: 10.5 -> ~3 us at B = 256)
-    constexpr int CH = 8;
-    for (int b = blockIdx.x * 64 + threadIdx.x; b < batch; b += gridDim.x * 64) {
-        float rhy = 0.f;
-        int dens = 0, count = 0, first = 0, last = 0, lo = 0, hi = 0;
-        for (int t0 = 0; t0 < steps; t0 += CH) {
-            int v[CH], dn[CH], nt[CH], md[CH];
-            float rw[CH];
-#pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                const int t = t0 + u < steps ? t0 + u : steps - 1;
-                const int64_t x = score[(int64_t)b * steps + t];
-                v[u] = (int)(x < 0 ? 0 : (x >= vocab ? vocab - 1 : x));
-                rw[u] = rhy_w[t];
-            }
-#pragma unroll
-            for (int u = 0; u < CH; ++u) { dn[u] = is_dens[v[u]]; nt[u] = is_note[v[u]]; md[u] = midi[v[u]]; }
-#pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                if (t0 + u >= steps) continue;
-                dens += dn[u];
-                if (nt[u]) {
-                    rhy += rw[u];
-                    const int m = md[u];
-                    if (count == 0) { first = lo = hi = m; }
-                    last = m;
-                    lo = m < lo ? m : lo;
-                    hi = m > hi ? m : hi;
-                    ++count;
-                }
-            }
-        }
-        float *o = out + (int64_t)b * 4;
-        o[0] = rhy / rhy_norm;
-        o[1] = count >= 2 ? (float)(hi - lo) / 26.f : 0.f;
-        o[2] = (float)dens / (float)steps;
-        o[3] = count >= 2 ? (float)(last - first) / 26.f : 0.f;
-    }
+__global__ __launch_bounds__(64) void measure_attributes_kernel(AttrArgs a) {
+    measure_attributes_rows(a, blockIdx.x * 64 + threadIdx.x, gridDim.x * 64);
 }
 
 static inline int blocks_for(int64_t n, int cap = 2048) {
@@ -562,7 +521,7 @@ extern "C" int arvae_measure_attributes(const int64_t *score, int32_t batch, int
                                              arvae_stream_t stream) {
     ARVAE_REQUIRE(score && midi_lut && is_note && is_density_note && rhythm_weights && out && batch > 0 && steps > 0 &&
                       vocab > 0 && rhythm_norm > 0.f, "measure_attributes: bad argument");
-    ARVAE_LAUNCH(measure_attributes_kernel, dim3((batch + 63) / 64), dim3(64), 0, as_stream(stream), score, batch, steps,
-                       midi_lut, is_note, is_density_note, vocab, rhythm_weights, rhythm_norm, out);
+    ARVAE_LAUNCH(measure_attributes_kernel, dim3((batch + 63) / 64), dim3(64), 0, as_stream(stream),
+                 AttrArgs{score, batch, steps, midi_lut, is_note, is_density_note, vocab, rhythm_weights, rhythm_norm, out});
     return check_launch("measure_attributes_kernel");
 }
