@@ -285,6 +285,46 @@ __global__ __launch_bounds__(256) void sum_into_kernel(const float *__restrict__
     if (threadIdx.x == 0) dst[0] += red[0];
 }
 
+// Three small sums that nothing in the pass waits for, as ONE launch at its end (round 5; each was a ~5 us launch of its own at the point
+// where its operand appeared): the tick RNN's first bias gradient (column sums of the note rows), the gradient of b_0 (a sum over
+// beats x batch numbers) and the encoder table's gradient added to the arena.  Workgroups [0, cs_blocks) the column sums, one the sum,
+// the rest the addition; each job's own fixed order is what it was.
+struct GradTail {
+    const float *cs_x; int cs_rows, cs_cols; float *cs_dst; int cs_blocks;
+    const float *sum_x; int sum_n; float *sum_dst;
+    const float *add_x; int add_n; float *add_dst;
+};
+__global__ __launch_bounds__(256) void grad_tail_kernel(GradTail t) {
+    __shared__ float red[256];
+    const int b = blockIdx.x;
+    if (b < t.cs_blocks) {
+        const int c = b * 256 + threadIdx.x;
+        if (c >= t.cs_cols) return;
+        float a = 0.f;
+        for (int r0 = 0; r0 < t.cs_rows; r0 += 16) {             // sixteen independent loads per round trip, summed in row order
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = t.cs_x[(int64_t)min(r0 + u, t.cs_rows - 1) * t.cs_cols + c];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a += r0 + u < t.cs_rows ? v[u] : 0.f;
+        }
+        t.cs_dst[c] += a;
+    } else if (b == t.cs_blocks) {
+        float a = 0.f;
+        for (int i = threadIdx.x; i < t.sum_n; i += 256) a += t.sum_x[i];
+        red[threadIdx.x] = a;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) t.sum_dst[0] += red[0];
+    } else {
+        const int i = (b - t.cs_blocks - 1) * 256 + threadIdx.x;
+        if (i < t.add_n) t.add_dst[i] += t.add_x[i];
+    }
+}
+
 static inline unsigned blocks_for(int64_t items, int cap = 2048) {
     const int64_t b = (items + 255) / 256;
     return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -788,8 +828,7 @@ extern "C" int arvae_measure_vae_backward(const arvae_measure_vae_t *m, int32_t 
     // layer 0's input projection: per-tick gradients summed per previous note and per beat row, then the small product's adjoints
     MV_TRY(arvae_tick_gi_bwd(w.dgi_t0, tokens, d.b, d.nb, d.tpb, d.v, 3 * Hd, w.dg_small, w.tick_ws, stream));
     // (every tick row carries the bias once and exactly one note entry: the bias gradient is the column sum of the note rows)
-    ARVAE_LAUNCH(colsum_into_kernel, dim3((3 * Hd + 255) / 256), dim3(256), 0, s, w.dg_small, d.v + 1, 3 * Hd, G + m->tick_b_ih[0]);
-    MV_TRY(check_launch("colsum_into_kernel"));
+    // (its column sums -- the bias gradient -- wait for the pass's closing launch: grad_tail_kernel)
     MV_TRY(lin_wgrad(&queue, d.ns, d.e + Hd, 3 * Hd, plain(w.dg_small), w.xs, G + m->tick_w_ih[0], nullptr, s));
     MV_TRY(lin_dgrad(d.ns, d.e + Hd, 3 * Hd, plain(w.dg_small), P + m->tick_w_ih[0], w.dx_small, s));
     MV_TRY(arvae_tick_rows_bwd(w.dx_small, d.v, d.e, Hd, d.rb, G + m->dec_table, G + m->x0, w.d_both + 2 * Hd, 3 * Hd, stream));
@@ -825,8 +864,7 @@ extern "C" int arvae_measure_vae_backward(const arvae_measure_vae_t *m, int32_t 
     // the constant input b_0 (decoder.py:436-440): the projection's gradients over all beats*batch rows (x0b holds b_0 once per row)
     MV_TRY(lin_wgrad(&queue, d.rb, 1, 3 * Hd, plain(w.dgi_b0), w.x0b, G + m->beat_w_ih[0], G + m->beat_b_ih[0], s));
     MV_TRY(lin_dgrad(d.rb, 1, 3 * Hd, plain(w.dgi_b0), P + m->beat_w_ih[0], w.d_x0, s));
-    ARVAE_LAUNCH(sum_into_kernel, dim3(1), dim3(256), 0, s, w.d_x0, d.rb, G + m->b0);
-    MV_TRY(check_launch("sum_into_kernel"));
+    // (the gradient of b_0, the sum of d_x0, in grad_tail_kernel)
     MV_TRY(lin_dgrad(d.b, d.z, 2 * Hd, gated(w.d_flatb, w.flatb, ARVAE_ACT_SELU), P + m->z2beat_w, w.d_z, s));
     MV_TRY(lin_wgrad(&queue, d.b, d.z, 2 * Hd, gated(w.d_flatb, w.flatb, ARVAE_ACT_SELU), z, G + m->z2beat_w, G + m->z2beat_b, s));
 
@@ -899,7 +937,11 @@ extern "C" int arvae_measure_vae_backward(const arvae_measure_vae_t *m, int32_t 
     // layer 0's projection table: per-position gradients summed per token, then the small product's adjoints
     MV_TRY(arvae_embed_bwd(score, w.dgi_e0, d.b, d.t, 6 * He, d.v, 1, w.dptab, 0, w.embed_ws, stream));
     MV_TRY(lin_dgrad(d.v, d.e, 6 * He, plain(w.dptab), P + m->enc_w_ih[0], w.d_table, s));
-    MV_TRY(arvae_scale_mask(w.d_table, nullptr, 1.f, (int64_t)d.v * d.e, 1, G + m->enc_table, stream));
+    {
+        GradTail t{w.dg_small, d.v + 1, 3 * Hd, G + m->tick_b_ih[0], (3 * Hd + 255) / 256, w.d_x0, d.rb, G + m->b0, w.d_table, d.v * d.e, G + m->enc_table};
+        ARVAE_LAUNCH(grad_tail_kernel, dim3(t.cs_blocks + 1 + (t.add_n + 255) / 256), dim3(256), 0, s, t);
+        MV_TRY(check_launch("grad_tail_kernel"));
+    }
     MV_TRY(lin_wgrad(&queue, d.v, d.e, 6 * He, plain(w.dptab), P + m->enc_table, G + m->enc_w_ih[0], G + m->enc_b_ih[0], s));
     MV_TRY(dense_wgrad_long_flush(queue.rows, s));
     return dense_wgrad_flush(&queue.batch, s);
