@@ -257,34 +257,6 @@ __global__ __launch_bounds__(256) void beat_input_kernel(const float *__restrict
         }
     }
 }
-// dst[c] += sum over the (few) rows of x[rows][cols]: a thread per column, fixed order (the note table's rows of the lookup gradient)
-__global__ __launch_bounds__(256) void colsum_into_kernel(const float *__restrict__ x, int rows, int cols, float *__restrict__ dst) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= cols) return;
-    float a = 0.f;
-    for (int r0 = 0; r0 < rows; r0 += 16) {                      // sixteen independent loads per round trip, summed in row order
-        float v[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = x[(int64_t)min(r0 + u, rows - 1) * cols + c];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) a += r0 + u < rows ? v[u] : 0.f;
-    }
-    dst[c] += a;
-}
-// dst[0] += sum of x[0 .. n): one workgroup, fixed order (the gradient of b_0 from its per-row gradients)
-__global__ __launch_bounds__(256) void sum_into_kernel(const float *__restrict__ x, int n, float *__restrict__ dst) {
-    __shared__ float red[256];
-    float a = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) a += x[i];
-    red[threadIdx.x] = a;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) dst[0] += red[0];
-}
-
 // Three small sums that nothing in the pass waits for, as ONE launch at its end (round 5; each was a ~5 us launch of its own at the point
 // where its operand appeared): the tick RNN's first bias gradient (column sums of the note rows), the gradient of b_0 (a sum over
 // beats x batch numbers) and the encoder table's gradient added to the arena.  Workgroups [0, cs_blocks) the column sums, one the sum,
