@@ -1,4 +1,5 @@
-// measure attributes (reference bar_dataset.py:338-500 via measure_vae_trainer.py:167-186) as a device function: one lane per measure,
+// Small independent jobs of the MeasureVAE step as device functions, so that they can ride in another launch's grid.
+// measure attributes (reference bar_dataset.py:338-500 via measure_vae_trainer.py:167-186): one lane per measure,
 //   out[b] = [rhythmic complexity, pitch range / 26, note density, contour / 26]
 // so that the labels can ride in another launch's grid (losses.hip: the cross-entropy launch of the MeasureVAE executor carries them;
 // they depend on the score alone).  sequence.hip's measure_attributes_kernel is the launch of its own.
@@ -60,6 +61,27 @@ __device__ __forceinline__ void measure_attributes_rows(const AttrArgs &a, int f
         o[1] = count >= 2 ? (float)(hi - lo) / 26.f : 0.f;
         o[2] = (float)dens / (float)steps;
         o[3] = count >= 2 ? (float)(last - first_m) / 26.f : 0.f;
+    }
+}
+
+// the beat RNN's constant input b_0 (decoder.py:436-440): its copies x0b[rows] (what the weight gradient reads) and its projection
+// gi[b][c] = b_0 * w[c] + bias[c], the same row for every measure -- a function of the parameters alone, so it rides in the first
+// lookup launch of the forward pass (sequence.hip embed_fwd4_beat_kernel) instead of being a launch of its own
+struct BeatInput {
+    const float *b0, *w, *bias;
+    int batch, cols, rows;
+    float *x0b, *gi;             // gi null: nothing to do
+};
+__device__ __forceinline__ void beat_input_items(const BeatInput &p, int64_t first, int64_t stride) {
+    const float v = p.b0[0];
+    const int64_t n_gi = (int64_t)p.batch * p.cols, total = n_gi + p.rows;
+    for (int64_t i = first; i < total; i += stride) {
+        if (i < n_gi) {
+            const int c = (int)(i % p.cols);
+            p.gi[i] = fmaf(v, p.w[c], p.bias[c]);
+        } else {
+            p.x0b[i - n_gi] = v;
+        }
     }
 }
 

@@ -21,6 +21,8 @@ namespace arvae {
 int token_recon_partials(const float *weights, const int64_t *score, int batch, int beats, int tpb, int32_t vocab, float *ws,
                          float *dweights, hipStream_t s, int *nb_out, const AttrArgs *attr);
 int token_recon_blocks(int64_t rows);
+bool embed_fwd_with_beat(const int64_t *idx, const float *table, int32_t batch, int32_t steps, int32_t dim, int32_t vocab, int32_t time_major,
+                         float *out, const BeatInput &beat, hipStream_t s, int *rc);
 // arvae_tick_gi_fwd that also copies the tokens it reads (sequence.hip)
 int tick_gi_fwd_copy(const float *g_small, const int64_t *tokens, const float *bias, int32_t batch, int32_t beats, int32_t ticks_per_beat,
                      int32_t vocab, int32_t cols, float *gi, int64_t *copy_to, hipStream_t s);
@@ -244,18 +246,8 @@ static bool measure_heads_fit(int hw, int zdim) { return hw >= 4 && hw <= 256 &&
 
 // the beat RNN's constant input b_0 (decoder.py:436-440): its copies x0b[rows] (what the weight gradient reads) and its projection
 // gi[b][c] = b_0 * w[c] + bias[c], the same row for every measure -- one launch instead of a broadcast and a 1-wide Linear layer
-__global__ __launch_bounds__(256) void beat_input_kernel(const float *__restrict__ b0, const float *__restrict__ w, const float *__restrict__ bias,
-                                                          int batch, int cols, int rows, float *__restrict__ x0b, float *__restrict__ gi) {
-    const float v = b0[0];
-    const int64_t n_gi = (int64_t)batch * cols, total = n_gi + rows;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        if (i < n_gi) {
-            const int c = (int)(i % cols);
-            gi[i] = fmaf(v, w[c], bias[c]);
-        } else {
-            x0b[i - n_gi] = v;
-        }
-    }
+__global__ __launch_bounds__(256) void beat_input_kernel(BeatInput p) {
+    beat_input_items(p, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256);
 }
 // Three small sums that nothing in the pass waits for, as ONE launch at its end (round 5; each was a ~5 us launch of its own at the point
 // where its operand appeared): the tick RNN's first bias gradient (column sums of the note rows), the gradient of b_0 (a sum over
@@ -564,7 +556,15 @@ extern "C" int arvae_measure_vae_forward(const arvae_measure_vae_t *m, int32_t b
 
     // ---- encoder (encoder.py:108-124): layer 0's input projection by lookup, both directions side by side
     MV_TRY(lin_fwd(d.v, d.e, 6 * He, P + m->enc_table, P + m->enc_w_ih[0], P + m->enc_b_ih[0], ARVAE_ACT_NONE, w.ptab, s));
-    MV_TRY(arvae_embed_fwd(score, w.ptab, d.b, d.t, 6 * He, d.v, 1, w.gi0, stream));
+    // (the beat RNN's constant input -- a function of the parameters alone -- rides in this lookup's grid: attributes.h)
+    bool beat_done = false;
+    {
+        const BeatInput bi{P + m->b0, P + m->beat_w_ih[0], P + m->beat_b_ih[0], d.b, 3 * Hd, d.rb, w.x0b, w.gi0b};
+        int rc = ARVAE_OK;
+        beat_done = embed_fwd_with_beat(score, w.ptab, d.b, d.t, 6 * He, d.v, 1, w.gi0, bi, s, &rc);
+        if (beat_done) MV_TRY(rc);
+        else MV_TRY(arvae_embed_fwd(score, w.ptab, d.b, d.t, 6 * He, d.v, 1, w.gi0, stream));
+    }
     arvae_gru_seq_t q[2];
     for (int layer = 0; layer < 2; ++layer) {
         const float *gi = layer == 0 ? w.gi0 : w.gi1;
@@ -616,9 +616,11 @@ extern "C" int arvae_measure_vae_forward(const arvae_measure_vae_t *m, int32_t b
 
     // ---- beat RNN (decoder.py:436-457): the same input b_0 at every beat
     MV_TRY(lin_fwd(d.b, d.z, 2 * Hd, z, P + m->z2beat_w, P + m->z2beat_b, ARVAE_ACT_SELU, w.flatb, s));
-    ARVAE_LAUNCH(beat_input_kernel, dim3(blocks_for((int64_t)d.b * 3 * Hd + d.rb)), dim3(256), 0, s, P + m->b0, P + m->beat_w_ih[0],
-                 P + m->beat_b_ih[0], d.b, 3 * Hd, d.rb, w.x0b, w.gi0b);
-    MV_TRY(check_launch("beat_input_kernel"));
+    if (!beat_done) {
+        ARVAE_LAUNCH(beat_input_kernel, dim3(blocks_for((int64_t)d.b * 3 * Hd + d.rb)), dim3(256), 0, s,
+                     BeatInput{P + m->b0, P + m->beat_w_ih[0], P + m->beat_b_ih[0], d.b, 3 * Hd, d.rb, w.x0b, w.gi0b});
+        MV_TRY(check_launch("beat_input_kernel"));
+    }
     arvae_gru_seq_t g{};
     g.gi = w.gi0b; g.gi_tstride = 0;
     g.w_hh = P + m->beat_w_hh[0]; g.b_hh = P + m->beat_b_hh[0]; g.h0 = w.flatb; g.h0_stride = 2 * Hd;   // view(B, 2, H)[:, 0]

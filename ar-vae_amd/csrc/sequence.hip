@@ -90,6 +90,27 @@ __global__ __launch_bounds__(256) void embed_fwd4_kernel(const int64_t *__restri
     }
 }
 
+// ... with the beat RNN's constant input riding in the grid's last workgroups (attributes.h)
+__global__ __launch_bounds__(256) void embed_fwd4_beat_kernel(const int64_t *__restrict__ idx, const float4 *__restrict__ table,
+                                                               int batch, int steps, int dim4, int vocab, int time_major,
+                                                               float4 *__restrict__ out, BeatInput beat, int nb) {
+    if ((int)blockIdx.x >= nb) {
+        beat_input_items(beat, (int64_t)((int)blockIdx.x - nb) * 256 + threadIdx.x, (int64_t)((int)gridDim.x - nb) * 256);
+        return;
+    }
+    const int lane = threadIdx.x & 63;
+    const int64_t rows = (int64_t)batch * steps, nw = (int64_t)nb * 4;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += nw) {
+        const int b = time_major ? (int)(row % batch) : (int)(row / steps);
+        const int t = time_major ? (int)(row / batch) : (int)(row % steps);
+        int64_t v = idx[(int64_t)b * steps + t];
+        v = v < 0 ? 0 : (v >= vocab ? vocab - 1 : v);
+        const float4 *src = table + v * dim4;
+        float4 *dst = out + row * dim4;
+        for (int d = lane; d < dim4; d += 64) dst[d] = src[d];
+    }
+}
+
 // dtable[v][d] += sum over positions with idx == v of g[row][d], in two launches with a fixed summation order:
 // (1) a workgroup stages EMBED_POS positions (indices + gradient rows) in LDS and one thread per (v, d) pair sums the rows
 // whose index is v; (2) the per-workgroup partials are added in workgroup order.
@@ -389,6 +410,21 @@ extern "C" int arvae_embed_fwd(const int64_t *idx, const float *table, int32_t b
                        table, batch, steps, dim, vocab, time_major, out);
     return check_launch("embed_fwd_kernel");
 }
+
+// arvae_embed_fwd (wide rows) with the beat RNN's constant input in the same launch (plan_measure.hip); false: not that case
+namespace arvae {
+bool embed_fwd_with_beat(const int64_t *idx, const float *table, int32_t batch, int32_t steps, int32_t dim, int32_t vocab, int32_t time_major,
+                         float *out, const BeatInput &beat, hipStream_t s, int *rc) {
+    if (!(dim % 4 == 0 && dim >= 64 && (reinterpret_cast<uintptr_t>(table) | reinterpret_cast<uintptr_t>(out)) % 16 == 0)) return false;
+    const int nb = (int)(((int64_t)batch * steps + 3) / 4);
+    const int64_t items = (int64_t)beat.batch * beat.cols + beat.rows;
+    const int nbeat = (int)((items + 255) / 256 > 512 ? 512 : (items + 255) / 256);
+    ARVAE_LAUNCH(embed_fwd4_beat_kernel, dim3((unsigned)(nb + nbeat)), dim3(256), 0, s, idx, reinterpret_cast<const float4 *>(table), batch, steps,
+                 dim / 4, vocab, time_major, reinterpret_cast<float4 *>(out), beat, nb);
+    *rc = check_launch("embed_fwd4_kernel(+ beat input)");
+    return true;
+}
+}  // namespace arvae
 
 extern "C" int64_t arvae_embed_bwd_ws_floats(int32_t batch, int32_t steps, int32_t dim, int32_t vocab) {
     if (dim > 128) return (int64_t)EMBED_WSPLIT * vocab * dim;
