@@ -502,13 +502,13 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_x3_kernel(GruSeqBatch batch
 // The SEQUENCE kernels take every scale from the data (round 5): W_hh's slice of a wave its own power of two (a column's scale
 // factors out of the dot product), the state the workgroup's max(1, max |h0|) -- a bound for the whole sequence, h_t being a convex
 // combination of a tanh output and h_(t-1) --, the backward pass's gradients a scale per batch row and step (gru_seq_bwd_h2_kernel):
-// nothing can overflow.  The FREE-RUNNING decoder (tick_free_run_h2_kernel) still uses the fixed scales of round 4, 2^4 for the
-// states (|h| < 4094 before fp16 overflows, absolute resolution 2^-29) and 2^8 for its three matrices (|w| < 255, resolution
-// 2^-33): two of its products share an accumulator, so their scales are tied, and its states are re-seeded every beat; the host
-// checks the ranges when run-time checks are on (ops.tick_free_run).
+// nothing can overflow.  The FREE-RUNNING decoder (tick_free_run_h2_kernel) takes its scales from the data as well: the three matrices'
+// from their maxima (tick_weight_amax_kernel, one launch in front of the weight prep; W_ih1 and W_hh1 share a scale because their
+// products share accumulators), the states' per beat from the workgroup's rows (a beat's states are convex combinations of tanh
+// outputs and the beat's initial state; the layer-1 input is a layer-0 state times 0 or the keep scale).
 typedef _Float16 f16x8g __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2g __attribute__((ext_vector_type(2)));
-constexpr float GRU_SH = 16.f, GRU_SW = 256.f, GRU_UNSCALE = 1.f / (16.f * 256.f);
+constexpr float GRU_SH = 16.f, GRU_UNSCALE = 1.f / (16.f * 256.f);     // (placeholders until a beat's first scale: never multiplied with)
 __device__ __forceinline__ void split2_pair(float x0, float x1, float s, unsigned &hi, unsigned &lo) {
     const float y0 = x0 * s, y1 = x1 * s;
     const f32x2g y = {y0, y1};
@@ -1630,8 +1630,34 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_x3_kernel(TickFreeRun p, 
 
 // the same free-running pass on the scaled two-term fp16 operands of gru_seq_fwd_h2_kernel: two thirds of the weight stream
 // (590 instead of 885 KB per tick and workgroup, the kernel's bound) and half the MFMAs
+// largest magnitude of each of the three matrices (one workgroup per matrix) -> wmax[0 .. 3): the free-running kernel's weight scales
+// (round 5; a fixed 2^8 before, which overflowed fp16 for |w| >= 255)
 template <int H>
-__global__ __launch_bounds__(256) void tick_weight_prep_h2_kernel(TickPrep p) {
+__global__ __launch_bounds__(1024) void tick_weight_amax_kernel(TickPrep p, float *__restrict__ wmax) {
+    __shared__ float red[16];
+    const float *w = blockIdx.x == 0 ? p.w[0] : blockIdx.x == 1 ? p.w[1] : p.w[2];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < 3 * H * H / 4; i += 1024) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(w + 4 * i);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int q = 0; q < 16; ++q) t = fmaxf(t, red[q]);
+        wmax[blockIdx.x] = t;
+    }
+}
+// the matrices' scales: W_hh0 its own, W_ih1 and W_hh1 one between them (their products with the layer-1 operands share accumulators)
+__device__ __forceinline__ GruPow2 tick_weight_scale(const float *wmax, int m) {
+    return gru_pow2(m == 0 ? wmax[0] : fmaxf(wmax[1], wmax[2]));
+}
+
+template <int H>
+__global__ __launch_bounds__(256) void tick_weight_prep_h2_kernel(TickPrep p, const float *__restrict__ wmax) {
     constexpr int NW = H / 16, KS = H / 32;
     const int tid = blockIdx.x * 256 + threadIdx.x;
     const int lane = tid & 63;
@@ -1646,7 +1672,7 @@ __global__ __launch_bounds__(256) void tick_weight_prep_h2_kernel(TickPrep p) {
     const f32x4 v0 = *reinterpret_cast<const f32x4 *>(src), v1 = *reinterpret_cast<const f32x4 *>(src + 4);
     const float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
     f16x8g hi, lo;
-    split2_x8(x, GRU_SW, hi, lo);
+    split2_x8(x, tick_weight_scale(wmax, m).s, hi, lo);
     uint4 *dst = p.out + ((int64_t)((m * KS + ks) * NW + w) * 6 + g * 2) * 64 + lane;
     dst[0] = __builtin_bit_cast(uint4, hi);
     dst[64] = __builtin_bit_cast(uint4, lo);
@@ -1681,6 +1707,7 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_h2_kernel(TickFreeRun p, 
     __shared__ __attribute__((aligned(16))) float h1f[16][HS];
     __shared__ __attribute__((aligned(16))) float wout_s[64][HS];
     __shared__ float cand_v[4][16];
+    __shared__ float hmax[H / 16];
     __shared__ int cand_i[4][16];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1729,6 +1756,13 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_h2_kernel(TickFreeRun p, 
 #pragma unroll
     for (int i = 0; i < E; ++i) tok[i] = p.vocab;
     const int ticks = p.beats * p.tpb;
+    // operand scales from the data (round 5): the matrices' from their maxima (tick_weight_amax_kernel, behind the packed weights), the
+    // states' per beat from the workgroup's rows -- every state of a beat is a convex combination of tanh outputs and the beat's
+    // initial state, the layer-1 input is a layer-0 state times a keep byte's 0 or keep_scale
+    const float *wmax = reinterpret_cast<const float *>(packed) + 9 * H * H;
+    const float w0_inv = tick_weight_scale(wmax, 0).inv, w12_inv = tick_weight_scale(wmax, 1).inv;
+    const float keep_bound = MASKED ? fmaxf(p.keep_scale, 1.f) : 1.f;
+    float h_s = GRU_SH, us0 = GRU_UNSCALE, us12 = GRU_UNSCALE;
     const int arow = gru_arow<E>(col);
     const int aoff = arow * HP + 8 * quad;                    // this lane's A-operand offset inside a plane
     auto elems = [&](const f32x4 &acc, float (&out)[E]) __attribute__((always_inline)) { gru_elems<E>(acc, out); };
@@ -1775,10 +1809,29 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_h2_kernel(TickFreeRun p, 
                 const int64_t br = (int64_t)beat * B + rows[i];
                 h0[i] = p.h0_l0[br * p.h0_stride + unit];
                 h1[i] = p.h0_l1[br * p.h0_stride + unit];
-                store_split2(&hA0[cur][lrow(i) * HP + unit], PLANE, h0[i]);
-                store_split2(&hA1[cur][lrow(i) * HP + unit], PLANE, h1[i]);
                 const float *g = p.gib + br * 3 * H + unit;
                 gb[i][0] = g[0]; gb[i][1] = g[H]; gb[i][2] = g[2 * H];
+            }
+            {   // the beat's state scale: max(keep bound, keep bound * |h0|, |h1|) over the workgroup's rows just below 2^15
+                float mx = keep_bound;
+#pragma unroll
+                for (int i = 0; i < E; ++i) mx = fmaxf(mx, fmaxf(keep_bound * fabsf(h0[i]), fabsf(h1[i])));
+                mx = row16_max(mx);
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                if (lane == 0) hmax[w] = mx;
+                lds_barrier();
+#pragma unroll
+                for (int q = 0; q < H / 16; ++q) mx = fmaxf(mx, hmax[q]);
+                const GruPow2 sh = gru_pow2(mx);
+                h_s = sh.s;
+                us0 = sh.inv * w0_inv;
+                us12 = sh.inv * w12_inv;
+            }
+#pragma unroll
+            for (int i = 0; i < E; ++i) {
+                store_split2_s(&hA0[cur][lrow(i) * HP + unit], PLANE, h0[i], h_s);
+                store_split2_s(&hA1[cur][lrow(i) * HP + unit], PLANE, h1[i], h_s);
             }
             lds_barrier();
         }
@@ -1801,12 +1854,12 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_h2_kernel(TickFreeRun p, 
             elems(acc0[0], ar); elems(acc0[1], az); elems(acc0[2], an);
 #pragma unroll
             for (int i = 0; i < E; ++i) {
-                const float r = fast_sigmoid(gi[i][0] + ar[i] * GRU_UNSCALE + b0r);
-                const float z = fast_sigmoid(gi[i][1] + az[i] * GRU_UNSCALE + b0z);
-                const float n = fast_tanh(gi[i][2] + r * (an[i] * GRU_UNSCALE + b0n));
+                const float r = fast_sigmoid(gi[i][0] + ar[i] * us0 + b0r);
+                const float z = fast_sigmoid(gi[i][1] + az[i] * us0 + b0z);
+                const float n = fast_tanh(gi[i][2] + r * (an[i] * us0 + b0n));
                 h0[i] = (1.f - z) * n + z * h0[i];
-                store_split2(&hA0[cur ^ 1][lrow(i) * HP + unit], PLANE, h0[i]);
-                store_split2(&midp[lrow(i) * HP + unit], PLANE, h0[i] * keep[i]);
+                store_split2_s(&hA0[cur ^ 1][lrow(i) * HP + unit], PLANE, h0[i], h_s);
+                store_split2_s(&midp[lrow(i) * HP + unit], PLANE, h0[i] * keep[i], h_s);
             }
         }
         TSTAMP(2);                                             // layer 0 gates (wait for the projections) + LDS writes
@@ -1839,11 +1892,11 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_h2_kernel(TickFreeRun p, 
             elems(a1[0], ar); elems(a1[1], az); elems(a1[2], ai); elems(a1[3], ah);
 #pragma unroll
             for (int i = 0; i < E; ++i) {
-                const float r = fast_sigmoid(ar[i] * GRU_UNSCALE + b1r);
-                const float z = fast_sigmoid(az[i] * GRU_UNSCALE + b1z);
-                const float n = fast_tanh(ai[i] * GRU_UNSCALE + b1in + r * (ah[i] * GRU_UNSCALE + b1hn));
+                const float r = fast_sigmoid(ar[i] * us12 + b1r);
+                const float z = fast_sigmoid(az[i] * us12 + b1z);
+                const float n = fast_tanh(ai[i] * us12 + b1in + r * (ah[i] * us12 + b1hn));
                 h1[i] = (1.f - z) * n + z * h1[i];
-                store_split2(&hA1[cur ^ 1][lrow(i) * HP + unit], PLANE, h1[i]);
+                store_split2_s(&hA1[cur ^ 1][lrow(i) * HP + unit], PLANE, h1[i], h_s);
                 h1f[lrow(i)][unit] = h1[i];
             }
         }
@@ -2127,7 +2180,9 @@ extern "C" int arvae_tick_free_run(const arvae_tick_weights_t *wts, const float 
         }
 #define TICK_H2(HH)                                                                                                              \
         {                                                                                                                        \
-            ARVAE_LAUNCH(tick_weight_prep_h2_kernel<HH>, dim3((items + 255) / 256), dim3(256), 0, st, tp);                       \
+            float *wmax_ = ws + 9 * HH * HH;      /* (behind the two-term layout: the workspace is sized for three terms) */ \
+            ARVAE_LAUNCH(tick_weight_amax_kernel<HH>, dim3(3), dim3(1024), 0, st, tp, wmax_);                                     \
+            ARVAE_LAUNCH(tick_weight_prep_h2_kernel<HH>, dim3((items + 255) / 256), dim3(256), 0, st, tp, wmax_);                 \
             if (m) TICK_H2_RW(HH, true, rw)                                                                                      \
             else TICK_H2_RW(HH, false, rw)                                                                                       \
         }

@@ -904,9 +904,12 @@ def test_measure_sequence_path_matches_stepwise(dev, monkeypatch):
             assert float((gseq - gstep).norm()) <= 2e-4 * float(gstep.norm()) + 1e-9, (teacher, k)
 
 
-@pytest.mark.parametrize('b,dropout,hid', [(256, 0.5, 128), (21, 0.0, 128), (37, 0.5, 64), (1501, 0.5, 128), (2101, 0.0, 64)])
-def test_tick_free_run_tokens_match_stepwise(dev, monkeypatch, b, dropout, hid):
-    """the one-launch free-running tick decoder feeds itself the same notes as the launch-per-tick pass."""
+@pytest.mark.parametrize('b,dropout,hid,big', [(256, 0.5, 128, False), (21, 0.0, 128, False), (37, 0.5, 64, False), (1501, 0.5, 128, False),
+                                               (2101, 0.0, 64, False), (64, 0.5, 128, True), (45, 0.0, 64, True)])
+def test_tick_free_run_tokens_match_stepwise(dev, monkeypatch, b, dropout, hid, big):
+    """the one-launch free-running tick decoder feeds itself the same notes as the launch-per-tick pass.
+    big: initial tick states of ~1e4 and recurrent tick weights of ~350 -- beyond what the FIXED fp16 operand scales of round 4 could
+    hold (4094 / 255: inf, then nan); the kernel takes its scales from the data since round 5."""
     from arvae_amd.measure_vae import MeasureVAE
     torch.manual_seed(23)
     ds = _FolkDataset()
@@ -914,6 +917,11 @@ def test_tick_free_run_tokens_match_stepwise(dev, monkeypatch, b, dropout, hid):
     with torch.no_grad():                                     # spread the logits so that the argmax varies
         model.decoder.tick_emb_to_note_emb[0].weight.mul_(4.0)
         model.decoder.tick_emb_to_note_emb[0].bias.add_(0.3)
+        if big:
+            model.decoder.beat_emb_to_tick_rnn_hidden[0].weight.mul_(20000.0)
+            for name in ('weight_hh_l0', 'weight_ih_l1', 'weight_hh_l1'):
+                getattr(model.decoder.rnn_tick, name).mul_(4000.0)
+            assert float(model.decoder.rnn_tick.weight_hh_l0.abs().max()) > 255.0
     model.decoder.teacher_forcing_prob = 0.0
     score = torch.from_numpy(syn.measure_batch(b, seed=28)).to(dev)
     eps = torch.from_numpy(syn.normal_noise((b, 32), seed=29))
