@@ -508,7 +508,6 @@ __global__ __launch_bounds__(H * 4) void gru_seq_fwd_x3_kernel(GruSeqBatch batch
 // outputs and the beat's initial state; the layer-1 input is a layer-0 state times 0 or the keep scale).
 typedef _Float16 f16x8g __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2g __attribute__((ext_vector_type(2)));
-constexpr float GRU_SH = 16.f, GRU_UNSCALE = 1.f / (16.f * 256.f);     // (placeholders until a beat's first scale: never multiplied with)
 __device__ __forceinline__ void split2_pair(float x0, float x1, float s, unsigned &hi, unsigned &lo) {
     const float y0 = x0 * s, y1 = x1 * s;
     const f32x2g y = {y0, y1};
@@ -526,17 +525,6 @@ __device__ __forceinline__ void split2_x8(const float (&x)[8], float s, f16x8g &
         h[j] = (int)a; l[j] = (int)b;
     }
     hi = __builtin_bit_cast(f16x8g, h); lo = __builtin_bit_cast(f16x8g, l);
-}
-__device__ __forceinline__ void store_split2(unsigned short *p, int plane, float x) {
-    unsigned a, b;
-    split2_pair(x, 0.f, GRU_SH, a, b);
-    p[0] = (unsigned short)a; p[plane] = (unsigned short)b;
-}
-__device__ __forceinline__ void store_split2_pair(unsigned short *p, int rowpitch, int plane, float x0, float x1) {
-    unsigned a, b;
-    split2_pair(x0, x1, GRU_SH, a, b);
-    p[0] = (unsigned short)a; p[rowpitch] = (unsigned short)(a >> 16);
-    p[plane] = (unsigned short)b; p[plane + rowpitch] = (unsigned short)(b >> 16);
 }
 __device__ __forceinline__ f16x8g lds_h8(const unsigned short *p) {
     return __builtin_bit_cast(f16x8g, *reinterpret_cast<const i32x4g *>(p));
@@ -1762,7 +1750,7 @@ __global__ __launch_bounds__(H * 4) void tick_free_run_h2_kernel(TickFreeRun p, 
     const float *wmax = reinterpret_cast<const float *>(packed) + 9 * H * H;
     const float w0_inv = tick_weight_scale(wmax, 0).inv, w12_inv = tick_weight_scale(wmax, 1).inv;
     const float keep_bound = MASKED ? fmaxf(p.keep_scale, 1.f) : 1.f;
-    float h_s = GRU_SH, us0 = GRU_UNSCALE, us12 = GRU_UNSCALE;
+    float h_s = 1.f, us0 = 1.f, us12 = 1.f;                   // (set at every beat's start: tick 0 starts one)
     const int arow = gru_arow<E>(col);
     const int aoff = arow * HP + 8 * quad;                    // this lane's A-operand offset inside a plane
     auto elems = [&](const f32x4 &acc, float (&out)[E]) __attribute__((always_inline)) { gru_elems<E>(acc, out); };
