@@ -10,7 +10,7 @@ import threading
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, 'libarvae_hip.so')
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 c_i32, c_i64, c_f32, c_f64, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_double, ctypes.c_void_p
 
@@ -158,7 +158,7 @@ SIGNATURES = {
     'arvae_philox_keep_mask': (c_i32, [c_vp, c_i64, c_f32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp]),
     'arvae_count_nonfinite': (c_i32, [c_vp, c_i64, c_vp, c_vp]),
     'arvae_count_out_of_range': (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
-    'arvae_adam_step': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_f64, c_f64, c_f64, c_f64, c_f32, c_i32, c_vp]),
+    'arvae_adam_step': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_f64, c_f64, c_f64, c_f64, c_f32, c_i32, c_vp, c_vp]),
     'arvae_comm_available': (c_i32, []),
     'arvae_comm_unique_id': (c_i32, [c_vp]),
     'arvae_comm_init': (c_i32, [c_vp, c_i32, c_i32, c_i32, _P(c_vp)]),

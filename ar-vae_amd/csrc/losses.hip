@@ -320,8 +320,21 @@ template <bool ZERO_G>
 __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ p, float *__restrict__ g,
                                                     float *__restrict__ m, float *__restrict__ v, int64_t count,
                                                     float step_size, float inv_bc2_sqrt, float beta1, float beta2,
-                                                    float omb1, float omb2, float eps, float gscale) {
+                                                    float omb1, float omb2, float eps, float gscale,
+                                                    unsigned *__restrict__ status) {
     const int64_t n4 = count >> 2;
+    // a pass that reported a failed hand-off (arvae_image_vae_t.status) left undefined gradients: nothing reaches p, m, v;
+    // the arena is still cleared for the next pass and the skipped update is counted (status[4]) for the host's step counter
+    if (status != nullptr && __builtin_amdgcn_readfirstlane((int)status[0]) != 0) {
+        if (ZERO_G) {
+            float4 *z4 = reinterpret_cast<float4 *>(g);
+            for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
+                z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (blockIdx.x == 0 && threadIdx.x < (count & 3)) g[(n4 << 2) + threadIdx.x] = 0.f;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) status[4] += 1u;
+        return;
+    }
     float4 *p4 = reinterpret_cast<float4 *>(p);
     float4 *g4 = reinterpret_cast<float4 *>(g);
     float4 *m4 = reinterpret_cast<float4 *>(m);
@@ -605,7 +618,7 @@ extern "C" int arvae_scale_by_scalar(const float *g, const float *x, int64_t cou
 
 extern "C" int arvae_adam_step(float *p, float *g, float *m, float *v, int64_t count, int64_t step, double lr,
                                double beta1, double beta2, double eps, float grad_scale, int32_t zero_grad,
-                               arvae_stream_t stream) {
+                               uint32_t *status, arvae_stream_t stream) {
     ARVAE_REQUIRE(p && g && m && v && count > 0 && step >= 1, "adam_step: bad argument");
     ARVAE_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
                   "adam_step: arenas must be 16-byte aligned");
@@ -614,10 +627,10 @@ extern "C" int arvae_adam_step(float *p, float *g, float *m, float *v, int64_t c
     if (zero_grad)
         ARVAE_LAUNCH(adam_kernel<true>, dim3(grid_for(count, 4)), dim3(256), 0, as_stream(stream), p, g, m, v, count,
                            (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), (float)beta1, (float)beta2, (float)(1.0 - beta1),
-                           (float)(1.0 - beta2), (float)eps, grad_scale);
+                           (float)(1.0 - beta2), (float)eps, grad_scale, status);
     else
         ARVAE_LAUNCH(adam_kernel<false>, dim3(grid_for(count, 4)), dim3(256), 0, as_stream(stream), p, g, m, v, count,
                            (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), (float)beta1, (float)beta2, (float)(1.0 - beta1),
-                           (float)(1.0 - beta2), (float)eps, grad_scale);
+                           (float)(1.0 - beta2), (float)eps, grad_scale, status);
     return check_launch("adam_step");
 }

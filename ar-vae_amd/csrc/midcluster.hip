@@ -184,7 +184,7 @@ __device__ __forceinline__ void mc_place(const McArgs &p, int b, int &cl, int &m
 // workgroups per XCD for > 300 ms (the 16th member of every cluster not dispatched) in 1 of ~8 runs; with four heads a cluster
 // draws on two XCDs.  The heads are zero at the start of a pass: the pass clears them itself once every cluster is placed
 // (mc_placed / mc_clear_heads), the step's prep launch clears everything.
-constexpr unsigned MC_E_FWD = 1u, MC_E_BWD = 2u, MC_E_TICKET = 4u;     // = ARVAE_STATUS_HANDOFF_FWD / _BWD / _TICKET (arvae_hip.h)
+constexpr unsigned MC_E_FWD = ARVAE_STATUS_HANDOFF_FWD, MC_E_BWD = ARVAE_STATUS_HANDOFF_BWD, MC_E_TICKET = ARVAE_STATUS_HANDOFF_TICKET;     // arvae_hip.h: float-safe bit patterns
 __device__ __forceinline__ int mc_ticket(const McArgs &p) {
     if (p.debug_static) return (int)blockIdx.x;          // diagnostic build, ARVAE_MIDC_STATIC: places by blockIdx (what tickets cost)
     __shared__ int place;

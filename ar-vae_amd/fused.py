@@ -51,6 +51,14 @@ def _layer_desc(link, is_up, act, dropout, w_off, b_off):
     return LayerDesc(link.desc(0), int(is_up), int(act), int(dropout), 0, int(w_off), int(b_off))
 
 
+class DeviceStatusError(RuntimeError):
+    """a pass reported a device-side failure in its status word; `.skipped` = optimizer updates the device withheld"""
+
+    def __init__(self, message, skipped=0):
+        super().__init__(message)
+        self.skipped = int(skipped)
+
+
 class FusedImageVAE:
     """Descriptor + workspace cache binding a MnistVAE/DspritesVAE to a FlatAdam arena."""
 
@@ -65,30 +73,30 @@ class FusedImageVAE:
         self._ws_owner = None
         self._overlap = None
         self._buckets = None
-        self._status = None              # the sticky device status word of this model's passes (arvae_image_vae_t.status)
         self.no_cluster = False          # set once a hand-off has given up: the latent block stays on the row kernels
 
     def status_word(self, device):
-        if self._status is None or self._status.device != device:
-            self._status = torch.zeros(1, dtype=torch.int32, device=device)
-        return self._status
+        """the sticky device status word of this model's passes (arvae_image_vae_t.status): it lives in the guard slot behind
+        the optimizer's gradient arena, where arvae_adam_step reads it before it touches the weights (optim.py)"""
+        return self.optimizer.status_words()
 
     def check_status(self):
         """Reads the status word (ONE device sync: call it where the host synchronises anyway -- Trainer.loss_and_acc_on_epoch
         does, next to the epoch means).  A hand-off between the workgroups of the clustered latent block that gave up (its
-        partners could not all become resident: csrc/midcluster.hip) left the results of that pass undefined: raise, and keep
-        every later pass on the kernels without in-launch hand-offs."""
-        if self._status is None:
-            return
-        bits = int(self._status.item())
+        partners could not all become resident: csrc/midcluster.hip) left the results of that pass undefined.  The update
+        kernel saw the same word and skipped that step and every step since (weights, moments and step count are those of
+        the last good step): raise DeviceStatusError, and keep every later pass on the kernels without in-launch hand-offs."""
+        bits, skipped = self.optimizer.take_status()
         if bits:
             self.no_cluster = True
-            self._status.zero_()
-            raise RuntimeError(
+            code = (bits >> 20) & 7 if (bits & 0xff800000) == 0x40000000 else 0     # exact on the rank that failed
+            raise DeviceStatusError(
                 f'libarvae_hip: an in-launch hand-off of the clustered latent block gave up (status {bits:#x}: '
-                f'{"forward " if bits & 1 else ""}{"backward " if bits & 2 else ""}{"tickets " if bits & 4 else ""}pass); the results of '
-                f'that training step are undefined.  The device is probably shared with other processes; later passes of this '
-                f'trainer use the row kernels (no hand-offs).')
+                f'{"forward " if code & 1 else ""}{"backward " if code & 2 else ""}{"tickets " if code & 4 else ""}'
+                f'{"reported by another rank, " if not code else ""}pass); the results of that training step were undefined and '
+                f'{skipped} optimizer update(s) were skipped on the device -- the weights are those of the last good step.  The '
+                f'device is probably shared with other processes; later passes of this trainer use the row kernels (no '
+                f'hand-offs).', skipped)
 
     def overlap(self, device):
         if self._overlap is None:

@@ -542,13 +542,15 @@ def token_recon(weights, targets):
 # ------------------------------------------------------------------------------------------------
 # Adam
 # ------------------------------------------------------------------------------------------------
-def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, zero_grad=False):
-    """one Adam update of the flat arenas; zero_grad: g is cleared by the same kernel once it has been consumed"""
+def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, zero_grad=False, status=None):
+    """one Adam update of the flat arenas; zero_grad: g is cleared by the same kernel once it has been consumed;
+    status (int32 device tensor of >= 5 words, optional): while status[0] != 0 the launch leaves p, m, v alone and counts
+    the skipped update in status[4] (include/arvae_hip.h, arvae_adam_step)"""
     _dev(p, g, m, v)
     lib = _lib.load()
     with _timed('adam', 0.0, 28.0 * p.numel()):
         _lib.check(lib.arvae_adam_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), int(step), lr, beta1, beta2,
-                                       eps, grad_scale, int(bool(zero_grad)), _stream()), 'adam_step')
+                                       eps, grad_scale, int(bool(zero_grad)), _ptr(status), _stream()), 'adam_step')
 
 
 # ------------------------------------------------------------------------------------------------

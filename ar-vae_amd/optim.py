@@ -15,10 +15,20 @@ view into a matching gradient arena, so
                  step()); FlatAdam(..., zero_grads_in_step=False) keeps torch's behaviour.
   all-reduce   = one collective on `grad_arena`,
   step()       = one multi-tensor kernel (arvae_adam_step).
+
+Guard slot.  Eight more floats sit behind the gradient arena in the same allocation.  Word 0 is the sticky device STATUS
+word of the passes that write this arena (arvae_image_vae_t.status: an in-launch hand-off that gave up ORs a float-safe
+code into it, include/arvae_hip.h ARVAE_STATUS_*); word 4 counts the updates arvae_adam_step skipped because of it.  The
+update kernel reads the word itself: a step whose gradients are undefined never reaches the weights, the moments or the
+step count, however late the host looks (`take_status`, once per epoch).  Under data parallelism the word travels with
+the gradients (`reduce_view`: arena + the first four guard words, ONE SUM all-reduce), so every rank skips the same updates.
 """
 import torch
 
 from . import ops
+
+
+GUARD_FLOATS = 8
 
 
 class FlatAdam:
@@ -34,6 +44,7 @@ class FlatAdam:
         self._write_epoch = -1         # ops.GRAD_WRITE_EPOCH at the last step(): direct writes since then dirty the arena
         self._hooked = False
         self.param_arena = self.grad_arena = self.exp_avg = self.exp_avg_sq = None
+        self._grad_store = self.guard = None
         self._offsets = []
 
     # -- arena management -----------------------------------------------------------------------
@@ -53,7 +64,13 @@ class FlatAdam:
             offsets.append(total)
             total += (p.numel() + 3) // 4 * 4                 # keep every tensor 16-byte aligned
         arena = torch.zeros(total, device=dev, dtype=torch.float32)
-        grads = torch.zeros(total, device=dev, dtype=torch.float32)
+        old_guard = self.guard
+        store = torch.zeros(total + GUARD_FLOATS, device=dev, dtype=torch.float32)
+        grads = store[:total]                                 # what zero_grad() clears and the passes write
+        self._grad_store = store
+        self.guard = store[total:].view(torch.int32)          # [0] status (reduced with the gradients), [4] skipped updates
+        if old_guard is not None:
+            self.guard.copy_(old_guard)
         old_m, old_v, old_off = self.exp_avg, self.exp_avg_sq, self._offsets
         self.exp_avg = torch.zeros(total, device=dev, dtype=torch.float32)
         self.exp_avg_sq = torch.zeros(total, device=dev, dtype=torch.float32)
@@ -85,6 +102,30 @@ class FlatAdam:
             self._build_arena()
         return self.param_arena
 
+    # -- the device status word (module docstring: "Guard slot") ---------------------------------
+    def status_words(self):
+        """int32 view of the guard slot on the arena's device: [0] = sticky status of the passes, [4] = skipped updates"""
+        self.ensure_arena()
+        return self.guard
+
+    def reduce_view(self):
+        """what a data-parallel step SUM all-reduces: the gradient arena and, behind it, the status word"""
+        self.ensure_arena()
+        return self._grad_store[:self.grad_arena.numel() + 4]
+
+    def take_status(self):
+        """-> (status bits, skipped updates) read from the device (ONE sync) and, when set, cleared: the step counter goes
+        back by the updates the kernel skipped, so the next applied update continues the bias corrections where the last
+        applied one left them."""
+        if self.guard is None:
+            return 0, 0
+        words = self.guard.tolist()
+        bits, skipped = words[0] & 0xffffffff, words[4]
+        if bits or skipped:
+            self.guard.zero_()
+            self.step_count -= skipped
+        return bits, skipped
+
     # -- torch.optim.Optimizer surface used by the trainer --------------------------------------
     def zero_grad(self, set_to_none=False):
         self.ensure_arena()
@@ -105,7 +146,8 @@ class FlatAdam:
                 p.grad = self.grad_arena[off:off + p.numel()].view(p.shape)
         self.step_count += 1
         ops.adam_step(self.param_arena, self.grad_arena, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
-                      self.betas[0], self.betas[1], self.eps, self.grad_scale, zero_grad=self.zero_grads_in_step)
+                      self.betas[0], self.betas[1], self.eps, self.grad_scale, zero_grad=self.zero_grads_in_step,
+                      status=self.guard)
         self._arena_clean = self.zero_grads_in_step
         self._write_epoch = ops.GRAD_WRITE_EPOCH[0]
 

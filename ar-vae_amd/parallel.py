@@ -470,6 +470,7 @@ class DataParallel:
         """True iff `ok` holds on EVERY rank (one MIN all-reduce of a flag): how ranks take a decision together"""
         flag = torch.full((1,), 1.0 if ok else 0.0, dtype=torch.float32, device=self.comm.device)
         self.comm.all_reduce(flag, 'min')
+        self.comm.wait_idle()                                    # bounded: a dead peer raises here instead of hanging .item()
         return bool(flag.item() > 0.5)
 
     def gather_columns(self, local, async_op=None, out=None):
@@ -525,11 +526,14 @@ class DataParallel:
         if self._pending:
             for lo, hi in self.remaining_buckets or ():
                 self.comm.all_reduce(optimizer.grad_arena[lo:hi])
+            self.comm.all_reduce(optimizer.reduce_view()[optimizer.grad_arena.numel():])    # the status word (optim.py)
             for work in self._pending:
                 work.wait()                                      # the launch stream waits for the side stream's collectives
             self._pending, self.remaining_buckets = [], None
         else:
-            self.comm.all_reduce(optimizer.grad_arena)
+            # gradients + the sticky device status word behind them (optim.py "Guard slot"): a pass that failed on ONE rank
+            # makes EVERY rank's update kernel skip this step, so the replicas stay identical
+            self.comm.all_reduce(optimizer.reduce_view())
         optimizer.grad_scale = 1.0 / self.world_size
 
     def mean_scalar(self, value):

@@ -109,6 +109,20 @@ class Trainer(ABC):
         return graphed(data=data)                              # errors of the step itself propagate
 
     def loss_and_acc_on_epoch(self, data_loader, epoch_num=None, train=True):
+        """-> (mean loss, mean accuracy) of one pass over `data_loader` (utils/trainer.py:114-154).  A pass that reported a
+        device-side failure (DeviceStatusError: an in-launch hand-off gave up, csrc/midcluster.hip) is run AGAIN, once: the
+        update kernel withheld every step from the failing one on (optim.py "Guard slot"), so the weights, the moments and
+        the step count are those of the last good step, and the trainer has left the kernels that can fail.  What the
+        repeated epoch costs is the good steps of the first attempt applied once more."""
+        from .fused import DeviceStatusError
+        try:
+            return self._epoch(data_loader, epoch_num, train)
+        except DeviceStatusError as e:
+            print(f'epoch {epoch_num}: {e}\n  -> repeating the epoch on the row kernels', flush=True)
+            self._graphed = None                                 # a captured step has the failed kernels baked in
+        return self._epoch(data_loader, epoch_num, train)
+
+    def _epoch(self, data_loader, epoch_num, train):
         loss_sum = acc_sum = None
         count = 0
         for batch_num, batch in enumerate(data_loader):
@@ -134,14 +148,19 @@ class Trainer(ABC):
                 acc_sum = a.clone() if acc_sum is None else acc_sum + a
             count += 1
         n = max(count, 1)
+        if self.data_parallel is not None:
+            # the first host wait of an epoch sits behind that epoch's collectives: bounded, with the communicator's
+            # asynchronous error polled (a peer that died shows as RuntimeError here, not as a hang in float() below)
+            self.data_parallel.comm.wait_idle()
         mean_loss = float(loss_sum) / n if loss_sum is not None else 0.0       # single sync per epoch
         mean_acc = float(acc_sum) / n if acc_sum is not None else 0.0
         self.check_device_status()                                             # (the stream is idle here: no extra wait)
         return mean_loss, mean_acc
 
     def check_device_status(self):
-        """Raises RuntimeError when a pass of this trainer reported a device-side failure in its status word (the reference
-        reads its loss on the host every step, utils/trainer.py:145-147; this build once per epoch, here)."""
+        """Raises DeviceStatusError (a RuntimeError) when a pass of this trainer reported a device-side failure in its status
+        word (the reference reads its loss on the host every step, utils/trainer.py:145-147; this build once per epoch, here;
+        the update kernel reads the same word every step and withholds the update, include/arvae_hip.h arvae_adam_step)."""
         fused = getattr(self, '_fused', None)
         if fused is not None and hasattr(fused, 'check_status'):
             fused.check_status()

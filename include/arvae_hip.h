@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ARVAE_ABI_VERSION 10  /* 10: arvae_comm_init(timeout_ms); arvae_image_vae_t.status / .flags (a sticky device status word: an in-launch hand-off between workgroups that gives up says so there instead of hanging; ARVAE_VAE_NO_CLUSTER keeps the pass on kernels without such hand-offs); 9: arvae_measure_vae_* (whole-model MeasureVAE step), row strides for h0 / dh0 / the beat embeddings (arvae_gru_seq_t, arvae_tick_*); 8: arvae_gru_seq_t.gi_rstride / dgi_rstride / h_fin (merged input projections of a bidirectional layer, final states written by the sequence launch); 7: arvae_comm_* (the data-parallel step's collectives: RCCL on the launch stream, owned by the library); 6: the 32-channel k4 s2 p1 links need caller workspace too (arvae_link_ws_floats / arvae_link_wgrad_ws_floats: the layer's weights as scaled fp16 terms and the operands' maxima); 5: arvae_adam_step(zero_grad), arvae_image_vae_finish, arvae_image_vae_t.milestones (events the executors record for the data-parallel caller's collectives); 4: arvae_philox_* and in-kernel eps (arvae_image_vae_t.rng_*), arvae_tick_free_run_supported, caller workspace for arvae_link_down/up (arvae_link_ws_floats); 3: arvae_gru_seq_*, embed_bwd workspace; 2: arvae_image_vae_backward reg_fused == 2 (unit regulariser gradient in dz_extra) */
+#define ARVAE_ABI_VERSION 11  /* 11: arvae_adam_step(status): the update is skipped while the sticky status word is set (a pass that reported a failed hand-off never reaches the weights), ARVAE_STATUS_* re-coded so that the word survives a float SUM all-reduce beside the gradients; 10: arvae_comm_init(timeout_ms); arvae_image_vae_t.status / .flags (a sticky device status word: an in-launch hand-off between workgroups that gives up says so there instead of hanging; ARVAE_VAE_NO_CLUSTER keeps the pass on kernels without such hand-offs); 9: arvae_measure_vae_* (whole-model MeasureVAE step), row strides for h0 / dh0 / the beat embeddings (arvae_gru_seq_t, arvae_tick_*); 8: arvae_gru_seq_t.gi_rstride / dgi_rstride / h_fin (merged input projections of a bidirectional layer, final states written by the sequence launch); 7: arvae_comm_* (the data-parallel step's collectives: RCCL on the launch stream, owned by the library); 6: the 32-channel k4 s2 p1 links need caller workspace too (arvae_link_ws_floats / arvae_link_wgrad_ws_floats: the layer's weights as scaled fp16 terms and the operands' maxima); 5: arvae_adam_step(zero_grad), arvae_image_vae_finish, arvae_image_vae_t.milestones (events the executors record for the data-parallel caller's collectives); 4: arvae_philox_* and in-kernel eps (arvae_image_vae_t.rng_*), arvae_tick_free_run_supported, caller workspace for arvae_link_down/up (arvae_link_ws_floats); 3: arvae_gru_seq_*, embed_bwd workspace; 2: arvae_image_vae_backward reg_fused == 2 (unit regulariser gradient in dz_extra) */
 
 #define ARVAE_OK 0
 #define ARVAE_E_INVALID (-1)  /* bad argument (null pointer, size out of range, unsupported shape) */
@@ -211,9 +211,17 @@ int arvae_scale_by_scalar(const float *g, const float *x, int64_t count, float *
  * `step` is the 1-based step number t.  grad_scale multiplies g first (1/world_size after a SUM
  * all-reduce; 1 otherwise).  zero_grad != 0: g is cleared once it has been consumed, i.e. the update and the NEXT
  * step's Trainer.zero_grad() (utils/trainer.py:136) are one kernel.
+ * status (optional, NULL: none): device words the caller owns.  status[0] is the sticky status word of the passes that
+ * produced g (arvae_image_vae_t.status, ARVAE_STATUS_*); while it is non-zero the launch changes NOTHING in p, m, v -- the
+ * gradient of a pass whose in-launch hand-off gave up is undefined and must not reach the weights (the reference would have
+ * raised at its per-step host read of the loss, utils/trainer.py:145-147; this build reads the word once per epoch) -- it
+ * still clears g when zero_grad is set, and adds one to status[4], the count of skipped updates: the caller that finally
+ * reads the word takes that many steps back off its step counter, so the bias corrections continue where the last
+ * APPLIED update left them.
  * ------------------------------------------------------------------------------------------------ */
 int arvae_adam_step(float *p, float *g, float *m, float *v, int64_t count, int64_t step, double lr, double beta1,
-                    double beta2, double eps, float grad_scale, int32_t zero_grad, arvae_stream_t stream);
+                    double beta2, double eps, float grad_scale, int32_t zero_grad, uint32_t *status,
+                    arvae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * MeasureVAE building blocks (GRU encoder / hierarchical GRU decoder over 24-tick measures).
@@ -423,9 +431,15 @@ typedef struct {
     int32_t reserved;
 } arvae_image_vae_t;
 
-#define ARVAE_STATUS_HANDOFF_FWD 1u    /* a hand-off of the clustered latent block's forward launch gave up  */
-#define ARVAE_STATUS_HANDOFF_BWD 2u    /* ... of its backward launch                                          */
-#define ARVAE_STATUS_HANDOFF_TICKET 4u /* a workgroup found no place in any cluster (corrupt ticket heads)    */
+/* The word is zero or a NORMAL POSITIVE fp32 bit pattern (2.0 .. 3.75: ARVAE_STATUS_SET + code bits in the top of the
+ * mantissa), so that a data-parallel caller can keep it in the tail of the buffer it SUM all-reduces as floats
+ * (ar-vae_amd/optim.py: the guard slot behind the gradient arena): a failure on one rank then reaches every rank's word
+ * with the gradients it polluted, and every rank's arvae_adam_step skips the same update.  After such a sum only
+ * "non-zero" is meaningful; on the rank that failed (and on a single rank) the code bits read back exactly. */
+#define ARVAE_STATUS_SET 0x40000000u
+#define ARVAE_STATUS_HANDOFF_FWD (ARVAE_STATUS_SET | (1u << 20))    /* a hand-off of the clustered latent block's forward launch gave up */
+#define ARVAE_STATUS_HANDOFF_BWD (ARVAE_STATUS_SET | (2u << 20))    /* ... of its backward launch                                         */
+#define ARVAE_STATUS_HANDOFF_TICKET (ARVAE_STATUS_SET | (4u << 20)) /* a workgroup found no place in any cluster (corrupt ticket heads)   */
 #define ARVAE_VAE_NO_CLUSTER 1         /* flags: the latent block on the row kernels (no in-launch hand-offs)  */
 
 typedef struct arvae_milestones {

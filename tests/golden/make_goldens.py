@@ -27,6 +27,9 @@ What is written:
   G4 dsprites_step_b{8,64}.npz   full ImageVAETrainer step + Adam
   G5 mnist_step_{eval,train}.npz full step, dropout off / explicit masks
   G6 measure_step_{tf,free,eval}.npz  MeasureVAETrainer step (V=35)
+  G8 dsprites_step_b512.npz, mnist_step_train_b1024.npz, measure_step_{tf,free}_b256.npz
+                       the same steps at BASELINE.json's batch sizes (configs[1], [2], [4]); z / mu / sigma keep their first
+                       HEAD_ROWS rows (+ whole-tensor sums), everything else as in G4-G6
   G7 attributes.npz    compute_attribute_labels                   (measure_vae_trainer.py:167-186)
   G9 inference_{dsprites,mnist,measure}.npz   the evaluation-only entry points:
                        compute_representations, loss_and_acc_test, compute_latent_interpolations{,2d}
@@ -140,6 +143,19 @@ def load_synth_weights(model, seed, gain=1.6):
     state = {k: t(v) for k, v in syn.synth_state(shapes, seed, gain).items()}
     model.load_state_dict(state)
     return shapes
+
+
+HEAD_ROWS = 64          # rows of z / mu / sigma the headline-size fixtures keep
+
+
+def head_rows(out, keys=('z', 'mu', 'sigma')):
+    """a headline-size fixture keeps the first HEAD_ROWS rows of the per-row outputs and their float64 sums"""
+    for k in keys:
+        full = np.asarray(out[k])
+        out[f'{k}_sum'] = full.astype(np.float64).sum()
+        out[f'{k}_abs_sum'] = np.abs(full.astype(np.float64)).sum()
+        out[k] = full[:HEAD_ROWS]
+    return out
 
 
 def grad_and_update_summaries(model, before):
@@ -339,6 +355,16 @@ def gen_image_steps():
                                               beta=1.0, gamma=10.0, delta=1.0, mask_seed=21))
 
 
+def gen_headline_steps():
+    """BASELINE.json configs[1] / [2] / [4] at their own batch sizes; seeds = the `..._at_baseline_batch_*` GPU tests"""
+    save('dsprites_step_b512.npz', **head_rows(image_step('dsprites', 512, 'train', wseed=1, xseed=1234, eseed=1,
+                                                          beta=4.0, gamma=10.0, delta=1.0)))
+    save('mnist_step_train_b1024.npz', **head_rows(image_step('mnist', 1024, 'train', wseed=3, xseed=4321, eseed=15,
+                                                              beta=1.0, gamma=10.0, delta=1.0, mask_seed=21)))
+    save('measure_step_tf_b256.npz', **head_rows(measure_step(256, 'train', wseed=4, sseed=5, eseed=1, teacher=True)))
+    save('measure_step_free_b256.npz', **head_rows(measure_step(256, 'train', wseed=4, sseed=5, eseed=2, teacher=False)))   # eseed 1: a 3e-5 top-1 margin
+
+
 # ----------------------------------------------------------------------------
 # G6 / G7: MeasureVAE
 # ----------------------------------------------------------------------------
@@ -517,5 +543,6 @@ if __name__ == '__main__':
     gen_recon()
     gen_image_steps()
     gen_measure_steps()
+    gen_headline_steps()
     gen_attributes()
     gen_inference()

@@ -93,7 +93,7 @@ def test_argument_validation_without_gpu(lib):
     # Up parts, + the inverse scale), and the input's 1024 partial maxima
     assert lib.arvae_link_ws_floats(ctypes.byref(LinkDesc(4, 32, 32, 32, 16, 16, 32, 4, 4, 2, 1, 0, 0, 0, 0))) == (2 * 32 * 64 + 4 * 16 * 64 + 1) * 4 + 2 * 1024
     assert lib.arvae_reg_loss_ws_floats(512, 5) == 2 * 512 * 5
-    assert lib.arvae_adam_step(None, None, None, None, 0, 0, 1e-4, 0.9, 0.999, 1e-8, 1.0, 0, None) == -1
+    assert lib.arvae_adam_step(None, None, None, None, 0, 0, 1e-4, 0.9, 0.999, 1e-8, 1.0, 0, None, None) == -1
     # the MeasureVAE sequence entry points
     from arvae_amd._lib import GruSeqDesc, TickWeights, DenseWgradJob
     assert lib.arvae_gru_seq_supported(128) == 1 and lib.arvae_gru_seq_supported(512) == 0

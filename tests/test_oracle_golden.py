@@ -106,19 +106,25 @@ def test_cross_entropy(golden_dir, b):
 
 
 # ---------------------------------------------------------------- G4 / G5
-def check_step(res, g, state_before, names, grad_rtol=1e-3):
+def check_step(res, g, state_before, names, grad_rtol=1e-3, samp_atol=1e-4):
     t = res['terms']
     for k in ('recons', 'dist', 'reg', 'loss', 'acc'):
         close(t[k], g[k], rtol=1e-4)
-    close(t['z'], g['z'], rtol=0, atol=1e-4)
-    close(t['mu'], g['mu'], rtol=0, atol=1e-4)
-    close(t['sigma'], g['sigma'], rtol=1e-4, atol=1e-5)
+    rows = g['z'].shape[0]                                      # headline-size fixtures keep the first rows + sums
+    close(t['z'][:rows], g['z'], rtol=0, atol=1e-4)
+    close(t['mu'][:rows], g['mu'], rtol=0, atol=1e-4)
+    close(t['sigma'][:rows], g['sigma'], rtol=1e-4, atol=1e-5)
+    if 'z_sum' in g:
+        for k in ('z', 'mu', 'sigma'):
+            full = np.asarray(t[k], np.float64)
+            close(full.sum(), g[f'{k}_sum'], rtol=1e-4, atol=1e-4 * full.shape[0])
+            close(np.abs(full).sum(), g[f'{k}_abs_sum'], rtol=1e-4)
     for name in names:
         gr = res['grads'][name].astype(np.float64).ravel()
         gn = float(g[f'gnorm/{name}'])
         close(np.sqrt((gr * gr).sum()), gn, rtol=grad_rtol)
         idx = syn.sample_indices(name, gr.size)
-        close(gr[idx], g[f'gsamp/{name}'], rtol=grad_rtol, atol=1e-4 * gn / np.sqrt(gr.size) + 1e-7)
+        close(gr[idx], g[f'gsamp/{name}'], rtol=grad_rtol, atol=samp_atol * gn / np.sqrt(gr.size) + 1e-7)
         d = (res['params'][name].astype(np.float64) - state_before[name].astype(np.float64)).ravel()
         close(np.sqrt((d * d).sum()), g[f'dnorm/{name}'], rtol=2e-3)
 
@@ -129,6 +135,9 @@ IMAGE_CASES = [
     ('dsprites_step_b8_cap_gauss.npz', 'dsprites', 8, 2, 77, 13, 1.0, 25.0, 'gaussian', None, 1.6),
     ('mnist_step_eval.npz', 'mnist', 8, 3, 4321, 14, 1.0, 0.0, 'bernoulli', None, 0.7),
     ('mnist_step_train.npz', 'mnist', 8, 3, 4321, 15, 1.0, 0.0, 'bernoulli', 21, 0.7),
+    # BASELINE.json configs[1] and [2] at their own batch sizes (tests/golden/make_goldens.py gen_headline_steps)
+    ('dsprites_step_b512.npz', 'dsprites', 512, 1, 1234, 1, 4.0, 0.0, 'bernoulli', None, 1.6),
+    ('mnist_step_train_b1024.npz', 'mnist', 1024, 3, 4321, 15, 1.0, 0.0, 'bernoulli', 21, 0.7),
 ]
 
 
@@ -142,7 +151,9 @@ def test_image_step(golden_dir, case):
     dims = (1, 2, 3, 4, 5) if kind == 'dsprites' else (1, 2, 3, 4, 5, 6)
     masks = None if mseed is None else syn.dropout_masks([(b,) + s for s in image_vae.MNIST_MASK_SHAPES], mseed)
     res = step.image_step(kind, state, x, lab, eps, dims, beta, 10.0, 1.0, capacity=cap, dec_dist=dist, masks=masks)
-    check_step(res, g, state, list(state))
+    # sampled gradient entries: two fp32 CPU runs (the reference with its thread count, the oracle with one thread) sum a
+    # 1024-image batch in different orders; entries near zero move by ~3e-4 of the tensor's RMS
+    check_step(res, g, state, list(state), samp_atol=1e-4 if b <= 64 else 4e-4)
     lg = res['terms']['logits'].ravel()
     close(lg.astype(np.float64).sum(), g['logits_sum'], rtol=1e-4, atol=1e-2)
     close(lg[syn.sample_indices('logits', lg.size, 64)], g['logits_samp'], rtol=1e-4, atol=1e-4)
@@ -156,22 +167,24 @@ def measure_state(wseed):
     return state
 
 
-MEASURE_CASES = [('measure_step_tf.npz', 5, 31, True), ('measure_step_free.npz', 5, 32, False),
-                 ('measure_step_eval.npz', 6, 33, False)]
+MEASURE_CASES = [('measure_step_tf.npz', 5, 31, True, 16), ('measure_step_free.npz', 5, 32, False, 16),
+                 ('measure_step_eval.npz', 6, 33, False, 16),
+                 # BASELINE.json configs[4] at its own batch size
+                 ('measure_step_tf_b256.npz', 5, 1, True, 256), ('measure_step_free_b256.npz', 5, 2, False, 256)]
 
 
 @pytest.mark.parametrize('case', MEASURE_CASES, ids=[c[0][:-4] for c in MEASURE_CASES])
 def test_measure_step(golden_dir, case):
-    fname, sseed, eseed, teacher = case
+    fname, sseed, eseed, teacher, b = case
     g = G(golden_dir, fname)
     state = measure_state(4)
-    score = syn.measure_batch(16, seed=sseed)
-    eps = syn.normal_noise((16, 32), seed=eseed)
+    score = syn.measure_batch(b, seed=sseed)
+    eps = syn.normal_noise((b, 32), seed=eseed)
     attr = attributes.attribute_labels(score, *syn.measure_tables())
     close(attr, g['attr'], rtol=1e-6, atol=1e-7)
     res = step.measure_step(state, score, eps, attr, (0, 1, 2, 3), 0.001, 1.0, 10.0, teacher)
     np.testing.assert_array_equal(res['terms']['samples'], g['samples'])
-    check_step(res, g, state, list(state), grad_rtol=2e-3)
+    check_step(res, g, state, list(state), grad_rtol=2e-3, samp_atol=1e-4 if b <= 64 else 4e-4)
     w = res['terms']['weights']
     close(w[0], g['weights_row0'], rtol=1e-4, atol=1e-5)
     close(w.ravel()[syn.sample_indices('weights', w.size, 128)], g['weights_samp'], rtol=1e-4, atol=1e-5)

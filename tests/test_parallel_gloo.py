@@ -16,15 +16,13 @@ DIMS = (1, 2, 3, 4, 5)
 BETA, GAMMA, DELTA = 4.0, 10.0, 1.0
 
 
-class ArenaStub:
-    """The two FlatAdam members DataParallel.reduce_gradients touches."""
-
-    def __init__(self, n):
-        self.grad_arena = torch.zeros(n)
-        self.grad_scale = 1.0
-
-    def ensure_arena(self):
-        return self.grad_arena
+def _cpu_arena(n):
+    """a real FlatAdam over one CPU parameter: the arena, its guard slot and reduce_view() are plain torch (only step() needs
+    the HIP library)"""
+    from arvae_amd.optim import FlatAdam
+    opt = FlatAdam([torch.nn.Parameter(torch.zeros(n))])
+    opt.ensure_arena()
+    return opt
 
 
 def _free_port():
@@ -63,9 +61,21 @@ def _worker(rank, world, port, b_total, out_path, capacity):
         loss = recon + kld + reg
         loss.backward()
         flat = torch.cat([p[k].grad.reshape(-1) for k in state])
-        opt = ArenaStub(flat.numel())
-        opt.grad_arena.copy_(flat)
+        opt = _cpu_arena(flat.numel())
+        opt.grad_arena[:flat.numel()].copy_(flat)
         dp.reduce_gradients(opt)
+        reduced = opt.grad_arena.clone()
+        clean = int(opt.status_words()[0]) == 0                # nobody failed: the status word behind the gradients stays 0
+        # a pass that fails on ONE rank (here: the last) must stop EVERY rank's update: the sticky word rides behind the
+        # gradients through the same SUM all-reduce (optim.py "Guard slot") and stays set through later steps
+        if rank == world - 1:
+            opt.status_words()[0] = 0x40000000 | (2 << 20)      # ARVAE_STATUS_HANDOFF_BWD
+        dp.reduce_gradients(opt)
+        dp.reduce_gradients(opt)
+        flagged = clean and dp.all_agree(int(opt.status_words()[0]) != 0) and int(opt.status_words()[4]) == 0
+        bits, skipped = opt.take_status()
+        flagged = flagged and bits != 0 and skipped == 0 and int(opt.status_words()[0]) == 0
+        opt.grad_arena.copy_(reduced)
         mean_loss = float(dp.mean_scalar(loss))
         gathered = dp.gather_columns(torch.full((bl, 2), float(rank)))
         # the rest of the transport's surface (what the HIP path calls on its communicator: several gathers as one call, a
@@ -76,18 +86,18 @@ def _worker(rank, world, port, b_total, out_path, capacity):
         sent = torch.full((5,), float(rank + 7))
         dp.comm.broadcast(sent, src=0)
         if rank == 0:
-            np.savez(out_path, grad=(opt.grad_arena * opt.grad_scale).numpy(), loss=mean_loss,
+            np.savez(out_path, grad=(opt.grad_arena[:flat.numel()] * opt.grad_scale).numpy(), loss=mean_loss,
                      gathered=gathered.numpy(), scale=opt.grad_scale, many0=many[0].numpy(), many1=many[1].numpy(),
-                     agree=np.array(agree), stats=np.array(stats), sent=sent.numpy(), capturable=dp.capturable)
+                     agree=np.array(agree), stats=np.array(stats), sent=sent.numpy(), capturable=dp.capturable,
+                     flagged=flagged)
     finally:
         dist.destroy_process_group()
 
 
 # KL mean of this batch: 3.686 (shards 3.564 / 3.807): c = 3.7 lies BETWEEN the shard means, so the local signs disagree
 # and only the all-reduced mean gives the single-process gradient; c = 30 flips the sign on every rank
-@pytest.mark.parametrize('capacity', [0.0, 3.7, 30.0])
-@pytest.mark.parametrize('world', [2])
-def test_two_rank_step_equals_single_process(tmp_path, world, capacity):
+@pytest.mark.parametrize('world,capacity', [(2, 0.0), (2, 3.7), (2, 30.0), (4, 0.0), (4, 3.7), (8, 0.0)])
+def test_ranks_step_equals_single_process(tmp_path, world, capacity):
     from arvae_amd import synthetic as syn
     from oracle import image_vae as o_vae
     from oracle import step as o_step
@@ -105,10 +115,12 @@ def test_two_rank_step_equals_single_process(tmp_path, world, capacity):
     assert np.linalg.norm(got['grad'] - want) <= 1e-4 * np.linalg.norm(want)
     # all_gather_into_tensor is rank-major: rows of rank 0 first
     bl = b_total // world
-    assert (got['gathered'][:bl] == 0).all() and (got['gathered'][bl:] == 1).all()
-    assert (got['many0'][:bl] == 0).all() and (got['many0'][bl:] == 1).all() and (got['many1'][:bl] == 10).all() and (got['many1'][bl:] == 11).all()
+    ranks = np.repeat(np.arange(world), bl)
+    assert (got['gathered'] == ranks[:, None]).all()
+    assert (got['many0'] == ranks[:, None]).all() and (got['many1'] == 10 + ranks[:, None]).all()
     assert got['agree'].tolist() == [True, False]               # one rank saying no is everybody's no
-    np.testing.assert_allclose(got['stats'], [0.5, 1.0])
+    np.testing.assert_allclose(got['stats'], [(world - 1) / 2, world - 1.0])
+    assert bool(got['flagged'])                                 # one rank's device status reaches every rank's update kernel
     assert (got['sent'] == 7).all() and not bool(got['capturable'])   # torch.distributed collectives are not captured into graphs
 
 
