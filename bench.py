@@ -140,6 +140,43 @@ ROCPROF_NAMES = {
 
 
 
+# ONE peak per arithmetic (MI355X_MICROARCH.md), against ALGORITHMIC FLOP (fp32-equivalent) and layer-boundary bytes:
+#   'f16x2'  the 32-channel conv kernels: fp16 MFMA on scaled two-term operands, 3 partial products per multiply-add
+#            -> 2500 / 3 = 833.3 TFLOP/s of fp32-equivalent work;
+#   'fp32'   v_mfma_f32_* kernels (single-channel layers, the latent block): 157.3 TFLOP/s;
+#   HBM      8.0 TB/s for every kernel.
+ARITH_PEAK_TFLOPS = {'f16x2': PEAK_BF16_MFMA_TFLOPS / F16X2_PRODUCTS, 'fp32': PEAK_F32_MFMA_TFLOPS}
+
+
+def arithmetic_of(label):
+    return 'f16x2' if label.startswith(('down32', 'up32', 'wgrad32', 'pair4', 'pair(down32', 'pair(up32')) else 'fp32'
+
+
+def kernel_rooflines(prof, prof_steps, pmc_kernels=None):
+    """every launch site of the step: launches per step, average launch duration (HIP events, this run), algorithmic FLOP and
+    bytes per launch, and its fractions of the two roofs -- each arithmetic against its ONE stated peak (ARITH_PEAK_TFLOPS), so
+    a kernel's `frac` does not depend on which kernel happens to be the step's longest.  Sorted by device time."""
+    rows = []
+    total = sum(v['ms'] for v in prof.values())
+    for label, v in prof.items():
+        calls = max(v['calls'], 1)
+        avg_s = v['ms'] / calls * 1e-3
+        flop, nbytes = v.get('flop', 0.0) / calls, v.get('bytes', 0.0) / calls
+        arith = arithmetic_of(label)
+        row = {'kernel': label, 'launches_per_step': v['calls'] / prof_steps, 'avg_launch_us': avg_s * 1e6,
+               'us_per_step': 1e3 * v['ms'] / prof_steps, 'share_of_device_time': v['ms'] / total if total else 0.0}
+        if nbytes > 0 and avg_s > 0:
+            hbm = nbytes / avg_s / 1e9 / PEAK_HBM_GBS
+            mf = flop / avg_s / 1e12 / ARITH_PEAK_TFLOPS[arith] if flop else 0.0
+            row.update({'algorithmic_bytes_per_launch': nbytes, 'algorithmic_flop_per_launch': flop, 'arithmetic': arith if flop else None,
+                        'hbm_frac': hbm, 'mfma_frac': mf if flop else None, 'bound': 'mfma' if mf >= hbm else 'hbm', 'frac': max(mf, hbm)})
+            if pmc_kernels and label in pmc_kernels:
+                row['traffic'] = pmc_kernels[label]['hbm_bytes_per_launch']
+        rows.append(row)
+    rows.sort(key=lambda r: -r['us_per_step'])
+    return rows
+
+
 def rocprof_names(label):
     """kernel names of a rocprofv3 trace behind a timeline label (labels that are not in the table are kernel names)"""
     return ROCPROF_NAMES.get(label, ['arvae::' + label] if label.endswith('_kernel') else None)
@@ -148,10 +185,15 @@ def rocprof_names(label):
 def sq_counters(workload, names):
     """rocprofv3 SQ counters of a kernel from the committed summary (profiles/r5_sq_counters.json, tools/pmc_sq_round.sh): the
     counter-derived share of SIMD-cycles with the matrix pipe busy, beside the FLOP / time arithmetic of this run."""
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'r5_sq_counters.json')) as f:
-            table = json.load(f).get(workload, {})
-    except (OSError, ValueError):
+    table = src = None
+    for tag in ('r6', 'r5'):
+        try:
+            with open(os.path.join(ROOT, 'profiles', f'{tag}_sq_counters.json')) as f:
+                table, src = json.load(f).get(workload, {}), f'profiles/{tag}_sq_counters.json'
+            break
+        except (OSError, ValueError):
+            continue
+    if table is None:
         return None
     for nm in names or []:
         key = nm.replace('arvae::', '')
@@ -159,7 +201,7 @@ def sq_counters(workload, names):
             if k.startswith(key) or key in k:
                 return {'kernel': k, 'mfma_busy_frac': v['mfma_busy_frac'], 'valu_per_mfma': v.get('valu_per_mfma'),
                         'avg_launch_us_profiled': v['avg_launch_us_profiled'],
-                        'source': 'profiles/r5_sq_counters.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / (1024 x GRBM_GUI_ACTIVE / 8))'}
+                        'source': src + ' (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES / (1024 x GRBM_GUI_ACTIVE / 8))'}
     return None
 
 
@@ -436,7 +478,7 @@ def side_roofline(kind, prof, prof_steps, batch):
     out = {'kernel': name, 'rocprof_names': list(key), 'launches_per_step': dom['calls'] / prof_steps,
            'avg_launch_us': 1e3 * dom['ms'] / dom['calls'], 'us_per_step': 1e3 * dom['ms'] / prof_steps,
            'share_of_device_time': dom['ms'] / total, 'device_time_us_per_step': 1e3 * total / prof_steps}
-    for tag in ('r5', 'r4', 'r3', 'r2'):      # the top kernel of the committed rocprofv3 --kernel-trace --stats summary of this workload
+    for tag in ('r6', 'r5', 'r4', 'r3', 'r2'):      # the top kernel of the committed rocprofv3 --kernel-trace --stats summary of this workload
         try:
             import csv
             with open(os.path.join(ROOT, 'profiles', f'{tag}_{kind}_kernel_stats.csv')) as f:
@@ -684,29 +726,34 @@ def run_dsprites(device, args, fence, rank, world, use_dp):
     # (every kernel of the step above 2 % of its device time has a KERNEL_WORK entry; `unaccounted_labels` lists the rest)
     dom_name, dom = max(((k, v) for k, v in prof.items() if v['bytes'] > 0), key=lambda kv: kv[1]['ms'])
     avg_ms = dom['ms'] / dom['calls']
-    split = dom_name.startswith(('down32', 'up32', 'wgrad32', 'pair4', 'pair(down32', 'pair(up32'))      # (fp16 two-term MFMA kernels)
-    mfma_peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
-    mfma_work = dom['flop'] * (F16X2_PRODUCTS if split else 1)
+    arith = arithmetic_of(dom_name)
+    split = arith == 'f16x2'                                                                              # (fp16 two-term MFMA kernels)
+    # ONE peak per arithmetic, against algorithmic (fp32-equivalent) FLOP: 2500 / 3 products for the two-term fp16 kernels,
+    # 157.3 for fp32-MFMA kernels (ARITH_PEAK_TFLOPS) -- the same pricing as every row of roofline.kernels
+    mfma_peak = ARITH_PEAK_TFLOPS[arith]
+    mfma_work = dom['flop']
     mfma_tf = mfma_work / dom['calls'] / (avg_ms * 1e-3) / 1e12
     hbm_gbs = dom['bytes'] / dom['calls'] / (avg_ms * 1e-3) / 1e9
     # the roof this kernel sits closer to binds it
     if mfma_tf / mfma_peak >= hbm_gbs / PEAK_HBM_GBS:
         roof = {'bound': 'mfma', 'achieved': mfma_tf, 'peak': mfma_peak, 'unit': 'TFLOP/s', 'frac': mfma_tf / mfma_peak,
-                'traffic': None}
+                'traffic': None, 'arithmetic': arith}
         if split:
-            roof['mfma_work'] = 'executed fp16 MFMA FLOP = 3 partial products x algorithmic FLOP (scaled two-term split, fp32-accurate)'
-            roof['fp32_equivalent_tflops'] = mfma_tf / F16X2_PRODUCTS
+            roof['mfma_work'] = ('algorithmic fp32-equivalent FLOP against the fp16 MFMA peak over the 3 partial products the scaled '
+                                 'two-term split issues per multiply-add (2500 / 3 TFLOP/s)')
+            roof['executed_fp16_tflops'] = mfma_tf * F16X2_PRODUCTS
     else:
         roof = {'bound': 'hbm', 'achieved': hbm_gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': hbm_gbs / PEAK_HBM_GBS,
-                'traffic': None}
+                'traffic': None, 'arithmetic': arith}
     roof['other_roof_frac'] = {'mfma': mfma_tf / mfma_peak, 'hbm_algorithmic_bytes': hbm_gbs / PEAK_HBM_GBS}
     # HBM traffic of that kernel from the PMC counters: collected in separate rocprofv3 --pmc passes of this
     # same command (FETCH_SIZE / WRITE_SIZE cannot share a pass) and committed under profiles/
-    step_traffic = None
-    for tag in ('r5', 'r4', 'r3', 'r2', 'r1'):
+    step_traffic = pmc_kernels = None
+    for tag in ('r6', 'r5', 'r4', 'r3', 'r2', 'r1'):
         try:
             with open(os.path.join(ROOT, 'profiles', f'{tag}_pmc_traffic.json')) as f:
                 pmc = json.load(f)
+            pmc_kernels = pmc['kernels']
             roof['traffic'] = pmc['kernels'][dom_name]['hbm_bytes_per_launch']
             roof['traffic_source'] = f'profiles/{tag}_pmc_traffic.json (rocprofv3 --pmc, 2*FETCH_SIZE + WRITE_SIZE, B=512)'
             # PMC bytes of one whole step: the file's own sum over every kernel it traced, or (older files, which list
@@ -720,11 +767,21 @@ def run_dsprites(device, args, fence, rank, world, use_dp):
         roof['traffic'] = step_traffic = None
     roof['step_traffic_bytes'] = step_traffic
     roof['step_algorithmic_bytes'] = BYTES_PER_IMAGE * b + PARAM_BYTES_PER_STEP
+    # the whole step against the same roofs (the figure that is comparable from round to round: it does not depend on which
+    # kernel is the longest): algorithmic bytes / FLOP of one step over the timed step
+    step_s = med / args.steps
+    roof['step'] = {'ms_per_step': 1e3 * step_s,
+                    'hbm_frac': (BYTES_PER_IMAGE * b + PARAM_BYTES_PER_STEP) / step_s / (PEAK_HBM_GBS * 1e9),
+                    'flop_frac_fp32_equivalent': FLOP_PER_IMAGE * b / step_s / (ARITH_PEAK_TFLOPS['f16x2'] * 1e12),
+                    'flop_peak_tflops': ARITH_PEAK_TFLOPS['f16x2'], 'hbm_peak_gbs': PEAK_HBM_GBS,
+                    'traffic_over_algorithmic_bytes': (step_traffic / (BYTES_PER_IMAGE * b + PARAM_BYTES_PER_STEP)) if step_traffic else None,
+                    'north_star_target_hbm_frac': 0.40}
+    roof['kernels'] = kernel_rooflines(prof, prof_steps, pmc_kernels if b == 512 else None)
     # the same kernels in the committed rocprofv3 --kernel-trace --stats summary (launches there run back to back; the live
     # figure above brackets every launch with its own events, which costs each kernel the overlap with its neighbours' tails)
     try:
         import csv
-        stats_csv = next(t for t in ('r5', 'r4', 'r3', 'r2') if os.path.exists(os.path.join(ROOT, 'profiles', f'{t}_dsprites_kernel_stats.csv')))
+        stats_csv = next(t for t in ('r6', 'r5', 'r4', 'r3', 'r2') if os.path.exists(os.path.join(ROOT, 'profiles', f'{t}_dsprites_kernel_stats.csv')))
         with open(os.path.join(ROOT, 'profiles', f'{stats_csv}_dsprites_kernel_stats.csv')) as f:
             rows = [r for r in csv.DictReader(f) if any(nm in r['Name'] for nm in (rocprof_names(dom_name) or []))]
         calls = sum(int(r['Calls']) for r in rows)
@@ -848,6 +905,10 @@ def main():
                 except Exception as e:                              # the headline line must not depend on a side workload
                     sec[kind] = {'error': f'{type(e).__name__}: {e}'}
             line['secondary'] = sec
+            # early in the line (a log tail keeps the front of a long JSON line's keys last: these three numbers are the round's)
+            head = {k: line[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step')}
+            head['secondary_ms_per_step'] = {k: v.get('ms_per_step') for k, v in sec.items()}
+            line = {**head, **{k: v for k, v in line.items() if k not in head}}
     comm_ok = True
     if args.workload == 'dsprites' and use_dp and world > 1 and not args.no_secondary and args.batch == 512:
         # BASELINE.json configs[4] ("MeasureVAE batch = 256, 1 -> 8 MI355X DP"): weak scaling, 256 measures per rank, the executor's
@@ -873,6 +934,10 @@ def main():
             comm_ok = False
         if line is not None and line.get('dp') is not None:
             line['dp']['overlap_trial'] = res
+            # the decision the numbers support: the timed regions above ran the schedule named in `collectives_on`
+            line['dp']['overlap_decision'] = ('trial failed: keep the collectives on the launch stream' if 'error' in res else
+                                              'ARVAE_DP_OVERLAP=1 is faster here' if res.get('overlap_faster') else
+                                              'collectives on the launch stream (the default) are as fast or faster here')
     if rank == 0 and line is not None:
         if out_fd is None:
             print(json.dumps(line), flush=True)
@@ -884,7 +949,12 @@ def main():
     elif COMM is not None:
         sys.stdout.flush()
         sys.stderr.flush()
-        os._exit(0)                           # the communicator is gone: do not wait for anybody on the way out (the line says why)
+        # The communicator is gone: do not wait for anybody on the way out.  Exit code: only OPTIONAL extras run after the
+        # headline measurement (the secondary workload, the overlap trial) can bring us here -- a failure of the timed
+        # data-parallel step itself raises out of main() and exits non-zero -- so the headline line above is valid and says
+        # which extra failed (`secondary.measure.error` / `dp.overlap_trial.error`); the ranks leave with 0 so that a
+        # launcher does not discard a good measurement, and with ARVAE_BENCH_STRICT=1 with 3.
+        os._exit(3 if os.environ.get('ARVAE_BENCH_STRICT') == '1' else 0)
 
 
 if __name__ == '__main__':

@@ -68,14 +68,20 @@ def _needs(world, transport):
         pytest.skip(f'needs {world} GPUs, this box has {torch.cuda.device_count()}')
 
 
-@pytest.mark.parametrize('transport', ['library', 'torch', 'staged'])
-@pytest.mark.parametrize('fused', [True, False], ids=['fused', 'per_layer'])
-@pytest.mark.parametrize('capacity', [0.0, 3.7])
-@pytest.mark.parametrize('world', [1, 2])
+# world 1 / 2: every transport x step form x capacity; world 4 / 8 (the SCALE run's rank counts: the gather order of eight
+# row blocks, reg_scale = 8, Adam's 1/8): host-staged, ranks sharing whatever GPUs the box has
+RANK_CASES = [(w, c, f, t) for w in (1, 2) for c in (0.0, 3.7) for f in (True, False) for t in ('library', 'torch', 'staged')]
+RANK_CASES += [(8, 0.0, True, 'staged'), (8, 3.7, True, 'staged'), (8, 0.0, False, 'staged'), (4, 0.0, True, 'staged'),
+               (8, 0.0, True, 'library'), (4, 0.0, True, 'library')]
+
+
+@pytest.mark.parametrize('world,capacity,fused,transport', RANK_CASES,
+                         ids=[f'{w}-{c}-{"fused" if f else "per_layer"}-{t}' for w, c, f, t in RANK_CASES])
 def test_rccl_ranks_equal_single_process(tmp_path, golden_dir, world, capacity, fused, transport):
-    """(transport 'staged', world 2: TWO ranks of the HIP path on whatever GPUs the box has -- both on cuda:0 on a one-GPU box --
+    """(transport 'staged', world >= 2: the ranks of the HIP path on whatever GPUs the box has -- all on cuda:0 on a one-GPU box --
     with the collectives staged through a gloo group on the host: the multi-rank LOGIC of the HIP path against the oracle's
-    single-process step, where RCCL itself cannot run for want of a second GPU)"""
+    single-process step, where RCCL itself cannot run for want of more GPUs.  World 8 = BASELINE.json configs[3]'s rank count:
+    8 x 8 rows against the oracle at B = 64 and the reference's golden dsprites_step_b64.npz)"""
     _needs(world, transport)
     if transport == 'torch' and not (fused and capacity == 0.0):
         pytest.skip('the torch.distributed transport is covered on the default step only')
@@ -151,8 +157,11 @@ def test_rccl_overlapped_collectives_change_nothing(tmp_path, world):
             np.testing.assert_array_equal(on[k], off[k], err_msg=k)
 
 
-@pytest.mark.parametrize('path', ['executor', 'layers'])
-@pytest.mark.parametrize('world,transport', [(1, 'library'), (2, 'library'), (2, 'staged')])
+MEASURE_RANK_CASES = [(w, t, p) for p in ('executor', 'layers') for w, t in ((1, 'library'), (2, 'library'), (2, 'staged'))]
+MEASURE_RANK_CASES += [(8, 'staged', 'executor'), (8, 'library', 'executor')]      # configs[4]'s rank count: 8 x 4 measures
+
+
+@pytest.mark.parametrize('world,transport,path', MEASURE_RANK_CASES, ids=[f'{w}-{t}-{p}' for w, t, p in MEASURE_RANK_CASES])
 def test_measure_data_parallel_step_replays_from_graphs(tmp_path, world, transport, path):
     """a data-parallel MeasureVAE step replayed from a HIP graph that holds its collective (the library's RCCL all-gather,
     recorded like the kernels around it; no torch process group, no watchdog thread in the worker) gives the eager
@@ -230,6 +239,11 @@ def test_bench_under_the_drivers_launcher_with_two_ranks():
     assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['config']['global_batch'] == 2 * line['config']['per_gpu_batch']
     assert np.isfinite(line['value']) and line['value'] > 0 and line['config']['rccl_world_size'] == 2
     assert line['config']['collectives'].startswith('StagedComm' if torch.cuda.device_count() < 2 else 'LibraryComm')
+    # what the step's two exchanges cost alone (HIP events, max over ranks) and what the overlap trial decided
+    dp = line['dp']
+    assert dp['world'] == 2 and dp['all_reduce_us'] > 0 and dp['all_gather_us'] > 0 and 0 < dp['share_of_step']
+    assert dp['grad_arena_bytes'] > 2_000_000 and ('overlap_faster' in dp['overlap_trial'] or 'error' in dp['overlap_trial'])
+    assert isinstance(dp['overlap_decision'], str)
 
 
 def test_bench_refuses_more_ranks_than_gpus():
@@ -248,6 +262,16 @@ def test_bench_line_has_the_contract_fields():
     assert line['steps'] == 5 and line['warmup'] == 2 and line['n_gpus'] == 1 and line['vs_baseline'] is None
     rf = line['roofline']
     assert rf['bound'] in ('hbm', 'mfma') and abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-9 and rf['rocprof_names']
+    # the step-level fractions and every launch site of the step, each priced against ONE peak per arithmetic
+    assert 0 < rf['step']['hbm_frac'] < 1 and 0 < rf['step']['flop_frac_fp32_equivalent'] < 1
+    assert abs(rf['step']['ms_per_step'] - line['ms_per_step']) < 1e-9
+    kernels = rf['kernels']
+    assert len(kernels) >= 10 and kernels[0]['us_per_step'] >= kernels[-1]['us_per_step']
+    assert abs(sum(k['share_of_device_time'] for k in kernels) - 1.0) < 1e-6
+    priced = [k for k in kernels if 'frac' in k]
+    assert len(priced) >= 8 and all(0 < k['frac'] < 1 and k['bound'] in ('hbm', 'mfma') for k in priced)
+    assert any(k['kernel'] == rf['kernel'] and abs(k['frac'] - rf['frac']) < 1e-9 for k in priced)
+    assert set(line['secondary_ms_per_step']) == {'mnist', 'measure'} and list(line).index('secondary_ms_per_step') < 10
     assert line['timing']['regions'] >= 3
     for kind in ('mnist', 'measure'):
         sec = line['secondary'][kind]
