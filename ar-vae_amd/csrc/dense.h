@@ -48,5 +48,7 @@ bool dense_wgrad_long_defer(LongWgradQueue *q, const arvae_link_t *l, const Oper
 int dense_wgrad_long_flush(LongWgradQueue *q, hipStream_t s);
 bool dense_wgrad_defer(DenseWgradBatch *b, const arvae_link_t *l, const Operand &g, const float *x, float *dw, float *dbias);
 int dense_wgrad_flush(DenseWgradBatch *b, hipStream_t s);
+struct SlabReduceBatch;
+int dense_wgrad_slab_flush(DenseWgradBatch *b, SlabReduceBatch *r, hipStream_t s);      // both closing queues of a backward pass, one launch
 
 }  // namespace arvae

@@ -12,6 +12,7 @@
 #include "diag.h"
 #include "common.h"
 #include "dense.h"
+#include "reduce.h"
 #include "x3tile.h"
 #include "wgrad_c1s.h"
 
@@ -829,6 +830,52 @@ __global__ __launch_bounds__(64 * NWB, 2) void dense_wgrad_c1_kernel(DenseWgradB
     const DenseArgs &p = b.job[j];
     const int tx = (p.n_out + 31) / 32;
     dense_wgrad_tile<NWB>(p, tile % tx, tile / tx, raw);
+}
+
+// The two closing launches of the image VAE's backward pass as ONE grid (round 6): the grouped Linear weight gradients (~400 tiles,
+// each two dependent round trips to L2: latency) and the fixed-order sum of the conv layers' weight-gradient slabs (~55 MB
+// streamed from HBM, ~1500 workgroups).  They write disjoint parts of the gradient arena.  Tiles first: they are dispatched one or
+// two to a CU and leave the memory system idle, the reducers fill the CUs' other slots (both are 512-thread workgroups under 128
+// registers) and stream beside them.  (Round 2 tried this with the roles interleaved and with the reducers first: 40.8 us and
+// the sum of the two, against 31.2 back to back -- the tile kernel then ran one 1024-thread workgroup per CU.)
+__global__ __launch_bounds__(64 * NWB, 2) void dense_wgrad_slab_kernel(DenseWgradBatch b, SlabReduceBatch r, int n_tiles) {
+    __shared__ __attribute__((aligned(16))) float raw[NWB * 16 * 64];
+    static_assert(64 * RED_Z == 64 * NWB && RED_Z * RED_OUT <= NWB * 16 * 64, "dense_wgrad_slab_kernel: one workgroup shape, one LDS block");
+    if ((int)blockIdx.x < n_tiles) {
+        int j = 0;
+        while (j + 1 < b.count && (int)blockIdx.x >= b.tile_end[j]) ++j;
+        const int tile = blockIdx.x - (j > 0 ? b.tile_end[j - 1] : 0);
+        const DenseArgs &p = b.job[j];
+        const int tx = (p.n_out + 31) / 32;
+        dense_wgrad_tile<NWB>(p, tile % tx, tile / tx, raw);
+        return;
+    }
+    const int bid = blockIdx.x - n_tiles;
+    float (*red)[RED_OUT] = reinterpret_cast<float (*)[RED_OUT]>(raw);
+    int j = 0, start = 0;
+#pragma unroll
+    for (int q = 0; q + 1 < SLAB_BATCH_MAX; ++q)
+        if (q + 1 < r.count && bid >= r.block_end[q]) { j = q + 1; start = r.block_end[q]; }
+    switch (j) {                         // constant indices into the by-value argument block
+#define ARVAE_JOB(J) case J: slab_reduce_block(r.job[J], bid - start, red); break;
+        ARVAE_JOB(0) ARVAE_JOB(1) ARVAE_JOB(2) ARVAE_JOB(3) ARVAE_JOB(4) ARVAE_JOB(5) ARVAE_JOB(6) ARVAE_JOB(7)
+#undef ARVAE_JOB
+        default: break;
+    }
+}
+
+// both queues in one launch when both hold work; either alone otherwise (ARVAE_NO_PAIR_CLOSE in the diagnostic build: back to back)
+int dense_wgrad_slab_flush(DenseWgradBatch *b, SlabReduceBatch *r, hipStream_t s) {
+    static const bool off = diag_env("ARVAE_NO_PAIR_CLOSE") != nullptr || diag_env("ARVAE_DENSE_BATCH_SPLIT") != nullptr;
+    if (off || b->count == 0 || r->count == 0) {
+        if (int rc = slab_reduce_flush(r, s)) return rc;
+        return dense_wgrad_flush(b, s);
+    }
+    const int n_tiles = b->tile_end[b->count - 1];
+    ARVAE_LAUNCH(dense_wgrad_slab_kernel, dim3(n_tiles + r->block_end[r->count - 1]), dim3(64 * NWB), 0, s, *b, *r, n_tiles);
+    b->count = 0;
+    r->count = 0;
+    return check_launch("pair(dense_wgrad_batch + slab_reduce_batch)");
 }
 
 bool dense_fits(const arvae_link_t *l) {

@@ -1023,12 +1023,11 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
         cur = dst;
         cur_amax = din_has ? grad_amax(dst) : nullptr;
     }
-    // The two closing kernels are independent (disjoint gradients): the slab reduction streams ~90 MB from HBM while the
+    // The two closing kernels are independent (disjoint gradients): the slab reduction streams ~55 MB from HBM while the
     // grouped Linear weight gradients are latency-bound in L2.  Side by side on a second stream they measured 22 us SLOWER
-    // per step than back to back (fork / join events cost more than the overlap returns; round 2), as one grid 40.8 us
-    // against 31.2: back to back it is.
-    if (int rc = slab_reduce_flush(&rdefer, flush_stream)) return rc;
-    if (int rc = dense_wgrad_flush(&defer, flush_stream)) return rc;
+    // per step than back to back (fork / join events cost more than the overlap returns; round 2); as ONE grid with the tiles
+    // dispatched first they co-reside on the CUs (dense.hip, dense_wgrad_slab_kernel: round 6).
+    if (int rc = dense_wgrad_slab_flush(&defer, &rdefer, flush_stream)) return rc;
     if (ms != nullptr) {                                 // milestones with no earlier point: everything is final here
         if (!dec_marked) mark(ms->dec_grads, st);
         if (!lin_marked) mark(ms->linear_grads, st);

@@ -103,6 +103,10 @@ KERNEL_WORK = {
     # fixed-order sum of the conv layers' weight-gradient slabs: 4 x 256 slabs of 64 KB (16x16 and 8x8 layers), 2 x 128
     # (4x4 layers), 2 x 256 x 2 KB (single-channel layers) + bias partials read, 2 MB of gradients written
     'slab_reduce_batch_kernel': (0, 0, 4 * 256 * 65664 + 2 * 128 * 65664 + 2 * 256 * 2176 + 2_000_000),
+    # round 6: the two closing launches as one grid (dense.hip dense_wgrad_slab_kernel): the Linear weight gradients' work and
+    # bytes + the slabs as the paired launches of rounds 3-5 leave them (4 x ~130 slabs of 64 KB, 2 x 16 tap slabs of 66 KB, the
+    # single-channel layers' 2 KB slabs) read once, 2 MB of gradients written
+    'pair(dense_wgrad_batch + slab_reduce_batch)': (400_896, 4 * 3102, 4 * 400_896 + 4 * 130 * 65664 + 2 * 16 * 67584 + 2 * 256 * 2176 + 2_000_000),
 }
 # the library's timeline labels one kernel FAMILY; these are the instantiations a rocprofv3 --kernel-trace of the
 # default build lists for it at B = 512 (profiles/*_kernel_stats.csv)
@@ -118,6 +122,7 @@ ROCPROF_NAMES = {
     'down32_kernel<4>': ['arvae::down32s_kernel<4, 1>', 'arvae::down32s_kernel<4, 2>'],
     'pair4(down32 + wgrad32)': ['arvae::pair4_down_kernel<2, 2>'], 'pair4(up32 + wgrad32)': ['arvae::pair4_up_kernel<3, 1>'],
     'pair_c1(down_c1 + wgrad_c1)': ['arvae::pair_c1_kernel<1>'], 'pair(wgrad_c1 + dense_wgrad_batch)': ['arvae::dense_wgrad_c1_kernel'],
+    'pair(dense_wgrad_batch + slab_reduce_batch)': ['arvae::dense_wgrad_slab_kernel'],
     'pair(down32<16> + wgrad32<16>)': ['arvae::pair_down_wgrad_kernel<16, 3, 2>'], 'pair(down32<8> + wgrad32<8>)': ['arvae::pair_down_wgrad_kernel<8, 3, 2>'],
     'pair(up32<16> + wgrad32<16>)': ['arvae::pair_up16_wgrad_kernel<3, 1>'], 'pair(up32<8> + wgrad32<8>)': ['arvae::pair_up8_wgrad_kernel<3, 1>'],
     'pair(up32<16> + wgrad32<16> + wgrad_c1)': ['arvae::pair_up16_wgrad_kernel<3, 1, true>'],
