@@ -33,6 +33,24 @@ struct DenseWgradBatch {
     DenseArgs job[DENSE_BATCH_MAX];
 };
 
+// C[M][N] = sum_k A[m][k] B(k, n) on the three-term bf16 MFMA, 64 x 64 tiles (dense.hip, wide_gemm_x3_kernel): the wide Linear
+// layers of the latent block.  A: [M][lda] (k contiguous).  B: b_krows == 0: [N][ldb] (k contiguous); b_krows == 1: [K][ldb] (n contiguous).
+constexpr int WIDE_MAX_SLICES = 16;
+struct WideGemm {
+    const float *a, *b;
+    int64_t lda, ldb;
+    int M, N, K, kslice, b_krows;
+    float *out;                 // finished: [M][ldo]; split: workspace, slice z at out + z * slice_floats
+    int64_t ldo, slice_floats;
+    const float *bias;          // finished: per output column, may be null
+    int act;                    // finished: activation (ARVAE_ACT_*)
+    const float *gate;          // finished: optional ReLU gate: out = gate[m][n] > 0 ? value : 0
+    unsigned *amax_out;         // finished: AMAX array of the result (conv32_common.h), may be null
+};
+int wide_gemm_slices(int M, int N, int K);
+bool wide_gemm_fits(const WideGemm &g, int slices);
+int wide_gemm(WideGemm g, int slices, bool partial, hipStream_t s);
+
 bool dense_fits(const arvae_link_t *l);
 int dense_fwd(const arvae_link_t *l, const float *x, const float *w, const float *bias, int act, float *y, hipStream_t s);
 int dense_dgrad(const arvae_link_t *l, const Operand &g, const float *w, const float *gate, float *dx, hipStream_t s);

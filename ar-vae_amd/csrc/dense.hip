@@ -9,8 +9,10 @@
 //
 // Channel permutations (hi_perm / lo_perm of arvae_link_t: the NCHW flatten between conv and dense
 // stacks over channels-last activations) are index remaps on the feature axis.
+#include <mutex>
 #include "diag.h"
 #include "common.h"
+#include "conv32_common.h"
 #include "dense.h"
 #include "reduce.h"
 #include "x3tile.h"
@@ -500,6 +502,169 @@ __device__ __forceinline__ void rows_gemm_x3_body(const RowsGemm &g, const int b
 template <int LA, int LB, int EP, bool VA, bool VB>
 __global__ __launch_bounds__(256) void rows_gemm_x3_kernel(RowsGemm g) {
     rows_gemm_x3_body<LA, LB, EP, VA, VB>(g, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// ================================================================================================================================
+// Wide Linear layers on the matrix pipe (round 6; Morpho-MNIST's Linear(2888, 256) / Linear(256, 2888), imagevae/mnist_vae.py:27-38,
+// BASELINE.json configs[2] "MFMA on fc z-projections").  The latent block's row kernels (midblock.hip) stream every matrix through
+// every workgroup on fp32 FMA chains: 80 + 85 us per step for these two layers' 6 GFLOP.  Here a layer's forward product and its
+// data gradient are tile GEMMs  C[M][N] = sum_k A[m][k] B(k, n)  on the three-term bf16 MFMA (x3tile.h: fp32-accurate, no operand
+// scales to carry), 64 x 64 tiles, 2 x 2 waves:
+//   * A is always "rows x K" (activations / gradients, [batch][features]); B is the layer's ONE per-step copy W'[n_mem][k_mem]
+//     (mid_prep: the NCHW-flatten permutation folded in) read as "rows x K" for the forward product and as "K x rows" -- through the
+//     transposing LDS read -- for the data gradient: no second layout;
+//   * both operands go through DOUBLE-BUFFERED LDS planes, three 32-deep chunks of global loads in flight per thread (register
+//     sets), ONE barrier per chunk; two workgroups per CU hide each other's split / commit work behind their MFMAs;
+//   * a long reduction (K = 2888 against 16 x 4 tiles) is split over blockIdx.z into workspace slices (EP_PARTIAL) that the
+//     CONSUMER sums in slice order -- the latent block's kernels do it in their prologue with the bias, the activation (forward)
+//     or its derivative (backward): no reduction launch; a short one (K = 256, 16 x 46 tiles) finishes in place (EP_FULL: bias,
+//     activation or ReLU gate, the tensor's AMAX entry for the conv kernel that reads it next).
+enum { WG_EP_PARTIAL = 0, WG_EP_FULL = 1 };
+constexpr int WG_DEPTH = 3;
+template <int LB>
+struct WideLds {
+    typedef TileLoader<RG_ROWSK, 64, true> LoadA;
+    typedef TileLoader<LB, 64, true> LoadB;
+    static constexpr int BUF = 3 * LoadA::PLANE + 3 * LoadB::PLANE;         // unsigned shorts per buffer
+    static constexpr size_t BYTES = (size_t)2 * BUF * sizeof(unsigned short) + 64;
+};
+template <int LB, int EP>
+__global__ __launch_bounds__(256, 2) void wide_gemm_x3_kernel(WideGemm g) {
+    typedef typename WideLds<LB>::LoadA LoadA;
+    typedef typename WideLds<LB>::LoadB LoadB;
+    constexpr int BUF = WideLds<LB>::BUF;
+    extern __shared__ __attribute__((aligned(16))) unsigned short wlds[];
+    const int lane = threadIdx.x & 63, half = lane >> 5, rc = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p0 = blockIdx.x * 64, q0 = blockIdx.y * 64;
+    const int rbeg = blockIdx.z * g.kslice, rend = min(g.K, rbeg + g.kslice);
+    const int nchunks = (rend - rbeg + RG_R - 1) / RG_R;
+    const int wp = wave & 1, wq = wave >> 1;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    LoadA la[WG_DEPTH];
+    LoadB lb[WG_DEPTH];
+    // chunk c -> register set c % 3; a chunk past the end re-reads the last one (unconditional loads: exact vmcnt counts) and is
+    // never multiplied
+    auto issue = [&](auto dc, int c) __attribute__((always_inline)) {
+        constexpr int d = decltype(dc)::value;
+        const int r0 = rbeg + RG_R * min(c, nchunks - 1);
+        la[d].load(g.a, g.lda, p0, g.M, r0, rend);
+        lb[d].load(g.b, g.ldb, q0, g.N, r0, rend);
+    };
+    auto commit = [&](auto dc, int c) __attribute__((always_inline)) {
+        constexpr int d = decltype(dc)::value;
+        unsigned short *buf = wlds + (c & 1) * BUF;
+        la[d].commit3(buf);
+        lb[d].commit3(buf + 3 * LoadA::PLANE);
+    };
+    const int abase = LoadA::lane_base(wp), bbase = LoadB::lane_base(wq);
+    auto multiply = [&](int c) __attribute__((always_inline)) {
+        const unsigned short *As = wlds + (c & 1) * BUF, *Bs = As + 3 * LoadA::PLANE;
+#pragma unroll
+        for (int s = 0; s < RG_R / 16; ++s) {
+            const rg_bf16x8 ah = LoadA::operand(As, abase, 0, s), am = LoadA::operand(As, abase, 1, s), al = LoadA::operand(As, abase, 2, s);
+            const rg_bf16x8 bh = LoadB::operand(Bs, bbase, 0, s), bm = LoadB::operand(Bs, bbase, 1, s), bl = LoadB::operand(Bs, bbase, 2, s);
+            X3_MFMA6(acc, ah, am, al, bh, bm, bl);
+        }
+    };
+    using D0 = std::integral_constant<int, 0>;
+    using D1 = std::integral_constant<int, 1>;
+    using D2 = std::integral_constant<int, 2>;
+    issue(D0{}, 0);
+    issue(D1{}, 1);
+    issue(D2{}, 2);
+    commit(D0{}, 0);
+    issue(D0{}, 3);
+    __syncthreads();
+    // chunk c is multiplied from buffer c & 1; meanwhile chunk c + 1 (register set (c + 1) % 3) goes to the other buffer and its set
+    // is refilled with chunk c + 4
+#define ARVAE_WG_STEP(D, DN)                                     \
+        if (c + D >= nchunks) break;                             \
+        multiply(c + D);                                         \
+        commit(DN{}, c + D + 1);                                 \
+        issue(DN{}, c + D + 4);                                  \
+        __syncthreads();
+    for (int c = 0;; c += WG_DEPTH) {
+        ARVAE_WG_STEP(0, D1)
+        ARVAE_WG_STEP(1, D2)
+        ARVAE_WG_STEP(2, D0)
+    }
+#undef ARVAE_WG_STEP
+    const int q = q0 + 32 * wq + rc;
+    if (EP == WG_EP_PARTIAL) {
+        float *out = g.out + (int64_t)blockIdx.z * g.slice_floats;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int p = p0 + 32 * wp + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (p < g.M && q < g.N) out[(int64_t)p * g.ldo + q] = acc[r];
+        }
+        return;
+    }
+    const float bias = (g.bias != nullptr && q < g.N) ? g.bias[q] : 0.f;
+    float amax = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int p = p0 + 32 * wp + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const bool ok = p < g.M && q < g.N;
+        const int64_t idx = (int64_t)(ok ? p : 0) * g.ldo + (ok ? q : 0);
+        float v = act_fwd(acc[r] + bias, g.act);
+        if (g.gate != nullptr) v = g.gate[idx] > 0.f ? v : 0.f;
+        if (ok) { g.out[idx] = v; amax = fmaxf(amax, fabsf(v)); }
+    }
+    if (g.amax_out != nullptr) {                                 // one AMAX writer unit per workgroup (conv32_common.h)
+        float *red = reinterpret_cast<float *>(wlds + 2 * BUF);
+        amax = wave_max(amax);
+        __syncthreads();
+        if (lane == 0) red[wave] = amax;
+        __syncthreads();
+        const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (wave == 0) {
+            const int unit = (blockIdx.y * gridDim.x + blockIdx.x), units = gridDim.x * gridDim.y;
+            amax_publish(g.amax_out, unit, units, m);
+        }
+    }
+}
+
+// K slices that fill the chip: tiles x slices ~ two workgroups per CU, a slice at least four chunks long
+int wide_gemm_slices(int M, int N, int K) {
+    const int tiles = ((M + 63) / 64) * ((N + 63) / 64), chunks = (K + RG_R - 1) / RG_R;
+    int s = (2 * device_cu_count() + tiles - 1) / tiles;
+    if (s > chunks / 4) s = chunks / 4;
+    if (s > WIDE_MAX_SLICES) s = WIDE_MAX_SLICES;
+    return s < 1 ? 1 : s;
+}
+bool wide_gemm_fits(const WideGemm &g, int slices) {
+    auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const int64_t a_bytes = (int64_t)g.M * g.lda * 4, b_bytes = (int64_t)(g.b_krows ? g.K : g.N) * g.ldb * 4;
+    const int tiles = ((g.M + 63) / 64) * ((g.N + 63) / 64);
+    return g.M > 0 && g.N > 0 && g.K > 0 && (g.K & 3) == 0 && (g.lda & 3) == 0 && (g.ldb & 3) == 0 && (g.N & 3) == 0 && al(g.a) && al(g.b) &&
+           a_bytes < ((int64_t)1 << 31) && b_bytes < ((int64_t)1 << 31) && slices >= 1 && slices <= WIDE_MAX_SLICES &&
+           (g.amax_out == nullptr || tiles <= AMAX_N);
+}
+// slices > 1 (or partial): g.out = workspace of `slices` x slice_floats, the consumer sums them; else the finished product
+int wide_gemm(WideGemm g, int slices, bool partial, hipStream_t s) {
+    ARVAE_REQUIRE(wide_gemm_fits(g, slices), "wide_gemm: operand shapes / alignment");
+    ARVAE_REQUIRE(partial || slices == 1, "wide_gemm: a split reduction leaves partial sums");
+    const int chunks = (g.K + RG_R - 1) / RG_R;
+    g.kslice = ((chunks + slices - 1) / slices) * RG_R;
+    const dim3 grid((g.M + 63) / 64, (g.N + 63) / 64, slices);
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute((const void *)wide_gemm_x3_kernel<RG_ROWSK, WG_EP_PARTIAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideLds<RG_ROWSK>::BYTES);
+        (void)hipFuncSetAttribute((const void *)wide_gemm_x3_kernel<RG_ROWSK, WG_EP_FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideLds<RG_ROWSK>::BYTES);
+        (void)hipFuncSetAttribute((const void *)wide_gemm_x3_kernel<RG_KROWS, WG_EP_PARTIAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideLds<RG_KROWS>::BYTES);
+        (void)hipFuncSetAttribute((const void *)wide_gemm_x3_kernel<RG_KROWS, WG_EP_FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideLds<RG_KROWS>::BYTES);
+    });
+    if (g.b_krows) {
+        if (partial) ARVAE_LAUNCH((wide_gemm_x3_kernel<RG_KROWS, WG_EP_PARTIAL>), grid, dim3(256), WideLds<RG_KROWS>::BYTES, s, g);
+        else ARVAE_LAUNCH((wide_gemm_x3_kernel<RG_KROWS, WG_EP_FULL>), grid, dim3(256), WideLds<RG_KROWS>::BYTES, s, g);
+    } else {
+        if (partial) ARVAE_LAUNCH((wide_gemm_x3_kernel<RG_ROWSK, WG_EP_PARTIAL>), grid, dim3(256), WideLds<RG_ROWSK>::BYTES, s, g);
+        else ARVAE_LAUNCH((wide_gemm_x3_kernel<RG_ROWSK, WG_EP_FULL>), grid, dim3(256), WideLds<RG_ROWSK>::BYTES, s, g);
+    }
+    return check_launch(partial ? "wide_gemm(partial)" : "wide_gemm(full)");
 }
 
 // The weight-gradient product on 128 x 128 output tiles (2 x 2 waves of 2 x 2 MFMA tiles each): four times the multiply-adds per

@@ -27,6 +27,7 @@ int conv32_amax(const float *x, int64_t count, unsigned *out, hipStream_t s);   
 
 
 constexpr int MID_T = 512;           // threads per workgroup
+constexpr int MID_WIDE_MIN = 1024;   // a first / last layer at least this wide on its outer side goes to the tile GEMMs (dense.hip)
 constexpr int MID_MAX_W = 3072;      // widest layer (Morpho-MNIST: 2888)
 constexpr int mid_red(int r) { return r * 4 * MID_T; }   // floats of cross-slice reduction scratch (slices * n <= 4 * MID_T)
 
@@ -64,6 +65,13 @@ struct MidArgs {
     const float *warm_ptr[2 * MID_MAX_LAYERS + 1];
     int warm_lines[2 * MID_MAX_LAYERS + 1];          // 128-byte lines
     int n_warm;
+    // Wide layers the tile GEMMs multiply (dense.hip wide_gemm_x3_kernel; round 6): the block's first encoder layer (skip_enc0)
+    // and / or its last decoder layer (skip_dec_last) are NOT run here.  What this kernel does for them is the consumer's half
+    // of a split reduction: forward, enc[0]'s output = act(bias + sum over `wide_slices` partial products, in slice order),
+    // saved like every layer's; backward, the gradient at dec[nd - 2]'s output = the slices' sum, times act'(saved output).
+    int skip_enc0, skip_dec_last, wide_slices;
+    const float *wide_partial;                       // [wide_slices][batch][width]
+    int64_t wide_slice_floats;
 };
 
 // The prep launch wrote the matrices from other XCDs, so a layer's first weight loads miss this XCD's L2 and every layer of the
@@ -245,7 +253,27 @@ __global__ __launch_bounds__(MID_T) void mid_forward_kernel(MidArgs p) {
     MID_STAMP(0);
     float warm[MID_WARM];
     mid_warm(p, warm);
-    {   // conv features of this workgroup's rows -> bufA (rows past the batch: zeros)
+    if (p.skip_enc0) {
+        // the first encoder layer was multiplied by the tile GEMM (split reduction): finish it -- slices summed in order, bias,
+        // activation, the saved output -- into bufA
+        const MidLayer l = p.enc[0];
+        const int n4 = l.n >> 2;
+        for (int i = tid; i < R * n4; i += MID_T) {
+            const int r = i / n4, c = i - r * n4, row = row0 + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < p.batch) {
+                v = l.bias != nullptr ? ld4(l.bias + 4 * c) : v;
+                const float *src = p.wide_partial + (int64_t)row * l.n + 4 * c;
+                for (int sl = 0; sl < p.wide_slices; ++sl) {
+                    const float4 t = ld4(src + sl * p.wide_slice_floats);
+                    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+                }
+                v = act4(v, l.act);
+                *reinterpret_cast<float4 *>(l.y + (int64_t)row * l.n + 4 * c) = v;
+            }
+            *reinterpret_cast<float4 *>(bufA + r * p.ld + 4 * c) = v;
+        }
+    } else {   // conv features of this workgroup's rows -> bufA (rows past the batch: zeros)
         const int k4 = p.enc[0].k >> 2;
         for (int i = tid; i < R * k4; i += MID_T) {
             const int r = i / k4, c = i - r * k4;
@@ -271,7 +299,7 @@ __global__ __launch_bounds__(MID_T) void mid_forward_kernel(MidArgs p) {
         MID_STAMP(stamp_no); ++stamp_no;
         float *t = cur; cur = nxt; nxt = t;
     };
-    for (int i = 0; i < p.ne; ++i) run_layer(p.enc[i]);
+    for (int i = p.skip_enc0 ? 1 : 0; i < p.ne; ++i) run_layer(p.enc[i]);
     // heads: one more layer of the chain, (mu | log_std) = hidden x [h][2 zdim] + bias, into the scratch rows `outs`
     mid_matmul<R>(
         cur, p.ld, p.h, p.hf, 2 * p.zdim, red,
@@ -295,8 +323,9 @@ __global__ __launch_bounds__(MID_T) void mid_forward_kernel(MidArgs p) {
     __syncthreads();
     { float *t = cur; cur = nxt; nxt = t; }
     MID_STAMP(stamp_no); ++stamp_no;
-    for (int i = 0; i < p.nd; ++i) run_layer(p.dec[i]);
-    mid_amax<R>(cur, p.ld, p.dec[p.nd - 1].n, red, p.amax_out);
+    const int nd_run = p.skip_dec_last ? p.nd - 1 : p.nd;      // (a skipped last layer: the tile GEMM multiplies dec[nd - 2]'s saved output)
+    for (int i = 0; i < nd_run; ++i) run_layer(p.dec[i]);
+    if (!p.skip_dec_last) mid_amax<R>(cur, p.ld, p.dec[p.nd - 1].n, red, p.amax_out);
     mid_warm_done(warm);
 }
 
@@ -308,7 +337,26 @@ __global__ __launch_bounds__(MID_T) void mid_backward_kernel(MidArgs p) {
     const int tid = threadIdx.x, row0 = blockIdx.x * R;
     float warm[MID_WARM];
     mid_warm(p, warm);
-    {   // gradient arriving at the last decoder Linear layer -> bufA as a pre-activation gradient
+    if (p.skip_dec_last) {
+        // the last decoder layer's data gradient was multiplied by the tile GEMM (split reduction): the slices' sum is the gradient
+        // at dec[nd - 2]'s OUTPUT; times act'(its saved output) = that layer's pre-activation gradient, kept for its weight gradient
+        const MidLayer l = p.dec[p.nd - 2];
+        const int n4 = l.n >> 2;
+        for (int i = tid; i < R * n4; i += MID_T) {
+            const int r = i / n4, c = i - r * n4, row = row0 + r;
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < p.batch) {
+                const float *src = p.wide_partial + (int64_t)row * l.n + 4 * c;
+                for (int sl = 0; sl < p.wide_slices; ++sl) {
+                    const float4 t = ld4(src + sl * p.wide_slice_floats);
+                    g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
+                }
+                g = dact4(g, ld4(l.y + (int64_t)row * l.n + 4 * c), l.act);
+                *reinterpret_cast<float4 *>(l.gpre + (int64_t)row * l.n + 4 * c) = g;
+            }
+            *reinterpret_cast<float4 *>(bufA + r * p.ld + 4 * c) = g;
+        }
+    } else {   // gradient arriving at the last decoder Linear layer -> bufA as a pre-activation gradient
         const MidLayer l = p.dec[p.nd - 1];
         const int n4 = l.n >> 2;
         for (int i = tid; i < R * n4; i += MID_T) {
@@ -348,7 +396,8 @@ __global__ __launch_bounds__(MID_T) void mid_backward_kernel(MidArgs p) {
         __syncthreads();
         float *t = cur; cur = nxt; nxt = t;
     };
-    for (int i = p.nd - 1; i >= 1; --i) back_layer(p.dec[i].mb, p.dec[i].n, p.dec[i].k, p.dec[i - 1].y, p.dec[i - 1].act, nullptr, p.dec[i - 1].gpre);
+    for (int i = p.nd - 1 - (p.skip_dec_last ? 1 : 0); i >= 1; --i)
+        back_layer(p.dec[i].mb, p.dec[i].n, p.dec[i].k, p.dec[i - 1].y, p.dec[i - 1].act, nullptr, p.dec[i - 1].gpre);
     // dec[0]: its input is z (k = zdim, no activation; its backward matrix is zero-padded to a multiple of 4 columns)
     {
         const MidLayer l = p.dec[0];
@@ -387,8 +436,10 @@ __global__ __launch_bounds__(MID_T) void mid_backward_kernel(MidArgs p) {
         back_layer(p.hb, 2 * p.zdim, p.h, last.y, last.act, nullptr, last.gpre);
     }
     for (int i = p.ne - 1; i >= 1; --i) back_layer(p.enc[i].mb, p.enc[i].n, p.enc[i].k, p.enc[i - 1].y, p.enc[i - 1].act, nullptr, p.enc[i - 1].gpre);
-    back_layer(p.enc[0].mb, p.enc[0].n, p.enc[0].k, nullptr, 0, p.gate0, p.d_x0);
-    mid_amax<R>(cur, p.ld, p.enc[0].k, red, p.amax_out);
+    if (!p.skip_enc0) {          // (skipped: the tile GEMM multiplies enc[0]'s pre-activation gradient, stored just above)
+        back_layer(p.enc[0].mb, p.enc[0].n, p.enc[0].k, nullptr, 0, p.gate0, p.d_x0);
+        mid_amax<R>(cur, p.ld, p.enc[0].k, red, p.amax_out);
+    }
     mid_warm_done(warm);
 }
 
@@ -511,6 +562,8 @@ struct MidPlan {
     McArgs cl;
     size_t lds_bytes;
     int rows;                    // batch rows per workgroup: 8 when two row buffers of that height fit LDS beside the scratch, else 4
+    // round 6: wide layers on the tile GEMMs (dense.hip wide_gemm_x3_kernel): the block's first encoder layer / last decoder layer
+    bool wide_e, wide_d;
 };
 
 // fills the layer tables from the model description; y / gpre buffers are given per layer by the caller afterwards
@@ -558,6 +611,16 @@ static void mid_describe(const arvae_image_vae_t *m, const float *params, float 
     };
     for (int i = 0; i < ne; ++i) add(m->enc[m->n_enc - ne + i], a.enc[i]);
     for (int i = 0; i < nd; ++i) add(m->dec[i], a.dec[i]);
+    // Wide layers go to the tile GEMMs (not for the dSprites-shaped block: the clustered kernels take that one whole); they keep
+    // ONE prepared copy, mb = W'[n_mem][k_mem], which the GEMMs read both ways
+    {
+        static const bool no_wide = diag_env("ARVAE_MID_NO_WIDE") != nullptr;     // diagnostic build: every layer on the row kernels
+        const bool shape_ok = !no_wide && !midc_topology(m, ne, nd);
+        pl.wide_e = shape_ok && ne >= 1 && a.enc[0].k >= MID_WIDE_MIN && a.enc[0].k % 4 == 0 && a.enc[0].n % 4 == 0;
+        pl.wide_d = shape_ok && nd >= 2 && a.dec[nd - 1].n >= MID_WIDE_MIN && a.dec[nd - 1].k % 4 == 0 && a.dec[nd - 1].n % 4 == 0;
+        if (pl.wide_e) { a.enc[0].mf = nullptr; pl.prep.job[0].mf = nullptr; }
+        if (pl.wide_d) { a.dec[nd - 1].mf = nullptr; pl.prep.job[ne + nd - 1].mf = nullptr; }
+    }
     {   // the two heads as one [h] -> [2 zdim] layer
         const int h = m->head_mu.link.chi, z2 = 2 * m->zdim;
         float *hf = prep_ws + off, *hb = hf + ((int64_t)h * z2 + 3) / 4 * 4, *hbias = hb + ((int64_t)h * z2 + 3) / 4 * 4;
@@ -647,6 +710,32 @@ static void mid_describe(const arvae_image_vae_t *m, const float *params, float 
     pl.lds_bytes = (size_t)(2 * pl.rows * a.ld + mid_red(pl.rows) + pl.rows * 32) * sizeof(float);
 }
 
+// LDS row pitch and size for the layers a pass runs inside the row kernel (a wide layer the tile GEMMs took is not one of them)
+static void mid_size_lds(MidPlan &pl, bool skip_enc0, bool skip_dec_last) {
+    MidArgs &a = pl.args;
+    int maxw = max(a.h, 2 * a.zdim);
+    for (int i = 0; i < a.ne; ++i) {
+        if (!(i == 0 && skip_enc0)) maxw = max(maxw, a.enc[i].k);
+        maxw = max(maxw, a.enc[i].n);
+    }
+    for (int i = 0; i < a.nd; ++i) {
+        maxw = max(maxw, a.dec[i].k);
+        if (!(i == a.nd - 1 && skip_dec_last)) maxw = max(maxw, a.dec[i].n);
+    }
+    a.ld = ((maxw + 3) / 4) * 4 + 4;
+    pl.lds_bytes = (size_t)(2 * pl.rows * a.ld + mid_red(pl.rows) + pl.rows * 32) * sizeof(float);
+}
+
+// workspace of the split reductions the tile GEMMs leave for the row kernels: WIDE_MAX_SLICES partial products of the narrow side
+int64_t mid_wide_ws_floats(const arvae_image_vae_t *m, int batch) {
+    int ne, nd;
+    if (!mid_fusable(m, &ne, &nd) || midc_topology(m, ne, nd)) return 0;
+    int64_t w = 0;
+    if (ne >= 1 && m->enc[m->n_enc - ne].link.chi >= MID_WIDE_MIN) w = max(w, (int64_t)m->enc[m->n_enc - ne].link.clo);
+    if (nd >= 2 && m->dec[nd - 1].link.clo >= MID_WIDE_MIN) w = max(w, (int64_t)m->dec[nd - 1].link.chi);
+    return (int64_t)WIDE_MAX_SLICES * batch * w;
+}
+
 static void midc_common(McArgs &c, const MidArgs &a, int batch) {
     c.batch = batch;
     c.clusters = (batch + MC_R - 1) / MC_R;
@@ -686,10 +775,32 @@ void mid_prep_args(const arvae_image_vae_t *m, const float *params, float *prep_
 // (1) weight layout prep unless prep_done, (2) the forward block.  enc_y / dec_y: saved outputs of the block's layers.
 int mid_forward(const arvae_image_vae_t *m, int batch, const float *params, float *prep_ws, const float *x0, float *const *enc_y,
                 float *const *dec_y, const float *eps, float *mu, float *log_std, float *sigma, float *z, hipStream_t s, bool prep_done,
-                unsigned *amax_out, const MidFold *fold) {
+                unsigned *amax_out, const MidFold *fold, float *wide_ws) {
     MidPlan pl;
     mid_describe(m, params, prep_ws, pl, batch);
     MidArgs &a = pl.args;
+    // the wide layers' tile GEMMs (dense.hip): F1 = x0 . W'_e0^T as a split reduction this kernel's prologue finishes; F2 behind it
+    WideGemm f1{}, f2{};
+    int f1_slices = 1;
+    bool wide_e = pl.wide_e && wide_ws != nullptr, wide_d = pl.wide_d;
+    if (wide_e) {
+        const MidLayer &l = a.enc[0];
+        f1.a = x0; f1.lda = l.k; f1.b = l.mb; f1.ldb = l.kb; f1.b_krows = 0; f1.M = batch; f1.N = l.n; f1.K = l.k;
+        f1.out = wide_ws; f1.ldo = l.n; f1.slice_floats = (int64_t)batch * l.n;
+        f1_slices = wide_gemm_slices(batch, l.n, l.k);
+        wide_e = wide_gemm_fits(f1, f1_slices);
+    }
+    if (wide_d) {
+        const MidLayer &l = a.dec[a.nd - 1];
+        f2.a = dec_y[a.nd - 2]; f2.lda = l.k; f2.b = l.mb; f2.ldb = l.kb; f2.b_krows = 0; f2.M = batch; f2.N = l.n; f2.K = l.k;
+        f2.out = dec_y[a.nd - 1]; f2.ldo = l.n; f2.bias = l.bias; f2.act = l.act; f2.amax_out = amax_out;
+        wide_d = wide_gemm_fits(f2, 1);
+        if (!wide_d && amax_out != nullptr) { f2.amax_out = nullptr; wide_d = wide_gemm_fits(f2, 1); }   // (more tiles than AMAX entries: a launch of its own below)
+    }
+    ARVAE_REQUIRE((wide_e || !pl.wide_e) && (wide_d || !pl.wide_d), "mid_forward: a wide Linear layer the tile GEMM cannot take (alignment / size)");
+    a.skip_enc0 = wide_e; a.skip_dec_last = wide_d;
+    if (wide_e) { a.wide_partial = wide_ws; a.wide_slices = f1_slices; a.wide_slice_floats = f1.slice_floats; }
+    mid_size_lds(pl, wide_e, wide_d);
     // AMAX of the last output: one writer unit per workgroup when they fit the array, else a reduction launch of its own
     const bool amax_in_kernel = (batch + pl.rows - 1) / pl.rows <= AMAX_N;
     a.amax_out = amax_in_kernel ? amax_out : nullptr;
@@ -707,7 +818,7 @@ int mid_forward(const arvae_image_vae_t *m, int batch, const float *params, floa
         nw = 0;
         for (int i = 1; i < a.ne; ++i) { a.warm_ptr[nw] = a.enc[i].mf; a.warm_lines[nw++] = lines((int64_t)a.enc[i].k * a.enc[i].n); }
         a.warm_ptr[nw] = a.hf; a.warm_lines[nw++] = lines((int64_t)a.h * 2 * a.zdim);
-        for (int i = 0; i < a.nd; ++i) { a.warm_ptr[nw] = a.dec[i].mf; a.warm_lines[nw++] = lines((int64_t)a.dec[i].k * a.dec[i].n); }
+        for (int i = 0; i < a.nd - (wide_d ? 1 : 0); ++i) { a.warm_ptr[nw] = a.dec[i].mf; a.warm_lines[nw++] = lines((int64_t)a.dec[i].k * a.dec[i].n); }
         if (diag_env("ARVAE_MID_NO_WARM") != nullptr) nw = 0;
     }
     mid_allow_lds();
@@ -715,6 +826,8 @@ int mid_forward(const arvae_image_vae_t *m, int batch, const float *params, floa
         ARVAE_LAUNCH(mid_prep_kernel, dim3(mid_prep_blocks(pl.prep)), dim3(256), 0, s, pl.prep);
         if (int rc = check_launch("mid_prep_kernel")) return rc;
     }
+    if (wide_e)
+        if (int rc = wide_gemm(f1, f1_slices, true, s)) return rc;
     if (midc_use(pl.cluster, batch, m->flags)) {
         McArgs &c = pl.cl;
         midc_common(c, a, batch);
@@ -735,6 +848,11 @@ int mid_forward(const arvae_image_vae_t *m, int batch, const float *params, floa
     else if (pl.rows == 8) ARVAE_LAUNCH(mid_forward_kernel<8>, dim3((batch + 7) / 8), dim3(MID_T), pl.lds_bytes, s, a);
     else ARVAE_LAUNCH(mid_forward_kernel<4>, dim3((batch + 3) / 4), dim3(MID_T), pl.lds_bytes, s, a);
     if (int rc = check_launch("mid_forward_kernel")) return rc;
+    if (wide_d) {
+        if (int rc = wide_gemm(f2, 1, false, s)) return rc;
+        if (amax_out != nullptr && f2.amax_out == nullptr) return conv32_amax(dec_y[a.nd - 1], (int64_t)batch * a.dec[a.nd - 1].n, amax_out, s);
+        return ARVAE_OK;
+    }
     if (amax_out != nullptr && !amax_in_kernel) return conv32_amax(dec_y[a.nd - 1], (int64_t)batch * a.dec[a.nd - 1].n, amax_out, s);
     return ARVAE_OK;
 }
@@ -743,10 +861,34 @@ int mid_backward(const arvae_image_vae_t *m, int batch, const float *params, flo
                  float *const *enc_g, float *const *dec_g, const float *g_out, int g_is_pre, const float *gate0, float *d_x0,
                  const float *eps, const float *mu, const float *sigma, const float *dz_reg, const float *dz_extra, const float *g_loss,
                  const float *kl, const float *cap, float beta, float reg_scale, float *d_mu, float *d_ls, hipStream_t s,
-                 unsigned *amax_out, const MidFold *fold) {
+                 unsigned *amax_out, const MidFold *fold, float *wide_ws) {
     MidPlan pl;
     mid_describe(m, params, prep_ws, pl, batch);
     MidArgs &a = pl.args;
+    // the wide layers' data gradients on the tile GEMMs (dense.hip): B1 = g_last . W'_d(last) as a split reduction this kernel's
+    // prologue finishes (needs the gradient w.r.t. the last layer's PRE-activation: else that layer stays on the row kernel);
+    // B2 = enc[0]'s pre-activation gradient . W'_e0 behind this kernel
+    WideGemm b1{}, b2{};
+    int b1_slices = 1;
+    bool wide_d = pl.wide_d && wide_ws != nullptr && g_is_pre, wide_e = pl.wide_e;
+    if (wide_d) {
+        const MidLayer &l = a.dec[a.nd - 1];
+        b1.a = g_out; b1.lda = l.n; b1.b = l.mb; b1.ldb = l.kb; b1.b_krows = 1; b1.M = batch; b1.N = l.k; b1.K = l.n;
+        b1.out = wide_ws; b1.ldo = l.k; b1.slice_floats = (int64_t)batch * l.k;
+        b1_slices = wide_gemm_slices(batch, l.k, l.n);
+        wide_d = wide_gemm_fits(b1, b1_slices);
+    }
+    if (wide_e) {
+        const MidLayer &l = a.enc[0];
+        b2.a = enc_g[0]; b2.lda = l.n; b2.b = l.mb; b2.ldb = l.kb; b2.b_krows = 1; b2.M = batch; b2.N = l.k; b2.K = l.n;
+        b2.out = d_x0; b2.ldo = l.k; b2.act = ARVAE_ACT_NONE; b2.gate = gate0; b2.amax_out = amax_out;
+        wide_e = wide_gemm_fits(b2, 1);
+        if (!wide_e && amax_out != nullptr) { b2.amax_out = nullptr; wide_e = wide_gemm_fits(b2, 1); }
+    }
+    ARVAE_REQUIRE(wide_e || !pl.wide_e, "mid_backward: a wide Linear layer the tile GEMM cannot take (alignment / size)");
+    a.skip_enc0 = wide_e; a.skip_dec_last = wide_d;
+    if (wide_d) { a.wide_partial = wide_ws; a.wide_slices = b1_slices; a.wide_slice_floats = b1.slice_floats; }
+    mid_size_lds(pl, wide_e, wide_d);
     const bool amax_in_kernel = (batch + pl.rows - 1) / pl.rows <= AMAX_N;
     a.amax_out = amax_in_kernel ? amax_out : nullptr;
     for (int i = 0; i < a.ne; ++i) { a.enc[i].y = enc_y[i]; a.enc[i].gpre = enc_g[i]; }
@@ -761,12 +903,14 @@ int mid_backward(const arvae_image_vae_t *m, int batch, const float *params, flo
         auto lines = [](int64_t floats) { return (int)((floats + 31) / 32); };
         int &nw = a.n_warm;
         nw = 0;
-        for (int i = a.nd - 2; i >= 0; --i) { a.warm_ptr[nw] = a.dec[i].mb; a.warm_lines[nw++] = lines((int64_t)a.dec[i].kb * a.dec[i].n); }
+        for (int i = a.nd - 2 - (wide_d ? 1 : 0); i >= 0; --i) { a.warm_ptr[nw] = a.dec[i].mb; a.warm_lines[nw++] = lines((int64_t)a.dec[i].kb * a.dec[i].n); }
         a.warm_ptr[nw] = a.hb; a.warm_lines[nw++] = lines((int64_t)a.h * 2 * a.zdim);
-        for (int i = a.ne - 1; i >= 0; --i) { a.warm_ptr[nw] = a.enc[i].mb; a.warm_lines[nw++] = lines((int64_t)a.enc[i].kb * a.enc[i].n); }
+        for (int i = a.ne - 1; i >= (wide_e ? 1 : 0); --i) { a.warm_ptr[nw] = a.enc[i].mb; a.warm_lines[nw++] = lines((int64_t)a.enc[i].kb * a.enc[i].n); }
         if (diag_env("ARVAE_MID_NO_WARM") != nullptr) nw = 0;
     }
     mid_allow_lds();
+    if (wide_d)
+        if (int rc = wide_gemm(b1, b1_slices, true, s)) return rc;
     if (midc_use(pl.cluster, batch, m->flags)) {
         McArgs &c = pl.cl;
         midc_common(c, a, batch);
@@ -789,6 +933,11 @@ int mid_backward(const arvae_image_vae_t *m, int batch, const float *params, flo
     else if (pl.rows == 8) ARVAE_LAUNCH(mid_backward_kernel<8>, dim3((batch + 7) / 8), dim3(MID_T), pl.lds_bytes, s, a);
     else ARVAE_LAUNCH(mid_backward_kernel<4>, dim3((batch + 3) / 4), dim3(MID_T), pl.lds_bytes, s, a);
     if (int rc = check_launch("mid_backward_kernel")) return rc;
+    if (wide_e) {
+        if (int rc = wide_gemm(b2, 1, false, s)) return rc;
+        if (amax_out != nullptr && b2.amax_out == nullptr) return conv32_amax(d_x0, (int64_t)batch * a.enc[0].k, amax_out, s);
+        return ARVAE_OK;
+    }
     if (amax_out != nullptr && !amax_in_kernel) return conv32_amax(d_x0, (int64_t)batch * a.enc[0].k, amax_out, s);
     return ARVAE_OK;
 }

@@ -95,12 +95,13 @@ __device__ __forceinline__ void mid_prep_block(const MidPrepArgs &a, int block) 
         return (p.w2 != nullptr && nf >= p.nsplit) ? p.w2[(int64_t)(nf - p.nsplit) * p.k + kf] : p.w[(int64_t)nf * p.k + kf];
     };
     // (a job carries the row-kernel layouts mf / mb or the cluster layouts cf / cb, whichever kernels will run: never both)
-    for (int e = (block - start) * 256 + threadIdx.x; e < (p.mf != nullptr ? total : p.n); e += stride) {
-        if (p.mf != nullptr) {
-            if (e < p.k * p.n) {
-                const int km = e / p.n, nm = e - km * p.n;        // forward matrix [k][n], written in order
-                p.mf[e] = src(p.np.to_feat(nm), p.kp.to_feat(km));
-            }
+    // (mb alone: a wide layer the tile GEMMs multiply -- dense.hip wide_gemm_x3_kernel reads the one [n][kb] copy both ways)
+    for (int e = (block - start) * 256 + threadIdx.x; e < (p.mb != nullptr ? total : p.n); e += stride) {
+        if (p.mf != nullptr && e < p.k * p.n) {
+            const int km = e / p.n, nm = e - km * p.n;            // forward matrix [k][n], written in order
+            p.mf[e] = src(p.np.to_feat(nm), p.kp.to_feat(km));
+        }
+        if (p.mb != nullptr) {
             const int nm2 = e / p.kb, km2 = e - nm2 * p.kb;      // backward matrix [n][kb], written in order
             p.mb[e] = km2 < p.k ? src(p.np.to_feat(nm2), p.kp.to_feat(km2)) : 0.f;
         }

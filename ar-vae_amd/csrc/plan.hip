@@ -90,7 +90,8 @@ bool mid_fusable(const arvae_image_vae_t *m, int *ne_out, int *nd_out);
 int64_t mid_prep_floats(const arvae_image_vae_t *m);
 int mid_forward(const arvae_image_vae_t *m, int batch, const float *params, float *prep_ws, const float *x0, float *const *enc_y,
                 float *const *dec_y, const float *eps, float *mu, float *log_std, float *sigma, float *z, hipStream_t s, bool prep_done,
-                unsigned *amax_out, const MidFold *fold);
+                unsigned *amax_out, const MidFold *fold, float *wide_ws);
+int64_t mid_wide_ws_floats(const arvae_image_vae_t *m, int batch);      // split-reduction workspace of the wide layers' tile GEMMs
 // the conv layers on either side of the latent block computed by the block's clustered kernels (midblock.hip)
 bool mid_fold_fits(const arvae_image_vae_t *m, int batch);
 int64_t mid_fold_slab_floats(const arvae_image_vae_t *m, int batch);
@@ -98,7 +99,7 @@ int mid_backward(const arvae_image_vae_t *m, int batch, const float *params, flo
                  float *const *enc_g, float *const *dec_g, const float *g_out, int g_is_pre, const float *gate0, float *d_x0,
                  const float *eps, const float *mu, const float *sigma, const float *dz_reg, const float *dz_extra, const float *g_loss,
                  const float *kl, const float *cap, float beta, float reg_scale, float *d_mu, float *d_ls, hipStream_t s,
-                 unsigned *amax_out, const MidFold *fold);
+                 unsigned *amax_out, const MidFold *fold, float *wide_ws);
 
 // loss-term pieces (losses.hip)
 int recon_partials(const float *logits, const float *x, int64_t count, int64_t batch, int32_t dist, float *ws,
@@ -174,7 +175,7 @@ struct Layout {
     // without (the image, or what a kernel outside the conv32 / conv_c1 / latent-block family wrote)
     int64_t enc_amax[ARVAE_MAX_LAYERS], dec_amax[ARVAE_MAX_LAYERS], enc_gamax[ARVAE_MAX_LAYERS], dec_gamax[ARVAE_MAX_LAYERS];
     int64_t ga_amax, gb_amax, tmp_amax, tmp2_amax;
-    int64_t log_std, dlogits, dz_reg, d_mu, d_ls, g_a, g_b, slab, link_ws, mid_prep, rec_ws, reg_ws, rec_out, kld_out, reg_out, total;
+    int64_t log_std, dlogits, dz_reg, d_mu, d_ls, g_a, g_b, slab, link_ws, mid_prep, mid_wide, rec_ws, reg_ws, rec_out, kld_out, reg_out, total;
     int64_t slab_floats;
 };
 
@@ -260,6 +261,10 @@ static int make_layout(const arvae_image_vae_t *m, int64_t n, int64_t n_cols, La
     L.slab = take(slab);
     L.link_ws = take(lws);               // scratch of one arvae_link_down / _up call at a time (stream-ordered)
     L.mid_prep = take(mid_prep_floats(m));   // the latent block's matrices in the layout its kernels stream (midblock.hip)
+    {
+        const int64_t w = mid_wide_ws_floats(m, (int)n);     // partial products of the wide Linear layers' split reductions (dense.hip)
+        L.mid_wide = w > 0 ? take(w) : -1;
+    }
     L.rec_ws = take(arvae_recon_ws_floats(out_elems(m->dec[m->n_dec - 1], n)));
     L.reg_ws = take(arvae_reg_loss_ws_floats(n, m->n_reg > 0 ? m->n_reg : 1));
     L.rec_out = take(4);
@@ -619,7 +624,8 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
             mf.hi_d_amax = U(L.dec_amax[mid_nd]);
         }
         if (int rc = mid_forward(m, batch, params, ws + L.mid_prep, fold ? ws + L.enc_out[m->n_enc - mid_ne - 1] : h, enc_y, dec_y, eps, mu,
-                                 ws + L.log_std, sigma, z, st, mid_prepped, U(L.dec_amax[mid_nd - 1]), fold ? &mf : nullptr))
+                                 ws + L.log_std, sigma, z, st, mid_prepped, U(L.dec_amax[mid_nd - 1]), fold ? &mf : nullptr,
+                                 L.mid_wide >= 0 ? ws + L.mid_wide : nullptr))
             return rc;
         h = fold ? ws + L.dec_out[mid_nd] : dec_y[mid_nd - 1];
         h_amax = fold ? U(L.dec_amax[mid_nd]) : U(L.dec_amax[mid_nd - 1]);
@@ -907,7 +913,7 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
         }
         if (int rc = mid_backward(m, batch, params, ws + L.mid_prep, enc_y, dec_y, enc_g, dec_g, g_last, (pre || fold) ? 1 : 0, gate0, d_x0, eps,
                                   mu, sigma, dz_reg, dz_extra, g_loss, ws + L.kld_out + 1, capacity, m->beta, reg_scale, ws + L.d_mu,
-                                  ws + L.d_ls, st, grad_amax(d_x0), fold ? &mf : nullptr))
+                                  ws + L.d_ls, st, grad_amax(d_x0), fold ? &mf : nullptr, L.mid_wide >= 0 ? ws + L.mid_wide : nullptr))
             return rc;
         if (fold) {                                          // the two layers' weight-gradient slabs: one per workgroup of the block's grid
             const int n_wg = (batch + 31) / 32;                  // one slab of sixteen tap blocks per cluster (reduce.h, SLAB_C32T)
