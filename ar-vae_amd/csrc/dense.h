@@ -34,19 +34,38 @@ struct DenseWgradBatch {
 };
 
 // C[M][N] = sum_k A[m][k] B(k, n) on the three-term bf16 MFMA, 64 x 64 tiles (dense.hip, wide_gemm_x3_kernel): the wide Linear
-// layers of the latent block.  A: [M][lda] (k contiguous).  B: b_krows == 0: [N][ldb] (k contiguous); b_krows == 1: [K][ldb] (n contiguous).
+// layers of the latent block.  A: fp32 [M][lda] (k contiguous), or (a_planes) its three bf16 terms as planes [3][M][lda] that are
+// a_pstride elements apart.  B: ALWAYS planes, b_pstride apart, zero-padded along the reduction axis to a multiple of 32:
+// b_krows == 0: [N][ldb] (k contiguous); b_krows == 1: [K][ldb] (n contiguous) -- the same copy read the other way.
 constexpr int WIDE_MAX_SLICES = 16;
 struct WideGemm {
-    const float *a, *b;
-    int64_t lda, ldb;
-    int M, N, K, kslice, b_krows;
+    const void *a, *b;
+    int64_t lda, ldb, a_pstride, b_pstride;
+    int M, N, K, kslice, a_planes, b_planes, b_krows;
     float *out;                 // finished: [M][ldo]; split: workspace, slice z at out + z * slice_floats
     int64_t ldo, slice_floats;
     const float *bias;          // finished: per output column, may be null
     int act;                    // finished: activation (ARVAE_ACT_*)
     const float *gate;          // finished: optional ReLU gate: out = gate[m][n] > 0 ? value : 0
     unsigned *amax_out;         // finished: AMAX array of the result (conv32_common.h), may be null
+    int dbg;                    // tools/probes/wide_gemm.py only (0 in the product): 1 no MFMAs, 2 no LDS commits, 4 no result stores
 };
+// dW'[p][q] (+)= sum_m A(p, m) B(q, m), operands [batch][features] ("K x rows"), exactly one of them as bf16 planes; rows / columns
+// of dW' land at p_perm / q_perm.to_feat(.) of the [rows][ldw] gradient; dbias (may be null) += row sums of A
+struct WideWgradJob {
+    const void *a, *b;
+    int64_t lda, ldb, a_pstride, b_pstride;
+    int a_planes, b_planes, P, Q, R;
+    float *dw, *dbias;
+    int64_t ldw;
+    Perm p_perm, q_perm;
+};
+struct WideWgradBatch {
+    int count, wg_end[2];
+    WideWgradJob job[2];
+};
+bool wide_wgrad_fits(const WideWgradJob &j);
+int wide_wgrad(const WideWgradJob *jobs, int count, hipStream_t s);
 int wide_gemm_slices(int M, int N, int K);
 bool wide_gemm_fits(const WideGemm &g, int slices);
 int wide_gemm(WideGemm g, int slices, bool partial, hipStream_t s);

@@ -521,52 +521,196 @@ __global__ __launch_bounds__(256) void rows_gemm_x3_kernel(RowsGemm g) {
 //     activation or ReLU gate, the tensor's AMAX entry for the conv kernel that reads it next).
 enum { WG_EP_PARTIAL = 0, WG_EP_FULL = 1 };
 constexpr int WG_DEPTH = 3;
-template <int LB>
-struct WideLds {
-    typedef TileLoader<RG_ROWSK, 64, true> LoadA;
-    typedef TileLoader<LB, 64, true> LoadB;
-    static constexpr int BUF = 3 * LoadA::PLANE + 3 * LoadB::PLANE;         // unsigned shorts per buffer
-    static constexpr size_t BYTES = (size_t)2 * BUF * sizeof(unsigned short) + 64;
+#ifndef ARVAE_WG_SINGLE
+#define ARVAE_WG_SINGLE 1
+#endif
+constexpr int WG_NBUF = ARVAE_WG_SINGLE ? 1 : 2;     // LDS buffers of the 64-tile kernels (128-tile: always 2)
+// Operand sources (T = tile extent along the operand's output axis, 64 or 128).  WideF32: an fp32 matrix, split into the three bf16
+// terms on its way to LDS (TileLoader: ~11 vector instructions per value pair).  WidePlanes: the three bf16 planes already in
+// memory -- the weights (mid_prep writes them once per step) and the small activations that dozens of tiles re-read (the latent
+// block's kernels write them beside the fp32 tensors): 16 bytes per plane and load straight into the LDS image, no vector ALU work.
+template <int LAY, int T_>
+struct WideF32 {
+    static constexpr int T = T_;
+    typedef X3Plane<LAY, T> Plane;
+    typedef TileLoader<LAY, T, true> Loader;
+    struct Regs { Loader t; };
+    const float *base;
+    int64_t ld;
+    int p0, pmax;
+    __device__ __forceinline__ void init(const void *b, int64_t ld_, int64_t, int p0_, int pmax_) { base = static_cast<const float *>(b); ld = ld_; p0 = p0_; pmax = pmax_; }
+    __device__ __forceinline__ void load(Regs &r, int r0, int rend) const { r.t.load(base, ld, p0, pmax, r0, rend); }
+    __device__ __forceinline__ void commit(const Regs &r, unsigned short *lds) const { r.t.commit3(lds); }
+    __device__ __forceinline__ void keep(const Regs &r) const {
+#pragma unroll
+        for (int i = 0; i < Loader::NV; ++i) asm volatile("" ::"v"(r.t.v[i].x), "v"(r.t.v[i].w));
+    }
 };
-template <int LB, int EP>
-__global__ __launch_bounds__(256, 2) void wide_gemm_x3_kernel(WideGemm g) {
-    typedef typename WideLds<LB>::LoadA LoadA;
-    typedef typename WideLds<LB>::LoadB LoadB;
-    constexpr int BUF = WideLds<LB>::BUF;
-    extern __shared__ __attribute__((aligned(16))) unsigned short wlds[];
-    const int lane = threadIdx.x & 63, half = lane >> 5, rc = lane & 31;
+template <int LAY, int T_>
+struct WidePlanes {
+    static constexpr int T = T_;
+    typedef X3Plane<LAY, T> Plane;
+    static constexpr int NV = T / 64;                            // 16-byte units per plane and thread: T x 32 bf16 = 256 x NV x 8
+    struct Regs { uint4 v[NV][3]; };
+    __amdgpu_buffer_rsrc_t rs;
+    unsigned voff[NV];
+    int lds_off[NV], rloc[NV], ld2, ps2;
+    // Planes in the TILED layout [3][K / 32][rows][32] of bf16 (x3tile.h x3_tiled_index), `pstride` elements apart, K zero-padded to
+    // whole chunks: the 32 x (rows) block of one chunk is contiguous, so a wave's load is whole cache lines whichever axis is the
+    // reduction -- "rows x K" (reduce along K: chunk c = block c, 64 bytes per row, rows adjacent) or "K x rows" (reduce along the
+    // rows: 32 consecutive rows of one K block are 2 KB).  (Row-major planes made every request half a line: 13 TB/s of L2 -> LDS,
+    // tools/probes/wide_gemm.py.)  `rows_` = the row count of the planes.
+    __device__ __forceinline__ void init(const void *b, int64_t rows_, int64_t pstride, int p0_, int pmax_) {
+        rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(b), 0, 0x7fffffff, 0x00020000);
+        ld2 = (int)rows_ * 64;                                   // bytes of one K block of all rows
+        ps2 = (int)(pstride * 2);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int u = threadIdx.x + 256 * i;
+            bool ok;
+            unsigned off;
+            if (LAY == RG_ROWSK) {                               // unit = (row u / 4, reduction indices 8 (u % 4) ..): chunk = K block
+                const int row = u >> 2, kg = u & 3;
+                rloc[i] = 0;
+                ok = p0_ + row < pmax_;
+                off = (unsigned)(((p0_ + row) * 32 + 8 * kg) * 2);
+                lds_off[i] = row * RG_XP + 8 * kg;
+            } else {                                             // unit = (reduction row u / (T / 8), outputs 8 (u % (T / 8)) ..)
+                const int r = u / (T / 8), qg = u % (T / 8);
+                const int q = p0_ + 8 * qg;
+                rloc[i] = r;
+                ok = q < pmax_;
+                off = (unsigned)((q >> 5) * ld2 + (r * 32 + (q & 31)) * 2);
+                lds_off[i] = r * Plane::TRP + 8 * qg;
+            }
+            voff[i] = ok ? off : 0xfffffff0u;
+        }
+    }
+    // (a chunk at or past `rend` reads zeros: the loop multiplies whole rounds of three chunks without a branch; "K x rows": this
+    // unit's reduction row must exist too -- activations' planes are not padded along the batch)
+    __device__ __forceinline__ void load(Regs &r, int r0, int rend) const {
+        const int so = r0 < rend ? (LAY == RG_ROWSK ? (r0 >> 5) * ld2 : r0 * 64) : 0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const bool in = LAY == RG_ROWSK ? r0 < rend : r0 + rloc[i] < rend;
+            const unsigned vo = in ? voff[i] : 0xfffffff0u;
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+                r.v[i][t] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(vo == 0xfffffff0u ? vo : vo + (unsigned)(t * ps2)), so, 0));
+        }
+    }
+    __device__ __forceinline__ void commit(const Regs &r, unsigned short *lds) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) *reinterpret_cast<uint4 *>(lds + t * Plane::PLANE + lds_off[i]) = r.v[i][t];
+    }
+    __device__ __forceinline__ void keep(const Regs &r) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) asm volatile("" ::"v"(r.v[i][t].x), "v"(r.v[i][t].w));
+    }
+};
+template <class SA, class SB>
+struct WideLds {
+    static constexpr int BUF = 3 * SA::Plane::PLANE + 3 * SB::Plane::PLANE;      // unsigned shorts per buffer
+    static constexpr int NBUF = SA::T == 128 ? 2 : WG_NBUF;
+    static constexpr size_t BYTES = (size_t)NBUF * BUF * sizeof(unsigned short) + 2048;    // + the bias-sum / AMAX scratch
+};
+// acc[a][b] = sum over the reduction range [rbeg, rend) of A(p, r) B(q, r) for this wave's NT x NT MFMA tiles of the workgroup's
+// (64 NT) x (64 NT) tile: wave (wp, wq) owns rows 32 (NT wp + a) .., columns 32 (NT wq + b) ...
+// BSUM (A "K x rows"): bsum = this thread's share of sum_r A(p0 + threadIdx.x % T, r) (r = its group's rows of every chunk; the
+// caller adds the 256 / T groups), the three terms re-added exactly.
+template <class SA, class SB, bool BSUM, int NT>
+__device__ __forceinline__ void wide_mainloop(const void *a, int64_t lda, int64_t a_pstride, int P, const void *b, int64_t ldb, int64_t b_pstride,
+                                              int Q, int p0, int q0, int rbeg, int rend, unsigned short *wlds, f32x16 (&acc)[NT][NT], float &bsum,
+                                              const int dbg = 0) {
+    typedef typename SA::Plane PA;
+    typedef typename SB::Plane PB;
+    constexpr int BUF = WideLds<SA, SB>::BUF, NBUF = WideLds<SA, SB>::NBUF, T = 64 * NT;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int p0 = blockIdx.x * 64, q0 = blockIdx.y * 64;
-    const int rbeg = blockIdx.z * g.kslice, rend = min(g.K, rbeg + g.kslice);
     const int nchunks = (rend - rbeg + RG_R - 1) / RG_R;
     const int wp = wave & 1, wq = wave >> 1;
-    f32x16 acc;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    LoadA la[WG_DEPTH];
-    LoadB lb[WG_DEPTH];
-    // chunk c -> register set c % 3; a chunk past the end re-reads the last one (unconditional loads: exact vmcnt counts) and is
-    // never multiplied
+    for (int x = 0; x < NT; ++x)
+#pragma unroll
+        for (int y = 0; y < NT; ++y)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[x][y][i] = 0.f;
+    SA sa;
+    SB sb;
+    sa.init(a, lda, a_pstride, p0, P);
+    sb.init(b, ldb, b_pstride, q0, Q);
+    typename SA::Regs ra[WG_DEPTH];
+    typename SB::Regs rb[WG_DEPTH];
+    // chunk c -> register set c % 3.  Chunks at or past the end of the slice load zeros (lane offsets beyond the buffer range), so
+    // the loop runs whole rounds of three chunks with NO branch inside: every s_waitcnt vmcnt in it is exact.  (With a `break`
+    // per step the loop header merged three exits and the first commit of every round drained the whole memory queue -- a full
+    // round trip per three chunks.)
     auto issue = [&](auto dc, int c) __attribute__((always_inline)) {
         constexpr int d = decltype(dc)::value;
-        const int r0 = rbeg + RG_R * min(c, nchunks - 1);
-        la[d].load(g.a, g.lda, p0, g.M, r0, rend);
-        lb[d].load(g.b, g.ldb, q0, g.N, r0, rend);
+        const int r0 = rbeg + RG_R * c;
+        sa.load(ra[d], r0 < rend ? r0 : rend, rend);
+        sb.load(rb[d], r0 < rend ? r0 : rend, rend);
     };
     auto commit = [&](auto dc, int c) __attribute__((always_inline)) {
         constexpr int d = decltype(dc)::value;
-        unsigned short *buf = wlds + (c & 1) * BUF;
-        la[d].commit3(buf);
-        lb[d].commit3(buf + 3 * LoadA::PLANE);
+        unsigned short *buf = wlds + (NBUF == 2 ? (c & 1) * BUF : 0);
+        if (dbg & 2) { sa.keep(ra[d]); sb.keep(rb[d]); return; }
+        sa.commit(ra[d], buf);
+        sb.commit(rb[d], buf + 3 * PA::PLANE);
     };
-    const int abase = LoadA::lane_base(wp), bbase = LoadB::lane_base(wq);
+    int abase[NT], bbase[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) { abase[i] = PA::lane_base(NT * wp + i); bbase[i] = PB::lane_base(NT * wq + i); }
+    // One MFMA tile per wave (NT = 1): two accumulators -- the three small products and the three large ones of a k-step go to
+    // different registers (an MFMA into the result of the previous one waits for it), summed once at the end.  Four tiles
+    // (NT = 2): product-major over the tiles, consecutive MFMAs never meet.  All operand reads of a k-step are requested before
+    // its first MFMA.
+    f32x16 acc2;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc2[i] = 0.f;
     auto multiply = [&](int c) __attribute__((always_inline)) {
-        const unsigned short *As = wlds + (c & 1) * BUF, *Bs = As + 3 * LoadA::PLANE;
+        const unsigned short *As = wlds + (NBUF == 2 ? (c & 1) * BUF : 0), *Bs = As + 3 * PA::PLANE;
+        if (dbg & 1) return;
 #pragma unroll
         for (int s = 0; s < RG_R / 16; ++s) {
-            const rg_bf16x8 ah = LoadA::operand(As, abase, 0, s), am = LoadA::operand(As, abase, 1, s), al = LoadA::operand(As, abase, 2, s);
-            const rg_bf16x8 bh = LoadB::operand(Bs, bbase, 0, s), bm = LoadB::operand(Bs, bbase, 1, s), bl = LoadB::operand(Bs, bbase, 2, s);
-            X3_MFMA6(acc, ah, am, al, bh, bm, bl);
+            rg_bf16x8 a3[NT][3], b3[NT][3];
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) { a3[i][t] = PA::operand(As, abase[i], t, s); b3[i][t] = PB::operand(Bs, bbase[i], t, s); }
+            if (NT == 1) {
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0][2], b3[0][0], acc2, 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0][1], b3[0][0], acc[0][0], 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0][0], b3[0][2], acc2, 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0][0], b3[0][1], acc[0][0], 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0][1], b3[0][1], acc2, 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0][0], b3[0][0], acc[0][0], 0, 0, 0);
+            } else {
+                // (a term, b term) of the six products, smallest first: (l, h) (h, l) (m, m) (m, h) (h, m) (h, h)
+#pragma unroll
+                for (int prod = 0; prod < 6; ++prod)
+#pragma unroll
+                    for (int x = 0; x < NT; ++x)
+#pragma unroll
+                        for (int y = 0; y < NT; ++y) {
+                            const int ta = prod == 0 ? 2 : ((prod == 2 || prod == 3) ? 1 : 0);
+                            const int tb = prod == 1 ? 2 : ((prod == 2 || prod == 4) ? 1 : 0);
+                            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[x][ta], b3[y][tb], acc[x][y], 0, 0, 0);
+                        }
+            }
+        }
+        if (BSUM) {                                              // 256 / T thread groups share a chunk's 32 reduction rows
+            constexpr int G = 256 / T, RPG = RG_R / G;
+            const int pp = threadIdx.x % T, r_lo = (threadIdx.x / T) * RPG;
+#pragma unroll
+            for (int r = 0; r < RPG; ++r) {
+                const unsigned short *e = As + (r_lo + r) * PA::TRP + pp;
+                bsum += (__builtin_bit_cast(float, (unsigned)e[0] << 16) + __builtin_bit_cast(float, (unsigned)e[PA::PLANE] << 16)) +
+                        __builtin_bit_cast(float, (unsigned)e[2 * PA::PLANE] << 16);
+            }
         }
     };
     using D0 = std::integral_constant<int, 0>;
@@ -579,42 +723,76 @@ __global__ __launch_bounds__(256, 2) void wide_gemm_x3_kernel(WideGemm g) {
     issue(D0{}, 3);
     __syncthreads();
     // chunk c is multiplied from buffer c & 1; meanwhile chunk c + 1 (register set (c + 1) % 3) goes to the other buffer and its set
-    // is refilled with chunk c + 4
+    // is refilled with chunk c + 4.  (One LDS buffer: a second barrier between the multiply and the commit; the workgroup is then
+    // 32 KB and four or five share a CU -- each other's loads, splits, MFMAs and stores overlap across workgroups instead.)
 #define ARVAE_WG_STEP(D, DN)                                     \
-        if (c + D >= nchunks) break;                             \
         multiply(c + D);                                         \
+        if (NBUF == 1) __syncthreads();                          \
         commit(DN{}, c + D + 1);                                 \
         issue(DN{}, c + D + 4);                                  \
         __syncthreads();
-    for (int c = 0;; c += WG_DEPTH) {
+    for (int c = 0; c < nchunks; c += WG_DEPTH) {
         ARVAE_WG_STEP(0, D1)
         ARVAE_WG_STEP(1, D2)
         ARVAE_WG_STEP(2, D0)
     }
 #undef ARVAE_WG_STEP
-    const int q = q0 + 32 * wq + rc;
-    if (EP == WG_EP_PARTIAL) {
-        float *out = g.out + (int64_t)blockIdx.z * g.slice_floats;
+    if (NT == 1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int p = p0 + 32 * wp + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (p < g.M && q < g.N) out[(int64_t)p * g.ldo + q] = acc[r];
-        }
-        return;
+        for (int i = 0; i < 16; ++i) acc[0][0][i] += acc2[i];
     }
-    const float bias = (g.bias != nullptr && q < g.N) ? g.bias[q] : 0.f;
+}
+
+template <class SA, class SB, int EP, int NT>
+__global__ __launch_bounds__(256, NT == 1 ? (WG_NBUF == 1 ? 3 : 2) : 1) void wide_gemm_x3_kernel(WideGemm g) {
+    constexpr int BUF = WideLds<SA, SB>::BUF, NBUF = WideLds<SA, SB>::NBUF, T = 64 * NT;
+    extern __shared__ __attribute__((aligned(16))) unsigned short wlds[];
+    const int lane = threadIdx.x & 63, half = lane >> 5, rc = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p0 = blockIdx.x * T, q0 = blockIdx.y * T;
+    const int rbeg = blockIdx.z * g.kslice, rend = min(g.K, rbeg + g.kslice);
+    const int wp = wave & 1, wq = wave >> 1;
+    f32x16 acc[NT][NT];
+    float unused = 0.f;
+    wide_mainloop<SA, SB, false, NT>(g.a, g.lda, g.a_pstride, g.M, g.b, g.ldb, g.b_pstride, g.N, p0, q0, rbeg, rend, wlds, acc, unused, g.dbg);
+    if (g.dbg & 4) { if (acc[0][0][0] == 123.456f) g.out[0] = acc[0][0][1]; return; }
     float amax = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int p = p0 + 32 * wp + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const bool ok = p < g.M && q < g.N;
-        const int64_t idx = (int64_t)(ok ? p : 0) * g.ldo + (ok ? q : 0);
-        float v = act_fwd(acc[r] + bias, g.act);
-        if (g.gate != nullptr) v = g.gate[idx] > 0.f ? v : 0.f;
-        if (ok) { g.out[idx] = v; amax = fmaxf(amax, fabsf(v)); }
+    for (int y = 0; y < NT; ++y) {
+        const int q = q0 + 32 * (NT * wq + y) + rc;
+        const float bias = (EP == WG_EP_FULL && g.bias != nullptr && q < g.N) ? g.bias[q] : 0.f;
+#pragma unroll
+        for (int x = 0; x < NT; ++x) {
+            if (EP == WG_EP_PARTIAL) {
+                float *out = g.out + (int64_t)blockIdx.z * g.slice_floats;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int p = p0 + 32 * (NT * wp + x) + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (p < g.M && q < g.N) out[(int64_t)p * g.ldo + q] = acc[x][y][r];
+                }
+            } else {
+                float gatev[16];
+                if (g.gate != nullptr) {                         // (all sixteen requested before the first is used)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int p = p0 + 32 * (NT * wp + x) + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        const bool ok = p < g.M && q < g.N;
+                        gatev[r] = g.gate[(int64_t)(ok ? p : 0) * g.ldo + (ok ? q : 0)];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int p = p0 + 32 * (NT * wp + x) + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const bool ok = p < g.M && q < g.N;
+                    float v = act_fwd(acc[x][y][r] + bias, g.act);
+                    if (g.gate != nullptr) v = gatev[r] > 0.f ? v : 0.f;
+                    if (ok) { g.out[(int64_t)p * g.ldo + q] = v; amax = fmaxf(amax, fabsf(v)); }
+                }
+            }
+        }
     }
-    if (g.amax_out != nullptr) {                                 // one AMAX writer unit per workgroup (conv32_common.h)
-        float *red = reinterpret_cast<float *>(wlds + 2 * BUF);
+    if (EP == WG_EP_FULL && g.amax_out != nullptr) {             // one AMAX writer unit per workgroup (conv32_common.h)
+        float *red = reinterpret_cast<float *>(wlds + NBUF * BUF);
         amax = wave_max(amax);
         __syncthreads();
         if (lane == 0) red[wave] = amax;
@@ -627,21 +805,163 @@ __global__ __launch_bounds__(256, 2) void wide_gemm_x3_kernel(WideGemm g) {
     }
 }
 
-// K slices that fill the chip: tiles x slices ~ two workgroups per CU, a slice at least four chunks long
+// The wide layers' WEIGHT gradients on the same main loop:  dW'[p][q] = sum over the batch of A(p, m) B(q, m), both operands
+// "K x rows" (activations / gradients are [batch][features]: the batch is the reduction axis), one of them arriving as planes (the
+// small one: the latent block's kernels wrote it pre-split), the other fp32.  A tile adds into dW at the permuted place of its
+// rows / columns (the gradient arena holds the reference's [n][k] layout in feature order) and, for its first column tile, the
+// bias gradient = A's row sums.  Replaces the two largest jobs of the grouped 32 x 32-tile launch (dense_wgrad_batch_kernel:
+// ~1450 of its tiles, ~50 of its 58 us at B = 1024).
+template <class SA, class SB>
+__device__ __forceinline__ void wide_wgrad_tile(const WideWgradJob &j, int tile, unsigned short *wlds) {
+    constexpr int BUF = WideLds<SA, SB>::BUF, NBUF = WideLds<SA, SB>::NBUF;
+    const int tp = (j.P + 63) / 64;
+    const int bx = tile % tp, by = tile / tp;
+    const int lane = threadIdx.x & 63, half = lane >> 5, rc = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wp = wave & 1, wq = wave >> 1;
+    const int p0 = bx * 64, q0 = by * 64;
+    const int q = q0 + 32 * wq + rc;
+    const bool qok = q < j.Q;
+    const int qf = j.q_perm.to_feat(qok ? q : 0);
+    // this lane's 16 elements of dW: requested now, added to after the reduction
+    float *outp[16];
+    float old[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int p = p0 + 32 * wp + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const bool ok = qok && p < j.P;
+        outp[r] = j.dw + (ok ? (int64_t)j.p_perm.to_feat(p) * j.ldw + qf : 0);
+        old[r] = *outp[r];
+    }
+    f32x16 acc[1][1];
+    float bsum = 0.f;
+    if (by == 0) wide_mainloop<SA, SB, true, 1>(j.a, j.lda, j.a_pstride, j.P, j.b, j.ldb, j.b_pstride, j.Q, p0, q0, 0, j.R, wlds, acc, bsum);
+    else wide_mainloop<SA, SB, false, 1>(j.a, j.lda, j.a_pstride, j.P, j.b, j.ldb, j.b_pstride, j.Q, p0, q0, 0, j.R, wlds, acc, bsum);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int p = p0 + 32 * wp + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (qok && p < j.P) *outp[r] = old[r] + acc[0][0][r];
+    }
+    if (by == 0 && j.dbias != nullptr) {                         // the four thread groups' shares of the row sums, in order
+        float *red = reinterpret_cast<float *>(wlds + NBUF * BUF);
+        red[threadIdx.x] = bsum;
+        __syncthreads();
+        if (threadIdx.x < 64 && p0 + (int)threadIdx.x < j.P) {
+            float *db = j.dbias + j.p_perm.to_feat(p0 + threadIdx.x);
+            *db += (red[threadIdx.x] + red[threadIdx.x + 64]) + (red[threadIdx.x + 128] + red[threadIdx.x + 192]);
+        }
+    }
+}
+__global__ __launch_bounds__(256, WG_NBUF == 1 ? 3 : 2) void wide_wgrad_x3_kernel(WideWgradBatch b) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short wlds[];
+    typedef WideF32<RG_KROWS, 64> F;
+    typedef WidePlanes<RG_KROWS, 64> PL;
+    const int jn = (b.count > 1 && (int)blockIdx.x >= b.wg_end[0]) ? 1 : 0;
+    const int tile = blockIdx.x - (jn ? b.wg_end[0] : 0);
+    if (jn == 0) {
+        if (b.job[0].a_planes) wide_wgrad_tile<PL, F>(b.job[0], tile, wlds);
+        else wide_wgrad_tile<F, PL>(b.job[0], tile, wlds);
+    } else {
+        if (b.job[1].a_planes) wide_wgrad_tile<PL, F>(b.job[1], tile, wlds);
+        else wide_wgrad_tile<F, PL>(b.job[1], tile, wlds);
+    }
+}
+bool wide_wgrad_fits(const WideWgradJob &j) {
+    auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    // (the planes: tiled layout, ld = their row count = the batch, reduced along the rows)
+    const bool planes_ok = j.a_planes ? (j.lda >= j.R && (j.P & 7) == 0 && (j.a_pstride & 7) == 0 && (j.ldb & 3) == 0 && (j.Q & 3) == 0)
+                                      : (j.ldb >= j.R && (j.Q & 7) == 0 && (j.b_pstride & 7) == 0 && (j.lda & 3) == 0 && (j.P & 3) == 0);
+    return j.P > 0 && j.Q > 0 && j.R > 0 && (j.a_planes != 0) != (j.b_planes != 0) && planes_ok && al(j.a) && al(j.b) &&
+           (int64_t)j.R * (j.a_planes ? j.ldb : j.lda) * 4 < ((int64_t)1 << 31) && (3 * (j.a_planes ? j.a_pstride : j.b_pstride)) * 2 < ((int64_t)1 << 31);
+}
+int wide_wgrad(const WideWgradJob *jobs, int count, hipStream_t s) {
+    ARVAE_REQUIRE(count >= 1 && count <= 2, "wide_wgrad: one or two jobs");
+    WideWgradBatch b{};
+    b.count = count;
+    int total = 0;
+    for (int i = 0; i < count; ++i) {
+        ARVAE_REQUIRE(wide_wgrad_fits(jobs[i]), "wide_wgrad: operand shapes / alignment");
+        b.job[i] = jobs[i];
+        total += ((jobs[i].P + 63) / 64) * ((jobs[i].Q + 63) / 64);
+        b.wg_end[i] = total;
+    }
+    typedef WideLds<WideF32<RG_KROWS, 64>, WidePlanes<RG_KROWS, 64>> Lds;
+    constexpr size_t lds_bytes = Lds::BYTES;
+    static std::once_flag once;
+    std::call_once(once, [] { (void)hipFuncSetAttribute((const void *)wide_wgrad_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lds::BYTES); });
+    ARVAE_LAUNCH(wide_wgrad_x3_kernel, dim3(total), dim3(256), lds_bytes, s, b);
+    return check_launch("wide_wgrad");
+}
+
+// tools/probes/wide_gemm.py: one launch of the tile GEMM on caller buffers (contents are the caller's business: timing only)
+extern "C" int arvae_debug_wide_gemm(int32_t a_planes, int32_t b_krows, int32_t partial, int32_t M, int32_t N, int32_t K, const void *a, const void *b,
+                                     float *out, int32_t slices, int32_t dbg, arvae_stream_t stream) {
+    const int kpad = (K + RG_R - 1) / RG_R * RG_R, npad = (N + 31) / 32 * 32;
+    WideGemm g{};
+    g.a = a; g.lda = a_planes ? M : K; g.a_pstride = (int64_t)M * kpad; g.a_planes = a_planes;
+    g.b = b; g.b_planes = 1; g.b_krows = b_krows;
+    g.ldb = b_krows ? kpad : npad; g.b_pstride = (int64_t)npad * kpad;      // (planes: ld = their row count; K x rows: the rows are the reduction)
+    g.M = M; g.N = N; g.K = K; g.out = out; g.ldo = N; g.slice_floats = (int64_t)M * N; g.act = ARVAE_ACT_NONE; g.dbg = dbg;
+    return wide_gemm(g, slices, partial != 0, as_stream(stream));
+}
+
+// the tile extent a product runs with: 128 x 128 (half the operand traffic per multiply-add: at 64 x 64 the four Morpho-MNIST
+// products were bound by L2 -> LDS bytes, 12 of their 23 us with every MFMA, LDS write and result store switched off,
+// tools/probes/wide_gemm.py) when both output extents have more than one 64-tile
+static int wide_tile(int M, int N) {
+    static const bool big = diag_env("ARVAE_WIDE_TILE128") != nullptr;      // diagnostic build: the 128 x 128 form
+    return (big && M > 64 && N > 64) ? 128 : 64;
+}
+// K slices that fill the chip: tiles x slices ~ one (128) or two (64) workgroups per CU, a slice at least four chunks long
 int wide_gemm_slices(int M, int N, int K) {
-    const int tiles = ((M + 63) / 64) * ((N + 63) / 64), chunks = (K + RG_R - 1) / RG_R;
-    int s = (2 * device_cu_count() + tiles - 1) / tiles;
+    const int T = wide_tile(M, N);
+    const int tiles = ((M + T - 1) / T) * ((N + T - 1) / T), chunks = (K + RG_R - 1) / RG_R;
+    int s = ((T == 128 ? 1 : 2) * device_cu_count() + tiles - 1) / tiles;
     if (s > chunks / 4) s = chunks / 4;
     if (s > WIDE_MAX_SLICES) s = WIDE_MAX_SLICES;
     return s < 1 ? 1 : s;
 }
 bool wide_gemm_fits(const WideGemm &g, int slices) {
     auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    const int64_t a_bytes = (int64_t)g.M * g.lda * 4, b_bytes = (int64_t)(g.b_krows ? g.K : g.N) * g.ldb * 4;
-    const int tiles = ((g.M + 63) / 64) * ((g.N + 63) / 64);
-    return g.M > 0 && g.N > 0 && g.K > 0 && (g.K & 3) == 0 && (g.lda & 3) == 0 && (g.ldb & 3) == 0 && (g.N & 3) == 0 && al(g.a) && al(g.b) &&
+    const int64_t a_bytes = g.a_planes ? 3 * g.a_pstride * 2 : (int64_t)g.M * g.lda * 4;
+    const int64_t b_bytes = 3 * g.b_pstride * 2;
+    const int T = wide_tile(g.M, g.N);
+    const int tiles = ((g.M + T - 1) / T) * ((g.N + T - 1) / T);
+    // fp32 A: 16-byte rows.  Plane operands (tiled layout, ld = their row count, K padded to whole chunks by their writer): "rows x K"
+    // needs at least the output rows; "K x rows" reduces along the rows (padded with zero rows for weights) and emits 8 columns per load
+    const bool a_ok = g.a_planes ? (g.lda >= g.M && (g.K % RG_R) == 0 && (g.a_pstride & 7) == 0) : ((g.lda & 3) == 0 && (g.K & 3) == 0);
+    const bool b_ok = (g.b_pstride & 7) == 0 && (g.b_krows ? (g.N & 7) == 0 && g.ldb >= g.K : g.ldb >= g.N);
+    return g.M > 0 && g.N > 0 && g.K > 0 && a_ok && b_ok && g.b_planes && (g.N & 3) == 0 && al(g.a) && al(g.b) &&
            a_bytes < ((int64_t)1 << 31) && b_bytes < ((int64_t)1 << 31) && slices >= 1 && slices <= WIDE_MAX_SLICES &&
            (g.amax_out == nullptr || tiles <= AMAX_N);
+}
+template <class SA, class SB, int EP, int NT>
+static void launch_wide(const WideGemm &g, dim3 grid, hipStream_t s) {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute((const void *)wide_gemm_x3_kernel<SA, SB, EP, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideLds<SA, SB>::BYTES);
+    });
+    constexpr size_t lds_bytes = WideLds<SA, SB>::BYTES;
+    ARVAE_LAUNCH((wide_gemm_x3_kernel<SA, SB, EP, NT>), grid, dim3(256), lds_bytes, s, g);
+}
+template <int NT>
+static void dispatch_wide(const WideGemm &g, bool partial, dim3 grid, hipStream_t s) {
+    constexpr int T = 64 * NT;
+    typedef WideF32<RG_ROWSK, T> AF;
+    typedef WidePlanes<RG_ROWSK, T> AP;
+    typedef WidePlanes<RG_ROWSK, T> BR;
+    typedef WidePlanes<RG_KROWS, T> BK;
+    const int sel = (g.a_planes ? 4 : 0) + (g.b_krows ? 2 : 0) + (partial ? 0 : 1);
+    switch (sel) {
+        case 0: launch_wide<AF, BR, WG_EP_PARTIAL, NT>(g, grid, s); break;
+        case 1: launch_wide<AF, BR, WG_EP_FULL, NT>(g, grid, s); break;
+        case 2: launch_wide<AF, BK, WG_EP_PARTIAL, NT>(g, grid, s); break;
+        case 3: launch_wide<AF, BK, WG_EP_FULL, NT>(g, grid, s); break;
+        case 4: launch_wide<AP, BR, WG_EP_PARTIAL, NT>(g, grid, s); break;
+        case 5: launch_wide<AP, BR, WG_EP_FULL, NT>(g, grid, s); break;
+        case 6: launch_wide<AP, BK, WG_EP_PARTIAL, NT>(g, grid, s); break;
+        default: launch_wide<AP, BK, WG_EP_FULL, NT>(g, grid, s); break;
+    }
 }
 // slices > 1 (or partial): g.out = workspace of `slices` x slice_floats, the consumer sums them; else the finished product
 int wide_gemm(WideGemm g, int slices, bool partial, hipStream_t s) {
@@ -649,21 +969,10 @@ int wide_gemm(WideGemm g, int slices, bool partial, hipStream_t s) {
     ARVAE_REQUIRE(partial || slices == 1, "wide_gemm: a split reduction leaves partial sums");
     const int chunks = (g.K + RG_R - 1) / RG_R;
     g.kslice = ((chunks + slices - 1) / slices) * RG_R;
-    const dim3 grid((g.M + 63) / 64, (g.N + 63) / 64, slices);
-    static std::once_flag once;
-    std::call_once(once, [] {
-        (void)hipFuncSetAttribute((const void *)wide_gemm_x3_kernel<RG_ROWSK, WG_EP_PARTIAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideLds<RG_ROWSK>::BYTES);
-        (void)hipFuncSetAttribute((const void *)wide_gemm_x3_kernel<RG_ROWSK, WG_EP_FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideLds<RG_ROWSK>::BYTES);
-        (void)hipFuncSetAttribute((const void *)wide_gemm_x3_kernel<RG_KROWS, WG_EP_PARTIAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideLds<RG_KROWS>::BYTES);
-        (void)hipFuncSetAttribute((const void *)wide_gemm_x3_kernel<RG_KROWS, WG_EP_FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)WideLds<RG_KROWS>::BYTES);
-    });
-    if (g.b_krows) {
-        if (partial) ARVAE_LAUNCH((wide_gemm_x3_kernel<RG_KROWS, WG_EP_PARTIAL>), grid, dim3(256), WideLds<RG_KROWS>::BYTES, s, g);
-        else ARVAE_LAUNCH((wide_gemm_x3_kernel<RG_KROWS, WG_EP_FULL>), grid, dim3(256), WideLds<RG_KROWS>::BYTES, s, g);
-    } else {
-        if (partial) ARVAE_LAUNCH((wide_gemm_x3_kernel<RG_ROWSK, WG_EP_PARTIAL>), grid, dim3(256), WideLds<RG_ROWSK>::BYTES, s, g);
-        else ARVAE_LAUNCH((wide_gemm_x3_kernel<RG_ROWSK, WG_EP_FULL>), grid, dim3(256), WideLds<RG_ROWSK>::BYTES, s, g);
-    }
+    const int T = wide_tile(g.M, g.N);
+    const dim3 grid((g.M + T - 1) / T, (g.N + T - 1) / T, slices);
+    if (T == 128) dispatch_wide<2>(g, partial, grid, s);
+    else dispatch_wide<1>(g, partial, grid, s);
     return check_launch(partial ? "wide_gemm(partial)" : "wide_gemm(full)");
 }
 

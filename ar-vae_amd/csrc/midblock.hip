@@ -39,6 +39,12 @@ struct MidLayer {
     float *gpre;         // gradient w.r.t. the pre-activation [batch][n] (backward writes it for the weight gradient)
     int k, n, act;
     int kb;              // row length of mb: k rounded up to a multiple of 4 (zero-padded: the decoder's first layer reads z)
+    // round 6: the saved output / the pre-activation gradient ALSO as their three bf16 terms, planes [3][batch][n] (x3tile.h), for the
+    // tile GEMMs that read them as pre-split operands (dense.hip wide_gemm_x3_kernel), or null
+    unsigned short *y_planes, *g_planes;
+    // ... and a wide layer's own prepared matrix for those GEMMs: planes [3][n_pad][kb_pad]
+    const unsigned short *w_planes;
+    int n_pad, kb_pad;
 };
 
 struct MidArgs {
@@ -219,6 +225,18 @@ __device__ __forceinline__ float4 dact4(float4 g, float4 y, int act) {       // 
                        g.w * act_bwd_from_out(y.w, act));
 }
 
+// four consecutive values (row, col .. col + 3; col a multiple of 4) of a [rows][n] tensor as their three bf16 terms into its TILED
+// planes (x3tile.h x3_tiled_index), `pstride` = rows * n elements apart
+__device__ __forceinline__ void store_planes(unsigned short *p, int64_t pstride, int rows, int row, int col, const float4 &v) {
+    const int64_t idx = x3_tiled_index(rows, row, col);
+    unsigned h0, m0, l0, h1, m1, l1;
+    rg_split3(v.x, v.y, h0, m0, l0);
+    rg_split3(v.z, v.w, h1, m1, l1);
+    *reinterpret_cast<uint2 *>(p + idx) = uint2{h0, h1};
+    *reinterpret_cast<uint2 *>(p + pstride + idx) = uint2{m0, m1};
+    *reinterpret_cast<uint2 *>(p + 2 * pstride + idx) = uint2{l0, l1};
+}
+
 // maximum magnitude of the R x n block a pass leaves in LDS (rows past the batch hold zeros): one AMAX writer unit per workgroup
 template <int R>
 __device__ __forceinline__ void mid_amax(const float *rows, int ld, int n, float *scratch, unsigned *out) {
@@ -293,7 +311,10 @@ __global__ __launch_bounds__(MID_T) void mid_forward_kernel(MidArgs p) {
             [&](int r, int q, float4 v, float4 b) {
                 v = act4(make_float4(v.x + b.x, v.y + b.y, v.z + b.z, v.w + b.w), l.act);
                 *reinterpret_cast<float4 *>(nxt + r * p.ld + 4 * q) = v;
-                if (row0 + r < p.batch) *reinterpret_cast<float4 *>(l.y + (int64_t)(row0 + r) * l.n + 4 * q) = v;
+                if (row0 + r < p.batch) {
+                    *reinterpret_cast<float4 *>(l.y + (int64_t)(row0 + r) * l.n + 4 * q) = v;
+                    if (l.y_planes != nullptr) store_planes(l.y_planes, (int64_t)p.batch * l.n, p.batch, row0 + r, 4 * q, v);
+                }
             });
         __syncthreads();
         MID_STAMP(stamp_no); ++stamp_no;
@@ -377,7 +398,8 @@ __global__ __launch_bounds__(MID_T) void mid_backward_kernel(MidArgs p) {
     // d(input of layer l) from d(pre-activation of l): [n] -> [k]; prev = the layer that produced the input (null: no activation)
     // y_prev / act_prev: saved output and activation of the layer that produced this layer's input (y_prev null: the input is
     // the conv feature map, gated by gate_relu when given); dst: where the input's pre-activation gradient goes
-    auto back_layer = [&](const float *mb, int n, int k, const float *y_prev, int act_prev, const float *gate_relu, float *dst) {
+    auto back_layer = [&](const float *mb, int n, int k, const float *y_prev, int act_prev, const float *gate_relu, float *dst,
+                          unsigned short *dst_planes = nullptr) {
         mid_matmul<R>(
             cur, p.ld, n, mb, k, red,
             [&](int r, int q) {
@@ -391,7 +413,10 @@ __global__ __launch_bounds__(MID_T) void mid_backward_kernel(MidArgs p) {
                 if (y_prev != nullptr) v = dact4(v, y, act_prev);
                 else if (gate_relu != nullptr) v = make_float4(y.x > 0.f ? v.x : 0.f, y.y > 0.f ? v.y : 0.f, y.z > 0.f ? v.z : 0.f, y.w > 0.f ? v.w : 0.f);
                 *reinterpret_cast<float4 *>(nxt + r * p.ld + 4 * q) = v;
-                if (row < p.batch && dst != nullptr) *reinterpret_cast<float4 *>(dst + (int64_t)row * k + 4 * q) = v;
+                if (row < p.batch && dst != nullptr) {
+                    *reinterpret_cast<float4 *>(dst + (int64_t)row * k + 4 * q) = v;
+                    if (dst_planes != nullptr) store_planes(dst_planes, (int64_t)p.batch * k, p.batch, row, 4 * q, v);
+                }
             });
         __syncthreads();
         float *t = cur; cur = nxt; nxt = t;
@@ -433,9 +458,10 @@ __global__ __launch_bounds__(MID_T) void mid_backward_kernel(MidArgs p) {
         }
         __syncthreads();
         { float *t = cur; cur = nxt; nxt = t; }
-        back_layer(p.hb, 2 * p.zdim, p.h, last.y, last.act, nullptr, last.gpre);
+        back_layer(p.hb, 2 * p.zdim, p.h, last.y, last.act, nullptr, last.gpre, last.g_planes);
     }
-    for (int i = p.ne - 1; i >= 1; --i) back_layer(p.enc[i].mb, p.enc[i].n, p.enc[i].k, p.enc[i - 1].y, p.enc[i - 1].act, nullptr, p.enc[i - 1].gpre);
+    for (int i = p.ne - 1; i >= 1; --i)
+        back_layer(p.enc[i].mb, p.enc[i].n, p.enc[i].k, p.enc[i - 1].y, p.enc[i - 1].act, nullptr, p.enc[i - 1].gpre, p.enc[i - 1].g_planes);
     if (!p.skip_enc0) {          // (skipped: the tile GEMM multiplies enc[0]'s pre-activation gradient, stored just above)
         back_layer(p.enc[0].mb, p.enc[0].n, p.enc[0].k, nullptr, 0, p.gate0, p.d_x0);
         mid_amax<R>(cur, p.ld, p.enc[0].k, red, p.amax_out);
@@ -618,8 +644,19 @@ static void mid_describe(const arvae_image_vae_t *m, const float *params, float 
         const bool shape_ok = !no_wide && !midc_topology(m, ne, nd);
         pl.wide_e = shape_ok && ne >= 1 && a.enc[0].k >= MID_WIDE_MIN && a.enc[0].k % 4 == 0 && a.enc[0].n % 4 == 0;
         pl.wide_d = shape_ok && nd >= 2 && a.dec[nd - 1].n >= MID_WIDE_MIN && a.dec[nd - 1].k % 4 == 0 && a.dec[nd - 1].n % 4 == 0;
-        if (pl.wide_e) { a.enc[0].mf = nullptr; pl.prep.job[0].mf = nullptr; }
-        if (pl.wide_d) { a.dec[nd - 1].mf = nullptr; pl.prep.job[ne + nd - 1].mf = nullptr; }
+        // their ONE prepared copy: the three bf16 terms of W'[n_mem][k_mem] as planes, in the space of the fp32 layouts they replace
+        auto to_planes = [&](MidLayer &ml, MidPrepJob &j) {
+            const int n_pad = (ml.n + 31) / 32 * 32, kb_pad = (ml.k + 31) / 32 * 32;
+            if ((int64_t)3 * n_pad * kb_pad * 2 > ((int64_t)ml.k * ml.n + (int64_t)ml.kb * ml.n) * 4) return false;
+            unsigned short *planes = reinterpret_cast<unsigned short *>(j.mf);
+            ml.w_planes = planes; ml.n_pad = n_pad; ml.kb_pad = kb_pad;
+            j.planes = planes; j.n_pad = n_pad; j.kb_pad = kb_pad;
+            ml.mf = ml.mb = nullptr;
+            j.mf = j.mb = nullptr;
+            return true;
+        };
+        if (pl.wide_e) pl.wide_e = to_planes(a.enc[0], pl.prep.job[0]);
+        if (pl.wide_d) pl.wide_d = to_planes(a.dec[nd - 1], pl.prep.job[ne + nd - 1]);
     }
     {   // the two heads as one [h] -> [2 zdim] layer
         const int h = m->head_mu.link.chi, z2 = 2 * m->zdim;
@@ -726,6 +763,7 @@ static void mid_size_lds(MidPlan &pl, bool skip_enc0, bool skip_dec_last) {
     pl.lds_bytes = (size_t)(2 * pl.rows * a.ld + mid_red(pl.rows) + pl.rows * 32) * sizeof(float);
 }
 
+static int64_t mid_wide_plane_floats(int64_t batch, int64_t w) { return (3 * batch * w / 2 + 3) / 4 * 4; }
 // workspace of the split reductions the tile GEMMs leave for the row kernels: WIDE_MAX_SLICES partial products of the narrow side
 int64_t mid_wide_ws_floats(const arvae_image_vae_t *m, int batch) {
     int ne, nd;
@@ -733,7 +771,8 @@ int64_t mid_wide_ws_floats(const arvae_image_vae_t *m, int batch) {
     int64_t w = 0;
     if (ne >= 1 && m->enc[m->n_enc - ne].link.chi >= MID_WIDE_MIN) w = max(w, (int64_t)m->enc[m->n_enc - ne].link.clo);
     if (nd >= 2 && m->dec[nd - 1].link.clo >= MID_WIDE_MIN) w = max(w, (int64_t)m->dec[nd - 1].link.chi);
-    return (int64_t)WIDE_MAX_SLICES * batch * w;
+    // partial products | planes of the encoder layer's pre-activation gradient | planes of the decoder layer's input (1.5 floats per value)
+    return w > 0 ? (int64_t)WIDE_MAX_SLICES * batch * w + 2 * mid_wide_plane_floats(batch, w) : 0;
 }
 
 static void midc_common(McArgs &c, const MidArgs &a, int batch) {
@@ -765,6 +804,21 @@ static void mid_allow_lds() {
     });
 }
 
+// the regions of the wide layers' workspace (mid_wide_ws_floats)
+struct MidWideWs { float *partial; unsigned short *g_planes, *y_planes; };
+static MidWideWs mid_wide_regions(const MidPlan &pl, int batch, float *ws) {
+    const MidArgs &a = pl.args;
+    MidWideWs r{ws, nullptr, nullptr};
+    if (ws == nullptr) return r;
+    int64_t w = 0;
+    if (pl.wide_e) w = max(w, (int64_t)a.enc[0].n);
+    if (pl.wide_d) w = max(w, (int64_t)a.dec[a.nd - 1].k);
+    float *g = ws + (int64_t)WIDE_MAX_SLICES * batch * w;
+    r.g_planes = reinterpret_cast<unsigned short *>(g);
+    r.y_planes = reinterpret_cast<unsigned short *>(g + mid_wide_plane_floats(batch, w));
+    return r;
+}
+
 // the prep launch's arguments alone (plan.hip hands them to conv32_weight_prep, which runs both preps as one launch)
 void mid_prep_args(const arvae_image_vae_t *m, const float *params, float *prep_ws, MidPrepArgs *out, int batch) {
     MidPlan pl;
@@ -782,24 +836,29 @@ int mid_forward(const arvae_image_vae_t *m, int batch, const float *params, floa
     // the wide layers' tile GEMMs (dense.hip): F1 = x0 . W'_e0^T as a split reduction this kernel's prologue finishes; F2 behind it
     WideGemm f1{}, f2{};
     int f1_slices = 1;
-    bool wide_e = pl.wide_e && wide_ws != nullptr, wide_d = pl.wide_d;
+    const bool wide_e = pl.wide_e, wide_d = pl.wide_d;
+    ARVAE_REQUIRE(!(wide_e || wide_d) || wide_ws != nullptr, "mid_forward: the wide layers' workspace is missing");
+    const MidWideWs wws = mid_wide_regions(pl, batch, wide_ws);
     if (wide_e) {
         const MidLayer &l = a.enc[0];
-        f1.a = x0; f1.lda = l.k; f1.b = l.mb; f1.ldb = l.kb; f1.b_krows = 0; f1.M = batch; f1.N = l.n; f1.K = l.k;
-        f1.out = wide_ws; f1.ldo = l.n; f1.slice_floats = (int64_t)batch * l.n;
+        f1.a = x0; f1.lda = l.k; f1.b = l.w_planes; f1.ldb = l.n_pad; f1.b_pstride = (int64_t)l.n_pad * l.kb_pad; f1.b_planes = 1; f1.b_krows = 0;
+        f1.M = batch; f1.N = l.n; f1.K = l.k;
+        f1.out = wws.partial; f1.ldo = l.n; f1.slice_floats = (int64_t)batch * l.n;
         f1_slices = wide_gemm_slices(batch, l.n, l.k);
-        wide_e = wide_gemm_fits(f1, f1_slices);
+        ARVAE_REQUIRE(wide_gemm_fits(f1, f1_slices), "mid_forward: the first Linear layer does not fit the tile GEMM (alignment / size)");
     }
     if (wide_d) {
         const MidLayer &l = a.dec[a.nd - 1];
-        f2.a = dec_y[a.nd - 2]; f2.lda = l.k; f2.b = l.mb; f2.ldb = l.kb; f2.b_krows = 0; f2.M = batch; f2.N = l.n; f2.K = l.k;
+        a.dec[a.nd - 2].y_planes = wws.y_planes;             // the row kernel leaves its last layer's output pre-split for F2
+        f2.a = wws.y_planes; f2.lda = batch; f2.a_pstride = (int64_t)batch * l.k; f2.a_planes = 1;
+        f2.b = l.w_planes; f2.ldb = l.n_pad; f2.b_pstride = (int64_t)l.n_pad * l.kb_pad; f2.b_planes = 1; f2.b_krows = 0;
+        f2.M = batch; f2.N = l.n; f2.K = l.k;
         f2.out = dec_y[a.nd - 1]; f2.ldo = l.n; f2.bias = l.bias; f2.act = l.act; f2.amax_out = amax_out;
-        wide_d = wide_gemm_fits(f2, 1);
-        if (!wide_d && amax_out != nullptr) { f2.amax_out = nullptr; wide_d = wide_gemm_fits(f2, 1); }   // (more tiles than AMAX entries: a launch of its own below)
+        if (!wide_gemm_fits(f2, 1)) f2.amax_out = nullptr;       // (more tiles than AMAX entries: a launch of its own below)
+        ARVAE_REQUIRE(wide_gemm_fits(f2, 1), "mid_forward: the last Linear layer does not fit the tile GEMM (alignment / size)");
     }
-    ARVAE_REQUIRE((wide_e || !pl.wide_e) && (wide_d || !pl.wide_d), "mid_forward: a wide Linear layer the tile GEMM cannot take (alignment / size)");
     a.skip_enc0 = wide_e; a.skip_dec_last = wide_d;
-    if (wide_e) { a.wide_partial = wide_ws; a.wide_slices = f1_slices; a.wide_slice_floats = f1.slice_floats; }
+    if (wide_e) { a.wide_partial = wws.partial; a.wide_slices = f1_slices; a.wide_slice_floats = f1.slice_floats; }
     mid_size_lds(pl, wide_e, wide_d);
     // AMAX of the last output: one writer unit per workgroup when they fit the array, else a reduction launch of its own
     const bool amax_in_kernel = (batch + pl.rows - 1) / pl.rows <= AMAX_N;
@@ -870,24 +929,37 @@ int mid_backward(const arvae_image_vae_t *m, int batch, const float *params, flo
     // B2 = enc[0]'s pre-activation gradient . W'_e0 behind this kernel
     WideGemm b1{}, b2{};
     int b1_slices = 1;
-    bool wide_d = pl.wide_d && wide_ws != nullptr && g_is_pre, wide_e = pl.wide_e;
+    const bool wide_d = pl.wide_d, wide_e = pl.wide_e;
+    ARVAE_REQUIRE(!(wide_e || wide_d) || wide_ws != nullptr, "mid_backward: the wide layers' workspace is missing");
+    const MidWideWs wws = mid_wide_regions(pl, batch, wide_ws);
     if (wide_d) {
         const MidLayer &l = a.dec[a.nd - 1];
-        b1.a = g_out; b1.lda = l.n; b1.b = l.mb; b1.ldb = l.kb; b1.b_krows = 1; b1.M = batch; b1.N = l.k; b1.K = l.n;
-        b1.out = wide_ws; b1.ldo = l.k; b1.slice_floats = (int64_t)batch * l.k;
+        if (!g_is_pre) {
+            // the split reduction multiplies a PRE-activation gradient: make it (into the layer's keep buffer, where the weight
+            // gradient looks for it) with the operand pass the per-layer path uses
+            const arvae_operand_t op{g_out, dec_y[a.nd - 1], nullptr, l.act};
+            if (int rc = arvae_operand_apply(&op, (int64_t)batch * l.n, dec_g[a.nd - 1], reinterpret_cast<arvae_stream_t>(s))) return rc;
+            g_out = dec_g[a.nd - 1];
+            g_is_pre = 1;
+        }
+        b1.a = g_out; b1.lda = l.n; b1.b = l.w_planes; b1.ldb = l.n_pad; b1.b_pstride = (int64_t)l.n_pad * l.kb_pad; b1.b_planes = 1; b1.b_krows = 1;
+        b1.M = batch; b1.N = l.k; b1.K = l.n;
+        b1.out = wws.partial; b1.ldo = l.k; b1.slice_floats = (int64_t)batch * l.k;
         b1_slices = wide_gemm_slices(batch, l.k, l.n);
-        wide_d = wide_gemm_fits(b1, b1_slices);
+        ARVAE_REQUIRE(wide_gemm_fits(b1, b1_slices), "mid_backward: the last Linear layer does not fit the tile GEMM (alignment / size)");
     }
     if (wide_e) {
         const MidLayer &l = a.enc[0];
-        b2.a = enc_g[0]; b2.lda = l.n; b2.b = l.mb; b2.ldb = l.kb; b2.b_krows = 1; b2.M = batch; b2.N = l.k; b2.K = l.n;
+        a.enc[0].g_planes = wws.g_planes;                    // the row kernel leaves this layer's pre-activation gradient pre-split for B2
+        b2.a = wws.g_planes; b2.lda = batch; b2.a_pstride = (int64_t)batch * l.n; b2.a_planes = 1;
+        b2.b = l.w_planes; b2.ldb = l.n_pad; b2.b_pstride = (int64_t)l.n_pad * l.kb_pad; b2.b_planes = 1; b2.b_krows = 1;
+        b2.M = batch; b2.N = l.k; b2.K = l.n;
         b2.out = d_x0; b2.ldo = l.k; b2.act = ARVAE_ACT_NONE; b2.gate = gate0; b2.amax_out = amax_out;
-        wide_e = wide_gemm_fits(b2, 1);
-        if (!wide_e && amax_out != nullptr) { b2.amax_out = nullptr; wide_e = wide_gemm_fits(b2, 1); }
+        if (!wide_gemm_fits(b2, 1)) b2.amax_out = nullptr;
+        ARVAE_REQUIRE(wide_gemm_fits(b2, 1), "mid_backward: the first Linear layer does not fit the tile GEMM (alignment / size)");
     }
-    ARVAE_REQUIRE(wide_e || !pl.wide_e, "mid_backward: a wide Linear layer the tile GEMM cannot take (alignment / size)");
     a.skip_enc0 = wide_e; a.skip_dec_last = wide_d;
-    if (wide_d) { a.wide_partial = wide_ws; a.wide_slices = b1_slices; a.wide_slice_floats = b1.slice_floats; }
+    if (wide_d) { a.wide_partial = wws.partial; a.wide_slices = b1_slices; a.wide_slice_floats = b1.slice_floats; }
     mid_size_lds(pl, wide_e, wide_d);
     const bool amax_in_kernel = (batch + pl.rows - 1) / pl.rows <= AMAX_N;
     a.amax_out = amax_in_kernel ? amax_out : nullptr;
@@ -940,6 +1012,47 @@ int mid_backward(const arvae_image_vae_t *m, int batch, const float *params, flo
     }
     if (amax_out != nullptr && !amax_in_kernel) return conv32_amax(d_x0, (int64_t)batch * a.enc[0].k, amax_out, s);
     return ARVAE_OK;
+}
+
+// The wide layers' weight gradients (dense.hip wide_wgrad_x3_kernel), called by the executor behind mid_backward: the encoder
+// layer's from its pre-activation gradient (planes, left by mid_backward) and the block's input x0; the decoder layer's from the
+// gradient at its pre-activation and its input (planes, left by mid_forward).  *took: bit 0 / 1 = the first encoder / last decoder
+// layer was done here (the caller keeps them out of the grouped launch).
+int mid_wide_wgrad(const arvae_image_vae_t *m, int batch, const float *params, float *prep_ws, float *wide_ws, const float *x0,
+                   const float *g_last_pre, float *grads, hipStream_t s, int *took) {
+    *took = 0;
+    static const bool off = diag_env("ARVAE_MID_NO_WIDE_WGRAD") != nullptr;      // diagnostic build: the grouped 32 x 32-tile launch
+    if (wide_ws == nullptr || off) return ARVAE_OK;
+    MidPlan pl;
+    mid_describe(m, params, prep_ws, pl, batch);
+    if (!pl.wide_e && !pl.wide_d) return ARVAE_OK;
+    const MidArgs &a = pl.args;
+    const MidWideWs wws = mid_wide_regions(pl, batch, wide_ws);
+    WideWgradJob jobs[2];
+    int n = 0;
+    if (pl.wide_e) {
+        const arvae_layer_t &l = m->enc[m->n_enc - a.ne];
+        const MidLayer &ml = a.enc[0];
+        WideWgradJob j{};
+        j.a = wws.g_planes; j.lda = batch; j.a_pstride = (int64_t)batch * ml.n; j.a_planes = 1;
+        j.b = x0; j.ldb = ml.k; j.b_planes = 0;
+        j.P = ml.n; j.Q = ml.k; j.R = batch;
+        j.dw = grads + l.w_off; j.ldw = ml.k; j.dbias = l.b_off >= 0 ? grads + l.b_off : nullptr;
+        j.p_perm = Perm{l.link.lo_perm_c, l.link.lo_perm_hw}; j.q_perm = Perm{l.link.hi_perm_c, l.link.hi_perm_hw};
+        if (wide_wgrad_fits(j)) { jobs[n++] = j; *took |= 1; }
+    }
+    if (pl.wide_d) {
+        const arvae_layer_t &l = m->dec[a.nd - 1];
+        const MidLayer &ml = a.dec[a.nd - 1];
+        WideWgradJob j{};
+        j.a = g_last_pre; j.lda = ml.n; j.a_planes = 0;
+        j.b = wws.y_planes; j.ldb = batch; j.b_pstride = (int64_t)batch * ml.k; j.b_planes = 1;
+        j.P = ml.n; j.Q = ml.k; j.R = batch;
+        j.dw = grads + l.w_off; j.ldw = ml.k; j.dbias = l.b_off >= 0 ? grads + l.b_off : nullptr;
+        j.p_perm = Perm{l.link.lo_perm_c, l.link.lo_perm_hw}; j.q_perm = Perm{l.link.hi_perm_c, l.link.hi_perm_hw};
+        if (wide_wgrad_fits(j)) { jobs[n++] = j; *took |= 2; }
+    }
+    return n > 0 ? wide_wgrad(jobs, n, s) : ARVAE_OK;
 }
 
 }  // namespace arvae

@@ -3,6 +3,7 @@
 #pragma once
 #include "common.h"
 #include "dense.h"
+#include "x3tile.h"
 
 namespace arvae {
 
@@ -19,6 +20,10 @@ struct MidPrepJob {
     // cf: reduce axis k in cf_kb blocks of 16, outputs n in cf_s slices of cf_ct tiles of 16; cb: reduce axis n, outputs k
     float *cf, *cb;
     int cf_kb, cf_ct, cf_s, cb_kb, cb_ct, cb_s;
+    // a wide layer the tile GEMMs multiply (dense.hip wide_gemm_x3_kernel; round 6): W'[n_mem][k_mem] as its three bf16 terms,
+    // planes [3][n_pad][kb_pad] (both axes zero-padded to multiples of 32: either may be the reduction axis), or null
+    unsigned short *planes;
+    int n_pad, kb_pad;
 };
 // A 32-channel k4 / s2 / p1 link between a 4x4 and an 8x8 map that the clustered latent block computes itself (round 5: the conv
 // layer in front of the block and the transposed one behind it, midcluster.hip): its weight wt[clo][chi][ky][kx] as the two
@@ -109,6 +114,25 @@ __device__ __forceinline__ void mid_prep_block(const MidPrepArgs &a, int block) 
             const int nf = p.np.to_feat(e);
             const float *bs = (p.w2 != nullptr && nf >= p.nsplit) ? p.b2 : p.b;
             p.bias[e] = bs != nullptr ? bs[(p.w2 != nullptr && nf >= p.nsplit) ? nf - p.nsplit : nf] : 0.f;
+        }
+    }
+    if (p.planes != nullptr) {
+        // TILED planes [3][kb_pad / 32][n_pad][32] (x3tile.h x3_tiled_index); pairs of consecutive k_mem: one 4-byte store per plane,
+        // written in order
+        const int pairs = p.n_pad * (p.kb_pad >> 1);
+        unsigned *pl = reinterpret_cast<unsigned *>(p.planes);
+        for (int e = (block - start) * 256 + threadIdx.x; e < pairs; e += stride) {
+            const int kblk = e / (p.n_pad * 16), rem = e - kblk * (p.n_pad * 16);
+            const int nm = rem >> 4, km = kblk * 32 + 2 * (rem & 15);
+            const bool n_ok = nm < p.n;
+            const int nf = p.np.to_feat(n_ok ? nm : 0);
+            const float x0 = (n_ok && km < p.k) ? src(nf, p.kp.to_feat(km)) : 0.f;
+            const float x1 = (n_ok && km + 1 < p.k) ? src(nf, p.kp.to_feat(km + 1)) : 0.f;
+            unsigned h, m, l;
+            rg_split3(x0, x1, h, m, l);
+            pl[e] = h;
+            pl[e + pairs] = m;
+            pl[e + 2 * pairs] = l;
         }
     }
     if (p.cf == nullptr) return;

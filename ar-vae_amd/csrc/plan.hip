@@ -92,6 +92,8 @@ int mid_forward(const arvae_image_vae_t *m, int batch, const float *params, floa
                 float *const *dec_y, const float *eps, float *mu, float *log_std, float *sigma, float *z, hipStream_t s, bool prep_done,
                 unsigned *amax_out, const MidFold *fold, float *wide_ws);
 int64_t mid_wide_ws_floats(const arvae_image_vae_t *m, int batch);      // split-reduction workspace of the wide layers' tile GEMMs
+int mid_wide_wgrad(const arvae_image_vae_t *m, int batch, const float *params, float *prep_ws, float *wide_ws, const float *x0,
+                   const float *g_last_pre, float *grads, hipStream_t s, int *took);
 // the conv layers on either side of the latent block computed by the block's clustered kernels (midblock.hip)
 bool mid_fold_fits(const arvae_image_vae_t *m, int batch);
 int64_t mid_fold_slab_floats(const arvae_image_vae_t *m, int batch);
@@ -931,12 +933,22 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
             if (dense_wgrad_defer(&defer, &lk, make_operand(&gop), in, dw, db)) return ARVAE_OK;
             return arvae_link_wgrad(&lk, &gop, &xin, dw, db, db ? 1 : 0, slab, stream);
         };
-        for (int i = mid_nd - 1; i >= 0; --i)
+        // (the wide layers' own weight-gradient launch first: dense.hip wide_wgrad_x3_kernel, Morpho-MNIST's 2888-wide layers)
+        int wide_took = 0;
+        if (L.mid_wide >= 0)
+            if (int rc = mid_wide_wgrad(m, batch, params, ws + L.mid_prep, ws + L.mid_wide, x0, (pre && !fold) ? g_last : dec_g[mid_nd - 1], grads,
+                                        st, &wide_took))
+                return rc;
+        for (int i = mid_nd - 1; i >= 0; --i) {
+            if (i == mid_nd - 1 && (wide_took & 2)) continue;
             if (int rc = queue(m->dec[i], (i == mid_nd - 1 && pre && !fold) ? g_last : dec_g[i], i > 0 ? dec_y[i - 1] : z)) return rc;
+        }
         if (int rc = queue(m->head_mu, ws + L.d_mu, hidden)) return rc;
         if (int rc = queue(m->head_log_std, ws + L.d_ls, hidden)) return rc;
-        for (int i = mid_ne - 1; i >= 0; --i)
+        for (int i = mid_ne - 1; i >= 0; --i) {
+            if (i == 0 && (wide_took & 1)) continue;
             if (int rc = queue(m->enc[e0 + i], enc_g[i], i > 0 ? enc_y[i - 1] : x0)) return rc;
+        }
         cur = fold ? mf.d_hi_e : d_x0;
         cur_amax = grad_amax(cur);
         pre = fold ? true : gate0 != nullptr;                // (folded: gated by the conv layer's saved input inside the launch)

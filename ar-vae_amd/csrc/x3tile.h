@@ -28,6 +28,11 @@ __device__ __forceinline__ rg_bf16x8 rg_lds_x8(const unsigned short *p) {
     return __builtin_bit_cast(rg_bf16x8, *reinterpret_cast<const rg_i32x4 *>(p));
 }
 
+// A matrix [rows][K] as bf16 planes in memory for the wide tile GEMMs (dense.hip WidePlanes): TILED [K / 32][rows][32] -- the
+// (32 reduction indices) x (all rows) block of one chunk is contiguous, whichever axis a product reduces along.  Element index
+// of (row, k) inside a plane:
+__host__ __device__ __forceinline__ int64_t x3_tiled_index(int64_t rows, int64_t row, int64_t k) { return ((k >> 5) * rows + row) * 32 + (k & 31); }
+
 // One operand tile (TP output indices x RG_R reduction indices) as three bf16 planes.
 //   "rows x K" (RG_ROWSK): [TP][RG_XP], reduction index contiguous; the MFMA operand (8 consecutive r per lane) is one
 //   ds_read_b128.   "K x rows" (RG_KROWS): memory order kept, [RG_R][RG_TRP] with the output index contiguous (one 8-byte
