@@ -156,6 +156,7 @@ SIGNATURES = {
                                            c_vp, c_vp, c_f32, c_vp, c_vp]),
     'arvae_philox_normal': (c_i32, [c_vp, c_i64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp]),
     'arvae_philox_keep_mask': (c_i32, [c_vp, c_i64, c_f32, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp]),
+    'arvae_philox_keep_masks': (c_i32, [c_i32, c_vp, c_vp, c_f32, ctypes.c_uint64, c_vp, ctypes.c_uint32, c_vp, c_vp]),
     'arvae_count_nonfinite': (c_i32, [c_vp, c_i64, c_vp, c_vp]),
     'arvae_count_out_of_range': (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
     'arvae_adam_step': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_f64, c_f64, c_f64, c_f64, c_f32, c_i32, c_vp, c_vp]),

@@ -893,7 +893,8 @@ int wide_wgrad(const WideWgradJob *jobs, int count, hipStream_t s) {
     return check_launch("wide_wgrad");
 }
 
-// tools/probes/wide_gemm.py: one launch of the tile GEMM on caller buffers (contents are the caller's business: timing only)
+// tools/probes/wide_gemm.py (diagnostic build): one launch of the tile GEMM on caller buffers (contents are the caller's business: timing only)
+#ifdef ARVAE_DIAG
 extern "C" int arvae_debug_wide_gemm(int32_t a_planes, int32_t b_krows, int32_t partial, int32_t M, int32_t N, int32_t K, const void *a, const void *b,
                                      float *out, int32_t slices, int32_t dbg, arvae_stream_t stream) {
     const int kpad = (K + RG_R - 1) / RG_R * RG_R, npad = (N + 31) / 32 * 32;
@@ -904,6 +905,7 @@ extern "C" int arvae_debug_wide_gemm(int32_t a_planes, int32_t b_krows, int32_t 
     g.M = M; g.N = N; g.K = K; g.out = out; g.ldo = N; g.slice_floats = (int64_t)M * N; g.act = ARVAE_ACT_NONE; g.dbg = dbg;
     return wide_gemm(g, slices, partial != 0, as_stream(stream));
 }
+#endif
 
 // the tile extent a product runs with: 128 x 128 (half the operand traffic per multiply-add: at 64 x 64 the four Morpho-MNIST
 // products were bound by L2 -> LDS bytes, 12 of their 23 us with every MFMA, LDS write and result store switched off,

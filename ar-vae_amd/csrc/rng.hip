@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void philox_keep_mask_kernel(uint8_t *__restri
 // several draws of a step as ONE launch (the MeasureVAE executor's encoder keep-mask, eps and decoder keep-masks were three ~5 us
 // launches in a row): blockIdx.x walks the jobs' block ranges; a draw is a pure function of (stream, element index), so the values
 // are those of the separate launches
-constexpr int RNG_BATCH_MAX = 4;
+constexpr int RNG_BATCH_MAX = 8;
 struct RngBatch {
     int count;
     int first_block[RNG_BATCH_MAX + 1];
@@ -107,6 +107,17 @@ int philox_draws(int n_draws, const int *kind, void *const *out, const int64_t *
 }  // namespace arvae
 
 using namespace arvae;
+
+extern "C" int arvae_philox_keep_masks(int32_t n_masks, uint8_t *const *outs, const int64_t *counts, float keep_prob, uint64_t seed,
+                                       const uint32_t *offsets, uint32_t step, const uint32_t *dev_step, arvae_stream_t stream) {
+    ARVAE_REQUIRE(n_masks >= 1 && n_masks <= RNG_BATCH_MAX && outs != nullptr && counts != nullptr && offsets != nullptr,
+                  "philox_keep_masks: 1..%d masks per launch", RNG_BATCH_MAX);
+    int kind[RNG_BATCH_MAX];
+    void *out[RNG_BATCH_MAX];
+    float keep[RNG_BATCH_MAX];
+    for (int j = 0; j < n_masks; ++j) { kind[j] = 1; out[j] = outs[j]; keep[j] = keep_prob; }
+    return philox_draws(n_masks, kind, out, counts, keep, offsets, seed, step, dev_step, as_stream(stream));
+}
 
 extern "C" int arvae_philox_normal(float *out, int64_t count, uint64_t seed, uint32_t offset, uint32_t step, const uint32_t *dev_step,
                                    arvae_stream_t stream) {

@@ -94,7 +94,7 @@ class MnistVAE(Model):
         if self._mask_queue:
             return [m.to(device).contiguous() for m in self._mask_queue.popleft()]
         shapes = [l.lo_shape(n) for _, l in self.enc_conv_plan] + [l.hi_shape(n) for _, l in self.dec_conv_plan[:-1]]
-        return [ops.keep_mask(s, self.dropout_p, device) for s in shapes]
+        return ops.keep_masks(shapes, self.dropout_p, device)        # (one launch for the five Dropout layers' masks)
 
     # -- encoder / decoder --------------------------------------------------------------------------
     def _encode_params(self, x, masks):

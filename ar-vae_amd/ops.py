@@ -1122,6 +1122,22 @@ def keep_mask(shape, p, device):
     return out
 
 
+def keep_masks(shapes, p, device):
+    """the keep-masks of several Dropout layers of one step as ONE launch (arvae_philox_keep_masks); mask j is the step's next
+    draw, byte for byte what keep_mask(shapes[j], ...) called in the same order would return"""
+    if len(shapes) > 8:
+        return [keep_mask(s, p, device) for s in shapes]
+    outs = [torch.empty(s, dtype=torch.uint8, device=device) for s in shapes]
+    _dev(*outs)
+    n = len(outs)
+    ptrs = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
+    counts = (ctypes.c_int64 * n)(*[o.numel() for o in outs])
+    offsets = (ctypes.c_uint32 * n)(*[rng_next_offset() for _ in outs])
+    _lib.check(_lib.load().arvae_philox_keep_masks(n, ptrs, counts, 1.0 - float(p), rng_seed(), offsets, 0, _ptr(rng_device_step(device)),
+                                                   _stream()), 'philox_keep_masks')
+    return outs
+
+
 def dropout_mask(x, mask, p=0.5):
     """y = x * mask / (1 - p) for an explicit uint8 keep-mask (None: identity)."""
     if mask is None:

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ARVAE_ABI_VERSION 11  /* 11: arvae_adam_step(status): the update is skipped while the sticky status word is set (a pass that reported a failed hand-off never reaches the weights), ARVAE_STATUS_* re-coded so that the word survives a float SUM all-reduce beside the gradients; 10: arvae_comm_init(timeout_ms); arvae_image_vae_t.status / .flags (a sticky device status word: an in-launch hand-off between workgroups that gives up says so there instead of hanging; ARVAE_VAE_NO_CLUSTER keeps the pass on kernels without such hand-offs); 9: arvae_measure_vae_* (whole-model MeasureVAE step), row strides for h0 / dh0 / the beat embeddings (arvae_gru_seq_t, arvae_tick_*); 8: arvae_gru_seq_t.gi_rstride / dgi_rstride / h_fin (merged input projections of a bidirectional layer, final states written by the sequence launch); 7: arvae_comm_* (the data-parallel step's collectives: RCCL on the launch stream, owned by the library); 6: the 32-channel k4 s2 p1 links need caller workspace too (arvae_link_ws_floats / arvae_link_wgrad_ws_floats: the layer's weights as scaled fp16 terms and the operands' maxima); 5: arvae_adam_step(zero_grad), arvae_image_vae_finish, arvae_image_vae_t.milestones (events the executors record for the data-parallel caller's collectives); 4: arvae_philox_* and in-kernel eps (arvae_image_vae_t.rng_*), arvae_tick_free_run_supported, caller workspace for arvae_link_down/up (arvae_link_ws_floats); 3: arvae_gru_seq_*, embed_bwd workspace; 2: arvae_image_vae_backward reg_fused == 2 (unit regulariser gradient in dz_extra) */
+#define ARVAE_ABI_VERSION 11  /* 11: arvae_philox_keep_masks (several Dropout masks, one launch); arvae_adam_step(status): the update is skipped while the sticky status word is set (a pass that reported a failed hand-off never reaches the weights), ARVAE_STATUS_* re-coded so that the word survives a float SUM all-reduce beside the gradients; 10: arvae_comm_init(timeout_ms); arvae_image_vae_t.status / .flags (a sticky device status word: an in-launch hand-off between workgroups that gives up says so there instead of hanging; ARVAE_VAE_NO_CLUSTER keeps the pass on kernels without such hand-offs); 9: arvae_measure_vae_* (whole-model MeasureVAE step), row strides for h0 / dh0 / the beat embeddings (arvae_gru_seq_t, arvae_tick_*); 8: arvae_gru_seq_t.gi_rstride / dgi_rstride / h_fin (merged input projections of a bidirectional layer, final states written by the sequence launch); 7: arvae_comm_* (the data-parallel step's collectives: RCCL on the launch stream, owned by the library); 6: the 32-channel k4 s2 p1 links need caller workspace too (arvae_link_ws_floats / arvae_link_wgrad_ws_floats: the layer's weights as scaled fp16 terms and the operands' maxima); 5: arvae_adam_step(zero_grad), arvae_image_vae_finish, arvae_image_vae_t.milestones (events the executors record for the data-parallel caller's collectives); 4: arvae_philox_* and in-kernel eps (arvae_image_vae_t.rng_*), arvae_tick_free_run_supported, caller workspace for arvae_link_down/up (arvae_link_ws_floats); 3: arvae_gru_seq_*, embed_bwd workspace; 2: arvae_image_vae_backward reg_fused == 2 (unit regulariser gradient in dz_extra) */
 
 #define ARVAE_OK 0
 #define ARVAE_E_INVALID (-1)  /* bad argument (null pointer, size out of range, unsupported shape) */
@@ -591,12 +591,16 @@ int arvae_measure_vae_backward(const arvae_measure_vae_t *model, int32_t batch, 
  * HIP graph advance the stream by itself.  The reference draws from torch's global generator instead; parity runs pass
  * explicit eps / masks, so only the distribution has to agree (tests: known-answer vectors, moments, determinism).
  * arvae_philox_normal: one N(0,1) value per element (Box-Muller).  arvae_philox_keep_mask: uint8 1 with probability
- * keep_prob (quantised to 1/256), out 16-byte aligned.
+ * keep_prob (quantised to 1/256), out 16-byte aligned.  arvae_philox_keep_masks: up to 8 such masks (the five Dropout(0.5)
+ * layers of imagevae/mnist_vae.py:16-47) as ONE launch; mask j is draw offsets[j] of the step: the same bytes as
+ * arvae_philox_keep_mask(outs[j], counts[j], keep_prob, seed, offsets[j], step, dev_step).
  * ------------------------------------------------------------------------------------------------ */
 int arvae_philox_normal(float *out, int64_t count, uint64_t seed, uint32_t offset, uint32_t step, const uint32_t *dev_step,
                         arvae_stream_t stream);
 int arvae_philox_keep_mask(uint8_t *out, int64_t count, float keep_prob, uint64_t seed, uint32_t offset, uint32_t step,
                            const uint32_t *dev_step, arvae_stream_t stream);
+int arvae_philox_keep_masks(int32_t n_masks, uint8_t *const *outs, const int64_t *counts, float keep_prob, uint64_t seed,
+                            const uint32_t *offsets, uint32_t step, const uint32_t *dev_step, arvae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Debug-mode failure checks (off by default; the Python side runs them with ARVAE_CHECK=1 and raises ValueError as the

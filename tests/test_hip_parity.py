@@ -1548,6 +1548,20 @@ def test_philox_draws_vs_oracle(dev):
     np.testing.assert_array_equal(mask.cpu().numpy(), philox.keep_mask(n, 0.5, seed, offset=1))
     assert lib.arvae_philox_keep_mask(ops._ptr(mask), n, 0.75, seed, 2, 0, None, st) == 0
     np.testing.assert_array_equal(mask.cpu().numpy(), philox.keep_mask(n, 0.75, seed, offset=2))
+    # several masks of a step as ONE launch (the five Dropout layers of the Morpho-MNIST model): mask j = draw offsets[j], byte
+    # for byte the single-mask launch's, ragged lengths included
+    try:
+        ops.rng_reseed(1234)
+        ops.RngState.dev_step = None
+        shapes = [(37, 64, 5, 5), (3, 7, 11), (16,), (1024, 8, 19, 19), (5, 64, 22, 22)]
+        first = ops.rng_next_offset() + 1
+        many = ops.keep_masks(shapes, 0.5, dev)
+        for j, (m, shp) in enumerate(zip(many, shapes)):
+            assert tuple(m.shape) == shp and m.dtype == torch.uint8
+            np.testing.assert_array_equal(m.cpu().numpy().ravel(), philox.keep_mask(int(np.prod(shp)), 0.5, ops.rng_seed(), offset=first + j))
+        assert 0.49 < float(many[3].float().mean()) < 0.51
+    finally:
+        ops.rng_reseed(torch.initial_seed())
 
 
 def test_device_draws_follow_the_data_parallel_rank(dev):

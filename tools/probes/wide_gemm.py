@@ -11,8 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from arvae_amd import _lib  # noqa: E402
 
-_lib.load()
-dll = ctypes.CDLL(os.environ.get('ARVAE_LIB') or _lib.LIB_PATH)
+dll = ctypes.CDLL(os.environ.get('ARVAE_LIB') or os.path.join(ROOT, 'ar-vae_amd', 'libarvae_hip_diag.so'))      # (arvae_debug_* live in the diagnostic build)
 fn = dll.arvae_debug_wide_gemm
 fn.restype = ctypes.c_int
 fn.argtypes = [ctypes.c_int] * 6 + [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
