@@ -4,7 +4,7 @@
 # (counters only: no trace domain beside them; the program directly after `--`), summarised per kernel for the kernels with the
 # most time in a step:  tools/pmc_sq_round.sh [tag]  ->  gpurun_out/prof_<tag>/<workload>_sq_counters.txt, sq_counters.json
 cd "$(dirname "$0")/.."
-tag=${1:-r5}
+tag=${1:-r6}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp

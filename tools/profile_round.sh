@@ -4,7 +4,7 @@
 # 1. kernel-trace stats of the default bench command (dSprites) and of the two secondary workloads,
 # 2. separate --pmc passes (FETCH_SIZE, WRITE_SIZE cannot share a pass) for the HBM traffic of the dSprites kernels.
 cd "$(dirname "$0")/.."
-tag=${1:-r5}
+tag=${1:-r6}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp

@@ -5,7 +5,7 @@
 #   3. the stress loop of the data-parallel MeasureVAE graph-replay path (tools/dp_replay_loop.sh).
 #   bash tools/run_dp_check.sh [tag=r5]   -> gpurun_out/dp_check_<tag>.txt, gpurun_out/<tag>_dp_timeline.txt
 cd "$(dirname "$0")/.."
-tag=${1:-r5}
+tag=${1:-r6}
 out=gpurun_out/dp_check_$tag.txt
 mkdir -p gpurun_out
 : > $out
