@@ -907,12 +907,18 @@ extern "C" int arvae_debug_wide_gemm(int32_t a_planes, int32_t b_krows, int32_t 
 }
 #endif
 
-// the tile extent a product runs with: 128 x 128 (half the operand traffic per multiply-add: at 64 x 64 the four Morpho-MNIST
-// products were bound by L2 -> LDS bytes, 12 of their 23 us with every MFMA, LDS write and result store switched off,
-// tools/probes/wide_gemm.py) when both output extents have more than one 64-tile
+// The tile extent a product runs with.  64 x 64, four or five 32 KB workgroups per CU.  The 128 x 128 form (half the operand
+// traffic per multiply-add, one 120 KB workgroup per CU) is kept in the diagnostic build for A/B runs: with every MFMA, LDS write
+// and result store switched off it moves its bytes in 9.3 us against 12.3 (tools/probes/wide_gemm.py), but one wave per SIMD then
+// runs loads, commits, MFMAs and stores one after the other: 31-34 us per product against 20-21.
 static int wide_tile(int M, int N) {
-    static const bool big = diag_env("ARVAE_WIDE_TILE128") != nullptr;      // diagnostic build: the 128 x 128 form
+#ifdef ARVAE_DIAG
+    static const bool big = diag_env("ARVAE_WIDE_TILE128") != nullptr;      // diagnostic build only: the 128 x 128 form
     return (big && M > 64 && N > 64) ? 128 : 64;
+#else
+    (void)M; (void)N;
+    return 64;
+#endif
 }
 // K slices that fill the chip: tiles x slices ~ one (128) or two (64) workgroups per CU, a slice at least four chunks long
 int wide_gemm_slices(int M, int N, int K) {
@@ -973,8 +979,11 @@ int wide_gemm(WideGemm g, int slices, bool partial, hipStream_t s) {
     g.kslice = ((chunks + slices - 1) / slices) * RG_R;
     const int T = wide_tile(g.M, g.N);
     const dim3 grid((g.M + T - 1) / T, (g.N + T - 1) / T, slices);
+#ifdef ARVAE_DIAG
     if (T == 128) dispatch_wide<2>(g, partial, grid, s);
-    else dispatch_wide<1>(g, partial, grid, s);
+    else
+#endif
+        dispatch_wide<1>(g, partial, grid, s);
     return check_launch(partial ? "wide_gemm(partial)" : "wide_gemm(full)");
 }
 
