@@ -1521,8 +1521,11 @@ template <int LO> static int launch_pair_big(const arvae_link_t *l, bool up, con
                                              const C1Wgrad *c1 = nullptr, int *grid_a_out = nullptr) {
     const int cus = cu_count() < AMAX_N / 4 ? cu_count() : AMAX_N / 4;
     int grid_a = cus * (c1 != nullptr ? pair_split_c1_percent() : pair_split_percent(LO, up)) / 100;
-    if (grid_a_out != nullptr) *grid_a_out = grid_a;
     if (grid_a < 1) grid_a = 1;
+    if (grid_a_out != nullptr) *grid_a_out = grid_a;             // (after the clamp: the caller sizes the slab reduction with it)
+    // the first layer's slabs (one per workgroup of the Up half) live in that layer's weight-gradient workspace, which make_layout
+    // sizes for wgrad_c1_groups() <= 256 workgroups (conv_c1.hip): a split or a CU cap that asks for more must not write past it
+    ARVAE_REQUIRE(c1 == nullptr || grid_a <= 256, "pair_up16_wgrad: %d workgroups of the Up half exceed the first layer's 256 weight-gradient slabs", grid_a);
     int total, spw, grid_b;
     stream_geometry(l, cus - grid_a, total, spw, grid_b);
     *grid_b_out = grid_b;

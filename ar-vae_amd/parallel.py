@@ -94,6 +94,23 @@ def all_present(store, key, rank, world, timeout):
         time.sleep(0.01)
 
 
+class CommInitError(RuntimeError):
+    """arvae_comm_init failed or timed out.  After a TIME-OUT its helper thread is still inside ncclCommInitRank: the process must
+    not go through a normal interpreter shutdown (HIP / RCCL static destructors beside that live thread can hang or crash) --
+    `leave_after_comm_failure()` is how the CLIs and bench.py go."""
+
+
+def leave_after_comm_failure(exc, code=5):
+    """print the error, flush, and leave the process without running destructors (see CommInitError)"""
+    import sys
+    print(f'libarvae_hip: {exc}; leaving the process', file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    os._exit(code)
+
+
+_KEYS_USED = set()          # store keys this process has built a communicator under (a key's rendezvous counter is never reset)
+
+
 class LibraryComm:
     """RCCL communicator owned through libarvae_hip.so (arvae_comm_*).  Collectives take contiguous device tensors and are
     enqueued on torch's CURRENT stream; nothing here synchronises except barrier()."""
@@ -110,6 +127,12 @@ class LibraryComm:
         self.rank, self.world_size = int(rank), int(world)
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         torch.cuda.set_device(self.device)
+        if self.world_size > 1:
+            # one communicator per store key: the key's unique id and its 'present' counter stay in the store, so a second
+            # rendezvous under the same key would pass the gate at once and read the previous id
+            if key in _KEYS_USED:
+                raise ValueError(f'store key {key!r} has been used for a communicator already: give every communicator of a job its own key')
+            _KEYS_USED.add(key)
         nbytes = 128
         self.handle = None
         if self.rank == 0:
@@ -128,8 +151,11 @@ class LibraryComm:
             # them inside RCCL
             self._all_present(store, key + '/present')
         handle = ctypes.c_void_p()
-        _lib.check(self.lib.arvae_comm_init(ident, self.rank, self.world_size, int(JOIN_TIMEOUT_S * 1000), ctypes.byref(handle)),
-                   'comm_init')
+        try:
+            _lib.check(self.lib.arvae_comm_init(ident, self.rank, self.world_size, int(JOIN_TIMEOUT_S * 1000), ctypes.byref(handle)),
+                       'comm_init')
+        except RuntimeError as e:
+            raise CommInitError(str(e)) from e
         self.handle = handle
         self.store = store                                      # rank 0 hosts it: alive as long as the communicator
         self._self_test()
@@ -418,7 +444,10 @@ def init_from_env():
         os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
-    return DataParallel(comm=connect())
+    try:
+        return DataParallel(comm=connect())
+    except CommInitError as e:                                  # (never returns: see CommInitError)
+        leave_after_comm_failure(e)
 
 
 class DataParallel:

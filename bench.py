@@ -893,7 +893,10 @@ def main():
         from arvae_amd import parallel
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
-        COMM = parallel.connect(rank, world, device)
+        try:
+            COMM = parallel.connect(rank, world, device)
+        except parallel.CommInitError as e:                      # the init helper thread may still be inside RCCL: no destructors
+            parallel.leave_after_comm_failure(e)
     fence = Fence(device, COMM)
 
     if args.workload != 'dsprites':
