@@ -465,6 +465,24 @@ def test_image_step_ragged_batches_vs_oracle(dev, b):
         assert np.linalg.norm(gr - want) <= 2e-3 * np.linalg.norm(want) + 1e-9, name
 
 
+@pytest.mark.parametrize('b,train', [(37, True), (130, True), (67, False)], ids=['b37_train', 'b130_train', 'b67_eval'])
+def test_mnist_step_ragged_batches_vs_oracle(dev, b, train):
+    """Morpho-MNIST at batch sizes that leave partial tiles in the wide Linear layers' tile GEMMs (round 6: dense.hip
+    wide_gemm_x3_kernel / wide_wgrad_x3_kernel: 64-row tiles with 37 / 3 / 2 live rows, split reductions of 16 / 4 / 8 slices, the
+    bf16 planes of the small activations read along a batch that is no multiple of the 32-row chunk) and in the 64-channel conv
+    kernels; train mode with explicit keep-masks, eval mode without."""
+    state = syn.synth_state(o_vae.SHAPES['mnist'], 3, 0.7)
+    x, lab = syn.mnist_batch(b, seed=900 + b)
+    eps = syn.normal_noise((b, 16), seed=910 + b)
+    masks = syn.dropout_masks([(b,) + s for s in o_vae.MNIST_MASK_SHAPES], 920 + b) if train else None
+    got = run_hip_image_step(dev, 'mnist', state, x, lab, eps, 1.0, 0.0, 'bernoulli', masks, train=train)
+    ref = o_step.image_step('mnist', state, x, lab, eps, (1, 2, 3, 4, 5, 6), 1.0, 10.0, 1.0, masks=masks)
+    _compare_step(got['terms'], got['loss'], got['acc'], got['grads'], ref, 2e-3)
+    outs = got['trainer'].last_outputs
+    close(outs['z'], ref['terms']['z'], rtol=0, atol=1e-4)
+    close(outs['mu'], ref['terms']['mu'], rtol=0, atol=1e-4)
+
+
 def _full_batch_grads(dev, scale, seed=7):
     from arvae_amd.image_vae import DspritesVAE
     from arvae_amd.image_vae_trainer import ImageVAETrainer
