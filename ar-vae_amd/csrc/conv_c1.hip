@@ -14,6 +14,7 @@
 #include "reduce.h"
 #include "prep32.h"
 #include "wgrad_c1s.h"
+#include "vae_finish.h"
 
 namespace arvae {
 
@@ -174,9 +175,17 @@ __global__ __launch_bounds__(256, 2) void up_c1_kernel(const float *__restrict__
                                                         const float *__restrict__ bias_p, float *__restrict__ out,
                                                         const float *__restrict__ x, float inv_b,
                                                         float *__restrict__ partial, float *__restrict__ dlogits, int n_img,
-                                                        int n_tiles) {
+                                                        int n_tiles, VaeFinishArgs fin = VaeFinishArgs{},
+                                                        VaeFinishArgs *__restrict__ fin_dst = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float lds[];                // 2 x T_FLOATS
     __shared__ float red[4];
+    // a training pass that leaves its finishing step to the backward pass (ARVAE_VAE_DEFER_FINISH, vae_finish.h): the step's
+    // arguments are parked in the workspace for the launch that will run it, and until it has run the pass's eight scalars read
+    // as NaN -- a caller that looks too early sees it
+    if (fin_dst != nullptr && blockIdx.x == 0) {
+        if (threadIdx.x == 0) *fin_dst = fin;
+        if (threadIdx.x < 8 && fin.scalars != nullptr) fin.scalars[threadIdx.x] = __builtin_nanf("");
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, li = lane & 15;
     float wreg[2][4];                                   // wt[c = 16s + 4g + j][tap = li]
 #pragma unroll
@@ -274,10 +283,22 @@ __global__ __launch_bounds__(64 * WGS_WAVES) void wgrad_c1s_kernel(Operand lo, O
 // more bytes than either alone, and a launch ramp and a tail are saved.
 template <int GATE>
 __global__ __launch_bounds__(64 * WGS_WAVES) void pair_c1_kernel(Operand d_img, const float *__restrict__ wt, Ep1 ep, int n_rows_d,
-                                                                 Operand w_lo, Operand w_img, float *__restrict__ slab, int n_rows_w, int grid_a) {
+                                                                 Operand w_lo, Operand w_img, float *__restrict__ slab, int n_rows_w, int grid_a,
+                                                                 int rider, const VaeFinishArgs *__restrict__ fin) {
     __shared__ __attribute__((aligned(16))) float raw[WGS_WAVES * LO1 * WS1 + WGS_WAVES * 4 * IMS];
-    if ((int)blockIdx.x < grid_a) down_c1s_body<GATE, WGS_WAVES>(d_img, wt, ep, n_rows_d, blockIdx.x, grid_a, raw);
-    else wgrad_c1s_body(w_lo, w_img, slab, n_rows_w, blockIdx.x - grid_a, gridDim.x - grid_a, raw, raw + WGS_WAVES * LO1 * WS1);
+    // round 6: the forward pass's finishing step, left to this launch by a training step (vae_finish.h), as workgroup 0 of the
+    // grid (rider = 1: the pair's own workgroups follow; the weight-gradient role gives up one workgroup so that the whole grid is
+    // still resident at once -- dispatched LAST the rider waited for a slot until the pair was done: no gain).  Nothing in this
+    // launch reads what it writes.
+    if (rider && blockIdx.x == 0) {
+        static_assert(64 * WGS_WAVES == 512, "the finishing body is instantiated for this kernel's 512 threads");
+        const VaeFinishArgs args = *fin;                        // (parked in the workspace by the forward pass's last launch)
+        vae_finish_body<512>(args, reinterpret_cast<float4 *>(raw));
+        return;
+    }
+    const int bid = (int)blockIdx.x - rider, nblk = (int)gridDim.x - rider;
+    if (bid < grid_a) down_c1s_body<GATE, WGS_WAVES>(d_img, wt, ep, n_rows_d, bid, grid_a, raw);
+    else wgrad_c1s_body(w_lo, w_img, slab, n_rows_w, bid - grid_a, nblk - grid_a, raw, raw + WGS_WAVES * LO1 * WS1);
 }
 static_assert(WGS_WAVES * LO1 * PS1 <= WGS_WAVES * LO1 * WS1, "pair_c1_kernel: the down body's row tiles fit the shared allocation");
 
@@ -479,9 +500,11 @@ int conv_c1_up(const arvae_link_t *l, const float *lo, const float *wt, const fl
 int conv_c1_up_recon_blocks(const arvae_link_t *l) { return up_c1_grid(l->n * (LO1 / TRU)); }
 
 int conv_c1_up_recon(const arvae_link_t *l, const float *lo, const float *wt, const float *bias, float *out, const float *x,
-                     int dist, float *partial, float *dlogits, hipStream_t s, int *nb_out) {
+                     int dist, float *partial, float *dlogits, hipStream_t s, int *nb_out, const VaeFinishArgs *fin, VaeFinishArgs *fin_dst) {
     const int tiles = l->n * (LO1 / TRU), grid = up_c1_grid(tiles);
     const float inv_b = 1.f / (float)l->n;
+    const VaeFinishArgs fa = fin != nullptr ? *fin : VaeFinishArgs{};
+    if (fin == nullptr) fin_dst = nullptr;
     static std::once_flag attr;
     std::call_once(attr, [&] {
         up_c1_lds(up_c1_kernel<ARVAE_RECON_BERNOULLI, true>);
@@ -489,10 +512,10 @@ int conv_c1_up_recon(const arvae_link_t *l, const float *lo, const float *wt, co
     });
     if (dist == ARVAE_RECON_BERNOULLI)
         ARVAE_LAUNCH((up_c1_kernel<ARVAE_RECON_BERNOULLI, true>), dim3(grid), dim3(256), 2 * T_FLOATS * 4, s, lo, wt, bias,
-                           out, x, inv_b, partial, dlogits, l->n, tiles);
+                           out, x, inv_b, partial, dlogits, l->n, tiles, fa, fin_dst);
     else
         ARVAE_LAUNCH((up_c1_kernel<ARVAE_RECON_GAUSSIAN, true>), dim3(grid), dim3(256), 2 * T_FLOATS * 4, s, lo, wt, bias,
-                           out, x, inv_b, partial, dlogits, l->n, tiles);
+                           out, x, inv_b, partial, dlogits, l->n, tiles, fa, fin_dst);
     *nb_out = grid;
     return check_launch("up_c1_kernel(recon)");
 }
@@ -513,6 +536,17 @@ int conv_c1_wgrad_partial(const arvae_link_t *l, const Operand &lo, const Operan
     return check_launch("wgrad_c1_kernel");
 }
 
+// the deferred finishing step by itself (a backward pass whose first launch is not the paired one above)
+__global__ __launch_bounds__(512) void vae_finish_deferred_kernel(const VaeFinishArgs *__restrict__ fin) {
+    __shared__ float4 red4[8];
+    const VaeFinishArgs args = *fin;
+    vae_finish_body<512>(args, red4);
+}
+int vae_finish_deferred(const VaeFinishArgs *fin_dev, hipStream_t s) {
+    ARVAE_LAUNCH(vae_finish_deferred_kernel, dim3(1), dim3(512), 0, s, fin_dev);
+    return check_launch("image_vae_backward(finish)");
+}
+
 // gated data gradient of the forward-UP single-channel link + its weight-gradient partials in one launch (pair_c1_kernel)
 bool conv_c1_pair_fits(const arvae_link_t *l) {
     static const bool off = diag_env("ARVAE_NO_PAIR_C1") != nullptr;
@@ -520,13 +554,14 @@ bool conv_c1_pair_fits(const arvae_link_t *l) {
 }
 int conv_c1_pair(const arvae_link_t *l, const Operand &g_img, const float *wt, const float *gate, const uint16_t *gate_bits, float *d_lo,
                  const Operand &w_lo, float *dwt, float *dbias, int bias_mode, float *slab, hipStream_t s, SlabJob *job,
-                 unsigned *amax_out) {
+                 unsigned *amax_out, const VaeFinishArgs *finish) {
     Ep1 ep{nullptr, gate, gate_bits, nullptr, d_lo, 0, amax_out};
-    const int n_rows = l->n * LO1, grid_a = 256, grid_b = wgrad_c1_groups(l);
-    const dim3 grid(grid_a + grid_b);
-    if (gate_bits != nullptr) ARVAE_LAUNCH(pair_c1_kernel<1>, grid, dim3(64 * WGS_WAVES), 0, s, g_img, wt, ep, n_rows, w_lo, g_img, slab, n_rows, grid_a);
-    else if (gate != nullptr) ARVAE_LAUNCH(pair_c1_kernel<2>, grid, dim3(64 * WGS_WAVES), 0, s, g_img, wt, ep, n_rows, w_lo, g_img, slab, n_rows, grid_a);
-    else ARVAE_LAUNCH(pair_c1_kernel<0>, grid, dim3(64 * WGS_WAVES), 0, s, g_img, wt, ep, n_rows, w_lo, g_img, slab, n_rows, grid_a);
+    const int rider = finish != nullptr ? 1 : 0;                // (+ the deferred finishing step's workgroup; finish: DEVICE pointer)
+    const int n_rows = l->n * LO1, grid_a = 256, grid_b = wgrad_c1_groups(l) - rider;
+    const dim3 grid(rider + grid_a + grid_b);
+    if (gate_bits != nullptr) ARVAE_LAUNCH(pair_c1_kernel<1>, grid, dim3(64 * WGS_WAVES), 0, s, g_img, wt, ep, n_rows, w_lo, g_img, slab, n_rows, grid_a, rider, finish);
+    else if (gate != nullptr) ARVAE_LAUNCH(pair_c1_kernel<2>, grid, dim3(64 * WGS_WAVES), 0, s, g_img, wt, ep, n_rows, w_lo, g_img, slab, n_rows, grid_a, rider, finish);
+    else ARVAE_LAUNCH(pair_c1_kernel<0>, grid, dim3(64 * WGS_WAVES), 0, s, g_img, wt, ep, n_rows, w_lo, g_img, slab, n_rows, grid_a, rider, finish);
     *job = SlabJob{slab, dwt, dbias, grid_b, SLAB_C1, bias_mode};
     return check_launch("pair_c1(down_c1 + wgrad_c1)");
 }

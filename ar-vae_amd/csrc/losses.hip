@@ -5,6 +5,7 @@
 #include "common.h"
 #include "attributes.h"
 #include "regloss.h"
+#include "vae_finish.h"
 
 namespace arvae {
 
@@ -35,11 +36,7 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(const float *__restrict
 // =================================================================================================
 // beta-KL: one workgroup (B*Z is a few thousand elements), fixed summation order
 // =================================================================================================
-__device__ __forceinline__ float kl_elem(float mu, float s, float m0, float s0) {
-    const float r = s / s0, d = (mu - m0) / s0;
-    const float var = r * r;
-    return 0.5f * (var + d * d - 1.f - logf(var));       // torch _kl_normal_normal
-}
+// (kl_elem: vae_finish.h)
 
 __global__ __launch_bounds__(256) void kld_fwd_kernel(const float *__restrict__ mu, const float *__restrict__ sg,
                                                        const float *__restrict__ pm, const float *__restrict__ ps,
@@ -387,77 +384,10 @@ __device__ __forceinline__ float block_sum_1024(float v, float *red) {       // 
     return t;
 }
 
-struct VaeFinishArgs {
-    const float *rec_partial; int nb; float inv_batch, inv_count, inv_rec;     // reconstruction (inv_rec scales the summed term)
-    const float *mu, *sigma; int64_t bz; float beta; const float *cap;         // KL
-    const float *row_loss, *row_grad; int64_t n_rows; int r; RegDims dims;     // regulariser (row_loss null: none)
-    int64_t ldz; float loss_scale, grad_scale, reg_scale; float *dz;
-    float *rec_out, *kld_out, *reg_out, *scalars;
-};
-
+// (VaeFinishArgs and the finishing body: vae_finish.h -- the last decoder layer's backward launch can carry it, conv_c1.hip)
 __global__ __launch_bounds__(1024) void vae_finish_kernel(VaeFinishArgs p) {
     __shared__ float4 red4[16];
-    // One workgroup, so the kernel is as long as its chain of dependent memory round trips: the first FU * 1024 elements of
-    // every array (all of them at the sizes of this repo's models) are loaded before anything is summed -- one round trip --
-    // and only what is left beyond that runs as plain loops.  Fixed summation order; 32-bit index math throughout.
-    constexpr int FU = 8;
-    float a = 0.f, b = 0.f, s = 0.f, t = 0.f;
-    const int bz = (int)p.bz;
-    const bool reg = p.row_loss != nullptr, want_dz = reg && p.dz != nullptr;
-    const int n_rows = (int)p.n_rows, ldz = (int)p.ldz, nr = reg ? n_rows * p.r : 0, nz = want_dz ? n_rows * ldz : 0;
-    int n_max = p.nb > bz ? p.nb : bz;
-    n_max = n_max > nr ? n_max : nr;
-    n_max = n_max > nz ? n_max : nz;
-    // passes of FU * 1024 elements of every array, all loads of a pass before its sums (one pass at the dSprites sizes, two for
-    // Morpho-MNIST's 1024 x 16 latent values)
-    for (int base = 0; base < n_max; base += FU * 1024) {
-        float2 rp[FU];
-        float mu[FU], sg[FU], rl[FU], rg[FU];
-        int dk[FU];
-#pragma unroll
-        for (int u = 0; u < FU; ++u) {
-            const int i = base + threadIdx.x + u * 1024;
-            rp[u] = reinterpret_cast<const float2 *>(p.rec_partial)[i < p.nb ? i : 0];
-            mu[u] = p.mu[i < bz ? i : 0];
-            sg[u] = p.sigma[i < bz ? i : 0];
-            rl[u] = reg ? p.row_loss[i < nr ? i : 0] : 0.f;
-            // dz[row][c] = grad_scale * row_grad[k][row] for c = dims[k], else 0: index arithmetic, then ONE unconditional load
-            const int ic = i < nz ? i : 0, row = ic / (ldz > 0 ? ldz : 1), c = ic - row * ldz;
-            int k = -1;
-#pragma unroll
-            for (int q = 0; q < 16; ++q)
-                if (q < p.r && p.dims.d[q] == c) k = q;
-            dk[u] = k;
-            rg[u] = want_dz ? p.row_grad[(k < 0 ? 0 : k) * n_rows + row] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < FU; ++u) {
-            const int i = base + threadIdx.x + u * 1024;
-            if (i < p.nb) { a += rp[u].x; b += rp[u].y; }
-            if (i < bz) s += kl_elem(mu[u], sg[u], 0.f, 1.f);
-            if (i < nr) t += rl[u];
-            if (i < nz) p.dz[i] = dk[u] < 0 ? 0.f : p.grad_scale * rg[u];
-        }
-    }
-    float4 v = make_float4(wave_sum(a), wave_sum(b), wave_sum(s), wave_sum(t));
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) red4[wave] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int w = 0; w < 16; ++w) { tot.x += red4[w].x; tot.y += red4[w].y; tot.z += red4[w].z; tot.w += red4[w].w; }
-        const float rec = tot.x * p.inv_rec, acc = tot.y * p.inv_count, kl = tot.z * p.inv_batch, reg = tot.w * p.loss_scale;
-        const float dist = p.beta * fabsf(kl - (p.cap ? p.cap[0] : 0.f));
-        p.rec_out[0] = rec; p.rec_out[1] = acc;
-        p.kld_out[0] = dist; p.kld_out[1] = kl;
-        if (p.row_loss != nullptr) p.reg_out[0] = reg;
-        const float rs = p.row_loss != nullptr ? p.reg_scale * reg : 0.f;
-        float *o = p.scalars;
-        o[ARVAE_VAE_RECON] = rec; o[ARVAE_VAE_ACC] = acc; o[ARVAE_VAE_DIST] = dist; o[ARVAE_VAE_KL] = kl;
-        o[ARVAE_VAE_REG] = rs; o[ARVAE_VAE_LOSS] = rec + dist + rs;
-        o[6] = o[7] = 0.f;
-    }
+    vae_finish_body<1024>(p, red4);
 }
 
 int recon_partial_blocks(int64_t count) { return grid_for(count, 8, RECON_MAX_BLOCKS); }
@@ -503,10 +433,10 @@ int reg_partials(const float *z_rows, const float *lab_rows, int64_t n_rows, con
     return check_launch("reg_loss");
 }
 
-int vae_finish(const float *rec_partial, int nb, int64_t batch, int64_t pix, const float *mu, const float *sigma,
-               int64_t zdim, float beta, const float *cap, const float *reg_ws, int64_t n_cols, int64_t ldz,
-               const int32_t *dims, int32_t r, float gamma, float delta, float reg_scale, float *dz, float *rec_out,
-               float *kld_out, float *reg_out, float *scalars, hipStream_t s, int64_t rec_rows) {
+VaeFinishArgs vae_finish_args(const float *rec_partial, int nb, int64_t batch, int64_t pix, const float *mu, const float *sigma,
+                              int64_t zdim, float beta, const float *cap, const float *reg_ws, int64_t n_cols, int64_t ldz,
+                              const int32_t *dims, int32_t r, float gamma, float delta, float reg_scale, float *dz, float *rec_out,
+                              float *kld_out, float *reg_out, float *scalars, int64_t rec_rows) {
     VaeFinishArgs p{};
     p.rec_partial = rec_partial; p.nb = nb; p.inv_batch = 1.f / (float)batch; p.inv_count = 1.f / (float)pix;
     p.inv_rec = rec_rows > 0 ? 1.f / (float)rec_rows : p.inv_batch;     // (a mean over rows instead of a per-sample sum: the token term)
@@ -520,8 +450,20 @@ int vae_finish(const float *rec_partial, int nb, int64_t batch, int64_t pix, con
     }
     p.reg_scale = reg_scale;
     p.rec_out = rec_out; p.kld_out = kld_out; p.reg_out = reg_out; p.scalars = scalars;
+    return p;
+}
+
+int vae_finish_launch(const VaeFinishArgs &p, hipStream_t s) {
     ARVAE_LAUNCH(vae_finish_kernel, dim3(1), dim3(1024), 0, s, p);
     return check_launch("image_vae_forward(finish)");
+}
+
+int vae_finish(const float *rec_partial, int nb, int64_t batch, int64_t pix, const float *mu, const float *sigma,
+               int64_t zdim, float beta, const float *cap, const float *reg_ws, int64_t n_cols, int64_t ldz,
+               const int32_t *dims, int32_t r, float gamma, float delta, float reg_scale, float *dz, float *rec_out,
+               float *kld_out, float *reg_out, float *scalars, hipStream_t s, int64_t rec_rows) {
+    return vae_finish_launch(vae_finish_args(rec_partial, nb, batch, pix, mu, sigma, zdim, beta, cap, reg_ws, n_cols, ldz, dims, r, gamma, delta,
+                                             reg_scale, dz, rec_out, kld_out, reg_out, scalars, rec_rows), s);
 }
 
 }  // namespace arvae

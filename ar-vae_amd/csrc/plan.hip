@@ -7,6 +7,7 @@
 #include "reduce.h"
 #include "midprep.h"
 #include "regloss.h"
+#include "vae_finish.h"
 #include "conv32_common.h"
 
 namespace arvae {
@@ -40,7 +41,13 @@ int conv32_up(const arvae_link_t *l, const Operand &lo, const float *bias, int r
               uint16_t *bits_out, float *out, hipStream_t s, const float *wprep, const unsigned *amax_in, unsigned *amax_out);
 int conv32_amax(const float *x, int64_t count, unsigned *out, hipStream_t s);
 int conv_c1_up_recon(const arvae_link_t *l, const float *lo, const float *wt, const float *bias, float *out, const float *x,
-                     int dist, float *partial, float *dlogits, hipStream_t s, int *nb_out);
+                     int dist, float *partial, float *dlogits, hipStream_t s, int *nb_out, const VaeFinishArgs *fin = nullptr,
+                     VaeFinishArgs *fin_dst = nullptr);
+int vae_finish_deferred(const VaeFinishArgs *fin_dev, hipStream_t s);
+VaeFinishArgs vae_finish_args(const float *rec_partial, int nb, int64_t batch, int64_t pix, const float *mu, const float *sigma,
+                              int64_t zdim, float beta, const float *cap, const float *reg_ws, int64_t n_cols, int64_t ldz,
+                              const int32_t *dims, int32_t r, float gamma, float delta, float reg_scale, float *dz, float *rec_out,
+                              float *kld_out, float *reg_out, float *scalars, int64_t rec_rows);
 bool conv32_up_reg_fits(const arvae_link_t *l);
 int conv32_up_reg(const arvae_link_t *l, const Operand &lo, const float *bias, uint16_t *bits_out, float *out, const float *wprep,
                   const unsigned *amax_in, unsigned *amax_out, const RegArgs &reg, int r, hipStream_t s);
@@ -60,7 +67,7 @@ int conv32_wgrad_partial(const arvae_link_t *l, const Operand &lo, const Operand
 bool conv_c1_pair_fits(const arvae_link_t *l);
 int conv_c1_pair(const arvae_link_t *l, const Operand &g_img, const float *wt, const float *gate, const uint16_t *gate_bits, float *d_lo,
                  const Operand &w_lo, float *dwt, float *dbias, int bias_mode, float *slab, hipStream_t s, SlabJob *job,
-                 unsigned *amax_out);
+                 unsigned *amax_out, const VaeFinishArgs *finish = nullptr);
 int conv_c1_wgrad_partial(const arvae_link_t *l, const Operand &lo, const Operand &img, float *dwt, float *dbias,
                           int bias_mode, float *slab, hipStream_t s, SlabJob *job);
 bool dense_wgrad_c1_fits(const DenseWgradBatch *b);
@@ -177,7 +184,7 @@ struct Layout {
     // without (the image, or what a kernel outside the conv32 / conv_c1 / latent-block family wrote)
     int64_t enc_amax[ARVAE_MAX_LAYERS], dec_amax[ARVAE_MAX_LAYERS], enc_gamax[ARVAE_MAX_LAYERS], dec_gamax[ARVAE_MAX_LAYERS];
     int64_t ga_amax, gb_amax, tmp_amax, tmp2_amax;
-    int64_t log_std, dlogits, dz_reg, d_mu, d_ls, g_a, g_b, slab, link_ws, mid_prep, mid_wide, rec_ws, reg_ws, rec_out, kld_out, reg_out, total;
+    int64_t log_std, dlogits, dz_reg, d_mu, d_ls, g_a, g_b, slab, link_ws, mid_prep, mid_wide, fin_args, rec_ws, reg_ws, rec_out, kld_out, reg_out, total;
     int64_t slab_floats;
 };
 
@@ -267,6 +274,8 @@ static int make_layout(const arvae_image_vae_t *m, int64_t n, int64_t n_cols, La
         const int64_t w = mid_wide_ws_floats(m, (int)n);     // partial products of the wide Linear layers' split reductions (dense.hip)
         L.mid_wide = w > 0 ? take(w) : -1;
     }
+    static_assert(sizeof(VaeFinishArgs) <= 64 * sizeof(float), "the parked finishing step's arguments fit their workspace slot");
+    L.fin_args = take(64);                // a deferred finishing step's arguments (ARVAE_VAE_DEFER_FINISH, vae_finish.h)
     L.rec_ws = take(arvae_recon_ws_floats(out_elems(m->dec[m->n_dec - 1], n)));
     L.reg_ws = take(arvae_reg_loss_ws_floats(n, m->n_reg > 0 ? m->n_reg : 1));
     L.rec_out = take(4);
@@ -281,6 +290,16 @@ static int make_layout(const arvae_image_vae_t *m, int64_t n, int64_t n_cols, La
 static inline void mark(void *event, hipStream_t st) {
     if (event != nullptr) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(event), st);
 }
+
+// the last decoder layer is the single-channel transposed conv whose launch also sums the reconstruction term (conv_c1.hip
+// up_c1_kernel<DIST, true>): the models a deferred finishing step exists for
+static bool recon_is_fused(const arvae_image_vae_t *m) {
+    const arvae_layer_t &last = m->dec[m->n_dec - 1];
+    return last.is_up && last.act == ARVAE_ACT_NONE && last.dropout == 0 && conv_c1_fits(&last.link) && arvae_recon_ws_floats(0) >= 2 * 1024;
+}
+// ARVAE_VAE_DEFER_FINISH honoured: the forward pass parks the finishing step's arguments (its last launch stores them), the
+// backward pass's first launch -- or a launch of its own right behind it -- runs it
+static bool finish_deferred(const arvae_image_vae_t *m) { return (m->flags & ARVAE_VAE_DEFER_FINISH) != 0 && recon_is_fused(m); }
 
 static arvae_operand_t plain(const float *v) { return arvae_operand_t{v, nullptr, nullptr, ARVAE_ACT_NONE}; }
 
@@ -346,7 +365,9 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
                           const uint16_t *gate_bits = nullptr, const float *wprep = nullptr, const GateOp *gate_op = nullptr,
                           const unsigned *g_amax = nullptr, const unsigned *in_amax = nullptr, unsigned *tmp_amax = nullptr,
                           unsigned *tmp2_amax = nullptr, unsigned *din_amax = nullptr, bool *din_has = nullptr, float *wide_prep = nullptr,
-                          const float *c1_img = nullptr, float *c1_slab = nullptr, SlabJob *c1_job = nullptr) {
+                          const float *c1_img = nullptr, float *c1_slab = nullptr, SlabJob *c1_job = nullptr,
+                          const VaeFinishArgs *finish = nullptr, bool *finish_taken = nullptr) {
+    // finish (device pointer) / finish_taken: the forward pass's deferred finishing step, for the launch that can carry it
     // c1_img / c1_slab / c1_job: this is the layer behind a single-channel first layer whose backward pass wants nothing but its
     // weight gradient: the paired launch of this layer computes that too and writes NO data gradient (conv32.hip, C1Wgrad);
     // c1_job->slab != nullptr afterwards says it did
@@ -412,8 +433,9 @@ static int layer_backward(const arvae_layer_t &l, int32_t n, const float *params
         g_op.scale = g_scale;
         SlabJob job;
         if (int rc = conv_c1_pair(&lk, g_op, w, gate_bits ? nullptr : gate, gate_bits, d_in, make_operand(&xin), dw, db, db ? 2 : 0, own_slab,
-                                  hs, &job, din_amax))
+                                  hs, &job, din_amax, finish))
             return rc;
+        if (finish != nullptr && finish_taken != nullptr) *finish_taken = true;
         slab_reduce_defer(rdefer, job);
         *gated = true;
         *din_has = din_amax != nullptr;
@@ -651,12 +673,11 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
     // decoder
     if (!mid) { h = heads_next ? ws + L.dec_out[0] : z; h_amax = nullptr; }
     int nb = 0;
-    const arvae_layer_t &last = m->dec[m->n_dec - 1];
-    const bool recon_fused = last.is_up && last.act == ARVAE_ACT_NONE && last.dropout == 0 && conv_c1_fits(&last.link) &&
-                             arvae_recon_ws_floats(0) >= 2 * 1024;
+    const bool recon_fused = recon_is_fused(m);
     // the regulariser needs z and the labels only: when this rank's batch is the whole batch its workgroups ride in the grid
     // of the first decoder convolution (conv32.hip, up32x_reg_kernel) instead of a launch of their own after the decoder
     const bool reg_here = m->n_reg > 0 && n_cols >= 0;
+    const bool defer_finish = finish_deferred(m) && n_cols != -2;
     bool reg_done = false;
     RegArgs reg_args{};
     if (reg_here) {
@@ -689,8 +710,18 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
             arvae_link_t lk = m->dec[i].link;
             lk.n = batch;
             const arvae_layer_t &l = m->dec[i];
+            // a training step may leave the finishing step to its backward pass (ARVAE_VAE_DEFER_FINISH): this launch then parks
+            // that step's arguments in the workspace and poisons the scalars (vae_finish.h)
+            VaeFinishArgs fa{};
+            if (defer_finish) {
+                const int64_t nc_d = reg_here ? reg_args.n_cols : (int64_t)batch;
+                fa = vae_finish_args(ws + L.rec_ws, conv_c1_up_recon_blocks(&lk), batch, out_elems(m->dec[m->n_dec - 1], batch), mu, sigma,
+                                     m->zdim, m->beta, capacity, reg_here ? ws + L.reg_ws : nullptr, nc_d, m->zdim, m->reg_dims, m->n_reg,
+                                     m->gamma, m->delta, reg_scale, ws + L.dz_reg, ws + L.rec_out, ws + L.kld_out, ws + L.reg_out, scalars, 0);
+            }
             if (int rc = conv_c1_up_recon(&lk, h, params + l.w_off, l.b_off >= 0 ? params + l.b_off : nullptr, logits, x,
-                                          m->recon_dist, ws + L.rec_ws, ws + L.dlogits, st, &nb))
+                                          m->recon_dist, ws + L.rec_ws, ws + L.dlogits, st, &nb, defer_finish ? &fa : nullptr,
+                                          reinterpret_cast<VaeFinishArgs *>(ws + L.fin_args)))
                 return rc;
             h_amax = nullptr;
         } else {
@@ -714,6 +745,7 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
         if (int rc = reg_partials(z, labels, batch, reg_args.zc, reg_args.lc, nc, m->zdim, ld_labels, reg_args.dims, m->n_reg, m->delta,
                                   ws + L.reg_ws, st))
             return rc;
+    if (defer_finish) return ARVAE_OK;                       // (arvae_image_vae_backward runs it: its arguments are parked in the workspace)
     return vae_finish(ws + L.rec_ws, nb, batch, pix, mu, sigma, m->zdim, m->beta, capacity,
                       reg_here ? ws + L.reg_ws : nullptr, nc, m->zdim, m->reg_dims, m->n_reg, m->gamma, m->delta, reg_scale,
                       ws + L.dz_reg, ws + L.rec_out, ws + L.kld_out, ws + L.reg_out, scalars, st);
@@ -837,6 +869,10 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
     const bool mid = mid_fusable(m, &mid_ne, &mid_nd);
     // (as the forward pass decided: the conv layers on either side of the latent block inside its launches)
     const bool fold = mid && fold_conv_layers(m, L, batch, masks, mid_ne, mid_nd);
+    // the forward pass left its finishing step (loss scalars, KL mean, the regulariser's z-gradient: the latent block below reads
+    // the last two) to this call (ARVAE_VAE_DEFER_FINISH)
+    bool finish_pending = finish_deferred(m);
+    const VaeFinishArgs *fin_dev = reinterpret_cast<const VaeFinishArgs *>(ws + L.fin_args);
     // decoder, last layer first (down to the latent block when that runs as one launch)
     const float *heads_next_g = nullptr;
     for (int i = m->n_dec - 1; i >= (mid ? mid_nd + (fold ? 1 : 0) : 0); --i) {
@@ -855,6 +891,9 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
             dst = nullptr;
         }
         bool din_has = false;
+        // (the last decoder layer's launch is the pass's first: it carries a deferred finishing step when it is the paired one)
+        const bool carry = finish_pending && i == m->n_dec - 1;
+        bool taken = false;
         if (int rc = layer_backward(m->dec[i], batch, params, grads, in, out, mask_of(dec_mask[i]), cur, pre, gate, dst,
                                     &gated, slab, ws + L.link_ws, &defer, L.dec_slab[i] >= 0 ? ws + L.dec_slab[i] : nullptr, &rdefer, stream,
                                     i == m->n_dec - 1 ? first_scale : nullptr,
@@ -862,8 +901,14 @@ extern "C" int arvae_image_vae_backward(const arvae_image_vae_t *m, int32_t batc
                                         ? reinterpret_cast<const uint16_t *>(ws + L.dec_bits[i - 1]) : nullptr,
                                     L.dec_wprep[i] >= 0 ? ws + L.dec_wprep[i] : nullptr, gate_op, cur_amax, in_amax_of(true, i),
                                     U(L.tmp_amax), U(L.tmp2_amax), grad_amax(dst), &din_has,
-                                    L.dec_wide[i][m->dec[i].is_up ? 0 : 1] >= 0 ? ws + L.dec_wide[i][m->dec[i].is_up ? 0 : 1] : nullptr))
+                                    L.dec_wide[i][m->dec[i].is_up ? 0 : 1] >= 0 ? ws + L.dec_wide[i][m->dec[i].is_up ? 0 : 1] : nullptr,
+                                    nullptr, nullptr, nullptr, carry ? fin_dev : nullptr, carry ? &taken : nullptr))
             return rc;
+        if (carry) {
+            if (!taken)
+                if (int rc = vae_finish_deferred(fin_dev, st)) return rc;
+            finish_pending = false;
+        }
         pre = gated;
         if (heads_next_g == nullptr) { cur = dst; cur_amax = din_has ? grad_amax(dst) : nullptr; }
     }

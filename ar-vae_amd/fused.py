@@ -207,7 +207,7 @@ class FusedImageVAE:
         return ws
 
     def run(self, x, labels, eps, masks, capacity, external_reg=False, reg_scale=1.0, dp=None, capacity_nonzero=False,
-            draw_eps=False):
+            draw_eps=False, defer_finish=False):
         """-> (loss[1] with grad_fn, scalars[8], acc, z, mu, sigma, logits); loss is scalars[LOSS:LOSS+1].
 
         dp (arvae_amd.parallel.DataParallel): evaluate the regulariser on this rank's row block against the columns
@@ -221,9 +221,13 @@ class FusedImageVAE:
         if draw_eps:
             d.rng_seed, d.rng_offset, d.rng_step = ops.rng_seed(), ops.rng_next_offset(), 0
             d.rng_dev_step = ops._ptr(ops.rng_device_step(x.device))
+        # defer_finish (ARVAE_VAE_DEFER_FINISH, include/arvae_hip.h): a training step whose backward() follows at once lets the
+        # backward pass's first launch carry the forward pass's finishing step -- the scalars (loss, its split, accuracy) read as
+        # NaN until backward() has run.  Never under data parallelism (the library finishes that pass itself).
+        defer = bool(defer_finish) and dp is None and not external_reg and torch.is_grad_enabled()
         anchor = self.optimizer.params[0]
         return _FusedStepFn.apply(anchor, self, x, labels, eps, masks, capacity, bool(external_reg), float(reg_scale), dp,
-                                  bool(capacity_nonzero))
+                                  bool(capacity_nonzero), defer)
 
 
 def _mask_array(masks):
@@ -235,10 +239,13 @@ def _mask_array(masks):
 
 class _FusedStepFn(Function):
     @staticmethod
-    def forward(ctx, anchor, fused, x, labels, eps, masks, capacity, external_reg, reg_scale, dp=None, capacity_nonzero=False):
+    def forward(ctx, anchor, fused, x, labels, eps, masks, capacity, external_reg, reg_scale, dp=None, capacity_nonzero=False,
+                defer_finish=False):
         ops._dev(x, labels, eps, capacity)
         lib = _lib.load()
         desc = fused.descriptor()
+        ctx.flags = (desc.flags & ~2) | (2 if defer_finish else 0)      # ARVAE_VAE_DEFER_FINISH: the same flags for this pass's backward
+        desc.flags = ctx.flags
         opt = fused.optimizer
         b = x.shape[0]
         dev = x.device
@@ -340,9 +347,11 @@ class _FusedStepFn(Function):
         dz_extra = g_z.contiguous() if (ctx.external_reg and g_z is not None) else None
         ws = ctx.ws
         opt.mark_dirty()                                         # gradients land in the arena without torch's accumulation
+        desc = fused.descriptor()
+        desc.flags = ctx.flags                                   # (as this pass's forward call had them: a deferred finishing step)
         with ops._timed('image_vae_backward'):
             _lib.check(lib.arvae_image_vae_backward(
-                ctypes.byref(fused.descriptor()), x.shape[0], ops._ptr(opt.param_arena), ops._ptr(opt.grad_arena),
+                ctypes.byref(desc), x.shape[0], ops._ptr(opt.param_arena), ops._ptr(opt.grad_arena),
                 ops._ptr(x), ops._ptr(eps), ctx.marr, ops._ptr(capacity), ops._ptr(mu), ops._ptr(sigma), ops._ptr(z),
                 ops._ptr(logits), ops._ptr(g_loss), ops._ptr(dz_extra), reg_mode, ctx.reg_scale,
                 ops._ptr(ws), ops._stream()), 'image_vae_backward')
@@ -359,4 +368,4 @@ class _FusedStepFn(Function):
                     ov.stream.wait_event(event)
                     dp.start_bucket(opt.grad_arena, lo, hi)
             dp.remaining_buckets = rest
-        return (None,) * 11
+        return (None,) * 12

@@ -8,6 +8,8 @@ two passes over the logits (BCE, accuracy) by one fused reduction.
 from typing import Tuple
 
 import numpy as np
+import os
+
 import torch
 
 from . import ops
@@ -64,6 +66,11 @@ class ImageVAETrainer(Trainer):
         self.last_terms = {}
         self.use_fused = True          # whole-model C calls (arvae_amd.fused); False = one autograd node per layer
         self._fused = None
+        # A TRAINING step (train=True, gradients enabled) leaves the forward pass's finishing step -- the sums that become the
+        # loss, its split and the accuracy -- to the first launch of loss.backward() (ARVAE_VAE_DEFER_FINISH): those scalars are
+        # final once backward() has run and read as NaN before.  The reference's loop (utils/trainer.py:136-147) and this
+        # build's read them after step(); set False for code that looks at the loss between the two calls.
+        self.defer_loss_finish = os.environ.get('ARVAE_DEFER_FINISH', '1') != '0'      # (the variable: same-box A/B runs)
 
     def cuda(self):
         super().cuda()
@@ -137,8 +144,11 @@ class ImageVAETrainer(Trainer):
         else:                                                    # drawn inside the fused heads kernel, written for backward
             eps, draw = torch.empty(n, model.z_dim, device=inputs.device), True
         dp = self.data_parallel
+        # (the epoch's first batch is logged from the host right below: it finishes inside the forward pass)
+        defer = train and self.defer_loss_finish and not (first_of_epoch and self.writer is not None)
         loss, scalars, accuracy, z, mu, sigma, logits = self._fused.run(x, labels, eps, masks, self.capacity, dp=dp,
-                                                                       capacity_nonzero=self._capacity_nonzero, draw_eps=draw)
+                                                                       capacity_nonzero=self._capacity_nonzero, draw_eps=draw,
+                                                                       defer_finish=defer)
         reg_loss = scalars[REG].detach() if self.use_reg_loss else None
         self.last_terms = {'recons': scalars[RECON].detach(), 'dist': scalars[DIST].detach(), 'reg': reg_loss}
         self.last_outputs = {'logits': logits.view(inputs.size()), 'z': z, 'mu': mu, 'sigma': sigma}

@@ -441,6 +441,12 @@ typedef struct {
 #define ARVAE_STATUS_HANDOFF_BWD (ARVAE_STATUS_SET | (2u << 20))    /* ... of its backward launch                                         */
 #define ARVAE_STATUS_HANDOFF_TICKET (ARVAE_STATUS_SET | (4u << 20)) /* a workgroup found no place in any cluster (corrupt ticket heads)   */
 #define ARVAE_VAE_NO_CLUSTER 1         /* flags: the latent block on the row kernels (no in-launch hand-offs)  */
+/* flags (ABI 11), a TRAINING step only: arvae_image_vae_forward leaves the pass's finishing step -- the sums that become
+ * scalars[] (loss, its terms, accuracy), the KL mean and the regulariser's z-gradient, ~9 us of one workgroup with the chip idle
+ * -- to arvae_image_vae_backward, whose first launch carries it as one more workgroup (or which launches it first thing where that
+ * launch is of another kind).  Until the backward call has run, scalars[0 .. 7] read as NaN.  Set the same flag for both calls
+ * of a step; never for a forward pass no backward pass follows. */
+#define ARVAE_VAE_DEFER_FINISH 2
 
 typedef struct arvae_milestones {
     void *z_ready, *dec_grads, *linear_grads;
