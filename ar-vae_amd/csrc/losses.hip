@@ -94,6 +94,17 @@ __global__ __launch_bounds__(256) void reg_loss_kernel(RegArgs p) {
     __shared__ float as[REG_CHUNK];
     reg_loss_block(p, blockIdx.x, blockIdx.y, xs, as);
 }
+// ... and, for a data-parallel training pass that leaves its finishing step to the backward pass (ARVAE_VAE_DEFER_FINISH,
+// vae_finish.h): this launch -- the pass's last -- parks that step's arguments in the workspace and poisons the scalars
+__global__ __launch_bounds__(256) void reg_loss_park_kernel(RegArgs p, VaeFinishArgs fin, VaeFinishArgs *__restrict__ fin_dst) {
+    __shared__ float xs[REG_CHUNK];
+    __shared__ float as[REG_CHUNK];
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        if (threadIdx.x == 0) *fin_dst = fin;
+        if (threadIdx.x < 8 && fin.scalars != nullptr) fin.scalars[threadIdx.x] = __builtin_nanf("");
+    }
+    reg_loss_block(p, blockIdx.x, blockIdx.y, xs, as);
+}
 
 // fixed-order finish: loss scalar + dense dz rows.  One workgroup, so what it costs is its chain of memory round trips: every
 // element's loads (row loss, the row gradient its dz entry takes) are issued before anything is summed or stored, 4096 elements
@@ -426,10 +437,11 @@ int recon_partials(const float *logits, const float *x, int64_t count, int64_t b
 // per-row partial sums of the all-pairs regulariser into ws = [row_loss | row_grad]
 int reg_partials(const float *z_rows, const float *lab_rows, int64_t n_rows, const float *z_cols, const float *lab_cols,
                  int64_t n_cols, int64_t ldz, int64_t ldl, const RegDims &rd, int32_t r, float delta, float *ws,
-                 hipStream_t s) {
+                 hipStream_t s, const VaeFinishArgs *park, VaeFinishArgs *park_dst) {
     const unsigned bx = (unsigned)((n_rows + REG_ROWS_PER_BLOCK - 1) / REG_ROWS_PER_BLOCK);
     RegArgs p{z_rows, lab_rows, n_rows, z_cols, lab_cols, n_cols, ldz, ldl, rd, delta, ws, ws + n_rows * r};
-    ARVAE_LAUNCH(reg_loss_kernel, dim3(bx, r), dim3(256), 0, s, p);
+    if (park != nullptr && park_dst != nullptr) ARVAE_LAUNCH(reg_loss_park_kernel, dim3(bx, r), dim3(256), 0, s, p, *park, park_dst);
+    else ARVAE_LAUNCH(reg_loss_kernel, dim3(bx, r), dim3(256), 0, s, p);
     return check_launch("reg_loss");
 }
 
@@ -518,7 +530,7 @@ extern "C" int arvae_reg_loss(const float *z_rows, const float *lab_rows, int64_
         ARVAE_REQUIRE(dims[i] >= 0 && dims[i] < ldz && dims[i] < ldl, "reg_loss: dim %d outside z/labels", dims[i]);
     float *row_loss = ws, *row_grad = ws + n_rows * r;
     hipStream_t s = as_stream(stream);
-    if (int rc = reg_partials(z_rows, lab_rows, n_rows, z_cols, lab_cols, n_cols, ldz, ldl, rd, r, delta, ws, s)) return rc;
+    if (int rc = reg_partials(z_rows, lab_rows, n_rows, z_cols, lab_cols, n_cols, ldz, ldl, rd, r, delta, ws, s, nullptr, nullptr)) return rc;
     const double nn = (double)n_cols * (double)n_cols;
     ARVAE_LAUNCH(reg_finish_kernel, dim3(1), dim3(1024), 0, s, row_loss, row_grad, n_rows, r, rd, ldz,
                        (float)(gamma / nn), (float)(2.0 * gamma * delta / nn), loss_out, dz);

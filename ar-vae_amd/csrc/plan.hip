@@ -115,7 +115,7 @@ int recon_partials(const float *logits, const float *x, int64_t count, int64_t b
                    float *dlogits, hipStream_t s, int *nb_out);
 int reg_partials(const float *z_rows, const float *lab_rows, int64_t n_rows, const float *z_cols, const float *lab_cols,
                  int64_t n_cols, int64_t ldz, int64_t ldl, const RegDims &rd, int32_t r, float delta, float *ws,
-                 hipStream_t s);
+                 hipStream_t s, const VaeFinishArgs *park = nullptr, VaeFinishArgs *park_dst = nullptr);
 int vae_finish(const float *rec_partial, int nb, int64_t batch, int64_t pix, const float *mu, const float *sigma,
                int64_t zdim, float beta, const float *cap, const float *reg_ws, int64_t n_cols, int64_t ldz,
                const int32_t *dims, int32_t r, float gamma, float delta, float reg_scale, float *dz, float *rec_out,
@@ -776,6 +776,15 @@ extern "C" int arvae_image_vae_finish(const arvae_image_vae_t *m, int32_t batch,
             ARVAE_REQUIRE(m->reg_dims[i] >= 0 && m->reg_dims[i] < m->zdim && m->reg_dims[i] < ld_labels,
                           "image_vae_finish: reg dim %d outside z/labels", m->reg_dims[i]);
         // the gathered columns index dims 0 .. zdim-1 / 0 .. ld_labels-1 like the local arrays (whole rows are gathered)
+        // (a training step may leave the finishing step to its backward pass -- ARVAE_VAE_DEFER_FINISH, as in the single-rank forward
+        // pass: the regulariser's launch, the last of this call, then parks that step's arguments and poisons the scalars)
+        if (finish_deferred(m)) {
+            const VaeFinishArgs fa = vae_finish_args(ws + L.rec_ws, nb, batch, pix, mu, sigma, m->zdim, m->beta, capacity, ws + L.reg_ws, n_cols, m->zdim,
+                                                     m->reg_dims, m->n_reg, m->gamma, m->delta, reg_scale, ws + L.dz_reg, ws + L.rec_out,
+                                                     ws + L.kld_out, ws + L.reg_out, scalars, 0);
+            return reg_partials(z, labels, batch, z_cols, lab_cols, n_cols, m->zdim, ld_labels, rd, m->n_reg, m->delta, ws + L.reg_ws, st, &fa,
+                                reinterpret_cast<VaeFinishArgs *>(ws + L.fin_args));
+        }
         if (int rc = reg_partials(z, labels, batch, z_cols, lab_cols, n_cols, m->zdim, ld_labels, rd, m->n_reg, m->delta, ws + L.reg_ws, st))
             return rc;
     }

@@ -31,7 +31,7 @@ int philox_draws(int n_draws, const int *kind, void *const *out, const int64_t *
                  uint64_t seed, uint32_t step, const uint32_t *dev_step, hipStream_t s);
 int reg_partials(const float *z_rows, const float *lab_rows, int64_t n_rows, const float *z_cols, const float *lab_cols,
                  int64_t n_cols, int64_t ldz, int64_t ldl, const RegDims &rd, int32_t r, float delta, float *ws,
-                 hipStream_t s);
+                 hipStream_t s, const struct VaeFinishArgs *park = nullptr, struct VaeFinishArgs *park_dst = nullptr);
 int vae_finish(const float *rec_partial, int nb, int64_t batch, int64_t pix, const float *mu, const float *sigma,
                int64_t zdim, float beta, const float *cap, const float *reg_ws, int64_t n_cols, int64_t ldz,
                const int32_t *dims, int32_t r, float gamma, float delta, float reg_scale, float *dz, float *rec_out,

@@ -223,8 +223,10 @@ class FusedImageVAE:
             d.rng_dev_step = ops._ptr(ops.rng_device_step(x.device))
         # defer_finish (ARVAE_VAE_DEFER_FINISH, include/arvae_hip.h): a training step whose backward() follows at once lets the
         # backward pass's first launch carry the forward pass's finishing step -- the scalars (loss, its split, accuracy) read as
-        # NaN until backward() has run.  Never under data parallelism (the library finishes that pass itself).
-        defer = bool(defer_finish) and dp is None and not external_reg and torch.is_grad_enabled()
+        # NaN until backward() has run.  Under data parallelism: when the library finishes the pass itself behind the gather
+        # (arvae_image_vae_finish: a regulariser, capacity 0), whose last launch then parks the step.
+        in_lib = dp is not None and len(self.reg_dims) > 0 and not capacity_nonzero
+        defer = bool(defer_finish) and (dp is None or in_lib) and not external_reg and torch.is_grad_enabled()
         anchor = self.optimizer.params[0]
         return _FusedStepFn.apply(anchor, self, x, labels, eps, masks, capacity, bool(external_reg), float(reg_scale), dp,
                                   bool(capacity_nonzero), defer)
