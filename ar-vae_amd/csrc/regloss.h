@@ -24,6 +24,18 @@ struct RegArgs {
     float *row_loss, *row_grad;  // [R][n_rows] each
 };
 
+// t = tanh(x) and 1 - t^2 from ONE hardware exponential and ONE reciprocal (v_exp_f32, v_rcp_f32: 1 ulp each): with
+// e = exp(-2 |x|), t = sign(x) (1 - e) / (1 + e) and 1 - t^2 = 4 e / (1 + e)^2 -- nine vector instructions where ocml's tanhf is ~30
+// with branches (the regulariser's workgroups ride in a convolution's grid and compete with its waves for the vector ALU), and
+// no cancellation in 1 - t^2 where |x| is large.  |t - tanh(x)| <= ~2e-7.
+__device__ __forceinline__ void tanh_sech2(float x, float &t, float &s2) {
+    const float e = __builtin_amdgcn_exp2f(-2.885390081777927f * fabsf(x));      // exp(-2 |x|) = 2^(-2 log2(e) |x|)
+    const float r = __builtin_amdgcn_rcpf(1.f + e);
+    const float m = (1.f - e) * r;
+    t = x < 0.f ? -m : m;
+    s2 = 4.f * e * r * r;
+}
+
 // workgroup (bx, by) of the grid; xs / as: REG_CHUNK floats of LDS each; 256 threads
 __device__ __forceinline__ void reg_loss_block(const RegArgs &p, const int bx, const int by, float *xs, float *as) {
     const float *__restrict__ zr = p.zr, *__restrict__ lr = p.lr, *__restrict__ zc = p.zc, *__restrict__ lc = p.lc;
@@ -55,12 +67,13 @@ __device__ __forceinline__ void reg_loss_block(const RegArgs &p, const int bx, c
             const float xj = xs[j], aj = as[j];
 #pragma unroll
             for (int r = 0; r < REG_ROWS_PER_WAVE; ++r) {
-                const float t = tanhf(delta * (xi[r] - xj));
+                float t, s2;
+                tanh_sech2(delta * (xi[r] - xj), t, s2);
                 const float da = ai[r] - aj;
                 const float s = da > 0.f ? 1.f : (da < 0.f ? -1.f : 0.f);
                 const float e = t - s;
                 sl[r] += fabsf(e);
-                sg[r] += (1.f - t * t) * (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f));
+                sg[r] += s2 * (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f));
             }
         }
     }
