@@ -483,6 +483,50 @@ def test_mnist_step_ragged_batches_vs_oracle(dev, b, train):
     close(outs['mu'], ref['terms']['mu'], rtol=0, atol=1e-4)
 
 
+def test_deferred_finishing_step_is_nan_until_backward_and_changes_nothing(dev):
+    """ARVAE_VAE_DEFER_FINISH (round 6): a training step leaves the forward pass's finishing launch to the first launch of its
+    backward pass.  Between the two calls the loss reads as NaN (poisoned by the forward pass's last launch: a caller that looks too
+    early sees it, not a stale number); after backward() it is the value of the step that finishes inside the forward pass (another
+    summation order over 512 instead of 1024 threads: rtol 1e-6), and the gradients are the same sums (the last decoder layer's
+    weight gradient is summed over 255 instead of 256 slabs, the rider takes a workgroup: relative L2 1e-6; the rest bit for bit)."""
+    from arvae_amd.image_vae import DspritesVAE
+    from arvae_amd.image_vae_trainer import ImageVAETrainer
+    b = 512
+    state = syn.synth_state(o_vae.DSPRITES_SHAPES, 5, 1.6)
+    x, lab = syn.dsprites_batch(b, seed=77)
+    eps = torch.from_numpy(syn.normal_noise((b, 10), seed=78))
+    xt, lt = torch.from_numpy(x).to(dev), torch.from_numpy(lab).to(dev)
+    got = {}
+    for defer in (True, False):
+        model = DspritesVAE()
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+        trainer = ImageVAETrainer(DspritesDataset(), model, lr=1e-4, reg_type=('all',), reg_dim=(1, 2, 3, 4, 5), beta=4.0, gamma=10.0,
+                                  capacity=0.0, rand=0, delta=1.0)
+        trainer.cuda()
+        trainer.defer_loss_finish = defer
+        model.train()
+        model.push_noise(eps)
+        trainer.zero_grad()
+        loss, acc = trainer.loss_and_acc_for_batch((xt, lt), 0, 0, True)
+        early = float(loss.detach())
+        assert np.isnan(early) == defer                          # poisoned until backward() / final at once
+        loss.backward()
+        torch.cuda.synchronize()
+        got[defer] = (float(loss.detach()), float(acc), {k: float(v) for k, v in trainer.last_terms.items()},
+                      trainer.optimizer.grad_arena.clone())
+        with torch.no_grad():                                    # an evaluation pass never defers
+            model.push_noise(eps)
+            l_eval, _ = trainer.loss_and_acc_for_batch((xt, lt), 0, 1, False)
+            assert np.isfinite(float(l_eval))
+    np.testing.assert_allclose(got[True][0], got[False][0], rtol=1e-6)
+    np.testing.assert_allclose(got[True][1], got[False][1], rtol=1e-6)
+    for k in ('recons', 'dist', 'reg'):
+        np.testing.assert_allclose(got[True][2][k], got[False][2][k], rtol=1e-6)
+    ga, gb = got[True][3].double(), got[False][3].double()
+    assert float((ga - gb).norm()) <= 1e-6 * float(gb.norm())
+    assert float((got[True][3] != got[False][3]).float().mean()) < 0.01        # (deconv4's 512 weights + bias of ~500 k entries)
+
+
 def _full_batch_grads(dev, scale, seed=7):
     from arvae_amd.image_vae import DspritesVAE
     from arvae_amd.image_vae_trainer import ImageVAETrainer
