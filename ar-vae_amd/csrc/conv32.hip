@@ -1497,7 +1497,13 @@ static int pair_split_percent(int lh, bool up) {              // share of the wo
     const int one = lh == 16 ? (up ? e16d : e16u) : (up ? e8d : e8u), both = lh == 16 ? e16 : e8;
     const int forced = one > 0 ? one : both;
     if (forced > 0 && forced < 100) return forced;
-    return lh == 16 ? (up ? 48 : 50) : 50;             // (same-box sweeps at B = 512: flat within 1 % from 48 to 52)
+    // 50 % everywhere: both halves then give workgroup w the SAME images (equal ranges of whole images at the benchmark batches)
+    // and workgroup w of either half sits on XCD w % 8 (grid_a a multiple of 8): the tensor both halves read (the gradient g) is
+    // fetched from HBM once and the later reader hits that XCD's L2.  Round 6, pair(down32<16> + wgrad32<16>) at B = 512, same
+    // box: 48 % (121 + 133 workgroups, 17 tiles against 31 steps: the ranges and the XCDs drift apart) 177.7 MB and 39.1 us per
+    // launch, 50 % (128 + 128, 16 tiles and 32 steps = the same four images) 112.7 MB and 36.9 us: one read of g (67 MB) gone
+    // (tools/run_l2_align_ab.sh, profiles/r6_l2_align_ab.txt; the counters are calibrated in profiles/r6_fetch_calib.txt)
+    return 50;
 }
 bool conv32_pair_fits(const arvae_link_t *l, bool up, const float *gate, const uint16_t *gate_bits, int bias_mode) {
     static const bool off4 = diag_env("ARVAE_NO_PAIR4") != nullptr || diag_env("ARVAE_NO_SMALL_TILES") != nullptr;
@@ -1522,6 +1528,14 @@ template <int LO> static int launch_pair_big(const arvae_link_t *l, bool up, con
     const int cus = cu_count() < AMAX_N / 4 ? cu_count() : AMAX_N / 4;
     int grid_a = cus * (c1 != nullptr ? pair_split_c1_percent() : pair_split_percent(LO, up)) / 100;
     if (grid_a < 1) grid_a = 1;
+    // every body walks a contiguous run of ceil(tiles / grid_a) tiles: the workgroups past the last non-empty run would find nothing
+    // to do, so the weight gradient gets them instead (round 6; the first-layer pair at B = 512: 158 workgroups asked for, 1024 tiles
+    // in runs of 7 -> 147 in use, the weight gradient 109 instead of 98 workgroups = 38 instead of 42 steps each)
+    const int tiles_a = up ? l->n * DownK<LO>::TILES_PER_IMG : (LO == 16 ? tiles_for<16, 128>(l->n) : tiles_for<8, 32>(l->n));
+    {
+        const int run = (tiles_a + grid_a - 1) / grid_a;
+        grid_a = (tiles_a + run - 1) / run;
+    }
     if (grid_a_out != nullptr) *grid_a_out = grid_a;             // (after the clamp: the caller sizes the slab reduction with it)
     // the first layer's slabs (one per workgroup of the Up half) live in that layer's weight-gradient workspace, which make_layout
     // sizes for wgrad_c1_groups() <= 256 workgroups (conv_c1.hip): a split or a CU cap that asks for more must not write past it
@@ -1535,8 +1549,7 @@ template <int LO> static int launch_pair_big(const arvae_link_t *l, bool up, con
         constexpr int LDS = MaxOf<LDS_W, DownK<LO>::LDS_DW * 4>::value;
         static std::once_flag attr;
         std::call_once(attr, [&] { allow_lds(pair_down_wgrad_kernel<LO, EP_GATE_B, 2>, LDS); });
-        const int tiles = l->n * DownK<LO>::TILES_PER_IMG;
-        ARVAE_LAUNCH((pair_down_wgrad_kernel<LO, EP_GATE_B, 2>), grid, dim3(512), LDS, s, g, ep, l->n, tiles, grid_a, x_in, g, slab, total, spw,
+        ARVAE_LAUNCH((pair_down_wgrad_kernel<LO, EP_GATE_B, 2>), grid, dim3(512), LDS, s, g, ep, l->n, tiles_a, grid_a, x_in, g, slab, total, spw,
                      amax_x, amax_g);
         return check_launch(LO == 16 ? "pair(down32<16> + wgrad32<16>)" : "pair(down32<8> + wgrad32<8>)");
     }
@@ -1548,19 +1561,19 @@ template <int LO> static int launch_pair_big(const arvae_link_t *l, bool up, con
             constexpr int LDS_C = MaxOf<LDS_W, LDS_U + 4 * C1W_WAVE_DW * 4>::value;
             static std::once_flag attr_c;
             std::call_once(attr_c, [&] { allow_lds(pair_up16_wgrad_kernel<EP_GATE_B, 1, true>, LDS_C); });
-            ARVAE_LAUNCH((pair_up16_wgrad_kernel<EP_GATE_B, 1, true>), grid, dim3(512), LDS_C, s, g, ep, l->n, tiles_for<16, 128>(l->n), grid_a, g, x_in,
+            ARVAE_LAUNCH((pair_up16_wgrad_kernel<EP_GATE_B, 1, true>), grid, dim3(512), LDS_C, s, g, ep, l->n, tiles_a, grid_a, g, x_in,
                          slab, total, spw, amax_g, amax_x, *c1);
             return check_launch("pair(up32<16> + wgrad32<16> + wgrad_c1)");
         }
         std::call_once(attr, [&] { allow_lds(pair_up16_wgrad_kernel<EP_GATE_B, 1>, LDS); });
-        ARVAE_LAUNCH((pair_up16_wgrad_kernel<EP_GATE_B, 1>), grid, dim3(512), LDS, s, g, ep, l->n, tiles_for<16, 128>(l->n), grid_a, g, x_in, slab,
+        ARVAE_LAUNCH((pair_up16_wgrad_kernel<EP_GATE_B, 1>), grid, dim3(512), LDS, s, g, ep, l->n, tiles_a, grid_a, g, x_in, slab,
                      total, spw, amax_g, amax_x, C1Wgrad{nullptr, nullptr});
         return check_launch("pair(up32<16> + wgrad32<16>)");
     } else {
         constexpr int LDS = MaxOf<LDS_W, 2 * PatchLoader<8, 1, 32>::PLANE_DW * 4>::value;
         static std::once_flag attr;
         std::call_once(attr, [&] { allow_lds(pair_up8_wgrad_kernel<EP_GATE_B, 1>, LDS); });
-        ARVAE_LAUNCH((pair_up8_wgrad_kernel<EP_GATE_B, 1>), grid, dim3(512), LDS, s, g, ep, l->n, tiles_for<8, 32>(l->n), grid_a, g, x_in, slab, total,
+        ARVAE_LAUNCH((pair_up8_wgrad_kernel<EP_GATE_B, 1>), grid, dim3(512), LDS, s, g, ep, l->n, tiles_a, grid_a, g, x_in, slab, total,
                      spw, amax_g, amax_x);
         return check_launch("pair(up32<8> + wgrad32<8>)");
     }
