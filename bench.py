@@ -366,6 +366,8 @@ def timed_regions(step, steps, warmup, fence, min_total_s=1.0, min_regions=3, ma
     timing = {'regions': len(host), 'steps_per_region': steps, 'ms_per_step_median': med * k,
               'ms_per_step_min': min(host) * k, 'ms_per_step_max': max(host) * k, 'ms_per_step_first_region': host[0] * k,
               'hip_event_ms_per_step_median': float(np.median(dev)) * k, 'timed_seconds_total': sum(host),
+              # the regions in order, thinned to <= 32 entries: a box's first second runs slower than its steady state
+              'ms_per_step_regions': [round(h * k, 4) for h in host[::max(1, (len(host) + 31) // 32)]],
               'rule': 'regions of exactly K steps, barrier + synchronize on both sides, repeated until >= 1 s is timed; '
                       'value and ms_per_step are the median region (host clock, max over ranks)'}
     return med, timing, loss
