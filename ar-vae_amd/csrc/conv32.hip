@@ -1303,6 +1303,50 @@ int conv32_down(const arvae_link_t *l, const Operand &hi, const float *bias, int
     return check_launch("down32_kernel<4>");
 }
 
+// ---- two stacked ReLU DOWN layers of the forward pass (16x16 then 8x8 output) in ONE launch (round 6) ---------------------------
+// Every tile of the lower layer needs ONE image of the upper layer's output, and down32p_body gives a workgroup a contiguous run
+// of tiles: with the same grid for both layers and runs of whole images, workgroup w computes the 8x8 layer on exactly the images
+// whose 16x16 layer it has just stored -- a dependency inside the workgroup (its stores drained, one barrier), not between
+// launches.  The second body's input scale is the workgroup's own maximum (down32p.h CHAIN); the tensor-wide AMAX arrays of both
+// outputs are published as always (the backward pass's weight gradients read them).  Saves the lower layer's launch: ramp, cold
+// prologue and drain of a 12 us launch that multiplies for 3.
+template <int MODE>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void chain_down_kernel(const float *__restrict__ hi, Ep32 ep_a, Ep32 ep_b,
+                                                                                                    int n_img, int tiles_a, int tiles_b) {
+    extern __shared__ __attribute__((aligned(16))) unsigned chain_lds[];
+    constexpr int BODY_DW = MaxOf<DownK<16>::LDS_DW, DownK<8>::LDS_DW>::value;
+    float *chain_max = reinterpret_cast<float *>(chain_lds + BODY_DW);
+    down32p_body<16, MODE, 1>(hi, ep_a, n_img, tiles_a, blockIdx.x, gridDim.x, chain_max);
+    __syncthreads();                                             // (a workgroup-scope release / acquire: this workgroup's stores are visible to its loads)
+    down32p_body<8, MODE, 2>(ep_a.out, ep_b, n_img, tiles_b, blockIdx.x, gridDim.x, chain_max);
+}
+static int chain_grid(const arvae_link_t *a, const arvae_link_t *b) {       // 0: the runs of the two layers do not cover the same images
+    if (a->n != b->n || a->n < 1) return 0;
+    const int tiles_a = a->n * DownK<16>::TILES_PER_IMG, tiles_b = b->n * DownK<8>::TILES_PER_IMG;
+    const int grid = grid_for_tiles(tiles_a);
+    const int run_a = (tiles_a + grid - 1) / grid, run_b = (tiles_b + grid - 1) / grid;
+    return (run_a * DownK<8>::TILES_PER_IMG == run_b * DownK<16>::TILES_PER_IMG) ? grid : 0;
+}
+bool conv32_down_chain_fits(const arvae_link_t *a, const arvae_link_t *b) {
+    static const bool off = diag_env("ARVAE_NO_DOWN_CHAIN") != nullptr;     // A/B switch: two launches
+    return !off && conv32_fits(a) && conv32_fits(b) && a->lh == 16 && b->lh == 8 && b->hh == a->lh && chain_grid(a, b) > 0;
+}
+// both layers: bias + ReLU, sign bits to bits_*; amax_in: of `hi`; amax_a / amax_b: where the outputs' maxima go
+int conv32_down_chain(const arvae_link_t *a, const arvae_link_t *b, const float *hi, const unsigned *amax_in, const float *bias_a,
+                      uint16_t *bits_a, float *out_a, const float *wprep_a, unsigned *amax_a, const float *bias_b, uint16_t *bits_b,
+                      float *out_b, const float *wprep_b, unsigned *amax_b, hipStream_t s) {
+    ARVAE_REQUIRE(conv32_down_chain_fits(a, b), "conv32_down_chain: these two layers do not chain");
+    ARVAE_REQUIRE(hi && amax_in && out_a && out_b && wprep_a && wprep_b, "conv32_down_chain: null pointer");
+    Ep32 ep_a{bias_a, nullptr, nullptr, bits_a, out_a, reinterpret_cast<const uint4 *>(wprep_a), amax_in, amax_a};
+    Ep32 ep_b{bias_b, nullptr, nullptr, bits_b, out_b, reinterpret_cast<const uint4 *>(wprep_b), nullptr, amax_b};
+    constexpr int LDS = (MaxOf<DownK<16>::LDS_DW, DownK<8>::LDS_DW>::value + 4) * 4;
+    static std::once_flag attr;
+    std::call_once(attr, [&] { allow_lds(chain_down_kernel<EP_RELU>, LDS); });
+    ARVAE_LAUNCH((chain_down_kernel<EP_RELU>), dim3(chain_grid(a, b)), dim3(512), LDS, s, hi, ep_a, ep_b, a->n, a->n * DownK<16>::TILES_PER_IMG,
+                 b->n * DownK<8>::TILES_PER_IMG);
+    return check_launch("chain(down32<16> + down32<8>)");
+}
+
 template <int LO> static int launch_up(const arvae_link_t *l, const Operand &lo, const Ep32 &ep, int relu, hipStream_t s) {
     switch (ep_mode(ep, relu)) {
         case EP_GATE_B: launch_up_v<LO, EP_GATE_B>(lo, ep, l->n, s); break;

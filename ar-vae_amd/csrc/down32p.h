@@ -54,8 +54,14 @@ template <int LO> struct DownK {
 // tile t+1's LDS image while tile t is multiplied.  (Round 3 measured this with six bf16 products per multiply-add: 1.9-2.1 us
 // per tile for 1.54 us of MFMA issue, the producers done after 1.4 us; with three fp16 products the MFMA issue is 0.77 us.)
 // (a body: the launch may carry another kernel's workgroups beside these -- BID / NBLK: this workgroup's index and their number)
-template <int LO, int MODE>
-__device__ __forceinline__ void down32p_body(const float *__restrict__ hi, Ep32 ep, int n_img, int n_tiles, const int BID, const int NBLK) {
+// CHAIN (round 6, chain_down_kernel in conv32.hip: two layers of the forward pass in one launch, workgroup w running the lower layer
+// on exactly the images whose upper layer it has just computed): 1 = the first body of a chain -- its consumer waves leave the
+// maxima of what they stored in chain_max[0..3] (LDS); 2 = the second body -- the input's scale comes from those four values
+// (the WORKGROUP's own maximum: a scale need only cover the values this workgroup reads; the tensor-wide AMAX array is complete
+// only when the whole launch is), ep.amax_in is not read.
+template <int LO, int MODE, int CHAIN = 0>
+__device__ __forceinline__ void down32p_body(const float *__restrict__ hi, Ep32 ep, int n_img, int n_tiles, const int BID, const int NBLK,
+                                             float *chain_max = nullptr) {
     using K = DownK<LO>;
     constexpr int HW = K::HW, PIX = K::PIX, SLOTS = K::SLOTS, HI = 2 * LO;
     extern __shared__ __attribute__((aligned(16))) unsigned ldsd[];
@@ -65,6 +71,11 @@ __device__ __forceinline__ void down32p_body(const float *__restrict__ hi, Ep32 
     const int t_end = min(n_tiles, t_first + per_wg);
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
+    // the input's scale: from its AMAX array, or (second body of a chain) from the workgroup's own four maxima
+    auto chain_scale = [&]() __attribute__((always_inline)) -> Pow2 {
+        const float m = fmaxf(fmaxf(chain_max[0], chain_max[1]), fmaxf(chain_max[2], chain_max[3]));
+        return pow2_for((unsigned)__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m)));
+    };
 
     if (wave >= 4) {
         // ============================================================================================ producers
@@ -76,7 +87,8 @@ __device__ __forceinline__ void down32p_body(const float *__restrict__ hi, Ep32 
         int q = pt & 7, pix0 = pt >> 3;                          // slot s of this thread = staged pixel pix0 + 32 s, channels 4 q .. 4 q + 3
         float4 lv[2][SLOTS];
         float sc_in = 1.f;                                       // the input tensor's scale (set behind the first tiles' loads)
-        const AmaxLoad al = amax_issue(ep.amax_in);
+        AmaxLoad al{};
+        if constexpr (CHAIN != 2) al = amax_issue(ep.amax_in);
         auto issue = [&](auto set_, int s, int tile) __attribute__((always_inline)) {
             constexpr int set = decltype(set_)::value;
             int img0, r0;
@@ -102,7 +114,8 @@ __device__ __forceinline__ void down32p_body(const float *__restrict__ hi, Ep32 
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) issue(S1{}, s, t_first + 1);
         if (pt < 2 * PSB2) ldsd[(pt / PSB2) * K::BUF + PIX * PSB2 + pt % PSB2] = 0u;   // the zero pixels
-        sc_in = amax_scale(al).s;
+        if constexpr (CHAIN != 2) sc_in = amax_scale(al).s;
+        else sc_in = chain_scale().s;
         __syncthreads();                                         // (the consumers' prologue barrier)
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) commit(S0{}, s, ldsd);    // first tile -> buffer 0
@@ -160,7 +173,8 @@ __device__ __forceinline__ void down32p_body(const float *__restrict__ hi, Ep32 
     int cst = 0;
     (void)cst;
     const int half = lane >> 5, rc = lane & 31;
-    const AmaxLoad al = amax_issue(ep.amax_in);
+    AmaxLoad al{};
+    if constexpr (CHAIN != 2) al = amax_issue(ep.amax_in);
     int xoff[2][4];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -193,7 +207,9 @@ __device__ __forceinline__ void down32p_body(const float *__restrict__ hi, Ep32 
 #pragma unroll
             for (int t = 0; t < 2; ++t) w2[st][t] = __builtin_bit_cast(f16x8, wp[(st * 2 + t) * 64]);
     }
-    const float inv = amax_scale(al).inv * prep_inv_scale(ep.wprep);      // accumulators -> fp32 results (exact)
+    float inv;                                                   // accumulators -> fp32 results (exact)
+    if constexpr (CHAIN != 2) inv = amax_scale(al).inv * prep_inv_scale(ep.wprep);
+    else inv = chain_scale().inv * prep_inv_scale(ep.wprep);
     float amax_run = 0.f;                                        // maximum magnitude of what this wave stores
     __syncthreads();                                             // zero pixels written
     __syncthreads();                                             // first tile staged
@@ -351,6 +367,10 @@ __device__ __forceinline__ void down32p_body(const float *__restrict__ hi, Ep32 
     load_parts();
     static_for<0, 9>(epi_item);                                  // the last tile's epilogue
     amax_publish(ep.amax_out, BID * 4 + wave, NBLK * 4, amax_run);
+    if constexpr (CHAIN == 1) {
+        const float m = wave_max(amax_run);
+        if (lane == 0) chain_max[wave] = m;
+    }
 }
 template <int LO, int MODE>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void down32p_kernel(const float *__restrict__ hi, Ep32 ep,

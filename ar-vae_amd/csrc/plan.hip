@@ -49,6 +49,10 @@ VaeFinishArgs vae_finish_args(const float *rec_partial, int nb, int64_t batch, i
                               const int32_t *dims, int32_t r, float gamma, float delta, float reg_scale, float *dz, float *rec_out,
                               float *kld_out, float *reg_out, float *scalars, int64_t rec_rows);
 bool conv32_up_reg_fits(const arvae_link_t *l);
+bool conv32_down_chain_fits(const arvae_link_t *a, const arvae_link_t *b);
+int conv32_down_chain(const arvae_link_t *a, const arvae_link_t *b, const float *hi, const unsigned *amax_in, const float *bias_a,
+                      uint16_t *bits_a, float *out_a, const float *wprep_a, unsigned *amax_a, const float *bias_b, uint16_t *bits_b,
+                      float *out_b, const float *wprep_b, unsigned *amax_b, hipStream_t s);
 int conv32_up_reg(const arvae_link_t *l, const Operand &lo, const float *bias, uint16_t *bits_out, float *out, const float *wprep,
                   const unsigned *amax_in, unsigned *amax_out, const RegArgs &reg, int r, hipStream_t s);
 int conv_c1_up_recon_blocks(const arvae_link_t *l);
@@ -626,6 +630,24 @@ extern "C" int arvae_image_vae_forward(const arvae_image_vae_t *m, int32_t batch
         mi += m->enc[i].dropout != 0;
         uint16_t *bits = L.enc_bits[i] >= 0 ? reinterpret_cast<uint16_t *>(ws + L.enc_bits[i]) : nullptr;
         bool has = false;
+        // two stacked 32-channel ReLU layers (16x16 then 8x8 output) as ONE launch (conv32.hip chain_down_kernel)
+        if (i + 1 < m->n_enc - mid_ne - (fold ? 1 : 0) && mask == nullptr && !(masks != nullptr && m->enc[i + 1].dropout) && bits != nullptr &&
+            L.enc_bits[i + 1] >= 0 && L.enc_wprep[i] >= 0 && L.enc_wprep[i + 1] >= 0 && h_amax != nullptr && !m->enc[i].is_up && !m->enc[i + 1].is_up) {
+            arvae_link_t la = m->enc[i].link, lb = m->enc[i + 1].link;
+            la.n = lb.n = batch;
+            if (conv32_down_chain_fits(&la, &lb)) {
+                const arvae_layer_t &a = m->enc[i], &b = m->enc[i + 1];
+                if (int rc = conv32_down_chain(&la, &lb, h, h_amax, a.b_off >= 0 ? params + a.b_off : nullptr, bits, ws + L.enc_out[i],
+                                               ws + L.enc_wprep[i], U(L.enc_amax[i]), b.b_off >= 0 ? params + b.b_off : nullptr,
+                                               reinterpret_cast<uint16_t *>(ws + L.enc_bits[i + 1]), ws + L.enc_out[i + 1],
+                                               ws + L.enc_wprep[i + 1], U(L.enc_amax[i + 1]), st))
+                    return rc;
+                ++i;
+                h = ws + L.enc_out[i];
+                h_amax = U(L.enc_amax[i]);
+                continue;
+            }
+        }
         // (a 32-channel layer's input keeps its AMAX array for the weight gradient: a missing one is made in the input's own slot)
         if (int rc = layer_forward(m->enc[i], batch, params, h, mask, ws + L.enc_out[i], bits, ws + L.link_ws, stream,
                                    L.enc_wprep[i] >= 0 ? ws + L.enc_wprep[i] : nullptr, h_amax, i > 0 ? U(L.enc_amax[i - 1]) : U(L.tmp_amax),

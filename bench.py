@@ -66,6 +66,9 @@ KERNEL_WORK = {
     'down32_kernel<16>': (4_194_304, 4 * (32768 + 8192)), 'up32_kernel<16>': (4_194_304, 4 * (8192 + 32768)),
     'wgrad32_kernel<16>': (4_194_304, 4 * (8192 + 32768)),
     'down32_kernel<8>': (1_048_576, 4 * (8192 + 2048)), 'up32_kernel<8>': (1_048_576, 4 * (2048 + 8192)),
+    # round 6: conv2 and conv3 of the forward pass as one launch (a workgroup runs the 8x8 layer on the images whose 16x16 layer it
+    # has just stored): the layer-boundary bytes of both layers (SURVEY 8(d) counts the 16x16 tensor written and read)
+    'chain(down32<16> + down32<8>)': (4_194_304 + 1_048_576, 4 * (32768 + 8192) + 4 * (8192 + 2048)),
     'wgrad32_kernel<8>': (1_048_576, 4 * (2048 + 8192)),
     'down32_kernel<4>': (262_144, 4 * (2048 + 512)), 'up32_kernel<4>': (262_144, 4 * (512 + 2048)),
     'wgrad32_kernel<4>': (262_144, 4 * (512 + 2048)),
@@ -117,6 +120,7 @@ ROCPROF_NAMES = {
     'wgrad32_kernel<8>': ['arvae::wgrad32r_kernel<8, 1>', 'arvae::wgrad32r_kernel<8, 2>'],
     'up32_kernel<8>': ['arvae::up32x_kernel<8, 1, 32>', 'arvae::up32x_kernel<8, 3, 32>'],
     'down32_kernel<8>': ['arvae::down32p_kernel<8, 1>', 'arvae::down32p_kernel<8, 3>'],
+    'chain(down32<16> + down32<8>)': ['arvae::chain_down_kernel<1>'],
     'wgrad32_kernel<4>': ['arvae::wgrad32x_kernel<4, 1>', 'arvae::wgrad32x_kernel<4, 2>'],
     'up32_kernel<4>': ['arvae::up32x_kernel<4, 1, 32>', 'arvae::up32x_kernel<4, 3, 32>'],
     'down32_kernel<4>': ['arvae::down32s_kernel<4, 1>', 'arvae::down32s_kernel<4, 2>'],
@@ -154,7 +158,7 @@ ARITH_PEAK_TFLOPS = {'f16x2': PEAK_BF16_MFMA_TFLOPS / F16X2_PRODUCTS, 'fp32': PE
 
 
 def arithmetic_of(label):
-    return 'f16x2' if label.startswith(('down32', 'up32', 'wgrad32', 'pair4', 'pair(down32', 'pair(up32')) else 'fp32'
+    return 'f16x2' if label.startswith(('down32', 'up32', 'wgrad32', 'pair4', 'pair(down32', 'pair(up32', 'chain(down32')) else 'fp32'
 
 
 def kernel_rooflines(prof, prof_steps, pmc_kernels=None):

@@ -1749,6 +1749,47 @@ def test_paired_launches_match_the_separate_launches(dev):
         close(res['pair']['g0'][k], res['split']['g0'][k], rtol=1e-5, atol=1e-9)
 
 
+def test_chained_forward_layers_match_the_two_launches(dev):
+    """conv2 + conv3 of the dSprites encoder as ONE launch (conv32.hip chain_down_kernel: a workgroup runs the 8x8 layer on the
+    images whose 16x16 layer it has just stored, its input scale the workgroup's own maximum) against ARVAE_NO_DOWN_CHAIN=1 (two
+    launches, the tensor-wide scale): B = 512 and a ragged 500 (runs of whole images in both) chain, B = 64 does not (one tile per
+    workgroup) -- the launch labels say which ran; losses and gradients agree to the rounding of a different power-of-two scale."""
+    code = (
+        "import sys, json, ctypes; sys.path.insert(0, %r)\n"
+        "import numpy as np, torch\n"
+        "from tests.test_hip_parity import run_hip_image_step\n"
+        "from arvae_amd import synthetic as syn, _lib\n"
+        "from oracle import image_vae as o_vae\n"
+        "lib = _lib.load()\n"
+        "out = {}\n"
+        "for b in (512, 500, 64):\n"
+        "    state = syn.synth_state(o_vae.SHAPES['dsprites'], 9, 1.6)\n"
+        "    x, lab = syn.dsprites_batch(b, seed=5)\n"
+        "    eps = syn.normal_noise((b, o_vae.Z_DIM['dsprites']), seed=6)\n"
+        "    torch.cuda.synchronize()\n"
+        "    lib.arvae_profile_begin(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))\n"
+        "    got = run_hip_image_step(torch.device('cuda:0'), 'dsprites', state, x, lab, eps, 4.0, 0.0, 'bernoulli', None, train=True)\n"
+        "    buf = ctypes.create_string_buffer(1 << 16)\n"
+        "    lib.arvae_profile_end(buf, len(buf))\n"
+        "    labels = sorted({ln.split('\\t')[0] for ln in buf.value.decode().splitlines()})\n"
+        "    out[str(b)] = {'loss': got['loss'], 'labels': labels, 'gn': {k: float(np.linalg.norm(v)) for k, v in got['grads'].items()}}\n"
+        "print(json.dumps(out))\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    res = {}
+    for flag, env in (('chain', {}), ('two', {'ARVAE_NO_DOWN_CHAIN': '1', 'ARVAE_LIB': DIAG_LIB})):
+        r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[flag] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    label = 'chain(down32<16> + down32<8>)'
+    for b in ('512', '500'):
+        assert label in res['chain'][b]['labels'] and 'down32_kernel<16>' not in res['chain'][b]['labels']
+    assert label not in res['chain']['64']['labels'] and 'down32_kernel<16>' in res['chain']['64']['labels']
+    for b in ('512', '500', '64'):
+        assert label not in res['two'][b]['labels']
+        close(res['chain'][b]['loss'], res['two'][b]['loss'], rtol=1e-6)
+        for k, v in res['two'][b]['gn'].items():
+            close(res['chain'][b]['gn'][k], v, rtol=1e-5, atol=1e-10)
+
+
 def test_latent_block_experiment_matches_the_per_layer_path(dev):
     """The latent block (csrc/midblock.hip, the default: the Linear stack + heads + reparameterisation as one launch per pass)
     must give the losses and gradients of the per-layer path (ARVAE_MIDBLOCK=0), dSprites B = 37 and Morpho-MNIST B = 8."""

@@ -28,6 +28,8 @@ def label(kernel_name):
         return 'pair(up32<16> + wgrad32<16>)'
     if n.startswith('pair_up8_wgrad_kernel'):
         return 'pair(up32<8> + wgrad32<8>)'
+    if n.startswith('chain_down_kernel'):
+        return 'chain(down32<16> + down32<8>)'
     if n.startswith('dense_wgrad_slab_kernel'):
         return 'pair(dense_wgrad_batch + slab_reduce_batch)'
     if n.startswith('dense_wgrad_c1_kernel'):
